@@ -1,0 +1,516 @@
+// TEST INFRASTRUCTURE — not product code.
+//
+// Thin extern "C" wrapper (ours) that is compiled against the *reference's own headers and
+// objects* (see oracle/ref/Makefile) so that tests can call the reference's kernel tables —
+// scalar row (enableOpt=false) and x86 SIMD row (enableOpt=true) — on seeded inputs, exactly
+// like test/vvenc_unit_test/vvenc_unit_test.cpp builds its `ref`/`opt` object pairs.
+// Used (a) to pin oracle/vvenc_oracle.c, (b) by tools/gen_golden.py to write tests/golden/*,
+// (c) optionally as bench.py's cpu_baseline (kind "reference").
+//
+// Nothing here is shipped: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+// may load oracle/_ref/libvvenc_ref.so.
+//
+// `#define private public` is a test-only trick to reach Quant::xQuant/xDeQuant/xNeedRdoq
+// (CommonLib/Quant.h:143-151) and MCTF's private search schedule (CommonLib/MCTF.h:190-204).
+
+#include <cstdint>
+#include <cstring>
+#include <cstdlib>
+#include <deque>
+#include <vector>
+#include <atomic>
+#include <sstream>
+#include <iostream>
+#include <fstream>
+#include <string>
+#include <list>
+#include <map>
+#include <array>
+#include <mutex>
+#include <thread>
+#include <condition_variable>
+#include <functional>
+#include <algorithm>
+#include <memory>
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <cassert>
+#include <cstdarg>
+#include <iomanip>
+#include <numeric>
+#include <set>
+#include <unordered_map>
+#include <stdexcept>
+#include <exception>
+#include <utility>
+
+#define private public
+#define protected public
+#include "CommonLib/CommonDef.h"
+#include "CommonLib/Unit.h"
+#include "CommonLib/Slice.h"
+#include "CommonLib/CodingStructure.h"
+#include "CommonLib/RdCost.h"
+#include "CommonLib/TrQuant.h"
+#include "CommonLib/TrQuant_EMT.h"
+#include "CommonLib/Quant.h"
+#include "CommonLib/MCTF.h"
+#include "CommonLib/Rom.h"
+#include "CommonLib/ContextModelling.h"
+#include "CommonLib/Picture.h"
+#include "vvenc/vvencCfg.h"
+#include "EncoderLib/EncCfg.h"
+#undef private
+#undef protected
+
+using namespace vvenc;
+
+#define API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+struct RdPair { RdCost* rc[2]; };
+RdPair& rdPair()
+{
+  static RdPair p = [] {
+    RdPair q;
+    q.rc[0] = new RdCost; q.rc[0]->create( false );
+    q.rc[1] = new RdCost; q.rc[1]->create( true );
+    return q;
+  }();
+  return p;
+}
+
+TCoeffOps& tcoeffOps( int simd )
+{
+  static TCoeffOps ops[2];
+  static bool init = false;
+  if( !init ) { ops[1].initTCoeffOps( true ); init = true; }
+  return ops[simd ? 1 : 0];
+}
+
+void selectTCoeffOps( int simd ) { g_tCoeffOps = tcoeffOps( simd ); }
+
+struct MctfPair { MCTF* m[2]; };
+MctfPair& mctfPair()
+{
+  static MctfPair p = [] { MctfPair q; q.m[0] = new MCTF( false ); q.m[1] = new MCTF( true ); return q; }();
+  return p;
+}
+
+Quant& quantObj()
+{
+  // Quant::Quant always installs the SIMD pointers when built with x86 SIMD (Quant.cpp:281-291);
+  static Quant q( nullptr, false );
+  return q;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Distortion (RdCost tables)   dfBase: value of the DFunc enum base (DF_SSE, DF_SAD, DF_HAD, DF_HAD_fast, DF_HAD_2SAD)
+// ---------------------------------------------------------------------------------------------
+API int vvref_df( const char* name )
+{
+  if( !strcmp( name, "SSE" ) )      return DF_SSE;
+  if( !strcmp( name, "SAD" ) )      return DF_SAD;
+  if( !strcmp( name, "HAD" ) )      return DF_HAD;
+  if( !strcmp( name, "HAD_fast" ) ) return DF_HAD_fast;
+  if( !strcmp( name, "HAD_2SAD" ) ) return DF_HAD_2SAD;
+  if( !strcmp( name, "SAD_WITH_MASK" ) ) return DF_SAD_WITH_MASK;
+  return -1;
+}
+
+API uint64_t vvref_dist( int simd, int dfBase, const int16_t* org, int orgStride, const int16_t* cur, int curStride,
+                         int w, int h, int bitDepth, int subShift )
+{
+  RdCost& rc = *rdPair().rc[simd ? 1 : 0];
+  DistParam dp;
+  dp.org = CPelBuf( org, orgStride, w, h );
+  dp.cur = CPelBuf( cur, curStride, w, h );
+  dp.bitDepth = bitDepth;
+  dp.subShift = subShift;
+  dp.compID   = COMP_Y;
+  int idx = dfBase;
+  if( dfBase != DF_HAD_2SAD && dfBase != DF_SAD_WITH_MASK ) idx += Log2( w );   // RdCost.cpp:177-181
+  return rc.m_afpDistortFunc[0][idx]( dp );
+}
+
+API void vvref_sad_x5( int simd, const int16_t* org, int orgStride, const int16_t* cur, int curStride,
+                       int w, int h, int bitDepth, int subShift, uint64_t* cost5, int calcCentre )
+{
+  RdCost& rc = *rdPair().rc[simd ? 1 : 0];
+  DistParam dp;
+  dp.org = CPelBuf( org, orgStride, w, h );
+  dp.cur = CPelBuf( cur, curStride, w, h );
+  dp.bitDepth = bitDepth;
+  dp.subShift = subShift;
+  dp.compID   = COMP_Y;
+  Distortion c[5] = { 0, 0, 0, 0, 0 };
+  rc.m_afpDistortFuncX5[Log2( w ) - 3]( dp, c, calcCentre != 0 );   // RdCost.cpp:252
+  for( int i = 0; i < 5; i++ ) cost5[i] = c[i];
+}
+
+API uint64_t vvref_fix_weighted_sse( int simd, const int16_t* org, int orgStride, const int16_t* cur, int curStride,
+                                     int w, int h, int bitDepth, uint32_t weight )
+{
+  RdCost& rc = *rdPair().rc[simd ? 1 : 0];
+  DistParam dp;
+  dp.org = CPelBuf( org, orgStride, w, h );
+  dp.cur = CPelBuf( cur, curStride, w, h );
+  dp.bitDepth = bitDepth;
+  dp.compID   = COMP_Y;
+  return rc.m_fxdWtdPredPtr( dp, weight );
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transform matrices and 1-D / 2-D transforms
+// ---------------------------------------------------------------------------------------------
+static const TMatrixCoeff* trMatrix( int trType, int log2N )
+{
+  switch( trType )
+  {
+  case DCT2:
+    switch( log2N ) {
+      case 1: return g_trCoreDCT2P2 [TRANSFORM_FORWARD][0];
+      case 2: return g_trCoreDCT2P4 [TRANSFORM_FORWARD][0];
+      case 3: return g_trCoreDCT2P8 [TRANSFORM_FORWARD][0];
+      case 4: return g_trCoreDCT2P16[TRANSFORM_FORWARD][0];
+      case 5: return g_trCoreDCT2P32[TRANSFORM_FORWARD][0];
+      case 6: return g_trCoreDCT2P64[TRANSFORM_FORWARD][0];
+    } break;
+  case DCT8:
+    switch( log2N ) {
+      case 2: return g_trCoreDCT8P4 [TRANSFORM_FORWARD][0];
+      case 3: return g_trCoreDCT8P8 [TRANSFORM_FORWARD][0];
+      case 4: return g_trCoreDCT8P16[TRANSFORM_FORWARD][0];
+      case 5: return g_trCoreDCT8P32[TRANSFORM_FORWARD][0];
+    } break;
+  case DST7:
+    switch( log2N ) {
+      case 2: return g_trCoreDST7P4 [TRANSFORM_FORWARD][0];
+      case 3: return g_trCoreDST7P8 [TRANSFORM_FORWARD][0];
+      case 4: return g_trCoreDST7P16[TRANSFORM_FORWARD][0];
+      case 5: return g_trCoreDST7P32[TRANSFORM_FORWARD][0];
+    } break;
+  }
+  return nullptr;
+}
+
+API int vvref_tr_type( const char* name )
+{
+  if( !strcmp( name, "DCT2" ) ) return DCT2;
+  if( !strcmp( name, "DCT8" ) ) return DCT8;
+  if( !strcmp( name, "DST7" ) ) return DST7;
+  return -1;
+}
+
+API int vvref_tr_matrix( int trType, int log2N, int16_t* out )
+{
+  const TMatrixCoeff* m = trMatrix( trType, log2N );
+  if( !m ) return -1;
+  const int N = 1 << log2N;
+  for( int i = 0; i < N * N; i++ ) out[i] = m[i];
+  return 0;
+}
+
+typedef void FwdFn( const TCoeff*, TCoeff*, int, int, int, int );
+typedef void InvFn( const TCoeff*, TCoeff*, int, int, int, int, const TCoeff, const TCoeff );
+
+static FwdFn* fwdFn( int trType, int log2N )
+{
+  // same layout as fastFwdTrans[NUM_TRANS_TYPE][g_numTransformMatrixSizes] (TrQuant.cpp:76-81), which has internal linkage
+  static FwdFn* const t[3][6] = {
+    { fastForwardDCT2_B2, fastForwardDCT2_B4, fastForwardDCT2_B8, fastForwardDCT2_B16, fastForwardDCT2_B32, fastForwardDCT2_B64 },
+    { nullptr,            fastForwardDCT8_B4, fastForwardDCT8_B8, fastForwardDCT8_B16, fastForwardDCT8_B32, nullptr },
+    { nullptr,            fastForwardDST7_B4, fastForwardDST7_B8, fastForwardDST7_B16, fastForwardDST7_B32, nullptr } };
+  return t[trType][log2N - 1];
+}
+static InvFn* invFn( int trType, int log2N )
+{
+  static InvFn* const t[3][6] = {
+    { fastInverseDCT2_B2, fastInverseDCT2_B4, fastInverseDCT2_B8, fastInverseDCT2_B16, fastInverseDCT2_B32, fastInverseDCT2_B64 },
+    { nullptr,            fastInverseDCT8_B4, fastInverseDCT8_B8, fastInverseDCT8_B16, fastInverseDCT8_B32, nullptr },
+    { nullptr,            fastInverseDST7_B4, fastInverseDST7_B8, fastInverseDST7_B16, fastInverseDST7_B32, nullptr } };
+  return t[trType][log2N - 1];
+}
+
+API int vvref_fwd_1d( int simd, int trType, int log2N, const int32_t* src, int32_t* dst, int shift, int line, int skipLine, int skipLine2 )
+{
+  FwdFn* f = fwdFn( trType, log2N );
+  if( !f ) return -1;
+  selectTCoeffOps( simd );
+  f( src, dst, shift, line, skipLine, skipLine2 );
+  return 0;
+}
+
+API int vvref_inv_1d( int simd, int trType, int log2N, const int32_t* src, int32_t* dst, int shift, int line, int skipLine, int skipLine2, int32_t clipMin, int32_t clipMax )
+{
+  InvFn* f = invFn( trType, log2N );
+  if( !f ) return -1;
+  selectTCoeffOps( simd );
+  f( src, dst, shift, line, skipLine, skipLine2, clipMin, clipMax );
+  return 0;
+}
+
+// The wiring of TrQuant::xT (TrQuant.cpp:481-564) around the reference's own 1-D functions and cpyCoeff ops.
+// (xT itself needs a TransformUnit/CodingStructure; the 1-D cores, zero-out and copies below ARE the reference's.)
+API int vvref_xT( int simd, const int16_t* resi, int resiStride, int32_t* coef, int width, int height,
+                  int trTypeHor, int trTypeVer, int bitDepth )
+{
+  const int maxLog2TrDynamicRange = 15;
+  const int TRANSFORM_MATRIX_SHIFT = g_transformMatrixShift[TRANSFORM_FORWARD];
+  int skipWidth  = ( trTypeHor != DCT2 && width  == 32 ) ? 16 : width  > JVET_C0024_ZERO_OUT_TH ? width  - JVET_C0024_ZERO_OUT_TH : 0;
+  int skipHeight = ( trTypeVer != DCT2 && height == 32 ) ? 16 : height > JVET_C0024_ZERO_OUT_TH ? height - JVET_C0024_ZERO_OUT_TH : 0;
+  selectTCoeffOps( simd );
+  TCoeff* block = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
+  TCoeff* tmp   = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
+  TCoeff* dst   = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
+  if( width & 3 )
+  {
+    for( int y = 0; y < height; y++ ) for( int x = 0; x < width; x++ ) block[y * width + x] = resi[y * resiStride + x];
+  }
+  else if( width & 7 ) g_tCoeffOps.cpyCoeff4( resi, resiStride, block, width, height );
+  else                 g_tCoeffOps.cpyCoeff8( resi, resiStride, block, width, height );
+
+  int rc = 0;
+  if( width > 1 && height > 1 )
+  {
+    const int shift_1st = ( Log2( width ) + bitDepth + TRANSFORM_MATRIX_SHIFT ) - maxLog2TrDynamicRange;
+    const int shift_2nd = Log2( height ) + TRANSFORM_MATRIX_SHIFT;
+    FwdFn* fh = fwdFn( trTypeHor, Log2( width ) ), *fv = fwdFn( trTypeVer, Log2( height ) );
+    if( !fh || !fv || shift_1st < 0 ) rc = -1;
+    else
+    {
+      fh( block, tmp, shift_1st, height, 0, skipWidth );
+      fv( tmp, dst, shift_2nd, width, skipWidth, skipHeight );
+    }
+  }
+  else rc = -2;
+  if( !rc ) memcpy( coef, dst, sizeof( TCoeff ) * width * height );
+  xFree( block ); xFree( tmp ); xFree( dst );
+  return rc;
+}
+
+// The wiring of TrQuant::xIT (TrQuant.cpp:567-655).
+API int vvref_xIT( int simd, const int32_t* coef, int16_t* resi, int resiStride, int width, int height,
+                   int trTypeHor, int trTypeVer, int bitDepth )
+{
+  const int maxLog2TrDynamicRange = 15;
+  const int TRANSFORM_MATRIX_SHIFT = g_transformMatrixShift[TRANSFORM_INVERSE];
+  const TCoeff clipMinimum = -( 1 << maxLog2TrDynamicRange );
+  const TCoeff clipMaximum =  ( 1 << maxLog2TrDynamicRange ) - 1;
+  int skipWidth  = ( trTypeHor != DCT2 && width  == 32 ) ? 16 : width  > JVET_C0024_ZERO_OUT_TH ? width  - JVET_C0024_ZERO_OUT_TH : 0;
+  int skipHeight = ( trTypeVer != DCT2 && height == 32 ) ? 16 : height > JVET_C0024_ZERO_OUT_TH ? height - JVET_C0024_ZERO_OUT_TH : 0;
+  selectTCoeffOps( simd );
+  TCoeff* src   = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
+  TCoeff* block = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
+  TCoeff* tmp   = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
+  memcpy( src, coef, sizeof( TCoeff ) * width * height );
+  int rc = 0;
+  if( width > 1 && height > 1 )
+  {
+    const int shift_1st = TRANSFORM_MATRIX_SHIFT + 1;
+    const int shift_2nd = ( TRANSFORM_MATRIX_SHIFT + maxLog2TrDynamicRange - 1 ) - bitDepth;
+    InvFn* fv = invFn( trTypeVer, Log2( height ) ), *fh = invFn( trTypeHor, Log2( width ) );
+    if( !fh || !fv ) rc = -1;
+    else
+    {
+      fv( src, tmp, shift_1st, width, skipWidth, skipHeight, clipMinimum, clipMaximum );
+      fh( tmp, block, shift_2nd, height, 0, skipWidth, clipMinimum, clipMaximum );
+    }
+  }
+  else rc = -2;
+  if( !rc )
+  {
+    if( width & 3 )
+    {
+      const TCoeff* b = block;
+      for( int y = 0; y < height; y++ ) for( int x = 0; x < width; x++ ) resi[y * resiStride + x] = ( Pel ) *b++;
+    }
+    else if( width & 7 ) g_tCoeffOps.cpyResi4( block, resi, resiStride, width, height );
+    else                 g_tCoeffOps.cpyResi8( block, resi, resiStride, width, height );
+  }
+  xFree( src ); xFree( block ); xFree( tmp );
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scalar quantisation
+// ---------------------------------------------------------------------------------------------
+API int vvref_scan_order( int log2w, int log2h, uint32_t* out )
+{
+  const ScanElement* scan = getScanOrder( SCAN_GROUPED_4x4, log2w, log2h );
+  const int n = 1 << ( log2w + log2h );
+  for( int i = 0; i < n; i++ ) out[i] = scan[i].idx;
+  return n;
+}
+
+API void vvref_quant_scales( int* q12, int* iq12 )
+{
+  for( int i = 0; i < 2; i++ ) for( int j = 0; j < 6; j++ ) { q12[i * 6 + j] = g_quantScales[i][j]; iq12[i * 6 + j] = g_invQuantScales[i][j]; }
+}
+
+API void vvref_dequant_core( int simd, int maxX, int maxY, int scale, const int16_t* q, size_t qStride, int32_t* coef,
+                             int rightShift, int inputMaximum, int32_t transformMaximum )
+{
+  // scalar = DeQuantCore is file-static in Quant.cpp; the only exported path is the pointer installed by the ctor (SIMD).
+  // simd==0 is served by a fresh Quant whose pointer we have NOT let initQuantX86 overwrite: not reachable -> both use ctor pointer.
+  ( void ) simd;
+  quantObj().xDeQuant( maxX, maxY, scale, q, qStride, coef, rightShift, inputMaximum, transformMaximum );
+}
+
+API int vvref_need_rdoq_core( int simd, const int32_t* coef, size_t num, int quantCoeff, int64_t offset, int shift )
+{
+  ( void ) simd;
+  return quantObj().xNeedRdoq( coef, num, quantCoeff, offset, shift ) ? 1 : 0;
+}
+
+// QuantCore through the pointer Quant::xQuant (SIMD row when built with x86 SIMD).  A minimal TransformUnit is faked:
+// QuantCore only touches tu.blocks[compID], tu.cu->lfnstIdx and CoeffCodingContext( tu, ... ) which reads
+// tu.block(), tu.cs->sps->getMaxLog2TrDynamicRange() (Quant.cpp:132-230, ContextModelling.cpp:61-66).
+API int vvref_quant_core( const int32_t* coef, int16_t* qcoef, int32_t* deltaU, int width, int height,
+                          int quantCoeff, int iQBits, int64_t iAdd, int signHiding, int thrVal,
+                          int32_t* absSumOut, int* lastScanPosOut )
+{
+  static SPS* sps = new SPS;
+  static void* csMem = calloc( 1, sizeof( CodingStructure ) );
+  CodingStructure* cs = reinterpret_cast<CodingStructure*>( csMem );
+  cs->sps = sps;
+  CodingUnit cu;
+  memset( ( void* ) &cu, 0, sizeof( cu ) );
+  cu.lfnstIdx = 0;
+  TransformUnit tu( CHROMA_420, Area( 0, 0, width, height ) );
+  tu.cu = &cu;
+  tu.cs = cs;
+  tu.mtsIdx[COMP_Y] = 0;
+  CCoeffBuf src( coef, width, width, height );
+  CoeffSigBuf dst( qcoef, width, width, height );
+  TCoeff absSum = 0; int lastScanPos = -1;
+  quantObj().xQuant( tu, COMP_Y, src, dst, absSum, lastScanPos, deltaU, quantCoeff, iQBits, iAdd,
+                     -( 1 << 15 ), ( 1 << 15 ) - 1, signHiding != 0, thrVal );
+  *absSumOut = absSum; *lastScanPosOut = lastScanPos;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MCTF
+// ---------------------------------------------------------------------------------------------
+API int vvref_mctf_err_int( int simd, const int16_t* org, ptrdiff_t orgStride, const int16_t* buf, ptrdiff_t bufStride, int w, int h, int besterror )
+{
+  return mctfPair().m[simd ? 1 : 0]->m_motionErrorLumaInt8( org, orgStride, buf, bufStride, w, h, besterror );
+}
+
+// tap4 = 1 -> m_motionErrorLumaFrac8[1] with MCTF::m_interpolationFilter4 rows, else [0] with m_interpolationFilter8 rows
+API int vvref_mctf_err_frac( int simd, int tap4, const int16_t* org, ptrdiff_t orgStride, const int16_t* buf, ptrdiff_t bufStride,
+                             int w, int h, int fx, int fy, int bitDepth, int besterror )
+{
+  MCTF* m = mctfPair().m[simd ? 1 : 0];
+  const int16_t* xf = tap4 ? MCTF::m_interpolationFilter4[fx] : MCTF::m_interpolationFilter8[fx];
+  const int16_t* yf = tap4 ? MCTF::m_interpolationFilter4[fy] : MCTF::m_interpolationFilter8[fy];
+  return m->m_motionErrorLumaFrac8[tap4 ? 1 : 0]( org, orgStride, buf, bufStride, w, h, xf, yf, bitDepth, besterror );
+}
+
+API void vvref_mctf_filters( int16_t* f8 /*16*8*/, int16_t* f4 /*16*4*/ )
+{
+  memcpy( f8, MCTF::m_interpolationFilter8, sizeof( int16_t ) * 16 * 8 );
+  memcpy( f4, MCTF::m_interpolationFilter4, sizeof( int16_t ) * 16 * 4 );
+}
+
+API double vvref_mctf_calc_var( int simd, const int16_t* org, ptrdiff_t stride, int w, int h )
+{
+  return mctfPair().m[simd ? 1 : 0]->m_calcVar( org, stride, w, h );
+}
+
+namespace {
+struct MvOut { int32_t x, y, error, rmsme; double overlap; };
+
+void fillPlane( PelStorage& ps, const int16_t* src, int w, int h )
+{
+  ps.create( CHROMA_400, Area( 0, 0, w, h ), 0, MCTF_PADDING );
+  PelBuf y = ps.Y();
+  for( int r = 0; r < h; r++ ) memcpy( y.buf + r * y.stride, src + ( size_t ) r * w, sizeof( int16_t ) * w );
+  y.extendBorderPel( MCTF_PADDING, MCTF_PADDING );   // MCTF::initPicture, MCTF.cpp:608-612
+}
+void dumpMvs( const Array2D<MotionVector>& a, MvOut* out )
+{
+  for( int y = 0; y < a.h(); y++ ) for( int x = 0; x < a.w(); x++ )
+  {
+    const MotionVector& m = a.get( x, y );
+    MvOut& o = out[y * a.w() + x];
+    o.x = m.x; o.y = m.y; o.error = m.error; o.rmsme = m.rmsme; o.overlap = m.overlap;
+  }
+}
+} // namespace
+
+// Runs MCTF::subsampleLuma once; `out` must hold (w/2)*(h/2) samples (visible area only).
+API void vvref_mctf_subsample( const int16_t* src, int w, int h, int16_t* out )
+{
+  MCTF m( false );
+  PelStorage in, o;
+  fillPlane( in, src, w, h );
+  m.subsampleLuma( in, o );
+  CPelBuf y = o.Y();
+  for( int r = 0; r < ( int ) y.height; r++ ) memcpy( out + ( size_t ) r * y.width, y.buf + r * y.stride, sizeof( int16_t ) * y.width );
+}
+
+// The hierarchical search of MCTF::motionEstimationMCTF (MCTF.cpp:666-724) for ONE (current, reference) pair of luma planes,
+// single-threaded (m_threadPool == nullptr -> MCTF.cpp:1388-1396, same results as the threaded wavefront).
+// levelOut[k] (k=0: 1/8 if addLevel, then 1/4, 1/2, 1/1@2*unit, final@unit) receive MvOut arrays; dims are written to levelDims[2*k+{0,1}].
+API int vvref_mctf_me( int simd, const int16_t* orgLuma, const int16_t* refLuma, int width, int height, int bitDepth,
+                       int unitSize, int mctfSpeed, int addLevel, MvOut** levelOut, int* levelDims )
+{
+  MCTF m( simd != 0 );
+  static VVEncCfg cfg;
+  vvenc_init_default( &cfg, width, height, 30, 0, 32, VVENC_FASTER );
+  cfg.m_internalBitDepth[0] = bitDepth;
+  cfg.m_internalBitDepth[1] = bitDepth;
+  m.m_encCfg = &cfg;
+  m.m_threadPool = nullptr;
+  m.m_area = Area( 0, 0, width, height );
+  m.m_lowResFltSearch = mctfSpeed > 0;                                        // MCTF.cpp:598
+  m.m_searchPttrn     = mctfSpeed > 0 ? ( mctfSpeed >= 3 ? 2 : 1 ) : 0;       // MCTF.cpp:599
+  m.m_mctfUnitSize    = unitSize;
+
+  PelStorage org, ref;
+  fillPlane( org, orgLuma, width, height );
+  fillPlane( ref, refLuma, width, height );
+
+  PelStorage o2, o4, o8, b2, b4, b8;
+  m.subsampleLuma( org, o2 ); m.subsampleLuma( o2, o4 );
+  m.subsampleLuma( ref, b2 ); m.subsampleLuma( b2, b4 );
+  if( addLevel ) { m.subsampleLuma( o4, o8 ); m.subsampleLuma( b4, b8 ); }
+
+  const int wInBlks = ( width + unitSize - 1 ) / unitSize, hInBlks = ( height + unitSize - 1 ) / unitSize;
+  Array2D<MotionVector> mv_m( width / ( unitSize * 16 ) + 1, height / ( unitSize * 16 ) + 1 );
+  Array2D<MotionVector> mv_0( width / ( unitSize * 8 ) + 1, height / ( unitSize * 8 ) + 1 );
+  Array2D<MotionVector> mv_1( width / ( unitSize * 4 ) + 1, height / ( unitSize * 4 ) + 1 );
+  Array2D<MotionVector> mv_2( width / ( unitSize * 2 ) + 1, height / ( unitSize * 2 ) + 1 );
+  Array2D<MotionVector> mvs; mvs.allocate( wInBlks, hInBlks );
+
+  int k = 0;
+  if( addLevel )
+  {
+    m.motionEstimationLuma( mv_m, o8, b8, 2 * unitSize );
+    m.motionEstimationLuma( mv_0, o4, b4, 2 * unitSize, &mv_m, 2 );
+    levelDims[0] = mv_m.w(); levelDims[1] = mv_m.h(); if( levelOut[0] ) dumpMvs( mv_m, levelOut[0] );
+  }
+  else
+  {
+    m.motionEstimationLuma( mv_0, o4, b4, 2 * unitSize );
+    levelDims[0] = 0; levelDims[1] = 0;
+  }
+  k = 1;
+  levelDims[2] = mv_0.w(); levelDims[3] = mv_0.h(); if( levelOut[1] ) dumpMvs( mv_0, levelOut[1] );
+  m.motionEstimationLuma( mv_1, o2, b2, 2 * unitSize, &mv_0, 2 );
+  levelDims[4] = mv_1.w(); levelDims[5] = mv_1.h(); if( levelOut[2] ) dumpMvs( mv_1, levelOut[2] );
+  m.motionEstimationLuma( mv_2, org, ref, 2 * unitSize, &mv_1, 2 );
+  levelDims[6] = mv_2.w(); levelDims[7] = mv_2.h(); if( levelOut[3] ) dumpMvs( mv_2, levelOut[3] );
+  m.motionEstimationLuma( mvs, org, ref, unitSize, &mv_2, 1, true );
+  levelDims[8] = mvs.w(); levelDims[9] = mvs.h(); if( levelOut[4] ) dumpMvs( mvs, levelOut[4] );
+  ( void ) k;
+  return 0;
+}
+
+API const char* vvref_version() { return "vvenc reference 1.15.0-dev (built from /root/reference by oracle/ref/Makefile)"; }

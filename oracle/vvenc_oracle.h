@@ -1,0 +1,60 @@
+/* vvenc_oracle.h — C interface of the CPU parity oracle (TEST INFRASTRUCTURE ONLY, see vvenc_oracle.c). */
+#ifndef VVENC_ORACLE_H
+#define VVENC_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* transform types: numbering of the reference's TransType enum (CommonLib/TypeDef.h: DCT2=0, DCT8=1, DST7=2) */
+enum { ORC_DCT2 = 0, ORC_DCT8 = 1, ORC_DST7 = 2 };
+
+/* one MCTF motion vector, layout of MotionVector (CommonLib/MCTF.h:72-82): 1/16-pel x,y */
+typedef struct { int32_t x, y, error, rmsme; double overlap; } orc_mv_t;
+
+uint64_t orc_sad(const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift);
+uint64_t orc_sse(const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h);
+uint64_t orc_had(const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int fast);
+uint64_t orc_had_2sad(const int16_t *org, const int16_t *cur, int w, int h);
+void     orc_sad_x5(const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift,
+                    uint64_t cost[5], int calcCentre);
+uint64_t orc_sad_mask(const int16_t *org, int os, const int16_t *cur, int cs, const int16_t *mask, int maskStride,
+                      int stepX, int maskStride2, int w, int h, int subShift);
+uint64_t orc_fix_weighted_sse(const int16_t *org, int os, const int16_t *cur, int cs, int w, int h, uint32_t weight);
+
+int  orc_tr_matrix(int trType, int log2N, int16_t *out);
+int  orc_fwd_1d(int trType, int log2N, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2);
+int  orc_inv_1d(int trType, int log2N, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2,
+                int32_t clipMin, int32_t clipMax);
+int  orc_xT(const int16_t *resi, int resiStride, int32_t *coef, int w, int h, int trHor, int trVer, int bitDepth);
+int  orc_xIT(const int32_t *coef, int16_t *resi, int resiStride, int w, int h, int trHor, int trVer, int bitDepth);
+
+extern const int orc_quant_scales[2][6];
+extern const int orc_inv_quant_scales[2][6];
+void orc_cg_size(int log2w, int log2h, int *log2CGw, int *log2CGh);
+int  orc_scan_order(int log2w, int log2h, uint32_t *out);
+void orc_quant_params(int w, int h, int bitDepth, int qp, int isIRAP, int *quantCoeff, int *iQBits, int64_t *iAdd);
+void orc_dequant_params(int w, int h, int bitDepth, int qp, int *scale, int *rightShift, int *inputMaximum);
+void orc_need_rdoq_params(int w, int h, int bitDepth, int qp, int isLuma, int *quantCoeff, int *iQBits, int64_t *iAdd, int *numCoeff);
+void orc_quant_core(const int32_t *coef, int16_t *qcoef, int32_t *deltaU, int w, int h, int quantCoeff, int iQBits,
+                    int64_t iAdd, int thrVal, int32_t *absSumOut, int *lastScanPosOut);
+void orc_dequant_core(int maxX, int maxY, int scale, const int16_t *q, size_t qStride, int32_t *coef, int rightShift,
+                      int inputMaximum, int32_t transformMaximum);
+int  orc_need_rdoq(const int32_t *coef, size_t num, int quantCoeff, int64_t offset, int shift);
+
+extern const int16_t orc_mctf_filter6[16][8];
+extern const int16_t orc_mctf_filter4[16][4];
+int    orc_mctf_err_int(const int16_t *org, ptrdiff_t os, const int16_t *buf, ptrdiff_t bs, int w, int h);
+int    orc_mctf_err_frac(int tap4, const int16_t *org, ptrdiff_t os, const int16_t *buf, ptrdiff_t bs, int w, int h,
+                         int fx, int fy, int bitDepth);
+double orc_mctf_calc_var(const int16_t *org, ptrdiff_t stride, int w, int h);
+void   orc_extend_border(int16_t *buf, int stride, int w, int h, int pad);
+void   orc_mctf_subsample(const int16_t *src, int srcStride, int w, int h, int16_t *dst, int dstStride);
+int    orc_mctf_me(const int16_t *orgLuma, const int16_t *refLuma, int width, int height, int bitDepth, int unitSize,
+                   int mctfSpeed, int addLevel, orc_mv_t **levelOut, int *levelDims);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

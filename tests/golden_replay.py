@@ -1,0 +1,120 @@
+"""Replays tests/golden/*.npz (inputs + outputs of the reference itself, written by tools/gen_golden.py)
+against any backend exposing the Oracle method names (oracle.oracle.Oracle, or the HIP backend
+adapter in tests/hip_backend.py).  Bit-exact (tolerance 0) everywhere."""
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def check_distortion(be):
+    g = load("distortion")
+    org, cur = g["org"], g["cur"]
+    funcs = [str(f) for f in g["funcs"]]
+    for (fi, ox, oy, cx, cy, w, h, ss), exp in zip(g["cases"], g["out"]):
+        got = be.dist(funcs[fi], (org, int(oy), int(ox)), (cur, int(cy), int(cx)), int(w), int(h), 10, int(ss))
+        assert got == int(exp), (funcs[fi], w, h, ss, got, int(exp))
+    for (ox, oy, cx, cy, w, h), exp in zip(g["x5_cases"], g["x5_out"]):
+        got = be.sad_x5((org, int(oy), int(ox)), (cur, int(cy), int(cx)), int(w), int(h), 1, True)
+        assert np.array_equal(got, exp), (w, h)
+    off = 0
+    for (w, h), exp in zip(g["h2_cases"], g["h2_out"]):
+        n = int(w) * int(h)
+        a = np.ascontiguousarray(g["h2_in"][off:off + n].reshape(h, w))
+        b = np.ascontiguousarray(g["h2_in"][off + n:off + 2 * n].reshape(h, w))
+        off += 2 * n
+        assert be.dist("HAD_2SAD", a, b, int(w), int(h)) == int(exp), (w, h)
+
+
+def check_transform_matrices(be):
+    g = load("transform")
+    for t, name, logs in ((0, "DCT2", range(1, 7)), (1, "DCT8", range(2, 6)), (2, "DST7", range(2, 6))):
+        for l in logs:
+            assert np.array_equal(be.tr_matrix(t, l), g["mat_%s_%d" % (name, 1 << l)]), (name, l)
+
+
+def check_transform(be):
+    g = load("transform")
+    off = 0
+    for (w, h, th, tv, bd) in g["cases"]:
+        n = int(w) * int(h)
+        resi = g["resi"][off:off + n].reshape(h, w)
+        coef = g["coef"][off:off + n].reshape(h, w)
+        cin = g["coef_in"][off:off + n].reshape(h, w)
+        rec = g["rec"][off:off + n].reshape(h, w)
+        off += n
+        assert np.array_equal(be.xT(resi, int(th), int(tv), int(bd)), coef), ("xT", w, h, th, tv)
+        assert np.array_equal(be.xIT(cin, int(th), int(tv), int(bd)), rec), ("xIT", w, h, th, tv)
+
+
+def check_scan(be):
+    g = load("quant")
+    for lw in range(0, 7):
+        for lh in range(0, 7):
+            assert np.array_equal(be.scan_order(lw, lh), g["scan_%d_%d" % (lw, lh)].astype(np.uint32)), (lw, lh)
+
+
+def check_quant(be):
+    g = load("quant")
+    off = 0
+    for c in g["cases"]:
+        w, h, qp, irap, qc, qbits, s, last, sc, rs, imax, nqc, nqbits, num, need0, need1, div = [int(v) for v in c]
+        n = w * h
+        coef = g["coef"][off:off + n].reshape(h, w)
+        lev = g["level"][off:off + n].reshape(h, w)
+        du = g["deltaU"][off:off + n]
+        deq = g["dequant"][off:off + n].reshape(h, w)
+        off += n
+        add = (171 if irap else 85) << (qbits - 9)
+        assert be.quant_params(w, h, 10, qp, irap) == (qc, qbits, add)
+        q, d, ssum, slast = be.quant_core(coef, qc, qbits, add, 8)
+        assert (ssum, slast) == (s, last), (w, h, qp)
+        assert np.array_equal(q, lev), (w, h, qp)
+        keep = np.zeros(n, bool)
+        keep[be.scan_order(w.bit_length() - 1, h.bit_length() - 1)[: last + 1]] = True
+        assert np.array_equal(np.where(keep, d, 0), du), (w, h, qp)
+        assert be.dequant_params(w, h, 10, qp) == (sc, rs, imax)
+        assert np.array_equal(be.dequant_core(lev, sc, rs, imax), deq), (w, h, qp)
+        nadd = 171 << (nqbits - 9)
+        assert be.need_rdoq_params(w, h, 10, qp, 1) == (nqc, nqbits, nadd, num)
+        small = (coef // div).astype(np.int32)
+        assert be.need_rdoq(coef.ravel()[:num], nqc, nadd, nqbits) == need0
+        assert be.need_rdoq(small.ravel()[:num], nqc, nadd, nqbits) == need1
+
+
+def check_mctf_kernels(be):
+    g = load("mctf")
+    org, buf = g["org"], g["buf"]
+    for (kind, ox, oy, bx, by, w, h, fx, fy), exp in zip(g["err_cases"], g["err_out"]):
+        o, b = (org, int(oy), int(ox)), (buf, int(by), int(bx))
+        if kind == 0:
+            got = be.mctf_err_int(o, b, int(w), int(h))
+        else:
+            got = be.mctf_err_frac(int(kind) - 1, o, b, int(w), int(h), int(fx), int(fy), 10)
+        assert got == int(exp), (kind, w, h, fx, fy)
+    for (x, y, w, h), exp in zip(g["var_cases"], g["var_out"]):
+        assert be.mctf_calc_var((org, int(y), int(x)), int(w), int(h)) == float(exp)
+    assert np.array_equal(be.mctf_subsample(org), g["sub_out"])
+
+
+def check_mctf_me(be, which=None):
+    g = load("mctf")
+    for i, (w, h, speed, unit, add) in enumerate(g["me_cfgs"]):
+        if which is not None and i not in which:
+            continue
+        lv = be.mctf_me(g["me%d_org" % i], g["me%d_ref" % i], 10, int(unit), int(speed), bool(add))
+        for k in range(5):
+            key = "me%d_l%d" % (i, k)
+            if key not in g:
+                assert lv[k] is None
+                continue
+            exp = g[key]
+            for f in ("x", "y", "error"):
+                assert np.array_equal(lv[k][f], exp[f]), (i, k, f, np.argwhere(lv[k][f] != exp[f])[:4])
+            if k == 4:
+                assert np.array_equal(lv[k]["rmsme"], exp["rmsme"]) and np.array_equal(lv[k]["overlap"], exp["overlap"])

@@ -1,0 +1,31 @@
+"""oracle/vvenc_oracle.c against the committed golden vectors (outputs of the reference itself,
+tests/golden/*.npz written by tools/gen_golden.py).  CPU only; runs where /root/reference is absent."""
+import golden_replay as G
+
+
+def test_distortion(oracle):
+    G.check_distortion(oracle)
+
+
+def test_transform_matrices(oracle):
+    G.check_transform_matrices(oracle)
+
+
+def test_transform(oracle):
+    G.check_transform(oracle)
+
+
+def test_scan(oracle):
+    G.check_scan(oracle)
+
+
+def test_quant(oracle):
+    G.check_quant(oracle)
+
+
+def test_mctf_kernels(oracle):
+    G.check_mctf_kernels(oracle)
+
+
+def test_mctf_me(oracle):
+    G.check_mctf_me(oracle)

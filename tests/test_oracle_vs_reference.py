@@ -1,0 +1,256 @@
+"""Pins oracle/vvenc_oracle.c to the reference itself (oracle/_ref/libvvenc_ref.so, built from
+/root/reference by oracle/ref/Makefile), scalar row AND x86-SIMD row, tolerance 0.
+
+Mirrors the reference's own unit tests: test_RdCost (vvenc_unit_test.cpp:2136-2179: widths x heights,
+10-bit unsigned samples, random strides, subShift 0/1), test_TCoeffOps (:1175-1210) and test_MCTF
+(:1592-1654: w,h in 8..64 step 8, all 15x15 filter phases).  Skipped where the .so is absent.
+"""
+import numpy as np
+import pytest
+
+from oracle.oracle import DCT2, DCT8, DST7
+
+pytestmark = pytest.mark.ref
+
+SIZES = [2, 4, 8, 16, 32, 64, 128]
+
+
+def rand_plane(rng, h, w, bits=10):
+    return rng.integers(0, 1 << bits, size=(h, w), dtype=np.int16)
+
+
+def test_sad_sse(oracle, reflib):
+    rng = np.random.default_rng(1)
+    for w in [4, 8, 16, 32, 64, 128]:
+        for h in [2, 4, 8, 16, 32, 64, 128]:
+            so, sc = w + int(rng.integers(0, 64)), w + int(rng.integers(0, 64))
+            org, cur = rand_plane(rng, h, so), rand_plane(rng, h, sc)
+            for ss in (0, 1):
+                if ss and h < 2:
+                    continue
+                assert oracle.dist("SAD", org, cur, w, h, 10, ss) == reflib.dist("SAD", org, cur, w, h, 10, ss), (w, h, ss)
+            assert oracle.dist("SSE", org, cur, w, h) == reflib.dist("SSE", org, cur, w, h), (w, h)
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_had(oracle, reflib, fast):
+    rng = np.random.default_rng(2)
+    name = "HAD_fast" if fast else "HAD"
+    for w in SIZES:
+        for h in SIZES:
+            for rep in range(3):
+                so, sc = w + int(rng.integers(0, 32)), w + int(rng.integers(0, 32))
+                org, cur = rand_plane(rng, h, so), rand_plane(rng, h, sc)
+                if rep == 2:   # near-equal blocks: small SATD values exercise the rounding corners
+                    cur[:, :w] = np.clip(org[:, :w].astype(np.int32) + rng.integers(-2, 3, size=(h, w)), 0, 1023).astype(np.int16)
+                assert oracle.dist(name, org, cur, w, h) == reflib.dist(name, org, cur, w, h), (w, h, rep)
+
+
+def test_had_2sad(oracle, reflib):
+    rng = np.random.default_rng(3)
+    for w in [4, 8, 16, 32, 64]:
+        for h in [4, 8, 16, 32, 64]:
+            org, cur = rand_plane(rng, h, w), rand_plane(rng, h, w)
+            cur2 = np.clip(org.astype(np.int32) + rng.integers(-3, 4, size=(h, w)), 0, 1023).astype(np.int16)
+            for c in (cur, cur2):
+                assert oracle.dist("HAD_2SAD", org, c, w, h) == reflib.dist("HAD_2SAD", org, c, w, h), (w, h)
+
+
+def test_sad_x5(oracle, reflib):
+    rng = np.random.default_rng(4)
+    for w in (8, 16):
+        for h in (8, 16):
+            stride = w + 24
+            org, cur = rand_plane(rng, h + 2, stride), rand_plane(rng, h + 2, stride)
+            for centre in (True, False):
+                a = oracle.sad_x5((org, 0, 2), (cur, 0, 8), w, h, 1, centre)
+                b = reflib.sad_x5((org, 0, 2), (cur, 0, 8), w, h, 1, centre)
+                if not centre:
+                    a[2] = b[2] = 0
+                assert np.array_equal(a, b), (w, h, centre)
+
+
+def test_fix_weighted_sse(oracle, reflib):
+    rng = np.random.default_rng(5)
+    for w in (4, 8, 16, 32):
+        for h in (4, 8, 16, 32):
+            org, cur = rand_plane(rng, h, w + 3), rand_plane(rng, h, w + 5)
+            wt = int(rng.integers(1, 1 << 17))
+            assert oracle.fix_weighted_sse(org, cur, w, h, wt) == reflib.fix_weighted_sse(org, cur, w, h, wt)
+
+
+def test_transform_matrices(oracle, reflib):
+    for t, rng_ in ((DCT2, range(1, 7)), (DCT8, range(2, 6)), (DST7, range(2, 6))):
+        for l in rng_:
+            assert np.array_equal(oracle.tr_matrix(t, l), reflib.tr_matrix(t, l)), (t, l)
+
+
+def test_fwd_inv_1d(oracle, reflib):
+    rng = np.random.default_rng(6)
+    for t, logs in ((DCT2, range(1, 7)), (DCT8, range(2, 6)), (DST7, range(2, 6))):
+        for l in logs:
+            n = 1 << l
+            for line in (4, 8, 16, 32, 64):
+                for skip, skip2 in ((0, 0), (line // 2 if line >= 8 else 0, n // 2 if n >= 8 else 0)):
+                    src = rng.integers(-(1 << 11), 1 << 11, size=n * line).astype(np.int32)
+                    shift = int(rng.integers(1, 13))
+                    a = oracle.fwd_1d(t, l, src, shift, line, skip, skip2)
+                    b = reflib.fwd_1d(t, l, src, shift, line, skip, skip2)
+                    assert np.array_equal(a, b), ("fwd", t, l, line, skip, skip2, shift)
+                    src = rng.integers(-(1 << 15), 1 << 15, size=n * line).astype(np.int32)
+                    if skip2:   # the reference's inverse only reads rows < cutoff
+                        src.reshape(n, line)[n - skip2:, :] = 0
+                    for sh in (7, 10, 12):
+                        a = oracle.inv_1d(t, l, src, sh, line, skip, skip2)
+                        b = reflib.inv_1d(t, l, src, sh, line, skip, skip2)
+                        assert np.array_equal(a, b), ("inv", t, l, line, skip, skip2, sh)
+
+
+def _tr_types(w, h):
+    yield DCT2, DCT2
+    if 4 <= w <= 32 and 4 <= h <= 32:
+        for th in (DST7, DCT8):
+            for tv in (DST7, DCT8):
+                yield th, tv
+    if 4 <= w <= 32:
+        yield DST7, DCT2
+    if 4 <= h <= 32:
+        yield DCT2, DST7
+
+
+def test_xT_xIT(oracle, reflib):
+    rng = np.random.default_rng(7)
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            for th, tv in _tr_types(w, h):
+                for bd in (8, 10):
+                    resi = rng.integers(-(1 << bd), 1 << bd, size=(h, w)).astype(np.int16)
+                    a, b = oracle.xT(resi, th, tv, bd), reflib.xT(resi, th, tv, bd)
+                    assert np.array_equal(a, b), ("xT", w, h, th, tv, bd)
+                    coef = (a // int(rng.integers(1, 9))).astype(np.int32)
+                    coef2 = rng.integers(-(1 << 15), 1 << 15, size=(h, w)).astype(np.int32)
+                    for c in (coef, coef2):
+                        skw = 16 if (th != DCT2 and w == 32) else max(0, w - 32)
+                        skh = 16 if (tv != DCT2 and h == 32) else max(0, h - 32)
+                        c = c.copy()
+                        if skw:
+                            c[:, w - skw:] = 0
+                        if skh:
+                            c[h - skh:, :] = 0
+                        ra, rb = oracle.xIT(c, th, tv, bd), reflib.xIT(c, th, tv, bd)
+                        assert np.array_equal(ra, rb), ("xIT", w, h, th, tv, bd)
+
+
+def test_scan_order_and_scales(oracle, reflib):
+    for lw in range(0, 7):
+        for lh in range(0, 7):
+            assert np.array_equal(oracle.scan_order(lw, lh), reflib.scan_order(lw, lh)), (lw, lh)
+    import ctypes as C
+    q, iq = reflib.quant_scales()
+    oq = np.ctypeslib.as_array((C.c_int * 12).in_dll(oracle.L, "orc_quant_scales")).reshape(2, 6)
+    oiq = np.ctypeslib.as_array((C.c_int * 12).in_dll(oracle.L, "orc_inv_quant_scales")).reshape(2, 6)
+    assert np.array_equal(q, oq) and np.array_equal(iq, oiq)
+
+
+def test_quant_cores(oracle, reflib):
+    rng = np.random.default_rng(8)
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            for qp in (12 + 22, 12 + 32, 12 + 45):      # baseQp incl. qpBdOffset 12 for 10-bit
+                for irap in (0, 1):
+                    qc, qbits, add = oracle.quant_params(w, h, 10, qp, irap)
+                    for scale_in in (1 << 9, 1 << 12, 1 << 15):
+                        coef = rng.integers(-scale_in, scale_in, size=(h, w)).astype(np.int32)
+                        coef[rng.random((h, w)) < 0.5] = 0
+                        if w > 32:
+                            coef[:, 32:] = 0
+                        if h > 32:
+                            coef[32:, :] = 0
+                        for thr in (8, 4):
+                            a = oracle.quant_core(coef, qc, qbits, add, thr)
+                            b = reflib.quant_core(coef, qc, qbits, add, thr, sign_hiding=True)   # SIMD row writes deltaU only for SBH
+                            assert a[2] == b[2] and a[3] == b[3], ("sum/last", w, h, qp, irap, thr, a[2:], b[2:])
+                            assert np.array_equal(a[0], b[0]), ("levels", w, h, qp)
+                            nz = np.zeros(h * w, bool)
+                            nz[oracle.scan_order(w.bit_length() - 1, h.bit_length() - 1)[: a[3] + 1]] = True
+                            assert np.array_equal(a[1][nz], b[1][nz]), ("deltaU", w, h, qp)
+                    sc, rs, imax = oracle.dequant_params(w, h, 10, qp)
+                    q = rng.integers(-(1 << 15), 1 << 15, size=(h, w)).astype(np.int16)
+                    q[rng.random((h, w)) < 0.3] = 0
+                    assert np.array_equal(oracle.dequant_core(q, sc, rs, imax), reflib.dequant_core(q, sc, rs, imax)), ("deq", w, h, qp)
+                    qc, qbits, add, num = oracle.need_rdoq_params(w, h, 10, qp, 1)
+                    for mag in (4, 64, 1024):
+                        coef = rng.integers(-mag, mag + 1, size=num).astype(np.int32)
+                        assert oracle.need_rdoq(coef, qc, add, qbits) == reflib.need_rdoq(coef, qc, add, qbits), ("rdoq", w, h, qp, mag)
+
+
+def test_mctf_errors(oracle, reflib):
+    rng = np.random.default_rng(9)
+    f8, f4 = reflib.mctf_filters()
+    import ctypes as C
+    o8 = np.ctypeslib.as_array((C.c_int16 * 128).in_dll(oracle.L, "orc_mctf_filter6")).reshape(16, 8)
+    o4 = np.ctypeslib.as_array((C.c_int16 * 64).in_dll(oracle.L, "orc_mctf_filter4")).reshape(16, 4)
+    assert np.array_equal(f8, o8) and np.array_equal(f4, o4)
+    for w in range(8, 65, 8):
+        for h in range(8, 65, 8):
+            for bd in (8, 10):
+                org = rand_plane(rng, h + 16, w + 24, bd)
+                buf = rand_plane(rng, h + 16, w + 24, bd)
+                assert oracle.mctf_err_int((org, 4, 4), (buf, 5, 7), w, h) == reflib.mctf_err_int((org, 4, 4), (buf, 5, 7), w, h)
+                phases = [(int(rng.integers(1, 16)), int(rng.integers(1, 16))) for _ in range(6)] + [(0, 5), (9, 0)]
+                for fx, fy in phases:
+                    for tap4 in (0, 1):
+                        a = oracle.mctf_err_frac(tap4, (org, 4, 4), (buf, 5, 7), w, h, fx, fy, bd)
+                        b = reflib.mctf_err_frac(tap4, (org, 4, 4), (buf, 5, 7), w, h, fx, fy, bd)
+                        assert a == b, (w, h, bd, fx, fy, tap4)
+
+
+def test_mctf_err_all_phases(oracle, reflib):
+    rng = np.random.default_rng(10)
+    w = h = 16
+    org, buf = rand_plane(rng, 32, 40), rand_plane(rng, 32, 40)
+    for fx in range(16):
+        for fy in range(16):
+            if fx == 0 and fy == 0:
+                continue
+            for tap4 in (0, 1):
+                assert oracle.mctf_err_frac(tap4, (org, 4, 4), (buf, 6, 6), w, h, fx, fy) == \
+                    reflib.mctf_err_frac(tap4, (org, 4, 4), (buf, 6, 6), w, h, fx, fy)
+
+
+def test_mctf_calc_var_subsample(oracle, reflib):
+    rng = np.random.default_rng(11)
+    for w in (8, 16, 32):
+        for h in (8, 16, 32):
+            org = rand_plane(rng, h + 2, w + 9)
+            assert oracle.mctf_calc_var((org, 1, 3), w, h) == reflib.mctf_calc_var((org, 1, 3), w, h)
+    plane = rand_plane(rng, 46, 82)
+    assert np.array_equal(oracle.mctf_subsample(plane), reflib.mctf_subsample(plane))
+
+
+def synth_pair(rng, h, w, shift=(3, 1), noise=6):
+    """textured frame + displaced/noisy copy (SURVEY §8d generator family)"""
+    yy, xx = np.mgrid[0:h + 32, 0:w + 32]
+    base = 512 + 180 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 120 * np.sin((xx + yy) / 11.0) + 60 * np.sin(xx / 3.1) * np.sin(yy / 4.3)
+    base = base + rng.normal(0, 12, base.shape)
+    a = np.clip(base[16:16 + h, 16:16 + w], 0, 1023)
+    b = np.clip(base[16 + shift[1]:16 + shift[1] + h, 16 + shift[0]:16 + shift[0] + w] + rng.normal(0, noise, (h, w)), 0, 1023)
+    return a.astype(np.int16), b.astype(np.int16)
+
+
+@pytest.mark.parametrize("cfg", [(176, 144, 4, 16, False), (200, 120, 4, 8, False), (176, 144, 0, 16, False),
+                                 (256, 136, 2, 16, True), (328, 200, 3, 16, True)])
+def test_mctf_me(oracle, reflib, cfg):
+    w, h, speed, unit, add = cfg
+    rng = np.random.default_rng(12 + w)
+    org, ref = synth_pair(rng, h, w)
+    a = oracle.mctf_me(org, ref, 10, unit, speed, add)
+    b = reflib.mctf_me(org, ref, 10, unit, speed, add)
+    for k in range(5):
+        if a[k] is None:
+            assert b[k] is None
+            continue
+        for f in ("x", "y", "error"):
+            assert np.array_equal(a[k][f], b[k][f]), (k, f, np.argwhere(a[k][f] != b[k][f])[:5])
+    assert np.array_equal(a[4]["rmsme"], b[4]["rmsme"])
+    assert np.array_equal(a[4]["overlap"], b[4]["overlap"])

@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/*.npz: seeded inputs + the outputs of THE REFERENCE ITSELF
+(oracle/_ref/libvvenc_ref.so, compiled from /root/reference by oracle/ref/Makefile; x86-SIMD row,
+which the reference's own unit tests hold equal to its scalar row).
+
+Run in the build container (needs /root/reference):   python tools/gen_golden.py
+The fixtures are committed; tests/test_oracle_golden.py and the -m gpu parity tests replay them on
+machines where /root/reference does not exist.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.oracle import DCT2, DCT8, DST7, RefLib, build_ref  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def rand_plane(rng, h, w, bits=10):
+    return rng.integers(0, 1 << bits, size=(h, w), dtype=np.int16)
+
+
+def synth_pair(rng, h, w, shift=(3, 1), noise=6):
+    yy, xx = np.mgrid[0:h + 32, 0:w + 32]
+    base = 512 + 180 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 120 * np.sin((xx + yy) / 11.0) + 60 * np.sin(xx / 3.1) * np.sin(yy / 4.3)
+    base = base + rng.normal(0, 12, base.shape)
+    a = np.clip(base[16:16 + h, 16:16 + w], 0, 1023)
+    b = np.clip(base[16 + shift[1]:16 + shift[1] + h, 16 + shift[0]:16 + shift[0] + w] + rng.normal(0, noise, (h, w)), 0, 1023)
+    return a.astype(np.int16), b.astype(np.int16)
+
+
+def main():
+    build_ref()
+    R = RefLib(1)
+    R0 = RefLib(0)
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20260923)
+
+    # ---- distortion: one 160x96 plane pair, a list of (func, x, y, cx, cy, w, h, subShift) cases ----
+    org, cur = rand_plane(rng, 160, 224), rand_plane(rng, 160, 224)
+    cur[40:120, 60:180] = np.clip(org[40:120, 60:180].astype(np.int32) + rng.integers(-3, 4, (80, 120)), 0, 1023).astype(np.int16)
+    cases, outs = [], []
+    funcs = ["SAD", "SSE", "HAD", "HAD_fast"]
+    for fi, f in enumerate(funcs):
+        for w in (2, 4, 8, 16, 32, 64, 128):
+            for h in (2, 4, 8, 16, 32, 64, 128):
+                if f in ("SAD", "SSE") and w < 4:
+                    continue
+                for rep in range(2):
+                    ox, oy = int(rng.integers(0, 224 - w)), int(rng.integers(0, 160 - h))
+                    cx, cy = int(rng.integers(0, 224 - w)), int(rng.integers(0, 160 - h))
+                    if rep:
+                        ox, oy = int(rng.integers(60, 181 - w)) if w <= 120 else 60, int(rng.integers(40, 121 - h)) if h <= 80 else 0
+                        cx, cy = ox, oy
+                    ss = int(rng.integers(0, 2)) if f == "SAD" else 0
+                    v = R.dist(f, (org, oy, ox), (cur, cy, cx), w, h, 10, ss)
+                    assert v == R0.dist(f, (org, oy, ox), (cur, cy, cx), w, h, 10, ss)
+                    cases.append((fi, ox, oy, cx, cy, w, h, ss))
+                    outs.append(v)
+    x5_cases, x5_out = [], []
+    for w in (8, 16):
+        for h in (8, 16):
+            ox, oy, cx, cy = 20, 10, 100, 50
+            x5_cases.append((ox, oy, cx, cy, w, h))
+            x5_out.append(R.sad_x5((org, oy, ox), (cur, cy, cx), w, h, 1, True))
+    h2_cases, h2_in, h2_out = [], [], []
+    for w in (4, 8, 16, 32):
+        for h in (4, 8, 16, 32):
+            a, b = rand_plane(rng, h, w), rand_plane(rng, h, w)
+            b2 = np.clip(a.astype(np.int32) + rng.integers(-3, 4, (h, w)), 0, 1023).astype(np.int16)
+            for bb in (b, b2):
+                h2_cases.append((w, h))
+                h2_in.append(np.concatenate([a.ravel(), bb.ravel()]))
+                h2_out.append(R.dist("HAD_2SAD", a, bb, w, h))
+    np.savez_compressed(os.path.join(OUT, "distortion.npz"), org=org, cur=cur, funcs=np.array(funcs),
+                        cases=np.array(cases, np.int32), out=np.array(outs, np.uint64),
+                        x5_cases=np.array(x5_cases, np.int32), x5_out=np.array(x5_out, np.uint64),
+                        h2_cases=np.array(h2_cases, np.int32), h2_in=np.concatenate(h2_in), h2_out=np.array(h2_out, np.uint64))
+
+    # ---- transforms ----
+    d = {}
+    for t, name, logs in ((DCT2, "DCT2", range(1, 7)), (DCT8, "DCT8", range(2, 6)), (DST7, "DST7", range(2, 6))):
+        for l in logs:
+            d["mat_%s_%d" % (name, 1 << l)] = R.tr_matrix(t, l)
+    tcases, tin, tcoef, tq, trec = [], [], [], [], []
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            combos = [(DCT2, DCT2)]
+            if 4 <= w <= 32 and 4 <= h <= 32:
+                combos += [(DST7, DST7), (DCT8, DST7), (DST7, DCT8), (DCT8, DCT8)]
+            for th, tv in combos:
+                bd = 10
+                resi = rng.integers(-(1 << bd), 1 << bd, size=(h, w)).astype(np.int16)
+                if rng.random() < 0.5:
+                    resi = (resi // 16).astype(np.int16)
+                coef = R.xT(resi, th, tv, bd)
+                assert np.array_equal(coef, R0.xT(resi, th, tv, bd))
+                cq = (coef // 5 * 5).astype(np.int32)
+                rec = R.xIT(cq, th, tv, bd)
+                assert np.array_equal(rec, R0.xIT(cq, th, tv, bd))
+                tcases.append((w, h, th, tv, bd))
+                tin.append(resi.ravel()); tcoef.append(coef.ravel()); tq.append(cq.ravel()); trec.append(rec.ravel())
+    d.update(cases=np.array(tcases, np.int32), resi=np.concatenate(tin), coef=np.concatenate(tcoef),
+             coef_in=np.concatenate(tq), rec=np.concatenate(trec))
+    np.savez_compressed(os.path.join(OUT, "transform.npz"), **d)
+
+    # ---- quant ----
+    from oracle.oracle import Oracle
+    O = Oracle()   # only for the (validated) parameter derivation helpers, outputs come from the reference
+    d = {}
+    for lw in range(0, 7):
+        for lh in range(0, 7):
+            d["scan_%d_%d" % (lw, lh)] = R.scan_order(lw, lh).astype(np.uint16 if lw + lh <= 12 else np.uint32)
+    q, iq = R.quant_scales()
+    d["quant_scales"], d["inv_quant_scales"] = q, iq
+    qcases, qin, qlev, qdu, qdeq, qneed = [], [], [], [], [], []
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            for qp in (34, 44, 57):
+                irap = int(rng.integers(0, 2))
+                qc, qbits, add = O.quant_params(w, h, 10, qp, irap)
+                mag = int(rng.choice([1 << 9, 1 << 12, 1 << 15]))
+                coef = rng.integers(-mag, mag, size=(h, w)).astype(np.int32)
+                coef[rng.random((h, w)) < 0.5] = 0
+                coef[:, 32:] = 0
+                coef[32:, :] = 0
+                lev, du, s, last = R.quant_core(coef, qc, qbits, add, 8, sign_hiding=True)
+                sc, rs, imax = O.dequant_params(w, h, 10, qp)
+                deq = R.dequant_core(lev, sc, rs, imax)
+                nqc, nqbits, nadd, num = O.need_rdoq_params(w, h, 10, qp, 1)
+                small = (coef // max(1, mag >> 4)).astype(np.int32)
+                need = (R.need_rdoq(coef.ravel()[:num], nqc, nadd, nqbits), R.need_rdoq(small.ravel()[:num], nqc, nadd, nqbits))
+                qcases.append((w, h, qp, irap, qc, qbits, s, last, sc, rs, imax, nqc, nqbits, num, need[0], need[1], max(1, mag >> 4)))
+                qdu_masked = du.copy()
+                keep = np.zeros(h * w, bool)
+                keep[R.scan_order(w.bit_length() - 1, h.bit_length() - 1)[: last + 1]] = True
+                qdu_masked[~keep] = 0
+                qin.append(coef.ravel()); qlev.append(lev.ravel()); qdu.append(qdu_masked); qdeq.append(deq.ravel())
+    d.update(cases=np.array(qcases, np.int64), coef=np.concatenate(qin), level=np.concatenate(qlev),
+             deltaU=np.concatenate(qdu), dequant=np.concatenate(qdeq))
+    np.savez_compressed(os.path.join(OUT, "quant.npz"), **d)
+
+    # ---- MCTF ----
+    d = {}
+    f8, f4 = R.mctf_filters()
+    d["filter8"], d["filter4"] = f8, f4
+    org, buf = rand_plane(rng, 96, 112), rand_plane(rng, 96, 112)
+    ecases, eout = [], []
+    for w in range(8, 65, 8):
+        for h in range(8, 65, 8):
+            ox, oy, bx, by = 8, 8, int(rng.integers(4, 40)), int(rng.integers(4, 20))
+            ecases.append((0, ox, oy, bx, by, w, h, 0, 0)); eout.append(R.mctf_err_int((org, oy, ox), (buf, by, bx), w, h))
+            for tap4 in (0, 1):
+                fx, fy = int(rng.integers(0, 16)), int(rng.integers(1, 16))
+                ecases.append((1 + tap4, ox, oy, bx, by, w, h, fx, fy))
+                eout.append(R.mctf_err_frac(tap4, (org, oy, ox), (buf, by, bx), w, h, fx, fy, 10))
+    for fx in range(16):
+        for fy in range(16):
+            if fx or fy:
+                for tap4 in (0, 1):
+                    ecases.append((1 + tap4, 8, 8, 30, 12, 16, 16, fx, fy))
+                    eout.append(R.mctf_err_frac(tap4, (org, 8, 8), (buf, 12, 30), 16, 16, fx, fy, 10))
+    vcases, vout = [], []
+    for w in (8, 16, 32):
+        for h in (8, 16, 32):
+            vcases.append((5, 3, w, h)); vout.append(R.mctf_calc_var((org, 3, 5), w, h))
+    d.update(org=org, buf=buf, err_cases=np.array(ecases, np.int32), err_out=np.array(eout, np.int32),
+             var_cases=np.array(vcases, np.int32), var_out=np.array(vout, np.float64), sub_out=R.mctf_subsample(org))
+    me_cfgs = [(176, 144, 4, 16, 0), (200, 120, 4, 8, 0), (176, 144, 0, 16, 0), (256, 136, 2, 16, 1), (328, 200, 4, 16, 1)]
+    d["me_cfgs"] = np.array(me_cfgs, np.int32)
+    for i, (w, h, speed, unit, add) in enumerate(me_cfgs):
+        a, b = synth_pair(np.random.default_rng(500 + i), h, w, shift=(3 + i, 1 + (i & 1)))
+        lv = R.mctf_me(a, b, 10, unit, speed, bool(add))
+        lv0 = R0.mctf_me(a, b, 10, unit, speed, bool(add))
+        d["me%d_org" % i], d["me%d_ref" % i] = a, b
+        for k in range(5):
+            if lv[k] is not None:
+                assert all(np.array_equal(lv[k][f], lv0[k][f]) for f in ("x", "y", "error"))
+                d["me%d_l%d" % (i, k)] = lv[k]
+    np.savez_compressed(os.path.join(OUT, "mctf.npz"), **d)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
