@@ -1,0 +1,205 @@
+/*
+ * vvenc_hip.h — C ABI of libvvenc_hip.so: the MI355X (gfx950) back-end for VVenC's block-level
+ * RDO hot path (distortion kernels, transform + scalar quantisation, MCTF block matching).
+ *
+ * This is the drop-in boundary one level below the reference's C++ function-pointer tables:
+ * the table-shaped shim (vvenc_amd/csrc/host/) forwards batches of CU/PU/TU
+ * candidates to these entry points.  All bulk pointers are DEVICE pointers (prefix d_) into HBM
+ * unless the name says `_host`; every call is asynchronous on the context's HIP stream and ordered
+ * with respect to the other calls on the same context.  Results are bit-exact with the
+ * reference's scalar and x86-SIMD kernels (citations: paths below /root/reference/source/Lib/).
+ *
+ * Error convention: every function returns VVHIP_OK (0) or a negative VVHIP_E_* code and records
+ * a message retrievable with vvhip_last_error().  The reference has no error codes at this level
+ * (programming errors THROW, CommonLib/TypeDef.h:635-636); the shim turns a non-zero return into
+ * the same exception.  There is NO CPU fallback anywhere behind this ABI.
+ *
+ * Types: Pel = int16_t, TCoeff = int32_t, TCoeffSig = int16_t, TMatrixCoeff = int16_t,
+ * Distortion = uint64_t (CommonLib/TypeDef.h:181-192).
+ */
+#ifndef VVENC_HIP_H
+#define VVENC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VVHIP_API __attribute__((visibility("default")))
+
+enum {
+  VVHIP_OK           = 0,
+  VVHIP_E_ARG        = -1,  /* invalid argument (size/type combination the reference THROWs on)  */
+  VVHIP_E_HIP        = -2,  /* a HIP runtime call failed; message holds hipGetErrorString          */
+  VVHIP_E_NOMEM      = -3,
+  VVHIP_E_UNSUPPORTED= -4
+};
+
+typedef struct vvhip_ctx vvhip_ctx;
+
+/* ---------------------------------------------------------------------------------------------
+ * Context, stream and raw device-memory helpers (so that a C/C++ host needs nothing but this ABI)
+ * ------------------------------------------------------------------------------------------- */
+VVHIP_API int         vvhip_create( vvhip_ctx** out, int device );     /* own non-blocking stream + ROM tables in HBM */
+VVHIP_API void        vvhip_destroy( vvhip_ctx* ctx );
+VVHIP_API const char* vvhip_last_error( const vvhip_ctx* ctx );        /* ctx may be NULL: error of vvhip_create       */
+VVHIP_API int         vvhip_set_stream( vvhip_ctx* ctx, void* hip_stream ); /* borrow a caller stream (NULL = own)      */
+VVHIP_API void*       vvhip_get_stream( vvhip_ctx* ctx );
+VVHIP_API int         vvhip_sync( vvhip_ctx* ctx );                    /* hipStreamSynchronize                          */
+VVHIP_API int         vvhip_malloc( vvhip_ctx* ctx, void** d_ptr, size_t bytes );
+VVHIP_API int         vvhip_free( vvhip_ctx* ctx, void* d_ptr );
+VVHIP_API int         vvhip_upload( vvhip_ctx* ctx, void* d_dst, const void* host_src, size_t bytes );   /* async on stream */
+VVHIP_API int         vvhip_download( vvhip_ctx* ctx, void* host_dst, const void* d_src, size_t bytes ); /* async + sync    */
+VVHIP_API const char* vvhip_version( void );
+
+/* ---------------------------------------------------------------------------------------------
+ * (A) Distortion kernels — replaces RdCost::m_afpDistortFunc[0][DF_*] / m_afpDistortFuncX5
+ *     (CommonLib/RdCost.h:117-121; scalar CommonLib/RdCost.cpp:301-2093; SIMD CommonLib/x86/RdCostX86.h)
+ *
+ * One call evaluates n candidates of ONE block size with ONE function.  A candidate is a pair of
+ * sample offsets relative to d_org / d_cur (the DistParam's org.buf / cur.buf; offsets may be
+ * negative = inside the picture margin).  out[i] is what distFunc(DistParam) returns.
+ * ------------------------------------------------------------------------------------------- */
+enum {                    /* reference table rows (CommonLib/TypeDef.h:339-382)                         */
+  VVHIP_DF_SSE      = 0,  /* DF_SSE + log2(w)        xGetSSE*        RdCost.cpp:651-1000               */
+  VVHIP_DF_SAD      = 1,  /* DF_SAD + log2(w)        xGetSAD*        RdCost.cpp:301-644  (subShift)    */
+  VVHIP_DF_HAD      = 2,  /* DF_HAD + log2(w)        xGetHADs<false> RdCost.cpp:1818-1938              */
+  VVHIP_DF_HAD_FAST = 3,  /* DF_HAD_fast + log2(w)   xGetHADs<true>                                    */
+  VVHIP_DF_HAD_2SAD = 4   /* DF_HAD_2SAD             xGetHAD2SADs    RdCost.cpp:1768-1816              */
+};
+
+typedef struct { int32_t org_off; int32_t cur_off; } vvhip_dist_item;
+
+VVHIP_API int vvhip_dist_batch( vvhip_ctx* ctx, int func,
+                                const int16_t* d_org, int org_stride,
+                                const int16_t* d_cur, int cur_stride,
+                                int width, int height, int sub_shift, int bit_depth,
+                                const vvhip_dist_item* d_items, int n, uint64_t* d_out );
+
+/* DMVR 5-position SAD: RdCost::xGetSAD8X5 / xGetSAD16X5 (RdCost.cpp:1984-2034). width 8 or 16.
+ * d_out5[5*i+k] = SAD(org+k, cur-k) >> 1; entry 2 is left untouched when calc_centre == 0.       */
+VVHIP_API int vvhip_sad_x5_batch( vvhip_ctx* ctx,
+                                  const int16_t* d_org, int org_stride,
+                                  const int16_t* d_cur, int cur_stride,
+                                  int width, int height, int sub_shift, int calc_centre,
+                                  const vvhip_dist_item* d_items, int n, uint64_t* d_out5 );
+
+/* Full-window SAD cost surface for one block size: for block b (top-left org sample offset
+ * d_block_org_off[b], co-located reference offset d_block_ref_off[b]) and every integer displacement
+ * (dx,dy), |dx| <= range_x, |dy| <= range_y:
+ *   d_out[(b*(2*range_y+1) + dy+range_y)*(2*range_x+1) + dx+range_x] = xGetSAD(org, ref + dy*stride + dx)
+ * (same subShift rule).  Exact integers, so any subset a host search asks for is bit-exact
+ * (SURVEY §7 "cost-surface precompute").  The reference window is staged once in LDS.            */
+VVHIP_API int vvhip_sad_surface( vvhip_ctx* ctx,
+                                 const int16_t* d_org, int org_stride,
+                                 const int16_t* d_ref, int ref_stride,
+                                 int width, int height, int sub_shift,
+                                 int range_x, int range_y,
+                                 const int32_t* d_block_org_off, const int32_t* d_block_ref_off, int n_blocks,
+                                 uint32_t* d_out );
+
+/* ---------------------------------------------------------------------------------------------
+ * (B) Transforms + scalar quantisation — replaces g_tCoeffOps.* as driven by TrQuant::xT / xIT
+ *     (CommonLib/TrQuant.cpp:481-655, TrQuant_EMT.cpp:152-420,1917-2000) and Quant::xQuant /
+ *     xDeQuant / xNeedRdoq (CommonLib/Quant.cpp:132-278 with the parameter derivation of
+ *     Quant::quant :735-833, Quant::dequant :520-610, Quant::xNeedRDOQ :835-891).
+ *
+ * A batch holds n TUs of ONE size and ONE transform-type pair.  TU i reads/writes its residual
+ * at d_resi + d_resi_off[i] (stride resi_stride); coefficient / level arrays are compact,
+ * n * width * height, TU-major, raster inside the TU (what TrQuant::m_plTempCoeff holds).
+ * ------------------------------------------------------------------------------------------- */
+enum { VVHIP_DCT2 = 0, VVHIP_DCT8 = 1, VVHIP_DST7 = 2 };   /* TransType, CommonLib/TypeDef.h */
+
+VVHIP_API int vvhip_fwd_transform_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const int32_t* d_resi_off,
+                                         int n, int width, int height, int tr_hor, int tr_ver, int bit_depth,
+                                         int32_t* d_coef );
+VVHIP_API int vvhip_inv_transform_batch( vvhip_ctx* ctx, const int32_t* d_coef,
+                                         int n, int width, int height, int tr_hor, int tr_ver, int bit_depth,
+                                         int16_t* d_resi, int resi_stride, const int32_t* d_resi_off );
+
+/* per-TU quantiser control: qp = QpParam::Qp (base QP incl. qpBdOffset); flags bit0 = slice isIRAP
+ * (iAdd 171 instead of 85, Quant.cpp:775), bit1 = luma (need-RDOQ offset 171 instead of 256, :874)   */
+typedef struct { int16_t qp; int16_t flags; } vvhip_tu_qp;
+
+VVHIP_API int vvhip_quant_batch( vvhip_ctx* ctx, const int32_t* d_coef, int n, int width, int height, int bit_depth,
+                                 const vvhip_tu_qp* d_qp, int thr_val,
+                                 int16_t* d_level, int32_t* d_delta_u /* may be NULL */,
+                                 int32_t* d_abs_sum, int32_t* d_last_scan_pos );
+VVHIP_API int vvhip_dequant_batch( vvhip_ctx* ctx, const int16_t* d_level, int n, int width, int height, int bit_depth,
+                                   const vvhip_tu_qp* d_qp, int32_t* d_coef );
+VVHIP_API int vvhip_need_rdoq_batch( vvhip_ctx* ctx, const int32_t* d_coef, int n, int width, int height, int bit_depth,
+                                     const vvhip_tu_qp* d_qp, uint8_t* d_need );
+
+/* Fused TU pipeline of the residual RDO loop (InterSearch::xEstimateInterResidualQT,
+ * EncoderLib/InterSearch.cpp:3663-3714): xT -> xNeedRDOQ + QuantCore -> DeQuantCore -> xIT -> SSE(resi, rec).
+ * Reads 2*w*h bytes, writes 2*w*h (levels) + 2*w*h (reconstructed residual) + 24 bytes of statistics per TU;
+ * intermediate coefficients never leave the CU (LDS).  Any output pointer may be NULL.          */
+typedef struct { int32_t abs_sum; int32_t last_scan_pos; int32_t need_rdoq; int32_t pad; uint64_t sse; } vvhip_tu_stats;
+
+VVHIP_API int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const int32_t* d_resi_off,
+                                  int n, int width, int height, int tr_hor, int tr_ver, int bit_depth,
+                                  const vvhip_tu_qp* d_qp, int thr_val,
+                                  int16_t* d_level, int16_t* d_rec_resi /* compact n*w*h */, vvhip_tu_stats* d_stats );
+
+/* ROM accessors (host memory out): the tables the kernels use, for parity checks against
+ * g_trCore* (CommonLib/RomTr.cpp:364-449) and getScanOrder (CommonLib/Rom.h:104).               */
+VVHIP_API int vvhip_get_tr_matrix_host( int tr_type, int log2_size, int16_t* host_out );
+VVHIP_API int vvhip_get_scan_order_host( int log2_w, int log2_h, uint32_t* host_out );
+
+/* ---------------------------------------------------------------------------------------------
+ * (C) MCTF block matching — replaces MCTF::m_motionErrorLumaInt8 / m_motionErrorLumaFrac8[2] /
+ *     m_calcVar and the search schedule around them (CommonLib/MCTF.h:160-170,
+ *     CommonLib/MCTF.cpp:122-257, 520-546, 1072-1397).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { int32_t org_off; int32_t buf_off; int16_t fx; int16_t fy; } vvhip_mctf_item;
+
+/* out[i] = motionErrorLumaInt (fx==fy==0) or motionErrorLumaFrac{6,4} with the reference's
+ * 1/16-pel filter rows fx, fy (tap4 != 0: m_interpolationFilter4, else m_interpolationFilter8).
+ * The full error is returned (the reference's `> besterror` early exit is semantically inert,
+ * MCTF.cpp:138-141 and callers :1201,:1223).                                                     */
+VVHIP_API int vvhip_mctf_error_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride,
+                                      const int16_t* d_buf, int buf_stride, int width, int height,
+                                      int tap4, int bit_depth, const vvhip_mctf_item* d_items, int n, int32_t* d_out );
+
+/* calcVarCore (MCTF.cpp:520-546) for n blocks of one size: out[i] = variance * 256 as int64
+ * (the double the reference returns is exactly out[i] / 256.0).                                   */
+VVHIP_API int vvhip_mctf_calc_var_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, int width, int height,
+                                         const int32_t* d_off, int n, int64_t* d_out_x256 );
+
+/* MCTF::subsampleLuma (MCTF.cpp:1072-1097) incl. the border extension by `pad` samples.
+ * d_dst points at sample (0,0) of a plane with >= pad samples of margin on every side.           */
+VVHIP_API int vvhip_mctf_subsample( vvhip_ctx* ctx, const int16_t* d_src, int src_stride, int src_width, int src_height,
+                                    int16_t* d_dst, int dst_stride, int pad );
+VVHIP_API int vvhip_extend_border( vvhip_ctx* ctx, int16_t* d_plane, int stride, int width, int height, int pad );
+
+/* layout of MotionVector (CommonLib/MCTF.h:72-82); x,y in 1/16 pel */
+typedef struct { int32_t x, y, error, rmsme; double overlap; } vvhip_mv;
+
+/* One level of MCTF::motionEstimationLuma (MCTF.cpp:1329-1397) = estimateLumaLn (:1166-1327) for every
+ * block of the level, including the above/left wavefront dependency, in one call.
+ * d_prev (may be NULL) is the coarser level's field, prev_w x prev_h, `factor` as in the reference.
+ * d_mvs is mvs_w x mvs_h and must have been initialised with vvhip_mctf_init_mvs (default MotionVector).
+ * search_pattern / low_res_filter: MCTF::m_searchPttrn / m_lowResFltSearch (MCTF.cpp:598-599).    */
+VVHIP_API int vvhip_mctf_init_mvs( vvhip_ctx* ctx, vvhip_mv* d_mvs, int count );
+VVHIP_API int vvhip_mctf_me_level( vvhip_ctx* ctx,
+                                   const int16_t* d_org, int org_stride, const int16_t* d_buf, int buf_stride,
+                                   int width, int height, int block_size,
+                                   const vvhip_mv* d_prev, int prev_w, int prev_h, int factor, int double_res,
+                                   int search_pattern, int low_res_filter, int bit_depth, int unit_size,
+                                   vvhip_mv* d_mvs, int mvs_w, int mvs_h );
+
+/* MCTF::motionEstimationMCTF (MCTF.cpp:666-707) for one current picture against n_refs reference
+ * pictures: builds the 2x/4x(/8x) pyramids, runs every level for all references concurrently.
+ * Planes are luma, `pad` (>= 128 = MCTF_PADDING) samples of replicated margin, pointers at sample (0,0).
+ * d_mvs_out[r] receives ceil(w/unit) x ceil(h/unit) motion vectors of reference r.                 */
+VVHIP_API int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const int16_t* const* d_refs_host_array,
+                                            int n_refs, int stride, int width, int height, int pad, int bit_depth,
+                                            int unit_size, int mctf_speed, int add_level,
+                                            vvhip_mv* const* d_mvs_out_host_array );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VVENC_HIP_H */

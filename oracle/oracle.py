@@ -226,6 +226,32 @@ class Oracle(_Base):
         coef = np.ascontiguousarray(coef, np.int32).ravel()
         return int(self.L.orc_need_rdoq(_p(coef), coef.size, quant_coeff, offset, shift))
 
+    # (qp, flags)-level entry points, same names as tests/hip_backend.py
+    def quant_tu(self, coef, qp, irap, thr_val=8, bit_depth=10):
+        h, w = np.asarray(coef).shape
+        qc, qbits, add = self.quant_params(w, h, bit_depth, qp, irap)
+        return self.quant_core(coef, qc, qbits, add, thr_val)
+
+    def dequant_tu(self, level, qp, bit_depth=10):
+        h, w = np.asarray(level).shape
+        sc, rs, imax = self.dequant_params(w, h, bit_depth, qp)
+        return self.dequant_core(level, sc, rs, imax)
+
+    def need_rdoq_tu(self, coef, qp, is_luma=1, bit_depth=10):
+        h, w = np.asarray(coef).shape
+        qc, qbits, add, num = self.need_rdoq_params(w, h, bit_depth, qp, is_luma)
+        return self.need_rdoq(np.asarray(coef).ravel()[:num], qc, add, qbits)
+
+    def tu_rdo(self, resi, qp, irap, tr_hor=DCT2, tr_ver=DCT2, bit_depth=10, thr_val=8, is_luma=1):
+        """the fused pipeline's definition, composed from the pinned pieces: xT -> needRdoq/QuantCore -> DeQuantCore -> xIT -> SSE"""
+        resi = np.ascontiguousarray(resi, np.int16)
+        coef = self.xT(resi, tr_hor, tr_ver, bit_depth)
+        need = self.need_rdoq_tu(coef, qp, is_luma, bit_depth)
+        lev, _, s, last = self.quant_tu(coef, qp, irap, thr_val, bit_depth)
+        rec = self.xIT(self.dequant_tu(lev, qp, bit_depth), tr_hor, tr_ver, bit_depth)
+        d = resi.astype(np.int64) - rec.astype(np.int64)
+        return lev, rec, dict(abs_sum=s, last_scan_pos=last, need_rdoq=need, sse=int((d * d).sum()))
+
     # ---- MCTF ----
     def mctf_err_int(self, org, buf, w, h):
         po, so = self._ptr_stride(org)

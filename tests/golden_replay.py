@@ -87,6 +87,31 @@ def check_quant(be):
         assert be.need_rdoq(small.ravel()[:num], nqc, nadd, nqbits) == need1
 
 
+def check_quant_qp(be):
+    """same golden cases through the (qp, flags) entry points (what the C ABI exposes)"""
+    g = load("quant")
+    off = 0
+    for c in g["cases"]:
+        w, h, qp, irap, qc, qbits, s, last, sc, rs, imax, nqc, nqbits, num, need0, need1, div = [int(v) for v in c]
+        n = w * h
+        coef = g["coef"][off:off + n].reshape(h, w)
+        lev = g["level"][off:off + n].reshape(h, w)
+        du = g["deltaU"][off:off + n]
+        deq = g["dequant"][off:off + n].reshape(h, w)
+        off += n
+        q, d, ssum, slast = be.quant_tu(coef, qp, irap, 8)
+        assert (ssum, slast) == (s, last), (w, h, qp, (ssum, slast), (s, last))
+        assert np.array_equal(q, lev), (w, h, qp)
+        keep = np.zeros(n, bool)
+        keep[be.scan_order(w.bit_length() - 1, h.bit_length() - 1)[: last + 1]] = True
+        assert np.array_equal(np.where(keep, d, 0), du), (w, h, qp)
+        assert np.array_equal(be.dequant_tu(lev, qp), deq), (w, h, qp)
+        small = (coef // div).astype(np.int32)
+        if h <= 32:   # the TU-level entry reads the first w*min(h,32) coefficients itself
+            assert be.need_rdoq_tu(coef, qp, 1) == need0, (w, h, qp)
+            assert be.need_rdoq_tu(small, qp, 1) == need1, (w, h, qp)
+
+
 def check_mctf_kernels(be):
     g = load("mctf")
     org, buf = g["org"], g["buf"]

@@ -1,0 +1,299 @@
+"""-m gpu: the HIP path (through the C ABI) against (1) the committed golden vectors = outputs of the reference itself,
+(2) the CPU oracle on seeded random batches, (3) size-independent properties at BASELINE sizes (1080p / 4K planes).
+Everything is bit-exact (tolerance 0): integer kernels, and the two IEEE-double corners (rectangular Hadamard tiles,
+MCTF error normalisation) are compiled without FMA contraction."""
+import numpy as np
+import pytest
+
+import golden_replay as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from hip_backend import HipBackend
+    return HipBackend()
+
+
+def rand_plane(rng, h, w, bits=10):
+    return rng.integers(0, 1 << bits, size=(h, w), dtype=np.int16)
+
+
+# ---------------------------------------------------------------- golden (reference outputs) ----
+def test_golden_distortion(hip):
+    G.check_distortion(hip)
+
+
+def test_golden_transform(hip):
+    G.check_transform_matrices(hip)
+    G.check_scan(hip)
+    G.check_transform(hip)
+
+
+def test_golden_quant(hip):
+    G.check_quant_qp(hip)
+
+
+def test_golden_mctf_kernels(hip):
+    G.check_mctf_kernels(hip)
+
+
+def test_golden_mctf_me(hip):
+    G.check_mctf_me(hip)
+
+
+# ---------------------------------------------------------------- oracle on random batches ----
+@pytest.mark.parametrize("func", ["SAD", "SSE", "HAD", "HAD_fast", "HAD_2SAD"])
+def test_dist_batches_vs_oracle(hip, oracle, func):
+    rng = np.random.default_rng(100)
+    org, cur = rand_plane(rng, 200, 328), rand_plane(rng, 200, 328)
+    cur[50:150, 100:300] = np.clip(org[50:150, 100:300].astype(np.int32) + rng.integers(-4, 5, (100, 200)), 0, 1023).astype(np.int16)
+    if func in ("SAD", "SSE"):      # signed samples too (residual-domain use)
+        org[150:, :] -= 512
+        cur[150:, :] -= 700
+    sizes = [(w, h) for w in (4, 8, 16, 32, 64, 128) for h in (4, 8, 16, 32, 64, 128)]
+    if func.startswith("HAD"):
+        sizes += [(2, 2), (2, 8), (8, 2), (4, 2)]
+    if func in ("SAD", "SSE"):
+        sizes += [(2, 4), (12, 8), (24, 16), (6, 6)]
+    for (w, h) in sizes:
+        n = 37
+        items = [(int(rng.integers(0, 328 - w + 1)), int(rng.integers(0, 200 - h + 1)),
+                  int(rng.integers(0, 328 - w + 1)), int(rng.integers(0, 200 - h + 1))) for _ in range(n)]
+        for ss in ((0, 1) if func == "SAD" and h >= 2 else (0,)):
+            got = hip.dist_many(func, org, cur, items, w, h, 10, ss)
+            for k, (ox, oy, cx, cy) in enumerate(items):
+                if func == "HAD_2SAD":
+                    a = np.ascontiguousarray(org[oy:oy + h, ox:ox + w]); b = np.ascontiguousarray(cur[cy:cy + h, cx:cx + w])
+                    exp = oracle.dist(func, a, b, w, h)
+                else:
+                    exp = oracle.dist(func, (org, oy, ox), (cur, cy, cx), w, h, 10, ss)
+                assert int(got[k]) == exp, (func, w, h, ss, k, int(got[k]), exp)
+
+
+def test_sad_x5_vs_oracle(hip, oracle):
+    rng = np.random.default_rng(101)
+    org, cur = rand_plane(rng, 64, 96), rand_plane(rng, 64, 96)
+    for w in (8, 16):
+        for h in (8, 16):
+            for centre in (True, False):
+                a = hip.sad_x5((org, 5, 10), (cur, 9, 40), w, h, 1, centre)
+                b = oracle.sad_x5((org, 5, 10), (cur, 9, 40), w, h, 1, centre)
+                if not centre:
+                    a = a.copy(); a[2] = 0; b[2] = 0
+                assert np.array_equal(a, b)
+
+
+def test_sad_surface_vs_oracle(hip, oracle):
+    from vvenc_amd.hotpath import Plane
+    rng = np.random.default_rng(102)
+    org, ref = rand_plane(rng, 160, 256), rand_plane(rng, 160, 256)
+    hp = hip.hp
+    po, pr = Plane.from_numpy(hp.device, org), Plane.from_numpy(hp.device, ref)
+    for (w, h, ss, rx, ry) in [(8, 8, 0, 4, 3), (16, 16, 1, 8, 8), (32, 32, 1, 16, 8), (64, 64, 1, 6, 6), (4, 4, 0, 2, 2)]:
+        blocks = [(int(rng.integers(rx, 256 - w - rx)), int(rng.integers(ry, 160 - h - ry))) for _ in range(5)]
+        oo = np.array([y * po.stride + x for x, y in blocks], np.int32)
+        ro = np.array([y * pr.stride + x for x, y in blocks], np.int32)
+        out = hp.sad_surface(po, pr, hp.to_device(oo), hp.to_device(ro), len(blocks), w, h, ss, rx, ry).cpu().numpy()
+        out = out.reshape(len(blocks), 2 * ry + 1, 2 * rx + 1)
+        for b, (x, y) in enumerate(blocks):
+            for dy in range(-ry, ry + 1):
+                for dx in range(-rx, rx + 1):
+                    assert int(out[b, dy + ry, dx + rx]) == oracle.dist("SAD", (org, y, x), (ref, y + dy, x + dx), w, h, 10, ss)
+
+
+def _tr_types(w, h):
+    yield 0, 0
+    if 4 <= w <= 32 and 4 <= h <= 32:
+        for th in (2, 1):
+            for tv in (2, 1):
+                yield th, tv
+    if 4 <= w <= 32:
+        yield 2, 0
+    if 4 <= h <= 32:
+        yield 0, 2
+
+
+def test_transform_batches_vs_oracle(hip, oracle):
+    rng = np.random.default_rng(103)
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            for th, tv in _tr_types(w, h):
+                for bd in (8, 10):
+                    n = 19
+                    resi = rng.integers(-(1 << bd), 1 << bd, size=(n, h, w)).astype(np.int16)
+                    resi[0] = (1 << bd) - 1
+                    resi[1] = -(1 << bd)
+                    got = hip.xT_many(resi, th, tv, bd)
+                    exp = np.stack([oracle.xT(resi[i], th, tv, bd) for i in range(n)])
+                    assert np.array_equal(got, exp), ("xT", w, h, th, tv, bd)
+                    coef = (exp // 3).astype(np.int32)
+                    coef[2] = rng.integers(-(1 << 15), 1 << 15, size=(h, w))
+                    got = hip.xIT_many(coef, th, tv, bd)
+                    exp = np.stack([oracle.xIT(coef[i], th, tv, bd) for i in range(n)])
+                    assert np.array_equal(got, exp), ("xIT", w, h, th, tv, bd)
+
+
+def test_quant_batches_vs_oracle(hip, oracle):
+    from vvenc_amd.hotpath import HotPath
+    rng = np.random.default_rng(104)
+    hp = hip.hp
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            n = 23
+            qps = rng.integers(12, 64, size=n)
+            irap = rng.integers(0, 2, size=n)
+            luma = rng.integers(0, 2, size=n)
+            mags = rng.choice([8, 1 << 9, 1 << 12, 1 << 15], size=n)
+            coef = np.stack([rng.integers(-m, m, size=(h, w)) for m in mags]).astype(np.int32)
+            coef[rng.random(coef.shape) < 0.5] = 0
+            coef[3] = 0
+            d_coef = hp.to_device(coef.ravel())
+            d_qp = hp.to_device(HotPath.tu_qp(qps, irap, luma))
+            for thr in (8, 4):
+                lev, du, s, last = hp.quant(d_coef, n, w, h, d_qp, 10, thr, True)
+                lev, du, s, last = lev.cpu().numpy().reshape(n, h, w), du.cpu().numpy().reshape(n, h * w), s.cpu().numpy(), last.cpu().numpy()
+                for i in range(n):
+                    c = coef[i].copy()
+                    c[:, 32:] = c[:, 32:]   # zero-out region is ignored by the quantiser (never scanned)
+                    e = oracle.quant_tu(c, int(qps[i]), int(irap[i]), thr)
+                    assert (int(s[i]), int(last[i])) == (e[2], e[3]), (w, h, i, thr)
+                    assert np.array_equal(lev[i], e[0]), (w, h, i)
+                    keep = np.zeros(h * w, bool)
+                    keep[oracle.scan_order(w.bit_length() - 1, h.bit_length() - 1)[: e[3] + 1]] = True
+                    assert np.array_equal(np.where(keep, du[i], 0), np.where(keep, e[1], 0)), (w, h, i)
+            deq = hp.dequant(hp.to_device(lev.ravel()), n, w, h, d_qp, 10).cpu().numpy().reshape(n, h, w)
+            need = hp.need_rdoq(d_coef, n, w, h, d_qp, 10).cpu().numpy()
+            for i in range(n):
+                assert np.array_equal(deq[i], oracle.dequant_tu(lev[i], int(qps[i]))), (w, h, i)
+                assert int(need[i]) == oracle.need_rdoq_tu(coef[i], int(qps[i]), int(luma[i])), (w, h, i)
+
+
+def test_fused_tu_rdo_vs_oracle(hip, oracle):
+    from vvenc_amd.hotpath import STATS_DTYPE, HotPath, Plane
+    rng = np.random.default_rng(105)
+    hp = hip.hp
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            for th, tv in [(0, 0)] + ([(2, 2), (1, 2)] if w <= 32 and h <= 32 else []):
+                n = 17
+                scale = rng.choice([4, 32, 256, 1023], size=n)
+                resi = np.stack([rng.integers(-s, s + 1, size=(h, w)) for s in scale]).astype(np.int16)
+                qps = rng.integers(20, 60, size=n)
+                irap = rng.integers(0, 2, size=n)
+                plane = Plane.from_numpy(hp.device, resi.reshape(n * h, w))
+                d_off = hp.to_device(np.arange(n, dtype=np.int32) * (h * plane.stride))
+                d_qp = hp.to_device(HotPath.tu_qp(qps, irap, 1))
+                lev, rec, st = hp.tu_rdo(plane, d_off, n, w, h, d_qp, th, tv, 10, 8)
+                lev, rec = lev.cpu().numpy().reshape(n, h, w), rec.cpu().numpy().reshape(n, h, w)
+                st = st.cpu().numpy().view(STATS_DTYPE).reshape(n)
+                for i in range(n):
+                    el, er, es = oracle.tu_rdo(resi[i], int(qps[i]), int(irap[i]), th, tv, 10, 8, 1)
+                    assert np.array_equal(lev[i], el), ("lev", w, h, th, tv, i)
+                    assert np.array_equal(rec[i], er), ("rec", w, h, th, tv, i)
+                    assert (int(st["abs_sum"][i]), int(st["last_scan_pos"][i]), int(st["need_rdoq"][i]), int(st["sse"][i])) == \
+                        (es["abs_sum"], es["last_scan_pos"], es["need_rdoq"], es["sse"]), (w, h, th, tv, i)
+
+
+def synth_pair(rng, h, w, shift=(3, 1), noise=6):
+    yy, xx = np.mgrid[0:h + 32, 0:w + 32]
+    base = 512 + 180 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 120 * np.sin((xx + yy) / 11.0) + 60 * np.sin(xx / 3.1) * np.sin(yy / 4.3)
+    base = base + rng.normal(0, 12, base.shape)
+    a = np.clip(base[16:16 + h, 16:16 + w], 0, 1023)
+    b = np.clip(base[16 + shift[1]:16 + shift[1] + h, 16 + shift[0]:16 + shift[0] + w] + rng.normal(0, noise, (h, w)), 0, 1023)
+    return a.astype(np.int16), b.astype(np.int16)
+
+
+@pytest.mark.parametrize("cfg", [(416, 240, 4, 16, False), (360, 200, 0, 16, False), (200, 136, 2, 8, False), (640, 360, 4, 16, True)])
+def test_mctf_levels_vs_oracle(hip, oracle, cfg):
+    w, h, speed, unit, add = cfg
+    org, ref = synth_pair(np.random.default_rng(106 + w), h, w, shift=(5, 2))
+    exp = oracle.mctf_me(org, ref, 10, unit, speed, add)
+    got = hip.mctf_me_levels(org, ref, 10, unit, speed, add)
+    for k in range(5):
+        if exp[k] is None:
+            continue
+        for f in ("x", "y", "error"):
+            assert np.array_equal(got[k][f], exp[k][f]), (k, f, np.argwhere(got[k][f] != exp[k][f])[:5])
+    assert np.array_equal(got[4]["rmsme"], exp[4]["rmsme"]) and np.array_equal(got[4]["overlap"], exp[4]["overlap"])
+    full = hip.mctf_me(org, ref, 10, unit, speed, add)[4]
+    for f in ("x", "y", "error", "rmsme", "overlap"):
+        assert np.array_equal(full[f], exp[4][f]), f
+
+
+def test_mctf_1080p_vs_oracle(hip, oracle):
+    """BASELINE config-2 geometry: 1920x1080 10-bit, faster preset (speed 4, unit 16, extra 1/8 level)."""
+    org, ref = synth_pair(np.random.default_rng(1080), 1080, 1920, shift=(3, 1), noise=3)
+    exp = oracle.mctf_me(org, ref, 10, 16, 4, True)[4]
+    got = hip.mctf_me(org, ref, 10, 16, 4, True)[4]
+    for f in ("x", "y", "error", "rmsme", "overlap"):
+        assert np.array_equal(got[f], exp[f]), (f, np.argwhere(got[f] != exp[f])[:5])
+
+
+# ---------------------------------------------------------------- size-independent properties at BASELINE sizes ----
+def test_properties_1080p_4k(hip):
+    """(1) cost surface == candidate-list SAD for the same displacements; (2) SAD(x, x) == 0 and HAD(x, x) == 0;
+    (3) SSE/SAD of a plane against itself shifted equals numpy's; (4) fused TU pipeline == unfused pipeline; all on full planes."""
+    from vvenc_amd.hotpath import STATS_DTYPE, HotPath, Plane
+    hp = hip.hp
+    for (W, H) in ((1920, 1080), (3840, 2160)):
+        rng = np.random.default_rng(W)
+        org = rng.integers(0, 1024, size=(H, W), dtype=np.int16)
+        ref = np.roll(org, (2, -3), (0, 1))
+        ref = np.clip(ref.astype(np.int32) + rng.integers(-8, 9, size=(H, W)), 0, 1023).astype(np.int16)
+        po, pr = hp.plane(org, 80), hp.plane(ref, 80)
+        S = 32
+        bx, by = np.meshgrid(np.arange(0, W - S + 1, S), np.arange(0, H - S + 1, S))
+        bx, by = bx.ravel(), by.ravel()
+        nb = bx.size
+        oo = (by * po.stride + bx).astype(np.int32)
+        d_oo = hp.to_device(oo)
+        # (2) identical blocks
+        items = np.stack([oo, oo], 1)
+        for f in ("SAD", "SSE", "HAD", "HAD_fast"):
+            z = hp.dist_batch(f, po, po, hp.to_device(items), nb, S, S, 1 if f == "SAD" else 0)
+            assert int(z.abs().max()) == 0
+        # (1) + (3): every block, displacement window +-4: surface vs list vs numpy
+        R = 4
+        surf = hp.sad_surface(po, pr, d_oo, d_oo, nb, S, S, 1, R, R).cpu().numpy().reshape(nb, 2 * R + 1, 2 * R + 1)
+        for (dx, dy) in ((0, 0), (-3, 2), (4, -4), (-4, 4)):
+            it = np.stack([oo, oo + dy * pr.stride + dx], 1).astype(np.int32)
+            lst = hp.dist_batch("SAD", po, pr, hp.to_device(it), nb, S, S, 1).cpu().numpy()
+            assert np.array_equal(lst, surf[:, dy + R, dx + R].astype(np.int64)), (W, dx, dy)
+            full = hp.dist_batch("SAD", po, pr, hp.to_device(it), nb, S, S, 0).cpu().numpy()
+            sse = hp.dist_batch("SSE", po, pr, hp.to_device(it), nb, S, S, 0).cpu().numpy()
+            # numpy check on interior blocks (inside the picture after displacement)
+            pad_ref = np.pad(ref.astype(np.int64), 80, mode="edge")
+            sel = rng.choice(nb, 64, replace=False)
+            for b in sel:
+                x, y = int(bx[b]), int(by[b])
+                a = org[y:y + S, x:x + S].astype(np.int64)
+                c = pad_ref[80 + y + dy:80 + y + dy + S, 80 + x + dx:80 + x + dx + S]
+                assert int(full[b]) == int(np.abs(a - c).sum())
+                assert int(sse[b]) == int(((a - c) ** 2).sum())
+        # (4) fused == unfused on residual = org - ref, every 32x32 TU of the frame
+        resi = (org.astype(np.int32) - ref.astype(np.int32)).astype(np.int16)
+        pres = hp.plane(resi, 0)
+        off = (by * pres.stride + bx).astype(np.int32)
+        d_off = hp.to_device(off)
+        qps = rng.integers(24, 50, size=nb)
+        d_qp = hp.to_device(HotPath.tu_qp(qps, 0, 1))
+        lev, rec, st = hp.tu_rdo(pres, d_off, nb, S, S, d_qp)
+        coef = hp.fwd_transform(pres, d_off, nb, S, S)
+        need = hp.need_rdoq(coef, nb, S, S, d_qp)
+        lev2, _, s2, last2 = hp.quant(coef, nb, S, S, d_qp, 10, 8, False)
+        deq = hp.dequant(lev2, nb, S, S, d_qp)
+        prec = Plane(hp.device, W, H, 0)
+        hp.inv_transform(deq, nb, S, S, prec, hp.to_device((by * prec.stride + bx).astype(np.int32)))
+        st = st.cpu().numpy().view(STATS_DTYPE).reshape(nb)
+        assert np.array_equal(lev.cpu().numpy(), lev2.cpu().numpy())
+        assert np.array_equal(st["abs_sum"], s2.cpu().numpy()) and np.array_equal(st["last_scan_pos"], last2.cpu().numpy())
+        assert np.array_equal(st["need_rdoq"], need.cpu().numpy().astype(np.int32))
+        rec_blocks = rec.cpu().numpy().reshape(nb, S, S)
+        full_rec = prec.visible().cpu().numpy()
+        d = resi.astype(np.int64)
+        for b in rng.choice(nb, 64, replace=False):
+            x, y = int(bx[b]), int(by[b])
+            assert np.array_equal(rec_blocks[b], full_rec[y:y + S, x:x + S])
+            assert int(st["sse"][b]) == int(((d[y:y + S, x:x + S] - rec_blocks[b]) ** 2).sum())

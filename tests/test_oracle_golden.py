@@ -23,6 +23,10 @@ def test_quant(oracle):
     G.check_quant(oracle)
 
 
+def test_quant_qp(oracle):
+    G.check_quant_qp(oracle)
+
+
 def test_mctf_kernels(oracle):
     G.check_mctf_kernels(oracle)
 

@@ -1,0 +1,55 @@
+// common.h — internal declarations shared by the HIP translation units of libvvenc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/vvenc_hip.h"
+
+struct vvhip_ctx
+{
+  int          device     = 0;
+  hipStream_t  stream     = nullptr;   // stream every launch goes to
+  hipStream_t  ownStream  = nullptr;
+  std::string  lastError;
+
+  // ROM in HBM (uploaded once by vvhip_create)
+  int16_t*     d_trMat    = nullptr;   // all transform matrices, see trMatOffset()
+  uint16_t*    d_scan     = nullptr;   // grouped diagonal scan orders, see scanOffset()
+  // scratch for vvhip_mctf_motion_estimation (grown on demand)
+  void*        d_scratch  = nullptr;
+  size_t       scratchBytes = 0;
+};
+
+int vvhip_fail( vvhip_ctx* ctx, int code, const char* fmt, ... );
+
+#define VVHIP_CHECK_HIP( ctx, expr )                                                        \
+  do { hipError_t e_ = ( expr );                                                            \
+       if( e_ != hipSuccess ) return vvhip_fail( ctx, VVHIP_E_HIP, "%s: %s (%s:%d)", #expr, \
+                                                 hipGetErrorString( e_ ), __FILE__, __LINE__ ); } while( 0 )
+
+#define VVHIP_LAUNCH_CHECK( ctx ) VVHIP_CHECK_HIP( ctx, hipGetLastError() )
+
+// ---- ROM layout -------------------------------------------------------------------------------
+// transform matrices: type-major, sizes 2..64; entry (type, log2N) lives at trMatOffset(type, log2N), N*N int16
+static inline __host__ __device__ int trMatOffset( int trType, int log2N )
+{
+  // sum_{l=1}^{log2N-1} 4^l = (4^log2N - 4) / 3 ; each type gets a full 2..64 slot (5460 entries)
+  return trType * 5460 + ( ( 1 << ( 2 * log2N ) ) - 4 ) / 3;
+}
+static const int kTrMatTotal = 3 * 5460;
+
+// scan orders for log2w, log2h in 0..6: entry lives at scanOffset(log2w, log2h), (w*h) uint16
+static inline __host__ __device__ int scanOffset( int log2w, int log2h )
+{
+  // prefix over (lw, lh) in row-major order of 2^(lw+lh): sum_{a<lw} 2^a*(127) + 2^lw * (2^lh - 1)
+  return ( ( 1 << log2w ) - 1 ) * 127 + ( 1 << log2w ) * ( ( 1 << log2h ) - 1 );
+}
+static const int kScanTotal = 127 * 127;
+
+void vvhip_build_tr_matrix( int trType, int log2N, int16_t* out );          // host
+void vvhip_build_scan_order( int log2w, int log2h, uint32_t* out );         // host
+void vvhip_cg_size( int log2w, int log2h, int* log2CGw, int* log2CGh );     // host
+
+static inline int ilog2i( int v ) { int l = 0; while( ( 1 << ( l + 1 ) ) <= v ) l++; return l; }
+static inline bool isPow2( int v ) { return v > 0 && ( v & ( v - 1 ) ) == 0; }

@@ -1,0 +1,221 @@
+// ctx.hip — context, stream, device-memory helpers and ROM tables of libvvenc_hip.so.
+//
+// ROM tables are rebuilt here from the standard's coefficient lists rather than stored:
+//   * DCT-2 / DST-7 / DCT-8 integer kernels  == g_trCore*      (CommonLib/RomTr.cpp:364-449)
+//   * grouped up-right diagonal coefficient scans == getScanOrder(SCAN_GROUPED_4x4,..) (CommonLib/Rom.cpp:1098-1284)
+// and are checked entry-by-entry against the reference in tests/ (golden + live reference).
+#include "common.h"
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+static std::string g_createError;
+
+int vvhip_fail( vvhip_ctx* ctx, int code, const char* fmt, ... )
+{
+  char buf[512];
+  va_list ap;
+  va_start( ap, fmt );
+  vsnprintf( buf, sizeof( buf ), fmt, ap );
+  va_end( ap );
+  if( ctx ) ctx->lastError = buf; else g_createError = buf;
+  return code;
+}
+
+// ---- transform matrices ----------------------------------------------------------------------
+// One coefficient per distinct angle (H.266 8.7.4.2): DCT-2 via m = (2n+1)k folded to [0,64];
+// DST-7 via j = (2k+1)(n+1) folded to [0,N]; DCT-8[k][n] = (-1)^k DST-7[k][N-1-n].
+static const int16_t kDct2Cos[65] = {
+  64, 91, 90, 90, 90, 90, 90, 90, 89, 88, 88, 87, 87, 86, 85, 84, 83, 83, 82, 81, 80, 79, 78, 77, 75, 73, 73, 71, 70, 69, 67, 65, 64,
+  62, 61, 59, 57, 56, 54, 52, 50, 48, 46, 44, 43, 41, 38, 37, 36, 33, 31, 28, 25, 24, 22, 20, 18, 15, 13, 11, 9, 7, 4, 2, 0 };
+static const int16_t kDst7Sin4[4]   = { 29, 55, 74, 84 };
+static const int16_t kDst7Sin8[8]   = { 17, 32, 46, 60, 71, 78, 85, 86 };
+static const int16_t kDst7Sin16[16] = { 8, 17, 25, 33, 40, 48, 55, 62, 68, 73, 77, 81, 85, 87, 88, 88 };
+static const int16_t kDst7Sin32[32] = { 4, 9, 13, 17, 21, 26, 30, 34, 38, 42, 46, 50, 53, 56, 60, 63,
+                                        66, 68, 72, 74, 77, 78, 80, 82, 84, 85, 86, 87, 88, 89, 90, 90 };
+
+static int16_t dct2At( int N, int k, int n )
+{
+  int m = ( ( 2 * n + 1 ) * k * ( 64 / N ) ) & 255;
+  int sign = 1;
+  if( m > 128 ) m = 256 - m;
+  if( m > 64 ) { m = 128 - m; sign = -1; }
+  return ( int16_t ) ( sign * kDct2Cos[m] );
+}
+
+static int16_t dst7At( int N, int k, int n )
+{
+  const int16_t* s = N == 4 ? kDst7Sin4 : N == 8 ? kDst7Sin8 : N == 16 ? kDst7Sin16 : kDst7Sin32;
+  const int period = 2 * N + 1;
+  int j = ( ( 2 * k + 1 ) * ( n + 1 ) ) % ( 2 * period );
+  int sign = 1;
+  if( j > period ) { j -= period; sign = -1; }
+  if( j > N ) j = period - j;
+  return j ? ( int16_t ) ( sign * s[j - 1] ) : ( int16_t ) 0;
+}
+
+void vvhip_build_tr_matrix( int trType, int log2N, int16_t* out )
+{
+  const int N = 1 << log2N;
+  for( int k = 0; k < N; k++ )
+    for( int n = 0; n < N; n++ )
+    {
+      int16_t v = 0;
+      if( trType == VVHIP_DCT2 ) v = dct2At( N, k, n );
+      else if( log2N >= 2 && log2N <= 5 )
+        v = trType == VVHIP_DST7 ? dst7At( N, k, n ) : ( int16_t ) ( ( k & 1 ? -1 : 1 ) * dst7At( N, k, N - 1 - n ) );
+      out[k * N + n] = v;
+    }
+}
+
+// ---- coefficient scan ------------------------------------------------------------------------
+void vvhip_cg_size( int log2w, int log2h, int* cgw, int* cgh )   // g_log2SbbSize, CommonLib/Rom.cpp:1138-1148
+{
+  if( log2w >= 2 && log2h >= 2 ) { *cgw = 2; *cgh = 2; }
+  else if( log2w == 0 ) { *cgw = 0; *cgh = log2h < 4 ? log2h : 4; }
+  else if( log2h == 0 ) { *cgh = 0; *cgw = log2w < 4 ? log2w : 4; }
+  else if( log2w == 1 ) { *cgw = 1; *cgh = log2h <= 2 ? 1 : 3; }
+  else                  { *cgh = 1; *cgw = log2w <= 2 ? 1 : 3; }
+}
+
+static void upRightDiagonal( int bw, int bh, std::vector<int>& xs, std::vector<int>& ys )
+{
+  xs.clear(); ys.clear();
+  for( int d = 0; d < bw + bh - 1; d++ )
+    for( int y = d < bh ? d : bh - 1, x = d - y; y >= 0 && x < bw; x++, y-- ) { xs.push_back( x ); ys.push_back( y ); }
+}
+
+void vvhip_build_scan_order( int log2w, int log2h, uint32_t* out )
+{
+  const int w = 1 << log2w, h = 1 << log2h;
+  int cgw, cgh;
+  vvhip_cg_size( log2w, log2h, &cgw, &cgh );
+  const int gw = 1 << cgw, gh = 1 << cgh, gsize = gw * gh;
+  const int wInG = ( w < 32 ? w : 32 ) >> cgw, hInG = ( h < 32 ? h : 32 ) >> cgh;
+  for( int i = 0; i < w * h; i++ ) out[i] = ( uint32_t ) ( w * h - 1 );   // zero-out region filler (reference does the same)
+  std::vector<int> gx, gy, px, py;
+  upRightDiagonal( wInG, hInG, gx, gy );
+  upRightDiagonal( gw, gh, px, py );
+  for( int g = 0; g < wInG * hInG; g++ )
+    for( int p = 0; p < gsize; p++ )
+      out[g * gsize + p] = ( uint32_t ) ( ( gy[g] * gh + py[p] ) * w + gx[g] * gw + px[p] );
+}
+
+extern "C" {
+
+int vvhip_get_tr_matrix_host( int tr_type, int log2_size, int16_t* host_out )
+{
+  if( tr_type < 0 || tr_type > 2 || log2_size < ( tr_type == VVHIP_DCT2 ? 1 : 2 ) || log2_size > ( tr_type == VVHIP_DCT2 ? 6 : 5 ) ) return VVHIP_E_ARG;
+  vvhip_build_tr_matrix( tr_type, log2_size, host_out );
+  return VVHIP_OK;
+}
+
+int vvhip_get_scan_order_host( int log2_w, int log2_h, uint32_t* host_out )
+{
+  if( log2_w < 0 || log2_w > 6 || log2_h < 0 || log2_h > 6 ) return VVHIP_E_ARG;
+  vvhip_build_scan_order( log2_w, log2_h, host_out );
+  return VVHIP_OK;
+}
+
+const char* vvhip_version( void ) { return "vvenc_hip 0.1 (gfx950)"; }
+
+int vvhip_create( vvhip_ctx** out, int device )
+{
+  if( !out ) return vvhip_fail( nullptr, VVHIP_E_ARG, "vvhip_create: out == NULL" );
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount( &count );
+  if( e != hipSuccess || count <= 0 )
+    return vvhip_fail( nullptr, VVHIP_E_HIP, "vvhip_create: no HIP device available (%s); this library has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString( e ) : "device count 0" );
+  if( device < 0 || device >= count ) return vvhip_fail( nullptr, VVHIP_E_ARG, "vvhip_create: device %d out of range (%d devices)", device, count );
+  vvhip_ctx* ctx = new vvhip_ctx;
+  ctx->device = device;
+  VVHIP_CHECK_HIP( nullptr, hipSetDevice( device ) );
+  VVHIP_CHECK_HIP( nullptr, hipStreamCreateWithFlags( &ctx->ownStream, hipStreamNonBlocking ) );
+  ctx->stream = ctx->ownStream;
+
+  std::vector<int16_t> mats( kTrMatTotal, 0 );
+  for( int t = 0; t < 3; t++ )
+    for( int l = ( t == VVHIP_DCT2 ? 1 : 2 ); l <= ( t == VVHIP_DCT2 ? 6 : 5 ); l++ )
+      vvhip_build_tr_matrix( t, l, mats.data() + trMatOffset( t, l ) );
+  std::vector<uint16_t> scans( kScanTotal, 0 );
+  std::vector<uint32_t> tmp( 4096 );
+  for( int lw = 0; lw <= 6; lw++ )
+    for( int lh = 0; lh <= 6; lh++ )
+    {
+      vvhip_build_scan_order( lw, lh, tmp.data() );
+      uint16_t* dst = scans.data() + scanOffset( lw, lh );
+      for( int i = 0; i < ( 1 << ( lw + lh ) ); i++ ) dst[i] = ( uint16_t ) tmp[i];
+    }
+  VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_trMat, mats.size() * sizeof( int16_t ) ) );
+  VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_scan, scans.size() * sizeof( uint16_t ) ) );
+  VVHIP_CHECK_HIP( nullptr, hipMemcpy( ctx->d_trMat, mats.data(), mats.size() * sizeof( int16_t ), hipMemcpyHostToDevice ) );
+  VVHIP_CHECK_HIP( nullptr, hipMemcpy( ctx->d_scan, scans.data(), scans.size() * sizeof( uint16_t ), hipMemcpyHostToDevice ) );
+  *out = ctx;
+  return VVHIP_OK;
+}
+
+void vvhip_destroy( vvhip_ctx* ctx )
+{
+  if( !ctx ) return;
+  ( void ) hipSetDevice( ctx->device );
+  if( ctx->ownStream ) ( void ) hipStreamSynchronize( ctx->ownStream );
+  if( ctx->d_trMat ) ( void ) hipFree( ctx->d_trMat );
+  if( ctx->d_scan ) ( void ) hipFree( ctx->d_scan );
+  if( ctx->d_scratch ) ( void ) hipFree( ctx->d_scratch );
+  if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );
+  delete ctx;
+}
+
+const char* vvhip_last_error( const vvhip_ctx* ctx ) { return ctx ? ctx->lastError.c_str() : g_createError.c_str(); }
+
+int vvhip_set_stream( vvhip_ctx* ctx, void* hip_stream )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  ctx->stream = hip_stream ? ( hipStream_t ) hip_stream : ctx->ownStream;
+  return VVHIP_OK;
+}
+
+void* vvhip_get_stream( vvhip_ctx* ctx ) { return ctx ? ( void* ) ctx->stream : nullptr; }
+
+int vvhip_sync( vvhip_ctx* ctx )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  return VVHIP_OK;
+}
+
+int vvhip_malloc( vvhip_ctx* ctx, void** d_ptr, size_t bytes )
+{
+  if( !ctx || !d_ptr ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipSetDevice( ctx->device ) );
+  hipError_t e = hipMalloc( d_ptr, bytes ? bytes : 1 );
+  if( e != hipSuccess ) return vvhip_fail( ctx, VVHIP_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString( e ) );
+  return VVHIP_OK;
+}
+
+int vvhip_free( vvhip_ctx* ctx, void* d_ptr )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipFree( d_ptr ) );
+  return VVHIP_OK;
+}
+
+int vvhip_upload( vvhip_ctx* ctx, void* d_dst, const void* host_src, size_t bytes )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( d_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream ) );
+  return VVHIP_OK;
+}
+
+int vvhip_download( vvhip_ctx* ctx, void* host_dst, const void* d_src, size_t bytes )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( host_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  return VVHIP_OK;
+}
+
+} // extern "C"

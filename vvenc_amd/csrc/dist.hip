@@ -1,0 +1,417 @@
+// dist.hip — distortion kernels (SAD / SSE / Hadamard-SATD / DMVR SADx5 / SAD cost surface) for gfx950.
+//
+// Reference semantics: CommonLib/RdCost.cpp:301-2093 (scalar) == CommonLib/x86/RdCostX86.h (SIMD);
+// table rows RdCost::m_afpDistortFunc[0][DF_*] (RdCost.h:120).  Everything is integer except the
+// rectangular Hadamard tiles' (int)(sad / sqrt(w*h) * 2) which is IEEE double divide + multiply.
+//
+// Execution model: a *team* of LPC consecutive lanes (1..64, power of two) owns one candidate, so a
+// 64-lane wavefront evaluates 64/LPC small candidates at once and a 64x64 candidate fills a whole
+// wave.  Lanes read 8/16-byte row segments straight from the picture planes (which stay resident in
+// L2 / Infinity Cache across the thousands of candidates of a frame); costs are reduced with
+// wave-level xor-shuffles; one lane stores the 64-bit Distortion.
+#include "common.h"
+
+namespace {
+
+typedef uint32_t u32x2 __attribute__( ( ext_vector_type( 2 ) ) );
+typedef uint32_t u32x4 __attribute__( ( ext_vector_type( 4 ) ) );
+struct __attribute__( ( packed, aligned( 2 ) ) ) U4  { uint32_t v; };
+struct __attribute__( ( packed, aligned( 2 ) ) ) U8  { u32x2 v; };
+struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+
+// picture samples are only 2-byte aligned (arbitrary motion vectors): gfx950 handles unaligned dword..dwordx4 loads
+__device__ __forceinline__ uint32_t ld4( const int16_t* p ) { return reinterpret_cast<const U4*>( p )->v; }
+__device__ __forceinline__ u32x2    ld8( const int16_t* p ) { return reinterpret_cast<const U8*>( p )->v; }
+__device__ __forceinline__ u32x4    ld16( const int16_t* p ) { return reinterpret_cast<const U16*>( p )->v; }
+
+__device__ __forceinline__ int lo16( uint32_t v ) { return ( int ) ( int16_t ) ( v & 0xffffu ); }
+__device__ __forceinline__ int hi16( uint32_t v ) { return ( int ) ( ( int32_t ) v >> 16 ); }
+
+// |a.lo-b.lo| + |a.hi-b.hi| + acc for SIGNED int16 pairs: bias both to unsigned order, then v_sad_u16
+__device__ __forceinline__ uint32_t sadPair( uint32_t a, uint32_t b, uint32_t acc )
+{
+  return __builtin_amdgcn_sad_u16( a ^ 0x80008000u, b ^ 0x80008000u, acc );
+}
+
+template<typename T>
+__device__ __forceinline__ T teamSum( T v, int lpc )
+{
+  for( int o = lpc >> 1; o > 0; o >>= 1 ) v += __shfl_xor( v, o );
+  return v;
+}
+
+enum { MODE_SAD = 0, MODE_SSE = 1, MODE_SAD_X5 = 2, MODE_SAD_MIN2 = 3 };
+
+// ---------------------------------------------------------------------------------------------
+// SAD / SSE over a candidate list.  CH = samples per lane per row segment (2, 4 or 8).
+// chunk c of a candidate = (row c / lpr, segment c % lpr); lanes of a team stride over chunks.
+// ---------------------------------------------------------------------------------------------
+template<int CH, int MODE>
+__global__ void __launch_bounds__( 256 )
+sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
+              int lpr /* lanes (segments) per row = w / CH */, int rowsEff, int subShift, int log2Lpc,
+              const vvhip_dist_item* __restrict__ items, int n, int calcCentre, uint64_t* __restrict__ out )
+{
+  const int gid  = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lpc  = 1 << log2Lpc;
+  const int team = gid >> log2Lpc;
+  const int lt   = gid & ( lpc - 1 );
+  const int nTeams = MODE == MODE_SAD_X5 ? n * 5 : n;
+  const bool valid = team < nTeams;
+
+  int orgOff = 0, curOff = 0, k = 0;
+  if( valid )
+  {
+    const int idx = MODE == MODE_SAD_X5 ? team / 5 : team;
+    k = MODE == MODE_SAD_X5 ? team - idx * 5 : 0;
+    const vvhip_dist_item it = items[idx];
+    orgOff = it.org_off + k;      // RdCost.cpp:1988-2001: org.buf += k, cur.buf -= k
+    curOff = it.cur_off - k;
+  }
+  const int16_t* po = org + orgOff;
+  const int16_t* pc = cur + curOff;
+  const int step = 1 << subShift;
+  const int chunks = valid ? lpr * rowsEff : 0;
+
+  uint32_t sad = 0;
+  uint64_t sse = 0;
+  for( int c = lt; c < chunks; c += lpc )
+  {
+    const int r = c / lpr, s = c - r * lpr;
+    const int y = r * step;
+    const int16_t* a = po + ( ptrdiff_t ) y * orgStride + s * CH;
+    const int16_t* b = pc + ( ptrdiff_t ) y * curStride + s * CH;
+    uint32_t va[CH / 2], vb[CH / 2];
+    if( CH == 2 ) { va[0] = ld4( a ); vb[0] = ld4( b ); }
+    else if( CH == 4 ) { u32x2 x = ld8( a ), z = ld8( b ); va[0] = x.x; va[CH / 2 - 1] = x.y; vb[0] = z.x; vb[CH / 2 - 1] = z.y; }
+    else { u32x4 x = ld16( a ), z = ld16( b );
+           va[0] = x.x; va[1 % ( CH / 2 )] = x.y; va[2 % ( CH / 2 )] = x.z; va[3 % ( CH / 2 )] = x.w;
+           vb[0] = z.x; vb[1 % ( CH / 2 )] = z.y; vb[2 % ( CH / 2 )] = z.z; vb[3 % ( CH / 2 )] = z.w; }
+#pragma unroll
+    for( int i = 0; i < CH / 2; i++ )
+    {
+      if( MODE == MODE_SSE )
+      {
+        const int d0 = lo16( va[i] ) - lo16( vb[i] ), d1 = hi16( va[i] ) - hi16( vb[i] );
+        sse += ( uint64_t ) ( ( int64_t ) d0 * d0 ) + ( uint64_t ) ( ( int64_t ) d1 * d1 );
+      }
+      else sad = sadPair( va[i], vb[i], sad );
+    }
+  }
+
+  if( MODE == MODE_SSE )
+  {
+    sse = teamSum( sse, lpc );
+    if( valid && lt == 0 ) out[team] = sse;
+  }
+  else
+  {
+    sad = teamSum( sad, lpc );
+    if( valid && lt == 0 )
+    {
+      const uint64_t v = ( uint64_t ) sad << subShift;                 // RdCost.cpp:334
+      if( MODE == MODE_SAD ) out[team] = v;
+      else if( MODE == MODE_SAD_X5 ) { if( k != 2 || calcCentre ) out[team] = v >> 1; }   // RdCost.cpp:2003-2007
+      else { const uint64_t h = out[team]; out[team] = h < 2 * v ? h : 2 * v; }          // RdCost.cpp:1815
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hadamard SATD.  A tile of TW x TH differences is held one row per lane (TH lanes = a tile team):
+// horizontal Walsh-Hadamard in registers, vertical across lanes with xor-shuffles.  SATD is a sum of
+// absolute coefficients, so butterfly order/sign conventions are irrelevant; only the DC term
+// (plain sum of differences) is special: |DC| is replaced by |DC| >> 2 in every tile type.
+// FAST16: the 16x16_fast tile = 8x8 Hadamard of 2x2-averaged org and cur (RdCost.cpp:1126-1223).
+// ---------------------------------------------------------------------------------------------
+template<int TW> __device__ __forceinline__ void loadRowDiff( const int16_t* a, const int16_t* b, int ( &d )[TW] )
+{
+  if( TW == 2 ) { const uint32_t x = ld4( a ), z = ld4( b ); d[0] = lo16( x ) - lo16( z ); d[1 % TW] = hi16( x ) - hi16( z ); }
+  else if( TW == 4 )
+  {
+    const u32x2 x = ld8( a ), z = ld8( b );
+    d[0] = lo16( x.x ) - lo16( z.x ); d[1 % TW] = hi16( x.x ) - hi16( z.x ); d[2 % TW] = lo16( x.y ) - lo16( z.y ); d[3 % TW] = hi16( x.y ) - hi16( z.y );
+  }
+  else
+  {
+#pragma unroll
+    for( int q = 0; q < TW / 8; q++ )
+    {
+      const u32x4 x = ld16( a + 8 * q ), z = ld16( b + 8 * q );
+      const uint32_t xs[4] = { x.x, x.y, x.z, x.w }, zs[4] = { z.x, z.y, z.z, z.w };
+#pragma unroll
+      for( int i = 0; i < 4; i++ )
+      {
+        d[( 8 * q + 2 * i ) % TW]     = lo16( xs[i] ) - lo16( zs[i] );
+        d[( 8 * q + 2 * i + 1 ) % TW] = hi16( xs[i] ) - hi16( zs[i] );
+      }
+    }
+  }
+}
+
+// rounded 2x2 averages of 16 samples x 2 rows -> 8 values
+__device__ __forceinline__ void avgRow16( const int16_t* p, int stride, int ( &o )[8] )
+{
+  const u32x4 a0 = ld16( p ), a1 = ld16( p + 8 ), b0 = ld16( p + stride ), b1 = ld16( p + stride + 8 );
+  const uint32_t t[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+  const uint32_t u[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+  for( int i = 0; i < 8; i++ ) o[i] = ( lo16( t[i] ) + hi16( t[i] ) + lo16( u[i] ) + hi16( u[i] ) + 2 ) >> 2;
+}
+
+template<int TW, int TH, bool FAST16>
+__global__ void __launch_bounds__( 256 )
+hadKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
+           int tilesX, int tilesPerCand, int log2Lpc,
+           const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+{
+  constexpr int PX = FAST16 ? 16 : TW;     // picture samples covered by a tile horizontally / vertically
+  constexpr int PY = FAST16 ? 16 : TH;
+  const int gid  = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lpc  = 1 << log2Lpc;
+  const int cand = gid >> log2Lpc;
+  const int lt   = gid & ( lpc - 1 );
+  const bool valid = cand < n;
+  const int row  = lt & ( TH - 1 );        // my row inside the tile
+  const int tt   = lt / TH;                // tile team inside the candidate
+  const int teams = lpc / TH;
+
+  int orgOff = 0, curOff = 0;
+  if( valid ) { const vvhip_dist_item it = items[cand]; orgOff = it.org_off; curOff = it.cur_off; }
+
+  uint64_t sum = 0;
+  const int tiles = valid ? tilesPerCand : 0;
+  // all lanes of a wave run the same trip count (teams own tiles tt, tt+teams, ..); tilesPerCand % teams == 0 or teams == 1 by construction
+  for( int t = tt; t < tiles; t += teams )
+  {
+    const int ty = t / tilesX, tx = t - ty * tilesX;
+    int d[TW];
+    if( FAST16 )
+    {
+      int ao[8], ac[8];
+      avgRow16( org + orgOff + ( ptrdiff_t ) ( ty * PY + 2 * row ) * orgStride + tx * PX, orgStride, ao );
+      avgRow16( cur + curOff + ( ptrdiff_t ) ( ty * PY + 2 * row ) * curStride + tx * PX, curStride, ac );
+#pragma unroll
+      for( int i = 0; i < 8; i++ ) d[i % TW] = ao[i] - ac[i];
+    }
+    else
+      loadRowDiff<TW>( org + orgOff + ( ptrdiff_t ) ( ty * PY + row ) * orgStride + tx * PX,
+                       cur + curOff + ( ptrdiff_t ) ( ty * PY + row ) * curStride + tx * PX, d );
+
+    // horizontal WHT (in registers)
+#pragma unroll
+    for( int len = 1; len < TW; len <<= 1 )
+#pragma unroll
+      for( int i = 0; i < TW; i += 2 * len )
+#pragma unroll
+        for( int j = i; j < i + len; j++ ) { const int a = d[j], b = d[j + len]; d[j] = a + b; d[j + len] = a - b; }
+    // vertical WHT (across the TH lanes of the tile team)
+#pragma unroll
+    for( int s = 1; s < TH; s <<= 1 )
+    {
+      const bool upper = ( row & s ) != 0;
+#pragma unroll
+      for( int i = 0; i < TW; i++ ) { const int o = __shfl_xor( d[i], s ); d[i] = upper ? o - d[i] : d[i] + o; }
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for( int i = 0; i < TW; i++ ) s += ( uint32_t ) abs( d[i] );
+    if( row == 0 ) { const uint32_t dc = ( uint32_t ) abs( d[0] ); s = s - dc + ( dc >> 2 ); }
+#pragma unroll
+    for( int o = 1; o < TH; o <<= 1 ) s += __shfl_xor( s, o );
+    if( row == 0 )
+    {
+      uint32_t v;
+      if( FAST16 )              v = ( ( s + 2 ) >> 2 ) << 2;                                         // RdCost.cpp:1220-1222
+      else if( TW != TH )       v = ( uint32_t ) ( int ) ( ( double ) ( int ) s / __builtin_sqrt( ( double ) ( TW * TH ) ) * 2 );  // :1467,1606,1682,1763
+      else if( TW == 8 )        v = ( s + 2 ) >> 2;                                                  // :1319
+      else if( TW == 4 )        v = ( s + 1 ) >> 1;                                                  // :1121
+      else                      v = s;                                                               // :1020-1023
+      sum += v;
+    }
+  }
+  sum = teamSum( sum, lpc );
+  if( valid && lt == 0 ) out[cand] = sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAD cost surface: one workgroup per block; the (w+2rx) x (h'+2ry) reference window is staged in
+// LDS once (coalesced row reads), the block's original rows live in LDS too; each wave then walks
+// displacements, lanes split the block's row segments.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__( 256 )
+sadSurfaceKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ ref, int refStride,
+                  int w, int h, int subShift, int rx, int ry,
+                  const int32_t* __restrict__ blkOrgOff, const int32_t* __restrict__ blkRefOff, uint32_t* __restrict__ out )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemRaw[];
+  int16_t* sOrg = reinterpret_cast<int16_t*>( smemRaw );          // rowsEff x w
+  const int step = 1 << subShift, rowsEff = h >> subShift;
+  const int winW = w + 2 * rx, winH = h + 2 * ry;
+  const int winStride = ( winW + 1 ) | 1;                          // odd number of int16 -> spreads LDS banks across rows
+  int16_t* sWin = sOrg + ( ( rowsEff * w + 7 ) & ~7 );
+
+  const int b = blockIdx.x;
+  const int16_t* po = org + blkOrgOff[b];
+  const int16_t* pr = ref + blkRefOff[b] - ( ptrdiff_t ) ry * refStride - rx;
+  for( int i = threadIdx.x; i < rowsEff * w; i += blockDim.x )
+  {
+    const int r = i / w, x = i - r * w;
+    sOrg[i] = po[( ptrdiff_t ) ( r * step ) * orgStride + x];
+  }
+  for( int i = threadIdx.x; i < winH * winW; i += blockDim.x )
+  {
+    const int r = i / winW, x = i - r * winW;
+    sWin[r * winStride + x] = pr[( ptrdiff_t ) r * refStride + x];
+  }
+  __syncthreads();
+
+  const int nx = 2 * rx + 1, ny = 2 * ry + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const int total = rowsEff * w;
+  for( int m = wave; m < nx * ny; m += waves )
+  {
+    const int my = m / nx, mx = m - my * nx;
+    uint32_t acc = 0;
+    for( int i = lane; i < total; i += 64 )
+    {
+      const int r = i / w, x = i - r * w;
+      const int a = sOrg[i];
+      const int c = sWin[( my + r * step ) * winStride + mx + x];
+      acc += ( uint32_t ) abs( a - c );
+    }
+    acc = teamSum( acc, 64 );
+    if( lane == 0 ) out[( size_t ) b * nx * ny + m] = acc << subShift;
+  }
+}
+
+int pow2Floor( int v ) { int p = 1; while( p * 2 <= v ) p <<= 1; return p; }
+
+template<int MODE>
+int launchSadSse( vvhip_ctx* ctx, const int16_t* d_org, int os, const int16_t* d_cur, int cs, int w, int h, int subShift,
+                  const vvhip_dist_item* items, int n, int calcCentre, uint64_t* out )
+{
+  const int rowsEff = h >> subShift;
+  const int CH = ( w % 8 == 0 ) ? 8 : ( w % 4 == 0 ) ? 4 : 2;
+  const int lpr = w / CH;
+  int lpc = pow2Floor( lpr * rowsEff );
+  if( lpc > 64 ) lpc = 64;
+  const int log2Lpc = ilog2i( lpc );
+  const long teams = ( long ) n * ( MODE == MODE_SAD_X5 ? 5 : 1 );
+  const long threads = teams * lpc;
+  const int block = 256;
+  const unsigned grid = ( unsigned ) ( ( threads + block - 1 ) / block );
+  if( grid == 0 ) return VVHIP_OK;
+#define LAUNCH( C ) hipLaunchKernelGGL( ( sadSseKernel<C, MODE> ), dim3( grid ), dim3( block ), 0, ctx->stream, \
+                                        d_org, os, d_cur, cs, lpr, rowsEff, subShift, log2Lpc, items, n, calcCentre, out )
+  if( CH == 8 ) LAUNCH( 8 ); else if( CH == 4 ) LAUNCH( 4 ); else LAUNCH( 2 );
+#undef LAUNCH
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+template<int TW, int TH, bool FAST16>
+int launchHad( vvhip_ctx* ctx, const int16_t* d_org, int os, const int16_t* d_cur, int cs, int w, int h,
+               const vvhip_dist_item* items, int n, uint64_t* out )
+{
+  constexpr int PX = FAST16 ? 16 : TW, PY = FAST16 ? 16 : TH;
+  const int tilesX = w / PX, tiles = tilesX * ( h / PY );
+  int lpc = TH * pow2Floor( tiles );      // tiles per candidate is a power of two for power-of-two blocks
+  if( lpc > 64 ) lpc = 64;
+  if( tiles % ( lpc / TH ) != 0 ) lpc = TH;   // odd tile counts (non power-of-two blocks): one tile team walks all tiles
+  const int log2Lpc = ilog2i( lpc );
+  const long threads = ( long ) n * lpc;
+  const int block = 256;
+  const unsigned grid = ( unsigned ) ( ( threads + block - 1 ) / block );
+  if( grid == 0 ) return VVHIP_OK;
+  hipLaunchKernelGGL( ( hadKernel<TW, TH, FAST16> ), dim3( grid ), dim3( block ), 0, ctx->stream,
+                      d_org, os, d_cur, cs, tilesX, tiles, log2Lpc, items, n, out );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+// tile-selection ladder of xGetHADs<fastHad>, RdCost.cpp:1836-1935
+int launchHadLadder( vvhip_ctx* ctx, bool fast, const int16_t* d_org, int os, const int16_t* d_cur, int cs, int w, int h,
+                     const vvhip_dist_item* items, int n, uint64_t* out )
+{
+  if( w > h && ( h & 7 ) == 0 && ( w & 15 ) == 0 )      return launchHad<16, 8, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( w < h && ( w & 7 ) == 0 && ( h & 15 ) == 0 ) return launchHad<8, 16, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( w > h && ( h & 3 ) == 0 && ( w & 7 ) == 0 )  return launchHad<8, 4, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( w < h && ( w & 3 ) == 0 && ( h & 7 ) == 0 )  return launchHad<4, 8, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( fast && h % 32 == 0 && w % 32 == 0 && h == w ) return launchHad<8, 8, true>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( h % 8 == 0 && w % 8 == 0 )                   return launchHad<8, 8, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( h % 4 == 0 && w % 4 == 0 )                   return launchHad<4, 4, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( h % 2 == 0 && w % 2 == 0 )                   return launchHad<2, 2, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  return vvhip_fail( ctx, VVHIP_E_ARG, "Hadamard: invalid size %dx%d (reference THROWs \"Invalid size\", RdCost.cpp:1934)", w, h );
+}
+
+} // namespace
+
+extern "C" {
+
+int vvhip_dist_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride,
+                      int width, int height, int sub_shift, int bit_depth, const vvhip_dist_item* d_items, int n, uint64_t* d_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( n < 0 || width < 1 || height < 1 || width > 128 || height > 128 || sub_shift < 0 || sub_shift > 1 )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_batch: bad geometry %dx%d subShift %d n %d", width, height, sub_shift, n );
+  if( bit_depth > 10 && bit_depth != 12 ) { /* any depth works: arithmetic is exact for all int16 inputs */ }
+  if( n == 0 ) return VVHIP_OK;
+  if( !d_org || !d_cur || !d_items || !d_out ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_batch: NULL pointer" );
+  switch( func )
+  {
+  case VVHIP_DF_SAD:
+    if( ( width & 1 ) || ( height >> sub_shift ) < 1 || ( height & ( ( 1 << sub_shift ) - 1 ) ) )
+      return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "SAD: width must be even and height a multiple of 1<<subShift (%dx%d)", width, height );
+    return launchSadSse<MODE_SAD>( ctx, d_org, org_stride, d_cur, cur_stride, width, height, sub_shift, d_items, n, 0, d_out );
+  case VVHIP_DF_SSE:
+    if( width & 1 ) return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "SSE: width must be even (%d)", width );
+    return launchSadSse<MODE_SSE>( ctx, d_org, org_stride, d_cur, cur_stride, width, height, 0, d_items, n, 0, d_out );
+  case VVHIP_DF_HAD:
+    return launchHadLadder( ctx, false, d_org, org_stride, d_cur, cur_stride, width, height, d_items, n, d_out );
+  case VVHIP_DF_HAD_FAST:
+    return launchHadLadder( ctx, true, d_org, org_stride, d_cur, cur_stride, width, height, d_items, n, d_out );
+  case VVHIP_DF_HAD_2SAD:
+  {
+    int rc = launchHadLadder( ctx, false, d_org, org_stride, d_cur, cur_stride, width, height, d_items, n, d_out );
+    if( rc ) return rc;
+    return launchSadSse<MODE_SAD_MIN2>( ctx, d_org, org_stride, d_cur, cur_stride, width, height, 0, d_items, n, 0, d_out );
+  }
+  default:
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_batch: unknown function %d", func );
+  }
+}
+
+int vvhip_sad_x5_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride,
+                        int width, int height, int sub_shift, int calc_centre, const vvhip_dist_item* d_items, int n, uint64_t* d_out5 )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( ( width != 8 && width != 16 ) || height < 1 || height > 128 || sub_shift < 0 || sub_shift > 1 || n < 0 )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_sad_x5_batch: width must be 8 or 16 (m_afpDistortFuncX5[log2w-3], RdCost.cpp:252), got %dx%d", width, height );
+  if( n == 0 ) return VVHIP_OK;
+  return launchSadSse<MODE_SAD_X5>( ctx, d_org, org_stride, d_cur, cur_stride, width, height, sub_shift, d_items, n, calc_centre, d_out5 );
+}
+
+int vvhip_sad_surface( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_ref, int ref_stride,
+                       int width, int height, int sub_shift, int range_x, int range_y,
+                       const int32_t* d_block_org_off, const int32_t* d_block_ref_off, int n_blocks, uint32_t* d_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( width < 2 || height < 2 || width > 128 || height > 128 || sub_shift < 0 || sub_shift > 1 || range_x < 0 || range_y < 0 || n_blocks < 0 )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_sad_surface: bad geometry" );
+  if( n_blocks == 0 ) return VVHIP_OK;
+  const int rowsEff = height >> sub_shift;
+  const int winW = width + 2 * range_x, winH = height + 2 * range_y;
+  const int winStride = ( winW + 1 ) | 1;
+  const size_t smem = ( size_t ) ( ( ( rowsEff * width + 7 ) & ~7 ) + winH * winStride ) * sizeof( int16_t );
+  if( smem > 160 * 1024 ) return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_sad_surface: window %dx%d needs %zu B of LDS (> 160 KiB)", winW, winH, smem );
+  if( smem > 64 * 1024 )
+    VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) sadSurfaceKernel, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) smem ) );
+  hipLaunchKernelGGL( sadSurfaceKernel, dim3( n_blocks ), dim3( 256 ), smem, ctx->stream,
+                      d_org, org_stride, d_ref, ref_stride, width, height, sub_shift, range_x, range_y,
+                      d_block_org_off, d_block_ref_off, d_out );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,547 @@
+// mctf.hip — MCTF hierarchical block matching for gfx950.
+//
+// Reference semantics (CommonLib/MCTF.cpp):
+//   motionErrorLumaInt :122-145, motionErrorLumaFrac6/4 :147-257 (clip after each pass), calcVarCore :520-546,
+//   subsampleLuma :1072-1097, motionErrorLuma :1099-1164, estimateLumaLn :1166-1327 (search schedule, strict-< argmin in scan
+//   order), motionEstimationLuma :1329-1397 (row tasks with above/left hand-off), motionEstimationMCTF :666-707 (pyramid).
+//
+// How the schedule is mapped to the GPU (per level, per (current, reference) pair):
+//   phase A  meSearchKernel    one wavefront per block; the candidate list of estimateLumaLn up to (not including) the above/left
+//                              tests is walked in the reference's order, each candidate's error is computed by the 64 lanes
+//                              together (16-byte row segments, two-pass sub-pel filter through LDS).  All blocks independent.
+//   phase B  meWavefrontKernel the above/left tests are a true recurrence (block (x,y) needs the FINAL vectors of (x,y-1) and
+//                              (x-1,y)).  One wavefront per block row walks the row left to right; rows hand vectors to the row
+//                              below through 8-byte {tag,x,y} granules (one relaxed agent-scope store / load each — placement
+//                              independent, no fences; MI355X guide §6 G16 form R2).  Critical path = cols + rows steps.
+//   phase C  meFinalizeKernel  (final 1/16-pel level only) variance-normalised error, rmsme, overlap in IEEE double, no FMA
+//                              contraction (-ffp-contract=off), MCTF.cpp:1308-1321.
+// The `> besterror` early exits of the reference are semantically inert (callers only use errors < best.error), so kernels
+// always produce the full sum.
+#include "common.h"
+#include <vector>
+
+namespace {
+
+typedef uint32_t u32x2 __attribute__( ( ext_vector_type( 2 ) ) );
+typedef uint32_t u32x4 __attribute__( ( ext_vector_type( 4 ) ) );
+struct __attribute__( ( packed, aligned( 2 ) ) ) U4  { uint32_t v; };
+struct __attribute__( ( packed, aligned( 2 ) ) ) U8  { u32x2 v; };
+struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+__device__ __forceinline__ uint32_t ld4( const int16_t* p ) { return reinterpret_cast<const U4*>( p )->v; }
+__device__ __forceinline__ u32x2 ld8( const int16_t* p ) { return reinterpret_cast<const U8*>( p )->v; }
+__device__ __forceinline__ u32x4 ld16( const int16_t* p ) { return reinterpret_cast<const U16*>( p )->v; }
+__device__ __forceinline__ int lo16( uint32_t v ) { return ( int ) ( int16_t ) ( v & 0xffffu ); }
+__device__ __forceinline__ int hi16( uint32_t v ) { return ( int ) ( ( int32_t ) v >> 16 ); }
+
+__device__ __forceinline__ int waveSum( int v )
+{
+#pragma unroll
+  for( int o = 32; o > 0; o >>= 1 ) v += __shfl_xor( v, o );
+  return v;
+}
+
+// 1/16-pel interpolation filters of the MCTF search.  Row f of kFilter4 = MCTF::m_interpolationFilter4[f] (MCTF.cpp:92-110),
+// row f of kFilter6 = taps [1..6] of MCTF::m_interpolationFilter8[f] (MCTF.cpp:72-90; taps 0 and 7 are zero and unused :164-169).
+__constant__ int8_t kFilter4[16][4] = {
+  { 0, 64, 0, 0 },    { -2, 62, 4, 0 },   { -2, 58, 10, -2 }, { -4, 56, 14, -2 }, { -4, 54, 16, -2 }, { -6, 52, 20, -2 }, { -6, 46, 28, -4 }, { -4, 42, 30, -4 },
+  { -4, 36, 36, -4 }, { -4, 30, 42, -4 }, { -4, 28, 46, -6 }, { -2, 20, 52, -6 }, { -2, 16, 54, -4 }, { -2, 14, 56, -4 }, { -2, 10, 58, -2 }, { 0, 4, 62, -2 } };
+__constant__ int8_t kFilter6[16][6] = {
+  { 0, 0, 64, 0, 0, 0 },     { 1, -3, 64, 4, -2, 0 },   { 1, -6, 62, 9, -3, 1 },   { 2, -8, 60, 14, -5, 1 },  { 2, -9, 57, 19, -7, 2 },  { 3, -10, 53, 24, -8, 2 },
+  { 3, -11, 50, 29, -9, 2 }, { 3, -11, 44, 35, -10, 3 }, { 1, -7, 38, 38, -7, 1 },  { 3, -10, 35, 44, -11, 3 }, { 2, -9, 29, 50, -11, 3 }, { 2, -8, 24, 53, -10, 3 },
+  { 2, -7, 19, 57, -9, 2 },  { 1, -5, 14, 60, -8, 2 },  { 1, -3, 9, 62, -6, 1 },   { 0, -2, 4, 64, -3, 1 } };
+
+// ---- error of one candidate, computed by a whole wavefront (all 64 lanes must call) -------------------------------------------
+// integer displacement: sum (org - buf)^2 over w x h, w,h multiples of 8 (MCTF.cpp:122-145)
+__device__ __forceinline__ int waveErrorInt( const int16_t* org, int os, const int16_t* buf, int bs, int w, int h, int lane )
+{
+  const int segs = w >> 3, total = segs * h;
+  int e = 0;
+  for( int i = lane; i < total; i += 64 )
+  {
+    const int y = i / segs, s = i - y * segs;
+    const u32x4 a = ld16( org + ( ptrdiff_t ) y * os + 8 * s ), b = ld16( buf + ( ptrdiff_t ) y * bs + 8 * s );
+    const uint32_t as[4] = { a.x, a.y, a.z, a.w }, bb[4] = { b.x, b.y, b.z, b.w };
+#pragma unroll
+    for( int q = 0; q < 4; q++ ) { const int d0 = lo16( as[q] ) - lo16( bb[q] ), d1 = hi16( as[q] ) - hi16( bb[q] ); e += d0 * d0 + d1 * d1; }
+  }
+  return waveSum( e );
+}
+
+// fractional displacement (MCTF.cpp:147-257): horizontal pass -> clip -> LDS -> vertical pass -> clip -> squared error.
+// TAP4: 4-tap filter rows (offsets -1..+2), else 6-tap (offsets -2..+3).  sTmp: (h + NT - 1) x w int16, private to the wave.
+template<bool TAP4>
+__device__ __forceinline__ int waveErrorFrac( const int16_t* org, int os, const int16_t* buf, int bs, int w, int h, int fx, int fy,
+                                              int maxVal, int16_t* sTmp, int lane )
+{
+  constexpr int NT = TAP4 ? 4 : 6, OFF = TAP4 ? 1 : 2;
+  int xf[NT], yf[NT];
+#pragma unroll
+  for( int t = 0; t < NT; t++ ) { xf[t] = TAP4 ? kFilter4[fx][t % 4] : kFilter6[fx][t % 6]; yf[t] = TAP4 ? kFilter4[fy][t % 4] : kFilter6[fy][t % 6]; }
+  const int rows = h + NT - 1;
+  const int pairs = w >> 1;                     // two horizontally adjacent outputs per lane-iteration
+  for( int i = lane; i < rows * pairs; i += 64 )
+  {
+    const int r = i / pairs, x = 2 * ( i - r * pairs );
+    const int16_t* p = buf + ( ptrdiff_t ) ( r - OFF ) * bs + x - OFF;
+    int smp[NT + 1];
+    if( TAP4 ) { const u32x2 v = ld8( p ); smp[0] = lo16( v.x ); smp[1] = hi16( v.x ); smp[2] = lo16( v.y ); smp[3] = hi16( v.y ); smp[4 % ( NT + 1 )] = p[4]; }
+    else       { const u32x4 v = ld16( p ); smp[0] = lo16( v.x ); smp[1] = hi16( v.x ); smp[2] = lo16( v.y ); smp[3] = hi16( v.y );
+                 smp[4 % ( NT + 1 )] = lo16( v.z ); smp[5 % ( NT + 1 )] = hi16( v.z ); smp[6 % ( NT + 1 )] = lo16( v.w ); }
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for( int t = 0; t < NT; t++ ) { s0 += xf[t] * smp[t]; s1 += xf[t] * smp[t + 1]; }
+    s0 = min( max( ( s0 + 32 ) >> 6, 0 ), maxVal );
+    s1 = min( max( ( s1 + 32 ) >> 6, 0 ), maxVal );
+    *reinterpret_cast<uint32_t*>( sTmp + r * w + x ) = ( uint32_t ) ( s0 & 0xffff ) | ( ( uint32_t ) s1 << 16 );
+  }
+  __syncthreads();                               // single-wave workgroups: orders the LDS writes above before the reads below
+  int e = 0;
+  for( int i = lane; i < h * pairs; i += 64 )
+  {
+    const int y = i / pairs, x = 2 * ( i - y * pairs );
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for( int t = 0; t < NT; t++ )
+    {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>( sTmp + ( y + t ) * w + x );
+      s0 += yf[t] * lo16( v ); s1 += yf[t] * hi16( v );
+    }
+    s0 = min( max( ( s0 + 32 ) >> 6, 0 ), maxVal );
+    s1 = min( max( ( s1 + 32 ) >> 6, 0 ), maxVal );
+    const uint32_t o = ld4( org + ( ptrdiff_t ) y * os + x );
+    const int d0 = s0 - lo16( o ), d1 = s1 - hi16( o );
+    e += d0 * d0 + d1 * d1;
+  }
+  __syncthreads();                               // sTmp is reused by the next candidate
+  return waveSum( e );
+}
+
+struct MeGeom
+{
+  const int16_t* org; int orgStride;
+  const int16_t* buf; int bufStride;
+  int width, height, bs;
+  int lowRes, maxVal;
+};
+
+// MCTF::motionErrorLuma, MCTF.cpp:1099-1164 (x,y block origin; dx,dy in 1/16 pel)
+__device__ __forceinline__ int meError( const MeGeom& g, int x, int y, int dx, int dy, int16_t* sTmp, int lane )
+{
+  const int fx = dx & 15, fy = dy & 15;
+  const int w = min( g.bs, g.width - x ) & ~7, h = min( g.bs, g.height - y ) & ~7;
+  const int16_t* o = g.org + x + ( ptrdiff_t ) y * g.orgStride;
+  if( ( fx | fy ) == 0 )
+    return waveErrorInt( o, g.orgStride, g.buf + x + dx / 16 + ( ptrdiff_t ) ( y + dy / 16 ) * g.bufStride, g.bufStride, w, h, lane );
+  const int16_t* b = g.buf + x + ( dx >> 4 ) + ( ptrdiff_t ) ( y + ( dy >> 4 ) ) * g.bufStride;
+  return g.lowRes ? waveErrorFrac<true>( o, g.orgStride, b, g.bufStride, w, h, fx, fy, g.maxVal, sTmp, lane )
+                  : waveErrorFrac<false>( o, g.orgStride, b, g.bufStride, w, h, fx, fy, g.maxVal, sTmp, lane );
+}
+
+#define ME_TRY( DX, DY ) do { const int dx_ = ( DX ), dy_ = ( DY ); const int e_ = meError( g, bx, by, dx_, dy_, sTmp, lane ); \
+                              if( e_ < bestE ) { bestX = dx_; bestY = dy_; bestE = e_; } } while( 0 )
+
+// ---- phase A -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__( 64 )
+meSearchKernel( MeGeom g, int nbx, const vvhip_mv* __restrict__ prev, int prevW, int prevH, int factor, int doubleRes, int searchPttrn,
+                vvhip_mv* __restrict__ mvs, int mvsW )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[( 32 + 5 ) * 32];
+  const int lane = threadIdx.x;
+  const int blk = blockIdx.x, byi = blk / nbx, bxi = blk - byi * nbx;
+  const int bs = g.bs, bx = bxi * bs, by = byi * bs;
+
+  int bestX = 0, bestY = 0, bestE = 0x7fffffff;
+  int range = doubleRes ? 0 : ( searchPttrn == 2 ? 3 : 5 );              // MCTF.cpp:1178
+  if( !prev ) range = 8;                                                  // :1183-1186
+  else
+  {
+    for( int py = -1; py <= 1; py++ )                                     // :1189-1208
+    {
+      const int ty = by / ( 2 * bs ) + py;
+      if( ty < 0 || ty >= prevH ) continue;
+      for( int px = -1; px <= 1; px++ )
+      {
+        const int tx = bx / ( 2 * bs ) + px;
+        if( tx < 0 || tx >= prevW ) continue;
+        const vvhip_mv old = prev[ty * prevW + tx];
+        ME_TRY( old.x * factor, old.y * factor );
+      }
+    }
+    ME_TRY( 0, 0 );                                                       // :1210-1214
+  }
+  {
+    const int pbx = bestX, pby = bestY;                                   // :1216-1228
+    const int d = ( !prev && searchPttrn == 2 ) ? 2 : 1;
+    for( int y2 = pby / 16 - range; y2 <= pby / 16 + range; y2 += d )
+      for( int x2 = pbx / 16 - range; x2 <= pbx / 16 + range; x2 += d )
+        ME_TRY( x2 * 16, y2 * 16 );
+  }
+  if( doubleRes )                                                         // :1229-1288
+  {
+    int pbx = bestX, pby = bestY;
+    const int dr = searchPttrn ? 6 : 12, d1 = searchPttrn == 2 ? 6 : 4;
+    for( int y2 = -dr; y2 <= dr; y2 += d1 )
+      for( int x2 = -dr; x2 <= dr; x2 += d1 )
+        if( x2 || y2 ) ME_TRY( pbx + x2, pby + y2 );
+    pbx = bestX; pby = bestY;
+    for( int y2 = -2; y2 <= 2; y2 += 2 )
+      for( int x2 = -2; x2 <= 2; x2 += 2 )
+        if( x2 || y2 ) ME_TRY( pbx + x2, pby + y2 );
+    pbx = bestX; pby = bestY;
+    for( int y2 = -1; y2 <= 1; y2++ )
+      for( int x2 = -1; x2 <= 1; x2++ )
+        if( x2 || y2 ) ME_TRY( pbx + x2, pby + y2 );
+  }
+  if( lane == 0 )
+  {
+    vvhip_mv& m = mvs[byi * mvsW + bxi];
+    m.x = bestX; m.y = bestY; m.error = bestE;
+  }
+}
+
+// ---- phase B -------------------------------------------------------------------------------------------------------------
+// granule = { tag (hi 32) , x (bits 16..31), y (bits 0..15) }; tag == 1 marks "final"
+__device__ __forceinline__ uint64_t packGranule( int x, int y ) { return ( 1ull << 32 ) | ( ( uint64_t ) ( uint16_t ) ( int16_t ) x << 16 ) | ( uint16_t ) ( int16_t ) y; }
+
+__global__ void __launch_bounds__( 64 )
+meWavefrontKernel( MeGeom g, int nbx, vvhip_mv* __restrict__ mvs, int mvsW, unsigned long long* granules /* nby x nbx, zeroed */, int* abortFlag )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[( 32 + 5 ) * 32];
+  const int lane = threadIdx.x;
+  const int byi = blockIdx.x, bs = g.bs, by = byi * bs;
+  int leftX = 0, leftY = 0;
+  for( int bxi = 0; bxi < nbx; bxi++ )
+  {
+    const int bx = bxi * bs;
+    vvhip_mv& m = mvs[byi * mvsW + bxi];
+    int bestX = m.x, bestY = m.y, bestE = m.error;
+    if( byi > 0 )                                                         // MCTF.cpp:1289-1297
+    {
+      unsigned long long gr = 0;
+      if( lane == 0 )
+      {
+        const unsigned long long* src = granules + ( size_t ) ( byi - 1 ) * nbx + bxi;
+        unsigned spins = 0;
+        while( true )
+        {
+          gr = __hip_atomic_load( src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+          if( ( gr >> 32 ) == 1ull ) break;
+          if( ( ++spins & 255u ) == 0 && ( __hip_atomic_load( abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) || spins > ( 1u << 20 ) ) )
+          { __hip_atomic_store( abortFlag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); gr = ~0ull; break; }
+          __builtin_amdgcn_s_sleep( 2 );
+        }
+      }
+      const uint32_t glo = __shfl( ( uint32_t ) gr, 0 ), ghi = __shfl( ( uint32_t ) ( gr >> 32 ), 0 );
+      if( ghi != 1u ) return;                                             // aborted: bounded spin expired (reported by the host)
+      ME_TRY( ( int ) ( int16_t ) ( glo >> 16 ), ( int ) ( int16_t ) ( glo & 0xffffu ) );
+    }
+    if( bxi > 0 ) ME_TRY( leftX, leftY );                                 // MCTF.cpp:1298-1306
+    leftX = bestX; leftY = bestY;
+    if( lane == 0 )
+    {
+      m.x = bestX; m.y = bestY; m.error = bestE;
+      __hip_atomic_store( granules + ( size_t ) byi * nbx + bxi, packGranule( bestX, bestY ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    }
+  }
+}
+
+// ---- phase C -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__( 256 )
+meFinalizeKernel( MeGeom g, int nbx, int nby, int bitDepth, int unitSize, vvhip_mv* __restrict__ mvs, int mvsW )
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if( i >= nbx * nby ) return;
+  const int byi = i / nbx, bxi = i - byi * nbx, bx = bxi * g.bs, by = byi * g.bs;
+  const int w = min( g.bs, g.width - bx ) & ~7, h = min( g.bs, g.height - by ) & ~7;
+  const int16_t* o = g.org + bx + ( ptrdiff_t ) by * g.orgStride;
+  int avg = 0;                                                            // calcVarCore, MCTF.cpp:520-546
+  for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) avg += o[( ptrdiff_t ) y * g.orgStride + x];
+  avg <<= 4;
+  avg = avg / ( w * h );
+  long long var = 0;
+  for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) { const int p = ( o[( ptrdiff_t ) y * g.orgStride + x] << 4 ) - avg; var += p * p; }
+  vvhip_mv& m = mvs[byi * mvsW + bxi];
+  const double bdScale = ( double ) ( 1 << ( 2 * ( 10 - bitDepth ) ) );   // MCTF.cpp:1314-1320
+  const double dvar = ( ( double ) var / 256.0 ) * bdScale;
+  const double mse  = m.error * bdScale / ( double ) ( w * h );
+  const int    e    = ( int ) ( 20 * ( ( m.error * bdScale + 5.0 ) / ( dvar + 5.0 ) ) + mse / 50.0 );
+  m.rmsme   = ( int32_t ) ( uint16_t ) ( 0.5 + __builtin_sqrt( mse ) );
+  m.overlap = ( ( double ) w * h ) / ( unitSize * unitSize );
+  m.error   = e;
+}
+
+__global__ void initMvsKernel( vvhip_mv* mvs, int count )
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if( i < count ) { vvhip_mv m; m.x = 0; m.y = 0; m.error = 0x7fffffff; m.rmsme = 65535; m.overlap = 0.0; mvs[i] = m; }   // MotionVector(), MCTF.h:79
+}
+
+// ---- stand-alone batches (table-entry shaped) -------------------------------------------------------------------------------
+__global__ void __launch_bounds__( 64 )
+mctfErrorBatchKernel( const int16_t* __restrict__ org, int os, const int16_t* __restrict__ buf, int bs, int w, int h, int tap4, int maxVal,
+                      const vvhip_mctf_item* __restrict__ items, int32_t* __restrict__ out )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[( 64 + 5 ) * 64];
+  const int lane = threadIdx.x;
+  const vvhip_mctf_item it = items[blockIdx.x];
+  const int16_t* o = org + it.org_off;
+  const int16_t* b = buf + it.buf_off;
+  int e;
+  if( ( it.fx | it.fy ) == 0 ) e = waveErrorInt( o, os, b, bs, w, h, lane );
+  else if( tap4 )              e = waveErrorFrac<true>( o, os, b, bs, w, h, it.fx, it.fy, maxVal, sTmp, lane );
+  else                         e = waveErrorFrac<false>( o, os, b, bs, w, h, it.fx, it.fy, maxVal, sTmp, lane );
+  if( lane == 0 ) out[blockIdx.x] = e;
+}
+
+__global__ void __launch_bounds__( 64 )
+calcVarBatchKernel( const int16_t* __restrict__ org, int os, int w, int h, const int32_t* __restrict__ off, int64_t* __restrict__ out )
+{
+  const int lane = threadIdx.x;
+  const int16_t* o = org + off[blockIdx.x];
+  int s = 0;
+  for( int i = lane; i < w * h; i += 64 ) { const int y = i / w, x = i - y * w; s += o[( ptrdiff_t ) y * os + x]; }
+  s = waveSum( s );
+  int avg = s << 4;
+  avg = avg / ( w * h );
+  long long v = 0;
+  for( int i = lane; i < w * h; i += 64 ) { const int y = i / w, x = i - y * w; const int p = ( o[( ptrdiff_t ) y * os + x] << 4 ) - avg; v += p * p; }
+  int lo = ( int ) ( uint32_t ) v, hi = ( int ) ( v >> 32 );
+  // 64-bit wave sum through two 32-bit shuffles per step
+  for( int o2 = 32; o2 > 0; o2 >>= 1 )
+  {
+    const uint32_t olo = ( uint32_t ) __shfl_xor( lo, o2 ); const int ohi = __shfl_xor( hi, o2 );
+    const long long other = ( ( long long ) ohi << 32 ) | olo;
+    const long long mine = ( ( long long ) hi << 32 ) | ( uint32_t ) lo;
+    const long long t = mine + other;
+    lo = ( int ) ( uint32_t ) t; hi = ( int ) ( t >> 32 );
+  }
+  if( lane == 0 ) out[blockIdx.x] = ( ( long long ) hi << 32 ) | ( uint32_t ) lo;
+}
+
+__global__ void __launch_bounds__( 256 )
+subsampleKernel( const int16_t* __restrict__ src, int ss, int16_t* __restrict__ dst, int ds, int nw, int nh )
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if( x >= nw || y >= nh ) return;
+  const int16_t* a = src + ( ptrdiff_t ) ( 2 * y ) * ss + 2 * x;
+  dst[( ptrdiff_t ) y * ds + x] = ( int16_t ) ( ( a[0] + a[ss] + a[1] + a[ss + 1] + 2 ) >> 2 );   // MCTF.cpp:1091
+}
+
+// left/right replication for rows [0,h)
+__global__ void __launch_bounds__( 256 )
+extendLRKernel( int16_t* plane, int stride, int w, int h, int pad )
+{
+  const int y = blockIdx.x;
+  int16_t* r = plane + ( ptrdiff_t ) y * stride;
+  const int16_t l = r[0], rr = r[w - 1];
+  for( int x = threadIdx.x; x < pad; x += blockDim.x ) { r[-1 - x] = l; r[w + x] = rr; }
+}
+// top/bottom replication of whole padded rows
+__global__ void __launch_bounds__( 256 )
+extendTBKernel( int16_t* plane, int stride, int w, int h, int pad )
+{
+  const int y = blockIdx.x;   // 0..2*pad-1
+  const int16_t* src = y < pad ? plane - pad : plane + ( ptrdiff_t ) ( h - 1 ) * stride - pad;
+  int16_t* dst = y < pad ? plane - ( ptrdiff_t ) ( y + 1 ) * stride - pad : plane + ( ptrdiff_t ) ( h + ( y - pad ) ) * stride - pad;
+  for( int x = threadIdx.x; x < w + 2 * pad; x += blockDim.x ) dst[x] = src[x];
+}
+
+int ensureScratch( vvhip_ctx* ctx, size_t bytes )
+{
+  if( ctx->scratchBytes >= bytes ) return VVHIP_OK;
+  if( ctx->d_scratch ) { VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) ); VVHIP_CHECK_HIP( ctx, hipFree( ctx->d_scratch ) ); ctx->d_scratch = nullptr; ctx->scratchBytes = 0; }
+  hipError_t e = hipMalloc( &ctx->d_scratch, bytes );
+  if( e != hipSuccess ) return vvhip_fail( ctx, VVHIP_E_NOMEM, "scratch hipMalloc(%zu): %s", bytes, hipGetErrorString( e ) );
+  ctx->scratchBytes = bytes;
+  return VVHIP_OK;
+}
+
+int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, const int16_t* d_buf, int bsd, int width, int height, int bs,
+             const vvhip_mv* d_prev, int prevW, int prevH, int factor, int doubleRes, int pttrn, int lowRes, int bitDepth, int unit,
+             vvhip_mv* d_mvs, int mvsW, int mvsH, unsigned long long* d_granules, int* d_abort )
+{
+  // blocks processed: bx + 8 <= width, by + 8 <= height (MCTF.cpp:1174,1357)
+  const int nbx = width >= 8 ? ( width - 8 ) / bs + 1 : 0, nby = height >= 8 ? ( height - 8 ) / bs + 1 : 0;
+  if( nbx <= 0 || nby <= 0 ) return VVHIP_OK;
+  if( nbx > mvsW || nby > mvsH ) return vvhip_fail( ctx, VVHIP_E_ARG, "MCTF level: motion field %dx%d too small for %dx%d blocks", mvsW, mvsH, nbx, nby );
+  MeGeom g; g.org = d_org; g.orgStride = os; g.buf = d_buf; g.bufStride = bsd; g.width = width; g.height = height; g.bs = bs;
+  g.lowRes = lowRes; g.maxVal = ( 1 << bitDepth ) - 1;
+  hipLaunchKernelGGL( meSearchKernel, dim3( nbx * nby ), dim3( 64 ), 0, ctx->stream, g, nbx, d_prev, prevW, prevH, factor, doubleRes, pttrn, d_mvs, mvsW );
+  VVHIP_LAUNCH_CHECK( ctx );
+  VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_granules, 0, sizeof( unsigned long long ) * ( size_t ) nbx * nby, ctx->stream ) );
+  hipLaunchKernelGGL( meWavefrontKernel, dim3( nby ), dim3( 64 ), 0, ctx->stream, g, nbx, d_mvs, mvsW, d_granules, d_abort );
+  VVHIP_LAUNCH_CHECK( ctx );
+  if( doubleRes )
+  {
+    hipLaunchKernelGGL( meFinalizeKernel, dim3( ( nbx * nby + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, g, nbx, nby, bitDepth, unit, d_mvs, mvsW );
+    VVHIP_LAUNCH_CHECK( ctx );
+  }
+  return VVHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int vvhip_mctf_error_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_buf, int buf_stride, int width, int height,
+                            int tap4, int bit_depth, const vvhip_mctf_item* d_items, int n, int32_t* d_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( width < 8 || height < 8 || width > 64 || height > 64 || ( width & 7 ) || ( height & 7 ) || n < 0 || bit_depth < 8 || bit_depth > 12 )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_error_batch: block %dx%d must be a multiple of 8 in 8..64 (MCTF.cpp:1113)", width, height );
+  if( n == 0 ) return VVHIP_OK;
+  hipLaunchKernelGGL( mctfErrorBatchKernel, dim3( n ), dim3( 64 ), 0, ctx->stream, d_org, org_stride, d_buf, buf_stride, width, height, tap4,
+                      ( 1 << bit_depth ) - 1, d_items, d_out );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_mctf_calc_var_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, int width, int height, const int32_t* d_off, int n, int64_t* d_out_x256 )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( width < 1 || height < 1 || width > 128 || height > 128 || n < 0 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_calc_var_batch: bad size" );
+  if( n == 0 ) return VVHIP_OK;
+  hipLaunchKernelGGL( calcVarBatchKernel, dim3( n ), dim3( 64 ), 0, ctx->stream, d_org, org_stride, width, height, d_off, ( int64_t* ) d_out_x256 );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_extend_border( vvhip_ctx* ctx, int16_t* d_plane, int stride, int width, int height, int pad )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( width < 1 || height < 1 || pad < 0 || stride < width + 2 * pad ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_extend_border: bad geometry" );
+  if( pad == 0 ) return VVHIP_OK;
+  hipLaunchKernelGGL( extendLRKernel, dim3( height ), dim3( 128 ), 0, ctx->stream, d_plane, stride, width, height, pad );
+  hipLaunchKernelGGL( extendTBKernel, dim3( 2 * pad ), dim3( 256 ), 0, ctx->stream, d_plane, stride, width, height, pad );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_mctf_subsample( vvhip_ctx* ctx, const int16_t* d_src, int src_stride, int src_width, int src_height, int16_t* d_dst, int dst_stride, int pad )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  const int nw = src_width / 2, nh = src_height / 2;
+  if( nw < 1 || nh < 1 || dst_stride < nw + 2 * pad ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_subsample: bad geometry" );
+  hipLaunchKernelGGL( subsampleKernel, dim3( ( nw + 255 ) / 256, nh ), dim3( 256 ), 0, ctx->stream, d_src, src_stride, d_dst, dst_stride, nw, nh );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return vvhip_extend_border( ctx, d_dst, dst_stride, nw, nh, pad );
+}
+
+int vvhip_mctf_init_mvs( vvhip_ctx* ctx, vvhip_mv* d_mvs, int count )
+{
+  if( !ctx || count < 0 ) return VVHIP_E_ARG;
+  if( count == 0 ) return VVHIP_OK;
+  hipLaunchKernelGGL( initMvsKernel, dim3( ( count + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_mvs, count );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_mctf_me_level( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_buf, int buf_stride, int width, int height, int block_size,
+                         const vvhip_mv* d_prev, int prev_w, int prev_h, int factor, int double_res, int search_pattern, int low_res_filter,
+                         int bit_depth, int unit_size, vvhip_mv* d_mvs, int mvs_w, int mvs_h )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( ( block_size != 8 && block_size != 16 && block_size != 32 ) || width < 8 || height < 8 || bit_depth < 8 || bit_depth > 10 )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_me_level: block size %d (8/16/32), bit depth %d (8..10, MCTF.cpp:1313)", block_size, bit_depth );
+  const int nbx = ( width - 8 ) / block_size + 1, nby = ( height - 8 ) / block_size + 1;
+  const size_t need = sizeof( unsigned long long ) * ( size_t ) nbx * nby + 256;
+  int rc = ensureScratch( ctx, need );
+  if( rc ) return rc;
+  int* d_abort = reinterpret_cast<int*>( ctx->d_scratch );
+  unsigned long long* d_gr = reinterpret_cast<unsigned long long*>( reinterpret_cast<char*>( ctx->d_scratch ) + 256 );
+  VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_abort, 0, 256, ctx->stream ) );
+  rc = meLevel( ctx, d_org, org_stride, d_buf, buf_stride, width, height, block_size, d_prev, prev_w, prev_h, factor, double_res, search_pattern,
+                low_res_filter, bit_depth, unit_size, d_mvs, mvs_w, mvs_h, d_gr, d_abort );
+  if( rc ) return rc;
+  int aborted = 0;
+  VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( &aborted, d_abort, sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  if( aborted ) return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_mctf_me_level: wavefront hand-off timed out" );
+  return VVHIP_OK;
+}
+
+int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const int16_t* const* d_refs, int n_refs, int stride, int width, int height,
+                                  int pad, int bit_depth, int unit_size, int mctf_speed, int add_level, vvhip_mv* const* d_mvs_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( n_refs < 0 || width < 64 || height < 64 || pad < 128 || stride < width + 2 * pad || ( unit_size != 8 && unit_size != 16 ) || bit_depth < 8 || bit_depth > 10 || mctf_speed < 0 || mctf_speed > 4 )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_motion_estimation: bad arguments (%dx%d stride %d pad %d unit %d bitDepth %d speed %d)", width, height, stride, pad, unit_size, bit_depth, mctf_speed );
+  if( n_refs == 0 ) return VVHIP_OK;
+  const int lowRes = mctf_speed > 0;                                        // MCTF.cpp:598
+  const int pttrn  = mctf_speed > 0 ? ( mctf_speed >= 3 ? 2 : 1 ) : 0;      // MCTF.cpp:599
+  const int u = unit_size;
+  const int P = 128;                                                        // MCTF_PADDING of the internal pyramid planes
+  // ---- scratch layout: [abort 256 B][granules][pyramid planes cur L1..L3][per ref: planes L1..L3][per ref: mv fields L(-1)..L2]
+  int lw[4], lh[4], ls[4];
+  lw[0] = width; lh[0] = height; ls[0] = stride;
+  for( int l = 1; l < 4; l++ ) { lw[l] = lw[l - 1] / 2; lh[l] = lh[l - 1] / 2; ls[l] = ( lw[l] + 2 * P + 7 ) & ~7; }
+  size_t planeElems[4] = { 0, 0, 0, 0 };
+  for( int l = 1; l < 4; l++ ) planeElems[l] = ( size_t ) ls[l] * ( lh[l] + 2 * P );
+  const size_t pyrElems = planeElems[1] + planeElems[2] + planeElems[3];
+  const int fw[4] = { width / ( u * 16 ) + 1, width / ( u * 8 ) + 1, width / ( u * 4 ) + 1, width / ( u * 2 ) + 1 };     // MCTF.cpp:682-684,694
+  const int fh[4] = { height / ( u * 16 ) + 1, height / ( u * 8 ) + 1, height / ( u * 4 ) + 1, height / ( u * 2 ) + 1 };
+  size_t fieldElems = 0;
+  for( int k = 0; k < 4; k++ ) fieldElems += ( size_t ) fw[k] * fh[k];
+  const int outW = ( width + u - 1 ) / u, outH = ( height + u - 1 ) / u;      // MCTF.cpp:671-672
+  const size_t granElems = ( size_t ) outW * outH + 64;
+  size_t off = 256;
+  const size_t offGran = off;  off += granElems * sizeof( unsigned long long );
+  off = ( off + 255 ) & ~( size_t ) 255;
+  const size_t offPyr = off;   off += ( size_t ) ( 1 + n_refs ) * pyrElems * sizeof( int16_t );
+  off = ( off + 255 ) & ~( size_t ) 255;
+  const size_t offFld = off;   off += ( size_t ) n_refs * fieldElems * sizeof( vvhip_mv );
+  int rc = ensureScratch( ctx, off );
+  if( rc ) return rc;
+  char* base = reinterpret_cast<char*>( ctx->d_scratch );
+  int* d_abort = reinterpret_cast<int*>( base );
+  unsigned long long* d_gr = reinterpret_cast<unsigned long long*>( base + offGran );
+  VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_abort, 0, 256, ctx->stream ) );
+
+  auto planePtr = [&]( int pic, int l ) -> int16_t* {   // pic 0 = current, 1.. = references; l = 1..3; returns pointer to sample (0,0)
+    int16_t* p = reinterpret_cast<int16_t*>( base + offPyr ) + ( size_t ) pic * pyrElems;
+    for( int k = 1; k < l; k++ ) p += planeElems[k];
+    return p + ( size_t ) P * ls[l] + P;
+  };
+  const int levels = add_level ? 3 : 2;
+  for( int pic = 0; pic <= n_refs; pic++ )
+  {
+    const int16_t* src = pic == 0 ? d_cur : d_refs[pic - 1];
+    int srcStride = stride;
+    for( int l = 1; l <= levels; l++ )
+    {
+      rc = vvhip_mctf_subsample( ctx, src, srcStride, lw[l - 1], lh[l - 1], planePtr( pic, l ), ls[l], P );   // MCTF.cpp:689-690,696,779-784
+      if( rc ) return rc;
+      src = planePtr( pic, l ); srcStride = ls[l];
+    }
+  }
+  for( int r = 0; r < n_refs; r++ )
+  {
+    vvhip_mv* f[4];
+    f[0] = reinterpret_cast<vvhip_mv*>( base + offFld ) + ( size_t ) r * fieldElems;
+    for( int k = 1; k < 4; k++ ) f[k] = f[k - 1] + ( size_t ) fw[k - 1] * fh[k - 1];
+    rc = vvhip_mctf_init_mvs( ctx, f[0], ( int ) fieldElems );                      if( rc ) return rc;
+    rc = vvhip_mctf_init_mvs( ctx, d_mvs_out[r], outW * outH );                     if( rc ) return rc;
+    const vvhip_mv* prev = nullptr; int pw = 0, ph = 0;
+    if( add_level )                                                                   // MCTF.cpp:692-699
+    {
+      rc = meLevel( ctx, planePtr( 0, 3 ), ls[3], planePtr( r + 1, 3 ), ls[3], lw[3], lh[3], 2 * u, nullptr, 0, 0, 1, 0, pttrn, lowRes, bit_depth, u, f[0], fw[0], fh[0], d_gr, d_abort );
+      if( rc ) return rc;
+      prev = f[0]; pw = fw[0]; ph = fh[0];
+    }
+    rc = meLevel( ctx, planePtr( 0, 2 ), ls[2], planePtr( r + 1, 2 ), ls[2], lw[2], lh[2], 2 * u, prev, pw, ph, 2, 0, pttrn, lowRes, bit_depth, u, f[1], fw[1], fh[1], d_gr, d_abort );   // :698 / :702
+    if( rc ) return rc;
+    rc = meLevel( ctx, planePtr( 0, 1 ), ls[1], planePtr( r + 1, 1 ), ls[1], lw[1], lh[1], 2 * u, f[1], fw[1], fh[1], 2, 0, pttrn, lowRes, bit_depth, u, f[2], fw[2], fh[2], d_gr, d_abort );   // :704
+    if( rc ) return rc;
+    rc = meLevel( ctx, d_cur, stride, d_refs[r], stride, width, height, 2 * u, f[2], fw[2], fh[2], 2, 0, pttrn, lowRes, bit_depth, u, f[3], fw[3], fh[3], d_gr, d_abort );                       // :705
+    if( rc ) return rc;
+    rc = meLevel( ctx, d_cur, stride, d_refs[r], stride, width, height, u, f[3], fw[3], fh[3], 1, 1, pttrn, lowRes, bit_depth, u, d_mvs_out[r], outW, outH, d_gr, d_abort );                    // :707
+    if( rc ) return rc;
+  }
+  int aborted = 0;
+  VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( &aborted, d_abort, sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  if( aborted ) return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_mctf_motion_estimation: wavefront hand-off timed out" );
+  return VVHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,252 @@
+"""HotPath — Python host layer over the C ABI (include/vvenc_hip.h).
+
+Mirrors the reference's kernel-object interface for this path in batched form:
+  RdCost      -> dist_batch / sad_x5_batch / sad_surface     (CommonLib/RdCost.h:117-121)
+  TCoeffOps   -> fwd_transform / inv_transform               (CommonLib/TrQuant_EMT.h:63-91 via TrQuant::xT/xIT)
+  Quant       -> quant / dequant / need_rdoq / tu_rdo        (CommonLib/Quant.h:143-151)
+  MCTF        -> mctf_error_batch / mctf_me_level / mctf_motion_estimation (CommonLib/MCTF.h:160-170)
+
+All tensors are torch CUDA tensors (HBM resident); only raw pointers cross the ABI.  torch is
+plumbing here (device memory + streams), nothing is computed with torch ops.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .lib import VVHipError, load_library
+
+DF = {"SSE": 0, "SAD": 1, "HAD": 2, "HAD_fast": 3, "HAD_2SAD": 4}
+DCT2, DCT8, DST7 = 0, 1, 2
+
+MV_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("error", "<i4"), ("rmsme", "<i4"), ("overlap", "<f8")])
+STATS_DTYPE = np.dtype([("abs_sum", "<i4"), ("last_scan_pos", "<i4"), ("need_rdoq", "<i4"), ("pad", "<i4"), ("sse", "<u8")])
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+class Plane:
+    """A picture plane in HBM with `pad` samples of margin on every side (int16 samples).
+
+    `buf_ptr` addresses sample (0,0); stride is in samples, like the reference's CPelBuf
+    (CommonLib/Buffer.h:149-159).
+    """
+
+    def __init__(self, device, width, height, pad=0, stride=None):
+        self.width, self.height, self.pad = int(width), int(height), int(pad)
+        self.stride = int(stride) if stride else ((self.width + 2 * self.pad + 7) // 8) * 8
+        self.storage = torch.zeros((self.height + 2 * self.pad, self.stride), dtype=torch.int16, device=device)
+
+    @classmethod
+    def from_numpy(cls, device, arr, pad=0):
+        arr = np.ascontiguousarray(arr, np.int16)
+        p = cls(device, arr.shape[1], arr.shape[0], pad)
+        p.storage[p.pad:p.pad + p.height, p.pad:p.pad + p.width] = torch.from_numpy(arr).to(device)
+        return p
+
+    @property
+    def origin(self):
+        return self.pad * self.stride + self.pad      # element offset of sample (0,0) inside storage
+
+    @property
+    def buf_ptr(self):
+        return C.c_void_p(self.storage.data_ptr() + 2 * self.origin)
+
+    def offset(self, x, y):
+        return y * self.stride + x
+
+    def visible(self):
+        return self.storage[self.pad:self.pad + self.height, self.pad:self.pad + self.width]
+
+
+class HotPath:
+    def __init__(self, device=None):
+        self.L = load_library()
+        if not torch.cuda.is_available():
+            raise VVHipError("no GPU visible: vvenc_amd has no CPU fallback (HIP path only)")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        ctx = C.c_void_p()
+        rc = self.L.vvhip_create(C.byref(ctx), idx)
+        if rc != 0:
+            raise VVHipError("vvhip_create failed (%d): %s" % (rc, self.L.vvhip_last_error(None).decode()))
+        self.ctx = ctx
+        self.use_torch_stream()
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.vvhip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing ----
+    def _ck(self, rc):
+        if rc != 0:
+            raise VVHipError("vvenc_hip error %d: %s" % (rc, self.L.vvhip_last_error(self.ctx).decode()))
+
+    def use_torch_stream(self):
+        """run on torch's current stream so tensor ops and kernels are ordered"""
+        with torch.cuda.device(self.device):
+            self._ck(self.L.vvhip_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def use_own_stream(self):
+        self._ck(self.L.vvhip_set_stream(self.ctx, None))
+
+    def stream_handle(self):
+        return self.L.vvhip_get_stream(self.ctx)
+
+    def sync(self):
+        self._ck(self.L.vvhip_sync(self.ctx))
+
+    def to_device(self, arr, dtype=None):
+        a = np.ascontiguousarray(arr, dtype) if dtype is not None else np.ascontiguousarray(arr)
+        if a.dtype.fields is not None:
+            return torch.from_numpy(a.view(np.uint8).reshape(a.shape + (a.dtype.itemsize,))).to(self.device)
+        if a.dtype == np.uint64:
+            a = a.view(np.int64)
+        if a.dtype == np.uint32:
+            a = a.view(np.int32)
+        if a.dtype == np.uint16:
+            a = a.view(np.int16)
+        return torch.from_numpy(a).to(self.device)
+
+    def plane(self, arr, pad=0, extend=True):
+        p = Plane.from_numpy(self.device, arr, pad)
+        if pad and extend:
+            self.extend_border(p)
+        return p
+
+    @staticmethod
+    def items(pairs):
+        """numpy (n,2) int32 array of (org_off, cur_off)"""
+        return np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+
+    # ---- (A) distortion ----
+    def dist_batch(self, func, org, cur, d_items, n, w, h, sub_shift=0, bit_depth=10, out=None):
+        if out is None:
+            out = torch.empty(n, dtype=torch.int64, device=self.device)
+        self._ck(self.L.vvhip_dist_batch(self.ctx, DF[func] if isinstance(func, str) else func, org.buf_ptr, org.stride,
+                                         cur.buf_ptr, cur.stride, w, h, sub_shift, bit_depth, _ptr(d_items), n, _ptr(out)))
+        return out
+
+    def sad_x5_batch(self, org, cur, d_items, n, w, h, sub_shift=1, calc_centre=True, out=None):
+        if out is None:
+            out = torch.zeros(n * 5, dtype=torch.int64, device=self.device)
+        self._ck(self.L.vvhip_sad_x5_batch(self.ctx, org.buf_ptr, org.stride, cur.buf_ptr, cur.stride, w, h, sub_shift,
+                                           int(calc_centre), _ptr(d_items), n, _ptr(out)))
+        return out
+
+    def sad_surface(self, org, ref, d_org_off, d_ref_off, n_blocks, w, h, sub_shift, range_x, range_y, out=None):
+        if out is None:
+            out = torch.empty(n_blocks * (2 * range_x + 1) * (2 * range_y + 1), dtype=torch.int32, device=self.device)
+        self._ck(self.L.vvhip_sad_surface(self.ctx, org.buf_ptr, org.stride, ref.buf_ptr, ref.stride, w, h, sub_shift,
+                                          range_x, range_y, _ptr(d_org_off), _ptr(d_ref_off), n_blocks, _ptr(out)))
+        return out
+
+    # ---- (B) transform / quant ----
+    def fwd_transform(self, resi, d_off, n, w, h, tr_hor=DCT2, tr_ver=DCT2, bit_depth=10, out=None):
+        if out is None:
+            out = torch.empty(n * w * h, dtype=torch.int32, device=self.device)
+        self._ck(self.L.vvhip_fwd_transform_batch(self.ctx, resi.buf_ptr, resi.stride, _ptr(d_off), n, w, h, tr_hor, tr_ver, bit_depth, _ptr(out)))
+        return out
+
+    def inv_transform(self, d_coef, n, w, h, resi_out, d_off, tr_hor=DCT2, tr_ver=DCT2, bit_depth=10):
+        self._ck(self.L.vvhip_inv_transform_batch(self.ctx, _ptr(d_coef), n, w, h, tr_hor, tr_ver, bit_depth,
+                                                  resi_out.buf_ptr, resi_out.stride, _ptr(d_off)))
+        return resi_out
+
+    @staticmethod
+    def tu_qp(qps, irap=0, luma=1):
+        a = np.zeros((len(qps), 2), np.int16)
+        a[:, 0] = qps
+        a[:, 1] = (np.asarray(irap, np.int16) & 1) | ((np.asarray(luma, np.int16) & 1) << 1)
+        return a
+
+    def quant(self, d_coef, n, w, h, d_qp, bit_depth=10, thr_val=8, want_delta_u=True):
+        level = torch.empty(n * w * h, dtype=torch.int16, device=self.device)
+        du = torch.zeros(n * w * h, dtype=torch.int32, device=self.device) if want_delta_u else None
+        s = torch.empty(n, dtype=torch.int32, device=self.device)
+        last = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._ck(self.L.vvhip_quant_batch(self.ctx, _ptr(d_coef), n, w, h, bit_depth, _ptr(d_qp), thr_val, _ptr(level), _ptr(du), _ptr(s), _ptr(last)))
+        return level, du, s, last
+
+    def dequant(self, d_level, n, w, h, d_qp, bit_depth=10):
+        out = torch.empty(n * w * h, dtype=torch.int32, device=self.device)
+        self._ck(self.L.vvhip_dequant_batch(self.ctx, _ptr(d_level), n, w, h, bit_depth, _ptr(d_qp), _ptr(out)))
+        return out
+
+    def need_rdoq(self, d_coef, n, w, h, d_qp, bit_depth=10):
+        out = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._ck(self.L.vvhip_need_rdoq_batch(self.ctx, _ptr(d_coef), n, w, h, bit_depth, _ptr(d_qp), _ptr(out)))
+        return out
+
+    def tu_rdo(self, resi, d_off, n, w, h, d_qp, tr_hor=DCT2, tr_ver=DCT2, bit_depth=10, thr_val=8, level=None, rec=None, stats=None):
+        if level is None:
+            level = torch.empty(n * w * h, dtype=torch.int16, device=self.device)
+        if rec is None:
+            rec = torch.empty(n * w * h, dtype=torch.int16, device=self.device)
+        if stats is None:
+            stats = torch.empty((n, STATS_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        self._ck(self.L.vvhip_tu_rdo_batch(self.ctx, resi.buf_ptr, resi.stride, _ptr(d_off), n, w, h, tr_hor, tr_ver, bit_depth,
+                                           _ptr(d_qp), thr_val, _ptr(level), _ptr(rec), _ptr(stats)))
+        return level, rec, stats
+
+    # ---- (C) MCTF ----
+    def extend_border(self, plane):
+        self._ck(self.L.vvhip_extend_border(self.ctx, plane.buf_ptr, plane.stride, plane.width, plane.height, plane.pad))
+
+    def mctf_subsample(self, src, pad=128):
+        dst = Plane(self.device, src.width // 2, src.height // 2, pad)
+        self._ck(self.L.vvhip_mctf_subsample(self.ctx, src.buf_ptr, src.stride, src.width, src.height, dst.buf_ptr, dst.stride, pad))
+        return dst
+
+    def mctf_error_batch(self, org, buf, d_items, n, w, h, tap4, bit_depth=10):
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._ck(self.L.vvhip_mctf_error_batch(self.ctx, org.buf_ptr, org.stride, buf.buf_ptr, buf.stride, w, h, int(tap4), bit_depth, _ptr(d_items), n, _ptr(out)))
+        return out
+
+    def mctf_calc_var_batch(self, org, d_off, n, w, h):
+        out = torch.empty(n, dtype=torch.int64, device=self.device)
+        self._ck(self.L.vvhip_mctf_calc_var_batch(self.ctx, org.buf_ptr, org.stride, w, h, _ptr(d_off), n, _ptr(out)))
+        return out
+
+    def new_mv_field(self, w, h):
+        t = torch.empty((h * w, MV_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        self._ck(self.L.vvhip_mctf_init_mvs(self.ctx, _ptr(t), w * h))
+        return t
+
+    def mctf_me_level(self, org, buf, block_size, prev, prev_dims, factor, double_res, mvs, mvs_dims, search_pattern=2, low_res=1, bit_depth=10, unit=16):
+        pw, ph = prev_dims if prev is not None else (0, 0)
+        self._ck(self.L.vvhip_mctf_me_level(self.ctx, org.buf_ptr, org.stride, buf.buf_ptr, buf.stride, org.width, org.height, block_size,
+                                            _ptr(prev), pw, ph, factor, int(double_res), search_pattern, int(low_res), bit_depth, unit,
+                                            _ptr(mvs), mvs_dims[0], mvs_dims[1]))
+        return mvs
+
+    def mctf_motion_estimation(self, cur, refs, bit_depth=10, unit=16, speed=4, add_level=None, out=None):
+        """cur / refs: Plane objects with identical geometry and pad >= 128 (borders extended)."""
+        if add_level is None:
+            add_level = cur.width >= 1920            # MCTF.cpp:768
+        ow, oh = (cur.width + unit - 1) // unit, (cur.height + unit - 1) // unit
+        if out is None:
+            out = [torch.empty((ow * oh, MV_DTYPE.itemsize), dtype=torch.uint8, device=self.device) for _ in refs]
+        ref_ptrs = (C.c_void_p * len(refs))(*[r.buf_ptr.value for r in refs])
+        out_ptrs = (C.c_void_p * len(refs))(*[o.data_ptr() for o in out])
+        for r in refs:
+            assert (r.width, r.height, r.stride, r.pad) == (cur.width, cur.height, cur.stride, cur.pad)
+        self._ck(self.L.vvhip_mctf_motion_estimation(self.ctx, cur.buf_ptr, ref_ptrs, len(refs), cur.stride, cur.width, cur.height, cur.pad,
+                                                     bit_depth, unit, speed, int(bool(add_level)), out_ptrs))
+        return out, (ow, oh)
+
+    @staticmethod
+    def mv_to_numpy(t, dims):
+        return t.cpu().numpy().view(MV_DTYPE).reshape(dims[1], dims[0])

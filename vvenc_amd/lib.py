@@ -1,0 +1,68 @@
+"""ctypes binding of libvvenc_hip.so — one prototype per symbol declared in include/vvenc_hip.h."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvvenc_hip.so")
+
+
+class VVHipError(RuntimeError):
+    pass
+
+
+vp, i32, u64p, sz = C.c_void_p, C.c_int, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); the list doubles as the export check in tests/test_abi.py
+PROTOTYPES = {
+    "vvhip_create": (i32, [C.POINTER(vp), i32]),
+    "vvhip_destroy": (None, [vp]),
+    "vvhip_last_error": (C.c_char_p, [vp]),
+    "vvhip_set_stream": (i32, [vp, vp]),
+    "vvhip_get_stream": (vp, [vp]),
+    "vvhip_sync": (i32, [vp]),
+    "vvhip_malloc": (i32, [vp, C.POINTER(vp), sz]),
+    "vvhip_free": (i32, [vp, vp]),
+    "vvhip_upload": (i32, [vp, vp, vp, sz]),
+    "vvhip_download": (i32, [vp, vp, vp, sz]),
+    "vvhip_version": (C.c_char_p, []),
+    "vvhip_dist_batch": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "vvhip_sad_x5_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "vvhip_sad_surface": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
+    "vvhip_fwd_transform_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "vvhip_inv_transform_batch": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "vvhip_quant_batch": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp]),
+    "vvhip_dequant_batch": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    "vvhip_need_rdoq_batch": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    "vvhip_tu_rdo_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
+    "vvhip_get_tr_matrix_host": (i32, [i32, i32, vp]),
+    "vvhip_get_scan_order_host": (i32, [i32, i32, vp]),
+    "vvhip_mctf_error_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "vvhip_mctf_calc_var_batch": (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
+    "vvhip_mctf_subsample": (i32, [vp, vp, i32, i32, i32, vp, i32, i32]),
+    "vvhip_extend_border": (i32, [vp, vp, i32, i32, i32, i32]),
+    "vvhip_mctf_init_mvs": (i32, [vp, vp, i32]),
+    "vvhip_mctf_me_level": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32]),
+    "vvhip_mctf_motion_estimation": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libvvenc_hip.so (built in-tree by `make -C vvenc_amd/csrc` / __graft_entry__.build()).
+    Raises VVHipError when it is missing: there is no fallback implementation."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise VVHipError("%s not found - build it with `make -C vvenc_amd/csrc` (hipcc --offload-arch=gfx950); "
+                         "vvenc_amd has no CPU fallback" % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI/header drift
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
