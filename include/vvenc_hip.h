@@ -45,7 +45,8 @@ typedef struct vvhip_ctx vvhip_ctx;
 VVHIP_API int         vvhip_create( vvhip_ctx** out, int device );     /* own non-blocking stream + ROM tables in HBM */
 VVHIP_API void        vvhip_destroy( vvhip_ctx* ctx );
 VVHIP_API const char* vvhip_last_error( const vvhip_ctx* ctx );        /* ctx may be NULL: error of vvhip_create       */
-VVHIP_API int         vvhip_set_stream( vvhip_ctx* ctx, void* hip_stream ); /* borrow a caller stream (NULL = own)      */
+VVHIP_API int         vvhip_set_stream( vvhip_ctx* ctx, void* hip_stream ); /* borrow a caller's hipStream_t (NULL = the default stream) */
+VVHIP_API int         vvhip_use_own_stream( vvhip_ctx* ctx );          /* back to the context's private stream          */
 VVHIP_API void*       vvhip_get_stream( vvhip_ctx* ctx );
 VVHIP_API int         vvhip_sync( vvhip_ctx* ctx );                    /* hipStreamSynchronize                          */
 VVHIP_API int         vvhip_malloc( vvhip_ctx* ctx, void** d_ptr, size_t bytes );

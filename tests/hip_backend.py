@@ -167,7 +167,14 @@ class HipBackend:
         if add_level is None:
             add_level = org.shape[1] >= 1920
         out, dims = self.hp.mctf_motion_estimation(cur, [r], bit_depth, unit, speed, add_level)
-        return [None, None, None, None, HotPath.mv_to_numpy(out[0], dims)]
+        final = HotPath.mv_to_numpy(out[0], dims)
+        if org.shape[1] * org.shape[0] > 700 * 400:
+            return [None, None, None, None, final]
+        # small pictures: also expose every pyramid level (through the per-level entry points) and cross-check the two routes
+        lv = self.mctf_me_levels(org, ref, bit_depth, unit, speed, add_level)
+        for f in ("x", "y", "error", "rmsme", "overlap"):
+            assert np.array_equal(lv[4][f], final[f]), "per-level route != full-hierarchy route (%s)" % f
+        return lv
 
     def mctf_me_levels(self, org, ref, bit_depth=10, unit=16, speed=4, add_level=False):
         """level-by-level through vvhip_mctf_subsample + vvhip_mctf_me_level (checks every pyramid level)"""

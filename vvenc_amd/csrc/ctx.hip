@@ -174,7 +174,14 @@ const char* vvhip_last_error( const vvhip_ctx* ctx ) { return ctx ? ctx->lastErr
 int vvhip_set_stream( vvhip_ctx* ctx, void* hip_stream )
 {
   if( !ctx ) return VVHIP_E_ARG;
-  ctx->stream = hip_stream ? ( hipStream_t ) hip_stream : ctx->ownStream;
+  ctx->stream = ( hipStream_t ) hip_stream;
+  return VVHIP_OK;
+}
+
+int vvhip_use_own_stream( vvhip_ctx* ctx )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  ctx->stream = ctx->ownStream;
   return VVHIP_OK;
 }
 

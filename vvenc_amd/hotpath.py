@@ -100,7 +100,7 @@ class HotPath:
             self._ck(self.L.vvhip_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def use_own_stream(self):
-        self._ck(self.L.vvhip_set_stream(self.ctx, None))
+        self._ck(self.L.vvhip_use_own_stream(self.ctx))
 
     def stream_handle(self):
         return self.L.vvhip_get_stream(self.ctx)

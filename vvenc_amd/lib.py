@@ -18,6 +18,7 @@ PROTOTYPES = {
     "vvhip_destroy": (None, [vp]),
     "vvhip_last_error": (C.c_char_p, [vp]),
     "vvhip_set_stream": (i32, [vp, vp]),
+    "vvhip_use_own_stream": (i32, [vp]),
     "vvhip_get_stream": (vp, [vp]),
     "vvhip_sync": (i32, [vp]),
     "vvhip_malloc": (i32, [vp, C.POINTER(vp), sz]),
@@ -55,6 +56,12 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # torch ships its own libamdhip64; it must be the process' (single) HIP runtime BEFORE our library is loaded so that
+    # device pointers and streams are shared.  (A pure C/C++ host links the system runtime instead and never sees torch.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise VVHipError("%s not found - build it with `make -C vvenc_amd/csrc` (hipcc --offload-arch=gfx950); "
                          "vvenc_amd has no CPU fallback" % p)
