@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the MI355X hot path (BASELINE.json metric) + roofline + CPU baseline.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+A step = one pass of the hot path over one synthetic 1920x1080 10-bit frame (vvenc_amd/workload.py: 12 distortion launches
+= 11 SAD + 8 HAD_fast + 1 SSE candidates per 8/16/32/64 block, and 3 fused transform/quant/dequant/inverse launches over the
+8/16/32 TU tilings; ~1.66e8 sample pairs + 6.2e6 coefficients, the per-frame totals measured on the reference).
+All inputs are resident in HBM before the timed region.  With N GPUs every rank owns its own pictures (round-robin picture
+sharding, no data-path collective): value = N*K frames / max-over-ranks time.
+
+Extra JSON objects: "roofline" for the dominant kernel class (HIP events on the launch stream inside the timed region,
+algorithmic bytes from SURVEY §8d), "cpu_baseline" (the reference's own AVX2 table entries from oracle/_ref, or the C port,
+timed on the host cores over a bounded sample of the same work lists).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from vvenc_amd import sharding  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+class EventTimers:
+    """per-kernel-class HIP event pairs on the launch stream (torch's current stream == the context's stream)"""
+
+    def __init__(self):
+        self.pairs = {}
+        self._open = {}
+
+    def start(self, key):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._open[key] = e
+
+    def stop(self, key):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.pairs.setdefault(key, []).append((self._open.pop(key), e))
+
+    def summary(self):
+        out = {}
+        for k, lst in self.pairs.items():
+            ms = [a.elapsed_time(b) for a, b in lst]
+            out[k] = {"launches": len(ms), "total_ms": float(sum(ms)), "avg_ms": float(sum(ms) / len(ms))}
+        return out
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """Times the CPU path on the host cores over a bounded sample of the SAME work lists and scales to frames/sec.
+    kind "reference": the reference's own x86-SIMD table entries (oracle/_ref/libvvenc_ref.so, built from /root/reference);
+    kind "port": oracle/liboracle.so (scalar C restatement) when the reference build is not present."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    org = np.ascontiguousarray(wl.org.storage.cpu().numpy())
+    ref = np.ascontiguousarray(wl.ref.storage.cpu().numpy())
+    resi = np.ascontiguousarray(wl.resi.storage.cpu().numpy())
+    org_p = org.ctypes.data + 2 * wl.org.origin
+    ref_p = ref.ctypes.data + 2 * wl.ref.origin
+    frac = 0.02
+    use_ref = O.RefLib.available()
+    if use_ref:
+        R = O.RefLib(1)
+        L = R.L
+        L.vvref_dist_batch.restype = None
+        L.vvref_dist_batch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.vvref_tu_rdo_batch.restype = None
+        L.vvref_tu_rdo_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    else:
+        orc = O.Oracle()
+        L = orc.L
+        L.orc_dist_batch.restype = None
+        L.orc_dist_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    fidx = {"SSE": 0, "SAD": 1, "HAD": 2, "HAD_fast": 3}
+
+    def run_sample(fr):
+        jobs = []
+        for (func, S, ss, n, _, _, items) in wl.dist_jobs:
+            m = max(cores, int(n * fr))
+            jobs.append(("d", func, S, ss, items[:m].copy()))
+        if use_ref:
+            for (S, n, _, _, _, _, _, off, qps) in wl.tu_jobs:
+                m = max(cores, int(n * fr))
+                jobs.append(("t", S, off[:m].copy(), qps[:m].copy()))
+
+        def worker(t):
+            for j in jobs:
+                if j[0] == "d":
+                    _, func, S, ss, items = j
+                    sl = items[t::cores]
+                    sl = np.ascontiguousarray(sl)
+                    out = np.zeros(len(sl), np.uint64)
+                    if use_ref:
+                        L.vvref_dist_batch(1, R._df[func], org_p, wl.org.stride, ref_p, wl.ref.stride, S, S, wl.bit_depth, ss,
+                                           sl.ctypes.data, len(sl), out.ctypes.data)
+                    else:
+                        L.orc_dist_batch(fidx[func], org_p, wl.org.stride, ref_p, wl.ref.stride, S, S, ss, sl.ctypes.data, len(sl), out.ctypes.data)
+                else:
+                    _, S, off, qps = j
+                    o = np.ascontiguousarray(off[t::cores])
+                    qf = np.zeros((len(o), 2), np.int16)
+                    qf[:, 0] = qps[t::cores]
+                    qf[:, 1] = 2
+                    sse = np.zeros(len(o), np.uint64)
+                    L.vvref_tu_rdo_batch(1, resi.ctypes.data, wl.resi.stride, o.ctypes.data, len(o), S, S, wl.bit_depth, qf.ctypes.data, 8,
+                                         None, None, sse.ctypes.data)
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return time.perf_counter() - t0
+
+    run_sample(0.002)                       # page in / warm caches
+    dt = run_sample(frac)
+    passes = 1
+    if dt < budget_s / 4:                   # grow the sample towards the budget (about 10-30 s of CPU work summed over the cores)
+        target = frac * (budget_s / 2) / max(dt, 1e-3)
+        frac = min(1.0, target)
+        passes = max(1, min(64, int(target / frac)))
+        dt = sum(run_sample(frac) for _ in range(passes))
+    fps = frac * passes / dt
+    note = "" if use_ref else " (transform/quant not in the port sample: distortion only)"
+    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
+            "sample": "%d x %.1f%% of one frame's work lists (every kernel class, all block sizes), %d threads, %.1f s wall%s; "
+                      "reference x86-SIMD (AVX2) table entries called back-to-back" % (passes, 100 * frac, cores, dt, note)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="skip per-kernel HIP events inside the timed region")
+    ap.add_argument("--bcast-ref", action="store_true", help="also broadcast the reference picture from its owner every step (RCCL)")
+    ap.add_argument("--with-mctf", type=int, default=0, help="also run the MCTF hierarchical ME against this many references per step")
+    args = ap.parse_args()
+
+    rank, local_rank, world = sharding.init()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: vvenc_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    from vvenc_amd.hotpath import HotPath
+    from vvenc_amd.workload import FrameWorkload
+    hp = HotPath("cuda:%d" % local_rank)
+    wl = FrameWorkload(hp, args.width, args.height, seed=1080 + rank)
+    mctf_refs = []
+    if args.with_mctf:
+        cur128 = hp.plane(wl.cur_np, 128)
+        mctf_refs = [hp.plane(np.roll(wl.ref_np, (k, -k), (0, 1)), 128) for k in range(args.with_mctf)]
+
+    def step(timers=None):
+        if args.bcast_ref and world > 1:
+            sharding.broadcast_picture(wl.ref.storage, src_rank=0)
+        wl.run(timers)
+        if mctf_refs:
+            hp.mctf_motion_estimation(cur128, mctf_refs, wl.bit_depth, 16, 4, args.width >= 1920)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    timers = None if args.no_kernel_timers else EventTimers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timers)
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = sharding.max_over_ranks(dt, device="cuda")
+
+    if rank != 0:
+        return
+    frames = args.steps * world
+    fps = frames / dt
+    out = {
+        "metric": "frames/sec + bit-exact vs CPU, 1080p/4K 10-bit preset=faster at 1/2/4/8 GPU",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i16", "data": "synthetic",
+        "config": {"workload": "%dx%d 10-bit synthetic frame, preset=faster hot-path work lists: SAD/SATD(HAD_fast)/SSE candidate batches "
+                               "(8..64 blocks, 20 candidates/block) + fused DCT-2/quant/dequant/IDCT TU batches (8..32)" % (args.width, args.height),
+                   "sample_pairs_per_frame": int(wl.pairs), "coefficients_per_frame": int(wl.coefs), "launches_per_frame": len(wl.dist_jobs) + len(wl.tu_jobs),
+                   "sharding": "pictures round-robin over ranks, no data-path collective" + (", reference-picture RCCL broadcast per step" if args.bcast_ref else ""),
+                   "mctf_refs_per_step": args.with_mctf},
+    }
+    if timers is not None:
+        ks = timers.summary()
+        for k in ks:
+            ks[k]["alg_bytes_per_frame"] = int(wl.alg_bytes[k])
+            ks[k]["alg_GBps"] = wl.alg_bytes[k] * args.steps / (ks[k]["total_ms"] * 1e-3) / 1e9
+        dom = max(ks, key=lambda k: ks[k]["total_ms"])
+        launches_per_frame = ks[dom]["launches"] / args.steps
+        out["kernels"] = ks
+        out["roofline"] = {"bound": "hbm", "kernel": {"SAD": "sadSseKernel<8,SAD>", "SSE": "sadSseKernel<8,SSE>", "HAD_fast": "hadKernel<8,8,*>", "TU": "tuRdoKernel"}[dom],
+                           "achieved": ks[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ks[dom]["alg_GBps"] / HBM_PEAK_GBS,
+                           "traffic": None,
+                           "alg_bytes_per_launch": wl.alg_bytes[dom] / launches_per_frame, "avg_launch_ms": ks[dom]["avg_ms"],
+                           "note": "algorithmic bytes = 4*w*h per candidate (+8 B result), rows halved under subShift; fused TU = 6*w*h + 24 B (SURVEY 8d)"}
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        except Exception as e:   # the baseline is a report, never a reason to lose the measurement
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

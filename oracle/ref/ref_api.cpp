@@ -513,4 +513,71 @@ API int vvref_mctf_me( int simd, const int16_t* orgLuma, const int16_t* refLuma,
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batch loops for CPU-baseline timing (bench.py cpu_baseline kind "reference"): the reference's own table entries
+// called back-to-back from C++, like InterSearch::xTZSearchHelp does (EncoderLib/InterSearch.cpp:410-438).
+// ---------------------------------------------------------------------------------------------
+struct DistItem { int32_t org_off, cur_off; };
+
+API void vvref_dist_batch( int simd, int dfBase, const int16_t* org, int orgStride, const int16_t* cur, int curStride,
+                           int w, int h, int bitDepth, int subShift, const DistItem* items, int n, uint64_t* out )
+{
+  RdCost& rc = *rdPair().rc[simd ? 1 : 0];
+  DistParam dp;
+  dp.org = CPelBuf( org, orgStride, w, h );
+  dp.cur = CPelBuf( cur, curStride, w, h );
+  dp.bitDepth = bitDepth;
+  dp.subShift = subShift;
+  dp.compID   = COMP_Y;
+  int idx = dfBase;
+  if( dfBase != DF_HAD_2SAD && dfBase != DF_SAD_WITH_MASK ) idx += Log2( w );
+  FpDistFunc f = rc.m_afpDistortFunc[0][idx];
+  for( int i = 0; i < n; i++ )
+  {
+    dp.org.buf = org + items[i].org_off;
+    dp.cur.buf = cur + items[i].cur_off;
+    out[i] = f( dp );
+  }
+}
+
+// xT -> needRdoq -> QuantCore -> DeQuantCore -> xIT -> SSE for n TUs (the fused pipeline's CPU twin; thread-safe only per simd value
+// because g_tCoeffOps is a process-wide global: callers use ONE simd setting per process run)
+API void vvref_tu_rdo_batch( int simd, const int16_t* resi, int resiStride, const int32_t* off, int n, int w, int h, int bitDepth,
+                             const int16_t* qpFlags /* n x {qp, flags} */, int thrVal, int16_t* levelOut, int16_t* recOut, uint64_t* sseOut )
+{
+  const int area = w * h;
+  TCoeff* coef = ( TCoeff* ) xMalloc( TCoeff, area );
+  TCoeff* deq  = ( TCoeff* ) xMalloc( TCoeff, area );
+  TCoeff* du   = ( TCoeff* ) xMalloc( TCoeff, area );
+  Pel*    rec  = ( Pel* ) xMalloc( Pel, area );
+  TCoeffSig* lev = ( TCoeffSig* ) xMalloc( TCoeffSig, area );
+  const int l = Log2( w ) + Log2( h ), sqrt2 = l & 1;
+  RdCost& rc = *rdPair().rc[simd ? 1 : 0];
+  for( int i = 0; i < n; i++ )
+  {
+    const int qp = qpFlags[2 * i], flags = qpFlags[2 * i + 1];
+    const int trShift = 15 - bitDepth - ( l >> 1 ) - sqrt2;
+    const int qBits = QUANT_SHIFT + qp / 6 + trShift;
+    const int scale = g_quantScales[sqrt2][qp % 6];
+    vvref_xT( simd, resi + off[i], resiStride, coef, w, h, DCT2, DCT2, bitDepth );
+    volatile int need = quantObj().xNeedRdoq( coef, ( size_t ) w * std::min( h, 32 ), scale, int64_t( ( flags & 2 ) ? 171 : 256 ) << ( qBits - 9 ), qBits );
+    ( void ) need;
+    int32_t absSum; int last;
+    vvref_quant_core( coef, lev, du, w, h, scale, qBits, int64_t( ( flags & 1 ) ? 171 : 85 ) << ( qBits - 9 ), 0, thrVal, &absSum, &last );
+    const int rightShift = IQUANT_SHIFT - ( trShift + qp / 6 );
+    const int tgt = std::min( 16, 32 + rightShift - 7 );
+    quantObj().xDeQuant( w - 1, h - 1, g_invQuantScales[sqrt2][qp % 6], lev, w, deq, rightShift, ( 1 << ( tgt - 1 ) ) - 1, 32767 );
+    vvref_xIT( simd, deq, rec, w, w, h, DCT2, DCT2, bitDepth );
+    DistParam dp;
+    dp.org = CPelBuf( resi + off[i], resiStride, w, h );
+    dp.cur = CPelBuf( rec, w, w, h );
+    dp.bitDepth = bitDepth; dp.compID = COMP_Y;
+    const uint64_t sse = rc.m_afpDistortFunc[0][DF_SSE + Log2( w )]( dp );
+    if( sseOut ) sseOut[i] = sse;
+    if( levelOut ) memcpy( levelOut + ( size_t ) i * area, lev, sizeof( int16_t ) * area );
+    if( recOut ) memcpy( recOut + ( size_t ) i * area, rec, sizeof( int16_t ) * area );
+  }
+  xFree( coef ); xFree( deq ); xFree( du ); xFree( rec ); xFree( lev );
+}
+
 API const char* vvref_version() { return "vvenc reference 1.15.0-dev (built from /root/reference by oracle/ref/Makefile)"; }

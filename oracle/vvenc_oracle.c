@@ -190,6 +190,18 @@ uint64_t orc_fix_weighted_sse(const int16_t *org, int os, const int16_t *cur, in
     return sum;
 }
 
+/* Candidate-list batch (CPU-baseline timing helper; same loop shape as InterSearch::xTZSearchHelp,
+ * EncoderLib/InterSearch.cpp:410-438).  func: 0 SSE, 1 SAD, 2 HAD, 3 HAD_fast. */
+void orc_dist_batch(int func, const int16_t *org, int os, const int16_t *cur, int cs, int w, int h, int subShift,
+                    const int32_t *items /* n x {org_off, cur_off} */, int n, uint64_t *out)
+{
+    for (int i = 0; i < n; i++) {
+        const int16_t *o = org + items[2 * i], *c = cur + items[2 * i + 1];
+        out[i] = func == 0 ? orc_sse(o, os, c, cs, w, h) : func == 1 ? orc_sad(o, os, c, cs, w, h, subShift)
+               : orc_had(o, os, c, cs, w, h, func == 3);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Transform matrices                                             (RomTr.cpp:364-449, Rom.h:164-179)
  * The VVC integer kernels are fully determined by one coefficient per distinct angle:

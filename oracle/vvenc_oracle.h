@@ -23,6 +23,9 @@ uint64_t orc_sad_mask(const int16_t *org, int os, const int16_t *cur, int cs, co
                       int stepX, int maskStride2, int w, int h, int subShift);
 uint64_t orc_fix_weighted_sse(const int16_t *org, int os, const int16_t *cur, int cs, int w, int h, uint32_t weight);
 
+void orc_dist_batch(int func, const int16_t *org, int os, const int16_t *cur, int cs, int w, int h, int subShift,
+                    const int32_t *items, int n, uint64_t *out);
+
 int  orc_tr_matrix(int trType, int log2N, int16_t *out);
 int  orc_fwd_1d(int trType, int log2N, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2);
 int  orc_inv_1d(int trType, int log2N, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2,

@@ -1,0 +1,68 @@
+"""Multi-GPU sharding of the hot path: one process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in CPU tests).
+
+The path partitions at PICTURE granularity: MCTF-filtered pictures and GOP-parallel pictures are independent
+units, so pictures are dealt round-robin to ranks and no collective sits in the per-candidate data path ("scaling": "weak").
+The one real exchange step of a sharded encoder is picture-granular: the rank that owns a newly reconstructed reference (or
+the rank that read the original frames) broadcasts that picture to the ranks encoding dependants — `broadcast_picture`.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def frames_of_rank(n_frames, rank, world):
+    """round-robin picture ownership (picture p -> rank p % world)"""
+    return list(range(rank, n_frames, world))
+
+
+def owner_of(frame, world):
+    return frame % world
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def broadcast_picture(storage, src_rank):
+    """broadcast one picture plane (int16 tensor incl. margins) from its owner to every rank; RCCL over xGMI on GPUs.
+    1080p luma incl. margin = 5.2 MB, 4K = 18.6 MB: one message per picture, never per block."""
+    if dist.is_initialized():
+        dist.broadcast(storage, src=src_rank)
+    return storage

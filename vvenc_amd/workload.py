@@ -1,0 +1,116 @@
+"""Synthetic per-frame hot-path workload (BASELINE.json configs[1..2]).
+
+One "frame" = the work the reference pushes through its kernel tables for one inter picture at preset
+faster, sized from the survey's measurements (~54 x 1.5*W*H sample pairs through
+DistParam::distFunc and ~2.05 x 1.5*W*H transformed coefficients per B-frame):
+
+  distortion  for every aligned SxS luma block, S in {8,16,32,64} (CU sizes of preset faster):
+                11 SAD candidates  (integer ME with bIntegerET: start + predictors + two 4-point rings;
+                                    subShift=1 for S>8, RdCost.cpp:187-193)
+                 8 HAD_fast cands  (pruned half/quarter-pel refinement, InterSearch.cpp:760-972)
+                 1 SSE             (getDistPart after reconstruction)
+              -> 4 sizes x 20 = 80 x W*H sample pairs  (~ 54 x 1.5 = 81)
+  transform   the luma plane tiled once each with 8x8, 16x16, 32x32 TUs through the fused
+              xT -> needRdoq/quant -> dequant -> xIT -> SSE pipeline  -> 3 x W*H coefficients (~ 2.05 x 1.5)
+
+Candidate displacements are seeded pseudo-random integer vectors within +-16 samples of a global pan.
+All of it is generated on the host once and stays resident in HBM; nothing here computes distortion.
+"""
+import numpy as np
+
+from .hotpath import HotPath, Plane
+
+SIZES = (8, 16, 32, 64)
+TU_SIZES = (8, 16, 32)
+N_SAD, N_HAD, N_SSE = 11, 8, 1
+
+
+def synth_frame_pair(width, height, seed, bit_depth=10):
+    """SURVEY §8d generator family: textured base + pan + per-frame noise (current, reference)"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height + 64, 0:width + 64].astype(np.float32)
+    base = 512 + 180 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 120 * np.sin((xx + yy) / 11.0) + 60 * np.sin(xx / 3.1) * np.sin(yy / 4.3)
+    base += rng.normal(0, 12, base.shape).astype(np.float32)
+    maxv = (1 << bit_depth) - 1
+    scale = maxv / 1023.0
+    cur = np.clip(base[32:32 + height, 32:32 + width] * scale, 0, maxv)
+    ref = np.clip((base[31:31 + height, 29:29 + width] + rng.normal(0, 3, (height, width))) * scale, 0, maxv)   # pan (3,1)
+    return cur.astype(np.int16), ref.astype(np.int16)
+
+
+class FrameWorkload:
+    """Device-resident work lists for one frame geometry."""
+
+    def __init__(self, hp: HotPath, width=1920, height=1080, seed=1080, margin=80, bit_depth=10):
+        self.hp, self.width, self.height, self.bit_depth = hp, width, height, bit_depth
+        cur, ref = synth_frame_pair(width, height, seed, bit_depth)
+        self.cur_np, self.ref_np = cur, ref
+        self.org = hp.plane(cur, margin)              # original picture (padding like PelStorage margins)
+        self.ref = hp.plane(ref, margin)              # reconstructed reference picture, margin = CTU+16 (EncStage.h:311)
+        resi = (cur.astype(np.int32) - ref.astype(np.int32)).astype(np.int16)
+        self.resi = hp.plane(resi, 0)
+        rng = np.random.default_rng(seed + 1)
+        self.dist_jobs = []     # (func, S, sub_shift, n, d_items, d_out, host_items)
+        self.pairs = 0
+        self.alg_bytes = {}
+        for S in SIZES:
+            bx, by = np.meshgrid(np.arange(0, width - S + 1, S), np.arange(0, height - S + 1, S))
+            bx, by = bx.ravel(), by.ravel()
+            nb = bx.size
+            for func, ncand in (("SAD", N_SAD), ("HAD_fast", N_HAD), ("SSE", N_SSE)):
+                dx = rng.integers(-16, 17, size=(nb, ncand)) + 3
+                dy = rng.integers(-16, 17, size=(nb, ncand)) + 1
+                org_off = np.repeat((by * self.org.stride + bx)[:, None], ncand, 1)
+                cur_off = (by[:, None] + dy) * self.ref.stride + (bx[:, None] + dx)
+                items = np.stack([org_off.ravel(), cur_off.ravel()], 1).astype(np.int32)
+                n = items.shape[0]
+                ss = 1 if (func == "SAD" and S > 8) else 0
+                d_items = hp.to_device(items)
+                d_out = hp.to_device(np.zeros(n, np.int64))
+                self.dist_jobs.append((func, S, ss, n, d_items, d_out, items))
+                self.pairs += n * S * S
+                # algorithmic bytes: 4*w*h per candidate (org + cur, int16), rows halved under subShift, + 8 B result
+                self.alg_bytes[func] = self.alg_bytes.get(func, 0) + n * (4 * S * (S >> ss) + 8)
+        self.tu_jobs = []       # (S, n, d_off, d_qp, d_level, d_rec, d_stats)
+        self.coefs = 0
+        for S in TU_SIZES:
+            bx, by = np.meshgrid(np.arange(0, width - S + 1, S), np.arange(0, height - S + 1, S))
+            off = (by.ravel() * self.resi.stride + bx.ravel()).astype(np.int32)
+            n = off.size
+            qps = rng.integers(30, 48, size=n)      # QP 32 +- with qpBdOffset 12 -> base QP around 44; spread like QPA
+            d_qp = hp.to_device(HotPath.tu_qp(qps, 0, 1))
+            import torch
+            lvl = torch.empty(n * S * S, dtype=torch.int16, device=hp.device)
+            rec = torch.empty(n * S * S, dtype=torch.int16, device=hp.device)
+            st = torch.empty((n, 24), dtype=torch.uint8, device=hp.device)
+            self.tu_jobs.append((S, n, hp.to_device(off), d_qp, lvl, rec, st, off, qps))
+            self.coefs += n * S * S
+            # fused pipeline: read residual 2 B, write level 2 B + reconstructed residual 2 B per sample, 24 B stats per TU
+            self.alg_bytes["TU"] = self.alg_bytes.get("TU", 0) + n * (6 * S * S + 24)
+
+    # one pass of the hot path over the frame: 12 distortion launches + 3 fused TU launches
+    def run(self, timers=None):
+        hp = self.hp
+        for (func, S, ss, n, d_items, d_out, _) in self.dist_jobs:
+            if timers is not None:
+                timers.start(func)
+            hp.dist_batch(func, self.org, self.ref, d_items, n, S, S, ss, self.bit_depth, out=d_out)
+            if timers is not None:
+                timers.stop(func)
+        for (S, n, d_off, d_qp, lvl, rec, st, _, _) in self.tu_jobs:
+            if timers is not None:
+                timers.start("TU")
+            hp.tu_rdo(self.resi, d_off, n, S, S, d_qp, 0, 0, self.bit_depth, 8, lvl, rec, st)
+            if timers is not None:
+                timers.stop("TU")
+
+    def checksum(self):
+        """order-independent digest of every result of the last run (used by tests: equal across ranks / reruns)"""
+        import torch
+        acc = 0
+        for job in self.dist_jobs:
+            acc ^= int(torch.sum(job[5]).item()) & 0xFFFFFFFFFFFF
+        for job in self.tu_jobs:
+            acc ^= int(torch.sum(job[4].to(torch.int64)).item()) & 0xFFFFFFFFFFFF
+            acc ^= (int(torch.sum(job[5].to(torch.int64)).item()) << 1) & 0xFFFFFFFFFFFF
+        return acc
