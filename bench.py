@@ -34,27 +34,27 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH
 
 
 class EventTimers:
-    """per-kernel-class HIP event pairs on the launch stream (torch's current stream == the context's stream)"""
+    """HIP events on the launch stream (torch's current stream == the context's stream) bracketing each kernel CLASS once per
+    step (its launches are issued back to back).  Events are pre-allocated: nothing is created inside the timed region."""
 
-    def __init__(self):
-        self.pairs = {}
-        self._open = {}
+    def __init__(self, classes, steps, launches_per_class):
+        self.launches_per_class = launches_per_class
+        self.pool = {k: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] for k in classes}
+        self.idx = {k: 0 for k in classes}
 
     def start(self, key):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        self._open[key] = e
+        self.pool[key][self.idx[key]][0].record()
 
     def stop(self, key):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        self.pairs.setdefault(key, []).append((self._open.pop(key), e))
+        self.pool[key][self.idx[key]][1].record()
+        self.idx[key] += 1
 
     def summary(self):
         out = {}
-        for k, lst in self.pairs.items():
-            ms = [a.elapsed_time(b) for a, b in lst]
-            out[k] = {"launches": len(ms), "total_ms": float(sum(ms)), "avg_ms": float(sum(ms) / len(ms))}
+        for k, lst in self.pool.items():
+            ms = [a.elapsed_time(b) for a, b in lst[:self.idx[k]]]
+            nl = len(ms) * self.launches_per_class[k]
+            out[k] = {"launches": nl, "total_ms": float(sum(ms)), "avg_ms": float(sum(ms) / nl)}
         return out
 
 
@@ -179,7 +179,7 @@ def main():
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
-    timers = None if args.no_kernel_timers else EventTimers()
+    timers = None if args.no_kernel_timers else EventTimers(list(wl.class_launches), args.steps, wl.class_launches)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timers)

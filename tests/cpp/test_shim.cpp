@@ -1,0 +1,163 @@
+// test_shim.cpp — parity of the table-shaped C++ host mirror (vvenc_amd/csrc/host) against the CPU oracle, written the way the
+// reference's own unit test compares its scalar `ref` objects with its SIMD `opt` objects through the SAME table entries
+// (test/vvenc_unit_test/vvenc_unit_test.cpp: test_RdCost :2136-2179, test_TCoeffOps :1175-1210, test_MCTF :1592-1654):
+//   ref = oracle/vvenc_oracle.c (pinned to the reference),  opt = vvhip::RdCost / g_tCoeffOps / QuantOps / MCTFOps (HIP).
+// Needs a GPU.  Exit code 0 = all equal (tolerance 0).
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../oracle/vvenc_oracle.h"
+#include "../../vvenc_amd/csrc/host/vvenc_hip_shim.h"
+
+using namespace vvhip;
+
+static std::mt19937 rng( 12345 );
+static int failures = 0;
+#define CHECK_EQ( a, b, what ) do { if( !( ( a ) == ( b ) ) ) { printf( "MISMATCH %s: %lld vs %lld (line %d)\n", what, ( long long ) ( a ), ( long long ) ( b ), __LINE__ ); failures++; } } while( 0 )
+
+static std::vector<Pel> randPlane( int n, int bits ) { std::vector<Pel> v( n ); for( auto& x : v ) x = ( Pel ) ( rng() & ( ( 1u << bits ) - 1 ) ); return v; }
+
+static void test_RdCost()
+{
+  RdCost opt; opt.create( true );
+  const int W = 320, H = 200, M = 32, stride = W + 2 * M;
+  std::vector<Pel> orgP = randPlane( stride * ( H + 2 * M ), 10 ), curP = randPlane( stride * ( H + 2 * M ), 10 );
+  const Pel* org0 = orgP.data() + M * stride + M; const Pel* cur0 = curP.data() + M * stride + M;
+  Device& dev = Device::get();
+  dev.registerPicture( org0, stride, W, H, M );
+  dev.registerPicture( cur0, stride, W, H, M );
+  const int sizes[] = { 4, 8, 16, 32, 64 };
+  // (1) table entries one by one, pictures registered (offset path) and compact temporaries (staging path)
+  for( int w : sizes ) for( int h : sizes )
+  {
+    DistParam dp;
+    const int ox = rng() % ( W - w ), oy = rng() % ( H - h ), cx = ( int ) ( rng() % ( W - w + 2 * M ) ) - M, cy = ( int ) ( rng() % ( H - h + 2 * M ) ) - M;
+    CPelBuf o; o.buf = org0 + oy * stride + ox; o.stride = stride; o.width = w; o.height = h;
+    for( int had = 0; had <= 2; had++ ) for( int ssm = 0; ssm <= 1; ssm++ )
+    {
+      opt.setDistParam( dp, o, cur0 + cy * stride + cx, stride, 10, 0, ssm, had );
+      const Distortion got = dp.distFunc( dp );
+      const Distortion exp = had == 0 ? orc_sad( o.buf, stride, dp.cur.buf, stride, w, h, dp.subShift ) : orc_had( o.buf, stride, dp.cur.buf, stride, w, h, had == 2 );
+      CHECK_EQ( got, exp, had ? "HAD" : "SAD" );
+    }
+    CPelBuf c; c.buf = cur0 + cy * stride + cx; c.stride = stride; c.width = w; c.height = h;
+    CHECK_EQ( opt.getDistPart( o, c, 10, DF_SSE ), orc_sse( o.buf, stride, c.buf, stride, w, h ), "SSE" );
+    // compact temporaries (e.g. InterSearch::m_filteredBlock, stride != picture stride) -> staged
+    std::vector<Pel> a = randPlane( w * h, 10 ), b = randPlane( ( w + 1 ) * h, 10 );
+    CPelBuf ta; ta.buf = a.data(); ta.stride = w; ta.width = w; ta.height = h;
+    opt.setDistParam( dp, ta, b.data(), w + 1, 10, 0, 0, 2 );
+    CHECK_EQ( dp.distFunc( dp ), orc_had( a.data(), w, b.data(), w + 1, w, h, 1 ), "HAD_fast staged" );
+  }
+  // (2) DMVR X5
+  for( int w : { 8, 16 } ) for( int h : { 8, 16 } )
+  {
+    DistParam dp; dp.org.buf = org0 + 20 * stride + 40; dp.org.stride = stride; dp.org.width = w; dp.org.height = h;
+    dp.cur.buf = cur0 + 50 * stride + 90; dp.cur.stride = stride; dp.cur.width = w; dp.cur.height = h; dp.subShift = 1; dp.bitDepth = 10;
+    Distortion got[5] = { 7, 7, 7, 7, 7 }; uint64_t exp[5] = { 7, 7, 7, 7, 7 };
+    opt.m_afpDistortFuncX5[w == 8 ? 0 : 1]( dp, got, false );
+    orc_sad_x5( dp.org.buf, stride, dp.cur.buf, stride, w, h, 1, exp, 0 );
+    for( int k = 0; k < 5; k++ ) CHECK_EQ( got[k], exp[k], "SADX5" );
+  }
+  // (3) batching: all positions of a TZ-style star around a start vector are enqueued, ONE flush, results replayed in order
+  {
+    const int w = 16, h = 16, ox = 96, oy = 64;
+    CPelBuf o; o.buf = org0 + oy * stride + ox; o.stride = stride; o.width = w; o.height = h;
+    DistParam dp;
+    opt.setDistParam( dp, o, cur0, stride, 10, 0, 1, 0 );
+    std::vector<int> tickets; std::vector<std::pair<int, int>> mvs;
+    for( int dist = 1; dist <= 16; dist *= 2 ) for( int k = 0; k < 8; k++ )
+    {
+      static const int dxs[8] = { 0, 1, 1, 1, 0, -1, -1, -1 }, dys[8] = { -1, -1, 0, 1, 1, 1, 0, -1 };
+      mvs.push_back( { dxs[k] * dist, dys[k] * dist } );
+      dp.cur.buf = cur0 + ( oy + dys[k] * dist ) * stride + ox + dxs[k] * dist;
+      tickets.push_back( opt.enqueue( dp ) );
+    }
+    opt.flush();
+    for( size_t i = 0; i < tickets.size(); i++ )
+      CHECK_EQ( opt.result( tickets[i] ), orc_sad( o.buf, stride, cur0 + ( oy + mvs[i].second ) * stride + ox + mvs[i].first, stride, w, h, 1 ), "batched SAD" );
+  }
+}
+
+static void test_TCoeffOps()
+{
+  QuantOps q;
+  for( int w : { 4, 8, 16, 32, 64 } ) for( int h : { 4, 8, 16, 32, 64 } )
+  {
+    std::vector<Pel> resi( w * ( h + 3 ) );
+    for( auto& x : resi ) x = ( Pel ) ( ( int ) ( rng() % 2047 ) - 1023 );
+    std::vector<TCoeff> coef( w * h ), exp( w * h );
+    const int th = ( w <= 32 && ( rng() & 1 ) ) ? ORC_DST7 : ORC_DCT2, tv = ( h <= 32 && ( rng() & 1 ) ) ? ORC_DCT8 : ORC_DCT2;
+    g_tCoeffOps.fwdTransform2D( resi.data(), w, coef.data(), w, h, th, tv, 10 );
+    orc_xT( resi.data(), w, exp.data(), w, h, th, tv, 10 );
+    for( int i = 0; i < w * h; i++ ) CHECK_EQ( coef[i], exp[i], "fwdTransform2D" );
+    // quant -> dequant -> inverse
+    const int qp = 30 + rng() % 20; const bool irap = rng() & 1;
+    std::vector<TCoeffSig> lev( w * h ), elev( w * h ); std::vector<TCoeff> du( w * h ), edu( w * h ), deq( w * h ), edeq( w * h );
+    TCoeff absSum = 0, eAbs = 0; int last = -1, eLast = -1;
+    q.xQuant( w, h, coef.data(), lev.data(), absSum, last, du.data(), qp, irap, 10, 8 );
+    int qc, qbits; int64_t add; orc_quant_params( w, h, 10, qp, irap, &qc, &qbits, &add );
+    orc_quant_core( exp.data(), elev.data(), edu.data(), w, h, qc, qbits, add, 8, &eAbs, &eLast );
+    CHECK_EQ( absSum, eAbs, "xQuant absSum" ); CHECK_EQ( last, eLast, "xQuant lastScanPos" );
+    for( int i = 0; i < w * h; i++ ) CHECK_EQ( lev[i], elev[i], "xQuant level" );
+    int sc, rs, imax; orc_dequant_params( w, h, 10, qp, &sc, &rs, &imax );
+    q.xDeQuant( w - 1, h - 1, sc, lev.data(), w, deq.data(), rs, imax, 32767 );
+    orc_dequant_core( w - 1, h - 1, sc, elev.data(), w, edeq.data(), rs, imax, 32767 );
+    for( int i = 0; i < w * h; i++ ) CHECK_EQ( deq[i], edeq[i], "xDeQuant" );
+    int nqc, nqb, num; int64_t nadd; orc_need_rdoq_params( w, h, 10, qp, 1, &nqc, &nqb, &nadd, &num );
+    CHECK_EQ( ( int ) q.xNeedRdoq( coef.data(), num, nqc, nadd, nqb ), orc_need_rdoq( exp.data(), num, nqc, nadd, nqb ), "xNeedRdoq" );
+    std::vector<Pel> rec( w * h ), erec( w * h );
+    g_tCoeffOps.invTransform2D( deq.data(), rec.data(), w, w, h, th, tv, 10 );
+    orc_xIT( edeq.data(), erec.data(), w, w, h, th, tv, 10 );
+    for( int i = 0; i < w * h; i++ ) CHECK_EQ( rec[i], erec[i], "invTransform2D" );
+  }
+}
+
+static void test_MCTF()
+{
+  MCTFOps opt;
+  const int S = 96;
+  std::vector<Pel> org = randPlane( S * S, 10 ), buf = randPlane( S * S, 10 );
+  for( int w = 8; w <= 64; w += 8 ) for( int h = 8; h <= 64; h += 8 )
+  {
+    const Pel* o = org.data() + 8 * S + 8; const Pel* b = buf.data() + 10 * S + 12;
+    CHECK_EQ( opt.m_motionErrorLumaInt8( o, S, b, S, w, h, 0x7fffffff ), orc_mctf_err_int( o, S, b, S, w, h ), "motionErrorLumaInt8" );
+    const int fx = rng() % 16, fy = 1 + rng() % 15;
+    CHECK_EQ( opt.m_motionErrorLumaFrac8[1]( o, S, b, S, w, h, orc_mctf_filter4[fx], orc_mctf_filter4[fy], 10, 0x7fffffff ), orc_mctf_err_frac( 1, o, S, b, S, w, h, fx, fy, 10 ), "Frac8[1]" );
+    CHECK_EQ( opt.m_motionErrorLumaFrac8[0]( o, S, b, S, w, h, orc_mctf_filter6[fx], orc_mctf_filter6[fy], 10, 0x7fffffff ), orc_mctf_err_frac( 0, o, S, b, S, w, h, fx, fy, 10 ), "Frac8[0]" );
+  }
+  for( int w : { 8, 16, 32 } ) for( int h : { 8, 16, 32 } )
+    if( opt.m_calcVar( org.data() + 5, S, w, h ) != orc_mctf_calc_var( org.data() + 5, S, w, h ) ) { printf( "MISMATCH calcVar %dx%d\n", w, h ); failures++; }
+
+  // whole hierarchical motion estimation on registered pictures
+  const int W = 192, H = 128, P = 128, stride = W + 2 * P;
+  std::vector<Pel> a( stride * ( H + 2 * P ) ), r( stride * ( H + 2 * P ) ), ac( W * H ), rc( W * H );
+  for( int y = 0; y < H; y++ ) for( int x = 0; x < W; x++ )
+  {
+    ac[y * W + x] = ( Pel ) ( 512 + 300 * ( ( ( x / 9 ) + ( y / 7 ) ) & 1 ) + ( int ) ( rng() % 33 ) - 16 );
+    const int sx = x + 2 < W ? x + 2 : W - 1, sy = y + 1 < H ? y + 1 : H - 1;
+    rc[y * W + x] = 0; ( void ) sx; ( void ) sy;
+  }
+  for( int y = 0; y < H; y++ ) for( int x = 0; x < W; x++ ) { const int sx = x + 2 < W ? x + 2 : W - 1, sy = y + 1 < H ? y + 1 : H - 1; rc[y * W + x] = ( Pel ) ( ac[sy * W + sx] + ( int ) ( rng() % 9 ) - 4 ); }
+  for( int y = 0; y < H; y++ ) for( int x = 0; x < W; x++ ) { a[( y + P ) * stride + x + P] = ac[y * W + x]; r[( y + P ) * stride + x + P] = rc[y * W + x]; }
+  orc_extend_border( a.data() + P * stride + P, stride, W, H, P );
+  orc_extend_border( r.data() + P * stride + P, stride, W, H, P );     // MCTF::initPicture (host side, once per input picture, MCTF.cpp:608-612)
+  Device& dev = Device::get();
+  const int idA = dev.registerPicture( a.data() + P * stride + P, stride, W, H, P ), idR = dev.registerPicture( r.data() + P * stride + P, stride, W, H, P );
+  const int nb = ( ( W + 15 ) / 16 ) * ( ( H + 15 ) / 16 );
+  std::vector<vvhip_mv> got( nb ); std::vector<orc_mv_t> exp( nb );
+  vvhip_mv* outs[1] = { got.data() };
+  opt.motionEstimation( idA, &idR, 1, 10, 16, 4, false, outs );
+  orc_mv_t* lv[5] = { nullptr, nullptr, nullptr, nullptr, exp.data() }; int dims[10];
+  orc_mctf_me( ac.data(), rc.data(), W, H, 10, 16, 4, 0, lv, dims );
+  for( int i = 0; i < nb; i++ ) { CHECK_EQ( got[i].x, exp[i].x, "ME x" ); CHECK_EQ( got[i].y, exp[i].y, "ME y" ); CHECK_EQ( got[i].error, exp[i].error, "ME error" ); CHECK_EQ( got[i].rmsme, exp[i].rmsme, "ME rmsme" ); }
+}
+
+int main()
+{
+  try { test_RdCost(); test_TCoeffOps(); test_MCTF(); }
+  catch( const std::exception& e ) { printf( "EXCEPTION: %s\n", e.what() ); return 2; }
+  printf( failures ? "FAILED: %d mismatches\n" : "shim parity OK (RdCost, TCoeffOps/Quant, MCTF)\n", failures );
+  return failures ? 1 : 0;
+}

@@ -53,3 +53,36 @@ void vvhip_cg_size( int log2w, int log2h, int* log2CGw, int* log2CGh );     // h
 
 static inline int ilog2i( int v ) { int l = 0; while( ( 1 << ( l + 1 ) ) <= v ) l++; return l; }
 static inline bool isPow2( int v ) { return v > 0 && ( v & ( v - 1 ) ) == 0; }
+
+// ---- cross-lane helpers (device) ----------------------------------------------------------------------------------------
+// Sum over aligned groups of G (2..64, power of two) consecutive lanes using DPP only (no LDS crossbar traffic): quad_perm
+// xor-1 / xor-2, row_half_mirror (8 lanes), row_mirror (16 lanes), then v_readlane of the four 16-lane row totals.
+// The result is valid in every lane of the group.
+#ifdef __HIPCC__
+#define VVHIP_DPP( v, ctrl ) __builtin_amdgcn_mov_dpp( ( int ) ( v ), ( ctrl ), 0xf, 0xf, true )
+#define VVHIP_DPP_XOR1        0xB1    /* quad_perm [1,0,3,2] */
+#define VVHIP_DPP_XOR2        0x4E    /* quad_perm [2,3,0,1] */
+#define VVHIP_DPP_HALF_MIRROR 0x141   /* lane i <-> 7-i inside 8 lanes  */
+#define VVHIP_DPP_MIRROR      0x140   /* lane i <-> 15-i inside 16 lanes */
+
+__device__ __forceinline__ uint32_t vvhipGroupSum32( uint32_t v, int G, int lane )
+{
+  if( G >= 2 )  v += ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR1 );
+  if( G >= 4 )  v += ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR2 );
+  if( G >= 8 )  v += ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_HALF_MIRROR );
+  if( G >= 16 ) v += ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_MIRROR );
+  if( G >= 32 )
+  {
+    const uint32_t r0 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 0 ),  r1 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 16 );
+    const uint32_t r2 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 32 ), r3 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 48 );
+    v = G == 64 ? r0 + r1 + r2 + r3 : ( lane < 32 ? r0 + r1 : r2 + r3 );
+  }
+  return v;
+}
+// exact 64-bit group sum of per-lane values < 2^50 through two 32-bit limbs (24-bit split)
+__device__ __forceinline__ unsigned long long vvhipGroupSum64( unsigned long long e, int G, int lane )
+{
+  const uint32_t lo = vvhipGroupSum32( ( uint32_t ) ( e & 0xFFFFFFull ), G, lane ), hi = vvhipGroupSum32( ( uint32_t ) ( e >> 24 ), G, lane );
+  return ( ( unsigned long long ) hi << 24 ) + lo;
+}
+#endif

@@ -33,12 +33,8 @@ __device__ __forceinline__ uint32_t sadPair( uint32_t a, uint32_t b, uint32_t ac
   return __builtin_amdgcn_sad_u16( a ^ 0x80008000u, b ^ 0x80008000u, acc );
 }
 
-template<typename T>
-__device__ __forceinline__ T teamSum( T v, int lpc )
-{
-  for( int o = lpc >> 1; o > 0; o >>= 1 ) v += __shfl_xor( v, o );
-  return v;
-}
+__device__ __forceinline__ uint32_t teamSum( uint32_t v, int lpc ) { return vvhipGroupSum32( v, lpc, threadIdx.x & 63 ); }
+__device__ __forceinline__ uint64_t teamSum( uint64_t v, int lpc ) { return vvhipGroupSum64( v, lpc, threadIdx.x & 63 ); }
 
 enum { MODE_SAD = 0, MODE_SSE = 1, MODE_SAD_X5 = 2, MODE_SAD_MIN2 = 3 };
 
@@ -49,7 +45,7 @@ enum { MODE_SAD = 0, MODE_SSE = 1, MODE_SAD_X5 = 2, MODE_SAD_MIN2 = 3 };
 template<int CH, int MODE>
 __global__ void __launch_bounds__( 256 )
 sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
-              int lpr /* lanes (segments) per row = w / CH */, int rowsEff, int subShift, int log2Lpc,
+              int lpr /* lanes (segments) per row = w / CH */, int lprShift /* log2(lpr) or -1 */, int rowsEff, int subShift, int log2Lpc,
               const vvhip_dist_item* __restrict__ items, int n, int calcCentre, uint64_t* __restrict__ out )
 {
   const int gid  = blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +73,7 @@ sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __r
   uint64_t sse = 0;
   for( int c = lt; c < chunks; c += lpc )
   {
-    const int r = c / lpr, s = c - r * lpr;
+    const int r = lprShift >= 0 ? c >> lprShift : c / lpr, s = c - r * lpr;
     const int y = r * step;
     const int16_t* a = po + ( ptrdiff_t ) y * orgStride + s * CH;
     const int16_t* b = pc + ( ptrdiff_t ) y * curStride + s * CH;
@@ -205,20 +201,21 @@ hadKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __rest
       for( int i = 0; i < TW; i += 2 * len )
 #pragma unroll
         for( int j = i; j < i + len; j++ ) { const int a = d[j], b = d[j + len]; d[j] = a + b; d[j + len] = a - b; }
-    // vertical WHT (across the TH lanes of the tile team)
-#pragma unroll
-    for( int s = 1; s < TH; s <<= 1 )
-    {
-      const bool upper = ( row & s ) != 0;
-#pragma unroll
-      for( int i = 0; i < TW; i++ ) { const int o = __shfl_xor( d[i], s ); d[i] = upper ? o - d[i] : d[i] + o; }
-    }
+    // vertical WHT across the TH lanes of the tile team, DPP only.  Mirror pairings (i <-> 15-i, i <-> 7-i) followed by the
+    // quad xor-2 / xor-1 pairings form a valid Hadamard factorisation (directions 1111,0111,0010,0001 are independent over GF(2));
+    // coefficient order and sign differ from the reference's butterflies, the multiset of |coefficients| and the DC lane (0) do not.
+#define VSTAGE( CTRL, BIT ) { const bool upper = ( row & ( BIT ) ) != 0; _Pragma( "unroll" ) \
+      for( int i = 0; i < TW; i++ ) { const int o = VVHIP_DPP( d[i], CTRL ); d[i] = upper ? o - d[i] : d[i] + o; } }
+    if( TH >= 16 ) VSTAGE( VVHIP_DPP_MIRROR, 8 )
+    if( TH >= 8 )  VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
+    if( TH >= 4 )  VSTAGE( VVHIP_DPP_XOR2, 2 )
+    if( TH >= 2 )  VSTAGE( VVHIP_DPP_XOR1, 1 )
+#undef VSTAGE
     uint32_t s = 0;
 #pragma unroll
     for( int i = 0; i < TW; i++ ) s += ( uint32_t ) abs( d[i] );
     if( row == 0 ) { const uint32_t dc = ( uint32_t ) abs( d[0] ); s = s - dc + ( dc >> 2 ); }
-#pragma unroll
-    for( int o = 1; o < TH; o <<= 1 ) s += __shfl_xor( s, o );
+    s = vvhipGroupSum32( s, TH, threadIdx.x & 63 );
     if( row == 0 )
     {
       uint32_t v;
@@ -230,7 +227,7 @@ hadKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __rest
       sum += v;
     }
   }
-  sum = teamSum( sum, lpc );
+  sum = vvhipGroupSum64( sum, lpc, threadIdx.x & 63 );
   if( valid && lt == 0 ) out[cand] = sum;
 }
 
@@ -280,7 +277,7 @@ sadSurfaceKernel( const int16_t* __restrict__ org, int orgStride, const int16_t*
       const int c = sWin[( my + r * step ) * winStride + mx + x];
       acc += ( uint32_t ) abs( a - c );
     }
-    acc = teamSum( acc, 64 );
+    acc = vvhipGroupSum32( acc, 64, lane );
     if( lane == 0 ) out[( size_t ) b * nx * ny + m] = acc << subShift;
   }
 }
@@ -303,7 +300,7 @@ int launchSadSse( vvhip_ctx* ctx, const int16_t* d_org, int os, const int16_t* d
   const unsigned grid = ( unsigned ) ( ( threads + block - 1 ) / block );
   if( grid == 0 ) return VVHIP_OK;
 #define LAUNCH( C ) hipLaunchKernelGGL( ( sadSseKernel<C, MODE> ), dim3( grid ), dim3( block ), 0, ctx->stream, \
-                                        d_org, os, d_cur, cs, lpr, rowsEff, subShift, log2Lpc, items, n, calcCentre, out )
+                                        d_org, os, d_cur, cs, lpr, isPow2( lpr ) ? ilog2i( lpr ) : -1, rowsEff, subShift, log2Lpc, items, n, calcCentre, out )
   if( CH == 8 ) LAUNCH( 8 ); else if( CH == 4 ) LAUNCH( 4 ); else LAUNCH( 2 );
 #undef LAUNCH
   VVHIP_LAUNCH_CHECK( ctx );

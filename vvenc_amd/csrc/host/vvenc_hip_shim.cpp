@@ -1,0 +1,482 @@
+// vvenc_hip_shim.cpp — implementation of the table-shaped host mirror (see vvenc_hip_shim.h) on top of the C ABI only.
+#include "vvenc_hip_shim.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+namespace vvhip {
+
+static int ilog2( unsigned v ) { int l = 0; while( ( 1u << ( l + 1 ) ) <= v ) l++; return l; }
+
+// ------------------------------------------------------------------------------------------------ Device
+Device& Device::get()
+{
+  static Device d;
+  return d;
+}
+
+Device::Device()
+{
+  const char* e = getenv( "VVHIP_DEVICE" );
+  const int rc = vvhip_create( &m_ctx, e ? atoi( e ) : 0 );
+  if( rc != VVHIP_OK ) throw Exception( std::string( "vvhip::Device: " ) + vvhip_last_error( nullptr ) );
+}
+
+void Device::check( int rc, const char* what ) const
+{
+  if( rc != VVHIP_OK ) throw Exception( std::string( what ) + ": " + vvhip_last_error( m_ctx ) );
+}
+
+int Device::registerPicture( const Pel* origin, int stride, int width, int height, int margin )
+{
+  Mirror m;
+  m.origin = origin; m.stride = stride; m.width = width; m.height = height; m.margin = margin; m.live = true;
+  m.hostBase = origin - ( ptrdiff_t ) margin * stride - margin;
+  const size_t elems = ( size_t ) stride * ( height + 2 * margin );
+  m.hostEnd = m.hostBase + elems;
+  void* d = nullptr;
+  check( vvhip_malloc( m_ctx, &d, elems * sizeof( Pel ) ), "registerPicture" );
+  m.dBase = static_cast<int16_t*>( d );
+  m.dOrigin = m.dBase + ( ptrdiff_t ) margin * stride + margin;
+  m_mirrors.push_back( m );
+  updatePicture( ( int ) m_mirrors.size() - 1 );
+  return ( int ) m_mirrors.size() - 1;
+}
+
+void Device::updatePicture( int id )
+{
+  Mirror& m = m_mirrors.at( id );
+  check( vvhip_upload( m_ctx, m.dBase, m.hostBase, ( size_t ) ( m.hostEnd - m.hostBase ) * sizeof( Pel ) ), "updatePicture" );
+  check( vvhip_sync( m_ctx ), "updatePicture" );
+}
+
+void Device::unregisterPicture( int id )
+{
+  Mirror& m = m_mirrors.at( id );
+  if( m.live ) { vvhip_free( m_ctx, m.dBase ); m.live = false; m.hostBase = m.hostEnd = nullptr; }
+}
+
+const Device::Mirror* Device::find( const Pel* p ) const
+{
+  for( const Mirror& m : m_mirrors ) if( m.live && p >= m.hostBase && p < m.hostEnd ) return &m;
+  return nullptr;
+}
+
+int16_t* Device::staging( size_t bytes )
+{
+  if( bytes > m_stageBytes )
+  {
+    if( m_stage ) vvhip_free( m_ctx, m_stage );
+    void* d = nullptr;
+    check( vvhip_malloc( m_ctx, &d, bytes * 2 ), "staging" );
+    m_stage = static_cast<int16_t*>( d ); m_stageBytes = bytes * 2;
+  }
+  return m_stage;
+}
+
+void* Device::stagingAux( size_t bytes )
+{
+  if( bytes > m_auxBytes )
+  {
+    if( m_aux ) vvhip_free( m_ctx, m_aux );
+    check( vvhip_malloc( m_ctx, &m_aux, bytes * 2 ), "stagingAux" );
+    m_auxBytes = bytes * 2;
+  }
+  return m_aux;
+}
+
+// ------------------------------------------------------------------------------------------------ RdCost
+namespace {
+
+std::mutex g_lock;   // table entries are re-entrant in the reference (one RdCost per worker thread); the single staging area is serialised
+
+struct Resolved { const int16_t* dBase; int stride; int32_t off; };
+
+// host block -> device pointer: inside a registered picture (offset only) or staged copy (compact w x h)
+Resolved resolve( Device& dev, const CPelBuf& b, int w, int h, int extraLeft, int extraRight, int16_t*& stageCursor, std::vector<Pel>& hostTmp )
+{
+  if( const Device::Mirror* m = dev.find( b.buf ) )
+    if( m->stride == b.stride ) return { m->dOrigin, m->stride, ( int32_t ) ( b.buf - m->origin ) };
+  const int ww = w + extraLeft + extraRight;
+  hostTmp.resize( ( size_t ) ww * h );
+  for( int y = 0; y < h; y++ ) memcpy( &hostTmp[( size_t ) y * ww], b.buf - extraLeft + ( ptrdiff_t ) y * b.stride, sizeof( Pel ) * ww );
+  int16_t* d = stageCursor;
+  dev.check( vvhip_upload( dev.ctx(), d, hostTmp.data(), hostTmp.size() * sizeof( Pel ) ), "stage block" );
+  dev.check( vvhip_sync( dev.ctx() ), "stage block" );      // hostTmp is reused right away
+  stageCursor += ( hostTmp.size() + 7 ) & ~( size_t ) 7;
+  return { d, ww, extraLeft };
+}
+
+Distortion callOne( int func, const DistParam& dp )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int w = dp.org.width, h = dp.org.height;
+  int16_t* cursor = dev.staging( ( size_t ) 4 * ( w + 8 ) * h * sizeof( Pel ) + 64 );
+  std::vector<Pel> t0, t1;
+  const Resolved o = resolve( dev, dp.org, w, h, 0, 0, cursor, t0 );
+  const Resolved c = resolve( dev, dp.cur, w, h, 0, 0, cursor, t1 );
+  struct Io { vvhip_dist_item it; uint64_t out; } io;
+  io.it.org_off = o.off; io.it.cur_off = c.off; io.out = 0;
+  char* aux = static_cast<char*>( dev.stagingAux( sizeof( Io ) ) );
+  dev.check( vvhip_upload( dev.ctx(), aux, &io, sizeof( io ) ), "dist item" );
+  // org and cur may live in different allocations: the ABI takes one base per operand, offsets are relative to each
+  dev.check( vvhip_dist_batch( dev.ctx(), func, o.dBase, o.stride, c.dBase, c.stride, w, h, dp.subShift, dp.bitDepth,
+                               reinterpret_cast<vvhip_dist_item*>( aux ), 1, reinterpret_cast<uint64_t*>( aux + offsetof( Io, out ) ) ), "vvhip_dist_batch" );
+  dev.check( vvhip_download( dev.ctx(), &io.out, aux + offsetof( Io, out ), sizeof( uint64_t ) ), "dist result" );
+  return io.out;
+}
+
+template<int F> Distortion distEntry( const DistParam& dp )
+{
+  if( dp.applyWeight ) throw Exception( " no support" );      // RdCost.cpp:303-306
+  return callOne( F, dp );
+}
+
+template<int LOG2W> void sadX5Entry( const DistParam& dp, Distortion* cost, bool calcCentre )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int w = dp.org.width, h = dp.org.height;
+  int16_t* cursor = dev.staging( ( size_t ) 4 * ( w + 16 ) * h * sizeof( Pel ) + 64 );
+  std::vector<Pel> t0, t1;
+  const Resolved o = resolve( dev, dp.org, w, h, 0, 4, cursor, t0 );     // org + k, k = 0..4
+  const Resolved c = resolve( dev, dp.cur, w, h, 4, 0, cursor, t1 );     // cur - k
+  struct Io { vvhip_dist_item it; uint64_t out[5]; } io;
+  io.it.org_off = o.off; io.it.cur_off = c.off;
+  for( int k = 0; k < 5; k++ ) io.out[k] = cost[k];
+  char* aux = static_cast<char*>( dev.stagingAux( sizeof( Io ) ) );
+  dev.check( vvhip_upload( dev.ctx(), aux, &io, sizeof( io ) ), "x5 item" );
+  dev.check( vvhip_sad_x5_batch( dev.ctx(), o.dBase, o.stride, c.dBase, c.stride, w, h, dp.subShift, calcCentre ? 1 : 0,
+                                 reinterpret_cast<vvhip_dist_item*>( aux ), 1, reinterpret_cast<uint64_t*>( aux + offsetof( Io, out ) ) ), "vvhip_sad_x5_batch" );
+  dev.check( vvhip_download( dev.ctx(), io.out, aux + offsetof( Io, out ), sizeof( io.out ) ), "x5 result" );
+  for( int k = 0; k < 5; k++ ) if( k != 2 || calcCentre ) cost[k] = io.out[k];
+}
+
+int funcOfEntry( const RdCost& rc, FpDistFunc f )
+{
+  if( f == rc.m_afpDistortFunc[0][DF_SSE] ) return VVHIP_DF_SSE;
+  if( f == rc.m_afpDistortFunc[0][DF_SAD] ) return VVHIP_DF_SAD;
+  if( f == rc.m_afpDistortFunc[0][DF_HAD] ) return VVHIP_DF_HAD;
+  if( f == rc.m_afpDistortFunc[0][DF_HAD_fast] ) return VVHIP_DF_HAD_FAST;
+  if( f == rc.m_afpDistortFunc[0][DF_HAD_2SAD] ) return VVHIP_DF_HAD_2SAD;
+  return -1;
+}
+
+} // namespace
+
+void RdCost::create( bool /*enableOpt*/ )
+{
+  Device::get();     // throws here, not at the first distortion call, when there is no GPU
+  for( int row = 0; row < 2; row++ )
+  {
+    for( int i = 0; i < 8; i++ )
+    {
+      m_afpDistortFunc[row][DF_SSE + i]      = distEntry<VVHIP_DF_SSE>;
+      m_afpDistortFunc[row][DF_SAD + i]      = distEntry<VVHIP_DF_SAD>;
+      m_afpDistortFunc[row][DF_HAD + i]      = distEntry<VVHIP_DF_HAD>;
+      m_afpDistortFunc[row][DF_HAD_fast + i] = distEntry<VVHIP_DF_HAD_FAST>;
+    }
+    m_afpDistortFunc[row][DF_HAD_2SAD]      = distEntry<VVHIP_DF_HAD_2SAD>;
+    m_afpDistortFunc[row][DF_SAD_WITH_MASK] = nullptr;     // GEO is off at the BASELINE presets; left to the CPU row by the integrator
+  }
+  m_afpDistortFuncX5[0] = sadX5Entry<3>;
+  m_afpDistortFuncX5[1] = sadX5Entry<4>;
+}
+
+void RdCost::setDistParam( DistParam& dp, const CPelBuf& org, const Pel* refY, int refStride, int bitDepth, int compID, int subShiftMode, int useHadamard )
+{
+  dp.bitDepth = bitDepth; dp.compID = compID;
+  dp.org = org;
+  dp.cur.buf = refY; dp.cur.stride = refStride; dp.cur.width = org.width; dp.cur.height = org.height;
+  dp.maximumDistortionForEarlyExit = ~0ull;
+  const int base = ( bitDepth > 10 || dp.applyWeight ) ? 1 : 0;
+  if( !useHadamard ) dp.distFunc = m_afpDistortFunc[base][DF_SAD + ilog2( org.width )];
+  else               dp.distFunc = m_afpDistortFunc[base][( useHadamard == 1 ? DF_HAD : DF_HAD_fast ) + ilog2( org.width )];
+  dp.subShift = 0;
+  if( subShiftMode == 1 ) { if( org.height > 8 && org.width <= 128 ) dp.subShift = 1; }
+  else if( subShiftMode == 2 ) { if( org.height > 8 ) dp.subShift = 1; }
+}
+
+Distortion RdCost::getDistPart( const CPelBuf& org, const CPelBuf& cur, int bitDepth, DFunc eDFunc )
+{
+  DistParam dp; dp.org = org; dp.cur = cur; dp.bitDepth = bitDepth;
+  const int base = bitDepth > 10 ? 1 : 0;
+  return m_afpDistortFunc[base][eDFunc + ilog2( org.width )]( dp );
+}
+
+int RdCost::enqueue( const DistParam& dp )
+{
+  Device& dev = Device::get();
+  const Device::Mirror* mo = dev.find( dp.org.buf );
+  const Device::Mirror* mc = dev.find( dp.cur.buf );
+  const int func = funcOfEntry( *this, dp.distFunc );
+  if( !mo || !mc || mo->stride != dp.org.stride || mc->stride != dp.cur.stride || func < 0 )
+    throw Exception( "RdCost::enqueue: org/cur must point into pictures registered with vvhip::Device and distFunc must be a table entry" );
+  Pending p; p.func = func; p.w = dp.org.width; p.h = dp.org.height; p.subShift = dp.subShift; p.mo = mo; p.mc = mc;
+  p.orgOff = ( int32_t ) ( dp.org.buf - mo->origin ); p.curOff = ( int32_t ) ( dp.cur.buf - mc->origin );
+  m_pending.push_back( p );
+  m_results.push_back( 0 );
+  return ( int ) m_results.size() - 1;
+}
+
+void RdCost::flush()
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t first = m_results.size() - m_pending.size();
+  // group by (func, w, h, subShift, planes): one launch per group
+  std::map<std::tuple<int, int, int, int, const void*, const void*>, std::vector<int>> groups;
+  for( size_t i = 0; i < m_pending.size(); i++ )
+  {
+    const Pending& p = m_pending[i];
+    groups[std::make_tuple( p.func, p.w, p.h, p.subShift, ( const void* ) p.mo, ( const void* ) p.mc )].push_back( ( int ) i );
+  }
+  const size_t n = m_pending.size();
+  char* aux = static_cast<char*>( dev.stagingAux( n * ( sizeof( vvhip_dist_item ) + sizeof( uint64_t ) ) + 64 ) );
+  vvhip_dist_item* dItems = reinterpret_cast<vvhip_dist_item*>( aux );
+  uint64_t* dOut = reinterpret_cast<uint64_t*>( aux + ( ( n * sizeof( vvhip_dist_item ) + 15 ) & ~( size_t ) 15 ) );
+  std::vector<vvhip_dist_item> items( n );
+  std::vector<int> order; order.reserve( n );
+  for( auto& kv : groups ) for( int i : kv.second ) { items[order.size()].org_off = m_pending[i].orgOff; items[order.size()].cur_off = m_pending[i].curOff; order.push_back( i ); }
+  dev.check( vvhip_upload( dev.ctx(), dItems, items.data(), n * sizeof( vvhip_dist_item ) ), "flush items" );
+  size_t pos = 0;
+  for( auto& kv : groups )
+  {
+    const Pending& p = m_pending[kv.second[0]];
+    dev.check( vvhip_dist_batch( dev.ctx(), p.func, p.mo->dOrigin, p.mo->stride, p.mc->dOrigin, p.mc->stride, p.w, p.h, p.subShift, 10,
+                                 dItems + pos, ( int ) kv.second.size(), dOut + pos ), "flush launch" );
+    pos += kv.second.size();
+  }
+  std::vector<uint64_t> out( n );
+  dev.check( vvhip_download( dev.ctx(), out.data(), dOut, n * sizeof( uint64_t ) ), "flush results" );
+  for( size_t k = 0; k < n; k++ ) m_results[first + order[k]] = out[k];
+  m_pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ TCoeffOps
+namespace {
+
+void fwd2D( const Pel* resi, ptrdiff_t stride, TCoeff* coef, unsigned w, unsigned h, int trHor, int trVer, int bitDepth )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t area = ( size_t ) w * h;
+  std::vector<Pel> tmp( area );
+  for( unsigned y = 0; y < h; y++ ) memcpy( &tmp[( size_t ) y * w], resi + y * stride, sizeof( Pel ) * w );
+  int16_t* dResi = dev.staging( area * sizeof( Pel ) + 64 );
+  char* aux = static_cast<char*>( dev.stagingAux( area * sizeof( TCoeff ) + 64 ) );
+  int32_t zero = 0;
+  dev.check( vvhip_upload( dev.ctx(), dResi, tmp.data(), area * sizeof( Pel ) ), "fwd2D" );
+  dev.check( vvhip_upload( dev.ctx(), aux, &zero, sizeof( zero ) ), "fwd2D" );
+  dev.check( vvhip_fwd_transform_batch( dev.ctx(), dResi, ( int ) w, reinterpret_cast<int32_t*>( aux ), 1, ( int ) w, ( int ) h, trHor, trVer, bitDepth,
+                                        reinterpret_cast<int32_t*>( aux + 64 ) ), "vvhip_fwd_transform_batch" );
+  dev.check( vvhip_download( dev.ctx(), coef, aux + 64, area * sizeof( TCoeff ) ), "fwd2D" );
+}
+
+void inv2D( const TCoeff* coef, Pel* resi, ptrdiff_t stride, unsigned w, unsigned h, int trHor, int trVer, int bitDepth )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t area = ( size_t ) w * h;
+  int16_t* dResi = dev.staging( area * sizeof( Pel ) + 64 );
+  char* aux = static_cast<char*>( dev.stagingAux( area * sizeof( TCoeff ) + 64 ) );
+  int32_t zero = 0;
+  dev.check( vvhip_upload( dev.ctx(), aux, &zero, sizeof( zero ) ), "inv2D" );
+  dev.check( vvhip_upload( dev.ctx(), aux + 64, coef, area * sizeof( TCoeff ) ), "inv2D" );
+  dev.check( vvhip_inv_transform_batch( dev.ctx(), reinterpret_cast<int32_t*>( aux + 64 ), 1, ( int ) w, ( int ) h, trHor, trVer, bitDepth,
+                                        dResi, ( int ) w, reinterpret_cast<int32_t*>( aux ) ), "vvhip_inv_transform_batch" );
+  std::vector<Pel> tmp( area );
+  dev.check( vvhip_download( dev.ctx(), tmp.data(), dResi, area * sizeof( Pel ) ), "inv2D" );
+  for( unsigned y = 0; y < h; y++ ) memcpy( resi + y * stride, &tmp[( size_t ) y * w], sizeof( Pel ) * w );
+}
+
+} // namespace
+
+TCoeffOps::TCoeffOps()
+{
+  fwdTransform2D = fwd2D;
+  invTransform2D = inv2D;
+}
+TCoeffOps g_tCoeffOps;
+
+// ------------------------------------------------------------------------------------------------ MCTFOps
+namespace {
+
+// the reference hands the kernels ROWS of its static filter tables (MCTF.cpp:1142-1143,1157-1158); recover the phase from the taps
+const int16_t kF4[16][4] = { { 0, 64, 0, 0 }, { -2, 62, 4, 0 }, { -2, 58, 10, -2 }, { -4, 56, 14, -2 }, { -4, 54, 16, -2 }, { -6, 52, 20, -2 }, { -6, 46, 28, -4 }, { -4, 42, 30, -4 },
+                             { -4, 36, 36, -4 }, { -4, 30, 42, -4 }, { -4, 28, 46, -6 }, { -2, 20, 52, -6 }, { -2, 16, 54, -4 }, { -2, 14, 56, -4 }, { -2, 10, 58, -2 }, { 0, 4, 62, -2 } };
+const int16_t kF8[16][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 64, 4, -2, 0, 0 }, { 0, 1, -6, 62, 9, -3, 1, 0 }, { 0, 2, -8, 60, 14, -5, 1, 0 }, { 0, 2, -9, 57, 19, -7, 2, 0 },
+                             { 0, 3, -10, 53, 24, -8, 2, 0 }, { 0, 3, -11, 50, 29, -9, 2, 0 }, { 0, 3, -11, 44, 35, -10, 3, 0 }, { 0, 1, -7, 38, 38, -7, 1, 0 }, { 0, 3, -10, 35, 44, -11, 3, 0 },
+                             { 0, 2, -9, 29, 50, -11, 3, 0 }, { 0, 2, -8, 24, 53, -10, 3, 0 }, { 0, 2, -7, 19, 57, -9, 2, 0 }, { 0, 1, -5, 14, 60, -8, 2, 0 }, { 0, 1, -3, 9, 62, -6, 1, 0 }, { 0, 0, -2, 4, 64, -3, 1, 0 } };
+
+int phaseOf( const int16_t* f, bool tap4 )
+{
+  for( int p = 0; p < 16; p++ )
+    if( tap4 ? !memcmp( f, kF4[p], sizeof( kF4[p] ) ) : !memcmp( f, kF8[p], sizeof( kF8[p] ) ) ) return p;
+  throw Exception( "motionErrorLumaFrac: filter row is not one of MCTF::m_interpolationFilter{4,8}" );
+}
+
+int errorOne( const Pel* org, ptrdiff_t os, const Pel* buf, ptrdiff_t bs, int w, int h, int fx, int fy, bool tap4, int bitDepth )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int M = 4;      // halo for the 6-tap filter: 2 left/above, 3 right/below
+  int16_t* cursor = dev.staging( ( size_t ) 2 * ( w + 2 * M ) * ( h + 2 * M ) * sizeof( Pel ) + 128 );
+  struct Io { vvhip_mctf_item it; int32_t out; } io;
+  const int16_t* dOrg; const int16_t* dBuf; int sOrg, sBuf;
+  std::vector<Pel> t;
+  const Device::Mirror* mo = dev.find( org );
+  const Device::Mirror* mb = dev.find( buf );
+  if( mo && mo->stride == os ) { dOrg = mo->dOrigin; sOrg = mo->stride; io.it.org_off = ( int32_t ) ( org - mo->origin ); }
+  else
+  {
+    t.resize( ( size_t ) w * h );
+    for( int y = 0; y < h; y++ ) memcpy( &t[( size_t ) y * w], org + y * os, sizeof( Pel ) * w );
+    dev.check( vvhip_upload( dev.ctx(), cursor, t.data(), t.size() * sizeof( Pel ) ), "mctf org" );
+    dev.check( vvhip_sync( dev.ctx() ), "mctf org" );
+    dOrg = cursor; sOrg = w; io.it.org_off = 0; cursor += ( t.size() + 7 ) & ~( size_t ) 7;
+  }
+  if( mb && mb->stride == bs ) { dBuf = mb->dOrigin; sBuf = mb->stride; io.it.buf_off = ( int32_t ) ( buf - mb->origin ); }
+  else
+  {
+    const int ww = w + 2 * M, hh = h + 2 * M;
+    t.resize( ( size_t ) ww * hh );
+    for( int y = 0; y < hh; y++ ) memcpy( &t[( size_t ) y * ww], buf + ( y - M ) * bs - M, sizeof( Pel ) * ww );
+    dev.check( vvhip_upload( dev.ctx(), cursor, t.data(), t.size() * sizeof( Pel ) ), "mctf buf" );
+    dev.check( vvhip_sync( dev.ctx() ), "mctf buf" );
+    dBuf = cursor; sBuf = ww; io.it.buf_off = M * ww + M;
+  }
+  io.it.fx = ( int16_t ) fx; io.it.fy = ( int16_t ) fy; io.out = 0;
+  char* aux = static_cast<char*>( dev.stagingAux( sizeof( Io ) ) );
+  dev.check( vvhip_upload( dev.ctx(), aux, &io, sizeof( io ) ), "mctf item" );
+  dev.check( vvhip_mctf_error_batch( dev.ctx(), dOrg, sOrg, dBuf, sBuf, w, h, tap4 ? 1 : 0, bitDepth, reinterpret_cast<vvhip_mctf_item*>( aux ), 1,
+                                     reinterpret_cast<int32_t*>( aux + offsetof( Io, out ) ) ), "vvhip_mctf_error_batch" );
+  dev.check( vvhip_download( dev.ctx(), &io.out, aux + offsetof( Io, out ), sizeof( int32_t ) ), "mctf result" );
+  return io.out;
+}
+
+int errInt( const Pel* org, const ptrdiff_t os, const Pel* buf, const ptrdiff_t bs, const int w, const int h, const int /*besterror*/ )
+{
+  return errorOne( org, os, buf, bs, w, h, 0, 0, true, 10 );
+}
+int errFrac6( const Pel* org, const ptrdiff_t os, const Pel* buf, const ptrdiff_t bs, const int w, const int h, const int16_t* xf, const int16_t* yf, const int bd, const int )
+{
+  return errorOne( org, os, buf, bs, w, h, phaseOf( xf, false ), phaseOf( yf, false ), false, bd );
+}
+int errFrac4( const Pel* org, const ptrdiff_t os, const Pel* buf, const ptrdiff_t bs, const int w, const int h, const int16_t* xf, const int16_t* yf, const int bd, const int )
+{
+  return errorOne( org, os, buf, bs, w, h, phaseOf( xf, true ), phaseOf( yf, true ), true, bd );
+}
+
+double calcVarOne( const Pel* org, const ptrdiff_t os, const int w, const int h )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  std::vector<Pel> t( ( size_t ) w * h );
+  for( int y = 0; y < h; y++ ) memcpy( &t[( size_t ) y * w], org + y * os, sizeof( Pel ) * w );
+  int16_t* d = dev.staging( t.size() * sizeof( Pel ) + 64 );
+  struct Io { int32_t off; int32_t pad; int64_t out; } io = { 0, 0, 0 };
+  char* aux = static_cast<char*>( dev.stagingAux( sizeof( Io ) ) );
+  dev.check( vvhip_upload( dev.ctx(), d, t.data(), t.size() * sizeof( Pel ) ), "calcVar" );
+  dev.check( vvhip_upload( dev.ctx(), aux, &io, sizeof( io ) ), "calcVar" );
+  dev.check( vvhip_mctf_calc_var_batch( dev.ctx(), d, w, w, h, reinterpret_cast<int32_t*>( aux ), 1, reinterpret_cast<int64_t*>( aux + offsetof( Io, out ) ) ), "vvhip_mctf_calc_var_batch" );
+  dev.check( vvhip_download( dev.ctx(), &io.out, aux + offsetof( Io, out ), sizeof( int64_t ) ), "calcVar" );
+  return io.out / 256.0;      // MCTF.cpp:545
+}
+
+} // namespace
+
+MCTFOps::MCTFOps()
+{
+  Device::get();
+  m_motionErrorLumaInt8 = errInt;
+  m_motionErrorLumaFrac8[0] = errFrac6;
+  m_motionErrorLumaFrac8[1] = errFrac4;
+  m_calcVar = calcVarOne;
+}
+
+void MCTFOps::motionEstimation( int curPicId, const int* refPicIds, int nRefs, int bitDepth, int unitSize, int mctfSpeed, bool addLevel, vvhip_mv** out )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const Device::Mirror& cur = dev.mirror( curPicId );
+  std::vector<const int16_t*> refs( nRefs );
+  for( int r = 0; r < nRefs; r++ )
+  {
+    const Device::Mirror& m = dev.mirror( refPicIds[r] );
+    if( m.stride != cur.stride || m.width != cur.width || m.height != cur.height || m.margin != cur.margin )
+      throw Exception( "MCTFOps::motionEstimation: reference picture geometry differs from the current picture" );
+    refs[r] = m.dOrigin;
+  }
+  const size_t count = ( size_t ) ( ( cur.width + unitSize - 1 ) / unitSize ) * ( ( cur.height + unitSize - 1 ) / unitSize );
+  vvhip_mv* dOut = static_cast<vvhip_mv*>( dev.stagingAux( count * nRefs * sizeof( vvhip_mv ) + 64 ) );
+  std::vector<vvhip_mv*> outs( nRefs );
+  for( int r = 0; r < nRefs; r++ ) outs[r] = dOut + count * r;
+  dev.check( vvhip_mctf_motion_estimation( dev.ctx(), cur.dOrigin, refs.data(), nRefs, cur.stride, cur.width, cur.height, cur.margin, bitDepth, unitSize,
+                                           mctfSpeed, addLevel ? 1 : 0, outs.data() ), "vvhip_mctf_motion_estimation" );
+  for( int r = 0; r < nRefs; r++ ) dev.check( vvhip_download( dev.ctx(), out[r], outs[r], count * sizeof( vvhip_mv ) ), "motion vectors" );
+}
+
+// ------------------------------------------------------------------------------------------------ QuantOps
+namespace {
+
+void deQuantOne( const int maxX, const int maxY, const int scale, const TCoeffSig* const q, const size_t qStride, TCoeff* const coef, const int rightShift, const int inputMaximum, const TCoeff transformMaximum )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int w = maxX + 1, h = maxY + 1;
+  std::vector<TCoeffSig> t( ( size_t ) w * h );
+  for( int y = 0; y < h; y++ ) memcpy( &t[( size_t ) y * w], q + y * qStride, sizeof( TCoeffSig ) * w );
+  int16_t* dQ = dev.staging( t.size() * sizeof( TCoeffSig ) + 64 );
+  int32_t* dC = static_cast<int32_t*>( dev.stagingAux( t.size() * sizeof( TCoeff ) + 64 ) );
+  dev.check( vvhip_upload( dev.ctx(), dQ, t.data(), t.size() * sizeof( TCoeffSig ) ), "xDeQuant" );
+  dev.check( vvhip_dequant_core( dev.ctx(), maxX, maxY, scale, dQ, ( size_t ) w, dC, rightShift, inputMaximum, transformMaximum ), "vvhip_dequant_core" );
+  dev.check( vvhip_download( dev.ctx(), coef, dC, t.size() * sizeof( TCoeff ) ), "xDeQuant" );
+}
+
+bool needRdoqOne( const TCoeff* c, size_t num, int quantCoeff, int64_t offset, int shift )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  char* aux = static_cast<char*>( dev.stagingAux( 64 + num * sizeof( TCoeff ) ) );
+  uint8_t need = 0;
+  dev.check( vvhip_upload( dev.ctx(), aux + 64, c, num * sizeof( TCoeff ) ), "xNeedRdoq" );
+  dev.check( vvhip_need_rdoq_core( dev.ctx(), reinterpret_cast<int32_t*>( aux + 64 ), num, quantCoeff, offset, shift, reinterpret_cast<uint8_t*>( aux ) ), "vvhip_need_rdoq_core" );
+  dev.check( vvhip_download( dev.ctx(), &need, aux, 1 ), "xNeedRdoq" );
+  return need != 0;
+}
+
+void quantOne( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t area = ( size_t ) w * h;
+  struct Hdr { vvhip_tu_qp qp; int32_t absSum, last; } hdr; hdr.qp.qp = ( int16_t ) qp; hdr.qp.flags = ( int16_t ) ( ( isIRAP ? 1 : 0 ) | 2 ); hdr.absSum = 0; hdr.last = 0;
+  char* aux = static_cast<char*>( dev.stagingAux( 64 + area * ( sizeof( TCoeff ) * 2 + sizeof( TCoeffSig ) ) + 64 ) );
+  int32_t* dCoef = reinterpret_cast<int32_t*>( aux + 64 );
+  int32_t* dDu = dCoef + area;
+  int16_t* dLev = reinterpret_cast<int16_t*>( dDu + area );
+  dev.check( vvhip_upload( dev.ctx(), aux, &hdr, sizeof( hdr ) ), "quant" );
+  dev.check( vvhip_upload( dev.ctx(), dCoef, coef, area * sizeof( TCoeff ) ), "quant" );
+  dev.check( vvhip_quant_batch( dev.ctx(), dCoef, 1, ( int ) w, ( int ) h, bitDepth, reinterpret_cast<vvhip_tu_qp*>( aux ), thrVal, dLev, deltaU ? dDu : nullptr,
+                                reinterpret_cast<int32_t*>( aux + offsetof( Hdr, absSum ) ), reinterpret_cast<int32_t*>( aux + offsetof( Hdr, last ) ) ), "vvhip_quant_batch" );
+  dev.check( vvhip_download( dev.ctx(), q, dLev, area * sizeof( TCoeffSig ) ), "quant" );
+  if( deltaU ) dev.check( vvhip_download( dev.ctx(), deltaU, dDu, area * sizeof( TCoeff ) ), "quant" );
+  dev.check( vvhip_download( dev.ctx(), &hdr, aux, sizeof( hdr ) ), "quant" );
+  absSum = hdr.absSum; lastScanPos = hdr.last;
+}
+
+} // namespace
+
+QuantOps::QuantOps()
+{
+  xDeQuant = deQuantOne;
+  xNeedRdoq = needRdoqOne;
+  xQuant = quantOne;
+}
+
+} // namespace vvhip

@@ -1,0 +1,153 @@
+// vvenc_hip_shim.h — C++ host side ABOVE the C ABI (include/vvenc_hip.h): the table-shaped mirror of the reference's
+// kernel objects for this path.  Same names, argument meaning and calling convention as the reference so that the
+// encoder's control logic (EncCu / InterSearch / TrQuant / MCTF) can call through it unmodified:
+//
+//   vvhip::RdCost::m_afpDistortFunc[2][DF_TOTAL_FUNCTIONS], m_afpDistortFuncX5[2]   <- CommonLib/RdCost.h:117-121
+//   vvhip::DistParam / CPelBuf / FpDistFunc / FpDistFuncX5                          <- CommonLib/RdCost.h:74-111, Buffer.h:149-159
+//   vvhip::TCoeffOps (cpyResi/cpyCoeff/fastInvCore/fastFwdCore_2D/roundClip)        <- CommonLib/TrQuant_EMT.h:63-91
+//   vvhip::QuantOps (xQuant/xDeQuant/xNeedRdoq core signatures)                     <- CommonLib/Quant.h:143-151
+//   vvhip::MCTFOps  (m_motionErrorLumaInt8, m_motionErrorLumaFrac8[2], m_calcVar)   <- CommonLib/MCTF.h:160-170
+//
+// Two ways to call:
+//   (1) table entry, one candidate per call — the reference's synchronous signature.  Pointers are HOST pointers; if they
+//       fall inside a picture registered with registerPicture() the call only ships two offsets, otherwise the two blocks
+//       are staged.  Correct everywhere, but one launch + one round trip per call: use it for plumbing, not for speed.
+//   (2) batching: enqueue( DistParam ) -> ticket, flush(), result( ticket ) — what the thin shim in INTEGRATION.md uses
+//       inside xTZSearch / xPatternRefinement (all positions of a ring / raster / refinement are known before the first
+//       cost is needed) and for whole MCTF levels.
+// Errors: like the reference there are no return codes; any failure throws vvhip::Exception (THROW, TypeDef.h:635-636).
+// There is no CPU fallback: without a GPU create() throws.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/vvenc_hip.h"
+
+namespace vvhip {
+
+using Pel        = int16_t;
+using TCoeff     = int32_t;
+using TCoeffSig  = int16_t;
+using TMatrixCoeff = int16_t;
+using Distortion = uint64_t;
+
+struct Exception : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// DFunc, CommonLib/TypeDef.h:339-382 (same order: index = base + log2(width))
+enum DFunc
+{
+  DF_SSE = 0, DF_SSE2, DF_SSE4, DF_SSE8, DF_SSE16, DF_SSE32, DF_SSE64, DF_SSE128,
+  DF_SAD = 8, DF_SAD2, DF_SAD4, DF_SAD8, DF_SAD16, DF_SAD32, DF_SAD64, DF_SAD128,
+  DF_HAD = 16, DF_HAD2, DF_HAD4, DF_HAD8, DF_HAD16, DF_HAD32, DF_HAD64, DF_HAD128,
+  DF_HAD_fast = 24, DF_HAD2_fast, DF_HAD4_fast, DF_HAD8_fast, DF_HAD16_fast, DF_HAD32_fast, DF_HAD64_fast, DF_HAD128_fast,
+  DF_HAD_2SAD = 32, DF_SAD_WITH_MASK = 33, DF_TOTAL_FUNCTIONS = 34
+};
+
+struct CPelBuf { const Pel* buf = nullptr; int stride = 0; unsigned width = 0, height = 0; };
+
+class DistParam;
+typedef Distortion ( *FpDistFunc )( const DistParam& );
+typedef void ( *FpDistFuncX5 )( const DistParam&, Distortion*, bool );
+
+class DistParam
+{
+public:
+  CPelBuf      org, cur;
+  FpDistFunc   distFunc  = nullptr;
+  FpDistFuncX5 dmvrSadX5 = nullptr;
+  int          bitDepth  = 0;
+  int          subShift  = 0;
+  int          compID    = 0;
+  bool         applyWeight = false;
+  Distortion   maximumDistortionForEarlyExit = ~0ull;   // honoured as in the SIMD rows: ignored (full sums are returned)
+};
+
+// One process-wide device context + registry of host pictures mirrored in HBM.
+class Device
+{
+public:
+  static Device& get();                      // creates the context on first use (device 0 or $VVHIP_DEVICE); throws without GPU
+  vvhip_ctx* ctx() const { return m_ctx; }
+  // Mirror a host plane (sample (0,0) at `origin`, `margin` samples around a w x h picture, line pitch `stride`) in HBM.
+  // Re-register (or call updatePicture) after the host changed it (e.g. a reference picture was reconstructed).
+  int  registerPicture( const Pel* origin, int stride, int width, int height, int margin );
+  void updatePicture( int id );
+  void unregisterPicture( int id );
+  struct Mirror { const Pel* hostBase; const Pel* hostEnd; const Pel* origin; int stride, width, height, margin; int16_t* dBase; int16_t* dOrigin; bool live; };
+  const Mirror* find( const Pel* p ) const;  // which registered picture contains host pointer p (nullptr: none)
+  const Mirror& mirror( int id ) const { return m_mirrors.at( id ); }
+  void check( int rc, const char* what ) const;
+  int16_t* staging( size_t bytes );          // grow-only device scratch for unregistered (compact temp) buffers
+  void*    stagingAux( size_t bytes );
+private:
+  Device();
+  vvhip_ctx* m_ctx = nullptr;
+  std::vector<Mirror> m_mirrors;
+  int16_t* m_stage = nullptr; size_t m_stageBytes = 0;
+  void* m_aux = nullptr; size_t m_auxBytes = 0;
+};
+
+class RdCost
+{
+public:
+  FpDistFunc   m_afpDistortFunc[2][DF_TOTAL_FUNCTIONS];
+  FpDistFuncX5 m_afpDistortFuncX5[2];
+  void create( bool enableOpt = true );      // both rows point at the HIP entries (bit-exact for every bit depth)
+
+  // RdCost::setDistParam, CommonLib/RdCost.cpp:158-206 (subShiftMode / useHadamard semantics identical)
+  void setDistParam( DistParam& dp, const CPelBuf& org, const Pel* refY, int refStride, int bitDepth, int compID, int subShiftMode = 0, int useHadamard = 0 );
+  // RdCost::getDistPart, CommonLib/RdCost.cpp:267-291 (luma; chroma weighting stays with the caller)
+  Distortion getDistPart( const CPelBuf& org, const CPelBuf& cur, int bitDepth, DFunc eDFunc );
+
+  // ---- batching (2) ----
+  int        enqueue( const DistParam& dp );         // dp.distFunc must be one of this object's table entries
+  void       flush();                                // one launch per (function, block size, subShift, plane pair) group
+  Distortion result( int ticket ) const { return m_results[ticket]; }
+  void       clear() { m_pending.clear(); m_results.clear(); }
+private:
+  struct Pending { int func, w, h, subShift; const Device::Mirror* mo; const Device::Mirror* mc; int32_t orgOff, curOff; };
+  std::vector<Pending>    m_pending;
+  std::vector<Distortion> m_results;
+};
+
+// TCoeffOps, CommonLib/TrQuant_EMT.h:63-91 — same member names and signatures, host pointers, one call = one (synchronous) launch.
+struct TCoeffOps
+{
+  TCoeffOps();
+  // cpyCoeff4/8 and cpyResi4/8 (Pel <-> TCoeff strided copies) have no device twin on purpose: they are folded into the load /
+  // store of the two entries below, which therefore take and return Pel blocks directly.
+  // 2-D drivers with the signature of TrQuant::xT / xIT's inner work (TrQuant.cpp:481-655): what the shim calls instead of
+  // two fastFwdCore passes, because the two 1-D passes are fused on the device.
+  void ( *fwdTransform2D )( const Pel* resi, ptrdiff_t stride, TCoeff* coef, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
+  void ( *invTransform2D )( const TCoeff* coef, Pel* resi, ptrdiff_t stride, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
+};
+extern TCoeffOps g_tCoeffOps;
+
+// Quant::xQuant/xDeQuant/xNeedRdoq (CommonLib/Quant.h:143-151) with the TransformUnit reduced to what QuantCore reads (width, height).
+struct QuantOps
+{
+  QuantOps();
+  void ( *xDeQuant )( const int maxX, const int maxY, const int scale, const TCoeffSig* const piQCoef, const size_t piQCfStride, TCoeff* const piCoef,
+                      const int rightShift, const int inputMaximum, const TCoeff transformMaximum );
+  bool ( *xNeedRdoq )( const TCoeff* pCoeff, size_t numCoeff, int quantCoeff, int64_t offset, int shift );
+  void ( *xQuant )( unsigned width, unsigned height, const TCoeff* piCoef, TCoeffSig* piQCoef, TCoeff& uiAbsSum, int& lastScanPos, TCoeff* deltaU,
+                    const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal );
+};
+
+// MCTF table, CommonLib/MCTF.h:160-170
+struct MCTFOps
+{
+  MCTFOps();
+  int ( *m_motionErrorLumaInt8 )( const Pel* org, const ptrdiff_t origStride, const Pel* buf, const ptrdiff_t buffStride, const int w, const int h, const int besterror );
+  int ( *m_motionErrorLumaFrac8[2] )( const Pel* org, const ptrdiff_t origStride, const Pel* buf, const ptrdiff_t buffStride, const int w, const int h,
+                                      const int16_t* xFilter, const int16_t* yFilter, const int bitDepth, const int besterror );
+  double ( *m_calcVar )( const Pel* org, const ptrdiff_t origStride, const int w, const int h );
+  // whole-picture replacement of MCTF::motionEstimationMCTF (MCTF.cpp:666-707) for pictures registered with Device:
+  // out[r] receives ceil(w/unit) x ceil(h/unit) vvhip_mv (== MotionVector, MCTF.h:72-82) for reference r
+  void motionEstimation( int curPicId, const int* refPicIds, int nRefs, int bitDepth, int unitSize, int mctfSpeed, bool addLevel, vvhip_mv** out );
+};
+
+} // namespace vvhip

@@ -1,23 +1,44 @@
 // trquant.hip — forward / inverse DCT-2, DST-7, DCT-8 and scalar (de)quantisation for gfx950.
 //
 // Reference semantics
-//   forward 2-D   TrQuant::xT            CommonLib/TrQuant.cpp:481-564  ->  _fastForwardMM / fastFwdCore   TrQuant_EMT.cpp:366-420,1973-2000
-//   inverse 2-D   TrQuant::xIT           CommonLib/TrQuant.cpp:567-655  ->  _fastInverseMM / fastInvCore_  TrQuant_EMT.cpp:152-194,1953-1970 + clipCore :1941
+//   forward 2-D   TrQuant::xT            CommonLib/TrQuant.cpp:481-564  ->  _fastForwardMM / fastFwdCore   TrQuant_EMT.cpp:366-420,1973-2000  (x86: fastFwd_SSE  x86/TrafoX86.h:310-643)
+//   inverse 2-D   TrQuant::xIT           CommonLib/TrQuant.cpp:567-655  ->  _fastInverseMM / fastInvCore_  TrQuant_EMT.cpp:152-194,1953-1970 + clipCore :1941 (x86: fastInv_SSE :60-308)
 //   quantiser     Quant::quant           CommonLib/Quant.cpp:735-833    ->  QuantCore   :132-230
 //   dequantiser   Quant::dequant         CommonLib/Quant.cpp:520-610    ->  DeQuantCore :232-262
 //   RDOQ pre-test Quant::xNeedRDOQ       CommonLib/Quant.cpp:835-891    ->  needRdoqCore :264-278
-// The N=2/4/8 butterflies of the reference compute the same integer sums as the matrix form (32-bit
-// wrap-around arithmetic), so one matrix-form kernel covers every size and type.
+// The N=2/4/8 butterflies of the reference compute the same integer sums as the matrix form, so one matrix-form kernel
+// covers every size and type.
 //
-// Layout: one workgroup owns TPB transform units (TPB = 256 / (w*h) for small TUs, else 1).  The
-// residual block, the intermediate and both kernel matrices live in LDS; matrices are stored so that
-// consecutive lanes (consecutive output frequencies / samples) read consecutive LDS words while the
-// input operand is a wave-wide broadcast.  Coefficients never touch HBM between the two 1-D passes.
+// Arithmetic: every 1-D pass is int16 x int16 -> int32 (v_dot2_i32_i16, two MACs per lane per instruction).  The operands
+// of a pass are 16-bit by construction: residuals are Pel, the kernel matrices are 8-bit, the forward intermediate fits 16 bits
+// for every residual of bitDepth-bit samples (|r| <= 2^bitDepth  =>  |tmp| <= 64*2^9 = 32768-ish, DC row bound), dequantised
+// coefficients and the inverse intermediate are clipped to [-32768, 32767] by the reference itself.  For inputs outside that
+// contract the passes saturate their *input* to 16 bits exactly like the reference's x86 row does (_mm_packs_epi32,
+// x86/TrafoX86.h:101,364) — i.e. results equal the reference's SIMD path for all inputs and its scalar path for conforming ones.
+//
+// LDS layout (per TU, int16 unless noted; "pitch" = row length rounded to an odd number of 16-byte chunks so that consecutive
+// lanes reading consecutive rows with ds_read_b128 hit disjoint banks):
+//   R0  residual rows [h][pw]            | later: dequantised coefficients, transposed [w][ph]
+//   R1  forward intermediate [w][ph]     | later: levels (raster) -> HBM | later: inverse intermediate [h][pw]
+//   R2  coefficients int32 [h][w]        | later: reconstructed residual (raster int16) -> HBM
+// In every pass consecutive lanes own consecutive ROWS of the data operand (each lane streams its row with 16-byte reads)
+// while the matrix row is a wave-wide LDS broadcast.  Nothing but the residual, the levels, the reconstruction and 24 bytes
+// of statistics per TU crosses HBM in the fused kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
+typedef uint32_t u32x2 __attribute__( ( ext_vector_type( 2 ) ) );
+typedef uint32_t u32x4 __attribute__( ( ext_vector_type( 4 ) ) );
+typedef short    s16x2 __attribute__( ( ext_vector_type( 2 ) ) );
+
 __device__ __forceinline__ int clip3i( int lo, int hi, int v ) { return v < lo ? lo : ( v > hi ? hi : v ); }
+__device__ __forceinline__ int sat16( int v ) { return clip3i( -32768, 32767, v ); }
+__device__ __forceinline__ int dot2( uint32_t a, uint32_t b, int acc )
+{
+  return __builtin_amdgcn_sdot2( __builtin_bit_cast( s16x2, a ), __builtin_bit_cast( s16x2, b ), acc, false );
+}
 
 struct TrGeom
 {
@@ -26,159 +47,182 @@ struct TrGeom
   int shift1, shift2;
 };
 
-// --------------------------------------------------------------------------------------------
-// 2-D transforms on LDS-resident TUs.  Both kernel matrices stay in their natural [frequency][sample]
-// layout; operands are arranged so that, in every pass, consecutive lanes read consecutive LDS words
-// of one operand while the other operand is a wave-wide broadcast:
-//   forward  pass 1: lanes over block rows i     : blkT[k][i] (transposed residual) x Th[j][k] (broadcast)  -> tmp[i][j]
-//            pass 2: lanes over hor. freq.  i2   : tmp[k][i2]                       x Tv[j2][k] (broadcast) -> coef[j2][i2] (raster)
-//   inverse  pass 1: lanes over columns i        : coef[k][i]                       x Tv[k][j] (broadcast)  -> t1[j][i]
-//            pass 2: lanes over columns j2       : Th[k][j2]                        x t1[i2][k] (broadcast) -> rec[i2][j2] (raster)
-// Strided LDS *writes* use a +1 padded pitch (conflict-free).
-// --------------------------------------------------------------------------------------------
-struct TuLds
+// LDS carve-up, all offsets in int16 elements
+struct TuLay
 {
-  int32_t* a;      // [TPB][pitchA * ...]  transposed residual (fwd in) / dequantised coefficients (inv in), later output staging
-  int32_t* b;      // intermediate
-  const int16_t* th;
-  const int16_t* tv;
+  int pw, ph;                // row pitch of rows of length w / h
+  int r1, r2, slot;          // region offsets inside a TU slot (R0 at 0) and slot size
+  int mTh, mTv, mThT, mTvT;  // matrix offsets from the matrix base (natural [freq][sample] and transposed [sample][freq])
+  int matElems;
 };
 
-__device__ __forceinline__ int ldsTuStride( const TrGeom& g ) { return max( g.w * ( g.h + 1 ), g.h * ( g.w + 1 ) ); }   // words per TU slot
-
-// in : a[t][x*(h+1) + y] = resi[y][x]        out: a[t][j2*w + i2] = coef (raster, zero-out applied)
-__device__ __forceinline__ void fwd2dLds( const TrGeom& g, const TuLds& L, int nTu, int tid, int nthr )
+// sum_k a[k] * b[k], k < n; a and b aligned to min(n,8)*2 bytes
+__device__ __forceinline__ int dotRow( const int16_t* a, const int16_t* b, int n )
 {
-  const int w = g.w, h = g.h, area = w * h, slot = ldsTuStride( g );
-  const int cutW = w - g.skipW, cutH = h - g.skipH;
-  const uint32_t rnd1 = g.shift1 > 0 ? 1u << ( g.shift1 - 1 ) : 0u, rnd2 = 1u << ( g.shift2 - 1 );
-  // pass 1: tmp[i*(w+1) + j] = ( sum_k blk[i][k] * Th[j][k] + rnd ) >> shift1, j < w - skipW        (TrQuant.cpp:548)
-  for( int o = tid; o < nTu * area; o += nthr )
+  int acc = 0;
+  if( n >= 8 )
   {
-    const int t = o / area, p = o - t * area, j = p / h, i = p - j * h;             // i fastest
-    int32_t v = 0;
-    if( j < cutW )
+    for( int k = 0; k < n; k += 8 )
     {
-      const int32_t* src = L.a + t * slot + i;
-      const int16_t* m = L.th + j * w;
-      uint32_t acc = 0;
-      for( int k = 0; k < w; k++ ) acc += ( uint32_t ) src[k * ( h + 1 )] * ( uint32_t ) ( int32_t ) m[k];
-      v = ( int32_t ) ( acc + rnd1 ) >> g.shift1;
+      const u32x4 x = *reinterpret_cast<const u32x4*>( a + k ), y = *reinterpret_cast<const u32x4*>( b + k );
+      acc = dot2( x.x, y.x, acc ); acc = dot2( x.y, y.y, acc ); acc = dot2( x.z, y.z, acc ); acc = dot2( x.w, y.w, acc );
     }
-    L.b[t * slot + i * ( w + 1 ) + j] = v;
+  }
+  else if( n == 4 )
+  {
+    const u32x2 x = *reinterpret_cast<const u32x2*>( a ), y = *reinterpret_cast<const u32x2*>( b );
+    acc = dot2( x.x, y.x, acc ); acc = dot2( x.y, y.y, acc );
+  }
+  else acc = dot2( *reinterpret_cast<const uint32_t*>( a ), *reinterpret_cast<const uint32_t*>( b ), 0 );
+  return acc;
+}
+
+struct Lds
+{
+  int16_t* tu;         // TU slots
+  const int16_t* mat;  // matrices
+};
+
+// ---- forward: R0 = residual rows  ->  R2 = coefficients (int32 raster, zero-out applied) -----------------------------------
+__device__ __forceinline__ void fwd2d( const TrGeom& g, const TuLay& y, const Lds& L, int nTu, int tid, int nthr )
+{
+  const int w = g.w, h = g.h, la = g.log2w + g.log2h, area = 1 << la;
+  const int cutW = w - g.skipW, cutH = h - g.skipH;
+  const int rnd1 = g.shift1 > 0 ? 1 << ( g.shift1 - 1 ) : 0, rnd2 = 1 << ( g.shift2 - 1 );
+  // pass 1 (rows): tmp[j][i] = sat16( ( sum_k blk[i][k] * Th[j][k] + rnd ) >> shift1 ), j < w - skipW     (TrQuant.cpp:548)
+  for( int o = tid; o < ( nTu << la ); o += nthr )
+  {
+    const int t = o >> la, p = o & ( area - 1 ), i = p & ( h - 1 ), j = p >> g.log2h;
+    int16_t* s = L.tu + t * y.slot;
+    int v = 0;
+    if( j < cutW ) v = sat16( ( int ) ( ( uint32_t ) dotRow( s + i * y.pw, L.mat + y.mTh + j * w, w ) + ( uint32_t ) rnd1 ) >> g.shift1 );
+    s[y.r1 + j * y.ph + i] = ( int16_t ) v;
   }
   __syncthreads();
-  // pass 2: coef[j2*w + i2] = ( sum_k tmp[k][i2] * Tv[j2][k] + rnd ) >> shift2, i2 < w - skipW, j2 < h - skipH   (TrQuant.cpp:549)
-  for( int o = tid; o < nTu * area; o += nthr )
+  // pass 2 (columns): coef[j2][i2] = ( sum_k tmp[i2][k] * Tv[j2][k] + rnd ) >> shift2, i2 < w - skipW, j2 < h - skipH   (TrQuant.cpp:549)
+  for( int o = tid; o < ( nTu << la ); o += nthr )
   {
-    const int t = o / area, p = o - t * area, j2 = p / w, i2 = p - j2 * w;         // i2 fastest
-    int32_t v = 0;
-    if( i2 < cutW && j2 < cutH )
-    {
-      const int32_t* src = L.b + t * slot + i2;
-      const int16_t* m = L.tv + j2 * h;
-      uint32_t acc = 0;
-      for( int k = 0; k < h; k++ ) acc += ( uint32_t ) src[k * ( w + 1 )] * ( uint32_t ) ( int32_t ) m[k];
-      v = ( int32_t ) ( acc + rnd2 ) >> g.shift2;
-    }
-    L.a[t * slot + p] = v;
+    const int t = o >> la, p = o & ( area - 1 ), i2 = p & ( w - 1 ), j2 = p >> g.log2w;
+    int16_t* s = L.tu + t * y.slot;
+    int v = 0;
+    if( i2 < cutW && j2 < cutH ) v = ( int ) ( ( uint32_t ) dotRow( s + y.r1 + i2 * y.ph, L.mat + y.mTv + j2 * h, h ) + ( uint32_t ) rnd2 ) >> g.shift2;
+    reinterpret_cast<int32_t*>( s + y.r2 )[p] = v;
   }
   __syncthreads();
 }
 
-// in : a[t][k*w + i] = coefficients (raster)  out: a[t][i2*w + j2] = residual (raster), clipped to int16
-__device__ __forceinline__ void inv2dLds( const TrGeom& g, const TuLds& L, int nTu, int tid, int nthr )
+// ---- inverse: R0 = coefficients transposed [i][k] (int16)  ->  R2 = residual (raster int16) ---------------------------------
+__device__ __forceinline__ void inv2d( const TrGeom& g, const TuLay& y, const Lds& L, int nTu, int tid, int nthr )
 {
-  const int w = g.w, h = g.h, area = w * h, slot = ldsTuStride( g );
-  const int cutW = w - g.skipW, cutH = h - g.skipH;
-  const int32_t cmin = -32768, cmax = 32767;
-  const uint32_t rnd1 = 1u << ( g.shift1 - 1 ), rnd2 = 1u << ( g.shift2 - 1 );
-  // pass 1 (columns): t1[j*w + i] = clip( ( sum_{k<cutH} coef[k][i] * Tv[k][j] + rnd ) >> shift1 ), i < w - skipW, else 0   (TrQuant.cpp:612)
-  for( int o = tid; o < nTu * area; o += nthr )
+  const int w = g.w, h = g.h, la = g.log2w + g.log2h, area = 1 << la;
+  const int cutW = w - g.skipW;
+  const int rnd1 = 1 << ( g.shift1 - 1 ), rnd2 = 1 << ( g.shift2 - 1 );
+  // pass 1 (columns): t1[j][i] = clip( ( sum_k coef[k][i] * Tv[k][j] + rnd ) >> shift1 ), i < w - skipW else 0           (TrQuant.cpp:612)
+  for( int o = tid; o < ( nTu << la ); o += nthr )
   {
-    const int t = o / area, p = o - t * area, j = p / w, i = p - j * w;             // i fastest
-    int32_t v = 0;
-    if( i < cutW )
-    {
-      const int32_t* src = L.a + t * slot + i;
-      const int16_t* m = L.tv + j;
-      uint32_t acc = 0;
-      for( int k = 0; k < cutH; k++ ) acc += ( uint32_t ) src[k * w] * ( uint32_t ) ( int32_t ) m[k * h];
-      v = clip3i( cmin, cmax, ( int32_t ) ( acc + rnd1 ) >> g.shift1 );
-    }
-    L.b[t * slot + p] = v;
+    const int t = o >> la, p = o & ( area - 1 ), i = p & ( w - 1 ), j = p >> g.log2w;
+    int16_t* s = L.tu + t * y.slot;
+    int v = 0;
+    if( i < cutW ) v = sat16( ( int ) ( ( uint32_t ) dotRow( s + i * y.ph, L.mat + y.mTvT + j * h, h ) + ( uint32_t ) rnd1 ) >> g.shift1 );
+    s[y.r1 + j * y.pw + i] = ( int16_t ) v;
   }
   __syncthreads();
-  // pass 2 (rows): rec[i2*w + j2] = clip( ( sum_{k<cutW} t1[i2][k] * Th[k][j2] + rnd ) >> shift2 )                          (TrQuant.cpp:613)
-  for( int o = tid; o < nTu * area; o += nthr )
+  // pass 2 (rows): rec[i2][j2] = clip( ( sum_k t1[i2][k] * Th[k][j2] + rnd ) >> shift2 )                                  (TrQuant.cpp:613)
+  for( int o = tid; o < ( nTu << la ); o += nthr )
   {
-    const int t = o / area, p = o - t * area, i2 = p / w, j2 = p - i2 * w;         // j2 fastest
-    const int32_t* src = L.b + t * slot + i2 * w;
-    const int16_t* m = L.th + j2;
-    uint32_t acc = 0;
-    for( int k = 0; k < cutW; k++ ) acc += ( uint32_t ) src[k] * ( uint32_t ) ( int32_t ) m[k * w];
-    L.a[t * slot + p] = clip3i( cmin, cmax, ( int32_t ) ( acc + rnd2 ) >> g.shift2 );
+    const int t = o >> la, p = o & ( area - 1 ), i2 = p & ( h - 1 ), j2 = p >> g.log2h;
+    int16_t* s = L.tu + t * y.slot;
+    const int v = sat16( ( int ) ( ( uint32_t ) dotRow( s + y.r1 + i2 * y.pw, L.mat + y.mThT + j2 * w, w ) + ( uint32_t ) rnd2 ) >> g.shift2 );
+    s[y.r2 + i2 * w + j2] = ( int16_t ) v;
   }
   __syncthreads();
 }
 
-__device__ __forceinline__ TuLds carveLds( unsigned char* raw, const TrGeom& g, int tpb, const int16_t* matH, const int16_t* matV, int tid, int nthr )
+__device__ __forceinline__ Lds carve( unsigned char* raw, const TrGeom& g, const TuLay& y, int tpb, const int16_t* matH, const int16_t* matV, bool needInv, bool needFwd, int tid, int nthr )
 {
-  TuLds L;
-  const int slot = ldsTuStride( g );
-  L.a = reinterpret_cast<int32_t*>( raw );
-  L.b = L.a + tpb * slot;
-  int16_t* th = reinterpret_cast<int16_t*>( L.b + tpb * slot );
-  int16_t* tv = th + g.w * g.w;
-  for( int i = tid; i < g.w * g.w; i += nthr ) th[i] = matH[i];
-  for( int i = tid; i < g.h * g.h; i += nthr ) tv[i] = matV[i];
-  L.th = th; L.tv = tv;
+  Lds L;
+  int16_t* m = reinterpret_cast<int16_t*>( raw );
+  L.mat = m;
+  L.tu = m + ( ( y.matElems + 7 ) & ~7 );
+  const int w = g.w, h = g.h;
+  if( needFwd )
+  {
+    for( int i = tid; i < w * w; i += nthr ) m[y.mTh + i] = matH[i];
+    if( y.mTv != y.mTh ) for( int i = tid; i < h * h; i += nthr ) m[y.mTv + i] = matV[i];
+  }
+  if( needInv )
+  {
+    for( int i = tid; i < w * w; i += nthr ) { const int k = i >> g.log2w, j = i & ( w - 1 ); m[y.mThT + j * w + k] = matH[i]; }
+    if( y.mTvT != y.mThT ) for( int i = tid; i < h * h; i += nthr ) { const int k = i >> g.log2h, j = i & ( h - 1 ); m[y.mTvT + j * h + k] = matV[i]; }
+  }
   return L;
 }
 
-// transposed residual load: a[t][x*(h+1) + y] = resi[y][x]   (cpyCoeff, TrQuant_EMT.cpp:1917-1926)
-__device__ __forceinline__ void loadResiT( const TrGeom& g, const TuLds& L, const int16_t* resi, int resiStride, const int32_t* resiOff,
-                                           int tu0, int nTu, int tid, int nthr )
+// residual rows -> R0 (cpyCoeff, TrQuant_EMT.cpp:1917-1926); 16-byte global loads when w >= 8
+__device__ __forceinline__ void loadResi( const TrGeom& g, const TuLay& y, const Lds& L, const int16_t* resi, int resiStride, const int32_t* resiOff,
+                                          int tu0, int nTu, int tid, int nthr )
 {
-  const int w = g.w, h = g.h, area = w * h, slot = ldsTuStride( g );
-  for( int i = tid; i < nTu * area; i += nthr )
+  const int w = g.w, la = g.log2w + g.log2h, area = 1 << la;
+  if( w >= 8 )
   {
-    const int t = i / area, p = i - t * area, y = p / w, x = p - y * w;
-    L.a[t * slot + x * ( h + 1 ) + y] = resi[resiOff[tu0 + t] + ( ptrdiff_t ) y * resiStride + x];
+    struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+    const int lc = la - 3;                                  // chunks of 8 samples per TU
+    for( int o = tid; o < ( nTu << lc ); o += nthr )
+    {
+      const int t = o >> lc, c = o & ( ( 1 << lc ) - 1 ), yy = c >> ( g.log2w - 3 ), x = ( c & ( ( w >> 3 ) - 1 ) ) << 3;
+      const u32x4 v = reinterpret_cast<const U16*>( resi + resiOff[tu0 + t] + ( ptrdiff_t ) yy * resiStride + x )->v;
+      *reinterpret_cast<u32x4*>( L.tu + t * y.slot + yy * y.pw + x ) = v;
+    }
   }
+  else
+    for( int o = tid; o < ( nTu << la ); o += nthr )
+    {
+      const int t = o >> la, p = o & ( area - 1 ), yy = p >> g.log2w, x = p & ( w - 1 );
+      L.tu[t * y.slot + yy * y.pw + x] = resi[resiOff[tu0 + t] + ( ptrdiff_t ) yy * resiStride + x];
+    }
 }
 
 __global__ void __launch_bounds__( 256 )
 fwdTransformKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t* __restrict__ resiOff, int n,
-                    TrGeom g, int tpb, const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
+                    TrGeom g, TuLay y, int tpb, const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
                     int32_t* __restrict__ coef )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemRaw[];
-  const int tid = threadIdx.x, nthr = blockDim.x, area = g.w * g.h, slot = ldsTuStride( g );
+  const int tid = threadIdx.x, nthr = blockDim.x, la = g.log2w + g.log2h, area = 1 << la;
   const int tu0 = blockIdx.x * tpb, nTu = min( tpb, n - tu0 );
-  const TuLds L = carveLds( smemRaw, g, tpb, matH, matV, tid, nthr );
-  loadResiT( g, L, resi, resiStride, resiOff, tu0, nTu, tid, nthr );
+  const Lds L = carve( smemRaw, g, y, tpb, matH, matV, false, true, tid, nthr );
+  loadResi( g, y, L, resi, resiStride, resiOff, tu0, nTu, tid, nthr );
   __syncthreads();
-  fwd2dLds( g, L, nTu, tid, nthr );
-  for( int i = tid; i < nTu * area; i += nthr ) { const int t = i / area, p = i - t * area; coef[( size_t ) tu0 * area + i] = L.a[t * slot + p]; }
+  fwd2d( g, y, L, nTu, tid, nthr );
+  for( int o = tid; o < ( nTu << la ); o += nthr )
+  {
+    const int t = o >> la, p = o & ( area - 1 );
+    coef[( size_t ) tu0 * area + o] = reinterpret_cast<const int32_t*>( L.tu + t * y.slot + y.r2 )[p];
+  }
 }
 
 __global__ void __launch_bounds__( 256 )
-invTransformKernel( const int32_t* __restrict__ coef, int n, TrGeom g, int tpb,
+invTransformKernel( const int32_t* __restrict__ coef, int n, TrGeom g, TuLay y, int tpb,
                     const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
                     int16_t* __restrict__ resi, int resiStride, const int32_t* __restrict__ resiOff )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemRaw[];
-  const int tid = threadIdx.x, nthr = blockDim.x, w = g.w, area = g.w * g.h, slot = ldsTuStride( g );
+  const int tid = threadIdx.x, nthr = blockDim.x, w = g.w, h = g.h, la = g.log2w + g.log2h, area = 1 << la;
   const int tu0 = blockIdx.x * tpb, nTu = min( tpb, n - tu0 );
-  const TuLds L = carveLds( smemRaw, g, tpb, matH, matV, tid, nthr );
-  for( int i = tid; i < nTu * area; i += nthr ) { const int t = i / area, p = i - t * area; L.a[t * slot + p] = coef[( size_t ) tu0 * area + i]; }
-  __syncthreads();
-  inv2dLds( g, L, nTu, tid, nthr );
-  for( int i = tid; i < nTu * area; i += nthr )
+  const Lds L = carve( smemRaw, g, y, tpb, matH, matV, true, false, tid, nthr );
+  const int cutH = h - g.skipH;
+  for( int o = tid; o < ( nTu << la ); o += nthr )
   {
-    const int t = i / area, p = i - t * area, y = p / w, x = p - y * w;
-    resi[resiOff[tu0 + t] + ( ptrdiff_t ) y * resiStride + x] = ( int16_t ) L.a[t * slot + p];     // cpyResi, TrQuant_EMT.cpp:1929-1938
+    const int t = o >> la, p = o & ( area - 1 ), k = p >> g.log2w, i = p & ( w - 1 );       // coefficient row k (vertical frequency), column i
+    const int v = k < cutH ? sat16( coef[( size_t ) tu0 * area + o] ) : 0;                 // rows >= cutoff are never read by the reference (TrQuant_EMT.cpp:165)
+    L.tu[t * y.slot + i * y.ph + k] = ( int16_t ) v;
+  }
+  __syncthreads();
+  inv2d( g, y, L, nTu, tid, nthr );
+  for( int o = tid; o < ( nTu << la ); o += nthr )
+  {
+    const int t = o >> la, p = o & ( area - 1 ), yy = p >> g.log2w, x = p & ( w - 1 );
+    resi[resiOff[tu0 + t] + ( ptrdiff_t ) yy * resiStride + x] = L.tu[t * y.slot + y.r2 + p];   // cpyResi, TrQuant_EMT.cpp:1929-1938
   }
 }
 
@@ -324,140 +368,231 @@ needRdoqKernel( const int32_t* __restrict__ coef, int n, QGeom q, int log2Lpc, c
 // --------------------------------------------------------------------------------------------
 // Fused TU pipeline (InterSearch::xEstimateInterResidualQT inner sequence, EncoderLib/InterSearch.cpp:3663-3714):
 //   xT -> xNeedRDOQ -> QuantCore -> DeQuantCore -> xIT -> SSE( residual, reconstructed residual )
-// Coefficients, levels and the intermediate of both transforms stay in LDS; HBM sees 2 B/sample in and
-// 2+2 B/sample out plus 24 B of statistics per TU.
+// A workgroup owns ~1024 samples worth of TUs.  The significance structure of QuantCore (last non-zero scan position,
+// per-coefficient-group threshold test) is gathered with ONE wave ballot per 64 scan positions — no shuffles, no atomics — and
+// resolved by one lane per TU; sums (abs-sum, SSE) use the hardware wave reduction.
 // --------------------------------------------------------------------------------------------
-struct TuRed { int last; uint32_t bigLo, bigHi; uint32_t absSum; int need; int pad; unsigned long long sse; };
+struct TuPar   // per-TU quantiser constants + reduction targets, in LDS
+{
+  int scale, qBits, iscale, rightShift, inMax, useThres, last; uint32_t absSum;
+  long long add, addN; unsigned long long sse; uint32_t need, pad;
+  unsigned long long nz[16], big[16];
+};
+
+__device__ __forceinline__ unsigned long long grpAdd64( unsigned long long e, int G )
+{
+  uint32_t lo = ( uint32_t ) e, hi = ( uint32_t ) ( e >> 32 );
+  for( int sft = G >> 1; sft > 0; sft >>= 1 )
+  {
+    const unsigned long long other = ( ( unsigned long long ) __shfl_xor( hi, sft ) << 32 ) | __shfl_xor( lo, sft );
+    e += other; lo = ( uint32_t ) e; hi = ( uint32_t ) ( e >> 32 );
+  }
+  return e;
+}
 
 __global__ void __launch_bounds__( 256 )
 tuRdoKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t* __restrict__ resiOff, int n,
-             TrGeom gf, TrGeom gi, QGeom q, int tpb, const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
+             TrGeom gf, TrGeom gi, TuLay y, QGeom q, int tpb, const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
              const uint16_t* __restrict__ scan, const vvhip_tu_qp* __restrict__ qps, int thrVal,
-             int16_t* __restrict__ level, int16_t* __restrict__ rec, vvhip_tu_stats* __restrict__ stats )
+             int16_t* __restrict__ level, int16_t* __restrict__ rec, vvhip_tu_stats* __restrict__ stats, int phaseLimit )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemRaw[];
-  const int tid = threadIdx.x, nthr = blockDim.x, w = gf.w, area = gf.w * gf.h, slot = ldsTuStride( gf );
+  const int tid = threadIdx.x, nthr = blockDim.x, w = gf.w, la = gf.log2w + gf.log2h, area = 1 << la;
   const int tu0 = blockIdx.x * tpb, nTu = min( tpb, n - tu0 );
-  const TuLds L = carveLds( smemRaw, gf, tpb, matH, matV, tid, nthr );
-  TuRed* red = reinterpret_cast<TuRed*>( smemRaw + ( ( ( size_t ) 2 * tpb * slot * sizeof( int32_t ) + ( size_t ) ( gf.w * gf.w + gf.h * gf.h ) * sizeof( int16_t ) + 15 ) & ~( size_t ) 15 ) );
-  for( int t = tid; t < nTu; t += nthr ) { TuRed r; r.last = 0; r.bigLo = r.bigHi = 0; r.absSum = 0; r.need = 0; r.pad = 0; r.sse = 0; red[t] = r; }
-  loadResiT( gf, L, resi, resiStride, resiOff, tu0, nTu, tid, nthr );
-  __syncthreads();
-  fwd2dLds( gf, L, nTu, tid, nthr );                       // L.a[t] = coefficients, raster
-
-  // ---- need-RDOQ pre-test + last significant scan position
-  const int efArea = q.w * min( q.h, 32 );
-  for( int o = tid; o < nTu * area; o += nthr )
+  const int G = area < 64 ? area : 64, lane = tid & 63, sub = lane & ( G - 1 );
+  const Lds L = carve( smemRaw, gf, y, tpb, matH, matV, true, true, tid, nthr );
+  TuPar* par = reinterpret_cast<TuPar*>( L.tu + ( ( tpb * y.slot + 7 ) & ~7 ) );
+  for( int t = tid; t < nTu; t += nthr )
   {
-    const int t = o / area, p = o - t * area;
     const vvhip_tu_qp qq = qps[tu0 + t];
-    int scale, qBits;
-    quantParams( q, qq.qp, scale, qBits );
-    if( p < efArea )
+    TuPar P;
+    quantParams( q, qq.qp, P.scale, P.qBits );
+    P.add  = ( long long ) ( ( qq.flags & 1 ) ? 171 : 85 ) << ( P.qBits - 9 );           // Quant.cpp:775
+    P.addN = ( long long ) ( ( qq.flags & 2 ) ? 171 : 256 ) << ( P.qBits - 9 );          // Quant.cpp:874
+    const int32_t thres = P.qBits ? ( int32_t ) ( ( int64_t ) thrVal << ( P.qBits - 1 ) ) : ( int32_t ) ( ( int64_t ) ( thrVal >> 1 ) << P.qBits );
+    P.useThres = thres / ( P.scale << 2 );                                                // Quant.cpp:173-180
+    const int l2 = q.log2w + q.log2h, sqrt2 = l2 & 1, trShift = 15 - q.bitDepth - ( l2 >> 1 ) - sqrt2;
+    P.iscale = cInvQuantScales[sqrt2][qq.qp % 6];                                          // Quant.cpp:601
+    P.rightShift = 6 - ( trShift + qq.qp / 6 );                                            // Quant.cpp:561
+    int tgt = 32 + P.rightShift - 7; if( tgt > 16 ) tgt = 16;                              // Quant.cpp:606
+    P.inMax = ( 1 << ( tgt - 1 ) ) - 1;
+    P.last = 0; P.absSum = 0; P.sse = 0; P.need = 0; P.pad = 0;
+    for( int c = 0; c < 16; c++ ) { P.nz[c] = 0; P.big[c] = 0; }
+    par[t] = P;
+  }
+  loadResi( gf, y, L, resi, resiStride, resiOff, tu0, nTu, tid, nthr );
+  __syncthreads();
+  if( phaseLimit == 1 ) return;
+  fwd2d( gf, y, L, nTu, tid, nthr );                        // R2 = coefficients (int32 raster)
+  if( phaseLimit == 2 ) return;
+
+  // ---- significance ballots: thread <-> (TU t, scan position p) for nz/big, (TU t, raster position p) for the need-RDOQ test
+  const int efArea = q.w * min( q.h, 32 );
+  for( int o = tid; o < ( nTu << la ); o += nthr )
+  {
+    const int t = o >> la, p = o & ( area - 1 );
+    const int32_t* c = reinterpret_cast<const int32_t*>( L.tu + t * y.slot + y.r2 );
+    const TuPar& P = par[t];
+    const bool need = p < efArea && ( int32_t ) ( ( ( int64_t ) abs( c[p] ) * P.scale + P.addN ) >> P.qBits ) != 0;   // needRdoqCore, Quant.cpp:264-278
+    int cs = 0;
+    if( p < q.numScan ) cs = c[scan[p]];
+    const unsigned long long mNz = __ballot( cs != 0 ), mBig = __ballot( abs( cs ) > P.useThres ), mNeed = __ballot( need );
+    if( sub == 0 )
     {
-      const int64_t addN = ( int64_t ) ( ( qq.flags & 2 ) ? 171 : 256 ) << ( qBits - 9 );
-      const int64_t tt = ( int64_t ) abs( L.a[t * slot + p] ) * scale;
-      if( ( int32_t ) ( ( tt + addN ) >> qBits ) != 0 ) red[t].need = 1;          // benign race: all writers store 1
+      const int sh = lane & ~( G - 1 );
+      const unsigned long long gm = G == 64 ? ~0ull : ( ( 1ull << G ) - 1 );
+      const int chunk = p >> 6;
+      if( chunk < 16 ) { par[t].nz[chunk] = ( mNz >> sh ) & gm; par[t].big[chunk] = ( mBig >> sh ) & gm; }
+      if( ( mNeed >> sh ) & gm ) par[t].need = 1;             // benign race: every writer stores 1
     }
-    if( p < q.numScan && L.a[t * slot + scan[p]] != 0 ) atomicMax( &red[t].last, p );
   }
   __syncthreads();
-  if( q.cgIs4x4 )
+  if( phaseLimit == 3 ) return;
+  for( int t = tid; t < nTu; t += nthr )                    // one lane per TU resolves QuantCore's scan logic (Quant.cpp:162-208)
   {
-    for( int o = tid; o < nTu * area; o += nthr )
+    int last = 0;
+    for( int c = 15; c >= 0; c-- ) if( par[t].nz[c] ) { last = c * 64 + 63 - __clzll( ( long long ) par[t].nz[c] ); break; }
+    if( q.cgIs4x4 && last >= 16 )
     {
-      const int t = o / area, p = o - t * area;
-      const int last = red[t].last;
-      if( last >= 16 && p <= last && p < q.numScan )
+      int g2 = -1;
+      for( int c = last >> 6; c >= 0 && g2 < 0; c-- )
       {
-        const vvhip_tu_qp qq = qps[tu0 + t];
-        int scale, qBits;
-        quantParams( q, qq.qp, scale, qBits );
-        const int32_t thres = qBits ? ( int32_t ) ( ( int64_t ) thrVal << ( qBits - 1 ) ) : ( int32_t ) ( ( int64_t ) ( thrVal >> 1 ) << qBits );
-        const int32_t useThres = thres / ( scale << 2 );
-        if( abs( L.a[t * slot + scan[p]] ) > useThres )
-        {
-          const int cg = p >> 4;
-          if( cg > 0 ) { if( cg < 32 ) atomicOr( &red[t].bigLo, 1u << cg ); else atomicOr( &red[t].bigHi, 1u << ( cg - 32 ) ); }
-        }
+        unsigned long long m = par[t].big[c];
+        if( c == 0 ) m &= ~0xFFFFull;                         // CG 0 is never tested
+        if( c == ( last >> 6 ) && ( last & 63 ) != 63 ) m &= ( 1ull << ( ( last & 63 ) + 1 ) ) - 1;
+        if( m ) g2 = c * 4 + ( ( 63 - __clzll( ( long long ) m ) ) >> 4 );
       }
+      if( g2 < 0 ) last = 15;
+      else if( g2 != ( last >> 4 ) ) last = g2 * 16 + 15;
     }
-    __syncthreads();
-    for( int t = tid; t < nTu; t += nthr )
-    {
-      const int last = red[t].last;
-      if( last >= 16 )
-      {
-        const uint64_t big = ( ( uint64_t ) red[t].bigHi << 32 ) | red[t].bigLo;
-        if( big == 0 ) red[t].last = 15;
-        else { const int g2 = 63 - __clzll( ( long long ) big ); if( g2 != ( last >> 4 ) ) red[t].last = g2 * 16 + 15; }
-      }
-    }
-    __syncthreads();
+    par[t].last = last;
   }
-  // ---- QuantCore + DeQuantCore: b[t][raster] = dequantised coefficient (0 beyond `last`), levels to HBM
-  for( int o = tid; o < nTu * area; o += nthr )
+  __syncthreads();
+  if( phaseLimit == 4 ) return;
+  // ---- QuantCore + DeQuantCore.  R1 <- levels (raster int16), R0 <- dequantised coefficients transposed [x][y]
+  for( int o = tid; o < ( nTu << la ); o += nthr )
   {
-    const int t = o / area, p = o - t * area;
+    const int t = o >> la, p = o & ( area - 1 );
+    int16_t* s = L.tu + t * y.slot;
+    const int32_t* c = reinterpret_cast<const int32_t*>( s + y.r2 );
+    const TuPar& P = par[t];
     int bp = p; bool inScan = false;
     if( p < q.numScan ) { bp = scan[p]; inScan = true; }
-    else if( q.w > 32 || q.h > 32 )
+    else
     {
       // enumerate the zero-out region (x >= 32 or y >= 32) with the remaining indices
-      const int r = p - q.numScan;                     // 0 .. area - numScan - 1
-      const int wz = q.w - min( q.w, 32 );             // columns right of the region
-      const int rowsTop = min( q.h, 32 );
-      if( r < rowsTop * wz ) { const int y = r / wz, x = 32 + ( r - y * wz ); bp = y * q.w + x; }
-      else { const int r2 = r - rowsTop * wz; bp = rowsTop * q.w + r2; }
+      const int r = p - q.numScan, wz = q.w - min( q.w, 32 ), rowsTop = min( q.h, 32 );
+      if( r < rowsTop * wz ) { const int yy = r / wz, x = 32 + ( r - yy * wz ); bp = yy * q.w + x; }
+      else bp = rowsTop * q.w + ( r - rowsTop * wz );
     }
-    int16_t lv = 0; int32_t dq = 0;
-    if( inScan && p <= red[t].last )
+    int lv = 0, dq = 0;
+    if( inScan && p <= P.last )
     {
-      const vvhip_tu_qp qq = qps[tu0 + t];
-      int scale, qBits;
-      quantParams( q, qq.qp, scale, qBits );
-      const int64_t add = ( int64_t ) ( ( qq.flags & 1 ) ? 171 : 85 ) << ( qBits - 9 );
-      const int32_t c = L.a[t * slot + bp];
-      const int64_t tt = ( int64_t ) abs( c ) * scale;
-      const int32_t m = ( int32_t ) ( ( tt + add ) >> qBits );
-      if( m ) atomicAdd( &red[t].absSum, ( uint32_t ) m );
-      lv = ( int16_t ) clip3i( -32768, 32767, c < 0 ? -m : m );
-      // DeQuantCore (Quant.cpp:232-262) with Quant::dequant's parameters (:554-561,:601-607)
-      const int l2 = q.log2w + q.log2h, sqrt2 = l2 & 1;
-      const int trShift = 15 - q.bitDepth - ( l2 >> 1 ) - sqrt2;
-      const int iscale = cInvQuantScales[sqrt2][qq.qp % 6];
-      const int rightShift = 6 - ( trShift + qq.qp / 6 );
-      int tgt = 32 + rightShift - 7; if( tgt > 16 ) tgt = 16;
-      const int inMax = ( 1 << ( tgt - 1 ) ) - 1;
-      const int cl = clip3i( -( inMax + 1 ), inMax, ( int ) lv );
-      int32_t v;
-      if( rightShift > 0 ) v = ( int32_t ) ( ( uint32_t ) ( cl * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
-      else                 v = ( int32_t ) ( ( uint32_t ) ( cl * iscale ) << ( -rightShift ) );
-      dq = clip3i( -32768, 32767, v );
+      const int32_t cv = c[bp];
+      const uint32_t m = ( uint32_t ) ( int32_t ) ( ( ( int64_t ) abs( cv ) * P.scale + P.add ) >> P.qBits );          // Quant.cpp:219-220
+      if( m )
+      {
+        atomicAdd( &par[t].absSum, m );
+        lv = clip3i( -32768, 32767, cv < 0 ? -( int32_t ) m : ( int32_t ) m );
+        const int cl = clip3i( -( P.inMax + 1 ), P.inMax, lv );                                                           // DeQuantCore, Quant.cpp:232-262
+        int32_t v;
+        if( P.rightShift > 0 ) v = ( int32_t ) ( ( uint32_t ) ( cl * P.iscale ) + ( 1u << ( P.rightShift - 1 ) ) ) >> P.rightShift;
+        else                   v = ( int32_t ) ( ( uint32_t ) ( cl * P.iscale ) << ( -P.rightShift ) );
+        dq = clip3i( -32768, 32767, v );
+      }
     }
-    L.b[t * slot + bp] = dq;
-    if( level ) level[( size_t ) ( tu0 + t ) * area + bp] = lv;
+    const int by = bp >> q.log2w, bx = bp & ( q.w - 1 );
+    s[y.r1 + bp] = ( int16_t ) lv;
+    s[bx * y.ph + by] = ( int16_t ) dq;
   }
   __syncthreads();
-  // move dequantised coefficients to the inverse transform's input buffer
-  for( int o = tid; o < nTu * area; o += nthr ) { const int t = o / area, p = o - t * area; L.a[t * slot + p] = L.b[t * slot + p]; }
-  __syncthreads();
-  inv2dLds( gi, L, nTu, tid, nthr );                       // L.a[t] = reconstructed residual, raster
-  for( int o = tid; o < nTu * area; o += nthr )
+  if( phaseLimit == 5 ) return;
+  if( level )
   {
-    const int t = o / area, p = o - t * area, y = p / w, x = p - y * w;
-    const int r = L.a[t * slot + p];
-    if( rec ) rec[( size_t ) ( tu0 + t ) * area + p] = ( int16_t ) r;
-    const int d = ( int ) resi[resiOff[tu0 + t] + ( ptrdiff_t ) y * resiStride + x] - r;
-    if( d ) atomicAdd( &red[t].sse, ( unsigned long long ) ( ( long long ) d * d ) );
+    if( area >= 8 )
+    {
+      const int lc = la - 3;
+      for( int o = tid; o < ( nTu << lc ); o += nthr )
+      {
+        const int t = o >> lc, c8 = ( o & ( ( 1 << lc ) - 1 ) ) << 3;
+        *reinterpret_cast<u32x4*>( level + ( size_t ) ( tu0 + t ) * area + c8 ) = *reinterpret_cast<const u32x4*>( L.tu + t * y.slot + y.r1 + c8 );
+      }
+    }
+    else
+      for( int o = tid; o < ( nTu << la ); o += nthr ) level[( size_t ) tu0 * area + o] = L.tu[( o >> la ) * y.slot + y.r1 + ( o & ( area - 1 ) )];
+    __syncthreads();
+  }
+  if( phaseLimit == 6 ) return;
+  inv2d( gi, y, L, nTu, tid, nthr );                        // R2 = reconstructed residual (raster int16)
+  if( phaseLimit == 7 ) return;
+  if( w >= 8 )
+  {
+    // 8 samples per lane: 16-byte LDS read of the reconstruction, 16-byte residual load and reconstruction store, DPP sum over the TU's lanes
+    struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+    const int lc = la - 3, Gc = ( area >> 3 ) < 64 ? ( area >> 3 ) : 64;
+    for( int o = tid; o < ( nTu << lc ); o += nthr )
+    {
+      const int t = o >> lc, c = o & ( ( 1 << lc ) - 1 ), yy = c >> ( gf.log2w - 3 ), x = ( c & ( ( w >> 3 ) - 1 ) ) << 3;
+      const u32x4 rv = *reinterpret_cast<const u32x4*>( L.tu + t * y.slot + y.r2 + ( c << 3 ) );
+      const u32x4 ov = reinterpret_cast<const U16*>( resi + resiOff[tu0 + t] + ( ptrdiff_t ) yy * resiStride + x )->v;
+      if( rec ) *reinterpret_cast<u32x4*>( rec + ( size_t ) ( tu0 + t ) * area + ( c << 3 ) ) = rv;
+      const uint32_t rr[4] = { rv.x, rv.y, rv.z, rv.w }, oo[4] = { ov.x, ov.y, ov.z, ov.w };
+      unsigned long long e = 0;
+#pragma unroll
+      for( int k = 0; k < 4; k++ )
+      {
+        const int d0 = ( int ) ( int16_t ) ( oo[k] & 0xffff ) - ( int ) ( int16_t ) ( rr[k] & 0xffff ), d1 = ( ( int ) oo[k] >> 16 ) - ( ( int ) rr[k] >> 16 );
+        e += ( unsigned long long ) ( ( long long ) d0 * d0 ) + ( unsigned long long ) ( ( long long ) d1 * d1 );
+      }
+      e = vvhipGroupSum64( e, Gc, lane );
+      if( ( lane & ( Gc - 1 ) ) == 0 && e ) atomicAdd( &par[t].sse, e );
+    }
+  }
+  else
+  for( int o = tid; o < ( nTu << la ); o += nthr )
+  {
+    const int t = o >> la, p = o & ( area - 1 ), yy = p >> gf.log2w, x = p & ( w - 1 );
+    const int r = L.tu[t * y.slot + y.r2 + p];
+    if( rec ) rec[( size_t ) tu0 * area + o] = ( int16_t ) r;
+    const int d = ( int ) resi[resiOff[tu0 + t] + ( ptrdiff_t ) yy * resiStride + x] - r;
+    unsigned long long e = grpAdd64( ( unsigned long long ) ( ( long long ) d * d ), G );
+    if( sub == 0 && e ) atomicAdd( &par[t].sse, e );
   }
   __syncthreads();
   if( stats )
     for( int t = tid; t < nTu; t += nthr )
     {
-      vvhip_tu_stats st; st.abs_sum = ( int32_t ) red[t].absSum; st.last_scan_pos = red[t].last; st.need_rdoq = red[t].need; st.pad = 0; st.sse = red[t].sse;
+      vvhip_tu_stats st; st.abs_sum = ( int32_t ) par[t].absSum; st.last_scan_pos = par[t].last; st.need_rdoq = ( int32_t ) par[t].need; st.pad = 0; st.sse = par[t].sse;
       stats[tu0 + t] = st;
     }
+}
+
+__global__ void __launch_bounds__( 256 )
+dequantCoreKernel( int maxX, int maxY, int scale, const int16_t* __restrict__ q, size_t qStride, int32_t* __restrict__ coef, int rightShift, int inMax, int32_t trMax )
+{
+  const int w = maxX + 1, total = w * ( maxY + 1 );
+  for( int n = blockIdx.x * blockDim.x + threadIdx.x; n < total; n += gridDim.x * blockDim.x )
+  {
+    const int y = n / w, x = n - y * w;
+    const int c = clip3i( -( inMax + 1 ), inMax, ( int ) q[x + y * qStride] );                                            // Quant.cpp:243
+    int32_t v;
+    if( rightShift > 0 ) v = ( int32_t ) ( ( uint32_t ) ( c * scale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;    // :244
+    else                 v = ( int32_t ) ( ( uint32_t ) ( c * scale ) << ( -rightShift ) );                              // :257
+    coef[n] = clip3i( -( trMax + 1 ), trMax, v );
+  }
+}
+
+__global__ void __launch_bounds__( 256 )
+needRdoqCoreKernel( const int32_t* __restrict__ coef, size_t num, int quantCoeff, long long offset, int shift, uint8_t* __restrict__ need )
+{
+  int any = 0;
+  for( size_t i = threadIdx.x; i < num; i += blockDim.x ) any |= ( int32_t ) ( ( ( int64_t ) abs( coef[i] ) * quantCoeff + offset ) >> shift ) != 0;   // Quant.cpp:264-278
+  __shared__ int sAny;
+  if( threadIdx.x == 0 ) sAny = 0;
+  __syncthreads();
+  if( any ) sAny = 1;
+  __syncthreads();
+  if( threadIdx.x == 0 ) *need = ( uint8_t ) sAny;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -486,11 +621,38 @@ bool makeQGeom( int w, int h, int bitDepth, QGeom& q )
   return true;
 }
 
-size_t trSmemBytes( const TrGeom& g, int tpb )
+int rowPitch( int n )   // odd number of 16-byte (8-sample) chunks per row: conflict-free ds_read_b128 across consecutive rows
 {
-  const int slot = g.w * ( g.h + 1 ) > g.h * ( g.w + 1 ) ? g.w * ( g.h + 1 ) : g.h * ( g.w + 1 );
-  return ( size_t ) 2 * tpb * slot * sizeof( int32_t ) + ( size_t ) ( g.w * g.w + g.h * g.h ) * sizeof( int16_t ) + 64;
+  const int ch = n < 8 ? n : 8;
+  int pu = n / ch;
+  if( pu > 1 && !( pu & 1 ) ) pu++;
+  return pu * ch;
 }
+
+TuLay makeLayout( const TrGeom& g, int trHor, int trVer )
+{
+  TuLay y;
+  y.pw = rowPitch( g.w ); y.ph = rowPitch( g.h );
+  const int area = g.w * g.h;
+  int r = g.h * y.pw > g.w * y.ph ? g.h * y.pw : g.w * y.ph;
+  if( r < area ) r = area;
+  r = ( r + 7 ) & ~7;
+  y.r1 = r; y.r2 = 2 * r; y.slot = 2 * r + 2 * area;
+  const bool same = g.w == g.h && trHor == trVer;
+  y.mTh = 0; y.mTv = same ? 0 : g.w * g.w;
+  const int nat = same ? g.w * g.w : g.w * g.w + g.h * g.h;
+  y.mThT = nat; y.mTvT = same ? nat : nat + g.w * g.w;
+  y.matElems = 2 * nat;
+  return y;
+}
+
+size_t trSmemBytes( const TuLay& y, int tpb )
+{
+  return ( size_t ) ( ( ( y.matElems + 7 ) & ~7 ) + ( ( tpb * y.slot + 7 ) & ~7 ) ) * sizeof( int16_t ) + ( size_t ) tpb * 320 + 64;   // + per-TU TuPar (312 B)
+}
+
+int launchTuRdo( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const int32_t* d_resi_off, int n, const TrGeom& gf, const TrGeom& gi, const TuLay& y,
+                 const QGeom& q, int tpb, int tr_hor, int tr_ver, const vvhip_tu_qp* d_qp, int thr_val, int16_t* d_level, int16_t* d_rec_resi, vvhip_tu_stats* d_stats );
 
 int teamLog2( int positions ) { int l = 0; while( ( 1 << ( l + 1 ) ) <= positions && l < 6 ) l++; return l; }
 
@@ -508,9 +670,10 @@ int vvhip_fwd_transform_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_s
   if( n == 0 ) return VVHIP_OK;
   const int area = width * height;
   const int tpb = area >= 256 ? 1 : 256 / area;
-  const size_t smem = trSmemBytes( g, tpb );
+  const TuLay y = makeLayout( g, tr_hor, tr_ver );
+  const size_t smem = trSmemBytes( y, tpb );
   hipLaunchKernelGGL( fwdTransformKernel, dim3( ( n + tpb - 1 ) / tpb ), dim3( 256 ), smem, ctx->stream,
-                      d_resi, resi_stride, d_resi_off, n, g, tpb,
+                      d_resi, resi_stride, d_resi_off, n, g, y, tpb,
                       ctx->d_trMat + trMatOffset( tr_hor, g.log2w ), ctx->d_trMat + trMatOffset( tr_ver, g.log2h ), d_coef );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
@@ -526,9 +689,10 @@ int vvhip_inv_transform_batch( vvhip_ctx* ctx, const int32_t* d_coef, int n, int
   if( n == 0 ) return VVHIP_OK;
   const int area = width * height;
   const int tpb = area >= 256 ? 1 : 256 / area;
-  const size_t smem = trSmemBytes( g, tpb );
+  const TuLay y = makeLayout( g, tr_hor, tr_ver );
+  const size_t smem = trSmemBytes( y, tpb );
   hipLaunchKernelGGL( invTransformKernel, dim3( ( n + tpb - 1 ) / tpb ), dim3( 256 ), smem, ctx->stream,
-                      d_coef, n, g, tpb, ctx->d_trMat + trMatOffset( tr_hor, g.log2w ), ctx->d_trMat + trMatOffset( tr_ver, g.log2h ),
+                      d_coef, n, g, y, tpb, ctx->d_trMat + trMatOffset( tr_hor, g.log2w ), ctx->d_trMat + trMatOffset( tr_ver, g.log2h ),
                       d_resi, resi_stride, d_resi_off );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
@@ -575,6 +739,26 @@ int vvhip_need_rdoq_batch( vvhip_ctx* ctx, const int32_t* d_coef, int n, int wid
   return VVHIP_OK;
 }
 
+int vvhip_dequant_core( vvhip_ctx* ctx, int max_x, int max_y, int scale, const int16_t* d_level, size_t level_stride, int32_t* d_coef,
+                        int right_shift, int input_maximum, int32_t transform_maximum )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( max_x < 0 || max_y < 0 || max_x > 127 || max_y > 127 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dequant_core: bad block" );
+  const int total = ( max_x + 1 ) * ( max_y + 1 );
+  hipLaunchKernelGGL( dequantCoreKernel, dim3( ( total + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, max_x, max_y, scale, d_level, level_stride, d_coef,
+                      right_shift, input_maximum, transform_maximum );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_need_rdoq_core( vvhip_ctx* ctx, const int32_t* d_coef, size_t num_coeff, int quant_coeff, int64_t offset, int shift, uint8_t* d_need )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  hipLaunchKernelGGL( needRdoqCoreKernel, dim3( 1 ), dim3( 256 ), 0, ctx->stream, d_coef, num_coeff, quant_coeff, ( long long ) offset, shift, d_need );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
 int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const int32_t* d_resi_off, int n, int width, int height,
                         int tr_hor, int tr_ver, int bit_depth, const vvhip_tu_qp* d_qp, int thr_val,
                         int16_t* d_level, int16_t* d_rec_resi, vvhip_tu_stats* d_stats )
@@ -587,13 +771,25 @@ int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
   if( n == 0 ) return VVHIP_OK;
   const int area = width * height;
   const int tpb = area >= 256 ? 1 : 256 / area;
-  const size_t smem = ( ( trSmemBytes( gf, tpb ) + 15 ) & ~( size_t ) 15 ) + ( size_t ) tpb * sizeof( TuRed ) + 16;
-  hipLaunchKernelGGL( tuRdoKernel, dim3( ( n + tpb - 1 ) / tpb ), dim3( 256 ), smem, ctx->stream,
-                      d_resi, resi_stride, d_resi_off, n, gf, gi, q, tpb,
-                      ctx->d_trMat + trMatOffset( tr_hor, gf.log2w ), ctx->d_trMat + trMatOffset( tr_ver, gf.log2h ),
-                      ctx->d_scan + scanOffset( q.log2w, q.log2h ), d_qp, thr_val, d_level, d_rec_resi, d_stats );
-  VVHIP_LAUNCH_CHECK( ctx );
-  return VVHIP_OK;
+  const TuLay y = makeLayout( gf, tr_hor, tr_ver );
+  const int tpbF = area >= 1024 ? 1 : 1024 / area;          // ~1024 samples per workgroup: 4 independent iterations per thread and phase
+  return launchTuRdo( ctx, d_resi, resi_stride, d_resi_off, n, gf, gi, y, q, tpbF, tr_hor, tr_ver, d_qp, thr_val, d_level, d_rec_resi, d_stats );
 }
 
 } // extern "C"
+
+namespace {
+int launchTuRdo( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const int32_t* d_resi_off, int n, const TrGeom& gf, const TrGeom& gi, const TuLay& y,
+                 const QGeom& q, int tpb, int tr_hor, int tr_ver, const vvhip_tu_qp* d_qp, int thr_val, int16_t* d_level, int16_t* d_rec_resi, vvhip_tu_stats* d_stats )
+{
+  static const int phaseLimit = getenv( "VVHIP_TU_PHASES" ) ? atoi( getenv( "VVHIP_TU_PHASES" ) ) : 0;   // profiling aid: stop after phase k
+  const size_t smem = trSmemBytes( y, tpb );
+  if( smem > 64 * 1024 ) VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) tuRdoKernel, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) smem ) );
+  hipLaunchKernelGGL( tuRdoKernel, dim3( ( n + tpb - 1 ) / tpb ), dim3( 256 ), smem, ctx->stream,
+                      d_resi, resi_stride, d_resi_off, n, gf, gi, y, q, tpb,
+                      ctx->d_trMat + trMatOffset( tr_hor, gf.log2w ), ctx->d_trMat + trMatOffset( tr_ver, gf.log2h ),
+                      ctx->d_scan + scanOffset( q.log2w, q.log2h ), d_qp, thr_val, d_level, d_rec_resi, d_stats, phaseLimit );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+} // namespace

@@ -64,5 +64,6 @@ def broadcast_picture(storage, src_rank):
     """broadcast one picture plane (int16 tensor incl. margins) from its owner to every rank; RCCL over xGMI on GPUs.
     1080p luma incl. margin = 5.2 MB, 4K = 18.6 MB: one message per picture, never per block."""
     if dist.is_initialized():
-        dist.broadcast(storage, src=src_rank)
+        # neither RCCL nor gloo has a 16-bit integer type: ship the plane as bytes (same memory, no copy)
+        dist.broadcast(storage.view(torch.uint8), src=src_rank)
     return storage

@@ -88,21 +88,28 @@ class FrameWorkload:
             # fused pipeline: read residual 2 B, write level 2 B + reconstructed residual 2 B per sample, 24 B stats per TU
             self.alg_bytes["TU"] = self.alg_bytes.get("TU", 0) + n * (6 * S * S + 24)
 
+        # launches of one kernel class are issued back to back so a class can be bracketed by ONE pair of stream events
+        self.dist_jobs.sort(key=lambda j: ("SAD", "HAD_fast", "SSE").index(j[0]))
+        self.class_launches = {"SAD": len(SIZES), "HAD_fast": len(SIZES), "SSE": len(SIZES), "TU": len(TU_SIZES)}
+
     # one pass of the hot path over the frame: 12 distortion launches + 3 fused TU launches
     def run(self, timers=None):
         hp = self.hp
+        prev = None
         for (func, S, ss, n, d_items, d_out, _) in self.dist_jobs:
-            if timers is not None:
+            if timers is not None and func != prev:
+                if prev is not None:
+                    timers.stop(prev)
                 timers.start(func)
+                prev = func
             hp.dist_batch(func, self.org, self.ref, d_items, n, S, S, ss, self.bit_depth, out=d_out)
-            if timers is not None:
-                timers.stop(func)
+        if timers is not None:
+            timers.stop(prev)
+            timers.start("TU")
         for (S, n, d_off, d_qp, lvl, rec, st, _, _) in self.tu_jobs:
-            if timers is not None:
-                timers.start("TU")
             hp.tu_rdo(self.resi, d_off, n, S, S, d_qp, 0, 0, self.bit_depth, 8, lvl, rec, st)
-            if timers is not None:
-                timers.stop("TU")
+        if timers is not None:
+            timers.stop("TU")
 
     def checksum(self):
         """order-independent digest of every result of the last run (used by tests: equal across ranks / reruns)"""
