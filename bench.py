@@ -69,7 +69,6 @@ def cpu_baseline(wl, budget_s=12.0):
     resi = np.ascontiguousarray(wl.resi.storage.cpu().numpy())
     org_p = org.ctypes.data + 2 * wl.org.origin
     ref_p = ref.ctypes.data + 2 * wl.ref.origin
-    frac = 0.02
     use_ref = O.RefLib.available()
     if use_ref:
         R = O.RefLib(1)
@@ -85,37 +84,45 @@ def cpu_baseline(wl, budget_s=12.0):
         L.orc_dist_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     fidx = {"SSE": 0, "SAD": 1, "HAD": 2, "HAD_fast": 3}
 
-    def run_sample(fr):
+    def run_sample(fr, passes=1):
         jobs = []
         for (func, S, ss, n, _, _, items) in wl.dist_jobs:
             m = max(cores, int(n * fr))
-            jobs.append(("d", func, S, ss, items[:m].copy()))
+            jobs.append(("d", func, S, ss, items[:m]))
         if use_ref:
             for (S, n, _, _, _, _, _, off, qps) in wl.tu_jobs:
                 m = max(cores, int(n * fr))
-                jobs.append(("t", S, off[:m].copy(), qps[:m].copy()))
-
-        def worker(t):
+                jobs.append(("t", S, off[:m], qps[:m]))
+        # per-thread slices are prepared before the clock starts; each thread then loops `passes` times inside ctypes calls (GIL released)
+        plans = []
+        for t in range(cores):
+            plan = []
             for j in jobs:
                 if j[0] == "d":
-                    _, func, S, ss, items = j
-                    sl = items[t::cores]
-                    sl = np.ascontiguousarray(sl)
-                    out = np.zeros(len(sl), np.uint64)
-                    if use_ref:
-                        L.vvref_dist_batch(1, R._df[func], org_p, wl.org.stride, ref_p, wl.ref.stride, S, S, wl.bit_depth, ss,
-                                           sl.ctypes.data, len(sl), out.ctypes.data)
-                    else:
-                        L.orc_dist_batch(fidx[func], org_p, wl.org.stride, ref_p, wl.ref.stride, S, S, ss, sl.ctypes.data, len(sl), out.ctypes.data)
+                    sl = np.ascontiguousarray(j[4][t::cores])
+                    plan.append(("d", j[1], j[2], j[3], sl, np.zeros(len(sl), np.uint64)))
                 else:
-                    _, S, off, qps = j
-                    o = np.ascontiguousarray(off[t::cores])
+                    o = np.ascontiguousarray(j[2][t::cores])
                     qf = np.zeros((len(o), 2), np.int16)
-                    qf[:, 0] = qps[t::cores]
+                    qf[:, 0] = j[3][t::cores]
                     qf[:, 1] = 2
-                    sse = np.zeros(len(o), np.uint64)
-                    L.vvref_tu_rdo_batch(1, resi.ctypes.data, wl.resi.stride, o.ctypes.data, len(o), S, S, wl.bit_depth, qf.ctypes.data, 8,
-                                         None, None, sse.ctypes.data)
+                    plan.append(("t", j[1], o, qf, np.zeros(len(o), np.uint64)))
+            plans.append(plan)
+
+        def worker(t):
+            for _ in range(passes):
+                for j in plans[t]:
+                    if j[0] == "d":
+                        _, func, S, ss, sl, out = j
+                        if use_ref:
+                            L.vvref_dist_batch(1, R._df[func], org_p, wl.org.stride, ref_p, wl.ref.stride, S, S, wl.bit_depth, ss,
+                                               sl.ctypes.data, len(sl), out.ctypes.data)
+                        else:
+                            L.orc_dist_batch(fidx[func], org_p, wl.org.stride, ref_p, wl.ref.stride, S, S, ss, sl.ctypes.data, len(sl), out.ctypes.data)
+                    else:
+                        _, S, o, qf, sse = j
+                        L.vvref_tu_rdo_batch(1, resi.ctypes.data, wl.resi.stride, o.ctypes.data, len(o), S, S, wl.bit_depth, qf.ctypes.data, 8,
+                                             None, None, sse.ctypes.data)
         th = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
         t0 = time.perf_counter()
         for x in th:
@@ -124,14 +131,11 @@ def cpu_baseline(wl, budget_s=12.0):
             x.join()
         return time.perf_counter() - t0
 
-    run_sample(0.002)                       # page in / warm caches
-    dt = run_sample(frac)
-    passes = 1
-    if dt < budget_s / 4:                   # grow the sample towards the budget (about 10-30 s of CPU work summed over the cores)
-        target = frac * (budget_s / 2) / max(dt, 1e-3)
-        frac = min(1.0, target)
-        passes = max(1, min(64, int(target / frac)))
-        dt = sum(run_sample(frac) for _ in range(passes))
+    run_sample(0.01)                        # page in / warm caches
+    frac = 1.0
+    dt1 = run_sample(frac, 1)
+    passes = int(max(1, min(4000, (budget_s / 3.0) / max(dt1, 1e-4))))
+    dt = run_sample(frac, passes) if passes > 1 else dt1
     fps = frac * passes / dt
     note = "" if use_ref else " (transform/quant not in the port sample: distortion only)"
     return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
