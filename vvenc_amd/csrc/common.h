@@ -79,6 +79,27 @@ __device__ __forceinline__ uint32_t vvhipGroupSum32( uint32_t v, int G, int lane
   }
   return v;
 }
+#define VVHIP_GROUP_REDUCE( NAME, OP )                                                                                         \
+__device__ __forceinline__ uint32_t NAME( uint32_t v, int G, int lane )                                                          \
+{                                                                                                                                \
+  if( G >= 2 )  { const uint32_t o = ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR1 ); v = OP; }                                      \
+  if( G >= 4 )  { const uint32_t o = ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR2 ); v = OP; }                                      \
+  if( G >= 8 )  { const uint32_t o = ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_HALF_MIRROR ); v = OP; }                               \
+  if( G >= 16 ) { const uint32_t o = ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_MIRROR ); v = OP; }                                    \
+  if( G >= 32 )                                                                                                                  \
+  {                                                                                                                              \
+    uint32_t r[4] = { ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 0 ), ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 16 ),       \
+                      ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 32 ), ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 48 ) };    \
+    uint32_t a, b;                                                                                                               \
+    { const uint32_t v = r[0], o = r[1]; a = OP; } { const uint32_t v = r[2], o = r[3]; b = OP; }                                \
+    if( G == 64 ) { const uint32_t v = a, o = b; a = OP; b = a; }                                                                \
+    v = lane < 32 ? a : b;                                                                                                       \
+  }                                                                                                                              \
+  return v;                                                                                                                      \
+}
+VVHIP_GROUP_REDUCE( vvhipGroupMax32, ( o > v ? o : v ) )
+VVHIP_GROUP_REDUCE( vvhipGroupOr32, ( v | o ) )
+
 // exact 64-bit group sum of per-lane values < 2^50 through two 32-bit limbs (24-bit split)
 __device__ __forceinline__ unsigned long long vvhipGroupSum64( unsigned long long e, int G, int lane )
 {

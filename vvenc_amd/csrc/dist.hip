@@ -232,6 +232,84 @@ hadKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Hadamard SATD, one whole tile per LANE (tiles up to 64 differences: 8x8, 16x16_fast, 8x4, 4x8, 4x4, 2x2).
+// Both butterfly directions run on registers: no cross-lane traffic at all and ~2-3x fewer instructions per
+// sample than the row-per-lane form above (which remains for the 128-difference 16x8 / 8x16 tiles).
+// A candidate's tiles sit on LPC consecutive lanes (LPC = min(#tiles, 64), power of two) and are summed with DPP.
+// ---------------------------------------------------------------------------------------------
+template<int TW, int TH, bool FAST16>
+__global__ void __launch_bounds__( 256 )
+hadTileKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
+               int tilesX, int tilesPerCand, int log2Lpc,
+               const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+{
+  constexpr int PX = FAST16 ? 16 : TW, PY = FAST16 ? 16 : TH;
+  const int gid  = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lpc  = 1 << log2Lpc;
+  const int cand = gid >> log2Lpc;
+  const int lt   = gid & ( lpc - 1 );
+  const bool valid = cand < n;
+  int orgOff = 0, curOff = 0;
+  if( valid ) { const vvhip_dist_item it = items[cand]; orgOff = it.org_off; curOff = it.cur_off; }
+  const int tiles = valid ? tilesPerCand : 0;
+
+  uint32_t sum = 0;
+  for( int t = lt; t < tiles; t += lpc )
+  {
+    const int ty = t / tilesX, tx = t - ty * tilesX;
+    const int16_t* po = org + orgOff + ( ptrdiff_t ) ( ty * PY ) * orgStride + tx * PX;
+    const int16_t* pc = cur + curOff + ( ptrdiff_t ) ( ty * PY ) * curStride + tx * PX;
+    int d[TH][TW];
+#pragma unroll
+    for( int r = 0; r < TH; r++ )
+    {
+      if( FAST16 )
+      {
+        int ao[8], ac[8];
+        avgRow16( po + ( ptrdiff_t ) ( 2 * r ) * orgStride, orgStride, ao );
+        avgRow16( pc + ( ptrdiff_t ) ( 2 * r ) * curStride, curStride, ac );
+#pragma unroll
+        for( int i = 0; i < 8; i++ ) d[r][i % TW] = ao[i] - ac[i];
+      }
+      else loadRowDiff<TW>( po + ( ptrdiff_t ) r * orgStride, pc + ( ptrdiff_t ) r * curStride, d[r] );
+      // horizontal WHT of this row
+#pragma unroll
+      for( int len = 1; len < TW; len <<= 1 )
+#pragma unroll
+        for( int i = 0; i < TW; i += 2 * len )
+#pragma unroll
+          for( int j = i; j < i + len; j++ ) { const int a = d[r][j], b = d[r][j + len]; d[r][j] = a + b; d[r][j + len] = a - b; }
+    }
+    // vertical WHT
+#pragma unroll
+    for( int len = 1; len < TH; len <<= 1 )
+#pragma unroll
+      for( int i = 0; i < TH; i += 2 * len )
+#pragma unroll
+        for( int j = i; j < i + len; j++ )
+#pragma unroll
+          for( int c = 0; c < TW; c++ ) { const int a = d[j][c], b = d[j + len][c]; d[j][c] = a + b; d[j + len][c] = a - b; }
+    uint32_t s = 0;
+#pragma unroll
+    for( int r = 0; r < TH; r++ )
+#pragma unroll
+      for( int c = 0; c < TW; c++ ) s += ( uint32_t ) abs( d[r][c] );
+    const uint32_t dc = ( uint32_t ) abs( d[0][0] );
+    s = s - dc + ( dc >> 2 );
+    uint32_t v;
+    if( FAST16 )        v = ( ( s + 2 ) >> 2 ) << 2;                                                                   // RdCost.cpp:1220-1222
+    else if( TW != TH ) v = ( uint32_t ) ( int ) ( ( double ) ( int ) s / __builtin_sqrt( ( double ) ( TW * TH ) ) * 2 );  // :1682,1763
+    else if( TW == 8 )  v = ( s + 2 ) >> 2;                                                                            // :1319
+    else if( TW == 4 )  v = ( s + 1 ) >> 1;                                                                            // :1121
+    else                v = s;                                                                                         // :1020-1023
+    sum += v;
+  }
+  // per-lane sums stay below 2^32 (<= 4 tiles x 64 x 2^20); the candidate total can exceed it only for full-range int16 data -> 64-bit group sum
+  const uint64_t tot = vvhipGroupSum64( sum, lpc, threadIdx.x & 63 );
+  if( valid && lt == 0 ) out[cand] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
 // SAD cost surface: one workgroup per block; the (w+2rx) x (h'+2ry) reference window is staged in
 // LDS once (coalesced row reads), the block's original rows live in LDS too; each wave then walks
 // displacements, lanes split the block's row segments.
@@ -327,18 +405,38 @@ int launchHad( vvhip_ctx* ctx, const int16_t* d_org, int os, const int16_t* d_cu
   return VVHIP_OK;
 }
 
+template<int TW, int TH, bool FAST16>
+int launchHadTile( vvhip_ctx* ctx, const int16_t* d_org, int os, const int16_t* d_cur, int cs, int w, int h,
+                   const vvhip_dist_item* items, int n, uint64_t* out )
+{
+  constexpr int PX = FAST16 ? 16 : TW, PY = FAST16 ? 16 : TH;
+  const int tilesX = w / PX, tiles = tilesX * ( h / PY );
+  int lpc = pow2Floor( tiles );
+  if( lpc > 64 ) lpc = 64;
+  if( tiles % lpc != 0 ) lpc = 1;
+  const int log2Lpc = ilog2i( lpc );
+  const long threads = ( long ) n * lpc;
+  const int block = 256;
+  const unsigned grid = ( unsigned ) ( ( threads + block - 1 ) / block );
+  if( grid == 0 ) return VVHIP_OK;
+  hipLaunchKernelGGL( ( hadTileKernel<TW, TH, FAST16> ), dim3( grid ), dim3( block ), 0, ctx->stream,
+                      d_org, os, d_cur, cs, tilesX, tiles, log2Lpc, items, n, out );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
 // tile-selection ladder of xGetHADs<fastHad>, RdCost.cpp:1836-1935
 int launchHadLadder( vvhip_ctx* ctx, bool fast, const int16_t* d_org, int os, const int16_t* d_cur, int cs, int w, int h,
                      const vvhip_dist_item* items, int n, uint64_t* out )
 {
   if( w > h && ( h & 7 ) == 0 && ( w & 15 ) == 0 )      return launchHad<16, 8, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
   else if( w < h && ( w & 7 ) == 0 && ( h & 15 ) == 0 ) return launchHad<8, 16, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
-  else if( w > h && ( h & 3 ) == 0 && ( w & 7 ) == 0 )  return launchHad<8, 4, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
-  else if( w < h && ( w & 3 ) == 0 && ( h & 7 ) == 0 )  return launchHad<4, 8, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
-  else if( fast && h % 32 == 0 && w % 32 == 0 && h == w ) return launchHad<8, 8, true>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
-  else if( h % 8 == 0 && w % 8 == 0 )                   return launchHad<8, 8, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
-  else if( h % 4 == 0 && w % 4 == 0 )                   return launchHad<4, 4, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
-  else if( h % 2 == 0 && w % 2 == 0 )                   return launchHad<2, 2, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( w > h && ( h & 3 ) == 0 && ( w & 7 ) == 0 )  return launchHadTile<8, 4, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( w < h && ( w & 3 ) == 0 && ( h & 7 ) == 0 )  return launchHadTile<4, 8, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( fast && h % 32 == 0 && w % 32 == 0 && h == w ) return launchHadTile<8, 8, true>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( h % 8 == 0 && w % 8 == 0 )                   return launchHadTile<8, 8, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( h % 4 == 0 && w % 4 == 0 )                   return launchHadTile<4, 4, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
+  else if( h % 2 == 0 && w % 2 == 0 )                   return launchHadTile<2, 2, false>( ctx, d_org, os, d_cur, cs, w, h, items, n, out );
   return vvhip_fail( ctx, VVHIP_E_ARG, "Hadamard: invalid size %dx%d (reference THROWs \"Invalid size\", RdCost.cpp:1934)", w, h );
 }
 

@@ -567,6 +567,236 @@ tuRdoKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t* __
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Fused TU pipeline, row-per-lane form for square N x N TUs (N = 8, 16, 32).
+// The N lanes of a TU sit in ONE wavefront, so the whole pipeline needs no workgroup barrier after the ROM is staged:
+//   lane r holds residual row r in registers -> forward rows (all N frequencies of its row) -> LDS transpose ->
+//   lane c holds column c of the intermediate -> forward columns -> the N coefficients of column c stay in registers ->
+//   QuantCore / DeQuantCore on registers (significance through DPP max/or over the TU's lanes) ->
+//   inverse columns straight from registers -> LDS transpose -> inverse rows -> reconstruction row + SSE against the
+//   residual row that never left the registers.
+// Matrix rows are wave-wide LDS broadcasts (16-byte reads), every multiply is v_dot2_i32_i16; ~6x fewer instructions per
+// sample than the sample-per-lane kernel above (which remains for non-square, 4-, 2- and 64-point TUs).
+// --------------------------------------------------------------------------------------------
+template<int N, int SPLIT>
+__global__ void __launch_bounds__( 256 )
+tuRdoRowKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t* __restrict__ resiOff, int n,
+                TrGeom gf, TrGeom gi, QGeom q, const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
+                const uint16_t* __restrict__ scan, const vvhip_tu_qp* __restrict__ qps, int thrVal,
+                int16_t* __restrict__ level, int16_t* __restrict__ rec, vvhip_tu_stats* __restrict__ stats )
+{
+  // SPLIT lanes share one row / column: lane (line, part) produces outputs [part*NO, (part+1)*NO) of its line; LPT lanes per TU (<= 64).
+  // Output loops are rolled (8 outputs per trip); per-lane coefficients live in a private LDS column (lane-major, conflict-free).
+  constexpr int LPT = N * SPLIT, TPB = 256 / LPT, ND = N / 2, NC = N / 8, NO = N / SPLIT, NOC = NO / 8;
+  constexpr int P = N == 8 ? 8 : N + 8;                       // tile row pitch (int16): odd number of 16-byte chunks
+  constexpr int LINES = 256 / SPLIT;                          // rows (= columns) handled by a workgroup
+  static_assert( LPT <= 64 && NO >= 8 && ( SPLIT == 1 || SPLIT == 2 ), "geometry" );
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sMat[4][N * N];       // Th, Tv, Th^T, Tv^T
+  __shared__ __attribute__( ( aligned( 16 ) ) ) uint16_t sInv[N * N];         // raster position -> scan position
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTile[TPB][N * P];
+  __shared__ int32_t  sCoef[NO][256];                                         // [output][thread]: private per-lane coefficients
+  __shared__ uint32_t sDq[ND][LINES];                                         // [k pair][line]: dequantised column, int16 pairs
+  struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+
+  const int tid = threadIdx.x;
+  for( int i = tid; i < N * N; i += 256 )
+  {
+    const int k = i / N, j = i - k * N;
+    const int16_t a = matH[i], b = matV[i];
+    sMat[0][i] = a; sMat[1][i] = b; sMat[2][j * N + k] = a; sMat[3][j * N + k] = b;
+    sInv[scan[i]] = ( uint16_t ) i;
+  }
+  __syncthreads();
+
+  const int tl = tid / LPT, li = tid & ( LPT - 1 ), r = li / SPLIT, part = li & ( SPLIT - 1 ), lane = tid & 63;
+  const int line = tid / SPLIT;                               // row / column index inside the workgroup
+  const int o0 = part * NO;                                   // first output index of this lane
+  const int tu = blockIdx.x * TPB + tl;
+  const bool valid = tu < n;
+  int16_t* tile = sTile[tl];
+  const int16_t* src = resi + ( valid ? resiOff[tu] : 0 ) + ( ptrdiff_t ) r * resiStride;
+
+#define DOT_ROW( ACC, VEC, MROW ) { ACC = 0; _Pragma( "unroll" ) for( int c_ = 0; c_ < NC; c_++ ) {                          \
+      const u32x4 m_ = *reinterpret_cast<const u32x4*>( ( MROW ) + 8 * c_ );                                                  \
+      ACC = dot2( VEC[4 * c_], m_.x, ACC ); ACC = dot2( VEC[4 * c_ + 1], m_.y, ACC ); ACC = dot2( VEC[4 * c_ + 2], m_.z, ACC ); ACC = dot2( VEC[4 * c_ + 3], m_.w, ACC ); } }
+#define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+
+  // ---- forward rows: tmp[j][r] = sat16( ( sum_k blk[r][k] * Th[j][k] + rnd ) >> shift1 )        (cpyCoeff + TrQuant.cpp:548)
+  {
+    uint32_t x[ND];
+#pragma unroll
+    for( int c = 0; c < NC; c++ )
+    {
+      u32x4 v = { 0, 0, 0, 0 };
+      if( valid ) v = reinterpret_cast<const U16*>( src + 8 * c )->v;
+      x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+    }
+    const int rnd1 = gf.shift1 > 0 ? 1 << ( gf.shift1 - 1 ) : 0;
+#pragma unroll 2
+    for( int jj = 0; jj < NO; jj++ )
+    {
+      const int j = o0 + jj;
+      int acc;
+      DOT_ROW( acc, x, &sMat[0][j * N] );
+      tile[j * P + r] = ( int16_t ) sat16( ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd1 ) >> gf.shift1 );
+    }
+  }
+  WAVE_SYNC();
+  // ---- forward columns (line = horizontal frequency c): coef[j2] = ( sum_k tmp[c][k] * Tv[j2][k] + rnd ) >> shift2   (TrQuant.cpp:549)
+  const int cidx = r;
+  {
+    uint32_t y[ND];
+#pragma unroll
+    for( int c = 0; c < NC; c++ ) { const u32x4 v = *reinterpret_cast<const u32x4*>( &tile[cidx * P + 8 * c] ); y[4 * c] = v.x; y[4 * c + 1] = v.y; y[4 * c + 2] = v.z; y[4 * c + 3] = v.w; }
+    const int rnd2 = 1 << ( gf.shift2 - 1 );
+    const bool colLive = cidx < N - gf.skipW;
+#pragma unroll 2
+    for( int jj = 0; jj < NO; jj++ )
+    {
+      const int j2 = o0 + jj;
+      int acc;
+      DOT_ROW( acc, y, &sMat[1][j2 * N] );
+      sCoef[jj][tid] = ( colLive && j2 < N - gf.skipH ) ? ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd2 ) >> gf.shift2 : 0;
+    }
+  }
+  // ---- quantiser constants of this TU
+  int scale, qBits;
+  const vvhip_tu_qp qq = valid ? qps[tu] : vvhip_tu_qp{ 32, 0 };
+  quantParams( q, qq.qp, scale, qBits );
+  const long long add  = ( long long ) ( ( qq.flags & 1 ) ? 171 : 85 ) << ( qBits - 9 );            // Quant.cpp:775
+  const long long addN = ( long long ) ( ( qq.flags & 2 ) ? 171 : 256 ) << ( qBits - 9 );           // Quant.cpp:874
+  const int32_t thres = qBits ? ( int32_t ) ( ( int64_t ) thrVal << ( qBits - 1 ) ) : ( int32_t ) ( ( int64_t ) ( thrVal >> 1 ) << qBits );
+  const int useThres = thres / ( scale << 2 );                                                      // Quant.cpp:173-180
+  const int trShift = 15 - q.bitDepth - q.log2w;
+  const int iscale = cInvQuantScales[0][qq.qp % 6];                                                  // Quant.cpp:601 (square: no sqrt2)
+  const int rightShift = 6 - ( trShift + qq.qp / 6 );                                                // Quant.cpp:561
+  int tgt = 32 + rightShift - 7; if( tgt > 16 ) tgt = 16;                                            // Quant.cpp:606
+  const int inMax = ( 1 << ( tgt - 1 ) ) - 1;
+
+  // ---- significance: last non-zero scan position, need-RDOQ flag, coefficient-group test (Quant.cpp:162-208, :264-278)
+  uint32_t last = 0, need = 0;
+  for( int jj = 0; jj < NO; jj++ )
+  {
+    const uint32_t si = sInv[( o0 + jj ) * N + cidx];
+    const int c = sCoef[jj][tid];
+    if( c != 0 && si > last ) last = si;
+    need |= ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) abs( c ) * scale + addN ) >> qBits ) != 0 );
+  }
+  last = vvhipGroupMax32( last, LPT, lane );
+  need = vvhipGroupOr32( need, LPT, lane );
+  if( last >= 16 )
+  {
+    uint32_t lo = 0, hi = 0;
+    for( int jj = 0; jj < NO; jj++ )
+    {
+      const uint32_t si = sInv[( o0 + jj ) * N + cidx];
+      if( si >= 16 && si <= last && abs( sCoef[jj][tid] ) > useThres ) { const int cg = si >> 4; if( cg < 32 ) lo |= 1u << cg; else hi |= 1u << ( cg - 32 ); }
+    }
+    lo = vvhipGroupOr32( lo, LPT, lane );
+    hi = N > 16 ? vvhipGroupOr32( hi, LPT, lane ) : 0u;
+    const unsigned long long big = ( ( unsigned long long ) hi << 32 ) | lo;
+    if( big == 0 ) last = 15;
+    else { const uint32_t g2 = 63 - __clzll( ( long long ) big ); if( g2 != ( last >> 4 ) ) last = g2 * 16 + 15; }
+  }
+  // ---- QuantCore + DeQuantCore (Quant.cpp:213-227, :232-262): level pairs -> tile (transpose for the raster store), dequantised pairs -> sDq
+  uint32_t absSum = 0;
+  for( int jj = 0; jj < NO; jj += 2 )
+  {
+    int lv[2], dq[2];
+#pragma unroll
+    for( int e = 0; e < 2; e++ )
+    {
+      lv[e] = 0; dq[e] = 0;
+      const int cv = sCoef[jj + e][tid];
+      if( cv != 0 && sInv[( o0 + jj + e ) * N + cidx] <= last )
+      {
+        const uint32_t m = ( uint32_t ) ( int32_t ) ( ( ( int64_t ) abs( cv ) * scale + add ) >> qBits );
+        if( m )
+        {
+          absSum += m;
+          lv[e] = clip3i( -32768, 32767, cv < 0 ? -( int32_t ) m : ( int32_t ) m );
+          const int cl = clip3i( -( inMax + 1 ), inMax, lv[e] );
+          int32_t v;
+          if( rightShift > 0 ) v = ( int32_t ) ( ( uint32_t ) ( cl * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
+          else                 v = ( int32_t ) ( ( uint32_t ) ( cl * iscale ) << ( -rightShift ) );
+          dq[e] = clip3i( -32768, 32767, v );
+        }
+      }
+    }
+    tile[( o0 + jj ) * P + cidx] = ( int16_t ) lv[0];
+    tile[( o0 + jj + 1 ) * P + cidx] = ( int16_t ) lv[1];
+    sDq[( o0 + jj ) / 2][line] = ( uint32_t ) ( dq[0] & 0xffff ) | ( ( uint32_t ) dq[1] << 16 );
+  }
+  absSum = vvhipGroupSum32( absSum, LPT, lane );
+  WAVE_SYNC();
+  // ---- levels: raster rows -> HBM (16-byte stores)
+  if( level && valid )
+#pragma unroll
+    for( int c = 0; c < NOC; c++ )
+      *reinterpret_cast<u32x4*>( level + ( size_t ) tu * N * N + r * N + o0 + 8 * c ) = *reinterpret_cast<const u32x4*>( &tile[r * P + o0 + 8 * c] );
+  WAVE_SYNC();
+  // ---- inverse columns: t1[j][c] = clip( ( sum_k deq[k][c] * Tv[k][j] + 64 ) >> 7 ), c < N - skipW   (TrQuant.cpp:612)
+  {
+    uint32_t dqp[ND];
+#pragma unroll
+    for( int k = 0; k < ND; k++ ) dqp[k] = sDq[k][line];
+    const int rnd1 = 1 << ( gi.shift1 - 1 );
+    const bool colLive = cidx < N - gi.skipW;
+#pragma unroll 2
+    for( int jj = 0; jj < NO; jj++ )
+    {
+      const int j = o0 + jj;
+      int acc;
+      DOT_ROW( acc, dqp, &sMat[3][j * N] );
+      tile[j * P + cidx] = ( int16_t ) ( colLive ? sat16( ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd1 ) >> gi.shift1 ) : 0 );
+    }
+  }
+  WAVE_SYNC();
+  // ---- inverse rows: rec[r][j2] = clip( ( sum_k t1[r][k] * Th[k][j2] + rnd ) >> shift2 ); SSE against the residual row (re-read: L2 hit)
+  unsigned long long sse = 0;
+  {
+    uint32_t t[ND];
+#pragma unroll
+    for( int c = 0; c < NC; c++ ) { const u32x4 v = *reinterpret_cast<const u32x4*>( &tile[r * P + 8 * c] ); t[4 * c] = v.x; t[4 * c + 1] = v.y; t[4 * c + 2] = v.z; t[4 * c + 3] = v.w; }
+    const int rnd2 = 1 << ( gi.shift2 - 1 );
+    for( int c8 = 0; c8 < NOC; c8++ )
+    {
+      u32x4 xv = { 0, 0, 0, 0 };
+      if( valid ) xv = reinterpret_cast<const U16*>( src + o0 + 8 * c8 )->v;
+      const uint32_t xs[4] = { xv.x, xv.y, xv.z, xv.w };
+      uint32_t rp[4];
+#pragma unroll
+      for( int pr = 0; pr < 4; pr++ )
+      {
+        int rv[2];
+#pragma unroll
+        for( int e = 0; e < 2; e++ )
+        {
+          int acc;
+          DOT_ROW( acc, t, &sMat[2][( o0 + 8 * c8 + 2 * pr + e ) * N] );
+          rv[e] = sat16( ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd2 ) >> gi.shift2 );
+        }
+        rp[pr] = ( uint32_t ) ( rv[0] & 0xffff ) | ( ( uint32_t ) rv[1] << 16 );
+        const int d0 = ( int ) ( int16_t ) ( xs[pr] & 0xffff ) - rv[0], d1 = ( ( int ) xs[pr] >> 16 ) - rv[1];
+        sse += ( unsigned long long ) ( ( long long ) d0 * d0 ) + ( unsigned long long ) ( ( long long ) d1 * d1 );
+      }
+      if( rec && valid )
+      {
+        u32x4 v; v.x = rp[0]; v.y = rp[1]; v.z = rp[2]; v.w = rp[3];
+        *reinterpret_cast<u32x4*>( rec + ( size_t ) tu * N * N + r * N + o0 + 8 * c8 ) = v;
+      }
+    }
+  }
+#undef DOT_ROW
+#undef WAVE_SYNC
+  sse = vvhipGroupSum64( sse, LPT, lane );
+  if( stats && valid && li == 0 )
+  {
+    vvhip_tu_stats st; st.abs_sum = ( int32_t ) absSum; st.last_scan_pos = ( int32_t ) last; st.need_rdoq = ( int32_t ) need; st.pad = 0; st.sse = sse;
+    stats[tu] = st;
+  }
+}
+
 __global__ void __launch_bounds__( 256 )
 dequantCoreKernel( int maxX, int maxY, int scale, const int16_t* __restrict__ q, size_t qStride, int32_t* __restrict__ coef, int rightShift, int inMax, int32_t trMax )
 {
@@ -771,6 +1001,19 @@ int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
   if( n == 0 ) return VVHIP_OK;
   const int area = width * height;
   const int tpb = area >= 256 ? 1 : 256 / area;
+  if( width == height && ( width == 8 || width == 16 || width == 32 ) && !getenv( "VVHIP_TU_GENERIC" ) )
+  {
+    const int16_t* mh = ctx->d_trMat + trMatOffset( tr_hor, gf.log2w );
+    const int16_t* mv = ctx->d_trMat + trMatOffset( tr_ver, gf.log2h );
+    const uint16_t* sc = ctx->d_scan + scanOffset( q.log2w, q.log2h );
+#define ROWK( NN, SP ) hipLaunchKernelGGL( ( tuRdoRowKernel<NN, SP> ), dim3( ( n + ( 256 / ( NN * SP ) ) - 1 ) / ( 256 / ( NN * SP ) ) ), dim3( 256 ), 0, ctx->stream, \
+                                           d_resi, resi_stride, d_resi_off, n, gf, gi, q, mh, mv, sc, d_qp, thr_val, d_level, d_rec_resi, d_stats )
+    static const int split16 = getenv( "VVHIP_TU_SPLIT16" ) ? atoi( getenv( "VVHIP_TU_SPLIT16" ) ) : 2;
+    if( width == 8 ) ROWK( 8, 1 ); else if( width == 16 ) { if( split16 == 2 ) ROWK( 16, 2 ); else ROWK( 16, 1 ); } else ROWK( 32, 2 );
+#undef ROWK
+    VVHIP_LAUNCH_CHECK( ctx );
+    return VVHIP_OK;
+  }
   const TuLay y = makeLayout( gf, tr_hor, tr_ver );
   const int tpbF = area >= 1024 ? 1 : 1024 / area;          // ~1024 samples per workgroup: 4 independent iterations per thread and phase
   return launchTuRdo( ctx, d_resi, resi_stride, d_resi_off, n, gf, gi, y, q, tpbF, tr_hor, tr_ver, d_qp, thr_val, d_level, d_rec_resi, d_stats );
