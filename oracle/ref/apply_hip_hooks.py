@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Writes hook-enabled COPIES of four reference translation units into oracle/_ref/gen/src/ (build output, git-ignored).
+Nothing of the reference is stored in the repository: the script inserts one-line calls to g_vvhipHooks (oracle/ref/hip_hooks.h)
+at anchor lines it looks up in the files where they lie under /root/reference.  This is the executable form of the binding
+shown in INTEGRATION.md §2.
+
+usage: apply_hip_hooks.py <reference CommonLib dir> <output dir>"""
+import os
+import sys
+
+src, out = sys.argv[1], sys.argv[2]
+os.makedirs(out, exist_ok=True)
+
+
+def patch(name, edits):
+    s = open(os.path.join(src, name)).read()
+    for kind, anchor, text in edits:
+        assert s.count(anchor) == 1, (name, anchor, s.count(anchor))
+        if kind == "before":
+            s = s.replace(anchor, text + anchor)
+        elif kind == "after":
+            s = s.replace(anchor, anchor + text)
+        else:
+            s = s.replace(anchor, text)
+    open(os.path.join(out, name), "w").write(s)
+
+
+INC = '\n#include "hip_hooks.h"\n'
+patch("RdCost.cpp", [
+    ("after", '#include "RdCost.h"', INC),
+    ("before", "  m_costMode      = VVENC_COST_STANDARD_LOSSY;",
+     "  if( enableOpt && g_vvhipHooks.initRdCost ) g_vvhipHooks.initRdCost( this );\n"),
+])
+patch("Quant.cpp", [
+    ("after", '#include "Quant.h"', INC),
+    ("after", "  initQuantX86();\n#endif\n", "  if( g_vvhipHooks.initQuant ) g_vvhipHooks.initQuant( this );\n"),
+])
+patch("TrQuant.cpp", [
+    ("after", '#include "TrQuant.h"', INC),
+    ("before", "  TCoeff* block = m_blk;",
+     "  if( g_vvhipHooks.fwd2D && width > 1 && height > 1 && !tu.cu->lfnstIdx &&\n"
+     "      g_vvhipHooks.fwd2D( resi.buf, resi.stride, dstCoeff.buf, width, height, trTypeHor, trTypeVer, bitDepth ) ) return;\n"),
+    ("before", "  TCoeff *block = m_blk;",
+     "  if( g_vvhipHooks.inv2D && width > 1 && height > 1 && !( tu.cs->sps->LFNST && tu.cu->lfnstIdx ) &&\n"
+     "      g_vvhipHooks.inv2D( pCoeff.buf, pResidual.buf, pResidual.stride, width, height, trTypeHor, trTypeVer, bitDepth ) ) return;\n"),
+])
+patch("MCTF.cpp", [
+    ("after", '#include "MCTF.h"', INC),
+    ("after", "    initMCTF_ARM();\n#endif\n  }\n", "  if( enableOpt && g_vvhipHooks.initMCTF ) g_vvhipHooks.initMCTF( this );\n"),
+    ("before", "    Array2D<MotionVector> mv_0(width / (m_mctfUnitSize * 8) + 1, height / (m_mctfUnitSize * 8) + 1);",
+     "    if( !( g_vvhipHooks.mctfMe && g_vvhipHooks.mctfMe( this, srcPic.picBuffer, origBuf, srcPic.mvs, addLevel ) ) )\n    {\n"),
+    ("after", "    motionEstimationLuma(srcPic.mvs, origBuf, srcPic.picBuffer, m_mctfUnitSize, &mv_2, 1, true);\n", "    }\n"),
+])
+print("hooked copies written to", out)

@@ -1,0 +1,194 @@
+// hip_hooks.cpp — TEST INFRASTRUCTURE.  Wires the reference encoder's kernel tables (in the hook-enabled build of oracle/ref/Makefile)
+// to the HIP back-end through the table-shaped C++ shim (vvenc_amd/csrc/host/vvenc_hip_shim.h): per-call trampolines for
+// RdCost::m_afpDistortFunc / m_afpDistortFuncX5, Quant::xQuant/xDeQuant/xNeedRdoq, MCTF::m_motionErrorLuma* / m_calcVar, the fused
+// 2-D transform entries in TrQuant::xT/xIT and the whole-picture MCTF motion estimation.  This is what INTEGRATION.md §2 describes.
+#include <cstdint>
+#include <cstring>
+#include <sstream>
+#include <iostream>
+#include <fstream>
+#include <string>
+#include <vector>
+#include <list>
+#include <map>
+#include <array>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <algorithm>
+#include <memory>
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <cassert>
+#include <cstdarg>
+#include <iomanip>
+#include <numeric>
+#include <set>
+#include <unordered_map>
+#include <stdexcept>
+#include <exception>
+#include <utility>
+
+#define private public
+#define protected public
+#include "CommonLib/CommonDef.h"
+#include "CommonLib/Unit.h"
+#include "CommonLib/RdCost.h"
+#include "CommonLib/Quant.h"
+#include "CommonLib/MCTF.h"
+#include "CommonLib/Picture.h"
+#include "EncoderLib/EncCfg.h"
+#undef private
+#undef protected
+
+#include "hip_hooks.h"
+#include "../../vvenc_amd/csrc/host/vvenc_hip_shim.h"
+
+VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+
+namespace {
+
+vvhip::RdCost*   g_rd = nullptr;
+vvhip::QuantOps* g_q  = nullptr;
+vvhip::MCTFOps*  g_m  = nullptr;
+std::atomic<uint64_t> g_calls[8];     // dist, x5, fwd, inv, quant, dequant, needrdoq, mctf
+
+vvhip::DistParam conv( const vvenc::DistParam& dp )
+{
+  vvhip::DistParam d;
+  d.org.buf = dp.org.buf; d.org.stride = ( int ) dp.org.stride; d.org.width = dp.org.width; d.org.height = dp.org.height;
+  d.cur.buf = dp.cur.buf; d.cur.stride = ( int ) dp.cur.stride; d.cur.width = dp.org.width; d.cur.height = dp.org.height;
+  d.bitDepth = dp.bitDepth; d.subShift = dp.subShift; d.applyWeight = dp.applyWeight;
+  return d;
+}
+
+template<int IDX> vvenc::Distortion distTramp( const vvenc::DistParam& dp )
+{
+  g_calls[0]++;
+  return g_rd->m_afpDistortFunc[0][IDX]( conv( dp ) );
+}
+template<int IDX> void x5Tramp( const vvenc::DistParam& dp, vvenc::Distortion* cost, bool calcCentre )
+{
+  g_calls[1]++;
+  vvhip::Distortion c[5]; for( int i = 0; i < 5; i++ ) c[i] = cost[i];
+  g_rd->m_afpDistortFuncX5[IDX]( conv( dp ), c, calcCentre );
+  for( int i = 0; i < 5; i++ ) cost[i] = c[i];
+}
+
+template<int I> struct Fill { static void go( vvenc::RdCost* rc ) { if( I != vvenc::DF_SAD_WITH_MASK ) rc->m_afpDistortFunc[0][I] = distTramp<I>; Fill<I - 1>::go( rc ); } };
+template<> struct Fill<-1> { static void go( vvenc::RdCost* ) {} };
+
+void initRdCost( vvenc::RdCost* rc )
+{
+  static_assert( ( int ) vvenc::DF_TOTAL_FUNCTIONS == ( int ) vvhip::DF_TOTAL_FUNCTIONS && ( int ) vvenc::DF_HAD_fast == ( int ) vvhip::DF_HAD_fast &&
+                 ( int ) vvenc::DF_HAD_2SAD == ( int ) vvhip::DF_HAD_2SAD && ( int ) vvenc::DF_SAD == ( int ) vvhip::DF_SAD, "DFunc numbering" );
+  Fill<vvenc::DF_TOTAL_FUNCTIONS - 1>::go( rc );      // row 0 (bitDepth <= 10); row 1 stays the scalar copy made before SIMD init (RdCost.cpp:126)
+  rc->m_afpDistortFuncX5[0] = x5Tramp<0>;
+  rc->m_afpDistortFuncX5[1] = x5Tramp<1>;
+}
+
+void xQuantTramp( const vvenc::TransformUnit tu, const vvenc::ComponentID compID, const vvenc::CCoeffBuf& piCoef, vvenc::CoeffSigBuf piQCoef, vvenc::TCoeff& uiAbsSum,
+                  int& lastScanPos, vvenc::TCoeff* deltaU, const int defaultQuantisationCoefficient, const int iQBits, const int64_t iAdd,
+                  const vvenc::TCoeff entropyCodingMinimum, const vvenc::TCoeff entropyCodingMaximum, const bool signHiding, const vvenc::TCoeff m_thrVal )
+{
+  g_calls[4]++;
+  const unsigned w = tu.blocks[compID].width, h = tu.blocks[compID].height;
+  std::vector<vvenc::TCoeffSig> lev( ( size_t ) w * h );
+  std::vector<vvenc::TCoeff> src( ( size_t ) w * h );
+  for( unsigned y = 0; y < h; y++ ) memcpy( &src[( size_t ) y * w], piCoef.buf + y * piCoef.stride, sizeof( vvenc::TCoeff ) * w );
+  g_q->xQuantCore( w, h, src.data(), lev.data(), uiAbsSum, lastScanPos, deltaU, defaultQuantisationCoefficient, iQBits, iAdd, m_thrVal );
+  for( unsigned y = 0; y < h; y++ ) memcpy( piQCoef.buf + y * piQCoef.stride, &lev[( size_t ) y * w], sizeof( vvenc::TCoeffSig ) * w );
+}
+void xDeQuantTramp( const int maxX, const int maxY, const int scale, const vvenc::TCoeffSig* const q, const size_t qStride, vvenc::TCoeff* const coef,
+                    const int rightShift, const int inputMaximum, const vvenc::TCoeff transformMaximum )
+{
+  g_calls[5]++;
+  g_q->xDeQuant( maxX, maxY, scale, q, qStride, coef, rightShift, inputMaximum, transformMaximum );
+}
+bool xNeedRdoqTramp( const vvenc::TCoeff* c, size_t n, int qc, int64_t off, int shift ) { g_calls[6]++; return g_q->xNeedRdoq( c, n, qc, off, shift ); }
+
+void initQuant( vvenc::Quant* q )
+{
+  q->xQuant = xQuantTramp;
+  q->xDeQuant = xDeQuantTramp;
+  q->xNeedRdoq = xNeedRdoqTramp;
+}
+
+int errInt( const vvenc::Pel* o, const ptrdiff_t os, const vvenc::Pel* b, const ptrdiff_t bs, const int w, const int h, const int best ) { g_calls[7]++; return g_m->m_motionErrorLumaInt8( o, os, b, bs, w, h, best ); }
+int errF6( const vvenc::Pel* o, const ptrdiff_t os, const vvenc::Pel* b, const ptrdiff_t bs, const int w, const int h, const int16_t* xf, const int16_t* yf, const int bd, const int best )
+{ g_calls[7]++; return g_m->m_motionErrorLumaFrac8[0]( o, os, b, bs, w, h, xf, yf, bd, best ); }
+int errF4( const vvenc::Pel* o, const ptrdiff_t os, const vvenc::Pel* b, const ptrdiff_t bs, const int w, const int h, const int16_t* xf, const int16_t* yf, const int bd, const int best )
+{ g_calls[7]++; return g_m->m_motionErrorLumaFrac8[1]( o, os, b, bs, w, h, xf, yf, bd, best ); }
+double calcVar( const vvenc::Pel* o, const ptrdiff_t os, const int w, const int h ) { return g_m->m_calcVar( o, os, w, h ); }
+
+void initMCTF( vvenc::MCTF* m )
+{
+  m->m_motionErrorLumaInt8 = errInt;
+  m->m_motionErrorLumaFrac8[0] = errF6;
+  m->m_motionErrorLumaFrac8[1] = errF4;
+  m->m_calcVar = calcVar;
+}
+
+bool fwd2D( const int16_t* resi, ptrdiff_t stride, int32_t* coef, unsigned w, unsigned h, int th, int tv, int bd )
+{
+  g_calls[2]++;
+  vvhip::g_tCoeffOps.fwdTransform2D( resi, stride, coef, w, h, th, tv, bd );
+  return true;
+}
+bool inv2D( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned w, unsigned h, int th, int tv, int bd )
+{
+  g_calls[3]++;
+  vvhip::g_tCoeffOps.invTransform2D( coef, resi, stride, w, h, th, tv, bd );
+  return true;
+}
+
+// whole hierarchical ME of MCTF::motionEstimationMCTF on the GPU; both pictures carry MCTF_PADDING extended margins (MCTF.cpp:608-612)
+bool mctfMe( vvenc::MCTF* m, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel )
+{
+  const vvenc::CPelBuf o = orig.Y(), r = refPic.Y();
+  const int w = o.width, h = o.height, unit = m->m_mctfUnitSize;
+  if( w < 64 || h < 64 || o.stride != r.stride ) return false;       // below the device entry point's minimum: keep the table-entry path
+  vvhip::Device& dev = vvhip::Device::get();
+  const int idO = dev.registerPicture( o.buf, ( int ) o.stride, w, h, vvenc::MCTF_PADDING );
+  const int idR = dev.registerPicture( r.buf, ( int ) r.stride, w, h, vvenc::MCTF_PADDING );
+  std::vector<vvhip_mv> out( ( size_t ) mvs.w() * mvs.h() );
+  vvhip_mv* outs[1] = { out.data() };
+  g_m->motionEstimation( idO, &idR, 1, m->m_encCfg->m_internalBitDepth[0], unit, m->m_encCfg->m_vvencMCTF.MCTFSpeed, addLevel, outs );
+  dev.unregisterPicture( idO ); dev.unregisterPicture( idR );
+  for( int y = 0; y < mvs.h(); y++ ) for( int x = 0; x < mvs.w(); x++ )
+  {
+    vvenc::MotionVector& d = mvs.get( x, y ); const vvhip_mv& s = out[( size_t ) y * mvs.w() + x];
+    d.x = s.x; d.y = s.y; d.error = s.error; d.rmsme = ( uint16_t ) s.rmsme; d.overlap = s.overlap;
+  }
+  g_calls[7] += 1000000;      // marks "whole-picture ME ran on the device"
+  return true;
+}
+
+} // namespace
+
+extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
+{
+  // mask bit0 RdCost, bit1 transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME
+  try
+  {
+    if( mask && !g_rd ) { g_rd = new vvhip::RdCost; g_rd->create( true ); g_q = new vvhip::QuantOps; g_m = new vvhip::MCTFOps; }
+  }
+  catch( const std::exception& e ) { fprintf( stderr, "vvref_install_hip_hooks: %s\n", e.what() ); return -1; }
+  g_vvhipHooks.initRdCost = ( mask & 1 ) ? initRdCost : nullptr;
+  g_vvhipHooks.fwd2D      = ( mask & 2 ) ? fwd2D : nullptr;
+  g_vvhipHooks.inv2D      = ( mask & 2 ) ? inv2D : nullptr;
+  g_vvhipHooks.initQuant  = ( mask & 4 ) ? initQuant : nullptr;
+  g_vvhipHooks.initMCTF   = ( mask & 8 ) ? initMCTF : nullptr;
+  g_vvhipHooks.mctfMe     = ( mask & 16 ) ? mctfMe : nullptr;
+  for( auto& c : g_calls ) c = 0;
+  return 0;
+}
+
+extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_calls( uint64_t* out8 )
+{
+  for( int i = 0; i < 8; i++ ) out8[i] = g_calls[i];
+}

@@ -1,0 +1,23 @@
+// hip_hooks.h — the (tiny) hook surface the build-time patched copies of four reference files call (oracle/ref/apply_hip_hooks.py).
+// TEST INFRASTRUCTURE: lets tests run the *real reference encoder* with its kernel tables pointed at the HIP back-end and compare
+// the bitstream byte-for-byte with the CPU run (the reference's own invariant, cmake/modules/vvencTests.cmake:52-53).
+// All hooks are null by default: the patched library then behaves exactly like the unpatched one.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace vvenc {
+class RdCost; class Quant; class MCTF; struct MotionVector; struct PelStorage;
+template<class T> struct Array2D;
+}
+
+struct VvhipHooks
+{
+  void ( *initRdCost )( vvenc::RdCost* );
+  void ( *initQuant )( vvenc::Quant* );
+  void ( *initMCTF )( vvenc::MCTF* );
+  bool ( *fwd2D )( const int16_t* resi, ptrdiff_t stride, int32_t* coef, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
+  bool ( *inv2D )( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
+  bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel );
+};
+extern VvhipHooks g_vvhipHooks;

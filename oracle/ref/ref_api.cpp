@@ -580,4 +580,58 @@ API void vvref_tu_rdo_batch( int simd, const int16_t* resi, int resiStride, cons
   xFree( coef ); xFree( deq ); xFree( du ); xFree( rec ); xFree( lev );
 }
 
+// ---------------------------------------------------------------------------------------------
+// End-to-end: the reference encoder itself through its C API (vvenc/vvenc.h), one call = one sequence -> bitstream bytes.
+// Planes are int16 samples (vvencYUVPlane), 4:2:0.  simd: NULL = auto (AVX2 here), "SCALAR", "SSE41", ...
+// ---------------------------------------------------------------------------------------------
+#include "vvenc/vvenc.h"
+namespace {
+void quietMsg( void*, int, const char*, va_list ) {}
+}
+API long vvref_encode( const int16_t* y, const int16_t* u, const int16_t* v, int width, int height, int frames, int inputBitDepth, int internalBitDepth,
+                       int preset, int qp, int threads, const char* simd, uint8_t* out, long outCap, double* secondsOut )
+{
+  vvenc_set_SIMD_extension( simd && simd[0] ? simd : nullptr );
+  vvenc_config cfg;
+  vvenc_init_default( &cfg, width, height, 30, 0, qp, ( vvencPresetMode ) preset );
+  cfg.m_inputBitDepth[0] = inputBitDepth;
+  cfg.m_internalBitDepth[0] = internalBitDepth;
+  cfg.m_numThreads = threads;
+  cfg.m_verbosity = VVENC_SILENT;
+  vvenc_set_msg_callback( &cfg, nullptr, quietMsg );
+  vvencEncoder* enc = vvenc_encoder_create();
+  if( !enc ) return -1;
+  if( vvenc_encoder_open( enc, &cfg ) != 0 ) { fprintf( stderr, "vvref_encode: open failed: %s\n", vvenc_get_last_error( enc ) ); vvenc_encoder_close( enc ); return -2; }
+  vvencYUVBuffer yuv; vvenc_YUVBuffer_default( &yuv );
+  vvenc_YUVBuffer_alloc_buffer( &yuv, VVENC_CHROMA_420, width, height );
+  vvencAccessUnit au; vvenc_accessUnit_default( &au );
+  vvenc_accessUnit_alloc_payload( &au, ( 3 * width * height ) / 2 + 1024 * 64 );
+  const int cw = width / 2, ch = height / 2;
+  long used = 0; bool done = false; int rc = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for( int f = 0; f < frames && !rc; f++ )
+  {
+    for( int r = 0; r < height; r++ ) memcpy( yuv.planes[0].ptr + ( size_t ) r * yuv.planes[0].stride, y + ( ( size_t ) f * height + r ) * width, sizeof( int16_t ) * width );
+    for( int r = 0; r < ch; r++ )
+    {
+      memcpy( yuv.planes[1].ptr + ( size_t ) r * yuv.planes[1].stride, u + ( ( size_t ) f * ch + r ) * cw, sizeof( int16_t ) * cw );
+      memcpy( yuv.planes[2].ptr + ( size_t ) r * yuv.planes[2].stride, v + ( ( size_t ) f * ch + r ) * cw, sizeof( int16_t ) * cw );
+    }
+    yuv.sequenceNumber = f; yuv.cts = f; yuv.ctsValid = true;
+    rc = vvenc_encode( enc, &yuv, &au, &done );
+    if( !rc && au.payloadUsedSize > 0 ) { if( used + au.payloadUsedSize > outCap ) rc = -100; else { memcpy( out + used, au.payload, au.payloadUsedSize ); used += au.payloadUsedSize; } }
+  }
+  while( !rc && !done )
+  {
+    rc = vvenc_encode( enc, nullptr, &au, &done );
+    if( !rc && au.payloadUsedSize > 0 ) { if( used + au.payloadUsedSize > outCap ) rc = -100; else { memcpy( out + used, au.payload, au.payloadUsedSize ); used += au.payloadUsedSize; } }
+  }
+  if( secondsOut ) *secondsOut = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+  if( rc ) fprintf( stderr, "vvref_encode: error %d: %s\n", rc, vvenc_get_last_error( enc ) );
+  vvenc_YUVBuffer_free_buffer( &yuv );
+  vvenc_accessUnit_free_payload( &au );
+  vvenc_encoder_close( enc );
+  return rc ? -3 : used;
+}
+
 API const char* vvref_version() { return "vvenc reference 1.15.0-dev (built from /root/reference by oracle/ref/Makefile)"; }

@@ -1,0 +1,50 @@
+"""helpers for the end-to-end bitstream tests: drive the reference encoder (compiled into oracle/_ref/) through its C API"""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libvvenc_ref.so")
+REF_HIP_SO = os.path.join(ROOT, "oracle", "_ref", "libvvenc_ref_hip.so")
+PRESET_FASTER = 0   # vvencPresetMode: VVENC_FASTER = 0, FAST = 1, MEDIUM = 2 (include/vvenc/vvencCfg.h)
+
+
+def synth_yuv(width, height, frames, bit_depth, seed):
+    """BASELINE config-1 style generator: moving sinusoid texture + noise, smooth chroma; returns int16 planes"""
+    rng = np.random.default_rng(seed)
+    maxv = (1 << bit_depth) - 1
+    s = maxv / 255.0
+    yy, xx = np.mgrid[0:height, 0:width]
+    ys, us, vs = [], [], []
+    for t in range(frames):
+        y = 128 + 60 * np.sin((xx + 2 * t) / 7.0) + 40 * np.cos((yy - t) / 5.0) + rng.integers(-4, 5, size=(height, width))
+        ys.append(np.clip(y * s, 0, maxv))
+        cy, cx = np.mgrid[0:height // 2, 0:width // 2]
+        us.append(np.clip((128 + 20 * np.sin((cx + t) / 9.0)) * s, 0, maxv))
+        vs.append(np.clip((128 + 20 * np.cos((cy - t) / 11.0)) * s, 0, maxv))
+    f = lambda a: np.ascontiguousarray(np.stack(a).astype(np.int16))
+    return f(ys), f(us), f(vs)
+
+
+def load(hip=False):
+    L = C.CDLL(REF_HIP_SO if hip else REF_SO)
+    L.vvref_encode.restype = C.c_long
+    L.vvref_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_double)]
+    if hip:
+        L.vvref_install_hip_hooks.argtypes = [C.c_int]
+        L.vvref_hip_hook_calls.argtypes = [C.c_void_p]
+    return L
+
+
+def encode(L, yuv, width, height, in_bd, int_bd, preset=PRESET_FASTER, qp=32, threads=1, simd=None):
+    y, u, v = yuv
+    out = np.zeros(4 << 20, np.uint8)
+    secs = C.c_double()
+    n = L.vvref_encode(y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, y.shape[0], in_bd, int_bd, preset, qp, threads,
+                       simd.encode() if simd else None, out.ctypes.data, out.size, C.byref(secs))
+    assert n > 0, n
+    bs = out[:n].tobytes()
+    return hashlib.md5(bs).hexdigest(), n, secs.value

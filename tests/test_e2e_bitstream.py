@@ -1,0 +1,79 @@
+"""End-to-end bit-exactness gate (BASELINE metric: "bit-exact vs CPU"): the REAL reference encoder, compiled from /root/reference into
+oracle/_ref/, encodes a synthetic clip
+  * with its scalar, SSE4.1 and AVX2 kernel rows (the reference's own invariant, cmake/modules/vvencTests.cmake:52-53)      [CPU tier]
+  * with its kernel tables pointed at the HIP back-end through the table-shaped shim (hook-enabled build, oracle/ref/hip_hooks.cpp):
+    RdCost distortion entries, fused 2-D transforms, Quant cores, MCTF error entries and the whole-picture MCTF ME          [GPU tier]
+and every bitstream must have the same md5.  Each run is a separate process (the SIMD level is process-wide state in the reference)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import e2e_util  # noqa: E402
+
+WORKER = r'''
+import sys, json
+sys.path.insert(0, %r)
+import e2e_util as E
+cfg = json.loads(sys.argv[1])
+L = E.load(cfg["hip"])
+if cfg["hip"]:
+    assert L.vvref_install_hip_hooks(cfg["mask"]) == 0
+yuv = E.synth_yuv(cfg["w"], cfg["h"], cfg["frames"], cfg["in_bd"], 1234)
+md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"], simd=cfg["simd"], threads=cfg.get("threads", 1))
+calls = None
+if cfg["hip"]:
+    import numpy as np
+    c = np.zeros(8, np.uint64); L.vvref_hip_hook_calls(c.ctypes.data); calls = [int(x) for x in c]
+print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
+''' % os.path.join(ROOT, "tests")
+
+
+def run(cfg, timeout=1700):
+    r = subprocess.run([sys.executable, "-c", WORKER, json.dumps(cfg)], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+CFG1 = dict(w=64, h=64, frames=8, in_bd=8, int_bd=8)          # BASELINE configs[0]
+CFG10 = dict(w=128, h=64, frames=9, in_bd=10, int_bd=10)      # a 10-bit clip
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("clip", [CFG1, CFG10], ids=["cfg0-64x64-8b", "128x64-10b"])
+def test_reference_rows_agree(clip):
+    if not os.path.exists(e2e_util.REF_SO):
+        pytest.skip("oracle/_ref not built")
+    res = [run(dict(clip, hip=False, simd=s, mask=0)) for s in (None, "SCALAR", "SSE41")]
+    assert len({r["md5"] for r in res}) == 1, res
+    if os.path.exists(e2e_util.REF_HIP_SO):      # the hook-enabled build with hooks off is the reference
+        assert run(dict(clip, hip=True, simd=None, mask=0))["md5"] == res[0]["md5"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", [CFG1, CFG10], ids=["cfg0-64x64-8b", "128x64-10b"])
+def test_hip_backend_bitstream_identical(clip):
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=31))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][0] > 1000 and hip["calls"][2] > 10, hip["calls"]      # the encoder really went through the HIP entries
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"]
+
+
+@pytest.mark.gpu
+def test_hip_table_entries_only_bitstream_identical():
+    """same gate with the MCTF search left to the reference's own schedule calling our per-candidate table entries
+    (m_motionErrorLumaInt8 / m_motionErrorLumaFrac8[1] / m_calcVar through the shim) instead of the whole-picture device ME"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    cpu = run(dict(CFG1, hip=False, simd=None, mask=0))
+    hip = run(dict(CFG1, hip=True, simd=None, mask=15))
+    print("cpu", cpu, "hip", hip)
+    assert 0 < hip["calls"][7] < 1000000, hip["calls"]
+    assert hip["md5"] == cpu["md5"]

@@ -450,7 +450,20 @@ bool needRdoqOne( const TCoeff* c, size_t num, int quantCoeff, int64_t offset, i
   return need != 0;
 }
 
+void quantImpl( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal,
+                bool raw, int rawScale, int rawQBits, int64_t rawAdd );
+
 void quantOne( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal )
+{
+  quantImpl( w, h, coef, q, absSum, lastScanPos, deltaU, qp, isIRAP, bitDepth, thrVal, false, 0, 0, 0 );
+}
+void quantCoreOne( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int quantCoeff, const int iQBits, const int64_t iAdd, const TCoeff thrVal )
+{
+  quantImpl( w, h, coef, q, absSum, lastScanPos, deltaU, 0, false, 10, thrVal, true, quantCoeff, iQBits, iAdd );
+}
+
+void quantImpl( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal,
+                bool raw, int rawScale, int rawQBits, int64_t rawAdd )
 {
   std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
@@ -462,6 +475,10 @@ void quantOne( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff&
   int16_t* dLev = reinterpret_cast<int16_t*>( dDu + area );
   dev.check( vvhip_upload( dev.ctx(), aux, &hdr, sizeof( hdr ) ), "quant" );
   dev.check( vvhip_upload( dev.ctx(), dCoef, coef, area * sizeof( TCoeff ) ), "quant" );
+  if( raw )
+    dev.check( vvhip_quant_core( dev.ctx(), dCoef, ( int ) w, ( int ) h, rawScale, rawQBits, rawAdd, thrVal, dLev, deltaU ? dDu : nullptr,
+                                 reinterpret_cast<int32_t*>( aux + offsetof( Hdr, absSum ) ), reinterpret_cast<int32_t*>( aux + offsetof( Hdr, last ) ) ), "vvhip_quant_core" );
+  else
   dev.check( vvhip_quant_batch( dev.ctx(), dCoef, 1, ( int ) w, ( int ) h, bitDepth, reinterpret_cast<vvhip_tu_qp*>( aux ), thrVal, dLev, deltaU ? dDu : nullptr,
                                 reinterpret_cast<int32_t*>( aux + offsetof( Hdr, absSum ) ), reinterpret_cast<int32_t*>( aux + offsetof( Hdr, last ) ) ), "vvhip_quant_batch" );
   dev.check( vvhip_download( dev.ctx(), q, dLev, area * sizeof( TCoeffSig ) ), "quant" );
@@ -477,6 +494,7 @@ QuantOps::QuantOps()
   xDeQuant = deQuantOne;
   xNeedRdoq = needRdoqOne;
   xQuant = quantOne;
+  xQuantCore = quantCoreOne;
 }
 
 } // namespace vvhip

@@ -42,8 +42,9 @@ enum DFunc
   DF_SSE = 0, DF_SSE2, DF_SSE4, DF_SSE8, DF_SSE16, DF_SSE32, DF_SSE64, DF_SSE128,
   DF_SAD = 8, DF_SAD2, DF_SAD4, DF_SAD8, DF_SAD16, DF_SAD32, DF_SAD64, DF_SAD128,
   DF_HAD = 16, DF_HAD2, DF_HAD4, DF_HAD8, DF_HAD16, DF_HAD32, DF_HAD64, DF_HAD128,
-  DF_HAD_fast = 24, DF_HAD2_fast, DF_HAD4_fast, DF_HAD8_fast, DF_HAD16_fast, DF_HAD32_fast, DF_HAD64_fast, DF_HAD128_fast,
-  DF_HAD_2SAD = 32, DF_SAD_WITH_MASK = 33, DF_TOTAL_FUNCTIONS = 34
+  DF_HAD_2SAD = 24, DF_SAD_WITH_MASK = 25,
+  DF_HAD_fast = 26, DF_HAD2_fast, DF_HAD4_fast, DF_HAD8_fast, DF_HAD16_fast, DF_HAD32_fast, DF_HAD64_fast, DF_HAD128_fast,
+  DF_TOTAL_FUNCTIONS = 34
 };
 
 struct CPelBuf { const Pel* buf = nullptr; int stride = 0; unsigned width = 0, height = 0; };
@@ -135,6 +136,9 @@ struct QuantOps
   bool ( *xNeedRdoq )( const TCoeff* pCoeff, size_t numCoeff, int quantCoeff, int64_t offset, int shift );
   void ( *xQuant )( unsigned width, unsigned height, const TCoeff* piCoef, TCoeffSig* piQCoef, TCoeff& uiAbsSum, int& lastScanPos, TCoeff* deltaU,
                     const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal );
+  // QuantCore's own argument list (Quant.cpp:132): what a trampoline for Quant::xQuant forwards (piQCoef compact, stride = width)
+  void ( *xQuantCore )( unsigned width, unsigned height, const TCoeff* piCoef, TCoeffSig* piQCoef, TCoeff& uiAbsSum, int& lastScanPos, TCoeff* deltaU,
+                        const int defaultQuantisationCoefficient, const int iQBits, const int64_t iAdd, const TCoeff thrVal );
 };
 
 // MCTF table, CommonLib/MCTF.h:160-170

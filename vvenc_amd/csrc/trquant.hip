@@ -244,7 +244,7 @@ __device__ __forceinline__ void quantParams( const QGeom& q, int qp, int& scale,
 
 // One team of LPC lanes per TU.  Scan positions are strided over the team.
 __global__ void __launch_bounds__( 256 )
-quantKernel( const int32_t* __restrict__ coef, int n, QGeom q, int log2Lpc, const vvhip_tu_qp* __restrict__ qps, int thrVal,
+quantKernel( const int32_t* __restrict__ coef, int n, QGeom q, int log2Lpc, const vvhip_tu_qp* __restrict__ qps, int rawScale, int rawQBits, long long rawAdd, int thrVal,
              const uint16_t* __restrict__ scan, int16_t* __restrict__ level, int32_t* __restrict__ deltaU,
              int32_t* __restrict__ absSumOut, int32_t* __restrict__ lastPosOut )
 {
@@ -256,12 +256,13 @@ quantKernel( const int32_t* __restrict__ coef, int n, QGeom q, int log2Lpc, cons
   int16_t* dst = level + ( size_t ) ( valid ? tu : 0 ) * area;
   int scale = 1, qBits = 16;
   int64_t add = 0;
-  if( valid )
+  if( valid && qps )
   {
     const vvhip_tu_qp p = qps[tu];
     quantParams( q, p.qp, scale, qBits );
     add = ( int64_t ) ( ( p.flags & 1 ) ? 171 : 85 ) << ( qBits - 9 );               // Quant.cpp:775
   }
+  else if( valid ) { scale = rawScale; qBits = rawQBits; add = rawAdd; }              // table-entry form: QuantCore's own argument list
   const int num = valid ? q.numScan : 0;
 
   // (1) last non-zero scan position (Quant.cpp:162-167); 0 if none
@@ -938,7 +939,21 @@ int vvhip_quant_batch( vvhip_ctx* ctx, const int32_t* d_coef, int n, int width, 
   const int log2Lpc = teamLog2( q.numScan );
   const long threads = ( long ) n << log2Lpc;
   hipLaunchKernelGGL( quantKernel, dim3( ( unsigned ) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, ctx->stream,
-                      d_coef, n, q, log2Lpc, d_qp, thr_val, ctx->d_scan + scanOffset( q.log2w, q.log2h ), d_level, d_delta_u, d_abs_sum, d_last_scan_pos );
+                      d_coef, n, q, log2Lpc, d_qp, 0, 0, 0ll, thr_val, ctx->d_scan + scanOffset( q.log2w, q.log2h ), d_level, d_delta_u, d_abs_sum, d_last_scan_pos );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_quant_core( vvhip_ctx* ctx, const int32_t* d_coef, int width, int height, int quant_coeff, int q_bits, int64_t add, int thr_val,
+                      int16_t* d_level, int32_t* d_delta_u, int32_t* d_abs_sum, int32_t* d_last_scan_pos )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  QGeom q;
+  if( !makeQGeom( width, height, 10, q ) || q_bits < 9 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_quant_core: unsupported TU %dx%d / qBits %d", width, height, q_bits );
+  const int log2Lpc = teamLog2( q.numScan );
+  hipLaunchKernelGGL( quantKernel, dim3( 1 ), dim3( 256 ), 0, ctx->stream,
+                      d_coef, 1, q, log2Lpc, ( const vvhip_tu_qp* ) nullptr, quant_coeff, q_bits, ( long long ) add, thr_val,
+                      ctx->d_scan + scanOffset( q.log2w, q.log2h ), d_level, d_delta_u, d_abs_sum, d_last_scan_pos );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
 }
