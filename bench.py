@@ -59,9 +59,10 @@ class EventTimers:
 
 
 def cpu_baseline(wl, budget_s=12.0):
-    """Times the CPU path on the host cores over a bounded sample of the SAME work lists and scales to frames/sec.
-    kind "reference": the reference's own x86-SIMD table entries (oracle/_ref/libvvenc_ref.so, built from /root/reference);
-    kind "port": oracle/liboracle.so (scalar C restatement) when the reference build is not present."""
+    """Times the CPU path on the host cores over the SAME work lists and scales to frames/sec.
+    kind "reference": the reference's own x86-SIMD (AVX2) table entries — oracle/_ref/libvvenc_ref.so, compiled from /root/reference —
+    driven by a C++ std::thread pool inside the library (one ctypes call, no Python in the timed loop), every kernel class and size;
+    kind "port": oracle/liboracle.so (scalar C restatement, one core, distortion lists only) when the reference build is absent."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     org = np.ascontiguousarray(wl.org.storage.cpu().numpy())
@@ -69,78 +70,73 @@ def cpu_baseline(wl, budget_s=12.0):
     resi = np.ascontiguousarray(wl.resi.storage.cpu().numpy())
     org_p = org.ctypes.data + 2 * wl.org.origin
     ref_p = ref.ctypes.data + 2 * wl.ref.origin
-    use_ref = O.RefLib.available()
-    if use_ref:
+    if O.RefLib.available():
         R = O.RefLib(1)
         L = R.L
-        L.vvref_dist_batch.restype = None
-        L.vvref_dist_batch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-        L.vvref_tu_rdo_batch.restype = None
-        L.vvref_tu_rdo_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    else:
-        orc = O.Oracle()
-        L = orc.L
-        L.orc_dist_batch.restype = None
-        L.orc_dist_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-    fidx = {"SSE": 0, "SAD": 1, "HAD": 2, "HAD_fast": 3}
 
-    def run_sample(fr, passes=1):
-        jobs = []
+        class FrameJob(C.Structure):
+            _fields_ = [("kind", C.c_int32), ("df", C.c_int32), ("size", C.c_int32), ("subShift", C.c_int32),
+                        ("items", C.c_void_p), ("aux", C.c_void_p), ("n", C.c_int32), ("pad", C.c_int32)]
+        keep, jobs = [], []
         for (func, S, ss, n, _, _, items) in wl.dist_jobs:
-            m = max(cores, int(n * fr))
-            jobs.append(("d", func, S, ss, items[:m]))
-        if use_ref:
-            for (S, n, _, _, _, _, _, off, qps) in wl.tu_jobs:
-                m = max(cores, int(n * fr))
-                jobs.append(("t", S, off[:m], qps[:m]))
-        # per-thread slices are prepared before the clock starts; each thread then loops `passes` times inside ctypes calls (GIL released)
-        plans = []
-        for t in range(cores):
-            plan = []
-            for j in jobs:
-                if j[0] == "d":
-                    sl = np.ascontiguousarray(j[4][t::cores])
-                    plan.append(("d", j[1], j[2], j[3], sl, np.zeros(len(sl), np.uint64)))
-                else:
-                    o = np.ascontiguousarray(j[2][t::cores])
-                    qf = np.zeros((len(o), 2), np.int16)
-                    qf[:, 0] = j[3][t::cores]
-                    qf[:, 1] = 2
-                    plan.append(("t", j[1], o, qf, np.zeros(len(o), np.uint64)))
-            plans.append(plan)
+            it = np.ascontiguousarray(items)
+            keep.append(it)
+            jobs.append(FrameJob(0, R._df[func], S, ss, it.ctypes.data, None, n, 0))
+        for (S, n, _, _, _, _, _, off, qps) in wl.tu_jobs:
+            o = np.ascontiguousarray(off)
+            qf = np.zeros((n, 2), np.int16)
+            qf[:, 0] = qps
+            qf[:, 1] = 2
+            keep += [o, qf]
+            jobs.append(FrameJob(1, 0, S, 0, o.ctypes.data, qf.ctypes.data, n, 0))
+        arr = (FrameJob * len(jobs))(*jobs)
+        L.vvref_run_jobs_mt.restype = C.c_double
+        L.vvref_run_jobs_mt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
 
-        def worker(t):
-            for _ in range(passes):
-                for j in plans[t]:
-                    if j[0] == "d":
-                        _, func, S, ss, sl, out = j
-                        if use_ref:
-                            L.vvref_dist_batch(1, R._df[func], org_p, wl.org.stride, ref_p, wl.ref.stride, S, S, wl.bit_depth, ss,
-                                               sl.ctypes.data, len(sl), out.ctypes.data)
-                        else:
-                            L.orc_dist_batch(fidx[func], org_p, wl.org.stride, ref_p, wl.ref.stride, S, S, ss, sl.ctypes.data, len(sl), out.ctypes.data)
-                    else:
-                        _, S, o, qf, sse = j
-                        L.vvref_tu_rdo_batch(1, resi.ctypes.data, wl.resi.stride, o.ctypes.data, len(o), S, S, wl.bit_depth, qf.ctypes.data, 8,
-                                             None, None, sse.ctypes.data)
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
-        t0 = time.perf_counter()
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        return time.perf_counter() - t0
+        def run(threads, passes):
+            return L.vvref_run_jobs_mt(org_p, wl.org.stride, ref_p, wl.ref.stride, resi.ctypes.data, wl.resi.stride, wl.bit_depth,
+                                       arr, len(jobs), threads, passes)
+        out = {}
+        cand = sorted({1, min(cores, 8), min(cores, 32), max(1, cores // 2), cores})
+        for threads in cand:                               # thread-count sweep: report the best the host can do
+            dt1 = run(threads, 1)
+            passes = int(max(1, min(2000, (budget_s / (2.0 * len(cand))) / max(dt1, 1e-4))))
+            dt = run(threads, passes)
+            out[threads] = (passes / dt, passes, dt)
+        best = max(out, key=lambda t: out[t][0])
+        fps, passes, dt = out[best]
+        return {"value": fps, "unit": "frames/s", "cores": best, "kind": "reference", "host_cpus": cores,
+                "sweep_fps": {str(t): round(out[t][0], 2) for t in cand},
+                "sample": "%d full passes over one frame's work lists (every kernel class, all block sizes) on %d std::threads in %.1f s wall; "
+                          "reference x86-SIMD (AVX2) table entries called back-to-back; best of a thread-count sweep" % (passes, best, dt)}
+    orc = O.Oracle()
+    L = orc.L
+    L.orc_dist_batch.restype = None
+    L.orc_dist_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    fidx = {"SSE": 0, "SAD": 1, "HAD": 2, "HAD_fast": 3}
+    frac = 0.05
+    t0 = time.perf_counter()
+    for (func, S, ss, n, _, _, items) in wl.dist_jobs:
+        m = max(1, int(n * frac))
+        sl = np.ascontiguousarray(items[:m])
+        outb = np.zeros(m, np.uint64)
+        L.orc_dist_batch(fidx[func], org_p, wl.org.stride, ref_p, wl.ref.stride, S, S, ss, sl.ctypes.data, m, outb.ctypes.data)
+    dt = time.perf_counter() - t0
+    return {"value": frac / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%.0f%% of one frame's distortion work lists (transform/quant not included) through the scalar C oracle, 1 thread, %.1f s" % (100 * frac, dt)}
 
-    run_sample(0.01)                        # page in / warm caches
-    frac = 1.0
-    dt1 = run_sample(frac, 1)
-    passes = int(max(1, min(4000, (budget_s / 3.0) / max(dt1, 1e-4))))
-    dt = run_sample(frac, passes) if passes > 1 else dt1
-    fps = frac * passes / dt
-    note = "" if use_ref else " (transform/quant not in the port sample: distortion only)"
-    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
-            "sample": "%d x %.1f%% of one frame's work lists (every kernel class, all block sizes), %d threads, %.1f s wall%s; "
-                      "reference x86-SIMD (AVX2) table entries called back-to-back" % (passes, 100 * frac, cores, dt, note)}
+
+def pmc_traffic(cls, args):
+    """HBM-side bytes per launch of the dominant class from the committed PMC passes (profiles/pmc_r01.json: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH doubled per the gfx950 correction).  Counters cannot be collected inside
+    this run; null when the profile does not cover the requested workload."""
+    try:
+        if (args.width, args.height) != (1920, 1080):
+            return None
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01.json")))
+        return d["classes"][cls]["traffic_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -218,7 +214,7 @@ def main():
         out["kernels"] = ks
         out["roofline"] = {"bound": "hbm", "kernel": {"SAD": "sadSseKernel<8,SAD>", "SSE": "sadSseKernel<8,SSE>", "HAD_fast": "hadKernel<8,8,*>", "TU": "tuRdoKernel"}[dom],
                            "achieved": ks[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ks[dom]["alg_GBps"] / HBM_PEAK_GBS,
-                           "traffic": None,
+                           "traffic": pmc_traffic(dom, args),
                            "alg_bytes_per_launch": wl.alg_bytes[dom] / launches_per_frame, "avg_launch_ms": ks[dom]["avg_ms"],
                            "note": "algorithmic bytes = 4*w*h per candidate (+8 B result), rows halved under subShift; fused TU = 6*w*h + 24 B (SURVEY 8d)"}
     if not args.no_cpu_baseline and world == 1:

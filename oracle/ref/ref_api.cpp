@@ -90,7 +90,11 @@ TCoeffOps& tcoeffOps( int simd )
   return ops[simd ? 1 : 0];
 }
 
-void selectTCoeffOps( int simd ) { g_tCoeffOps = tcoeffOps( simd ); }
+void selectTCoeffOps( int simd )
+{
+  static std::atomic<int> cur( -1 );               // g_tCoeffOps is process-wide: rewrite it only when the selection changes (no cache-line ping-pong)
+  if( cur.load( std::memory_order_relaxed ) != simd ) { g_tCoeffOps = tcoeffOps( simd ); cur.store( simd ); }
+}
 
 struct MctfPair { MCTF* m[2]; };
 MctfPair& mctfPair()
@@ -264,9 +268,9 @@ API int vvref_xT( int simd, const int16_t* resi, int resiStride, int32_t* coef, 
   int skipWidth  = ( trTypeHor != DCT2 && width  == 32 ) ? 16 : width  > JVET_C0024_ZERO_OUT_TH ? width  - JVET_C0024_ZERO_OUT_TH : 0;
   int skipHeight = ( trTypeVer != DCT2 && height == 32 ) ? 16 : height > JVET_C0024_ZERO_OUT_TH ? height - JVET_C0024_ZERO_OUT_TH : 0;
   selectTCoeffOps( simd );
-  TCoeff* block = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
-  TCoeff* tmp   = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
-  TCoeff* dst   = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
+  struct Scratch { TCoeff* p[3]; Scratch() { for( auto& q : p ) q = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY ); } ~Scratch() { for( auto& q : p ) xFree( q ); } };
+  static thread_local Scratch sc;
+  TCoeff* block = sc.p[0]; TCoeff* tmp = sc.p[1]; TCoeff* dst = sc.p[2];
   if( width & 3 )
   {
     for( int y = 0; y < height; y++ ) for( int x = 0; x < width; x++ ) block[y * width + x] = resi[y * resiStride + x];
@@ -289,7 +293,6 @@ API int vvref_xT( int simd, const int16_t* resi, int resiStride, int32_t* coef, 
   }
   else rc = -2;
   if( !rc ) memcpy( coef, dst, sizeof( TCoeff ) * width * height );
-  xFree( block ); xFree( tmp ); xFree( dst );
   return rc;
 }
 
@@ -304,9 +307,9 @@ API int vvref_xIT( int simd, const int32_t* coef, int16_t* resi, int resiStride,
   int skipWidth  = ( trTypeHor != DCT2 && width  == 32 ) ? 16 : width  > JVET_C0024_ZERO_OUT_TH ? width  - JVET_C0024_ZERO_OUT_TH : 0;
   int skipHeight = ( trTypeVer != DCT2 && height == 32 ) ? 16 : height > JVET_C0024_ZERO_OUT_TH ? height - JVET_C0024_ZERO_OUT_TH : 0;
   selectTCoeffOps( simd );
-  TCoeff* src   = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
-  TCoeff* block = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
-  TCoeff* tmp   = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY );
+  struct Scratch { TCoeff* p[3]; Scratch() { for( auto& q : p ) q = ( TCoeff* ) xMalloc( TCoeff, MAX_TB_SIZEY * MAX_TB_SIZEY ); } ~Scratch() { for( auto& q : p ) xFree( q ); } };
+  static thread_local Scratch sc;
+  TCoeff* src = sc.p[0]; TCoeff* block = sc.p[1]; TCoeff* tmp = sc.p[2];
   memcpy( src, coef, sizeof( TCoeff ) * width * height );
   int rc = 0;
   if( width > 1 && height > 1 )
@@ -332,7 +335,6 @@ API int vvref_xIT( int simd, const int32_t* coef, int16_t* resi, int resiStride,
     else if( width & 7 ) g_tCoeffOps.cpyResi4( block, resi, resiStride, width, height );
     else                 g_tCoeffOps.cpyResi8( block, resi, resiStride, width, height );
   }
-  xFree( src ); xFree( block ); xFree( tmp );
   return rc;
 }
 
@@ -578,6 +580,40 @@ API void vvref_tu_rdo_batch( int simd, const int16_t* resi, int resiStride, cons
     if( recOut ) memcpy( recOut + ( size_t ) i * area, rec, sizeof( int16_t ) * area );
   }
   xFree( coef ); xFree( deq ); xFree( du ); xFree( rec ); xFree( lev );
+}
+
+// Multi-threaded driver for bench.py's cpu_baseline (kind "reference"): `threads` std::threads, each walks its contiguous share of
+// every job `passes` times through the reference's SIMD table entries; returns wall seconds.  jobs: kind 0 = distortion list
+// (df = DFunc base), kind 1 = fused TU pipeline twin (vvref_tu_rdo_batch).
+struct FrameJob { int32_t kind, df, size, subShift; const void* items; const void* aux; int32_t n, pad; };
+
+API double vvref_run_jobs_mt( const int16_t* org, int orgStride, const int16_t* cur, int curStride, const int16_t* resi, int resiStride, int bitDepth,
+                              const FrameJob* jobs, int nJobs, int threads, int passes )
+{
+  rdPair(); quantObj(); selectTCoeffOps( 1 );
+  { static SPS* warm = new SPS; ( void ) warm; }
+  auto worker = [&]( int t )
+  {
+    std::vector<uint64_t> out;
+    for( int p = 0; p < passes; p++ )
+      for( int j = 0; j < nJobs; j++ )
+      {
+        const FrameJob& jb = jobs[j];
+        const int per = ( jb.n + threads - 1 ) / threads, b = std::min( jb.n, t * per ), e = std::min( jb.n, b + per );
+        if( e <= b ) continue;
+        out.resize( e - b );
+        if( jb.kind == 0 )
+          vvref_dist_batch( 1, jb.df, org, orgStride, cur, curStride, jb.size, jb.size, bitDepth, jb.subShift, ( const DistItem* ) jb.items + b, e - b, out.data() );
+        else
+          vvref_tu_rdo_batch( 1, resi, resiStride, ( const int32_t* ) jb.items + b, e - b, jb.size, jb.size, bitDepth, ( const int16_t* ) jb.aux + 2 * b, 8, nullptr, nullptr, out.data() );
+      }
+  };
+  worker( 0 );      // warm-up pass on the calling thread (also initialises the lazily built statics before threads start)
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for( int t = 0; t < threads; t++ ) th.emplace_back( worker, t );
+  for( auto& x : th ) x.join();
+  return std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
 }
 
 // ---------------------------------------------------------------------------------------------
