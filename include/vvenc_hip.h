@@ -79,6 +79,12 @@ VVHIP_API int vvhip_dist_batch( vvhip_ctx* ctx, int func,
                                 int width, int height, int sub_shift, int bit_depth,
                                 const vvhip_dist_item* d_items, int n, uint64_t* d_out );
 
+/* Several batches of ONE function over the same plane pair (e.g. all block sizes of a frame's SAD work list) in as few launches as
+ * possible: semantically n_jobs x vvhip_dist_batch; jobs the merged kernels cannot take run as separate launches.  `jobs` is a HOST array. */
+typedef struct { int32_t width, height, sub_shift, n; const vvhip_dist_item* d_items; uint64_t* d_out; } vvhip_dist_job;
+VVHIP_API int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,
+                                const vvhip_dist_job* jobs_host, int n_jobs );
+
 /* DMVR 5-position SAD: RdCost::xGetSAD8X5 / xGetSAD16X5 (RdCost.cpp:1984-2034). width 8 or 16.
  * d_out5[5*i+k] = SAD(org+k, cur-k) >> 1; entry 2 is left untouched when calc_centre == 0.       */
 VVHIP_API int vvhip_sad_x5_batch( vvhip_ctx* ctx,

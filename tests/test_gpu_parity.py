@@ -297,3 +297,27 @@ def test_properties_1080p_4k(hip):
             x, y = int(bx[b]), int(by[b])
             assert np.array_equal(rec_blocks[b], full_rec[y:y + S, x:x + S])
             assert int(st["sse"][b]) == int(((d[y:y + S, x:x + S] - rec_blocks[b]) ** 2).sum())
+
+
+def test_dist_multi_equals_batches(hip):
+    """vvhip_dist_multi (merged launches) == one vvhip_dist_batch per job, for every function and a mix of mergeable / unmergeable sizes"""
+    import torch
+    hp = hip.hp
+    rng = np.random.default_rng(107)
+    org, cur = rand_plane(rng, 256, 384), rand_plane(rng, 256, 384)
+    po, pc = hp.plane(org, 0), hp.plane(cur, 0)
+    for func in ("SAD", "SSE", "HAD", "HAD_fast"):
+        jobs, refs = [], []
+        for (w, h, ss) in [(8, 8, 0), (16, 16, 1), (4, 4, 0), (32, 32, 1), (64, 64, 1), (16, 8, 0), (128, 128, 1), (8, 8, 0), (24, 24, 0), (32, 32, 0), (64, 64, 0)]:
+            if func != "SAD":
+                ss = 0
+            n = int(rng.integers(1, 300))
+            it = np.stack([rng.integers(0, 256 - h, n) * po.stride + rng.integers(0, 384 - w, n),
+                           rng.integers(0, 256 - h, n) * pc.stride + rng.integers(0, 384 - w, n)], 1).astype(np.int32)
+            d_it = hp.to_device(it)
+            out = torch.full((n,), -1, dtype=torch.int64, device=hp.device)
+            jobs.append((w, h, ss, n, d_it, out))
+            refs.append(hp.dist_batch(func, po, pc, d_it, n, w, h, ss).cpu().numpy())
+        hp.dist_multi(func, po, pc, jobs)
+        for (w, h, ss, n, _, out), ref in zip(jobs, refs):
+            assert np.array_equal(out.cpu().numpy(), ref), (func, w, h, ss)

@@ -43,12 +43,12 @@ enum { MODE_SAD = 0, MODE_SSE = 1, MODE_SAD_X5 = 2, MODE_SAD_MIN2 = 3 };
 // chunk c of a candidate = (row c / lpr, segment c % lpr); lanes of a team stride over chunks.
 // ---------------------------------------------------------------------------------------------
 template<int CH, int MODE>
-__global__ void __launch_bounds__( 256 )
-sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
-              int lpr /* lanes (segments) per row = w / CH */, int lprShift /* log2(lpr) or -1 */, int rowsEff, int subShift, int log2Lpc,
-              const vvhip_dist_item* __restrict__ items, int n, int calcCentre, uint64_t* __restrict__ out )
+__device__ __forceinline__ void
+sadSseBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
+            int lpr /* lanes (segments) per row = w / CH */, int lprShift /* log2(lpr) or -1 */, int rowsEff, int subShift, int log2Lpc,
+            const vvhip_dist_item* __restrict__ items, int n, int calcCentre, uint64_t* __restrict__ out )
 {
-  const int gid  = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gid  = blockIndex * blockDim.x + threadIdx.x;
   const int lpc  = 1 << log2Lpc;
   const int team = gid >> log2Lpc;
   const int lt   = gid & ( lpc - 1 );
@@ -111,6 +111,31 @@ sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __r
       else { const uint64_t h = out[team]; out[team] = h < 2 * v ? h : 2 * v; }          // RdCost.cpp:1815
     }
   }
+}
+
+template<int CH, int MODE>
+__global__ void __launch_bounds__( 256 )
+sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
+              int lpr, int lprShift, int rowsEff, int subShift, int log2Lpc,
+              const vvhip_dist_item* __restrict__ items, int n, int calcCentre, uint64_t* __restrict__ out )
+{
+  sadSseBody<CH, MODE>( blockIdx.x, org, orgStride, cur, curStride, lpr, lprShift, rowsEff, subShift, log2Lpc, items, n, calcCentre, out );
+}
+
+// Several (function-compatible) batches in ONE launch: a workgroup finds its job from the block-range table (wave-uniform scalar
+// work) and runs the same body.  Removes the launch gaps and the tails of the short per-size launches of a frame's work lists.
+struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, fast16, tilesX, tilesPerCand; const vvhip_dist_item* items; uint64_t* out; };
+struct DistMultiJobs { int nJobs; DistJobGeom j[8]; };
+
+template<int MODE>
+__global__ void __launch_bounds__( 256 )
+sadSseMultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride, DistMultiJobs jobs )
+{
+  int k = 0;
+#pragma unroll
+  for( int i = 1; i < 8; i++ ) if( i < jobs.nJobs && ( int ) blockIdx.x >= jobs.j[i].blockStart ) k = i;
+  const DistJobGeom& g = jobs.j[k];
+  sadSseBody<8, MODE>( blockIdx.x - g.blockStart, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -238,13 +263,13 @@ hadKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __rest
 // A candidate's tiles sit on LPC consecutive lanes (LPC = min(#tiles, 64), power of two) and are summed with DPP.
 // ---------------------------------------------------------------------------------------------
 template<int TW, int TH, bool FAST16>
-__global__ void __launch_bounds__( 256 )
-hadTileKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
-               int tilesX, int tilesPerCand, int log2Lpc,
-               const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+__device__ __forceinline__ void
+hadTileBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
+             int tilesX, int tilesPerCand, int log2Lpc,
+             const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
 {
   constexpr int PX = FAST16 ? 16 : TW, PY = FAST16 ? 16 : TH;
-  const int gid  = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gid  = blockIndex * blockDim.x + threadIdx.x;
   const int lpc  = 1 << log2Lpc;
   const int cand = gid >> log2Lpc;
   const int lt   = gid & ( lpc - 1 );
@@ -307,6 +332,26 @@ hadTileKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __
   // per-lane sums stay below 2^32 (<= 4 tiles x 64 x 2^20); the candidate total can exceed it only for full-range int16 data -> 64-bit group sum
   const uint64_t tot = vvhipGroupSum64( sum, lpc, threadIdx.x & 63 );
   if( valid && lt == 0 ) out[cand] = tot;
+}
+
+template<int TW, int TH, bool FAST16>
+__global__ void __launch_bounds__( 256 )
+hadTileKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
+               int tilesX, int tilesPerCand, int log2Lpc,
+               const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+{
+  hadTileBody<TW, TH, FAST16>( blockIdx.x, org, orgStride, cur, curStride, tilesX, tilesPerCand, log2Lpc, items, n, out );
+}
+
+__global__ void __launch_bounds__( 256 )
+hadTile8MultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride, DistMultiJobs jobs )
+{
+  int k = 0;
+#pragma unroll
+  for( int i = 1; i < 8; i++ ) if( i < jobs.nJobs && ( int ) blockIdx.x >= jobs.j[i].blockStart ) k = i;
+  const DistJobGeom& g = jobs.j[k];
+  if( g.fast16 ) hadTileBody<8, 8, true>( blockIdx.x - g.blockStart, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  else           hadTileBody<8, 8, false>( blockIdx.x - g.blockStart, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -475,6 +520,66 @@ int vvhip_dist_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_st
   default:
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_batch: unknown function %d", func );
   }
+}
+
+int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,
+                      const vvhip_dist_job* jobs, int n_jobs )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi: bad job list" );
+  // mergeable: SAD / SSE with width % 8 == 0, Hadamard whose ladder ends on the 8x8 or 16x16_fast tile; everything else runs as separate launches
+  auto mergeable = [&]( const vvhip_dist_job& jb ) {
+    if( jb.n <= 0 || jb.width < 8 || jb.height < 1 || jb.width > 128 || jb.height > 128 ) return false;
+    if( func == VVHIP_DF_SAD ) return ( jb.width & 7 ) == 0 && jb.sub_shift >= 0 && jb.sub_shift <= 1 && ( jb.height >> jb.sub_shift ) >= 1 && !( jb.height & ( ( 1 << jb.sub_shift ) - 1 ) );
+    if( func == VVHIP_DF_SSE ) return ( jb.width & 7 ) == 0;
+    if( func == VVHIP_DF_HAD || func == VVHIP_DF_HAD_FAST ) return jb.width == jb.height && ( jb.width & 7 ) == 0;
+    return false; };
+  int i = 0;
+  while( i < n_jobs )
+  {
+    if( !mergeable( jobs[i] ) )
+    {
+      if( jobs[i].n > 0 )
+      {
+        const int rc = vvhip_dist_batch( ctx, func, d_org, org_stride, d_cur, cur_stride, jobs[i].width, jobs[i].height, jobs[i].sub_shift, bit_depth, jobs[i].d_items, jobs[i].n, jobs[i].d_out );
+        if( rc ) return rc;
+      }
+      i++;
+      continue;
+    }
+    DistMultiJobs mj; mj.nJobs = 0;
+    long blocks = 0;
+    while( i < n_jobs && mj.nJobs < 8 && mergeable( jobs[i] ) )
+    {
+      const vvhip_dist_job& jb = jobs[i];
+      DistJobGeom& g = mj.j[mj.nJobs];
+      g.items = jb.d_items; g.out = jb.d_out; g.n = jb.n; g.blockStart = ( int ) blocks; g.fast16 = 0; g.tilesX = 0; g.tilesPerCand = 0;
+      g.lpr = 0; g.lprShift = 0; g.rowsEff = 0; g.subShift = 0;
+      int lpc;
+      if( func == VVHIP_DF_SAD || func == VVHIP_DF_SSE )
+      {
+        g.subShift = func == VVHIP_DF_SAD ? jb.sub_shift : 0;
+        g.rowsEff = jb.height >> g.subShift; g.lpr = jb.width / 8; g.lprShift = isPow2( g.lpr ) ? ilog2i( g.lpr ) : -1;
+        lpc = pow2Floor( g.lpr * g.rowsEff ); if( lpc > 64 ) lpc = 64;
+      }
+      else
+      {
+        g.fast16 = ( func == VVHIP_DF_HAD_FAST && jb.width % 32 == 0 ) ? 1 : 0;
+        const int px = g.fast16 ? 16 : 8;
+        g.tilesX = jb.width / px; g.tilesPerCand = g.tilesX * ( jb.height / px );
+        lpc = pow2Floor( g.tilesPerCand ); if( lpc > 64 ) lpc = 64;
+        if( g.tilesPerCand % lpc ) lpc = 1;
+      }
+      g.log2Lpc = ilog2i( lpc );
+      blocks += ( ( long ) jb.n * lpc + 255 ) / 256;
+      mj.nJobs++; i++;
+    }
+    if( func == VVHIP_DF_SAD )      hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SAD> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else if( func == VVHIP_DF_SSE ) hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SSE> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else                            hipLaunchKernelGGL( hadTile8MultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    VVHIP_LAUNCH_CHECK( ctx );
+  }
+  return VVHIP_OK;
 }
 
 int vvhip_sad_x5_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride,

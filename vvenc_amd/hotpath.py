@@ -139,6 +139,21 @@ class HotPath:
                                          cur.buf_ptr, cur.stride, w, h, sub_shift, bit_depth, _ptr(d_items), n, _ptr(out)))
         return out
 
+    class _DistJob(C.Structure):
+        _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("sub_shift", C.c_int32), ("n", C.c_int32), ("d_items", C.c_void_p), ("d_out", C.c_void_p)]
+
+    def make_dist_jobs(self, jobs):
+        """jobs: list of (w, h, sub_shift, n, d_items, d_out) -> prepared host job table (keep the tensors alive while it is in use)"""
+        arr = (self._DistJob * len(jobs))(*[self._DistJob(w, h, ss, n, it.data_ptr(), out.data_ptr()) for (w, h, ss, n, it, out) in jobs])
+        return arr, len(jobs), jobs
+
+    def dist_multi(self, func, org, cur, jobs, bit_depth=10):
+        """one merged launch per function where the kernels allow it; `jobs` = list of tuples or a table from make_dist_jobs"""
+        if isinstance(jobs, list):
+            jobs = self.make_dist_jobs(jobs)
+        self._ck(self.L.vvhip_dist_multi(self.ctx, DF[func] if isinstance(func, str) else func, org.buf_ptr, org.stride, cur.buf_ptr, cur.stride,
+                                         bit_depth, jobs[0], jobs[1]))
+
     def sad_x5_batch(self, org, cur, d_items, n, w, h, sub_shift=1, calc_centre=True, out=None):
         if out is None:
             out = torch.zeros(n * 5, dtype=torch.int64, device=self.device)

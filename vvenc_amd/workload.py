@@ -92,20 +92,36 @@ class FrameWorkload:
         self.dist_jobs.sort(key=lambda j: ("SAD", "HAD_fast", "SSE").index(j[0]))
         self.class_launches = {"SAD": len(SIZES), "HAD_fast": len(SIZES), "SSE": len(SIZES), "TU": len(TU_SIZES)}
 
-    # one pass of the hot path over the frame: 12 distortion launches + 3 fused TU launches
+        self.merged = True      # one vvhip_dist_multi launch per function (all block sizes) instead of one launch per size
+        self.job_tables = {func: hp.make_dist_jobs([(S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f == func])
+                           for func in ("SAD", "HAD_fast", "SSE")}
+        self.class_launches_merged = {"SAD": 1, "HAD_fast": 1, "SSE": 1, "TU": len(TU_SIZES)}
+
+    # one pass of the hot path over the frame: 3 merged distortion launches (or 12 per-size ones) + 3 fused TU launches
     def run(self, timers=None):
         hp = self.hp
         prev = None
-        for (func, S, ss, n, d_items, d_out, _) in self.dist_jobs:
-            if timers is not None and func != prev:
-                if prev is not None:
-                    timers.stop(prev)
-                timers.start(func)
-                prev = func
-            hp.dist_batch(func, self.org, self.ref, d_items, n, S, S, ss, self.bit_depth, out=d_out)
-        if timers is not None:
-            timers.stop(prev)
-            timers.start("TU")
+        if self.merged:
+            for func in ("SAD", "HAD_fast", "SSE"):
+                if timers is not None:
+                    timers.start(func)
+                hp.dist_multi(func, self.org, self.ref, self.job_tables[func], self.bit_depth)
+                if timers is not None:
+                    timers.stop(func)
+            prev = "SSE"
+            if timers is not None:
+                timers.start("TU")
+        else:
+            for (func, S, ss, n, d_items, d_out, _) in self.dist_jobs:
+                if timers is not None and func != prev:
+                    if prev is not None:
+                        timers.stop(prev)
+                    timers.start(func)
+                    prev = func
+                hp.dist_batch(func, self.org, self.ref, d_items, n, S, S, ss, self.bit_depth, out=d_out)
+            if timers is not None:
+                timers.stop(prev)
+                timers.start("TU")
         for (S, n, d_off, d_qp, lvl, rec, st, _, _) in self.tu_jobs:
             hp.tu_rdo(self.resi, d_off, n, S, S, d_qp, 0, 0, self.bit_depth, 8, lvl, rec, st)
         if timers is not None:
