@@ -359,49 +359,69 @@ hadTile8MultiKernel( const int16_t* __restrict__ org, int orgStride, const int16
 // LDS once (coalesced row reads), the block's original rows live in LDS too; each wave then walks
 // displacements, lanes split the block's row segments.
 // ---------------------------------------------------------------------------------------------
+// LDS-tiled full-search SAD.  One workgroup per block:
+//   * the reference window (w + 2*rx) x (h + 2*ry) is read from the picture ONCE (coalesced rows) into LDS, twice: copy A as is and copy B
+//     shifted by one sample, so that any 2-sample pair (x + dx, x + dx + 1), x even, is an aligned 32-bit LDS word in A (dx even) or B (dx odd);
+//   * the block's original rows are staged too and read back as wave-wide broadcasts;
+//   * lanes own CANDIDATES (consecutive dx, 4 consecutive dy each): per original word a lane issues 4 window reads and 4 v_sad_u16, i.e. the
+//     picture data is re-used (2rx+1)(2ry+1) times from LDS and never re-fetched.
+//   * a block's displacement rows can be split over several workgroups (gridDim.y) so that big blocks still fill 256 CUs; every workgroup
+//     stages only the window rows its displacement rows touch.  Samples are stored biased (x ^ 0x8000) so v_sad_u16 is exact for signed Pel.
+template<int KDY>
 __global__ void __launch_bounds__( 256 )
 sadSurfaceKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ ref, int refStride,
-                  int w, int h, int subShift, int rx, int ry,
+                  int w, int h, int subShift, int rx, int ry, int pitchDw, int copyBOffDw, int groupsPerSplit,
                   const int32_t* __restrict__ blkOrgOff, const int32_t* __restrict__ blkRefOff, uint32_t* __restrict__ out )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemRaw[];
-  int16_t* sOrg = reinterpret_cast<int16_t*>( smemRaw );          // rowsEff x w
-  const int step = 1 << subShift, rowsEff = h >> subShift;
-  const int winW = w + 2 * rx, winH = h + 2 * ry;
-  const int winStride = ( winW + 1 ) | 1;                          // odd number of int16 -> spreads LDS banks across rows
-  int16_t* sWin = sOrg + ( ( rowsEff * w + 7 ) & ~7 );
+  uint32_t* sWin = reinterpret_cast<uint32_t*>( smemRaw );                     // copy A at 0, copy B at copyBOffDw (dwords)
+  const int step = 1 << subShift, rowsEff = h >> subShift, wDw = w >> 1;
+  const int nx = 2 * rx + 1, ny = 2 * ry + 1, nyG = ( ny + KDY - 1 ) / KDY;
+  const int g0 = blockIdx.y * groupsPerSplit, g1 = min( nyG, g0 + groupsPerSplit );   // displacement-row groups of this workgroup
+  const int dyFirst = g0 * KDY;                                                          // first displacement row (0-based, = dy + ry)
+  const int winW = w + 2 * rx, winRows = h + ( g1 - g0 ) * KDY;                          // rows [dyFirst, dyFirst + winRows) of the full window
+  uint32_t* sOrg = sWin + 2 * copyBOffDw;
+  uint16_t* a16 = reinterpret_cast<uint16_t*>( sWin );
+  uint16_t* b16 = reinterpret_cast<uint16_t*>( sWin + copyBOffDw );
+  uint16_t* o16 = reinterpret_cast<uint16_t*>( sOrg );
 
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int16_t* po = org + blkOrgOff[b];
-  const int16_t* pr = ref + blkRefOff[b] - ( ptrdiff_t ) ry * refStride - rx;
-  for( int i = threadIdx.x; i < rowsEff * w; i += blockDim.x )
+  const int16_t* pr = ref + blkRefOff[b] + ( ptrdiff_t ) ( dyFirst - ry ) * refStride - rx;
+  const int rowsAvail = h + 2 * ry - dyFirst;                                            // window rows that exist below dyFirst
+  for( int i = tid; i < rowsEff * w; i += blockDim.x ) { const int r = i / w, x = i - r * w; o16[i] = ( uint16_t ) po[( ptrdiff_t ) ( r * step ) * orgStride + x] ^ 0x8000u; }
+  const int pitch = 2 * pitchDw;
+  for( int i = tid; i < winRows * ( winW + 1 ); i += blockDim.x )
   {
-    const int r = i / w, x = i - r * w;
-    sOrg[i] = po[( ptrdiff_t ) ( r * step ) * orgStride + x];
-  }
-  for( int i = threadIdx.x; i < winH * winW; i += blockDim.x )
-  {
-    const int r = i / winW, x = i - r * winW;
-    sWin[r * winStride + x] = pr[( ptrdiff_t ) r * refStride + x];
+    const int r = i / ( winW + 1 ), x = i - r * ( winW + 1 );
+    uint16_t v = 0;
+    if( r < rowsAvail && x < winW ) v = ( uint16_t ) pr[( ptrdiff_t ) r * refStride + x] ^ 0x8000u;
+    if( x < winW ) a16[r * pitch + x] = v;
+    if( x > 0 ) b16[r * pitch + x - 1] = v;          // B[i] = A[i + 1]
   }
   __syncthreads();
 
-  const int nx = 2 * rx + 1, ny = 2 * ry + 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  const int total = rowsEff * w;
-  for( int m = wave; m < nx * ny; m += waves )
+  for( int m = tid; m < nx * ( g1 - g0 ); m += blockDim.x )
   {
-    const int my = m / nx, mx = m - my * nx;
-    uint32_t acc = 0;
-    for( int i = lane; i < total; i += 64 )
+    const int gl = m / nx, mx = m - gl * nx, my0 = ( g0 + gl ) * KDY;
+    const uint32_t* base = sWin + ( ( mx & 1 ) ? copyBOffDw : 0 ) + ( mx >> 1 ) + gl * KDY * pitchDw;
+    uint32_t acc[KDY];
+#pragma unroll
+    for( int k = 0; k < KDY; k++ ) acc[k] = 0;
+    for( int r = 0; r < rowsEff; r++ )
     {
-      const int r = i / w, x = i - r * w;
-      const int a = sOrg[i];
-      const int c = sWin[( my + r * step ) * winStride + mx + x];
-      acc += ( uint32_t ) abs( a - c );
+      const uint32_t* rowp = base + r * step * pitchDw;
+      const uint32_t* op = sOrg + r * wDw;
+      for( int xp = 0; xp < wDw; xp++ )
+      {
+        const uint32_t o = op[xp];
+#pragma unroll
+        for( int k = 0; k < KDY; k++ ) acc[k] = __builtin_amdgcn_sad_u16( rowp[k * pitchDw + xp], o, acc[k] );
+      }
     }
-    acc = vvhipGroupSum32( acc, 64, lane );
-    if( lane == 0 ) out[( size_t ) b * nx * ny + m] = acc << subShift;
+#pragma unroll
+    for( int k = 0; k < KDY; k++ )
+      if( my0 + k < ny ) out[( size_t ) b * nx * ny + ( my0 + k ) * nx + mx] = acc[k] << subShift;
   }
 }
 
@@ -597,19 +617,33 @@ int vvhip_sad_surface( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, con
                        const int32_t* d_block_org_off, const int32_t* d_block_ref_off, int n_blocks, uint32_t* d_out )
 {
   if( !ctx ) return VVHIP_E_ARG;
-  if( width < 2 || height < 2 || width > 128 || height > 128 || sub_shift < 0 || sub_shift > 1 || range_x < 0 || range_y < 0 || n_blocks < 0 )
+  if( width < 2 || height < 2 || width > 128 || height > 128 || ( width & 1 ) || sub_shift < 0 || sub_shift > 1 || range_x < 0 || range_y < 0 || n_blocks < 0 ||
+      ( height & ( ( 1 << sub_shift ) - 1 ) ) )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_sad_surface: bad geometry" );
   if( n_blocks == 0 ) return VVHIP_OK;
   const int rowsEff = height >> sub_shift;
-  const int winW = width + 2 * range_x, winH = height + 2 * range_y;
-  const int winStride = ( winW + 1 ) | 1;
-  const size_t smem = ( size_t ) ( ( ( rowsEff * width + 7 ) & ~7 ) + winH * winStride ) * sizeof( int16_t );
-  if( smem > 160 * 1024 ) return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_sad_surface: window %dx%d needs %zu B of LDS (> 160 KiB)", winW, winH, smem );
-  if( smem > 64 * 1024 )
-    VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) sadSurfaceKernel, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) smem ) );
-  hipLaunchKernelGGL( sadSurfaceKernel, dim3( n_blocks ), dim3( 256 ), smem, ctx->stream,
-                      d_org, org_stride, d_ref, ref_stride, width, height, sub_shift, range_x, range_y,
-                      d_block_org_off, d_block_ref_off, d_out );
+  const int nx = 2 * range_x + 1, ny = 2 * range_y + 1;
+  // displacement rows per lane (power of two): minimise wave trips x (window reads + one org read)
+  int kdy = 1, bestCost = 1 << 30;
+  for( int k = 1; k <= 8; k *= 2 )
+  {
+    const int slots = nx * ( ( ny + k - 1 ) / k ), cost = ( ( slots + 63 ) / 64 ) * ( k + 1 );
+    if( cost < bestCost ) { bestCost = cost; kdy = k; }
+  }
+  const int nyG = ( ny + kdy - 1 ) / kdy;
+  int splits = ( 1024 + n_blocks - 1 ) / n_blocks; if( splits > nyG ) splits = nyG; if( splits < 1 ) splits = 1;
+  const int groupsPerSplit = ( nyG + splits - 1 ) / splits;
+  splits = ( nyG + groupsPerSplit - 1 ) / groupsPerSplit;
+  const int winW = width + 2 * range_x, winRows = height + groupsPerSplit * kdy;
+  int pitchDw = ( winW + 2 ) / 2; pitchDw |= 1;                                   // odd dword pitch: consecutive window rows start on different banks
+  int copyB = pitchDw * winRows; copyB = ( ( copyB + 31 ) & ~31 ) + 16;           // copy B sits 16 banks away from copy A
+  const size_t smem = ( size_t ) ( 2 * copyB + ( rowsEff * width ) / 2 + 8 ) * sizeof( uint32_t );
+  if( smem > 160 * 1024 ) return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_sad_surface: window %dx%d needs %zu B of LDS (> 160 KiB)", winW, winRows, smem );
+#define SURF( K ) { if( smem > 64 * 1024 ) VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) sadSurfaceKernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) smem ) ); \
+    hipLaunchKernelGGL( ( sadSurfaceKernel<K> ), dim3( n_blocks, splits ), dim3( 256 ), smem, ctx->stream, d_org, org_stride, d_ref, ref_stride, width, height, sub_shift, \
+                        range_x, range_y, pitchDw, copyB, groupsPerSplit, d_block_org_off, d_block_ref_off, d_out ); }
+  switch( kdy ) { case 1: SURF( 1 ) break; case 2: SURF( 2 ) break; case 4: SURF( 4 ) break; default: SURF( 8 ) break; }
+#undef SURF
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
 }
