@@ -93,6 +93,25 @@ VVHIP_API int vvhip_sad_x5_batch( vvhip_ctx* ctx,
                                   int width, int height, int sub_shift, int calc_centre,
                                   const vvhip_dist_item* d_items, int n, uint64_t* d_out5 );
 
+/* GEO masked SAD: RdCost::xGetSADwMask (RdCost.cpp:2062-2093), table slot DF_SAD_WITH_MASK (TypeDef.h:339-382).
+ *   d_out[i] = ( sum over processed rows r, columns x of |org - cur| * mask[...] ) << sub_shift
+ * with the mask walked exactly as the reference does: +step_x per sample, + mask_stride*(1<<sub_shift) + mask_stride2 per
+ * processed row, starting at d_mask + d_mask_off[i] (d_mask_off may be NULL: every candidate starts at d_mask).               */
+VVHIP_API int vvhip_sad_mask_batch( vvhip_ctx* ctx,
+                                    const int16_t* d_org, int org_stride,
+                                    const int16_t* d_cur, int cur_stride,
+                                    const int16_t* d_mask, int mask_stride, int step_x, int mask_stride2,
+                                    int width, int height, int sub_shift, int bit_depth,
+                                    const vvhip_dist_item* d_items, const int32_t* d_mask_off, int n, uint64_t* d_out );
+
+/* Fixed-weight SSE: RdCost::m_fxdWtdPredPtr = fixWeightedSSE_Core (RdCost.cpp:1948-1982, RdCost.h:117).
+ *   d_out[i] = sum ( int )( ( weight_i * d*d + 2^15 ) >> 16 ),  width even or 1.                                               */
+VVHIP_API int vvhip_fix_weighted_sse_batch( vvhip_ctx* ctx,
+                                            const int16_t* d_org, int org_stride,
+                                            const int16_t* d_cur, int cur_stride,
+                                            int width, int height, int bit_depth,
+                                            const vvhip_dist_item* d_items, const uint32_t* d_weights, int n, uint64_t* d_out );
+
 /* Full-window SAD cost surface for one block size: for block b (top-left org sample offset
  * d_block_org_off[b], co-located reference offset d_block_ref_off[b]) and every integer displacement
  * (dx,dy), |dx| <= range_x, |dy| <= range_y:

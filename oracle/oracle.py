@@ -87,6 +87,8 @@ class Oracle(_Base):
         L.orc_had_2sad.argtypes = [vp, vp, i32, i32]
         L.orc_sad_x5.restype = None
         L.orc_sad_x5.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32]
+        L.orc_sad_mask.restype = u64
+        L.orc_sad_mask.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32]
         L.orc_fix_weighted_sse.restype = u64
         L.orc_fix_weighted_sse.argtypes = [vp, i32, vp, i32, i32, i32, C.c_uint32]
         L.orc_tr_matrix.argtypes = [i32, i32, vp]
@@ -147,6 +149,13 @@ class Oracle(_Base):
         po, so = self._ptr_stride(org)
         pc, sc = self._ptr_stride(cur)
         return self.L.orc_fix_weighted_sse(po, so, pc, sc, w, h, weight)
+
+    def sad_mask(self, org, cur, mask, step_x, mask_stride2, w, h, sub_shift=0):
+        """mask: (array, y, x) view whose first sample is the first mask sample read; mask_stride = the array's row pitch"""
+        po, so = self._ptr_stride(org)
+        pc, sc = self._ptr_stride(cur)
+        pm, sm = self._ptr_stride(mask)
+        return self.L.orc_sad_mask(po, so, pc, sc, pm, sm, step_x, mask_stride2, w, h, sub_shift)
 
     # ---- transforms ----
     def tr_matrix(self, tr_type, log2n):
@@ -325,6 +334,8 @@ class RefLib(_Base):
         L.vvref_sad_x5.argtypes = [i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32]
         L.vvref_fix_weighted_sse.restype = u64
         L.vvref_fix_weighted_sse.argtypes = [i32, vp, i32, vp, i32, i32, i32, i32, C.c_uint32]
+        L.vvref_sad_mask.restype = u64
+        L.vvref_sad_mask.argtypes = [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32]
         L.vvref_tr_matrix.argtypes = [i32, i32, vp]
         L.vvref_fwd_1d.argtypes = [i32, i32, i32, vp, vp, i32, i32, i32, i32]
         L.vvref_inv_1d.argtypes = [i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32]
@@ -367,6 +378,12 @@ class RefLib(_Base):
         po, so = self._ptr_stride(org)
         pc, sc = self._ptr_stride(cur)
         return self.L.vvref_fix_weighted_sse(self.simd, po, so, pc, sc, w, h, 10, weight)
+
+    def sad_mask(self, org, cur, mask, step_x, mask_stride2, w, h, sub_shift=0):
+        po, so = self._ptr_stride(org)
+        pc, sc = self._ptr_stride(cur)
+        pm, sm = self._ptr_stride(mask)
+        return self.L.vvref_sad_mask(self.simd, po, so, pc, sc, pm, sm, step_x, mask_stride2, w, h, 10, sub_shift)
 
     def tr_matrix(self, tr_type, log2n):
         n = 1 << log2n

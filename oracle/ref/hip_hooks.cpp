@@ -63,6 +63,7 @@ vvhip::DistParam conv( const vvenc::DistParam& dp )
   d.org.buf = dp.org.buf; d.org.stride = ( int ) dp.org.stride; d.org.width = dp.org.width; d.org.height = dp.org.height;
   d.cur.buf = dp.cur.buf; d.cur.stride = ( int ) dp.cur.stride; d.cur.width = dp.org.width; d.cur.height = dp.org.height;
   d.bitDepth = dp.bitDepth; d.subShift = dp.subShift; d.applyWeight = dp.applyWeight;
+  d.mask = dp.mask; d.maskStride = dp.maskStride; d.stepX = dp.stepX; d.maskStride2 = dp.maskStride2;
   return d;
 }
 
@@ -79,7 +80,12 @@ template<int IDX> void x5Tramp( const vvenc::DistParam& dp, vvenc::Distortion* c
   for( int i = 0; i < 5; i++ ) cost[i] = c[i];
 }
 
-template<int I> struct Fill { static void go( vvenc::RdCost* rc ) { if( I != vvenc::DF_SAD_WITH_MASK ) rc->m_afpDistortFunc[0][I] = distTramp<I>; Fill<I - 1>::go( rc ); } };
+template<int I> struct Fill { static void go( vvenc::RdCost* rc ) { rc->m_afpDistortFunc[0][I] = distTramp<I>; Fill<I - 1>::go( rc ); } };
+vvenc::Distortion fxdWtdTramp( const vvenc::DistParam& dp, uint32_t fixedWeight )
+{
+  g_calls[0]++;
+  return g_rd->m_fxdWtdPredPtr( conv( dp ), fixedWeight );
+}
 template<> struct Fill<-1> { static void go( vvenc::RdCost* ) {} };
 
 void initRdCost( vvenc::RdCost* rc )
@@ -89,6 +95,7 @@ void initRdCost( vvenc::RdCost* rc )
   Fill<vvenc::DF_TOTAL_FUNCTIONS - 1>::go( rc );      // row 0 (bitDepth <= 10); row 1 stays the scalar copy made before SIMD init (RdCost.cpp:126)
   rc->m_afpDistortFuncX5[0] = x5Tramp<0>;
   rc->m_afpDistortFuncX5[1] = x5Tramp<1>;
+  rc->m_fxdWtdPredPtr = fxdWtdTramp;
 }
 
 void xQuantTramp( const vvenc::TransformUnit tu, const vvenc::ComponentID compID, const vvenc::CCoeffBuf& piCoef, vvenc::CoeffSigBuf piQCoef, vvenc::TCoeff& uiAbsSum,

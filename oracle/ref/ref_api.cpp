@@ -156,6 +156,23 @@ API void vvref_sad_x5( int simd, const int16_t* org, int orgStride, const int16_
   for( int i = 0; i < 5; i++ ) cost5[i] = c[i];
 }
 
+// DF_SAD_WITH_MASK (RdCost.cpp:2062-2093, SIMD row RdCostX86.h:2629).  The SIMD row derives the row advance from maskStride alone and
+// mirrors the mask for stepX == -1, so it equals the scalar row only for the two parameterisations setDistParamGeo produces:
+// (stepX 1, maskStride2 -w) and (stepX -1, maskStride2 +w).
+API uint64_t vvref_sad_mask( int simd, const int16_t* org, int orgStride, const int16_t* cur, int curStride,
+                             const int16_t* mask, int maskStride, int stepX, int maskStride2, int w, int h, int bitDepth, int subShift )
+{
+  RdCost& rc = *rdPair().rc[simd ? 1 : 0];
+  DistParam dp;
+  dp.org = CPelBuf( org, orgStride, w, h );
+  dp.cur = CPelBuf( cur, curStride, w, h );
+  dp.bitDepth = bitDepth;
+  dp.subShift = subShift;
+  dp.compID   = COMP_Y;
+  dp.mask = mask; dp.maskStride = maskStride; dp.stepX = stepX; dp.maskStride2 = maskStride2;
+  return rc.m_afpDistortFunc[0][DF_SAD_WITH_MASK]( dp );
+}
+
 API uint64_t vvref_fix_weighted_sse( int simd, const int16_t* org, int orgStride, const int16_t* cur, int curStride,
                                      int w, int h, int bitDepth, uint32_t weight )
 {

@@ -60,6 +60,20 @@ static void test_RdCost()
     orc_sad_x5( dp.org.buf, stride, dp.cur.buf, stride, w, h, 1, exp, 0 );
     for( int k = 0; k < 5; k++ ) CHECK_EQ( got[k], exp[k], "SADX5" );
   }
+  // (2b) GEO masked SAD (both walks setDistParamGeo produces) and the fixed-weight SSE pointer
+  {
+    std::vector<int16_t> mask( 200 * 300 );
+    for( int y = 0; y < 200; y++ ) for( int x = 0; x < 300; x++ ) { int v = ( x - y ) / 3 + 4; mask[y * 300 + x] = ( int16_t ) ( v < 0 ? 0 : v > 8 ? 8 : v ); }
+    for( int w : { 8, 16, 32 } ) for( int h : { 8, 32 } ) for( int stepX : { 1, -1 } ) for( int ss : { 0, 1 } )
+    {
+      CPelBuf o; o.buf = org0 + 30 * stride + 50; o.stride = stride; o.width = w; o.height = h;
+      const int16_t* m = mask.data() + 20 * 300 + 100 + ( stepX < 0 ? w - 1 : 0 );
+      DistParam dp; dp.subShift = ss;
+      opt.setDistParamGeo( dp, o, cur0 + 60 * stride + 80, stride, m, 300, stepX, -stepX * w, 10, 0 );
+      CHECK_EQ( dp.distFunc( dp ), orc_sad_mask( o.buf, stride, dp.cur.buf, stride, m, 300, stepX, -stepX * w, w, h, ss ), "SAD_WITH_MASK" );
+      CHECK_EQ( opt.m_fxdWtdPredPtr( dp, 40000u + w ), orc_fix_weighted_sse( o.buf, stride, dp.cur.buf, stride, w, h, 40000u + w ), "fxdWtdPred" );
+    }
+  }
   // (3) batching: all positions of a TZ-style star around a start vector are enqueued, ONE flush, results replayed in order
   {
     const int w = 16, h = 16, ox = 96, oy = 64;

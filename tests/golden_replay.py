@@ -31,6 +31,17 @@ def check_distortion(be):
         assert be.dist("HAD_2SAD", a, b, int(w), int(h)) == int(exp), (w, h)
 
 
+def check_distortion_ext(be):
+    g = load("distortion_ext")
+    org, cur, mask = g["org"], g["cur"], g["mask"]
+    for (ox, oy, cx, cy, mx, my, sx, ms2, w, h, ss), exp in zip(g["mask_cases"], g["mask_out"]):
+        got = be.sad_mask((org, int(oy), int(ox)), (cur, int(cy), int(cx)), (mask, int(my), int(mx)), int(sx), int(ms2), int(w), int(h), int(ss))
+        assert got == int(exp), ("mask", w, h, ss, sx, got, int(exp))
+    for (ox, oy, cx, cy, w, h, wt), exp in zip(g["wsse_cases"], g["wsse_out"]):
+        got = be.fix_weighted_sse((org, int(oy), int(ox)), (cur, int(cy), int(cx)), int(w), int(h), int(wt))
+        assert got == int(exp), ("wsse", w, h, wt, got, int(exp))
+
+
 def check_transform_matrices(be):
     g = load("transform")
     for t, name, logs in ((0, "DCT2", range(1, 7)), (1, "DCT8", range(2, 6)), (2, "DST7", range(2, 6))):

@@ -54,6 +54,25 @@ class HipBackend:
         out = self.hp.sad_x5_batch(po, pc, d_it, 1, w, h, sub_shift, calc_centre)
         return out.cpu().numpy().view(np.uint64)
 
+    def sad_mask(self, org, cur, mask, step_x, mask_stride2, w, h, sub_shift=0):
+        o, oy, ox = _split(org)
+        c, cy, cx = _split(cur)
+        m, my, mx = _split(mask)
+        po, pc, pm = self._plane(o), self._plane(c), self._plane(m)
+        d_it = self.hp.to_device(np.array([(oy * po.stride + ox, cy * pc.stride + cx)], np.int32))
+        d_mo = self.hp.to_device(np.array([my * pm.stride + mx], np.int32))
+        out = self.hp.sad_mask_batch(po, pc, pm, step_x, mask_stride2, d_it, d_mo, 1, w, h, sub_shift)
+        return int(out.cpu().numpy().view(np.uint64)[0])
+
+    def fix_weighted_sse(self, org, cur, w, h, weight):
+        o, oy, ox = _split(org)
+        c, cy, cx = _split(cur)
+        po, pc = self._plane(o), self._plane(c)
+        d_it = self.hp.to_device(np.array([(oy * po.stride + ox, cy * pc.stride + cx)], np.int32))
+        d_w = self.hp.to_device(np.array([weight], np.uint32).view(np.int32))
+        out = self.hp.fix_weighted_sse_batch(po, pc, d_it, d_w, 1, w, h)
+        return int(out.cpu().numpy().view(np.uint64)[0])
+
     # ---- transforms ----
     def tr_matrix(self, tr_type, log2n):
         n = 1 << log2n

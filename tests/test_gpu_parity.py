@@ -25,6 +25,10 @@ def test_golden_distortion(hip):
     G.check_distortion(hip)
 
 
+def test_golden_distortion_ext(hip):
+    G.check_distortion_ext(hip)
+
+
 def test_golden_transform(hip):
     G.check_transform_matrices(hip)
     G.check_scan(hip)
@@ -83,6 +87,33 @@ def test_sad_x5_vs_oracle(hip, oracle):
                 if not centre:
                     a = a.copy(); a[2] = 0; b[2] = 0
                 assert np.array_equal(a, b)
+
+
+def test_sad_mask_and_weighted_sse_batches_vs_oracle(hip, oracle):
+    """DF_SAD_WITH_MASK and m_fxdWtdPredPtr in batch form: per-candidate mask offsets / weights, odd sizes, signed masks"""
+    rng = np.random.default_rng(102)
+    org, cur = rand_plane(rng, 120, 200), rand_plane(rng, 120, 200)
+    mask = rng.integers(-9, 9, size=(260, 448)).astype(np.int16)      # 448 = a multiple of 64: the device plane keeps this pitch, so reads that run across a row end see the same samples
+    hp = hip.hp
+    po, pc, pm = hip._plane(org), hip._plane(cur), hip._plane(mask)
+    for (w, h) in ((4, 4), (8, 8), (16, 8), (8, 32), (64, 64), (12, 6), (128, 16)):
+        n = 29
+        pos = [(int(rng.integers(0, 200 - w + 1)), int(rng.integers(0, 120 - h + 1)), int(rng.integers(0, 200 - w + 1)), int(rng.integers(0, 120 - h + 1)),
+                int(rng.integers(130, 280)), int(rng.integers(0, 120))) for _ in range(n)]
+        d_it = hp.to_device(np.array([(oy * po.stride + ox, cy * pc.stride + cx) for (ox, oy, cx, cy, _, _) in pos], np.int32))
+        d_mo = hp.to_device(np.array([my * pm.stride + mx for (_, _, _, _, mx, my) in pos], np.int32))
+        for ss in ((0, 1) if h % 2 == 0 else (0,)):
+            for step_x, ms2 in ((1, -w), (-1, w), (1, 3), (2, -5)):
+                got = hp.sad_mask_batch(po, pc, pm, step_x, ms2, d_it, d_mo, n, w, h, ss).cpu().numpy().view(np.uint64)
+                for k, (ox, oy, cx, cy, mx, my) in enumerate(pos):
+                    exp = oracle.sad_mask((org, oy, ox), (cur, cy, cx), (mask, my, mx), step_x, ms2, w, h, ss)
+                    assert int(got[k]) == exp, ("mask", w, h, ss, step_x, ms2, k, int(got[k]), exp)
+        if w % 2 == 0:
+            wts = rng.integers(1, 1 << 20, size=n).astype(np.uint32)
+            got = hp.fix_weighted_sse_batch(po, pc, d_it, hp.to_device(wts.view(np.int32)), n, w, h).cpu().numpy().view(np.uint64)
+            for k, (ox, oy, cx, cy, _, _) in enumerate(pos):
+                exp = oracle.fix_weighted_sse((org, oy, ox), (cur, cy, cx), w, h, int(wts[k]))
+                assert int(got[k]) == exp, ("wsse", w, h, k, int(got[k]), exp)
 
 
 def test_sad_surface_vs_oracle(hip, oracle):

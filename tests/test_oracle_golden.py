@@ -7,6 +7,10 @@ def test_distortion(oracle):
     G.check_distortion(oracle)
 
 
+def test_distortion_ext(oracle):
+    G.check_distortion_ext(oracle)
+
+
 def test_transform_matrices(oracle):
     G.check_transform_matrices(oracle)
 

@@ -79,6 +79,29 @@ def test_fix_weighted_sse(oracle, reflib):
             assert oracle.fix_weighted_sse(org, cur, w, h, wt) == reflib.fix_weighted_sse(org, cur, w, h, wt)
 
 
+def geo_like_mask(rng, rows, cols):
+    """GEO blending weights are 0..8 along a ramp (the reference's g_globalGeoWeights); any int16 works for the kernel"""
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    return np.clip((xx - yy) // 2 + 4 + rng.integers(-1, 2, (rows, cols)), 0, 8).astype(np.int16)
+
+
+def test_sad_with_mask(oracle, reflib):
+    # the two parameterisations RdCost::setDistParamGeo produces: forward (stepX 1, maskStride2 -w) and mirrored (stepX -1, maskStride2 +w)
+    rng = np.random.default_rng(55)
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            if reflib.simd and w < 8:
+                continue     # the SIMD row walks 8 samples at a time (RdCostX86.h:2692): defined for GEO's widths (>= 8) only
+            org, cur = rand_plane(rng, h + 2, w + 7), rand_plane(rng, h + 2, w + 9)
+            mask = geo_like_mask(rng, 2 * h + 8, 2 * w + 16)
+            for ss in (0, 1):
+                for step_x in (1, -1):
+                    mx = 5 if step_x == 1 else 5 + w - 1
+                    a = oracle.sad_mask((org, 1, 2), (cur, 1, 3), (mask, 3, mx), step_x, -step_x * w, w, h, ss)
+                    b = reflib.sad_mask((org, 1, 2), (cur, 1, 3), (mask, 3, mx), step_x, -step_x * w, w, h, ss)
+                    assert a == b, (w, h, ss, step_x, a, b)
+
+
 def test_transform_matrices(oracle, reflib):
     for t, rng_ in ((DCT2, range(1, 7)), (DCT8, range(2, 6)), (DST7, range(2, 6))):
         for l in rng_:

@@ -32,11 +32,45 @@ def synth_pair(rng, h, w, shift=(3, 1), noise=6):
     return a.astype(np.int16), b.astype(np.int16)
 
 
+def gen_distortion_ext(R, R0):
+    """GEO masked SAD (DF_SAD_WITH_MASK) and fixed-weight SSE (m_fxdWtdPredPtr) -> distortion_ext.npz"""
+    rng = np.random.default_rng(20260924)
+    org, cur = rand_plane(rng, 96, 160), rand_plane(rng, 96, 160)
+    yy, xx = np.mgrid[0:200, 0:300]
+    mask = np.clip((xx - yy) // 3 + 4 + rng.integers(-1, 2, (200, 300)), 0, 8).astype(np.int16)
+    mcases, mout = [], []
+    for w in (8, 16, 32, 64):
+        for h in (8, 16, 32, 64):
+            for ss in (0, 1):
+                for step_x in (1, -1):
+                    ox, oy, cx, cy = (int(rng.integers(0, 160 - w)), int(rng.integers(0, 96 - h)), int(rng.integers(0, 160 - w)), int(rng.integers(0, 96 - h)))
+                    mx, my = int(rng.integers(70, 150)), int(rng.integers(0, 60))
+                    v = R.sad_mask((org, oy, ox), (cur, cy, cx), (mask, my, mx), step_x, -step_x * w, w, h, ss)
+                    assert v == R0.sad_mask((org, oy, ox), (cur, cy, cx), (mask, my, mx), step_x, -step_x * w, w, h, ss)
+                    mcases.append((ox, oy, cx, cy, mx, my, step_x, -step_x * w, w, h, ss))
+                    mout.append(v)
+    wcases, wout = [], []
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            ox, oy, cx, cy = (int(rng.integers(0, 160 - w)), int(rng.integers(0, 96 - h)), int(rng.integers(0, 160 - w)), int(rng.integers(0, 96 - h)))
+            wt = int(rng.integers(1, 1 << 17))
+            v = R.fix_weighted_sse((org, oy, ox), (cur, cy, cx), w, h, wt)
+            assert v == R0.fix_weighted_sse((org, oy, ox), (cur, cy, cx), w, h, wt)
+            wcases.append((ox, oy, cx, cy, w, h, wt))
+            wout.append(v)
+    np.savez_compressed(os.path.join(OUT, "distortion_ext.npz"), org=org, cur=cur, mask=mask,
+                        mask_cases=np.array(mcases, np.int32), mask_out=np.array(mout, np.uint64),
+                        wsse_cases=np.array(wcases, np.int64), wsse_out=np.array(wout, np.uint64))
+
+
 def main():
     build_ref()
     R = RefLib(1)
     R0 = RefLib(0)
     os.makedirs(OUT, exist_ok=True)
+    gen_distortion_ext(R, R0)
+    if "--ext-only" in sys.argv:
+        return
     rng = np.random.default_rng(20260923)
 
     # ---- distortion: one 160x96 plane pair, a list of (func, x, y, cx, cy, w, h, subShift) cases ----

@@ -9,6 +9,7 @@
 // wave.  Lanes read 8/16-byte row segments straight from the picture planes (which stay resident in
 // L2 / Infinity Cache across the thousands of candidates of a frame); costs are reduced with
 // wave-level xor-shuffles; one lane stores the 64-bit Distortion.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -124,8 +125,16 @@ sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __r
 
 // Several (function-compatible) batches in ONE launch: a workgroup finds its job from the block-range table (wave-uniform scalar
 // work) and runs the same body.  Removes the launch gaps and the tails of the short per-size launches of a frame's work lists.
-struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, fast16, tilesX, tilesPerCand; const vvhip_dist_item* items; uint64_t* out; };
-struct DistMultiJobs { int nJobs; DistJobGeom j[8]; };
+struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand; const vvhip_dist_item* items; uint64_t* out; };
+struct DistMultiJobs { int nJobs, xcdRemap; DistJobGeom j[8]; };
+
+// Workgroups are dealt round-robin to the 8 XCDs (private L2 each).  Work lists are in raster order of the picture, so giving XCD x
+// the x-th contiguous eighth of a list makes every L2 stream one band of the planes instead of all of them.
+__device__ __forceinline__ int xcdBand( int local, int nBlocks )
+{
+  const int q = nBlocks >> 3;
+  return local < ( q << 3 ) ? ( local & 7 ) * q + ( local >> 3 ) : local;
+}
 
 template<int MODE>
 __global__ void __launch_bounds__( 256 )
@@ -135,7 +144,9 @@ sadSseMultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
 #pragma unroll
   for( int i = 1; i < 8; i++ ) if( i < jobs.nJobs && ( int ) blockIdx.x >= jobs.j[i].blockStart ) k = i;
   const DistJobGeom& g = jobs.j[k];
-  sadSseBody<8, MODE>( blockIdx.x - g.blockStart, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+  int blk = blockIdx.x - g.blockStart;
+  if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
+  sadSseBody<8, MODE>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,8 +361,59 @@ hadTile8MultiKernel( const int16_t* __restrict__ org, int orgStride, const int16
 #pragma unroll
   for( int i = 1; i < 8; i++ ) if( i < jobs.nJobs && ( int ) blockIdx.x >= jobs.j[i].blockStart ) k = i;
   const DistJobGeom& g = jobs.j[k];
-  if( g.fast16 ) hadTileBody<8, 8, true>( blockIdx.x - g.blockStart, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
-  else           hadTileBody<8, 8, false>( blockIdx.x - g.blockStart, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  int blk = blockIdx.x - g.blockStart;
+  if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
+  if( g.fast16 ) hadTileBody<8, 8, true>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  else           hadTileBody<8, 8, false>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEO masked SAD (RdCost.cpp:2062-2093) and fixed-weight SSE (RdCost.cpp:1948-1982): one wave per candidate, lanes stride the
+// (processed row, column) pairs.  Both are off the BASELINE presets' path (GEO off, luma-level dQP off): correctness first.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__( 256 )
+sadMaskKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
+               const int16_t* __restrict__ mask, int maskRowAdvance, int stepX, int w, int rowsEff, int subShift,
+               const vvhip_dist_item* __restrict__ items, const int32_t* __restrict__ maskOff, int n, uint64_t* __restrict__ out )
+{
+  const int lane = threadIdx.x & 63, cand = blockIdx.x * 4 + ( threadIdx.x >> 6 );
+  if( cand >= n ) return;
+  const int16_t* po = org + items[cand].org_off;
+  const int16_t* pc = cur + items[cand].cur_off;
+  const int16_t* pm = mask + ( maskOff ? maskOff[cand] : 0 );
+  const int step = 1 << subShift;
+  unsigned long long sum = 0;
+  for( int i = lane; i < rowsEff * w; i += 64 )
+  {
+    const int r = i / w, x = i - r * w;
+    const int d = ( int ) po[( ptrdiff_t ) r * step * orgStride + x] - ( int ) pc[( ptrdiff_t ) r * step * curStride + x];
+    sum += ( unsigned long long ) ( long long ) ( ( d < 0 ? -d : d ) * ( int ) pm[( ptrdiff_t ) r * maskRowAdvance + x * stepX] );   // int product, then widened (:2081)
+  }
+  // per-lane partial sums may be "negative" (sign-extended) with a negative mask: add the two 32-bit halves separately, mod 2^64
+  const uint32_t lo = ( uint32_t ) sum, hi = ( uint32_t ) ( sum >> 32 );
+  const unsigned long long sLo = vvhipGroupSum64( lo, 64, lane ), sHi = vvhipGroupSum64( hi, 64, lane );
+  if( lane == 0 ) out[cand] = ( sLo + ( sHi << 32 ) ) << subShift;
+}
+
+__global__ void __launch_bounds__( 256 )
+fixWeightedSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride, int w, int h,
+                      const vvhip_dist_item* __restrict__ items, const uint32_t* __restrict__ weights, int n, uint64_t* __restrict__ out )
+{
+  const int lane = threadIdx.x & 63, cand = blockIdx.x * 4 + ( threadIdx.x >> 6 );
+  if( cand >= n ) return;
+  const int16_t* po = org + items[cand].org_off;
+  const int16_t* pc = cur + items[cand].cur_off;
+  const long long wt = weights[cand];
+  unsigned long long sum = 0;
+  for( int i = lane; i < w * h; i += 64 )
+  {
+    const int r = i / w, x = i - r * w;
+    const int d = ( int ) po[( ptrdiff_t ) r * orgStride + x] - ( int ) pc[( ptrdiff_t ) r * curStride + x];
+    sum += ( unsigned long long ) ( long long ) ( int ) ( ( wt * ( d * d ) + ( 1 << 15 ) ) >> 16 );       // Intermediate_Int cast (:1950)
+  }
+  const uint32_t lo = ( uint32_t ) sum, hi = ( uint32_t ) ( sum >> 32 );
+  const unsigned long long sLo = vvhipGroupSum64( lo, 64, lane ), sHi = vvhipGroupSum64( hi, 64, lane );
+  if( lane == 0 ) out[cand] = sLo + ( sHi << 32 );          // width 1 counts its single column twice and halves (:1981): same value
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -568,6 +630,8 @@ int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_st
       continue;
     }
     DistMultiJobs mj; mj.nJobs = 0;
+    static const int xcdRemapEnv = []{ const char* e = getenv( "VVHIP_XCD_REMAP" ); return e ? atoi( e ) : 1; }();
+    mj.xcdRemap = xcdRemapEnv;
     long blocks = 0;
     while( i < n_jobs && mj.nJobs < 8 && mergeable( jobs[i] ) )
     {
@@ -591,7 +655,8 @@ int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_st
         if( g.tilesPerCand % lpc ) lpc = 1;
       }
       g.log2Lpc = ilog2i( lpc );
-      blocks += ( ( long ) jb.n * lpc + 255 ) / 256;
+      g.nBlocks = ( int ) ( ( ( long ) jb.n * lpc + 255 ) / 256 );
+      blocks += g.nBlocks;
       mj.nJobs++; i++;
     }
     if( func == VVHIP_DF_SAD )      hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SAD> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
@@ -610,6 +675,36 @@ int vvhip_sad_x5_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, co
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_sad_x5_batch: width must be 8 or 16 (m_afpDistortFuncX5[log2w-3], RdCost.cpp:252), got %dx%d", width, height );
   if( n == 0 ) return VVHIP_OK;
   return launchSadSse<MODE_SAD_X5>( ctx, d_org, org_stride, d_cur, cur_stride, width, height, sub_shift, d_items, n, calc_centre, d_out5 );
+}
+
+int vvhip_sad_mask_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride,
+                          const int16_t* d_mask, int mask_stride, int step_x, int mask_stride2,
+                          int width, int height, int sub_shift, int bit_depth,
+                          const vvhip_dist_item* d_items, const int32_t* d_mask_off, int n, uint64_t* d_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !d_org || !d_cur || !d_mask || width < 1 || height < 1 || width > 128 || height > 128 || sub_shift < 0 || sub_shift > 1 || n < 0 ||
+      bit_depth < 8 || bit_depth > 16 || ( height & ( ( 1 << sub_shift ) - 1 ) ) )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_sad_mask_batch: bad arguments (%dx%d subShift %d)", width, height, sub_shift );
+  if( n == 0 ) return VVHIP_OK;
+  // the mask pointer advances by stepX per sample, then by maskStride*step + maskStride2 per processed row (RdCost.cpp:2079-2088)
+  const int rowAdvance = width * step_x + mask_stride * ( 1 << sub_shift ) + mask_stride2;
+  hipLaunchKernelGGL( sadMaskKernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, d_mask, rowAdvance, step_x,
+                      width, height >> sub_shift, sub_shift, d_items, d_mask_off, n, d_out );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_fix_weighted_sse_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride,
+                                  int width, int height, int bit_depth, const vvhip_dist_item* d_items, const uint32_t* d_weights, int n, uint64_t* d_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !d_org || !d_cur || !d_weights || width < 1 || height < 1 || width > 128 || height > 128 || n < 0 || bit_depth < 8 || bit_depth > 16 || ( ( width & 1 ) && width != 1 ) )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_fix_weighted_sse_batch: width must be even or 1 (RdCost.cpp:1967), got %dx%d", width, height );
+  if( n == 0 ) return VVHIP_OK;
+  hipLaunchKernelGGL( fixWeightedSseKernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, width, height, d_items, d_weights, n, d_out );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
 }
 
 int vvhip_sad_surface( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_ref, int ref_stride,

@@ -136,6 +136,54 @@ template<int F> Distortion distEntry( const DistParam& dp )
   return callOne( F, dp );
 }
 
+// DF_SAD_WITH_MASK: the mask window the walk touches is staged as a compact buffer and the walk re-expressed on it
+Distortion sadMaskEntry( const DistParam& dp )
+{
+  if( dp.applyWeight ) throw Exception( " no support" );
+  if( !dp.mask ) throw Exception( "vvhip::RdCost: DF_SAD_WITH_MASK entry called without a mask" );
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int w = dp.org.width, h = dp.org.height, step = 1 << dp.subShift, rowsEff = h >> dp.subShift;
+  const ptrdiff_t rowAdvance = ( ptrdiff_t ) w * dp.stepX + ( ptrdiff_t ) dp.maskStride * step + dp.maskStride2;
+  // gather exactly the mask samples read, in (processed row, column) order: compact rowsEff x w, stepX 1, row advance w
+  std::vector<Pel> m( ( size_t ) rowsEff * w ), t0, t1;
+  for( int r = 0; r < rowsEff; r++ ) for( int x = 0; x < w; x++ ) m[( size_t ) r * w + x] = dp.mask[r * rowAdvance + ( ptrdiff_t ) x * dp.stepX];
+  int16_t* cursor = dev.staging( ( size_t ) 6 * ( w + 8 ) * h * sizeof( Pel ) + 64 );
+  const Resolved o = resolve( dev, dp.org, w, h, 0, 0, cursor, t0 );
+  const Resolved c = resolve( dev, dp.cur, w, h, 0, 0, cursor, t1 );
+  int16_t* dMask = cursor;
+  dev.check( vvhip_upload( dev.ctx(), dMask, m.data(), m.size() * sizeof( Pel ) ), "stage mask" );
+  struct Io { vvhip_dist_item it; uint64_t out; } io;
+  io.it.org_off = o.off; io.it.cur_off = c.off; io.out = 0;
+  char* aux = static_cast<char*>( dev.stagingAux( sizeof( Io ) ) );
+  dev.check( vvhip_upload( dev.ctx(), aux, &io, sizeof( io ) ), "dist item" );
+  // compact mask: +1 per sample leaves the pointer at the next row already -> maskStride 0, maskStride2 0 after the w steps
+  dev.check( vvhip_sad_mask_batch( dev.ctx(), o.dBase, o.stride, c.dBase, c.stride, dMask, 0, 1, 0, w, h, dp.subShift, dp.bitDepth,
+                                   reinterpret_cast<vvhip_dist_item*>( aux ), nullptr, 1, reinterpret_cast<uint64_t*>( aux + offsetof( Io, out ) ) ), "vvhip_sad_mask_batch" );
+  dev.check( vvhip_download( dev.ctx(), &io.out, aux + offsetof( Io, out ), sizeof( uint64_t ) ), "dist result" );
+  return io.out;
+}
+
+Distortion fxdWtdEntry( const DistParam& dp, uint32_t fixedWeight )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int w = dp.org.width, h = dp.org.height;
+  int16_t* cursor = dev.staging( ( size_t ) 4 * ( w + 8 ) * h * sizeof( Pel ) + 64 );
+  std::vector<Pel> t0, t1;
+  const Resolved o = resolve( dev, dp.org, w, h, 0, 0, cursor, t0 );
+  const Resolved c = resolve( dev, dp.cur, w, h, 0, 0, cursor, t1 );
+  struct Io { vvhip_dist_item it; uint32_t weight, pad; uint64_t out; } io;
+  io.it.org_off = o.off; io.it.cur_off = c.off; io.weight = fixedWeight; io.pad = 0; io.out = 0;
+  char* aux = static_cast<char*>( dev.stagingAux( sizeof( Io ) ) );
+  dev.check( vvhip_upload( dev.ctx(), aux, &io, sizeof( io ) ), "dist item" );
+  dev.check( vvhip_fix_weighted_sse_batch( dev.ctx(), o.dBase, o.stride, c.dBase, c.stride, w, h, dp.bitDepth, reinterpret_cast<vvhip_dist_item*>( aux ),
+                                           reinterpret_cast<uint32_t*>( aux + offsetof( Io, weight ) ), 1, reinterpret_cast<uint64_t*>( aux + offsetof( Io, out ) ) ),
+             "vvhip_fix_weighted_sse_batch" );
+  dev.check( vvhip_download( dev.ctx(), &io.out, aux + offsetof( Io, out ), sizeof( uint64_t ) ), "dist result" );
+  return io.out;
+}
+
 template<int LOG2W> void sadX5Entry( const DistParam& dp, Distortion* cost, bool calcCentre )
 {
   std::lock_guard<std::mutex> g( g_lock );
@@ -181,10 +229,21 @@ void RdCost::create( bool /*enableOpt*/ )
       m_afpDistortFunc[row][DF_HAD_fast + i] = distEntry<VVHIP_DF_HAD_FAST>;
     }
     m_afpDistortFunc[row][DF_HAD_2SAD]      = distEntry<VVHIP_DF_HAD_2SAD>;
-    m_afpDistortFunc[row][DF_SAD_WITH_MASK] = nullptr;     // GEO is off at the BASELINE presets; left to the CPU row by the integrator
+    m_afpDistortFunc[row][DF_SAD_WITH_MASK] = sadMaskEntry;
   }
+  m_fxdWtdPredPtr = fxdWtdEntry;
   m_afpDistortFuncX5[0] = sadX5Entry<3>;
   m_afpDistortFuncX5[1] = sadX5Entry<4>;
+}
+
+void RdCost::setDistParamGeo( DistParam& dp, const CPelBuf& org, const Pel* refY, int refStride, const Pel* mask, int maskStride, int stepX, int maskStride2, int bitDepth, int compID )
+{
+  dp.bitDepth = bitDepth; dp.compID = compID;
+  dp.org = org;
+  dp.cur.buf = refY; dp.cur.stride = refStride; dp.cur.width = org.width; dp.cur.height = org.height;
+  dp.mask = mask; dp.maskStride = maskStride; dp.stepX = stepX; dp.maskStride2 = maskStride2;     // subShift is left as it is, as in the reference
+  dp.maximumDistortionForEarlyExit = ~0ull;
+  dp.distFunc = m_afpDistortFunc[0][DF_SAD_WITH_MASK];
 }
 
 void RdCost::setDistParam( DistParam& dp, const CPelBuf& org, const Pel* refY, int refStride, int bitDepth, int compID, int subShiftMode, int useHadamard )

@@ -64,7 +64,15 @@ public:
   int          compID    = 0;
   bool         applyWeight = false;
   Distortion   maximumDistortionForEarlyExit = ~0ull;   // honoured as in the SIMD rows: ignored (full sums are returned)
+  const void*    wpCur   = nullptr;                     // weighted prediction is refused like the reference does (RdCost.cpp:303-306)
+  const CPelBuf* orgLuma = nullptr;
+  // GEO masked SAD (DF_SAD_WITH_MASK, RdCost.h:100-103): mask walks +stepX per sample, +maskStride*(1<<subShift)+maskStride2 per row
+  const Pel*   mask        = nullptr;
+  int          maskStride  = 0;
+  int          stepX       = 0;
+  int          maskStride2 = 0;
 };
+typedef Distortion ( *FpFxdWtdDistFunc )( const DistParam&, uint32_t fixedWeight );      // RdCost.h:117
 
 // One process-wide device context + registry of host pictures mirrored in HBM.
 class Device
@@ -96,10 +104,13 @@ class RdCost
 public:
   FpDistFunc   m_afpDistortFunc[2][DF_TOTAL_FUNCTIONS];
   FpDistFuncX5 m_afpDistortFuncX5[2];
+  FpFxdWtdDistFunc m_fxdWtdPredPtr;            // fixWeightedSSE_Core, RdCost.cpp:1948-1982
   void create( bool enableOpt = true );      // both rows point at the HIP entries (bit-exact for every bit depth)
 
   // RdCost::setDistParam, CommonLib/RdCost.cpp:158-206 (subShiftMode / useHadamard semantics identical)
   void setDistParam( DistParam& dp, const CPelBuf& org, const Pel* refY, int refStride, int bitDepth, int compID, int subShiftMode = 0, int useHadamard = 0 );
+  // RdCost::setDistParamGeo, CommonLib/RdCost.cpp:2036-2060
+  void setDistParamGeo( DistParam& dp, const CPelBuf& org, const Pel* refY, int refStride, const Pel* mask, int maskStride, int stepX, int maskStride2, int bitDepth, int compID );
   // RdCost::getDistPart, CommonLib/RdCost.cpp:267-291 (luma; chroma weighting stays with the caller)
   Distortion getDistPart( const CPelBuf& org, const CPelBuf& cur, int bitDepth, DFunc eDFunc );
 

@@ -1015,7 +1015,6 @@ int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_batch: unsupported %dx%d types (%d,%d) bitDepth %d", width, height, tr_hor, tr_ver, bit_depth );
   if( n == 0 ) return VVHIP_OK;
   const int area = width * height;
-  const int tpb = area >= 256 ? 1 : 256 / area;
   if( width == height && ( width == 8 || width == 16 || width == 32 ) && !getenv( "VVHIP_TU_GENERIC" ) )
   {
     const int16_t* mh = ctx->d_trMat + trMatOffset( tr_hor, gf.log2w );

@@ -161,6 +161,22 @@ class HotPath:
                                            int(calc_centre), _ptr(d_items), n, _ptr(out)))
         return out
 
+    def sad_mask_batch(self, org, cur, mask, step_x, mask_stride2, d_items, d_mask_off, n, w, h, sub_shift=0, bit_depth=10, out=None):
+        """GEO masked SAD (DF_SAD_WITH_MASK); `mask` is a Plane, d_mask_off per-candidate first-sample offsets (or None)"""
+        if out is None:
+            out = torch.zeros(n, dtype=torch.int64, device=self.device)
+        self._ck(self.L.vvhip_sad_mask_batch(self.ctx, org.buf_ptr, org.stride, cur.buf_ptr, cur.stride, mask.buf_ptr, mask.stride, step_x, mask_stride2,
+                                             w, h, sub_shift, bit_depth, _ptr(d_items), _ptr(d_mask_off) if d_mask_off is not None else None, n, _ptr(out)))
+        return out
+
+    def fix_weighted_sse_batch(self, org, cur, d_items, d_weights, n, w, h, bit_depth=10, out=None):
+        """fixed-weight SSE (RdCost::m_fxdWtdPredPtr); d_weights: uint32 per candidate (stored in an int32 tensor)"""
+        if out is None:
+            out = torch.zeros(n, dtype=torch.int64, device=self.device)
+        self._ck(self.L.vvhip_fix_weighted_sse_batch(self.ctx, org.buf_ptr, org.stride, cur.buf_ptr, cur.stride, w, h, bit_depth,
+                                                     _ptr(d_items), _ptr(d_weights), n, _ptr(out)))
+        return out
+
     def sad_surface(self, org, ref, d_org_off, d_ref_off, n_blocks, w, h, sub_shift, range_x, range_y, out=None):
         if out is None:
             out = torch.empty(n_blocks * (2 * range_x + 1) * (2 * range_y + 1), dtype=torch.int32, device=self.device)

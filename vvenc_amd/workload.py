@@ -86,16 +86,18 @@ class FrameWorkload:
             self.tu_jobs.append((S, n, hp.to_device(off), d_qp, lvl, rec, st, off, qps))
             self.coefs += n * S * S
             # fused pipeline: read residual 2 B, write level 2 B + reconstructed residual 2 B per sample, 24 B stats per TU
-            self.alg_bytes["TU"] = self.alg_bytes.get("TU", 0) + n * (6 * S * S + 24)
+            self.alg_bytes["TU%d" % S] = n * (6 * S * S + 24)
 
         # launches of one kernel class are issued back to back so a class can be bracketed by ONE pair of stream events
         self.dist_jobs.sort(key=lambda j: ("SAD", "HAD_fast", "SSE").index(j[0]))
-        self.class_launches = {"SAD": len(SIZES), "HAD_fast": len(SIZES), "SSE": len(SIZES), "TU": len(TU_SIZES)}
+        self.class_launches = {"SAD": len(SIZES), "HAD_fast": len(SIZES), "SSE": len(SIZES)}
+        self.class_launches.update({"TU%d" % S: 1 for S in TU_SIZES})        # each fused TU size is its own kernel instantiation
 
         self.merged = True      # one vvhip_dist_multi launch per function (all block sizes) instead of one launch per size
         self.job_tables = {func: hp.make_dist_jobs([(S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f == func])
                            for func in ("SAD", "HAD_fast", "SSE")}
-        self.class_launches_merged = {"SAD": 1, "HAD_fast": 1, "SSE": 1, "TU": len(TU_SIZES)}
+        self.class_launches_merged = {"SAD": 1, "HAD_fast": 1, "SSE": 1}
+        self.class_launches_merged.update({"TU%d" % S: 1 for S in TU_SIZES})
 
     # one pass of the hot path over the frame: 3 merged distortion launches (or 12 per-size ones) + 3 fused TU launches
     def run(self, timers=None):
@@ -108,9 +110,6 @@ class FrameWorkload:
                 hp.dist_multi(func, self.org, self.ref, self.job_tables[func], self.bit_depth)
                 if timers is not None:
                     timers.stop(func)
-            prev = "SSE"
-            if timers is not None:
-                timers.start("TU")
         else:
             for (func, S, ss, n, d_items, d_out, _) in self.dist_jobs:
                 if timers is not None and func != prev:
@@ -121,11 +120,12 @@ class FrameWorkload:
                 hp.dist_batch(func, self.org, self.ref, d_items, n, S, S, ss, self.bit_depth, out=d_out)
             if timers is not None:
                 timers.stop(prev)
-                timers.start("TU")
         for (S, n, d_off, d_qp, lvl, rec, st, _, _) in self.tu_jobs:
+            if timers is not None:
+                timers.start("TU%d" % S)
             hp.tu_rdo(self.resi, d_off, n, S, S, d_qp, 0, 0, self.bit_depth, 8, lvl, rec, st)
-        if timers is not None:
-            timers.stop("TU")
+            if timers is not None:
+                timers.stop("TU%d" % S)
 
     def checksum(self):
         """order-independent digest of every result of the last run (used by tests: equal across ranks / reruns)"""
