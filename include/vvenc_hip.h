@@ -179,6 +179,22 @@ VVHIP_API int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int res
                                   const vvhip_tu_qp* d_qp, int thr_val,
                                   int16_t* d_level, int16_t* d_rec_resi /* compact n*w*h */, vvhip_tu_stats* d_stats );
 
+/* ---- the g_tCoeffOps table slots one-to-one (CommonLib/TrQuant_EMT.h:63-91), device pointers, caller's matrix ------------------
+ * vvhip_fast_fwd_core  <- fastFwdCore_2D/_1D[log2(tr_size)-2]  (TrQuant_EMT.cpp:1973-2000):
+ *     dst[j*line + i] = ( sum_k src[i*tr_size + k] * tc[j*tr_size + k] + 2^(shift-1) ) >> shift,  i < reduced_line, j < cutoff
+ * vvhip_fast_inv_core  <- fastInvCore[log2(tr_size)-2]         (:1953-1970): dst[i*tr_size + j] += sum_{k<rows} src[k*lines + i] * it[k*tr_size + j]
+ *     (ACCUMULATES: the reference's caller zeroes dst first, :159)
+ * vvhip_round_clip     <- roundClip4/8 (clipCore :1941-1950), vvhip_cpy_resi <- cpyResi4/8 (:1929-1938), vvhip_cpy_coeff <- cpyCoeff4/8 (:1917-1926).
+ * The batched path uses the fused 2-D entries above; these give every slot of the table a device provider.                     */
+VVHIP_API int vvhip_fast_fwd_core( vvhip_ctx* ctx, int tr_size, const int16_t* d_tc, const int32_t* d_src, int32_t* d_dst,
+                                   unsigned line, unsigned reduced_line, unsigned cutoff, int shift );
+VVHIP_API int vvhip_fast_inv_core( vvhip_ctx* ctx, int tr_size, const int16_t* d_it, const int32_t* d_src, int32_t* d_dst,
+                                   unsigned lines, unsigned reduced_lines, unsigned rows );
+VVHIP_API int vvhip_round_clip( vvhip_ctx* ctx, int32_t* d_dst, unsigned width, unsigned height, unsigned stride,
+                                int32_t out_min, int32_t out_max, int32_t round, int32_t shift );
+VVHIP_API int vvhip_cpy_resi( vvhip_ctx* ctx, const int32_t* d_src, int16_t* d_dst, ptrdiff_t stride, unsigned width, unsigned height );
+VVHIP_API int vvhip_cpy_coeff( vvhip_ctx* ctx, const int16_t* d_src, ptrdiff_t stride, int32_t* d_dst, unsigned width, unsigned height );
+
 /* ROM accessors (host memory out): the tables the kernels use, for parity checks against
  * g_trCore* (CommonLib/RomTr.cpp:364-449) and getScanOrder (CommonLib/Rom.h:104).               */
 VVHIP_API int vvhip_get_tr_matrix_host( int tr_type, int log2_size, int16_t* host_out );

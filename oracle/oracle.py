@@ -70,6 +70,41 @@ class _Base:
         stride = arr.shape[1]
         return _view_ptr(arr, y0 * stride + x0), stride
 
+    # ---- g_tCoeffOps table slots (TrQuant_EMT.h:63-91), caller's matrix ----
+    def fast_fwd_core(self, tc, src, line, reduced_line, cutoff, shift):
+        """tc: (N, N) int16, src: (line, N) int32 -> dst (N, line) int32 (entries outside reduced_line x cutoff stay 0)"""
+        n = tc.shape[0]
+        tc, src = _aligned(np.ascontiguousarray(tc, np.int16)), _aligned(np.ascontiguousarray(src, np.int32))
+        dst = _aligned(np.zeros((n, line), np.int32))
+        self._slot("fast_fwd_core", n, _p(tc), _p(src), _p(dst), line, reduced_line, cutoff, shift)
+        return dst
+
+    def fast_inv_core(self, it, src, dst0, lines, reduced_lines, rows):
+        """it: (N, N) int16, src: (N, lines) int32, dst0: (lines, N) int32 start values -> accumulated copy"""
+        n = it.shape[0]
+        it, src = _aligned(np.ascontiguousarray(it, np.int16)), _aligned(np.ascontiguousarray(src, np.int32))
+        dst = _aligned(np.ascontiguousarray(dst0, np.int32))
+        self._slot("fast_inv_core", n, _p(it), _p(src), _p(dst), lines, reduced_lines, rows)
+        return dst
+
+    def round_clip(self, buf, w, h, stride, mn, mx, rnd, shift):
+        dst = _aligned(np.ascontiguousarray(buf, np.int32))
+        self._slot("round_clip", None, _p(dst), w, h, stride, mn, mx, rnd, shift)
+        return dst
+
+    def cpy_resi(self, src, w, h, stride):
+        src = _aligned(np.ascontiguousarray(src, np.int32))
+        dst = np.full((h, stride), -77, np.int16)
+        self._slot("cpy_resi", None, _p(src), _p(dst), C.c_ssize_t(stride), w, h)
+        return dst
+
+    def cpy_coeff(self, src, w, h):
+        """src: (h, stride) int16"""
+        src = np.ascontiguousarray(src, np.int16)
+        dst = _aligned(np.zeros((h, w), np.int32))
+        self._slot("cpy_coeff", None, _p(src), C.c_ssize_t(src.shape[1]), _p(dst), w, h)
+        return dst
+
 
 class Oracle(_Base):
     def __init__(self):
@@ -119,6 +154,13 @@ class Oracle(_Base):
         L.orc_mctf_me.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
 
     name = "oracle"
+
+    def _slot(self, name, n, *a):
+        f = getattr(self.L, "orc_" + name)
+        f.restype = None
+        if n is not None:
+            a = (n,) + a
+        f(*[C.c_void_p(x) if isinstance(x, int) and x > (1 << 32) else x for x in a])
 
     # ---- distortion ----
     def dist(self, func, org, cur, w, h, bit_depth=10, sub_shift=0):
@@ -359,6 +401,12 @@ class RefLib(_Base):
         L.vvref_mctf_me.argtypes = [i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
         self._df = {n: L.vvref_df(n.encode()) for n in ("SSE", "SAD", "HAD", "HAD_fast", "HAD_2SAD")}
         assert (L.vvref_tr_type(b"DCT2"), L.vvref_tr_type(b"DCT8"), L.vvref_tr_type(b"DST7")) == (DCT2, DCT8, DST7)
+
+    def _slot(self, name, n, *a):
+        f = getattr(self.L, "vvref_" + name)
+        f.restype = None
+        a = (self.simd,) + ((n.bit_length() - 1,) if n is not None else ()) + a
+        f(*[C.c_void_p(x) if isinstance(x, int) and x > (1 << 32) else x for x in a])
 
     def dist(self, func, org, cur, w, h, bit_depth=10, sub_shift=0):
         if func == "HAD_2SAD":   # RdCost.cpp:1778 "assumes compact, aligned buffering": the SIMD row uses aligned loads

@@ -40,6 +40,7 @@
 #include "CommonLib/RdCost.h"
 #include "CommonLib/Quant.h"
 #include "CommonLib/MCTF.h"
+#include "CommonLib/TrQuant_EMT.h"
 #include "CommonLib/Picture.h"
 #include "EncoderLib/EncCfg.h"
 #undef private
@@ -177,9 +178,32 @@ bool mctfMe( vvenc::MCTF* m, const vvenc::PelStorage& refPic, const vvenc::PelSt
 
 } // namespace
 
+static int g_slotMask = 0;
+
+// bit5: the reference's global g_tCoeffOps takes the shim's ten slots AS THEY ARE — identical signatures, no trampoline, no source
+// patch (the table is a public global, TrQuant_EMT.h:91).  Called again after every SIMD (re-)initialisation.
+template<int K> void fwdSlot( const vvenc::TMatrixCoeff* tc, const vvenc::TCoeff* src, vvenc::TCoeff* dst, unsigned line, unsigned red, unsigned cut, int shift )
+{ g_calls[2]++; vvhip::g_tCoeffOps.fastFwdCore_2D[K]( tc, src, dst, line, red, cut, shift ); }
+template<int K> void invSlot( const vvenc::TMatrixCoeff* it, const vvenc::TCoeff* src, vvenc::TCoeff* dst, unsigned lines, unsigned red, unsigned rows )
+{ g_calls[3]++; vvhip::g_tCoeffOps.fastInvCore[K]( it, src, dst, lines, red, rows ); }
+
+extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_after_simd_init()
+{
+  if( !( g_slotMask & 32 ) ) return;
+  vvenc::TCoeffOps& t = vvenc::g_tCoeffOps;
+  const vvhip::TCoeffOps& h = vvhip::g_tCoeffOps;
+  t.cpyResi4 = h.cpyResi4; t.cpyResi8 = h.cpyResi8; t.cpyCoeff4 = h.cpyCoeff4; t.cpyCoeff8 = h.cpyCoeff8;
+  t.roundClip4 = h.roundClip4; t.roundClip8 = h.roundClip8;
+  // (the two matrix cores go through a counting wrapper so the test can see they were used; h's entries have the same signature)
+  t.fastFwdCore_2D[0] = fwdSlot<0>; t.fastFwdCore_2D[1] = fwdSlot<1>; t.fastFwdCore_2D[2] = fwdSlot<2>; t.fastFwdCore_2D[3] = fwdSlot<3>; t.fastFwdCore_2D[4] = fwdSlot<4>;
+  t.fastFwdCore_1D[0] = fwdSlot<0>; t.fastFwdCore_1D[1] = fwdSlot<1>; t.fastFwdCore_1D[2] = fwdSlot<2>; t.fastFwdCore_1D[3] = fwdSlot<3>; t.fastFwdCore_1D[4] = fwdSlot<4>;
+  t.fastInvCore[0] = invSlot<0>; t.fastInvCore[1] = invSlot<1>; t.fastInvCore[2] = invSlot<2>; t.fastInvCore[3] = invSlot<3>; t.fastInvCore[4] = invSlot<4>;
+}
+
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
 {
-  // mask bit0 RdCost, bit1 transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME
+  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots
+  g_slotMask = mask;
   try
   {
     if( mask && !g_rd ) { g_rd = new vvhip::RdCost; g_rd->create( true ); g_q = new vvhip::QuantOps; g_m = new vvhip::MCTFOps; }

@@ -275,6 +275,18 @@ API int vvref_inv_1d( int simd, int trType, int log2N, const int32_t* src, int32
   return 0;
 }
 
+// The g_tCoeffOps slots called directly (TrQuant_EMT.h:63-91): scalar row = the *Core functions, SIMD row = TrafoX86.h.
+API void vvref_fast_fwd_core( int simd, int log2N, const int16_t* tc, const int32_t* src, int32_t* dst, unsigned line, unsigned reducedLine, unsigned cutoff, int shift )
+{ tcoeffOps( simd ).fastFwdCore_2D[log2N - 2]( tc, src, dst, line, reducedLine, cutoff, shift ); }
+API void vvref_fast_inv_core( int simd, int log2N, const int16_t* it, const int32_t* src, int32_t* dst, unsigned lines, unsigned reducedLines, unsigned rows )
+{ tcoeffOps( simd ).fastInvCore[log2N - 2]( it, src, dst, lines, reducedLines, rows ); }
+API void vvref_round_clip( int simd, int32_t* dst, unsigned w, unsigned h, unsigned stride, int32_t mn, int32_t mx, int32_t round, int32_t shift )
+{ if( w & 7 ) tcoeffOps( simd ).roundClip4( dst, w, h, stride, mn, mx, round, shift ); else tcoeffOps( simd ).roundClip8( dst, w, h, stride, mn, mx, round, shift ); }
+API void vvref_cpy_resi( int simd, const int32_t* src, int16_t* dst, ptrdiff_t stride, unsigned w, unsigned h )
+{ if( w & 7 ) tcoeffOps( simd ).cpyResi4( src, dst, stride, w, h ); else tcoeffOps( simd ).cpyResi8( src, dst, stride, w, h ); }
+API void vvref_cpy_coeff( int simd, const int16_t* src, ptrdiff_t stride, int32_t* dst, unsigned w, unsigned h )
+{ if( w & 7 ) tcoeffOps( simd ).cpyCoeff4( src, stride, dst, w, h ); else tcoeffOps( simd ).cpyCoeff8( src, stride, dst, w, h ); }
+
 // The wiring of TrQuant::xT (TrQuant.cpp:481-564) around the reference's own 1-D functions and cpyCoeff ops.
 // (xT itself needs a TransformUnit/CodingStructure; the 1-D cores, zero-out and copies below ARE the reference's.)
 API int vvref_xT( int simd, const int16_t* resi, int resiStride, int32_t* coef, int width, int height,
@@ -641,6 +653,9 @@ API double vvref_run_jobs_mt( const int16_t* org, int orgStride, const int16_t* 
 namespace {
 void quietMsg( void*, int, const char*, va_list ) {}
 }
+// the hook-enabled build re-installs table-level device slots after the SIMD initialisation rewrote the global tables
+extern "C" void vvref_after_simd_init() __attribute__( ( weak ) );
+
 API long vvref_encode( const int16_t* y, const int16_t* u, const int16_t* v, int width, int height, int frames, int inputBitDepth, int internalBitDepth,
                        int preset, int qp, int threads, const char* simd, uint8_t* out, long outCap, double* secondsOut )
 {
@@ -655,6 +670,7 @@ API long vvref_encode( const int16_t* y, const int16_t* u, const int16_t* v, int
   vvencEncoder* enc = vvenc_encoder_create();
   if( !enc ) return -1;
   if( vvenc_encoder_open( enc, &cfg ) != 0 ) { fprintf( stderr, "vvref_encode: open failed: %s\n", vvenc_get_last_error( enc ) ); vvenc_encoder_close( enc ); return -2; }
+  if( vvref_after_simd_init ) vvref_after_simd_init();        // the encoder's constructor re-ran the SIMD initialisation (vvencimpl.cpp:96)
   vvencYUVBuffer yuv; vvenc_YUVBuffer_default( &yuv );
   vvenc_YUVBuffer_alloc_buffer( &yuv, VVENC_CHROMA_420, width, height );
   vvencAccessUnit au; vvenc_accessUnit_default( &au );

@@ -297,6 +297,52 @@ int orc_inv_1d(int trType, int log2N, const int32_t *src, int32_t *dst, int shif
     return 0;
 }
 
+/* The g_tCoeffOps table slots themselves (TrQuant_EMT.h:63-91), with the caller's matrix pointer: scalar cores
+ * TrQuant_EMT.cpp:1917-2000.  32-bit wrap-around arithmetic as the reference's int sums / SIMD mullo. */
+void orc_fast_fwd_core(int trSize, const int16_t *tc, const int32_t *src, int32_t *dst, unsigned line, unsigned reducedLine,
+                       unsigned cutoff, int shift)
+{   /* :1973-2000 */
+    const uint32_t rnd = 1u << (shift - 1);
+    for (unsigned i = 0; i < reducedLine; i++)
+        for (unsigned j = 0; j < cutoff; j++) {
+            uint32_t sum = 0;
+            for (int k = 0; k < trSize; k++) sum += (uint32_t)src[i * trSize + k] * (uint32_t)(int32_t)tc[j * trSize + k];
+            dst[j * line + i] = (int32_t)(sum + rnd) >> shift;
+        }
+}
+
+void orc_fast_inv_core(int trSize, const int16_t *it, const int32_t *src, int32_t *dst, unsigned lines, unsigned reducedLines,
+                       unsigned rows)
+{   /* :1953-1970: accumulates into dst (the caller zeroed it, :159) */
+    for (unsigned i = 0; i < reducedLines; i++)
+        for (int j = 0; j < trSize; j++) {
+            uint32_t sum = (uint32_t)dst[i * trSize + j];
+            for (unsigned k = 0; k < rows; k++) sum += (uint32_t)src[k * lines + i] * (uint32_t)(int32_t)it[k * trSize + j];
+            dst[i * trSize + j] = (int32_t)sum;
+        }
+}
+
+void orc_round_clip(int32_t *dst, unsigned w, unsigned h, unsigned stride, int32_t mn, int32_t mx, int32_t round, int32_t shift)
+{   /* clipCore :1941-1950 */
+    for (unsigned y = 0; y < h; y++)
+        for (unsigned x = 0; x < w; x++) {
+            const int32_t v = (int32_t)((uint32_t)dst[y * stride + x] + (uint32_t)round) >> shift;
+            dst[y * stride + x] = v < mn ? mn : (v > mx ? mx : v);
+        }
+}
+
+void orc_cpy_resi(const int32_t *src, int16_t *dst, ptrdiff_t stride, unsigned w, unsigned h)
+{   /* cpyResiCore :1929-1938 */
+    for (unsigned y = 0; y < h; y++)
+        for (unsigned x = 0; x < w; x++) dst[y * stride + x] = (int16_t)src[y * w + x];
+}
+
+void orc_cpy_coeff(const int16_t *src, ptrdiff_t stride, int32_t *dst, unsigned w, unsigned h)
+{   /* cpyCoeffCore :1917-1926 */
+    for (unsigned y = 0; y < h; y++)
+        for (unsigned x = 0; x < w; x++) dst[y * w + x] = src[y * stride + x];
+}
+
 static int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) l++; return l; }
 
 static void tr_skips(int w, int h, int trHor, int trVer, int *skipW, int *skipH)

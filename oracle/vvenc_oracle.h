@@ -27,6 +27,11 @@ void orc_dist_batch(int func, const int16_t *org, int os, const int16_t *cur, in
                     const int32_t *items, int n, uint64_t *out);
 
 int  orc_tr_matrix(int trType, int log2N, int16_t *out);
+void orc_fast_fwd_core(int trSize, const int16_t *tc, const int32_t *src, int32_t *dst, unsigned line, unsigned reducedLine, unsigned cutoff, int shift);
+void orc_fast_inv_core(int trSize, const int16_t *it, const int32_t *src, int32_t *dst, unsigned lines, unsigned reducedLines, unsigned rows);
+void orc_round_clip(int32_t *dst, unsigned w, unsigned h, unsigned stride, int32_t mn, int32_t mx, int32_t round, int32_t shift);
+void orc_cpy_resi(const int32_t *src, int16_t *dst, ptrdiff_t stride, unsigned w, unsigned h);
+void orc_cpy_coeff(const int16_t *src, ptrdiff_t stride, int32_t *dst, unsigned w, unsigned h);
 int  orc_fwd_1d(int trType, int log2N, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2);
 int  orc_inv_1d(int trType, int log2N, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2,
                 int32_t clipMin, int32_t clipMax);

@@ -126,6 +126,41 @@ static void test_TCoeffOps()
     orc_xIT( edeq.data(), erec.data(), w, w, h, th, tv, 10 );
     for( int i = 0; i < w * h; i++ ) CHECK_EQ( rec[i], erec[i], "invTransform2D" );
   }
+  // the ten table slots themselves, against the scalar cores' restatement
+  {
+    std::mt19937 rng( 77 );
+    for( int l = 2; l <= 6; l++ )
+    {
+      const int N = 1 << l;
+      std::vector<int16_t> tc( N * N );
+      vvhip_get_tr_matrix_host( VVHIP_DCT2, l, tc.data() );
+      for( unsigned line : { 4u, 16u, 64u } )
+      {
+        const unsigned red = line >= 16 ? line / 2 : line, cut = N >= 32 ? N / 2 : N;
+        std::vector<TCoeff> src( line * N ), got( N * line, 7 ), exp( N * line, 7 );
+        for( auto& v : src ) v = ( int ) ( rng() % 65536 ) - 32768;
+        g_tCoeffOps.fastFwdCore_2D[l - 2]( tc.data(), src.data(), got.data(), line, red, cut, 9 );
+        orc_fast_fwd_core( N, tc.data(), src.data(), exp.data(), line, red, cut, 9 );
+        if( got != exp ) { printf( "MISMATCH fastFwdCore N=%d line=%u\n", N, line ); failures++; }
+        std::vector<TCoeff> isrc( N * line ), igot( line * N, 0 ), iexp( line * N, 0 );
+        for( auto& v : isrc ) v = ( int ) ( rng() % 65536 ) - 32768;
+        g_tCoeffOps.fastInvCore[l - 2]( tc.data(), isrc.data(), igot.data(), line, red, cut );
+        orc_fast_inv_core( N, tc.data(), isrc.data(), iexp.data(), line, red, cut );
+        if( igot != iexp ) { printf( "MISMATCH fastInvCore N=%d line=%u\n", N, line ); failures++; }
+        g_tCoeffOps.roundClip8( igot.data(), N, red, N, -32768, 32767, 64, 7 );
+        orc_round_clip( iexp.data(), N, red, N, -32768, 32767, 64, 7 );
+        if( igot != iexp ) { printf( "MISMATCH roundClip N=%d line=%u\n", N, line ); failures++; }
+        std::vector<Pel> pg( line * ( N + 3 ), 5 ), pe( line * ( N + 3 ), 5 );
+        g_tCoeffOps.cpyResi8( igot.data(), pg.data(), N + 3, N, red );
+        orc_cpy_resi( iexp.data(), pe.data(), N + 3, N, red );
+        if( pg != pe ) { printf( "MISMATCH cpyResi N=%d line=%u\n", N, line ); failures++; }
+        std::vector<TCoeff> cg( N * red ), ce( N * red );
+        g_tCoeffOps.cpyCoeff4( pg.data(), N + 3, cg.data(), N, red );
+        orc_cpy_coeff( pe.data(), N + 3, ce.data(), N, red );
+        if( cg != ce ) { printf( "MISMATCH cpyCoeff N=%d line=%u\n", N, line ); failures++; }
+      }
+    }
+  }
 }
 
 static void test_MCTF()

@@ -77,3 +77,16 @@ def test_hip_table_entries_only_bitstream_identical():
     print("cpu", cpu, "hip", hip)
     assert 0 < hip["calls"][7] < 1000000, hip["calls"]
     assert hip["md5"] == cpu["md5"]
+
+
+@pytest.mark.gpu
+def test_hip_tcoeffops_slots_bitstream_identical():
+    """the reference's global g_tCoeffOps pointed at the device slots (identical signatures, zero source change): every matrix-core
+    pass, round/clip and Pel<->TCoeff copy of the encode runs on the GPU one call at a time; bitstream must not change"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    cpu = run(dict(CFG1, hip=False, simd=None, mask=0))
+    hip = run(dict(CFG1, hip=True, simd=None, mask=32))
+    print("cpu", cpu, "hip", hip)
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+    assert hip["calls"][2] > 100 and hip["calls"][3] > 100, hip["calls"]

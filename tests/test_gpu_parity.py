@@ -116,6 +116,48 @@ def test_sad_mask_and_weighted_sse_batches_vs_oracle(hip, oracle):
                 assert int(got[k]) == exp, ("wsse", w, h, k, int(got[k]), exp)
 
 
+def test_tcoeffops_slots_vs_oracle(hip, oracle):
+    """the five g_tCoeffOps slot kinds through the C ABI (device pointers), caller-supplied matrices"""
+    import torch
+    hp = hip.hp
+    rng = np.random.default_rng(166)
+
+    def dev(a):
+        return hp.to_device(np.ascontiguousarray(a))
+    for t, logs in ((0, range(2, 7)), (2, range(2, 6)), (1, range(2, 6))):
+        for l in logs:
+            n = 1 << l
+            tc = hip.tr_matrix(t, l)
+            d_tc = dev(tc)
+            for line in (4, 8, 32, 64):
+                skip, skip2 = (line // 2 if line >= 8 else 0), (n // 2 if n >= 32 else 0)
+                for red, cut in ((line, n), (line - skip, n - skip2)):
+                    src = rng.integers(-(1 << 15), 1 << 15, size=(line, n)).astype(np.int32)
+                    shift = int(rng.integers(1, 12))
+                    d_dst = torch.zeros(n * line, dtype=torch.int32, device=hp.device)
+                    hp._ck(hp.L.vvhip_fast_fwd_core(hp.ctx, n, d_tc.data_ptr(), dev(src).data_ptr(), d_dst.data_ptr(), line, red, cut, shift))
+                    assert np.array_equal(d_dst.cpu().numpy().reshape(n, line), oracle.fast_fwd_core(tc, src, line, red, cut, shift)), ("fwd", t, n, line, red, cut)
+                    srci = rng.integers(-(1 << 15), 1 << 15, size=(n, line)).astype(np.int32)
+                    d0 = rng.integers(-1000, 1000, size=(line, n)).astype(np.int32)
+                    d_acc = dev(d0)
+                    hp._ck(hp.L.vvhip_fast_inv_core(hp.ctx, n, d_tc.data_ptr(), dev(srci).data_ptr(), d_acc.data_ptr(), line, red, cut))
+                    assert np.array_equal(d_acc.cpu().numpy().reshape(line, n), oracle.fast_inv_core(tc, srci, d0, line, red, cut)), ("inv", t, n, line, red, cut)
+    for w in (4, 8, 16, 64):
+        for h in (2, 8, 64):
+            buf = rng.integers(-(1 << 24), 1 << 24, size=(h, w + 4)).astype(np.int32)
+            d = dev(buf)
+            hp._ck(hp.L.vvhip_round_clip(hp.ctx, d.data_ptr(), w, h, w + 4, -32768, 32767, 64, 7))
+            assert np.array_equal(d.cpu().numpy().reshape(h, w + 4), oracle.round_clip(buf, w, h, w + 4, -32768, 32767, 64, 7)), ("clip", w, h)
+            src = rng.integers(-(1 << 17), 1 << 17, size=(h, w)).astype(np.int32)
+            d_pel = torch.full((h * (w + 8),), -77, dtype=torch.int16, device=hp.device)
+            hp._ck(hp.L.vvhip_cpy_resi(hp.ctx, dev(src).data_ptr(), d_pel.data_ptr(), w + 8, w, h))
+            assert np.array_equal(d_pel.cpu().numpy().reshape(h, w + 8), oracle.cpy_resi(src, w, h, w + 8)), ("cpyResi", w, h)
+            pel = rng.integers(-(1 << 15), 1 << 15, size=(h, w + 8)).astype(np.int16)
+            d_c = torch.zeros(h * w, dtype=torch.int32, device=hp.device)
+            hp._ck(hp.L.vvhip_cpy_coeff(hp.ctx, dev(pel).data_ptr(), w + 8, d_c.data_ptr(), w, h))
+            assert np.array_equal(d_c.cpu().numpy().reshape(h, w), oracle.cpy_coeff(pel, w, h)), ("cpyCoeff", w, h)
+
+
 def test_sad_surface_vs_oracle(hip, oracle):
     from vvenc_amd.hotpath import Plane
     rng = np.random.default_rng(102)

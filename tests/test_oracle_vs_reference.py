@@ -108,6 +108,36 @@ def test_transform_matrices(oracle, reflib):
             assert np.array_equal(oracle.tr_matrix(t, l), reflib.tr_matrix(t, l)), (t, l)
 
 
+def test_tcoeffops_table_slots(oracle, reflib):
+    """every g_tCoeffOps slot called directly (TrQuant_EMT.h:63-91) with the reference's own matrices"""
+    rng = np.random.default_rng(66)
+    for t, logs in ((DCT2, range(2, 7)), (DST7, range(2, 6)), (DCT8, range(2, 6))):
+        for l in logs:
+            n = 1 << l
+            tc = reflib.tr_matrix(t, l)
+            for line in (4, 8, 16, 32, 64):
+                for (skip, skip2) in ((0, 0), (line // 2 if line >= 8 else 0, n // 2 if n >= 32 else 0)):
+                    red, cut = line - skip, n - skip2
+                    src = rng.integers(-(1 << 15), 1 << 15, size=(line, n)).astype(np.int32)
+                    shift = int(rng.integers(1, 12))
+                    a = oracle.fast_fwd_core(tc, src, line, red, cut, shift)
+                    b = reflib.fast_fwd_core(tc, src, line, red, cut, shift)
+                    assert np.array_equal(a[:cut, :red], b[:cut, :red]), ("fwd", t, n, line, red, cut)    # SIMD may write past reducedLine (UT:1116-1117)
+                    srci = rng.integers(-(1 << 15), 1 << 15, size=(n, line)).astype(np.int32)
+                    d0 = rng.integers(-1000, 1000, size=(line, n)).astype(np.int32)
+                    a = oracle.fast_inv_core(tc, srci, d0, line, red, cut)
+                    b = reflib.fast_inv_core(tc, srci, d0, line, red, cut)
+                    assert np.array_equal(a, b), ("inv", t, n, line, red, cut)
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 64):
+            buf = rng.integers(-(1 << 24), 1 << 24, size=(h, w)).astype(np.int32)
+            assert np.array_equal(oracle.round_clip(buf, w, h, w, -32768, 32767, 64, 7), reflib.round_clip(buf, w, h, w, -32768, 32767, 64, 7)), ("clip", w, h)
+            src = rng.integers(-(1 << 15), 1 << 15, size=(h, w)).astype(np.int32)
+            assert np.array_equal(oracle.cpy_resi(src, w, h, w + 8), reflib.cpy_resi(src, w, h, w + 8)), ("cpyResi", w, h)
+            pel = rng.integers(-(1 << 15), 1 << 15, size=(h, w + 8)).astype(np.int16)
+            assert np.array_equal(oracle.cpy_coeff(pel, w, h), reflib.cpy_coeff(pel, w, h)), ("cpyCoeff", w, h)
+
+
 def test_fwd_inv_1d(oracle, reflib):
     rng = np.random.default_rng(6)
     for t, logs in ((DCT2, range(1, 7)), (DCT8, range(2, 6)), (DST7, range(2, 6))):

@@ -353,12 +353,91 @@ void inv2D( const TCoeff* coef, Pel* resi, ptrdiff_t stride, unsigned w, unsigne
   for( unsigned y = 0; y < h; y++ ) memcpy( resi + y * stride, &tmp[( size_t ) y * w], sizeof( Pel ) * w );
 }
 
+// ---- the table's own slots (host pointers, one synchronous launch each) ----
+char* auxArea( Device& dev, size_t bytes ) { return static_cast<char*>( dev.stagingAux( bytes + 256 ) ); }
+
+template<int N> void fwdCore( const TMatrixCoeff* tc, const TCoeff* src, TCoeff* dst, unsigned line, unsigned reducedLine, unsigned cutoff, int shift )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t mB = sizeof( TMatrixCoeff ) * N * N, sB = sizeof( TCoeff ) * ( size_t ) line * N, dB = sizeof( TCoeff ) * ( size_t ) line * cutoff;
+  char* aux = auxArea( dev, mB + sB + dB );
+  char* dM = aux; char* dS = aux + ( ( mB + 63 ) & ~( size_t ) 63 ); char* dD = dS + ( ( sB + 63 ) & ~( size_t ) 63 );
+  dev.check( vvhip_upload( dev.ctx(), dM, tc, mB ), "fastFwdCore" );
+  dev.check( vvhip_upload( dev.ctx(), dS, src, sizeof( TCoeff ) * ( size_t ) reducedLine * N ), "fastFwdCore" );
+  dev.check( vvhip_upload( dev.ctx(), dD, dst, dB ), "fastFwdCore" );          // entries the core does not write keep the caller's values
+  dev.check( vvhip_fast_fwd_core( dev.ctx(), N, reinterpret_cast<int16_t*>( dM ), reinterpret_cast<int32_t*>( dS ), reinterpret_cast<int32_t*>( dD ), line, reducedLine, cutoff, shift ), "vvhip_fast_fwd_core" );
+  dev.check( vvhip_download( dev.ctx(), dst, dD, dB ), "fastFwdCore" );
+}
+
+template<int N> void invCore( const TMatrixCoeff* it, const TCoeff* src, TCoeff* dst, unsigned lines, unsigned reducedLines, unsigned rows )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t mB = sizeof( TMatrixCoeff ) * N * N, sB = sizeof( TCoeff ) * ( size_t ) lines * N, dB = sizeof( TCoeff ) * ( size_t ) reducedLines * N;
+  char* aux = auxArea( dev, mB + sB + dB );
+  char* dM = aux; char* dS = aux + ( ( mB + 63 ) & ~( size_t ) 63 ); char* dD = dS + ( ( sB + 63 ) & ~( size_t ) 63 );
+  dev.check( vvhip_upload( dev.ctx(), dM, it, mB ), "fastInvCore" );
+  dev.check( vvhip_upload( dev.ctx(), dS, src, sizeof( TCoeff ) * ( size_t ) rows * lines ), "fastInvCore" );
+  dev.check( vvhip_upload( dev.ctx(), dD, dst, dB ), "fastInvCore" );          // accumulates into the caller's (zeroed) dst
+  dev.check( vvhip_fast_inv_core( dev.ctx(), N, reinterpret_cast<int16_t*>( dM ), reinterpret_cast<int32_t*>( dS ), reinterpret_cast<int32_t*>( dD ), lines, reducedLines, rows ), "vvhip_fast_inv_core" );
+  dev.check( vvhip_download( dev.ctx(), dst, dD, dB ), "fastInvCore" );
+}
+
+void roundClipSlot( TCoeff* dst, unsigned width, unsigned height, unsigned stride, const TCoeff outputMin, const TCoeff outputMax, const TCoeff round, const TCoeff shift )
+{
+  if( !width || !height ) return;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t bytes = sizeof( TCoeff ) * ( ( size_t ) ( height - 1 ) * stride + width );
+  char* aux = auxArea( dev, bytes );
+  dev.check( vvhip_upload( dev.ctx(), aux, dst, bytes ), "roundClip" );
+  dev.check( vvhip_round_clip( dev.ctx(), reinterpret_cast<int32_t*>( aux ), width, height, stride, outputMin, outputMax, round, shift ), "vvhip_round_clip" );
+  dev.check( vvhip_download( dev.ctx(), dst, aux, bytes ), "roundClip" );
+}
+
+void cpyResiSlot( const TCoeff* src, Pel* dst, ptrdiff_t stride, unsigned width, unsigned height )
+{
+  if( !width || !height ) return;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t area = ( size_t ) width * height;
+  char* aux = auxArea( dev, area * ( sizeof( TCoeff ) + sizeof( Pel ) ) );
+  char* dD = aux + ( ( area * sizeof( TCoeff ) + 63 ) & ~( size_t ) 63 );
+  dev.check( vvhip_upload( dev.ctx(), aux, src, area * sizeof( TCoeff ) ), "cpyResi" );
+  dev.check( vvhip_cpy_resi( dev.ctx(), reinterpret_cast<int32_t*>( aux ), reinterpret_cast<int16_t*>( dD ), width, width, height ), "vvhip_cpy_resi" );   // compact on the device ...
+  std::vector<Pel> tmp( area );
+  dev.check( vvhip_download( dev.ctx(), tmp.data(), dD, area * sizeof( Pel ) ), "cpyResi" );
+  for( unsigned y = 0; y < height; y++ ) memcpy( dst + ( ptrdiff_t ) y * stride, &tmp[( size_t ) y * width], sizeof( Pel ) * width );                      // ... strided on the host
+}
+
+void cpyCoeffSlot( const Pel* src, ptrdiff_t stride, TCoeff* dst, unsigned width, unsigned height )
+{
+  if( !width || !height ) return;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t area = ( size_t ) width * height;
+  std::vector<Pel> tmp( area );
+  for( unsigned y = 0; y < height; y++ ) memcpy( &tmp[( size_t ) y * width], src + ( ptrdiff_t ) y * stride, sizeof( Pel ) * width );
+  char* aux = auxArea( dev, area * ( sizeof( TCoeff ) + sizeof( Pel ) ) );
+  char* dD = aux + ( ( area * sizeof( Pel ) + 63 ) & ~( size_t ) 63 );
+  dev.check( vvhip_upload( dev.ctx(), aux, tmp.data(), area * sizeof( Pel ) ), "cpyCoeff" );
+  dev.check( vvhip_cpy_coeff( dev.ctx(), reinterpret_cast<int16_t*>( aux ), width, reinterpret_cast<int32_t*>( dD ), width, height ), "vvhip_cpy_coeff" );
+  dev.check( vvhip_download( dev.ctx(), dst, dD, area * sizeof( TCoeff ) ), "cpyCoeff" );
+}
+
 } // namespace
 
 TCoeffOps::TCoeffOps()
 {
   fwdTransform2D = fwd2D;
   invTransform2D = inv2D;
+  cpyResi4 = cpyResi8 = cpyResiSlot;
+  cpyCoeff4 = cpyCoeff8 = cpyCoeffSlot;
+  roundClip4 = roundClip8 = roundClipSlot;
+  fastInvCore[0] = invCore<4>;  fastInvCore[1] = invCore<8>;  fastInvCore[2] = invCore<16>;  fastInvCore[3] = invCore<32>;  fastInvCore[4] = invCore<64>;
+  fastFwdCore_2D[0] = fastFwdCore_1D[0] = fwdCore<4>;   fastFwdCore_2D[1] = fastFwdCore_1D[1] = fwdCore<8>;   fastFwdCore_2D[2] = fastFwdCore_1D[2] = fwdCore<16>;
+  fastFwdCore_2D[3] = fastFwdCore_1D[3] = fwdCore<32>;  fastFwdCore_2D[4] = fastFwdCore_1D[4] = fwdCore<64>;
 }
 TCoeffOps g_tCoeffOps;
 

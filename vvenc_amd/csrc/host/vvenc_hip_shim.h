@@ -129,10 +129,18 @@ private:
 struct TCoeffOps
 {
   TCoeffOps();
-  // cpyCoeff4/8 and cpyResi4/8 (Pel <-> TCoeff strided copies) have no device twin on purpose: they are folded into the load /
-  // store of the two entries below, which therefore take and return Pel blocks directly.
-  // 2-D drivers with the signature of TrQuant::xT / xIT's inner work (TrQuant.cpp:481-655): what the shim calls instead of
-  // two fastFwdCore passes, because the two 1-D passes are fused on the device.
+  // the table's own ten slots, reference signatures (host pointers; dst of fastInvCore is accumulated into, as in the reference)
+  void ( *cpyResi8 )( const TCoeff* src, Pel* dst, ptrdiff_t stride, unsigned width, unsigned height );
+  void ( *cpyResi4 )( const TCoeff* src, Pel* dst, ptrdiff_t stride, unsigned width, unsigned height );
+  void ( *cpyCoeff8 )( const Pel* src, ptrdiff_t stride, TCoeff* dst, unsigned width, unsigned height );
+  void ( *cpyCoeff4 )( const Pel* src, ptrdiff_t stride, TCoeff* dst, unsigned width, unsigned height );
+  void ( *fastInvCore[5] )( const TMatrixCoeff* it, const TCoeff* src, TCoeff* dst, unsigned lines, unsigned reducedLines, unsigned rows );
+  void ( *fastFwdCore_2D[5] )( const TMatrixCoeff* it, const TCoeff* src, TCoeff* dst, unsigned lines, unsigned reducedLines, unsigned cutoff, int shift );
+  void ( *fastFwdCore_1D[5] )( const TMatrixCoeff* it, const TCoeff* src, TCoeff* dst, unsigned lines, unsigned reducedLines, unsigned cutoff, int shift );
+  void ( *roundClip4 )( TCoeff* dst, unsigned width, unsigned height, unsigned stride, const TCoeff outputMin, const TCoeff outputMax, const TCoeff round, const TCoeff shift );
+  void ( *roundClip8 )( TCoeff* dst, unsigned width, unsigned height, unsigned stride, const TCoeff outputMin, const TCoeff outputMax, const TCoeff round, const TCoeff shift );
+  // 2-D drivers with the signature of TrQuant::xT / xIT's inner work (TrQuant.cpp:481-655): what a batching integration calls instead
+  // of two 1-D passes + copies, because both passes (and the Pel <-> TCoeff conversion) are fused on the device.
   void ( *fwdTransform2D )( const Pel* resi, ptrdiff_t stride, TCoeff* coef, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
   void ( *invTransform2D )( const TCoeff* coef, Pel* resi, ptrdiff_t stride, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
 };

@@ -887,9 +887,65 @@ int launchTuRdo( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const i
 
 int teamLog2( int positions ) { int l = 0; while( ( 1 << ( l + 1 ) ) <= positions && l < 6 ) l++; return l; }
 
+// ---------------------------------------------------------------------------------------------
+// The g_tCoeffOps table slots one-to-one (TrQuant_EMT.h:63-91): 1-D matrix cores with the CALLER's matrix, round/clip and the
+// Pel <-> TCoeff copies.  The fused 2-D kernels above are what the batched path uses; these exist so that every slot of the
+// table has a device provider with the reference's signature.  One thread per output, 32-bit wrap-around sums.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__( 256 )
+fastFwdCoreKernel( int trSize, const int16_t* __restrict__ tc, const int32_t* __restrict__ src, int32_t* __restrict__ dst, unsigned line, unsigned reducedLine, unsigned cutoff, int shift )
+{
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if( idx >= reducedLine * cutoff ) return;
+  const unsigned j = idx / reducedLine, i = idx - j * reducedLine;
+  uint32_t sum = 0;
+  for( int k = 0; k < trSize; k++ ) sum += ( uint32_t ) src[i * trSize + k] * ( uint32_t ) ( int32_t ) tc[j * trSize + k];     // TrQuant_EMT.cpp:1987-1991
+  dst[j * line + i] = ( int32_t ) ( sum + ( 1u << ( shift - 1 ) ) ) >> shift;
+}
+
+__global__ void __launch_bounds__( 256 )
+fastInvCoreKernel( int trSize, const int16_t* __restrict__ it, const int32_t* __restrict__ src, int32_t* __restrict__ dst, unsigned lines, unsigned reducedLines, unsigned rows )
+{
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if( idx >= reducedLines * trSize ) return;
+  const unsigned i = idx / trSize, j = idx - i * trSize;
+  uint32_t sum = ( uint32_t ) dst[idx];                                                                                       // accumulates (:1964)
+  for( unsigned k = 0; k < rows; k++ ) sum += ( uint32_t ) src[k * lines + i] * ( uint32_t ) ( int32_t ) it[k * trSize + j];
+  dst[idx] = ( int32_t ) sum;
+}
+
+__global__ void __launch_bounds__( 256 )
+roundClipKernel( int32_t* __restrict__ dst, unsigned w, unsigned h, unsigned stride, int32_t mn, int32_t mx, int32_t round, int32_t shift )
+{
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if( idx >= w * h ) return;
+  const unsigned y = idx / w, x = idx - y * w;
+  const int32_t v = ( int32_t ) ( ( uint32_t ) dst[y * stride + x] + ( uint32_t ) round ) >> shift;                            // clipCore :1943
+  dst[y * stride + x] = v < mn ? mn : ( v > mx ? mx : v );
+}
+
+__global__ void __launch_bounds__( 256 )
+cpyResiKernel( const int32_t* __restrict__ src, int16_t* __restrict__ dst, ptrdiff_t stride, unsigned w, unsigned h )
+{
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if( idx >= w * h ) return;
+  const unsigned y = idx / w, x = idx - y * w;
+  dst[( ptrdiff_t ) y * stride + x] = ( int16_t ) src[idx];
+}
+
+__global__ void __launch_bounds__( 256 )
+cpyCoeffKernel( const int16_t* __restrict__ src, ptrdiff_t stride, int32_t* __restrict__ dst, unsigned w, unsigned h )
+{
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if( idx >= w * h ) return;
+  const unsigned y = idx / w, x = idx - y * w;
+  dst[idx] = src[( ptrdiff_t ) y * stride + x];
+}
+
 } // namespace
 
 extern "C" {
+
 
 int vvhip_fwd_transform_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const int32_t* d_resi_off,
                                int n, int width, int height, int tr_hor, int tr_ver, int bit_depth, int32_t* d_coef )
@@ -992,6 +1048,62 @@ int vvhip_dequant_core( vvhip_ctx* ctx, int max_x, int max_y, int scale, const i
   const int total = ( max_x + 1 ) * ( max_y + 1 );
   hipLaunchKernelGGL( dequantCoreKernel, dim3( ( total + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, max_x, max_y, scale, d_level, level_stride, d_coef,
                       right_shift, input_maximum, transform_maximum );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+static bool trSizeOk( int n ) { return n == 4 || n == 8 || n == 16 || n == 32 || n == 64; }
+
+int vvhip_fast_fwd_core( vvhip_ctx* ctx, int tr_size, const int16_t* d_tc, const int32_t* d_src, int32_t* d_dst, unsigned line, unsigned reduced_line, unsigned cutoff, int shift )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !trSizeOk( tr_size ) || !d_tc || !d_src || !d_dst || reduced_line > line || cutoff > ( unsigned ) tr_size || line > 64 || shift < 1 || shift > 31 )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_fast_fwd_core: trSize %d line %u/%u cutoff %u shift %d", tr_size, reduced_line, line, cutoff, shift );
+  const unsigned total = reduced_line * cutoff;
+  if( !total ) return VVHIP_OK;
+  hipLaunchKernelGGL( fastFwdCoreKernel, dim3( ( total + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, tr_size, d_tc, d_src, d_dst, line, reduced_line, cutoff, shift );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_fast_inv_core( vvhip_ctx* ctx, int tr_size, const int16_t* d_it, const int32_t* d_src, int32_t* d_dst, unsigned lines, unsigned reduced_lines, unsigned rows )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !trSizeOk( tr_size ) || !d_it || !d_src || !d_dst || reduced_lines > lines || rows > ( unsigned ) tr_size || lines > 64 )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_fast_inv_core: trSize %d lines %u/%u rows %u", tr_size, reduced_lines, lines, rows );
+  const unsigned total = reduced_lines * tr_size;
+  if( !total ) return VVHIP_OK;
+  hipLaunchKernelGGL( fastInvCoreKernel, dim3( ( total + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, tr_size, d_it, d_src, d_dst, lines, reduced_lines, rows );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_round_clip( vvhip_ctx* ctx, int32_t* d_dst, unsigned width, unsigned height, unsigned stride, int32_t out_min, int32_t out_max, int32_t round, int32_t shift )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !d_dst || width > stride || shift < 0 || shift > 31 || ( uint64_t ) width * height > ( 1u << 24 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_round_clip: bad arguments" );
+  if( !( width * height ) ) return VVHIP_OK;
+  hipLaunchKernelGGL( roundClipKernel, dim3( ( width * height + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_dst, width, height, stride, out_min, out_max, round, shift );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_cpy_resi( vvhip_ctx* ctx, const int32_t* d_src, int16_t* d_dst, ptrdiff_t stride, unsigned width, unsigned height )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !d_src || !d_dst || ( uint64_t ) width * height > ( 1u << 24 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_cpy_resi: bad arguments" );
+  if( !( width * height ) ) return VVHIP_OK;
+  hipLaunchKernelGGL( cpyResiKernel, dim3( ( width * height + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_src, d_dst, stride, width, height );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_cpy_coeff( vvhip_ctx* ctx, const int16_t* d_src, ptrdiff_t stride, int32_t* d_dst, unsigned width, unsigned height )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !d_src || !d_dst || ( uint64_t ) width * height > ( 1u << 24 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_cpy_coeff: bad arguments" );
+  if( !( width * height ) ) return VVHIP_OK;
+  hipLaunchKernelGGL( cpyCoeffKernel, dim3( ( width * height + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_src, stride, d_dst, width, height );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
 }
