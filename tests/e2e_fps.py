@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""End-to-end frames/sec of the REAL reference encoder (oracle/_ref, compiled from /root/reference) on a BASELINE-config-2 style clip,
+CPU kernels vs the same encoder with the whole-picture MCTF motion estimation running on the MI355X (hook mask 16), same host, same
+threads, bitstream md5 compared (SURVEY §8d "Metric").  Test infrastructure: prints one JSON line; run it through gpurun.
+
+  python tests/e2e_fps.py [--width 1920 --height 1080 --frames 17 --threads 8 --masks 0,16]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def synth_clip(width, height, frames, seed=1080):
+    """SURVEY §8d config-2 generator: textured base, global pan (3,1) px/frame, 128x128 object moving (7,2) px/frame, per-frame noise;
+    10-bit, chroma = affine of subsampled luma"""
+    rng = np.random.default_rng(seed)
+    pad = 64 + 8 * frames
+    yy, xx = np.mgrid[0:height + pad, 0:width + pad]
+    base = 512 + 180 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 120 * np.sin((xx + yy) / 11.0) + 60 * np.sin(xx / 3.1) * np.sin(yy / 4.3)
+    base = base + rng.normal(0, 12, base.shape)
+    obj = 700 + 150 * np.sin(np.mgrid[0:128, 0:128][1] / 5.0)
+    ys, us, vs = [], [], []
+    for t in range(frames):
+        f = base[t:t + height, 3 * t:3 * t + width].copy()
+        oy, ox = (100 + 2 * t) % (height - 128), (200 + 7 * t) % (width - 128)
+        f[oy:oy + 128, ox:ox + 128] = obj
+        f = np.clip(f + rng.normal(0, 3, f.shape), 0, 1023)
+        ys.append(f)
+        sub = f[::2, ::2]
+        us.append(np.clip(512 + 0.2 * (sub - 512), 0, 1023))
+        vs.append(np.clip(512 - 0.15 * (sub - 512), 0, 1023))
+    g = lambda a: np.ascontiguousarray(np.stack(a).astype(np.int16))
+    return g(ys), g(us), g(vs)
+
+
+WORKER = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import e2e_util as E, e2e_fps as F
+cfg = json.loads(sys.argv[1])
+L = E.load(cfg["mask"] != 0)
+if cfg["mask"]:
+    import torch  # one HIP runtime in the process
+    assert L.vvref_install_hip_hooks(cfg["mask"]) == 0
+yuv = F.synth_clip(cfg["w"], cfg["h"], cfg["frames"])
+md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], 10, 10, threads=cfg["threads"])
+calls = None
+if cfg["mask"]:
+    c = np.zeros(8, np.uint64); L.vvref_hip_hook_calls(c.ctypes.data); calls = [int(x) for x in c]
+print(json.dumps({"mask": cfg["mask"], "md5": md5, "bytes": n, "secs": secs, "fps": cfg["frames"] / secs, "calls": calls}))
+''' % os.path.join(ROOT, "tests")
+
+
+def run(cfg, timeout=3000):
+    r = subprocess.run([sys.executable, "-c", WORKER, json.dumps(cfg)], capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-3000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=17)
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--masks", default="0,16")
+    a = ap.parse_args()
+    res = [run(dict(w=a.width, h=a.height, frames=a.frames, threads=a.threads, mask=int(m))) for m in a.masks.split(",")]
+    out = {"clip": "%dx%d 10-bit synthetic (config-2 generator), %d frames, preset faster, QP 32" % (a.width, a.height, a.frames),
+           "threads": a.threads, "host_cpus": os.cpu_count(), "runs": res, "bitstreams_identical": len({r["md5"] for r in res}) == 1}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
