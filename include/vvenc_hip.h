@@ -179,6 +179,20 @@ VVHIP_API int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int res
                                   const vvhip_tu_qp* d_qp, int thr_val,
                                   int16_t* d_level, int16_t* d_rec_resi /* compact n*w*h */, vvhip_tu_stats* d_stats );
 
+/* A frame's TU work lists in one call: every job is one vvhip_tu_rdo_batch argument set on the same residual plane.  Square 8/16/32
+ * TUs (any transform types) are merged into ONE launch, largest size first — the per-size launches are each too small to fill
+ * the device; other shapes run as individual launches.  Results are identical to per-job vvhip_tu_rdo_batch calls.               */
+typedef struct
+{
+  int32_t width, height, tr_hor, tr_ver, n, thr_val;
+  const int32_t*     d_resi_off;
+  const vvhip_tu_qp* d_qp;
+  int16_t*           d_level;
+  int16_t*           d_rec_resi;
+  vvhip_tu_stats*    d_stats;
+} vvhip_tu_job;
+VVHIP_API int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, int bit_depth, const vvhip_tu_job* jobs_host, int n_jobs );
+
 /* ---- the g_tCoeffOps table slots one-to-one (CommonLib/TrQuant_EMT.h:63-91), device pointers, caller's matrix ------------------
  * vvhip_fast_fwd_core  <- fastFwdCore_2D/_1D[log2(tr_size)-2]  (TrQuant_EMT.cpp:1973-2000):
  *     dst[j*line + i] = ( sum_k src[i*tr_size + k] * tc[j*tr_size + k] + 2^(shift-1) ) >> shift,  i < reduced_line, j < cutoff

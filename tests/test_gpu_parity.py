@@ -394,3 +394,31 @@ def test_dist_multi_equals_batches(hip):
         hp.dist_multi(func, po, pc, jobs)
         for (w, h, ss, n, _, out), ref in zip(jobs, refs):
             assert np.array_equal(out.cpu().numpy(), ref), (func, w, h, ss)
+
+
+def test_tu_rdo_multi_equals_batches(hip):
+    """vvhip_tu_rdo_multi (square 8/16/32 lists merged into one launch, others alone) == one vvhip_tu_rdo_batch per job"""
+    import torch
+    from vvenc_amd.hotpath import HotPath, DCT2, DST7, DCT8
+    hp = hip.hp
+    rng = np.random.default_rng(208)
+    resi = rng.integers(-300, 300, size=(192, 320)).astype(np.int16)
+    pr = hp.plane(resi, 0)
+    jobs, refs = [], []
+    for (w, h, th, tv) in [(8, 8, DCT2, DCT2), (32, 32, DCT2, DCT2), (16, 16, DST7, DST7), (16, 16, DCT2, DCT2), (4, 4, DST7, DST7), (32, 32, DST7, DCT8), (64, 64, DCT2, DCT2),
+                           (16, 8, DCT2, DCT2), (8, 8, DCT8, DST7)]:
+        n = int(rng.integers(1, 200))
+        off = (rng.integers(0, 192 - h + 1, n) * pr.stride + rng.integers(0, 320 - w + 1, n)).astype(np.int32)
+        d_off = hp.to_device(off)
+        d_qp = hp.to_device(HotPath.tu_qp(rng.integers(20, 50, size=n), int(rng.integers(0, 2)), 1))
+        lv = torch.full((n * w * h,), -5, dtype=torch.int16, device=hp.device)
+        rc = torch.full((n * w * h,), -5, dtype=torch.int16, device=hp.device)
+        st = torch.zeros((n, 24), dtype=torch.uint8, device=hp.device)
+        jobs.append((w, h, th, tv, n, 8, d_off, d_qp, lv, rc, st))
+        a, b, c = hp.tu_rdo(pr, d_off, n, w, h, d_qp, th, tv, 10, 8)
+        refs.append((a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy()))
+    hp.tu_rdo_multi(pr, jobs, 10)
+    for (w, h, th, tv, n, _, _, _, lv, rc, st), (a, b, c) in zip(jobs, refs):
+        assert np.array_equal(lv.cpu().numpy(), a), ("level", w, h, th, tv)
+        assert np.array_equal(rc.cpu().numpy(), b), ("rec", w, h, th, tv)
+        assert np.array_equal(st.cpu().numpy(), c), ("stats", w, h, th, tv)

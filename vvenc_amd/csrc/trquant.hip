@@ -579,25 +579,44 @@ tuRdoKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t* __
 // Matrix rows are wave-wide LDS broadcasts (16-byte reads), every multiply is v_dot2_i32_i16; ~6x fewer instructions per
 // sample than the sample-per-lane kernel above (which remains for non-square, 4-, 2- and 64-point TUs).
 // --------------------------------------------------------------------------------------------
+struct TuRowArgs
+{
+  const int32_t* resiOff; int n;
+  TrGeom gf, gi; QGeom q;
+  const int16_t* matH; const int16_t* matV; const uint16_t* scan;
+  const vvhip_tu_qp* qps; int thrVal;
+  int16_t* level; int16_t* rec; vvhip_tu_stats* stats;
+};
+
+template<int N, int SPLIT> struct TuRowLds
+{
+  static constexpr int LPT = N * SPLIT, TPB = 256 / LPT, ND = N / 2, NO = N / SPLIT, P = N == 8 ? 8 : N + 8, LINES = 256 / SPLIT;
+  static constexpr int oMat = 0, oInv = oMat + 4 * N * N * 2, oTile = oInv + N * N * 2, oCoef = ( oTile + TPB * N * P * 2 + 15 ) & ~15,
+                       oDq = oCoef + NO * 256 * 4, bytes = oDq + ND * LINES * 4;
+};
+
 template<int N, int SPLIT>
-__global__ void __launch_bounds__( 256 )
-tuRdoRowKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t* __restrict__ resiOff, int n,
-                TrGeom gf, TrGeom gi, QGeom q, const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
-                const uint16_t* __restrict__ scan, const vvhip_tu_qp* __restrict__ qps, int thrVal,
-                int16_t* __restrict__ level, int16_t* __restrict__ rec, vvhip_tu_stats* __restrict__ stats )
+__device__ __forceinline__ void
+tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int16_t* __restrict__ resi, const int resiStride, const TuRowArgs& A )
 {
   // SPLIT lanes share one row / column: lane (line, part) produces outputs [part*NO, (part+1)*NO) of its line; LPT lanes per TU (<= 64).
   // Output loops are rolled (8 outputs per trip); per-lane coefficients live in a private LDS column (lane-major, conflict-free).
+  typedef TuRowLds<N, SPLIT> L;
   constexpr int LPT = N * SPLIT, TPB = 256 / LPT, ND = N / 2, NC = N / 8, NO = N / SPLIT, NOC = NO / 8;
-  constexpr int P = N == 8 ? 8 : N + 8;                       // tile row pitch (int16): odd number of 16-byte chunks
+  constexpr int P = L::P;                                     // tile row pitch (int16): odd number of 16-byte chunks
   constexpr int LINES = 256 / SPLIT;                          // rows (= columns) handled by a workgroup
   static_assert( LPT <= 64 && NO >= 8 && ( SPLIT == 1 || SPLIT == 2 ), "geometry" );
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sMat[4][N * N];       // Th, Tv, Th^T, Tv^T
-  __shared__ __attribute__( ( aligned( 16 ) ) ) uint16_t sInv[N * N];         // raster position -> scan position
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTile[TPB][N * P];
-  __shared__ int32_t  sCoef[NO][256];                                         // [output][thread]: private per-lane coefficients
-  __shared__ uint32_t sDq[ND][LINES];                                         // [k pair][line]: dequantised column, int16 pairs
+  int16_t  ( *sMat )[N * N]   = reinterpret_cast<int16_t ( * )[N * N]>( smem + L::oMat );       // Th, Tv, Th^T, Tv^T
+  uint16_t* sInv              = reinterpret_cast<uint16_t*>( smem + L::oInv );                  // raster position -> scan position
+  int16_t  ( *sTile )[N * P]  = reinterpret_cast<int16_t ( * )[N * P]>( smem + L::oTile );
+  int32_t  ( *sCoef )[256]    = reinterpret_cast<int32_t ( * )[256]>( smem + L::oCoef );        // [output][thread]: private per-lane coefficients
+  uint32_t ( *sDq )[LINES]    = reinterpret_cast<uint32_t ( * )[LINES]>( smem + L::oDq );       // [k pair][line]: dequantised column, int16 pairs
   struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+  const int32_t* __restrict__ resiOff = A.resiOff; const int n = A.n;
+  const TrGeom& gf = A.gf; const TrGeom& gi = A.gi; const QGeom& q = A.q;
+  const int16_t* __restrict__ matH = A.matH; const int16_t* __restrict__ matV = A.matV; const uint16_t* __restrict__ scan = A.scan;
+  const vvhip_tu_qp* __restrict__ qps = A.qps; const int thrVal = A.thrVal;
+  int16_t* __restrict__ level = A.level; int16_t* __restrict__ rec = A.rec; vvhip_tu_stats* __restrict__ stats = A.stats;
 
   const int tid = threadIdx.x;
   for( int i = tid; i < N * N; i += 256 )
@@ -612,7 +631,7 @@ tuRdoRowKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t*
   const int tl = tid / LPT, li = tid & ( LPT - 1 ), r = li / SPLIT, part = li & ( SPLIT - 1 ), lane = tid & 63;
   const int line = tid / SPLIT;                               // row / column index inside the workgroup
   const int o0 = part * NO;                                   // first output index of this lane
-  const int tu = blockIdx.x * TPB + tl;
+  const int tu = blockIndex * TPB + tl;
   const bool valid = tu < n;
   int16_t* tile = sTile[tl];
   const int16_t* src = resi + ( valid ? resiOff[tu] : 0 ) + ( ptrdiff_t ) r * resiStride;
@@ -796,6 +815,32 @@ tuRdoRowKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t*
     vvhip_tu_stats st; st.abs_sum = ( int32_t ) absSum; st.last_scan_pos = ( int32_t ) last; st.need_rdoq = ( int32_t ) need; st.pad = 0; st.sse = sse;
     stats[tu] = st;
   }
+}
+
+template<int N, int SPLIT>
+__global__ void __launch_bounds__( 256 )
+tuRdoRowKernel( const int16_t* __restrict__ resi, int resiStride, TuRowArgs args )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smem[TuRowLds<N, SPLIT>::bytes];
+  tuRdoRowBody<N, SPLIT>( smem, blockIdx.x, resi, resiStride, args );
+}
+
+// Several square TU sizes of one residual plane in ONE launch (largest first): the per-size launches are each too small to fill
+// the 1024 SIMDs (a 1080p frame has 1980 32x32 TUs = 2 waves per SIMD), together they overlap.
+struct TuMultiJobs { int nJobs; int blockStart[4]; int size[4]; TuRowArgs j[4]; };
+
+__global__ void __launch_bounds__( 256 )
+tuRdoRowMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMultiJobs jobs )
+{
+  constexpr int B32 = TuRowLds<32, 2>::bytes, B16 = TuRowLds<16, 2>::bytes, B8 = TuRowLds<8, 1>::bytes;
+  __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smem[B32 > B16 ? ( B32 > B8 ? B32 : B8 ) : ( B16 > B8 ? B16 : B8 )];
+  int k = 0;
+#pragma unroll
+  for( int i = 1; i < 4; i++ ) if( i < jobs.nJobs && ( int ) blockIdx.x >= jobs.blockStart[i] ) k = i;
+  const int blk = blockIdx.x - jobs.blockStart[k];
+  if( jobs.size[k] == 32 )      tuRdoRowBody<32, 2>( smem, blk, resi, resiStride, jobs.j[k] );
+  else if( jobs.size[k] == 16 ) tuRdoRowBody<16, 2>( smem, blk, resi, resiStride, jobs.j[k] );
+  else                          tuRdoRowBody<8, 1>( smem, blk, resi, resiStride, jobs.j[k] );
 }
 
 __global__ void __launch_bounds__( 256 )
@@ -1052,6 +1097,52 @@ int vvhip_dequant_core( vvhip_ctx* ctx, int max_x, int max_y, int scale, const i
   return VVHIP_OK;
 }
 
+int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, int bit_depth, const vvhip_tu_job* jobs, int n_jobs )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: bad job table" );
+  // square 8/16/32 TUs share the row-per-lane kernel: up to 4 of them go into one launch, largest size first; anything else runs alone
+  auto mergeable = []( const vvhip_tu_job& j ) { return j.n > 0 && j.width == j.height && ( j.width == 8 || j.width == 16 || j.width == 32 ); };
+  int order[64], nm = 0;
+  for( int i = 0; i < n_jobs; i++ )
+  {
+    if( jobs[i].n < 0 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: job %d has n < 0", i );
+    if( mergeable( jobs[i] ) && nm < 64 && !getenv( "VVHIP_TU_GENERIC" ) ) order[nm++] = i;
+    else if( jobs[i].n > 0 )
+    {
+      const int rc = vvhip_tu_rdo_batch( ctx, d_resi, resi_stride, jobs[i].d_resi_off, jobs[i].n, jobs[i].width, jobs[i].height, jobs[i].tr_hor, jobs[i].tr_ver, bit_depth,
+                                         jobs[i].d_qp, jobs[i].thr_val, jobs[i].d_level, jobs[i].d_rec_resi, jobs[i].d_stats );
+      if( rc ) return rc;
+    }
+  }
+  for( int a = 1; a < nm; a++ ) for( int b = a; b > 0 && jobs[order[b]].width > jobs[order[b - 1]].width; b-- ) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  for( int first = 0; first < nm; first += 4 )
+  {
+    TuMultiJobs mj; mj.nJobs = 0;
+    long blocks = 0;
+    for( int i = first; i < nm && i < first + 4; i++ )
+    {
+      const vvhip_tu_job& jb = jobs[order[i]];
+      TuRowArgs& ra = mj.j[mj.nJobs];
+      if( !makeGeom( jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth, false, ra.gf ) || !makeGeom( jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth, true, ra.gi ) ||
+          !makeQGeom( jb.width, jb.height, bit_depth, ra.q ) )
+        return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: unsupported %dx%d types (%d,%d) bitDepth %d", jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth );
+      ra.resiOff = jb.d_resi_off; ra.n = jb.n;
+      ra.matH = ctx->d_trMat + trMatOffset( jb.tr_hor, ra.gf.log2w ); ra.matV = ctx->d_trMat + trMatOffset( jb.tr_ver, ra.gf.log2h );
+      ra.scan = ctx->d_scan + scanOffset( ra.q.log2w, ra.q.log2h );
+      ra.qps = jb.d_qp; ra.thrVal = jb.thr_val; ra.level = jb.d_level; ra.rec = jb.d_rec_resi; ra.stats = jb.d_stats;
+      const int tpb = 256 / ( jb.width * ( jb.width == 8 ? 1 : 2 ) );
+      mj.blockStart[mj.nJobs] = ( int ) blocks; mj.size[mj.nJobs] = jb.width;
+      blocks += ( jb.n + tpb - 1 ) / tpb;
+      mj.nJobs++;
+    }
+    for( int i = mj.nJobs; i < 4; i++ ) { mj.blockStart[i] = 0x7fffffff; mj.size[i] = 0; }
+    hipLaunchKernelGGL( tuRdoRowMultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, mj );
+    VVHIP_LAUNCH_CHECK( ctx );
+  }
+  return VVHIP_OK;
+}
+
 static bool trSizeOk( int n ) { return n == 4 || n == 8 || n == 16 || n == 32 || n == 64; }
 
 int vvhip_fast_fwd_core( vvhip_ctx* ctx, int tr_size, const int16_t* d_tc, const int32_t* d_src, int32_t* d_dst, unsigned line, unsigned reduced_line, unsigned cutoff, int shift )
@@ -1132,8 +1223,10 @@ int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
     const int16_t* mh = ctx->d_trMat + trMatOffset( tr_hor, gf.log2w );
     const int16_t* mv = ctx->d_trMat + trMatOffset( tr_ver, gf.log2h );
     const uint16_t* sc = ctx->d_scan + scanOffset( q.log2w, q.log2h );
+    TuRowArgs ra; ra.resiOff = d_resi_off; ra.n = n; ra.gf = gf; ra.gi = gi; ra.q = q; ra.matH = mh; ra.matV = mv; ra.scan = sc;
+    ra.qps = d_qp; ra.thrVal = thr_val; ra.level = d_level; ra.rec = d_rec_resi; ra.stats = d_stats;
 #define ROWK( NN, SP ) hipLaunchKernelGGL( ( tuRdoRowKernel<NN, SP> ), dim3( ( n + ( 256 / ( NN * SP ) ) - 1 ) / ( 256 / ( NN * SP ) ) ), dim3( 256 ), 0, ctx->stream, \
-                                           d_resi, resi_stride, d_resi_off, n, gf, gi, q, mh, mv, sc, d_qp, thr_val, d_level, d_rec_resi, d_stats )
+                                           d_resi, resi_stride, ra )
     static const int split16 = getenv( "VVHIP_TU_SPLIT16" ) ? atoi( getenv( "VVHIP_TU_SPLIT16" ) ) : 2;
     if( width == 8 ) ROWK( 8, 1 ); else if( width == 16 ) { if( split16 == 2 ) ROWK( 16, 2 ); else ROWK( 16, 1 ); } else ROWK( 32, 2 );
 #undef ROWK

@@ -232,6 +232,24 @@ class HotPath:
                                            _ptr(d_qp), thr_val, _ptr(level), _ptr(rec), _ptr(stats)))
         return level, rec, stats
 
+    class _TuJob(C.Structure):
+        _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("tr_hor", C.c_int32), ("tr_ver", C.c_int32), ("n", C.c_int32), ("thr_val", C.c_int32),
+                    ("d_resi_off", C.c_void_p), ("d_qp", C.c_void_p), ("d_level", C.c_void_p), ("d_rec_resi", C.c_void_p), ("d_stats", C.c_void_p)]
+
+    def make_tu_jobs(self, jobs):
+        """jobs: list of (w, h, tr_hor, tr_ver, n, thr_val, d_off, d_qp, level, rec, stats) -> prepared host job table (tensors must stay alive)"""
+        arr = (self._TuJob * len(jobs))(*[self._TuJob(w, h, th, tv, n, thr, off.data_ptr(), qp.data_ptr(),
+                                                      lv.data_ptr() if lv is not None else None, rc.data_ptr() if rc is not None else None,
+                                                      st.data_ptr() if st is not None else None)
+                                          for (w, h, th, tv, n, thr, off, qp, lv, rc, st) in jobs])
+        return arr, len(jobs), jobs
+
+    def tu_rdo_multi(self, resi, jobs, bit_depth=10):
+        """all TU lists of a residual plane in one call (square 8/16/32 sizes share one launch)"""
+        if isinstance(jobs, list):
+            jobs = self.make_tu_jobs(jobs)
+        self._ck(self.L.vvhip_tu_rdo_multi(self.ctx, resi.buf_ptr, resi.stride, bit_depth, jobs[0], jobs[1]))
+
     # ---- (C) MCTF ----
     def extend_border(self, plane):
         self._ck(self.L.vvhip_extend_border(self.ctx, plane.buf_ptr, plane.stride, plane.width, plane.height, plane.pad))

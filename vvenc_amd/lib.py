@@ -41,6 +41,7 @@ PROTOTYPES = {
     "vvhip_quant_core": (i32, [vp, vp, i32, i32, i32, i32, C.c_int64, i32, vp, vp, vp, vp]),
     "vvhip_need_rdoq_core": (i32, [vp, vp, sz, i32, C.c_int64, i32, vp]),
     "vvhip_tu_rdo_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
+    "vvhip_tu_rdo_multi": (i32, [vp, vp, i32, i32, vp, i32]),
     "vvhip_fast_fwd_core": (i32, [vp, i32, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, i32]),
     "vvhip_fast_inv_core": (i32, [vp, i32, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint]),
     "vvhip_round_clip": (i32, [vp, vp, C.c_uint, C.c_uint, C.c_uint, i32, i32, i32, i32]),

@@ -16,6 +16,8 @@ DistParam::distFunc and ~2.05 x 1.5*W*H transformed coefficients per B-frame):
 Candidate displacements are seeded pseudo-random integer vectors within +-16 samples of a global pan.
 All of it is generated on the host once and stays resident in HBM; nothing here computes distortion.
 """
+import os
+
 import numpy as np
 
 from .hotpath import HotPath, Plane
@@ -93,13 +95,14 @@ class FrameWorkload:
         self.class_launches = {"SAD": len(SIZES), "HAD_fast": len(SIZES), "SSE": len(SIZES)}
         self.class_launches.update({"TU%d" % S: 1 for S in TU_SIZES})        # each fused TU size is its own kernel instantiation
 
-        self.merged = True      # one vvhip_dist_multi launch per function (all block sizes) instead of one launch per size
+        self.merged = os.environ.get("VVHIP_WORKLOAD_UNMERGED", "0") != "1"      # one vvhip_dist_multi launch per function (all block sizes) instead of one launch per size
         self.job_tables = {func: hp.make_dist_jobs([(S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f == func])
                            for func in ("SAD", "HAD_fast", "SSE")}
-        self.class_launches_merged = {"SAD": 1, "HAD_fast": 1, "SSE": 1}
-        self.class_launches_merged.update({"TU%d" % S: 1 for S in TU_SIZES})
+        self.tu_table = hp.make_tu_jobs([(S, S, 0, 0, n, 8, d_off, d_qp, lvl, rec, st) for (S, n, d_off, d_qp, lvl, rec, st, _, _) in self.tu_jobs])
+        self.alg_bytes["TU"] = sum(self.alg_bytes["TU%d" % S] for S in TU_SIZES)
+        self.class_launches_merged = {"SAD": 1, "HAD_fast": 1, "SSE": 1, "TU": 1}
 
-    # one pass of the hot path over the frame: 3 merged distortion launches (or 12 per-size ones) + 3 fused TU launches
+    # one pass of the hot path over the frame: 3 merged distortion launches + 1 merged fused-TU launch (or 12 + 3 per-size ones)
     def run(self, timers=None):
         hp = self.hp
         prev = None
@@ -120,6 +123,13 @@ class FrameWorkload:
                 hp.dist_batch(func, self.org, self.ref, d_items, n, S, S, ss, self.bit_depth, out=d_out)
             if timers is not None:
                 timers.stop(prev)
+        if self.merged:
+            if timers is not None:
+                timers.start("TU")
+            hp.tu_rdo_multi(self.resi, self.tu_table, self.bit_depth)
+            if timers is not None:
+                timers.stop("TU")
+            return
         for (S, n, d_off, d_qp, lvl, rec, st, _, _) in self.tu_jobs:
             if timers is not None:
                 timers.start("TU%d" % S)
