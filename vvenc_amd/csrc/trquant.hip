@@ -586,13 +586,14 @@ struct TuRowArgs
   const int16_t* matH; const int16_t* matV; const uint16_t* scan;
   const vvhip_tu_qp* qps; int thrVal;
   int16_t* level; int16_t* rec; vvhip_tu_stats* stats;
+  int phaseLimit;          // profiling aid ($VVHIP_TU_PHASES): stop after phase k, 0 = run everything
 };
 
 template<int N, int SPLIT> struct TuRowLds
 {
   static constexpr int LPT = N * SPLIT, TPB = 256 / LPT, ND = N / 2, NO = N / SPLIT, P = N == 8 ? 8 : N + 8, LINES = 256 / SPLIT;
   static constexpr int oMat = 0, oInv = oMat + 4 * N * N * 2, oTile = oInv + N * N * 2, oCoef = ( oTile + TPB * N * P * 2 + 15 ) & ~15,
-                       oDq = oCoef + NO * 256 * 4, bytes = oDq + ND * LINES * 4;
+                       bytes = oCoef + NO * 256 * 4;
 };
 
 template<int N, int SPLIT>
@@ -604,13 +605,11 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
   typedef TuRowLds<N, SPLIT> L;
   constexpr int LPT = N * SPLIT, TPB = 256 / LPT, ND = N / 2, NC = N / 8, NO = N / SPLIT, NOC = NO / 8;
   constexpr int P = L::P;                                     // tile row pitch (int16): odd number of 16-byte chunks
-  constexpr int LINES = 256 / SPLIT;                          // rows (= columns) handled by a workgroup
   static_assert( LPT <= 64 && NO >= 8 && ( SPLIT == 1 || SPLIT == 2 ), "geometry" );
   int16_t  ( *sMat )[N * N]   = reinterpret_cast<int16_t ( * )[N * N]>( smem + L::oMat );       // Th, Tv, Th^T, Tv^T
   uint16_t* sInv              = reinterpret_cast<uint16_t*>( smem + L::oInv );                  // raster position -> scan position
   int16_t  ( *sTile )[N * P]  = reinterpret_cast<int16_t ( * )[N * P]>( smem + L::oTile );
   int32_t  ( *sCoef )[256]    = reinterpret_cast<int32_t ( * )[256]>( smem + L::oCoef );        // [output][thread]: private per-lane coefficients
-  uint32_t ( *sDq )[LINES]    = reinterpret_cast<uint32_t ( * )[LINES]>( smem + L::oDq );       // [k pair][line]: dequantised column, int16 pairs
   struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
   const int32_t* __restrict__ resiOff = A.resiOff; const int n = A.n;
   const TrGeom& gf = A.gf; const TrGeom& gi = A.gi; const QGeom& q = A.q;
@@ -619,6 +618,23 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
   int16_t* __restrict__ level = A.level; int16_t* __restrict__ rec = A.rec; vvhip_tu_stats* __restrict__ stats = A.stats;
 
   const int tid = threadIdx.x;
+  const int tl = tid / LPT, li = tid & ( LPT - 1 ), r = li / SPLIT, part = li & ( SPLIT - 1 ), lane = tid & 63;
+  const int line = tid / SPLIT;                               // row / column index inside the workgroup
+  const int o0 = part * NO;                                   // first output index of this lane
+  const int tu = blockIndex * TPB + tl;
+  const bool valid = tu < n;
+  int16_t* tile = sTile[tl];
+  // the dependent global loads (offset -> residual row, QP) are issued before the ROM is staged so that their latencies overlap
+  const int16_t* src = resi + ( valid ? resiOff[tu] : 0 ) + ( ptrdiff_t ) r * resiStride;
+  const vvhip_tu_qp qq = valid ? qps[tu] : vvhip_tu_qp{ 32, 0 };
+  uint32_t x[ND];
+#pragma unroll
+  for( int c = 0; c < NC; c++ )
+  {
+    u32x4 v = { 0, 0, 0, 0 };
+    if( valid ) v = reinterpret_cast<const U16*>( src + 8 * c )->v;
+    x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+  }
   for( int i = tid; i < N * N; i += 256 )
   {
     const int k = i / N, j = i - k * N;
@@ -627,14 +643,7 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
     sInv[scan[i]] = ( uint16_t ) i;
   }
   __syncthreads();
-
-  const int tl = tid / LPT, li = tid & ( LPT - 1 ), r = li / SPLIT, part = li & ( SPLIT - 1 ), lane = tid & 63;
-  const int line = tid / SPLIT;                               // row / column index inside the workgroup
-  const int o0 = part * NO;                                   // first output index of this lane
-  const int tu = blockIndex * TPB + tl;
-  const bool valid = tu < n;
-  int16_t* tile = sTile[tl];
-  const int16_t* src = resi + ( valid ? resiOff[tu] : 0 ) + ( ptrdiff_t ) r * resiStride;
+  if( A.phaseLimit == 1 ) return;
 
 #define DOT_ROW( ACC, VEC, MROW ) { ACC = 0; _Pragma( "unroll" ) for( int c_ = 0; c_ < NC; c_++ ) {                          \
       const u32x4 m_ = *reinterpret_cast<const u32x4*>( ( MROW ) + 8 * c_ );                                                  \
@@ -643,14 +652,6 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
 
   // ---- forward rows: tmp[j][r] = sat16( ( sum_k blk[r][k] * Th[j][k] + rnd ) >> shift1 )        (cpyCoeff + TrQuant.cpp:548)
   {
-    uint32_t x[ND];
-#pragma unroll
-    for( int c = 0; c < NC; c++ )
-    {
-      u32x4 v = { 0, 0, 0, 0 };
-      if( valid ) v = reinterpret_cast<const U16*>( src + 8 * c )->v;
-      x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
-    }
     const int rnd1 = gf.shift1 > 0 ? 1 << ( gf.shift1 - 1 ) : 0;
 #pragma unroll 2
     for( int jj = 0; jj < NO; jj++ )
@@ -662,6 +663,7 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
     }
   }
   WAVE_SYNC();
+  if( A.phaseLimit == 2 ) return;
   // ---- forward columns (line = horizontal frequency c): coef[j2] = ( sum_k tmp[c][k] * Tv[j2][k] + rnd ) >> shift2   (TrQuant.cpp:549)
   const int cidx = r;
   {
@@ -679,9 +681,9 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
       sCoef[jj][tid] = ( colLive && j2 < N - gf.skipH ) ? ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd2 ) >> gf.shift2 : 0;
     }
   }
+  if( A.phaseLimit == 3 ) return;
   // ---- quantiser constants of this TU
   int scale, qBits;
-  const vvhip_tu_qp qq = valid ? qps[tu] : vvhip_tu_qp{ 32, 0 };
   quantParams( q, qq.qp, scale, qBits );
   const long long add  = ( long long ) ( ( qq.flags & 1 ) ? 171 : 85 ) << ( qBits - 9 );            // Quant.cpp:775
   const long long addN = ( long long ) ( ( qq.flags & 2 ) ? 171 : 256 ) << ( qBits - 9 );           // Quant.cpp:874
@@ -694,16 +696,20 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
   const int inMax = ( 1 << ( tgt - 1 ) ) - 1;
 
   // ---- significance: last non-zero scan position, need-RDOQ flag, coefficient-group test (Quant.cpp:162-208, :264-278)
-  uint32_t last = 0, need = 0;
+  // needRdoqCore asks whether ANY coefficient quantises to non-zero with the RDOQ offset: the quantiser is monotonic in |c|, so it is
+  // one 64-bit test on the TU's largest magnitude.
+  uint32_t last = 0, maxAbs = 0;
   for( int jj = 0; jj < NO; jj++ )
   {
     const uint32_t si = sInv[( o0 + jj ) * N + cidx];
     const int c = sCoef[jj][tid];
-    if( c != 0 && si > last ) last = si;
-    need |= ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) abs( c ) * scale + addN ) >> qBits ) != 0 );
+    const uint32_t ac = ( uint32_t ) abs( c );
+    maxAbs = ac > maxAbs ? ac : maxAbs;
+    last = ( c != 0 && si > last ) ? si : last;
   }
   last = vvhipGroupMax32( last, LPT, lane );
-  need = vvhipGroupOr32( need, LPT, lane );
+  maxAbs = vvhipGroupMax32( maxAbs, LPT, lane );
+  const uint32_t need = ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) maxAbs * scale + addN ) >> qBits ) != 0 );
   if( last >= 16 )
   {
     uint32_t lo = 0, hi = 0;
@@ -718,35 +724,40 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
     if( big == 0 ) last = 15;
     else { const uint32_t g2 = 63 - __clzll( ( long long ) big ); if( g2 != ( last >> 4 ) ) last = g2 * 16 + 15; }
   }
-  // ---- QuantCore + DeQuantCore (Quant.cpp:213-227, :232-262): level pairs -> tile (transpose for the raster store), dequantised pairs -> sDq
+  if( A.phaseLimit == 4 ) return;
+  // ---- QuantCore + DeQuantCore (Quant.cpp:213-227, :232-262), branch-free per coefficient: level pairs -> tile (transpose for the raster
+  // store), dequantised pairs -> the lane's own sCoef column (rows 0..NO/2-1, already consumed).  When every |c| of the wave fits 16 bits
+  // the level is a 24-bit multiply-add in 32 bits (|c|*scale < 2^31, add < 2^29.5); otherwise the 64-bit form.
   uint32_t absSum = 0;
-  for( int jj = 0; jj < NO; jj += 2 )
-  {
-    int lv[2], dq[2];
-#pragma unroll
-    for( int e = 0; e < 2; e++ )
-    {
-      lv[e] = 0; dq[e] = 0;
-      const int cv = sCoef[jj + e][tid];
-      if( cv != 0 && sInv[( o0 + jj + e ) * N + cidx] <= last )
-      {
-        const uint32_t m = ( uint32_t ) ( int32_t ) ( ( ( int64_t ) abs( cv ) * scale + add ) >> qBits );
-        if( m )
-        {
-          absSum += m;
-          lv[e] = clip3i( -32768, 32767, cv < 0 ? -( int32_t ) m : ( int32_t ) m );
-          const int cl = clip3i( -( inMax + 1 ), inMax, lv[e] );
-          int32_t v;
-          if( rightShift > 0 ) v = ( int32_t ) ( ( uint32_t ) ( cl * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
-          else                 v = ( int32_t ) ( ( uint32_t ) ( cl * iscale ) << ( -rightShift ) );
-          dq[e] = clip3i( -32768, 32767, v );
-        }
-      }
-    }
-    tile[( o0 + jj ) * P + cidx] = ( int16_t ) lv[0];
-    tile[( o0 + jj + 1 ) * P + cidx] = ( int16_t ) lv[1];
-    sDq[( o0 + jj ) / 2][line] = ( uint32_t ) ( dq[0] & 0xffff ) | ( ( uint32_t ) dq[1] << 16 );
+  const bool narrow = __builtin_amdgcn_ballot_w64( maxAbs >= 65536u || qBits > 30 ) == 0ull;
+  const uint32_t add32 = ( uint32_t ) add;
+  const int rndDq = rightShift > 0 ? 1 << ( rightShift - 1 ) : 0;
+#define TU_LEVEL_PAIR( MEXPR )                                                                                                       \
+  for( int jj = 0; jj < NO; jj += 2 )                                                                                                \
+  {                                                                                                                                  \
+    int lv[2], dq[2];                                                                                                                \
+    _Pragma( "unroll" ) for( int e = 0; e < 2; e++ )                                                                                 \
+    {                                                                                                                                \
+      const int cv = sCoef[jj + e][tid];                                                                                             \
+      const uint32_t ac = ( uint32_t ) abs( cv );                                                                                    \
+      uint32_t m = MEXPR;                                                                                                            \
+      m = sInv[( o0 + jj + e ) * N + cidx] <= last ? m : 0u;                                                                         \
+      absSum += m;                                                                                                                   \
+      const int sm = cv < 0 ? -( int32_t ) m : ( int32_t ) m;                                                                        \
+      lv[e] = clip3i( -32768, 32767, sm );                                                                                           \
+      const int cl = clip3i( -( inMax + 1 ), inMax, lv[e] );                                                                         \
+      const int pr = __mul24( cl, iscale );                                                                                          \
+      const int32_t v = rightShift > 0 ? ( int32_t ) ( ( uint32_t ) pr + ( uint32_t ) rndDq ) >> rightShift : ( int32_t ) ( ( uint32_t ) pr << ( -rightShift ) ); \
+      dq[e] = clip3i( -32768, 32767, v );                                                                                            \
+    }                                                                                                                                \
+    tile[( o0 + jj ) * P + cidx] = ( int16_t ) lv[0];                                                                                \
+    tile[( o0 + jj + 1 ) * P + cidx] = ( int16_t ) lv[1];                                                                            \
+    sCoef[jj >> 1][tid] = ( int32_t ) ( ( uint32_t ) ( dq[0] & 0xffff ) | ( ( uint32_t ) dq[1] << 16 ) );                            \
   }
+  if( narrow ) { TU_LEVEL_PAIR( ( ( uint32_t ) __umul24( ac, ( uint32_t ) scale ) + add32 ) >> qBits ) }
+  else         { TU_LEVEL_PAIR( ( uint32_t ) ( int32_t ) ( ( ( int64_t ) ac * scale + add ) >> qBits ) ) }
+#undef TU_LEVEL_PAIR
+  if( A.phaseLimit == 5 ) return;
   absSum = vvhipGroupSum32( absSum, LPT, lane );
   WAVE_SYNC();
   // ---- levels: raster rows -> HBM (16-byte stores)
@@ -755,11 +766,12 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
     for( int c = 0; c < NOC; c++ )
       *reinterpret_cast<u32x4*>( level + ( size_t ) tu * N * N + r * N + o0 + 8 * c ) = *reinterpret_cast<const u32x4*>( &tile[r * P + o0 + 8 * c] );
   WAVE_SYNC();
+  if( A.phaseLimit == 6 ) return;
   // ---- inverse columns: t1[j][c] = clip( ( sum_k deq[k][c] * Tv[k][j] + 64 ) >> 7 ), c < N - skipW   (TrQuant.cpp:612)
   {
     uint32_t dqp[ND];
 #pragma unroll
-    for( int k = 0; k < ND; k++ ) dqp[k] = sDq[k][line];
+    for( int k = 0; k < ND; k++ ) dqp[k] = ( uint32_t ) sCoef[k % ( NO / 2 )][line * SPLIT + k / ( NO / 2 )];     // pair k of the column: lane part k / (NO/2), its row k % (NO/2)
     const int rnd1 = 1 << ( gi.shift1 - 1 );
     const bool colLive = cidx < N - gi.skipW;
 #pragma unroll 2
@@ -772,6 +784,7 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
     }
   }
   WAVE_SYNC();
+  if( A.phaseLimit == 7 ) return;
   // ---- inverse rows: rec[r][j2] = clip( ( sum_k t1[r][k] * Th[k][j2] + rnd ) >> shift2 ); SSE against the residual row (re-read: L2 hit)
   unsigned long long sse = 0;
   {
@@ -989,6 +1002,8 @@ cpyCoeffKernel( const int16_t* __restrict__ src, ptrdiff_t stride, int32_t* __re
 
 } // namespace
 
+static int tuPhaseLimit() { static const int v = getenv( "VVHIP_TU_PHASES" ) ? atoi( getenv( "VVHIP_TU_PHASES" ) ) : 0; return v; }
+
 extern "C" {
 
 
@@ -1130,7 +1145,7 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
       ra.resiOff = jb.d_resi_off; ra.n = jb.n;
       ra.matH = ctx->d_trMat + trMatOffset( jb.tr_hor, ra.gf.log2w ); ra.matV = ctx->d_trMat + trMatOffset( jb.tr_ver, ra.gf.log2h );
       ra.scan = ctx->d_scan + scanOffset( ra.q.log2w, ra.q.log2h );
-      ra.qps = jb.d_qp; ra.thrVal = jb.thr_val; ra.level = jb.d_level; ra.rec = jb.d_rec_resi; ra.stats = jb.d_stats;
+      ra.qps = jb.d_qp; ra.thrVal = jb.thr_val; ra.level = jb.d_level; ra.rec = jb.d_rec_resi; ra.stats = jb.d_stats; ra.phaseLimit = tuPhaseLimit();
       const int tpb = 256 / ( jb.width * ( jb.width == 8 ? 1 : 2 ) );
       mj.blockStart[mj.nJobs] = ( int ) blocks; mj.size[mj.nJobs] = jb.width;
       blocks += ( jb.n + tpb - 1 ) / tpb;
@@ -1224,7 +1239,7 @@ int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
     const int16_t* mv = ctx->d_trMat + trMatOffset( tr_ver, gf.log2h );
     const uint16_t* sc = ctx->d_scan + scanOffset( q.log2w, q.log2h );
     TuRowArgs ra; ra.resiOff = d_resi_off; ra.n = n; ra.gf = gf; ra.gi = gi; ra.q = q; ra.matH = mh; ra.matV = mv; ra.scan = sc;
-    ra.qps = d_qp; ra.thrVal = thr_val; ra.level = d_level; ra.rec = d_rec_resi; ra.stats = d_stats;
+    ra.qps = d_qp; ra.thrVal = thr_val; ra.level = d_level; ra.rec = d_rec_resi; ra.stats = d_stats; ra.phaseLimit = tuPhaseLimit();
 #define ROWK( NN, SP ) hipLaunchKernelGGL( ( tuRdoRowKernel<NN, SP> ), dim3( ( n + ( 256 / ( NN * SP ) ) - 1 ) / ( 256 / ( NN * SP ) ) ), dim3( 256 ), 0, ctx->stream, \
                                            d_resi, resi_stride, ra )
     static const int split16 = getenv( "VVHIP_TU_SPLIT16" ) ? atoi( getenv( "VVHIP_TU_SPLIT16" ) ) : 2;
