@@ -209,6 +209,41 @@ VVHIP_API int vvhip_round_clip( vvhip_ctx* ctx, int32_t* d_dst, unsigned width, 
 VVHIP_API int vvhip_cpy_resi( vvhip_ctx* ctx, const int32_t* d_src, int16_t* d_dst, ptrdiff_t stride, unsigned width, unsigned height );
 VVHIP_API int vvhip_cpy_coeff( vvhip_ctx* ctx, const int16_t* d_src, ptrdiff_t stride, int32_t* d_dst, unsigned width, unsigned height );
 
+/* ======================================================================================================================
+ * SURVEY 8f rank 1 — sub-pel interpolation for fractional motion estimation / motion compensation
+ * ====================================================================================================================== */
+/* One pass of the separable interpolation on one block with the caller's taps: the table slots
+ * InterpolationFilter::m_filterHor / m_filterVer [tap index][isFirst][isLast] (CommonLib/InterpolationFilter.h:113-114),
+ * scalar core filter<N,isVertical,isFirst,isLast> (InterpolationFilter.cpp:356-441).  taps = 8, 6 or 4; coeff_host is the
+ * table ROW as the reference passes it (8 entries for 8 and 6 taps — the 6-tap core skips the first entry —, 4 for 4 taps).  */
+VVHIP_API int vvhip_if_filter( vvhip_ctx* ctx, int taps, int is_vertical, int is_first, int is_last, int bit_depth,
+                               const int16_t* d_src, int src_stride, int16_t* d_dst, int dst_stride, int width, int height,
+                               const int16_t* coeff_host );
+/* m_filterCopy[isFirst][isLast] (InterpolationFilter.h:115, filterCopy :255-333). */
+VVHIP_API int vvhip_if_copy( vvhip_ctx* ctx, int is_first, int is_last, int bit_depth,
+                             const int16_t* d_src, int src_stride, int16_t* d_dst, int dst_stride, int width, int height, int bi_mc_for_dmvr );
+
+/* A sub-pel candidate: original block at org_off, reference block whose integer position is ref_off, vector fraction in 1/16 sample. */
+typedef struct { int32_t org_off, ref_off; int16_t frac_x, frac_y; } vvhip_subpel_item;
+
+/* Motion-compensated luma prediction blocks (compact, d_out[i*w*h + y*w + x]): the passes InterPredInterpolation::xPredInterBlk runs
+ * (CommonLib/InterPrediction.cpp:832-865; no BDOF/DMVR) — frac_y == 0: horizontal only, frac_x == 0: vertical only, else horizontal
+ * (14-bit intermediate) then vertical.  rnd_res = !bi (InterPrediction.cpp:775): 1 = final samples clipped to the bit depth, 0 = the
+ * 14-bit intermediate a bi-prediction average consumes.
+ * filter_mode 0: the motion-compensation taps (8-tap m_lumaFilter; 6-tap m_lumaFilter4x4 for 4x4 blocks);
+ *             1 / 2: the reduced sets of the fast sub-pel search (m_meReduceTap 1 / 2: m_lumaFilter4x4 / m_chromaFilter[frac << 1],
+ *             InterpolationFilter.cpp:586-593).  use_alt_hpel: m_lumaAltHpelIFilter at phase 8 (IMV_HPEL).                       */
+VVHIP_API int vvhip_interp_luma_batch( vvhip_ctx* ctx, const int16_t* d_ref, int ref_stride, const vvhip_subpel_item* d_items, int n,
+                                       int width, int height, int bit_depth, int rnd_res, int filter_mode, int use_alt_hpel,
+                                       int16_t* d_out );
+
+/* What InterSearch::xPatternRefinement computes per tested position (EncoderLib/InterSearch.cpp:850-873, minus the MV-bit cost the
+ * host adds): distortion (func = VVHIP_DF_SAD / _HAD / _HAD_FAST / _SSE, subShift 0) between the original block and the block
+ * interpolated at the candidate's fractional vector.  One call = all sub-pel candidates of a stage for many blocks.               */
+VVHIP_API int vvhip_subpel_dist_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_ref, int ref_stride,
+                                       int width, int height, int bit_depth, int filter_mode, int use_alt_hpel,
+                                       const vvhip_subpel_item* d_items, int n, uint64_t* d_out );
+
 /* ROM accessors (host memory out): the tables the kernels use, for parity checks against
  * g_trCore* (CommonLib/RomTr.cpp:364-449) and getScanOrder (CommonLib/Rom.h:104).               */
 VVHIP_API int vvhip_get_tr_matrix_host( int tr_type, int log2_size, int16_t* host_out );

@@ -70,6 +70,62 @@ class _Base:
         stride = arr.shape[1]
         return _view_ptr(arr, y0 * stride + x0), stride
 
+    # ---- interpolation filter (InterpolationFilter.cpp) ----
+    def if_coeff(self, set_, phase):
+        out = np.zeros(8, np.int16)
+        n = getattr(self.L, self._pfx + "if_coeff")(set_, phase, _p(out))
+        return n, out
+
+    @staticmethod
+    def _if_src(src):
+        """src: (array, y, x) view with enough margin around the block for the taps"""
+        arr, y0, x0 = src
+        arr = _i16(arr)
+        assert arr.flags["C_CONTIGUOUS"] and arr.ndim == 2
+        return _view_ptr(arr, y0 * arr.shape[1] + x0), arr.shape[1]
+
+    def if_filter(self, n, vertical, first, last, bd, src, w, h, coeff):
+        ps, ss = self._if_src(src)
+        dst = np.full((h + 2, w + 32), -99, np.int16)      # slack: the x86 rows store whole vectors
+        c = np.ascontiguousarray(coeff, np.int16)
+        self._if_call("if_filter", n, int(vertical), int(first), int(last), bd, ps, ss, _p(dst), w + 32, w, h, _p(c))
+        return dst[:h, :w].copy()
+
+    def if_copy(self, first, last, bd, src, w, h, bi_mc=False):
+        ps, ss = self._if_src(src)
+        dst = np.full((h + 2, w + 32), -99, np.int16)      # slack: the x86 rows store whole vectors
+        self._if_call("if_copy", int(first), int(last), bd, ps, ss, _p(dst), w + 32, w, h, int(bi_mc))
+        return dst[:h, :w].copy()
+
+    def if_luma_1d(self, vertical, src, w, h, frac, first, last, bd=10, alt=False, reduce_tap=0):
+        ps, ss = self._if_src(src)
+        dst = np.full((h + 2, w + 32), -99, np.int16)      # slack: the x86 rows store whole vectors
+        self._if_call("if_luma_1d", int(vertical), ps, ss, _p(dst), w + 32, w, h, frac, int(first), int(last), bd, int(alt), reduce_tap)
+        return dst[:h, :w].copy()
+
+    def if_pred_luma(self, ref, w, h, xfrac, yfrac, rnd=True, bd=10, alt=False):
+        ps, ss = self._if_src(ref)
+        dst = np.full((h + 2, w + 32), -99, np.int16)      # slack: the x86 rows store whole vectors
+        self._if_call("if_pred_luma", ps, ss, _p(dst), w + 32, w, h, xfrac, yfrac, int(rnd), bd, int(alt))
+        return dst[:h, :w].copy()
+
+    def if_pred_luma_me(self, ref, w, h, xfrac, yfrac, bd=10, alt=False, reduce_tap=0):
+        """the two passes InterSearch::xPatternRefinement / xExtDIFUpSampling* run for one sub-pel position (InterSearch.cpp:818-848):
+        horizontal pass with isLast=false over the rows the vertical taps need, vertical pass isFirst=false isLast=true"""
+        arr, y0, x0 = ref
+        rows = h + 7
+        tmp = self.if_luma_1d(0, (arr, y0 - 3, x0), w, rows, xfrac, 1, 0, bd, alt, reduce_tap)
+        pad = np.zeros((rows + 8, w + 16), np.int16)
+        pad[4:4 + rows, 8:8 + w] = tmp
+        return self.if_luma_1d(1, (pad, 4 + 3, 8), w, h, yfrac, 0, 1, bd, alt, reduce_tap)
+
+    def _if_call(self, name, *a):
+        f = getattr(self.L, self._pfx + name)
+        f.restype = None
+        if self._pfx == "vvref_":
+            a = (self.simd,) + a
+        f(*a)
+
     # ---- g_tCoeffOps table slots (TrQuant_EMT.h:63-91), caller's matrix ----
     def fast_fwd_core(self, tc, src, line, reduced_line, cutoff, shift):
         """tc: (N, N) int16, src: (line, N) int32 -> dst (N, line) int32 (entries outside reduced_line x cutoff stay 0)"""
@@ -107,6 +163,7 @@ class _Base:
 
 
 class Oracle(_Base):
+    _pfx = "orc_"
     def __init__(self):
         if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "vvenc_oracle.c")):
             build_oracle()
@@ -358,6 +415,7 @@ def _mctf_me(fn, simd, org, ref, bit_depth, unit, speed, add_level):
 
 
 class RefLib(_Base):
+    _pfx = "vvref_"
     """The reference's own kernels (scalar row simd=0, x86 SIMD row simd=1)."""
 
     @staticmethod

@@ -59,6 +59,7 @@
 #include "CommonLib/Rom.h"
 #include "CommonLib/ContextModelling.h"
 #include "CommonLib/Picture.h"
+#include "CommonLib/InterpolationFilter.h"
 #include "vvenc/vvencCfg.h"
 #include "EncoderLib/EncCfg.h"
 #undef private
@@ -653,6 +654,80 @@ API double vvref_run_jobs_mt( const int16_t* org, int orgStride, const int16_t* 
 namespace {
 void quietMsg( void*, int, const char*, va_list ) {}
 }
+// ---------------------------------------------------------------------------------------------
+// InterpolationFilter (CommonLib/InterpolationFilter.{h,cpp}, x86 row x86/InterpolationFilterX86.h)
+// ---------------------------------------------------------------------------------------------
+namespace {
+InterpolationFilter& ifObj( int simd )
+{
+  static InterpolationFilter* f[2] = { nullptr, nullptr };
+  if( !f[0] ) { f[0] = new InterpolationFilter; f[1] = new InterpolationFilter; f[1]->initInterpolationFilter( true ); }
+  return *f[simd ? 1 : 0];
+}
+int tapIdx( int N ) { return N == 8 ? 0 : N == 4 ? 1 : N == 2 ? 2 : 3; }     // InterpolationFilter.cpp:463-482
+}
+
+API int vvref_if_coeff( int set, int phase, int16_t* out8 )
+{
+  for( int i = 0; i < 8; i++ ) out8[i] = 0;
+  switch( set )
+  {
+  case 0: for( int i = 0; i < 8; i++ ) out8[i] = InterpolationFilter::m_lumaFilter[phase][i]; return 8;
+  case 1: for( int i = 0; i < 8; i++ ) out8[i] = InterpolationFilter::m_lumaFilter4x4[phase][i]; return 6;
+  case 2: for( int i = 0; i < 4; i++ ) out8[i] = InterpolationFilter::m_chromaFilter[phase][i]; return 4;
+  case 3: for( int i = 0; i < 8; i++ ) out8[i] = InterpolationFilter::m_lumaAltHpelIFilter[i]; return 6;
+  case 4: for( int i = 0; i < 2; i++ ) out8[i] = InterpolationFilter::m_bilinearFilterPrec4[phase][i]; return 2;
+  }
+  return -1;
+}
+
+// the table slots m_filterHor / m_filterVer [tap index][isFirst][isLast] (InterpolationFilter.h:113-114)
+API void vvref_if_filter( int simd, int N, int isVertical, int isFirst, int isLast, int bitDepth, const int16_t* src, int srcStride, int16_t* dst, int dstStride,
+                          int width, int height, const int16_t* coeff )
+{
+  InterpolationFilter& f = ifObj( simd );
+  ClpRng clp; clp.bd = bitDepth;
+  ( isVertical ? f.m_filterVer : f.m_filterHor )[tapIdx( N )][isFirst ? 1 : 0][isLast ? 1 : 0]( clp, src, srcStride, dst, dstStride, width, height, coeff );
+}
+
+API void vvref_if_copy( int simd, int isFirst, int isLast, int bitDepth, const int16_t* src, int srcStride, int16_t* dst, int dstStride, int width, int height, int biMCForDMVR )
+{
+  ClpRng clp; clp.bd = bitDepth;
+  ifObj( simd ).m_filterCopy[isFirst ? 1 : 0][isLast ? 1 : 0]( clp, src, srcStride, dst, dstStride, width, height, biMCForDMVR != 0 );
+}
+
+// public dispatchers filterHor / filterVer for luma (InterpolationFilter.cpp:557-661)
+API void vvref_if_luma_1d( int simd, int vertical, const int16_t* src, int srcStride, int16_t* dst, int dstStride, int width, int height, int frac,
+                           int isFirst, int isLast, int bitDepth, int useAltHpelIf, int reduceTap )
+{
+  InterpolationFilter& f = ifObj( simd );
+  ClpRng clp; clp.bd = bitDepth;
+  if( vertical ) f.filterVer( COMP_Y, src, srcStride, dst, dstStride, width, height, frac, isFirst != 0, isLast != 0, CHROMA_420, clp, useAltHpelIf != 0, 0, reduceTap );
+  else           f.filterHor( COMP_Y, src, srcStride, dst, dstStride, width, height, frac, isLast != 0, CHROMA_420, clp, useAltHpelIf != 0, 0, reduceTap );
+}
+
+// The interpolation calls of InterPredInterpolation::xPredInterBlk (InterPrediction.cpp:832-865; no BDOF / DMVR / bilinear) made on the
+// reference's own InterpolationFilter object (the function itself needs a CodingUnit and a Picture).
+API void vvref_if_pred_luma( int simd, const int16_t* ref, int refStride, int16_t* dst, int dstStride, int width, int height, int xFrac, int yFrac,
+                             int rndRes, int bitDepth, int useAltHpelIf )
+{
+  InterpolationFilter& f = ifObj( simd );
+  ClpRng clp; clp.bd = bitDepth;
+  const bool alt = useAltHpelIf != 0, rnd = rndRes != 0;
+  if( yFrac == 0 )      f.filterHor( COMP_Y, ref, refStride, dst, dstStride, width, height, xFrac, rnd, CHROMA_420, clp, alt, 0 );
+  else if( xFrac == 0 ) f.filterVer( COMP_Y, ref, refStride, dst, dstStride, width, height, yFrac, true, rnd, CHROMA_420, clp, alt, 0 );
+  else if( width == 4 && height == 4 ) f.filter4x4( COMP_Y, ref, refStride, dst, dstStride, 4, 4, xFrac, yFrac, rnd, CHROMA_420, clp, alt );
+  else if( width == 16 ) f.filter16xH( COMP_Y, ref, refStride, dst, dstStride, 16, height, xFrac, yFrac, rnd, CHROMA_420, clp, alt );
+  else if( width == 8 )  f.filter8xH( COMP_Y, ref, refStride, dst, dstStride, 8, height, xFrac, yFrac, rnd, CHROMA_420, clp, alt );
+  else
+  {
+    static thread_local std::vector<Pel> tmp;
+    tmp.resize( ( size_t ) width * ( height + 8 ) );
+    f.filterHor( COMP_Y, ref - 3 * refStride, refStride, tmp.data(), width, width, height + 7, xFrac, false, CHROMA_420, clp, alt, 0 );
+    f.filterVer( COMP_Y, tmp.data() + 3 * width, width, dst, dstStride, width, height, yFrac, false, rnd, CHROMA_420, clp, alt, 0 );
+  }
+}
+
 // the hook-enabled build re-installs table-level device slots after the SIMD initialisation rewrote the global tables
 extern "C" void vvref_after_simd_init() __attribute__( ( weak ) );
 

@@ -797,3 +797,139 @@ int orc_mctf_me(const int16_t *orgLuma, const int16_t *refLuma, int width, int h
     for (int l = 0; l < 4; l++) { plane_free(&o[l]); plane_free(&r[l]); }
     return 0;
 }
+
+/* ================================================================================================
+ * SURVEY §8f rank 1 — sub-pel interpolation                               (InterpolationFilter.cpp)
+ * ==============================================================================================*/
+/* Tap tables (the VVC luma 8-tap, luma 6-tap "4x4/affine", alternative half-pel and chroma 4-tap sets, InterpolationFilter.cpp:64-142)
+ * are mirror-symmetric in the phase: row P-p is row p reversed.  Only phases 0..P/2 are stored. */
+static const int8_t if_luma8_half[9][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 63, 4, -2, 1, 0 }, { -1, 2, -5, 62, 8, -3, 1, 0 }, { -1, 3, -8, 60, 13, -4, 1, 0 },
+    { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 52, 26, -8, 3, -1 }, { -1, 3, -9, 47, 31, -10, 4, -1 }, { -1, 4, -11, 45, 34, -10, 4, -1 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 } };
+static const int8_t if_luma6_half[9][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 63, 4, -2, 1, 0 }, { 0, 1, -5, 62, 8, -3, 1, 0 }, { 0, 2, -8, 60, 13, -4, 1, 0 },
+    { 0, 3, -10, 58, 17, -5, 1, 0 }, { 0, 3, -11, 52, 26, -8, 2, 0 }, { 0, 2, -9, 47, 31, -10, 3, 0 }, { 0, 3, -11, 45, 34, -10, 3, 0 },
+    { 0, 3, -11, 40, 40, -11, 3, 0 } };
+static const int8_t if_alt_hpel[8] = { 0, 3, 9, 20, 20, 9, 3, 0 };
+static const int8_t if_chroma_half[17][4] = {
+    { 0, 64, 0, 0 }, { -1, 63, 2, 0 }, { -2, 62, 4, 0 }, { -2, 60, 7, -1 }, { -2, 58, 10, -2 }, { -3, 57, 12, -2 }, { -4, 56, 14, -2 },
+    { -4, 55, 15, -2 }, { -4, 54, 16, -2 }, { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 }, { -6, 46, 28, -4 }, { -5, 44, 29, -4 },
+    { -4, 42, 30, -4 }, { -4, 39, 33, -4 }, { -4, 36, 36, -4 } };
+
+/* set: 0 = m_lumaFilter (8 taps), 1 = m_lumaFilter4x4 (8 entries, used as 6 taps from entry 1), 2 = m_chromaFilter (4 taps, phase 0..32),
+ * 3 = m_lumaAltHpelIFilter (phase ignored), 4 = m_bilinearFilterPrec4 (2 taps).  Returns the tap count the reference filters with;
+ * coeff[] receives the table row exactly as the reference passes it (8 entries for sets 0/1/3). */
+int orc_if_coeff(int set, int phase, int16_t coeff[8])
+{
+    for (int i = 0; i < 8; i++) coeff[i] = 0;
+    if (set == 0 || set == 1) {
+        if (phase < 0 || phase > 16) return -1;
+        const int8_t (*t)[8] = set == 0 ? if_luma8_half : if_luma6_half;
+        /* the table rows are mirror images in the phase around the two centre taps 3 and 4: row[16-p][k] = row[p][7-k] */
+        for (int k = 0; k < 8; k++) coeff[k] = phase <= 8 ? t[phase][k] : t[16 - phase][7 - k];
+        return set == 0 ? 8 : 6;
+    }
+    if (set == 2) {
+        if (phase < 0 || phase > 32) return -1;
+        for (int k = 0; k < 4; k++) coeff[k] = phase <= 16 ? if_chroma_half[phase][k] : if_chroma_half[32 - phase][3 - k];
+        return 4;
+    }
+    if (set == 3) { for (int k = 0; k < 8; k++) coeff[k] = if_alt_hpel[k]; return 6; }
+    if (set == 4) { if (phase < 0 || phase > 15) return -1; coeff[0] = (int16_t)(16 - phase); coeff[1] = (int16_t)phase; return 2; }
+    return -1;
+}
+
+/* InterpolationFilter::filter<N,isVertical,isFirst,isLast> (InterpolationFilter.cpp:356-441).  coeff = the table row (for N == 6 the
+ * reference skips its first entry, :361-364).  Output is truncated to Pel like the reference's `Pel val`. */
+void orc_if_filter(int N, int isVertical, int isFirst, int isLast, int bitDepth, const int16_t *src, int srcStride, int16_t *dst,
+                   int dstStride, int width, int height, const int16_t *coeff)
+{
+    if (N == 6) coeff++;
+    const int cStride = isVertical ? srcStride : 1;
+    src -= (N / 2 - 1) * cStride;
+    const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2;
+    int shift = 6, offset;
+    if (N != 2) {
+        if (isLast) { shift += isFirst ? 0 : headRoom; offset = 1 << (shift - 1); offset += isFirst ? 0 : (8192 << 6); }
+        else        { shift -= isFirst ? headRoom : 0; offset = isFirst ? -(8192 << shift) : 0; }
+    } else {
+        if (isFirst) { shift = 4 - (10 - bitDepth); offset = 1 << (shift - 1); }
+        else         { shift = 4; offset = 1 << (shift - 1); }
+    }
+    const int maxv = (1 << bitDepth) - 1;
+    for (int row = 0; row < height; row++) {
+        for (int col = 0; col < width; col++) {
+            int sum = 0;
+            for (int k = 0; k < N; k++) sum += src[col + k * cStride] * coeff[k];
+            int16_t val = (int16_t)((sum + offset) >> shift);
+            if (isLast) val = val < 0 ? 0 : (val > maxv ? (int16_t)maxv : val);
+            dst[col] = val;
+        }
+        src += srcStride;
+        dst += dstStride;
+    }
+}
+
+/* InterpolationFilter::filterCopy<isFirst,isLast> (:255-333). */
+void orc_if_copy(int isFirst, int isLast, int bitDepth, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width,
+                 int height, int biMCForDMVR)
+{
+    const int shift = 14 - bitDepth > 2 ? 14 - bitDepth : 2, maxv = (1 << bitDepth) - 1;
+    for (int row = 0; row < height; row++, src += srcStride, dst += dstStride)
+        for (int col = 0; col < width; col++) {
+            if (isFirst == isLast) dst[col] = src[col];
+            else if (isFirst) dst[col] = biMCForDMVR ? (int16_t)(src[col] << (10 - bitDepth))
+                                                      : (int16_t)((int16_t)((uint16_t)src[col] << shift) - 8192);
+            else {
+                /* rightShiftU( val + offset, shift ) on the int promotion: arithmetic shift (CommonDef.h:755), :319-322 */
+                int16_t val = (int16_t)(((int)src[col] + (int)(int16_t)((1 << (shift - 1)) + 8192)) >> shift);
+                dst[col] = val < 0 ? 0 : (val > maxv ? (int16_t)maxv : val);
+            }
+        }
+}
+
+/* Luma filter choice of InterpolationFilter::filterHor/filterVer (:557-601, :617-661) for nFilterIdx 0. */
+static int if_luma_set(int frac, int width, int height, int useAltHpelIf, int reduceTap, int vertical)
+{
+    if (reduceTap == 0 || (useAltHpelIf && frac == 8)) {
+        if (useAltHpelIf && frac == 8) return 3;
+        if ((width == 4 && height == 4) || (!vertical && width == 4 && height == 4 + 8 - 1)) return 1;
+        return 0;
+    }
+    return reduceTap == 1 ? 1 : 2;
+}
+
+/* InterpolationFilter::filterHor / filterVer, luma (compID Y), nFilterIdx 0. */
+void orc_if_luma_1d(int vertical, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width, int height, int frac,
+                    int isFirst, int isLast, int bitDepth, int useAltHpelIf, int reduceTap)
+{
+    if (frac == 0) {
+        if (!vertical) { isFirst = 1; }
+        orc_if_copy(isFirst, isLast, bitDepth, src, srcStride, dst, dstStride, width, height, 0);   /* :559-565, :619-622 */
+        return;
+    }
+    int16_t c[8];
+    const int set = if_luma_set(frac, width, height, useAltHpelIf, reduceTap, vertical);
+    const int N = orc_if_coeff(set, set == 2 ? frac << 1 : frac, c);
+    orc_if_filter(N, vertical, vertical ? isFirst : 1, isLast, bitDepth, src, srcStride, dst, dstStride, width, height, c);
+}
+
+/* Motion-compensated luma prediction block at a 1/16-sample vector: the dispatch of InterPredInterpolation::xPredInterBlk
+ * (InterPrediction.cpp:832-865) without BDOF/DMVR; rndRes = !bi.  The fused 2-D entries (filter4x4/8xH/16xH, :682-761) compute the
+ * same two passes with int intermediates (:826-935). */
+void orc_if_pred_luma(const int16_t *ref, int refStride, int16_t *dst, int dstStride, int width, int height, int xFrac, int yFrac,
+                      int rndRes, int bitDepth, int useAltHpelIf)
+{
+    if (yFrac == 0) { orc_if_luma_1d(0, ref, refStride, dst, dstStride, width, height, xFrac, 1, rndRes, bitDepth, useAltHpelIf, 0); return; }
+    if (xFrac == 0) { orc_if_luma_1d(1, ref, refStride, dst, dstStride, width, height, yFrac, 1, rndRes, bitDepth, useAltHpelIf, 0); return; }
+    static _Thread_local int16_t tmp[(128 + 8) * 128];
+    int16_t ch[8], cv[8];
+    int sh, sv;
+    if (width == 4 && height == 4) sh = sv = useAltHpelIf ? 3 : 1;      /* filter4x4 :688-693: the alternative row replaces BOTH directions */
+    else { sh = (useAltHpelIf && xFrac == 8) ? 3 : 0; sv = (useAltHpelIf && yFrac == 8) ? 3 : 0; }   /* filter8xH/16xH :719-720,:747-748; generic :860-864 */
+    /* the fused entries run 8 taps over the full 8-entry rows; rows of the 6-tap sets start and end with 0, so 6 taps from entry 1 are the same sums */
+    const int Nh = orc_if_coeff(sh, xFrac, ch), Nv = orc_if_coeff(sv, yFrac, cv);
+    orc_if_filter(Nh, 0, 1, 0, bitDepth, ref - 3 * refStride, refStride, tmp, width, width, height + 7, ch);
+    orc_if_filter(Nv, 1, 0, rndRes, bitDepth, tmp + 3 * width, width, dst, dstStride, width, height, cv);
+}

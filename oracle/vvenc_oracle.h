@@ -62,6 +62,13 @@ void   orc_mctf_subsample(const int16_t *src, int srcStride, int w, int h, int16
 int    orc_mctf_me(const int16_t *orgLuma, const int16_t *refLuma, int width, int height, int bitDepth, int unitSize,
                    int mctfSpeed, int addLevel, orc_mv_t **levelOut, int *levelDims);
 
+/* sub-pel interpolation (InterpolationFilter.cpp) */
+int  orc_if_coeff(int set, int phase, int16_t coeff[8]);
+void orc_if_filter(int N, int isVertical, int isFirst, int isLast, int bitDepth, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width, int height, const int16_t *coeff);
+void orc_if_copy(int isFirst, int isLast, int bitDepth, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width, int height, int biMCForDMVR);
+void orc_if_luma_1d(int vertical, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width, int height, int frac, int isFirst, int isLast, int bitDepth, int useAltHpelIf, int reduceTap);
+void orc_if_pred_luma(const int16_t *ref, int refStride, int16_t *dst, int dstStride, int width, int height, int xFrac, int yFrac, int rndRes, int bitDepth, int useAltHpelIf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,3 +154,47 @@ def check_mctf_me(be, which=None):
                 assert np.array_equal(lv[k][f], exp[f]), (i, k, f, np.argwhere(lv[k][f] != exp[f])[:4])
             if k == 4:
                 assert np.array_equal(lv[k]["rmsme"], exp["rmsme"]) and np.array_equal(lv[k]["overlap"], exp["overlap"])
+
+
+def check_interp(be, slots=True):
+    """SURVEY 8f rank 1: interpolation filter fixtures (reference outputs).  `be` needs if_filter/if_copy (slots) and if_pred_luma;
+    the two-pass sub-pel form is checked through if_pred_luma_me when the backend has it, else through if_pred_luma(mode=reduce_tap)."""
+    g = load("interp")
+    plane, inter = g["plane"], g["inter"]
+    if slots:
+        off = 0
+        for (n, set_, p, w, h, vertical, first, last) in g["slot_cases"]:
+            _, c = _coeff(be, int(set_), int(p))
+            exp = g["slot_out"][off:off + w * h].reshape(h, w); off += w * h
+            got = be.if_filter(int(n), int(vertical), int(first), int(last), 10, (plane if first else inter, 24, 32), int(w), int(h), c)
+            assert np.array_equal(got, exp), ("slot", n, set_, p, w, h, vertical, first, last)
+        off = 0
+        for (w, h, first, last, bi) in g["copy_cases"]:
+            exp = g["copy_out"][off:off + w * h].reshape(h, w); off += w * h
+            got = be.if_copy(int(first), int(last), 10, (plane if first else inter, 24, 32), int(w), int(h), bool(bi))
+            assert np.array_equal(got, exp), ("copy", w, h, first, last, bi)
+    off = 0
+    for (bd, w, h, xf, yf, alt, rnd) in g["pred_cases"]:
+        exp = g["pred_out"][off:off + w * h].reshape(h, w); off += w * h
+        got = be.if_pred_luma((g["plane%d" % bd], 24, 20), int(w), int(h), int(xf), int(yf), bool(rnd), int(bd), bool(alt))
+        assert np.array_equal(got, exp), ("pred", bd, w, h, xf, yf, alt, rnd)
+    off = 0
+    for (w, h, xf, yf, alt, rt) in g["me_cases"]:
+        exp = g["me_out"][off:off + w * h].reshape(h, w); off += w * h
+        if hasattr(be, "if_pred_luma_me"):
+            got = be.if_pred_luma_me((plane, 24, 20), int(w), int(h), int(xf), int(yf), 10, bool(alt), int(rt))
+        else:
+            got = be.if_pred_luma((plane, 24, 20), int(w), int(h), int(xf), int(yf), True, 10, bool(alt), int(rt))
+        assert np.array_equal(got, exp), ("me", w, h, xf, yf, alt, rt)
+
+
+_COEFF_CACHE = {}
+
+
+def _coeff(be, set_, p):
+    if hasattr(be, "if_coeff"):
+        return be.if_coeff(set_, p)
+    if not _COEFF_CACHE:
+        from oracle.oracle import Oracle
+        _COEFF_CACHE["o"] = Oracle()
+    return _COEFF_CACHE["o"].if_coeff(set_, p)

@@ -73,6 +73,33 @@ class HipBackend:
         out = self.hp.fix_weighted_sse_batch(po, pc, d_it, d_w, 1, w, h)
         return int(out.cpu().numpy().view(np.uint64)[0])
 
+    # ---- interpolation ----
+    def _if_planes(self, src, w, h):
+        import torch
+        arr, y0, x0 = src
+        p = self._plane(arr)
+        d_dst = torch.full(((h + 2) * (w + 32),), -99, dtype=torch.int16, device=self.hp.device)
+        return p, y0 * p.stride + x0, d_dst
+
+    def if_filter(self, n, vertical, first, last, bd, src, w, h, coeff):
+        p, off, d = self._if_planes(src, w, h)
+        self.hp.if_filter(n, vertical, first, last, bd, p.storage, p.origin + off, p.stride, d, 0, w + 32, w, h, coeff)
+        return d.cpu().numpy().reshape(h + 2, w + 32)[:h, :w].copy()
+
+    def if_copy(self, first, last, bd, src, w, h, bi_mc=False):
+        p, off, d = self._if_planes(src, w, h)
+        self.hp.if_copy(first, last, bd, p.storage, p.origin + off, p.stride, d, 0, w + 32, w, h, bi_mc)
+        return d.cpu().numpy().reshape(h + 2, w + 32)[:h, :w].copy()
+
+    def if_pred_luma(self, ref, w, h, xfrac, yfrac, rnd=True, bd=10, alt=False, mode=0):
+        from vvenc_amd.hotpath import SUBPEL_DTYPE
+        arr, y0, x0 = ref
+        p = self._plane(arr)
+        it = np.zeros(1, SUBPEL_DTYPE)
+        it["ref_off"], it["frac_x"], it["frac_y"] = y0 * p.stride + x0, xfrac, yfrac
+        out = self.hp.interp_luma_batch(p, self.hp.to_device(it), 1, w, h, bd, rnd, mode, alt)
+        return out.cpu().numpy().reshape(h, w)
+
     # ---- transforms ----
     def tr_matrix(self, tr_type, log2n):
         n = 1 << log2n

@@ -29,6 +29,10 @@ def test_golden_distortion_ext(hip):
     G.check_distortion_ext(hip)
 
 
+def test_golden_interp(hip):
+    G.check_interp(hip)
+
+
 def test_golden_transform(hip):
     G.check_transform_matrices(hip)
     G.check_scan(hip)
@@ -422,3 +426,41 @@ def test_tu_rdo_multi_equals_batches(hip):
         assert np.array_equal(lv.cpu().numpy(), a), ("level", w, h, th, tv)
         assert np.array_equal(rc.cpu().numpy(), b), ("rec", w, h, th, tv)
         assert np.array_equal(st.cpu().numpy(), c), ("stats", w, h, th, tv)
+
+
+def test_subpel_candidates_vs_oracle(hip, oracle):
+    """batched sub-pel prediction blocks and their distortion (what xPatternRefinement scores), every tap mode"""
+    from vvenc_amd.hotpath import SUBPEL_DTYPE
+    hp = hip.hp
+    rng = np.random.default_rng(301)
+    yy, xx = np.mgrid[0:160, 0:256]
+    ref = np.clip(512 + 200 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + rng.normal(0, 25, (160, 256)), 0, 1023).astype(np.int16)
+    org = np.clip(np.roll(ref, (1, 2), (0, 1)).astype(np.int32) + rng.integers(-6, 7, (160, 256)), 0, 1023).astype(np.int16)
+    po, pr = hp.plane(org, 0), hp.plane(ref, 0)
+    for (w, h) in ((8, 8), (16, 16), (32, 16), (64, 64), (4, 4), (8, 4), (128, 32)):
+        n = 23
+        it = np.zeros(n, SUBPEL_DTYPE)
+        pos = [(int(rng.integers(8, 256 - w - 8)), int(rng.integers(8, 160 - h - 8)), int(rng.integers(8, 256 - w - 8)), int(rng.integers(8, 160 - h - 8)),
+                int(rng.integers(0, 16)), int(rng.integers(0, 16))) for _ in range(n)]
+        for mode, alt, funcs in ((0, False, ("SAD", "HAD", "HAD_fast", "SSE")), (0, True, ("HAD",)), (1, False, ("HAD_fast",)), (2, True, ("SAD",))):
+            q = 8 if alt else 1
+            for k, (ox, oy, rx, ry, fx, fy) in enumerate(pos):
+                it[k] = (oy * po.stride + ox, ry * pr.stride + rx, fx // q * q % 16, fy // q * q % 16)
+            d_it = hp.to_device(it)
+            pred = hp.interp_luma_batch(pr, d_it, n, w, h, 10, True, mode, alt).cpu().numpy().reshape(n, h, w)
+            exp_pred = []
+            for k, (ox, oy, rx, ry, _, _) in enumerate(pos):
+                fx, fy = int(it[k]["frac_x"]), int(it[k]["frac_y"])
+                e = oracle.if_pred_luma((ref, ry, rx), w, h, fx, fy, True, 10, alt) if mode == 0 else oracle.if_pred_luma_me((ref, ry, rx), w, h, fx, fy, 10, alt, mode)
+                assert np.array_equal(pred[k], e), ("pred", w, h, mode, alt, fx, fy)
+                exp_pred.append(np.ascontiguousarray(e))
+            for func in funcs:
+                got = hp.subpel_dist_batch(func, po, pr, d_it, n, w, h, 10, mode, alt).cpu().numpy().view(np.uint64)
+                for k, (ox, oy, _, _, _, _) in enumerate(pos):
+                    exp = oracle.dist(func, (org, oy, ox), exp_pred[k], w, h, 10, 0)
+                    assert int(got[k]) == exp, ("dist", func, w, h, mode, alt, k, int(got[k]), exp)
+        # the 14-bit intermediate a bi-prediction average consumes
+        pred = hp.interp_luma_batch(pr, d_it, n, w, h, 10, False, 0, False).cpu().numpy().reshape(n, h, w)
+        for k, (_, _, rx, ry, _, _) in enumerate(pos):
+            fx, fy = int(it[k]["frac_x"]), int(it[k]["frac_y"])
+            assert np.array_equal(pred[k], oracle.if_pred_luma((ref, ry, rx), w, h, fx, fy, False, 10, False)), ("bi", w, h, fx, fy)

@@ -37,3 +37,7 @@ def test_mctf_kernels(oracle):
 
 def test_mctf_me(oracle):
     G.check_mctf_me(oracle)
+
+
+def test_interp(oracle):
+    G.check_interp(oracle)

@@ -307,3 +307,80 @@ def test_mctf_me(oracle, reflib, cfg):
             assert np.array_equal(a[k][f], b[k][f]), (k, f, np.argwhere(a[k][f] != b[k][f])[:5])
     assert np.array_equal(a[4]["rmsme"], b[4]["rmsme"])
     assert np.array_equal(a[4]["overlap"], b[4]["overlap"])
+
+
+# ---------------------------------------------------------------- interpolation filter ----
+def test_if_tables(oracle, reflib):
+    for set_, phases in ((0, range(17)), (1, range(17)), (2, range(33)), (3, (0,)), (4, range(16))):
+        for p in phases:
+            na, a = oracle.if_coeff(set_, p)
+            nb, b = reflib.if_coeff(set_, p)
+            assert na == nb and np.array_equal(a, b), (set_, p, a, b)
+
+
+def test_if_table_slots(oracle, reflib):
+    """m_filterHor / m_filterVer [taps][isFirst][isLast] and m_filterCopy [isFirst][isLast] (InterpolationFilter.h:113-115)"""
+    rng = np.random.default_rng(81)
+    for bd in (8, 10):
+        plane = rng.integers(0, 1 << bd, size=(96, 112)).astype(np.int16)
+        inter = (rng.integers(0, 1 << 14, size=(96, 112)) - 8192).astype(np.int16)        # 14-bit intermediates of a first pass
+        inter[::7, ::5] -= 300                                                              # ... with the under/overshoot real filters produce
+        inter[3::11, 2::3] += 300
+        for n, set_, phases in ((8, 0, (1, 5, 8, 13)), (6, 1, (2, 8, 15)), (6, 3, (0,)), (4, 2, (3, 16, 29)), (2, 4, (5, 9))):
+            for p in phases:
+                _, c = oracle.if_coeff(set_, p)
+                for (w, h) in ((4, 4), (8, 8), (16, 4), (32, 16), (64, 24), (12, 8), (1, 16)):
+                    if reflib.simd and w == 1 and n != 2:
+                        pass
+                    for vertical in (0, 1):
+                        for first in (0, 1):
+                            for last in (0, 1):
+                                if n == 2 and not (first and not last):
+                                    continue      # bilinear taps: DMVR's first pass only (the SIMD row keeps 16-bit sums, valid for sample input)
+                                src = (plane if first else inter, 20, 24)
+                                a = oracle.if_filter(n, vertical, first, last, bd, src, w, h, c)
+                                b = reflib.if_filter(n, vertical, first, last, bd, src, w, h, c)
+                                assert np.array_equal(a, b), ("filter", bd, n, p, w, h, vertical, first, last)
+        for (w, h) in ((4, 4), (8, 16), (64, 8), (12, 4)):
+            for first in (0, 1):
+                for last in (0, 1):
+                    src = (plane if first or last == first else inter, 10, 12)
+                    a = oracle.if_copy(first, last, bd, src, w, h)
+                    b = reflib.if_copy(first, last, bd, src, w, h)
+                    assert np.array_equal(a, b), ("copy", bd, w, h, first, last)
+            a = oracle.if_copy(1, 0, bd, (plane, 10, 12), w, h, True)
+            b = reflib.if_copy(1, 0, bd, (plane, 10, 12), w, h, True)
+            assert np.array_equal(a, b), ("copy DMVR", bd, w, h)
+
+
+def test_if_luma_dispatch_and_prediction(oracle, reflib):
+    """filterHor/filterVer luma dispatch (tap reduction, alternative half-pel filter, 4x4 rule) and the xPredInterBlk call pattern"""
+    rng = np.random.default_rng(82)
+    plane = rng.integers(0, 1024, size=(120, 160)).astype(np.int16)
+    inter = (rng.integers(0, 1 << 14, size=(120, 160)) - 8192).astype(np.int16)
+    for (w, h) in ((4, 4), (4, 11), (8, 8), (16, 16), (32, 8), (64, 64), (4, 8), (12, 16)):
+        for frac in (0, 1, 4, 8, 12, 15):
+            for alt in (False, True):
+                for rt in (0, 1, 2):
+                    for last in (0, 1):
+                        a = oracle.if_luma_1d(0, (plane, 20, 24), w, h, frac, 1, last, 10, alt, rt)
+                        b = reflib.if_luma_1d(0, (plane, 20, 24), w, h, frac, 1, last, 10, alt, rt)
+                        assert np.array_equal(a, b), ("hor", w, h, frac, alt, rt, last)
+                        for first in (0, 1):
+                            if frac == 0 and not first and not last:
+                                continue      # a middle pass that copies does not occur (x86 row has no such entry: it clips)
+                            src = (plane if first else inter, 20, 24)
+                            a = oracle.if_luma_1d(1, src, w, h, frac, first, last, 10, alt, rt)
+                            b = reflib.if_luma_1d(1, src, w, h, frac, first, last, 10, alt, rt)
+                            assert np.array_equal(a, b), ("ver", w, h, frac, alt, rt, first, last)
+    for bd in (8, 10):
+        pl = (plane >> (10 - bd)).astype(np.int16)
+        for (w, h) in ((4, 4), (8, 4), (8, 8), (16, 8), (16, 16), (32, 32), (64, 16), (128, 64), (4, 8), (24, 8)):
+            for (xf, yf) in ((0, 0), (8, 0), (0, 8), (8, 8), (3, 0), (0, 13), (5, 11), (15, 1), (4, 12)):
+                for alt in (False, True):
+                    if alt and (xf % 8 or yf % 8):
+                        continue        # IMV_HPEL vectors are multiples of half a sample
+                    for rnd in (True, False):
+                        a = oracle.if_pred_luma((pl, 20, 16), w, h, xf, yf, rnd, bd, alt)
+                        b = reflib.if_pred_luma((pl, 20, 16), w, h, xf, yf, rnd, bd, alt)
+                        assert np.array_equal(a, b), ("pred", bd, w, h, xf, yf, alt, rnd)

@@ -63,12 +63,66 @@ def gen_distortion_ext(R, R0):
                         wsse_cases=np.array(wcases, np.int64), wsse_out=np.array(wout, np.uint64))
 
 
+def gen_interp(R, R0):
+    """interpolation filter slots, luma dispatch, prediction blocks -> interp.npz"""
+    rng = np.random.default_rng(20260925)
+    plane = rng.integers(0, 1024, size=(112, 176)).astype(np.int16)
+    plane[30:90, 40:140] = np.clip(512 + 200 * np.sin(np.mgrid[0:60, 0:100][1] / 6.0) + rng.normal(0, 20, (60, 100)), 0, 1023).astype(np.int16)
+    inter = (rng.integers(0, 1 << 14, size=(112, 176)) - 8192).astype(np.int16)
+    d = dict(plane=plane, inter=inter)
+    slot_cases, slot_out = [], []
+    for n, set_, phases in ((8, 0, (1, 8, 13)), (6, 1, (2, 8)), (6, 3, (0,)), (4, 2, (3, 16, 29))):
+        for p in phases:
+            _, c = R.if_coeff(set_, p)
+            for (w, h) in ((4, 4), (8, 8), (16, 4), (32, 16), (64, 24)):
+                for vertical in (0, 1):
+                    for first in (0, 1):
+                        for last in (0, 1):
+                            src = (plane if first else inter, 24, 32)
+                            o = R.if_filter(n, vertical, first, last, 10, src, w, h, c)
+                            assert np.array_equal(o, R0.if_filter(n, vertical, first, last, 10, src, w, h, c))
+                            slot_cases.append((n, set_, p, w, h, vertical, first, last))
+                            slot_out.append(o.ravel())
+    copy_cases, copy_out = [], []
+    for (w, h) in ((4, 4), (8, 16), (64, 8)):
+        for first, last, bi in ((1, 1, 0), (1, 0, 0), (0, 1, 0), (1, 0, 1)):
+            src = (plane if first else inter, 24, 32)
+            o = R.if_copy(first, last, 10, src, w, h, bool(bi))
+            assert np.array_equal(o, R0.if_copy(first, last, 10, src, w, h, bool(bi)))
+            copy_cases.append((w, h, first, last, bi)); copy_out.append(o.ravel())
+    pred_cases, pred_out = [], []
+    for bd in (8, 10):
+        pl = (plane >> (10 - bd)).astype(np.int16)
+        d["plane%d" % bd] = pl
+        for (w, h) in ((4, 4), (8, 4), (8, 8), (16, 8), (16, 16), (32, 32), (64, 16), (128, 64), (4, 8), (24, 8)):
+            for (xf, yf) in ((0, 0), (8, 0), (0, 8), (8, 8), (3, 0), (0, 13), (5, 11), (15, 1), (4, 12)):
+                for alt in (0, 1):
+                    if alt and (xf % 8 or yf % 8):
+                        continue
+                    for rnd in (1, 0):
+                        o = R.if_pred_luma((pl, 24, 20), w, h, xf, yf, bool(rnd), bd, bool(alt))
+                        assert np.array_equal(o, R0.if_pred_luma((pl, 24, 20), w, h, xf, yf, bool(rnd), bd, bool(alt)))
+                        pred_cases.append((bd, w, h, xf, yf, alt, rnd)); pred_out.append(o.ravel())
+    me_cases, me_out = [], []
+    for (w, h) in ((8, 8), (16, 16), (32, 16), (64, 64)):
+        for (xf, yf) in ((8, 0), (0, 8), (8, 8), (4, 0), (12, 4), (4, 12), (0, 4), (8, 12)):
+            for alt in (0, 1):
+                for rt in (0, 1, 2):
+                    o = R.if_pred_luma_me((plane, 24, 20), w, h, xf, yf, 10, bool(alt), rt)
+                    assert np.array_equal(o, R0.if_pred_luma_me((plane, 24, 20), w, h, xf, yf, 10, bool(alt), rt))
+                    me_cases.append((w, h, xf, yf, alt, rt)); me_out.append(o.ravel())
+    d.update(slot_cases=np.array(slot_cases, np.int32), slot_out=np.concatenate(slot_out), copy_cases=np.array(copy_cases, np.int32), copy_out=np.concatenate(copy_out),
+             pred_cases=np.array(pred_cases, np.int32), pred_out=np.concatenate(pred_out), me_cases=np.array(me_cases, np.int32), me_out=np.concatenate(me_out))
+    np.savez_compressed(os.path.join(OUT, "interp.npz"), **d)
+
+
 def main():
     build_ref()
     R = RefLib(1)
     R0 = RefLib(0)
     os.makedirs(OUT, exist_ok=True)
     gen_distortion_ext(R, R0)
+    gen_interp(R, R0)
     if "--ext-only" in sys.argv:
         return
     rng = np.random.default_rng(20260923)

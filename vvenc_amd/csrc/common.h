@@ -19,6 +19,9 @@ struct vvhip_ctx
   // scratch for vvhip_mctf_motion_estimation (grown on demand)
   void*        d_scratch  = nullptr;
   size_t       scratchBytes = 0;
+  // scratch of vvhip_subpel_dist_batch: predicted blocks + distortion items (grown on demand)
+  void*        d_subpel   = nullptr;
+  size_t       subpelBytes = 0;
 };
 
 int vvhip_fail( vvhip_ctx* ctx, int code, const char* fmt, ... );

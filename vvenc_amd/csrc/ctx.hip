@@ -165,6 +165,7 @@ void vvhip_destroy( vvhip_ctx* ctx )
   if( ctx->d_trMat ) ( void ) hipFree( ctx->d_trMat );
   if( ctx->d_scan ) ( void ) hipFree( ctx->d_scan );
   if( ctx->d_scratch ) ( void ) hipFree( ctx->d_scratch );
+  if( ctx->d_subpel ) ( void ) hipFree( ctx->d_subpel );
   if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );
   delete ctx;
 }

@@ -1,0 +1,286 @@
+// interp.hip — SURVEY §8f rank 1: sub-pel interpolation for fractional motion estimation / motion compensation.
+//
+// Reference behaviour (all integer, bit-exact):
+//   InterpolationFilter::filter<N,isVertical,isFirst,isLast>      CommonLib/InterpolationFilter.cpp:356-441
+//   InterpolationFilter::filterCopy<isFirst,isLast>               :255-333
+//   InterpolationFilter::filterHor / filterVer (luma dispatch)    :557-661
+//   InterPredInterpolation::xPredInterBlk (which passes run)      CommonLib/InterPrediction.cpp:832-865
+//   InterSearch::xPatternRefinement (sub-pel candidates + cost)   EncoderLib/InterSearch.cpp:760-880
+// One pass: val = ( sum_k c[k] * src[(k - (N/2-1)) * step] + offset ) >> shift, truncated to Pel, clipped to [0, 2^bd-1] when it is the
+// last pass.  A first-and-not-last pass keeps 14-bit precision minus IF_INTERNAL_OFFS; the second pass undoes both.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+// VVC tap sets, phases 0..P/2; row P-p is row p reversed (InterpolationFilter.cpp:64-142)
+__constant__ int8_t cLuma8[9][8] = {
+  { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 63, 4, -2, 1, 0 }, { -1, 2, -5, 62, 8, -3, 1, 0 }, { -1, 3, -8, 60, 13, -4, 1, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+  { -1, 4, -11, 52, 26, -8, 3, -1 }, { -1, 3, -9, 47, 31, -10, 4, -1 }, { -1, 4, -11, 45, 34, -10, 4, -1 }, { -1, 4, -11, 40, 40, -11, 4, -1 } };
+__constant__ int8_t cLuma6[9][8] = {
+  { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 63, 4, -2, 1, 0 }, { 0, 1, -5, 62, 8, -3, 1, 0 }, { 0, 2, -8, 60, 13, -4, 1, 0 }, { 0, 3, -10, 58, 17, -5, 1, 0 },
+  { 0, 3, -11, 52, 26, -8, 2, 0 }, { 0, 2, -9, 47, 31, -10, 3, 0 }, { 0, 3, -11, 45, 34, -10, 3, 0 }, { 0, 3, -11, 40, 40, -11, 3, 0 } };
+__constant__ int8_t cAltHpel[8] = { 0, 3, 9, 20, 20, 9, 3, 0 };
+__constant__ int8_t cChroma4[17][4] = {
+  { 0, 64, 0, 0 }, { -1, 63, 2, 0 }, { -2, 62, 4, 0 }, { -2, 60, 7, -1 }, { -2, 58, 10, -2 }, { -3, 57, 12, -2 }, { -4, 56, 14, -2 }, { -4, 55, 15, -2 }, { -4, 54, 16, -2 },
+  { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 }, { -6, 46, 28, -4 }, { -5, 44, 29, -4 }, { -4, 42, 30, -4 }, { -4, 39, 33, -4 }, { -4, 36, 36, -4 } };
+
+enum { SET_LUMA8 = 0, SET_LUMA6 = 1, SET_CHROMA4 = 2, SET_ALT = 3 };
+
+// taps as an 8-entry window around the sample (window entry j multiplies src[(j - 3) * step]); k0/k1 = first / last entry that is read
+struct Taps { int c[8]; int k0, k1; };
+
+__device__ __forceinline__ Taps loadTaps( int set, int phase )
+{
+  Taps t;
+#pragma unroll
+  for( int j = 0; j < 8; j++ ) t.c[j] = 0;
+  if( set == SET_LUMA8 || set == SET_LUMA6 )
+  {
+#pragma unroll
+    for( int j = 0; j < 8; j++ )
+    {
+      const int p = phase <= 8 ? phase : 16 - phase, jj = phase <= 8 ? j : 7 - j;
+      t.c[j] = set == SET_LUMA8 ? cLuma8[p][jj] : cLuma6[p][jj];
+    }
+    t.k0 = set == SET_LUMA8 ? 0 : 1; t.k1 = set == SET_LUMA8 ? 7 : 6;
+  }
+  else if( set == SET_ALT )
+  {
+#pragma unroll
+    for( int j = 0; j < 8; j++ ) t.c[j] = cAltHpel[j];
+    t.k0 = 1; t.k1 = 6;
+  }
+  else      // 4 chroma taps sit on window entries 2..5; phase is in 1/32
+  {
+#pragma unroll
+    for( int j = 0; j < 4; j++ ) t.c[2 + j] = phase <= 16 ? cChroma4[phase][j] : cChroma4[32 - phase][3 - j];
+    t.k0 = 2; t.k1 = 5;
+  }
+  return t;
+}
+
+struct PassGeom { int shift, offset, clipMax; };     // clipMax < 0: no clip
+
+__host__ __device__ inline PassGeom passGeom( int isFirst, int isLast, int bitDepth )    // InterpolationFilter.cpp:388-408 (N != 2)
+{
+  const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2;
+  PassGeom g; g.shift = 6; g.clipMax = isLast ? ( 1 << bitDepth ) - 1 : -1;
+  if( isLast ) { g.shift += isFirst ? 0 : headRoom; g.offset = ( 1 << ( g.shift - 1 ) ) + ( isFirst ? 0 : ( 8192 << 6 ) ); }
+  else         { g.shift -= isFirst ? headRoom : 0; g.offset = isFirst ? -( 8192 << g.shift ) : 0; }
+  return g;
+}
+
+__device__ __forceinline__ int16_t finish( int sum, const PassGeom& g )
+{
+  int16_t v = ( int16_t ) ( ( sum + g.offset ) >> g.shift );          // Pel val (:433)
+  if( g.clipMax >= 0 ) v = v < 0 ? ( int16_t ) 0 : ( v > g.clipMax ? ( int16_t ) g.clipMax : v );
+  return v;
+}
+
+// -------- table-slot form: one block, one pass, caller's coefficients (m_filterHor / m_filterVer [taps][isFirst][isLast]) --------
+struct SlotCoeff { int16_t c[8]; };
+
+__global__ void __launch_bounds__( 256 )
+ifSlotKernel( const int16_t* __restrict__ src, int srcStride, int16_t* __restrict__ dst, int dstStride, int width, int height, int N, int step, SlotCoeff co, PassGeom g )
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if( idx >= width * height ) return;
+  const int y = idx / width, x = idx - y * width;
+  const int16_t* p = src + ( ptrdiff_t ) y * srcStride + x - ( N / 2 - 1 ) * step;
+  int sum = 0;
+  for( int k = 0; k < N; k++ ) sum += ( int ) p[( ptrdiff_t ) k * step] * co.c[k];
+  dst[( ptrdiff_t ) y * dstStride + x] = finish( sum, g );
+}
+
+// m_filterCopy[isFirst][isLast] (:255-333); mode 0 copy, 1 first-not-last, 2 last-not-first, 3 first pass of DMVR's bilinear MC
+__global__ void __launch_bounds__( 256 )
+ifCopyKernel( const int16_t* __restrict__ src, int srcStride, int16_t* __restrict__ dst, int dstStride, int width, int height, int mode, int bitDepth )
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if( idx >= width * height ) return;
+  const int y = idx / width, x = idx - y * width;
+  const int16_t s = src[( ptrdiff_t ) y * srcStride + x];
+  const int shift = 14 - bitDepth > 2 ? 14 - bitDepth : 2, maxv = ( 1 << bitDepth ) - 1;
+  int16_t v;
+  if( mode == 0 ) v = s;
+  else if( mode == 1 ) v = ( int16_t ) ( ( int16_t ) ( ( uint16_t ) s << shift ) - 8192 );
+  else if( mode == 3 ) v = ( int16_t ) ( s << ( 10 - bitDepth ) );
+  else
+  {
+    const int16_t t = ( int16_t ) ( ( ( int ) s + ( int ) ( int16_t ) ( ( 1 << ( shift - 1 ) ) + 8192 ) ) >> shift );    // rightShiftU on the int promotion (:319-322)
+    v = t < 0 ? ( int16_t ) 0 : ( t > maxv ? ( int16_t ) maxv : t );
+  }
+  dst[( ptrdiff_t ) y * dstStride + x] = v;
+}
+
+// -------- batched prediction blocks: n blocks of w x h at 1/16-sample vectors, compact output --------
+// filterMode 0: the tap sets xPredInterBlk uses (8 taps; 6-tap set for 4x4 blocks); 1 / 2: the reduced sets of the fast sub-pel search
+// (m_meReduceTap: 6-tap set / 4-tap chroma set); the alternative half-pel filter replaces phase 8 when useAlt (for 4x4 in mode 0: always).
+__device__ __forceinline__ int tapSet( int frac, int w, int h, int filterMode, int useAlt, bool both )
+{
+  // 4x4 blocks: filter4x4 swaps in the alternative row for BOTH directions whatever the phase (:692-693); the 1-D dispatch only at phase 8 (:570-580)
+  if( filterMode == 0 ) return ( w == 4 && h == 4 ) ? ( ( useAlt && ( both || frac == 8 ) ) ? SET_ALT : SET_LUMA6 ) : ( ( useAlt && frac == 8 ) ? SET_ALT : SET_LUMA8 );
+  if( useAlt && frac == 8 ) return SET_ALT;
+  return filterMode == 1 ? SET_LUMA6 : SET_CHROMA4;
+}
+
+__global__ void __launch_bounds__( 256 )
+ifPredBatchKernel( const int16_t* __restrict__ ref, int refStride, const vvhip_subpel_item* __restrict__ items, int n, int w, int h, int bitDepth,
+                   int rndRes, int filterMode, int useAlt, int blocksPerWg, int16_t* __restrict__ out, vvhip_dist_item* __restrict__ distItems )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[];       // blocksPerWg x (h + 7) x w first-pass samples
+  const int tpb = 256 / blocksPerWg, sub = threadIdx.x / tpb, t = threadIdx.x - sub * tpb;
+  const int blk = blockIdx.x * blocksPerWg + sub;
+  const bool valid = blk < n;
+  vvhip_subpel_item it = { 0, 0, 0, 0 };
+  if( valid ) it = items[blk];
+  const int xf = it.frac_x & 15, yf = it.frac_y & 15;
+  const int16_t* src = ref + it.ref_off;
+  int16_t* dst = out + ( size_t ) blk * w * h;
+  int16_t* tmp = sTmp + ( size_t ) sub * ( h + 7 ) * w;
+  if( valid && t == 0 && distItems ) { vvhip_dist_item d; d.org_off = it.org_off; d.cur_off = blk * w * h; distItems[blk] = d; }
+
+  const bool both = xf != 0 && yf != 0;          // uniform per sub-block; barriers below are reached by every thread
+  if( valid && both )
+  {
+    const Taps th = loadTaps( tapSet( xf, w, h, filterMode, useAlt, true ), filterMode == 2 && !( useAlt && xf == 8 ) ? xf << 1 : xf );
+    const PassGeom g1 = passGeom( 1, 0, bitDepth );
+    for( int i = t; i < ( h + 7 ) * w; i += tpb )
+    {
+      const int r = i / w, x = i - r * w;
+      const int16_t* p = src + ( ptrdiff_t ) ( r - 3 ) * refStride + x - 3;
+      int sum = 0;
+#pragma unroll
+      for( int j = 0; j < 8; j++ ) if( j >= th.k0 && j <= th.k1 ) sum += ( int ) p[j] * th.c[j];
+      tmp[i] = finish( sum, g1 );
+    }
+  }
+  __syncthreads();
+  if( !valid ) return;
+  if( both )
+  {
+    const Taps tv = loadTaps( tapSet( yf, w, h, filterMode, useAlt, true ), filterMode == 2 && !( useAlt && yf == 8 ) ? yf << 1 : yf );
+    const PassGeom g2 = passGeom( 0, rndRes, bitDepth );
+    for( int i = t; i < h * w; i += tpb )
+    {
+      const int y = i / w, x = i - y * w;
+      const int16_t* p = tmp + y * w + x;             // row (y + 3) - 3 of the first-pass buffer
+      int sum = 0;
+#pragma unroll
+      for( int j = 0; j < 8; j++ ) if( j >= tv.k0 && j <= tv.k1 ) sum += ( int ) p[j * w] * tv.c[j];
+      dst[i] = finish( sum, g2 );
+    }
+  }
+  else if( xf != 0 || yf != 0 )
+  {
+    const bool ver = xf == 0;
+    const int f = ver ? yf : xf;
+    const Taps tt = loadTaps( tapSet( f, w, h, filterMode, useAlt, false ), filterMode == 2 && !( useAlt && f == 8 ) ? f << 1 : f );
+    const PassGeom g = passGeom( 1, rndRes, bitDepth );
+    const int step = ver ? refStride : 1;
+    for( int i = t; i < h * w; i += tpb )
+    {
+      const int y = i / w, x = i - y * w;
+      const int16_t* p = src + ( ptrdiff_t ) y * refStride + x - 3 * step;
+      int sum = 0;
+#pragma unroll
+      for( int j = 0; j < 8; j++ ) if( j >= tt.k0 && j <= tt.k1 ) sum += ( int ) p[( ptrdiff_t ) j * step] * tt.c[j];
+      dst[i] = finish( sum, g );
+    }
+  }
+  else
+  {
+    const int shift = 14 - bitDepth > 2 ? 14 - bitDepth : 2;
+    for( int i = t; i < h * w; i += tpb )
+    {
+      const int y = i / w, x = i - y * w;
+      const int16_t s = src[( ptrdiff_t ) y * refStride + x];
+      dst[i] = rndRes ? s : ( int16_t ) ( ( int16_t ) ( ( uint16_t ) s << shift ) - 8192 );      // copy / filterCopy<true,false> (:559-565)
+    }
+  }
+}
+
+} // namespace
+
+extern "C" {
+
+int vvhip_if_filter( vvhip_ctx* ctx, int taps, int is_vertical, int is_first, int is_last, int bit_depth,
+                     const int16_t* d_src, int src_stride, int16_t* d_dst, int dst_stride, int width, int height, const int16_t* coeff_host )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( ( taps != 8 && taps != 6 && taps != 4 ) || !d_src || !d_dst || !coeff_host || width < 1 || height < 1 || width > 4096 || height > 4096 || bit_depth < 8 || bit_depth > 12 )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_if_filter: taps %d block %dx%d bitDepth %d", taps, width, height, bit_depth );
+  SlotCoeff co;
+  for( int k = 0; k < 8; k++ ) co.c[k] = 0;
+  for( int k = 0; k < taps; k++ ) co.c[k] = coeff_host[k + ( taps == 6 ? 1 : 0 )];         // the 6-tap cores skip the row's first entry (:361-364)
+  const PassGeom g = passGeom( is_first != 0, is_last != 0, bit_depth );
+  hipLaunchKernelGGL( ifSlotKernel, dim3( ( width * height + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_src, src_stride, d_dst, dst_stride, width, height, taps,
+                      is_vertical ? src_stride : 1, co, g );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_if_copy( vvhip_ctx* ctx, int is_first, int is_last, int bit_depth, const int16_t* d_src, int src_stride, int16_t* d_dst, int dst_stride,
+                   int width, int height, int bi_mc_for_dmvr )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !d_src || !d_dst || width < 1 || height < 1 || width > 4096 || height > 4096 || bit_depth < 8 || bit_depth > 12 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_if_copy: bad arguments" );
+  const int mode = ( !is_first == !is_last ) ? 0 : is_first ? ( bi_mc_for_dmvr ? 3 : 1 ) : 2;
+  hipLaunchKernelGGL( ifCopyKernel, dim3( ( width * height + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_src, src_stride, d_dst, dst_stride, width, height, mode, bit_depth );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+static int launchPred( vvhip_ctx* ctx, const int16_t* d_ref, int ref_stride, const vvhip_subpel_item* d_items, int n, int width, int height, int bit_depth,
+                       int rnd_res, int filter_mode, int use_alt_hpel, int16_t* d_out, vvhip_dist_item* d_dist_items )
+{
+  int bpw = 256 / ( width * height ); if( bpw < 1 ) bpw = 1; if( bpw > 8 ) bpw = 8;
+  const size_t smem = ( size_t ) bpw * ( height + 7 ) * width * sizeof( int16_t );
+  hipLaunchKernelGGL( ifPredBatchKernel, dim3( ( n + bpw - 1 ) / bpw ), dim3( 256 ), smem, ctx->stream, d_ref, ref_stride, d_items, n, width, height, bit_depth,
+                      rnd_res ? 1 : 0, filter_mode, use_alt_hpel ? 1 : 0, bpw, d_out, d_dist_items );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+static bool predArgsOk( int width, int height, int bit_depth, int filter_mode, int n )
+{
+  return width >= 4 && height >= 4 && width <= 128 && height <= 128 && bit_depth >= 8 && bit_depth <= 12 && filter_mode >= 0 && filter_mode <= 2 && n >= 0;
+}
+
+int vvhip_interp_luma_batch( vvhip_ctx* ctx, const int16_t* d_ref, int ref_stride, const vvhip_subpel_item* d_items, int n,
+                             int width, int height, int bit_depth, int rnd_res, int filter_mode, int use_alt_hpel, int16_t* d_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !predArgsOk( width, height, bit_depth, filter_mode, n ) || ( n && ( !d_ref || !d_items || !d_out ) ) )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_interp_luma_batch: block %dx%d bitDepth %d mode %d", width, height, bit_depth, filter_mode );
+  if( n == 0 ) return VVHIP_OK;
+  return launchPred( ctx, d_ref, ref_stride, d_items, n, width, height, bit_depth, rnd_res, filter_mode, use_alt_hpel, d_out, nullptr );
+}
+
+int vvhip_subpel_dist_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_ref, int ref_stride,
+                             int width, int height, int bit_depth, int filter_mode, int use_alt_hpel,
+                             const vvhip_subpel_item* d_items, int n, uint64_t* d_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !predArgsOk( width, height, bit_depth, filter_mode, n ) || ( n && ( !d_org || !d_ref || !d_items || !d_out ) ) )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_subpel_dist_batch: block %dx%d bitDepth %d mode %d", width, height, bit_depth, filter_mode );
+  if( n == 0 ) return VVHIP_OK;
+  // predictions go to a grow-only scratch (compact blocks), then the ordinary distortion kernels score them against the originals
+  const size_t predBytes = ( ( size_t ) n * width * height * sizeof( int16_t ) + 255 ) & ~( size_t ) 255, need = predBytes + ( size_t ) n * sizeof( vvhip_dist_item );
+  if( need > ctx->subpelBytes )
+  {
+    VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+    if( ctx->d_subpel ) VVHIP_CHECK_HIP( ctx, hipFree( ctx->d_subpel ) );
+    ctx->d_subpel = nullptr; ctx->subpelBytes = 0;
+    VVHIP_CHECK_HIP( ctx, hipMalloc( &ctx->d_subpel, need + need / 4 ) );
+    ctx->subpelBytes = need + need / 4;
+  }
+  int16_t* pred = static_cast<int16_t*>( ctx->d_subpel );
+  vvhip_dist_item* di = reinterpret_cast<vvhip_dist_item*>( static_cast<char*>( ctx->d_subpel ) + predBytes );
+  const int rc = launchPred( ctx, d_ref, ref_stride, d_items, n, width, height, bit_depth, 1, filter_mode, use_alt_hpel, pred, di );
+  if( rc ) return rc;
+  return vvhip_dist_batch( ctx, func, d_org, org_stride, pred, width, width, height, 0, bit_depth, di, n, d_out );
+}
+
+} // extern "C"

@@ -20,6 +20,7 @@ DF = {"SSE": 0, "SAD": 1, "HAD": 2, "HAD_fast": 3, "HAD_2SAD": 4}
 DCT2, DCT8, DST7 = 0, 1, 2
 
 MV_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("error", "<i4"), ("rmsme", "<i4"), ("overlap", "<f8")])
+SUBPEL_DTYPE = np.dtype([("org_off", "<i4"), ("ref_off", "<i4"), ("frac_x", "<i2"), ("frac_y", "<i2")])
 STATS_DTYPE = np.dtype([("abs_sum", "<i4"), ("last_scan_pos", "<i4"), ("need_rdoq", "<i4"), ("pad", "<i4"), ("sse", "<u8")])
 
 
@@ -249,6 +250,33 @@ class HotPath:
         if isinstance(jobs, list):
             jobs = self.make_tu_jobs(jobs)
         self._ck(self.L.vvhip_tu_rdo_multi(self.ctx, resi.buf_ptr, resi.stride, bit_depth, jobs[0], jobs[1]))
+
+    # ---- sub-pel interpolation ----
+    def if_filter(self, taps, vertical, first, last, bit_depth, d_src, src_off, src_stride, d_dst, dst_off, dst_stride, w, h, coeff):
+        """one pass on one block with the caller's taps (InterpolationFilter::m_filterHor / m_filterVer slot)"""
+        c = np.ascontiguousarray(coeff, np.int16)
+        self._ck(self.L.vvhip_if_filter(self.ctx, taps, int(vertical), int(first), int(last), bit_depth, C.c_void_p(d_src.data_ptr() + 2 * src_off), src_stride,
+                                        C.c_void_p(d_dst.data_ptr() + 2 * dst_off), dst_stride, w, h, c.ctypes.data_as(C.c_void_p)))
+
+    def if_copy(self, first, last, bit_depth, d_src, src_off, src_stride, d_dst, dst_off, dst_stride, w, h, bi_mc=False):
+        self._ck(self.L.vvhip_if_copy(self.ctx, int(first), int(last), bit_depth, C.c_void_p(d_src.data_ptr() + 2 * src_off), src_stride,
+                                      C.c_void_p(d_dst.data_ptr() + 2 * dst_off), dst_stride, w, h, int(bi_mc)))
+
+    def interp_luma_batch(self, ref, d_items, n, w, h, bit_depth=10, rnd_res=True, filter_mode=0, use_alt_hpel=False, out=None):
+        """motion-compensated luma prediction blocks at 1/16-sample vectors (d_items: SUBPEL_DTYPE records) -> (n, h, w) int16"""
+        if out is None:
+            out = torch.empty(n * w * h, dtype=torch.int16, device=self.device)
+        self._ck(self.L.vvhip_interp_luma_batch(self.ctx, ref.buf_ptr, ref.stride, _ptr(d_items), n, w, h, bit_depth, int(rnd_res), filter_mode,
+                                                int(use_alt_hpel), _ptr(out)))
+        return out
+
+    def subpel_dist_batch(self, func, org, ref, d_items, n, w, h, bit_depth=10, filter_mode=0, use_alt_hpel=False, out=None):
+        """distortion of sub-pel candidates: interpolate at the fractional vector, score against the original block"""
+        if out is None:
+            out = torch.empty(n, dtype=torch.int64, device=self.device)
+        self._ck(self.L.vvhip_subpel_dist_batch(self.ctx, DF[func] if isinstance(func, str) else func, org.buf_ptr, org.stride, ref.buf_ptr, ref.stride,
+                                                w, h, bit_depth, filter_mode, int(use_alt_hpel), _ptr(d_items), n, _ptr(out)))
+        return out
 
     # ---- (C) MCTF ----
     def extend_border(self, plane):

@@ -47,6 +47,10 @@ PROTOTYPES = {
     "vvhip_round_clip": (i32, [vp, vp, C.c_uint, C.c_uint, C.c_uint, i32, i32, i32, i32]),
     "vvhip_cpy_resi": (i32, [vp, vp, vp, C.c_ssize_t, C.c_uint, C.c_uint]),
     "vvhip_cpy_coeff": (i32, [vp, vp, C.c_ssize_t, vp, C.c_uint, C.c_uint]),
+    "vvhip_if_filter": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "vvhip_if_copy": (i32, [vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32]),
+    "vvhip_interp_luma_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "vvhip_subpel_dist_batch": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "vvhip_get_tr_matrix_host": (i32, [i32, i32, vp]),
     "vvhip_get_scan_order_host": (i32, [i32, i32, vp]),
     "vvhip_mctf_error_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
