@@ -214,7 +214,7 @@ VVHIP_API int vvhip_cpy_coeff( vvhip_ctx* ctx, const int16_t* d_src, ptrdiff_t s
  * ====================================================================================================================== */
 /* One pass of the separable interpolation on one block with the caller's taps: the table slots
  * InterpolationFilter::m_filterHor / m_filterVer [tap index][isFirst][isLast] (CommonLib/InterpolationFilter.h:113-114),
- * scalar core filter<N,isVertical,isFirst,isLast> (InterpolationFilter.cpp:356-441).  taps = 8, 6 or 4; coeff_host is the
+ * scalar core filter<N,isVertical,isFirst,isLast> (InterpolationFilter.cpp:356-441).  taps = 8, 6, 4 or 2 (bilinear); coeff_host is the
  * table ROW as the reference passes it (8 entries for 8 and 6 taps — the 6-tap core skips the first entry —, 4 for 4 taps).  */
 VVHIP_API int vvhip_if_filter( vvhip_ctx* ctx, int taps, int is_vertical, int is_first, int is_last, int bit_depth,
                                const int16_t* d_src, int src_stride, int16_t* d_dst, int dst_stride, int width, int height,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes hook-enabled COPIES of four reference translation units into oracle/_ref/gen/src/ (build output, git-ignored).
+"""Writes hook-enabled COPIES of five reference translation units into oracle/_ref/gen/src/ (build output, git-ignored).
 Nothing of the reference is stored in the repository: the script inserts one-line calls to g_vvhipHooks (oracle/ref/hip_hooks.h)
 at anchor lines it looks up in the files where they lie under /root/reference.  This is the executable form of the binding
 shown in INTEGRATION.md §2.
@@ -50,5 +50,11 @@ patch("MCTF.cpp", [
     ("before", "    Array2D<MotionVector> mv_0(width / (m_mctfUnitSize * 8) + 1, height / (m_mctfUnitSize * 8) + 1);",
      "    if( !( g_vvhipHooks.mctfMe && g_vvhipHooks.mctfMe( this, srcPic.picBuffer, origBuf, srcPic.mvs, addLevel ) ) )\n    {\n"),
     ("after", "    motionEstimationLuma(srcPic.mvs, origBuf, srcPic.picBuffer, m_mctfUnitSize, &mv_2, 1, true);\n", "    }\n"),
+])
+patch("InterpolationFilter.cpp", [
+    ("after", '#include "InterpolationFilter.h"', INC),
+    ("before", "void InterpolationFilter::initInterpolationFilter( bool enable )\n{\n",
+     ""),   # (anchor check only: the hook goes at the end of the function body)
+    ("after", "    initInterpolationFilterARM();\n#endif\n  }\n#endif\n", "  if( enable && g_vvhipHooks.initIF ) g_vvhipHooks.initIF( this );\n"),
 ])
 print("hooked copies written to", out)

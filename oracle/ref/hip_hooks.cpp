@@ -41,6 +41,7 @@
 #include "CommonLib/Quant.h"
 #include "CommonLib/MCTF.h"
 #include "CommonLib/TrQuant_EMT.h"
+#include "CommonLib/InterpolationFilter.h"
 #include "CommonLib/Picture.h"
 #include "EncoderLib/EncCfg.h"
 #undef private
@@ -49,14 +50,14 @@
 #include "hip_hooks.h"
 #include "../../vvenc_amd/csrc/host/vvenc_hip_shim.h"
 
-VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 
 namespace {
 
 vvhip::RdCost*   g_rd = nullptr;
 vvhip::QuantOps* g_q  = nullptr;
 vvhip::MCTFOps*  g_m  = nullptr;
-std::atomic<uint64_t> g_calls[8];     // dist, x5, fwd, inv, quant, dequant, needrdoq, mctf
+std::atomic<uint64_t> g_calls[10];    // dist, x5, fwd, inv, quant, dequant, needrdoq, mctf, interpolation, (spare)
 
 vvhip::DistParam conv( const vvenc::DistParam& dp )
 {
@@ -154,6 +155,36 @@ bool inv2D( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned w, un
   return true;
 }
 
+// ---- InterpolationFilter tables: every slot of m_filterHor / m_filterVer / m_filterCopy / m_filter4x4 / m_filter8xH /
+// m_filter16xH forwards to the shim's slot of the same index (the only difference between the two signatures is the ClpRng type)
+vvhip::InterpolationFilter* g_if = nullptr;
+template<int I, int F, int L> void ifHorT( const vvenc::ClpRng& c, vvenc::Pel const* s, int ss, vvenc::Pel* d, int ds, int w, int h, vvenc::TFilterCoeff const* co )
+{ g_calls[8]++; const vvhip::ClpRng cc = { c.bd }; g_if->m_filterHor[I][F][L]( cc, s, ss, d, ds, w, h, co ); }
+template<int I, int F, int L> void ifVerT( const vvenc::ClpRng& c, vvenc::Pel const* s, int ss, vvenc::Pel* d, int ds, int w, int h, vvenc::TFilterCoeff const* co )
+{ g_calls[8]++; const vvhip::ClpRng cc = { c.bd }; g_if->m_filterVer[I][F][L]( cc, s, ss, d, ds, w, h, co ); }
+template<int F, int L> void ifCopyT( const vvenc::ClpRng& c, vvenc::Pel const* s, int ss, vvenc::Pel* d, int ds, int w, int h, bool bi )
+{ g_calls[8]++; const vvhip::ClpRng cc = { c.bd }; g_if->m_filterCopy[F][L]( cc, s, ss, d, ds, w, h, bi ); }
+template<int K, int I, int L> void ifFusedT( const vvenc::ClpRng& c, vvenc::Pel const* s, int ss, vvenc::Pel* d, int ds, int w, int h, vvenc::TFilterCoeff const* ch, vvenc::TFilterCoeff const* cv )
+{
+  g_calls[8]++;
+  const vvhip::ClpRng cc = { c.bd };
+  ( K == 0 ? g_if->m_filter4x4[I][L] : K == 1 ? g_if->m_filter8xH[I][L] : g_if->m_filter16xH[I][L] )( cc, s, ss, d, ds, w, h, ch, cv );
+}
+template<int I> void fillIf1D( vvenc::InterpolationFilter* f )
+{
+  f->m_filterHor[I][0][0] = ifHorT<I, 0, 0>; f->m_filterHor[I][0][1] = ifHorT<I, 0, 1>; f->m_filterHor[I][1][0] = ifHorT<I, 1, 0>; f->m_filterHor[I][1][1] = ifHorT<I, 1, 1>;
+  f->m_filterVer[I][0][0] = ifVerT<I, 0, 0>; f->m_filterVer[I][0][1] = ifVerT<I, 0, 1>; f->m_filterVer[I][1][0] = ifVerT<I, 1, 0>; f->m_filterVer[I][1][1] = ifVerT<I, 1, 1>;
+}
+void initIF( vvenc::InterpolationFilter* f )
+{
+  // the luma / chroma tap tables (indices 0 = 8, 1 = 4, 3 = 6 taps) and the copies; the bilinear (DMVR) entries stay on the CPU
+  fillIf1D<0>( f ); fillIf1D<1>( f ); fillIf1D<3>( f );
+  f->m_filterCopy[0][1] = ifCopyT<0, 1>; f->m_filterCopy[1][0] = ifCopyT<1, 0>; f->m_filterCopy[1][1] = ifCopyT<1, 1>; f->m_filterCopy[0][0] = ifCopyT<0, 0>;
+  f->m_filter4x4[0][0] = ifFusedT<0, 0, 0>; f->m_filter4x4[0][1] = ifFusedT<0, 0, 1>; f->m_filter4x4[1][0] = ifFusedT<0, 1, 0>; f->m_filter4x4[1][1] = ifFusedT<0, 1, 1>;
+  f->m_filter8xH[0][0] = ifFusedT<1, 0, 0>; f->m_filter8xH[0][1] = ifFusedT<1, 0, 1>; f->m_filter8xH[1][0] = ifFusedT<1, 1, 0>; f->m_filter8xH[1][1] = ifFusedT<1, 1, 1>;
+  f->m_filter16xH[0][0] = ifFusedT<2, 0, 0>; f->m_filter16xH[0][1] = ifFusedT<2, 0, 1>; f->m_filter16xH[1][0] = ifFusedT<2, 1, 0>; f->m_filter16xH[1][1] = ifFusedT<2, 1, 1>;
+}
+
 // whole hierarchical ME of MCTF::motionEstimationMCTF on the GPU; both pictures carry MCTF_PADDING extended margins (MCTF.cpp:608-612)
 bool mctfMe( vvenc::MCTF* m, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel )
 {
@@ -202,11 +233,11 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_after_simd_in
 
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
 {
-  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots
+  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables
   g_slotMask = mask;
   try
   {
-    if( mask && !g_rd ) { g_rd = new vvhip::RdCost; g_rd->create( true ); g_q = new vvhip::QuantOps; g_m = new vvhip::MCTFOps; }
+    if( mask && !g_rd ) { g_rd = new vvhip::RdCost; g_rd->create( true ); g_q = new vvhip::QuantOps; g_m = new vvhip::MCTFOps; g_if = new vvhip::InterpolationFilter; }
   }
   catch( const std::exception& e ) { fprintf( stderr, "vvref_install_hip_hooks: %s\n", e.what() ); return -1; }
   g_vvhipHooks.initRdCost = ( mask & 1 ) ? initRdCost : nullptr;
@@ -215,6 +246,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
   g_vvhipHooks.initQuant  = ( mask & 4 ) ? initQuant : nullptr;
   g_vvhipHooks.initMCTF   = ( mask & 8 ) ? initMCTF : nullptr;
   g_vvhipHooks.mctfMe     = ( mask & 16 ) ? mctfMe : nullptr;
+  g_vvhipHooks.initIF     = ( mask & 64 ) ? initIF : nullptr;
   for( auto& c : g_calls ) c = 0;
   return 0;
 }
@@ -222,4 +254,8 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
 extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_calls( uint64_t* out8 )
 {
   for( int i = 0; i < 8; i++ ) out8[i] = g_calls[i];
+}
+extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_calls_ex( uint64_t* out, int n )
+{
+  for( int i = 0; i < n && i < 10; i++ ) out[i] = g_calls[i];
 }

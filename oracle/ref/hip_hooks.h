@@ -7,7 +7,7 @@
 #include <cstdint>
 
 namespace vvenc {
-class RdCost; class Quant; class MCTF; struct MotionVector; struct PelStorage;
+class RdCost; class Quant; class MCTF; class InterpolationFilter; struct MotionVector; struct PelStorage;
 template<class T> struct Array2D;
 }
 
@@ -18,6 +18,7 @@ struct VvhipHooks
   void ( *initMCTF )( vvenc::MCTF* );
   bool ( *fwd2D )( const int16_t* resi, ptrdiff_t stride, int32_t* coef, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
   bool ( *inv2D )( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
+  void ( *initIF )( vvenc::InterpolationFilter* );
   bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel );
 };
 extern VvhipHooks g_vvhipHooks;

@@ -163,6 +163,64 @@ static void test_TCoeffOps()
   }
 }
 
+static void test_InterpolationFilter()
+{
+  // table slots, luma dispatch and the two-pass prediction, opt = shim tables, ref = oracle restatement
+  std::mt19937 rng( 99 );
+  const int S = 96, H = 80;
+  std::vector<Pel> plane( S * H ), inter( S * H );
+  for( auto& v : plane ) v = ( Pel ) ( rng() % 1024 );
+  for( auto& v : inter ) v = ( Pel ) ( ( int ) ( rng() % 16384 ) - 8192 );
+  InterpolationFilter opt;
+  const ClpRng clp = { 10 };
+  auto cmp = [&]( const std::vector<Pel>& a, const std::vector<Pel>& b, const char* what, int w, int h ) { if( a != b ) { printf( "MISMATCH %s %dx%d\n", what, w, h ); failures++; } };
+  for( int w : { 4, 8, 16, 64 } ) for( int h : { 4, 8, 32 } )
+  {
+    const Pel* src = plane.data() + 20 * S + 16; const Pel* isrc = inter.data() + 20 * S + 16;
+    std::vector<Pel> got( ( w + 3 ) * h ), exp( ( w + 3 ) * h );
+    for( int frac : { 3, 8, 13 } ) for( int first = 0; first < 2; first++ ) for( int last = 0; last < 2; last++ )
+    {
+      std::fill( got.begin(), got.end(), 7 ); std::fill( exp.begin(), exp.end(), 7 );
+      opt.m_filterHor[0][first][last]( clp, first ? src : isrc, S, got.data(), w + 3, w, h, InterpolationFilter::lumaFilter( frac ) );
+      int16_t c[8]; orc_if_coeff( 0, frac, c );
+      orc_if_filter( 8, 0, first, last, 10, first ? src : isrc, S, exp.data(), w + 3, w, h, c );
+      cmp( got, exp, "m_filterHor[0]", w, h );
+      std::fill( got.begin(), got.end(), 7 ); std::fill( exp.begin(), exp.end(), 7 );
+      opt.m_filterVer[3][first][last]( clp, first ? src : isrc, S, got.data(), w + 3, w, h, InterpolationFilter::lumaFilter4x4( frac ) );
+      orc_if_coeff( 1, frac, c );
+      orc_if_filter( 6, 1, first, last, 10, first ? src : isrc, S, exp.data(), w + 3, w, h, c );
+      cmp( got, exp, "m_filterVer[3]", w, h );
+      std::fill( got.begin(), got.end(), 7 ); std::fill( exp.begin(), exp.end(), 7 );
+      opt.m_filterHor[1][first][last]( clp, first ? src : isrc, S, got.data(), w + 3, w, h, InterpolationFilter::chromaFilter( 2 * frac + 1 ) );
+      orc_if_coeff( 2, 2 * frac + 1, c );
+      orc_if_filter( 4, 0, first, last, 10, first ? src : isrc, S, exp.data(), w + 3, w, h, c );
+      cmp( got, exp, "m_filterHor[1]", w, h );
+    }
+    for( int alt = 0; alt < 2; alt++ ) for( int rt = 0; rt < 3; rt++ ) for( int frac : { 0, 4, 8 } )
+    {
+      std::fill( got.begin(), got.end(), 7 ); std::fill( exp.begin(), exp.end(), 7 );
+      opt.filterHor( src, S, got.data(), w + 3, w, h, frac, true, clp, alt != 0, rt );
+      orc_if_luma_1d( 0, src, S, exp.data(), w + 3, w, h, frac, 1, 1, 10, alt, rt );
+      cmp( got, exp, "filterHor", w, h );
+      std::fill( got.begin(), got.end(), 7 ); std::fill( exp.begin(), exp.end(), 7 );
+      opt.filterVer( isrc, S, got.data(), w + 3, w, h, frac, false, true, clp, alt != 0, rt );
+      orc_if_luma_1d( 1, isrc, S, exp.data(), w + 3, w, h, frac, 0, 1, 10, alt, rt );
+      cmp( got, exp, "filterVer", w, h );
+    }
+    // fused two-pass slots against the prediction-block restatement (both fractions non-zero)
+    if( w == 8 || w == 16 || ( w == 4 && h == 4 ) )
+      for( int rnd = 0; rnd < 2; rnd++ )
+      {
+        std::fill( got.begin(), got.end(), 7 ); std::fill( exp.begin(), exp.end(), 7 );
+        const int xf = 5, yf = 11;
+        if( w == 4 ) opt.m_filter4x4[0][rnd]( clp, src, S, got.data(), w + 3, 4, 4, InterpolationFilter::lumaFilter4x4( xf ), InterpolationFilter::lumaFilter4x4( yf ) );
+        else         ( w == 8 ? opt.m_filter8xH[0][rnd] : opt.m_filter16xH[0][rnd] )( clp, src, S, got.data(), w + 3, w, h, InterpolationFilter::lumaFilter( xf ), InterpolationFilter::lumaFilter( yf ) );
+        orc_if_pred_luma( src, S, exp.data(), w + 3, w, h, xf, yf, rnd, 10, 0 );
+        cmp( got, exp, "fused two-pass", w, h );
+      }
+  }
+}
+
 static void test_MCTF()
 {
   MCTFOps opt;
@@ -205,7 +263,7 @@ static void test_MCTF()
 
 int main()
 {
-  try { test_RdCost(); test_TCoeffOps(); test_MCTF(); }
+  try { test_RdCost(); test_TCoeffOps(); test_InterpolationFilter(); test_MCTF(); }
   catch( const std::exception& e ) { printf( "EXCEPTION: %s\n", e.what() ); return 2; }
   printf( failures ? "FAILED: %d mismatches\n" : "shim parity OK (RdCost, TCoeffOps/Quant, MCTF)\n", failures );
   return failures ? 1 : 0;

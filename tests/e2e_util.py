@@ -36,6 +36,7 @@ def load(hip=False):
     if hip:
         L.vvref_install_hip_hooks.argtypes = [C.c_int]
         L.vvref_hip_hook_calls.argtypes = [C.c_void_p]
+        L.vvref_hip_hook_calls_ex.argtypes = [C.c_void_p, C.c_int]
     return L
 
 

@@ -28,7 +28,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(8, np.uint64); L.vvref_hip_hook_calls(c.ctypes.data); calls = [int(x) for x in c]
+    c = np.zeros(10, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 10); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -90,3 +90,17 @@ def test_hip_tcoeffops_slots_bitstream_identical():
     print("cpu", cpu, "hip", hip)
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
     assert hip["calls"][2] > 100 and hip["calls"][3] > 100, hip["calls"]
+
+
+@pytest.mark.gpu
+def test_hip_interpolation_tables_bitstream_identical():
+    """every InterpolationFilter table slot of the encoder (m_filterHor/Ver, m_filterCopy, m_filter4x4/8xH/16xH) points at
+    the device entries, so all motion compensation and sub-pel refinement planes of the encode are interpolated on the GPU (one call at a
+    time); bitstream must not change"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    cpu = run(dict(CFG1, hip=False, simd=None, mask=0))
+    hip = run(dict(CFG1, hip=True, simd=None, mask=64))
+    print("cpu", cpu, "hip", hip)
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+    assert hip["calls"][8] > 100, hip["calls"]

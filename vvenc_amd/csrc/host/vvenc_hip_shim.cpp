@@ -441,6 +441,151 @@ TCoeffOps::TCoeffOps()
 }
 TCoeffOps g_tCoeffOps;
 
+// ------------------------------------------------------------------------------------------------ InterpolationFilter
+namespace {
+
+struct IfTables
+{
+  TFilterCoeff luma8[17][8], luma6[17][8], alt[8], chroma[33][4];
+  IfTables()
+  {
+    // phases 0..8 (luma, 1/16) and 0..16 (chroma, 1/32); the other half is the mirror image (InterpolationFilter.cpp:64-142)
+    static const int8_t l8[9][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 63, 4, -2, 1, 0 }, { -1, 2, -5, 62, 8, -3, 1, 0 }, { -1, 3, -8, 60, 13, -4, 1, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+                                     { -1, 4, -11, 52, 26, -8, 3, -1 }, { -1, 3, -9, 47, 31, -10, 4, -1 }, { -1, 4, -11, 45, 34, -10, 4, -1 }, { -1, 4, -11, 40, 40, -11, 4, -1 } };
+    static const int8_t l6[9][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 63, 4, -2, 1, 0 }, { 0, 1, -5, 62, 8, -3, 1, 0 }, { 0, 2, -8, 60, 13, -4, 1, 0 }, { 0, 3, -10, 58, 17, -5, 1, 0 },
+                                     { 0, 3, -11, 52, 26, -8, 2, 0 }, { 0, 2, -9, 47, 31, -10, 3, 0 }, { 0, 3, -11, 45, 34, -10, 3, 0 }, { 0, 3, -11, 40, 40, -11, 3, 0 } };
+    static const int8_t c4[17][4] = { { 0, 64, 0, 0 }, { -1, 63, 2, 0 }, { -2, 62, 4, 0 }, { -2, 60, 7, -1 }, { -2, 58, 10, -2 }, { -3, 57, 12, -2 }, { -4, 56, 14, -2 }, { -4, 55, 15, -2 },
+                                      { -4, 54, 16, -2 }, { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 }, { -6, 46, 28, -4 }, { -5, 44, 29, -4 }, { -4, 42, 30, -4 }, { -4, 39, 33, -4 }, { -4, 36, 36, -4 } };
+    static const int8_t a[8] = { 0, 3, 9, 20, 20, 9, 3, 0 };
+    for( int p = 0; p <= 16; p++ ) for( int k = 0; k < 8; k++ ) { luma8[p][k] = p <= 8 ? l8[p][k] : l8[16 - p][7 - k]; luma6[p][k] = p <= 8 ? l6[p][k] : l6[16 - p][7 - k]; }
+    for( int p = 0; p <= 32; p++ ) for( int k = 0; k < 4; k++ ) chroma[p][k] = p <= 16 ? c4[p][k] : c4[32 - p][3 - k];
+    for( int k = 0; k < 8; k++ ) alt[k] = a[k];
+  }
+};
+const IfTables& ifTables() { static const IfTables t; return t; }
+
+// stage the (w + left + right) x (h + top + bottom) neighbourhood of a host block compactly on the device; returns the device pointer of the block's sample (0,0)
+int16_t* stageRegion( Device& dev, int16_t* dArea, const Pel* src, int srcStride, int w, int h, int left, int right, int top, int bottom, std::vector<Pel>& tmp, int& pitch )
+{
+  pitch = w + left + right;
+  const int rows = h + top + bottom;
+  tmp.resize( ( size_t ) pitch * rows );
+  for( int y = 0; y < rows; y++ ) memcpy( &tmp[( size_t ) y * pitch], src + ( ptrdiff_t ) ( y - top ) * srcStride - left, sizeof( Pel ) * pitch );
+  dev.check( vvhip_upload( dev.ctx(), dArea, tmp.data(), tmp.size() * sizeof( Pel ) ), "interpolation source" );
+  return dArea + ( size_t ) top * pitch + left;
+}
+
+void fetchBlock( Device& dev, const int16_t* dBlk, Pel* dst, int dstStride, int w, int h, std::vector<Pel>& tmp )
+{
+  tmp.resize( ( size_t ) w * h );
+  dev.check( vvhip_download( dev.ctx(), tmp.data(), dBlk, tmp.size() * sizeof( Pel ) ), "interpolation result" );
+  for( int y = 0; y < h; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride, &tmp[( size_t ) y * w], sizeof( Pel ) * w );
+}
+
+template<int N, bool VER, bool FIRST, bool LAST>
+void ifSlot( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeff )
+{
+  if( width <= 0 || height <= 0 ) return;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int lo = N / 2 - 1, hi = N / 2;
+  const size_t srcElems = ( size_t ) ( width + ( VER ? 0 : N ) ) * ( height + ( VER ? N : 0 ) ), dstElems = ( size_t ) width * height;
+  int16_t* area = dev.staging( ( srcElems + dstElems ) * sizeof( Pel ) + 256 );
+  std::vector<Pel> tmp;
+  int pitch;
+  const int16_t* dSrc = stageRegion( dev, area, src, srcStride, width, height, VER ? 0 : lo, VER ? 0 : hi, VER ? lo : 0, VER ? hi : 0, tmp, pitch );
+  int16_t* dDst = area + ( ( srcElems + 63 ) & ~( size_t ) 63 );
+  dev.check( vvhip_if_filter( dev.ctx(), N, VER, FIRST, LAST, clpRng.bd, dSrc, pitch, dDst, width, width, height, coeff ), "vvhip_if_filter" );
+  fetchBlock( dev, dDst, dst, dstStride, width, height, tmp );
+}
+
+template<bool FIRST, bool LAST>
+void ifCopySlot( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, bool biMCForDMVR )
+{
+  if( width <= 0 || height <= 0 ) return;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const size_t elems = ( size_t ) width * height;
+  int16_t* area = dev.staging( 2 * elems * sizeof( Pel ) + 256 );
+  std::vector<Pel> tmp;
+  int pitch;
+  const int16_t* dSrc = stageRegion( dev, area, src, srcStride, width, height, 0, 0, 0, 0, tmp, pitch );
+  int16_t* dDst = area + ( ( elems + 63 ) & ~( size_t ) 63 );
+  dev.check( vvhip_if_copy( dev.ctx(), FIRST, LAST, clpRng.bd, dSrc, pitch, dDst, width, width, height, biMCForDMVR ), "vvhip_if_copy" );
+  fetchBlock( dev, dDst, dst, dstStride, width, height, tmp );
+}
+
+// fused entries (filterWxH_N8 / _N4 / _N2, InterpolationFilter.cpp:772-1010): horizontal first pass over the rows the vertical taps need, then the vertical pass
+template<int N, bool LAST>
+void ifFused( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeffH, TFilterCoeff const* coeffV )
+{
+  if( width <= 0 || height <= 0 ) return;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int lo = N / 2 - 1, hi = N / 2, rows = height + N - 1;
+  const size_t srcElems = ( size_t ) ( width + N ) * rows, midElems = ( size_t ) width * rows, dstElems = ( size_t ) width * height;
+  int16_t* area = dev.staging( ( srcElems + midElems + dstElems ) * sizeof( Pel ) + 512 );
+  std::vector<Pel> tmp;
+  int pitch;
+  const int16_t* dSrc = stageRegion( dev, area, src, srcStride, width, height, lo, hi, lo, hi, tmp, pitch );
+  int16_t* dMid = area + ( ( srcElems + 63 ) & ~( size_t ) 63 );
+  int16_t* dDst = dMid + ( ( midElems + 63 ) & ~( size_t ) 63 );
+  // the 8-entry rows of the 6-tap sets begin and end with 0: running 8 taps on them is the same sum (the reference's fused cores do exactly that)
+  dev.check( vvhip_if_filter( dev.ctx(), N, 0, 1, 0, clpRng.bd, dSrc - ( ptrdiff_t ) lo * pitch, pitch, dMid, width, width, rows, coeffH ), "vvhip_if_filter (hor)" );
+  dev.check( vvhip_if_filter( dev.ctx(), N, 1, 0, LAST, clpRng.bd, dMid + ( size_t ) lo * width, width, dDst, width, width, height, coeffV ), "vvhip_if_filter (ver)" );
+  fetchBlock( dev, dDst, dst, dstStride, width, height, tmp );
+}
+
+} // namespace
+
+InterpolationFilter::InterpolationFilter()
+{
+  Device::get();
+#define IF_FILL( T, IDX, N ) T[IDX][0][0] = ifSlot<N, T##_V, false, false>; T[IDX][0][1] = ifSlot<N, T##_V, false, true>; T[IDX][1][0] = ifSlot<N, T##_V, true, false>; T[IDX][1][1] = ifSlot<N, T##_V, true, true>;
+  constexpr bool m_filterHor_V = false, m_filterVer_V = true;
+  IF_FILL( m_filterHor, 0, 8 ) IF_FILL( m_filterHor, 1, 4 ) IF_FILL( m_filterHor, 2, 2 ) IF_FILL( m_filterHor, 3, 6 )
+  IF_FILL( m_filterVer, 0, 8 ) IF_FILL( m_filterVer, 1, 4 ) IF_FILL( m_filterVer, 2, 2 ) IF_FILL( m_filterVer, 3, 6 )
+#undef IF_FILL
+  m_filterCopy[0][0] = ifCopySlot<false, false>; m_filterCopy[0][1] = ifCopySlot<false, true>; m_filterCopy[1][0] = ifCopySlot<true, false>; m_filterCopy[1][1] = ifCopySlot<true, true>;
+  m_filter4x4[0][0] = ifFused<8, false>; m_filter4x4[0][1] = ifFused<8, true>; m_filter4x4[1][0] = ifFused<4, false>; m_filter4x4[1][1] = ifFused<4, true>;
+  m_filter8xH[0][0] = m_filter16xH[0][0] = ifFused<8, false>; m_filter8xH[0][1] = m_filter16xH[0][1] = ifFused<8, true>;
+  m_filter8xH[1][0] = m_filter16xH[1][0] = ifFused<4, false>; m_filter8xH[1][1] = m_filter16xH[1][1] = ifFused<4, true>;
+  m_filter8xH[2][0] = m_filter16xH[2][0] = ifFused<2, false>; m_filter8xH[2][1] = m_filter16xH[2][1] = ifFused<2, true>;
+}
+
+const TFilterCoeff* InterpolationFilter::lumaFilter( int frac )    { return ifTables().luma8[frac]; }
+const TFilterCoeff* InterpolationFilter::lumaFilter4x4( int frac ) { return ifTables().luma6[frac]; }
+const TFilterCoeff* InterpolationFilter::lumaAltHpelIFilter()      { return ifTables().alt; }
+const TFilterCoeff* InterpolationFilter::chromaFilter( int frac32 ) { return ifTables().chroma[frac32]; }
+
+void InterpolationFilter::filterHor( Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, int frac, bool isLast, const ClpRng& clpRng, bool useAltHpelIf, int reduceTap )
+{
+  if( frac == 0 ) { m_filterCopy[1][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, false ); return; }        // :559-565 (copyBuffer == filterCopy<true,true>)
+  if( frac < 0 || frac >= 16 ) throw Exception( "Invalid fraction" );
+  if( reduceTap == 0 || ( useAltHpelIf && frac == 8 ) )
+  {
+    if( useAltHpelIf && frac == 8 ) m_filterHor[3][1][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, lumaAltHpelIFilter() );
+    else if( ( width == 4 && height == 4 ) || ( width == 4 && height == 4 + 8 - 1 ) ) m_filterHor[3][1][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, lumaFilter4x4( frac ) );
+    else m_filterHor[0][1][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, lumaFilter( frac ) );
+  }
+  else if( reduceTap == 1 ) m_filterHor[3][1][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, lumaFilter4x4( frac ) );
+  else                      m_filterHor[1][1][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, chromaFilter( frac << 1 ) );
+}
+
+void InterpolationFilter::filterVer( Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, int frac, bool isFirst, bool isLast, const ClpRng& clpRng, bool useAltHpelIf, int reduceTap )
+{
+  if( frac == 0 ) { m_filterCopy[isFirst][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, false ); return; }  // :619-622
+  if( frac < 0 || frac >= 16 ) throw Exception( "Invalid fraction" );
+  if( reduceTap == 0 || ( useAltHpelIf && frac == 8 ) )
+  {
+    if( useAltHpelIf && frac == 8 ) m_filterVer[3][isFirst][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, lumaAltHpelIFilter() );
+    else if( width == 4 && height == 4 ) m_filterVer[3][isFirst][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, lumaFilter4x4( frac ) );
+    else m_filterVer[0][isFirst][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, lumaFilter( frac ) );
+  }
+  else if( reduceTap == 1 ) m_filterVer[3][isFirst][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, lumaFilter4x4( frac ) );
+  else                      m_filterVer[1][isFirst][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, chromaFilter( frac << 1 ) );
+}
+
 // ------------------------------------------------------------------------------------------------ MCTFOps
 namespace {
 

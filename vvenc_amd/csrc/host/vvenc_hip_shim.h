@@ -173,4 +173,31 @@ struct MCTFOps
   void motionEstimation( int curPicId, const int* refPicIds, int nRefs, int bitDepth, int unitSize, int mctfSpeed, bool addLevel, vvhip_mv** out );
 };
 
+// InterpolationFilter, CommonLib/InterpolationFilter.h:70-155: the function-pointer tables of the separable
+// sub-pel filter with the reference's signatures (host pointers, one synchronous launch per call) and the two public dispatchers.
+struct ClpRng { int bd; static constexpr int min() { return 0; } int max() const { return ( 1 << bd ) - 1; } };      // CommonDef.h:542-548
+typedef int16_t TFilterCoeff;
+class InterpolationFilter
+{
+public:
+  InterpolationFilter();
+  void initInterpolationFilter( bool /*enable*/ ) {}
+  // [tap index: 0 = 8, 1 = 4, 2 = 2 (bilinear), 3 = 6 taps][isFirst][isLast]
+  void ( *m_filterHor[4][2][2] )( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeff );
+  void ( *m_filterVer[4][2][2] )( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeff );
+  void ( *m_filterCopy[2][2] )( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, bool biMCForDMVR );
+  // fused two-pass entries [0 = 8 taps, 1 = 4 taps (, 2 = 2 taps)][isLast]: horizontal pass (14-bit) then vertical pass
+  void ( *m_filter4x4[2][2] )( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeffH, TFilterCoeff const* coeffV );
+  void ( *m_filter8xH[3][2] )( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeffH, TFilterCoeff const* coeffV );
+  void ( *m_filter16xH[3][2] )( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeffH, TFilterCoeff const* coeffV );
+  // luma dispatch of InterpolationFilter::filterHor / filterVer (InterpolationFilter.cpp:557-661; nFilterIdx 0)
+  void filterHor( Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, int frac, bool isLast, const ClpRng& clpRng, bool useAltHpelIf = false, int reduceTap = 0 );
+  void filterVer( Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, int frac, bool isFirst, bool isLast, const ClpRng& clpRng, bool useAltHpelIf = false, int reduceTap = 0 );
+  // tap rows as the reference's static tables hold them (8 entries for the luma sets, 4 for chroma)
+  static const TFilterCoeff* lumaFilter( int frac );          // m_lumaFilter[frac]
+  static const TFilterCoeff* lumaFilter4x4( int frac );       // m_lumaFilter4x4[frac]
+  static const TFilterCoeff* lumaAltHpelIFilter();            // m_lumaAltHpelIFilter
+  static const TFilterCoeff* chromaFilter( int frac32 );      // m_chromaFilter[frac32]
+};
+
 } // namespace vvhip

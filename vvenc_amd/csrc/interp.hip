@@ -62,10 +62,16 @@ __device__ __forceinline__ Taps loadTaps( int set, int phase )
 
 struct PassGeom { int shift, offset, clipMax; };     // clipMax < 0: no clip
 
-__host__ __device__ inline PassGeom passGeom( int isFirst, int isLast, int bitDepth )    // InterpolationFilter.cpp:388-408 (N != 2)
+__host__ __device__ inline PassGeom passGeom( int isFirst, int isLast, int bitDepth, int taps = 8 )    // InterpolationFilter.cpp:388-423
 {
   const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2;
   PassGeom g; g.shift = 6; g.clipMax = isLast ? ( 1 << bitDepth ) - 1 : -1;
+  if( taps == 2 )      // bilinear taps of DMVR's search (IF_FILTER_PREC_BILINEAR 4, IF_INTERNAL_PREC_BILINEAR 10), :410-423
+  {
+    g.shift = isFirst ? 4 - ( 10 - bitDepth ) : 4;
+    g.offset = 1 << ( g.shift - 1 );
+    return g;
+  }
   if( isLast ) { g.shift += isFirst ? 0 : headRoom; g.offset = ( 1 << ( g.shift - 1 ) ) + ( isFirst ? 0 : ( 8192 << 6 ) ); }
   else         { g.shift -= isFirst ? headRoom : 0; g.offset = isFirst ? -( 8192 << g.shift ) : 0; }
   return g;
@@ -209,12 +215,12 @@ int vvhip_if_filter( vvhip_ctx* ctx, int taps, int is_vertical, int is_first, in
                      const int16_t* d_src, int src_stride, int16_t* d_dst, int dst_stride, int width, int height, const int16_t* coeff_host )
 {
   if( !ctx ) return VVHIP_E_ARG;
-  if( ( taps != 8 && taps != 6 && taps != 4 ) || !d_src || !d_dst || !coeff_host || width < 1 || height < 1 || width > 4096 || height > 4096 || bit_depth < 8 || bit_depth > 12 )
+  if( ( taps != 8 && taps != 6 && taps != 4 && taps != 2 ) || ( taps == 2 && is_first && bit_depth > 10 ) || !d_src || !d_dst || !coeff_host || width < 1 || height < 1 || width > 4096 || height > 4096 || bit_depth < 8 || bit_depth > 12 )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_if_filter: taps %d block %dx%d bitDepth %d", taps, width, height, bit_depth );
   SlotCoeff co;
   for( int k = 0; k < 8; k++ ) co.c[k] = 0;
   for( int k = 0; k < taps; k++ ) co.c[k] = coeff_host[k + ( taps == 6 ? 1 : 0 )];         // the 6-tap cores skip the row's first entry (:361-364)
-  const PassGeom g = passGeom( is_first != 0, is_last != 0, bit_depth );
+  const PassGeom g = passGeom( is_first != 0, is_last != 0, bit_depth, taps );
   hipLaunchKernelGGL( ifSlotKernel, dim3( ( width * height + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_src, src_stride, d_dst, dst_stride, width, height, taps,
                       is_vertical ? src_stride : 1, co, g );
   VVHIP_LAUNCH_CHECK( ctx );
