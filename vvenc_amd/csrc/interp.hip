@@ -207,6 +207,145 @@ ifPredBatchKernel( const int16_t* __restrict__ ref, int refStride, const vvhip_s
   }
 }
 
+// ---- wide form (w a multiple of 8): a thread produces 8 horizontally adjacent samples from a register window / 16-byte LDS rows ----
+struct __attribute__( ( packed, aligned( 2 ) ) ) Chunk8 { int16_t v[8]; };
+
+__device__ __forceinline__ void mac8( int ( &acc )[8], const int ( &win )[15], const Taps& t )
+{
+#pragma unroll
+  for( int i = 0; i < 8; i++ )
+  {
+    int s = 0;
+#pragma unroll
+    for( int j = 0; j < 8; j++ ) s = __mul24( win[i + j], t.c[j] ) + s;       // |sample| < 2^15, |tap| < 2^7: 24-bit multiply is exact
+    acc[i] = s;
+  }
+}
+
+// 15 samples x0-3 .. x0+11 of one row: two 8-sample loads that overlap by one sample (no read past x0+11)
+__device__ __forceinline__ void loadWindow( const int16_t* rowAtX0, int ( &win )[15] )
+{
+  const Chunk8 a = *reinterpret_cast<const Chunk8*>( rowAtX0 - 3 ), b = *reinterpret_cast<const Chunk8*>( rowAtX0 + 4 );
+#pragma unroll
+  for( int k = 0; k < 8; k++ ) win[k] = a.v[k];
+#pragma unroll
+  for( int k = 1; k < 8; k++ ) win[7 + k] = b.v[k];
+}
+
+struct __attribute__( ( aligned( 16 ) ) ) Row8 { int16_t v[8]; };      // 16-byte aligned 8-sample segment (LDS rows, compact outputs)
+
+__device__ __forceinline__ void store8( int16_t* dst, const int ( &acc )[8], const PassGeom& g )
+{
+  Row8 o;
+#pragma unroll
+  for( int i = 0; i < 8; i++ ) o.v[i] = finish( acc[i], g );
+  *reinterpret_cast<Row8*>( dst ) = o;
+}
+
+__global__ void __launch_bounds__( 256 )
+ifPredBatchWideKernel( const int16_t* __restrict__ ref, int refStride, const vvhip_subpel_item* __restrict__ items, int n, int w, int h, int bitDepth,
+                       int rndRes, int filterMode, int useAlt, int blocksPerWg, int16_t* __restrict__ out, vvhip_dist_item* __restrict__ distItems )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[];       // blocksPerWg x (h + 7) x w first-pass samples
+  const int tpb = 256 / blocksPerWg, sub = threadIdx.x / tpb, t = threadIdx.x - sub * tpb;
+  const int blk = blockIdx.x * blocksPerWg + sub;
+  const bool valid = blk < n;
+  vvhip_subpel_item it = { 0, 0, 0, 0 };
+  if( valid ) it = items[blk];
+  const int xf = it.frac_x & 15, yf = it.frac_y & 15;
+  const int16_t* src = ref + it.ref_off;
+  int16_t* dst = out + ( size_t ) blk * w * h;
+  int16_t* tmp = sTmp + ( size_t ) sub * ( h + 7 ) * w;
+  if( valid && t == 0 && distItems ) { vvhip_dist_item d; d.org_off = it.org_off; d.cur_off = blk * w * h; distItems[blk] = d; }
+  const int w8 = w >> 3;
+  const bool both = xf != 0 && yf != 0;
+  if( valid && both )
+  {
+    const Taps th = loadTaps( tapSet( xf, w, h, filterMode, useAlt, true ), filterMode == 2 && !( useAlt && xf == 8 ) ? xf << 1 : xf );
+    const PassGeom g1 = passGeom( 1, 0, bitDepth );
+    for( int i = t; i < ( h + 7 ) * w8; i += tpb )
+    {
+      const int r = i / w8, x0 = ( i - r * w8 ) << 3;
+      int win[15], acc[8];
+      loadWindow( src + ( ptrdiff_t ) ( r - 3 ) * refStride + x0, win );
+      mac8( acc, win, th );
+      store8( tmp + r * w + x0, acc, g1 );
+    }
+  }
+  __syncthreads();
+  if( !valid ) return;
+  if( both )
+  {
+    const Taps tv = loadTaps( tapSet( yf, w, h, filterMode, useAlt, true ), filterMode == 2 && !( useAlt && yf == 8 ) ? yf << 1 : yf );
+    const PassGeom g2 = passGeom( 0, rndRes, bitDepth );
+    for( int i = t; i < h * w8; i += tpb )
+    {
+      const int y = i / w8, x0 = ( i - y * w8 ) << 3;
+      int acc[8];
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) acc[k] = 0;
+#pragma unroll
+      for( int j = 0; j < 8; j++ )
+      {
+        const Row8 row = *reinterpret_cast<const Row8*>( tmp + ( y + j ) * w + x0 );      // 16-byte aligned LDS row segment
+#pragma unroll
+        for( int k = 0; k < 8; k++ ) acc[k] = __mul24( ( int ) row.v[k], tv.c[j] ) + acc[k];
+      }
+      store8( dst + y * w + x0, acc, g2 );
+    }
+  }
+  else if( xf != 0 )
+  {
+    const Taps tt = loadTaps( tapSet( xf, w, h, filterMode, useAlt, false ), filterMode == 2 && !( useAlt && xf == 8 ) ? xf << 1 : xf );
+    const PassGeom g = passGeom( 1, rndRes, bitDepth );
+    for( int i = t; i < h * w8; i += tpb )
+    {
+      const int y = i / w8, x0 = ( i - y * w8 ) << 3;
+      int win[15], acc[8];
+      loadWindow( src + ( ptrdiff_t ) y * refStride + x0, win );
+      mac8( acc, win, tt );
+      store8( dst + y * w + x0, acc, g );
+    }
+  }
+  else if( yf != 0 )
+  {
+    const Taps tt = loadTaps( tapSet( yf, w, h, filterMode, useAlt, false ), filterMode == 2 && !( useAlt && yf == 8 ) ? yf << 1 : yf );
+    const PassGeom g = passGeom( 1, rndRes, bitDepth );
+    for( int i = t; i < h * w8; i += tpb )
+    {
+      const int y = i / w8, x0 = ( i - y * w8 ) << 3;
+      int acc[8];
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) acc[k] = 0;
+#pragma unroll
+      for( int j = 0; j < 8; j++ )
+        if( j >= tt.k0 && j <= tt.k1 )          // rows outside the tap support are not touched (they may lie outside the picture margin)
+        {
+          const Chunk8 row = *reinterpret_cast<const Chunk8*>( src + ( ptrdiff_t ) ( y + j - 3 ) * refStride + x0 );
+#pragma unroll
+          for( int k = 0; k < 8; k++ ) acc[k] = __mul24( ( int ) row.v[k], tt.c[j] ) + acc[k];
+        }
+      store8( dst + y * w + x0, acc, g );
+    }
+  }
+  else
+  {
+    const int shift = 14 - bitDepth > 2 ? 14 - bitDepth : 2;
+    for( int i = t; i < h * w8; i += tpb )
+    {
+      const int y = i / w8, x0 = ( i - y * w8 ) << 3;
+      Chunk8 c = *reinterpret_cast<const Chunk8*>( src + ( ptrdiff_t ) y * refStride + x0 );
+      if( !rndRes )
+#pragma unroll
+        for( int k = 0; k < 8; k++ ) c.v[k] = ( int16_t ) ( ( int16_t ) ( ( uint16_t ) c.v[k] << shift ) - 8192 );
+      Row8 o;
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) o.v[k] = c.v[k];
+      *reinterpret_cast<Row8*>( dst + y * w + x0 ) = o;
+    }
+  }
+}
+
 } // namespace
 
 extern "C" {
@@ -241,6 +380,16 @@ int vvhip_if_copy( vvhip_ctx* ctx, int is_first, int is_last, int bit_depth, con
 static int launchPred( vvhip_ctx* ctx, const int16_t* d_ref, int ref_stride, const vvhip_subpel_item* d_items, int n, int width, int height, int bit_depth,
                        int rnd_res, int filter_mode, int use_alt_hpel, int16_t* d_out, vvhip_dist_item* d_dist_items )
 {
+  if( ( width & 7 ) == 0 )
+  {
+    int tpb = 16; while( tpb < 256 && tpb * 8 < width * height ) tpb <<= 1;          // one thread per 8 output samples, at least 16 threads per block
+    const int bpw = 256 / tpb;
+    const size_t smem = ( size_t ) bpw * ( height + 7 ) * width * sizeof( int16_t );
+    hipLaunchKernelGGL( ifPredBatchWideKernel, dim3( ( n + bpw - 1 ) / bpw ), dim3( 256 ), smem, ctx->stream, d_ref, ref_stride, d_items, n, width, height, bit_depth,
+                        rnd_res ? 1 : 0, filter_mode, use_alt_hpel ? 1 : 0, bpw, d_out, d_dist_items );
+    VVHIP_LAUNCH_CHECK( ctx );
+    return VVHIP_OK;
+  }
   int bpw = 256 / ( width * height ); if( bpw < 1 ) bpw = 1; if( bpw > 8 ) bpw = 8;
   const size_t smem = ( size_t ) bpw * ( height + 7 ) * width * sizeof( int16_t );
   hipLaunchKernelGGL( ifPredBatchKernel, dim3( ( n + bpw - 1 ) / bpw ), dim3( 256 ), smem, ctx->stream, d_ref, ref_stride, d_items, n, width, height, bit_depth,
