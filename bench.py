@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip per-kernel HIP events inside the timed region")
     ap.add_argument("--bcast-ref", action="store_true", help="also broadcast the reference picture from its owner every step (RCCL)")
+    ap.add_argument("--with-subpel", action="store_true", help="also run the fractional-ME stage per step (16 interpolated HAD_fast candidates per block; SURVEY 8f rank 1)")
     ap.add_argument("--with-mctf", type=int, default=0, help="also run the MCTF hierarchical ME against this many references per step")
     args = ap.parse_args()
 
@@ -177,6 +178,8 @@ def main():
     from vvenc_amd.workload import FrameWorkload
     hp = HotPath("cuda:%d" % local_rank)
     wl = FrameWorkload(hp, args.width, args.height, seed=1080 + rank)
+    if args.with_subpel:
+        wl.enable_subpel()
     mctf_refs = []
     if args.with_mctf:
         cur128 = hp.plane(wl.cur_np, 128)
@@ -227,7 +230,7 @@ def main():
                                "(8..64 blocks, 20 candidates/block) + fused DCT-2/quant/dequant/IDCT TU batches (8..32)" % (args.width, args.height),
                    "sample_pairs_per_frame": int(wl.pairs), "coefficients_per_frame": int(wl.coefs), "launches_per_frame": 4 if wl.merged else len(wl.dist_jobs) + len(wl.tu_jobs),
                    "sharding": "pictures round-robin over ranks, no data-path collective" + (", reference-picture RCCL broadcast per step" if args.bcast_ref else ""),
-                   "mctf_refs_per_step": args.with_mctf},
+                   "mctf_refs_per_step": args.with_mctf, "subpel_candidates_per_block": 16 if args.with_subpel else 0},
     }
     if timers is not None:
         ks = wsum                                             # all classes, measured over the warm-up steps
@@ -244,7 +247,7 @@ def main():
         ks[dom] = td
         launches_per_frame = ks[dom]["launches"] / args.steps
         out["kernels"] = ks
-        out["roofline"] = {"bound": "hbm", "kernel": {"SAD": "sadSseMultiKernel<SAD>", "SSE": "sadSseMultiKernel<SSE>", "HAD_fast": "hadTile8MultiKernel", "TU": "tuRdoRowMultiKernel", "TU8": "tuRdoRowKernel<8,1>", "TU16": "tuRdoRowKernel<16,2>", "TU32": "tuRdoRowKernel<32,2>"}[dom],
+        out["roofline"] = {"bound": "hbm", "kernel": {"SAD": "sadSseMultiKernel<SAD>", "SSE": "sadSseMultiKernel<SSE>", "HAD_fast": "hadTile8MultiKernel", "TU": "tuRdoRowMultiKernel", "SUBPEL": "ifPredBatchWideKernel + hadTileKernel", "TU8": "tuRdoRowKernel<8,1>", "TU16": "tuRdoRowKernel<16,2>", "TU32": "tuRdoRowKernel<32,2>"}[dom],
                            "achieved": ks[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ks[dom]["alg_GBps"] / HBM_PEAK_GBS,
                            "traffic": pmc_traffic(dom, args),
                            "alg_bytes_per_launch": wl.alg_bytes[dom] / launches_per_frame, "avg_launch_ms": ks[dom]["avg_ms"],

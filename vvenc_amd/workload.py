@@ -102,6 +102,44 @@ class FrameWorkload:
         self.alg_bytes["TU"] = sum(self.alg_bytes["TU%d" % S] for S in TU_SIZES)
         self.class_launches_merged = {"SAD": 1, "HAD_fast": 1, "SSE": 1, "TU": 1}
 
+    # ---- optional fractional-ME stage: 16 sub-pel candidates (8 half-sample + 8 quarter-sample positions around a seeded
+    # integer vector) per block of every size, interpolated and scored with HAD_fast like InterSearch::xPatternRefinement
+    def enable_subpel(self):
+        import torch
+        from .hotpath import SUBPEL_DTYPE
+        hp = self.hp
+        rng = np.random.default_rng(4242)
+        offs = [(-2, 0), (2, 0), (0, -2), (0, 2), (-2, -2), (2, -2), (-2, 2), (2, 2), (-1, 0), (1, 0), (0, -1), (0, 1), (-1, -1), (1, -1), (-1, 1), (1, 1)]
+        self.subpel_jobs = []
+        self.alg_bytes["SUBPEL"] = 0
+        for S in SIZES:
+            bx, by = np.meshgrid(np.arange(0, self.width - S + 1, S), np.arange(0, self.height - S + 1, S))
+            bx, by = bx.ravel(), by.ravel()
+            nb = bx.size
+            mvx, mvy = rng.integers(-12, 13, nb) * 4 + 12, rng.integers(-12, 13, nb) * 4 + 4          # quarter-sample units
+            it = np.zeros(nb * len(offs), SUBPEL_DTYPE)
+            for k, (dx, dy) in enumerate(offs):
+                qx, qy = mvx + dx, mvy + dy
+                sl = slice(k * nb, (k + 1) * nb)
+                it["org_off"][sl] = by * self.org.stride + bx
+                it["ref_off"][sl] = (by + (qy >> 2)) * self.ref.stride + bx + (qx >> 2)
+                it["frac_x"][sl] = (qx & 3) << 2
+                it["frac_y"][sl] = (qy & 3) << 2
+            n = it.size
+            self.subpel_jobs.append((S, n, hp.to_device(it), torch.empty(n, dtype=torch.int64, device=hp.device), it))
+            # per candidate: (S+7)^2 reference samples in, S^2 original samples in, 8 B out
+            self.alg_bytes["SUBPEL"] += n * (2 * (S + 7) * (S + 7) + 2 * S * S + 8)
+        self.class_launches["SUBPEL"] = 2 * len(SIZES)
+        self.class_launches_merged["SUBPEL"] = 2 * len(SIZES)
+
+    def run_subpel(self, timers=None):
+        if timers is not None:
+            timers.start("SUBPEL")
+        for (S, n, d_it, out, _) in self.subpel_jobs:
+            self.hp.subpel_dist_batch("HAD_fast", self.org, self.ref, d_it, n, S, S, self.bit_depth, 0, False, out=out)
+        if timers is not None:
+            timers.stop("SUBPEL")
+
     # one pass of the hot path over the frame: 3 merged distortion launches + 1 merged fused-TU launch (or 12 + 3 per-size ones)
     def run(self, timers=None):
         hp = self.hp
@@ -129,6 +167,8 @@ class FrameWorkload:
             hp.tu_rdo_multi(self.resi, self.tu_table, self.bit_depth)
             if timers is not None:
                 timers.stop("TU")
+            if getattr(self, "subpel_jobs", None):
+                self.run_subpel(timers)
             return
         for (S, n, d_off, d_qp, lvl, rec, st, _, _) in self.tu_jobs:
             if timers is not None:
