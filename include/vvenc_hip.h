@@ -300,6 +300,25 @@ VVHIP_API int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur
                                             int unit_size, int mctf_speed, int add_level,
                                             vvhip_mv* const* d_mvs_out_host_array );
 
+/* ======================================================================================================================
+ * SURVEY 8f rank 2 — MCTF apply side: motion-compensated bilateral temporal filter of one component plane
+ * (MCTF::bilateralFilter / xFinalizeBlkLine, CommonLib/MCTF.cpp:1399-1552, with applyFrac8Core_6Tap/_4Tap :259-358,
+ * applyPlanarCorrectionCore :372-421 and applyBlockCore :423-518 fused per block).  Equals the reference's SCALAR row; the reference's
+ * own unit test holds its x86 row to +-1 of that.
+ *   d_org / d_refs[i] : sample (0,0) of planes whose margins cover the motion vectors (MCTF_PADDING 128 luma, 64 chroma)
+ *   d_mvs[i]          : final-level motion field of reference i (what vvhip_mctf_motion_estimation returns), mv_w blocks per row
+ *   chroma_shift      : 0 luma, 1 the chroma planes of 4:2:0 (vectors and block size are halved)
+ *   ref_strengths     : host array, m_refStrengths[row][|POC offset| - 1] per reference (MCTF.cpp:112-117)
+ *   weight_scaling / sigma_sq : per channel, see vvhip_mctf_filter_params
+ * d_refs / d_mvs are HOST arrays of device pointers.                                                                              */
+VVHIP_API int vvhip_mctf_apply_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, int width, int height, int chroma_shift,
+                                      int bit_depth, int unit_size, int low_res_flt_apply, int qp, int num_refs,
+                                      const int16_t* const* d_refs, int ref_stride, const vvhip_mv* const* d_mvs, int mv_w,
+                                      const double* ref_strengths, double weight_scaling, double sigma_sq,
+                                      int16_t* d_out, int out_stride );
+/* sigmaSq and weightScaling exactly as MCTF::bilateralFilter (:1491-1501) and xFinalizeBlkLine (:1417) derive them (host only). */
+VVHIP_API int vvhip_mctf_filter_params( int qp, int bit_depth, double overall_strength, int is_chroma, double* sigma_sq, double* weight_scaling );
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,6 +126,50 @@ class _Base:
             a = (self.simd,) + a
         f(*a)
 
+    # ---- MCTF apply side (MCTF.cpp:259-518, 1399-1552) ----
+    REF_STRENGTHS = ((0.84375, 0.6, 0.4286, 0.3333, 0.2727, 0.2308), (1.12500, 1.0, 0.7143, 0.5556, 0.4545, 0.3846))      # MCTF.cpp:112-117
+
+    def mctf_apply_frac(self, tap4, src, w, h, fx, fy, bit_depth=10, chroma=False):
+        ps, ss = self._ptr_stride(src)
+        dst = np.full((h + 2, w + 32), -99, np.int16)
+        a = (int(tap4), ps, C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w + 32), w, h, fx, fy, bit_depth)
+        if self._pfx == "vvref_":
+            a = (self.simd, int(chroma)) + a
+        f = getattr(self.L, self._pfx + "mctf_apply_frac"); f.restype = None; f(*a)
+        return dst[:h, :w].copy()
+
+    def mctf_planar_correction(self, ref, block, w, h, bit_depth, motion_error):
+        pr, rs = self._ptr_stride(ref)
+        dst = np.full((h + 2, w + 32), 0, np.int16)
+        dst[:h, :w] = block
+        a = (pr, C.c_ssize_t(rs), _p(dst), C.c_ssize_t(w + 32), w, h, bit_depth, int(motion_error))
+        if self._pfx == "vvref_":
+            a = (self.simd,) + a
+        f = getattr(self.L, self._pfx + "mctf_planar_correction"); f.restype = None; f(*a)
+        return dst[:h, :w].copy()
+
+    def mctf_apply_block(self, src, corrected, verror, ref_strengths, weight_scaling, sigma_sq, w, h, bit_depth=10):
+        ps, ss = self._ptr_stride(src)
+        n = len(corrected)
+        keep = [_aligned(np.ascontiguousarray(c, np.int16)) for c in corrected]
+        ptrs = (C.c_void_p * n)(*[k.ctypes.data for k in keep])
+        ve = np.ascontiguousarray(verror, np.int32)
+        rs = np.ascontiguousarray(ref_strengths, np.float64)
+        dst = np.full((h + 2, w + 32), -99, np.int16)
+        a = (ps, C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w + 32), w, h, bit_depth, ptrs, n, _p(ve), _p(rs), C.c_double(weight_scaling), C.c_double(sigma_sq))
+        if self._pfx == "vvref_":
+            a = (self.simd,) + a
+        f = getattr(self.L, self._pfx + "mctf_apply_block"); f.restype = None; f(*a)
+        return dst[:h, :w].copy()
+
+    @staticmethod
+    def mctf_filter_params(qp, bit_depth, overall_strength, chroma):
+        """sigmaSq / weightScaling as MCTF::bilateralFilter and xFinalizeBlkLine derive them (MCTF.cpp:1491-1501, :1417)"""
+        luma_sigma = 9.0 * (128.0 + 3.0 / 256.0 * qp * qp * qp)
+        bdw = 1024.0 / (1 << bit_depth)
+        sigma = (30.0 * 30.0 if chroma else luma_sigma) / (bdw * bdw)
+        return sigma, overall_strength * (0.55 if chroma else 0.4)
+
     # ---- g_tCoeffOps table slots (TrQuant_EMT.h:63-91), caller's matrix ----
     def fast_fwd_core(self, tc, src, line, reduced_line, cutoff, shift):
         """tc: (N, N) int16, src: (line, N) int32 -> dst (N, line) int32 (entries outside reduced_line x cutoff stay 0)"""
@@ -382,6 +426,30 @@ class Oracle(_Base):
         self.L.orc_mctf_subsample(_p(plane), w, w, h, _p(out), w // 2)
         return out
 
+    def mctf_bilateral(self, org, refs, mvs, ref_index, bit_depth=10, qp=32, unit=16, low_res=True, pic_reordering=True, overall_strength=0.95):
+        """org: (Y, U, V) arrays; refs: list of (Y, U, V); mvs: list of MV_DTYPE arrays (final level); -> (Y, U, V) filtered"""
+        h, w = org[0].shape
+        wb = (w + unit - 1) // unit
+        strengths = np.array([self.REF_STRENGTHS[0 if pic_reordering else 1][k] for k in ref_index], np.float64)
+        out = []
+        for c in range(3):
+            cs = 1 if c else 0
+            pad = 128 >> cs
+            po = np.ascontiguousarray(np.pad(org[c], pad, mode="edge"), np.int16)
+            prs = [np.ascontiguousarray(np.pad(r[c], pad, mode="edge"), np.int16) for r in refs]
+            stride = po.shape[1]
+            sigma, scaling = self.mctf_filter_params(qp, bit_depth, overall_strength, c > 0)
+            o = np.zeros_like(org[c], dtype=np.int16)
+            rp = (C.c_void_p * len(refs))(*[_view_ptr(p, pad * stride + pad).value for p in prs])
+            keep = [np.ascontiguousarray(m) for m in mvs]
+            mp = (C.c_void_p * len(refs))(*[k.ctypes.data for k in keep])
+            f = self.L.orc_mctf_bilateral_plane
+            f.restype = None
+            f(_view_ptr(po, pad * stride + pad), C.c_ssize_t(stride), org[c].shape[1], org[c].shape[0], cs, bit_depth, unit, int(low_res), qp, len(refs), rp,
+              C.c_ssize_t(stride), mp, wb, _p(strengths), C.c_double(scaling), C.c_double(sigma), _p(o), C.c_ssize_t(o.shape[1]))
+            out.append(o)
+        return tuple(out)
+
     def mctf_me(self, org, ref, bit_depth=10, unit=16, speed=4, add_level=None):
         return _mctf_me(self.L.orc_mctf_me, None, org, ref, bit_depth, unit, speed, add_level)
 
@@ -582,6 +650,21 @@ class RefLib(_Base):
         out = np.zeros((h // 2, w // 2), np.int16)
         self.L.vvref_mctf_subsample(_p(plane), w, h, _p(out))
         return out
+
+    def mctf_bilateral(self, org, refs, mvs, ref_index, bit_depth=10, qp=32, unit=16, low_res=True, pic_reordering=True, overall_strength=0.95):
+        h, w = org[0].shape
+        keep = [np.ascontiguousarray(p, np.int16) for p in org] + [np.ascontiguousarray(p, np.int16) for r in refs for p in r]
+        op = (C.c_void_p * 3)(*[k.ctypes.data for k in keep[:3]])
+        rp = (C.c_void_p * (3 * len(refs)))(*[k.ctypes.data for k in keep[3:]])
+        km = [np.ascontiguousarray(m) for m in mvs]
+        mp = (C.c_void_p * len(refs))(*[k.ctypes.data for k in km])
+        idx = np.ascontiguousarray(ref_index, np.int32)
+        outs = [np.zeros_like(p, dtype=np.int16) for p in org]
+        outp = (C.c_void_p * 3)(*[o.ctypes.data for o in outs])
+        rc = self.L.vvref_mctf_bilateral(self.simd, w, h, bit_depth, qp, unit, int(low_res), int(pic_reordering), op, len(refs), rp, mp, _p(idx),
+                                         C.c_double(overall_strength), outp)
+        assert rc == 0
+        return tuple(outs)
 
     def mctf_me(self, org, ref, bit_depth=10, unit=16, speed=4, add_level=None):
         return _mctf_me(self.L.vvref_mctf_me, self.simd, org, ref, bit_depth, unit, speed, add_level)

@@ -546,6 +546,92 @@ API int vvref_mctf_me( int simd, const int16_t* orgLuma, const int16_t* refLuma,
 }
 
 // ---------------------------------------------------------------------------------------------
+// MCTF apply side — table entries m_applyFrac / m_applyPlanarCorrection / m_applyBlock (MCTF.h:167-170) and the
+// whole-picture MCTF::bilateralFilter (MCTF.cpp:1489-1552) on 4:2:0 planes.
+// ---------------------------------------------------------------------------------------------
+API void vvref_mctf_apply_frac( int simd, int chroma, int tap4, const int16_t* org, ptrdiff_t os, int16_t* dst, ptrdiff_t ds, int w, int h, int fx, int fy, int bitDepth )
+{
+  MCTF& m = *mctfPair().m[simd ? 1 : 0];
+  if( tap4 ) m.m_applyFrac[chroma ? 1 : 0][1]( org, os, dst, ds, w, h, MCTF::m_interpolationFilter4[fx], MCTF::m_interpolationFilter4[fy], bitDepth );
+  else       m.m_applyFrac[chroma ? 1 : 0][0]( org, os, dst, ds, w, h, MCTF::m_interpolationFilter8[fx], MCTF::m_interpolationFilter8[fy], bitDepth );
+}
+
+API void vvref_mctf_planar_correction( int simd, const int16_t* ref, ptrdiff_t rs, int16_t* dst, ptrdiff_t ds, int w, int h, int bitDepth, int motionError )
+{
+  ClpRng clp; clp.bd = bitDepth;
+  mctfPair().m[simd ? 1 : 0]->m_applyPlanarCorrection( ref, rs, dst, ds, w, h, clp, ( uint16_t ) motionError );
+}
+
+API void vvref_mctf_apply_block( int simd, const int16_t* src, ptrdiff_t ss, int16_t* dst, ptrdiff_t ds, int w, int h, int bitDepth, const int16_t* const* corrected, int numRefs,
+                                 const int* verror, const double* refStrengths, double weightScaling, double sigmaSq )
+{
+  ClpRng clp; clp.bd = bitDepth;
+  const CPelBuf srcBuf( src, ss, w, h );
+  PelBuf dstBuf( dst, ds, w, h );
+  const Pel* corr[2 * VVENC_MCTF_RANGE] = { nullptr, };
+  for( int i = 0; i < numRefs; i++ ) corr[i] = corrected[i];
+  mctfPair().m[simd ? 1 : 0]->m_applyBlock( srcBuf, dstBuf, CompArea( COMP_Y, CHROMA_400, Area( 0, 0, w, h ) ), clp, corr, numRefs, verror, refStrengths, weightScaling, sigmaSq );
+}
+
+namespace {
+void fillYuv( PelStorage& ps, const int16_t* const yuv[3], int w, int h )
+{
+  ps.create( CHROMA_420, Area( 0, 0, w, h ), 0, MCTF_PADDING );
+  for( int c = 0; c < 3; c++ )
+  {
+    PelBuf b = ps.bufs[c];
+    for( int r = 0; r < ( int ) b.height; r++ ) memcpy( b.buf + r * b.stride, yuv[c] + ( size_t ) r * b.width, sizeof( int16_t ) * b.width );
+    b.extendBorderPel( MCTF_PADDING >> ( c ? 1 : 0 ), MCTF_PADDING >> ( c ? 1 : 0 ) );
+  }
+}
+}
+
+// org / refs[i]: 3 compact planes each (Y w x h, U and V w/2 x h/2); mvs[i]: final-level motion field of reference i (ceil(w/unit) x ceil(h/unit) MvOut);
+// refIndex[i] = TemporalFilterSourcePicInfo::index (|POC offset| - 1, row RA of m_refStrengths when picReordering).  out: 3 compact planes.
+API int vvref_mctf_bilateral( int simd, int width, int height, int bitDepth, int qp, int unitSize, int lowResFltApply, int picReordering, const int16_t* const* org,
+                              int numRefs, const int16_t* const* refs /* 3 per reference */, const MvOut* const* mvs, const int* refIndex, double overallStrength,
+                              int16_t* const* out )
+{
+  MCTF m( simd != 0 );
+  static VVEncCfg cfg;
+  vvenc_init_default( &cfg, width, height, 30, 0, qp, VVENC_FASTER );
+  cfg.m_internalBitDepth[0] = cfg.m_internalBitDepth[1] = bitDepth;
+  cfg.m_internChromaFormat = VVENC_CHROMA_420;
+  cfg.m_QP = qp;
+  cfg.m_picReordering = picReordering != 0;
+  m.m_encCfg = &cfg;
+  m.m_threadPool = nullptr;
+  m.m_area = Area( 0, 0, width, height );
+  m.m_mctfUnitSize = unitSize;
+  m.m_lowResFltApply = lowResFltApply != 0;
+  PelStorage orgPic, newPic;
+  fillYuv( orgPic, org, width, height );
+  newPic.create( CHROMA_420, Area( 0, 0, width, height ), 0, MCTF_PADDING );
+  std::deque<TemporalFilterSourcePicInfo> infos;
+  const int wB = ( width + unitSize - 1 ) / unitSize, hB = ( height + unitSize - 1 ) / unitSize;
+  for( int i = 0; i < numRefs; i++ )
+  {
+    infos.emplace_back();
+    TemporalFilterSourcePicInfo& s = infos.back();
+    fillYuv( s.picBuffer, refs + 3 * i, width, height );
+    s.mvs.allocate( wB, hB );
+    for( int y = 0; y < hB; y++ ) for( int x = 0; x < wB; x++ )
+    {
+      MotionVector& d = s.mvs.get( x, y ); const MvOut& v = mvs[i][y * wB + x];
+      d.x = v.x; d.y = v.y; d.error = v.error; d.rmsme = ( uint16_t ) v.rmsme; d.overlap = v.overlap;
+    }
+    s.index = refIndex[i];
+  }
+  m.bilateralFilter( orgPic, infos, newPic, overallStrength );
+  for( int c = 0; c < 3; c++ )
+  {
+    CPelBuf b = newPic.bufs[c];
+    for( int r = 0; r < ( int ) b.height; r++ ) memcpy( out[c] + ( size_t ) r * b.width, b.buf + r * b.stride, sizeof( int16_t ) * b.width );
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Batch loops for CPU-baseline timing (bench.py cpu_baseline kind "reference"): the reference's own table entries
 // called back-to-back from C++, like InterSearch::xTZSearchHelp does (EncoderLib/InterSearch.cpp:410-438).
 // ---------------------------------------------------------------------------------------------

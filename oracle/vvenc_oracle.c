@@ -933,3 +933,170 @@ void orc_if_pred_luma(const int16_t *ref, int refStride, int16_t *dst, int dstSt
     orc_if_filter(Nh, 0, 1, 0, bitDepth, ref - 3 * refStride, refStride, tmp, width, width, height + 7, ch);
     orc_if_filter(Nv, 1, 0, rndRes, bitDepth, tmp + 3 * width, width, dst, dstStride, width, height, cv);
 }
+
+/* ================================================================================================
+ * SURVEY §8f rank 2 — MCTF apply side (motion-compensated bilateral temporal filter)   (MCTF.cpp)
+ * Float corners follow the reference's SCALAR row operation by operation (float / double mix as the
+ * C++ expressions promote); the reference's own unit test allows +-1 between its scalar and SIMD rows.
+ * ==============================================================================================*/
+/* applyFrac8Core_6Tap / _4Tap, MCTF.cpp:259-358: two passes, first pass NOT clipped (only truncated to Pel), second clipped. */
+void orc_mctf_apply_frac(int tap4, const int16_t *org, ptrdiff_t os, int16_t *dst, ptrdiff_t ds, int w, int h, int fx, int fy,
+                         int bitDepth)
+{
+    const int maxv = (1 << bitDepth) - 1;
+    static _Thread_local int16_t tmp[64 + 8][64];
+    if (tap4) {
+        const int16_t *xf = orc_mctf_filter4[fx], *yf = orc_mctf_filter4[fy];
+        for (int by = 0; by < h + 3; by++)
+            for (int bx = 0; bx < w; bx++) {
+                const int16_t *p = org + (by - 1) * os + bx - 1;
+                int sum = xf[0] * p[0] + xf[1] * p[1] + xf[2] * p[2] + xf[3] * p[3];
+                tmp[by][bx] = (int16_t)((sum + 32) >> 6);
+            }
+        for (int by = 0; by < h; by++)
+            for (int bx = 0; bx < w; bx++) {
+                int sum = yf[0] * tmp[by][bx] + yf[1] * tmp[by + 1][bx] + yf[2] * tmp[by + 2][bx] + yf[3] * tmp[by + 3][bx];
+                dst[by * ds + bx] = (int16_t)clip_pel((sum + 32) >> 6, maxv);
+            }
+    } else {
+        const int16_t *xf = orc_mctf_filter6[fx], *yf = orc_mctf_filter6[fy];
+        for (int by = 1; by < h + 6; by++)
+            for (int bx = 0; bx < w; bx++) {
+                const int16_t *p = org + (by - 3) * os + bx - 3;
+                int sum = 0;
+                for (int k = 1; k <= 6; k++) sum += xf[k] * p[k];
+                tmp[by][bx] = (int16_t)((sum + 32) >> 6);
+            }
+        for (int by = 0; by < h; by++)
+            for (int bx = 0; bx < w; bx++) {
+                int sum = 0;
+                for (int k = 1; k <= 6; k++) sum += yf[k] * tmp[by + k][bx];
+                dst[by * ds + bx] = (int16_t)clip_pel((sum + 32) >> 6, maxv);
+            }
+    }
+}
+
+/* applyPlanarCorrectionCore, MCTF.cpp:372-421 (w, h powers of two). */
+void orc_mctf_planar_correction(const int16_t *ref, ptrdiff_t rs, int16_t *dst, ptrdiff_t ds, int w, int h, int bitDepth,
+                                uint16_t motionError)
+{
+    static const int32_t xSzm[6] = { 0, 1, 20, 336, 5440, 87296 };
+    const int32_t blockSize = w * h, log2Width = ilog2(w), maxPel = (1 << bitDepth) - 1;
+    const uint32_t me2 = (uint32_t)motionError * (uint32_t)motionError;
+    const int32_t mWeight = (int32_t)(me2 < 512u ? me2 : 512u);
+    const int32_t xSum = (blockSize * (w - 1)) >> 1;
+    int32_t x1yzm = 0, x2yzm = 0, ySum = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int32_t z = dst[y * ds + x] - ref[y * rs + x];
+            x1yzm += x * z; x2yzm += y * z; ySum += z;
+        }
+    const int64_t denom = blockSize * xSzm[log2Width];
+    int64_t numer = (int64_t)mWeight * ((int64_t)x1yzm * blockSize - xSum * ySum);
+    int32_t b1 = (int32_t)((numer < 0 ? numer - (denom >> 1) : numer + (denom >> 1)) / denom);
+    b1 = b1 < INT16_MIN ? INT16_MIN : (b1 > INT16_MAX ? INT16_MAX : b1);
+    numer = (int64_t)mWeight * ((int64_t)x2yzm * blockSize - xSum * ySum);
+    int32_t b2 = (int32_t)((numer < 0 ? numer - (denom >> 1) : numer + (denom >> 1)) / denom);
+    b2 = b2 > INT16_MAX ? INT16_MAX : (b2 < INT16_MIN ? INT16_MIN : b2);
+    const int32_t b0 = (mWeight * ySum - (b1 + b2) * xSum + (blockSize >> 1)) >> (log2Width << 1);
+    if (b0 == 0 && b1 == 0 && b2 == 0) return;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int32_t p = (b0 + b1 * x + b2 * y + 256) >> 9;
+            const int32_t z = dst[y * ds + x] - p;
+            dst[y * ds + x] = (int16_t)(z < 0 ? 0 : (z > maxPel ? maxPel : z));
+        }
+}
+
+static float mctf_fast_exp(float n, float d)
+{   /* MCTF.cpp:359-367 */
+    float x = 1.0f + n / (d * 1024);
+    x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
+    return x;
+}
+
+/* applyBlockCore, MCTF.cpp:423-518.  corrected[i]: compact w x h blocks. */
+void orc_mctf_apply_block(const int16_t *src, ptrdiff_t ss, int16_t *dst, ptrdiff_t ds, int w, int h, int bitDepth,
+                          const int16_t *const *corrected, int numRefs, const int *verror, const double *refStrengths,
+                          double weightScaling, double sigmaSq)
+{
+    const int16_t maxv = (int16_t)((1 << bitDepth) - 1);
+    int vnoise[16] = { 0 };
+    float vsw[16] = { 0 }, vww[16] = { 0 };
+    int minError = INT32_MAX;
+    for (int i = 0; i < numRefs; i++) {
+        int64_t variance = 0, diffsum = 0;
+        const int16_t *ref = corrected[i];
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const int diff = src[y * ss + x] - ref[y * w + x];
+                variance += diff * diff;
+                if (x != w - 1) { const int dR = src[y * ss + x + 1] - ref[y * w + x + 1]; diffsum += (dR - diff) * (dR - diff); }
+                if (y != h - 1) { const int dD = src[(y + 1) * ss + x] - ref[(y + 1) * w + x]; diffsum += (dD - diff) * (dD - diff); }
+            }
+        variance *= (int64_t)1 << (2 * (10 - bitDepth));
+        diffsum *= (int64_t)1 << (2 * (10 - bitDepth));
+        const int cntV = w * h, cntD = 2 * cntV - w - h;
+        vnoise[i] = (int)round((15.0 * cntD / cntV * variance + 5.0) / (diffsum + 5.0));
+        minError = verror[i] < minError ? verror[i] : minError;
+    }
+    for (int i = 0; i < numRefs; i++) {
+        const int error = verror[i], noise = vnoise[i];
+        float ww = 1, sw = 1;
+        ww *= (noise < 25) ? 1.0 : 0.6;
+        sw *= (noise < 25) ? 1.0 : 0.8;
+        ww *= (error < 50) ? 1.2 : ((error > 100) ? 0.6 : 1.0);
+        sw *= (error < 50) ? 1.0 : 0.8;
+        ww *= ((minError + 1.0) / (error + 1.0));
+        vww[i] = ww * weightScaling * refStrengths[i];
+        vsw[i] = sw * 2 * sigmaSq;
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int16_t orgVal = src[y * ss + x];
+            float temporalWeightSum = 1.0;
+            float newVal = (float)orgVal;
+            for (int i = 0; i < numRefs; i++) {
+                const int refVal = corrected[i][y * w + x];
+                const int diff = refVal - orgVal;
+                const float diffSq = diff * diff;
+                float weight = vww[i] * mctf_fast_exp(-diffSq, vsw[i]);
+                newVal += weight * refVal;
+                temporalWeightSum += weight;
+            }
+            newVal /= temporalWeightSum;
+            int16_t sampleVal = (int16_t)(newVal + 0.5);
+            sampleVal = sampleVal < 0 ? 0 : (sampleVal > maxv ? maxv : sampleVal);
+            dst[y * ds + x] = sampleVal;
+        }
+}
+
+/* MCTF::bilateralFilter + xFinalizeBlkLine, MCTF.cpp:1399-1552, one component plane (csx = csy = 0 luma, 1 chroma of 4:2:0).
+ * org / refs[i]: sample (0,0) of planes with enough margin for the vectors; mvs[i]: the final-level motion field of reference i
+ * (mvW blocks per row); weightScaling / sigmaSq as xFinalizeBlkLine derives them for the component. */
+void orc_mctf_bilateral_plane(const int16_t *org, ptrdiff_t orgStride, int width, int height, int cs, int bitDepth, int unitSize,
+                              int lowResFltApply, int qp, int numRefs, const int16_t *const *refs, ptrdiff_t refStride,
+                              const orc_mv_t *const *mvs, int mvW, const double *refStrengths, double weightScaling, double sigmaSq,
+                              int16_t *out, ptrdiff_t outStride)
+{
+    const int blk = unitSize >> cs;
+    static _Thread_local int16_t bufs[16][64 * 64];
+    for (int by = 0, yb = 0; by < height; by += blk, yb++)
+        for (int bx = 0, xb = 0; bx < width; bx += blk, xb++) {
+            const int h = blk < height - by ? blk : height - by, w = blk < width - bx ? blk : width - bx;
+            const int16_t *corrected[16];
+            int verror[16];
+            for (int i = 0; i < numRefs; i++) {
+                const orc_mv_t *mv = &mvs[i][yb * mvW + xb];
+                const int dx = mv->x >> cs, dy = mv->y >> cs, xInt = mv->x >> (4 + cs), yInt = mv->y >> (4 + cs);
+                const int16_t *src = refs[i] + (ptrdiff_t)(by + yInt) * refStride + bx + xInt;
+                orc_mctf_apply_frac(lowResFltApply, src, refStride, bufs[i], w, w, h, dx & 15, dy & 15, bitDepth);
+                if (mv->rmsme > 0 && qp <= 32 && w == h && w <= 32)          /* "deblocking", :1473-1476 */
+                    orc_mctf_planar_correction(org + (ptrdiff_t)by * orgStride + bx, orgStride, bufs[i], w, w, h, bitDepth, (uint16_t)mv->rmsme);
+                corrected[i] = bufs[i];
+                verror[i] = mv->error;
+            }
+            orc_mctf_apply_block(org + (ptrdiff_t)by * orgStride + bx, orgStride, out + (ptrdiff_t)by * outStride + bx, outStride, w, h,
+                                 bitDepth, corrected, numRefs, verror, refStrengths, weightScaling, sigmaSq);
+        }
+}

@@ -69,6 +69,15 @@ void orc_if_copy(int isFirst, int isLast, int bitDepth, const int16_t *src, int 
 void orc_if_luma_1d(int vertical, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width, int height, int frac, int isFirst, int isLast, int bitDepth, int useAltHpelIf, int reduceTap);
 void orc_if_pred_luma(const int16_t *ref, int refStride, int16_t *dst, int dstStride, int width, int height, int xFrac, int yFrac, int rndRes, int bitDepth, int useAltHpelIf);
 
+/* MCTF apply (MCTF.cpp:259-518, 1399-1552) */
+void orc_mctf_apply_frac(int tap4, const int16_t *org, ptrdiff_t os, int16_t *dst, ptrdiff_t ds, int w, int h, int fx, int fy, int bitDepth);
+void orc_mctf_planar_correction(const int16_t *ref, ptrdiff_t rs, int16_t *dst, ptrdiff_t ds, int w, int h, int bitDepth, uint16_t motionError);
+void orc_mctf_apply_block(const int16_t *src, ptrdiff_t ss, int16_t *dst, ptrdiff_t ds, int w, int h, int bitDepth, const int16_t *const *corrected,
+                          int numRefs, const int *verror, const double *refStrengths, double weightScaling, double sigmaSq);
+void orc_mctf_bilateral_plane(const int16_t *org, ptrdiff_t orgStride, int width, int height, int cs, int bitDepth, int unitSize, int lowResFltApply,
+                              int qp, int numRefs, const int16_t *const *refs, ptrdiff_t refStride, const orc_mv_t *const *mvs, int mvW,
+                              const double *refStrengths, double weightScaling, double sigmaSq, int16_t *out, ptrdiff_t outStride);
+
 #ifdef __cplusplus
 }
 #endif

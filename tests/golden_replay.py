@@ -198,3 +198,17 @@ def _coeff(be, set_, p):
         from oracle.oracle import Oracle
         _COEFF_CACHE["o"] = Oracle()
     return _COEFF_CACHE["o"].if_coeff(set_, p)
+
+
+def check_mctf_apply(be):
+    """whole-picture bilateral temporal filter against the reference's scalar row, exact"""
+    g = load("mctf_apply")
+    for k, row in enumerate(g["cases"]):
+        w, h, bd, qp, low_res, nrefs = [int(v) for v in row[:6]]
+        ref_index = [int(v) for v in row[6:6 + nrefs]]
+        org = tuple(g["c%d_org%d" % (k, c)] for c in range(3))
+        refs = [tuple(g["c%d_ref%d_%d" % (k, i, c)] for c in range(3)) for i in range(nrefs)]
+        mvs = [g["c%d_mv%d" % (k, i)] for i in range(nrefs)]
+        out = be.mctf_bilateral(org, refs, mvs, ref_index, bd, qp, 16, bool(low_res), True, 0.95)
+        for c in range(3):
+            assert np.array_equal(out[c], g["c%d_out%d" % (k, c)]), ("mctf apply", k, c, int(np.abs(out[c].astype(np.int32) - g["c%d_out%d" % (k, c)]).max()))

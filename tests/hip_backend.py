@@ -73,6 +73,10 @@ class HipBackend:
         out = self.hp.fix_weighted_sse_batch(po, pc, d_it, d_w, 1, w, h)
         return int(out.cpu().numpy().view(np.uint64)[0])
 
+    # ---- MCTF apply ----
+    def mctf_bilateral(self, org, refs, mvs, ref_index, bit_depth=10, qp=32, unit=16, low_res=True, pic_reordering=True, overall_strength=0.95):
+        return self.hp.mctf_bilateral(org, refs, mvs, ref_index, bit_depth, qp, unit, low_res, pic_reordering, overall_strength)
+
     # ---- interpolation ----
     def _if_planes(self, src, w, h):
         import torch

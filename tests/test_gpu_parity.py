@@ -29,6 +29,10 @@ def test_golden_distortion_ext(hip):
     G.check_distortion_ext(hip)
 
 
+def test_golden_mctf_apply(hip):
+    G.check_mctf_apply(hip)
+
+
 def test_golden_interp(hip):
     G.check_interp(hip)
 
@@ -464,3 +468,29 @@ def test_subpel_candidates_vs_oracle(hip, oracle):
         for k, (_, _, rx, ry, _, _) in enumerate(pos):
             fx, fy = int(it[k]["frac_x"]), int(it[k]["frac_y"])
             assert np.array_equal(pred[k], oracle.if_pred_luma((ref, ry, rx), w, h, fx, fy, False, 10, False)), ("bi", w, h, fx, fy)
+
+
+def test_mctf_apply_1080p_vs_oracle(hip, oracle):
+    """SURVEY 8f rank 2 at BASELINE size: device motion estimation -> device bilateral filter (luma + 4:2:0 chroma) equals the oracle fed
+    with the same motion fields; all float corners included (exact)"""
+    import torch
+    from vvenc_amd.workload import synth_frame_pair
+    hp = hip.hp
+    W, H = 1920, 1080
+    cur, ref = synth_frame_pair(W, H, 77)
+    refs_y = [ref, np.roll(ref, (1, -2), (0, 1))]
+    def yuv(y):
+        return (y, np.clip(y[::2, ::2] // 2 + 256, 0, 1023).astype(np.int16), np.clip(1023 - y[::2, ::2] // 3, 0, 1023).astype(np.int16))
+    org = yuv(cur)
+    refs = [yuv(r) for r in refs_y]
+    pc = hp.plane(cur, 128)
+    prs = [hp.plane(r, 128) for r in refs_y]
+    outs, dims = hp.mctf_motion_estimation(pc, prs, 10, 16, 4, True)
+    mvs = [o.cpu().numpy().view(np.uint8).reshape(-1) for o in outs]
+    from vvenc_amd.hotpath import MV_DTYPE
+    mvs = [m.view(MV_DTYPE) for m in mvs]
+    got = hp.mctf_bilateral(org, refs, mvs, [0, 1], 10, 32, 16, True, True, 0.95)
+    exp = oracle.mctf_bilateral(org, refs, mvs, [0, 1], 10, 32, 16, True, True, 0.95)
+    for c in range(3):
+        assert np.array_equal(got[c], exp[c]), (c, int(np.abs(got[c].astype(np.int32) - exp[c]).max()))
+        assert not np.array_equal(got[c], org[c])

@@ -41,3 +41,7 @@ def test_mctf_me(oracle):
 
 def test_interp(oracle):
     G.check_interp(oracle)
+
+
+def test_mctf_apply(oracle):
+    G.check_mctf_apply(oracle)

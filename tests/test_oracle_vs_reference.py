@@ -384,3 +384,81 @@ def test_if_luma_dispatch_and_prediction(oracle, reflib):
                         a = oracle.if_pred_luma((pl, 20, 16), w, h, xf, yf, rnd, bd, alt)
                         b = reflib.if_pred_luma((pl, 20, 16), w, h, xf, yf, rnd, bd, alt)
                         assert np.array_equal(a, b), ("pred", bd, w, h, xf, yf, alt, rnd)
+
+
+# ---------------------------------------------------------------- MCTF apply side ----
+def _mctf_tol(reflib):
+    """the reference's own unit test holds its SIMD row to +-1 of the scalar row for the float bilateral filter (vvenc_unit_test.cpp:1280-1282);
+    the oracle restates the SCALAR row and must match it exactly"""
+    return 1 if reflib.simd else 0
+
+
+def test_mctf_apply_frac_and_planar(oracle, reflib):
+    rng = np.random.default_rng(91)
+    for bd in (8, 10):
+        plane = rng.integers(0, 1 << bd, size=(120, 160)).astype(np.int16)
+        # the x86 rows are written for the block shapes the filter produces (unit 16 -> 16/8 wide, picture-edge remainders in steps of 4)
+        for (w, h) in ((16, 16), (8, 8), (16, 8), (8, 4), (4, 4)) + (() if reflib.simd else ((12, 16), (8, 3), (32, 32))):
+            for tap4 in (False, True):
+                for (fx, fy) in ((0, 0), (8, 8), (3, 13), (15, 1), (0, 5), (11, 0)):
+                    for chroma in (False, True):
+                        if reflib.simd and not tap4 and w % (4 if chroma else 8):
+                            continue          # m_applyFrac[luma][0] is the 8-column AVX2/SSE core, [chroma][0] the 4-column one (MCTFX86.h:1497-1498)
+                        a = oracle.mctf_apply_frac(tap4, (plane, 30, 40), w, h, fx, fy, bd)
+                        b = reflib.mctf_apply_frac(tap4, (plane, 30, 40), w, h, fx, fy, bd, chroma)
+                        assert np.array_equal(a, b), ("applyFrac", bd, w, h, tap4, fx, fy, chroma)
+        for (w, h) in ((4, 4), (8, 8), (16, 16), (32, 32)):
+            for me in (1, 7, 22, 40, 300):
+                blk = np.clip(plane[30:30 + h, 40:40 + w].astype(np.int32) + rng.integers(-20, 21, (h, w)) + np.arange(w)[None, :] * 2 - np.arange(h)[:, None], 0, (1 << bd) - 1)
+                a = oracle.mctf_planar_correction((plane, 30, 40), blk.astype(np.int16), w, h, bd, me)
+                b = reflib.mctf_planar_correction((plane, 30, 40), blk.astype(np.int16), w, h, bd, me)
+                assert np.array_equal(a, b), ("planar", bd, w, h, me)
+
+
+def test_mctf_apply_block(oracle, reflib):
+    rng = np.random.default_rng(92)
+    tol = _mctf_tol(reflib)
+    worst = 0
+    for bd in (8, 10):
+        plane = rng.integers(0, 1 << bd, size=(96, 128)).astype(np.int16)
+        for (w, h) in ((16, 16), (8, 8), (16, 6), (4, 4)):
+            for nrefs in (1, 2, 4, 8):
+                src = (plane, 20, 24)
+                base = plane[20:20 + h, 24:24 + w].astype(np.int32)
+                corrected = [np.clip(base + rng.integers(-s_, s_ + 1, (h, w)), 0, (1 << bd) - 1).astype(np.int16) for s_ in rng.integers(1, 60, nrefs)]
+                verror = rng.integers(0, 200, nrefs)
+                strengths = [oracle.REF_STRENGTHS[0][k % 6] for k in range(nrefs)]
+                for qp in (22, 32, 44):
+                    sigma, scaling = oracle.mctf_filter_params(qp, bd, 0.95, False)
+                    a = oracle.mctf_apply_block(src, corrected, verror, strengths, scaling, sigma, w, h, bd)
+                    b = reflib.mctf_apply_block(src, corrected, verror, strengths, scaling, sigma, w, h, bd)
+                    d = int(np.abs(a.astype(np.int32) - b).max())
+                    worst = max(worst, d)
+                    assert d <= tol, ("applyBlock", bd, w, h, nrefs, qp, d)
+    print("max |oracle - reference| =", worst)
+
+
+def test_mctf_bilateral_picture(oracle, reflib):
+    """whole-picture MCTF::bilateralFilter on 4:2:0 planes with the motion fields of the (already pinned) hierarchical ME"""
+    from oracle.oracle import MV_DTYPE
+    rng = np.random.default_rng(93)
+    tol = _mctf_tol(reflib)
+    for (w, h, bd, qp, low_res) in ((96, 64, 10, 32, True), (80, 48, 8, 27, False), (64, 64, 10, 40, True)):
+        yy, xx = np.mgrid[0:h + 16, 0:w + 16]
+        base = (512 + 200 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 90 * np.sin((xx + yy) / 5.0)) * ((1 << bd) / 1024.0)
+        def pic(dx, dy, noise):
+            y = np.clip(base[8 + dy:8 + dy + h, 8 + dx:8 + dx + w] + rng.normal(0, noise, (h, w)), 0, (1 << bd) - 1).astype(np.int16)
+            u = np.clip(y[::2, ::2] // 2 + (1 << (bd - 2)), 0, (1 << bd) - 1).astype(np.int16)
+            v = np.clip((1 << bd) - 1 - y[::2, ::2] // 3, 0, (1 << bd) - 1).astype(np.int16)
+            return y, u, v
+        org = pic(0, 0, 4)
+        refs = [pic(1, 0, 4), pic(-1, 1, 5), pic(2, -1, 4), pic(-2, 0, 6)]
+        ref_index = [0, 0, 1, 1]
+        mvs = [oracle.mctf_me(org[0], r[0], bd, 16, 4, False)[4].ravel() for r in refs]
+        assert all(m.dtype == MV_DTYPE for m in mvs)
+        a = oracle.mctf_bilateral(org, refs, mvs, ref_index, bd, qp, 16, low_res, True, 0.95)
+        b = reflib.mctf_bilateral(org, refs, mvs, ref_index, bd, qp, 16, low_res, True, 0.95)
+        for c in range(3):
+            d = int(np.abs(a[c].astype(np.int32) - b[c]).max())
+            assert d <= tol, ("bilateral", w, h, bd, c, d)
+            assert not np.array_equal(a[c], org[c])        # the filter did something

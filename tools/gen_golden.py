@@ -116,6 +116,41 @@ def gen_interp(R, R0):
     np.savez_compressed(os.path.join(OUT, "interp.npz"), **d)
 
 
+def gen_mctf_apply(R, R0):
+    """SURVEY 8f rank 2: whole-picture MCTF::bilateralFilter outputs of the reference's SCALAR row (the x86 row is held to +-1 of it by the
+    reference's own unit test; here they agree exactly, asserted) -> mctf_apply.npz"""
+    from oracle.oracle import Oracle
+    O = Oracle()          # only for the (pinned) motion fields that feed the filter
+    rng = np.random.default_rng(20260926)
+    d = {}
+    cases = []
+    for k, (w, h, bd, qp, low_res, nrefs) in enumerate(((96, 64, 10, 32, 1, 4), (80, 48, 8, 27, 0, 2), (128, 72, 10, 40, 1, 4), (64, 64, 10, 22, 0, 3))):
+        yy, xx = np.mgrid[0:h + 16, 0:w + 16]
+        base = (512 + 200 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 90 * np.sin((xx + yy) / 5.0)) * ((1 << bd) / 1024.0)
+        def pic(dx, dy, noise):
+            y = np.clip(base[8 + dy:8 + dy + h, 8 + dx:8 + dx + w] + rng.normal(0, noise, (h, w)), 0, (1 << bd) - 1).astype(np.int16)
+            u = np.clip(y[::2, ::2] // 2 + (1 << (bd - 2)), 0, (1 << bd) - 1).astype(np.int16)
+            v = np.clip((1 << bd) - 1 - y[::2, ::2] // 3, 0, (1 << bd) - 1).astype(np.int16)
+            return y, u, v
+        org = pic(0, 0, 4)
+        refs = [pic(*m, n) for m, n in (((1, 0), 4), ((-1, 1), 5), ((2, -1), 4), ((-2, 0), 6))[:nrefs]]
+        ref_index = [0, 0, 1, 1][:nrefs]
+        mvs = [O.mctf_me(org[0], r[0], bd, 16, 4, False)[4].ravel() for r in refs]
+        out0 = R0.mctf_bilateral(org, refs, mvs, ref_index, bd, qp, 16, bool(low_res), True, 0.95)
+        out1 = R.mctf_bilateral(org, refs, mvs, ref_index, bd, qp, 16, bool(low_res), True, 0.95)
+        for c in range(3):
+            assert np.abs(out0[c].astype(np.int32) - out1[c]).max() <= 1
+            d["c%d_org%d" % (k, c)] = org[c]
+            d["c%d_out%d" % (k, c)] = out0[c]
+            for i, r in enumerate(refs):
+                d["c%d_ref%d_%d" % (k, i, c)] = r[c]
+        for i, m in enumerate(mvs):
+            d["c%d_mv%d" % (k, i)] = m
+        cases.append((w, h, bd, qp, low_res, nrefs) + tuple(ref_index) + (0,) * (4 - nrefs))
+    d["cases"] = np.array(cases, np.int32)
+    np.savez_compressed(os.path.join(OUT, "mctf_apply.npz"), **d)
+
+
 def main():
     build_ref()
     R = RefLib(1)
@@ -123,6 +158,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     gen_distortion_ext(R, R0)
     gen_interp(R, R0)
+    gen_mctf_apply(R, R0)
     if "--ext-only" in sys.argv:
         return
     rng = np.random.default_rng(20260923)

@@ -1,0 +1,264 @@
+// mctfapply.hip — SURVEY §8f rank 2: the apply side of the motion-compensated temporal pre-filter.
+//
+// Reference behaviour (scalar row, followed operation by operation — the float corners keep the C++ promotions of the source):
+//   applyFrac8Core_6Tap / _4Tap       CommonLib/MCTF.cpp:259-358   (first pass truncated to Pel, NOT clipped; second pass clipped)
+//   applyPlanarCorrectionCore         :372-421                     (fixed-point plane fit of the compensation error, "deblocking")
+//   applyBlockCore                    :423-518                     (noise estimate, per-reference weights, bilateral blend with fastExp :359-367)
+//   MCTF::xFinalizeBlkLine            :1399-1487                   (per block: compensate every reference, correct, blend)
+//   MCTF::bilateralFilter             :1489-1552                   (sigma / strength per channel, all block rows)
+// The reference's unit test allows +-1 between its scalar and x86 rows here (test/vvenc_unit_test/vvenc_unit_test.cpp:1280-1282); this
+// kernel equals the scalar row (IEEE float/double, no contraction: -ffp-contract=off, correctly rounded division).
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+__constant__ int16_t cApply6[16][8] = {      // MCTF::m_interpolationFilter8 (MCTF.cpp:72-90), taps 1..6 are used
+  { 0, 0, 0, 64, 0, 0, 0, 0 },    { 0, 1, -3, 64, 4, -2, 0, 0 },    { 0, 1, -6, 62, 9, -3, 1, 0 },    { 0, 2, -8, 60, 14, -5, 1, 0 },
+  { 0, 2, -9, 57, 19, -7, 2, 0 }, { 0, 3, -10, 53, 24, -8, 2, 0 },  { 0, 3, -11, 50, 29, -9, 2, 0 },  { 0, 3, -11, 44, 35, -10, 3, 0 },
+  { 0, 1, -7, 38, 38, -7, 1, 0 }, { 0, 3, -10, 35, 44, -11, 3, 0 }, { 0, 2, -9, 29, 50, -11, 3, 0 },  { 0, 2, -8, 24, 53, -10, 3, 0 },
+  { 0, 2, -7, 19, 57, -9, 2, 0 }, { 0, 1, -5, 14, 60, -8, 2, 0 },   { 0, 1, -3, 9, 62, -6, 1, 0 },    { 0, 0, -2, 4, 64, -3, 1, 0 } };
+__constant__ int16_t cApply4[16][4] = {      // MCTF::m_interpolationFilter4 (MCTF.cpp:92-110)
+  { 0, 64, 0, 0 },    { -2, 62, 4, 0 },   { -2, 58, 10, -2 }, { -4, 56, 14, -2 }, { -4, 54, 16, -2 }, { -6, 52, 20, -2 }, { -6, 46, 28, -4 }, { -4, 42, 30, -4 },
+  { -4, 36, 36, -4 }, { -4, 30, 42, -4 }, { -4, 28, 46, -6 }, { -2, 20, 52, -6 }, { -2, 16, 54, -4 }, { -2, 14, 56, -4 }, { -2, 10, 58, -2 }, { 0, 4, 62, -2 } };
+
+constexpr int MAX_REFS = 12;     // 2 * VVENC_MCTF_RANGE
+constexpr int MAX_BLK  = 32;     // unit sizes 8/16/32 (luma), halves for 4:2:0 chroma
+
+struct ApplyArgs
+{
+  const int16_t* refs[MAX_REFS];
+  const vvhip_mv* mvs[MAX_REFS];
+  double refStrengths[MAX_REFS];
+  double weightScaling, sigmaSq;
+  int numRefs, cs, bitDepth, blk, lowRes, qp, mvW, width, height;
+};
+
+__device__ __forceinline__ float fastExp( float n, float d )     // MCTF.cpp:359-367
+{
+  float x = 1.0f + n / ( d * 1024 );
+  x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
+  return x;
+}
+
+__global__ void __launch_bounds__( 256 )
+mctfApplyKernel( const int16_t* __restrict__ org, int orgStride, int refStride, int16_t* __restrict__ out, int outStride, ApplyArgs A )
+{
+  __shared__ int16_t sCorr[MAX_REFS][MAX_BLK * MAX_BLK / 4];     // sized for blocks up to 16x16 (256 samples) per reference; see host check
+  __shared__ int16_t sTmp[( 16 + 7 ) * 16];
+  __shared__ long long sSum[4];                                  // block sums (planar: x*z, y*z, z; noise: variance, diffsum)
+  __shared__ int sB[3];
+  __shared__ int sNoise[MAX_REFS], sErr[MAX_REFS];
+
+  const int blk = A.blk, bxI = blockIdx.x, byI = blockIdx.y;
+  const int bx = bxI * blk, by = byI * blk;
+  const int w = min( blk, A.width - bx ), h = min( blk, A.height - by );
+  const int tid = threadIdx.x, nThr = blockDim.x, lane = tid & 63;
+  const int maxv = ( 1 << A.bitDepth ) - 1;
+  const int16_t* orgBlk = org + ( ptrdiff_t ) by * orgStride + bx;
+
+  for( int i = 0; i < A.numRefs; i++ )
+  {
+    const vvhip_mv mv = A.mvs[i][byI * A.mvW + bxI];
+    const int dx = mv.x >> A.cs, dy = mv.y >> A.cs, xInt = mv.x >> ( 4 + A.cs ), yInt = mv.y >> ( 4 + A.cs );
+    const int16_t* src = A.refs[i] + ( ptrdiff_t ) ( by + yInt ) * refStride + bx + xInt;
+    // ---- applyFrac: horizontal pass into sTmp (Pel truncation, no clip), vertical pass into sCorr[i] (clip)
+    if( A.lowRes )
+    {
+      const int16_t* xf = cApply4[dx & 15]; const int16_t* yf = cApply4[dy & 15];
+      for( int e = tid; e < ( h + 3 ) * w; e += nThr )
+      {
+        const int r = e / w, x = e - r * w;
+        const int16_t* p = src + ( ptrdiff_t ) ( r - 1 ) * refStride + x - 1;
+        const int sum = xf[0] * p[0] + xf[1] * p[1] + xf[2] * p[2] + xf[3] * p[3];
+        sTmp[r * w + x] = ( int16_t ) ( ( sum + 32 ) >> 6 );
+      }
+      __syncthreads();
+      for( int e = tid; e < h * w; e += nThr )
+      {
+        const int y = e / w, x = e - y * w;
+        const int sum = yf[0] * sTmp[y * w + x] + yf[1] * sTmp[( y + 1 ) * w + x] + yf[2] * sTmp[( y + 2 ) * w + x] + yf[3] * sTmp[( y + 3 ) * w + x];
+        const int v = ( sum + 32 ) >> 6;
+        sCorr[i][e] = ( int16_t ) ( v < 0 ? 0 : ( v > maxv ? maxv : v ) );
+      }
+    }
+    else
+    {
+      const int16_t* xf = cApply6[dx & 15]; const int16_t* yf = cApply6[dy & 15];
+      for( int e = tid; e < ( h + 5 ) * w; e += nThr )       // rows 1 .. h+5 of the reference's temp array <-> source rows -2 .. h+2
+      {
+        const int r = e / w + 1, x = e - ( r - 1 ) * w;
+        const int16_t* p = src + ( ptrdiff_t ) ( r - 3 ) * refStride + x - 3;
+        int sum = 0;
+#pragma unroll
+        for( int k = 1; k <= 6; k++ ) sum += xf[k] * p[k];
+        sTmp[r * w + x] = ( int16_t ) ( ( sum + 32 ) >> 6 );
+      }
+      __syncthreads();
+      for( int e = tid; e < h * w; e += nThr )
+      {
+        const int y = e / w, x = e - y * w;
+        int sum = 0;
+#pragma unroll
+        for( int k = 1; k <= 6; k++ ) sum += yf[k] * sTmp[( y + k ) * w + x];
+        const int v = ( sum + 32 ) >> 6;
+        sCorr[i][e] = ( int16_t ) ( v < 0 ? 0 : ( v > maxv ? maxv : v ) );
+      }
+    }
+    if( tid < 4 ) sSum[tid] = 0;
+    __syncthreads();
+    // ---- planar correction of the compensated block (MCTF.cpp:1473-1476)
+    if( mv.rmsme > 0 && A.qp <= 32 && w == h && w <= 32 )
+    {
+      int x1 = 0, x2 = 0, ys = 0;
+      for( int e = tid; e < h * w; e += nThr )
+      {
+        const int y = e / w, x = e - y * w;
+        const int z = ( int ) sCorr[i][e] - ( int ) orgBlk[( ptrdiff_t ) y * orgStride + x];
+        x1 += x * z; x2 += y * z; ys += z;
+      }
+      // sums fit int32 (|z| < 2^12, x < 32, <= 1024 samples); add as sign-extended 64-bit through LDS atomics
+      atomicAdd( ( unsigned long long* ) &sSum[0], ( unsigned long long ) ( long long ) x1 );
+      atomicAdd( ( unsigned long long* ) &sSum[1], ( unsigned long long ) ( long long ) x2 );
+      atomicAdd( ( unsigned long long* ) &sSum[2], ( unsigned long long ) ( long long ) ys );
+      __syncthreads();
+      if( tid == 0 )
+      {
+        const int xSzm[6] = { 0, 1, 20, 336, 5440, 87296 };
+        const int blockSize = w * h; int log2Width = 0; while( ( 2 << log2Width ) <= w ) log2Width++;
+        const unsigned me2 = ( unsigned ) ( uint16_t ) mv.rmsme * ( unsigned ) ( uint16_t ) mv.rmsme;
+        const int mWeight = ( int ) ( me2 < 512u ? me2 : 512u );
+        const int xSum = ( blockSize * ( w - 1 ) ) >> 1;
+        const int x1yzm = ( int ) sSum[0], x2yzm = ( int ) sSum[1], ySum = ( int ) sSum[2];
+        const long long denom = ( long long ) blockSize * xSzm[log2Width];
+        long long numer = ( long long ) mWeight * ( ( long long ) x1yzm * blockSize - xSum * ySum );
+        int b1 = ( int ) ( ( numer < 0 ? numer - ( denom >> 1 ) : numer + ( denom >> 1 ) ) / denom );
+        b1 = b1 < -32768 ? -32768 : ( b1 > 32767 ? 32767 : b1 );
+        numer = ( long long ) mWeight * ( ( long long ) x2yzm * blockSize - xSum * ySum );
+        int b2 = ( int ) ( ( numer < 0 ? numer - ( denom >> 1 ) : numer + ( denom >> 1 ) ) / denom );
+        b2 = b2 > 32767 ? 32767 : ( b2 < -32768 ? -32768 : b2 );
+        sB[0] = ( mWeight * ySum - ( b1 + b2 ) * xSum + ( blockSize >> 1 ) ) >> ( log2Width << 1 );
+        sB[1] = b1; sB[2] = b2;
+        sSum[0] = 0; sSum[1] = 0; sSum[2] = 0;
+      }
+      __syncthreads();
+      const int b0 = sB[0], b1 = sB[1], b2 = sB[2];
+      if( b0 != 0 || b1 != 0 || b2 != 0 )
+        for( int e = tid; e < h * w; e += nThr )
+        {
+          const int y = e / w, x = e - y * w;
+          const int p = ( b0 + b1 * x + b2 * y + 256 ) >> 9;
+          const int z = ( int ) sCorr[i][e] - p;
+          sCorr[i][e] = ( int16_t ) ( z < 0 ? 0 : ( z > maxv ? maxv : z ) );
+        }
+      __syncthreads();
+    }
+    // ---- noise estimate of reference i (MCTF.cpp:445-477)
+    {
+      long long variance = 0, diffsum = 0;
+      for( int e = tid; e < h * w; e += nThr )
+      {
+        const int y = e / w, x = e - y * w;
+        const int diff = ( int ) orgBlk[( ptrdiff_t ) y * orgStride + x] - ( int ) sCorr[i][e];
+        variance += diff * diff;
+        if( x != w - 1 ) { const int dR = ( int ) orgBlk[( ptrdiff_t ) y * orgStride + x + 1] - ( int ) sCorr[i][e + 1]; diffsum += ( dR - diff ) * ( dR - diff ); }
+        if( y != h - 1 ) { const int dD = ( int ) orgBlk[( ptrdiff_t ) ( y + 1 ) * orgStride + x] - ( int ) sCorr[i][e + w]; diffsum += ( dD - diff ) * ( dD - diff ); }
+      }
+      atomicAdd( ( unsigned long long* ) &sSum[0], ( unsigned long long ) variance );
+      atomicAdd( ( unsigned long long* ) &sSum[1], ( unsigned long long ) diffsum );
+      __syncthreads();
+      if( tid == 0 )
+      {
+        long long var = sSum[0], dsum = sSum[1];
+        var  *= ( long long ) 1 << ( 2 * ( 10 - A.bitDepth ) );
+        dsum *= ( long long ) 1 << ( 2 * ( 10 - A.bitDepth ) );
+        const int cntV = w * h, cntD = 2 * cntV - w - h;
+        sNoise[i] = ( int ) round( ( 15.0 * cntD / cntV * var + 5.0 ) / ( dsum + 5.0 ) );
+        sErr[i] = mv.error;
+      }
+      __syncthreads();
+    }
+    ( void ) lane;
+  }
+
+  // ---- per-reference weights (every thread evaluates the same scalar expressions) and the blend (MCTF.cpp:479-517)
+  int minError = 0x7fffffff;
+  for( int i = 0; i < A.numRefs; i++ ) minError = sErr[i] < minError ? sErr[i] : minError;
+  float vww[MAX_REFS], vsw[MAX_REFS];
+#pragma unroll
+  for( int i = 0; i < MAX_REFS; i++ )
+  {
+    vww[i] = 0.0f; vsw[i] = 1.0f;
+    if( i < A.numRefs )
+    {
+      const int error = sErr[i], noise = sNoise[i];
+      float ww = 1, sw = 1;
+      ww *= ( noise < 25 ) ? 1.0 : 0.6;
+      sw *= ( noise < 25 ) ? 1.0 : 0.8;
+      ww *= ( error < 50 ) ? 1.2 : ( ( error > 100 ) ? 0.6 : 1.0 );
+      sw *= ( error < 50 ) ? 1.0 : 0.8;
+      ww *= ( ( minError + 1.0 ) / ( error + 1.0 ) );
+      vww[i] = ww * A.weightScaling * A.refStrengths[i];
+      vsw[i] = sw * 2 * A.sigmaSq;
+    }
+  }
+  for( int e = tid; e < h * w; e += nThr )
+  {
+    const int y = e / w, x = e - y * w;
+    const int16_t orgVal = orgBlk[( ptrdiff_t ) y * orgStride + x];
+    float temporalWeightSum = 1.0;
+    float newVal = ( float ) orgVal;
+#pragma unroll
+    for( int i = 0; i < MAX_REFS; i++ )
+      if( i < A.numRefs )
+      {
+        const int refVal = sCorr[i][e];
+        const int diff = refVal - orgVal;
+        const float diffSq = diff * diff;
+        const float weight = vww[i] * fastExp( -diffSq, vsw[i] );
+        newVal += weight * refVal;
+        temporalWeightSum += weight;
+      }
+    newVal /= temporalWeightSum;
+    int16_t sampleVal = ( int16_t ) ( newVal + 0.5 );
+    sampleVal = sampleVal < 0 ? ( int16_t ) 0 : ( sampleVal > maxv ? ( int16_t ) maxv : sampleVal );
+    out[( ptrdiff_t ) ( by + y ) * outStride + bx + x] = sampleVal;
+  }
+}
+
+} // namespace
+
+extern "C" {
+
+int vvhip_mctf_apply_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, int width, int height, int chroma_shift, int bit_depth, int unit_size,
+                            int low_res_flt_apply, int qp, int num_refs, const int16_t* const* d_refs, int ref_stride, const vvhip_mv* const* d_mvs, int mv_w,
+                            const double* ref_strengths, double weight_scaling, double sigma_sq, int16_t* d_out, int out_stride )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  const int blk = unit_size >> chroma_shift;
+  if( !d_org || !d_out || !d_refs || !d_mvs || !ref_strengths || width < 1 || height < 1 || chroma_shift < 0 || chroma_shift > 1 || bit_depth < 8 || bit_depth > 12 ||
+      num_refs < 1 || num_refs > MAX_REFS || blk < 4 || blk > 16 || ( blk & ( blk - 1 ) ) || mv_w < ( width + blk - 1 ) / blk )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_apply_plane: %dx%d unit %d shift %d refs %d (unit >> shift must be 4, 8 or 16; <= %d references)", width, height, unit_size,
+                       chroma_shift, num_refs, MAX_REFS );
+  ApplyArgs a;
+  for( int i = 0; i < MAX_REFS; i++ ) { a.refs[i] = i < num_refs ? d_refs[i] : nullptr; a.mvs[i] = i < num_refs ? d_mvs[i] : nullptr; a.refStrengths[i] = i < num_refs ? ref_strengths[i] : 0.0; }
+  a.weightScaling = weight_scaling; a.sigmaSq = sigma_sq; a.numRefs = num_refs; a.cs = chroma_shift; a.bitDepth = bit_depth; a.blk = blk; a.lowRes = low_res_flt_apply ? 1 : 0;
+  a.qp = qp; a.mvW = mv_w; a.width = width; a.height = height;
+  const dim3 grid( ( width + blk - 1 ) / blk, ( height + blk - 1 ) / blk );
+  hipLaunchKernelGGL( mctfApplyKernel, grid, dim3( blk * blk < 64 ? 64 : blk * blk ), 0, ctx->stream, d_org, org_stride, ref_stride, d_out, out_stride, a );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+int vvhip_mctf_filter_params( int qp, int bit_depth, double overall_strength, int is_chroma, double* sigma_sq, double* weight_scaling )
+{
+  if( !sigma_sq || !weight_scaling || bit_depth < 8 || bit_depth > 16 ) return VVHIP_E_ARG;
+  const double lumaSigmaSq = 9.0 * ( 128.0 + 3.0 / 256.0 * qp * qp * qp );          // MCTF.cpp:68,1491 (m_sigmaMultiplier 9.0)
+  const double chromaSigmaSq = 30 * 30;
+  const double bitDepthDiffWeighting = 1024.0 / ( double ) ( 1 << bit_depth );      // :1498-1499
+  *sigma_sq = ( is_chroma ? chromaSigmaSq : lumaSigmaSq ) / ( bitDepthDiffWeighting * bitDepthDiffWeighting );
+  *weight_scaling = overall_strength * ( is_chroma ? 0.55 : 0.4 );                  // :67,1417 (m_chromaFactor 0.55)
+  return VVHIP_OK;
+}
+
+} // extern "C"

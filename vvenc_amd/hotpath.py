@@ -251,6 +251,42 @@ class HotPath:
             jobs = self.make_tu_jobs(jobs)
         self._ck(self.L.vvhip_tu_rdo_multi(self.ctx, resi.buf_ptr, resi.stride, bit_depth, jobs[0], jobs[1]))
 
+    # ---- MCTF apply side ----
+    REF_STRENGTHS = ((0.84375, 0.6, 0.4286, 0.3333, 0.2727, 0.2308), (1.12500, 1.0, 0.7143, 0.5556, 0.4545, 0.3846))      # MCTF.cpp:112-117
+
+    def mctf_filter_params(self, qp, bit_depth, overall_strength, chroma):
+        s, w = C.c_double(), C.c_double()
+        self._ck(self.L.vvhip_mctf_filter_params(qp, bit_depth, overall_strength, int(chroma), C.byref(s), C.byref(w)))
+        return s.value, w.value
+
+    def mctf_apply_plane(self, org, refs, d_mvs, mv_w, chroma_shift, ref_strengths, weight_scaling, sigma_sq, bit_depth=10, unit=16, low_res=True, qp=32, out=None):
+        """bilateral temporal filter of one plane: org / refs are Planes (same stride), d_mvs a list of device motion fields (MV_DTYPE records)"""
+        if out is None:
+            out = Plane(self.device, org.width, org.height, 0)
+        assert all(r.stride == refs[0].stride for r in refs)
+        rp = (C.c_void_p * len(refs))(*[r.buf_ptr.value for r in refs])
+        mp = (C.c_void_p * len(refs))(*[m.data_ptr() for m in d_mvs])
+        rs = (C.c_double * len(refs))(*[float(x) for x in ref_strengths])
+        self._ck(self.L.vvhip_mctf_apply_plane(self.ctx, org.buf_ptr, org.stride, org.width, org.height, chroma_shift, bit_depth, unit, int(low_res), qp, len(refs),
+                                               rp, refs[0].stride, mp, mv_w, rs, weight_scaling, sigma_sq, out.buf_ptr, out.stride))
+        return out
+
+    def mctf_bilateral(self, org_yuv, refs_yuv, mvs_np, ref_index, bit_depth=10, qp=32, unit=16, low_res=True, pic_reordering=True, overall_strength=0.95):
+        """MCTF::bilateralFilter on 4:2:0 numpy planes (uploads with the reference's margins); returns numpy (Y, U, V)"""
+        h, w = org_yuv[0].shape
+        mv_w = (w + unit - 1) // unit
+        d_mvs = [self.to_device(np.ascontiguousarray(m)) for m in mvs_np]
+        strengths = [self.REF_STRENGTHS[0 if pic_reordering else 1][k] for k in ref_index]
+        outs = []
+        for c in range(3):
+            cs = 1 if c else 0
+            po = self.plane(org_yuv[c], 128 >> cs)
+            prs = [self.plane(r[c], 128 >> cs) for r in refs_yuv]
+            sigma, scaling = self.mctf_filter_params(qp, bit_depth, overall_strength, c > 0)
+            o = self.mctf_apply_plane(po, prs, d_mvs, mv_w, cs, strengths, scaling, sigma, bit_depth, unit, low_res, qp)
+            outs.append(o.visible().cpu().numpy())
+        return tuple(outs)
+
     # ---- SURVEY 8f rank 1: sub-pel interpolation ----
     def if_filter(self, taps, vertical, first, last, bit_depth, d_src, src_off, src_stride, d_dst, dst_off, dst_stride, w, h, coeff):
         """one pass on one block with the caller's taps (InterpolationFilter::m_filterHor / m_filterVer slot)"""
