@@ -50,6 +50,8 @@ patch("MCTF.cpp", [
     ("before", "    Array2D<MotionVector> mv_0(width / (m_mctfUnitSize * 8) + 1, height / (m_mctfUnitSize * 8) + 1);",
      "    if( !( g_vvhipHooks.mctfMe && g_vvhipHooks.mctfMe( this, srcPic.picBuffer, origBuf, srcPic.mvs, addLevel ) ) )\n    {\n"),
     ("after", "    motionEstimationLuma(srcPic.mvs, origBuf, srcPic.picBuffer, m_mctfUnitSize, &mv_2, 1, true);\n", "    }\n"),
+    ("before", "  const double lumaSigmaSq = m_sigmaMultiplier * ( 128.0 + 3.0 / 256.0 * m_encCfg->m_QP * m_encCfg->m_QP * m_encCfg->m_QP );",
+     "  if( g_vvhipHooks.mctfApply && g_vvhipHooks.mctfApply( this, orgPic, &srcFrameInfo, newOrgPic, overallStrength ) ) return;\n"),
 ])
 patch("InterpolationFilter.cpp", [
     ("after", '#include "InterpolationFilter.h"', INC),

@@ -50,14 +50,14 @@
 #include "hip_hooks.h"
 #include "../../vvenc_amd/csrc/host/vvenc_hip_shim.h"
 
-VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 
 namespace {
 
 vvhip::RdCost*   g_rd = nullptr;
 vvhip::QuantOps* g_q  = nullptr;
 vvhip::MCTFOps*  g_m  = nullptr;
-std::atomic<uint64_t> g_calls[10];    // dist, x5, fwd, inv, quant, dequant, needrdoq, mctf, interpolation, (spare)
+std::atomic<uint64_t> g_calls[10];    // dist, x5, fwd, inv, quant, dequant, needrdoq, mctf, interpolation, whole-picture MCTF filter
 
 vvhip::DistParam conv( const vvenc::DistParam& dp )
 {
@@ -155,6 +155,42 @@ bool inv2D( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned w, un
   return true;
 }
 
+// whole MCTF::bilateralFilter (MCTF.cpp:1489-1552) on the GPU: every plane of the original and of the references is mirrored, the motion fields
+// the (CPU or GPU) search left in srcFrameInfo[i].mvs are uploaded, one launch per component plane
+bool mctfApply( const vvenc::MCTF* m, const vvenc::PelStorage& orgPic, void* infoDeque, vvenc::PelStorage& newOrgPic, double overallStrength )
+{
+  std::deque<vvenc::TemporalFilterSourcePicInfo>& info = *static_cast<std::deque<vvenc::TemporalFilterSourcePicInfo>*>( infoDeque );
+  const int nRefs = ( int ) info.size(), unit = m->m_mctfUnitSize;
+  const int numComp = ( int ) vvenc::getNumberValidComponents( m->m_encCfg->m_internChromaFormat );
+  if( nRefs < 1 || nRefs > 12 || ( unit != 8 && unit != 16 ) || ( numComp == 3 && m->m_encCfg->m_internChromaFormat != CHROMA_420 ) ) return false;
+  vvhip::Device& dev = vvhip::Device::get();
+  std::vector<int> orgIds( 3, -1 ), refIds( 3 * nRefs, -1 ), all;
+  auto reg = [&]( const vvenc::CPelBuf& b, int margin ) { const int id = dev.registerPicture( b.buf, ( int ) b.stride, b.width, b.height, margin ); all.push_back( id ); return id; };
+  for( int c = 0; c < numComp; c++ ) orgIds[c] = reg( orgPic.bufs[c], vvenc::MCTF_PADDING >> ( c ? 1 : 0 ) );
+  for( int r = 0; r < nRefs; r++ ) for( int c = 0; c < numComp; c++ ) refIds[3 * r + c] = reg( info[r].picBuffer.bufs[c], vvenc::MCTF_PADDING >> ( c ? 1 : 0 ) );
+  const int mvW = info[0].mvs.w(), mvH = info[0].mvs.h();
+  std::vector<std::vector<vvhip_mv>> mvs( nRefs, std::vector<vvhip_mv>( ( size_t ) mvW * mvH ) );
+  std::vector<const vvhip_mv*> mvPtr( nRefs );
+  std::vector<double> strengths( nRefs );
+  for( int r = 0; r < nRefs; r++ )
+  {
+    for( int y = 0; y < mvH; y++ ) for( int x = 0; x < mvW; x++ )
+    {
+      const vvenc::MotionVector& s = info[r].mvs.get( x, y ); vvhip_mv& d = mvs[r][( size_t ) y * mvW + x];
+      d.x = s.x; d.y = s.y; d.error = s.error; d.rmsme = s.rmsme; d.overlap = s.overlap;
+    }
+    mvPtr[r] = mvs[r].data();
+    strengths[r] = vvenc::MCTF::m_refStrengths[m->m_encCfg->m_picReordering ? 0 : 1][info[r].index];      // MCTF.cpp:1405,1480
+  }
+  vvenc::Pel* outs[3]; int strides[3];
+  for( int c = 0; c < numComp; c++ ) { outs[c] = newOrgPic.bufs[c].buf; strides[c] = ( int ) newOrgPic.bufs[c].stride; }
+  g_m->bilateralFilter( orgIds.data(), refIds.data(), nRefs, mvPtr.data(), strengths.data(), m->m_encCfg->m_QP, m->m_encCfg->m_internalBitDepth[0], unit, m->m_lowResFltApply,
+                        overallStrength, numComp, outs, strides );
+  for( int id : all ) dev.unregisterPicture( id );
+  g_calls[9]++;
+  return true;
+}
+
 // ---- InterpolationFilter tables: every slot of m_filterHor / m_filterVer / m_filterCopy / m_filter4x4 / m_filter8xH /
 // m_filter16xH forwards to the shim's slot of the same index (the only difference between the two signatures is the ClpRng type)
 vvhip::InterpolationFilter* g_if = nullptr;
@@ -233,7 +269,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_after_simd_in
 
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
 {
-  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables
+  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter
   g_slotMask = mask;
   try
   {
@@ -247,6 +283,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
   g_vvhipHooks.initMCTF   = ( mask & 8 ) ? initMCTF : nullptr;
   g_vvhipHooks.mctfMe     = ( mask & 16 ) ? mctfMe : nullptr;
   g_vvhipHooks.initIF     = ( mask & 64 ) ? initIF : nullptr;
+  g_vvhipHooks.mctfApply  = ( mask & 128 ) ? mctfApply : nullptr;
   for( auto& c : g_calls ) c = 0;
   return 0;
 }

@@ -19,6 +19,7 @@ struct VvhipHooks
   bool ( *fwd2D )( const int16_t* resi, ptrdiff_t stride, int32_t* coef, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
   bool ( *inv2D )( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
   void ( *initIF )( vvenc::InterpolationFilter* );
+  bool ( *mctfApply )( const vvenc::MCTF*, const vvenc::PelStorage& orgPic, void* srcFrameInfoDeque, vvenc::PelStorage& newOrgPic, double overallStrength );
   bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel );
 };
 extern VvhipHooks g_vvhipHooks;

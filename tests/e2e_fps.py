@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end frames/sec of the REAL reference encoder (oracle/_ref, compiled from /root/reference) on a BASELINE-config-2 style clip,
-CPU kernels vs the same encoder with the whole-picture MCTF motion estimation running on the MI355X (hook mask 16), same host, same
+CPU kernels vs the same encoder with the MCTF stage on the MI355X (hook mask 16 = whole-picture motion estimation, + 128 = bilateral filter), same host, same
 threads, bitstream md5 compared (SURVEY §8d "Metric").  Test infrastructure: prints one JSON line; run it through gpurun.
 
   python tests/e2e_fps.py [--width 1920 --height 1080 --frames 17 --threads 8 --masks 0,16]
@@ -54,7 +54,7 @@ yuv = F.synth_clip(cfg["w"], cfg["h"], cfg["frames"])
 md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], 10, 10, threads=cfg["threads"])
 calls = None
 if cfg["mask"]:
-    c = np.zeros(8, np.uint64); L.vvref_hip_hook_calls(c.ctypes.data); calls = [int(x) for x in c]
+    c = np.zeros(10, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 10); calls = [int(x) for x in c]
 print(json.dumps({"mask": cfg["mask"], "md5": md5, "bytes": n, "secs": secs, "fps": cfg["frames"] / secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames", type=int, default=17)
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--masks", default="0,16")
+    ap.add_argument("--masks", default="0,16,144")
     a = ap.parse_args()
     res = [run(dict(w=a.width, h=a.height, frames=a.frames, threads=a.threads, mask=int(m))) for m in a.masks.split(",")]
     out = {"clip": "%dx%d 10-bit synthetic (config-2 generator), %d frames, preset faster, QP 32" % (a.width, a.height, a.frames),

@@ -104,3 +104,18 @@ def test_hip_interpolation_tables_bitstream_identical():
     print("cpu", cpu, "hip", hip)
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
     assert hip["calls"][8] > 100, hip["calls"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", [CFG1, CFG10], ids=["cfg0-64x64-8b", "128x64-10b"])
+def test_hip_mctf_stage_on_device_bitstream_identical(clip):
+    """the whole MCTF stage of the encoder on the GPU — hierarchical motion estimation (mask 16) AND the bilateral filter
+    (mask 128) — against the CPU encode.  The device filter equals the reference's scalar row; its AVX2 row (the CPU run here) is allowed
+    +-1 by the reference's unit test, and on these clips the bitstreams are identical."""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=16 + 128))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][9] >= 1 and hip["calls"][7] >= 1000000, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)

@@ -41,9 +41,11 @@ int Device::registerPicture( const Pel* origin, int stride, int width, int heigh
   check( vvhip_malloc( m_ctx, &d, elems * sizeof( Pel ) ), "registerPicture" );
   m.dBase = static_cast<int16_t*>( d );
   m.dOrigin = m.dBase + ( ptrdiff_t ) margin * stride + margin;
-  m_mirrors.push_back( m );
-  updatePicture( ( int ) m_mirrors.size() - 1 );
-  return ( int ) m_mirrors.size() - 1;
+  int id = -1;
+  for( size_t i = 0; i < m_mirrors.size(); i++ ) if( !m_mirrors[i].live ) { id = ( int ) i; break; }      // reuse the slot of an unregistered picture
+  if( id < 0 ) { m_mirrors.push_back( m ); id = ( int ) m_mirrors.size() - 1; } else m_mirrors[id] = m;
+  updatePicture( id );
+  return id;
 }
 
 void Device::updatePicture( int id )
@@ -702,6 +704,40 @@ void MCTFOps::motionEstimation( int curPicId, const int* refPicIds, int nRefs, i
   dev.check( vvhip_mctf_motion_estimation( dev.ctx(), cur.dOrigin, refs.data(), nRefs, cur.stride, cur.width, cur.height, cur.margin, bitDepth, unitSize,
                                            mctfSpeed, addLevel ? 1 : 0, outs.data() ), "vvhip_mctf_motion_estimation" );
   for( int r = 0; r < nRefs; r++ ) dev.check( vvhip_download( dev.ctx(), out[r], outs[r], count * sizeof( vvhip_mv ) ), "motion vectors" );
+}
+
+void MCTFOps::bilateralFilter( const int* orgIds, const int* refIds, int nRefs, const vvhip_mv* const* mvs, const double* refStrengths, int qp, int bitDepth, int unitSize,
+                               bool lowResFltApply, double overallStrength, int numComp, Pel* const* out, const int* outStride )
+{
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const Device::Mirror& y = dev.mirror( orgIds[0] );
+  const int mvW = ( y.width + unitSize - 1 ) / unitSize, mvH = ( y.height + unitSize - 1 ) / unitSize;
+  const size_t count = ( size_t ) mvW * mvH;
+  vvhip_mv* dMv = static_cast<vvhip_mv*>( dev.stagingAux( count * nRefs * sizeof( vvhip_mv ) + 64 ) );
+  std::vector<const vvhip_mv*> dMvs( nRefs );
+  for( int r = 0; r < nRefs; r++ ) { dev.check( vvhip_upload( dev.ctx(), dMv + count * r, mvs[r], count * sizeof( vvhip_mv ) ), "motion vectors" ); dMvs[r] = dMv + count * r; }
+  std::vector<Pel> tmp;
+  for( int c = 0; c < numComp; c++ )
+  {
+    const Device::Mirror& o = dev.mirror( orgIds[c] );
+    std::vector<const int16_t*> refs( nRefs );
+    for( int r = 0; r < nRefs; r++ )
+    {
+      const Device::Mirror& m = dev.mirror( refIds[3 * r + c] );
+      if( m.stride != o.stride || m.width != o.width || m.height != o.height ) throw Exception( "MCTFOps::bilateralFilter: reference plane geometry differs from the original's" );
+      refs[r] = m.dOrigin;
+    }
+    double sigmaSq, weightScaling;
+    dev.check( vvhip_mctf_filter_params( qp, bitDepth, overallStrength, c > 0, &sigmaSq, &weightScaling ), "vvhip_mctf_filter_params" );
+    const size_t elems = ( size_t ) o.width * o.height;
+    int16_t* dOut = dev.staging( elems * sizeof( Pel ) + 64 );
+    dev.check( vvhip_mctf_apply_plane( dev.ctx(), o.dOrigin, o.stride, o.width, o.height, c > 0 ? 1 : 0, bitDepth, unitSize, lowResFltApply ? 1 : 0, qp, nRefs, refs.data(), o.stride,
+                                       dMvs.data(), mvW, refStrengths, weightScaling, sigmaSq, dOut, o.width ), "vvhip_mctf_apply_plane" );
+    tmp.resize( elems );
+    dev.check( vvhip_download( dev.ctx(), tmp.data(), dOut, elems * sizeof( Pel ) ), "filtered plane" );
+    for( int r = 0; r < o.height; r++ ) memcpy( out[c] + ( ptrdiff_t ) r * outStride[c], &tmp[( size_t ) r * o.width], sizeof( Pel ) * o.width );
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ QuantOps

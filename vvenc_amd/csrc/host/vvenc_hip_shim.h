@@ -171,6 +171,12 @@ struct MCTFOps
   // whole-picture replacement of MCTF::motionEstimationMCTF (MCTF.cpp:666-707) for pictures registered with Device:
   // out[r] receives ceil(w/unit) x ceil(h/unit) vvhip_mv (== MotionVector, MCTF.h:72-82) for reference r
   void motionEstimation( int curPicId, const int* refPicIds, int nRefs, int bitDepth, int unitSize, int mctfSpeed, bool addLevel, vvhip_mv** out );
+  // whole-picture replacement of MCTF::bilateralFilter (MCTF.cpp:1489-1552) for planes registered with Device, one id per
+  // component plane (numComp 1 or 3, 4:2:0): orgIds[c], refIds[3*r + c]; mvs[r] = final-level motion field of reference r (host, as
+  // motionEstimation returned it); refStrengths[r] = m_refStrengths[row][index] (MCTF.cpp:112-117,1480); out[c] receives the filtered plane.
+  // Equals the reference's scalar row (its x86 row is within +-1 by the reference's own unit test).
+  void bilateralFilter( const int* orgIds, const int* refIds, int nRefs, const vvhip_mv* const* mvs, const double* refStrengths, int qp, int bitDepth, int unitSize,
+                        bool lowResFltApply, double overallStrength, int numComp, Pel* const* out, const int* outStride );
 };
 
 // InterpolationFilter, CommonLib/InterpolationFilter.h:70-155: the function-pointer tables of the separable
