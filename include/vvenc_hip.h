@@ -319,6 +319,19 @@ VVHIP_API int vvhip_mctf_apply_plane( vvhip_ctx* ctx, const int16_t* d_org, int 
 /* sigmaSq and weightScaling exactly as MCTF::bilateralFilter (:1491-1501) and xFinalizeBlkLine (:1417) derive them (host only). */
 VVHIP_API int vvhip_mctf_filter_params( int qp, int bit_depth, double overall_strength, int is_chroma, double* sigma_sq, double* weight_scaling );
 
+/* ======================================================================================================================
+ * SURVEY 8f rank 3 — DMVR refinement search (decoder-normative, integer): DMVR::xProcessDMVR, CommonLib/InterPrediction.cpp:1262-1392.
+ * Per sub-block (dx, dy in {8, 16}; DMVR_SUBCU_SIZE 16): bilinear prediction of both lists around the (already clipped) merge vectors
+ * (InterpolationFilter::filterN2_2D), centre cost with early exit, 25-point mirrored SAD search (dmvrSadX5 semantics, strict < in the
+ * reference's scan order), parametric sub-pel error surface.
+ *   ref0_off / ref1_off : the sub-block's integer position for the merge vector of list 0 / 1 (mv >> 4), frac* = mv & 15
+ *   result              : mvd = cu.mvdL0SubPu[num] in 1/16 sample (list 1 moves by -mvd), min_cost = the value the BDOF switch compares
+ *                         with 2*dx*dy (:1386).  The final motion compensation stays with the caller (vvhip_interp_luma_batch).          */
+typedef struct { int32_t ref0_off, ref1_off; int16_t frac0_x, frac0_y, frac1_x, frac1_y; } vvhip_dmvr_item;
+typedef struct { int16_t mvd_x, mvd_y; int32_t pad; uint64_t min_cost; } vvhip_dmvr_result;
+VVHIP_API int vvhip_dmvr_refine_batch( vvhip_ctx* ctx, const int16_t* d_ref0, int stride0, const int16_t* d_ref1, int stride1,
+                                       const vvhip_dmvr_item* d_items, int n, int dx, int dy, int bit_depth, vvhip_dmvr_result* d_out );
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,6 +170,32 @@ class _Base:
         sigma = (30.0 * 30.0 if chroma else luma_sigma) / (bdw * bdw)
         return sigma, overall_strength * (0.55 if chroma else 0.4)
 
+    # ---- DMVR refinement search ----
+    def if_bilinear(self, src, w, h, fx, fy, bd=10):
+        ps, ss = self._if_src(src)
+        dst = np.full((h + 2, w + 32), -99, np.int16)
+        self._if_call("if_bilinear", ps, ss, _p(dst), w + 32, w, h, fx, fy, bd)
+        return dst[:h, :w].copy()
+
+    def dmvr_subpel_error_surface(self, sad5):
+        s5 = np.ascontiguousarray(sad5, np.uint64)
+        d = np.zeros(2, np.int32)
+        f = getattr(self.L, self._pfx + "dmvr_subpel_error_surface"); f.restype = None
+        f(_p(s5), _p(d))
+        return d
+
+    def dmvr_refine(self, ref0, ref1, frac0, frac1, dx, dy, bd=10):
+        """ref0 / ref1: (array, y, x) = the sub-block's integer position for the merge vector; frac = (x, y) in 1/16; -> (mvd_x, mvd_y, minCost)"""
+        p0, s0 = self._if_src(ref0)
+        p1, s1 = self._if_src(ref1)
+        mvd = np.zeros(2, np.int16)
+        f = getattr(self.L, self._pfx + "dmvr_refine"); f.restype = C.c_uint64
+        a = (p0, s0, frac0[0], frac0[1], p1, s1, frac1[0], frac1[1], dx, dy, bd, _p(mvd))
+        if self._pfx == "vvref_":
+            a = (self.simd,) + a
+        cost = f(*a)
+        return int(mvd[0]), int(mvd[1]), int(cost)
+
     # ---- g_tCoeffOps table slots (TrQuant_EMT.h:63-91), caller's matrix ----
     def fast_fwd_core(self, tc, src, line, reduced_line, cutoff, shift):
         """tc: (N, N) int16, src: (line, N) int32 -> dst (N, line) int32 (entries outside reduced_line x cutoff stay 0)"""

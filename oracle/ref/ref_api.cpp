@@ -814,6 +814,67 @@ API void vvref_if_pred_luma( int simd, const int16_t* ref, int refStride, int16_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// DMVR refinement search.  DMVR::xProcessDMVR (InterPrediction.cpp:1246-1400) needs a CodingUnit, a slice and reference
+// pictures; the pieces it is made of are the reference's own and are called here: InterpolationFilter::filterN2_2D (bilinear prediction),
+// RdCost::setDistParam(.., isDMVR) -> distFunc / dmvrSadX5, xSubPelErrorSrfc.  Only the 25-point loop around them is restated (:1322-1384).
+// ---------------------------------------------------------------------------------------------
+namespace vvenc { void xSubPelErrorSrfc( uint64_t* sadBuffer, int32_t* deltaMv ); }
+
+API void vvref_if_bilinear( int simd, const int16_t* src, int srcStride, int16_t* dst, int dstStride, int w, int h, int fracX, int fracY, int bitDepth )
+{
+  ClpRng clp; clp.bd = bitDepth;
+  ifObj( simd ).filterN2_2D( COMP_Y, src, srcStride, dst, dstStride, w, h, fracX, fracY, clp );
+}
+
+API void vvref_dmvr_subpel_error_surface( const uint64_t* sad5, int32_t* deltaMv )
+{
+  uint64_t b[5]; for( int i = 0; i < 5; i++ ) b[i] = sad5[i];
+  xSubPelErrorSrfc( b, deltaMv );
+}
+
+API uint64_t vvref_dmvr_refine( int simd, const int16_t* ref0, int stride0, int fx0, int fy0, const int16_t* ref1, int stride1, int fx1, int fy1, int dx, int dy,
+                                int bitDepth, int16_t* mvd )
+{
+  RdCost& rc = *rdPair().rc[simd ? 1 : 0];
+  ClpRng clp; clp.bd = bitDepth;
+  const int bs = dx + 4;
+  Pel* p0 = ( Pel* ) xMalloc( Pel, bs * ( dy + 4 ) + 16 ); Pel* p1 = ( Pel* ) xMalloc( Pel, bs * ( dy + 4 ) + 16 );
+  ifObj( simd ).filterN2_2D( COMP_Y, ref0 - 2 * stride0 - 2, stride0, p0, bs, dx + 4, dy + 4, fx0, fy0, clp );
+  ifObj( simd ).filterN2_2D( COMP_Y, ref1 - 2 * stride1 - 2, stride1, p1, bs, dx + 4, dy + 4, fx1, fy1, clp );
+  const Pel* l0 = p0 + 2 * bs + 2; const Pel* l1 = p1 + 2 * bs + 2;
+  DistParam dp = rc.setDistParam( nullptr, nullptr, bs, bs, bitDepth, COMP_Y, dx, dy, 1, true );
+  dp.org.buf = l0; dp.cur.buf = l1;
+  uint64_t minCost = dp.distFunc( dp ) >> 1;
+  minCost -= ( minCost >> 2 );
+  mvd[0] = mvd[1] = 0;
+  if( minCost >= ( uint64_t ) ( dx * dy ) )
+  {
+    uint64_t sadArray[25];
+    int16_t total[2] = { 0, 0 }, delta[2] = { 0, 0 };
+    sadArray[12] = minCost;
+    for( int ver = -2; ver <= 2; ver++ )
+    {
+      const ptrdiff_t offset = -2 + ver * bs;
+      dp.org.buf = l0 + offset; dp.cur.buf = l1 - offset;
+      dp.dmvrSadX5( dp, &sadArray[( ver + 2 ) * 5], ver != 0 );
+      for( int hor = -2; hor <= 2; hor++ ) if( sadArray[( ver + 2 ) * 5 + hor + 2] < minCost ) { minCost = sadArray[( ver + 2 ) * 5 + hor + 2]; delta[0] = hor; delta[1] = ver; }
+    }
+    total[0] = delta[0] * 16; total[1] = delta[1] * 16;
+    if( abs( total[0] ) != 32 && abs( total[1] ) != 32 )
+    {
+      uint64_t* p = &sadArray[12 + delta[1] * 5 + delta[0]];
+      uint64_t sb[5] = { p[0], p[-1], p[-5], p[1], p[5] };
+      int32_t t[2] = { 0, 0 };
+      xSubPelErrorSrfc( sb, t );
+      total[0] += t[0]; total[1] += t[1];
+    }
+    mvd[0] = total[0]; mvd[1] = total[1];
+  }
+  xFree( p0 ); xFree( p1 );
+  return minCost;
+}
+
 // the hook-enabled build re-installs table-level device slots after the SIMD initialisation rewrote the global tables
 extern "C" void vvref_after_simd_init() __attribute__( ( weak ) );
 

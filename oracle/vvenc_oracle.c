@@ -1100,3 +1100,94 @@ void orc_mctf_bilateral_plane(const int16_t *org, ptrdiff_t orgStride, int width
                                  bitDepth, corrected, numRefs, verror, refStrengths, weightScaling, sigmaSq);
         }
 }
+
+/* ================================================================================================
+ * SURVEY §8f rank 3 — DMVR refinement search                                 (InterPrediction.cpp)
+ * ==============================================================================================*/
+/* InterpolationFilter::filterN2_2D (InterpolationFilter.cpp:662-673) with scalarFilterN2_2D (:675-681): the bilinear prediction DMVR
+ * searches on (10-bit internal precision, no clipping). */
+void orc_if_bilinear(const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h, int fracX, int fracY, int bitDepth)
+{
+    int16_t ch[8], cv[8];
+    orc_if_coeff(4, fracX, ch);
+    orc_if_coeff(4, fracY, cv);
+    if (fracX && fracY) {
+        static _Thread_local int16_t tmp[(128 + 8) * (128 + 8)];
+        orc_if_filter(2, 0, 1, 0, bitDepth, src, srcStride, tmp, w, w, h + 1, ch);
+        orc_if_filter(2, 1, 0, 0, bitDepth, tmp, w, dst, dstStride, w, h, cv);
+    } else if (fracX) orc_if_filter(2, 0, 1, 0, bitDepth, src, srcStride, dst, dstStride, w, h, ch);
+    else if (fracY)   orc_if_filter(2, 1, 1, 0, bitDepth, src, srcStride, dst, dstStride, w, h, cv);
+    else              orc_if_copy(1, 0, bitDepth, src, srcStride, dst, dstStride, w, h, 1);
+}
+
+static int32_t dmvr_div_maxq7(int64_t N, int64_t D)
+{   /* div_for_maxq7, InterPrediction.cpp:1131-1165: three steps of restoring division, quotient magnitude <= 7 */
+    int32_t sign = 0, q = 0;
+    if (N < 0) { sign = 1; N = -N; }
+    D <<= 3;
+    if (N >= D) { N -= D; q++; }
+    q <<= 1;
+    D >>= 1;
+    if (N >= D) { N -= D; q++; }
+    q <<= 1;
+    if (N >= (D >> 1)) q++;
+    return sign ? -q : q;
+}
+
+/* xSubPelErrorSrfc (:1167-1187): parametric error surface from the centre cost and its four neighbours (left, top, right, bottom). */
+void orc_dmvr_subpel_error_surface(const uint64_t sad[5], int32_t deltaMv[2])
+{
+    for (int hv = 0; hv < 2; hv++) {
+        const int64_t numerator = (int64_t)((sad[hv + 1] - sad[hv + 3]) << 4);
+        const int64_t denominator = (int64_t)(sad[hv + 1] + sad[hv + 3] - (sad[0] << 1));
+        if (denominator != 0) {
+            if (sad[hv + 1] != sad[0] && sad[hv + 3] != sad[0]) deltaMv[hv] = dmvr_div_maxq7(numerator, denominator);
+            else deltaMv[hv] = sad[hv + 1] == sad[0] ? -8 : 8;
+        }
+    }
+}
+
+/* The refinement search of DMVR::xProcessDMVR for one sub-block (InterPrediction.cpp:1312-1384): l0c / l1c point at the CENTRE position of
+ * the two bilinear predictions (which extend 2 samples to every side).  mvd = cu.mvdL0SubPu (1/16 sample); returns the final minCost
+ * (the BDOF switch compares it with 2*dx*dy, :1386). */
+uint64_t orc_dmvr_search(const int16_t *l0c, const int16_t *l1c, int stride, int dx, int dy, int16_t mvd[2])
+{
+    uint64_t sadArray[25];
+    uint64_t minCost = orc_sad(l0c, stride, l1c, stride, dx, dy, 1) >> 1;      /* DF_SAD, subShift 1 (:1310, :1332) */
+    minCost -= minCost >> 2;
+    mvd[0] = mvd[1] = 0;
+    if (minCost < (uint64_t)(dx * dy)) return minCost;
+    int16_t delta[2] = { 0, 0 }, total[2] = { 0, 0 };
+    sadArray[12] = minCost;
+    for (int ver = -2; ver <= 2; ver++) {
+        const ptrdiff_t offset = -2 + (ptrdiff_t)ver * stride;
+        orc_sad_x5(l0c + offset, stride, l1c - offset, stride, dx, dy, 1, &sadArray[(ver + 2) * 5], ver != 0);
+        for (int hor = -2; hor <= 2; hor++) {
+            const uint64_t cost = sadArray[(ver + 2) * 5 + hor + 2];
+            if (cost < minCost) { minCost = cost; delta[0] = (int16_t)hor; delta[1] = (int16_t)ver; }
+        }
+    }
+    total[0] = (int16_t)(delta[0] * 16); total[1] = (int16_t)(delta[1] * 16);
+    /* xDMVRSubPixelErrorSurface (:1227-1244): only when the best integer offset is not on the border of the 5x5 window */
+    if (abs(total[0]) != (2 << 4) && abs(total[1]) != (2 << 4)) {
+        const uint64_t *p = &sadArray[12 + delta[1] * 5 + delta[0]];
+        const uint64_t sb[5] = { p[0], p[-1], p[-5], p[1], p[5] };
+        int32_t t[2] = { 0, 0 };
+        orc_dmvr_subpel_error_surface(sb, t);
+        total[0] = (int16_t)(total[0] + t[0]); total[1] = (int16_t)(total[1] + t[1]);
+    }
+    mvd[0] = total[0]; mvd[1] = total[1];
+    return minCost;
+}
+
+/* One DMVR sub-block end to end: bilinear prediction of both lists around the (clipped) merge vectors, then the search.
+ * ref0/ref1 point at the sub-block's integer position for the merge vector (mv >> 4); frac* = mv & 15. */
+uint64_t orc_dmvr_refine(const int16_t *ref0, int stride0, int fx0, int fy0, const int16_t *ref1, int stride1, int fx1, int fy1, int dx,
+                         int dy, int bitDepth, int16_t mvd[2])
+{
+    static _Thread_local int16_t p0[(16 + 4) * (16 + 4)], p1[(16 + 4) * (16 + 4)];
+    const int bs = dx + 4;
+    orc_if_bilinear(ref0 - 2 * stride0 - 2, stride0, p0, bs, dx + 4, dy + 4, fx0, fy0, bitDepth);      /* mergeMV - 2 samples (:1285-1288) */
+    orc_if_bilinear(ref1 - 2 * stride1 - 2, stride1, p1, bs, dx + 4, dy + 4, fx1, fy1, bitDepth);
+    return orc_dmvr_search(p0 + 2 * bs + 2, p1 + 2 * bs + 2, bs, dx, dy, mvd);
+}

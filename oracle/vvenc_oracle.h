@@ -78,6 +78,13 @@ void orc_mctf_bilateral_plane(const int16_t *org, ptrdiff_t orgStride, int width
                               int qp, int numRefs, const int16_t *const *refs, ptrdiff_t refStride, const orc_mv_t *const *mvs, int mvW,
                               const double *refStrengths, double weightScaling, double sigmaSq, int16_t *out, ptrdiff_t outStride);
 
+/* DMVR refinement search (InterPrediction.cpp:1167-1187, 1227-1244, 1312-1384; InterpolationFilter.cpp:662-681) */
+void     orc_if_bilinear(const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h, int fracX, int fracY, int bitDepth);
+void     orc_dmvr_subpel_error_surface(const uint64_t sad[5], int32_t deltaMv[2]);
+uint64_t orc_dmvr_search(const int16_t *l0c, const int16_t *l1c, int stride, int dx, int dy, int16_t mvd[2]);
+uint64_t orc_dmvr_refine(const int16_t *ref0, int stride0, int fx0, int fy0, const int16_t *ref1, int stride1, int fx1, int fy1, int dx, int dy,
+                         int bitDepth, int16_t mvd[2]);
+
 #ifdef __cplusplus
 }
 #endif

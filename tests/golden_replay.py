@@ -212,3 +212,12 @@ def check_mctf_apply(be):
         out = be.mctf_bilateral(org, refs, mvs, ref_index, bd, qp, 16, bool(low_res), True, 0.95)
         for c in range(3):
             assert np.array_equal(out[c], g["c%d_out%d" % (k, c)]), ("mctf apply", k, c, int(np.abs(out[c].astype(np.int32) - g["c%d_out%d" % (k, c)]).max()))
+
+
+def check_dmvr(be):
+    """DMVR refinement search fixtures"""
+    g = load("dmvr")
+    r0 = g["r0"]
+    for (si, x0, y0, f0x, f0y, f1x, f1y, dx, dy), exp in zip(g["cases"], g["out"]):
+        got = be.dmvr_refine((r0, int(y0), int(x0)), (g["r1_%d" % si], int(y0), int(x0)), (int(f0x), int(f0y)), (int(f1x), int(f1y)), int(dx), int(dy), 10)
+        assert tuple(got) == tuple(int(v) for v in exp), (si, x0, y0, dx, dy, got, exp)

@@ -73,6 +73,18 @@ class HipBackend:
         out = self.hp.fix_weighted_sse_batch(po, pc, d_it, d_w, 1, w, h)
         return int(out.cpu().numpy().view(np.uint64)[0])
 
+    # ---- DMVR refinement search ----
+    def dmvr_refine(self, ref0, ref1, frac0, frac1, dx, dy, bd=10):
+        from vvenc_amd.hotpath import DMVR_ITEM_DTYPE, DMVR_RESULT_DTYPE
+        a0, y0, x0 = ref0
+        a1, y1, x1 = ref1
+        p0, p1 = self._plane(a0), self._plane(a1)
+        it = np.zeros(1, DMVR_ITEM_DTYPE)
+        it["ref0_off"], it["ref1_off"] = y0 * p0.stride + x0, y1 * p1.stride + x1
+        it["frac0_x"], it["frac0_y"], it["frac1_x"], it["frac1_y"] = frac0[0], frac0[1], frac1[0], frac1[1]
+        r = self.hp.dmvr_refine_batch(p0, p1, self.hp.to_device(it), 1, dx, dy, bd).cpu().numpy().reshape(-1).view(DMVR_RESULT_DTYPE)[0]
+        return int(r["mvd_x"]), int(r["mvd_y"]), int(r["min_cost"])
+
     # ---- MCTF apply ----
     def mctf_bilateral(self, org, refs, mvs, ref_index, bit_depth=10, qp=32, unit=16, low_res=True, pic_reordering=True, overall_strength=0.95):
         return self.hp.mctf_bilateral(org, refs, mvs, ref_index, bit_depth, qp, unit, low_res, pic_reordering, overall_strength)

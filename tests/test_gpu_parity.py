@@ -29,6 +29,10 @@ def test_golden_distortion_ext(hip):
     G.check_distortion_ext(hip)
 
 
+def test_golden_dmvr(hip):
+    G.check_dmvr(hip)
+
+
 def test_golden_mctf_apply(hip):
     G.check_mctf_apply(hip)
 
@@ -494,3 +498,35 @@ def test_mctf_apply_1080p_vs_oracle(hip, oracle):
     for c in range(3):
         assert np.array_equal(got[c], exp[c]), (c, int(np.abs(got[c].astype(np.int32) - exp[c]).max()))
         assert not np.array_equal(got[c], org[c])
+
+
+def test_dmvr_refine_vs_oracle(hip, oracle):
+    """batched DMVR refinement search (bilinear predictions, 25 mirrored SADs, error surface) == oracle (== reference rows)"""
+    from vvenc_amd.hotpath import DMVR_ITEM_DTYPE, DMVR_RESULT_DTYPE
+    hp = hip.hp
+    rng = np.random.default_rng(401)
+    yy, xx = np.mgrid[0:200, 0:320]
+    tex = 512 + 220 * np.sin(xx / 6.0) * np.cos(yy / 5.0) + 80 * np.sin((xx - yy) / 3.0)
+    for bd in (10, 8):
+        sc = (1 << bd) / 1024.0
+        r0 = np.clip((tex + rng.normal(0, 6, tex.shape)) * sc, 0, (1 << bd) - 1).astype(np.int16)
+        moved = 0
+        for (sx, sy) in ((0, 0), (1, -1), (-2, 1), (2, 2)):
+            r1 = np.clip((np.roll(tex, (2 * sy, 2 * sx), (0, 1)) + rng.normal(0, 6, tex.shape)) * sc, 0, (1 << bd) - 1).astype(np.int16)
+            p0, p1 = hp.plane(r0, 0), hp.plane(r1, 0)
+            for (dx, dy) in ((16, 16), (8, 8), (16, 8), (8, 16)):
+                n = 41
+                it = np.zeros(n, DMVR_ITEM_DTYPE)
+                pos = [(int(rng.integers(8, 320 - dx - 8)), int(rng.integers(8, 200 - dy - 8))) for _ in range(n)]
+                it["ref0_off"] = [y * p0.stride + x for (x, y) in pos]
+                it["ref1_off"] = [y * p1.stride + x for (x, y) in pos]
+                for f in ("frac0_x", "frac0_y", "frac1_x", "frac1_y"):
+                    it[f] = rng.integers(0, 16, n)
+                it[:5]["frac0_x"] = 0; it[:3]["frac0_y"] = 0; it[2:7]["frac1_x"] = 0; it[:8]["frac1_y"] = 0
+                res = hp.dmvr_refine_batch(p0, p1, hp.to_device(it), n, dx, dy, bd).cpu().numpy().reshape(-1).view(DMVR_RESULT_DTYPE)
+                for k, (x, y) in enumerate(pos):
+                    exp = oracle.dmvr_refine((r0, y, x), (r1, y, x), (int(it[k]["frac0_x"]), int(it[k]["frac0_y"])), (int(it[k]["frac1_x"]), int(it[k]["frac1_y"])), dx, dy, bd)
+                    got = (int(res[k]["mvd_x"]), int(res[k]["mvd_y"]), int(res[k]["min_cost"]))
+                    assert got == exp, (bd, sx, sy, dx, dy, k, got, exp)
+                    moved += got[0] != 0 or got[1] != 0
+        assert moved > 100

@@ -45,3 +45,7 @@ def test_interp(oracle):
 
 def test_mctf_apply(oracle):
     G.check_mctf_apply(oracle)
+
+
+def test_dmvr(oracle):
+    G.check_dmvr(oracle)

@@ -462,3 +462,44 @@ def test_mctf_bilateral_picture(oracle, reflib):
             d = int(np.abs(a[c].astype(np.int32) - b[c]).max())
             assert d <= tol, ("bilateral", w, h, bd, c, d)
             assert not np.array_equal(a[c], org[c])        # the filter did something
+
+
+# ---------------------------------------------------------------- DMVR refinement search ----
+def test_dmvr_bilinear_and_error_surface(oracle, reflib):
+    rng = np.random.default_rng(95)
+    for bd in (8, 10):
+        plane = rng.integers(0, 1 << bd, size=(80, 112)).astype(np.int16)
+        for (w, h) in ((20, 20), (12, 12), (20, 12), (12, 20), (8, 8)):
+            for fx in (0, 1, 8, 15):
+                for fy in (0, 3, 8, 14):
+                    a = oracle.if_bilinear((plane, 20, 24), w, h, fx, fy, bd)
+                    b = reflib.if_bilinear((plane, 20, 24), w, h, fx, fy, bd)
+                    assert np.array_equal(a, b), ("bilinear", bd, w, h, fx, fy)
+    for _ in range(400):
+        c = int(rng.integers(0, 4000))
+        s5 = [c] + [int(c + rng.integers(0, 600) * rng.integers(0, 2)) for _ in range(4)]
+        assert np.array_equal(oracle.dmvr_subpel_error_surface(s5), reflib.dmvr_subpel_error_surface(s5)), s5
+
+
+def test_dmvr_refine(oracle, reflib):
+    """bilinear predictions of both lists + 25-point mirrored SAD search + sub-pel error surface, per 8x8..16x16 sub-block"""
+    rng = np.random.default_rng(96)
+    yy, xx = np.mgrid[0:120, 0:160]
+    tex = 512 + 220 * np.sin(xx / 6.0) * np.cos(yy / 5.0) + 80 * np.sin((xx - yy) / 3.0)
+    moved = 0
+    for bd in (10, 8):
+        sc = (1 << bd) / 1024.0
+        r0 = np.clip((tex + rng.normal(0, 6, tex.shape)) * sc, 0, (1 << bd) - 1).astype(np.int16)
+        for (sx, sy) in ((0, 0), (1, 0), (-1, 1), (2, -2), (0, 2)):
+            # list 1 shows the mirror-shifted texture, so the true refinement is (sx, sy)
+            r1 = np.clip((np.roll(tex, (2 * sy, 2 * sx), (0, 1)) + rng.normal(0, 6, tex.shape)) * sc, 0, (1 << bd) - 1).astype(np.int16)
+            for (dx, dy) in ((16, 16), (8, 8), (16, 8), (8, 16)):
+                for k in range(6):
+                    x0, y0 = int(rng.integers(16, 120)), int(rng.integers(16, 90))
+                    f0 = (int(rng.integers(0, 16)), int(rng.integers(0, 16)))
+                    f1 = (int(rng.integers(0, 16)), int(rng.integers(0, 16)))
+                    a = oracle.dmvr_refine((r0, y0, x0), (r1, y0, x0), f0, f1, dx, dy, bd)
+                    b = reflib.dmvr_refine((r0, y0, x0), (r1, y0, x0), f0, f1, dx, dy, bd)
+                    assert a == b, (bd, sx, sy, dx, dy, k, a, b)
+                    moved += a[0] != 0 or a[1] != 0
+    assert moved > 50

@@ -151,6 +151,30 @@ def gen_mctf_apply(R, R0):
     np.savez_compressed(os.path.join(OUT, "mctf_apply.npz"), **d)
 
 
+def gen_dmvr(R, R0):
+    """DMVR refinement search results of the reference's pieces (bilinear prediction, SAD / SAD-X5, error surface) -> dmvr.npz"""
+    rng = np.random.default_rng(20260927)
+    yy, xx = np.mgrid[0:120, 0:192]
+    tex = 512 + 220 * np.sin(xx / 6.0) * np.cos(yy / 5.0) + 80 * np.sin((xx - yy) / 3.0)
+    r0 = np.clip(tex + rng.normal(0, 6, tex.shape), 0, 1023).astype(np.int16)
+    d = dict(r0=r0)
+    cases, outs = [], []
+    for si, (sx, sy) in enumerate(((0, 0), (1, 0), (-1, 1), (2, -2))):
+        r1 = np.clip(np.roll(tex, (2 * sy, 2 * sx), (0, 1)) + rng.normal(0, 6, tex.shape), 0, 1023).astype(np.int16)
+        d["r1_%d" % si] = r1
+        for (dx, dy) in ((16, 16), (8, 8), (16, 8), (8, 16)):
+            for k in range(12):
+                x0, y0 = int(rng.integers(16, 192 - 32)), int(rng.integers(16, 120 - 32))
+                f = [int(v) for v in rng.integers(0, 16, 4)]
+                if k < 3:
+                    f[k] = 0; f[3 - k] = 0
+                a = R.dmvr_refine((r0, y0, x0), (r1, y0, x0), (f[0], f[1]), (f[2], f[3]), dx, dy, 10)
+                assert a == R0.dmvr_refine((r0, y0, x0), (r1, y0, x0), (f[0], f[1]), (f[2], f[3]), dx, dy, 10)
+                cases.append((si, x0, y0, f[0], f[1], f[2], f[3], dx, dy)); outs.append(a)
+    d["cases"] = np.array(cases, np.int32); d["out"] = np.array(outs, np.int64)
+    np.savez_compressed(os.path.join(OUT, "dmvr.npz"), **d)
+
+
 def main():
     build_ref()
     R = RefLib(1)
@@ -159,6 +183,7 @@ def main():
     gen_distortion_ext(R, R0)
     gen_interp(R, R0)
     gen_mctf_apply(R, R0)
+    gen_dmvr(R, R0)
     if "--ext-only" in sys.argv:
         return
     rng = np.random.default_rng(20260923)

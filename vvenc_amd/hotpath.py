@@ -20,6 +20,8 @@ DF = {"SSE": 0, "SAD": 1, "HAD": 2, "HAD_fast": 3, "HAD_2SAD": 4}
 DCT2, DCT8, DST7 = 0, 1, 2
 
 MV_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("error", "<i4"), ("rmsme", "<i4"), ("overlap", "<f8")])
+DMVR_ITEM_DTYPE = np.dtype([("ref0_off", "<i4"), ("ref1_off", "<i4"), ("frac0_x", "<i2"), ("frac0_y", "<i2"), ("frac1_x", "<i2"), ("frac1_y", "<i2")])
+DMVR_RESULT_DTYPE = np.dtype([("mvd_x", "<i2"), ("mvd_y", "<i2"), ("pad", "<i4"), ("min_cost", "<u8")])
 SUBPEL_DTYPE = np.dtype([("org_off", "<i4"), ("ref_off", "<i4"), ("frac_x", "<i2"), ("frac_y", "<i2")])
 STATS_DTYPE = np.dtype([("abs_sum", "<i4"), ("last_scan_pos", "<i4"), ("need_rdoq", "<i4"), ("pad", "<i4"), ("sse", "<u8")])
 
@@ -250,6 +252,14 @@ class HotPath:
         if isinstance(jobs, list):
             jobs = self.make_tu_jobs(jobs)
         self._ck(self.L.vvhip_tu_rdo_multi(self.ctx, resi.buf_ptr, resi.stride, bit_depth, jobs[0], jobs[1]))
+
+    # ---- DMVR refinement search ----
+    def dmvr_refine_batch(self, ref0, ref1, d_items, n, dx, dy, bit_depth=10, out=None):
+        """d_items: DMVR_ITEM_DTYPE records -> tensor of DMVR_RESULT_DTYPE records (as uint8 rows)"""
+        if out is None:
+            out = torch.empty((n, DMVR_RESULT_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        self._ck(self.L.vvhip_dmvr_refine_batch(self.ctx, ref0.buf_ptr, ref0.stride, ref1.buf_ptr, ref1.stride, _ptr(d_items), n, dx, dy, bit_depth, _ptr(out)))
+        return out
 
     # ---- SURVEY 8f rank 2: MCTF apply side ----
     REF_STRENGTHS = ((0.84375, 0.6, 0.4286, 0.3333, 0.2727, 0.2308), (1.12500, 1.0, 0.7143, 0.5556, 0.4545, 0.3846))      # MCTF.cpp:112-117
