@@ -875,6 +875,60 @@ API uint64_t vvref_dmvr_refine( int simd, const int16_t* ref0, int stride0, int 
   return minCost;
 }
 
+// ---------------------------------------------------------------------------------------------
+// CPU timing loops for the SURVEY 8f rows (tests/perf_side_by_side.py): the reference's own entries called back-to-back from C++ on
+// `threads` std::threads; return wall seconds.
+// ---------------------------------------------------------------------------------------------
+struct SubpelItem { int32_t org_off, ref_off; int16_t frac_x, frac_y; };
+API double vvref_subpel_batch_mt( const int16_t* org, int orgStride, const int16_t* ref, int refStride, const SubpelItem* items, int n, int w, int h, int bitDepth,
+                                  int dfBase, int threads, uint64_t* out )
+{
+  rdPair(); ifObj( 1 );
+  auto worker = [&]( int t )
+  {
+    const int per = ( n + threads - 1 ) / threads, b = std::min( n, t * per ), e = std::min( n, b + per );
+    RdCost& rc = *rdPair().rc[1];
+    std::vector<Pel> pred( ( size_t ) w * h + 64 );
+    for( int i = b; i < e; i++ )
+    {
+      vvref_if_pred_luma( 1, ref + items[i].ref_off, refStride, pred.data(), w, w, h, items[i].frac_x, items[i].frac_y, 1, bitDepth, 0 );
+      DistParam dp;
+      dp.org = CPelBuf( org + items[i].org_off, orgStride, w, h ); dp.cur = CPelBuf( pred.data(), w, w, h );
+      dp.bitDepth = bitDepth; dp.subShift = 0; dp.compID = COMP_Y;
+      out[i] = rc.m_afpDistortFunc[0][dfBase + Log2( w )]( dp );
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for( int t = 0; t < threads; t++ ) th.emplace_back( worker, t );
+  for( auto& x : th ) x.join();
+  return std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+}
+
+struct DmvrItem { int32_t ref0_off, ref1_off; int16_t f0x, f0y, f1x, f1y; };
+struct DmvrResult { int16_t mvd_x, mvd_y; int32_t pad; uint64_t min_cost; };
+API double vvref_dmvr_batch_mt( const int16_t* ref0, int stride0, const int16_t* ref1, int stride1, const DmvrItem* items, int n, int dx, int dy, int bitDepth,
+                                int threads, DmvrResult* out )
+{
+  rdPair(); ifObj( 1 );
+  auto worker = [&]( int t )
+  {
+    const int per = ( n + threads - 1 ) / threads, b = std::min( n, t * per ), e = std::min( n, b + per );
+    for( int i = b; i < e; i++ )
+    {
+      int16_t mvd[2];
+      out[i].min_cost = vvref_dmvr_refine( 1, ref0 + items[i].ref0_off, stride0, items[i].f0x, items[i].f0y, ref1 + items[i].ref1_off, stride1, items[i].f1x, items[i].f1y,
+                                           dx, dy, bitDepth, mvd );
+      out[i].mvd_x = mvd[0]; out[i].mvd_y = mvd[1]; out[i].pad = 0;
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for( int t = 0; t < threads; t++ ) th.emplace_back( worker, t );
+  for( auto& x : th ) x.join();
+  return std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+}
+
 // the hook-enabled build re-installs table-level device slots after the SIMD initialisation rewrote the global tables
 extern "C" void vvref_after_simd_init() __attribute__( ( weak ) );
 
