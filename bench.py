@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip per-kernel HIP events inside the timed region")
     ap.add_argument("--bcast-ref", action="store_true", help="also broadcast the reference picture from its owner every step (RCCL)")
+    ap.add_argument("--overlap-streams", type=int, default=4, help="extra measurement: the frame's launches on this many HIP streams (0/1 = skip)")
     ap.add_argument("--with-subpel", action="store_true", help="also run the fractional-ME stage per step (16 interpolated HAD_fast candidates per block; SURVEY 8f rank 1)")
     ap.add_argument("--with-mctf", type=int, default=0, help="also run the MCTF hierarchical ME against this many references per step")
     args = ap.parse_args()
@@ -217,6 +218,20 @@ def main():
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt, device="cuda")
 
+    # extra (not `value`): the same steps with the four independent launches of a frame on four HIP streams
+    overlap = None
+    if args.overlap_streams > 1 and wl.merged:
+        streams = [torch.cuda.Stream() for _ in range(args.overlap_streams)]
+        for _ in range(max(args.warmup, 1)):
+            wl.run_overlapped(streams)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.run_overlapped(streams)
+        torch.cuda.synchronize()
+        dto = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
+        overlap = {"streams": args.overlap_streams, "value": args.steps * world / dto, "unit": "frames/s", "ms_per_step": 1000.0 * dto / args.steps,
+                   "note": "same work, the 4 launches of a frame issued on separate HIP streams (no per-kernel events); not the headline value"}
     if rank != 0:
         return
     frames = args.steps * world
@@ -252,6 +267,8 @@ def main():
                            "traffic": pmc_traffic(dom, args),
                            "alg_bytes_per_launch": wl.alg_bytes[dom] / launches_per_frame, "avg_launch_ms": ks[dom]["avg_ms"],
                            "note": "algorithmic bytes = 4*w*h per candidate (+8 B result), rows halved under subShift; fused TU = 6*w*h + 24 B (SURVEY 8d)"}
+    if overlap is not None:
+        out["overlap"] = overlap
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(wl)

@@ -140,6 +140,18 @@ class FrameWorkload:
         if timers is not None:
             timers.stop("SUBPEL")
 
+    def run_overlapped(self, streams):
+        """the same four launches, each on its own HIP stream (they are independent work lists): successive steps pipeline per stream"""
+        import torch
+        hp = self.hp
+        calls = [lambda f=f: hp.dist_multi(f, self.org, self.ref, self.job_tables[f], self.bit_depth) for f in ("SAD", "HAD_fast", "SSE")]
+        calls.append(lambda: hp.tu_rdo_multi(self.resi, self.tu_table, self.bit_depth))
+        for i, c in enumerate(calls):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                hp.use_torch_stream()
+                c()
+        hp.use_torch_stream()
+
     # one pass of the hot path over the frame: 3 merged distortion launches + 1 merged fused-TU launch (or 12 + 3 per-size ones)
     def run(self, timers=None):
         hp = self.hp
