@@ -33,11 +33,9 @@ __device__ __forceinline__ u32x4 ld16( const int16_t* p ) { return reinterpret_c
 __device__ __forceinline__ int lo16( uint32_t v ) { return ( int ) ( int16_t ) ( v & 0xffffu ); }
 __device__ __forceinline__ int hi16( uint32_t v ) { return ( int ) ( ( int32_t ) v >> 16 ); }
 
-__device__ __forceinline__ int waveSum( int v )
+__device__ __forceinline__ int waveSum( int v )       // DPP row operations + 4 readlanes instead of six ds_bpermute shuffles
 {
-#pragma unroll
-  for( int o = 32; o > 0; o >>= 1 ) v += __shfl_xor( v, o );
-  return v;
+  return ( int ) vvhipGroupSum32( ( uint32_t ) v, 64, threadIdx.x & 63 );
 }
 
 // 1/16-pel interpolation filters of the MCTF search.  Row f of kFilter4 = MCTF::m_interpolationFilter4[f] (MCTF.cpp:92-110),
@@ -137,8 +135,11 @@ __device__ __forceinline__ int meError( const MeGeom& g, int x, int y, int dx, i
                   : waveErrorFrac<false>( o, g.orgStride, b, g.bufStride, w, h, fx, fy, g.maxVal, sTmp, lane );
 }
 
-#define ME_TRY( DX, DY ) do { const int dx_ = ( DX ), dy_ = ( DY ); const int e_ = meError( g, bx, by, dx_, dy_, sTmp, lane ); \
-                              if( e_ < bestE ) { bestX = dx_; bestY = dy_; bestE = e_; } } while( 0 )
+// A candidate equal to the current best vector cannot win (same error, the update needs a strictly smaller one): it is not evaluated.
+#define ME_TRY( DX, DY ) do { const int dx_ = ( DX ), dy_ = ( DY );                                                              \
+                              if( bestE == 0x7fffffff || dx_ != bestX || dy_ != bestY ) {                                       \
+                                const int e_ = meError( g, bx, by, dx_, dy_, sTmp, lane );                                       \
+                                if( e_ < bestE ) { bestX = dx_; bestY = dy_; bestE = e_; } } } while( 0 )
 
 // ---- phase A -------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__( 64 )
@@ -215,6 +216,7 @@ meWavefrontKernel( MeGeom g, int nbx, vvhip_mv* __restrict__ mvs, int mvsW, unsi
     const int bx = bxi * bs;
     vvhip_mv& m = mvs[byi * mvsW + bxi];
     int bestX = m.x, bestY = m.y, bestE = m.error;
+    int aboveX = 0, aboveY = 0; bool haveAbove = false;
     if( byi > 0 )                                                         // MCTF.cpp:1289-1297
     {
       unsigned long long gr = 0;
@@ -233,9 +235,11 @@ meWavefrontKernel( MeGeom g, int nbx, vvhip_mv* __restrict__ mvs, int mvsW, unsi
       }
       const uint32_t glo = __shfl( ( uint32_t ) gr, 0 ), ghi = __shfl( ( uint32_t ) ( gr >> 32 ), 0 );
       if( ghi != 1u ) return;                                             // aborted: bounded spin expired (reported by the host)
-      ME_TRY( ( int ) ( int16_t ) ( glo >> 16 ), ( int ) ( int16_t ) ( glo & 0xffffu ) );
+      aboveX = ( int ) ( int16_t ) ( glo >> 16 ); aboveY = ( int ) ( int16_t ) ( glo & 0xffffu ); haveAbove = true;
+      ME_TRY( aboveX, aboveY );
     }
-    if( bxi > 0 ) ME_TRY( leftX, leftY );                                 // MCTF.cpp:1298-1306
+    // the left block's vector: evaluated unless it is the vector just tested (same error: loses to it or ties with the unchanged best)
+    if( bxi > 0 && !( haveAbove && leftX == aboveX && leftY == aboveY ) ) ME_TRY( leftX, leftY );                  // MCTF.cpp:1298-1306
     leftX = bestX; leftY = bestY;
     if( lane == 0 )
     {
