@@ -119,3 +119,17 @@ def test_hip_mctf_stage_on_device_bitstream_identical(clip):
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][9] >= 1 and hip["calls"][7] >= 1000000, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+def test_hip_backend_multithreaded_encoder_bitstream_identical():
+    """the encoder's own worker threads (4) call the table entries concurrently (RdCost/TrQuant/Quant are per worker, g_tCoeffOps and MCTF
+    are shared: SURVEY 8b "Threading"); the shim serialises its staging area.  Every table on the device (mask 31 + interpolation 64 +
+    MCTF filter 128), bitstream equal to the single-threaded CPU encode's (the reference's multi-threading is deterministic)."""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    cpu = run(dict(CFG10, hip=False, simd=None, mask=0, threads=4))
+    hip = run(dict(CFG10, hip=True, simd=None, mask=31 + 64 + 128, threads=4))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][0] > 1000 and hip["calls"][8] > 100 and hip["calls"][9] >= 1, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
