@@ -41,51 +41,56 @@ __device__ __forceinline__ float fastExp( float n, float d )     // MCTF.cpp:359
   return x;
 }
 
+#define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+
+// One workgroup (4 waves) per filter block.  The references are independent until the blend, so wave v compensates, corrects and measures
+// references v, v+4, ... on its own (wave-level synchronisation only, private LDS scratch, DPP reductions); one workgroup barrier, then all
+// 256 threads blend.
 __global__ void __launch_bounds__( 256 )
 mctfApplyKernel( const int16_t* __restrict__ org, int orgStride, int refStride, int16_t* __restrict__ out, int outStride, ApplyArgs A )
 {
-  __shared__ int16_t sCorr[MAX_REFS][MAX_BLK * MAX_BLK / 4];     // sized for blocks up to 16x16 (256 samples) per reference; see host check
-  __shared__ int16_t sTmp[( 16 + 7 ) * 16];
-  __shared__ long long sSum[4];                                  // block sums (planar: x*z, y*z, z; noise: variance, diffsum)
-  __shared__ int sB[3];
+  __shared__ int16_t sCorr[MAX_REFS][MAX_BLK * MAX_BLK / 4];     // blocks up to 16x16 (256 samples) per reference; see host check
+  __shared__ int16_t sTmpAll[4][( 16 + 7 ) * 16];
   __shared__ int sNoise[MAX_REFS], sErr[MAX_REFS];
 
   const int blk = A.blk, bxI = blockIdx.x, byI = blockIdx.y;
   const int bx = bxI * blk, by = byI * blk;
   const int w = min( blk, A.width - bx ), h = min( blk, A.height - by );
-  const int tid = threadIdx.x, nThr = blockDim.x, lane = tid & 63;
+  const int tid = threadIdx.x, nThr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int maxv = ( 1 << A.bitDepth ) - 1;
   const int16_t* orgBlk = org + ( ptrdiff_t ) by * orgStride + bx;
+  int16_t* sTmp = sTmpAll[wave];
 
-  for( int i = 0; i < A.numRefs; i++ )
+  for( int i = wave; i < A.numRefs; i += ( nThr >> 6 ) )
   {
     const vvhip_mv mv = A.mvs[i][byI * A.mvW + bxI];
     const int dx = mv.x >> A.cs, dy = mv.y >> A.cs, xInt = mv.x >> ( 4 + A.cs ), yInt = mv.y >> ( 4 + A.cs );
     const int16_t* src = A.refs[i] + ( ptrdiff_t ) ( by + yInt ) * refStride + bx + xInt;
-    // ---- applyFrac: horizontal pass into sTmp (Pel truncation, no clip), vertical pass into sCorr[i] (clip)
+    int16_t* corr = sCorr[i];
+    // ---- applyFrac: horizontal pass into sTmp (Pel truncation, no clip), vertical pass into corr (clip)
     if( A.lowRes )
     {
       const int16_t* xf = cApply4[dx & 15]; const int16_t* yf = cApply4[dy & 15];
-      for( int e = tid; e < ( h + 3 ) * w; e += nThr )
+      for( int e = lane; e < ( h + 3 ) * w; e += 64 )
       {
         const int r = e / w, x = e - r * w;
         const int16_t* p = src + ( ptrdiff_t ) ( r - 1 ) * refStride + x - 1;
         const int sum = xf[0] * p[0] + xf[1] * p[1] + xf[2] * p[2] + xf[3] * p[3];
         sTmp[r * w + x] = ( int16_t ) ( ( sum + 32 ) >> 6 );
       }
-      __syncthreads();
-      for( int e = tid; e < h * w; e += nThr )
+      WAVE_SYNC();
+      for( int e = lane; e < h * w; e += 64 )
       {
         const int y = e / w, x = e - y * w;
         const int sum = yf[0] * sTmp[y * w + x] + yf[1] * sTmp[( y + 1 ) * w + x] + yf[2] * sTmp[( y + 2 ) * w + x] + yf[3] * sTmp[( y + 3 ) * w + x];
         const int v = ( sum + 32 ) >> 6;
-        sCorr[i][e] = ( int16_t ) ( v < 0 ? 0 : ( v > maxv ? maxv : v ) );
+        corr[e] = ( int16_t ) ( v < 0 ? 0 : ( v > maxv ? maxv : v ) );
       }
     }
     else
     {
       const int16_t* xf = cApply6[dx & 15]; const int16_t* yf = cApply6[dy & 15];
-      for( int e = tid; e < ( h + 5 ) * w; e += nThr )       // rows 1 .. h+5 of the reference's temp array <-> source rows -2 .. h+2
+      for( int e = lane; e < ( h + 5 ) * w; e += 64 )       // rows 1 .. h+5 of the reference's temp array <-> source rows -2 .. h+2
       {
         const int r = e / w + 1, x = e - ( r - 1 ) * w;
         const int16_t* p = src + ( ptrdiff_t ) ( r - 3 ) * refStride + x - 3;
@@ -94,92 +99,76 @@ mctfApplyKernel( const int16_t* __restrict__ org, int orgStride, int refStride, 
         for( int k = 1; k <= 6; k++ ) sum += xf[k] * p[k];
         sTmp[r * w + x] = ( int16_t ) ( ( sum + 32 ) >> 6 );
       }
-      __syncthreads();
-      for( int e = tid; e < h * w; e += nThr )
+      WAVE_SYNC();
+      for( int e = lane; e < h * w; e += 64 )
       {
         const int y = e / w, x = e - y * w;
         int sum = 0;
 #pragma unroll
         for( int k = 1; k <= 6; k++ ) sum += yf[k] * sTmp[( y + k ) * w + x];
         const int v = ( sum + 32 ) >> 6;
-        sCorr[i][e] = ( int16_t ) ( v < 0 ? 0 : ( v > maxv ? maxv : v ) );
+        corr[e] = ( int16_t ) ( v < 0 ? 0 : ( v > maxv ? maxv : v ) );
       }
     }
-    if( tid < 4 ) sSum[tid] = 0;
-    __syncthreads();
-    // ---- planar correction of the compensated block (MCTF.cpp:1473-1476)
+    WAVE_SYNC();
+    // ---- planar correction of the compensated block (MCTF.cpp:1473-1476): every lane evaluates the (wave-uniform) plane parameters
     if( mv.rmsme > 0 && A.qp <= 32 && w == h && w <= 32 )
     {
       int x1 = 0, x2 = 0, ys = 0;
-      for( int e = tid; e < h * w; e += nThr )
+      for( int e = lane; e < h * w; e += 64 )
       {
         const int y = e / w, x = e - y * w;
-        const int z = ( int ) sCorr[i][e] - ( int ) orgBlk[( ptrdiff_t ) y * orgStride + x];
+        const int z = ( int ) corr[e] - ( int ) orgBlk[( ptrdiff_t ) y * orgStride + x];
         x1 += x * z; x2 += y * z; ys += z;
       }
-      // sums fit int32 (|z| < 2^12, x < 32, <= 1024 samples); add as sign-extended 64-bit through LDS atomics
-      atomicAdd( ( unsigned long long* ) &sSum[0], ( unsigned long long ) ( long long ) x1 );
-      atomicAdd( ( unsigned long long* ) &sSum[1], ( unsigned long long ) ( long long ) x2 );
-      atomicAdd( ( unsigned long long* ) &sSum[2], ( unsigned long long ) ( long long ) ys );
-      __syncthreads();
-      if( tid == 0 )
-      {
-        const int xSzm[6] = { 0, 1, 20, 336, 5440, 87296 };
-        const int blockSize = w * h; int log2Width = 0; while( ( 2 << log2Width ) <= w ) log2Width++;
-        const unsigned me2 = ( unsigned ) ( uint16_t ) mv.rmsme * ( unsigned ) ( uint16_t ) mv.rmsme;
-        const int mWeight = ( int ) ( me2 < 512u ? me2 : 512u );
-        const int xSum = ( blockSize * ( w - 1 ) ) >> 1;
-        const int x1yzm = ( int ) sSum[0], x2yzm = ( int ) sSum[1], ySum = ( int ) sSum[2];
-        const long long denom = ( long long ) blockSize * xSzm[log2Width];
-        long long numer = ( long long ) mWeight * ( ( long long ) x1yzm * blockSize - xSum * ySum );
-        int b1 = ( int ) ( ( numer < 0 ? numer - ( denom >> 1 ) : numer + ( denom >> 1 ) ) / denom );
-        b1 = b1 < -32768 ? -32768 : ( b1 > 32767 ? 32767 : b1 );
-        numer = ( long long ) mWeight * ( ( long long ) x2yzm * blockSize - xSum * ySum );
-        int b2 = ( int ) ( ( numer < 0 ? numer - ( denom >> 1 ) : numer + ( denom >> 1 ) ) / denom );
-        b2 = b2 > 32767 ? 32767 : ( b2 < -32768 ? -32768 : b2 );
-        sB[0] = ( mWeight * ySum - ( b1 + b2 ) * xSum + ( blockSize >> 1 ) ) >> ( log2Width << 1 );
-        sB[1] = b1; sB[2] = b2;
-        sSum[0] = 0; sSum[1] = 0; sSum[2] = 0;
-      }
-      __syncthreads();
-      const int b0 = sB[0], b1 = sB[1], b2 = sB[2];
+      // the block sums fit int32 (|z| < 2^12, x < 32, <= 1024 samples): modular 32-bit wave sums are exact
+      const int x1yzm = ( int ) vvhipGroupSum32( ( uint32_t ) x1, 64, lane ), x2yzm = ( int ) vvhipGroupSum32( ( uint32_t ) x2, 64, lane ), ySum = ( int ) vvhipGroupSum32( ( uint32_t ) ys, 64, lane );
+      const int xSzm[6] = { 0, 1, 20, 336, 5440, 87296 };
+      const int blockSize = w * h; int log2Width = 0; while( ( 2 << log2Width ) <= w ) log2Width++;
+      const unsigned me2 = ( unsigned ) ( uint16_t ) mv.rmsme * ( unsigned ) ( uint16_t ) mv.rmsme;
+      const int mWeight = ( int ) ( me2 < 512u ? me2 : 512u );
+      const int xSum = ( blockSize * ( w - 1 ) ) >> 1;
+      const long long denom = ( long long ) blockSize * xSzm[log2Width];
+      long long numer = ( long long ) mWeight * ( ( long long ) x1yzm * blockSize - xSum * ySum );
+      int b1 = ( int ) ( ( numer < 0 ? numer - ( denom >> 1 ) : numer + ( denom >> 1 ) ) / denom );
+      b1 = b1 < -32768 ? -32768 : ( b1 > 32767 ? 32767 : b1 );
+      numer = ( long long ) mWeight * ( ( long long ) x2yzm * blockSize - xSum * ySum );
+      int b2 = ( int ) ( ( numer < 0 ? numer - ( denom >> 1 ) : numer + ( denom >> 1 ) ) / denom );
+      b2 = b2 > 32767 ? 32767 : ( b2 < -32768 ? -32768 : b2 );
+      const int b0 = ( mWeight * ySum - ( b1 + b2 ) * xSum + ( blockSize >> 1 ) ) >> ( log2Width << 1 );
       if( b0 != 0 || b1 != 0 || b2 != 0 )
-        for( int e = tid; e < h * w; e += nThr )
+        for( int e = lane; e < h * w; e += 64 )
         {
           const int y = e / w, x = e - y * w;
           const int p = ( b0 + b1 * x + b2 * y + 256 ) >> 9;
-          const int z = ( int ) sCorr[i][e] - p;
-          sCorr[i][e] = ( int16_t ) ( z < 0 ? 0 : ( z > maxv ? maxv : z ) );
+          const int z = ( int ) corr[e] - p;
+          corr[e] = ( int16_t ) ( z < 0 ? 0 : ( z > maxv ? maxv : z ) );
         }
-      __syncthreads();
+      WAVE_SYNC();
     }
     // ---- noise estimate of reference i (MCTF.cpp:445-477)
     {
-      long long variance = 0, diffsum = 0;
-      for( int e = tid; e < h * w; e += nThr )
+      unsigned long long variance = 0, diffsum = 0;
+      for( int e = lane; e < h * w; e += 64 )
       {
         const int y = e / w, x = e - y * w;
-        const int diff = ( int ) orgBlk[( ptrdiff_t ) y * orgStride + x] - ( int ) sCorr[i][e];
-        variance += diff * diff;
-        if( x != w - 1 ) { const int dR = ( int ) orgBlk[( ptrdiff_t ) y * orgStride + x + 1] - ( int ) sCorr[i][e + 1]; diffsum += ( dR - diff ) * ( dR - diff ); }
-        if( y != h - 1 ) { const int dD = ( int ) orgBlk[( ptrdiff_t ) ( y + 1 ) * orgStride + x] - ( int ) sCorr[i][e + w]; diffsum += ( dD - diff ) * ( dD - diff ); }
+        const int diff = ( int ) orgBlk[( ptrdiff_t ) y * orgStride + x] - ( int ) corr[e];
+        variance += ( unsigned ) ( diff * diff );
+        if( x != w - 1 ) { const int dR = ( int ) orgBlk[( ptrdiff_t ) y * orgStride + x + 1] - ( int ) corr[e + 1]; diffsum += ( unsigned ) ( ( dR - diff ) * ( dR - diff ) ); }
+        if( y != h - 1 ) { const int dD = ( int ) orgBlk[( ptrdiff_t ) ( y + 1 ) * orgStride + x] - ( int ) corr[e + w]; diffsum += ( unsigned ) ( ( dD - diff ) * ( dD - diff ) ); }
       }
-      atomicAdd( ( unsigned long long* ) &sSum[0], ( unsigned long long ) variance );
-      atomicAdd( ( unsigned long long* ) &sSum[1], ( unsigned long long ) diffsum );
-      __syncthreads();
-      if( tid == 0 )
+      long long var = ( long long ) vvhipGroupSum64( variance, 64, lane ), dsum = ( long long ) vvhipGroupSum64( diffsum, 64, lane );      // per-lane values < 2^50
+      if( lane == 0 )
       {
-        long long var = sSum[0], dsum = sSum[1];
         var  *= ( long long ) 1 << ( 2 * ( 10 - A.bitDepth ) );
         dsum *= ( long long ) 1 << ( 2 * ( 10 - A.bitDepth ) );
         const int cntV = w * h, cntD = 2 * cntV - w - h;
         sNoise[i] = ( int ) round( ( 15.0 * cntD / cntV * var + 5.0 ) / ( dsum + 5.0 ) );
         sErr[i] = mv.error;
       }
-      __syncthreads();
     }
-    ( void ) lane;
   }
+  __syncthreads();
 
   // ---- per-reference weights (every thread evaluates the same scalar expressions) and the blend (MCTF.cpp:479-517)
   int minError = 0x7fffffff;
@@ -245,7 +234,7 @@ int vvhip_mctf_apply_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride
   a.weightScaling = weight_scaling; a.sigmaSq = sigma_sq; a.numRefs = num_refs; a.cs = chroma_shift; a.bitDepth = bit_depth; a.blk = blk; a.lowRes = low_res_flt_apply ? 1 : 0;
   a.qp = qp; a.mvW = mv_w; a.width = width; a.height = height;
   const dim3 grid( ( width + blk - 1 ) / blk, ( height + blk - 1 ) / blk );
-  hipLaunchKernelGGL( mctfApplyKernel, grid, dim3( blk * blk < 64 ? 64 : blk * blk ), 0, ctx->stream, d_org, org_stride, ref_stride, d_out, out_stride, a );
+  hipLaunchKernelGGL( mctfApplyKernel, grid, dim3( 256 ), 0, ctx->stream, d_org, org_stride, ref_stride, d_out, out_stride, a );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
 }
