@@ -244,6 +244,18 @@ VVHIP_API int vvhip_subpel_dist_batch( vvhip_ctx* ctx, int func, const int16_t* 
                                        int width, int height, int bit_depth, int filter_mode, int use_alt_hpel,
                                        const vvhip_subpel_item* d_items, int n, uint64_t* d_out );
 
+/* Pattern refinement in one call: for every block, n_offsets sub-pel positions around ITS base vector (d_bases[b]: original block, integer
+ * position and fraction of the base vector) — candidate k is base + offsets_host[k] (dx, dy in 1/16 sample, |.| <= 16) —
+ *   d_out[b * n_offsets + k] = distortion( original block, block interpolated at candidate k )       (func as vvhip_subpel_dist_batch)
+ * i.e. one stage of InterSearch::xPatternRefinement (EncoderLib/InterSearch.cpp:760-880: the 8 half-sample neighbours, then the 8
+ * quarter-sample neighbours) for many blocks.  Same values as vvhip_subpel_dist_batch on the expanded candidate list; the reference
+ * window is staged in LDS once per block and the horizontal pass is shared between positions with the same
+ * horizontal offset; the distortion kernels then score the prediction blocks.  width a multiple of 8, blocks up to 64x64; the
+ * reference plane needs 5 samples of margin beyond every block.                                                                                                       */
+VVHIP_API int vvhip_subpel_refine_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_ref, int ref_stride,
+                                         int width, int height, int bit_depth, int filter_mode, int use_alt_hpel,
+                                         const vvhip_subpel_item* d_bases, int n_blocks, const int16_t* offsets_host, int n_offsets, uint64_t* d_out );
+
 /* ROM accessors (host memory out): the tables the kernels use, for parity checks against
  * g_trCore* (CommonLib/RomTr.cpp:364-449) and getScanOrder (CommonLib/Rom.h:104).               */
 VVHIP_API int vvhip_get_tr_matrix_host( int tr_type, int log2_size, int16_t* host_out );

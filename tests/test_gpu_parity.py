@@ -530,3 +530,38 @@ def test_dmvr_refine_vs_oracle(hip, oracle):
                     assert got == exp, (bd, sx, sy, dx, dy, k, got, exp)
                     moved += got[0] != 0 or got[1] != 0
         assert moved > 100
+
+
+def test_subpel_refine_equals_candidate_list(hip):
+    """vvhip_subpel_refine_batch (LDS window, shared horizontal passes) == vvhip_subpel_dist_batch on the expanded candidate list, which is
+    pinned to the oracle/reference above; half-sample and quarter-sample stages, every function and tap mode, fractional base vectors"""
+    from vvenc_amd.hotpath import SUBPEL_DTYPE
+    hp = hip.hp
+    rng = np.random.default_rng(302)
+    yy, xx = np.mgrid[0:200, 0:320]
+    ref = np.clip(512 + 200 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + rng.normal(0, 25, (200, 320)), 0, 1023).astype(np.int16)
+    org = np.clip(np.roll(ref, (1, 2), (0, 1)).astype(np.int32) + rng.integers(-6, 7, (200, 320)), 0, 1023).astype(np.int16)
+    po, pr = hp.plane(org, 0), hp.plane(ref, 0)
+    half = [(-8, 0), (8, 0), (0, -8), (0, 8), (-8, -8), (8, -8), (-8, 8), (8, 8)]
+    quarter = [(-4, 0), (4, 0), (0, -4), (0, 4), (-4, -4), (4, -4), (-4, 4), (4, 4), (0, 0)]
+    wide = [(-16, 16), (16, -16), (3, -13), (-11, 7)]
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (32, 16)):
+        nb = 19
+        bases = np.zeros(nb, SUBPEL_DTYPE)
+        for k in range(nb):
+            ox, oy = int(rng.integers(8, 320 - w - 8)), int(rng.integers(8, 200 - h - 8))
+            rx, ry = int(rng.integers(8, 320 - w - 8)), int(rng.integers(8, 200 - h - 8))
+            bases[k] = (oy * po.stride + ox, ry * pr.stride + rx, int(rng.integers(0, 4)) * 4, int(rng.integers(0, 4)) * 4)
+        d_b = hp.to_device(bases)
+        for offs, mode, alt, funcs in ((half, 0, False, ("HAD", "HAD_fast", "SAD", "SSE")), (quarter, 0, False, ("HAD_fast",)), (half, 1, False, ("HAD",)),
+                                       (quarter, 2, True, ("SAD",)), (wide, 0, True, ("SSE", "HAD_fast"))):
+            cand = np.zeros(nb * len(offs), SUBPEL_DTYPE)
+            for b in range(nb):
+                for k, (dx, dy) in enumerate(offs):
+                    tx, ty = int(bases[b]["frac_x"]) + dx, int(bases[b]["frac_y"]) + dy
+                    cand[b * len(offs) + k] = (bases[b]["org_off"], int(bases[b]["ref_off"]) + (ty >> 4) * pr.stride + (tx >> 4), tx & 15, ty & 15)
+            d_c = hp.to_device(cand)
+            for func in funcs:
+                got = hp.subpel_refine_batch(func, po, pr, d_b, nb, offs, w, h, 10, mode, alt).cpu().numpy()
+                exp = hp.subpel_dist_batch(func, po, pr, d_c, cand.size, w, h, 10, mode, alt).cpu().numpy()
+                assert np.array_equal(got, exp), (w, h, func, mode, alt, np.argwhere(got != exp)[:4].ravel(), got[:4], exp[:4])

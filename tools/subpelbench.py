@@ -39,5 +39,16 @@ for S in (8, 16, 32, 64):
     pred = torch.empty(n * S * S, dtype=torch.int16, device=hp.device)
     t_pred = timeit(lambda: hp.interp_luma_batch(pr, d_it, n, S, S, 10, True, 0, False, out=pred))
     t_all = timeit(lambda: hp.subpel_dist_batch("HAD_fast", po, pr, d_it, n, S, S, 10, 0, False, out=out))
+    # the same 16 positions through the pattern-refinement entry (window + original staged once per block)
+    bases = np.zeros(nb, SUBPEL_DTYPE)
+    bases["org_off"] = by * po.stride + bx
+    bases["ref_off"] = (by + (mvy >> 2)) * pr.stride + bx + (mvx >> 2)
+    bases["frac_x"] = (mvx & 3) << 2
+    bases["frac_y"] = (mvy & 3) << 2
+    d_b = hp.to_device(bases)
+    offs16 = [(4 * dx, 4 * dy) for (dx, dy) in offs]
+    out2 = torch.empty(n, dtype=torch.int64, device=hp.device)
+    t_ref = timeit(lambda: hp.subpel_refine_batch("HAD_fast", po, pr, d_b, nb, offs16, S, S, 10, 0, False, out=out2))
+    ok = torch.equal(out2.view(nb, 16).t().contiguous().view(-1), out)
     alg = n * ((S + 7) * (S + 7) * 2 + S * S * 2 + 8)
-    print("subpel S=%2d cands=%8d : interp %8.1f us, interp+HAD %8.1f us, %6.2f Gsamples/s predicted, algorithmic %7.1f GB/s" % (S, n, t_pred, t_all, n * S * S / t_all / 1e3, alg / t_all / 1e3))
+    print("subpel S=%2d cands=%8d : interp %8.1f us, interp+HAD %8.1f us (%7.1f GB/s algorithmic) | refine entry %8.1f us (%7.1f GB/s algorithmic, %6.2f Gsamples/s), equal=%s" % (S, n, t_pred, t_all, alg / t_all / 1e3, t_ref, alg / t_ref / 1e3, n * S * S / t_ref / 1e3, ok))

@@ -346,6 +346,124 @@ ifPredBatchWideKernel( const int16_t* __restrict__ ref, int refStride, const vvh
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pattern refinement (InterSearch::xPatternRefinement, EncoderLib/InterSearch.cpp:760-880): K sub-pel positions around ONE base vector per
+// block.  One block per 64 or 256 threads: the reference window (h+9) x (w+10) is staged in LDS once (coalesced HBM reads); the
+// horizontal pass runs once per DISTINCT horizontal offset (3 for the 8-neighbour stages — the reference shares its planes the same
+// way) over all window rows into LDS; the vertical passes of all K positions then run concurrently and write the prediction blocks
+// (compact, candidate-list order) for the distortion kernels.  Every position is horizontal-then-vertical with the copy forms for a
+// zero phase: the same values as the single-pass forms the reference's dispatch uses for one-directional vectors (floor(floor(a)+b)/c
+// = floor((a+b)/c) for integer b, c).
+// ---------------------------------------------------------------------------------------------
+struct RefineOffsets { int n, nHor; int16_t dx[16], dy[16], horDx[16]; int8_t horOf[16]; };
+
+// base vectors x offsets -> explicit candidate list (large blocks go through the per-candidate kernel: enough parallelism per candidate)
+__global__ void __launch_bounds__( 256 )
+refineExpandKernel( const vvhip_subpel_item* __restrict__ bases, int nBlocks, int refStride, RefineOffsets offs, vvhip_subpel_item* __restrict__ cand )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= nBlocks * offs.n ) return;
+  const int b = i / offs.n, k = i - b * offs.n;
+  const vvhip_subpel_item base = bases[b];
+  const int tx = ( base.frac_x & 15 ) + offs.dx[k], ty = ( base.frac_y & 15 ) + offs.dy[k];
+  vvhip_subpel_item c; c.org_off = base.org_off; c.ref_off = base.ref_off + ( ty >> 4 ) * refStride + ( tx >> 4 ); c.frac_x = ( int16_t ) ( tx & 15 ); c.frac_y = ( int16_t ) ( ty & 15 );
+  cand[i] = c;
+}
+
+__global__ void __launch_bounds__( 256 )
+refinePredKernel( const int16_t* __restrict__ ref, int refStride, const vvhip_subpel_item* __restrict__ bases, int nBlocks, int w, int h, int bitDepth, int filterMode,
+                  int useAlt, int blocksPerWg, RefineOffsets offs, int16_t* __restrict__ pred, vvhip_dist_item* __restrict__ distItems )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sRef[];
+  const int tpb = 256 / blocksPerWg, sub = threadIdx.x / tpb, t = threadIdx.x - sub * tpb;
+  const int blk = blockIdx.x * blocksPerWg + sub;
+  const bool valid = blk < nBlocks;
+  const int wp = w + 10, rows = h + 9, w8 = w >> 3;
+  const int oTmp = ( rows * wp + 7 ) & ~7, slotElems = oTmp + offs.nHor * rows * w;            // every region starts on 16 bytes (w is a multiple of 8)
+  int16_t* win = sRef + ( size_t ) sub * slotElems;      // window rows y-4 .. y+h+4, columns x-4 .. x+w+5
+  int16_t* tmp = win + oTmp;                              // [horizontal variant][window row][w]: first-pass samples, column shift applied
+  vvhip_subpel_item base = { 0, 0, 0, 0 };
+  if( valid )
+  {
+    base = bases[blk];
+    const int16_t* src = ref + base.ref_off - 4 * ( ptrdiff_t ) refStride - 4;
+    for( int e = t; e < rows * wp; e += tpb ) { const int r = e / wp, c = e - r * wp; win[e] = src[( ptrdiff_t ) r * refStride + c]; }
+    if( blockIdx.y == 0 ) for( int k = t; k < offs.n; k += tpb ) { vvhip_dist_item d; d.org_off = base.org_off; d.cur_off = ( blk * offs.n + k ) * w * h; distItems[( size_t ) blk * offs.n + k] = d; }
+  }
+#define REFINE_SYNC() { if( tpb == 64 ) { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); }
+  REFINE_SYNC();
+  const int sh = 14 - bitDepth > 2 ? 14 - bitDepth : 2, maxv = ( 1 << bitDepth ) - 1;
+  if( valid )
+  {
+    // ---- horizontal pass, every distinct horizontal offset x every window row: tmp[v][r][x] <-> picture column x + sx
+    const PassGeom g1 = passGeom( 1, 0, bitDepth );
+    for( int i = t; i < offs.nHor * rows * w8; i += tpb )
+    {
+      const int v = i / ( rows * w8 ), rem = i - v * rows * w8, r = rem / w8, x0 = ( rem - r * w8 ) << 3;
+      const int txx = ( base.frac_x & 15 ) + offs.horDx[v], sx = txx >> 4, fx = txx & 15;
+      int16_t* dst = tmp + ( v * rows + r ) * w + x0;
+      if( fx )
+      {
+        const Taps th = loadTaps( tapSet( fx, w, h, filterMode, useAlt, true ), filterMode == 2 && !( useAlt && fx == 8 ) ? fx << 1 : fx );
+        const int16_t* p = win + r * wp + x0 + sx + 1;
+        int wv[15], accv[8];
+#pragma unroll
+        for( int j = 0; j < 15; j++ ) wv[j] = p[j];
+        mac8( accv, wv, th );
+        store8( dst, accv, g1 );
+      }
+      else
+      {
+        Row8 o;
+#pragma unroll
+        for( int c = 0; c < 8; c++ ) o.v[c] = ( int16_t ) ( ( int16_t ) ( ( uint16_t ) win[r * wp + x0 + c + sx + 4] << sh ) - 8192 );       // filterCopy<true,false>
+        *reinterpret_cast<Row8*>( dst ) = o;
+      }
+    }
+  }
+  REFINE_SYNC();
+  if( !valid ) return;
+  // ---- vertical passes of this workgroup's share of the positions (gridDim.y splits them when there are few blocks): prediction row y <->
+  // window rows y + sy + 1 .. + 8 (taps), last pass (clip)
+  const PassGeom g2 = passGeom( 0, 1, bitDepth );
+  const int kPer = ( offs.n + gridDim.y - 1 ) / gridDim.y, k0 = blockIdx.y * kPer, k1 = min( offs.n, k0 + kPer );
+  for( int i = t; i < ( k1 - k0 ) * h * w8; i += tpb )
+  {
+    const int k = k0 + i / ( h * w8 ), rem = i - ( k - k0 ) * h * w8, y = rem / w8, x0 = ( rem - y * w8 ) << 3;
+    const int tyy = ( base.frac_y & 15 ) + offs.dy[k], sy = tyy >> 4, fy = tyy & 15;
+    const int16_t* tv_ = tmp + offs.horOf[k] * rows * w;
+    int16_t* dst = pred + ( ( size_t ) blk * offs.n + k ) * w * h + y * w + x0;
+    if( fy )
+    {
+      const Taps tv = loadTaps( tapSet( fy, w, h, filterMode, useAlt, true ), filterMode == 2 && !( useAlt && fy == 8 ) ? fy << 1 : fy );
+      int accv[8];
+#pragma unroll
+      for( int c = 0; c < 8; c++ ) accv[c] = 0;
+#pragma unroll
+      for( int j = 0; j < 8; j++ )
+      {
+        const Row8 row = *reinterpret_cast<const Row8*>( tv_ + ( y + sy + 1 + j ) * w + x0 );
+#pragma unroll
+        for( int c = 0; c < 8; c++ ) accv[c] = __mul24( ( int ) row.v[c], tv.c[j] ) + accv[c];
+      }
+      store8( dst, accv, g2 );
+    }
+    else
+    {
+      const Row8 row = *reinterpret_cast<const Row8*>( tv_ + ( y + sy + 4 ) * w + x0 );
+      Row8 o;
+#pragma unroll
+      for( int c = 0; c < 8; c++ )
+      {
+        const int16_t v = ( int16_t ) ( ( ( int ) row.v[c] + ( int ) ( int16_t ) ( ( 1 << ( sh - 1 ) ) + 8192 ) ) >> sh );     // filterCopy<false,true>
+        o.v[c] = v < 0 ? ( int16_t ) 0 : ( v > maxv ? ( int16_t ) maxv : v );
+      }
+      *reinterpret_cast<Row8*>( dst ) = o;
+    }
+  }
+#undef REFINE_SYNC
+}
+
 } // namespace
 
 extern "C" {
@@ -436,6 +554,62 @@ int vvhip_subpel_dist_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int
   const int rc = launchPred( ctx, d_ref, ref_stride, d_items, n, width, height, bit_depth, 1, filter_mode, use_alt_hpel, pred, di );
   if( rc ) return rc;
   return vvhip_dist_batch( ctx, func, d_org, org_stride, pred, width, width, height, 0, bit_depth, di, n, d_out );
+}
+
+int vvhip_subpel_refine_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_ref, int ref_stride,
+                               int width, int height, int bit_depth, int filter_mode, int use_alt_hpel,
+                               const vvhip_subpel_item* d_bases, int n_blocks, const int16_t* offsets_host, int n_offsets, uint64_t* d_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !predArgsOk( width, height, bit_depth, filter_mode, n_blocks ) || ( width & 7 ) || width > 64 || height > 64 || n_offsets < 1 || n_offsets > 16 || !offsets_host ||
+      ( n_blocks && ( !d_org || !d_ref || !d_bases || !d_out ) ) )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_subpel_refine_batch: block %dx%d (width a multiple of 8, up to 64x64), %d offsets (1..16)", width, height, n_offsets );
+  RefineOffsets ro; ro.n = n_offsets; ro.nHor = 0;
+  for( int k = 0; k < 16; k++ ) { ro.dx[k] = k < n_offsets ? offsets_host[2 * k] : 0; ro.dy[k] = k < n_offsets ? offsets_host[2 * k + 1] : 0; ro.horDx[k] = 0; ro.horOf[k] = 0; }
+  for( int k = 0; k < n_offsets; k++ )
+  {
+    if( ro.dx[k] < -16 || ro.dx[k] > 16 || ro.dy[k] < -16 || ro.dy[k] > 16 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_subpel_refine_batch: offsets are limited to +-16 (one sample)" );
+    int v = 0; while( v < ro.nHor && ro.horDx[v] != ro.dx[k] ) v++;
+    if( v == ro.nHor ) ro.horDx[ro.nHor++] = ro.dx[k];          // distinct horizontal offsets share one first pass
+    ro.horOf[k] = ( int8_t ) v;
+  }
+  if( n_blocks == 0 ) return VVHIP_OK;
+  const size_t n = ( size_t ) n_blocks * n_offsets;
+  const size_t predBytes = ( n * width * height * sizeof( int16_t ) + 255 ) & ~( size_t ) 255, itemBytes = ( n * sizeof( vvhip_dist_item ) + 255 ) & ~( size_t ) 255;
+  const size_t need = predBytes + itemBytes + n * sizeof( vvhip_subpel_item );
+  if( need > ctx->subpelBytes )
+  {
+    VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+    if( ctx->d_subpel ) VVHIP_CHECK_HIP( ctx, hipFree( ctx->d_subpel ) );
+    ctx->d_subpel = nullptr; ctx->subpelBytes = 0;
+    VVHIP_CHECK_HIP( ctx, hipMalloc( &ctx->d_subpel, need + need / 4 ) );
+    ctx->subpelBytes = need + need / 4;
+  }
+  int16_t* pred = static_cast<int16_t*>( ctx->d_subpel );
+  vvhip_dist_item* di = reinterpret_cast<vvhip_dist_item*>( static_cast<char*>( ctx->d_subpel ) + predBytes );
+  if( width * height > 1024 )
+  {
+    vvhip_subpel_item* cand = reinterpret_cast<vvhip_subpel_item*>( static_cast<char*>( ctx->d_subpel ) + predBytes + itemBytes );
+    hipLaunchKernelGGL( refineExpandKernel, dim3( ( unsigned ) ( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, ctx->stream, d_bases, n_blocks, ref_stride, ro, cand );
+    VVHIP_LAUNCH_CHECK( ctx );
+    const int rc = launchPred( ctx, d_ref, ref_stride, cand, ( int ) n, width, height, bit_depth, 1, filter_mode, use_alt_hpel, pred, di );
+    if( rc ) return rc;
+    return vvhip_dist_batch( ctx, func, d_org, org_stride, pred, width, width, height, 0, bit_depth, di, ( int ) n, d_out );
+  }
+  const int rows = height + 9, wp = width + 10;
+  const size_t slotElems = ( size_t ) ( ( rows * wp + 7 ) & ~7 ) + ( size_t ) ro.nHor * rows * width;
+  int tpb = width * height <= 256 ? 64 : 256;
+  if( slotElems * ( 256 / tpb ) * sizeof( int16_t ) > 150 * 1024 ) tpb = 256;
+  const int bpw = 256 / tpb;
+  const size_t smem = slotElems * bpw * sizeof( int16_t );
+  if( smem > 150 * 1024 ) return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_subpel_refine_batch: %d distinct horizontal offsets of a %dx%d block need %zu B of LDS", ro.nHor, width, height, smem );
+  if( smem > 64 * 1024 ) VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) refinePredKernel, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) smem ) );
+  const int nWg = ( n_blocks + bpw - 1 ) / bpw;
+  const int splitK = 1;      // (the kernel can spread the positions over gridDim.y workgroups; re-staging the window costs more than it gains)
+  hipLaunchKernelGGL( refinePredKernel, dim3( nWg, splitK ), dim3( 256 ), smem, ctx->stream, d_ref, ref_stride, d_bases, n_blocks, width, height,
+                      bit_depth, filter_mode, use_alt_hpel ? 1 : 0, bpw, ro, pred, di );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return vvhip_dist_batch( ctx, func, d_org, org_stride, pred, width, width, height, 0, bit_depth, di, ( int ) n, d_out );
 }
 
 } // extern "C"

@@ -324,6 +324,15 @@ class HotPath:
                                                 w, h, bit_depth, filter_mode, int(use_alt_hpel), _ptr(d_items), n, _ptr(out)))
         return out
 
+    def subpel_refine_batch(self, func, org, ref, d_bases, n_blocks, offsets, w, h, bit_depth=10, filter_mode=0, use_alt_hpel=False, out=None):
+        """one xPatternRefinement stage for many blocks: offsets = [(dx, dy), ...] in 1/16 sample around each block's base vector -> (n_blocks, len(offsets)) costs"""
+        offs = np.ascontiguousarray(offsets, np.int16).reshape(-1, 2)
+        if out is None:
+            out = torch.empty(n_blocks * offs.shape[0], dtype=torch.int64, device=self.device)
+        self._ck(self.L.vvhip_subpel_refine_batch(self.ctx, DF[func] if isinstance(func, str) else func, org.buf_ptr, org.stride, ref.buf_ptr, ref.stride, w, h, bit_depth,
+                                                  filter_mode, int(use_alt_hpel), _ptr(d_bases), n_blocks, offs.ctypes.data_as(C.c_void_p), offs.shape[0], _ptr(out)))
+        return out
+
     # ---- (C) MCTF ----
     def extend_border(self, plane):
         self._ck(self.L.vvhip_extend_border(self.ctx, plane.buf_ptr, plane.stride, plane.width, plane.height, plane.pad))

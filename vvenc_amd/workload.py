@@ -102,32 +102,31 @@ class FrameWorkload:
         self.alg_bytes["TU"] = sum(self.alg_bytes["TU%d" % S] for S in TU_SIZES)
         self.class_launches_merged = {"SAD": 1, "HAD_fast": 1, "SSE": 1, "TU": 1}
 
-    # ---- optional fractional-ME stage: 16 sub-pel candidates (8 half-sample + 8 quarter-sample positions around a seeded
-    # integer vector) per block of every size, interpolated and scored with HAD_fast like InterSearch::xPatternRefinement
+    # ---- optional fractional-ME stage: 16 sub-pel positions (8 half-sample + 8 quarter-sample neighbours of a seeded
+    # base vector) per block of every size, interpolated and scored with HAD_fast like InterSearch::xPatternRefinement — one
+    # vvhip_subpel_refine_batch call per block size
+    SUBPEL_OFFSETS = [(-8, 0), (8, 0), (0, -8), (0, 8), (-8, -8), (8, -8), (-8, 8), (8, 8), (-4, 0), (4, 0), (0, -4), (0, 4), (-4, -4), (4, -4), (-4, 4), (4, 4)]
+
     def enable_subpel(self):
         import torch
         from .hotpath import SUBPEL_DTYPE
         hp = self.hp
         rng = np.random.default_rng(4242)
-        offs = [(-2, 0), (2, 0), (0, -2), (0, 2), (-2, -2), (2, -2), (-2, 2), (2, 2), (-1, 0), (1, 0), (0, -1), (0, 1), (-1, -1), (1, -1), (-1, 1), (1, 1)]
         self.subpel_jobs = []
         self.alg_bytes["SUBPEL"] = 0
         for S in SIZES:
             bx, by = np.meshgrid(np.arange(0, self.width - S + 1, S), np.arange(0, self.height - S + 1, S))
             bx, by = bx.ravel(), by.ravel()
             nb = bx.size
-            mvx, mvy = rng.integers(-12, 13, nb) * 4 + 12, rng.integers(-12, 13, nb) * 4 + 4          # quarter-sample units
-            it = np.zeros(nb * len(offs), SUBPEL_DTYPE)
-            for k, (dx, dy) in enumerate(offs):
-                qx, qy = mvx + dx, mvy + dy
-                sl = slice(k * nb, (k + 1) * nb)
-                it["org_off"][sl] = by * self.org.stride + bx
-                it["ref_off"][sl] = (by + (qy >> 2)) * self.ref.stride + bx + (qx >> 2)
-                it["frac_x"][sl] = (qx & 3) << 2
-                it["frac_y"][sl] = (qy & 3) << 2
-            n = it.size
-            self.subpel_jobs.append((S, n, hp.to_device(it), torch.empty(n, dtype=torch.int64, device=hp.device), it))
-            # per candidate: (S+7)^2 reference samples in, S^2 original samples in, 8 B out
+            mvx, mvy = rng.integers(-12, 13, nb) * 4 + 12, rng.integers(-12, 13, nb) * 4 + 4          # base vectors, quarter-sample units
+            bases = np.zeros(nb, SUBPEL_DTYPE)
+            bases["org_off"] = by * self.org.stride + bx
+            bases["ref_off"] = (by + (mvy >> 2)) * self.ref.stride + bx + (mvx >> 2)
+            bases["frac_x"] = (mvx & 3) << 2
+            bases["frac_y"] = (mvy & 3) << 2
+            n = nb * len(self.SUBPEL_OFFSETS)
+            self.subpel_jobs.append((S, nb, hp.to_device(bases), torch.empty(n, dtype=torch.int64, device=hp.device), bases))
+            # per position: (S+7)^2 reference samples in, S^2 original samples in, 8 B out
             self.alg_bytes["SUBPEL"] += n * (2 * (S + 7) * (S + 7) + 2 * S * S + 8)
         self.class_launches["SUBPEL"] = 2 * len(SIZES)
         self.class_launches_merged["SUBPEL"] = 2 * len(SIZES)
@@ -135,8 +134,8 @@ class FrameWorkload:
     def run_subpel(self, timers=None):
         if timers is not None:
             timers.start("SUBPEL")
-        for (S, n, d_it, out, _) in self.subpel_jobs:
-            self.hp.subpel_dist_batch("HAD_fast", self.org, self.ref, d_it, n, S, S, self.bit_depth, 0, False, out=out)
+        for (S, nb, d_b, out, _) in self.subpel_jobs:
+            self.hp.subpel_refine_batch("HAD_fast", self.org, self.ref, d_b, nb, self.SUBPEL_OFFSETS, S, S, self.bit_depth, 0, False, out=out)
         if timers is not None:
             timers.stop("SUBPEL")
 
