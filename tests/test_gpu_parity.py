@@ -565,3 +565,32 @@ def test_subpel_refine_equals_candidate_list(hip):
                 got = hp.subpel_refine_batch(func, po, pr, d_b, nb, offs, w, h, 10, mode, alt).cpu().numpy()
                 exp = hp.subpel_dist_batch(func, po, pr, d_c, cand.size, w, h, 10, mode, alt).cpu().numpy()
                 assert np.array_equal(got, exp), (w, h, func, mode, alt, np.argwhere(got != exp)[:4].ravel(), got[:4], exp[:4])
+
+
+def test_bad_arguments_are_reported_not_crashed(hip):
+    """error convention of the C ABI: negative code + message from vvhip_last_error, the context stays usable"""
+    import ctypes as C
+    import torch
+    from vvenc_amd.lib import VVHipError
+    hp = hip.hp
+    plane = hp.plane(np.zeros((64, 64), np.int16), 0)
+    items = hp.to_device(np.zeros((4, 2), np.int32))
+    out = torch.zeros(4, dtype=torch.int64, device=hp.device)
+    bad = [
+        lambda: hp.dist_batch("SAD", plane, plane, items, 4, 3, 8),                                   # width 3
+        lambda: hp.dist_batch("HAD", plane, plane, items, 4, 256, 256),                               # block larger than 128
+        lambda: hp.sad_x5_batch(plane, plane, items, 1, 32, 8),                                       # X5 exists for widths 8 and 16 only
+        lambda: hp.fwd_transform(plane, items[:, 0].contiguous(), 4, 128, 8),                         # no 128-point transform
+        lambda: hp.fwd_transform(plane, items[:, 0].contiguous(), 4, 64, 64, 2, 2),                   # DST-7 stops at 32
+        lambda: hp.interp_luma_batch(plane, items, 1, 256, 8),                                        # block too large
+        lambda: hp.subpel_refine_batch("HAD", plane, plane, items, 1, [(40, 0)], 8, 8),               # offset beyond one sample
+        lambda: hp.dmvr_refine_batch(plane, plane, items, 1, 32, 16),                                 # DMVR sub-blocks are at most 16x16
+        lambda: hp.mctf_apply_plane(plane, [plane], [items], 1, 0, [1.0], 1.0, 1.0, 10, 64),          # unit 64 unsupported
+    ]
+    for k, f in enumerate(bad):
+        with pytest.raises(VVHipError) as e:
+            f()
+        assert "vvhip" in str(e.value) or "vvenc_hip" in str(e.value), (k, str(e.value))
+    # still alive
+    good = hp.dist_batch("SAD", plane, plane, items, 4, 8, 8, out=out)
+    assert int(good.sum().item()) == 0
