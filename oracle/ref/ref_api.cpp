@@ -4,7 +4,7 @@
 // objects* (see oracle/ref/Makefile) so that tests can call the reference's kernel tables —
 // scalar row (enableOpt=false) and x86 SIMD row (enableOpt=true) — on seeded inputs, exactly
 // like test/vvenc_unit_test/vvenc_unit_test.cpp builds its `ref`/`opt` object pairs.
-// Used (a) to pin oracle/vvenc_oracle.c, (b) by tools/gen_golden.py to write tests/golden/*,
+// Used (a) to pin oracle/vvenc_oracle.c, (b) by tests/gen_golden.py to write tests/golden/*,
 // (c) optionally as bench.py's cpu_baseline (kind "reference").
 //
 // Nothing here is shipped: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg

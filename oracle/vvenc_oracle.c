@@ -10,7 +10,7 @@
  *   (a) against the reference itself, compiled from /root/reference by oracle/ref/Makefile into
  *       oracle/_ref/libvvenc_ref.so (scalar row AND x86-SIMD row of the reference's dispatch
  *       tables) — tests/test_oracle_vs_reference.py, runs where /root/reference exists;
- *   (b) against golden vectors written from that library by tools/gen_golden.py and committed
+ *   (b) against golden vectors written from that library by tests/gen_golden.py and committed
  *       under tests/golden/ — tests/test_oracle_golden.py, runs everywhere.
  *
  * Each function cites the reference lines it restates (paths relative to

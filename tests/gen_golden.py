@@ -3,7 +3,7 @@
 (oracle/_ref/libvvenc_ref.so, compiled from /root/reference by oracle/ref/Makefile; x86-SIMD row,
 which the reference's own unit tests hold equal to its scalar row).
 
-Run in the build container (needs /root/reference):   python tools/gen_golden.py
+Run in the build container (needs /root/reference):   python tests/gen_golden.py
 The fixtures are committed; tests/test_oracle_golden.py and the -m gpu parity tests replay them on
 machines where /root/reference does not exist.
 """

@@ -1,4 +1,4 @@
-"""Replays tests/golden/*.npz (inputs + outputs of the reference itself, written by tools/gen_golden.py)
+"""Replays tests/golden/*.npz (inputs + outputs of the reference itself, written by tests/gen_golden.py)
 against any backend exposing the Oracle method names (oracle.oracle.Oracle, or the HIP backend
 adapter in tests/hip_backend.py).  Bit-exact (tolerance 0) everywhere."""
 import os

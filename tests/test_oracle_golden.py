@@ -1,5 +1,5 @@
 """oracle/vvenc_oracle.c against the committed golden vectors (outputs of the reference itself,
-tests/golden/*.npz written by tools/gen_golden.py).  CPU only; runs where /root/reference is absent."""
+tests/golden/*.npz written by tests/gen_golden.py).  CPU only; runs where /root/reference is absent."""
 import golden_replay as G
 
 
