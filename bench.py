@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip per-kernel HIP events inside the timed region")
     ap.add_argument("--bcast-ref", action="store_true", help="also broadcast the reference picture from its owner every step (RCCL)")
-    ap.add_argument("--overlap-streams", type=int, default=4, help="extra measurement: the frame's launches on this many HIP streams (0/1 = skip)")
+    ap.add_argument("--overlap-streams", type=int, default=3, help="extra measurement: the frame's launches on this many HIP streams (0/1 = skip)")
     ap.add_argument("--with-subpel", action="store_true", help="also run the fractional-ME stage per step (16 interpolated HAD_fast candidates per block; SURVEY 8f rank 1)")
     ap.add_argument("--with-mctf", type=int, default=0, help="also run the MCTF hierarchical ME against this many references per step")
     args = ap.parse_args()
@@ -218,7 +218,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt, device="cuda")
 
-    # extra (not `value`): the same steps with the four independent launches of a frame on four HIP streams
+    # extra (not `value`): the same steps with the three independent launches of a frame on separate HIP streams
     overlap = None
     if args.overlap_streams > 1 and wl.merged:
         streams = [torch.cuda.Stream() for _ in range(args.overlap_streams)]
@@ -231,7 +231,7 @@ def main():
         torch.cuda.synchronize()
         dto = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
         overlap = {"streams": args.overlap_streams, "value": args.steps * world / dto, "unit": "frames/s", "ms_per_step": 1000.0 * dto / args.steps,
-                   "note": "same work, the 4 launches of a frame issued on separate HIP streams (no per-kernel events); not the headline value"}
+                   "note": "same work, the 3 launches of a frame issued on separate HIP streams (no per-kernel events); not the headline value"}
     if rank != 0:
         return
     frames = args.steps * world
@@ -243,7 +243,7 @@ def main():
         "dtype": "i16", "data": "synthetic",
         "config": {"workload": "%dx%d 10-bit synthetic frame, preset=faster hot-path work lists: SAD/SATD(HAD_fast)/SSE candidate batches "
                                "(8..64 blocks, 20 candidates/block) + fused DCT-2/quant/dequant/IDCT TU batches (8..32)" % (args.width, args.height),
-                   "sample_pairs_per_frame": int(wl.pairs), "coefficients_per_frame": int(wl.coefs), "launches_per_frame": 4 if wl.merged else len(wl.dist_jobs) + len(wl.tu_jobs),
+                   "sample_pairs_per_frame": int(wl.pairs), "coefficients_per_frame": int(wl.coefs), "launches_per_frame": 3 if wl.merged else len(wl.dist_jobs) + len(wl.tu_jobs),
                    "sharding": "pictures round-robin over ranks, no data-path collective" + (", reference-picture RCCL broadcast per step" if args.bcast_ref else ""),
                    "mctf_refs_per_step": args.with_mctf, "subpel_candidates_per_block": 16 if args.with_subpel else 0},
     }
@@ -262,7 +262,7 @@ def main():
         ks[dom] = td
         launches_per_frame = ks[dom]["launches"] / args.steps
         out["kernels"] = ks
-        out["roofline"] = {"bound": "hbm", "kernel": {"SAD": "sadSseMultiKernel<SAD>", "SSE": "sadSseMultiKernel<SSE>", "HAD_fast": "hadTile8MultiKernel", "TU": "tuRdoRowMultiKernel", "SUBPEL": "refinePredKernel + hadTileKernel", "TU8": "tuRdoRowKernel<8,1>", "TU16": "tuRdoRowKernel<16,2>", "TU32": "tuRdoRowKernel<32,2>"}[dom],
+        out["roofline"] = {"bound": "hbm", "kernel": {"SAD_SSE": "sadSseMixedKernel", "SAD": "sadSseMultiKernel<SAD>", "SSE": "sadSseMultiKernel<SSE>", "HAD_fast": "hadTile8MultiKernel", "TU": "tuRdoRowMultiKernel", "SUBPEL": "refinePredKernel + hadTileKernel", "TU8": "tuRdoRowKernel<8,1>", "TU16": "tuRdoRowKernel<16,2>", "TU32": "tuRdoRowKernel<32,2>"}[dom],
                            "achieved": ks[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ks[dom]["alg_GBps"] / HBM_PEAK_GBS,
                            "traffic": pmc_traffic(dom, args),
                            "alg_bytes_per_launch": wl.alg_bytes[dom] / launches_per_frame, "avg_launch_ms": ks[dom]["avg_ms"],

@@ -85,6 +85,12 @@ typedef struct { int32_t width, height, sub_shift, n; const vvhip_dist_item* d_i
 VVHIP_API int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,
                                 const vvhip_dist_job* jobs_host, int n_jobs );
 
+/* The same with a function per job: consecutive jobs of one kernel family — SAD and SSE, or HAD and HAD_fast — share a launch (a frame's
+ * SAD and SSE lists are both short, memory-side work; together they fill the device better).                                         */
+typedef struct { int32_t func, width, height, sub_shift, n, pad; const vvhip_dist_item* d_items; uint64_t* d_out; } vvhip_dist_fjob;
+VVHIP_API int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,
+                                     const vvhip_dist_fjob* jobs_host, int n_jobs );
+
 /* DMVR 5-position SAD: RdCost::xGetSAD8X5 / xGetSAD16X5 (RdCost.cpp:1984-2034). width 8 or 16.
  * d_out5[5*i+k] = SAD(org+k, cur-k) >> 1; entry 2 is left untouched when calc_centre == 0.       */
 VVHIP_API int vvhip_sad_x5_batch( vvhip_ctx* ctx,

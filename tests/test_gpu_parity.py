@@ -391,6 +391,7 @@ def test_dist_multi_equals_batches(hip):
     rng = np.random.default_rng(107)
     org, cur = rand_plane(rng, 256, 384), rand_plane(rng, 256, 384)
     po, pc = hp.plane(org, 0), hp.plane(cur, 0)
+    allj, allr = [], []
     for func in ("SAD", "SSE", "HAD", "HAD_fast"):
         jobs, refs = [], []
         for (w, h, ss) in [(8, 8, 0), (16, 16, 1), (4, 4, 0), (32, 32, 1), (64, 64, 1), (16, 8, 0), (128, 128, 1), (8, 8, 0), (24, 24, 0), (32, 32, 0), (64, 64, 0)]:
@@ -406,6 +407,16 @@ def test_dist_multi_equals_batches(hip):
         hp.dist_multi(func, po, pc, jobs)
         for (w, h, ss, n, _, out), ref in zip(jobs, refs):
             assert np.array_equal(out.cpu().numpy(), ref), (func, w, h, ss)
+        allj += [(func,) + j for j in jobs]; allr += refs
+    # every function in ONE job table (vvhip_dist_multi_func): SAD and SSE jobs interleaved share launches, so do HAD and HAD_fast
+    order = rng.permutation(len(allj))
+    mixed = []
+    for k in order:
+        f, w, h, ss, n, it, _ = allj[k]
+        mixed.append((f, w, h, ss, n, it, torch.full((n,), -1, dtype=torch.int64, device=hp.device)))
+    hp.dist_multi_func(po, pc, mixed)
+    for k, j in zip(order, mixed):
+        assert np.array_equal(j[6].cpu().numpy(), allr[k]), ("mixed", j[0], j[1], j[2], j[3])
 
 
 def test_tu_rdo_multi_equals_batches(hip):

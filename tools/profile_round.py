@@ -22,6 +22,8 @@ def class_of(name):
     """bench.py's kernel class of a rocprof kernel name"""
     n = name.replace("(anonymous namespace)::", "").replace("void ", "").replace(" ", "")
     head = n.split("(")[0]
+    if head.startswith("sadSseMixedKernel"):
+        return "SAD_SSE"
     if head.startswith("sadSseMultiKernel<"):
         arg = head[len("sadSseMultiKernel<"):].rstrip(">")
         return "SSE" if arg.endswith("1") else "SAD"

@@ -10,6 +10,7 @@
 // L2 / Infinity Cache across the thousands of candidates of a frame); costs are reduced with
 // wave-level xor-shuffles; one lane stores the 64-bit Distortion.
 #include <stdlib.h>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -125,7 +126,7 @@ sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __r
 
 // Several (function-compatible) batches in ONE launch: a workgroup finds its job from the block-range table (wave-uniform scalar
 // work) and runs the same body.  Removes the launch gaps and the tails of the short per-size launches of a frame's work lists.
-struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand; const vvhip_dist_item* items; uint64_t* out; };
+struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand, sse; const vvhip_dist_item* items; uint64_t* out; };
 struct DistMultiJobs { int nJobs, xcdRemap; DistJobGeom j[8]; };
 
 // Workgroups are dealt round-robin to the 8 XCDs (private L2 each).  Work lists are in raster order of the picture, so giving XCD x
@@ -147,6 +148,20 @@ sadSseMultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
   sadSseBody<8, MODE>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+}
+
+// SAD and SSE lists of one frame in the same launch (per-job mode): both are short, memory-side kernels with the same geometry
+__global__ void __launch_bounds__( 256 )
+sadSseMixedKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride, DistMultiJobs jobs )
+{
+  int k = 0;
+#pragma unroll
+  for( int i = 1; i < 8; i++ ) if( i < jobs.nJobs && ( int ) blockIdx.x >= jobs.j[i].blockStart ) k = i;
+  const DistJobGeom& g = jobs.j[k];
+  int blk = blockIdx.x - g.blockStart;
+  if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
+  if( g.sse ) sadSseBody<8, MODE_SSE>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+  else        sadSseBody<8, MODE_SAD>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -604,26 +619,25 @@ int vvhip_dist_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_st
   }
 }
 
-int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,
-                      const vvhip_dist_job* jobs, int n_jobs )
+// jobs with their own function each: consecutive jobs of the same kernel family (SAD/SSE, or HAD/HAD_fast) share a launch
+static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth, const vvhip_dist_fjob* jobs, int n_jobs )
 {
-  if( !ctx ) return VVHIP_E_ARG;
-  if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi: bad job list" );
   // mergeable: SAD / SSE with width % 8 == 0, Hadamard whose ladder ends on the 8x8 or 16x16_fast tile; everything else runs as separate launches
-  auto mergeable = [&]( const vvhip_dist_job& jb ) {
-    if( jb.n <= 0 || jb.width < 8 || jb.height < 1 || jb.width > 128 || jb.height > 128 ) return false;
-    if( func == VVHIP_DF_SAD ) return ( jb.width & 7 ) == 0 && jb.sub_shift >= 0 && jb.sub_shift <= 1 && ( jb.height >> jb.sub_shift ) >= 1 && !( jb.height & ( ( 1 << jb.sub_shift ) - 1 ) );
-    if( func == VVHIP_DF_SSE ) return ( jb.width & 7 ) == 0;
-    if( func == VVHIP_DF_HAD || func == VVHIP_DF_HAD_FAST ) return jb.width == jb.height && ( jb.width & 7 ) == 0;
-    return false; };
+  auto family = [&]( const vvhip_dist_fjob& jb ) -> int {
+    if( jb.n <= 0 || jb.width < 8 || jb.height < 1 || jb.width > 128 || jb.height > 128 ) return 0;
+    if( jb.func == VVHIP_DF_SAD ) return ( ( jb.width & 7 ) == 0 && jb.sub_shift >= 0 && jb.sub_shift <= 1 && ( jb.height >> jb.sub_shift ) >= 1 && !( jb.height & ( ( 1 << jb.sub_shift ) - 1 ) ) ) ? 1 : 0;
+    if( jb.func == VVHIP_DF_SSE ) return ( jb.width & 7 ) == 0 ? 1 : 0;
+    if( jb.func == VVHIP_DF_HAD || jb.func == VVHIP_DF_HAD_FAST ) return ( jb.width == jb.height && ( jb.width & 7 ) == 0 ) ? 2 : 0;
+    return 0; };
   int i = 0;
   while( i < n_jobs )
   {
-    if( !mergeable( jobs[i] ) )
+    const int fam = family( jobs[i] );
+    if( !fam )
     {
       if( jobs[i].n > 0 )
       {
-        const int rc = vvhip_dist_batch( ctx, func, d_org, org_stride, d_cur, cur_stride, jobs[i].width, jobs[i].height, jobs[i].sub_shift, bit_depth, jobs[i].d_items, jobs[i].n, jobs[i].d_out );
+        const int rc = vvhip_dist_batch( ctx, jobs[i].func, d_org, org_stride, d_cur, cur_stride, jobs[i].width, jobs[i].height, jobs[i].sub_shift, bit_depth, jobs[i].d_items, jobs[i].n, jobs[i].d_out );
         if( rc ) return rc;
       }
       i++;
@@ -633,22 +647,24 @@ int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_st
     static const int xcdRemapEnv = []{ const char* e = getenv( "VVHIP_XCD_REMAP" ); return e ? atoi( e ) : 1; }();
     mj.xcdRemap = xcdRemapEnv;
     long blocks = 0;
-    while( i < n_jobs && mj.nJobs < 8 && mergeable( jobs[i] ) )
+    bool anySad = false, anySse = false;
+    while( i < n_jobs && mj.nJobs < 8 && family( jobs[i] ) == fam )
     {
-      const vvhip_dist_job& jb = jobs[i];
+      const vvhip_dist_fjob& jb = jobs[i];
       DistJobGeom& g = mj.j[mj.nJobs];
       g.items = jb.d_items; g.out = jb.d_out; g.n = jb.n; g.blockStart = ( int ) blocks; g.fast16 = 0; g.tilesX = 0; g.tilesPerCand = 0;
-      g.lpr = 0; g.lprShift = 0; g.rowsEff = 0; g.subShift = 0;
+      g.lpr = 0; g.lprShift = 0; g.rowsEff = 0; g.subShift = 0; g.sse = 0;
       int lpc;
-      if( func == VVHIP_DF_SAD || func == VVHIP_DF_SSE )
+      if( fam == 1 )
       {
-        g.subShift = func == VVHIP_DF_SAD ? jb.sub_shift : 0;
+        g.sse = jb.func == VVHIP_DF_SSE ? 1 : 0; ( g.sse ? anySse : anySad ) = true;
+        g.subShift = g.sse ? 0 : jb.sub_shift;
         g.rowsEff = jb.height >> g.subShift; g.lpr = jb.width / 8; g.lprShift = isPow2( g.lpr ) ? ilog2i( g.lpr ) : -1;
         lpc = pow2Floor( g.lpr * g.rowsEff ); if( lpc > 64 ) lpc = 64;
       }
       else
       {
-        g.fast16 = ( func == VVHIP_DF_HAD_FAST && jb.width % 32 == 0 ) ? 1 : 0;
+        g.fast16 = ( jb.func == VVHIP_DF_HAD_FAST && jb.width % 32 == 0 ) ? 1 : 0;
         const int px = g.fast16 ? 16 : 8;
         g.tilesX = jb.width / px; g.tilesPerCand = g.tilesX * ( jb.height / px );
         lpc = pow2Floor( g.tilesPerCand ); if( lpc > 64 ) lpc = 64;
@@ -659,12 +675,31 @@ int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_st
       blocks += g.nBlocks;
       mj.nJobs++; i++;
     }
-    if( func == VVHIP_DF_SAD )      hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SAD> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
-    else if( func == VVHIP_DF_SSE ) hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SSE> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
-    else                            hipLaunchKernelGGL( hadTile8MultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    if( fam == 2 )            hipLaunchKernelGGL( hadTile8MultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else if( anySad && anySse ) hipLaunchKernelGGL( sadSseMixedKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else if( anySad )         hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SAD> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else                      hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SSE> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
     VVHIP_LAUNCH_CHECK( ctx );
   }
   return VVHIP_OK;
+}
+
+int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth, const vvhip_dist_fjob* jobs, int n_jobs )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi_func: bad job list" );
+  return distMultiFunc( ctx, d_org, org_stride, d_cur, cur_stride, bit_depth, jobs, n_jobs );
+}
+
+int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,
+                      const vvhip_dist_job* jobs, int n_jobs )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi: bad job list" );
+  std::vector<vvhip_dist_fjob> fj( n_jobs );
+  for( int i = 0; i < n_jobs; i++ ) { fj[i].func = func; fj[i].width = jobs[i].width; fj[i].height = jobs[i].height; fj[i].sub_shift = jobs[i].sub_shift; fj[i].n = jobs[i].n; fj[i].pad = 0;
+                                      fj[i].d_items = jobs[i].d_items; fj[i].d_out = jobs[i].d_out; }
+  return distMultiFunc( ctx, d_org, org_stride, d_cur, cur_stride, bit_depth, fj.data(), n_jobs );
 }
 
 int vvhip_sad_x5_batch( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride,

@@ -157,6 +157,21 @@ class HotPath:
         self._ck(self.L.vvhip_dist_multi(self.ctx, DF[func] if isinstance(func, str) else func, org.buf_ptr, org.stride, cur.buf_ptr, cur.stride,
                                          bit_depth, jobs[0], jobs[1]))
 
+    class _DistFJob(C.Structure):
+        _fields_ = [("func", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("sub_shift", C.c_int32), ("n", C.c_int32), ("pad", C.c_int32),
+                    ("d_items", C.c_void_p), ("d_out", C.c_void_p)]
+
+    def make_dist_fjobs(self, jobs):
+        """jobs: list of (func, w, h, sub_shift, n, d_items, d_out) -> prepared host job table for dist_multi_func"""
+        arr = (self._DistFJob * len(jobs))(*[self._DistFJob(DF[f] if isinstance(f, str) else f, w, h, ss, n, 0, it.data_ptr(), out.data_ptr()) for (f, w, h, ss, n, it, out) in jobs])
+        return arr, len(jobs), jobs
+
+    def dist_multi_func(self, org, cur, jobs, bit_depth=10):
+        """a frame's distortion lists with a function per job; SAD+SSE and HAD+HAD_fast jobs share launches"""
+        if isinstance(jobs, list):
+            jobs = self.make_dist_fjobs(jobs)
+        self._ck(self.L.vvhip_dist_multi_func(self.ctx, org.buf_ptr, org.stride, cur.buf_ptr, cur.stride, bit_depth, jobs[0], jobs[1]))
+
     def sad_x5_batch(self, org, cur, d_items, n, w, h, sub_shift=1, calc_centre=True, out=None):
         if out is None:
             out = torch.zeros(n * 5, dtype=torch.int64, device=self.device)

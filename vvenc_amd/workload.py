@@ -100,7 +100,11 @@ class FrameWorkload:
                            for func in ("SAD", "HAD_fast", "SSE")}
         self.tu_table = hp.make_tu_jobs([(S, S, 0, 0, n, 8, d_off, d_qp, lvl, rec, st) for (S, n, d_off, d_qp, lvl, rec, st, _, _) in self.tu_jobs])
         self.alg_bytes["TU"] = sum(self.alg_bytes["TU%d" % S] for S in TU_SIZES)
-        self.class_launches_merged = {"SAD": 1, "HAD_fast": 1, "SSE": 1, "TU": 1}
+        self.class_launches_merged = {"SAD_SSE": 1, "HAD_fast": 1, "TU": 1}
+        self.alg_bytes["SAD_SSE"] = self.alg_bytes["SAD"] + self.alg_bytes["SSE"]
+        # SAD and SSE lists share one launch (vvhip_dist_multi_func), the Hadamard lists another
+        self.fjob_tables = {"SAD_SSE": hp.make_dist_fjobs([(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f in ("SAD", "SSE")]),
+                            "HAD_fast": hp.make_dist_fjobs([(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f == "HAD_fast"])}
 
     # ---- optional fractional-ME stage: 16 sub-pel positions (8 half-sample + 8 quarter-sample neighbours of a seeded
     # base vector) per block of every size, interpolated and scored with HAD_fast like InterSearch::xPatternRefinement — one
@@ -143,7 +147,7 @@ class FrameWorkload:
         """the same four launches, each on its own HIP stream (they are independent work lists): successive steps pipeline per stream"""
         import torch
         hp = self.hp
-        calls = [lambda f=f: hp.dist_multi(f, self.org, self.ref, self.job_tables[f], self.bit_depth) for f in ("SAD", "HAD_fast", "SSE")]
+        calls = [lambda c=c: hp.dist_multi_func(self.org, self.ref, self.fjob_tables[c], self.bit_depth) for c in ("SAD_SSE", "HAD_fast")]
         calls.append(lambda: hp.tu_rdo_multi(self.resi, self.tu_table, self.bit_depth))
         for i, c in enumerate(calls):
             with torch.cuda.stream(streams[i % len(streams)]):
@@ -151,17 +155,17 @@ class FrameWorkload:
                 c()
         hp.use_torch_stream()
 
-    # one pass of the hot path over the frame: 3 merged distortion launches + 1 merged fused-TU launch (or 12 + 3 per-size ones)
+    # one pass of the hot path over the frame: 2 merged distortion launches (SAD+SSE, Hadamard) + 1 merged fused-TU launch (or 12 + 3 per-size ones)
     def run(self, timers=None):
         hp = self.hp
         prev = None
         if self.merged:
-            for func in ("SAD", "HAD_fast", "SSE"):
+            for cls in ("SAD_SSE", "HAD_fast"):
                 if timers is not None:
-                    timers.start(func)
-                hp.dist_multi(func, self.org, self.ref, self.job_tables[func], self.bit_depth)
+                    timers.start(cls)
+                hp.dist_multi_func(self.org, self.ref, self.fjob_tables[cls], self.bit_depth)
                 if timers is not None:
-                    timers.stop(func)
+                    timers.stop(cls)
         else:
             for (func, S, ss, n, d_items, d_out, _) in self.dist_jobs:
                 if timers is not None and func != prev:
