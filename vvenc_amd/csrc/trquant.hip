@@ -587,6 +587,7 @@ struct TuRowArgs
   const vvhip_tu_qp* qps; int thrVal;
   int16_t* level; int16_t* rec; vvhip_tu_stats* stats;
   int phaseLimit;          // profiling aid ($VVHIP_TU_PHASES): stop after phase k, 0 = run everything
+  int groupStride;         // workgroups assigned to this job (a workgroup walks groups b, b + groupStride, ...)
 };
 
 template<int N, int SPLIT> struct TuRowLds
@@ -621,20 +622,6 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
   const int tl = tid / LPT, li = tid & ( LPT - 1 ), r = li / SPLIT, part = li & ( SPLIT - 1 ), lane = tid & 63;
   const int line = tid / SPLIT;                               // row / column index inside the workgroup
   const int o0 = part * NO;                                   // first output index of this lane
-  const int tu = blockIndex * TPB + tl;
-  const bool valid = tu < n;
-  int16_t* tile = sTile[tl];
-  // the dependent global loads (offset -> residual row, QP) are issued before the ROM is staged so that their latencies overlap
-  const int16_t* src = resi + ( valid ? resiOff[tu] : 0 ) + ( ptrdiff_t ) r * resiStride;
-  const vvhip_tu_qp qq = valid ? qps[tu] : vvhip_tu_qp{ 32, 0 };
-  uint32_t x[ND];
-#pragma unroll
-  for( int c = 0; c < NC; c++ )
-  {
-    u32x4 v = { 0, 0, 0, 0 };
-    if( valid ) v = reinterpret_cast<const U16*>( src + 8 * c )->v;
-    x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
-  }
   for( int i = tid; i < N * N; i += 256 )
   {
     const int k = i / N, j = i - k * N;
@@ -644,189 +631,207 @@ tuRdoRowBody( unsigned char* __restrict__ smem, const int blockIndex, const int1
   }
   __syncthreads();
   if( A.phaseLimit == 1 ) return;
-
-#define DOT_ROW( ACC, VEC, MROW ) { ACC = 0; _Pragma( "unroll" ) for( int c_ = 0; c_ < NC; c_++ ) {                          \
-      const u32x4 m_ = *reinterpret_cast<const u32x4*>( ( MROW ) + 8 * c_ );                                                  \
-      ACC = dot2( VEC[4 * c_], m_.x, ACC ); ACC = dot2( VEC[4 * c_ + 1], m_.y, ACC ); ACC = dot2( VEC[4 * c_ + 2], m_.z, ACC ); ACC = dot2( VEC[4 * c_ + 3], m_.w, ACC ); } }
-#define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
-
-  // ---- forward rows: tmp[j][r] = sat16( ( sum_k blk[r][k] * Th[j][k] + rnd ) >> shift1 )        (cpyCoeff + TrQuant.cpp:548)
+  // persistent form: a workgroup stages the ROM once and walks groups blockIndex, blockIndex + groupStride, ... (all LDS hand-offs below are inside a wave)
+  for( int grp = blockIndex; grp * TPB < n; grp += A.groupStride )
   {
-    const int rnd1 = gf.shift1 > 0 ? 1 << ( gf.shift1 - 1 ) : 0;
-#pragma unroll 2
-    for( int jj = 0; jj < NO; jj++ )
+    const int tu = grp * TPB + tl;
+    const bool valid = tu < n;
+    int16_t* tile = sTile[tl];
+    // the dependent global loads (offset -> residual row, QP) are issued before the ROM is staged so that their latencies overlap
+    const int16_t* src = resi + ( valid ? resiOff[tu] : 0 ) + ( ptrdiff_t ) r * resiStride;
+    const vvhip_tu_qp qq = valid ? qps[tu] : vvhip_tu_qp{ 32, 0 };
+    uint32_t x[ND];
+  #pragma unroll
+    for( int c = 0; c < NC; c++ )
     {
-      const int j = o0 + jj;
-      int acc;
-      DOT_ROW( acc, x, &sMat[0][j * N] );
-      tile[j * P + r] = ( int16_t ) sat16( ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd1 ) >> gf.shift1 );
+      u32x4 v = { 0, 0, 0, 0 };
+      if( valid ) v = reinterpret_cast<const U16*>( src + 8 * c )->v;
+      x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
     }
-  }
-  WAVE_SYNC();
-  if( A.phaseLimit == 2 ) return;
-  // ---- forward columns (line = horizontal frequency c): coef[j2] = ( sum_k tmp[c][k] * Tv[j2][k] + rnd ) >> shift2   (TrQuant.cpp:549)
-  const int cidx = r;
-  {
-    uint32_t y[ND];
-#pragma unroll
-    for( int c = 0; c < NC; c++ ) { const u32x4 v = *reinterpret_cast<const u32x4*>( &tile[cidx * P + 8 * c] ); y[4 * c] = v.x; y[4 * c + 1] = v.y; y[4 * c + 2] = v.z; y[4 * c + 3] = v.w; }
-    const int rnd2 = 1 << ( gf.shift2 - 1 );
-    const bool colLive = cidx < N - gf.skipW;
-#pragma unroll 2
-    for( int jj = 0; jj < NO; jj++ )
-    {
-      const int j2 = o0 + jj;
-      int acc;
-      DOT_ROW( acc, y, &sMat[1][j2 * N] );
-      sCoef[jj][tid] = ( colLive && j2 < N - gf.skipH ) ? ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd2 ) >> gf.shift2 : 0;
-    }
-  }
-  if( A.phaseLimit == 3 ) return;
-  // ---- quantiser constants of this TU
-  int scale, qBits;
-  quantParams( q, qq.qp, scale, qBits );
-  const long long add  = ( long long ) ( ( qq.flags & 1 ) ? 171 : 85 ) << ( qBits - 9 );            // Quant.cpp:775
-  const long long addN = ( long long ) ( ( qq.flags & 2 ) ? 171 : 256 ) << ( qBits - 9 );           // Quant.cpp:874
-  const int32_t thres = qBits ? ( int32_t ) ( ( int64_t ) thrVal << ( qBits - 1 ) ) : ( int32_t ) ( ( int64_t ) ( thrVal >> 1 ) << qBits );
-  const int useThres = thres / ( scale << 2 );                                                      // Quant.cpp:173-180
-  const int trShift = 15 - q.bitDepth - q.log2w;
-  const int iscale = cInvQuantScales[0][qq.qp % 6];                                                  // Quant.cpp:601 (square: no sqrt2)
-  const int rightShift = 6 - ( trShift + qq.qp / 6 );                                                // Quant.cpp:561
-  int tgt = 32 + rightShift - 7; if( tgt > 16 ) tgt = 16;                                            // Quant.cpp:606
-  const int inMax = ( 1 << ( tgt - 1 ) ) - 1;
 
-  // ---- significance: last non-zero scan position, need-RDOQ flag, coefficient-group test (Quant.cpp:162-208, :264-278)
-  // needRdoqCore asks whether ANY coefficient quantises to non-zero with the RDOQ offset: the quantiser is monotonic in |c|, so it is
-  // one 64-bit test on the TU's largest magnitude.
-  uint32_t last = 0, maxAbs = 0;
-  for( int jj = 0; jj < NO; jj++ )
-  {
-    const uint32_t si = sInv[( o0 + jj ) * N + cidx];
-    const int c = sCoef[jj][tid];
-    const uint32_t ac = ( uint32_t ) abs( c );
-    maxAbs = ac > maxAbs ? ac : maxAbs;
-    last = ( c != 0 && si > last ) ? si : last;
-  }
-  last = vvhipGroupMax32( last, LPT, lane );
-  maxAbs = vvhipGroupMax32( maxAbs, LPT, lane );
-  const uint32_t need = ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) maxAbs * scale + addN ) >> qBits ) != 0 );
-  if( last >= 16 )
-  {
-    uint32_t lo = 0, hi = 0;
+  #define DOT_ROW( ACC, VEC, MROW ) { ACC = 0; _Pragma( "unroll" ) for( int c_ = 0; c_ < NC; c_++ ) {                          \
+        const u32x4 m_ = *reinterpret_cast<const u32x4*>( ( MROW ) + 8 * c_ );                                                  \
+        ACC = dot2( VEC[4 * c_], m_.x, ACC ); ACC = dot2( VEC[4 * c_ + 1], m_.y, ACC ); ACC = dot2( VEC[4 * c_ + 2], m_.z, ACC ); ACC = dot2( VEC[4 * c_ + 3], m_.w, ACC ); } }
+  #define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+
+    // ---- forward rows: tmp[j][r] = sat16( ( sum_k blk[r][k] * Th[j][k] + rnd ) >> shift1 )        (cpyCoeff + TrQuant.cpp:548)
+    {
+      const int rnd1 = gf.shift1 > 0 ? 1 << ( gf.shift1 - 1 ) : 0;
+  #pragma unroll 2
+      for( int jj = 0; jj < NO; jj++ )
+      {
+        const int j = o0 + jj;
+        int acc;
+        DOT_ROW( acc, x, &sMat[0][j * N] );
+        tile[j * P + r] = ( int16_t ) sat16( ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd1 ) >> gf.shift1 );
+      }
+    }
+    WAVE_SYNC();
+    if( A.phaseLimit == 2 ) return;
+    // ---- forward columns (line = horizontal frequency c): coef[j2] = ( sum_k tmp[c][k] * Tv[j2][k] + rnd ) >> shift2   (TrQuant.cpp:549)
+    const int cidx = r;
+    {
+      uint32_t y[ND];
+  #pragma unroll
+      for( int c = 0; c < NC; c++ ) { const u32x4 v = *reinterpret_cast<const u32x4*>( &tile[cidx * P + 8 * c] ); y[4 * c] = v.x; y[4 * c + 1] = v.y; y[4 * c + 2] = v.z; y[4 * c + 3] = v.w; }
+      const int rnd2 = 1 << ( gf.shift2 - 1 );
+      const bool colLive = cidx < N - gf.skipW;
+  #pragma unroll 2
+      for( int jj = 0; jj < NO; jj++ )
+      {
+        const int j2 = o0 + jj;
+        int acc;
+        DOT_ROW( acc, y, &sMat[1][j2 * N] );
+        sCoef[jj][tid] = ( colLive && j2 < N - gf.skipH ) ? ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd2 ) >> gf.shift2 : 0;
+      }
+    }
+    if( A.phaseLimit == 3 ) return;
+    // ---- quantiser constants of this TU
+    int scale, qBits;
+    quantParams( q, qq.qp, scale, qBits );
+    const long long add  = ( long long ) ( ( qq.flags & 1 ) ? 171 : 85 ) << ( qBits - 9 );            // Quant.cpp:775
+    const long long addN = ( long long ) ( ( qq.flags & 2 ) ? 171 : 256 ) << ( qBits - 9 );           // Quant.cpp:874
+    const int32_t thres = qBits ? ( int32_t ) ( ( int64_t ) thrVal << ( qBits - 1 ) ) : ( int32_t ) ( ( int64_t ) ( thrVal >> 1 ) << qBits );
+    const int useThres = thres / ( scale << 2 );                                                      // Quant.cpp:173-180
+    const int trShift = 15 - q.bitDepth - q.log2w;
+    const int iscale = cInvQuantScales[0][qq.qp % 6];                                                  // Quant.cpp:601 (square: no sqrt2)
+    const int rightShift = 6 - ( trShift + qq.qp / 6 );                                                // Quant.cpp:561
+    int tgt = 32 + rightShift - 7; if( tgt > 16 ) tgt = 16;                                            // Quant.cpp:606
+    const int inMax = ( 1 << ( tgt - 1 ) ) - 1;
+
+    // ---- significance: last non-zero scan position, need-RDOQ flag, coefficient-group test (Quant.cpp:162-208, :264-278)
+    // needRdoqCore asks whether ANY coefficient quantises to non-zero with the RDOQ offset: the quantiser is monotonic in |c|, so it is
+    // one 64-bit test on the TU's largest magnitude.
+    uint32_t last = 0, maxAbs = 0;
     for( int jj = 0; jj < NO; jj++ )
     {
       const uint32_t si = sInv[( o0 + jj ) * N + cidx];
-      if( si >= 16 && si <= last && abs( sCoef[jj][tid] ) > useThres ) { const int cg = si >> 4; if( cg < 32 ) lo |= 1u << cg; else hi |= 1u << ( cg - 32 ); }
+      const int c = sCoef[jj][tid];
+      const uint32_t ac = ( uint32_t ) abs( c );
+      maxAbs = ac > maxAbs ? ac : maxAbs;
+      last = ( c != 0 && si > last ) ? si : last;
     }
-    lo = vvhipGroupOr32( lo, LPT, lane );
-    hi = N > 16 ? vvhipGroupOr32( hi, LPT, lane ) : 0u;
-    const unsigned long long big = ( ( unsigned long long ) hi << 32 ) | lo;
-    if( big == 0 ) last = 15;
-    else { const uint32_t g2 = 63 - __clzll( ( long long ) big ); if( g2 != ( last >> 4 ) ) last = g2 * 16 + 15; }
-  }
-  if( A.phaseLimit == 4 ) return;
-  // ---- QuantCore + DeQuantCore (Quant.cpp:213-227, :232-262), branch-free per coefficient: level pairs -> tile (transpose for the raster
-  // store), dequantised pairs -> the lane's own sCoef column (rows 0..NO/2-1, already consumed).  When every |c| of the wave fits 16 bits
-  // the level is a 24-bit multiply-add in 32 bits (|c|*scale < 2^31, add < 2^29.5); otherwise the 64-bit form.
-  uint32_t absSum = 0;
-  const bool narrow = __builtin_amdgcn_ballot_w64( maxAbs >= 65536u || qBits > 30 ) == 0ull;
-  const uint32_t add32 = ( uint32_t ) add;
-  const int rndDq = rightShift > 0 ? 1 << ( rightShift - 1 ) : 0;
-#define TU_LEVEL_PAIR( MEXPR )                                                                                                       \
-  for( int jj = 0; jj < NO; jj += 2 )                                                                                                \
-  {                                                                                                                                  \
-    int lv[2], dq[2];                                                                                                                \
-    _Pragma( "unroll" ) for( int e = 0; e < 2; e++ )                                                                                 \
-    {                                                                                                                                \
-      const int cv = sCoef[jj + e][tid];                                                                                             \
-      const uint32_t ac = ( uint32_t ) abs( cv );                                                                                    \
-      uint32_t m = MEXPR;                                                                                                            \
-      m = sInv[( o0 + jj + e ) * N + cidx] <= last ? m : 0u;                                                                         \
-      absSum += m;                                                                                                                   \
-      const int sm = cv < 0 ? -( int32_t ) m : ( int32_t ) m;                                                                        \
-      lv[e] = clip3i( -32768, 32767, sm );                                                                                           \
-      const int cl = clip3i( -( inMax + 1 ), inMax, lv[e] );                                                                         \
-      const int pr = __mul24( cl, iscale );                                                                                          \
-      const int32_t v = rightShift > 0 ? ( int32_t ) ( ( uint32_t ) pr + ( uint32_t ) rndDq ) >> rightShift : ( int32_t ) ( ( uint32_t ) pr << ( -rightShift ) ); \
-      dq[e] = clip3i( -32768, 32767, v );                                                                                            \
-    }                                                                                                                                \
-    tile[( o0 + jj ) * P + cidx] = ( int16_t ) lv[0];                                                                                \
-    tile[( o0 + jj + 1 ) * P + cidx] = ( int16_t ) lv[1];                                                                            \
-    sCoef[jj >> 1][tid] = ( int32_t ) ( ( uint32_t ) ( dq[0] & 0xffff ) | ( ( uint32_t ) dq[1] << 16 ) );                            \
-  }
-  if( narrow ) { TU_LEVEL_PAIR( ( ( uint32_t ) __umul24( ac, ( uint32_t ) scale ) + add32 ) >> qBits ) }
-  else         { TU_LEVEL_PAIR( ( uint32_t ) ( int32_t ) ( ( ( int64_t ) ac * scale + add ) >> qBits ) ) }
-#undef TU_LEVEL_PAIR
-  if( A.phaseLimit == 5 ) return;
-  absSum = vvhipGroupSum32( absSum, LPT, lane );
-  WAVE_SYNC();
-  // ---- levels: raster rows -> HBM (16-byte stores)
-  if( level && valid )
-#pragma unroll
-    for( int c = 0; c < NOC; c++ )
-      *reinterpret_cast<u32x4*>( level + ( size_t ) tu * N * N + r * N + o0 + 8 * c ) = *reinterpret_cast<const u32x4*>( &tile[r * P + o0 + 8 * c] );
-  WAVE_SYNC();
-  if( A.phaseLimit == 6 ) return;
-  // ---- inverse columns: t1[j][c] = clip( ( sum_k deq[k][c] * Tv[k][j] + 64 ) >> 7 ), c < N - skipW   (TrQuant.cpp:612)
-  {
-    uint32_t dqp[ND];
-#pragma unroll
-    for( int k = 0; k < ND; k++ ) dqp[k] = ( uint32_t ) sCoef[k % ( NO / 2 )][line * SPLIT + k / ( NO / 2 )];     // pair k of the column: lane part k / (NO/2), its row k % (NO/2)
-    const int rnd1 = 1 << ( gi.shift1 - 1 );
-    const bool colLive = cidx < N - gi.skipW;
-#pragma unroll 2
-    for( int jj = 0; jj < NO; jj++ )
+    last = vvhipGroupMax32( last, LPT, lane );
+    maxAbs = vvhipGroupMax32( maxAbs, LPT, lane );
+    const uint32_t need = ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) maxAbs * scale + addN ) >> qBits ) != 0 );
+    if( last >= 16 )
     {
-      const int j = o0 + jj;
-      int acc;
-      DOT_ROW( acc, dqp, &sMat[3][j * N] );
-      tile[j * P + cidx] = ( int16_t ) ( colLive ? sat16( ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd1 ) >> gi.shift1 ) : 0 );
-    }
-  }
-  WAVE_SYNC();
-  if( A.phaseLimit == 7 ) return;
-  // ---- inverse rows: rec[r][j2] = clip( ( sum_k t1[r][k] * Th[k][j2] + rnd ) >> shift2 ); SSE against the residual row (re-read: L2 hit)
-  unsigned long long sse = 0;
-  {
-    uint32_t t[ND];
-#pragma unroll
-    for( int c = 0; c < NC; c++ ) { const u32x4 v = *reinterpret_cast<const u32x4*>( &tile[r * P + 8 * c] ); t[4 * c] = v.x; t[4 * c + 1] = v.y; t[4 * c + 2] = v.z; t[4 * c + 3] = v.w; }
-    const int rnd2 = 1 << ( gi.shift2 - 1 );
-    for( int c8 = 0; c8 < NOC; c8++ )
-    {
-      u32x4 xv = { 0, 0, 0, 0 };
-      if( valid ) xv = reinterpret_cast<const U16*>( src + o0 + 8 * c8 )->v;
-      const uint32_t xs[4] = { xv.x, xv.y, xv.z, xv.w };
-      uint32_t rp[4];
-#pragma unroll
-      for( int pr = 0; pr < 4; pr++ )
+      uint32_t lo = 0, hi = 0;
+      for( int jj = 0; jj < NO; jj++ )
       {
-        int rv[2];
-#pragma unroll
-        for( int e = 0; e < 2; e++ )
+        const uint32_t si = sInv[( o0 + jj ) * N + cidx];
+        if( si >= 16 && si <= last && abs( sCoef[jj][tid] ) > useThres ) { const int cg = si >> 4; if( cg < 32 ) lo |= 1u << cg; else hi |= 1u << ( cg - 32 ); }
+      }
+      lo = vvhipGroupOr32( lo, LPT, lane );
+      hi = N > 16 ? vvhipGroupOr32( hi, LPT, lane ) : 0u;
+      const unsigned long long big = ( ( unsigned long long ) hi << 32 ) | lo;
+      if( big == 0 ) last = 15;
+      else { const uint32_t g2 = 63 - __clzll( ( long long ) big ); if( g2 != ( last >> 4 ) ) last = g2 * 16 + 15; }
+    }
+    if( A.phaseLimit == 4 ) return;
+    // ---- QuantCore + DeQuantCore (Quant.cpp:213-227, :232-262), branch-free per coefficient: level pairs -> tile (transpose for the raster
+    // store), dequantised pairs -> the lane's own sCoef column (rows 0..NO/2-1, already consumed).  When every |c| of the wave fits 16 bits
+    // the level is a 24-bit multiply-add in 32 bits (|c|*scale < 2^31, add < 2^29.5); otherwise the 64-bit form.
+    uint32_t absSum = 0;
+    const bool narrow = __builtin_amdgcn_ballot_w64( maxAbs >= 65536u || qBits > 30 ) == 0ull;
+    const uint32_t add32 = ( uint32_t ) add;
+    const int rndDq = rightShift > 0 ? 1 << ( rightShift - 1 ) : 0;
+  #define TU_LEVEL_PAIR( MEXPR )                                                                                                       \
+    for( int jj = 0; jj < NO; jj += 2 )                                                                                                \
+    {                                                                                                                                  \
+      int lv[2], dq[2];                                                                                                                \
+      _Pragma( "unroll" ) for( int e = 0; e < 2; e++ )                                                                                 \
+      {                                                                                                                                \
+        const int cv = sCoef[jj + e][tid];                                                                                             \
+        const uint32_t ac = ( uint32_t ) abs( cv );                                                                                    \
+        uint32_t m = MEXPR;                                                                                                            \
+        m = sInv[( o0 + jj + e ) * N + cidx] <= last ? m : 0u;                                                                         \
+        absSum += m;                                                                                                                   \
+        const int sm = cv < 0 ? -( int32_t ) m : ( int32_t ) m;                                                                        \
+        lv[e] = clip3i( -32768, 32767, sm );                                                                                           \
+        const int cl = clip3i( -( inMax + 1 ), inMax, lv[e] );                                                                         \
+        const int pr = __mul24( cl, iscale );                                                                                          \
+        const int32_t v = rightShift > 0 ? ( int32_t ) ( ( uint32_t ) pr + ( uint32_t ) rndDq ) >> rightShift : ( int32_t ) ( ( uint32_t ) pr << ( -rightShift ) ); \
+        dq[e] = clip3i( -32768, 32767, v );                                                                                            \
+      }                                                                                                                                \
+      tile[( o0 + jj ) * P + cidx] = ( int16_t ) lv[0];                                                                                \
+      tile[( o0 + jj + 1 ) * P + cidx] = ( int16_t ) lv[1];                                                                            \
+      sCoef[jj >> 1][tid] = ( int32_t ) ( ( uint32_t ) ( dq[0] & 0xffff ) | ( ( uint32_t ) dq[1] << 16 ) );                            \
+    }
+    if( narrow ) { TU_LEVEL_PAIR( ( ( uint32_t ) __umul24( ac, ( uint32_t ) scale ) + add32 ) >> qBits ) }
+    else         { TU_LEVEL_PAIR( ( uint32_t ) ( int32_t ) ( ( ( int64_t ) ac * scale + add ) >> qBits ) ) }
+  #undef TU_LEVEL_PAIR
+    if( A.phaseLimit == 5 ) return;
+    absSum = vvhipGroupSum32( absSum, LPT, lane );
+    WAVE_SYNC();
+    // ---- levels: raster rows -> HBM (16-byte stores)
+    if( level && valid )
+  #pragma unroll
+      for( int c = 0; c < NOC; c++ )
+        *reinterpret_cast<u32x4*>( level + ( size_t ) tu * N * N + r * N + o0 + 8 * c ) = *reinterpret_cast<const u32x4*>( &tile[r * P + o0 + 8 * c] );
+    WAVE_SYNC();
+    if( A.phaseLimit == 6 ) return;
+    // ---- inverse columns: t1[j][c] = clip( ( sum_k deq[k][c] * Tv[k][j] + 64 ) >> 7 ), c < N - skipW   (TrQuant.cpp:612)
+    {
+      uint32_t dqp[ND];
+  #pragma unroll
+      for( int k = 0; k < ND; k++ ) dqp[k] = ( uint32_t ) sCoef[k % ( NO / 2 )][line * SPLIT + k / ( NO / 2 )];     // pair k of the column: lane part k / (NO/2), its row k % (NO/2)
+      const int rnd1 = 1 << ( gi.shift1 - 1 );
+      const bool colLive = cidx < N - gi.skipW;
+  #pragma unroll 2
+      for( int jj = 0; jj < NO; jj++ )
+      {
+        const int j = o0 + jj;
+        int acc;
+        DOT_ROW( acc, dqp, &sMat[3][j * N] );
+        tile[j * P + cidx] = ( int16_t ) ( colLive ? sat16( ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd1 ) >> gi.shift1 ) : 0 );
+      }
+    }
+    WAVE_SYNC();
+    if( A.phaseLimit == 7 ) return;
+    // ---- inverse rows: rec[r][j2] = clip( ( sum_k t1[r][k] * Th[k][j2] + rnd ) >> shift2 ); SSE against the residual row (re-read: L2 hit)
+    unsigned long long sse = 0;
+    {
+      uint32_t t[ND];
+  #pragma unroll
+      for( int c = 0; c < NC; c++ ) { const u32x4 v = *reinterpret_cast<const u32x4*>( &tile[r * P + 8 * c] ); t[4 * c] = v.x; t[4 * c + 1] = v.y; t[4 * c + 2] = v.z; t[4 * c + 3] = v.w; }
+      const int rnd2 = 1 << ( gi.shift2 - 1 );
+      for( int c8 = 0; c8 < NOC; c8++ )
+      {
+        u32x4 xv = { 0, 0, 0, 0 };
+        if( valid ) xv = reinterpret_cast<const U16*>( src + o0 + 8 * c8 )->v;
+        const uint32_t xs[4] = { xv.x, xv.y, xv.z, xv.w };
+        uint32_t rp[4];
+  #pragma unroll
+        for( int pr = 0; pr < 4; pr++ )
         {
-          int acc;
-          DOT_ROW( acc, t, &sMat[2][( o0 + 8 * c8 + 2 * pr + e ) * N] );
-          rv[e] = sat16( ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd2 ) >> gi.shift2 );
+          int rv[2];
+  #pragma unroll
+          for( int e = 0; e < 2; e++ )
+          {
+            int acc;
+            DOT_ROW( acc, t, &sMat[2][( o0 + 8 * c8 + 2 * pr + e ) * N] );
+            rv[e] = sat16( ( int ) ( ( uint32_t ) acc + ( uint32_t ) rnd2 ) >> gi.shift2 );
+          }
+          rp[pr] = ( uint32_t ) ( rv[0] & 0xffff ) | ( ( uint32_t ) rv[1] << 16 );
+          const int d0 = ( int ) ( int16_t ) ( xs[pr] & 0xffff ) - rv[0], d1 = ( ( int ) xs[pr] >> 16 ) - rv[1];
+          sse += ( unsigned long long ) ( ( long long ) d0 * d0 ) + ( unsigned long long ) ( ( long long ) d1 * d1 );
         }
-        rp[pr] = ( uint32_t ) ( rv[0] & 0xffff ) | ( ( uint32_t ) rv[1] << 16 );
-        const int d0 = ( int ) ( int16_t ) ( xs[pr] & 0xffff ) - rv[0], d1 = ( ( int ) xs[pr] >> 16 ) - rv[1];
-        sse += ( unsigned long long ) ( ( long long ) d0 * d0 ) + ( unsigned long long ) ( ( long long ) d1 * d1 );
-      }
-      if( rec && valid )
-      {
-        u32x4 v; v.x = rp[0]; v.y = rp[1]; v.z = rp[2]; v.w = rp[3];
-        *reinterpret_cast<u32x4*>( rec + ( size_t ) tu * N * N + r * N + o0 + 8 * c8 ) = v;
+        if( rec && valid )
+        {
+          u32x4 v; v.x = rp[0]; v.y = rp[1]; v.z = rp[2]; v.w = rp[3];
+          *reinterpret_cast<u32x4*>( rec + ( size_t ) tu * N * N + r * N + o0 + 8 * c8 ) = v;
+        }
       }
     }
-  }
-#undef DOT_ROW
-#undef WAVE_SYNC
-  sse = vvhipGroupSum64( sse, LPT, lane );
-  if( stats && valid && li == 0 )
-  {
-    vvhip_tu_stats st; st.abs_sum = ( int32_t ) absSum; st.last_scan_pos = ( int32_t ) last; st.need_rdoq = ( int32_t ) need; st.pad = 0; st.sse = sse;
-    stats[tu] = st;
+  #undef DOT_ROW
+  #undef WAVE_SYNC
+    sse = vvhipGroupSum64( sse, LPT, lane );
+    if( stats && valid && li == 0 )
+    {
+      vvhip_tu_stats st; st.abs_sum = ( int32_t ) absSum; st.last_scan_pos = ( int32_t ) last; st.need_rdoq = ( int32_t ) need; st.pad = 0; st.sse = sse;
+      stats[tu] = st;
+    }
   }
 }
 
@@ -1002,6 +1007,7 @@ cpyCoeffKernel( const int16_t* __restrict__ src, ptrdiff_t stride, int32_t* __re
 
 } // namespace
 
+static int tuRepeat() { static const int v = getenv( "VVHIP_TU_REPEAT" ) ? atoi( getenv( "VVHIP_TU_REPEAT" ) ) : 2; return v < 1 ? 1 : v; }     // groups per workgroup
 static int tuPhaseLimit() { static const int v = getenv( "VVHIP_TU_PHASES" ) ? atoi( getenv( "VVHIP_TU_PHASES" ) ) : 0; return v; }
 
 extern "C" {
@@ -1148,7 +1154,9 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
       ra.qps = jb.d_qp; ra.thrVal = jb.thr_val; ra.level = jb.d_level; ra.rec = jb.d_rec_resi; ra.stats = jb.d_stats; ra.phaseLimit = tuPhaseLimit();
       const int tpb = 256 / ( jb.width * ( jb.width == 8 ? 1 : 2 ) );
       mj.blockStart[mj.nJobs] = ( int ) blocks; mj.size[mj.nJobs] = jb.width;
-      blocks += ( jb.n + tpb - 1 ) / tpb;
+      const int groups = ( jb.n + tpb - 1 ) / tpb;
+      ra.groupStride = ( groups + tuRepeat() - 1 ) / tuRepeat();
+      blocks += ra.groupStride;
       mj.nJobs++;
     }
     for( int i = mj.nJobs; i < 4; i++ ) { mj.blockStart[i] = 0x7fffffff; mj.size[i] = 0; }
@@ -1240,10 +1248,10 @@ int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
     const uint16_t* sc = ctx->d_scan + scanOffset( q.log2w, q.log2h );
     TuRowArgs ra; ra.resiOff = d_resi_off; ra.n = n; ra.gf = gf; ra.gi = gi; ra.q = q; ra.matH = mh; ra.matV = mv; ra.scan = sc;
     ra.qps = d_qp; ra.thrVal = thr_val; ra.level = d_level; ra.rec = d_rec_resi; ra.stats = d_stats; ra.phaseLimit = tuPhaseLimit();
-#define ROWK( NN, SP ) hipLaunchKernelGGL( ( tuRdoRowKernel<NN, SP> ), dim3( ( n + ( 256 / ( NN * SP ) ) - 1 ) / ( 256 / ( NN * SP ) ) ), dim3( 256 ), 0, ctx->stream, \
-                                           d_resi, resi_stride, ra )
+#define ROWK( NN, SP ) { const int groups = ( n + ( 256 / ( NN * SP ) ) - 1 ) / ( 256 / ( NN * SP ) ); ra.groupStride = ( groups + tuRepeat() - 1 ) / tuRepeat(); \
+                         hipLaunchKernelGGL( ( tuRdoRowKernel<NN, SP> ), dim3( ra.groupStride ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, ra ); }
     static const int split16 = getenv( "VVHIP_TU_SPLIT16" ) ? atoi( getenv( "VVHIP_TU_SPLIT16" ) ) : 2;
-    if( width == 8 ) ROWK( 8, 1 ); else if( width == 16 ) { if( split16 == 2 ) ROWK( 16, 2 ); else ROWK( 16, 1 ); } else ROWK( 32, 2 );
+    if( width == 8 ) ROWK( 8, 1 ) else if( width == 16 ) { if( split16 == 2 ) ROWK( 16, 2 ) else ROWK( 16, 1 ) } else ROWK( 32, 2 )
 #undef ROWK
     VVHIP_LAUNCH_CHECK( ctx );
     return VVHIP_OK;
