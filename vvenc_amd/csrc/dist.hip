@@ -44,7 +44,9 @@ enum { MODE_SAD = 0, MODE_SSE = 1, MODE_SAD_X5 = 2, MODE_SAD_MIN2 = 3 };
 // SAD / SSE over a candidate list.  CH = samples per lane per row segment (2, 4 or 8).
 // chunk c of a candidate = (row c / lpr, segment c % lpr); lanes of a team stride over chunks.
 // ---------------------------------------------------------------------------------------------
-template<int CH, int MODE>
+// U candidates per lane team are processed together: their (dependent) item and row loads are all in flight before the first reduction —
+// small blocks have one chunk per lane, so without this a wave has only two loads outstanding.
+template<int CH, int MODE, int U = 1>
 __device__ __forceinline__ void
 sadSseBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
             int lpr /* lanes (segments) per row = w / CH */, int lprShift /* log2(lpr) or -1 */, int rowsEff, int subShift, int log2Lpc,
@@ -52,65 +54,82 @@ sadSseBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, cons
 {
   const int gid  = blockIndex * blockDim.x + threadIdx.x;
   const int lpc  = 1 << log2Lpc;
-  const int team = gid >> log2Lpc;
   const int lt   = gid & ( lpc - 1 );
   const int nTeams = MODE == MODE_SAD_X5 ? n * 5 : n;
-  const bool valid = team < nTeams;
-
-  int orgOff = 0, curOff = 0, k = 0;
-  if( valid )
-  {
-    const int idx = MODE == MODE_SAD_X5 ? team / 5 : team;
-    k = MODE == MODE_SAD_X5 ? team - idx * 5 : 0;
-    const vvhip_dist_item it = items[idx];
-    orgOff = it.org_off + k;      // RdCost.cpp:1988-2001: org.buf += k, cur.buf -= k
-    curOff = it.cur_off - k;
-  }
-  const int16_t* po = org + orgOff;
-  const int16_t* pc = cur + curOff;
   const int step = 1 << subShift;
-  const int chunks = valid ? lpr * rowsEff : 0;
+  int team[U], k[U];
+  bool valid[U];
+  const int16_t* po[U]; const int16_t* pc[U];
+#pragma unroll
+  for( int u = 0; u < U; u++ )
+  {
+    team[u] = ( gid >> log2Lpc ) * U + u;
+    valid[u] = team[u] < nTeams;
+    int orgOff = 0, curOff = 0; k[u] = 0;
+    if( valid[u] )
+    {
+      const int idx = MODE == MODE_SAD_X5 ? team[u] / 5 : team[u];
+      k[u] = MODE == MODE_SAD_X5 ? team[u] - idx * 5 : 0;
+      const vvhip_dist_item it = items[idx];
+      orgOff = it.org_off + k[u];      // RdCost.cpp:1988-2001: org.buf += k, cur.buf -= k
+      curOff = it.cur_off - k[u];
+    }
+    po[u] = org + orgOff; pc[u] = cur + curOff;
+  }
+  const int chunks = lpr * rowsEff;
 
-  uint32_t sad = 0;
-  uint64_t sse = 0;
+  uint32_t sad[U];
+  uint64_t sse[U];
+#pragma unroll
+  for( int u = 0; u < U; u++ ) { sad[u] = 0; sse[u] = 0; }
   for( int c = lt; c < chunks; c += lpc )
   {
     const int r = lprShift >= 0 ? c >> lprShift : c / lpr, s = c - r * lpr;
     const int y = r * step;
-    const int16_t* a = po + ( ptrdiff_t ) y * orgStride + s * CH;
-    const int16_t* b = pc + ( ptrdiff_t ) y * curStride + s * CH;
-    uint32_t va[CH / 2], vb[CH / 2];
-    if( CH == 2 ) { va[0] = ld4( a ); vb[0] = ld4( b ); }
-    else if( CH == 4 ) { u32x2 x = ld8( a ), z = ld8( b ); va[0] = x.x; va[CH / 2 - 1] = x.y; vb[0] = z.x; vb[CH / 2 - 1] = z.y; }
-    else { u32x4 x = ld16( a ), z = ld16( b );
-           va[0] = x.x; va[1 % ( CH / 2 )] = x.y; va[2 % ( CH / 2 )] = x.z; va[3 % ( CH / 2 )] = x.w;
-           vb[0] = z.x; vb[1 % ( CH / 2 )] = z.y; vb[2 % ( CH / 2 )] = z.z; vb[3 % ( CH / 2 )] = z.w; }
+    uint32_t va[U][CH / 2], vb[U][CH / 2];
 #pragma unroll
-    for( int i = 0; i < CH / 2; i++ )
+    for( int u = 0; u < U; u++ )
     {
-      if( MODE == MODE_SSE )
-      {
-        const int d0 = lo16( va[i] ) - lo16( vb[i] ), d1 = hi16( va[i] ) - hi16( vb[i] );
-        sse += ( uint64_t ) ( ( int64_t ) d0 * d0 ) + ( uint64_t ) ( ( int64_t ) d1 * d1 );
-      }
-      else sad = sadPair( va[i], vb[i], sad );
+      const int16_t* a = po[u] + ( ptrdiff_t ) y * orgStride + s * CH;
+      const int16_t* b = pc[u] + ( ptrdiff_t ) y * curStride + s * CH;
+      if( CH == 2 ) { va[u][0] = ld4( a ); vb[u][0] = ld4( b ); }
+      else if( CH == 4 ) { u32x2 x = ld8( a ), z = ld8( b ); va[u][0] = x.x; va[u][CH / 2 - 1] = x.y; vb[u][0] = z.x; vb[u][CH / 2 - 1] = z.y; }
+      else { u32x4 x = ld16( a ), z = ld16( b );
+             va[u][0] = x.x; va[u][1 % ( CH / 2 )] = x.y; va[u][2 % ( CH / 2 )] = x.z; va[u][3 % ( CH / 2 )] = x.w;
+             vb[u][0] = z.x; vb[u][1 % ( CH / 2 )] = z.y; vb[u][2 % ( CH / 2 )] = z.z; vb[u][3 % ( CH / 2 )] = z.w; }
     }
+#pragma unroll
+    for( int u = 0; u < U; u++ )
+#pragma unroll
+      for( int i = 0; i < CH / 2; i++ )
+      {
+        if( MODE == MODE_SSE )
+        {
+          const int d0 = lo16( va[u][i] ) - lo16( vb[u][i] ), d1 = hi16( va[u][i] ) - hi16( vb[u][i] );
+          sse[u] += ( uint64_t ) ( ( int64_t ) d0 * d0 ) + ( uint64_t ) ( ( int64_t ) d1 * d1 );
+        }
+        else sad[u] = sadPair( va[u][i], vb[u][i], sad[u] );
+      }
   }
 
-  if( MODE == MODE_SSE )
+#pragma unroll
+  for( int u = 0; u < U; u++ )
   {
-    sse = teamSum( sse, lpc );
-    if( valid && lt == 0 ) out[team] = sse;
-  }
-  else
-  {
-    sad = teamSum( sad, lpc );
-    if( valid && lt == 0 )
+    if( MODE == MODE_SSE )
     {
-      const uint64_t v = ( uint64_t ) sad << subShift;                 // RdCost.cpp:334
-      if( MODE == MODE_SAD ) out[team] = v;
-      else if( MODE == MODE_SAD_X5 ) { if( k != 2 || calcCentre ) out[team] = v >> 1; }   // RdCost.cpp:2003-2007
-      else { const uint64_t h = out[team]; out[team] = h < 2 * v ? h : 2 * v; }          // RdCost.cpp:1815
+      const uint64_t t = teamSum( sse[u], lpc );
+      if( valid[u] && lt == 0 ) out[team[u]] = t;
+    }
+    else
+    {
+      const uint32_t t = teamSum( sad[u], lpc );
+      if( valid[u] && lt == 0 )
+      {
+        const uint64_t v = ( uint64_t ) t << subShift;                 // RdCost.cpp:334
+        if( MODE == MODE_SAD ) out[team[u]] = v;
+        else if( MODE == MODE_SAD_X5 ) { if( k[u] != 2 || calcCentre ) out[team[u]] = v >> 1; }   // RdCost.cpp:2003-2007
+        else { const uint64_t h = out[team[u]]; out[team[u]] = h < 2 * v ? h : 2 * v; }          // RdCost.cpp:1815
+      }
     }
   }
 }
@@ -126,6 +145,7 @@ sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __r
 
 // Several (function-compatible) batches in ONE launch: a workgroup finds its job from the block-range table (wave-uniform scalar
 // work) and runs the same body.  Removes the launch gaps and the tails of the short per-size launches of a frame's work lists.
+constexpr int DIST_U = 2;          // candidates per lane team in the merged SAD / SSE launches
 struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand, sse; const vvhip_dist_item* items; uint64_t* out; };
 struct DistMultiJobs { int nJobs, xcdRemap; DistJobGeom j[8]; };
 
@@ -147,7 +167,7 @@ sadSseMultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  sadSseBody<8, MODE>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+  sadSseBody<8, MODE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
 }
 
 // SAD and SSE lists of one frame in the same launch (per-job mode): both are short, memory-side kernels with the same geometry
@@ -160,8 +180,8 @@ sadSseMixedKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  if( g.sse ) sadSseBody<8, MODE_SSE>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
-  else        sadSseBody<8, MODE_SAD>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+  if( g.sse ) sadSseBody<8, MODE_SSE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+  else        sadSseBody<8, MODE_SAD, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -671,7 +691,7 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
         if( g.tilesPerCand % lpc ) lpc = 1;
       }
       g.log2Lpc = ilog2i( lpc );
-      g.nBlocks = ( int ) ( ( ( long ) jb.n * lpc + 255 ) / 256 );
+      g.nBlocks = fam == 1 ? ( int ) ( ( ( ( long ) jb.n + DIST_U - 1 ) / DIST_U * lpc + 255 ) / 256 ) : ( int ) ( ( ( long ) jb.n * lpc + 255 ) / 256 );
       blocks += g.nBlocks;
       mj.nJobs++; i++;
     }
