@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Writes hook-enabled COPIES of five reference translation units into oracle/_ref/gen/src/ (build output, git-ignored).
+"""Writes hook-enabled COPIES of six reference translation units into oracle/_ref/gen/src/ (build output, git-ignored).
 Nothing of the reference is stored in the repository: the script inserts one-line calls to g_vvhipHooks (oracle/ref/hip_hooks.h)
 at anchor lines it looks up in the files where they lie under /root/reference.  This is the executable form of the binding
 shown in INTEGRATION.md §2.
 
-usage: apply_hip_hooks.py <reference CommonLib dir> <output dir>"""
+usage: apply_hip_hooks.py <reference source/Lib dir> <output dir>"""
 import os
 import sys
 
@@ -12,8 +12,8 @@ src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
 
 
-def patch(name, edits):
-    s = open(os.path.join(src, name)).read()
+def patch(name, edits, sub="CommonLib"):
+    s = open(os.path.join(src, sub, name)).read()
     for kind, anchor, text in edits:
         assert s.count(anchor) == 1, (name, anchor, s.count(anchor))
         if kind == "before":
@@ -59,4 +59,15 @@ patch("InterpolationFilter.cpp", [
      ""),   # (anchor check only: the hook goes at the end of the function body)
     ("after", "    initInterpolationFilterARM();\n#endif\n  }\n#endif\n", "  if( enable && g_vvhipHooks.initIF ) g_vvhipHooks.initIF( this );\n"),
 ])
+# batched call site: all sub-pel positions of one xPatternRefinement stage are scored by ONE device call up
+# front; the reference's own loop (skip rules, break rules, MV-bit costs, strict < update, patternId bookkeeping) then replays them
+patch("InterSearch.cpp", [
+    ("after", '#include "InterSearch.h"', INC),
+    ("after", "  const Mv* pcMvRefine = (iFrac == 2 ? s_acMvRefineH : s_acMvRefineQ);\n",
+     "  uint64_t hipCost[9];\n"
+     "  const bool hipOk = g_vvhipHooks.patternCosts && g_vvhipHooks.patternCosts( pcPatternKey, pattern, baseRefMv.hor, baseRefMv.ver, iFrac, pcMvRefine, clpRng.bd,\n"
+     "                         m_pcEncCfg->m_bUseHADME ? ( m_pcEncCfg->m_fastHad ? 2 : 1 ) : 0, reduceTap, useAltHpelIf, hipCost );\n"),
+    ("replace", "    m_cDistParam.cur.buf   = piRefPos;\n    uiDist = m_cDistParam.distFunc( m_cDistParam );\n",
+     "    m_cDistParam.cur.buf   = piRefPos;\n    uiDist = hipOk ? hipCost[i] : m_cDistParam.distFunc( m_cDistParam );\n"),
+], sub="EncoderLib")
 print("hooked copies written to", out)

@@ -7,7 +7,8 @@
 #include <cstdint>
 
 namespace vvenc {
-class RdCost; class Quant; class MCTF; class InterpolationFilter; struct MotionVector; struct PelStorage;
+class RdCost; class Quant; class MCTF; class InterpolationFilter; class Mv; struct MotionVector; struct PelStorage;
+template<class T> struct AreaBuf;
 template<class T> struct Array2D;
 }
 
@@ -19,6 +20,8 @@ struct VvhipHooks
   bool ( *fwd2D )( const int16_t* resi, ptrdiff_t stride, int32_t* coef, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
   bool ( *inv2D )( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
   void ( *initIF )( vvenc::InterpolationFilter* );
+  bool ( *patternCosts )( const vvenc::AreaBuf<const int16_t>* key, const vvenc::AreaBuf<const int16_t>* pattern, int baseHor, int baseVer, int iFrac, const vvenc::Mv* refine,
+                          int bitDepth, int hadMode, int reduceTap, bool useAltHpelIf, uint64_t* cost9 );
   bool ( *mctfApply )( const vvenc::MCTF*, const vvenc::PelStorage& orgPic, void* srcFrameInfoDeque, vvenc::PelStorage& newOrgPic, double overallStrength );
   bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel );
 };

@@ -28,7 +28,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(10, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 10); calls = [int(x) for x in c]
+    c = np.zeros(11, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 11); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -132,4 +132,19 @@ def test_hip_backend_multithreaded_encoder_bitstream_identical():
     hip = run(dict(CFG10, hip=True, simd=None, mask=31 + 64 + 128, threads=4))
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][0] > 1000 and hip["calls"][8] > 100 and hip["calls"][9] >= 1, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", [CFG1, CFG10], ids=["cfg0-64x64-8b", "128x64-10b"])
+def test_hip_batched_subpel_refinement_bitstream_identical(clip):
+    """the batching boundary at work inside the real encoder: every half- and quarter-sample stage of InterSearch::xPatternRefinement gets its
+    (up to) nine candidate costs from ONE vvhip_subpel_refine_batch call (through vvhip::RdCost::patternRefineCosts); the encoder's own loop
+    replays them (skip and break rules, MV-bit costs, strict < update, patternId bookkeeping).  Everything else on the CPU."""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=256))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][10] > 50, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)

@@ -238,6 +238,36 @@ void RdCost::create( bool /*enableOpt*/ )
   m_afpDistortFuncX5[1] = sadX5Entry<4>;
 }
 
+bool RdCost::patternRefineCosts( const CPelBuf& org, const Pel* refBlk, int refStride, const int ( *qpel )[2], int n, int bitDepth, int hadMode, int reduceTap, bool useAltHpelIf,
+                                 Distortion* out )
+{
+  const int w = org.width, h = org.height;
+  if( ( w & 7 ) || w > 64 || h > 64 || h < 4 || n < 1 || n > 16 || reduceTap < 0 || reduceTap > 2 ) return false;
+  if( ( hadMode == 1 || hadMode == 2 ) && ( h & 3 ) ) return false;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int M0 = 5, M1 = 6, pitch = w + M0 + M1, rows = h + M0 + M1;
+  std::vector<Pel> host( ( size_t ) w * h + ( size_t ) pitch * rows );
+  for( int y = 0; y < h; y++ ) memcpy( &host[( size_t ) y * w], org.buf + ( ptrdiff_t ) y * org.stride, sizeof( Pel ) * w );
+  Pel* win = host.data() + ( size_t ) w * h;
+  for( int y = 0; y < rows; y++ ) memcpy( win + ( size_t ) y * pitch, refBlk + ( ptrdiff_t ) ( y - M0 ) * refStride - M0, sizeof( Pel ) * pitch );
+  int16_t* dArea = dev.staging( host.size() * sizeof( Pel ) + 256 );
+  dev.check( vvhip_upload( dev.ctx(), dArea, host.data(), host.size() * sizeof( Pel ) ), "pattern refinement" );
+  struct Io { vvhip_subpel_item base; uint32_t pad; uint64_t cost[16]; } io;
+  memset( &io, 0, sizeof( io ) );
+  io.base.org_off = 0; io.base.ref_off = M0 * pitch + M0; io.base.frac_x = 0; io.base.frac_y = 0;
+  char* aux = static_cast<char*>( dev.stagingAux( sizeof( Io ) ) );
+  dev.check( vvhip_upload( dev.ctx(), aux, &io, sizeof( io ) ), "pattern refinement" );
+  int16_t offs[32];
+  for( int i = 0; i < n; i++ ) { offs[2 * i] = ( int16_t ) ( qpel[i][0] * 4 ); offs[2 * i + 1] = ( int16_t ) ( qpel[i][1] * 4 ); }
+  const int func = hadMode == 0 ? VVHIP_DF_SAD : hadMode == 1 ? VVHIP_DF_HAD : VVHIP_DF_HAD_FAST;
+  dev.check( vvhip_subpel_refine_batch( dev.ctx(), func, dArea, w, dArea + ( size_t ) w * h, pitch, w, h, bitDepth, reduceTap, useAltHpelIf ? 1 : 0,
+                                        reinterpret_cast<vvhip_subpel_item*>( aux ), 1, offs, n, reinterpret_cast<uint64_t*>( aux + offsetof( Io, cost ) ) ), "vvhip_subpel_refine_batch" );
+  dev.check( vvhip_download( dev.ctx(), io.cost, aux + offsetof( Io, cost ), sizeof( uint64_t ) * n ), "pattern refinement" );
+  for( int i = 0; i < n; i++ ) out[i] = io.cost[i];
+  return true;
+}
+
 void RdCost::setDistParamGeo( DistParam& dp, const CPelBuf& org, const Pel* refY, int refStride, const Pel* mask, int maskStride, int stepX, int maskStride2, int bitDepth, int compID )
 {
   dp.bitDepth = bitDepth; dp.compID = compID;

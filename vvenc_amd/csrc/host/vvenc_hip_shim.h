@@ -114,6 +114,14 @@ public:
   // RdCost::getDistPart, CommonLib/RdCost.cpp:267-291 (luma; chroma weighting stays with the caller)
   Distortion getDistPart( const CPelBuf& org, const CPelBuf& cur, int bitDepth, DFunc eDFunc );
 
+  // One stage of InterSearch::xPatternRefinement (EncoderLib/InterSearch.cpp:760-880) in ONE device call: the distortion of the original block
+  // against the reference block interpolated at each of n (<= 9) displacements qpel[i] = (hor, ver) in quarter samples around refBlk
+  // (= pattern->buf, the block at the best integer vector; the reference picture's margin must be readable, 6 samples are touched).
+  // hadMode 0 SAD, 1 HAD, 2 HAD_fast (m_bUseHADME / m_fastHad); reduceTap = m_meReduceTap; returns false for shapes the device entry
+  // does not take (the caller keeps its CPU path).  The MV-bit cost and the strict-< update stay with the caller's loop.
+  bool patternRefineCosts( const CPelBuf& org, const Pel* refBlk, int refStride, const int ( *qpel )[2], int n, int bitDepth, int hadMode, int reduceTap, bool useAltHpelIf,
+                           Distortion* out );
+
   // ---- batching (2) ----
   int        enqueue( const DistParam& dp );         // dp.distFunc must be one of this object's table entries
   void       flush();                                // one launch per (function, block size, subShift, plane pair) group
