@@ -59,6 +59,26 @@ patch("InterpolationFilter.cpp", [
      ""),   # (anchor check only: the hook goes at the end of the function body)
     ("after", "    initInterpolationFilterARM();\n#endif\n  }\n#endif\n", "  if( enable && g_vvhipHooks.initIF ) g_vvhipHooks.initIF( this );\n"),
 ])
+# DMVR: the refinement search of every sub-block of the CU in one device call; the reference's loop then only copies results
+patch("InterPrediction.cpp", [
+    ("after", '#include "InterPrediction.h"', INC),
+    ("before", "    DistParam distParam = m_pcRdCost->setDistParam( nullptr, nullptr, bilinearBufStride, bilinearBufStride, bd, COMP_Y, dx, dy, 1, true );",
+     "    int16_t  hipMvd[2 * MAX_NUM_SUBCU_DMVR]; uint64_t hipCost[MAX_NUM_SUBCU_DMVR];\n"
+     "    bool hipDmvr = false;\n"
+     "    if( g_vvhipHooks.dmvrSearch )\n"
+     "    {\n"
+     "      const Picture* r0 = cu.slice->getRefPic( L0, cu.refIdx[L0] ); const Picture* r1 = cu.slice->getRefPic( L1, cu.refIdx[L1] );\n"
+     "      const int s0 = r0->getRecoBufStride( COMP_Y ), s1 = r1->getRecoBufStride( COMP_Y );\n"
+     "      const Pel* p0 = r0->getRecoBufPtr( COMP_Y ) + ( puPos.x + ( mergeMVL0.hor >> MV_FRACTIONAL_BITS_INTERNAL ) ) + ( puPos.y + ( mergeMVL0.ver >> MV_FRACTIONAL_BITS_INTERNAL ) ) * s0;\n"
+     "      const Pel* p1 = r1->getRecoBufPtr( COMP_Y ) + ( puPos.x + ( mergeMVL1.hor >> MV_FRACTIONAL_BITS_INTERNAL ) ) + ( puPos.y + ( mergeMVL1.ver >> MV_FRACTIONAL_BITS_INTERNAL ) ) * s1;\n"
+     "      hipDmvr = g_vvhipHooks.dmvrSearch( p0, s0, mergeMVL0.hor & 15, mergeMVL0.ver & 15, p1, s1, mergeMVL1.hor & 15, mergeMVL1.ver & 15,\n"
+     "                                         cu.lwidth(), cu.lheight(), dx, dy, bd, hipMvd, hipCost );\n"
+     "    }\n"),
+    ("before", "        distParam.org.buf = addrL0;\n        distParam.cur.buf = addrL1;\n        minCost  = distParam.distFunc( distParam ) >> 1;",
+     "        if( hipDmvr ) { cu.mvdL0SubPu[num] = Mv( hipMvd[2 * num], hipMvd[2 * num + 1] ); minCost = hipCost[num]; } else {\n"),
+    ("before", "        bioAppliedType[num] = ( minCost < bioEnabledThres ) ? false : bioApplied;", "        }\n"),
+])
+
 # batched call site: all sub-pel positions of one xPatternRefinement stage are scored by ONE device call up
 # front; the reference's own loop (skip rules, break rules, MV-bit costs, strict < update, patternId bookkeeping) then replays them
 patch("InterSearch.cpp", [

@@ -51,7 +51,7 @@
 #include "hip_hooks.h"
 #include "../../vvenc_amd/csrc/host/vvenc_hip_shim.h"
 
-VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 
 namespace {
 
@@ -208,6 +208,17 @@ bool patternCosts( const vvenc::CPelBuf* key, const vvenc::CPelBuf* pattern, int
   return true;
 }
 
+// the refinement search of DMVR::xProcessDMVR for all sub-blocks of one CU in one device call (InterPrediction.cpp:1312-1392)
+std::atomic<uint64_t> g_dmvrCalls( 0 );
+bool dmvrSearch( const int16_t* ref0, int stride0, int fx0, int fy0, const int16_t* ref1, int stride1, int fx1, int fy1, int cuWidth, int cuHeight, int dx, int dy, int bitDepth,
+                 int16_t* mvd, uint64_t* minCost )
+{
+  static vvhip::DMVROps ops;
+  if( !ops.refineCu( ref0, stride0, fx0, fy0, ref1, stride1, fx1, fy1, cuWidth, cuHeight, dx, dy, bitDepth, mvd, minCost ) ) return false;
+  g_dmvrCalls++;
+  return true;
+}
+
 // ---- InterpolationFilter tables: every slot of m_filterHor / m_filterVer / m_filterCopy / m_filter4x4 / m_filter8xH /
 // m_filter16xH forwards to the shim's slot of the same index (the only difference between the two signatures is the ClpRng type)
 vvhip::InterpolationFilter* g_if = nullptr;
@@ -286,7 +297,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_after_simd_in
 
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
 {
-  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch)
+  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU
   g_slotMask = mask;
   try
   {
@@ -302,6 +313,8 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
   g_vvhipHooks.initIF     = ( mask & 64 ) ? initIF : nullptr;
   g_vvhipHooks.mctfApply  = ( mask & 128 ) ? mctfApply : nullptr;
   g_vvhipHooks.patternCosts = ( mask & 256 ) ? patternCosts : nullptr;
+  g_vvhipHooks.dmvrSearch = ( mask & 512 ) ? dmvrSearch : nullptr;
+  g_dmvrCalls = 0;
   g_patternCalls = 0;
   for( auto& c : g_calls ) c = 0;
   return 0;
@@ -315,4 +328,5 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
 {
   for( int i = 0; i < n && i < 10; i++ ) out[i] = g_calls[i];
   if( n > 10 ) out[10] = g_patternCalls;
+  if( n > 11 ) out[11] = g_dmvrCalls;
 }

@@ -28,7 +28,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(11, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 11); calls = [int(x) for x in c]
+    c = np.zeros(12, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 12); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -147,4 +147,19 @@ def test_hip_batched_subpel_refinement_bitstream_identical(clip):
     hip = run(dict(clip, hip=True, simd=None, mask=256))
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][10] > 50, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", [CFG1, CFG10], ids=["cfg0-64x64-8b", "128x64-10b"])
+def test_hip_dmvr_search_bitstream_identical(clip):
+    """SURVEY 8f rank 3 against the real DMVR::xProcessDMVR: the refinement search of every sub-block of a CU comes from ONE
+    vvhip_dmvr_refine_batch call (vvhip::DMVROps::refineCu); the encoder copies mvdL0SubPu / the BDOF switch from the results and does the final
+    motion compensation itself.  DMVR is decoder-normative: any deviation changes the bitstream."""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=512))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][11] > 10, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)

@@ -618,6 +618,42 @@ void InterpolationFilter::filterVer( Pel const* src, int srcStride, Pel* dst, in
   else                      m_filterVer[1][isFirst][isLast]( clpRng, src, srcStride, dst, dstStride, width, height, chromaFilter( frac << 1 ) );
 }
 
+// ------------------------------------------------------------------------------------------------ DMVROps
+bool DMVROps::refineCu( const Pel* ref0, int stride0, int fx0, int fy0, const Pel* ref1, int stride1, int fx1, int fy1, int cuWidth, int cuHeight, int dx, int dy, int bitDepth,
+                        int16_t* mvd, uint64_t* minCost )
+{
+  if( ( dx != 8 && dx != 16 ) || ( dy != 8 && dy != 16 ) || cuWidth % dx || cuHeight % dy || bitDepth > 10 ) return false;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  // the bilinear prediction of the (w+4) x (h+4) area reads one more column / row: stage (w+5) x (h+5) of each list, compact
+  const int pw = cuWidth + 5, ph = cuHeight + 5;
+  std::vector<Pel> host( ( size_t ) 2 * pw * ph );
+  for( int y = 0; y < ph; y++ )
+  {
+    memcpy( &host[( size_t ) y * pw], ref0 + ( ptrdiff_t ) y * stride0, sizeof( Pel ) * pw );
+    memcpy( &host[( size_t ) ( ph + y ) * pw], ref1 + ( ptrdiff_t ) y * stride1, sizeof( Pel ) * pw );
+  }
+  int16_t* dArea = dev.staging( host.size() * sizeof( Pel ) + 256 );
+  dev.check( vvhip_upload( dev.ctx(), dArea, host.data(), host.size() * sizeof( Pel ) ), "DMVR windows" );
+  const int nx = cuWidth / dx, ny = cuHeight / dy, n = nx * ny;
+  std::vector<vvhip_dmvr_item> items( n );
+  for( int by = 0; by < ny; by++ ) for( int bx = 0; bx < nx; bx++ )
+  {
+    vvhip_dmvr_item& it = items[by * nx + bx];
+    // the device entry subtracts the 2-sample search margin itself: hand it the position 2 samples inside the staged window
+    it.ref0_off = ( by * dy + 2 ) * pw + bx * dx + 2; it.ref1_off = it.ref0_off;
+    it.frac0_x = ( int16_t ) fx0; it.frac0_y = ( int16_t ) fy0; it.frac1_x = ( int16_t ) fx1; it.frac1_y = ( int16_t ) fy1;
+  }
+  char* aux = static_cast<char*>( dev.stagingAux( ( size_t ) n * ( sizeof( vvhip_dmvr_item ) + sizeof( vvhip_dmvr_result ) ) + 64 ) );
+  vvhip_dmvr_result* dRes = reinterpret_cast<vvhip_dmvr_result*>( aux + ( ( ( size_t ) n * sizeof( vvhip_dmvr_item ) + 15 ) & ~( size_t ) 15 ) );
+  dev.check( vvhip_upload( dev.ctx(), aux, items.data(), ( size_t ) n * sizeof( vvhip_dmvr_item ) ), "DMVR items" );
+  dev.check( vvhip_dmvr_refine_batch( dev.ctx(), dArea, pw, dArea + ( size_t ) pw * ph, pw, reinterpret_cast<vvhip_dmvr_item*>( aux ), n, dx, dy, bitDepth, dRes ), "vvhip_dmvr_refine_batch" );
+  std::vector<vvhip_dmvr_result> res( n );
+  dev.check( vvhip_download( dev.ctx(), res.data(), dRes, ( size_t ) n * sizeof( vvhip_dmvr_result ) ), "DMVR results" );
+  for( int i = 0; i < n; i++ ) { mvd[2 * i] = res[i].mvd_x; mvd[2 * i + 1] = res[i].mvd_y; minCost[i] = res[i].min_cost; }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ MCTFOps
 namespace {
 

@@ -168,6 +168,16 @@ struct QuantOps
                         const int defaultQuantisationCoefficient, const int iQBits, const int64_t iAdd, const TCoeff thrVal );
 };
 
+// DMVR refinement search of one CU in one device call (DMVR::xProcessDMVR, CommonLib/InterPrediction.cpp:1262-1392).
+struct DMVROps
+{
+  // ref0 / ref1: the reference samples at the CU's position displaced by the integer part of the (clipped) merge vectors MINUS 2 samples in
+  // both directions (= what the reference hands to its bilinear xPredInterBlk, :1285-1302); frac* = the vectors' 1/16 fractions.
+  // Sub-blocks dx x dy (<= 16) in raster order: mvd[2*num], mvd[2*num+1] = cu.mvdL0SubPu[num]; minCost[num] = the value compared with 2*dx*dy (:1386).
+  bool refineCu( const Pel* ref0, int stride0, int fx0, int fy0, const Pel* ref1, int stride1, int fx1, int fy1, int cuWidth, int cuHeight, int dx, int dy, int bitDepth,
+                 int16_t* mvd, uint64_t* minCost );
+};
+
 // MCTF table, CommonLib/MCTF.h:160-170
 struct MCTFOps
 {
