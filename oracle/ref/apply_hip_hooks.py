@@ -83,6 +83,12 @@ patch("InterPrediction.cpp", [
 # front; the reference's own loop (skip rules, break rules, MV-bit costs, strict < update, patternId bookkeeping) then replays them
 patch("InterSearch.cpp", [
     ("after", '#include "InterSearch.h"', INC),
+    # integer TZ search: a diamond round's positions are scored by one device call when the round starts, xTZSearchHelp looks them up
+    ("replace", "  m_cDistParam.cur.buf = piRefSrch;\n\n  uiSad = m_cDistParam.distFunc( m_cDistParam );",
+     "  m_cDistParam.cur.buf = piRefSrch;\n\n  if( !( g_vvhipHooks.tzLookup && g_vvhipHooks.tzLookup( &m_cDistParam, rcStruct.piRefY, iSearchX, iSearchY, &uiSad ) ) )\n    uiSad = m_cDistParam.distFunc( m_cDistParam );"),
+    ("replace", "  rcStruct.uiBestRound += 1;\n\n  if ( iDist == 1 )",
+     "  rcStruct.uiBestRound += 1;\n  if( g_vvhipHooks.tzPrefetch ) g_vvhipHooks.tzPrefetch( &m_cDistParam, rcStruct.piRefY, rcStruct.iRefStride, iStartX, iStartY, iDist, bCheckCornersAtDist1, sr.left, sr.right, sr.top, sr.bottom );\n\n  if ( iDist == 1 )"),
+    ("before", "  if( cu.cs->picture->useME )\n  {\n    switch ( m_motionEstimationSearchMethodSCC )", "  if( g_vvhipHooks.tzReset ) g_vvhipHooks.tzReset();\n"),
     ("after", "  const Mv* pcMvRefine = (iFrac == 2 ? s_acMvRefineH : s_acMvRefineQ);\n",
      "  uint64_t hipCost[9];\n"
      "  const bool hipOk = g_vvhipHooks.patternCosts && g_vvhipHooks.patternCosts( pcPatternKey, pattern, baseRefMv.hor, baseRefMv.ver, iFrac, pcMvRefine, clpRng.bd,\n"

@@ -51,7 +51,7 @@
 #include "hip_hooks.h"
 #include "../../vvenc_amd/csrc/host/vvenc_hip_shim.h"
 
-VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 
 namespace {
 
@@ -208,6 +208,57 @@ bool patternCosts( const vvenc::CPelBuf* key, const vvenc::CPelBuf* pattern, int
   return true;
 }
 
+// ---- integer TZ search (InterSearch::xTZ8PointDiamondSearch, EncoderLib/InterSearch.cpp:557-760): the positions a diamond round may test are
+// scored by ONE device call when the round starts; xTZSearchHelp (:410-438) then takes its SAD from this table and runs its own update
+// logic (MV-bit cost, strict <, early-exit bookkeeping).  Values are exact, so a position the round skips is simply never looked up.
+struct TzTable { const int16_t* org = nullptr; const int16_t* ref = nullptr; int subShift = -1, n = 0; int xy[24][2]; uint64_t sad[24]; };
+thread_local TzTable t_tz;
+std::atomic<uint64_t> g_tzRounds( 0 ), g_tzHits( 0 );
+
+void tzReset() { t_tz.n = 0; t_tz.org = nullptr; }
+
+void tzPrefetch( const vvenc::DistParam* dp, const int16_t* refY, int refStride, int sx, int sy, int d, bool corners, int left, int right, int top, int bottom )
+{
+  TzTable& t = t_tz;
+  t.n = 0; t.org = nullptr;
+  if( dp->applyWeight || dp->org.width < 4 || dp->org.width > 128 || dp->org.height > 128 ) return;
+  auto add = [&]( int x, int y ) { if( x >= left && x <= right && y >= top && y <= bottom && t.n < 24 ) { t.xy[t.n][0] = x; t.xy[t.n][1] = y; t.n++; } };
+  if( d == 1 )
+  {
+    add( sx, sy - 1 ); add( sx - 1, sy ); add( sx + 1, sy ); add( sx, sy + 1 );
+    if( corners ) { add( sx - 1, sy - 1 ); add( sx + 1, sy - 1 ); add( sx - 1, sy + 1 ); add( sx + 1, sy + 1 ); }
+  }
+  else if( d <= 8 )
+  {
+    const int h = d >> 1;
+    add( sx, sy - d ); add( sx - h, sy - h ); add( sx + h, sy - h ); add( sx - d, sy ); add( sx + d, sy ); add( sx - h, sy + h ); add( sx + h, sy + h ); add( sx, sy + d );
+  }
+  else
+  {
+    add( sx, sy - d ); add( sx - d, sy ); add( sx + d, sy ); add( sx, sy + d );
+    for( int i = 1; i < 4; i++ )
+    {
+      const int q = ( d >> 2 ) * i;
+      add( sx - q, sy - d + q ); add( sx + q, sy - d + q ); add( sx - q, sy + d - q ); add( sx + q, sy + d - q );
+    }
+  }
+  if( t.n == 0 ) return;
+  vvhip::CPelBuf org; org.buf = dp->org.buf; org.stride = ( int ) dp->org.stride; org.width = dp->org.width; org.height = dp->org.height;
+  vvhip::Distortion c[24];
+  g_rd->distAtPositions( VVHIP_DF_SAD, org, refY, refStride, dp->subShift, dp->bitDepth, t.xy, t.n, c );
+  for( int i = 0; i < t.n; i++ ) t.sad[i] = c[i];
+  t.org = dp->org.buf; t.ref = refY; t.subShift = dp->subShift;
+  g_tzRounds++;
+}
+
+bool tzLookup( const vvenc::DistParam* dp, const int16_t* refY, int x, int y, uint64_t* sad )
+{
+  const TzTable& t = t_tz;
+  if( t.org != dp->org.buf || t.ref != refY || t.subShift != dp->subShift ) return false;
+  for( int i = 0; i < t.n; i++ ) if( t.xy[i][0] == x && t.xy[i][1] == y ) { *sad = t.sad[i]; g_tzHits++; return true; }
+  return false;
+}
+
 // the refinement search of DMVR::xProcessDMVR for all sub-blocks of one CU in one device call (InterPrediction.cpp:1312-1392)
 std::atomic<uint64_t> g_dmvrCalls( 0 );
 bool dmvrSearch( const int16_t* ref0, int stride0, int fx0, int fy0, const int16_t* ref1, int stride1, int fx1, int fy1, int cuWidth, int cuHeight, int dx, int dy, int bitDepth,
@@ -297,7 +348,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_after_simd_in
 
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
 {
-  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU
+  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round)
   g_slotMask = mask;
   try
   {
@@ -314,6 +365,8 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
   g_vvhipHooks.mctfApply  = ( mask & 128 ) ? mctfApply : nullptr;
   g_vvhipHooks.patternCosts = ( mask & 256 ) ? patternCosts : nullptr;
   g_vvhipHooks.dmvrSearch = ( mask & 512 ) ? dmvrSearch : nullptr;
+  g_vvhipHooks.tzReset = ( mask & 1024 ) ? tzReset : nullptr; g_vvhipHooks.tzPrefetch = ( mask & 1024 ) ? tzPrefetch : nullptr; g_vvhipHooks.tzLookup = ( mask & 1024 ) ? tzLookup : nullptr;
+  g_tzRounds = 0; g_tzHits = 0;
   g_dmvrCalls = 0;
   g_patternCalls = 0;
   for( auto& c : g_calls ) c = 0;
@@ -329,4 +382,6 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
   for( int i = 0; i < n && i < 10; i++ ) out[i] = g_calls[i];
   if( n > 10 ) out[10] = g_patternCalls;
   if( n > 11 ) out[11] = g_dmvrCalls;
+  if( n > 12 ) out[12] = g_tzRounds;
+  if( n > 13 ) out[13] = g_tzHits;
 }

@@ -7,7 +7,7 @@
 #include <cstdint>
 
 namespace vvenc {
-class RdCost; class Quant; class MCTF; class InterpolationFilter; class Mv; struct MotionVector; struct PelStorage;
+class RdCost; class Quant; class MCTF; class InterpolationFilter; class Mv; class DistParam; struct MotionVector; struct PelStorage;
 template<class T> struct AreaBuf;
 template<class T> struct Array2D;
 }
@@ -22,6 +22,10 @@ struct VvhipHooks
   void ( *initIF )( vvenc::InterpolationFilter* );
   bool ( *patternCosts )( const vvenc::AreaBuf<const int16_t>* key, const vvenc::AreaBuf<const int16_t>* pattern, int baseHor, int baseVer, int iFrac, const vvenc::Mv* refine,
                           int bitDepth, int hadMode, int reduceTap, bool useAltHpelIf, uint64_t* cost9 );
+  // integer TZ search: all positions of a diamond round are scored by one device call up front; xTZSearchHelp looks the SAD up
+  void ( *tzReset )();
+  void ( *tzPrefetch )( const vvenc::DistParam* dp, const int16_t* refY, int refStride, int startX, int startY, int dist, bool corners, int left, int right, int top, int bottom );
+  bool ( *tzLookup )( const vvenc::DistParam* dp, const int16_t* refY, int x, int y, uint64_t* sad );
   bool ( *dmvrSearch )( const int16_t* ref0, int stride0, int fx0, int fy0, const int16_t* ref1, int stride1, int fx1, int fy1, int cuWidth, int cuHeight, int dx, int dy, int bitDepth,
                         int16_t* mvd, uint64_t* minCost );
   bool ( *mctfApply )( const vvenc::MCTF*, const vvenc::PelStorage& orgPic, void* srcFrameInfoDeque, vvenc::PelStorage& newOrgPic, double overallStrength );

@@ -28,7 +28,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(12, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 12); calls = [int(x) for x in c]
+    c = np.zeros(14, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 14); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -168,12 +168,27 @@ def test_hip_dmvr_search_bitstream_identical(clip):
 @pytest.mark.gpu
 def test_hip_everything_on_device_bitstream_identical():
     """all hooks at once on a larger clip (208x120 10-bit, 9 frames, 2 encoder threads): every kernel table, the interpolation tables, whole-picture
-    MCTF ME + filter, batched sub-pel refinement stages and per-CU DMVR searches"""
+    MCTF ME + filter, batched integer diamond rounds, batched sub-pel refinement stages and per-CU DMVR searches"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
         pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
-    hip = run(dict(clip, hip=True, simd=None, mask=31 + 64 + 128 + 256 + 512))
+    hip = run(dict(clip, hip=True, simd=None, mask=31 + 64 + 128 + 256 + 512 + 1024))
     print("cpu", cpu, "hip", hip)
-    assert hip["calls"][0] > 1000 and hip["calls"][8] > 100 and hip["calls"][9] >= 1 and hip["calls"][10] > 50 and hip["calls"][11] > 5, hip["calls"]
+    assert hip["calls"][0] > 1000 and hip["calls"][8] > 100 and hip["calls"][9] >= 1 and hip["calls"][10] > 50 and hip["calls"][11] > 5 and hip["calls"][12] > 50, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", [CFG1, CFG10], ids=["cfg0-64x64-8b", "128x64-10b"])
+def test_hip_batched_tz_diamond_rounds_bitstream_identical(clip):
+    """integer motion search through the batching boundary: when a TZ diamond round starts (InterSearch::xTZ8PointDiamondSearch) all positions it
+    may test are scored by ONE device call (vvhip::RdCost::distAtPositions -> vvhip_dist_batch); xTZSearchHelp takes its SAD from that table and
+    runs its own update logic (MV-bit cost, strict <).  Everything else on the CPU."""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=1024))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][12] > 50 and hip["calls"][13] > hip["calls"][12], hip["calls"]      # rounds, looked-up positions
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)

@@ -238,6 +238,32 @@ void RdCost::create( bool /*enableOpt*/ )
   m_afpDistortFuncX5[1] = sadX5Entry<4>;
 }
 
+void RdCost::distAtPositions( int func, const CPelBuf& org, const Pel* refBase, int refStride, int subShift, int bitDepth, const int ( *xy )[2], int n, Distortion* out )
+{
+  if( n <= 0 ) return;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int w = org.width, h = org.height;
+  int x0 = xy[0][0], x1 = xy[0][0], y0 = xy[0][1], y1 = xy[0][1];
+  for( int i = 1; i < n; i++ ) { x0 = std::min( x0, xy[i][0] ); x1 = std::max( x1, xy[i][0] ); y0 = std::min( y0, xy[i][1] ); y1 = std::max( y1, xy[i][1] ); }
+  const int pw = x1 - x0 + w, ph = y1 - y0 + h;
+  std::vector<Pel> host( ( size_t ) w * h + ( size_t ) pw * ph );
+  for( int y = 0; y < h; y++ ) memcpy( &host[( size_t ) y * w], org.buf + ( ptrdiff_t ) y * org.stride, sizeof( Pel ) * w );
+  Pel* win = host.data() + ( size_t ) w * h;
+  for( int y = 0; y < ph; y++ ) memcpy( win + ( size_t ) y * pw, refBase + ( ptrdiff_t ) ( y0 + y ) * refStride + x0, sizeof( Pel ) * pw );
+  int16_t* dArea = dev.staging( host.size() * sizeof( Pel ) + 256 );
+  dev.check( vvhip_upload( dev.ctx(), dArea, host.data(), host.size() * sizeof( Pel ) ), "search stage" );
+  std::vector<vvhip_dist_item> items( n );
+  for( int i = 0; i < n; i++ ) { items[i].org_off = 0; items[i].cur_off = ( xy[i][1] - y0 ) * pw + ( xy[i][0] - x0 ); }
+  char* aux = static_cast<char*>( dev.stagingAux( ( size_t ) n * ( sizeof( vvhip_dist_item ) + sizeof( uint64_t ) ) + 64 ) );
+  uint64_t* dOut = reinterpret_cast<uint64_t*>( aux + ( ( ( size_t ) n * sizeof( vvhip_dist_item ) + 15 ) & ~( size_t ) 15 ) );
+  dev.check( vvhip_upload( dev.ctx(), aux, items.data(), ( size_t ) n * sizeof( vvhip_dist_item ) ), "search stage" );
+  dev.check( vvhip_dist_batch( dev.ctx(), func, dArea, w, dArea + ( size_t ) w * h, pw, w, h, subShift, bitDepth, reinterpret_cast<vvhip_dist_item*>( aux ), n, dOut ), "vvhip_dist_batch" );
+  std::vector<uint64_t> res( n );
+  dev.check( vvhip_download( dev.ctx(), res.data(), dOut, ( size_t ) n * sizeof( uint64_t ) ), "search stage" );
+  for( int i = 0; i < n; i++ ) out[i] = res[i];
+}
+
 bool RdCost::patternRefineCosts( const CPelBuf& org, const Pel* refBlk, int refStride, const int ( *qpel )[2], int n, int bitDepth, int hadMode, int reduceTap, bool useAltHpelIf,
                                  Distortion* out )
 {

@@ -122,6 +122,11 @@ public:
   bool patternRefineCosts( const CPelBuf& org, const Pel* refBlk, int refStride, const int ( *qpel )[2], int n, int bitDepth, int hadMode, int reduceTap, bool useAltHpelIf,
                            Distortion* out );
 
+  // The candidate positions of one integer-search stage (a TZ diamond round, a raster row, a refinement star; InterSearch::xTZSearchHelp,
+  // EncoderLib/InterSearch.cpp:410-438) in ONE device call: out[i] = func( org, refBase + xy[i][1]*refStride + xy[i][0] ) with the given
+  // subShift.  Host buffers: the original block and the bounding window of the positions are staged per call.
+  void distAtPositions( int func, const CPelBuf& org, const Pel* refBase, int refStride, int subShift, int bitDepth, const int ( *xy )[2], int n, Distortion* out );
+
   // ---- batching (2) ----
   int        enqueue( const DistParam& dp );         // dp.distFunc must be one of this object's table entries
   void       flush();                                // one launch per (function, block size, subShift, plane pair) group
