@@ -48,7 +48,7 @@ patch("MCTF.cpp", [
     ("after", '#include "MCTF.h"', INC),
     ("after", "    initMCTF_ARM();\n#endif\n  }\n", "  if( enableOpt && g_vvhipHooks.initMCTF ) g_vvhipHooks.initMCTF( this );\n"),
     ("before", "    Array2D<MotionVector> mv_0(width / (m_mctfUnitSize * 8) + 1, height / (m_mctfUnitSize * 8) + 1);",
-     "    if( !( g_vvhipHooks.mctfMe && g_vvhipHooks.mctfMe( this, srcPic.picBuffer, origBuf, srcPic.mvs, addLevel ) ) )\n    {\n"),
+     "    if( !( g_vvhipHooks.mctfMe && g_vvhipHooks.mctfMe( this, srcPic.picBuffer, origBuf, srcPic.mvs, addLevel, curPic->poc, m_filterPoc ) ) )\n    {\n"),
     ("after", "    motionEstimationLuma(srcPic.mvs, origBuf, srcPic.picBuffer, m_mctfUnitSize, &mv_2, 1, true);\n", "    }\n"),
     ("before", "  const double lumaSigmaSq = m_sigmaMultiplier * ( 128.0 + 3.0 / 256.0 * m_encCfg->m_QP * m_encCfg->m_QP * m_encCfg->m_QP );",
      "  if( g_vvhipHooks.mctfApply && g_vvhipHooks.mctfApply( this, orgPic, &srcFrameInfo, newOrgPic, overallStrength ) ) return;\n"),

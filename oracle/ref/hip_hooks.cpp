@@ -156,6 +156,59 @@ bool inv2D( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned w, un
   return true;
 }
 
+// ---- resident original pictures: MCTF reads every original picture many times (as the current picture once, as a neighbour of up to
+// 2*range filtered pictures, luma for the search and all planes for the filter).  The hooks keep the planes mirrored on the device, keyed by
+// the host buffer AND the picture order count (buffers are recycled for later pictures), least-recently-used eviction.
+struct ResidentPic { const vvenc::Pel* key; int poc; int ids[3]; int nComp; uint64_t stamp; };
+std::vector<ResidentPic> g_resident;
+uint64_t g_residentStamp = 0, g_residentUploads = 0, g_residentHits = 0;
+
+void dropResident( size_t i )
+{
+  vvhip::Device& dev = vvhip::Device::get();
+  for( int c = 0; c < g_resident[i].nComp; c++ ) dev.unregisterPicture( g_resident[i].ids[c] );
+  g_resident.erase( g_resident.begin() + i );
+}
+
+// mirror ids of the picture's first nComp planes; poc < 0: match the most recent entry of this host buffer (the search of the same filter call
+// validated it), uploading (uncached identity) when there is none
+ResidentPic& residentPlanes( const vvenc::PelStorage& ps, int poc, int nComp )
+{
+  vvhip::Device& dev = vvhip::Device::get();
+  const vvenc::Pel* key = ps.bufs[0].buf;
+  int found = -1;
+  for( size_t i = 0; i < g_resident.size(); )
+  {
+    ResidentPic& e = g_resident[i];
+    if( e.key == key && poc >= 0 && e.poc != poc ) { dropResident( i ); continue; }            // the host buffer now holds another picture
+    if( e.key == key && ( found < 0 || e.stamp > g_resident[found].stamp ) ) found = ( int ) i;
+    i++;
+  }
+  if( found < 0 )
+  {
+    if( g_resident.size() >= 16 )
+    {
+      size_t lru = 0;
+      for( size_t i = 1; i < g_resident.size(); i++ ) if( g_resident[i].stamp < g_resident[lru].stamp ) lru = i;
+      dropResident( lru );
+    }
+    ResidentPic e; e.key = key; e.poc = poc; e.nComp = 0; e.ids[0] = e.ids[1] = e.ids[2] = -1; e.stamp = 0;
+    g_resident.push_back( e );
+    found = ( int ) g_resident.size() - 1;
+  }
+  else g_residentHits++;
+  ResidentPic& e = g_resident[found];
+  for( int c = e.nComp; c < nComp; c++ )
+  {
+    const vvenc::CPelBuf b = ps.bufs[c];
+    e.ids[c] = dev.registerPicture( b.buf, ( int ) b.stride, b.width, b.height, vvenc::MCTF_PADDING >> ( c ? 1 : 0 ), false );      // id use only: never aliased by the per-call entries
+    g_residentUploads++;
+  }
+  if( nComp > e.nComp ) e.nComp = nComp;
+  e.stamp = ++g_residentStamp;
+  return e;
+}
+
 // whole MCTF::bilateralFilter (MCTF.cpp:1489-1552) on the GPU: every plane of the original and of the references is mirrored, the motion fields
 // the (CPU or GPU) search left in srcFrameInfo[i].mvs are uploaded, one launch per component plane
 bool mctfApply( const vvenc::MCTF* m, const vvenc::PelStorage& orgPic, void* infoDeque, vvenc::PelStorage& newOrgPic, double overallStrength )
@@ -165,10 +218,11 @@ bool mctfApply( const vvenc::MCTF* m, const vvenc::PelStorage& orgPic, void* inf
   const int numComp = ( int ) vvenc::getNumberValidComponents( m->m_encCfg->m_internChromaFormat );
   if( nRefs < 1 || nRefs > 12 || ( unit != 8 && unit != 16 ) || ( numComp == 3 && m->m_encCfg->m_internChromaFormat != CHROMA_420 ) ) return false;
   vvhip::Device& dev = vvhip::Device::get();
-  std::vector<int> orgIds( 3, -1 ), refIds( 3 * nRefs, -1 ), all;
-  auto reg = [&]( const vvenc::CPelBuf& b, int margin ) { const int id = dev.registerPicture( b.buf, ( int ) b.stride, b.width, b.height, margin ); all.push_back( id ); return id; };
-  for( int c = 0; c < numComp; c++ ) orgIds[c] = reg( orgPic.bufs[c], vvenc::MCTF_PADDING >> ( c ? 1 : 0 ) );
-  for( int r = 0; r < nRefs; r++ ) for( int c = 0; c < numComp; c++ ) refIds[3 * r + c] = reg( info[r].picBuffer.bufs[c], vvenc::MCTF_PADDING >> ( c ? 1 : 0 ) );
+  std::vector<int> orgIds( 3, -1 ), refIds( 3 * nRefs, -1 );
+  const bool searchOnDevice = g_vvhipHooks.mctfMe != nullptr;        // then the pictures of this filter call are already resident (and validated by POC)
+  if( !searchOnDevice ) while( !g_resident.empty() ) dropResident( 0 );
+  { const ResidentPic& e = residentPlanes( orgPic, -1, numComp ); for( int c = 0; c < numComp; c++ ) orgIds[c] = e.ids[c]; }
+  for( int r = 0; r < nRefs; r++ ) { const ResidentPic& e = residentPlanes( info[r].picBuffer, -1, numComp ); for( int c = 0; c < numComp; c++ ) refIds[3 * r + c] = e.ids[c]; }
   const int mvW = info[0].mvs.w(), mvH = info[0].mvs.h();
   std::vector<std::vector<vvhip_mv>> mvs( nRefs, std::vector<vvhip_mv>( ( size_t ) mvW * mvH ) );
   std::vector<const vvhip_mv*> mvPtr( nRefs );
@@ -187,7 +241,7 @@ bool mctfApply( const vvenc::MCTF* m, const vvenc::PelStorage& orgPic, void* inf
   for( int c = 0; c < numComp; c++ ) { outs[c] = newOrgPic.bufs[c].buf; strides[c] = ( int ) newOrgPic.bufs[c].stride; }
   g_m->bilateralFilter( orgIds.data(), refIds.data(), nRefs, mvPtr.data(), strengths.data(), m->m_encCfg->m_QP, m->m_encCfg->m_internalBitDepth[0], unit, m->m_lowResFltApply,
                         overallStrength, numComp, outs, strides );
-  for( int id : all ) dev.unregisterPicture( id );
+  if( !searchOnDevice ) while( !g_resident.empty() ) dropResident( 0 );
   g_calls[9]++;
   return true;
 }
@@ -301,18 +355,16 @@ void initIF( vvenc::InterpolationFilter* f )
 }
 
 // whole hierarchical ME of MCTF::motionEstimationMCTF on the GPU; both pictures carry MCTF_PADDING extended margins (MCTF.cpp:608-612)
-bool mctfMe( vvenc::MCTF* m, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel )
+bool mctfMe( vvenc::MCTF* m, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel, int refPoc, int curPoc )
 {
   const vvenc::CPelBuf o = orig.Y(), r = refPic.Y();
   const int w = o.width, h = o.height, unit = m->m_mctfUnitSize;
   if( w < 64 || h < 64 || o.stride != r.stride ) return false;       // below the device entry point's minimum: keep the table-entry path
-  vvhip::Device& dev = vvhip::Device::get();
-  const int idO = dev.registerPicture( o.buf, ( int ) o.stride, w, h, vvenc::MCTF_PADDING );
-  const int idR = dev.registerPicture( r.buf, ( int ) r.stride, w, h, vvenc::MCTF_PADDING );
+  const int idO = residentPlanes( orig, curPoc, 1 ).ids[0];
+  const int idR = residentPlanes( refPic, refPoc, 1 ).ids[0];
   std::vector<vvhip_mv> out( ( size_t ) mvs.w() * mvs.h() );
   vvhip_mv* outs[1] = { out.data() };
   g_m->motionEstimation( idO, &idR, 1, m->m_encCfg->m_internalBitDepth[0], unit, m->m_encCfg->m_vvencMCTF.MCTFSpeed, addLevel, outs );
-  dev.unregisterPicture( idO ); dev.unregisterPicture( idR );
   for( int y = 0; y < mvs.h(); y++ ) for( int x = 0; x < mvs.w(); x++ )
   {
     vvenc::MotionVector& d = mvs.get( x, y ); const vvhip_mv& s = out[( size_t ) y * mvs.w() + x];

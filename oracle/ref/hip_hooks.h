@@ -29,6 +29,6 @@ struct VvhipHooks
   bool ( *dmvrSearch )( const int16_t* ref0, int stride0, int fx0, int fy0, const int16_t* ref1, int stride1, int fx1, int fy1, int cuWidth, int cuHeight, int dx, int dy, int bitDepth,
                         int16_t* mvd, uint64_t* minCost );
   bool ( *mctfApply )( const vvenc::MCTF*, const vvenc::PelStorage& orgPic, void* srcFrameInfoDeque, vvenc::PelStorage& newOrgPic, double overallStrength );
-  bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel );
+  bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel, int refPoc, int curPoc );
 };
 extern VvhipHooks g_vvhipHooks;

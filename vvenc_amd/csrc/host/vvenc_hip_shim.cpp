@@ -30,10 +30,10 @@ void Device::check( int rc, const char* what ) const
   if( rc != VVHIP_OK ) throw Exception( std::string( what ) + ": " + vvhip_last_error( m_ctx ) );
 }
 
-int Device::registerPicture( const Pel* origin, int stride, int width, int height, int margin )
+int Device::registerPicture( const Pel* origin, int stride, int width, int height, int margin, bool findable )
 {
   Mirror m;
-  m.origin = origin; m.stride = stride; m.width = width; m.height = height; m.margin = margin; m.live = true;
+  m.origin = origin; m.stride = stride; m.width = width; m.height = height; m.margin = margin; m.live = true; m.findable = findable;
   m.hostBase = origin - ( ptrdiff_t ) margin * stride - margin;
   const size_t elems = ( size_t ) stride * ( height + 2 * margin );
   m.hostEnd = m.hostBase + elems;
@@ -63,7 +63,7 @@ void Device::unregisterPicture( int id )
 
 const Device::Mirror* Device::find( const Pel* p ) const
 {
-  for( const Mirror& m : m_mirrors ) if( m.live && p >= m.hostBase && p < m.hostEnd ) return &m;
+  for( const Mirror& m : m_mirrors ) if( m.live && m.findable && p >= m.hostBase && p < m.hostEnd ) return &m;
   return nullptr;
 }
 

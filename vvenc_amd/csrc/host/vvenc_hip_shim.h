@@ -82,10 +82,12 @@ public:
   vvhip_ctx* ctx() const { return m_ctx; }
   // Mirror a host plane (sample (0,0) at `origin`, `margin` samples around a w x h picture, line pitch `stride`) in HBM.
   // Re-register (or call updatePicture) after the host changed it (e.g. a reference picture was reconstructed).
-  int  registerPicture( const Pel* origin, int stride, int width, int height, int margin );
+  // findable = false: the mirror is used through its id only and never substituted for host pointers by the per-call table entries
+  // (for pictures whose host buffer may be rewritten while the mirror is kept)
+  int  registerPicture( const Pel* origin, int stride, int width, int height, int margin, bool findable = true );
   void updatePicture( int id );
   void unregisterPicture( int id );
-  struct Mirror { const Pel* hostBase; const Pel* hostEnd; const Pel* origin; int stride, width, height, margin; int16_t* dBase; int16_t* dOrigin; bool live; };
+  struct Mirror { const Pel* hostBase; const Pel* hostEnd; const Pel* origin; int stride, width, height, margin; int16_t* dBase; int16_t* dOrigin; bool live; bool findable; };
   const Mirror* find( const Pel* p ) const;  // which registered picture contains host pointer p (nullptr: none)
   const Mirror& mirror( int id ) const { return m_mirrors.at( id ); }
   void check( int rc, const char* what ) const;
