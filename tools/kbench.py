@@ -28,6 +28,11 @@ for (S, n, d_off, d_qp, lvl, rec, st, _, _) in wl.tu_jobs:
     print("TU fused  S=%2d n=%7d  %8.2f us  alg %7.1f GB/s" % (S, n, us, n * (6 * S * S + 24) / us / 1e3))
     us = timeit(lambda: hp.fwd_transform(wl.resi, d_off, n, S, S))
     print("  fwd only            %8.2f us" % us)
+us = timeit(lambda: hp.tu_rdo_multi(wl.resi, wl.tu_table, wl.bit_depth))
+print("TU merged launch (8+16+32)   %8.2f us" % us)
+for c in ("SAD_SSE", "HAD_fast"):
+    us = timeit(lambda: hp.dist_multi_func(wl.org, wl.ref, wl.fjob_tables[c], wl.bit_depth))
+    print("%-8s merged launch       %8.2f us" % (c, us))
 # host overhead of a whole step
 t0 = time.perf_counter()
 for _ in range(200): wl.run()

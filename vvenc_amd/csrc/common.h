@@ -16,6 +16,8 @@ struct vvhip_ctx
   // ROM in HBM (uploaded once by vvhip_create)
   int16_t*     d_trMat    = nullptr;   // all transform matrices, see trMatOffset()
   uint16_t*    d_scan     = nullptr;   // grouped diagonal scan orders, see scanOffset()
+  struct VvhipTuMxOps* d_tuMx = nullptr;   // matrix-core operand records of the fused TU kernel: [type][size 8,16,32], see VvhipTuMxOps
+  uint16_t*    d_tuMxPos  = nullptr;   // scan position of every (lane, register) of a 32x32 tile, per size: [3][64][16]
   // scratch for vvhip_mctf_motion_estimation (grown on demand)
   void*        d_scratch  = nullptr;
   size_t       scratchBytes = 0;
@@ -49,6 +51,25 @@ static inline __host__ __device__ int scanOffset( int log2w, int log2h )
   return ( ( 1 << log2w ) - 1 ) * 127 + ( 1 << log2w ) * ( ( 1 << log2h ) - 1 );
 }
 static const int kScanTotal = 127 * 127;
+
+// ---- matrix-core operands of the fused TU kernel (trquant.hip, tuMx*) ---------------------------------------------------------
+// A 32x32 tile holds (32/N)^2 TUs of size N side by side; "big" is the block-diagonal 32x32 matrix of 32/N copies of the N-point kernel
+// matrix (all entries fit 8 bits).  v_mfma_i32_32x32x32_i8 takes 16 bytes per lane for each operand: lane l = 32*h + r supplies row r (A) /
+// column r (B) and K-slots (h, 0..15); result register v of lane l holds row mxHw(h, v), column r.  The data operand of every pass is the
+// previous pass's result registers (slot s = register s), so the matrix operand's K-slot (h, s) is bound to index mxHw(h, s); and the
+// A-side matrices supply their rows in the order mxSigma, which makes result register (h, v) hold logical row 16h + v — a lane's 16
+// registers are 16 consecutive rows of ONE column: one 16-point TU, two 8-point TUs or half a 32-point TU.
+static inline __host__ __device__ int mxHw( int h, int s ) { return 8 * ( s >> 2 ) + 4 * h + ( s & 3 ); }
+static inline __host__ __device__ int mxSigma( int i )     { return 16 * ( ( i >> 2 ) & 1 ) + 4 * ( i >> 3 ) + ( i & 3 ); }   // mxSigma( mxHw( h, v ) ) == 16h + v
+struct VvhipTuMxOps
+{
+  int8_t  nat[64][16];         // B side, forward rows:     lane l: big[l % 32][16h + s]                   (data slots = samples 16h + s of the lane's row)
+  int8_t  rowP[64][16];        // A side, forward columns:  lane l: big[mxSigma(l % 32)][mxHw(h, s)]
+  int8_t  natT[64][16];        // B side, inverse columns:  lane l: big[16h + s][l % 32]
+  int8_t  colP[64][16];        // A side, inverse rows:     lane l: big[mxHw(h, s)][mxSigma(l % 32)]
+  int32_t rowSum[32];          // 128 * sum_x big[r][x]: corrections for the (byte - 128) form of the data's low bytes
+  int32_t colSum[32];          // 128 * sum_k big[k][c]
+};
 
 void vvhip_build_tr_matrix( int trType, int log2N, int16_t* out );          // host
 void vvhip_build_scan_order( int log2w, int log2h, uint32_t* out );         // host

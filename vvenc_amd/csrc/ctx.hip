@@ -149,6 +149,47 @@ int vvhip_create( vvhip_ctx** out, int device )
       uint16_t* dst = scans.data() + scanOffset( lw, lh );
       for( int i = 0; i < ( 1 << ( lw + lh ) ); i++ ) dst[i] = ( uint16_t ) tmp[i];
     }
+  // matrix-core operand records (common.h: VvhipTuMxOps) and per-register scan positions for 8-, 16- and 32-point square TUs
+  std::vector<VvhipTuMxOps> mx( 9 );
+  std::vector<uint16_t> mxPos( 3 * 64 * 16 );
+  for( int z = 0; z < 3; z++ )
+  {
+    const int l2 = 3 + z, n = 1 << l2;
+    for( int t = 0; t < 3; t++ )
+    {
+      const int16_t* m = mats.data() + trMatOffset( t, l2 );
+      auto big = [&]( int r, int c ) -> int { return ( r / n == c / n ) ? m[( r % n ) * n + ( c % n )] : 0; };
+      VvhipTuMxOps& o = mx[t * 3 + z];
+      for( int r = 0; r < 32; r++ )
+      {
+        int rs = 0, cs = 0;
+        for( int c = 0; c < 32; c++ )
+        {
+          if( big( r, c ) < -128 || big( r, c ) > 127 ) return vvhip_fail( nullptr, VVHIP_E_HIP, "vvhip_create: transform matrix entry outside 8 bits" );
+          rs += big( r, c ); cs += big( c, r );
+        }
+        o.rowSum[r] = 128 * rs; o.colSum[r] = 128 * cs;
+      }
+      for( int l = 0; l < 64; l++ )
+        for( int k = 0; k < 16; k++ )
+        {
+          const int h = l / 32, r = l % 32;
+          o.nat[l][k]  = ( int8_t ) big( r, 16 * h + k );
+          o.rowP[l][k] = ( int8_t ) big( mxSigma( r ), mxHw( h, k ) );
+          o.natT[l][k] = ( int8_t ) big( 16 * h + k, r );
+          o.colP[l][k] = ( int8_t ) big( mxHw( h, k ), mxSigma( r ) );
+        }
+    }
+    const uint16_t* sc = scans.data() + scanOffset( l2, l2 );          // scan position -> raster position
+    std::vector<uint16_t> inv( n * n );
+    for( int i = 0; i < n * n; i++ ) inv[sc[i]] = ( uint16_t ) i;
+    for( int l = 0; l < 64; l++ )
+      for( int v = 0; v < 16; v++ ) mxPos[( z * 64 + l ) * 16 + v] = inv[( ( 16 * ( l / 32 ) + v ) % n ) * n + ( l % 32 ) % n];
+  }
+  VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_tuMx, mx.size() * sizeof( VvhipTuMxOps ) ) );
+  VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_tuMxPos, mxPos.size() * sizeof( uint16_t ) ) );
+  VVHIP_CHECK_HIP( nullptr, hipMemcpy( ctx->d_tuMx, mx.data(), mx.size() * sizeof( VvhipTuMxOps ), hipMemcpyHostToDevice ) );
+  VVHIP_CHECK_HIP( nullptr, hipMemcpy( ctx->d_tuMxPos, mxPos.data(), mxPos.size() * sizeof( uint16_t ), hipMemcpyHostToDevice ) );
   VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_trMat, mats.size() * sizeof( int16_t ) ) );
   VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_scan, scans.size() * sizeof( uint16_t ) ) );
   VVHIP_CHECK_HIP( nullptr, hipMemcpy( ctx->d_trMat, mats.data(), mats.size() * sizeof( int16_t ), hipMemcpyHostToDevice ) );
@@ -164,6 +205,8 @@ void vvhip_destroy( vvhip_ctx* ctx )
   if( ctx->ownStream ) ( void ) hipStreamSynchronize( ctx->ownStream );
   if( ctx->d_trMat ) ( void ) hipFree( ctx->d_trMat );
   if( ctx->d_scan ) ( void ) hipFree( ctx->d_scan );
+  if( ctx->d_tuMx ) ( void ) hipFree( ctx->d_tuMx );
+  if( ctx->d_tuMxPos ) ( void ) hipFree( ctx->d_tuMxPos );
   if( ctx->d_scratch ) ( void ) hipFree( ctx->d_scratch );
   if( ctx->d_subpel ) ( void ) hipFree( ctx->d_subpel );
   if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );

@@ -26,6 +26,7 @@
 // of statistics per TU crosses HBM in the fused kernel.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -861,6 +862,367 @@ tuRdoRowMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMultiJo
   else                          tuRdoRowBody<8, 1>( smem, blk, resi, resiStride, jobs.j[k] );
 }
 
+
+// --------------------------------------------------------------------------------------------
+// Fused TU pipeline on the matrix cores, square N x N TUs (N = 8, 16, 32): ONE wavefront per 32x32 tile of (32/N)^2 TUs.
+// Every 1-D pass is a 32x32x32 integer matrix product (v_mfma_i32_32x32x32_i8).  The kernel matrices are 8-bit; the 16-bit data operand
+// is split into its high byte and (low byte - 128), two products per pass, recombined as (hi << 8) + lo with the 128 * sum(matrix row)
+// correction and the rounding offset preloaded into the accumulator.  All sums are exact (|sum| <= 32 * 2^15 * 90 < 2^31), so the
+// results equal the dot-product kernels above bit for bit.  For N < 32 the matrices are block-diagonal (common.h: VvhipTuMxOps).
+// The four passes alternate the side the data sits on, and the K-slots of the operands are bound to the rows a lane's result registers
+// hold (mxIdx), so results feed the next pass from the lane's own registers — no LDS transpose, no cross-lane traffic between passes:
+//   residual (A: lane = row y, slots x)         x  Th   (B)  ->  D1: lane = hor. frequency k, registers = y
+//   Tv (A)   x  D1 (B: lane = k, slots y)                    ->  D2: lane = k, registers = ver. frequency k2     = coefficients
+//   QuantCore / DeQuantCore on the 16 registers; significance / abs-sum by DPP over the TU's lanes
+//   dequantised (A: lane = k, slots k2)         x  Tv^T (B)  ->  D3: lane = y, registers = k
+//   Th^T (A) x  D3 (B: lane = y, slots k)                    ->  D4: lane = y, registers = x   = reconstruction, same layout as the input
+// LDS is used only to turn the level registers into 16-byte raster stores.  Waves are independent (no workgroup barrier).
+// --------------------------------------------------------------------------------------------
+typedef int v4i  __attribute__( ( ext_vector_type( 4 ) ) );
+typedef int v16i __attribute__( ( ext_vector_type( 16 ) ) );
+
+struct TuMxArgs
+{
+  const int32_t* resiOff; int n;
+  int shF1, shF2, shI1, shI2, skipW, skipH;
+  QGeom q;
+  const VvhipTuMxOps* opH; const VvhipTuMxOps* opV; const uint16_t* pos;
+  const vvhip_tu_qp* qps; int thrVal;
+  int16_t* level; int16_t* rec; vvhip_tu_stats* stats;
+  int tiles;               // 32x32 tiles of this job
+  int phaseLimit;          // profiling aid ($VVHIP_TU_PHASES): skip the rest of a tile after phase k, 0 = run everything
+  int waveStride;          // waves assigned to this job (wave w walks tiles w, w + waveStride, ...)
+};
+
+// 16 values of 16-bit range -> the two byte operands (slot s = register s): low bytes - 128 (xor 0x80) and high bytes
+__device__ __forceinline__ void mxSplit( const int* d, v4i& lo, v4i& hi )
+{
+#pragma unroll
+  for( int g = 0; g < 4; g++ )
+  {
+    const uint32_t p01 = __builtin_amdgcn_perm( ( uint32_t ) d[4 * g + 1], ( uint32_t ) d[4 * g], 0x05040100u );
+    const uint32_t p23 = __builtin_amdgcn_perm( ( uint32_t ) d[4 * g + 3], ( uint32_t ) d[4 * g + 2], 0x05040100u );
+    lo[g] = ( int ) ( __builtin_amdgcn_perm( p23, p01, 0x06040200u ) ^ 0x80808080u );
+    hi[g] = ( int ) __builtin_amdgcn_perm( p23, p01, 0x07050301u );
+  }
+}
+
+// quantiser constants of one TU from its QP (Quant.cpp:775, :874, :173-180, :561, :601-606); the scale tables as select chains (no memory)
+struct TuMxQ { int scale, qBits, thres, iscale, rightShift, inMax; long long addQ, addN; };
+__device__ __forceinline__ int tuMxSel6( int r, int a0, int a1, int a2, int a3, int a4, int a5 )
+{
+  return r == 0 ? a0 : r == 1 ? a1 : r == 2 ? a2 : r == 3 ? a3 : r == 4 ? a4 : a5;
+}
+__device__ __forceinline__ TuMxQ tuMxParams( const QGeom& q, const vvhip_tu_qp qq, const int thrVal )
+{
+  TuMxQ P;
+  const int per = qq.qp / 6, rem = qq.qp - 6 * per;
+  const int trShift = 15 - q.bitDepth - q.log2w;                                              // square TU: no sqrt2 scaling
+  P.scale = tuMxSel6( rem, 26214, 23302, 20560, 18396, 16384, 14564 );                        // Rom.cpp:1390
+  P.iscale = tuMxSel6( rem, 40, 45, 51, 57, 64, 72 );                                         // Rom.cpp:1396
+  P.qBits = 14 + per + trShift;
+  P.addQ = ( long long ) ( ( qq.flags & 1 ) ? 171 : 85 ) << ( P.qBits - 9 );
+  P.addN = ( long long ) ( ( qq.flags & 2 ) ? 171 : 256 ) << ( P.qBits - 9 );
+  P.thres = P.qBits ? ( int32_t ) ( ( int64_t ) thrVal << ( P.qBits - 1 ) ) : ( int32_t ) ( ( int64_t ) ( thrVal >> 1 ) << P.qBits );
+  P.rightShift = 6 - ( trShift + per );
+  int tgt = 32 + P.rightShift - 7; if( tgt > 16 ) tgt = 16;
+  P.inMax = ( 1 << ( tgt - 1 ) ) - 1;
+  return P;
+}
+
+// 16 pre-saturation values -> byte operands of sat16( value ): v_cvt_pk_i16_i32 saturates and packs two values per instruction
+typedef short s16x2v __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ void mxSplitSat( const int* d, v4i& lo, v4i& hi )
+{
+#pragma unroll
+  for( int g = 0; g < 4; g++ )
+  {
+    const uint32_t p01 = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( d[4 * g], d[4 * g + 1] ) );
+    const uint32_t p23 = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( d[4 * g + 2], d[4 * g + 3] ) );
+    lo[g] = ( int ) ( __builtin_amdgcn_perm( p23, p01, 0x06040200u ) ^ 0x80808080u );
+    hi[g] = ( int ) __builtin_amdgcn_perm( p23, p01, 0x07050301u );
+  }
+}
+
+template<int N>
+__device__ __forceinline__ void
+tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, const int waveIndex, const int16_t* __restrict__ resi, const int resiStride, const TuMxArgs& A )
+{
+  // A lane's 16 registers are 16 consecutive rows (coefficient side) / samples (residual side) 16h .. 16h+15 of its column / row:
+  // R TUs per lane with VPR registers each; a TU's lanes are G consecutive lanes (N = 32: the same 32 lanes of both halves).
+  constexpr int TPS = 32 / N, TPT = TPS * TPS, R = N == 8 ? 2 : 1, VPR = 16 / R, G = N == 32 ? 64 : N;
+  constexpr int LP = 40;                                              // staging pitch (int16): rows 80 bytes apart
+  struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+  const int lane = threadIdx.x & 63, h = lane >> 5, c32 = lane & 31;
+  const int blkL = c32 / N, inL = c32 % N;                            // the lane's row (residual side) / column (coefficient side): TU block, index inside
+  const int blk0 = N == 32 ? 0 : N == 16 ? h : 2 * h;                 // first TU block along the register direction
+  const v16i zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+#define TUMX_KEEP( ARR ) { int k_ = 0; _Pragma( "unroll" ) for( int v = 0; v < 16; v++ ) k_ ^= ARR[v]; if( k_ == 0x12345678 ) A.stats[0].pad = 1; }   /* phase profiling: keeps the values live */
+
+  // ---- per-wave constants.  The zero-out of the 32-point DST-7 / DCT-8 (coefficients beyond 16 dropped, TrQuant.cpp:496-497) is folded
+  // into the operands: a dead column k gets an all-zero Th operand (its intermediate becomes 0), a dead row k2 an all-zero Tv operand row;
+  // with the correction dropped as well the result is ( rnd >> shift ) = 0.
+  const int rndF1 = A.shF1 > 0 ? 1 << ( A.shF1 - 1 ) : 0, rndF2 = 1 << ( A.shF2 - 1 ), rndI1 = 1 << ( A.shI1 - 1 ), rndI2 = 1 << ( A.shI2 - 1 );
+  const bool liveCol = inL < N - A.skipW, liveRow = mxSigma( c32 ) % N < N - A.skipH;
+  const v4i zero4 = { 0, 0, 0, 0 };
+  const v4i opP1 = liveCol ? *reinterpret_cast<const v4i*>( A.opH->nat[lane] ) : zero4;
+  const v4i opP2 = liveRow ? *reinterpret_cast<const v4i*>( A.opV->rowP[lane] ) : zero4;
+  const v4i opI1 = *reinterpret_cast<const v4i*>( A.opV->natT[lane] ), opI2 = *reinterpret_cast<const v4i*>( A.opH->colP[lane] );
+  const int cP1 = ( liveCol ? A.opH->rowSum[c32] : 0 ) + rndF1, cI1 = A.opV->colSum[c32] + rndI1;
+  // accumulator preloads of the two passes whose matrix sits on the A side (they depend on the result register = logical row 16h + v): LDS
+  sInit[c32]      = ( c32 % N < N - A.skipH ? A.opV->rowSum[c32] : 0 ) + rndF2;
+  sInit[32 + c32] = A.opH->colSum[c32] + rndI2;
+  uint32_t pos[16];
+  {
+    const u32x4 p0 = *reinterpret_cast<const u32x4*>( A.pos + lane * 16 ), p1 = *reinterpret_cast<const u32x4*>( A.pos + lane * 16 + 8 );
+    const uint32_t pw[8] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w };
+#pragma unroll
+    for( int v = 0; v < 16; v++ ) pos[v] = ( v & 1 ) ? pw[v >> 1] >> 16 : pw[v >> 1] & 0xffffu;
+  }
+  WAVE_SYNC();
+  if( A.phaseLimit == 1 ) return;
+
+  for( int tile = waveIndex; tile < A.tiles; tile += A.waveStride )
+  {
+    // ---- residual: lane = row Y of the tile, samples X = 16h .. 16h+15 (the K-slots of this lane) as two 16-byte runs
+    uint32_t xr[8];
+    v4i aLo, aHi;
+#pragma unroll
+    for( int c = 0; c < 2; c++ )
+    {
+      const int X0 = 16 * h + 8 * c;
+      const int tu = tile * TPT + blkL * TPS + X0 / N;
+      u32x4 v = { 0, 0, 0, 0 };
+      if( tu < A.n ) v = reinterpret_cast<const U16*>( resi + A.resiOff[tu] + ( ptrdiff_t ) inL * resiStride + X0 % N )->v;
+      xr[4 * c] = v.x; xr[4 * c + 1] = v.y; xr[4 * c + 2] = v.z; xr[4 * c + 3] = v.w;
+    }
+#pragma unroll
+    for( int g = 0; g < 4; g++ )
+    {
+      aLo[g] = ( int ) ( __builtin_amdgcn_perm( xr[2 * g + 1], xr[2 * g], 0x06040200u ) ^ 0x80808080u );
+      aHi[g] = ( int ) __builtin_amdgcn_perm( xr[2 * g + 1], xr[2 * g], 0x07050301u );
+    }
+    vvhip_tu_qp qqs[R];                                               // QPs of the lane's TUs on the coefficient side: column block blkL, row blocks blk0 + r
+#pragma unroll
+    for( int r = 0; r < R; r++ ) { const int tu = tile * TPT + ( blk0 + r ) * TPS + blkL; qqs[r] = tu < A.n ? A.qps[tu] : vvhip_tu_qp{ 32, 0 }; }
+    if( A.phaseLimit == 2 ) { int k_ = 0; _Pragma( "unroll" ) for( int g = 0; g < 4; g++ ) k_ ^= aLo[g] ^ aHi[g]; if( k_ == 0x12345678 ) A.stats[0].pad = 1; continue; }
+
+    int d[16];
+    v4i bLo, bHi;
+    // ---- forward rows: tmp[y][k] = sat16( ( sum_x blk[y][x] * Th[k][x] + rnd ) >> shift1 )                 (TrQuant.cpp:548)
+    {
+      v16i c;
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) c[v] = cP1;
+      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, opP1, c, 0, 0, 0 );
+      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, opP1, zero16, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shF1;
+      mxSplitSat( d, bLo, bHi );
+    }
+    // ---- forward columns: coef[k2][k] = ( sum_y Tv[k2][y] * tmp[y][k] + rnd ) >> shift2                      (TrQuant.cpp:549)
+    {
+      v16i c;
+#pragma unroll
+      for( int g = 0; g < 4; g++ ) { const v4i t = *reinterpret_cast<const v4i*>( &sInit[h * 16 + 4 * g] ); c[4 * g] = t.x; c[4 * g + 1] = t.y; c[4 * g + 2] = t.z; c[4 * g + 3] = t.w; }
+      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( opP2, bLo, c, 0, 0, 0 );
+      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( opP2, bHi, zero16, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shF2;
+    }
+    if( A.phaseLimit == 3 ) { TUMX_KEEP( d ); continue; }
+
+    // ---- per TU: significance, QuantCore, DeQuantCore on the registers (the lane's TUs are walked in lockstep: their reduction chains overlap).
+    // Significance: last non-zero scan position; largest magnitude (need-RDOQ is one test on it: the quantiser is monotonic); highest scan
+    // position >= 16 whose magnitude passes the coefficient-group threshold |c| > thres / (4 * scale)  <=>  |c| * scale > thres >> 2 (such a
+    // coefficient is non-zero, hence <= last).  The product is the one the level needs anyway (24-bit multiply while |c| < 2^16; larger
+    // magnitudes take the 64-bit path and redo the test there)                                             (Quant.cpp:162-208, :264-278)
+    uint32_t last[R], need[R], big[R];
+    bool wide = false;
+#pragma unroll
+    for( int r = 0; r < R; r++ )
+    {
+      const TuMxQ P = tuMxParams( A.q, qqs[r], A.thrVal );
+      uint32_t l = 0, mx = 0, bg = 0;
+      const int thr4 = P.thres >> 2;
+#pragma unroll
+      for( int v = r * VPR; v < ( r + 1 ) * VPR; v++ )
+      {
+        const uint32_t ac = ( uint32_t ) abs( d[v] );
+        mx = ac > mx ? ac : mx;
+        l = ( ac != 0 && pos[v] > l ) ? pos[v] : l;
+        bg = ( ( int ) __umul24( ac, ( uint32_t ) P.scale ) > thr4 && pos[v] > bg ) ? pos[v] : bg;
+      }
+      l = vvhipGroupMax32( l, G, lane ); mx = vvhipGroupMax32( mx, G, lane ); bg = vvhipGroupMax32( bg, G, lane );
+      need[r] = ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) mx * P.scale + P.addN ) >> P.qBits ) != 0 );
+      wide |= mx >= 65536u || P.qBits > 30;
+      last[r] = l; big[r] = bg;
+    }
+    const bool narrow = __builtin_amdgcn_ballot_w64( wide ) == 0ull;
+    if( !narrow )
+#pragma unroll
+      for( int r = 0; r < R; r++ )
+      {
+        const TuMxQ P = tuMxParams( A.q, qqs[r], A.thrVal );
+        uint32_t bg = 0;
+#pragma unroll
+        for( int v = r * VPR; v < ( r + 1 ) * VPR; v++ )
+          bg = ( ( long long ) abs( d[v] ) * ( P.scale << 2 ) > ( long long ) P.thres && pos[v] > bg ) ? pos[v] : bg;
+        big[r] = vvhipGroupMax32( bg, G, lane );
+      }
+#pragma unroll
+    for( int r = 0; r < R; r++ )
+      if( last[r] >= 16 )
+      {
+        if( big[r] < 16 ) last[r] = 15;
+        else if( ( big[r] >> 4 ) != ( last[r] >> 4 ) ) last[r] = ( big[r] >> 4 ) * 16 + 15;
+      }
+    if( A.phaseLimit == 4 ) { TUMX_KEEP( d ); continue; }
+    // levels -> staging tile (raster), dequantised values replace the coefficients.  When every |c| fits 16 bits the level is a 24-bit
+    // multiply-add in 32 bits (|c| * scale < 2^31, add < 2^29.5); otherwise the 64-bit form.  DeQuantCore's two shift directions are one
+    // formula: a left shift is folded into the multiplier, a right shift carries its rounding offset.                (Quant.cpp:213-262)
+    uint32_t absSum[R];
+#define TUMX_LEVELS( MEXPR )                                                                                                           \
+    _Pragma( "unroll" ) for( int r = 0; r < R; r++ )                                                                                   \
+    {                                                                                                                                  \
+      const TuMxQ P = tuMxParams( A.q, qqs[r], A.thrVal );                                                                             \
+      uint32_t sum = 0;                                                                                                                \
+      const uint32_t add32 = ( uint32_t ) P.addQ; ( void ) add32;                                                                      \
+      const int rsPos = P.rightShift > 0 ? P.rightShift : 0, rndDq = P.rightShift > 0 ? 1 << ( P.rightShift - 1 ) : 0;                \
+      const int iscaleL = P.rightShift < 0 ? P.iscale << ( -P.rightShift ) : P.iscale;                                                 \
+      _Pragma( "unroll" ) for( int v = r * VPR; v < ( r + 1 ) * VPR; v++ )                                                             \
+      {                                                                                                                                \
+        const int cv = d[v];                                                                                                           \
+        const uint32_t ac = ( uint32_t ) abs( cv );                                                                                    \
+        uint32_t m = MEXPR;                                                                                                            \
+        m = pos[v] <= last[r] ? m : 0u;                                                                                                \
+        sum += m;                                                                                                                      \
+        const int sm = cv < 0 ? -( int32_t ) m : ( int32_t ) m;                                                                        \
+        const int lv = clip3i( -32768, 32767, sm );                                                                                    \
+        stage[( 16 * h + v ) * LP + c32] = ( int16_t ) lv;                                                                             \
+        const int cl = clip3i( -( P.inMax + 1 ), P.inMax, lv );                                                                        \
+        const int32_t w_ = ( int32_t ) ( ( uint32_t ) __mul24( cl, iscaleL ) + ( uint32_t ) rndDq ) >> rsPos;   /* |cl| < 2^15, multiplier < 2^23 */ \
+        d[v] = clip3i( -32768, 32767, w_ );                                                                                            \
+      }                                                                                                                                \
+      absSum[r] = sum;                                                                                                                 \
+    }
+    if( narrow ) { TUMX_LEVELS( ( ( uint32_t ) __umul24( ac, ( uint32_t ) P.scale ) + add32 ) >> P.qBits ) }
+    else         { TUMX_LEVELS( ( uint32_t ) ( int32_t ) ( ( ( int64_t ) ac * P.scale + P.addQ ) >> P.qBits ) ) }
+#undef TUMX_LEVELS
+#pragma unroll
+    for( int r = 0; r < R; r++ )
+    {
+      const uint32_t sum = vvhipGroupSum32( absSum[r], G, lane );
+      const int tu = tile * TPT + ( blk0 + r ) * TPS + blkL;
+      if( A.stats && ( N < 32 || h == 0 ) && inL == r && tu < A.n )
+      {
+        int32_t* st = reinterpret_cast<int32_t*>( A.stats + tu );
+        st[0] = ( int32_t ) sum; st[1] = ( int32_t ) last[r]; st[2] = ( int32_t ) need[r]; st[3] = 0;
+      }
+    }
+    if( A.phaseLimit == 5 ) { TUMX_KEEP( d ); continue; }
+    WAVE_SYNC();
+    // ---- levels: staging rows -> raster, 16-byte stores (chunk q: row q / 4 of the tile, samples 8 * (q % 4) ..)
+    if( A.level )
+#pragma unroll
+      for( int u = 0; u < 2; u++ )
+      {
+        const int q = lane + 64 * u, Y = q >> 2, X = 8 * ( q & 3 );
+        const int tu = tile * TPT + ( Y / N ) * TPS + X / N;
+        if( tu < A.n ) *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * N * N + ( Y % N ) * N + X % N ) = *reinterpret_cast<const u32x4*>( &stage[Y * LP + X] );
+      }
+    WAVE_SYNC();
+
+    if( A.phaseLimit == 6 ) { TUMX_KEEP( d ); continue; }
+    // ---- inverse columns: t1[y][k] = clip( ( sum_k2 deq[k2][k] * Tv[k2][y] + 64 ) >> 7 )                  (TrQuant.cpp:612)
+    mxSplit( d, aLo, aHi );
+    {
+      v16i c;
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) c[v] = cI1;
+      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, opI1, c, 0, 0, 0 );
+      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, opI1, zero16, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shI1;
+      mxSplitSat( d, bLo, bHi );
+    }
+    // ---- inverse rows: rec[y][x] = clip( ( sum_k t1[y][k] * Th[k][x] + rnd ) >> shift2 ); SSE against the residual (re-read: L2 hit, issued
+    // ahead of the matrix products — cheaper than holding 8 registers through the quantiser)                                  (:613)
+    uint32_t xr2[8];
+#pragma unroll
+    for( int c = 0; c < 2; c++ )
+    {
+      const int X0 = 16 * h + 8 * c;
+      const int tu = tile * TPT + blkL * TPS + X0 / N;
+      u32x4 v = { 0, 0, 0, 0 };
+      if( tu < A.n ) v = reinterpret_cast<const U16*>( resi + A.resiOff[tu] + ( ptrdiff_t ) inL * resiStride + X0 % N )->v;
+      xr2[4 * c] = v.x; xr2[4 * c + 1] = v.y; xr2[4 * c + 2] = v.z; xr2[4 * c + 3] = v.w;
+    }
+    {
+      v16i c;
+#pragma unroll
+      for( int g = 0; g < 4; g++ ) { const v4i t = *reinterpret_cast<const v4i*>( &sInit[32 + h * 16 + 4 * g] ); c[4 * g] = t.x; c[4 * g + 1] = t.y; c[4 * g + 2] = t.z; c[4 * g + 3] = t.w; }
+      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( opI2, bLo, c, 0, 0, 0 );
+      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( opI2, bHi, zero16, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shI2;
+    }
+    if( A.phaseLimit == 7 ) { TUMX_KEEP( d ); continue; }
+    unsigned long long sse[R];
+#pragma unroll
+    for( int r = 0; r < R; r++ ) sse[r] = 0;
+#pragma unroll
+    for( int c = 0; c < 2; c++ )
+    {
+      const int X0 = 16 * h + 8 * c;
+      const int tu = tile * TPT + blkL * TPS + X0 / N;
+      uint32_t rp[4];
+#pragma unroll
+      for( int k = 0; k < 4; k++ )
+      {
+        const int v = 8 * c + 2 * k;
+        rp[k] = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( d[v], d[v + 1] ) );           // saturate + pack
+        const int e0 = ( int ) ( int16_t ) ( xr2[4 * c + k] & 0xffff ) - ( int ) ( int16_t ) ( rp[k] & 0xffff ), e1 = ( ( int ) xr2[4 * c + k] >> 16 ) - ( ( int ) rp[k] >> 16 );
+        sse[R == 2 ? c : 0] += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 );
+      }
+      if( A.rec && tu < A.n )
+      {
+        u32x4 v; v.x = rp[0]; v.y = rp[1]; v.z = rp[2]; v.w = rp[3];
+        *reinterpret_cast<u32x4*>( A.rec + ( size_t ) tu * N * N + inL * N + X0 % N ) = v;
+      }
+    }
+#pragma unroll
+    for( int r = 0; r < R; r++ )
+    {
+      const unsigned long long t = vvhipGroupSum64( sse[r], G, lane );
+      const int tu = tile * TPT + blkL * TPS + blk0 + r;
+      if( A.stats && ( N < 32 || h == 0 ) && inL == r && tu < A.n ) A.stats[tu].sse = t;
+    }
+  }
+#undef WAVE_SYNC
+#undef TUMX_KEEP
+}
+
+struct TuMxJobs { int nJobs; int waveStart[4]; int size[4]; TuMxArgs j[4]; };
+
+__global__ void __launch_bounds__( 256, 3 )      // <= 168 registers: three waves per SIMD, their memory latencies overlap
+tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t stage[4][32 * 40];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t sInit[4][64];
+  const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) );
+  const int wave = blockIdx.x * 4 + wv;
+  int k = 0;
+#pragma unroll
+  for( int i = 1; i < 4; i++ ) if( i < jobs.nJobs && wave >= jobs.waveStart[i] ) k = i;
+  const int w = wave - jobs.waveStart[k];
+  if( w >= jobs.j[k].waveStride ) return;
+  if( jobs.size[k] == 32 )      tuMxBody<32>( stage[wv], sInit[wv], w, resi, resiStride, jobs.j[k] );
+  else if( jobs.size[k] == 16 ) tuMxBody<16>( stage[wv], sInit[wv], w, resi, resiStride, jobs.j[k] );
+  else                          tuMxBody<8>( stage[wv], sInit[wv], w, resi, resiStride, jobs.j[k] );
+}
+
 __global__ void __launch_bounds__( 256 )
 dequantCoreKernel( int maxX, int maxY, int scale, const int16_t* __restrict__ q, size_t qStride, int32_t* __restrict__ coef, int rightShift, int inMax, int32_t trMax )
 {
@@ -1007,6 +1369,8 @@ cpyCoeffKernel( const int16_t* __restrict__ src, ptrdiff_t stride, int32_t* __re
 
 } // namespace
 
+// fused square-TU kernel: 0 = matrix cores (default), 1 = dot-product row kernel ($VVHIP_TU_KERNEL=row)
+static int tuKernelForm() { static const int v = getenv( "VVHIP_TU_KERNEL" ) && !strcmp( getenv( "VVHIP_TU_KERNEL" ), "row" ) ? 1 : 0; return v; }
 static int tuRepeat() { static const int v = getenv( "VVHIP_TU_REPEAT" ) ? atoi( getenv( "VVHIP_TU_REPEAT" ) ) : 2; return v < 1 ? 1 : v; }     // groups per workgroup
 static int tuPhaseLimit() { static const int v = getenv( "VVHIP_TU_PHASES" ) ? atoi( getenv( "VVHIP_TU_PHASES" ) ) : 0; return v; }
 
@@ -1160,7 +1524,32 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
       mj.nJobs++;
     }
     for( int i = mj.nJobs; i < 4; i++ ) { mj.blockStart[i] = 0x7fffffff; mj.size[i] = 0; }
-    hipLaunchKernelGGL( tuRdoRowMultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, mj );
+    if( tuKernelForm() == 0 )
+    {
+      // matrix-core form: one wave per 32x32 tile of (32/N)^2 TUs
+      TuMxJobs xj; xj.nJobs = mj.nJobs;
+      long waves = 0;
+      for( int i = 0; i < mj.nJobs; i++ )
+      {
+        const vvhip_tu_job& jb = jobs[order[first + i]];
+        const TuRowArgs& ra = mj.j[i];
+        TuMxArgs& xa = xj.j[i];
+        const int z = ra.gf.log2w - 3, tpt = ( 32 / jb.width ) * ( 32 / jb.width );
+        xa.resiOff = jb.d_resi_off; xa.n = jb.n;
+        xa.shF1 = ra.gf.shift1; xa.shF2 = ra.gf.shift2; xa.shI1 = ra.gi.shift1; xa.shI2 = ra.gi.shift2; xa.skipW = ra.gf.skipW; xa.skipH = ra.gf.skipH;
+        xa.q = ra.q;
+        xa.opH = ctx->d_tuMx + jb.tr_hor * 3 + z; xa.opV = ctx->d_tuMx + jb.tr_ver * 3 + z; xa.pos = ctx->d_tuMxPos + z * 64 * 16;
+        xa.qps = jb.d_qp; xa.thrVal = jb.thr_val; xa.level = jb.d_level; xa.rec = jb.d_rec_resi; xa.stats = jb.d_stats;
+        xa.tiles = ( jb.n + tpt - 1 ) / tpt; xa.phaseLimit = tuPhaseLimit();
+        xa.waveStride = ( xa.tiles + tuRepeat() - 1 ) / tuRepeat();
+        xj.waveStart[i] = ( int ) waves; xj.size[i] = jb.width;
+        waves += xa.waveStride;
+      }
+      for( int i = mj.nJobs; i < 4; i++ ) { xj.waveStart[i] = 0x7fffffff; xj.size[i] = 0; }
+      hipLaunchKernelGGL( tuMxMultiKernel, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
+    }
+    else
+      hipLaunchKernelGGL( tuRdoRowMultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, mj );
     VVHIP_LAUNCH_CHECK( ctx );
   }
   return VVHIP_OK;
@@ -1241,6 +1630,12 @@ int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_batch: unsupported %dx%d types (%d,%d) bitDepth %d", width, height, tr_hor, tr_ver, bit_depth );
   if( n == 0 ) return VVHIP_OK;
   const int area = width * height;
+  if( width == height && ( width == 8 || width == 16 || width == 32 ) && !getenv( "VVHIP_TU_GENERIC" ) && tuKernelForm() == 0 )
+  {
+    vvhip_tu_job jb; jb.width = width; jb.height = height; jb.tr_hor = tr_hor; jb.tr_ver = tr_ver; jb.n = n; jb.thr_val = thr_val;
+    jb.d_resi_off = d_resi_off; jb.d_qp = d_qp; jb.d_level = d_level; jb.d_rec_resi = d_rec_resi; jb.d_stats = d_stats;
+    return vvhip_tu_rdo_multi( ctx, d_resi, resi_stride, bit_depth, &jb, 1 );
+  }
   if( width == height && ( width == 8 || width == 16 || width == 32 ) && !getenv( "VVHIP_TU_GENERIC" ) )
   {
     const int16_t* mh = ctx->d_trMat + trMatOffset( tr_hor, gf.log2w );
