@@ -946,7 +946,7 @@ __device__ __forceinline__ void mxSplitSat( const int* d, v4i& lo, v4i& hi )
 
 template<int N>
 __device__ __forceinline__ void
-tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, const int waveIndex, const int16_t* __restrict__ resi, const int resiStride, const TuMxArgs& A )
+tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restrict__ sOps, const int waveIndex, const int16_t* __restrict__ resi, const int resiStride, const TuMxArgs& A )
 {
   // A lane's 16 registers are 16 consecutive rows (coefficient side) / samples (residual side) 16h .. 16h+15 of its column / row:
   // R TUs per lane with VPR registers each; a TU's lanes are G consecutive lanes (N = 32: the same 32 lanes of both halves).
@@ -966,9 +966,11 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, const int wa
   const int rndF1 = A.shF1 > 0 ? 1 << ( A.shF1 - 1 ) : 0, rndF2 = 1 << ( A.shF2 - 1 ), rndI1 = 1 << ( A.shI1 - 1 ), rndI2 = 1 << ( A.shI2 - 1 );
   const bool liveCol = inL < N - A.skipW, liveRow = mxSigma( c32 ) % N < N - A.skipH;
   const v4i zero4 = { 0, 0, 0, 0 };
-  const v4i opP1 = liveCol ? *reinterpret_cast<const v4i*>( A.opH->nat[lane] ) : zero4;
-  const v4i opP2 = liveRow ? *reinterpret_cast<const v4i*>( A.opV->rowP[lane] ) : zero4;
-  const v4i opI1 = *reinterpret_cast<const v4i*>( A.opV->natT[lane] ), opI2 = *reinterpret_cast<const v4i*>( A.opH->colP[lane] );
+  // the four matrix operands live in LDS (lane-private 16-byte slots), fetched right before their products: 16 registers less through the quantiser
+  sOps[lane]       = liveCol ? *reinterpret_cast<const v4i*>( A.opH->nat[lane] ) : zero4;
+  sOps[64 + lane]  = liveRow ? *reinterpret_cast<const v4i*>( A.opV->rowP[lane] ) : zero4;
+  sOps[128 + lane] = *reinterpret_cast<const v4i*>( A.opV->natT[lane] );
+  sOps[192 + lane] = *reinterpret_cast<const v4i*>( A.opH->colP[lane] );
   const int cP1 = ( liveCol ? A.opH->rowSum[c32] : 0 ) + rndF1, cI1 = A.opV->colSum[c32] + rndI1;
   // accumulator preloads of the two passes whose matrix sits on the A side (they depend on the result register = logical row 16h + v): LDS
   sInit[c32]      = ( c32 % N < N - A.skipH ? A.opV->rowSum[c32] : 0 ) + rndF2;
@@ -1015,6 +1017,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, const int wa
       v16i c;
 #pragma unroll
       for( int v = 0; v < 16; v++ ) c[v] = cP1;
+      const v4i opP1 = sOps[lane];
       const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, opP1, c, 0, 0, 0 );
       const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, opP1, zero16, 0, 0, 0 );
 #pragma unroll
@@ -1026,6 +1029,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, const int wa
       v16i c;
 #pragma unroll
       for( int g = 0; g < 4; g++ ) { const v4i t = *reinterpret_cast<const v4i*>( &sInit[h * 16 + 4 * g] ); c[4 * g] = t.x; c[4 * g + 1] = t.y; c[4 * g + 2] = t.z; c[4 * g + 3] = t.w; }
+      const v4i opP2 = sOps[64 + lane];
       const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( opP2, bLo, c, 0, 0, 0 );
       const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( opP2, bHi, zero16, 0, 0, 0 );
 #pragma unroll
@@ -1141,6 +1145,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, const int wa
       v16i c;
 #pragma unroll
       for( int v = 0; v < 16; v++ ) c[v] = cI1;
+      const v4i opI1 = sOps[128 + lane];
       const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, opI1, c, 0, 0, 0 );
       const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, opI1, zero16, 0, 0, 0 );
 #pragma unroll
@@ -1163,6 +1168,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, const int wa
       v16i c;
 #pragma unroll
       for( int g = 0; g < 4; g++ ) { const v4i t = *reinterpret_cast<const v4i*>( &sInit[32 + h * 16 + 4 * g] ); c[4 * g] = t.x; c[4 * g + 1] = t.y; c[4 * g + 2] = t.z; c[4 * g + 3] = t.w; }
+      const v4i opI2 = sOps[192 + lane];
       const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( opI2, bLo, c, 0, 0, 0 );
       const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( opI2, bHi, zero16, 0, 0, 0 );
 #pragma unroll
@@ -1211,6 +1217,7 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
 {
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t stage[4][32 * 40];
   __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t sInit[4][64];
+  __shared__ v4i sOps[4][256];
   const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) );
   const int wave = blockIdx.x * 4 + wv;
   int k = 0;
@@ -1218,9 +1225,9 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   for( int i = 1; i < 4; i++ ) if( i < jobs.nJobs && wave >= jobs.waveStart[i] ) k = i;
   const int w = wave - jobs.waveStart[k];
   if( w >= jobs.j[k].waveStride ) return;
-  if( jobs.size[k] == 32 )      tuMxBody<32>( stage[wv], sInit[wv], w, resi, resiStride, jobs.j[k] );
-  else if( jobs.size[k] == 16 ) tuMxBody<16>( stage[wv], sInit[wv], w, resi, resiStride, jobs.j[k] );
-  else                          tuMxBody<8>( stage[wv], sInit[wv], w, resi, resiStride, jobs.j[k] );
+  if( jobs.size[k] == 32 )      tuMxBody<32>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
+  else if( jobs.size[k] == 16 ) tuMxBody<16>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
+  else                          tuMxBody<8>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
 }
 
 __global__ void __launch_bounds__( 256 )
