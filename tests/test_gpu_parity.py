@@ -281,6 +281,55 @@ def test_fused_tu_rdo_vs_oracle(hip, oracle):
                         (es["abs_sum"], es["last_scan_pos"], es["need_rdoq"], es["sse"]), (w, h, th, tv, i)
 
 
+def test_fused_tu_matrix_core_vs_oracle_and_row_kernel(hip, oracle, monkeypatch):
+    """the matrix-core form of the fused TU kernel (8/16/32-point square TUs as int8 MFMA products): every transform-type pair, bit depths 8 and 10,
+    ragged tile counts, unaligned residual offsets, per-TU QPs over the whole range, residual magnitudes up to the 16-bit limit (the 64-bit
+    quantiser path) — against the oracle for conforming residuals and against the dot-product row kernel for everything"""
+    import torch
+    from vvenc_amd.hotpath import STATS_DTYPE, HotPath
+    rng = np.random.default_rng(511)
+    hp = hip.hp
+    H, W = 200, 328
+    for bd in (10, 8):
+        for S in (8, 16, 32):
+            for th in (0, 1, 2):
+                for tv in (0, 1, 2):
+                    n = int(rng.integers(1, 70))
+                    amp = rng.choice([2, 40, (1 << bd) - 1, 5000, 32767], size=n)
+                    resi = np.zeros((H, W), np.int16)
+                    off = np.zeros(n, np.int32)
+                    pr_stride = None
+                    blocks = []
+                    ys = rng.integers(0, H - S + 1, n); xs = rng.integers(0, W - S + 1, n)
+                    # non-overlapping content is not required: TUs only read the plane
+                    resi[:] = rng.integers(-40, 41, size=(H, W))
+                    for i in range(n):
+                        if amp[i] > 40:
+                            resi[ys[i]:ys[i] + S, xs[i]:xs[i] + S] = rng.integers(-int(amp[i]), int(amp[i]) + 1, size=(S, S))
+                    pr = hp.plane(resi, 0)
+                    off = (ys * pr.stride + xs).astype(np.int32)
+                    qps = rng.integers(0, 64, size=n); irap = rng.integers(0, 2, size=n)
+                    d_off = hp.to_device(off); d_qp = hp.to_device(HotPath.tu_qp(qps, irap, 1))
+                    monkeypatch.delenv("VVHIP_TU_KERNEL", raising=False)
+                    lev, rec, st = hp.tu_rdo(pr, d_off, n, S, S, d_qp, th, tv, bd, 8)
+                    monkeypatch.setenv("VVHIP_TU_KERNEL", "row")
+                    lev2, rec2, st2 = hp.tu_rdo(pr, d_off, n, S, S, d_qp, th, tv, bd, 8)
+                    monkeypatch.delenv("VVHIP_TU_KERNEL", raising=False)
+                    assert torch.equal(lev, lev2) and torch.equal(rec, rec2) and torch.equal(st, st2), (bd, S, th, tv)
+                    lev, rec = lev.cpu().numpy().reshape(n, S, S), rec.cpu().numpy().reshape(n, S, S)
+                    st = st.cpu().numpy().view(STATS_DTYPE).reshape(n)
+                    cur = resi                      # plane content at call time
+                    for i in range(n):
+                        blk = cur[ys[i]:ys[i] + S, xs[i]:xs[i] + S]
+                        if np.abs(blk).max() >= (1 << bd):
+                            continue                # beyond the bitDepth contract: covered by the row-kernel comparison above
+                        el, er, es = oracle.tu_rdo(blk, int(qps[i]), int(irap[i]), th, tv, bd, 8, 1)
+                        assert np.array_equal(lev[i], el), ("lev", bd, S, th, tv, i)
+                        assert np.array_equal(rec[i], er), ("rec", bd, S, th, tv, i)
+                        assert (int(st["abs_sum"][i]), int(st["last_scan_pos"][i]), int(st["need_rdoq"][i]), int(st["sse"][i])) == \
+                            (es["abs_sum"], es["last_scan_pos"], es["need_rdoq"], es["sse"]), (bd, S, th, tv, i)
+
+
 def synth_pair(rng, h, w, shift=(3, 1), noise=6):
     yy, xx = np.mgrid[0:h + 32, 0:w + 32]
     base = 512 + 180 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 120 * np.sin((xx + yy) / 11.0) + 60 * np.sin(xx / 3.1) * np.sin(yy / 4.3)

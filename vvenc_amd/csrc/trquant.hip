@@ -1377,7 +1377,7 @@ cpyCoeffKernel( const int16_t* __restrict__ src, ptrdiff_t stride, int32_t* __re
 } // namespace
 
 // fused square-TU kernel: 0 = matrix cores (default), 1 = dot-product row kernel ($VVHIP_TU_KERNEL=row)
-static int tuKernelForm() { static const int v = getenv( "VVHIP_TU_KERNEL" ) && !strcmp( getenv( "VVHIP_TU_KERNEL" ), "row" ) ? 1 : 0; return v; }
+static int tuKernelForm() { const char* e = getenv( "VVHIP_TU_KERNEL" ); return e && !strcmp( e, "row" ) ? 1 : 0; }     // read per call: tests switch it
 static int tuRepeat() { static const int v = getenv( "VVHIP_TU_REPEAT" ) ? atoi( getenv( "VVHIP_TU_REPEAT" ) ) : 2; return v < 1 ? 1 : v; }     // groups per workgroup
 static int tuPhaseLimit() { static const int v = getenv( "VVHIP_TU_PHASES" ) ? atoi( getenv( "VVHIP_TU_PHASES" ) ) : 0; return v; }
 
