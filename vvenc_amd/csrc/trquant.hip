@@ -907,6 +907,32 @@ __device__ __forceinline__ void mxSplit( const int* d, v4i& lo, v4i& hi )
   }
 }
 
+// max over aligned groups of G lanes of two packed unsigned 16-bit values at once (v_pk_max_u16)
+typedef unsigned short u16x2v __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ uint32_t pkMaxU16( uint32_t a, uint32_t b )
+{
+  return __builtin_bit_cast( uint32_t, __builtin_elementwise_max( __builtin_bit_cast( u16x2v, a ), __builtin_bit_cast( u16x2v, b ) ) );
+}
+__device__ __forceinline__ uint32_t tuMxGroupMaxPk16( uint32_t v, int G, int lane )
+{
+  v = pkMaxU16( v, ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR1 ) );
+  v = pkMaxU16( v, ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR2 ) );
+  v = pkMaxU16( v, ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_HALF_MIRROR ) );
+  if( G >= 16 ) v = pkMaxU16( v, ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_MIRROR ) );
+  if( G >= 32 )
+  {
+    const uint32_t r0 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 0 ),  r1 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 16 );
+    const uint32_t r2 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 32 ), r3 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) v, 48 );
+    const uint32_t a = pkMaxU16( r0, r1 ), b = pkMaxU16( r2, r3 );
+    v = G == 64 ? pkMaxU16( a, b ) : ( lane < 32 ? a : b );
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t sadU32( uint32_t a, uint32_t b, uint32_t acc ) { uint32_t r; asm( "v_sad_u32 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( b ), "v"( acc ) ); return r; }
+// clip( x, lo, hi ) with run-time bounds lo <= hi as ONE v_med3_i32 (the compiler emits min + max when it cannot prove lo <= hi)
+__device__ __forceinline__ int med3i( int x, int lo, int hi ) { int r; asm( "v_med3_i32 %0, %1, %2, %3" : "=v"( r ) : "v"( x ), "v"( lo ), "v"( hi ) ); return r; }
+
 // quantiser constants of one TU from its QP (Quant.cpp:775, :874, :173-180, :561, :601-606); the scale tables as select chains (no memory)
 struct TuMxQ { int scale, qBits, thres, iscale, rightShift, inMax; long long addQ, addN; };
 __device__ __forceinline__ int tuMxSel6( int r, int a0, int a1, int a2, int a3, int a4, int a5 )
@@ -1058,9 +1084,10 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
         l = ( ac != 0 && pos[v] > l ) ? pos[v] : l;
         bg = ( ( int ) __umul24( ac, ( uint32_t ) P.scale ) > thr4 && pos[v] > bg ) ? pos[v] : bg;
       }
-      l = vvhipGroupMax32( l, G, lane ); mx = vvhipGroupMax32( mx, G, lane ); bg = vvhipGroupMax32( bg, G, lane );
+      { const uint32_t lb = tuMxGroupMaxPk16( l | ( bg << 16 ), G, lane ); l = lb & 0xffffu; bg = lb >> 16; }     // both < 1024
+      mx = vvhipGroupMax32( mx, G, lane );
       need[r] = ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) mx * P.scale + P.addN ) >> P.qBits ) != 0 );
-      wide |= mx >= 65536u || P.qBits > 30;
+      wide |= mx >= 65536u || P.qBits > 30 || P.qBits < 9;
       last[r] = l; big[r] = bg;
     }
     const bool narrow = __builtin_amdgcn_ballot_w64( wide ) == 0ull;
@@ -1092,7 +1119,6 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
     {                                                                                                                                  \
       const TuMxQ P = tuMxParams( A.q, qqs[r], A.thrVal );                                                                             \
       uint32_t sum = 0;                                                                                                                \
-      const uint32_t add32 = ( uint32_t ) P.addQ; ( void ) add32;                                                                      \
       const int rsPos = P.rightShift > 0 ? P.rightShift : 0, rndDq = P.rightShift > 0 ? 1 << ( P.rightShift - 1 ) : 0;                \
       const int iscaleL = P.rightShift < 0 ? P.iscale << ( -P.rightShift ) : P.iscale;                                                 \
       _Pragma( "unroll" ) for( int v = r * VPR; v < ( r + 1 ) * VPR; v++ )                                                             \
@@ -1105,14 +1131,41 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
         const int sm = cv < 0 ? -( int32_t ) m : ( int32_t ) m;                                                                        \
         const int lv = clip3i( -32768, 32767, sm );                                                                                    \
         stage[( 16 * h + v ) * LP + c32] = ( int16_t ) lv;                                                                             \
-        const int cl = clip3i( -( P.inMax + 1 ), P.inMax, lv );                                                                        \
+        const int cl = med3i( lv, ~P.inMax, P.inMax );                                                                                 \
         const int32_t w_ = ( int32_t ) ( ( uint32_t ) __mul24( cl, iscaleL ) + ( uint32_t ) rndDq ) >> rsPos;   /* |cl| < 2^15, multiplier < 2^23 */ \
         d[v] = clip3i( -32768, 32767, w_ );                                                                                            \
       }                                                                                                                                \
       absSum[r] = sum;                                                                                                                 \
     }
-    if( narrow ) { TUMX_LEVELS( ( ( uint32_t ) __umul24( ac, ( uint32_t ) P.scale ) + add32 ) >> P.qBits ) }
-    else         { TUMX_LEVELS( ( uint32_t ) ( int32_t ) ( ( ( int64_t ) ac * P.scale + P.addQ ) >> P.qBits ) ) }
+    if( narrow )
+    {
+      // signed form: sign(c) * ( ( |c| * scale + add ) >> qBits )  ==  ( c * scale + ( c < 0 ? 2^qBits - 1 - add : add ) ) >> qBits (arithmetic),
+      // because -floor( X / 2^q ) == floor( ( -X + 2^q - 1 ) / 2^q ); |c * scale| + add < 2^31 here.  |level| sums through v_sad_u32 on biased values.
+#pragma unroll
+      for( int r = 0; r < R; r++ )
+      {
+        const TuMxQ P = tuMxParams( A.q, qqs[r], A.thrVal );
+        uint32_t sum = 0;
+        const int addP = ( int ) P.addQ, addM = ( int ) ( ( 1u << P.qBits ) - 1u ) - addP;
+        const int rsPos = P.rightShift > 0 ? P.rightShift : 0, rndDq = P.rightShift > 0 ? 1 << ( P.rightShift - 1 ) : 0;
+        const int iscaleL = P.rightShift < 0 ? P.iscale << ( -P.rightShift ) : P.iscale;
+#pragma unroll
+        for( int v = r * VPR; v < ( r + 1 ) * VPR; v++ )
+        {
+          const int cv = d[v];
+          int sm = ( __mul24( cv, P.scale ) + ( cv < 0 ? addM : addP ) ) >> P.qBits;
+          sm = pos[v] <= last[r] ? sm : 0;
+          sum = sadU32( ( uint32_t ) ( sm + ( 1 << 24 ) ), 1u << 24, sum );                                      // |sm| < 2^24 (qBits >= 9)
+          const int lv = clip3i( -32768, 32767, sm );
+          stage[( 16 * h + v ) * LP + c32] = ( int16_t ) lv;
+          const int cl = med3i( lv, ~P.inMax, P.inMax );
+          const int32_t w_ = ( int32_t ) ( ( uint32_t ) __mul24( cl, iscaleL ) + ( uint32_t ) rndDq ) >> rsPos;   // |cl| < 2^15, multiplier < 2^23
+          d[v] = clip3i( -32768, 32767, w_ );
+        }
+        absSum[r] = sum;
+      }
+    }
+    else { TUMX_LEVELS( ( uint32_t ) ( int32_t ) ( ( ( int64_t ) ac * P.scale + P.addQ ) >> P.qBits ) ) }
 #undef TUMX_LEVELS
 #pragma unroll
     for( int r = 0; r < R; r++ )
