@@ -29,7 +29,7 @@ def class_of(name):
         return "SSE" if arg.endswith("1") else "SAD"
     if head.startswith("hadTile8MultiKernel"):
         return "HAD_fast"
-    if head.startswith("tuRdoRowMultiKernel"):
+    if head.startswith("tuRdoRowMultiKernel") or head.startswith("tuMxMultiKernel"):
         return "TU"
     if head.startswith("tuRdoRowKernel<"):
         return "TU" + head[len("tuRdoRowKernel<"):].split(",")[0]
