@@ -196,6 +196,44 @@ class _Base:
         cost = f(*a)
         return int(mvd[0]), int(mvd[1]), int(cost)
 
+    # ---- ALF encoder statistics ----
+    ALF_REC = 13 * 13 + 13 + 1
+
+    @staticmethod
+    def alf_pad(plane, margin=8):
+        """replicated border, like the reference's extended m_tempBuf -> (padded array, margin)"""
+        return np.ascontiguousarray(np.pad(np.ascontiguousarray(plane, np.int16), margin, mode="edge")), margin
+
+    def alf_classify(self, rec, bit_depth=10, vb_ctu_height=128, vb_pos=124):
+        """rec: (H, W) int16 luma (H, W multiples of 4) -> (H/4, W/4, 2) uint8 {classIdx, transposeIdx}"""
+        h, w = rec.shape
+        pad, m = self.alf_pad(rec)
+        cls = np.zeros((h // 4, w // 4, 2), np.uint8)
+        base = pad.ctypes.data + 2 * (m * pad.shape[1] + m)
+        f = getattr(self.L, self._pfx + "alf_classify"); f.restype = None if self._pfx == "orc_" else C.c_int
+        a = (C.c_void_p(base), C.c_ssize_t(pad.shape[1]) if self._pfx == "orc_" else pad.shape[1], w, h, bit_depth + 4, vb_ctu_height, vb_pos)
+        if self._pfx == "vvref_":
+            a = a + (self.simd,)
+        f(*a, _p(cls))
+        return cls
+
+    def alf_stats_plane(self, org, rec, ctu_size, filter_length, cls=None, vb_ctu_height=128, vb_pos=124):
+        """-> (numCtus, numClasses, ALF_REC) float32: E[13][13], y[13], pixAcc per CTU and class, accumulated in the reference's order"""
+        h, w = rec.shape
+        pad, m = self.alf_pad(rec)
+        org = np.ascontiguousarray(org, np.int16)
+        ncls = 25 if cls is not None else 1
+        nctu = ((w + ctu_size - 1) // ctu_size) * ((h + ctu_size - 1) // ctu_size)
+        out = np.zeros((nctu, ncls, self.ALF_REC), np.float32)
+        base = pad.ctypes.data + 2 * (m * pad.shape[1] + m)
+        clsp = _p(np.ascontiguousarray(cls, np.uint8)) if cls is not None else None
+        f = getattr(self.L, self._pfx + "alf_stats_plane"); f.restype = None if self._pfx == "orc_" else C.c_int
+        if self._pfx == "orc_":
+            f(_p(org), C.c_ssize_t(org.shape[1]), C.c_void_p(base), C.c_ssize_t(pad.shape[1]), w, h, ctu_size, filter_length, clsp, vb_ctu_height, vb_pos, _p(out))
+        else:
+            f(_p(org), org.shape[1], C.c_void_p(base), pad.shape[1], w, h, ctu_size, filter_length, clsp, vb_ctu_height, vb_pos, self.simd, _p(out))
+        return out
+
     # ---- g_tCoeffOps table slots (TrQuant_EMT.h:63-91), caller's matrix ----
     def fast_fwd_core(self, tc, src, line, reduced_line, cutoff, shift):
         """tc: (N, N) int16, src: (line, N) int32 -> dst (N, line) int32 (entries outside reduced_line x cutoff stay 0)"""

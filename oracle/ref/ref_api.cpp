@@ -62,6 +62,8 @@
 #include "CommonLib/InterpolationFilter.h"
 #include "vvenc/vvencCfg.h"
 #include "EncoderLib/EncCfg.h"
+#include "CommonLib/AdaptiveLoopFilter.h"
+#include "EncoderLib/EncAdaptiveLoopFilter.h"
 #undef private
 #undef protected
 
@@ -930,6 +932,83 @@ API double vvref_dmvr_batch_mt( const int16_t* ref0, int stride0, const int16_t*
 }
 
 // the hook-enabled build re-installs table-level device slots after the SIMD initialisation rewrote the global tables
+// ---- ALF encoder statistics — the reference's own classification and covariance accumulation ---------------------
+// cls: 2 bytes per 4x4 block {classIdx, transposeIdx}, width/4 per row.  simd = 0: scalar table entry, 1: the x86 row.  Walks the picture in
+// 128x128 CTUs exactly like deriveClassification (AdaptiveLoopFilter.cpp:505-522, m_CLASSIFICATION_BLK_SIZE 128).
+API int vvref_alf_classify( const int16_t* rec, int stride, int width, int height, int shift, int vbCTUHeight, int vbPos, int simd, uint8_t* cls )
+{
+  static AdaptiveLoopFilter* alf[2] = { nullptr, nullptr };
+  if( !alf[simd != 0] ) alf[simd != 0] = new AdaptiveLoopFilter( simd != 0 );
+  std::vector<AlfClassifier> tmp( 32 * 32 );
+  const CPelBuf src( rec, stride, width, height );
+  for( int y = 0; y < height; y += 128 )
+    for( int x = 0; x < width; x += 128 )
+    {
+      const int w = std::min( 128, width - x ), h = std::min( 128, height - y );
+      const Area blk( x, y, w, h );
+      alf[simd != 0]->m_deriveClassificationBlk( tmp.data(), src, blk, blk, shift, vbCTUHeight, vbPos );
+      for( int i = 0; i < h; i += 4 )
+        for( int j = 0; j < w; j += 4 )
+        {
+          const AlfClassifier& c = tmp[( i / 4 ) * 32 + j / 4];
+          uint8_t* o = cls + 2 * ( ( size_t ) ( ( y + i ) / 4 ) * ( width / 4 ) + ( x + j ) / 4 );
+          o[0] = c.classIdx; o[1] = c.transposeIdx;
+        }
+    }
+  return 0;
+}
+
+// Statistics of one plane, CTU by CTU, through EncAdaptiveLoopFilter::getPreBlkStats (EncAdaptiveLoopFilter.cpp:3376) with linear filters
+// (numBins 1).  out: [numCtus][numClasses][13*13 + 13 + 1] floats (E row-major, y, pixAcc); cls == NULL: chroma (one class).
+API int vvref_alf_stats_plane( const int16_t* org, int orgStride, const int16_t* rec, int recStride, int width, int height, int ctuSize, int filterLength,
+                               const uint8_t* cls, int vbCTUHeight, int vbPos, int simd, float* out )
+{
+  static EncAdaptiveLoopFilter* enc[2] = { nullptr, nullptr };
+  static VVEncCfg cfg;
+  if( !enc[simd != 0] )
+  {
+    memset( ( void* ) &cfg, 0, sizeof( cfg ) );                       // m_useNonLinearAlfLuma / Chroma = false
+    enc[simd != 0] = new EncAdaptiveLoopFilter( simd != 0 );
+    enc[simd != 0]->m_encCfg = &cfg;
+  }
+  EncAdaptiveLoopFilter& E = *enc[simd != 0];
+  const AlfFilterShape shape( filterLength );
+  const int numClasses = cls ? MAX_NUM_ALF_CLASSES : 1, rec_ = 13 * 13 + 13 + 1;
+  std::vector<AlfCovariance> cov( numClasses );
+  for( auto& c : cov ) c.create( shape.numCoeff, 1 );
+  std::vector<AlfClassifier> cl( 32 * 32 );
+  const int ctusX = ( width + ctuSize - 1 ) / ctuSize, ctusY = ( height + ctuSize - 1 ) / ctuSize;
+  for( int cy = 0; cy < ctusY; cy++ )
+    for( int cx = 0; cx < ctusX; cx++ )
+    {
+      const int x0 = cx * ctuSize, y0 = cy * ctuSize, w = std::min( ctuSize, width - x0 ), h = std::min( ctuSize, height - y0 );
+      for( auto& c : cov ) c.reset();
+      if( cls )
+        for( int i = 0; i < h; i += 4 )
+          for( int j = 0; j < w; j += 4 )
+          {
+            const uint8_t* c = cls + 2 * ( ( size_t ) ( ( y0 + i ) / 4 ) * ( width / 4 ) + ( x0 + j ) / 4 );
+            cl[( i / 4 ) * 32 + j / 4] = AlfClassifier( c[0], c[1] );
+          }
+      const CompArea area( cls ? COMP_Y : COMP_Cb, CHROMA_420, Area( x0, y0, w, h ) );
+      E.getPreBlkStats( cov.data(), shape, cls ? cl.data() : nullptr, const_cast<Pel*>( org ) + ( ptrdiff_t ) y0 * orgStride + x0, orgStride,
+                        const_cast<Pel*>( rec ) + ( ptrdiff_t ) y0 * recStride + x0, recStride, area, cls ? CH_L : CH_C, vbCTUHeight, vbPos );
+      float* o = out + ( size_t ) ( cy * ctusX + cx ) * numClasses * rec_;
+      for( int c = 0; c < numClasses; c++, o += rec_ )
+      {
+        memset( o, 0, sizeof( float ) * rec_ );
+        for( int k = 0; k < shape.numCoeff; k++ )
+        {
+          for( int l = 0; l < shape.numCoeff; l++ ) o[k * 13 + l] = cov[c].E[0][0][k][l];
+          o[169 + k] = cov[c].y[0][k];
+        }
+        o[182] = cov[c].pixAcc;
+      }
+    }
+  for( auto& c : cov ) c.destroy();
+  return 0;
+}
+
 extern "C" void vvref_after_simd_init() __attribute__( ( weak ) );
 
 API long vvref_encode( const int16_t* y, const int16_t* u, const int16_t* v, int width, int height, int frames, int inputBitDepth, int internalBitDepth,

@@ -1191,3 +1191,173 @@ uint64_t orc_dmvr_refine(const int16_t *ref0, int stride0, int fx0, int fy0, con
     orc_if_bilinear(ref1 - 2 * stride1 - 2, stride1, p1, bs, dx + 4, dy + 4, fx1, fy1, bitDepth);
     return orc_dmvr_search(p0 + 2 * bs + 2, p1 + 2 * bs + 2, bs, dx, dy, mvd);
 }
+
+
+/* ============================================================================================================================
+ * ALF encoder statistics.
+ *   classification   AdaptiveLoopFilter::deriveClassificationBlk   CommonLib/AdaptiveLoopFilter.cpp:524-728 (restated per 4x4 block: the
+ *                    reference's laplacian rows / 4-column sums depend on absolute positions only)
+ *   ELocal           EncAdaptiveLoopFilter::calcLinCovariance4      EncoderLib/EncAdaptiveLoopFilter.cpp:3707-3921 (linear filters, numBins 1)
+ *   accumulation     getPreBlkStats :3376-3541 + getPreBlkStatsAccum :3266-3319 (x86: one int32 sum per 4x4 block and entry, converted to
+ *                    float and ADDED in float — x86/EncAdaptiveLoopFilterX86.h:160-236; the order of the float additions is the raster
+ *                    order of the 4x4 blocks inside the CTU area, per class)
+ * ============================================================================================================================ */
+static int alf_abs(int v) { return v < 0 ? -v : v; }
+
+void orc_alf_classify(const int16_t *rec, ptrdiff_t stride, int width, int height, int shift, int vbCTUHeight, int vbPos, uint8_t *cls)
+{
+  static const int th[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
+  static const int transposeTable[8] = { 0, 1, 0, 2, 2, 3, 1, 3 };
+  const int bw = width / 4;
+  for (int Y = 0; Y < height; Y += 4)
+    for (int X = 0; X < width; X += 4)
+    {
+      int lap[4][4][4];                                         /* [dir][row pair r][col pair c], 2x2-subsampled positions (Y-2+2r, X-2+2c) */
+      for (int r = 0; r < 4; r++)
+      {
+        const int y = Y - 2 + 2 * r;                            /* row of src1 (:558) */
+        const int16_t *s1 = rec + (ptrdiff_t)y * stride, *s0 = s1 - stride, *s2 = s1 + stride, *s3 = s1 + 2 * stride;
+        if (y > 0 && (y & (vbCTUHeight - 1)) == vbPos - 2) s3 = s2;        /* :559-566 */
+        else if (y > 0 && (y & (vbCTUHeight - 1)) == vbPos) s0 = s1;
+        for (int c = 0; c < 4; c++)
+        {
+          const int x = X - 2 + 2 * c;
+          const int16_t *pY = s1 + x, *pYdown = s0 + x, *pYup = s2 + x, *pYup2 = s3 + x;
+          const int16_t y0 = (int16_t)(pY[0] << 1), yup1 = (int16_t)(pYup[1] << 1);
+          lap[0][r][c] = alf_abs(y0 - pYdown[0] - pYup[0]) + alf_abs(yup1 - pY[1] - pYup2[1]);       /* VER  :583 */
+          lap[1][r][c] = alf_abs(y0 - pY[1] - pY[-1]) + alf_abs(yup1 - pYup[2] - pYup[0]);           /* HOR  :584 */
+          lap[2][r][c] = alf_abs(y0 - pYdown[-1] - pYup[1]) + alf_abs(yup1 - pY[0] - pYup2[2]);      /* DIAG0 :585 */
+          lap[3][r][c] = alf_abs(y0 - pYup[-1] - pYdown[1]) + alf_abs(yup1 - pYup2[0] - pY[2]);      /* DIAG1 :586 */
+        }
+      }
+      const int ym = Y % vbCTUHeight;
+      const int r0 = ym == vbPos ? 1 : 0, r1 = ym == vbPos - 4 ? 3 : 4;    /* :630-650 */
+      int sum[4];
+      for (int d = 0; d < 4; d++)
+      {
+        sum[d] = 0;
+        for (int r = r0; r < r1; r++) for (int c = 0; c < 4; c++) sum[d] += lap[d][r][c];
+      }
+      const int sumV = sum[0], sumH = sum[1], sumD0 = sum[2], sumD1 = sum[3];
+      const int tempAct = sumV + sumH;
+      const int yb = Y & (vbCTUHeight - 1);
+      int activity = (tempAct * ((yb == vbPos - 4 || yb == vbPos) ? 96 : 64)) >> shift;                /* :655-663 */
+      activity = activity < 0 ? 0 : (activity > 15 ? 15 : activity);
+      int classIdx = th[activity];
+      int hv1, hv0, d1, d0, hvd1, hvd0, dirTempHV, dirTempD, mainDirection, secondaryDirection;
+      if (sumV > sumH) { hv1 = sumV; hv0 = sumH; dirTempHV = 1; } else { hv1 = sumH; hv0 = sumV; dirTempHV = 3; }
+      if (sumD0 > sumD1) { d1 = sumD0; d0 = sumD1; dirTempD = 0; } else { d1 = sumD1; d0 = sumD0; dirTempD = 2; }
+      if ((uint32_t)d1 * (uint32_t)hv0 > (uint32_t)hv1 * (uint32_t)d0) { hvd1 = d1; hvd0 = d0; mainDirection = dirTempD; secondaryDirection = dirTempHV; }
+      else { hvd1 = hv1; hvd0 = hv0; mainDirection = dirTempHV; secondaryDirection = dirTempD; }
+      int directionStrength = 0;
+      if (hvd1 > 2 * hvd0) directionStrength = 1;
+      if (hvd1 * 2 > 9 * hvd0) directionStrength = 2;
+      if (directionStrength) classIdx += (((mainDirection & 1) << 1) + directionStrength) * 5;
+      uint8_t *o = cls + 2 * ((size_t)(Y / 4) * bw + X / 4);
+      o[0] = (uint8_t)classIdx;
+      o[1] = (uint8_t)transposeTable[mainDirection * 2 + (secondaryDirection >> 1)];
+    }
+}
+
+static int alf_clip_idx(int clipToBdry, int i, int clip) { return clipToBdry ? (i > clip ? i : clip) : i; }
+
+/* ELocal of one 4x4 block (rec -> its top-left sample): [numCoeff][16] int16, sample index = row * 4 + column */
+void orc_alf_elocal(const int16_t *rec, ptrdiff_t stride, int L, int transposeIdx, const int clipTopRow[4], const int clipBotRow[4], int16_t *ELocal)
+{
+  for (int ii = 0; ii < 4; ii++)
+  {
+    const int16_t *r0 = rec + ii * stride;
+    const int cb = clipBotRow[ii] != 4;                       /* :3438-3455 picks the clipping instantiation */
+    const int ct = clipTopRow[ii], cbr = clipBotRow[ii];
+    int k = 0;
+#define ALF_OFF0(i) ((ptrdiff_t)alf_clip_idx(cb, (i), ct) * stride)
+#define ALF_OFF1(i) (-(ptrdiff_t)alf_clip_idx(cb, (i), -cbr) * stride)
+#define ALF_PUT(P0, P1) { for (int x = 0; x < 4; x++) ELocal[k * 16 + ii * 4 + x] = (int16_t)((P0)[x] + (P1)[x] - (int16_t)(r0[x] << 1)); k++; }
+    if (transposeIdx == 0)
+    {
+      for (int i = -L; i < 0; i++) for (int j = -L - i; j <= L + i; j++) ALF_PUT(r0 + ALF_OFF0(i) + j, r0 + ALF_OFF1(i) - j)
+      for (int j = -L; j < 0; j++) ALF_PUT(r0 + j, r0 - j)
+    }
+    else if (transposeIdx == 1)
+    {
+      for (int j = -L; j < 0; j++) for (int i = -L - j; i <= L + j; i++) ALF_PUT(r0 + j + ALF_OFF0(i), r0 - j + ALF_OFF1(i))
+      for (int i = -L; i < 0; i++) ALF_PUT(r0 + ALF_OFF0(i), r0 + ALF_OFF1(i))
+    }
+    else if (transposeIdx == 2)
+    {
+      for (int i = -L; i < 0; i++) for (int j = L + i; j >= -L - i; j--) ALF_PUT(r0 + ALF_OFF0(i) + j, r0 + ALF_OFF1(i) - j)
+      for (int j = -L; j < 0; j++) ALF_PUT(r0 + j, r0 - j)
+    }
+    else
+    {
+      for (int j = -L; j < 0; j++) for (int i = L + j; i >= -L - j; i--) ALF_PUT(r0 + j + ALF_OFF0(i), r0 - j + ALF_OFF1(i))
+      for (int i = -L; i < 0; i++) ALF_PUT(r0 + ALF_OFF0(i), r0 + ALF_OFF1(i))
+    }
+    for (int x = 0; x < 4; x++) ELocal[k * 16 + ii * 4 + x] = r0[x];
+#undef ALF_OFF0
+#undef ALF_OFF1
+#undef ALF_PUT
+  }
+}
+
+void orc_alf_stats_area(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int x0, int y0, int w, int h, int filterLength,
+                        const uint8_t *cls, int clsStride, int vbCTUHeight, int vbPos, float *out)
+{
+  const int L = filterLength >> 1, nc = filterLength * filterLength / 4 + 1;
+  for (int i = 0; i < h; i += 4)
+  {
+    int clipTopRow[4] = { -4, -4, -4, -4 }, clipBotRow[4] = { 4, 4, 4, 4 };
+    for (int ii = 0; ii < 4; ii++)
+    {
+      const int vbDistance = ((y0 + i + ii) % vbCTUHeight) - vbPos;       /* :3399-3411 */
+      if (vbDistance >= -3 && vbDistance < 0) { clipBotRow[ii] = -vbDistance - 1; clipTopRow[ii] = -clipBotRow[ii]; }
+      else if (vbDistance >= 0 && vbDistance < 3) { clipTopRow[ii] = -vbDistance; clipBotRow[ii] = -clipTopRow[ii]; }
+    }
+    for (int j = 0; j < w; j += 4)
+    {
+      int classIdx = 0, transposeIdx = 0;
+      if (cls) { const uint8_t *c = cls + 2 * ((size_t)((y0 + i) / 4) * clsStride + (x0 + j) / 4); classIdx = c[0]; transposeIdx = c[1]; }
+      const int16_t *o = org + (ptrdiff_t)(y0 + i) * orgStride + x0 + j, *r = rec + (ptrdiff_t)(y0 + i) * recStride + x0 + j;
+      int16_t yLocal[16], ELocal[13 * 16];
+      for (int ii = 0; ii < 4; ii++) for (int jj = 0; jj < 4; jj++) yLocal[ii * 4 + jj] = (int16_t)(o[jj + ii * orgStride] - r[jj + ii * recStride]);
+      orc_alf_elocal(r, recStride, L, transposeIdx, clipTopRow, clipBotRow, ELocal);
+      float *E = out + (size_t)classIdx * ORC_ALF_REC, *yv = E + 169, *pix = E + 182;
+      for (int k = 0; k < nc; k++)
+      {
+        for (int l = k; l < nc; l++)
+        {
+          int32_t sum = 0;
+          for (int p = 0; p < 16; p++) sum += (int32_t)ELocal[l * 16 + p] * ELocal[k * 16 + p];
+          E[k * 13 + l] += (float)sum;
+        }
+        int32_t sum = 0;
+        for (int p = 0; p < 16; p++) sum += (int32_t)ELocal[k * 16 + p] * yLocal[p];
+        yv[k] += (float)sum;
+      }
+      int32_t sum = 0;
+      for (int p = 0; p < 16; p++) sum += (int32_t)yLocal[p] * yLocal[p];
+      *pix += (float)sum;
+    }
+  }
+  const int numClasses = cls ? 25 : 1;                                  /* :3493-3512 mirror the upper triangle */
+  for (int c = 0; c < numClasses; c++)
+  {
+    float *E = out + (size_t)c * ORC_ALF_REC;
+    for (int k = 1; k < nc; k++) for (int l = 0; l < k; l++) E[k * 13 + l] = E[l * 13 + k];
+  }
+}
+
+void orc_alf_stats_plane(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int width, int height, int ctuSize, int filterLength,
+                         const uint8_t *cls, int vbCTUHeight, int vbPos, float *out)
+{
+  const int numClasses = cls ? 25 : 1, ctusX = (width + ctuSize - 1) / ctuSize, ctusY = (height + ctuSize - 1) / ctuSize;
+  memset(out, 0, sizeof(float) * (size_t)ctusX * ctusY * numClasses * ORC_ALF_REC);
+  for (int cy = 0; cy < ctusY; cy++)
+    for (int cx = 0; cx < ctusX; cx++)
+    {
+      const int x0 = cx * ctuSize, y0 = cy * ctuSize;
+      const int w = x0 + ctuSize > width ? width - x0 : ctuSize, h = y0 + ctuSize > height ? height - y0 : ctuSize;
+      orc_alf_stats_area(org, orgStride, rec, recStride, x0, y0, w, h, filterLength, cls, width / 4, vbCTUHeight, vbPos,
+                         out + (size_t)(cy * ctusX + cx) * numClasses * ORC_ALF_REC);
+    }
+}

@@ -85,6 +85,18 @@ uint64_t orc_dmvr_search(const int16_t *l0c, const int16_t *l1c, int stride, int
 uint64_t orc_dmvr_refine(const int16_t *ref0, int stride0, int fx0, int fy0, const int16_t *ref1, int stride1, int fx1, int fy1, int dx, int dy,
                          int bitDepth, int16_t mvd[2]);
 
+/* ALF encoder statistics (AdaptiveLoopFilter.cpp:524-728, EncAdaptiveLoopFilter.cpp:3266-3541, 3707-3921;
+ * x86/EncAdaptiveLoopFilterX86.h:160-236).  Planes carry a replicated border of >= 4 samples (the reference works on its extended m_tempBuf).
+ * cls: 2 bytes per 4x4 block {classIdx, transposeIdx}, (width/4) per row.  Statistics record per class: ORC_ALF_REC floats =
+ * E[13][13] (row-major, symmetric), y[13], pixAcc; for the 5x5 chroma shape only the first 7 rows/columns are used.                 */
+#define ORC_ALF_REC (13 * 13 + 13 + 1)
+void orc_alf_classify(const int16_t *rec, ptrdiff_t stride, int width, int height, int shift, int vbCTUHeight, int vbPos, uint8_t *cls);
+void orc_alf_elocal(const int16_t *rec, ptrdiff_t stride, int halfFilterLength, int transposeIdx, const int clipTopRow[4], const int clipBotRow[4], int16_t *ELocal /* [numCoeff][16] */);
+void orc_alf_stats_area(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int x0, int y0, int w, int h, int filterLength,
+                        const uint8_t *cls /* NULL: one class */, int clsStride /* blocks per picture row */, int vbCTUHeight, int vbPos, float *out /* [numClasses][ORC_ALF_REC], accumulated into */);
+void orc_alf_stats_plane(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int width, int height, int ctuSize, int filterLength,
+                         const uint8_t *cls, int vbCTUHeight, int vbPos, float *out /* [numCtus][numClasses][ORC_ALF_REC], zeroed here */);
+
 #ifdef __cplusplus
 }
 #endif
