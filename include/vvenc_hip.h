@@ -350,6 +350,22 @@ typedef struct { int16_t mvd_x, mvd_y; int32_t pad; uint64_t min_cost; } vvhip_d
 VVHIP_API int vvhip_dmvr_refine_batch( vvhip_ctx* ctx, const int16_t* d_ref0, int stride0, const int16_t* d_ref1, int stride1,
                                        const vvhip_dmvr_item* d_items, int n, int dx, int dy, int bit_depth, vvhip_dmvr_result* d_out );
 
+/* ======================================================================================================================
+ * SURVEY 8f rank 4 — ALF encoder statistics (P_ALF, 19.5 % of single-thread time at preset faster).
+ *   vvhip_alf_classify    <- AdaptiveLoopFilter::m_deriveClassificationBlk (deriveClassificationBlk, CommonLib/AdaptiveLoopFilter.cpp:524-728):
+ *       class index / transpose index of every 4x4 luma block of a picture; d_cls holds 2 bytes per block {classIdx, transposeIdx},
+ *       width/4 blocks per row.  vb_ctu_height / vb_pos = m_alfVBLumaCTUHeight / m_alfVBLumaPos (:411-415: CTU height, CTU height - 4).
+ *   vvhip_alf_stats_plane <- EncAdaptiveLoopFilter::getPreBlkStats + m_getPreBlkStatsAccum for every CTU of a plane
+ *       (EncoderLib/EncAdaptiveLoopFilter.cpp:3376-3541, :3266-3319), linear filters (numBins 1): filter_length 7 with d_cls (luma, 25
+ *       classes) or 5 with d_cls == NULL (chroma, one class; ctu_size / vb_* in chroma samples).  d_out: [numCtus][numClasses][183] floats per
+ *       record = E[13][13] (row-major, symmetric), y[13], pixAcc.  The float additions happen in the reference's order (4x4 blocks of a
+ *       CTU in raster order, per class): results are bit-identical.  Blocks classified {255, 255} are skipped (m_ALF_UNUSED_CLASSIDX).
+ * d_rec carries a replicated border of >= 4 samples (the reference reads its extended m_tempBuf); width / height multiples of 4.      */
+#define VVHIP_ALF_REC 183
+VVHIP_API int vvhip_alf_classify( vvhip_ctx* ctx, const int16_t* d_rec, int stride, int width, int height, int bit_depth, int vb_ctu_height, int vb_pos, uint8_t* d_cls );
+VVHIP_API int vvhip_alf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_rec, int rec_stride, int width, int height, int ctu_size,
+                                     int filter_length, const uint8_t* d_cls /* NULL: chroma */, int vb_ctu_height, int vb_pos, float* d_out );
+
 #ifdef __cplusplus
 }
 #endif

@@ -1316,7 +1316,12 @@ void orc_alf_stats_area(const int16_t *org, ptrdiff_t orgStride, const int16_t *
     for (int j = 0; j < w; j += 4)
     {
       int classIdx = 0, transposeIdx = 0;
-      if (cls) { const uint8_t *c = cls + 2 * ((size_t)((y0 + i) / 4) * clsStride + (x0 + j) / 4); classIdx = c[0]; transposeIdx = c[1]; }
+      if (cls)
+      {
+        const uint8_t *c = cls + 2 * ((size_t)((y0 + i) / 4) * clsStride + (x0 + j) / 4);
+        if (c[0] == 255 && c[1] == 255) continue;                       /* m_ALF_UNUSED_CLASSIDX / _TRANSPOSIDX :3416 */
+        classIdx = c[0]; transposeIdx = c[1];
+      }
       const int16_t *o = org + (ptrdiff_t)(y0 + i) * orgStride + x0 + j, *r = rec + (ptrdiff_t)(y0 + i) * recStride + x0 + j;
       int16_t yLocal[16], ELocal[13 * 16];
       for (int ii = 0; ii < 4; ii++) for (int jj = 0; jj < 4; jj++) yLocal[ii * 4 + jj] = (int16_t)(o[jj + ii * orgStride] - r[jj + ii * recStride]);

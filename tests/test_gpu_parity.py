@@ -654,3 +654,42 @@ def test_bad_arguments_are_reported_not_crashed(hip):
     # still alive
     good = hp.dist_batch("SAD", plane, plane, items, 4, 8, 8, out=out)
     assert int(good.sum().item()) == 0
+
+
+def _alf_pictures(rng, h, w, smooth):
+    yy, xx = np.mgrid[0:h, 0:w]
+    if smooth:
+        base = 512 + 90 * np.sin(xx / 41.0) * np.cos(yy / 33.0) + 40 * np.sin((xx - yy) / 17.0) + rng.normal(0, 1.5, (h, w)) + 25 * (((xx // 24) + (yy // 40)) % 2)
+    else:
+        base = 512 + 200 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 80 * np.sin((xx + 2 * yy) / 5.0) + rng.normal(0, 20, (h, w))
+    rec = np.clip(base, 0, 1023).astype(np.int16)
+    org = np.clip(rec.astype(np.int32) + rng.integers(-12, 13, (h, w)), 0, 1023).astype(np.int16)
+    return org, rec
+
+
+@pytest.mark.parametrize("cfg", [(272, 400, 128, False), (264, 392, 128, True), (136, 200, 64, True), (64, 64, 32, False)])
+def test_alf_classification_and_statistics_vs_oracle(hip, oracle, cfg):
+    """ALF classification (integer) and covariance statistics (float sums in the reference's order) — bit-exact, luma 7x7 with
+    25 classes and chroma 5x5, partial CTUs, virtual-boundary rows"""
+    h, w, ctu, smooth = cfg
+    hp = hip.hp
+    org, rec = _alf_pictures(np.random.default_rng(700 + h), h, w, smooth)
+    vbh, vbp = ctu, ctu - 4
+    prec, porg = hp.plane(rec, 8), hp.plane(org, 0)
+    d_cls = hp.alf_classify(prec, 10, vbh, vbp)
+    exp_cls = oracle.alf_classify(rec, 10, vbh, vbp)
+    assert np.array_equal(d_cls.cpu().numpy(), exp_cls)
+    got = hp.alf_stats_plane(porg, prec, ctu, 7, d_cls, vbh, vbp).cpu().numpy()
+    exp = oracle.alf_stats_plane(org, rec, ctu, 7, exp_cls, vbh, vbp)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), ("luma", np.abs(got - exp).max())
+    c_org, c_rec = np.ascontiguousarray(org[::2, ::2]), np.ascontiguousarray(rec[::2, ::2])
+    if c_rec.shape[0] % 4 == 0 and c_rec.shape[1] % 4 == 0:
+        pcr, pco = hp.plane(c_rec, 8), hp.plane(c_org, 0)
+        got = hp.alf_stats_plane(pco, pcr, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2).cpu().numpy()
+        exp = oracle.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), ("chroma", np.abs(got - exp).max())
+    # blocks marked unused are skipped
+    cls2 = exp_cls.copy(); cls2[::3, 1::2] = 255
+    got = hp.alf_stats_plane(porg, prec, ctu, 7, hp.to_device(cls2), vbh, vbp).cpu().numpy()
+    exp = oracle.alf_stats_plane(org, rec, ctu, 7, cls2, vbh, vbp)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), "unused blocks"

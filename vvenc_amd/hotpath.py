@@ -276,6 +276,26 @@ class HotPath:
         self._ck(self.L.vvhip_dmvr_refine_batch(self.ctx, ref0.buf_ptr, ref0.stride, ref1.buf_ptr, ref1.stride, _ptr(d_items), n, dx, dy, bit_depth, _ptr(out)))
         return out
 
+    # ---- ALF encoder statistics ----
+    ALF_REC = 183
+
+    def alf_classify(self, rec, bit_depth=10, vb_ctu_height=128, vb_pos=124, out=None):
+        """rec: luma Plane with a replicated margin >= 4 -> uint8 tensor (H/4, W/4, 2) {classIdx, transposeIdx}"""
+        if out is None:
+            out = torch.empty((rec.height // 4, rec.width // 4, 2), dtype=torch.uint8, device=self.device)
+        self._ck(self.L.vvhip_alf_classify(self.ctx, rec.buf_ptr, rec.stride, rec.width, rec.height, bit_depth, vb_ctu_height, vb_pos, _ptr(out)))
+        return out
+
+    def alf_stats_plane(self, org, rec, ctu_size, filter_length, d_cls=None, vb_ctu_height=128, vb_pos=124, out=None):
+        """covariance records of every CTU of a plane -> float32 tensor (numCtus, 25 or 1, ALF_REC): E[13][13], y[13], pixAcc"""
+        nctu = ((rec.width + ctu_size - 1) // ctu_size) * ((rec.height + ctu_size - 1) // ctu_size)
+        ncls = 25 if d_cls is not None else 1
+        if out is None:
+            out = torch.empty((nctu, ncls, self.ALF_REC), dtype=torch.float32, device=self.device)
+        self._ck(self.L.vvhip_alf_stats_plane(self.ctx, org.buf_ptr, org.stride, rec.buf_ptr, rec.stride, rec.width, rec.height, ctu_size, filter_length,
+                                              _ptr(d_cls) if d_cls is not None else None, vb_ctu_height, vb_pos, _ptr(out)))
+        return out
+
     # ---- SURVEY 8f rank 2: MCTF apply side ----
     REF_STRENGTHS = ((0.84375, 0.6, 0.4286, 0.3333, 0.2727, 0.2308), (1.12500, 1.0, 0.7143, 0.5556, 0.4545, 0.3846))      # MCTF.cpp:112-117
 
