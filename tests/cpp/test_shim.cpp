@@ -5,6 +5,9 @@
 // Needs a GPU.  Exit code 0 = all equal (tolerance 0).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
 #include <random>
 #include <vector>
 
@@ -261,10 +264,43 @@ static void test_MCTF()
   for( int i = 0; i < nb; i++ ) { CHECK_EQ( got[i].x, exp[i].x, "ME x" ); CHECK_EQ( got[i].y, exp[i].y, "ME y" ); CHECK_EQ( got[i].error, exp[i].error, "ME error" ); CHECK_EQ( got[i].rmsme, exp[i].rmsme, "ME rmsme" ); }
 }
 
+static void test_ALF()
+{
+  // ref = oracle (pinned to deriveClassificationBlk / getPreBlkStats), opt = vvhip::ALFOps; floats compared by their bit patterns
+  ALFOps opt;
+  const int W = 200, H = 136, B = 8, stride = W + 2 * B, ctu = 64;
+  std::vector<Pel> recP( ( size_t ) stride * ( H + 2 * B ) ), orgP( ( size_t ) W * H );
+  for( int y = 0; y < H; y++ ) for( int x = 0; x < W; x++ )
+  {
+    const int v = 512 + ( int ) ( 150 * std::sin( x / 9.0 ) * std::cos( y / 7.0 ) ) + ( int ) ( rng() % 31 ) - 15;
+    recP[( size_t ) ( y + B ) * stride + x + B] = ( Pel ) std::min( 1023, std::max( 0, v ) );
+    orgP[( size_t ) y * W + x] = ( Pel ) std::min( 1023, std::max( 0, v + ( int ) ( rng() % 21 ) - 10 ) );
+  }
+  for( int y = 0; y < H + 2 * B; y++ ) for( int x = 0; x < stride; x++ )                     // replicated border
+  {
+    const int sy = std::min( H - 1, std::max( 0, y - B ) ), sx = std::min( W - 1, std::max( 0, x - B ) );
+    recP[( size_t ) y * stride + x] = recP[( size_t ) ( sy + B ) * stride + sx + B];
+  }
+  const Pel* rec = recP.data() + ( size_t ) B * stride + B;
+  std::vector<uint8_t> cg( ( W / 4 ) * ( H / 4 ) * 2 ), ce( cg.size() );
+  if( !opt.deriveClassification( rec, stride, W, H, 10, ctu, ctu - 4, cg.data() ) ) { printf( "ALF classification refused\n" ); failures++; return; }
+  orc_alf_classify( rec, stride, W, H, 14, ctu, ctu - 4, ce.data() );
+  for( size_t i = 0; i < cg.size(); i++ ) CHECK_EQ( cg[i], ce[i], "ALF class" );
+  const int ctus = ( ( W + ctu - 1 ) / ctu ) * ( ( H + ctu - 1 ) / ctu );
+  std::vector<float> sg( ( size_t ) ctus * 25 * ORC_ALF_REC ), se( sg.size() );
+  if( !opt.getStatistics( orgP.data(), W, rec, stride, W, H, ctu, 7, ce.data(), ctu, ctu - 4, sg.data() ) ) { printf( "ALF statistics refused\n" ); failures++; return; }
+  orc_alf_stats_plane( orgP.data(), W, rec, stride, W, H, ctu, 7, ce.data(), ctu, ctu - 4, se.data() );
+  for( size_t i = 0; i < sg.size(); i++ ) { uint32_t a, b; memcpy( &a, &sg[i], 4 ); memcpy( &b, &se[i], 4 ); CHECK_EQ( a, b, "ALF luma statistics" ); }
+  std::vector<float> cgS( ( size_t ) ctus * ORC_ALF_REC ), ceS( cgS.size() );
+  if( !opt.getStatistics( orgP.data(), W, rec, stride, W, H, ctu, 5, nullptr, ctu, ctu - 2, cgS.data() ) ) { printf( "ALF chroma statistics refused\n" ); failures++; return; }
+  orc_alf_stats_plane( orgP.data(), W, rec, stride, W, H, ctu, 5, nullptr, ctu, ctu - 2, ceS.data() );
+  for( size_t i = 0; i < cgS.size(); i++ ) { uint32_t a, b; memcpy( &a, &cgS[i], 4 ); memcpy( &b, &ceS[i], 4 ); CHECK_EQ( a, b, "ALF 5x5 statistics" ); }
+}
+
 int main()
 {
-  try { test_RdCost(); test_TCoeffOps(); test_InterpolationFilter(); test_MCTF(); }
+  try { test_RdCost(); test_TCoeffOps(); test_InterpolationFilter(); test_MCTF(); test_ALF(); }
   catch( const std::exception& e ) { printf( "EXCEPTION: %s\n", e.what() ); return 2; }
-  printf( failures ? "FAILED: %d mismatches\n" : "shim parity OK (RdCost, TCoeffOps/Quant, MCTF)\n", failures );
+  printf( failures ? "FAILED: %d mismatches\n" : "shim parity OK (RdCost, TCoeffOps/Quant, InterpolationFilter, MCTF, ALF)\n", failures );
   return failures ? 1 : 0;
 }

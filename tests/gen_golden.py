@@ -175,6 +175,35 @@ def gen_dmvr(R, R0):
     np.savez_compressed(os.path.join(OUT, "dmvr.npz"), **d)
 
 
+def gen_alf(R, R0):
+    """ALF classification and covariance statistics of the reference (x86 row == scalar row) -> alf.npz.
+    Statistics are stored as the float32 bit patterns of two CTUs per case (the whole array is checked by its sum of bit patterns)."""
+    rng = np.random.default_rng(20260928)
+    d = {}
+    cases = []
+    for k, (h, w, ctu, smooth) in enumerate(((144, 208, 128, False), (136, 200, 64, True), (72, 96, 32, True))):
+        yy, xx = np.mgrid[0:h, 0:w]
+        if smooth:
+            base = 512 + 90 * np.sin(xx / 41.0) * np.cos(yy / 33.0) + 40 * np.sin((xx - yy) / 17.0) + rng.normal(0, 1.5, (h, w)) + 25 * (((xx // 24) + (yy // 40)) % 2)
+        else:
+            base = 512 + 200 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 80 * np.sin((xx + 2 * yy) / 5.0) + rng.normal(0, 20, (h, w))
+        rec = np.clip(base, 0, 1023).astype(np.int16)
+        org = np.clip(rec.astype(np.int32) + rng.integers(-12, 13, (h, w)), 0, 1023).astype(np.int16)
+        cls = R.alf_classify(rec, 10, ctu, ctu - 4)
+        assert np.array_equal(cls, R0.alf_classify(rec, 10, ctu, ctu - 4))
+        st = R.alf_stats_plane(org, rec, ctu, 7, cls, ctu, ctu - 4)
+        assert np.array_equal(st.view(np.uint32), R0.alf_stats_plane(org, rec, ctu, 7, cls, ctu, ctu - 4).view(np.uint32))
+        c_org, c_rec = np.ascontiguousarray(org[::2, ::2]), np.ascontiguousarray(rec[::2, ::2])
+        sc = R.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2)
+        assert np.array_equal(sc.view(np.uint32), R0.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2).view(np.uint32))
+        d["c%d_org" % k] = org; d["c%d_rec" % k] = rec; d["c%d_cls" % k] = cls
+        d["c%d_luma_head" % k] = st[:2].view(np.uint32).copy(); d["c%d_luma_sum" % k] = np.array([int(st.view(np.uint32).astype(np.uint64).sum())], np.uint64)
+        d["c%d_chroma_head" % k] = sc[:2].view(np.uint32).copy(); d["c%d_chroma_sum" % k] = np.array([int(sc.view(np.uint32).astype(np.uint64).sum())], np.uint64)
+        cases.append((h, w, ctu))
+    d["cases"] = np.array(cases, np.int32)
+    np.savez_compressed(os.path.join(OUT, "alf.npz"), **d)
+
+
 def main():
     build_ref()
     R = RefLib(1)
@@ -184,6 +213,7 @@ def main():
     gen_interp(R, R0)
     gen_mctf_apply(R, R0)
     gen_dmvr(R, R0)
+    gen_alf(R, R0)
     if "--ext-only" in sys.argv:
         return
     rng = np.random.default_rng(20260923)

@@ -221,3 +221,18 @@ def check_dmvr(be):
     for (si, x0, y0, f0x, f0y, f1x, f1y, dx, dy), exp in zip(g["cases"], g["out"]):
         got = be.dmvr_refine((r0, int(y0), int(x0)), (g["r1_%d" % si], int(y0), int(x0)), (int(f0x), int(f0y)), (int(f1x), int(f1y)), int(dx), int(dy), 10)
         assert tuple(got) == tuple(int(v) for v in exp), (si, x0, y0, dx, dy, got, exp)
+
+
+def check_alf(be):
+    """ALF classification + covariance statistics fixtures (float32 bit patterns)"""
+    g = load("alf")
+    for k, (h, w, ctu) in enumerate(g["cases"]):
+        org, rec = g["c%d_org" % k], g["c%d_rec" % k]
+        ctu = int(ctu)
+        cls = be.alf_classify(rec, 10, ctu, ctu - 4)
+        assert np.array_equal(np.asarray(cls), g["c%d_cls" % k]), ("alf classes", k)
+        st = np.asarray(be.alf_stats_plane(org, rec, ctu, 7, g["c%d_cls" % k], ctu, ctu - 4)).view(np.uint32)
+        assert np.array_equal(st[:2], g["c%d_luma_head" % k]) and int(st.astype(np.uint64).sum()) == int(g["c%d_luma_sum" % k][0]), ("alf luma", k)
+        c_org, c_rec = np.ascontiguousarray(org[::2, ::2]), np.ascontiguousarray(rec[::2, ::2])
+        sc = np.asarray(be.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2)).view(np.uint32)
+        assert np.array_equal(sc[:2], g["c%d_chroma_head" % k]) and int(sc.astype(np.uint64).sum()) == int(g["c%d_chroma_sum" % k][0]), ("alf chroma", k)

@@ -86,6 +86,15 @@ class HipBackend:
         return int(r["mvd_x"]), int(r["mvd_y"]), int(r["min_cost"])
 
     # ---- MCTF apply ----
+    def alf_classify(self, rec, bit_depth=10, vb_ctu_height=128, vb_pos=124):
+        return self.hp.alf_classify(self.hp.plane(np.ascontiguousarray(rec, np.int16), 8), bit_depth, vb_ctu_height, vb_pos).cpu().numpy()
+
+    def alf_stats_plane(self, org, rec, ctu_size, filter_length, cls=None, vb_ctu_height=128, vb_pos=124):
+        hp = self.hp
+        d_cls = hp.to_device(np.ascontiguousarray(cls, np.uint8)) if cls is not None else None
+        return hp.alf_stats_plane(hp.plane(np.ascontiguousarray(org, np.int16), 0), hp.plane(np.ascontiguousarray(rec, np.int16), 8), ctu_size, filter_length,
+                                  d_cls, vb_ctu_height, vb_pos).cpu().numpy()
+
     def mctf_bilateral(self, org, refs, mvs, ref_index, bit_depth=10, qp=32, unit=16, low_res=True, pic_reordering=True, overall_strength=0.95):
         return self.hp.mctf_bilateral(org, refs, mvs, ref_index, bit_depth, qp, unit, low_res, pic_reordering, overall_strength)
 

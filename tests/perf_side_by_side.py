@@ -39,6 +39,7 @@ def main():
     L = R.L
     W, H = 1920, 1080
     cur, ref = synth_frame_pair(W, H, W)
+    yy_, xx_ = np.mgrid[0:H, 0:W]
     rows = []
 
     # ---- f1: 16 sub-pel HAD candidates per 16x16 block
@@ -118,6 +119,28 @@ def main():
     diff = max(int(np.abs(fout[c].visible().cpu().numpy().astype(np.int32) - cpu_f[c]).max()) for c in range(3))
     rows.append(("f2 MCTF bilateral filter, 1080p Y+U+V, 4 references (CPU: reference AVX2 row, 1 thread, incl. plane set-up; max |diff| %d, allowed 1)" % diff,
                  us_f, t_f * 1e6, float("nan"), diff <= 1))
+
+    # ---- f4: ALF encoder statistics (classification + luma 7x7 + two chroma 5x5 planes), 1080p
+    a_rec = np.clip(512 + 140 * np.sin(xx_ / 23.0) * np.cos(yy_ / 19.0) + 60 * np.sin((xx_ + 2 * yy_) / 9.0) + rng.normal(0, 6, (H, W)) + 30 * (((xx_ // 48) + (yy_ // 32)) % 2), 0, 1023).astype(np.int16)
+    a_org = np.clip(a_rec.astype(np.int32) + rng.integers(-10, 11, (H, W)), 0, 1023).astype(np.int16)
+    c_rec, c_org = np.ascontiguousarray(a_rec[::2, ::2][:536]), np.ascontiguousarray(a_org[::2, ::2][:536])
+    prec, porg, pcr, pco = hp.plane(a_rec, 8), hp.plane(a_org, 0), hp.plane(c_rec, 8), hp.plane(c_org, 0)
+    d_cls = hp.alf_classify(prec)
+    st = hp.alf_stats_plane(porg, prec, 128, 7, d_cls)
+    sc = hp.alf_stats_plane(pco, pcr, 64, 5, None, 64, 62)
+    def run_alf():
+        hp.alf_classify(prec, out=d_cls)
+        hp.alf_stats_plane(porg, prec, 128, 7, d_cls, out=st)
+        hp.alf_stats_plane(pco, pcr, 64, 5, None, 64, 62, out=sc)
+        hp.alf_stats_plane(pco, pcr, 64, 5, None, 64, 62, out=sc)
+    us_alf = gpu_us(run_alf, 10)
+    t0 = time.perf_counter()
+    cr = R.alf_classify(a_rec); sr = R.alf_stats_plane(a_org, a_rec, 128, 7, cr)
+    scr = R.alf_stats_plane(c_org, c_rec, 64, 5, None, 64, 62); R.alf_stats_plane(c_org, c_rec, 64, 5, None, 64, 62)
+    t_alf = time.perf_counter() - t0
+    same = np.array_equal(d_cls.cpu().numpy(), cr) and np.array_equal(st.cpu().numpy().view(np.uint32), sr.view(np.uint32)) and np.array_equal(sc.cpu().numpy().view(np.uint32), scr.view(np.uint32))
+    rows.append(("f4 ALF statistics, 1080p: classification of 129 600 blocks + covariance records of 135 luma CTUs x 25 classes + 2 chroma planes (CPU: reference AVX2 row, "
+                 "1 thread, incl. the wrapper's plane padding; floats compared bit for bit)", us_alf, t_alf * 1e6, float("nan"), same))
 
     print("| row / work list | MI355X (us) | reference AVX2, 1 thread (us) | reference AVX2, %d threads (us) | results equal |" % args.threads)
     print("|---|---|---|---|---|")

@@ -33,6 +33,10 @@ def test_golden_dmvr(hip):
     G.check_dmvr(hip)
 
 
+def test_golden_alf(hip):
+    G.check_alf(hip)
+
+
 def test_golden_mctf_apply(hip):
     G.check_mctf_apply(hip)
 

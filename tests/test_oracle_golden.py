@@ -49,3 +49,7 @@ def test_mctf_apply(oracle):
 
 def test_dmvr(oracle):
     G.check_dmvr(oracle)
+
+
+def test_alf(oracle):
+    G.check_alf(oracle)

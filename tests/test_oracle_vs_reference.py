@@ -503,3 +503,37 @@ def test_dmvr_refine(oracle, reflib):
                     assert a == b, (bd, sx, sy, dx, dy, k, a, b)
                     moved += a[0] != 0 or a[1] != 0
     assert moved > 50
+
+
+def _alf_case(rng, h, w, smooth):
+    yy, xx = np.mgrid[0:h, 0:w]
+    if smooth:
+        base = 512 + 90 * np.sin(xx / 41.0) * np.cos(yy / 33.0) + 40 * np.sin((xx - yy) / 17.0) + rng.normal(0, 1.5, (h, w)) + 25 * (((xx // 24) + (yy // 40)) % 2)
+    else:
+        base = 512 + 200 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 80 * np.sin((xx + 2 * yy) / 5.0) + rng.normal(0, 20, (h, w))
+    rec = np.clip(base, 0, 1023).astype(np.int16)
+    org = np.clip(rec.astype(np.int32) + rng.integers(-12, 13, (h, w)), 0, 1023).astype(np.int16)
+    return org, rec
+
+
+@pytest.mark.parametrize("cfg", [(272, 400, 128, False, 10), (264, 392, 128, True, 10), (136, 200, 64, True, 8), (64, 64, 32, False, 10)])
+def test_alf_classification_and_statistics(oracle, reflib, cfg):
+    """deriveClassificationBlk and getPreBlkStats (+ the accumulate table entry) of the reference, scalar and x86 rows, against the
+    restatement: classes equal, covariance floats bit-identical (the additions happen in the same order), partial CTUs and virtual-boundary rows"""
+    h, w, ctu, smooth, bd = cfg
+    org, rec = _alf_case(np.random.default_rng(800 + h), h, w, smooth)
+    if bd == 8:
+        org, rec = (org >> 2).astype(np.int16), (rec >> 2).astype(np.int16)
+    cls = oracle.alf_classify(rec, bd, ctu, ctu - 4)
+    assert np.array_equal(cls, reflib.alf_classify(rec, bd, ctu, ctu - 4))
+    assert cls[..., 0].max() < 25 and cls[..., 1].max() < 4
+    a = oracle.alf_stats_plane(org, rec, ctu, 7, cls, ctu, ctu - 4)
+    b = reflib.alf_stats_plane(org, rec, ctu, 7, cls, ctu, ctu - 4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    c_org, c_rec = np.ascontiguousarray(org[::2, ::2]), np.ascontiguousarray(rec[::2, ::2])
+    if c_rec.shape[0] % 4 == 0 and c_rec.shape[1] % 4 == 0:
+        a = oracle.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2)
+        b = reflib.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    cls2 = cls.copy(); cls2[1::2, ::3] = 255
+    assert np.array_equal(oracle.alf_stats_plane(org, rec, ctu, 7, cls2, ctu, ctu - 4).view(np.uint32), reflib.alf_stats_plane(org, rec, ctu, 7, cls2, ctu, ctu - 4).view(np.uint32))

@@ -680,6 +680,62 @@ bool DMVROps::refineCu( const Pel* ref0, int stride0, int fx0, int fy0, const Pe
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------ ALFOps
+namespace {
+// stages a plane with its 4-sample border compactly: returns the device pointer of sample (0,0) and the pitch
+int16_t* stageBordered( Device& dev, const Pel* p, int stride, int w, int h, int border, size_t slotOffset, int& pitch )
+{
+  pitch = ( w + 2 * border + 7 ) & ~7;
+  std::vector<Pel> host( ( size_t ) pitch * ( h + 2 * border ) );
+  for( int y = -border; y < h + border; y++ ) memcpy( &host[( size_t ) ( y + border ) * pitch], p + ( ptrdiff_t ) y * stride - border, sizeof( Pel ) * ( w + 2 * border ) );
+  int16_t* base = dev.staging( slotOffset + host.size() * sizeof( Pel ) + 256 ) + slotOffset / sizeof( Pel );
+  dev.check( vvhip_upload( dev.ctx(), base, host.data(), host.size() * sizeof( Pel ) ), "ALF plane" );
+  return base + ( size_t ) border * pitch + border;
+}
+} // namespace
+
+bool ALFOps::deriveClassification( const Pel* rec, int recStride, int width, int height, int bitDepth, int vbCTUHeight, int vbPos, uint8_t* cls )
+{
+  if( ( width & 3 ) || ( height & 3 ) || width < 4 || height < 4 ) return false;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  int pitch;
+  const int16_t* dRec = stageBordered( dev, rec, recStride, width, height, 4, 0, pitch );
+  const size_t n = ( size_t ) ( width / 4 ) * ( height / 4 ) * 2;
+  uint8_t* dCls = static_cast<uint8_t*>( dev.stagingAux( n + 64 ) );
+  dev.check( vvhip_alf_classify( dev.ctx(), dRec, pitch, width, height, bitDepth, vbCTUHeight, vbPos, dCls ), "vvhip_alf_classify" );
+  dev.check( vvhip_download( dev.ctx(), cls, dCls, n ), "ALF classes" );
+  return true;
+}
+
+bool ALFOps::getStatistics( const Pel* org, int orgStride, const Pel* rec, int recStride, int width, int height, int ctuSize, int filterLength,
+                            const uint8_t* cls, int vbCTUHeight, int vbPos, float* out )
+{
+  if( ( width & 3 ) || ( height & 3 ) || width < 4 || height < 4 || ( filterLength != 7 && filterLength != 5 ) || ctuSize > 128 ) return false;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  // one staging allocation: [rec with border][org compact]
+  const int recPitchGuess = ( width + 8 + 7 ) & ~7;
+  const size_t recBytes = ( ( size_t ) recPitchGuess * ( height + 8 ) * sizeof( Pel ) + 255 ) & ~( size_t ) 255;
+  const int orgPitch = ( width + 7 ) & ~7;
+  std::vector<Pel> horg( ( size_t ) orgPitch * height );
+  for( int y = 0; y < height; y++ ) memcpy( &horg[( size_t ) y * orgPitch], org + ( ptrdiff_t ) y * orgStride, sizeof( Pel ) * width );
+  dev.staging( recBytes + horg.size() * sizeof( Pel ) + 512 );                         // grow once, so that the second request does not move the first
+  int pitch;
+  const int16_t* dRec = stageBordered( dev, rec, recStride, width, height, 4, 0, pitch );
+  int16_t* dOrg = dev.staging( recBytes + horg.size() * sizeof( Pel ) + 512 ) + recBytes / sizeof( Pel );
+  dev.check( vvhip_upload( dev.ctx(), dOrg, horg.data(), horg.size() * sizeof( Pel ) ), "ALF org plane" );
+  const int numClasses = cls ? 25 : 1, ctus = ( ( width + ctuSize - 1 ) / ctuSize ) * ( ( height + ctuSize - 1 ) / ctuSize );
+  const size_t nCls = cls ? ( size_t ) ( width / 4 ) * ( height / 4 ) * 2 : 0, outBytes = ( size_t ) ctus * numClasses * VVHIP_ALF_REC * sizeof( float );
+  char* aux = static_cast<char*>( dev.stagingAux( ( ( nCls + 255 ) & ~( size_t ) 255 ) + outBytes + 64 ) );
+  float* dOut = reinterpret_cast<float*>( aux + ( ( nCls + 255 ) & ~( size_t ) 255 ) );
+  if( cls ) dev.check( vvhip_upload( dev.ctx(), aux, cls, nCls ), "ALF classes" );
+  dev.check( vvhip_alf_stats_plane( dev.ctx(), dOrg, orgPitch, dRec, pitch, width, height, ctuSize, filterLength, cls ? reinterpret_cast<const uint8_t*>( aux ) : nullptr,
+                                    vbCTUHeight, vbPos, dOut ), "vvhip_alf_stats_plane" );
+  dev.check( vvhip_download( dev.ctx(), out, dOut, outBytes ), "ALF statistics" );
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ MCTFOps
 namespace {
 

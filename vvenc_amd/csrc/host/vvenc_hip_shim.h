@@ -185,6 +185,18 @@ struct DMVROps
                  int16_t* mvd, uint64_t* minCost );
 };
 
+// ALF encoder statistics: whole-plane forms of AdaptiveLoopFilter::m_deriveClassificationBlk (CommonLib/AdaptiveLoopFilter.h,
+// table entry set at AdaptiveLoopFilter.cpp:73) and EncAdaptiveLoopFilter::getPreBlkStats + m_getPreBlkStatsAccum (EncAdaptiveLoopFilter.h:438).
+// rec points at sample (0,0) of a plane that carries a replicated border of >= 4 samples (the reference's extended m_tempBuf).
+struct ALFOps
+{
+  // cls: 2 bytes per 4x4 block {classIdx, transposeIdx} = AlfClassifier, width/4 per row.  vbCTUHeight / vbPos = m_alfVBLumaCTUHeight / m_alfVBLumaPos.
+  bool deriveClassification( const Pel* rec, int recStride, int width, int height, int bitDepth, int vbCTUHeight, int vbPos, uint8_t* cls );
+  // per CTU and class one record of 183 floats: E[13][13], y[13], pixAcc (AlfCovariance with numBins 1); cls == nullptr: chroma (filterLength 5, one class)
+  bool getStatistics( const Pel* org, int orgStride, const Pel* rec, int recStride, int width, int height, int ctuSize, int filterLength,
+                      const uint8_t* cls, int vbCTUHeight, int vbPos, float* out );
+};
+
 // MCTF table, CommonLib/MCTF.h:160-170
 struct MCTFOps
 {
