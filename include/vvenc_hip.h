@@ -360,11 +360,13 @@ VVHIP_API int vvhip_dmvr_refine_batch( vvhip_ctx* ctx, const int16_t* d_ref0, in
  *       classes) or 5 with d_cls == NULL (chroma, one class; ctu_size / vb_* in chroma samples).  d_out: [numCtus][numClasses][183] floats per
  *       record = E[13][13] (row-major, symmetric), y[13], pixAcc.  The float additions happen in the reference's order (4x4 blocks of a
  *       CTU in raster order, per class): results are bit-identical.  Blocks classified {255, 255} are skipped (m_ALF_UNUSED_CLASSIDX).
+ *       d_init (optional, same layout as d_out; may alias it): the records the additions start from — a statistics unit that spans several CTUs
+ *       (alfUnitSize > CTU size: getStatisticsASU, :1568-1590) continues its float chains from CTU to CTU.
  * d_rec carries a replicated border of >= 4 samples (the reference reads its extended m_tempBuf); width / height multiples of 4.      */
 #define VVHIP_ALF_REC 183
 VVHIP_API int vvhip_alf_classify( vvhip_ctx* ctx, const int16_t* d_rec, int stride, int width, int height, int bit_depth, int vb_ctu_height, int vb_pos, uint8_t* d_cls );
 VVHIP_API int vvhip_alf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_rec, int rec_stride, int width, int height, int ctu_size,
-                                     int filter_length, const uint8_t* d_cls /* NULL: chroma */, int vb_ctu_height, int vb_pos, float* d_out );
+                                     int filter_length, const uint8_t* d_cls /* NULL: chroma */, int vb_ctu_height, int vb_pos, const float* d_init /* may be NULL */, float* d_out );
 
 #ifdef __cplusplus
 }

@@ -217,17 +217,18 @@ class _Base:
         f(*a, _p(cls))
         return cls
 
-    def alf_stats_plane(self, org, rec, ctu_size, filter_length, cls=None, vb_ctu_height=128, vb_pos=124):
+    def alf_stats_plane(self, org, rec, ctu_size, filter_length, cls=None, vb_ctu_height=128, vb_pos=124, init=None):
         """-> (numCtus, numClasses, ALF_REC) float32: E[13][13], y[13], pixAcc per CTU and class, accumulated in the reference's order"""
         h, w = rec.shape
         pad, m = self.alf_pad(rec)
         org = np.ascontiguousarray(org, np.int16)
         ncls = 25 if cls is not None else 1
         nctu = ((w + ctu_size - 1) // ctu_size) * ((h + ctu_size - 1) // ctu_size)
-        out = np.zeros((nctu, ncls, self.ALF_REC), np.float32)
+        out = np.zeros((nctu, ncls, self.ALF_REC), np.float32) if init is None else np.ascontiguousarray(init, np.float32).copy().reshape(nctu, ncls, self.ALF_REC)
         base = pad.ctypes.data + 2 * (m * pad.shape[1] + m)
         clsp = _p(np.ascontiguousarray(cls, np.uint8)) if cls is not None else None
-        f = getattr(self.L, self._pfx + "alf_stats_plane"); f.restype = None if self._pfx == "orc_" else C.c_int
+        assert init is None or self._pfx == "orc_"
+        f = getattr(self.L, self._pfx + ("alf_stats_plane" if init is None else "alf_stats_plane_acc")); f.restype = None if self._pfx == "orc_" else C.c_int
         if self._pfx == "orc_":
             f(_p(org), C.c_ssize_t(org.shape[1]), C.c_void_p(base), C.c_ssize_t(pad.shape[1]), w, h, ctu_size, filter_length, clsp, vb_ctu_height, vb_pos, _p(out))
         else:

@@ -97,3 +97,60 @@ patch("InterSearch.cpp", [
      "    m_cDistParam.cur.buf   = piRefPos;\n    uiDist = hipOk ? hipCost[i] : m_cDistParam.distFunc( m_cDistParam );\n"),
 ], sub="EncoderLib")
 print("hooked copies written to", out)
+
+# ALF statistics of a CTU: classification + covariance records from ONE hook call; the reference's own accumulators are
+# filled from the returned records (they start at zero: one CTU per statistics unit).  Virtual-boundary CTUs and non-linear ALF stay on the CPU.
+patch("EncAdaptiveLoopFilter.cpp", [
+    ("after", '#include "EncAdaptiveLoopFilter.h"', INC),
+    ("before", "    Area blk( xPos, yPos, width, height );\n    deriveClassification(",
+     "    bool hipAlf = false;\n"
+     "    if( g_vvhipHooks.alfCtu && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && numberOfComponents == 3 )\n"
+     "    {\n"
+     "      static thread_local std::vector<float> hipStats( 3 * MAX_NUM_ALF_CLASSES * 183 );\n"
+     "      static thread_local std::vector<uint8_t> hipCls( 32 * 32 * 2 );\n"
+     "      const UnitArea hArea( m_chromaFormat, Area( xPos, yPos, width, height ) );\n"
+     "      const Pel* hRec[3]; const Pel* hOrg[3]; int hRs[3], hOs[3]; bool hEn[3]; float* hSt[3];\n"
+     "      for( int c = 0; c < 3; c++ )\n"
+     "      {\n"
+     "        const CompArea& ca = hArea.block( ComponentID( c ) );\n"
+     "        hRec[c] = recYuv.get( ComponentID( c ) ).bufAt( ca ); hRs[c] = recYuv.get( ComponentID( c ) ).stride;\n"
+     "        hOrg[c] = orgYuv.get( ComponentID( c ) ).bufAt( ca ); hOs[c] = orgYuv.get( ComponentID( c ) ).stride;\n"
+     "        hEn[c] = m_alfFilterStatEnabled[c]; hSt[c] = hipStats.data() + ( size_t ) c * MAX_NUM_ALF_CLASSES * 183;\n"
+     "        // the records the float chains continue from: a statistics unit may span several CTUs (getStatisticsASU)\n"
+     "        const int nCls = c ? 1 : MAX_NUM_ALF_CLASSES, nCo = m_filterShapes[toChannelType( ComponentID( c ) )].numCoeff;\n"
+     "        if( hEn[c] ) for( int k = 0; k < nCls; k++ )\n"
+     "        {\n"
+     "          const AlfCovariance& cov = m_alfCovariance[c][asuRsAddr][k]; float* r = hSt[c] + ( size_t ) k * 183;\n"
+     "          memset( r, 0, 183 * sizeof( float ) );\n"
+     "          for( int a = 0; a < nCo; a++ ) { for( int b = 0; b < nCo; b++ ) r[a * 13 + b] = cov.E[0][0][a < b ? a : b][a < b ? b : a]; r[169 + a] = cov.y[0][a]; }\n"
+     "          r[182] = cov.pixAcc;\n"
+     "        }\n"
+     "      }\n"
+     "      hipAlf = g_vvhipHooks.alfCtu( hRec, hRs, hOrg, hOs, width, height, getComponentScaleX( COMP_Cb, m_chromaFormat ), m_inputBitDepth[CH_L],\n"
+     "                                    m_alfVBLumaCTUHeight, m_alfVBLumaPos, m_alfVBChmaCTUHeight, m_alfVBChmaPos, hEn, hipCls.data(), hSt );\n"
+     "      if( hipAlf )\n"
+     "      {\n"
+     "        AlfClassifier* cl = &m_classifier[numClassBlocksInCTU * ctuRsAddr];\n"
+     "        bool used[MAX_NUM_ALF_CLASSES] = { false };\n"
+     "        for( int i = 0; i < height; i += 4 ) for( int j = 0; j < width; j += 4 )\n"
+     "        {\n"
+     "          const uint8_t* c = hipCls.data() + 2 * ( ( i / 4 ) * ( width / 4 ) + j / 4 );\n"
+     "          cl[( i / 4 ) * ( MAX_CU_SIZE / 4 ) + j / 4] = AlfClassifier( c[0], c[1] ); used[c[0]] = true;\n"
+     "        }\n"
+     "        for( int c = 0; c < 3; c++ )\n"
+     "        {\n"
+     "          if( !hEn[c] ) continue;\n"
+     "          const int nCls = c ? 1 : MAX_NUM_ALF_CLASSES, nCo = m_filterShapes[toChannelType( ComponentID( c ) )].numCoeff;\n"
+     "          for( int k = 0; k < nCls; k++ )\n"
+     "          {\n"
+     "            if( c == 0 && !used[k] ) continue;\n"
+     "            AlfCovariance& cov = m_alfCovariance[c][asuRsAddr][k]; const float* r = hSt[c] + ( size_t ) k * 183;\n"
+     "            for( int a = 0; a < nCo; a++ ) { for( int b = 0; b < nCo; b++ ) cov.E[0][0][a][b] = r[a * 13 + b]; cov.y[0][a] = r[169 + a]; }\n"
+     "            cov.pixAcc = r[182]; cov.all0 = false;\n"
+     "          }\n"
+     "        }\n"
+     "      }\n"
+     "    }\n"
+     "    if( !hipAlf )\n    {\n"),
+    ("before", "  }  \n}\n\nvoid EncAdaptiveLoopFilter::copyCTUforALF(", "    }\n"),
+], sub="EncoderLib")

@@ -398,9 +398,23 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_after_simd_in
   t.fastInvCore[0] = invSlot<0>; t.fastInvCore[1] = invSlot<1>; t.fastInvCore[2] = invSlot<2>; t.fastInvCore[3] = invSlot<3>; t.fastInvCore[4] = invSlot<4>;
 }
 
+std::atomic<uint64_t> g_alfCtus{ 0 };
+bool alfCtu( const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int chromaShift,
+             int bitDepth, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] )
+{
+  static vvhip::ALFOps alf;
+  if( ( width & 3 ) || ( height & 3 ) || ( ( width >> chromaShift ) & 3 ) || ( ( height >> chromaShift ) & 3 ) ) return false;
+  if( !alf.deriveClassification( rec[0], recStride[0], width, height, bitDepth, vbLumaH, vbLumaPos, cls ) ) return false;
+  if( enabled[0] && !alf.getStatistics( org[0], orgStride[0], rec[0], recStride[0], width, height, 128, 7, cls, vbLumaH, vbLumaPos, stats[0], stats[0] ) ) return false;
+  for( int c = 1; c < 3; c++ )
+    if( enabled[c] && !alf.getStatistics( org[c], orgStride[c], rec[c], recStride[c], width >> chromaShift, height >> chromaShift, 128, 5, nullptr, vbChromaH, vbChromaPos, stats[c], stats[c] ) ) return false;
+  g_alfCtus++;
+  return true;
+}
+
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
 {
-  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round)
+  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round), bit11 ALF statistics per CTU (classification + covariance records)
   g_slotMask = mask;
   try
   {
@@ -417,6 +431,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
   g_vvhipHooks.mctfApply  = ( mask & 128 ) ? mctfApply : nullptr;
   g_vvhipHooks.patternCosts = ( mask & 256 ) ? patternCosts : nullptr;
   g_vvhipHooks.dmvrSearch = ( mask & 512 ) ? dmvrSearch : nullptr;
+  g_vvhipHooks.alfCtu = ( mask & 2048 ) ? alfCtu : nullptr; g_alfCtus = 0;
   g_vvhipHooks.tzReset = ( mask & 1024 ) ? tzReset : nullptr; g_vvhipHooks.tzPrefetch = ( mask & 1024 ) ? tzPrefetch : nullptr; g_vvhipHooks.tzLookup = ( mask & 1024 ) ? tzLookup : nullptr;
   g_tzRounds = 0; g_tzHits = 0;
   g_dmvrCalls = 0;
@@ -436,4 +451,5 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
   if( n > 11 ) out[11] = g_dmvrCalls;
   if( n > 12 ) out[12] = g_tzRounds;
   if( n > 13 ) out[13] = g_tzHits;
+  if( n > 14 ) out[14] = g_alfCtus;
 }

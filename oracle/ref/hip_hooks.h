@@ -29,6 +29,9 @@ struct VvhipHooks
   bool ( *dmvrSearch )( const int16_t* ref0, int stride0, int fx0, int fy0, const int16_t* ref1, int stride1, int fx1, int fy1, int cuWidth, int cuHeight, int dx, int dy, int bitDepth,
                         int16_t* mvd, uint64_t* minCost );
   bool ( *mctfApply )( const vvenc::MCTF*, const vvenc::PelStorage& orgPic, void* srcFrameInfoDeque, vvenc::PelStorage& newOrgPic, double overallStrength );
+  // ALF statistics of one CTU: classes of the luma 4x4 blocks and the covariance records of up to three components
+  bool ( *alfCtu )( const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int chromaShift,
+                    int bitDepth, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls /* [h/4][w/4][2] */, float* const stats[3] /* in: the records to continue from, out: updated */ );
   bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel, int refPoc, int curPoc );
 };
 extern VvhipHooks g_vvhipHooks;

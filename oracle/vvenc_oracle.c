@@ -1357,6 +1357,14 @@ void orc_alf_stats_plane(const int16_t *org, ptrdiff_t orgStride, const int16_t 
 {
   const int numClasses = cls ? 25 : 1, ctusX = (width + ctuSize - 1) / ctuSize, ctusY = (height + ctuSize - 1) / ctuSize;
   memset(out, 0, sizeof(float) * (size_t)ctusX * ctusY * numClasses * ORC_ALF_REC);
+  orc_alf_stats_plane_acc(org, orgStride, rec, recStride, width, height, ctuSize, filterLength, cls, vbCTUHeight, vbPos, out);
+}
+
+/* the same walk continuing from the records already in out: what a statistics unit of several CTUs does (getStatisticsASU :1568-1590) */
+void orc_alf_stats_plane_acc(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int width, int height, int ctuSize, int filterLength,
+                             const uint8_t *cls, int vbCTUHeight, int vbPos, float *out)
+{
+  const int numClasses = cls ? 25 : 1, ctusX = (width + ctuSize - 1) / ctuSize, ctusY = (height + ctuSize - 1) / ctuSize;
   for (int cy = 0; cy < ctusY; cy++)
     for (int cx = 0; cx < ctusX; cx++)
     {

@@ -96,6 +96,8 @@ void orc_alf_stats_area(const int16_t *org, ptrdiff_t orgStride, const int16_t *
                         const uint8_t *cls /* NULL: one class */, int clsStride /* blocks per picture row */, int vbCTUHeight, int vbPos, float *out /* [numClasses][ORC_ALF_REC], accumulated into */);
 void orc_alf_stats_plane(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int width, int height, int ctuSize, int filterLength,
                          const uint8_t *cls, int vbCTUHeight, int vbPos, float *out /* [numCtus][numClasses][ORC_ALF_REC], zeroed here */);
+void orc_alf_stats_plane_acc(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int width, int height, int ctuSize, int filterLength,
+                             const uint8_t *cls, int vbCTUHeight, int vbPos, float *out /* continues from the records already there */);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(14, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 14); calls = [int(x) for x in c]
+    c = np.zeros(15, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 15); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -163,6 +163,34 @@ def test_hip_dmvr_search_bitstream_identical(clip):
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][11] > 10, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+def test_hip_alf_statistics_bitstream_identical():
+    """SURVEY 8f rank 4 inside the real encoder: every CTU's ALF classification and covariance records (luma 7x7 x 25 classes, both chroma 5x5) come from the
+    device (hook mask 2048, vvhip::ALFOps) instead of deriveClassification / getPreBlkStats.  The ALF filter derivation works on these floats — a single
+    differently rounded sum can change a coefficient — so identical bitstreams pin the float accumulation order in the real pipeline."""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=2048))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][14] > 4, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+def test_hip_alf_statistics_1080p_bitstream_identical():
+    """the same at 1080p (preset faster: 64x64 CTUs inside 128x128 statistics units, so the float chains continue from CTU to CTU through the
+    start records): 510 CTUs per ALF picture, 8 encoder threads"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    import e2e_fps
+    res = [e2e_fps.run(dict(w=1920, h=1080, frames=9, threads=8, mask=m)) for m in (0, 2048)]
+    print(res)
+    assert res[1]["calls"][14] >= 510, res[1]["calls"]
+    assert res[0]["md5"] == res[1]["md5"] and res[0]["bytes"] == res[1]["bytes"], res
 
 
 @pytest.mark.gpu

@@ -692,6 +692,13 @@ def test_alf_classification_and_statistics_vs_oracle(hip, oracle, cfg):
         got = hp.alf_stats_plane(pco, pcr, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2).cpu().numpy()
         exp = oracle.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2)
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), ("chroma", np.abs(got - exp).max())
+    # chains continued from given records (statistics units spanning several CTUs): a second picture accumulated onto the first one's records
+    org2, rec2 = _alf_pictures(np.random.default_rng(900 + h), h, w, not smooth)
+    p2r, p2o = hp.plane(rec2, 8), hp.plane(org2, 0)
+    first = hp.alf_stats_plane(porg, prec, ctu, 7, d_cls, vbh, vbp)
+    got = hp.alf_stats_plane(p2o, p2r, ctu, 7, d_cls, vbh, vbp, init=first, out=first).cpu().numpy()
+    exp = oracle.alf_stats_plane(org2, rec2, ctu, 7, exp_cls, vbh, vbp, init=oracle.alf_stats_plane(org, rec, ctu, 7, exp_cls, vbh, vbp))
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), "continued chains"
     # blocks marked unused are skipped
     cls2 = exp_cls.copy(); cls2[::3, 1::2] = 255
     got = hp.alf_stats_plane(porg, prec, ctu, 7, hp.to_device(cls2), vbh, vbp).cpu().numpy()

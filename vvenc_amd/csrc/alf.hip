@@ -76,7 +76,7 @@ alfClassifyKernel( const int16_t* __restrict__ rec, int stride, int width, int h
 
 struct AlfStatArgs
 {
-  const int16_t* org; const int16_t* rec; const uint8_t* cls; int32_t* sums; float* out;
+  const int16_t* org; const int16_t* rec; const uint8_t* cls; int32_t* sums; const float* init; float* out;
   int orgStride, recStride, width, height, ctuSize, ctusX, nc, shape, vbH, vbPos, blocksPerCtuRow;
 };
 
@@ -192,6 +192,13 @@ alfOrderedAddKernel( AlfStatArgs A )
   f32x32 acc;
 #pragma unroll
   for( int c = 0; c < 32; c++ ) acc[c] = 0.0f;
+  if( A.init && tid < nE )                                     // continue the chains of an earlier CTU of the same statistics unit
+  {
+    int ra, rb; alfEntryRows( tid, nc, ra, rb );
+    const float* in = A.init + ( size_t ) ctu * NCLS * ALF_REC + ( rb == 13 ? ( ra == 13 ? 182 : 169 + ra ) : ra * 13 + rb );
+#pragma unroll
+    for( int c = 0; c < NCLS; c++ ) acc[c] = in[c * ALF_REC];
+  }
   int clsRow[ALF_MAXB];
 #pragma unroll
   for( int r = 0; r < ALF_MAXB; r++ )
@@ -289,14 +296,14 @@ int vvhip_alf_classify( vvhip_ctx* ctx, const int16_t* d_rec, int stride, int wi
 }
 
 int vvhip_alf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_rec, int rec_stride, int width, int height, int ctu_size,
-                           int filter_length, const uint8_t* d_cls, int vb_ctu_height, int vb_pos, float* d_out )
+                           int filter_length, const uint8_t* d_cls, int vb_ctu_height, int vb_pos, const float* d_init, float* d_out )
 {
   if( !ctx ) return VVHIP_E_ARG;
   if( width < 4 || height < 4 || ( width & 3 ) || ( height & 3 ) || ( filter_length != 7 && filter_length != 5 ) || ctu_size < 8 || ctu_size > 128 || ( ctu_size & 3 ) ||
       vb_ctu_height < 4 || ( vb_ctu_height & ( vb_ctu_height - 1 ) ) || vb_pos < 0 || !d_org || !d_rec || !d_out )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_alf_stats_plane: %dx%d (multiples of 4), CTU %d (<= 128), filter length %d (7 luma / 5 chroma)", width, height, ctu_size, filter_length );
   AlfStatArgs A;
-  A.org = d_org; A.rec = d_rec; A.cls = d_cls; A.out = d_out; A.orgStride = org_stride; A.recStride = rec_stride; A.width = width; A.height = height;
+  A.org = d_org; A.rec = d_rec; A.cls = d_cls; A.init = d_init; A.out = d_out; A.orgStride = org_stride; A.recStride = rec_stride; A.width = width; A.height = height;
   A.ctuSize = ctu_size; A.ctusX = ( width + ctu_size - 1 ) / ctu_size; A.nc = filter_length * filter_length / 4 + 1;
   A.shape = filter_length == 7 ? 0 : 1; A.vbH = vb_ctu_height; A.vbPos = vb_pos; A.blocksPerCtuRow = ctu_size >> 2;
   static AlfTaps taps; static bool built = false;

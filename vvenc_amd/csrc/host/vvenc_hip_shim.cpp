@@ -709,7 +709,7 @@ bool ALFOps::deriveClassification( const Pel* rec, int recStride, int width, int
 }
 
 bool ALFOps::getStatistics( const Pel* org, int orgStride, const Pel* rec, int recStride, int width, int height, int ctuSize, int filterLength,
-                            const uint8_t* cls, int vbCTUHeight, int vbPos, float* out )
+                            const uint8_t* cls, int vbCTUHeight, int vbPos, float* out, const float* init )
 {
   if( ( width & 3 ) || ( height & 3 ) || width < 4 || height < 4 || ( filterLength != 7 && filterLength != 5 ) || ctuSize > 128 ) return false;
   std::lock_guard<std::mutex> g( g_lock );
@@ -730,8 +730,9 @@ bool ALFOps::getStatistics( const Pel* org, int orgStride, const Pel* rec, int r
   char* aux = static_cast<char*>( dev.stagingAux( ( ( nCls + 255 ) & ~( size_t ) 255 ) + outBytes + 64 ) );
   float* dOut = reinterpret_cast<float*>( aux + ( ( nCls + 255 ) & ~( size_t ) 255 ) );
   if( cls ) dev.check( vvhip_upload( dev.ctx(), aux, cls, nCls ), "ALF classes" );
+  if( init ) dev.check( vvhip_upload( dev.ctx(), dOut, init, outBytes ), "ALF start records" );
   dev.check( vvhip_alf_stats_plane( dev.ctx(), dOrg, orgPitch, dRec, pitch, width, height, ctuSize, filterLength, cls ? reinterpret_cast<const uint8_t*>( aux ) : nullptr,
-                                    vbCTUHeight, vbPos, dOut ), "vvhip_alf_stats_plane" );
+                                    vbCTUHeight, vbPos, init ? dOut : nullptr, dOut ), "vvhip_alf_stats_plane" );
   dev.check( vvhip_download( dev.ctx(), out, dOut, outBytes ), "ALF statistics" );
   return true;
 }

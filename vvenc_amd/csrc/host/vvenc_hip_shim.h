@@ -192,9 +192,10 @@ struct ALFOps
 {
   // cls: 2 bytes per 4x4 block {classIdx, transposeIdx} = AlfClassifier, width/4 per row.  vbCTUHeight / vbPos = m_alfVBLumaCTUHeight / m_alfVBLumaPos.
   bool deriveClassification( const Pel* rec, int recStride, int width, int height, int bitDepth, int vbCTUHeight, int vbPos, uint8_t* cls );
-  // per CTU and class one record of 183 floats: E[13][13], y[13], pixAcc (AlfCovariance with numBins 1); cls == nullptr: chroma (filterLength 5, one class)
+  // per CTU and class one record of 183 floats: E[13][13], y[13], pixAcc (AlfCovariance with numBins 1); cls == nullptr: chroma (filterLength 5, one class);
+  // init (optional, same layout): the values the float chains start from (statistics units that span several CTUs)
   bool getStatistics( const Pel* org, int orgStride, const Pel* rec, int recStride, int width, int height, int ctuSize, int filterLength,
-                      const uint8_t* cls, int vbCTUHeight, int vbPos, float* out );
+                      const uint8_t* cls, int vbCTUHeight, int vbPos, float* out, const float* init = nullptr );
 };
 
 // MCTF table, CommonLib/MCTF.h:160-170
