@@ -196,14 +196,14 @@ def test_hip_alf_statistics_1080p_bitstream_identical():
 @pytest.mark.gpu
 def test_hip_everything_on_device_bitstream_identical():
     """all hooks at once on a larger clip (208x120 10-bit, 9 frames, 2 encoder threads): every kernel table, the interpolation tables, whole-picture
-    MCTF ME + filter, batched integer diamond rounds, batched sub-pel refinement stages and per-CU DMVR searches"""
+    MCTF ME + filter, batched integer diamond rounds, batched sub-pel refinement stages, per-CU DMVR searches and per-CTU ALF statistics"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
         pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
-    hip = run(dict(clip, hip=True, simd=None, mask=31 + 64 + 128 + 256 + 512 + 1024))
+    hip = run(dict(clip, hip=True, simd=None, mask=31 + 64 + 128 + 256 + 512 + 1024 + 2048))
     print("cpu", cpu, "hip", hip)
-    assert hip["calls"][0] > 1000 and hip["calls"][8] > 100 and hip["calls"][9] >= 1 and hip["calls"][10] > 50 and hip["calls"][11] > 5 and hip["calls"][12] > 50, hip["calls"]
+    assert hip["calls"][0] > 1000 and hip["calls"][8] > 100 and hip["calls"][9] >= 1 and hip["calls"][10] > 50 and hip["calls"][11] > 5 and hip["calls"][12] > 50 and hip["calls"][14] > 4, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
 
 

@@ -150,10 +150,11 @@ alfBlockSumsKernel( AlfStatArgs A, AlfTaps T )
     }
   }
   __syncthreads();
-  int32_t* sums = A.sums + ( ( size_t ) ctu * A.blocksPerCtuRow * A.blocksPerCtuRow + ( size_t ) blockIdx.y * A.blocksPerCtuRow ) * nE;
+  // layout [ctu][block row][entry][32 blocks]: kernel B's lane (= entry) reads one block row as 128 contiguous bytes
+  int32_t* sums = A.sums + ( ( size_t ) ctu * A.blocksPerCtuRow + blockIdx.y ) * ALF_NE * ALF_MAXB;
   for( int t = tid; t < nb * nE; t += 256 )
   {
-    const int b = t / nE, e = t - b * nE;
+    const int e = t / nb, b = t - e * nb;
     const int4* pa = reinterpret_cast<const int4*>( &sLoc[b][sPair[e][0]][0] );
     const int4* pb = reinterpret_cast<const int4*>( &sLoc[b][sPair[e][1]][0] );
     typedef short s2 __attribute__( ( ext_vector_type( 2 ) ) );
@@ -167,7 +168,7 @@ alfBlockSumsKernel( AlfStatArgs A, AlfTaps T )
       s = __builtin_amdgcn_sdot2( __builtin_bit_cast( s2, va.z ), __builtin_bit_cast( s2, vb.z ), s, false );
       s = __builtin_amdgcn_sdot2( __builtin_bit_cast( s2, va.w ), __builtin_bit_cast( s2, vb.w ), s, false );
     }
-    sums[t] = s;                                                                                // [block][entry], contiguous
+    sums[e * ALF_MAXB + b] = s;
   }
 }
 
@@ -187,7 +188,8 @@ alfOrderedAddKernel( AlfStatArgs A )
   const int nb = w >> 2, rows = h >> 2, nc = A.nc;
   const int nE = nc * ( nc + 1 ) / 2 + nc + 1;
   const int e = tid < nE ? tid : 0;
-  const int32_t* sums = A.sums + ( size_t ) ctu * A.blocksPerCtuRow * A.blocksPerCtuRow * nE + e;
+  const int4* sums = reinterpret_cast<const int4*>( A.sums + ( size_t ) ctu * A.blocksPerCtuRow * ALF_NE * ALF_MAXB + ( size_t ) e * ALF_MAXB );
+  constexpr int ROW_I4 = ALF_NE * ALF_MAXB / 4;                // int4 per block row
   typedef float f32x32 __attribute__( ( ext_vector_type( 32 ) ) );
   f32x32 acc;
 #pragma unroll
@@ -206,39 +208,30 @@ alfOrderedAddKernel( AlfStatArgs A )
     clsRow[r] = 0xffff;
     if( NCLS > 1 && r < rows && lane < nb ) { const uint8_t* c = A.cls + 2 * ( ( size_t ) ( ( y0 >> 2 ) + r ) * ( A.width >> 2 ) + ( x0 >> 2 ) + lane ); clsRow[r] = ( int ) c[0] | ( ( int ) c[1] << 8 ); }
   }
-  int sv[ALF_MAXB];
-#pragma unroll
-  for( int q = 0; q < ALF_MAXB; q++ ) sv[q] = q < nb ? sums[( size_t ) q * nE] : 0;
+  // ring of 4 block rows of sums (8 x 16-byte loads each): row br + 3 is requested before row br is added — the scratch array comes from
+  // HBM / Infinity Cache with ~2 us latency and a row's additions take ~0.6 us; two waves per CU own the whole register file
+  int4 r0[8], r1[8], r2[8], r3[8];
+#define ALF_FETCH( DST, R ) { const int rr_ = ( R ) < rows ? ( R ) : rows - 1; _Pragma( "unroll" ) for( int q = 0; q < 8; q++ ) DST[q] = sums[( size_t ) rr_ * ROW_I4 + q]; }
+#define ALF_ADD( SRC, R ) if( ( R ) < rows ) { int myCls = 0;                                                                            \
+    _Pragma( "unroll" ) for( int r = 0; r < ALF_MAXB; r++ ) myCls = r == ( R ) ? clsRow[r] : myCls;                                      \
+    _Pragma( "unroll" ) for( int q = 0; q < ALF_MAXB; q++ ) if( q < nb )                                                                 \
+    {                                                                                                                                    \
+      const int4 v_ = SRC[q >> 2];                                                                                                       \
+      const float f = ( float ) ( ( q & 3 ) == 0 ? v_.x : ( q & 3 ) == 1 ? v_.y : ( q & 3 ) == 2 ? v_.z : v_.w );                        \
+      if( NCLS == 1 ) acc[0] += f;                                                                                                       \
+      else { const int ct = __builtin_amdgcn_readlane( myCls, q ); if( ct != 0xffff ) acc[ct & 31] += f; }   /* 0xffff: m_ALF_UNUSED_CLASSIDX / _TRANSPOSIDX (:3416) */ \
+    } }
+  ALF_FETCH( r0, 0 ) ALF_FETCH( r1, 1 ) ALF_FETCH( r2, 2 )
 #pragma unroll 1
-  for( int br = 0; br < rows; br++ )
+  for( int br = 0; br < rows; br += 4 )
   {
-    int myCls = 0;
-#pragma unroll
-    for( int r = 0; r < ALF_MAXB; r++ ) myCls = r == br ? clsRow[r] : myCls;
-    int cur[ALF_MAXB];
-#pragma unroll
-    for( int q = 0; q < ALF_MAXB; q++ ) cur[q] = sv[q];
-    if( br + 1 < rows )
-    {
-      const int32_t* row = sums + ( size_t ) ( br + 1 ) * A.blocksPerCtuRow * nE;
-#pragma unroll
-      for( int q = 0; q < ALF_MAXB; q++ ) sv[q] = q < nb ? row[( size_t ) q * nE] : 0;
-    }
-#pragma unroll
-    for( int q = 0; q < ALF_MAXB; q++ )
-    {
-      if( q < nb )
-      {
-        const float f = ( float ) cur[q];
-        if( NCLS == 1 ) acc[0] += f;
-        else
-        {
-          const int ct = __builtin_amdgcn_readlane( myCls, q );
-          if( ct != 0xffff ) acc[ct & 31] += f;                                                 // 0xffff: m_ALF_UNUSED_CLASSIDX / _TRANSPOSIDX (:3416)
-        }
-      }
-    }
+    ALF_FETCH( r3, br + 3 ) ALF_ADD( r0, br )
+    ALF_FETCH( r0, br + 4 ) ALF_ADD( r1, br + 1 )
+    ALF_FETCH( r1, br + 5 ) ALF_ADD( r2, br + 2 )
+    ALF_FETCH( r2, br + 6 ) ALF_ADD( r3, br + 3 )
   }
+#undef ALF_FETCH
+#undef ALF_ADD
   // records: E symmetric (upper triangle mirrored, :3493-3512), y, pixAcc; slots of unused coefficients are 0
   float* out = A.out + ( size_t ) ctu * NCLS * ALF_REC;
   for( int t = tid; t < NCLS * ALF_REC; t += 128 )
@@ -309,8 +302,7 @@ int vvhip_alf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride,
   static AlfTaps taps; static bool built = false;
   if( !built ) { buildTaps( taps ); built = true; }
   const int ctus = A.ctusX * ( ( height + ctu_size - 1 ) / ctu_size );
-  const int nE = A.nc * ( A.nc + 1 ) / 2 + A.nc + 1;
-  const size_t need = ( size_t ) ctus * A.blocksPerCtuRow * A.blocksPerCtuRow * nE * sizeof( int32_t );      // per-block int32 sums between the two kernels
+  const size_t need = ( size_t ) ctus * A.blocksPerCtuRow * ALF_NE * ALF_MAXB * sizeof( int32_t );           // per-block int32 sums between the two kernels
   if( need > ctx->scratchBytes )
   {
     VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
