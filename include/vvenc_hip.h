@@ -368,6 +368,15 @@ VVHIP_API int vvhip_alf_classify( vvhip_ctx* ctx, const int16_t* d_rec, int stri
 VVHIP_API int vvhip_alf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_rec, int rec_stride, int width, int height, int ctu_size,
                                      int filter_length, const uint8_t* d_cls /* NULL: chroma */, int vb_ctu_height, int vb_pos, const float* d_init /* may be NULL */, float* d_out );
 
+/* CC-ALF statistics <- EncAdaptiveLoopFilter::getBlkStatsCcAlf per chroma CTU (EncoderLib/EncAdaptiveLoopFilter.cpp:6061-6357; local terms
+ * calcCovariance4CcAlf :6359-6422): 7 luma differences around the co-located luma sample against org - ALF-filtered chroma (d_slf_c).  One record of
+ * VVHIP_ALF_REC floats per chroma CTU: E[0..6][0..6] (row pitch 13), y[0..6], pixAcc; float additions in the reference's order (bit-identical).
+ * d_rec_luma carries a replicated border of >= 2 samples; shift_x / shift_y = chroma subsampling (4:2:0: 1, 1); vb_* and pic_height in luma samples
+ * (the last CTU row has no virtual boundary, :6079-6082); d_init as in vvhip_alf_stats_plane.                                                  */
+VVHIP_API int vvhip_ccalf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org_c, int org_stride, const int16_t* d_slf_c, int slf_stride, const int16_t* d_rec_luma, int rec_stride,
+                                       int width_c, int height_c, int ctu_size_c, int shift_x, int shift_y, int vb_ctu_height, int vb_pos, int pic_height,
+                                       const float* d_init /* may be NULL */, float* d_out );
+
 #ifdef __cplusplus
 }
 #endif

@@ -235,6 +235,23 @@ class _Base:
             f(_p(org), org.shape[1], C.c_void_p(base), pad.shape[1], w, h, ctu_size, filter_length, clsp, vb_ctu_height, vb_pos, self.simd, _p(out))
         return out
 
+    def ccalf_stats_plane(self, org_c, slf_c, rec_luma, ctu_size_c, vb_ctu_height=128, vb_pos=124, init=None):
+        """CC-ALF covariance records per chroma CTU (4:2:0) -> (numCtus, ALF_REC) float32; only E[:7,:7], y[:7], pixAcc are defined"""
+        hc, wc = slf_c.shape
+        pad, m = self.alf_pad(rec_luma)
+        org_c, slf_c = np.ascontiguousarray(org_c, np.int16), np.ascontiguousarray(slf_c, np.int16)
+        nctu = ((wc + ctu_size_c - 1) // ctu_size_c) * ((hc + ctu_size_c - 1) // ctu_size_c)
+        out = np.zeros((nctu, self.ALF_REC), np.float32) if init is None else np.ascontiguousarray(init, np.float32).copy().reshape(nctu, self.ALF_REC)
+        base = pad.ctypes.data + 2 * (m * pad.shape[1] + m)
+        f = getattr(self.L, self._pfx + "ccalf_stats_plane"); f.restype = None if self._pfx == "orc_" else C.c_int
+        if self._pfx == "orc_":
+            f(_p(org_c), C.c_ssize_t(org_c.shape[1]), _p(slf_c), C.c_ssize_t(slf_c.shape[1]), C.c_void_p(base), C.c_ssize_t(pad.shape[1]), wc, hc, ctu_size_c, 1, 1,
+              vb_ctu_height, vb_pos, rec_luma.shape[0], _p(out))
+        else:
+            assert init is None
+            f(_p(org_c), org_c.shape[1], _p(slf_c), slf_c.shape[1], C.c_void_p(base), pad.shape[1], wc, hc, ctu_size_c, vb_ctu_height, vb_pos, rec_luma.shape[0], self.simd, _p(out))
+        return out
+
     # ---- g_tCoeffOps table slots (TrQuant_EMT.h:63-91), caller's matrix ----
     def fast_fwd_core(self, tc, src, line, reduced_line, cutoff, shift):
         """tc: (N, N) int16, src: (line, N) int32 -> dst (N, line) int32 (entries outside reduced_line x cutoff stay 0)"""

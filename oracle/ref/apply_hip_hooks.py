@@ -153,4 +153,24 @@ patch("EncAdaptiveLoopFilter.cpp", [
      "    }\n"
      "    if( !hipAlf )\n    {\n"),
     ("before", "  }  \n}\n\nvoid EncAdaptiveLoopFilter::copyCTUforALF(", "    }\n"),
+    # CC-ALF statistics of a CTU and chroma component (one CTU per covariance, reset before): the record comes from the device
+    ("replace", "    getBlkStatsCcAlf( m_alfCovarianceCcAlf[compIdx - 1][filterIdx][ctuRsAddr], m_filterShapesCcAlf[compIdx - 1], orgYuv, recYuv, area, area, compID, yPos );\n  }\n}",
+     "    bool hipCc = false;\n"
+     "    if( g_vvhipHooks.ccAlfCtu && m_chromaFormat == CHROMA_420 )\n"
+     "    {\n"
+     "      float r[183];\n"
+     "      const CompArea& ca = area.block( compID );\n"
+     "      // CTU-local call: the last CTU row has no virtual boundary (:6079-6082) -> a boundary position no row reaches\n"
+     "      const int hipVbPos = ( yPos + m_maxCUHeight ) >= m_picHeight ? 1 << 20 : m_alfVBLumaPos; const int picHFromHere = 1 << 30;\n"
+     "      hipCc = g_vvhipHooks.ccAlfCtu( orgYuv.get( compID ).bufAt( ca ), orgYuv.get( compID ).stride, recYuv.get( compID ).bufAt( area.chromaPos() ), recYuv.get( compID ).stride,\n"
+     "                                     recYuv.get( COMP_Y ).bufAt( area.lumaPos() ), recYuv.get( COMP_Y ).stride, ca.width, ca.height, m_alfVBLumaCTUHeight, hipVbPos, picHFromHere, r );\n"
+     "      if( hipCc )\n"
+     "      {\n"
+     "        AlfCovariance& cov = m_alfCovarianceCcAlf[compIdx - 1][filterIdx][ctuRsAddr];\n"
+     "        for( int a = 0; a < 7; a++ ) { for( int b = 0; b < 7; b++ ) cov.E[0][0][a][b] += r[a * 13 + b]; cov.y[0][a] += r[169 + a]; }\n"
+     "        cov.pixAcc += r[182];\n"
+     "      }\n"
+     "    }\n"
+     "    if( !hipCc )\n"
+     "    getBlkStatsCcAlf( m_alfCovarianceCcAlf[compIdx - 1][filterIdx][ctuRsAddr], m_filterShapesCcAlf[compIdx - 1], orgYuv, recYuv, area, area, compID, yPos );\n  }\n}"),
 ], sub="EncoderLib")

@@ -1009,6 +1009,45 @@ API int vvref_alf_stats_plane( const int16_t* org, int orgStride, const int16_t*
   return 0;
 }
 
+// CC-ALF statistics of one chroma plane, CTU by CTU, through EncAdaptiveLoopFilter::getBlkStatsCcAlf (EncAdaptiveLoopFilter.cpp:6061); 4:2:0.
+// out: [numCtus][183] floats, only E[0..6][0..6], y[0..6], pixAcc are meaningful (the x86 loop touches an uninitialised 8th row).
+API int vvref_ccalf_stats_plane( const int16_t* orgC, int orgStride, const int16_t* slfC, int slfStride, const int16_t* recLuma, int recStride,
+                                 int widthC, int heightC, int ctuSizeC, int vbCTUHeight, int vbPos, int picHeight, int simd, float* out )
+{
+  static EncAdaptiveLoopFilter* enc[2] = { nullptr, nullptr };
+  if( !enc[simd != 0] ) enc[simd != 0] = new EncAdaptiveLoopFilter( simd != 0 );
+  EncAdaptiveLoopFilter& E = *enc[simd != 0];
+  E.m_chromaFormat = CHROMA_420; E.m_alfVBLumaCTUHeight = vbCTUHeight; E.m_alfVBLumaPos = vbPos; E.m_picHeight = picHeight; E.m_maxCUHeight = ctuSizeC * 2; E.m_maxCUWidth = ctuSizeC * 2;
+  const AlfFilterShape shape( size_CC_ALF );
+  AlfCovariance cov; cov.create( shape.numCoeff, 1 );
+  // PelUnitBufs over the caller's planes: luma of rec, the chroma component as Cb of both
+  const int wL = widthC * 2, hL = heightC * 2;
+  PelUnitBuf recYuv, orgYuv;
+  recYuv.chromaFormat = CHROMA_420; orgYuv.chromaFormat = CHROMA_420;
+  recYuv.bufs.push_back( PelBuf( const_cast<Pel*>( recLuma ), recStride, wL, hL ) );
+  recYuv.bufs.push_back( PelBuf( const_cast<Pel*>( slfC ), slfStride, widthC, heightC ) );
+  recYuv.bufs.push_back( PelBuf( const_cast<Pel*>( slfC ), slfStride, widthC, heightC ) );
+  static std::vector<Pel> dummyY; dummyY.assign( ( size_t ) wL * hL, 0 );
+  orgYuv.bufs.push_back( PelBuf( dummyY.data(), wL, wL, hL ) );
+  orgYuv.bufs.push_back( PelBuf( const_cast<Pel*>( orgC ), orgStride, widthC, heightC ) );
+  orgYuv.bufs.push_back( PelBuf( const_cast<Pel*>( orgC ), orgStride, widthC, heightC ) );
+  const int ctusX = ( widthC + ctuSizeC - 1 ) / ctuSizeC, ctusY = ( heightC + ctuSizeC - 1 ) / ctuSizeC;
+  for( int cy = 0; cy < ctusY; cy++ )
+    for( int cx = 0; cx < ctusX; cx++ )
+    {
+      const int xL = cx * ctuSizeC * 2, yL = cy * ctuSizeC * 2, w = std::min( ctuSizeC * 2, wL - xL ), h = std::min( ctuSizeC * 2, hL - yL );
+      cov.reset();
+      const UnitArea area( CHROMA_420, Area( xL, yL, w, h ) );
+      E.getBlkStatsCcAlf( cov, shape, orgYuv, recYuv, area, area, COMP_Cb, yL );
+      float* o = out + ( size_t ) ( cy * ctusX + cx ) * 183;
+      memset( o, 0, sizeof( float ) * 183 );
+      for( int k = 0; k < 7; k++ ) { for( int l = 0; l < 7; l++ ) o[k * 13 + l] = cov.E[0][0][k][l]; o[169 + k] = cov.y[0][k]; }
+      o[182] = cov.pixAcc;
+    }
+  cov.destroy();
+  return 0;
+}
+
 extern "C" void vvref_after_simd_init() __attribute__( ( weak ) );
 
 API long vvref_encode( const int16_t* y, const int16_t* u, const int16_t* v, int width, int height, int frames, int inputBitDepth, int internalBitDepth,

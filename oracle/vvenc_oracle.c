@@ -1374,3 +1374,65 @@ void orc_alf_stats_plane_acc(const int16_t *org, ptrdiff_t orgStride, const int1
                          out + (size_t)(cy * ctusX + cx) * numClasses * ORC_ALF_REC);
     }
 }
+
+
+/* ---- CC-ALF statistics: getBlkStatsCcAlf (EncAdaptiveLoopFilter.cpp:6061-6357) per chroma CTU, scalar form (:6318-6345) with the x86 form's
+ * float additions (one int32 sum per 4x4 block and entry).  Only coefficients 0..6 are defined (the x86 loop also touches row 7 of an
+ * uninitialised buffer; those entries are not used by the derivation). */
+void orc_ccalf_stats_plane(const int16_t *orgC, ptrdiff_t orgStride, const int16_t *slfC, ptrdiff_t slfStride, const int16_t *recLuma, ptrdiff_t recStride,
+                           int widthC, int heightC, int ctuSizeC, int sx, int sy, int vbCTUHeight, int vbPosIn, int picHeight, float *out)
+{
+  const int ctusX = (widthC + ctuSizeC - 1) / ctuSizeC, ctusY = (heightC + ctuSizeC - 1) / ctuSizeC;
+  const int dx1 = 1 << sx;
+  for (int cy = 0; cy < ctusY; cy++)
+    for (int cx = 0; cx < ctusX; cx++)
+    {
+      const int x0 = cx * ctuSizeC, y0 = cy * ctuSizeC;
+      const int w = x0 + ctuSizeC > widthC ? widthC - x0 : ctuSizeC, h = y0 + ctuSizeC > heightC ? heightC - y0 : ctuSizeC;
+      const int yPos = y0 << sy;
+      const int vbPos = (yPos + (ctuSizeC << sy)) >= picHeight ? picHeight : vbPosIn;          /* :6079-6082 */
+      float *E = out + (size_t)(cy * ctusX + cx) * ORC_ALF_REC, *yv = E + 169, *pix = E + 182;
+      for (int i = 0; i < h; i += 4)
+        for (int j = 0; j < w; j += 4)
+        {
+          int16_t EL[7][16], yL[16];
+          for (int ii = 0; ii < 4; ii++)
+          {
+            const int vbd = (((i + ii) << sy) % vbCTUHeight) - vbPos;                            /* :6100-6103 (rows relative to the CTU) */
+            const int16_t *r0 = recLuma + (ptrdiff_t)((y0 + i + ii) << sy) * recStride + ((x0 + j) << sx);
+            const int16_t *rm1 = r0 - recStride, *rp1 = r0 + recStride, *rp2 = r0 + 2 * recStride;
+            if (vbd == -2 || vbd == 1) rp2 = rp1;                                               /* :6368-6376 */
+            else if (vbd == -1 || vbd == 0) { rm1 = r0; rp2 = rp1 = r0; }
+            for (int jj = 0; jj < 4; jj++)
+            {
+              const int d = jj * dx1;
+              const int16_t c = r0[d];
+              EL[0][ii * 4 + jj] = (int16_t)(rm1[d] - c);
+              EL[1][ii * 4 + jj] = (int16_t)(r0[d - 1] - c);
+              EL[2][ii * 4 + jj] = (int16_t)(r0[d + 1] - c);
+              EL[3][ii * 4 + jj] = (int16_t)(rp1[d - 1] - c);
+              EL[4][ii * 4 + jj] = (int16_t)(rp1[d] - c);
+              EL[5][ii * 4 + jj] = (int16_t)(rp1[d + 1] - c);
+              EL[6][ii * 4 + jj] = (int16_t)(rp2[d] - c);
+              yL[ii * 4 + jj] = (int16_t)(orgC[(ptrdiff_t)(y0 + i + ii) * orgStride + x0 + j + jj] - slfC[(ptrdiff_t)(y0 + i + ii) * slfStride + x0 + j + jj]);
+            }
+          }
+          for (int k = 0; k < 7; k++)
+          {
+            for (int l = k; l < 7; l++)
+            {
+              int32_t sum = 0;
+              for (int p = 0; p < 16; p++) sum += (int32_t)EL[k][p] * EL[l][p];
+              E[k * 13 + l] += (float)sum;
+            }
+            int32_t sum = 0;
+            for (int p = 0; p < 16; p++) sum += (int32_t)EL[k][p] * yL[p];
+            yv[k] += (float)sum;
+          }
+          int32_t sum = 0;
+          for (int p = 0; p < 16; p++) sum += (int32_t)yL[p] * yL[p];
+          *pix += (float)sum;
+        }
+      for (int k = 1; k < 7; k++) for (int l = 0; l < k; l++) E[k * 13 + l] = E[l * 13 + k];    /* :6349-6355 */
+    }
+}

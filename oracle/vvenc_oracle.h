@@ -99,6 +99,12 @@ void orc_alf_stats_plane(const int16_t *org, ptrdiff_t orgStride, const int16_t 
 void orc_alf_stats_plane_acc(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int width, int height, int ctuSize, int filterLength,
                              const uint8_t *cls, int vbCTUHeight, int vbPos, float *out /* continues from the records already there */);
 
+/* CC-ALF statistics (EncAdaptiveLoopFilter.cpp:6061-6357 getBlkStatsCcAlf, :6359-6422 calcCovariance4CcAlf): per chroma CTU one record (the first
+ * 7 rows / columns of E, y[0..6], pixAcc); local terms = 7 luma differences around the co-located luma sample, target = org - ALF-filtered chroma.
+ * recLuma carries a replicated border >= 2.  sx / sy = chroma subsampling shifts; vbCTUHeight / vbPos / picHeight in luma samples.                */
+void orc_ccalf_stats_plane(const int16_t *orgC, ptrdiff_t orgStride, const int16_t *slfC, ptrdiff_t slfStride, const int16_t *recLuma, ptrdiff_t recStride,
+                           int widthC, int heightC, int ctuSizeC, int sx, int sy, int vbCTUHeight, int vbPos, int picHeight, float *out /* [numCtus][ORC_ALF_REC], continues from the records there */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,11 @@ def gen_alf(R, R0):
         d["c%d_org" % k] = org; d["c%d_rec" % k] = rec; d["c%d_cls" % k] = cls
         d["c%d_luma_head" % k] = st[:2].view(np.uint32).copy(); d["c%d_luma_sum" % k] = np.array([int(st.view(np.uint32).astype(np.uint64).sum())], np.uint64)
         d["c%d_chroma_head" % k] = sc[:2].view(np.uint32).copy(); d["c%d_chroma_sum" % k] = np.array([int(sc.view(np.uint32).astype(np.uint64).sum())], np.uint64)
+        # CC-ALF: the "ALF-filtered" chroma plane is a perturbed copy (any plane serves: the statistics only read it)
+        slf = np.clip(c_rec.astype(np.int32) + rng.integers(-3, 4, c_rec.shape), 0, 1023).astype(np.int16)
+        cc = R.ccalf_stats_plane(c_org, slf, rec, ctu // 2, ctu, ctu - 4)
+        assert np.array_equal(cc.view(np.uint32), R0.ccalf_stats_plane(c_org, slf, rec, ctu // 2, ctu, ctu - 4).view(np.uint32))
+        d["c%d_slf" % k] = slf; d["c%d_ccalf" % k] = cc.view(np.uint32).copy()
         cases.append((h, w, ctu))
     d["cases"] = np.array(cases, np.int32)
     np.savez_compressed(os.path.join(OUT, "alf.npz"), **d)

@@ -236,3 +236,5 @@ def check_alf(be):
         c_org, c_rec = np.ascontiguousarray(org[::2, ::2]), np.ascontiguousarray(rec[::2, ::2])
         sc = np.asarray(be.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2)).view(np.uint32)
         assert np.array_equal(sc[:2], g["c%d_chroma_head" % k]) and int(sc.astype(np.uint64).sum()) == int(g["c%d_chroma_sum" % k][0]), ("alf chroma", k)
+        cc = np.asarray(be.ccalf_stats_plane(c_org, g["c%d_slf" % k], rec, ctu // 2, ctu, ctu - 4)).view(np.uint32)
+        assert np.array_equal(cc, g["c%d_ccalf" % k]), ("cc-alf", k)

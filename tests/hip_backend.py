@@ -95,6 +95,11 @@ class HipBackend:
         return hp.alf_stats_plane(hp.plane(np.ascontiguousarray(org, np.int16), 0), hp.plane(np.ascontiguousarray(rec, np.int16), 8), ctu_size, filter_length,
                                   d_cls, vb_ctu_height, vb_pos).cpu().numpy()
 
+    def ccalf_stats_plane(self, org_c, slf_c, rec_luma, ctu_size_c, vb_ctu_height=128, vb_pos=124):
+        hp = self.hp
+        return hp.ccalf_stats_plane(hp.plane(np.ascontiguousarray(org_c, np.int16), 0), hp.plane(np.ascontiguousarray(slf_c, np.int16), 0),
+                                    hp.plane(np.ascontiguousarray(rec_luma, np.int16), 8), ctu_size_c, vb_ctu_height, vb_pos).cpu().numpy()
+
     def mctf_bilateral(self, org, refs, mvs, ref_index, bit_depth=10, qp=32, unit=16, low_res=True, pic_reordering=True, overall_strength=0.95):
         return self.hp.mctf_bilateral(org, refs, mvs, ref_index, bit_depth, qp, unit, low_res, pic_reordering, overall_strength)
 

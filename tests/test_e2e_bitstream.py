@@ -28,7 +28,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(15, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 15); calls = [int(x) for x in c]
+    c = np.zeros(16, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 16); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -174,9 +174,9 @@ def test_hip_alf_statistics_bitstream_identical():
         pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
-    hip = run(dict(clip, hip=True, simd=None, mask=2048))
+    hip = run(dict(clip, hip=True, simd=None, mask=2048 + 4096))
     print("cpu", cpu, "hip", hip)
-    assert hip["calls"][14] > 4, hip["calls"]
+    assert hip["calls"][14] > 4 and hip["calls"][15] > 4, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
 
 
@@ -187,9 +187,9 @@ def test_hip_alf_statistics_1080p_bitstream_identical():
     if not os.path.exists(e2e_util.REF_HIP_SO):
         pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
     import e2e_fps
-    res = [e2e_fps.run(dict(w=1920, h=1080, frames=9, threads=8, mask=m)) for m in (0, 2048)]
+    res = [e2e_fps.run(dict(w=1920, h=1080, frames=9, threads=8, mask=m)) for m in (0, 2048 + 4096)]
     print(res)
-    assert res[1]["calls"][14] >= 510, res[1]["calls"]
+    assert res[1]["calls"][14] >= 510 and res[1]["calls"][15] >= 510, res[1]["calls"]
     assert res[0]["md5"] == res[1]["md5"] and res[0]["bytes"] == res[1]["bytes"], res
 
 
@@ -201,7 +201,7 @@ def test_hip_everything_on_device_bitstream_identical():
         pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
-    hip = run(dict(clip, hip=True, simd=None, mask=31 + 64 + 128 + 256 + 512 + 1024 + 2048))
+    hip = run(dict(clip, hip=True, simd=None, mask=31 + 64 + 128 + 256 + 512 + 1024 + 2048 + 4096))
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][0] > 1000 and hip["calls"][8] > 100 and hip["calls"][9] >= 1 and hip["calls"][10] > 50 and hip["calls"][11] > 5 and hip["calls"][12] > 50 and hip["calls"][14] > 4, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)

@@ -704,3 +704,22 @@ def test_alf_classification_and_statistics_vs_oracle(hip, oracle, cfg):
     got = hp.alf_stats_plane(porg, prec, ctu, 7, hp.to_device(cls2), vbh, vbp).cpu().numpy()
     exp = oracle.alf_stats_plane(org, rec, ctu, 7, cls2, vbh, vbp)
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), "unused blocks"
+
+
+@pytest.mark.parametrize("cfg", [(272, 400, 64), (136, 200, 32), (128, 128, 64), (64, 96, 16)])
+def test_ccalf_statistics_vs_oracle(hip, oracle, cfg):
+    """CC-ALF covariance records (getBlkStatsCcAlf): 7 luma differences vs org - ALF-filtered chroma, float sums in the reference's order; partial CTUs, virtual
+    boundary rows, the boundary-free last CTU row, and continued chains"""
+    h, w, ctu_c = cfg
+    hp = hip.hp
+    rng = np.random.default_rng(1000 + h)
+    _, rec = _alf_pictures(rng, h, w, False)
+    slf = np.clip(500 + 0.3 * (rec[::2, ::2].astype(np.float64) - 512) + rng.normal(0, 4, (h // 2, w // 2)), 0, 1023).astype(np.int16)
+    org = np.clip(slf.astype(np.int32) + rng.integers(-9, 10, slf.shape), 0, 1023).astype(np.int16)
+    prec, pslf, porg = hp.plane(rec, 8), hp.plane(slf, 0), hp.plane(org, 0)
+    got = hp.ccalf_stats_plane(porg, pslf, prec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4)
+    exp = oracle.ccalf_stats_plane(org, slf, rec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32)), np.abs(got.cpu().numpy() - exp).max()
+    got2 = hp.ccalf_stats_plane(porg, pslf, prec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4, init=got, out=got).cpu().numpy()
+    exp2 = oracle.ccalf_stats_plane(org, slf, rec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4, init=exp)
+    assert np.array_equal(got2.view(np.uint32), exp2.view(np.uint32)), "continued chains"

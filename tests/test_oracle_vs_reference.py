@@ -537,3 +537,16 @@ def test_alf_classification_and_statistics(oracle, reflib, cfg):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     cls2 = cls.copy(); cls2[1::2, ::3] = 255
     assert np.array_equal(oracle.alf_stats_plane(org, rec, ctu, 7, cls2, ctu, ctu - 4).view(np.uint32), reflib.alf_stats_plane(org, rec, ctu, 7, cls2, ctu, ctu - 4).view(np.uint32))
+
+
+@pytest.mark.parametrize("cfg", [(272, 400, 64), (136, 200, 32), (128, 128, 64)])
+def test_ccalf_statistics(oracle, reflib, cfg):
+    """getBlkStatsCcAlf of the reference (scalar and x86 rows) against the restatement: float bit patterns of E[:7,:7], y[:7], pixAcc per chroma CTU"""
+    h, w, ctu_c = cfg
+    rng = np.random.default_rng(1100 + h)
+    _, rec = _alf_case(rng, h, w, False)
+    slf = np.clip(500 + 0.3 * (rec[::2, ::2].astype(np.float64) - 512) + rng.normal(0, 4, (h // 2, w // 2)), 0, 1023).astype(np.int16)
+    org = np.clip(slf.astype(np.int32) + rng.integers(-9, 10, slf.shape), 0, 1023).astype(np.int16)
+    a = oracle.ccalf_stats_plane(org, slf, rec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4)
+    b = reflib.ccalf_stats_plane(org, slf, rec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

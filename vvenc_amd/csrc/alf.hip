@@ -77,6 +77,7 @@ alfClassifyKernel( const int16_t* __restrict__ rec, int stride, int width, int h
 struct AlfStatArgs
 {
   const int16_t* org; const int16_t* rec; const uint8_t* cls; int32_t* sums; const float* init; float* out;
+  const int16_t* slf; int slfStride, sx, sy, picHeight;      // CC-ALF: ALF-filtered chroma, chroma subsampling shifts, luma picture height
   int orgStride, recStride, width, height, ctuSize, ctusX, nc, shape, vbH, vbPos, blocksPerCtuRow;
 };
 
@@ -91,6 +92,8 @@ __device__ __forceinline__ void alfEntryRows( int e, int nc, int& ra, int& rb ) 
 // Kernel A — everything that does not depend on the order: one workgroup per (CTU, block row): the rec window and org - rec of the row go to
 // LDS, all threads build the local terms of the row's 4x4 blocks (calcLinCovariance4) and the int32 dot products of every (block, entry)
 // pair -> sums[ctu][block][entry] (exact integers).
+// MODE 0: ALF (rec = the plane itself), MODE 1: CC-ALF (rec = luma, org / slf = chroma; getBlkStatsCcAlf :6061-6357, calcCovariance4CcAlf :6359-6422)
+template<int MODE>
 __global__ void __launch_bounds__( 256 )
 alfBlockSumsKernel( AlfStatArgs A, AlfTaps T )
 {
@@ -108,11 +111,23 @@ alfBlockSumsKernel( AlfStatArgs A, AlfTaps T )
   const int nE = nc * ( nc + 1 ) / 2 + nc + 1;
   if( tid < nE ) { int ra, rb; alfEntryRows( tid, nc, ra, rb ); sPair[tid][0] = ( uint8_t ) ra; sPair[tid][1] = ( uint8_t ) rb; }
   if( tid >= 192 && tid < 240 ) sTap[( tid - 192 ) / 12][( tid - 192 ) % 12] = T.t[A.shape][( tid - 192 ) / 12][( tid - 192 ) % 12];
-  for( int t = tid; t < 10 * ( ( w + 6 + 1 ) >> 1 ); t += 256 )
+  if( MODE == 0 )
+    for( int t = tid; t < 10 * ( ( w + 6 + 1 ) >> 1 ); t += 256 )
+    {
+      const int pw = ( w + 6 + 1 ) >> 1, r = t / pw, c = 2 * ( t - r * pw );
+      const int16_t* src = A.rec + ( ptrdiff_t ) ( y0 + i - 3 + r ) * A.recStride + x0 - 3 + c;
+      sRec[r][c] = src[0]; sRec[r][c + 1] = src[1];                                             // (the margin of >= 4 covers the odd last column)
+    }
+  else
   {
-    const int pw = ( w + 6 + 1 ) >> 1, r = t / pw, c = 2 * ( t - r * pw );
-    const int16_t* src = A.rec + ( ptrdiff_t ) ( y0 + i - 3 + r ) * A.recStride + x0 - 3 + c;
-    sRec[r][c] = src[0]; sRec[r][c + 1] = src[1];                                               // (the margin of >= 4 covers the odd last column)
+    // luma rows (y << sy) - 1 .. ((y + 3) << sy) + 2, columns (x0 << sx) - 1 .. ((x0 + w - 1) << sx) + 1
+    const int nr = ( 3 << A.sy ) + 4, ncol = ( ( w - 1 ) << A.sx ) + 3, pw = ( ncol + 1 ) >> 1;
+    for( int t = tid; t < nr * pw; t += 256 )
+    {
+      const int r = t / pw, c = 2 * ( t - r * pw );
+      const int16_t* src = A.rec + ( ptrdiff_t ) ( ( ( y0 + i ) << A.sy ) - 1 + r ) * A.recStride + ( x0 << A.sx ) - 1 + c;
+      sRec[r][c] = src[0]; sRec[r][c + 1] = src[1];
+    }
   }
   if( tid < nb ) sTr[tid] = A.cls ? A.cls[2 * ( ( size_t ) ( ( y0 + i ) >> 2 ) * ( A.width >> 2 ) + ( x0 >> 2 ) + tid ) + 1] & 3 : 0;
   __syncthreads();
@@ -121,6 +136,35 @@ alfBlockSumsKernel( AlfStatArgs A, AlfTaps T )
   {
     const int b = t / ( ALF_ROWS * 4 ), rem = t - b * ( ALF_ROWS * 4 ), k = rem >> 2, ii = rem & 3;
     int16_t* dst = &sLoc[b][k][ii * 4];
+    if( MODE == 1 )
+    {
+      if( k == 13 )
+      {
+        const int16_t* o = A.org + ( ptrdiff_t ) ( y0 + i + ii ) * A.orgStride + x0 + 4 * b;
+        const int16_t* f = A.slf + ( ptrdiff_t ) ( y0 + i + ii ) * A.slfStride + x0 + 4 * b;
+#pragma unroll
+        for( int x = 0; x < 4; x++ ) dst[x] = ( int16_t ) ( o[x] - f[x] );
+      }
+      else if( k < 7 )
+      {
+        // rows of the luma window: centre row r0, above / below / two below, folded at the virtual boundary (:6368-6376; no boundary in the last CTU row :6079)
+        const int vbPos = ( ( y0 << A.sy ) + ( A.ctuSize << A.sy ) ) >= A.picHeight ? A.picHeight : A.vbPos;
+        const int vbd = ( ( ( i + ii ) << A.sy ) & ( A.vbH - 1 ) ) - vbPos;
+        const int r0 = 1 + ( ii << A.sy );
+        int rm1 = r0 - 1, rp1 = r0 + 1, rp2 = r0 + 2;
+        if( vbd == -2 || vbd == 1 ) rp2 = rp1;
+        else if( vbd == -1 || vbd == 0 ) { rm1 = r0; rp1 = r0; rp2 = r0; }
+        const int row = k == 0 ? rm1 : k < 3 ? r0 : k < 6 ? rp1 : rp2;
+        const int dx = ( k == 1 || k == 3 ) ? -1 : ( k == 2 || k == 5 ) ? 1 : 0;
+#pragma unroll
+        for( int x = 0; x < 4; x++ )
+        {
+          const int col = 1 + ( ( 4 * b + x ) << A.sx );
+          dst[x] = ( int16_t ) ( sRec[row][col + dx] - sRec[r0][col] );
+        }
+      }
+      continue;
+    }
     const int16_t* c0 = &sRec[3 + ii][3 + 4 * b];
     if( k == 13 )
     {
@@ -274,6 +318,30 @@ void buildTaps( AlfTaps& T )
 
 } // namespace
 
+static int alfLaunchStats( vvhip_ctx* ctx, AlfStatArgs& A, int width, int height, int ctu_size, bool ccalf )
+{
+  static AlfTaps taps; static bool built = false;
+  if( !built ) { buildTaps( taps ); built = true; }
+  const int ctus = A.ctusX * ( ( height + ctu_size - 1 ) / ctu_size );
+  const size_t need = ( size_t ) ctus * A.blocksPerCtuRow * ALF_NE * ALF_MAXB * sizeof( int32_t );           // per-block int32 sums between the two kernels
+  if( need > ctx->scratchBytes )
+  {
+    VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+    if( ctx->d_scratch ) ( void ) hipFree( ctx->d_scratch );
+    ctx->d_scratch = nullptr; ctx->scratchBytes = 0;
+    VVHIP_CHECK_HIP( ctx, hipMalloc( &ctx->d_scratch, need ) );
+    ctx->scratchBytes = need;
+  }
+  A.sums = ( int32_t* ) ctx->d_scratch;
+  if( ccalf ) hipLaunchKernelGGL( alfBlockSumsKernel<1>, dim3( ctus, A.blocksPerCtuRow ), dim3( 256 ), 0, ctx->stream, A, taps );
+  else        hipLaunchKernelGGL( alfBlockSumsKernel<0>, dim3( ctus, A.blocksPerCtuRow ), dim3( 256 ), 0, ctx->stream, A, taps );
+  VVHIP_LAUNCH_CHECK( ctx );
+  if( A.cls ) hipLaunchKernelGGL( alfOrderedAddKernel<25>, dim3( ctus ), dim3( 128 ), 0, ctx->stream, A );
+  else        hipLaunchKernelGGL( alfOrderedAddKernel<1>, dim3( ctus ), dim3( 128 ), 0, ctx->stream, A );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
 extern "C" {
 
 int vvhip_alf_classify( vvhip_ctx* ctx, const int16_t* d_rec, int stride, int width, int height, int bit_depth, int vb_ctu_height, int vb_pos, uint8_t* d_cls )
@@ -296,28 +364,25 @@ int vvhip_alf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride,
       vb_ctu_height < 4 || ( vb_ctu_height & ( vb_ctu_height - 1 ) ) || vb_pos < 0 || !d_org || !d_rec || !d_out )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_alf_stats_plane: %dx%d (multiples of 4), CTU %d (<= 128), filter length %d (7 luma / 5 chroma)", width, height, ctu_size, filter_length );
   AlfStatArgs A;
-  A.org = d_org; A.rec = d_rec; A.cls = d_cls; A.init = d_init; A.out = d_out; A.orgStride = org_stride; A.recStride = rec_stride; A.width = width; A.height = height;
+  A.org = d_org; A.rec = d_rec; A.cls = d_cls; A.init = d_init; A.out = d_out; A.slf = nullptr; A.slfStride = 0; A.sx = 0; A.sy = 0; A.picHeight = 0; A.orgStride = org_stride; A.recStride = rec_stride; A.width = width; A.height = height;
   A.ctuSize = ctu_size; A.ctusX = ( width + ctu_size - 1 ) / ctu_size; A.nc = filter_length * filter_length / 4 + 1;
   A.shape = filter_length == 7 ? 0 : 1; A.vbH = vb_ctu_height; A.vbPos = vb_pos; A.blocksPerCtuRow = ctu_size >> 2;
-  static AlfTaps taps; static bool built = false;
-  if( !built ) { buildTaps( taps ); built = true; }
-  const int ctus = A.ctusX * ( ( height + ctu_size - 1 ) / ctu_size );
-  const size_t need = ( size_t ) ctus * A.blocksPerCtuRow * ALF_NE * ALF_MAXB * sizeof( int32_t );           // per-block int32 sums between the two kernels
-  if( need > ctx->scratchBytes )
-  {
-    VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
-    if( ctx->d_scratch ) ( void ) hipFree( ctx->d_scratch );
-    ctx->d_scratch = nullptr; ctx->scratchBytes = 0;
-    VVHIP_CHECK_HIP( ctx, hipMalloc( &ctx->d_scratch, need ) );
-    ctx->scratchBytes = need;
-  }
-  A.sums = ( int32_t* ) ctx->d_scratch;
-  hipLaunchKernelGGL( alfBlockSumsKernel, dim3( ctus, A.blocksPerCtuRow ), dim3( 256 ), 0, ctx->stream, A, taps );
-  VVHIP_LAUNCH_CHECK( ctx );
-  if( d_cls ) hipLaunchKernelGGL( alfOrderedAddKernel<25>, dim3( ctus ), dim3( 128 ), 0, ctx->stream, A );
-  else        hipLaunchKernelGGL( alfOrderedAddKernel<1>, dim3( ctus ), dim3( 128 ), 0, ctx->stream, A );
-  VVHIP_LAUNCH_CHECK( ctx );
-  return VVHIP_OK;
+  return alfLaunchStats( ctx, A, width, height, ctu_size, false );
+}
+
+int vvhip_ccalf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org_c, int org_stride, const int16_t* d_slf_c, int slf_stride, const int16_t* d_rec_luma, int rec_stride,
+                             int width_c, int height_c, int ctu_size_c, int shift_x, int shift_y, int vb_ctu_height, int vb_pos, int pic_height, const float* d_init, float* d_out )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( width_c < 4 || height_c < 4 || ( width_c & 3 ) || ( height_c & 3 ) || ctu_size_c < 8 || ( ctu_size_c << shift_x ) > 128 || ( ctu_size_c & 3 ) || shift_x < 0 || shift_x > 1 || shift_y < 0 || shift_y > 1 ||
+      vb_ctu_height < 4 || ( vb_ctu_height & ( vb_ctu_height - 1 ) ) || !d_org_c || !d_slf_c || !d_rec_luma || !d_out )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_ccalf_stats_plane: chroma %dx%d (multiples of 4), chroma CTU %d, shifts %d/%d", width_c, height_c, ctu_size_c, shift_x, shift_y );
+  AlfStatArgs A;
+  A.org = d_org_c; A.rec = d_rec_luma; A.cls = nullptr; A.init = d_init; A.out = d_out; A.orgStride = org_stride; A.recStride = rec_stride; A.width = width_c; A.height = height_c;
+  A.slf = d_slf_c; A.slfStride = slf_stride; A.sx = shift_x; A.sy = shift_y; A.picHeight = pic_height;
+  A.ctuSize = ctu_size_c; A.ctusX = ( width_c + ctu_size_c - 1 ) / ctu_size_c; A.nc = 7;
+  A.shape = 1; A.vbH = vb_ctu_height; A.vbPos = vb_pos; A.blocksPerCtuRow = ctu_size_c >> 2;
+  return alfLaunchStats( ctx, A, width_c, height_c, ctu_size_c, true );
 }
 
 } // extern "C"

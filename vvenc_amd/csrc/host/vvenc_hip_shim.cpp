@@ -737,6 +737,37 @@ bool ALFOps::getStatistics( const Pel* org, int orgStride, const Pel* rec, int r
   return true;
 }
 
+bool ALFOps::getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC, int slfStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC,
+                                 int vbCTUHeight, int vbPos, int picHeight, float* out, const float* init )
+{
+  if( ( widthC & 3 ) || ( heightC & 3 ) || widthC < 4 || heightC < 4 || ctuSizeC > 64 ) return false;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int wL = widthC * 2, hL = heightC * 2;
+  const int recPitch = ( wL + 8 + 7 ) & ~7;
+  const size_t recBytes = ( ( size_t ) recPitch * ( hL + 8 ) * sizeof( Pel ) + 255 ) & ~( size_t ) 255;
+  const int cPitch = ( widthC + 7 ) & ~7;
+  std::vector<Pel> hc( ( size_t ) 2 * cPitch * heightC );
+  for( int y = 0; y < heightC; y++ )
+  {
+    memcpy( &hc[( size_t ) y * cPitch], orgC + ( ptrdiff_t ) y * orgStride, sizeof( Pel ) * widthC );
+    memcpy( &hc[( size_t ) ( heightC + y ) * cPitch], slfC + ( ptrdiff_t ) y * slfStride, sizeof( Pel ) * widthC );
+  }
+  dev.staging( recBytes + hc.size() * sizeof( Pel ) + 512 );
+  int pitch;
+  const int16_t* dRec = stageBordered( dev, recLuma, recStride, wL, hL, 4, 0, pitch );
+  int16_t* dC = dev.staging( recBytes + hc.size() * sizeof( Pel ) + 512 ) + recBytes / sizeof( Pel );
+  dev.check( vvhip_upload( dev.ctx(), dC, hc.data(), hc.size() * sizeof( Pel ) ), "CC-ALF chroma planes" );
+  const int ctus = ( ( widthC + ctuSizeC - 1 ) / ctuSizeC ) * ( ( heightC + ctuSizeC - 1 ) / ctuSizeC );
+  const size_t outBytes = ( size_t ) ctus * VVHIP_ALF_REC * sizeof( float );
+  float* dOut = static_cast<float*>( dev.stagingAux( outBytes + 64 ) );
+  if( init ) dev.check( vvhip_upload( dev.ctx(), dOut, init, outBytes ), "CC-ALF start records" );
+  dev.check( vvhip_ccalf_stats_plane( dev.ctx(), dC, cPitch, dC + ( size_t ) cPitch * heightC, cPitch, dRec, pitch, widthC, heightC, ctuSizeC, 1, 1, vbCTUHeight, vbPos, picHeight,
+                                      init ? dOut : nullptr, dOut ), "vvhip_ccalf_stats_plane" );
+  dev.check( vvhip_download( dev.ctx(), out, dOut, outBytes ), "CC-ALF statistics" );
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ MCTFOps
 namespace {
 

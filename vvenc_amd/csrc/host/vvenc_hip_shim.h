@@ -196,6 +196,10 @@ struct ALFOps
   // init (optional, same layout): the values the float chains start from (statistics units that span several CTUs)
   bool getStatistics( const Pel* org, int orgStride, const Pel* rec, int recStride, int width, int height, int ctuSize, int filterLength,
                       const uint8_t* cls, int vbCTUHeight, int vbPos, float* out, const float* init = nullptr );
+  // EncAdaptiveLoopFilter::getBlkStatsCcAlf per chroma CTU (4:2:0): org / slf = chroma planes (slf = ALF-filtered), recLuma with a replicated border >= 2;
+  // one record per chroma CTU (E[0..6][0..6], y[0..6], pixAcc), vb* / picHeight in luma samples
+  bool getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC, int slfStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC,
+                           int vbCTUHeight, int vbPos, int picHeight, float* out, const float* init = nullptr );
 };
 
 // MCTF table, CommonLib/MCTF.h:160-170

@@ -296,6 +296,15 @@ class HotPath:
                                               _ptr(d_cls) if d_cls is not None else None, vb_ctu_height, vb_pos, _ptr(init) if init is not None else None, _ptr(out)))
         return out
 
+    def ccalf_stats_plane(self, org_c, slf_c, rec_luma, ctu_size_c, vb_ctu_height=128, vb_pos=124, shift=(1, 1), out=None, init=None):
+        """CC-ALF covariance records of every chroma CTU -> float32 tensor (numCtus, ALF_REC); org_c / slf_c chroma Planes, rec_luma with margin >= 2"""
+        nctu = ((slf_c.width + ctu_size_c - 1) // ctu_size_c) * ((slf_c.height + ctu_size_c - 1) // ctu_size_c)
+        if out is None:
+            out = torch.empty((nctu, self.ALF_REC), dtype=torch.float32, device=self.device)
+        self._ck(self.L.vvhip_ccalf_stats_plane(self.ctx, org_c.buf_ptr, org_c.stride, slf_c.buf_ptr, slf_c.stride, rec_luma.buf_ptr, rec_luma.stride, slf_c.width, slf_c.height,
+                                                ctu_size_c, shift[0], shift[1], vb_ctu_height, vb_pos, rec_luma.height, _ptr(init) if init is not None else None, _ptr(out)))
+        return out
+
     # ---- SURVEY 8f rank 2: MCTF apply side ----
     REF_STRENGTHS = ((0.84375, 0.6, 0.4286, 0.3333, 0.2727, 0.2308), (1.12500, 1.0, 0.7143, 0.5556, 0.4545, 0.3846))      # MCTF.cpp:112-117
 
