@@ -94,7 +94,11 @@ sadSseBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, cons
       const int16_t* b = pc[u] + ( ptrdiff_t ) y * curStride + s * CH;
       if( CH == 2 ) { va[u][0] = ld4( a ); vb[u][0] = ld4( b ); }
       else if( CH == 4 ) { u32x2 x = ld8( a ), z = ld8( b ); va[u][0] = x.x; va[u][CH / 2 - 1] = x.y; vb[u][0] = z.x; vb[u][CH / 2 - 1] = z.y; }
-      else { u32x4 x = ld16( a ), z = ld16( b );
+      else { u32x4 x, z = ld16( b );
+             // candidates of one block follow each other in the lists: the original rows are fetched once per lane team (L1 request rate is what
+             // bounds this kernel, not the bytes: a cache-hot reload costs as much as a miss that hits L2)
+             if( u > 0 && po[u] == po[0] ) { x.x = va[0][0]; x.y = va[0][1 % ( CH / 2 )]; x.z = va[0][2 % ( CH / 2 )]; x.w = va[0][3 % ( CH / 2 )]; }
+             else x = ld16( a );
              va[u][0] = x.x; va[u][1 % ( CH / 2 )] = x.y; va[u][2 % ( CH / 2 )] = x.z; va[u][3 % ( CH / 2 )] = x.w;
              vb[u][0] = z.x; vb[u][1 % ( CH / 2 )] = z.y; vb[u][2 % ( CH / 2 )] = z.z; vb[u][3 % ( CH / 2 )] = z.w; }
     }
@@ -145,7 +149,10 @@ sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __r
 
 // Several (function-compatible) batches in ONE launch: a workgroup finds its job from the block-range table (wave-uniform scalar
 // work) and runs the same body.  Removes the launch gaps and the tails of the short per-size launches of a frame's work lists.
-constexpr int DIST_U = 2;          // candidates per lane team in the merged SAD / SSE launches
+#ifndef VVHIP_DIST_U
+#define VVHIP_DIST_U 2
+#endif
+constexpr int DIST_U = VVHIP_DIST_U;   // candidates per lane team in the merged SAD / SSE launches (they share the original rows when they belong to one block)
 struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand, sse; const vvhip_dist_item* items; uint64_t* out; };
 struct DistMultiJobs { int nJobs, xcdRemap; DistJobGeom j[8]; };
 
@@ -378,6 +385,110 @@ hadTileBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, con
   // per-lane sums stay below 2^32 (<= 4 tiles x 64 x 2^20); the candidate total can exceed it only for full-range int16 data -> 64-bit group sum
   const uint64_t tot = vvhipGroupSum64( sum, lpc, threadIdx.x & 63 );
   if( valid && lt == 0 ) out[cand] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 8x8 / 16x16_fast Hadamard tile per lane in PACKED 16-bit arithmetic, for bit depths <= 10 (the same contract as the reference's x86
+// rows: xCalcHAD8x8_SSE / xCalcHAD16x16_fast_SSE CHECK( iBitDepth > 10 ), x86/RdCostX86.h:655-659,800-804).
+// The 64 differences of a tile are 32 dwords of two samples.  Differences of <= 10-bit samples are 11 bits signed; five butterfly stages
+// over the dword index (v_pk_add_i16 / v_pk_sub_i16: both halves at once) stay within 16 bits (1023 * 32 < 32768).  The sixth stage pairs the
+// two halves of a dword, and |a + b| + |a - b| = 2 * max( |a|, |b| ): it never has to be carried out.  Half the registers and half the
+// instructions of the 32-bit form; the sum of absolute coefficients is identical for conforming inputs.
+// ---------------------------------------------------------------------------------------------
+typedef short s16x2v __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ uint32_t pkAdd( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2v, a ) + __builtin_bit_cast( s16x2v, b ) ); }
+__device__ __forceinline__ uint32_t pkSub( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2v, a ) - __builtin_bit_cast( s16x2v, b ) ); }
+__device__ __forceinline__ uint32_t pkAbs( uint32_t a )
+{
+  const s16x2v v = __builtin_bit_cast( s16x2v, a ), z = { 0, 0 };
+  return __builtin_bit_cast( uint32_t, __builtin_elementwise_max( v, z - v ) );
+}
+
+// rounded 2x2 averages of 16 samples x 2 rows -> 8 values as 4 packed dwords
+__device__ __forceinline__ void avgRow16Pk( const int16_t* p, int stride, uint32_t ( &o )[4] )
+{
+  const u32x4 a0 = ld16( p ), a1 = ld16( p + 8 ), b0 = ld16( p + stride ), b1 = ld16( p + stride + 8 );
+  const uint32_t t[8] = { pkAdd( a0.x, b0.x ), pkAdd( a0.y, b0.y ), pkAdd( a0.z, b0.z ), pkAdd( a0.w, b0.w ), pkAdd( a1.x, b1.x ), pkAdd( a1.y, b1.y ), pkAdd( a1.z, b1.z ), pkAdd( a1.w, b1.w ) };
+#pragma unroll
+  for( int i = 0; i < 4; i++ )
+  {
+    const uint32_t lo = __builtin_amdgcn_perm( t[2 * i + 1], t[2 * i], 0x05040100u ), hi = __builtin_amdgcn_perm( t[2 * i + 1], t[2 * i], 0x07060302u );   // (t0.lo, t1.lo), (t0.hi, t1.hi)
+    const uint32_t s = pkAdd( pkAdd( lo, hi ), 0x00020002u );
+    o[i] = ( s >> 2 ) & 0x3fff3fffu;                                                          // both halves >> 2 (sums are < 2^13, unsigned)
+  }
+}
+
+template<bool FAST16>
+__device__ __forceinline__ void
+hadTilePkBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
+               int tilesX, int tilesPerCand, int log2Lpc,
+               const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+{
+  constexpr int PX = FAST16 ? 16 : 8, PY = FAST16 ? 16 : 8;
+  const int gid  = blockIndex * blockDim.x + threadIdx.x;
+  const int lpc  = 1 << log2Lpc;
+  const int cand = gid >> log2Lpc;
+  const int lt   = gid & ( lpc - 1 );
+  const bool valid = cand < n;
+  int orgOff = 0, curOff = 0;
+  if( valid ) { const vvhip_dist_item it = items[cand]; orgOff = it.org_off; curOff = it.cur_off; }
+  const int tiles = valid ? tilesPerCand : 0;
+
+  uint32_t sum = 0;
+  for( int t = lt; t < tiles; t += lpc )
+  {
+    const int ty = t / tilesX, tx = t - ty * tilesX;
+    const int16_t* po = org + orgOff + ( ptrdiff_t ) ( ty * PY ) * orgStride + tx * PX;
+    const int16_t* pc = cur + curOff + ( ptrdiff_t ) ( ty * PY ) * curStride + tx * PX;
+    uint32_t d[32];                                           // dword 4 * r + q: differences (r, 2q), (r, 2q + 1)
+#pragma unroll
+    for( int r = 0; r < 8; r++ )
+    {
+      if( FAST16 )
+      {
+        uint32_t ao[4], ac[4];
+        avgRow16Pk( po + ( ptrdiff_t ) ( 2 * r ) * orgStride, orgStride, ao );
+        avgRow16Pk( pc + ( ptrdiff_t ) ( 2 * r ) * curStride, curStride, ac );
+#pragma unroll
+        for( int q = 0; q < 4; q++ ) d[4 * r + q] = pkSub( ao[q], ac[q] );
+      }
+      else
+      {
+        const u32x4 x = ld16( po + ( ptrdiff_t ) r * orgStride ), z = ld16( pc + ( ptrdiff_t ) r * curStride );
+        d[4 * r] = pkSub( x.x, z.x ); d[4 * r + 1] = pkSub( x.y, z.y ); d[4 * r + 2] = pkSub( x.z, z.z ); d[4 * r + 3] = pkSub( x.w, z.w );
+      }
+    }
+    // five Walsh-Hadamard stages over the dword index (both halves in parallel)
+#pragma unroll
+    for( int len = 1; len < 32; len <<= 1 )
+#pragma unroll
+      for( int i = 0; i < 32; i += 2 * len )
+#pragma unroll
+        for( int j = i; j < i + len; j++ ) { const uint32_t a = d[j], b = d[j + len]; d[j] = pkAdd( a, b ); d[j + len] = pkSub( a, b ); }
+    // sixth stage + sum of magnitudes: |a + b| + |a - b| = 2 max( |a|, |b| ); dword 0 holds the DC (a + b), which counts a quarter
+    uint32_t m = 0;
+#pragma unroll
+    for( int i = 1; i < 32; i++ ) { const uint32_t ax = pkAbs( d[i] ); const uint32_t lo = ax & 0xffffu, hi = ax >> 16; m += lo > hi ? lo : hi; }
+    const int a0 = ( int ) ( int16_t ) ( d[0] & 0xffffu ), b0 = ( int ) d[0] >> 16;
+    const uint32_t dc = ( uint32_t ) abs( a0 + b0 );
+    const uint32_t s = 2 * m + ( uint32_t ) abs( a0 - b0 ) + ( dc >> 2 );
+    sum += FAST16 ? ( ( s + 2 ) >> 2 ) << 2 : ( s + 2 ) >> 2;                                 // RdCost.cpp:1220-1222 / :1319
+  }
+  const uint64_t tot = vvhipGroupSum64( sum, lpc, threadIdx.x & 63 );
+  if( valid && lt == 0 ) out[cand] = tot;
+}
+
+__global__ void __launch_bounds__( 256 )
+hadTile8PkMultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride, DistMultiJobs jobs )
+{
+  int k = 0;
+#pragma unroll
+  for( int i = 1; i < 8; i++ ) if( i < jobs.nJobs && ( int ) blockIdx.x >= jobs.j[i].blockStart ) k = i;
+  const DistJobGeom& g = jobs.j[k];
+  int blk = blockIdx.x - g.blockStart;
+  if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
+  if( g.fast16 ) hadTilePkBody<true>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  else           hadTilePkBody<false>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
 }
 
 template<int TW, int TH, bool FAST16>
@@ -695,7 +806,10 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       blocks += g.nBlocks;
       mj.nJobs++; i++;
     }
-    if( fam == 2 )            hipLaunchKernelGGL( hadTile8MultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    // bit depths <= 10: the packed 16-bit tile (the reference's x86 rows have the same limit); VVHIP_HAD_PK=0 forces the 32-bit form
+    static const int hadPk = []{ const char* e = getenv( "VVHIP_HAD_PK" ); return e ? atoi( e ) : 1; }();
+    if( fam == 2 && bit_depth <= 10 && hadPk ) hipLaunchKernelGGL( hadTile8PkMultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else if( fam == 2 )       hipLaunchKernelGGL( hadTile8MultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
     else if( anySad && anySse ) hipLaunchKernelGGL( sadSseMixedKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
     else if( anySad )         hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SAD> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
     else                      hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SSE> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
