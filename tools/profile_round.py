@@ -27,7 +27,7 @@ def class_of(name):
     if head.startswith("sadSseMultiKernel<"):
         arg = head[len("sadSseMultiKernel<"):].rstrip(">")
         return "SSE" if arg.endswith("1") else "SAD"
-    if head.startswith("hadTile8MultiKernel"):
+    if head.startswith("hadTile8MultiKernel") or head.startswith("hadTile8PkMultiKernel"):
         return "HAD_fast"
     if head.startswith("tuRdoRowMultiKernel") or head.startswith("tuMxMultiKernel"):
         return "TU"
