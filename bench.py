@@ -262,7 +262,7 @@ def main():
         ks[dom] = td
         launches_per_frame = ks[dom]["launches"] / args.steps
         out["kernels"] = ks
-        out["roofline"] = {"bound": "hbm", "kernel": {"SAD_SSE": "sadSseMixedKernel", "SAD": "sadSseMultiKernel<SAD>", "SSE": "sadSseMultiKernel<SSE>", "HAD_fast": "hadTile8PkMultiKernel", "TU": "tuMxMultiKernel", "SUBPEL": "refinePredKernel + hadTileKernel", "TU8": "tuMxMultiKernel", "TU16": "tuMxMultiKernel", "TU32": "tuMxMultiKernel"}[dom],
+        out["roofline"] = {"bound": "hbm", "kernel": {"SAD_SSE": "sadSseMixedKernel", "SAD": "sadSseMultiKernel<SAD>", "SSE": "sadSseMultiKernel<SSE>", "HAD_fast": "hadTile8PkMultiKernel", "TU": "tuMxMultiKernel<false>", "SUBPEL": "refinePredKernel + hadTileKernel", "TU8": "tuMxMultiKernel<false>", "TU16": "tuMxMultiKernel<false>", "TU32": "tuMxMultiKernel<false>"}[dom],
                            "achieved": ks[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ks[dom]["alg_GBps"] / HBM_PEAK_GBS,
                            "traffic": pmc_traffic(dom, args),
                            "alg_bytes_per_launch": wl.alg_bytes[dom] / launches_per_frame, "avg_launch_ms": ks[dom]["avg_ms"],

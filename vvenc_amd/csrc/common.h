@@ -16,8 +16,8 @@ struct vvhip_ctx
   // ROM in HBM (uploaded once by vvhip_create)
   int16_t*     d_trMat    = nullptr;   // all transform matrices, see trMatOffset()
   uint16_t*    d_scan     = nullptr;   // grouped diagonal scan orders, see scanOffset()
-  struct VvhipTuMxOps* d_tuMx = nullptr;   // matrix-core operand records of the fused TU kernel: [type][size 8,16,32], see VvhipTuMxOps
-  uint16_t*    d_tuMxPos  = nullptr;   // scan position of every (lane, register) of a 32x32 tile, per size: [3][64][16]
+  struct VvhipTuMxOps* d_tuMx = nullptr;   // matrix-core operand records of the fused TU kernel: [type][size 4,8,16,32], see VvhipTuMxOps
+  uint16_t*    d_tuMxPos  = nullptr;   // scan position of every (lane, register) of a 32x32 tile, per size: [4][64][16]
   // scratch for vvhip_mctf_motion_estimation (grown on demand)
   void*        d_scratch  = nullptr;
   size_t       scratchBytes = 0;

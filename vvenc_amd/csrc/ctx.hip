@@ -149,17 +149,17 @@ int vvhip_create( vvhip_ctx** out, int device )
       uint16_t* dst = scans.data() + scanOffset( lw, lh );
       for( int i = 0; i < ( 1 << ( lw + lh ) ); i++ ) dst[i] = ( uint16_t ) tmp[i];
     }
-  // matrix-core operand records (common.h: VvhipTuMxOps) and per-register scan positions for 8-, 16- and 32-point square TUs
-  std::vector<VvhipTuMxOps> mx( 9 );
-  std::vector<uint16_t> mxPos( 3 * 64 * 16 );
-  for( int z = 0; z < 3; z++ )
+  // matrix-core operand records (common.h: VvhipTuMxOps) and per-register scan positions for 4-, 8-, 16- and 32-point square TUs: record [type * 4 + log2N - 2]
+  std::vector<VvhipTuMxOps> mx( 12 );
+  std::vector<uint16_t> mxPos( 4 * 64 * 16 );
+  for( int z = 0; z < 4; z++ )
   {
-    const int l2 = 3 + z, n = 1 << l2;
+    const int l2 = 2 + z, n = 1 << l2;
     for( int t = 0; t < 3; t++ )
     {
       const int16_t* m = mats.data() + trMatOffset( t, l2 );
       auto big = [&]( int r, int c ) -> int { return ( r / n == c / n ) ? m[( r % n ) * n + ( c % n )] : 0; };
-      VvhipTuMxOps& o = mx[t * 3 + z];
+      VvhipTuMxOps& o = mx[t * 4 + z];
       for( int r = 0; r < 32; r++ )
       {
         int rs = 0, cs = 0;

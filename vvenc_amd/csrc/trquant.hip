@@ -917,7 +917,7 @@ __device__ __forceinline__ uint32_t tuMxGroupMaxPk16( uint32_t v, int G, int lan
 {
   v = pkMaxU16( v, ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR1 ) );
   v = pkMaxU16( v, ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR2 ) );
-  v = pkMaxU16( v, ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_HALF_MIRROR ) );
+  if( G >= 8 ) v = pkMaxU16( v, ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_HALF_MIRROR ) );
   if( G >= 16 ) v = pkMaxU16( v, ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_MIRROR ) );
   if( G >= 32 )
   {
@@ -976,12 +976,14 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 {
   // A lane's 16 registers are 16 consecutive rows (coefficient side) / samples (residual side) 16h .. 16h+15 of its column / row:
   // R TUs per lane with VPR registers each; a TU's lanes are G consecutive lanes (N = 32: the same 32 lanes of both halves).
-  constexpr int TPS = 32 / N, TPT = TPS * TPS, R = N == 8 ? 2 : 1, VPR = 16 / R, G = N == 32 ? 64 : N;
+  constexpr int TPS = 32 / N, TPT = TPS * TPS, R = N >= 16 ? 1 : 16 / N, VPR = 16 / R, G = N == 32 ? 64 : N;
+  constexpr int PS = N < 8 ? N : 8, NP = 16 / PS;                     // a lane's 16 samples are fetched / stored in NP runs of PS samples (one TU each)
   constexpr int LP = 40;                                              // staging pitch (int16): rows 80 bytes apart
   struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+  struct __attribute__( ( packed, aligned( 2 ) ) ) U8 { u32x2 v; };
   const int lane = threadIdx.x & 63, h = lane >> 5, c32 = lane & 31;
   const int blkL = c32 / N, inL = c32 % N;                            // the lane's row (residual side) / column (coefficient side): TU block, index inside
-  const int blk0 = N == 32 ? 0 : N == 16 ? h : 2 * h;                 // first TU block along the register direction
+  const int blk0 = ( 16 * h ) / N;                                    // first TU block along the register direction
   const v16i zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
 #define TUMX_KEEP( ARR ) { int k_ = 0; _Pragma( "unroll" ) for( int v = 0; v < 16; v++ ) k_ ^= ARR[v]; if( k_ == 0x12345678 ) A.stats[0].pad = 1; }   /* phase profiling: keeps the values live */
@@ -1013,17 +1015,27 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 
   for( int tile = waveIndex; tile < A.tiles; tile += A.waveStride )
   {
-    // ---- residual: lane = row Y of the tile, samples X = 16h .. 16h+15 (the K-slots of this lane) as two 16-byte runs
+    // ---- residual: lane = row Y of the tile, samples X = 16h .. 16h+15 (the K-slots of this lane) in NP runs of PS samples
     uint32_t xr[8];
     v4i aLo, aHi;
 #pragma unroll
-    for( int c = 0; c < 2; c++ )
+    for( int c = 0; c < NP; c++ )
     {
-      const int X0 = 16 * h + 8 * c;
+      const int X0 = 16 * h + PS * c;
       const int tu = tile * TPT + blkL * TPS + X0 / N;
-      u32x4 v = { 0, 0, 0, 0 };
-      if( tu < A.n ) v = reinterpret_cast<const U16*>( resi + A.resiOff[tu] + ( ptrdiff_t ) inL * resiStride + X0 % N )->v;
-      xr[4 * c] = v.x; xr[4 * c + 1] = v.y; xr[4 * c + 2] = v.z; xr[4 * c + 3] = v.w;
+      const int16_t* src = resi + ( tu < A.n ? A.resiOff[tu] : 0 ) + ( ptrdiff_t ) inL * resiStride + X0 % N;
+      if( PS == 8 )
+      {
+        u32x4 v = { 0, 0, 0, 0 };
+        if( tu < A.n ) v = reinterpret_cast<const U16*>( src )->v;
+        xr[4 * c] = v.x; xr[( 4 * c + 1 ) & 7] = v.y; xr[( 4 * c + 2 ) & 7] = v.z; xr[( 4 * c + 3 ) & 7] = v.w;
+      }
+      else
+      {
+        u32x2 v = { 0, 0 };
+        if( tu < A.n ) v = reinterpret_cast<const U8*>( src )->v;
+        xr[( 2 * c ) & 7] = v.x; xr[( 2 * c + 1 ) & 7] = v.y;
+      }
     }
 #pragma unroll
     for( int g = 0; g < 4; g++ )
@@ -1180,14 +1192,19 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
     }
     if( A.phaseLimit == 5 ) { TUMX_KEEP( d ); continue; }
     WAVE_SYNC();
-    // ---- levels: staging rows -> raster, 16-byte stores (chunk q: row q / 4 of the tile, samples 8 * (q % 4) ..)
+    // ---- levels: staging rows -> raster in runs of PS samples (run q: row q / (32 / PS) of the tile, samples PS * (q % (32 / PS)) ..)
     if( A.level )
 #pragma unroll
-      for( int u = 0; u < 2; u++ )
+      for( int u = 0; u < 16 / PS; u++ )
       {
-        const int q = lane + 64 * u, Y = q >> 2, X = 8 * ( q & 3 );
+        const int q = lane + 64 * u, Y = q / ( 32 / PS ), X = PS * ( q % ( 32 / PS ) );
         const int tu = tile * TPT + ( Y / N ) * TPS + X / N;
-        if( tu < A.n ) *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * N * N + ( Y % N ) * N + X % N ) = *reinterpret_cast<const u32x4*>( &stage[Y * LP + X] );
+        if( tu < A.n )
+        {
+          int16_t* dst = A.level + ( size_t ) tu * N * N + ( Y % N ) * N + X % N;
+          if( PS == 8 ) *reinterpret_cast<u32x4*>( dst ) = *reinterpret_cast<const u32x4*>( &stage[Y * LP + X] );
+          else          *reinterpret_cast<u32x2*>( dst ) = *reinterpret_cast<const u32x2*>( &stage[Y * LP + X] );
+        }
       }
     WAVE_SYNC();
 
@@ -1209,13 +1226,23 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
     // ahead of the matrix products — cheaper than holding 8 registers through the quantiser)                                  (:613)
     uint32_t xr2[8];
 #pragma unroll
-    for( int c = 0; c < 2; c++ )
+    for( int c = 0; c < NP; c++ )
     {
-      const int X0 = 16 * h + 8 * c;
+      const int X0 = 16 * h + PS * c;
       const int tu = tile * TPT + blkL * TPS + X0 / N;
-      u32x4 v = { 0, 0, 0, 0 };
-      if( tu < A.n ) v = reinterpret_cast<const U16*>( resi + A.resiOff[tu] + ( ptrdiff_t ) inL * resiStride + X0 % N )->v;
-      xr2[4 * c] = v.x; xr2[4 * c + 1] = v.y; xr2[4 * c + 2] = v.z; xr2[4 * c + 3] = v.w;
+      const int16_t* src = resi + ( tu < A.n ? A.resiOff[tu] : 0 ) + ( ptrdiff_t ) inL * resiStride + X0 % N;
+      if( PS == 8 )
+      {
+        u32x4 v = { 0, 0, 0, 0 };
+        if( tu < A.n ) v = reinterpret_cast<const U16*>( src )->v;
+        xr2[4 * c] = v.x; xr2[( 4 * c + 1 ) & 7] = v.y; xr2[( 4 * c + 2 ) & 7] = v.z; xr2[( 4 * c + 3 ) & 7] = v.w;
+      }
+      else
+      {
+        u32x2 v = { 0, 0 };
+        if( tu < A.n ) v = reinterpret_cast<const U8*>( src )->v;
+        xr2[( 2 * c ) & 7] = v.x; xr2[( 2 * c + 1 ) & 7] = v.y;
+      }
     }
     {
       v16i c;
@@ -1232,23 +1259,24 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 #pragma unroll
     for( int r = 0; r < R; r++ ) sse[r] = 0;
 #pragma unroll
-    for( int c = 0; c < 2; c++ )
+    for( int c = 0; c < NP; c++ )
     {
-      const int X0 = 16 * h + 8 * c;
+      const int X0 = 16 * h + PS * c;
       const int tu = tile * TPT + blkL * TPS + X0 / N;
-      uint32_t rp[4];
+      uint32_t rp[PS / 2];
 #pragma unroll
-      for( int k = 0; k < 4; k++ )
+      for( int k = 0; k < PS / 2; k++ )
       {
-        const int v = 8 * c + 2 * k;
+        const int v = PS * c + 2 * k, xi = ( PS / 2 ) * c + k;
         rp[k] = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( d[v], d[v + 1] ) );           // saturate + pack
-        const int e0 = ( int ) ( int16_t ) ( xr2[4 * c + k] & 0xffff ) - ( int ) ( int16_t ) ( rp[k] & 0xffff ), e1 = ( ( int ) xr2[4 * c + k] >> 16 ) - ( ( int ) rp[k] >> 16 );
-        sse[R == 2 ? c : 0] += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 );
+        const int e0 = ( int ) ( int16_t ) ( xr2[xi] & 0xffff ) - ( int ) ( int16_t ) ( rp[k] & 0xffff ), e1 = ( ( int ) xr2[xi] >> 16 ) - ( ( int ) rp[k] >> 16 );
+        sse[( PS * c ) / N < R ? ( PS * c ) / N : 0] += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 );
       }
       if( A.rec && tu < A.n )
       {
-        u32x4 v; v.x = rp[0]; v.y = rp[1]; v.z = rp[2]; v.w = rp[3];
-        *reinterpret_cast<u32x4*>( A.rec + ( size_t ) tu * N * N + inL * N + X0 % N ) = v;
+        int16_t* dst = A.rec + ( size_t ) tu * N * N + inL * N + X0 % N;
+        if( PS == 8 ) { u32x4 v; v.x = rp[0]; v.y = rp[1 % ( PS / 2 )]; v.z = rp[2 % ( PS / 2 )]; v.w = rp[3 % ( PS / 2 )]; *reinterpret_cast<u32x4*>( dst ) = v; }
+        else          { u32x2 v; v.x = rp[0]; v.y = rp[1 % ( PS / 2 )]; *reinterpret_cast<u32x2*>( dst ) = v; }
       }
     }
 #pragma unroll
@@ -1265,6 +1293,8 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 
 struct TuMxJobs { int nJobs; int waveStart[4]; int size[4]; TuMxArgs j[4]; };
 
+// WITH4: also carries the 4-point variant (its four TUs per lane cost registers: launches without 4x4 lists use the kernel without it)
+template<bool WITH4>
 __global__ void __launch_bounds__( 256, 3 )      // <= 168 registers: three waves per SIMD, their memory latencies overlap
 tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs )
 {
@@ -1280,7 +1310,8 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   if( w >= jobs.j[k].waveStride ) return;
   if( jobs.size[k] == 32 )      tuMxBody<32>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
   else if( jobs.size[k] == 16 ) tuMxBody<16>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
-  else                          tuMxBody<8>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
+  else if( jobs.size[k] == 8 )  tuMxBody<8>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
+  else if( WITH4 )              tuMxBody<4>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
 }
 
 __global__ void __launch_bounds__( 256 )
@@ -1547,7 +1578,7 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
   if( !ctx ) return VVHIP_E_ARG;
   if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: bad job table" );
   // square 8/16/32 TUs share the row-per-lane kernel: up to 4 of them go into one launch, largest size first; anything else runs alone
-  auto mergeable = []( const vvhip_tu_job& j ) { return j.n > 0 && j.width == j.height && ( j.width == 8 || j.width == 16 || j.width == 32 ); };
+  auto mergeable = []( const vvhip_tu_job& j ) { return j.n > 0 && j.width == j.height && ( j.width == 8 || j.width == 16 || j.width == 32 || ( j.width == 4 && tuKernelForm() == 0 ) ); };     // 4x4 only in the matrix-core form
   int order[64], nm = 0;
   for( int i = 0; i < n_jobs; i++ )
   {
@@ -1594,11 +1625,11 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
         const vvhip_tu_job& jb = jobs[order[first + i]];
         const TuRowArgs& ra = mj.j[i];
         TuMxArgs& xa = xj.j[i];
-        const int z = ra.gf.log2w - 3, tpt = ( 32 / jb.width ) * ( 32 / jb.width );
+        const int z = ra.gf.log2w - 2, tpt = ( 32 / jb.width ) * ( 32 / jb.width );
         xa.resiOff = jb.d_resi_off; xa.n = jb.n;
         xa.shF1 = ra.gf.shift1; xa.shF2 = ra.gf.shift2; xa.shI1 = ra.gi.shift1; xa.shI2 = ra.gi.shift2; xa.skipW = ra.gf.skipW; xa.skipH = ra.gf.skipH;
         xa.q = ra.q;
-        xa.opH = ctx->d_tuMx + jb.tr_hor * 3 + z; xa.opV = ctx->d_tuMx + jb.tr_ver * 3 + z; xa.pos = ctx->d_tuMxPos + z * 64 * 16;
+        xa.opH = ctx->d_tuMx + jb.tr_hor * 4 + z; xa.opV = ctx->d_tuMx + jb.tr_ver * 4 + z; xa.pos = ctx->d_tuMxPos + z * 64 * 16;
         xa.qps = jb.d_qp; xa.thrVal = jb.thr_val; xa.level = jb.d_level; xa.rec = jb.d_rec_resi; xa.stats = jb.d_stats;
         xa.tiles = ( jb.n + tpt - 1 ) / tpt; xa.phaseLimit = tuPhaseLimit();
         xa.waveStride = ( xa.tiles + tuRepeat() - 1 ) / tuRepeat();
@@ -1606,7 +1637,10 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
         waves += xa.waveStride;
       }
       for( int i = mj.nJobs; i < 4; i++ ) { xj.waveStart[i] = 0x7fffffff; xj.size[i] = 0; }
-      hipLaunchKernelGGL( tuMxMultiKernel, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
+      bool any4 = false;
+      for( int i = 0; i < xj.nJobs; i++ ) any4 |= xj.size[i] == 4;
+      if( any4 ) hipLaunchKernelGGL( tuMxMultiKernel<true>, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
+      else       hipLaunchKernelGGL( tuMxMultiKernel<false>, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
     }
     else
       hipLaunchKernelGGL( tuRdoRowMultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, mj );
@@ -1690,7 +1724,7 @@ int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_batch: unsupported %dx%d types (%d,%d) bitDepth %d", width, height, tr_hor, tr_ver, bit_depth );
   if( n == 0 ) return VVHIP_OK;
   const int area = width * height;
-  if( width == height && ( width == 8 || width == 16 || width == 32 ) && !getenv( "VVHIP_TU_GENERIC" ) && tuKernelForm() == 0 )
+  if( width == height && ( width == 4 || width == 8 || width == 16 || width == 32 ) && !getenv( "VVHIP_TU_GENERIC" ) && tuKernelForm() == 0 )
   {
     vvhip_tu_job jb; jb.width = width; jb.height = height; jb.tr_hor = tr_hor; jb.tr_ver = tr_ver; jb.n = n; jb.thr_val = thr_val;
     jb.d_resi_off = d_resi_off; jb.d_qp = d_qp; jb.d_level = d_level; jb.d_rec_resi = d_rec_resi; jb.d_stats = d_stats;
