@@ -368,6 +368,11 @@ VVHIP_API int vvhip_alf_classify( vvhip_ctx* ctx, const int16_t* d_rec, int stri
 VVHIP_API int vvhip_alf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_rec, int rec_stride, int width, int height, int ctu_size,
                                      int filter_length, const uint8_t* d_cls /* NULL: chroma */, int vb_ctu_height, int vb_pos, const float* d_init /* may be NULL */, float* d_out );
 
+/* The same with statistics units larger than a CTU (alfUnitSize > CTU size, EncAdaptiveLoopFilter::getStatisticsASU :1568-1590): one record set per unit of
+ * unit_size x unit_size samples (<= 128), the float chains run through the unit's CTUs (ctu_size, raster order) and the blocks inside each CTU.          */
+VVHIP_API int vvhip_alf_stats_plane_units( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_rec, int rec_stride, int width, int height, int unit_size,
+                                           int ctu_size, int filter_length, const uint8_t* d_cls, int vb_ctu_height, int vb_pos, const float* d_init, float* d_out );
+
 /* CC-ALF statistics <- EncAdaptiveLoopFilter::getBlkStatsCcAlf per chroma CTU (EncoderLib/EncAdaptiveLoopFilter.cpp:6061-6357; local terms
  * calcCovariance4CcAlf :6359-6422): 7 luma differences around the co-located luma sample against org - ALF-filtered chroma (d_slf_c).  One record of
  * VVHIP_ALF_REC floats per chroma CTU: E[0..6][0..6] (row pitch 13), y[0..6], pixAcc; float additions in the reference's order (bit-identical).

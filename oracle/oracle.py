@@ -217,7 +217,7 @@ class _Base:
         f(*a, _p(cls))
         return cls
 
-    def alf_stats_plane(self, org, rec, ctu_size, filter_length, cls=None, vb_ctu_height=128, vb_pos=124, init=None):
+    def alf_stats_plane(self, org, rec, ctu_size, filter_length, cls=None, vb_ctu_height=128, vb_pos=124, init=None, ctu_in_unit=None):
         """-> (numCtus, numClasses, ALF_REC) float32: E[13][13], y[13], pixAcc per CTU and class, accumulated in the reference's order"""
         h, w = rec.shape
         pad, m = self.alf_pad(rec)
@@ -228,6 +228,14 @@ class _Base:
         base = pad.ctypes.data + 2 * (m * pad.shape[1] + m)
         clsp = _p(np.ascontiguousarray(cls, np.uint8)) if cls is not None else None
         assert init is None or self._pfx == "orc_"
+        if ctu_in_unit is not None:
+            assert init is None
+            f = getattr(self.L, self._pfx + "alf_stats_plane_units"); f.restype = None if self._pfx == "orc_" else C.c_int
+            if self._pfx == "orc_":
+                f(_p(org), C.c_ssize_t(org.shape[1]), C.c_void_p(base), C.c_ssize_t(pad.shape[1]), w, h, ctu_size, ctu_in_unit, filter_length, clsp, vb_ctu_height, vb_pos, _p(out))
+            else:
+                f(_p(org), org.shape[1], C.c_void_p(base), pad.shape[1], w, h, ctu_size, ctu_in_unit, filter_length, clsp, vb_ctu_height, vb_pos, self.simd, _p(out))
+            return out
         f = getattr(self.L, self._pfx + ("alf_stats_plane" if init is None else "alf_stats_plane_acc")); f.restype = None if self._pfx == "orc_" else C.c_int
         if self._pfx == "orc_":
             f(_p(org), C.c_ssize_t(org.shape[1]), C.c_void_p(base), C.c_ssize_t(pad.shape[1]), w, h, ctu_size, filter_length, clsp, vb_ctu_height, vb_pos, _p(out))

@@ -960,8 +960,17 @@ API int vvref_alf_classify( const int16_t* rec, int stride, int width, int heigh
 
 // Statistics of one plane, CTU by CTU, through EncAdaptiveLoopFilter::getPreBlkStats (EncAdaptiveLoopFilter.cpp:3376) with linear filters
 // (numBins 1).  out: [numCtus][numClasses][13*13 + 13 + 1] floats (E row-major, y, pixAcc); cls == NULL: chroma (one class).
+API int vvref_alf_stats_plane_units( const int16_t* org, int orgStride, const int16_t* rec, int recStride, int width, int height, int unitSize, int ctuSize, int filterLength,
+                                     const uint8_t* cls, int vbCTUHeight, int vbPos, int simd, float* out );
 API int vvref_alf_stats_plane( const int16_t* org, int orgStride, const int16_t* rec, int recStride, int width, int height, int ctuSize, int filterLength,
                                const uint8_t* cls, int vbCTUHeight, int vbPos, int simd, float* out )
+{
+  return vvref_alf_stats_plane_units( org, orgStride, rec, recStride, width, height, ctuSize, ctuSize, filterLength, cls, vbCTUHeight, vbPos, simd, out );
+}
+
+// statistics units made of several CTUs, walked like EncAdaptiveLoopFilter::getStatisticsASU (EncAdaptiveLoopFilter.cpp:1568-1590): one covariance set per unit
+API int vvref_alf_stats_plane_units( const int16_t* org, int orgStride, const int16_t* rec, int recStride, int width, int height, int unitSize, int ctuSize, int filterLength,
+                                     const uint8_t* cls, int vbCTUHeight, int vbPos, int simd, float* out )
 {
   static EncAdaptiveLoopFilter* enc[2] = { nullptr, nullptr };
   static VVEncCfg cfg;
@@ -977,23 +986,27 @@ API int vvref_alf_stats_plane( const int16_t* org, int orgStride, const int16_t*
   std::vector<AlfCovariance> cov( numClasses );
   for( auto& c : cov ) c.create( shape.numCoeff, 1 );
   std::vector<AlfClassifier> cl( 32 * 32 );
-  const int ctusX = ( width + ctuSize - 1 ) / ctuSize, ctusY = ( height + ctuSize - 1 ) / ctuSize;
-  for( int cy = 0; cy < ctusY; cy++ )
-    for( int cx = 0; cx < ctusX; cx++ )
+  const int ux = ( width + unitSize - 1 ) / unitSize, uy = ( height + unitSize - 1 ) / unitSize;
+  for( int ay = 0; ay < uy; ay++ )
+    for( int ax = 0; ax < ux; ax++ )
     {
-      const int x0 = cx * ctuSize, y0 = cy * ctuSize, w = std::min( ctuSize, width - x0 ), h = std::min( ctuSize, height - y0 );
       for( auto& c : cov ) c.reset();
-      if( cls )
-        for( int i = 0; i < h; i += 4 )
-          for( int j = 0; j < w; j += 4 )
-          {
-            const uint8_t* c = cls + 2 * ( ( size_t ) ( ( y0 + i ) / 4 ) * ( width / 4 ) + ( x0 + j ) / 4 );
-            cl[( i / 4 ) * 32 + j / 4] = AlfClassifier( c[0], c[1] );
-          }
-      const CompArea area( cls ? COMP_Y : COMP_Cb, CHROMA_420, Area( x0, y0, w, h ) );
-      E.getPreBlkStats( cov.data(), shape, cls ? cl.data() : nullptr, const_cast<Pel*>( org ) + ( ptrdiff_t ) y0 * orgStride + x0, orgStride,
-                        const_cast<Pel*>( rec ) + ( ptrdiff_t ) y0 * recStride + x0, recStride, area, cls ? CH_L : CH_C, vbCTUHeight, vbPos );
-      float* o = out + ( size_t ) ( cy * ctusX + cx ) * numClasses * rec_;
+      for( int y0 = ay * unitSize; y0 < ( ay + 1 ) * unitSize && y0 < height; y0 += ctuSize )
+        for( int x0 = ax * unitSize; x0 < ( ax + 1 ) * unitSize && x0 < width; x0 += ctuSize )
+        {
+          const int w = std::min( ctuSize, width - x0 ), h = std::min( ctuSize, height - y0 );
+          if( cls )
+            for( int i = 0; i < h; i += 4 )
+              for( int j = 0; j < w; j += 4 )
+              {
+                const uint8_t* c = cls + 2 * ( ( size_t ) ( ( y0 + i ) / 4 ) * ( width / 4 ) + ( x0 + j ) / 4 );
+                cl[( i / 4 ) * 32 + j / 4] = AlfClassifier( c[0], c[1] );
+              }
+          const CompArea area( cls ? COMP_Y : COMP_Cb, CHROMA_420, Area( x0, y0, w, h ) );
+          E.getPreBlkStats( cov.data(), shape, cls ? cl.data() : nullptr, const_cast<Pel*>( org ) + ( ptrdiff_t ) y0 * orgStride + x0, orgStride,
+                            const_cast<Pel*>( rec ) + ( ptrdiff_t ) y0 * recStride + x0, recStride, area, cls ? CH_L : CH_C, vbCTUHeight, vbPos );
+        }
+      float* o = out + ( size_t ) ( ay * ux + ax ) * numClasses * rec_;
       for( int c = 0; c < numClasses; c++, o += rec_ )
       {
         memset( o, 0, sizeof( float ) * rec_ );

@@ -1436,3 +1436,20 @@ void orc_ccalf_stats_plane(const int16_t *orgC, ptrdiff_t orgStride, const int16
       for (int k = 1; k < 7; k++) for (int l = 0; l < k; l++) E[k * 13 + l] = E[l * 13 + k];    /* :6349-6355 */
     }
 }
+
+
+void orc_alf_stats_plane_units(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int width, int height, int unitSize, int ctuSize, int filterLength,
+                               const uint8_t *cls, int vbCTUHeight, int vbPos, float *out)
+{
+  const int numClasses = cls ? 25 : 1, ux = (width + unitSize - 1) / unitSize, uy = (height + unitSize - 1) / unitSize;
+  memset(out, 0, sizeof(float) * (size_t)ux * uy * numClasses * ORC_ALF_REC);
+  for (int ay = 0; ay < uy; ay++)
+    for (int ax = 0; ax < ux; ax++)
+      for (int y0 = ay * unitSize; y0 < (ay + 1) * unitSize && y0 < height; y0 += ctuSize)      /* :1582-1588 */
+        for (int x0 = ax * unitSize; x0 < (ax + 1) * unitSize && x0 < width; x0 += ctuSize)
+        {
+          const int w = x0 + ctuSize > width ? width - x0 : ctuSize, h = y0 + ctuSize > height ? height - y0 : ctuSize;
+          orc_alf_stats_area(org, orgStride, rec, recStride, x0, y0, w, h, filterLength, cls, width / 4, vbCTUHeight, vbPos,
+                             out + (size_t)(ay * ux + ax) * numClasses * ORC_ALF_REC);
+        }
+}

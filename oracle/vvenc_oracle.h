@@ -99,6 +99,10 @@ void orc_alf_stats_plane(const int16_t *org, ptrdiff_t orgStride, const int16_t 
 void orc_alf_stats_plane_acc(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int width, int height, int ctuSize, int filterLength,
                              const uint8_t *cls, int vbCTUHeight, int vbPos, float *out /* continues from the records already there */);
 
+/* statistics units of unitSize x unitSize samples made of CTUs (getStatisticsASU :1568-1590): CTUs of a unit in raster order, one record set per unit */
+void orc_alf_stats_plane_units(const int16_t *org, ptrdiff_t orgStride, const int16_t *rec, ptrdiff_t recStride, int width, int height, int unitSize, int ctuSize, int filterLength,
+                               const uint8_t *cls, int vbCTUHeight, int vbPos, float *out /* [numUnits][numClasses][ORC_ALF_REC], zeroed here */);
+
 /* CC-ALF statistics (EncAdaptiveLoopFilter.cpp:6061-6357 getBlkStatsCcAlf, :6359-6422 calcCovariance4CcAlf): per chroma CTU one record (the first
  * 7 rows / columns of E, y[0..6], pixAcc); local terms = 7 luma differences around the co-located luma sample, target = org - ALF-filtered chroma.
  * recLuma carries a replicated border >= 2.  sx / sy = chroma subsampling shifts; vbCTUHeight / vbPos / picHeight in luma samples.                */

@@ -699,6 +699,11 @@ def test_alf_classification_and_statistics_vs_oracle(hip, oracle, cfg):
     got = hp.alf_stats_plane(p2o, p2r, ctu, 7, d_cls, vbh, vbp, init=first, out=first).cpu().numpy()
     exp = oracle.alf_stats_plane(org2, rec2, ctu, 7, exp_cls, vbh, vbp, init=oracle.alf_stats_plane(org, rec, ctu, 7, exp_cls, vbh, vbp))
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), "continued chains"
+    # statistics units of 2x2 CTUs (alfUnitSize 128 over 64x64 CTUs): chains through the unit's CTUs in raster order
+    if ctu <= 64:
+        got = hp.alf_stats_plane(porg, prec, 2 * ctu, 7, d_cls, vbh, vbp, ctu_in_unit=ctu).cpu().numpy()
+        exp = oracle.alf_stats_plane(org, rec, 2 * ctu, 7, exp_cls, vbh, vbp, ctu_in_unit=ctu)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), "units of 2x2 CTUs"
     # blocks marked unused are skipped
     cls2 = exp_cls.copy(); cls2[::3, 1::2] = 255
     got = hp.alf_stats_plane(porg, prec, ctu, 7, hp.to_device(cls2), vbh, vbp).cpu().numpy()

@@ -535,6 +535,11 @@ def test_alf_classification_and_statistics(oracle, reflib, cfg):
         a = oracle.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2)
         b = reflib.alf_stats_plane(c_org, c_rec, ctu // 2, 5, None, ctu // 2, ctu // 2 - 2)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # statistics units of 2x2 CTUs (alfUnitSize 128 over 64x64 CTUs, what preset faster uses): the chains run through the unit's CTUs
+    if ctu <= 64:
+        a = oracle.alf_stats_plane(org, rec, 2 * ctu, 7, cls, ctu, ctu - 4, ctu_in_unit=ctu)
+        b = reflib.alf_stats_plane(org, rec, 2 * ctu, 7, cls, ctu, ctu - 4, ctu_in_unit=ctu)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     cls2 = cls.copy(); cls2[1::2, ::3] = 255
     assert np.array_equal(oracle.alf_stats_plane(org, rec, ctu, 7, cls2, ctu, ctu - 4).view(np.uint32), reflib.alf_stats_plane(org, rec, ctu, 7, cls2, ctu, ctu - 4).view(np.uint32))
 

@@ -78,6 +78,7 @@ struct AlfStatArgs
 {
   const int16_t* org; const int16_t* rec; const uint8_t* cls; int32_t* sums; const float* init; float* out;
   const int16_t* slf; int slfStride, sx, sy, picHeight;      // CC-ALF: ALF-filtered chroma, chroma subsampling shifts, luma picture height
+  int subBlk;                                                // traversal sub-unit (CTU inside a statistics unit) in 4x4 blocks per side
   int orgStride, recStride, width, height, ctuSize, ctusX, nc, shape, vbH, vbPos, blocksPerCtuRow;
 };
 
@@ -255,25 +256,33 @@ alfOrderedAddKernel( AlfStatArgs A )
   // ring of 4 block rows of sums (8 x 16-byte loads each): row br + 3 is requested before row br is added — the scratch array comes from
   // HBM / Infinity Cache with ~2 us latency and a row's additions take ~0.6 us; two waves per CU own the whole register file
   int4 r0[8], r1[8], r2[8], r3[8];
-#define ALF_FETCH( DST, R ) { const int rr_ = ( R ) < rows ? ( R ) : rows - 1; _Pragma( "unroll" ) for( int q = 0; q < 8; q++ ) DST[q] = sums[( size_t ) rr_ * ROW_I4 + q]; }
-#define ALF_ADD( SRC, R ) if( ( R ) < rows ) { int myCls = 0;                                                                            \
-    _Pragma( "unroll" ) for( int r = 0; r < ALF_MAXB; r++ ) myCls = r == ( R ) ? clsRow[r] : myCls;                                      \
-    _Pragma( "unroll" ) for( int q = 0; q < ALF_MAXB; q++ ) if( q < nb )                                                                 \
+  // traversal: a statistics unit may consist of several CTUs (alfUnitSize > CTU size): CTU by CTU in raster order, blocks in raster order inside
+  // a CTU (getStatisticsASU, :1568-1590).  Step s = (CTU row sy, CTU column sx, block row br inside the CTU); subBlk = CTU size in blocks.
+  const int subBlk = A.subBlk, nSubX = ( nb + subBlk - 1 ) / subBlk, nSubY = ( rows + subBlk - 1 ) / subBlk, steps = nSubY * nSubX * subBlk;
+#define ALF_STEP( S, UR, Q0 ) const int sy_ = ( S ) / ( nSubX * subBlk ), rem_ = ( S ) - sy_ * nSubX * subBlk, sx_ = rem_ / subBlk; \
+                              const int UR = sy_ * subBlk + ( rem_ - sx_ * subBlk ), Q0 = sx_ * subBlk;
+#define ALF_FETCH( DST, S ) { ALF_STEP( S, ur_, q0_ ) ( void ) q0_; const int rr_ = ur_ < rows ? ur_ : rows - 1;                                \
+    _Pragma( "unroll" ) for( int q = 0; q < 8; q++ ) DST[q] = sums[( size_t ) rr_ * ROW_I4 + q]; }
+#define ALF_ADD( SRC, S ) if( ( S ) < steps ) { ALF_STEP( S, ur_, q0_ ) if( ur_ < rows ) { int myCls = 0;                                      \
+    const int q1_ = min( nb, q0_ + subBlk );                                                                                             \
+    _Pragma( "unroll" ) for( int r = 0; r < ALF_MAXB; r++ ) myCls = r == ur_ ? clsRow[r] : myCls;                                        \
+    _Pragma( "unroll" ) for( int q = 0; q < ALF_MAXB; q++ ) if( q >= q0_ && q < q1_ )                                                    \
     {                                                                                                                                    \
       const int4 v_ = SRC[q >> 2];                                                                                                       \
       const float f = ( float ) ( ( q & 3 ) == 0 ? v_.x : ( q & 3 ) == 1 ? v_.y : ( q & 3 ) == 2 ? v_.z : v_.w );                        \
       if( NCLS == 1 ) acc[0] += f;                                                                                                       \
       else { const int ct = __builtin_amdgcn_readlane( myCls, q ); if( ct != 0xffff ) acc[ct & 31] += f; }   /* 0xffff: m_ALF_UNUSED_CLASSIDX / _TRANSPOSIDX (:3416) */ \
-    } }
+    } } }
   ALF_FETCH( r0, 0 ) ALF_FETCH( r1, 1 ) ALF_FETCH( r2, 2 )
 #pragma unroll 1
-  for( int br = 0; br < rows; br += 4 )
+  for( int st = 0; st < steps; st += 4 )
   {
-    ALF_FETCH( r3, br + 3 ) ALF_ADD( r0, br )
-    ALF_FETCH( r0, br + 4 ) ALF_ADD( r1, br + 1 )
-    ALF_FETCH( r1, br + 5 ) ALF_ADD( r2, br + 2 )
-    ALF_FETCH( r2, br + 6 ) ALF_ADD( r3, br + 3 )
+    ALF_FETCH( r3, st + 3 ) ALF_ADD( r0, st )
+    ALF_FETCH( r0, st + 4 ) ALF_ADD( r1, st + 1 )
+    ALF_FETCH( r1, st + 5 ) ALF_ADD( r2, st + 2 )
+    ALF_FETCH( r2, st + 6 ) ALF_ADD( r3, st + 3 )
   }
+#undef ALF_STEP
 #undef ALF_FETCH
 #undef ALF_ADD
   // records: E symmetric (upper triangle mirrored, :3493-3512), y, pixAcc; slots of unused coefficients are 0
@@ -356,17 +365,27 @@ int vvhip_alf_classify( vvhip_ctx* ctx, const int16_t* d_rec, int stride, int wi
   return VVHIP_OK;
 }
 
+int vvhip_alf_stats_plane_units( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_rec, int rec_stride, int width, int height, int unit_size, int ctu_size,
+                                 int filter_length, const uint8_t* d_cls, int vb_ctu_height, int vb_pos, const float* d_init, float* d_out );
+
 int vvhip_alf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_rec, int rec_stride, int width, int height, int ctu_size,
                            int filter_length, const uint8_t* d_cls, int vb_ctu_height, int vb_pos, const float* d_init, float* d_out )
 {
+  return vvhip_alf_stats_plane_units( ctx, d_org, org_stride, d_rec, rec_stride, width, height, ctu_size, ctu_size, filter_length, d_cls, vb_ctu_height, vb_pos, d_init, d_out );
+}
+
+int vvhip_alf_stats_plane_units( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_rec, int rec_stride, int width, int height, int unit_size, int ctu_in_unit,
+                                 int filter_length, const uint8_t* d_cls, int vb_ctu_height, int vb_pos, const float* d_init, float* d_out )
+{
+  const int ctu_size = unit_size;
   if( !ctx ) return VVHIP_E_ARG;
   if( width < 4 || height < 4 || ( width & 3 ) || ( height & 3 ) || ( filter_length != 7 && filter_length != 5 ) || ctu_size < 8 || ctu_size > 128 || ( ctu_size & 3 ) ||
-      vb_ctu_height < 4 || ( vb_ctu_height & ( vb_ctu_height - 1 ) ) || vb_pos < 0 || !d_org || !d_rec || !d_out )
+      vb_ctu_height < 4 || ( vb_ctu_height & ( vb_ctu_height - 1 ) ) || vb_pos < 0 || !d_org || !d_rec || !d_out || ctu_in_unit < 8 || ( ctu_in_unit & 3 ) || unit_size % ctu_in_unit )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_alf_stats_plane: %dx%d (multiples of 4), CTU %d (<= 128), filter length %d (7 luma / 5 chroma)", width, height, ctu_size, filter_length );
   AlfStatArgs A;
   A.org = d_org; A.rec = d_rec; A.cls = d_cls; A.init = d_init; A.out = d_out; A.slf = nullptr; A.slfStride = 0; A.sx = 0; A.sy = 0; A.picHeight = 0; A.orgStride = org_stride; A.recStride = rec_stride; A.width = width; A.height = height;
   A.ctuSize = ctu_size; A.ctusX = ( width + ctu_size - 1 ) / ctu_size; A.nc = filter_length * filter_length / 4 + 1;
-  A.shape = filter_length == 7 ? 0 : 1; A.vbH = vb_ctu_height; A.vbPos = vb_pos; A.blocksPerCtuRow = ctu_size >> 2;
+  A.shape = filter_length == 7 ? 0 : 1; A.vbH = vb_ctu_height; A.vbPos = vb_pos; A.blocksPerCtuRow = ctu_size >> 2; A.subBlk = ctu_in_unit >> 2;
   return alfLaunchStats( ctx, A, width, height, ctu_size, false );
 }
 
@@ -381,7 +400,7 @@ int vvhip_ccalf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org_c, int org_str
   A.org = d_org_c; A.rec = d_rec_luma; A.cls = nullptr; A.init = d_init; A.out = d_out; A.orgStride = org_stride; A.recStride = rec_stride; A.width = width_c; A.height = height_c;
   A.slf = d_slf_c; A.slfStride = slf_stride; A.sx = shift_x; A.sy = shift_y; A.picHeight = pic_height;
   A.ctuSize = ctu_size_c; A.ctusX = ( width_c + ctu_size_c - 1 ) / ctu_size_c; A.nc = 7;
-  A.shape = 1; A.vbH = vb_ctu_height; A.vbPos = vb_pos; A.blocksPerCtuRow = ctu_size_c >> 2;
+  A.shape = 1; A.vbH = vb_ctu_height; A.vbPos = vb_pos; A.blocksPerCtuRow = ctu_size_c >> 2; A.subBlk = ctu_size_c >> 2;
   return alfLaunchStats( ctx, A, width_c, height_c, ctu_size_c, true );
 }
 

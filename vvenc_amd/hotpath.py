@@ -286,13 +286,13 @@ class HotPath:
         self._ck(self.L.vvhip_alf_classify(self.ctx, rec.buf_ptr, rec.stride, rec.width, rec.height, bit_depth, vb_ctu_height, vb_pos, _ptr(out)))
         return out
 
-    def alf_stats_plane(self, org, rec, ctu_size, filter_length, d_cls=None, vb_ctu_height=128, vb_pos=124, out=None, init=None):
+    def alf_stats_plane(self, org, rec, ctu_size, filter_length, d_cls=None, vb_ctu_height=128, vb_pos=124, out=None, init=None, ctu_in_unit=None):
         """covariance records of every CTU of a plane -> float32 tensor (numCtus, 25 or 1, ALF_REC): E[13][13], y[13], pixAcc"""
         nctu = ((rec.width + ctu_size - 1) // ctu_size) * ((rec.height + ctu_size - 1) // ctu_size)
         ncls = 25 if d_cls is not None else 1
         if out is None:
             out = torch.empty((nctu, ncls, self.ALF_REC), dtype=torch.float32, device=self.device)
-        self._ck(self.L.vvhip_alf_stats_plane(self.ctx, org.buf_ptr, org.stride, rec.buf_ptr, rec.stride, rec.width, rec.height, ctu_size, filter_length,
+        self._ck(self.L.vvhip_alf_stats_plane_units(self.ctx, org.buf_ptr, org.stride, rec.buf_ptr, rec.stride, rec.width, rec.height, ctu_size, ctu_in_unit or ctu_size, filter_length,
                                               _ptr(d_cls) if d_cls is not None else None, vb_ctu_height, vb_pos, _ptr(init) if init is not None else None, _ptr(out)))
         return out
 

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "vvhip_dmvr_refine_batch": (i32, [vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "vvhip_alf_classify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "vvhip_ccalf_stats_plane": (i32, [vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "vvhip_alf_stats_plane_units": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
     "vvhip_alf_stats_plane": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
     "vvhip_subpel_refine_batch": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]),
     "vvhip_get_tr_matrix_host": (i32, [i32, i32, vp]),
