@@ -153,6 +153,57 @@ patch("EncAdaptiveLoopFilter.cpp", [
      "    }\n"
      "    if( !hipAlf )\n    {\n"),
     ("before", "  }  \n}\n\nvoid EncAdaptiveLoopFilter::copyCTUforALF(", "    }\n"),
+    # whole-picture ALF statistics: the per-CTU tasks do nothing, the first thing deriveFilter does is ONE device call for the picture
+    ("before", "  const PreCalcValues& pcv = *cs.pcv;\n  const int xC = ( ctuRsAddr % pcv.widthInCtus ) << pcv.maxCUSizeLog2;",
+     "  if( ( g_vvhipHooks.alfPicture && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) ) return;\n"),
+    ("after", "  initCABACEstimator( cs.slice );\n\n  // Accumulate ALF statistic\n",
+     "  if( ( g_vvhipHooks.alfPicture && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) && numCtus == ( int ) m_numCTUsInPic )\n"
+     "  {\n"
+     "    static thread_local std::vector<uint8_t> hCls; static thread_local std::vector<float> hSt[3];\n"
+     "    hCls.resize( ( size_t ) ( m_picWidth / 4 ) * ( m_picHeight / 4 ) * 2 );\n"
+     "    const Pel* hRec[3]; const Pel* hOrg[3]; int hRs[3], hOs[3]; bool hEn[3]; float* hP[3];\n"
+     "    PelUnitBuf hOrgYuv = pic.getOrigBuf();\n"
+     "    for( int c = 0; c < 3; c++ )\n"
+     "    {\n"
+     "      hRec[c] = m_tempBuf.get( ComponentID( c ) ).buf; hRs[c] = m_tempBuf.get( ComponentID( c ) ).stride;\n"
+     "      hOrg[c] = hOrgYuv.get( ComponentID( c ) ).buf; hOs[c] = hOrgYuv.get( ComponentID( c ) ).stride;\n"
+     "      hEn[c] = m_alfFilterStatEnabled[c]; hSt[c].resize( ( size_t ) m_numAsusInPic * ( c ? 1 : MAX_NUM_ALF_CLASSES ) * 183 ); hP[c] = hSt[c].data();\n"
+     "    }\n"
+     "    const bool hOk = g_vvhipHooks.alfPicture( hRec, hRs, hOrg, hOs, m_picWidth, m_picHeight, m_inputBitDepth[CH_L], m_maxCUHeight, m_maxAsuHeight,\n"
+     "                                              m_alfVBLumaCTUHeight, m_alfVBLumaPos, m_alfVBChmaCTUHeight, m_alfVBChmaPos, hEn, hCls.data(), hP );\n"
+     "    CHECK( !hOk, \"HIP ALF picture statistics failed\" );\n"
+     "    const int hBw = m_picWidth / 4, hCtuBlk = ( MAX_CU_SIZE * MAX_CU_SIZE ) >> 4;\n"
+     "    for( int ctu = 0; ctu < ( int ) m_numCTUsInPic; ctu++ )\n"
+     "    {\n"
+     "      const int x0 = ( ctu % m_numCTUsInWidth ) * m_maxCUWidth, y0 = ( ctu / m_numCTUsInWidth ) * m_maxCUHeight;\n"
+     "      const int w = std::min( m_maxCUWidth, m_picWidth - x0 ), h = std::min( m_maxCUHeight, m_picHeight - y0 );\n"
+     "      for( int i = 0; i < h; i += 4 ) for( int j = 0; j < w; j += 4 )\n"
+     "      {\n"
+     "        const uint8_t* c = hCls.data() + 2 * ( ( size_t ) ( ( y0 + i ) / 4 ) * hBw + ( x0 + j ) / 4 );\n"
+     "        m_classifier[hCtuBlk * ctu + ( i / 4 ) * ( MAX_CU_SIZE / 4 ) + j / 4] = AlfClassifier( c[0], c[1] );\n"
+     "      }\n"
+     "    }\n"
+     "    for( int a = 0; a < m_numAsusInPic; a++ )\n"
+     "    {\n"
+     "      const int x0 = ( a % m_numAsusInWidth ) * m_maxAsuWidth, y0 = ( a / m_numAsusInWidth ) * m_maxAsuHeight;\n"
+     "      const int w = std::min( m_maxAsuWidth, m_picWidth - x0 ), h = std::min( m_maxAsuHeight, m_picHeight - y0 );\n"
+     "      bool used[MAX_NUM_ALF_CLASSES] = { false };\n"
+     "      for( int i = 0; i < h; i += 4 ) for( int j = 0; j < w; j += 4 ) used[hCls[2 * ( ( size_t ) ( ( y0 + i ) / 4 ) * hBw + ( x0 + j ) / 4 )]] = true;\n"
+     "      for( int c = 0; c < 3; c++ )\n"
+     "      {\n"
+     "        if( !hEn[c] ) continue;\n"
+     "        const int nCls = c ? 1 : MAX_NUM_ALF_CLASSES, nCo = m_filterShapes[toChannelType( ComponentID( c ) )].numCoeff;\n"
+     "        for( int k = 0; k < nCls; k++ )\n"
+     "        {\n"
+     "          AlfCovariance& cov = m_alfCovariance[c][a][k]; const float* r = hP[c] + ( ( size_t ) a * nCls + k ) * 183;\n"
+     "          cov.reset();\n"
+     "          if( c == 0 && !used[k] ) continue;\n"
+     "          for( int p = 0; p < nCo; p++ ) { for( int q = 0; q < nCo; q++ ) cov.E[0][0][p][q] = r[p * 13 + q]; cov.y[0][p] = r[169 + p]; }\n"
+     "          cov.pixAcc = r[182]; cov.all0 = false;\n"
+     "        }\n"
+     "      }\n"
+     "    }\n"
+     "  }\n"),
     # CC-ALF statistics of a CTU and chroma component (one CTU per covariance, reset before): the record comes from the device
     ("replace", "    getBlkStatsCcAlf( m_alfCovarianceCcAlf[compIdx - 1][filterIdx][ctuRsAddr], m_filterShapesCcAlf[compIdx - 1], orgYuv, recYuv, area, area, compID, yPos );\n  }\n}",
      "    bool hipCc = false;\n"

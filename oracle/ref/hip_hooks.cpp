@@ -412,6 +412,16 @@ bool alfCtu( const int16_t* const rec[3], const int recStride[3], const int16_t*
   return true;
 }
 
+std::atomic<uint64_t> g_alfPictures{ 0 };
+bool alfPicture( const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int bitDepth,
+                 int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] )
+{
+  static vvhip::ALFOps alf;
+  if( !alf.pictureStatistics( rec, recStride, org, orgStride, width, height, bitDepth, ctuSize, unitSize, vbLumaH, vbLumaPos, vbChromaH, vbChromaPos, enabled, cls, stats ) ) return false;
+  g_alfPictures++;
+  return true;
+}
+
 std::atomic<uint64_t> g_ccAlfCtus{ 0 };
 bool ccAlfCtu( const int16_t* orgC, int orgStride, const int16_t* slfC, int slfStride, const int16_t* recLuma, int recStride, int widthC, int heightC,
                int vbCTUHeight, int vbPos, int picHeightFromHere, float* record )
@@ -424,7 +434,7 @@ bool ccAlfCtu( const int16_t* orgC, int orgStride, const int16_t* slfC, int slfS
 
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
 {
-  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round), bit11 ALF statistics per CTU (classification + covariance records), bit12 CC-ALF statistics per CTU and chroma component
+  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round), bit11 ALF statistics per CTU (classification + covariance records), bit12 CC-ALF statistics per CTU and chroma component, bit13 ALF statistics of a whole picture in one call (the per-CTU statistics tasks become no-ops)
   g_slotMask = mask;
   try
   {
@@ -443,6 +453,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
   g_vvhipHooks.dmvrSearch = ( mask & 512 ) ? dmvrSearch : nullptr;
   g_vvhipHooks.alfCtu = ( mask & 2048 ) ? alfCtu : nullptr; g_alfCtus = 0;
   g_vvhipHooks.ccAlfCtu = ( mask & 4096 ) ? ccAlfCtu : nullptr; g_ccAlfCtus = 0;
+  g_vvhipHooks.alfPicture = ( mask & 8192 ) ? alfPicture : nullptr; g_alfPictures = 0;
   g_vvhipHooks.tzReset = ( mask & 1024 ) ? tzReset : nullptr; g_vvhipHooks.tzPrefetch = ( mask & 1024 ) ? tzPrefetch : nullptr; g_vvhipHooks.tzLookup = ( mask & 1024 ) ? tzLookup : nullptr;
   g_tzRounds = 0; g_tzHits = 0;
   g_dmvrCalls = 0;
@@ -464,4 +475,5 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
   if( n > 13 ) out[13] = g_tzHits;
   if( n > 14 ) out[14] = g_alfCtus;
   if( n > 15 ) out[15] = g_ccAlfCtus;
+  if( n > 16 ) out[16] = g_alfPictures;
 }

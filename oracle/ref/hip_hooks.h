@@ -32,6 +32,9 @@ struct VvhipHooks
   // ALF statistics of one CTU: classes of the luma 4x4 blocks and the covariance records of up to three components
   bool ( *alfCtu )( const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int chromaShift,
                     int bitDepth, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls /* [h/4][w/4][2] */, float* const stats[3] /* in: the records to continue from, out: updated */ );
+  // ALF statistics of a whole picture in one call (classes in picture raster, one record set per statistics unit)
+  bool ( *alfPicture )( const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int bitDepth,
+                        int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] );
   // CC-ALF statistics of one CTU and chroma component: record of 183 floats (E[0..6][0..6] with row pitch 13, y[0..6], pixAcc)
   bool ( *ccAlfCtu )( const int16_t* orgC, int orgStride, const int16_t* slfC, int slfStride, const int16_t* recLuma, int recStride, int widthC, int heightC,
                       int vbCTUHeight, int vbPos, int picHeightFromHere, float* record );

@@ -28,7 +28,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(16, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 16); calls = [int(x) for x in c]
+    c = np.zeros(17, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 17); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -178,6 +178,25 @@ def test_hip_alf_statistics_bitstream_identical():
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][14] > 4 and hip["calls"][15] > 4, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+def test_hip_alf_picture_statistics_bitstream_identical():
+    """the whole-picture form (hook mask 8192): the per-CTU statistics tasks of the encoder do nothing, EncAdaptiveLoopFilter::deriveFilter starts with ONE device
+    call per picture (classification + luma / chroma records of every 128x128 statistics unit, CTU-by-CTU chains inside a unit); small clip and 1080p"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=8192))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][16] >= 1, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+    import e2e_fps
+    res = [e2e_fps.run(dict(w=1920, h=1080, frames=9, threads=8, mask=m)) for m in (0, 8192)]
+    print(res)
+    assert res[1]["calls"][16] >= 1, res[1]["calls"]
+    assert res[0]["md5"] == res[1]["md5"] and res[0]["bytes"] == res[1]["bytes"], res
 
 
 @pytest.mark.gpu

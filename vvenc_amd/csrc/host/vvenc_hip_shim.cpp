@@ -737,6 +737,48 @@ bool ALFOps::getStatistics( const Pel* org, int orgStride, const Pel* rec, int r
   return true;
 }
 
+bool ALFOps::pictureStatistics( const Pel* const rec[3], const int recStride[3], const Pel* const org[3], const int orgStride[3], int width, int height, int bitDepth,
+                                int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] )
+{
+  if( ( width & 7 ) || ( height & 7 ) || unitSize > 128 || unitSize % ctuSize ) return false;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  // the planes go up as they lie in the encoder's buffers (their own strides; rec with 4 border rows / columns): six uploads, no host repacking
+  int w[3], h[3], rp[3], op[3]; size_t rOff[3], oOff[3], total = 0;
+  for( int c = 0; c < 3; c++ )
+  {
+    w[c] = c ? width >> 1 : width; h[c] = c ? height >> 1 : height;
+    rp[c] = recStride[c]; op[c] = orgStride[c];
+    rOff[c] = total; total += ( ( size_t ) rp[c] * ( h[c] + 8 ) + 8 + 127 ) & ~( size_t ) 127;
+  }
+  for( int c = 0; c < 3; c++ ) { oOff[c] = total; total += ( ( size_t ) op[c] * h[c] + 127 ) & ~( size_t ) 127; }
+  int16_t* d = dev.staging( total * sizeof( Pel ) + 256 );
+  for( int c = 0; c < 3; c++ )
+  {
+    // rows -4 .. h+3, starting 4 samples left of column 0; the last row ends at its right border
+    const size_t recElems = ( size_t ) rp[c] * ( h[c] + 7 ) + w[c] + 8;
+    dev.check( vvhip_upload( dev.ctx(), d + rOff[c], rec[c] - ( ptrdiff_t ) 4 * rp[c] - 4, recElems * sizeof( Pel ) ), "ALF rec plane" );
+    const size_t orgElems = ( size_t ) op[c] * ( h[c] - 1 ) + w[c];
+    dev.check( vvhip_upload( dev.ctx(), d + oOff[c], org[c], orgElems * sizeof( Pel ) ), "ALF org plane" );
+  }
+  const int units = ( ( width + unitSize - 1 ) / unitSize ) * ( ( height + unitSize - 1 ) / unitSize );
+  const size_t nCls = ( size_t ) ( width / 4 ) * ( height / 4 ) * 2;
+  const size_t stBytes[3] = { ( size_t ) units * 25 * VVHIP_ALF_REC * sizeof( float ), ( size_t ) units * VVHIP_ALF_REC * sizeof( float ), ( size_t ) units * VVHIP_ALF_REC * sizeof( float ) };
+  const size_t clsPad = ( nCls + 255 ) & ~( size_t ) 255;
+  char* aux = static_cast<char*>( dev.stagingAux( clsPad + stBytes[0] + stBytes[1] + stBytes[2] + 64 ) );
+  uint8_t* dCls = reinterpret_cast<uint8_t*>( aux );
+  float* dSt[3] = { reinterpret_cast<float*>( aux + clsPad ), reinterpret_cast<float*>( aux + clsPad + stBytes[0] ), reinterpret_cast<float*>( aux + clsPad + stBytes[0] + stBytes[1] ) };
+  const int16_t* dRec[3]; const int16_t* dOrg[3];
+  for( int c = 0; c < 3; c++ ) { dRec[c] = d + rOff[c] + ( size_t ) 4 * rp[c] + 4; dOrg[c] = d + oOff[c]; }     // sample (0,0) of each plane
+  dev.check( vvhip_alf_classify( dev.ctx(), dRec[0], rp[0], width, height, bitDepth, vbLumaH, vbLumaPos, dCls ), "vvhip_alf_classify" );
+  if( enabled[0] ) dev.check( vvhip_alf_stats_plane_units( dev.ctx(), dOrg[0], op[0], dRec[0], rp[0], width, height, unitSize, ctuSize, 7, dCls, vbLumaH, vbLumaPos, nullptr, dSt[0] ), "vvhip_alf_stats_plane_units" );
+  for( int c = 1; c < 3; c++ )
+    if( enabled[c] ) dev.check( vvhip_alf_stats_plane_units( dev.ctx(), dOrg[c], op[c], dRec[c], rp[c], w[c], h[c], unitSize >> 1, ctuSize >> 1, 5, nullptr, vbChromaH, vbChromaPos, nullptr, dSt[c] ), "vvhip_alf_stats_plane_units (chroma)" );
+  dev.check( vvhip_download( dev.ctx(), cls, dCls, nCls ), "ALF classes" );
+  for( int c = 0; c < 3; c++ ) if( enabled[c] ) dev.check( vvhip_download( dev.ctx(), stats[c], dSt[c], stBytes[c] ), "ALF statistics" );
+  return true;
+}
+
 bool ALFOps::getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC, int slfStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC,
                                  int vbCTUHeight, int vbPos, int picHeight, float* out, const float* init )
 {

@@ -196,6 +196,11 @@ struct ALFOps
   // init (optional, same layout): the values the float chains start from (statistics units that span several CTUs)
   bool getStatistics( const Pel* org, int orgStride, const Pel* rec, int recStride, int width, int height, int ctuSize, int filterLength,
                       const uint8_t* cls, int vbCTUHeight, int vbPos, float* out, const float* init = nullptr );
+  // whole-picture form (4:2:0): every plane is uploaded once; classes of the luma blocks (picture raster) and the records of every statistics unit
+  // (unitSize x unitSize luma samples, made of CTUs of ctuSize: EncAdaptiveLoopFilter::getStatisticsASU) for the enabled components.
+  // stats[c]: [numUnits][c == 0 ? 25 : 1][183]
+  bool pictureStatistics( const Pel* const rec[3], const int recStride[3], const Pel* const org[3], const int orgStride[3], int width, int height, int bitDepth,
+                          int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] );
   // EncAdaptiveLoopFilter::getBlkStatsCcAlf per chroma CTU (4:2:0): org / slf = chroma planes (slf = ALF-filtered), recLuma with a replicated border >= 2;
   // one record per chroma CTU (E[0..6][0..6], y[0..6], pixAcc), vb* / picHeight in luma samples
   bool getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC, int slfStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC,
