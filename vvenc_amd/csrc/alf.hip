@@ -222,7 +222,7 @@ alfBlockSumsKernel( AlfStatArgs A, AlfTaps T )
 // (lane b of the wave holds the classes of column b; v_readlane -> SGPR), so acc[class] += f is an indexed register access
 // (s_set_gpr_idx), not a branch tree.  Sums of a whole block row (<= 32 blocks) are fetched one row ahead of the additions, the classes of
 // the whole CTU up front: no HBM latency inside the ordered loop.  NCLS = 25 (luma) or 1 (chroma).
-template<int NCLS>
+template<int NCLS, bool UNITS>      // UNITS: statistics units of several CTUs (traversal table); otherwise one CTU per unit: plain raster walk
 __global__ void __launch_bounds__( 128 )
 alfOrderedAddKernel( AlfStatArgs A )
 {
@@ -259,14 +259,20 @@ alfOrderedAddKernel( AlfStatArgs A )
   // traversal: a statistics unit may consist of several CTUs (alfUnitSize > CTU size): CTU by CTU in raster order, blocks in raster order inside
   // a CTU (getStatisticsASU, :1568-1590).  Step s = (CTU row sy, CTU column sx, block row br inside the CTU); subBlk = CTU size in blocks.
   const int subBlk = A.subBlk, nSubX = ( nb + subBlk - 1 ) / subBlk, nSubY = ( rows + subBlk - 1 ) / subBlk, steps = nSubY * nSubX * subBlk;
-#define ALF_STEP( S, UR, Q0 ) const int sy_ = ( S ) / ( nSubX * subBlk ), rem_ = ( S ) - sy_ * nSubX * subBlk, sx_ = rem_ / subBlk; \
-                              const int UR = sy_ * subBlk + ( rem_ - sx_ * subBlk ), Q0 = sx_ * subBlk;
+  __shared__ uint16_t sStep[4 * ALF_MAXB + 8];               // step -> unit block row | first block << 8 (computed once: no divisions in the ordered loop)
+  for( int st = tid; st < steps + 8; st += 128 )
+  {
+    const int sy = st / ( nSubX * subBlk ), rem = st - sy * nSubX * subBlk, sx = rem / subBlk;
+    sStep[st] = ( uint16_t ) ( ( sy * subBlk + ( rem - sx * subBlk ) ) | ( ( sx * subBlk ) << 8 ) );
+  }
+  __syncthreads();
+#define ALF_STEP( S, UR, Q0 ) const int code_ = UNITS ? __builtin_amdgcn_readfirstlane( ( int ) sStep[S] ) : ( S ); const int UR = code_ & 0xff, Q0 = code_ >> 8;
 #define ALF_FETCH( DST, S ) { ALF_STEP( S, ur_, q0_ ) ( void ) q0_; const int rr_ = ur_ < rows ? ur_ : rows - 1;                                \
     _Pragma( "unroll" ) for( int q = 0; q < 8; q++ ) DST[q] = sums[( size_t ) rr_ * ROW_I4 + q]; }
 #define ALF_ADD( SRC, S ) if( ( S ) < steps ) { ALF_STEP( S, ur_, q0_ ) if( ur_ < rows ) { int myCls = 0;                                      \
     const int q1_ = min( nb, q0_ + subBlk );                                                                                             \
     _Pragma( "unroll" ) for( int r = 0; r < ALF_MAXB; r++ ) myCls = r == ur_ ? clsRow[r] : myCls;                                        \
-    _Pragma( "unroll" ) for( int q = 0; q < ALF_MAXB; q++ ) if( q >= q0_ && q < q1_ )                                                    \
+    _Pragma( "unroll" ) for( int q = 0; q < ALF_MAXB; q++ ) if( UNITS ? ( q >= q0_ && q < q1_ ) : q < nb )                                \
     {                                                                                                                                    \
       const int4 v_ = SRC[q >> 2];                                                                                                       \
       const float f = ( float ) ( ( q & 3 ) == 0 ? v_.x : ( q & 3 ) == 1 ? v_.y : ( q & 3 ) == 2 ? v_.z : v_.w );                        \
@@ -345,8 +351,9 @@ static int alfLaunchStats( vvhip_ctx* ctx, AlfStatArgs& A, int width, int height
   if( ccalf ) hipLaunchKernelGGL( alfBlockSumsKernel<1>, dim3( ctus, A.blocksPerCtuRow ), dim3( 256 ), 0, ctx->stream, A, taps );
   else        hipLaunchKernelGGL( alfBlockSumsKernel<0>, dim3( ctus, A.blocksPerCtuRow ), dim3( 256 ), 0, ctx->stream, A, taps );
   VVHIP_LAUNCH_CHECK( ctx );
-  if( A.cls ) hipLaunchKernelGGL( alfOrderedAddKernel<25>, dim3( ctus ), dim3( 128 ), 0, ctx->stream, A );
-  else        hipLaunchKernelGGL( alfOrderedAddKernel<1>, dim3( ctus ), dim3( 128 ), 0, ctx->stream, A );
+  const bool units = A.subBlk != A.blocksPerCtuRow;
+  if( A.cls ) { if( units ) hipLaunchKernelGGL( ( alfOrderedAddKernel<25, true> ), dim3( ctus ), dim3( 128 ), 0, ctx->stream, A ); else hipLaunchKernelGGL( ( alfOrderedAddKernel<25, false> ), dim3( ctus ), dim3( 128 ), 0, ctx->stream, A ); }
+  else        { if( units ) hipLaunchKernelGGL( ( alfOrderedAddKernel<1, true> ), dim3( ctus ), dim3( 128 ), 0, ctx->stream, A ); else hipLaunchKernelGGL( ( alfOrderedAddKernel<1, false> ), dim3( ctus ), dim3( 128 ), 0, ctx->stream, A ); }
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
 }
