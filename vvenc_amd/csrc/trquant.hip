@@ -988,6 +988,34 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 #define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
 #define TUMX_KEEP( ARR ) { int k_ = 0; _Pragma( "unroll" ) for( int v = 0; v < 16; v++ ) k_ ^= ARR[v]; if( k_ == 0x12345678 ) A.stats[0].pad = 1; }   /* phase profiling: keeps the values live */
 
+  // residual of a tile: lane = row Y of the tile, samples X = 16h .. 16h+15 (the K-slots of this lane) in NP runs of PS samples.  The wave's first
+  // tile is requested BEFORE the constants below: the offset -> residual chain and the ROM -> LDS chain overlap.
+  auto loadResidual = [&]( const int tile, uint32_t* xr )
+  {
+#pragma unroll
+    for( int c = 0; c < NP; c++ )
+    {
+      const int X0 = 16 * h + PS * c;
+      const int tu = tile * TPT + blkL * TPS + X0 / N;
+      const bool ok = tile < A.tiles && tu < A.n;
+      const int16_t* src = resi + ( ok ? A.resiOff[tu] : 0 ) + ( ptrdiff_t ) inL * resiStride + X0 % N;
+      if( PS == 8 )
+      {
+        u32x4 v = { 0, 0, 0, 0 };
+        if( ok ) v = reinterpret_cast<const U16*>( src )->v;
+        xr[4 * c] = v.x; xr[( 4 * c + 1 ) & 7] = v.y; xr[( 4 * c + 2 ) & 7] = v.z; xr[( 4 * c + 3 ) & 7] = v.w;
+      }
+      else
+      {
+        u32x2 v = { 0, 0 };
+        if( ok ) v = reinterpret_cast<const U8*>( src )->v;
+        xr[( 2 * c ) & 7] = v.x; xr[( 2 * c + 1 ) & 7] = v.y;
+      }
+    }
+  };
+  uint32_t xr[8];
+  loadResidual( waveIndex, xr );
+
   // ---- per-wave constants.  The zero-out of the 32-point DST-7 / DCT-8 (coefficients beyond 16 dropped, TrQuant.cpp:496-497) is folded
   // into the operands: a dead column k gets an all-zero Th operand (its intermediate becomes 0), a dead row k2 an all-zero Tv operand row;
   // with the correction dropped as well the result is ( rnd >> shift ) = 0.
@@ -1015,28 +1043,8 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 
   for( int tile = waveIndex; tile < A.tiles; tile += A.waveStride )
   {
-    // ---- residual: lane = row Y of the tile, samples X = 16h .. 16h+15 (the K-slots of this lane) in NP runs of PS samples
-    uint32_t xr[8];
     v4i aLo, aHi;
-#pragma unroll
-    for( int c = 0; c < NP; c++ )
-    {
-      const int X0 = 16 * h + PS * c;
-      const int tu = tile * TPT + blkL * TPS + X0 / N;
-      const int16_t* src = resi + ( tu < A.n ? A.resiOff[tu] : 0 ) + ( ptrdiff_t ) inL * resiStride + X0 % N;
-      if( PS == 8 )
-      {
-        u32x4 v = { 0, 0, 0, 0 };
-        if( tu < A.n ) v = reinterpret_cast<const U16*>( src )->v;
-        xr[4 * c] = v.x; xr[( 4 * c + 1 ) & 7] = v.y; xr[( 4 * c + 2 ) & 7] = v.z; xr[( 4 * c + 3 ) & 7] = v.w;
-      }
-      else
-      {
-        u32x2 v = { 0, 0 };
-        if( tu < A.n ) v = reinterpret_cast<const U8*>( src )->v;
-        xr[( 2 * c ) & 7] = v.x; xr[( 2 * c + 1 ) & 7] = v.y;
-      }
-    }
+    if( tile != waveIndex ) loadResidual( tile, xr );
 #pragma unroll
     for( int g = 0; g < 4; g++ )
     {
