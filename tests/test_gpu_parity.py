@@ -640,6 +640,8 @@ def test_bad_arguments_are_reported_not_crashed(hip):
     plane = hp.plane(np.zeros((64, 64), np.int16), 0)
     items = hp.to_device(np.zeros((4, 2), np.int32))
     out = torch.zeros(4, dtype=torch.int64, device=hp.device)
+    plane8 = hp.plane(np.zeros((64, 64), np.int16), 8)
+    cls8 = torch.zeros((16, 16, 2), dtype=torch.uint8, device=hp.device)
     bad = [
         lambda: hp.dist_batch("SAD", plane, plane, items, 4, 3, 8),                                   # width 3
         lambda: hp.dist_batch("HAD", plane, plane, items, 4, 256, 256),                               # block larger than 128
@@ -650,6 +652,12 @@ def test_bad_arguments_are_reported_not_crashed(hip):
         lambda: hp.subpel_refine_batch("HAD", plane, plane, items, 1, [(40, 0)], 8, 8),               # offset beyond one sample
         lambda: hp.dmvr_refine_batch(plane, plane, items, 1, 32, 16),                                 # DMVR sub-blocks are at most 16x16
         lambda: hp.mctf_apply_plane(plane, [plane], [items], 1, 0, [1.0], 1.0, 1.0, 10, 64),          # unit 64 unsupported
+        lambda: hp.alf_classify(hp.plane(np.zeros((66, 64), np.int16), 8)),                             # height not a multiple of 4
+        lambda: hp.alf_classify(plane8, 10, 96, 92),                                                  # CTU height not a power of two
+        lambda: hp.alf_stats_plane(plane, plane8, 256, 7, cls8),                                      # statistics unit larger than 128
+        lambda: hp.alf_stats_plane(plane, plane8, 64, 9, cls8),                                       # filter length 9
+        lambda: hp.alf_stats_plane(plane, plane8, 128, 7, cls8, ctu_in_unit=48),                      # unit not a multiple of the CTU
+        lambda: hp.ccalf_stats_plane(plane, plane, plane8, 128),                                      # chroma CTU 128 = luma 256
     ]
     for k, f in enumerate(bad):
         with pytest.raises(VVHipError) as e:
