@@ -17,6 +17,7 @@ struct vvhip_ctx
   int16_t*     d_trMat    = nullptr;   // all transform matrices, see trMatOffset()
   uint16_t*    d_scan     = nullptr;   // grouped diagonal scan orders, see scanOffset()
   struct VvhipTuMxOps* d_tuMx = nullptr;   // matrix-core operand records of the fused TU kernel: [type][size 4,8,16,32], see VvhipTuMxOps
+  struct VvhipTuMx64Ops* d_tuMx64 = nullptr;   // the 64-point DCT-2 record
   uint16_t*    d_tuMxPos  = nullptr;   // scan position of every (lane, register) of a 32x32 tile, per size: [4][64][16]
   // scratch for vvhip_mctf_motion_estimation (grown on demand)
   void*        d_scratch  = nullptr;
@@ -69,6 +70,19 @@ struct VvhipTuMxOps
   int8_t  colP[64][16];        // A side, inverse rows:     lane l: big[mxHw(h, s)][mxSigma(l % 32)]
   int32_t rowSum[32];          // 128 * sum_x big[r][x]: corrections for the (byte - 128) form of the data's low bytes
   int32_t colSum[32];          // 128 * sum_k big[k][c]
+};
+
+// 64-point DCT-2 with its zero-out (only the 32 low frequencies per direction survive, TrQuant.cpp:496-497): one wave per 64x64 TU, the
+// residual as two row tiles x two column chunks of 32, every contraction over 64 split into two accumulating products.
+struct VvhipTuMx64Ops
+{
+  int8_t  natX[2][64][16];     // forward rows,    B side, x chunk c:  T[l % 32][32c + 16h + s]
+  int8_t  rowPY[2][64][16];    // forward columns, A side, row tile t: T[mxSigma(l % 32)][32t + mxHw(h, s)]
+  int8_t  natTY[2][64][16];    // inverse columns, B side, row tile t: T[16h + s][32t + l % 32]
+  int8_t  colPX[2][64][16];    // inverse rows,    A side, x chunk c:  T[mxHw(h, s)][32c + mxSigma(l % 32)]
+  int32_t rowSum[32];          // 128 * sum_{x < 64} T[k][x]
+  int32_t colSum[64];          // 128 * sum_{k < 32} T[k][x]
+  uint16_t pos[64][16];        // scan position of coefficient (16h + v, l % 32) inside the 64x64 TU
 };
 
 void vvhip_build_tr_matrix( int trType, int log2N, int16_t* out );          // host

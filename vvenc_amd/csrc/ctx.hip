@@ -186,6 +186,29 @@ int vvhip_create( vvhip_ctx** out, int device )
     for( int l = 0; l < 64; l++ )
       for( int v = 0; v < 16; v++ ) mxPos[( z * 64 + l ) * 16 + v] = inv[( ( 16 * ( l / 32 ) + v ) % n ) * n + ( l % 32 ) % n];
   }
+  {
+    static VvhipTuMx64Ops o64;
+    const int16_t* m = mats.data() + trMatOffset( VVHIP_DCT2, 6 );
+    auto T = [&]( int r, int c ) -> int { return m[r * 64 + c]; };
+    for( int r = 0; r < 32; r++ ) { int rs = 0; for( int c = 0; c < 64; c++ ) { if( T( r, c ) < -128 || T( r, c ) > 127 ) return vvhip_fail( nullptr, VVHIP_E_HIP, "vvhip_create: 64-point matrix entry outside 8 bits" ); rs += T( r, c ); } o64.rowSum[r] = 128 * rs; }
+    for( int c = 0; c < 64; c++ ) { int cs = 0; for( int r = 0; r < 32; r++ ) cs += T( r, c ); o64.colSum[c] = 128 * cs; }
+    for( int q = 0; q < 2; q++ )
+      for( int l = 0; l < 64; l++ )
+        for( int k = 0; k < 16; k++ )
+        {
+          const int h = l / 32, r = l % 32;
+          o64.natX[q][l][k]  = ( int8_t ) T( r, 32 * q + 16 * h + k );
+          o64.rowPY[q][l][k] = ( int8_t ) T( mxSigma( r ), 32 * q + mxHw( h, k ) );
+          o64.natTY[q][l][k] = ( int8_t ) T( 16 * h + k, 32 * q + r );
+          o64.colPX[q][l][k] = ( int8_t ) T( mxHw( h, k ), 32 * q + mxSigma( r ) );
+        }
+    const uint16_t* sc = scans.data() + scanOffset( 6, 6 );            // scan position -> raster position (64-wide), first 32*32 positions = the 32x32 region
+    std::vector<uint16_t> inv( 64 * 64, 0xffff );
+    for( int i = 0; i < 32 * 32; i++ ) inv[sc[i]] = ( uint16_t ) i;
+    for( int l = 0; l < 64; l++ ) for( int v = 0; v < 16; v++ ) o64.pos[l][v] = inv[( 16 * ( l / 32 ) + v ) * 64 + l % 32];
+    VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_tuMx64, sizeof( o64 ) ) );
+    VVHIP_CHECK_HIP( nullptr, hipMemcpy( ctx->d_tuMx64, &o64, sizeof( o64 ), hipMemcpyHostToDevice ) );
+  }
   VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_tuMx, mx.size() * sizeof( VvhipTuMxOps ) ) );
   VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_tuMxPos, mxPos.size() * sizeof( uint16_t ) ) );
   VVHIP_CHECK_HIP( nullptr, hipMemcpy( ctx->d_tuMx, mx.data(), mx.size() * sizeof( VvhipTuMxOps ), hipMemcpyHostToDevice ) );
@@ -207,6 +230,7 @@ void vvhip_destroy( vvhip_ctx* ctx )
   if( ctx->d_scan ) ( void ) hipFree( ctx->d_scan );
   if( ctx->d_tuMx ) ( void ) hipFree( ctx->d_tuMx );
   if( ctx->d_tuMxPos ) ( void ) hipFree( ctx->d_tuMxPos );
+  if( ctx->d_tuMx64 ) ( void ) hipFree( ctx->d_tuMx64 );
   if( ctx->d_scratch ) ( void ) hipFree( ctx->d_scratch );
   if( ctx->d_subpel ) ( void ) hipFree( ctx->d_subpel );
   if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );

@@ -1299,16 +1299,223 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 #undef TUMX_KEEP
 }
 
+// --------------------------------------------------------------------------------------------
+// 64x64 TUs (DCT-2 only; 32x32 coefficients survive the zero-out): one wave per TU.  The residual is two row tiles of 32 rows, every row in two
+// chunks of 32 samples; a contraction over 64 is two products accumulating into the same registers.  Quantiser section = the 32-point one.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void
+tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */, v4i* __restrict__ sOps /* [512] */, const int waveIndex,
+            const int16_t* __restrict__ resi, const int resiStride, const TuMxArgs& A )
+{
+  constexpr int LP = 40;
+  struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+  const VvhipTuMx64Ops* __restrict__ O = reinterpret_cast<const VvhipTuMx64Ops*>( A.opH );
+  const int lane = threadIdx.x & 63, h = lane >> 5, c32 = lane & 31;
+  const v16i zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+  const int rndF1 = 1 << ( A.shF1 - 1 ), rndF2 = 1 << ( A.shF2 - 1 ), rndI1 = 1 << ( A.shI1 - 1 ), rndI2 = 1 << ( A.shI2 - 1 );
+  // operand slots: 0,1 natX[c]  2,3 rowPY[t]  4,5 natTY[t]  6,7 colPX[c]
+#pragma unroll
+  for( int q = 0; q < 2; q++ )
+  {
+    sOps[( 0 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->natX[q][lane] );
+    sOps[( 2 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->rowPY[q][lane] );
+    sOps[( 4 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->natTY[q][lane] );
+    sOps[( 6 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->colPX[q][lane] );
+  }
+  const int cP1 = O->rowSum[c32] + rndF1;
+  const int cI1[2] = { O->colSum[c32] + rndI1, O->colSum[32 + c32] + rndI1 };
+  sInit[c32] = O->rowSum[c32] + rndF2;                         // forward columns: by result row k2 = 16h + v
+  sInit[32 + lane] = O->colSum[lane] + rndI2;                  // inverse rows: by result column x = 32c + 16h + v
+  uint32_t pos[16];
+  {
+    const u32x4 p0 = *reinterpret_cast<const u32x4*>( &O->pos[lane][0] ), p1 = *reinterpret_cast<const u32x4*>( &O->pos[lane][8] );
+    const uint32_t pw[8] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w };
+#pragma unroll
+    for( int v = 0; v < 16; v++ ) pos[v] = ( v & 1 ) ? pw[v >> 1] >> 16 : pw[v >> 1] & 0xffffu;
+  }
+  WAVE_SYNC();
+
+  for( int tu = waveIndex; tu < A.n; tu += A.waveStride )
+  {
+    const int16_t* src = resi + A.resiOff[tu];
+    const vvhip_tu_qp qq = A.qps[tu];
+    int d[16];
+    v4i bLo[2], bHi[2];
+    // ---- forward rows, two row tiles: tmp[y][k] = sat16( ( sum_{x<64} blk[y][x] * T[k][x] + rnd ) >> shift1 ), k < 32            (TrQuant.cpp:548)
+#pragma unroll
+    for( int t = 0; t < 2; t++ )
+    {
+      v16i lo, hi = zero16;
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) lo[v] = cP1;
+#pragma unroll
+      for( int c = 0; c < 2; c++ )
+      {
+        const int16_t* p = src + ( ptrdiff_t ) ( 32 * t + c32 ) * resiStride + 32 * c + 16 * h;
+        const u32x4 x0 = reinterpret_cast<const U16*>( p )->v, x1 = reinterpret_cast<const U16*>( p + 8 )->v;
+        const uint32_t xr[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
+        v4i aLo, aHi;
+#pragma unroll
+        for( int g = 0; g < 4; g++ )
+        {
+          aLo[g] = ( int ) ( __builtin_amdgcn_perm( xr[2 * g + 1], xr[2 * g], 0x06040200u ) ^ 0x80808080u );
+          aHi[g] = ( int ) __builtin_amdgcn_perm( xr[2 * g + 1], xr[2 * g], 0x07050301u );
+        }
+        const v4i op = sOps[c * 64 + lane];
+        lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, op, lo, 0, 0, 0 );
+        hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, op, hi, 0, 0, 0 );
+      }
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shF1;
+      mxSplitSat( d, bLo[t], bHi[t] );
+    }
+    // ---- forward columns: coef[k2][k] = ( sum_{y<64} T[k2][y] * tmp[y][k] + rnd ) >> shift2, k2 < 32                              (TrQuant.cpp:549)
+    {
+      v16i lo, hi = zero16;
+#pragma unroll
+      for( int g = 0; g < 4; g++ ) { const v4i t4 = *reinterpret_cast<const v4i*>( &sInit[h * 16 + 4 * g] ); lo[4 * g] = t4.x; lo[4 * g + 1] = t4.y; lo[4 * g + 2] = t4.z; lo[4 * g + 3] = t4.w; }
+#pragma unroll
+      for( int t = 0; t < 2; t++ )
+      {
+        const v4i op = sOps[( 2 + t ) * 64 + lane];
+        lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bLo[t], lo, 0, 0, 0 );
+        hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bHi[t], hi, 0, 0, 0 );
+      }
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shF2;
+    }
+    // ---- significance, QuantCore, DeQuantCore on the 32x32 coefficients: exactly the 32-point section of tuMxBody
+    const TuMxQ P = tuMxParams( A.q, qq, A.thrVal );
+    uint32_t last = 0, mx = 0, big = 0;
+    const int thr4 = P.thres >> 2;
+#pragma unroll
+    for( int v = 0; v < 16; v++ )
+    {
+      const uint32_t ac = ( uint32_t ) abs( d[v] );
+      mx = ac > mx ? ac : mx;
+      last = ( ac != 0 && pos[v] > last ) ? pos[v] : last;
+      big = ( ( int ) __umul24( ac, ( uint32_t ) P.scale ) > thr4 && pos[v] > big ) ? pos[v] : big;
+    }
+    { const uint32_t lb = tuMxGroupMaxPk16( last | ( big << 16 ), 64, lane ); last = lb & 0xffffu; big = lb >> 16; }
+    mx = vvhipGroupMax32( mx, 64, lane );
+    const uint32_t need = ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) mx * P.scale + P.addN ) >> P.qBits ) != 0 );
+    const bool narrow = !( mx >= 65536u || P.qBits > 30 || P.qBits < 9 );
+    if( !narrow )
+    {
+      big = 0;
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) big = ( ( long long ) abs( d[v] ) * ( P.scale << 2 ) > ( long long ) P.thres && pos[v] > big ) ? pos[v] : big;
+      big = vvhipGroupMax32( big, 64, lane );
+    }
+    if( last >= 16 )
+    {
+      if( big < 16 ) last = 15;
+      else if( ( big >> 4 ) != ( last >> 4 ) ) last = ( big >> 4 ) * 16 + 15;
+    }
+    uint32_t sum = 0;
+    {
+      const int addP = ( int ) P.addQ, addM = ( int ) ( ( 1u << ( P.qBits & 31 ) ) - 1u ) - addP;
+      const int rsPos = P.rightShift > 0 ? P.rightShift : 0, rndDq = P.rightShift > 0 ? 1 << ( P.rightShift - 1 ) : 0;
+      const int iscaleL = P.rightShift < 0 ? P.iscale << ( -P.rightShift ) : P.iscale;
+#pragma unroll
+      for( int v = 0; v < 16; v++ )
+      {
+        const int cv = d[v];
+        int sm;
+        if( narrow ) sm = ( __mul24( cv, P.scale ) + ( cv < 0 ? addM : addP ) ) >> P.qBits;
+        else { const int m = ( int ) ( ( ( int64_t ) abs( cv ) * P.scale + P.addQ ) >> P.qBits ); sm = cv < 0 ? -m : m; }
+        sm = pos[v] <= last ? sm : 0;
+        sum += ( uint32_t ) abs( sm );
+        const int lv = clip3i( -32768, 32767, sm );
+        stage[( 16 * h + v ) * LP + c32] = ( int16_t ) lv;
+        const int cl = med3i( lv, ~P.inMax, P.inMax );
+        const int32_t w_ = ( int32_t ) ( ( uint32_t ) __mul24( cl, iscaleL ) + ( uint32_t ) rndDq ) >> rsPos;
+        d[v] = clip3i( -32768, 32767, w_ );
+      }
+    }
+    sum = vvhipGroupSum32( sum, 64, lane );
+    if( A.stats && lane == 0 )
+    {
+      int32_t* st = reinterpret_cast<int32_t*>( A.stats + tu );
+      st[0] = ( int32_t ) sum; st[1] = ( int32_t ) last; st[2] = ( int32_t ) need; st[3] = 0;
+    }
+    WAVE_SYNC();
+    // ---- levels: 64x64 raster, the 32x32 region from the staging tile, zeros elsewhere (512 runs of 8 samples, 8 per lane)
+    if( A.level )
+#pragma unroll
+      for( int u = 0; u < 8; u++ )
+      {
+        const int q = lane + 64 * u, Y = q >> 3, X = 8 * ( q & 7 );
+        u32x4 v = { 0, 0, 0, 0 };
+        if( Y < 32 && X < 32 ) v = *reinterpret_cast<const u32x4*>( &stage[Y * LP + X] );
+        *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * 4096 + Y * 64 + X ) = v;
+      }
+    WAVE_SYNC();
+    // ---- inverse columns, two row tiles: t1[y][k] = clip( ( sum_{k2<32} deq[k2][k] * T[k2][y] + 64 ) >> 7 )                       (TrQuant.cpp:612)
+    v4i aLo, aHi;
+    mxSplit( d, aLo, aHi );
+#pragma unroll
+    for( int t = 0; t < 2; t++ )
+    {
+      v16i c;
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) c[v] = cI1[t];
+      const v4i op = sOps[( 4 + t ) * 64 + lane];
+      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, op, c, 0, 0, 0 );
+      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, op, zero16, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shI1;
+      mxSplitSat( d, bLo[t], bHi[t] );
+    }
+    // ---- inverse rows: rec[y][x] = clip( ( sum_{k<32} t1[y][k] * T[k][x] + rnd ) >> shift2 ), row tile t x column chunk c; SSE vs the residual (:613)
+    unsigned long long sse = 0;
+#pragma unroll
+    for( int t = 0; t < 2; t++ )
+#pragma unroll
+      for( int c = 0; c < 2; c++ )
+      {
+        const int16_t* p = src + ( ptrdiff_t ) ( 32 * t + c32 ) * resiStride + 32 * c + 16 * h;
+        const u32x4 x0 = reinterpret_cast<const U16*>( p )->v, x1 = reinterpret_cast<const U16*>( p + 8 )->v;
+        const uint32_t xr[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
+        v16i ci;
+#pragma unroll
+        for( int g = 0; g < 4; g++ ) { const v4i t4 = *reinterpret_cast<const v4i*>( &sInit[32 + 32 * c + h * 16 + 4 * g] ); ci[4 * g] = t4.x; ci[4 * g + 1] = t4.y; ci[4 * g + 2] = t4.z; ci[4 * g + 3] = t4.w; }
+        const v4i op = sOps[( 6 + c ) * 64 + lane];
+        const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bLo[t], ci, 0, 0, 0 );
+        const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bHi[t], zero16, 0, 0, 0 );
+        uint32_t rp[8];
+#pragma unroll
+        for( int k = 0; k < 8; k++ )
+        {
+          const int v0 = ( ( hi[2 * k] << 8 ) + lo[2 * k] ) >> A.shI2, v1 = ( ( hi[2 * k + 1] << 8 ) + lo[2 * k + 1] ) >> A.shI2;
+          rp[k] = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( v0, v1 ) );
+          const int e0 = ( int ) ( int16_t ) ( xr[k] & 0xffff ) - ( int ) ( int16_t ) ( rp[k] & 0xffff ), e1 = ( ( int ) xr[k] >> 16 ) - ( ( int ) rp[k] >> 16 );
+          sse += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 );
+        }
+        if( A.rec )
+        {
+          int16_t* dst = A.rec + ( size_t ) tu * 4096 + ( 32 * t + c32 ) * 64 + 32 * c + 16 * h;
+          u32x4 a, b; a.x = rp[0]; a.y = rp[1]; a.z = rp[2]; a.w = rp[3]; b.x = rp[4]; b.y = rp[5]; b.z = rp[6]; b.w = rp[7];
+          *reinterpret_cast<u32x4*>( dst ) = a; *reinterpret_cast<u32x4*>( dst + 8 ) = b;
+        }
+      }
+    sse = vvhipGroupSum64( sse, 64, lane );
+    if( A.stats && lane == 0 ) A.stats[tu].sse = sse;
+  }
+#undef WAVE_SYNC
+}
+
 struct TuMxJobs { int nJobs; int waveStart[4]; int size[4]; TuMxArgs j[4]; };
 
-// WITH4: also carries the 4-point variant (its four TUs per lane cost registers: launches without 4x4 lists use the kernel without it)
+// WITH4: also carries the 4-point variant (four TUs per lane cost registers) and the 64-point one: launches without such lists use the kernel without them
 template<bool WITH4>
 __global__ void __launch_bounds__( 256, 3 )      // <= 168 registers: three waves per SIMD, their memory latencies overlap
 tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs )
 {
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t stage[4][32 * 40];
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t sInit[4][64];
-  __shared__ v4i sOps[4][256];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t sInit[4][WITH4 ? 96 : 64];
+  __shared__ v4i sOps[4][WITH4 ? 512 : 256];
   const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) );
   const int wave = blockIdx.x * 4 + wv;
   int k = 0;
@@ -1319,7 +1526,8 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   if( jobs.size[k] == 32 )      tuMxBody<32>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
   else if( jobs.size[k] == 16 ) tuMxBody<16>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
   else if( jobs.size[k] == 8 )  tuMxBody<8>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
-  else if( WITH4 )              tuMxBody<4>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
+  else if( WITH4 && jobs.size[k] == 4 )  tuMxBody<4>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
+  else if( WITH4 && jobs.size[k] == 64 ) tuMx64Body( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
 }
 
 __global__ void __launch_bounds__( 256 )
@@ -1586,7 +1794,8 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
   if( !ctx ) return VVHIP_E_ARG;
   if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: bad job table" );
   // square 8/16/32 TUs share the row-per-lane kernel: up to 4 of them go into one launch, largest size first; anything else runs alone
-  auto mergeable = []( const vvhip_tu_job& j ) { return j.n > 0 && j.width == j.height && ( j.width == 8 || j.width == 16 || j.width == 32 || ( j.width == 4 && tuKernelForm() == 0 ) ); };     // 4x4 only in the matrix-core form
+  auto mergeable = []( const vvhip_tu_job& j ) { return j.n > 0 && j.width == j.height && ( j.width == 8 || j.width == 16 || j.width == 32 ||
+                                                        ( tuKernelForm() == 0 && ( j.width == 4 || ( j.width == 64 && j.tr_hor == VVHIP_DCT2 && j.tr_ver == VVHIP_DCT2 ) ) ) ); };     // 4x4 / 64x64 only in the matrix-core form
   int order[64], nm = 0;
   for( int i = 0; i < n_jobs; i++ )
   {
@@ -1599,12 +1808,22 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
       if( rc ) return rc;
     }
   }
-  for( int a = 1; a < nm; a++ ) for( int b = a; b > 0 && jobs[order[b]].width > jobs[order[b - 1]].width; b-- ) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
-  for( int first = 0; first < nm; first += 4 )
+  // launch groups of up to 4 jobs, largest size first; 4x4 and 64x64 lists go into groups of their own (the kernel instance that carries those
+  // variants needs more registers than the 8/16/32 one)
+  auto isExtra = [&]( int i ) { return jobs[order[i]].width == 4 || jobs[order[i]].width == 64; };
+  auto before = [&]( int a, int b ) { const bool ea = isExtra( a ), eb = isExtra( b ); return ea != eb ? !ea : jobs[order[a]].width > jobs[order[b]].width; };
+  for( int a = 1; a < nm; a++ ) for( int b = a; b > 0 && before( b, b - 1 ); b-- ) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  int nRegular = 0;
+  while( nRegular < nm && !isExtra( nRegular ) ) nRegular++;
+  for( int first = 0, next = 0; first < nm; first = next )
   {
+    next = first + 4;
+    if( first < nRegular && next > nRegular ) next = nRegular;          // do not mix the two kinds
+    const int groupEnd = next < nm ? next : nm;
+
     TuMultiJobs mj; mj.nJobs = 0;
     long blocks = 0;
-    for( int i = first; i < nm && i < first + 4; i++ )
+    for( int i = first; i < groupEnd; i++ )
     {
       const vvhip_tu_job& jb = jobs[order[i]];
       TuRowArgs& ra = mj.j[mj.nJobs];
@@ -1633,11 +1852,12 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
         const vvhip_tu_job& jb = jobs[order[first + i]];
         const TuRowArgs& ra = mj.j[i];
         TuMxArgs& xa = xj.j[i];
-        const int z = ra.gf.log2w - 2, tpt = ( 32 / jb.width ) * ( 32 / jb.width );
+        const int z = ra.gf.log2w - 2, tpt = jb.width == 64 ? 1 : ( 32 / jb.width ) * ( 32 / jb.width );
         xa.resiOff = jb.d_resi_off; xa.n = jb.n;
         xa.shF1 = ra.gf.shift1; xa.shF2 = ra.gf.shift2; xa.shI1 = ra.gi.shift1; xa.shI2 = ra.gi.shift2; xa.skipW = ra.gf.skipW; xa.skipH = ra.gf.skipH;
         xa.q = ra.q;
         xa.opH = ctx->d_tuMx + jb.tr_hor * 4 + z; xa.opV = ctx->d_tuMx + jb.tr_ver * 4 + z; xa.pos = ctx->d_tuMxPos + z * 64 * 16;
+        if( jb.width == 64 ) { xa.opH = reinterpret_cast<const VvhipTuMxOps*>( ctx->d_tuMx64 ); xa.opV = xa.opH; xa.pos = nullptr; }
         xa.qps = jb.d_qp; xa.thrVal = jb.thr_val; xa.level = jb.d_level; xa.rec = jb.d_rec_resi; xa.stats = jb.d_stats;
         xa.tiles = ( jb.n + tpt - 1 ) / tpt; xa.phaseLimit = tuPhaseLimit();
         xa.waveStride = ( xa.tiles + tuRepeat() - 1 ) / tuRepeat();
@@ -1646,7 +1866,7 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
       }
       for( int i = mj.nJobs; i < 4; i++ ) { xj.waveStart[i] = 0x7fffffff; xj.size[i] = 0; }
       bool any4 = false;
-      for( int i = 0; i < xj.nJobs; i++ ) any4 |= xj.size[i] == 4;
+      for( int i = 0; i < xj.nJobs; i++ ) any4 |= xj.size[i] == 4 || xj.size[i] == 64;
       if( any4 ) hipLaunchKernelGGL( tuMxMultiKernel<true>, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
       else       hipLaunchKernelGGL( tuMxMultiKernel<false>, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
     }
@@ -1732,7 +1952,7 @@ int vvhip_tu_rdo_batch( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_batch: unsupported %dx%d types (%d,%d) bitDepth %d", width, height, tr_hor, tr_ver, bit_depth );
   if( n == 0 ) return VVHIP_OK;
   const int area = width * height;
-  if( width == height && ( width == 4 || width == 8 || width == 16 || width == 32 ) && !getenv( "VVHIP_TU_GENERIC" ) && tuKernelForm() == 0 )
+  if( width == height && ( width == 4 || width == 8 || width == 16 || width == 32 || ( width == 64 && tr_hor == VVHIP_DCT2 && tr_ver == VVHIP_DCT2 ) ) && !getenv( "VVHIP_TU_GENERIC" ) && tuKernelForm() == 0 )
   {
     vvhip_tu_job jb; jb.width = width; jb.height = height; jb.tr_hor = tr_hor; jb.tr_ver = tr_ver; jb.n = n; jb.thr_val = thr_val;
     jb.d_resi_off = d_resi_off; jb.d_qp = d_qp; jb.d_level = d_level; jb.d_rec_resi = d_rec_resi; jb.d_stats = d_stats;
