@@ -802,17 +802,23 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
         if( g.tilesPerCand % lpc ) lpc = 1;
       }
       g.log2Lpc = ilog2i( lpc );
-      g.nBlocks = fam == 1 ? ( int ) ( ( ( ( long ) jb.n + DIST_U - 1 ) / DIST_U * lpc + 255 ) / 256 ) : ( int ) ( ( ( long ) jb.n * lpc + 255 ) / 256 );
+      // workgroup size: lane teams never talk to each other, so the Hadamard launches use single-wave workgroups (a wave's registers are free again
+      // the moment it retires: 34.6 -> 31.3 us); the SAD / SSE launch is indifferent (34.5 / 35.2 / 35.0 us for 256 / 128 / 64) and keeps 256
+      static const int wgEnv = []{ const char* e = getenv( "VVHIP_DIST_WG" ); const int v = e ? atoi( e ) : 0; return ( v == 64 || v == 128 || v == 256 ) ? v : 0; }();
+      const int wgSize = wgEnv ? wgEnv : ( fam == 2 ? 64 : 256 );
+      g.nBlocks = fam == 1 ? ( int ) ( ( ( ( long ) jb.n + DIST_U - 1 ) / DIST_U * lpc + wgSize - 1 ) / wgSize ) : ( int ) ( ( ( long ) jb.n * lpc + wgSize - 1 ) / wgSize );
       blocks += g.nBlocks;
       mj.nJobs++; i++;
     }
+    static const int wgEnvL = []{ const char* e = getenv( "VVHIP_DIST_WG" ); const int v = e ? atoi( e ) : 0; return ( v == 64 || v == 128 || v == 256 ) ? v : 0; }();
+    const int wgSizeL = wgEnvL ? wgEnvL : ( fam == 2 ? 64 : 256 );
     // bit depths <= 10: the packed 16-bit tile (the reference's x86 rows have the same limit); VVHIP_HAD_PK=0 forces the 32-bit form
     static const int hadPk = []{ const char* e = getenv( "VVHIP_HAD_PK" ); return e ? atoi( e ) : 1; }();
-    if( fam == 2 && bit_depth <= 10 && hadPk ) hipLaunchKernelGGL( hadTile8PkMultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
-    else if( fam == 2 )       hipLaunchKernelGGL( hadTile8MultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
-    else if( anySad && anySse ) hipLaunchKernelGGL( sadSseMixedKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
-    else if( anySad )         hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SAD> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
-    else                      hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SSE> ), dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    if( fam == 2 && bit_depth <= 10 && hadPk ) hipLaunchKernelGGL( hadTile8PkMultiKernel, dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else if( fam == 2 )       hipLaunchKernelGGL( hadTile8MultiKernel, dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else if( anySad && anySse ) hipLaunchKernelGGL( sadSseMixedKernel, dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else if( anySad )         hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SAD> ), dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else                      hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SSE> ), dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
     VVHIP_LAUNCH_CHECK( ctx );
   }
   return VVHIP_OK;
