@@ -132,7 +132,53 @@ alfBlockSumsKernel( AlfStatArgs A, AlfTaps T )
   }
   if( tid < nb ) sTr[tid] = A.cls ? A.cls[2 * ( ( size_t ) ( ( y0 + i ) >> 2 ) * ( A.width >> 2 ) + ( x0 >> 2 ) + tid ) + 1] & 3 : 0;
   __syncthreads();
-  // local terms: item (block b, row k, sample row ii) = 4 samples; k == 13: org - rec                              (:3423-3457, :3707-3921)
+  // local terms (:3423-3457, :3707-3921).  ALF: a lane pair per (block, sample row) — the centre samples, the virtual-boundary reach and the
+  // block's tap table are set up once, lane 0 / 1 of the pair take the even / odd term rows (row 13 = org - rec).
+  if( MODE == 0 )
+  {
+    const int item = tid >> 1, half = tid & 1;
+    if( item < nb * 4 )
+    {
+      const int b = item >> 2, ii = item & 3;
+      const int16_t* c0 = &sRec[3 + ii][3 + 4 * b];
+      const int cen[4] = { c0[0], c0[1], c0[2], c0[3] };
+      const int vbd = ( ( y0 + i + ii ) & ( A.vbH - 1 ) ) - A.vbPos;        // vertical reach against the virtual boundary (:3394-3411)
+      int clipTop = -4, clipBot = 4;
+      if( vbd >= -3 && vbd < 0 ) { clipBot = -vbd - 1; clipTop = -clipBot; }
+      else if( vbd >= 0 && vbd < 3 ) { clipTop = -vbd; clipBot = -clipTop; }
+      const AlfTap* taps = sTap[sTr[b]];
+      for( int k = half; k < ALF_ROWS; k += 2 )
+      {
+        int v[4];
+        if( k == 13 )
+        {
+          const int16_t* o = A.org + ( ptrdiff_t ) ( y0 + i + ii ) * A.orgStride + x0 + 4 * b;
+#pragma unroll
+          for( int x = 0; x < 4; x++ ) v[x] = ( int16_t ) ( o[x] - cen[x] );
+        }
+        else if( k == nc - 1 )
+        {
+#pragma unroll
+          for( int x = 0; x < 4; x++ ) v[x] = cen[x];
+        }
+        else if( k < nc - 1 )
+        {
+          const AlfTap tp = taps[k];
+          int o0 = tp.i, o1 = -( int ) tp.i;
+          if( clipBot != 4 && tp.i != 0 ) { o0 = max( ( int ) tp.i, clipTop ); o1 = -max( ( int ) tp.i, -clipBot ); }     // the clipped form only when clipBotRow != 4 (:3438)
+          const int16_t* pa = c0 + o0 * ALF_WIN_P + tp.j;
+          const int16_t* pb = c0 + o1 * ALF_WIN_P - tp.j;
+#pragma unroll
+          for( int x = 0; x < 4; x++ ) v[x] = ( int16_t ) ( pa[x] + pb[x] - ( int16_t ) ( cen[x] << 1 ) );
+        }
+        else continue;
+        uint32_t* dst = reinterpret_cast<uint32_t*>( &sLoc[b][k][ii * 4] );
+        dst[0] = ( uint32_t ) ( v[0] & 0xffff ) | ( ( uint32_t ) v[1] << 16 );
+        dst[1] = ( uint32_t ) ( v[2] & 0xffff ) | ( ( uint32_t ) v[3] << 16 );
+      }
+    }
+  }
+  else
   for( int t = tid; t < nb * ALF_ROWS * 4; t += 256 )
   {
     const int b = t / ( ALF_ROWS * 4 ), rem = t - b * ( ALF_ROWS * 4 ), k = rem >> 2, ii = rem & 3;
