@@ -381,8 +381,7 @@ void buildTaps( AlfTaps& T )
 
 static int alfLaunchStats( vvhip_ctx* ctx, AlfStatArgs& A, int width, int height, int ctu_size, bool ccalf )
 {
-  static AlfTaps taps; static bool built = false;
-  if( !built ) { buildTaps( taps ); built = true; }
+  static const AlfTaps taps = []{ AlfTaps t; buildTaps( t ); return t; }();       // thread-safe one-time initialisation
   const int ctus = A.ctusX * ( ( height + ctu_size - 1 ) / ctu_size );
   const size_t need = ( size_t ) ctus * A.blocksPerCtuRow * ALF_NE * ALF_MAXB * sizeof( int32_t );           // per-block int32 sums between the two kernels
   if( need > ctx->scratchBytes )
