@@ -260,6 +260,38 @@ class _Base:
             f(_p(org_c), org_c.shape[1], _p(slf_c), slf_c.shape[1], C.c_void_p(base), pad.shape[1], wc, hc, ctu_size_c, vb_ctu_height, vb_pos, rec_luma.shape[0], self.simd, _p(out))
         return out
 
+    def alf_filter_plane(self, src, ctu_size, bit_depth, filter_length, coeff_sets, clip_sets, ctu_set, cls=None, dst=None, vb_ctu_height=128, vb_pos=124):
+        """filterBlk over the enabled CTUs of a plane.  src: (H, W) int16; coeff_sets / clip_sets: (numSets, numClasses, 13) int16;
+        ctu_set: (numCtus,) int16, < 0 = CTU keeps dst.  -> filtered plane (dst defaults to a copy of src)"""
+        h, w = src.shape
+        pad, m = self.alf_pad(src)
+        out = np.ascontiguousarray(src if dst is None else dst, np.int16).copy()
+        base = pad.ctypes.data + 2 * (m * pad.shape[1] + m)
+        cf, cp = np.ascontiguousarray(coeff_sets, np.int16), np.ascontiguousarray(clip_sets, np.int16)
+        cs = np.ascontiguousarray(ctu_set, np.int16)
+        clsp = _p(np.ascontiguousarray(cls, np.uint8)) if cls is not None else None
+        f = getattr(self.L, self._pfx + "alf_filter_plane"); f.restype = None if self._pfx == "orc_" else C.c_int
+        if self._pfx == "orc_":
+            f(C.c_void_p(base), C.c_ssize_t(pad.shape[1]), _p(out), C.c_ssize_t(w), w, h, ctu_size, bit_depth, filter_length, clsp, _p(cf), _p(cp), _p(cs), vb_ctu_height, vb_pos)
+        else:
+            f(C.c_void_p(base), pad.shape[1], _p(out), w, w, h, ctu_size, bit_depth, filter_length, clsp, _p(cf), _p(cp), _p(cs), vb_ctu_height, vb_pos,
+              int(bool((cp != (1 << bit_depth)).any())), self.simd)
+        return out
+
+    def ccalf_filter_plane(self, dst_c, rec_luma, ctu_size_c, bit_depth, coeff, ctu_filter, vb_ctu_height=128, vb_pos=124):
+        """filterBlkCcAlf over a chroma plane (4:2:0).  coeff: (numFilters, 8) int16; ctu_filter: (numCtus,) uint8, 0 = off, k = filter k-1 -> corrected plane"""
+        hc, wc = dst_c.shape
+        pad, m = self.alf_pad(rec_luma)
+        out = np.ascontiguousarray(dst_c, np.int16).copy()
+        base = pad.ctypes.data + 2 * (m * pad.shape[1] + m)
+        cf, fl = np.ascontiguousarray(coeff, np.int16), np.ascontiguousarray(ctu_filter, np.uint8)
+        f = getattr(self.L, self._pfx + "ccalf_filter_plane"); f.restype = None if self._pfx == "orc_" else C.c_int
+        if self._pfx == "orc_":
+            f(_p(out), C.c_ssize_t(wc), C.c_void_p(base), C.c_ssize_t(pad.shape[1]), wc, hc, ctu_size_c, 1, 1, bit_depth, _p(cf), _p(fl), vb_ctu_height, vb_pos)
+        else:
+            f(_p(out), wc, C.c_void_p(base), pad.shape[1], wc, hc, ctu_size_c, bit_depth, _p(cf), _p(fl), vb_ctu_height, vb_pos, self.simd)
+        return out
+
     # ---- g_tCoeffOps table slots (TrQuant_EMT.h:63-91), caller's matrix ----
     def fast_fwd_core(self, tc, src, line, reduced_line, cutoff, shift):
         """tc: (N, N) int16, src: (line, N) int32 -> dst (N, line) int32 (entries outside reduced_line x cutoff stay 0)"""

@@ -1061,6 +1061,86 @@ API int vvref_ccalf_stats_plane( const int16_t* orgC, int orgStride, const int16
   return 0;
 }
 
+
+// ---- ALF / CC-ALF filtering through the reference's own table entries, CTU by CTU like EncAdaptiveLoopFilter::reconstructCTU (:2035-2066, branch
+// without virtual picture boundaries) and applyCcAlfFilterCTU (:6606-6699).  coeffSets / clipSets: [numSets][numClasses][13]; ctuSet[ctu] < 0: skipped.
+// nonLinear selects the table entry like m_encCfg->m_useNonLinearAlfLuma / Chroma does (the x86 row's entry 0 ignores the clipping values).
+static CodingStructure& alfDummyCs()
+{
+  static XUCache xu;
+  static CodingStructure cs( xu, nullptr );
+  static Slice sl;
+  static SPS sps;
+  sps.chromaFormatIdc = CHROMA_420;
+  sl.sps = &sps;
+  cs.slice = &sl;
+  return cs;
+}
+
+API int vvref_alf_filter_plane( const int16_t* src, int srcStride, int16_t* dst, int dstStride, int width, int height, int ctuSize, int bitDepth, int filterLength,
+                                const uint8_t* cls, const int16_t* coeffSets, const int16_t* clipSets, const int16_t* ctuSet, int vbCTUHeight, int vbPos, int nonLinear, int simd )
+{
+  static AdaptiveLoopFilter* alf[2] = { nullptr, nullptr };
+  if( !alf[simd != 0] ) alf[simd != 0] = new AdaptiveLoopFilter( simd != 0 );
+  AdaptiveLoopFilter& A = *alf[simd != 0];
+  CodingStructure& cs = alfDummyCs();
+  const int numClasses = cls ? MAX_NUM_ALF_CLASSES : 1, ctusX = ( width + ctuSize - 1 ) / ctuSize;
+  const ComponentID comp = cls ? COMP_Y : COMP_Cb;
+  ClpRng rng; rng.bd = bitDepth;
+  std::vector<AlfClassifier> cl( 32 * 32 );
+  for( int y0 = 0; y0 < height; y0 += ctuSize )
+    for( int x0 = 0; x0 < width; x0 += ctuSize )
+    {
+      const int set = ctuSet[( y0 / ctuSize ) * ctusX + x0 / ctuSize];
+      if( set < 0 ) continue;
+      const int w = std::min( ctuSize, width - x0 ), h = std::min( ctuSize, height - y0 );
+      if( cls )
+        for( int i = 0; i < h; i += 4 )
+          for( int j = 0; j < w; j += 4 )
+          {
+            const uint8_t* c = cls + 2 * ( ( size_t ) ( ( y0 + i ) / 4 ) * ( width / 4 ) + ( x0 + j ) / 4 );
+            cl[( i / 4 ) * 32 + j / 4] = AlfClassifier( c[0], c[1] );
+          }
+      PelUnitBuf recDst, recSrc;
+      recDst.chromaFormat = recSrc.chromaFormat = CHROMA_420;
+      for( int k = 0; k < ( cls ? 1 : 2 ); k++ )
+      {
+        recDst.bufs.push_back( PelBuf( dst, dstStride, width, height ) );
+        recSrc.bufs.push_back( PelBuf( const_cast<Pel*>( src ) + ( ptrdiff_t ) y0 * srcStride + x0, srcStride, w, h ) );
+      }
+      const Area blkDst( x0, y0, w, h ), blk( 0, 0, w, h );
+      const short* cf = coeffSets + ( size_t ) set * numClasses * MAX_NUM_ALF_LUMA_COEFF;
+      const short* cp = clipSets + ( size_t ) set * numClasses * MAX_NUM_ALF_LUMA_COEFF;
+      if( filterLength == 7 ) A.m_filter7x7Blk[nonLinear != 0]( cl.data(), recDst, recSrc, blkDst, blk, comp, cf, cp, rng, cs, vbCTUHeight, vbPos );
+      else                    A.m_filter5x5Blk[nonLinear != 0]( cl.data(), recDst, recSrc, blkDst, blk, comp, cf, cp, rng, cs, vbCTUHeight, vbPos );
+    }
+  return 0;
+}
+
+API int vvref_ccalf_filter_plane( int16_t* dstC, int dstStride, const int16_t* recLuma, int recStride, int widthC, int heightC, int ctuSizeC, int bitDepth,
+                                  const int16_t* coeff, const uint8_t* ctuFilter, int vbCTUHeight, int vbPos, int simd )
+{
+  static AdaptiveLoopFilter* alf[2] = { nullptr, nullptr };
+  if( !alf[simd != 0] ) alf[simd != 0] = new AdaptiveLoopFilter( simd != 0 );
+  AdaptiveLoopFilter& A = *alf[simd != 0];
+  CodingStructure& cs = alfDummyCs();
+  ClpRngs rngs; rngs.bd = bitDepth;
+  const int ctusX = ( widthC + ctuSizeC - 1 ) / ctuSizeC;
+  PelUnitBuf recYuv; recYuv.chromaFormat = CHROMA_420;
+  recYuv.bufs.push_back( PelBuf( const_cast<Pel*>( recLuma ), recStride, widthC * 2, heightC * 2 ) );
+  const PelBuf dstBuf( dstC, dstStride, widthC, heightC );
+  for( int y0 = 0; y0 < heightC; y0 += ctuSizeC )
+    for( int x0 = 0; x0 < widthC; x0 += ctuSizeC )
+    {
+      const int f = ctuFilter[( y0 / ctuSizeC ) * ctusX + x0 / ctuSizeC];
+      if( !f ) continue;
+      const int w = std::min( ctuSizeC, widthC - x0 ), h = std::min( ctuSizeC, heightC - y0 );
+      const Area blkDst( x0, y0, w, h ), blkSrc( x0 * 2, y0 * 2, w * 2, h * 2 );
+      A.m_filterCcAlf( dstBuf, recYuv, blkDst, blkSrc, COMP_Cb, coeff + ( size_t ) ( f - 1 ) * MAX_NUM_CC_ALF_CHROMA_COEFF, rngs, cs, vbCTUHeight, vbPos );
+    }
+  return 0;
+}
+
 extern "C" void vvref_after_simd_init() __attribute__( ( weak ) );
 
 API long vvref_encode( const int16_t* y, const int16_t* u, const int16_t* v, int width, int height, int frames, int inputBitDepth, int internalBitDepth,

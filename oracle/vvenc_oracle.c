@@ -1453,3 +1453,79 @@ void orc_alf_stats_plane_units(const int16_t *org, ptrdiff_t orgStride, const in
                              out + (size_t)(ay * ux + ax) * numClasses * ORC_ALF_REC);
         }
 }
+
+
+/* ---- ALF filtering: AdaptiveLoopFilter::filterBlk<ALF_FILTER_7 / ALF_FILTER_5> (AdaptiveLoopFilter.cpp:730-967) for every CTU of a plane the way
+ * EncAdaptiveLoopFilter::reconstructCTU calls it when no slice / tile / virtual picture boundary crosses the CTU (EncAdaptiveLoopFilter.cpp:2035-2066).
+ * Tap pairs as (dy, dx) of the first sample of the point-symmetric pair; rows beyond the virtual boundary fold back onto the nearest allowed row. */
+static const int8_t alf_tap7[12][2] = { {3,0}, {2,1}, {2,0}, {2,-1}, {1,2}, {1,1}, {1,0}, {1,-1}, {1,-2}, {0,3}, {0,2}, {0,1} };
+static const int8_t alf_tap5[6][2]  = { {2,0}, {1,1}, {1,0}, {1,-1}, {0,2}, {0,1} };
+/* coefficient order per transposeIdx (:805-849) */
+static const uint8_t alf_perm7[4][13] = { {0,1,2,3,4,5,6,7,8,9,10,11,12}, {9,4,10,8,1,5,11,7,3,0,2,6,12}, {0,3,2,1,8,7,6,5,4,9,10,11,12}, {9,8,10,4,3,7,11,5,1,0,2,6,12} };
+static const uint8_t alf_perm5[4][7]  = { {0,1,2,3,4,5,6}, {4,1,5,3,0,2,6}, {0,3,2,1,4,5,6}, {4,3,5,1,0,2,6} };
+
+static int alf_clamp(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+
+void orc_alf_filter_plane(const int16_t *src, ptrdiff_t srcStride, int16_t *dst, ptrdiff_t dstStride, int width, int height, int ctuSize, int bitDepth, int filterLength,
+                          const uint8_t *cls, const int16_t *coeffSets, const int16_t *clipSets, const int16_t *ctuSet, int vbCTUHeight, int vbPos)
+{
+  const int numClasses = cls ? 25 : 1, taps = filterLength == 7 ? 12 : 6, ctusX = (width + ctuSize - 1) / ctuSize, maxVal = (1 << bitDepth) - 1;
+  for (int y = 0; y < height; y++)
+  {
+    const int yVb = y & (vbCTUHeight - 1);
+    const int dist = yVb < vbPos ? vbPos - 1 - yVb : yVb - vbPos;                 /* rows the filter may reach on either side (:881-897) */
+    const int nearVb = yVb == vbPos - 1 || yVb == vbPos;                           /* :898-899 */
+    for (int x = 0; x < width; x++)
+    {
+      const int set = ctuSet[(y / ctuSize) * ctusX + x / ctuSize];
+      if (set < 0) continue;                                                       /* m_ctuEnableFlag off: the CTU keeps its samples */
+      int classIdx = 0, tr = 0;
+      if (cls) { const uint8_t *c = cls + 2 * ((size_t)(y / 4) * (width / 4) + x / 4); classIdx = c[0]; tr = c[1]; }
+      const int16_t *cf = coeffSets + ((size_t)set * numClasses + classIdx) * 13, *cl = clipSets + ((size_t)set * numClasses + classIdx) * 13;
+      const int16_t *p = src + (ptrdiff_t)y * srcStride + x;
+      const int cur = p[0];
+      int sum = 0;
+      for (int k = 0; k < taps; k++)
+      {
+        int dy = filterLength == 7 ? alf_tap7[k][0] : alf_tap5[k][0];
+        const int dx = filterLength == 7 ? alf_tap7[k][1] : alf_tap5[k][1];
+        const int src_k = filterLength == 7 ? alf_perm7[tr][k] : alf_perm5[tr][k];
+        if (dy > dist) dy = dist;
+        const int c = cl[src_k];
+        const int a = p[dy * srcStride + dx] - cur, b = p[-dy * srcStride - dx] - cur;
+        sum += cf[src_k] * (alf_clamp(-c, c, a) + alf_clamp(-c, c, b));           /* clipALF, AdaptiveLoopFilter.h:85-88 */
+      }
+      sum = nearVb ? (sum + 512) >> 10 : (sum + 64) >> 7;                          /* :940-947, m_NUM_BITS 8 */
+      dst[(ptrdiff_t)y * dstStride + x] = (int16_t)alf_clamp(0, maxVal, sum + cur);
+    }
+  }
+}
+
+/* ---- CC-ALF filtering: AdaptiveLoopFilter::filterBlkCcAlf (AdaptiveLoopFilter.cpp:969-1058) over the CTUs of a chroma plane as
+ * EncAdaptiveLoopFilter::applyCcAlfFilterCTU drives it (EncAdaptiveLoopFilter.cpp:6606-6699, branch without virtual picture boundaries). */
+void orc_ccalf_filter_plane(int16_t *dstC, ptrdiff_t dstStride, const int16_t *recLuma, ptrdiff_t recStride, int widthC, int heightC, int ctuSizeC, int sx, int sy, int bitDepth,
+                            const int16_t *coeff, const uint8_t *ctuFilter, int vbCTUHeight, int vbPos)
+{
+  const int ctusX = (widthC + ctuSizeC - 1) / ctuSizeC, maxVal = (1 << bitDepth) - 1, half = (1 << bitDepth) >> 1;
+  for (int y = 0; y < heightC; y++)
+  {
+    const int pos = (y << sy) & (vbCTUHeight - 1);
+    if (sy == 0 && (pos == vbPos || pos == vbPos + 1)) continue;                   /* :1016-1019 */
+    ptrdiff_t o1 = recStride, o2 = -recStride, o3 = 2 * recStride;
+    if (pos == vbPos - 2 || pos == vbPos + 1) o3 = o1;                             /* :1020-1029 */
+    else if (pos == vbPos - 1 || pos == vbPos) o1 = o2 = o3 = 0;
+    for (int x = 0; x < widthC; x++)
+    {
+      const int f = ctuFilter[(y / ctuSizeC) * ctusX + x / ctuSizeC];
+      if (!f) continue;
+      const int16_t *cf = coeff + (size_t)(f - 1) * 8;
+      const int16_t *l = recLuma + (ptrdiff_t)(y << sy) * recStride + (x << sx);
+      const int c = l[0];
+      int sum = cf[0] * (l[o2] - c) + cf[1] * (l[-1] - c) + cf[2] * (l[1] - c) + cf[3] * (l[o1 - 1] - c) + cf[4] * (l[o1] - c) + cf[5] * (l[o1 + 1] - c) + cf[6] * (l[o3] - c);
+      sum = (sum + 64) >> 7;                                                       /* m_scaleBits 7 */
+      sum = alf_clamp(0, maxVal, sum + half) - half;
+      int16_t *d = dstC + (ptrdiff_t)y * dstStride + x;
+      *d = (int16_t)alf_clamp(0, maxVal, sum + *d);
+    }
+  }
+}

@@ -109,6 +109,14 @@ void orc_alf_stats_plane_units(const int16_t *org, ptrdiff_t orgStride, const in
 void orc_ccalf_stats_plane(const int16_t *orgC, ptrdiff_t orgStride, const int16_t *slfC, ptrdiff_t slfStride, const int16_t *recLuma, ptrdiff_t recStride,
                            int widthC, int heightC, int ctuSizeC, int sx, int sy, int vbCTUHeight, int vbPos, int picHeight, float *out /* [numCtus][ORC_ALF_REC], continues from the records there */);
 
+/* ALF / CC-ALF filtering of a plane (AdaptiveLoopFilter.cpp:730-967 filterBlk, :969-1058 filterBlkCcAlf; call sites EncAdaptiveLoopFilter.cpp:2035-2066, :6606-6699).
+ * src carries a replicated border of >= 3 (7x7) / 2 (5x5) samples; coeffSets / clipSets: [numSets][numClasses][13] (25 classes with cls, 1 without);
+ * ctuSet[ctu] < 0: CTU not filtered (dst untouched).  CC-ALF: coeff [numFilters][8], ctuFilter[ctu] 0 = off, k = filter k-1; dstC is corrected in place. */
+void orc_alf_filter_plane(const int16_t *src, ptrdiff_t srcStride, int16_t *dst, ptrdiff_t dstStride, int width, int height, int ctuSize, int bitDepth, int filterLength,
+                          const uint8_t *cls, const int16_t *coeffSets, const int16_t *clipSets, const int16_t *ctuSet, int vbCTUHeight, int vbPos);
+void orc_ccalf_filter_plane(int16_t *dstC, ptrdiff_t dstStride, const int16_t *recLuma, ptrdiff_t recStride, int widthC, int heightC, int ctuSizeC, int sx, int sy, int bitDepth,
+                            const int16_t *coeff, const uint8_t *ctuFilter, int vbCTUHeight, int vbPos);
+
 #ifdef __cplusplus
 }
 #endif

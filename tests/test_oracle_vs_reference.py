@@ -555,3 +555,58 @@ def test_ccalf_statistics(oracle, reflib, cfg):
     a = oracle.ccalf_stats_plane(org, slf, rec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4)
     b = reflib.ccalf_stats_plane(org, slf, rec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _alf_filter_sets(rng, num_sets, num_classes, bd, nonlinear=True):
+    """random filter sets in the value range of the syntax: 7-bit signed coefficients, clipping values of AlfClipIdx 0..3"""
+    coeff = rng.integers(-40, 41, (num_sets, num_classes, 13)).astype(np.int16)
+    coeff[..., 12] = 0
+    clips = np.array([1 << bd, 1 << (bd - 3), 1 << (bd - 5), 1 << max(1, bd - 7)], np.int16) if bd < 15 else None
+    clip = clips[rng.integers(0, 4, (num_sets, num_classes, 13))] if nonlinear else np.full((num_sets, num_classes, 13), 1 << bd, np.int16)
+    return coeff, np.ascontiguousarray(clip, np.int16)
+
+
+@pytest.mark.parametrize("cfg", [(272, 400, 128, False, 10), (264, 392, 64, True, 10), (136, 200, 64, True, 8), (64, 64, 32, False, 10)])
+def test_alf_filtering(oracle, reflib, cfg):
+    """filterBlk<7x7> / <5x5> table entries of the reference (scalar and x86 rows), driven CTU by CTU like reconstructCTU, against the restatement:
+    every transpose index, clipping values, virtual-boundary rows, disabled CTUs, partial CTUs"""
+    h, w, ctu, smooth, bd = cfg
+    rng = np.random.default_rng(1300 + h)
+    _, rec = _alf_case(rng, h, w, smooth)
+    if bd == 8:
+        rec = (rec >> 2).astype(np.int16)
+    cls = oracle.alf_classify(rec, bd, ctu, ctu - 4)
+    nctu = -(-h // ctu) * -(-w // ctu)
+    for nonlinear in (False, True):
+        coeff, clip = _alf_filter_sets(rng, 3, 25, bd, nonlinear)
+        ctu_set = rng.integers(-1, 3, nctu).astype(np.int16)
+        a = oracle.alf_filter_plane(rec, ctu, bd, 7, coeff, clip, ctu_set, cls, None, ctu, ctu - 4)
+        b = reflib.alf_filter_plane(rec, ctu, bd, 7, coeff, clip, ctu_set, cls, None, ctu, ctu - 4)
+        assert np.array_equal(a, b)
+        assert not np.array_equal(a, rec)
+        c_rec = np.ascontiguousarray(rec[::2, ::2])
+        if c_rec.shape[0] % 4 == 0 and c_rec.shape[1] % 4 == 0:
+            coeff, clip = _alf_filter_sets(rng, 4, 1, bd, nonlinear)
+            ctu_set = rng.integers(-1, 4, nctu).astype(np.int16)
+            a = oracle.alf_filter_plane(c_rec, ctu // 2, bd, 5, coeff, clip, ctu_set, None, None, ctu // 2, ctu // 2 - 2)
+            b = reflib.alf_filter_plane(c_rec, ctu // 2, bd, 5, coeff, clip, ctu_set, None, None, ctu // 2, ctu // 2 - 2)
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("cfg", [(272, 400, 64, 10), (136, 200, 32, 8), (128, 128, 64, 10)])
+def test_ccalf_filtering(oracle, reflib, cfg):
+    """filterBlkCcAlf of the reference (scalar and x86 rows), CTU by CTU like applyCcAlfFilterCTU, against the restatement"""
+    h, w, ctu_c, bd = cfg
+    rng = np.random.default_rng(1400 + h)
+    _, rec = _alf_case(rng, h, w, False)
+    if bd == 8:
+        rec = (rec >> 2).astype(np.int16)
+    chroma = np.clip((1 << (bd - 1)) + rng.normal(0, 1 << (bd - 2), (h // 2, w // 2)), 0, (1 << bd) - 1).astype(np.int16)
+    coeff = np.zeros((4, 8), np.int16)
+    coeff[:, :7] = np.array([0, 1, 2, 4, 8, 16, 32, 64], np.int16)[rng.integers(0, 8, (4, 7))] * rng.choice([-1, 1], (4, 7))     # CC-ALF coefficients are signed powers of two
+    nctu = -(-(h // 2) // ctu_c) * -(-(w // 2) // ctu_c)
+    ctu_filter = rng.integers(0, 5, nctu).astype(np.uint8)
+    a = oracle.ccalf_filter_plane(chroma, rec, ctu_c, bd, coeff, ctu_filter, 2 * ctu_c, 2 * ctu_c - 4)
+    b = reflib.ccalf_filter_plane(chroma, rec, ctu_c, bd, coeff, ctu_filter, 2 * ctu_c, 2 * ctu_c - 4)
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, chroma)
