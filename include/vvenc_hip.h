@@ -382,6 +382,23 @@ VVHIP_API int vvhip_ccalf_stats_plane( vvhip_ctx* ctx, const int16_t* d_org_c, i
                                        int width_c, int height_c, int ctu_size_c, int shift_x, int shift_y, int vb_ctu_height, int vb_pos, int pic_height,
                                        const float* d_init /* may be NULL */, float* d_out );
 
+/* ALF filtering of a plane <- AdaptiveLoopFilter::m_filter7x7Blk / m_filter5x5Blk (filterBlk<ALF_FILTER_7 / ALF_FILTER_5>, CommonLib/AdaptiveLoopFilter.cpp:730-967) applied to
+ * every enabled CTU the way EncAdaptiveLoopFilter::reconstructCTU does when no slice / tile / virtual picture boundary crosses the CTU (EncoderLib/EncAdaptiveLoopFilter.cpp:2035-2066).
+ * filter_length 7 with d_cls (luma: class / transpose index per 4x4 block as written by vvhip_alf_classify, 25 classes) or 5 with d_cls == NULL (chroma, one class).
+ * d_coeff / d_clip: [num_sets][numClasses][13] int16 — the reference's m_coeffApsLuma / m_fixedFilterSetCoeffDec / m_chromaCoeffFinal rows and the matching clipping values;
+ * d_clip == NULL selects the linear table entries (m_filter*Blk[0]: the x86 row ignores the clipping values there).  d_ctu_set[ctu]: filter set (luma: alfCtuFilterIndex;
+ * chroma: m_ctuAlternative) of the CTU, < 0 = m_ctuEnableFlag off (the CTU's samples in d_dst stay untouched).  d_src carries a replicated border of >= 4 samples and must not
+ * overlap d_dst; any strides (in samples) and alignment.  vb_ctu_height / vb_pos as in vvhip_alf_classify (chroma: m_alfVBChmaCTUHeight / m_alfVBChmaPos).                       */
+VVHIP_API int vvhip_alf_filter_plane( vvhip_ctx* ctx, const int16_t* d_src, ptrdiff_t src_stride, int16_t* d_dst, ptrdiff_t dst_stride, int width, int height, int ctu_size, int bit_depth,
+                                      int filter_length, const uint8_t* d_cls, const int16_t* d_coeff, const int16_t* d_clip /* NULL: linear */, const int16_t* d_ctu_set,
+                                      int vb_ctu_height, int vb_pos );
+
+/* CC-ALF filtering of a chroma plane <- AdaptiveLoopFilter::m_filterCcAlf (filterBlkCcAlf, CommonLib/AdaptiveLoopFilter.cpp:969-1058) as EncAdaptiveLoopFilter::applyCcAlfFilterCTU
+ * drives it (EncoderLib/EncAdaptiveLoopFilter.cpp:6606-6699): d_dst_c (the ALF-filtered chroma plane) is corrected in place from the unfiltered luma d_rec_luma (replicated border
+ * >= 2).  d_coeff: [num_filters][8] int16 (ccAlfCoeff, 7 used); d_ctu_filter[ctu]: 0 = off, k = filter k-1 (m_ccAlfFilterControl).  vb_* in luma samples.                        */
+VVHIP_API int vvhip_ccalf_filter_plane( vvhip_ctx* ctx, int16_t* d_dst_c, ptrdiff_t dst_stride, const int16_t* d_rec_luma, ptrdiff_t rec_stride, int width_c, int height_c, int ctu_size_c,
+                                        int shift_x, int shift_y, int bit_depth, const int16_t* d_coeff, const uint8_t* d_ctu_filter, int vb_ctu_height, int vb_pos );
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,6 +295,30 @@ static void test_ALF()
   if( !opt.getStatistics( orgP.data(), W, rec, stride, W, H, ctu, 5, nullptr, ctu, ctu - 2, cgS.data() ) ) { printf( "ALF chroma statistics refused\n" ); failures++; return; }
   orc_alf_stats_plane( orgP.data(), W, rec, stride, W, H, ctu, 5, nullptr, ctu, ctu - 2, ceS.data() );
   for( size_t i = 0; i < cgS.size(); i++ ) { uint32_t a, b; memcpy( &a, &cgS[i], 4 ); memcpy( &b, &ceS[i], 4 ); CHECK_EQ( a, b, "ALF 5x5 statistics" ); }
+  // filtering: three filter sets with clipping values, some CTUs off; then the linear 5x5 entry and the cross-component correction
+  std::vector<short> cf( 3 * 25 * 13 ), cp( cf.size() ), set( ctus );
+  const short clips[4] = { 1024, 128, 32, 8 };
+  for( size_t i = 0; i < cf.size(); i++ ) { cf[i] = ( i % 13 ) == 12 ? 0 : ( short ) ( ( int ) ( rng() % 81 ) - 40 ); cp[i] = clips[rng() % 4]; }
+  for( int i = 0; i < ctus; i++ ) set[i] = ( short ) ( ( int ) ( rng() % 4 ) - 1 );
+  std::vector<Pel> fg( ( size_t ) W * H ), fe( fg.size() );
+  for( int y = 0; y < H; y++ ) for( int x = 0; x < W; x++ ) fg[( size_t ) y * W + x] = fe[( size_t ) y * W + x] = rec[( ptrdiff_t ) y * stride + x];
+  if( !opt.filterPlane( rec, stride, fg.data(), W, W, H, ctu, 10, 7, ce.data(), cf.data(), cp.data(), 3, set.data(), ctu, ctu - 4 ) ) { printf( "ALF filtering refused\n" ); failures++; return; }
+  orc_alf_filter_plane( rec, stride, fe.data(), W, W, H, ctu, 10, 7, ce.data(), cf.data(), cp.data(), set.data(), ctu, ctu - 4 );
+  for( size_t i = 0; i < fg.size(); i++ ) CHECK_EQ( fg[i], fe[i], "ALF 7x7 filtering" );
+  std::vector<short> lin( cf.size(), 1024 );
+  if( !opt.filterPlane( rec, stride, fg.data(), W, W, H, ctu, 10, 5, nullptr, cf.data(), nullptr, 3, set.data(), ctu, ctu - 2 ) ) { printf( "ALF 5x5 filtering refused\n" ); failures++; return; }
+  orc_alf_filter_plane( rec, stride, fe.data(), W, W, H, ctu, 10, 5, nullptr, cf.data(), lin.data(), set.data(), ctu, ctu - 2 );
+  for( size_t i = 0; i < fg.size(); i++ ) CHECK_EQ( fg[i], fe[i], "ALF 5x5 filtering" );
+  const int WC = W / 2, HC = H / 2, ctuC = ctu / 2, ctusC = ( ( WC + ctuC - 1 ) / ctuC ) * ( ( HC + ctuC - 1 ) / ctuC );
+  std::vector<Pel> qg( ( size_t ) WC * HC ), qe( qg.size() );
+  for( size_t i = 0; i < qg.size(); i++ ) qg[i] = qe[i] = ( Pel ) ( rng() % 1024 );
+  std::vector<int16_t> ccf( 4 * 8, 0 );
+  for( int f = 0; f < 4; f++ ) for( int k = 0; k < 7; k++ ) ccf[f * 8 + k] = ( int16_t ) ( ( ( rng() & 1 ) ? 1 : -1 ) * ( ( 1 << ( rng() % 7 ) ) >> 1 ) );
+  std::vector<uint8_t> ctl( ctusC );
+  for( auto& c : ctl ) c = ( uint8_t ) ( rng() % 5 );
+  if( !opt.filterCcAlf( qg.data(), WC, rec, stride, WC, HC, ctuC, 10, ccf.data(), 4, ctl.data(), ctu, ctu - 4 ) ) { printf( "CC-ALF filtering refused\n" ); failures++; return; }
+  orc_ccalf_filter_plane( qe.data(), WC, rec, stride, WC, HC, ctuC, 1, 1, 10, ccf.data(), ctl.data(), ctu, ctu - 4 );
+  for( size_t i = 0; i < qg.size(); i++ ) CHECK_EQ( qg[i], qe[i], "CC-ALF filtering" );
 }
 
 int main()

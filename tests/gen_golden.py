@@ -209,16 +209,55 @@ def gen_alf(R, R0):
     np.savez_compressed(os.path.join(OUT, "alf.npz"), **d)
 
 
+def gen_alf_filter(R, R0):
+    """ALF / CC-ALF filtering by the reference's table entries (x86 row == scalar row), CTU by CTU like reconstructCTU / applyCcAlfFilterCTU -> alf_filter.npz"""
+    rng = np.random.default_rng(20260929)
+    d = {}
+    cases = []
+    for k, (h, w, ctu, nonlinear) in enumerate(((144, 208, 128, False), (136, 200, 64, True), (72, 96, 32, True))):
+        yy, xx = np.mgrid[0:h, 0:w]
+        rec = np.clip(512 + 200 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 80 * np.sin((xx + 2 * yy) / 5.0) + rng.normal(0, 20, (h, w)), 0, 1023).astype(np.int16)
+        cls = R.alf_classify(rec, 10, ctu, ctu - 4)
+        nctu = -(-h // ctu) * -(-w // ctu)
+        clips = np.array([1024, 128, 32, 8], np.int16)
+        coeff = rng.integers(-40, 41, (3, 25, 13)).astype(np.int16); coeff[..., 12] = 0
+        clip = clips[rng.integers(0, 4, (3, 25, 13))] if nonlinear else np.full((3, 25, 13), 1024, np.int16)
+        ctu_set = rng.integers(-1, 3, nctu).astype(np.int16)
+        luma = R.alf_filter_plane(rec, ctu, 10, 7, coeff, clip, ctu_set, cls, None, ctu, ctu - 4)
+        assert np.array_equal(luma, R0.alf_filter_plane(rec, ctu, 10, 7, coeff, clip, ctu_set, cls, None, ctu, ctu - 4))
+        c_rec = np.ascontiguousarray(rec[::2, ::2])
+        c_coeff = rng.integers(-40, 41, (4, 1, 13)).astype(np.int16); c_coeff[..., 12] = 0
+        c_clip = clips[rng.integers(0, 4, (4, 1, 13))] if nonlinear else np.full((4, 1, 13), 1024, np.int16)
+        c_set = rng.integers(-1, 4, nctu).astype(np.int16)
+        chroma = R.alf_filter_plane(c_rec, ctu // 2, 10, 5, c_coeff, c_clip, c_set, None, None, ctu // 2, ctu // 2 - 2)
+        assert np.array_equal(chroma, R0.alf_filter_plane(c_rec, ctu // 2, 10, 5, c_coeff, c_clip, c_set, None, None, ctu // 2, ctu // 2 - 2))
+        cc_coeff = np.zeros((4, 8), np.int16)
+        cc_coeff[:, :7] = np.array([0, 1, 2, 4, 8, 16, 32, 64], np.int16)[rng.integers(0, 8, (4, 7))] * rng.choice([-1, 1], (4, 7))
+        cc_ctu = rng.integers(0, 5, nctu).astype(np.uint8)
+        cc = R.ccalf_filter_plane(chroma, rec, ctu // 2, 10, cc_coeff, cc_ctu, ctu, ctu - 4)
+        assert np.array_equal(cc, R0.ccalf_filter_plane(chroma, rec, ctu // 2, 10, cc_coeff, cc_ctu, ctu, ctu - 4))
+        for name, v in (("rec", rec), ("cls", cls), ("coeff", coeff), ("clip", clip), ("set", ctu_set), ("luma", luma), ("c_coeff", c_coeff), ("c_clip", c_clip), ("c_set", c_set),
+                        ("chroma", chroma), ("cc_coeff", cc_coeff), ("cc_ctu", cc_ctu), ("cc", cc)):
+            d["c%d_%s" % (k, name)] = v
+        cases.append((h, w, ctu, int(nonlinear)))
+    d["cases"] = np.array(cases, np.int32)
+    np.savez_compressed(os.path.join(OUT, "alf_filter.npz"), **d)
+
+
 def main():
     build_ref()
     R = RefLib(1)
     R0 = RefLib(0)
     os.makedirs(OUT, exist_ok=True)
+    if "--alf-filter-only" in sys.argv:
+        gen_alf_filter(R, R0)
+        return
     gen_distortion_ext(R, R0)
     gen_interp(R, R0)
     gen_mctf_apply(R, R0)
     gen_dmvr(R, R0)
     gen_alf(R, R0)
+    gen_alf_filter(R, R0)
     if "--ext-only" in sys.argv:
         return
     rng = np.random.default_rng(20260923)

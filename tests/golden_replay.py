@@ -238,3 +238,18 @@ def check_alf(be):
         assert np.array_equal(sc[:2], g["c%d_chroma_head" % k]) and int(sc.astype(np.uint64).sum()) == int(g["c%d_chroma_sum" % k][0]), ("alf chroma", k)
         cc = np.asarray(be.ccalf_stats_plane(c_org, g["c%d_slf" % k], rec, ctu // 2, ctu, ctu - 4)).view(np.uint32)
         assert np.array_equal(cc, g["c%d_ccalf" % k]), ("cc-alf", k)
+
+
+def check_alf_filter(be):
+    """ALF / CC-ALF filtering fixtures: whole filtered planes of the reference (linear and non-linear entries, disabled CTUs, virtual-boundary rows)"""
+    g = load("alf_filter")
+    for k, (h, w, ctu, nonlinear) in enumerate(g["cases"]):
+        ctu = int(ctu)
+        rec = g["c%d_rec" % k]
+        luma = be.alf_filter_plane(rec, ctu, 10, 7, g["c%d_coeff" % k], g["c%d_clip" % k], g["c%d_set" % k], g["c%d_cls" % k], None, ctu, ctu - 4)
+        assert np.array_equal(np.asarray(luma), g["c%d_luma" % k]), ("alf filter luma", k)
+        c_rec = np.ascontiguousarray(rec[::2, ::2])
+        chroma = be.alf_filter_plane(c_rec, ctu // 2, 10, 5, g["c%d_c_coeff" % k], g["c%d_c_clip" % k], g["c%d_c_set" % k], None, None, ctu // 2, ctu // 2 - 2)
+        assert np.array_equal(np.asarray(chroma), g["c%d_chroma" % k]), ("alf filter chroma", k)
+        cc = be.ccalf_filter_plane(g["c%d_chroma" % k], rec, ctu // 2, 10, g["c%d_cc_coeff" % k], g["c%d_cc_ctu" % k], ctu, ctu - 4)
+        assert np.array_equal(np.asarray(cc), g["c%d_cc" % k]), ("cc-alf filter", k)

@@ -100,6 +100,22 @@ class HipBackend:
         return hp.ccalf_stats_plane(hp.plane(np.ascontiguousarray(org_c, np.int16), 0), hp.plane(np.ascontiguousarray(slf_c, np.int16), 0),
                                     hp.plane(np.ascontiguousarray(rec_luma, np.int16), 8), ctu_size_c, vb_ctu_height, vb_pos).cpu().numpy()
 
+    def alf_filter_plane(self, src, ctu_size, bit_depth, filter_length, coeff_sets, clip_sets, ctu_set, cls=None, dst=None, vb_ctu_height=128, vb_pos=124, linear_entry=False):
+        hp = self.hp
+        s = np.ascontiguousarray(src, np.int16)
+        d = hp.plane(s if dst is None else np.ascontiguousarray(dst, np.int16), 0)
+        hp.alf_filter_plane(hp.plane(s, 8), d, ctu_size, bit_depth, filter_length, hp.to_device(np.ascontiguousarray(coeff_sets, np.int16)),
+                            None if linear_entry else hp.to_device(np.ascontiguousarray(clip_sets, np.int16)), hp.to_device(np.ascontiguousarray(ctu_set, np.int16)),
+                            hp.to_device(np.ascontiguousarray(cls, np.uint8)) if cls is not None else None, vb_ctu_height, vb_pos)
+        return d.visible().cpu().numpy()
+
+    def ccalf_filter_plane(self, dst_c, rec_luma, ctu_size_c, bit_depth, coeff, ctu_filter, vb_ctu_height=128, vb_pos=124):
+        hp = self.hp
+        d = hp.plane(np.ascontiguousarray(dst_c, np.int16), 0)
+        hp.ccalf_filter_plane(d, hp.plane(np.ascontiguousarray(rec_luma, np.int16), 8), ctu_size_c, bit_depth, hp.to_device(np.ascontiguousarray(coeff, np.int16)),
+                              hp.to_device(np.ascontiguousarray(ctu_filter, np.uint8)), vb_ctu_height, vb_pos)
+        return d.visible().cpu().numpy()
+
     def mctf_bilateral(self, org, refs, mvs, ref_index, bit_depth=10, qp=32, unit=16, low_res=True, pic_reordering=True, overall_strength=0.95):
         return self.hp.mctf_bilateral(org, refs, mvs, ref_index, bit_depth, qp, unit, low_res, pic_reordering, overall_strength)
 

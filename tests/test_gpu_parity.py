@@ -37,6 +37,10 @@ def test_golden_alf(hip):
     G.check_alf(hip)
 
 
+def test_golden_alf_filter(hip):
+    G.check_alf_filter(hip)
+
+
 def test_golden_mctf_apply(hip):
     G.check_mctf_apply(hip)
 
@@ -658,6 +662,10 @@ def test_bad_arguments_are_reported_not_crashed(hip):
         lambda: hp.alf_stats_plane(plane, plane8, 64, 9, cls8),                                       # filter length 9
         lambda: hp.alf_stats_plane(plane, plane8, 128, 7, cls8, ctu_in_unit=48),                      # unit not a multiple of the CTU
         lambda: hp.ccalf_stats_plane(plane, plane, plane8, 128),                                      # chroma CTU 128 = luma 256
+        lambda: hp.alf_filter_plane(plane8, plane, 64, 10, 7, items, None, items),                    # 7x7 needs the classes
+        lambda: hp.alf_filter_plane(plane8, plane, 64, 10, 5, items, None, items, cls8),              # 5x5 has one class
+        lambda: hp.alf_filter_plane(plane8, plane, 64, 14, 5, items, None, items),                    # bit depth
+        lambda: hp.ccalf_filter_plane(plane, plane8, 32, 10, items, items, 96, 92),                   # CTU height not a power of two
     ]
     for k, f in enumerate(bad):
         with pytest.raises(VVHipError) as e:
@@ -736,3 +744,68 @@ def test_ccalf_statistics_vs_oracle(hip, oracle, cfg):
     got2 = hp.ccalf_stats_plane(porg, pslf, prec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4, init=got, out=got).cpu().numpy()
     exp2 = oracle.ccalf_stats_plane(org, slf, rec, ctu_c, 2 * ctu_c, 2 * ctu_c - 4, init=exp)
     assert np.array_equal(got2.view(np.uint32), exp2.view(np.uint32)), "continued chains"
+
+
+def _alf_filter_sets(rng, num_sets, num_classes, bd, nonlinear):
+    coeff = rng.integers(-40, 41, (num_sets, num_classes, 13)).astype(np.int16)
+    coeff[..., 12] = 0
+    clips = np.array([1 << bd, 1 << (bd - 3), 1 << (bd - 5), 1 << max(1, bd - 7)], np.int16)
+    clip = clips[rng.integers(0, 4, (num_sets, num_classes, 13))] if nonlinear else np.full((num_sets, num_classes, 13), 1 << bd, np.int16)
+    return coeff, np.ascontiguousarray(clip, np.int16)
+
+
+@pytest.mark.parametrize("cfg", [(272, 400, 128, False, 10), (264, 1048, 64, True, 10), (136, 200, 64, True, 8), (64, 64, 32, False, 10), (20, 12, 16, False, 10)])
+def test_alf_filtering_vs_oracle(hip, oracle, cfg):
+    """SURVEY 8f rank 4, apply side: filterBlk 7x7 (25 classes, 4 transposes) and 5x5 over the enabled CTUs of a plane — linear entry (no clipping values), non-linear
+    entry, rows folded at the virtual boundary and the 3-bit larger shift next to it, disabled CTUs untouched, partial tiles / CTUs, strided unaligned destination"""
+    h, w, ctu, smooth, bd = cfg
+    hp = hip.hp
+    rng = np.random.default_rng(1500 + h)
+    _, rec = _alf_pictures(rng, h, w, smooth)
+    if bd == 8:
+        rec = (rec >> 2).astype(np.int16)
+    cls = oracle.alf_classify(rec, bd, ctu, ctu - 4)
+    nctu = -(-h // ctu) * -(-w // ctu)
+    for nonlinear in (False, True):
+        coeff, clip = _alf_filter_sets(rng, 3, 25, bd, nonlinear)
+        ctu_set = rng.integers(-1, 3, nctu).astype(np.int16)
+        exp = oracle.alf_filter_plane(rec, ctu, bd, 7, coeff, clip, ctu_set, cls, None, ctu, ctu - 4)
+        got = hip.alf_filter_plane(rec, ctu, bd, 7, coeff, clip, ctu_set, cls, None, ctu, ctu - 4, linear_entry=not nonlinear)
+        assert np.array_equal(got, exp), ("luma", nonlinear, np.argwhere(got != exp)[:4])
+        if not nonlinear:                                   # the non-linear entry with clipping values that never bite gives the same picture
+            assert np.array_equal(hip.alf_filter_plane(rec, ctu, bd, 7, coeff, clip, ctu_set, cls, None, ctu, ctu - 4), exp)
+        c_rec = np.ascontiguousarray(rec[::2, ::2])
+        if c_rec.shape[0] % 4 == 0 and c_rec.shape[1] % 4 == 0:
+            coeff, clip = _alf_filter_sets(rng, 4, 1, bd, nonlinear)
+            ctu_set = rng.integers(-1, 4, nctu).astype(np.int16)
+            exp = oracle.alf_filter_plane(c_rec, ctu // 2, bd, 5, coeff, clip, ctu_set, None, None, ctu // 2, ctu // 2 - 2)
+            got = hip.alf_filter_plane(c_rec, ctu // 2, bd, 5, coeff, clip, ctu_set, None, None, ctu // 2, ctu // 2 - 2, linear_entry=not nonlinear)
+            assert np.array_equal(got, exp), ("chroma", nonlinear)
+    # destination with an odd stride and a 2-byte aligned origin: the 16-bit store path
+    coeff, clip = _alf_filter_sets(rng, 2, 25, bd, True)
+    ctu_set = rng.integers(-1, 2, nctu).astype(np.int16)
+    import torch
+    from vvenc_amd.hotpath import Plane
+    dst = Plane(hp.device, w, h, 1, stride=w + 3)
+    dst.storage[1:1 + h, 1:1 + w] = torch.from_numpy(rec).to(hp.device)
+    hp.alf_filter_plane(hp.plane(rec, 4), dst, ctu, bd, 7, hp.to_device(coeff), hp.to_device(clip), hp.to_device(ctu_set), hp.to_device(cls), ctu, ctu - 4)
+    assert np.array_equal(dst.visible().cpu().numpy(), oracle.alf_filter_plane(rec, ctu, bd, 7, coeff, clip, ctu_set, cls, None, ctu, ctu - 4))
+
+
+@pytest.mark.parametrize("cfg", [(272, 400, 64, 10), (136, 200, 32, 8), (128, 128, 64, 10), (64, 96, 16, 10)])
+def test_ccalf_filtering_vs_oracle(hip, oracle, cfg):
+    """filterBlkCcAlf over a chroma plane: 7 luma differences, per-CTU filter choice, rows next to the luma virtual boundary"""
+    h, w, ctu_c, bd = cfg
+    rng = np.random.default_rng(1600 + h)
+    _, rec = _alf_pictures(rng, h, w, False)
+    if bd == 8:
+        rec = (rec >> 2).astype(np.int16)
+    chroma = np.clip((1 << (bd - 1)) + rng.normal(0, 1 << (bd - 2), (h // 2, w // 2)), 0, (1 << bd) - 1).astype(np.int16)
+    coeff = np.zeros((4, 8), np.int16)
+    coeff[:, :7] = np.array([0, 1, 2, 4, 8, 16, 32, 64], np.int16)[rng.integers(0, 8, (4, 7))] * rng.choice([-1, 1], (4, 7))
+    nctu = -(-(h // 2) // ctu_c) * -(-(w // 2) // ctu_c)
+    ctu_filter = rng.integers(0, 5, nctu).astype(np.uint8)
+    exp = oracle.ccalf_filter_plane(chroma, rec, ctu_c, bd, coeff, ctu_filter, 2 * ctu_c, 2 * ctu_c - 4)
+    got = hip.ccalf_filter_plane(chroma, rec, ctu_c, bd, coeff, ctu_filter, 2 * ctu_c, 2 * ctu_c - 4)
+    assert np.array_equal(got, exp)
+    assert not np.array_equal(exp, chroma)

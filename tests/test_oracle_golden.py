@@ -53,3 +53,7 @@ def test_dmvr(oracle):
 
 def test_alf(oracle):
     G.check_alf(oracle)
+
+
+def test_alf_filter(oracle):
+    G.check_alf_filter(oracle)

@@ -810,6 +810,68 @@ bool ALFOps::getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC
   return true;
 }
 
+bool ALFOps::filterPlane( const Pel* src, int srcStride, Pel* dst, int dstStride, int width, int height, int ctuSize, int bitDepth, int filterLength, const uint8_t* cls,
+                          const short* coeffSets, const short* clipSets, int numSets, const short* ctuSet, int vbCTUHeight, int vbPos )
+{
+  if( ( width & 3 ) || ( height & 3 ) || width < 4 || height < 4 || ( filterLength != 7 && filterLength != 5 ) || ( filterLength == 7 ) != ( cls != nullptr ) || numSets < 1 ) return false;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  // staging: [src with border][dst compact]; aux: [classes][coefficients][clipping values][CTU sets]
+  const int srcPitchGuess = ( width + 8 + 7 ) & ~7;
+  const size_t srcBytes = ( ( size_t ) srcPitchGuess * ( height + 8 ) * sizeof( Pel ) + 255 ) & ~( size_t ) 255;
+  const int dstPitch = ( width + 7 ) & ~7;
+  std::vector<Pel> hdst( ( size_t ) dstPitch * height );
+  for( int y = 0; y < height; y++ ) memcpy( &hdst[( size_t ) y * dstPitch], dst + ( ptrdiff_t ) y * dstStride, sizeof( Pel ) * width );
+  dev.staging( srcBytes + hdst.size() * sizeof( Pel ) + 512 );
+  int pitch;
+  const int16_t* dSrc = stageBordered( dev, src, srcStride, width, height, 4, 0, pitch );
+  int16_t* dDst = dev.staging( srcBytes + hdst.size() * sizeof( Pel ) + 512 ) + srcBytes / sizeof( Pel );
+  dev.check( vvhip_upload( dev.ctx(), dDst, hdst.data(), hdst.size() * sizeof( Pel ) ), "ALF destination plane" );
+  const int numClasses = cls ? 25 : 1, ctus = ( ( width + ctuSize - 1 ) / ctuSize ) * ( ( height + ctuSize - 1 ) / ctuSize );
+  const size_t nCls = ( ( cls ? ( size_t ) ( width / 4 ) * ( height / 4 ) * 2 : 0 ) + 255 ) & ~( size_t ) 255;
+  const size_t nCoef = ( ( size_t ) numSets * numClasses * 13 * sizeof( short ) + 255 ) & ~( size_t ) 255, nSet = ( size_t ) ctus * sizeof( short );
+  char* aux = static_cast<char*>( dev.stagingAux( nCls + 2 * nCoef + nSet + 64 ) );
+  if( cls ) dev.check( vvhip_upload( dev.ctx(), aux, cls, ( size_t ) ( width / 4 ) * ( height / 4 ) * 2 ), "ALF classes" );
+  dev.check( vvhip_upload( dev.ctx(), aux + nCls, coeffSets, ( size_t ) numSets * numClasses * 13 * sizeof( short ) ), "ALF coefficients" );
+  if( clipSets ) dev.check( vvhip_upload( dev.ctx(), aux + nCls + nCoef, clipSets, ( size_t ) numSets * numClasses * 13 * sizeof( short ) ), "ALF clipping values" );
+  dev.check( vvhip_upload( dev.ctx(), aux + nCls + 2 * nCoef, ctuSet, nSet ), "ALF CTU filter sets" );
+  dev.check( vvhip_alf_filter_plane( dev.ctx(), dSrc, pitch, dDst, dstPitch, width, height, ctuSize, bitDepth, filterLength, cls ? reinterpret_cast<const uint8_t*>( aux ) : nullptr,
+                                     reinterpret_cast<const int16_t*>( aux + nCls ), clipSets ? reinterpret_cast<const int16_t*>( aux + nCls + nCoef ) : nullptr,
+                                     reinterpret_cast<const int16_t*>( aux + nCls + 2 * nCoef ), vbCTUHeight, vbPos ), "vvhip_alf_filter_plane" );
+  dev.check( vvhip_download( dev.ctx(), hdst.data(), dDst, hdst.size() * sizeof( Pel ) ), "ALF filtered plane" );
+  for( int y = 0; y < height; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride, &hdst[( size_t ) y * dstPitch], sizeof( Pel ) * width );
+  return true;
+}
+
+bool ALFOps::filterCcAlf( Pel* dstC, int dstStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC, int bitDepth, const int16_t* coeff, int numFilters,
+                          const uint8_t* ctuFilter, int vbCTUHeight, int vbPos )
+{
+  if( widthC < 1 || heightC < 1 || numFilters < 1 ) return false;
+  std::lock_guard<std::mutex> g( g_lock );
+  Device& dev = Device::get();
+  const int wL = widthC * 2, hL = heightC * 2;
+  const int recPitch = ( wL + 8 + 7 ) & ~7;
+  const size_t recBytes = ( ( size_t ) recPitch * ( hL + 8 ) * sizeof( Pel ) + 255 ) & ~( size_t ) 255;
+  const int cPitch = ( widthC + 7 ) & ~7;
+  std::vector<Pel> hc( ( size_t ) cPitch * heightC );
+  for( int y = 0; y < heightC; y++ ) memcpy( &hc[( size_t ) y * cPitch], dstC + ( ptrdiff_t ) y * dstStride, sizeof( Pel ) * widthC );
+  dev.staging( recBytes + hc.size() * sizeof( Pel ) + 512 );
+  int pitch;
+  const int16_t* dRec = stageBordered( dev, recLuma, recStride, wL, hL, 4, 0, pitch );
+  int16_t* dC = dev.staging( recBytes + hc.size() * sizeof( Pel ) + 512 ) + recBytes / sizeof( Pel );
+  dev.check( vvhip_upload( dev.ctx(), dC, hc.data(), hc.size() * sizeof( Pel ) ), "CC-ALF chroma plane" );
+  const int ctus = ( ( widthC + ctuSizeC - 1 ) / ctuSizeC ) * ( ( heightC + ctuSizeC - 1 ) / ctuSizeC );
+  const size_t nCoef = ( ( size_t ) numFilters * 8 * sizeof( int16_t ) + 255 ) & ~( size_t ) 255;
+  char* aux = static_cast<char*>( dev.stagingAux( nCoef + ctus + 64 ) );
+  dev.check( vvhip_upload( dev.ctx(), aux, coeff, ( size_t ) numFilters * 8 * sizeof( int16_t ) ), "CC-ALF coefficients" );
+  dev.check( vvhip_upload( dev.ctx(), aux + nCoef, ctuFilter, ctus ), "CC-ALF filter control" );
+  dev.check( vvhip_ccalf_filter_plane( dev.ctx(), dC, cPitch, dRec, pitch, widthC, heightC, ctuSizeC, 1, 1, bitDepth, reinterpret_cast<const int16_t*>( aux ),
+                                       reinterpret_cast<const uint8_t*>( aux + nCoef ), vbCTUHeight, vbPos ), "vvhip_ccalf_filter_plane" );
+  dev.check( vvhip_download( dev.ctx(), hc.data(), dC, hc.size() * sizeof( Pel ) ), "CC-ALF corrected plane" );
+  for( int y = 0; y < heightC; y++ ) memcpy( dstC + ( ptrdiff_t ) y * dstStride, &hc[( size_t ) y * cPitch], sizeof( Pel ) * widthC );
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ MCTFOps
 namespace {
 

@@ -205,6 +205,14 @@ struct ALFOps
   // one record per chroma CTU (E[0..6][0..6], y[0..6], pixAcc), vb* / picHeight in luma samples
   bool getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC, int slfStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC,
                            int vbCTUHeight, int vbPos, int picHeight, float* out, const float* init = nullptr );
+  // AdaptiveLoopFilter::m_filter7x7Blk / m_filter5x5Blk (CommonLib/AdaptiveLoopFilter.h:129-136) over the enabled CTUs of a plane, the way EncAdaptiveLoopFilter::reconstructCTU
+  // drives them: src with a replicated border >= 4; dst receives the filtered samples of the CTUs with ctuSet[ctu] >= 0 (filter set of the CTU), the others keep theirs.
+  // coeffSets / clipSets: [numSets][cls ? 25 : 1][13]; clipSets == nullptr selects the linear entries ([0]).  cls as written by deriveClassification (luma), nullptr for chroma.
+  bool filterPlane( const Pel* src, int srcStride, Pel* dst, int dstStride, int width, int height, int ctuSize, int bitDepth, int filterLength, const uint8_t* cls,
+                    const short* coeffSets, const short* clipSets, int numSets, const short* ctuSet, int vbCTUHeight, int vbPos );
+  // AdaptiveLoopFilter::m_filterCcAlf (:124) over a chroma plane (4:2:0) as applyCcAlfFilterCTU drives it: dstC corrected in place; coeff [numFilters][8]; ctuFilter[ctu] 0 = off
+  bool filterCcAlf( Pel* dstC, int dstStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC, int bitDepth, const int16_t* coeff, int numFilters,
+                    const uint8_t* ctuFilter, int vbCTUHeight, int vbPos );
 };
 
 // MCTF table, CommonLib/MCTF.h:160-170

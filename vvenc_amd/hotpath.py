@@ -305,6 +305,19 @@ class HotPath:
                                                 ctu_size_c, shift[0], shift[1], vb_ctu_height, vb_pos, rec_luma.height, _ptr(init) if init is not None else None, _ptr(out)))
         return out
 
+    def alf_filter_plane(self, src, dst, ctu_size, bit_depth, filter_length, d_coeff, d_clip, d_ctu_set, d_cls=None, vb_ctu_height=128, vb_pos=124):
+        """filterBlk over the enabled CTUs: src Plane (replicated margin >= 4) -> dst Plane (CTUs with d_ctu_set < 0 keep their samples).
+        d_coeff / d_clip: int16 (numSets, 25 or 1, 13); d_clip None = linear filters; d_ctu_set: int16 per CTU"""
+        self._ck(self.L.vvhip_alf_filter_plane(self.ctx, src.buf_ptr, src.stride, dst.buf_ptr, dst.stride, src.width, src.height, ctu_size, bit_depth, filter_length,
+                                               _ptr(d_cls) if d_cls is not None else None, _ptr(d_coeff), _ptr(d_clip) if d_clip is not None else None, _ptr(d_ctu_set), vb_ctu_height, vb_pos))
+        return dst
+
+    def ccalf_filter_plane(self, dst_c, rec_luma, ctu_size_c, bit_depth, d_coeff, d_ctu_filter, vb_ctu_height=128, vb_pos=124, shift=(1, 1)):
+        """filterBlkCcAlf: corrects the chroma Plane dst_c in place from rec_luma (margin >= 2).  d_coeff: int16 (numFilters, 8); d_ctu_filter: uint8 per CTU (0 = off)"""
+        self._ck(self.L.vvhip_ccalf_filter_plane(self.ctx, dst_c.buf_ptr, dst_c.stride, rec_luma.buf_ptr, rec_luma.stride, dst_c.width, dst_c.height, ctu_size_c, shift[0], shift[1], bit_depth,
+                                                 _ptr(d_coeff), _ptr(d_ctu_filter), vb_ctu_height, vb_pos))
+        return dst_c
+
     # ---- SURVEY 8f rank 2: MCTF apply side ----
     REF_STRENGTHS = ((0.84375, 0.6, 0.4286, 0.3333, 0.2727, 0.2308), (1.12500, 1.0, 0.7143, 0.5556, 0.4545, 0.3846))      # MCTF.cpp:112-117
 
