@@ -224,4 +224,17 @@ patch("EncAdaptiveLoopFilter.cpp", [
      "    }\n"
      "    if( !hipCc )\n"
      "    getBlkStatsCcAlf( m_alfCovarianceCcAlf[compIdx - 1][filterIdx][ctuRsAddr], m_filterShapesCcAlf[compIdx - 1], orgYuv, recYuv, area, area, compID, yPos );\n  }\n}"),
+    # ALF filtering of a CTU (reconstructCTU, the branch without virtual picture boundaries): the table entries' work goes to the device block by block
+    ("replace", "        m_filter7x7Blk[nonLinAlfLuma]( &m_classifier[numClassBlocksInCTU * ctuRsAddr], recBuf, recExtBufCTU, blk, blkSrc, COMP_Y, coeff, clip, clpRngs[COMP_Y], cs, m_alfVBLumaCTUHeight, m_alfVBLumaPos );",
+     "        if( !( g_vvhipHooks.alfFilterBlk && g_vvhipHooks.alfFilterBlk( &m_classifier[numClassBlocksInCTU * ctuRsAddr], recBuf.get( COMP_Y ).bufAt( blk.x, blk.y ), recBuf.get( COMP_Y ).stride,\n"
+     "                 recExtBufCTU.get( COMP_Y ).buf, recExtBufCTU.get( COMP_Y ).stride, width, height, 7, coeff, nonLinAlfLuma ? clip : nullptr, clpRngs[COMP_Y].bd, m_alfVBLumaCTUHeight, m_alfVBLumaPos ) ) )\n"
+     "        m_filter7x7Blk[nonLinAlfLuma]( &m_classifier[numClassBlocksInCTU * ctuRsAddr], recBuf, recExtBufCTU, blk, blkSrc, COMP_Y, coeff, clip, clpRngs[COMP_Y], cs, m_alfVBLumaCTUHeight, m_alfVBLumaPos );"),
+    ("replace", "          m_filter5x5Blk[nonLinAlfChroma]( m_classifier, recBuf, recExtBufCTU, blk, blkSrc, compID, m_chromaCoeffFinal[alt_num], m_chromaClippFinal[alt_num], clpRngs[compIdx], cs, m_alfVBChmaCTUHeight, m_alfVBChmaPos );",
+     "          if( !( g_vvhipHooks.alfFilterBlk && g_vvhipHooks.alfFilterBlk( nullptr, recBuf.get( compID ).bufAt( blk.x, blk.y ), recBuf.get( compID ).stride, recExtBufCTU.get( compID ).buf, recExtBufCTU.get( compID ).stride,\n"
+     "                   blk.width, blk.height, 5, m_chromaCoeffFinal[alt_num], nonLinAlfChroma ? m_chromaClippFinal[alt_num] : nullptr, clpRngs[compIdx].bd, m_alfVBChmaCTUHeight, m_alfVBChmaPos ) ) )\n"
+     "          m_filter5x5Blk[nonLinAlfChroma]( m_classifier, recBuf, recExtBufCTU, blk, blkSrc, compID, m_chromaCoeffFinal[alt_num], m_chromaClippFinal[alt_num], clpRngs[compIdx], cs, m_alfVBChmaCTUHeight, m_alfVBChmaPos );"),
+    ("replace", "        m_filterCcAlf( dstBuf, recYuvExt, blkDst, blkSrc, compID, filterCoeff, clpRngs, cs, m_alfVBLumaCTUHeight, m_alfVBLumaPos );",
+     "        if( !( g_vvhipHooks.ccAlfFilterBlk && m_chromaFormat == CHROMA_420 && g_vvhipHooks.ccAlfFilterBlk( const_cast<Pel*>( dstBuf.bufAt( blkDst.x, blkDst.y ) ), dstBuf.stride, recYuvExt.get( COMP_Y ).bufAt( blkSrc.x, blkSrc.y ),\n"
+     "                 recYuvExt.get( COMP_Y ).stride, blkDst.width, blkDst.height, filterCoeff, clpRngs[compID].bd, m_alfVBLumaCTUHeight, m_alfVBLumaPos ) ) )\n"
+     "        m_filterCcAlf( dstBuf, recYuvExt, blkDst, blkSrc, compID, filterCoeff, clpRngs, cs, m_alfVBLumaCTUHeight, m_alfVBLumaPos );"),
 ], sub="EncoderLib")

@@ -432,9 +432,36 @@ bool ccAlfCtu( const int16_t* orgC, int orgStride, const int16_t* slfC, int slfS
   return true;
 }
 
+std::atomic<uint64_t> g_alfFilterBlks{ 0 }, g_ccAlfFilterBlks{ 0 };
+bool alfFilterBlk( const void* classifier, int16_t* dst, int dstStride, const int16_t* src, int srcStride, int width, int height, int filterLength,
+                   const short* coeff, const short* clip, int bitDepth, int vbCTUHeight, int vbPos )
+{
+  static vvhip::ALFOps alf;
+  if( ( width & 3 ) || ( height & 3 ) || width > 128 || height > 128 ) return false;
+  uint8_t cls[32 * 32 * 2];
+  if( classifier )
+  {
+    const uint8_t* c = static_cast<const uint8_t*>( classifier );                  // AlfClassifier = { uint8_t classIdx, transposeIdx }, 32 per row
+    for( int i = 0; i < height / 4; i++ ) memcpy( cls + ( size_t ) i * ( width / 4 ) * 2, c + ( size_t ) i * 32 * 2, ( size_t ) ( width / 4 ) * 2 );
+  }
+  const short set0 = 0;
+  if( !alf.filterPlane( src, srcStride, dst, dstStride, width, height, 128, bitDepth, filterLength, classifier ? cls : nullptr, coeff, clip, 1, &set0, vbCTUHeight, vbPos ) ) return false;
+  g_alfFilterBlks++;
+  return true;
+}
+
+bool ccAlfFilterBlk( int16_t* dstC, int dstStride, const int16_t* recLuma, int recStride, int widthC, int heightC, const int16_t* coeff, int bitDepth, int vbCTUHeight, int vbPos )
+{
+  static vvhip::ALFOps alf;
+  const uint8_t on = 1;
+  if( !alf.filterCcAlf( dstC, dstStride, recLuma, recStride, widthC, heightC, 64, bitDepth, coeff, 1, &on, vbCTUHeight, vbPos ) ) return false;
+  g_ccAlfFilterBlks++;
+  return true;
+}
+
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
 {
-  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round), bit11 ALF statistics per CTU (classification + covariance records), bit12 CC-ALF statistics per CTU and chroma component, bit13 ALF statistics of a whole picture in one call (the per-CTU statistics tasks become no-ops)
+  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round), bit11 ALF statistics per CTU (classification + covariance records), bit12 CC-ALF statistics per CTU and chroma component, bit13 ALF statistics of a whole picture in one call (the per-CTU statistics tasks become no-ops), bit14 ALF filtering per CTU block (7x7 / 5x5 table entries), bit15 CC-ALF filtering per CTU block
   g_slotMask = mask;
   try
   {
@@ -454,6 +481,8 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
   g_vvhipHooks.alfCtu = ( mask & 2048 ) ? alfCtu : nullptr; g_alfCtus = 0;
   g_vvhipHooks.ccAlfCtu = ( mask & 4096 ) ? ccAlfCtu : nullptr; g_ccAlfCtus = 0;
   g_vvhipHooks.alfPicture = ( mask & 8192 ) ? alfPicture : nullptr; g_alfPictures = 0;
+  g_vvhipHooks.alfFilterBlk = ( mask & 16384 ) ? alfFilterBlk : nullptr; g_alfFilterBlks = 0;
+  g_vvhipHooks.ccAlfFilterBlk = ( mask & 32768 ) ? ccAlfFilterBlk : nullptr; g_ccAlfFilterBlks = 0;
   g_vvhipHooks.tzReset = ( mask & 1024 ) ? tzReset : nullptr; g_vvhipHooks.tzPrefetch = ( mask & 1024 ) ? tzPrefetch : nullptr; g_vvhipHooks.tzLookup = ( mask & 1024 ) ? tzLookup : nullptr;
   g_tzRounds = 0; g_tzHits = 0;
   g_dmvrCalls = 0;
@@ -476,4 +505,6 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
   if( n > 14 ) out[14] = g_alfCtus;
   if( n > 15 ) out[15] = g_ccAlfCtus;
   if( n > 16 ) out[16] = g_alfPictures;
+  if( n > 17 ) out[17] = g_alfFilterBlks;
+  if( n > 18 ) out[18] = g_ccAlfFilterBlks;
 }

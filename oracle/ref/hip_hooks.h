@@ -38,6 +38,11 @@ struct VvhipHooks
   // CC-ALF statistics of one CTU and chroma component: record of 183 floats (E[0..6][0..6] with row pitch 13, y[0..6], pixAcc)
   bool ( *ccAlfCtu )( const int16_t* orgC, int orgStride, const int16_t* slfC, int slfStride, const int16_t* recLuma, int recStride, int widthC, int heightC,
                       int vbCTUHeight, int vbPos, int picHeightFromHere, float* record );
+  // ALF filtering of one CTU block (reconstructCTU, branch without virtual picture boundaries): classifier = the CTU's AlfClassifier array (row pitch MAX_CU_SIZE / 4) or
+  // nullptr (chroma, 5x5); clip == nullptr: the linear table entry.  CC-ALF: the chroma block is corrected in place from the unfiltered luma.
+  bool ( *alfFilterBlk )( const void* classifier, int16_t* dst, int dstStride, const int16_t* src, int srcStride, int width, int height, int filterLength,
+                          const short* coeff, const short* clip, int bitDepth, int vbCTUHeight, int vbPos );
+  bool ( *ccAlfFilterBlk )( int16_t* dstC, int dstStride, const int16_t* recLuma, int recStride, int widthC, int heightC, const int16_t* coeff, int bitDepth, int vbCTUHeight, int vbPos );
   bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel, int refPoc, int curPoc );
 };
 extern VvhipHooks g_vvhipHooks;

@@ -28,7 +28,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(17, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 17); calls = [int(x) for x in c]
+    c = np.zeros(19, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 19); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -213,14 +213,34 @@ def test_hip_alf_statistics_1080p_bitstream_identical():
 
 
 @pytest.mark.gpu
-def test_hip_everything_on_device_bitstream_identical():
-    """all hooks at once on a larger clip (208x120 10-bit, 9 frames, 2 encoder threads): every kernel table, the interpolation tables, whole-picture
-    MCTF ME + filter, batched integer diamond rounds, batched sub-pel refinement stages, per-CU DMVR searches and per-CTU ALF statistics"""
+def test_hip_alf_filtering_bitstream_identical():
+    """ALF apply side inside the real encoder (hook masks 16384 + 32768): every CTU block that EncAdaptiveLoopFilter::reconstructCTU hands to m_filter7x7Blk / m_filter5x5Blk
+    and applyCcAlfFilterCTU hands to m_filterCcAlf is filtered on the device instead.  The filtered reconstruction is the reference of the following pictures, so one
+    differing sample changes the bitstream.  Small clip, and 1080p with the statistics on the device as well (8 encoder threads)."""
     if not os.path.exists(e2e_util.REF_HIP_SO):
         pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
-    hip = run(dict(clip, hip=True, simd=None, mask=31 + 64 + 128 + 256 + 512 + 1024 + 2048 + 4096))
+    hip = run(dict(clip, hip=True, simd=None, mask=16384 + 32768))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][17] > 4, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+    import e2e_fps
+    res = [e2e_fps.run(dict(w=1920, h=1080, frames=9, threads=8, mask=m)) for m in (0, 8192 + 16384 + 32768)]
+    print(res)
+    assert res[1]["calls"][17] >= 500, res[1]["calls"]
+    assert res[0]["md5"] == res[1]["md5"] and res[0]["bytes"] == res[1]["bytes"], res
+
+
+@pytest.mark.gpu
+def test_hip_everything_on_device_bitstream_identical():
+    """all hooks at once on a larger clip (208x120 10-bit, 9 frames, 2 encoder threads): every kernel table, the interpolation tables, whole-picture
+    MCTF ME + filter, batched integer diamond rounds, batched sub-pel refinement stages, per-CU DMVR searches, per-CTU ALF statistics and ALF / CC-ALF filtering"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=31 + 64 + 128 + 256 + 512 + 1024 + 2048 + 4096 + 16384 + 32768))
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][0] > 1000 and hip["calls"][8] > 100 and hip["calls"][9] >= 1 and hip["calls"][10] > 50 and hip["calls"][11] > 5 and hip["calls"][12] > 50 and hip["calls"][14] > 4, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
