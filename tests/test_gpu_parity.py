@@ -364,6 +364,32 @@ def test_mctf_levels_vs_oracle(hip, oracle, cfg):
         assert np.array_equal(full[f], exp[4][f]), f
 
 
+def test_mctf_references_searched_together(hip, oracle):
+    """all references of a picture advance through the hierarchy in the same launches (blockIdx.y = reference; more than 8 references go in chunks): every
+    reference's field equals the field of a call with that reference alone, and the oracle's for two of them"""
+    from vvenc_amd.hotpath import HotPath
+    hp = hip.hp
+    w, h = 416, 240
+    rng = np.random.default_rng(4242)
+    org, _ = synth_pair(rng, h, w, shift=(0, 0))
+    refs = []
+    for k in range(10):
+        _, r = synth_pair(np.random.default_rng(4242), h, w, shift=(k % 5 - 2, (k * 3) % 4 - 1), noise=2 + k)
+        refs.append(r)
+    pc = hp.plane(org, 128)
+    prs = [hp.plane(r, 128) for r in refs]
+    out, dims = hp.mctf_motion_estimation(pc, prs, 10, 16, 4, False)
+    fields = [HotPath.mv_to_numpy(o, dims) for o in out]
+    for k in (0, 3, 7, 8, 9):
+        alone, _ = hp.mctf_motion_estimation(pc, [prs[k]], 10, 16, 4, False)
+        assert np.array_equal(HotPath.mv_to_numpy(alone[0], dims), fields[k]), k
+    for k in (1, 9):
+        exp = oracle.mctf_me(org, refs[k], 10, 16, 4, False)[4]
+        for f in ("x", "y", "error", "rmsme", "overlap"):
+            assert np.array_equal(fields[k][f], exp[f]), (k, f)
+    assert any(not np.array_equal(fields[0]["x"], fields[k]["x"]) for k in range(1, 10))
+
+
 def test_mctf_1080p_vs_oracle(hip, oracle):
     """BASELINE config-2 geometry: 1920x1080 10-bit, faster preset (speed 4, unit 16, extra 1/8 level)."""
     org, ref = synth_pair(np.random.default_rng(1080), 1080, 1920, shift=(3, 1), noise=3)

@@ -6,11 +6,12 @@ import numpy as np, torch
 from vvenc_amd.hotpath import HotPath
 from vvenc_amd.workload import synth_frame_pair
 hp = HotPath()
-for (W, H) in ((1920, 1080), (3840, 2160)):
+ME_ONLY = "--me1080" in sys.argv          # only the 1080p 4-reference search (clean kernel traces)
+for (W, H) in ((1920, 1080),) if ME_ONLY else ((1920, 1080), (3840, 2160)):
     cur, ref = synth_frame_pair(W, H, W)
     pc = hp.plane(cur, 128)
     refs = [hp.plane(np.roll(ref, (k, -2 * k), (0, 1)), 128) for k in range(4)]
-    for nref in (1, 4):
+    for nref in (4,) if ME_ONLY else (1, 4):
         out, dims = hp.mctf_motion_estimation(pc, refs[:nref], 10, 16, 4, True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -21,6 +22,8 @@ for (W, H) in ((1920, 1080), (3840, 2160)):
         ms = (time.perf_counter() - t0) / reps * 1e3
         print("%dx%d refs=%d : %.2f ms per filtered picture (%.2f ms per reference), blocks %dx%d" % (W, H, nref, ms, ms / nref, dims[0], dims[1]))
 
+if ME_ONLY:
+    sys.exit(0)
 # ---- apply side: bilateral temporal filter of the three 4:2:0 planes with 4 references
 from vvenc_amd.hotpath import MV_DTYPE
 for (W, H) in ((1920, 1080), (3840, 2160)):

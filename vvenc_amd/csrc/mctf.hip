@@ -122,6 +122,14 @@ struct MeGeom
   int lowRes, maxVal;
 };
 
+// The references of a picture are searched independently of each other (MCTF.cpp:666-707 loops over them): every level runs all of them in ONE launch,
+// blockIdx.y = reference.  Same geometry for all; per reference its plane, the coarser level's field, the field written and the hand-off granules.
+constexpr int ME_MAX_REFS = 8;
+struct MeRefs
+{
+  const int16_t* buf[ME_MAX_REFS]; const vvhip_mv* prev[ME_MAX_REFS]; vvhip_mv* mvs[ME_MAX_REFS]; unsigned long long* gran[ME_MAX_REFS];
+};
+
 // MCTF::motionErrorLuma, MCTF.cpp:1099-1164 (x,y block origin; dx,dy in 1/16 pel)
 __device__ __forceinline__ int meError( const MeGeom& g, int x, int y, int dx, int dy, int16_t* sTmp, int lane )
 {
@@ -143,11 +151,13 @@ __device__ __forceinline__ int meError( const MeGeom& g, int x, int y, int dx, i
 
 // ---- phase A -------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__( 64 )
-meSearchKernel( MeGeom g, int nbx, const vvhip_mv* __restrict__ prev, int prevW, int prevH, int factor, int doubleRes, int searchPttrn,
-                vvhip_mv* __restrict__ mvs, int mvsW )
+meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int factor, int doubleRes, int searchPttrn, int mvsW )
 {
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[( 32 + 5 ) * 32];
   const int lane = threadIdx.x;
+  g.buf = R.buf[blockIdx.y];
+  const vvhip_mv* __restrict__ prev = R.prev[blockIdx.y];
+  vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.y];
   const int blk = blockIdx.x, byi = blk / nbx, bxi = blk - byi * nbx;
   const int bs = g.bs, bx = bxi * bs, by = byi * bs;
 
@@ -205,10 +215,13 @@ meSearchKernel( MeGeom g, int nbx, const vvhip_mv* __restrict__ prev, int prevW,
 __device__ __forceinline__ uint64_t packGranule( int x, int y ) { return ( 1ull << 32 ) | ( ( uint64_t ) ( uint16_t ) ( int16_t ) x << 16 ) | ( uint16_t ) ( int16_t ) y; }
 
 __global__ void __launch_bounds__( 64 )
-meWavefrontKernel( MeGeom g, int nbx, vvhip_mv* __restrict__ mvs, int mvsW, unsigned long long* granules /* nby x nbx, zeroed */, int* abortFlag )
+meWavefrontKernel( MeGeom g, const MeRefs R, int nbx, int mvsW, int* abortFlag )
 {
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[( 32 + 5 ) * 32];
   const int lane = threadIdx.x;
+  g.buf = R.buf[blockIdx.y];
+  vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.y];
+  unsigned long long* granules = R.gran[blockIdx.y];                      // nby x nbx, zeroed
   const int byi = blockIdx.x, bs = g.bs, by = byi * bs;
   int leftX = 0, leftY = 0;
   for( int bxi = 0; bxi < nbx; bxi++ )
@@ -251,8 +264,9 @@ meWavefrontKernel( MeGeom g, int nbx, vvhip_mv* __restrict__ mvs, int mvsW, unsi
 
 // ---- phase C -------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__( 256 )
-meFinalizeKernel( MeGeom g, int nbx, int nby, int bitDepth, int unitSize, vvhip_mv* __restrict__ mvs, int mvsW )
+meFinalizeKernel( MeGeom g, const MeRefs R, int nbx, int nby, int bitDepth, int unitSize, int mvsW )
 {
+  vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if( i >= nbx * nby ) return;
   const int byi = i / nbx, bxi = i - byi * nbx, bx = bxi * g.bs, by = byi * g.bs;
@@ -360,24 +374,25 @@ int ensureScratch( vvhip_ctx* ctx, size_t bytes )
   return VVHIP_OK;
 }
 
-int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, const int16_t* d_buf, int bsd, int width, int height, int bs,
-             const vvhip_mv* d_prev, int prevW, int prevH, int factor, int doubleRes, int pttrn, int lowRes, int bitDepth, int unit,
-             vvhip_mv* d_mvs, int mvsW, int mvsH, unsigned long long* d_granules, int* d_abort )
+// one hierarchy level for nRefs references at once (R.gran[r]: nbx * nby granules per reference, one contiguous region starting at R.gran[0] with pitch granPitch)
+int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, int height, int bs, const MeRefs& R, int nRefs, size_t granPitch,
+             int prevW, int prevH, int factor, int doubleRes, int pttrn, int lowRes, int bitDepth, int unit, int mvsW, int mvsH, int* d_abort )
 {
   // blocks processed: bx + 8 <= width, by + 8 <= height (MCTF.cpp:1174,1357)
   const int nbx = width >= 8 ? ( width - 8 ) / bs + 1 : 0, nby = height >= 8 ? ( height - 8 ) / bs + 1 : 0;
   if( nbx <= 0 || nby <= 0 ) return VVHIP_OK;
   if( nbx > mvsW || nby > mvsH ) return vvhip_fail( ctx, VVHIP_E_ARG, "MCTF level: motion field %dx%d too small for %dx%d blocks", mvsW, mvsH, nbx, nby );
-  MeGeom g; g.org = d_org; g.orgStride = os; g.buf = d_buf; g.bufStride = bsd; g.width = width; g.height = height; g.bs = bs;
+  MeGeom g; g.org = d_org; g.orgStride = os; g.buf = nullptr; g.bufStride = bsd; g.width = width; g.height = height; g.bs = bs;
   g.lowRes = lowRes; g.maxVal = ( 1 << bitDepth ) - 1;
-  hipLaunchKernelGGL( meSearchKernel, dim3( nbx * nby ), dim3( 64 ), 0, ctx->stream, g, nbx, d_prev, prevW, prevH, factor, doubleRes, pttrn, d_mvs, mvsW );
+  hipLaunchKernelGGL( meSearchKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, doubleRes, pttrn, mvsW );
   VVHIP_LAUNCH_CHECK( ctx );
-  VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_granules, 0, sizeof( unsigned long long ) * ( size_t ) nbx * nby, ctx->stream ) );
-  hipLaunchKernelGGL( meWavefrontKernel, dim3( nby ), dim3( 64 ), 0, ctx->stream, g, nbx, d_mvs, mvsW, d_granules, d_abort );
+  VVHIP_CHECK_HIP( ctx, hipMemsetAsync( R.gran[0], 0, sizeof( unsigned long long ) * ( granPitch * ( size_t ) ( nRefs - 1 ) + ( size_t ) nbx * nby ), ctx->stream ) );
+  // blocks are dispatched in linear order (x fastest): the row a wave waits for — same reference, one row up — always has the smaller linear index
+  hipLaunchKernelGGL( meWavefrontKernel, dim3( nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, d_abort );
   VVHIP_LAUNCH_CHECK( ctx );
   if( doubleRes )
   {
-    hipLaunchKernelGGL( meFinalizeKernel, dim3( ( nbx * nby + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, g, nbx, nby, bitDepth, unit, d_mvs, mvsW );
+    hipLaunchKernelGGL( meFinalizeKernel, dim3( ( nbx * nby + 255 ) / 256, nRefs ), dim3( 256 ), 0, ctx->stream, g, R, nbx, nby, bitDepth, unit, mvsW );
     VVHIP_LAUNCH_CHECK( ctx );
   }
   return VVHIP_OK;
@@ -454,8 +469,10 @@ int vvhip_mctf_me_level( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, c
   int* d_abort = reinterpret_cast<int*>( ctx->d_scratch );
   unsigned long long* d_gr = reinterpret_cast<unsigned long long*>( reinterpret_cast<char*>( ctx->d_scratch ) + 256 );
   VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_abort, 0, 256, ctx->stream ) );
-  rc = meLevel( ctx, d_org, org_stride, d_buf, buf_stride, width, height, block_size, d_prev, prev_w, prev_h, factor, double_res, search_pattern,
-                low_res_filter, bit_depth, unit_size, d_mvs, mvs_w, mvs_h, d_gr, d_abort );
+  MeRefs R = {};
+  R.buf[0] = d_buf; R.prev[0] = d_prev; R.mvs[0] = d_mvs; R.gran[0] = d_gr;
+  rc = meLevel( ctx, d_org, org_stride, buf_stride, width, height, block_size, R, 1, 0, prev_w, prev_h, factor, double_res, search_pattern,
+                low_res_filter, bit_depth, unit_size, mvs_w, mvs_h, d_abort );
   if( rc ) return rc;
   int aborted = 0;
   VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( &aborted, d_abort, sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
@@ -489,7 +506,7 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
   const int outW = ( width + u - 1 ) / u, outH = ( height + u - 1 ) / u;      // MCTF.cpp:671-672
   const size_t granElems = ( size_t ) outW * outH + 64;
   size_t off = 256;
-  const size_t offGran = off;  off += granElems * sizeof( unsigned long long );
+  const size_t offGran = off;  off += granElems * sizeof( unsigned long long ) * ( size_t ) ( n_refs < ME_MAX_REFS ? n_refs : ME_MAX_REFS );
   off = ( off + 255 ) & ~( size_t ) 255;
   const size_t offPyr = off;   off += ( size_t ) ( 1 + n_refs ) * pyrElems * sizeof( int16_t );
   off = ( off + 255 ) & ~( size_t ) 255;
@@ -518,28 +535,35 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
       src = planePtr( pic, l ); srcStride = ls[l];
     }
   }
-  for( int r = 0; r < n_refs; r++ )
+  rc = vvhip_mctf_init_mvs( ctx, reinterpret_cast<vvhip_mv*>( base + offFld ), ( int ) ( fieldElems * n_refs ) );   if( rc ) return rc;
+  for( int r0 = 0; r0 < n_refs; r0 += ME_MAX_REFS )                                    // all references of a chunk advance through the hierarchy together
   {
-    vvhip_mv* f[4];
-    f[0] = reinterpret_cast<vvhip_mv*>( base + offFld ) + ( size_t ) r * fieldElems;
-    for( int k = 1; k < 4; k++ ) f[k] = f[k - 1] + ( size_t ) fw[k - 1] * fh[k - 1];
-    rc = vvhip_mctf_init_mvs( ctx, f[0], ( int ) fieldElems );                      if( rc ) return rc;
-    rc = vvhip_mctf_init_mvs( ctx, d_mvs_out[r], outW * outH );                     if( rc ) return rc;
-    const vvhip_mv* prev = nullptr; int pw = 0, ph = 0;
-    if( add_level )                                                                   // MCTF.cpp:692-699
+    const int nr = n_refs - r0 < ME_MAX_REFS ? n_refs - r0 : ME_MAX_REFS;
+    vvhip_mv* f[ME_MAX_REFS][4];
+    MeRefs R = {};
+    for( int k = 0; k < nr; k++ )
     {
-      rc = meLevel( ctx, planePtr( 0, 3 ), ls[3], planePtr( r + 1, 3 ), ls[3], lw[3], lh[3], 2 * u, nullptr, 0, 0, 1, 0, pttrn, lowRes, bit_depth, u, f[0], fw[0], fh[0], d_gr, d_abort );
-      if( rc ) return rc;
-      prev = f[0]; pw = fw[0]; ph = fh[0];
+      f[k][0] = reinterpret_cast<vvhip_mv*>( base + offFld ) + ( size_t ) ( r0 + k ) * fieldElems;
+      for( int l = 1; l < 4; l++ ) f[k][l] = f[k][l - 1] + ( size_t ) fw[l - 1] * fh[l - 1];
+      rc = vvhip_mctf_init_mvs( ctx, d_mvs_out[r0 + k], outW * outH );                 if( rc ) return rc;
+      R.gran[k] = d_gr + ( size_t ) k * granElems;
     }
-    rc = meLevel( ctx, planePtr( 0, 2 ), ls[2], planePtr( r + 1, 2 ), ls[2], lw[2], lh[2], 2 * u, prev, pw, ph, 2, 0, pttrn, lowRes, bit_depth, u, f[1], fw[1], fh[1], d_gr, d_abort );   // :698 / :702
-    if( rc ) return rc;
-    rc = meLevel( ctx, planePtr( 0, 1 ), ls[1], planePtr( r + 1, 1 ), ls[1], lw[1], lh[1], 2 * u, f[1], fw[1], fh[1], 2, 0, pttrn, lowRes, bit_depth, u, f[2], fw[2], fh[2], d_gr, d_abort );   // :704
-    if( rc ) return rc;
-    rc = meLevel( ctx, d_cur, stride, d_refs[r], stride, width, height, 2 * u, f[2], fw[2], fh[2], 2, 0, pttrn, lowRes, bit_depth, u, f[3], fw[3], fh[3], d_gr, d_abort );                       // :705
-    if( rc ) return rc;
-    rc = meLevel( ctx, d_cur, stride, d_refs[r], stride, width, height, u, f[3], fw[3], fh[3], 1, 1, pttrn, lowRes, bit_depth, u, d_mvs_out[r], outW, outH, d_gr, d_abort );                    // :707
-    if( rc ) return rc;
+    auto level = [&]( int l, int bs, int inField, int outField, int factor, int dbl ) -> int      // l: pyramid level (0 = full resolution); fields 0..3, 4 = result
+    {
+      for( int k = 0; k < nr; k++ )
+      {
+        R.buf[k]  = l ? planePtr( r0 + k + 1, l ) : d_refs[r0 + k];
+        R.prev[k] = inField < 0 ? nullptr : f[k][inField];
+        R.mvs[k]  = outField == 4 ? d_mvs_out[r0 + k] : f[k][outField];
+      }
+      return meLevel( ctx, l ? planePtr( 0, l ) : d_cur, ls[l], ls[l], lw[l], lh[l], bs, R, nr, granElems, inField < 0 ? 0 : fw[inField], inField < 0 ? 0 : fh[inField], factor, dbl, pttrn, lowRes,
+                      bit_depth, u, outField == 4 ? outW : fw[outField], outField == 4 ? outH : fh[outField], d_abort );
+    };
+    if( add_level ) { rc = level( 3, 2 * u, -1, 0, 1, 0 ); if( rc ) return rc; }        // MCTF.cpp:692-699
+    rc = level( 2, 2 * u, add_level ? 0 : -1, 1, 2, 0 );  if( rc ) return rc;           // :698 / :702
+    rc = level( 1, 2 * u, 1, 2, 2, 0 );                   if( rc ) return rc;           // :704
+    rc = level( 0, 2 * u, 2, 3, 2, 0 );                   if( rc ) return rc;           // :705
+    rc = level( 0, u, 3, 4, 1, 1 );                       if( rc ) return rc;           // :707
   }
   int aborted = 0;
   VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( &aborted, d_abort, sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
