@@ -33,6 +33,9 @@ __device__ __forceinline__ u32x4 ld16( const int16_t* p ) { return reinterpret_c
 __device__ __forceinline__ int lo16( uint32_t v ) { return ( int ) ( int16_t ) ( v & 0xffffu ); }
 __device__ __forceinline__ int hi16( uint32_t v ) { return ( int ) ( ( int32_t ) v >> 16 ); }
 
+// LDS hand-over inside ONE wavefront (DS operations of a wave execute in order; the fence keeps the compiler from reordering them)
+#define ME_WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+
 __device__ __forceinline__ int waveSum( int v )       // DPP row operations + 4 readlanes instead of six ds_bpermute shuffles
 {
   return ( int ) vvhipGroupSum32( ( uint32_t ) v, 64, threadIdx.x & 63 );
@@ -92,7 +95,7 @@ __device__ __forceinline__ int waveErrorFrac( const int16_t* org, int os, const 
     s1 = min( max( ( s1 + 32 ) >> 6, 0 ), maxVal );
     *reinterpret_cast<uint32_t*>( sTmp + r * w + x ) = ( uint32_t ) ( s0 & 0xffff ) | ( ( uint32_t ) s1 << 16 );
   }
-  __syncthreads();                               // single-wave workgroups: orders the LDS writes above before the reads below
+  ME_WAVE_SYNC();                                // sTmp is private to the wave: its LDS writes above are ordered before the reads below
   int e = 0;
   for( int i = lane; i < h * pairs; i += 64 )
   {
@@ -110,7 +113,7 @@ __device__ __forceinline__ int waveErrorFrac( const int16_t* org, int os, const 
     const int d0 = s0 - lo16( o ), d1 = s1 - hi16( o );
     e += d0 * d0 + d1 * d1;
   }
-  __syncthreads();                               // sTmp is reused by the next candidate
+  ME_WAVE_SYNC();                                // sTmp is reused by the next candidate
   return waveSum( e );
 }
 
@@ -267,17 +270,21 @@ __global__ void __launch_bounds__( 256 )
 meFinalizeKernel( MeGeom g, const MeRefs R, int nbx, int nby, int bitDepth, int unitSize, int mvsW )
 {
   vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.y];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * 4 + ( threadIdx.x >> 6 ), lane = threadIdx.x & 63;          // one wave per block
   if( i >= nbx * nby ) return;
   const int byi = i / nbx, bxi = i - byi * nbx, bx = bxi * g.bs, by = byi * g.bs;
   const int w = min( g.bs, g.width - bx ) & ~7, h = min( g.bs, g.height - by ) & ~7;
   const int16_t* o = g.org + bx + ( ptrdiff_t ) by * g.orgStride;
-  int avg = 0;                                                            // calcVarCore, MCTF.cpp:520-546
-  for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) avg += o[( ptrdiff_t ) y * g.orgStride + x];
+  int sum = 0;                                                            // calcVarCore, MCTF.cpp:520-546
+  for( int k = lane; k < w * h; k += 64 ) { const int y = k / w, x = k - y * w; sum += o[( ptrdiff_t ) y * g.orgStride + x]; }
+  int avg = waveSum( sum );
   avg <<= 4;
   avg = avg / ( w * h );
   long long var = 0;
-  for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ ) { const int p = ( o[( ptrdiff_t ) y * g.orgStride + x] << 4 ) - avg; var += p * p; }
+  for( int k = lane; k < w * h; k += 64 ) { const int y = k / w, x = k - y * w; const int p = ( o[( ptrdiff_t ) y * g.orgStride + x] << 4 ) - avg; var += p * p; }
+#pragma unroll
+  for( int d = 32; d >= 1; d >>= 1 ) var += __shfl_xor( var, d );
+  if( lane ) return;
   vvhip_mv& m = mvs[byi * mvsW + bxi];
   const double bdScale = ( double ) ( 1 << ( 2 * ( 10 - bitDepth ) ) );   // MCTF.cpp:1314-1320
   const double dvar = ( ( double ) var / 256.0 ) * bdScale;
@@ -392,7 +399,7 @@ int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, i
   VVHIP_LAUNCH_CHECK( ctx );
   if( doubleRes )
   {
-    hipLaunchKernelGGL( meFinalizeKernel, dim3( ( nbx * nby + 255 ) / 256, nRefs ), dim3( 256 ), 0, ctx->stream, g, R, nbx, nby, bitDepth, unit, mvsW );
+    hipLaunchKernelGGL( meFinalizeKernel, dim3( ( nbx * nby + 3 ) / 4, nRefs ), dim3( 256 ), 0, ctx->stream, g, R, nbx, nby, bitDepth, unit, mvsW );
     VVHIP_LAUNCH_CHECK( ctx );
   }
   return VVHIP_OK;
