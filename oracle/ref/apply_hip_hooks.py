@@ -237,4 +237,49 @@ patch("EncAdaptiveLoopFilter.cpp", [
      "        if( !( g_vvhipHooks.ccAlfFilterBlk && m_chromaFormat == CHROMA_420 && g_vvhipHooks.ccAlfFilterBlk( const_cast<Pel*>( dstBuf.bufAt( blkDst.x, blkDst.y ) ), dstBuf.stride, recYuvExt.get( COMP_Y ).bufAt( blkSrc.x, blkSrc.y ),\n"
      "                 recYuvExt.get( COMP_Y ).stride, blkDst.width, blkDst.height, filterCoeff, clpRngs[compID].bd, m_alfVBLumaCTUHeight, m_alfVBLumaPos ) ) )\n"
      "        m_filterCcAlf( dstBuf, recYuvExt, blkDst, blkSrc, compID, filterCoeff, clpRngs, cs, m_alfVBLumaCTUHeight, m_alfVBLumaPos );"),
+    # ALF reconstruction of the whole picture in one shim call: the first reconstruction task of a picture filters every enabled CTU of the three planes, the other tasks
+    # find the picture done (they wait on the hook's lock while it is in progress) and return
+    ("before", "  // copy unfiltered reco (including padded / extented area)\n",
+     "  if( g_vvhipHooks.alfFilterPicture && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled && m_encCfg->m_ifpLines == 0 )\n"
+     "  {\n"
+     "    if( g_vvhipHooks.alfFilterPicture( this, cs.picture->poc, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, true ) ) return;\n"
+     "    const int hNumCtus = ( int ) m_numCTUsInPic, hBw = m_picWidth / 4, hCtuBlk = ( MAX_CU_SIZE * MAX_CU_SIZE ) >> 4;\n"
+     "    std::vector<uint8_t> hCls( ( size_t ) hBw * ( m_picHeight / 4 ) * 2 );\n"
+     "    std::vector<short> hSet[3];\n"
+     "    const short* hFilterIdx = cs.picture->m_alfCtbFilterIndex.data();\n"
+     "    bool hAny[3] = { false, false, false };\n"
+     "    for( int c = 0; c < 3; c++ )\n"
+     "    {\n"
+     "      hSet[c].resize( hNumCtus );\n"
+     "      for( int ctu = 0; ctu < hNumCtus; ctu++ )\n"
+     "      {\n"
+     "        hSet[c][ctu] = !m_ctuEnableFlag[c][ctu] ? -1 : c == 0 ? hFilterIdx[ctu] : m_ctuAlternative[c][ctu];\n"
+     "        hAny[c] |= hSet[c][ctu] >= 0;\n"
+     "      }\n"
+     "    }\n"
+     "    for( int ctu = 0; ctu < hNumCtus; ctu++ )\n"
+     "    {\n"
+     "      const int x0 = ( ctu % m_numCTUsInWidth ) * m_maxCUWidth, y0 = ( ctu / m_numCTUsInWidth ) * m_maxCUHeight;\n"
+     "      const int w = std::min( m_maxCUWidth, m_picWidth - x0 ), h = std::min( m_maxCUHeight, m_picHeight - y0 );\n"
+     "      for( int i = 0; i < h; i += 4 ) for( int j = 0; j < w; j += 4 )\n"
+     "      {\n"
+     "        const AlfClassifier& k = m_classifier[hCtuBlk * ctu + ( i / 4 ) * ( MAX_CU_SIZE / 4 ) + j / 4];\n"
+     "        uint8_t* o = hCls.data() + 2 * ( ( size_t ) ( ( y0 + i ) / 4 ) * hBw + ( x0 + j ) / 4 ); o[0] = k.classIdx; o[1] = k.transposeIdx;\n"
+     "      }\n"
+     "    }\n"
+     "    // luma filter sets in the order of alfCtbFilterIndex: the fixed sets, then the APS sets of the slice\n"
+     "    const int hSetLen = MAX_NUM_ALF_CLASSES * MAX_NUM_ALF_LUMA_COEFF, hNumSets = NUM_FIXED_FILTER_SETS + ALF_CTB_MAX_NUM_APS;\n"
+     "    std::vector<short> hCoeff( ( size_t ) hNumSets * hSetLen ), hClip( hCoeff.size() );\n"
+     "    for( int k = 0; k < NUM_FIXED_FILTER_SETS; k++ ) { memcpy( &hCoeff[( size_t ) k * hSetLen], m_fixedFilterSetCoeffDec[k], sizeof( short ) * hSetLen ); memcpy( &hClip[( size_t ) k * hSetLen], m_clipDefault, sizeof( short ) * hSetLen ); }\n"
+     "    for( int k = 0; k < ALF_CTB_MAX_NUM_APS; k++ ) { memcpy( &hCoeff[( size_t ) ( NUM_FIXED_FILTER_SETS + k ) * hSetLen], m_coeffApsLuma[k], sizeof( short ) * hSetLen ); memcpy( &hClip[( size_t ) ( NUM_FIXED_FILTER_SETS + k ) * hSetLen], m_clippApsLuma[k], sizeof( short ) * hSetLen ); }\n"
+     "    PelUnitBuf& hRecBuf = cs.getRecoBufRef();\n"
+     "    const Pel* hSrc[3]; Pel* hDst[3]; int hSs[3], hDs[3];\n"
+     "    for( int c = 0; c < 3; c++ ) { hSrc[c] = m_tempBuf.get( ComponentID( c ) ).buf; hSs[c] = m_tempBuf.get( ComponentID( c ) ).stride; hDst[c] = hRecBuf.get( ComponentID( c ) ).buf; hDs[c] = hRecBuf.get( ComponentID( c ) ).stride; }\n"
+     "    const short* hChromaSet[2] = { hAny[1] ? hSet[1].data() : nullptr, hAny[2] ? hSet[2].data() : nullptr };\n"
+     "    const bool hOk = g_vvhipHooks.alfFilterPicture( this, cs.picture->poc, hSrc, hSs, hDst, hDs, m_picWidth, m_picHeight, m_inputBitDepth[CH_L], m_maxCUHeight, hCls.data(), hCoeff.data(),\n"
+     "        m_encCfg->m_useNonLinearAlfLuma ? hClip.data() : nullptr, hNumSets, hAny[0] ? hSet[0].data() : nullptr, &m_chromaCoeffFinal[0][0], m_encCfg->m_useNonLinearAlfChroma ? &m_chromaClippFinal[0][0] : nullptr,\n"
+     "        VVENC_MAX_NUM_ALF_ALTERNATIVES_CHROMA, hChromaSet, m_alfVBLumaCTUHeight, m_alfVBLumaPos, m_alfVBChmaCTUHeight, m_alfVBChmaPos, false );\n"
+     "    CHECK( !hOk, \"HIP ALF picture filtering failed\" );\n"
+     "    return;\n"
+     "  }\n"),
 ], sub="EncoderLib")

@@ -459,9 +459,28 @@ bool ccAlfFilterBlk( int16_t* dstC, int dstStride, const int16_t* recLuma, int r
   return true;
 }
 
+std::atomic<uint64_t> g_alfFilterPictures{ 0 };
+std::mutex g_alfPicLock;
+std::map<const void*, int> g_alfPicDone;                                          // EncAdaptiveLoopFilter object -> poc of the picture it has filtered last
+bool alfFilterPicture( const void* owner, int poc, const int16_t* const src[3], const int srcStride[3], int16_t* const dst[3], const int dstStride[3], int width, int height, int bitDepth,
+                       int ctuSize, const uint8_t* cls, const short* lumaCoeff, const short* lumaClip, int numLumaSets, const short* lumaCtuSet, const short* chromaCoeff,
+                       const short* chromaClip, int numChromaSets, const short* const chromaCtuSet[2], int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, bool alreadyDoneOnly )
+{
+  static vvhip::ALFOps alf;
+  std::lock_guard<std::mutex> g( g_alfPicLock );                                  // later CTU tasks of the picture wait here until the first one has finished it
+  auto it = g_alfPicDone.find( owner );
+  if( it != g_alfPicDone.end() && it->second == poc ) return true;
+  if( alreadyDoneOnly ) return false;
+  if( !alf.filterPicture( src, srcStride, dst, dstStride, width, height, bitDepth, ctuSize, cls, lumaCoeff, lumaClip, numLumaSets, lumaCtuSet, chromaCoeff, chromaClip, numChromaSets,
+                          chromaCtuSet, vbLumaH, vbLumaPos, vbChromaH, vbChromaPos ) ) return false;
+  g_alfPicDone[owner] = poc;
+  g_alfFilterPictures++;
+  return true;
+}
+
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
 {
-  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round), bit11 ALF statistics per CTU (classification + covariance records), bit12 CC-ALF statistics per CTU and chroma component, bit13 ALF statistics of a whole picture in one call (the per-CTU statistics tasks become no-ops), bit14 ALF filtering per CTU block (7x7 / 5x5 table entries), bit15 CC-ALF filtering per CTU block
+  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round), bit11 ALF statistics per CTU (classification + covariance records), bit12 CC-ALF statistics per CTU and chroma component, bit13 ALF statistics of a whole picture in one call (the per-CTU statistics tasks become no-ops), bit14 ALF filtering per CTU block (7x7 / 5x5 table entries), bit15 CC-ALF filtering per CTU block, bit16 ALF filtering of a whole picture in one shim call (issued by the first reconstruction task of the picture)
   g_slotMask = mask;
   try
   {
@@ -483,6 +502,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
   g_vvhipHooks.alfPicture = ( mask & 8192 ) ? alfPicture : nullptr; g_alfPictures = 0;
   g_vvhipHooks.alfFilterBlk = ( mask & 16384 ) ? alfFilterBlk : nullptr; g_alfFilterBlks = 0;
   g_vvhipHooks.ccAlfFilterBlk = ( mask & 32768 ) ? ccAlfFilterBlk : nullptr; g_ccAlfFilterBlks = 0;
+  g_vvhipHooks.alfFilterPicture = ( mask & 65536 ) ? alfFilterPicture : nullptr; g_alfFilterPictures = 0; g_alfPicDone.clear();
   g_vvhipHooks.tzReset = ( mask & 1024 ) ? tzReset : nullptr; g_vvhipHooks.tzPrefetch = ( mask & 1024 ) ? tzPrefetch : nullptr; g_vvhipHooks.tzLookup = ( mask & 1024 ) ? tzLookup : nullptr;
   g_tzRounds = 0; g_tzHits = 0;
   g_dmvrCalls = 0;
@@ -507,4 +527,5 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
   if( n > 16 ) out[16] = g_alfPictures;
   if( n > 17 ) out[17] = g_alfFilterBlks;
   if( n > 18 ) out[18] = g_ccAlfFilterBlks;
+  if( n > 19 ) out[19] = g_alfFilterPictures;
 }

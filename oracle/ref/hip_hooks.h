@@ -43,6 +43,10 @@ struct VvhipHooks
   bool ( *alfFilterBlk )( const void* classifier, int16_t* dst, int dstStride, const int16_t* src, int srcStride, int width, int height, int filterLength,
                           const short* coeff, const short* clip, int bitDepth, int vbCTUHeight, int vbPos );
   bool ( *ccAlfFilterBlk )( int16_t* dstC, int dstStride, const int16_t* recLuma, int recStride, int widthC, int heightC, const int16_t* coeff, int bitDepth, int vbCTUHeight, int vbPos );
+  // ALF reconstruction of a whole picture by the first CTU task that reaches it (the others find it done): owner / poc identify the picture
+  bool ( *alfFilterPicture )( const void* owner, int poc, const int16_t* const src[3], const int srcStride[3], int16_t* const dst[3], const int dstStride[3], int width, int height, int bitDepth,
+                              int ctuSize, const uint8_t* cls, const short* lumaCoeff, const short* lumaClip, int numLumaSets, const short* lumaCtuSet, const short* chromaCoeff,
+                              const short* chromaClip, int numChromaSets, const short* const chromaCtuSet[2], int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, bool alreadyDoneOnly );
   bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel, int refPoc, int curPoc );
 };
 extern VvhipHooks g_vvhipHooks;

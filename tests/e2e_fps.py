@@ -54,7 +54,7 @@ yuv = F.synth_clip(cfg["w"], cfg["h"], cfg["frames"])
 md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], 10, 10, threads=cfg["threads"])
 calls = None
 if cfg["mask"]:
-    c = np.zeros(19, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 19); calls = [int(x) for x in c]
+    c = np.zeros(20, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 20); calls = [int(x) for x in c]
 print(json.dumps({"mask": cfg["mask"], "md5": md5, "bytes": n, "secs": secs, "fps": cfg["frames"] / secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 

@@ -28,7 +28,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(19, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 19); calls = [int(x) for x in c]
+    c = np.zeros(20, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 20); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -229,6 +229,25 @@ def test_hip_alf_filtering_bitstream_identical():
     res = [e2e_fps.run(dict(w=1920, h=1080, frames=9, threads=8, mask=m)) for m in (0, 8192 + 16384 + 32768)]
     print(res)
     assert res[1]["calls"][17] >= 500, res[1]["calls"]
+    assert res[0]["md5"] == res[1]["md5"] and res[0]["bytes"] == res[1]["bytes"], res
+
+
+@pytest.mark.gpu
+def test_hip_alf_picture_filtering_bitstream_identical():
+    """the whole ALF stage of a picture in two shim calls (hook masks 8192 + 65536): statistics of every unit before the derivation, and after it the filtering of every
+    enabled CTU of the three planes by the first reconstruction task of the picture (the other tasks find the picture done); CC-ALF per block (32768)"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=8192 + 65536))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][19] >= 1 and hip["calls"][17] == 0, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+    import e2e_fps
+    res = [e2e_fps.run(dict(w=1920, h=1080, frames=9, threads=8, mask=m)) for m in (0, 8192 + 65536 + 32768)]
+    print(res)
+    assert res[1]["calls"][19] >= 2 and res[1]["calls"][17] == 0, res[1]["calls"]
     assert res[0]["md5"] == res[1]["md5"] and res[0]["bytes"] == res[1]["bytes"], res
 
 

@@ -821,12 +821,10 @@ bool ALFOps::filterPlane( const Pel* src, int srcStride, Pel* dst, int dstStride
   const size_t srcBytes = ( ( size_t ) srcPitchGuess * ( height + 8 ) * sizeof( Pel ) + 255 ) & ~( size_t ) 255;
   const int dstPitch = ( width + 7 ) & ~7;
   std::vector<Pel> hdst( ( size_t ) dstPitch * height );
-  for( int y = 0; y < height; y++ ) memcpy( &hdst[( size_t ) y * dstPitch], dst + ( ptrdiff_t ) y * dstStride, sizeof( Pel ) * width );
   dev.staging( srcBytes + hdst.size() * sizeof( Pel ) + 512 );
   int pitch;
   const int16_t* dSrc = stageBordered( dev, src, srcStride, width, height, 4, 0, pitch );
-  int16_t* dDst = dev.staging( srcBytes + hdst.size() * sizeof( Pel ) + 512 ) + srcBytes / sizeof( Pel );
-  dev.check( vvhip_upload( dev.ctx(), dDst, hdst.data(), hdst.size() * sizeof( Pel ) ), "ALF destination plane" );
+  int16_t* dDst = dev.staging( srcBytes + hdst.size() * sizeof( Pel ) + 512 ) + srcBytes / sizeof( Pel );      // not initialised: only the enabled CTUs are read back
   const int numClasses = cls ? 25 : 1, ctus = ( ( width + ctuSize - 1 ) / ctuSize ) * ( ( height + ctuSize - 1 ) / ctuSize );
   const size_t nCls = ( ( cls ? ( size_t ) ( width / 4 ) * ( height / 4 ) * 2 : 0 ) + 255 ) & ~( size_t ) 255;
   const size_t nCoef = ( ( size_t ) numSets * numClasses * 13 * sizeof( short ) + 255 ) & ~( size_t ) 255, nSet = ( size_t ) ctus * sizeof( short );
@@ -839,7 +837,25 @@ bool ALFOps::filterPlane( const Pel* src, int srcStride, Pel* dst, int dstStride
                                      reinterpret_cast<const int16_t*>( aux + nCls ), clipSets ? reinterpret_cast<const int16_t*>( aux + nCls + nCoef ) : nullptr,
                                      reinterpret_cast<const int16_t*>( aux + nCls + 2 * nCoef ), vbCTUHeight, vbPos ), "vvhip_alf_filter_plane" );
   dev.check( vvhip_download( dev.ctx(), hdst.data(), dDst, hdst.size() * sizeof( Pel ) ), "ALF filtered plane" );
-  for( int y = 0; y < height; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride, &hdst[( size_t ) y * dstPitch], sizeof( Pel ) * width );
+  const int ctusX = ( width + ctuSize - 1 ) / ctuSize;
+  for( int c = 0; c < ctus; c++ )
+  {
+    if( ctuSet[c] < 0 ) continue;                                                        // the CTU keeps the caller's samples
+    const int x0 = ( c % ctusX ) * ctuSize, y0 = ( c / ctusX ) * ctuSize, w = std::min( ctuSize, width - x0 ), h = std::min( ctuSize, height - y0 );
+    for( int y = y0; y < y0 + h; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride + x0, &hdst[( size_t ) y * dstPitch + x0], sizeof( Pel ) * w );
+  }
+  return true;
+}
+
+bool ALFOps::filterPicture( const Pel* const src[3], const int srcStride[3], Pel* const dst[3], const int dstStride[3], int width, int height, int bitDepth, int ctuSize,
+                            const uint8_t* cls, const short* lumaCoeff, const short* lumaClip, int numLumaSets, const short* lumaCtuSet,
+                            const short* chromaCoeff, const short* chromaClip, int numChromaSets, const short* const chromaCtuSet[2],
+                            int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos )
+{
+  if( lumaCtuSet && !filterPlane( src[0], srcStride[0], dst[0], dstStride[0], width, height, ctuSize, bitDepth, 7, cls, lumaCoeff, lumaClip, numLumaSets, lumaCtuSet, vbLumaH, vbLumaPos ) ) return false;
+  for( int c = 0; c < 2; c++ )
+    if( chromaCtuSet[c] && !filterPlane( src[1 + c], srcStride[1 + c], dst[1 + c], dstStride[1 + c], width / 2, height / 2, ctuSize / 2, bitDepth, 5, nullptr, chromaCoeff, chromaClip,
+                                         numChromaSets, chromaCtuSet[c], vbChromaH, vbChromaPos ) ) return false;
   return true;
 }
 

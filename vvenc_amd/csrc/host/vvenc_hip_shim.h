@@ -210,6 +210,12 @@ struct ALFOps
   // coeffSets / clipSets: [numSets][cls ? 25 : 1][13]; clipSets == nullptr selects the linear entries ([0]).  cls as written by deriveClassification (luma), nullptr for chroma.
   bool filterPlane( const Pel* src, int srcStride, Pel* dst, int dstStride, int width, int height, int ctuSize, int bitDepth, int filterLength, const uint8_t* cls,
                     const short* coeffSets, const short* clipSets, int numSets, const short* ctuSet, int vbCTUHeight, int vbPos );
+  // whole-picture form (4:2:0) of the ALF reconstruction: luma with numLumaSets filter sets (lumaCtuSet == nullptr: luma off), both chroma planes with the numChromaSets
+  // alternatives (chromaCtuSet[c] == nullptr: plane off); src[c] = the unfiltered planes with their replicated border, dst[c] = the reconstruction picture
+  bool filterPicture( const Pel* const src[3], const int srcStride[3], Pel* const dst[3], const int dstStride[3], int width, int height, int bitDepth, int ctuSize,
+                      const uint8_t* cls, const short* lumaCoeff, const short* lumaClip, int numLumaSets, const short* lumaCtuSet,
+                      const short* chromaCoeff, const short* chromaClip, int numChromaSets, const short* const chromaCtuSet[2],
+                      int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos );
   // AdaptiveLoopFilter::m_filterCcAlf (:124) over a chroma plane (4:2:0) as applyCcAlfFilterCTU drives it: dstC corrected in place; coeff [numFilters][8]; ctuFilter[ctu] 0 = off
   bool filterCcAlf( Pel* dstC, int dstStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC, int bitDepth, const int16_t* coeff, int numFilters,
                     const uint8_t* ctuFilter, int vbCTUHeight, int vbPos );
