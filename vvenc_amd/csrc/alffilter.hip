@@ -95,7 +95,6 @@ alfFilterKernel( const AlfFilterArgs A )
 #pragma unroll
         for( int k = 0; k < NT; k++ )
         {
-          constexpr int dummy = 0; ( void ) dummy;
           const int dy = alfDy( FL, k ), dx = alfDx( FL, k );
           const int a = ALF_S( r + R + dy, j + dx ), b = ALF_S( r + R - dy, j - dx );
           if( NONLIN ) sum += cf[k] * ( alfMed3( a - cur, -cl[k], cl[k] ) + alfMed3( b - cur, -cl[k], cl[k] ) );
