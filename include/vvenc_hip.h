@@ -49,6 +49,14 @@ VVHIP_API int         vvhip_set_stream( vvhip_ctx* ctx, void* hip_stream ); /* b
 VVHIP_API int         vvhip_use_own_stream( vvhip_ctx* ctx );          /* back to the context's private stream          */
 VVHIP_API void*       vvhip_get_stream( vvhip_ctx* ctx );
 VVHIP_API int         vvhip_sync( vvhip_ctx* ctx );                    /* hipStreamSynchronize                          */
+/* Launch graphs: the batch entry points only enqueue kernels on the context's stream, so a frame's fixed sequence of calls (the lists of one picture: same tables,
+ * same buffers) can be recorded once and replayed with one hipGraphLaunch instead of one dispatch per call.  Between begin and end no call may synchronise, allocate
+ * (call every entry point once beforehand so scratch buffers exist) or touch another stream.  No counterpart in the reference: its table entries are synchronous calls. */
+typedef struct vvhip_graph vvhip_graph;
+VVHIP_API int         vvhip_graph_begin( vvhip_ctx* ctx );                         /* hipStreamBeginCapture on the context's stream */
+VVHIP_API int         vvhip_graph_end( vvhip_ctx* ctx, vvhip_graph** out );        /* end capture + instantiate                     */
+VVHIP_API int         vvhip_graph_launch( vvhip_ctx* ctx, vvhip_graph* graph );    /* replay on the context's stream                */
+VVHIP_API void        vvhip_graph_destroy( vvhip_graph* graph );
 VVHIP_API int         vvhip_malloc( vvhip_ctx* ctx, void** d_ptr, size_t bytes );
 VVHIP_API int         vvhip_free( vvhip_ctx* ctx, void* d_ptr );
 VVHIP_API int         vvhip_upload( vvhip_ctx* ctx, void* d_dst, const void* host_src, size_t bytes );   /* async on stream */

@@ -835,3 +835,43 @@ def test_ccalf_filtering_vs_oracle(hip, oracle, cfg):
     got = hip.ccalf_filter_plane(chroma, rec, ctu_c, bd, coeff, ctu_filter, 2 * ctu_c, 2 * ctu_c - 4)
     assert np.array_equal(got, exp)
     assert not np.array_equal(exp, chroma)
+
+
+def test_launch_graph_replays_batch_calls(hip, oracle):
+    """vvhip_graph_*: a fixed sequence of batch calls recorded once on the context's stream and replayed — results equal the direct calls', also after the inputs changed"""
+    import torch
+    hp = hip.hp
+    rng = np.random.default_rng(77)
+    org = rng.integers(0, 1024, (128, 192), dtype=np.int16)
+    cur = np.clip(np.roll(org, (1, -2), (0, 1)).astype(np.int32) + rng.integers(-6, 7, org.shape), 0, 1023).astype(np.int16)
+    po, pc = hp.plane(org, 16), hp.plane(cur, 16)
+    bx, by = np.meshgrid(np.arange(0, 192 - 16 + 1, 16), np.arange(0, 128 - 16 + 1, 16))
+    items = np.stack([(by.ravel() * po.stride + bx.ravel()), ((by.ravel() + 1) * pc.stride + bx.ravel() - 2)], 1).astype(np.int32)
+    d_items = hp.to_device(items)
+    n = items.shape[0]
+    out_sad = torch.zeros(n, dtype=torch.int64, device=hp.device)
+    out_had = torch.zeros(n, dtype=torch.int64, device=hp.device)
+
+    def calls():
+        hp.dist_batch("SAD", po, pc, d_items, n, 16, 16, out=out_sad)
+        hp.dist_batch("HAD", po, pc, d_items, n, 16, 16, out=out_had)
+
+    calls()
+    torch.cuda.synchronize()
+    exp_sad, exp_had = out_sad.clone(), out_had.clone()
+    g = hp.graph_capture(calls)
+    out_sad.zero_(); out_had.zero_()
+    hp.graph_launch(g)
+    torch.cuda.synchronize()
+    assert torch.equal(out_sad, exp_sad) and torch.equal(out_had, exp_had)
+    # same graph, new picture content in the same buffers
+    cur2 = np.clip(cur.astype(np.int32) + rng.integers(-20, 21, cur.shape), 0, 1023).astype(np.int16)
+    pc.storage[pc.pad:pc.pad + pc.height, pc.pad:pc.pad + pc.width] = torch.from_numpy(cur2).to(hp.device)
+    hp.graph_launch(g)
+    torch.cuda.synchronize()
+    got = out_sad.cpu().numpy()
+    o32, c32 = org.astype(np.int64), cur2.astype(np.int64)
+    ref = np.array([np.abs(o32[y:y + 16, x:x + 16] - c32[y + 1:y + 17, x - 2:x + 14]).sum() if x >= 2 and y + 17 <= 128 else -1 for x, y in zip(bx.ravel(), by.ravel())])
+    ok = ref >= 0
+    assert np.array_equal(got[ok], ref[ok])
+    hp.graph_destroy(g)

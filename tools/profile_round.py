@@ -79,7 +79,7 @@ def main():
         elif x == "--": extra = a; break
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    base = ["--no-cpu-baseline", "--overlap-streams", "0"] + extra      # the trace must hold the serialized launches only
+    base = ["--no-cpu-baseline", "--overlap-streams", "0", "--graph", "0"] + extra      # the trace must hold the serialized launches only
     db1, line = run_pass(os.path.join(out, "prof_%s_trace" % tag), ["--kernel-trace", "--stats"], ["--steps", steps, "--warmup", warm] + base)
     db2, _ = run_pass(os.path.join(out, "prof_%s_fetch" % tag), ["--pmc", "FETCH_SIZE"], ["--steps", "5", "--warmup", "1"] + base)
     db3, _ = run_pass(os.path.join(out, "prof_%s_write" % tag), ["--pmc", "WRITE_SIZE"], ["--steps", "5", "--warmup", "1"] + base)

@@ -262,6 +262,43 @@ int vvhip_sync( vvhip_ctx* ctx )
   return VVHIP_OK;
 }
 
+struct vvhip_graph { hipGraph_t graph; hipGraphExec_t exec; };
+
+int vvhip_graph_begin( vvhip_ctx* ctx )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipStreamBeginCapture( ctx->stream, hipStreamCaptureModeThreadLocal ) );
+  return VVHIP_OK;
+}
+
+int vvhip_graph_end( vvhip_ctx* ctx, vvhip_graph** out )
+{
+  if( !ctx || !out ) return VVHIP_E_ARG;
+  *out = nullptr;
+  hipGraph_t g = nullptr;
+  VVHIP_CHECK_HIP( ctx, hipStreamEndCapture( ctx->stream, &g ) );
+  hipGraphExec_t e = nullptr;
+  hipError_t err = hipGraphInstantiate( &e, g, nullptr, nullptr, 0 );
+  if( err != hipSuccess ) { ( void ) hipGraphDestroy( g ); return vvhip_fail( ctx, VVHIP_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString( err ) ); }
+  *out = new vvhip_graph{ g, e };
+  return VVHIP_OK;
+}
+
+int vvhip_graph_launch( vvhip_ctx* ctx, vvhip_graph* graph )
+{
+  if( !ctx || !graph ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipGraphLaunch( graph->exec, ctx->stream ) );
+  return VVHIP_OK;
+}
+
+void vvhip_graph_destroy( vvhip_graph* graph )
+{
+  if( !graph ) return;
+  ( void ) hipGraphExecDestroy( graph->exec );
+  ( void ) hipGraphDestroy( graph->graph );
+  delete graph;
+}
+
 int vvhip_malloc( vvhip_ctx* ctx, void** d_ptr, size_t bytes )
 {
   if( !ctx || !d_ptr ) return VVHIP_E_ARG;

@@ -102,6 +102,24 @@ class HotPath:
         with torch.cuda.device(self.device):
             self._ck(self.L.vvhip_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    # ---- launch graphs: record a fixed sequence of batch calls once, replay it with one hipGraphLaunch ----
+    def graph_capture(self, fn):
+        """runs fn() under stream capture (fn may only issue batch calls whose scratch already exists) -> graph handle for graph_launch"""
+        self._ck(self.L.vvhip_graph_begin(self.ctx))
+        try:
+            fn()
+        finally:
+            g = C.c_void_p()
+            rc = self.L.vvhip_graph_end(self.ctx, C.byref(g))
+        self._ck(rc)
+        return g
+
+    def graph_launch(self, g):
+        self._ck(self.L.vvhip_graph_launch(self.ctx, g))
+
+    def graph_destroy(self, g):
+        self.L.vvhip_graph_destroy(g)
+
     def use_own_stream(self):
         self._ck(self.L.vvhip_use_own_stream(self.ctx))
 

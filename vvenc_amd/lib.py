@@ -59,6 +59,10 @@ PROTOTYPES = {
     "vvhip_ccalf_stats_plane": (i32, [vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "vvhip_alf_stats_plane_units": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
     "vvhip_alf_stats_plane": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
+    "vvhip_graph_begin": (i32, [vp]),
+    "vvhip_graph_end": (i32, [vp, vp]),
+    "vvhip_graph_launch": (i32, [vp, vp]),
+    "vvhip_graph_destroy": (None, [vp]),
     "vvhip_alf_filter_plane": (i32, [vp, vp, C.c_ssize_t, vp, C.c_ssize_t, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32]),
     "vvhip_ccalf_filter_plane": (i32, [vp, vp, C.c_ssize_t, vp, C.c_ssize_t, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32]),
     "vvhip_subpel_refine_batch": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]),
