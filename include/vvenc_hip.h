@@ -51,7 +51,7 @@ VVHIP_API void*       vvhip_get_stream( vvhip_ctx* ctx );
 VVHIP_API int         vvhip_sync( vvhip_ctx* ctx );                    /* hipStreamSynchronize                          */
 /* Launch graphs: the batch entry points only enqueue kernels on the context's stream, so a frame's fixed sequence of calls (the lists of one picture: same tables,
  * same buffers) can be recorded once and replayed with one hipGraphLaunch instead of one dispatch per call.  Between begin and end no call may synchronise, allocate
- * (call every entry point once beforehand so scratch buffers exist) or touch another stream.  No counterpart in the reference: its table entries are synchronous calls. */
+ * (call every entry point once beforehand so scratch buffers exist) or touch another stream; the stream must not be the legacy default stream (vvhip_use_own_stream).  No counterpart in the reference: its table entries are synchronous calls. */
 typedef struct vvhip_graph vvhip_graph;
 VVHIP_API int         vvhip_graph_begin( vvhip_ctx* ctx );                         /* hipStreamBeginCapture on the context's stream */
 VVHIP_API int         vvhip_graph_end( vvhip_ctx* ctx, vvhip_graph** out );        /* end capture + instantiate                     */

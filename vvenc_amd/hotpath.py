@@ -105,13 +105,17 @@ class HotPath:
     # ---- launch graphs: record a fixed sequence of batch calls once, replay it with one hipGraphLaunch ----
     def graph_capture(self, fn):
         """runs fn() under stream capture (fn may only issue batch calls whose scratch already exists) -> graph handle for graph_launch"""
-        self._ck(self.L.vvhip_graph_begin(self.ctx))
+        self.use_own_stream()                        # torch's current stream may be the legacy default stream, which cannot be captured
         try:
-            fn()
+            self._ck(self.L.vvhip_graph_begin(self.ctx))
+            try:
+                fn()
+            finally:
+                g = C.c_void_p()
+                rc = self.L.vvhip_graph_end(self.ctx, C.byref(g))
+            self._ck(rc)
         finally:
-            g = C.c_void_p()
-            rc = self.L.vvhip_graph_end(self.ctx, C.byref(g))
-        self._ck(rc)
+            self.use_torch_stream()
         return g
 
     def graph_launch(self, g):
