@@ -875,3 +875,27 @@ def test_launch_graph_replays_batch_calls(hip, oracle):
     ok = ref >= 0
     assert np.array_equal(got[ok], ref[ok])
     hp.graph_destroy(g)
+
+
+def test_alf_4k_vs_oracle(hip, oracle):
+    """SURVEY 8f rank 4 at BASELINE's largest picture (3840x2160, CTU 128): classes, luma covariance records (float bit patterns) and the filtered luma plane against the
+    oracle; size-independent property on top: an all-zero filter set returns the unfiltered plane"""
+    hp = hip.hp
+    h, w, ctu = 2160, 3840, 128
+    org, rec = _alf_pictures(np.random.default_rng(2160), h, w, False)
+    prec, porg = hp.plane(rec, 8), hp.plane(org, 0)
+    d_cls = hp.alf_classify(prec, 10, ctu, ctu - 4)
+    exp_cls = oracle.alf_classify(rec, 10, ctu, ctu - 4)
+    assert np.array_equal(d_cls.cpu().numpy(), exp_cls)
+    got = hp.alf_stats_plane(porg, prec, ctu, 7, d_cls, ctu, ctu - 4).cpu().numpy()
+    exp = oracle.alf_stats_plane(org, rec, ctu, 7, exp_cls, ctu, ctu - 4)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    rng = np.random.default_rng(2161)
+    coeff, clip = _alf_filter_sets(rng, 3, 25, 10, True)
+    nctu = -(-h // ctu) * -(-w // ctu)
+    ctu_set = rng.integers(-1, 3, nctu).astype(np.int16)
+    exp = oracle.alf_filter_plane(rec, ctu, 10, 7, coeff, clip, ctu_set, exp_cls, None, ctu, ctu - 4)
+    got = hip.alf_filter_plane(rec, ctu, 10, 7, coeff, clip, ctu_set, exp_cls, None, ctu, ctu - 4)
+    assert np.array_equal(got, exp)
+    zero = np.zeros_like(coeff)
+    assert np.array_equal(hip.alf_filter_plane(rec, ctu, 10, 7, zero, clip, np.zeros(nctu, np.int16), exp_cls, None, ctu, ctu - 4), rec)
