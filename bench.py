@@ -235,23 +235,34 @@ def main():
                    "note": "same work, the 3 launches of a frame issued on separate HIP streams (no per-kernel events); not the headline value"}
     graph = None
     if args.graph and wl.merged and not mctf_refs and not args.with_subpel:
-        # the frame's launches recorded once as a HIP graph and replayed with one hipGraphLaunch per step (the call sequence of a picture is fixed)
+        # the frame's launches recorded once as a HIP graph and replayed with one hipGraphLaunch per step (the call sequence of a picture is fixed).
+        # An extra measurement must never take the headline line down: failures are caught per rank and every rank runs the same collectives.
+        gh, err, dtl = None, None, 0.0
         try:
             gh = hp.graph_capture(lambda: wl.run(None))
             for _ in range(max(args.warmup, 1)):
                 hp.graph_launch(gh)
             torch.cuda.synchronize()
-            sharding.barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                hp.graph_launch(gh)
-            torch.cuda.synchronize()
-            dtg = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
-            hp.graph_destroy(gh)
+        except Exception as e:
+            err = str(e)[:200]
+        sharding.barrier()
+        if err is None:
+            try:
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    hp.graph_launch(gh)
+                torch.cuda.synchronize()
+                dtl = time.perf_counter() - t1
+                hp.graph_destroy(gh)
+            except Exception as e:
+                err = str(e)[:200]
+        dtg = sharding.max_over_ranks(dtl, device="cuda")
+        bad = sharding.max_over_ranks(0.0 if err is None else 1.0, device="cuda")
+        if bad > 0.0:
+            graph = {"error": err or "failed on another rank"}
+        else:
             graph = {"value": args.steps * world / dtg, "unit": "frames/s", "ms_per_step": 1000.0 * dtg / args.steps,
                      "note": "same work, the 3 launches of a frame captured once as a HIP graph and replayed (no per-kernel events); not the headline value"}
-        except Exception as e:                                   # an extra measurement must never take the headline line down
-            graph = {"error": str(e)[:200]}
     if rank != 0:
         return
     frames = args.steps * world
