@@ -252,6 +252,19 @@ def test_hip_alf_picture_filtering_bitstream_identical():
 
 
 @pytest.mark.gpu
+def test_hip_4k_picture_level_stages_bitstream_identical():
+    """BASELINE's 4K geometry (3840x2160 10-bit, preset faster) in the real encoder: the picture-level stages on the device — MCTF search + bilateral filter (144), ALF
+    statistics (8192) and ALF filtering (65536) of whole pictures — 9 frames, 8 encoder threads"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    import e2e_fps
+    res = [e2e_fps.run(dict(w=3840, h=2160, frames=9, threads=8, mask=m)) for m in (0, 144 + 8192 + 65536)]
+    print(res)
+    assert res[1]["calls"][9] >= 1 and res[1]["calls"][16] >= 1 and res[1]["calls"][19] >= 1, res[1]["calls"]
+    assert res[0]["md5"] == res[1]["md5"] and res[0]["bytes"] == res[1]["bytes"], res
+
+
+@pytest.mark.gpu
 def test_hip_everything_on_device_bitstream_identical():
     """all hooks at once on a larger clip (208x120 10-bit, 9 frames, 2 encoder threads): every kernel table, the interpolation tables, whole-picture
     MCTF ME + filter, batched integer diamond rounds, batched sub-pel refinement stages, per-CU DMVR searches, per-CTU ALF statistics and ALF / CC-ALF filtering"""
