@@ -1,3 +1,5 @@
+"""Per-phase timing of the fused TU kernels: runs tools/kbench.py with the kernels cut after phase k (VVHIP_TU_PHASES).  The cut changes the results, so the
+knob only exists in a library built with `make -C vvenc_amd/csrc FLAGS+=-DVVHIP_DEV_KNOBS` (development aid, not part of the product build)."""
 import sys, os, subprocess, re
 for ph in [1,2,3,4,5,6,7,0]:
     env=dict(os.environ, VVHIP_TU_PHASES=str(ph))

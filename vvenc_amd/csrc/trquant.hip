@@ -1679,7 +1679,12 @@ cpyCoeffKernel( const int16_t* __restrict__ src, ptrdiff_t stride, int32_t* __re
 // fused square-TU kernel: 0 = matrix cores (default), 1 = dot-product row kernel ($VVHIP_TU_KERNEL=row)
 static int tuKernelForm() { const char* e = getenv( "VVHIP_TU_KERNEL" ); return e && !strcmp( e, "row" ) ? 1 : 0; }     // read per call: tests switch it
 static int tuRepeat() { static const int v = getenv( "VVHIP_TU_REPEAT" ) ? atoi( getenv( "VVHIP_TU_REPEAT" ) ) : 2; return v < 1 ? 1 : v; }     // groups per workgroup
+// profiling aid (tools/tuphase.py): stop the fused kernels after phase k — changes the results, so it only exists in builds with -DVVHIP_DEV_KNOBS
+#ifdef VVHIP_DEV_KNOBS
 static int tuPhaseLimit() { static const int v = getenv( "VVHIP_TU_PHASES" ) ? atoi( getenv( "VVHIP_TU_PHASES" ) ) : 0; return v; }
+#else
+static int tuPhaseLimit() { return 0; }
+#endif
 
 extern "C" {
 
@@ -1984,7 +1989,7 @@ namespace {
 int launchTuRdo( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const int32_t* d_resi_off, int n, const TrGeom& gf, const TrGeom& gi, const TuLay& y,
                  const QGeom& q, int tpb, int tr_hor, int tr_ver, const vvhip_tu_qp* d_qp, int thr_val, int16_t* d_level, int16_t* d_rec_resi, vvhip_tu_stats* d_stats )
 {
-  static const int phaseLimit = getenv( "VVHIP_TU_PHASES" ) ? atoi( getenv( "VVHIP_TU_PHASES" ) ) : 0;   // profiling aid: stop after phase k
+  const int phaseLimit = tuPhaseLimit();
   const size_t smem = trSmemBytes( y, tpb );
   if( smem > 64 * 1024 ) VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) tuRdoKernel, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) smem ) );
   hipLaunchKernelGGL( tuRdoKernel, dim3( ( n + tpb - 1 ) / tpb ), dim3( 256 ), smem, ctx->stream,
