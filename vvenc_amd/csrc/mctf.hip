@@ -371,6 +371,41 @@ extendTBKernel( int16_t* plane, int stride, int w, int h, int pad )
   for( int x = threadIdx.x; x < w + 2 * pad; x += blockDim.x ) dst[x] = src[x];
 }
 
+// the pyramid level of several pictures (current + references) in one launch each: blockIdx.z / .y = picture
+constexpr int ME_MAX_PICS = 1 + ME_MAX_REFS;
+struct MePlanes { const int16_t* src[ME_MAX_PICS]; int16_t* dst[ME_MAX_PICS]; };
+
+__global__ void __launch_bounds__( 256 )
+subsampleBatchKernel( const MePlanes P, int ss, int ds, int nw, int nh )
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if( x >= nw || y >= nh ) return;
+  const int16_t* a = P.src[blockIdx.z] + ( ptrdiff_t ) ( 2 * y ) * ss + 2 * x;
+  P.dst[blockIdx.z][( ptrdiff_t ) y * ds + x] = ( int16_t ) ( ( a[0] + a[ss] + a[1] + a[ss + 1] + 2 ) >> 2 );   // MCTF.cpp:1091
+}
+__global__ void __launch_bounds__( 128 )
+extendLRBatchKernel( const MePlanes P, int stride, int w, int h, int pad )
+{
+  int16_t* r = P.dst[blockIdx.y] + ( ptrdiff_t ) blockIdx.x * stride;
+  const int16_t l = r[0], rr = r[w - 1];
+  for( int x = threadIdx.x; x < pad; x += blockDim.x ) { r[-1 - x] = l; r[w + x] = rr; }
+}
+__global__ void __launch_bounds__( 256 )
+extendTBBatchKernel( const MePlanes P, int stride, int w, int h, int pad )
+{
+  int16_t* plane = P.dst[blockIdx.y];
+  const int y = blockIdx.x;   // 0..2*pad-1
+  const int16_t* src = y < pad ? plane - pad : plane + ( ptrdiff_t ) ( h - 1 ) * stride - pad;
+  int16_t* dst = y < pad ? plane - ( ptrdiff_t ) ( y + 1 ) * stride - pad : plane + ( ptrdiff_t ) ( h + ( y - pad ) ) * stride - pad;
+  for( int x = threadIdx.x; x < w + 2 * pad; x += blockDim.x ) dst[x] = src[x];
+}
+
+__global__ void initMvsBatchKernel( const MeRefs R, int count )       // R.mvs[blockIdx.y]: the result field of a reference
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if( i < count ) { vvhip_mv m; m.x = 0; m.y = 0; m.error = 0x7fffffff; m.rmsme = 65535; m.overlap = 0.0; R.mvs[blockIdx.y][i] = m; }   // MotionVector(), MCTF.h:79
+}
+
 int ensureScratch( vvhip_ctx* ctx, size_t bytes )
 {
   if( ctx->scratchBytes >= bytes ) return VVHIP_OK;
@@ -531,17 +566,22 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
     return p + ( size_t ) P * ls[l] + P;
   };
   const int levels = add_level ? 3 : 2;
-  for( int pic = 0; pic <= n_refs; pic++ )
-  {
-    const int16_t* src = pic == 0 ? d_cur : d_refs[pic - 1];
-    int srcStride = stride;
-    for( int l = 1; l <= levels; l++ )
+  for( int l = 1; l <= levels; l++ )                                                     // MCTF.cpp:689-690,696,779-784: one level of every picture per launch
+    for( int p0 = 0; p0 <= n_refs; p0 += ME_MAX_PICS )
     {
-      rc = vvhip_mctf_subsample( ctx, src, srcStride, lw[l - 1], lh[l - 1], planePtr( pic, l ), ls[l], P );   // MCTF.cpp:689-690,696,779-784
-      if( rc ) return rc;
-      src = planePtr( pic, l ); srcStride = ls[l];
+      const int np = n_refs + 1 - p0 < ME_MAX_PICS ? n_refs + 1 - p0 : ME_MAX_PICS;
+      MePlanes Q = {};
+      for( int k = 0; k < np; k++ )
+      {
+        const int pic = p0 + k;
+        Q.src[k] = l == 1 ? ( pic == 0 ? d_cur : d_refs[pic - 1] ) : planePtr( pic, l - 1 );
+        Q.dst[k] = planePtr( pic, l );
+      }
+      hipLaunchKernelGGL( subsampleBatchKernel, dim3( ( lw[l] + 255 ) / 256, lh[l], np ), dim3( 256 ), 0, ctx->stream, Q, ls[l - 1], ls[l], lw[l], lh[l] );
+      hipLaunchKernelGGL( extendLRBatchKernel, dim3( lh[l], np ), dim3( 128 ), 0, ctx->stream, Q, ls[l], lw[l], lh[l], P );
+      hipLaunchKernelGGL( extendTBBatchKernel, dim3( 2 * P, np ), dim3( 256 ), 0, ctx->stream, Q, ls[l], lw[l], lh[l], P );
+      VVHIP_LAUNCH_CHECK( ctx );
     }
-  }
   rc = vvhip_mctf_init_mvs( ctx, reinterpret_cast<vvhip_mv*>( base + offFld ), ( int ) ( fieldElems * n_refs ) );   if( rc ) return rc;
   for( int r0 = 0; r0 < n_refs; r0 += ME_MAX_REFS )                                    // all references of a chunk advance through the hierarchy together
   {
@@ -552,9 +592,11 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
     {
       f[k][0] = reinterpret_cast<vvhip_mv*>( base + offFld ) + ( size_t ) ( r0 + k ) * fieldElems;
       for( int l = 1; l < 4; l++ ) f[k][l] = f[k][l - 1] + ( size_t ) fw[l - 1] * fh[l - 1];
-      rc = vvhip_mctf_init_mvs( ctx, d_mvs_out[r0 + k], outW * outH );                 if( rc ) return rc;
+      R.mvs[k] = d_mvs_out[r0 + k];
       R.gran[k] = d_gr + ( size_t ) k * granElems;
     }
+    hipLaunchKernelGGL( initMvsBatchKernel, dim3( ( outW * outH + 255 ) / 256, nr ), dim3( 256 ), 0, ctx->stream, R, outW * outH );
+    VVHIP_LAUNCH_CHECK( ctx );
     auto level = [&]( int l, int bs, int inField, int outField, int factor, int dbl ) -> int      // l: pyramid level (0 = full resolution); fields 0..3, 4 = result
     {
       for( int k = 0; k < nr; k++ )
