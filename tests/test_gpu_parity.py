@@ -780,7 +780,7 @@ def _alf_filter_sets(rng, num_sets, num_classes, bd, nonlinear):
     return coeff, np.ascontiguousarray(clip, np.int16)
 
 
-@pytest.mark.parametrize("cfg", [(272, 400, 128, False, 10), (264, 1048, 64, True, 10), (136, 200, 64, True, 8), (64, 64, 32, False, 10), (20, 12, 16, False, 10)])
+@pytest.mark.parametrize("cfg", [(272, 400, 128, False, 10), (264, 1048, 64, True, 10), (136, 200, 64, True, 8), (64, 64, 32, False, 10), (20, 12, 16, False, 10), (72, 104, 32, False, 12)])
 def test_alf_filtering_vs_oracle(hip, oracle, cfg):
     """SURVEY 8f rank 4, apply side: filterBlk 7x7 (25 classes, 4 transposes) and 5x5 over the enabled CTUs of a plane — linear entry (no clipping values), non-linear
     entry, rows folded at the virtual boundary and the 3-bit larger shift next to it, disabled CTUs untouched, partial tiles / CTUs, strided unaligned destination"""
@@ -790,6 +790,8 @@ def test_alf_filtering_vs_oracle(hip, oracle, cfg):
     _, rec = _alf_pictures(rng, h, w, smooth)
     if bd == 8:
         rec = (rec >> 2).astype(np.int16)
+    if bd == 12:
+        rec = ((rec.astype(np.int32) << 2) + rng.integers(0, 4, rec.shape)).astype(np.int16)
     cls = oracle.alf_classify(rec, bd, ctu, ctu - 4)
     nctu = -(-h // ctu) * -(-w // ctu)
     for nonlinear in (False, True):

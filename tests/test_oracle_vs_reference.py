@@ -566,7 +566,7 @@ def _alf_filter_sets(rng, num_sets, num_classes, bd, nonlinear=True):
     return coeff, np.ascontiguousarray(clip, np.int16)
 
 
-@pytest.mark.parametrize("cfg", [(272, 400, 128, False, 10), (264, 392, 64, True, 10), (136, 200, 64, True, 8), (64, 64, 32, False, 10)])
+@pytest.mark.parametrize("cfg", [(272, 400, 128, False, 10), (264, 392, 64, True, 10), (136, 200, 64, True, 8), (64, 64, 32, False, 10), (72, 104, 32, False, 12)])
 def test_alf_filtering(oracle, reflib, cfg):
     """filterBlk<7x7> / <5x5> table entries of the reference (scalar and x86 rows), driven CTU by CTU like reconstructCTU, against the restatement:
     every transpose index, clipping values, virtual-boundary rows, disabled CTUs, partial CTUs"""
@@ -575,6 +575,8 @@ def test_alf_filtering(oracle, reflib, cfg):
     _, rec = _alf_case(rng, h, w, smooth)
     if bd == 8:
         rec = (rec >> 2).astype(np.int16)
+    if bd == 12:
+        rec = ((rec.astype(np.int32) << 2) + rng.integers(0, 4, rec.shape)).astype(np.int16)
     cls = oracle.alf_classify(rec, bd, ctu, ctu - 4)
     nctu = -(-h // ctu) * -(-w // ctu)
     for nonlinear in (False, True):
