@@ -267,10 +267,9 @@ meWavefrontKernel( MeGeom g, const MeRefs R, int nbx, int mvsW, int* abortFlag )
 
 // ---- phase C -------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__( 256 )
-meFinalizeKernel( MeGeom g, const MeRefs R, int nbx, int nby, int bitDepth, int unitSize, int mvsW )
+meFinalizeKernel( MeGeom g, const MeRefs R, int nRefs, int nbx, int nby, int bitDepth, int unitSize, int mvsW )
 {
-  vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.y];
-  const int i = blockIdx.x * 4 + ( threadIdx.x >> 6 ), lane = threadIdx.x & 63;          // one wave per block
+  const int i = blockIdx.x * 4 + ( threadIdx.x >> 6 ), lane = threadIdx.x & 63;          // one wave per block; the block's variance serves every reference
   if( i >= nbx * nby ) return;
   const int byi = i / nbx, bxi = i - byi * nbx, bx = bxi * g.bs, by = byi * g.bs;
   const int w = min( g.bs, g.width - bx ) & ~7, h = min( g.bs, g.height - by ) & ~7;
@@ -284,8 +283,8 @@ meFinalizeKernel( MeGeom g, const MeRefs R, int nbx, int nby, int bitDepth, int 
   for( int k = lane; k < w * h; k += 64 ) { const int y = k / w, x = k - y * w; const int p = ( o[( ptrdiff_t ) y * g.orgStride + x] << 4 ) - avg; var += p * p; }
 #pragma unroll
   for( int d = 32; d >= 1; d >>= 1 ) var += __shfl_xor( var, d );
-  if( lane ) return;
-  vvhip_mv& m = mvs[byi * mvsW + bxi];
+  if( lane >= nRefs ) return;                                             // lane r finishes reference r
+  vvhip_mv& m = R.mvs[lane][byi * mvsW + bxi];
   const double bdScale = ( double ) ( 1 << ( 2 * ( 10 - bitDepth ) ) );   // MCTF.cpp:1314-1320
   const double dvar = ( ( double ) var / 256.0 ) * bdScale;
   const double mse  = m.error * bdScale / ( double ) ( w * h );
@@ -434,7 +433,7 @@ int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, i
   VVHIP_LAUNCH_CHECK( ctx );
   if( doubleRes )
   {
-    hipLaunchKernelGGL( meFinalizeKernel, dim3( ( nbx * nby + 3 ) / 4, nRefs ), dim3( 256 ), 0, ctx->stream, g, R, nbx, nby, bitDepth, unit, mvsW );
+    hipLaunchKernelGGL( meFinalizeKernel, dim3( ( nbx * nby + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, g, R, nRefs, nbx, nby, bitDepth, unit, mvsW );
     VVHIP_LAUNCH_CHECK( ctx );
   }
   return VVHIP_OK;
