@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Writes hook-enabled COPIES of six reference translation units into oracle/_ref/gen/src/ (build output, git-ignored).
-Nothing of the reference is stored in the repository: the script inserts one-line calls to g_vvhipHooks (oracle/ref/hip_hooks.h)
-at anchor lines it looks up in the files where they lie under /root/reference.  This is the executable form of the binding
-shown in INTEGRATION.md §2.
+"""The VVenC side of the binding as an executable patch (PRODUCT: what a VVenC maintainer applies; INTEGRATION.md section 2 walks through it).
 
-usage: apply_hip_hooks.py <reference source/Lib dir> <output dir>"""
+Writes hook-enabled COPIES of ten reference translation units into an output directory (build output, git-ignored): the script inserts one-line calls to
+g_vvhipHooks (bindings/vvenc/vvenc_hip_binding.h) at anchor lines it looks up in the files where they lie under the reference tree — nothing of the reference is
+stored in this repository.  With every hook null the patched encoder is the unpatched one (bitstream tests).  Run-time selection: --SIMD=HIP[:mask]
+(VVEncImpl::setSIMDExtension, source/Lib/vvenc/vvencimpl.cpp:800-851).
+
+usage: apply_binding.py <reference source/Lib dir> <output dir>"""
 import os
 import sys
 
@@ -25,7 +27,7 @@ def patch(name, edits, sub="CommonLib"):
     open(os.path.join(out, name), "w").write(s)
 
 
-INC = '\n#include "hip_hooks.h"\n'
+INC = '\n#include "vvenc_hip_binding.h"\n'
 patch("RdCost.cpp", [
     ("after", '#include "RdCost.h"', INC),
     ("before", "  m_costMode      = VVENC_COST_STANDARD_LOSSY;",
@@ -50,6 +52,13 @@ patch("MCTF.cpp", [
     ("before", "    Array2D<MotionVector> mv_0(width / (m_mctfUnitSize * 8) + 1, height / (m_mctfUnitSize * 8) + 1);",
      "    if( !( g_vvhipHooks.mctfMe && g_vvhipHooks.mctfMe( this, srcPic.picBuffer, origBuf, srcPic.mvs, addLevel, curPic->poc, m_filterPoc ) ) )\n    {\n"),
     ("after", "    motionEstimationLuma(srcPic.mvs, origBuf, srcPic.picBuffer, m_mctfUnitSize, &mv_2, 1, true);\n", "    }\n"),
+    ("replace", "    subsampleLuma( origBuf,         origSubsampled2 );\n    subsampleLuma( origSubsampled2, origSubsampled4 );\n    if (condAddLevel)\n    {\n      subsampleLuma(origSubsampled4, origSubsampled8);\n    }\n",
+     "    const bool hipMe = g_vvhipHooks.mctfMe && g_vvhipHooks.mctfWants && g_vvhipHooks.mctfWants( this, m_area.width, m_area.height );\n"
+     "    if( !hipMe )\n    {\n"
+     "    subsampleLuma( origBuf,         origSubsampled2 );\n    subsampleLuma( origSubsampled2, origSubsampled4 );\n    if (condAddLevel)\n    {\n      subsampleLuma(origSubsampled4, origSubsampled8);\n    }\n"
+     "    }\n"),
+    ("before", "    for ( int i = dropFramesFront; i < picFifo.size() - dropFramesBack; i++ )\n    {\n      Picture* curPic = picFifo[ i ];\n      if ( curPic->poc == m_filterPoc )",
+     "    if( hipMe && g_vvhipHooks.mctfPrefetch ) g_vvhipHooks.mctfPrefetch( this, &picFifo, dropFramesFront, dropFramesBack, origBuf, condAddLevel, m_filterPoc );\n"),
     ("before", "  const double lumaSigmaSq = m_sigmaMultiplier * ( 128.0 + 3.0 / 256.0 * m_encCfg->m_QP * m_encCfg->m_QP * m_encCfg->m_QP );",
      "  if( g_vvhipHooks.mctfApply && g_vvhipHooks.mctfApply( this, orgPic, &srcFrameInfo, newOrgPic, overallStrength ) ) return;\n"),
 ])
@@ -96,7 +105,6 @@ patch("InterSearch.cpp", [
     ("replace", "    m_cDistParam.cur.buf   = piRefPos;\n    uiDist = m_cDistParam.distFunc( m_cDistParam );\n",
      "    m_cDistParam.cur.buf   = piRefPos;\n    uiDist = hipOk ? hipCost[i] : m_cDistParam.distFunc( m_cDistParam );\n"),
 ], sub="EncoderLib")
-print("hooked copies written to", out)
 
 # ALF statistics of a CTU: classification + covariance records from ONE hook call; the reference's own accumulators are
 # filled from the returned records (they start at zero: one CTU per statistics unit).  Virtual-boundary CTUs and non-linear ALF stay on the CPU.
@@ -157,6 +165,7 @@ patch("EncAdaptiveLoopFilter.cpp", [
     ("before", "  const PreCalcValues& pcv = *cs.pcv;\n  const int xC = ( ctuRsAddr % pcv.widthInCtus ) << pcv.maxCUSizeLog2;",
      "  if( ( g_vvhipHooks.alfPicture && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) ) return;\n"),
     ("after", "  initCABACEstimator( cs.slice );\n\n  // Accumulate ALF statistic\n",
+     "  if( g_vvhipHooks.alfBeginPicture ) g_vvhipHooks.alfBeginPicture( this, cs.picture->poc );\n"
      "  if( ( g_vvhipHooks.alfPicture && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) && numCtus == ( int ) m_numCTUsInPic )\n"
      "  {\n"
      "    static thread_local std::vector<uint8_t> hCls; static thread_local std::vector<float> hSt[3];\n"
@@ -169,7 +178,7 @@ patch("EncAdaptiveLoopFilter.cpp", [
      "      hOrg[c] = hOrgYuv.get( ComponentID( c ) ).buf; hOs[c] = hOrgYuv.get( ComponentID( c ) ).stride;\n"
      "      hEn[c] = m_alfFilterStatEnabled[c]; hSt[c].resize( ( size_t ) m_numAsusInPic * ( c ? 1 : MAX_NUM_ALF_CLASSES ) * 183 ); hP[c] = hSt[c].data();\n"
      "    }\n"
-     "    const bool hOk = g_vvhipHooks.alfPicture( hRec, hRs, hOrg, hOs, m_picWidth, m_picHeight, m_inputBitDepth[CH_L], m_maxCUHeight, m_maxAsuHeight,\n"
+     "    const bool hOk = g_vvhipHooks.alfPicture( this, cs.picture->poc, hRec, hRs, hOrg, hOs, m_picWidth, m_picHeight, m_inputBitDepth[CH_L], m_maxCUHeight, m_maxAsuHeight,\n"
      "                                              m_alfVBLumaCTUHeight, m_alfVBLumaPos, m_alfVBChmaCTUHeight, m_alfVBChmaPos, hEn, hCls.data(), hP );\n"
      "    CHECK( !hOk, \"HIP ALF picture statistics failed\" );\n"
      "    const int hBw = m_picWidth / 4, hCtuBlk = ( MAX_CU_SIZE * MAX_CU_SIZE ) >> 4;\n"
@@ -283,3 +292,28 @@ patch("EncAdaptiveLoopFilter.cpp", [
      "    return;\n"
      "  }\n"),
 ], sub="EncoderLib")
+
+# one picture <-> one device: a worker thread that starts a CTU task of a picture binds itself to that picture's GPU (several GPUs only)
+patch("EncSlice.cpp", [
+    ("after", '#include "EncSlice.h"', INC),
+    ("after", "  CtuEncParam* ctuEncParam       = static_cast<CtuEncParam*>( taskParam );\n  Picture* pic                   = ctuEncParam->pic;\n",
+     "  if( !checkReadyState && g_vvhipHooks.bindPicture ) g_vvhipHooks.bindPicture( pic->poc );\n"),
+], sub="EncoderLib")
+
+# run-time selection through the reference's own switch: --SIMD=HIP[:mask] / vvenc_set_SIMD_extension( "HIP" ) installs the binding, the CPU levels below it stay at their best
+patch("vvencimpl.cpp", [
+    ("after", '#include "vvencimpl.h"', INC),
+    ("replace", "  const std::string simdReqStr( simdId ? simdId : \"\" );\n",
+     "  std::string hipReq( simdId ? simdId : \"\" );\n"
+     "  bool hipSelected = false;\n"
+     "  if( hipReq.compare( 0, 3, \"HIP\" ) == 0 )\n"
+     "  {\n"
+     "    if( vvenc_hip_select( hipReq.c_str() ) != 0 ) { MsgLog msg; msg.log( VVENC_ERROR, \"\\nrequested SIMD level (%s) not available: no MI355X context\\n\", hipReq.c_str() ); return nullptr; }\n"
+     "    hipSelected = true; hipReq.clear();\n"
+     "  }\n"
+     "  const std::string simdReqStr( hipReq );\n"),
+    ("replace", "    return read_x86_extension_name().c_str();\n# endif   // !TARGET_SIMD_ARM",
+     "    if( hipSelected ) { static std::string hipName; hipName = \"HIP+\" + read_x86_extension_name(); return hipName.c_str(); }\n"
+     "    return read_x86_extension_name().c_str();\n# endif   // !TARGET_SIMD_ARM"),
+], sub="vvenc")
+print("binding applied to", out)

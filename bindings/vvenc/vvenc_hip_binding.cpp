@@ -48,10 +48,11 @@
 #undef private
 #undef protected
 
-#include "hip_hooks.h"
+#include "vvenc_hip_binding.h"
 #include "../../vvenc_amd/csrc/host/vvenc_hip_shim.h"
+#include "EncoderLib/EncStage.h"
 
-VvhipHooks g_vvhipHooks = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+VvhipHooks g_vvhipHooks = {};
 
 namespace {
 
@@ -59,6 +60,7 @@ vvhip::RdCost*   g_rd = nullptr;
 vvhip::QuantOps* g_q  = nullptr;
 vvhip::MCTFOps*  g_m  = nullptr;
 std::atomic<uint64_t> g_calls[10];    // dist, x5, fwd, inv, quant, dequant, needrdoq, mctf, interpolation, whole-picture MCTF filter
+std::atomic<uint64_t> g_lfnstQuantFallbacks{ 0 }, g_mctfDeviceCalls{ 0 };
 
 vvhip::DistParam conv( const vvenc::DistParam& dp )
 {
@@ -101,10 +103,20 @@ void initRdCost( vvenc::RdCost* rc )
   rc->m_fxdWtdPredPtr = fxdWtdTramp;
 }
 
+// the CPU entries this binding replaced (the same functions for every Quant object): LFNST TUs keep going there — QuantCore then looks at the first coefficient
+// group only (iCGNum = 1, Quant.cpp:152-159), which the device core (lfnstIdx == 0 by contract, include/vvenc_hip.h) does not reproduce
+decltype( vvenc::Quant::xQuant ) g_cpuQuant = nullptr;
+
 void xQuantTramp( const vvenc::TransformUnit tu, const vvenc::ComponentID compID, const vvenc::CCoeffBuf& piCoef, vvenc::CoeffSigBuf piQCoef, vvenc::TCoeff& uiAbsSum,
                   int& lastScanPos, vvenc::TCoeff* deltaU, const int defaultQuantisationCoefficient, const int iQBits, const int64_t iAdd,
                   const vvenc::TCoeff entropyCodingMinimum, const vvenc::TCoeff entropyCodingMaximum, const bool signHiding, const vvenc::TCoeff m_thrVal )
 {
+  if( tu.cu->lfnstIdx && g_cpuQuant )
+  {
+    g_lfnstQuantFallbacks++;
+    g_cpuQuant( tu, compID, piCoef, piQCoef, uiAbsSum, lastScanPos, deltaU, defaultQuantisationCoefficient, iQBits, iAdd, entropyCodingMinimum, entropyCodingMaximum, signHiding, m_thrVal );
+    return;
+  }
   g_calls[4]++;
   const unsigned w = tu.blocks[compID].width, h = tu.blocks[compID].height;
   std::vector<vvenc::TCoeffSig> lev( ( size_t ) w * h );
@@ -123,6 +135,7 @@ bool xNeedRdoqTramp( const vvenc::TCoeff* c, size_t n, int qc, int64_t off, int 
 
 void initQuant( vvenc::Quant* q )
 {
+  if( q->xQuant != xQuantTramp ) g_cpuQuant = q->xQuant;
   q->xQuant = xQuantTramp;
   q->xDeQuant = xDeQuantTramp;
   q->xNeedRdoq = xNeedRdoqTramp;
@@ -156,43 +169,76 @@ bool inv2D( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned w, un
   return true;
 }
 
-// ---- resident original pictures: MCTF reads every original picture many times (as the current picture once, as a neighbour of up to
-// 2*range filtered pictures, luma for the search and all planes for the filter).  The hooks keep the planes mirrored on the device, keyed by
-// the host buffer AND the picture order count (buffers are recycled for later pictures), least-recently-used eviction.
-struct ResidentPic { const vvenc::Pel* key; int poc; int ids[3]; int nComp; uint64_t stamp; };
+// ---- several GPUs: one picture <-> one device.  $VVHIP_GPUS = number of devices this encoder spreads its pictures over ("all": every visible device;
+// default 1 = the default device only).  MCTF-filtered pictures are independent of each other (originals only, MCTF.cpp:666-724): filtered picture k goes to device
+// k mod N; the CTU tasks and in-loop stages of a picture run on device poc mod N (bindPicture / the whole-picture ALF hooks).  Pictures a device needs that already
+// sit in another device's HBM are copied device-to-device (hipMemcpyPeerAsync over xGMI) instead of crossing PCIe again.
+int numGpus()
+{
+  static const int n = []{
+    const char* e = getenv( "VVHIP_GPUS" );
+    const int have = vvhip::Device::gpuCount();
+    int want = !e ? 1 : ( !strcmp( e, "all" ) ? have : atoi( e ) );
+    if( want < 1 ) want = 1;
+    return want > have ? ( have > 0 ? have : 1 ) : want; }();
+  return n;
+}
+int gpuOfFilteredPicture( int filterPoc ) { static std::atomic<int> next{ 0 }; static std::mutex m; static std::map<int, int> of;
+  std::lock_guard<std::mutex> g( m ); auto it = of.find( filterPoc ); if( it != of.end() ) return it->second;
+  const int gpu = ( vvhip::Device::defaultGpu() + next++ ) % numGpus(); if( of.size() > 64 ) of.erase( of.begin() ); of[filterPoc] = gpu; return gpu; }
+int gpuOfPicture( int poc ) { return ( vvhip::Device::defaultGpu() + ( poc < 0 ? 0 : poc ) ) % numGpus(); }
+struct GpuScope      // binds the calling thread to a device for one hook call
+{
+  explicit GpuScope( int gpu ) { if( numGpus() > 1 ) { vvhip::Device::selectGpu( gpu ); on = true; } }
+  ~GpuScope() { if( on ) vvhip::Device::selectGpu( -1 ); }
+  bool on = false;
+};
+void bindPicture( int poc ) { if( numGpus() > 1 ) vvhip::Device::selectGpu( gpuOfPicture( poc ) ); }
+
+// ---- resident original pictures: MCTF reads every original picture many times (as the current picture once, as a neighbour of up to 2*range filtered pictures,
+// luma for the search and all planes for the filter).  The binding keeps the planes mirrored in HBM — keyed by host buffer, picture order count (buffers are recycled
+// for later pictures) AND device — with least-recently-used eviction; the host planes are pinned in place once (recycled buffers), so an upload is one DMA.
+struct ResidentPic { const vvenc::Pel* key; int poc; int gpu; int ids[3]; int nComp; uint64_t stamp; };
 std::vector<ResidentPic> g_resident;
-uint64_t g_residentStamp = 0, g_residentUploads = 0, g_residentHits = 0;
+std::mutex g_mctfLock;                                      // the MCTF stage runs on one thread; the lock makes the hooks safe for parallel-GOP set-ups too
+uint64_t g_residentStamp = 0;
+std::atomic<uint64_t> g_residentUploads{ 0 }, g_residentHits{ 0 }, g_residentPeerCopies{ 0 };
 
 void dropResident( size_t i )
 {
+  GpuScope sc( g_resident[i].gpu );
   vvhip::Device& dev = vvhip::Device::get();
   for( int c = 0; c < g_resident[i].nComp; c++ ) dev.unregisterPicture( g_resident[i].ids[c] );
   g_resident.erase( g_resident.begin() + i );
 }
 
-// mirror ids of the picture's first nComp planes; poc < 0: match the most recent entry of this host buffer (the search of the same filter call
-// validated it), uploading (uncached identity) when there is none
+// mirror ids of the picture's first nComp planes ON THE CALLING THREAD'S GPU; poc < 0: match the most recent entry of this host buffer (the search of the same
+// filter call validated it), uploading (uncached identity) when there is none
 ResidentPic& residentPlanes( const vvenc::PelStorage& ps, int poc, int nComp )
 {
   vvhip::Device& dev = vvhip::Device::get();
+  const int gpu = dev.gpu();
   const vvenc::Pel* key = ps.bufs[0].buf;
-  int found = -1;
+  int found = -1, other = -1;
   for( size_t i = 0; i < g_resident.size(); )
   {
     ResidentPic& e = g_resident[i];
     if( e.key == key && poc >= 0 && e.poc != poc ) { dropResident( i ); continue; }            // the host buffer now holds another picture
-    if( e.key == key && ( found < 0 || e.stamp > g_resident[found].stamp ) ) found = ( int ) i;
+    if( e.key == key && e.gpu == gpu && ( found < 0 || e.stamp > g_resident[found].stamp ) ) found = ( int ) i;
+    if( e.key == key && e.gpu != gpu && ( other < 0 || e.nComp > g_resident[other].nComp ) ) other = ( int ) i;
     i++;
   }
   if( found < 0 )
   {
-    if( g_resident.size() >= 16 )
+    const size_t cap = 16 * ( size_t ) numGpus();
+    if( g_resident.size() >= cap )
     {
       size_t lru = 0;
       for( size_t i = 1; i < g_resident.size(); i++ ) if( g_resident[i].stamp < g_resident[lru].stamp ) lru = i;
+      if( ( int ) lru < other ) other--; else if( ( int ) lru == other ) other = -1;
       dropResident( lru );
     }
-    ResidentPic e; e.key = key; e.poc = poc; e.nComp = 0; e.ids[0] = e.ids[1] = e.ids[2] = -1; e.stamp = 0;
+    ResidentPic e; e.key = key; e.poc = poc; e.gpu = gpu; e.nComp = 0; e.ids[0] = e.ids[1] = e.ids[2] = -1; e.stamp = 0;
     g_resident.push_back( e );
     found = ( int ) g_resident.size() - 1;
   }
@@ -201,12 +247,94 @@ ResidentPic& residentPlanes( const vvenc::PelStorage& ps, int poc, int nComp )
   for( int c = e.nComp; c < nComp; c++ )
   {
     const vvenc::CPelBuf b = ps.bufs[c];
-    e.ids[c] = dev.registerPicture( b.buf, ( int ) b.stride, b.width, b.height, vvenc::MCTF_PADDING >> ( c ? 1 : 0 ), false );      // id use only: never aliased by the per-call entries
-    g_residentUploads++;
+    const int margin = vvenc::MCTF_PADDING >> ( c ? 1 : 0 );
+    if( other >= 0 && g_resident[other].nComp > c )
+    {
+      // the plane already sits in another GPU's HBM: device-to-device over xGMI
+      const ResidentPic& o = g_resident[other];
+      vvhip::Device::selectGpu( o.gpu ); vvhip::Device& src = vvhip::Device::get();
+      vvhip::Device::selectGpu( gpu );
+      e.ids[c] = src.copyMirrorTo( o.ids[c], dev );
+      g_residentPeerCopies++;
+    }
+    else
+    {
+      vvhip::Device::pinHost( b.buf - ( ptrdiff_t ) margin * b.stride - margin, ( size_t ) b.stride * ( b.height + 2 * margin ) * sizeof( vvenc::Pel ) );
+      e.ids[c] = dev.registerPicture( b.buf, ( int ) b.stride, b.width, b.height, margin, false );      // id use only: never aliased by the per-call entries
+      g_residentUploads++;
+    }
   }
   if( nComp > e.nComp ) e.nComp = nComp;
   e.stamp = ++g_residentStamp;
   return e;
+}
+
+// ---- whole hierarchical ME of MCTF::motionEstimationMCTF on the GPU; pictures carry MCTF_PADDING extended margins (MCTF.cpp:608-612).
+// mctfPrefetch: the references of the first loop of MCTF::filter are known before the loop starts -> ONE device call scores them all (their pyramid levels and
+// search stages share launches, vvhip_mctf_motion_estimation); mctfMe then hands each field over, or computes a single reference (the adaptive extra ones).
+bool mctfWants( const vvenc::MCTF* m, int width, int height ) { return width >= 64 && height >= 64 && ( m->m_mctfUnitSize == 8 || m->m_mctfUnitSize == 16 ); }
+
+struct MeCache { int curPoc = -1; std::map<int, std::vector<vvhip_mv>> fields; } g_meCache;
+
+void motionFieldsOnDevice( vvenc::MCTF* m, const vvenc::PelStorage& orig, int curPoc, const std::vector<const vvenc::PelStorage*>& refs, const std::vector<int>& refPocs, bool addLevel )
+{
+  const int nRefs = ( int ) refs.size();
+  if( !nRefs ) return;
+  const int unit = m->m_mctfUnitSize;
+  const vvenc::CPelBuf o = orig.Y();
+  const size_t count = ( size_t ) ( ( o.width + unit - 1 ) / unit ) * ( ( o.height + unit - 1 ) / unit );
+  const int idO = residentPlanes( orig, curPoc, 1 ).ids[0];
+  std::vector<int> idR( nRefs );
+  for( int r = 0; r < nRefs; r++ )
+  {
+    if( refs[r]->Y().stride != o.stride ) throw vvhip::Exception( "HIP MCTF: original pictures with different strides" );
+    idR[r] = residentPlanes( *refs[r], refPocs[r], 1 ).ids[0];
+  }
+  std::vector<vvhip_mv*> outs( nRefs );
+  for( int r = 0; r < nRefs; r++ ) { std::vector<vvhip_mv>& f = g_meCache.fields[refPocs[r]]; f.resize( count ); outs[r] = f.data(); }
+  g_m->motionEstimation( idO, idR.data(), nRefs, m->m_encCfg->m_internalBitDepth[0], unit, m->m_encCfg->m_vvencMCTF.MCTFSpeed, addLevel, outs.data() );
+  g_mctfDeviceCalls++;
+}
+
+void mctfPrefetch( vvenc::MCTF* m, const void* picFifoDeque, int dropFront, int dropBack, const vvenc::PelStorage& orig, bool addLevel, int filterPoc )
+{
+  std::lock_guard<std::mutex> g( g_mctfLock );
+  GpuScope sc( gpuOfFilteredPicture( filterPoc ) );
+  const std::deque<vvenc::Picture*>& fifo = *static_cast<const std::deque<vvenc::Picture*>*>( picFifoDeque );
+  g_meCache.curPoc = filterPoc; g_meCache.fields.clear();
+  std::vector<const vvenc::PelStorage*> refs; std::vector<int> pocs; std::vector<vvenc::PelStorage> keep;
+  keep.reserve( fifo.size() );
+  for( int i = dropFront; i < ( int ) fifo.size() - dropBack; i++ )
+  {
+    if( fifo[i]->poc == filterPoc ) continue;
+    keep.emplace_back(); keep.back().createFromBuf( fifo[i]->getOrigBuf() );
+    pocs.push_back( fifo[i]->poc );
+  }
+  for( auto& k : keep ) refs.push_back( &k );
+  motionFieldsOnDevice( m, orig, filterPoc, refs, pocs, addLevel );
+}
+
+bool mctfMe( vvenc::MCTF* m, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel, int refPoc, int curPoc )
+{
+  if( !mctfWants( m, orig.Y().width, orig.Y().height ) ) return false;       // below the device entry point's minimum: the table-entry path
+  std::lock_guard<std::mutex> g( g_mctfLock );
+  GpuScope sc( gpuOfFilteredPicture( curPoc ) );
+  if( g_meCache.curPoc != curPoc ) { g_meCache.curPoc = curPoc; g_meCache.fields.clear(); }
+  auto it = g_meCache.fields.find( refPoc );
+  if( it == g_meCache.fields.end() )
+  {
+    motionFieldsOnDevice( m, orig, curPoc, { &refPic }, { refPoc }, addLevel );
+    it = g_meCache.fields.find( refPoc );
+  }
+  const std::vector<vvhip_mv>& out = it->second;
+  if( out.size() != ( size_t ) mvs.w() * mvs.h() ) throw vvhip::Exception( "HIP MCTF: motion field size" );
+  for( int y = 0; y < mvs.h(); y++ ) for( int x = 0; x < mvs.w(); x++ )
+  {
+    vvenc::MotionVector& d = mvs.get( x, y ); const vvhip_mv& s = out[( size_t ) y * mvs.w() + x];
+    d.x = s.x; d.y = s.y; d.error = s.error; d.rmsme = ( uint16_t ) s.rmsme; d.overlap = s.overlap;
+  }
+  g_calls[7] += 1000000;      // marks "whole-picture ME ran on the device"
+  return true;
 }
 
 // whole MCTF::bilateralFilter (MCTF.cpp:1489-1552) on the GPU: every plane of the original and of the references is mirrored, the motion fields
@@ -217,9 +345,10 @@ bool mctfApply( const vvenc::MCTF* m, const vvenc::PelStorage& orgPic, void* inf
   const int nRefs = ( int ) info.size(), unit = m->m_mctfUnitSize;
   const int numComp = ( int ) vvenc::getNumberValidComponents( m->m_encCfg->m_internChromaFormat );
   if( nRefs < 1 || nRefs > 12 || ( unit != 8 && unit != 16 ) || ( numComp == 3 && m->m_encCfg->m_internChromaFormat != CHROMA_420 ) ) return false;
-  vvhip::Device& dev = vvhip::Device::get();
+  std::lock_guard<std::mutex> g( g_mctfLock );
+  GpuScope sc( gpuOfFilteredPicture( m->m_filterPoc ) );
   std::vector<int> orgIds( 3, -1 ), refIds( 3 * nRefs, -1 );
-  const bool searchOnDevice = g_vvhipHooks.mctfMe != nullptr;        // then the pictures of this filter call are already resident (and validated by POC)
+  const bool searchOnDevice = g_vvhipHooks.mctfMe != nullptr && mctfWants( m, orgPic.Y().width, orgPic.Y().height );   // then the pictures of this filter call are already resident (and validated by POC)
   if( !searchOnDevice ) while( !g_resident.empty() ) dropResident( 0 );
   { const ResidentPic& e = residentPlanes( orgPic, -1, numComp ); for( int c = 0; c < numComp; c++ ) orgIds[c] = e.ids[c]; }
   for( int r = 0; r < nRefs; r++ ) { const ResidentPic& e = residentPlanes( info[r].picBuffer, -1, numComp ); for( int c = 0; c < numComp; c++ ) refIds[3 * r + c] = e.ids[c]; }
@@ -354,26 +483,6 @@ void initIF( vvenc::InterpolationFilter* f )
   f->m_filter16xH[0][0] = ifFusedT<2, 0, 0>; f->m_filter16xH[0][1] = ifFusedT<2, 0, 1>; f->m_filter16xH[1][0] = ifFusedT<2, 1, 0>; f->m_filter16xH[1][1] = ifFusedT<2, 1, 1>;
 }
 
-// whole hierarchical ME of MCTF::motionEstimationMCTF on the GPU; both pictures carry MCTF_PADDING extended margins (MCTF.cpp:608-612)
-bool mctfMe( vvenc::MCTF* m, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel, int refPoc, int curPoc )
-{
-  const vvenc::CPelBuf o = orig.Y(), r = refPic.Y();
-  const int w = o.width, h = o.height, unit = m->m_mctfUnitSize;
-  if( w < 64 || h < 64 || o.stride != r.stride ) return false;       // below the device entry point's minimum: keep the table-entry path
-  const int idO = residentPlanes( orig, curPoc, 1 ).ids[0];
-  const int idR = residentPlanes( refPic, refPoc, 1 ).ids[0];
-  std::vector<vvhip_mv> out( ( size_t ) mvs.w() * mvs.h() );
-  vvhip_mv* outs[1] = { out.data() };
-  g_m->motionEstimation( idO, &idR, 1, m->m_encCfg->m_internalBitDepth[0], unit, m->m_encCfg->m_vvencMCTF.MCTFSpeed, addLevel, outs );
-  for( int y = 0; y < mvs.h(); y++ ) for( int x = 0; x < mvs.w(); x++ )
-  {
-    vvenc::MotionVector& d = mvs.get( x, y ); const vvhip_mv& s = out[( size_t ) y * mvs.w() + x];
-    d.x = s.x; d.y = s.y; d.error = s.error; d.rmsme = ( uint16_t ) s.rmsme; d.overlap = s.overlap;
-  }
-  g_calls[7] += 1000000;      // marks "whole-picture ME ran on the device"
-  return true;
-}
-
 } // namespace
 
 static int g_slotMask = 0;
@@ -412,12 +521,35 @@ bool alfCtu( const int16_t* const rec[3], const int recStride[3], const int16_t*
   return true;
 }
 
+// ---- whole-picture ALF stages: one vvhip::ALFOps per EncAdaptiveLoopFilter object (it keeps the unfiltered planes and the classes of its current picture in HBM
+// between the statistics call and the filtering call), on the picture's GPU
+std::mutex g_alfPicLock;
+struct AlfPictureState { std::unique_ptr<vvhip::ALFOps> ops; int donePoc = -1; bool done = false; std::mutex busy; };
+std::map<const void*, std::unique_ptr<AlfPictureState>> g_alfState;
+AlfPictureState& alfState( const void* owner )
+{
+  std::lock_guard<std::mutex> g( g_alfPicLock );
+  std::unique_ptr<AlfPictureState>& st = g_alfState[owner];
+  if( !st ) { st.reset( new AlfPictureState ); st->ops.reset( new vvhip::ALFOps ); }
+  return *st;
+}
+
+// EncAdaptiveLoopFilter::deriveFilter starts on a picture: whatever this ALF object filtered before is history (same POC in a later pass / encode included)
+void alfBeginPicture( const void* owner, int /*poc*/ )
+{
+  AlfPictureState& st = alfState( owner );
+  std::lock_guard<std::mutex> g( st.busy );
+  st.done = false; st.donePoc = -1;
+}
+
 std::atomic<uint64_t> g_alfPictures{ 0 };
-bool alfPicture( const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int bitDepth,
+bool alfPicture( const void* owner, int poc, const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int bitDepth,
                  int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] )
 {
-  static vvhip::ALFOps alf;
-  if( !alf.pictureStatistics( rec, recStride, org, orgStride, width, height, bitDepth, ctuSize, unitSize, vbLumaH, vbLumaPos, vbChromaH, vbChromaPos, enabled, cls, stats ) ) return false;
+  AlfPictureState& st = alfState( owner );
+  std::lock_guard<std::mutex> g( st.busy );
+  GpuScope sc( gpuOfPicture( poc ) );
+  if( !st.ops->pictureStatistics( rec, recStride, org, orgStride, width, height, bitDepth, ctuSize, unitSize, vbLumaH, vbLumaPos, vbChromaH, vbChromaPos, enabled, cls, stats ) ) return false;
   g_alfPictures++;
   return true;
 }
@@ -460,39 +592,47 @@ bool ccAlfFilterBlk( int16_t* dstC, int dstStride, const int16_t* recLuma, int r
 }
 
 std::atomic<uint64_t> g_alfFilterPictures{ 0 };
-std::mutex g_alfPicLock;
-std::map<const void*, int> g_alfPicDone;                                          // EncAdaptiveLoopFilter object -> poc of the picture it has filtered last
 bool alfFilterPicture( const void* owner, int poc, const int16_t* const src[3], const int srcStride[3], int16_t* const dst[3], const int dstStride[3], int width, int height, int bitDepth,
                        int ctuSize, const uint8_t* cls, const short* lumaCoeff, const short* lumaClip, int numLumaSets, const short* lumaCtuSet, const short* chromaCoeff,
                        const short* chromaClip, int numChromaSets, const short* const chromaCtuSet[2], int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, bool alreadyDoneOnly )
 {
-  static vvhip::ALFOps alf;
-  std::lock_guard<std::mutex> g( g_alfPicLock );                                  // later CTU tasks of the picture wait here until the first one has finished it
-  auto it = g_alfPicDone.find( owner );
-  if( it != g_alfPicDone.end() && it->second == poc ) return true;
+  AlfPictureState& st = alfState( owner );
+  std::lock_guard<std::mutex> g( st.busy );                                       // later CTU tasks of the picture wait here until the first one has finished it
+  if( st.done && st.donePoc == poc ) return true;                                 // (reset by alfBeginPicture when deriveFilter starts on the next picture)
   if( alreadyDoneOnly ) return false;
-  if( !alf.filterPicture( src, srcStride, dst, dstStride, width, height, bitDepth, ctuSize, cls, lumaCoeff, lumaClip, numLumaSets, lumaCtuSet, chromaCoeff, chromaClip, numChromaSets,
-                          chromaCtuSet, vbLumaH, vbLumaPos, vbChromaH, vbChromaPos ) ) return false;
-  g_alfPicDone[owner] = poc;
+  GpuScope sc( gpuOfPicture( poc ) );
+  if( !st.ops->filterPicture( src, srcStride, dst, dstStride, width, height, bitDepth, ctuSize, cls, lumaCoeff, lumaClip, numLumaSets, lumaCtuSet, chromaCoeff, chromaClip, numChromaSets,
+                              chromaCtuSet, vbLumaH, vbLumaPos, vbChromaH, vbChromaPos ) ) return false;
+  st.done = true; st.donePoc = poc;
   g_alfFilterPictures++;
   return true;
 }
 
-extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask )
+// ---- installation.  Hook mask (also the argument of --SIMD=HIP:<mask>):
+//   1 RdCost tables   2 fused 2-D transforms (TrQuant::xT / xIT)   4 Quant cores   8 MCTF table entries   16 MCTF whole-picture motion estimation   32 g_tCoeffOps slots
+//   64 InterpolationFilter tables   128 MCTF bilateral filter   256 batched sub-pel refinement stages   512 DMVR refinement search per CU   1024 TZ diamond rounds
+//   2048 ALF statistics per CTU   4096 CC-ALF statistics per CTU   8192 ALF statistics per picture   16384 ALF filtering per CTU block   32768 CC-ALF filtering per CTU block
+//   65536 ALF filtering per picture
+// VVENC_HIP_PRODUCTION: the stages that take whole pictures off the host (what --SIMD=HIP selects).
+static const int VVENC_HIP_PRODUCTION = 16 + 128 + 8192 + 65536;
+
+extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_install( int mask )
 {
-  // mask bit0 RdCost, bit1 fused 2-D transforms, bit2 Quant, bit3 MCTF table entries, bit4 MCTF whole-picture ME, bit5 g_tCoeffOps slots, bit6 InterpolationFilter tables, bit7 MCTF bilateral filter, bit8 batched sub-pel refinement stages (InterSearch), bit9 DMVR refinement search per CU, bit10 integer TZ diamond rounds (one call per round), bit11 ALF statistics per CTU (classification + covariance records), bit12 CC-ALF statistics per CTU and chroma component, bit13 ALF statistics of a whole picture in one call (the per-CTU statistics tasks become no-ops), bit14 ALF filtering per CTU block (7x7 / 5x5 table entries), bit15 CC-ALF filtering per CTU block, bit16 ALF filtering of a whole picture in one shim call (issued by the first reconstruction task of the picture)
   g_slotMask = mask;
   try
   {
     if( mask && !g_rd ) { g_rd = new vvhip::RdCost; g_rd->create( true ); g_q = new vvhip::QuantOps; g_m = new vvhip::MCTFOps; g_if = new vvhip::InterpolationFilter; }
   }
-  catch( const std::exception& e ) { fprintf( stderr, "vvref_install_hip_hooks: %s\n", e.what() ); return -1; }
+  catch( const std::exception& e ) { fprintf( stderr, "vvenc_hip_install: %s\n", e.what() ); return -1; }
   g_vvhipHooks.initRdCost = ( mask & 1 ) ? initRdCost : nullptr;
   g_vvhipHooks.fwd2D      = ( mask & 2 ) ? fwd2D : nullptr;
   g_vvhipHooks.inv2D      = ( mask & 2 ) ? inv2D : nullptr;
   g_vvhipHooks.initQuant  = ( mask & 4 ) ? initQuant : nullptr;
   g_vvhipHooks.initMCTF   = ( mask & 8 ) ? initMCTF : nullptr;
   g_vvhipHooks.mctfMe     = ( mask & 16 ) ? mctfMe : nullptr;
+  g_vvhipHooks.mctfWants  = ( mask & 16 ) ? mctfWants : nullptr;
+  g_vvhipHooks.mctfPrefetch = ( mask & 16 ) ? mctfPrefetch : nullptr;
+  g_vvhipHooks.bindPicture = mask ? bindPicture : nullptr;
   g_vvhipHooks.initIF     = ( mask & 64 ) ? initIF : nullptr;
   g_vvhipHooks.mctfApply  = ( mask & 128 ) ? mctfApply : nullptr;
   g_vvhipHooks.patternCosts = ( mask & 256 ) ? patternCosts : nullptr;
@@ -500,21 +640,37 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_ho
   g_vvhipHooks.alfCtu = ( mask & 2048 ) ? alfCtu : nullptr; g_alfCtus = 0;
   g_vvhipHooks.ccAlfCtu = ( mask & 4096 ) ? ccAlfCtu : nullptr; g_ccAlfCtus = 0;
   g_vvhipHooks.alfPicture = ( mask & 8192 ) ? alfPicture : nullptr; g_alfPictures = 0;
+  g_vvhipHooks.alfBeginPicture = ( mask & ( 8192 | 65536 ) ) ? alfBeginPicture : nullptr;
   g_vvhipHooks.alfFilterBlk = ( mask & 16384 ) ? alfFilterBlk : nullptr; g_alfFilterBlks = 0;
   g_vvhipHooks.ccAlfFilterBlk = ( mask & 32768 ) ? ccAlfFilterBlk : nullptr; g_ccAlfFilterBlks = 0;
-  g_vvhipHooks.alfFilterPicture = ( mask & 65536 ) ? alfFilterPicture : nullptr; g_alfFilterPictures = 0; g_alfPicDone.clear();
+  g_vvhipHooks.alfFilterPicture = ( mask & 65536 ) ? alfFilterPicture : nullptr; g_alfFilterPictures = 0;
+  { std::lock_guard<std::mutex> g( g_alfPicLock ); for( auto& kv : g_alfState ) { kv.second->done = false; kv.second->donePoc = -1; kv.second->ops->dropResident(); } }
   g_vvhipHooks.tzReset = ( mask & 1024 ) ? tzReset : nullptr; g_vvhipHooks.tzPrefetch = ( mask & 1024 ) ? tzPrefetch : nullptr; g_vvhipHooks.tzLookup = ( mask & 1024 ) ? tzLookup : nullptr;
   g_tzRounds = 0; g_tzHits = 0;
   g_dmvrCalls = 0;
   g_patternCalls = 0;
+  g_lfnstQuantFallbacks = 0; g_mctfDeviceCalls = 0;
   for( auto& c : g_calls ) c = 0;
   return 0;
+}
+extern "C" __attribute__( ( visibility( "default" ) ) ) int vvref_install_hip_hooks( int mask ) { return vvenc_hip_install( mask ); }      // (name the tests grew up with)
+
+extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_select( const char* spec )
+{
+  if( !spec || strncmp( spec, "HIP", 3 ) != 0 ) return -1;
+  int mask = VVENC_HIP_PRODUCTION;
+  if( spec[3] == ':' ) mask = ( int ) strtol( spec + 4, nullptr, 0 );
+  else if( spec[3] != 0 ) return -1;
+  return vvenc_hip_install( mask );
 }
 
 extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_calls( uint64_t* out8 )
 {
   for( int i = 0; i < 8; i++ ) out8[i] = g_calls[i];
 }
+// counters: 0-9 table-entry classes (8 interpolation, 9 MCTF filter pictures), 10 sub-pel stages, 11 DMVR searches, 12 TZ rounds, 13 TZ hits, 14 ALF CTUs, 15 CC-ALF CTUs,
+// 16 ALF statistics pictures, 17 ALF filter blocks, 18 CC-ALF filter blocks, 19 ALF filter pictures, 20 LFNST TUs left to the CPU quantiser, 21 MCTF device ME calls,
+// 22 original-picture uploads, 23 resident hits, 24 device-to-device picture copies, 25 PCIe bytes up, 26 PCIe bytes down, 27 worker contexts, 28 GPUs in use
 extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_calls_ex( uint64_t* out, int n )
 {
   for( int i = 0; i < n && i < 10; i++ ) out[i] = g_calls[i];
@@ -528,4 +684,14 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
   if( n > 17 ) out[17] = g_alfFilterBlks;
   if( n > 18 ) out[18] = g_ccAlfFilterBlks;
   if( n > 19 ) out[19] = g_alfFilterPictures;
+  if( n > 20 ) out[20] = g_lfnstQuantFallbacks;
+  if( n > 21 ) out[21] = g_mctfDeviceCalls;
+  if( n > 22 ) out[22] = g_residentUploads;
+  if( n > 23 ) out[23] = g_residentHits;
+  if( n > 24 ) out[24] = g_residentPeerCopies;
+  if( n > 28 )
+  {
+    const vvhip::Device::Stats st = vvhip::Device::stats();
+    out[25] = st.uploadBytes; out[26] = st.downloadBytes; out[27] = st.contexts; out[28] = ( uint64_t ) numGpus();
+  }
 }

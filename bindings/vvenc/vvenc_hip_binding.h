@@ -1,7 +1,8 @@
-// hip_hooks.h — the (tiny) hook surface the build-time patched copies of four reference files call (oracle/ref/apply_hip_hooks.py).
-// TEST INFRASTRUCTURE: lets tests run the *real reference encoder* with its kernel tables pointed at the HIP back-end and compare
-// the bitstream byte-for-byte with the CPU run (the reference's own invariant, cmake/modules/vvencTests.cmake:52-53).
-// All hooks are null by default: the patched library then behaves exactly like the unpatched one.
+// vvenc_hip_binding.h — the hook surface of the VVenC <-> MI355X binding (PRODUCT: what a VVenC maintainer adds to the encoder).
+// bindings/vvenc/apply_binding.py inserts one-line calls to g_vvhipHooks into ten reference translation units (the copies are made at build time, nothing of the
+// reference is stored here); vvenc_hip_binding.cpp points the hooks at the table-shaped shim (vvenc_amd/csrc/host/vvenc_hip_shim.h) above the C ABI.
+// Selection at run time goes through the reference's own switch: --SIMD=HIP[:mask] / vvenc_set_SIMD_extension("HIP[:mask]") (vvencimpl.cpp:800-851).
+// All hooks are null by default: the patched library then behaves exactly like the unpatched one (its bitstreams are the CPU encoder's, tests/test_e2e_bitstream.py).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -17,6 +18,14 @@ struct VvhipHooks
   void ( *initRdCost )( vvenc::RdCost* );
   void ( *initQuant )( vvenc::Quant* );
   void ( *initMCTF )( vvenc::MCTF* );
+  // whole-picture MCTF search on the device: mctfWants answers up front (the CPU pyramid of the original is then skipped), mctfPrefetch scores ALL references of the
+  // first loop of MCTF::filter (MCTF.cpp:788-796) in ONE device call, mctfMe hands the field of one reference to motionEstimationMCTF (from that call, or computed now)
+  bool ( *mctfWants )( const vvenc::MCTF* m, int width, int height );
+  void ( *mctfPrefetch )( vvenc::MCTF* m, const void* picFifoDeque, int dropFront, int dropBack, const vvenc::PelStorage& orig, bool addLevel, int filterPoc );
+  // the worker thread starts a CTU task of the picture with this POC: binds the thread to the picture's GPU (one picture <-> one device)
+  void ( *bindPicture )( int poc );
+  // EncAdaptiveLoopFilter::deriveFilter starts on a new picture (resets the whole-picture filtering bookkeeping of this ALF object)
+  void ( *alfBeginPicture )( const void* owner, int poc );
   bool ( *fwd2D )( const int16_t* resi, ptrdiff_t stride, int32_t* coef, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
   bool ( *inv2D )( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );
   void ( *initIF )( vvenc::InterpolationFilter* );
@@ -33,7 +42,7 @@ struct VvhipHooks
   bool ( *alfCtu )( const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int chromaShift,
                     int bitDepth, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls /* [h/4][w/4][2] */, float* const stats[3] /* in: the records to continue from, out: updated */ );
   // ALF statistics of a whole picture in one call (classes in picture raster, one record set per statistics unit)
-  bool ( *alfPicture )( const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int bitDepth,
+  bool ( *alfPicture )( const void* owner, int poc, const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int bitDepth,
                         int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] );
   // CC-ALF statistics of one CTU and chroma component: record of 183 floats (E[0..6][0..6] with row pitch 13, y[0..6], pixAcc)
   bool ( *ccAlfCtu )( const int16_t* orgC, int orgStride, const int16_t* slfC, int slfStride, const int16_t* recLuma, int recStride, int widthC, int heightC,
@@ -50,3 +59,9 @@ struct VvhipHooks
   bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel, int refPoc, int curPoc );
 };
 extern VvhipHooks g_vvhipHooks;
+
+// run-time selection (called by the patched VVEncImpl::setSIMDExtension for a request that starts with "HIP"):
+//   "HIP"            the production set: whole-picture stages on the device (MCTF search + filter, ALF statistics + filtering)
+//   "HIP:<mask>"     explicit hook mask (decimal or 0x...), see vvenc_hip_install
+// returns 0, or -1 when no MI355X context can be created (the encoder then reports the SIMD request as unsupported)
+extern "C" int vvenc_hip_select( const char* spec );

@@ -61,6 +61,21 @@ VVHIP_API int         vvhip_malloc( vvhip_ctx* ctx, void** d_ptr, size_t bytes )
 VVHIP_API int         vvhip_free( vvhip_ctx* ctx, void* d_ptr );
 VVHIP_API int         vvhip_upload( vvhip_ctx* ctx, void* d_dst, const void* host_src, size_t bytes );   /* async on stream */
 VVHIP_API int         vvhip_download( vvhip_ctx* ctx, void* host_dst, const void* d_src, size_t bytes ); /* async + sync    */
+VVHIP_API int         vvhip_download_async( vvhip_ctx* ctx, void* host_dst, const void* d_src, size_t bytes ); /* no sync: pair with vvhip_sync; host_dst should be pinned */
+/* strided forms (pitches and width in BYTES): a picture window moves without a packing pass on the host (hipMemcpy2DAsync)               */
+VVHIP_API int         vvhip_upload_2d( vvhip_ctx* ctx, void* d_dst, size_t dst_pitch, const void* host_src, size_t src_pitch, size_t width_bytes, size_t rows );
+VVHIP_API int         vvhip_download_2d( vvhip_ctx* ctx, void* host_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width_bytes, size_t rows ); /* async + sync */
+/* Pin a caller-owned host range in place (hipHostRegister) so that uploads / downloads touching it are true asynchronous DMA at full PCIe rate instead of
+ * being staged through the runtime's bounce buffers.  The encoder's picture buffers are recycled for the whole run: register once, unregister before free.   */
+VVHIP_API int         vvhip_host_register( vvhip_ctx* ctx, const void* host_ptr, size_t bytes );
+VVHIP_API int         vvhip_host_unregister( vvhip_ctx* ctx, const void* host_ptr );
+/* Several GPUs in one process (one context per device and worker thread): number of devices, the device of a context, and a device-to-device copy of a
+ * picture over xGMI (hipMemcpyPeerAsync on dst's stream, ordered after the work already queued on src's stream) — how an original or reconstructed
+ * picture reaches the GPU that serves the pictures depending on it without a round trip through the host.                                        */
+VVHIP_API int         vvhip_device_count( void );
+VVHIP_API int         vvhip_get_device( const vvhip_ctx* ctx );
+VVHIP_API int         vvhip_make_current( vvhip_ctx* ctx );              /* hipSetDevice( the context's device ) for the calling thread: call when a thread switches GPUs */
+VVHIP_API int         vvhip_copy_peer( vvhip_ctx* dst_ctx, void* d_dst, vvhip_ctx* src_ctx, const void* d_src, size_t bytes );
 VVHIP_API const char* vvhip_version( void );
 
 /* ---------------------------------------------------------------------------------------------
@@ -94,8 +109,13 @@ VVHIP_API int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, 
                                 const vvhip_dist_job* jobs_host, int n_jobs );
 
 /* The same with a function per job: consecutive jobs of one kernel family — SAD and SSE, or HAD and HAD_fast — share a launch (a frame's
- * SAD and SSE lists are both short, memory-side work; together they fill the device better).                                         */
-typedef struct { int32_t func, width, height, sub_shift, n, pad; const vvhip_dist_item* d_items; uint64_t* d_out; } vvhip_dist_fjob;
+ * SAD and SSE lists are both short, memory-side work; together they fill the device better).
+ * flags: VVHIP_DIST_FLAG_SAMPLES = the caller asserts that BOTH operands of the job hold samples in [0, 2^bit_depth) (original vs reconstructed /
+ * predicted picture samples).  Without it the Hadamard jobs accept everything the encoder hands to a HAD table entry at that bit depth, including
+ * the bi-prediction pattern 2*org - pred (values -(2^bd - 1) .. 2*(2^bd - 1), EncoderLib/InterSearch.cpp:1996-2003), through a slightly wider tile;
+ * results are identical wherever both forms are defined.  vvhip_dist_multi (no flags field) always uses the general form.                 */
+#define VVHIP_DIST_FLAG_SAMPLES 1
+typedef struct { int32_t func, width, height, sub_shift, n, flags; const vvhip_dist_item* d_items; uint64_t* d_out; } vvhip_dist_fjob;
 VVHIP_API int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,
                                      const vvhip_dist_fjob* jobs_host, int n_jobs );
 

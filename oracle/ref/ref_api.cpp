@@ -1143,16 +1143,32 @@ API int vvref_ccalf_filter_plane( int16_t* dstC, int dstStride, const int16_t* r
 
 extern "C" void vvref_after_simd_init() __attribute__( ( weak ) );
 
-API long vvref_encode( const int16_t* y, const int16_t* u, const int16_t* v, int width, int height, int frames, int inputBitDepth, int internalBitDepth,
-                       int preset, int qp, int threads, const char* simd, uint8_t* out, long outCap, double* secondsOut )
+// options: "name=value;name=value" handed to vvenc_set_param one by one after the preset (e.g. "RDOQ=0;LFNST=1"); simd may be "HIP[:mask]" in the build with the binding
+API long vvref_encode_ex( const int16_t* y, const int16_t* u, const int16_t* v, int width, int height, int frames, int inputBitDepth, int internalBitDepth,
+                          int preset, int qp, int threads, const char* simd, const char* options, uint8_t* out, long outCap, double* secondsOut )
 {
-  vvenc_set_SIMD_extension( simd && simd[0] ? simd : nullptr );
+  if( simd && simd[0] && !vvenc_set_SIMD_extension( simd ) ) { fprintf( stderr, "vvref_encode: SIMD request %s refused\n", simd ); return -4; }
+  if( !( simd && simd[0] ) ) vvenc_set_SIMD_extension( nullptr );
   vvenc_config cfg;
   vvenc_init_default( &cfg, width, height, 30, 0, qp, ( vvencPresetMode ) preset );
   cfg.m_inputBitDepth[0] = inputBitDepth;
   cfg.m_internalBitDepth[0] = internalBitDepth;
   cfg.m_numThreads = threads;
   cfg.m_verbosity = VVENC_SILENT;
+  if( options && options[0] )
+  {
+    std::string o( options );
+    size_t pos = 0;
+    while( pos < o.size() )
+    {
+      size_t end = o.find( ';', pos ); if( end == std::string::npos ) end = o.size();
+      const std::string kv = o.substr( pos, end - pos ); pos = end + 1;
+      const size_t eq = kv.find( '=' );
+      if( eq == std::string::npos ) continue;
+      const int rc = vvenc_set_param( &cfg, kv.substr( 0, eq ).c_str(), kv.substr( eq + 1 ).c_str() );
+      if( rc != 0 ) { fprintf( stderr, "vvref_encode: vvenc_set_param( %s ) -> %d\n", kv.c_str(), rc ); return -5; }
+    }
+  }
   vvenc_set_msg_callback( &cfg, nullptr, quietMsg );
   vvencEncoder* enc = vvenc_encoder_create();
   if( !enc ) return -1;
@@ -1188,6 +1204,12 @@ API long vvref_encode( const int16_t* y, const int16_t* u, const int16_t* v, int
   vvenc_accessUnit_free_payload( &au );
   vvenc_encoder_close( enc );
   return rc ? -3 : used;
+}
+
+API long vvref_encode( const int16_t* y, const int16_t* u, const int16_t* v, int width, int height, int frames, int inputBitDepth, int internalBitDepth,
+                       int preset, int qp, int threads, const char* simd, uint8_t* out, long outCap, double* secondsOut )
+{
+  return vvref_encode_ex( y, u, v, width, height, frames, inputBitDepth, internalBitDepth, preset, qp, threads, simd, nullptr, out, outCap, secondsOut );
 }
 
 API const char* vvref_version() { return "vvenc reference 1.15.0-dev (built from /root/reference by oracle/ref/Makefile)"; }

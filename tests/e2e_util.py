@@ -8,7 +8,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libvvenc_ref.so")
 REF_HIP_SO = os.path.join(ROOT, "oracle", "_ref", "libvvenc_ref_hip.so")
-PRESET_FASTER = 0   # vvencPresetMode: VVENC_FASTER = 0, FAST = 1, MEDIUM = 2 (include/vvenc/vvencCfg.h)
+PRESET_FASTER, PRESET_FAST, PRESET_MEDIUM = 0, 1, 2   # vvencPresetMode (include/vvenc/vvencCfg.h)
+PRESETS = {"faster": 0, "fast": 1, "medium": 2}
 
 
 def synth_yuv(width, height, frames, bit_depth, seed):
@@ -30,9 +31,9 @@ def synth_yuv(width, height, frames, bit_depth, seed):
 
 def load(hip=False):
     L = C.CDLL(REF_HIP_SO if hip else REF_SO)
-    L.vvref_encode.restype = C.c_long
-    L.vvref_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                               C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_double)]
+    L.vvref_encode_ex.restype = C.c_long
+    L.vvref_encode_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_char_p, C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_double)]
     if hip:
         L.vvref_install_hip_hooks.argtypes = [C.c_int]
         L.vvref_hip_hook_calls.argtypes = [C.c_void_p]
@@ -40,12 +41,13 @@ def load(hip=False):
     return L
 
 
-def encode(L, yuv, width, height, in_bd, int_bd, preset=PRESET_FASTER, qp=32, threads=1, simd=None):
+def encode(L, yuv, width, height, in_bd, int_bd, preset=PRESET_FASTER, qp=32, threads=1, simd=None, options=None):
+    """simd: None / "SCALAR" / "SSE41" / ... / "HIP[:mask]" (the reference's own switch); options: "name=value;..." for vvenc_set_param"""
     y, u, v = yuv
-    out = np.zeros(4 << 20, np.uint8)
+    out = np.zeros(8 << 20, np.uint8)
     secs = C.c_double()
-    n = L.vvref_encode(y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, y.shape[0], in_bd, int_bd, preset, qp, threads,
-                       simd.encode() if simd else None, out.ctypes.data, out.size, C.byref(secs))
+    n = L.vvref_encode_ex(y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, y.shape[0], in_bd, int_bd, preset, qp, threads,
+                          simd.encode() if simd else None, options.encode() if options else None, out.ctypes.data, out.size, C.byref(secs))
     assert n > 0, n
     bs = out[:n].tobytes()
     return hashlib.md5(bs).hexdigest(), n, secs.value

@@ -502,6 +502,41 @@ def test_dist_multi_equals_batches(hip):
         assert np.array_equal(j[6].cpu().numpy(), allr[k]), ("mixed", j[0], j[1], j[2], j[3])
 
 
+@pytest.mark.parametrize("case", ["bipred-10", "samples-10-flag", "samples-12", "samples-8-flag"])
+def test_dist_multi_hadamard_input_ranges(hip, oracle, case):
+    """the merged Hadamard launches against the oracle on every input domain the encoder has: the bi-prediction pattern 2*org - pred (signed, |difference|
+    up to 2046; the general packed tile), plain samples with VVHIP_DIST_FLAG_SAMPLES (all-packed tile), and 12-bit samples (hadTile8MultiKernel, 32-bit tile)"""
+    import torch
+    hp = hip.hp
+    rng = np.random.default_rng(311)
+    bd = {"bipred-10": 10, "samples-10-flag": 10, "samples-12": 12, "samples-8-flag": 8}[case]
+    H, W = 192, 320
+    if case == "bipred-10":
+        org = rng.integers(-1023, 2047, size=(H, W)).astype(np.int16)
+        org[:64, :64] = np.where(rng.integers(0, 2, (64, 64)) == 1, 2046, -1023).astype(np.int16)     # extremes
+    else:
+        org = rand_plane(rng, H, W, bd)
+    cur = rand_plane(rng, H, W, bd)
+    if case == "bipred-10":
+        cur[:64, :64] = np.where(org[:64, :64] > 0, 0, 1023).astype(np.int16)
+    po, pc = hp.plane(org, 0), hp.plane(cur, 0)
+    jobs, pos = [], []
+    for func in ("HAD", "HAD_fast"):
+        for S in (8, 16, 32, 64):
+            n = 40
+            oy, ox = rng.integers(0, H - S + 1, n), rng.integers(0, W - S + 1, n)
+            cy, cx = rng.integers(0, H - S + 1, n), rng.integers(0, W - S + 1, n)
+            oy[0], ox[0], cy[0], cx[0] = 0, 0, 0, 0
+            it = np.stack([oy * po.stride + ox, cy * pc.stride + cx], 1).astype(np.int32)
+            jobs.append((func, S, S, 0, n, hp.to_device(it), torch.full((n,), -1, dtype=torch.int64, device=hp.device)))
+            pos.append((oy, ox, cy, cx))
+    hp.dist_multi_func(po, pc, hp.make_dist_fjobs(jobs, flags=hp.DIST_FLAG_SAMPLES if case.endswith("flag") else 0), bd)
+    for (func, S, _, _, n, _, out), (oy, ox, cy, cx) in zip(jobs, pos):
+        got = out.cpu().numpy()
+        for k in range(n):
+            assert int(got[k]) == oracle.dist(func, (org, int(oy[k]), int(ox[k])), (cur, int(cy[k]), int(cx[k])), S, S, bd), (case, func, S, k)
+
+
 def test_tu_rdo_multi_equals_batches(hip):
     """vvhip_tu_rdo_multi (square 8/16/32 lists merged into one launch, others alone) == one vvhip_tu_rdo_batch per job"""
     import torch

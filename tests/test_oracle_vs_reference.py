@@ -46,6 +46,22 @@ def test_had(oracle, reflib, fast):
                 assert oracle.dist(name, org, cur, w, h) == reflib.dist(name, org, cur, w, h), (w, h, rep)
 
 
+@pytest.mark.parametrize("fast", [0, 1])
+def test_had_bipred_pattern_range(oracle, reflib, fast):
+    """the bi-prediction pattern 2*org - pred (values -1023..2046 at 10 bit, InterSearch.cpp:1996-2003) through the HAD entries: the oracle equals the
+    reference's scalar and x86 rows on that input range too (the x86 8x8 tile widens to 32 bit after three 16-bit stages)"""
+    rng = np.random.default_rng(22)
+    name = "HAD_fast" if fast else "HAD"
+    for w, h in [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16)]:
+        for rep in range(3):
+            org = rng.integers(-1023, 2047, size=(h, w + 8)).astype(np.int16)
+            cur = rng.integers(0, 1024, size=(h, w + 5)).astype(np.int16)
+            if rep == 2:    # extremes: every difference at +-2046
+                org[:, :] = np.where(rng.integers(0, 2, org.shape) == 1, 2046, -1023).astype(np.int16)
+                cur[:, :] = np.where(org[:, :w + 5] > 0, 0, 1023).astype(np.int16)
+            assert oracle.dist(name, org, cur, w, h) == reflib.dist(name, org, cur, w, h), (w, h, rep)
+
+
 def test_had_2sad(oracle, reflib):
     rng = np.random.default_rng(3)
     for w in [4, 8, 16, 32, 64]:

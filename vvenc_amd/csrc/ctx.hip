@@ -330,4 +330,79 @@ int vvhip_download( vvhip_ctx* ctx, void* host_dst, const void* d_src, size_t by
   return VVHIP_OK;
 }
 
+int vvhip_download_async( vvhip_ctx* ctx, void* host_dst, const void* d_src, size_t bytes )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( host_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream ) );
+  return VVHIP_OK;
+}
+
+int vvhip_upload_2d( vvhip_ctx* ctx, void* d_dst, size_t dst_pitch, const void* host_src, size_t src_pitch, size_t width_bytes, size_t rows )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !rows || !width_bytes ) return VVHIP_OK;
+  VVHIP_CHECK_HIP( ctx, hipMemcpy2DAsync( d_dst, dst_pitch, host_src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, ctx->stream ) );
+  return VVHIP_OK;
+}
+
+int vvhip_download_2d( vvhip_ctx* ctx, void* host_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width_bytes, size_t rows )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !rows || !width_bytes ) return VVHIP_OK;
+  VVHIP_CHECK_HIP( ctx, hipMemcpy2DAsync( host_dst, dst_pitch, d_src, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost, ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  return VVHIP_OK;
+}
+
+int vvhip_host_register( vvhip_ctx* ctx, const void* host_ptr, size_t bytes )
+{
+  if( !ctx || !host_ptr || !bytes ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipSetDevice( ctx->device ) );
+  hipError_t e = hipHostRegister( const_cast<void*>( host_ptr ), bytes, hipHostRegisterPortable );
+  if( e == hipErrorHostMemoryAlreadyRegistered ) { ( void ) hipGetLastError(); return VVHIP_OK; }
+  if( e != hipSuccess ) { ( void ) hipGetLastError(); return vvhip_fail( ctx, VVHIP_E_HIP, "hipHostRegister(%zu): %s", bytes, hipGetErrorString( e ) ); }
+  return VVHIP_OK;
+}
+
+int vvhip_host_unregister( vvhip_ctx* ctx, const void* host_ptr )
+{
+  if( !ctx || !host_ptr ) return VVHIP_E_ARG;
+  hipError_t e = hipHostUnregister( const_cast<void*>( host_ptr ) );
+  if( e != hipSuccess ) { ( void ) hipGetLastError(); return vvhip_fail( ctx, VVHIP_E_HIP, "hipHostUnregister: %s", hipGetErrorString( e ) ); }
+  return VVHIP_OK;
+}
+
+int vvhip_device_count( void )
+{
+  int count = 0;
+  if( hipGetDeviceCount( &count ) != hipSuccess ) { ( void ) hipGetLastError(); return 0; }
+  return count;
+}
+
+int vvhip_get_device( const vvhip_ctx* ctx ) { return ctx ? ctx->device : -1; }
+
+int vvhip_make_current( vvhip_ctx* ctx )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipSetDevice( ctx->device ) );
+  return VVHIP_OK;
+}
+
+int vvhip_copy_peer( vvhip_ctx* dst_ctx, void* d_dst, vvhip_ctx* src_ctx, const void* d_src, size_t bytes )
+{
+  if( !dst_ctx || !src_ctx || !d_dst || !d_src ) return VVHIP_E_ARG;
+  if( !bytes ) return VVHIP_OK;
+  // order the copy after what the source context has queued (the producer of d_src), then run it on the destination's stream
+  hipEvent_t ev = nullptr;
+  VVHIP_CHECK_HIP( dst_ctx, hipSetDevice( src_ctx->device ) );
+  VVHIP_CHECK_HIP( dst_ctx, hipEventCreateWithFlags( &ev, hipEventDisableTiming ) );
+  hipError_t e = hipEventRecord( ev, src_ctx->stream );
+  if( e == hipSuccess ) e = hipSetDevice( dst_ctx->device );
+  if( e == hipSuccess ) e = hipStreamWaitEvent( dst_ctx->stream, ev, 0 );
+  if( e == hipSuccess ) e = hipMemcpyPeerAsync( d_dst, dst_ctx->device, d_src, src_ctx->device, bytes, dst_ctx->stream );
+  ( void ) hipEventDestroy( ev );
+  if( e != hipSuccess ) return vvhip_fail( dst_ctx, VVHIP_E_HIP, "vvhip_copy_peer: %s", hipGetErrorString( e ) );
+  return VVHIP_OK;
+}
+
 } // extern "C"

@@ -390,10 +390,14 @@ hadTileBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, con
 // ---------------------------------------------------------------------------------------------
 // 8x8 / 16x16_fast Hadamard tile per lane in PACKED 16-bit arithmetic, for bit depths <= 10 (the same contract as the reference's x86
 // rows: xCalcHAD8x8_SSE / xCalcHAD16x16_fast_SSE CHECK( iBitDepth > 10 ), x86/RdCostX86.h:655-659,800-804).
-// The 64 differences of a tile are 32 dwords of two samples.  Differences of <= 10-bit samples are 11 bits signed; five butterfly stages
-// over the dword index (v_pk_add_i16 / v_pk_sub_i16: both halves at once) stay within 16 bits (1023 * 32 < 32768).  The sixth stage pairs the
-// two halves of a dword, and |a + b| + |a - b| = 2 * max( |a|, |b| ): it never has to be carried out.  Half the registers and half the
-// instructions of the 32-bit form; the sum of absolute coefficients is identical for conforming inputs.
+// The 64 differences of a tile are 32 dwords of two samples.  Two forms:
+//   WIDE (default): inputs may be anything the encoder hands to a <= 10-bit HAD entry, including the bi-prediction pattern 2*org - pred
+//     (values -1023..2046, InterSearch.cpp:1996-2003), so |difference| <= 2047.  Four butterfly stages over the dword index run packed
+//     (v_pk_add_i16 / v_pk_sub_i16: 2047 * 16 < 32768), the fifth is carried out in 32 bits (the reference's x86 row widens after its third
+//     stage, x86/RdCostX86.h:700-760), the sixth never has to be: |a + b| + |a - b| = 2 * max( |a|, |b| ).  The 2x2 averages of the fast tile
+//     use an arithmetic packed shift (signed inputs).
+//   NARROW (job flag VVHIP_DIST_FLAG_SAMPLES: the caller asserts both operands are samples in [0, 2^bit_depth)): |difference| <= 1023, all
+//     five dword stages stay packed (1023 * 32 < 32768).  Fewer instructions; identical results on that domain.
 // ---------------------------------------------------------------------------------------------
 typedef short s16x2v __attribute__( ( ext_vector_type( 2 ) ) );
 __device__ __forceinline__ uint32_t pkAdd( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2v, a ) + __builtin_bit_cast( s16x2v, b ) ); }
@@ -404,7 +408,8 @@ __device__ __forceinline__ uint32_t pkAbs( uint32_t a )
   return __builtin_bit_cast( uint32_t, __builtin_elementwise_max( v, z - v ) );
 }
 
-// rounded 2x2 averages of 16 samples x 2 rows -> 8 values as 4 packed dwords
+// rounded 2x2 averages of 16 samples x 2 rows -> 8 values as 4 packed dwords; SIGNED: inputs may be negative (arithmetic shift)
+template<bool SIGNED>
 __device__ __forceinline__ void avgRow16Pk( const int16_t* p, int stride, uint32_t ( &o )[4] )
 {
   const u32x4 a0 = ld16( p ), a1 = ld16( p + 8 ), b0 = ld16( p + stride ), b1 = ld16( p + stride + 8 );
@@ -414,11 +419,12 @@ __device__ __forceinline__ void avgRow16Pk( const int16_t* p, int stride, uint32
   {
     const uint32_t lo = __builtin_amdgcn_perm( t[2 * i + 1], t[2 * i], 0x05040100u ), hi = __builtin_amdgcn_perm( t[2 * i + 1], t[2 * i], 0x07060302u );   // (t0.lo, t1.lo), (t0.hi, t1.hi)
     const uint32_t s = pkAdd( pkAdd( lo, hi ), 0x00020002u );
-    o[i] = ( s >> 2 ) & 0x3fff3fffu;                                                          // both halves >> 2 (sums are < 2^13, unsigned)
+    if( SIGNED ) o[i] = __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2v, s ) >> 2 );   // v_pk_ashrrev_i16 (|sum| <= 4 * 2046 + 2)
+    else         o[i] = ( s >> 2 ) & 0x3fff3fffu;                                               // both halves >> 2 (sums are < 2^13, unsigned)
   }
 }
 
-template<bool FAST16>
+template<bool FAST16, bool WIDE>
 __device__ __forceinline__ void
 hadTilePkBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
                int tilesX, int tilesPerCand, int log2Lpc,
@@ -447,8 +453,8 @@ hadTilePkBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, c
       if( FAST16 )
       {
         uint32_t ao[4], ac[4];
-        avgRow16Pk( po + ( ptrdiff_t ) ( 2 * r ) * orgStride, orgStride, ao );
-        avgRow16Pk( pc + ( ptrdiff_t ) ( 2 * r ) * curStride, curStride, ac );
+        avgRow16Pk<WIDE>( po + ( ptrdiff_t ) ( 2 * r ) * orgStride, orgStride, ao );
+        avgRow16Pk<WIDE>( pc + ( ptrdiff_t ) ( 2 * r ) * curStride, curStride, ac );
 #pragma unroll
         for( int q = 0; q < 4; q++ ) d[4 * r + q] = pkSub( ao[q], ac[q] );
       }
@@ -458,26 +464,47 @@ hadTilePkBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, c
         d[4 * r] = pkSub( x.x, z.x ); d[4 * r + 1] = pkSub( x.y, z.y ); d[4 * r + 2] = pkSub( x.z, z.z ); d[4 * r + 3] = pkSub( x.w, z.w );
       }
     }
-    // five Walsh-Hadamard stages over the dword index (both halves in parallel)
+    // Walsh-Hadamard stages over the dword index (both halves in parallel): five packed (NARROW) or four packed + one in 32 bits (WIDE)
 #pragma unroll
-    for( int len = 1; len < 32; len <<= 1 )
+    for( int len = 1; len < ( WIDE ? 16 : 32 ); len <<= 1 )
 #pragma unroll
       for( int i = 0; i < 32; i += 2 * len )
 #pragma unroll
         for( int j = i; j < i + len; j++ ) { const uint32_t a = d[j], b = d[j + len]; d[j] = pkAdd( a, b ); d[j + len] = pkSub( a, b ); }
-    // sixth stage + sum of magnitudes: |a + b| + |a - b| = 2 max( |a|, |b| ); dword 0 holds the DC (a + b), which counts a quarter
-    uint32_t m = 0;
+    uint32_t s;
+    if( WIDE )
+    {
+      // fifth stage (dwords j, j + 16) in 32 bits; sixth stage + magnitudes through 2 max( |lo|, |hi| ); the pair holding the DC is dword 0's sum
+      uint32_t m = 0, dcTerm = 0;
 #pragma unroll
-    for( int i = 1; i < 32; i++ ) { const uint32_t ax = pkAbs( d[i] ); const uint32_t lo = ax & 0xffffu, hi = ax >> 16; m += lo > hi ? lo : hi; }
-    const int a0 = ( int ) ( int16_t ) ( d[0] & 0xffffu ), b0 = ( int ) d[0] >> 16;
-    const uint32_t dc = ( uint32_t ) abs( a0 + b0 );
-    const uint32_t s = 2 * m + ( uint32_t ) abs( a0 - b0 ) + ( dc >> 2 );
+      for( int j = 0; j < 16; j++ )
+      {
+        const int al = ( int ) ( int16_t ) ( d[j] & 0xffffu ), ah = ( int ) d[j] >> 16, bl = ( int ) ( int16_t ) ( d[j + 16] & 0xffffu ), bh = ( int ) d[j + 16] >> 16;
+        const int pl = al + bl, ph = ah + bh, ml = al - bl, mh = ah - bh;
+        const uint32_t aml = ( uint32_t ) abs( ml ), amh = ( uint32_t ) abs( mh );
+        m += aml > amh ? aml : amh;
+        if( j == 0 ) { const uint32_t dc = ( uint32_t ) abs( pl + ph ); dcTerm = ( uint32_t ) abs( pl - ph ) + ( dc >> 2 ); }
+        else { const uint32_t apl = ( uint32_t ) abs( pl ), aph = ( uint32_t ) abs( ph ); m += apl > aph ? apl : aph; }
+      }
+      s = 2 * m + dcTerm;
+    }
+    else
+    {
+      // sixth stage + sum of magnitudes: |a + b| + |a - b| = 2 max( |a|, |b| ); dword 0 holds the DC (a + b), which counts a quarter
+      uint32_t m = 0;
+#pragma unroll
+      for( int i = 1; i < 32; i++ ) { const uint32_t ax = pkAbs( d[i] ); const uint32_t lo = ax & 0xffffu, hi = ax >> 16; m += lo > hi ? lo : hi; }
+      const int a0 = ( int ) ( int16_t ) ( d[0] & 0xffffu ), b0 = ( int ) d[0] >> 16;
+      const uint32_t dc = ( uint32_t ) abs( a0 + b0 );
+      s = 2 * m + ( uint32_t ) abs( a0 - b0 ) + ( dc >> 2 );
+    }
     sum += FAST16 ? ( ( s + 2 ) >> 2 ) << 2 : ( s + 2 ) >> 2;                                 // RdCost.cpp:1220-1222 / :1319
   }
   const uint64_t tot = vvhipGroupSum64( sum, lpc, threadIdx.x & 63 );
   if( valid && lt == 0 ) out[cand] = tot;
 }
 
+template<bool WIDE>
 __global__ void __launch_bounds__( 256 )
 hadTile8PkMultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride, DistMultiJobs jobs )
 {
@@ -487,8 +514,8 @@ hadTile8PkMultiKernel( const int16_t* __restrict__ org, int orgStride, const int
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  if( g.fast16 ) hadTilePkBody<true>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
-  else           hadTilePkBody<false>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  if( g.fast16 ) hadTilePkBody<true, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  else           hadTilePkBody<false, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
 }
 
 template<int TW, int TH, bool FAST16>
@@ -758,7 +785,7 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
     if( jb.n <= 0 || jb.width < 8 || jb.height < 1 || jb.width > 128 || jb.height > 128 ) return 0;
     if( jb.func == VVHIP_DF_SAD ) return ( ( jb.width & 7 ) == 0 && jb.sub_shift >= 0 && jb.sub_shift <= 1 && ( jb.height >> jb.sub_shift ) >= 1 && !( jb.height & ( ( 1 << jb.sub_shift ) - 1 ) ) ) ? 1 : 0;
     if( jb.func == VVHIP_DF_SSE ) return ( jb.width & 7 ) == 0 ? 1 : 0;
-    if( jb.func == VVHIP_DF_HAD || jb.func == VVHIP_DF_HAD_FAST ) return ( jb.width == jb.height && ( jb.width & 7 ) == 0 ) ? 2 : 0;
+    if( jb.func == VVHIP_DF_HAD || jb.func == VVHIP_DF_HAD_FAST ) return ( jb.width == jb.height && ( jb.width & 7 ) == 0 ) ? ( ( jb.flags & VVHIP_DIST_FLAG_SAMPLES ) ? 3 : 2 ) : 0;
     return 0; };
   int i = 0;
   while( i < n_jobs )
@@ -805,17 +832,18 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       // workgroup size: lane teams never talk to each other, so the Hadamard launches use single-wave workgroups (a wave's registers are free again
       // the moment it retires: 34.6 -> 31.3 us); the SAD / SSE launch is indifferent (34.5 / 35.2 / 35.0 us for 256 / 128 / 64) and keeps 256
       static const int wgEnv = []{ const char* e = getenv( "VVHIP_DIST_WG" ); const int v = e ? atoi( e ) : 0; return ( v == 64 || v == 128 || v == 256 ) ? v : 0; }();
-      const int wgSize = wgEnv ? wgEnv : ( fam == 2 ? 64 : 256 );
+      const int wgSize = wgEnv ? wgEnv : ( fam >= 2 ? 64 : 256 );
       g.nBlocks = fam == 1 ? ( int ) ( ( ( ( long ) jb.n + DIST_U - 1 ) / DIST_U * lpc + wgSize - 1 ) / wgSize ) : ( int ) ( ( ( long ) jb.n * lpc + wgSize - 1 ) / wgSize );
       blocks += g.nBlocks;
       mj.nJobs++; i++;
     }
     static const int wgEnvL = []{ const char* e = getenv( "VVHIP_DIST_WG" ); const int v = e ? atoi( e ) : 0; return ( v == 64 || v == 128 || v == 256 ) ? v : 0; }();
-    const int wgSizeL = wgEnvL ? wgEnvL : ( fam == 2 ? 64 : 256 );
+    const int wgSizeL = wgEnvL ? wgEnvL : ( fam >= 2 ? 64 : 256 );
     // bit depths <= 10: the packed 16-bit tile (the reference's x86 rows have the same limit); VVHIP_HAD_PK=0 forces the 32-bit form
     static const int hadPk = []{ const char* e = getenv( "VVHIP_HAD_PK" ); return e ? atoi( e ) : 1; }();
-    if( fam == 2 && bit_depth <= 10 && hadPk ) hipLaunchKernelGGL( hadTile8PkMultiKernel, dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
-    else if( fam == 2 )       hipLaunchKernelGGL( hadTile8MultiKernel, dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    if( fam == 3 && bit_depth <= 10 && hadPk )      hipLaunchKernelGGL( hadTile8PkMultiKernel<false>, dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else if( fam >= 2 && bit_depth <= 10 && hadPk ) hipLaunchKernelGGL( hadTile8PkMultiKernel<true>, dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
+    else if( fam >= 2 )       hipLaunchKernelGGL( hadTile8MultiKernel, dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
     else if( anySad && anySse ) hipLaunchKernelGGL( sadSseMixedKernel, dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
     else if( anySad )         hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SAD> ), dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
     else                      hipLaunchKernelGGL( ( sadSseMultiKernel<MODE_SSE> ), dim3( ( unsigned ) blocks ), dim3( wgSizeL ), 0, ctx->stream, d_org, org_stride, d_cur, cur_stride, mj );
@@ -837,7 +865,7 @@ int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_st
   if( !ctx ) return VVHIP_E_ARG;
   if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi: bad job list" );
   std::vector<vvhip_dist_fjob> fj( n_jobs );
-  for( int i = 0; i < n_jobs; i++ ) { fj[i].func = func; fj[i].width = jobs[i].width; fj[i].height = jobs[i].height; fj[i].sub_shift = jobs[i].sub_shift; fj[i].n = jobs[i].n; fj[i].pad = 0;
+  for( int i = 0; i < n_jobs; i++ ) { fj[i].func = func; fj[i].width = jobs[i].width; fj[i].height = jobs[i].height; fj[i].sub_shift = jobs[i].sub_shift; fj[i].n = jobs[i].n; fj[i].flags = 0;
                                       fj[i].d_items = jobs[i].d_items; fj[i].d_out = jobs[i].d_out; }
   return distMultiFunc( ctx, d_org, org_stride, d_cur, cur_stride, bit_depth, fj.data(), n_jobs );
 }

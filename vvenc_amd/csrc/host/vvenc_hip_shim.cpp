@@ -4,33 +4,112 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <tuple>
 
 namespace vvhip {
 
 static int ilog2( unsigned v ) { int l = 0; while( ( 1u << ( l + 1 ) ) <= v ) l++; return l; }
 
 // ------------------------------------------------------------------------------------------------ Device
-Device& Device::get()
+namespace {
+std::atomic<uint64_t> g_upBytes{ 0 }, g_downBytes{ 0 }, g_ups{ 0 }, g_downs{ 0 }, g_contexts{ 0 };
+// every transfer of this translation unit is counted (Device::stats): the macros below route the C ABI's copy calls through these
+inline int countedUpload( vvhip_ctx* c, void* d, const void* h, size_t n ) { g_upBytes += n; g_ups++; return vvhip_upload( c, d, h, n ); }
+inline int countedDownload( vvhip_ctx* c, void* h, const void* d, size_t n ) { g_downBytes += n; g_downs++; return vvhip_download( c, h, d, n ); }
+inline int countedDownloadAsync( vvhip_ctx* c, void* h, const void* d, size_t n ) { g_downBytes += n; g_downs++; return vvhip_download_async( c, h, d, n ); }
+#define vvhip_upload countedUpload
+#define vvhip_download countedDownload
+#define vvhip_download_async countedDownloadAsync
+
+// mirrors of one GPU, shared by that GPU's contexts.  Entries are never moved (deque) so Mirror pointers stay valid while the picture is registered.
+struct Registry { mutable std::mutex m; std::deque<Device::Mirror> mirrors; };
+Registry& registry( int gpu )
 {
-  static Device d;
-  return d;
+  static std::mutex m; static std::map<int, std::unique_ptr<Registry>> regs;
+  std::lock_guard<std::mutex> g( m );
+  std::unique_ptr<Registry>& r = regs[gpu];
+  if( !r ) r.reset( new Registry );
+  return *r;
+}
+} // namespace
+
+// contexts outlive their threads: a finished worker's context goes back to the pool and serves the next new thread (no HIP teardown at thread or process exit)
+struct DevicePool
+{
+  std::mutex m; std::multimap<int, Device*> idle;
+  Device* take( int gpu )
+  {
+    { std::lock_guard<std::mutex> g( m ); auto it = idle.find( gpu ); if( it != idle.end() ) { Device* d = it->second; idle.erase( it ); return d; } }
+    return new Device( gpu );
+  }
+  void give( Device* d ) { std::lock_guard<std::mutex> g( m ); idle.emplace( d->gpu(), d ); }
+  static DevicePool& get() { static DevicePool* p = new DevicePool; return *p; }      // leaked on purpose (see above)
+};
+namespace {
+struct ThreadDevices
+{
+  int selected = -1; std::map<int, Device*> byGpu; int current = -2;
+  ~ThreadDevices() { for( auto& kv : byGpu ) DevicePool::get().give( kv.second ); }
+};
+thread_local ThreadDevices t_dev;
 }
 
-Device::Device()
+int Device::defaultGpu() { static const int g = []{ const char* e = getenv( "VVHIP_DEVICE" ); return e ? atoi( e ) : 0; }(); return g; }
+int Device::gpuCount() { return vvhip_device_count(); }
+void Device::selectGpu( int gpu ) { t_dev.selected = gpu; }
+
+Device& Device::get()
 {
-  const char* e = getenv( "VVHIP_DEVICE" );
-  const int rc = vvhip_create( &m_ctx, e ? atoi( e ) : 0 );
-  if( rc != VVHIP_OK ) throw Exception( std::string( "vvhip::Device: " ) + vvhip_last_error( nullptr ) );
+  ThreadDevices& t = t_dev;
+  const int gpu = t.selected >= 0 ? t.selected : defaultGpu();
+  Device*& d = t.byGpu[gpu];
+  if( !d ) d = DevicePool::get().take( gpu );
+  if( t.current != gpu ) { d->check( vvhip_make_current( d->m_ctx ), "vvhip_make_current" ); t.current = gpu; }
+  return *d;
 }
+
+Device::Device( int gpu ) : m_gpu( gpu )
+{
+  const int rc = vvhip_create( &m_ctx, gpu );
+  if( rc != VVHIP_OK ) throw Exception( std::string( "vvhip::Device: " ) + vvhip_last_error( nullptr ) );
+  g_contexts++;
+}
+Device::~Device() {}
+
+Device::Stats Device::stats() { return { g_upBytes.load(), g_downBytes.load(), g_ups.load(), g_downs.load(), g_contexts.load() }; }
 
 void Device::check( int rc, const char* what ) const
 {
   if( rc != VVHIP_OK ) throw Exception( std::string( what ) + ": " + vvhip_last_error( m_ctx ) );
 }
 
-int Device::registerPicture( const Pel* origin, int stride, int width, int height, int margin, bool findable )
+bool Device::pinHost( const void* p, size_t bytes )
+{
+  static const bool on = []{ const char* e = getenv( "VVHIP_PIN" ); return !e || atoi( e ) != 0; }();
+  if( !on || !p || !bytes ) return false;
+  static std::mutex m; static std::map<uintptr_t, size_t> pinned;      // page-aligned base -> bytes
+  const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>( p ) & ~( page - 1 ), e = ( reinterpret_cast<uintptr_t>( p ) + bytes + page - 1 ) & ~( page - 1 );
+  std::lock_guard<std::mutex> g( m );
+  auto it = pinned.upper_bound( a );
+  if( it != pinned.begin() ) { auto pr = std::prev( it ); if( pr->first <= a && pr->first + pr->second >= e ) return true; }       // already inside a pinned range
+  // ranges that overlap the new one were pinned for an earlier incarnation of (part of) this buffer: drop them first
+  Device& dev = Device::get();
+  for( it = pinned.begin(); it != pinned.end(); )
+  {
+    if( it->first < e && it->first + it->second > a ) { vvhip_host_unregister( dev.ctx(), reinterpret_cast<void*>( it->first ) ); it = pinned.erase( it ); }
+    else ++it;
+  }
+  if( vvhip_host_register( dev.ctx(), reinterpret_cast<void*>( a ), e - a ) != VVHIP_OK ) return false;
+  pinned[a] = e - a;
+  return true;
+}
+
+int Device::registerPicture( const Pel* origin, int stride, int width, int height, int margin, bool findable, bool upload )
 {
   Mirror m;
   m.origin = origin; m.stride = stride; m.width = width; m.height = height; m.margin = margin; m.live = true; m.findable = findable;
@@ -41,29 +120,58 @@ int Device::registerPicture( const Pel* origin, int stride, int width, int heigh
   check( vvhip_malloc( m_ctx, &d, elems * sizeof( Pel ) ), "registerPicture" );
   m.dBase = static_cast<int16_t*>( d );
   m.dOrigin = m.dBase + ( ptrdiff_t ) margin * stride + margin;
+  Registry& r = registry( m_gpu );
   int id = -1;
-  for( size_t i = 0; i < m_mirrors.size(); i++ ) if( !m_mirrors[i].live ) { id = ( int ) i; break; }      // reuse the slot of an unregistered picture
-  if( id < 0 ) { m_mirrors.push_back( m ); id = ( int ) m_mirrors.size() - 1; } else m_mirrors[id] = m;
-  updatePicture( id );
+  {
+    std::lock_guard<std::mutex> g( r.m );
+    for( size_t i = 0; i < r.mirrors.size(); i++ ) if( !r.mirrors[i].live ) { id = ( int ) i; break; }      // reuse the slot of an unregistered picture
+    if( id < 0 ) { r.mirrors.push_back( m ); id = ( int ) r.mirrors.size() - 1; } else r.mirrors[id] = m;
+  }
+  if( upload ) updatePicture( id );
   return id;
+}
+
+const Device::Mirror& Device::mirror( int id ) const
+{
+  Registry& r = registry( m_gpu );
+  std::lock_guard<std::mutex> g( r.m );
+  return r.mirrors.at( id );
 }
 
 void Device::updatePicture( int id )
 {
-  Mirror& m = m_mirrors.at( id );
+  const Mirror m = mirror( id );
   check( vvhip_upload( m_ctx, m.dBase, m.hostBase, ( size_t ) ( m.hostEnd - m.hostBase ) * sizeof( Pel ) ), "updatePicture" );
   check( vvhip_sync( m_ctx ), "updatePicture" );
 }
 
 void Device::unregisterPicture( int id )
 {
-  Mirror& m = m_mirrors.at( id );
-  if( m.live ) { vvhip_free( m_ctx, m.dBase ); m.live = false; m.hostBase = m.hostEnd = nullptr; }
+  Registry& r = registry( m_gpu );
+  int16_t* d = nullptr;
+  {
+    std::lock_guard<std::mutex> g( r.m );
+    Mirror& m = r.mirrors.at( id );
+    if( m.live ) { d = m.dBase; m.live = false; m.hostBase = m.hostEnd = nullptr; }
+  }
+  if( d ) vvhip_free( m_ctx, d );
+}
+
+int Device::copyMirrorTo( int id, Device& dst )
+{
+  const Mirror m = mirror( id );
+  const int did = dst.registerPicture( m.origin, m.stride, m.width, m.height, m.margin, m.findable, false );
+  const Mirror dm = dst.mirror( did );
+  dst.check( vvhip_copy_peer( dst.ctx(), dm.dBase, m_ctx, m.dBase, ( size_t ) ( m.hostEnd - m.hostBase ) * sizeof( Pel ) ), "vvhip_copy_peer" );
+  dst.check( vvhip_sync( dst.ctx() ), "vvhip_copy_peer" );
+  return did;
 }
 
 const Device::Mirror* Device::find( const Pel* p ) const
 {
-  for( const Mirror& m : m_mirrors ) if( m.live && m.findable && p >= m.hostBase && p < m.hostEnd ) return &m;
+  Registry& r = registry( m_gpu );
+  std::lock_guard<std::mutex> g( r.m );
+  for( const Mirror& m : r.mirrors ) if( m.live && m.findable && p >= m.hostBase && p < m.hostEnd ) return &m;
   return nullptr;
 }
 
@@ -71,7 +179,7 @@ int16_t* Device::staging( size_t bytes )
 {
   if( bytes > m_stageBytes )
   {
-    if( m_stage ) vvhip_free( m_ctx, m_stage );
+    if( m_stage ) { vvhip_sync( m_ctx ); vvhip_free( m_ctx, m_stage ); }
     void* d = nullptr;
     check( vvhip_malloc( m_ctx, &d, bytes * 2 ), "staging" );
     m_stage = static_cast<int16_t*>( d ); m_stageBytes = bytes * 2;
@@ -83,7 +191,7 @@ void* Device::stagingAux( size_t bytes )
 {
   if( bytes > m_auxBytes )
   {
-    if( m_aux ) vvhip_free( m_ctx, m_aux );
+    if( m_aux ) { vvhip_sync( m_ctx ); vvhip_free( m_ctx, m_aux ); }
     check( vvhip_malloc( m_ctx, &m_aux, bytes * 2 ), "stagingAux" );
     m_auxBytes = bytes * 2;
   }
@@ -93,7 +201,7 @@ void* Device::stagingAux( size_t bytes )
 // ------------------------------------------------------------------------------------------------ RdCost
 namespace {
 
-std::mutex g_lock;   // table entries are re-entrant in the reference (one RdCost per worker thread); the single staging area is serialised
+// table entries are re-entrant like the reference's (one RdCost per worker thread): every thread stages through its own context, no host lock
 
 struct Resolved { const int16_t* dBase; int stride; int32_t off; };
 
@@ -114,7 +222,6 @@ Resolved resolve( Device& dev, const CPelBuf& b, int w, int h, int extraLeft, in
 
 Distortion callOne( int func, const DistParam& dp )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int w = dp.org.width, h = dp.org.height;
   int16_t* cursor = dev.staging( ( size_t ) 4 * ( w + 8 ) * h * sizeof( Pel ) + 64 );
@@ -143,7 +250,6 @@ Distortion sadMaskEntry( const DistParam& dp )
 {
   if( dp.applyWeight ) throw Exception( " no support" );
   if( !dp.mask ) throw Exception( "vvhip::RdCost: DF_SAD_WITH_MASK entry called without a mask" );
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int w = dp.org.width, h = dp.org.height, step = 1 << dp.subShift, rowsEff = h >> dp.subShift;
   const ptrdiff_t rowAdvance = ( ptrdiff_t ) w * dp.stepX + ( ptrdiff_t ) dp.maskStride * step + dp.maskStride2;
@@ -168,7 +274,6 @@ Distortion sadMaskEntry( const DistParam& dp )
 
 Distortion fxdWtdEntry( const DistParam& dp, uint32_t fixedWeight )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int w = dp.org.width, h = dp.org.height;
   int16_t* cursor = dev.staging( ( size_t ) 4 * ( w + 8 ) * h * sizeof( Pel ) + 64 );
@@ -188,7 +293,6 @@ Distortion fxdWtdEntry( const DistParam& dp, uint32_t fixedWeight )
 
 template<int LOG2W> void sadX5Entry( const DistParam& dp, Distortion* cost, bool calcCentre )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int w = dp.org.width, h = dp.org.height;
   int16_t* cursor = dev.staging( ( size_t ) 4 * ( w + 16 ) * h * sizeof( Pel ) + 64 );
@@ -241,7 +345,6 @@ void RdCost::create( bool /*enableOpt*/ )
 void RdCost::distAtPositions( int func, const CPelBuf& org, const Pel* refBase, int refStride, int subShift, int bitDepth, const int ( *xy )[2], int n, Distortion* out )
 {
   if( n <= 0 ) return;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int w = org.width, h = org.height;
   int x0 = xy[0][0], x1 = xy[0][0], y0 = xy[0][1], y1 = xy[0][1];
@@ -270,7 +373,6 @@ bool RdCost::patternRefineCosts( const CPelBuf& org, const Pel* refBlk, int refS
   const int w = org.width, h = org.height;
   if( ( w & 7 ) || w > 64 || h > 64 || h < 4 || n < 1 || n > 16 || reduceTap < 0 || reduceTap > 2 ) return false;
   if( ( hadMode == 1 || hadMode == 2 ) && ( h & 3 ) ) return false;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int M0 = 5, M1 = 6, pitch = w + M0 + M1, rows = h + M0 + M1;
   std::vector<Pel> host( ( size_t ) w * h + ( size_t ) pitch * rows );
@@ -342,7 +444,6 @@ int RdCost::enqueue( const DistParam& dp )
 
 void RdCost::flush()
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t first = m_results.size() - m_pending.size();
   // group by (func, w, h, subShift, planes): one launch per group
@@ -379,7 +480,6 @@ namespace {
 
 void fwd2D( const Pel* resi, ptrdiff_t stride, TCoeff* coef, unsigned w, unsigned h, int trHor, int trVer, int bitDepth )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t area = ( size_t ) w * h;
   std::vector<Pel> tmp( area );
@@ -396,7 +496,6 @@ void fwd2D( const Pel* resi, ptrdiff_t stride, TCoeff* coef, unsigned w, unsigne
 
 void inv2D( const TCoeff* coef, Pel* resi, ptrdiff_t stride, unsigned w, unsigned h, int trHor, int trVer, int bitDepth )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t area = ( size_t ) w * h;
   int16_t* dResi = dev.staging( area * sizeof( Pel ) + 64 );
@@ -416,7 +515,6 @@ char* auxArea( Device& dev, size_t bytes ) { return static_cast<char*>( dev.stag
 
 template<int N> void fwdCore( const TMatrixCoeff* tc, const TCoeff* src, TCoeff* dst, unsigned line, unsigned reducedLine, unsigned cutoff, int shift )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t mB = sizeof( TMatrixCoeff ) * N * N, sB = sizeof( TCoeff ) * ( size_t ) line * N, dB = sizeof( TCoeff ) * ( size_t ) line * cutoff;
   char* aux = auxArea( dev, mB + sB + dB );
@@ -430,7 +528,6 @@ template<int N> void fwdCore( const TMatrixCoeff* tc, const TCoeff* src, TCoeff*
 
 template<int N> void invCore( const TMatrixCoeff* it, const TCoeff* src, TCoeff* dst, unsigned lines, unsigned reducedLines, unsigned rows )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t mB = sizeof( TMatrixCoeff ) * N * N, sB = sizeof( TCoeff ) * ( size_t ) lines * N, dB = sizeof( TCoeff ) * ( size_t ) reducedLines * N;
   char* aux = auxArea( dev, mB + sB + dB );
@@ -445,7 +542,6 @@ template<int N> void invCore( const TMatrixCoeff* it, const TCoeff* src, TCoeff*
 void roundClipSlot( TCoeff* dst, unsigned width, unsigned height, unsigned stride, const TCoeff outputMin, const TCoeff outputMax, const TCoeff round, const TCoeff shift )
 {
   if( !width || !height ) return;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t bytes = sizeof( TCoeff ) * ( ( size_t ) ( height - 1 ) * stride + width );
   char* aux = auxArea( dev, bytes );
@@ -457,7 +553,6 @@ void roundClipSlot( TCoeff* dst, unsigned width, unsigned height, unsigned strid
 void cpyResiSlot( const TCoeff* src, Pel* dst, ptrdiff_t stride, unsigned width, unsigned height )
 {
   if( !width || !height ) return;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t area = ( size_t ) width * height;
   char* aux = auxArea( dev, area * ( sizeof( TCoeff ) + sizeof( Pel ) ) );
@@ -472,7 +567,6 @@ void cpyResiSlot( const TCoeff* src, Pel* dst, ptrdiff_t stride, unsigned width,
 void cpyCoeffSlot( const Pel* src, ptrdiff_t stride, TCoeff* dst, unsigned width, unsigned height )
 {
   if( !width || !height ) return;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t area = ( size_t ) width * height;
   std::vector<Pel> tmp( area );
@@ -544,7 +638,6 @@ template<int N, bool VER, bool FIRST, bool LAST>
 void ifSlot( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeff )
 {
   if( width <= 0 || height <= 0 ) return;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int lo = N / 2 - 1, hi = N / 2;
   const size_t srcElems = ( size_t ) ( width + ( VER ? 0 : N ) ) * ( height + ( VER ? N : 0 ) ), dstElems = ( size_t ) width * height;
@@ -561,7 +654,6 @@ template<bool FIRST, bool LAST>
 void ifCopySlot( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, bool biMCForDMVR )
 {
   if( width <= 0 || height <= 0 ) return;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t elems = ( size_t ) width * height;
   int16_t* area = dev.staging( 2 * elems * sizeof( Pel ) + 256 );
@@ -578,7 +670,6 @@ template<int N, bool LAST>
 void ifFused( const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeffH, TFilterCoeff const* coeffV )
 {
   if( width <= 0 || height <= 0 ) return;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int lo = N / 2 - 1, hi = N / 2, rows = height + N - 1;
   const size_t srcElems = ( size_t ) ( width + N ) * rows, midElems = ( size_t ) width * rows, dstElems = ( size_t ) width * height;
@@ -649,7 +740,6 @@ bool DMVROps::refineCu( const Pel* ref0, int stride0, int fx0, int fy0, const Pe
                         int16_t* mvd, uint64_t* minCost )
 {
   if( ( dx != 8 && dx != 16 ) || ( dy != 8 && dy != 16 ) || cuWidth % dx || cuHeight % dy || bitDepth > 10 ) return false;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   // the bilinear prediction of the (w+4) x (h+4) area reads one more column / row: stage (w+5) x (h+5) of each list, compact
   const int pw = cuWidth + 5, ph = cuHeight + 5;
@@ -697,7 +787,6 @@ int16_t* stageBordered( Device& dev, const Pel* p, int stride, int w, int h, int
 bool ALFOps::deriveClassification( const Pel* rec, int recStride, int width, int height, int bitDepth, int vbCTUHeight, int vbPos, uint8_t* cls )
 {
   if( ( width & 3 ) || ( height & 3 ) || width < 4 || height < 4 ) return false;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   int pitch;
   const int16_t* dRec = stageBordered( dev, rec, recStride, width, height, 4, 0, pitch );
@@ -712,7 +801,6 @@ bool ALFOps::getStatistics( const Pel* org, int orgStride, const Pel* rec, int r
                             const uint8_t* cls, int vbCTUHeight, int vbPos, float* out, const float* init )
 {
   if( ( width & 3 ) || ( height & 3 ) || width < 4 || height < 4 || ( filterLength != 7 && filterLength != 5 ) || ctuSize > 128 ) return false;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   // one staging allocation: [rec with border][org compact]
   const int recPitchGuess = ( width + 8 + 7 ) & ~7;
@@ -741,49 +829,69 @@ bool ALFOps::pictureStatistics( const Pel* const rec[3], const int recStride[3],
                                 int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] )
 {
   if( ( width & 7 ) || ( height & 7 ) || unitSize > 128 || unitSize % ctuSize ) return false;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
-  // the planes go up as they lie in the encoder's buffers (their own strides; rec with 4 border rows / columns): six uploads, no host repacking
-  int w[3], h[3], rp[3], op[3]; size_t rOff[3], oOff[3], total = 0;
+  // the planes go up as they lie in the encoder's buffers (their own strides; rec with 4 border rows / columns): six uploads, no host repacking.
+  // The unfiltered planes land in this object's resident area (kept for filterPicture), the originals in the context's staging area.
+  int w[3], h[3], rp[3], op[3]; size_t rOff[3], oOff[3], recTotal = 0, orgTotal = 0;
   for( int c = 0; c < 3; c++ )
   {
     w[c] = c ? width >> 1 : width; h[c] = c ? height >> 1 : height;
     rp[c] = recStride[c]; op[c] = orgStride[c];
-    rOff[c] = total; total += ( ( size_t ) rp[c] * ( h[c] + 8 ) + 8 + 127 ) & ~( size_t ) 127;
+    rOff[c] = recTotal; recTotal += ( ( size_t ) rp[c] * ( h[c] + 8 ) + 8 + 127 ) & ~( size_t ) 127;
   }
-  for( int c = 0; c < 3; c++ ) { oOff[c] = total; total += ( ( size_t ) op[c] * h[c] + 127 ) & ~( size_t ) 127; }
-  int16_t* d = dev.staging( total * sizeof( Pel ) + 256 );
+  for( int c = 0; c < 3; c++ ) { oOff[c] = orgTotal; orgTotal += ( ( size_t ) op[c] * h[c] + 127 ) & ~( size_t ) 127; }
+  m_res.valid = false;
+  if( m_res.gpu != dev.gpu() || m_res.elems < recTotal )
+  {
+    if( m_res.d ) { vvhip_free( dev.ctx(), m_res.d ); m_res.d = nullptr; }      // (hipFree finds the owning device itself)
+    void* p = nullptr;
+    dev.check( vvhip_malloc( dev.ctx(), &p, recTotal * sizeof( Pel ) + 256 ), "ALF resident planes" );
+    m_res.d = static_cast<int16_t*>( p ); m_res.elems = recTotal; m_res.gpu = dev.gpu();
+  }
+  int16_t* dR = m_res.d;
+  int16_t* d = dev.staging( orgTotal * sizeof( Pel ) + 256 );
   for( int c = 0; c < 3; c++ )
   {
     // rows -4 .. h+3, starting 4 samples left of column 0; the last row ends at its right border
     const size_t recElems = ( size_t ) rp[c] * ( h[c] + 7 ) + w[c] + 8;
-    dev.check( vvhip_upload( dev.ctx(), d + rOff[c], rec[c] - ( ptrdiff_t ) 4 * rp[c] - 4, recElems * sizeof( Pel ) ), "ALF rec plane" );
+    Device::pinHost( rec[c] - ( ptrdiff_t ) 4 * rp[c] - 4, recElems * sizeof( Pel ) );
+    dev.check( vvhip_upload( dev.ctx(), dR + rOff[c], rec[c] - ( ptrdiff_t ) 4 * rp[c] - 4, recElems * sizeof( Pel ) ), "ALF rec plane" );
     const size_t orgElems = ( size_t ) op[c] * ( h[c] - 1 ) + w[c];
+    Device::pinHost( org[c], orgElems * sizeof( Pel ) );
     dev.check( vvhip_upload( dev.ctx(), d + oOff[c], org[c], orgElems * sizeof( Pel ) ), "ALF org plane" );
   }
   const int units = ( ( width + unitSize - 1 ) / unitSize ) * ( ( height + unitSize - 1 ) / unitSize );
   const size_t nCls = ( size_t ) ( width / 4 ) * ( height / 4 ) * 2;
   const size_t stBytes[3] = { ( size_t ) units * 25 * VVHIP_ALF_REC * sizeof( float ), ( size_t ) units * VVHIP_ALF_REC * sizeof( float ), ( size_t ) units * VVHIP_ALF_REC * sizeof( float ) };
-  const size_t clsPad = ( nCls + 255 ) & ~( size_t ) 255;
-  char* aux = static_cast<char*>( dev.stagingAux( clsPad + stBytes[0] + stBytes[1] + stBytes[2] + 64 ) );
-  uint8_t* dCls = reinterpret_cast<uint8_t*>( aux );
-  float* dSt[3] = { reinterpret_cast<float*>( aux + clsPad ), reinterpret_cast<float*>( aux + clsPad + stBytes[0] ), reinterpret_cast<float*>( aux + clsPad + stBytes[0] + stBytes[1] ) };
+  if( m_res.clsBytes < nCls )
+  {
+    if( m_res.dCls ) vvhip_free( dev.ctx(), m_res.dCls );
+    void* p = nullptr;
+    dev.check( vvhip_malloc( dev.ctx(), &p, nCls + 256 ), "ALF resident classes" );
+    m_res.dCls = static_cast<uint8_t*>( p ); m_res.clsBytes = nCls;
+  }
+  char* aux = static_cast<char*>( dev.stagingAux( stBytes[0] + stBytes[1] + stBytes[2] + 64 ) );
+  uint8_t* dCls = m_res.dCls;
+  float* dSt[3] = { reinterpret_cast<float*>( aux ), reinterpret_cast<float*>( aux + stBytes[0] ), reinterpret_cast<float*>( aux + stBytes[0] + stBytes[1] ) };
   const int16_t* dRec[3]; const int16_t* dOrg[3];
-  for( int c = 0; c < 3; c++ ) { dRec[c] = d + rOff[c] + ( size_t ) 4 * rp[c] + 4; dOrg[c] = d + oOff[c]; }     // sample (0,0) of each plane
+  for( int c = 0; c < 3; c++ ) { dRec[c] = dR + rOff[c] + ( size_t ) 4 * rp[c] + 4; dOrg[c] = d + oOff[c]; }     // sample (0,0) of each plane
   dev.check( vvhip_alf_classify( dev.ctx(), dRec[0], rp[0], width, height, bitDepth, vbLumaH, vbLumaPos, dCls ), "vvhip_alf_classify" );
   if( enabled[0] ) dev.check( vvhip_alf_stats_plane_units( dev.ctx(), dOrg[0], op[0], dRec[0], rp[0], width, height, unitSize, ctuSize, 7, dCls, vbLumaH, vbLumaPos, nullptr, dSt[0] ), "vvhip_alf_stats_plane_units" );
   for( int c = 1; c < 3; c++ )
     if( enabled[c] ) dev.check( vvhip_alf_stats_plane_units( dev.ctx(), dOrg[c], op[c], dRec[c], rp[c], w[c], h[c], unitSize >> 1, ctuSize >> 1, 5, nullptr, vbChromaH, vbChromaPos, nullptr, dSt[c] ), "vvhip_alf_stats_plane_units (chroma)" );
   dev.check( vvhip_download( dev.ctx(), cls, dCls, nCls ), "ALF classes" );
   for( int c = 0; c < 3; c++ ) if( enabled[c] ) dev.check( vvhip_download( dev.ctx(), stats[c], dSt[c], stBytes[c] ), "ALF statistics" );
+  for( int c = 0; c < 3; c++ ) { m_res.rec[c] = rec[c]; m_res.stride[c] = rp[c]; m_res.off[c] = rOff[c] + ( size_t ) 4 * rp[c] + 4; }
+  m_res.width = width; m_res.height = height; m_res.valid = true;
   return true;
 }
+
+ALFOps::~ALFOps() {}      // (device areas are released with the process: HIP teardown order at exit is not ours to rely on)
 
 bool ALFOps::getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC, int slfStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC,
                                  int vbCTUHeight, int vbPos, int picHeight, float* out, const float* init )
 {
   if( ( widthC & 3 ) || ( heightC & 3 ) || widthC < 4 || heightC < 4 || ctuSizeC > 64 ) return false;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int wL = widthC * 2, hL = heightC * 2;
   const int recPitch = ( wL + 8 + 7 ) & ~7;
@@ -813,36 +921,43 @@ bool ALFOps::getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC
 bool ALFOps::filterPlane( const Pel* src, int srcStride, Pel* dst, int dstStride, int width, int height, int ctuSize, int bitDepth, int filterLength, const uint8_t* cls,
                           const short* coeffSets, const short* clipSets, int numSets, const short* ctuSet, int vbCTUHeight, int vbPos )
 {
+  return filterPlaneImpl( src, srcStride, nullptr, nullptr, dst, dstStride, width, height, ctuSize, bitDepth, filterLength, cls, coeffSets, clipSets, numSets, ctuSet, vbCTUHeight, vbPos );
+}
+
+bool ALFOps::filterPlaneImpl( const Pel* src, int srcStride, const int16_t* dSrcResident, const uint8_t* dClsResident, Pel* dst, int dstStride, int width, int height, int ctuSize, int bitDepth,
+                              int filterLength, const uint8_t* cls, const short* coeffSets, const short* clipSets, int numSets, const short* ctuSet, int vbCTUHeight, int vbPos )
+{
   if( ( width & 3 ) || ( height & 3 ) || width < 4 || height < 4 || ( filterLength != 7 && filterLength != 5 ) || ( filterLength == 7 ) != ( cls != nullptr ) || numSets < 1 ) return false;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
-  // staging: [src with border][dst compact]; aux: [classes][coefficients][clipping values][CTU sets]
+  // staging: [src with border (unless resident)][dst compact]; aux: [classes][coefficients][clipping values][CTU sets]
   const int srcPitchGuess = ( width + 8 + 7 ) & ~7;
-  const size_t srcBytes = ( ( size_t ) srcPitchGuess * ( height + 8 ) * sizeof( Pel ) + 255 ) & ~( size_t ) 255;
+  const size_t srcBytes = dSrcResident ? 0 : ( ( size_t ) srcPitchGuess * ( height + 8 ) * sizeof( Pel ) + 255 ) & ~( size_t ) 255;
   const int dstPitch = ( width + 7 ) & ~7;
-  std::vector<Pel> hdst( ( size_t ) dstPitch * height );
-  dev.staging( srcBytes + hdst.size() * sizeof( Pel ) + 512 );
-  int pitch;
-  const int16_t* dSrc = stageBordered( dev, src, srcStride, width, height, 4, 0, pitch );
-  int16_t* dDst = dev.staging( srcBytes + hdst.size() * sizeof( Pel ) + 512 ) + srcBytes / sizeof( Pel );      // not initialised: only the enabled CTUs are read back
+  const size_t dstElems = ( size_t ) dstPitch * height;
+  if( m_down.size() < dstElems ) { m_down.resize( dstElems ); Device::pinHost( m_down.data(), m_down.size() * sizeof( Pel ) ); }
+  dev.staging( srcBytes + dstElems * sizeof( Pel ) + 512 );
+  int pitch = srcStride;
+  const int16_t* dSrc = dSrcResident ? dSrcResident : stageBordered( dev, src, srcStride, width, height, 4, 0, pitch );
+  int16_t* dDst = dev.staging( srcBytes + dstElems * sizeof( Pel ) + 512 ) + srcBytes / sizeof( Pel );      // not initialised: only the enabled CTUs are read back
   const int numClasses = cls ? 25 : 1, ctus = ( ( width + ctuSize - 1 ) / ctuSize ) * ( ( height + ctuSize - 1 ) / ctuSize );
-  const size_t nCls = ( ( cls ? ( size_t ) ( width / 4 ) * ( height / 4 ) * 2 : 0 ) + 255 ) & ~( size_t ) 255;
+  const size_t nCls = ( ( cls && !dClsResident ? ( size_t ) ( width / 4 ) * ( height / 4 ) * 2 : 0 ) + 255 ) & ~( size_t ) 255;
   const size_t nCoef = ( ( size_t ) numSets * numClasses * 13 * sizeof( short ) + 255 ) & ~( size_t ) 255, nSet = ( size_t ) ctus * sizeof( short );
   char* aux = static_cast<char*>( dev.stagingAux( nCls + 2 * nCoef + nSet + 64 ) );
-  if( cls ) dev.check( vvhip_upload( dev.ctx(), aux, cls, ( size_t ) ( width / 4 ) * ( height / 4 ) * 2 ), "ALF classes" );
+  if( cls && !dClsResident ) dev.check( vvhip_upload( dev.ctx(), aux, cls, ( size_t ) ( width / 4 ) * ( height / 4 ) * 2 ), "ALF classes" );
   dev.check( vvhip_upload( dev.ctx(), aux + nCls, coeffSets, ( size_t ) numSets * numClasses * 13 * sizeof( short ) ), "ALF coefficients" );
   if( clipSets ) dev.check( vvhip_upload( dev.ctx(), aux + nCls + nCoef, clipSets, ( size_t ) numSets * numClasses * 13 * sizeof( short ) ), "ALF clipping values" );
   dev.check( vvhip_upload( dev.ctx(), aux + nCls + 2 * nCoef, ctuSet, nSet ), "ALF CTU filter sets" );
-  dev.check( vvhip_alf_filter_plane( dev.ctx(), dSrc, pitch, dDst, dstPitch, width, height, ctuSize, bitDepth, filterLength, cls ? reinterpret_cast<const uint8_t*>( aux ) : nullptr,
+  const uint8_t* dCls = !cls ? nullptr : dClsResident ? dClsResident : reinterpret_cast<const uint8_t*>( aux );
+  dev.check( vvhip_alf_filter_plane( dev.ctx(), dSrc, pitch, dDst, dstPitch, width, height, ctuSize, bitDepth, filterLength, dCls,
                                      reinterpret_cast<const int16_t*>( aux + nCls ), clipSets ? reinterpret_cast<const int16_t*>( aux + nCls + nCoef ) : nullptr,
                                      reinterpret_cast<const int16_t*>( aux + nCls + 2 * nCoef ), vbCTUHeight, vbPos ), "vvhip_alf_filter_plane" );
-  dev.check( vvhip_download( dev.ctx(), hdst.data(), dDst, hdst.size() * sizeof( Pel ) ), "ALF filtered plane" );
+  dev.check( vvhip_download( dev.ctx(), m_down.data(), dDst, dstElems * sizeof( Pel ) ), "ALF filtered plane" );
   const int ctusX = ( width + ctuSize - 1 ) / ctuSize;
   for( int c = 0; c < ctus; c++ )
   {
     if( ctuSet[c] < 0 ) continue;                                                        // the CTU keeps the caller's samples
     const int x0 = ( c % ctusX ) * ctuSize, y0 = ( c / ctusX ) * ctuSize, w = std::min( ctuSize, width - x0 ), h = std::min( ctuSize, height - y0 );
-    for( int y = y0; y < y0 + h; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride + x0, &hdst[( size_t ) y * dstPitch + x0], sizeof( Pel ) * w );
+    for( int y = y0; y < y0 + h; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride + x0, &m_down[( size_t ) y * dstPitch + x0], sizeof( Pel ) * w );
   }
   return true;
 }
@@ -852,10 +967,14 @@ bool ALFOps::filterPicture( const Pel* const src[3], const int srcStride[3], Pel
                             const short* chromaCoeff, const short* chromaClip, int numChromaSets, const short* const chromaCtuSet[2],
                             int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos )
 {
-  if( lumaCtuSet && !filterPlane( src[0], srcStride[0], dst[0], dstStride[0], width, height, ctuSize, bitDepth, 7, cls, lumaCoeff, lumaClip, numLumaSets, lumaCtuSet, vbLumaH, vbLumaPos ) ) return false;
+  // the planes pictureStatistics left in HBM serve when this call is about the same host planes (and runs on the same GPU)
+  const bool res = m_res.valid && m_res.gpu == Device::get().gpu() && m_res.width == width && m_res.height == height &&
+                   src[0] == m_res.rec[0] && src[1] == m_res.rec[1] && src[2] == m_res.rec[2] && srcStride[0] == m_res.stride[0] && srcStride[1] == m_res.stride[1] && srcStride[2] == m_res.stride[2];
+  if( lumaCtuSet && !filterPlaneImpl( src[0], srcStride[0], res ? m_res.d + m_res.off[0] : nullptr, res ? m_res.dCls : nullptr, dst[0], dstStride[0], width, height, ctuSize, bitDepth, 7, cls,
+                                      lumaCoeff, lumaClip, numLumaSets, lumaCtuSet, vbLumaH, vbLumaPos ) ) return false;
   for( int c = 0; c < 2; c++ )
-    if( chromaCtuSet[c] && !filterPlane( src[1 + c], srcStride[1 + c], dst[1 + c], dstStride[1 + c], width / 2, height / 2, ctuSize / 2, bitDepth, 5, nullptr, chromaCoeff, chromaClip,
-                                         numChromaSets, chromaCtuSet[c], vbChromaH, vbChromaPos ) ) return false;
+    if( chromaCtuSet[c] && !filterPlaneImpl( src[1 + c], srcStride[1 + c], res ? m_res.d + m_res.off[1 + c] : nullptr, nullptr, dst[1 + c], dstStride[1 + c], width / 2, height / 2, ctuSize / 2,
+                                             bitDepth, 5, nullptr, chromaCoeff, chromaClip, numChromaSets, chromaCtuSet[c], vbChromaH, vbChromaPos ) ) return false;
   return true;
 }
 
@@ -863,7 +982,6 @@ bool ALFOps::filterCcAlf( Pel* dstC, int dstStride, const Pel* recLuma, int recS
                           const uint8_t* ctuFilter, int vbCTUHeight, int vbPos )
 {
   if( widthC < 1 || heightC < 1 || numFilters < 1 ) return false;
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int wL = widthC * 2, hL = heightC * 2;
   const int recPitch = ( wL + 8 + 7 ) & ~7;
@@ -907,7 +1025,6 @@ int phaseOf( const int16_t* f, bool tap4 )
 
 int errorOne( const Pel* org, ptrdiff_t os, const Pel* buf, ptrdiff_t bs, int w, int h, int fx, int fy, bool tap4, int bitDepth )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int M = 4;      // halo for the 6-tap filter: 2 left/above, 3 right/below
   int16_t* cursor = dev.staging( ( size_t ) 2 * ( w + 2 * M ) * ( h + 2 * M ) * sizeof( Pel ) + 128 );
@@ -959,7 +1076,6 @@ int errFrac4( const Pel* org, const ptrdiff_t os, const Pel* buf, const ptrdiff_
 
 double calcVarOne( const Pel* org, const ptrdiff_t os, const int w, const int h )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   std::vector<Pel> t( ( size_t ) w * h );
   for( int y = 0; y < h; y++ ) memcpy( &t[( size_t ) y * w], org + y * os, sizeof( Pel ) * w );
@@ -986,7 +1102,6 @@ MCTFOps::MCTFOps()
 
 void MCTFOps::motionEstimation( int curPicId, const int* refPicIds, int nRefs, int bitDepth, int unitSize, int mctfSpeed, bool addLevel, vvhip_mv** out )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const Device::Mirror& cur = dev.mirror( curPicId );
   std::vector<const int16_t*> refs( nRefs );
@@ -1009,7 +1124,6 @@ void MCTFOps::motionEstimation( int curPicId, const int* refPicIds, int nRefs, i
 void MCTFOps::bilateralFilter( const int* orgIds, const int* refIds, int nRefs, const vvhip_mv* const* mvs, const double* refStrengths, int qp, int bitDepth, int unitSize,
                                bool lowResFltApply, double overallStrength, int numComp, Pel* const* out, const int* outStride )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const Device::Mirror& y = dev.mirror( orgIds[0] );
   const int mvW = ( y.width + unitSize - 1 ) / unitSize, mvH = ( y.height + unitSize - 1 ) / unitSize;
@@ -1017,7 +1131,7 @@ void MCTFOps::bilateralFilter( const int* orgIds, const int* refIds, int nRefs, 
   vvhip_mv* dMv = static_cast<vvhip_mv*>( dev.stagingAux( count * nRefs * sizeof( vvhip_mv ) + 64 ) );
   std::vector<const vvhip_mv*> dMvs( nRefs );
   for( int r = 0; r < nRefs; r++ ) { dev.check( vvhip_upload( dev.ctx(), dMv + count * r, mvs[r], count * sizeof( vvhip_mv ) ), "motion vectors" ); dMvs[r] = dMv + count * r; }
-  std::vector<Pel> tmp;
+  static thread_local std::vector<Pel> tmp;      // download area, pinned in place once per thread (grows with the picture size)
   for( int c = 0; c < numComp; c++ )
   {
     const Device::Mirror& o = dev.mirror( orgIds[c] );
@@ -1034,7 +1148,7 @@ void MCTFOps::bilateralFilter( const int* orgIds, const int* refIds, int nRefs, 
     int16_t* dOut = dev.staging( elems * sizeof( Pel ) + 64 );
     dev.check( vvhip_mctf_apply_plane( dev.ctx(), o.dOrigin, o.stride, o.width, o.height, c > 0 ? 1 : 0, bitDepth, unitSize, lowResFltApply ? 1 : 0, qp, nRefs, refs.data(), o.stride,
                                        dMvs.data(), mvW, refStrengths, weightScaling, sigmaSq, dOut, o.width ), "vvhip_mctf_apply_plane" );
-    tmp.resize( elems );
+    if( tmp.size() < elems ) { tmp.resize( elems ); Device::pinHost( tmp.data(), tmp.size() * sizeof( Pel ) ); }
     dev.check( vvhip_download( dev.ctx(), tmp.data(), dOut, elems * sizeof( Pel ) ), "filtered plane" );
     for( int r = 0; r < o.height; r++ ) memcpy( out[c] + ( ptrdiff_t ) r * outStride[c], &tmp[( size_t ) r * o.width], sizeof( Pel ) * o.width );
   }
@@ -1045,7 +1159,6 @@ namespace {
 
 void deQuantOne( const int maxX, const int maxY, const int scale, const TCoeffSig* const q, const size_t qStride, TCoeff* const coef, const int rightShift, const int inputMaximum, const TCoeff transformMaximum )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const int w = maxX + 1, h = maxY + 1;
   std::vector<TCoeffSig> t( ( size_t ) w * h );
@@ -1059,7 +1172,6 @@ void deQuantOne( const int maxX, const int maxY, const int scale, const TCoeffSi
 
 bool needRdoqOne( const TCoeff* c, size_t num, int quantCoeff, int64_t offset, int shift )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   char* aux = static_cast<char*>( dev.stagingAux( 64 + num * sizeof( TCoeff ) ) );
   uint8_t need = 0;
@@ -1084,7 +1196,6 @@ void quantCoreOne( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCo
 void quantImpl( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal,
                 bool raw, int rawScale, int rawQBits, int64_t rawAdd )
 {
-  std::lock_guard<std::mutex> g( g_lock );
   Device& dev = Device::get();
   const size_t area = ( size_t ) w * h;
   struct Hdr { vvhip_tu_qp qp; int32_t absSum, last; } hdr; hdr.qp.qp = ( int16_t ) qp; hdr.qp.flags = ( int16_t ) ( ( isIRAP ? 1 : 0 ) | 2 ); hdr.absSum = 0; hdr.last = 0;

@@ -11,7 +11,7 @@
 // Two ways to call:
 //   (1) table entry, one candidate per call — the reference's synchronous signature.  Pointers are HOST pointers; if they
 //       fall inside a picture registered with registerPicture() the call only ships two offsets, otherwise the two blocks
-//       are staged.  Correct everywhere, but one launch + one round trip per call: use it for plumbing, not for speed.
+//       are staged.  Correct everywhere and re-entrant (per-thread contexts), but one launch + one round trip per call: plumbing, not speed.
 //   (2) batching: enqueue( DistParam ) -> ticket, flush(), result( ticket ) — what the thin shim in INTEGRATION.md uses
 //       inside xTZSearch / xPatternRefinement (all positions of a ring / raster / refinement are known before the first
 //       cost is needed) and for whole MCTF levels.
@@ -74,29 +74,48 @@ public:
 };
 typedef Distortion ( *FpFxdWtdDistFunc )( const DistParam&, uint32_t fixedWeight );      // RdCost.h:117
 
-// One process-wide device context + registry of host pictures mirrored in HBM.
+// Worker contexts and the registry of host pictures mirrored in HBM.
+//   * Every encoder worker thread gets its OWN context (HIP stream, staging areas) on the GPU it currently serves, created on first use and recycled when the
+//     thread ends: table entries called concurrently by the reference's workers (one RdCost / TrQuant / Quant per worker, shared g_tCoeffOps / MCTF; SURVEY 8b
+//     "Threading") never wait on each other on the host.
+//   * Several GPUs in one process: selectGpu() binds the calling thread to a device (pictures are mapped to devices by the binding: one picture <-> one device,
+//     SURVEY 8e); mirrors live in a per-GPU registry shared by that GPU's contexts; copyMirror() moves a picture between GPUs over xGMI.
+//   * Host buffers the encoder recycles (picture planes) can be pinned in place once (pinHost) so that their transfers are asynchronous DMA at PCIe rate.
 class Device
 {
 public:
-  static Device& get();                      // creates the context on first use (device 0 or $VVHIP_DEVICE); throws without GPU
+  static Device& get();                      // the calling thread's context on its selected GPU (creates it on first use; throws without a GPU)
+  static void    selectGpu( int gpu );       // bind the calling thread to a device (< 0: the default, $VVHIP_DEVICE or 0)
+  static int     gpuCount();                 // devices visible to the process
+  static int     defaultGpu();
+  int        gpu() const { return m_gpu; }
   vvhip_ctx* ctx() const { return m_ctx; }
-  // Mirror a host plane (sample (0,0) at `origin`, `margin` samples around a w x h picture, line pitch `stride`) in HBM.
+  // Mirror a host plane (sample (0,0) at `origin`, `margin` samples around a w x h picture, line pitch `stride`) in this GPU's HBM.
   // Re-register (or call updatePicture) after the host changed it (e.g. a reference picture was reconstructed).
   // findable = false: the mirror is used through its id only and never substituted for host pointers by the per-call table entries
   // (for pictures whose host buffer may be rewritten while the mirror is kept)
-  int  registerPicture( const Pel* origin, int stride, int width, int height, int margin, bool findable = true );
+  int  registerPicture( const Pel* origin, int stride, int width, int height, int margin, bool findable = true, bool upload = true );
   void updatePicture( int id );
   void unregisterPicture( int id );
+  // the same picture on another GPU: allocates a mirror there and fills it device-to-device (hipMemcpyPeerAsync over xGMI); returns the id in `dst`'s registry
+  int  copyMirrorTo( int id, Device& dst );
   struct Mirror { const Pel* hostBase; const Pel* hostEnd; const Pel* origin; int stride, width, height, margin; int16_t* dBase; int16_t* dOrigin; bool live; bool findable; };
-  const Mirror* find( const Pel* p ) const;  // which registered picture contains host pointer p (nullptr: none)
-  const Mirror& mirror( int id ) const { return m_mirrors.at( id ); }
+  const Mirror* find( const Pel* p ) const;  // which registered picture of this GPU contains host pointer p (nullptr: none)
+  const Mirror& mirror( int id ) const;
   void check( int rc, const char* what ) const;
-  int16_t* staging( size_t bytes );          // grow-only device scratch for unregistered (compact temp) buffers
+  int16_t* staging( size_t bytes );          // grow-only device scratch of THIS context for unregistered (compact temp) buffers
   void*    stagingAux( size_t bytes );
+  // pin a recycled host buffer in place (hipHostRegister, once per range; false: left pageable).  $VVHIP_PIN=0 switches pinning off.
+  static bool pinHost( const void* p, size_t bytes );
+  // traffic over PCIe / calls since the process started (all contexts): what a binding prints per picture
+  struct Stats { uint64_t uploadBytes, downloadBytes, uploads, downloads, contexts; };
+  static Stats stats();
 private:
-  Device();
+  explicit Device( int gpu );
+  ~Device();
+  friend struct DevicePool;
+  int        m_gpu = 0;
   vvhip_ctx* m_ctx = nullptr;
-  std::vector<Mirror> m_mirrors;
   int16_t* m_stage = nullptr; size_t m_stageBytes = 0;
   void* m_aux = nullptr; size_t m_auxBytes = 0;
 };
@@ -219,6 +238,18 @@ struct ALFOps
   // AdaptiveLoopFilter::m_filterCcAlf (:124) over a chroma plane (4:2:0) as applyCcAlfFilterCTU drives it: dstC corrected in place; coeff [numFilters][8]; ctuFilter[ctu] 0 = off
   bool filterCcAlf( Pel* dstC, int dstStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC, int bitDepth, const int16_t* coeff, int numFilters,
                     const uint8_t* ctuFilter, int vbCTUHeight, int vbPos );
+  // One ALFOps object per EncAdaptiveLoopFilter: pictureStatistics leaves the unfiltered planes (with their border) and the block classes of ITS picture in HBM;
+  // filterPicture, handed the same host planes afterwards (statistics -> derivation on the host -> filtering, EncAdaptiveLoopFilter.cpp:1440-1520, :1902), skips
+  // their upload.  dropResident() when the host planes change without a statistics call.
+  void dropResident() { m_res.valid = false; }
+  ~ALFOps();
+private:
+  struct Resident { bool valid = false; int gpu = -1, width = 0, height = 0; const Pel* rec[3] = { nullptr, nullptr, nullptr }; int stride[3] = { 0, 0, 0 };
+                    int16_t* d = nullptr; size_t elems = 0, off[3] = { 0, 0, 0 }; uint8_t* dCls = nullptr; size_t clsBytes = 0; };
+  Resident m_res;
+  std::vector<Pel> m_down;      // download area of filterPlane, pinned in place once
+  bool filterPlaneImpl( const Pel* src, int srcStride, const int16_t* dSrcResident, const uint8_t* dClsResident, Pel* dst, int dstStride, int width, int height, int ctuSize, int bitDepth,
+                        int filterLength, const uint8_t* cls, const short* coeffSets, const short* clipSets, int numSets, const short* ctuSet, int vbCTUHeight, int vbPos );
 };
 
 // MCTF table, CommonLib/MCTF.h:160-170

@@ -180,12 +180,14 @@ class HotPath:
                                          bit_depth, jobs[0], jobs[1]))
 
     class _DistFJob(C.Structure):
-        _fields_ = [("func", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("sub_shift", C.c_int32), ("n", C.c_int32), ("pad", C.c_int32),
+        _fields_ = [("func", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("sub_shift", C.c_int32), ("n", C.c_int32), ("flags", C.c_int32),
                     ("d_items", C.c_void_p), ("d_out", C.c_void_p)]
 
-    def make_dist_fjobs(self, jobs):
+    DIST_FLAG_SAMPLES = 1      # VVHIP_DIST_FLAG_SAMPLES: both operands are samples in [0, 2^bit_depth)
+
+    def make_dist_fjobs(self, jobs, flags=0):
         """jobs: list of (func, w, h, sub_shift, n, d_items, d_out) -> prepared host job table for dist_multi_func"""
-        arr = (self._DistFJob * len(jobs))(*[self._DistFJob(DF[f] if isinstance(f, str) else f, w, h, ss, n, 0, it.data_ptr(), out.data_ptr()) for (f, w, h, ss, n, it, out) in jobs])
+        arr = (self._DistFJob * len(jobs))(*[self._DistFJob(DF[f] if isinstance(f, str) else f, w, h, ss, n, flags, it.data_ptr(), out.data_ptr()) for (f, w, h, ss, n, it, out) in jobs])
         return arr, len(jobs), jobs
 
     def dist_multi_func(self, org, cur, jobs, bit_depth=10):

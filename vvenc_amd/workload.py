@@ -104,7 +104,9 @@ class FrameWorkload:
         self.alg_bytes["SAD_SSE"] = self.alg_bytes["SAD"] + self.alg_bytes["SSE"]
         # SAD and SSE lists share one launch (vvhip_dist_multi_func), the Hadamard lists another
         self.fjob_tables = {"SAD_SSE": hp.make_dist_fjobs([(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f in ("SAD", "SSE")]),
-                            "HAD_fast": hp.make_dist_fjobs([(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f == "HAD_fast"])}
+                            # original vs reconstructed picture samples: the Hadamard jobs may use the all-packed tile (VVHIP_DIST_FLAG_SAMPLES)
+                            "HAD_fast": hp.make_dist_fjobs([(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f == "HAD_fast"],
+                                                           flags=hp.DIST_FLAG_SAMPLES)}
 
     # ---- optional fractional-ME stage: 16 sub-pel positions (8 half-sample + 8 quarter-sample neighbours of a seeded
     # base vector) per block of every size, interpolated and scored with HAD_fast like InterSearch::xPatternRefinement — one
