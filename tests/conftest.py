@@ -9,6 +9,7 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    config.addinivalue_line("markers", "sim: host-logic tests of shim + binding against the CPU test double of the device library (tests/sim)")
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs oracle/_ref/libvvenc_ref.so (the compiled reference)")
 

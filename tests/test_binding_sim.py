@@ -1,0 +1,103 @@
+"""CPU tier: the HOST LOGIC above the C ABI — table-shaped shim, per-thread contexts, picture registry, the VVenC binding (hooks, batching and replay, --SIMD=HIP
+selection, picture -> device mapping) — exercised without a GPU.  The real reference encoder (oracle/_ref, compiled from /root/reference) runs with the binding installed
+while tests/sim/libvvhip_sim.so, a TEST DOUBLE of the device library (device memory = host memory, kernels = the CPU oracle), is injected with LD_PRELOAD; the bitstream
+must equal the CPU encoder's.  This says nothing about the HIP kernels (the -m gpu tests do); it pins everything around them, for every preset of BASELINE.json."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import e2e_util  # noqa: E402
+from test_e2e_bitstream import run, ALL_TABLES, BATCHED_SITES  # noqa: E402
+
+SIM = os.path.join(ROOT, "tests", "sim", "libvvhip_sim.so")
+pytestmark = pytest.mark.sim
+
+
+def need():
+    if not (os.path.exists(e2e_util.REF_HIP_SO) and os.path.exists(SIM)):
+        pytest.skip("needs oracle/_ref/libvvenc_ref_hip.so and tests/sim/libvvhip_sim.so (python __graft_entry__.py)")
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present: the test double refuses to stand in for it")
+
+
+def sim_env(**extra):
+    e = {"LD_PRELOAD": SIM}
+    e.update({k: str(v) for k, v in extra.items()})
+    return e
+
+
+CLIP = dict(w=208, h=120, in_bd=10, int_bd=10)
+
+
+@pytest.mark.parametrize("preset", ["faster", "fast", "medium"])
+def test_every_hook_every_preset(preset):
+    """all tables + batched search sites + per-CTU ALF hooks, one encoder thread"""
+    need()
+    clip = dict(CLIP, frames=5, preset=preset)
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, mask=ALL_TABLES + BATCHED_SITES + 2048 + 4096 + 16384 + 32768), env=sim_env())
+    assert hip["calls"][0] > 1000 and hip["calls"][10] > 50 and hip["calls"][12] > 50 and hip["calls"][14] >= 4, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.parametrize("preset", ["faster", "medium"])
+def test_simd_switch_selects_the_binding(preset):
+    """--SIMD=HIP through vvenc_set_SIMD_extension: production set (MCTF search with all references of a picture in one device call + filter, ALF statistics + filtering with
+    resident planes), 4 encoder threads -> several worker contexts"""
+    need()
+    clip = dict(CLIP, frames=17, preset=preset, threads=4)
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, simd="HIP"), env=sim_env())
+    c = hip["calls"]
+    assert c[9] >= 1 and c[16] >= 1 and c[19] >= 1, c
+    assert c[21] >= 1 and c[7] // 1000000 > c[21], c                   # fewer device ME calls than motion fields: references were batched
+    assert c[27] >= 2 and c[28] == 1, c                                # worker contexts, one GPU
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+def test_simd_switch_refuses_without_device():
+    """no device library double, no GPU: --SIMD=HIP must fail loudly (the encoder reports the request as unsupported), never fall back silently"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import e2e_util as E; L = E.load(True); "
+                        "yuv = E.synth_yuv(64, 64, 2, 8, 1); E.encode(L, yuv, 64, 64, 8, 8, simd='HIP')" % os.path.join(ROOT, "tests")], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and ("no MI355X context" in r.stderr or "refused" in r.stderr), (r.returncode, r.stderr[-500:])
+
+
+def test_pictures_shard_over_devices():
+    """one picture <-> one device: two and four simulated devices, MCTF-filtered pictures and ALF pictures round-robin, originals needed on a second device are copied
+    device-to-device; bitstream unchanged"""
+    need()
+    clip = dict(CLIP, frames=25, preset="medium", threads=4)
+    cpu = run(dict(clip, hip=False, mask=0))
+    for n in (2, 4):
+        hip = run(dict(clip, hip=True, simd="HIP"), env=sim_env(VVHIP_SIM_DEVICES=n, VVHIP_GPUS="all"))
+        c = hip["calls"]
+        assert c[28] == n and c[27] >= n, c                            # GPUs in use, contexts on each
+        assert c[24] >= 1, c                                           # device-to-device picture copies happened
+        assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (n, cpu, hip)
+
+
+def test_lfnst_tus_stay_with_the_cpu_quantiser():
+    need()
+    clip = dict(CLIP, frames=5, preset="fast", options="RDOQ=0;DepQuant=0;LFNST=1")
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, mask=4), env=sim_env())
+    assert hip["calls"][4] > 1000 and hip["calls"][20] > 100, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+def test_shim_tables_against_the_double():
+    """tests/cpp/test_shim (the C++ parity test of the table-shaped shim, a -m gpu test on a GPU box) against the test double: staging, registry and batching paths"""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_shim")
+    if not (os.path.exists(exe) and os.path.exists(SIM)) or os.path.exists("/dev/kfd"):
+        pytest.skip("tests/cpp/test_shim or the test double not built, or GPU present")
+    e = dict(os.environ, LD_PRELOAD=SIM)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0 and "shim parity OK" in r.stdout, (r.stdout[-500:], r.stderr[-500:])

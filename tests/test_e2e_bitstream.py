@@ -21,20 +21,28 @@ sys.path.insert(0, %r)
 import e2e_util as E
 cfg = json.loads(sys.argv[1])
 L = E.load(cfg["hip"])
-if cfg["hip"]:
-    assert L.vvref_install_hip_hooks(cfg["mask"]) == 0
-yuv = E.synth_yuv(cfg["w"], cfg["h"], cfg["frames"], cfg["in_bd"], 1234)
-md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"], simd=cfg["simd"], threads=cfg.get("threads", 1))
+simd = cfg.get("simd")
+if cfg["hip"] and not (simd or "").startswith("HIP"):
+    assert L.vvref_install_hip_hooks(cfg["mask"]) == 0           # test entry; "simd": "HIP[:mask]" goes through the encoder's own --SIMD switch instead
+if cfg.get("clip") == "pan":
+    import e2e_fps as F
+    yuv = F.synth_clip(cfg["w"], cfg["h"], cfg["frames"])
+else:
+    yuv = E.synth_yuv(cfg["w"], cfg["h"], cfg["frames"], cfg["in_bd"], 1234)
+md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"], preset=E.PRESETS[cfg.get("preset", "faster")], simd=simd, threads=cfg.get("threads", 1),
+                        options=cfg.get("options"))
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(20, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 20); calls = [int(x) for x in c]
+    c = np.zeros(29, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 29); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
 
-def run(cfg, timeout=1700):
-    r = subprocess.run([sys.executable, "-c", WORKER, json.dumps(cfg)], capture_output=True, text=True, timeout=timeout)
+def run(cfg, timeout=1700, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, "-c", WORKER, json.dumps(cfg)], capture_output=True, text=True, timeout=timeout, env=e)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
@@ -290,4 +298,95 @@ def test_hip_batched_tz_diamond_rounds_bitstream_identical(clip):
     hip = run(dict(clip, hip=True, simd=None, mask=1024))
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][12] > 50 and hip["calls"][13] > hip["calls"][12], hip["calls"]      # rounds, looked-up positions
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# presets fast and medium (BASELINE configs[3..4] geometry: CTU 128 + MTT => rectangular CUs, GEO, SMVD, affine, LFNST, DepQuant, two references per list;
+# source/Lib/vvenc/vvencCfg.cpp:2751-2893) through the same gates, on a 10-bit clip large enough for CTU 128 + MTT.  Four encoder threads: the table entries
+# are called concurrently through per-thread device contexts.
+CLIP416 = dict(w=416, h=240, in_bd=10, int_bd=10, threads=4)
+ALL_TABLES = 31 + 64 + 128            # every kernel table, whole-picture MCTF search + filter
+BATCHED_SITES = 1024 + 256 + 512      # TZ diamond rounds, sub-pel refinement stages, DMVR per CU
+PICTURE_STAGES = 16 + 128 + 8192 + 65536
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["faster", "fast", "medium"])
+def test_hip_presets_all_tables_bitstream_identical(preset):
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(CLIP416, frames=5, preset=preset)
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, mask=ALL_TABLES))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][0] > 10000 and hip["calls"][2] > 1000 and hip["calls"][8] > 1000, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["faster", "fast", "medium"])
+def test_hip_presets_batched_search_sites_bitstream_identical(preset):
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(CLIP416, frames=5, preset=preset)
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, mask=BATCHED_SITES))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][10] > 100 and hip["calls"][12] > 100, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["faster", "fast", "medium"])
+def test_hip_presets_picture_stages_through_simd_switch_bitstream_identical(preset):
+    """the production selection, --SIMD=HIP (vvenc_set_SIMD_extension("HIP") -> VVEncImpl::setSIMDExtension -> vvenc_hip_select): MCTF search + filter, ALF statistics and
+    ALF filtering of whole pictures on the device; 17 frames so that MCTF filters two pictures"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(CLIP416, frames=17, preset=preset)
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, simd="HIP"))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][9] >= 1 and hip["calls"][21] >= 1 and hip["calls"][16] >= 1 and hip["calls"][19] >= 1, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+def test_hip_lfnst_quantiser_guard_bitstream_identical():
+    """with RDOQ and DepQuant off the encoder's scalar quantiser (Quant::xQuant) is the main path, and LFNST TUs must see QuantCore's first-coefficient-group
+    rule (Quant.cpp:152-159): the binding leaves them to the CPU entry, everything else goes to the device core"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(w=208, h=120, frames=5, in_bd=10, int_bd=10, preset="fast", options="RDOQ=0;DepQuant=0;LFNST=1")
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, mask=4))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][4] > 1000 and hip["calls"][20] > 100, hip["calls"]      # device quantiser calls, LFNST TUs left to the CPU
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+def test_hip_4k_medium_picture_stages_bitstream_identical():
+    """BASELINE configs[3] geometry: 3840x2160 10-bit, preset medium (CTU 128, MTT), picture-level stages on the device through --SIMD=HIP, 9 frames, 8 threads"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(w=3840, h=2160, frames=9, in_bd=10, int_bd=10, threads=8, preset="medium", clip="pan")
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, simd="HIP"))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][9] >= 1 and hip["calls"][16] >= 1 and hip["calls"][19] >= 1, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+def test_hip_8k_fast_picture_stages_bitstream_identical():
+    """BASELINE configs[4] geometry: 7680x4320 10-bit, preset fast, picture-level stages on the device, 3 frames, 8 threads"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(w=7680, h=4320, frames=3, in_bd=10, int_bd=10, threads=8, preset="fast", clip="pan")
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, simd="HIP"))
+    print("cpu", cpu, "hip", hip)
+    assert hip["calls"][16] >= 1 and hip["calls"][19] >= 1, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)

@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <memory>
 #include <vector>
 
 static std::string g_createError;
@@ -130,7 +131,9 @@ int vvhip_create( vvhip_ctx** out, int device )
     return vvhip_fail( nullptr, VVHIP_E_HIP, "vvhip_create: no HIP device available (%s); this library has no CPU fallback",
                        e != hipSuccess ? hipGetErrorString( e ) : "device count 0" );
   if( device < 0 || device >= count ) return vvhip_fail( nullptr, VVHIP_E_ARG, "vvhip_create: device %d out of range (%d devices)", device, count );
-  vvhip_ctx* ctx = new vvhip_ctx;
+  // released to the caller only on success: every early return below destroys the context with whatever it already owns
+  struct Guard { vvhip_ctx* c; ~Guard() { if( c ) vvhip_destroy( c ); } } guard{ new vvhip_ctx };
+  vvhip_ctx* ctx = guard.c;
   ctx->device = device;
   VVHIP_CHECK_HIP( nullptr, hipSetDevice( device ) );
   VVHIP_CHECK_HIP( nullptr, hipStreamCreateWithFlags( &ctx->ownStream, hipStreamNonBlocking ) );
@@ -187,7 +190,8 @@ int vvhip_create( vvhip_ctx** out, int device )
       for( int v = 0; v < 16; v++ ) mxPos[( z * 64 + l ) * 16 + v] = inv[( ( 16 * ( l / 32 ) + v ) % n ) * n + ( l % 32 ) % n];
   }
   {
-    static VvhipTuMx64Ops o64;
+    std::unique_ptr<VvhipTuMx64Ops> o64p( new VvhipTuMx64Ops );      // (local: contexts may be created concurrently, one per device / worker thread)
+    VvhipTuMx64Ops& o64 = *o64p;
     const int16_t* m = mats.data() + trMatOffset( VVHIP_DCT2, 6 );
     auto T = [&]( int r, int c ) -> int { return m[r * 64 + c]; };
     for( int r = 0; r < 32; r++ ) { int rs = 0; for( int c = 0; c < 64; c++ ) { if( T( r, c ) < -128 || T( r, c ) > 127 ) return vvhip_fail( nullptr, VVHIP_E_HIP, "vvhip_create: 64-point matrix entry outside 8 bits" ); rs += T( r, c ); } o64.rowSum[r] = 128 * rs; }
@@ -217,6 +221,7 @@ int vvhip_create( vvhip_ctx** out, int device )
   VVHIP_CHECK_HIP( nullptr, hipMalloc( ( void** ) &ctx->d_scan, scans.size() * sizeof( uint16_t ) ) );
   VVHIP_CHECK_HIP( nullptr, hipMemcpy( ctx->d_trMat, mats.data(), mats.size() * sizeof( int16_t ), hipMemcpyHostToDevice ) );
   VVHIP_CHECK_HIP( nullptr, hipMemcpy( ctx->d_scan, scans.data(), scans.size() * sizeof( uint16_t ), hipMemcpyHostToDevice ) );
+  guard.c = nullptr;
   *out = ctx;
   return VVHIP_OK;
 }
@@ -242,6 +247,14 @@ const char* vvhip_last_error( const vvhip_ctx* ctx ) { return ctx ? ctx->lastErr
 int vvhip_set_stream( vvhip_ctx* ctx, void* hip_stream )
 {
   if( !ctx ) return VVHIP_E_ARG;
+  if( hip_stream )
+  {
+    // a borrowed stream must live on the context's device: the ROM tables and scratch areas do
+    hipDevice_t dev = 0;
+    if( hipStreamGetDevice( ( hipStream_t ) hip_stream, &dev ) == hipSuccess && ( int ) dev != ctx->device )
+      return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_set_stream: the stream belongs to device %d, the context to device %d", ( int ) dev, ctx->device );
+    ( void ) hipGetLastError();
+  }
   ctx->stream = ( hipStream_t ) hip_stream;
   return VVHIP_OK;
 }

@@ -25,6 +25,15 @@ PROTOTYPES = {
     "vvhip_free": (i32, [vp, vp]),
     "vvhip_upload": (i32, [vp, vp, vp, sz]),
     "vvhip_download": (i32, [vp, vp, vp, sz]),
+    "vvhip_download_async": (i32, [vp, vp, vp, sz]),
+    "vvhip_upload_2d": (i32, [vp, vp, sz, vp, sz, sz, sz]),
+    "vvhip_download_2d": (i32, [vp, vp, sz, vp, sz, sz, sz]),
+    "vvhip_host_register": (i32, [vp, vp, sz]),
+    "vvhip_host_unregister": (i32, [vp, vp]),
+    "vvhip_device_count": (i32, []),
+    "vvhip_get_device": (i32, [vp]),
+    "vvhip_make_current": (i32, [vp]),
+    "vvhip_copy_peer": (i32, [vp, vp, vp, vp, sz]),
     "vvhip_version": (C.c_char_p, []),
     "vvhip_dist_batch": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "vvhip_dist_multi": (i32, [vp, i32, vp, i32, vp, i32, i32, vp, i32]),
