@@ -511,7 +511,7 @@ std::atomic<uint64_t> g_alfCtus{ 0 };
 bool alfCtu( const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int chromaShift,
              int bitDepth, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] )
 {
-  static vvhip::ALFOps alf;
+  static thread_local vvhip::ALFOps alf;      // (the object carries per-thread download areas)
   if( ( width & 3 ) || ( height & 3 ) || ( ( width >> chromaShift ) & 3 ) || ( ( height >> chromaShift ) & 3 ) ) return false;
   if( !alf.deriveClassification( rec[0], recStride[0], width, height, bitDepth, vbLumaH, vbLumaPos, cls ) ) return false;
   if( enabled[0] && !alf.getStatistics( org[0], orgStride[0], rec[0], recStride[0], width, height, 128, 7, cls, vbLumaH, vbLumaPos, stats[0], stats[0] ) ) return false;
@@ -558,7 +558,7 @@ std::atomic<uint64_t> g_ccAlfCtus{ 0 };
 bool ccAlfCtu( const int16_t* orgC, int orgStride, const int16_t* slfC, int slfStride, const int16_t* recLuma, int recStride, int widthC, int heightC,
                int vbCTUHeight, int vbPos, int picHeightFromHere, float* record )
 {
-  static vvhip::ALFOps alf;
+  static thread_local vvhip::ALFOps alf;      // (the object carries per-thread download areas)
   if( !alf.getStatisticsCcAlf( orgC, orgStride, slfC, slfStride, recLuma, recStride, widthC, heightC, 64, vbCTUHeight, vbPos, picHeightFromHere, record ) ) return false;
   g_ccAlfCtus++;
   return true;
@@ -568,7 +568,7 @@ std::atomic<uint64_t> g_alfFilterBlks{ 0 }, g_ccAlfFilterBlks{ 0 };
 bool alfFilterBlk( const void* classifier, int16_t* dst, int dstStride, const int16_t* src, int srcStride, int width, int height, int filterLength,
                    const short* coeff, const short* clip, int bitDepth, int vbCTUHeight, int vbPos )
 {
-  static vvhip::ALFOps alf;
+  static thread_local vvhip::ALFOps alf;      // (the object carries per-thread download areas)
   if( ( width & 3 ) || ( height & 3 ) || width > 128 || height > 128 ) return false;
   uint8_t cls[32 * 32 * 2];
   if( classifier )
@@ -584,7 +584,7 @@ bool alfFilterBlk( const void* classifier, int16_t* dst, int dstStride, const in
 
 bool ccAlfFilterBlk( int16_t* dstC, int dstStride, const int16_t* recLuma, int recStride, int widthC, int heightC, const int16_t* coeff, int bitDepth, int vbCTUHeight, int vbPos )
 {
-  static vvhip::ALFOps alf;
+  static thread_local vvhip::ALFOps alf;      // (the object carries per-thread download areas)
   const uint8_t on = 1;
   if( !alf.filterCcAlf( dstC, dstStride, recLuma, recStride, widthC, heightC, 64, bitDepth, coeff, 1, &on, vbCTUHeight, vbPos ) ) return false;
   g_ccAlfFilterBlks++;

@@ -69,6 +69,9 @@ VVHIP_API int         vvhip_download_2d( vvhip_ctx* ctx, void* host_dst, size_t 
  * being staged through the runtime's bounce buffers.  The encoder's picture buffers are recycled for the whole run: register once, unregister before free.   */
 VVHIP_API int         vvhip_host_register( vvhip_ctx* ctx, const void* host_ptr, size_t bytes );
 VVHIP_API int         vvhip_host_unregister( vvhip_ctx* ctx, const void* host_ptr );
+/* pinned host memory owned by the library's caller (hipHostMalloc): download / upload areas that are not the encoder's own buffers                                  */
+VVHIP_API int         vvhip_host_alloc( vvhip_ctx* ctx, void** host_ptr, size_t bytes );
+VVHIP_API int         vvhip_host_free( vvhip_ctx* ctx, void* host_ptr );
 /* Several GPUs in one process (one context per device and worker thread): number of devices, the device of a context, and a device-to-device copy of a
  * picture over xGMI (hipMemcpyPeerAsync on dst's stream, ordered after the work already queued on src's stream) — how an original or reconstructed
  * picture reaches the GPU that serves the pictures depending on it without a round trip through the host.                                        */

@@ -86,6 +86,8 @@ int         vvhip_download_2d( vvhip_ctx* ctx, void* h, size_t dpitch, const voi
 int         vvhip_copy_peer( vvhip_ctx* dst, void* d_dst, vvhip_ctx* src, const void* d_src, size_t bytes ) { if( !dst || !src ) return VVHIP_E_ARG; memcpy( d_dst, d_src, bytes ); return VVHIP_OK; }
 int         vvhip_host_register( vvhip_ctx* ctx, const void*, size_t ) { return ctx ? VVHIP_OK : VVHIP_E_ARG; }
 int         vvhip_host_unregister( vvhip_ctx* ctx, const void* ) { return ctx ? VVHIP_OK : VVHIP_E_ARG; }
+int         vvhip_host_alloc( vvhip_ctx* ctx, void** p, size_t bytes ) { if( !ctx || !p ) return VVHIP_E_ARG; *p = malloc( bytes ? bytes : 1 ); return *p ? VVHIP_OK : VVHIP_E_NOMEM; }
+int         vvhip_host_free( vvhip_ctx* ctx, void* p ) { if( !ctx ) return VVHIP_E_ARG; free( p ); return VVHIP_OK; }
 const char* vvhip_version( void ) { return "vvenc_hip SIMULATED (CPU oracle test double; not a product build)"; }
 
 // ------------------------------------------------------------------------------------------------ (A) distortion

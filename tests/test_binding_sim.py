@@ -44,6 +44,17 @@ def test_every_hook_every_preset(preset):
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
 
 
+def test_every_hook_four_encoder_threads():
+    """the reference's worker threads call the table entries and the per-CTU hooks concurrently: per-thread contexts and per-thread hook state, no host lock"""
+    need()
+    clip = dict(CLIP, frames=9, preset="faster", threads=4)
+    cpu = run(dict(clip, hip=False, mask=0))
+    for _ in range(2):
+        hip = run(dict(clip, hip=True, mask=ALL_TABLES + BATCHED_SITES + 2048 + 4096 + 16384 + 32768), env=sim_env())
+        assert hip["calls"][17] > 4 and hip["calls"][27] >= 2, hip["calls"]
+        assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
 @pytest.mark.parametrize("preset", ["faster", "medium"])
 def test_simd_switch_selects_the_binding(preset):
     """--SIMD=HIP through vvenc_set_SIMD_extension: production set (MCTF search with all references of a picture in one device call + filter, ALF statistics + filtering with

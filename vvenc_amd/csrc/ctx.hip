@@ -385,6 +385,22 @@ int vvhip_host_unregister( vvhip_ctx* ctx, const void* host_ptr )
   return VVHIP_OK;
 }
 
+int vvhip_host_alloc( vvhip_ctx* ctx, void** host_ptr, size_t bytes )
+{
+  if( !ctx || !host_ptr ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipSetDevice( ctx->device ) );
+  hipError_t e = hipHostMalloc( host_ptr, bytes ? bytes : 1, hipHostMallocPortable );
+  if( e != hipSuccess ) { ( void ) hipGetLastError(); return vvhip_fail( ctx, VVHIP_E_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString( e ) ); }
+  return VVHIP_OK;
+}
+
+int vvhip_host_free( vvhip_ctx* ctx, void* host_ptr )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipHostFree( host_ptr ) );
+  return VVHIP_OK;
+}
+
 int vvhip_device_count( void )
 {
   int count = 0;

@@ -91,7 +91,7 @@ void Device::check( int rc, const char* what ) const
 bool Device::pinHost( const void* p, size_t bytes )
 {
   static const bool on = []{ const char* e = getenv( "VVHIP_PIN" ); return !e || atoi( e ) != 0; }();
-  if( !on || !p || !bytes ) return false;
+  if( !on || !p || bytes < ( 256u << 10 ) ) return false;      // picture-sized, recycled buffers only
   static std::mutex m; static std::map<uintptr_t, size_t> pinned;      // page-aligned base -> bytes
   const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>( p ) & ~( page - 1 ), e = ( reinterpret_cast<uintptr_t>( p ) + bytes + page - 1 ) & ~( page - 1 );
   std::lock_guard<std::mutex> g( m );
@@ -107,6 +107,20 @@ bool Device::pinHost( const void* p, size_t bytes )
   if( vvhip_host_register( dev.ctx(), reinterpret_cast<void*>( a ), e - a ) != VVHIP_OK ) return false;
   pinned[a] = e - a;
   return true;
+}
+
+Pel* PinnedBuffer::get( size_t elems )
+{
+  if( elems > m_elems )
+  {
+    Device& dev = Device::get();
+    if( m_p ) { vvhip_sync( dev.ctx() ); vvhip_host_free( dev.ctx(), m_p ); m_p = nullptr; m_elems = 0; }
+    void* p = nullptr;
+    const size_t want = elems + elems / 4;
+    dev.check( vvhip_host_alloc( dev.ctx(), &p, want * sizeof( Pel ) ), "pinned host area" );
+    m_p = static_cast<Pel*>( p ); m_elems = want;
+  }
+  return m_p;
 }
 
 int Device::registerPicture( const Pel* origin, int stride, int width, int height, int margin, bool findable, bool upload )
@@ -934,7 +948,7 @@ bool ALFOps::filterPlaneImpl( const Pel* src, int srcStride, const int16_t* dSrc
   const size_t srcBytes = dSrcResident ? 0 : ( ( size_t ) srcPitchGuess * ( height + 8 ) * sizeof( Pel ) + 255 ) & ~( size_t ) 255;
   const int dstPitch = ( width + 7 ) & ~7;
   const size_t dstElems = ( size_t ) dstPitch * height;
-  if( m_down.size() < dstElems ) { m_down.resize( dstElems ); Device::pinHost( m_down.data(), m_down.size() * sizeof( Pel ) ); }
+  Pel* down = m_down.get( dstElems );
   dev.staging( srcBytes + dstElems * sizeof( Pel ) + 512 );
   int pitch = srcStride;
   const int16_t* dSrc = dSrcResident ? dSrcResident : stageBordered( dev, src, srcStride, width, height, 4, 0, pitch );
@@ -951,13 +965,13 @@ bool ALFOps::filterPlaneImpl( const Pel* src, int srcStride, const int16_t* dSrc
   dev.check( vvhip_alf_filter_plane( dev.ctx(), dSrc, pitch, dDst, dstPitch, width, height, ctuSize, bitDepth, filterLength, dCls,
                                      reinterpret_cast<const int16_t*>( aux + nCls ), clipSets ? reinterpret_cast<const int16_t*>( aux + nCls + nCoef ) : nullptr,
                                      reinterpret_cast<const int16_t*>( aux + nCls + 2 * nCoef ), vbCTUHeight, vbPos ), "vvhip_alf_filter_plane" );
-  dev.check( vvhip_download( dev.ctx(), m_down.data(), dDst, dstElems * sizeof( Pel ) ), "ALF filtered plane" );
+  dev.check( vvhip_download( dev.ctx(), down, dDst, dstElems * sizeof( Pel ) ), "ALF filtered plane" );
   const int ctusX = ( width + ctuSize - 1 ) / ctuSize;
   for( int c = 0; c < ctus; c++ )
   {
     if( ctuSet[c] < 0 ) continue;                                                        // the CTU keeps the caller's samples
     const int x0 = ( c % ctusX ) * ctuSize, y0 = ( c / ctusX ) * ctuSize, w = std::min( ctuSize, width - x0 ), h = std::min( ctuSize, height - y0 );
-    for( int y = y0; y < y0 + h; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride + x0, &m_down[( size_t ) y * dstPitch + x0], sizeof( Pel ) * w );
+    for( int y = y0; y < y0 + h; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride + x0, down + ( size_t ) y * dstPitch + x0, sizeof( Pel ) * w );
   }
   return true;
 }
@@ -1131,7 +1145,7 @@ void MCTFOps::bilateralFilter( const int* orgIds, const int* refIds, int nRefs, 
   vvhip_mv* dMv = static_cast<vvhip_mv*>( dev.stagingAux( count * nRefs * sizeof( vvhip_mv ) + 64 ) );
   std::vector<const vvhip_mv*> dMvs( nRefs );
   for( int r = 0; r < nRefs; r++ ) { dev.check( vvhip_upload( dev.ctx(), dMv + count * r, mvs[r], count * sizeof( vvhip_mv ) ), "motion vectors" ); dMvs[r] = dMv + count * r; }
-  static thread_local std::vector<Pel> tmp;      // download area, pinned in place once per thread (grows with the picture size)
+  static thread_local PinnedBuffer tmpBuf;       // download area of this thread
   for( int c = 0; c < numComp; c++ )
   {
     const Device::Mirror& o = dev.mirror( orgIds[c] );
@@ -1148,9 +1162,9 @@ void MCTFOps::bilateralFilter( const int* orgIds, const int* refIds, int nRefs, 
     int16_t* dOut = dev.staging( elems * sizeof( Pel ) + 64 );
     dev.check( vvhip_mctf_apply_plane( dev.ctx(), o.dOrigin, o.stride, o.width, o.height, c > 0 ? 1 : 0, bitDepth, unitSize, lowResFltApply ? 1 : 0, qp, nRefs, refs.data(), o.stride,
                                        dMvs.data(), mvW, refStrengths, weightScaling, sigmaSq, dOut, o.width ), "vvhip_mctf_apply_plane" );
-    if( tmp.size() < elems ) { tmp.resize( elems ); Device::pinHost( tmp.data(), tmp.size() * sizeof( Pel ) ); }
-    dev.check( vvhip_download( dev.ctx(), tmp.data(), dOut, elems * sizeof( Pel ) ), "filtered plane" );
-    for( int r = 0; r < o.height; r++ ) memcpy( out[c] + ( ptrdiff_t ) r * outStride[c], &tmp[( size_t ) r * o.width], sizeof( Pel ) * o.width );
+    Pel* tmp = tmpBuf.get( elems );
+    dev.check( vvhip_download( dev.ctx(), tmp, dOut, elems * sizeof( Pel ) ), "filtered plane" );
+    for( int r = 0; r < o.height; r++ ) memcpy( out[c] + ( ptrdiff_t ) r * outStride[c], tmp + ( size_t ) r * o.width, sizeof( Pel ) * o.width );
   }
 }
 

@@ -120,6 +120,16 @@ private:
   void* m_aux = nullptr; size_t m_auxBytes = 0;
 };
 
+// grow-only pinned host area owned by the shim (hipHostMalloc through the C ABI): where picture-sized results land before they are scattered into the encoder's buffers
+class PinnedBuffer
+{
+public:
+  Pel* get( size_t elems );                  // at least `elems` samples (contents are not preserved when it grows)
+  ~PinnedBuffer() {}                         // (released with the process: HIP teardown order at exit is not ours to rely on)
+private:
+  Pel* m_p = nullptr; size_t m_elems = 0;
+};
+
 class RdCost
 {
 public:
@@ -247,7 +257,7 @@ private:
   struct Resident { bool valid = false; int gpu = -1, width = 0, height = 0; const Pel* rec[3] = { nullptr, nullptr, nullptr }; int stride[3] = { 0, 0, 0 };
                     int16_t* d = nullptr; size_t elems = 0, off[3] = { 0, 0, 0 }; uint8_t* dCls = nullptr; size_t clsBytes = 0; };
   Resident m_res;
-  std::vector<Pel> m_down;      // download area of filterPlane, pinned in place once
+  PinnedBuffer m_down;          // download area of filterPlane
   bool filterPlaneImpl( const Pel* src, int srcStride, const int16_t* dSrcResident, const uint8_t* dClsResident, Pel* dst, int dstStride, int width, int height, int ctuSize, int bitDepth,
                         int filterLength, const uint8_t* cls, const short* coeffSets, const short* clipSets, int numSets, const short* ctuSet, int vbCTUHeight, int vbPos );
 };

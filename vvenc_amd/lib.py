@@ -30,6 +30,8 @@ PROTOTYPES = {
     "vvhip_download_2d": (i32, [vp, vp, sz, vp, sz, sz, sz]),
     "vvhip_host_register": (i32, [vp, vp, sz]),
     "vvhip_host_unregister": (i32, [vp, vp]),
+    "vvhip_host_alloc": (i32, [vp, C.POINTER(vp), sz]),
+    "vvhip_host_free": (i32, [vp, vp]),
     "vvhip_device_count": (i32, []),
     "vvhip_get_device": (i32, [vp]),
     "vvhip_make_current": (i32, [vp]),
