@@ -312,6 +312,8 @@ patch("vvencimpl.cpp", [
      "    hipSelected = true; hipReq.clear();\n"
      "  }\n"
      "  const std::string simdReqStr( hipReq );\n"),
+    # the encoder is being closed: its picture buffers are about to be freed -> the binding drops device mirrors and host pins BEFORE that happens
+    ("before", "      m_pEncLib->uninitEncoderLib();\n      delete m_pEncLib;", "      vvenc_hip_release();\n"),
     ("replace", "    return read_x86_extension_name().c_str();\n# endif   // !TARGET_SIMD_ARM",
      "    if( hipSelected ) { static std::string hipName; hipName = \"HIP+\" + read_x86_extension_name(); return hipName.c_str(); }\n"
      "    return read_x86_extension_name().c_str();\n# endif   // !TARGET_SIMD_ARM"),

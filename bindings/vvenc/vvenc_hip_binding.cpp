@@ -664,6 +664,18 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_select( co
   return vvenc_hip_install( mask );
 }
 
+extern "C" __attribute__( ( visibility( "default" ) ) ) void vvenc_hip_release( void )
+{
+  if( !g_rd ) return;                                                  // the binding was never installed: nothing lives on a device
+  try
+  {
+    { std::lock_guard<std::mutex> g( g_mctfLock ); while( !g_resident.empty() ) dropResident( 0 ); g_meCache.curPoc = -1; g_meCache.fields.clear(); }
+    { std::lock_guard<std::mutex> g( g_alfPicLock ); for( auto& kv : g_alfState ) { kv.second->done = false; kv.second->donePoc = -1; kv.second->ops->dropResident(); } }
+    vvhip::Device::unpinAll();
+  }
+  catch( const std::exception& e ) { fprintf( stderr, "vvenc_hip_release: %s\n", e.what() ); }
+}
+
 extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_calls( uint64_t* out8 )
 {
   for( int i = 0; i < 8; i++ ) out8[i] = g_calls[i];

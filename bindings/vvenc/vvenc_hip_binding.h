@@ -65,3 +65,5 @@ extern VvhipHooks g_vvhipHooks;
 //   "HIP:<mask>"     explicit hook mask (decimal or 0x...), see vvenc_hip_install
 // returns 0, or -1 when no MI355X context can be created (the encoder then reports the SIMD request as unsupported)
 extern "C" int vvenc_hip_select( const char* spec );
+// an encoder instance closes (VVEncImpl::uninit, before its buffers are freed): resident pictures are dropped, in-place host pins released.  Hooks stay installed.
+extern "C" void vvenc_hip_release( void );

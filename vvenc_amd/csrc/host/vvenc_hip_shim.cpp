@@ -19,7 +19,31 @@ static int ilog2( unsigned v ) { int l = 0; while( ( 1u << ( l + 1 ) ) <= v ) l+
 namespace {
 std::atomic<uint64_t> g_upBytes{ 0 }, g_downBytes{ 0 }, g_ups{ 0 }, g_downs{ 0 }, g_contexts{ 0 };
 // every transfer of this translation unit is counted (Device::stats): the macros below route the C ABI's copy calls through these
-inline int countedUpload( vvhip_ctx* c, void* d, const void* h, size_t n ) { g_upBytes += n; g_ups++; return vvhip_upload( c, d, h, n ); }
+// host ranges pinned in place (Device::pinHost): whole pages INSIDE a recycled picture buffer.  A copy whose host range starts inside a pinned range must end inside it
+// (the runtime treats it as pinned as a whole), so an upload is cut at the borders of the pinned ranges it touches: the page-aligned body goes as asynchronous DMA, the
+// sub-page head and tail as ordinary (staged) copies.
+std::mutex g_pinLock;
+std::map<uintptr_t, size_t> g_pinned;      // page-aligned base -> bytes
+inline int countedUpload( vvhip_ctx* c, void* d, const void* h, size_t n )
+{
+  g_upBytes += n; g_ups++;
+  uintptr_t s = reinterpret_cast<uintptr_t>( h ); const uintptr_t e = s + n;
+  char* dst = static_cast<char*>( d );
+  while( s < e )
+  {
+    uintptr_t cut = e;
+    {
+      std::lock_guard<std::mutex> g( g_pinLock );
+      auto it = g_pinned.upper_bound( s );
+      if( it != g_pinned.begin() && std::prev( it )->first + std::prev( it )->second > s ) cut = std::min( e, std::prev( it )->first + std::prev( it )->second );      // inside a pinned range: up to its end
+      else if( it != g_pinned.end() && it->first < e ) cut = it->first;                                                                                              // pageable: up to the next pinned range
+    }
+    const int rc = vvhip_upload( c, dst, reinterpret_cast<const void*>( s ), cut - s );
+    if( rc ) return rc;
+    dst += cut - s; s = cut;
+  }
+  return VVHIP_OK;
+}
 inline int countedDownload( vvhip_ctx* c, void* h, const void* d, size_t n ) { g_downBytes += n; g_downs++; return vvhip_download( c, h, d, n ); }
 inline int countedDownloadAsync( vvhip_ctx* c, void* h, const void* d, size_t n ) { g_downBytes += n; g_downs++; return vvhip_download_async( c, h, d, n ); }
 #define vvhip_upload countedUpload
@@ -92,21 +116,30 @@ bool Device::pinHost( const void* p, size_t bytes )
 {
   static const bool on = []{ const char* e = getenv( "VVHIP_PIN" ); return !e || atoi( e ) != 0; }();
   if( !on || !p || bytes < ( 256u << 10 ) ) return false;      // picture-sized, recycled buffers only
-  static std::mutex m; static std::map<uintptr_t, size_t> pinned;      // page-aligned base -> bytes
-  const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>( p ) & ~( page - 1 ), e = ( reinterpret_cast<uintptr_t>( p ) + bytes + page - 1 ) & ~( page - 1 );
-  std::lock_guard<std::mutex> g( m );
-  auto it = pinned.upper_bound( a );
-  if( it != pinned.begin() ) { auto pr = std::prev( it ); if( pr->first <= a && pr->first + pr->second >= e ) return true; }       // already inside a pinned range
-  // ranges that overlap the new one were pinned for an earlier incarnation of (part of) this buffer: drop them first
+  // whole pages inside the buffer: a neighbouring allocation never shares a pinned page
+  const uintptr_t page = 4096, a = ( reinterpret_cast<uintptr_t>( p ) + page - 1 ) & ~( page - 1 ), e = ( reinterpret_cast<uintptr_t>( p ) + bytes ) & ~( page - 1 );
+  if( e <= a ) return false;
   Device& dev = Device::get();
-  for( it = pinned.begin(); it != pinned.end(); )
+  std::lock_guard<std::mutex> g( g_pinLock );
+  auto it = g_pinned.upper_bound( a );
+  if( it != g_pinned.begin() ) { auto pr = std::prev( it ); if( pr->first <= a && pr->first + pr->second >= e ) return true; }       // already inside a pinned range
+  // ranges that overlap the new one were pinned for an earlier incarnation of (part of) this buffer: drop them first
+  for( it = g_pinned.begin(); it != g_pinned.end(); )
   {
-    if( it->first < e && it->first + it->second > a ) { vvhip_host_unregister( dev.ctx(), reinterpret_cast<void*>( it->first ) ); it = pinned.erase( it ); }
+    if( it->first < e && it->first + it->second > a ) { vvhip_host_unregister( dev.ctx(), reinterpret_cast<void*>( it->first ) ); it = g_pinned.erase( it ); }
     else ++it;
   }
   if( vvhip_host_register( dev.ctx(), reinterpret_cast<void*>( a ), e - a ) != VVHIP_OK ) return false;
-  pinned[a] = e - a;
+  g_pinned[a] = e - a;
   return true;
+}
+
+void Device::unpinAll()
+{
+  Device& dev = Device::get();
+  std::lock_guard<std::mutex> g( g_pinLock );
+  for( auto& kv : g_pinned ) vvhip_host_unregister( dev.ctx(), reinterpret_cast<void*>( kv.first ) );
+  g_pinned.clear();
 }
 
 Pel* PinnedBuffer::get( size_t elems )

@@ -107,6 +107,7 @@ public:
   void*    stagingAux( size_t bytes );
   // pin a recycled host buffer in place (hipHostRegister, once per range; false: left pageable).  $VVHIP_PIN=0 switches pinning off.
   static bool pinHost( const void* p, size_t bytes );
+  static void unpinAll();                    // before the owner frees the buffers (encoder close)
   // traffic over PCIe / calls since the process started (all contexts): what a binding prints per picture
   struct Stats { uint64_t uploadBytes, downloadBytes, uploads, downloads, contexts; };
   static Stats stats();
