@@ -700,36 +700,50 @@ API void vvref_tu_rdo_batch( int simd, const int16_t* resi, int resiStride, cons
   xFree( coef ); xFree( deq ); xFree( du ); xFree( rec ); xFree( lev );
 }
 
-// Multi-threaded driver for bench.py's cpu_baseline (kind "reference"): `threads` std::threads, each walks its contiguous share of
-// every job `passes` times through the reference's SIMD table entries; returns wall seconds.  jobs: kind 0 = distortion list
-// (df = DFunc base), kind 1 = fused TU pipeline twin (vvref_tu_rdo_batch).
-struct FrameJob { int32_t kind, df, size, subShift; const void* items; const void* aux; int32_t n, pad; };
+// Multi-threaded driver for bench.py's cpu_baseline (kind "reference") and its in-run parity check: `threads` std::threads pull chunks of CHUNK items from ONE atomic
+// counter over all jobs (dynamic load balance: a late thread never leaves others idle, and the mix of cheap 8x8 and expensive 64x64 work evens out), `passes` times, through
+// the reference's SIMD table entries; returns wall seconds.  jobs: kind 0 = distortion list (df = DFunc base), kind 1 = fused TU pipeline twin (vvref_tu_rdo_batch).
+// out (may be NULL): n uint64 results of the job (distortion / SSE of the reconstructed residual) — what bench.py compares with the device's outputs.
+// Scratch is per thread and allocated before the clock starts.
+struct FrameJob { int32_t kind, df, size, subShift; const void* items; const void* aux; int32_t n, pad; uint64_t* out; };
 
 API double vvref_run_jobs_mt( const int16_t* org, int orgStride, const int16_t* cur, int curStride, const int16_t* resi, int resiStride, int bitDepth,
                               const FrameJob* jobs, int nJobs, int threads, int passes )
 {
   rdPair(); quantObj(); selectTCoeffOps( 1 );
   { static SPS* warm = new SPS; ( void ) warm; }
-  auto worker = [&]( int t )
+  const int CHUNK = 256;
+  struct Chunk { int job, begin, end; };
+  std::vector<Chunk> chunks;
+  // expensive work first (largest blocks): the tail of the pass is made of cheap chunks
+  std::vector<int> order( nJobs );
+  for( int j = 0; j < nJobs; j++ ) order[j] = j;
+  std::stable_sort( order.begin(), order.end(), [&]( int a, int b ) { return jobs[a].size * ( 1 + 8 * jobs[a].kind ) > jobs[b].size * ( 1 + 8 * jobs[b].kind ); } );
+  for( int j : order ) for( int b = 0; b < jobs[j].n; b += CHUNK ) chunks.push_back( { j, b, std::min( jobs[j].n, b + CHUNK ) } );
+  std::vector<std::atomic<int>> next( passes + 1 );
+  for( auto& n : next ) n = 0;
+  auto worker = [&]( int pass0, int pass1 )
   {
-    std::vector<uint64_t> out;
-    for( int p = 0; p < passes; p++ )
-      for( int j = 0; j < nJobs; j++ )
+    uint64_t scratch[CHUNK];
+    for( int p = pass0; p < pass1; p++ )
+      for( ;; )
       {
-        const FrameJob& jb = jobs[j];
-        const int per = ( jb.n + threads - 1 ) / threads, b = std::min( jb.n, t * per ), e = std::min( jb.n, b + per );
-        if( e <= b ) continue;
-        out.resize( e - b );
+        const int c = next[p]++;
+        if( c >= ( int ) chunks.size() ) break;
+        const Chunk& ck = chunks[c];
+        const FrameJob& jb = jobs[ck.job];
+        uint64_t* o = jb.out ? jb.out + ck.begin : scratch;
         if( jb.kind == 0 )
-          vvref_dist_batch( 1, jb.df, org, orgStride, cur, curStride, jb.size, jb.size, bitDepth, jb.subShift, ( const DistItem* ) jb.items + b, e - b, out.data() );
+          vvref_dist_batch( 1, jb.df, org, orgStride, cur, curStride, jb.size, jb.size, bitDepth, jb.subShift, ( const DistItem* ) jb.items + ck.begin, ck.end - ck.begin, o );
         else
-          vvref_tu_rdo_batch( 1, resi, resiStride, ( const int32_t* ) jb.items + b, e - b, jb.size, jb.size, bitDepth, ( const int16_t* ) jb.aux + 2 * b, 8, nullptr, nullptr, out.data() );
+          vvref_tu_rdo_batch( 1, resi, resiStride, ( const int32_t* ) jb.items + ck.begin, ck.end - ck.begin, jb.size, jb.size, bitDepth, ( const int16_t* ) jb.aux + 2 * ck.begin, 8, nullptr, nullptr, o );
       }
   };
-  worker( 0 );      // warm-up pass on the calling thread (also initialises the lazily built statics before threads start)
-  const auto t0 = std::chrono::steady_clock::now();
+  worker( passes, passes + 1 );      // warm-up pass on the calling thread (also initialises the lazily built statics before threads start)
   std::vector<std::thread> th;
-  for( int t = 0; t < threads; t++ ) th.emplace_back( worker, t );
+  th.reserve( threads );
+  const auto t0 = std::chrono::steady_clock::now();
+  for( int t = 0; t < threads; t++ ) th.emplace_back( worker, 0, passes );
   for( auto& x : th ) x.join();
   return std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
 }

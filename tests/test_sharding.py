@@ -17,6 +17,13 @@ def test_two_rank_gloo(tmp_path):
     res = [json.load(open(os.path.join(str(tmp_path), "rank%d.json" % k))) for k in range(2)]
     assert sorted(res[0]["mine"] + res[1]["mine"]) == list(range(13))
     assert res[0]["dt_max"] == res[1]["dt_max"] and res[0]["total_frames"] == 13
+    # the two ranks together produced exactly the motion fields one process produces (keys owned and published round-robin, dependent pictures dealt round-robin)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    single = dist_worker.sharded_motion_fields(0, 1)
+    merged = dict(res[0]["fields"]); merged.update(res[1]["fields"])
+    assert set(res[0]["fields"]).isdisjoint(res[1]["fields"]) and len(res[0]["fields"]) > 0 and len(res[1]["fields"]) > 0
+    assert merged == single and len(single) == 6, (merged, single)
 
 
 def test_single_process_defaults():

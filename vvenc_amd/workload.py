@@ -27,25 +27,30 @@ TU_SIZES = (8, 16, 32)
 N_SAD, N_HAD, N_SSE = 11, 8, 1
 
 
-def synth_frame_pair(width, height, seed, bit_depth=10):
-    """SURVEY §8d generator family: textured base + pan + per-frame noise (current, reference)"""
+def synth_frame_pair(width, height, seed, bit_depth=10, frame_index=0):
+    """SURVEY §8d generator family: textured base + pan + per-frame noise (current, reference).  frame_index > 0: another picture of the same sequence (the current
+    picture is taken further along the pan and gets its own noise; the reference picture is the same for every index)"""
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:height + 64, 0:width + 64].astype(np.float32)
     base = 512 + 180 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 120 * np.sin((xx + yy) / 11.0) + 60 * np.sin(xx / 3.1) * np.sin(yy / 4.3)
     base += rng.normal(0, 12, base.shape).astype(np.float32)
     maxv = (1 << bit_depth) - 1
     scale = maxv / 1023.0
-    cur = np.clip(base[32:32 + height, 32:32 + width] * scale, 0, maxv)
     ref = np.clip((base[31:31 + height, 29:29 + width] + rng.normal(0, 3, (height, width))) * scale, 0, maxv)   # pan (3,1)
+    k = int(frame_index) % 8
+    cur = base[32 + k:32 + k + height, 32 + 3 * k:32 + 3 * k + width]
+    if frame_index:
+        cur = cur + np.random.default_rng(seed + 7919 * int(frame_index)).normal(0, 3, (height, width)).astype(np.float32)
+    cur = np.clip(cur * scale, 0, maxv)
     return cur.astype(np.int16), ref.astype(np.int16)
 
 
 class FrameWorkload:
     """Device-resident work lists for one frame geometry."""
 
-    def __init__(self, hp: HotPath, width=1920, height=1080, seed=1080, margin=80, bit_depth=10):
+    def __init__(self, hp: HotPath, width=1920, height=1080, seed=1080, margin=80, bit_depth=10, frame_index=0):
         self.hp, self.width, self.height, self.bit_depth = hp, width, height, bit_depth
-        cur, ref = synth_frame_pair(width, height, seed, bit_depth)
+        cur, ref = synth_frame_pair(width, height, seed, bit_depth, frame_index)
         self.cur_np, self.ref_np = cur, ref
         self.org = hp.plane(cur, margin)              # original picture (padding like PelStorage margins)
         self.ref = hp.plane(ref, margin)              # reconstructed reference picture, margin = CTU+16 (EncStage.h:311)
