@@ -9,15 +9,23 @@
 //   phase A  meSearchKernel    one wavefront per block; the candidate list of estimateLumaLn up to (not including) the above/left
 //                              tests is walked in the reference's order, each candidate's error is computed by the 64 lanes
 //                              together (16-byte row segments, two-pass sub-pel filter through LDS).  All blocks independent.
-//   phase B  meWavefrontKernel the above/left tests are a true recurrence (block (x,y) needs the FINAL vectors of (x,y-1) and
-//                              (x-1,y)).  One wavefront per block row walks the row left to right; rows hand vectors to the row
-//                              below through 8-byte {tag,x,y} granules (one relaxed agent-scope store / load each — placement
-//                              independent, no fences; MI355X guide §6 G16 form R2).  Critical path = cols + rows steps.
+//   phase B  the above/left tests are a true recurrence (block (x,y) needs the FINAL vectors of (x,y-1) and (x-1,y)), critical path
+//            cols + rows blocks.  The expensive part of a step — the error of a candidate vector, ~1-2 us of dependent loads —
+//            is taken OFF the critical path:
+//              meNeighbourKernel  (all blocks in parallel) scores every block at the phase-A vectors of its upper and left
+//                                 neighbour: in smooth fields the neighbours' final vectors ARE their phase-A vectors;
+//              meDiagKernel       one workgroup per reference sweeps the anti-diagonals, a lane per block of the diagonal: the
+//                                 neighbours' final vectors come from LDS (written on the previous diagonal), their errors from
+//                                 the records above; only a vector no record knows is scored on the spot by the lane's wavefront.
+//            A step is a few LDS operations and two LDS-only barriers instead of two candidate evaluations.
+//            meWavefrontKernel (one wavefront per block row, rows hand vectors down through {tag,x,y} granules) remains for fields whose
+//            diagonals exceed a workgroup.
 //   phase C  meFinalizeKernel  (final 1/16-pel level only) variance-normalised error, rmsme, overlap in IEEE double, no FMA
 //                              contraction (-ffp-contract=off), MCTF.cpp:1308-1321.
 // The `> besterror` early exits of the reference are semantically inert (callers only use errors < best.error), so kernels
 // always produce the full sum.
 #include "common.h"
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -51,6 +59,14 @@ __constant__ int8_t kFilter6[16][6] = {
   { 3, -11, 50, 29, -9, 2 }, { 3, -11, 44, 35, -10, 3 }, { 1, -7, 38, 38, -7, 1 },  { 3, -10, 35, 44, -11, 3 }, { 2, -9, 29, 50, -11, 3 }, { 2, -8, 24, 53, -10, 3 },
   { 2, -7, 19, 57, -9, 2 },  { 1, -5, 14, 60, -8, 2 },  { 1, -3, 9, 62, -6, 1 },   { 0, -2, 4, 64, -3, 1 } };
 
+// packed 16-bit helpers: two samples per dword.  v_dot2_i32_i16 multiplies both halves and accumulates in 32 bits — exact for 10-bit samples,
+// 7-bit taps and 11-bit differences (sums of squares stay below 2^31 for the block sizes of the search, as in the reference's int).
+typedef short s16x2 __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ int sdot2( uint32_t a, uint32_t b, int c ) { return __builtin_amdgcn_sdot2( __builtin_bit_cast( s16x2, a ), __builtin_bit_cast( s16x2, b ), c, false ); }
+__device__ __forceinline__ uint32_t pk16( int lo, int hi ) { return ( uint32_t ) ( lo & 0xffff ) | ( ( uint32_t ) hi << 16 ); }
+__device__ __forceinline__ uint32_t pkSub16( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, a ) - __builtin_bit_cast( s16x2, b ) ); }
+__device__ __forceinline__ int clipPel( int v, int maxVal ) { return min( max( v, 0 ), maxVal ); }
+
 // ---- error of one candidate, computed by a whole wavefront (all 64 lanes must call) -------------------------------------------
 // integer displacement: sum (org - buf)^2 over w x h, w,h multiples of 8 (MCTF.cpp:122-145)
 __device__ __forceinline__ int waveErrorInt( const int16_t* org, int os, const int16_t* buf, int bs, int w, int h, int lane )
@@ -61,11 +77,50 @@ __device__ __forceinline__ int waveErrorInt( const int16_t* org, int os, const i
   {
     const int y = i / segs, s = i - y * segs;
     const u32x4 a = ld16( org + ( ptrdiff_t ) y * os + 8 * s ), b = ld16( buf + ( ptrdiff_t ) y * bs + 8 * s );
-    const uint32_t as[4] = { a.x, a.y, a.z, a.w }, bb[4] = { b.x, b.y, b.z, b.w };
-#pragma unroll
-    for( int q = 0; q < 4; q++ ) { const int d0 = lo16( as[q] ) - lo16( bb[q] ), d1 = hi16( as[q] ) - hi16( bb[q] ); e += d0 * d0 + d1 * d1; }
+    const uint32_t d0 = pkSub16( a.x, b.x ), d1 = pkSub16( a.y, b.y ), d2 = pkSub16( a.z, b.z ), d3 = pkSub16( a.w, b.w );
+    e = sdot2( d0, d0, e ); e = sdot2( d1, d1, e ); e = sdot2( d2, d2, e ); e = sdot2( d3, d3, e );
   }
   return waveSum( e );
+}
+
+// ---- the 4-tap sub-pel error in two separable pieces, packed arithmetic (blocks 8 or 16 wide; the search of MCTFSpeed > 0) -------------------
+// horizontal pass of `rows` rows starting at src (= first row, block column 0; taps reach columns -1 .. w+2): dst[r * w + x] = clip( ( sum_t f[t] * src[r][x - 1 + t] + 32 ) >> 6 )
+__device__ __forceinline__ void horPass4( const int16_t* src, int bs, int rows, int w, int fx, int maxVal, int16_t* dst, int lane )
+{
+  const uint32_t c01 = pk16( kFilter4[fx][0], kFilter4[fx][1] ), c23 = pk16( kFilter4[fx][2], kFilter4[fx][3] );
+  const int pshift = w == 16 ? 3 : 2, pairs = 1 << pshift;
+  for( int i = lane; i < ( rows << pshift ); i += 64 )
+  {
+    const int r = i >> pshift, x = 2 * ( i & ( pairs - 1 ) );
+    const int16_t* p = src + ( ptrdiff_t ) r * bs + x - 1;
+    const u32x2 v = ld8( p );                      // (s0,s1) (s2,s3)
+    const uint32_t v4 = ld4( p + 4 );              // (s4,s5)
+    const uint32_t a = __builtin_amdgcn_alignbit( v.y, v.x, 16 ), b = __builtin_amdgcn_alignbit( v4, v.y, 16 );      // (s1,s2) (s3,s4)
+    const int t0 = clipPel( sdot2( v.x, c01, sdot2( v.y, c23, 32 ) ) >> 6, maxVal );
+    const int t1 = clipPel( sdot2( a, c01, sdot2( b, c23, 32 ) ) >> 6, maxVal );
+    *reinterpret_cast<uint32_t*>( dst + r * w + x ) = pk16( t0, t1 );
+  }
+}
+// vertical pass over rows tmp[0 .. h+2] + squared error against the original block; returns this lane's partial sum
+__device__ __forceinline__ int verError4( const int16_t* org, int os, const int16_t* tmp, int w, int h, int fy, int maxVal, int lane )
+{
+  const uint32_t c01 = pk16( kFilter4[fy][0], kFilter4[fy][1] ), c23 = pk16( kFilter4[fy][2], kFilter4[fy][3] );
+  const int pshift = w == 16 ? 3 : 2, pairs = 1 << pshift;
+  int e = 0;
+  for( int i = lane; i < ( h << pshift ); i += 64 )
+  {
+    const int y = i >> pshift, x = 2 * ( i & ( pairs - 1 ) );
+    const int16_t* q = tmp + y * w + x;
+    const uint32_t v0 = *reinterpret_cast<const uint32_t*>( q ), v1 = *reinterpret_cast<const uint32_t*>( q + w ),
+                   v2 = *reinterpret_cast<const uint32_t*>( q + 2 * w ), v3 = *reinterpret_cast<const uint32_t*>( q + 3 * w );
+    const uint32_t l01 = __builtin_amdgcn_perm( v1, v0, 0x05040100u ), h01 = __builtin_amdgcn_perm( v1, v0, 0x07060302u );      // (v0.lo,v1.lo) (v0.hi,v1.hi)
+    const uint32_t l23 = __builtin_amdgcn_perm( v3, v2, 0x05040100u ), h23 = __builtin_amdgcn_perm( v3, v2, 0x07060302u );
+    const int s0 = clipPel( sdot2( l01, c01, sdot2( l23, c23, 32 ) ) >> 6, maxVal );
+    const int s1 = clipPel( sdot2( h01, c01, sdot2( h23, c23, 32 ) ) >> 6, maxVal );
+    const uint32_t d = pkSub16( pk16( s0, s1 ), ld4( org + ( ptrdiff_t ) y * os + x ) );
+    e = sdot2( d, d, e );
+  }
+  return e;
 }
 
 // fractional displacement (MCTF.cpp:147-257): horizontal pass -> clip -> LDS -> vertical pass -> clip -> squared error.
@@ -152,6 +207,50 @@ __device__ __forceinline__ int meError( const MeGeom& g, int x, int y, int dx, i
                                 const int e_ = meError( g, bx, by, dx_, dy_, sTmp, lane );                                       \
                                 if( e_ < bestE ) { bestX = dx_; bestY = dy_; bestE = e_; } } } while( 0 )
 
+// One refinement ring of estimateLumaLn's final level (MCTF.cpp:1229-1288): the 8 positions (cx + x2, cy + y2), x2, y2 in {-a, 0, a} without the centre, tested in the
+// reference's order (y2 outer, x2 inner) with its strict-< update.  The three x positions share their horizontal passes: one pass per x position over the rows any of its
+// y positions needs, then a vertical pass + error per candidate (3 horizontal + 8 vertical passes instead of 8 + 8).  Same integers as motionErrorLumaFrac4 per candidate
+// (an integer position through the filters is the identity: row 0 of the filter table is {0,64,0,0} and samples are already inside the clipping range).
+__device__ __forceinline__ void meRing3( const MeGeom& g, int bx, int by, int cx, int cy, int a, int& bestX, int& bestY, int& bestE, int16_t* sTmp, int lane )
+{
+  const int w = min( g.bs, g.width - bx ) & ~7, h = min( g.bs, g.height - by ) & ~7;
+  const bool shared = g.lowRes && ( w == 8 || w == 16 ) && h <= 16;
+  if( !shared )
+  {
+    for( int y2 = -a; y2 <= a; y2 += a )
+      for( int x2 = -a; x2 <= a; x2 += a )
+        if( x2 || y2 )
+        {
+          const int dx_ = cx + x2, dy_ = cy + y2;
+          if( dx_ != bestX || dy_ != bestY ) { const int e_ = meError( g, bx, by, dx_, dy_, sTmp, lane ); if( e_ < bestE ) { bestX = dx_; bestY = dy_; bestE = e_; } }
+        }
+    return;
+  }
+  const int iyMin = ( cy - a ) >> 4, iyMax = ( cy + a ) >> 4, nrows = iyMax - iyMin + h + 3, region = nrows * w;
+  const int16_t* o = g.org + bx + ( ptrdiff_t ) by * g.orgStride;
+#pragma unroll
+  for( int v = 0; v < 3; v++ )
+  {
+    const int X = cx + ( v - 1 ) * a;
+    horPass4( g.buf + bx + ( X >> 4 ) + ( ptrdiff_t ) ( by + iyMin - 1 ) * g.bufStride, g.bufStride, nrows, w, X & 15, g.maxVal, sTmp + v * region, lane );
+  }
+  ME_WAVE_SYNC();
+  for( int y2 = -a; y2 <= a; y2 += a )
+  {
+    const int Y = cy + y2, ro = ( Y >> 4 ) - iyMin;
+#pragma unroll
+    for( int v = 0; v < 3; v++ )
+    {
+      if( v == 1 && y2 == 0 ) continue;
+      const int X = cx + ( v - 1 ) * a;
+      if( X == bestX && Y == bestY ) continue;
+      const int e_ = waveSum( verError4( o, g.orgStride, sTmp + v * region + ro * w, w, h, Y & 15, g.maxVal, lane ) );
+      if( e_ < bestE ) { bestX = X; bestY = Y; bestE = e_; }
+    }
+  }
+  ME_WAVE_SYNC();                                // sTmp is reused by the next ring / candidate
+}
+
 // ---- phase A -------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__( 64 )
 meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int factor, int doubleRes, int searchPttrn, int mvsW )
@@ -194,17 +293,15 @@ meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int fac
   {
     int pbx = bestX, pby = bestY;
     const int dr = searchPttrn ? 6 : 12, d1 = searchPttrn == 2 ? 6 : 4;
-    for( int y2 = -dr; y2 <= dr; y2 += d1 )
-      for( int x2 = -dr; x2 <= dr; x2 += d1 )
-        if( x2 || y2 ) ME_TRY( pbx + x2, pby + y2 );
+    if( d1 == dr ) meRing3( g, bx, by, pbx, pby, dr, bestX, bestY, bestE, sTmp, lane );      // the 3 x 3 ring of search pattern 2
+    else
+      for( int y2 = -dr; y2 <= dr; y2 += d1 )
+        for( int x2 = -dr; x2 <= dr; x2 += d1 )
+          if( x2 || y2 ) ME_TRY( pbx + x2, pby + y2 );
     pbx = bestX; pby = bestY;
-    for( int y2 = -2; y2 <= 2; y2 += 2 )
-      for( int x2 = -2; x2 <= 2; x2 += 2 )
-        if( x2 || y2 ) ME_TRY( pbx + x2, pby + y2 );
+    meRing3( g, bx, by, pbx, pby, 2, bestX, bestY, bestE, sTmp, lane );
     pbx = bestX; pby = bestY;
-    for( int y2 = -1; y2 <= 1; y2++ )
-      for( int x2 = -1; x2 <= 1; x2++ )
-        if( x2 || y2 ) ME_TRY( pbx + x2, pby + y2 );
+    meRing3( g, bx, by, pbx, pby, 1, bestX, bestY, bestE, sTmp, lane );
   }
   if( lane == 0 )
   {
@@ -262,6 +359,125 @@ meWavefrontKernel( MeGeom g, const MeRefs R, int nbx, int mvsW, int* abortFlag )
       m.x = bestX; m.y = bestY; m.error = bestE;
       __hip_atomic_store( granules + ( size_t ) byi * nbx + bxi, packGranule( bestX, bestY ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     }
+  }
+}
+
+// ---- phase B, parallel part: errors at the neighbours' phase-A vectors ---------------------------------------------------------
+struct NbRec { int eU, eL, upX, upY, leftX, leftY; };      // e < 0: not scored (the vector equals one whose error is known)
+
+__global__ void __launch_bounds__( 64 )
+meNeighbourKernel( MeGeom g, const MeRefs R, int nbx, int mvsW )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[( 32 + 5 ) * 32];
+  const int lane = threadIdx.x;
+  g.buf = R.buf[blockIdx.y];
+  const vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.y];
+  NbRec* __restrict__ nb = reinterpret_cast<NbRec*>( R.gran[blockIdx.y] );
+  const int blk = blockIdx.x, byi = blk / nbx, bxi = blk - byi * nbx;
+  const int bs = g.bs, bx = bxi * bs, by = byi * bs;
+  const vvhip_mv own = mvs[byi * mvsW + bxi];
+  NbRec r; r.eU = -1; r.eL = -1; r.upX = r.upY = r.leftX = r.leftY = 0;
+  if( byi > 0 )
+  {
+    const vvhip_mv up = mvs[( byi - 1 ) * mvsW + bxi];
+    r.upX = up.x; r.upY = up.y;
+    if( up.x != own.x || up.y != own.y ) r.eU = meError( g, bx, by, up.x, up.y, sTmp, lane );
+  }
+  if( bxi > 0 )
+  {
+    const vvhip_mv lf = mvs[byi * mvsW + bxi - 1];
+    r.leftX = lf.x; r.leftY = lf.y;
+    if( ( lf.x != own.x || lf.y != own.y ) && !( byi > 0 && lf.x == r.upX && lf.y == r.upY ) ) r.eL = meError( g, bx, by, lf.x, lf.y, sTmp, lane );
+  }
+  if( lane == 0 ) nb[byi * nbx + bxi] = r;
+}
+
+// ---- phase B, sequential part: anti-diagonal sweep -------------------------------------------------------------------------------
+// workgroup barrier that orders LDS traffic only: the sweep's global loads (fetched a diagonal ahead) and stores (results, nobody in the launch reads them back)
+// stay in flight across it
+#define ME_LDS_BARRIER() asm volatile( "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory" )
+constexpr int ME_DIAG_MAX_THREADS = 320, ME_DIAG_MAX_COLS = 1024;
+
+// the rare on-the-spot evaluation of the sweep, kept out of line: the sweep's loop stays a few dozen instructions in registers (inlined, the two-pass error code made
+// the compiler spill the loop's state to scratch — a global-memory round trip on every step of the chain: 219 -> 128 us on the final level of a 1080p picture)
+__device__ __attribute__( ( noinline ) ) int meErrorCall( const MeGeom* g, int x, int y, int dx, int dy, int16_t* sTmp, int lane ) { return meError( *g, x, y, dx, dy, sTmp, lane ); }
+
+__global__ void __launch_bounds__( ME_DIAG_MAX_THREADS )
+meDiagKernel( MeGeom g, const MeRefs R, int nbx, int nby, int mvsW )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmpAll[ME_DIAG_MAX_THREADS / 64][( 32 + 5 ) * 32];
+  __shared__ int finX[ME_DIAG_MAX_COLS], finY[ME_DIAG_MAX_COLS];      // final vector of the last finished block of every block column
+  __shared__ MeGeom sG;
+  const int t = threadIdx.x, lane = t & 63;
+  int16_t* sTmp = sTmpAll[t >> 6];
+  g.buf = R.buf[blockIdx.x];
+  if( t == 0 ) sG = g;
+  __syncthreads();
+  vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.x];
+  const NbRec* __restrict__ nb = reinterpret_cast<const NbRec*>( R.gran[blockIdx.x] );
+  const int bs = g.bs, nd = nbx + nby - 1;
+  // the block's own phase-A result and its neighbour record do not depend on the sweep: they are fetched one diagonal ahead
+  // (two ahead, and three diagonals at a time parked in LDS, both measured slower: 166 / 312 us against 128 us)
+  int nX = 0, nY = 0, nE = 0, nEU = -1, nEL = -1, nUX = 0, nUY = 0, nLX = 0, nLY = 0;
+  auto fetch = [&]( int d ) {
+    const int xlo = d - ( nby - 1 ) > 0 ? d - ( nby - 1 ) : 0, xhi = d < nbx - 1 ? d : nbx - 1;
+    if( d < nd && t <= xhi - xlo )
+    {
+      const int x = xlo + t, y = d - x;
+      const vvhip_mv o = mvs[y * mvsW + x]; const NbRec r = nb[y * nbx + x];
+      nX = o.x; nY = o.y; nE = o.error; nEU = r.eU; nEL = r.eL; nUX = r.upX; nUY = r.upY; nLX = r.leftX; nLY = r.leftY;
+    } };
+  fetch( 0 );
+  for( int d = 0; d < nd; d++ )
+  {
+    const int xlo = d - ( nby - 1 ) > 0 ? d - ( nby - 1 ) : 0, xhi = d < nbx - 1 ? d : nbx - 1;
+    const bool active = t <= xhi - xlo;
+    const int x = xlo + t, y = d - x;
+    const int ownX = nX, ownY = nY, ownE = nE, rEU = nEU, rEL = nEL, rUX = nUX, rUY = nUY, rLX = nLX, rLY = nLY;
+    fetch( d + 1 );
+    int bestX = ownX, bestY = ownY, bestE = ownE;
+    int upX = 0, upY = 0, lfX = 0, lfY = 0;
+    if( active )
+    {
+      if( y > 0 ) { upX = finX[x]; upY = finY[x]; }
+      if( x > 0 ) { lfX = finX[x - 1]; lfY = finY[x - 1]; }
+    }
+    ME_LDS_BARRIER();                                                       // every lane has read the previous diagonal's vectors
+    // error of vector (vx, vy) for this block if a record knows it, else -1
+    auto known = [&]( int vx, int vy, int e1x, int e1y, int e1 ) -> int {
+      if( vx == ownX && vy == ownY ) return ownE;
+      if( rEU >= 0 && vx == rUX && vy == rUY ) return rEU;
+      if( rEL >= 0 && vx == rLX && vy == rLY ) return rEL;
+      if( e1 >= 0 && vx == e1x && vy == e1y ) return e1;
+      return -1; };
+    // scores the vectors no record knows, one at a time, by the whole wavefront of the lane that needs it
+    auto scoreMissing = [&]( bool missing, int vx, int vy, int& e ) {
+      unsigned long long m = __ballot( missing );
+      while( m )
+      {
+        const int l = __ffsll( ( long long ) m ) - 1;
+        const int lx = __shfl( x, l ), ly = __shfl( y, l ), lvx = __shfl( vx, l ), lvy = __shfl( vy, l );
+        const int v = meErrorCall( &sG, lx * bs, ly * bs, lvx, lvy, sTmp, lane );
+        if( lane == l ) e = v;
+        m &= m - 1;
+      } };
+    // the upper block's final vector (MCTF.cpp:1289-1297)
+    const bool try1 = active && y > 0 && ( upX != bestX || upY != bestY );
+    int e1 = try1 ? known( upX, upY, 0, 0, -1 ) : -1;
+    scoreMissing( try1 && e1 < 0, upX, upY, e1 );
+    if( try1 && e1 < bestE ) { bestX = upX; bestY = upY; bestE = e1; }
+    // the left block's final vector, unless it is the vector just tested (:1298-1306)
+    const bool try2 = active && x > 0 && !( y > 0 && lfX == upX && lfY == upY ) && ( lfX != bestX || lfY != bestY );
+    int e2 = try2 ? known( lfX, lfY, upX, upY, try1 ? e1 : -1 ) : -1;
+    scoreMissing( try2 && e2 < 0, lfX, lfY, e2 );
+    if( try2 && e2 < bestE ) { bestX = lfX; bestY = lfY; bestE = e2; }
+    if( active )
+    {
+      vvhip_mv& m = mvs[y * mvsW + x];
+      m.x = bestX; m.y = bestY; m.error = bestE;
+      finX[x] = bestX; finY[x] = bestY;
+    }
+    ME_LDS_BARRIER();
   }
 }
 
@@ -427,10 +643,22 @@ int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, i
   g.lowRes = lowRes; g.maxVal = ( 1 << bitDepth ) - 1;
   hipLaunchKernelGGL( meSearchKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, doubleRes, pttrn, mvsW );
   VVHIP_LAUNCH_CHECK( ctx );
-  VVHIP_CHECK_HIP( ctx, hipMemsetAsync( R.gran[0], 0, sizeof( unsigned long long ) * ( granPitch * ( size_t ) ( nRefs - 1 ) + ( size_t ) nbx * nby ), ctx->stream ) );
-  // blocks are dispatched in linear order (x fastest): the row a wave waits for — same reference, one row up — always has the smaller linear index
-  hipLaunchKernelGGL( meWavefrontKernel, dim3( nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, d_abort );
-  VVHIP_LAUNCH_CHECK( ctx );
+  static const int useDiag = []{ const char* e = getenv( "VVHIP_MCTF_DIAG" ); return e ? atoi( e ) : 1; }();
+  const int diagLen = nbx < nby ? nbx : nby;
+  if( useDiag && diagLen <= ME_DIAG_MAX_THREADS && nbx <= ME_DIAG_MAX_COLS )
+  {
+    // (the granule area holds the neighbour records here: 3 granules = one NbRec per block)
+    hipLaunchKernelGGL( meNeighbourKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW );
+    hipLaunchKernelGGL( meDiagKernel, dim3( nRefs ), dim3( ( ( diagLen + 63 ) / 64 ) * 64 ), 0, ctx->stream, g, R, nbx, nby, mvsW );
+    VVHIP_LAUNCH_CHECK( ctx );
+  }
+  else
+  {
+    VVHIP_CHECK_HIP( ctx, hipMemsetAsync( R.gran[0], 0, sizeof( unsigned long long ) * ( granPitch * ( size_t ) ( nRefs - 1 ) + ( size_t ) nbx * nby ), ctx->stream ) );
+    // blocks are dispatched in linear order (x fastest): the row a wave waits for — same reference, one row up — always has the smaller linear index
+    hipLaunchKernelGGL( meWavefrontKernel, dim3( nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, d_abort );
+    VVHIP_LAUNCH_CHECK( ctx );
+  }
   if( doubleRes )
   {
     hipLaunchKernelGGL( meFinalizeKernel, dim3( ( nbx * nby + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, g, R, nRefs, nbx, nby, bitDepth, unit, mvsW );
@@ -504,7 +732,7 @@ int vvhip_mctf_me_level( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, c
   if( ( block_size != 8 && block_size != 16 && block_size != 32 ) || width < 8 || height < 8 || bit_depth < 8 || bit_depth > 10 )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_me_level: block size %d (8/16/32), bit depth %d (8..10, MCTF.cpp:1313)", block_size, bit_depth );
   const int nbx = ( width - 8 ) / block_size + 1, nby = ( height - 8 ) / block_size + 1;
-  const size_t need = sizeof( unsigned long long ) * ( size_t ) nbx * nby + 256;
+  const size_t need = 3 * sizeof( unsigned long long ) * ( size_t ) nbx * nby + 256;      // one NbRec (3 granules) per block
   int rc = ensureScratch( ctx, need );
   if( rc ) return rc;
   int* d_abort = reinterpret_cast<int*>( ctx->d_scratch );
@@ -545,7 +773,7 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
   size_t fieldElems = 0;
   for( int k = 0; k < 4; k++ ) fieldElems += ( size_t ) fw[k] * fh[k];
   const int outW = ( width + u - 1 ) / u, outH = ( height + u - 1 ) / u;      // MCTF.cpp:671-672
-  const size_t granElems = ( size_t ) outW * outH + 64;
+  const size_t granElems = 3 * ( ( size_t ) outW * outH + 64 );      // per reference: one NbRec (3 granules) per block of the finest level
   size_t off = 256;
   const size_t offGran = off;  off += granElems * sizeof( unsigned long long ) * ( size_t ) ( n_refs < ME_MAX_REFS ? n_refs : ME_MAX_REFS );
   off = ( off + 255 ) & ~( size_t ) 255;
