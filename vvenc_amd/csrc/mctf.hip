@@ -201,11 +201,32 @@ __device__ __forceinline__ int meError( const MeGeom& g, int x, int y, int dx, i
                   : waveErrorFrac<false>( o, g.orgStride, b, g.bufStride, w, h, fx, fy, g.maxVal, sTmp, lane );
 }
 
+// Integer-vector candidates of a FULL 32 x 32 block (every level but the last works on 32 x 32 blocks and integer vectors only: ~60 candidates per block).  The original
+// block stays in registers for all of them (8 dwords per lane: rows l >> 2 and 16 + (l >> 2), 16-byte segment l & 3); a candidate is two 16-byte loads, eight packed
+// subtractions and eight dot products per lane — no per-candidate index arithmetic.
+struct Org32 { u32x4 a, b; int off; };
+__device__ __forceinline__ Org32 loadOrg32( const int16_t* o, int os, int cs, int lane )
+{
+  const int r = lane >> 2, s = lane & 3;
+  Org32 O; O.a = ld16( o + ( ptrdiff_t ) r * os + 8 * s ); O.b = ld16( o + ( ptrdiff_t ) ( r + 16 ) * os + 8 * s ); O.off = r * cs + 8 * s;
+  return O;
+}
+__device__ __forceinline__ int errInt32( const Org32& O, const int16_t* c, int cs, int lane )
+{
+  const u32x4 x = ld16( c + O.off ), y = ld16( c + O.off + 16 * cs );
+  int e = 0;
+  uint32_t d;
+  d = pkSub16( O.a.x, x.x ); e = sdot2( d, d, e ); d = pkSub16( O.a.y, x.y ); e = sdot2( d, d, e ); d = pkSub16( O.a.z, x.z ); e = sdot2( d, d, e ); d = pkSub16( O.a.w, x.w ); e = sdot2( d, d, e );
+  d = pkSub16( O.b.x, y.x ); e = sdot2( d, d, e ); d = pkSub16( O.b.y, y.y ); e = sdot2( d, d, e ); d = pkSub16( O.b.z, y.z ); e = sdot2( d, d, e ); d = pkSub16( O.b.w, y.w ); e = sdot2( d, d, e );
+  return waveSum( e );
+}
+
 // A candidate equal to the current best vector cannot win (same error, the update needs a strictly smaller one): it is not evaluated.
 #define ME_TRY( DX, DY ) do { const int dx_ = ( DX ), dy_ = ( DY );                                                              \
                               if( bestE == 0x7fffffff || dx_ != bestX || dy_ != bestY ) {                                       \
-                                const int e_ = meError( g, bx, by, dx_, dy_, sTmp, lane );                                       \
+                                const int e_ = ME_ERROR( dx_, dy_ );                                                             \
                                 if( e_ < bestE ) { bestX = dx_; bestY = dy_; bestE = e_; } } } while( 0 )
+#define ME_ERROR( DX, DY ) meError( g, bx, by, ( DX ), ( DY ), sTmp, lane )
 
 // One refinement ring of estimateLumaLn's final level (MCTF.cpp:1229-1288): the 8 positions (cx + x2, cy + y2), x2, y2 in {-a, 0, a} without the centre, tested in the
 // reference's order (y2 outer, x2 inner) with its strict-< update.  The three x positions share their horizontal passes: one pass per x position over the rows any of its
@@ -264,6 +285,13 @@ meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int fac
   const int bs = g.bs, bx = bxi * bs, by = byi * bs;
 
   int bestX = 0, bestY = 0, bestE = 0x7fffffff;
+  // full 32 x 32 blocks: integer vectors are scored from registers (errInt32); anything else takes the general path
+  const bool full32 = bs == 32 && bx + 32 <= g.width && by + 32 <= g.height;
+  Org32 O32 = {};
+  if( full32 ) O32 = loadOrg32( g.org + bx + ( ptrdiff_t ) by * g.orgStride, g.orgStride, g.bufStride, lane );
+#undef ME_ERROR
+#define ME_ERROR( DX, DY ) ( ( full32 && ( ( ( DX ) | ( DY ) ) & 15 ) == 0 ) ? errInt32( O32, g.buf + bx + ( DX ) / 16 + ( ptrdiff_t ) ( by + ( DY ) / 16 ) * g.bufStride, g.bufStride, lane ) \
+                                                                           : meError( g, bx, by, ( DX ), ( DY ), sTmp, lane ) )
   int range = doubleRes ? 0 : ( searchPttrn == 2 ? 3 : 5 );              // MCTF.cpp:1178
   if( !prev ) range = 8;                                                  // :1183-1186
   else
@@ -309,6 +337,9 @@ meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int fac
     m.x = bestX; m.y = bestY; m.error = bestE;
   }
 }
+
+#undef ME_ERROR
+#define ME_ERROR( DX, DY ) meError( g, bx, by, ( DX ), ( DY ), sTmp, lane )
 
 // ---- phase B -------------------------------------------------------------------------------------------------------------
 // granule = { tag (hi 32) , x (bits 16..31), y (bits 0..15) }; tag == 1 marks "final"
