@@ -226,13 +226,13 @@ def parity_check(hp, wl, mctf=None):
         res["checked"] = {"distortion_candidates": nd}
     if mctf is not None:
         cur_np, ref_np, field = mctf
-        h, w = 544, 960                                     # a quarter-size crop of the same pictures keeps the scalar oracle within seconds
+        h, w = cur_np.shape                                 # the whole picture (the scalar oracle takes a fraction of a second)
         t0 = time.perf_counter()
         orc = O.Oracle()
-        exp = orc.mctf_me(np.ascontiguousarray(cur_np[:h, :w]), np.ascontiguousarray(ref_np[:h, :w]), wl.bit_depth, 16, 4, False)[4]
+        exp = orc.mctf_me(np.ascontiguousarray(cur_np[:h, :w]), np.ascontiguousarray(ref_np[:h, :w]), wl.bit_depth, 16, 4, w >= 1920)[4]
         cp = hp.plane(np.ascontiguousarray(cur_np[:h, :w]), 128)
         rp = hp.plane(np.ascontiguousarray(ref_np[:h, :w]), 128)
-        outs, dims = hp.mctf_motion_estimation(cp, [rp], wl.bit_depth, 16, 4, False)
+        outs, dims = hp.mctf_motion_estimation(cp, [rp], wl.bit_depth, 16, 4, w >= 1920)
         got = hp.mv_to_numpy(outs[0], dims)
         bad = sum(int((got[k] != exp[k]).sum()) for k in ("x", "y", "error", "rmsme", "overlap"))
         res["mismatches"] += bad
@@ -389,7 +389,7 @@ def main():
     ap.add_argument("--e2e-frames", type=int, default=65)
     ap.add_argument("--e2e-threads", type=int, default=8)
     ap.add_argument("--graph", type=int, default=1, help="extra measurement: the frame's launches replayed from a HIP graph (0 = skip)")
-    ap.add_argument("--overlap-streams", type=int, default=3, help="extra measurement: the frame's launches on this many HIP streams (0/1 = skip)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the three launches of a picture are issued on (1 = one stream, serialized)")
     ap.add_argument("--with-subpel", action="store_true", help="also run the fractional-ME stage per step (16 interpolated HAD_fast candidates per block; SURVEY 8f rank 1)")
     ap.add_argument("--inner", action="store_true", help="(internal) the short run rocprofv3 wraps: frame launches + MCTF stages, no extras, no output line")
     args = ap.parse_args()
@@ -430,15 +430,20 @@ def main():
         ex.publish(0, 0)
 
     step_no = [0]
+    # the three launches of a picture are independent work lists: each goes to its own HIP stream (they share the device, and the steps pipeline per stream)
+    streams = [torch.cuda.Stream() for _ in range(3)] if (args.streams > 1 and wl.merged) else None
 
     def step(timers=None):
         if ex is not None:
             s = step_no[0]
-            ex.publish(s + 1, (s + 1) % world)            # the next picture's reference is in flight while this picture's launches run
-            ex.wait(s)
+            ex.publish(s + 1, (s + 1) % world, readers=streams or ())     # the next picture's reference is in flight while this picture's launches run
+            ex.wait(s, streams)
             wl.ref = ref_planes[s % 2]
             step_no[0] += 1
-        wl.run(timers)
+        if streams:
+            wl.run_overlapped(streams, timers)
+        else:
+            wl.run(timers)
 
     classes = wl.class_launches_merged if wl.merged else wl.class_launches
     # warm-up: every kernel class is bracketed by events (per-class breakdown + choice of the dominant class) ...
@@ -467,20 +472,19 @@ def main():
     if ex is not None:
         wl.ref = ref_planes[0]
 
-    # extra (not `value`): the same steps with the three independent launches of a frame on separate HIP streams / replayed from a HIP graph
+    # extra (not `value`): the same steps with the three launches serialized on ONE stream, and replayed from a HIP graph
     overlap = None
-    if args.overlap_streams > 1 and wl.merged:
-        streams = [torch.cuda.Stream() for _ in range(args.overlap_streams)]
+    if streams:
         for _ in range(max(args.warmup, 1)):
-            wl.run_overlapped(streams)
+            wl.run(None)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            wl.run_overlapped(streams)
+            wl.run(None)
         torch.cuda.synchronize()
         dto = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
-        overlap = {"streams": args.overlap_streams, "value": args.steps * world / dto, "unit": "frames/s", "ms_per_step": 1000.0 * dto / args.steps,
-                   "note": "same work, the 3 launches of a frame issued on separate HIP streams (no per-kernel events, no picture exchange); not the headline value"}
+        overlap = {"streams": 1, "value": args.steps * world / dto, "unit": "frames/s", "ms_per_step": 1000.0 * dto / args.steps,
+                   "note": "same work, the 3 launches of a picture serialized on one HIP stream (no per-kernel events, no picture exchange); not the headline value"}
     graph = None
     if args.graph and wl.merged and not args.with_subpel:
         gh, err, dtl = None, None, 0.0
@@ -518,7 +522,7 @@ def main():
         "dtype": "i16", "data": "synthetic",
         "config": {"workload": "%dx%d 10-bit synthetic picture, preset=faster hot-path work lists: SAD/SATD(HAD_fast)/SSE candidate batches "
                                "(8..64 blocks, 20 candidates/block) + fused DCT-2/quant/dequant/IDCT TU batches (8..32); BASELINE configs[1]" % (args.width, args.height),
-                   "sample_pairs_per_frame": int(wl.pairs), "coefficients_per_frame": int(wl.coefs), "launches_per_frame": 3 if wl.merged else len(wl.dist_jobs) + len(wl.tu_jobs),
+                   "sample_pairs_per_frame": int(wl.pairs), "coefficients_per_frame": int(wl.coefs), "launches_per_frame": 3 if wl.merged else len(wl.dist_jobs) + len(wl.tu_jobs), "hip_streams": len(streams) if streams else 1,
                    "sharding": "one picture per rank and step, pictures of one sequence round-robin over ranks, no data-path collective"
                                + (", reference picture (luma + chroma, %.1f MB) RCCL-broadcast from its owner every step inside the timed region, overlapped with the launches"
                                   % (sum(p.numel() * 2 for p in ex.slots[0]) / 1e6) if ex is not None else ""),
@@ -574,7 +578,7 @@ def main():
                            "frac_hbm_traffic": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                            "limiter": "issue rate of 16-byte gathers (candidate rows are scattered 16..128-byte pieces) and occupancy, not a memory level (DESIGN §3)"}
     if overlap is not None:
-        out["overlap"] = overlap
+        out["single_stream"] = overlap
     if graph is not None:
         out["graph"] = graph
 
@@ -595,11 +599,12 @@ def main():
         try:
             w4 = FrameWorkload(hp, 3840, 2160, seed=2160)
             t4 = EventTimers(list(w4.class_launches_merged), 12, w4.class_launches_merged)
-            w4.run(None)
+            run4 = (lambda t: w4.run_overlapped(streams, t)) if streams else w4.run
+            run4(None)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(10):
-                w4.run(t4)
+                run4(t4)
             torch.cuda.synchronize()
             d4 = time.perf_counter() - t1
             s4 = t4.summary()

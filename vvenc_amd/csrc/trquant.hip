@@ -1266,6 +1266,21 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
     unsigned long long sse[R];
 #pragma unroll
     for( int r = 0; r < R; r++ ) sse[r] = 0;
+    // SSE: when every residual and reconstructed sample of the wave is within +-4095 (any residual of <= 12-bit video) a difference fits 14 bits, a lane's 16 squares
+    // fit 32 bits and the sum is eight packed subtractions + eight v_dot2_i32_i16; otherwise (arbitrary int16 input) the 64-bit multiply-adds
+    uint32_t rpAll[8];
+    uint32_t magn = 0;
+#pragma unroll
+    for( int k = 0; k < 8; k++ )
+    {
+      rpAll[k] = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( d[2 * k], d[2 * k + 1] ) );          // saturate + pack
+      magn |= ( rpAll[k] ^ ( uint32_t ) ( ( int ) ( rpAll[k] << 16 ) >> 31 & 0xffff ) ^ ( uint32_t ) ( ( int ) rpAll[k] >> 31 << 16 ) );   // x ^ sign(x) per half: < 4096 iff -4096 <= x <= 4095
+      magn |= ( xr2[k] ^ ( uint32_t ) ( ( int ) ( xr2[k] << 16 ) >> 31 & 0xffff ) ^ ( uint32_t ) ( ( int ) xr2[k] >> 31 << 16 ) );
+    }
+    const bool smallDiff = __builtin_amdgcn_ballot_w64( ( magn & 0xf000f000u ) != 0 ) == 0ull;
+    uint32_t sse32[R];
+#pragma unroll
+    for( int r = 0; r < R; r++ ) sse32[r] = 0;
 #pragma unroll
     for( int c = 0; c < NP; c++ )
     {
@@ -1275,10 +1290,19 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 #pragma unroll
       for( int k = 0; k < PS / 2; k++ )
       {
-        const int v = PS * c + 2 * k, xi = ( PS / 2 ) * c + k;
-        rp[k] = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( d[v], d[v + 1] ) );           // saturate + pack
-        const int e0 = ( int ) ( int16_t ) ( xr2[xi] & 0xffff ) - ( int ) ( int16_t ) ( rp[k] & 0xffff ), e1 = ( ( int ) xr2[xi] >> 16 ) - ( ( int ) rp[k] >> 16 );
-        sse[( PS * c ) / N < R ? ( PS * c ) / N : 0] += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 );
+        const int xi = ( PS / 2 ) * c + k;
+        rp[k] = rpAll[xi];
+        const int slot = ( PS * c ) / N < R ? ( PS * c ) / N : 0;
+        if( smallDiff )
+        {
+          const uint32_t df = __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, xr2[xi] ) - __builtin_bit_cast( s16x2, rp[k] ) );
+          sse32[slot] = ( uint32_t ) dot2( df, df, ( int ) sse32[slot] );
+        }
+        else
+        {
+          const int e0 = ( int ) ( int16_t ) ( xr2[xi] & 0xffff ) - ( int ) ( int16_t ) ( rp[k] & 0xffff ), e1 = ( ( int ) xr2[xi] >> 16 ) - ( ( int ) rp[k] >> 16 );
+          sse[slot] += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 );
+        }
       }
       if( A.rec && tu < A.n )
       {
@@ -1290,7 +1314,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 #pragma unroll
     for( int r = 0; r < R; r++ )
     {
-      const unsigned long long t = vvhipGroupSum64( sse[r], G, lane );
+      const unsigned long long t = vvhipGroupSum64( smallDiff ? ( unsigned long long ) sse32[r] : sse[r], G, lane );      // (the group sum is exact up to 2^50 per lane)
       const int tu = tile * TPT + blkL * TPS + blk0 + r;
       if( A.stats && ( N < 32 || h == 0 ) && inL == r && tu < A.n ) A.stats[tu].sse = t;
     }

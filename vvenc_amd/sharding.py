@@ -93,7 +93,8 @@ class PictureExchange:
     def slot(self, frame):
         return self.slots[frame % self.n_slots]
 
-    def publish(self, frame, owner):
+    def publish(self, frame, owner, readers=()):
+        """readers: extra (compute) streams whose earlier work reads / writes this slot — the broadcast waits for them too"""
         planes = self.slot(frame)
         self.bytes_published += sum(p.numel() * p.element_size() for p in planes)
         if not dist.is_initialized():
@@ -102,6 +103,8 @@ class PictureExchange:
         if self.is_cuda:
             # the broadcast must see what the compute stream wrote into the slot (owner) / must not overwrite a slot still being read (others)
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            for r in readers:
+                self.stream.wait_stream(r)
             with torch.cuda.stream(self.stream):
                 for p in planes:
                     broadcast_picture(p, owner)
@@ -111,12 +114,14 @@ class PictureExchange:
         else:
             self.pending[frame] = [broadcast_picture(p, owner, async_op=True) for p in planes]
 
-    def wait(self, frame):
+    def wait(self, frame, streams=None):
+        """streams: the compute streams that will read the picture (default: the current stream)"""
         h = self.pending.pop(frame, None)
         if h is None:
             return self.slot(frame)
         if self.is_cuda:
-            torch.cuda.current_stream(self.device).wait_event(h)
+            for st in (streams or [torch.cuda.current_stream(self.device)]):
+                st.wait_event(h)
         else:
             for w in h:
                 w.wait()

@@ -150,16 +150,21 @@ class FrameWorkload:
         if timers is not None:
             timers.stop("SUBPEL")
 
-    def run_overlapped(self, streams):
-        """the same four launches, each on its own HIP stream (they are independent work lists): successive steps pipeline per stream"""
+    def run_overlapped(self, streams, timers=None):
+        """the same three launches, each on its own HIP stream (they are independent work lists): they share the device and successive steps pipeline per stream.
+        timers: per-class HIP events, recorded on the class's own stream"""
         import torch
         hp = self.hp
-        calls = [lambda c=c: hp.dist_multi_func(self.org, self.ref, self.fjob_tables[c], self.bit_depth) for c in ("SAD_SSE", "HAD_fast")]
-        calls.append(lambda: hp.tu_rdo_multi(self.resi, self.tu_table, self.bit_depth))
-        for i, c in enumerate(calls):
+        calls = [(c, (lambda c=c: hp.dist_multi_func(self.org, self.ref, self.fjob_tables[c], self.bit_depth))) for c in ("SAD_SSE", "HAD_fast")]
+        calls.append(("TU", lambda: hp.tu_rdo_multi(self.resi, self.tu_table, self.bit_depth)))
+        for i, (cls, c) in enumerate(calls):
             with torch.cuda.stream(streams[i % len(streams)]):
                 hp.use_torch_stream()
+                if timers is not None:
+                    timers.start(cls)
                 c()
+                if timers is not None:
+                    timers.stop(cls)
         hp.use_torch_stream()
 
     # one pass of the hot path over the frame: 2 merged distortion launches (SAD+SSE, Hadamard) + 1 merged fused-TU launch (or 12 + 3 per-size ones)
