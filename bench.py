@@ -446,21 +446,13 @@ def main():
             wl.run(timers)
 
     classes = wl.class_launches_merged if wl.merged else wl.class_launches
-    # warm-up: every kernel class is bracketed by events (per-class breakdown + choice of the dominant class) ...
-    # (the first warm-up step carries the cold-launch costs and is left out of the per-class figures when there is more than one)
-    wtimers = None if args.no_kernel_timers else EventTimers(list(classes), max(args.warmup, 1), classes)
-    nwarm = max(args.warmup, 1) if wtimers is not None else args.warmup
-    for i in range(nwarm):
-        step(wtimers if (i > 0 or nwarm == 1) else None)
+    for _ in range(args.warmup):
+        step(None)
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
-    # ... timed region: only the dominant class keeps its event pair (2 event records per step instead of 6: events are not free)
-    timers, dom_cls, wsum = None, None, None
-    if wtimers is not None:
-        wsum = wtimers.summary()
-        dom_cls = max(wsum, key=lambda k: wsum[k]["total_ms"])
-        timers = EventTimers([dom_cls], args.steps, classes)
+    # timed region: every kernel class keeps an event pair on its own stream (concurrent launch durations: the classes share the device)
+    timers = None if args.no_kernel_timers else EventTimers(list(classes), args.steps, classes)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timers)
@@ -472,19 +464,21 @@ def main():
     if ex is not None:
         wl.ref = ref_planes[0]
 
-    # extra (not `value`): the same steps with the three launches serialized on ONE stream, and replayed from a HIP graph
-    overlap = None
-    if streams:
+    # the same K steps with the three launches SERIALIZED on one stream: the regime in which a kernel's launch duration is its own (roofline), and the one the
+    # rocprofv3 trace of the inner run shows; also an extra throughput figure (not `value`)
+    overlap, stimers = None, None
+    if streams or timers is not None:
         for _ in range(max(args.warmup, 1)):
             wl.run(None)
         torch.cuda.synchronize()
+        stimers = None if args.no_kernel_timers else EventTimers(list(classes), args.steps, classes)
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            wl.run(None)
+            wl.run(stimers)
         torch.cuda.synchronize()
         dto = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
         overlap = {"streams": 1, "value": args.steps * world / dto, "unit": "frames/s", "ms_per_step": 1000.0 * dto / args.steps,
-                   "note": "same work, the 3 launches of a picture serialized on one HIP stream (no per-kernel events, no picture exchange); not the headline value"}
+                   "note": "same work, the 3 launches of a picture serialized on one HIP stream (per-class events, no picture exchange); not the headline value"}
     graph = None
     if args.graph and wl.merged and not args.with_subpel:
         gh, err, dtl = None, None, 0.0
@@ -539,18 +533,16 @@ def main():
         except Exception as e:
             out["kernel_trace"] = {"error": str(e)[:300]}
 
-    if timers is not None:
-        ks = wsum                                             # all classes, measured over the warm-up steps
-        nw = max(nwarm - 1, 1)
+    if stimers is not None:
+        ks = stimers.summary()                                # every class, K steps, launches serialized on one stream
+        conc = timers.summary() if timers is not None else {}
+        dom_cls = max(ks, key=lambda k: ks[k]["total_ms"])
         for k in ks:
             ks[k]["alg_bytes_per_frame"] = int(wl.alg_bytes[k])
-            ks[k]["alg_GBps"] = wl.alg_bytes[k] * nw / (ks[k]["total_ms"] * 1e-3) / 1e9
-            ks[k]["measured_over"] = "%d warm-up steps" % nw
-        td = timers.summary()[dom_cls]                        # the dominant class, measured over the timed region
-        td["alg_bytes_per_frame"] = int(wl.alg_bytes[dom_cls])
-        td["alg_GBps"] = wl.alg_bytes[dom_cls] * args.steps / (td["total_ms"] * 1e-3) / 1e9
-        td["measured_over"] = "%d timed steps" % args.steps
-        ks[dom_cls] = td
+            ks[k]["alg_GBps"] = wl.alg_bytes[k] * args.steps / (ks[k]["total_ms"] * 1e-3) / 1e9
+            ks[k]["measured_over"] = "%d steps, launches serialized on one stream" % args.steps
+            if k in conc:
+                ks[k]["avg_ms_in_timed_region"] = conc[k]["avg_ms"]      # on its own stream, concurrently with the other two classes
         for k in ks:
             ub = unique_bytes(wl, k) if k in ("SAD_SSE", "HAD_fast", "TU") else None
             if ub:
@@ -573,6 +565,10 @@ def main():
                            "basis": "NOMINAL: per-candidate algorithmic bytes (4*w*h per candidate + 8 B result, rows halved under subShift; fused TU = 6*w*h + 24 B; SURVEY 8d) / HIP-event launch time. "
                                     "Candidates of a block share their original block and overlap in the reference window, so most of these bytes are served by L2 / Infinity Cache; the physical positions are the next three fields",
                            "alg_bytes_per_launch": alg_launch, "avg_launch_ms": ks[dom_cls]["avg_ms"],
+                           "avg_launch_ms_measured": "HIP events on the launch stream, %d steps with the picture's launches serialized (the kernel alone on the device; the rocprofv3 trace of the inner run shows the same regime); "
+                                                     "in the timed region the three classes run concurrently on three streams and this class's launches last avg_launch_ms_concurrent" % args.steps,
+                           "avg_launch_ms_concurrent": ks[dom_cls].get("avg_ms_in_timed_region"),
+                           "aggregate_alg_GBps_timed_region": sum(wl.alg_bytes[k] for k in classes) * frames / dt / 1e9,
                            "frac_l2": ks[dom_cls]["alg_GBps"] / L2_PEAK_GBS, "l2_peak_GBps": L2_PEAK_GBS,
                            "unique_bytes_per_launch": ks[dom_cls].get("unique_bytes_per_launch"), "frac_hbm_unique": ks[dom_cls].get("frac_hbm_unique"),
                            "frac_hbm_traffic": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,

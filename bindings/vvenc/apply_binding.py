@@ -298,6 +298,14 @@ patch("EncSlice.cpp", [
     ("after", '#include "EncSlice.h"', INC),
     ("after", "  CtuEncParam* ctuEncParam       = static_cast<CtuEncParam*>( taskParam );\n  Picture* pic                   = ctuEncParam->pic;\n",
      "  if( !checkReadyState && g_vvhipHooks.bindPicture ) g_vvhipHooks.bindPicture( pic->poc );\n"),
+    # a CTU row of the reconstruction is final (borders extended): its luma rows go to the picture's device mirrors
+    ("before", "          // for IFP lines synchro, do an additional increment signaling that CTU row is ready",
+     "          if( g_vvhipHooks.reconRows )\n"
+     "          {\n"
+     "            const CPelBuf hY = recoBuf.Y();\n"
+     "            const int hTop = ctuPosY == 0 ? margin : 0, hBot = ctuPosY + 1 == pcv.heightInCtus ? margin : 0;\n"
+     "            g_vvhipHooks.reconRows( hY.buf, ( int ) hY.stride, hY.width, hY.height, margin, y - hTop, height + hTop + hBot );\n"
+     "          }\n"),
 ], sub="EncoderLib")
 
 # run-time selection through the reference's own switch: --SIMD=HIP[:mask] / vvenc_set_SIMD_extension( "HIP" ) installs the binding, the CPU levels below it stay at their best

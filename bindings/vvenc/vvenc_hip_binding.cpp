@@ -375,6 +375,49 @@ bool mctfApply( const vvenc::MCTF* m, const vvenc::PelStorage& orgPic, void* inf
   return true;
 }
 
+// ---- resident reconstruction pictures: every finished (border-extended) CTU row of a picture's luma reconstruction is uploaded to that picture's mirror on every GPU
+// in use (the "broadcast of reference pictures" of SURVEY 8e, host -> each device: the producer is the host).  Mirrors are keyed by the host buffer (buffers are recycled
+// for later pictures: rows are simply overwritten as the next picture finishes them) and marked reference-only.
+struct ReconMirror { int ids[16]; int stride, width, height, margin; };
+std::mutex g_reconLock;
+std::map<const int16_t*, ReconMirror> g_recon;
+std::atomic<uint64_t> g_reconRowUploads{ 0 };
+
+void reconRows( const int16_t* origin, int stride, int width, int height, int margin, int y0, int rows )
+{
+  const int nGpus = std::min( numGpus(), 16 );
+  ReconMirror rm;
+  {
+    std::lock_guard<std::mutex> g( g_reconLock );
+    auto it = g_recon.find( origin );
+    if( it != g_recon.end() && ( it->second.stride != stride || it->second.width != width || it->second.height != height || it->second.margin != margin ) )
+    {
+      for( int k = 0; k < nGpus; k++ ) { GpuScope sc( ( vvhip::Device::defaultGpu() + k ) % numGpus() ); vvhip::Device::get().unregisterPicture( it->second.ids[k] ); }
+      g_recon.erase( it ); it = g_recon.end();
+    }
+    if( it == g_recon.end() )
+    {
+      ReconMirror n; n.stride = stride; n.width = width; n.height = height; n.margin = margin;
+      vvhip::Device::pinHost( origin - ( ptrdiff_t ) margin * stride - margin, ( size_t ) stride * ( height + 2 * margin ) * sizeof( int16_t ) );
+      for( int k = 0; k < nGpus; k++ )
+      {
+        GpuScope sc( ( vvhip::Device::defaultGpu() + k ) % numGpus() );
+        vvhip::Device& dev = vvhip::Device::get();
+        n.ids[k] = dev.registerPicture( origin, stride, width, height, margin, false, false );
+        dev.setReference( n.ids[k] );
+      }
+      it = g_recon.emplace( origin, n ).first;
+    }
+    rm = it->second;
+  }
+  for( int k = 0; k < nGpus; k++ )
+  {
+    GpuScope sc( ( vvhip::Device::defaultGpu() + k ) % numGpus() );
+    vvhip::Device::get().updatePictureRows( rm.ids[k], y0, rows );
+  }
+  g_reconRowUploads++;
+}
+
 // one xPatternRefinement stage (EncoderLib/InterSearch.cpp:760-880) scored by ONE batched device call: positions = (refine[i] + base) * iFrac in
 // quarter samples around the block at the best integer vector; the encoder's loop replays the costs (skip / break rules, MV bits, strict <)
 std::atomic<uint64_t> g_patternCalls( 0 );
@@ -633,6 +676,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_install( i
   g_vvhipHooks.mctfWants  = ( mask & 16 ) ? mctfWants : nullptr;
   g_vvhipHooks.mctfPrefetch = ( mask & 16 ) ? mctfPrefetch : nullptr;
   g_vvhipHooks.bindPicture = mask ? bindPicture : nullptr;
+  g_vvhipHooks.reconRows = ( mask & ( 256 | 1024 ) ) ? reconRows : nullptr;      // the search sites that address reference pictures in HBM
   g_vvhipHooks.initIF     = ( mask & 64 ) ? initIF : nullptr;
   g_vvhipHooks.mctfApply  = ( mask & 128 ) ? mctfApply : nullptr;
   g_vvhipHooks.patternCosts = ( mask & 256 ) ? patternCosts : nullptr;
@@ -671,6 +715,11 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvenc_hip_release( 
   {
     { std::lock_guard<std::mutex> g( g_mctfLock ); while( !g_resident.empty() ) dropResident( 0 ); g_meCache.curPoc = -1; g_meCache.fields.clear(); }
     { std::lock_guard<std::mutex> g( g_alfPicLock ); for( auto& kv : g_alfState ) { kv.second->done = false; kv.second->donePoc = -1; kv.second->ops->dropResident(); } }
+    {
+      std::lock_guard<std::mutex> g( g_reconLock );
+      for( auto& kv : g_recon ) for( int k = 0; k < std::min( numGpus(), 16 ); k++ ) { GpuScope sc( ( vvhip::Device::defaultGpu() + k ) % numGpus() ); vvhip::Device::get().unregisterPicture( kv.second.ids[k] ); }
+      g_recon.clear();
+    }
     vvhip::Device::unpinAll();
   }
   catch( const std::exception& e ) { fprintf( stderr, "vvenc_hip_release: %s\n", e.what() ); }
@@ -682,7 +731,8 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
 }
 // counters: 0-9 table-entry classes (8 interpolation, 9 MCTF filter pictures), 10 sub-pel stages, 11 DMVR searches, 12 TZ rounds, 13 TZ hits, 14 ALF CTUs, 15 CC-ALF CTUs,
 // 16 ALF statistics pictures, 17 ALF filter blocks, 18 CC-ALF filter blocks, 19 ALF filter pictures, 20 LFNST TUs left to the CPU quantiser, 21 MCTF device ME calls,
-// 22 original-picture uploads, 23 resident hits, 24 device-to-device picture copies, 25 PCIe bytes up, 26 PCIe bytes down, 27 worker contexts, 28 GPUs in use
+// 22 original-picture uploads, 23 resident hits, 24 device-to-device picture copies, 25 PCIe bytes up, 26 PCIe bytes down, 27 worker contexts, 28 GPUs in use,
+// 29 reconstruction CTU-row uploads, 30 search-stage calls served from a resident reference picture
 extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_calls_ex( uint64_t* out, int n )
 {
   for( int i = 0; i < n && i < 10; i++ ) out[i] = g_calls[i];
@@ -701,9 +751,11 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
   if( n > 22 ) out[22] = g_residentUploads;
   if( n > 23 ) out[23] = g_residentHits;
   if( n > 24 ) out[24] = g_residentPeerCopies;
+  if( n > 29 ) out[29] = g_reconRowUploads;
   if( n > 28 )
   {
     const vvhip::Device::Stats st = vvhip::Device::stats();
     out[25] = st.uploadBytes; out[26] = st.downloadBytes; out[27] = st.contexts; out[28] = ( uint64_t ) numGpus();
+    if( n > 30 ) out[30] = st.residentReferenceCalls;
   }
 }

@@ -24,6 +24,9 @@ struct VvhipHooks
   void ( *mctfPrefetch )( vvenc::MCTF* m, const void* picFifoDeque, int dropFront, int dropBack, const vvenc::PelStorage& orig, bool addLevel, int filterPoc );
   // the worker thread starts a CTU task of the picture with this POC: binds the thread to the picture's GPU (one picture <-> one device)
   void ( *bindPicture )( int poc );
+  // a CTU row of a picture's luma reconstruction is final (in-loop filters done, borders extended, EncSlice.cpp:1381-1386): rows [y0, y0 + rows) incl. margin rows go to
+  // the device mirror of that picture on every GPU in use — the motion-search hooks then address reference pictures in HBM instead of staging windows per call
+  void ( *reconRows )( const int16_t* origin, int stride, int width, int height, int margin, int y0, int rows );
   // EncAdaptiveLoopFilter::deriveFilter starts on a new picture (resets the whole-picture filtering bookkeeping of this ALF object)
   void ( *alfBeginPicture )( const void* owner, int poc );
   bool ( *fwd2D )( const int16_t* resi, ptrdiff_t stride, int32_t* coef, unsigned width, unsigned height, int trTypeHor, int trTypeVer, int bitDepth );

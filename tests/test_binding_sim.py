@@ -95,6 +95,19 @@ def test_pictures_shard_over_devices():
         assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (n, cpu, hip)
 
 
+def test_reference_pictures_resident_for_the_search_sites():
+    """reconstructed pictures are mirrored CTU row by CTU row (EncSlice border extension); the TZ diamond rounds and the sub-pel refinement stages then address the reference
+    picture in device memory (offsets only) instead of staging a window per call; two logical devices: every device gets every reconstruction"""
+    need()
+    clip = dict(CLIP, frames=9, preset="medium", threads=4)
+    cpu = run(dict(clip, hip=False, mask=0))
+    for env in (sim_env(), sim_env(VVHIP_LOGICAL_GPUS=2, VVHIP_GPUS=2)):
+        hip = run(dict(clip, hip=True, mask=1 + 256 + 1024), env=env)
+        c = hip["calls"]
+        assert c[29] >= 9 and c[30] > 1000 and c[10] > 100 and c[12] > 100, c      # CTU-row uploads, search calls served from resident pictures
+        assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
 def test_lfnst_tus_stay_with_the_cpu_quantiser():
     need()
     clip = dict(CLIP, frames=5, preset="fast", options="RDOQ=0;DepQuant=0;LFNST=1")

@@ -34,7 +34,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(29, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 29); calls = [int(x) for x in c]
+    c = np.zeros(31, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 31); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -334,6 +334,7 @@ def test_hip_presets_batched_search_sites_bitstream_identical(preset):
     hip = run(dict(clip, hip=True, mask=BATCHED_SITES))
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][10] > 100 and hip["calls"][12] > 100, hip["calls"]
+    assert hip["calls"][29] >= 5 and hip["calls"][30] > 100, hip["calls"]      # reconstruction rows mirrored, search stages served from the resident reference pictures
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
 
 
@@ -389,4 +390,20 @@ def test_hip_8k_fast_picture_stages_bitstream_identical():
     hip = run(dict(clip, hip=True, simd="HIP"))
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][16] >= 1 and hip["calls"][19] >= 1, hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+def test_hip_pictures_shard_over_logical_devices_bitstream_identical():
+    """SURVEY 8e in the binding, on one physical GPU: VVHIP_LOGICAL_GPUS=2 makes the shim present two devices (both on GPU 0), VVHIP_GPUS=2 makes the binding spread the
+    pictures over them — per-device registries, thread -> device binding per picture, device-to-device copies (hipMemcpyPeerAsync) of originals another device already holds.
+    Preset medium (overlapping MCTF windows => peer copies), 25 frames, 4 threads; bitstream equal to the CPU encode's"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+    clip = dict(CLIP416, frames=25, preset="medium")
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, simd="HIP"), env={"VVHIP_LOGICAL_GPUS": "2", "VVHIP_GPUS": "2"})
+    print("cpu", cpu, "hip", hip)
+    c = hip["calls"]
+    assert c[28] == 2 and c[24] >= 1 and c[9] >= 1, c          # two devices in use, device-to-device picture copies, MCTF filter pictures
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)

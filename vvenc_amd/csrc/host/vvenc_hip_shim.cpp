@@ -17,7 +17,7 @@ static int ilog2( unsigned v ) { int l = 0; while( ( 1u << ( l + 1 ) ) <= v ) l+
 
 // ------------------------------------------------------------------------------------------------ Device
 namespace {
-std::atomic<uint64_t> g_upBytes{ 0 }, g_downBytes{ 0 }, g_ups{ 0 }, g_downs{ 0 }, g_contexts{ 0 };
+std::atomic<uint64_t> g_upBytes{ 0 }, g_downBytes{ 0 }, g_ups{ 0 }, g_downs{ 0 }, g_contexts{ 0 }, g_refCalls{ 0 };
 // every transfer of this translation unit is counted (Device::stats): the macros below route the C ABI's copy calls through these
 // host ranges pinned in place (Device::pinHost): whole pages INSIDE a recycled picture buffer.  A copy whose host range starts inside a pinned range must end inside it
 // (the runtime treats it as pinned as a whole), so an upload is cut at the borders of the pinned ranges it touches: the page-aligned body goes as asynchronous DMA, the
@@ -84,7 +84,10 @@ thread_local ThreadDevices t_dev;
 }
 
 int Device::defaultGpu() { static const int g = []{ const char* e = getenv( "VVHIP_DEVICE" ); return e ? atoi( e ) : 0; }(); return g; }
-int Device::gpuCount() { return vvhip_device_count(); }
+// $VVHIP_LOGICAL_GPUS = N: the shim presents N devices whatever the box has; logical device g lives on physical device g mod (physical count).  Every structure above the
+// C ABI (per-device registries, thread -> device binding, device-to-device picture copies) then runs exactly as on N GPUs — how the sharded path is tested on a 1-GPU box.
+static int logicalGpus() { static const int n = []{ const char* e = getenv( "VVHIP_LOGICAL_GPUS" ); return e ? atoi( e ) : 0; }(); return n; }
+int Device::gpuCount() { return logicalGpus() > 0 ? logicalGpus() : vvhip_device_count(); }
 void Device::selectGpu( int gpu ) { t_dev.selected = gpu; }
 
 Device& Device::get()
@@ -99,13 +102,14 @@ Device& Device::get()
 
 Device::Device( int gpu ) : m_gpu( gpu )
 {
-  const int rc = vvhip_create( &m_ctx, gpu );
+  const int phys = vvhip_device_count();
+  const int rc = vvhip_create( &m_ctx, logicalGpus() > 0 && phys > 0 ? gpu % phys : gpu );
   if( rc != VVHIP_OK ) throw Exception( std::string( "vvhip::Device: " ) + vvhip_last_error( nullptr ) );
   g_contexts++;
 }
 Device::~Device() {}
 
-Device::Stats Device::stats() { return { g_upBytes.load(), g_downBytes.load(), g_ups.load(), g_downs.load(), g_contexts.load() }; }
+Device::Stats Device::stats() { return { g_upBytes.load(), g_downBytes.load(), g_ups.load(), g_downs.load(), g_contexts.load(), g_refCalls.load() }; }
 
 void Device::check( int rc, const char* what ) const
 {
@@ -159,7 +163,7 @@ Pel* PinnedBuffer::get( size_t elems )
 int Device::registerPicture( const Pel* origin, int stride, int width, int height, int margin, bool findable, bool upload )
 {
   Mirror m;
-  m.origin = origin; m.stride = stride; m.width = width; m.height = height; m.margin = margin; m.live = true; m.findable = findable;
+  m.origin = origin; m.stride = stride; m.width = width; m.height = height; m.margin = margin; m.live = true; m.findable = findable; m.reference = false;
   m.hostBase = origin - ( ptrdiff_t ) margin * stride - margin;
   const size_t elems = ( size_t ) stride * ( height + 2 * margin );
   m.hostEnd = m.hostBase + elems;
@@ -192,6 +196,17 @@ void Device::updatePicture( int id )
   check( vvhip_sync( m_ctx ), "updatePicture" );
 }
 
+void Device::updatePictureRows( int id, int y0, int rows )
+{
+  const Mirror m = mirror( id );
+  if( y0 < -m.margin ) { rows -= -m.margin - y0; y0 = -m.margin; }
+  if( y0 + rows > m.height + m.margin ) rows = m.height + m.margin - y0;
+  if( rows <= 0 ) return;
+  const ptrdiff_t off = ( ptrdiff_t ) ( y0 + m.margin ) * m.stride;
+  check( vvhip_upload( m_ctx, m.dBase + off, m.hostBase + off, ( size_t ) rows * m.stride * sizeof( Pel ) ), "updatePictureRows" );
+  check( vvhip_sync( m_ctx ), "updatePictureRows" );
+}
+
 void Device::unregisterPicture( int id )
 {
   Registry& r = registry( m_gpu );
@@ -219,6 +234,22 @@ const Device::Mirror* Device::find( const Pel* p ) const
   Registry& r = registry( m_gpu );
   std::lock_guard<std::mutex> g( r.m );
   for( const Mirror& m : r.mirrors ) if( m.live && m.findable && p >= m.hostBase && p < m.hostEnd ) return &m;
+  return nullptr;
+}
+
+void Device::setReference( int id )
+{
+  Registry& r = registry( m_gpu );
+  std::lock_guard<std::mutex> g( r.m );
+  Mirror& m = r.mirrors.at( id );
+  m.reference = true; m.findable = false;
+}
+
+const Device::Mirror* Device::findReference( const Pel* p ) const
+{
+  Registry& r = registry( m_gpu );
+  std::lock_guard<std::mutex> g( r.m );
+  for( const Mirror& m : r.mirrors ) if( m.live && m.reference && p >= m.hostBase && p < m.hostEnd ) return &m;
   return nullptr;
 }
 
@@ -396,7 +427,10 @@ void RdCost::distAtPositions( int func, const CPelBuf& org, const Pel* refBase, 
   const int w = org.width, h = org.height;
   int x0 = xy[0][0], x1 = xy[0][0], y0 = xy[0][1], y1 = xy[0][1];
   for( int i = 1; i < n; i++ ) { x0 = std::min( x0, xy[i][0] ); x1 = std::max( x1, xy[i][0] ); y0 = std::min( y0, xy[i][1] ); y1 = std::max( y1, xy[i][1] ); }
-  const int pw = x1 - x0 + w, ph = y1 - y0 + h;
+  const Device::Mirror* mr = dev.findReference( refBase );
+  const bool resident = mr && mr->stride == refStride;      // the reference picture is mirrored in HBM (binding: reconstructed pictures, row by row): only offsets travel
+  if( resident ) g_refCalls++;
+  const int pw = resident ? 0 : x1 - x0 + w, ph = resident ? 0 : y1 - y0 + h;
   std::vector<Pel> host( ( size_t ) w * h + ( size_t ) pw * ph );
   for( int y = 0; y < h; y++ ) memcpy( &host[( size_t ) y * w], org.buf + ( ptrdiff_t ) y * org.stride, sizeof( Pel ) * w );
   Pel* win = host.data() + ( size_t ) w * h;
@@ -404,11 +438,17 @@ void RdCost::distAtPositions( int func, const CPelBuf& org, const Pel* refBase, 
   int16_t* dArea = dev.staging( host.size() * sizeof( Pel ) + 256 );
   dev.check( vvhip_upload( dev.ctx(), dArea, host.data(), host.size() * sizeof( Pel ) ), "search stage" );
   std::vector<vvhip_dist_item> items( n );
-  for( int i = 0; i < n; i++ ) { items[i].org_off = 0; items[i].cur_off = ( xy[i][1] - y0 ) * pw + ( xy[i][0] - x0 ); }
+  const ptrdiff_t base = resident ? refBase - mr->origin : 0;
+  for( int i = 0; i < n; i++ )
+  {
+    items[i].org_off = 0;
+    items[i].cur_off = resident ? ( int32_t ) ( base + ( ptrdiff_t ) xy[i][1] * refStride + xy[i][0] ) : ( xy[i][1] - y0 ) * pw + ( xy[i][0] - x0 );
+  }
   char* aux = static_cast<char*>( dev.stagingAux( ( size_t ) n * ( sizeof( vvhip_dist_item ) + sizeof( uint64_t ) ) + 64 ) );
   uint64_t* dOut = reinterpret_cast<uint64_t*>( aux + ( ( ( size_t ) n * sizeof( vvhip_dist_item ) + 15 ) & ~( size_t ) 15 ) );
   dev.check( vvhip_upload( dev.ctx(), aux, items.data(), ( size_t ) n * sizeof( vvhip_dist_item ) ), "search stage" );
-  dev.check( vvhip_dist_batch( dev.ctx(), func, dArea, w, dArea + ( size_t ) w * h, pw, w, h, subShift, bitDepth, reinterpret_cast<vvhip_dist_item*>( aux ), n, dOut ), "vvhip_dist_batch" );
+  dev.check( vvhip_dist_batch( dev.ctx(), func, dArea, w, resident ? mr->dOrigin : dArea + ( size_t ) w * h, resident ? refStride : pw, w, h, subShift, bitDepth,
+                               reinterpret_cast<vvhip_dist_item*>( aux ), n, dOut ), "vvhip_dist_batch" );
   std::vector<uint64_t> res( n );
   dev.check( vvhip_download( dev.ctx(), res.data(), dOut, ( size_t ) n * sizeof( uint64_t ) ), "search stage" );
   for( int i = 0; i < n; i++ ) out[i] = res[i];
@@ -421,8 +461,11 @@ bool RdCost::patternRefineCosts( const CPelBuf& org, const Pel* refBlk, int refS
   if( ( w & 7 ) || w > 64 || h > 64 || h < 4 || n < 1 || n > 16 || reduceTap < 0 || reduceTap > 2 ) return false;
   if( ( hadMode == 1 || hadMode == 2 ) && ( h & 3 ) ) return false;
   Device& dev = Device::get();
-  const int M0 = 5, M1 = 6, pitch = w + M0 + M1, rows = h + M0 + M1;
-  std::vector<Pel> host( ( size_t ) w * h + ( size_t ) pitch * rows );
+  const Device::Mirror* mr = dev.findReference( refBlk );
+  const bool resident = mr && mr->stride == refStride;      // reference picture mirrored in HBM: the block's window is not staged
+  if( resident ) g_refCalls++;
+  const int M0 = 5, M1 = 6, pitch = resident ? refStride : w + M0 + M1, rows = resident ? 0 : h + M0 + M1;
+  std::vector<Pel> host( ( size_t ) w * h + ( resident ? 0 : ( size_t ) pitch * rows ) );
   for( int y = 0; y < h; y++ ) memcpy( &host[( size_t ) y * w], org.buf + ( ptrdiff_t ) y * org.stride, sizeof( Pel ) * w );
   Pel* win = host.data() + ( size_t ) w * h;
   for( int y = 0; y < rows; y++ ) memcpy( win + ( size_t ) y * pitch, refBlk + ( ptrdiff_t ) ( y - M0 ) * refStride - M0, sizeof( Pel ) * pitch );
@@ -430,13 +473,14 @@ bool RdCost::patternRefineCosts( const CPelBuf& org, const Pel* refBlk, int refS
   dev.check( vvhip_upload( dev.ctx(), dArea, host.data(), host.size() * sizeof( Pel ) ), "pattern refinement" );
   struct Io { vvhip_subpel_item base; uint32_t pad; uint64_t cost[16]; } io;
   memset( &io, 0, sizeof( io ) );
-  io.base.org_off = 0; io.base.ref_off = M0 * pitch + M0; io.base.frac_x = 0; io.base.frac_y = 0;
+  io.base.org_off = 0; io.base.ref_off = resident ? ( int32_t ) ( refBlk - mr->origin ) : M0 * pitch + M0; io.base.frac_x = 0; io.base.frac_y = 0;
   char* aux = static_cast<char*>( dev.stagingAux( sizeof( Io ) ) );
   dev.check( vvhip_upload( dev.ctx(), aux, &io, sizeof( io ) ), "pattern refinement" );
+  const int16_t* dRef = resident ? mr->dOrigin : dArea + ( size_t ) w * h;
   int16_t offs[32];
   for( int i = 0; i < n; i++ ) { offs[2 * i] = ( int16_t ) ( qpel[i][0] * 4 ); offs[2 * i + 1] = ( int16_t ) ( qpel[i][1] * 4 ); }
   const int func = hadMode == 0 ? VVHIP_DF_SAD : hadMode == 1 ? VVHIP_DF_HAD : VVHIP_DF_HAD_FAST;
-  dev.check( vvhip_subpel_refine_batch( dev.ctx(), func, dArea, w, dArea + ( size_t ) w * h, pitch, w, h, bitDepth, reduceTap, useAltHpelIf ? 1 : 0,
+  dev.check( vvhip_subpel_refine_batch( dev.ctx(), func, dArea, w, dRef, pitch, w, h, bitDepth, reduceTap, useAltHpelIf ? 1 : 0,
                                         reinterpret_cast<vvhip_subpel_item*>( aux ), 1, offs, n, reinterpret_cast<uint64_t*>( aux + offsetof( Io, cost ) ) ), "vvhip_subpel_refine_batch" );
   dev.check( vvhip_download( dev.ctx(), io.cost, aux + offsetof( Io, cost ), sizeof( uint64_t ) * n ), "pattern refinement" );
   for( int i = 0; i < n; i++ ) out[i] = io.cost[i];

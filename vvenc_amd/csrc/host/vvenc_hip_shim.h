@@ -96,11 +96,18 @@ public:
   // (for pictures whose host buffer may be rewritten while the mirror is kept)
   int  registerPicture( const Pel* origin, int stride, int width, int height, int margin, bool findable = true, bool upload = true );
   void updatePicture( int id );
+  // rows [y0, y0 + rows) of the picture (y relative to sample row 0; the margins are rows < 0 and >= height), whole padded lines: a reconstructed picture is
+  // mirrored CTU row by CTU row as the encoder finishes (and border-extends) it.  Synchronous: other threads' contexts may read the rows when this returns.
+  void updatePictureRows( int id, int y0, int rows );
   void unregisterPicture( int id );
   // the same picture on another GPU: allocates a mirror there and fills it device-to-device (hipMemcpyPeerAsync over xGMI); returns the id in `dst`'s registry
   int  copyMirrorTo( int id, Device& dst );
-  struct Mirror { const Pel* hostBase; const Pel* hostEnd; const Pel* origin; int stride, width, height, margin; int16_t* dBase; int16_t* dOrigin; bool live; bool findable; };
+  struct Mirror { const Pel* hostBase; const Pel* hostEnd; const Pel* origin; int stride, width, height, margin; int16_t* dBase; int16_t* dOrigin; bool live; bool findable; bool reference; };
   const Mirror* find( const Pel* p ) const;  // which registered picture of this GPU contains host pointer p (nullptr: none)
+  // reference pictures (reconstructions mirrored row by row, setReference): looked up by the motion-search entry points only — never by the generic table entries,
+  // which may be handed the same host buffer while it is being rewritten as the current picture's reconstruction
+  void setReference( int id );
+  const Mirror* findReference( const Pel* p ) const;
   const Mirror& mirror( int id ) const;
   void check( int rc, const char* what ) const;
   int16_t* staging( size_t bytes );          // grow-only device scratch of THIS context for unregistered (compact temp) buffers
@@ -109,7 +116,7 @@ public:
   static bool pinHost( const void* p, size_t bytes );
   static void unpinAll();                    // before the owner frees the buffers (encoder close)
   // traffic over PCIe / calls since the process started (all contexts): what a binding prints per picture
-  struct Stats { uint64_t uploadBytes, downloadBytes, uploads, downloads, contexts; };
+  struct Stats { uint64_t uploadBytes, downloadBytes, uploads, downloads, contexts, residentReferenceCalls; };
   static Stats stats();
 private:
   explicit Device( int gpu );
