@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Collects the round's profile evidence on the GPU box (run through gpurun from the repo root):
 
-  1. rocprofv3 --kernel-trace --stats   -- python bench.py --steps S --warmup W --no-cpu-baseline
+  1. rocprofv3 --kernel-trace --stats   -- python bench.py --inner --steps S --warmup W     (the inner run bench.py itself profiles: the picture's three launches
+                                                                                              serialized on one stream + two MCTF stages; no extras, no output line)
   2. rocprofv3 --pmc FETCH_SIZE         -- same command, fewer steps   (separate pass, no tracing domains)
   3. rocprofv3 --pmc WRITE_SIZE         -- same
 
@@ -79,12 +80,12 @@ def main():
         elif x == "--": extra = a; break
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    base = ["--no-cpu-baseline", "--overlap-streams", "0", "--graph", "0"] + extra      # the trace must hold the serialized launches only
+    base = ["--inner"] + extra      # the trace holds the serialized launches (+ the MCTF stage kernels) only
     db1, line = run_pass(os.path.join(out, "prof_%s_trace" % tag), ["--kernel-trace", "--stats"], ["--steps", steps, "--warmup", warm] + base)
     db2, _ = run_pass(os.path.join(out, "prof_%s_fetch" % tag), ["--pmc", "FETCH_SIZE"], ["--steps", "5", "--warmup", "1"] + base)
     db3, _ = run_pass(os.path.join(out, "prof_%s_write" % tag), ["--pmc", "WRITE_SIZE"], ["--steps", "5", "--warmup", "1"] + base)
 
-    md = ["# Round 1 — profile `%s`" % tag, "",
+    md = ["# Profile `%s`" % tag, "",
           "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps %s --warmup %s %s` on 1x MI355X (rocpd database, summarised by tools/profile_round.py)." % (steps, warm, " ".join(base)), "",
           "| kernel | calls | total (us) | avg (us) | min (us) | max (us) | % |", "|---|---|---|---|---|---|---|"]
     rows = kernel_table(db1)
@@ -108,7 +109,7 @@ def main():
         f = 2.0 * 1024.0 * e["fetch_kb"] / max(1, e["launches_fetch"])
         w = 1024.0 * e["write_kb"] / max(1, e["launches_write"])
         pmc["classes"][cls] = {"launches": e["launches_fetch"], "fetch_bytes_per_launch_x2_corrected": f, "write_bytes_per_launch": w, "traffic_bytes_per_launch": f + w}
-    md += ["", "## bench line of the traced run", "", "```", line or "(none)", "```", ""]
+    md += ["", "(the inner run prints no bench line; the bench line of the round is profiles/bench_%s.json)" % tag, ""]
     open(os.path.join(out, "%s.md" % tag), "w").write("\n".join(md))
     json.dump(pmc, open(os.path.join(out, "pmc_%s.json" % tag), "w"), indent=1)
     print("\n".join(md[:30]))
