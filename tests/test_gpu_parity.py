@@ -936,3 +936,60 @@ def test_alf_4k_vs_oracle(hip, oracle):
     assert np.array_equal(got, exp)
     zero = np.zeros_like(coeff)
     assert np.array_equal(hip.alf_filter_plane(rec, ctu, 10, 7, zero, clip, np.zeros(nctu, np.int16), exp_cls, None, ctu, ctu - 4), rec)
+
+
+def test_transfer_and_multi_device_entry_points(hip):
+    """the round-2 C-ABI additions: pinned host areas, in-place pinning, strided copies, device enumeration and the device-to-device picture copy (same device here)"""
+    import ctypes as C
+    L, ctx = hip.hp.L, hip.hp.ctx
+    assert L.vvhip_device_count() >= 1 and L.vvhip_get_device(ctx) == 0 and L.vvhip_make_current(ctx) == 0
+    rng = np.random.default_rng(5)
+    src = rng.integers(-2000, 2000, size=(96, 200)).astype(np.int16)
+    d = C.c_void_p(); d2 = C.c_void_p()
+    assert L.vvhip_malloc(ctx, C.byref(d), src.nbytes) == 0 and L.vvhip_malloc(ctx, C.byref(d2), src.nbytes) == 0
+    # strided upload of a window, device-to-device copy, strided download
+    win = src[8:72, 16:144]
+    assert L.vvhip_upload_2d(ctx, d, 128 * 2, src.ctypes.data + (8 * 200 + 16) * 2, 200 * 2, 128 * 2, 64) == 0
+    assert L.vvhip_copy_peer(ctx, d2, ctx, d, 128 * 2 * 64) == 0
+    back = np.zeros((64, 160), np.int16)
+    assert L.vvhip_download_2d(ctx, back.ctypes.data, 160 * 2, d2, 128 * 2, 128 * 2, 64) == 0
+    assert np.array_equal(back[:, :128], win) and not back[:, 128:].any()
+    # pinned area owned by the library's caller + asynchronous download
+    h = C.c_void_p()
+    assert L.vvhip_host_alloc(ctx, C.byref(h), src.nbytes) == 0
+    assert L.vvhip_upload(ctx, d, src.ctypes.data, src.nbytes) == 0
+    assert L.vvhip_download_async(ctx, h, d, src.nbytes) == 0 and L.vvhip_sync(ctx) == 0
+    assert np.array_equal(np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_int16)), shape=src.shape), src)
+    assert L.vvhip_host_free(ctx, h) == 0
+    # in-place pinning of a caller buffer (whole pages), upload from inside it, unpin
+    big = np.zeros(1 << 20, np.int16)
+    big[:] = rng.integers(0, 1024, big.size)
+    a = (big.ctypes.data + 4095) & ~4095
+    n = ((big.ctypes.data + big.nbytes) & ~4095) - a
+    assert L.vvhip_host_register(ctx, C.c_void_p(a), n) == 0
+    assert L.vvhip_host_register(ctx, C.c_void_p(a), n) == 0          # registering again is not an error
+    d3 = C.c_void_p()
+    assert L.vvhip_malloc(ctx, C.byref(d3), n) == 0
+    assert L.vvhip_upload(ctx, d3, C.c_void_p(a), n) == 0
+    chk = np.zeros(n // 2, np.int16)
+    assert L.vvhip_download(ctx, chk.ctypes.data, d3, n) == 0
+    assert np.array_equal(chk, big[(a - big.ctypes.data) // 2:(a - big.ctypes.data) // 2 + n // 2])
+    assert L.vvhip_host_unregister(ctx, C.c_void_p(a)) == 0
+    for p in (d, d2, d3):
+        assert L.vvhip_free(ctx, p) == 0
+
+
+def test_bench_multi_rank_path_on_one_device(tmp_path):
+    """bench.py's N > 1 path (different pictures of one sequence per rank, PictureExchange broadcasts on their own stream inside the timed region, three compute streams) with
+    two ranks sharing the one GPU and gloo as the collective back-end ($VVHIP_SHARE_DEVICE / $VVHIP_DIST_BACKEND): the code the driver runs under RCCL on 2/4/8 GPUs"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VVHIP_SHARE_DEVICE="1", VVHIP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--width", "640", "--height", "384"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["exchange"]["pictures"] >= 8 and d["exchange"]["bytes_per_rank"] > 0, d
+    assert d["parity"]["status"] == "bit-exact", d["parity"]

@@ -25,7 +25,10 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # $VVHIP_DIST_BACKEND=gloo + $VVHIP_SHARE_DEVICE=1: every rank on GPU 0, collectives through gloo — how the N>1 path is exercised on a 1-GPU box (tests)
+            backend = os.environ.get("VVHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("VVHIP_SHARE_DEVICE") == "1":
+            local_rank = 0
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
