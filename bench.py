@@ -421,13 +421,23 @@ def main():
         shp = tuple(wl.ref.storage.shape)
         cshape = (shp[0] // 2, shp[1] // 2)
         ex = sharding.PictureExchange([shp, cshape, cshape], slots=2, device=hp.device)
-        ref_planes = []
+        ref_planes, ref_tiled = [], []
         for s in range(2):
             ex.slots[s][0].copy_(wl.ref.storage)
             pl = Plane(hp.device, wl.ref.width, wl.ref.height, wl.ref.pad, wl.ref.stride)
             pl.storage = ex.slots[s][0]
             ref_planes.append(pl)
-        ex.publish(0, 0)
+            ref_tiled.append(hp.tile_plane(pl) if wl.tiled else None)
+
+        def retile(slot_index):
+            # the tiled copy of the received reference picture, on the exchange stream right behind the broadcast
+            def f(planes):
+                if wl.tiled:
+                    hp.use_torch_stream()
+                    hp.tile_plane(ref_planes[slot_index], ref_tiled[slot_index])
+                    hp.use_torch_stream()
+            return f
+        ex.publish(0, 0, after=retile(0))
 
     step_no = [0]
     # the three launches of a picture are independent work lists: each goes to its own HIP stream (they share the device, and the steps pipeline per stream)
@@ -436,9 +446,9 @@ def main():
     def step(timers=None):
         if ex is not None:
             s = step_no[0]
-            ex.publish(s + 1, (s + 1) % world, readers=streams or ())     # the next picture's reference is in flight while this picture's launches run
+            ex.publish(s + 1, (s + 1) % world, readers=streams or (), after=retile((s + 1) % 2))     # the next picture's reference is in flight while this picture's launches run
             ex.wait(s, streams)
-            wl.ref = ref_planes[s % 2]
+            wl.ref, wl.ref_tiled = ref_planes[s % 2], ref_tiled[s % 2]
             step_no[0] += 1
         if streams:
             wl.run_overlapped(streams, timers)
@@ -476,7 +486,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt, device="cuda")
     if ex is not None:
-        wl.ref = ref_planes[0]
+        wl.ref, wl.ref_tiled = ref_planes[0], ref_tiled[0]
 
     # extra (not `value`): the same K steps serialized on one stream without any event
     overlap = None

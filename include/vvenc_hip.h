@@ -122,6 +122,18 @@ typedef struct { int32_t func, width, height, sub_shift, n, flags; const vvhip_d
 VVHIP_API int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,
                                      const vvhip_dist_fjob* jobs_host, int n_jobs );
 
+/* The same lists on 8x8-TILED copies of the planes (no counterpart in the reference: a memory-layout decision for the MI355X).  A 128-byte cache line holds one 8x8 tile of
+ * int16 samples; in a row-major plane an 8x8 block is eight 16-byte pieces in eight lines and every piece drags a whole line out of L2 — the 8x8 lists run at the L2's line
+ * rate.  vvhip_plane_tile8 makes the tiled copy of a padded plane (d_base = first sample of the padded plane, `rows` lines of `stride` samples; d_tiled holds
+ * vvhip_tiled8_elems( stride, rows ) samples; re-tile when the plane changes).  vvhip_dist_multi_func_tiled = vvhip_dist_multi_func, identical results, with the Hadamard jobs
+ * and the 8x8 SAD / SSE jobs of bit depths <= 10 reading the tiled copies (tiled may be NULL: no difference to vvhip_dist_multi_func).  *_margin = samples of margin around
+ * sample (0,0) of the plane the tiled copy was made from (d_org / d_cur still address sample (0,0) of the row-major planes, used by the other jobs).                          */
+typedef struct { const int16_t* d_org_tiled; const int16_t* d_cur_tiled; int32_t org_margin, cur_margin; } vvhip_tiled_planes;
+VVHIP_API size_t vvhip_tiled8_elems( int stride, int rows );
+VVHIP_API int vvhip_plane_tile8( vvhip_ctx* ctx, const int16_t* d_base, int stride, int rows, int16_t* d_tiled );
+VVHIP_API int vvhip_dist_multi_func_tiled( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, const vvhip_tiled_planes* tiled_host, int bit_depth,
+                                           const vvhip_dist_fjob* jobs_host, int n_jobs );
+
 /* DMVR 5-position SAD: RdCost::xGetSAD8X5 / xGetSAD16X5 (RdCost.cpp:1984-2034). width 8 or 16.
  * d_out5[5*i+k] = SAD(org+k, cur-k) >> 1; entry 2 is left untouched when calc_centre == 0.       */
 VVHIP_API int vvhip_sad_x5_batch( vvhip_ctx* ctx,

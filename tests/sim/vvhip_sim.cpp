@@ -119,6 +119,16 @@ int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* o, int os, const int16
   for( int i = 0; i < n; i++ ) { const int rc = vvhip_dist_batch( ctx, jobs[i].func, o, os, c, cs, jobs[i].width, jobs[i].height, jobs[i].sub_shift, bd, jobs[i].d_items, jobs[i].n, jobs[i].d_out ); if( rc ) return rc; }
   return VVHIP_OK;
 }
+size_t vvhip_tiled8_elems( int stride, int rows ) { return ( size_t ) ( ( rows + 7 ) / 8 ) * ( ( stride + 7 ) / 8 ) * 64 + 128; }
+int vvhip_plane_tile8( vvhip_ctx* ctx, const int16_t* base, int stride, int rows, int16_t* tiled )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  const int tpr = ( stride + 7 ) / 8;
+  for( int y = 0; y < rows; y++ ) for( int x = 0; x < stride; x++ ) tiled[( ( size_t ) ( y >> 3 ) * tpr + ( x >> 3 ) ) * 64 + ( y & 7 ) * 8 + ( x & 7 )] = base[( size_t ) y * stride + x];
+  return VVHIP_OK;
+}
+int vvhip_dist_multi_func_tiled( vvhip_ctx* ctx, const int16_t* o, int os, const int16_t* c, int cs, const vvhip_tiled_planes*, int bd, const vvhip_dist_fjob* jobs, int n )
+{ return vvhip_dist_multi_func( ctx, o, os, c, cs, bd, jobs, n ); }      // (the layout is a device-side matter: same results by contract)
 int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* o, int os, const int16_t* c, int cs, int bd, const vvhip_dist_job* jobs, int n )
 {
   for( int i = 0; i < n; i++ ) { const int rc = vvhip_dist_batch( ctx, func, o, os, c, cs, jobs[i].width, jobs[i].height, jobs[i].sub_shift, bd, jobs[i].d_items, jobs[i].n, jobs[i].d_out ); if( rc ) return rc; }

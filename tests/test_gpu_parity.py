@@ -938,6 +938,42 @@ def test_alf_4k_vs_oracle(hip, oracle):
     assert np.array_equal(hip.alf_filter_plane(rec, ctu, 10, 7, zero, clip, np.zeros(nctu, np.int16), exp_cls, None, ctu, ctu - 4), rec)
 
 
+@pytest.mark.parametrize("aligned", [True, False])
+def test_dist_multi_func_tiled_equals_row_major(hip, oracle, aligned):
+    """the 8x8-tiled plane copies (one cache line = one 8x8 tile): vvhip_dist_multi_func_tiled == vvhip_dist_multi_func == oracle for every function and size, original blocks
+    on the tile grid (a picture tiling) or anywhere, candidates anywhere incl. inside the margins; general and VVHIP_DIST_FLAG_SAMPLES Hadamard forms"""
+    import torch
+    hp = hip.hp
+    rng = np.random.default_rng(911 + int(aligned))
+    H, W, pad = 136, 200, 24
+    org, cur = rand_plane(rng, H, W), rand_plane(rng, H, W)
+    po, pc = hp.plane(org, pad), hp.plane(cur, pad)
+    to, tc = hp.tile_plane(po), hp.tile_plane(pc)
+    opad = np.pad(org, pad, mode="edge")
+    cpad = np.pad(cur, pad, mode="edge")
+    for flags in (0, hp.DIST_FLAG_SAMPLES):
+        jobs, pos = [], []
+        for func in ("SAD", "SSE", "HAD", "HAD_fast"):
+            for (S, ss) in ((8, 0), (16, 1), (32, 1), (64, 1), (16, 0)):
+                if func != "SAD":
+                    ss = 0
+                n = 37
+                ox = rng.integers(0, (W - S) // 8 + 1, n) * 8 if aligned else rng.integers(-pad, W + pad - S + 1, n)
+                oy = rng.integers(0, (H - S) // 8 + 1, n) * 8 if aligned else rng.integers(-pad, H + pad - S + 1, n)
+                cx, cy = rng.integers(-pad, W + pad - S + 1, n), rng.integers(-pad, H + pad - S + 1, n)
+                it = np.stack([oy * po.stride + ox, cy * pc.stride + cx], 1).astype(np.int32)
+                jobs.append((func, S, S, ss, n, hp.to_device(it), torch.full((n,), -1, dtype=torch.int64, device=hp.device)))
+                pos.append((ox, oy, cx, cy))
+        plain = [(f, w, h, ss, n, it, torch.full((n,), -2, dtype=torch.int64, device=hp.device)) for (f, w, h, ss, n, it, _) in jobs]
+        hp.dist_multi_func_tiled(po, pc, to, tc, hp.make_dist_fjobs(jobs, flags=flags), 10)
+        hp.dist_multi_func(po, pc, hp.make_dist_fjobs(plain, flags=flags), 10)
+        for (func, S, _, ss, n, _, out), (_, _, _, _, _, _, out2), (ox, oy, cx, cy) in zip(jobs, plain, pos):
+            got, ref = out.cpu().numpy(), out2.cpu().numpy()
+            assert np.array_equal(got, ref), (aligned, flags, func, S)
+            for k in (0, 7, n - 1):
+                assert int(got[k]) == oracle.dist(func, (opad, int(oy[k]) + pad, int(ox[k]) + pad), (cpad, int(cy[k]) + pad, int(cx[k]) + pad), S, S, 10, ss), (func, S, k)
+
+
 def test_transfer_and_multi_device_entry_points(hip):
     """the round-2 C-ABI additions: pinned host areas, in-place pinning, strided copies, device enumeration and the device-to-device picture copy (same device here)"""
     import ctypes as C

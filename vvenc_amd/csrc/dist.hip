@@ -153,8 +153,71 @@ sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __r
 #define VVHIP_DIST_U 2
 #endif
 constexpr int DIST_U = VVHIP_DIST_U;   // candidates per lane team in the merged SAD / SSE launches (they share the original rows when they belong to one block)
-struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand, sse; const vvhip_dist_item* items; uint64_t* out; };
-struct DistMultiJobs { int nJobs, xcdRemap; DistJobGeom j[8]; };
+struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand, sse, tiled; const vvhip_dist_item* items; uint64_t* out; };
+// 8x8-tiled copies of the two planes (vvhip_plane_tile8): a 128-byte cache line = ONE 8x8 tile of int16 samples.  An 8x8 candidate of a row-major plane is eight 16-byte
+// pieces in eight cache lines — every piece drags a whole line out of L2, which is what bounds the 8x8 lists (they run at the L2's line rate); in the tiled copy the same
+// candidate lies in at most four lines, an aligned original block in one.
+struct Tiled8 { const int16_t* org; const int16_t* cur; int orgTpr, curTpr, orgBias, curBias, orgStride, curStride; unsigned long long orgMagic, curMagic; };
+struct DistMultiJobs { int nJobs, xcdRemap; DistJobGeom j[8]; Tiled8 T; };
+
+// sample offset relative to sample (0,0) of a row-major plane -> coordinates inside the padded plane (bias = margin * stride + margin; magic = 2^40 / stride + 1)
+__device__ __forceinline__ void tiledXY( int off, int bias, int stride, unsigned long long magic, int& x, int& y )
+{
+  const uint32_t o = ( uint32_t ) ( off + bias );
+  int q = ( int ) ( ( ( unsigned long long ) o * magic ) >> 40 );
+  int r = ( int ) o - q * stride;
+  if( r < 0 ) { q--; r += stride; } else if( r >= stride ) { q++; r -= stride; }
+  x = r; y = q;
+}
+// eight samples (x .. x+7, y) of a tiled plane: two aligned 16-byte tile rows, funnel-shifted by x & 7
+__device__ __forceinline__ u32x4 tiledRow8( const int16_t* __restrict__ t, int tpr, int x, int y )
+{
+  const int16_t* p = t + ( ( size_t ) ( y >> 3 ) * tpr + ( x >> 3 ) ) * 64 + ( y & 7 ) * 8;
+  const u32x4 a = *reinterpret_cast<const u32x4*>( p );
+  const int sh = x & 7;
+  if( __builtin_amdgcn_ballot_w64( sh != 0 ) == 0ull ) return a;                       // the whole wave is tile-aligned (original blocks of a picture tiling)
+  const u32x4 b = *reinterpret_cast<const u32x4*>( p + 64 );                            // (reads the next tile also when sh == 0: inside the padded plane by construction)
+  const uint32_t s0 = a.x, s1 = a.y, s2 = a.z, s3 = a.w, s4 = b.x, s5 = b.y, s6 = b.z, s7 = b.w;
+  const bool k1 = ( sh & 2 ) != 0, k2 = ( sh & 4 ) != 0;
+  const uint32_t u0 = k1 ? s1 : s0, u1 = k1 ? s2 : s1, u2 = k1 ? s3 : s2, u3 = k1 ? s4 : s3, u4 = k1 ? s5 : s4, u5 = k1 ? s6 : s5, u6 = k1 ? s7 : s6;
+  const uint32_t v0 = k2 ? u2 : u0, v1 = k2 ? u3 : u1, v2 = k2 ? u4 : u2, v3 = k2 ? u5 : u3, v4 = k2 ? u6 : u4;
+  const uint32_t bits = ( sh & 1 ) * 16;
+  u32x4 o;
+  o.x = __builtin_amdgcn_alignbit( v1, v0, bits ); o.y = __builtin_amdgcn_alignbit( v2, v1, bits ); o.z = __builtin_amdgcn_alignbit( v3, v2, bits ); o.w = __builtin_amdgcn_alignbit( v4, v3, bits );
+  return o;
+}
+
+// SAD / SSE of 8x8 candidates on the tiled copies: 8 lanes per candidate, lane = row
+template<int MODE>
+__device__ __forceinline__ void
+sadSse8TiledBody( int blockIndex, const Tiled8& T, const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+{
+  const int gid = blockIndex * blockDim.x + threadIdx.x, cand = gid >> 3, r = gid & 7;
+  const bool valid = cand < n;
+  int ox = 0, oy = 0, cx = 0, cy = 0;
+  if( valid )
+  {
+    const vvhip_dist_item it = items[cand];
+    tiledXY( it.org_off, T.orgBias, T.orgStride, T.orgMagic, ox, oy );
+    tiledXY( it.cur_off, T.curBias, T.curStride, T.curMagic, cx, cy );
+  }
+  const u32x4 a = tiledRow8( T.org, T.orgTpr, ox, oy + r ), b = tiledRow8( T.cur, T.curTpr, cx, cy + r );
+  if( MODE == MODE_SSE )
+  {
+    const uint32_t as[4] = { a.x, a.y, a.z, a.w }, bs[4] = { b.x, b.y, b.z, b.w };
+    uint64_t e = 0;
+#pragma unroll
+    for( int i = 0; i < 4; i++ ) { const int d0 = lo16( as[i] ) - lo16( bs[i] ), d1 = hi16( as[i] ) - hi16( bs[i] ); e += ( uint64_t ) ( ( int64_t ) d0 * d0 ) + ( uint64_t ) ( ( int64_t ) d1 * d1 ); }
+    const uint64_t t = vvhipGroupSum64( e, 8, threadIdx.x & 63 );
+    if( valid && r == 0 ) out[cand] = t;
+  }
+  else
+  {
+    uint32_t sd = sadPair( a.x, b.x, 0 ); sd = sadPair( a.y, b.y, sd ); sd = sadPair( a.z, b.z, sd ); sd = sadPair( a.w, b.w, sd );
+    const uint32_t t = vvhipGroupSum32( sd, 8, threadIdx.x & 63 );
+    if( valid && r == 0 ) out[cand] = t;
+  }
+}
 
 // Workgroups are dealt round-robin to the 8 XCDs (private L2 each).  Work lists are in raster order of the picture, so giving XCD x
 // the x-th contiguous eighth of a list makes every L2 stream one band of the planes instead of all of them.
@@ -174,7 +237,8 @@ sadSseMultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  sadSseBody<8, MODE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+  if( g.tiled ) sadSse8TiledBody<MODE>( blk, jobs.T, g.items, g.n, g.out );
+  else          sadSseBody<8, MODE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
 }
 
 // SAD and SSE lists of one frame in the same launch (per-job mode): both are short, memory-side kernels with the same geometry
@@ -187,7 +251,8 @@ sadSseMixedKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  if( g.sse ) sadSseBody<8, MODE_SSE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+  if( g.tiled ) { if( g.sse ) sadSse8TiledBody<MODE_SSE>( blk, jobs.T, g.items, g.n, g.out ); else sadSse8TiledBody<MODE_SAD>( blk, jobs.T, g.items, g.n, g.out ); }
+  else if( g.sse ) sadSseBody<8, MODE_SSE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
   else        sadSseBody<8, MODE_SAD, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
 }
 
@@ -410,9 +475,8 @@ __device__ __forceinline__ uint32_t pkAbs( uint32_t a )
 
 // rounded 2x2 averages of 16 samples x 2 rows -> 8 values as 4 packed dwords; SIGNED: inputs may be negative (arithmetic shift)
 template<bool SIGNED>
-__device__ __forceinline__ void avgRow16Pk( const int16_t* p, int stride, uint32_t ( &o )[4] )
+__device__ __forceinline__ void avgRow16PkData( const u32x4 a0, const u32x4 a1, const u32x4 b0, const u32x4 b1, uint32_t ( &o )[4] )
 {
-  const u32x4 a0 = ld16( p ), a1 = ld16( p + 8 ), b0 = ld16( p + stride ), b1 = ld16( p + stride + 8 );
   const uint32_t t[8] = { pkAdd( a0.x, b0.x ), pkAdd( a0.y, b0.y ), pkAdd( a0.z, b0.z ), pkAdd( a0.w, b0.w ), pkAdd( a1.x, b1.x ), pkAdd( a1.y, b1.y ), pkAdd( a1.z, b1.z ), pkAdd( a1.w, b1.w ) };
 #pragma unroll
   for( int i = 0; i < 4; i++ )
@@ -423,12 +487,18 @@ __device__ __forceinline__ void avgRow16Pk( const int16_t* p, int stride, uint32
     else         o[i] = ( s >> 2 ) & 0x3fff3fffu;                                               // both halves >> 2 (sums are < 2^13, unsigned)
   }
 }
+template<bool SIGNED>
+__device__ __forceinline__ void avgRow16Pk( const int16_t* p, int stride, uint32_t ( &o )[4] )
+{
+  avgRow16PkData<SIGNED>( ld16( p ), ld16( p + 8 ), ld16( p + stride ), ld16( p + stride + 8 ), o );
+}
 
-template<bool FAST16, bool WIDE>
+// TILED: the samples come from the 8x8-tiled copies of the planes (Tiled8): an 8x8 Hadamard tile of the original is one cache line, of the candidate at most four
+template<bool FAST16, bool WIDE, bool TILED = false>
 __device__ __forceinline__ void
 hadTilePkBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
                int tilesX, int tilesPerCand, int log2Lpc,
-               const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+               const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out, const Tiled8* __restrict__ T = nullptr )
 {
   constexpr int PX = FAST16 ? 16 : 8, PY = FAST16 ? 16 : 8;
   const int gid  = blockIndex * blockDim.x + threadIdx.x;
@@ -439,6 +509,12 @@ hadTilePkBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, c
   int orgOff = 0, curOff = 0;
   if( valid ) { const vvhip_dist_item it = items[cand]; orgOff = it.org_off; curOff = it.cur_off; }
   const int tiles = valid ? tilesPerCand : 0;
+  int ox = 0, oy = 0, cx = 0, cy = 0;
+  if( TILED )
+  {
+    tiledXY( orgOff, T->orgBias, T->orgStride, T->orgMagic, ox, oy );
+    tiledXY( curOff, T->curBias, T->curStride, T->curMagic, cx, cy );
+  }
 
   uint32_t sum = 0;
   for( int t = lt; t < tiles; t += lpc )
@@ -453,14 +529,24 @@ hadTilePkBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, c
       if( FAST16 )
       {
         uint32_t ao[4], ac[4];
-        avgRow16Pk<WIDE>( po + ( ptrdiff_t ) ( 2 * r ) * orgStride, orgStride, ao );
-        avgRow16Pk<WIDE>( pc + ( ptrdiff_t ) ( 2 * r ) * curStride, curStride, ac );
+        if( TILED )
+        {
+          const int X = ox + tx * PX, Y = oy + ty * PY + 2 * r, CX = cx + tx * PX, CY = cy + ty * PY + 2 * r;
+          avgRow16PkData<WIDE>( tiledRow8( T->org, T->orgTpr, X, Y ), tiledRow8( T->org, T->orgTpr, X + 8, Y ), tiledRow8( T->org, T->orgTpr, X, Y + 1 ), tiledRow8( T->org, T->orgTpr, X + 8, Y + 1 ), ao );
+          avgRow16PkData<WIDE>( tiledRow8( T->cur, T->curTpr, CX, CY ), tiledRow8( T->cur, T->curTpr, CX + 8, CY ), tiledRow8( T->cur, T->curTpr, CX, CY + 1 ), tiledRow8( T->cur, T->curTpr, CX + 8, CY + 1 ), ac );
+        }
+        else
+        {
+          avgRow16Pk<WIDE>( po + ( ptrdiff_t ) ( 2 * r ) * orgStride, orgStride, ao );
+          avgRow16Pk<WIDE>( pc + ( ptrdiff_t ) ( 2 * r ) * curStride, curStride, ac );
+        }
 #pragma unroll
         for( int q = 0; q < 4; q++ ) d[4 * r + q] = pkSub( ao[q], ac[q] );
       }
       else
       {
-        const u32x4 x = ld16( po + ( ptrdiff_t ) r * orgStride ), z = ld16( pc + ( ptrdiff_t ) r * curStride );
+        const u32x4 x = TILED ? tiledRow8( T->org, T->orgTpr, ox + tx * PX, oy + ty * PY + r ) : ld16( po + ( ptrdiff_t ) r * orgStride );
+        const u32x4 z = TILED ? tiledRow8( T->cur, T->curTpr, cx + tx * PX, cy + ty * PY + r ) : ld16( pc + ( ptrdiff_t ) r * curStride );
         d[4 * r] = pkSub( x.x, z.x ); d[4 * r + 1] = pkSub( x.y, z.y ); d[4 * r + 2] = pkSub( x.z, z.z ); d[4 * r + 3] = pkSub( x.w, z.w );
       }
     }
@@ -514,7 +600,12 @@ hadTile8PkMultiKernel( const int16_t* __restrict__ org, int orgStride, const int
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  if( g.fast16 ) hadTilePkBody<true, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  if( g.tiled )
+  {
+    if( g.fast16 ) hadTilePkBody<true, WIDE, true>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out, &jobs.T );
+    else           hadTilePkBody<false, WIDE, true>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out, &jobs.T );
+  }
+  else if( g.fast16 ) hadTilePkBody<true, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
   else           hadTilePkBody<false, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
 }
 
@@ -660,6 +751,24 @@ sadSurfaceKernel( const int16_t* __restrict__ org, int orgStride, const int16_t*
   }
 }
 
+// row-major padded plane -> 8x8-tiled copy: thread = one 16-byte tile row
+__global__ void __launch_bounds__( 256 )
+tile8Kernel( const int16_t* __restrict__ src, int stride, int rows, int tpr, int16_t* __restrict__ dst )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int rowsPad = ( rows + 7 ) & ~7;
+  if( i >= rowsPad * tpr ) return;
+  const int y = i / tpr, tx = i - y * tpr;
+  u32x4 v = { 0, 0, 0, 0 };
+  if( y < rows )
+  {
+    const int16_t* p = src + ( size_t ) y * stride + 8 * tx;
+    if( 8 * tx + 8 <= stride ) v = ld16( p );
+    else { int16_t t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; for( int k = 0; 8 * tx + k < stride; k++ ) t[k] = p[k]; v = *reinterpret_cast<const u32x4*>( t ); }
+  }
+  *reinterpret_cast<u32x4*>( dst + ( ( size_t ) ( y >> 3 ) * tpr + tx ) * 64 + ( y & 7 ) * 8 ) = v;
+}
+
 int pow2Floor( int v ) { int p = 1; while( p * 2 <= v ) p <<= 1; return p; }
 
 template<int MODE>
@@ -778,7 +887,8 @@ int vvhip_dist_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_st
 }
 
 // jobs with their own function each: consecutive jobs of the same kernel family (SAD/SSE, or HAD/HAD_fast) share a launch
-static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth, const vvhip_dist_fjob* jobs, int n_jobs )
+static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth, const vvhip_dist_fjob* jobs, int n_jobs,
+                          const vvhip_tiled_planes* tiled = nullptr )
 {
   // mergeable: SAD / SSE with width % 8 == 0, Hadamard whose ladder ends on the 8x8 or 16x16_fast tile; everything else runs as separate launches
   auto family = [&]( const vvhip_dist_fjob& jb ) -> int {
@@ -801,7 +911,17 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       i++;
       continue;
     }
-    DistMultiJobs mj; mj.nJobs = 0;
+    DistMultiJobs mj; mj.nJobs = 0; mj.T = {};
+    static const int useTiled = []{ const char* e = getenv( "VVHIP_TILED" ); return e ? atoi( e ) : 1; }();
+    const bool haveTiled = tiled && useTiled && tiled->d_org_tiled && tiled->d_cur_tiled && bit_depth <= 10;
+    if( haveTiled )
+    {
+      mj.T.org = tiled->d_org_tiled; mj.T.cur = tiled->d_cur_tiled;
+      mj.T.orgStride = org_stride; mj.T.curStride = cur_stride;
+      mj.T.orgTpr = ( org_stride + 7 ) / 8; mj.T.curTpr = ( cur_stride + 7 ) / 8;
+      mj.T.orgBias = tiled->org_margin * org_stride + tiled->org_margin; mj.T.curBias = tiled->cur_margin * cur_stride + tiled->cur_margin;
+      mj.T.orgMagic = ( 1ull << 40 ) / ( unsigned ) org_stride + 1; mj.T.curMagic = ( 1ull << 40 ) / ( unsigned ) cur_stride + 1;
+    }
     static const int xcdRemapEnv = []{ const char* e = getenv( "VVHIP_XCD_REMAP" ); return e ? atoi( e ) : 1; }();
     mj.xcdRemap = xcdRemapEnv;
     long blocks = 0;
@@ -811,17 +931,21 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       const vvhip_dist_fjob& jb = jobs[i];
       DistJobGeom& g = mj.j[mj.nJobs];
       g.items = jb.d_items; g.out = jb.d_out; g.n = jb.n; g.blockStart = ( int ) blocks; g.fast16 = 0; g.tilesX = 0; g.tilesPerCand = 0;
-      g.lpr = 0; g.lprShift = 0; g.rowsEff = 0; g.subShift = 0; g.sse = 0;
+      g.lpr = 0; g.lprShift = 0; g.rowsEff = 0; g.subShift = 0; g.sse = 0; g.tiled = 0;
       int lpc;
+      bool tiledSad = false;
       if( fam == 1 )
       {
         g.sse = jb.func == VVHIP_DF_SSE ? 1 : 0; ( g.sse ? anySse : anySad ) = true;
         g.subShift = g.sse ? 0 : jb.sub_shift;
         g.rowsEff = jb.height >> g.subShift; g.lpr = jb.width / 8; g.lprShift = isPow2( g.lpr ) ? ilog2i( g.lpr ) : -1;
         lpc = pow2Floor( g.lpr * g.rowsEff ); if( lpc > 64 ) lpc = 64;
+        // 8x8 lists (every row of the block is read): the tiled copies, 8 lanes per candidate
+        if( haveTiled && jb.width == 8 && jb.height == 8 && g.subShift == 0 ) { g.tiled = 1; tiledSad = true; lpc = 8; }
       }
       else
       {
+        g.tiled = haveTiled ? 1 : 0;
         g.fast16 = ( jb.func == VVHIP_DF_HAD_FAST && jb.width % 32 == 0 ) ? 1 : 0;
         const int px = g.fast16 ? 16 : 8;
         g.tilesX = jb.width / px; g.tilesPerCand = g.tilesX * ( jb.height / px );
@@ -833,7 +957,7 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       // the moment it retires: 34.6 -> 31.3 us); the SAD / SSE launch is indifferent (34.5 / 35.2 / 35.0 us for 256 / 128 / 64) and keeps 256
       static const int wgEnv = []{ const char* e = getenv( "VVHIP_DIST_WG" ); const int v = e ? atoi( e ) : 0; return ( v == 64 || v == 128 || v == 256 ) ? v : 0; }();
       const int wgSize = wgEnv ? wgEnv : ( fam >= 2 ? 64 : 256 );
-      g.nBlocks = fam == 1 ? ( int ) ( ( ( ( long ) jb.n + DIST_U - 1 ) / DIST_U * lpc + wgSize - 1 ) / wgSize ) : ( int ) ( ( ( long ) jb.n * lpc + wgSize - 1 ) / wgSize );
+      g.nBlocks = ( fam == 1 && !tiledSad ) ? ( int ) ( ( ( ( long ) jb.n + DIST_U - 1 ) / DIST_U * lpc + wgSize - 1 ) / wgSize ) : ( int ) ( ( ( long ) jb.n * lpc + wgSize - 1 ) / wgSize );
       blocks += g.nBlocks;
       mj.nJobs++; i++;
     }
@@ -857,6 +981,31 @@ int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* d_org, int org_stride,
   if( !ctx ) return VVHIP_E_ARG;
   if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi_func: bad job list" );
   return distMultiFunc( ctx, d_org, org_stride, d_cur, cur_stride, bit_depth, jobs, n_jobs );
+}
+
+int vvhip_dist_multi_func_tiled( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, const vvhip_tiled_planes* tiled, int bit_depth,
+                                 const vvhip_dist_fjob* jobs, int n_jobs )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi_func_tiled: bad job list" );
+  if( tiled && ( tiled->org_margin < 0 || tiled->cur_margin < 0 || org_stride < 8 || cur_stride < 8 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi_func_tiled: bad tiled-plane geometry" );
+  return distMultiFunc( ctx, d_org, org_stride, d_cur, cur_stride, bit_depth, jobs, n_jobs, tiled );
+}
+
+size_t vvhip_tiled8_elems( int stride, int rows )
+{
+  return ( size_t ) ( ( rows + 7 ) / 8 ) * ( ( stride + 7 ) / 8 ) * 64 + 128;      // (+ two tiles of slack: the funnel shift may touch the tile after the last one)
+}
+
+int vvhip_plane_tile8( vvhip_ctx* ctx, const int16_t* d_base, int stride, int rows, int16_t* d_tiled )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !d_base || !d_tiled || stride < 8 || rows < 1 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_plane_tile8: bad arguments" );
+  const int tpr = ( stride + 7 ) / 8, rowsPad = ( rows + 7 ) & ~7;
+  const long n = ( long ) rowsPad * tpr;
+  hipLaunchKernelGGL( tile8Kernel, dim3( ( unsigned ) ( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, ctx->stream, d_base, stride, rows, tpr, d_tiled );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
 }
 
 int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,

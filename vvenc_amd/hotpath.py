@@ -196,6 +196,26 @@ class HotPath:
             jobs = self.make_dist_fjobs(jobs)
         self._ck(self.L.vvhip_dist_multi_func(self.ctx, org.buf_ptr, org.stride, cur.buf_ptr, cur.stride, bit_depth, jobs[0], jobs[1]))
 
+    # ---- 8x8-tiled copies of planes (one 128-byte cache line = one 8x8 tile): what the 8x8 SAD / SSE lists and every Hadamard list read on the MI355X
+    class _TiledPlanes(C.Structure):
+        _fields_ = [("d_org_tiled", C.c_void_p), ("d_cur_tiled", C.c_void_p), ("org_margin", C.c_int32), ("cur_margin", C.c_int32)]
+
+    def tile_plane(self, plane, out=None):
+        """tiled copy of a whole padded Plane (re-tile after the plane changes); returns the int16 tensor holding it"""
+        rows = plane.storage.shape[0]
+        n = int(self.L.vvhip_tiled8_elems(plane.stride, rows))
+        if out is None:
+            out = torch.empty(n, dtype=torch.int16, device=self.device)
+        self._ck(self.L.vvhip_plane_tile8(self.ctx, plane.storage.data_ptr(), plane.stride, rows, out.data_ptr()))
+        return out
+
+    def dist_multi_func_tiled(self, org, cur, org_tiled, cur_tiled, jobs, bit_depth=10):
+        """dist_multi_func with the tiled copies of both planes at hand (identical results)"""
+        if isinstance(jobs, list):
+            jobs = self.make_dist_fjobs(jobs)
+        t = self._TiledPlanes(org_tiled.data_ptr(), cur_tiled.data_ptr(), org.pad, cur.pad)
+        self._ck(self.L.vvhip_dist_multi_func_tiled(self.ctx, org.buf_ptr, org.stride, cur.buf_ptr, cur.stride, C.byref(t), bit_depth, jobs[0], jobs[1]))
+
     def sad_x5_batch(self, org, cur, d_items, n, w, h, sub_shift=1, calc_centre=True, out=None):
         if out is None:
             out = torch.zeros(n * 5, dtype=torch.int64, device=self.device)

@@ -40,6 +40,9 @@ PROTOTYPES = {
     "vvhip_dist_batch": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "vvhip_dist_multi": (i32, [vp, i32, vp, i32, vp, i32, i32, vp, i32]),
     "vvhip_dist_multi_func": (i32, [vp, vp, i32, vp, i32, i32, vp, i32]),
+    "vvhip_tiled8_elems": (sz, [i32, i32]),
+    "vvhip_plane_tile8": (i32, [vp, vp, i32, i32, vp]),
+    "vvhip_dist_multi_func_tiled": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32]),
     "vvhip_sad_mask_batch": (i32, [vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
     "vvhip_fix_weighted_sse_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp]),
     "vvhip_sad_x5_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),

@@ -96,11 +96,14 @@ class PictureExchange:
     def slot(self, frame):
         return self.slots[frame % self.n_slots]
 
-    def publish(self, frame, owner, readers=()):
-        """readers: extra (compute) streams whose earlier work reads / writes this slot — the broadcast waits for them too"""
+    def publish(self, frame, owner, readers=(), after=None):
+        """readers: extra (compute) streams whose earlier work reads / writes this slot — the broadcast waits for them too.
+        after(planes): device work derived from the received picture (e.g. its tiled copy), enqueued on the exchange stream behind the broadcast and covered by wait()"""
         planes = self.slot(frame)
         self.bytes_published += sum(p.numel() * p.element_size() for p in planes)
         if not dist.is_initialized():
+            if after is not None:
+                after(planes)
             self.pending[frame] = None
             return
         if self.is_cuda:
@@ -111,11 +114,18 @@ class PictureExchange:
             with torch.cuda.stream(self.stream):
                 for p in planes:
                     broadcast_picture(p, owner)
+                if after is not None:
+                    after(planes)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
             self.pending[frame] = ev
         else:
             self.pending[frame] = [broadcast_picture(p, owner, async_op=True) for p in planes]
+            if after is not None:
+                for w in self.pending[frame]:
+                    w.wait()
+                self.pending[frame] = []
+                after(planes)
 
     def wait(self, frame, streams=None):
         """streams: the compute streams that will read the picture (default: the current stream)"""

@@ -56,6 +56,10 @@ class FrameWorkload:
         self.ref = hp.plane(ref, margin)              # reconstructed reference picture, margin = CTU+16 (EncStage.h:311)
         resi = (cur.astype(np.int32) - ref.astype(np.int32)).astype(np.int16)
         self.resi = hp.plane(resi, 0)
+        # 8x8-tiled copies of the two planes, resident like the planes themselves (made once per picture: tile_ref() again when the reference plane changes)
+        self.tiled = os.environ.get("VVHIP_WORKLOAD_TILED", "1") != "0"
+        self.org_tiled = hp.tile_plane(self.org) if self.tiled else None
+        self.ref_tiled = hp.tile_plane(self.ref) if self.tiled else None
         rng = np.random.default_rng(seed + 1)
         self.dist_jobs = []     # (func, S, sub_shift, n, d_items, d_out, host_items)
         self.pairs = 0
@@ -150,12 +154,24 @@ class FrameWorkload:
         if timers is not None:
             timers.stop("SUBPEL")
 
+    def tile_ref(self, ref=None, out=None):
+        """the reference plane changed (a new picture arrived): refresh its tiled copy"""
+        if self.tiled:
+            self.ref_tiled = self.hp.tile_plane(ref if ref is not None else self.ref, out if out is not None else self.ref_tiled)
+        return self.ref_tiled
+
+    def _dist(self, cls):
+        if self.tiled:
+            self.hp.dist_multi_func_tiled(self.org, self.ref, self.org_tiled, self.ref_tiled, self.fjob_tables[cls], self.bit_depth)
+        else:
+            self.hp.dist_multi_func(self.org, self.ref, self.fjob_tables[cls], self.bit_depth)
+
     def run_overlapped(self, streams, timers=None):
         """the same three launches, each on its own HIP stream (they are independent work lists): they share the device and successive steps pipeline per stream.
         timers: per-class HIP events, recorded on the class's own stream"""
         import torch
         hp = self.hp
-        calls = [(c, (lambda c=c: hp.dist_multi_func(self.org, self.ref, self.fjob_tables[c], self.bit_depth))) for c in ("SAD_SSE", "HAD_fast")]
+        calls = [(c, (lambda c=c: self._dist(c))) for c in ("SAD_SSE", "HAD_fast")]
         calls.append(("TU", lambda: hp.tu_rdo_multi(self.resi, self.tu_table, self.bit_depth)))
         for i, (cls, c) in enumerate(calls):
             with torch.cuda.stream(streams[i % len(streams)]):
@@ -175,7 +191,7 @@ class FrameWorkload:
             for cls in ("SAD_SSE", "HAD_fast"):
                 if timers is not None:
                     timers.start(cls)
-                hp.dist_multi_func(self.org, self.ref, self.fjob_tables[cls], self.bit_depth)
+                self._dist(cls)
                 if timers is not None:
                     timers.stop(cls)
         else:
