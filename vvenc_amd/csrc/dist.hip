@@ -600,12 +600,10 @@ hadTile8PkMultiKernel( const int16_t* __restrict__ org, int orgStride, const int
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  if( g.tiled )
-  {
-    if( g.fast16 ) hadTilePkBody<true, WIDE, true>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out, &jobs.T );
-    else           hadTilePkBody<false, WIDE, true>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out, &jobs.T );
-  }
-  else if( g.fast16 ) hadTilePkBody<true, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  // (the TILED instantiations of the body are not dispatched: measured, the Hadamard lists lose on the tiled copies — the funnel shifts cost the per-lane-tile kernel more
+  //  than the saved line fills bring, 34.7 -> 69 us with every size tiled, 44 us with the 8x8 candidates alone — and merely compiling them into this kernel costs its other
+  //  jobs registers: 34.7 -> 41 us)
+  if( g.fast16 ) hadTilePkBody<true, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
   else           hadTilePkBody<false, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
 }
 
@@ -945,7 +943,7 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       }
       else
       {
-        g.tiled = haveTiled ? 1 : 0;
+        g.tiled = 0;      // Hadamard lists stay on the row-major planes (see hadTile8PkMultiKernel)
         g.fast16 = ( jb.func == VVHIP_DF_HAD_FAST && jb.width % 32 == 0 ) ? 1 : 0;
         const int px = g.fast16 ? 16 : 8;
         g.tilesX = jb.width / px; g.tilesPerCand = g.tilesX * ( jb.height / px );
