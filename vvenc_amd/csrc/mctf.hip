@@ -368,11 +368,12 @@ meWavefrontKernel( MeGeom g, const MeRefs R, int nbx, int mvsW, int* abortFlag )
       {
         const unsigned long long* src = granules + ( size_t ) ( byi - 1 ) * nbx + bxi;
         unsigned spins = 0;
-        while( true )
+        const unsigned long long t0 = wall_clock64();                      // constant-rate counter (100 MHz): the bound is TIME (2 s), not iterations — a preempted or
+        while( true )                                                     // time-shared producer must not look like a dead one
         {
           gr = __hip_atomic_load( src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
           if( ( gr >> 32 ) == 1ull ) break;
-          if( ( ++spins & 255u ) == 0 && ( __hip_atomic_load( abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) || spins > ( 1u << 20 ) ) )
+          if( ( ++spins & 255u ) == 0 && ( __hip_atomic_load( abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) || wall_clock64() - t0 > 200000000ull ) )
           { __hip_atomic_store( abortFlag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); gr = ~0ull; break; }
           __builtin_amdgcn_s_sleep( 2 );
         }

@@ -80,13 +80,22 @@ class PictureExchange:
     """Decoded-picture-buffer ring replicated on every rank.
 
     `slots` pictures of `planes` tensors each (luma + the two chroma planes, with their margins — what a reference picture is).  The owner of picture p
-    writes it into slot(p) and every rank calls publish(p, owner): one broadcast per plane, issued on the exchange's own stream (GPU) so it overlaps the kernels of the
+    writes it into slot(p) and every rank calls publish(p, owner): one broadcast per picture (its planes are views into one allocation), issued on the exchange's own stream (GPU) so it overlaps the kernels of the
     picture being worked on; wait(p) makes the compute stream wait for it (stream-ordered, no host sync).  Every rank must publish the same pictures in the same order.
     bytes_published counts what this rank sent or received."""
 
     def __init__(self, plane_shapes, slots=2, device="cpu", dtype=torch.int16):
         self.device = torch.device(device)
-        self.slots = [[torch.zeros(s, dtype=dtype, device=self.device) for s in plane_shapes] for _ in range(slots)]
+        # one contiguous allocation per picture: the planes are views into it, the whole picture travels in ONE collective
+        sizes = [int(torch.Size(s).numel()) for s in plane_shapes]
+        self.flat = [torch.zeros(sum(sizes), dtype=dtype, device=self.device) for _ in range(slots)]
+        self.slots = []
+        for f in self.flat:
+            off, planes = 0, []
+            for s, n in zip(plane_shapes, sizes):
+                planes.append(f[off:off + n].view(s))
+                off += n
+            self.slots.append(planes)
         self.n_slots = slots
         self.pending = {}          # frame -> [work handles] / event
         self.bytes_published = 0
@@ -112,15 +121,14 @@ class PictureExchange:
             for r in readers:
                 self.stream.wait_stream(r)
             with torch.cuda.stream(self.stream):
-                for p in planes:
-                    broadcast_picture(p, owner)
+                broadcast_picture(self.flat[frame % self.n_slots], owner)
                 if after is not None:
                     after(planes)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
             self.pending[frame] = ev
         else:
-            self.pending[frame] = [broadcast_picture(p, owner, async_op=True) for p in planes]
+            self.pending[frame] = [broadcast_picture(self.flat[frame % self.n_slots], owner, async_op=True)]
             if after is not None:
                 for w in self.pending[frame]:
                     w.wait()
