@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -924,9 +925,20 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
     mj.xcdRemap = xcdRemapEnv;
     long blocks = 0;
     bool anySad = false, anySse = false;
-    while( i < n_jobs && mj.nJobs < 8 && family( jobs[i] ) == fam )
+    // the jobs of a launch, heaviest workgroups first: workgroups start in grid order, so the long ones (64x64 SSE: eight row pieces per lane) must not be the
+    // last to start while the one-piece-per-lane 8x8 lists have long drained
+    int order[8], nOrder = 0;
+    while( i < n_jobs && nOrder < 8 && family( jobs[i] ) == fam ) order[nOrder++] = i++;
+    static const int sortJobs = []{ const char* e = getenv( "VVHIP_DIST_SORT" ); return e ? atoi( e ) : 1; }();
+    auto weight = [&]( const vvhip_dist_fjob& jb ) -> long {
+      if( fam == 1 ) { const int rows = jb.func == VVHIP_DF_SSE ? jb.height : jb.height >> jb.sub_shift; int l = pow2Floor( jb.width / 8 * rows ); if( l > 64 ) l = 64; return ( long ) jb.width / 8 * rows / l; }
+      const bool f16 = jb.func == VVHIP_DF_HAD_FAST && jb.width % 32 == 0;
+      const int px = f16 ? 16 : 8, tpc = ( jb.width / px ) * ( jb.height / px ); int l = pow2Floor( tpc ); if( l > 64 ) l = 64; if( tpc % l ) l = 1;
+      return ( long ) tpc / l * ( f16 ? 4 : 1 ); };
+    if( sortJobs ) std::stable_sort( order, order + nOrder, [&]( int a, int b ) { return weight( jobs[a] ) > weight( jobs[b] ); } );
+    for( int oi = 0; oi < nOrder; oi++ )
     {
-      const vvhip_dist_fjob& jb = jobs[i];
+      const vvhip_dist_fjob& jb = jobs[order[oi]];
       DistJobGeom& g = mj.j[mj.nJobs];
       g.items = jb.d_items; g.out = jb.d_out; g.n = jb.n; g.blockStart = ( int ) blocks; g.fast16 = 0; g.tilesX = 0; g.tilesPerCand = 0;
       g.lpr = 0; g.lprShift = 0; g.rowsEff = 0; g.subShift = 0; g.sse = 0; g.tiled = 0;
@@ -957,7 +969,7 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       const int wgSize = wgEnv ? wgEnv : ( fam >= 2 ? 64 : 256 );
       g.nBlocks = ( fam == 1 && !tiledSad ) ? ( int ) ( ( ( ( long ) jb.n + DIST_U - 1 ) / DIST_U * lpc + wgSize - 1 ) / wgSize ) : ( int ) ( ( ( long ) jb.n * lpc + wgSize - 1 ) / wgSize );
       blocks += g.nBlocks;
-      mj.nJobs++; i++;
+      mj.nJobs++;
     }
     static const int wgEnvL = []{ const char* e = getenv( "VVHIP_DIST_WG" ); const int v = e ? atoi( e ) : 0; return ( v == 64 || v == 128 || v == 256 ) ? v : 0; }();
     const int wgSizeL = wgEnvL ? wgEnvL : ( fam >= 2 ? 64 : 256 );
