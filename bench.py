@@ -54,13 +54,13 @@ class EventTimers:
         self.pool = {k: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] for k in classes}
         self.idx = {k: 0 for k in classes}
 
-    def start(self, key):
+    def start(self, key, stream=None):
         if key in self.pool:
-            self.pool[key][self.idx[key]][0].record()
+            self.pool[key][self.idx[key]][0].record(stream) if stream is not None else self.pool[key][self.idx[key]][0].record()
 
-    def stop(self, key):
+    def stop(self, key, stream=None):
         if key in self.pool:
-            self.pool[key][self.idx[key]][1].record()
+            self.pool[key][self.idx[key]][1].record(stream) if stream is not None else self.pool[key][self.idx[key]][1].record()
             self.idx[key] += 1
 
     def summary(self):
@@ -421,20 +421,24 @@ def main():
         shp = tuple(wl.ref.storage.shape)
         cshape = (shp[0] // 2, shp[1] // 2)
         ex = sharding.PictureExchange([shp, cshape, cshape], slots=2, device=hp.device)
-        ref_planes, ref_tiled = [], []
+        ref_planes, ref_tiled, ref_shift = [], [], []
         for s in range(2):
             ex.slots[s][0].copy_(wl.ref.storage)
             pl = Plane(hp.device, wl.ref.width, wl.ref.height, wl.ref.pad, wl.ref.stride)
             pl.storage = ex.slots[s][0]
             ref_planes.append(pl)
             ref_tiled.append(hp.tile_plane(pl) if wl.tiled else None)
+            ref_shift.append(hp.shift_plane(pl) if wl.shifted else None)
 
         def retile(slot_index):
-            # the tiled copy of the received reference picture, on the exchange stream right behind the broadcast
+            # the derived copies (8x8-tiled, one-sample-shifted) of the received reference picture, on the exchange stream right behind the broadcast
             def f(planes):
-                if wl.tiled:
+                if wl.tiled or wl.shifted:
                     hp.use_torch_stream()
-                    hp.tile_plane(ref_planes[slot_index], ref_tiled[slot_index])
+                    if wl.tiled:
+                        hp.tile_plane(ref_planes[slot_index], ref_tiled[slot_index])
+                    if wl.shifted:
+                        hp.shift_plane(ref_planes[slot_index], ref_shift[slot_index])
                     hp.use_torch_stream()
             return f
         ex.publish(0, 0, after=retile(0))
@@ -448,7 +452,7 @@ def main():
             s = step_no[0]
             ex.publish(s + 1, (s + 1) % world, readers=streams or (), after=retile((s + 1) % 2))     # the next picture's reference is in flight while this picture's launches run
             ex.wait(s, streams)
-            wl.ref, wl.ref_tiled = ref_planes[s % 2], ref_tiled[s % 2]
+            wl.ref, wl.ref_tiled, wl.ref_shift = ref_planes[s % 2], ref_tiled[s % 2], ref_shift[s % 2]
             step_no[0] += 1
         if streams:
             wl.run_overlapped(streams, timers)
@@ -486,7 +490,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt, device="cuda")
     if ex is not None:
-        wl.ref, wl.ref_tiled = ref_planes[0], ref_tiled[0]
+        wl.ref, wl.ref_tiled, wl.ref_shift = ref_planes[0], ref_tiled[0], ref_shift[0]
 
     # extra (not `value`): the same K steps serialized on one stream without any event
     overlap = None

@@ -128,7 +128,14 @@ VVHIP_API int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* d_org, int o
  * vvhip_tiled8_elems( stride, rows ) samples; re-tile when the plane changes).  vvhip_dist_multi_func_tiled = vvhip_dist_multi_func, identical results, with the 8x8 SAD / SSE jobs
  * of bit depths <= 10 reading the tiled copies (the Hadamard jobs were measured slower there and stay on the row-major planes) (tiled may be NULL: no difference to vvhip_dist_multi_func).  *_margin = samples of margin around
  * sample (0,0) of the plane the tiled copy was made from (d_org / d_cur still address sample (0,0) of the row-major planes, used by the other jobs).                          */
-typedef struct { const int16_t* d_org_tiled; const int16_t* d_cur_tiled; int32_t org_margin, cur_margin; } vvhip_tiled_planes;
+typedef struct { const int16_t* d_org_tiled; const int16_t* d_cur_tiled; int32_t org_margin, cur_margin;
+                 const int16_t* d_cur_shift1;   /* optional (NULL: none): the sample of a ONE-SAMPLE-SHIFTED copy of the reference plane buffer that corresponds to d_cur, i.e.
+                                                   d_cur_shift1[k] == d_cur[k + 1] for every sample of the padded plane (vvhip_plane_shift1 over the whole buffer).  Candidates at odd
+                                                   sample addresses (half of all motion vectors) are then read from the copy with dword-aligned loads — an only 2-byte-aligned
+                                                   16-byte lane load is split by the memory pipeline and costs 1.8x; every job on the row-major planes uses it */
+               } vvhip_tiled_planes;
+/* d_dst[i] = d_src[i + 1] for i < elems - 1, d_dst[elems - 1] = 0; both buffers with the same alignment modulo 4 bytes */
+VVHIP_API int vvhip_plane_shift1( vvhip_ctx* ctx, const int16_t* d_src, size_t elems, int16_t* d_dst );
 VVHIP_API size_t vvhip_tiled8_elems( int stride, int rows );
 VVHIP_API int vvhip_plane_tile8( vvhip_ctx* ctx, const int16_t* d_base, int stride, int rows, int16_t* d_tiled );
 VVHIP_API int vvhip_dist_multi_func_tiled( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, const vvhip_tiled_planes* tiled_host, int bit_depth,

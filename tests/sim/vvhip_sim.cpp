@@ -119,6 +119,7 @@ int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* o, int os, const int16
   for( int i = 0; i < n; i++ ) { const int rc = vvhip_dist_batch( ctx, jobs[i].func, o, os, c, cs, jobs[i].width, jobs[i].height, jobs[i].sub_shift, bd, jobs[i].d_items, jobs[i].n, jobs[i].d_out ); if( rc ) return rc; }
   return VVHIP_OK;
 }
+int vvhip_plane_shift1( vvhip_ctx* ctx, const int16_t* s, size_t n, int16_t* d ) { if( !ctx ) return VVHIP_E_ARG; for( size_t i = 0; i < n; i++ ) d[i] = i + 1 < n ? s[i + 1] : ( int16_t ) 0; return VVHIP_OK; }
 size_t vvhip_tiled8_elems( int stride, int rows ) { return ( size_t ) ( ( rows + 7 ) / 8 ) * ( ( stride + 7 ) / 8 ) * 64 + 128; }
 int vvhip_plane_tile8( vvhip_ctx* ctx, const int16_t* base, int stride, int rows, int16_t* tiled )
 {

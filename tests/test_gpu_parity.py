@@ -967,6 +967,15 @@ def test_dist_multi_func_tiled_equals_row_major(hip, oracle, aligned):
         plain = [(f, w, h, ss, n, it, torch.full((n,), -2, dtype=torch.int64, device=hp.device)) for (f, w, h, ss, n, it, _) in jobs]
         hp.dist_multi_func_tiled(po, pc, to, tc, hp.make_dist_fjobs(jobs, flags=flags), 10)
         hp.dist_multi_func(po, pc, hp.make_dist_fjobs(plain, flags=flags), 10)
+        # + the one-sample-shifted copy of the reference plane (candidates at odd sample addresses read it with dword-aligned loads): with and without the tiled copies,
+        # packed (10-bit) and 32-bit (12-bit call) Hadamard forms
+        sh = hp.shift_plane(pc)
+        assert np.array_equal(sh.cpu().numpy().ravel()[:-1], pc.storage.cpu().numpy().ravel()[1:]) and int(sh.cpu().numpy().ravel()[-1]) == 0
+        for (t_o, t_c, bd) in ((to, tc, 10), (None, None, 10), (None, None, 12)):
+            shifted = [(f, w, h, ss, n, it, torch.full((n,), -3, dtype=torch.int64, device=hp.device)) for (f, w, h, ss, n, it, _) in jobs]
+            hp.dist_multi_func_tiled(po, pc, t_o, t_c, hp.make_dist_fjobs(shifted, flags=flags), bd, cur_shift=sh)
+            for (func, S, _, ss, n, _, out2), (_, _, _, _, _, _, out3) in zip(plain, shifted):
+                assert np.array_equal(out2.cpu().numpy(), out3.cpu().numpy()), (aligned, flags, func, S, bd, t_o is None)
         for (func, S, _, ss, n, _, out), (_, _, _, _, _, _, out2), (ox, oy, cx, cy) in zip(jobs, plain, pos):
             got, ref = out.cpu().numpy(), out2.cpu().numpy()
             assert np.array_equal(got, ref), (aligned, flags, func, S)

@@ -14,5 +14,5 @@ sel = [J[n] for n in names]
 tab = hp.make_dist_fjobs(sel, flags=hp.DIST_FLAG_SAMPLES if names[0].startswith("HAD") else 0)
 for _ in range(reps):
     if "--row-major" in sys.argv: hp.dist_multi_func(wl.org, wl.ref, tab, wl.bit_depth)
-    else: hp.dist_multi_func_tiled(wl.org, wl.ref, wl.org_tiled, wl.ref_tiled, tab, wl.bit_depth)
+    else: hp.dist_multi_func_tiled(wl.org, wl.ref, wl.org_tiled, wl.ref_tiled, tab, wl.bit_depth, cur_shift=wl.ref_shift)
 torch.cuda.synchronize()

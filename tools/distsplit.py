@@ -25,7 +25,7 @@ for cls, funcs, flags in (("SAD_SSE", ("SAD", "SSE"), 0), ("HAD_fast", ("HAD_fas
     jobs = [(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in wl.dist_jobs if f in funcs]
     def run(sel):
         tab = hp.make_dist_fjobs(sel, flags=flags)
-        return timeit(lambda: hp.dist_multi_func_tiled(wl.org, wl.ref, wl.org_tiled, wl.ref_tiled, tab, wl.bit_depth))
+        return timeit(lambda: hp.dist_multi_func_tiled(wl.org, wl.ref, wl.org_tiled, wl.ref_tiled, tab, wl.bit_depth, cur_shift=wl.ref_shift))
     print("%s all jobs: %.2f us" % (cls, run(jobs)))
     for j in jobs:
         print("   only %-8s %2d: %6.2f us     without it: %6.2f us" % (j[0], j[1], run([j]), run([k for k in jobs if k is not j])))

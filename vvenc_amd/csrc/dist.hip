@@ -27,6 +27,15 @@ __device__ __forceinline__ uint32_t ld4( const int16_t* p ) { return reinterpret
 __device__ __forceinline__ u32x2    ld8( const int16_t* p ) { return reinterpret_cast<const U8*>( p )->v; }
 __device__ __forceinline__ u32x4    ld16( const int16_t* p ) { return reinterpret_cast<const U16*>( p )->v; }
 
+// A 16-byte lane load at an address that is only 2-byte aligned (odd sample offset: half of all motion vectors) is split by the memory pipeline into dword pieces — measured,
+// a Hadamard list whose candidates all sit at odd x costs 1.8x the same list at even x, and a wave with mixed parities pays the odd price.  With a second copy of the
+// reference plane shifted by ONE sample at hand (shift1[k] == plane[k + 1]), an odd address reads the copy one sample earlier: every load is dword-aligned.
+// delta = ( shift1 - plane ) - 1 in samples, 0 without the copy (the load is then the plain unaligned one).
+__device__ __forceinline__ const int16_t* shiftSel( const int16_t* p, ptrdiff_t delta )
+{
+  return ( reinterpret_cast<uintptr_t>( p ) & 2 ) ? p + delta : p;
+}
+
 __device__ __forceinline__ int lo16( uint32_t v ) { return ( int ) ( int16_t ) ( v & 0xffffu ); }
 __device__ __forceinline__ int hi16( uint32_t v ) { return ( int ) ( ( int32_t ) v >> 16 ); }
 
@@ -51,7 +60,7 @@ template<int CH, int MODE, int U = 1>
 __device__ __forceinline__ void
 sadSseBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
             int lpr /* lanes (segments) per row = w / CH */, int lprShift /* log2(lpr) or -1 */, int rowsEff, int subShift, int log2Lpc,
-            const vvhip_dist_item* __restrict__ items, int n, int calcCentre, uint64_t* __restrict__ out )
+            const vvhip_dist_item* __restrict__ items, int n, int calcCentre, uint64_t* __restrict__ out, ptrdiff_t curShift = 0 )
 {
   const int gid  = blockIndex * blockDim.x + threadIdx.x;
   const int lpc  = 1 << log2Lpc;
@@ -76,6 +85,7 @@ sadSseBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, cons
       curOff = it.cur_off - k[u];
     }
     po[u] = org + orgOff; pc[u] = cur + curOff;
+    if( CH == 8 && curShift && !( curStride & 1 ) ) pc[u] = shiftSel( pc[u], curShift );      // (even stride: every row of the candidate has the parity of its first)
   }
   const int chunks = lpr * rowsEff;
 
@@ -154,12 +164,12 @@ sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __r
 #define VVHIP_DIST_U 2
 #endif
 constexpr int DIST_U = VVHIP_DIST_U;   // candidates per lane team in the merged SAD / SSE launches (they share the original rows when they belong to one block)
-struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand, sse, tiled; const vvhip_dist_item* items; uint64_t* out; };
+struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand, sse, tiled, shift; const vvhip_dist_item* items; uint64_t* out; };
 // 8x8-tiled copies of the two planes (vvhip_plane_tile8): a 128-byte cache line = ONE 8x8 tile of int16 samples.  An 8x8 candidate of a row-major plane is eight 16-byte
 // pieces in eight cache lines — every piece drags a whole line out of L2, which is what bounds the 8x8 lists (they run at the L2's line rate); in the tiled copy the same
 // candidate lies in at most four lines, an aligned original block in one.
 struct Tiled8 { const int16_t* org; const int16_t* cur; int orgTpr, curTpr, orgBias, curBias, orgStride, curStride; unsigned long long orgMagic, curMagic; };
-struct DistMultiJobs { int nJobs, xcdRemap; DistJobGeom j[8]; Tiled8 T; };
+struct DistMultiJobs { int nJobs, xcdRemap; DistJobGeom j[8]; Tiled8 T; ptrdiff_t curShift; };
 
 // sample offset relative to sample (0,0) of a row-major plane -> coordinates inside the padded plane (bias = margin * stride + margin; magic = 2^40 / stride + 1)
 __device__ __forceinline__ void tiledXY( int off, int bias, int stride, unsigned long long magic, int& x, int& y )
@@ -239,7 +249,7 @@ sadSseMultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
   if( g.tiled ) sadSse8TiledBody<MODE>( blk, jobs.T, g.items, g.n, g.out );
-  else          sadSseBody<8, MODE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+  else          sadSseBody<8, MODE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out, g.shift ? jobs.curShift : 0 );
 }
 
 // SAD and SSE lists of one frame in the same launch (per-job mode): both are short, memory-side kernels with the same geometry
@@ -253,8 +263,8 @@ sadSseMixedKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
   if( g.tiled ) { if( g.sse ) sadSse8TiledBody<MODE_SSE>( blk, jobs.T, g.items, g.n, g.out ); else sadSse8TiledBody<MODE_SAD>( blk, jobs.T, g.items, g.n, g.out ); }
-  else if( g.sse ) sadSseBody<8, MODE_SSE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
-  else        sadSseBody<8, MODE_SAD, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out );
+  else if( g.sse ) sadSseBody<8, MODE_SSE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out, g.shift ? jobs.curShift : 0 );
+  else        sadSseBody<8, MODE_SAD, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out, g.shift ? jobs.curShift : 0 );
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,7 +395,7 @@ template<int TW, int TH, bool FAST16>
 __device__ __forceinline__ void
 hadTileBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
              int tilesX, int tilesPerCand, int log2Lpc,
-             const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+             const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out, ptrdiff_t curShift = 0 )
 {
   constexpr int PX = FAST16 ? 16 : TW, PY = FAST16 ? 16 : TH;
   const int gid  = blockIndex * blockDim.x + threadIdx.x;
@@ -403,6 +413,7 @@ hadTileBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, con
     const int ty = t / tilesX, tx = t - ty * tilesX;
     const int16_t* po = org + orgOff + ( ptrdiff_t ) ( ty * PY ) * orgStride + tx * PX;
     const int16_t* pc = cur + curOff + ( ptrdiff_t ) ( ty * PY ) * curStride + tx * PX;
+    if( ( FAST16 || TW == 8 ) && curShift && !( curStride & 1 ) ) pc = shiftSel( pc, curShift );
     int d[TH][TW];
 #pragma unroll
     for( int r = 0; r < TH; r++ )
@@ -499,7 +510,7 @@ template<bool FAST16, bool WIDE, bool TILED = false>
 __device__ __forceinline__ void
 hadTilePkBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, const int16_t* __restrict__ cur, int curStride,
                int tilesX, int tilesPerCand, int log2Lpc,
-               const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out, const Tiled8* __restrict__ T = nullptr )
+               const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out, const Tiled8* __restrict__ T = nullptr, ptrdiff_t curShift = 0 )
 {
   constexpr int PX = FAST16 ? 16 : 8, PY = FAST16 ? 16 : 8;
   const int gid  = blockIndex * blockDim.x + threadIdx.x;
@@ -523,6 +534,7 @@ hadTilePkBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, c
     const int ty = t / tilesX, tx = t - ty * tilesX;
     const int16_t* po = org + orgOff + ( ptrdiff_t ) ( ty * PY ) * orgStride + tx * PX;
     const int16_t* pc = cur + curOff + ( ptrdiff_t ) ( ty * PY ) * curStride + tx * PX;
+    if( !TILED && curShift && !( curStride & 1 ) ) pc = shiftSel( pc, curShift );
     uint32_t d[32];                                           // dword 4 * r + q: differences (r, 2q), (r, 2q + 1)
 #pragma unroll
     for( int r = 0; r < 8; r++ )
@@ -604,8 +616,8 @@ hadTile8PkMultiKernel( const int16_t* __restrict__ org, int orgStride, const int
   // (the TILED instantiations of the body are not dispatched: measured, the Hadamard lists lose on the tiled copies — the funnel shifts cost the per-lane-tile kernel more
   //  than the saved line fills bring, 34.7 -> 69 us with every size tiled, 44 us with the 8x8 candidates alone — and merely compiling them into this kernel costs its other
   //  jobs registers: 34.7 -> 41 us)
-  if( g.fast16 ) hadTilePkBody<true, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
-  else           hadTilePkBody<false, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  if( g.fast16 ) hadTilePkBody<true, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out, nullptr, g.shift ? jobs.curShift : 0 );
+  else           hadTilePkBody<false, WIDE>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out, nullptr, g.shift ? jobs.curShift : 0 );
 }
 
 template<int TW, int TH, bool FAST16>
@@ -626,8 +638,8 @@ hadTile8MultiKernel( const int16_t* __restrict__ org, int orgStride, const int16
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  if( g.fast16 ) hadTileBody<8, 8, true>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
-  else           hadTileBody<8, 8, false>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out );
+  if( g.fast16 ) hadTileBody<8, 8, true>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out, g.shift ? jobs.curShift : 0 );
+  else           hadTileBody<8, 8, false>( blk, org, orgStride, cur, curStride, g.tilesX, g.tilesPerCand, g.log2Lpc, g.items, g.n, g.out, g.shift ? jobs.curShift : 0 );
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -748,6 +760,16 @@ sadSurfaceKernel( const int16_t* __restrict__ org, int orgStride, const int16_t*
     for( int k = 0; k < KDY; k++ )
       if( my0 + k < ny ) out[( size_t ) b * nx * ny + ( my0 + k ) * nx + mx] = acc[k] << subShift;
   }
+}
+
+// dst[i] = src[i + 1] (the last element 0): thread = eight samples
+__global__ void __launch_bounds__( 256 )
+shift1Kernel( const int16_t* __restrict__ src, size_t elems, int16_t* __restrict__ dst )
+{
+  const size_t i = ( ( size_t ) blockIdx.x * 256 + threadIdx.x ) * 8;
+  if( i >= elems ) return;
+  if( i + 9 <= elems && !( reinterpret_cast<uintptr_t>( dst + i ) & 15 ) ) { *reinterpret_cast<u32x4*>( dst + i ) = ld16( src + i + 1 ); return; }
+  for( size_t k = i; k < elems && k < i + 8; k++ ) dst[k] = k + 1 < elems ? src[k + 1] : ( int16_t ) 0;
 }
 
 // row-major padded plane -> 8x8-tiled copy: thread = one 16-byte tile row
@@ -911,6 +933,10 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       continue;
     }
     DistMultiJobs mj; mj.nJobs = 0; mj.T = {};
+    // one-sample-shifted copy of the reference plane (see shiftSel): both buffers must share their alignment modulo 4 bytes
+    static const int useShift = []{ const char* e = getenv( "VVHIP_SHIFT1" ); return e ? atoi( e ) : 1; }();
+    mj.curShift = ( useShift && tiled && tiled->d_cur_shift1 && !( ( reinterpret_cast<uintptr_t>( d_cur ) ^ reinterpret_cast<uintptr_t>( tiled->d_cur_shift1 ) ) & 3 ) )
+                  ? ( tiled->d_cur_shift1 - d_cur ) - 1 : 0;
     static const int useTiled = []{ const char* e = getenv( "VVHIP_TILED" ); return e ? atoi( e ) : 1; }();
     const bool haveTiled = tiled && useTiled && tiled->d_org_tiled && tiled->d_cur_tiled && bit_depth <= 10;
     if( haveTiled )
@@ -942,6 +968,10 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       DistJobGeom& g = mj.j[mj.nJobs];
       g.items = jb.d_items; g.out = jb.d_out; g.n = jb.n; g.blockStart = ( int ) blocks; g.fast16 = 0; g.tilesX = 0; g.tilesPerCand = 0;
       g.lpr = 0; g.lprShift = 0; g.rowsEff = 0; g.subShift = 0; g.sse = 0; g.tiled = 0;
+      // the shifted copy pays where a lane's 16 bytes are a granule access of their own: every Hadamard tile row, SAD rows of <= 16 samples.  Wider rows are several
+      // adjacent lanes that coalesce either way, and splitting a block's candidates over two copies of its window only costs L1 hits there (measured: 32-wide SAD and
+      // the SSE lists lose 10-30 %, 16-wide SAD gains 25 %, the Hadamard lists 25-40 %)
+      g.shift = ( fam >= 2 || ( jb.func == VVHIP_DF_SAD && jb.width <= 16 ) ) ? 1 : 0;
       int lpc;
       bool tiledSad = false;
       if( fam == 1 )
@@ -1000,6 +1030,15 @@ int vvhip_dist_multi_func_tiled( vvhip_ctx* ctx, const int16_t* d_org, int org_s
   if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi_func_tiled: bad job list" );
   if( tiled && ( tiled->org_margin < 0 || tiled->cur_margin < 0 || org_stride < 8 || cur_stride < 8 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dist_multi_func_tiled: bad tiled-plane geometry" );
   return distMultiFunc( ctx, d_org, org_stride, d_cur, cur_stride, bit_depth, jobs, n_jobs, tiled );
+}
+
+int vvhip_plane_shift1( vvhip_ctx* ctx, const int16_t* d_src, size_t elems, int16_t* d_dst )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( !d_src || !d_dst || elems < 1 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_plane_shift1: bad arguments" );
+  hipLaunchKernelGGL( shift1Kernel, dim3( ( unsigned ) ( ( elems + 8 * 256 - 1 ) / ( 8 * 256 ) ) ), dim3( 256 ), 0, ctx->stream, d_src, elems, d_dst );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
 }
 
 size_t vvhip_tiled8_elems( int stride, int rows )

@@ -81,6 +81,31 @@ class HotPath:
         self.ctx = ctx
         self.use_torch_stream()
 
+    def fork(self, stream):
+        """a second context on the same device, bound for good to `stream` (a torch.cuda.Stream): launches of independent work lists go to their own streams without any
+        per-call stream switching on the host (what the binding's worker threads do with their per-thread contexts)"""
+        o = object.__new__(HotPath)
+        o.L, o.device = self.L, self.device
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        ctx = C.c_void_p()
+        rc = self.L.vvhip_create(C.byref(ctx), idx)
+        if rc != 0:
+            raise VVHipError("vvhip_create failed (%d): %s" % (rc, self.L.vvhip_last_error(None).decode()))
+        o.ctx = ctx
+        o.stream = stream
+        o._ck(self.L.vvhip_set_stream(ctx, C.c_void_p(stream.cuda_stream)))
+        return o
+
+    def bound(self, fn_name, *args):
+        """a zero-argument callable issuing L.<fn_name>(ctx, *args) with the ctypes arguments converted once (per-step launches of fixed work lists)"""
+        fn, ctx, a, ck = getattr(self.L, fn_name), self.ctx, args, self._ck
+
+        def call():
+            rc = fn(ctx, *a)
+            if rc:
+                ck(rc)
+        return call
+
     def close(self):
         if getattr(self, "ctx", None):
             self.L.vvhip_destroy(self.ctx)
@@ -198,7 +223,7 @@ class HotPath:
 
     # ---- 8x8-tiled copies of planes (one 128-byte cache line = one 8x8 tile): what the 8x8 SAD / SSE lists and every Hadamard list read on the MI355X
     class _TiledPlanes(C.Structure):
-        _fields_ = [("d_org_tiled", C.c_void_p), ("d_cur_tiled", C.c_void_p), ("org_margin", C.c_int32), ("cur_margin", C.c_int32)]
+        _fields_ = [("d_org_tiled", C.c_void_p), ("d_cur_tiled", C.c_void_p), ("org_margin", C.c_int32), ("cur_margin", C.c_int32), ("d_cur_shift1", C.c_void_p)]
 
     def tile_plane(self, plane, out=None):
         """tiled copy of a whole padded Plane (re-tile after the plane changes); returns the int16 tensor holding it"""
@@ -209,11 +234,19 @@ class HotPath:
         self._ck(self.L.vvhip_plane_tile8(self.ctx, plane.storage.data_ptr(), plane.stride, rows, out.data_ptr()))
         return out
 
-    def dist_multi_func_tiled(self, org, cur, org_tiled, cur_tiled, jobs, bit_depth=10):
-        """dist_multi_func with the tiled copies of both planes at hand (identical results)"""
+    def shift_plane(self, plane, out=None):
+        """copy of a whole padded Plane shifted by one sample (out[k] == storage[k + 1]): odd sample addresses become dword-aligned loads; re-make after the plane changes"""
+        if out is None:
+            out = torch.empty_like(plane.storage)
+        self._ck(self.L.vvhip_plane_shift1(self.ctx, plane.storage.data_ptr(), plane.storage.numel(), out.data_ptr()))
+        return out
+
+    def dist_multi_func_tiled(self, org, cur, org_tiled, cur_tiled, jobs, bit_depth=10, cur_shift=None):
+        """dist_multi_func with the tiled copies of both planes (either may be None) and the one-sample-shifted copy of the reference plane at hand (identical results)"""
         if isinstance(jobs, list):
             jobs = self.make_dist_fjobs(jobs)
-        t = self._TiledPlanes(org_tiled.data_ptr(), cur_tiled.data_ptr(), org.pad, cur.pad)
+        t = self._TiledPlanes(org_tiled.data_ptr() if org_tiled is not None else None, cur_tiled.data_ptr() if cur_tiled is not None else None, org.pad, cur.pad,
+                              cur_shift.data_ptr() + 2 * cur.origin if cur_shift is not None else None)
         self._ck(self.L.vvhip_dist_multi_func_tiled(self.ctx, org.buf_ptr, org.stride, cur.buf_ptr, cur.stride, C.byref(t), bit_depth, jobs[0], jobs[1]))
 
     def sad_x5_batch(self, org, cur, d_items, n, w, h, sub_shift=1, calc_centre=True, out=None):

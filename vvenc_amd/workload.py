@@ -60,6 +60,9 @@ class FrameWorkload:
         self.tiled = os.environ.get("VVHIP_WORKLOAD_TILED", "1") != "0"
         self.org_tiled = hp.tile_plane(self.org) if self.tiled else None
         self.ref_tiled = hp.tile_plane(self.ref) if self.tiled else None
+        # one-sample-shifted copy of the reference plane (dword-aligned loads for candidates at odd sample addresses), resident like the tiled copies
+        self.shifted = os.environ.get("VVHIP_WORKLOAD_SHIFT1", "1") != "0"
+        self.ref_shift = hp.shift_plane(self.ref) if self.shifted else None
         rng = np.random.default_rng(seed + 1)
         self.dist_jobs = []     # (func, S, sub_shift, n, d_items, d_out, host_items)
         self.pairs = 0
@@ -155,33 +158,61 @@ class FrameWorkload:
             timers.stop("SUBPEL")
 
     def tile_ref(self, ref=None, out=None):
-        """the reference plane changed (a new picture arrived): refresh its tiled copy"""
+        """the reference plane changed (a new picture arrived): refresh its derived copies (8x8-tiled, one-sample-shifted)"""
         if self.tiled:
             self.ref_tiled = self.hp.tile_plane(ref if ref is not None else self.ref, out if out is not None else self.ref_tiled)
+        if self.shifted:
+            self.ref_shift = self.hp.shift_plane(ref if ref is not None else self.ref, self.ref_shift)
         return self.ref_tiled
 
     def _dist(self, cls):
-        if self.tiled:
-            self.hp.dist_multi_func_tiled(self.org, self.ref, self.org_tiled, self.ref_tiled, self.fjob_tables[cls], self.bit_depth)
+        if self.tiled or self.shifted:
+            self.hp.dist_multi_func_tiled(self.org, self.ref, self.org_tiled, self.ref_tiled, self.fjob_tables[cls], self.bit_depth, cur_shift=self.ref_shift)
         else:
             self.hp.dist_multi_func(self.org, self.ref, self.fjob_tables[cls], self.bit_depth)
 
+    def _lanes(self, streams):
+        """one forked context per stream, and per class a pre-bound launch (the arguments of a picture's three launches never change between steps, except the reference
+        plane of the sharded run: the bound calls are rebuilt when it does)"""
+        import ctypes as C
+        key = (tuple(id(s) for s in streams), self.ref.storage.data_ptr(), id(self.ref_tiled), id(self.ref_shift))
+        if getattr(self, "_lane_key", None) != key:
+            if getattr(self, "_lane_ctx", None) is None or self._lane_streams != key[0]:
+                self._lane_ctx = [self.hp.fork(s) for s in streams]
+                self._lane_streams = key[0]
+            self._lane_cache = getattr(self, "_lane_cache", {})
+            ck = key[1:]
+            if ck not in self._lane_cache:
+                hp, calls = self.hp, []
+                self._tiled_struct = getattr(self, "_tiled_struct", [])
+                for i, cls in enumerate(("SAD_SSE", "HAD_fast", "TU")):
+                    lane = self._lane_ctx[i % len(self._lane_ctx)]
+                    if cls == "TU":
+                        tab = self.tu_table
+                        calls.append((cls, lane, lane.bound("vvhip_tu_rdo_multi", self.resi.buf_ptr, self.resi.stride, self.bit_depth, tab[0], tab[1])))
+                    else:
+                        tab = self.fjob_tables[cls]
+                        t = hp._TiledPlanes(self.org_tiled.data_ptr() if self.tiled else None, self.ref_tiled.data_ptr() if self.tiled else None, self.org.pad, self.ref.pad,
+                                            self.ref_shift.data_ptr() + 2 * self.ref.origin if self.shifted else None)
+                        self._tiled_struct.append(t)          # (kept alive: the bound call holds a pointer to it)
+                        calls.append((cls, lane, lane.bound("vvhip_dist_multi_func_tiled", self.org.buf_ptr, self.org.stride, self.ref.buf_ptr, self.ref.stride, C.byref(t), self.bit_depth,
+                                                            tab[0], tab[1])))
+                self._lane_cache[ck] = calls
+            self._lane_calls = self._lane_cache[ck]
+            self._lane_key = key
+        return self._lane_calls
+
     def run_overlapped(self, streams, timers=None):
         """the same three launches, each on its own HIP stream (they are independent work lists): they share the device and successive steps pipeline per stream.
+        Every stream has its own context (HotPath.fork) and every launch is a pre-bound call, so a step costs the host three foreign calls and nothing else.
         timers: per-class HIP events, recorded on the class's own stream"""
-        import torch
-        hp = self.hp
-        calls = [(c, (lambda c=c: self._dist(c))) for c in ("SAD_SSE", "HAD_fast")]
-        calls.append(("TU", lambda: hp.tu_rdo_multi(self.resi, self.tu_table, self.bit_depth)))
-        for i, (cls, c) in enumerate(calls):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                hp.use_torch_stream()
-                if timers is not None:
-                    timers.start(cls)
-                c()
-                if timers is not None:
-                    timers.stop(cls)
-        hp.use_torch_stream()
+        for cls, lane, call in self._lanes(streams):
+            if timers is not None and cls in timers.pool:
+                timers.start(cls, lane.stream)
+                call()
+                timers.stop(cls, lane.stream)
+            else:
+                call()
 
     # one pass of the hot path over the frame: 2 merged distortion launches (SAD+SSE, Hadamard) + 1 merged fused-TU launch (or 12 + 3 per-size ones)
     def run(self, timers=None):
