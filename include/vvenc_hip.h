@@ -116,7 +116,8 @@ VVHIP_API int vvhip_dist_multi( vvhip_ctx* ctx, int func, const int16_t* d_org, 
  * flags: VVHIP_DIST_FLAG_SAMPLES = the caller asserts that BOTH operands of the job hold samples in [0, 2^bit_depth) (original vs reconstructed /
  * predicted picture samples).  Without it the Hadamard jobs accept everything the encoder hands to a HAD table entry at that bit depth, including
  * the bi-prediction pattern 2*org - pred (values -(2^bd - 1) .. 2*(2^bd - 1), EncoderLib/InterSearch.cpp:1996-2003), through a slightly wider tile;
- * results are identical wherever both forms are defined.  vvhip_dist_multi (no flags field) always uses the general form.                 */
+ * results are identical wherever both forms are defined.  An SSE job with the flag (bit depth <= 12; here the flag may also stand for residuals, |operand| < 2^bit_depth)
+ * squares packed 16-bit differences (v_dot2_i32_i16).  vvhip_dist_multi (no flags field) always uses the general form.                 */
 #define VVHIP_DIST_FLAG_SAMPLES 1
 typedef struct { int32_t func, width, height, sub_shift, n, flags; const vvhip_dist_item* d_items; uint64_t* d_out; } vvhip_dist_fjob;
 VVHIP_API int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, int bit_depth,

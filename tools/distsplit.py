@@ -7,8 +7,9 @@ from vvenc_amd.hotpath import HotPath
 from vvenc_amd.workload import FrameWorkload
 
 hp = HotPath()
-wl = FrameWorkload(hp, 1920, 1080)
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+W, H = (3840, 2160) if "--4k" in sys.argv else (1920, 1080)
+wl = FrameWorkload(hp, W, H)
+reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200
 
 
 def timeit(fn):
@@ -21,7 +22,7 @@ def timeit(fn):
     return a.elapsed_time(b) / reps * 1e3
 
 
-for cls, funcs, flags in (("SAD_SSE", ("SAD", "SSE"), 0), ("HAD_fast", ("HAD_fast",), hp.DIST_FLAG_SAMPLES)):
+for cls, funcs, flags in (("SAD_SSE", ("SAD", "SSE"), hp.DIST_FLAG_SAMPLES), ("HAD_fast", ("HAD_fast",), hp.DIST_FLAG_SAMPLES)):
     jobs = [(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in wl.dist_jobs if f in funcs]
     def run(sel):
         tab = hp.make_dist_fjobs(sel, flags=flags)

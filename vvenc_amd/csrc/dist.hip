@@ -48,7 +48,16 @@ __device__ __forceinline__ uint32_t sadPair( uint32_t a, uint32_t b, uint32_t ac
 __device__ __forceinline__ uint32_t teamSum( uint32_t v, int lpc ) { return vvhipGroupSum32( v, lpc, threadIdx.x & 63 ); }
 __device__ __forceinline__ uint64_t teamSum( uint64_t v, int lpc ) { return vvhipGroupSum64( v, lpc, threadIdx.x & 63 ); }
 
-enum { MODE_SAD = 0, MODE_SSE = 1, MODE_SAD_X5 = 2, MODE_SAD_MIN2 = 3 };
+enum { MODE_SAD = 0, MODE_SSE = 1, MODE_SAD_X5 = 2, MODE_SAD_MIN2 = 3, MODE_SSE_PK = 4 };
+
+// MODE_SSE_PK: SSE of operands the caller declares to be samples of a bit depth <= 12 (VVHIP_DIST_FLAG_SAMPLES): a difference fits 16 bits, eight squares fit 32 —
+// packed subtraction + v_dot2_i32_i16 per sample pair instead of two widened subtractions and two 64-bit multiply-adds
+typedef short s16x2q __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ int sqPair( uint32_t a, uint32_t b, int acc )
+{
+  const s16x2q d = __builtin_bit_cast( s16x2q, a ) - __builtin_bit_cast( s16x2q, b );
+  return __builtin_amdgcn_sdot2( d, d, acc, false );
+}
 
 // ---------------------------------------------------------------------------------------------
 // SAD / SSE over a candidate list.  CH = samples per lane per row segment (2, 4 or 8).
@@ -115,6 +124,14 @@ sadSseBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, cons
     }
 #pragma unroll
     for( int u = 0; u < U; u++ )
+      if( MODE == MODE_SSE_PK )
+      {
+        int e = 0;
+#pragma unroll
+        for( int i = 0; i < CH / 2; i++ ) e = sqPair( va[u][i], vb[u][i], e );
+        sse[u] += ( uint32_t ) e;
+      }
+      else
 #pragma unroll
       for( int i = 0; i < CH / 2; i++ )
       {
@@ -130,7 +147,7 @@ sadSseBody( int blockIndex, const int16_t* __restrict__ org, int orgStride, cons
 #pragma unroll
   for( int u = 0; u < U; u++ )
   {
-    if( MODE == MODE_SSE )
+    if( MODE == MODE_SSE || MODE == MODE_SSE_PK )
     {
       const uint64_t t = teamSum( sse[u], lpc );
       if( valid[u] && lt == 0 ) out[team[u]] = t;
@@ -213,7 +230,13 @@ sadSse8TiledBody( int blockIndex, const Tiled8& T, const vvhip_dist_item* __rest
     tiledXY( it.cur_off, T.curBias, T.curStride, T.curMagic, cx, cy );
   }
   const u32x4 a = tiledRow8( T.org, T.orgTpr, ox, oy + r ), b = tiledRow8( T.cur, T.curTpr, cx, cy + r );
-  if( MODE == MODE_SSE )
+  if( MODE == MODE_SSE_PK )
+  {
+    int e = sqPair( a.x, b.x, 0 ); e = sqPair( a.y, b.y, e ); e = sqPair( a.z, b.z, e ); e = sqPair( a.w, b.w, e );
+    const uint32_t t = vvhipGroupSum32( ( uint32_t ) e, 8, threadIdx.x & 63 );         // 64 squares < 2^26 each
+    if( valid && r == 0 ) out[cand] = t;
+  }
+  else if( MODE == MODE_SSE )
   {
     const uint32_t as[4] = { a.x, a.y, a.z, a.w }, bs[4] = { b.x, b.y, b.z, b.w };
     uint64_t e = 0;
@@ -248,7 +271,12 @@ sadSseMultiKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  if( g.tiled ) sadSse8TiledBody<MODE>( blk, jobs.T, g.items, g.n, g.out );
+  if( MODE == MODE_SSE && g.sse == 2 )
+  {
+    if( g.tiled ) sadSse8TiledBody<MODE_SSE_PK>( blk, jobs.T, g.items, g.n, g.out );
+    else          sadSseBody<8, MODE_SSE_PK, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out, g.shift ? jobs.curShift : 0 );
+  }
+  else if( g.tiled ) sadSse8TiledBody<MODE>( blk, jobs.T, g.items, g.n, g.out );
   else          sadSseBody<8, MODE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out, g.shift ? jobs.curShift : 0 );
 }
 
@@ -262,7 +290,12 @@ sadSseMixedKernel( const int16_t* __restrict__ org, int orgStride, const int16_t
   const DistJobGeom& g = jobs.j[k];
   int blk = blockIdx.x - g.blockStart;
   if( jobs.xcdRemap ) blk = xcdBand( blk, g.nBlocks );
-  if( g.tiled ) { if( g.sse ) sadSse8TiledBody<MODE_SSE>( blk, jobs.T, g.items, g.n, g.out ); else sadSse8TiledBody<MODE_SAD>( blk, jobs.T, g.items, g.n, g.out ); }
+  if( g.sse == 2 )
+  {
+    if( g.tiled ) sadSse8TiledBody<MODE_SSE_PK>( blk, jobs.T, g.items, g.n, g.out );
+    else          sadSseBody<8, MODE_SSE_PK, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out, g.shift ? jobs.curShift : 0 );
+  }
+  else if( g.tiled ) { if( g.sse ) sadSse8TiledBody<MODE_SSE>( blk, jobs.T, g.items, g.n, g.out ); else sadSse8TiledBody<MODE_SAD>( blk, jobs.T, g.items, g.n, g.out ); }
   else if( g.sse ) sadSseBody<8, MODE_SSE, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out, g.shift ? jobs.curShift : 0 );
   else        sadSseBody<8, MODE_SAD, DIST_U>( blk, org, orgStride, cur, curStride, g.lpr, g.lprShift, g.rowsEff, g.subShift, g.log2Lpc, g.items, g.n, 0, g.out, g.shift ? jobs.curShift : 0 );
 }
@@ -976,7 +1009,7 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       bool tiledSad = false;
       if( fam == 1 )
       {
-        g.sse = jb.func == VVHIP_DF_SSE ? 1 : 0; ( g.sse ? anySse : anySad ) = true;
+        g.sse = jb.func == VVHIP_DF_SSE ? ( ( ( jb.flags & VVHIP_DIST_FLAG_SAMPLES ) && bit_depth <= 12 ) ? 2 : 1 ) : 0; ( g.sse ? anySse : anySad ) = true;
         g.subShift = g.sse ? 0 : jb.sub_shift;
         g.rowsEff = jb.height >> g.subShift; g.lpr = jb.width / 8; g.lprShift = isPow2( g.lpr ) ? ilog2i( g.lpr ) : -1;
         lpc = pow2Floor( g.lpr * g.rowsEff ); if( lpc > 64 ) lpc = 64;

@@ -115,7 +115,7 @@ class FrameWorkload:
         self.class_launches_merged = {"SAD_SSE": 1, "HAD_fast": 1, "TU": 1}
         self.alg_bytes["SAD_SSE"] = self.alg_bytes["SAD"] + self.alg_bytes["SSE"]
         # SAD and SSE lists share one launch (vvhip_dist_multi_func), the Hadamard lists another
-        self.fjob_tables = {"SAD_SSE": hp.make_dist_fjobs([(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f in ("SAD", "SSE")]),
+        self.fjob_tables = {"SAD_SSE": hp.make_dist_fjobs([(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f in ("SAD", "SSE")], flags=hp.DIST_FLAG_SAMPLES),
                             # original vs reconstructed picture samples: the Hadamard jobs may use the all-packed tile (VVHIP_DIST_FLAG_SAMPLES)
                             "HAD_fast": hp.make_dist_fjobs([(f, S, S, ss, n, it, out) for (f, S, ss, n, it, out, _) in self.dist_jobs if f == "HAD_fast"],
                                                            flags=hp.DIST_FLAG_SAMPLES)}
