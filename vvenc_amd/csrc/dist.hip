@@ -215,29 +215,28 @@ __device__ __forceinline__ u32x4 tiledRow8( const int16_t* __restrict__ t, int t
   return o;
 }
 
-// SAD / SSE of 8x8 candidates on the tiled copies: 8 lanes per candidate, lane = row
-template<int MODE>
+// SAD / SSE of 8x8 candidates on the tiled copies.  The list is VALU-issue-bound, not memory-bound (four v_sad_u16 per lane against an offset -> (x, y) division, tile addresses
+// and a funnel shift), so nothing is computed twice: a wave takes 64 candidates, lane L decomposes candidate L, and in round j the eight lanes of team t (lane = row) work on
+// candidate 8t + j, whose coordinates they fetch from lane 8t + j (ds_bpermute); lane j of the team keeps that round's total, so candidate L's result ends in lane L:
+// 64 coalesced result stores per wave.
+// (general SSE, arbitrary int16 operands: 64-bit row sums — the plain form, 8 lanes per candidate and 8 candidates per wave; workgroups are sized for it by the host)
 __device__ __forceinline__ void
-sadSse8TiledBody( int blockIndex, const Tiled8& T, const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+sse8TiledGeneralBody( int blockIndex, const Tiled8& T, const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
 {
-  const int gid = blockIndex * blockDim.x + threadIdx.x, cand = gid >> 3, r = gid & 7;
-  const bool valid = cand < n;
-  int ox = 0, oy = 0, cx = 0, cy = 0;
-  if( valid )
+  const int gid = blockIndex * blockDim.x + threadIdx.x, r = gid & 7;
+  // this workgroup's candidates are [blockIndex * blockDim, + blockDim): eight passes of blockDim / 8
+  for( int pass = 0; pass < 8; pass++ )
   {
-    const vvhip_dist_item it = items[cand];
-    tiledXY( it.org_off, T.orgBias, T.orgStride, T.orgMagic, ox, oy );
-    tiledXY( it.cur_off, T.curBias, T.curStride, T.curMagic, cx, cy );
-  }
-  const u32x4 a = tiledRow8( T.org, T.orgTpr, ox, oy + r ), b = tiledRow8( T.cur, T.curTpr, cx, cy + r );
-  if( MODE == MODE_SSE_PK )
-  {
-    int e = sqPair( a.x, b.x, 0 ); e = sqPair( a.y, b.y, e ); e = sqPair( a.z, b.z, e ); e = sqPair( a.w, b.w, e );
-    const uint32_t t = vvhipGroupSum32( ( uint32_t ) e, 8, threadIdx.x & 63 );         // 64 squares < 2^26 each
-    if( valid && r == 0 ) out[cand] = t;
-  }
-  else if( MODE == MODE_SSE )
-  {
+    const int cand = blockIndex * blockDim.x + pass * ( blockDim.x >> 3 ) + ( threadIdx.x >> 3 );
+    const bool valid = cand < n;
+    int ox = 0, oy = 0, cx = 0, cy = 0;
+    if( valid )
+    {
+      const vvhip_dist_item it = items[cand];
+      tiledXY( it.org_off, T.orgBias, T.orgStride, T.orgMagic, ox, oy );
+      tiledXY( it.cur_off, T.curBias, T.curStride, T.curMagic, cx, cy );
+    }
+    const u32x4 a = tiledRow8( T.org, T.orgTpr, ox, oy + r ), b = tiledRow8( T.cur, T.curTpr, cx, cy + r );
     const uint32_t as[4] = { a.x, a.y, a.z, a.w }, bs[4] = { b.x, b.y, b.z, b.w };
     uint64_t e = 0;
 #pragma unroll
@@ -245,12 +244,39 @@ sadSse8TiledBody( int blockIndex, const Tiled8& T, const vvhip_dist_item* __rest
     const uint64_t t = vvhipGroupSum64( e, 8, threadIdx.x & 63 );
     if( valid && r == 0 ) out[cand] = t;
   }
-  else
+}
+
+template<int MODE>
+__device__ __forceinline__ void
+sadSse8TiledBody( int blockIndex, const Tiled8& T, const vvhip_dist_item* __restrict__ items, int n, uint64_t* __restrict__ out )
+{
+  if( MODE == MODE_SSE ) { sse8TiledGeneralBody( blockIndex, T, items, n, out ); return; }
+  const int lane = threadIdx.x & 63, r = lane & 7;
+  const int cand = blockIndex * blockDim.x + threadIdx.x;                  // the candidate this lane decomposes and stores
+  const bool valid = cand < n;
+  uint32_t po = 0, pc = 0;                                                  // ( x | y << 16 ) in the padded planes (both < 2^16: checked on the host)
+  if( valid )
   {
-    uint32_t sd = sadPair( a.x, b.x, 0 ); sd = sadPair( a.y, b.y, sd ); sd = sadPair( a.z, b.z, sd ); sd = sadPair( a.w, b.w, sd );
-    const uint32_t t = vvhipGroupSum32( sd, 8, threadIdx.x & 63 );
-    if( valid && r == 0 ) out[cand] = t;
+    const vvhip_dist_item it = items[cand];
+    int ox, oy, cx, cy;
+    tiledXY( it.org_off, T.orgBias, T.orgStride, T.orgMagic, ox, oy );
+    tiledXY( it.cur_off, T.curBias, T.curStride, T.curMagic, cx, cy );
+    po = ( uint32_t ) ox | ( ( uint32_t ) oy << 16 ); pc = ( uint32_t ) cx | ( ( uint32_t ) cy << 16 );
   }
+  uint32_t tot = 0;
+#pragma unroll 2
+  for( int j = 0; j < 8; j++ )
+  {
+    const int srcLane = ( ( lane & ~7 ) + j ) << 2;
+    const uint32_t qo = ( uint32_t ) __builtin_amdgcn_ds_bpermute( srcLane, ( int ) po ), qc = ( uint32_t ) __builtin_amdgcn_ds_bpermute( srcLane, ( int ) pc );
+    const u32x4 a = tiledRow8( T.org, T.orgTpr, ( int ) ( qo & 0xffffu ), ( int ) ( qo >> 16 ) + r ), b = tiledRow8( T.cur, T.curTpr, ( int ) ( qc & 0xffffu ), ( int ) ( qc >> 16 ) + r );
+    uint32_t e;
+    if( MODE == MODE_SSE_PK ) { int q = sqPair( a.x, b.x, 0 ); q = sqPair( a.y, b.y, q ); q = sqPair( a.z, b.z, q ); q = sqPair( a.w, b.w, q ); e = ( uint32_t ) q; }      // 8 squares < 2^26 each
+    else { e = sadPair( a.x, b.x, 0 ); e = sadPair( a.y, b.y, e ); e = sadPair( a.z, b.z, e ); e = sadPair( a.w, b.w, e ); }
+    const uint32_t t = vvhipGroupSum32( e, 8, lane );          // every lane of the team gets the candidate's total; lane j of the team keeps it
+    tot = r == j ? t : tot;
+  }
+  if( valid ) out[cand] = tot;
 }
 
 // Workgroups are dealt round-robin to the 8 XCDs (private L2 each).  Work lists are in raster order of the picture, so giving XCD x
@@ -971,7 +997,7 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
     mj.curShift = ( useShift && tiled && tiled->d_cur_shift1 && !( ( reinterpret_cast<uintptr_t>( d_cur ) ^ reinterpret_cast<uintptr_t>( tiled->d_cur_shift1 ) ) & 3 ) )
                   ? ( tiled->d_cur_shift1 - d_cur ) - 1 : 0;
     static const int useTiled = []{ const char* e = getenv( "VVHIP_TILED" ); return e ? atoi( e ) : 1; }();
-    const bool haveTiled = tiled && useTiled && tiled->d_org_tiled && tiled->d_cur_tiled && bit_depth <= 10;
+    const bool haveTiled = tiled && useTiled && tiled->d_org_tiled && tiled->d_cur_tiled && bit_depth <= 10 && org_stride < 65536 && cur_stride < 65536;
     if( haveTiled )
     {
       mj.T.org = tiled->d_org_tiled; mj.T.cur = tiled->d_cur_tiled;
@@ -1031,6 +1057,7 @@ static int distMultiFunc( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, 
       static const int wgEnv = []{ const char* e = getenv( "VVHIP_DIST_WG" ); const int v = e ? atoi( e ) : 0; return ( v == 64 || v == 128 || v == 256 ) ? v : 0; }();
       const int wgSize = wgEnv ? wgEnv : ( fam >= 2 ? 64 : 256 );
       g.nBlocks = ( fam == 1 && !tiledSad ) ? ( int ) ( ( ( ( long ) jb.n + DIST_U - 1 ) / DIST_U * lpc + wgSize - 1 ) / wgSize ) : ( int ) ( ( ( long ) jb.n * lpc + wgSize - 1 ) / wgSize );
+      if( tiledSad ) g.nBlocks = ( jb.n + wgSize - 1 ) / wgSize;            // the tiled body: one candidate per lane (sadSse8TiledBody)
       blocks += g.nBlocks;
       mj.nJobs++;
     }
