@@ -1269,15 +1269,17 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
     // SSE: when every residual and reconstructed sample of the wave is within +-4095 (any residual of <= 12-bit video) a difference fits 14 bits, a lane's 16 squares
     // fit 32 bits and the sum is eight packed subtractions + eight v_dot2_i32_i16; otherwise (arbitrary int16 input) the 64-bit multiply-adds
     uint32_t rpAll[8];
+    typedef unsigned short u16x2t __attribute__( ( ext_vector_type( 2 ) ) );
     uint32_t magn = 0;
 #pragma unroll
     for( int k = 0; k < 8; k++ )
     {
       rpAll[k] = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( d[2 * k], d[2 * k + 1] ) );          // saturate + pack
-      magn |= ( rpAll[k] ^ ( uint32_t ) ( ( int ) ( rpAll[k] << 16 ) >> 31 & 0xffff ) ^ ( uint32_t ) ( ( int ) rpAll[k] >> 31 << 16 ) );   // x ^ sign(x) per half: < 4096 iff -4096 <= x <= 4095
-      magn |= ( xr2[k] ^ ( uint32_t ) ( ( int ) ( xr2[k] << 16 ) >> 31 & 0xffff ) ^ ( uint32_t ) ( ( int ) xr2[k] >> 31 << 16 ) );
+      // -4096 <= x <= 4095  <=>  ( uint16 ) ( x + 4096 ) < 8192: one packed add and one and-or per pair of samples
+      magn |= __builtin_bit_cast( uint32_t, __builtin_bit_cast( u16x2t, rpAll[k] ) + __builtin_bit_cast( u16x2t, 0x10001000u ) ) & 0xe000e000u;
+      magn |= __builtin_bit_cast( uint32_t, __builtin_bit_cast( u16x2t, xr2[k] ) + __builtin_bit_cast( u16x2t, 0x10001000u ) ) & 0xe000e000u;
     }
-    const bool smallDiff = __builtin_amdgcn_ballot_w64( ( magn & 0xf000f000u ) != 0 ) == 0ull;
+    const bool smallDiff = __builtin_amdgcn_ballot_w64( magn != 0 ) == 0ull;
     uint32_t sse32[R];
 #pragma unroll
     for( int r = 0; r < R; r++ ) sse32[r] = 0;
