@@ -627,7 +627,9 @@ def main():
                            "frac_l2": ks[dom_cls]["alg_GBps"] / L2_PEAK_GBS, "l2_peak_GBps": L2_PEAK_GBS,
                            "unique_bytes_per_launch": ks[dom_cls].get("unique_bytes_per_launch"), "frac_hbm_unique": ks[dom_cls].get("frac_hbm_unique"),
                            "frac_hbm_traffic": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                           "limiter": "issue rate of 16-byte gathers (candidate rows are scattered 16..128-byte pieces) and occupancy, not a memory level (DESIGN §3)"}
+                           "limiter": "L1 (TCP) access rate and VALU issue, not a memory level: one L1 access per 64-byte granule and instruction (rocprofv3 TCP_TOTAL_CACHE_ACCESSES: 9.7 M per "
+                                      "launch = 15.8 us at 256 CUs x 2.4 GHz) next to 7.8 M VALU wave-instructions (12.8 us of the SIMDs); frac > 1 on the nominal basis only says that the "
+                                      "candidates' bytes are re-read from L1 / L2, never from HBM (DESIGN §6, profiles/r02_d_pmc_merged_launches.log)"}
     if overlap is not None:
         out["single_stream"] = overlap
     if graph is not None:
