@@ -124,10 +124,10 @@ VVHIP_API int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* d_org, int o
                                      const vvhip_dist_fjob* jobs_host, int n_jobs );
 
 /* The same lists on 8x8-TILED copies of the planes (no counterpart in the reference: a memory-layout decision for the MI355X).  A 128-byte cache line holds one 8x8 tile of
- * int16 samples; in a row-major plane an 8x8 block is eight 16-byte pieces in eight lines and every piece drags a whole line out of L2 — the 8x8 lists run at the L2's line
- * rate.  vvhip_plane_tile8 makes the tiled copy of a padded plane (d_base = first sample of the padded plane, `rows` lines of `stride` samples; d_tiled holds
+ * int16 samples; in a row-major plane an 8x8 block is eight 16-byte pieces in eight lines, each its own L1 access (29 accesses per 8x8 SAD candidate, 10.5 on the tiled
+ * copy: the lists run at the L1's access rate).  vvhip_plane_tile8 makes the tiled copy of a padded plane (d_base = first sample of the padded plane, `rows` lines of `stride` samples; d_tiled holds
  * vvhip_tiled8_elems( stride, rows ) samples; re-tile when the plane changes).  vvhip_dist_multi_func_tiled = vvhip_dist_multi_func, identical results, with the 8x8 SAD / SSE jobs
- * of bit depths <= 10 reading the tiled copies (the Hadamard jobs were measured slower there and stay on the row-major planes) (tiled may be NULL: no difference to vvhip_dist_multi_func).  *_margin = samples of margin around
+ * of bit depths <= 10 reading the tiled copies (the Hadamard jobs were measured slower there and stay on the row-major planes) (tiled may be NULL: no difference to vvhip_dist_multi_func; either tiled pointer may be NULL: those jobs stay on the row-major planes).  *_margin = samples of margin around
  * sample (0,0) of the plane the tiled copy was made from (d_org / d_cur still address sample (0,0) of the row-major planes, used by the other jobs).                          */
 typedef struct { const int16_t* d_org_tiled; const int16_t* d_cur_tiled; int32_t org_margin, cur_margin;
                  const int16_t* d_cur_shift1;   /* optional (NULL: none): the sample of a ONE-SAMPLE-SHIFTED copy of the reference plane buffer that corresponds to d_cur, i.e.

@@ -183,8 +183,8 @@ sadSseKernel( const int16_t* __restrict__ org, int orgStride, const int16_t* __r
 constexpr int DIST_U = VVHIP_DIST_U;   // candidates per lane team in the merged SAD / SSE launches (they share the original rows when they belong to one block)
 struct DistJobGeom { int lpr, lprShift, rowsEff, subShift, log2Lpc, n, blockStart, nBlocks, fast16, tilesX, tilesPerCand, sse, tiled, shift; const vvhip_dist_item* items; uint64_t* out; };
 // 8x8-tiled copies of the two planes (vvhip_plane_tile8): a 128-byte cache line = ONE 8x8 tile of int16 samples.  An 8x8 candidate of a row-major plane is eight 16-byte
-// pieces in eight cache lines — every piece drags a whole line out of L2, which is what bounds the 8x8 lists (they run at the L2's line rate); in the tiled copy the same
-// candidate lies in at most four lines, an aligned original block in one.
+// pieces in eight cache lines — every piece is an L1 access of its own (and a line fill out of L2), which is what bounds the 8x8 lists; in the tiled copy the same
+// candidate lies in at most four lines, an aligned original block in one (29 -> 10.5 L1 accesses per SAD candidate).
 struct Tiled8 { const int16_t* org; const int16_t* cur; int orgTpr, curTpr, orgBias, curBias, orgStride, curStride; unsigned long long orgMagic, curMagic; };
 struct DistMultiJobs { int nJobs, xcdRemap; DistJobGeom j[8]; Tiled8 T; ptrdiff_t curShift; };
 
