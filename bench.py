@@ -434,16 +434,15 @@ def main():
             ref_tiled.append(hp.tile_plane(pl) if wl.tiled else None)
             ref_shift.append(hp.shift_plane(pl) if wl.shifted else None)
 
+        hp_ex = hp.fork(ex.stream) if ex.stream is not None else hp      # a context bound to the exchange stream: no stream switching per picture
+
         def retile(slot_index):
             # the derived copies (8x8-tiled, one-sample-shifted) of the received reference picture, on the exchange stream right behind the broadcast
             def f(planes):
-                if wl.tiled or wl.shifted:
-                    hp.use_torch_stream()
-                    if wl.tiled:
-                        hp.tile_plane(ref_planes[slot_index], ref_tiled[slot_index])
-                    if wl.shifted:
-                        hp.shift_plane(ref_planes[slot_index], ref_shift[slot_index])
-                    hp.use_torch_stream()
+                if wl.tiled:
+                    hp_ex.tile_plane(ref_planes[slot_index], ref_tiled[slot_index])
+                if wl.shifted:
+                    hp_ex.shift_plane(ref_planes[slot_index], ref_shift[slot_index])
             return f
         ex.publish(0, 0, after=retile(0))
 
