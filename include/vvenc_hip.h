@@ -137,6 +137,11 @@ typedef struct { const int16_t* d_org_tiled; const int16_t* d_cur_tiled; int32_t
                } vvhip_tiled_planes;
 /* d_dst[i] = d_src[i + 1] for i < elems - 1, d_dst[elems - 1] = 0; both buffers with the same alignment modulo 4 bytes */
 VVHIP_API int vvhip_plane_shift1( vvhip_ctx* ctx, const int16_t* d_src, size_t elems, int16_t* d_dst );
+/* all three derived copies of a picture's planes in one launch (what a caller does once per picture): the 8x8-tiled copy of the original plane, the 8x8-tiled and the one-sample-shifted
+ * copy of the reference plane.  *_base = first sample of the padded plane buffer, `rows` lines of `stride` samples; any output may be NULL (skipped).
+ * d_cur_shift1 covers the whole buffer (stride * rows samples) like vvhip_plane_shift1. */
+VVHIP_API int vvhip_planes_derive( vvhip_ctx* ctx, const int16_t* d_org_base, int org_stride, int org_rows, int16_t* d_org_tiled,
+                                   const int16_t* d_cur_base, int cur_stride, int cur_rows, int16_t* d_cur_tiled, int16_t* d_cur_shift1 );
 VVHIP_API size_t vvhip_tiled8_elems( int stride, int rows );
 VVHIP_API int vvhip_plane_tile8( vvhip_ctx* ctx, const int16_t* d_base, int stride, int rows, int16_t* d_tiled );
 VVHIP_API int vvhip_dist_multi_func_tiled( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride, const vvhip_tiled_planes* tiled_host, int bit_depth,

@@ -120,6 +120,14 @@ int vvhip_dist_multi_func( vvhip_ctx* ctx, const int16_t* o, int os, const int16
   return VVHIP_OK;
 }
 int vvhip_plane_shift1( vvhip_ctx* ctx, const int16_t* s, size_t n, int16_t* d ) { if( !ctx ) return VVHIP_E_ARG; for( size_t i = 0; i < n; i++ ) d[i] = i + 1 < n ? s[i + 1] : ( int16_t ) 0; return VVHIP_OK; }
+int vvhip_planes_derive( vvhip_ctx* ctx, const int16_t* ob, int os, int orows, int16_t* ot, const int16_t* cb, int cs, int crows, int16_t* ct, int16_t* sh )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( ot ) vvhip_plane_tile8( ctx, ob, os, orows, ot );
+  if( ct ) vvhip_plane_tile8( ctx, cb, cs, crows, ct );
+  if( sh ) vvhip_plane_shift1( ctx, cb, ( size_t ) cs * crows, sh );
+  return VVHIP_OK;
+}
 size_t vvhip_tiled8_elems( int stride, int rows ) { return ( size_t ) ( ( rows + 7 ) / 8 ) * ( ( stride + 7 ) / 8 ) * 64 + 128; }
 int vvhip_plane_tile8( vvhip_ctx* ctx, const int16_t* base, int stride, int rows, int16_t* tiled )
 {

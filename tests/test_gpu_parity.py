@@ -970,6 +970,11 @@ def test_dist_multi_func_tiled_equals_row_major(hip, oracle, aligned):
         # + the one-sample-shifted copy of the reference plane (candidates at odd sample addresses read it with dword-aligned loads): with and without the tiled copies,
         # packed (10-bit) and 32-bit (12-bit call) Hadamard forms
         sh = hp.shift_plane(pc)
+        # the three copies in one launch (vvhip_planes_derive) == the single-copy entry points
+        to2, tc2, sh2 = torch.full_like(to, -7), torch.full_like(tc, -7), torch.full_like(sh, -7)
+        hp.planes_derive(po, pc, to2, tc2, sh2)
+        n_t = (po.storage.shape[0] + 7) // 8 * ((po.stride + 7) // 8) * 64
+        assert torch.equal(to2[:n_t], to[:n_t]) and torch.equal(tc2[:n_t], tc[:n_t]) and torch.equal(sh2, sh)
         assert np.array_equal(sh.cpu().numpy().ravel()[:-1], pc.storage.cpu().numpy().ravel()[1:]) and int(sh.cpu().numpy().ravel()[-1]) == 0
         for (t_o, t_c, bd) in ((to, tc, 10), (None, None, 10), (None, None, 12)):
             shifted = [(f, w, h, ss, n, it, torch.full((n,), -3, dtype=torch.int64, device=hp.device)) for (f, w, h, ss, n, it, _) in jobs]

@@ -821,32 +821,76 @@ sadSurfaceKernel( const int16_t* __restrict__ org, int orgStride, const int16_t*
   }
 }
 
+__device__ __forceinline__ void shift1Unit( size_t i, const int16_t* __restrict__ src, size_t elems, int16_t* __restrict__ dst );
 // dst[i] = src[i + 1] (the last element 0): thread = eight samples
 __global__ void __launch_bounds__( 256 )
 shift1Kernel( const int16_t* __restrict__ src, size_t elems, int16_t* __restrict__ dst )
 {
-  const size_t i = ( ( size_t ) blockIdx.x * 256 + threadIdx.x ) * 8;
+  shift1Unit( ( ( size_t ) blockIdx.x * 256 + threadIdx.x ) * 8, src, elems, dst );
+}
+__device__ __forceinline__ void shift1Unit( size_t i, const int16_t* __restrict__ src, size_t elems, int16_t* __restrict__ dst )
+{
   if( i >= elems ) return;
-  if( i + 9 <= elems && !( reinterpret_cast<uintptr_t>( dst + i ) & 15 ) ) { *reinterpret_cast<u32x4*>( dst + i ) = ld16( src + i + 1 ); return; }
+  if( i + 8 <= elems && !( ( reinterpret_cast<uintptr_t>( dst + i ) | reinterpret_cast<uintptr_t>( src + i ) ) & 15 ) )
+  {
+    // an aligned vector + the dword behind it, funnel-shifted by one sample (a 16-byte load at a 2-byte-aligned address would be split into dwords by the memory pipeline)
+    const u32x4 v = *reinterpret_cast<const u32x4*>( src + i );
+    uint32_t nx = 0;
+    if( i + 10 <= elems ) nx = *reinterpret_cast<const uint32_t*>( src + i + 8 ); else if( i + 8 < elems ) nx = ( uint32_t ) ( uint16_t ) src[i + 8];
+    u32x4 o;
+    o.x = __builtin_amdgcn_alignbit( v.y, v.x, 16 ); o.y = __builtin_amdgcn_alignbit( v.z, v.y, 16 ); o.z = __builtin_amdgcn_alignbit( v.w, v.z, 16 ); o.w = __builtin_amdgcn_alignbit( nx, v.w, 16 );
+    *reinterpret_cast<u32x4*>( dst + i ) = o;
+    return;
+  }
   for( size_t k = i; k < elems && k < i + 8; k++ ) dst[k] = k + 1 < elems ? src[k + 1] : ( int16_t ) 0;
 }
 
-// row-major padded plane -> 8x8-tiled copy: thread = one 16-byte tile row
+// row-major padded plane -> 8x8-tiled copy.  A workgroup takes a band of 8 rows x 64 tiles: coalesced row reads (64 x 16 bytes per row), transposed through LDS (pitch 9 tile rows:
+// conflict-free), coalesced tile writes (64 x 128 bytes).  Grid = ceil(rows / 8) x ceil(tpr / 64) workgroups.
+constexpr int TILE_BAND = 64;
+__device__ __forceinline__ void tile8Band( int blk, const int16_t* __restrict__ src, int stride, int rows, int tpr, int16_t* __restrict__ dst, u32x4* __restrict__ sT )
+{
+  const int groups = ( tpr + TILE_BAND - 1 ) / TILE_BAND, band = blk / groups, tx0 = ( blk - band * groups ) * TILE_BAND, t = threadIdx.x;
+#pragma unroll
+  for( int k = 0; k < 2; k++ )
+  {
+    const int p = t + 256 * k, r = p >> 6, tx = p & 63, y = band * 8 + r, X = tx0 + tx;
+    u32x4 v = { 0, 0, 0, 0 };
+    if( X < tpr && y < rows )
+    {
+      const int16_t* q = src + ( size_t ) y * stride + 8 * X;
+      if( 8 * X + 8 <= stride ) v = ld16( q );
+      else { int16_t tmp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; for( int j = 0; 8 * X + j < stride; j++ ) tmp[j] = q[j]; v = *reinterpret_cast<const u32x4*>( tmp ); }
+    }
+    sT[tx * 9 + r] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for( int k = 0; k < 2; k++ )
+  {
+    const int q = t + 256 * k, tile = q >> 3, r = q & 7, X = tx0 + tile;
+    if( X < tpr ) *reinterpret_cast<u32x4*>( dst + ( ( size_t ) band * tpr + X ) * 64 + r * 8 ) = sT[tile * 9 + r];
+  }
+}
+__device__ __forceinline__ void shift1Unit( size_t i, const int16_t* __restrict__ src, size_t elems, int16_t* __restrict__ dst );
+
 __global__ void __launch_bounds__( 256 )
 tile8Kernel( const int16_t* __restrict__ src, int stride, int rows, int tpr, int16_t* __restrict__ dst )
 {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int rowsPad = ( rows + 7 ) & ~7;
-  if( i >= rowsPad * tpr ) return;
-  const int y = i / tpr, tx = i - y * tpr;
-  u32x4 v = { 0, 0, 0, 0 };
-  if( y < rows )
-  {
-    const int16_t* p = src + ( size_t ) y * stride + 8 * tx;
-    if( 8 * tx + 8 <= stride ) v = ld16( p );
-    else { int16_t t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; for( int k = 0; 8 * tx + k < stride; k++ ) t[k] = p[k]; v = *reinterpret_cast<const u32x4*>( t ); }
-  }
-  *reinterpret_cast<u32x4*>( dst + ( ( size_t ) ( y >> 3 ) * tpr + tx ) * 64 + ( y & 7 ) * 8 ) = v;
+  __shared__ u32x4 sT[TILE_BAND * 9];
+  tile8Band( blockIdx.x, src, stride, rows, tpr, dst, sT );
+}
+
+// every copy the library derives from a picture's planes in ONE launch: block ranges [0, b0) tile the original plane, [b0, b1) tile the reference plane, [b1, ..) shift it
+struct DeriveArgs { const int16_t* org; int orgStride, orgRows, orgTpr; int16_t* orgTiled; const int16_t* cur; int curStride, curRows, curTpr; int16_t* curTiled; int16_t* curShift; size_t curElems; int b0, b1; };
+__global__ void __launch_bounds__( 256 )
+deriveKernel( DeriveArgs a )
+{
+  __shared__ u32x4 sT[TILE_BAND * 9];
+  const int b = blockIdx.x;
+  if( b < a.b0 )      tile8Band( b, a.org, a.orgStride, a.orgRows, a.orgTpr, a.orgTiled, sT );
+  else if( b < a.b1 ) tile8Band( b - a.b0, a.cur, a.curStride, a.curRows, a.curTpr, a.curTiled, sT );
+  else                shift1Unit( ( ( size_t ) ( b - a.b1 ) * 256 + threadIdx.x ) * 8, a.cur, a.curElems, a.curShift );
 }
 
 int pow2Floor( int v ) { int p = 1; while( p * 2 <= v ) p <<= 1; return p; }
@@ -1092,6 +1136,28 @@ int vvhip_dist_multi_func_tiled( vvhip_ctx* ctx, const int16_t* d_org, int org_s
   return distMultiFunc( ctx, d_org, org_stride, d_cur, cur_stride, bit_depth, jobs, n_jobs, tiled );
 }
 
+static long tile8Blocks( int rows, int tpr ) { return ( long ) ( ( rows + 7 ) / 8 ) * ( ( tpr + TILE_BAND - 1 ) / TILE_BAND ); }
+
+int vvhip_planes_derive( vvhip_ctx* ctx, const int16_t* d_org_base, int org_stride, int org_rows, int16_t* d_org_tiled,
+                         const int16_t* d_cur_base, int cur_stride, int cur_rows, int16_t* d_cur_tiled, int16_t* d_cur_shift1 )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( ( d_org_tiled && ( !d_org_base || org_stride < 8 || org_rows < 1 ) ) || ( ( d_cur_tiled || d_cur_shift1 ) && ( !d_cur_base || cur_stride < 8 || cur_rows < 1 ) ) )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_planes_derive: bad arguments" );
+  DeriveArgs a = {};
+  a.org = d_org_base; a.orgStride = org_stride; a.orgRows = org_rows; a.orgTpr = ( org_stride + 7 ) / 8; a.orgTiled = d_org_tiled;
+  a.cur = d_cur_base; a.curStride = cur_stride; a.curRows = cur_rows; a.curTpr = ( cur_stride + 7 ) / 8; a.curTiled = d_cur_tiled; a.curShift = d_cur_shift1;
+  a.curElems = ( size_t ) cur_stride * cur_rows;
+  const long n0 = d_org_tiled ? tile8Blocks( org_rows, a.orgTpr ) : 0, n1 = d_cur_tiled ? tile8Blocks( cur_rows, a.curTpr ) : 0;
+  const long n2 = d_cur_shift1 ? ( long ) ( ( a.curElems + 7 ) / 8 ) : 0;
+  a.b0 = ( int ) n0; a.b1 = a.b0 + ( int ) n1;
+  const long blocks = a.b1 + ( n2 + 255 ) / 256;
+  if( !blocks ) return VVHIP_OK;
+  hipLaunchKernelGGL( deriveKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, a );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
 int vvhip_plane_shift1( vvhip_ctx* ctx, const int16_t* d_src, size_t elems, int16_t* d_dst )
 {
   if( !ctx ) return VVHIP_E_ARG;
@@ -1110,9 +1176,8 @@ int vvhip_plane_tile8( vvhip_ctx* ctx, const int16_t* d_base, int stride, int ro
 {
   if( !ctx ) return VVHIP_E_ARG;
   if( !d_base || !d_tiled || stride < 8 || rows < 1 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_plane_tile8: bad arguments" );
-  const int tpr = ( stride + 7 ) / 8, rowsPad = ( rows + 7 ) & ~7;
-  const long n = ( long ) rowsPad * tpr;
-  hipLaunchKernelGGL( tile8Kernel, dim3( ( unsigned ) ( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, ctx->stream, d_base, stride, rows, tpr, d_tiled );
+  const int tpr = ( stride + 7 ) / 8;
+  hipLaunchKernelGGL( tile8Kernel, dim3( ( unsigned ) tile8Blocks( rows, tpr ) ), dim3( 256 ), 0, ctx->stream, d_base, stride, rows, tpr, d_tiled );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
 }

@@ -241,6 +241,12 @@ class HotPath:
         self._ck(self.L.vvhip_plane_shift1(self.ctx, plane.storage.data_ptr(), plane.storage.numel(), out.data_ptr()))
         return out
 
+    def planes_derive(self, org, cur, org_tiled=None, cur_tiled=None, cur_shift=None):
+        """the derived copies of a picture's two planes in one launch (outputs that are None are skipped)"""
+        self._ck(self.L.vvhip_planes_derive(self.ctx, org.storage.data_ptr(), org.stride, org.storage.shape[0], org_tiled.data_ptr() if org_tiled is not None else None,
+                                            cur.storage.data_ptr(), cur.stride, cur.storage.shape[0], cur_tiled.data_ptr() if cur_tiled is not None else None,
+                                            cur_shift.data_ptr() if cur_shift is not None else None))
+
     def dist_multi_func_tiled(self, org, cur, org_tiled, cur_tiled, jobs, bit_depth=10, cur_shift=None):
         """dist_multi_func with the tiled copies of both planes (either may be None) and the one-sample-shifted copy of the reference plane at hand (identical results)"""
         if isinstance(jobs, list):

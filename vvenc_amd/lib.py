@@ -43,6 +43,7 @@ PROTOTYPES = {
     "vvhip_tiled8_elems": (sz, [i32, i32]),
     "vvhip_plane_tile8": (i32, [vp, vp, i32, i32, vp]),
     "vvhip_plane_shift1": (i32, [vp, vp, C.c_size_t, vp]),
+    "vvhip_planes_derive": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp]),
     "vvhip_dist_multi_func_tiled": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32]),
     "vvhip_sad_mask_batch": (i32, [vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
     "vvhip_fix_weighted_sse_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp]),

@@ -171,11 +171,15 @@ class FrameWorkload:
         else:
             self.hp.dist_multi_func(self.org, self.ref, self.fjob_tables[cls], self.bit_depth)
 
-    def _lanes(self, streams):
+    def _lanes(self, streams, derive=False):
         """one forked context per stream, and per class a pre-bound launch (the arguments of a picture's three launches never change between steps, except the reference
-        plane of the sharded run: the bound calls are rebuilt when it does)"""
+        plane of the sharded run: the bound calls are rebuilt when it does).
+        derive: every step is a new picture, so the copies the library derives from its planes are made per step, by the lane that reads them and in front of its launch (stream
+        order, no events): the SAD / SSE lane makes the tiled copies of both planes and its shifted reference copy in ONE launch (vvhip_planes_derive), the Hadamard lane its own
+        shifted copy.  Without it the lanes read the copies made when the workload was built (tile_ref() refreshes them)."""
         import ctypes as C
-        key = (tuple(id(s) for s in streams), self.ref.storage.data_ptr(), id(self.ref_tiled), id(self.ref_shift))
+        import torch
+        key = (tuple(id(s) for s in streams), self.ref.storage.data_ptr(), id(self.ref_tiled), id(self.ref_shift), bool(derive))
         if getattr(self, "_lane_key", None) != key:
             if getattr(self, "_lane_ctx", None) is None or self._lane_streams != key[0]:
                 self._lane_ctx = [self.hp.fork(s) for s in streams]
@@ -185,28 +189,45 @@ class FrameWorkload:
             if ck not in self._lane_cache:
                 hp, calls = self.hp, []
                 self._tiled_struct = getattr(self, "_tiled_struct", [])
+                if derive and (self.tiled or self.shifted) and getattr(self, "_lane_copies", None) is None:
+                    # per-lane derived copies (each lane rewrites its own, in stream order behind its previous launch)
+                    self._lane_copies = {"SAD_SSE": (torch.empty_like(self.org_tiled) if self.tiled else None, torch.empty_like(self.ref_tiled) if self.tiled else None,
+                                                     torch.empty_like(self.ref.storage) if self.shifted else None),
+                                         "HAD_fast": (None, None, torch.empty_like(self.ref.storage) if self.shifted else None)}
+                rows_o, rows_c = self.org.storage.shape[0], self.ref.storage.shape[0]
                 for i, cls in enumerate(("SAD_SSE", "HAD_fast", "TU")):
                     lane = self._lane_ctx[i % len(self._lane_ctx)]
                     if cls == "TU":
                         tab = self.tu_table
-                        calls.append((cls, lane, lane.bound("vvhip_tu_rdo_multi", self.resi.buf_ptr, self.resi.stride, self.bit_depth, tab[0], tab[1])))
-                    else:
-                        tab = self.fjob_tables[cls]
-                        t = hp._TiledPlanes(self.org_tiled.data_ptr() if self.tiled else None, self.ref_tiled.data_ptr() if self.tiled else None, self.org.pad, self.ref.pad,
-                                            self.ref_shift.data_ptr() + 2 * self.ref.origin if self.shifted else None)
-                        self._tiled_struct.append(t)          # (kept alive: the bound call holds a pointer to it)
-                        calls.append((cls, lane, lane.bound("vvhip_dist_multi_func_tiled", self.org.buf_ptr, self.org.stride, self.ref.buf_ptr, self.ref.stride, C.byref(t), self.bit_depth,
-                                                            tab[0], tab[1])))
+                        calls.append((cls, lane, None, lane.bound("vvhip_tu_rdo_multi", self.resi.buf_ptr, self.resi.stride, self.bit_depth, tab[0], tab[1])))
+                        continue
+                    tab = self.fjob_tables[cls]
+                    pre = None
+                    o_t, r_t, r_s = (self.org_tiled if self.tiled else None), (self.ref_tiled if self.tiled else None), (self.ref_shift if self.shifted else None)
+                    if derive and (self.tiled or self.shifted):
+                        o_t, r_t, r_s = self._lane_copies[cls]
+                        if cls == "HAD_fast":
+                            o_t, r_t = None, None                  # (the Hadamard lists do not read the tiled copies)
+                        if o_t is not None or r_t is not None or r_s is not None:
+                            pre = lane.bound("vvhip_planes_derive", self.org.storage.data_ptr(), self.org.stride, rows_o, o_t.data_ptr() if o_t is not None else None,
+                                             self.ref.storage.data_ptr(), self.ref.stride, rows_c, r_t.data_ptr() if r_t is not None else None, r_s.data_ptr() if r_s is not None else None)
+                    t = hp._TiledPlanes(o_t.data_ptr() if o_t is not None else None, r_t.data_ptr() if r_t is not None else None, self.org.pad, self.ref.pad,
+                                        r_s.data_ptr() + 2 * self.ref.origin if r_s is not None else None)
+                    self._tiled_struct.append(t)          # (kept alive: the bound call holds a pointer to it)
+                    calls.append((cls, lane, pre, lane.bound("vvhip_dist_multi_func_tiled", self.org.buf_ptr, self.org.stride, self.ref.buf_ptr, self.ref.stride, C.byref(t), self.bit_depth,
+                                                             tab[0], tab[1])))
                 self._lane_cache[ck] = calls
             self._lane_calls = self._lane_cache[ck]
             self._lane_key = key
         return self._lane_calls
 
-    def run_overlapped(self, streams, timers=None):
+    def run_overlapped(self, streams, timers=None, derive=False):
         """the same three launches, each on its own HIP stream (they are independent work lists): they share the device and successive steps pipeline per stream.
-        Every stream has its own context (HotPath.fork) and every launch is a pre-bound call, so a step costs the host three foreign calls and nothing else.
-        timers: per-class HIP events, recorded on the class's own stream"""
-        for cls, lane, call in self._lanes(streams):
+        Every stream has its own context (HotPath.fork) and every launch is a pre-bound call, so a step costs the host three (derive: five) foreign calls and nothing else.
+        timers: per-class HIP events, recorded on the class's own stream (around the class's launch, behind its derive launch)"""
+        for cls, lane, pre, call in self._lanes(streams, derive):
+            if pre is not None:
+                pre()
             if timers is not None and cls in timers.pool:
                 timers.start(cls, lane.stream)
                 call()
