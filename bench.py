@@ -414,7 +414,13 @@ def main():
         wl.enable_subpel()
 
     if args.inner:
+        # the launches of a step, serialized on one stream: the two derive launches of the picture's plane copies (as the lanes issue them) + the three list launches
+        sh2 = torch.empty_like(wl.ref.storage) if wl.shifted else None
         for _ in range(args.warmup + args.steps):
+            if (wl.tiled or wl.shifted) and not args.static_copies:
+                hp.planes_derive(wl.org, wl.ref, wl.org_tiled if wl.tiled else None, wl.ref_tiled if wl.tiled else None, wl.ref_shift if wl.shifted else None)
+                if wl.shifted:
+                    hp.planes_derive(wl.org, wl.ref, None, None, sh2)
             wl.run(None)
         mctf_stage(hp, wl, 4, reps=2)
         torch.cuda.synchronize()
