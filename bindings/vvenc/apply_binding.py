@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The VVenC side of the binding as an executable patch (PRODUCT: what a VVenC maintainer applies; INTEGRATION.md section 2 walks through it).
 
-Writes hook-enabled COPIES of ten reference translation units into an output directory (build output, git-ignored): the script inserts one-line calls to
+Writes hook-enabled COPIES of eleven reference translation units into an output directory (build output, git-ignored): the script inserts one-line calls to
 g_vvhipHooks (bindings/vvenc/vvenc_hip_binding.h) at anchor lines it looks up in the files where they lie under the reference tree — nothing of the reference is
 stored in this repository.  With every hook null the patched encoder is the unpatched one (bitstream tests).  Run-time selection: --SIMD=HIP[:mask]
 (VVEncImpl::setSIMDExtension, source/Lib/vvenc/vvencimpl.cpp:800-851).
@@ -40,6 +40,7 @@ patch("Quant.cpp", [
 patch("TrQuant.cpp", [
     ("after", '#include "TrQuant.h"', INC),
     ("before", "  TCoeff* block = m_blk;",
+     "  if( g_vvhipHooks.recTu && width > 1 && height > 1 ) g_vvhipHooks.recTu( &tu, ( int ) compID, resi.buf, ( long ) resi.stride, width, height, trTypeHor, trTypeVer, bitDepth );\n"
      "  if( g_vvhipHooks.fwd2D && width > 1 && height > 1 && !tu.cu->lfnstIdx &&\n"
      "      g_vvhipHooks.fwd2D( resi.buf, resi.stride, dstCoeff.buf, width, height, trTypeHor, trTypeVer, bitDepth ) ) return;\n"),
     ("before", "  TCoeff *block = m_blk;",
@@ -74,18 +75,20 @@ patch("InterPrediction.cpp", [
     ("before", "    DistParam distParam = m_pcRdCost->setDistParam( nullptr, nullptr, bilinearBufStride, bilinearBufStride, bd, COMP_Y, dx, dy, 1, true );",
      "    int16_t  hipMvd[2 * MAX_NUM_SUBCU_DMVR]; uint64_t hipCost[MAX_NUM_SUBCU_DMVR];\n"
      "    bool hipDmvr = false;\n"
-     "    if( g_vvhipHooks.dmvrSearch )\n"
+     "    if( g_vvhipHooks.dmvrSearch || g_vvhipHooks.recDmvrBegin )\n"
      "    {\n"
      "      const Picture* r0 = cu.slice->getRefPic( L0, cu.refIdx[L0] ); const Picture* r1 = cu.slice->getRefPic( L1, cu.refIdx[L1] );\n"
      "      const int s0 = r0->getRecoBufStride( COMP_Y ), s1 = r1->getRecoBufStride( COMP_Y );\n"
      "      const Pel* p0 = r0->getRecoBufPtr( COMP_Y ) + ( puPos.x + ( mergeMVL0.hor >> MV_FRACTIONAL_BITS_INTERNAL ) ) + ( puPos.y + ( mergeMVL0.ver >> MV_FRACTIONAL_BITS_INTERNAL ) ) * s0;\n"
      "      const Pel* p1 = r1->getRecoBufPtr( COMP_Y ) + ( puPos.x + ( mergeMVL1.hor >> MV_FRACTIONAL_BITS_INTERNAL ) ) + ( puPos.y + ( mergeMVL1.ver >> MV_FRACTIONAL_BITS_INTERNAL ) ) * s1;\n"
-     "      hipDmvr = g_vvhipHooks.dmvrSearch( p0, s0, mergeMVL0.hor & 15, mergeMVL0.ver & 15, p1, s1, mergeMVL1.hor & 15, mergeMVL1.ver & 15,\n"
+     "      if( g_vvhipHooks.recDmvrBegin ) g_vvhipHooks.recDmvrBegin( &cu, p0, s0, mergeMVL0.hor & 15, mergeMVL0.ver & 15, p1, s1, mergeMVL1.hor & 15, mergeMVL1.ver & 15, cu.lwidth(), cu.lheight(), dx, dy );\n"
+     "      hipDmvr = g_vvhipHooks.dmvrSearch && g_vvhipHooks.dmvrSearch( p0, s0, mergeMVL0.hor & 15, mergeMVL0.ver & 15, p1, s1, mergeMVL1.hor & 15, mergeMVL1.ver & 15,\n"
      "                                         cu.lwidth(), cu.lheight(), dx, dy, bd, hipMvd, hipCost );\n"
      "    }\n"),
     ("before", "        distParam.org.buf = addrL0;\n        distParam.cur.buf = addrL1;\n        minCost  = distParam.distFunc( distParam ) >> 1;",
      "        if( hipDmvr ) { cu.mvdL0SubPu[num] = Mv( hipMvd[2 * num], hipMvd[2 * num + 1] ); minCost = hipCost[num]; } else {\n"),
-    ("before", "        bioAppliedType[num] = ( minCost < bioEnabledThres ) ? false : bioApplied;", "        }\n"),
+    ("before", "        bioAppliedType[num] = ( minCost < bioEnabledThres ) ? false : bioApplied;",
+     "        }\n        if( g_vvhipHooks.recDmvrResult ) g_vvhipHooks.recDmvrResult( num, cu.mvdL0SubPu[num].hor, cu.mvdL0SubPu[num].ver, minCost );\n"),
 ])
 
 # batched call site: all sub-pel positions of one xPatternRefinement stage are scored by ONE device call up
@@ -98,12 +101,20 @@ patch("InterSearch.cpp", [
     ("replace", "  rcStruct.uiBestRound += 1;\n\n  if ( iDist == 1 )",
      "  rcStruct.uiBestRound += 1;\n  if( g_vvhipHooks.tzPrefetch ) g_vvhipHooks.tzPrefetch( &m_cDistParam, rcStruct.piRefY, rcStruct.iRefStride, iStartX, iStartY, iDist, bCheckCornersAtDist1, sr.left, sr.right, sr.top, sr.bottom );\n\n  if ( iDist == 1 )"),
     ("before", "  if( cu.cs->picture->useME )\n  {\n    switch ( m_motionEstimationSearchMethodSCC )", "  if( g_vvhipHooks.tzReset ) g_vvhipHooks.tzReset();\n"),
+    ("replace", "  cStruct.uiBestSad     = MAX_DISTORTION;\n\n\n  CodedCUInfo &relatedCU = m_modeCtrl->getBlkInfo( cu );",
+     "  cStruct.uiBestSad     = MAX_DISTORTION;\n"
+     "  if( g_vvhipHooks.recMeBegin ) g_vvhipHooks.recMeBegin( cu.lx(), cu.ly(), cu.lwidth(), cu.lheight(), ( int ) refPicList, iRefIdxPred, refPic->poc, bBi, pcPatternKey->buf, ( int ) pcPatternKey->stride, buf.buf, ( int ) buf.stride );\n\n"
+     "  CodedCUInfo &relatedCU = m_modeCtrl->getBlkInfo( cu );"),
+    ("before", "  DTRACE(g_trace_ctx, D_ME, \"   MECost<L%d,%d>: %6d (%d)  MV:%d,%d\\n\"", "  if( g_vvhipHooks.recMeEnd ) g_vvhipHooks.recMeEnd();\n"),
+    ("before", "  rcMvFrac = pcMvRefine[uiDirecBest];", "  if( g_vvhipHooks.recStageEnd ) g_vvhipHooks.recStageEnd();\n"),
     ("after", "  const Mv* pcMvRefine = (iFrac == 2 ? s_acMvRefineH : s_acMvRefineQ);\n",
+     "  if( g_vvhipHooks.recStageBegin ) g_vvhipHooks.recStageBegin( pattern->buf, baseRefMv.hor, baseRefMv.ver, iFrac, m_pcEncCfg->m_bUseHADME ? ( m_pcEncCfg->m_fastHad ? 2 : 1 ) : 0, reduceTap, useAltHpelIf );\n"
      "  uint64_t hipCost[9];\n"
      "  const bool hipOk = g_vvhipHooks.patternCosts && g_vvhipHooks.patternCosts( pcPatternKey, pattern, baseRefMv.hor, baseRefMv.ver, iFrac, pcMvRefine, clpRng.bd,\n"
      "                         m_pcEncCfg->m_bUseHADME ? ( m_pcEncCfg->m_fastHad ? 2 : 1 ) : 0, reduceTap, useAltHpelIf, hipCost );\n"),
     ("replace", "    m_cDistParam.cur.buf   = piRefPos;\n    uiDist = m_cDistParam.distFunc( m_cDistParam );\n",
-     "    m_cDistParam.cur.buf   = piRefPos;\n    uiDist = hipOk ? hipCost[i] : m_cDistParam.distFunc( m_cDistParam );\n"),
+     "    m_cDistParam.cur.buf   = piRefPos;\n    uiDist = hipOk ? hipCost[i] : m_cDistParam.distFunc( m_cDistParam );\n"
+     "    if( g_vvhipHooks.recStageCost ) g_vvhipHooks.recStageCost( ( int ) i, uiDist );\n"),
 ], sub="EncoderLib")
 
 # ALF statistics of a CTU: classification + covariance records from ONE hook call; the reference's own accumulators are
@@ -293,11 +304,18 @@ patch("EncAdaptiveLoopFilter.cpp", [
      "  }\n"),
 ], sub="EncoderLib")
 
+# the recorder learns where a block's compact copy of the original maps to (EncCu keeps one copy per partitioning depth, EncCu.cpp:556-567,1398-1407)
+patch("EncCu.cpp", [
+    ("after", '#include "EncCu.h"', INC),
+    ("before", "  m_modeCtrl.initBlk( tempCS->area, slice.pic->poc );", "  if( g_vvhipHooks.recCu ) g_vvhipHooks.recCu( tempCS );\n"),
+], sub="EncoderLib")
+
 # one picture <-> one device: a worker thread that starts a CTU task of a picture binds itself to that picture's GPU (several GPUs only)
 patch("EncSlice.cpp", [
     ("after", '#include "EncSlice.h"', INC),
     ("after", "  CtuEncParam* ctuEncParam       = static_cast<CtuEncParam*>( taskParam );\n  Picture* pic                   = ctuEncParam->pic;\n",
-     "  if( !checkReadyState && g_vvhipHooks.bindPicture ) g_vvhipHooks.bindPicture( pic->poc );\n"),
+     "  if( !checkReadyState && g_vvhipHooks.bindPicture ) g_vvhipHooks.bindPicture( pic->poc );\n"
+     "  if( !checkReadyState && g_vvhipHooks.recPicture ) g_vvhipHooks.recPicture( pic );\n"),
     # a CTU row of the reconstruction is final (borders extended): its luma rows go to the picture's device mirrors
     ("before", "          // for IFP lines synchro, do an additional increment signaling that CTU row is ready",
      "          if( g_vvhipHooks.reconRows )\n"

@@ -1,7 +1,8 @@
-// hip_hooks.cpp — TEST INFRASTRUCTURE.  Wires the reference encoder's kernel tables (in the hook-enabled build of oracle/ref/Makefile)
-// to the HIP back-end through the table-shaped C++ shim (vvenc_amd/csrc/host/vvenc_hip_shim.h): per-call trampolines for
-// RdCost::m_afpDistortFunc / m_afpDistortFuncX5, Quant::xQuant/xDeQuant/xNeedRdoq, MCTF::m_motionErrorLuma* / m_calcVar, the fused
-// 2-D transform entries in TrQuant::xT/xIT and the whole-picture MCTF motion estimation.  This is what INTEGRATION.md §2 describes.
+// vvenc_hip_binding.cpp — the VVenC side of the MI355X binding (PRODUCT; built into bindings/vvenc/_build/libvvenc_hip_enc.so by bindings/vvenc/Makefile).
+// Bodies of the hooks apply_binding.py inserts into the encoder (vvenc_hip_binding.h): they point the reference's kernel tables and picture-level stages at the
+// table-shaped C++ shim (vvenc_amd/csrc/host/vvenc_hip_shim.h) above the C ABI — per-call trampolines for RdCost::m_afpDistortFunc / m_afpDistortFuncX5,
+// Quant::xQuant / xDeQuant / xNeedRdoq, MCTF::m_motionErrorLuma* / m_calcVar, the fused 2-D transform entries of TrQuant::xT / xIT, the batched search sites, the
+// whole-picture MCTF and ALF stages, picture residency and the picture -> GPU mapping.  INTEGRATION.md section 2 walks through it.
 #include <cstdint>
 #include <cstring>
 #include <sstream>
@@ -49,6 +50,7 @@
 #undef protected
 
 #include "vvenc_hip_binding.h"
+#include "vvenc_hip_recorder.h"
 #include "../../vvenc_amd/csrc/host/vvenc_hip_shim.h"
 #include "EncoderLib/EncStage.h"
 
@@ -655,19 +657,27 @@ bool alfFilterPicture( const void* owner, int poc, const int16_t* const src[3], 
 //   1 RdCost tables   2 fused 2-D transforms (TrQuant::xT / xIT)   4 Quant cores   8 MCTF table entries   16 MCTF whole-picture motion estimation   32 g_tCoeffOps slots
 //   64 InterpolationFilter tables   128 MCTF bilateral filter   256 batched sub-pel refinement stages   512 DMVR refinement search per CU   1024 TZ diamond rounds
 //   2048 ALF statistics per CTU   4096 CC-ALF statistics per CTU   8192 ALF statistics per picture   16384 ALF filtering per CTU block   32768 CC-ALF filtering per CTU block
-//   65536 ALF filtering per picture
+//   65536 ALF filtering per picture   131072 work-list RECORDER (the encoder keeps its CPU kernels; vvenc_hip_recorder.h; needs no device)
 // VVENC_HIP_PRODUCTION: the stages that take whole pictures off the host (what --SIMD=HIP selects).
 static const int VVENC_HIP_PRODUCTION = 16 + 128 + 8192 + 65536;
+static const int VVENC_HIP_RECORD = 131072;
+void recInitRdCost( vvenc::RdCost* rc ) { vvrec::initRdCost( rc ); }
 
 extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_install( int mask )
 {
   g_slotMask = mask;
   try
   {
-    if( mask && !g_rd ) { g_rd = new vvhip::RdCost; g_rd->create( true ); g_q = new vvhip::QuantOps; g_m = new vvhip::MCTFOps; g_if = new vvhip::InterpolationFilter; }
+    if( ( mask & ~VVENC_HIP_RECORD ) && !g_rd ) { g_rd = new vvhip::RdCost; g_rd->create( true ); g_q = new vvhip::QuantOps; g_m = new vvhip::MCTFOps; g_if = new vvhip::InterpolationFilter; }
   }
   catch( const std::exception& e ) { fprintf( stderr, "vvenc_hip_install: %s\n", e.what() ); return -1; }
-  g_vvhipHooks.initRdCost = ( mask & 1 ) ? initRdCost : nullptr;
+  const bool rec = ( mask & VVENC_HIP_RECORD ) != 0;
+  if( rec && !vvrec::active() ) { fprintf( stderr, "vvenc_hip_install: the recorder needs $VVHIP_RECORD_DIR\n" ); return -1; }
+  g_vvhipHooks.initRdCost = rec ? recInitRdCost : ( mask & 1 ) ? initRdCost : nullptr;      // (the recorder wraps the CPU entries: it excludes the device table)
+  g_vvhipHooks.recPicture = rec ? vvrec::picture : nullptr; g_vvhipHooks.recCu = rec ? vvrec::cu : nullptr;
+  g_vvhipHooks.recMeBegin = rec ? vvrec::meBegin : nullptr; g_vvhipHooks.recMeEnd = rec ? vvrec::meEnd : nullptr;
+  g_vvhipHooks.recStageBegin = rec ? vvrec::stageBegin : nullptr; g_vvhipHooks.recStageCost = rec ? vvrec::stageCost : nullptr; g_vvhipHooks.recStageEnd = rec ? vvrec::stageEnd : nullptr;
+  g_vvhipHooks.recTu = rec ? vvrec::tu : nullptr; g_vvhipHooks.recDmvrBegin = rec ? vvrec::dmvrBegin : nullptr; g_vvhipHooks.recDmvrResult = rec ? vvrec::dmvrResult : nullptr;
   g_vvhipHooks.fwd2D      = ( mask & 2 ) ? fwd2D : nullptr;
   g_vvhipHooks.inv2D      = ( mask & 2 ) ? inv2D : nullptr;
   g_vvhipHooks.initQuant  = ( mask & 4 ) ? initQuant : nullptr;
@@ -675,7 +685,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_install( i
   g_vvhipHooks.mctfMe     = ( mask & 16 ) ? mctfMe : nullptr;
   g_vvhipHooks.mctfWants  = ( mask & 16 ) ? mctfWants : nullptr;
   g_vvhipHooks.mctfPrefetch = ( mask & 16 ) ? mctfPrefetch : nullptr;
-  g_vvhipHooks.bindPicture = mask ? bindPicture : nullptr;
+  g_vvhipHooks.bindPicture = ( mask & ~VVENC_HIP_RECORD ) ? bindPicture : nullptr;
   g_vvhipHooks.reconRows = ( mask & ( 256 | 1024 ) ) ? reconRows : nullptr;      // the search sites that address reference pictures in HBM
   g_vvhipHooks.initIF     = ( mask & 64 ) ? initIF : nullptr;
   g_vvhipHooks.mctfApply  = ( mask & 128 ) ? mctfApply : nullptr;
@@ -710,6 +720,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_select( co
 
 extern "C" __attribute__( ( visibility( "default" ) ) ) void vvenc_hip_release( void )
 {
+  if( g_vvhipHooks.recPicture ) vvrec::flush();                         // the recorder writes its lists when the encoder closes
   if( !g_rd ) return;                                                  // the binding was never installed: nothing lives on a device
   try
   {

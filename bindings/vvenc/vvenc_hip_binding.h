@@ -60,6 +60,20 @@ struct VvhipHooks
                               int ctuSize, const uint8_t* cls, const short* lumaCoeff, const short* lumaClip, int numLumaSets, const short* lumaCtuSet, const short* chromaCoeff,
                               const short* chromaClip, int numChromaSets, const short* const chromaCtuSet[2], int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, bool alreadyDoneOnly );
   bool ( *mctfMe )( vvenc::MCTF*, const vvenc::PelStorage& refPic, const vvenc::PelStorage& orig, vvenc::Array2D<vvenc::MotionVector>& mvs, bool addLevel, int refPoc, int curPoc );
+  // ---- work-list recorder (hook bit 131072, vvenc_hip_recorder.h): the encoder runs on its CPU kernels and every call of the hot path is written down with the operands' places
+  void ( *recPicture )( const void* picture );                      // a worker thread starts a CTU task of this Picture
+  void ( *recCu )( const void* codingStructure );                   // EncCu::xCompressCU starts on a block (where its compact copy of the original maps to)
+  void ( *recMeBegin )( int cuX, int cuY, int w, int h, int list, int refIdx, int refPoc, bool bi, const int16_t* pattern, int patternStride, const int16_t* refY, int refStride );
+  void ( *recMeEnd )();
+  void ( *recStageBegin )( const int16_t* patternRoi, int baseHor, int baseVer, int iFrac, int hadMode, int reduceTap, bool altHpel );
+  void ( *recStageCost )( int i, uint64_t dist );
+  void ( *recStageEnd )();
+  void ( *recTu )( const void* transformUnit, int comp, const int16_t* resi, long stride, int w, int h, int trHor, int trVer, int bitDepth );
+  void ( *recDmvrBegin )( const void* cu, const int16_t* ref0, int stride0, int fx0, int fy0, const int16_t* ref1, int stride1, int fx1, int fy1, int cuW, int cuH, int dx, int dy );
+  void ( *recDmvrResult )( int num, int mvdX, int mvdY, uint64_t minCost );
+  // ---- batched call sites of the residual loop and the merge pruning (hook bits 262144 / 524288)
+  // all merge candidates of a CU in one device call: predictions are compact w x h blocks, pitch = w * h samples from pred0 on; sad / satd may be null
+  bool ( *mergeCosts )( const int16_t* org, int orgStride, const int16_t* const* preds, const int* predStrides, int n, int w, int h, int bitDepth, int hadMode, uint64_t* costs );
 };
 extern VvhipHooks g_vvhipHooks;
 

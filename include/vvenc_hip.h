@@ -254,6 +254,9 @@ typedef struct
   vvhip_tu_stats*    d_stats;
 } vvhip_tu_job;
 VVHIP_API int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, int bit_depth, const vvhip_tu_job* jobs_host, int n_jobs );
+/* The same with a residual row pitch PER JOB (resi_strides_host[i] for jobs_host[i]): lists whose residual blocks are stored compactly, one after the other (pitch = width), as a
+ * caller that gathers the TUs of many CUs into one buffer has them — e.g. every TU InterSearch::xEstimateInterResidualQT tests for a picture (EncoderLib/InterSearch.cpp:3663-3714). */
+VVHIP_API int vvhip_tu_rdo_multi_strided( vvhip_ctx* ctx, const int16_t* d_resi, const int32_t* resi_strides_host, int bit_depth, const vvhip_tu_job* jobs_host, int n_jobs );
 
 /* ---- the g_tCoeffOps table slots one-to-one (CommonLib/TrQuant_EMT.h:63-91), device pointers, caller's matrix ------------------
  * vvhip_fast_fwd_core  <- fastFwdCore_2D/_1D[log2(tr_size)-2]  (TrQuant_EMT.cpp:1973-2000):
@@ -317,6 +320,44 @@ VVHIP_API int vvhip_subpel_dist_batch( vvhip_ctx* ctx, int func, const int16_t* 
 VVHIP_API int vvhip_subpel_refine_batch( vvhip_ctx* ctx, int func, const int16_t* d_org, int org_stride, const int16_t* d_ref, int ref_stride,
                                          int width, int height, int bit_depth, int filter_mode, int use_alt_hpel,
                                          const vvhip_subpel_item* d_bases, int n_blocks, const int16_t* offsets_host, int n_offsets, uint64_t* d_out );
+
+/* ======================================================================================================================
+ * Motion-search plans (round 3): what ONE picture's inter search pushes through the distortion tables, in ONE launch.
+ * Built for work lists with the shape the encoder really produces (recorded from it, vvenc_amd/recorded.py): per InterSearch::xMotionEstimation call
+ * (EncoderLib/InterSearch.cpp:1976-2130) ~20 integer candidates inside a few samples of each other (start points, 4-point diamond + square at distance 1,
+ * :2385-2410) followed by one or two xPatternRefinement stages (:760-880) of <= 9 sub-pel positions around the winner; blocks 4..64 square, most sample pairs in
+ * 64x64 blocks; plus merge / AMVP / intra / residual distortions on compact prediction blocks.
+ *   integer job  : the block's candidate positions as displacements from ref_off; the kernel stages the candidates' bounding window of the reference plane in
+ *                  LDS once (two copies, one sample apart: every dword of every displacement is aligned) and scores all candidates from it.
+ *                  cost[first_cand + i] = xGetSAD*( org block, ref block at (dx_i, dy_i) ) incl. the subShift rule (RdCost.cpp:301-644).
+ *   stage job    : position k (k = 0..8, evaluated when bit k of mask is set) lies ( refine[k] + (base_qx, base_qy) ) * i_frac quarter samples from the block at
+ *                  ref_off, refine = s_acMvRefineH (i_frac 2) / s_acMvRefineQ (i_frac 1) (InterSearch.cpp:67-91).  The kernel interpolates like
+ *                  xPatternRefinement's planes (filter_mode / alt_hpel as vvhip_interp_luma_batch; horizontal pass shared between positions) and scores each
+ *                  prediction against the original block directly from LDS — the predictions never exist in HBM.  cost[9 * stage + k] as the table entry
+ *                  `func` (VVHIP_DF_SAD / _HAD / _HAD_FAST) returns it; positions outside the mask are left untouched.
+ *   item         : one plain table call: func on (org block, cur block) of any two planes / pools of the plan's plane table.
+ * Offsets are in samples from sample (0,0) of the job's plane (negative = margin); planes must be readable 16 bytes beyond every block / window row they hold.
+ * Square blocks, width 4 (items only), 8, 16, 32 or 64; bit depths <= 10 (the packed Hadamard tile, like the reference's x86 rows).
+ * A plan owns device copies of the job tables and the schedule derived from them (which wave takes which jobs, heaviest first); running it is one launch.
+ * ====================================================================================================================== */
+typedef struct { const int16_t* d_base; int32_t stride; int32_t reserved; } vvhip_me_plane;
+typedef struct { int32_t org_off, ref_off; int16_t width, height; uint8_t org_plane, ref_plane, sub_shift, reserved; int16_t min_dx, min_dy, win_w, win_h; int32_t first_cand, n_cand; } vvhip_me_int_job;
+typedef struct { int16_t dx, dy; } vvhip_me_cand;
+typedef struct { int32_t org_off, ref_off; int16_t width, height; uint8_t org_plane, ref_plane, i_frac, filter_mode, alt_hpel, func; int8_t base_qx, base_qy; uint16_t mask; uint16_t reserved; } vvhip_me_stage_job;
+typedef struct { int32_t org_off, cur_off; uint8_t org_plane, cur_plane, func, sub_shift; int16_t width, height; } vvhip_me_item;
+typedef struct vvhip_me_plan vvhip_me_plan;
+/* all job arrays are HOST arrays (copied); any of the three lists may be empty.  win_* / min_* of an integer job may be left 0: the library derives the window from the candidates
+ * and splits jobs whose candidates spread further than max_window samples (0: default 24) into several windows. */
+VVHIP_API int  vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int n_int_jobs, const vvhip_me_cand* cands, int n_cands,
+                                     const vvhip_me_stage_job* stage_jobs, int n_stage_jobs, const vvhip_me_item* items, int n_items,
+                                     int bit_depth, int max_window, vvhip_me_plan** out );
+VVHIP_API void vvhip_me_plan_destroy( vvhip_ctx* ctx, vvhip_me_plan* plan );
+/* planes_host: the plan's plane table for THIS run (<= 16 entries; device pointers to sample (0,0)).  d_cand_cost: n_cands, d_stage_cost: 9 * n_stage_jobs,
+ * d_item_cost: n_items Distortion values; pointers of empty lists may be NULL.                                                                              */
+VVHIP_API int  vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes,
+                                  uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost );
+/* what the schedule looks like (for measurements): waves per list and LDS bytes per wave */
+VVHIP_API int  vvhip_me_plan_info( const vvhip_me_plan* plan, int* waves_int, int* waves_stage, int* waves_item, int* lds_bytes );
 
 /* ROM accessors (host memory out): the tables the kernels use, for parity checks against
  * g_trCore* (CommonLib/RomTr.cpp:364-449) and getScanOrder (CommonLib/Rom.h:104).               */

@@ -1,4 +1,5 @@
-"""helpers for the end-to-end bitstream tests: drive the reference encoder (compiled into oracle/_ref/) through its C API"""
+"""helpers for the end-to-end bitstream tests: drive the reference encoder through its C API — the plain build (oracle/_ref/libvvenc_ref.so, the CPU oracle) and
+the build WITH the MI355X binding (bindings/vvenc/_build/libvvenc_hip_enc.so, product; bindings/vvenc/Makefile)"""
 import ctypes as C
 import hashlib
 import os
@@ -7,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libvvenc_ref.so")
-REF_HIP_SO = os.path.join(ROOT, "oracle", "_ref", "libvvenc_ref_hip.so")
+REF_HIP_SO = os.path.join(ROOT, "bindings", "vvenc", "_build", "libvvenc_hip_enc.so")
 PRESET_FASTER, PRESET_FAST, PRESET_MEDIUM = 0, 1, 2   # vvencPresetMode (include/vvenc/vvencCfg.h)
 PRESETS = {"faster": 0, "fast": 1, "medium": 2}
 
@@ -31,6 +32,8 @@ def synth_yuv(width, height, frames, bit_depth, seed):
 
 def load(hip=False):
     L = C.CDLL(REF_HIP_SO if hip else REF_SO)
+    if hip:
+        L.vvref_encode_ex = L.vvenc_hip_encode          # (same argument list: bindings/vvenc/enc_driver.cpp)
     L.vvref_encode_ex.restype = C.c_long
     L.vvref_encode_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_char_p, C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_double)]

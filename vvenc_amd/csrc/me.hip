@@ -1,0 +1,731 @@
+// me.hip — motion-search plans: the distortion work of one picture's inter search in ONE launch (include/vvenc_hip.h, "Motion-search plans").
+//
+// Shaped by the work lists the reference encoder really produces (recorded from it: bindings/vvenc/vvenc_hip_recorder.*, vvenc_amd/recorded.py), not by uniform
+// synthetic ones: an InterSearch::xMotionEstimation call (EncoderLib/InterSearch.cpp:1976-2130) scores ~20 integer positions that lie within a few samples of each
+// other (start points, then the 4-point diamond and square at distance 1, :2385-2410; a third of them repeated), then one or two xPatternRefinement stages
+// (:760-880) of <= 9 sub-pel positions; two thirds of all sample pairs belong to 64x64 blocks.  Three kinds of work, one wave (= one workgroup) per unit:
+//   integer job   the bounding window of the job's candidates is staged ONCE in LDS (samples biased for v_sad_u16), the original block next to it; every candidate is then
+//                 scored from LDS by a team of lanes (dword reads at the even address below the candidate + v_alignbit for odd displacements): the L1 sees the window once
+//                 per job instead of once per candidate.                                                    xGetSAD*, CommonLib/RdCost.cpp:301-644
+//   stage bundle  a few refinement stages of one block size.  Per stage and 32-column strip: horizontal pass of the <= 3 distinct horizontal positions straight from
+//                 the plane into LDS (14-bit intermediates, InterpolationFilter.cpp:356-441), then one lane per (position, Hadamard tile): vertical pass out of LDS,
+//                 difference to the original block, 8x8 / 16x16_fast Hadamard in packed 16-bit registers — the prediction never exists in memory.
+//                                                                                                             xGetHADs<fast>, RdCost.cpp:1818-1938; tiles :1126-1322
+//   item bundle   plain table calls (merge / AMVP / intra candidates, residual SSE) on blocks of any two planes: lane teams on 8-sample row chunks (SAD, SSE) or one
+//                 Hadamard tile per lane.
+// Results are bit-exact with the reference's table entries (tests: recorded costs of the real encoder, and the per-function kernels of dist.hip / interp.hip).
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "common.h"
+
+struct vvhip_me_plan
+{
+  int bitDepth = 0, nCands = 0, nStages = 0, nItems = 0;
+  int wavesInt = 0, wavesStage = 0, wavesItem = 0, ldsBytes = 0;
+  void* d_blob = nullptr;                  // one allocation: every table below
+  const void* d_intJobs = nullptr; const void* d_cands = nullptr; const void* d_stageJobs = nullptr; const void* d_stageOrder = nullptr; const void* d_stageWaves = nullptr;
+  const void* d_items = nullptr; const void* d_itemOrder = nullptr; const void* d_itemWaves = nullptr;
+};
+
+namespace {
+
+typedef uint32_t u32x2 __attribute__( ( ext_vector_type( 2 ) ) );
+typedef uint32_t u32x4 __attribute__( ( ext_vector_type( 4 ) ) );
+typedef short s16x2 __attribute__( ( ext_vector_type( 2 ) ) );
+struct __attribute__( ( packed, aligned( 2 ) ) ) U8  { u32x2 v; };
+struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+__device__ __forceinline__ u32x2 ld8( const int16_t* p )  { return reinterpret_cast<const U8*>( p )->v; }
+__device__ __forceinline__ u32x4 ld16( const int16_t* p ) { return reinterpret_cast<const U16*>( p )->v; }
+__device__ __forceinline__ int lo16( uint32_t v ) { return ( int ) ( int16_t ) ( v & 0xffffu ); }
+__device__ __forceinline__ int hi16( uint32_t v ) { return ( int ) ( ( int32_t ) v >> 16 ); }
+__device__ __forceinline__ uint32_t pkAdd( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, a ) + __builtin_bit_cast( s16x2, b ) ); }
+__device__ __forceinline__ uint32_t pkSub( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, a ) - __builtin_bit_cast( s16x2, b ) ); }
+__device__ __forceinline__ uint32_t pack2( int lo, int hi ) { return ( ( uint32_t ) lo & 0xffffu ) | ( ( uint32_t ) hi << 16 ); }
+constexpr uint32_t BIAS = 0x80008000u;      // signed int16 pair -> unsigned order (v_sad_u16 on biased operands is |a - b| of the signed values)
+
+struct MePlanes { const int16_t* p[16]; int stride[16]; };
+
+// ---- plan-side job records (device) ------------------------------------------------------------------------------------------------------------
+struct IntJob   { int32_t orgOff, refOff; int16_t w, h; uint8_t orgPlane, refPlane, subShift, pad; int16_t minDx, minDy, winW, winH; int32_t firstCand, nCand; };   // one window
+struct PlanCand { int16_t dx, dy; int32_t outIndex; };
+struct WaveSpan { int32_t first, count; };                                                                                                               // into an order array
+struct MeArgs
+{
+  const IntJob* intJobs; const PlanCand* cands; int wavesInt;
+  const vvhip_me_stage_job* stageJobs; const int32_t* stageOrder; const WaveSpan* stageWaves; int wavesStage;
+  const vvhip_me_item* items; const int32_t* itemOrder; const WaveSpan* itemWaves; int wavesItem;
+  uint64_t* candCost; uint64_t* stageCost; uint64_t* itemCost;
+  int bitDepth;
+};
+
+// =================================================================================================================================================
+// Hadamard tiles on 64 differences held as 32 packed dwords (dword 4r + q = differences (r, 2q), (r, 2q + 1)); |difference| <= 2047 (bit depths <= 10, also for the
+// bi-prediction pattern 2 * org - pred).  Four packed butterfly stages, the fifth in 32 bits, the sixth never: |a + b| + |a - b| = 2 max( |a|, |b| ); the DC counts a quarter.
+// Returns the tile's sum of absolute coefficients BEFORE the per-tile normalisation.
+// =================================================================================================================================================
+__device__ __forceinline__ uint32_t hadamard64( uint32_t ( &d )[32] )
+{
+#pragma unroll
+  for( int len = 1; len < 16; len <<= 1 )
+#pragma unroll
+    for( int i = 0; i < 32; i += 2 * len )
+#pragma unroll
+      for( int j = i; j < i + len; j++ ) { const uint32_t a = d[j], b = d[j + len]; d[j] = pkAdd( a, b ); d[j + len] = pkSub( a, b ); }
+  uint32_t m = 0, dcTerm = 0;
+#pragma unroll
+  for( int j = 0; j < 16; j++ )
+  {
+    const int al = lo16( d[j] ), ah = hi16( d[j] ), bl = lo16( d[j + 16] ), bh = hi16( d[j + 16] );
+    const int pl = al + bl, ph = ah + bh, ml = al - bl, mh = ah - bh;
+    const uint32_t aml = ( uint32_t ) abs( ml ), amh = ( uint32_t ) abs( mh );
+    m += aml > amh ? aml : amh;
+    if( j == 0 ) { const uint32_t dc = ( uint32_t ) abs( pl + ph ); dcTerm = ( uint32_t ) abs( pl - ph ) + ( dc >> 2 ); }
+    else { const uint32_t apl = ( uint32_t ) abs( pl ), aph = ( uint32_t ) abs( ph ); m += apl > aph ? apl : aph; }
+  }
+  return 2 * m + dcTerm;
+}
+
+// rounded 2x2 averages of two rows of 16 samples (4 + 4 dwords each) -> 8 values as 4 packed dwords, signed inputs (xCalcHADs16x16_fast, RdCost.cpp:1126-1160)
+__device__ __forceinline__ void avg2x2( const uint32_t ( &a )[8], const uint32_t ( &b )[8], uint32_t ( &o )[4] )
+{
+#pragma unroll
+  for( int i = 0; i < 4; i++ )
+  {
+    const uint32_t t0 = pkAdd( a[2 * i], b[2 * i] ), t1 = pkAdd( a[2 * i + 1], b[2 * i + 1] );
+    const uint32_t lo = __builtin_amdgcn_perm( t1, t0, 0x05040100u ), hi = __builtin_amdgcn_perm( t1, t0, 0x07060302u );      // (t0.lo, t1.lo), (t0.hi, t1.hi)
+    const uint32_t s = pkAdd( pkAdd( lo, hi ), 0x00020002u );
+    o[i] = __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, s ) >> 2 );
+  }
+}
+
+// 4x4 Hadamard of 16 differences (xCalcHADs4x4, RdCost.cpp:1028-1124): sum of |coefficients| with the DC a quarter, then ( satd + 1 ) >> 1
+__device__ __forceinline__ uint32_t hadamard4x4( int ( &d )[16] )
+{
+#pragma unroll
+  for( int r = 0; r < 4; r++ )
+  {
+    const int a = d[4 * r], b = d[4 * r + 1], c = d[4 * r + 2], e = d[4 * r + 3];
+    const int s0 = a + b, s1 = a - b, s2 = c + e, s3 = c - e;
+    d[4 * r] = s0 + s2; d[4 * r + 1] = s1 + s3; d[4 * r + 2] = s0 - s2; d[4 * r + 3] = s1 - s3;
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for( int c = 0; c < 4; c++ )
+  {
+    const int a = d[c], b = d[4 + c], e = d[8 + c], f = d[12 + c];
+    const int s0 = a + b, s1 = a - b, s2 = e + f, s3 = e - f;
+    const int v0 = s0 + s2, v1 = s1 + s3, v2 = s0 - s2, v3 = s1 - s3;
+    s += ( c == 0 ? ( ( uint32_t ) abs( v0 ) >> 2 ) : ( uint32_t ) abs( v0 ) ) + ( uint32_t ) abs( v1 ) + ( uint32_t ) abs( v2 ) + ( uint32_t ) abs( v3 );
+  }
+  return ( s + 1 ) >> 1;
+}
+
+// =================================================================================================================================================
+// (A) integer candidates of one window
+// =================================================================================================================================================
+__device__ __forceinline__ int winPitch( int winW ) { int p = ( winW + 2 + 7 ) & ~7; if( !( ( p >> 3 ) & 1 ) ) p += 8; return p; }      // an odd number of 16-byte chunks per row
+
+__device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int wave, int16_t* lds )
+{
+  const IntJob j = a.intJobs[wave];
+  const int lane = threadIdx.x;
+  const int w = j.w, ss = j.subShift, rowsEff = j.h >> ss, lpr = w >> 3;
+  const int pitch = winPitch( j.winW );
+  int16_t* win = lds;
+  int16_t* orgL = lds + j.winH * pitch;                              // rowsEff x w, compact (16-byte rows)
+  {
+    const int16_t* ref = P.p[j.refPlane] + j.refOff + ( ptrdiff_t ) j.minDy * P.stride[j.refPlane] + j.minDx;
+    const int cpr = pitch >> 3, n = j.winH * cpr, rs = P.stride[j.refPlane];
+    for( int i = lane; i < n; i += 64 )
+    {
+      const int r = i / cpr, c = i - r * cpr;
+      u32x4 v = ld16( ref + ( ptrdiff_t ) r * rs + c * 8 );
+      v.x ^= BIAS; v.y ^= BIAS; v.z ^= BIAS; v.w ^= BIAS;
+      *reinterpret_cast<u32x4*>( win + r * pitch + c * 8 ) = v;
+    }
+    const int16_t* org = P.p[j.orgPlane] + j.orgOff;
+    const int os = P.stride[j.orgPlane], m = rowsEff * lpr;
+    for( int i = lane; i < m; i += 64 )
+    {
+      const int r = i / lpr, c = i - r * lpr;
+      u32x4 v = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 );
+      v.x ^= BIAS; v.y ^= BIAS; v.z ^= BIAS; v.w ^= BIAS;
+      *reinterpret_cast<u32x4*>( orgL + r * w + c * 8 ) = v;
+    }
+  }
+  __syncthreads();
+  const int chunks = rowsEff * lpr;
+  int lpc = 64; while( lpc > chunks ) lpc >>= 1;                     // lanes per candidate: a power of two <= min( 64, chunks )   (chunks is a power of two for square blocks)
+  const int teams = 64 / lpc, lt = lane & ( lpc - 1 ), team = lane / lpc;
+  const int lprShift = 31 - __builtin_clz( lpr );
+  for( int c0 = 0; c0 < j.nCand; c0 += teams )
+  {
+    const int ci = c0 + team;
+    const bool valid = ci < j.nCand;
+    const PlanCand cd = a.cands[j.firstCand + ( valid ? ci : 0 )];
+    const int x = cd.dx - j.minDx, y = cd.dy - j.minDy;
+    const int16_t* base = win + y * pitch + ( x & ~1 );
+    const uint32_t sh = ( x & 1 ) * 16;
+    uint32_t sad = 0;
+    for( int c = lt; c < chunks; c += lpc )
+    {
+      const int r = c >> lprShift, s = c & ( lpr - 1 );
+      const uint32_t* pc = reinterpret_cast<const uint32_t*>( base + ( r << ss ) * pitch + s * 8 );
+      const u32x4 o = *reinterpret_cast<const u32x4*>( orgL + r * w + s * 8 );
+      const uint32_t v0 = pc[0], v1 = pc[1], v2 = pc[2], v3 = pc[3], v4 = pc[4];
+      sad = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( v1, v0, sh ), o.x, sad );
+      sad = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( v2, v1, sh ), o.y, sad );
+      sad = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( v3, v2, sh ), o.z, sad );
+      sad = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( v4, v3, sh ), o.w, sad );
+    }
+    const uint32_t t = vvhipGroupSum32( sad, lpc, lane );
+    if( valid && lt == 0 ) a.candCost[cd.outIndex] = ( uint64_t ) t << ss;       // RdCost.cpp:334
+  }
+}
+
+// =================================================================================================================================================
+// (B) sub-pel refinement stages
+// =================================================================================================================================================
+__constant__ int8_t kLuma8[9][8] = {
+  { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 63, 4, -2, 1, 0 }, { -1, 2, -5, 62, 8, -3, 1, 0 }, { -1, 3, -8, 60, 13, -4, 1, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+  { -1, 4, -11, 52, 26, -8, 3, -1 }, { -1, 3, -9, 47, 31, -10, 4, -1 }, { -1, 4, -11, 45, 34, -10, 4, -1 }, { -1, 4, -11, 40, 40, -11, 4, -1 } };
+__constant__ int8_t kLuma6[9][8] = {
+  { 0, 0, 0, 64, 0, 0, 0, 0 }, { 0, 1, -3, 63, 4, -2, 1, 0 }, { 0, 1, -5, 62, 8, -3, 1, 0 }, { 0, 2, -8, 60, 13, -4, 1, 0 }, { 0, 3, -10, 58, 17, -5, 1, 0 },
+  { 0, 3, -11, 52, 26, -8, 2, 0 }, { 0, 2, -9, 47, 31, -10, 3, 0 }, { 0, 3, -11, 45, 34, -10, 3, 0 }, { 0, 3, -11, 40, 40, -11, 3, 0 } };
+__constant__ int8_t kAltHpel[8] = { 0, 3, 9, 20, 20, 9, 3, 0 };
+__constant__ int8_t kChroma4[17][4] = {
+  { 0, 64, 0, 0 }, { -1, 63, 2, 0 }, { -2, 62, 4, 0 }, { -2, 60, 7, -1 }, { -2, 58, 10, -2 }, { -3, 57, 12, -2 }, { -4, 56, 14, -2 }, { -4, 55, 15, -2 }, { -4, 54, 16, -2 },
+  { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 }, { -6, 46, 28, -4 }, { -5, 44, 29, -4 }, { -4, 42, 30, -4 }, { -4, 39, 33, -4 }, { -4, 36, 36, -4 } };
+__constant__ int8_t kRefineH[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };      // InterSearch.cpp:67-78
+__constant__ int8_t kRefineQ[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } };      // :80-91
+
+// the 8 window taps (entry k multiplies the sample at offset k - 3) of phase `frac` (1/16 sample) in the tap set the stage's search uses:
+// filter_mode 0 = 8 taps, 1 = 6 taps, 2 = the 4 chroma taps at twice the phase (m_meReduceTap, InterpolationFilter.cpp:586-593); alt half-pel at phase 8
+__device__ __forceinline__ void stageTaps( int frac, int filterMode, int altHpel, int ( &c )[8] )
+{
+#pragma unroll
+  for( int k = 0; k < 8; k++ ) c[k] = 0;
+  if( altHpel && frac == 8 ) {
+#pragma unroll
+    for( int k = 0; k < 8; k++ ) c[k] = kAltHpel[k];
+    return; }
+  if( filterMode == 2 )
+  {
+    const int ph = frac << 1;
+#pragma unroll
+    for( int k = 0; k < 4; k++ ) c[2 + k] = ph <= 16 ? kChroma4[ph][k] : kChroma4[32 - ph][3 - k];
+    return;
+  }
+  const int p = frac <= 8 ? frac : 16 - frac;
+#pragma unroll
+  for( int k = 0; k < 8; k++ ) { const int kk = frac <= 8 ? k : 7 - k; c[k] = filterMode == 0 ? kLuma8[p][kk] : kLuma6[p][kk]; }
+}
+
+// position k of a stage -> displacement in 1/16 sample from the stage's integer base: ( refine[k] + base ) * iFrac quarter samples
+__device__ __forceinline__ void stagePos( const vvhip_me_stage_job& j, int k, int& tx, int& ty )
+{
+  const int rx = j.i_frac == 2 ? kRefineH[k][0] : kRefineQ[k][0], ry = j.i_frac == 2 ? kRefineH[k][1] : kRefineQ[k][1];
+  tx = ( rx + j.base_qx ) * j.i_frac * 4; ty = ( ry + j.base_qy ) * j.i_frac * 4;
+}
+
+// 8 predicted samples (row y, columns x0 .. x0 + 7 of the strip) of a position: vertical pass over the first-pass rows in LDS, last pass (clip)
+__device__ __forceinline__ void predRow8( const int16_t* tmpV /* variant, strip-local */, int tw, int y, int x0, int sy, const int ( &cv )[8], bool copyV, int shift1, int maxv, int rnd2, int shift2, uint32_t ( &o )[4] )
+{
+  int acc[8];
+  if( copyV )
+  {
+    // zero vertical phase: filterCopy<false,true> of the first-pass sample (InterpolationFilter.cpp:309-322)
+    const u32x4 r = *reinterpret_cast<const u32x4*>( tmpV + ( y + sy + 4 ) * tw + x0 );
+    const uint32_t rr[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+    for( int i = 0; i < 4; i++ ) { acc[2 * i] = ( lo16( rr[i] ) + ( int ) ( int16_t ) ( ( 1 << ( shift1 - 1 ) ) + 8192 ) ) >> shift1; acc[2 * i + 1] = ( hi16( rr[i] ) + ( int ) ( int16_t ) ( ( 1 << ( shift1 - 1 ) ) + 8192 ) ) >> shift1; }
+  }
+  else
+  {
+#pragma unroll
+    for( int i = 0; i < 8; i++ ) acc[i] = rnd2;
+#pragma unroll
+    for( int k = 0; k < 8; k++ )
+    {
+      if( cv[k] == 0 ) continue;                                       // (wave-divergent only between positions with different phases; rows outside the tap support are never read)
+      const u32x4 r = *reinterpret_cast<const u32x4*>( tmpV + ( y + sy + 1 + k ) * tw + x0 );
+      const uint32_t rr[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+      for( int i = 0; i < 4; i++ ) { acc[2 * i] = __mul24( lo16( rr[i] ), cv[k] ) + acc[2 * i]; acc[2 * i + 1] = __mul24( hi16( rr[i] ), cv[k] ) + acc[2 * i + 1]; }
+    }
+#pragma unroll
+    for( int i = 0; i < 8; i++ ) acc[i] = ( int ) ( int16_t ) ( acc[i] >> shift2 );          // Pel val (InterpolationFilter.cpp:433)
+  }
+#pragma unroll
+  for( int i = 0; i < 4; i++ )
+  {
+    const int a0 = acc[2 * i] < 0 ? 0 : ( acc[2 * i] > maxv ? maxv : acc[2 * i] ), a1 = acc[2 * i + 1] < 0 ? 0 : ( acc[2 * i + 1] > maxv ? maxv : acc[2 * i + 1] );
+    o[i] = pack2( a0, a1 );
+  }
+}
+
+__device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, int wave, int16_t* lds )
+{
+  const WaveSpan span = a.stageWaves[wave];
+  const int lane = threadIdx.x, bd = a.bitDepth;
+  const int headRoom = 14 - bd > 2 ? 14 - bd : 2, maxv = ( 1 << bd ) - 1;
+  const int shift1 = 6 - headRoom, off1 = -( 8192 << shift1 );                       // first (not last) pass: InterpolationFilter.cpp:401-408
+  const int shift2 = 6 + headRoom, rnd2 = ( 1 << ( shift2 - 1 ) ) + ( 8192 << 6 );   // second and last pass: :394-400
+  uint32_t* costL = reinterpret_cast<uint32_t*>( lds );                              // [stage in bundle][9] running sums
+  int16_t* tmp = lds + 2 * 9 * span.count + ( ( 2 * 9 * span.count ) & 7 ? 8 - ( ( 2 * 9 * span.count ) & 7 ) : 0 );
+  for( int i = lane; i < 9 * span.count; i += 64 ) costL[i] = 0;
+
+  for( int si = 0; si < span.count; si++ )
+  {
+    const int stage = a.stageOrder[span.first + si];
+    const vvhip_me_stage_job j = a.stageJobs[stage];
+    const int w = j.width, h = j.height, rows = h + 8;
+    const int16_t* ref = P.p[j.ref_plane] + j.ref_off;
+    const int rs = P.stride[j.ref_plane];
+    const int16_t* org = P.p[j.org_plane] + j.org_off;
+    const int os = P.stride[j.org_plane];
+    // the distinct horizontal displacements of the evaluated positions (<= 3: the refinement offsets are -1, 0, 1): one first pass each, shared like the reference's planes
+    int hx0 = 0, hx1 = 0, hx2 = 0, nHor = 0;
+    for( int k = 0; k < 9; k++ )
+    {
+      if( !( ( j.mask >> k ) & 1 ) ) continue;
+      int tx, ty; stagePos( j, k, tx, ty );
+      if( ( nHor > 0 && tx == hx0 ) || ( nHor > 1 && tx == hx1 ) || ( nHor > 2 && tx == hx2 ) ) continue;
+      if( nHor == 0 ) hx0 = tx; else if( nHor == 1 ) hx1 = tx; else hx2 = tx;
+      nHor++;
+    }
+    const bool fast16 = j.func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
+    const int tile = fast16 ? 16 : 8;
+    for( int col0 = 0; col0 < w; col0 += 32 )
+    {
+      const int tw = w - col0 < 32 ? w - col0 : 32, tw8 = tw >> 3;                   // strip width (8, 16 or 32)
+      __syncthreads();                                                             // the previous strip's readers are done with tmp
+      // ---- horizontal pass: tmp[v][r][x] <-> plane row r - 4, column col0 + x + sx[v]   (first pass, 14-bit intermediates)
+      for( int i = lane; i < nHor * rows * tw8; i += 64 )
+      {
+        const int v = i / ( rows * tw8 ), rem = i - v * rows * tw8, r = rem / tw8, x0 = ( rem - r * tw8 ) << 3;
+        const int txv = v == 0 ? hx0 : ( v == 1 ? hx1 : hx2 ), sxv = txv >> 4, fxv = txv & 15;
+        const int16_t* p = ref + ( ptrdiff_t ) ( r - 4 ) * rs + col0 + x0 + sxv;
+        uint32_t o[4];
+        if( fxv )
+        {
+          int ch[8]; stageTaps( fxv, j.filter_mode, j.alt_hpel, ch );
+          const u32x4 A = ld16( p - 3 ), B = ld16( p + 4 );                          // samples -3 .. 4 and 4 .. 11
+          const uint32_t aw[4] = { A.x, A.y, A.z, A.w }, bw[4] = { B.x, B.y, B.z, B.w };
+          int win[15];
+#pragma unroll
+          for( int q = 0; q < 4; q++ ) { win[2 * q] = lo16( aw[q] ); win[2 * q + 1] = hi16( aw[q] ); }
+#pragma unroll
+          for( int q = 0; q < 4; q++ ) { if( q ) win[7 + 2 * q] = lo16( bw[q] ); if( 8 + 2 * q < 15 ) win[8 + 2 * q] = hi16( bw[q] ); }
+          int acc[8];
+#pragma unroll
+          for( int x = 0; x < 8; x++ )
+          {
+            int s = off1;
+#pragma unroll
+            for( int k = 0; k < 8; k++ ) s = __mul24( win[x + k], ch[k] ) + s;
+            acc[x] = ( int ) ( int16_t ) ( s >> shift1 );
+          }
+#pragma unroll
+          for( int q = 0; q < 4; q++ ) o[q] = pack2( acc[2 * q], acc[2 * q + 1] );
+        }
+        else
+        {
+          const u32x4 A = ld16( p );                                                 // filterCopy<true,false>: ( sample << headRoom ) - 8192 (InterpolationFilter.cpp:285-296)
+          const uint32_t aw[4] = { A.x, A.y, A.z, A.w };
+#pragma unroll
+          for( int q = 0; q < 4; q++ ) o[q] = pack2( ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) lo16( aw[q] ) << headRoom ) - 8192 ), ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) hi16( aw[q] ) << headRoom ) - 8192 ) );
+        }
+        u32x4 ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        *reinterpret_cast<u32x4*>( tmp + ( v * rows + r ) * tw + x0 ) = ov;
+      }
+      __syncthreads();
+      // ---- one lane per (position, tile of this strip)
+      const int tilesX = tw / tile, tilesY = h / tile, tilesPerPos = tilesX * tilesY;
+      for( int task = lane; task < 9 * tilesPerPos; task += 64 )
+      {
+        const int k = task / tilesPerPos, t = task - k * tilesPerPos;
+        if( !( ( j.mask >> k ) & 1 ) ) continue;
+        const int tyi = t / tilesX, txi = t - tyi * tilesX;
+        int txk, tyk; stagePos( j, k, txk, tyk );
+        const int hv = txk == hx0 ? 0 : ( txk == hx1 ? 1 : 2 ), syk = tyk >> 4, fyk = tyk & 15;
+        const int16_t* tmpV = tmp + hv * rows * tw;
+        int cv[8]; stageTaps( fyk, j.filter_mode, j.alt_hpel, cv );
+        const bool copyV = fyk == 0;
+        const int x0 = txi * tile, y0 = tyi * tile;
+        const int16_t* po = org + ( ptrdiff_t ) y0 * os + col0 + x0;
+        uint32_t val;
+        if( j.func == VVHIP_DF_SAD )
+        {
+          uint32_t sad = 0;
+#pragma unroll
+          for( int r = 0; r < 8; r++ )
+          {
+            uint32_t pr[4]; predRow8( tmpV, tw, y0 + r, x0, syk, cv, copyV, headRoom, maxv, rnd2, shift2, pr );
+            const u32x4 o = ld16( po + ( ptrdiff_t ) r * os );
+            sad = __builtin_amdgcn_sad_u16( o.x ^ BIAS, pr[0] ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( o.y ^ BIAS, pr[1] ^ BIAS, sad );
+            sad = __builtin_amdgcn_sad_u16( o.z ^ BIAS, pr[2] ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( o.w ^ BIAS, pr[3] ^ BIAS, sad );
+          }
+          val = sad;
+        }
+        else if( fast16 )
+        {
+          uint32_t d[32];
+#pragma unroll
+          for( int r = 0; r < 8; r++ )
+          {
+            uint32_t pa[8], pb[8], oa[8], ob[8], ap[4], ao[4];
+            { uint32_t q[4]; predRow8( tmpV, tw, y0 + 2 * r, x0, syk, cv, copyV, headRoom, maxv, rnd2, shift2, q ); pa[0] = q[0]; pa[1] = q[1]; pa[2] = q[2]; pa[3] = q[3];
+              predRow8( tmpV, tw, y0 + 2 * r, x0 + 8, syk, cv, copyV, headRoom, maxv, rnd2, shift2, q ); pa[4] = q[0]; pa[5] = q[1]; pa[6] = q[2]; pa[7] = q[3];
+              predRow8( tmpV, tw, y0 + 2 * r + 1, x0, syk, cv, copyV, headRoom, maxv, rnd2, shift2, q ); pb[0] = q[0]; pb[1] = q[1]; pb[2] = q[2]; pb[3] = q[3];
+              predRow8( tmpV, tw, y0 + 2 * r + 1, x0 + 8, syk, cv, copyV, headRoom, maxv, rnd2, shift2, q ); pb[4] = q[0]; pb[5] = q[1]; pb[6] = q[2]; pb[7] = q[3]; }
+            { const int16_t* p0 = po + ( ptrdiff_t ) ( 2 * r ) * os; const u32x4 x0v = ld16( p0 ), x1v = ld16( p0 + 8 ), y0v = ld16( p0 + os ), y1v = ld16( p0 + os + 8 );
+              oa[0] = x0v.x; oa[1] = x0v.y; oa[2] = x0v.z; oa[3] = x0v.w; oa[4] = x1v.x; oa[5] = x1v.y; oa[6] = x1v.z; oa[7] = x1v.w;
+              ob[0] = y0v.x; ob[1] = y0v.y; ob[2] = y0v.z; ob[3] = y0v.w; ob[4] = y1v.x; ob[5] = y1v.y; ob[6] = y1v.z; ob[7] = y1v.w; }
+            avg2x2( pa, pb, ap ); avg2x2( oa, ob, ao );
+#pragma unroll
+            for( int q = 0; q < 4; q++ ) d[4 * r + q] = pkSub( ao[q], ap[q] );
+          }
+          const uint32_t s = hadamard64( d );
+          val = ( ( s + 2 ) >> 2 ) << 2;                                             // RdCost.cpp:1218-1222
+        }
+        else
+        {
+          uint32_t d[32];
+#pragma unroll
+          for( int r = 0; r < 8; r++ )
+          {
+            uint32_t pr[4]; predRow8( tmpV, tw, y0 + r, x0, syk, cv, copyV, headRoom, maxv, rnd2, shift2, pr );
+            const u32x4 o = ld16( po + ( ptrdiff_t ) r * os );
+            d[4 * r] = pkSub( o.x, pr[0] ); d[4 * r + 1] = pkSub( o.y, pr[1] ); d[4 * r + 2] = pkSub( o.z, pr[2] ); d[4 * r + 3] = pkSub( o.w, pr[3] );
+          }
+          const uint32_t s = hadamard64( d );
+          val = ( s + 2 ) >> 2;                                                      // RdCost.cpp:1317-1319
+        }
+        atomicAdd( &costL[9 * si + k], val );
+      }
+    }
+  }
+  __syncthreads();
+  for( int i = lane; i < 9 * span.count; i += 64 )
+  {
+    const int si = i / 9, k = i - 9 * si;
+    const int stage = a.stageOrder[span.first + si];
+    if( ( a.stageJobs[stage].mask >> k ) & 1 ) a.stageCost[( size_t ) 9 * stage + k] = costL[i];
+  }
+}
+
+// =================================================================================================================================================
+// (C) plain table calls on blocks of any two planes
+// =================================================================================================================================================
+__device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, int wave )
+{
+  const WaveSpan span = a.itemWaves[wave];
+  const int lane = threadIdx.x;
+  const vvhip_me_item first = a.items[a.itemOrder[span.first]];                     // every item of the span has this function and geometry
+  const int w = first.width, h = first.height, func = first.func, ss = func == VVHIP_DF_SAD ? first.sub_shift : 0;
+  if( func == VVHIP_DF_SAD || func == VVHIP_DF_SSE )
+  {
+    const int cw = w >= 8 ? 8 : 4, lpr = w / cw, rowsEff = h >> ss, chunks = rowsEff * lpr;
+    int lpc = 64; while( lpc > chunks ) lpc >>= 1;
+    const int teams = 64 / lpc, lt = lane & ( lpc - 1 ), team = lane / lpc;
+    for( int i0 = 0; i0 < span.count; i0 += teams )
+    {
+      const int ii = i0 + team;
+      const bool valid = ii < span.count;
+      const int idx = a.itemOrder[span.first + ( valid ? ii : 0 )];
+      const vvhip_me_item it = a.items[idx];
+      const int16_t* po = P.p[it.org_plane] + it.org_off; const int os = P.stride[it.org_plane];
+      const int16_t* pc = P.p[it.cur_plane] + it.cur_off; const int cs = P.stride[it.cur_plane];
+      uint32_t sad = 0; uint64_t sse = 0;
+      for( int c = lt; c < chunks; c += lpc )
+      {
+        const int r = c / lpr, s = c - r * lpr;
+        const int16_t* pa = po + ( ptrdiff_t ) ( r << ss ) * os + s * cw;
+        const int16_t* pb = pc + ( ptrdiff_t ) ( r << ss ) * cs + s * cw;
+        uint32_t va[4], vb[4];
+        if( cw == 8 ) { const u32x4 x = ld16( pa ), z = ld16( pb ); va[0] = x.x; va[1] = x.y; va[2] = x.z; va[3] = x.w; vb[0] = z.x; vb[1] = z.y; vb[2] = z.z; vb[3] = z.w; }
+        else { const u32x2 x = ld8( pa ), z = ld8( pb ); va[0] = x.x; va[1] = x.y; va[2] = va[3] = 0; vb[0] = z.x; vb[1] = z.y; vb[2] = vb[3] = 0; }
+#pragma unroll
+        for( int q = 0; q < 4; q++ )
+        {
+          if( func == VVHIP_DF_SAD ) sad = __builtin_amdgcn_sad_u16( va[q] ^ BIAS, vb[q] ^ BIAS, sad );
+          else { const int d0 = lo16( va[q] ) - lo16( vb[q] ), d1 = hi16( va[q] ) - hi16( vb[q] ); sse += ( uint64_t ) ( ( int64_t ) d0 * d0 ) + ( uint64_t ) ( ( int64_t ) d1 * d1 ); }
+        }
+      }
+      if( func == VVHIP_DF_SAD ) { const uint32_t t = vvhipGroupSum32( sad, lpc, lane ); if( valid && lt == 0 ) a.itemCost[idx] = ( uint64_t ) t << ss; }
+      else { const uint64_t t = vvhipGroupSum64( sse, lpc, lane ); if( valid && lt == 0 ) a.itemCost[idx] = t; }
+    }
+    return;
+  }
+  // Hadamard family: one tile per lane.  HAD_fast on 32 / 64: 16x16_fast tiles; width 4: the 4x4 tile; else 8x8 tiles.  HAD_2SAD = min( HAD, 2 SAD ) (RdCost.cpp:1768-1816).
+  const bool fast16 = func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
+  const int tile = w == 4 ? 4 : ( fast16 ? 16 : 8 ), tilesX = w / tile, tiles = tilesX * ( h / tile );
+  int lpc = 64; while( lpc > tiles ) lpc >>= 1;
+  const int teams = 64 / lpc, lt = lane & ( lpc - 1 ), team = lane / lpc;
+  for( int i0 = 0; i0 < span.count; i0 += teams )
+  {
+    const int ii = i0 + team;
+    const bool valid = ii < span.count;
+    const int idx = a.itemOrder[span.first + ( valid ? ii : 0 )];
+    const vvhip_me_item it = a.items[idx];
+    const int16_t* po = P.p[it.org_plane] + it.org_off; const int os = P.stride[it.org_plane];
+    const int16_t* pc = P.p[it.cur_plane] + it.cur_off; const int cs = P.stride[it.cur_plane];
+    uint32_t sum = 0, sad = 0;
+    for( int t = lt; t < tiles; t += lpc )
+    {
+      const int tyi = t / tilesX, txi = t - tyi * tilesX;
+      const int16_t* qa = po + ( ptrdiff_t ) ( tyi * tile ) * os + txi * tile;
+      const int16_t* qb = pc + ( ptrdiff_t ) ( tyi * tile ) * cs + txi * tile;
+      if( tile == 4 )
+      {
+        int d[16];
+#pragma unroll
+        for( int r = 0; r < 4; r++ )
+        {
+          const u32x2 x = ld8( qa + ( ptrdiff_t ) r * os ), z = ld8( qb + ( ptrdiff_t ) r * cs );
+          d[4 * r] = lo16( x.x ) - lo16( z.x ); d[4 * r + 1] = hi16( x.x ) - hi16( z.x ); d[4 * r + 2] = lo16( x.y ) - lo16( z.y ); d[4 * r + 3] = hi16( x.y ) - hi16( z.y );
+          if( func == VVHIP_DF_HAD_2SAD ) { sad = __builtin_amdgcn_sad_u16( x.x ^ BIAS, z.x ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( x.y ^ BIAS, z.y ^ BIAS, sad ); }
+        }
+        sum += hadamard4x4( d );
+      }
+      else if( fast16 )
+      {
+        uint32_t d[32];
+#pragma unroll
+        for( int r = 0; r < 8; r++ )
+        {
+          uint32_t oa[8], ob[8], ca[8], cb[8], ao[4], ac[4];
+          const int16_t* p0 = qa + ( ptrdiff_t ) ( 2 * r ) * os; const int16_t* p1 = qb + ( ptrdiff_t ) ( 2 * r ) * cs;
+          { const u32x4 x0v = ld16( p0 ), x1v = ld16( p0 + 8 ), y0v = ld16( p0 + os ), y1v = ld16( p0 + os + 8 );
+            oa[0] = x0v.x; oa[1] = x0v.y; oa[2] = x0v.z; oa[3] = x0v.w; oa[4] = x1v.x; oa[5] = x1v.y; oa[6] = x1v.z; oa[7] = x1v.w;
+            ob[0] = y0v.x; ob[1] = y0v.y; ob[2] = y0v.z; ob[3] = y0v.w; ob[4] = y1v.x; ob[5] = y1v.y; ob[6] = y1v.z; ob[7] = y1v.w; }
+          { const u32x4 x0v = ld16( p1 ), x1v = ld16( p1 + 8 ), y0v = ld16( p1 + cs ), y1v = ld16( p1 + cs + 8 );
+            ca[0] = x0v.x; ca[1] = x0v.y; ca[2] = x0v.z; ca[3] = x0v.w; ca[4] = x1v.x; ca[5] = x1v.y; ca[6] = x1v.z; ca[7] = x1v.w;
+            cb[0] = y0v.x; cb[1] = y0v.y; cb[2] = y0v.z; cb[3] = y0v.w; cb[4] = y1v.x; cb[5] = y1v.y; cb[6] = y1v.z; cb[7] = y1v.w; }
+          avg2x2( oa, ob, ao ); avg2x2( ca, cb, ac );
+#pragma unroll
+          for( int q = 0; q < 4; q++ ) d[4 * r + q] = pkSub( ao[q], ac[q] );
+        }
+        const uint32_t s = hadamard64( d );
+        sum += ( ( s + 2 ) >> 2 ) << 2;
+      }
+      else
+      {
+        uint32_t d[32];
+#pragma unroll
+        for( int r = 0; r < 8; r++ )
+        {
+          const u32x4 x = ld16( qa + ( ptrdiff_t ) r * os ), z = ld16( qb + ( ptrdiff_t ) r * cs );
+          d[4 * r] = pkSub( x.x, z.x ); d[4 * r + 1] = pkSub( x.y, z.y ); d[4 * r + 2] = pkSub( x.z, z.z ); d[4 * r + 3] = pkSub( x.w, z.w );
+          if( func == VVHIP_DF_HAD_2SAD )
+          { sad = __builtin_amdgcn_sad_u16( x.x ^ BIAS, z.x ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( x.y ^ BIAS, z.y ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( x.z ^ BIAS, z.z ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( x.w ^ BIAS, z.w ^ BIAS, sad ); }
+        }
+        const uint32_t s = hadamard64( d );
+        sum += ( s + 2 ) >> 2;
+      }
+    }
+    const uint64_t tot = vvhipGroupSum64( sum, lpc, lane );
+    if( func == VVHIP_DF_HAD_2SAD )
+    {
+      const uint64_t s2 = 2ull * vvhipGroupSum32( sad, lpc, lane );
+      if( valid && lt == 0 ) a.itemCost[idx] = tot < s2 ? tot : s2;
+    }
+    else if( valid && lt == 0 ) a.itemCost[idx] = tot;
+  }
+}
+
+__global__ void __launch_bounds__( 64 )
+meSearchKernel( MePlanes P, MeArgs a )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t meLds[];
+  // heaviest kind first in grid order: stage bundles, then integer windows, then item bundles
+  int wave = blockIdx.x;
+  if( wave < a.wavesStage ) { stageBody( P, a, wave, meLds ); return; }
+  wave -= a.wavesStage;
+  if( wave < a.wavesInt ) { intBody( P, a, wave, meLds ); return; }
+  wave -= a.wavesInt;
+  itemBody( P, a, wave );
+}
+
+int hostWinPitch( int winW ) { int p = ( winW + 2 + 7 ) & ~7; if( !( ( p >> 3 ) & 1 ) ) p += 8; return p; }
+
+} // namespace
+
+extern "C" {
+
+int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int n_int_jobs, const vvhip_me_cand* cands, int n_cands,
+                          const vvhip_me_stage_job* stage_jobs, int n_stage_jobs, const vvhip_me_item* items, int n_items, int bit_depth, int max_window, vvhip_me_plan** out )
+{
+  if( !ctx || !out ) return VVHIP_E_ARG;
+  *out = nullptr;
+  if( n_int_jobs < 0 || n_cands < 0 || n_stage_jobs < 0 || n_items < 0 || ( n_int_jobs && ( !int_jobs || !cands ) ) || ( n_stage_jobs && !stage_jobs ) || ( n_items && !items ) )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: bad lists" );
+  if( bit_depth < 8 || bit_depth > 10 ) return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_me_plan_create: bit depth %d (the packed Hadamard tile covers <= 10)", bit_depth );
+  if( max_window <= 0 ) max_window = 24;
+  auto squareOk = []( int w, int h, int minW ) { return w == h && ( w == 4 || w == 8 || w == 16 || w == 32 || w == 64 ) && w >= minW; };
+
+  // ---- integer jobs: one window per cluster of candidates (greedy in list order: a candidate joins the first window it keeps within max_window)
+  std::vector<IntJob> ij; std::vector<PlanCand> pc;
+  int ldsInt = 0;
+  for( int i = 0; i < n_int_jobs; i++ )
+  {
+    const vvhip_me_int_job& s = int_jobs[i];
+    if( !squareOk( s.width, s.height, 8 ) || s.org_plane > 15 || s.ref_plane > 15 || s.sub_shift > 1 || s.first_cand < 0 || s.n_cand < 0 || s.first_cand + s.n_cand > n_cands )
+      return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: integer job %d (%dx%d, candidates %d+%d)", i, s.width, s.height, s.first_cand, s.n_cand );
+    struct Win { int x0, y0, x1, y1; std::vector<PlanCand> c; };
+    std::vector<Win> wins;
+    for( int k = 0; k < s.n_cand; k++ )
+    {
+      const vvhip_me_cand& c = cands[s.first_cand + k];
+      PlanCand p; p.dx = c.dx; p.dy = c.dy; p.outIndex = s.first_cand + k;
+      bool placed = false;
+      for( Win& wn : wins )
+      {
+        const int x0 = std::min( wn.x0, ( int ) c.dx ), y0 = std::min( wn.y0, ( int ) c.dy ), x1 = std::max( wn.x1, ( int ) c.dx ), y1 = std::max( wn.y1, ( int ) c.dy );
+        if( x1 - x0 <= max_window && y1 - y0 <= max_window ) { wn.x0 = x0; wn.y0 = y0; wn.x1 = x1; wn.y1 = y1; wn.c.push_back( p ); placed = true; break; }
+      }
+      if( !placed ) { Win wn; wn.x0 = wn.x1 = c.dx; wn.y0 = wn.y1 = c.dy; wn.c.push_back( p ); wins.push_back( wn ); }
+    }
+    for( const Win& wn : wins )
+    {
+      IntJob j; j.orgOff = s.org_off; j.refOff = s.ref_off; j.w = s.width; j.h = s.height; j.orgPlane = s.org_plane; j.refPlane = s.ref_plane; j.subShift = s.sub_shift; j.pad = 0;
+      j.minDx = ( int16_t ) wn.x0; j.minDy = ( int16_t ) wn.y0; j.winW = ( int16_t ) ( wn.x1 - wn.x0 + s.width ); j.winH = ( int16_t ) ( wn.y1 - wn.y0 + s.height );
+      j.firstCand = ( int32_t ) pc.size(); j.nCand = ( int32_t ) wn.c.size();
+      pc.insert( pc.end(), wn.c.begin(), wn.c.end() );
+      ij.push_back( j );
+      ldsInt = std::max( ldsInt, ( j.winH * hostWinPitch( j.winW ) + ( s.height >> s.sub_shift ) * s.width ) * 2 );
+    }
+  }
+  // heaviest windows first
+  std::stable_sort( ij.begin(), ij.end(), []( const IntJob& a, const IntJob& b ) { return ( long ) a.nCand * a.w * ( a.h >> a.subShift ) + ( long ) a.winW * a.winH > ( long ) b.nCand * b.w * ( b.h >> b.subShift ) + ( long ) b.winW * b.winH; } );
+
+  // ---- stage bundles: stages of one block size, ~64 (position, tile) tasks per pass
+  std::vector<int32_t> stOrder( n_stage_jobs ); std::vector<WaveSpan> stWaves;
+  int ldsStage = 0;
+  for( int i = 0; i < n_stage_jobs; i++ )
+  {
+    const vvhip_me_stage_job& s = stage_jobs[i];
+    if( !squareOk( s.width, s.height, 8 ) || s.org_plane > 15 || s.ref_plane > 15 || ( s.i_frac != 1 && s.i_frac != 2 ) || s.filter_mode > 2 ||
+        ( s.func != VVHIP_DF_SAD && s.func != VVHIP_DF_HAD && s.func != VVHIP_DF_HAD_FAST ) || s.base_qx < -3 || s.base_qx > 3 || s.base_qy < -3 || s.base_qy > 3 || ( s.mask >> 9 ) )
+      return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: stage job %d (%dx%d, iFrac %d, mode %d, func %d)", i, s.width, s.height, s.i_frac, s.filter_mode, s.func );
+    stOrder[i] = i;
+  }
+  auto tasksOf = [&]( const vvhip_me_stage_job& s ) { const bool f16 = s.func == VVHIP_DF_HAD_FAST && ( s.width & 31 ) == 0; const int t = f16 ? 16 : 8; return __builtin_popcount( s.mask ) * ( s.width / t ) * ( s.height / t ); };
+  std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a]; const auto& y = stage_jobs[b]; return x.width != y.width ? x.width > y.width : tasksOf( x ) > tasksOf( y ); } );
+  for( int i = 0; i < n_stage_jobs; )
+  {
+    const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i]];
+    int count = 0, tasks = 0;
+    while( i + count < n_stage_jobs && count < 8 )
+    {
+      const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count]];
+      if( s.width != s0.width || ( count && tasks + tasksOf( s ) > 64 ) ) break;
+      tasks += tasksOf( s ); count++;
+    }
+    WaveSpan sp; sp.first = i; sp.count = count; stWaves.push_back( sp );
+    const int tw = std::min( ( int ) s0.width, 32 ), costElems = ( 2 * 9 * count + 7 ) & ~7;
+    ldsStage = std::max( ldsStage, ( costElems + 3 * ( s0.height + 8 ) * tw ) * 2 );
+    i += count;
+  }
+
+  // ---- item bundles: same function and geometry, a few team passes per wave
+  std::vector<int32_t> itOrder( n_items ); std::vector<WaveSpan> itWaves;
+  for( int i = 0; i < n_items; i++ )
+  {
+    const vvhip_me_item& s = items[i];
+    const bool fOk = s.func == VVHIP_DF_SAD || s.func == VVHIP_DF_SSE || s.func == VVHIP_DF_HAD || s.func == VVHIP_DF_HAD_FAST || s.func == VVHIP_DF_HAD_2SAD;
+    if( !squareOk( s.width, s.height, 4 ) || !fOk || s.org_plane > 15 || s.cur_plane > 15 || s.sub_shift > 1 || ( s.sub_shift && s.func != VVHIP_DF_SAD ) )
+      return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: item %d (func %d, %dx%d)", i, s.func, s.width, s.height );
+    itOrder[i] = i;
+  }
+  auto itemKey = [&]( int i ) { const auto& s = items[i]; return ( ( long ) s.width << 16 ) | ( s.func << 8 ) | s.sub_shift; };
+  std::stable_sort( itOrder.begin(), itOrder.end(), [&]( int a, int b ) { return itemKey( a ) > itemKey( b ); } );
+  for( int i = 0; i < n_items; )
+  {
+    const vvhip_me_item& s0 = items[itOrder[i]];
+    int lanesPer;
+    if( s0.func == VVHIP_DF_SAD || s0.func == VVHIP_DF_SSE ) { const int cw = s0.width >= 8 ? 8 : 4; lanesPer = ( s0.height >> ( s0.func == VVHIP_DF_SAD ? s0.sub_shift : 0 ) ) * ( s0.width / cw ); }
+    else { const bool f16 = s0.func == VVHIP_DF_HAD_FAST && ( s0.width & 31 ) == 0; const int t = s0.width == 4 ? 4 : ( f16 ? 16 : 8 ); lanesPer = ( s0.width / t ) * ( s0.height / t ); }
+    if( lanesPer > 64 ) lanesPer = 64;
+    const int perWave = std::max( 1, 64 / lanesPer ) * 4;            // four passes of lane teams per wave
+    int count = 0;
+    while( i + count < n_items && count < perWave && itemKey( itOrder[i + count] ) == itemKey( itOrder[i] ) ) count++;
+    WaveSpan sp; sp.first = i; sp.count = count; itWaves.push_back( sp );
+    i += count;
+  }
+
+  // ---- one device allocation for every table
+  auto pad = []( size_t b ) { return ( b + 255 ) & ~( size_t ) 255; };
+  const size_t bInt = pad( ij.size() * sizeof( IntJob ) ), bCand = pad( pc.size() * sizeof( PlanCand ) ), bSt = pad( ( size_t ) n_stage_jobs * sizeof( vvhip_me_stage_job ) ),
+               bStO = pad( stOrder.size() * 4 ), bStW = pad( stWaves.size() * sizeof( WaveSpan ) ), bIt = pad( ( size_t ) n_items * sizeof( vvhip_me_item ) ), bItO = pad( itOrder.size() * 4 ),
+               bItW = pad( itWaves.size() * sizeof( WaveSpan ) );
+  const size_t total = bInt + bCand + bSt + bStO + bStW + bIt + bItO + bItW + 256;
+  std::vector<char> host( total, 0 );
+  size_t o = 0;
+  auto put = [&]( const void* src, size_t bytes, size_t padded ) { const size_t at = o; if( bytes ) memcpy( host.data() + o, src, bytes ); o += padded; return at; };
+  const size_t oInt = put( ij.data(), ij.size() * sizeof( IntJob ), bInt ), oCand = put( pc.data(), pc.size() * sizeof( PlanCand ), bCand ),
+               oSt = put( stage_jobs, ( size_t ) n_stage_jobs * sizeof( vvhip_me_stage_job ), bSt ), oStO = put( stOrder.data(), stOrder.size() * 4, bStO ),
+               oStW = put( stWaves.data(), stWaves.size() * sizeof( WaveSpan ), bStW ), oIt = put( items, ( size_t ) n_items * sizeof( vvhip_me_item ), bIt ),
+               oItO = put( itOrder.data(), itOrder.size() * 4, bItO ), oItW = put( itWaves.data(), itWaves.size() * sizeof( WaveSpan ), bItW );
+  vvhip_me_plan* p = new vvhip_me_plan;
+  hipError_t e = hipMalloc( &p->d_blob, total );
+  if( e != hipSuccess ) { delete p; return vvhip_fail( ctx, VVHIP_E_NOMEM, "vvhip_me_plan_create: hipMalloc( %zu ): %s", total, hipGetErrorString( e ) ); }
+  e = hipMemcpyAsync( p->d_blob, host.data(), total, hipMemcpyHostToDevice, ctx->stream );
+  if( e == hipSuccess ) e = hipStreamSynchronize( ctx->stream );
+  if( e != hipSuccess ) { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: upload: %s", hipGetErrorString( e ) ); }
+  char* b = static_cast<char*>( p->d_blob );
+  p->d_intJobs = b + oInt; p->d_cands = b + oCand; p->d_stageJobs = b + oSt; p->d_stageOrder = b + oStO; p->d_stageWaves = b + oStW; p->d_items = b + oIt; p->d_itemOrder = b + oItO; p->d_itemWaves = b + oItW;
+  p->bitDepth = bit_depth; p->nCands = n_cands; p->nStages = n_stage_jobs; p->nItems = n_items;
+  p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size();
+  p->ldsBytes = ( std::max( ldsInt, ldsStage ) + 15 ) & ~15;
+  if( p->ldsBytes > 64 * 1024 )
+  {
+    e = hipFuncSetAttribute( ( const void* ) meSearchKernel, hipFuncAttributeMaxDynamicSharedMemorySize, p->ldsBytes );
+    if( e != hipSuccess ) { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: %d bytes of LDS: %s", p->ldsBytes, hipGetErrorString( e ) ); }
+  }
+  *out = p;
+  return VVHIP_OK;
+}
+
+void vvhip_me_plan_destroy( vvhip_ctx* ctx, vvhip_me_plan* plan )
+{
+  if( !plan ) return;
+  if( ctx ) ( void ) hipStreamSynchronize( ctx->stream );
+  if( plan->d_blob ) ( void ) hipFree( plan->d_blob );
+  delete plan;
+}
+
+int vvhip_me_plan_info( const vvhip_me_plan* plan, int* waves_int, int* waves_stage, int* waves_item, int* lds_bytes )
+{
+  if( !plan ) return VVHIP_E_ARG;
+  if( waves_int ) *waves_int = plan->wavesInt;
+  if( waves_stage ) *waves_stage = plan->wavesStage;
+  if( waves_item ) *waves_item = plan->wavesItem;
+  if( lds_bytes ) *lds_bytes = plan->ldsBytes;
+  return VVHIP_OK;
+}
+
+int vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes, uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost )
+{
+  if( !ctx || !plan ) return VVHIP_E_ARG;
+  if( !planes_host || n_planes < 1 || n_planes > 16 || ( plan->nCands && !d_cand_cost ) || ( plan->nStages && !d_stage_cost ) || ( plan->nItems && !d_item_cost ) )
+    return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_run: bad arguments" );
+  MePlanes P;
+  for( int i = 0; i < 16; i++ ) { P.p[i] = planes_host[i < n_planes ? i : 0].d_base; P.stride[i] = planes_host[i < n_planes ? i : 0].stride; }
+  MeArgs a;
+  a.intJobs = static_cast<const IntJob*>( plan->d_intJobs ); a.cands = static_cast<const PlanCand*>( plan->d_cands ); a.wavesInt = plan->wavesInt;
+  a.stageJobs = static_cast<const vvhip_me_stage_job*>( plan->d_stageJobs ); a.stageOrder = static_cast<const int32_t*>( plan->d_stageOrder );
+  a.stageWaves = static_cast<const WaveSpan*>( plan->d_stageWaves ); a.wavesStage = plan->wavesStage;
+  a.items = static_cast<const vvhip_me_item*>( plan->d_items ); a.itemOrder = static_cast<const int32_t*>( plan->d_itemOrder ); a.itemWaves = static_cast<const WaveSpan*>( plan->d_itemWaves ); a.wavesItem = plan->wavesItem;
+  a.candCost = d_cand_cost; a.stageCost = d_stage_cost; a.itemCost = d_item_cost; a.bitDepth = plan->bitDepth;
+  const int grid = plan->wavesInt + plan->wavesStage + plan->wavesItem;
+  if( grid == 0 ) return VVHIP_OK;
+  hipLaunchKernelGGL( meSearchKernel, dim3( ( unsigned ) grid ), dim3( 64 ), ( size_t ) plan->ldsBytes, ctx->stream, P, a );
+  VVHIP_LAUNCH_CHECK( ctx );
+  return VVHIP_OK;
+}
+
+} // extern "C"

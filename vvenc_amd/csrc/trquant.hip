@@ -892,6 +892,7 @@ struct TuMxArgs
   int tiles;               // 32x32 tiles of this job
   int phaseLimit;          // profiling aid ($VVHIP_TU_PHASES): skip the rest of a tile after phase k, 0 = run everything
   int waveStride;          // waves assigned to this job (wave w walks tiles w, w + waveStride, ...)
+  int resiStride;          // row pitch of this job's residual blocks; 0: the launch's common pitch (vvhip_tu_rdo_multi_strided: compact per-TU blocks, pitch = width)
 };
 
 // 16 values of 16-bit range -> the two byte operands (slot s = register s): low bytes - 128 (xor 0x80) and high bytes
@@ -1549,11 +1550,12 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   for( int i = 1; i < 4; i++ ) if( i < jobs.nJobs && wave >= jobs.waveStart[i] ) k = i;
   const int w = wave - jobs.waveStart[k];
   if( w >= jobs.j[k].waveStride ) return;
-  if( jobs.size[k] == 32 )      tuMxBody<32>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
-  else if( jobs.size[k] == 16 ) tuMxBody<16>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
-  else if( jobs.size[k] == 8 )  tuMxBody<8>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
-  else if( WITH4 && jobs.size[k] == 4 )  tuMxBody<4>( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
-  else if( WITH4 && jobs.size[k] == 64 ) tuMx64Body( stage[wv], sInit[wv], sOps[wv], w, resi, resiStride, jobs.j[k] );
+  const int rs = jobs.j[k].resiStride ? jobs.j[k].resiStride : resiStride;
+  if( jobs.size[k] == 32 )      tuMxBody<32>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
+  else if( jobs.size[k] == 16 ) tuMxBody<16>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
+  else if( jobs.size[k] == 8 )  tuMxBody<8>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
+  else if( WITH4 && jobs.size[k] == 4 )  tuMxBody<4>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
+  else if( WITH4 && jobs.size[k] == 64 ) tuMx64Body( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
 }
 
 __global__ void __launch_bounds__( 256 )
@@ -1820,7 +1822,21 @@ int vvhip_dequant_core( vvhip_ctx* ctx, int max_x, int max_y, int scale, const i
   return VVHIP_OK;
 }
 
+static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const int32_t* strides, int bit_depth, const vvhip_tu_job* jobs, int n_jobs );
+
 int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, int bit_depth, const vvhip_tu_job* jobs, int n_jobs )
+{
+  return tuRdoMulti( ctx, d_resi, resi_stride, nullptr, bit_depth, jobs, n_jobs );
+}
+
+int vvhip_tu_rdo_multi_strided( vvhip_ctx* ctx, const int16_t* d_resi, const int32_t* resi_strides_host, int bit_depth, const vvhip_tu_job* jobs, int n_jobs )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( n_jobs && !resi_strides_host ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi_strided: no strides" );
+  return tuRdoMulti( ctx, d_resi, 0, resi_strides_host, bit_depth, jobs, n_jobs );
+}
+
+static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, const int32_t* strides, int bit_depth, const vvhip_tu_job* jobs, int n_jobs )
 {
   if( !ctx ) return VVHIP_E_ARG;
   if( n_jobs < 0 || ( n_jobs && !jobs ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: bad job table" );
@@ -1831,10 +1847,10 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
   for( int i = 0; i < n_jobs; i++ )
   {
     if( jobs[i].n < 0 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: job %d has n < 0", i );
-    if( mergeable( jobs[i] ) && nm < 64 && !getenv( "VVHIP_TU_GENERIC" ) ) order[nm++] = i;
+    if( mergeable( jobs[i] ) && nm < 64 && !getenv( "VVHIP_TU_GENERIC" ) && ( !strides || tuKernelForm() == 0 ) ) order[nm++] = i;
     else if( jobs[i].n > 0 )
     {
-      const int rc = vvhip_tu_rdo_batch( ctx, d_resi, resi_stride, jobs[i].d_resi_off, jobs[i].n, jobs[i].width, jobs[i].height, jobs[i].tr_hor, jobs[i].tr_ver, bit_depth,
+      const int rc = vvhip_tu_rdo_batch( ctx, d_resi, strides ? strides[i] : resi_stride, jobs[i].d_resi_off, jobs[i].n, jobs[i].width, jobs[i].height, jobs[i].tr_hor, jobs[i].tr_ver, bit_depth,
                                          jobs[i].d_qp, jobs[i].thr_val, jobs[i].d_level, jobs[i].d_rec_resi, jobs[i].d_stats );
       if( rc ) return rc;
     }
@@ -1892,6 +1908,7 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
         xa.qps = jb.d_qp; xa.thrVal = jb.thr_val; xa.level = jb.d_level; xa.rec = jb.d_rec_resi; xa.stats = jb.d_stats;
         xa.tiles = ( jb.n + tpt - 1 ) / tpt; xa.phaseLimit = tuPhaseLimit();
         xa.waveStride = ( xa.tiles + tuRepeat() - 1 ) / tuRepeat();
+        xa.resiStride = strides ? strides[order[first + i]] : 0;
         xj.waveStart[i] = ( int ) waves; xj.size[i] = jb.width;
         waves += xa.waveStride;
       }

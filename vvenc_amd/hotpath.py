@@ -351,6 +351,34 @@ class HotPath:
             jobs = self.make_tu_jobs(jobs)
         self._ck(self.L.vvhip_tu_rdo_multi(self.ctx, resi.buf_ptr, resi.stride, bit_depth, jobs[0], jobs[1]))
 
+    def tu_rdo_multi_strided(self, d_resi, strides, jobs, bit_depth=10):
+        """the same with a residual row pitch per job (compact per-TU blocks in one buffer: pitch = width)"""
+        if isinstance(jobs, list):
+            jobs = self.make_tu_jobs(jobs)
+        arr = (C.c_int32 * len(strides))(*strides)
+        self._ck(self.L.vvhip_tu_rdo_multi_strided(self.ctx, _ptr(d_resi), C.cast(arr, C.c_void_p), bit_depth, jobs[0], jobs[1]))
+
+    # ---- motion-search plans: integer candidates + sub-pel stages + plain table calls of a picture in one launch ----
+    def me_plan_create(self, int_jobs, cands, stage_jobs, items, bit_depth=10, max_window=0):
+        """numpy record arrays (vvenc_amd/replay.py dtypes mirror vvhip_me_int_job / _cand / _stage_job / _item) -> plan handle"""
+        keep = [np.ascontiguousarray(a) for a in (int_jobs, cands, stage_jobs, items)]
+        plan = C.c_void_p()
+        self._ck(self.L.vvhip_me_plan_create(self.ctx, keep[0].ctypes.data if keep[0].size else None, int(keep[0].size), keep[1].ctypes.data if keep[1].size else None, int(keep[1].size),
+                                             keep[2].ctypes.data if keep[2].size else None, int(keep[2].size), keep[3].ctypes.data if keep[3].size else None, int(keep[3].size),
+                                             bit_depth, max_window, C.byref(plan)))
+        return plan
+
+    def me_plan_destroy(self, plan):
+        self.L.vvhip_me_plan_destroy(self.ctx, plan)
+
+    def me_plan_info(self, plan):
+        v = [C.c_int() for _ in range(4)]
+        self._ck(self.L.vvhip_me_plan_info(plan, *[C.cast(C.pointer(x), C.c_void_p) for x in v]))
+        return {"waves_int": v[0].value, "waves_stage": v[1].value, "waves_item": v[2].value, "lds_bytes": v[3].value}
+
+    def me_plan_run(self, plan, plane_table, n_planes, cand_cost, stage_cost, item_cost):
+        self._ck(self.L.vvhip_me_plan_run(self.ctx, plan, C.cast(plane_table, C.c_void_p), n_planes, _ptr(cand_cost), _ptr(stage_cost), _ptr(item_cost)))
+
     # ---- SURVEY 8f rank 3: DMVR refinement search ----
     def dmvr_refine_batch(self, ref0, ref1, d_items, n, dx, dy, bit_depth=10, out=None):
         """d_items: DMVR_ITEM_DTYPE records -> tensor of DMVR_RESULT_DTYPE records (as uint8 rows)"""

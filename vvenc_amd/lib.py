@@ -59,6 +59,11 @@ PROTOTYPES = {
     "vvhip_need_rdoq_core": (i32, [vp, vp, sz, i32, C.c_int64, i32, vp]),
     "vvhip_tu_rdo_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
     "vvhip_tu_rdo_multi": (i32, [vp, vp, i32, i32, vp, i32]),
+    "vvhip_tu_rdo_multi_strided": (i32, [vp, vp, vp, i32, vp, i32]),
+    "vvhip_me_plan_create": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(vp)]),
+    "vvhip_me_plan_destroy": (None, [vp, vp]),
+    "vvhip_me_plan_run": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "vvhip_me_plan_info": (i32, [vp, vp, vp, vp, vp]),
     "vvhip_fast_fwd_core": (i32, [vp, i32, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, i32]),
     "vvhip_fast_inv_core": (i32, [vp, i32, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint]),
     "vvhip_round_clip": (i32, [vp, vp, C.c_uint, C.c_uint, C.c_uint, i32, i32, i32, i32]),

@@ -1,0 +1,284 @@
+"""Replay of RECORDED work lists on the MI355X (bench.py, tests): turns a recorded picture (vvenc_amd/recorded.py) into device-resident planes, a motion-search plan
+(vvhip_me_plan_*: integer candidates, sub-pel refinement stages and plain table calls in one launch), the TU lists of the fused transform pipeline
+(vvhip_tu_rdo_multi_strided) and the DMVR list (vvhip_dmvr_refine_batch), and checks the results against the costs the REAL encoder computed while it was recorded.
+
+Plane table of a picture's plan (<= 16 entries):  0..2 original Y / Cb / Cr (as the encoder's CTU copies read them), 3.. luma reconstruction of each reference picture
+(with its margin), then five views of the sample pool, one per block width 4 / 8 / 16 / 32 / 64 (pool blocks are compact: row pitch = block width).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import recorded as R
+from .hotpath import DF, HotPath, Plane, STATS_DTYPE, DMVR_ITEM_DTYPE, DMVR_RESULT_DTYPE
+
+ME_INT_JOB = np.dtype([("org_off", "<i4"), ("ref_off", "<i4"), ("width", "<i2"), ("height", "<i2"), ("org_plane", "u1"), ("ref_plane", "u1"), ("sub_shift", "u1"), ("reserved", "u1"),
+                       ("min_dx", "<i2"), ("min_dy", "<i2"), ("win_w", "<i2"), ("win_h", "<i2"), ("first_cand", "<i4"), ("n_cand", "<i4")])
+ME_CAND = np.dtype([("dx", "<i2"), ("dy", "<i2")])
+ME_STAGE_JOB = np.dtype([("org_off", "<i4"), ("ref_off", "<i4"), ("width", "<i2"), ("height", "<i2"), ("org_plane", "u1"), ("ref_plane", "u1"), ("i_frac", "u1"), ("filter_mode", "u1"),
+                         ("alt_hpel", "u1"), ("func", "u1"), ("base_qx", "i1"), ("base_qy", "i1"), ("mask", "<u2"), ("reserved", "<u2")])
+ME_ITEM = np.dtype([("org_off", "<i4"), ("cur_off", "<i4"), ("org_plane", "u1"), ("cur_plane", "u1"), ("func", "u1"), ("sub_shift", "u1"), ("width", "<i2"), ("height", "<i2")])
+assert ME_INT_JOB.itemsize == 32 and ME_STAGE_JOB.itemsize == 24 and ME_ITEM.itemsize == 16
+
+
+class MePlane(C.Structure):
+    _fields_ = [("d_base", C.c_void_p), ("stride", C.c_int32), ("reserved", C.c_int32)]
+
+
+FAMILY_TO_FUNC = {"SSE": DF["SSE"], "SAD": DF["SAD"], "HAD": DF["HAD"], "HAD_fast": DF["HAD_fast"], "HAD_2SAD": DF["HAD_2SAD"]}
+POOL_WIDTHS = (4, 8, 16, 32, 64)
+
+
+def _family_codes(df):
+    """table index (DFunc, CommonLib/TypeDef.h:339-382) -> C ABI function code"""
+    df = df.astype(np.int32)
+    out = np.full(df.shape, -1, np.int32)
+    out[df < 8] = DF["SSE"]
+    out[(df >= 8) & (df < 16)] = DF["SAD"]
+    out[(df >= 16) & (df < 24)] = DF["HAD"]
+    out[df == 24] = DF["HAD_2SAD"]
+    out[df >= 26] = DF["HAD_fast"]
+    return out
+
+
+class RecordedWorkload:
+    """one recorded picture, resident in HBM, ready to replay"""
+
+    def __init__(self, hp: HotPath, pic: R.RecordedPicture, max_window=16, bit_depth=10):
+        self.hp, self.pic, self.bit_depth = hp, pic, bit_depth
+        dev = hp.device
+        # ---- planes
+        self.planes = []
+        for i in range(pic.planes.size):
+            arr, m = pic.plane_array(i)
+            p = pic.planes[i]
+            if m == 0:                                  # original planes come without margin: give them 8 replicated samples (no job reads them; chunk loads may)
+                pl = hp.plane(np.ascontiguousarray(arr), 8)
+            else:
+                pl = Plane(dev, int(p["width"]), int(p["height"]), m)
+                rows, cols = arr.shape
+                pl.storage[:rows, :cols] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+            self.planes.append(pl)
+        pool_np = np.concatenate([np.asarray(pic.pool), np.zeros(64, np.int16)])          # (+ slack: chunk loads may run past the last block)
+        self.pool = torch.from_numpy(pool_np).to(dev)
+        self.n_pic_planes = len(self.planes)
+        self.pool_plane = {w: self.n_pic_planes + k for k, w in enumerate(POOL_WIDTHS)}
+        assert self.n_pic_planes + len(POOL_WIDTHS) <= 16
+        tab = (MePlane * 16)()
+        for i, pl in enumerate(self.planes):
+            tab[i] = MePlane(pl.storage.data_ptr() + 2 * pl.origin, pl.stride, 0)
+        for w, k in self.pool_plane.items():
+            tab[k] = MePlane(self.pool.data_ptr(), w, 0)
+        self.plane_table, self.n_planes = tab, self.n_pic_planes + len(POOL_WIDTHS)
+        strides = np.array([pl.stride for pl in self.planes], np.int64)
+
+        me, cand, st, d = pic.me, pic.cand, pic.stage, pic.dist
+        # ---- motion-estimation jobs: original block = plane 0 at the CU, or a pool pattern (bi-prediction: 2 * org - other prediction)
+        me_w = me["w"].astype(np.int64)
+        pooled = me["patternPool"] >= 0
+        me_org_plane = np.where(pooled, np.array([self.pool_plane.get(int(w), 255) for w in me["w"]], np.int64), 0)
+        me_org_off = np.where(pooled, me["patternPool"].astype(np.int64), me["cuY"].astype(np.int64) * strides[0] + me["cuX"])
+        ref_ok = me["refPlane"] >= 3
+        me_ref_stride = np.where(ref_ok, strides[np.clip(me["refPlane"], 0, self.n_pic_planes - 1)], 0)
+        # integer candidates: SAD candidates of square 8..64 blocks go into windows; anything else (HAD of the integer refinement, odd shapes) becomes a plain item
+        c_me = cand["me"]
+        c_func = _family_codes(cand["df"])
+        c_w, c_h = me["w"][c_me], me["h"][c_me]
+        int_ok = (c_func == DF["SAD"]) & (c_w == c_h) & np.isin(c_w, (8, 16, 32, 64)) & ref_ok[c_me]
+        # per ME: every candidate must share the subShift to form one job (they do: one setDistParam per search); split off the rest
+        first_ss = np.zeros(me.size, np.int64)
+        if cand.size:
+            first_idx = me["firstCand"].clip(0, max(cand.size - 1, 0))
+            first_ss = cand["subShift"][first_idx].astype(np.int64)
+        int_ok &= cand["subShift"] == first_ss[c_me]
+        sel = np.nonzero(int_ok)[0]
+        self.cand_index = sel                                            # recorded candidate -> plan candidate (same order)
+        pc = np.zeros(sel.size, ME_CAND)
+        pc["dx"] = cand["x"][sel] - me["cuX"][c_me[sel]]
+        pc["dy"] = cand["y"][sel] - me["cuY"][c_me[sel]]
+        # jobs = runs of consecutive selected candidates with the same me
+        jobs = np.zeros(0, ME_INT_JOB)
+        if sel.size:
+            mes = c_me[sel]
+            brk = np.nonzero(np.diff(mes) != 0)[0] + 1
+            starts = np.concatenate([[0], brk])
+            counts = np.diff(np.concatenate([starts, [sel.size]]))
+            jm = mes[starts]
+            jobs = np.zeros(starts.size, ME_INT_JOB)
+            jobs["org_off"] = me_org_off[jm]
+            jobs["ref_off"] = me["cuY"][jm].astype(np.int64) * me_ref_stride[jm] + me["cuX"][jm]
+            jobs["width"], jobs["height"] = me["w"][jm], me["h"][jm]
+            jobs["org_plane"], jobs["ref_plane"] = me_org_plane[jm], me["refPlane"][jm]
+            jobs["sub_shift"] = first_ss[jm]
+            jobs["first_cand"], jobs["n_cand"] = starts, counts
+        self.int_jobs, self.plan_cands = jobs, pc
+        self.cand_expected = cand["cost"][sel].copy()
+
+        # ---- refinement stages
+        s_me = st["me"]
+        s_ok = ref_ok[s_me] & (me["w"][s_me] == me["h"][s_me]) & np.isin(me["w"][s_me], (8, 16, 32, 64)) if st.size else np.zeros(0, bool)
+        ssel = np.nonzero(s_ok)[0]
+        self.stage_index = ssel
+        sj = np.zeros(ssel.size, ME_STAGE_JOB)
+        if ssel.size:
+            sm = s_me[ssel]
+            sj["org_off"] = me_org_off[sm]
+            sj["ref_off"] = st["baseY"][ssel].astype(np.int64) * me_ref_stride[sm] + st["baseX"][ssel]
+            sj["width"], sj["height"] = me["w"][sm], me["h"][sm]
+            sj["org_plane"], sj["ref_plane"] = me_org_plane[sm], me["refPlane"][sm]
+            sj["i_frac"], sj["filter_mode"], sj["alt_hpel"] = st["iFrac"][ssel], st["reduceTap"][ssel], st["altHpel"][ssel]
+            sj["func"] = np.array([DF["SAD"], DF["HAD"], DF["HAD_fast"]], np.uint8)[st["hadMode"][ssel]]
+            sj["base_qx"], sj["base_qy"] = st["baseHor"][ssel], st["baseVer"][ssel]
+            ev = st["cost"][ssel] != R.SKIPPED
+            sj["mask"] = (ev * (1 << np.arange(9))).sum(1)
+            self.stage_expected, self.stage_evaluated = st["cost"][ssel].copy(), ev
+        else:
+            self.stage_expected, self.stage_evaluated = np.zeros((0, 9), np.uint64), np.zeros((0, 9), bool)
+        self.stage_jobs = sj
+
+        # ---- plain table calls: the recorder's `dist` records + the integer candidates that did not fit a window job
+        def operand(plane, x, y, w):
+            pl = plane.astype(np.int64)
+            is_pool = pl < 0
+            st_ = strides[np.clip(pl, 0, self.n_pic_planes - 1)]
+            off = np.where(is_pool, x.astype(np.int64), y.astype(np.int64) * st_ + x)
+            pidx = np.where(is_pool, np.array([self.pool_plane.get(int(v), 255) for v in w], np.int64) if w.size else np.zeros(0, np.int64), pl)
+            return pidx, off
+        items = np.zeros(d.size, ME_ITEM)
+        if d.size:
+            po, oo = operand(d["org_plane"], d["org_x"], d["org_y"], d["w"])
+            pcu, oc = operand(d["cur_plane"], d["cur_x"], d["cur_y"], d["w"])
+            items["org_off"], items["cur_off"], items["org_plane"], items["cur_plane"] = oo, oc, po, pcu
+            items["func"], items["sub_shift"], items["width"], items["height"] = _family_codes(d["df"]), d["subShift"], d["w"], d["h"]
+        rest = np.nonzero(~int_ok)[0]
+        extra = np.zeros(rest.size, ME_ITEM)
+        if rest.size:
+            rm = c_me[rest]
+            extra["org_off"], extra["org_plane"] = me_org_off[rm], me_org_plane[rm]
+            extra["cur_off"] = cand["y"][rest].astype(np.int64) * me_ref_stride[rm] + cand["x"][rest]
+            extra["cur_plane"], extra["func"], extra["sub_shift"] = me["refPlane"][rm], c_func[rest], cand["subShift"][rest]
+            extra["width"], extra["height"] = me["w"][rm], me["h"][rm]
+        all_items = np.concatenate([items, extra])
+        expected = np.concatenate([d["cost"], cand["cost"][rest]]) if all_items.size else np.zeros(0, np.uint64)
+        ok = (all_items["width"] == all_items["height"]) & np.isin(all_items["width"], (4, 8, 16, 32, 64)) & (all_items["org_plane"] < 16) & (all_items["cur_plane"] < 16) & \
+             (all_items["func"] <= 4) & ((all_items["sub_shift"] == 0) | (all_items["func"] == DF["SAD"]))
+        self.items_dropped = int((~ok).sum())
+        self.items, self.item_expected = np.ascontiguousarray(all_items[ok]), expected[ok]
+
+        # ---- the plan + result buffers
+        self.plan = hp.me_plan_create(self.int_jobs, self.plan_cands, self.stage_jobs, self.items, bit_depth, max_window)
+        self.cand_cost = torch.zeros(max(1, self.plan_cands.size), dtype=torch.int64, device=dev)
+        self.stage_cost = torch.zeros(max(1, 9 * self.stage_jobs.size), dtype=torch.int64, device=dev)
+        self.item_cost = torch.zeros(max(1, self.items.size), dtype=torch.int64, device=dev)
+        self.me_info = hp.me_plan_info(self.plan)
+        self._me_call = hp.bound("vvhip_me_plan_run", self.plan, C.cast(self.plane_table, C.c_void_p), self.n_planes, C.c_void_p(self.cand_cost.data_ptr()),
+                                 C.c_void_p(self.stage_cost.data_ptr()), C.c_void_p(self.item_cost.data_ptr()))
+
+        # ---- TU lists: one job per (size, transform types, residual pitch = width); residual blocks live in the pool
+        tu = pic.tu
+        self.tu_groups = []
+        tu_jobs, strides_l = [], []
+        if tu.size:
+            key = np.stack([tu["w"], tu["h"], tu["trHor"], tu["trVer"]], 1).astype(np.int64)
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            for g, (w, h, th, tv) in enumerate(uniq):
+                sel_t = np.nonzero(inv.ravel() == g)[0]
+                if w != h or int(w) not in (4, 8, 16, 32, 64):
+                    continue
+                n = sel_t.size
+                off = hp.to_device(tu["pool"][sel_t].astype(np.int32))
+                qf = np.zeros((n, 2), np.int16)
+                qf[:, 0] = tu["qp"][sel_t]
+                qf[:, 1] = (tu["flags"][sel_t] & 1) | (((tu["flags"][sel_t] >> 1) & 1) << 1)
+                d_qp = hp.to_device(qf)
+                lvl = torch.empty(n * int(w) * int(h), dtype=torch.int16, device=dev)
+                rec = torch.empty(n * int(w) * int(h), dtype=torch.int16, device=dev)
+                stt = torch.empty((n, 24), dtype=torch.uint8, device=dev)
+                self.tu_groups.append(dict(w=int(w), h=int(h), tr_hor=int(th), tr_ver=int(tv), n=n, index=sel_t, d_off=off, d_qp=d_qp, level=lvl, rec=rec, stats=stt, qf=qf))
+                tu_jobs.append((int(w), int(h), int(th), int(tv), n, 8, off, d_qp, lvl, rec, stt))
+                strides_l.append(int(w))
+        self.tu_table = hp.make_tu_jobs(tu_jobs) if tu_jobs else None
+        self.tu_strides = (C.c_int32 * max(1, len(strides_l)))(*strides_l)
+        self.tu_coefficients = int(sum(g["n"] * g["w"] * g["h"] for g in self.tu_groups))
+        self._tu_call = hp.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), bit_depth, self.tu_table[0], self.tu_table[1]) if tu_jobs else None
+
+        # ---- DMVR: one list per (reference 0, reference 1, sub-block size)
+        self.dmvr_groups = []
+        dm = pic.dmvr
+        if dm.size:
+            key = np.stack([dm["ref0Plane"], dm["ref1Plane"], dm["dx"], dm["dy"]], 1).astype(np.int64)
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            for g, (r0, r1, dx, dy) in enumerate(uniq):
+                sel_d = np.nonzero(inv.ravel() == g)[0]
+                it = np.zeros(sel_d.size, DMVR_ITEM_DTYPE)
+                it["ref0_off"] = dm["y0"][sel_d].astype(np.int64) * strides[r0] + dm["x0"][sel_d]
+                it["ref1_off"] = dm["y1"][sel_d].astype(np.int64) * strides[r1] + dm["x1"][sel_d]
+                for f in ("frac0_x", "frac0_y", "frac1_x", "frac1_y"):
+                    it[f] = dm[f.replace("_", "")][sel_d]
+                out = torch.zeros((sel_d.size, 16), dtype=torch.uint8, device=dev)
+                self.dmvr_groups.append(dict(r0=int(r0), r1=int(r1), dx=int(dx), dy=int(dy), n=sel_d.size, index=sel_d, d_items=hp.to_device(it), out=out))
+        self._dmvr_calls = [hp.bound("vvhip_dmvr_refine_batch", self.planes[g["r0"]].buf_ptr, self.planes[g["r0"]].stride, self.planes[g["r1"]].buf_ptr, self.planes[g["r1"]].stride,
+                                     C.c_void_p(g["d_items"].data_ptr()), g["n"], g["dx"], g["dy"], bit_depth, C.c_void_p(g["out"].data_ptr())) for g in self.dmvr_groups]
+
+        # ---- accounting (SURVEY 8d figures per unit)
+        ev_pairs = int((self.stage_evaluated.sum(1) * self.stage_jobs["width"].astype(np.int64) * self.stage_jobs["height"]).sum()) if self.stage_jobs.size else 0
+        cand_pairs = int((me["w"][c_me[sel]].astype(np.int64) * me["h"][c_me[sel]]).sum()) if sel.size else 0
+        item_pairs = int((self.items["width"].astype(np.int64) * self.items["height"]).sum())
+        self.pairs = {"integer_candidates": cand_pairs, "subpel_positions": ev_pairs, "table_calls": item_pairs}
+        rows_eff = (me["h"][c_me[sel]].astype(np.int64) >> cand["subShift"][sel]) if sel.size else np.zeros(0, np.int64)
+        self.alg_bytes_me = int((4 * me["w"][c_me[sel]].astype(np.int64) * rows_eff + 8).sum()) if sel.size else 0
+        # a sub-pel position reads (w + 3)(h + 3) reference samples with the 4-tap search filter ((w + 7)(h + 7) with 8 taps) + w * h original samples, writes 8 bytes
+        if self.stage_jobs.size:
+            taps = np.where(self.stage_jobs["filter_mode"] == 2, 3, np.where(self.stage_jobs["filter_mode"] == 1, 5, 7)).astype(np.int64)
+            w_, h_ = self.stage_jobs["width"].astype(np.int64), self.stage_jobs["height"].astype(np.int64)
+            self.alg_bytes_me += int((self.stage_evaluated.sum(1) * (2 * (w_ + taps) * (h_ + taps) + 2 * w_ * h_ + 8)).sum())
+        self.alg_bytes_me += int((4 * self.items["width"].astype(np.int64) * (self.items["height"].astype(np.int64) >> self.items["sub_shift"]) + 8).sum())
+        self.alg_bytes_tu = int(sum(g["n"] * (6 * g["w"] * g["h"] + 24) for g in self.tu_groups))
+        self.alg_bytes_dmvr = int(sum(g["n"] * (2 * 2 * (g["dx"] + 5) * (g["dy"] + 5) + 16) for g in self.dmvr_groups))
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def run_me(self):
+        self._me_call()
+
+    def run_tu(self):
+        if self._tu_call is not None:
+            self._tu_call()
+
+    def run_dmvr(self):
+        for c in self._dmvr_calls:
+            c()
+
+    def run(self, timers=None):
+        """one pass over the picture's recorded hot-path work on the context's stream"""
+        for cls, fn in (("ME", self.run_me), ("TU", self.run_tu), ("DMVR", self.run_dmvr)):
+            if timers is not None:
+                timers.start(cls)
+            fn()
+            if timers is not None:
+                timers.stop(cls)
+
+    @property
+    def class_launches(self):
+        return {"ME": 1, "TU": max(1, len({(g["w"] in (4, 64)) for g in self.tu_groups})), "DMVR": max(1, len(self.dmvr_groups))}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def check_against_recording(self):
+        """device results vs what the reference encoder computed when the lists were recorded -> dict of mismatch counts"""
+        torch.cuda.synchronize()
+        out = {}
+        got = self.cand_cost.cpu().numpy().view(np.uint64)[:self.plan_cands.size]
+        out["integer_candidates"] = (int(self.plan_cands.size), int((got != self.cand_expected).sum()))
+        gs = self.stage_cost.cpu().numpy().view(np.uint64)[:9 * self.stage_jobs.size].reshape(-1, 9)
+        out["subpel_positions"] = (int(self.stage_evaluated.sum()), int(((gs != self.stage_expected) & self.stage_evaluated).sum()))
+        gi = self.item_cost.cpu().numpy().view(np.uint64)[:self.items.size]
+        out["table_calls"] = (int(self.items.size), int((gi != self.item_expected).sum()))
+        dm = self.pic.dmvr
+        n_d = bad_d = 0
+        for g in self.dmvr_groups:
+            res = g["out"].cpu().numpy().view(DMVR_RESULT_DTYPE).reshape(-1)
+            e = dm[g["index"]]
+            bad_d += int(((res["mvd_x"] != e["mvdX"]) | (res["mvd_y"] != e["mvdY"]) | (res["min_cost"] != e["minCost"])).sum())
+            n_d += g["n"]
+        out["dmvr_subblocks"] = (n_d, bad_d)
+        return out
