@@ -171,7 +171,12 @@ template<int IDX> vvenc::Distortion recTramp( const vvenc::DistParam& dp )
     int x, y;
     if( t.mePlane >= 0 && inPlane( t.ps->planes[t.mePlane], dp.cur.buf, ( int ) dp.cur.stride, w, h, x, y ) )
     {
-      CandRec c; c.me = t.meIdx; c.x = x; c.y = y; c.df = ( uint8_t ) IDX; c.subShift = ( uint8_t ) dp.subShift; c.pad0 = c.pad1 = 0; c.cost = d;
+      // The x86 rows of the 64-wide SAD return a PARTIAL sum as soon as it exceeds maximumDistortionForEarlyExit (checked every fourth processed row,
+      // x86/RdCostX86.h:390-410, 535-555; the scalar row after every row, RdCost.cpp:326): any such value only ever loses the comparison with the best cost.  The record holds what
+      // the same table entry returns with the exit disabled — the value a device list delivers — and flags that the encoder saw the partial one.
+      vvenc::Distortion full = d;
+      if( w >= 64 && dp.maximumDistortionForEarlyExit != vvenc::MAX_DISTORTION ) { vvenc::DistParam q = dp; q.maximumDistortionForEarlyExit = vvenc::MAX_DISTORTION; full = g_cpu[IDX]( q ); }
+      CandRec c; c.me = t.meIdx; c.x = x; c.y = y; c.df = ( uint8_t ) IDX; c.subShift = ( uint8_t ) dp.subShift; c.pad0 = full != d; c.pad1 = 0; c.cost = full;
       t.log->cand.push_back( c );
       t.log->me[t.meIdx].nCand++;
       return d;

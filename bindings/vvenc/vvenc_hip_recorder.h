@@ -18,7 +18,7 @@ namespace vvrec {
 #pragma pack( push, 1 )
 struct Operand { int16_t plane; int16_t pad; int32_t x, y; };            // plane >= 0: index into the picture's plane table, block at sample (x, y); plane == -1: pool, x = sample offset, y = stride
 struct MeRec    { int32_t cuX, cuY; int16_t w, h; int16_t refPlane; uint8_t bi, list; int32_t patternPool; int32_t firstCand, nCand, firstStage, nStage; };   // patternPool < 0: the original block at (cuX, cuY)
-struct CandRec  { int32_t me; int32_t x, y; uint8_t df, subShift, pad0, pad1; uint64_t cost; };                                                                // block position in the reference plane
+struct CandRec  { int32_t me; int32_t x, y; uint8_t df, subShift, pad0 /* 1: the encoder's own call returned an early-exit partial sum, cost holds the full one */, pad1; uint64_t cost; };   // block position in the reference plane
 struct StageRec { int32_t me; int32_t baseX, baseY; int16_t baseHor, baseVer; uint8_t iFrac, hadMode, reduceTap, altHpel; int32_t pad; uint64_t cost[9]; };   // cost ~0ull: position skipped by the encoder
 struct DistRec  { uint8_t df, subShift, bitDepth, ctx; int16_t w, h; Operand org, cur; uint64_t cost; };                                                      // calls outside xMotionEstimation
 struct TuRec    { uint8_t comp, trHor, trVer, flags; int16_t w, h; int16_t qp, bitDepth; int32_t x, y; int32_t pool; };                                        // flags: 1 IRAP, 2 luma, 4 intra CU

@@ -23,7 +23,8 @@
 struct vvhip_me_plan
 {
   int bitDepth = 0, nCands = 0, nStages = 0, nItems = 0;
-  int wavesInt = 0, wavesStage = 0, wavesItem = 0, ldsBytes = 0;
+  int wavesInt = 0, wavesStage = 0, wavesItem = 0, ldsInt = 0, ldsStage = 0;
+  int stageSetWaves[3] = { 0, 0, 0 };      // stage bundles per tap support (4-tap search set, 6 taps / alternative half-pel, 8 taps), in schedule order
   void* d_blob = nullptr;                  // one allocation: every table below
   const void* d_intJobs = nullptr; const void* d_cands = nullptr; const void* d_stageJobs = nullptr; const void* d_stageOrder = nullptr; const void* d_stageWaves = nullptr;
   const void* d_items = nullptr; const void* d_itemOrder = nullptr; const void* d_itemWaves = nullptr;
@@ -203,24 +204,16 @@ __constant__ int8_t kRefineQ[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }
 
 // the 8 window taps (entry k multiplies the sample at offset k - 3) of phase `frac` (1/16 sample) in the tap set the stage's search uses:
 // filter_mode 0 = 8 taps, 1 = 6 taps, 2 = the 4 chroma taps at twice the phase (m_meReduceTap, InterpolationFilter.cpp:586-593); alt half-pel at phase 8
-__device__ __forceinline__ void stageTaps( int frac, int filterMode, int altHpel, int ( &c )[8] )
+__device__ __forceinline__ int stageTap( int frac, int k, int filterMode, int altHpel )
 {
-#pragma unroll
-  for( int k = 0; k < 8; k++ ) c[k] = 0;
-  if( altHpel && frac == 8 ) {
-#pragma unroll
-    for( int k = 0; k < 8; k++ ) c[k] = kAltHpel[k];
-    return; }
+  if( altHpel && frac == 8 ) return kAltHpel[k];
   if( filterMode == 2 )
   {
     const int ph = frac << 1;
-#pragma unroll
-    for( int k = 0; k < 4; k++ ) c[2 + k] = ph <= 16 ? kChroma4[ph][k] : kChroma4[32 - ph][3 - k];
-    return;
+    return ( k < 2 || k > 5 ) ? 0 : ( ph <= 16 ? kChroma4[ph][k - 2] : kChroma4[32 - ph][5 - k] );
   }
-  const int p = frac <= 8 ? frac : 16 - frac;
-#pragma unroll
-  for( int k = 0; k < 8; k++ ) { const int kk = frac <= 8 ? k : 7 - k; c[k] = filterMode == 0 ? kLuma8[p][kk] : kLuma6[p][kk]; }
+  const int p = frac <= 8 ? frac : 16 - frac, kk = frac <= 8 ? k : 7 - k;
+  return filterMode == 0 ? kLuma8[p][kk] : kLuma6[p][kk];
 }
 
 // position k of a stage -> displacement in 1/16 sample from the stage's integer base: ( refine[k] + base ) * iFrac quarter samples
@@ -230,8 +223,13 @@ __device__ __forceinline__ void stagePos( const vvhip_me_stage_job& j, int k, in
   tx = ( rx + j.base_qx ) * j.i_frac * 4; ty = ( ry + j.base_qy ) * j.i_frac * 4;
 }
 
-// 8 predicted samples (row y, columns x0 .. x0 + 7 of the strip) of a position: vertical pass over the first-pass rows in LDS, last pass (clip)
-__device__ __forceinline__ void predRow8( const int16_t* tmpV /* variant, strip-local */, int tw, int y, int x0, int sy, const int ( &cv )[8], bool copyV, int shift1, int maxv, int rnd2, int shift2, uint32_t ( &o )[4] )
+struct PredGeom { int shiftCopy, maxv, rnd2, shift2; };
+
+// 8 predicted samples (row y, columns x0 .. x0 + 7 of the strip) of a position: vertical pass over the first-pass rows in LDS (taps K0 .. K1 of the window), last pass (clip).
+// tapV: the position's 8 window taps in LDS (int32)
+// (a real call: inlined, the sixteen rows of a 16x16_fast tile are scheduled on top of each other and the kernel needs > 400 registers)
+template<int K0, int K1>
+__device__ __noinline__ u32x4 predRow8( const int16_t* tmpV, int tw, int y, int x0, int sy, const int* tapV, bool copyV, const PredGeom g )
 {
   int acc[8];
   if( copyV )
@@ -239,42 +237,53 @@ __device__ __forceinline__ void predRow8( const int16_t* tmpV /* variant, strip-
     // zero vertical phase: filterCopy<false,true> of the first-pass sample (InterpolationFilter.cpp:309-322)
     const u32x4 r = *reinterpret_cast<const u32x4*>( tmpV + ( y + sy + 4 ) * tw + x0 );
     const uint32_t rr[4] = { r.x, r.y, r.z, r.w };
+    const int add = ( int ) ( int16_t ) ( ( 1 << ( g.shiftCopy - 1 ) ) + 8192 );
 #pragma unroll
-    for( int i = 0; i < 4; i++ ) { acc[2 * i] = ( lo16( rr[i] ) + ( int ) ( int16_t ) ( ( 1 << ( shift1 - 1 ) ) + 8192 ) ) >> shift1; acc[2 * i + 1] = ( hi16( rr[i] ) + ( int ) ( int16_t ) ( ( 1 << ( shift1 - 1 ) ) + 8192 ) ) >> shift1; }
+    for( int i = 0; i < 4; i++ ) { acc[2 * i] = ( lo16( rr[i] ) + add ) >> g.shiftCopy; acc[2 * i + 1] = ( hi16( rr[i] ) + add ) >> g.shiftCopy; }
   }
   else
   {
 #pragma unroll
-    for( int i = 0; i < 8; i++ ) acc[i] = rnd2;
+    for( int i = 0; i < 8; i++ ) acc[i] = g.rnd2;
 #pragma unroll
-    for( int k = 0; k < 8; k++ )
+    for( int k = K0; k <= K1; k++ )
     {
-      if( cv[k] == 0 ) continue;                                       // (wave-divergent only between positions with different phases; rows outside the tap support are never read)
+      const int c = tapV[k];
       const u32x4 r = *reinterpret_cast<const u32x4*>( tmpV + ( y + sy + 1 + k ) * tw + x0 );
       const uint32_t rr[4] = { r.x, r.y, r.z, r.w };
 #pragma unroll
-      for( int i = 0; i < 4; i++ ) { acc[2 * i] = __mul24( lo16( rr[i] ), cv[k] ) + acc[2 * i]; acc[2 * i + 1] = __mul24( hi16( rr[i] ), cv[k] ) + acc[2 * i + 1]; }
+      for( int i = 0; i < 4; i++ ) { acc[2 * i] = __mul24( lo16( rr[i] ), c ) + acc[2 * i]; acc[2 * i + 1] = __mul24( hi16( rr[i] ), c ) + acc[2 * i + 1]; }
     }
 #pragma unroll
-    for( int i = 0; i < 8; i++ ) acc[i] = ( int ) ( int16_t ) ( acc[i] >> shift2 );          // Pel val (InterpolationFilter.cpp:433)
+    for( int i = 0; i < 8; i++ ) acc[i] = ( int ) ( int16_t ) ( acc[i] >> g.shift2 );          // Pel val (InterpolationFilter.cpp:433)
   }
-#pragma unroll
-  for( int i = 0; i < 4; i++ )
-  {
-    const int a0 = acc[2 * i] < 0 ? 0 : ( acc[2 * i] > maxv ? maxv : acc[2 * i] ), a1 = acc[2 * i + 1] < 0 ? 0 : ( acc[2 * i + 1] > maxv ? maxv : acc[2 * i + 1] );
-    o[i] = pack2( a0, a1 );
-  }
+  u32x4 o;
+  o.x = pack2( min( max( acc[0], 0 ), g.maxv ), min( max( acc[1], 0 ), g.maxv ) ); o.y = pack2( min( max( acc[2], 0 ), g.maxv ), min( max( acc[3], 0 ), g.maxv ) );
+  o.z = pack2( min( max( acc[4], 0 ), g.maxv ), min( max( acc[5], 0 ), g.maxv ) ); o.w = pack2( min( max( acc[6], 0 ), g.maxv ), min( max( acc[7], 0 ), g.maxv ) );
+  return o;
 }
 
-__device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, int wave, int16_t* lds )
+// rounded 2x2 averages of 8 columns x 2 rows (4 + 4 dwords) -> 4 values as 2 packed dwords (signed inputs)
+__device__ __forceinline__ void avg2x2Half( const uint32_t ( &a )[4], const uint32_t ( &b )[4], uint32_t& o0, uint32_t& o1 )
 {
-  const WaveSpan span = a.stageWaves[wave];
+  const uint32_t t0 = pkAdd( a[0], b[0] ), t1 = pkAdd( a[1], b[1] ), t2 = pkAdd( a[2], b[2] ), t3 = pkAdd( a[3], b[3] );
+  const uint32_t l0 = __builtin_amdgcn_perm( t1, t0, 0x05040100u ), h0 = __builtin_amdgcn_perm( t1, t0, 0x07060302u );
+  const uint32_t l1 = __builtin_amdgcn_perm( t3, t2, 0x05040100u ), h1 = __builtin_amdgcn_perm( t3, t2, 0x07060302u );
+  o0 = __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, pkAdd( pkAdd( l0, h0 ), 0x00020002u ) ) >> 2 );
+  o1 = __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, pkAdd( pkAdd( l1, h1 ), 0x00020002u ) ) >> 2 );
+}
+
+// one stage bundle.  K0 .. K1: the window taps the bundle's filter set can use (wave-uniform: 4-tap search 2..5, 6 taps / alternative half-pel 1..6, 8 taps 0..7)
+template<int K0, int K1>
+__device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, const WaveSpan span, int16_t* lds )
+{
   const int lane = threadIdx.x, bd = a.bitDepth;
-  const int headRoom = 14 - bd > 2 ? 14 - bd : 2, maxv = ( 1 << bd ) - 1;
+  const int headRoom = 14 - bd > 2 ? 14 - bd : 2;
   const int shift1 = 6 - headRoom, off1 = -( 8192 << shift1 );                       // first (not last) pass: InterpolationFilter.cpp:401-408
-  const int shift2 = 6 + headRoom, rnd2 = ( 1 << ( shift2 - 1 ) ) + ( 8192 << 6 );   // second and last pass: :394-400
-  uint32_t* costL = reinterpret_cast<uint32_t*>( lds );                              // [stage in bundle][9] running sums
-  int16_t* tmp = lds + 2 * 9 * span.count + ( ( 2 * 9 * span.count ) & 7 ? 8 - ( ( 2 * 9 * span.count ) & 7 ) : 0 );
+  PredGeom pg; pg.shiftCopy = headRoom; pg.maxv = ( 1 << bd ) - 1; pg.shift2 = 6 + headRoom; pg.rnd2 = ( 1 << ( pg.shift2 - 1 ) ) + ( 8192 << 6 );   // second and last pass: :394-400
+  uint32_t* costL = reinterpret_cast<uint32_t*>( lds );                              // [stage in bundle][9] running sums (72 dwords), then the tap table [16 phases][8] of the current stage
+  int* tapL = reinterpret_cast<int*>( lds ) + 72;
+  int16_t* tmp = lds + 2 * ( 72 + 128 );
   for( int i = lane; i < 9 * span.count; i += 64 ) costL[i] = 0;
 
   for( int si = 0; si < span.count; si++ )
@@ -298,10 +307,12 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, i
     }
     const bool fast16 = j.func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
     const int tile = fast16 ? 16 : 8;
+    __syncthreads();                                                               // the previous stage's readers are done with the tap table
+    for( int i = lane; i < 128; i += 64 ) tapL[i] = stageTap( i >> 3, i & 7, j.filter_mode, j.alt_hpel );
     for( int col0 = 0; col0 < w; col0 += 32 )
     {
       const int tw = w - col0 < 32 ? w - col0 : 32, tw8 = tw >> 3;                   // strip width (8, 16 or 32)
-      __syncthreads();                                                             // the previous strip's readers are done with tmp
+      __syncthreads();                                                             // tap table written; the previous strip's readers are done with tmp
       // ---- horizontal pass: tmp[v][r][x] <-> plane row r - 4, column col0 + x + sx[v]   (first pass, 14-bit intermediates)
       for( int i = lane; i < nHor * rows * tw8; i += 64 )
       {
@@ -311,25 +322,27 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, i
         uint32_t o[4];
         if( fxv )
         {
-          int ch[8]; stageTaps( fxv, j.filter_mode, j.alt_hpel, ch );
-          const u32x4 A = ld16( p - 3 ), B = ld16( p + 4 );                          // samples -3 .. 4 and 4 .. 11
+          // window samples K0 - 3 .. K1 + 4 around the 8 outputs: two overlapping 16-byte loads (8 + K1 - K0 <= 15 samples)
+          constexpr int L = 8 + K1 - K0;
+          const u32x4 A = ld16( p + K0 - 3 ), B = ld16( p + K0 - 3 + L - 8 );
           const uint32_t aw[4] = { A.x, A.y, A.z, A.w }, bw[4] = { B.x, B.y, B.z, B.w };
-          int win[15];
+          int win[L];
 #pragma unroll
           for( int q = 0; q < 4; q++ ) { win[2 * q] = lo16( aw[q] ); win[2 * q + 1] = hi16( aw[q] ); }
 #pragma unroll
-          for( int q = 0; q < 4; q++ ) { if( q ) win[7 + 2 * q] = lo16( bw[q] ); if( 8 + 2 * q < 15 ) win[8 + 2 * q] = hi16( bw[q] ); }
-          int acc[8];
+          for( int q = 0; q < 8; q++ ) if( L - 8 + q >= 8 ) win[L - 8 + q] = ( q & 1 ) ? hi16( bw[q >> 1] ) : lo16( bw[q >> 1] );
+          const int* ch = tapL + fxv * 8;
+          int c[K1 - K0 + 1];
 #pragma unroll
-          for( int x = 0; x < 8; x++ )
+          for( int k = K0; k <= K1; k++ ) c[k - K0] = ch[k];
+#pragma unroll
+          for( int q = 0; q < 4; q++ )
           {
-            int s = off1;
+            int s0 = off1, s1 = off1;
 #pragma unroll
-            for( int k = 0; k < 8; k++ ) s = __mul24( win[x + k], ch[k] ) + s;
-            acc[x] = ( int ) ( int16_t ) ( s >> shift1 );
+            for( int k = 0; k <= K1 - K0; k++ ) { s0 = __mul24( win[2 * q + k], c[k] ) + s0; s1 = __mul24( win[2 * q + 1 + k], c[k] ) + s1; }
+            o[q] = pack2( ( int ) ( int16_t ) ( s0 >> shift1 ), ( int ) ( int16_t ) ( s1 >> shift1 ) );
           }
-#pragma unroll
-          for( int q = 0; q < 4; q++ ) o[q] = pack2( acc[2 * q], acc[2 * q + 1] );
         }
         else
         {
@@ -352,7 +365,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, i
         int txk, tyk; stagePos( j, k, txk, tyk );
         const int hv = txk == hx0 ? 0 : ( txk == hx1 ? 1 : 2 ), syk = tyk >> 4, fyk = tyk & 15;
         const int16_t* tmpV = tmp + hv * rows * tw;
-        int cv[8]; stageTaps( fyk, j.filter_mode, j.alt_hpel, cv );
+        const int* tapV = tapL + fyk * 8;
         const bool copyV = fyk == 0;
         const int x0 = txi * tile, y0 = tyi * tile;
         const int16_t* po = org + ( ptrdiff_t ) y0 * os + col0 + x0;
@@ -360,13 +373,13 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, i
         if( j.func == VVHIP_DF_SAD )
         {
           uint32_t sad = 0;
-#pragma unroll
+#pragma unroll 2
           for( int r = 0; r < 8; r++ )
           {
-            uint32_t pr[4]; predRow8( tmpV, tw, y0 + r, x0, syk, cv, copyV, headRoom, maxv, rnd2, shift2, pr );
+            const u32x4 pr = predRow8<K0, K1>( tmpV, tw, y0 + r, x0, syk, tapV, copyV, pg );
             const u32x4 o = ld16( po + ( ptrdiff_t ) r * os );
-            sad = __builtin_amdgcn_sad_u16( o.x ^ BIAS, pr[0] ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( o.y ^ BIAS, pr[1] ^ BIAS, sad );
-            sad = __builtin_amdgcn_sad_u16( o.z ^ BIAS, pr[2] ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( o.w ^ BIAS, pr[3] ^ BIAS, sad );
+            sad = __builtin_amdgcn_sad_u16( o.x ^ BIAS, pr.x ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( o.y ^ BIAS, pr.y ^ BIAS, sad );
+            sad = __builtin_amdgcn_sad_u16( o.z ^ BIAS, pr.z ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( o.w ^ BIAS, pr.w ^ BIAS, sad );
           }
           val = sad;
         }
@@ -376,17 +389,21 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, i
 #pragma unroll
           for( int r = 0; r < 8; r++ )
           {
-            uint32_t pa[8], pb[8], oa[8], ob[8], ap[4], ao[4];
-            { uint32_t q[4]; predRow8( tmpV, tw, y0 + 2 * r, x0, syk, cv, copyV, headRoom, maxv, rnd2, shift2, q ); pa[0] = q[0]; pa[1] = q[1]; pa[2] = q[2]; pa[3] = q[3];
-              predRow8( tmpV, tw, y0 + 2 * r, x0 + 8, syk, cv, copyV, headRoom, maxv, rnd2, shift2, q ); pa[4] = q[0]; pa[5] = q[1]; pa[6] = q[2]; pa[7] = q[3];
-              predRow8( tmpV, tw, y0 + 2 * r + 1, x0, syk, cv, copyV, headRoom, maxv, rnd2, shift2, q ); pb[0] = q[0]; pb[1] = q[1]; pb[2] = q[2]; pb[3] = q[3];
-              predRow8( tmpV, tw, y0 + 2 * r + 1, x0 + 8, syk, cv, copyV, headRoom, maxv, rnd2, shift2, q ); pb[4] = q[0]; pb[5] = q[1]; pb[6] = q[2]; pb[7] = q[3]; }
-            { const int16_t* p0 = po + ( ptrdiff_t ) ( 2 * r ) * os; const u32x4 x0v = ld16( p0 ), x1v = ld16( p0 + 8 ), y0v = ld16( p0 + os ), y1v = ld16( p0 + os + 8 );
-              oa[0] = x0v.x; oa[1] = x0v.y; oa[2] = x0v.z; oa[3] = x0v.w; oa[4] = x1v.x; oa[5] = x1v.y; oa[6] = x1v.z; oa[7] = x1v.w;
-              ob[0] = y0v.x; ob[1] = y0v.y; ob[2] = y0v.z; ob[3] = y0v.w; ob[4] = y1v.x; ob[5] = y1v.y; ob[6] = y1v.z; ob[7] = y1v.w; }
-            avg2x2( pa, pb, ap ); avg2x2( oa, ob, ao );
 #pragma unroll
-            for( int q = 0; q < 4; q++ ) d[4 * r + q] = pkSub( ao[q], ap[q] );
+            for( int hf = 0; hf < 2; hf++ )
+            {
+              uint32_t ap0, ap1, ao0, ao1;
+              const u32x4 qa = predRow8<K0, K1>( tmpV, tw, y0 + 2 * r, x0 + 8 * hf, syk, tapV, copyV, pg );
+              const u32x4 qb = predRow8<K0, K1>( tmpV, tw, y0 + 2 * r + 1, x0 + 8 * hf, syk, tapV, copyV, pg );
+              const uint32_t pa[4] = { qa.x, qa.y, qa.z, qa.w }, pb[4] = { qb.x, qb.y, qb.z, qb.w };
+              avg2x2Half( pa, pb, ap0, ap1 );
+              const int16_t* p0 = po + ( ptrdiff_t ) ( 2 * r ) * os + 8 * hf;
+              const u32x4 xa = ld16( p0 ), xb = ld16( p0 + os );
+              const uint32_t oa[4] = { xa.x, xa.y, xa.z, xa.w }, ob[4] = { xb.x, xb.y, xb.z, xb.w };
+              avg2x2Half( oa, ob, ao0, ao1 );
+              d[4 * r + 2 * hf] = pkSub( ao0, ap0 ); d[4 * r + 2 * hf + 1] = pkSub( ao1, ap1 );
+            }
+            __builtin_amdgcn_sched_barrier( 0 );                                     // keep the rows apart: the scheduler otherwise interleaves all sixteen and runs out of registers
           }
           const uint32_t s = hadamard64( d );
           val = ( ( s + 2 ) >> 2 ) << 2;                                             // RdCost.cpp:1218-1222
@@ -397,9 +414,10 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, i
 #pragma unroll
           for( int r = 0; r < 8; r++ )
           {
-            uint32_t pr[4]; predRow8( tmpV, tw, y0 + r, x0, syk, cv, copyV, headRoom, maxv, rnd2, shift2, pr );
+            const u32x4 pr = predRow8<K0, K1>( tmpV, tw, y0 + r, x0, syk, tapV, copyV, pg );
             const u32x4 o = ld16( po + ( ptrdiff_t ) r * os );
-            d[4 * r] = pkSub( o.x, pr[0] ); d[4 * r + 1] = pkSub( o.y, pr[1] ); d[4 * r + 2] = pkSub( o.z, pr[2] ); d[4 * r + 3] = pkSub( o.w, pr[3] );
+            d[4 * r] = pkSub( o.x, pr.x ); d[4 * r + 1] = pkSub( o.y, pr.y ); d[4 * r + 2] = pkSub( o.z, pr.z ); d[4 * r + 3] = pkSub( o.w, pr.w );
+            __builtin_amdgcn_sched_barrier( 0 );
           }
           const uint32_t s = hadamard64( d );
           val = ( s + 2 ) >> 2;                                                      // RdCost.cpp:1317-1319
@@ -537,17 +555,27 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
   }
 }
 
+// three kernels (their register budgets differ widely); a plan's run launches the ones it needs back to back
+// (one instance per tap support: the 4-tap search filter of the fast presets must not pay the registers of the 8-tap window)
+template<int K0, int K1>
 __global__ void __launch_bounds__( 64 )
-meSearchKernel( MePlanes P, MeArgs a )
+meStageKernel( MePlanes P, MeArgs a, int firstWave )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t meLds[];
-  // heaviest kind first in grid order: stage bundles, then integer windows, then item bundles
-  int wave = blockIdx.x;
-  if( wave < a.wavesStage ) { stageBody( P, a, wave, meLds ); return; }
-  wave -= a.wavesStage;
-  if( wave < a.wavesInt ) { intBody( P, a, wave, meLds ); return; }
-  wave -= a.wavesInt;
-  itemBody( P, a, wave );
+  stageBody<K0, K1>( P, a, a.stageWaves[firstWave + blockIdx.x], meLds );
+}
+
+__global__ void __launch_bounds__( 64 )
+meIntKernel( MePlanes P, MeArgs a )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t meLds[];
+  intBody( P, a, blockIdx.x, meLds );
+}
+
+__global__ void __launch_bounds__( 64 )
+meItemKernel( MePlanes P, MeArgs a )
+{
+  itemBody( P, a, blockIdx.x );
 }
 
 int hostWinPitch( int winW ) { int p = ( winW + 2 + 7 ) & ~7; if( !( ( p >> 3 ) & 1 ) ) p += 8; return p; }
@@ -614,7 +642,10 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     stOrder[i] = i;
   }
   auto tasksOf = [&]( const vvhip_me_stage_job& s ) { const bool f16 = s.func == VVHIP_DF_HAD_FAST && ( s.width & 31 ) == 0; const int t = f16 ? 16 : 8; return __builtin_popcount( s.mask ) * ( s.width / t ) * ( s.height / t ); };
-  std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a]; const auto& y = stage_jobs[b]; return x.width != y.width ? x.width > y.width : tasksOf( x ) > tasksOf( y ); } );
+  auto setOf = []( const vvhip_me_stage_job& s ) { return ( s.filter_mode == 2 && !s.alt_hpel ) ? 0 : ( s.filter_mode == 0 ? 2 : 1 ); };      // which tap support the bundle's kernel instance uses
+  std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a]; const auto& y = stage_jobs[b];
+                    return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( x.width != y.width ? x.width > y.width : tasksOf( x ) > tasksOf( y ) ); } );
+  int setWaves[3] = { 0, 0, 0 };
   for( int i = 0; i < n_stage_jobs; )
   {
     const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i]];
@@ -622,12 +653,13 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     while( i + count < n_stage_jobs && count < 8 )
     {
       const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count]];
-      if( s.width != s0.width || ( count && tasks + tasksOf( s ) > 64 ) ) break;
+      if( s.width != s0.width || setOf( s ) != setOf( s0 ) || ( count && tasks + tasksOf( s ) > 64 ) ) break;
       tasks += tasksOf( s ); count++;
     }
     WaveSpan sp; sp.first = i; sp.count = count; stWaves.push_back( sp );
-    const int tw = std::min( ( int ) s0.width, 32 ), costElems = ( 2 * 9 * count + 7 ) & ~7;
-    ldsStage = std::max( ldsStage, ( costElems + 3 * ( s0.height + 8 ) * tw ) * 2 );
+    setWaves[setOf( s0 )]++;
+    const int tw = std::min( ( int ) s0.width, 32 );
+    ldsStage = std::max( ldsStage, ( 2 * ( 72 + 128 ) + 3 * ( s0.height + 8 ) * tw ) * 2 );      // cost sums + tap table + three first-pass strips
     i += count;
   }
 
@@ -680,12 +712,10 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   p->d_intJobs = b + oInt; p->d_cands = b + oCand; p->d_stageJobs = b + oSt; p->d_stageOrder = b + oStO; p->d_stageWaves = b + oStW; p->d_items = b + oIt; p->d_itemOrder = b + oItO; p->d_itemWaves = b + oItW;
   p->bitDepth = bit_depth; p->nCands = n_cands; p->nStages = n_stage_jobs; p->nItems = n_items;
   p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size();
-  p->ldsBytes = ( std::max( ldsInt, ldsStage ) + 15 ) & ~15;
-  if( p->ldsBytes > 64 * 1024 )
-  {
-    e = hipFuncSetAttribute( ( const void* ) meSearchKernel, hipFuncAttributeMaxDynamicSharedMemorySize, p->ldsBytes );
-    if( e != hipSuccess ) { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: %d bytes of LDS: %s", p->ldsBytes, hipGetErrorString( e ) ); }
-  }
+  p->ldsInt = ( ldsInt + 15 ) & ~15; p->ldsStage = ( ldsStage + 15 ) & ~15;
+  for( int k = 0; k < 3; k++ ) p->stageSetWaves[k] = setWaves[k];
+  if( p->ldsInt > 64 * 1024 || p->ldsStage > 64 * 1024 )
+  { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_me_plan_create: %d / %d bytes of LDS per wave (max_window too large?)", ldsInt, ldsStage ); }
   *out = p;
   return VVHIP_OK;
 }
@@ -704,7 +734,7 @@ int vvhip_me_plan_info( const vvhip_me_plan* plan, int* waves_int, int* waves_st
   if( waves_int ) *waves_int = plan->wavesInt;
   if( waves_stage ) *waves_stage = plan->wavesStage;
   if( waves_item ) *waves_item = plan->wavesItem;
-  if( lds_bytes ) *lds_bytes = plan->ldsBytes;
+  if( lds_bytes ) *lds_bytes = plan->ldsInt > plan->ldsStage ? plan->ldsInt : plan->ldsStage;
   return VVHIP_OK;
 }
 
@@ -721,9 +751,14 @@ int vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me
   a.stageWaves = static_cast<const WaveSpan*>( plan->d_stageWaves ); a.wavesStage = plan->wavesStage;
   a.items = static_cast<const vvhip_me_item*>( plan->d_items ); a.itemOrder = static_cast<const int32_t*>( plan->d_itemOrder ); a.itemWaves = static_cast<const WaveSpan*>( plan->d_itemWaves ); a.wavesItem = plan->wavesItem;
   a.candCost = d_cand_cost; a.stageCost = d_stage_cost; a.itemCost = d_item_cost; a.bitDepth = plan->bitDepth;
-  const int grid = plan->wavesInt + plan->wavesStage + plan->wavesItem;
-  if( grid == 0 ) return VVHIP_OK;
-  hipLaunchKernelGGL( meSearchKernel, dim3( ( unsigned ) grid ), dim3( 64 ), ( size_t ) plan->ldsBytes, ctx->stream, P, a );
+  int firstWave = 0;
+  if( plan->stageSetWaves[0] ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) plan->stageSetWaves[0] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  firstWave += plan->stageSetWaves[0];
+  if( plan->stageSetWaves[1] ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) plan->stageSetWaves[1] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  firstWave += plan->stageSetWaves[1];
+  if( plan->stageSetWaves[2] ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) plan->stageSetWaves[2] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  if( plan->wavesInt )   hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->wavesInt ), dim3( 64 ), ( size_t ) plan->ldsInt, ctx->stream, P, a );
+  if( plan->wavesItem )  hipLaunchKernelGGL( meItemKernel, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
 }

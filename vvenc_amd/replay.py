@@ -212,8 +212,9 @@ class RecordedWorkload:
             for g, (r0, r1, dx, dy) in enumerate(uniq):
                 sel_d = np.nonzero(inv.ravel() == g)[0]
                 it = np.zeros(sel_d.size, DMVR_ITEM_DTYPE)
-                it["ref0_off"] = dm["y0"][sel_d].astype(np.int64) * strides[r0] + dm["x0"][sel_d]
-                it["ref1_off"] = dm["y1"][sel_d].astype(np.int64) * strides[r1] + dm["x1"][sel_d]
+                # recorded (x, y): top-left of the CU's bilinear search area = 2 samples (DMVR_NUM_ITERATION) before the sub-block at the merge vector, which is what the entry point takes
+                it["ref0_off"] = (dm["y0"][sel_d].astype(np.int64) + 2) * strides[r0] + dm["x0"][sel_d] + 2
+                it["ref1_off"] = (dm["y1"][sel_d].astype(np.int64) + 2) * strides[r1] + dm["x1"][sel_d] + 2
                 for f in ("frac0_x", "frac0_y", "frac1_x", "frac1_y"):
                     it[f] = dm[f.replace("_", "")][sel_d]
                 out = torch.zeros((sel_d.size, 16), dtype=torch.uint8, device=dev)
