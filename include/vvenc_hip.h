@@ -334,7 +334,7 @@ VVHIP_API int vvhip_subpel_refine_batch( vvhip_ctx* ctx, int func, const int16_t
  *                  ref_off, refine = s_acMvRefineH (i_frac 2) / s_acMvRefineQ (i_frac 1) (InterSearch.cpp:67-91).  The kernel interpolates like
  *                  xPatternRefinement's planes (filter_mode / alt_hpel as vvhip_interp_luma_batch; horizontal pass shared between positions) and scores each
  *                  prediction against the original block directly from LDS — the predictions never exist in HBM.  cost[9 * stage + k] as the table entry
- *                  `func` (VVHIP_DF_SAD / _HAD / _HAD_FAST) returns it; positions outside the mask are left untouched.
+ *                  `func` (VVHIP_DF_SAD / _HAD / _HAD_FAST) returns it; positions outside the mask read 0.
  *   item         : one plain table call: func on (org block, cur block) of any two planes / pools of the plan's plane table.
  * Offsets are in samples from sample (0,0) of the job's plane (negative = margin); planes must be readable 16 bytes beyond every block / window row they hold.
  * Square blocks, width 4 (items only), 8, 16, 32 or 64; bit depths <= 10 (the packed Hadamard tile, like the reference's x86 rows).

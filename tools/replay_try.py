@@ -24,6 +24,8 @@ for poc, pic in pics.items():
     for _ in range(n): wl.run_dmvr()
     ev[3].record()
     torch.cuda.synchronize()
-    print(json.dumps({"poc": poc, "tl": pic.tlayer, "build_s": round(t1 - t0, 2), "check": chk, "info": wl.me_info, "dropped": wl.items_dropped,
+    line = json.dumps({"poc": poc, "tl": pic.tlayer, "build_s": round(t1 - t0, 2), "check": chk, "info": wl.me_info, "dropped": wl.items_dropped,
                       "us": {"me": 1000 * ev[0].elapsed_time(ev[1]) / n, "tu": 1000 * ev[1].elapsed_time(ev[2]) / n, "dmvr": 1000 * ev[2].elapsed_time(ev[3]) / n},
-                      "n": {"int_jobs": int(wl.int_jobs.size), "cands": int(wl.plan_cands.size), "stages": int(wl.stage_jobs.size), "items": int(wl.items.size), "tus": sum(g["n"] for g in wl.tu_groups)}}))
+                      "n": {"int_jobs": int(wl.int_jobs.size), "cands": int(wl.plan_cands.size), "stages": int(wl.stage_jobs.size), "items": int(wl.items.size), "tus": sum(g["n"] for g in wl.tu_groups)}})
+    print(line)
+    open("/root/repo/gpurun_out/replay_try.jsonl", "a").write(line + "\n")

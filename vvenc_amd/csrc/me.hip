@@ -24,6 +24,7 @@ struct vvhip_me_plan
 {
   int bitDepth = 0, nCands = 0, nStages = 0, nItems = 0;
   int wavesInt = 0, wavesStage = 0, wavesItem = 0, ldsInt = 0, ldsStage = 0;
+  int intBig = 0, ldsIntSmall = 0;          // the first intBig windows need up to ldsInt bytes of LDS, the others at most ldsIntSmall (two launches: small blocks keep their occupancy)
   int stageSetWaves[3] = { 0, 0, 0 };      // stage bundles per tap support (4-tap search set, 6 taps / alternative half-pel, 8 taps), in schedule order
   void* d_blob = nullptr;                  // one allocation: every table below
   const void* d_intJobs = nullptr; const void* d_cands = nullptr; const void* d_stageJobs = nullptr; const void* d_stageOrder = nullptr; const void* d_stageWaves = nullptr;
@@ -139,21 +140,35 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
   {
     const int16_t* ref = P.p[j.refPlane] + j.refOff + ( ptrdiff_t ) j.minDy * P.stride[j.refPlane] + j.minDx;
     const int cpr = pitch >> 3, n = j.winH * cpr, rs = P.stride[j.refPlane];
-    for( int i = lane; i < n; i += 64 )
+    for( int i0 = lane; i0 < n; i0 += 256 )                            // four loads in flight per lane (the loop is latency-bound otherwise)
     {
-      const int r = i / cpr, c = i - r * cpr;
-      u32x4 v = ld16( ref + ( ptrdiff_t ) r * rs + c * 8 );
-      v.x ^= BIAS; v.y ^= BIAS; v.z ^= BIAS; v.w ^= BIAS;
-      *reinterpret_cast<u32x4*>( win + r * pitch + c * 8 ) = v;
+      u32x4 v[4]; int at[4];
+#pragma unroll
+      for( int q = 0; q < 4; q++ )
+      {
+        const int i = i0 + 64 * q < n ? i0 + 64 * q : i0, r = i / cpr, c = i - r * cpr;
+        at[q] = r * pitch + c * 8;
+        v[q] = ld16( ref + ( ptrdiff_t ) r * rs + c * 8 );
+      }
+#pragma unroll
+      for( int q = 0; q < 4; q++ )
+        if( i0 + 64 * q < n ) { u32x4 x = v[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( win + at[q] ) = x; }
     }
     const int16_t* org = P.p[j.orgPlane] + j.orgOff;
     const int os = P.stride[j.orgPlane], m = rowsEff * lpr;
-    for( int i = lane; i < m; i += 64 )
+    for( int i0 = lane; i0 < m; i0 += 256 )
     {
-      const int r = i / lpr, c = i - r * lpr;
-      u32x4 v = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 );
-      v.x ^= BIAS; v.y ^= BIAS; v.z ^= BIAS; v.w ^= BIAS;
-      *reinterpret_cast<u32x4*>( orgL + r * w + c * 8 ) = v;
+      u32x4 v[4]; int at[4];
+#pragma unroll
+      for( int q = 0; q < 4; q++ )
+      {
+        const int i = i0 + 64 * q < m ? i0 + 64 * q : i0, r = i / lpr, c = i - r * lpr;
+        at[q] = r * w + c * 8;
+        v[q] = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 );
+      }
+#pragma unroll
+      for( int q = 0; q < 4; q++ )
+        if( i0 + 64 * q < m ) { u32x4 x = v[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( orgL + at[q] ) = x; }
     }
   }
   __syncthreads();
@@ -223,215 +238,230 @@ __device__ __forceinline__ void stagePos( const vvhip_me_stage_job& j, int k, in
   tx = ( rx + j.base_qx ) * j.i_frac * 4; ty = ( ry + j.base_qy ) * j.i_frac * 4;
 }
 
-struct PredGeom { int shiftCopy, maxv, rnd2, shift2; };
-
-// 8 predicted samples (row y, columns x0 .. x0 + 7 of the strip) of a position: vertical pass over the first-pass rows in LDS (taps K0 .. K1 of the window), last pass (clip).
-// tapV: the position's 8 window taps in LDS (int32)
-// (a real call: inlined, the sixteen rows of a 16x16_fast tile are scheduled on top of each other and the kernel needs > 400 registers)
-template<int K0, int K1>
-__device__ __noinline__ u32x4 predRow8( const int16_t* tmpV, int tw, int y, int x0, int sy, const int* tapV, bool copyV, const PredGeom g )
+typedef short s16x2h __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ int dot2( uint32_t a, uint32_t b, int c ) { return __builtin_amdgcn_sdot2( __builtin_bit_cast( s16x2h, a ), __builtin_bit_cast( s16x2h, b ), c, false ); }
+// two ints -> saturated int16 pair, clamped to [0, maxv] (maxv < 2^15)
+__device__ __forceinline__ uint32_t clampPack( int lo, int hi, uint32_t maxPk )
 {
+  const s16x2h v = __builtin_amdgcn_cvt_pk_i16( lo, hi ), z = { 0, 0 };
+  return __builtin_bit_cast( uint32_t, __builtin_elementwise_min( __builtin_elementwise_max( v, z ), __builtin_bit_cast( s16x2h, maxPk ) ) );
+}
+
+// One bundle of (stage, band) units.  K0 .. K1: the window taps the bundle's filter set can use (wave-uniform: 4-tap search 2..5, 6 taps / alternative half-pel 1..6, 8 taps 0..7).
+// A band = <= 16 rows of a block (one row of 16x16_fast tiles); the bands of a block are independent units (their partial costs are added with integer atomics, which
+// commute: results do not depend on the schedule).  Per unit two cooperative phases:
+//   H   first pass of the <= 3 distinct horizontal positions, rows band + K0 - 4 .. band + BH + K1 - 4, straight from the plane into LDS: 8 outputs per lane from two
+//       overlapping 16-byte loads, tap PAIRS as v_dot2_i32_i16 on the even / odd sample pairs of the window (no unpacking);
+//   VD  eight lanes per (position, tile), lane r = tile row r: second pass of the lane's own prediction row(s) out of LDS (v_dot2 with (c, 0) / (0, c)), clip, difference to
+//       the original row(s), horizontal butterflies in registers, vertical ones across the eight lanes with DPP (the factorisation of dist.hip's hadKernel), |DC| >> 2,
+//       per-tile normalisation — the prediction never leaves registers.
+// 8 clipped prediction samples of band row y (columns x0 .. x0 + 7) of a position, as four sample pairs
+template<int K0, int K1>
+__device__ __forceinline__ void predRow( const int16_t* tv /* first-pass band of the position's horizontal variant, at column x0 */, int w, int y, int syk, int fyk, const int* tapL,
+                                         int rnd2, int shift2, int headRoom, uint32_t maxPk, uint32_t ( &o )[4] )
+{
+  constexpr int NT = K1 - K0 + 1;
   int acc[8];
-  if( copyV )
+  if( fyk )
   {
-    // zero vertical phase: filterCopy<false,true> of the first-pass sample (InterpolationFilter.cpp:309-322)
-    const u32x4 r = *reinterpret_cast<const u32x4*>( tmpV + ( y + sy + 4 ) * tw + x0 );
-    const uint32_t rr[4] = { r.x, r.y, r.z, r.w };
-    const int add = ( int ) ( int16_t ) ( ( 1 << ( g.shiftCopy - 1 ) ) + 8192 );
 #pragma unroll
-    for( int i = 0; i < 4; i++ ) { acc[2 * i] = ( lo16( rr[i] ) + add ) >> g.shiftCopy; acc[2 * i + 1] = ( hi16( rr[i] ) + add ) >> g.shiftCopy; }
+    for( int i = 0; i < 8; i++ ) acc[i] = rnd2;
+#pragma unroll
+    for( int t = 0; t < NT; t++ )
+    {
+      const int c = tapL[fyk * 8 + K0 + t];
+      const uint32_t cl = ( uint32_t ) c & 0xffffu, ch = ( uint32_t ) c << 16;
+      const u32x4 r = *reinterpret_cast<const u32x4*>( tv + ( y + syk + t + 1 ) * w );
+      acc[0] = dot2( r.x, cl, acc[0] ); acc[1] = dot2( r.x, ch, acc[1] ); acc[2] = dot2( r.y, cl, acc[2] ); acc[3] = dot2( r.y, ch, acc[3] );
+      acc[4] = dot2( r.z, cl, acc[4] ); acc[5] = dot2( r.z, ch, acc[5] ); acc[6] = dot2( r.w, cl, acc[6] ); acc[7] = dot2( r.w, ch, acc[7] );
+    }
+#pragma unroll
+    for( int i = 0; i < 8; i++ ) acc[i] >>= shift2;
   }
   else
   {
+    // zero vertical phase: filterCopy<false,true> of the first-pass sample (InterpolationFilter.cpp:309-322)
+    const u32x4 r = *reinterpret_cast<const u32x4*>( tv + ( y + syk + 4 - K0 ) * w );
+    const uint32_t rw[4] = { r.x, r.y, r.z, r.w };
+    const int add = ( int ) ( int16_t ) ( ( 1 << ( headRoom - 1 ) ) + 8192 );
 #pragma unroll
-    for( int i = 0; i < 8; i++ ) acc[i] = g.rnd2;
-#pragma unroll
-    for( int k = K0; k <= K1; k++ )
-    {
-      const int c = tapV[k];
-      const u32x4 r = *reinterpret_cast<const u32x4*>( tmpV + ( y + sy + 1 + k ) * tw + x0 );
-      const uint32_t rr[4] = { r.x, r.y, r.z, r.w };
-#pragma unroll
-      for( int i = 0; i < 4; i++ ) { acc[2 * i] = __mul24( lo16( rr[i] ), c ) + acc[2 * i]; acc[2 * i + 1] = __mul24( hi16( rr[i] ), c ) + acc[2 * i + 1]; }
-    }
-#pragma unroll
-    for( int i = 0; i < 8; i++ ) acc[i] = ( int ) ( int16_t ) ( acc[i] >> g.shift2 );          // Pel val (InterpolationFilter.cpp:433)
+    for( int i = 0; i < 4; i++ ) { acc[2 * i] = ( lo16( rw[i] ) + add ) >> headRoom; acc[2 * i + 1] = ( hi16( rw[i] ) + add ) >> headRoom; }
   }
-  u32x4 o;
-  o.x = pack2( min( max( acc[0], 0 ), g.maxv ), min( max( acc[1], 0 ), g.maxv ) ); o.y = pack2( min( max( acc[2], 0 ), g.maxv ), min( max( acc[3], 0 ), g.maxv ) );
-  o.z = pack2( min( max( acc[4], 0 ), g.maxv ), min( max( acc[5], 0 ), g.maxv ) ); o.w = pack2( min( max( acc[6], 0 ), g.maxv ), min( max( acc[7], 0 ), g.maxv ) );
-  return o;
+  o[0] = clampPack( acc[0], acc[1], maxPk ); o[1] = clampPack( acc[2], acc[3], maxPk ); o[2] = clampPack( acc[4], acc[5], maxPk ); o[3] = clampPack( acc[6], acc[7], maxPk );
 }
 
-// rounded 2x2 averages of 8 columns x 2 rows (4 + 4 dwords) -> 4 values as 2 packed dwords (signed inputs)
-__device__ __forceinline__ void avg2x2Half( const uint32_t ( &a )[4], const uint32_t ( &b )[4], uint32_t& o0, uint32_t& o1 )
+// 4 rounded 2x2 averages ( a + b rows, 8 columns ) as ints
+__device__ __forceinline__ void avgInts( const uint32_t ( &ra )[4], const uint32_t ( &rb )[4], int ( &o )[4] )
 {
-  const uint32_t t0 = pkAdd( a[0], b[0] ), t1 = pkAdd( a[1], b[1] ), t2 = pkAdd( a[2], b[2] ), t3 = pkAdd( a[3], b[3] );
-  const uint32_t l0 = __builtin_amdgcn_perm( t1, t0, 0x05040100u ), h0 = __builtin_amdgcn_perm( t1, t0, 0x07060302u );
-  const uint32_t l1 = __builtin_amdgcn_perm( t3, t2, 0x05040100u ), h1 = __builtin_amdgcn_perm( t3, t2, 0x07060302u );
-  o0 = __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, pkAdd( pkAdd( l0, h0 ), 0x00020002u ) ) >> 2 );
-  o1 = __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, pkAdd( pkAdd( l1, h1 ), 0x00020002u ) ) >> 2 );
+#pragma unroll
+  for( int i = 0; i < 4; i++ ) o[i] = ( lo16( ra[i] ) + hi16( ra[i] ) + lo16( rb[i] ) + hi16( rb[i] ) + 2 ) >> 2;
 }
 
-// one stage bundle.  K0 .. K1: the window taps the bundle's filter set can use (wave-uniform: 4-tap search 2..5, 6 taps / alternative half-pel 1..6, 8 taps 0..7)
 template<int K0, int K1>
 __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, const WaveSpan span, int16_t* lds )
 {
+  constexpr int NT = K1 - K0 + 1, NP = NT / 2, B0 = ( NT - 2 ) / 2;
   const int lane = threadIdx.x, bd = a.bitDepth;
   const int headRoom = 14 - bd > 2 ? 14 - bd : 2;
   const int shift1 = 6 - headRoom, off1 = -( 8192 << shift1 );                       // first (not last) pass: InterpolationFilter.cpp:401-408
-  PredGeom pg; pg.shiftCopy = headRoom; pg.maxv = ( 1 << bd ) - 1; pg.shift2 = 6 + headRoom; pg.rnd2 = ( 1 << ( pg.shift2 - 1 ) ) + ( 8192 << 6 );   // second and last pass: :394-400
-  uint32_t* costL = reinterpret_cast<uint32_t*>( lds );                              // [stage in bundle][9] running sums (72 dwords), then the tap table [16 phases][8] of the current stage
-  int* tapL = reinterpret_cast<int*>( lds ) + 72;
-  int16_t* tmp = lds + 2 * ( 72 + 128 );
-  for( int i = lane; i < 9 * span.count; i += 64 ) costL[i] = 0;
+  const int shift2 = 6 + headRoom, rnd2 = ( 1 << ( shift2 - 1 ) ) + ( 8192 << 6 );   // second and last pass: :394-400
+  const uint32_t maxPk = ( uint32_t ) ( ( 1 << bd ) - 1 ) * 0x00010001u;
+  int* tapL = reinterpret_cast<int*>( lds );                                         // [16 phases][8] taps of the current unit's stage
+  uint32_t* tapP = reinterpret_cast<uint32_t*>( lds ) + 128;                         // [16 phases][4] tap pairs (K0 + 2i, K0 + 2i + 1)
+  int* posL = reinterpret_cast<int*>( lds ) + 128 + 64;                              // [9] evaluated positions: k | ( tx + 64 ) << 8 | ( ty + 64 ) << 20
+  uint32_t* costL = reinterpret_cast<uint32_t*>( lds ) + 128 + 64 + 16;              // [9] sums of the current unit
+  int16_t* tmp = lds + 2 * ( 128 + 64 + 16 + 16 );
 
   for( int si = 0; si < span.count; si++ )
   {
-    const int stage = a.stageOrder[span.first + si];
+    const int unit = a.stageOrder[span.first + si], stage = unit & 0xffffff, y0 = ( unit >> 24 ) << 4;
     const vvhip_me_stage_job j = a.stageJobs[stage];
-    const int w = j.width, h = j.height, rows = h + 8;
+    const int w = j.width, h = j.height, G = w >> 3, log2G = 31 - __builtin_clz( G );
+    const int BH = h < 16 ? h : 16, rowsT = BH + NT;
     const int16_t* ref = P.p[j.ref_plane] + j.ref_off;
     const int rs = P.stride[j.ref_plane];
     const int16_t* org = P.p[j.org_plane] + j.org_off;
     const int os = P.stride[j.org_plane];
-    // the distinct horizontal displacements of the evaluated positions (<= 3: the refinement offsets are -1, 0, 1): one first pass each, shared like the reference's planes
-    int hx0 = 0, hx1 = 0, hx2 = 0, nHor = 0;
+    // the evaluated positions and their distinct horizontal displacements (<= 3: the refinement offsets are -1, 0, 1): one first pass each, shared like the reference's planes
+    int hx0 = 0, hx1 = 0, hx2 = 0, nHor = 0, nPos = 0;
+    __syncthreads();                                                               // the previous unit's readers are done with the tables and tmp
     for( int k = 0; k < 9; k++ )
     {
       if( !( ( j.mask >> k ) & 1 ) ) continue;
       int tx, ty; stagePos( j, k, tx, ty );
+      if( lane == 0 ) posL[nPos] = k | ( ( tx + 64 ) << 8 ) | ( ( ty + 64 ) << 20 );
+      nPos++;
       if( ( nHor > 0 && tx == hx0 ) || ( nHor > 1 && tx == hx1 ) || ( nHor > 2 && tx == hx2 ) ) continue;
       if( nHor == 0 ) hx0 = tx; else if( nHor == 1 ) hx1 = tx; else hx2 = tx;
       nHor++;
     }
-    const bool fast16 = j.func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
-    const int tile = fast16 ? 16 : 8;
-    __syncthreads();                                                               // the previous stage's readers are done with the tap table
     for( int i = lane; i < 128; i += 64 ) tapL[i] = stageTap( i >> 3, i & 7, j.filter_mode, j.alt_hpel );
-    for( int col0 = 0; col0 < w; col0 += 32 )
+    { const int f = lane >> 2, i = lane & 3; tapP[lane] = i < NP ? pack2( stageTap( f, K0 + 2 * i, j.filter_mode, j.alt_hpel ), stageTap( f, K0 + 2 * i + 1, j.filter_mode, j.alt_hpel ) ) : 0u; }
+    if( lane < 9 ) costL[lane] = 0;
+    const bool fast16 = j.func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
+    const int tile = fast16 ? 16 : 8, tilesX = w / tile, tilesB = tilesX * ( BH / tile );
+    __syncthreads();
+    // ---- H: tmp[v][r][x] <-> plane row y0 + K0 - 4 + r, column x + sx[v]
+    for( int u = lane; u < nHor * rowsT * G; u += 64 )
     {
-      const int tw = w - col0 < 32 ? w - col0 : 32, tw8 = tw >> 3;                   // strip width (8, 16 or 32)
-      __syncthreads();                                                             // tap table written; the previous strip's readers are done with tmp
-      // ---- horizontal pass: tmp[v][r][x] <-> plane row r - 4, column col0 + x + sx[v]   (first pass, 14-bit intermediates)
-      for( int i = lane; i < nHor * rows * tw8; i += 64 )
+      const int x0 = ( u & ( G - 1 ) ) << 3, rr = u >> log2G, v = rr / rowsT, r = rr - v * rowsT;
+      const int txv = v == 0 ? hx0 : ( v == 1 ? hx1 : hx2 ), sxv = txv >> 4, fxv = txv & 15;
+      const int16_t* p = ref + ( ptrdiff_t ) ( y0 + K0 - 4 + r ) * rs + x0 + sxv;
+      u32x4 ov;
+      if( fxv )
       {
-        const int v = i / ( rows * tw8 ), rem = i - v * rows * tw8, r = rem / tw8, x0 = ( rem - r * tw8 ) << 3;
-        const int txv = v == 0 ? hx0 : ( v == 1 ? hx1 : hx2 ), sxv = txv >> 4, fxv = txv & 15;
-        const int16_t* p = ref + ( ptrdiff_t ) ( r - 4 ) * rs + col0 + x0 + sxv;
+        // window samples s[0 .. 6 + NT] = p[K0 - 3 ..]: A = s[0..7] as even pairs W[0..3], B = s[NT - 1 .. NT + 6] as odd pairs S[B0 .. B0 + 3]; the missing pairs by v_alignbit
+        const u32x4 A = ld16( p + K0 - 3 ), B = ld16( p + K0 - 3 + NT - 1 );
+        uint32_t W[4 + NP], S[4 + NP];
+        W[0] = A.x; W[1] = A.y; W[2] = A.z; W[3] = A.w;
+        S[B0] = B.x; S[B0 + 1] = B.y; S[B0 + 2] = B.z; S[B0 + 3] = B.w;
+#pragma unroll
+        for( int m = B0 - 1; m >= 0; m-- ) S[m] = __builtin_amdgcn_alignbit( W[m + 1], W[m], 16 );
+#pragma unroll
+        for( int m = 4; m < 4 + NP - 1; m++ ) W[m] = __builtin_amdgcn_alignbit( S[m], S[m - 1], 16 );
+        uint32_t cp[NP];
+#pragma unroll
+        for( int i = 0; i < NP; i++ ) cp[i] = tapP[fxv * 4 + i];
         uint32_t o[4];
-        if( fxv )
+#pragma unroll
+        for( int q = 0; q < 4; q++ )
         {
-          // window samples K0 - 3 .. K1 + 4 around the 8 outputs: two overlapping 16-byte loads (8 + K1 - K0 <= 15 samples)
-          constexpr int L = 8 + K1 - K0;
-          const u32x4 A = ld16( p + K0 - 3 ), B = ld16( p + K0 - 3 + L - 8 );
-          const uint32_t aw[4] = { A.x, A.y, A.z, A.w }, bw[4] = { B.x, B.y, B.z, B.w };
-          int win[L];
+          int e = off1, d = off1;
 #pragma unroll
-          for( int q = 0; q < 4; q++ ) { win[2 * q] = lo16( aw[q] ); win[2 * q + 1] = hi16( aw[q] ); }
-#pragma unroll
-          for( int q = 0; q < 8; q++ ) if( L - 8 + q >= 8 ) win[L - 8 + q] = ( q & 1 ) ? hi16( bw[q >> 1] ) : lo16( bw[q >> 1] );
-          const int* ch = tapL + fxv * 8;
-          int c[K1 - K0 + 1];
-#pragma unroll
-          for( int k = K0; k <= K1; k++ ) c[k - K0] = ch[k];
-#pragma unroll
-          for( int q = 0; q < 4; q++ )
-          {
-            int s0 = off1, s1 = off1;
-#pragma unroll
-            for( int k = 0; k <= K1 - K0; k++ ) { s0 = __mul24( win[2 * q + k], c[k] ) + s0; s1 = __mul24( win[2 * q + 1 + k], c[k] ) + s1; }
-            o[q] = pack2( ( int ) ( int16_t ) ( s0 >> shift1 ), ( int ) ( int16_t ) ( s1 >> shift1 ) );
-          }
+          for( int i = 0; i < NP; i++ ) { e = dot2( W[q + i], cp[i], e ); d = dot2( S[q + i], cp[i], d ); }
+          o[q] = pack2( e >> shift1, d >> shift1 );
         }
-        else
-        {
-          const u32x4 A = ld16( p );                                                 // filterCopy<true,false>: ( sample << headRoom ) - 8192 (InterpolationFilter.cpp:285-296)
-          const uint32_t aw[4] = { A.x, A.y, A.z, A.w };
-#pragma unroll
-          for( int q = 0; q < 4; q++ ) o[q] = pack2( ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) lo16( aw[q] ) << headRoom ) - 8192 ), ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) hi16( aw[q] ) << headRoom ) - 8192 ) );
-        }
-        u32x4 ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
-        *reinterpret_cast<u32x4*>( tmp + ( v * rows + r ) * tw + x0 ) = ov;
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
       }
-      __syncthreads();
-      // ---- one lane per (position, tile of this strip)
-      const int tilesX = tw / tile, tilesY = h / tile, tilesPerPos = tilesX * tilesY;
-      for( int task = lane; task < 9 * tilesPerPos; task += 64 )
+      else
       {
-        const int k = task / tilesPerPos, t = task - k * tilesPerPos;
-        if( !( ( j.mask >> k ) & 1 ) ) continue;
-        const int tyi = t / tilesX, txi = t - tyi * tilesX;
-        int txk, tyk; stagePos( j, k, txk, tyk );
-        const int hv = txk == hx0 ? 0 : ( txk == hx1 ? 1 : 2 ), syk = tyk >> 4, fyk = tyk & 15;
-        const int16_t* tmpV = tmp + hv * rows * tw;
-        const int* tapV = tapL + fyk * 8;
-        const bool copyV = fyk == 0;
-        const int x0 = txi * tile, y0 = tyi * tile;
-        const int16_t* po = org + ( ptrdiff_t ) y0 * os + col0 + x0;
-        uint32_t val;
-        if( j.func == VVHIP_DF_SAD )
-        {
-          uint32_t sad = 0;
-#pragma unroll 2
-          for( int r = 0; r < 8; r++ )
-          {
-            const u32x4 pr = predRow8<K0, K1>( tmpV, tw, y0 + r, x0, syk, tapV, copyV, pg );
-            const u32x4 o = ld16( po + ( ptrdiff_t ) r * os );
-            sad = __builtin_amdgcn_sad_u16( o.x ^ BIAS, pr.x ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( o.y ^ BIAS, pr.y ^ BIAS, sad );
-            sad = __builtin_amdgcn_sad_u16( o.z ^ BIAS, pr.z ^ BIAS, sad ); sad = __builtin_amdgcn_sad_u16( o.w ^ BIAS, pr.w ^ BIAS, sad );
-          }
-          val = sad;
-        }
-        else if( fast16 )
-        {
-          uint32_t d[32];
+        const u32x4 A = ld16( p );                                                 // filterCopy<true,false>: ( sample << headRoom ) - 8192 (InterpolationFilter.cpp:285-296)
+        const uint32_t aw[4] = { A.x, A.y, A.z, A.w };
+        uint32_t o[4];
 #pragma unroll
-          for( int r = 0; r < 8; r++ )
-          {
-#pragma unroll
-            for( int hf = 0; hf < 2; hf++ )
-            {
-              uint32_t ap0, ap1, ao0, ao1;
-              const u32x4 qa = predRow8<K0, K1>( tmpV, tw, y0 + 2 * r, x0 + 8 * hf, syk, tapV, copyV, pg );
-              const u32x4 qb = predRow8<K0, K1>( tmpV, tw, y0 + 2 * r + 1, x0 + 8 * hf, syk, tapV, copyV, pg );
-              const uint32_t pa[4] = { qa.x, qa.y, qa.z, qa.w }, pb[4] = { qb.x, qb.y, qb.z, qb.w };
-              avg2x2Half( pa, pb, ap0, ap1 );
-              const int16_t* p0 = po + ( ptrdiff_t ) ( 2 * r ) * os + 8 * hf;
-              const u32x4 xa = ld16( p0 ), xb = ld16( p0 + os );
-              const uint32_t oa[4] = { xa.x, xa.y, xa.z, xa.w }, ob[4] = { xb.x, xb.y, xb.z, xb.w };
-              avg2x2Half( oa, ob, ao0, ao1 );
-              d[4 * r + 2 * hf] = pkSub( ao0, ap0 ); d[4 * r + 2 * hf + 1] = pkSub( ao1, ap1 );
-            }
-            __builtin_amdgcn_sched_barrier( 0 );                                     // keep the rows apart: the scheduler otherwise interleaves all sixteen and runs out of registers
-          }
-          const uint32_t s = hadamard64( d );
-          val = ( ( s + 2 ) >> 2 ) << 2;                                             // RdCost.cpp:1218-1222
-        }
-        else
-        {
-          uint32_t d[32];
-#pragma unroll
-          for( int r = 0; r < 8; r++ )
-          {
-            const u32x4 pr = predRow8<K0, K1>( tmpV, tw, y0 + r, x0, syk, tapV, copyV, pg );
-            const u32x4 o = ld16( po + ( ptrdiff_t ) r * os );
-            d[4 * r] = pkSub( o.x, pr.x ); d[4 * r + 1] = pkSub( o.y, pr.y ); d[4 * r + 2] = pkSub( o.z, pr.z ); d[4 * r + 3] = pkSub( o.w, pr.w );
-            __builtin_amdgcn_sched_barrier( 0 );
-          }
-          const uint32_t s = hadamard64( d );
-          val = ( s + 2 ) >> 2;                                                      // RdCost.cpp:1317-1319
-        }
-        atomicAdd( &costL[9 * si + k], val );
+        for( int q = 0; q < 4; q++ ) o[q] = pack2( ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) lo16( aw[q] ) << headRoom ) - 8192 ), ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) hi16( aw[q] ) << headRoom ) - 8192 ) );
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
       }
+      *reinterpret_cast<u32x4*>( tmp + ( v * rowsT + r ) * w + x0 ) = ov;
     }
-  }
-  __syncthreads();
-  for( int i = lane; i < 9 * span.count; i += 64 )
-  {
-    const int si = i / 9, k = i - 9 * si;
-    const int stage = a.stageOrder[span.first + si];
-    if( ( a.stageJobs[stage].mask >> k ) & 1 ) a.stageCost[( size_t ) 9 * stage + k] = costL[i];
+    __syncthreads();
+    // ---- VD: eight lanes per (position, tile), lane r = tile row r
+    for( int u0 = 0; u0 < nPos * tilesB * 8; u0 += 64 )
+    {
+      const int u = u0 + lane, r = u & 7, tt = u >> 3;
+      const bool valid = u < nPos * tilesB * 8;
+      const int pi = valid ? tt / tilesB : 0, t = valid ? tt - pi * tilesB : 0;
+      const int tyi = t / tilesX, txi = t - tyi * tilesX;
+      const int pk = posL[pi], txk = ( ( pk >> 8 ) & 0xfff ) - 64, tyk = ( ( pk >> 20 ) & 0xfff ) - 64;
+      const int hv = txk == hx0 ? 0 : ( txk == hx1 ? 1 : 2 ), syk = tyk >> 4, fyk = tyk & 15;
+      int d[8];
+      if( fast16 )
+      {
+        const int16_t* tv = tmp + hv * rowsT * w + txi * 16;
+        const int16_t* po = org + ( ptrdiff_t ) ( y0 + 2 * r ) * os + txi * 16;
+        const u32x4 c0v = ld16( po ), c1v = ld16( po + 8 ), e0 = ld16( po + os ), e1 = ld16( po + os + 8 );
+        uint32_t pa[4], pb[4]; int ap[4], ao[4];
+        predRow<K0, K1>( tv, w, 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
+        predRow<K0, K1>( tv, w, 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
+        avgInts( pa, pb, ap );
+        { const uint32_t oa[4] = { c0v.x, c0v.y, c0v.z, c0v.w }, ob[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( oa, ob, ao ); }      // RdCost.cpp:1138-1160
+#pragma unroll
+        for( int i = 0; i < 4; i++ ) d[i] = ao[i] - ap[i];
+        predRow<K0, K1>( tv + 8, w, 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
+        predRow<K0, K1>( tv + 8, w, 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
+        avgInts( pa, pb, ap );
+        { const uint32_t oa[4] = { c1v.x, c1v.y, c1v.z, c1v.w }, ob[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( oa, ob, ao ); }
+#pragma unroll
+        for( int i = 0; i < 4; i++ ) d[4 + i] = ao[i] - ap[i];
+      }
+      else
+      {
+        const int16_t* tv = tmp + hv * rowsT * w + txi * 8;
+        const u32x4 ovv = ld16( org + ( ptrdiff_t ) ( y0 + tyi * 8 + r ) * os + txi * 8 );
+        uint32_t pw[4];
+        predRow<K0, K1>( tv, w, tyi * 8 + r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pw );
+        const uint32_t ow[4] = { ovv.x, ovv.y, ovv.z, ovv.w };
+#pragma unroll
+        for( int i = 0; i < 4; i++ ) { d[2 * i] = lo16( ow[i] ) - lo16( pw[i] ); d[2 * i + 1] = hi16( ow[i] ) - hi16( pw[i] ); }
+      }
+      uint32_t sres;
+      if( j.func == VVHIP_DF_SAD )
+      {
+        uint32_t s = 0;
+#pragma unroll
+        for( int i = 0; i < 8; i++ ) s += ( uint32_t ) abs( d[i] );
+        sres = vvhipGroupSum32( s, 8, lane );
+      }
+      else
+      {
+#pragma unroll
+        for( int len = 1; len < 8; len <<= 1 )
+#pragma unroll
+          for( int i = 0; i < 8; i += 2 * len )
+#pragma unroll
+            for( int q = i; q < i + len; q++ ) { const int x = d[q], z = d[q + len]; d[q] = x + z; d[q + len] = x - z; }
+#define ME_VSTAGE( CTRL, BIT ) { const bool upper = ( r & ( BIT ) ) != 0; _Pragma( "unroll" ) \
+        for( int i = 0; i < 8; i++ ) { const int o = VVHIP_DPP( d[i], CTRL ); d[i] = upper ? o - d[i] : d[i] + o; } }
+        ME_VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
+        ME_VSTAGE( VVHIP_DPP_XOR2, 2 )
+        ME_VSTAGE( VVHIP_DPP_XOR1, 1 )
+#undef ME_VSTAGE
+        uint32_t s = 0;
+#pragma unroll
+        for( int i = 0; i < 8; i++ ) s += ( uint32_t ) abs( d[i] );
+        if( r == 0 ) { const uint32_t dc = ( uint32_t ) abs( d[0] ); s = s - dc + ( dc >> 2 ); }
+        s = vvhipGroupSum32( s, 8, lane );
+        sres = fast16 ? ( ( s + 2 ) >> 2 ) << 2 : ( s + 2 ) >> 2;                  // RdCost.cpp:1218-1222 / 1317-1319
+      }
+      if( valid && r == 0 ) atomicAdd( &costL[pk & 0xff], sres );
+    }
+    __syncthreads();
+    // the unit's share of the stage's costs (blocks of one band: the only share)
+    if( lane < 9 && ( ( j.mask >> lane ) & 1 ) )
+    {
+      if( h <= 16 ) a.stageCost[( size_t ) 9 * stage + lane] = costL[lane];
+      else atomicAdd( reinterpret_cast<unsigned long long*>( a.stageCost ) + ( size_t ) 9 * stage + lane, ( unsigned long long ) costL[lane] );
+    }
   }
 }
 
@@ -566,10 +596,10 @@ meStageKernel( MePlanes P, MeArgs a, int firstWave )
 }
 
 __global__ void __launch_bounds__( 64 )
-meIntKernel( MePlanes P, MeArgs a )
+meIntKernel( MePlanes P, MeArgs a, int firstWave )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t meLds[];
-  intBody( P, a, blockIdx.x, meLds );
+  intBody( P, a, firstWave + blockIdx.x, meLds );
 }
 
 __global__ void __launch_bounds__( 64 )
@@ -627,11 +657,16 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
       ldsInt = std::max( ldsInt, ( j.winH * hostWinPitch( j.winW ) + ( s.height >> s.sub_shift ) * s.width ) * 2 );
     }
   }
-  // heaviest windows first
-  std::stable_sort( ij.begin(), ij.end(), []( const IntJob& a, const IntJob& b ) { return ( long ) a.nCand * a.w * ( a.h >> a.subShift ) + ( long ) a.winW * a.winH > ( long ) b.nCand * b.w * ( b.h >> b.subShift ) + ( long ) b.winW * b.winH; } );
+  // windows that need much LDS first (their own launch), inside each class heaviest first
+  auto ldsOf = []( const IntJob& j ) { return ( j.winH * hostWinPitch( j.winW ) + ( j.h >> j.subShift ) * j.w ) * 2; };
+  const int ldsSmallCap = 6 * 1024;
+  std::stable_sort( ij.begin(), ij.end(), [&]( const IntJob& a, const IntJob& b ) { const bool ba = ldsOf( a ) > ldsSmallCap, bb = ldsOf( b ) > ldsSmallCap; if( ba != bb ) return ba;
+                    return ( long ) a.nCand * a.w * ( a.h >> a.subShift ) + ( long ) a.winW * a.winH > ( long ) b.nCand * b.w * ( b.h >> b.subShift ) + ( long ) b.winW * b.winH; } );
+  int intBig = 0, ldsIntSmall = 0;
+  for( const IntJob& j : ij ) { if( ldsOf( j ) > ldsSmallCap ) intBig++; else ldsIntSmall = std::max( ldsIntSmall, ldsOf( j ) ); }
 
-  // ---- stage bundles: stages of one block size, ~64 (position, tile) tasks per pass
-  std::vector<int32_t> stOrder( n_stage_jobs ); std::vector<WaveSpan> stWaves;
+  // ---- stage units: (stage, band of <= 16 rows); a wave takes a bundle of units of one block width and tap support worth ~320 second-pass row groups
+  std::vector<WaveSpan> stWaves;
   int ldsStage = 0;
   for( int i = 0; i < n_stage_jobs; i++ )
   {
@@ -639,27 +674,28 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     if( !squareOk( s.width, s.height, 8 ) || s.org_plane > 15 || s.ref_plane > 15 || ( s.i_frac != 1 && s.i_frac != 2 ) || s.filter_mode > 2 ||
         ( s.func != VVHIP_DF_SAD && s.func != VVHIP_DF_HAD && s.func != VVHIP_DF_HAD_FAST ) || s.base_qx < -3 || s.base_qx > 3 || s.base_qy < -3 || s.base_qy > 3 || ( s.mask >> 9 ) )
       return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: stage job %d (%dx%d, iFrac %d, mode %d, func %d)", i, s.width, s.height, s.i_frac, s.filter_mode, s.func );
-    stOrder[i] = i;
   }
-  auto tasksOf = [&]( const vvhip_me_stage_job& s ) { const bool f16 = s.func == VVHIP_DF_HAD_FAST && ( s.width & 31 ) == 0; const int t = f16 ? 16 : 8; return __builtin_popcount( s.mask ) * ( s.width / t ) * ( s.height / t ); };
   auto setOf = []( const vvhip_me_stage_job& s ) { return ( s.filter_mode == 2 && !s.alt_hpel ) ? 0 : ( s.filter_mode == 0 ? 2 : 1 ); };      // which tap support the bundle's kernel instance uses
-  std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a]; const auto& y = stage_jobs[b];
-                    return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( x.width != y.width ? x.width > y.width : tasksOf( x ) > tasksOf( y ) ); } );
+  auto unitWork = [&]( const vvhip_me_stage_job& s ) { return __builtin_popcount( s.mask ) * ( s.width / 8 ) * std::min( ( int ) s.height, 16 ); };      // 8-sample row groups of the second pass
+  std::vector<int32_t> stOrder;
+  for( int i = 0; i < n_stage_jobs; i++ ) if( stage_jobs[i].mask ) for( int b = 0; b < ( stage_jobs[i].height + 15 ) / 16; b++ ) stOrder.push_back( i | ( b << 24 ) );
+  std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & 0xffffff]; const auto& y = stage_jobs[b & 0xffffff];
+                    return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( x.width != y.width ? x.width > y.width : unitWork( x ) > unitWork( y ) ); } );
   int setWaves[3] = { 0, 0, 0 };
-  for( int i = 0; i < n_stage_jobs; )
+  for( size_t i = 0; i < stOrder.size(); )
   {
-    const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i]];
-    int count = 0, tasks = 0;
-    while( i + count < n_stage_jobs && count < 8 )
+    const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i] & 0xffffff];
+    int count = 0, work = 0;
+    while( i + count < stOrder.size() && count < 8 )
     {
-      const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count]];
-      if( s.width != s0.width || setOf( s ) != setOf( s0 ) || ( count && tasks + tasksOf( s ) > 64 ) ) break;
-      tasks += tasksOf( s ); count++;
+      const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count] & 0xffffff];
+      if( s.width != s0.width || setOf( s ) != setOf( s0 ) || ( count && work + unitWork( s ) > 320 ) ) break;
+      work += unitWork( s ); count++;
     }
-    WaveSpan sp; sp.first = i; sp.count = count; stWaves.push_back( sp );
+    WaveSpan sp; sp.first = ( int32_t ) i; sp.count = count; stWaves.push_back( sp );
     setWaves[setOf( s0 )]++;
-    const int tw = std::min( ( int ) s0.width, 32 );
-    ldsStage = std::max( ldsStage, ( 2 * ( 72 + 128 ) + 3 * ( s0.height + 8 ) * tw ) * 2 );      // cost sums + tap table + three first-pass strips
+    const int bh = std::min( ( int ) s0.height, 16 ), nt = setOf( s0 ) == 0 ? 4 : ( setOf( s0 ) == 1 ? 6 : 8 );
+    ldsStage = std::max( ldsStage, ( 2 * ( 128 + 64 + 16 + 16 ) + 3 * ( bh + nt ) * s0.width ) * 2 );      // tables + three first-pass bands
     i += count;
   }
 
@@ -682,7 +718,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     if( s0.func == VVHIP_DF_SAD || s0.func == VVHIP_DF_SSE ) { const int cw = s0.width >= 8 ? 8 : 4; lanesPer = ( s0.height >> ( s0.func == VVHIP_DF_SAD ? s0.sub_shift : 0 ) ) * ( s0.width / cw ); }
     else { const bool f16 = s0.func == VVHIP_DF_HAD_FAST && ( s0.width & 31 ) == 0; const int t = s0.width == 4 ? 4 : ( f16 ? 16 : 8 ); lanesPer = ( s0.width / t ) * ( s0.height / t ); }
     if( lanesPer > 64 ) lanesPer = 64;
-    const int perWave = std::max( 1, 64 / lanesPer ) * 4;            // four passes of lane teams per wave
+    const int perWave = std::max( 1, 64 / lanesPer );                // one pass of lane teams per wave: the items are latency-bound, waves are what overlaps them
     int count = 0;
     while( i + count < n_items && count < perWave && itemKey( itOrder[i + count] ) == itemKey( itOrder[i] ) ) count++;
     WaveSpan sp; sp.first = i; sp.count = count; itWaves.push_back( sp );
@@ -714,6 +750,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size();
   p->ldsInt = ( ldsInt + 15 ) & ~15; p->ldsStage = ( ldsStage + 15 ) & ~15;
   for( int k = 0; k < 3; k++ ) p->stageSetWaves[k] = setWaves[k];
+  p->intBig = intBig; p->ldsIntSmall = ( ldsIntSmall + 15 ) & ~15;
   if( p->ldsInt > 64 * 1024 || p->ldsStage > 64 * 1024 )
   { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_me_plan_create: %d / %d bytes of LDS per wave (max_window too large?)", ldsInt, ldsStage ); }
   *out = p;
@@ -751,13 +788,16 @@ int vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me
   a.stageWaves = static_cast<const WaveSpan*>( plan->d_stageWaves ); a.wavesStage = plan->wavesStage;
   a.items = static_cast<const vvhip_me_item*>( plan->d_items ); a.itemOrder = static_cast<const int32_t*>( plan->d_itemOrder ); a.itemWaves = static_cast<const WaveSpan*>( plan->d_itemWaves ); a.wavesItem = plan->wavesItem;
   a.candCost = d_cand_cost; a.stageCost = d_stage_cost; a.itemCost = d_item_cost; a.bitDepth = plan->bitDepth;
+  // blocks taller than 16 rows are scored band by band (integer atomic adds into the cost array): it starts from zero
+  if( plan->nStages ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_stage_cost, 0, ( size_t ) 9 * plan->nStages * sizeof( uint64_t ), ctx->stream ) );
   int firstWave = 0;
   if( plan->stageSetWaves[0] ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) plan->stageSetWaves[0] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
   firstWave += plan->stageSetWaves[0];
   if( plan->stageSetWaves[1] ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) plan->stageSetWaves[1] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
   firstWave += plan->stageSetWaves[1];
   if( plan->stageSetWaves[2] ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) plan->stageSetWaves[2] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
-  if( plan->wavesInt )   hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->wavesInt ), dim3( 64 ), ( size_t ) plan->ldsInt, ctx->stream, P, a );
+  if( plan->intBig )                  hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->intBig ), dim3( 64 ), ( size_t ) plan->ldsInt, ctx->stream, P, a, 0 );
+  if( plan->wavesInt > plan->intBig ) hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( plan->wavesInt - plan->intBig ) ), dim3( 64 ), ( size_t ) plan->ldsIntSmall, ctx->stream, P, a, plan->intBig );
   if( plan->wavesItem )  hipLaunchKernelGGL( meItemKernel, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
