@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py — frames/sec of the MI355X hot path (BASELINE.json metric) with roofline, in-run parity, the MCTF stage, a 4K pass, the end-to-end encoder and the CPU baseline.
+"""bench.py — pictures/sec of the MI355X hot path on work lists RECORDED from the reference encoder, with a physical roofline, in-run parity against the encoder's own
+values, the MCTF stage, the end-to-end encoder (1080p and 4K) and the CPU baseline.
 
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
-`value` (the headline, BASELINE configs[1] "SAD/SATD + DCT batch"): a step = one pass of the hot path over one synthetic 1920x1080 10-bit picture
-(vvenc_amd/workload.py: 11 SAD + 8 HAD_fast + 1 SSE candidates per 8/16/32/64 block and the fused xT -> quant -> dequant -> xIT -> SSE pipeline over the 8/16/32 TU
-tilings = the per-frame totals measured on the reference), three launches, inputs resident in HBM.  With N GPUs every rank works on a DIFFERENT picture of one
-sequence; the reference picture of step s+1 is published by its owner to every rank (RCCL broadcast of luma + chroma over xGMI, vvenc_amd/sharding.PictureExchange) inside
-the timed region, overlapped with the kernels of step s: value = N*K pictures / max-over-ranks time, "scaling": "weak".
+`value` (BASELINE configs[1]): a step = ONE picture's hot-path work exactly as the reference encoder produced it.  Before the clock starts the encoder built with the
+binding (bindings/vvenc) encodes the 1920x1080 10-bit config-2 clip (65 frames, preset faster) on its CPU kernels with the work-list recorder on (hook bit 131072): every call
+through RdCost's table, every InterSearch::xMotionEstimation with its integer candidates and xPatternRefinement stages, every TU of TrQuant::xT with its residual, every DMVR
+sub-block — for one picture of each temporal layer.  The lists + the pictures' planes are uploaded once; step s replays the picture whose layer POC s mod 32 has in the
+encoder's GOP (1 x TL0 (intra), 1 x TL1, 2 x TL2, 4 x TL3, 8 x TL4, 16 x TL5 per 32 steps):
+    motion-search plan   integer candidates (LDS windows) + sub-pel refinement stages (interpolation fused with the Hadamard) + merge / AMVP / intra / SSE table calls
+    TU lists             fused xT -> needRdoq -> quant -> dequant -> xIT -> SSE, luma + chroma, DCT-2 / DST-7, 4..64
+    DMVR lists           bilinear prediction + 25-point search + error surface per sub-block
+on three HIP streams.  With N GPUs rank r takes steps r, r + N, ... of the same cycle; the reconstructed picture a sharded encoder would hand to the ranks encoding the
+pictures that reference it is broadcast (RCCL) every --exchange-every steps inside the timed region, overlapped; value = N * K pictures / max-over-ranks time, "weak".
 
-Extra objects of the same JSON line (rank 0; each can be switched off, each failure is reported in place and never costs the headline):
-  roofline      dominant kernel class: algorithmic bytes per launch / HIP-event launch time (the per-candidate figure of SURVEY §8d, labelled nominal), the same time against the
-                L2 ceiling (frac_l2), the unique bytes of the launch against HBM (frac_hbm_unique), and counter traffic per launch (FETCH_SIZE x2 + WRITE_SIZE, collected
-                by this run's own rocprofv3 --pmc passes when rocprofv3 is there, else read from the committed profile)
-  parity        every output of the timed launches (all distortion candidates, every TU's SSE / abs-sum) compared with the reference's x86-SIMD table entries on the same
-                lists, and one MCTF motion field with the oracle: "bit-exact" or the mismatch count
-  mctf          BASELINE configs[2] stage at 1080p: hierarchical ME against 4 references + bilateral filter of Y, U, V; ms per picture, critical-path bound
-  pass_4k       the same three launches + the MCTF stage on a 3840x2160 picture (configs[2] geometry)
-  kernel_trace  rocprofv3 --kernel-trace of a short inner run (per-kernel average durations, incl. the MCTF kernels)
-  e2e           the real reference encoder, 1080p x 65 frames, preset faster: CPU kernels vs --SIMD=HIP (whole-picture stages on the device), fps + bitstream md5 equality
-  cpu_baseline  the reference's own AVX2 table entries on the host cores over the same work lists (thread sweep, dynamic chunking), or the scalar C port
+Extra objects of the JSON line (rank 0; each can be switched off; a failure is reported in place and never costs the headline):
+  roofline      dominant kernel: PHYSICAL position — HBM traffic per launch from this run's own rocprofv3 --pmc passes / HIP-event launch time / 8 TB/s — next to the L1 access
+                and VALU issue fractions that actually bound these kernels; the nominal per-candidate figure of SURVEY 8d is kept as nominal_alg_GBps
+  kernels       every kernel of a step: launches and average duration per layer and GOP-weighted, algorithmic bytes
+  parity        every value the timed launches produced against (a) the costs the REAL encoder computed while it was recorded and (b) the reference's x86-SIMD entries
+                driven over the same TU lists (SSE, abs sums, last scan positions, need-RDOQ flags, level checksums): "bit-exact" or the mismatch count
+  mctf          BASELINE configs[2] stage at 1080p and 4K: hierarchical ME against 4 references + bilateral filter, ms per picture
+  e2e / e2e_4k  the real encoder, 1080p x 65 and 3840x2160 x 65, preset faster: CPU kernels vs --SIMD=HIP, fps + bitstream md5 equality
+  cpu_baseline  the reference's own AVX2 entries on the host cores over the same recorded lists (one pass per layer, GOP-weighted)
 """
 import argparse
 import ctypes as C
@@ -34,58 +38,160 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from vvenc_amd import sharding  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-L2_PEAK_GBS = 34500.0    # aggregate L2 bandwidth of the 8 XCDs, same guide (L2 section)
-KERNEL_OF_CLASS = {"SAD_SSE": "sadSseMixedKernel", "HAD_fast": "hadTile8PkMultiKernel<false>", "TU": "tuMxMultiKernel<false>"}
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+CLOCK_GHZ, N_CU, N_SIMD = 2.4, 256, 1024
+LAYER_POCS = {0: 31, 1: 15, 2: 23, 3: 3, 4: 5, 5: 2}          # one recorded picture per temporal layer of the 65-frame encode (its GOP anchors at POC 31 / 63)
+KERNEL_NAMES = {"ME_stage": "meStageKernel", "ME_int": "meIntKernel", "ME_item": "meItemKernel", "TU": "tuMxMultiKernel", "DMVR": "dmvrRefineKernel"}
 
 
-class EventTimers:
-    """HIP events on the launch stream (torch's current stream == the context's stream) bracketing each kernel CLASS once per
-    step (its launches are issued back to back).  Events are pre-allocated: nothing is created inside the timed region."""
-
-    def __init__(self, classes, steps, launches_per_class):
-        self.launches_per_class = launches_per_class
-        self.pool = {k: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] for k in classes}
-        self.idx = {k: 0 for k in classes}
-
-    def start(self, key, stream=None):
-        if key in self.pool:
-            self.pool[key][self.idx[key]][0].record(stream) if stream is not None else self.pool[key][self.idx[key]][0].record()
-
-    def stop(self, key, stream=None):
-        if key in self.pool:
-            self.pool[key][self.idx[key]][1].record(stream) if stream is not None else self.pool[key][self.idx[key]][1].record()
-            self.idx[key] += 1
-
-    def summary(self):
-        out = {}
-        for k, lst in self.pool.items():
-            ms = [a.elapsed_time(b) for a, b in lst[:self.idx[k]]]
-            nl = max(1, len(ms) * self.launches_per_class[k])
-            out[k] = {"launches": nl, "total_ms": float(sum(ms)), "avg_ms": float(sum(ms) / nl)}
-        return out
+def layer_of_step(s):
+    """temporal layer of POC s mod 32 in the recorded encode's GOP structure"""
+    p = s % 32
+    if p == 31:
+        return 0
+    for layer, mod in ((1, 16), (2, 8), (3, 4), (4, 2)):
+        if p % mod == mod - 1:
+            return layer
+    return 5
 
 
-def timed_ms(fn, reps, warm=1):
-    """average wall-clock ms of fn() on the current stream, HIP events"""
-    for _ in range(warm):
-        fn()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps
+GOP_WEIGHT = {l: sum(1 for s in range(32) if layer_of_step(s) == l) for l in range(6)}
 
 
-# ------------------------------------------------------------------------------------------------------------------------ CPU side
+# ---------------------------------------------------------------------------------------------------------------------- recording
+def prepare_recordings(width, height, frames, pocs, tag="faster", threads=8):
+    """the recorded lists of the pictures `pocs` (cached under /tmp: the rocprofv3 passes and later runs reuse them)"""
+    from vvenc_amd import recorded as R
+    d = os.path.join("/tmp", "vvhip_rec_%dx%d_%d_%s" % (width, height, frames, tag))
+    info = {"dir": d, "recorded_now": False}
+    need = [p for p in pocs if not os.path.exists(os.path.join(d, "poc%d.json" % p))]
+    if need:
+        t0 = time.perf_counter()
+        res = R.record(d, width, height, frames, pocs=need, threads=threads, preset=tag)
+        info.update(recorded_now=True, record_s=round(time.perf_counter() - t0, 2), encoder_md5=res["md5"], encoder_s=round(res["secs"], 2))
+    return {p: R.RecordedPicture(os.path.join(d, "poc%d" % p)) for p in pocs}, info
+
+
+# ---------------------------------------------------------------------------------------------------------------------- reference twin (parity + CPU baseline)
+class RecJob(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("df", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("subShift", C.c_int32), ("trHor", C.c_int32), ("trVer", C.c_int32), ("n", C.c_int32),
+                ("org", C.c_void_p), ("cur", C.c_void_p), ("orgStride", C.c_int32), ("curStride", C.c_int32), ("items", C.c_void_p), ("aux", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p)]
+
+
+REC_STAGE = np.dtype([("org_off", "<i4"), ("ref_off", "<i4"), ("base_qx", "i1"), ("base_qy", "i1"), ("i_frac", "u1"), ("filter_mode", "u1"), ("alt_hpel", "u1"), ("had_mode", "u1"), ("mask", "<u2")])
+
+
+class ReferenceJobs:
+    """a recorded picture's lists as job records of oracle/_ref's multi-threaded driver (vvref_run_recorded_mt): the reference's own x86-SIMD table entries on host copies of
+    the same planes, pool and lists the device replays.  Test infrastructure: used by the parity check and the cpu_baseline leg only."""
+
+    def __init__(self, wl, with_outputs):
+        from oracle import oracle as O
+        self.L = O.RefLib(1).L
+        self.L.vvref_run_recorded_mt.restype = C.c_double
+        self.L.vvref_run_recorded_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        wl = getattr(wl, "lists", wl)                       # the HOST lists (vvenc_amd.replay.RecordedLists) of a device workload
+        self.wl, self.keep, jobs = wl, [], []
+        host_planes = [pl.storage for pl in wl.planes]
+        pool = wl.pool
+
+        def base(idx):
+            if idx < wl.n_pic_planes:
+                pl = wl.planes[idx]
+                return host_planes[idx].ctypes.data + 2 * pl.origin, pl.stride
+            w = [k for k, v in wl.pool_plane.items() if v == idx][0]
+            return pool.ctypes.data, w
+        df_of = {0: 0, 1: 8, 2: 16, 3: 26, 4: 24}          # C ABI function code -> DFunc base of the reference's table (TypeDef.h:339-382)
+        # integer candidates + plain table calls as distortion lists grouped by (function, size, subShift, operand planes)
+        ij, pc = wl.int_jobs, wl.plan_cands
+        recs = []
+        if pc.size:
+            jidx = np.repeat(np.arange(ij.size), ij["n_cand"])
+            ref_stride = np.array([base(int(p))[1] for p in ij["ref_plane"]], np.int64)
+            cur_off = ij["ref_off"][jidx].astype(np.int64) + pc["dy"].astype(np.int64) * ref_stride[jidx] + pc["dx"]
+            recs.append(np.stack([np.full(pc.size, 1), ij["width"][jidx], ij["sub_shift"][jidx], ij["org_plane"][jidx], ij["ref_plane"][jidx], ij["org_off"][jidx], cur_off], 1).astype(np.int64))
+        it = wl.items
+        if it.size:
+            recs.append(np.stack([it["func"], it["width"], it["sub_shift"], it["org_plane"], it["cur_plane"], it["org_off"], it["cur_off"]], 1).astype(np.int64))
+        self.dist_groups = []
+        if recs:
+            allr = np.concatenate(recs)
+            key = allr[:, :5]
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            inv = inv.ravel()
+            for g, (func, w, ss, po, pcu) in enumerate(uniq):
+                sel = np.nonzero(inv == g)[0]
+                items = np.ascontiguousarray(allr[sel][:, 5:7].astype(np.int32))
+                out = np.zeros(sel.size, np.uint64) if with_outputs else None
+                (ob, os_), (cb, cs) = base(int(po)), base(int(pcu))
+                if int(func) == 4:
+                    # HAD_2SAD's SAD part assumes compact, 32-byte aligned operands (CHECKD + _mm256_load_si256, x86/RdCostX86.h:2556-2600; the encoder calls it on IntraSearch's
+                    # compact buffers): gather both operands of the list into aligned compact buffers for the reference entry
+                    w_ = int(w)
+                    yy, xx = np.mgrid[0:w_, 0:w_]
+
+                    def gather(pidx, offs):
+                        if pidx < wl.n_pic_planes:
+                            pl = wl.planes[pidx]
+                            flat, o0, st = pl.storage.reshape(-1), pl.origin, pl.stride
+                        else:
+                            flat, o0, st = pool, 0, w_
+                        idx = (o0 + offs.astype(np.int64))[:, None, None] + yy[None] * st + xx[None]
+                        buf = np.zeros(sel.size * w_ * w_ + 32, np.int16)
+                        shift = (-buf.ctypes.data // 2) % 16                     # first sample at a 32-byte boundary
+                        buf[shift:shift + sel.size * w_ * w_] = flat[idx].reshape(-1)
+                        self.keep.append(buf)
+                        return buf.ctypes.data + 2 * shift
+                    ob, cb = gather(int(po), items[:, 0]), gather(int(pcu), items[:, 1])
+                    os_ = cs = w_
+                    items = np.ascontiguousarray(np.stack([np.arange(sel.size) * w_ * w_] * 2, 1).astype(np.int32))
+                self.keep += [items, out]
+                self.dist_groups.append((sel, out))
+                jobs.append(RecJob(0, df_of[int(func)], int(w), int(w), int(ss), 0, 0, sel.size, ob, cb, os_, cs, items.ctypes.data, None, out.ctypes.data if out is not None else None, None))
+        self.n_cands = int(pc.size)
+        # TU lists
+        self.tu_outs = []
+        for g in wl.tu_groups:
+            off = np.ascontiguousarray(g["off"])
+            qf = np.ascontiguousarray(g["qf"])
+            out = np.zeros(g["n"], np.uint64) if with_outputs else None
+            out2 = np.zeros((g["n"], 4), np.int32) if with_outputs else None
+            self.keep += [off, qf, out, out2]
+            self.tu_outs.append((out, out2))
+            jobs.append(RecJob(1, 0, g["w"], g["h"], 0, g["tr_hor"], g["tr_ver"], g["n"], pool.ctypes.data, None, g["w"], 0, off.ctypes.data, qf.ctypes.data,
+                               out.ctypes.data if out is not None else None, out2.ctypes.data if out2 is not None else None))
+        # refinement stages grouped by (size, planes)
+        sj = wl.stage_jobs
+        self.stage_groups = []
+        if sj.size:
+            key = np.stack([sj["width"], sj["org_plane"], sj["ref_plane"]], 1).astype(np.int64)
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            inv = inv.ravel()
+            for g, (w, po, pr) in enumerate(uniq):
+                sel = np.nonzero(inv == g)[0]
+                st = np.zeros(sel.size, REC_STAGE)
+                for f in ("org_off", "ref_off", "base_qx", "base_qy", "i_frac", "filter_mode", "alt_hpel", "mask"):
+                    st[f] = sj[f][sel]
+                st["had_mode"] = np.array([0, 0, 1, 2, 0], np.uint8)[sj["func"][sel]]          # SSE(unused) / SAD -> 0, HAD -> 1, HAD_fast -> 2
+                out = np.zeros((sel.size, 9), np.uint64) if with_outputs else None
+                (ob, os_), (cb, cs) = base(int(po)), base(int(pr))
+                self.keep += [st, out]
+                self.stage_groups.append((sel, out))
+                jobs.append(RecJob(2, 0, int(w), int(w), 0, 0, 0, sel.size, ob, cb, os_, cs, st.ctypes.data, None, out.ctypes.data if out is not None else None, None))
+        self.arr = (RecJob * max(1, len(jobs)))(*jobs)
+        self.n = len(jobs)
+
+    def run(self, threads, passes):
+        return self.L.vvref_run_recorded_mt(self.arr, self.n, self.wl.bit_depth, threads, passes)
+
+
 def host_cpu_info():
     info = {"os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
     for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
@@ -96,307 +202,198 @@ def host_cpu_info():
     return info
 
 
-class RefJobs:
-    """the frame's work lists as job records of oracle/_ref's multi-threaded driver (vvref_run_jobs_mt): the reference's own x86-SIMD table entries"""
-
-    class FrameJob(C.Structure):
-        _fields_ = [("kind", C.c_int32), ("df", C.c_int32), ("size", C.c_int32), ("subShift", C.c_int32),
-                    ("items", C.c_void_p), ("aux", C.c_void_p), ("n", C.c_int32), ("pad", C.c_int32), ("out", C.c_void_p)]
-
-    def __init__(self, wl, with_outputs):
-        from oracle import oracle as O
-        self.R = O.RefLib(1)
-        self.L = self.R.L
-        self.wl = wl
-        self.org = np.ascontiguousarray(wl.org.storage.cpu().numpy())
-        self.ref = np.ascontiguousarray(wl.ref.storage.cpu().numpy())
-        self.resi = np.ascontiguousarray(wl.resi.storage.cpu().numpy())
-        self.keep, jobs, self.outs = [], [], []
-        for (func, S, ss, n, _, _, items) in wl.dist_jobs:
-            it = np.ascontiguousarray(items)
-            o = np.zeros(n, np.uint64) if with_outputs else None
-            self.keep.append(it)
-            self.outs.append(o)
-            jobs.append(self.FrameJob(0, self.R._df[func], S, ss, it.ctypes.data, None, n, 0, o.ctypes.data if o is not None else None))
-        for (S, n, _, _, _, _, _, off, qps) in wl.tu_jobs:
-            o_ = np.ascontiguousarray(off)
-            qf = np.zeros((n, 2), np.int16)
-            qf[:, 0] = qps
-            qf[:, 1] = 2
-            o = np.zeros(n, np.uint64) if with_outputs else None
-            self.keep += [o_, qf]
-            self.outs.append(o)
-            jobs.append(self.FrameJob(1, 0, S, 0, o_.ctypes.data, qf.ctypes.data, n, 0, o.ctypes.data if o is not None else None))
-        self.arr = (self.FrameJob * len(jobs))(*jobs)
-        self.n = len(jobs)
-        self.L.vvref_run_jobs_mt.restype = C.c_double
-        self.L.vvref_run_jobs_mt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
-
-    def run(self, threads, passes):
-        wl = self.wl
-        return self.L.vvref_run_jobs_mt(self.org.ctypes.data + 2 * wl.org.origin, wl.org.stride, self.ref.ctypes.data + 2 * wl.ref.origin, wl.ref.stride,
-                                        self.resi.ctypes.data, wl.resi.stride, wl.bit_depth, self.arr, self.n, threads, passes)
+def usable_cores(info):
+    n = info["affinity"]
+    q = info.get("cgroup_cpu.max", "")
+    try:
+        a, b = q.split()
+        if a != "max":
+            n = min(n, max(1, int(int(a) / int(b))))
+    except Exception:
+        pass
+    return n
 
 
-def cpu_baseline(wl, budget_s=12.0):
-    """Times the CPU path on the host cores over the SAME work lists and scales to frames/sec.
-    kind "reference": the reference's own x86-SIMD (AVX2) table entries — oracle/_ref/libvvenc_ref.so, compiled from /root/reference — driven by std::threads inside
-    the library that pull 256-item chunks from one atomic counter (no Python, no allocation in the timed loop), every kernel class and size;
-    kind "port": oracle/liboracle.so (scalar C restatement, one core, distortion lists only) when the reference build is absent."""
+def cpu_baseline(workloads):
+    """the reference's own x86-SIMD (AVX2) entries over the SAME recorded lists on the host cores: one warm pass + one timed pass per layer, GOP-weighted pictures/s"""
     from oracle import oracle as O
     info = host_cpu_info()
-    cores = info["affinity"]
-    if O.RefLib.available():
-        J = RefJobs(wl, with_outputs=False)
-        out = {}
-        cand = sorted({1, min(cores, 8), min(cores, 16), min(cores, 32), min(cores, 64), cores})
-        for threads in cand:                               # thread-count sweep: report the best the host can do
-            dt1 = J.run(threads, 1)
-            passes = int(max(1, min(2000, (budget_s / (2.0 * len(cand))) / max(dt1, 1e-4))))
-            dt = J.run(threads, passes)
-            out[threads] = (passes / dt, passes, dt)
-        best = max(out, key=lambda t: out[t][0])
-        fps, passes, dt = out[best]
-        one = out[1][0]
-        return {"value": fps, "unit": "frames/s", "cores": best, "kind": "reference", "host": info,
-                "sweep_fps": {str(t): round(out[t][0], 2) for t in cand},
-                "parallel_efficiency": {str(t): round(out[t][0] / (one * t), 3) for t in cand},
-                "sample": "%d full passes over one frame's work lists (every kernel class, all block sizes) on %d std::threads in %.1f s wall; "
-                          "reference x86-SIMD (AVX2) table entries called back-to-back, 256-item chunks from one atomic counter; best of a thread-count sweep" % (passes, best, dt),
-                "scaling_note": "threads beyond what the sweep's efficiency column supports do not help: the lists are memory-side work on ~25 MB of planes and index lists per pass, "
-                                "and the lease's usable cores are what `host` shows (affinity / cgroup quota), not os.cpu_count()"}
-    orc = O.Oracle()
-    L = orc.L
-    L.orc_dist_batch.restype = None
-    L.orc_dist_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-    fidx = {"SSE": 0, "SAD": 1, "HAD": 2, "HAD_fast": 3}
-    org = np.ascontiguousarray(wl.org.storage.cpu().numpy())
-    ref = np.ascontiguousarray(wl.ref.storage.cpu().numpy())
-    frac = 0.05
-    t0 = time.perf_counter()
-    for (func, S, ss, n, _, _, items) in wl.dist_jobs:
-        m = max(1, int(n * frac))
-        sl = np.ascontiguousarray(items[:m])
-        outb = np.zeros(m, np.uint64)
-        L.orc_dist_batch(fidx[func], org.ctypes.data + 2 * wl.org.origin, wl.org.stride, ref.ctypes.data + 2 * wl.ref.origin, wl.ref.stride, S, S, ss, sl.ctypes.data, m, outb.ctypes.data)
-    dt = time.perf_counter() - t0
-    return {"value": frac / dt, "unit": "frames/s", "cores": 1, "kind": "port", "host": info,
-            "sample": "%.0f%% of one frame's distortion work lists (transform/quant not included) through the scalar C oracle, 1 thread, %.1f s" % (100 * frac, dt)}
+    if not O.RefLib.available():
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "oracle/_ref (the compiled reference) is not built", "host": info}
+    cores = usable_cores(info)
+    per_layer, t_all = {}, time.perf_counter()
+    for layer, wl in workloads.items():
+        J = ReferenceJobs(wl, with_outputs=False)
+        dt = J.run(cores, 1)
+        per_layer[layer] = dt
+        del J
+    tot_w = sum(GOP_WEIGHT[l] for l in per_layer)
+    sec_per_pic = sum(GOP_WEIGHT[l] * per_layer[l] for l in per_layer) / tot_w
+    return {"value": 1.0 / sec_per_pic, "unit": "frames/s", "cores": cores, "kind": "reference", "host": info,
+            "seconds_per_picture_by_layer": {str(l): round(v, 4) for l, v in per_layer.items()},
+            "sample": "one full pass (after a warm-up pass) over every recorded list of one picture per temporal layer — integer SAD candidates, sub-pel refinement stages "
+                      "(one first pass per horizontal position like xPatternRefinement, then second pass + Hadamard per evaluated position), merge / AMVP / intra / SSE table "
+                      "calls, the fused TU pipeline's twin — through the reference's x86-SIMD (AVX2) entries on %d std::threads pulling chunks from one atomic counter; "
+                      "GOP-weighted over the layers; %.1f s wall in total; DMVR lists not included" % (cores, time.perf_counter() - t_all)}
 
 
-def parity_check(hp, wl, mctf=None):
-    """every result of the launches this run timed against the CPU reference on the same lists (bit-exact or counted)"""
+def parity_check(workloads):
+    """(a) device vs the values the real encoder computed while the lists were recorded; (b) device TU results vs the reference's x86-SIMD entries on the same lists"""
     from oracle import oracle as O
-    res = {"status": None, "checked": {}, "mismatches": 0}
-    if O.RefLib.available():
-        J = RefJobs(wl, with_outputs=True)
-        J.run(min(16, len(os.sched_getaffinity(0))), 1)
-        res["against"] = "the reference's x86-SIMD table entries (oracle/_ref, compiled from the reference) on the same work lists"
-        k = 0
-        nd = nt = 0
-        for job in wl.dist_jobs:
-            got = job[5].cpu().numpy().view(np.uint64)
-            res["mismatches"] += int((got != J.outs[k]).sum())
-            nd += got.size
-            k += 1
-        from vvenc_amd.hotpath import STATS_DTYPE
-        for job in wl.tu_jobs:
-            st = job[6].cpu().numpy().view(STATS_DTYPE).reshape(-1)
-            res["mismatches"] += int((st["sse"] != J.outs[k]).sum())
-            nt += st.size
-            k += 1
-        res["checked"] = {"distortion_candidates": nd, "tus_sse_after_fwd_quant_dequant_inv": nt}
-    else:
-        orc = O.Oracle()
-        res["against"] = "the scalar C oracle (oracle/liboracle.so) on a 2% sample of every distortion list"
-        org = np.ascontiguousarray(wl.org.storage.cpu().numpy())
-        ref = np.ascontiguousarray(wl.ref.storage.cpu().numpy())
-        L = orc.L
-        L.orc_dist_batch.restype = None
-        L.orc_dist_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-        fidx = {"SSE": 0, "SAD": 1, "HAD": 2, "HAD_fast": 3}
-        nd = 0
-        for (func, S, ss, n, _, d_out, items) in wl.dist_jobs:
-            sel = np.arange(0, n, 50)
-            sl = np.ascontiguousarray(items[sel])
-            outb = np.zeros(sel.size, np.uint64)
-            L.orc_dist_batch(fidx[func], org.ctypes.data + 2 * wl.org.origin, wl.org.stride, ref.ctypes.data + 2 * wl.ref.origin, wl.ref.stride, S, S, ss, sl.ctypes.data, sel.size, outb.ctypes.data)
-            res["mismatches"] += int((d_out.cpu().numpy().view(np.uint64)[sel] != outb).sum())
-            nd += sel.size
-        res["checked"] = {"distortion_candidates": nd}
-    if mctf is not None:
-        cur_np, ref_np, field = mctf
-        h, w = cur_np.shape                                 # the whole picture (the scalar oracle takes a fraction of a second)
-        t0 = time.perf_counter()
-        orc = O.Oracle()
-        exp = orc.mctf_me(np.ascontiguousarray(cur_np[:h, :w]), np.ascontiguousarray(ref_np[:h, :w]), wl.bit_depth, 16, 4, w >= 1920)[4]
-        cp = hp.plane(np.ascontiguousarray(cur_np[:h, :w]), 128)
-        rp = hp.plane(np.ascontiguousarray(ref_np[:h, :w]), 128)
-        outs, dims = hp.mctf_motion_estimation(cp, [rp], wl.bit_depth, 16, 4, w >= 1920)
-        got = hp.mv_to_numpy(outs[0], dims)
-        bad = sum(int((got[k] != exp[k]).sum()) for k in ("x", "y", "error", "rmsme", "overlap"))
+    from vvenc_amd.hotpath import STATS_DTYPE
+    res = {"status": None, "mismatches": 0, "checked": {}, "against": "the costs the reference encoder itself computed when the lists were recorded (integer SAD, sub-pel Hadamard, "
+           "table calls, DMVR vectors + costs)"}
+    tot = {}
+    for layer, wl in workloads.items():
+        wl.run()
+        for k, (n, bad) in wl.check_against_recording().items():
+            a = tot.setdefault(k, [0, 0])
+            a[0] += n
+            a[1] += bad
+    for k, (n, bad) in tot.items():
+        res["checked"][k] = n
         res["mismatches"] += bad
-        res["checked"]["mctf_motion_vectors"] = int(got.size)
-        res["mctf_oracle_s"] = round(time.perf_counter() - t0, 2)
+    if O.RefLib.available():
+        n_tu = bad_tu = 0
+        cores = usable_cores(host_cpu_info())
+        for layer, wl in workloads.items():
+            J = ReferenceJobs(wl, with_outputs=True)
+            J.arr = (RecJob * max(1, len(wl.tu_groups)))(*[j for j in J.arr[:J.n] if j.kind == 1])      # TU jobs only (the rest is checked against the recording)
+            J.n = len(wl.tu_groups)
+            J.run(cores, 1)
+            torch.cuda.synchronize()
+            for g, (sse, st4) in zip(wl.tu_groups, J.tu_outs):
+                st = g["stats"].cpu().numpy().view(STATS_DTYPE).reshape(-1)
+                lv = g["level"].view(g["n"], -1).to(torch.int64)
+                idx = torch.arange(1, lv.shape[1] + 1, device=lv.device, dtype=torch.int64)
+                cs = ((lv * idx).sum(1) & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
+                bad = (st["sse"] != sse) | (st["abs_sum"] != st4[:, 0]) | (st["need_rdoq"] != st4[:, 2]) | (cs != st4[:, 3].view(np.uint32))
+                has = st4[:, 0] != 0
+                bad |= has & (st["last_scan_pos"] != st4[:, 1])          # (the last position is defined when a level is non-zero)
+                bad_tu += int(bad.sum())
+                n_tu += g["n"]
+            del J
+        res["checked"]["tus_sse_abssum_last_needrdoq_levels"] = n_tu
+        res["mismatches"] += bad_tu
+        res["against"] += "; TU outputs against the reference's x86-SIMD entries (oracle/_ref) on the same residuals"
     res["status"] = "bit-exact" if res["mismatches"] == 0 else "MISMATCH"
     return res
 
 
-# ------------------------------------------------------------------------------------------------------------------------ device side
-def mctf_stage(hp, wl, refs=4, reps=5):
-    """BASELINE configs[2] stage: hierarchical motion estimation of one picture against `refs` references (one vvhip_mctf_motion_estimation call: pyramid levels and search
-    stages of all references share launches) and the bilateral filter of Y, U, V with the fields just found"""
-    W, H, bd = wl.width, wl.height, wl.bit_depth
-    cur = hp.plane(wl.cur_np, 128)
-    ref_np = [np.roll(wl.ref_np, (k, -2 * k), (0, 1)) for k in range(refs)]
-    ref_pl = [hp.plane(r, 128) for r in ref_np]
-    add_level = W >= 1920
-    out = {"width": W, "height": H, "references": refs, "unit": 16, "mctf_speed": 4}
-    outs, dims = hp.mctf_motion_estimation(cur, ref_pl, bd, 16, 4, add_level)
-    out["me_ms_per_picture"] = timed_ms(lambda: hp.mctf_motion_estimation(cur, ref_pl, bd, 16, 4, add_level, out=outs), reps)
-    out["me_ms_one_reference"] = timed_ms(lambda: hp.mctf_motion_estimation(cur, ref_pl[:1], bd, 16, 4, add_level, out=outs[:1]), reps)
-    # bilateral filter: luma + both chroma planes (4:2:0), the fields stay on the device
-    def yuv(y):
-        return (y, np.clip(y[::2, ::2] // 2 + 256, 0, (1 << bd) - 1).astype(np.int16), np.clip((1 << bd) - 1 - y[::2, ::2] // 3, 0, (1 << bd) - 1).astype(np.int16))
-    o3 = yuv(wl.cur_np)
-    r3 = [yuv(r) for r in ref_np]
-    planes_o = [hp.plane(o3[c], 128 >> (1 if c else 0)) for c in range(3)]
-    planes_r = [[hp.plane(r[c], 128 >> (1 if c else 0)) for r in r3] for c in range(3)]
-    outp = [hp.plane(np.zeros_like(o3[c]), 0) for c in range(3)]
-    strengths = [hp.REF_STRENGTHS[0][min(k, 5)] for k in (0, 0, 1, 1)[:refs]]
-    prm = [hp.mctf_filter_params(32, bd, 0.95, c > 0) for c in range(3)]
-    mv_w = dims[0]
-
-    def apply():
-        for c in range(3):
-            hp.mctf_apply_plane(planes_o[c], planes_r[c], outs, mv_w, 1 if c else 0, strengths, prm[c][1], prm[c][0], bd, 16, True, 32, out=outp[c])
-    out["filter_ms_per_picture"] = timed_ms(apply, reps)
-    nb = dims[0] * dims[1]
-    out["blocks_final_level"] = nb
-    out["bound"] = ("phase A (candidate scoring, all blocks of a level in parallel): VALU + LDS (4-tap separable interpolation per candidate, ~60 candidates per block on the final level); "
-                    "phase B (above/left predictor test, MCTF.cpp:1289-1306): critical path of rows+cols dependent steps per level (%d+%d on the final level) x the hand-off latency; "
-                    "HBM traffic is the pyramid (~1.33 x 2 planes x %d references), far below either" % (dims[1], dims[0], refs))
-    out["hbm_bytes_unique"] = int(1.34 * W * H * 2 * (1 + refs))
-    out["me_frac_hbm_unique"] = out["hbm_bytes_unique"] / (out["me_ms_per_picture"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-    return out, (wl.cur_np, ref_np[0], None)
-
-
-def unique_bytes(wl, cls):
-    """HBM bytes one launch of the class must move at least: the planes it reads once + its index lists + its results"""
-    planes = 2 * (wl.org.storage.numel() + wl.ref.storage.numel())
-    if cls == "TU":
-        return int(2 * wl.resi.storage.numel() + sum(j[1] * (4 + 4 + 2 * 2 * j[0] * j[0] + 24) for j in wl.tu_jobs))
-    funcs = ("SAD", "SSE") if cls == "SAD_SSE" else (cls,)
-    n = sum(j[3] for j in wl.dist_jobs if j[0] in funcs)
-    return int(planes + n * (8 + 8))
-
-
-def run_inner_profile(args, kind):
-    """one rocprofv3 pass over a short inner run of this script; returns the rocpd database path"""
-    outdir = os.path.join("/tmp", "vvhip_prof_%d_%s" % (os.getpid(), kind))
+# ---------------------------------------------------------------------------------------------------------------------- profiling passes
+def run_inner_profile(args, prof, steps, tag):
+    outdir = os.path.join("/tmp", "vvhip_prof_%d_%s" % (os.getpid(), tag))
     shutil.rmtree(outdir, ignore_errors=True)
-    prof = {"trace": ["--kernel-trace", "--stats"], "fetch": ["--pmc", "FETCH_SIZE"], "write": ["--pmc", "WRITE_SIZE"]}[kind]
-    cmd = ["rocprofv3"] + prof + ["-d", outdir, "--", sys.executable, os.path.abspath(__file__), "--inner", "--steps", "10" if kind == "trace" else "4", "--warmup", "2",
+    cmd = ["rocprofv3"] + prof + ["-d", outdir, "--", sys.executable, os.path.abspath(__file__), "--inner", "--steps", str(steps), "--warmup", "0",
                                   "--width", str(args.width), "--height", str(args.height)]
-    env = dict(os.environ, TMPDIR="/tmp")
-    r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     if r.returncode != 0:
-        raise RuntimeError("rocprofv3 %s pass: rc %d: %s" % (kind, r.returncode, r.stdout[-400:]))
+        raise RuntimeError("rocprofv3 %s pass: rc %d: %s" % (tag, r.returncode, r.stdout[-400:]))
     dbs = sorted(glob.glob(os.path.join(outdir, "**", "*.db"), recursive=True), key=os.path.getmtime)
     if not dbs:
-        raise RuntimeError("rocprofv3 %s pass left no database" % kind)
+        raise RuntimeError("rocprofv3 %s pass left no database" % tag)
     return dbs[-1], outdir
 
 
+def class_of_kernel(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    for cls, sub in KERNEL_NAMES.items():
+        if n.startswith(sub):
+            return cls
+    return None
+
+
 def live_profile(args):
-    """kernel trace + the two PMC passes of a short inner run (separate passes, as the MI355X guide prescribes); FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 B)"""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    """kernel trace + one --pmc pass per counter over a short inner run (32 steps = one GOP cycle, launches serialized): per kernel class the average duration and counters
+    per launch.  FETCH_SIZE is doubled (gfx950 counts a 128-byte request as 64 B, MI355X_MICROARCH.md)."""
     import profile_round as P
-    out = {}
-    db, d1 = run_inner_profile(args, "trace")
+    out, dirs = {}, []
+    db, d = run_inner_profile(args, ["--kernel-trace", "--stats"], 32, "trace")
+    dirs.append(d)
     rows = P.kernel_table(db)
     tot = sum(r[2] for r in rows) or 1
-    out["kernel_trace"] = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --inner --steps 10 --warmup 2 (3 frame launches per step + 2 MCTF stages)",
+    out["kernel_trace"] = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --inner --steps 32 (one GOP cycle of recorded pictures, launches serialized on one stream)",
                            "kernels": [{"name": k.replace("(anonymous namespace)::", "")[:90], "calls": n, "avg_us": round(av / 1e3, 2), "total_us": round(s / 1e3, 1), "pct": round(100.0 * s / tot, 1)}
-                                       for k, n, s, av, mn, mx in rows[:14]]}
-    classes = {}
-    dirs = [d1]
-    for kind, key in (("fetch", "fetch_kb"), ("write", "write_kb")):
-        db, d = run_inner_profile(args, kind)
-        dirs.append(d)
-        for k, c, n, s, av in P.counter_table(db):
-            cls = P.class_of(k)
-            if cls:
-                e = classes.setdefault(cls, {"fetch_kb": 0.0, "write_kb": 0.0, "n_fetch_kb": 0, "n_write_kb": 0})
-                e[key] += s
-                e["n_" + key] += n
-    out["pmc"] = {cls: {"fetch_bytes_per_launch_x2_corrected": 2.0 * 1024.0 * e["fetch_kb"] / max(1, e["n_fetch_kb"]), "write_bytes_per_launch": 1024.0 * e["write_kb"] / max(1, e["n_write_kb"])}
-                  for cls, e in classes.items()}
-    for c in out["pmc"].values():
-        c["traffic_bytes_per_launch"] = c["fetch_bytes_per_launch_x2_corrected"] + c["write_bytes_per_launch"]
+                                       for k, n, s, av, mn, mx in rows[:12]]}
+    cls = {}
+    for k, n, s, av, mn, mx in rows:
+        c = class_of_kernel(k)
+        if c:
+            e = cls.setdefault(c, {"launches": 0, "total_ns": 0.0})
+            e["launches"] += n
+            e["total_ns"] += s
+    for counter, key, scale in (("FETCH_SIZE", "fetch_bytes", 2.0 * 1024.0), ("WRITE_SIZE", "write_bytes", 1024.0), ("TCP_TOTAL_CACHE_ACCESSES_sum", "l1_accesses", 1.0), ("SQ_INSTS_VALU", "valu_insts", 1.0),
+                                ("SQ_INSTS_LDS", "lds_insts", 1.0)):
+        try:
+            db, d = run_inner_profile(args, ["--pmc", counter], 32, counter)
+            dirs.append(d)
+            for k, c, n, s, av in P.counter_table(db):
+                kc = class_of_kernel(k)
+                if kc:
+                    e = cls.setdefault(kc, {})
+                    e[key] = e.get(key, 0.0) + s * scale
+                    e["n_" + key] = e.get("n_" + key, 0) + n
+        except Exception as ex:
+            out.setdefault("pmc_errors", []).append("%s: %s" % (counter, str(ex)[:160]))
+    out["per_class"] = cls
     for d in dirs:
         shutil.rmtree(d, ignore_errors=True)
     return out
 
 
-def file_pmc(cls, args):
-    """fallback: the committed PMC passes of the same command (profiles/pmc_r0x.json)"""
-    if (args.width, args.height) != (1920, 1080):
-        return None, None
-    for name in ("pmc_r02.json", "pmc_r01.json"):
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            return d["classes"][cls]["traffic_bytes_per_launch"], "profiles/" + name
-        except Exception:
-            continue
-    return None, None
+# ---------------------------------------------------------------------------------------------------------------------- device side
+class Mctf1080:
+    """what tools/bench_synthetic.mctf_stage needs from a workload: one picture pair of the config-2 generator"""
+
+    def __init__(self, width, height, bit_depth=10):
+        from vvenc_amd.workload import synth_frame_pair
+        self.width, self.height, self.bit_depth = width, height, bit_depth
+        self.cur_np, self.ref_np = synth_frame_pair(width, height, 1080 if width == 1920 else 2160, bit_depth)
 
 
-def e2e_encoder(frames, threads):
-    """the real reference encoder end to end (SURVEY §8d metric): CPU kernels vs --SIMD=HIP, same clip, same threads; subprocesses (the SIMD level is process-wide)"""
+def e2e_encoder(width, height, frames, threads, pairs):
+    """the real reference encoder end to end (SURVEY 8d metric): CPU kernels vs --SIMD=HIP, same clip, same threads; subprocesses (the SIMD level is process-wide)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import e2e_fps
     import e2e_util
     if not (os.path.exists(e2e_util.REF_SO) and os.path.exists(e2e_util.REF_HIP_SO)):
-        return {"skipped": "oracle/_ref (the compiled reference encoder, with and without the binding) is not built"}
-    prod = 16 + 128 + 8192 + 65536
-    # one discarded run (clip cache, page cache, clocks), then five alternating pairs; medians (single runs of a 1.4 s encode scatter by +-4 %)
-    e2e_fps.run(dict(w=1920, h=1080, frames=frames, threads=threads, mask=0), timeout=600)
-    runs = [e2e_fps.run(dict(w=1920, h=1080, frames=frames, threads=threads, mask=m), timeout=600) for m in (0, prod) * 5]
+        return {"skipped": "the compiled reference encoder (oracle/_ref) and the encoder with the binding (bindings/vvenc/_build) are not both built"}
+    prod = e2e_production_mask()
+    e2e_fps.run(dict(w=width, h=height, frames=frames, threads=threads, mask=0), timeout=900)          # discarded run: clip cache, page cache, clocks
+    runs = [e2e_fps.run(dict(w=width, h=height, frames=frames, threads=threads, mask=m), timeout=900) for m in (0, prod) * pairs]
     med = lambda v: sorted(v)[len(v) // 2]
     cpu = med([r["fps"] for r in runs if r["mask"] == 0])
     hip = med([r["fps"] for r in runs if r["mask"] == prod])
-    return {"clip": "1920x1080 10-bit synthetic (config-2 generator), %d frames, preset faster, QP 32" % frames, "threads": threads,
+    return {"clip": "%dx%d 10-bit synthetic (config-2 generator), %d frames, preset faster, QP 32" % (width, height, frames), "threads": threads,
             "cpu_fps": round(cpu, 2), "hip_fps": round(hip, 2), "speedup": round(hip / cpu, 3), "runs_fps": [round(r["fps"], 2) for r in runs],
-            "runs_order": "cpu, hip alternating, five pairs after one discarded run; cpu_fps / hip_fps are medians",
-            "bitstreams_identical": len({r["md5"] for r in runs}) == 1, "md5": runs[0]["md5"],
-            "device_stages": "MCTF motion estimation (all references of a picture per call) + bilateral filter, ALF statistics + ALF filtering of whole pictures (--SIMD=HIP production mask %d)" % prod,
-            "pcie_MB_per_picture": runs[1].get("pcie_MB_per_picture"), "median_of": 5,
-            "note": "the encoder's CTU-level control flow (mode decision, CABAC, RDOQ) stays on the host and bounds the gain (SURVEY §6: the hot path is 30-35% of one thread)"}
+            "runs_order": "cpu, hip alternating, %d pairs after one discarded run; cpu_fps / hip_fps are medians" % pairs,
+            "bitstreams_identical": len({r["md5"] for r in runs}) == 1, "md5": runs[0]["md5"], "hook_mask": prod,
+            "device_stages": "MCTF motion estimation (all references of a picture per call) + bilateral filter, ALF statistics of whole pictures (--SIMD=HIP production mask)",
+            "pcie_MB_per_picture": runs[1].get("pcie_MB_per_picture")}
 
 
-# ------------------------------------------------------------------------------------------------------------------------ main
+def e2e_production_mask():
+    return 16 + 128 + 8192
+
+
+# ---------------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams a picture's three launch groups are issued on (1 = serialized)")
+    ap.add_argument("--exchange-every", type=int, default=1, help="N > 1: one reference-picture broadcast every this many steps (a step is one picture)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timers", action="store_true", help="skip per-kernel HIP events inside the timed region")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-mctf", action="store_true")
     ap.add_argument("--no-4k", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 passes of the inner run (kernel trace, FETCH_SIZE, WRITE_SIZE)")
-    ap.add_argument("--e2e-frames", type=int, default=65)
+    ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 passes of the inner run (kernel trace + one pass per counter)")
     ap.add_argument("--e2e-threads", type=int, default=8)
-    ap.add_argument("--graph", type=int, default=1, help="extra measurement: the frame's launches replayed from a HIP graph (0 = skip)")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the three launches of a picture are issued on (1 = one stream, serialized)")
-    ap.add_argument("--with-subpel", action="store_true", help="also run the fractional-ME stage per step (16 interpolated HAD_fast candidates per block; SURVEY 8f rank 1)")
-    ap.add_argument("--static-copies", action="store_true", help="make the derived plane copies (tiled, shifted) once outside the timed region instead of per step")
-    ap.add_argument("--inner", action="store_true", help="(internal) the short run rocprofv3 wraps: frame launches + MCTF stages, no extras, no output line")
+    ap.add_argument("--inner", action="store_true", help="(internal) the short run rocprofv3 wraps: the recorded pictures' launches serialized on one stream, no extras, no output line")
     args = ap.parse_args()
 
     rank, local_rank, world = sharding.init()
@@ -406,176 +403,147 @@ def main():
         raise SystemExit("bench.py needs an MI355X: vvenc_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     from vvenc_amd.hotpath import HotPath, Plane
-    from vvenc_amd.workload import FrameWorkload
+    from vvenc_amd.replay import RecordedWorkload
     hp = HotPath("cuda:%d" % local_rank)
-    # rank r works on picture r + step*world of ONE sequence (pan of the same texture); the reference picture is the same on every rank
-    wl = FrameWorkload(hp, args.width, args.height, seed=1080, frame_index=rank)
-    if args.with_subpel:
-        wl.enable_subpel()
+
+    # ---- the recorded lists (rank 0 records when the cache is cold, the others wait)
+    rec_info = {}
+    if rank == 0:
+        pics, rec_info = prepare_recordings(args.width, args.height, 65, sorted(LAYER_POCS.values()))
+    sharding.barrier()
+    if rank != 0:
+        pics, _ = prepare_recordings(args.width, args.height, 65, sorted(LAYER_POCS.values()))
+    workloads = {layer: RecordedWorkload(hp, pics[poc]) for layer, poc in LAYER_POCS.items()}
 
     if args.inner:
-        # the launches of a step, serialized on one stream: the two derive launches of the picture's plane copies (as the lanes issue them) + the three list launches
-        sh2 = torch.empty_like(wl.ref.storage) if wl.shifted else None
-        for _ in range(args.warmup + args.steps):
-            if (wl.tiled or wl.shifted) and not args.static_copies:
-                hp.planes_derive(wl.org, wl.ref, wl.org_tiled if wl.tiled else None, wl.ref_tiled if wl.tiled else None, wl.ref_shift if wl.shifted else None)
-                if wl.shifted:
-                    hp.planes_derive(wl.org, wl.ref, None, None, sh2)
-            wl.run(None)
-        mctf_stage(hp, wl, 4, reps=2)
+        for s in range(args.warmup + args.steps):
+            workloads[layer_of_step(s)].run()
         torch.cuda.synchronize()
         return
 
-    # ---- the reference-picture exchange of the sharded sequence (N > 1): DPB ring of two pictures (luma + 2 chroma planes with margins)
-    ex, ref_planes = None, None
+    # ---- lanes: the motion-search plan, the TU lists and the DMVR lists of a picture are independent work: three HIP streams, one forked context each
+    lanes = None
+    if args.streams > 1:
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        lanes = [hp.fork(s) for s in streams]
+        for wl in workloads.values():
+            wl.bind_lanes(lanes)
+
+    # ---- the reference-picture exchange of the sharded sequence (N > 1): ring of two reconstructed pictures (luma + 2 chroma planes with margins)
+    ex = None
     if world > 1:
-        shp = tuple(wl.ref.storage.shape)
-        cshape = (shp[0] // 2, shp[1] // 2)
-        ex = sharding.PictureExchange([shp, cshape, cshape], slots=2, device=hp.device)
-        ref_planes, ref_tiled, ref_shift = [], [], []
-        for s in range(2):
-            ex.slots[s][0].copy_(wl.ref.storage)
-            pl = Plane(hp.device, wl.ref.width, wl.ref.height, wl.ref.pad, wl.ref.stride)
-            pl.storage = ex.slots[s][0]
-            ref_planes.append(pl)
-            ref_tiled.append(hp.tile_plane(pl) if wl.tiled else None)      # (for the serialized extras; the timed steps derive their own, see `derive`)
-            ref_shift.append(hp.shift_plane(pl) if wl.shifted else None)
-
+        m = 80
+        shp = (args.height + 2 * m, ((args.width + 2 * m + 7) // 8) * 8)
+        ex = sharding.PictureExchange([shp, (shp[0] // 2, shp[1] // 2), (shp[0] // 2, shp[1] // 2)], slots=2, device=hp.device)
         ex.publish(0, 0)
+    step_no = [rank]                                     # rank r replays pictures r, r + N, ... of the cycle
 
-    step_no = [0]
-    # Every step is a different picture, so the copies this library derives from a picture's planes (8x8-tiled original and reference, one-sample-shifted reference) are made
-    # INSIDE the step, by the lanes that read them, in front of their launches (--static-copies: made once, outside the timed region — the regime of the `single_stream` / `graph` extras)
-    derive = (wl.tiled or wl.shifted) and wl.merged and args.streams > 1 and (world > 1 or not args.static_copies)      # (N > 1: a received reference picture always gets its copies)
-    # the three launches of a picture are independent work lists: each goes to its own HIP stream (they share the device, and the steps pipeline per stream)
-    streams = [torch.cuda.Stream() for _ in range(3)] if (args.streams > 1 and wl.merged) else None
-
-    def step(timers=None):
+    def step():
+        s = step_no[0]
         if ex is not None:
-            s = step_no[0]
-            ex.publish(s + 1, (s + 1) % world, readers=streams or ())     # the next picture's reference is in flight while this picture's launches run
-            ex.wait(s, streams)
-            wl.ref, wl.ref_tiled, wl.ref_shift = ref_planes[s % 2], ref_tiled[s % 2], ref_shift[s % 2]
-            step_no[0] += 1
-        if streams:
-            wl.run_overlapped(streams, timers, derive=derive)
+            k = (s - rank) // world                      # this rank's step count
+            if k % args.exchange_every == 0:
+                e = k // args.exchange_every
+                ex.publish(e + 1, (e + 1) % world, readers=streams if lanes else ())      # the next reference picture is in flight while this picture's launches run
+                ex.wait(e, streams if lanes else None)
+        wl = workloads[layer_of_step(s)]
+        if lanes:
+            wl.run_lanes()
         else:
-            wl.run(timers)
+            wl.run()
+        step_no[0] = s + world
 
-    classes = wl.class_launches_merged if wl.merged else wl.class_launches
     for _ in range(args.warmup):
-        step(None)
+        step()
     torch.cuda.synchronize()
-    # Untimed settling of the device (besides the W warm-up steps): the FIRST process on a freshly acquired box stalls ~30 ms once, a few milliseconds into its first phase of
-    # multi-queue concurrency (measured: 50 steps drain in 34 ms instead of 2 ms; any earlier GPU process on the box, however small, removes it).  Batches of the same steps until
-    # two consecutive batches agree and at least 150 ms have passed; world > 1: a fixed count, so that every rank publishes the same pictures.
+    # untimed settling (a freshly acquired box stalls once, a few milliseconds into its first multi-queue phase): whole GOP cycles until two agree
     if world == 1:
-        tw, prev, batches = time.perf_counter(), None, 0
-        while True:
+        prev = None
+        for _ in range(40):
             tb = time.perf_counter()
-            for _ in range(50):
-                step(None)
+            for _ in range(32):
+                step()
             torch.cuda.synchronize()
             cur = time.perf_counter() - tb
-            batches += 1
-            if (time.perf_counter() - tw > 0.15 and prev is not None and abs(cur - prev) < 0.2 * min(cur, prev)) or batches >= 200:
+            if prev is not None and abs(cur - prev) < 0.15 * min(cur, prev):
                 break
             prev = cur
     else:
-        for _ in range(100):
-            step(None)
+        for _ in range(64):
+            step()
         torch.cuda.synchronize()
-    # K steps with the three launches SERIALIZED on one stream and every class bracketed by events: the regime in which a kernel's launch duration is its own (roofline),
-    # and the one the rocprofv3 trace of the inner run shows.  Outside the timed region (events are not free: ~3 us of host time each).
-    stimers, dom_cls = None, None
-    if not args.no_kernel_timers:
-        wl.run(None)
-        stimers = EventTimers(list(classes), args.steps, classes)
-        for _ in range(args.steps):
-            wl.run(stimers)
-        torch.cuda.synchronize()
-        ssum = stimers.summary()
-        dom_cls = max(ssum, key=lambda k: ssum[k]["total_ms"])
-        for _ in range(2):
-            step(None)
-        torch.cuda.synchronize()
+
+    # ---- per-kernel durations: every layer's launches serialized on one stream, HIP events around each kernel (inside the library for the plan's kernels); outside the timed region
+    per_layer = {}
+    for layer, wl in workloads.items():
+        hp.me_plan_set_timing(wl.plan, True)
+        acc = {"ME_stage": 0.0, "ME_int": 0.0, "ME_item": 0.0, "TU": 0.0, "DMVR": 0.0}
+        reps = 8
+        for _ in range(reps + 1):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            wl.run_me()
+            e[0].record()
+            wl.run_tu()
+            e[1].record()
+            wl.run_dmvr()
+            e[2].record()
+            torch.cuda.synchronize()
+            t = hp.me_plan_last_times(wl.plan)
+            if _ == 0:
+                continue
+            acc["ME_stage"] += t[0]
+            acc["ME_int"] += t[1] + t[2]
+            acc["ME_item"] += t[3]
+            acc["TU"] += e[0].elapsed_time(e[1])
+            acc["DMVR"] += e[1].elapsed_time(e[2])
+        hp.me_plan_set_timing(wl.plan, False)
+        per_layer[layer] = {k: v / reps for k, v in acc.items()}
+
+    step_no[0] = rank
     sharding.barrier()
     torch.cuda.synchronize()
-    # timed region: only the dominant class keeps an event pair, on its own stream (its launch duration while the classes share the device)
-    timers = EventTimers([dom_cls], args.steps, classes) if dom_cls else None
     enq = [0.0] * (args.steps + 1)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(timers)
+        step()
         enq[i + 1] = time.perf_counter()
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
-    dt = dt_local
     enq[0] = t0
     enq_us = sorted(1e6 * (b - a) for a, b in zip(enq[:-1], enq[1:]))
-    dt = sharding.max_over_ranks(dt, device="cuda")
-    if ex is not None:
-        wl.ref, wl.ref_tiled, wl.ref_shift = ref_planes[0], ref_tiled[0], ref_shift[0]
+    dt = sharding.max_over_ranks(dt_local, device="cuda")
 
-    # extra (not `value`): the same K steps on the three streams with the derived plane copies made ONCE (what a sequence of lists against the same picture costs)
-    static_copies = None
-    if streams and derive and world == 1:
-        torch.cuda.synchronize()
-        for _ in range(max(args.warmup, 1)):
-            wl.run_overlapped(streams, None, derive=False)
-        torch.cuda.synchronize()
+    # extras (not `value`): the same K steps serialized on one stream; and, N > 1, without the picture exchange
+    serial = None
+    if lanes:
+        step_no[0] = rank
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            wl.run_overlapped(streams, None, derive=False)
+        for i in range(args.steps):
+            workloads[layer_of_step(step_no[0])].run()
+            step_no[0] += world
         torch.cuda.synchronize()
-        dts = time.perf_counter() - t1
-        static_copies = {"value": args.steps / dts, "unit": "frames/s", "ms_per_step": 1000.0 * dts / args.steps,
-                         "note": "same three launches on three streams, the tiled / shifted plane copies made once outside the timed steps (lists of one picture); not the headline value"}
-    # extra (not `value`): the same K steps serialized on one stream without any event
-    overlap = None
-    if streams:
-        for _ in range(max(args.warmup, 1)):
-            wl.run(None)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            wl.run(None)
-        torch.cuda.synchronize()
-        dto = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
-        overlap = {"streams": 1, "value": args.steps * world / dto, "unit": "frames/s", "ms_per_step": 1000.0 * dto / args.steps,
-                   "note": "same work, the 3 launches of a picture serialized on one HIP stream (no events, no picture exchange, derived plane copies made once); not the headline value"}
-    graph = None
-    if args.graph and wl.merged and not args.with_subpel:
-        gh, err, dtl = None, None, 0.0
-        try:
-            gh = hp.graph_capture(lambda: wl.run(None))
-            for _ in range(max(args.warmup, 1)):
-                hp.graph_launch(gh)
-            torch.cuda.synchronize()
-        except Exception as e:
-            err = str(e)[:200]
+        dts = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
+        serial = {"value": args.steps * world / dts, "unit": "frames/s", "ms_per_step": 1000.0 * dts / args.steps, "note": "same pictures, every launch on ONE stream (no picture exchange); not the headline value"}
+    no_exchange = None
+    if ex is not None:
+        step_no[0] = rank
         sharding.barrier()
-        if err is None:
-            try:
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    hp.graph_launch(gh)
-                torch.cuda.synchronize()
-                dtl = time.perf_counter() - t1
-                hp.graph_destroy(gh)
-            except Exception as e:
-                err = str(e)[:200]
-        dtg = sharding.max_over_ranks(dtl, device="cuda")
-        bad = sharding.max_over_ranks(0.0 if err is None else 1.0, device="cuda")
-        graph = {"error": err or "failed on another rank"} if bad > 0.0 else \
-            {"value": args.steps * world / dtg, "unit": "frames/s", "ms_per_step": 1000.0 * dtg / args.steps,
-             "note": "same work, the 3 launches of a frame captured once as a HIP graph and replayed (no per-kernel events, no picture exchange); not the headline value"}
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            wl = workloads[layer_of_step(step_no[0])]
+            wl.run_lanes() if lanes else wl.run()
+            step_no[0] += world
+        torch.cuda.synchronize()
+        dtn = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
+        no_exchange = {"value": args.steps * world / dtn, "unit": "frames/s", "ms_per_step": 1000.0 * dtn / args.steps, "note": "same steps without the reference-picture broadcast: kernel scaling alone"}
     if rank != 0:
         return
 
     frames = args.steps * world
+    pairs_by_layer = {l: workloads[l].pic.sample_pairs for l in workloads}
+    wsum = float(sum(GOP_WEIGHT.values()))
     out = {
         "metric": "frames/sec + bit-exact vs CPU, 1080p/4K 10-bit preset=faster at 1/2/4/8 GPU",
         "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -583,128 +551,112 @@ def main():
         "dtype": "i16", "data": "synthetic",
         "host_enqueue_us_per_step": {"p50": round(enq_us[len(enq_us) // 2], 1), "p90": round(enq_us[int(len(enq_us) * 0.9)], 1), "max": round(enq_us[-1], 1),
                                      "drain_ms_after_last_enqueue": round(1000.0 * (t0 + dt_local - enq[-1]), 3)},
-        "config": {"workload": "%dx%d 10-bit synthetic picture, preset=faster hot-path work lists: SAD/SATD(HAD_fast)/SSE candidate batches "
-                               "(8..64 blocks, 20 candidates/block) + fused DCT-2/quant/dequant/IDCT TU batches (8..32); BASELINE configs[1]" % (args.width, args.height),
-                   "sample_pairs_per_frame": int(wl.pairs), "coefficients_per_frame": int(wl.coefs), "launches_per_frame": (5 if derive else 3) if wl.merged else len(wl.dist_jobs) + len(wl.tu_jobs), "hip_streams": len(streams) if streams else 1,
+        "config": {"workload": "work lists RECORDED from the reference encoder (bindings/vvenc recorder, hook bit 131072): %dx%d 10-bit synthetic config-2 clip, 65 frames, preset faster; one picture "
+                               "per temporal layer (POC %s); step s replays the picture of the layer POC s mod 32 has in the encoder's GOP; BASELINE configs[1]"
+                               % (args.width, args.height, ", ".join("%d = TL%d" % (p, l) for l, p in LAYER_POCS.items())),
+                   "pictures_per_32_steps_by_layer": {str(l): GOP_WEIGHT[l] for l in GOP_WEIGHT},
+                   "sample_pairs_per_frame": int(sum(GOP_WEIGHT[l] * pairs_by_layer[l] for l in pairs_by_layer) / wsum),
+                   "sample_pairs_per_frame_by_layer": {str(l): int(v) for l, v in pairs_by_layer.items()},
+                   "sample_pairs_note": "counted like the reference's own counter (CommonLib/SearchSpaceCounter.cpp:106-165 via RdCost.cpp:150-156: w x h per table call, DMVR excluded): "
+                                        "%.1f x 1.5 W H GOP-weighted; the light recording of all 65 pictures of this encode gives 56.7 x" % (sum(GOP_WEIGHT[l] * pairs_by_layer[l] for l in pairs_by_layer) / wsum / (1.5 * args.width * args.height)),
+                   "coefficients_per_frame": int(sum(GOP_WEIGHT[l] * workloads[l].tu_coefficients for l in workloads) / wsum),
+                   "work_per_layer": {str(l): {"me_calls": int(workloads[l].pic.me.size), "integer_candidates": int(workloads[l].plan_cands.size), "subpel_stages": int(workloads[l].stage_jobs.size),
+                                               "subpel_positions": int(workloads[l].stage_evaluated.sum()), "table_calls": int(workloads[l].items.size), "tus": int(sum(g["n"] for g in workloads[l].tu_groups)),
+                                               "dmvr_subblocks": int(sum(g["n"] for g in workloads[l].dmvr_groups)), "plan": workloads[l].me_info} for l in workloads},
+                   "subpel_candidates_per_block": round(float(np.mean([workloads[l].stage_evaluated.sum() / max(1, workloads[l].pic.me.size) for l in workloads if workloads[l].pic.me.size])), 2),
+                   "launches_per_frame": "motion-search plan (clear + refinement stages + integer windows x 2 LDS classes + table calls) + 1-2 TU launches + 0-1 DMVR launch",
+                   "hip_streams": 3 if lanes else 1, "recording": rec_info,
                    "sharding": "one picture per rank and step, pictures of one sequence round-robin over ranks, no data-path collective"
-                               + (", reference picture (luma + chroma, %.1f MB) RCCL-broadcast from its owner every step inside the timed region, overlapped with the launches"
-                                  % (sum(p.numel() * 2 for p in ex.slots[0]) / 1e6) if ex is not None else ""),
-                   "subpel_candidates_per_block": 16 if args.with_subpel else 0},
+                               + (", reconstructed picture (luma + chroma, %.1f MB) RCCL-broadcast from its owner every %d step(s) inside the timed region, overlapped with the launches"
+                                  % (sum(p.numel() * 2 for p in ex.slots[0]) / 1e6, args.exchange_every) if ex is not None else "")},
     }
-    if static_copies:
-        out["static_derived_copies"] = static_copies
+    if serial:
+        out["single_stream"] = serial
     if ex is not None:
-        out["exchange"] = {"bytes_per_rank": int(ex.bytes_published), "pictures": step_no[0] + 1, "collective": "broadcast (RCCL)", "overlapped": True}
-    if wl.tiled or wl.shifted:
-        out["derived_copies"] = ("8x8-tiled original + reference and one-sample-shifted reference (SAD / SSE lane, one launch) + one-sample-shifted reference (Hadamard lane): made for every "
-                                 "step's picture INSIDE the timed region, on the lane that reads them" if derive else "made once outside the timed region (--static-copies / one stream)")
+        out["exchange"] = {"bytes_per_rank": int(ex.bytes_published), "collective": "broadcast (RCCL)", "overlapped": True, "every_steps": args.exchange_every,
+                           "exchange_ms_per_picture": round(1000.0 * (dt - (args.steps * world / no_exchange["value"])) / args.steps, 4) if no_exchange else None}
+        out["no_exchange"] = no_exchange
 
+    # ---- kernels + roofline
+    alg = {l: {"ME_stage": None, "ME_int": None, "ME_item": None, "TU": workloads[l].alg_bytes_tu, "DMVR": workloads[l].alg_bytes_dmvr} for l in workloads}
+    for l, wl in workloads.items():
+        alg[l].update(wl.alg_bytes_by_kernel)
+    kern = {}
+    for k in ("ME_stage", "ME_int", "ME_item", "TU", "DMVR"):
+        ms = sum(GOP_WEIGHT[l] * per_layer[l][k] for l in per_layer) / wsum
+        ab = sum(GOP_WEIGHT[l] * (alg[l][k] or 0) for l in per_layer) / wsum
+        kern[k] = {"kernel": KERNEL_NAMES[k], "avg_ms_per_picture": ms, "ms_by_layer": {str(l): round(per_layer[l][k], 4) for l in per_layer}, "alg_bytes_per_picture": int(ab),
+                   "nominal_alg_GBps": (ab / (ms * 1e-3) / 1e9) if ms > 0 else None}
+    out["kernels"] = kern
+    out["kernels_measured"] = "HIP events on the launch stream around every kernel (inside vvhip_me_plan_run for the plan's kernels), 8 passes per layer with the launches serialized; GOP-weighted"
     live = None
     if not args.no_profile and world == 1 and shutil.which("rocprofv3"):
         try:
             live = live_profile(args)
             out["kernel_trace"] = live["kernel_trace"]
+            if live.get("pmc_errors"):
+                out["pmc_errors"] = live["pmc_errors"]
         except Exception as e:
             out["kernel_trace"] = {"error": str(e)[:300]}
+    dom = max(kern, key=lambda k: kern[k]["avg_ms_per_picture"])
+    roof = {"kernel": KERNEL_NAMES[dom], "class": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": kern[dom]["avg_ms_per_picture"],
+            "nominal_alg_GBps": kern[dom]["nominal_alg_GBps"], "alg_bytes_per_launch": kern[dom]["alg_bytes_per_picture"],
+            "basis": "PHYSICAL: HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes over the inner run of this command) / HIP-event launch duration / 8 TB/s. "
+                     "nominal_alg_GBps is SURVEY 8d's per-unit figure (4 w h per distortion call, (w + taps)(h + taps) 2 + 2 w h per sub-pel position, 6 w h + 24 per TU) over the same "
+                     "duration: an upper bound of the bytes the kernel would read without any reuse, not what reaches HBM"}
+    if live and dom in live.get("per_class", {}):
+        c = live["per_class"][dom]
+        n = max(1, c.get("launches", 1))
+        per = lambda key: (c.get(key, 0.0) / max(1, c.get("n_" + key, 0))) if c.get("n_" + key) else None
+        t_s = (c["total_ns"] / n) * 1e-9 if c.get("total_ns") else kern[dom]["avg_ms_per_picture"] * 1e-3
+        fetch, write, l1, valu, ldsi = per("fetch_bytes"), per("write_bytes"), per("l1_accesses"), per("valu_insts"), per("lds_insts")
+        traffic = (fetch or 0.0) + (write or 0.0) if fetch is not None else None
+        roof.update({"traffic": traffic, "trace_avg_launch_ms": t_s * 1e3,
+                     "achieved": (traffic / t_s / 1e9) if traffic else None, "frac": (traffic / t_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "traffic_over_alg_bytes": (traffic / kern[dom]["alg_bytes_per_picture"]) if traffic and kern[dom]["alg_bytes_per_picture"] else None,
+                     "l1_accesses_per_launch": l1, "l1_access_frac": (l1 / (N_CU * CLOCK_GHZ * 1e9 * t_s)) if l1 else None,
+                     "valu_insts_per_launch": valu, "valu_issue_frac": (valu * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9 * t_s)) if valu else None,
+                     "lds_insts_per_launch": ldsi})
+        fr = {"hbm": roof["frac"] or 0.0, "l1_access": roof["l1_access_frac"] or 0.0, "valu": roof["valu_issue_frac"] or 0.0}
+        order = sorted(fr, key=lambda k: -fr[k])
+        roof["bound"] = "+".join(k for k in order if fr[k] >= 0.6 * fr[order[0]] and fr[k] > 0) or "hbm"
+        roof["limiter"] = "fractions of the launch time: HBM traffic %.3f, L1 (TCP) access slots %.3f (one access per 64-byte granule and instruction, %d CUs x %.1f GHz), VALU issue slots %.3f " \
+                          "(wave instructions x 4 cycles / %d SIMDs); the rest is latency the resident waves do not cover" % (fr["hbm"], fr["l1_access"], fr["valu"], N_CU, CLOCK_GHZ, N_SIMD)
+        out["pmc"] = {k: {kk: v for kk, v in c.items()} for k, c in live["per_class"].items()}
+    else:
+        roof.update({"bound": "hbm", "traffic": None, "achieved": kern[dom]["nominal_alg_GBps"], "frac": None, "note": "no live PMC pass (rocprofv3 absent or --no-profile): no physical fraction reported"})
+    out["roofline"] = roof
 
-    if stimers is not None:
-        ks = stimers.summary()                                # every class, K steps, launches serialized on one stream
-        conc = timers.summary() if timers is not None else {}
-        for k in ks:
-            ks[k]["alg_bytes_per_frame"] = int(wl.alg_bytes[k])
-            ks[k]["alg_GBps"] = wl.alg_bytes[k] * args.steps / (ks[k]["total_ms"] * 1e-3) / 1e9
-            ks[k]["measured_over"] = "%d steps, launches serialized on one stream" % args.steps
-            if k in conc:
-                ks[k]["avg_ms_in_timed_region"] = conc[k]["avg_ms"]      # on its own stream, concurrently with the other two classes
-        for k in ks:
-            ub = unique_bytes(wl, k) if k in ("SAD_SSE", "HAD_fast", "TU") else None
-            if ub:
-                ks[k]["unique_bytes_per_launch"] = ub
-                ks[k]["frac_hbm_unique"] = ub / (ks[k]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                ks[k]["frac_l2"] = ks[k]["alg_GBps"] / L2_PEAK_GBS
-        out["kernels"] = ks
-        lpf = classes[dom_cls]
-        traffic, tsrc = None, None
-        if live and dom_cls in live.get("pmc", {}):
-            traffic, tsrc = live["pmc"][dom_cls]["traffic_bytes_per_launch"], "this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over the inner run (FETCH_SIZE x2, gfx950)"
-            out["pmc"] = live["pmc"]
-        else:
-            traffic, tsrc = file_pmc(dom_cls, args)
-        avg_s = ks[dom_cls]["avg_ms"] * 1e-3
-        alg_launch = wl.alg_bytes[dom_cls] / lpf
-        out["roofline"] = {"bound": "hbm", "kernel": KERNEL_OF_CLASS.get(dom_cls, dom_cls),
-                           "achieved": ks[dom_cls]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ks[dom_cls]["alg_GBps"] / HBM_PEAK_GBS,
-                           "traffic": traffic, "traffic_source": tsrc,
-                           "basis": "NOMINAL: per-candidate algorithmic bytes (4*w*h per candidate + 8 B result, rows halved under subShift; fused TU = 6*w*h + 24 B; SURVEY 8d) / HIP-event launch time. "
-                                    "Candidates of a block share their original block and overlap in the reference window, so most of these bytes are served by L2 / Infinity Cache; the physical positions are the next three fields",
-                           "alg_bytes_per_launch": alg_launch, "avg_launch_ms": ks[dom_cls]["avg_ms"],
-                           "avg_launch_ms_measured": "HIP events on the launch stream, %d steps with the picture's launches serialized (the kernel alone on the device; the rocprofv3 trace of the inner run shows the same regime); "
-                                                     "in the timed region the three classes run concurrently on three streams and this class's launches last avg_launch_ms_concurrent" % args.steps,
-                           "avg_launch_ms_concurrent": ks[dom_cls].get("avg_ms_in_timed_region"),
-                           "aggregate_alg_GBps_timed_region": sum(wl.alg_bytes[k] for k in classes) * frames / dt / 1e9,
-                           "frac_l2": ks[dom_cls]["alg_GBps"] / L2_PEAK_GBS, "l2_peak_GBps": L2_PEAK_GBS,
-                           "unique_bytes_per_launch": ks[dom_cls].get("unique_bytes_per_launch"), "frac_hbm_unique": ks[dom_cls].get("frac_hbm_unique"),
-                           "frac_hbm_traffic": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                           "limiter": "L1 (TCP) access rate and VALU issue, not a memory level: one L1 access per 64-byte granule and instruction (rocprofv3 TCP_TOTAL_CACHE_ACCESSES: 9.7 M per "
-                                      "launch = 15.8 us at 256 CUs x 2.4 GHz) next to 7.8 M VALU wave-instructions (12.8 us of the SIMDs); frac > 1 on the nominal basis only says that the "
-                                      "candidates' bytes are re-read from L1 / L2, never from HBM (DESIGN §6, profiles/r02_d_pmc_merged_launches.log)"}
-    if overlap is not None:
-        out["single_stream"] = overlap
-    if graph is not None:
-        out["graph"] = graph
-
-    mctf_parity = None
-    if not args.no_mctf and world == 1:
-        try:
-            out["mctf"], mctf_parity = mctf_stage(hp, wl, 4)
-        except Exception as e:
-            out["mctf"] = {"error": str(e)[:300]}
     if not args.no_parity:
         try:
-            wl.run(None)
-            torch.cuda.synchronize()
-            out["parity"] = parity_check(hp, wl, mctf_parity)
+            out["parity"] = parity_check(workloads)
         except Exception as e:
             out["parity"] = {"status": "not checked", "error": str(e)[:300]}
-    if not args.no_4k and world == 1 and (args.width, args.height) == (1920, 1080):
+    if not args.no_mctf and world == 1:
         try:
-            w4 = FrameWorkload(hp, 3840, 2160, seed=2160)
-            # per-class launch durations: launches serialized on one stream, every class bracketed by events (the regime of the 1080p `kernels` block) ...
-            t4 = EventTimers(list(w4.class_launches_merged), 12, w4.class_launches_merged)
-            w4.run(None)
-            for _ in range(10):
-                w4.run(t4)
-            torch.cuda.synchronize()
-            s4 = t4.summary()
-            # ... and the picture rate with the three launches on their streams, no events (the regime of `value`)
-            run4 = (lambda t: w4.run_overlapped(streams, t, derive=derive)) if streams else w4.run
-            run4(None)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                run4(None)
-            torch.cuda.synchronize()
-            d4 = time.perf_counter() - t1
-            m4, _ = mctf_stage(hp, w4, 4, reps=3)
-            out["pass_4k"] = {"config": "BASELINE configs[2]: 3840x2160 10-bit picture, the same three launches + the MCTF stage (hierarchical ME vs 4 references, 5 pyramid levels; bilateral filter)",
-                              "frame_launches_ms_per_step": 1000.0 * d4 / 10, "frames_per_s_launches_only": 10 / d4,
-                              "kernels": {k: {"avg_ms": v["avg_ms"], "alg_GBps": w4.alg_bytes[k] / (v["avg_ms"] * 1e-3) / 1e9, "frac_l2": w4.alg_bytes[k] / (v["avg_ms"] * 1e-3) / 1e9 / L2_PEAK_GBS,
-                                              "frac_hbm_unique": unique_bytes(w4, k) / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k, v in s4.items()},
-                              "mctf": m4,
-                              "ms_per_picture_with_mctf": 1000.0 * d4 / 10 + m4["me_ms_per_picture"] + m4["filter_ms_per_picture"]}
-            del w4
+            import bench_synthetic as BS
+            m, _ = BS.mctf_stage(hp, Mctf1080(args.width, args.height), 4)
+            out["mctf"] = {k: v for k, v in m.items() if k != "me_frac_hbm_unique"}
+            if not args.no_4k:
+                m4, _ = BS.mctf_stage(hp, Mctf1080(3840, 2160), 4, reps=3)
+                out["mctf_4k"] = {k: v for k, v in m4.items() if k != "me_frac_hbm_unique"}
         except Exception as e:
-            out["pass_4k"] = {"error": str(e)[:300]}
+            out["mctf"] = {"error": str(e)[:300]}
     if not args.no_e2e and world == 1:
         try:
-            out["e2e"] = e2e_encoder(args.e2e_frames, args.e2e_threads)
+            out["e2e"] = e2e_encoder(1920, 1080, 65, args.e2e_threads, 5)
         except Exception as e:
             out["e2e"] = {"error": str(e)[:300]}
+        if not args.no_4k:
+            try:
+                out["e2e_4k"] = e2e_encoder(3840, 2160, 65, args.e2e_threads, 3)
+            except Exception as e:
+                out["e2e_4k"] = {"error": str(e)[:300]}
     if not args.no_cpu_baseline and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(wl)
+            out["cpu_baseline"] = cpu_baseline(workloads)
         except Exception as e:   # the baseline is a report, never a reason to lose the measurement
-            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
     print(json.dumps(out))
 
 

@@ -658,8 +658,10 @@ bool alfFilterPicture( const void* owner, int poc, const int16_t* const src[3], 
 //   64 InterpolationFilter tables   128 MCTF bilateral filter   256 batched sub-pel refinement stages   512 DMVR refinement search per CU   1024 TZ diamond rounds
 //   2048 ALF statistics per CTU   4096 CC-ALF statistics per CTU   8192 ALF statistics per picture   16384 ALF filtering per CTU block   32768 CC-ALF filtering per CTU block
 //   65536 ALF filtering per picture   131072 work-list RECORDER (the encoder keeps its CPU kernels; vvenc_hip_recorder.h; needs no device)
-// VVENC_HIP_PRODUCTION: the stages that take whole pictures off the host (what --SIMD=HIP selects).
-static const int VVENC_HIP_PRODUCTION = 16 + 128 + 8192 + 65536;
+// VVENC_HIP_PRODUCTION: the stages that take whole pictures off the host AND pay at every thread count (what --SIMD=HIP selects): MCTF search + filter, whole-picture ALF
+// statistics.  Whole-picture ALF filtering (65536) is bit-exact too but stays out: the first reconstruction task of a picture filters while the others wait on it, which
+// costs 2.7 % at 8 encoder threads (profiles/r02_e2e_encoder_fps.md) — a production mask must never lose.
+static const int VVENC_HIP_PRODUCTION = 16 + 128 + 8192;
 static const int VVENC_HIP_RECORD = 131072;
 void recInitRdCost( vvenc::RdCost* rc ) { vvrec::initRdCost( rc ); }
 

@@ -356,6 +356,10 @@ VVHIP_API void vvhip_me_plan_destroy( vvhip_ctx* ctx, vvhip_me_plan* plan );
  * d_item_cost: n_items Distortion values; pointers of empty lists may be NULL.                                                                              */
 VVHIP_API int  vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes,
                                   uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost );
+/* per-kernel HIP events inside vvhip_me_plan_run (measurements: bench.py's roofline): with timing on, vvhip_me_plan_last_times waits for the last run and returns the
+ * milliseconds of its four parts — refinement-stage kernel (incl. the clearing of its cost array), integer windows that need much LDS, the other integer windows, table calls. */
+VVHIP_API int  vvhip_me_plan_set_timing( vvhip_ctx* ctx, vvhip_me_plan* plan, int on );
+VVHIP_API int  vvhip_me_plan_last_times( vvhip_ctx* ctx, const vvhip_me_plan* plan, float* ms4_host );
 /* what the schedule looks like (for measurements): waves per list and LDS bytes per wave */
 VVHIP_API int  vvhip_me_plan_info( const vvhip_me_plan* plan, int* waves_int, int* waves_stage, int* waves_item, int* lds_bytes );
 

@@ -25,6 +25,7 @@ struct vvhip_me_plan
   int bitDepth = 0, nCands = 0, nStages = 0, nItems = 0;
   int wavesInt = 0, wavesStage = 0, wavesItem = 0, ldsInt = 0, ldsStage = 0;
   int intBig = 0, ldsIntSmall = 0;          // the first intBig windows need up to ldsInt bytes of LDS, the others at most ldsIntSmall (two launches: small blocks keep their occupancy)
+  bool timing = false; hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };      // optional per-kernel events of the last run (vvhip_me_plan_set_timing)
   int stageSetWaves[3] = { 0, 0, 0 };      // stage bundles per tap support (4-tap search set, 6 taps / alternative half-pel, 8 taps), in schedule order
   void* d_blob = nullptr;                  // one allocation: every table below
   const void* d_intJobs = nullptr; const void* d_cands = nullptr; const void* d_stageJobs = nullptr; const void* d_stageOrder = nullptr; const void* d_stageWaves = nullptr;
@@ -762,6 +763,7 @@ void vvhip_me_plan_destroy( vvhip_ctx* ctx, vvhip_me_plan* plan )
   if( !plan ) return;
   if( ctx ) ( void ) hipStreamSynchronize( ctx->stream );
   if( plan->d_blob ) ( void ) hipFree( plan->d_blob );
+  for( hipEvent_t e : plan->ev ) if( e ) ( void ) hipEventDestroy( e );
   delete plan;
 }
 
@@ -772,6 +774,22 @@ int vvhip_me_plan_info( const vvhip_me_plan* plan, int* waves_int, int* waves_st
   if( waves_stage ) *waves_stage = plan->wavesStage;
   if( waves_item ) *waves_item = plan->wavesItem;
   if( lds_bytes ) *lds_bytes = plan->ldsInt > plan->ldsStage ? plan->ldsInt : plan->ldsStage;
+  return VVHIP_OK;
+}
+
+int vvhip_me_plan_set_timing( vvhip_ctx* ctx, vvhip_me_plan* plan, int on )
+{
+  if( !ctx || !plan ) return VVHIP_E_ARG;
+  if( on ) for( hipEvent_t& e : plan->ev ) if( !e ) VVHIP_CHECK_HIP( ctx, hipEventCreate( &e ) );
+  plan->timing = on != 0;
+  return VVHIP_OK;
+}
+
+int vvhip_me_plan_last_times( vvhip_ctx* ctx, const vvhip_me_plan* plan, float* ms4 )
+{
+  if( !ctx || !plan || !ms4 || !plan->timing ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipEventSynchronize( plan->ev[4] ) );
+  for( int k = 0; k < 4; k++ ) VVHIP_CHECK_HIP( ctx, hipEventElapsedTime( &ms4[k], plan->ev[k], plan->ev[k + 1] ) );
   return VVHIP_OK;
 }
 
@@ -788,6 +806,8 @@ int vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me
   a.stageWaves = static_cast<const WaveSpan*>( plan->d_stageWaves ); a.wavesStage = plan->wavesStage;
   a.items = static_cast<const vvhip_me_item*>( plan->d_items ); a.itemOrder = static_cast<const int32_t*>( plan->d_itemOrder ); a.itemWaves = static_cast<const WaveSpan*>( plan->d_itemWaves ); a.wavesItem = plan->wavesItem;
   a.candCost = d_cand_cost; a.stageCost = d_stage_cost; a.itemCost = d_item_cost; a.bitDepth = plan->bitDepth;
+  const bool tm = plan->timing;
+  if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[0], ctx->stream ) );
   // blocks taller than 16 rows are scored band by band (integer atomic adds into the cost array): it starts from zero
   if( plan->nStages ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_stage_cost, 0, ( size_t ) 9 * plan->nStages * sizeof( uint64_t ), ctx->stream ) );
   int firstWave = 0;
@@ -796,10 +816,14 @@ int vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me
   if( plan->stageSetWaves[1] ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) plan->stageSetWaves[1] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
   firstWave += plan->stageSetWaves[1];
   if( plan->stageSetWaves[2] ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) plan->stageSetWaves[2] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[1], ctx->stream ) );
   if( plan->intBig )                  hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->intBig ), dim3( 64 ), ( size_t ) plan->ldsInt, ctx->stream, P, a, 0 );
+  if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[2], ctx->stream ) );
   if( plan->wavesInt > plan->intBig ) hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( plan->wavesInt - plan->intBig ) ), dim3( 64 ), ( size_t ) plan->ldsIntSmall, ctx->stream, P, a, plan->intBig );
+  if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[3], ctx->stream ) );
   if( plan->wavesItem )  hipLaunchKernelGGL( meItemKernel, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a );
   VVHIP_LAUNCH_CHECK( ctx );
+  if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[4], ctx->stream ) );
   return VVHIP_OK;
 }
 

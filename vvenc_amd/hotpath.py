@@ -376,6 +376,15 @@ class HotPath:
         self._ck(self.L.vvhip_me_plan_info(plan, *[C.cast(C.pointer(x), C.c_void_p) for x in v]))
         return {"waves_int": v[0].value, "waves_stage": v[1].value, "waves_item": v[2].value, "lds_bytes": v[3].value}
 
+    def me_plan_set_timing(self, plan, on=True):
+        self._ck(self.L.vvhip_me_plan_set_timing(self.ctx, plan, 1 if on else 0))
+
+    def me_plan_last_times(self, plan):
+        """ms of the last run's parts: refinement stages, integer windows (large LDS class), integer windows (small), table calls"""
+        ms = (C.c_float * 4)()
+        self._ck(self.L.vvhip_me_plan_last_times(self.ctx, plan, C.cast(ms, C.c_void_p)))
+        return [float(x) for x in ms]
+
     def me_plan_run(self, plan, plane_table, n_planes, cand_cost, stage_cost, item_cost):
         self._ck(self.L.vvhip_me_plan_run(self.ctx, plan, C.cast(plane_table, C.c_void_p), n_planes, _ptr(cand_cost), _ptr(stage_cost), _ptr(item_cost)))
 

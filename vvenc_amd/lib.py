@@ -64,6 +64,8 @@ PROTOTYPES = {
     "vvhip_me_plan_destroy": (None, [vp, vp]),
     "vvhip_me_plan_run": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "vvhip_me_plan_info": (i32, [vp, vp, vp, vp, vp]),
+    "vvhip_me_plan_set_timing": (i32, [vp, vp, i32]),
+    "vvhip_me_plan_last_times": (i32, [vp, vp, vp]),
     "vvhip_fast_fwd_core": (i32, [vp, i32, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, i32]),
     "vvhip_fast_inv_core": (i32, [vp, i32, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint]),
     "vvhip_round_clip": (i32, [vp, vp, C.c_uint, C.c_uint, C.c_uint, i32, i32, i32, i32]),

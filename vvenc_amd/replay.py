@@ -42,35 +42,35 @@ def _family_codes(df):
     return out
 
 
-class RecordedWorkload:
-    """one recorded picture, resident in HBM, ready to replay"""
+class HostPlane:
+    """a picture plane in host memory with the layout the device planes get: `pad` samples of margin, row pitch a multiple of 8 samples"""
 
-    def __init__(self, hp: HotPath, pic: R.RecordedPicture, max_window=16, bit_depth=10):
-        self.hp, self.pic, self.bit_depth = hp, pic, bit_depth
-        dev = hp.device
-        # ---- planes
+    def __init__(self, arr_with_margin, margin, pad):
+        h2, w2 = arr_with_margin.shape
+        self.width, self.height, self.pad = w2 - 2 * margin, h2 - 2 * margin, pad
+        self.stride = ((self.width + 2 * pad + 7) // 8) * 8
+        self.storage = np.zeros((self.height + 2 * pad + 1, self.stride), np.int16)          # (+ one row of slack: chunk loads may run past the last row)
+        inner = arr_with_margin if margin == pad else np.pad(arr_with_margin[margin:margin + self.height, margin:margin + self.width], pad, mode="edge")
+        self.storage[:self.height + 2 * pad, :self.width + 2 * pad] = inner
+        self.origin = pad * self.stride + pad
+
+
+class RecordedLists:
+    """one recorded picture as HOST-side lists in the layouts of the C ABI (vvhip_me_* records, TU / DMVR groups) over host planes; RecordedWorkload puts them on the device,
+    the tests' reference driver runs them on the CPU"""
+
+    def __init__(self, pic: R.RecordedPicture, bit_depth=10):
+        self.pic, self.bit_depth = pic, bit_depth
+        # ---- planes: originals get 8 replicated samples of margin (no job reads them; chunk loads may), reconstructions keep theirs
         self.planes = []
         for i in range(pic.planes.size):
             arr, m = pic.plane_array(i)
-            p = pic.planes[i]
-            if m == 0:                                  # original planes come without margin: give them 8 replicated samples (no job reads them; chunk loads may)
-                pl = hp.plane(np.ascontiguousarray(arr), 8)
-            else:
-                pl = Plane(dev, int(p["width"]), int(p["height"]), m)
-                rows, cols = arr.shape
-                pl.storage[:rows, :cols] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
-            self.planes.append(pl)
-        pool_np = np.concatenate([np.asarray(pic.pool), np.zeros(64, np.int16)])          # (+ slack: chunk loads may run past the last block)
-        self.pool = torch.from_numpy(pool_np).to(dev)
+            self.planes.append(HostPlane(np.asarray(arr), m, m if m else 8))
+        self.pool = np.concatenate([np.asarray(pic.pool), np.zeros(64, np.int16)])          # (+ slack)
         self.n_pic_planes = len(self.planes)
         self.pool_plane = {w: self.n_pic_planes + k for k, w in enumerate(POOL_WIDTHS)}
         assert self.n_pic_planes + len(POOL_WIDTHS) <= 16
-        tab = (MePlane * 16)()
-        for i, pl in enumerate(self.planes):
-            tab[i] = MePlane(pl.storage.data_ptr() + 2 * pl.origin, pl.stride, 0)
-        for w, k in self.pool_plane.items():
-            tab[k] = MePlane(self.pool.data_ptr(), w, 0)
-        self.plane_table, self.n_planes = tab, self.n_pic_planes + len(POOL_WIDTHS)
+        self.n_planes = self.n_pic_planes + len(POOL_WIDTHS)
         strides = np.array([pl.stride for pl in self.planes], np.int64)
 
         me, cand, st, d = pic.me, pic.cand, pic.stage, pic.dist
@@ -166,19 +166,9 @@ class RecordedWorkload:
         self.items_dropped = int((~ok).sum())
         self.items, self.item_expected = np.ascontiguousarray(all_items[ok]), expected[ok]
 
-        # ---- the plan + result buffers
-        self.plan = hp.me_plan_create(self.int_jobs, self.plan_cands, self.stage_jobs, self.items, bit_depth, max_window)
-        self.cand_cost = torch.zeros(max(1, self.plan_cands.size), dtype=torch.int64, device=dev)
-        self.stage_cost = torch.zeros(max(1, 9 * self.stage_jobs.size), dtype=torch.int64, device=dev)
-        self.item_cost = torch.zeros(max(1, self.items.size), dtype=torch.int64, device=dev)
-        self.me_info = hp.me_plan_info(self.plan)
-        self._me_call = hp.bound("vvhip_me_plan_run", self.plan, C.cast(self.plane_table, C.c_void_p), self.n_planes, C.c_void_p(self.cand_cost.data_ptr()),
-                                 C.c_void_p(self.stage_cost.data_ptr()), C.c_void_p(self.item_cost.data_ptr()))
-
-        # ---- TU lists: one job per (size, transform types, residual pitch = width); residual blocks live in the pool
+        # ---- TU lists: one job per (size, transform types); residual blocks live in the pool (pitch = width)
         tu = pic.tu
         self.tu_groups = []
-        tu_jobs, strides_l = [], []
         if tu.size:
             key = np.stack([tu["w"], tu["h"], tu["trHor"], tu["trVer"]], 1).astype(np.int64)
             uniq, inv = np.unique(key, axis=0, return_inverse=True)
@@ -186,23 +176,11 @@ class RecordedWorkload:
                 sel_t = np.nonzero(inv.ravel() == g)[0]
                 if w != h or int(w) not in (4, 8, 16, 32, 64):
                     continue
-                n = sel_t.size
-                off = hp.to_device(tu["pool"][sel_t].astype(np.int32))
-                qf = np.zeros((n, 2), np.int16)
+                qf = np.zeros((sel_t.size, 2), np.int16)
                 qf[:, 0] = tu["qp"][sel_t]
                 qf[:, 1] = (tu["flags"][sel_t] & 1) | (((tu["flags"][sel_t] >> 1) & 1) << 1)
-                d_qp = hp.to_device(qf)
-                lvl = torch.empty(n * int(w) * int(h), dtype=torch.int16, device=dev)
-                rec = torch.empty(n * int(w) * int(h), dtype=torch.int16, device=dev)
-                stt = torch.empty((n, 24), dtype=torch.uint8, device=dev)
-                self.tu_groups.append(dict(w=int(w), h=int(h), tr_hor=int(th), tr_ver=int(tv), n=n, index=sel_t, d_off=off, d_qp=d_qp, level=lvl, rec=rec, stats=stt, qf=qf))
-                tu_jobs.append((int(w), int(h), int(th), int(tv), n, 8, off, d_qp, lvl, rec, stt))
-                strides_l.append(int(w))
-        self.tu_table = hp.make_tu_jobs(tu_jobs) if tu_jobs else None
-        self.tu_strides = (C.c_int32 * max(1, len(strides_l)))(*strides_l)
+                self.tu_groups.append(dict(w=int(w), h=int(h), tr_hor=int(th), tr_ver=int(tv), n=int(sel_t.size), index=sel_t, off=tu["pool"][sel_t].astype(np.int32), qf=qf))
         self.tu_coefficients = int(sum(g["n"] * g["w"] * g["h"] for g in self.tu_groups))
-        self._tu_call = hp.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), bit_depth, self.tu_table[0], self.tu_table[1]) if tu_jobs else None
-
         # ---- DMVR: one list per (reference 0, reference 1, sub-block size)
         self.dmvr_groups = []
         dm = pic.dmvr
@@ -217,10 +195,7 @@ class RecordedWorkload:
                 it["ref1_off"] = (dm["y1"][sel_d].astype(np.int64) + 2) * strides[r1] + dm["x1"][sel_d] + 2
                 for f in ("frac0_x", "frac0_y", "frac1_x", "frac1_y"):
                     it[f] = dm[f.replace("_", "")][sel_d]
-                out = torch.zeros((sel_d.size, 16), dtype=torch.uint8, device=dev)
-                self.dmvr_groups.append(dict(r0=int(r0), r1=int(r1), dx=int(dx), dy=int(dy), n=sel_d.size, index=sel_d, d_items=hp.to_device(it), out=out))
-        self._dmvr_calls = [hp.bound("vvhip_dmvr_refine_batch", self.planes[g["r0"]].buf_ptr, self.planes[g["r0"]].stride, self.planes[g["r1"]].buf_ptr, self.planes[g["r1"]].stride,
-                                     C.c_void_p(g["d_items"].data_ptr()), g["n"], g["dx"], g["dy"], bit_depth, C.c_void_p(g["out"].data_ptr())) for g in self.dmvr_groups]
+                self.dmvr_groups.append(dict(r0=int(r0), r1=int(r1), dx=int(dx), dy=int(dy), n=int(sel_d.size), index=sel_d, items=it))
 
         # ---- accounting (SURVEY 8d figures per unit)
         ev_pairs = int((self.stage_evaluated.sum(1) * self.stage_jobs["width"].astype(np.int64) * self.stage_jobs["height"]).sum()) if self.stage_jobs.size else 0
@@ -229,16 +204,84 @@ class RecordedWorkload:
         self.pairs = {"integer_candidates": cand_pairs, "subpel_positions": ev_pairs, "table_calls": item_pairs}
         rows_eff = (me["h"][c_me[sel]].astype(np.int64) >> cand["subShift"][sel]) if sel.size else np.zeros(0, np.int64)
         self.alg_bytes_me = int((4 * me["w"][c_me[sel]].astype(np.int64) * rows_eff + 8).sum()) if sel.size else 0
+        self.alg_bytes_by_kernel = {"ME_int": self.alg_bytes_me, "ME_stage": 0, "ME_item": 0}
         # a sub-pel position reads (w + 3)(h + 3) reference samples with the 4-tap search filter ((w + 7)(h + 7) with 8 taps) + w * h original samples, writes 8 bytes
         if self.stage_jobs.size:
             taps = np.where(self.stage_jobs["filter_mode"] == 2, 3, np.where(self.stage_jobs["filter_mode"] == 1, 5, 7)).astype(np.int64)
             w_, h_ = self.stage_jobs["width"].astype(np.int64), self.stage_jobs["height"].astype(np.int64)
-            self.alg_bytes_me += int((self.stage_evaluated.sum(1) * (2 * (w_ + taps) * (h_ + taps) + 2 * w_ * h_ + 8)).sum())
-        self.alg_bytes_me += int((4 * self.items["width"].astype(np.int64) * (self.items["height"].astype(np.int64) >> self.items["sub_shift"]) + 8).sum())
+            self.alg_bytes_by_kernel["ME_stage"] = int((self.stage_evaluated.sum(1) * (2 * (w_ + taps) * (h_ + taps) + 2 * w_ * h_ + 8)).sum())
+        self.alg_bytes_by_kernel["ME_item"] = int((4 * self.items["width"].astype(np.int64) * (self.items["height"].astype(np.int64) >> self.items["sub_shift"]) + 8).sum())
+        self.alg_bytes_me = sum(self.alg_bytes_by_kernel.values())
         self.alg_bytes_tu = int(sum(g["n"] * (6 * g["w"] * g["h"] + 24) for g in self.tu_groups))
         self.alg_bytes_dmvr = int(sum(g["n"] * (2 * 2 * (g["dx"] + 5) * (g["dy"] + 5) + 16) for g in self.dmvr_groups))
 
+
+
+class RecordedWorkload:
+    """one recorded picture, resident in HBM, ready to replay"""
+
+    def __init__(self, hp: HotPath, pic, max_window=16, bit_depth=10):
+        lists = pic if isinstance(pic, RecordedLists) else RecordedLists(pic, bit_depth)
+        self.hp, self.lists, self.pic, self.bit_depth = hp, lists, lists.pic, lists.bit_depth
+        dev = hp.device
+        for k in ("n_pic_planes", "pool_plane", "n_planes", "int_jobs", "plan_cands", "cand_expected", "cand_index", "stage_jobs", "stage_index", "stage_expected", "stage_evaluated", "items",
+                  "item_expected", "items_dropped", "tu_coefficients", "pairs", "alg_bytes_me", "alg_bytes_by_kernel", "alg_bytes_tu", "alg_bytes_dmvr"):
+            setattr(self, k, getattr(lists, k))
+        self.planes = []
+        for hpl in lists.planes:
+            pl = Plane(dev, hpl.width, hpl.height, hpl.pad)
+            assert pl.stride == hpl.stride
+            pl.storage = torch.from_numpy(hpl.storage).to(dev)
+            self.planes.append(pl)
+        self.pool = torch.from_numpy(lists.pool).to(dev)
+        tab = (MePlane * 16)()
+        for i, pl in enumerate(self.planes):
+            tab[i] = MePlane(pl.storage.data_ptr() + 2 * pl.origin, pl.stride, 0)
+        for w, k in self.pool_plane.items():
+            tab[k] = MePlane(self.pool.data_ptr(), w, 0)
+        self.plane_table = tab
+        # ---- the plan + result buffers
+        self.plan = hp.me_plan_create(self.int_jobs, self.plan_cands, self.stage_jobs, self.items, bit_depth, max_window)
+        self.cand_cost = torch.zeros(max(1, self.plan_cands.size), dtype=torch.int64, device=dev)
+        self.stage_cost = torch.zeros(max(1, 9 * self.stage_jobs.size), dtype=torch.int64, device=dev)
+        self.item_cost = torch.zeros(max(1, self.items.size), dtype=torch.int64, device=dev)
+        self.me_info = hp.me_plan_info(self.plan)
+        self._me_call = hp.bound("vvhip_me_plan_run", self.plan, C.cast(self.plane_table, C.c_void_p), self.n_planes, C.c_void_p(self.cand_cost.data_ptr()),
+                                 C.c_void_p(self.stage_cost.data_ptr()), C.c_void_p(self.item_cost.data_ptr()))
+
+        # ---- TU lists and DMVR lists on the device
+        self.tu_groups, tu_jobs, strides_l = [], [], []
+        for g in lists.tu_groups:
+            n, w, h = g["n"], g["w"], g["h"]
+            d = dict(g, d_off=hp.to_device(g["off"]), d_qp=hp.to_device(g["qf"]), level=torch.empty(n * w * h, dtype=torch.int16, device=dev),
+                     rec=torch.empty(n * w * h, dtype=torch.int16, device=dev), stats=torch.empty((n, 24), dtype=torch.uint8, device=dev))
+            self.tu_groups.append(d)
+            tu_jobs.append((w, h, g["tr_hor"], g["tr_ver"], n, 8, d["d_off"], d["d_qp"], d["level"], d["rec"], d["stats"]))
+            strides_l.append(w)
+        self.tu_table = hp.make_tu_jobs(tu_jobs) if tu_jobs else None
+        self.tu_strides = (C.c_int32 * max(1, len(strides_l)))(*strides_l)
+        self._tu_call = hp.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), bit_depth, self.tu_table[0], self.tu_table[1]) if tu_jobs else None
+        self.dmvr_groups = [dict(g, d_items=hp.to_device(g["items"]), out=torch.zeros((g["n"], 16), dtype=torch.uint8, device=dev)) for g in lists.dmvr_groups]
+        self._dmvr_calls = [hp.bound("vvhip_dmvr_refine_batch", self.planes[g["r0"]].buf_ptr, self.planes[g["r0"]].stride, self.planes[g["r1"]].buf_ptr, self.planes[g["r1"]].stride,
+                                     C.c_void_p(g["d_items"].data_ptr()), g["n"], g["dx"], g["dy"], bit_depth, C.c_void_p(g["out"].data_ptr())) for g in self.dmvr_groups]
+
     # ------------------------------------------------------------------------------------------------------------------
+    def bind_lanes(self, lanes):
+        """lanes: three HotPath contexts (HotPath.fork) bound to three HIP streams -> the picture's launches as pre-bound calls: motion-search plan on lane 0, TU lists on
+        lane 1, DMVR lists on lane 2 (independent work: they share the device)"""
+        hp0, hp1, hp2 = lanes
+        me = hp0.bound("vvhip_me_plan_run", self.plan, C.cast(self.plane_table, C.c_void_p), self.n_planes, C.c_void_p(self.cand_cost.data_ptr()),
+                       C.c_void_p(self.stage_cost.data_ptr()), C.c_void_p(self.item_cost.data_ptr()))
+        tu = hp1.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), self.bit_depth, self.tu_table[0], self.tu_table[1]) if self.tu_table else None
+        dm = [hp2.bound("vvhip_dmvr_refine_batch", self.planes[g["r0"]].buf_ptr, self.planes[g["r0"]].stride, self.planes[g["r1"]].buf_ptr, self.planes[g["r1"]].stride,
+                        C.c_void_p(g["d_items"].data_ptr()), g["n"], g["dx"], g["dy"], self.bit_depth, C.c_void_p(g["out"].data_ptr())) for g in self.dmvr_groups]
+        self._lane_calls = [c for c in [me, tu] + dm if c is not None]
+        return self._lane_calls
+
+    def run_lanes(self):
+        for c in self._lane_calls:
+            c()
+
     def run_me(self):
         self._me_call()
 
