@@ -611,9 +611,11 @@ def main():
         t_s = (c["total_ns"] / n) * 1e-9 if c.get("total_ns") else kern[dom]["avg_ms_per_picture"] * 1e-3
         fetch, write, l1, valu, ldsi = per("fetch_bytes"), per("write_bytes"), per("l1_accesses"), per("valu_insts"), per("lds_insts")
         traffic = (fetch or 0.0) + (write or 0.0) if fetch is not None else None
-        roof.update({"traffic": traffic, "trace_avg_launch_ms": t_s * 1e3,
+        roof.update({"traffic": traffic, "avg_launch_ms": t_s * 1e3, "launches_per_picture": round(n / 32.0, 2), "ms_per_picture": kern[dom]["avg_ms_per_picture"],
+                     "alg_bytes_per_launch": kern[dom]["alg_bytes_per_picture"] / max(1e-9, n / 32.0), "avg_launch_ms_measured": "rocprofv3 kernel trace of the inner run (the same regime as the HIP-event "
+                     "figure ms_per_picture: launches serialized), averaged over the class's launches of one GOP cycle",
                      "achieved": (traffic / t_s / 1e9) if traffic else None, "frac": (traffic / t_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "traffic_over_alg_bytes": (traffic / kern[dom]["alg_bytes_per_picture"]) if traffic and kern[dom]["alg_bytes_per_picture"] else None,
+                     "traffic_over_alg_bytes": (traffic * (n / 32.0) / kern[dom]["alg_bytes_per_picture"]) if traffic and kern[dom]["alg_bytes_per_picture"] else None,
                      "l1_accesses_per_launch": l1, "l1_access_frac": (l1 / (N_CU * CLOCK_GHZ * 1e9 * t_s)) if l1 else None,
                      "valu_insts_per_launch": valu, "valu_issue_frac": (valu * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9 * t_s)) if valu else None,
                      "lds_insts_per_launch": ldsi})
@@ -621,7 +623,7 @@ def main():
         order = sorted(fr, key=lambda k: -fr[k])
         roof["bound"] = "+".join(k for k in order if fr[k] >= 0.6 * fr[order[0]] and fr[k] > 0) or "hbm"
         roof["limiter"] = "fractions of the launch time: HBM traffic %.3f, L1 (TCP) access slots %.3f (one access per 64-byte granule and instruction, %d CUs x %.1f GHz), VALU issue slots %.3f " \
-                          "(wave instructions x 4 cycles / %d SIMDs); the rest is latency the resident waves do not cover" % (fr["hbm"], fr["l1_access"], fr["valu"], N_CU, CLOCK_GHZ, N_SIMD)
+                          "(wave instructions x 4 cycles / %d SIMDs); the rest is latency the resident waves do not cover" % (fr["hbm"], fr["l1_access"], N_CU, CLOCK_GHZ, fr["valu"], N_SIMD)
         out["pmc"] = {k: {kk: v for kk, v in c.items()} for k, c in live["per_class"].items()}
     else:
         roof.update({"bound": "hbm", "traffic": None, "achieved": kern[dom]["nominal_alg_GBps"], "frac": None, "note": "no live PMC pass (rocprofv3 absent or --no-profile): no physical fraction reported"})

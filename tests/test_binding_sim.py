@@ -57,14 +57,14 @@ def test_every_hook_four_encoder_threads():
 
 @pytest.mark.parametrize("preset", ["faster", "medium"])
 def test_simd_switch_selects_the_binding(preset):
-    """--SIMD=HIP through vvenc_set_SIMD_extension: production set (MCTF search with all references of a picture in one device call + filter, ALF statistics + filtering with
-    resident planes), 4 encoder threads -> several worker contexts"""
+    """--SIMD=HIP through vvenc_set_SIMD_extension: production set (MCTF search with all references of a picture in one device call + filter, whole-picture ALF statistics;
+    whole-picture ALF filtering is bit-exact but not in the set: it loses at 8 encoder threads), 4 encoder threads -> several worker contexts"""
     need()
     clip = dict(CLIP, frames=17, preset=preset, threads=4)
     cpu = run(dict(clip, hip=False, mask=0))
     hip = run(dict(clip, hip=True, simd="HIP"), env=sim_env())
     c = hip["calls"]
-    assert c[9] >= 1 and c[16] >= 1 and c[19] >= 1, c
+    assert c[9] >= 1 and c[16] >= 1 and c[19] == 0, c
     assert c[21] >= 1 and c[7] // 1000000 > c[21], c                   # fewer device ME calls than motion fields: references were batched
     assert c[27] >= 2 and c[28] == 1, c                                # worker contexts, one GPU
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)

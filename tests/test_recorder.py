@@ -1,0 +1,108 @@
+"""CPU tier: the work-list recorder of the binding (bindings/vvenc/vvenc_hip_recorder.*, hook bit 131072) and the host side of the replay (vvenc_amd/recorded.py, replay.py).
+
+The encoder built with the binding records its own hot-path calls while it encodes on the CPU kernels (no device involved).  Checked here:
+  * recording does not change the encode (bitstream = the plain reference encoder's);
+  * the record layouts the loader mirrors, the picture header, the sample-pair counter (what CommonLib/SearchSpaceCounter.cpp counts);
+  * CONSISTENCY with the reference: the reference's own x86-SIMD table entries, driven over the recorded lists on host copies of the recorded planes (oracle/_ref's
+    vvref_run_recorded_mt: plain distortion lists, and the sub-pel stages rebuilt from their descriptors with the reference's InterpolationFilter), return exactly the costs
+    the encoder computed — i.e. operands, positions, tap sets and masks were recorded right;
+  * the host lists built for the device (window jobs, stage jobs, items, TU groups) cover every recorded call."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import e2e_util  # noqa: E402
+
+
+def need():
+    if not (os.path.exists(e2e_util.REF_SO) and os.path.exists(e2e_util.REF_HIP_SO)):
+        pytest.skip("needs oracle/_ref/libvvenc_ref.so and bindings/vvenc/_build/libvvenc_hip_enc.so (built from /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def recording(tmp_path_factory):
+    need()
+    from vvenc_amd import recorded as R
+    d = tmp_path_factory.mktemp("rec")
+    res = R.record(str(d), 416, 240, 17, pocs=(), threads=4)
+    return res, R.load_dir(str(d))
+
+
+def test_recording_leaves_the_encode_unchanged(recording):
+    import e2e_fps
+    res, pics = recording
+    cpu = e2e_fps.run(dict(w=416, h=240, frames=17, threads=4, mask=0))
+    assert res["md5"] == cpu["md5"] and res["bytes"] == cpu["bytes"]
+    assert len(pics) == 17
+
+
+def test_record_layouts_and_counters(recording):
+    from vvenc_amd import recorded as R
+    _, pics = recording
+    assert R.DT["me"].itemsize == 36 and R.DT["cand"].itemsize == 24 and R.DT["stage"].itemsize == 96 and R.DT["dist"].itemsize == 40 and R.DT["tu"].itemsize == 24 and R.DT["dmvr"].itemsize == 48
+    inter = [p for p in pics.values() if p.slice_type != 2]
+    assert inter and any(p.slice_type == 2 for p in pics.values())
+    for p in pics.values():
+        s = p.summary()
+        # every table call is either an integer candidate, an evaluated sub-pel position or a plain call: the three add up to the counter (w x h per call, DMVR excluded)
+        assert s["int_candidate_pairs"] + s["subpel_pairs"] + s["other_pairs"] == p.sample_pairs, s
+        assert int(p.meta["sample_pairs_in_subpel_stages"]) == s["subpel_pairs"]
+        assert p.planes[0]["kind"] == 0 and p.planes[0]["width"] == 416 and all(p.planes[i]["kind"] == 1 for i in range(3, p.planes.size))
+    for p in inter:
+        assert p.me.size and p.cand.size and p.stage.size and p.tu.size
+        assert (p.me["nCand"].sum() == p.cand.size) and (p.me["nStage"].sum() == p.stage.size)
+        assert set(np.unique(p.stage["iFrac"])) <= {1, 2} and (p.stage["reduceTap"] == 2).all() and (p.stage["hadMode"] == 2).all()      # preset faster: 4-tap search filter, HAD_fast
+
+
+def test_reference_entries_reproduce_the_recorded_costs(recording):
+    import bench
+    from vvenc_amd.replay import RecordedLists
+    _, pics = recording
+    n_dist = n_stage = 0
+    for poc, pic in pics.items():
+        L = RecordedLists(pic)
+        assert L.items_dropped == 0
+        # coverage: every recorded candidate is a window candidate or an item, every stage a stage job, every TU in a group
+        assert L.plan_cands.size + L.items.size == pic.cand.size + pic.dist.size
+        assert L.stage_jobs.size == pic.stage.size and sum(g["n"] for g in L.tu_groups) == pic.tu.size
+        J = bench.ReferenceJobs(L, with_outputs=True)
+        J.run(4, 1)
+        exp = np.concatenate([L.cand_expected, L.item_expected])
+        got = np.zeros(exp.size, np.uint64)
+        for sel, out in J.dist_groups:
+            got[sel] = out
+        assert np.array_equal(got, exp), (poc, int((got != exp).sum()))
+        for sel, out in J.stage_groups:
+            assert np.array_equal(out[L.stage_evaluated[sel]], L.stage_expected[sel][L.stage_evaluated[sel]]), poc
+        n_dist += exp.size
+        n_stage += int(L.stage_evaluated.sum())
+    assert n_dist > 50000 and n_stage > 3000, (n_dist, n_stage)
+
+
+def test_early_exit_partial_sums_are_flagged_not_recorded(tmp_path):
+    """64-wide SADs: the x86 row returns a partial sum once it exceeds the best cost so far (x86/RdCostX86.h:390-410); the record holds the full value and flags the call"""
+    need()
+    from vvenc_amd import recorded as R
+    R.record(str(tmp_path), 416, 240, 9, pocs=(4,), threads=1)
+    pic = R.load_dir(str(tmp_path))[4]
+    c = pic.cand
+    w = pic.me["w"][c["me"]]
+    flagged = c["pad"] & 0xff
+    assert (flagged[w < 64] == 0).all()
+    assert flagged[w == 64].any()                                   # the synthetic pan makes the search leave its start point: some candidates do exit early
+    # a flagged value is what the full sum is: recompute a few from the planes
+    org, _ = pic.plane_array(0)
+    k = np.nonzero((flagged == 1) & (pic.me["patternPool"][c["me"]] < 0))[0][:20]
+    for i in k:
+        m = pic.me[c["me"][i]]
+        arr, mg = pic.plane_array(int(m["refPlane"]))
+        o = org[m["cuY"]:m["cuY"] + 64, m["cuX"]:m["cuX"] + 64].astype(np.int64)
+        r = arr[c["y"][i] + mg:c["y"][i] + mg + 64, c["x"][i] + mg:c["x"][i] + mg + 64].astype(np.int64)
+        ss = int(c["subShift"][i])
+        assert int(np.abs(o[::1 << ss] - r[::1 << ss]).sum()) << ss == int(c["cost"][i])
