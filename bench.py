@@ -384,7 +384,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams a picture's three launch groups are issued on (1 = serialized)")
+    ap.add_argument("--streams", type=int, default=5, help="HIP streams a picture's independent launch groups are issued on: 5 = refinement stages / integer windows / table calls / TU / DMVR, "
+                                                           "3 = motion-search plan / TU / DMVR, 1 = serialized")
     ap.add_argument("--exchange-every", type=int, default=1, help="N > 1: one reference-picture broadcast every this many steps (a step is one picture)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -424,7 +425,7 @@ def main():
     # ---- lanes: the motion-search plan, the TU lists and the DMVR lists of a picture are independent work: three HIP streams, one forked context each
     lanes = None
     if args.streams > 1:
-        streams = [torch.cuda.Stream() for _ in range(3)]
+        streams = [torch.cuda.Stream() for _ in range(5 if args.streams >= 5 else 3)]
         lanes = [hp.fork(s) for s in streams]
         for wl in workloads.values():
             wl.bind_lanes(lanes)
@@ -565,7 +566,7 @@ def main():
                                                "dmvr_subblocks": int(sum(g["n"] for g in workloads[l].dmvr_groups)), "plan": workloads[l].me_info} for l in workloads},
                    "subpel_candidates_per_block": round(float(np.mean([workloads[l].stage_evaluated.sum() / max(1, workloads[l].pic.me.size) for l in workloads if workloads[l].pic.me.size])), 2),
                    "launches_per_frame": "motion-search plan (clear + refinement stages + integer windows x 2 LDS classes + table calls) + 1-2 TU launches + 0-1 DMVR launch",
-                   "hip_streams": 3 if lanes else 1, "recording": rec_info,
+                   "hip_streams": len(lanes) if lanes else 1, "recording": rec_info,
                    "sharding": "one picture per rank and step, pictures of one sequence round-robin over ranks, no data-path collective"
                                + (", reconstructed picture (luma + chroma, %.1f MB) RCCL-broadcast from its owner every %d step(s) inside the timed region, overlapped with the launches"
                                   % (sum(p.numel() * 2 for p in ex.slots[0]) / 1e6, args.exchange_every) if ex is not None else "")},

@@ -356,6 +356,10 @@ VVHIP_API void vvhip_me_plan_destroy( vvhip_ctx* ctx, vvhip_me_plan* plan );
  * d_item_cost: n_items Distortion values; pointers of empty lists may be NULL.                                                                              */
 VVHIP_API int  vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes,
                                   uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost );
+/* the same, restricted to some of the plan's three independent parts (bit 0: refinement stages, bit 1: integer windows, bit 2: table calls): a caller with several
+ * contexts / streams issues the parts on different streams so that they share the device (bench.py) */
+VVHIP_API int  vvhip_me_plan_run_parts( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes,
+                                        uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost, int parts );
 /* per-kernel HIP events inside vvhip_me_plan_run (measurements: bench.py's roofline): with timing on, vvhip_me_plan_last_times waits for the last run and returns the
  * milliseconds of its four parts — refinement-stage kernel (incl. the clearing of its cost array), integer windows that need much LDS, the other integer windows, table calls. */
 VVHIP_API int  vvhip_me_plan_set_timing( vvhip_ctx* ctx, vvhip_me_plan* plan, int on );

@@ -26,6 +26,7 @@ struct vvhip_me_plan
   int wavesInt = 0, wavesStage = 0, wavesItem = 0, ldsInt = 0, ldsStage = 0;
   int intBig = 0, ldsIntSmall = 0;          // the first intBig windows need up to ldsInt bytes of LDS, the others at most ldsIntSmall (two launches: small blocks keep their occupancy)
   bool timing = false; hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };      // optional per-kernel events of the last run (vvhip_me_plan_set_timing)
+  int stageSetBig[3] = { 0, 0, 0 };        // of each tap support's bundles, the leading ones of 32- and 64-wide blocks (their own launch; four-wave workgroups were measured slower: 62 -> 95 us)
   int stageSetWaves[3] = { 0, 0, 0 };      // stage bundles per tap support (4-tap search set, 6 taps / alternative half-pel, 8 taps), in schedule order
   void* d_blob = nullptr;                  // one allocation: every table below
   const void* d_intJobs = nullptr; const void* d_cands = nullptr; const void* d_stageJobs = nullptr; const void* d_stageOrder = nullptr; const void* d_stageWaves = nullptr;
@@ -133,7 +134,7 @@ __device__ __forceinline__ int winPitch( int winW ) { int p = ( winW + 2 + 7 ) &
 __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int wave, int16_t* lds )
 {
   const IntJob j = a.intJobs[wave];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
   const int w = j.w, ss = j.subShift, rowsEff = j.h >> ss, lpr = w >> 3;
   const int pitch = winPitch( j.winW );
   int16_t* win = lds;
@@ -141,41 +142,41 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
   {
     const int16_t* ref = P.p[j.refPlane] + j.refOff + ( ptrdiff_t ) j.minDy * P.stride[j.refPlane] + j.minDx;
     const int cpr = pitch >> 3, n = j.winH * cpr, rs = P.stride[j.refPlane];
-    for( int i0 = lane; i0 < n; i0 += 256 )                            // four loads in flight per lane (the loop is latency-bound otherwise)
+    for( int i0 = tid; i0 < n; i0 += 4 * nthr )                        // four loads in flight per lane (the loop is latency-bound otherwise)
     {
       u32x4 v[4]; int at[4];
 #pragma unroll
       for( int q = 0; q < 4; q++ )
       {
-        const int i = i0 + 64 * q < n ? i0 + 64 * q : i0, r = i / cpr, c = i - r * cpr;
+        const int i = i0 + nthr * q < n ? i0 + nthr * q : i0, r = i / cpr, c = i - r * cpr;
         at[q] = r * pitch + c * 8;
         v[q] = ld16( ref + ( ptrdiff_t ) r * rs + c * 8 );
       }
 #pragma unroll
       for( int q = 0; q < 4; q++ )
-        if( i0 + 64 * q < n ) { u32x4 x = v[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( win + at[q] ) = x; }
+        if( i0 + nthr * q < n ) { u32x4 x = v[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( win + at[q] ) = x; }
     }
     const int16_t* org = P.p[j.orgPlane] + j.orgOff;
     const int os = P.stride[j.orgPlane], m = rowsEff * lpr;
-    for( int i0 = lane; i0 < m; i0 += 256 )
+    for( int i0 = tid; i0 < m; i0 += 4 * nthr )
     {
       u32x4 v[4]; int at[4];
 #pragma unroll
       for( int q = 0; q < 4; q++ )
       {
-        const int i = i0 + 64 * q < m ? i0 + 64 * q : i0, r = i / lpr, c = i - r * lpr;
+        const int i = i0 + nthr * q < m ? i0 + nthr * q : i0, r = i / lpr, c = i - r * lpr;
         at[q] = r * w + c * 8;
         v[q] = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 );
       }
 #pragma unroll
       for( int q = 0; q < 4; q++ )
-        if( i0 + 64 * q < m ) { u32x4 x = v[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( orgL + at[q] ) = x; }
+        if( i0 + nthr * q < m ) { u32x4 x = v[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( orgL + at[q] ) = x; }
     }
   }
   __syncthreads();
   const int chunks = rowsEff * lpr;
   int lpc = 64; while( lpc > chunks ) lpc >>= 1;                     // lanes per candidate: a power of two <= min( 64, chunks )   (chunks is a power of two for square blocks)
-  const int teams = 64 / lpc, lt = lane & ( lpc - 1 ), team = lane / lpc;
+  const int teams = nthr / lpc, lt = tid & ( lpc - 1 ), team = tid / lpc;
   const int lprShift = 31 - __builtin_clz( lpr );
   for( int c0 = 0; c0 < j.nCand; c0 += teams )
   {
@@ -302,7 +303,7 @@ template<int K0, int K1>
 __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, const WaveSpan span, int16_t* lds )
 {
   constexpr int NT = K1 - K0 + 1, NP = NT / 2, B0 = ( NT - 2 ) / 2;
-  const int lane = threadIdx.x, bd = a.bitDepth;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, bd = a.bitDepth;
   const int headRoom = 14 - bd > 2 ? 14 - bd : 2;
   const int shift1 = 6 - headRoom, off1 = -( 8192 << shift1 );                       // first (not last) pass: InterpolationFilter.cpp:401-408
   const int shift2 = 6 + headRoom, rnd2 = ( 1 << ( shift2 - 1 ) ) + ( 8192 << 6 );   // second and last pass: :394-400
@@ -319,6 +320,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     const vvhip_me_stage_job j = a.stageJobs[stage];
     const int w = j.width, h = j.height, G = w >> 3, log2G = 31 - __builtin_clz( G );
     const int BH = h < 16 ? h : 16, rowsT = BH + NT;
+    const int ldsPitch = w + 8;                                                    // LDS row pitch: an odd number of 16-byte chunks (rows of a tile column land in different banks)
     const int16_t* ref = P.p[j.ref_plane] + j.ref_off;
     const int rs = P.stride[j.ref_plane];
     const int16_t* org = P.p[j.org_plane] + j.org_off;
@@ -330,66 +332,83 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     {
       if( !( ( j.mask >> k ) & 1 ) ) continue;
       int tx, ty; stagePos( j, k, tx, ty );
-      if( lane == 0 ) posL[nPos] = k | ( ( tx + 64 ) << 8 ) | ( ( ty + 64 ) << 20 );
+      if( tid == 0 ) posL[nPos] = k | ( ( tx + 64 ) << 8 ) | ( ( ty + 64 ) << 20 );
       nPos++;
       if( ( nHor > 0 && tx == hx0 ) || ( nHor > 1 && tx == hx1 ) || ( nHor > 2 && tx == hx2 ) ) continue;
       if( nHor == 0 ) hx0 = tx; else if( nHor == 1 ) hx1 = tx; else hx2 = tx;
       nHor++;
     }
-    for( int i = lane; i < 128; i += 64 ) tapL[i] = stageTap( i >> 3, i & 7, j.filter_mode, j.alt_hpel );
-    { const int f = lane >> 2, i = lane & 3; tapP[lane] = i < NP ? pack2( stageTap( f, K0 + 2 * i, j.filter_mode, j.alt_hpel ), stageTap( f, K0 + 2 * i + 1, j.filter_mode, j.alt_hpel ) ) : 0u; }
-    if( lane < 9 ) costL[lane] = 0;
+    for( int i = tid; i < 128; i += nthr ) tapL[i] = stageTap( i >> 3, i & 7, j.filter_mode, j.alt_hpel );
+    if( tid < 64 ) { const int f = tid >> 2, i = tid & 3; tapP[tid] = i < NP ? pack2( stageTap( f, K0 + 2 * i, j.filter_mode, j.alt_hpel ), stageTap( f, K0 + 2 * i + 1, j.filter_mode, j.alt_hpel ) ) : 0u; }
+    if( tid < 9 ) costL[tid] = 0;
     const bool fast16 = j.func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
     const int tile = fast16 ? 16 : 8, tilesX = w / tile, tilesB = tilesX * ( BH / tile );
     __syncthreads();
-    // ---- H: tmp[v][r][x] <-> plane row y0 + K0 - 4 + r, column x + sx[v]
-    for( int u = lane; u < nHor * rowsT * G; u += 64 )
+    // ---- H: tmp[v][r][x] <-> plane row y0 + K0 - 4 + r, column x + sx[v].  Two units per lane and trip, their four loads issued before the first is used (a unit is short:
+    //      without it every trip of the wave waits out a full memory latency)
+    const int nH = nHor * rowsT * G;
+    for( int ub = tid; ub < nH; ub += 2 * nthr )
     {
-      const int x0 = ( u & ( G - 1 ) ) << 3, rr = u >> log2G, v = rr / rowsT, r = rr - v * rowsT;
-      const int txv = v == 0 ? hx0 : ( v == 1 ? hx1 : hx2 ), sxv = txv >> 4, fxv = txv & 15;
-      const int16_t* p = ref + ( ptrdiff_t ) ( y0 + K0 - 4 + r ) * rs + x0 + sxv;
-      u32x4 ov;
-      if( fxv )
+      u32x4 LA[2], LB[2]; int fxs[2], at[2]; bool ok[2];
+#pragma unroll
+      for( int q = 0; q < 2; q++ )
       {
-        // window samples s[0 .. 6 + NT] = p[K0 - 3 ..]: A = s[0..7] as even pairs W[0..3], B = s[NT - 1 .. NT + 6] as odd pairs S[B0 .. B0 + 3]; the missing pairs by v_alignbit
-        const u32x4 A = ld16( p + K0 - 3 ), B = ld16( p + K0 - 3 + NT - 1 );
-        uint32_t W[4 + NP], S[4 + NP];
-        W[0] = A.x; W[1] = A.y; W[2] = A.z; W[3] = A.w;
-        S[B0] = B.x; S[B0 + 1] = B.y; S[B0 + 2] = B.z; S[B0 + 3] = B.w;
+        const int u = ub + q * nthr;
+        ok[q] = u < nH;
+        const int uu = ok[q] ? u : ub;
+        const int x0 = ( uu & ( G - 1 ) ) << 3, rr = uu >> log2G, v = rr / rowsT, r = rr - v * rowsT;
+        const int txv = v == 0 ? hx0 : ( v == 1 ? hx1 : hx2 ), sxv = txv >> 4;
+        fxs[q] = txv & 15; at[q] = ( v * rowsT + r ) * ldsPitch + x0;
+        const int16_t* p = ref + ( ptrdiff_t ) ( y0 + K0 - 4 + r ) * rs + x0 + sxv;
+        // window samples s[0 .. 6 + NT] = p[K0 - 3 ..]: A = s[0..7] as even pairs W[0..3], B = s[NT - 1 .. NT + 6] as odd pairs S[B0 .. B0 + 3]; zero phase: A = p[0..7]
+        LA[q] = ld16( fxs[q] ? p + K0 - 3 : p ); LB[q] = ld16( p + K0 - 3 + NT - 1 );
+      }
 #pragma unroll
-        for( int m = B0 - 1; m >= 0; m-- ) S[m] = __builtin_amdgcn_alignbit( W[m + 1], W[m], 16 );
-#pragma unroll
-        for( int m = 4; m < 4 + NP - 1; m++ ) W[m] = __builtin_amdgcn_alignbit( S[m], S[m - 1], 16 );
-        uint32_t cp[NP];
-#pragma unroll
-        for( int i = 0; i < NP; i++ ) cp[i] = tapP[fxv * 4 + i];
-        uint32_t o[4];
-#pragma unroll
-        for( int q = 0; q < 4; q++ )
+      for( int q = 0; q < 2; q++ )
+      {
+        if( !ok[q] ) continue;
+        const int fxv = fxs[q];
+        const u32x4 A = LA[q], B = LB[q];
+        u32x4 ov;
+        if( fxv )
         {
-          int e = off1, d = off1;
+          uint32_t W[4 + NP], S[4 + NP];
+          W[0] = A.x; W[1] = A.y; W[2] = A.z; W[3] = A.w;
+          S[B0] = B.x; S[B0 + 1] = B.y; S[B0 + 2] = B.z; S[B0 + 3] = B.w;
 #pragma unroll
-          for( int i = 0; i < NP; i++ ) { e = dot2( W[q + i], cp[i], e ); d = dot2( S[q + i], cp[i], d ); }
-          o[q] = pack2( e >> shift1, d >> shift1 );
+          for( int m = B0 - 1; m >= 0; m-- ) S[m] = __builtin_amdgcn_alignbit( W[m + 1], W[m], 16 );      // the missing pairs by v_alignbit
+#pragma unroll
+          for( int m = 4; m < 4 + NP - 1; m++ ) W[m] = __builtin_amdgcn_alignbit( S[m], S[m - 1], 16 );
+          uint32_t cp[NP];
+#pragma unroll
+          for( int i = 0; i < NP; i++ ) cp[i] = tapP[fxv * 4 + i];
+          uint32_t o[4];
+#pragma unroll
+          for( int qq = 0; qq < 4; qq++ )
+          {
+            int e = off1, d = off1;
+#pragma unroll
+            for( int i = 0; i < NP; i++ ) { e = dot2( W[qq + i], cp[i], e ); d = dot2( S[qq + i], cp[i], d ); }
+            o[qq] = pack2( e >> shift1, d >> shift1 );
+          }
+          ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
         }
-        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
-      }
-      else
-      {
-        const u32x4 A = ld16( p );                                                 // filterCopy<true,false>: ( sample << headRoom ) - 8192 (InterpolationFilter.cpp:285-296)
-        const uint32_t aw[4] = { A.x, A.y, A.z, A.w };
-        uint32_t o[4];
+        else
+        {
+          const uint32_t aw[4] = { A.x, A.y, A.z, A.w };                               // filterCopy<true,false>: ( sample << headRoom ) - 8192 (InterpolationFilter.cpp:285-296)
+          uint32_t o[4];
 #pragma unroll
-        for( int q = 0; q < 4; q++ ) o[q] = pack2( ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) lo16( aw[q] ) << headRoom ) - 8192 ), ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) hi16( aw[q] ) << headRoom ) - 8192 ) );
-        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+          for( int qq = 0; qq < 4; qq++ ) o[qq] = pack2( ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) lo16( aw[qq] ) << headRoom ) - 8192 ), ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) hi16( aw[qq] ) << headRoom ) - 8192 ) );
+          ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        }
+        *reinterpret_cast<u32x4*>( tmp + at[q] ) = ov;
       }
-      *reinterpret_cast<u32x4*>( tmp + ( v * rowsT + r ) * w + x0 ) = ov;
     }
     __syncthreads();
     // ---- VD: eight lanes per (position, tile), lane r = tile row r
-    for( int u0 = 0; u0 < nPos * tilesB * 8; u0 += 64 )
+    for( int u0 = 0; u0 < nPos * tilesB * 8; u0 += nthr )
     {
-      const int u = u0 + lane, r = u & 7, tt = u >> 3;
+      const int u = u0 + tid, r = u & 7, tt = u >> 3;
       const bool valid = u < nPos * tilesB * 8;
       const int pi = valid ? tt / tilesB : 0, t = valid ? tt - pi * tilesB : 0;
       const int tyi = t / tilesX, txi = t - tyi * tilesX;
@@ -398,18 +417,18 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       int d[8];
       if( fast16 )
       {
-        const int16_t* tv = tmp + hv * rowsT * w + txi * 16;
+        const int16_t* tv = tmp + hv * rowsT * ldsPitch + txi * 16;
         const int16_t* po = org + ( ptrdiff_t ) ( y0 + 2 * r ) * os + txi * 16;
         const u32x4 c0v = ld16( po ), c1v = ld16( po + 8 ), e0 = ld16( po + os ), e1 = ld16( po + os + 8 );
         uint32_t pa[4], pb[4]; int ap[4], ao[4];
-        predRow<K0, K1>( tv, w, 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
-        predRow<K0, K1>( tv, w, 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
+        predRow<K0, K1>( tv, ldsPitch, 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
+        predRow<K0, K1>( tv, ldsPitch, 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
         { const uint32_t oa[4] = { c0v.x, c0v.y, c0v.z, c0v.w }, ob[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( oa, ob, ao ); }      // RdCost.cpp:1138-1160
 #pragma unroll
         for( int i = 0; i < 4; i++ ) d[i] = ao[i] - ap[i];
-        predRow<K0, K1>( tv + 8, w, 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
-        predRow<K0, K1>( tv + 8, w, 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
+        predRow<K0, K1>( tv + 8, ldsPitch, 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
+        predRow<K0, K1>( tv + 8, ldsPitch, 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
         { const uint32_t oa[4] = { c1v.x, c1v.y, c1v.z, c1v.w }, ob[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( oa, ob, ao ); }
 #pragma unroll
@@ -417,10 +436,10 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       }
       else
       {
-        const int16_t* tv = tmp + hv * rowsT * w + txi * 8;
+        const int16_t* tv = tmp + hv * rowsT * ldsPitch + txi * 8;
         const u32x4 ovv = ld16( org + ( ptrdiff_t ) ( y0 + tyi * 8 + r ) * os + txi * 8 );
         uint32_t pw[4];
-        predRow<K0, K1>( tv, w, tyi * 8 + r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pw );
+        predRow<K0, K1>( tv, ldsPitch, tyi * 8 + r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pw );
         const uint32_t ow[4] = { ovv.x, ovv.y, ovv.z, ovv.w };
 #pragma unroll
         for( int i = 0; i < 4; i++ ) { d[2 * i] = lo16( ow[i] ) - lo16( pw[i] ); d[2 * i + 1] = hi16( ow[i] ) - hi16( pw[i] ); }
@@ -458,10 +477,10 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     }
     __syncthreads();
     // the unit's share of the stage's costs (blocks of one band: the only share)
-    if( lane < 9 && ( ( j.mask >> lane ) & 1 ) )
+    if( tid < 9 && ( ( j.mask >> tid ) & 1 ) )
     {
-      if( h <= 16 ) a.stageCost[( size_t ) 9 * stage + lane] = costL[lane];
-      else atomicAdd( reinterpret_cast<unsigned long long*>( a.stageCost ) + ( size_t ) 9 * stage + lane, ( unsigned long long ) costL[lane] );
+      if( h <= 16 ) a.stageCost[( size_t ) 9 * stage + tid] = costL[tid];
+      else atomicAdd( reinterpret_cast<unsigned long long*>( a.stageCost ) + ( size_t ) 9 * stage + tid, ( unsigned long long ) costL[tid] );
     }
   }
 }
@@ -596,7 +615,7 @@ meStageKernel( MePlanes P, MeArgs a, int firstWave )
   stageBody<K0, K1>( P, a, a.stageWaves[firstWave + blockIdx.x], meLds );
 }
 
-__global__ void __launch_bounds__( 64 )
+__global__ void __launch_bounds__( 256 )
 meIntKernel( MePlanes P, MeArgs a, int firstWave )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t meLds[];
@@ -682,7 +701,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   for( int i = 0; i < n_stage_jobs; i++ ) if( stage_jobs[i].mask ) for( int b = 0; b < ( stage_jobs[i].height + 15 ) / 16; b++ ) stOrder.push_back( i | ( b << 24 ) );
   std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & 0xffffff]; const auto& y = stage_jobs[b & 0xffffff];
                     return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( x.width != y.width ? x.width > y.width : unitWork( x ) > unitWork( y ) ); } );
-  int setWaves[3] = { 0, 0, 0 };
+  int setWaves[3] = { 0, 0, 0 }, setBig[3] = { 0, 0, 0 };
   for( size_t i = 0; i < stOrder.size(); )
   {
     const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i] & 0xffffff];
@@ -695,8 +714,9 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     }
     WaveSpan sp; sp.first = ( int32_t ) i; sp.count = count; stWaves.push_back( sp );
     setWaves[setOf( s0 )]++;
+    if( s0.width >= 32 ) setBig[setOf( s0 )]++;
     const int bh = std::min( ( int ) s0.height, 16 ), nt = setOf( s0 ) == 0 ? 4 : ( setOf( s0 ) == 1 ? 6 : 8 );
-    ldsStage = std::max( ldsStage, ( 2 * ( 128 + 64 + 16 + 16 ) + 3 * ( bh + nt ) * s0.width ) * 2 );      // tables + three first-pass bands
+    ldsStage = std::max( ldsStage, ( 2 * ( 128 + 64 + 16 + 16 ) + 3 * ( bh + nt ) * ( s0.width + 8 ) ) * 2 );      // tables + three first-pass bands (row pitch width + 8)
     i += count;
   }
 
@@ -750,7 +770,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   p->bitDepth = bit_depth; p->nCands = n_cands; p->nStages = n_stage_jobs; p->nItems = n_items;
   p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size();
   p->ldsInt = ( ldsInt + 15 ) & ~15; p->ldsStage = ( ldsStage + 15 ) & ~15;
-  for( int k = 0; k < 3; k++ ) p->stageSetWaves[k] = setWaves[k];
+  for( int k = 0; k < 3; k++ ) { p->stageSetWaves[k] = setWaves[k]; p->stageSetBig[k] = setBig[k]; }
   p->intBig = intBig; p->ldsIntSmall = ( ldsIntSmall + 15 ) & ~15;
   if( p->ldsInt > 64 * 1024 || p->ldsStage > 64 * 1024 )
   { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_me_plan_create: %d / %d bytes of LDS per wave (max_window too large?)", ldsInt, ldsStage ); }
@@ -793,7 +813,19 @@ int vvhip_me_plan_last_times( vvhip_ctx* ctx, const vvhip_me_plan* plan, float* 
   return VVHIP_OK;
 }
 
+static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes, uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost, int parts );
+
 int vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes, uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost )
+{
+  return mePlanRun( ctx, plan, planes_host, n_planes, d_cand_cost, d_stage_cost, d_item_cost, 7 );
+}
+
+int vvhip_me_plan_run_parts( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes, uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost, int parts )
+{
+  return mePlanRun( ctx, plan, planes_host, n_planes, d_cand_cost, d_stage_cost, d_item_cost, parts );
+}
+
+static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes, uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost, int parts )
 {
   if( !ctx || !plan ) return VVHIP_E_ARG;
   if( !planes_host || n_planes < 1 || n_planes > 16 || ( plan->nCands && !d_cand_cost ) || ( plan->nStages && !d_stage_cost ) || ( plan->nItems && !d_item_cost ) )
@@ -806,22 +838,24 @@ int vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me
   a.stageWaves = static_cast<const WaveSpan*>( plan->d_stageWaves ); a.wavesStage = plan->wavesStage;
   a.items = static_cast<const vvhip_me_item*>( plan->d_items ); a.itemOrder = static_cast<const int32_t*>( plan->d_itemOrder ); a.itemWaves = static_cast<const WaveSpan*>( plan->d_itemWaves ); a.wavesItem = plan->wavesItem;
   a.candCost = d_cand_cost; a.stageCost = d_stage_cost; a.itemCost = d_item_cost; a.bitDepth = plan->bitDepth;
-  const bool tm = plan->timing;
+  const bool tm = plan->timing && parts == 7;
+  const bool doStage = ( parts & 1 ) != 0, doInt = ( parts & 2 ) != 0, doItem = ( parts & 4 ) != 0;
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[0], ctx->stream ) );
   // blocks taller than 16 rows are scored band by band (integer atomic adds into the cost array): it starts from zero
-  if( plan->nStages ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_stage_cost, 0, ( size_t ) 9 * plan->nStages * sizeof( uint64_t ), ctx->stream ) );
+  if( plan->nStages && doStage ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_stage_cost, 0, ( size_t ) 9 * plan->nStages * sizeof( uint64_t ), ctx->stream ) );
   int firstWave = 0;
-  if( plan->stageSetWaves[0] ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) plan->stageSetWaves[0] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  // (one launch per tap support: bundles of 32- / 64-wide blocks first; splitting them from the small blocks' bundles or giving them four-wave workgroups was measured slower)
+  if( plan->stageSetWaves[0] && doStage ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) plan->stageSetWaves[0] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
   firstWave += plan->stageSetWaves[0];
-  if( plan->stageSetWaves[1] ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) plan->stageSetWaves[1] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  if( plan->stageSetWaves[1] && doStage ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) plan->stageSetWaves[1] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
   firstWave += plan->stageSetWaves[1];
-  if( plan->stageSetWaves[2] ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) plan->stageSetWaves[2] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  if( plan->stageSetWaves[2] && doStage ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) plan->stageSetWaves[2] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[1], ctx->stream ) );
-  if( plan->intBig )                  hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->intBig ), dim3( 64 ), ( size_t ) plan->ldsInt, ctx->stream, P, a, 0 );
+  if( plan->intBig && doInt )                  hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->intBig ), dim3( 256 ), ( size_t ) plan->ldsInt, ctx->stream, P, a, 0 );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[2], ctx->stream ) );
-  if( plan->wavesInt > plan->intBig ) hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( plan->wavesInt - plan->intBig ) ), dim3( 64 ), ( size_t ) plan->ldsIntSmall, ctx->stream, P, a, plan->intBig );
+  if( plan->wavesInt > plan->intBig && doInt ) hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( plan->wavesInt - plan->intBig ) ), dim3( 64 ), ( size_t ) plan->ldsIntSmall, ctx->stream, P, a, plan->intBig );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[3], ctx->stream ) );
-  if( plan->wavesItem )  hipLaunchKernelGGL( meItemKernel, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a );
+  if( plan->wavesItem && doItem )  hipLaunchKernelGGL( meItemKernel, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a );
   VVHIP_LAUNCH_CHECK( ctx );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[4], ctx->stream ) );
   return VVHIP_OK;

@@ -267,15 +267,19 @@ class RecordedWorkload:
 
     # ------------------------------------------------------------------------------------------------------------------
     def bind_lanes(self, lanes):
-        """lanes: three HotPath contexts (HotPath.fork) bound to three HIP streams -> the picture's launches as pre-bound calls: motion-search plan on lane 0, TU lists on
-        lane 1, DMVR lists on lane 2 (independent work: they share the device)"""
-        hp0, hp1, hp2 = lanes
-        me = hp0.bound("vvhip_me_plan_run", self.plan, C.cast(self.plane_table, C.c_void_p), self.n_planes, C.c_void_p(self.cand_cost.data_ptr()),
-                       C.c_void_p(self.stage_cost.data_ptr()), C.c_void_p(self.item_cost.data_ptr()))
+        """lanes: HotPath contexts (HotPath.fork) bound to HIP streams -> the picture's launches as pre-bound calls.  Five lanes: refinement stages / integer windows / table calls of
+        the motion-search plan, TU lists, DMVR lists (all independent: they share the device); three lanes: the whole plan on lane 0"""
+        args = (self.plan, C.cast(self.plane_table, C.c_void_p), self.n_planes, C.c_void_p(self.cand_cost.data_ptr()), C.c_void_p(self.stage_cost.data_ptr()), C.c_void_p(self.item_cost.data_ptr()))
+        if len(lanes) >= 5:
+            me = [lanes[0].bound("vvhip_me_plan_run_parts", *args, 1), lanes[1].bound("vvhip_me_plan_run_parts", *args, 2), lanes[2].bound("vvhip_me_plan_run_parts", *args, 4)]
+            hp1, hp2 = lanes[3], lanes[4]
+        else:
+            me = [lanes[0].bound("vvhip_me_plan_run", *args)]
+            hp1, hp2 = lanes[1], lanes[2]
         tu = hp1.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), self.bit_depth, self.tu_table[0], self.tu_table[1]) if self.tu_table else None
         dm = [hp2.bound("vvhip_dmvr_refine_batch", self.planes[g["r0"]].buf_ptr, self.planes[g["r0"]].stride, self.planes[g["r1"]].buf_ptr, self.planes[g["r1"]].stride,
                         C.c_void_p(g["d_items"].data_ptr()), g["n"], g["dx"], g["dy"], self.bit_depth, C.c_void_p(g["out"].data_ptr())) for g in self.dmvr_groups]
-        self._lane_calls = [c for c in [me, tu] + dm if c is not None]
+        self._lane_calls = [c for c in me + [tu] + dm if c is not None]
         return self._lane_calls
 
     def run_lanes(self):
