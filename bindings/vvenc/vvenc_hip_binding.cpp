@@ -189,11 +189,11 @@ int gpuOfFilteredPicture( int filterPoc ) { static std::atomic<int> next{ 0 }; s
   std::lock_guard<std::mutex> g( m ); auto it = of.find( filterPoc ); if( it != of.end() ) return it->second;
   const int gpu = ( vvhip::Device::defaultGpu() + next++ ) % numGpus(); if( of.size() > 64 ) of.erase( of.begin() ); of[filterPoc] = gpu; return gpu; }
 int gpuOfPicture( int poc ) { return ( vvhip::Device::defaultGpu() + ( poc < 0 ? 0 : poc ) ) % numGpus(); }
-struct GpuScope      // binds the calling thread to a device for one hook call
+struct GpuScope      // binds the calling thread to a device for one hook call; scopes nest (dropResident inside a search call, a worker thread bound to its picture's GPU)
 {
-  explicit GpuScope( int gpu ) { if( numGpus() > 1 ) { vvhip::Device::selectGpu( gpu ); on = true; } }
-  ~GpuScope() { if( on ) vvhip::Device::selectGpu( -1 ); }
-  bool on = false;
+  explicit GpuScope( int gpu ) { if( numGpus() > 1 ) { prev = vvhip::Device::selectedGpu(); vvhip::Device::selectGpu( gpu ); on = true; } }
+  ~GpuScope() { if( on ) vvhip::Device::selectGpu( prev ); }
+  bool on = false; int prev = -1;
 };
 void bindPicture( int poc ) { if( numGpus() > 1 ) vvhip::Device::selectGpu( gpuOfPicture( poc ) ); }
 

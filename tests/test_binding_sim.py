@@ -95,6 +95,18 @@ def test_pictures_shard_over_devices():
         assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (n, cpu, hip)
 
 
+def test_sharded_long_sequence_recycles_picture_buffers():
+    """65 frames on three devices: the encoder recycles its original-picture buffers for later POCs, so resident mirrors are dropped and re-made while worker threads and the MCTF
+    thread hold bindings to different devices (nested device scopes: ADVICE r2, GpuScope) — same bitstream, and every device served MCTF calls"""
+    need()
+    clip = dict(CLIP, frames=65, preset="faster", threads=4)
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, simd="HIP"), env=sim_env(VVHIP_SIM_DEVICES=3, VVHIP_GPUS="all"))
+    c = hip["calls"]
+    assert c[28] == 3 and c[21] >= 6 and c[22] > 16 * 3, c                 # three devices, MCTF device calls, more uploads than the resident capacity: buffers were recycled
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
 def test_reference_pictures_resident_for_the_search_sites():
     """reconstructed pictures are mirrored CTU row by CTU row (EncSlice border extension); the TZ diamond rounds and the sub-pel refinement stages then address the reference
     picture in device memory (offsets only) instead of staging a window per call; two logical devices: every device gets every reconstruction"""

@@ -423,13 +423,16 @@ int vvhip_copy_peer( vvhip_ctx* dst_ctx, void* d_dst, vvhip_ctx* src_ctx, const 
   if( !bytes ) return VVHIP_OK;
   // order the copy after what the source context has queued (the producer of d_src), then run it on the destination's stream
   hipEvent_t ev = nullptr;
+  int before = -1;
+  ( void ) hipGetDevice( &before );                      // the calling thread's current device is restored on every path (the shim caches it per thread)
   VVHIP_CHECK_HIP( dst_ctx, hipSetDevice( src_ctx->device ) );
-  VVHIP_CHECK_HIP( dst_ctx, hipEventCreateWithFlags( &ev, hipEventDisableTiming ) );
-  hipError_t e = hipEventRecord( ev, src_ctx->stream );
+  hipError_t e = hipEventCreateWithFlags( &ev, hipEventDisableTiming );
+  if( e == hipSuccess ) e = hipEventRecord( ev, src_ctx->stream );
   if( e == hipSuccess ) e = hipSetDevice( dst_ctx->device );
   if( e == hipSuccess ) e = hipStreamWaitEvent( dst_ctx->stream, ev, 0 );
   if( e == hipSuccess ) e = hipMemcpyPeerAsync( d_dst, dst_ctx->device, d_src, src_ctx->device, bytes, dst_ctx->stream );
-  ( void ) hipEventDestroy( ev );
+  if( ev ) ( void ) hipEventDestroy( ev );
+  if( before >= 0 ) ( void ) hipSetDevice( before );
   if( e != hipSuccess ) return vvhip_fail( dst_ctx, VVHIP_E_HIP, "vvhip_copy_peer: %s", hipGetErrorString( e ) );
   return VVHIP_OK;
 }

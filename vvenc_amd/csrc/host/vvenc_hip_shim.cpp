@@ -89,6 +89,7 @@ int Device::defaultGpu() { static const int g = []{ const char* e = getenv( "VVH
 static int logicalGpus() { static const int n = []{ const char* e = getenv( "VVHIP_LOGICAL_GPUS" ); return e ? atoi( e ) : 0; }(); return n; }
 int Device::gpuCount() { return logicalGpus() > 0 ? logicalGpus() : vvhip_device_count(); }
 void Device::selectGpu( int gpu ) { t_dev.selected = gpu; }
+int Device::selectedGpu() { return t_dev.selected; }
 
 Device& Device::get()
 {
@@ -932,6 +933,10 @@ bool ALFOps::pictureStatistics( const Pel* const rec[3], const int recStride[3],
   }
   for( int c = 0; c < 3; c++ ) { oOff[c] = orgTotal; orgTotal += ( ( size_t ) op[c] * h[c] + 127 ) & ~( size_t ) 127; }
   m_res.valid = false;
+  if( m_res.gpu != dev.gpu() && m_res.dCls )      // the class buffer lives (and is read by the filter kernels) on the same GPU as the planes: it moves with them
+  {
+    vvhip_free( dev.ctx(), m_res.dCls ); m_res.dCls = nullptr; m_res.clsBytes = 0;
+  }
   if( m_res.gpu != dev.gpu() || m_res.elems < recTotal )
   {
     if( m_res.d ) { vvhip_free( dev.ctx(), m_res.d ); m_res.d = nullptr; }      // (hipFree finds the owning device itself)

@@ -86,6 +86,7 @@ class Device
 public:
   static Device& get();                      // the calling thread's context on its selected GPU (creates it on first use; throws without a GPU)
   static void    selectGpu( int gpu );       // bind the calling thread to a device (< 0: the default, $VVHIP_DEVICE or 0)
+  static int     selectedGpu();              // the calling thread's binding as selectGpu set it (< 0: default) — scopes save and restore it
   static int     gpuCount();                 // devices visible to the process
   static int     defaultGpu();
   int        gpu() const { return m_gpu; }
