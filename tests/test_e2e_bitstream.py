@@ -1,7 +1,7 @@
 """End-to-end bit-exactness gate (BASELINE metric: "bit-exact vs CPU"): the REAL reference encoder, compiled from /root/reference into
 oracle/_ref/, encodes a synthetic clip
   * with its scalar, SSE4.1 and AVX2 kernel rows (the reference's own invariant, cmake/modules/vvencTests.cmake:52-53)      [CPU tier]
-  * with its kernel tables pointed at the HIP back-end through the table-shaped shim (hook-enabled build, oracle/ref/hip_hooks.cpp):
+  * with its kernel tables pointed at the HIP back-end through the table-shaped shim (build with the binding, bindings/vvenc/):
     RdCost distortion entries, fused 2-D transforms, Quant cores, MCTF error entries and the whole-picture MCTF ME          [GPU tier]
 and every bitstream must have the same md5.  Each run is a separate process (the SIMD level is process-wide state in the reference)."""
 import json
@@ -66,7 +66,7 @@ def test_reference_rows_agree(clip):
 @pytest.mark.parametrize("clip", [CFG1, CFG10], ids=["cfg0-64x64-8b", "128x64-10b"])
 def test_hip_backend_bitstream_identical(clip):
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=31))
     print("cpu", cpu, "hip", hip)
@@ -79,7 +79,7 @@ def test_hip_table_entries_only_bitstream_identical():
     """same gate with the MCTF search left to the reference's own schedule calling our per-candidate table entries
     (m_motionErrorLumaInt8 / m_motionErrorLumaFrac8[1] / m_calcVar through the shim) instead of the whole-picture device ME"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     cpu = run(dict(CFG1, hip=False, simd=None, mask=0))
     hip = run(dict(CFG1, hip=True, simd=None, mask=15))
     print("cpu", cpu, "hip", hip)
@@ -92,7 +92,7 @@ def test_hip_tcoeffops_slots_bitstream_identical():
     """the reference's global g_tCoeffOps pointed at the device slots (identical signatures, zero source change): every matrix-core
     pass, round/clip and Pel<->TCoeff copy of the encode runs on the GPU one call at a time; bitstream must not change"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     cpu = run(dict(CFG1, hip=False, simd=None, mask=0))
     hip = run(dict(CFG1, hip=True, simd=None, mask=32))
     print("cpu", cpu, "hip", hip)
@@ -106,7 +106,7 @@ def test_hip_interpolation_tables_bitstream_identical():
     the device entries, so all motion compensation and sub-pel refinement planes of the encode are interpolated on the GPU (one call at a
     time); bitstream must not change"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     cpu = run(dict(CFG1, hip=False, simd=None, mask=0))
     hip = run(dict(CFG1, hip=True, simd=None, mask=64))
     print("cpu", cpu, "hip", hip)
@@ -121,7 +121,7 @@ def test_hip_mctf_stage_on_device_bitstream_identical(clip):
     (mask 128) — against the CPU encode.  The device filter equals the reference's scalar row; its AVX2 row (the CPU run here) is allowed
     +-1 by the reference's unit test, and on these clips the bitstreams are identical."""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=16 + 128))
     print("cpu", cpu, "hip", hip)
@@ -135,7 +135,7 @@ def test_hip_backend_multithreaded_encoder_bitstream_identical():
     are shared: SURVEY 8b "Threading"); the shim serialises its staging area.  Every table on the device (mask 31 + interpolation 64 +
     MCTF filter 128), bitstream equal to the single-threaded CPU encode's (the reference's multi-threading is deterministic)."""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     cpu = run(dict(CFG10, hip=False, simd=None, mask=0, threads=4))
     hip = run(dict(CFG10, hip=True, simd=None, mask=31 + 64 + 128, threads=4))
     print("cpu", cpu, "hip", hip)
@@ -150,7 +150,7 @@ def test_hip_batched_subpel_refinement_bitstream_identical(clip):
     (up to) nine candidate costs from ONE vvhip_subpel_refine_batch call (through vvhip::RdCost::patternRefineCosts); the encoder's own loop
     replays them (skip and break rules, MV-bit costs, strict < update, patternId bookkeeping).  Everything else on the CPU."""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=256))
     print("cpu", cpu, "hip", hip)
@@ -165,7 +165,7 @@ def test_hip_dmvr_search_bitstream_identical(clip):
     vvhip_dmvr_refine_batch call (vvhip::DMVROps::refineCu); the encoder copies mvdL0SubPu / the BDOF switch from the results and does the final
     motion compensation itself.  DMVR is decoder-normative: any deviation changes the bitstream."""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=512))
     print("cpu", cpu, "hip", hip)
@@ -179,7 +179,7 @@ def test_hip_alf_statistics_bitstream_identical():
     device (hook mask 2048, vvhip::ALFOps) instead of deriveClassification / getPreBlkStats.  The ALF filter derivation works on these floats — a single
     differently rounded sum can change a coefficient — so identical bitstreams pin the float accumulation order in the real pipeline."""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=2048 + 4096))
@@ -193,7 +193,7 @@ def test_hip_alf_picture_statistics_bitstream_identical():
     """the whole-picture form (hook mask 8192): the per-CTU statistics tasks of the encoder do nothing, EncAdaptiveLoopFilter::deriveFilter starts with ONE device
     call per picture (classification + luma / chroma records of every 128x128 statistics unit, CTU-by-CTU chains inside a unit); small clip and 1080p"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=8192))
@@ -212,7 +212,7 @@ def test_hip_alf_statistics_1080p_bitstream_identical():
     """the same at 1080p (preset faster: 64x64 CTUs inside 128x128 statistics units, so the float chains continue from CTU to CTU through the
     start records): 510 CTUs per ALF picture, 8 encoder threads"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     import e2e_fps
     res = [e2e_fps.run(dict(w=1920, h=1080, frames=9, threads=8, mask=m)) for m in (0, 2048 + 4096)]
     print(res)
@@ -226,7 +226,7 @@ def test_hip_alf_filtering_bitstream_identical():
     and applyCcAlfFilterCTU hands to m_filterCcAlf is filtered on the device instead.  The filtered reconstruction is the reference of the following pictures, so one
     differing sample changes the bitstream.  Small clip, and 1080p with the statistics on the device as well (8 encoder threads)."""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=16384 + 32768))
@@ -245,7 +245,7 @@ def test_hip_alf_picture_filtering_bitstream_identical():
     """the whole ALF stage of a picture in two shim calls (hook masks 8192 + 65536): statistics of every unit before the derivation, and after it the filtering of every
     enabled CTU of the three planes by the first reconstruction task of the picture (the other tasks find the picture done); CC-ALF per block (32768)"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=8192 + 65536))
@@ -264,7 +264,7 @@ def test_hip_4k_picture_level_stages_bitstream_identical():
     """BASELINE's 4K geometry (3840x2160 10-bit, preset faster) in the real encoder: the picture-level stages on the device — MCTF search + bilateral filter (144), ALF
     statistics (8192) and ALF filtering (65536) of whole pictures — 9 frames, 8 encoder threads"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     import e2e_fps
     res = [e2e_fps.run(dict(w=3840, h=2160, frames=9, threads=8, mask=m)) for m in (0, 144 + 8192 + 65536)]
     print(res)
@@ -277,7 +277,7 @@ def test_hip_everything_on_device_bitstream_identical():
     """all hooks at once on a larger clip (208x120 10-bit, 9 frames, 2 encoder threads): every kernel table, the interpolation tables, whole-picture
     MCTF ME + filter, batched integer diamond rounds, batched sub-pel refinement stages, per-CU DMVR searches, per-CTU ALF statistics and ALF / CC-ALF filtering"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(w=208, h=120, frames=9, in_bd=10, int_bd=10, threads=2)
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=31 + 64 + 128 + 256 + 512 + 1024 + 2048 + 4096 + 16384 + 32768))
@@ -293,7 +293,7 @@ def test_hip_batched_tz_diamond_rounds_bitstream_identical(clip):
     may test are scored by ONE device call (vvhip::RdCost::distAtPositions -> vvhip_dist_batch); xTZSearchHelp takes its SAD from that table and
     runs its own update logic (MV-bit cost, strict <).  Everything else on the CPU."""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     cpu = run(dict(clip, hip=False, simd=None, mask=0))
     hip = run(dict(clip, hip=True, simd=None, mask=1024))
     print("cpu", cpu, "hip", hip)
@@ -315,7 +315,7 @@ PICTURE_STAGES = 16 + 128 + 8192 + 65536
 @pytest.mark.parametrize("preset", ["faster", "fast", "medium"])
 def test_hip_presets_all_tables_bitstream_identical(preset):
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(CLIP416, frames=5, preset=preset)
     cpu = run(dict(clip, hip=False, mask=0))
     hip = run(dict(clip, hip=True, mask=ALL_TABLES))
@@ -328,7 +328,7 @@ def test_hip_presets_all_tables_bitstream_identical(preset):
 @pytest.mark.parametrize("preset", ["faster", "fast", "medium"])
 def test_hip_presets_batched_search_sites_bitstream_identical(preset):
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(CLIP416, frames=5, preset=preset)
     cpu = run(dict(clip, hip=False, mask=0))
     hip = run(dict(clip, hip=True, mask=BATCHED_SITES))
@@ -341,16 +341,18 @@ def test_hip_presets_batched_search_sites_bitstream_identical(preset):
 @pytest.mark.gpu
 @pytest.mark.parametrize("preset", ["faster", "fast", "medium"])
 def test_hip_presets_picture_stages_through_simd_switch_bitstream_identical(preset):
-    """the production selection, --SIMD=HIP (vvenc_set_SIMD_extension("HIP") -> VVEncImpl::setSIMDExtension -> vvenc_hip_select): MCTF search + filter, ALF statistics and
-    ALF filtering of whole pictures on the device; 17 frames so that MCTF filters two pictures"""
+    """the production selection, --SIMD=HIP (vvenc_set_SIMD_extension("HIP") -> VVEncImpl::setSIMDExtension -> vvenc_hip_select): MCTF search + filter and ALF statistics of
+    whole pictures on the device (whole-picture ALF filtering is an explicit mask: it loses at 8 encoder threads); 17 frames so that MCTF filters two pictures"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(CLIP416, frames=17, preset=preset)
     cpu = run(dict(clip, hip=False, mask=0))
     hip = run(dict(clip, hip=True, simd="HIP"))
     print("cpu", cpu, "hip", hip)
-    assert hip["calls"][9] >= 1 and hip["calls"][21] >= 1 and hip["calls"][16] >= 1 and hip["calls"][19] >= 1, hip["calls"]
+    assert hip["calls"][9] >= 1 and hip["calls"][21] >= 1 and hip["calls"][16] >= 1 and hip["calls"][19] == 0, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+    full = run(dict(clip, hip=True, simd="HIP:%d" % PICTURE_STAGES))          # + whole-picture ALF filtering
+    assert full["calls"][19] >= 1 and full["md5"] == cpu["md5"], (cpu, full)
 
 
 @pytest.mark.gpu
@@ -358,7 +360,7 @@ def test_hip_lfnst_quantiser_guard_bitstream_identical():
     """with RDOQ and DepQuant off the encoder's scalar quantiser (Quant::xQuant) is the main path, and LFNST TUs must see QuantCore's first-coefficient-group
     rule (Quant.cpp:152-159): the binding leaves them to the CPU entry, everything else goes to the device core"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(w=208, h=120, frames=5, in_bd=10, int_bd=10, preset="fast", options="RDOQ=0;DepQuant=0;LFNST=1")
     cpu = run(dict(clip, hip=False, mask=0))
     hip = run(dict(clip, hip=True, mask=4))
@@ -371,10 +373,10 @@ def test_hip_lfnst_quantiser_guard_bitstream_identical():
 def test_hip_4k_medium_picture_stages_bitstream_identical():
     """BASELINE configs[3] geometry: 3840x2160 10-bit, preset medium (CTU 128, MTT), picture-level stages on the device through --SIMD=HIP, 9 frames, 8 threads"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(w=3840, h=2160, frames=9, in_bd=10, int_bd=10, threads=8, preset="medium", clip="pan")
     cpu = run(dict(clip, hip=False, mask=0))
-    hip = run(dict(clip, hip=True, simd="HIP"))
+    hip = run(dict(clip, hip=True, simd="HIP:73872"))          # production set + whole-picture ALF filtering (65536)
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][9] >= 1 and hip["calls"][16] >= 1 and hip["calls"][19] >= 1, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
@@ -384,10 +386,10 @@ def test_hip_4k_medium_picture_stages_bitstream_identical():
 def test_hip_8k_fast_picture_stages_bitstream_identical():
     """BASELINE configs[4] geometry: 7680x4320 10-bit, preset fast, picture-level stages on the device, 3 frames, 8 threads"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(w=7680, h=4320, frames=3, in_bd=10, int_bd=10, threads=8, preset="fast", clip="pan")
     cpu = run(dict(clip, hip=False, mask=0))
-    hip = run(dict(clip, hip=True, simd="HIP"))
+    hip = run(dict(clip, hip=True, simd="HIP:73872"))
     print("cpu", cpu, "hip", hip)
     assert hip["calls"][16] >= 1 and hip["calls"][19] >= 1, hip["calls"]
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
@@ -399,11 +401,41 @@ def test_hip_pictures_shard_over_logical_devices_bitstream_identical():
     pictures over them — per-device registries, thread -> device binding per picture, device-to-device copies (hipMemcpyPeerAsync) of originals another device already holds.
     Preset medium (overlapping MCTF windows => peer copies), 25 frames, 4 threads; bitstream equal to the CPU encode's"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(CLIP416, frames=25, preset="medium")
     cpu = run(dict(clip, hip=False, mask=0))
     hip = run(dict(clip, hip=True, simd="HIP"), env={"VVHIP_LOGICAL_GPUS": "2", "VVHIP_GPUS": "2"})
     print("cpu", cpu, "hip", hip)
     c = hip["calls"]
     assert c[28] == 2 and c[24] >= 1 and c[9] >= 1, c          # two devices in use, device-to-device picture copies, MCTF filter pictures
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+# ---- BASELINE configs at FULL length (VERDICT r2 item 5)
+@pytest.mark.gpu
+def test_config2_4k_65_frames_faster_production_bitstream_identical():
+    """BASELINE configs[2]: 3840x2160 10-bit, 65 frames, preset faster, --SIMD=HIP (MCTF block matching + filter and whole-picture ALF statistics on the MI355X), 8 encoder
+    threads: the bitstream of the whole sequence equals the CPU encoder's"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
+    import e2e_fps
+    cpu = e2e_fps.run(dict(w=3840, h=2160, frames=65, threads=8, mask=0), timeout=1200)
+    hip = e2e_fps.run(dict(w=3840, h=2160, frames=65, threads=8, mask=16 + 128 + 8192), timeout=1200)
+    print(cpu, hip)
+    assert hip["calls"][9] >= 8 and hip["calls"][16] >= 60 and hip["calls"][21] >= 8, hip["calls"]      # MCTF-filtered pictures, ALF statistics pictures, device ME calls
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+def test_config3_4k_medium_33_frames_two_logical_devices_bitstream_identical():
+    """BASELINE configs[3] geometry at GOP length + 1: 3840x2160 10-bit, 33 frames, preset medium (CTU 128, MTT), pictures sharded over two logical devices (one physical GPU:
+    per-device registries, thread -> device binding, device-to-device picture copies), --SIMD=HIP"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
+    clip = dict(w=3840, h=2160, frames=33, in_bd=10, int_bd=10, threads=8, preset="medium", clip="pan")
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, simd="HIP"), env={"VVHIP_LOGICAL_GPUS": "2", "VVHIP_GPUS": "2"})
+    print("cpu", cpu, "hip", hip)
+    c = hip["calls"]
+    assert c[28] == 2 and c[9] >= 4 and c[16] >= 30, c
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
