@@ -174,10 +174,10 @@ patch("EncAdaptiveLoopFilter.cpp", [
     ("before", "  }  \n}\n\nvoid EncAdaptiveLoopFilter::copyCTUforALF(", "    }\n"),
     # whole-picture ALF statistics: the per-CTU tasks do nothing, the first thing deriveFilter does is ONE device call for the picture
     ("before", "  const PreCalcValues& pcv = *cs.pcv;\n  const int xC = ( ctuRsAddr % pcv.widthInCtus ) << pcv.maxCUSizeLog2;",
-     "  if( ( g_vvhipHooks.alfPicture && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) ) return;\n"),
+     "  if( ( g_vvhipHooks.alfPicture && g_vvhipHooks.alfPictureOn( ( int ) m_numCTUsInPic, m_encCfg->m_numThreads ) && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) ) return;\n"),
     ("after", "  initCABACEstimator( cs.slice );\n\n  // Accumulate ALF statistic\n",
      "  if( g_vvhipHooks.alfBeginPicture ) g_vvhipHooks.alfBeginPicture( this, cs.picture->poc );\n"
-     "  if( ( g_vvhipHooks.alfPicture && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) && numCtus == ( int ) m_numCTUsInPic )\n"
+     "  if( ( g_vvhipHooks.alfPicture && g_vvhipHooks.alfPictureOn( ( int ) m_numCTUsInPic, m_encCfg->m_numThreads ) && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) && numCtus == ( int ) m_numCTUsInPic )\n"
      "  {\n"
      "    static thread_local std::vector<uint8_t> hCls; static thread_local std::vector<float> hSt[3];\n"
      "    hCls.resize( ( size_t ) ( m_picWidth / 4 ) * ( m_picHeight / 4 ) * 2 );\n"

@@ -588,6 +588,14 @@ void alfBeginPicture( const void* owner, int /*poc*/ )
 }
 
 std::atomic<uint64_t> g_alfPictures{ 0 };
+// The whole-picture statistics call runs inside the serial part of the ALF stage (deriveFilter): one upload + three launches + a download per picture against CPU work that is
+// spread over the worker threads.  It pays when the pool is saturated — measured: 1080p (510 CTUs) with 2 / 4 threads +16 / +14 %, 4K (2040 CTUs) with 8 threads +8...13 %,
+// 1080p with 8 threads +-0 (profiles/r02_e2e_encoder_fps.md, r03) — so the hook is taken from $VVHIP_ALF_MIN_CTUS_PER_THREAD CTUs per encoder thread on (default 100).
+bool alfPictureOn( int numCtusInPic, int numThreads )
+{
+  static const int minPerThread = []{ const char* e = getenv( "VVHIP_ALF_MIN_CTUS_PER_THREAD" ); return e ? atoi( e ) : 100; }();
+  return numCtusInPic >= minPerThread * ( numThreads > 0 ? numThreads : 1 );
+}
 bool alfPicture( const void* owner, int poc, const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int bitDepth,
                  int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] )
 {
@@ -696,6 +704,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_install( i
   g_vvhipHooks.alfCtu = ( mask & 2048 ) ? alfCtu : nullptr; g_alfCtus = 0;
   g_vvhipHooks.ccAlfCtu = ( mask & 4096 ) ? ccAlfCtu : nullptr; g_ccAlfCtus = 0;
   g_vvhipHooks.alfPicture = ( mask & 8192 ) ? alfPicture : nullptr; g_alfPictures = 0;
+  g_vvhipHooks.alfPictureOn = alfPictureOn;
   g_vvhipHooks.alfBeginPicture = ( mask & ( 8192 | 65536 ) ) ? alfBeginPicture : nullptr;
   g_vvhipHooks.alfFilterBlk = ( mask & 16384 ) ? alfFilterBlk : nullptr; g_alfFilterBlks = 0;
   g_vvhipHooks.ccAlfFilterBlk = ( mask & 32768 ) ? ccAlfFilterBlk : nullptr; g_ccAlfFilterBlks = 0;

@@ -9,6 +9,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the small test clips have a handful of CTUs per encoder thread: take the whole-picture ALF statistics hook regardless of the binding's saturation rule (vvenc_hip_binding.cpp: alfPictureOn)
+os.environ.setdefault("VVHIP_ALF_MIN_CTUS_PER_THREAD", "0")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import e2e_util  # noqa: E402
 from test_e2e_bitstream import run, ALL_TABLES, BATCHED_SITES  # noqa: E402
@@ -68,6 +70,18 @@ def test_simd_switch_selects_the_binding(preset):
     assert c[21] >= 1 and c[7] // 1000000 > c[21], c                   # fewer device ME calls than motion fields: references were batched
     assert c[27] >= 2 and c[28] == 1, c                                # worker contexts, one GPU
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+def test_alf_picture_statistics_follow_the_saturation_rule():
+    """the whole-picture ALF statistics call sits in the serial filter derivation: the binding takes it only from $VVHIP_ALF_MIN_CTUS_PER_THREAD CTUs per encoder thread on
+    (default 100: 1080p with <= 4 threads, 4K with <= 16); below it the per-CTU CPU tasks stay — same bitstream either way"""
+    need()
+    clip = dict(CLIP, frames=9, preset="faster", threads=4)
+    cpu = run(dict(clip, hip=False, mask=0))
+    off = run(dict(clip, hip=True, simd="HIP"), env=sim_env(VVHIP_ALF_MIN_CTUS_PER_THREAD=100))
+    on = run(dict(clip, hip=True, simd="HIP"), env=sim_env(VVHIP_ALF_MIN_CTUS_PER_THREAD=1))
+    assert off["calls"][16] == 0 and on["calls"][16] >= 1 and off["calls"][9] >= 1, (off["calls"], on["calls"])
+    assert off["md5"] == cpu["md5"] and on["md5"] == cpu["md5"]
 
 
 def test_simd_switch_refuses_without_device():

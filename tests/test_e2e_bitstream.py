@@ -12,6 +12,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the small test clips have a handful of CTUs per encoder thread: take the whole-picture ALF statistics hook regardless of the binding's saturation rule (vvenc_hip_binding.cpp: alfPictureOn)
+os.environ.setdefault("VVHIP_ALF_MIN_CTUS_PER_THREAD", "0")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import e2e_util  # noqa: E402
 

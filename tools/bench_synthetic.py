@@ -258,6 +258,34 @@ def mctf_stage(hp, wl, refs=4, reps=5):
     outs, dims = hp.mctf_motion_estimation(cur, ref_pl, bd, 16, 4, add_level)
     out["me_ms_per_picture"] = timed_ms(lambda: hp.mctf_motion_estimation(cur, ref_pl, bd, 16, 4, add_level, out=outs), reps)
     out["me_ms_one_reference"] = timed_ms(lambda: hp.mctf_motion_estimation(cur, ref_pl[:1], bd, 16, 4, add_level, out=outs[:1]), reps)
+    # MCTF-filtered pictures are independent of each other (MCTF.cpp:666-724: originals only): k pictures in flight, one context + stream + host thread each (the call ends with a
+    # host synchronisation: the hand-off abort flag).  The sweep of a picture (phase B) is one workgroup per reference: alone it leaves the device empty.
+    import threading
+    import time as _t
+    for k in (2, 4):
+        try:
+            ctxs = [hp.fork(torch.cuda.Stream()) for _ in range(k)]
+            fouts = [ctxs[i].mctf_motion_estimation(cur, ref_pl, bd, 16, 4, add_level)[0] for i in range(k)]
+            torch.cuda.synchronize()
+
+            def work(i, n):
+                for _ in range(n):
+                    ctxs[i].mctf_motion_estimation(cur, ref_pl, bd, 16, 4, add_level, out=fouts[i])
+            n = max(2, reps)
+            th = [threading.Thread(target=work, args=(i, n)) for i in range(k)]
+            t0 = _t.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            out["me_ms_per_picture_%d_in_flight" % k] = 1000.0 * (_t.perf_counter() - t0) / (n * k)
+            same = all(bool(torch.equal(fouts[i][r], outs[r])) for i in range(k) for r in range(refs))
+            out["in_flight_fields_identical"] = bool(out.get("in_flight_fields_identical", True) and same)
+            for c in ctxs:
+                c.close()
+        except Exception as e:
+            out["me_in_flight_error"] = str(e)[:200]
     # bilateral filter: luma + both chroma planes (4:2:0), the fields stay on the device
     def yuv(y):
         return (y, np.clip(y[::2, ::2] // 2 + 256, 0, (1 << bd) - 1).astype(np.int16), np.clip((1 << bd) - 1 - y[::2, ::2] // 3, 0, (1 << bd) - 1).astype(np.int16))
