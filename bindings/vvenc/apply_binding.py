@@ -41,6 +41,8 @@ patch("TrQuant.cpp", [
     ("after", '#include "TrQuant.h"', INC),
     ("before", "  TCoeff* block = m_blk;",
      "  if( g_vvhipHooks.recTu && width > 1 && height > 1 ) g_vvhipHooks.recTu( &tu, ( int ) compID, resi.buf, ( long ) resi.stride, width, height, trTypeHor, trTypeVer, bitDepth );\n"
+     "  if( g_vvhipHooks.tuLookup && width > 2 && height > 2 && !tu.cu->lfnstIdx && trTypeHor == DCT2 && trTypeVer == DCT2 &&\n"
+     "      g_vvhipHooks.tuLookup( resi.buf, resi.stride, dstCoeff.buf, width, height ) ) return;\n"
      "  if( g_vvhipHooks.fwd2D && width > 1 && height > 1 && !tu.cu->lfnstIdx &&\n"
      "      g_vvhipHooks.fwd2D( resi.buf, resi.stride, dstCoeff.buf, width, height, trTypeHor, trTypeVer, bitDepth ) ) return;\n"),
     ("before", "  TCoeff *block = m_blk;",
@@ -107,6 +109,16 @@ patch("InterSearch.cpp", [
      "  CodedCUInfo &relatedCU = m_modeCtrl->getBlkInfo( cu );"),
     ("before", "  DTRACE(g_trace_ctx, D_ME, \"   MECost<L%d,%d>: %6d (%d)  MV:%d,%d\\n\"", "  if( g_vvhipHooks.recMeEnd ) g_vvhipHooks.recMeEnd();\n"),
     ("before", "  rcMvFrac = pcMvRefine[uiDirecBest];", "  if( g_vvhipHooks.recStageEnd ) g_vvhipHooks.recStageEnd();\n"),
+    # residual loop (xEstimateInterResidualQT): the forward transforms of all component TUs of the CU in ONE device round trip before the component loop; TrQuant::xT then finds
+    # its coefficients ready (tuLookup in front of the CPU cores).  need-RDOQ / RDOQ / rate estimation stay where they are.
+    ("before", "    for( uint32_t c = 0; c < numTBlocks; c++ )\n    {\n      const ComponentID compID    = ComponentID(c);\n      const CompArea&   compArea  = tu.blocks[compID];\n      const int channelBitDepth   = sps.bitDepths[toChannelType(compID)];",
+     "    if( g_vvhipHooks.tuPrefetch && !cu.lfnstIdx && !tu.noResidual )\n"
+     "    {\n"
+     "      const Pel* hR[3]; int hS[3], hW[3], hH[3], hN = 0;\n"
+     "      for( uint32_t c = 0; c < numTBlocks; c++ ) if( tu.blocks[c].valid() && tu.blocks[c].width > 2 && tu.blocks[c].height > 2 )\n"
+     "      { const CPelBuf b = orgResiBuf.get( ComponentID( c ) ); hR[hN] = b.buf; hS[hN] = ( int ) b.stride; hW[hN] = b.width; hH[hN] = b.height; hN++; }\n"
+     "      if( hN ) g_vvhipHooks.tuPrefetch( hR, hS, hW, hH, hN, sps.bitDepths[CH_L] );\n"
+     "    }\n"),
     ("after", "  const Mv* pcMvRefine = (iFrac == 2 ? s_acMvRefineH : s_acMvRefineQ);\n",
      "  if( g_vvhipHooks.recStageBegin ) g_vvhipHooks.recStageBegin( pattern->buf, baseRefMv.hor, baseRefMv.ver, iFrac, m_pcEncCfg->m_bUseHADME ? ( m_pcEncCfg->m_fastHad ? 2 : 1 ) : 0, reduceTap, useAltHpelIf );\n"
      "  uint64_t hipCost[9];\n"
@@ -308,6 +320,42 @@ patch("EncAdaptiveLoopFilter.cpp", [
 patch("EncCu.cpp", [
     ("after", '#include "EncCu.h"', INC),
     ("before", "  m_modeCtrl.initBlk( tempCS->area, slice.pic->poc );", "  if( g_vvhipHooks.recCu ) g_vvhipHooks.recCu( tempCS );\n"),
+    # merge SATD pruning (addRegularCandsToPruningList): the predictions of all regular merge candidates of the CU are scored by ONE device call after the loop that generates them;
+    # the list insertions then happen in the same order with the same costs (the item pool gets room for a CU's candidates to be outside the list at once)
+    ("replace", "  m_mergeItemList.init( encCfg.m_maxMergeRdCandNumTotal, m_pcEncCfg->m_Geo > 1 ? 3 : 1, chromaFormat, uiMaxSize, uiMaxSize );",
+     "  m_mergeItemList.init( encCfg.m_maxMergeRdCandNumTotal, g_vvhipHooks.mergeCosts ? MRG_MAX_NUM_CANDS + 3 : ( m_pcEncCfg->m_Geo > 1 ? 3 : 1 ), chromaFormat, uiMaxSize, uiMaxSize );"),
+    ("replace", "         = pu.ciip\n         = false;\n\n  for( uint32_t uiMergeCand = 0; uiMergeCand < mergeCtx.numValidMergeCand; uiMergeCand++ )\n  {\n    if( sameMv[uiMergeCand] ) continue;\n\n    mergeCtx.setMergeInfo   ( pu, uiMergeCand );",
+     "         = pu.ciip\n         = false;\n\n"
+     "  const bool hipMrg = g_vvhipHooks.mergeCosts != nullptr && ( localUnitArea.lwidth() & 7 ) == 0 && localUnitArea.lwidth() == localUnitArea.lheight() && localUnitArea.lwidth() <= 64;\n"
+     "  MergeItem* hipItem[MRG_MAX_NUM_CANDS]; const Pel* hipPred[MRG_MAX_NUM_CANDS]; int hipStride[MRG_MAX_NUM_CANDS]; uint64_t hipBits[MRG_MAX_NUM_CANDS]; int hipN = 0;\n"
+     "  for( uint32_t uiMergeCand = 0; uiMergeCand < mergeCtx.numValidMergeCand; uiMergeCand++ )\n  {\n    if( sameMv[uiMergeCand] ) continue;\n\n    mergeCtx.setMergeInfo   ( pu, uiMergeCand );"),
+    ("replace", "    regularMerge->cost      = calcLumaCost4MergePrediction( ctxStart, dstBuf, sqrtLambdaForFirstPassIntra, pu, distParam );\n"
+                "    if( CU::checkDMVRCondition( pu ) ) std::copy_n( pu.mvdL0SubPu, getDmvrMvdNum( pu ), m_subPuMvOffset[uiMergeCand].data() );\n"
+                "    m_mergeItemList         . insertMergeItemToList( regularMerge );\n  }\n}",
+     "    if( hipMrg )\n"
+     "    {\n"
+     "      hipItem[hipN] = regularMerge; hipPred[hipN] = dstBuf.Y().buf; hipStride[hipN] = ( int ) dstBuf.Y().stride;\n"
+     "      m_CABACEstimator->getCtx() = ctxStart; hipBits[hipN] = xCalcPuMeBits( pu ); hipN++;\n"
+     "    }\n"
+     "    else\n"
+     "    regularMerge->cost      = calcLumaCost4MergePrediction( ctxStart, dstBuf, sqrtLambdaForFirstPassIntra, pu, distParam );\n"
+     "    if( CU::checkDMVRCondition( pu ) ) std::copy_n( pu.mvdL0SubPu, getDmvrMvdNum( pu ), m_subPuMvOffset[uiMergeCand].data() );\n"
+     "    if( !hipMrg )\n"
+     "    m_mergeItemList         . insertMergeItemToList( regularMerge );\n  }\n"
+     "  if( hipN )\n"
+     "  {\n"
+     "    uint64_t hipCost[MRG_MAX_NUM_CANDS];\n"
+     "    const bool hipOk = g_vvhipHooks.mergeCosts( distParam.org.buf, ( int ) distParam.org.stride, hipPred, hipStride, hipN, distParam.org.width, distParam.org.height, distParam.bitDepth,\n"
+     "                                                m_pcEncCfg->m_fastHad ? 2 : 1, hipCost );\n"
+     "    for( int i = 0; i < hipN; i++ )\n"
+     "    {\n"
+     "      Distortion dist = hipCost[i];\n"
+     "      if( !hipOk ) { distParam.cur.buf = hipPred[i]; distParam.cur.stride = hipStride[i]; dist = distParam.distFunc( distParam ); }\n"
+     "      hipItem[i]->cost = ( double ) dist + ( double ) hipBits[i] * sqrtLambdaForFirstPassIntra;\n"
+     "      m_uiSadBestForQPA = std::min( dist, m_uiSadBestForQPA );\n"
+     "      m_mergeItemList.insertMergeItemToList( hipItem[i] );\n"
+     "    }\n"
+     "  }\n}"),
 ], sub="EncoderLib")
 
 # one picture <-> one device: a worker thread that starts a CTU task of a picture binds itself to that picture's GPU (several GPUs only)

