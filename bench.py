@@ -386,7 +386,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--streams", type=int, default=5, help="HIP streams a picture's independent launch groups are issued on: 5 = refinement stages / integer windows / table calls / TU / DMVR, "
                                                            "3 = motion-search plan / TU / DMVR, 1 = serialized")
-    ap.add_argument("--exchange-every", type=int, default=1, help="N > 1: one reference-picture broadcast every this many steps (a step is one picture)")
+    ap.add_argument("--exchange-every", type=int, default=2, help="N > 1: one reference-picture broadcast every this many steps (a step is one picture; default 2: 16 of the 32 "
+                    "pictures of a random-access GOP cycle, temporal layers 0-4, are references of other pictures and have to reach the other GPUs, the 16 of layer 5 do not)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-mctf", action="store_true")
@@ -438,6 +439,7 @@ def main():
         ex = sharding.PictureExchange([shp, (shp[0] // 2, shp[1] // 2), (shp[0] // 2, shp[1] // 2)], slots=2, device=hp.device)
         ex.publish(0, 0)
     step_no = [rank]                                     # rank r replays pictures r, r + N, ... of the cycle
+    ex_count = [0]
 
     def step():
         s = step_no[0]
@@ -446,6 +448,7 @@ def main():
             if k % args.exchange_every == 0:
                 e = k // args.exchange_every
                 ex.publish(e + 1, (e + 1) % world, readers=streams if lanes else ())      # the next reference picture is in flight while this picture's launches run
+                ex_count[0] += 1
                 ex.wait(e, streams if lanes else None)
         wl = workloads[layer_of_step(s)]
         if lanes:
@@ -574,7 +577,7 @@ def main():
     if serial:
         out["single_stream"] = serial
     if ex is not None:
-        out["exchange"] = {"bytes_per_rank": int(ex.bytes_published), "collective": "broadcast (RCCL)", "overlapped": True, "every_steps": args.exchange_every,
+        out["exchange"] = {"pictures": ex_count[0], "bytes_per_rank": int(ex.bytes_published), "collective": "broadcast (RCCL)", "overlapped": True, "every_steps": args.exchange_every,
                            "exchange_ms_per_picture": round(1000.0 * (dt - (args.steps * world / no_exchange["value"])) / args.steps, 4) if no_exchange else None}
         out["no_exchange"] = no_exchange
 

@@ -293,10 +293,11 @@ __device__ __forceinline__ void predRow( const int16_t* tv /* first-pass band of
 }
 
 // 4 rounded 2x2 averages ( a + b rows, 8 columns ) as ints
+// (operands are samples or bi-prediction patterns 2 org - pred, |value| < 2^13: the packed vertical sum stays inside 16 bits; the horizontal sum + rounding is a signed dot product with (1, 1))
 __device__ __forceinline__ void avgInts( const uint32_t ( &ra )[4], const uint32_t ( &rb )[4], int ( &o )[4] )
 {
 #pragma unroll
-  for( int i = 0; i < 4; i++ ) o[i] = ( lo16( ra[i] ) + hi16( ra[i] ) + lo16( rb[i] ) + hi16( rb[i] ) + 2 ) >> 2;
+  for( int i = 0; i < 4; i++ ) o[i] = dot2( pkAdd( ra[i], rb[i] ), 0x00010001u, 2 ) >> 2;
 }
 
 template<int K0, int K1>

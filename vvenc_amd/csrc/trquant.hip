@@ -1533,7 +1533,7 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
 #undef WAVE_SYNC
 }
 
-struct TuMxJobs { int nJobs; int waveStart[4]; int size[4]; TuMxArgs j[4]; };
+struct TuMxJobs { int nJobs; int waveStart[8]; int size[8]; TuMxArgs j[8]; };
 
 // WITH4: also carries the 4-point variant (four TUs per lane cost registers) and the 64-point one: launches without such lists use the kernel without them
 template<bool WITH4>
@@ -1547,7 +1547,7 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   const int wave = blockIdx.x * 4 + wv;
   int k = 0;
 #pragma unroll
-  for( int i = 1; i < 4; i++ ) if( i < jobs.nJobs && wave >= jobs.waveStart[i] ) k = i;
+  for( int i = 1; i < 8; i++ ) if( i < jobs.nJobs && wave >= jobs.waveStart[i] ) k = i;
   const int w = wave - jobs.waveStart[k];
   if( w >= jobs.j[k].waveStride ) return;
   const int rs = jobs.j[k].resiStride ? jobs.j[k].resiStride : resiStride;
@@ -1855,25 +1855,51 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
       if( rc ) return rc;
     }
   }
-  // launch groups of up to 4 jobs, largest size first; 4x4 and 64x64 lists go into groups of their own (the kernel instance that carries those
-  // variants needs more registers than the 8/16/32 one)
+  // launch groups, largest size first (a wave of the largest size runs longest: it has to start first).  Matrix-core form: up to 8 jobs per launch; the 4x4 and 64x64
+  // variants live in a second kernel instance (more code, same register bound) — a picture's lists go into ONE launch of that instance when they are small (a recorded
+  // B picture is ~3 000 waves: three launches of a few hundred waves each would mostly be ramp-up and drain), into one launch per kind otherwise.  Row form: 4 jobs, 8/16/32 only.
+  const bool mx = tuKernelForm() == 0;
+  const int groupMax = mx ? 8 : 4;
   auto isExtra = [&]( int i ) { return jobs[order[i]].width == 4 || jobs[order[i]].width == 64; };
-  auto before = [&]( int a, int b ) { const bool ea = isExtra( a ), eb = isExtra( b ); return ea != eb ? !ea : jobs[order[a]].width > jobs[order[b]].width; };
+  auto tilesOf = [&]( int i ) { const vvhip_tu_job& jb = jobs[order[i]]; const int tpt = jb.width == 64 ? 1 : ( 32 / jb.width ) * ( 32 / jb.width ); return ( long ) ( jb.n + tpt - 1 ) / tpt; };
+  long allTiles = 0;
+  for( int i = 0; i < nm; i++ ) allTiles += tilesOf( i );
+  static const long oneLaunchTiles = getenv( "VVHIP_TU_ONE_LAUNCH_TILES" ) ? atol( getenv( "VVHIP_TU_ONE_LAUNCH_TILES" ) ) : 8192;
+  static const long repeat1Tiles = getenv( "VVHIP_TU_REPEAT1_TILES" ) ? atol( getenv( "VVHIP_TU_REPEAT1_TILES" ) ) : 4096;
+  const bool oneLaunch = mx && nm <= groupMax && allTiles <= oneLaunchTiles;
+  auto before = [&]( int a, int b ) { const bool ea = isExtra( a ), eb = isExtra( b ); return ( !oneLaunch && ea != eb ) ? !ea : jobs[order[a]].width > jobs[order[b]].width; };
   for( int a = 1; a < nm; a++ ) for( int b = a; b > 0 && before( b, b - 1 ); b-- ) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
   int nRegular = 0;
-  while( nRegular < nm && !isExtra( nRegular ) ) nRegular++;
+  while( !oneLaunch && nRegular < nm && !isExtra( nRegular ) ) nRegular++;
   for( int first = 0, next = 0; first < nm; first = next )
   {
-    next = first + 4;
-    if( first < nRegular && next > nRegular ) next = nRegular;          // do not mix the two kinds
+    next = first + groupMax;
+    if( !oneLaunch && first < nRegular && next > nRegular ) next = nRegular;          // do not mix the two kinds
     const int groupEnd = next < nm ? next : nm;
 
     TuMultiJobs mj; mj.nJobs = 0;
-    long blocks = 0;
+    TuRowArgs rowArgs[8];
+    int nJobs = 0;
+    long blocks = 0, groupTiles = 0;
+    for( int i = first; i < groupEnd; i++ ) groupTiles += tilesOf( i );
+    // tiles per wave (matrix-core form): the launch should be ONE resident round of waves (3 per SIMD) with balanced work — a second round that is a tenth full costs a whole
+    // wave duration.  Work budget B per wave in 32x32-tile units (a 64x64 TU counts 4): the smallest B for which the launch fits; capped, long lists simply take several rounds.
+    static const long residentWaves = getenv( "VVHIP_TU_RESIDENT_WAVES" ) ? atol( getenv( "VVHIP_TU_RESIDENT_WAVES" ) ) : 3072;
+    int budget = 0;
+    auto repeatOf = [&]( int i ) { const int work = jobs[order[i]].width == 64 ? 4 : 1; const int r = budget / work; return r < 1 ? 1 : r; };
+    if( mx && groupTiles <= repeat1Tiles * 4 )
+    {
+      for( budget = 1; budget < 8; budget++ )
+      {
+        long waves = 0;
+        for( int i = first; i < groupEnd; i++ ) waves += ( tilesOf( i ) + repeatOf( i ) - 1 ) / repeatOf( i );
+        if( waves <= residentWaves ) break;
+      }
+    }
     for( int i = first; i < groupEnd; i++ )
     {
       const vvhip_tu_job& jb = jobs[order[i]];
-      TuRowArgs& ra = mj.j[mj.nJobs];
+      TuRowArgs& ra = rowArgs[nJobs];
       if( !makeGeom( jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth, false, ra.gf ) || !makeGeom( jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth, true, ra.gi ) ||
           !makeQGeom( jb.width, jb.height, bit_depth, ra.q ) )
         return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: unsupported %dx%d types (%d,%d) bitDepth %d", jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth );
@@ -1881,23 +1907,26 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
       ra.matH = ctx->d_trMat + trMatOffset( jb.tr_hor, ra.gf.log2w ); ra.matV = ctx->d_trMat + trMatOffset( jb.tr_ver, ra.gf.log2h );
       ra.scan = ctx->d_scan + scanOffset( ra.q.log2w, ra.q.log2h );
       ra.qps = jb.d_qp; ra.thrVal = jb.thr_val; ra.level = jb.d_level; ra.rec = jb.d_rec_resi; ra.stats = jb.d_stats; ra.phaseLimit = tuPhaseLimit();
-      const int tpb = 256 / ( jb.width * ( jb.width == 8 ? 1 : 2 ) );
-      mj.blockStart[mj.nJobs] = ( int ) blocks; mj.size[mj.nJobs] = jb.width;
-      const int groups = ( jb.n + tpb - 1 ) / tpb;
-      ra.groupStride = ( groups + tuRepeat() - 1 ) / tuRepeat();
-      blocks += ra.groupStride;
-      mj.nJobs++;
+      if( !mx )
+      {
+        const int tpb = 256 / ( jb.width * ( jb.width == 8 ? 1 : 2 ) );
+        mj.blockStart[nJobs] = ( int ) blocks; mj.size[nJobs] = jb.width;
+        const int groups = ( jb.n + tpb - 1 ) / tpb;
+        ra.groupStride = ( groups + tuRepeat() - 1 ) / tuRepeat();
+        blocks += ra.groupStride;
+        mj.j[nJobs] = ra;
+      }
+      nJobs++;
     }
-    for( int i = mj.nJobs; i < 4; i++ ) { mj.blockStart[i] = 0x7fffffff; mj.size[i] = 0; }
-    if( tuKernelForm() == 0 )
+    if( mx )
     {
       // matrix-core form: one wave per 32x32 tile of (32/N)^2 TUs
-      TuMxJobs xj; xj.nJobs = mj.nJobs;
+      TuMxJobs xj; xj.nJobs = nJobs;
       long waves = 0;
-      for( int i = 0; i < mj.nJobs; i++ )
+      for( int i = 0; i < nJobs; i++ )
       {
         const vvhip_tu_job& jb = jobs[order[first + i]];
-        const TuRowArgs& ra = mj.j[i];
+        const TuRowArgs& ra = rowArgs[i];
         TuMxArgs& xa = xj.j[i];
         const int z = ra.gf.log2w - 2, tpt = jb.width == 64 ? 1 : ( 32 / jb.width ) * ( 32 / jb.width );
         xa.resiOff = jb.d_resi_off; xa.n = jb.n;
@@ -1907,19 +1936,24 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
         if( jb.width == 64 ) { xa.opH = reinterpret_cast<const VvhipTuMxOps*>( ctx->d_tuMx64 ); xa.opV = xa.opH; xa.pos = nullptr; }
         xa.qps = jb.d_qp; xa.thrVal = jb.thr_val; xa.level = jb.d_level; xa.rec = jb.d_rec_resi; xa.stats = jb.d_stats;
         xa.tiles = ( jb.n + tpt - 1 ) / tpt; xa.phaseLimit = tuPhaseLimit();
-        xa.waveStride = ( xa.tiles + tuRepeat() - 1 ) / tuRepeat();
+        const int repeat = budget ? repeatOf( first + i ) : tuRepeat();
+        xa.waveStride = ( xa.tiles + repeat - 1 ) / repeat;
         xa.resiStride = strides ? strides[order[first + i]] : 0;
         xj.waveStart[i] = ( int ) waves; xj.size[i] = jb.width;
         waves += xa.waveStride;
       }
-      for( int i = mj.nJobs; i < 4; i++ ) { xj.waveStart[i] = 0x7fffffff; xj.size[i] = 0; }
+      for( int i = nJobs; i < 8; i++ ) { xj.waveStart[i] = 0x7fffffff; xj.size[i] = 0; }
       bool any4 = false;
       for( int i = 0; i < xj.nJobs; i++ ) any4 |= xj.size[i] == 4 || xj.size[i] == 64;
       if( any4 ) hipLaunchKernelGGL( tuMxMultiKernel<true>, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
       else       hipLaunchKernelGGL( tuMxMultiKernel<false>, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
     }
     else
+    {
+      mj.nJobs = nJobs;
+      for( int i = nJobs; i < 4; i++ ) { mj.blockStart[i] = 0x7fffffff; mj.size[i] = 0; }
       hipLaunchKernelGGL( tuRdoRowMultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, mj );
+    }
     VVHIP_LAUNCH_CHECK( ctx );
   }
   return VVHIP_OK;
