@@ -686,7 +686,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   int intBig = 0, ldsIntSmall = 0;
   for( const IntJob& j : ij ) { if( ldsOf( j ) > ldsSmallCap ) intBig++; else ldsIntSmall = std::max( ldsIntSmall, ldsOf( j ) ); }
 
-  // ---- stage units: (stage, band of <= 16 rows); a wave takes a bundle of units of one block width and tap support worth ~320 second-pass row groups
+  // ---- stage units: (stage, band of <= 16 rows); a wave takes a bundle of units of one block width and tap support worth ~160 second-pass row groups
   std::vector<WaveSpan> stWaves;
   int ldsStage = 0;
   for( int i = 0; i < n_stage_jobs; i++ )
@@ -703,6 +703,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & 0xffffff]; const auto& y = stage_jobs[b & 0xffffff];
                     return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( x.width != y.width ? x.width > y.width : unitWork( x ) > unitWork( y ) ); } );
   int setWaves[3] = { 0, 0, 0 }, setBig[3] = { 0, 0, 0 };
+  static const int bundleWork = getenv( "VVHIP_ME_BUNDLE_WORK" ) ? atoi( getenv( "VVHIP_ME_BUNDLE_WORK" ) ) : 160;      // measured on the recorded 1080p lists: 80 / 160 / 320 / 640 / 1280 -> 59.0 / 58.7 / 61.9 / 67.9 / 71.1 us
   for( size_t i = 0; i < stOrder.size(); )
   {
     const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i] & 0xffffff];
@@ -710,7 +711,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     while( i + count < stOrder.size() && count < 8 )
     {
       const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count] & 0xffffff];
-      if( s.width != s0.width || setOf( s ) != setOf( s0 ) || ( count && work + unitWork( s ) > 320 ) ) break;
+      if( s.width != s0.width || setOf( s ) != setOf( s0 ) || ( count && work + unitWork( s ) > bundleWork ) ) break;
       work += unitWork( s ); count++;
     }
     WaveSpan sp; sp.first = ( int32_t ) i; sp.count = count; stWaves.push_back( sp );
@@ -845,12 +846,13 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   // blocks taller than 16 rows are scored band by band (integer atomic adds into the cost array): it starts from zero
   if( plan->nStages && doStage ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_stage_cost, 0, ( size_t ) 9 * plan->nStages * sizeof( uint64_t ), ctx->stream ) );
   int firstWave = 0;
+  static const int ldsPadExp = getenv( "VVHIP_ME_LDS_PAD" ) ? atoi( getenv( "VVHIP_ME_LDS_PAD" ) ) : 0;      // experiment: occupancy sensitivity of the stage kernel
   // (one launch per tap support: bundles of 32- / 64-wide blocks first; splitting them from the small blocks' bundles or giving them four-wave workgroups was measured slower)
-  if( plan->stageSetWaves[0] && doStage ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) plan->stageSetWaves[0] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  if( plan->stageSetWaves[0] && doStage ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) plan->stageSetWaves[0] ), dim3( 64 ), ( size_t ) plan->ldsStage + ldsPadExp, ctx->stream, P, a, firstWave );
   firstWave += plan->stageSetWaves[0];
-  if( plan->stageSetWaves[1] && doStage ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) plan->stageSetWaves[1] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  if( plan->stageSetWaves[1] && doStage ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) plan->stageSetWaves[1] ), dim3( 64 ), ( size_t ) plan->ldsStage + ldsPadExp, ctx->stream, P, a, firstWave );
   firstWave += plan->stageSetWaves[1];
-  if( plan->stageSetWaves[2] && doStage ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) plan->stageSetWaves[2] ), dim3( 64 ), ( size_t ) plan->ldsStage, ctx->stream, P, a, firstWave );
+  if( plan->stageSetWaves[2] && doStage ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) plan->stageSetWaves[2] ), dim3( 64 ), ( size_t ) plan->ldsStage + ldsPadExp, ctx->stream, P, a, firstWave );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[1], ctx->stream ) );
   if( plan->intBig && doInt )                  hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->intBig ), dim3( 256 ), ( size_t ) plan->ldsInt, ctx->stream, P, a, 0 );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[2], ctx->stream ) );

@@ -1867,7 +1867,12 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
   static const long oneLaunchTiles = getenv( "VVHIP_TU_ONE_LAUNCH_TILES" ) ? atol( getenv( "VVHIP_TU_ONE_LAUNCH_TILES" ) ) : 8192;
   static const long repeat1Tiles = getenv( "VVHIP_TU_REPEAT1_TILES" ) ? atol( getenv( "VVHIP_TU_REPEAT1_TILES" ) ) : 4096;
   const bool oneLaunch = mx && nm <= groupMax && allTiles <= oneLaunchTiles;
-  auto before = [&]( int a, int b ) { const bool ea = isExtra( a ), eb = isExtra( b ); return ( !oneLaunch && ea != eb ) ? !ea : jobs[order[a]].width > jobs[order[b]].width; };
+  // short lists first: a size that only a handful of waves run finds its code in no instruction cache (the five bodies are 74 KB) and those waves take several times a warm
+  // wave's duration — started first, they finish under the long lists instead of after them
+  static const long smallFirstTiles = getenv( "VVHIP_TU_SMALL_FIRST" ) ? atol( getenv( "VVHIP_TU_SMALL_FIRST" ) ) : 256;
+  auto isShort = [&]( int i ) { return oneLaunch && tilesOf( i ) < smallFirstTiles; };
+  auto before = [&]( int a, int b ) { const bool ea = isExtra( a ), eb = isExtra( b ), sa = isShort( a ), sb = isShort( b );
+                                      return ( !oneLaunch && ea != eb ) ? !ea : ( sa != sb ? sa : jobs[order[a]].width > jobs[order[b]].width ); };
   for( int a = 1; a < nm; a++ ) for( int b = a; b > 0 && before( b, b - 1 ); b-- ) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
   int nRegular = 0;
   while( !oneLaunch && nRegular < nm && !isExtra( nRegular ) ) nRegular++;
