@@ -139,7 +139,22 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
   const int pitch = winPitch( j.winW );
   int16_t* win = lds;
   int16_t* orgL = lds + j.winH * pitch;                              // rowsEff x w, compact (16-byte rows)
+  PlanCand* candL = reinterpret_cast<PlanCand*>( orgL + rowsEff * w );    // the job's candidates (8 bytes each)
   {
+    // every global request of the job is issued before the first one is waited for: the candidate records, the original block (<= 4 chunks per lane: any square block up to
+    // 64x64), then the window in batches of four chunks per lane — the job is one memory latency + the LDS work, not four latencies in a row
+    PlanCand myCand = { 0, 0, 0 };
+    if( tid < j.nCand ) myCand = a.cands[j.firstCand + tid];
+    const int16_t* org = P.p[j.orgPlane] + j.orgOff;
+    const int os = P.stride[j.orgPlane], m = rowsEff * lpr;
+    u32x4 ov[4]; int oat[4];
+#pragma unroll
+    for( int q = 0; q < 4; q++ )
+    {
+      const int i = tid + nthr * q < m ? tid + nthr * q : 0, r = i / lpr, c = i - r * lpr;
+      oat[q] = r * w + c * 8;
+      ov[q] = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 );
+    }
     const int16_t* ref = P.p[j.refPlane] + j.refOff + ( ptrdiff_t ) j.minDy * P.stride[j.refPlane] + j.minDx;
     const int cpr = pitch >> 3, n = j.winH * cpr, rs = P.stride[j.refPlane];
     for( int i0 = tid; i0 < n; i0 += 4 * nthr )                        // four loads in flight per lane (the loop is latency-bound otherwise)
@@ -156,22 +171,17 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
       for( int q = 0; q < 4; q++ )
         if( i0 + nthr * q < n ) { u32x4 x = v[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( win + at[q] ) = x; }
     }
-    const int16_t* org = P.p[j.orgPlane] + j.orgOff;
-    const int os = P.stride[j.orgPlane], m = rowsEff * lpr;
-    for( int i0 = tid; i0 < m; i0 += 4 * nthr )
+#pragma unroll
+    for( int q = 0; q < 4; q++ )
+      if( tid + nthr * q < m ) { u32x4 x = ov[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( orgL + oat[q] ) = x; }
+    for( int i0 = tid + 4 * nthr; i0 < m; i0 += nthr )                 // (blocks beyond four chunks per lane: none of the square sizes; kept for safety)
     {
-      u32x4 v[4]; int at[4];
-#pragma unroll
-      for( int q = 0; q < 4; q++ )
-      {
-        const int i = i0 + nthr * q < m ? i0 + nthr * q : i0, r = i / lpr, c = i - r * lpr;
-        at[q] = r * w + c * 8;
-        v[q] = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 );
-      }
-#pragma unroll
-      for( int q = 0; q < 4; q++ )
-        if( i0 + nthr * q < m ) { u32x4 x = v[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( orgL + at[q] ) = x; }
+      const int r = i0 / lpr, c = i0 - r * lpr;
+      u32x4 x = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 ); x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS;
+      *reinterpret_cast<u32x4*>( orgL + r * w + c * 8 ) = x;
     }
+    if( tid < j.nCand ) candL[tid] = myCand;
+    for( int i = tid + nthr; i < j.nCand; i += nthr ) candL[i] = a.cands[j.firstCand + i];
   }
   __syncthreads();
   const int chunks = rowsEff * lpr;
@@ -182,7 +192,7 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
   {
     const int ci = c0 + team;
     const bool valid = ci < j.nCand;
-    const PlanCand cd = a.cands[j.firstCand + ( valid ? ci : 0 )];
+    const PlanCand cd = candL[valid ? ci : 0];
     const int x = cd.dx - j.minDx, y = cd.dy - j.minDy;
     const int16_t* base = win + y * pitch + ( x & ~1 );
     const uint32_t sh = ( x & 1 ) * 16;
@@ -318,7 +328,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
   for( int si = 0; si < span.count; si++ )
   {
     const int unit = a.stageOrder[span.first + si], stage = unit & 0xffffff, y0 = ( unit >> 24 ) << 4;
-    const vvhip_me_stage_job j = a.stageJobs[stage];
+    const vvhip_me_stage_job j = a.stageJobs[span.first + si];                     // (the job table is in schedule order, one record per unit)
     const int w = j.width, h = j.height, G = w >> 3, log2G = 31 - __builtin_clz( G );
     const int BH = h < 16 ? h : 16, rowsT = BH + NT;
     const int ldsPitch = w + 8;                                                    // LDS row pitch: an odd number of 16-byte chunks (rows of a tile column land in different banks)
@@ -493,7 +503,7 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
 {
   const WaveSpan span = a.itemWaves[wave];
   const int lane = threadIdx.x;
-  const vvhip_me_item first = a.items[a.itemOrder[span.first]];                     // every item of the span has this function and geometry
+  const vvhip_me_item first = a.items[span.first];                                  // every item of the span has this function and geometry (the table is in schedule order)
   const int w = first.width, h = first.height, func = first.func, ss = func == VVHIP_DF_SAD ? first.sub_shift : 0;
   if( func == VVHIP_DF_SAD || func == VVHIP_DF_SSE )
   {
@@ -504,8 +514,8 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
     {
       const int ii = i0 + team;
       const bool valid = ii < span.count;
-      const int idx = a.itemOrder[span.first + ( valid ? ii : 0 )];
-      const vvhip_me_item it = a.items[idx];
+      const int idx = a.itemOrder[span.first + ( valid ? ii : 0 )];            // where the result goes
+      const vvhip_me_item it = a.items[span.first + ( valid ? ii : 0 )];
       const int16_t* po = P.p[it.org_plane] + it.org_off; const int os = P.stride[it.org_plane];
       const int16_t* pc = P.p[it.cur_plane] + it.cur_off; const int cs = P.stride[it.cur_plane];
       uint32_t sad = 0; uint64_t sse = 0;
@@ -539,7 +549,7 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
     const int ii = i0 + team;
     const bool valid = ii < span.count;
     const int idx = a.itemOrder[span.first + ( valid ? ii : 0 )];
-    const vvhip_me_item it = a.items[idx];
+    const vvhip_me_item it = a.items[span.first + ( valid ? ii : 0 )];
     const int16_t* po = P.p[it.org_plane] + it.org_off; const int os = P.stride[it.org_plane];
     const int16_t* pc = P.p[it.cur_plane] + it.cur_off; const int cs = P.stride[it.cur_plane];
     uint32_t sum = 0, sad = 0;
@@ -675,11 +685,11 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
       j.firstCand = ( int32_t ) pc.size(); j.nCand = ( int32_t ) wn.c.size();
       pc.insert( pc.end(), wn.c.begin(), wn.c.end() );
       ij.push_back( j );
-      ldsInt = std::max( ldsInt, ( j.winH * hostWinPitch( j.winW ) + ( s.height >> s.sub_shift ) * s.width ) * 2 );
+      ldsInt = std::max( ldsInt, ( j.winH * hostWinPitch( j.winW ) + ( s.height >> s.sub_shift ) * s.width ) * 2 + j.nCand * ( int ) sizeof( PlanCand ) );
     }
   }
   // windows that need much LDS first (their own launch), inside each class heaviest first
-  auto ldsOf = []( const IntJob& j ) { return ( j.winH * hostWinPitch( j.winW ) + ( j.h >> j.subShift ) * j.w ) * 2; };
+  auto ldsOf = []( const IntJob& j ) { return ( j.winH * hostWinPitch( j.winW ) + ( j.h >> j.subShift ) * j.w ) * 2 + j.nCand * ( int ) sizeof( PlanCand ); };      // window + original + candidate records
   const int ldsSmallCap = 6 * 1024;
   std::stable_sort( ij.begin(), ij.end(), [&]( const IntJob& a, const IntJob& b ) { const bool ba = ldsOf( a ) > ldsSmallCap, bb = ldsOf( b ) > ldsSmallCap; if( ba != bb ) return ba;
                     return ( long ) a.nCand * a.w * ( a.h >> a.subShift ) + ( long ) a.winW * a.winH > ( long ) b.nCand * b.w * ( b.h >> b.subShift ) + ( long ) b.winW * b.winH; } );
@@ -748,9 +758,15 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     i += count;
   }
 
+  // ---- the tables go to the device in SCHEDULE order (a wave reads its jobs at the schedule index: no order -> record indirection on the critical path of a short-lived wave;
+  //      the order arrays only say where a result goes)
+  std::vector<vvhip_me_stage_job> stUnits( stOrder.size() );
+  for( size_t i = 0; i < stOrder.size(); i++ ) stUnits[i] = stage_jobs[stOrder[i] & 0xffffff];
+  std::vector<vvhip_me_item> itSorted( n_items );
+  for( int i = 0; i < n_items; i++ ) itSorted[i] = items[itOrder[i]];
   // ---- one device allocation for every table
   auto pad = []( size_t b ) { return ( b + 255 ) & ~( size_t ) 255; };
-  const size_t bInt = pad( ij.size() * sizeof( IntJob ) ), bCand = pad( pc.size() * sizeof( PlanCand ) ), bSt = pad( ( size_t ) n_stage_jobs * sizeof( vvhip_me_stage_job ) ),
+  const size_t bInt = pad( ij.size() * sizeof( IntJob ) ), bCand = pad( pc.size() * sizeof( PlanCand ) ), bSt = pad( stUnits.size() * sizeof( vvhip_me_stage_job ) ),
                bStO = pad( stOrder.size() * 4 ), bStW = pad( stWaves.size() * sizeof( WaveSpan ) ), bIt = pad( ( size_t ) n_items * sizeof( vvhip_me_item ) ), bItO = pad( itOrder.size() * 4 ),
                bItW = pad( itWaves.size() * sizeof( WaveSpan ) );
   const size_t total = bInt + bCand + bSt + bStO + bStW + bIt + bItO + bItW + 256;
@@ -758,8 +774,8 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   size_t o = 0;
   auto put = [&]( const void* src, size_t bytes, size_t padded ) { const size_t at = o; if( bytes ) memcpy( host.data() + o, src, bytes ); o += padded; return at; };
   const size_t oInt = put( ij.data(), ij.size() * sizeof( IntJob ), bInt ), oCand = put( pc.data(), pc.size() * sizeof( PlanCand ), bCand ),
-               oSt = put( stage_jobs, ( size_t ) n_stage_jobs * sizeof( vvhip_me_stage_job ), bSt ), oStO = put( stOrder.data(), stOrder.size() * 4, bStO ),
-               oStW = put( stWaves.data(), stWaves.size() * sizeof( WaveSpan ), bStW ), oIt = put( items, ( size_t ) n_items * sizeof( vvhip_me_item ), bIt ),
+               oSt = put( stUnits.data(), stUnits.size() * sizeof( vvhip_me_stage_job ), bSt ), oStO = put( stOrder.data(), stOrder.size() * 4, bStO ),
+               oStW = put( stWaves.data(), stWaves.size() * sizeof( WaveSpan ), bStW ), oIt = put( itSorted.data(), ( size_t ) n_items * sizeof( vvhip_me_item ), bIt ),
                oItO = put( itOrder.data(), itOrder.size() * 4, bItO ), oItW = put( itWaves.data(), itWaves.size() * sizeof( WaveSpan ), bItW );
   vvhip_me_plan* p = new vvhip_me_plan;
   hipError_t e = hipMalloc( &p->d_blob, total );
