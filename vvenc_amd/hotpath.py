@@ -380,7 +380,7 @@ class HotPath:
         self._ck(self.L.vvhip_me_plan_set_timing(self.ctx, plan, 1 if on else 0))
 
     def me_plan_last_times(self, plan):
-        """ms of the last run's parts: refinement stages, integer windows (large LDS class), integer windows (small), table calls"""
+        """ms of the last run's parts: refinement stages, integer windows (one launch for both LDS classes), 0, table calls"""
         ms = (C.c_float * 4)()
         self._ck(self.L.vvhip_me_plan_last_times(self.ctx, plan, C.cast(ms, C.c_void_p)))
         return [float(x) for x in ms]
