@@ -6,30 +6,22 @@
 //     centre cost, early exit                           :1330-1337
 //     25-point mirrored search with dmvrSadX5           :1344-1366 (RdCost::xGetSAD8X5/16X5, RdCost.cpp:1984-2034)
 //     parametric sub-pel error surface                  :1227-1244, xSubPelErrorSrfc :1167-1187, div_for_maxq7 :1131-1165
-// One wavefront per sub-block (<= 16x16): both bilinear predictions (dx+4) x (dy+4) are built in LDS, 50 lanes evaluate the 25 mirrored
-// positions (two row halves each), one lane replays the reference's scan order (strict <) and the error surface.
+// One wavefront per sub-block (<= 16x16).  Three lane-parallel steps through LDS, then a one-lane epilogue:
+//   1  rows 0 .. dy+4 of both source windows straight from the planes: a lane = 8 adjacent samples of a row (one 16-byte load + one dword), horizontal taps as
+//      v_dot2_i32_i16 on sample pairs (v_alignbit makes the odd pairs), Pel truncation by packing;
+//   2  vertical taps on row pairs (v_perm interleaves the rows for v_dot2), results stored biased for v_sad_u16;
+//   3  25 mirrored positions x dy/2 rows: eight lanes per position (lane = row), a row is dx/2 dwords of each prediction + v_alignbit for odd columns, DPP sum;
+//   one lane replays the reference's scan order (strict <) and the error surface.
 #include "common.h"
 
 namespace {
 
-constexpr int DMVR_PITCH = 20;                 // dx + 4 <= 20
-constexpr int DMVR_ELEMS = DMVR_PITCH * 20;
+constexpr int DP = 24;                         // LDS row pitch in samples (dx + 4 <= 20 used, dword reads reach 22)
 
-__device__ __forceinline__ int16_t bilinearSample( const int16_t* p, int stride, int fx, int fy, int bitDepth )
-{
-  // filterN2_2D: both fractions -> horizontal first pass on rows y, y+1 (isFirst, not last), vertical second pass; one fraction -> a single
-  // first pass; none -> filterCopy<true,false>(biMCForDMVR): sample << (10 - bitDepth).  Every pass truncates to Pel.
-  const int sh1 = 4 - ( 10 - bitDepth ), of1 = 1 << ( sh1 - 1 );
-  if( fx && fy )
-  {
-    const int16_t t0 = ( int16_t ) ( ( ( 16 - fx ) * p[0] + fx * p[1] + of1 ) >> sh1 );
-    const int16_t t1 = ( int16_t ) ( ( ( 16 - fx ) * p[stride] + fx * p[stride + 1] + of1 ) >> sh1 );
-    return ( int16_t ) ( ( ( 16 - fy ) * t0 + fy * t1 + 8 ) >> 4 );
-  }
-  if( fx ) return ( int16_t ) ( ( ( 16 - fx ) * p[0] + fx * p[1] + of1 ) >> sh1 );
-  if( fy ) return ( int16_t ) ( ( ( 16 - fy ) * p[0] + fy * p[stride] + of1 ) >> sh1 );
-  return ( int16_t ) ( p[0] << ( 10 - bitDepth ) );
-}
+typedef uint32_t u32x4 __attribute__( ( ext_vector_type( 4 ) ) );
+typedef short dmvrS2 __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ int dmvrDot2( uint32_t a, uint32_t b, int c ) { return __builtin_amdgcn_sdot2( __builtin_bit_cast( dmvrS2, a ), __builtin_bit_cast( dmvrS2, b ), c, false ); }
+__device__ __forceinline__ uint32_t dmvrPack( int lo, int hi ) { return ( ( uint32_t ) lo & 0xffffu ) | ( ( uint32_t ) hi << 16 ); }      // truncation to Pel like the reference's casts
 
 __device__ __forceinline__ int divMaxQ7( long long N, long long D )       // div_for_maxq7
 {
@@ -49,47 +41,122 @@ __global__ void __launch_bounds__( 256 )
 dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* __restrict__ ref1, int stride1, const vvhip_dmvr_item* __restrict__ items, int n,
                   int dx, int dy, int bitDepth, vvhip_dmvr_result* __restrict__ out )
 {
-  __shared__ int16_t sPred[4][2][DMVR_ELEMS];
-  __shared__ uint32_t sCost[4][25][2];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sT[4][2][22 * DP];      // first-pass rows
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sR[4][2][20 * DP];      // bilinear predictions, biased
+  __shared__ uint32_t sCost[4][32];
+  struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+  struct __attribute__( ( packed, aligned( 2 ) ) ) U4 { uint32_t v; };
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blk = blockIdx.x * 4 + wv;
   if( blk >= n ) return;                                   // whole waves leave together; no workgroup barrier below
   const vvhip_dmvr_item it = items[blk];
-  int16_t* p0 = sPred[wv][0]; int16_t* p1 = sPred[wv][1];
-  const int bw = dx + 4, bh = dy + 4;
+  const int bw = dx + 4, bh = dy + 4, segs = ( bw + 7 ) >> 3;
+  const int sh1 = 4 - ( 10 - bitDepth ), of1 = 1 << ( sh1 - 1 );
   const int16_t* s0 = ref0 + it.ref0_off - 2 * stride0 - 2;       // mergeMV - (2, 2) samples (:1285-1288)
   const int16_t* s1 = ref1 + it.ref1_off - 2 * stride1 - 2;
-  for( int e = lane; e < bw * bh; e += 64 )
+#define DMVR_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+  // ---- 1: filterN2_2D first pass (fraction x != 0) or the samples themselves, rows 0 .. bh (the second pass of row bh - 1 reads row bh).  Both trips' loads first.
   {
-    const int y = e / bw, x = e - y * bw;
-    p0[y * DMVR_PITCH + x] = bilinearSample( s0 + ( ptrdiff_t ) y * stride0 + x, stride0, it.frac0_x & 15, it.frac0_y & 15, bitDepth );
-    p1[y * DMVR_PITCH + x] = bilinearSample( s1 + ( ptrdiff_t ) y * stride1 + x, stride1, it.frac1_x & 15, it.frac1_y & 15, bitDepth );
-  }
-  __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
-
-  // mirrored SAD on every second row (subShift 1; (sum << 1) >> 1 == sum): position q = (ver + 2) * 5 + hor + 2, lanes 2q, 2q+1 take the row halves
-  const int16_t* c0 = p0 + 2 * DMVR_PITCH + 2; const int16_t* c1 = p1 + 2 * DMVR_PITCH + 2;
-  if( lane < 50 )
-  {
-    const int q = lane >> 1, half = lane & 1, ver = q / 5 - 2, hor = q - ( q / 5 ) * 5 - 2;
-    const int off = hor + ver * DMVR_PITCH;
-    const int rows = dy >> 1, r0 = half * ( ( rows + 1 ) >> 1 ), r1 = half ? rows : ( ( rows + 1 ) >> 1 );
-    uint32_t sum = 0;
-    for( int r = r0; r < r1; r++ )
-      for( int x = 0; x < dx; x++ )
+    const int perList = ( bh + 1 ) * segs, jobs = 2 * perList;
+    u32x4 A[2]; uint32_t B[2]; int at[2], fxs[2]; bool ok[2];
+#pragma unroll
+    for( int q = 0; q < 2; q++ )
+    {
+      const int jb = lane + 64 * q;
+      ok[q] = jb < jobs;
+      const int jv = ok[q] ? jb : 0, list = jv >= perList, rem = jv - list * perList, y = rem / segs, x0 = ( rem - y * segs ) * 8;
+      const int16_t* src = ( list ? s1 + ( ptrdiff_t ) y * stride1 : s0 + ( ptrdiff_t ) y * stride0 ) + x0;
+      fxs[q] = ( list ? it.frac1_x : it.frac0_x ) & 15;
+      at[q] = list * 22 * DP + y * DP + x0;
+      A[q] = reinterpret_cast<const U16*>( src )->v; B[q] = reinterpret_cast<const U4*>( src + 8 )->v;
+    }
+#pragma unroll
+    for( int q = 0; q < 2; q++ )
+    {
+      if( !ok[q] ) continue;
+      u32x4 o = A[q];
+      if( fxs[q] )
       {
-        const int d = ( int ) c0[2 * r * DMVR_PITCH + x + off] - ( int ) c1[2 * r * DMVR_PITCH + x - off];
-        sum += ( uint32_t ) ( d < 0 ? -d : d );
+        const uint32_t w = dmvrPack( 16 - fxs[q], fxs[q] );
+        const uint32_t e[5] = { A[q].x, A[q].y, A[q].z, A[q].w, B[q] };
+        uint32_t r[4];
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+          r[i] = dmvrPack( dmvrDot2( e[i], w, of1 ) >> sh1, dmvrDot2( __builtin_amdgcn_alignbit( e[i + 1], e[i], 16 ), w, of1 ) >> sh1 );
+        o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
       }
-    sCost[wv][q][half] = sum;
+      *reinterpret_cast<u32x4*>( &sT[wv][0][at[q]] ) = o;
+    }
   }
-  __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
+  DMVR_SYNC();
+  // ---- 2: second pass (fraction y != 0), the copy's precision shift when neither fraction is set; stored with the sign bit flipped (v_sad_u16 on biased values is exact)
+  {
+    const int perList = bh * segs, jobs = 2 * perList;
+    for( int jb = lane; jb < jobs; jb += 64 )
+    {
+      const int list = jb >= perList, rem = jb - list * perList, y = rem / segs, x0 = ( rem - y * segs ) * 8;
+      const int fx = ( list ? it.frac1_x : it.frac0_x ) & 15, fy = ( list ? it.frac1_y : it.frac0_y ) & 15;
+      const u32x4 a = *reinterpret_cast<const u32x4*>( &sT[wv][list][y * DP + x0] );
+      u32x4 o = a;
+      if( fy )
+      {
+        const u32x4 b = *reinterpret_cast<const u32x4*>( &sT[wv][list][( y + 1 ) * DP + x0] );
+        const int rnd = fx ? 8 : of1, sh = fx ? 4 : sh1;
+        const uint32_t w = dmvrPack( 16 - fy, fy );
+        const uint32_t aw[4] = { a.x, a.y, a.z, a.w }, bw_[4] = { b.x, b.y, b.z, b.w };
+        uint32_t r[4];
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+          r[i] = dmvrPack( dmvrDot2( __builtin_amdgcn_perm( bw_[i], aw[i], 0x05040100u ), w, rnd ) >> sh, dmvrDot2( __builtin_amdgcn_perm( bw_[i], aw[i], 0x07060302u ), w, rnd ) >> sh );
+        o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+      }
+      else if( !fx )
+      {
+        const int s = 10 - bitDepth;
+        const uint32_t aw[4] = { a.x, a.y, a.z, a.w };
+        uint32_t r[4];
+#pragma unroll
+        for( int i = 0; i < 4; i++ ) r[i] = dmvrPack( ( int ) ( int16_t ) ( aw[i] & 0xffffu ) << s, ( ( int ) aw[i] >> 16 ) << s );
+        o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+      }
+      o.x ^= 0x80008000u; o.y ^= 0x80008000u; o.z ^= 0x80008000u; o.w ^= 0x80008000u;
+      *reinterpret_cast<u32x4*>( &sR[wv][list][y * DP + x0] ) = o;
+    }
+  }
+  DMVR_SYNC();
+  // ---- 3: mirrored SAD on every second row (subShift 1; (sum << 1) >> 1 == sum): position q = (ver + 2) * 5 + hor + 2; eight lanes per position, lane = row
+  {
+    const int rows = dy >> 1, dw = dx >> 1;
+    for( int pass = 0; pass < 4; pass++ )
+    {
+      const int job = pass * 64 + lane, q = job >> 3, r = job & 7;
+      const bool valid = q < 25 && r < rows;
+      const int qv = valid ? q : 12, rv = valid ? r : 0;
+      const int ver = qv / 5 - 2, hor = qv - ( qv / 5 ) * 5 - 2;
+      const int c0 = 2 + hor, c1 = 2 - hor;
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>( &sR[wv][0][( 2 + 2 * rv + ver ) * DP + ( c0 & ~1 )] );
+      const uint32_t* p1 = reinterpret_cast<const uint32_t*>( &sR[wv][1][( 2 + 2 * rv - ver ) * DP + ( c1 & ~1 )] );
+      const uint32_t sh0 = ( c0 & 1 ) * 16, shB = ( c1 & 1 ) * 16;
+      uint32_t sum = 0;
+      uint32_t x0 = p0[0], y0 = p1[0];
+      for( int i = 0; i < dw; i++ )
+      {
+        const uint32_t x1 = p0[i + 1], y1 = p1[i + 1];
+        sum = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( x1, x0, sh0 ), __builtin_amdgcn_alignbit( y1, y0, shB ), sum );
+        x0 = x1; y0 = y1;
+      }
+      sum = vvhipGroupSum32( valid ? sum : 0u, 8, lane );
+      if( valid && r == 0 ) sCost[wv][q] = sum;
+    }
+  }
+  DMVR_SYNC();
+#undef DMVR_SYNC
 
   if( lane == 0 )
   {
     unsigned long long sad[25];
 #pragma unroll
-    for( int q = 0; q < 25; q++ ) sad[q] = ( unsigned long long ) sCost[wv][q][0] + sCost[wv][q][1];
+    for( int q = 0; q < 25; q++ ) sad[q] = sCost[wv][q];
     // centre: distFunc(SAD, subShift 1) >> 1, minus a quarter (:1332-1333); the X5 costs are SAD >> 1 without that reduction
     unsigned long long minCost = sad[12];
     minCost -= minCost >> 2;
