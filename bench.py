@@ -393,6 +393,7 @@ def main():
     ap.add_argument("--no-mctf", action="store_true")
     ap.add_argument("--no-4k", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--profile-md", default=None, help="also write the rocprofv3 summary of this run (kernel table + counters per kernel class) as markdown to this path")
     ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 passes of the inner run (kernel trace + one pass per counter)")
     ap.add_argument("--e2e-threads", type=int, default=8)
     ap.add_argument("--inner", action="store_true", help="(internal) the short run rocprofv3 wraps: the recorded pictures' launches serialized on one stream, no extras, no output line")
@@ -629,6 +630,36 @@ def main():
         roof["limiter"] = "fractions of the launch time: HBM traffic %.3f, L1 (TCP) access slots %.3f (one access per 64-byte granule and instruction, %d CUs x %.1f GHz), VALU issue slots %.3f " \
                           "(wave instructions x 4 cycles / %d SIMDs); the rest is latency the resident waves do not cover" % (fr["hbm"], fr["l1_access"], N_CU, CLOCK_GHZ, fr["valu"], N_SIMD)
         out["pmc"] = {k: {kk: v for kk, v in c.items()} for k, c in live["per_class"].items()}
+        # the same three positions for every kernel class of the step (per launch, from the same passes)
+        allk = {}
+        for k, c in live["per_class"].items():
+            n = max(1, c.get("launches", 1))
+            t_k = (c["total_ns"] / n) * 1e-9 if c.get("total_ns") else None
+            if not t_k:
+                continue
+            pk = lambda key: (c.get(key, 0.0) / max(1, c.get("n_" + key, 0))) if c.get("n_" + key) else None
+            f_, w_, l_, v_ = pk("fetch_bytes"), pk("write_bytes"), pk("l1_accesses"), pk("valu_insts")
+            allk[k] = {"kernel": KERNEL_NAMES.get(k, k), "launches_per_picture": round(n / 32.0, 2), "avg_launch_us": round(t_k * 1e6, 2),
+                       "hbm_traffic_MB": round(((f_ or 0) + (w_ or 0)) / 1e6, 2) if f_ is not None else None,
+                       "hbm_frac": round(((f_ or 0) + (w_ or 0)) / t_k / 1e9 / HBM_PEAK_GBS, 4) if f_ is not None else None,
+                       "l1_access_frac": round(l_ / (N_CU * CLOCK_GHZ * 1e9 * t_k), 4) if l_ else None,
+                       "valu_issue_frac": round(v_ * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9 * t_k), 4) if v_ else None}
+        out["roofline_all_kernels"] = allk
+        if args.profile_md:
+            try:
+                with open(args.profile_md, "w") as f:
+                    f.write("# rocprofv3 summary of `python bench.py` (written by bench.py --profile-md from its own passes)\n\n")
+                    f.write("Inner run: `%s`\n\n" % live["kernel_trace"]["command"])
+                    f.write("## rocprofv3 --kernel-trace --stats\n\n| kernel | calls | avg us | total us | % |\n|---|---|---|---|---|\n")
+                    for r in live["kernel_trace"]["kernels"]:
+                        f.write("| `%s` | %d | %.2f | %.1f | %.1f |\n" % (r["name"], r["calls"], r["avg_us"], r["total_us"], r["pct"]))
+                    f.write("\n## rocprofv3 --pmc, one pass per counter (FETCH_SIZE x 2 x 1024 B, WRITE_SIZE x 1024 B), per launch\n\n"
+                            "| class | kernel | launches per picture | avg launch us | HBM traffic MB | HBM frac of 8 TB/s | L1 access frac | VALU issue frac |\n|---|---|---|---|---|---|---|---|\n")
+                    for k, r in allk.items():
+                        f.write("| %s | `%s` | %s | %s | %s | %s | %s | %s |\n" % (k, r["kernel"], r["launches_per_picture"], r["avg_launch_us"], r["hbm_traffic_MB"], r["hbm_frac"], r["l1_access_frac"], r["valu_issue_frac"]))
+                    f.write("\nHIP-event time per picture (GOP-weighted, launches serialized): " + ", ".join("%s %.1f us" % (k, kern[k]["avg_ms_per_picture"] * 1e3) for k in kern) + "\n")
+            except Exception as e:
+                out["profile_md_error"] = str(e)[:200]
     else:
         roof.update({"bound": "hbm", "traffic": None, "achieved": kern[dom]["nominal_alg_GBps"], "frac": None, "note": "no live PMC pass (rocprofv3 absent or --no-profile): no physical fraction reported"})
     out["roofline"] = roof

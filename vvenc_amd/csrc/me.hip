@@ -311,6 +311,11 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
   int16_t* tmp = lds + 2 * ( 128 + 64 + 16 + 16 );
 
   int curTab = -1;
+  if( K0 == 2 )                                                                      // the 4-tap search set has ONE table (filter_mode 2, no alternative half-sample filter):
+  {                                                                                  // requested at once, next to the first unit's record instead of behind it
+    for( int i = tid; i < 192; i += nthr ) reinterpret_cast<int*>( lds )[i] = a.tapTables[4 * 192 + i];
+    curTab = 4;
+  }
   for( int si = 0; si < span.count; si++ )
   {
     const int unit = a.stageOrder[span.first + si], stage = unit & 0xffffff, y0 = ( unit >> 24 ) << 4;
