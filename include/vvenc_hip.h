@@ -49,6 +49,8 @@ VVHIP_API int         vvhip_set_stream( vvhip_ctx* ctx, void* hip_stream ); /* b
 VVHIP_API int         vvhip_use_own_stream( vvhip_ctx* ctx );          /* back to the context's private stream          */
 VVHIP_API void*       vvhip_get_stream( vvhip_ctx* ctx );
 VVHIP_API int         vvhip_sync( vvhip_ctx* ctx );                    /* hipStreamSynchronize                          */
+VVHIP_API int         vvhip_sync_all_devices( vvhip_ctx* ctx );        /* hipDeviceSynchronize on every device, the calling thread's current device restored: before host memory other
+                                                                        * contexts may still be copying from is unpinned or released */
 /* Launch graphs: the batch entry points only enqueue kernels on the context's stream, so a frame's fixed sequence of calls (the lists of one picture: same tables,
  * same buffers) can be recorded once and replayed with one hipGraphLaunch instead of one dispatch per call.  Between begin and end no call may synchronise, allocate
  * (call every entry point once beforehand so scratch buffers exist) or touch another stream; the stream must not be the legacy default stream (vvhip_use_own_stream).  No counterpart in the reference: its table entries are synchronous calls. */

@@ -275,6 +275,24 @@ int vvhip_sync( vvhip_ctx* ctx )
   return VVHIP_OK;
 }
 
+int vvhip_sync_all_devices( vvhip_ctx* ctx )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  int prev = 0, n = 0;
+  VVHIP_CHECK_HIP( ctx, hipGetDevice( &prev ) );
+  VVHIP_CHECK_HIP( ctx, hipGetDeviceCount( &n ) );
+  hipError_t first = hipSuccess;
+  for( int d = 0; d < n; d++ )
+  {
+    hipError_t e = hipSetDevice( d );
+    if( e == hipSuccess ) e = hipDeviceSynchronize();
+    if( e != hipSuccess && first == hipSuccess ) first = e;
+  }
+  ( void ) hipSetDevice( prev );
+  VVHIP_CHECK_HIP( ctx, first );
+  return VVHIP_OK;
+}
+
 struct vvhip_graph { hipGraph_t graph; hipGraphExec_t exec; };
 
 int vvhip_graph_begin( vvhip_ctx* ctx )

@@ -50,7 +50,7 @@ inline int countedDownloadAsync( vvhip_ctx* c, void* h, const void* d, size_t n 
 #define vvhip_download countedDownload
 #define vvhip_download_async countedDownloadAsync
 
-// mirrors of one GPU, shared by that GPU's contexts.  Entries are never moved (deque) so Mirror pointers stay valid while the picture is registered.
+// mirrors of one GPU, shared by that GPU's contexts.  Readers get copies made under the lock (a slot is reused after unregisterPicture).
 struct Registry { mutable std::mutex m; std::deque<Device::Mirror> mirrors; };
 Registry& registry( int gpu )
 {
@@ -128,9 +128,12 @@ bool Device::pinHost( const void* p, size_t bytes )
   std::lock_guard<std::mutex> g( g_pinLock );
   auto it = g_pinned.upper_bound( a );
   if( it != g_pinned.begin() ) { auto pr = std::prev( it ); if( pr->first <= a && pr->first + pr->second >= e ) return true; }       // already inside a pinned range
-  // ranges that overlap the new one were pinned for an earlier incarnation of (part of) this buffer: drop them first
+  // ranges that overlap the new one were pinned for an earlier incarnation of (part of) this buffer: drop them first — after every device has finished the copies other worker
+  // contexts may still have in flight from them (uploads are issued outside this lock)
+  bool synced = false;
   for( it = g_pinned.begin(); it != g_pinned.end(); )
   {
+    if( !synced && it->first < e && it->first + it->second > a ) { vvhip_sync_all_devices( dev.ctx() ); synced = true; }
     if( it->first < e && it->first + it->second > a ) { vvhip_host_unregister( dev.ctx(), reinterpret_cast<void*>( it->first ) ); it = g_pinned.erase( it ); }
     else ++it;
   }
@@ -143,6 +146,7 @@ void Device::unpinAll()
 {
   Device& dev = Device::get();
   std::lock_guard<std::mutex> g( g_pinLock );
+  if( !g_pinned.empty() ) vvhip_sync_all_devices( dev.ctx() );
   for( auto& kv : g_pinned ) vvhip_host_unregister( dev.ctx(), reinterpret_cast<void*>( kv.first ) );
   g_pinned.clear();
 }
@@ -183,7 +187,7 @@ int Device::registerPicture( const Pel* origin, int stride, int width, int heigh
   return id;
 }
 
-const Device::Mirror& Device::mirror( int id ) const
+Device::Mirror Device::mirror( int id ) const
 {
   Registry& r = registry( m_gpu );
   std::lock_guard<std::mutex> g( r.m );
@@ -230,12 +234,12 @@ int Device::copyMirrorTo( int id, Device& dst )
   return did;
 }
 
-const Device::Mirror* Device::find( const Pel* p ) const
+Device::Found Device::find( const Pel* p ) const
 {
   Registry& r = registry( m_gpu );
   std::lock_guard<std::mutex> g( r.m );
-  for( const Mirror& m : r.mirrors ) if( m.live && m.findable && p >= m.hostBase && p < m.hostEnd ) return &m;
-  return nullptr;
+  for( const Mirror& m : r.mirrors ) if( m.live && m.findable && p >= m.hostBase && p < m.hostEnd ) { Found f; f.ok = true; f.m = m; return f; }
+  return Found();
 }
 
 void Device::setReference( int id )
@@ -246,12 +250,12 @@ void Device::setReference( int id )
   m.reference = true; m.findable = false;
 }
 
-const Device::Mirror* Device::findReference( const Pel* p ) const
+Device::Found Device::findReference( const Pel* p ) const
 {
   Registry& r = registry( m_gpu );
   std::lock_guard<std::mutex> g( r.m );
-  for( const Mirror& m : r.mirrors ) if( m.live && m.reference && p >= m.hostBase && p < m.hostEnd ) return &m;
-  return nullptr;
+  for( const Mirror& m : r.mirrors ) if( m.live && m.reference && p >= m.hostBase && p < m.hostEnd ) { Found f; f.ok = true; f.m = m; return f; }
+  return Found();
 }
 
 int16_t* Device::staging( size_t bytes )
@@ -287,7 +291,7 @@ struct Resolved { const int16_t* dBase; int stride; int32_t off; };
 // host block -> device pointer: inside a registered picture (offset only) or staged copy (compact w x h)
 Resolved resolve( Device& dev, const CPelBuf& b, int w, int h, int extraLeft, int extraRight, int16_t*& stageCursor, std::vector<Pel>& hostTmp )
 {
-  if( const Device::Mirror* m = dev.find( b.buf ) )
+  if( const auto m = dev.find( b.buf ) )
     if( m->stride == b.stride ) return { m->dOrigin, m->stride, ( int32_t ) ( b.buf - m->origin ) };
   const int ww = w + extraLeft + extraRight;
   hostTmp.resize( ( size_t ) ww * h );
@@ -428,7 +432,7 @@ void RdCost::distAtPositions( int func, const CPelBuf& org, const Pel* refBase, 
   const int w = org.width, h = org.height;
   int x0 = xy[0][0], x1 = xy[0][0], y0 = xy[0][1], y1 = xy[0][1];
   for( int i = 1; i < n; i++ ) { x0 = std::min( x0, xy[i][0] ); x1 = std::max( x1, xy[i][0] ); y0 = std::min( y0, xy[i][1] ); y1 = std::max( y1, xy[i][1] ); }
-  const Device::Mirror* mr = dev.findReference( refBase );
+  const auto mr = dev.findReference( refBase );
   const bool resident = mr && mr->stride == refStride;      // the reference picture is mirrored in HBM (binding: reconstructed pictures, row by row): only offsets travel
   if( resident ) g_refCalls++;
   const int pw = resident ? 0 : x1 - x0 + w, ph = resident ? 0 : y1 - y0 + h;
@@ -462,7 +466,7 @@ bool RdCost::patternRefineCosts( const CPelBuf& org, const Pel* refBlk, int refS
   if( ( w & 7 ) || w > 64 || h > 64 || h < 4 || n < 1 || n > 16 || reduceTap < 0 || reduceTap > 2 ) return false;
   if( ( hadMode == 1 || hadMode == 2 ) && ( h & 3 ) ) return false;
   Device& dev = Device::get();
-  const Device::Mirror* mr = dev.findReference( refBlk );
+  const auto mr = dev.findReference( refBlk );
   const bool resident = mr && mr->stride == refStride;      // reference picture mirrored in HBM: the block's window is not staged
   if( resident ) g_refCalls++;
   const int M0 = 5, M1 = 6, pitch = resident ? refStride : w + M0 + M1, rows = resident ? 0 : h + M0 + M1;
@@ -522,12 +526,12 @@ Distortion RdCost::getDistPart( const CPelBuf& org, const CPelBuf& cur, int bitD
 int RdCost::enqueue( const DistParam& dp )
 {
   Device& dev = Device::get();
-  const Device::Mirror* mo = dev.find( dp.org.buf );
-  const Device::Mirror* mc = dev.find( dp.cur.buf );
+  const auto mo = dev.find( dp.org.buf );
+  const auto mc = dev.find( dp.cur.buf );
   const int func = funcOfEntry( *this, dp.distFunc );
   if( !mo || !mc || mo->stride != dp.org.stride || mc->stride != dp.cur.stride || func < 0 )
     throw Exception( "RdCost::enqueue: org/cur must point into pictures registered with vvhip::Device and distFunc must be a table entry" );
-  Pending p; p.func = func; p.w = dp.org.width; p.h = dp.org.height; p.subShift = dp.subShift; p.mo = mo; p.mc = mc;
+  Pending p; p.func = func; p.w = dp.org.width; p.h = dp.org.height; p.subShift = dp.subShift; p.mo = *mo; p.mc = *mc;
   p.orgOff = ( int32_t ) ( dp.org.buf - mo->origin ); p.curOff = ( int32_t ) ( dp.cur.buf - mc->origin );
   m_pending.push_back( p );
   m_results.push_back( 0 );
@@ -543,7 +547,7 @@ void RdCost::flush()
   for( size_t i = 0; i < m_pending.size(); i++ )
   {
     const Pending& p = m_pending[i];
-    groups[std::make_tuple( p.func, p.w, p.h, p.subShift, ( const void* ) p.mo, ( const void* ) p.mc )].push_back( ( int ) i );
+    groups[std::make_tuple( p.func, p.w, p.h, p.subShift, ( const void* ) p.mo.dOrigin, ( const void* ) p.mc.dOrigin )].push_back( ( int ) i );
   }
   const size_t n = m_pending.size();
   char* aux = static_cast<char*>( dev.stagingAux( n * ( sizeof( vvhip_dist_item ) + sizeof( uint64_t ) ) + 64 ) );
@@ -557,7 +561,7 @@ void RdCost::flush()
   for( auto& kv : groups )
   {
     const Pending& p = m_pending[kv.second[0]];
-    dev.check( vvhip_dist_batch( dev.ctx(), p.func, p.mo->dOrigin, p.mo->stride, p.mc->dOrigin, p.mc->stride, p.w, p.h, p.subShift, 10,
+    dev.check( vvhip_dist_batch( dev.ctx(), p.func, p.mo.dOrigin, p.mo.stride, p.mc.dOrigin, p.mc.stride, p.w, p.h, p.subShift, 10,
                                  dItems + pos, ( int ) kv.second.size(), dOut + pos ), "flush launch" );
     pos += kv.second.size();
   }
@@ -1127,8 +1131,8 @@ int errorOne( const Pel* org, ptrdiff_t os, const Pel* buf, ptrdiff_t bs, int w,
   struct Io { vvhip_mctf_item it; int32_t out; } io;
   const int16_t* dOrg; const int16_t* dBuf; int sOrg, sBuf;
   std::vector<Pel> t;
-  const Device::Mirror* mo = dev.find( org );
-  const Device::Mirror* mb = dev.find( buf );
+  const auto mo = dev.find( org );
+  const auto mb = dev.find( buf );
   if( mo && mo->stride == os ) { dOrg = mo->dOrigin; sOrg = mo->stride; io.it.org_off = ( int32_t ) ( org - mo->origin ); }
   else
   {

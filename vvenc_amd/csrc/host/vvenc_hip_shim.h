@@ -104,12 +104,15 @@ public:
   // the same picture on another GPU: allocates a mirror there and fills it device-to-device (hipMemcpyPeerAsync over xGMI); returns the id in `dst`'s registry
   int  copyMirrorTo( int id, Device& dst );
   struct Mirror { const Pel* hostBase; const Pel* hostEnd; const Pel* origin; int stride, width, height, margin; int16_t* dBase; int16_t* dOrigin; bool live; bool findable; bool reference; };
-  const Mirror* find( const Pel* p ) const;  // which registered picture of this GPU contains host pointer p (nullptr: none)
+  // (find / findReference / mirror hand out COPIES taken under the registry's lock: another thread may register into a freed slot at any time; the device memory of a picture
+  //  is released by unregisterPicture only — the caller that owns the picture's life cycle — and hipFree itself waits for the device's work in flight)
+  struct Found { bool ok = false; Mirror m; explicit operator bool() const { return ok; } const Mirror* operator->() const { return &m; } const Mirror& operator*() const { return m; } };
+  Found find( const Pel* p ) const;  // which registered picture of this GPU contains host pointer p (nullptr: none)
   // reference pictures (reconstructions mirrored row by row, setReference): looked up by the motion-search entry points only — never by the generic table entries,
   // which may be handed the same host buffer while it is being rewritten as the current picture's reconstruction
   void setReference( int id );
-  const Mirror* findReference( const Pel* p ) const;
-  const Mirror& mirror( int id ) const;
+  Found findReference( const Pel* p ) const;
+  Mirror mirror( int id ) const;
   void check( int rc, const char* what ) const;
   int16_t* staging( size_t bytes );          // grow-only device scratch of THIS context for unregistered (compact temp) buffers
   void*    stagingAux( size_t bytes );
@@ -173,7 +176,7 @@ public:
   Distortion result( int ticket ) const { return m_results[ticket]; }
   void       clear() { m_pending.clear(); m_results.clear(); }
 private:
-  struct Pending { int func, w, h, subShift; const Device::Mirror* mo; const Device::Mirror* mc; int32_t orgOff, curOff; };
+  struct Pending { int func, w, h, subShift; Device::Mirror mo, mc; int32_t orgOff, curOff; };
   std::vector<Pending>    m_pending;
   std::vector<Distortion> m_results;
 };

@@ -21,6 +21,7 @@ PROTOTYPES = {
     "vvhip_use_own_stream": (i32, [vp]),
     "vvhip_get_stream": (vp, [vp]),
     "vvhip_sync": (i32, [vp]),
+    "vvhip_sync_all_devices": (i32, [vp]),
     "vvhip_malloc": (i32, [vp, C.POINTER(vp), sz]),
     "vvhip_free": (i32, [vp, vp]),
     "vvhip_upload": (i32, [vp, vp, vp, sz]),
