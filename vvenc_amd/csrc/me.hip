@@ -7,7 +7,7 @@
 //   integer job   the bounding window of the job's candidates is staged ONCE in LDS (samples biased for v_sad_u16), the original block next to it; every candidate is then
 //                 scored from LDS by a team of lanes (dword reads at the even address below the candidate + v_alignbit for odd displacements): the L1 sees the window once
 //                 per job instead of once per candidate.                                                    xGetSAD*, CommonLib/RdCost.cpp:301-644
-//   stage bundle  a few (stage, band of <= 16 rows) units of one block width.  Per unit: horizontal pass of the <= 3 distinct horizontal positions straight from the plane
+//   stage bundle  a few (stage, band of <= 32 rows) units of one block width.  Per unit: horizontal pass of the <= 3 distinct horizontal positions straight from the plane
 //                 into LDS (14-bit intermediates, InterpolationFilter.cpp:356-441), then eight lanes per (position, Hadamard tile): vertical pass of the lane's own row(s)
 //                 out of LDS, difference to the original block, 8x8 / 16x16_fast Hadamard with the vertical butterflies across the eight lanes (DPP) — the prediction never
 //                 exists in memory.                                                                        xGetHADs<fast>, RdCost.cpp:1818-1938; tiles :1126-1322
@@ -318,27 +318,41 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
   }
   for( int si = 0; si < span.count; si++ )
   {
-    const int unit = a.stageOrder[span.first + si], stage = unit & 0xffffff, y0 = ( unit >> 24 ) << 4;
+    const int unit = a.stageOrder[span.first + si], stage = unit & 0xffffff;
     const vvhip_me_stage_job j = a.stageJobs[span.first + si];                     // (the job table is in schedule order, one record per unit)
     const int w = j.width, h = j.height, G = w >> 3, log2G = 31 - __builtin_clz( G );
-    const int BH = h < 16 ? h : 16, rowsT = BH + NT;
+    const int BH = h < 32 ? h : 32, rowsT = BH + NT, y0 = ( unit >> 24 ) * BH;        // a band = <= 32 rows of the block (two rows of 16x16_fast tiles)
     const int ldsPitch = w + 8;                                                    // LDS row pitch: an odd number of 16-byte chunks (rows of a tile column land in different banks)
     const int16_t* ref = P.p[j.ref_plane] + j.ref_off;
     const int rs = P.stride[j.ref_plane];
     const int16_t* org = P.p[j.org_plane] + j.org_off;
     const int os = P.stride[j.org_plane];
     // the evaluated positions and their distinct horizontal displacements (<= 3: the refinement offsets are -1, 0, 1): one first pass each, shared like the reference's planes
-    int hx0 = 0, hx1 = 0, hx2 = 0, nHor = 0, nPos = 0;
+    int hx0 = 0, hx1 = 0, hx2 = 0, nHor = 0, nPos = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0;
     __syncthreads();                                                               // the previous unit's readers are done with the tables and tmp
     for( int k = 0; k < 9; k++ )
     {
       if( !( ( j.mask >> k ) & 1 ) ) continue;
       int tx, ty; stagePos( j, k, tx, ty );
-      if( tid == 0 ) posL[nPos] = k | ( ( tx + 64 ) << 8 ) | ( ( ty + 64 ) << 20 );
       nPos++;
-      if( ( nHor > 0 && tx == hx0 ) || ( nHor > 1 && tx == hx1 ) || ( nHor > 2 && tx == hx2 ) ) continue;
-      if( nHor == 0 ) hx0 = tx; else if( nHor == 1 ) hx1 = tx; else hx2 = tx;
+      if( nHor > 0 && tx == hx0 ) { cnt0++; continue; }
+      if( nHor > 1 && tx == hx1 ) { cnt1++; continue; }
+      if( nHor > 2 && tx == hx2 ) { cnt2++; continue; }
+      if( nHor == 0 ) { hx0 = tx; cnt0++; } else if( nHor == 1 ) { hx1 = tx; cnt1++; } else { hx2 = tx; cnt2++; }
       nHor++;
+    }
+    ( void ) cnt2;
+    // posL: the evaluated positions grouped by their horizontal displacement (variant 0 first): a pass of the unit works on the positions of the variants it holds in LDS
+    if( tid == 0 )
+    {
+      int f0 = 0, f1 = cnt0, f2 = cnt0 + cnt1;
+      for( int k = 0; k < 9; k++ )
+      {
+        if( !( ( j.mask >> k ) & 1 ) ) continue;
+        int tx, ty; stagePos( j, k, tx, ty );
+        const int slot = tx == hx0 ? f0++ : ( ( nHor > 1 && tx == hx1 ) ? f1++ : f2++ );
+        posL[slot] = k | ( ( tx + 64 ) << 8 ) | ( ( ty + 64 ) << 20 );
+      }
     }
     // the tap tables of the unit's (tap set, alternative half-sample filter) from the plan, 192 dwords: fetched when they differ from the previous unit's (a bundle of the
     // 4-tap search set never changes them)
@@ -351,10 +365,18 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     if( tid < 9 ) costL[tid] = 0;
     const bool fast16 = j.func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
     const int tile = fast16 ? 16 : 8, tilesX = w / tile, tilesB = tilesX * ( BH / tile );
-    __syncthreads();
-    // ---- H: tmp[v][r][x] <-> plane row y0 + K0 - 4 + r, column x + sx[v].  HU units per lane and trip, all their loads issued before the first is used (a unit is short:
+    // Blocks of 32 and 64 samples keep ONE horizontal variant in LDS at a time (a pass = first pass of the variant, then every position that uses it: with 32-row bands a
+    // position of a 64-wide block is exactly 64 lanes of second-pass work), smaller blocks all (<= 3) of them: 6 KB of LDS per wave instead of 9.5 — the kernel is
+    // occupancy-bound — and half as many units for the 64x64 blocks.
+    const int vpp = w <= 16 ? nHor : 1;
+    for( int v0 = 0; v0 < nHor; v0 += vpp )
+    {
+    const int nV = nHor - v0 < vpp ? nHor - v0 : vpp;
+    const int pBeg = v0 == 0 ? 0 : ( v0 == 1 ? cnt0 : cnt0 + cnt1 ), pEnd = v0 + nV >= 3 ? nPos : ( v0 + nV == 2 ? cnt0 + cnt1 : ( v0 + nV == 1 ? cnt0 : 0 ) );
+    __syncthreads();                                                               // tables and positions are written; the previous pass's readers are done with tmp
+    // ---- H: tmp[v - v0][r][x] <-> plane row y0 + K0 - 4 + r, column x + sx[v].  HU units per lane and trip, all their loads issued before the first is used (a unit is short:
     //      without it every trip of the wave waits out a full memory latency)
-    const int nH = nHor * rowsT * G;
+    const int nH = nV * rowsT * G;
     for( int ub = tid; ub < nH; ub += HU * nthr )
     {
       u32x4 LA[HU], LB[HU]; int fxs[HU], at[HU]; bool ok[HU];
@@ -364,9 +386,9 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
         const int u = ub + q * nthr;
         ok[q] = u < nH;
         const int uu = ok[q] ? u : ub;
-        const int x0 = ( uu & ( G - 1 ) ) << 3, rr = uu >> log2G, v = rr / rowsT, r = rr - v * rowsT;
+        const int x0 = ( uu & ( G - 1 ) ) << 3, rr = uu >> log2G, vl = rr / rowsT, r = rr - vl * rowsT, v = v0 + vl;
         const int txv = v == 0 ? hx0 : ( v == 1 ? hx1 : hx2 ), sxv = txv >> 4;
-        fxs[q] = txv & 15; at[q] = ( v * rowsT + r ) * ldsPitch + x0;
+        fxs[q] = txv & 15; at[q] = ( vl * rowsT + r ) * ldsPitch + x0;
         const int16_t* p = ref + ( ptrdiff_t ) ( y0 + K0 - 4 + r ) * rs + x0 + sxv;
         // window samples s[0 .. 6 + NT] = p[K0 - 3 ..]: A = s[0..7] as even pairs W[0..3], B = s[NT - 1 .. NT + 6] as odd pairs S[B0 .. B0 + 3]; zero phase: A = p[0..7]
         LA[q] = ld16( fxs[q] ? p + K0 - 3 : p ); LB[q] = ld16( p + K0 - 3 + NT - 1 );
@@ -414,29 +436,30 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     }
     __syncthreads();
     // ---- VD: eight lanes per (position, tile), lane r = tile row r
-    for( int u0 = 0; u0 < nPos * tilesB * 8; u0 += nthr )
+    const int nSlots = ( pEnd - pBeg ) * tilesB * 8;
+    for( int u0 = 0; u0 < nSlots; u0 += nthr )
     {
       const int u = u0 + tid, r = u & 7, tt = u >> 3;
-      const bool valid = u < nPos * tilesB * 8;
-      const int pi = valid ? tt / tilesB : 0, t = valid ? tt - pi * tilesB : 0;
+      const bool valid = u < nSlots;
+      const int pl = valid ? tt / tilesB : 0, t = valid ? tt - pl * tilesB : 0, pi = pBeg + pl;
       const int tyi = t / tilesX, txi = t - tyi * tilesX;
       const int pk = posL[pi], txk = ( ( pk >> 8 ) & 0xfff ) - 64, tyk = ( ( pk >> 20 ) & 0xfff ) - 64;
-      const int hv = txk == hx0 ? 0 : ( txk == hx1 ? 1 : 2 ), syk = tyk >> 4, fyk = tyk & 15;
+      const int hv = ( txk == hx0 ? 0 : ( ( nHor > 1 && txk == hx1 ) ? 1 : 2 ) ) - v0, syk = tyk >> 4, fyk = tyk & 15;
       int d[8];
       if( fast16 )
       {
         const int16_t* tv = tmp + hv * rowsT * ldsPitch + txi * 16;
-        const int16_t* po = org + ( ptrdiff_t ) ( y0 + 2 * r ) * os + txi * 16;
+        const int16_t* po = org + ( ptrdiff_t ) ( y0 + tyi * 16 + 2 * r ) * os + txi * 16;
         const u32x4 c0v = ld16( po ), c1v = ld16( po + 8 ), e0 = ld16( po + os ), e1 = ld16( po + os + 8 );
         uint32_t pa[4], pb[4]; int ap[4], ao[4];
-        predRow<K0, K1>( tv, ldsPitch, 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
-        predRow<K0, K1>( tv, ldsPitch, 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
+        predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
+        predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
         { const uint32_t oa[4] = { c0v.x, c0v.y, c0v.z, c0v.w }, ob[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( oa, ob, ao ); }      // RdCost.cpp:1138-1160
 #pragma unroll
         for( int i = 0; i < 4; i++ ) d[i] = ao[i] - ap[i];
-        predRow<K0, K1>( tv + 8, ldsPitch, 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
-        predRow<K0, K1>( tv + 8, ldsPitch, 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
+        predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
+        predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
         { const uint32_t oa[4] = { c1v.x, c1v.y, c1v.z, c1v.w }, ob[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( oa, ob, ao ); }
 #pragma unroll
@@ -483,11 +506,12 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       }
       if( valid && r == 0 ) atomicAdd( &costL[pk & 0xff], sres );
     }
+    }      // passes
     __syncthreads();
     // the unit's share of the stage's costs (blocks of one band: the only share)
     if( tid < 9 && ( ( j.mask >> tid ) & 1 ) )
     {
-      if( h <= 16 ) a.stageCost[( size_t ) 9 * stage + tid] = costL[tid];
+      if( h <= 32 ) a.stageCost[( size_t ) 9 * stage + tid] = costL[tid];
       else atomicAdd( reinterpret_cast<unsigned long long*>( a.stageCost ) + ( size_t ) 9 * stage + tid, ( unsigned long long ) costL[tid] );
     }
   }
@@ -726,7 +750,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   int intBig = 0, ldsIntSmall = 0;
   for( const IntJob& j : ij ) { if( ldsOf( j ) > ldsSmallCap ) intBig++; else ldsIntSmall = std::max( ldsIntSmall, ldsOf( j ) ); }
 
-  // ---- stage units: (stage, band of <= 16 rows); a wave takes a bundle of units of one block width and tap support worth ~160 second-pass row groups
+  // ---- stage units: (stage, band of <= 32 rows); a wave takes a bundle of units of one block width and tap support worth ~160 second-pass row groups
   std::vector<WaveSpan> stWaves;
   int ldsStage = 0;
   for( int i = 0; i < n_stage_jobs; i++ )
@@ -737,9 +761,9 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
       return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: stage job %d (%dx%d, iFrac %d, mode %d, func %d)", i, s.width, s.height, s.i_frac, s.filter_mode, s.func );
   }
   auto setOf = []( const vvhip_me_stage_job& s ) { return ( s.filter_mode == 2 && !s.alt_hpel ) ? 0 : ( s.filter_mode == 0 ? 2 : 1 ); };      // which tap support the bundle's kernel instance uses
-  auto unitWork = [&]( const vvhip_me_stage_job& s ) { return __builtin_popcount( s.mask ) * ( s.width / 8 ) * std::min( ( int ) s.height, 16 ); };      // 8-sample row groups of the second pass
+  auto unitWork = [&]( const vvhip_me_stage_job& s ) { return __builtin_popcount( s.mask ) * ( s.width / 8 ) * std::min( ( int ) s.height, 32 ); };      // 8-sample row groups of the second pass
   std::vector<int32_t> stOrder;
-  for( int i = 0; i < n_stage_jobs; i++ ) if( stage_jobs[i].mask ) for( int b = 0; b < ( stage_jobs[i].height + 15 ) / 16; b++ ) stOrder.push_back( i | ( b << 24 ) );
+  for( int i = 0; i < n_stage_jobs; i++ ) if( stage_jobs[i].mask ) for( int b = 0; b < ( stage_jobs[i].height + 31 ) / 32; b++ ) stOrder.push_back( i | ( b << 24 ) );
   std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & 0xffffff]; const auto& y = stage_jobs[b & 0xffffff];
                     return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( x.width != y.width ? x.width > y.width : unitWork( x ) > unitWork( y ) ); } );
   int setWaves[3] = { 0, 0, 0 }, setBig[3] = { 0, 0, 0 };
@@ -757,8 +781,8 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     WaveSpan sp; sp.first = ( int32_t ) i; sp.count = count; stWaves.push_back( sp );
     setWaves[setOf( s0 )]++;
     if( s0.width >= 32 ) setBig[setOf( s0 )]++;
-    const int bh = std::min( ( int ) s0.height, 16 ), nt = setOf( s0 ) == 0 ? 4 : ( setOf( s0 ) == 1 ? 6 : 8 );
-    ldsStage = std::max( ldsStage, ( 2 * ( 128 + 64 + 16 + 16 ) + 3 * ( bh + nt ) * ( s0.width + 8 ) ) * 2 );      // tables + three first-pass bands (row pitch width + 8)
+    const int bh = std::min( ( int ) s0.height, 32 ), nt = setOf( s0 ) == 0 ? 4 : ( setOf( s0 ) == 1 ? 6 : 8 ), vpp = s0.width <= 16 ? 3 : 1;
+    ldsStage = std::max( ldsStage, ( 2 * ( 128 + 64 + 16 + 16 ) + vpp * ( bh + nt ) * ( s0.width + 8 ) ) * 2 );      // tables + the first-pass bands a pass holds (row pitch width + 8)
     i += count;
   }
 
