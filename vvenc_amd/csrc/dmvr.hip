@@ -64,7 +64,7 @@ dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* 
     {
       const int jb = lane + 64 * q;
       ok[q] = jb < jobs;
-      const int jv = ok[q] ? jb : 0, list = jv >= perList, rem = jv - list * perList, y = rem / segs, x0 = ( rem - y * segs ) * 8;
+      const int jv = ok[q] ? jb : 0, list = jv >= perList, rem = jv - list * perList, y = segs == 3 ? rem / 3 : rem >> 1, x0 = ( rem - y * segs ) * 8;      // segs is 2 or 3
       const int16_t* src = ( list ? s1 + ( ptrdiff_t ) y * stride1 : s0 + ( ptrdiff_t ) y * stride0 ) + x0;
       fxs[q] = ( list ? it.frac1_x : it.frac0_x ) & 15;
       at[q] = list * 22 * DP + y * DP + x0;
@@ -94,7 +94,7 @@ dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* 
     const int perList = bh * segs, jobs = 2 * perList;
     for( int jb = lane; jb < jobs; jb += 64 )
     {
-      const int list = jb >= perList, rem = jb - list * perList, y = rem / segs, x0 = ( rem - y * segs ) * 8;
+      const int list = jb >= perList, rem = jb - list * perList, y = segs == 3 ? rem / 3 : rem >> 1, x0 = ( rem - y * segs ) * 8;
       const int fx = ( list ? it.frac1_x : it.frac0_x ) & 15, fy = ( list ? it.frac1_y : it.frac0_y ) & 15;
       const u32x4 a = *reinterpret_cast<const u32x4*>( &sT[wv][list][y * DP + x0] );
       u32x4 o = a;

@@ -106,7 +106,7 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
 {
   const IntJob j = a.intJobs[wave];
   const int tid = ONE_WAVE ? ( int ) ( threadIdx.x & 63 ) : ( int ) threadIdx.x, nthr = ONE_WAVE ? 64 : ( int ) blockDim.x, lane = tid & 63;
-  const int w = j.w, ss = j.subShift, rowsEff = j.h >> ss, lpr = w >> 3;
+  const int w = j.w, ss = j.subShift, rowsEff = j.h >> ss, lpr = w >> 3, lprShift = 31 - __builtin_clz( lpr );
   const int pitch = winPitch( j.winW ), half0 = ( j.winH + 1 ) >> 1;
   int16_t* win = lds;
   int16_t* orgL = lds + ( ( j.winH * pitch + 7 ) & ~7 );                 // rowsEff x w, compact (16-byte rows)
@@ -122,20 +122,21 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
 #pragma unroll
     for( int q = 0; q < 4; q++ )
     {
-      const int i = tid + nthr * q < m ? tid + nthr * q : 0, r = i / lpr, c = i - r * lpr;
+      const int i = tid + nthr * q < m ? tid + nthr * q : 0, r = i >> lprShift, c = i & ( lpr - 1 );
       oat[q] = r * w + c * 8;
       ov[q] = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 );
     }
     const int16_t* ref = P.p[j.refPlane] + j.refOff + ( ptrdiff_t ) j.minDy * P.stride[j.refPlane] + j.minDx;
     // window rows: with row sub-sampling the even and the odd rows are two separate halves (a candidate reads every second row: consecutive rows of one half)
     const int cpr = ( j.winW + 2 + 7 ) >> 3, n = j.winH * cpr, rs = P.stride[j.refPlane];      // 16-byte chunks per row
+    const uint32_t cprInv = ( uint32_t ) ( ( ( 1ull << 32 ) + ( uint32_t ) cpr - 1u ) / ( uint32_t ) cpr );      // wave-uniform, once per job (cpr >= 2)
     for( int i0 = tid; i0 < n; i0 += 4 * nthr )                        // four loads in flight per lane (the loop is latency-bound otherwise)
     {
       u32x4 v[4]; int at[4], cc[4];
 #pragma unroll
       for( int q = 0; q < 4; q++ )
       {
-        const int i = i0 + nthr * q < n ? i0 + nthr * q : i0, r = i / cpr, c = i - r * cpr;
+        const int i = i0 + nthr * q < n ? i0 + nthr * q : i0, r = ( int ) __umulhi( ( uint32_t ) i, cprInv ), c = i - r * cpr;      // i / cpr by the reciprocal (exact: i * cpr < 2^32)
         const int dr = ss ? ( ( r & 1 ) ? half0 : 0 ) + ( r >> 1 ) : r;
         at[q] = dr * pitch + c * 8; cc[q] = c;
         v[q] = ld16( ref + ( ptrdiff_t ) r * rs + c * 8 );
@@ -166,7 +167,6 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
   const int chunks = rowsEff * lpr;
   int lpc = 64; while( lpc > chunks ) lpc >>= 1;                     // lanes per candidate: a power of two <= min( 64, chunks )   (chunks is a power of two for square blocks)
   const int teams = nthr / lpc, lt = tid & ( lpc - 1 ), team = tid / lpc;
-  const int lprShift = 31 - __builtin_clz( lpr );
   for( int c0 = 0; c0 < j.nCand; c0 += teams )
   {
     const int ci = c0 + team;
@@ -177,16 +177,20 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
     const int16_t* base = win + rowBase * pitch + ( x & ~1 );
     const uint32_t sh = ( x & 1 ) * 16;
     uint32_t sad = 0;
-    for( int c = lt; c < chunks; c += lpc )
+    // a lane's chunks are lpc apart: the same column piece, rowStep rows further down — both LDS addresses advance by constants (chunks and lpc are powers of two, lpc >= lpr)
+    const uint32_t* pc = reinterpret_cast<const uint32_t*>( base + ( lt >> lprShift ) * pitch + ( lt & ( lpr - 1 ) ) * 8 );
+    const u32x4* po = reinterpret_cast<const u32x4*>( orgL + ( lt >> lprShift ) * w + ( lt & ( lpr - 1 ) ) * 8 );
+    const int rowStep = lpc >> lprShift, curStep = rowStep * ( pitch >> 1 ), orgStep = rowStep * ( w >> 3 );
+#pragma unroll 2
+    for( int it = chunks / lpc; it > 0; it-- )
     {
-      const int r = c >> lprShift, s = c & ( lpr - 1 );
-      const uint32_t* pc = reinterpret_cast<const uint32_t*>( base + r * pitch + s * 8 );
-      const u32x4 o = *reinterpret_cast<const u32x4*>( orgL + r * w + s * 8 );
+      const u32x4 o = *po;
       const uint32_t v0 = pc[0], v1 = pc[1], v2 = pc[2], v3 = pc[3], v4 = pc[4];
       sad = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( v1, v0, sh ), o.x, sad );
       sad = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( v2, v1, sh ), o.y, sad );
       sad = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( v3, v2, sh ), o.z, sad );
       sad = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( v4, v3, sh ), o.w, sad );
+      pc += curStep; po += orgStep;
     }
     const uint32_t t = vvhipGroupSum32( sad, lpc, lane );
     if( valid && lt == 0 ) a.candCost[cd.outIndex] = ( uint64_t ) t << ss;       // RdCost.cpp:334
@@ -364,7 +368,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     }
     if( tid < 9 ) costL[tid] = 0;
     const bool fast16 = j.func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
-    const int tile = fast16 ? 16 : 8, tilesX = w / tile, tilesB = tilesX * ( BH / tile );
+    const int tile = fast16 ? 16 : 8, tilesX = w / tile, tilesB = tilesX * ( BH / tile ), log2TX = 31 - __builtin_clz( tilesX ), log2TB = 31 - __builtin_clz( tilesB );
     // Blocks of 32 and 64 samples keep ONE horizontal variant in LDS at a time (a pass = first pass of the variant, then every position that uses it: with 32-row bands a
     // position of a 64-wide block is exactly 64 lanes of second-pass work), smaller blocks all (<= 3) of them: 6 KB of LDS per wave instead of 9.5 — the kernel is
     // occupancy-bound — and half as many units for the 64x64 blocks.
@@ -386,7 +390,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
         const int u = ub + q * nthr;
         ok[q] = u < nH;
         const int uu = ok[q] ? u : ub;
-        const int x0 = ( uu & ( G - 1 ) ) << 3, rr = uu >> log2G, vl = rr / rowsT, r = rr - vl * rowsT, v = v0 + vl;
+        const int x0 = ( uu & ( G - 1 ) ) << 3, rr = uu >> log2G, vl = ( rr >= rowsT ) + ( rr >= 2 * rowsT ), r = rr - vl * rowsT, v = v0 + vl;      // (nV <= 3 variants: no division)
         const int txv = v == 0 ? hx0 : ( v == 1 ? hx1 : hx2 ), sxv = txv >> 4;
         fxs[q] = txv & 15; at[q] = ( vl * rowsT + r ) * ldsPitch + x0;
         const int16_t* p = ref + ( ptrdiff_t ) ( y0 + K0 - 4 + r ) * rs + x0 + sxv;
@@ -441,8 +445,8 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     {
       const int u = u0 + tid, r = u & 7, tt = u >> 3;
       const bool valid = u < nSlots;
-      const int pl = valid ? tt / tilesB : 0, t = valid ? tt - pl * tilesB : 0, pi = pBeg + pl;
-      const int tyi = t / tilesX, txi = t - tyi * tilesX;
+      const int pl = valid ? tt >> log2TB : 0, t = valid ? tt & ( tilesB - 1 ) : 0, pi = pBeg + pl;      // tilesX, tilesB are powers of two
+      const int tyi = t >> log2TX, txi = t & ( tilesX - 1 );
       const int pk = posL[pi], txk = ( ( pk >> 8 ) & 0xfff ) - 64, tyk = ( ( pk >> 20 ) & 0xfff ) - 64;
       const int hv = ( txk == hx0 ? 0 : ( ( nHor > 1 && txk == hx1 ) ? 1 : 2 ) ) - v0, syk = tyk >> 4, fyk = tyk & 15;
       int d[8];
@@ -534,7 +538,7 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
   const int w = first.width, h = first.height, func = first.func, ss = func == VVHIP_DF_SAD ? first.sub_shift : 0;
   if( func == VVHIP_DF_SAD || func == VVHIP_DF_SSE )
   {
-    const int cw = w >= 8 ? 8 : 4, lpr = w / cw, rowsEff = h >> ss, chunks = rowsEff * lpr;
+    const int cw = w >= 8 ? 8 : 4, lpr = w / cw, lprShift = 31 - __builtin_clz( lpr ), rowsEff = h >> ss, chunks = rowsEff * lpr;
     int lpc = 64; while( lpc > chunks ) lpc >>= 1;
     const int teams = 64 / lpc, lt = lane & ( lpc - 1 ), team = lane / lpc;
     for( int i0 = 0; i0 < span.count; i0 += teams )
@@ -546,11 +550,14 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
       const int16_t* po = planeL[it.org_plane] + it.org_off; const int os = strideL[it.org_plane];
       const int16_t* pc = planeL[it.cur_plane] + it.cur_off; const int cs = strideL[it.cur_plane];
       uint32_t sad = 0; uint64_t sse = 0;
-      for( int c = lt; c < chunks; c += lpc )                          // (four chunks per lane in flight were measured slower: 23.8 -> 24.6 us, the intra picture 123 -> 143 us)
+      // a lane's chunks are lpc apart: the same column piece, rowStep rows further down (lpr, chunks, lpc are powers of two, lpc >= lpr): no division, constant address steps.
+      // (four chunks per lane in flight were measured slower: 23.8 -> 24.6 us, the intra picture 123 -> 143 us)
+      const int r0 = lt >> lprShift, s0 = lt & ( lpr - 1 ), rowStep = lpc >> lprShift;
+      const int16_t* pa = po + ( ptrdiff_t ) ( r0 << ss ) * os + s0 * cw;
+      const int16_t* pb = pc + ( ptrdiff_t ) ( r0 << ss ) * cs + s0 * cw;
+      const ptrdiff_t stepA = ( ptrdiff_t ) ( rowStep << ss ) * os, stepB = ( ptrdiff_t ) ( rowStep << ss ) * cs;
+      for( int it = chunks / lpc; it > 0; it--, pa += stepA, pb += stepB )
       {
-        const int r = c / lpr, s = c - r * lpr;
-        const int16_t* pa = po + ( ptrdiff_t ) ( r << ss ) * os + s * cw;
-        const int16_t* pb = pc + ( ptrdiff_t ) ( r << ss ) * cs + s * cw;
         uint32_t va[4], vb[4];
         if( cw == 8 ) { const u32x4 x = ld16( pa ), z = ld16( pb ); va[0] = x.x; va[1] = x.y; va[2] = x.z; va[3] = x.w; vb[0] = z.x; vb[1] = z.y; vb[2] = z.z; vb[3] = z.w; }
         else { const u32x2 x = ld8( pa ), z = ld8( pb ); va[0] = x.x; va[1] = x.y; va[2] = va[3] = 0; vb[0] = z.x; vb[1] = z.y; vb[2] = vb[3] = 0; }
@@ -595,15 +602,15 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
   __shared__ uint32_t accL[128];                                      // per item of the span: Hadamard sum, SAD
   accL[lane] = 0; accL[64 + lane] = 0;
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
-  const int slotsPerItem = tiles * 8, total = span.count * slotsPerItem;
+  const int slotsPerItem = tiles * 8, total = span.count * slotsPerItem, log2Slots = 31 - __builtin_clz( slotsPerItem ), log2TX = 31 - __builtin_clz( tilesX );
   for( int s0 = 0; s0 < total; s0 += 64 )
   {
     const int sl = s0 + lane;
     const bool valid = sl < total;
-    const int sv = valid ? sl : 0, ii = sv / slotsPerItem, rem = sv - ii * slotsPerItem, t = rem >> 3, r = rem & 7;
+    const int sv = valid ? sl : 0, ii = sv >> log2Slots, rem = sv & ( slotsPerItem - 1 ), t = rem >> 3, r = rem & 7;      // (powers of two)
     const vvhip_me_item it = a.items[span.first + ii];
     const int os = strideL[it.org_plane], cs = strideL[it.cur_plane];
-    const int tyi = t / tilesX, txi = t - tyi * tilesX;
+    const int tyi = t >> log2TX, txi = t & ( tilesX - 1 );
     const int16_t* qa = planeL[it.org_plane] + it.org_off + ( ptrdiff_t ) ( tyi * tile ) * os + txi * tile;
     const int16_t* qb = planeL[it.cur_plane] + it.cur_off + ( ptrdiff_t ) ( tyi * tile ) * cs + txi * tile;
     int d[8]; uint32_t sad = 0;
