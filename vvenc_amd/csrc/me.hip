@@ -495,8 +495,8 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
           for( int i = 0; i < 8; i += 2 * len )
 #pragma unroll
             for( int q = i; q < i + len; q++ ) { const int x = d[q], z = d[q + len]; d[q] = x + z; d[q + len] = x - z; }
-#define ME_VSTAGE( CTRL, BIT ) { const bool upper = ( r & ( BIT ) ) != 0; _Pragma( "unroll" ) \
-        for( int i = 0; i < 8; i++ ) { const int o = VVHIP_DPP( d[i], CTRL ); d[i] = upper ? o - d[i] : d[i] + o; } }
+#define ME_VSTAGE( CTRL, BIT ) { const int sgn = ( r & ( BIT ) ) ? -1 : 1; _Pragma( "unroll" ) /* upper lane of a pair: other - own, lower: own + other; |d| < 2^23 */ \
+        for( int i = 0; i < 8; i++ ) { const int t = __mul24( d[i], sgn ); d[i] = VVHIP_DPP( d[i], CTRL ) + t; } }
         ME_VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
         ME_VSTAGE( VVHIP_DPP_XOR2, 2 )
         ME_VSTAGE( VVHIP_DPP_XOR1, 1 )
@@ -646,8 +646,8 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
       for( int i = 0; i < 8; i += 2 * len )
 #pragma unroll
         for( int q = i; q < i + len; q++ ) { const int x = d[q], z = d[q + len]; d[q] = x + z; d[q + len] = x - z; }
-#define ME_VSTAGE( CTRL, BIT ) { const bool upper = ( r & ( BIT ) ) != 0; _Pragma( "unroll" ) \
-    for( int i = 0; i < 8; i++ ) { const int o = VVHIP_DPP( d[i], CTRL ); d[i] = upper ? o - d[i] : d[i] + o; } }
+#define ME_VSTAGE( CTRL, BIT ) { const int sgn = ( r & ( BIT ) ) ? -1 : 1; _Pragma( "unroll" ) \
+    for( int i = 0; i < 8; i++ ) { const int t = __mul24( d[i], sgn ); d[i] = VVHIP_DPP( d[i], CTRL ) + t; } }
     ME_VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
     ME_VSTAGE( VVHIP_DPP_XOR2, 2 )
     ME_VSTAGE( VVHIP_DPP_XOR1, 1 )
