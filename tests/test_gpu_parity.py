@@ -2,6 +2,8 @@
 (2) the CPU oracle on seeded random batches, (3) size-independent properties at BASELINE sizes (1080p / 4K planes).
 Everything is bit-exact (tolerance 0): integer kernels, and the two IEEE-double corners (rectangular Hadamard tiles,
 MCTF error normalisation) are compiled without FMA contraction."""
+import os
+
 import numpy as np
 import pytest
 
@@ -563,6 +565,44 @@ def test_tu_rdo_multi_equals_batches(hip):
         assert np.array_equal(lv.cpu().numpy(), a), ("level", w, h, th, tv)
         assert np.array_equal(rc.cpu().numpy(), b), ("rec", w, h, th, tv)
         assert np.array_equal(st.cpu().numpy(), c), ("stats", w, h, th, tv)
+
+
+@pytest.mark.parametrize("mix", [{64: 30, 32: 70, 16: 150, 8: 300, 4: 500}, {64: 900, 32: 2200, 16: 700}, {32: 9000, 64: 300, 4: 3000, 8: 4000}], ids=["short-lists", "one-round-budget", "long-lists"])
+def test_tu_rdo_multi_strided_launch_shapes(hip, mix):
+    """vvhip_tu_rdo_multi_strided on compact residual blocks (pitch = width), the launch shapes of the matrix-core form: every list of a picture in ONE launch with the short lists
+    first, a wave budget that makes the launch one resident round (several tiles per wave), and separate launches per kernel instance for long lists — all equal to the
+    generic per-job kernel ($VVHIP_TU_GENERIC, read per call)"""
+    import torch
+    from vvenc_amd.hotpath import HotPath, DCT2, DST7
+    hp = hip.hp
+    rng = np.random.default_rng(77)
+    spec = [(w, n, DCT2) for w, n in mix.items()] + [(16, 40, DST7), (8, 25, DST7)]
+    total = sum(n * w * w for w, n, _ in spec)
+    pool = hp.to_device(rng.integers(-400, 400, total, dtype=np.int16))
+
+    def run():
+        jobs, strides, at = [], [], 0
+        for w, n, tr in spec:
+            off = hp.to_device((at + np.arange(n, dtype=np.int32) * w * w).astype(np.int32))
+            qp = hp.to_device(HotPath.tu_qp(np.random.default_rng(w + n).integers(22, 48, size=n), 1, 1))
+            lv = torch.full((n * w * w,), -7, dtype=torch.int16, device=hp.device)
+            rc = torch.full((n * w * w,), -7, dtype=torch.int16, device=hp.device)
+            st = torch.zeros((n, 24), dtype=torch.uint8, device=hp.device)
+            jobs.append((w, w, tr, tr, n, 8, off, qp, lv, rc, st)); strides.append(w)
+            at += n * w * w
+        hp.tu_rdo_multi_strided(pool, strides, jobs)
+        torch.cuda.synchronize()
+        return [(j[8].cpu().numpy(), j[9].cpu().numpy(), j[10].cpu().numpy()) for j in jobs]
+
+    got = run()
+    os.environ["VVHIP_TU_GENERIC"] = "1"
+    try:
+        exp = run()
+    finally:
+        del os.environ["VVHIP_TU_GENERIC"]
+    for (w, n, tr), g, e in zip(spec, got, exp):
+        for name, a, b in zip(("level", "rec", "stats"), g, e):
+            assert np.array_equal(a, b), (name, w, n, tr)
 
 
 def test_subpel_candidates_vs_oracle(hip, oracle):
