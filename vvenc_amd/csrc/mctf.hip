@@ -276,7 +276,7 @@ __device__ __forceinline__ void meRing3( const MeGeom& g, int bx, int by, int cx
 __global__ void __launch_bounds__( 64 )
 meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int factor, int doubleRes, int searchPttrn, int mvsW )
 {
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[( 32 + 5 ) * 32];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[48 * 52];      // the integer-grid window of a 32 x 32 block with range 8 (48 rows, pitch 50); > ( 32 + 5 ) * 32 of the sub-pel passes
   const int lane = threadIdx.x;
   g.buf = R.buf[blockIdx.y];
   const vvhip_mv* __restrict__ prev = R.prev[blockIdx.y];
@@ -313,6 +313,57 @@ meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int fac
   {
     const int pbx = bestX, pby = bestY;                                   // :1216-1228
     const int d = ( !prev && searchPttrn == 2 ) ? 2 : 1;
+    if( full32 && range > 0 )
+    {
+      // the dense integer grid of a full 32 x 32 block from an LDS WINDOW: ( 32 + 2 range )^2 samples staged once (every request in flight before the first is used),
+      // then every position is two rows of five dword reads per lane (v_alignbit for odd columns) against the original block held in registers — a candidate no longer
+      // waits for global memory, and consecutive candidates are independent (their reductions overlap).  Same scan order and strict-< update as the reference; a position
+      // equal to the current best vector has the same error and cannot win, so evaluating it is harmless.
+      const int gx0 = pbx / 16 - range, gy0 = pby / 16 - range, W = 32 + 2 * range;
+      const int PS = 2 * ( ( ( W + 3 ) >> 1 ) | 1 ), cpr = ( W + 7 ) >> 3, total = W * cpr;      // odd dword pitch: the five-dword reads of a 32-lane group cover all banks
+      const uint32_t cprInv = ( 65536u + ( uint32_t ) cpr - 1u ) / ( uint32_t ) cpr;              // i / cpr for i < 288, cpr <= 6: exact
+      const int16_t* src = g.buf + bx + gx0 + ( ptrdiff_t ) ( by + gy0 ) * g.bufStride;
+      for( int i0 = lane; i0 < total; i0 += 5 * 64 )
+      {
+        u32x4 v[5]; int at[5], left[5];
+#pragma unroll
+        for( int q = 0; q < 5; q++ )
+        {
+          const int i = i0 + 64 * q < total ? i0 + 64 * q : i0, r = ( int ) ( ( ( uint32_t ) i * cprInv ) >> 16 ), c = i - r * cpr;
+          at[q] = r * PS + 8 * c; left[q] = ( PS >> 1 ) - 4 * c;
+          v[q] = ld16( src + ( ptrdiff_t ) r * g.bufStride + 8 * c );
+        }
+#pragma unroll
+        for( int q = 0; q < 5; q++ )
+          if( i0 + 64 * q < total )
+          {
+            uint32_t* dst = reinterpret_cast<uint32_t*>( sTmp + at[q] );
+            dst[0] = v[q].x; if( left[q] > 1 ) dst[1] = v[q].y; if( left[q] > 2 ) dst[2] = v[q].z; if( left[q] > 3 ) dst[3] = v[q].w;
+          }
+      }
+      ME_WAVE_SYNC();
+      const int r = lane >> 2, sgm = lane & 3;
+      const uint32_t* rowA = reinterpret_cast<const uint32_t*>( sTmp + r * PS + 8 * sgm );
+      for( int gy = 0; gy <= 2 * range; gy += d )
+      {
+        for( int gx = 0; gx <= 2 * range; gx += d )
+        {
+          const uint32_t* pa = rowA + ( ( gy * PS + gx ) >> 1 );             // ( gy * PS + gx ) & ~1 samples on: PS and 8 sgm are even, the parity is gx's
+          const uint32_t* pb = pa + 8 * PS;                                   // 16 rows further down
+          const uint32_t sh = ( gx & 1 ) * 16;
+          const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], a4 = pa[4], b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3], b4 = pb[4];
+          int e = 0; uint32_t df;
+          df = pkSub16( O32.a.x, __builtin_amdgcn_alignbit( a1, a0, sh ) ); e = sdot2( df, df, e ); df = pkSub16( O32.a.y, __builtin_amdgcn_alignbit( a2, a1, sh ) ); e = sdot2( df, df, e );
+          df = pkSub16( O32.a.z, __builtin_amdgcn_alignbit( a3, a2, sh ) ); e = sdot2( df, df, e ); df = pkSub16( O32.a.w, __builtin_amdgcn_alignbit( a4, a3, sh ) ); e = sdot2( df, df, e );
+          df = pkSub16( O32.b.x, __builtin_amdgcn_alignbit( b1, b0, sh ) ); e = sdot2( df, df, e ); df = pkSub16( O32.b.y, __builtin_amdgcn_alignbit( b2, b1, sh ) ); e = sdot2( df, df, e );
+          df = pkSub16( O32.b.z, __builtin_amdgcn_alignbit( b3, b2, sh ) ); e = sdot2( df, df, e ); df = pkSub16( O32.b.w, __builtin_amdgcn_alignbit( b4, b3, sh ) ); e = sdot2( df, df, e );
+          const int e_ = waveSum( e );
+          if( e_ < bestE ) { bestX = ( gx0 + gx ) * 16; bestY = ( gy0 + gy ) * 16; bestE = e_; }
+        }
+      }
+      ME_WAVE_SYNC();                                                         // sTmp is reused by the refinement rings
+    }
+    else
     for( int y2 = pby / 16 - range; y2 <= pby / 16 + range; y2 += d )
       for( int x2 = pbx / 16 - range; x2 <= pbx / 16 + range; x2 += d )
         ME_TRY( x2 * 16, y2 * 16 );
