@@ -1535,14 +1535,18 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
 
 struct TuMxJobs { int nJobs; int waveStart[8]; int size[8]; TuMxArgs j[8]; };
 
-// WITH4: also carries the 4-point variant (four TUs per lane cost registers) and the 64-point one: launches without such lists use the kernel without them
-template<bool WITH4>
-__global__ void __launch_bounds__( 256, 3 )      // <= 168 registers: three waves per SIMD, their memory latencies overlap
+// Three instances, by what the launch's lists need (registers differ widely): KIND 0 the 8/16/32-point bodies (168 registers: three waves per SIMD, their memory latencies
+// overlap), KIND 1 also the 4-point body (four TUs per lane), KIND 2 also the 64-point body.  The 64x64 body wants ~230 registers: capped at 168 it spilled inside its main path
+// and ONE 64x64 TU took 13.5 us (the length of a whole picture's launch); with two waves per SIMD it takes 8.3 us and a recorded picture's launch 21.0 instead of 24.5 us
+// — although every other size of that launch also runs at two waves per SIMD (a 32x32-only list: 10.1 -> 12.5 us, which is why KIND 0 / 1 keep their bound).
+template<int KIND>
+__global__ void __launch_bounds__( 256, KIND == 2 ? 2 : 3 )
 tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs )
 {
+  constexpr bool WITH4 = KIND >= 1, WITH64 = KIND == 2;
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t stage[4][32 * 40];
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t sInit[4][WITH4 ? 96 : 64];
-  __shared__ v4i sOps[4][WITH4 ? 512 : 256];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t sInit[4][WITH64 ? 96 : 64];
+  __shared__ v4i sOps[4][WITH64 ? 512 : 256];
   const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) );
   const int wave = blockIdx.x * 4 + wv;
   int k = 0;
@@ -1554,8 +1558,8 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   if( jobs.size[k] == 32 )      tuMxBody<32>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
   else if( jobs.size[k] == 16 ) tuMxBody<16>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
   else if( jobs.size[k] == 8 )  tuMxBody<8>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
-  else if( WITH4 && jobs.size[k] == 4 )  tuMxBody<4>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
-  else if( WITH4 && jobs.size[k] == 64 ) tuMx64Body( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
+  else if( WITH4 && jobs.size[k] == 4 )   tuMxBody<4>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
+  else if( WITH64 && jobs.size[k] == 64 ) tuMx64Body( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
 }
 
 __global__ void __launch_bounds__( 256 )
@@ -1889,7 +1893,12 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
     for( int i = first; i < groupEnd; i++ ) groupTiles += tilesOf( i );
     // tiles per wave (matrix-core form): the launch should be ONE resident round of waves (3 per SIMD) with balanced work — a second round that is a tenth full costs a whole
     // wave duration.  Work budget B per wave in 32x32-tile units (a 64x64 TU counts 4): the smallest B for which the launch fits; capped, long lists simply take several rounds.
-    static const long residentWaves = getenv( "VVHIP_TU_RESIDENT_WAVES" ) ? atol( getenv( "VVHIP_TU_RESIDENT_WAVES" ) ) : 3072;
+    static const long residentEnv = getenv( "VVHIP_TU_RESIDENT_WAVES" ) ? atol( getenv( "VVHIP_TU_RESIDENT_WAVES" ) ) : 0;
+    bool has64 = false;
+    for( int i = first; i < groupEnd; i++ ) has64 |= jobs[order[i]].width == 64;
+    // (the 64-point instance holds 2 048 waves; on the recorded mix 64:955 32:2 133 16:600 8:800 4:600 = 3 298 tiles a budget for 2 048 / 3 072 / 4 096 waves gives 22.4 / 20.7 / 17.6 us:
+    //  with its long 64x64 waves in front, one tile per wave and a second partial round beat fewer, longer waves)
+    const long residentWaves = residentEnv ? residentEnv : ( has64 ? 4096 : 3072 );
     int budget = 0;
     auto repeatOf = [&]( int i ) { const int work = jobs[order[i]].width == 64 ? 4 : 1; const int r = budget / work; return r < 1 ? 1 : r; };
     if( mx && groupTiles <= repeat1Tiles * 4 )
@@ -1950,8 +1959,12 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
       for( int i = nJobs; i < 8; i++ ) { xj.waveStart[i] = 0x7fffffff; xj.size[i] = 0; }
       bool any4 = false;
       for( int i = 0; i < xj.nJobs; i++ ) any4 |= xj.size[i] == 4 || xj.size[i] == 64;
-      if( any4 ) hipLaunchKernelGGL( tuMxMultiKernel<true>, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
-      else       hipLaunchKernelGGL( tuMxMultiKernel<false>, dim3( ( unsigned ) ( ( waves + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
+      bool any64 = false;
+      for( int i = 0; i < xj.nJobs; i++ ) any64 |= xj.size[i] == 64;
+      const dim3 grid( ( unsigned ) ( ( waves + 3 ) / 4 ) );
+      if( any64 )     hipLaunchKernelGGL( tuMxMultiKernel<2>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
+      else if( any4 ) hipLaunchKernelGGL( tuMxMultiKernel<1>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
+      else            hipLaunchKernelGGL( tuMxMultiKernel<0>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
     }
     else
     {
