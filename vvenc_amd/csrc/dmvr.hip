@@ -154,16 +154,15 @@ dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* 
 
   if( lane == 0 )
   {
-    unsigned long long sad[25];
-#pragma unroll
-    for( int q = 0; q < 25; q++ ) sad[q] = sCost[wv][q];
+    // (the 25 costs stay in LDS: the scan and the error surface index them dynamically — a private array would live in scratch memory)
+    uint32_t* sad = sCost[wv];
     // centre: distFunc(SAD, subShift 1) >> 1, minus a quarter (:1332-1333); the X5 costs are SAD >> 1 without that reduction
     unsigned long long minCost = sad[12];
     minCost -= minCost >> 2;
     int tx = 0, ty = 0;
     if( minCost >= ( unsigned long long ) ( dx * dy ) )
     {
-      sad[12] = minCost;
+      sad[12] = ( uint32_t ) minCost;
       int bh_ = 0, bv_ = 0;
       for( int ver = -2; ver <= 2; ver++ )
         for( int hor = -2; hor <= 2; hor++ )
@@ -174,7 +173,7 @@ dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* 
       tx = bh_ * 16; ty = bv_ * 16;
       if( bh_ != 2 && bh_ != -2 && bv_ != 2 && bv_ != -2 )                       // xDMVRSubPixelErrorSurface (:1230-1231)
       {
-        const unsigned long long* p = &sad[12 + bv_ * 5 + bh_];
+        const uint32_t* p = &sad[12 + bv_ * 5 + bh_];
         const unsigned long long sb[5] = { p[0], p[-1], p[-5], p[1], p[5] };
         int t[2] = { 0, 0 };
 #pragma unroll
