@@ -627,6 +627,7 @@ def main():
         fr = {"hbm": roof["frac"] or 0.0, "l1_access": roof["l1_access_frac"] or 0.0, "valu": roof["valu_issue_frac"] or 0.0}
         order = sorted(fr, key=lambda k: -fr[k])
         roof["bound"] = "+".join(k for k in order if fr[k] >= 0.6 * fr[order[0]] and fr[k] > 0) or "hbm"
+        roof["binding_resource"], roof["binding_frac"] = order[0], fr[order[0]]      # the resource closest to its ceiling and how close (frac stays the HBM figure)
         roof["limiter"] = "fractions of the launch time: HBM traffic %.3f, L1 (TCP) access slots %.3f (one access per 64-byte granule and instruction, %d CUs x %.1f GHz), VALU issue slots %.3f " \
                           "(wave instructions x 4 cycles / %d SIMDs); the rest is latency the resident waves do not cover" % (fr["hbm"], fr["l1_access"], N_CU, CLOCK_GHZ, fr["valu"], N_SIMD)
         out["pmc"] = {k: {kk: v for kk, v in c.items()} for k, c in live["per_class"].items()}
