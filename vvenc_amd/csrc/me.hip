@@ -303,7 +303,9 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
 {
   constexpr int NT = K1 - K0 + 1, NP = NT / 2, B0 = ( NT - 2 ) / 2;
   constexpr int HU = VVHIP_ME_HU;                                                    // first-pass units a lane has in flight per trip
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, bd = a.bitDepth;
+  // a unit belongs to ONE wave: the workgroup's other waves work on other bundles (their own LDS slice); every hand-over through LDS is inside the wave
+#define ST_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+  const int tid = threadIdx.x & 63, nthr = 64, lane = tid, bd = a.bitDepth;
   const int headRoom = 14 - bd > 2 ? 14 - bd : 2;
   const int shift1 = 6 - headRoom, off1 = -( 8192 << shift1 );                       // first (not last) pass: InterpolationFilter.cpp:401-408
   const int shift2 = 6 + headRoom, rnd2 = ( 1 << ( shift2 - 1 ) ) + ( 8192 << 6 );   // second and last pass: :394-400
@@ -333,7 +335,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     const int os = P.stride[j.org_plane];
     // the evaluated positions and their distinct horizontal displacements (<= 3: the refinement offsets are -1, 0, 1): one first pass each, shared like the reference's planes
     int hx0 = 0, hx1 = 0, hx2 = 0, nHor = 0, nPos = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0;
-    __syncthreads();                                                               // the previous unit's readers are done with the tables and tmp
+    ST_SYNC();                                                                    // the previous unit's readers are done with the tables and tmp
     for( int k = 0; k < 9; k++ )
     {
       if( !( ( j.mask >> k ) & 1 ) ) continue;
@@ -377,7 +379,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     {
     const int nV = nHor - v0 < vpp ? nHor - v0 : vpp;
     const int pBeg = v0 == 0 ? 0 : ( v0 == 1 ? cnt0 : cnt0 + cnt1 ), pEnd = v0 + nV >= 3 ? nPos : ( v0 + nV == 2 ? cnt0 + cnt1 : ( v0 + nV == 1 ? cnt0 : 0 ) );
-    __syncthreads();                                                               // tables and positions are written; the previous pass's readers are done with tmp
+    ST_SYNC();                                                                    // tables and positions are written; the previous pass's readers are done with tmp
     // ---- H: tmp[v - v0][r][x] <-> plane row y0 + K0 - 4 + r, column x + sx[v].  HU units per lane and trip, all their loads issued before the first is used (a unit is short:
     //      without it every trip of the wave waits out a full memory latency)
     const int nH = nV * rowsT * G;
@@ -438,7 +440,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
         *reinterpret_cast<u32x4*>( tmp + at[q] ) = ov;
       }
     }
-    __syncthreads();
+    ST_SYNC();     
     // ---- VD: eight lanes per (position, tile), lane r = tile row r
     const int nSlots = ( pEnd - pBeg ) * tilesB * 8;
     for( int u0 = 0; u0 < nSlots; u0 += nthr )
@@ -511,7 +513,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       if( valid && r == 0 ) atomicAdd( &costL[pk & 0xff], sres );
     }
     }      // passes
-    __syncthreads();
+    ST_SYNC();     
     // the unit's share of the stage's costs (blocks of one band: the only share)
     if( tid < 9 && ( ( j.mask >> tid ) & 1 ) )
     {
@@ -531,8 +533,8 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
   __shared__ const int16_t* planeL[16];
   __shared__ int strideL[16];
   const WaveSpan span = a.itemWaves[wave];
-  const int lane = threadIdx.x;
-  if( lane < 16 ) { planeL[lane] = P.p[lane]; strideL[lane] = P.stride[lane]; }
+  const int lane = threadIdx.x & 63;
+  if( lane < 16 ) { planeL[lane] = P.p[lane]; strideL[lane] = P.stride[lane]; }      // (every wave of the workgroup writes the same values)
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
   const vvhip_me_item first = a.items[span.first];                                  // every item of the span has this function and geometry (the table is in schedule order)
   const int w = first.width, h = first.height, func = first.func, ss = func == VVHIP_DF_SAD ? first.sub_shift : 0;
@@ -599,7 +601,8 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
     if( valid ) a.itemCost[idx] = ( func == VVHIP_DF_HAD_2SAD && s2 < tot ) ? s2 : tot;
     return;
   }
-  __shared__ uint32_t accL[128];                                      // per item of the span: Hadamard sum, SAD
+  __shared__ uint32_t accAll[4][128];                                 // per wave and item of its span: Hadamard sum, SAD
+  uint32_t* accL = accAll[threadIdx.x >> 6];
   accL[lane] = 0; accL[64 + lane] = 0;
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
   const int slotsPerItem = tiles * 8, total = span.count * slotsPerItem, log2Slots = 31 - __builtin_clz( slotsPerItem ), log2TX = 31 - __builtin_clz( tilesX );
@@ -673,11 +676,12 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
 // three kernels (their register budgets differ widely); a plan's run launches the ones it needs back to back
 // (one instance per tap support: the 4-tap search filter of the fast presets must not pay the registers of the 8-tap window)
 template<int K0, int K1>
-__global__ void __launch_bounds__( 64 )
-meStageKernel( MePlanes P, MeArgs a, int firstWave )
+__global__ void __launch_bounds__( 256 )
+meStageKernel( MePlanes P, MeArgs a, int firstWave, int nWaves, int ldsPerWave )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t meLds[];
-  stageBody<K0, K1>( P, a, a.stageWaves[firstWave + blockIdx.x], meLds );
+  const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) ), wave = blockIdx.x * ( int ) ( blockDim.x >> 6 ) + wv;
+  if( wave < nWaves ) stageBody<K0, K1>( P, a, a.stageWaves[firstWave + wave], meLds + wv * ( ldsPerWave >> 1 ) );
 }
 
 // workgroups 0 .. nBig - 1: one large window each (four waves share it); the others: four small windows each, one per wave
@@ -691,10 +695,15 @@ meIntKernel( MePlanes P, MeArgs a, int nBig, int ldsSmall )
   if( job < a.wavesInt ) intBody<true>( P, a, job, meLds + wv * ( ldsSmall >> 1 ) );
 }
 
-__global__ void __launch_bounds__( 64 )
+// WAVES independent waves per workgroup (wave-level synchronisation only).  A B picture's ~13 000 one-pass waves are bound by the rate workgroups start at: four per workgroup
+// 23.6 -> 21.2 us (eight: 19.2, but long lists lose: a workgroup holds its slots until its slowest wave ends — the intra picture's 168 000 waves 116 -> 129 / 143 us), so long
+// lists keep single-wave workgroups
+template<int WAVES>
+__global__ void __launch_bounds__( 64 * WAVES )
 meItemKernel( MePlanes P, MeArgs a )
 {
-  itemBody( P, a, blockIdx.x );
+  const int wave = blockIdx.x * WAVES + ( int ) ( threadIdx.x >> 6 );
+  if( wave < a.wavesItem ) itemBody( P, a, wave );
 }
 
 int hostWinPitch( int winW ) { return 2 * ( ( ( winW + 3 ) >> 1 ) | 1 ); }
@@ -938,12 +947,14 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   if( plan->nStages && doStage ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_stage_cost, 0, ( size_t ) 9 * plan->nStages * sizeof( uint64_t ), ctx->stream ) );
   int firstWave = 0;
   static const int ldsPadExp = getenv( "VVHIP_ME_LDS_PAD" ) ? atoi( getenv( "VVHIP_ME_LDS_PAD" ) ) : 0;      // experiment: occupancy sensitivity of the stage kernel
+  static const int stW = getenv( "VVHIP_ME_STAGE_WAVES" ) ? atoi( getenv( "VVHIP_ME_STAGE_WAVES" ) ) : 1;      // independent waves per workgroup: 1 / 2 / 4 measured alike (51.2 / 51.9 / 51.5 us)
+  const size_t ldsSt = ( ( size_t ) plan->ldsStage + ldsPadExp + 15 ) & ~( size_t ) 15;
   // (one launch per tap support: bundles of 32- / 64-wide blocks first; splitting them from the small blocks' bundles or giving them four-wave workgroups was measured slower)
-  if( plan->stageSetWaves[0] && doStage ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) plan->stageSetWaves[0] ), dim3( 64 ), ( size_t ) plan->ldsStage + ldsPadExp, ctx->stream, P, a, firstWave );
+  if( plan->stageSetWaves[0] && doStage ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) ( ( plan->stageSetWaves[0] + stW - 1 ) / stW ) ), dim3( 64 * stW ), ( size_t ) stW * ldsSt, ctx->stream, P, a, firstWave, plan->stageSetWaves[0], ( int ) ldsSt );
   firstWave += plan->stageSetWaves[0];
-  if( plan->stageSetWaves[1] && doStage ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) plan->stageSetWaves[1] ), dim3( 64 ), ( size_t ) plan->ldsStage + ldsPadExp, ctx->stream, P, a, firstWave );
+  if( plan->stageSetWaves[1] && doStage ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) ( ( plan->stageSetWaves[1] + stW - 1 ) / stW ) ), dim3( 64 * stW ), ( size_t ) stW * ldsSt, ctx->stream, P, a, firstWave, plan->stageSetWaves[1], ( int ) ldsSt );
   firstWave += plan->stageSetWaves[1];
-  if( plan->stageSetWaves[2] && doStage ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) plan->stageSetWaves[2] ), dim3( 64 ), ( size_t ) plan->ldsStage + ldsPadExp, ctx->stream, P, a, firstWave );
+  if( plan->stageSetWaves[2] && doStage ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) ( ( plan->stageSetWaves[2] + stW - 1 ) / stW ) ), dim3( 64 * stW ), ( size_t ) stW * ldsSt, ctx->stream, P, a, firstWave, plan->stageSetWaves[2], ( int ) ldsSt );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[1], ctx->stream ) );
   if( plan->wavesInt && doInt )
   {
@@ -953,7 +964,10 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   }
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[2], ctx->stream ) );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[3], ctx->stream ) );
-  if( plan->wavesItem && doItem )  hipLaunchKernelGGL( meItemKernel, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a );
+  if( plan->wavesItem && doItem )  {
+    if( plan->wavesItem <= 65536 ) hipLaunchKernelGGL( meItemKernel<4>, dim3( ( unsigned ) ( ( plan->wavesItem + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a );
+    else                           hipLaunchKernelGGL( meItemKernel<1>, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a );
+  }
   VVHIP_LAUNCH_CHECK( ctx );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[4], ctx->stream ) );
   return VVHIP_OK;
