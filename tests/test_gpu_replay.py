@@ -25,16 +25,17 @@ def hp():
     return HotPath()
 
 
-def _plan_vs_kernels(hp, seed, sizes, filter_mode, func_stage, max_window, signed_org=False, n_jobs=40):
+def _plan_vs_kernels(hp, seed, sizes, filter_mode, func_stage, max_window, signed_org=False, n_jobs=40, bd=10):
     """random integer jobs / stages / items on one original and one reference plane, scored by a plan and by the per-function kernels"""
     import torch
     from vvenc_amd import replay as RP
     from vvenc_amd.hotpath import DF, SUBPEL_DTYPE
     rng = np.random.default_rng(seed)
     H, W, M = 256, 320, 80
-    lo = -1023 if signed_org else 0
-    org = hp.plane(rng.integers(lo, 2047 if signed_org else 1024, size=(H, W), dtype=np.int16), 8)
-    ref = hp.plane(rng.integers(0, 1024, size=(H, W), dtype=np.int16), M)
+    top = 1 << bd
+    lo = -(top - 1) if signed_org else 0
+    org = hp.plane(rng.integers(lo, 2 * top - 1 if signed_org else top, size=(H, W), dtype=np.int16), 8)
+    ref = hp.plane(rng.integers(0, top, size=(H, W), dtype=np.int16), M)
     jobs, cands, stages, items = [], [], [], []
     for _ in range(n_jobs):
         S = int(rng.choice(sizes))
@@ -65,7 +66,7 @@ def _plan_vs_kernels(hp, seed, sizes, filter_mode, func_stage, max_window, signe
     it = np.zeros(len(items), RP.ME_ITEM)
     for k, v in enumerate(items):
         it[k] = v
-    plan = hp.me_plan_create(ij, pc, sj, it, 10, max_window)
+    plan = hp.me_plan_create(ij, pc, sj, it, bd, max_window)
     tab = (RP.MePlane * 16)()
     tab[0] = RP.MePlane(org.storage.data_ptr() + 2 * org.origin, org.stride, 0)
     tab[1] = RP.MePlane(ref.storage.data_ptr() + 2 * ref.origin, ref.stride, 0)
@@ -80,7 +81,7 @@ def _plan_vs_kernels(hp, seed, sizes, filter_mode, func_stage, max_window, signe
     name = {v: k for k, v in DF.items()}
     for k, j in enumerate(jobs):
         its = np.array([(j[0], j[1] + dy * ref.stride + dx) for dx, dy in cands[j[7]:j[7] + j[8]]], np.int32)
-        exp = hp.dist_batch("SAD", org, ref, hp.to_device(its), len(its), j[2], j[3], j[6], 10).cpu().numpy()
+        exp = hp.dist_batch("SAD", org, ref, hp.to_device(its), len(its), j[2], j[3], j[6], bd).cpu().numpy()
         assert np.array_equal(cc[j[7]:j[7] + j[8]], exp), ("integer job", k, j, cc[j[7]:j[7] + j[8]][:6], exp[:6])
     from vvenc_amd.recorded import REFINE_H, REFINE_Q
     for k, s in enumerate(stages):
@@ -91,12 +92,12 @@ def _plan_vs_kernels(hp, seed, sizes, filter_mode, func_stage, max_window, signe
         for a, p in enumerate(sel):
             tx, ty = int(q[p][0]), int(q[p][1])
             its[a] = (s[0], s[1] + (ty >> 4) * ref.stride + (tx >> 4), tx & 15, ty & 15)
-        exp = hp.subpel_dist_batch(name[s[9]], org, ref, hp.to_device(its), len(sel), s[2], s[3], 10, s[7], bool(s[8])).cpu().numpy()
+        exp = hp.subpel_dist_batch(name[s[9]], org, ref, hp.to_device(its), len(sel), s[2], s[3], bd, s[7], bool(s[8])).cpu().numpy()
         got = sc[k][sel]
         assert np.array_equal(got, exp), ("stage", k, s, got, exp)
         assert all(sc[k][p] == 0 for p in range(9) if p not in sel)
     for k, v in enumerate(items):
-        exp = hp.dist_batch(name[v[4]], org, ref, hp.to_device(np.array([(v[0], v[1])], np.int32)), 1, v[6], v[7], v[5], 10).cpu().numpy()[0]
+        exp = hp.dist_batch(name[v[4]], org, ref, hp.to_device(np.array([(v[0], v[1])], np.int32)), 1, v[6], v[7], v[5], bd).cpu().numpy()[0]
         assert ic[k] == exp, ("item", k, v, ic[k], exp)
 
 
@@ -111,6 +112,14 @@ def test_me_plan_split_windows_and_signed_patterns(hp):
     from vvenc_amd.hotpath import DF
     _plan_vs_kernels(hp, 7, (8, 16, 32, 64), 2, DF["HAD_fast"], max_window=8, signed_org=True)
     _plan_vs_kernels(hp, 8, (8, 64), 0, DF["HAD"], max_window=24, signed_org=True, n_jobs=12)
+
+
+def test_me_plan_8_bit(hp):
+    """bit depth 8 (BASELINE configs[0]): no headroom shift in the first pass, 14 - 8 = 6 bits in the second; every tap set"""
+    from vvenc_amd.hotpath import DF
+    _plan_vs_kernels(hp, 31, (8, 16, 32, 64), 2, DF["HAD_fast"], max_window=16, bd=8, n_jobs=24)
+    _plan_vs_kernels(hp, 32, (8, 16, 64), 0, DF["HAD"], max_window=16, bd=8, n_jobs=16)
+    _plan_vs_kernels(hp, 33, (16, 32), 1, DF["SAD"], max_window=16, bd=8, signed_org=True, n_jobs=16)
 
 
 def test_me_plan_rejects_bad_jobs(hp):
