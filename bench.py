@@ -39,6 +39,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+# a picture's five launch groups go to five HIP streams: the runtime maps streams onto 4 hardware queues by default (two groups would share one and serialize);
+# measured on the recorded 1080p lists: 2 / 4 / 8 queues -> 8 519 / 12 036 / 12 326 pictures/s
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -570,7 +573,7 @@ def main():
                                                "dmvr_subblocks": int(sum(g["n"] for g in workloads[l].dmvr_groups)), "plan": workloads[l].me_info} for l in workloads},
                    "subpel_candidates_per_block": round(float(np.mean([workloads[l].stage_evaluated.sum() / max(1, workloads[l].pic.me.size) for l in workloads if workloads[l].pic.me.size])), 2),
                    "launches_per_frame": "motion-search plan (clear + refinement stages + integer windows x 2 LDS classes + table calls) + 1-2 TU launches + 0-1 DMVR launch",
-                   "hip_streams": len(lanes) if lanes else 1, "recording": rec_info,
+                   "hip_streams": len(lanes) if lanes else 1, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "recording": rec_info,
                    "sharding": "one picture per rank and step, pictures of one sequence round-robin over ranks, no data-path collective"
                                + (", reconstructed picture (luma + chroma, %.1f MB) RCCL-broadcast from its owner every %d step(s) inside the timed region, overlapped with the launches"
                                   % (sum(p.numel() * 2 for p in ex.slots[0]) / 1e6, args.exchange_every) if ex is not None else "")},
