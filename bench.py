@@ -432,8 +432,19 @@ def main():
     if args.streams > 1:
         streams = [torch.cuda.Stream() for _ in range(5 if args.streams >= 5 else 3)]
         lanes = [hp.fork(s) for s in streams]
-        for wl in workloads.values():
-            wl.bind_lanes(lanes)
+        if args.streams >= 10:
+            # two sets of five streams: the pictures of the top temporal layer (every second picture of the GOP) on one set, all others on the second — consecutive pictures
+            # then overlap kernel by kernel (the drain of one picture's launch runs under the next picture's ramp-up); a layer always uses the same set, so two runs on the same
+            # output buffers never overlap.  Measured: 11 787 against 12 134 pictures/s with one set — not the default.
+            streams2 = [torch.cuda.Stream() for _ in range(5)]
+            lanes2 = [hp.fork(s) for s in streams2]
+            top = max(workloads)
+            for l, wl in workloads.items():
+                wl.bind_lanes(lanes if l == top else lanes2)
+            streams, lanes = streams + streams2, lanes + lanes2
+        else:
+            for wl in workloads.values():
+                wl.bind_lanes(lanes)
 
     # ---- the reference-picture exchange of the sharded sequence (N > 1): ring of two reconstructed pictures (luma + 2 chroma planes with margins)
     ex = None
