@@ -49,6 +49,8 @@ VVHIP_API int         vvhip_set_stream( vvhip_ctx* ctx, void* hip_stream ); /* b
 VVHIP_API int         vvhip_use_own_stream( vvhip_ctx* ctx );          /* back to the context's private stream          */
 VVHIP_API void*       vvhip_get_stream( vvhip_ctx* ctx );
 VVHIP_API int         vvhip_sync( vvhip_ctx* ctx );                    /* hipStreamSynchronize                          */
+VVHIP_API int         vvhip_set_blocking_sync( vvhip_ctx* ctx, int on ); /* on: vvhip_sync and the downloads wait on a blocking event (the thread sleeps) instead of hipStreamSynchronize —
+                                                                        * for hosts whose cores are all busy (an encoder's worker threads); default off (lowest latency) */
 VVHIP_API int         vvhip_sync_all_devices( vvhip_ctx* ctx );        /* hipDeviceSynchronize on every device, the calling thread's current device restored: before host memory other
                                                                         * contexts may still be copying from is unpinned or released */
 /* Launch graphs: the batch entry points only enqueue kernels on the context's stream, so a frame's fixed sequence of calls (the lists of one picture: same tables,

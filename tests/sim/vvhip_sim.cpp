@@ -58,6 +58,7 @@ int         vvhip_use_own_stream( vvhip_ctx* ctx ) { return ctx ? VVHIP_OK : VVH
 void*       vvhip_get_stream( vvhip_ctx* ) { return nullptr; }
 int         vvhip_sync( vvhip_ctx* ctx ) { return ctx ? VVHIP_OK : VVHIP_E_ARG; }
 int         vvhip_sync_all_devices( vvhip_ctx* ctx ) { return ctx ? VVHIP_OK : VVHIP_E_ARG; }
+int         vvhip_set_blocking_sync( vvhip_ctx* ctx, int ) { return ctx ? VVHIP_OK : VVHIP_E_ARG; }
 int         vvhip_device_count( void ) { return vvhip_sim_device_count(); }
 int         vvhip_get_device( const vvhip_ctx* ctx ) { return ctx ? ctx->device : -1; }
 int         vvhip_make_current( vvhip_ctx* ctx ) { return ctx ? VVHIP_OK : VVHIP_E_ARG; }

@@ -25,7 +25,20 @@ struct vvhip_ctx
   // scratch of vvhip_subpel_dist_batch: predicted blocks + distortion items (grown on demand)
   void*        d_subpel   = nullptr;
   size_t       subpelBytes = 0;
+  // how the host waits for the stream (vvhip_set_blocking_sync): false = hipStreamSynchronize (the runtime's low-latency wait), true = a blocking event — the calling thread
+  // sleeps, which matters when the host's cores are all busy encoding
+  bool         blockingSync = false;
+  hipEvent_t   syncEvent  = nullptr;
 };
+
+// every host wait of the library on a context's stream goes through this
+inline hipError_t vvhip_wait_stream( vvhip_ctx* ctx )
+{
+  if( !ctx->blockingSync ) return hipStreamSynchronize( ctx->stream );
+  if( !ctx->syncEvent ) { const hipError_t e = hipEventCreateWithFlags( &ctx->syncEvent, hipEventBlockingSync | hipEventDisableTiming ); if( e != hipSuccess ) return e; }
+  const hipError_t e = hipEventRecord( ctx->syncEvent, ctx->stream );
+  return e != hipSuccess ? e : hipEventSynchronize( ctx->syncEvent );
+}
 
 int vvhip_fail( vvhip_ctx* ctx, int code, const char* fmt, ... );
 

@@ -238,6 +238,7 @@ void vvhip_destroy( vvhip_ctx* ctx )
   if( ctx->d_tuMx64 ) ( void ) hipFree( ctx->d_tuMx64 );
   if( ctx->d_scratch ) ( void ) hipFree( ctx->d_scratch );
   if( ctx->d_subpel ) ( void ) hipFree( ctx->d_subpel );
+  if( ctx->syncEvent ) ( void ) hipEventDestroy( ctx->syncEvent );
   if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );
   delete ctx;
 }
@@ -268,10 +269,17 @@ int vvhip_use_own_stream( vvhip_ctx* ctx )
 
 void* vvhip_get_stream( vvhip_ctx* ctx ) { return ctx ? ( void* ) ctx->stream : nullptr; }
 
+int vvhip_set_blocking_sync( vvhip_ctx* ctx, int on )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  ctx->blockingSync = on != 0;
+  return VVHIP_OK;
+}
+
 int vvhip_sync( vvhip_ctx* ctx )
 {
   if( !ctx ) return VVHIP_E_ARG;
-  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) );
   return VVHIP_OK;
 }
 
@@ -357,7 +365,7 @@ int vvhip_download( vvhip_ctx* ctx, void* host_dst, const void* d_src, size_t by
 {
   if( !ctx ) return VVHIP_E_ARG;
   VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( host_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream ) );
-  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) );
   return VVHIP_OK;
 }
 
@@ -381,7 +389,7 @@ int vvhip_download_2d( vvhip_ctx* ctx, void* host_dst, size_t dst_pitch, const v
   if( !ctx ) return VVHIP_E_ARG;
   if( !rows || !width_bytes ) return VVHIP_OK;
   VVHIP_CHECK_HIP( ctx, hipMemcpy2DAsync( host_dst, dst_pitch, d_src, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost, ctx->stream ) );
-  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) );
   return VVHIP_OK;
 }
 

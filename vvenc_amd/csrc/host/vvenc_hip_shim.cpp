@@ -106,6 +106,9 @@ Device::Device( int gpu ) : m_gpu( gpu )
   const int phys = vvhip_device_count();
   const int rc = vvhip_create( &m_ctx, logicalGpus() > 0 && phys > 0 ? gpu % phys : gpu );
   if( rc != VVHIP_OK ) throw Exception( std::string( "vvhip::Device: " ) + vvhip_last_error( nullptr ) );
+  // the shim's callers are an encoder's worker threads: while they wait for the device their core should go to another worker ($VVHIP_SYNC=spin: the runtime's busy wait)
+  static const bool spin = []{ const char* e = getenv( "VVHIP_SYNC" ); return e && !strcmp( e, "spin" ); }();
+  vvhip_set_blocking_sync( m_ctx, spin ? 0 : 1 );
   g_contexts++;
 }
 Device::~Device() {}

@@ -828,7 +828,7 @@ int vvhip_mctf_me_level( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, c
   if( rc ) return rc;
   int aborted = 0;
   VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( &aborted, d_abort, sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
-  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) );
   if( aborted ) return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_mctf_me_level: wavefront hand-off timed out" );
   return VVHIP_OK;
 }
@@ -926,7 +926,7 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
   }
   int aborted = 0;
   VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( &aborted, d_abort, sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
-  VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) );
   if( aborted ) return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_mctf_motion_estimation: wavefront hand-off timed out" );
   return VVHIP_OK;
 }

@@ -22,6 +22,7 @@ PROTOTYPES = {
     "vvhip_get_stream": (vp, [vp]),
     "vvhip_sync": (i32, [vp]),
     "vvhip_sync_all_devices": (i32, [vp]),
+    "vvhip_set_blocking_sync": (i32, [vp, i32]),
     "vvhip_malloc": (i32, [vp, C.POINTER(vp), sz]),
     "vvhip_free": (i32, [vp, vp]),
     "vvhip_upload": (i32, [vp, vp, vp, sz]),
