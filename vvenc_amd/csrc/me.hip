@@ -299,7 +299,7 @@ __device__ __forceinline__ void avgInts( const uint32_t ( &ra )[4], const uint32
 }
 
 template<int K0, int K1>
-__device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, const WaveSpan span, int16_t* lds )
+__device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, const WaveSpan span, int16_t* lds, uint32_t* pairCost, const int wv )
 {
   constexpr int NT = K1 - K0 + 1, NP = NT / 2, B0 = ( NT - 2 ) / 2;
   constexpr int HU = VVHIP_ME_HU;                                                    // first-pass units a lane has in flight per trip
@@ -514,11 +514,14 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     }
     }      // passes
     ST_SYNC();     
-    // the unit's share of the stage's costs (blocks of one band: the only share)
-    if( tid < 9 && ( ( j.mask >> tid ) & 1 ) )
+    // the stage's nine costs (0 for positions outside the mask).  A 64x64 block is two bands = the two waves of this workgroup (the schedule puts them side by side): the
+    // second wave hands its sums over through LDS, the first stores the totals — no atomics on the cost array, no clearing of it before the launch
+    if( h <= 32 ) { if( tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] : 0u; }
+    else
     {
-      if( h <= 32 ) a.stageCost[( size_t ) 9 * stage + tid] = costL[tid];
-      else atomicAdd( reinterpret_cast<unsigned long long*>( a.stageCost ) + ( size_t ) 9 * stage + tid, ( unsigned long long ) costL[tid] );
+      if( wv == 1 && tid < 9 ) pairCost[tid] = costL[tid];
+      __syncthreads();
+      if( wv == 0 && tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] + pairCost[tid] : 0u;
     }
   }
 }
@@ -675,13 +678,16 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
 
 // three kernels (their register budgets differ widely); a plan's run launches the ones it needs back to back
 // (one instance per tap support: the 4-tap search filter of the fast presets must not pay the registers of the 8-tap window)
+// two waves per workgroup, one bundle each: independent (wave-level synchronisation, own LDS slice) except for the two bands of a 64x64 block, which the schedule gives to
+// the two waves of one workgroup (they add their sums through LDS)
 template<int K0, int K1>
-__global__ void __launch_bounds__( 256 )
+__global__ void __launch_bounds__( 128 )
 meStageKernel( MePlanes P, MeArgs a, int firstWave, int nWaves, int ldsPerWave )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t meLds[];
-  const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) ), wave = blockIdx.x * ( int ) ( blockDim.x >> 6 ) + wv;
-  if( wave < nWaves ) stageBody<K0, K1>( P, a, a.stageWaves[firstWave + wave], meLds + wv * ( ldsPerWave >> 1 ) );
+  __shared__ uint32_t pairCost[16];
+  const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) ), wave = blockIdx.x * 2 + wv;
+  if( wave < nWaves ) stageBody<K0, K1>( P, a, a.stageWaves[firstWave + wave], meLds + wv * ( ldsPerWave >> 1 ), pairCost, wv );
 }
 
 // workgroups 0 .. nBig - 1: one large window each (four waves share it); the others: four small windows each, one per wave
@@ -791,7 +797,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     while( i + count < stOrder.size() && count < 8 )
     {
       const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count] & 0xffffff];
-      if( s.width != s0.width || setOf( s ) != setOf( s0 ) || ( count && work + unitWork( s ) > bundleWork ) ) break;
+      if( s.width != s0.width || setOf( s ) != setOf( s0 ) || ( count && ( work + unitWork( s ) > bundleWork || s.height > 32 ) ) ) break;      // (a band of a 64x64 block: a wave of its own, next to its sibling)
       work += unitWork( s ); count++;
     }
     WaveSpan sp; sp.first = ( int32_t ) i; sp.count = count; stWaves.push_back( sp );
@@ -943,11 +949,9 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   const bool tm = plan->timing && parts == 7;
   const bool doStage = ( parts & 1 ) != 0, doInt = ( parts & 2 ) != 0, doItem = ( parts & 4 ) != 0;
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[0], ctx->stream ) );
-  // blocks taller than 16 rows are scored band by band (integer atomic adds into the cost array): it starts from zero
-  if( plan->nStages && doStage ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_stage_cost, 0, ( size_t ) 9 * plan->nStages * sizeof( uint64_t ), ctx->stream ) );
   int firstWave = 0;
   static const int ldsPadExp = getenv( "VVHIP_ME_LDS_PAD" ) ? atoi( getenv( "VVHIP_ME_LDS_PAD" ) ) : 0;      // experiment: occupancy sensitivity of the stage kernel
-  static const int stW = getenv( "VVHIP_ME_STAGE_WAVES" ) ? atoi( getenv( "VVHIP_ME_STAGE_WAVES" ) ) : 1;      // independent waves per workgroup: 1 / 2 / 4 measured alike (51.2 / 51.9 / 51.5 us)
+  constexpr int stW = 2;                                                                // waves per workgroup (see meStageKernel)
   const size_t ldsSt = ( ( size_t ) plan->ldsStage + ldsPadExp + 15 ) & ~( size_t ) 15;
   // (one launch per tap support: bundles of 32- / 64-wide blocks first; splitting them from the small blocks' bundles or giving them four-wave workgroups was measured slower)
   if( plan->stageSetWaves[0] && doStage ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) ( ( plan->stageSetWaves[0] + stW - 1 ) / stW ) ), dim3( 64 * stW ), ( size_t ) stW * ldsSt, ctx->stream, P, a, firstWave, plan->stageSetWaves[0], ( int ) ldsSt );
