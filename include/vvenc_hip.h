@@ -365,7 +365,7 @@ VVHIP_API int  vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, con
 VVHIP_API int  vvhip_me_plan_run_parts( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes,
                                         uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost, int parts );
 /* per-kernel HIP events inside vvhip_me_plan_run (measurements: bench.py's roofline): with timing on, vvhip_me_plan_last_times waits for the last run and returns the
- * milliseconds of its parts — [0] refinement-stage kernel (incl. the clearing of its cost array), [1] integer windows (both LDS classes: one launch), [2] 0 (was: the small
+ * milliseconds of its parts — [0] refinement-stage kernel(s), [1] integer windows (both LDS classes: one launch), [2] 0 (was: the small
  * windows' own launch), [3] table calls. */
 VVHIP_API int  vvhip_me_plan_set_timing( vvhip_ctx* ctx, vvhip_me_plan* plan, int on );
 VVHIP_API int  vvhip_me_plan_last_times( vvhip_ctx* ctx, const vvhip_me_plan* plan, float* ms4_host );
