@@ -808,6 +808,18 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     i += count;
   }
 
+  // the kernel relies on it: the two bands of a 64x64 stage are the waves 2g, 2g + 1 of their tap support's launch
+  for( int k = 0, first = 0; k < 3; first += setWaves[k], k++ )
+    for( int w = 0; w < setWaves[k]; w++ )
+    {
+      const WaveSpan& sp = stWaves[first + w];
+      const int u = stOrder[sp.first];
+      if( stage_jobs[u & 0xffffff].height <= 32 ) continue;
+      const int sib = ( w & 1 ) ? w - 1 : w + 1;
+      if( sp.count != 1 || sib >= setWaves[k] || stWaves[first + sib].count != 1 || ( stOrder[stWaves[first + sib].first] & 0xffffff ) != ( u & 0xffffff ) )
+        return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: schedule error (bands of stage %d are not one workgroup)", u & 0xffffff );
+    }
+
   // ---- item bundles: same function and geometry, a few team passes per wave
   std::vector<int32_t> itOrder( n_items ); std::vector<WaveSpan> itWaves;
   for( int i = 0; i < n_items; i++ )
