@@ -284,10 +284,10 @@ def parity_check(workloads):
 
 
 # ---------------------------------------------------------------------------------------------------------------------- profiling passes
-def run_inner_profile(args, prof, steps, tag):
+def run_inner_profile(args, prof, steps, tag, mode="--inner"):
     outdir = os.path.join("/tmp", "vvhip_prof_%d_%s" % (os.getpid(), tag))
     shutil.rmtree(outdir, ignore_errors=True)
-    cmd = ["rocprofv3"] + prof + ["-d", outdir, "--", sys.executable, os.path.abspath(__file__), "--inner", "--steps", str(steps), "--warmup", "0",
+    cmd = ["rocprofv3"] + prof + ["-d", outdir, "--", sys.executable, os.path.abspath(__file__), mode, "--steps", str(steps), "--warmup", "0",
                                   "--width", str(args.width), "--height", str(args.height)]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     if r.returncode != 0:
@@ -339,6 +339,36 @@ def live_profile(args):
         except Exception as ex:
             out.setdefault("pmc_errors", []).append("%s: %s" % (counter, str(ex)[:160]))
     out["per_class"] = cls
+    for d in dirs:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def mctf_profile(args):
+    """the MCTF motion estimation under rocprofv3 (7 calls of one 1080p picture against 4 references): per picture the time of the parallel candidate scoring, of the sequential
+    sweep (= the critical path of phase B: one workgroup per reference) and the VALU issue fraction of the scoring kernel"""
+    import profile_round as P
+    out, dirs = {}, []
+    db, d = run_inner_profile(args, ["--kernel-trace", "--stats"], 1, "mctf_trace", "--inner-mctf")
+    dirs.append(d)
+    calls = 7.0
+    t = {}
+    for k, n, sm, av, mn, mx in P.kernel_table(db):
+        name = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        if name.startswith("me") or name.startswith("subsample") or name.startswith("extend") or name.startswith("initMvs"):
+            t[name] = t.get(name, 0.0) + sm
+    out["us_per_picture_by_kernel"] = {k: round(v / 1e3 / calls, 1) for k, v in sorted(t.items(), key=lambda kv: -kv[1])}
+    out["phase_a_us"] = round(t.get("meSearchKernel", 0.0) / 1e3 / calls, 1)
+    out["critical_path_us"] = round((t.get("meDiagKernel", 0.0) + t.get("meWavefrontKernel", 0.0)) / 1e3 / calls, 1)
+    out["critical_path_note"] = "the anti-diagonal sweep of phase B (MCTF.cpp:1289-1306): one workgroup per reference, cols + rows dependent steps per level; everything else of the call is parallel over blocks"
+    try:
+        db, d = run_inner_profile(args, ["--pmc", "SQ_INSTS_VALU"], 1, "mctf_valu", "--inner-mctf")
+        dirs.append(d)
+        for k, c, n, sm, av in P.counter_table(db):
+            if "meSearchKernel" in k and t.get("meSearchKernel"):
+                out["phase_a_valu_issue_frac"] = round(sm * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9 * t["meSearchKernel"] * 1e-9), 3)
+    except Exception as ex:
+        out["pmc_error"] = str(ex)[:160]
     for d in dirs:
         shutil.rmtree(d, ignore_errors=True)
     return out
@@ -399,6 +429,7 @@ def main():
     ap.add_argument("--profile-md", default=None, help="also write the rocprofv3 summary of this run (kernel table + counters per kernel class) as markdown to this path")
     ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 passes of the inner run (kernel trace + one pass per counter)")
     ap.add_argument("--e2e-threads", type=int, default=8)
+    ap.add_argument("--inner-mctf", action="store_true", help="(internal) the short run rocprofv3 wraps for the MCTF stage: six motion estimations of one 1080p picture against 4 references")
     ap.add_argument("--inner", action="store_true", help="(internal) the short run rocprofv3 wraps: the recorded pictures' launches serialized on one stream, no extras, no output line")
     args = ap.parse_args()
 
@@ -411,6 +442,15 @@ def main():
     from vvenc_amd.hotpath import HotPath, Plane
     from vvenc_amd.replay import RecordedWorkload
     hp = HotPath("cuda:%d" % local_rank)
+    if args.inner_mctf:
+        wl = Mctf1080(args.width, args.height)
+        cur = hp.plane(wl.cur_np, 128)
+        refs = [hp.plane(np.roll(wl.ref_np, (k, -2 * k), (0, 1)), 128) for k in range(4)]
+        outs, _ = hp.mctf_motion_estimation(cur, refs, wl.bit_depth, 16, 4, args.width >= 1920)
+        for _ in range(6):
+            hp.mctf_motion_estimation(cur, refs, wl.bit_depth, 16, 4, args.width >= 1920, out=outs)
+        torch.cuda.synchronize()
+        return
 
     # ---- the recorded lists (rank 0 records when the cache is cold, the others wait)
     rec_info = {}
@@ -689,6 +729,11 @@ def main():
             import bench_synthetic as BS
             m, _ = BS.mctf_stage(hp, Mctf1080(args.width, args.height), 4)
             out["mctf"] = {k: v for k, v in m.items() if k != "me_frac_hbm_unique"}
+            if not args.no_profile and shutil.which("rocprofv3"):
+                try:
+                    out["mctf"]["profile"] = mctf_profile(args)
+                except Exception as e:
+                    out["mctf"]["profile"] = {"error": str(e)[:200]}
             if not args.no_4k:
                 m4, _ = BS.mctf_stage(hp, Mctf1080(3840, 2160), 4, reps=3)
                 out["mctf_4k"] = {k: v for k, v in m4.items() if k != "me_frac_hbm_unique"}
