@@ -21,7 +21,7 @@ pytestmark = pytest.mark.sim
 
 def need():
     if not (os.path.exists(e2e_util.REF_HIP_SO) and os.path.exists(SIM)):
-        pytest.skip("needs oracle/_ref/libvvenc_ref_hip.so and tests/sim/libvvhip_sim.so (python __graft_entry__.py)")
+        pytest.skip("needs bindings/vvenc/_build/libvvenc_hip_enc.so and tests/sim/libvvhip_sim.so (python __graft_entry__.py)")
     if os.path.exists("/dev/kfd"):
         pytest.skip("a GPU is present: the test double refuses to stand in for it")
 
@@ -111,7 +111,7 @@ def test_merge_pruning_batched_site():
 def test_simd_switch_refuses_without_device():
     """no device library double, no GPU: --SIMD=HIP must fail loudly (the encoder reports the request as unsupported), never fall back silently"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
-        pytest.skip("oracle/_ref/libvvenc_ref_hip.so not built")
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so not built")
     if os.path.exists("/dev/kfd"):
         pytest.skip("GPU present")
     r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import e2e_util as E; L = E.load(True); "
