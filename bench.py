@@ -105,40 +105,40 @@ class ReferenceJobs:
         host_planes = [pl.storage for pl in wl.planes]
         pool = wl.pool
 
-        def base(idx):
+        def base(idx, w):
+            """(address of sample (0,0), row pitch) of plane-table entry idx for blocks of width w (the pool holds compact blocks: pitch = width)"""
             if idx < wl.n_pic_planes:
                 pl = wl.planes[idx]
                 return host_planes[idx].ctypes.data + 2 * pl.origin, pl.stride
-            w = [k for k, v in wl.pool_plane.items() if v == idx][0]
-            return pool.ctypes.data, w
+            return pool.ctypes.data, int(w)
         df_of = {0: 0, 1: 8, 2: 16, 3: 26, 4: 24}          # C ABI function code -> DFunc base of the reference's table (TypeDef.h:339-382)
         # integer candidates + plain table calls as distortion lists grouped by (function, size, subShift, operand planes)
         ij, pc = wl.int_jobs, wl.plan_cands
         recs = []
         if pc.size:
             jidx = np.repeat(np.arange(ij.size), ij["n_cand"])
-            ref_stride = np.array([base(int(p))[1] for p in ij["ref_plane"]], np.int64)
+            ref_stride = np.array([base(int(p), 0)[1] for p in ij["ref_plane"]], np.int64)
             cur_off = ij["ref_off"][jidx].astype(np.int64) + pc["dy"].astype(np.int64) * ref_stride[jidx] + pc["dx"]
-            recs.append(np.stack([np.full(pc.size, 1), ij["width"][jidx], ij["sub_shift"][jidx], ij["org_plane"][jidx], ij["ref_plane"][jidx], ij["org_off"][jidx], cur_off], 1).astype(np.int64))
+            recs.append(np.stack([np.full(pc.size, 1), ij["width"][jidx], ij["height"][jidx], ij["sub_shift"][jidx], ij["org_plane"][jidx], ij["ref_plane"][jidx], ij["org_off"][jidx], cur_off], 1).astype(np.int64))
         it = wl.items
         if it.size:
-            recs.append(np.stack([it["func"], it["width"], it["sub_shift"], it["org_plane"], it["cur_plane"], it["org_off"], it["cur_off"]], 1).astype(np.int64))
+            recs.append(np.stack([it["func"], it["width"], it["height"], it["sub_shift"], it["org_plane"], it["cur_plane"], it["org_off"], it["cur_off"]], 1).astype(np.int64))
         self.dist_groups = []
         if recs:
             allr = np.concatenate(recs)
-            key = allr[:, :5]
+            key = allr[:, :6]
             uniq, inv = np.unique(key, axis=0, return_inverse=True)
             inv = inv.ravel()
-            for g, (func, w, ss, po, pcu) in enumerate(uniq):
+            for g, (func, w, h, ss, po, pcu) in enumerate(uniq):
                 sel = np.nonzero(inv == g)[0]
-                items = np.ascontiguousarray(allr[sel][:, 5:7].astype(np.int32))
+                items = np.ascontiguousarray(allr[sel][:, 6:8].astype(np.int32))
                 out = np.zeros(sel.size, np.uint64) if with_outputs else None
-                (ob, os_), (cb, cs) = base(int(po)), base(int(pcu))
+                (ob, os_), (cb, cs) = base(int(po), w), base(int(pcu), w)
                 if int(func) == 4:
                     # HAD_2SAD's SAD part assumes compact, 32-byte aligned operands (CHECKD + _mm256_load_si256, x86/RdCostX86.h:2556-2600; the encoder calls it on IntraSearch's
                     # compact buffers): gather both operands of the list into aligned compact buffers for the reference entry
-                    w_ = int(w)
-                    yy, xx = np.mgrid[0:w_, 0:w_]
+                    w_, h_ = int(w), int(h)
+                    yy, xx = np.mgrid[0:h_, 0:w_]
 
                     def gather(pidx, offs):
                         if pidx < wl.n_pic_planes:
@@ -147,17 +147,32 @@ class ReferenceJobs:
                         else:
                             flat, o0, st = pool, 0, w_
                         idx = (o0 + offs.astype(np.int64))[:, None, None] + yy[None] * st + xx[None]
-                        buf = np.zeros(sel.size * w_ * w_ + 32, np.int16)
+                        buf = np.zeros(sel.size * w_ * h_ + 32, np.int16)
                         shift = (-buf.ctypes.data // 2) % 16                     # first sample at a 32-byte boundary
-                        buf[shift:shift + sel.size * w_ * w_] = flat[idx].reshape(-1)
+                        buf[shift:shift + sel.size * w_ * h_] = flat[idx].reshape(-1)
                         self.keep.append(buf)
                         return buf.ctypes.data + 2 * shift
                     ob, cb = gather(int(po), items[:, 0]), gather(int(pcu), items[:, 1])
                     os_ = cs = w_
-                    items = np.ascontiguousarray(np.stack([np.arange(sel.size) * w_ * w_] * 2, 1).astype(np.int32))
+                    items = np.ascontiguousarray(np.stack([np.arange(sel.size) * w_ * h_] * 2, 1).astype(np.int32))
                 self.keep += [items, out]
                 self.dist_groups.append((sel, out))
-                jobs.append(RecJob(0, df_of[int(func)], int(w), int(w), int(ss), 0, 0, sel.size, ob, cb, os_, cs, items.ctypes.data, None, out.ctypes.data if out is not None else None, None))
+                jobs.append(RecJob(0, df_of[int(func)], int(w), int(h), int(ss), 0, 0, sel.size, ob, cb, os_, cs, items.ctypes.data, None, out.ctypes.data if out is not None else None, None))
+        # masked SADs (GEO): grouped by (size, subShift, operand planes); the weight blocks are compact pool blocks
+        mi = getattr(wl, "mask_items", np.zeros(0))
+        self.mask_groups = []
+        if mi.size:
+            key = np.stack([mi["width"], mi["height"], mi["sub_shift"], mi["org_plane"], mi["cur_plane"]], 1).astype(np.int64)
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            inv = inv.ravel()
+            for g, (w, h, ss, po, pcu) in enumerate(uniq):
+                sel = np.nonzero(inv == g)[0]
+                items = np.ascontiguousarray(np.stack([mi["org_off"][sel], mi["cur_off"][sel], mi["mask_off"][sel]], 1).astype(np.int32))
+                out = np.zeros(sel.size, np.uint64) if with_outputs else None
+                (ob, os_), (cb, cs) = base(int(po), w), base(int(pcu), w)
+                self.keep += [items, out]
+                self.mask_groups.append((sel, out))
+                jobs.append(RecJob(3, 25, int(w), int(h), int(ss), 0, 0, sel.size, ob, cb, os_, cs, items.ctypes.data, pool.ctypes.data, out.ctypes.data if out is not None else None, None))
         self.n_cands = int(pc.size)
         # TU lists
         self.tu_outs = []
@@ -174,20 +189,20 @@ class ReferenceJobs:
         sj = wl.stage_jobs
         self.stage_groups = []
         if sj.size:
-            key = np.stack([sj["width"], sj["org_plane"], sj["ref_plane"]], 1).astype(np.int64)
+            key = np.stack([sj["width"], sj["height"], sj["org_plane"], sj["ref_plane"]], 1).astype(np.int64)
             uniq, inv = np.unique(key, axis=0, return_inverse=True)
             inv = inv.ravel()
-            for g, (w, po, pr) in enumerate(uniq):
+            for g, (w, h, po, pr) in enumerate(uniq):
                 sel = np.nonzero(inv == g)[0]
                 st = np.zeros(sel.size, REC_STAGE)
                 for f in ("org_off", "ref_off", "base_qx", "base_qy", "i_frac", "filter_mode", "alt_hpel", "mask"):
                     st[f] = sj[f][sel]
                 st["had_mode"] = np.array([0, 0, 1, 2, 0], np.uint8)[sj["func"][sel]]          # SSE(unused) / SAD -> 0, HAD -> 1, HAD_fast -> 2
                 out = np.zeros((sel.size, 9), np.uint64) if with_outputs else None
-                (ob, os_), (cb, cs) = base(int(po)), base(int(pr))
+                (ob, os_), (cb, cs) = base(int(po), w), base(int(pr), w)
                 self.keep += [st, out]
                 self.stage_groups.append((sel, out))
-                jobs.append(RecJob(2, 0, int(w), int(w), 0, 0, 0, sel.size, ob, cb, os_, cs, st.ctypes.data, None, out.ctypes.data if out is not None else None, None))
+                jobs.append(RecJob(2, 0, int(w), int(h), 0, 0, 0, sel.size, ob, cb, os_, cs, st.ctypes.data, None, out.ctypes.data if out is not None else None, None))
         self.arr = (RecJob * max(1, len(jobs)))(*jobs)
         self.n = len(jobs)
 

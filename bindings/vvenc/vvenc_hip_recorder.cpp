@@ -54,6 +54,7 @@ struct ThreadLog
 {
   std::vector<MeRec> me; std::vector<CandRec> cand; std::vector<StageRec> stage; std::vector<DistRec> dist; std::vector<TuRec> tu; std::vector<DmvrRec> dmvr;
   std::vector<int16_t> pool;
+  std::map<std::array<intptr_t, 7>, int32_t> masks;      // GEO weight blocks already in the pool: (pointer, stepX, maskStride, maskStride2, w, h, subShift) -> offset
   uint64_t pairs[3] = { 0, 0, 0 };      // sample pairs through the table: luma, chroma, inside sub-pel stages (subset of luma)
   uint64_t calls = 0;
 };
@@ -186,6 +187,27 @@ template<int IDX> vvenc::Distortion recTramp( const vvenc::DistParam& dp )
   r.org = classify( dp.org.buf, ( int ) dp.org.stride, w, h );
   r.cur = classify( dp.cur.buf, ( int ) dp.cur.stride, w, h );
   r.cost = d;
+  r.maskPool = -1;
+  if( IDX == vvenc::DF_SAD_WITH_MASK && dp.mask && !g_light )
+  {
+    // the weights as the call walks them (xGetSADwMask, RdCost.cpp:2062-2093): per evaluated row w values stepX apart, then maskStride << subShift and maskStride2 further
+    const std::array<intptr_t, 7> key = { ( intptr_t ) dp.mask, dp.stepX, dp.maskStride, dp.maskStride2, w, h, dp.subShift };
+    auto f = t.log->masks.find( key );
+    if( f == t.log->masks.end() )
+    {
+      std::vector<int16_t>& pool = t.log->pool;
+      while( pool.size() & 7 ) pool.push_back( 0 );
+      const int32_t off = ( int32_t ) pool.size();
+      const int16_t* m = dp.mask;
+      for( int y = 0; y < ( h >> dp.subShift ); y++ )
+      {
+        for( int x = 0; x < w; x++ ) { pool.push_back( *m ); m += dp.stepX; }
+        m += ( ptrdiff_t ) dp.maskStride * ( 1 << dp.subShift ) + dp.maskStride2;
+      }
+      f = t.log->masks.emplace( key, off ).first;
+    }
+    r.maskPool = f->second;
+  }
   t.log->dist.push_back( r );
   return d;
 }
@@ -367,7 +389,7 @@ void flush()
       for( MeRec m : l.me ) { m.firstCand += cand0; m.firstStage += stage0; if( m.patternPool >= 0 ) m.patternPool += pool0; all.me.push_back( m ); }
       for( CandRec c : l.cand ) { c.me += me0; all.cand.push_back( c ); }
       for( StageRec s : l.stage ) { s.me += me0; all.stage.push_back( s ); }
-      for( DistRec d : l.dist ) { if( d.org.plane < 0 && d.org.x >= 0 ) d.org.x += pool0; if( d.cur.plane < 0 && d.cur.x >= 0 ) d.cur.x += pool0; all.dist.push_back( d ); }
+      for( DistRec d : l.dist ) { if( d.org.plane < 0 && d.org.x >= 0 ) d.org.x += pool0; if( d.cur.plane < 0 && d.cur.x >= 0 ) d.cur.x += pool0; if( d.maskPool >= 0 ) d.maskPool += pool0; all.dist.push_back( d ); }
       for( TuRec u : l.tu ) { u.pool += pool0; all.tu.push_back( u ); }
       all.dmvr.insert( all.dmvr.end(), l.dmvr.begin(), l.dmvr.end() );
       all.pool.insert( all.pool.end(), l.pool.begin(), l.pool.end() );

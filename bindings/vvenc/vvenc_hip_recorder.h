@@ -20,7 +20,7 @@ struct Operand { int16_t plane; int16_t pad; int32_t x, y; };            // plan
 struct MeRec    { int32_t cuX, cuY; int16_t w, h; int16_t refPlane; uint8_t bi, list; int32_t patternPool; int32_t firstCand, nCand, firstStage, nStage; };   // patternPool < 0: the original block at (cuX, cuY)
 struct CandRec  { int32_t me; int32_t x, y; uint8_t df, subShift, pad0 /* 1: the encoder's own call returned an early-exit partial sum, cost holds the full one */, pad1; uint64_t cost; };   // block position in the reference plane
 struct StageRec { int32_t me; int32_t baseX, baseY; int16_t baseHor, baseVer; uint8_t iFrac, hadMode, reduceTap, altHpel; int32_t pad; uint64_t cost[9]; };   // cost ~0ull: position skipped by the encoder
-struct DistRec  { uint8_t df, subShift, bitDepth, ctx; int16_t w, h; Operand org, cur; uint64_t cost; };                                                      // calls outside xMotionEstimation
+struct DistRec  { uint8_t df, subShift, bitDepth, ctx; int16_t w, h; Operand org, cur; uint64_t cost; int32_t maskPool; };      // calls outside xMotionEstimation; maskPool >= 0 (DF_SAD_WITH_MASK): the weights the call walked, as a compact w x ( h >> subShift ) pool block
 struct TuRec    { uint8_t comp, trHor, trVer, flags; int16_t w, h; int16_t qp, bitDepth; int32_t x, y; int32_t pool; };                                        // flags: 1 IRAP, 2 luma, 4 intra CU
 struct DmvrRec  { int16_t ref0Plane, ref1Plane; int32_t x0, y0, x1, y1; int16_t frac0x, frac0y, frac1x, frac1y; int16_t dx, dy; int16_t mvdX, mvdY; int32_t pad; uint64_t minCost; };
 struct PlaneRec { int32_t kind /* 0 original (as the CTU copies read it), 1 reconstruction of a reference picture */, poc, comp, width, height, stride, margin; int64_t fileOffset; };

@@ -329,35 +329,52 @@ VVHIP_API int vvhip_subpel_refine_batch( vvhip_ctx* ctx, int func, const int16_t
  * Motion-search plans (round 3): what ONE picture's inter search pushes through the distortion tables, in ONE launch.
  * Built for work lists with the shape the encoder really produces (recorded from it, vvenc_amd/recorded.py): per InterSearch::xMotionEstimation call
  * (EncoderLib/InterSearch.cpp:1976-2130) ~20 integer candidates inside a few samples of each other (start points, 4-point diamond + square at distance 1,
- * :2385-2410) followed by one or two xPatternRefinement stages (:760-880) of <= 9 sub-pel positions around the winner; blocks 4..64 square, most sample pairs in
- * 64x64 blocks; plus merge / AMVP / intra / residual distortions on compact prediction blocks.
+ * :2385-2410) followed by one or two xPatternRefinement stages (:760-880) of <= 9 sub-pel positions around the winner; blocks 4..64 square at the fast presets (most sample pairs in
+ * 64x64 blocks), rectangular 4..128 at preset medium; plus merge / AMVP / intra / residual distortions on compact prediction blocks.
  *   integer job  : the block's candidate positions as displacements from ref_off; the kernel stages the candidates' bounding window of the reference plane in
- *                  LDS once (two copies, one sample apart: every dword of every displacement is aligned) and scores all candidates from it.
+ *                  LDS once (samples biased for v_sad_u16; odd displacements are taken from the even dword below with v_alignbit) and scores all candidates from it.
  *                  cost[first_cand + i] = xGetSAD*( org block, ref block at (dx_i, dy_i) ) incl. the subShift rule (RdCost.cpp:301-644).
  *   stage job    : position k (k = 0..8, evaluated when bit k of mask is set) lies ( refine[k] + (base_qx, base_qy) ) * i_frac quarter samples from the block at
  *                  ref_off, refine = s_acMvRefineH (i_frac 2) / s_acMvRefineQ (i_frac 1) (InterSearch.cpp:67-91).  The kernel interpolates like
  *                  xPatternRefinement's planes (filter_mode / alt_hpel as vvhip_interp_luma_batch; horizontal pass shared between positions) and scores each
  *                  prediction against the original block directly from LDS — the predictions never exist in HBM.  cost[9 * stage + k] as the table entry
- *                  `func` (VVHIP_DF_SAD / _HAD / _HAD_FAST) returns it; positions outside the mask read 0.
+ *                  `func` (VVHIP_DF_SAD / _HAD / _HAD_FAST) returns it; positions outside the mask read 0 (every stage's nine costs are written by every run).
+ *                  Every evaluated position must lie within one sample of the block at ref_off vertically and horizontally ((refine + base) * i_frac in -4..4
+ *                  quarter samples): the kernel stages exactly that neighbourhood; plan creation rejects anything else.
  *   item         : one plain table call: func on (org block, cur block) of any two planes / pools of the plan's plane table.
+ *   masked item  : DF_SAD_WITH_MASK (xGetSADwMask, RdCost.cpp:2062-2093: GEO partitions of preset medium and slower): sum |org - cur| * mask over the rows the
+ *                  subShift rule keeps, << subShift.  The mask block is COMPACT (row pitch = width, one row per evaluated row: the caller has applied the
+ *                  reference's stepX / maskStride / maskStride2 walk).  Its costs follow the plain items': d_item_cost[n_items + i].
  * Offsets are in samples from sample (0,0) of the job's plane (negative = margin); planes must be readable 16 bytes beyond every block / window row they hold.
- * Square blocks, width 4 (items only), 8, 16, 32 or 64; bit depths <= 10 (the packed Hadamard tile, like the reference's x86 rows).
- * A plan owns device copies of the job tables and the schedule derived from them (which wave takes which jobs, heaviest first); running it is one launch.
+ * A plane table entry with stride 0 is a pool of COMPACT blocks: the row pitch of a block read from it is the block's own width.
+ * Shapes (round 4: everything preset medium's CTU 128 + multi-type tree produces): width and height independent powers of two — integer jobs 8..128 x 4..128,
+ * stage jobs 4..128 x 4..128 (not 4x4), items 2..128 x 2..128; the Hadamard family follows the reference's tile ladder (16x8, 8x16, 8x4, 4x8 with the
+ * double-precision normalisation, 16x16_fast, 8x8, 4x4, 2x2: RdCost.cpp:1818-1938); bit depths <= 10 (the packed Hadamard tile, like the reference's x86 rows).
+ * A plan owns device copies of the job tables and the schedule derived from them (which wave takes which jobs, heaviest first); running it is one launch per kind.
  * ====================================================================================================================== */
 typedef struct { const int16_t* d_base; int32_t stride; int32_t reserved; } vvhip_me_plane;
 typedef struct { int32_t org_off, ref_off; int16_t width, height; uint8_t org_plane, ref_plane, sub_shift, reserved; int16_t min_dx, min_dy, win_w, win_h; int32_t first_cand, n_cand; } vvhip_me_int_job;
 typedef struct { int16_t dx, dy; } vvhip_me_cand;
 typedef struct { int32_t org_off, ref_off; int16_t width, height; uint8_t org_plane, ref_plane, i_frac, filter_mode, alt_hpel, func; int8_t base_qx, base_qy; uint16_t mask; uint16_t reserved; } vvhip_me_stage_job;
 typedef struct { int32_t org_off, cur_off; uint8_t org_plane, cur_plane, func, sub_shift; int16_t width, height; } vvhip_me_item;
+typedef struct { int32_t org_off, cur_off, mask_off; uint8_t org_plane, cur_plane, mask_plane, sub_shift; int16_t width, height; int32_t reserved; } vvhip_me_mask_item;
+typedef struct
+{
+  const vvhip_me_int_job* int_jobs; int32_t n_int_jobs; const vvhip_me_cand* cands; int32_t n_cands;
+  const vvhip_me_stage_job* stage_jobs; int32_t n_stage_jobs; const vvhip_me_item* items; int32_t n_items;
+  const vvhip_me_mask_item* mask_items; int32_t n_mask_items;
+} vvhip_me_lists;
 typedef struct vvhip_me_plan vvhip_me_plan;
 /* all job arrays are HOST arrays (copied); any of the three lists may be empty.  win_* / min_* of an integer job may be left 0: the library derives the window from the candidates
  * and splits jobs whose candidates spread further than max_window samples (0: default 24) into several windows. */
 VVHIP_API int  vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int n_int_jobs, const vvhip_me_cand* cands, int n_cands,
                                      const vvhip_me_stage_job* stage_jobs, int n_stage_jobs, const vvhip_me_item* items, int n_items,
                                      int bit_depth, int max_window, vvhip_me_plan** out );
+/* the same with every list in one record (adds the masked items) */
+VVHIP_API int  vvhip_me_plan_create_lists( vvhip_ctx* ctx, const vvhip_me_lists* lists, int bit_depth, int max_window, vvhip_me_plan** out );
 VVHIP_API void vvhip_me_plan_destroy( vvhip_ctx* ctx, vvhip_me_plan* plan );
 /* planes_host: the plan's plane table for THIS run (<= 16 entries; device pointers to sample (0,0)).  d_cand_cost: n_cands, d_stage_cost: 9 * n_stage_jobs,
- * d_item_cost: n_items Distortion values; pointers of empty lists may be NULL.                                                                              */
+ * d_item_cost: n_items + n_mask_items Distortion values; pointers of empty lists may be NULL.                                                               */
 VVHIP_API int  vvhip_me_plan_run( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes,
                                   uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost );
 /* the same, restricted to some of the plan's three independent parts (bit 0: refinement stages, bit 1: integer windows, bit 2: table calls): a caller with several

@@ -961,7 +961,8 @@ API double vvref_dmvr_batch_mt( const int16_t* ref0, int stride0, const int16_t*
 // Recorded work lists (vvenc_amd/recorded.py) on the reference's own entries: CPU baseline and in-run parity of bench.py's replay.  Every job carries its operand bases
 // and pitches (picture planes or compact pool blocks).  kind 0: distortion list (df = DFunc base; items {org_off, cur_off}); kind 1: the fused TU pipeline's twin
 // (items = residual offsets, aux = {qp, flags} pairs; out = SSE, out2 = {abs sum, last scan position, need-RDOQ, level checksum} per TU); kind 2: sub-pel refinement stages as xPatternRefinement computes them — one first
-// pass per distinct horizontal position, second pass + distortion per evaluated position (items = RecStage; out = 9 costs per stage, untouched where not evaluated).
+// pass per distinct horizontal position, second pass + distortion per evaluated position (items = RecStage; out = 9 costs per stage, untouched where not evaluated);
+// kind 3: masked SAD on compact weight blocks (items = {org_off, cur_off, mask_off}, aux = mask base).
 // `threads` std::threads pull chunks from one atomic counter, `passes` times; returns wall seconds.
 // ---------------------------------------------------------------------------------------------
 struct RecStage { int32_t org_off, ref_off; int8_t base_qx, base_qy; uint8_t i_frac, filter_mode, alt_hpel, had_mode; uint16_t mask; };
@@ -1011,9 +1012,9 @@ API double vvref_run_recorded_mt( const RecJob* jobs, int nJobs, int bitDepth, i
   std::vector<Chunk> chunks;
   std::vector<int> order( nJobs );
   for( int j = 0; j < nJobs; j++ ) order[j] = j;
-  auto weight = [&]( int a ) { return ( long ) jobs[a].w * jobs[a].h * ( jobs[a].kind == 0 ? 1 : ( jobs[a].kind == 1 ? 8 : 24 ) ); };
+  auto weight = [&]( int a ) { return ( long ) jobs[a].w * jobs[a].h * ( ( jobs[a].kind == 0 || jobs[a].kind == 3 ) ? 1 : ( jobs[a].kind == 1 ? 8 : 24 ) ); };
   std::stable_sort( order.begin(), order.end(), [&]( int a, int b ) { return weight( a ) > weight( b ); } );
-  for( int j : order ) { const int CH = jobs[j].kind == 0 ? 256 : ( jobs[j].kind == 1 ? 32 : 8 ); for( int b = 0; b < jobs[j].n; b += CH ) chunks.push_back( { j, b, std::min( jobs[j].n, b + CH ) } ); }
+  for( int j : order ) { const int CH = ( jobs[j].kind == 0 || jobs[j].kind == 3 ) ? 256 : ( jobs[j].kind == 1 ? 32 : 8 ); for( int b = 0; b < jobs[j].n; b += CH ) chunks.push_back( { j, b, std::min( jobs[j].n, b + CH ) } ); }
   std::vector<std::atomic<int>> next( passes + 1 );
   for( auto& n : next ) n = 0;
   auto worker = [&]( int pass0, int pass1 )
@@ -1031,6 +1032,18 @@ API double vvref_run_recorded_mt( const RecJob* jobs, int nJobs, int bitDepth, i
         else if( jb.kind == 1 )
           tuRdoBatchTyped( 1, jb.org, jb.orgStride, ( const int32_t* ) jb.items + ck.begin, ck.end - ck.begin, jb.w, jb.h, jb.trHor, jb.trVer, bitDepth, ( const int16_t* ) jb.aux + 2 * ck.begin, 8, nullptr, nullptr,
                            jb.out ? jb.out + ck.begin : scratch, jb.out2 ? jb.out2 + 4 * ( size_t ) ck.begin : nullptr );
+        else if( jb.kind == 3 )
+        {
+          // masked SAD (DF_SAD_WITH_MASK) on compact weight blocks: items = { org_off, cur_off, mask_off }, aux = the base the mask offsets refer to.  One mask row of w weights
+          // per evaluated row: maskStride << subShift = w, maskStride2 = -w (the parameterisation both the scalar and the SIMD row walk identically, see vvref_sad_mask)
+          const int32_t* it = ( const int32_t* ) jb.items;
+          for( int i = ck.begin; i < ck.end; i++ )
+          {
+            const uint64_t v = vvref_sad_mask( 1, jb.org + it[3 * i], jb.orgStride, jb.cur + it[3 * i + 1], jb.curStride, ( const int16_t* ) jb.aux + it[3 * i + 2], jb.w >> jb.subShift, 1, -jb.w,
+                                               jb.w, jb.h, bitDepth, jb.subShift );
+            if( jb.out ) jb.out[i] = v;
+          }
+        }
         else
           recStages( jb, ck.begin, ck.end, bitDepth, jb.out ? jb.out : scratch - ( size_t ) 9 * ck.begin );
       }

@@ -156,7 +156,9 @@ def _replay_and_check(hp, pics, with_tu_twin=True):
         for k, (n, bad) in wl.check_against_recording().items():
             assert bad == 0, (poc, k, n, bad)
             tot[k] = tot.get(k, 0) + n
-        assert wl.items_dropped == 0
+        assert wl.nothing_dropped, (poc, wl.dropped)                     # every recorded call is in a list of the plan / a TU group
+        assert wl.plan_cands.size + wl.items.size + wl.mask_items.size == pic.cand.size + pic.dist.size and wl.stage_jobs.size == pic.stage.size
+        assert sum(g["n"] for g in wl.tu_groups) == pic.tu.size
     if with_tu_twin:
         wls = {i: RecordedWorkload(hp, pic) for i, pic in enumerate(pics.values())}
         r = bench.parity_check(wls)
@@ -174,16 +176,24 @@ def test_recorded_lists_small_clip(hp, tmp_path):
 
 
 def test_recorded_lists_medium_preset(hp, tmp_path):
-    """preset medium (CTU 128, MTT: rectangular blocks, 8-tap search filter, two references per list): what fits the plan's square sizes replays bit-exactly, the rest is
-    counted as dropped and must be a minority"""
-    import torch
-    from vvenc_amd.replay import RecordedWorkload
+    """preset medium (BASELINE configs[3]'s preset: CTU 128, multi-type tree -> rectangular blocks 4..128, GEO's masked SADs, two references per list): NOTHING of the
+    recording is left out, every recorded output replays bit-exactly, the TU lists (rectangular, DST-7, 2-wide chroma) against the reference's own entries"""
     pics = _record(tmp_path, 416, 240, 9, pocs=(4, 8), preset="medium")
-    for poc, pic in pics.items():
-        wl = RecordedWorkload(hp, pic)
-        wl.run()
-        for k, (n, bad) in wl.check_against_recording().items():
-            assert bad == 0, (poc, k, n, bad)
+    assert len(pics) == 2
+    shapes = set()
+    for pic in pics.values():
+        shapes |= set(zip(pic.me["w"].tolist(), pic.me["h"].tolist()))
+    assert any(w != h for w, h in shapes) and any(w == 128 or h == 128 for w, h in shapes), shapes          # the recording does hold what the test is about
+    tot = _replay_and_check(hp, pics)
+    assert tot["integer_candidates"] > 50000 and tot["subpel_positions"] > 5000 and tot["table_calls"] > 30000 and tot["masked_sad_calls"] > 10000 and tot["tus"] > 5000, tot
+
+
+def test_recorded_lists_medium_preset_4k_picture(hp, tmp_path):
+    """one 3840x2160 picture of a preset-medium encode (BASELINE configs[3] geometry: 128x128 blocks in numbers): nothing dropped, bit-exact"""
+    pics = _record(tmp_path, 3840, 2160, 9, pocs=(4,), preset="medium")
+    assert len(pics) == 1 and (pics[4].me["w"] == 128).sum() > 100
+    tot = _replay_and_check(hp, pics)
+    assert tot["integer_candidates"] > 200000 and tot["subpel_positions"] > 20000 and tot["tus"] > 10000, tot
 
 
 def test_recorded_lists_1080p_layers(hp, tmp_path):

@@ -45,7 +45,7 @@ def test_recording_leaves_the_encode_unchanged(recording):
 def test_record_layouts_and_counters(recording):
     from vvenc_amd import recorded as R
     _, pics = recording
-    assert R.DT["me"].itemsize == 36 and R.DT["cand"].itemsize == 24 and R.DT["stage"].itemsize == 96 and R.DT["dist"].itemsize == 40 and R.DT["tu"].itemsize == 24 and R.DT["dmvr"].itemsize == 48
+    assert R.DT["me"].itemsize == 36 and R.DT["cand"].itemsize == 24 and R.DT["stage"].itemsize == 96 and R.DT["dist"].itemsize == 44 and R.DT["tu"].itemsize == 24 and R.DT["dmvr"].itemsize == 48
     inter = [p for p in pics.values() if p.slice_type != 2]
     assert inter and any(p.slice_type == 2 for p in pics.values())
     for p in pics.values():
@@ -67,7 +67,7 @@ def test_reference_entries_reproduce_the_recorded_costs(recording):
     n_dist = n_stage = 0
     for poc, pic in pics.items():
         L = RecordedLists(pic)
-        assert L.items_dropped == 0
+        assert L.items_dropped == 0 and L.nothing_dropped and L.mask_items.size == 0
         # coverage: every recorded candidate is a window candidate or an item, every stage a stage job, every TU in a group
         assert L.plan_cands.size + L.items.size == pic.cand.size + pic.dist.size
         assert L.stage_jobs.size == pic.stage.size and sum(g["n"] for g in L.tu_groups) == pic.tu.size
@@ -83,6 +83,42 @@ def test_reference_entries_reproduce_the_recorded_costs(recording):
         n_dist += exp.size
         n_stage += int(L.stage_evaluated.sum())
     assert n_dist > 50000 and n_stage > 3000, (n_dist, n_stage)
+
+
+def test_medium_preset_lists_are_complete_and_consistent(tmp_path):
+    """preset medium (CTU 128 + multi-type tree, GEO): rectangular blocks up to 128x128 and masked SADs.  The host lists hold EVERY recorded call (nothing dropped), and the
+    reference's own entries driven over them — generic-shape SADs, the rectangular Hadamard tiles, DF_SAD_WITH_MASK on the recorded weight blocks, stages rebuilt from their
+    descriptors — return the costs the encoder computed"""
+    need()
+    import bench
+    from vvenc_amd import recorded as R
+    from vvenc_amd.replay import RecordedLists
+    R.record(str(tmp_path), 416, 240, 9, pocs=(4, 8), threads=4, preset="medium")
+    pics = R.load_dir(str(tmp_path))
+    assert len(pics) == 2
+    shapes, n_mask = set(), 0
+    for poc, pic in pics.items():
+        L = RecordedLists(pic)
+        assert L.nothing_dropped, L.dropped
+        assert L.plan_cands.size + L.items.size + L.mask_items.size == pic.cand.size + pic.dist.size
+        assert L.stage_jobs.size == pic.stage.size and sum(g["n"] for g in L.tu_groups) == pic.tu.size
+        shapes |= set(zip(L.stage_jobs["width"].tolist(), L.stage_jobs["height"].tolist())) | set(zip(L.int_jobs["width"].tolist(), L.int_jobs["height"].tolist()))
+        assert any(g["w"] != g["h"] for g in L.tu_groups)
+        J = bench.ReferenceJobs(L, with_outputs=True)
+        J.run(4, 1)
+        exp = np.concatenate([L.cand_expected, L.item_expected])
+        got = np.zeros(exp.size, np.uint64)
+        for sel, out in J.dist_groups:
+            got[sel] = out
+        assert np.array_equal(got, exp), (poc, int((got != exp).sum()))
+        gm = np.zeros(L.mask_items.size, np.uint64)
+        for sel, out in J.mask_groups:
+            gm[sel] = out
+        assert np.array_equal(gm, L.mask_expected), (poc, int((gm != L.mask_expected).sum()))
+        n_mask += gm.size
+        for sel, out in J.stage_groups:
+            assert np.array_equal(out[L.stage_evaluated[sel]], L.stage_expected[sel][L.stage_evaluated[sel]]), poc
+    assert any(w != h for w, h in shapes) and any(w == 128 for w, h in shapes) and n_mask > 10000, (shapes, n_mask)
 
 
 def test_early_exit_partial_sums_are_flagged_not_recorded(tmp_path):

@@ -28,15 +28,16 @@
 
 struct vvhip_me_plan
 {
-  int bitDepth = 0, nCands = 0, nStages = 0, nItems = 0;
+  int bitDepth = 0, nCands = 0, nStages = 0, nItems = 0, nMaskItems = 0, maxPlane = 0;
   int wavesInt = 0, wavesStage = 0, wavesItem = 0, ldsInt = 0, ldsStage = 0;
   int intBig = 0, ldsIntSmall = 0;          // the first intBig windows need up to ldsInt bytes of LDS, the others at most ldsIntSmall (two launches: small blocks keep their occupancy)
+  bool intSplit = false;                    // the large windows need far more LDS than four small ones: two launches (the small windows keep their occupancy)
   bool timing = false; hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };      // optional per-kernel events of the last run (vvhip_me_plan_set_timing)
   int stageSetBig[3] = { 0, 0, 0 };        // of each tap support's bundles, the leading ones of 32- and 64-wide blocks (their own launch; four-wave workgroups were measured slower: 62 -> 95 us)
   int stageSetWaves[3] = { 0, 0, 0 };      // stage bundles per tap support (4-tap search set, 6 taps / alternative half-pel, 8 taps), in schedule order
   void* d_blob = nullptr;                  // one allocation: every table below
   const void* d_intJobs = nullptr; const void* d_cands = nullptr; const void* d_stageJobs = nullptr; const void* d_stageOrder = nullptr; const void* d_stageWaves = nullptr;
-  const void* d_items = nullptr; const void* d_itemOrder = nullptr; const void* d_itemWaves = nullptr; const void* d_tapTables = nullptr;
+  const void* d_items = nullptr; const void* d_itemOrder = nullptr; const void* d_itemWaves = nullptr; const void* d_tapTables = nullptr; const void* d_maskItems = nullptr;
 };
 
 namespace {
@@ -66,6 +67,7 @@ struct MeArgs
   const vvhip_me_stage_job* stageJobs; const int32_t* stageOrder; const WaveSpan* stageWaves; int wavesStage;
   const int32_t* tapTables;      // [6 = filter_mode * 2 + alt_hpel][192]: 16 phases x 8 taps, then 16 phases x 4 tap pairs of the table's tap support
   const vvhip_me_item* items; const int32_t* itemOrder; const WaveSpan* itemWaves; int wavesItem;
+  const vvhip_me_mask_item* maskItems;      // in schedule order; their waves follow the plain items' (WaveSpan.count < 0), their costs follow the plain items' costs
   uint64_t* candCost; uint64_t* stageCost; uint64_t* itemCost;
   int bitDepth;
 };
@@ -112,12 +114,12 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
   int16_t* orgL = lds + ( ( j.winH * pitch + 7 ) & ~7 );                 // rowsEff x w, compact (16-byte rows)
   PlanCand* candL = reinterpret_cast<PlanCand*>( orgL + rowsEff * w );    // the job's candidates (8 bytes each)
   {
-    // every global request of the job is issued before the first one is waited for: the candidate records, the original block (<= 4 chunks per lane: any square block up to
-    // 64x64), then the window in batches of four chunks per lane — the job is one memory latency + the LDS work, not four latencies in a row
+    // every global request of the job is issued before the first one is waited for: the candidate records, the original block (<= 4 chunks per lane: any block up to
+    // 64x64, 128x128 with row sub-sampling), then the window in batches of four chunks per lane — the job is one memory latency + the LDS work, not four latencies in a row
     PlanCand myCand = { 0, 0, 0 };
     if( tid < j.nCand ) myCand = a.cands[j.firstCand + tid];
     const int16_t* org = P.p[j.orgPlane] + j.orgOff;
-    const int os = P.stride[j.orgPlane], m = rowsEff * lpr;
+    const int os = P.stride[j.orgPlane] ? P.stride[j.orgPlane] : w, m = rowsEff * lpr;      // (stride 0: a pool of compact blocks)
     u32x4 ov[4]; int oat[4];
 #pragma unroll
     for( int q = 0; q < 4; q++ )
@@ -153,9 +155,9 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
 #pragma unroll
     for( int q = 0; q < 4; q++ )
       if( tid + nthr * q < m ) { u32x4 x = ov[q]; x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS; *reinterpret_cast<u32x4*>( orgL + oat[q] ) = x; }
-    for( int i0 = tid + 4 * nthr; i0 < m; i0 += nthr )                 // (blocks beyond four chunks per lane: none of the square sizes; kept for safety)
+    for( int i0 = tid + 4 * nthr; i0 < m; i0 += nthr )                 // (blocks beyond four chunks per lane: 128x128 without row sub-sampling, large blocks of a one-wave job)
     {
-      const int r = i0 / lpr, c = i0 - r * lpr;
+      const int r = i0 >> lprShift, c = i0 & ( lpr - 1 );
       u32x4 x = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 ); x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS;
       *reinterpret_cast<u32x4*>( orgL + r * w + c * 8 ) = x;
     }
@@ -165,7 +167,7 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
   if( ONE_WAVE ) { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
   else __syncthreads();
   const int chunks = rowsEff * lpr;
-  int lpc = 64; while( lpc > chunks ) lpc >>= 1;                     // lanes per candidate: a power of two <= min( 64, chunks )   (chunks is a power of two for square blocks)
+  int lpc = 64; while( lpc > chunks ) lpc >>= 1;                     // lanes per candidate: a power of two <= min( 64, chunks )   (width, height and so chunks are powers of two)
   const int teams = nthr / lpc, lt = tid & ( lpc - 1 ), team = tid / lpc;
   for( int c0 = 0; c0 < j.nCand; c0 += teams )
   {
@@ -298,6 +300,71 @@ __device__ __forceinline__ void avgInts( const uint32_t ( &ra )[4], const uint32
   for( int i = 0; i < 4; i++ ) o[i] = dot2( pkAdd( ra[i], rb[i] ), 0x00010001u, 2 ) >> 2;
 }
 
+// ---- Hadamard tiles --------------------------------------------------------------------------------------------------------------------------
+// The reference's tile ladder (xGetHADs, RdCost.cpp:1818-1938: first match wins).  Every tile type is scored by a TEAM of LT lanes that hold 8 differences each
+// (the tile's 8 x LT = 16, 32, 64 or 128 values): an 8-point Walsh-Hadamard transform in the lane's registers, then log2( LT ) butterfly stages across the lanes with DPP —
+//   8x8   lane r = row r                                   16x16_fast  lane r = rows 2r, 2r + 1, 2x2 averages of 16 columns (RdCost.cpp:1126-1223)
+//   16x8  lane r = row r & 7, columns 8 ( r >> 3 ) ..      8x16        lane r = row r                      (128 values: 16 lanes)
+//   8x4   lane r = row r                                   4x8         lane r = rows 2r, 2r + 1 of 4 columns (the register transform then covers x0, x1, y0)
+//   4x4   lane r = rows 2r, 2r + 1
+// The pairings (in registers: the three index bits a lane holds; across lanes: i <-> 15 - i, i <-> 7 - i, i ^ 2, i ^ 1) are linearly independent over GF(2), so each is a
+// valid Hadamard factorisation: the multiset of |coefficients| is the reference's, and the DC coefficient — the only one treated specially (|DC| >> 2 in every tile type) —
+// ends in register 0 of lane 0.  Normalisation per tile type as the reference: RdCost.cpp:1119-1121 (4x4), :1317-1319 (8x8), :1218-1222 (16x16_fast),
+// :1467 / :1606 (16x8 / 8x16: ( int ) ( sad / sqrt( 16.0 * 8 ) * 2 ) in IEEE double), :1682 / :1763 (8x4 / 4x8: sqrt( 4.0 * 8 )).
+enum { TK_8x8 = 0, TK_16F = 1, TK_16x8 = 2, TK_8x16 = 3, TK_8x4 = 4, TK_4x8 = 5, TK_4x4 = 6, TK_2x2 = 7, TK_ROWS = 8 /* no transform: rows of 8 samples (SAD-scored stages) */ };
+__host__ __device__ __forceinline__ int hadTileKind( int w, int h, bool fast )
+{
+  if( w > h && !( h & 7 ) && !( w & 15 ) ) return TK_16x8;
+  if( w < h && !( w & 7 ) && !( h & 15 ) ) return TK_8x16;
+  if( w > h && !( h & 3 ) && !( w & 7 ) )  return TK_8x4;
+  if( w < h && !( w & 3 ) && !( h & 7 ) )  return TK_4x8;
+  if( fast && w == h && !( w & 31 ) )      return TK_16F;
+  if( !( w & 7 ) && !( h & 7 ) )           return TK_8x8;
+  if( !( w & 3 ) && !( h & 3 ) )           return TK_4x4;
+  return TK_2x2;
+}
+__host__ __device__ __forceinline__ int tileW( int kind ) { return ( kind == TK_16F || kind == TK_16x8 ) ? 16 : ( ( kind == TK_4x8 || kind == TK_4x4 ) ? 4 : ( kind == TK_2x2 ? 2 : 8 ) ); }
+__host__ __device__ __forceinline__ int tileH( int kind ) { return ( kind == TK_16F || kind == TK_8x16 ) ? 16 : ( ( kind == TK_8x4 || kind == TK_4x4 ) ? 4 : ( kind == TK_2x2 ? 2 : 8 ) ); }
+__host__ __device__ __forceinline__ int tileLanes( int kind ) { return ( kind == TK_16x8 || kind == TK_8x16 ) ? 16 : ( ( kind == TK_8x4 || kind == TK_4x8 ) ? 4 : ( kind == TK_4x4 ? 2 : ( kind == TK_2x2 ? 1 : 8 ) ) ); }
+
+__device__ __forceinline__ uint32_t hadNorm( uint32_t s, int kind )
+{
+  if( kind == TK_8x8 ) return ( s + 2 ) >> 2;
+  if( kind == TK_16F ) return ( ( s + 2 ) >> 2 ) << 2;
+  if( kind == TK_4x4 ) return ( s + 1 ) >> 1;
+  if( kind == TK_16x8 || kind == TK_8x16 ) return ( uint32_t ) ( int ) ( ( double ) ( int ) s / __builtin_sqrt( 16.0 * 8 ) * 2 );
+  if( kind == TK_8x4 || kind == TK_4x8 )   return ( uint32_t ) ( int ) ( ( double ) ( int ) s / __builtin_sqrt( 4.0 * 8 ) * 2 );
+  return s;
+}
+
+// the team's transform: d = the lane's 8 differences, r = the lane's index inside its team of LT lanes (teams are aligned groups of consecutive lanes).
+// Returns the tile's normalised SATD in every lane of the team.  |d| < 2^23 / 128 on entry (differences of <= 12-bit values).
+__device__ __forceinline__ uint32_t hadTeam( int ( &d )[8], int r, int LT, int kind, int lane )
+{
+#pragma unroll
+  for( int len = 1; len < 8; len <<= 1 )
+#pragma unroll
+    for( int i = 0; i < 8; i += 2 * len )
+#pragma unroll
+      for( int q = i; q < i + len; q++ ) { const int x = d[q], z = d[q + len]; d[q] = x + z; d[q + len] = x - z; }
+#define ME_VSTAGE( CTRL, BIT ) { const int sgn = ( r & ( BIT ) ) ? -1 : 1; _Pragma( "unroll" ) /* upper lane of a pair: other - own, lower: own + other; |d| < 2^23 */ \
+  for( int i = 0; i < 8; i++ ) { const int t = __mul24( d[i], sgn ); d[i] = VVHIP_DPP( d[i], CTRL ) + t; } }
+  if( LT >= 16 ) ME_VSTAGE( VVHIP_DPP_MIRROR, 8 )
+  if( LT >= 8 )  ME_VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
+  if( LT >= 4 )  ME_VSTAGE( VVHIP_DPP_XOR2, 2 )
+  if( LT >= 2 )  ME_VSTAGE( VVHIP_DPP_XOR1, 1 )
+#undef ME_VSTAGE
+  uint32_t s = 0;
+#pragma unroll
+  for( int i = 0; i < 8; i++ ) s += ( uint32_t ) abs( d[i] );
+  if( r == 0 ) { const uint32_t dc = ( uint32_t ) abs( d[0] ); s = s - dc + ( dc >> 2 ); }
+  s = vvhipGroupSum32( s, LT, lane );
+  return hadNorm( s, kind );
+}
+
+// a stage unit in the schedule: stage index | band of 32 rows << 24 | 64-column half << 27 | continues the previous unit's sums << 28 | the next unit continues << 29
+constexpr int ST_UNIT_CONT = 1 << 28, ST_UNIT_MORE = 1 << 29;
+
 template<int K0, int K1>
 __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, const WaveSpan span, int16_t* lds, uint32_t* pairCost, const int wv )
 {
@@ -313,7 +380,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
   int* tapL = reinterpret_cast<int*>( lds );                                         // [16 phases][8] taps of the current unit's stage
   uint32_t* tapP = reinterpret_cast<uint32_t*>( lds ) + 128;                         // [16 phases][4] tap pairs (K0 + 2i, K0 + 2i + 1)
   int* posL = reinterpret_cast<int*>( lds ) + 128 + 64;                              // [9] evaluated positions: k | ( tx + 64 ) << 8 | ( ty + 64 ) << 20
-  uint32_t* costL = reinterpret_cast<uint32_t*>( lds ) + 128 + 64 + 16;              // [9] sums of the current unit
+  uint32_t* costL = reinterpret_cast<uint32_t*>( lds ) + 128 + 64 + 16;              // [9] sums of the current stage
   int16_t* tmp = lds + 2 * ( 128 + 64 + 16 + 16 );
 
   int curTab = -1;
@@ -326,13 +393,15 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
   {
     const int unit = a.stageOrder[span.first + si], stage = unit & 0xffffff;
     const vvhip_me_stage_job j = a.stageJobs[span.first + si];                     // (the job table is in schedule order, one record per unit)
-    const int w = j.width, h = j.height, G = w >> 3, log2G = 31 - __builtin_clz( G );
-    const int BH = h < 32 ? h : 32, rowsT = BH + NT, y0 = ( unit >> 24 ) * BH;        // a band = <= 32 rows of the block (two rows of 16x16_fast tiles)
-    const int ldsPitch = w + 8;                                                    // LDS row pitch: an odd number of 16-byte chunks (rows of a tile column land in different banks)
-    const int16_t* ref = P.p[j.ref_plane] + j.ref_off;
+    // the unit: <= 32 rows x <= 64 columns of the block (a band of one 64-column half).  Blocks of more than one unit (h > 32 or w > 64) are shared by the two waves of the
+    // workgroup; a wave adds the sums of its units (ST_UNIT_CONT / _MORE) before the two waves meet
+    const int w = j.width, h = j.height, uw = w < 64 ? w : 64, uwH = uw < 8 ? 8 : uw, G = uwH >> 3, log2G = 31 - __builtin_clz( G );
+    const int BH = h < 32 ? h : 32, rowsT = BH + NT, y0 = ( ( unit >> 24 ) & 7 ) * BH, xoff = ( ( unit >> 27 ) & 1 ) * 64;
+    const int ldsPitch = uwH + 8;                                                  // LDS row pitch: an odd number of 16-byte chunks (rows of a tile column land in different banks)
+    const int16_t* ref = P.p[j.ref_plane] + j.ref_off + xoff;
     const int rs = P.stride[j.ref_plane];
-    const int16_t* org = P.p[j.org_plane] + j.org_off;
-    const int os = P.stride[j.org_plane];
+    const int16_t* org = P.p[j.org_plane] + j.org_off + xoff;
+    const int os = P.stride[j.org_plane] ? P.stride[j.org_plane] : w;             // (stride 0: a compact pool block — bi-prediction patterns)
     // the evaluated positions and their distinct horizontal displacements (<= 3: the refinement offsets are -1, 0, 1): one first pass each, shared like the reference's planes
     int hx0 = 0, hx1 = 0, hx2 = 0, nHor = 0, nPos = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0;
     ST_SYNC();                                                                    // the previous unit's readers are done with the tables and tmp
@@ -368,13 +437,18 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       for( int i = tid; i < 192; i += nthr ) reinterpret_cast<int*>( lds )[i] = a.tapTables[tabId * 192 + i];
       curTab = tabId;
     }
-    if( tid < 9 ) costL[tid] = 0;
-    const bool fast16 = j.func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
-    const int tile = fast16 ? 16 : 8, tilesX = w / tile, tilesB = tilesX * ( BH / tile ), log2TX = 31 - __builtin_clz( tilesX ), log2TB = 31 - __builtin_clz( tilesB );
-    // Blocks of 32 and 64 samples keep ONE horizontal variant in LDS at a time (a pass = first pass of the variant, then every position that uses it: with 32-row bands a
-    // position of a 64-wide block is exactly 64 lanes of second-pass work), smaller blocks all (<= 3) of them: 6 KB of LDS per wave instead of 9.5 — the kernel is
+    if( !( unit & ST_UNIT_CONT ) && tid < 9 ) costL[tid] = 0;
+    // the tile type follows from the BLOCK's shape (the reference's ladder), the unit holds whole tiles of it
+    // (SAD-scored stages: no transform — the lanes are dealt like an 8x8 / 8x4 tile's, or like the 4x8 tile's for a 4-wide block)
+    const int kind = j.func == VVHIP_DF_SAD ? TK_ROWS : hadTileKind( w, h, j.func == VVHIP_DF_HAD_FAST );
+    const bool rows4 = kind == TK_4x8 || ( kind == TK_ROWS && uw == 4 );                 // two rows of four samples per lane
+    const int PW = rows4 ? 4 : ( kind == TK_ROWS ? 8 : tileW( kind ) ), PH = rows4 ? 8 : ( kind == TK_ROWS ? ( BH < 8 ? BH : 8 ) : tileH( kind ) );
+    const int LT = rows4 ? 4 : ( kind == TK_ROWS ? PH : tileLanes( kind ) ), log2LT = 31 - __builtin_clz( LT );
+    const int tilesX = uw / PW, tilesB = tilesX * ( BH / PH ), log2TX = 31 - __builtin_clz( tilesX ), log2TB = 31 - __builtin_clz( tilesB );
+    // Units of 32 and 64 columns keep ONE horizontal variant in LDS at a time (a pass = first pass of the variant, then every position that uses it: with 32-row bands a
+    // position of a 64-wide unit is exactly 64 lanes of second-pass work), narrower ones all (<= 3) of them: 6 KB of LDS per wave instead of 9.5 — the kernel is
     // occupancy-bound — and half as many units for the 64x64 blocks.
-    const int vpp = w <= 16 ? nHor : 1;
+    const int vpp = uw <= 16 ? nHor : 1;
     for( int v0 = 0; v0 < nHor; v0 += vpp )
     {
     const int nV = nHor - v0 < vpp ? nHor - v0 : vpp;
@@ -441,20 +515,21 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       }
     }
     ST_SYNC();     
-    // ---- VD: eight lanes per (position, tile), lane r = tile row r
-    const int nSlots = ( pEnd - pBeg ) * tilesB * 8;
+    // ---- VD: LT lanes per (position, tile); what a lane holds: see the tile table above
+    const int nSlots = ( pEnd - pBeg ) * tilesB * LT;
     for( int u0 = 0; u0 < nSlots; u0 += nthr )
     {
-      const int u = u0 + tid, r = u & 7, tt = u >> 3;
+      const int u = u0 + tid, r = u & ( LT - 1 ), tt = u >> log2LT;
       const bool valid = u < nSlots;
       const int pl = valid ? tt >> log2TB : 0, t = valid ? tt & ( tilesB - 1 ) : 0, pi = pBeg + pl;      // tilesX, tilesB are powers of two
       const int tyi = t >> log2TX, txi = t & ( tilesX - 1 );
       const int pk = posL[pi], txk = ( ( pk >> 8 ) & 0xfff ) - 64, tyk = ( ( pk >> 20 ) & 0xfff ) - 64;
       const int hv = ( txk == hx0 ? 0 : ( ( nHor > 1 && txk == hx1 ) ? 1 : 2 ) ) - v0, syk = tyk >> 4, fyk = tyk & 15;
+      const int16_t* tvp = tmp + hv * rowsT * ldsPitch;
       int d[8];
-      if( fast16 )
+      if( kind == TK_16F )
       {
-        const int16_t* tv = tmp + hv * rowsT * ldsPitch + txi * 16;
+        const int16_t* tv = tvp + txi * 16;
         const int16_t* po = org + ( ptrdiff_t ) ( y0 + tyi * 16 + 2 * r ) * os + txi * 16;
         const u32x4 c0v = ld16( po ), c1v = ld16( po + 8 ), e0 = ld16( po + os ), e1 = ld16( po + os + 8 );
         uint32_t pa[4], pb[4]; int ap[4], ao[4];
@@ -471,57 +546,51 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
 #pragma unroll
         for( int i = 0; i < 4; i++ ) d[4 + i] = ao[i] - ap[i];
       }
+      else if( rows4 )
+      {
+        // a 4-wide block (one tile column): two rows of four samples per lane; the first pass worked on 8 columns, the upper four are not part of the block
+        const int row = tyi * 8 + 2 * r;
+        const int16_t* po = org + ( ptrdiff_t ) ( y0 + row ) * os;
+        const u32x2 oa = ld8( po ), ob = ld8( po + os );
+        uint32_t pa[4], pb[4];
+        predRow<K0, K1>( tvp, ldsPitch, row, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
+        predRow<K0, K1>( tvp, ldsPitch, row + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
+        d[0] = lo16( oa.x ) - lo16( pa[0] ); d[1] = hi16( oa.x ) - hi16( pa[0] ); d[2] = lo16( oa.y ) - lo16( pa[1] ); d[3] = hi16( oa.y ) - hi16( pa[1] );
+        d[4] = lo16( ob.x ) - lo16( pb[0] ); d[5] = hi16( ob.x ) - hi16( pb[0] ); d[6] = lo16( ob.y ) - lo16( pb[1] ); d[7] = hi16( ob.y ) - hi16( pb[1] );
+      }
       else
       {
-        const int16_t* tv = tmp + hv * rowsT * ldsPitch + txi * 8;
-        const u32x4 ovv = ld16( org + ( ptrdiff_t ) ( y0 + tyi * 8 + r ) * os + txi * 8 );
+        const int row = kind == TK_16x8 ? tyi * 8 + ( r & 7 ) : tyi * PH + r, col = kind == TK_16x8 ? txi * 16 + 8 * ( r >> 3 ) : txi * 8;
+        const u32x4 ovv = ld16( org + ( ptrdiff_t ) ( y0 + row ) * os + col );
         uint32_t pw[4];
-        predRow<K0, K1>( tv, ldsPitch, tyi * 8 + r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pw );
+        predRow<K0, K1>( tvp + col, ldsPitch, row, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pw );
         const uint32_t ow[4] = { ovv.x, ovv.y, ovv.z, ovv.w };
 #pragma unroll
         for( int i = 0; i < 4; i++ ) { d[2 * i] = lo16( ow[i] ) - lo16( pw[i] ); d[2 * i + 1] = hi16( ow[i] ) - hi16( pw[i] ); }
       }
       uint32_t sres;
-      if( j.func == VVHIP_DF_SAD )
+      if( kind == TK_ROWS )
       {
         uint32_t s = 0;
 #pragma unroll
         for( int i = 0; i < 8; i++ ) s += ( uint32_t ) abs( d[i] );
-        sres = vvhipGroupSum32( s, 8, lane );
+        sres = vvhipGroupSum32( s, LT, lane );
       }
-      else
-      {
-#pragma unroll
-        for( int len = 1; len < 8; len <<= 1 )
-#pragma unroll
-          for( int i = 0; i < 8; i += 2 * len )
-#pragma unroll
-            for( int q = i; q < i + len; q++ ) { const int x = d[q], z = d[q + len]; d[q] = x + z; d[q + len] = x - z; }
-#define ME_VSTAGE( CTRL, BIT ) { const int sgn = ( r & ( BIT ) ) ? -1 : 1; _Pragma( "unroll" ) /* upper lane of a pair: other - own, lower: own + other; |d| < 2^23 */ \
-        for( int i = 0; i < 8; i++ ) { const int t = __mul24( d[i], sgn ); d[i] = VVHIP_DPP( d[i], CTRL ) + t; } }
-        ME_VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
-        ME_VSTAGE( VVHIP_DPP_XOR2, 2 )
-        ME_VSTAGE( VVHIP_DPP_XOR1, 1 )
-#undef ME_VSTAGE
-        uint32_t s = 0;
-#pragma unroll
-        for( int i = 0; i < 8; i++ ) s += ( uint32_t ) abs( d[i] );
-        if( r == 0 ) { const uint32_t dc = ( uint32_t ) abs( d[0] ); s = s - dc + ( dc >> 2 ); }
-        s = vvhipGroupSum32( s, 8, lane );
-        sres = fast16 ? ( ( s + 2 ) >> 2 ) << 2 : ( s + 2 ) >> 2;                  // RdCost.cpp:1218-1222 / 1317-1319
-      }
+      else sres = hadTeam( d, r, LT, kind, lane );
       if( valid && r == 0 ) atomicAdd( &costL[pk & 0xff], sres );
     }
     }      // passes
     ST_SYNC();     
-    // the stage's nine costs (0 for positions outside the mask).  A 64x64 block is two bands = the two waves of this workgroup (the schedule puts them side by side): the
-    // second wave hands its sums over through LDS, the first stores the totals — no atomics on the cost array, no clearing of it before the launch
-    if( h <= 32 ) { if( tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] : 0u; }
+    if( unit & ST_UNIT_MORE ) continue;                                            // the wave's next unit belongs to the same stage and adds to the same sums
+    // the stage's nine costs (0 for positions outside the mask).  A block of several units is shared by the two waves of this workgroup (the schedule puts them side by
+    // side, half of the units each): the second wave hands its sums over through LDS, the first stores the totals — no atomics on the cost array, no clearing of it before the launch
+    if( h <= 32 && w <= 64 ) { if( tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] : 0u; }
     else
     {
       if( wv == 1 && tid < 9 ) pairCost[tid] = costL[tid];
       __syncthreads();
       if( wv == 0 && tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] + pairCost[tid] : 0u;
+      __syncthreads();                                                           // (a workgroup may hold several such pairs in a row: pairCost is read before the next pair writes it)
     }
   }
 }
@@ -529,7 +598,43 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
 // =================================================================================================================================================
 // (C) plain table calls on blocks of any two planes
 // =================================================================================================================================================
-__device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, int wave )
+__device__ __forceinline__ uint32_t ld4( const int16_t* p ) { struct __attribute__( ( packed, aligned( 2 ) ) ) U4 { uint32_t v; }; return reinterpret_cast<const U4*>( p )->v; }
+
+// masked SAD (xGetSADwMask, RdCost.cpp:2062-2093): lane teams on row chunks like the plain SAD; the mask block is compact, one row per evaluated row
+__device__ __forceinline__ void maskItemBody( const MeArgs& a, const WaveSpan span, int nItems, const int16_t* const* planeL, const int* strideL, int lane )
+{
+  const int first = span.first, count = -span.count;
+  const vvhip_me_mask_item f = a.maskItems[first];
+  const int w = f.width, h = f.height, ss = f.sub_shift;
+  const int cw = w >= 8 ? 8 : ( w >= 4 ? 4 : 2 ), lpr = w / cw, lprShift = 31 - __builtin_clz( lpr ), rowsEff = h >> ss, chunks = rowsEff * lpr;
+  int lpc = 64; while( lpc > chunks ) lpc >>= 1;
+  const int teams = 64 / lpc, lt = lane & ( lpc - 1 ), team = lane / lpc;
+  for( int i0 = 0; i0 < count; i0 += teams )
+  {
+    const int ii = i0 + team;
+    const bool valid = ii < count;
+    const int idx = a.itemOrder[nItems + first + ( valid ? ii : 0 )];
+    const vvhip_me_mask_item it = a.maskItems[first + ( valid ? ii : 0 )];
+    const int os = strideL[it.org_plane] ? strideL[it.org_plane] : w, cs = strideL[it.cur_plane] ? strideL[it.cur_plane] : w;
+    const int16_t* po = planeL[it.org_plane] + it.org_off; const int16_t* pc = planeL[it.cur_plane] + it.cur_off; const int16_t* pm = planeL[it.mask_plane] + it.mask_off;
+    const int r0 = lt >> lprShift, s0 = lt & ( lpr - 1 ), rowStep = lpc >> lprShift;
+    uint32_t sum = 0;
+    for( int r = r0; r < rowsEff; r += rowStep )
+    {
+      const int16_t* qa = po + ( ptrdiff_t ) ( r << ss ) * os + s0 * cw; const int16_t* qb = pc + ( ptrdiff_t ) ( r << ss ) * cs + s0 * cw; const int16_t* qm = pm + r * w + s0 * cw;
+      uint32_t va[4] = { 0, 0, 0, 0 }, vb[4] = { 0, 0, 0, 0 }, vm[4] = { 0, 0, 0, 0 };
+      if( cw == 8 )      { const u32x4 x = ld16( qa ), z = ld16( qb ), m = ld16( qm ); va[0] = x.x; va[1] = x.y; va[2] = x.z; va[3] = x.w; vb[0] = z.x; vb[1] = z.y; vb[2] = z.z; vb[3] = z.w; vm[0] = m.x; vm[1] = m.y; vm[2] = m.z; vm[3] = m.w; }
+      else if( cw == 4 ) { const u32x2 x = ld8( qa ), z = ld8( qb ), m = ld8( qm ); va[0] = x.x; va[1] = x.y; vb[0] = z.x; vb[1] = z.y; vm[0] = m.x; vm[1] = m.y; }
+      else               { va[0] = ld4( qa ); vb[0] = ld4( qb ); vm[0] = ld4( qm ); }
+#pragma unroll
+      for( int q = 0; q < 4; q++ ) sum += ( uint32_t ) ( abs( lo16( va[q] ) - lo16( vb[q] ) ) * lo16( vm[q] ) + abs( hi16( va[q] ) - hi16( vb[q] ) ) * hi16( vm[q] ) );
+    }
+    const uint32_t t = vvhipGroupSum32( sum, lpc, lane );
+    if( valid && lt == 0 ) a.itemCost[idx] = ( uint64_t ) t << ss;                 // RdCost.cpp:2090
+  }
+}
+
+__device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, int wave, int nItems )
 {
   // the plane table in LDS: an item's planes are per-lane indices, and a per-lane index into the kernel arguments is a memory access behind the item record — one more link
   // in a chain (wave record -> item -> plane -> samples) that is all a short-lived wave does
@@ -539,11 +644,12 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
   const int lane = threadIdx.x & 63;
   if( lane < 16 ) { planeL[lane] = P.p[lane]; strideL[lane] = P.stride[lane]; }      // (every wave of the workgroup writes the same values)
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
+  if( span.count < 0 ) { maskItemBody( a, span, nItems, planeL, strideL, lane ); return; }
   const vvhip_me_item first = a.items[span.first];                                  // every item of the span has this function and geometry (the table is in schedule order)
   const int w = first.width, h = first.height, func = first.func, ss = func == VVHIP_DF_SAD ? first.sub_shift : 0;
   if( func == VVHIP_DF_SAD || func == VVHIP_DF_SSE )
   {
-    const int cw = w >= 8 ? 8 : 4, lpr = w / cw, lprShift = 31 - __builtin_clz( lpr ), rowsEff = h >> ss, chunks = rowsEff * lpr;
+    const int cw = w >= 8 ? 8 : ( w >= 4 ? 4 : 2 ), lpr = w / cw, lprShift = 31 - __builtin_clz( lpr ), rowsEff = h >> ss, chunks = rowsEff * lpr;
     int lpc = 64; while( lpc > chunks ) lpc >>= 1;
     const int teams = 64 / lpc, lt = lane & ( lpc - 1 ), team = lane / lpc;
     for( int i0 = 0; i0 < span.count; i0 += teams )
@@ -552,8 +658,8 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
       const bool valid = ii < span.count;
       const int idx = a.itemOrder[span.first + ( valid ? ii : 0 )];            // where the result goes
       const vvhip_me_item it = a.items[span.first + ( valid ? ii : 0 )];
-      const int16_t* po = planeL[it.org_plane] + it.org_off; const int os = strideL[it.org_plane];
-      const int16_t* pc = planeL[it.cur_plane] + it.cur_off; const int cs = strideL[it.cur_plane];
+      const int16_t* po = planeL[it.org_plane] + it.org_off; const int os = strideL[it.org_plane] ? strideL[it.org_plane] : w;      // (stride 0: a pool of compact blocks)
+      const int16_t* pc = planeL[it.cur_plane] + it.cur_off; const int cs = strideL[it.cur_plane] ? strideL[it.cur_plane] : w;
       uint32_t sad = 0; uint64_t sse = 0;
       // a lane's chunks are lpc apart: the same column piece, rowStep rows further down (lpr, chunks, lpc are powers of two, lpc >= lpr): no division, constant address steps.
       // (four chunks per lane in flight were measured slower: 23.8 -> 24.6 us, the intra picture 123 -> 143 us)
@@ -565,7 +671,8 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
       {
         uint32_t va[4], vb[4];
         if( cw == 8 ) { const u32x4 x = ld16( pa ), z = ld16( pb ); va[0] = x.x; va[1] = x.y; va[2] = x.z; va[3] = x.w; vb[0] = z.x; vb[1] = z.y; vb[2] = z.z; vb[3] = z.w; }
-        else { const u32x2 x = ld8( pa ), z = ld8( pb ); va[0] = x.x; va[1] = x.y; va[2] = va[3] = 0; vb[0] = z.x; vb[1] = z.y; vb[2] = vb[3] = 0; }
+        else if( cw == 4 ) { const u32x2 x = ld8( pa ), z = ld8( pb ); va[0] = x.x; va[1] = x.y; va[2] = va[3] = 0; vb[0] = z.x; vb[1] = z.y; vb[2] = vb[3] = 0; }
+        else { va[0] = ld4( pa ); vb[0] = ld4( pb ); va[1] = va[2] = va[3] = 0; vb[1] = vb[2] = vb[3] = 0; }
 #pragma unroll
         for( int q = 0; q < 4; q++ )
         {
@@ -578,20 +685,17 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
     }
     return;
   }
-  // Hadamard family.  HAD_fast on 32 / 64: 16x16_fast tiles; width 4: the 4x4 tile (one lane each); else 8x8 tiles.  HAD_2SAD = min( HAD, 2 SAD ) (RdCost.cpp:1768-1816).
-  // 8x8 and 16x16_fast tiles: EIGHT lanes per tile, lane r = tile row r (two rows and their 2x2 averages for the fast tile) — every sample of an item is requested at once
-  // (one memory latency per item; one lane per tile was 8 dependent row groups and 119 registers), horizontal butterflies in registers, vertical ones across the eight lanes with
-  // DPP, the factorisation of the refinement-stage kernel.  Tile sums meet in LDS per item.
-  const bool fast16 = func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 && w == h;
-  const int tile = w == 4 ? 4 : ( fast16 ? 16 : 8 ), tilesX = w / tile, tiles = tilesX * ( h / tile );
-  if( tile == 4 )
+  // Hadamard family: the reference's tile ladder (hadTileKind), a team of lanes per tile (table in front of hadTeam; every sample of an item is requested at once: one memory
+  // latency per item), one lane per 4x4 block and per 2x2 tile.  HAD_2SAD = min( HAD, 2 SAD ) (RdCost.cpp:1768-1816; its SAD runs over all samples of the block).
+  const int kind = hadTileKind( w, h, func == VVHIP_DF_HAD_FAST );
+  if( kind == TK_4x4 )                                                   // (only the 4x4 block: 4 x N and N x 4 blocks use the 4x8 / 8x4 tiles)
   {
     const int ii = lane;
     const bool valid = ii < span.count;
     const int idx = a.itemOrder[span.first + ( valid ? ii : 0 )];
     const vvhip_me_item it = a.items[span.first + ( valid ? ii : 0 )];
-    const int16_t* qa = planeL[it.org_plane] + it.org_off; const int os = strideL[it.org_plane];
-    const int16_t* qb = planeL[it.cur_plane] + it.cur_off; const int cs = strideL[it.cur_plane];
+    const int16_t* qa = planeL[it.org_plane] + it.org_off; const int os = strideL[it.org_plane] ? strideL[it.org_plane] : w;
+    const int16_t* qb = planeL[it.cur_plane] + it.cur_off; const int cs = strideL[it.cur_plane] ? strideL[it.cur_plane] : w;
     int d[16]; uint32_t sad = 0;
 #pragma unroll
     for( int r = 0; r < 4; r++ )
@@ -605,66 +709,75 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
     return;
   }
   __shared__ uint32_t accAll[4][128];                                 // per wave and item of its span: Hadamard sum, SAD
-  uint32_t* accL = accAll[threadIdx.x >> 6];
+  uint32_t* accL = accAll[( threadIdx.x >> 6 ) & 3];
   accL[lane] = 0; accL[64 + lane] = 0;
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
-  const int slotsPerItem = tiles * 8, total = span.count * slotsPerItem, log2Slots = 31 - __builtin_clz( slotsPerItem ), log2TX = 31 - __builtin_clz( tilesX );
+  const int PW = tileW( kind ), PH = tileH( kind ), LT = tileLanes( kind ), log2LT = 31 - __builtin_clz( LT );
+  const int tilesX = w / PW, tiles = tilesX * ( h / PH );
+  const int slotsPerItem = tiles * LT, total = span.count * slotsPerItem, log2Slots = 31 - __builtin_clz( slotsPerItem ), log2TX = 31 - __builtin_clz( tilesX );
   for( int s0 = 0; s0 < total; s0 += 64 )
   {
     const int sl = s0 + lane;
     const bool valid = sl < total;
-    const int sv = valid ? sl : 0, ii = sv >> log2Slots, rem = sv & ( slotsPerItem - 1 ), t = rem >> 3, r = rem & 7;      // (powers of two)
+    const int sv = valid ? sl : 0, ii = sv >> log2Slots, rem = sv & ( slotsPerItem - 1 ), t = rem >> log2LT, r = rem & ( LT - 1 );      // (powers of two)
     const vvhip_me_item it = a.items[span.first + ii];
-    const int os = strideL[it.org_plane], cs = strideL[it.cur_plane];
+    const int os = strideL[it.org_plane] ? strideL[it.org_plane] : w, cs = strideL[it.cur_plane] ? strideL[it.cur_plane] : w;
     const int tyi = t >> log2TX, txi = t & ( tilesX - 1 );
-    const int16_t* qa = planeL[it.org_plane] + it.org_off + ( ptrdiff_t ) ( tyi * tile ) * os + txi * tile;
-    const int16_t* qb = planeL[it.cur_plane] + it.cur_off + ( ptrdiff_t ) ( tyi * tile ) * cs + txi * tile;
-    int d[8]; uint32_t sad = 0;
-    if( fast16 )
+    const int16_t* qa = planeL[it.org_plane] + it.org_off + ( ptrdiff_t ) ( tyi * PH ) * os + txi * PW;
+    const int16_t* qb = planeL[it.cur_plane] + it.cur_off + ( ptrdiff_t ) ( tyi * PH ) * cs + txi * PW;
+    int d[8]; uint32_t sad = 0, sres;
+    if( kind == TK_2x2 )
     {
-      const int16_t* p0 = qa + ( ptrdiff_t ) ( 2 * r ) * os; const int16_t* p1 = qb + ( ptrdiff_t ) ( 2 * r ) * cs;
-      const u32x4 a0 = ld16( p0 ), a1 = ld16( p0 + 8 ), b0 = ld16( p0 + os ), b1 = ld16( p0 + os + 8 );
-      const u32x4 c0 = ld16( p1 ), c1 = ld16( p1 + 8 ), e0 = ld16( p1 + cs ), e1 = ld16( p1 + cs + 8 );
-      int ao[4], ac[4];
-      { const uint32_t x[4] = { a0.x, a0.y, a0.z, a0.w }, y[4] = { b0.x, b0.y, b0.z, b0.w }; avgInts( x, y, ao ); }
-      { const uint32_t x[4] = { c0.x, c0.y, c0.z, c0.w }, y[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( x, y, ac ); }
-#pragma unroll
-      for( int i = 0; i < 4; i++ ) d[i] = ao[i] - ac[i];
-      { const uint32_t x[4] = { a1.x, a1.y, a1.z, a1.w }, y[4] = { b1.x, b1.y, b1.z, b1.w }; avgInts( x, y, ao ); }
-      { const uint32_t x[4] = { c1.x, c1.y, c1.z, c1.w }, y[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( x, y, ac ); }
-#pragma unroll
-      for( int i = 0; i < 4; i++ ) d[4 + i] = ao[i] - ac[i];
+      // xCalcHADs2x2 (RdCost.cpp:1006-1026): one lane per tile
+      const uint32_t x0 = ld4( qa ), x1 = ld4( qa + os ), z0 = ld4( qb ), z1 = ld4( qb + cs );
+      const int d0 = lo16( x0 ) - lo16( z0 ), d1 = hi16( x0 ) - hi16( z0 ), d2 = lo16( x1 ) - lo16( z1 ), d3 = hi16( x1 ) - hi16( z1 );
+      const int m0 = d0 + d2, m1 = d1 + d3, m2 = d0 - d2, m3 = d1 - d3;
+      sres = ( ( uint32_t ) abs( m0 + m1 ) >> 2 ) + ( uint32_t ) abs( m0 - m1 ) + ( uint32_t ) abs( m2 + m3 ) + ( uint32_t ) abs( m2 - m3 );
+      sad = ( uint32_t ) ( abs( d0 ) + abs( d1 ) + abs( d2 ) + abs( d3 ) );
     }
     else
     {
-      const u32x4 x = ld16( qa + ( ptrdiff_t ) r * os ), z = ld16( qb + ( ptrdiff_t ) r * cs );
-      const uint32_t xw[4] = { x.x, x.y, x.z, x.w }, zw[4] = { z.x, z.y, z.z, z.w };
-#pragma unroll
-      for( int i = 0; i < 4; i++ )
+      if( kind == TK_16F )
       {
-        d[2 * i] = lo16( xw[i] ) - lo16( zw[i] ); d[2 * i + 1] = hi16( xw[i] ) - hi16( zw[i] );
-        if( func == VVHIP_DF_HAD_2SAD ) sad = __builtin_amdgcn_sad_u16( xw[i] ^ BIAS, zw[i] ^ BIAS, sad );
+        const int16_t* p0 = qa + ( ptrdiff_t ) ( 2 * r ) * os; const int16_t* p1 = qb + ( ptrdiff_t ) ( 2 * r ) * cs;
+        const u32x4 a0 = ld16( p0 ), a1 = ld16( p0 + 8 ), b0 = ld16( p0 + os ), b1 = ld16( p0 + os + 8 );
+        const u32x4 c0 = ld16( p1 ), c1 = ld16( p1 + 8 ), e0 = ld16( p1 + cs ), e1 = ld16( p1 + cs + 8 );
+        int ao[4], ac[4];
+        { const uint32_t x[4] = { a0.x, a0.y, a0.z, a0.w }, y[4] = { b0.x, b0.y, b0.z, b0.w }; avgInts( x, y, ao ); }
+        { const uint32_t x[4] = { c0.x, c0.y, c0.z, c0.w }, y[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( x, y, ac ); }
+#pragma unroll
+        for( int i = 0; i < 4; i++ ) d[i] = ao[i] - ac[i];
+        { const uint32_t x[4] = { a1.x, a1.y, a1.z, a1.w }, y[4] = { b1.x, b1.y, b1.z, b1.w }; avgInts( x, y, ao ); }
+        { const uint32_t x[4] = { c1.x, c1.y, c1.z, c1.w }, y[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( x, y, ac ); }
+#pragma unroll
+        for( int i = 0; i < 4; i++ ) d[4 + i] = ao[i] - ac[i];
       }
+      else if( kind == TK_4x8 )
+      {
+        const u32x2 xa = ld8( qa + ( ptrdiff_t ) ( 2 * r ) * os ), xb = ld8( qa + ( ptrdiff_t ) ( 2 * r + 1 ) * os ), za = ld8( qb + ( ptrdiff_t ) ( 2 * r ) * cs ), zb = ld8( qb + ( ptrdiff_t ) ( 2 * r + 1 ) * cs );
+        const uint32_t xw[4] = { xa.x, xa.y, xb.x, xb.y }, zw[4] = { za.x, za.y, zb.x, zb.y };
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+        {
+          d[2 * i] = lo16( xw[i] ) - lo16( zw[i] ); d[2 * i + 1] = hi16( xw[i] ) - hi16( zw[i] );
+          if( func == VVHIP_DF_HAD_2SAD ) sad = __builtin_amdgcn_sad_u16( xw[i] ^ BIAS, zw[i] ^ BIAS, sad );
+        }
+      }
+      else
+      {
+        const int row = kind == TK_16x8 ? ( r & 7 ) : r, col = kind == TK_16x8 ? 8 * ( r >> 3 ) : 0;
+        const u32x4 x = ld16( qa + ( ptrdiff_t ) row * os + col ), z = ld16( qb + ( ptrdiff_t ) row * cs + col );
+        const uint32_t xw[4] = { x.x, x.y, x.z, x.w }, zw[4] = { z.x, z.y, z.z, z.w };
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+        {
+          d[2 * i] = lo16( xw[i] ) - lo16( zw[i] ); d[2 * i + 1] = hi16( xw[i] ) - hi16( zw[i] );
+          if( func == VVHIP_DF_HAD_2SAD ) sad = __builtin_amdgcn_sad_u16( xw[i] ^ BIAS, zw[i] ^ BIAS, sad );
+        }
+      }
+      sres = hadTeam( d, r, LT, kind, lane );
+      if( func == VVHIP_DF_HAD_2SAD ) sad = vvhipGroupSum32( sad, LT, lane );
     }
-#pragma unroll
-    for( int len = 1; len < 8; len <<= 1 )
-#pragma unroll
-      for( int i = 0; i < 8; i += 2 * len )
-#pragma unroll
-        for( int q = i; q < i + len; q++ ) { const int x = d[q], z = d[q + len]; d[q] = x + z; d[q + len] = x - z; }
-#define ME_VSTAGE( CTRL, BIT ) { const int sgn = ( r & ( BIT ) ) ? -1 : 1; _Pragma( "unroll" ) \
-    for( int i = 0; i < 8; i++ ) { const int t = __mul24( d[i], sgn ); d[i] = VVHIP_DPP( d[i], CTRL ) + t; } }
-    ME_VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
-    ME_VSTAGE( VVHIP_DPP_XOR2, 2 )
-    ME_VSTAGE( VVHIP_DPP_XOR1, 1 )
-#undef ME_VSTAGE
-    uint32_t sm = 0;
-#pragma unroll
-    for( int i = 0; i < 8; i++ ) sm += ( uint32_t ) abs( d[i] );
-    if( r == 0 ) { const uint32_t dc = ( uint32_t ) abs( d[0] ); sm = sm - dc + ( dc >> 2 ); }
-    sm = vvhipGroupSum32( sm, 8, lane );
-    const uint32_t sres = fast16 ? ( ( sm + 2 ) >> 2 ) << 2 : ( sm + 2 ) >> 2;      // RdCost.cpp:1218-1222 / 1317-1319
-    if( func == VVHIP_DF_HAD_2SAD ) sad = vvhipGroupSum32( sad, 8, lane );
     if( valid && r == 0 ) { atomicAdd( &accL[ii], sres ); if( func == VVHIP_DF_HAD_2SAD ) atomicAdd( &accL[64 + ii], sad ); }
   }
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
@@ -692,12 +805,13 @@ meStageKernel( MePlanes P, MeArgs a, int firstWave, int nWaves, int ldsPerWave )
 
 // workgroups 0 .. nBig - 1: one large window each (four waves share it); the others: four small windows each, one per wave
 __global__ void __launch_bounds__( 256 )
-meIntKernel( MePlanes P, MeArgs a, int nBig, int ldsSmall )
+meIntKernel( MePlanes P, MeArgs a, int nBig, int ldsSmall, int blockBase )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t meLds[];
-  if( ( int ) blockIdx.x < nBig ) { intBody<false>( P, a, blockIdx.x, meLds ); return; }
+  const int blk = ( int ) blockIdx.x + blockBase;                                   // (the two window classes may be two launches: vvhip_me_plan.intSplit)
+  if( blk < nBig ) { intBody<false>( P, a, blk, meLds ); return; }
   const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) );
-  const int job = nBig + ( ( int ) blockIdx.x - nBig ) * 4 + wv;
+  const int job = nBig + ( blk - nBig ) * 4 + wv;
   if( job < a.wavesInt ) intBody<true>( P, a, job, meLds + wv * ( ldsSmall >> 1 ) );
 }
 
@@ -706,10 +820,10 @@ meIntKernel( MePlanes P, MeArgs a, int nBig, int ldsSmall )
 // lists keep single-wave workgroups
 template<int WAVES>
 __global__ void __launch_bounds__( 64 * WAVES )
-meItemKernel( MePlanes P, MeArgs a )
+meItemKernel( MePlanes P, MeArgs a, int nItems )
 {
   const int wave = blockIdx.x * WAVES + ( int ) ( threadIdx.x >> 6 );
-  if( wave < a.wavesItem ) itemBody( P, a, wave );
+  if( wave < a.wavesItem ) itemBody( P, a, wave, nItems );
 }
 
 int hostWinPitch( int winW ) { return 2 * ( ( ( winW + 3 ) >> 1 ) | 1 ); }
@@ -719,16 +833,36 @@ int hostWinSamples( int winW, int winH ) { return ( winH * hostWinPitch( winW ) 
 
 extern "C" {
 
+static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth, int max_window, vvhip_me_plan** out );
+
 int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int n_int_jobs, const vvhip_me_cand* cands, int n_cands,
                           const vvhip_me_stage_job* stage_jobs, int n_stage_jobs, const vvhip_me_item* items, int n_items, int bit_depth, int max_window, vvhip_me_plan** out )
 {
+  vvhip_me_lists L; L.int_jobs = int_jobs; L.n_int_jobs = n_int_jobs; L.cands = cands; L.n_cands = n_cands; L.stage_jobs = stage_jobs; L.n_stage_jobs = n_stage_jobs;
+  L.items = items; L.n_items = n_items; L.mask_items = nullptr; L.n_mask_items = 0;
+  return mePlanCreate( ctx, L, bit_depth, max_window, out );
+}
+
+int vvhip_me_plan_create_lists( vvhip_ctx* ctx, const vvhip_me_lists* lists, int bit_depth, int max_window, vvhip_me_plan** out )
+{
+  if( !ctx || !lists ) return VVHIP_E_ARG;
+  return mePlanCreate( ctx, *lists, bit_depth, max_window, out );
+}
+
+static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth, int max_window, vvhip_me_plan** out )
+{
   if( !ctx || !out ) return VVHIP_E_ARG;
   *out = nullptr;
-  if( n_int_jobs < 0 || n_cands < 0 || n_stage_jobs < 0 || n_items < 0 || ( n_int_jobs && ( !int_jobs || !cands ) ) || ( n_stage_jobs && !stage_jobs ) || ( n_items && !items ) )
+  const vvhip_me_int_job* int_jobs = L.int_jobs; const vvhip_me_cand* cands = L.cands; const vvhip_me_stage_job* stage_jobs = L.stage_jobs; const vvhip_me_item* items = L.items;
+  const vvhip_me_mask_item* mask_items = L.mask_items;
+  const int n_int_jobs = L.n_int_jobs, n_cands = L.n_cands, n_stage_jobs = L.n_stage_jobs, n_items = L.n_items, n_mask = L.n_mask_items;
+  if( n_int_jobs < 0 || n_cands < 0 || n_stage_jobs < 0 || n_items < 0 || n_mask < 0 || ( n_int_jobs && ( !int_jobs || !cands ) ) || ( n_stage_jobs && !stage_jobs ) || ( n_items && !items ) || ( n_mask && !mask_items ) )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: bad lists" );
+  if( n_stage_jobs >= ( 1 << 24 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: %d stage jobs (the schedule packs the stage index into 24 bits)", n_stage_jobs );
   if( bit_depth < 8 || bit_depth > 10 ) return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_me_plan_create: bit depth %d (the packed Hadamard tile covers <= 10)", bit_depth );
   if( max_window <= 0 ) max_window = 24;
-  auto squareOk = []( int w, int h, int minW ) { return w == h && ( w == 4 || w == 8 || w == 16 || w == 32 || w == 64 ) && w >= minW; };
+  // block shapes: width and height independent powers of two (CTU 128 + multi-type tree: RdCost.cpp:301-336 generic SAD, the rectangular Hadamard tiles :1324-1766)
+  auto shapeOk = []( int w, int h, int minW, int minH ) { return isPow2( w ) && isPow2( h ) && w >= minW && h >= minH && w <= 128 && h <= 128; };
 
   // ---- integer jobs: one window per cluster of candidates (greedy in list order: a candidate joins the first window it keeps within max_window)
   std::vector<IntJob> ij; std::vector<PlanCand> pc;
@@ -737,10 +871,12 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   for( int i = 0; i < n_int_jobs; i++ )
   {
     const vvhip_me_int_job& s = int_jobs[i];
-    if( !squareOk( s.width, s.height, 8 ) || s.org_plane > 15 || s.ref_plane > 15 || s.sub_shift > 1 || s.first_cand < 0 || s.n_cand < 0 || s.first_cand + s.n_cand > n_cands )
+    if( !shapeOk( s.width, s.height, 8, 4 ) || s.org_plane > 15 || s.ref_plane > 15 || s.sub_shift > 1 || ( s.height >> s.sub_shift ) < 1 || s.first_cand < 0 || s.n_cand < 0 || s.first_cand + s.n_cand > n_cands )
       return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: integer job %d (%dx%d, candidates %d+%d)", i, s.width, s.height, s.first_cand, s.n_cand );
     struct Win { int x0, y0, x1, y1; std::vector<PlanCand> c; };
     std::vector<Win> wins;
+    // a 128-wide block's window must still fit the LDS of a workgroup: its reach shrinks with the block
+    const int reach = std::min( max_window, s.width * s.height >= 128 * 64 ? 16 : max_window );
     for( int k = 0; k < s.n_cand; k++ )
     {
       const vvhip_me_cand& c = cands[s.first_cand + k];
@@ -750,7 +886,7 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
       {
         if( ( int ) wn.c.size() >= candCap ) continue;          // a window's candidates are one workgroup's serial work: long lists (raster searches: ~300 positions) are cut
         const int x0 = std::min( wn.x0, ( int ) c.dx ), y0 = std::min( wn.y0, ( int ) c.dy ), x1 = std::max( wn.x1, ( int ) c.dx ), y1 = std::max( wn.y1, ( int ) c.dy );
-        if( x1 - x0 <= max_window && y1 - y0 <= max_window ) { wn.x0 = x0; wn.y0 = y0; wn.x1 = x1; wn.y1 = y1; wn.c.push_back( p ); placed = true; break; }
+        if( x1 - x0 <= reach && y1 - y0 <= reach ) { wn.x0 = x0; wn.y0 = y0; wn.x1 = x1; wn.y1 = y1; wn.c.push_back( p ); placed = true; break; }
       }
       if( !placed ) { Win wn; wn.x0 = wn.x1 = c.dx; wn.y0 = wn.y1 = c.dy; wn.c.push_back( p ); wins.push_back( wn ); }
     }
@@ -772,72 +908,97 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   int intBig = 0, ldsIntSmall = 0;
   for( const IntJob& j : ij ) { if( ldsOf( j ) > ldsSmallCap ) intBig++; else ldsIntSmall = std::max( ldsIntSmall, ldsOf( j ) ); }
 
-  // ---- stage units: (stage, band of <= 32 rows); a wave takes a bundle of units of one block width and tap support worth ~160 second-pass row groups
+  // ---- stage units: (stage, band of <= 32 rows, half of <= 64 columns); a wave takes a bundle of units of one unit width and tap support worth ~160 second-pass row groups.
+  //      A stage of several units (h > 32 or w > 64) is shared by the two waves of ONE workgroup, half of its units each.
   std::vector<WaveSpan> stWaves;
   int ldsStage = 0;
   for( int i = 0; i < n_stage_jobs; i++ )
   {
     const vvhip_me_stage_job& s = stage_jobs[i];
-    if( !squareOk( s.width, s.height, 8 ) || s.org_plane > 15 || s.ref_plane > 15 || ( s.i_frac != 1 && s.i_frac != 2 ) || s.filter_mode > 2 ||
-        ( s.func != VVHIP_DF_SAD && s.func != VVHIP_DF_HAD && s.func != VVHIP_DF_HAD_FAST ) || s.base_qx < -3 || s.base_qx > 3 || s.base_qy < -3 || s.base_qy > 3 || ( s.mask >> 9 ) )
-      return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: stage job %d (%dx%d, iFrac %d, mode %d, func %d)", i, s.width, s.height, s.i_frac, s.filter_mode, s.func );
+    bool ok = shapeOk( s.width, s.height, 4, 4 ) && !( s.width == 4 && s.height == 4 ) && s.org_plane <= 15 && s.ref_plane <= 15 && ( s.i_frac == 1 || s.i_frac == 2 ) && s.filter_mode <= 2 &&
+              ( s.func == VVHIP_DF_SAD || s.func == VVHIP_DF_HAD || s.func == VVHIP_DF_HAD_FAST ) && !( s.mask >> 9 );
+    // every evaluated position within one sample of the block (in 1/16 sample: -16 .. 16): the kernel stages the band's rows K0 - 4 .. BH + K1 - 4 and nothing else, so a
+    // vertical displacement beyond that would read another variant's rows or the tap tables (s_acMvRefineH / Q offsets are -1 .. 1; InterSearch.cpp:67-91)
+    for( int k = 0; ok && k < 9; k++ )
+      if( ( s.mask >> k ) & 1 )
+      {
+        static const int8_t rxT[9] = { 0, 0, 0, -1, 1, -1, 1, -1, 1 }, ryH[9] = { 0, -1, 1, 0, 0, -1, -1, 1, 1 }, ryQ[9] = { 0, -1, 1, -1, -1, 0, 0, 1, 1 };
+        const int tx = ( rxT[k] + s.base_qx ) * s.i_frac * 4, ty = ( ( s.i_frac == 2 ? ryH[k] : ryQ[k] ) + s.base_qy ) * s.i_frac * 4;
+        if( tx < -16 || tx > 16 || ty < -16 || ty > 16 ) ok = false;
+      }
+    if( !ok )
+      return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: stage job %d (%dx%d, iFrac %d, mode %d, func %d, base %d,%d, mask %x)", i, s.width, s.height, s.i_frac, s.filter_mode, s.func, s.base_qx, s.base_qy, s.mask );
   }
   auto setOf = []( const vvhip_me_stage_job& s ) { return ( s.filter_mode == 2 && !s.alt_hpel ) ? 0 : ( s.filter_mode == 0 ? 2 : 1 ); };      // which tap support the bundle's kernel instance uses
-  auto unitWork = [&]( const vvhip_me_stage_job& s ) { return __builtin_popcount( s.mask ) * ( s.width / 8 ) * std::min( ( int ) s.height, 32 ); };      // 8-sample row groups of the second pass
+  auto unitW = []( const vvhip_me_stage_job& s ) { return std::min( ( int ) s.width, 64 ); };
+  auto unitH = []( const vvhip_me_stage_job& s ) { return std::min( ( int ) s.height, 32 ); };
+  auto unitsOf = [&]( const vvhip_me_stage_job& s ) { return ( s.width / unitW( s ) ) * ( s.height / unitH( s ) ); };
+  auto unitWork = [&]( const vvhip_me_stage_job& s ) { return __builtin_popcount( s.mask ) * std::max( 1, unitW( s ) / 8 ) * unitH( s ); };      // 8-sample row groups of the second pass
   std::vector<int32_t> stOrder;
-  for( int i = 0; i < n_stage_jobs; i++ ) if( stage_jobs[i].mask ) for( int b = 0; b < ( stage_jobs[i].height + 31 ) / 32; b++ ) stOrder.push_back( i | ( b << 24 ) );
+  for( int i = 0; i < n_stage_jobs; i++ )      // (a stage without evaluated positions still gets its unit: the kernel writes its nine zeros)
+  {
+    const vvhip_me_stage_job& s = stage_jobs[i];
+    const int bands = s.height / unitH( s ), halves = s.width / unitW( s ), n = bands * halves, perWave = n > 1 ? n / 2 : 1;
+    for( int u = 0; u < n; u++ )
+      stOrder.push_back( i | ( ( u % bands ) << 24 ) | ( ( u / bands ) << 27 ) | ( ( u % perWave ) ? ST_UNIT_CONT : 0 ) | ( ( u % perWave ) != perWave - 1 ? ST_UNIT_MORE : 0 ) );
+  }
+  // per tap support: the stages of several units first (their waves must be the pairs 2g, 2g + 1 of the launch), then by unit width and work
   std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & 0xffffff]; const auto& y = stage_jobs[b & 0xffffff];
-                    return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( x.width != y.width ? x.width > y.width : unitWork( x ) > unitWork( y ) ); } );
+                    const bool px = unitsOf( x ) > 1, py = unitsOf( y ) > 1;
+                    return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( px != py ? px : ( unitW( x ) != unitW( y ) ? unitW( x ) > unitW( y ) : unitWork( x ) > unitWork( y ) ) ); } );
   int setWaves[3] = { 0, 0, 0 }, setBig[3] = { 0, 0, 0 };
   static const int bundleWork = getenv( "VVHIP_ME_BUNDLE_WORK" ) ? atoi( getenv( "VVHIP_ME_BUNDLE_WORK" ) ) : 160;      // measured on the recorded 1080p lists: 80 / 160 / 320 / 640 / 1280 -> 59.0 / 58.7 / 61.9 / 67.9 / 71.1 us
   for( size_t i = 0; i < stOrder.size(); )
   {
     const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i] & 0xffffff];
     int count = 0, work = 0;
-    while( i + count < stOrder.size() && count < 8 )
-    {
-      const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count] & 0xffffff];
-      if( s.width != s0.width || setOf( s ) != setOf( s0 ) || ( count && ( work + unitWork( s ) > bundleWork || s.height > 32 ) ) ) break;      // (a band of a 64x64 block: a wave of its own, next to its sibling)
-      work += unitWork( s ); count++;
-    }
+    if( unitsOf( s0 ) > 1 ) count = unitsOf( s0 ) / 2;      // half of a shared stage's units: a wave of its own, next to its sibling
+    else
+      while( i + count < stOrder.size() && count < 8 )
+      {
+        const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count] & 0xffffff];
+        if( unitW( s ) != unitW( s0 ) || setOf( s ) != setOf( s0 ) || unitsOf( s ) > 1 || ( count && work + unitWork( s ) > bundleWork ) ) break;
+        work += unitWork( s ); count++;
+      }
     WaveSpan sp; sp.first = ( int32_t ) i; sp.count = count; stWaves.push_back( sp );
     setWaves[setOf( s0 )]++;
     if( s0.width >= 32 ) setBig[setOf( s0 )]++;
-    const int bh = std::min( ( int ) s0.height, 32 ), nt = setOf( s0 ) == 0 ? 4 : ( setOf( s0 ) == 1 ? 6 : 8 ), vpp = s0.width <= 16 ? 3 : 1;
-    ldsStage = std::max( ldsStage, ( 2 * ( 128 + 64 + 16 + 16 ) + vpp * ( bh + nt ) * ( s0.width + 8 ) ) * 2 );      // tables + the first-pass bands a pass holds (row pitch width + 8)
+    const int bh = unitH( s0 ), nt = setOf( s0 ) == 0 ? 4 : ( setOf( s0 ) == 1 ? 6 : 8 ), uw = std::max( 8, unitW( s0 ) ), vpp = unitW( s0 ) <= 16 ? 3 : 1;
+    ldsStage = std::max( ldsStage, ( 2 * ( 128 + 64 + 16 + 16 ) + vpp * ( bh + nt ) * ( uw + 8 ) ) * 2 );      // tables + the first-pass bands a pass holds (row pitch unit width + 8)
     i += count;
   }
 
-  // the kernel relies on it: the two bands of a 64x64 stage are the waves 2g, 2g + 1 of their tap support's launch
+  // the kernel relies on it: the two halves of a shared stage's units are the waves 2g, 2g + 1 of their tap support's launch
   for( int k = 0, first = 0; k < 3; first += setWaves[k], k++ )
     for( int w = 0; w < setWaves[k]; w++ )
     {
       const WaveSpan& sp = stWaves[first + w];
       const int u = stOrder[sp.first];
-      if( stage_jobs[u & 0xffffff].height <= 32 ) continue;
+      const vvhip_me_stage_job& s = stage_jobs[u & 0xffffff];
+      if( unitsOf( s ) <= 1 ) continue;
       const int sib = ( w & 1 ) ? w - 1 : w + 1;
-      if( sp.count != 1 || sib >= setWaves[k] || stWaves[first + sib].count != 1 || ( stOrder[stWaves[first + sib].first] & 0xffffff ) != ( u & 0xffffff ) )
-        return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: schedule error (bands of stage %d are not one workgroup)", u & 0xffffff );
+      if( sp.count != unitsOf( s ) / 2 || sib >= setWaves[k] || stWaves[first + sib].count != sp.count || ( stOrder[stWaves[first + sib].first] & 0xffffff ) != ( u & 0xffffff ) )
+        return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: schedule error (the units of stage %d are not one workgroup)", u & 0xffffff );
     }
 
   // ---- item bundles: same function and geometry, a few team passes per wave
-  std::vector<int32_t> itOrder( n_items ); std::vector<WaveSpan> itWaves;
+  std::vector<int32_t> itOrder( ( size_t ) n_items + n_mask ); std::vector<WaveSpan> itWaves;
   for( int i = 0; i < n_items; i++ )
   {
     const vvhip_me_item& s = items[i];
     const bool fOk = s.func == VVHIP_DF_SAD || s.func == VVHIP_DF_SSE || s.func == VVHIP_DF_HAD || s.func == VVHIP_DF_HAD_FAST || s.func == VVHIP_DF_HAD_2SAD;
-    if( !squareOk( s.width, s.height, 4 ) || !fOk || s.org_plane > 15 || s.cur_plane > 15 || s.sub_shift > 1 || ( s.sub_shift && s.func != VVHIP_DF_SAD ) )
+    if( !shapeOk( s.width, s.height, 2, 2 ) || !fOk || s.org_plane > 15 || s.cur_plane > 15 || s.sub_shift > 1 || ( s.sub_shift && ( s.func != VVHIP_DF_SAD || s.height < 2 ) ) )
       return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: item %d (func %d, %dx%d)", i, s.func, s.width, s.height );
     itOrder[i] = i;
   }
-  auto itemKey = [&]( int i ) { const auto& s = items[i]; return ( ( long ) s.width << 16 ) | ( s.func << 8 ) | s.sub_shift; };
-  std::stable_sort( itOrder.begin(), itOrder.end(), [&]( int a, int b ) { return itemKey( a ) > itemKey( b ); } );
+  auto itemKey = [&]( int i ) { const auto& s = items[i]; return ( ( long ) s.width << 32 ) | ( ( long ) s.height << 16 ) | ( s.func << 8 ) | s.sub_shift; };
+  std::stable_sort( itOrder.begin(), itOrder.begin() + n_items, [&]( int a, int b ) { return itemKey( a ) > itemKey( b ); } );
   for( int i = 0; i < n_items; )
   {
     const vvhip_me_item& s0 = items[itOrder[i]];
     int lanesPer;
-    if( s0.func == VVHIP_DF_SAD || s0.func == VVHIP_DF_SSE ) { const int cw = s0.width >= 8 ? 8 : 4; lanesPer = ( s0.height >> ( s0.func == VVHIP_DF_SAD ? s0.sub_shift : 0 ) ) * ( s0.width / cw ); }
-    else { const bool f16 = s0.func == VVHIP_DF_HAD_FAST && ( s0.width & 31 ) == 0; const int t = s0.width == 4 ? 4 : ( f16 ? 16 : 8 ); lanesPer = ( s0.width / t ) * ( s0.height / t ) * ( t == 4 ? 1 : 8 ); }      // eight lanes per 8x8 / 16x16_fast tile
+    if( s0.func == VVHIP_DF_SAD || s0.func == VVHIP_DF_SSE ) { const int cw = s0.width >= 8 ? 8 : ( s0.width >= 4 ? 4 : 2 ); lanesPer = ( s0.height >> ( s0.func == VVHIP_DF_SAD ? s0.sub_shift : 0 ) ) * ( s0.width / cw ); }
+    else { const int kind = hadTileKind( s0.width, s0.height, s0.func == VVHIP_DF_HAD_FAST ); lanesPer = kind == TK_4x4 ? 1 : ( s0.width / tileW( kind ) ) * ( s0.height / tileH( kind ) ) * tileLanes( kind ); }
     if( lanesPer > 64 ) lanesPer = 64;
     const int perWave = std::max( 1, 64 / lanesPer );                // one pass of lane teams per wave: the items are latency-bound, waves are what overlaps them
     int count = 0;
@@ -845,13 +1006,40 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
     WaveSpan sp; sp.first = i; sp.count = count; itWaves.push_back( sp );
     i += count;
   }
+  // masked items: their waves follow (count < 0 marks them), their schedule entries and costs sit behind the plain items'
+  for( int i = 0; i < n_mask; i++ )
+  {
+    const vvhip_me_mask_item& s = mask_items[i];
+    if( !shapeOk( s.width, s.height, 2, 2 ) || s.org_plane > 15 || s.cur_plane > 15 || s.mask_plane > 15 || s.sub_shift > 1 || ( s.sub_shift && s.height < 2 ) )
+      return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: masked item %d (%dx%d)", i, s.width, s.height );
+    itOrder[n_items + i] = i;
+  }
+  auto maskKey = [&]( int i ) { const auto& s = mask_items[i]; return ( ( long ) s.width << 32 ) | ( ( long ) s.height << 16 ) | s.sub_shift; };
+  std::stable_sort( itOrder.begin() + n_items, itOrder.end(), [&]( int a, int b ) { return maskKey( a ) > maskKey( b ); } );
+  for( int i = 0; i < n_mask; )
+  {
+    const vvhip_me_mask_item& s0 = mask_items[itOrder[n_items + i]];
+    const int cw = s0.width >= 8 ? 8 : ( s0.width >= 4 ? 4 : 2 );
+    const int lanesPer = std::min( 64, ( s0.height >> s0.sub_shift ) * ( s0.width / cw ) ), perWave = std::max( 1, 64 / lanesPer );
+    int count = 0;
+    while( i + count < n_mask && count < perWave && maskKey( itOrder[n_items + i + count] ) == maskKey( itOrder[n_items + i] ) ) count++;
+    WaveSpan sp; sp.first = i; sp.count = -count; itWaves.push_back( sp );
+    i += count;
+  }
 
+  int maxPlane = 0;                                                   // the run's plane table must cover every index the lists use
+  for( int i = 0; i < n_int_jobs; i++ ) maxPlane = std::max( maxPlane, ( int ) std::max( int_jobs[i].org_plane, int_jobs[i].ref_plane ) );
+  for( int i = 0; i < n_stage_jobs; i++ ) maxPlane = std::max( maxPlane, ( int ) std::max( stage_jobs[i].org_plane, stage_jobs[i].ref_plane ) );
+  for( int i = 0; i < n_items; i++ ) maxPlane = std::max( maxPlane, ( int ) std::max( items[i].org_plane, items[i].cur_plane ) );
+  for( int i = 0; i < n_mask; i++ ) maxPlane = std::max( maxPlane, ( int ) std::max( mask_items[i].mask_plane, std::max( mask_items[i].org_plane, mask_items[i].cur_plane ) ) );
   // ---- the tables go to the device in SCHEDULE order (a wave reads its jobs at the schedule index: no order -> record indirection on the critical path of a short-lived wave;
   //      the order arrays only say where a result goes)
   std::vector<vvhip_me_stage_job> stUnits( stOrder.size() );
   for( size_t i = 0; i < stOrder.size(); i++ ) stUnits[i] = stage_jobs[stOrder[i] & 0xffffff];
   std::vector<vvhip_me_item> itSorted( n_items );
   for( int i = 0; i < n_items; i++ ) itSorted[i] = items[itOrder[i]];
+  std::vector<vvhip_me_mask_item> mkSorted( n_mask );
+  for( int i = 0; i < n_mask; i++ ) { mkSorted[i] = mask_items[itOrder[n_items + i]]; itOrder[n_items + i] += n_items; }      // (the order entry = where the cost goes)
   // ---- the interpolation tap tables the stage kernels stage into LDS: per (filter_mode, alternative half-sample filter) 16 phases x 8 window taps, then 16 phases x 4 packed
   //      tap pairs ( K0 + 2 i, K0 + 2 i + 1 ) of the tap support the table's kernel instance uses
   std::vector<int32_t> tapTab( 6 * 192, 0 );
@@ -869,16 +1057,17 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   auto pad = []( size_t b ) { return ( b + 255 ) & ~( size_t ) 255; };
   const size_t bInt = pad( ij.size() * sizeof( IntJob ) ), bCand = pad( pc.size() * sizeof( PlanCand ) ), bSt = pad( stUnits.size() * sizeof( vvhip_me_stage_job ) ),
                bStO = pad( stOrder.size() * 4 ), bStW = pad( stWaves.size() * sizeof( WaveSpan ) ), bIt = pad( ( size_t ) n_items * sizeof( vvhip_me_item ) ), bItO = pad( itOrder.size() * 4 ),
-               bItW = pad( itWaves.size() * sizeof( WaveSpan ) );
+               bItW = pad( itWaves.size() * sizeof( WaveSpan ) ), bMk = pad( mkSorted.size() * sizeof( vvhip_me_mask_item ) );
   const size_t bTap = pad( tapTab.size() * 4 );
-  const size_t total = bInt + bCand + bSt + bStO + bStW + bIt + bItO + bItW + bTap + 256;
+  const size_t total = bInt + bCand + bSt + bStO + bStW + bIt + bItO + bItW + bTap + bMk + 256;
   std::vector<char> host( total, 0 );
   size_t o = 0;
   auto put = [&]( const void* src, size_t bytes, size_t padded ) { const size_t at = o; if( bytes ) memcpy( host.data() + o, src, bytes ); o += padded; return at; };
   const size_t oInt = put( ij.data(), ij.size() * sizeof( IntJob ), bInt ), oCand = put( pc.data(), pc.size() * sizeof( PlanCand ), bCand ),
                oSt = put( stUnits.data(), stUnits.size() * sizeof( vvhip_me_stage_job ), bSt ), oStO = put( stOrder.data(), stOrder.size() * 4, bStO ),
                oStW = put( stWaves.data(), stWaves.size() * sizeof( WaveSpan ), bStW ), oIt = put( itSorted.data(), ( size_t ) n_items * sizeof( vvhip_me_item ), bIt ),
-               oItO = put( itOrder.data(), itOrder.size() * 4, bItO ), oItW = put( itWaves.data(), itWaves.size() * sizeof( WaveSpan ), bItW ), oTap = put( tapTab.data(), tapTab.size() * 4, bTap );
+               oItO = put( itOrder.data(), itOrder.size() * 4, bItO ), oItW = put( itWaves.data(), itWaves.size() * sizeof( WaveSpan ), bItW ), oTap = put( tapTab.data(), tapTab.size() * 4, bTap ),
+               oMk = put( mkSorted.data(), mkSorted.size() * sizeof( vvhip_me_mask_item ), bMk );
   vvhip_me_plan* p = new vvhip_me_plan;
   hipError_t e = hipMalloc( &p->d_blob, total );
   if( e != hipSuccess ) { delete p; return vvhip_fail( ctx, VVHIP_E_NOMEM, "vvhip_me_plan_create: hipMalloc( %zu ): %s", total, hipGetErrorString( e ) ); }
@@ -886,13 +1075,15 @@ int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int 
   if( e == hipSuccess ) e = hipStreamSynchronize( ctx->stream );
   if( e != hipSuccess ) { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: upload: %s", hipGetErrorString( e ) ); }
   char* b = static_cast<char*>( p->d_blob );
-  p->d_intJobs = b + oInt; p->d_cands = b + oCand; p->d_stageJobs = b + oSt; p->d_stageOrder = b + oStO; p->d_stageWaves = b + oStW; p->d_items = b + oIt; p->d_itemOrder = b + oItO; p->d_itemWaves = b + oItW; p->d_tapTables = b + oTap;
-  p->bitDepth = bit_depth; p->nCands = n_cands; p->nStages = n_stage_jobs; p->nItems = n_items;
+  p->d_intJobs = b + oInt; p->d_cands = b + oCand; p->d_stageJobs = b + oSt; p->d_stageOrder = b + oStO; p->d_stageWaves = b + oStW; p->d_items = b + oIt; p->d_itemOrder = b + oItO; p->d_itemWaves = b + oItW; p->d_tapTables = b + oTap; p->d_maskItems = b + oMk;
+  p->bitDepth = bit_depth; p->nCands = n_cands; p->nStages = n_stage_jobs; p->nItems = n_items; p->nMaskItems = n_mask; p->maxPlane = maxPlane;
   p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size();
   p->ldsInt = ( ldsInt + 15 ) & ~15; p->ldsStage = ( ldsStage + 15 ) & ~15;
   for( int k = 0; k < 3; k++ ) { p->stageSetWaves[k] = setWaves[k]; p->stageSetBig[k] = setBig[k]; }
   p->intBig = intBig; p->ldsIntSmall = ( ldsIntSmall + 15 ) & ~15;
-  if( p->ldsInt > 64 * 1024 || p->ldsStage > 64 * 1024 )
+  // 128-wide blocks make the large windows' LDS several times what four small windows need: their own launch then, so that the small windows keep their occupancy
+  p->intSplit = intBig > 0 && intBig < ( int ) ij.size() && p->ldsInt > 2 * 4 * p->ldsIntSmall && p->ldsInt > 32 * 1024;
+  if( p->ldsInt > 160 * 1024 || p->ldsStage > 64 * 1024 )
   { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_me_plan_create: %d / %d bytes of LDS per wave (max_window too large?)", ldsInt, ldsStage ); }
   *out = p;
   return VVHIP_OK;
@@ -948,8 +1139,9 @@ int vvhip_me_plan_run_parts( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vv
 static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_plane* planes_host, int n_planes, uint64_t* d_cand_cost, uint64_t* d_stage_cost, uint64_t* d_item_cost, int parts )
 {
   if( !ctx || !plan ) return VVHIP_E_ARG;
-  if( !planes_host || n_planes < 1 || n_planes > 16 || ( plan->nCands && !d_cand_cost ) || ( plan->nStages && !d_stage_cost ) || ( plan->nItems && !d_item_cost ) )
+  if( !planes_host || n_planes < 1 || n_planes > 16 || ( plan->nCands && !d_cand_cost ) || ( plan->nStages && !d_stage_cost ) || ( ( plan->nItems || plan->nMaskItems ) && !d_item_cost ) )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_run: bad arguments" );
+  if( plan->maxPlane >= n_planes ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_run: the plan's lists use plane %d, the table has %d", plan->maxPlane, n_planes );
   MePlanes P;
   for( int i = 0; i < 16; i++ ) { P.p[i] = planes_host[i < n_planes ? i : 0].d_base; P.stride[i] = planes_host[i < n_planes ? i : 0].stride; }
   MeArgs a;
@@ -957,6 +1149,7 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   a.stageJobs = static_cast<const vvhip_me_stage_job*>( plan->d_stageJobs ); a.stageOrder = static_cast<const int32_t*>( plan->d_stageOrder );
   a.stageWaves = static_cast<const WaveSpan*>( plan->d_stageWaves ); a.wavesStage = plan->wavesStage; a.tapTables = static_cast<const int32_t*>( plan->d_tapTables );
   a.items = static_cast<const vvhip_me_item*>( plan->d_items ); a.itemOrder = static_cast<const int32_t*>( plan->d_itemOrder ); a.itemWaves = static_cast<const WaveSpan*>( plan->d_itemWaves ); a.wavesItem = plan->wavesItem;
+  a.maskItems = static_cast<const vvhip_me_mask_item*>( plan->d_maskItems );
   a.candCost = d_cand_cost; a.stageCost = d_stage_cost; a.itemCost = d_item_cost; a.bitDepth = plan->bitDepth;
   const bool tm = plan->timing && parts == 7;
   const bool doStage = ( parts & 1 ) != 0, doInt = ( parts & 2 ) != 0, doItem = ( parts & 4 ) != 0;
@@ -976,13 +1169,19 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   {
     // one launch for both window classes (two launches of a few thousand short-lived waves each were mostly ramp-up and drain: 20.6 + 18.0 us on a recorded 1080p picture)
     const int nSmall = plan->wavesInt - plan->intBig, lds = std::max( plan->intBig ? plan->ldsInt : 0, nSmall ? 4 * plan->ldsIntSmall : 0 );
-    hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( plan->intBig + ( nSmall + 3 ) / 4 ) ), dim3( 256 ), ( size_t ) lds, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall );
+    if( plan->ldsInt > 64 * 1024 ) VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) meIntKernel, hipFuncAttributeMaxDynamicSharedMemorySize, plan->ldsInt ) );
+    if( plan->intSplit )
+    {
+      hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->intBig ), dim3( 256 ), ( size_t ) plan->ldsInt, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, 0 );
+      hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( ( nSmall + 3 ) / 4 ) ), dim3( 256 ), ( size_t ) 4 * plan->ldsIntSmall, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, plan->intBig );
+    }
+    else hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( plan->intBig + ( nSmall + 3 ) / 4 ) ), dim3( 256 ), ( size_t ) lds, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, 0 );
   }
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[2], ctx->stream ) );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[3], ctx->stream ) );
   if( plan->wavesItem && doItem )  {
-    if( plan->wavesItem <= 65536 ) hipLaunchKernelGGL( meItemKernel<4>, dim3( ( unsigned ) ( ( plan->wavesItem + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a );
-    else                           hipLaunchKernelGGL( meItemKernel<1>, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a );
+    if( plan->wavesItem <= 65536 ) hipLaunchKernelGGL( meItemKernel<4>, dim3( ( unsigned ) ( ( plan->wavesItem + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a, plan->nItems );
+    else                           hipLaunchKernelGGL( meItemKernel<1>, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a, plan->nItems );
   }
   VVHIP_LAUNCH_CHECK( ctx );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[4], ctx->stream ) );

@@ -359,13 +359,24 @@ class HotPath:
         self._ck(self.L.vvhip_tu_rdo_multi_strided(self.ctx, _ptr(d_resi), C.cast(arr, C.c_void_p), bit_depth, jobs[0], jobs[1]))
 
     # ---- motion-search plans: integer candidates + sub-pel stages + plain table calls of a picture in one launch ----
-    def me_plan_create(self, int_jobs, cands, stage_jobs, items, bit_depth=10, max_window=0):
-        """numpy record arrays (vvenc_amd/replay.py dtypes mirror vvhip_me_int_job / _cand / _stage_job / _item) -> plan handle"""
+    def me_plan_create(self, int_jobs, cands, stage_jobs, items, bit_depth=10, max_window=0, mask_items=None):
+        """numpy record arrays (vvenc_amd/replay.py dtypes mirror vvhip_me_int_job / _cand / _stage_job / _item / _mask_item) -> plan handle"""
         keep = [np.ascontiguousarray(a) for a in (int_jobs, cands, stage_jobs, items)]
         plan = C.c_void_p()
-        self._ck(self.L.vvhip_me_plan_create(self.ctx, keep[0].ctypes.data if keep[0].size else None, int(keep[0].size), keep[1].ctypes.data if keep[1].size else None, int(keep[1].size),
-                                             keep[2].ctypes.data if keep[2].size else None, int(keep[2].size), keep[3].ctypes.data if keep[3].size else None, int(keep[3].size),
-                                             bit_depth, max_window, C.byref(plan)))
+        if mask_items is None or not mask_items.size:
+            self._ck(self.L.vvhip_me_plan_create(self.ctx, keep[0].ctypes.data if keep[0].size else None, int(keep[0].size), keep[1].ctypes.data if keep[1].size else None, int(keep[1].size),
+                                                 keep[2].ctypes.data if keep[2].size else None, int(keep[2].size), keep[3].ctypes.data if keep[3].size else None, int(keep[3].size),
+                                                 bit_depth, max_window, C.byref(plan)))
+            return plan
+        keep.append(np.ascontiguousarray(mask_items))
+
+        class Lists(C.Structure):          # vvhip_me_lists
+            _fields_ = [(n, t) for k in range(5) for n, t in (("p%d" % k, C.c_void_p), ("n%d" % k, C.c_int32))]
+        L = Lists()
+        for k, a in enumerate(keep):
+            setattr(L, "p%d" % k, a.ctypes.data if a.size else None)
+            setattr(L, "n%d" % k, int(a.size))
+        self._ck(self.L.vvhip_me_plan_create_lists(self.ctx, C.cast(C.pointer(L), C.c_void_p), bit_depth, max_window, C.byref(plan)))
         return plan
 
     def me_plan_destroy(self, plan):

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "vvhip_tu_rdo_multi": (i32, [vp, vp, i32, i32, vp, i32]),
     "vvhip_tu_rdo_multi_strided": (i32, [vp, vp, vp, i32, vp, i32]),
     "vvhip_me_plan_create": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(vp)]),
+    "vvhip_me_plan_create_lists": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
     "vvhip_me_plan_destroy": (None, [vp, vp]),
     "vvhip_me_plan_run": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "vvhip_me_plan_run_parts": (i32, [vp, vp, vp, i32, vp, vp, vp, i32]),

@@ -23,7 +23,7 @@ DT = {
     "stage": np.dtype([("me", "<i4"), ("baseX", "<i4"), ("baseY", "<i4"), ("baseHor", "<i2"), ("baseVer", "<i2"), ("iFrac", "u1"), ("hadMode", "u1"), ("reduceTap", "u1"),
                        ("altHpel", "u1"), ("pad", "<i4"), ("cost", "<u8", (9,))]),
     "dist": np.dtype([("df", "u1"), ("subShift", "u1"), ("bitDepth", "u1"), ("ctx", "u1"), ("w", "<i2"), ("h", "<i2"),
-                      ("org_plane", "<i2"), ("org_pad", "<i2"), ("org_x", "<i4"), ("org_y", "<i4"), ("cur_plane", "<i2"), ("cur_pad", "<i2"), ("cur_x", "<i4"), ("cur_y", "<i4"), ("cost", "<u8")]),
+                      ("org_plane", "<i2"), ("org_pad", "<i2"), ("org_x", "<i4"), ("org_y", "<i4"), ("cur_plane", "<i2"), ("cur_pad", "<i2"), ("cur_x", "<i4"), ("cur_y", "<i4"), ("cost", "<u8"), ("maskPool", "<i4")]),
     "tu": np.dtype([("comp", "u1"), ("trHor", "u1"), ("trVer", "u1"), ("flags", "u1"), ("w", "<i2"), ("h", "<i2"), ("qp", "<i2"), ("bitDepth", "<i2"), ("x", "<i4"), ("y", "<i4"), ("pool", "<i4")]),
     "dmvr": np.dtype([("ref0Plane", "<i2"), ("ref1Plane", "<i2"), ("x0", "<i4"), ("y0", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("frac0x", "<i2"), ("frac0y", "<i2"), ("frac1x", "<i2"), ("frac1y", "<i2"),
                       ("dx", "<i2"), ("dy", "<i2"), ("mvdX", "<i2"), ("mvdY", "<i2"), ("pad", "<i4"), ("minCost", "<u8")]),

@@ -3,7 +3,10 @@
 (vvhip_tu_rdo_multi_strided) and the DMVR list (vvhip_dmvr_refine_batch), and checks the results against the costs the REAL encoder computed while it was recorded.
 
 Plane table of a picture's plan (<= 16 entries):  0..2 original Y / Cb / Cr (as the encoder's CTU copies read them), 3.. luma reconstruction of each reference picture
-(with its margin), then five views of the sample pool, one per block width 4 / 8 / 16 / 32 / 64 (pool blocks are compact: row pitch = block width).
+(with its margin), then ONE entry with stride 0 for the sample pool (compact blocks: the row pitch of a pool block is the block's width).
+
+Nothing of a recording is left out (round 4): every block shape of preset medium's CTU 128 + multi-type tree (width and height independent powers of two 2..128) goes through the
+plan, GEO's masked SADs included; `dropped` counts what could not be placed and the tests assert it is empty.
 """
 import ctypes as C
 
@@ -19,7 +22,9 @@ ME_CAND = np.dtype([("dx", "<i2"), ("dy", "<i2")])
 ME_STAGE_JOB = np.dtype([("org_off", "<i4"), ("ref_off", "<i4"), ("width", "<i2"), ("height", "<i2"), ("org_plane", "u1"), ("ref_plane", "u1"), ("i_frac", "u1"), ("filter_mode", "u1"),
                          ("alt_hpel", "u1"), ("func", "u1"), ("base_qx", "i1"), ("base_qy", "i1"), ("mask", "<u2"), ("reserved", "<u2")])
 ME_ITEM = np.dtype([("org_off", "<i4"), ("cur_off", "<i4"), ("org_plane", "u1"), ("cur_plane", "u1"), ("func", "u1"), ("sub_shift", "u1"), ("width", "<i2"), ("height", "<i2")])
-assert ME_INT_JOB.itemsize == 32 and ME_STAGE_JOB.itemsize == 24 and ME_ITEM.itemsize == 16
+ME_MASK_ITEM = np.dtype([("org_off", "<i4"), ("cur_off", "<i4"), ("mask_off", "<i4"), ("org_plane", "u1"), ("cur_plane", "u1"), ("mask_plane", "u1"), ("sub_shift", "u1"),
+                         ("width", "<i2"), ("height", "<i2"), ("reserved", "<i4")])
+assert ME_INT_JOB.itemsize == 32 and ME_STAGE_JOB.itemsize == 24 and ME_ITEM.itemsize == 16 and ME_MASK_ITEM.itemsize == 24
 
 
 class MePlane(C.Structure):
@@ -27,19 +32,25 @@ class MePlane(C.Structure):
 
 
 FAMILY_TO_FUNC = {"SSE": DF["SSE"], "SAD": DF["SAD"], "HAD": DF["HAD"], "HAD_fast": DF["HAD_fast"], "HAD_2SAD": DF["HAD_2SAD"]}
-POOL_WIDTHS = (4, 8, 16, 32, 64)
+FUNC_SAD_MASK = 5          # (host-side marker only: masked SADs are their own list of the plan)
 
 
 def _family_codes(df):
     """table index (DFunc, CommonLib/TypeDef.h:339-382) -> C ABI function code"""
     df = df.astype(np.int32)
-    out = np.full(df.shape, -1, np.int32)
+    out = np.full(df.shape, 255, np.int32)
     out[df < 8] = DF["SSE"]
     out[(df >= 8) & (df < 16)] = DF["SAD"]
     out[(df >= 16) & (df < 24)] = DF["HAD"]
     out[df == 24] = DF["HAD_2SAD"]
+    out[df == 25] = FUNC_SAD_MASK
     out[df >= 26] = DF["HAD_fast"]
     return out
+
+
+def _pow2(v):
+    v = v.astype(np.int64)
+    return (v > 0) & ((v & (v - 1)) == 0)
 
 
 class HostPlane:
@@ -66,26 +77,26 @@ class RecordedLists:
         for i in range(pic.planes.size):
             arr, m = pic.plane_array(i)
             self.planes.append(HostPlane(np.asarray(arr), m, m if m else 8))
-        self.pool = np.concatenate([np.asarray(pic.pool), np.zeros(64, np.int16)])          # (+ slack)
+        self.pool = np.concatenate([np.asarray(pic.pool), np.zeros(256, np.int16)])          # (+ slack)
         self.n_pic_planes = len(self.planes)
-        self.pool_plane = {w: self.n_pic_planes + k for k, w in enumerate(POOL_WIDTHS)}
-        assert self.n_pic_planes + len(POOL_WIDTHS) <= 16
-        self.n_planes = self.n_pic_planes + len(POOL_WIDTHS)
+        self.pool_index = self.n_pic_planes                     # ONE pool entry, stride 0: a pool block's row pitch is its own width
+        assert self.n_pic_planes + 1 <= 16
+        self.n_planes = self.n_pic_planes + 1
         strides = np.array([pl.stride for pl in self.planes], np.int64)
+        self.dropped = {}
 
         me, cand, st, d = pic.me, pic.cand, pic.stage, pic.dist
         # ---- motion-estimation jobs: original block = plane 0 at the CU, or a pool pattern (bi-prediction: 2 * org - other prediction)
-        me_w = me["w"].astype(np.int64)
         pooled = me["patternPool"] >= 0
-        me_org_plane = np.where(pooled, np.array([self.pool_plane.get(int(w), 255) for w in me["w"]], np.int64), 0)
+        me_org_plane = np.where(pooled, self.pool_index, 0)
         me_org_off = np.where(pooled, me["patternPool"].astype(np.int64), me["cuY"].astype(np.int64) * strides[0] + me["cuX"])
         ref_ok = me["refPlane"] >= 3
         me_ref_stride = np.where(ref_ok, strides[np.clip(me["refPlane"], 0, self.n_pic_planes - 1)], 0)
-        # integer candidates: SAD candidates of square 8..64 blocks go into windows; anything else (HAD of the integer refinement, odd shapes) becomes a plain item
+        shape_ok = _pow2(me["w"]) & _pow2(me["h"]) & (me["w"] <= 128) & (me["h"] <= 128)
+        # integer candidates: SAD candidates of blocks at least 8 wide go into windows; anything else (the Hadamards of the integer refinement, 4-wide blocks) becomes a plain item
         c_me = cand["me"]
         c_func = _family_codes(cand["df"])
-        c_w, c_h = me["w"][c_me], me["h"][c_me]
-        int_ok = (c_func == DF["SAD"]) & (c_w == c_h) & np.isin(c_w, (8, 16, 32, 64)) & ref_ok[c_me]
+        int_ok = (c_func == DF["SAD"]) & shape_ok[c_me] & (me["w"][c_me] >= 8) & (me["h"][c_me] >= 4) & ref_ok[c_me]
         # per ME: every candidate must share the subShift to form one job (they do: one setDistParam per search); split off the rest
         first_ss = np.zeros(me.size, np.int64)
         if cand.size:
@@ -115,9 +126,10 @@ class RecordedLists:
         self.int_jobs, self.plan_cands = jobs, pc
         self.cand_expected = cand["cost"][sel].copy()
 
-        # ---- refinement stages
+        # ---- refinement stages (any block shape; 4x4 inter blocks do not exist)
         s_me = st["me"]
-        s_ok = ref_ok[s_me] & (me["w"][s_me] == me["h"][s_me]) & np.isin(me["w"][s_me], (8, 16, 32, 64)) if st.size else np.zeros(0, bool)
+        s_ok = ref_ok[s_me] & shape_ok[s_me] & ~((me["w"][s_me] == 4) & (me["h"][s_me] == 4)) if st.size else np.zeros(0, bool)
+        self.dropped["stages"] = int((~s_ok).sum())
         ssel = np.nonzero(s_ok)[0]
         self.stage_index = ssel
         sj = np.zeros(ssel.size, ME_STAGE_JOB)
@@ -138,19 +150,19 @@ class RecordedLists:
         self.stage_jobs = sj
 
         # ---- plain table calls: the recorder's `dist` records + the integer candidates that did not fit a window job
-        def operand(plane, x, y, w):
+        def operand(plane, x, y):
             pl = plane.astype(np.int64)
             is_pool = pl < 0
             st_ = strides[np.clip(pl, 0, self.n_pic_planes - 1)]
             off = np.where(is_pool, x.astype(np.int64), y.astype(np.int64) * st_ + x)
-            pidx = np.where(is_pool, np.array([self.pool_plane.get(int(v), 255) for v in w], np.int64) if w.size else np.zeros(0, np.int64), pl)
-            return pidx, off
+            return np.where(is_pool, self.pool_index, pl), off
         items = np.zeros(d.size, ME_ITEM)
+        d_func = _family_codes(d["df"]) if d.size else np.zeros(0, np.int32)
         if d.size:
-            po, oo = operand(d["org_plane"], d["org_x"], d["org_y"], d["w"])
-            pcu, oc = operand(d["cur_plane"], d["cur_x"], d["cur_y"], d["w"])
+            po, oo = operand(d["org_plane"], d["org_x"], d["org_y"])
+            pcu, oc = operand(d["cur_plane"], d["cur_x"], d["cur_y"])
             items["org_off"], items["cur_off"], items["org_plane"], items["cur_plane"] = oo, oc, po, pcu
-            items["func"], items["sub_shift"], items["width"], items["height"] = _family_codes(d["df"]), d["subShift"], d["w"], d["h"]
+            items["func"], items["sub_shift"], items["width"], items["height"] = np.minimum(d_func, 255), d["subShift"], d["w"], d["h"]
         rest = np.nonzero(~int_ok)[0]
         extra = np.zeros(rest.size, ME_ITEM)
         if rest.size:
@@ -161,25 +173,40 @@ class RecordedLists:
             extra["width"], extra["height"] = me["w"][rm], me["h"][rm]
         all_items = np.concatenate([items, extra])
         expected = np.concatenate([d["cost"], cand["cost"][rest]]) if all_items.size else np.zeros(0, np.uint64)
-        ok = (all_items["width"] == all_items["height"]) & np.isin(all_items["width"], (4, 8, 16, 32, 64)) & (all_items["org_plane"] < 16) & (all_items["cur_plane"] < 16) & \
-             (all_items["func"] <= 4) & ((all_items["sub_shift"] == 0) | (all_items["func"] == DF["SAD"]))
-        self.items_dropped = int((~ok).sum())
-        self.items, self.item_expected = np.ascontiguousarray(all_items[ok]), expected[ok]
+        is_mask = np.concatenate([d_func == FUNC_SAD_MASK, np.zeros(rest.size, bool)]) if all_items.size else np.zeros(0, bool)
+        mask_pool = np.concatenate([d["maskPool"].astype(np.int64), np.full(rest.size, -1, np.int64)]) if all_items.size else np.zeros(0, np.int64)
+        ok = _pow2(all_items["width"]) & _pow2(all_items["height"]) & (all_items["width"] >= 2) & (all_items["height"] >= 2) & (all_items["width"] <= 128) & (all_items["height"] <= 128) & \
+            (all_items["org_plane"] < 16) & (all_items["cur_plane"] < 16) & ((all_items["sub_shift"] == 0) | (all_items["func"] == DF["SAD"]) | is_mask)
+        plain = ok & ~is_mask & (all_items["func"] <= 4)
+        masked = ok & is_mask & (mask_pool >= 0)
+        self.items_dropped = int((~(plain | masked)).sum())
+        self.dropped["table_calls"] = self.items_dropped
+        self.items, self.item_expected = np.ascontiguousarray(all_items[plain]), expected[plain]
+        mi = np.zeros(int(masked.sum()), ME_MASK_ITEM)
+        if mi.size:
+            src = all_items[masked]
+            for f in ("org_off", "cur_off", "org_plane", "cur_plane", "sub_shift", "width", "height"):
+                mi[f] = src[f]
+            mi["mask_off"], mi["mask_plane"] = mask_pool[masked], self.pool_index
+        self.mask_items, self.mask_expected = mi, expected[masked]
 
         # ---- TU lists: one job per (size, transform types); residual blocks live in the pool (pitch = width)
         tu = pic.tu
         self.tu_groups = []
+        n_tu_dropped = 0
         if tu.size:
             key = np.stack([tu["w"], tu["h"], tu["trHor"], tu["trVer"]], 1).astype(np.int64)
             uniq, inv = np.unique(key, axis=0, return_inverse=True)
             for g, (w, h, th, tv) in enumerate(uniq):
                 sel_t = np.nonzero(inv.ravel() == g)[0]
-                if w != h or int(w) not in (4, 8, 16, 32, 64):
+                if int(w) not in (2, 4, 8, 16, 32, 64) or int(h) not in (2, 4, 8, 16, 32, 64):
+                    n_tu_dropped += sel_t.size
                     continue
                 qf = np.zeros((sel_t.size, 2), np.int16)
                 qf[:, 0] = tu["qp"][sel_t]
                 qf[:, 1] = (tu["flags"][sel_t] & 1) | (((tu["flags"][sel_t] >> 1) & 1) << 1)
                 self.tu_groups.append(dict(w=int(w), h=int(h), tr_hor=int(th), tr_ver=int(tv), n=int(sel_t.size), index=sel_t, off=tu["pool"][sel_t].astype(np.int32), qf=qf))
+        self.dropped["tus"] = int(n_tu_dropped)
         self.tu_coefficients = int(sum(g["n"] * g["w"] * g["h"] for g in self.tu_groups))
         # ---- DMVR: one list per (reference 0, reference 1, sub-block size)
         self.dmvr_groups = []
@@ -196,11 +223,12 @@ class RecordedLists:
                 for f in ("frac0_x", "frac0_y", "frac1_x", "frac1_y"):
                     it[f] = dm[f.replace("_", "")][sel_d]
                 self.dmvr_groups.append(dict(r0=int(r0), r1=int(r1), dx=int(dx), dy=int(dy), n=int(sel_d.size), index=sel_d, items=it))
+        self.nothing_dropped = not any(self.dropped.values())
 
         # ---- accounting (SURVEY 8d figures per unit)
         ev_pairs = int((self.stage_evaluated.sum(1) * self.stage_jobs["width"].astype(np.int64) * self.stage_jobs["height"]).sum()) if self.stage_jobs.size else 0
         cand_pairs = int((me["w"][c_me[sel]].astype(np.int64) * me["h"][c_me[sel]]).sum()) if sel.size else 0
-        item_pairs = int((self.items["width"].astype(np.int64) * self.items["height"]).sum())
+        item_pairs = int((self.items["width"].astype(np.int64) * self.items["height"]).sum()) + int((mi["width"].astype(np.int64) * mi["height"]).sum())
         self.pairs = {"integer_candidates": cand_pairs, "subpel_positions": ev_pairs, "table_calls": item_pairs}
         rows_eff = (me["h"][c_me[sel]].astype(np.int64) >> cand["subShift"][sel]) if sel.size else np.zeros(0, np.int64)
         self.alg_bytes_me = int((4 * me["w"][c_me[sel]].astype(np.int64) * rows_eff + 8).sum()) if sel.size else 0
@@ -210,11 +238,11 @@ class RecordedLists:
             taps = np.where(self.stage_jobs["filter_mode"] == 2, 3, np.where(self.stage_jobs["filter_mode"] == 1, 5, 7)).astype(np.int64)
             w_, h_ = self.stage_jobs["width"].astype(np.int64), self.stage_jobs["height"].astype(np.int64)
             self.alg_bytes_by_kernel["ME_stage"] = int((self.stage_evaluated.sum(1) * (2 * (w_ + taps) * (h_ + taps) + 2 * w_ * h_ + 8)).sum())
-        self.alg_bytes_by_kernel["ME_item"] = int((4 * self.items["width"].astype(np.int64) * (self.items["height"].astype(np.int64) >> self.items["sub_shift"]) + 8).sum())
+        self.alg_bytes_by_kernel["ME_item"] = int((4 * self.items["width"].astype(np.int64) * (self.items["height"].astype(np.int64) >> self.items["sub_shift"]) + 8).sum()) + \
+            int((6 * mi["width"].astype(np.int64) * (mi["height"].astype(np.int64) >> mi["sub_shift"]) + 8).sum())
         self.alg_bytes_me = sum(self.alg_bytes_by_kernel.values())
         self.alg_bytes_tu = int(sum(g["n"] * (6 * g["w"] * g["h"] + 24) for g in self.tu_groups))
         self.alg_bytes_dmvr = int(sum(g["n"] * (2 * 2 * (g["dx"] + 5) * (g["dy"] + 5) + 16) for g in self.dmvr_groups))
-
 
 
 class RecordedWorkload:
@@ -224,7 +252,7 @@ class RecordedWorkload:
         lists = pic if isinstance(pic, RecordedLists) else RecordedLists(pic, bit_depth)
         self.hp, self.lists, self.pic, self.bit_depth = hp, lists, lists.pic, lists.bit_depth
         dev = hp.device
-        for k in ("n_pic_planes", "pool_plane", "n_planes", "int_jobs", "plan_cands", "cand_expected", "cand_index", "stage_jobs", "stage_index", "stage_expected", "stage_evaluated", "items",
+        for k in ("n_pic_planes", "pool_index", "n_planes", "mask_items", "mask_expected", "dropped", "nothing_dropped", "int_jobs", "plan_cands", "cand_expected", "cand_index", "stage_jobs", "stage_index", "stage_expected", "stage_evaluated", "items",
                   "item_expected", "items_dropped", "tu_coefficients", "pairs", "alg_bytes_me", "alg_bytes_by_kernel", "alg_bytes_tu", "alg_bytes_dmvr"):
             setattr(self, k, getattr(lists, k))
         self.planes = []
@@ -237,14 +265,13 @@ class RecordedWorkload:
         tab = (MePlane * 16)()
         for i, pl in enumerate(self.planes):
             tab[i] = MePlane(pl.storage.data_ptr() + 2 * pl.origin, pl.stride, 0)
-        for w, k in self.pool_plane.items():
-            tab[k] = MePlane(self.pool.data_ptr(), w, 0)
+        tab[self.pool_index] = MePlane(self.pool.data_ptr(), 0, 0)            # stride 0: compact blocks, row pitch = block width
         self.plane_table = tab
         # ---- the plan + result buffers
-        self.plan = hp.me_plan_create(self.int_jobs, self.plan_cands, self.stage_jobs, self.items, bit_depth, max_window)
+        self.plan = hp.me_plan_create(self.int_jobs, self.plan_cands, self.stage_jobs, self.items, bit_depth, max_window, mask_items=self.mask_items)
         self.cand_cost = torch.zeros(max(1, self.plan_cands.size), dtype=torch.int64, device=dev)
         self.stage_cost = torch.zeros(max(1, 9 * self.stage_jobs.size), dtype=torch.int64, device=dev)
-        self.item_cost = torch.zeros(max(1, self.items.size), dtype=torch.int64, device=dev)
+        self.item_cost = torch.zeros(max(1, self.items.size + self.mask_items.size), dtype=torch.int64, device=dev)
         self.me_info = hp.me_plan_info(self.plan)
         self._me_call = hp.bound("vvhip_me_plan_run", self.plan, C.cast(self.plane_table, C.c_void_p), self.n_planes, C.c_void_p(self.cand_cost.data_ptr()),
                                  C.c_void_p(self.stage_cost.data_ptr()), C.c_void_p(self.item_cost.data_ptr()))
@@ -319,8 +346,10 @@ class RecordedWorkload:
         out["integer_candidates"] = (int(self.plan_cands.size), int((got != self.cand_expected).sum()))
         gs = self.stage_cost.cpu().numpy().view(np.uint64)[:9 * self.stage_jobs.size].reshape(-1, 9)
         out["subpel_positions"] = (int(self.stage_evaluated.sum()), int(((gs != self.stage_expected) & self.stage_evaluated).sum()))
-        gi = self.item_cost.cpu().numpy().view(np.uint64)[:self.items.size]
-        out["table_calls"] = (int(self.items.size), int((gi != self.item_expected).sum()))
+        gi = self.item_cost.cpu().numpy().view(np.uint64)[:self.items.size + self.mask_items.size]
+        out["table_calls"] = (int(self.items.size), int((gi[:self.items.size] != self.item_expected).sum()))
+        if self.mask_items.size:
+            out["masked_sad_calls"] = (int(self.mask_items.size), int((gi[self.items.size:] != self.mask_expected).sum()))
         dm = self.pic.dmvr
         n_d = bad_d = 0
         for g in self.dmvr_groups:
