@@ -21,6 +21,14 @@
 #ifndef VVHIP_ME_HU
 #define VVHIP_ME_HU 2
 #endif
+// register budgets (waves per SIMD the compiler must make room for; 512 registers per lane and SIMD): without them the allocator takes what the default occupancy target
+// leaves (87 / 68 registers) although it needs no spill at 80 / 52 — and these kernels are short-lived waves whose latencies only more resident waves hide
+#ifndef VVHIP_ME_STAGE_WAVES
+#define VVHIP_ME_STAGE_WAVES 6
+#endif
+#ifndef VVHIP_ME_ITEM_WAVES
+#define VVHIP_ME_ITEM_WAVES 8
+#endif
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -29,12 +37,13 @@
 struct vvhip_me_plan
 {
   int bitDepth = 0, nCands = 0, nStages = 0, nItems = 0, nMaskItems = 0, maxPlane = 0;
-  int wavesInt = 0, wavesStage = 0, wavesItem = 0, ldsInt = 0, ldsStage = 0;
+  int wavesInt = 0, wavesStage = 0, wavesItem = 0, wavesItemMain = 0, ldsInt = 0, ldsStage = 0;      // wavesItemMain: the leading item waves the lean body takes (the rest: generic body, own launch)
   int intBig = 0, ldsIntSmall = 0;          // the first intBig windows need up to ldsInt bytes of LDS, the others at most ldsIntSmall (two launches: small blocks keep their occupancy)
   bool intSplit = false;                    // the large windows need far more LDS than four small ones: two launches (the small windows keep their occupancy)
   bool timing = false; hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };      // optional per-kernel events of the last run (vvhip_me_plan_set_timing)
-  int stageSetBig[3] = { 0, 0, 0 };        // of each tap support's bundles, the leading ones of 32- and 64-wide blocks (their own launch; four-wave workgroups were measured slower: 62 -> 95 us)
-  int stageSetWaves[3] = { 0, 0, 0 };      // stage bundles per tap support (4-tap search set, 6 taps / alternative half-pel, 8 taps), in schedule order
+  // stage bundles per launch class, in schedule order: class = 2 * tap support (4-tap search set, 6 taps / alternative half-pel, 8 taps) + generic (0: the square 8..64 blocks of
+  // the fast presets, every tile quantity a compile-time constant; 1: any shape)
+  int stageSetWaves[6] = { 0, 0, 0, 0, 0, 0 }, stageSetLds[6] = { 0, 0, 0, 0, 0, 0 };
   void* d_blob = nullptr;                  // one allocation: every table below
   const void* d_intJobs = nullptr; const void* d_cands = nullptr; const void* d_stageJobs = nullptr; const void* d_stageOrder = nullptr; const void* d_stageWaves = nullptr;
   const void* d_items = nullptr; const void* d_itemOrder = nullptr; const void* d_itemWaves = nullptr; const void* d_tapTables = nullptr; const void* d_maskItems = nullptr;
@@ -329,8 +338,7 @@ __host__ __device__ __forceinline__ int tileLanes( int kind ) { return ( kind ==
 
 __device__ __forceinline__ uint32_t hadNorm( uint32_t s, int kind )
 {
-  if( kind == TK_8x8 ) return ( s + 2 ) >> 2;
-  if( kind == TK_16F ) return ( ( s + 2 ) >> 2 ) << 2;
+  if( kind == TK_8x8 || kind == TK_16F ) { const uint32_t v = ( s + 2 ) >> 2; return kind == TK_16F ? v << 2 : v; }
   if( kind == TK_4x4 ) return ( s + 1 ) >> 1;
   if( kind == TK_16x8 || kind == TK_8x16 ) return ( uint32_t ) ( int ) ( ( double ) ( int ) s / __builtin_sqrt( 16.0 * 8 ) * 2 );
   if( kind == TK_8x4 || kind == TK_4x8 )   return ( uint32_t ) ( int ) ( ( double ) ( int ) s / __builtin_sqrt( 4.0 * 8 ) * 2 );
@@ -365,7 +373,9 @@ __device__ __forceinline__ uint32_t hadTeam( int ( &d )[8], int r, int LT, int k
 // a stage unit in the schedule: stage index | band of 32 rows << 24 | 64-column half << 27 | continues the previous unit's sums << 28 | the next unit continues << 29
 constexpr int ST_UNIT_CONT = 1 << 28, ST_UNIT_MORE = 1 << 29;
 
-template<int K0, int K1>
+// GEN = false: the shapes of the fast presets (CTU 64, quad-tree only) — square 8..64, tiles 8x8 / 16x16_fast / SAD rows, eight lanes per tile: every tile quantity is a
+// compile-time constant.  GEN = true: any shape (CTU 128 + multi-type tree); such units run in their own launch (their own registers, their own LDS size).
+template<int K0, int K1, bool GEN>
 __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, const WaveSpan span, int16_t* lds, uint32_t* pairCost, const int wv )
 {
   constexpr int NT = K1 - K0 + 1, NP = NT / 2, B0 = ( NT - 2 ) / 2;
@@ -440,11 +450,13 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     if( !( unit & ST_UNIT_CONT ) && tid < 9 ) costL[tid] = 0;
     // the tile type follows from the BLOCK's shape (the reference's ladder), the unit holds whole tiles of it
     // (SAD-scored stages: no transform — the lanes are dealt like an 8x8 / 8x4 tile's, or like the 4x8 tile's for a 4-wide block)
-    const int kind = j.func == VVHIP_DF_SAD ? TK_ROWS : hadTileKind( w, h, j.func == VVHIP_DF_HAD_FAST );
-    const bool rows4 = kind == TK_4x8 || ( kind == TK_ROWS && uw == 4 );                 // two rows of four samples per lane
-    const int PW = rows4 ? 4 : ( kind == TK_ROWS ? 8 : tileW( kind ) ), PH = rows4 ? 8 : ( kind == TK_ROWS ? ( BH < 8 ? BH : 8 ) : tileH( kind ) );
-    const int LT = rows4 ? 4 : ( kind == TK_ROWS ? PH : tileLanes( kind ) ), log2LT = 31 - __builtin_clz( LT );
-    const int tilesX = uw / PW, tilesB = tilesX * ( BH / PH ), log2TX = 31 - __builtin_clz( tilesX ), log2TB = 31 - __builtin_clz( tilesB );
+    const int kind = j.func == VVHIP_DF_SAD ? TK_ROWS : ( GEN ? hadTileKind( w, h, j.func == VVHIP_DF_HAD_FAST ) : ( ( j.func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 ) ? TK_16F : TK_8x8 ) );
+    const bool rows4 = GEN && ( kind == TK_4x8 || ( kind == TK_ROWS && uw == 4 ) );      // two rows of four samples per lane
+    const int log2PW = !GEN ? ( kind == TK_16F ? 4 : 3 ) : ( rows4 ? 2 : ( kind == TK_ROWS ? 3 : 31 - __builtin_clz( tileW( kind ) ) ) );
+    const int log2PH = !GEN ? ( kind == TK_16F ? 4 : 3 ) : ( rows4 ? 3 : ( kind == TK_ROWS ? ( BH < 8 ? 31 - __builtin_clz( BH ) : 3 ) : 31 - __builtin_clz( tileH( kind ) ) ) );
+    const int log2LT = !GEN ? 3 : ( rows4 ? 2 : ( kind == TK_ROWS ? log2PH : 31 - __builtin_clz( tileLanes( kind ) ) ) ), LT = 1 << log2LT;
+    // (everything is a power of two: tile counts by shifts — no integer division per unit)
+    const int log2TX = ( 31 - __builtin_clz( uw ) ) - log2PW, log2TB = log2TX + ( 31 - __builtin_clz( BH ) ) - log2PH, tilesX = 1 << log2TX, tilesB = 1 << log2TB;
     // Units of 32 and 64 columns keep ONE horizontal variant in LDS at a time (a pass = first pass of the variant, then every position that uses it: with 32-row bands a
     // position of a 64-wide unit is exactly 64 lanes of second-pass work), narrower ones all (<= 3) of them: 6 KB of LDS per wave instead of 9.5 — the kernel is
     // occupancy-bound — and half as many units for the 64x64 blocks.
@@ -560,7 +572,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       }
       else
       {
-        const int row = kind == TK_16x8 ? tyi * 8 + ( r & 7 ) : tyi * PH + r, col = kind == TK_16x8 ? txi * 16 + 8 * ( r >> 3 ) : txi * 8;
+        const int row = ( GEN && kind == TK_16x8 ) ? tyi * 8 + ( r & 7 ) : ( tyi << log2PH ) + r, col = ( GEN && kind == TK_16x8 ) ? txi * 16 + 8 * ( r >> 3 ) : txi * 8;
         const u32x4 ovv = ld16( org + ( ptrdiff_t ) ( y0 + row ) * os + col );
         uint32_t pw[4];
         predRow<K0, K1>( tvp + col, ldsPitch, row, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pw );
@@ -576,7 +588,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
         for( int i = 0; i < 8; i++ ) s += ( uint32_t ) abs( d[i] );
         sres = vvhipGroupSum32( s, LT, lane );
       }
-      else sres = hadTeam( d, r, LT, kind, lane );
+      else sres = hadTeam( d, r, GEN ? LT : 8, GEN ? kind : ( kind == TK_16F ? TK_16F : TK_8x8 ), lane );
       if( valid && r == 0 ) atomicAdd( &costL[pk & 0xff], sres );
     }
     }      // passes
@@ -606,9 +618,9 @@ __device__ __forceinline__ void maskItemBody( const MeArgs& a, const WaveSpan sp
   const int first = span.first, count = -span.count;
   const vvhip_me_mask_item f = a.maskItems[first];
   const int w = f.width, h = f.height, ss = f.sub_shift;
-  const int cw = w >= 8 ? 8 : ( w >= 4 ? 4 : 2 ), lpr = w / cw, lprShift = 31 - __builtin_clz( lpr ), rowsEff = h >> ss, chunks = rowsEff * lpr;
-  int lpc = 64; while( lpc > chunks ) lpc >>= 1;
-  const int teams = 64 / lpc, lt = lane & ( lpc - 1 ), team = lane / lpc;
+  const int cw = w >= 8 ? 8 : ( w >= 4 ? 4 : 2 ), lprShift = ( 31 - __builtin_clz( w ) ) - ( 31 - __builtin_clz( cw ) ), lpr = 1 << lprShift, rowsEff = h >> ss, chunks = rowsEff * lpr;
+  const int lpcShift = chunks >= 64 ? 6 : 31 - __builtin_clz( chunks ), lpc = 1 << lpcShift;          // lanes per item: min( 64, chunks ), a power of two
+  const int teams = 64 >> lpcShift, lt = lane & ( lpc - 1 ), team = lane >> lpcShift;
   for( int i0 = 0; i0 < count; i0 += teams )
   {
     const int ii = i0 + team;
@@ -634,6 +646,9 @@ __device__ __forceinline__ void maskItemBody( const MeArgs& a, const WaveSpan sp
   }
 }
 
+// GEN = false: what the fast presets call (and every SAD / SSE at least four samples wide): lane teams on row chunks, 8x8 / 16x16_fast tiles with eight lanes per tile, the 4x4
+// block — the round-3 body, 57 registers.  GEN = true (its own launch): the rectangular tiles, 2x2 tiles, two-sample-wide blocks, masked SADs.
+template<bool GEN>
 __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, int wave, int nItems )
 {
   // the plane table in LDS: an item's planes are per-lane indices, and a per-lane index into the kernel arguments is a memory access behind the item record — one more link
@@ -644,14 +659,14 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
   const int lane = threadIdx.x & 63;
   if( lane < 16 ) { planeL[lane] = P.p[lane]; strideL[lane] = P.stride[lane]; }      // (every wave of the workgroup writes the same values)
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
-  if( span.count < 0 ) { maskItemBody( a, span, nItems, planeL, strideL, lane ); return; }
+  if( GEN && span.count < 0 ) { maskItemBody( a, span, nItems, planeL, strideL, lane ); return; }
   const vvhip_me_item first = a.items[span.first];                                  // every item of the span has this function and geometry (the table is in schedule order)
   const int w = first.width, h = first.height, func = first.func, ss = func == VVHIP_DF_SAD ? first.sub_shift : 0;
   if( func == VVHIP_DF_SAD || func == VVHIP_DF_SSE )
   {
-    const int cw = w >= 8 ? 8 : ( w >= 4 ? 4 : 2 ), lpr = w / cw, lprShift = 31 - __builtin_clz( lpr ), rowsEff = h >> ss, chunks = rowsEff * lpr;
-    int lpc = 64; while( lpc > chunks ) lpc >>= 1;
-    const int teams = 64 / lpc, lt = lane & ( lpc - 1 ), team = lane / lpc;
+    const int cw = w >= 8 ? 8 : ( ( !GEN || w >= 4 ) ? 4 : 2 ), lprShift = ( 31 - __builtin_clz( w ) ) - ( 31 - __builtin_clz( cw ) ), lpr = 1 << lprShift, rowsEff = h >> ss, chunks = rowsEff * lpr;
+    const int lpcShift = chunks >= 64 ? 6 : 31 - __builtin_clz( chunks ), lpc = 1 << lpcShift;          // lanes per item: min( 64, chunks ), a power of two
+    const int teams = 64 >> lpcShift, lt = lane & ( lpc - 1 ), team = lane >> lpcShift;
     for( int i0 = 0; i0 < span.count; i0 += teams )
     {
       const int ii = i0 + team;
@@ -667,11 +682,11 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
       const int16_t* pa = po + ( ptrdiff_t ) ( r0 << ss ) * os + s0 * cw;
       const int16_t* pb = pc + ( ptrdiff_t ) ( r0 << ss ) * cs + s0 * cw;
       const ptrdiff_t stepA = ( ptrdiff_t ) ( rowStep << ss ) * os, stepB = ( ptrdiff_t ) ( rowStep << ss ) * cs;
-      for( int it = chunks / lpc; it > 0; it--, pa += stepA, pb += stepB )
+      for( int it = chunks >> lpcShift; it > 0; it--, pa += stepA, pb += stepB )
       {
         uint32_t va[4], vb[4];
         if( cw == 8 ) { const u32x4 x = ld16( pa ), z = ld16( pb ); va[0] = x.x; va[1] = x.y; va[2] = x.z; va[3] = x.w; vb[0] = z.x; vb[1] = z.y; vb[2] = z.z; vb[3] = z.w; }
-        else if( cw == 4 ) { const u32x2 x = ld8( pa ), z = ld8( pb ); va[0] = x.x; va[1] = x.y; va[2] = va[3] = 0; vb[0] = z.x; vb[1] = z.y; vb[2] = vb[3] = 0; }
+        else if( !GEN || cw == 4 ) { const u32x2 x = ld8( pa ), z = ld8( pb ); va[0] = x.x; va[1] = x.y; va[2] = va[3] = 0; vb[0] = z.x; vb[1] = z.y; vb[2] = vb[3] = 0; }
         else { va[0] = ld4( pa ); vb[0] = ld4( pb ); va[1] = va[2] = va[3] = 0; vb[1] = vb[2] = vb[3] = 0; }
 #pragma unroll
         for( int q = 0; q < 4; q++ )
@@ -687,8 +702,8 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
   }
   // Hadamard family: the reference's tile ladder (hadTileKind), a team of lanes per tile (table in front of hadTeam; every sample of an item is requested at once: one memory
   // latency per item), one lane per 4x4 block and per 2x2 tile.  HAD_2SAD = min( HAD, 2 SAD ) (RdCost.cpp:1768-1816; its SAD runs over all samples of the block).
-  const int kind = hadTileKind( w, h, func == VVHIP_DF_HAD_FAST );
-  if( kind == TK_4x4 )                                                   // (only the 4x4 block: 4 x N and N x 4 blocks use the 4x8 / 8x4 tiles)
+  const int kind = GEN ? hadTileKind( w, h, func == VVHIP_DF_HAD_FAST ) : ( w == 4 ? TK_4x4 : ( ( func == VVHIP_DF_HAD_FAST && ( w & 31 ) == 0 ) ? TK_16F : TK_8x8 ) );
+  if( !GEN && kind == TK_4x4 )                                           // (only the 4x4 block: 4 x N and N x 4 blocks use the 4x8 / 8x4 tiles)
   {
     const int ii = lane;
     const bool valid = ii < span.count;
@@ -712,9 +727,9 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
   uint32_t* accL = accAll[( threadIdx.x >> 6 ) & 3];
   accL[lane] = 0; accL[64 + lane] = 0;
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
-  const int PW = tileW( kind ), PH = tileH( kind ), LT = tileLanes( kind ), log2LT = 31 - __builtin_clz( LT );
-  const int tilesX = w / PW, tiles = tilesX * ( h / PH );
-  const int slotsPerItem = tiles * LT, total = span.count * slotsPerItem, log2Slots = 31 - __builtin_clz( slotsPerItem ), log2TX = 31 - __builtin_clz( tilesX );
+  const int PW = GEN ? tileW( kind ) : ( kind == TK_16F ? 16 : 8 ), PH = GEN ? tileH( kind ) : PW, LT = GEN ? tileLanes( kind ) : 8, log2LT = GEN ? 31 - __builtin_clz( LT ) : 3;
+  const int log2TX = ( 31 - __builtin_clz( w ) ) - ( 31 - __builtin_clz( PW ) ), tilesX = 1 << log2TX, log2Slots = log2TX + ( 31 - __builtin_clz( h ) ) - ( 31 - __builtin_clz( PH ) ) + log2LT;
+  const int slotsPerItem = 1 << log2Slots, total = span.count * slotsPerItem;
   for( int s0 = 0; s0 < total; s0 += 64 )
   {
     const int sl = s0 + lane;
@@ -726,7 +741,7 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
     const int16_t* qa = planeL[it.org_plane] + it.org_off + ( ptrdiff_t ) ( tyi * PH ) * os + txi * PW;
     const int16_t* qb = planeL[it.cur_plane] + it.cur_off + ( ptrdiff_t ) ( tyi * PH ) * cs + txi * PW;
     int d[8]; uint32_t sad = 0, sres;
-    if( kind == TK_2x2 )
+    if( GEN && kind == TK_2x2 )
     {
       // xCalcHADs2x2 (RdCost.cpp:1006-1026): one lane per tile
       const uint32_t x0 = ld4( qa ), x1 = ld4( qa + os ), z0 = ld4( qb ), z1 = ld4( qb + cs );
@@ -752,7 +767,7 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
 #pragma unroll
         for( int i = 0; i < 4; i++ ) d[4 + i] = ao[i] - ac[i];
       }
-      else if( kind == TK_4x8 )
+      else if( GEN && kind == TK_4x8 )
       {
         const u32x2 xa = ld8( qa + ( ptrdiff_t ) ( 2 * r ) * os ), xb = ld8( qa + ( ptrdiff_t ) ( 2 * r + 1 ) * os ), za = ld8( qb + ( ptrdiff_t ) ( 2 * r ) * cs ), zb = ld8( qb + ( ptrdiff_t ) ( 2 * r + 1 ) * cs );
         const uint32_t xw[4] = { xa.x, xa.y, xb.x, xb.y }, zw[4] = { za.x, za.y, zb.x, zb.y };
@@ -765,7 +780,7 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
       }
       else
       {
-        const int row = kind == TK_16x8 ? ( r & 7 ) : r, col = kind == TK_16x8 ? 8 * ( r >> 3 ) : 0;
+        const int row = ( GEN && kind == TK_16x8 ) ? ( r & 7 ) : r, col = ( GEN && kind == TK_16x8 ) ? 8 * ( r >> 3 ) : 0;
         const u32x4 x = ld16( qa + ( ptrdiff_t ) row * os + col ), z = ld16( qb + ( ptrdiff_t ) row * cs + col );
         const uint32_t xw[4] = { x.x, x.y, x.z, x.w }, zw[4] = { z.x, z.y, z.z, z.w };
 #pragma unroll
@@ -775,8 +790,8 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
           if( func == VVHIP_DF_HAD_2SAD ) sad = __builtin_amdgcn_sad_u16( xw[i] ^ BIAS, zw[i] ^ BIAS, sad );
         }
       }
-      sres = hadTeam( d, r, LT, kind, lane );
-      if( func == VVHIP_DF_HAD_2SAD ) sad = vvhipGroupSum32( sad, LT, lane );
+      sres = hadTeam( d, r, GEN ? LT : 8, GEN ? kind : ( kind == TK_16F ? TK_16F : TK_8x8 ), lane );
+      if( func == VVHIP_DF_HAD_2SAD ) sad = vvhipGroupSum32( sad, GEN ? LT : 8, lane );
     }
     if( valid && r == 0 ) { atomicAdd( &accL[ii], sres ); if( func == VVHIP_DF_HAD_2SAD ) atomicAdd( &accL[64 + ii], sad ); }
   }
@@ -793,14 +808,14 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
 // (one instance per tap support: the 4-tap search filter of the fast presets must not pay the registers of the 8-tap window)
 // two waves per workgroup, one bundle each: independent (wave-level synchronisation, own LDS slice) except for the two bands of a 64x64 block, which the schedule gives to
 // the two waves of one workgroup (they add their sums through LDS)
-template<int K0, int K1>
-__global__ void __launch_bounds__( 128 )
+template<int K0, int K1, bool GEN>
+__global__ void __launch_bounds__( 128 ) __attribute__( ( amdgpu_waves_per_eu( VVHIP_ME_STAGE_WAVES, VVHIP_ME_STAGE_WAVES ) ) )
 meStageKernel( MePlanes P, MeArgs a, int firstWave, int nWaves, int ldsPerWave )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t meLds[];
   __shared__ uint32_t pairCost[16];
   const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) ), wave = blockIdx.x * 2 + wv;
-  if( wave < nWaves ) stageBody<K0, K1>( P, a, a.stageWaves[firstWave + wave], meLds + wv * ( ldsPerWave >> 1 ), pairCost, wv );
+  if( wave < nWaves ) stageBody<K0, K1, GEN>( P, a, a.stageWaves[firstWave + wave], meLds + wv * ( ldsPerWave >> 1 ), pairCost, wv );
 }
 
 // workgroups 0 .. nBig - 1: one large window each (four waves share it); the others: four small windows each, one per wave
@@ -817,13 +832,13 @@ meIntKernel( MePlanes P, MeArgs a, int nBig, int ldsSmall, int blockBase )
 
 // WAVES independent waves per workgroup (wave-level synchronisation only).  A B picture's ~13 000 one-pass waves are bound by the rate workgroups start at: four per workgroup
 // 23.6 -> 21.2 us (eight: 19.2, but long lists lose: a workgroup holds its slots until its slowest wave ends — the intra picture's 168 000 waves 116 -> 129 / 143 us), so long
-// lists keep single-wave workgroups
-template<int WAVES>
-__global__ void __launch_bounds__( 64 * WAVES )
-meItemKernel( MePlanes P, MeArgs a, int nItems )
+// lists keep single-wave workgroups.  GEN: see itemBody (waves firstWave .. of the plan's item schedule)
+template<int WAVES, bool GEN>
+__global__ void __launch_bounds__( 64 * WAVES ) __attribute__( ( amdgpu_waves_per_eu( VVHIP_ME_ITEM_WAVES, VVHIP_ME_ITEM_WAVES ) ) )
+meItemKernel( MePlanes P, MeArgs a, int nItems, int firstWave, int nWaves )
 {
   const int wave = blockIdx.x * WAVES + ( int ) ( threadIdx.x >> 6 );
-  if( wave < a.wavesItem ) itemBody( P, a, wave, nItems );
+  if( wave < nWaves ) itemBody<GEN>( P, a, firstWave + wave, nItems );
 }
 
 int hostWinPitch( int winW ) { return 2 * ( ( ( winW + 3 ) >> 1 ) | 1 ); }
@@ -929,7 +944,8 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     if( !ok )
       return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: stage job %d (%dx%d, iFrac %d, mode %d, func %d, base %d,%d, mask %x)", i, s.width, s.height, s.i_frac, s.filter_mode, s.func, s.base_qx, s.base_qy, s.mask );
   }
-  auto setOf = []( const vvhip_me_stage_job& s ) { return ( s.filter_mode == 2 && !s.alt_hpel ) ? 0 : ( s.filter_mode == 0 ? 2 : 1 ); };      // which tap support the bundle's kernel instance uses
+  auto tapSetOf = []( const vvhip_me_stage_job& s ) { return ( s.filter_mode == 2 && !s.alt_hpel ) ? 0 : ( s.filter_mode == 0 ? 2 : 1 ); };      // which tap support the bundle's kernel instance uses
+  auto setOf = [&]( const vvhip_me_stage_job& s ) { const bool sq = s.width == s.height && s.width >= 8 && s.width <= 64; return 2 * tapSetOf( s ) + ( sq ? 0 : 1 ); };      // launch class
   auto unitW = []( const vvhip_me_stage_job& s ) { return std::min( ( int ) s.width, 64 ); };
   auto unitH = []( const vvhip_me_stage_job& s ) { return std::min( ( int ) s.height, 32 ); };
   auto unitsOf = [&]( const vvhip_me_stage_job& s ) { return ( s.width / unitW( s ) ) * ( s.height / unitH( s ) ); };
@@ -946,7 +962,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & 0xffffff]; const auto& y = stage_jobs[b & 0xffffff];
                     const bool px = unitsOf( x ) > 1, py = unitsOf( y ) > 1;
                     return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( px != py ? px : ( unitW( x ) != unitW( y ) ? unitW( x ) > unitW( y ) : unitWork( x ) > unitWork( y ) ) ); } );
-  int setWaves[3] = { 0, 0, 0 }, setBig[3] = { 0, 0, 0 };
+  int setWaves[6] = { 0, 0, 0, 0, 0, 0 }, setLds[6] = { 0, 0, 0, 0, 0, 0 };
   static const int bundleWork = getenv( "VVHIP_ME_BUNDLE_WORK" ) ? atoi( getenv( "VVHIP_ME_BUNDLE_WORK" ) ) : 160;      // measured on the recorded 1080p lists: 80 / 160 / 320 / 640 / 1280 -> 59.0 / 58.7 / 61.9 / 67.9 / 71.1 us
   for( size_t i = 0; i < stOrder.size(); )
   {
@@ -962,14 +978,15 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
       }
     WaveSpan sp; sp.first = ( int32_t ) i; sp.count = count; stWaves.push_back( sp );
     setWaves[setOf( s0 )]++;
-    if( s0.width >= 32 ) setBig[setOf( s0 )]++;
-    const int bh = unitH( s0 ), nt = setOf( s0 ) == 0 ? 4 : ( setOf( s0 ) == 1 ? 6 : 8 ), uw = std::max( 8, unitW( s0 ) ), vpp = unitW( s0 ) <= 16 ? 3 : 1;
-    ldsStage = std::max( ldsStage, ( 2 * ( 128 + 64 + 16 + 16 ) + vpp * ( bh + nt ) * ( uw + 8 ) ) * 2 );      // tables + the first-pass bands a pass holds (row pitch unit width + 8)
+    const int bh = unitH( s0 ), nt = tapSetOf( s0 ) == 0 ? 4 : ( tapSetOf( s0 ) == 1 ? 6 : 8 ), uw = std::max( 8, unitW( s0 ) ), vpp = unitW( s0 ) <= 16 ? 3 : 1;
+    const int ldsUnit = ( 2 * ( 128 + 64 + 16 + 16 ) + vpp * ( bh + nt ) * ( uw + 8 ) ) * 2;      // tables + the first-pass bands a pass holds (row pitch unit width + 8)
+    setLds[setOf( s0 )] = std::max( setLds[setOf( s0 )], ( ldsUnit + 15 ) & ~15 );
+    ldsStage = std::max( ldsStage, ldsUnit );
     i += count;
   }
 
   // the kernel relies on it: the two halves of a shared stage's units are the waves 2g, 2g + 1 of their tap support's launch
-  for( int k = 0, first = 0; k < 3; first += setWaves[k], k++ )
+  for( int k = 0, first = 0; k < 6; first += setWaves[k], k++ )
     for( int w = 0; w < setWaves[k]; w++ )
     {
       const WaveSpan& sp = stWaves[first + w];
@@ -991,8 +1008,12 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
       return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: item %d (func %d, %dx%d)", i, s.func, s.width, s.height );
     itOrder[i] = i;
   }
-  auto itemKey = [&]( int i ) { const auto& s = items[i]; return ( ( long ) s.width << 32 ) | ( ( long ) s.height << 16 ) | ( s.func << 8 ) | s.sub_shift; };
+  // the generic body's items (rectangular Hadamard tiles, 2x2 tiles, two-sample-wide blocks) behind the others: their waves are a launch of their own
+  auto itemGen = [&]( int i ) { const auto& s = items[i]; if( s.func == VVHIP_DF_SAD || s.func == VVHIP_DF_SSE ) return s.width < 4;
+                                const int kind = hadTileKind( s.width, s.height, s.func == VVHIP_DF_HAD_FAST ); return !( kind == TK_8x8 || kind == TK_16F || ( kind == TK_4x4 && s.width == 4 && s.height == 4 ) ); };
+  auto itemKey = [&]( int i ) { const auto& s = items[i]; return ( itemGen( i ) ? 0l : 1l << 48 ) | ( ( long ) s.width << 32 ) | ( ( long ) s.height << 16 ) | ( s.func << 8 ) | s.sub_shift; };
   std::stable_sort( itOrder.begin(), itOrder.begin() + n_items, [&]( int a, int b ) { return itemKey( a ) > itemKey( b ); } );
+  int wavesItemMain = 0;
   for( int i = 0; i < n_items; )
   {
     const vvhip_me_item& s0 = items[itOrder[i]];
@@ -1004,6 +1025,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     int count = 0;
     while( i + count < n_items && count < perWave && itemKey( itOrder[i + count] ) == itemKey( itOrder[i] ) ) count++;
     WaveSpan sp; sp.first = i; sp.count = count; itWaves.push_back( sp );
+    if( !itemGen( itOrder[i] ) ) wavesItemMain = ( int ) itWaves.size();
     i += count;
   }
   // masked items: their waves follow (count < 0 marks them), their schedule entries and costs sit behind the plain items'
@@ -1077,9 +1099,9 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   char* b = static_cast<char*>( p->d_blob );
   p->d_intJobs = b + oInt; p->d_cands = b + oCand; p->d_stageJobs = b + oSt; p->d_stageOrder = b + oStO; p->d_stageWaves = b + oStW; p->d_items = b + oIt; p->d_itemOrder = b + oItO; p->d_itemWaves = b + oItW; p->d_tapTables = b + oTap; p->d_maskItems = b + oMk;
   p->bitDepth = bit_depth; p->nCands = n_cands; p->nStages = n_stage_jobs; p->nItems = n_items; p->nMaskItems = n_mask; p->maxPlane = maxPlane;
-  p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size();
+  p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size(); p->wavesItemMain = wavesItemMain;
   p->ldsInt = ( ldsInt + 15 ) & ~15; p->ldsStage = ( ldsStage + 15 ) & ~15;
-  for( int k = 0; k < 3; k++ ) { p->stageSetWaves[k] = setWaves[k]; p->stageSetBig[k] = setBig[k]; }
+  for( int k = 0; k < 6; k++ ) { p->stageSetWaves[k] = setWaves[k]; p->stageSetLds[k] = setLds[k]; }
   p->intBig = intBig; p->ldsIntSmall = ( ldsIntSmall + 15 ) & ~15;
   // 128-wide blocks make the large windows' LDS several times what four small windows need: their own launch then, so that the small windows keep their occupancy
   p->intSplit = intBig > 0 && intBig < ( int ) ij.size() && p->ldsInt > 2 * 4 * p->ldsIntSmall && p->ldsInt > 32 * 1024;
@@ -1157,13 +1179,16 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   int firstWave = 0;
   static const int ldsPadExp = getenv( "VVHIP_ME_LDS_PAD" ) ? atoi( getenv( "VVHIP_ME_LDS_PAD" ) ) : 0;      // experiment: occupancy sensitivity of the stage kernel
   constexpr int stW = 2;                                                                // waves per workgroup (see meStageKernel)
-  const size_t ldsSt = ( ( size_t ) plan->ldsStage + ldsPadExp + 15 ) & ~( size_t ) 15;
-  // (one launch per tap support: bundles of 32- / 64-wide blocks first; splitting them from the small blocks' bundles or giving them four-wave workgroups was measured slower)
-  if( plan->stageSetWaves[0] && doStage ) hipLaunchKernelGGL( ( meStageKernel<2, 5> ), dim3( ( unsigned ) ( ( plan->stageSetWaves[0] + stW - 1 ) / stW ) ), dim3( 64 * stW ), ( size_t ) stW * ldsSt, ctx->stream, P, a, firstWave, plan->stageSetWaves[0], ( int ) ldsSt );
-  firstWave += plan->stageSetWaves[0];
-  if( plan->stageSetWaves[1] && doStage ) hipLaunchKernelGGL( ( meStageKernel<1, 6> ), dim3( ( unsigned ) ( ( plan->stageSetWaves[1] + stW - 1 ) / stW ) ), dim3( 64 * stW ), ( size_t ) stW * ldsSt, ctx->stream, P, a, firstWave, plan->stageSetWaves[1], ( int ) ldsSt );
-  firstWave += plan->stageSetWaves[1];
-  if( plan->stageSetWaves[2] && doStage ) hipLaunchKernelGGL( ( meStageKernel<0, 7> ), dim3( ( unsigned ) ( ( plan->stageSetWaves[2] + stW - 1 ) / stW ) ), dim3( 64 * stW ), ( size_t ) stW * ldsSt, ctx->stream, P, a, firstWave, plan->stageSetWaves[2], ( int ) ldsSt );
+  // one launch per class (tap support x fast-preset shapes / any shape), each with the LDS its own units need; inside a class: shared stages first, then by unit width
+  // (splitting the wide blocks' bundles from the small blocks' or giving them four-wave workgroups was measured slower)
+#define ME_STAGE_LAUNCH( CLS, K0, K1, GEN ) \
+  if( plan->stageSetWaves[CLS] && doStage ) { const size_t ldsSt = ( ( size_t ) plan->stageSetLds[CLS] + ldsPadExp + 15 ) & ~( size_t ) 15; \
+    hipLaunchKernelGGL( ( meStageKernel<K0, K1, GEN> ), dim3( ( unsigned ) ( ( plan->stageSetWaves[CLS] + stW - 1 ) / stW ) ), dim3( 64 * stW ), ( size_t ) stW * ldsSt, ctx->stream, P, a, firstWave, plan->stageSetWaves[CLS], ( int ) ldsSt ); } \
+  firstWave += plan->stageSetWaves[CLS];
+  ME_STAGE_LAUNCH( 0, 2, 5, false ) ME_STAGE_LAUNCH( 1, 2, 5, true )
+  ME_STAGE_LAUNCH( 2, 1, 6, false ) ME_STAGE_LAUNCH( 3, 1, 6, true )
+  ME_STAGE_LAUNCH( 4, 0, 7, false ) ME_STAGE_LAUNCH( 5, 0, 7, true )
+#undef ME_STAGE_LAUNCH
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[1], ctx->stream ) );
   if( plan->wavesInt && doInt )
   {
@@ -1179,9 +1204,19 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   }
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[2], ctx->stream ) );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[3], ctx->stream ) );
-  if( plan->wavesItem && doItem )  {
-    if( plan->wavesItem <= 65536 ) hipLaunchKernelGGL( meItemKernel<4>, dim3( ( unsigned ) ( ( plan->wavesItem + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a, plan->nItems );
-    else                           hipLaunchKernelGGL( meItemKernel<1>, dim3( ( unsigned ) plan->wavesItem ), dim3( 64 ), 0, ctx->stream, P, a, plan->nItems );
+  if( plan->wavesItem && doItem )
+  {
+    const int nMain = plan->wavesItemMain, nGen = plan->wavesItem - nMain;
+    if( nMain )
+    {
+      if( nMain <= 65536 ) hipLaunchKernelGGL( ( meItemKernel<4, false> ), dim3( ( unsigned ) ( ( nMain + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a, plan->nItems, 0, nMain );
+      else                 hipLaunchKernelGGL( ( meItemKernel<1, false> ), dim3( ( unsigned ) nMain ), dim3( 64 ), 0, ctx->stream, P, a, plan->nItems, 0, nMain );
+    }
+    if( nGen )
+    {
+      if( nGen <= 65536 ) hipLaunchKernelGGL( ( meItemKernel<4, true> ), dim3( ( unsigned ) ( ( nGen + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a, plan->nItems, nMain, nGen );
+      else                hipLaunchKernelGGL( ( meItemKernel<1, true> ), dim3( ( unsigned ) nGen ), dim3( 64 ), 0, ctx->stream, P, a, plan->nItems, nMain, nGen );
+    }
   }
   VVHIP_LAUNCH_CHECK( ctx );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[4], ctx->stream ) );

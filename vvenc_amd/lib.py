@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvvenc_hip.so")
+LIB_PATH = os.environ.get("VVHIP_LIB") or os.path.join(HERE, "libvvenc_hip.so")          # ($VVHIP_LIB: A/B measurements against another build of the library)
 
 
 class VVHipError(RuntimeError):
