@@ -28,6 +28,8 @@
 #include <array>
 #include <mutex>
 #include <thread>
+#include <sched.h>
+#include <pthread.h>
 #include <condition_variable>
 #include <functional>
 #include <algorithm>
@@ -752,10 +754,22 @@ API double vvref_run_jobs_mt( const int16_t* org, int orgStride, const int16_t* 
       }
   };
   worker( passes, passes + 1 );      // warm-up pass on the calling thread (also initialises the lazily built statics before threads start)
+  // $VVREF_PIN: worker t stays on the t-th CPU of the process's affinity mask (a timing that does not depend on where the scheduler puts 16 threads on a 256-CPU host)
+  std::vector<int> cpus;
+  if( getenv( "VVREF_PIN" ) && atoi( getenv( "VVREF_PIN" ) ) )
+  {
+    cpu_set_t set; CPU_ZERO( &set );
+    if( sched_getaffinity( 0, sizeof( set ), &set ) == 0 ) for( int c = 0; c < CPU_SETSIZE; c++ ) if( CPU_ISSET( c, &set ) ) cpus.push_back( c );
+  }
+  auto pinned = [&]( int t, int pass0, int pass1 )
+  {
+    if( ( int ) cpus.size() >= threads ) { cpu_set_t one; CPU_ZERO( &one ); CPU_SET( cpus[( size_t ) t * ( cpus.size() / threads )], &one ); pthread_setaffinity_np( pthread_self(), sizeof( one ), &one ); }
+    worker( pass0, pass1 );
+  };
   std::vector<std::thread> th;
   th.reserve( threads );
   const auto t0 = std::chrono::steady_clock::now();
-  for( int t = 0; t < threads; t++ ) th.emplace_back( worker, 0, passes );
+  for( int t = 0; t < threads; t++ ) th.emplace_back( pinned, t, 0, passes );
   for( auto& x : th ) x.join();
   return std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
 }
@@ -1049,10 +1063,22 @@ API double vvref_run_recorded_mt( const RecJob* jobs, int nJobs, int bitDepth, i
       }
   };
   worker( passes, passes + 1 );      // warm-up pass on the calling thread (also initialises the lazily built statics before threads start)
+  // $VVREF_PIN: worker t stays on the t-th CPU of the process's affinity mask (a timing that does not depend on where the scheduler puts 16 threads on a 256-CPU host)
+  std::vector<int> cpus;
+  if( getenv( "VVREF_PIN" ) && atoi( getenv( "VVREF_PIN" ) ) )
+  {
+    cpu_set_t set; CPU_ZERO( &set );
+    if( sched_getaffinity( 0, sizeof( set ), &set ) == 0 ) for( int c = 0; c < CPU_SETSIZE; c++ ) if( CPU_ISSET( c, &set ) ) cpus.push_back( c );
+  }
+  auto pinned = [&]( int t, int pass0, int pass1 )
+  {
+    if( ( int ) cpus.size() >= threads ) { cpu_set_t one; CPU_ZERO( &one ); CPU_SET( cpus[( size_t ) t * ( cpus.size() / threads )], &one ); pthread_setaffinity_np( pthread_self(), sizeof( one ), &one ); }
+    worker( pass0, pass1 );
+  };
   std::vector<std::thread> th;
   th.reserve( threads );
   const auto t0 = std::chrono::steady_clock::now();
-  for( int t = 0; t < threads; t++ ) th.emplace_back( worker, 0, passes );
+  for( int t = 0; t < threads; t++ ) th.emplace_back( pinned, t, 0, passes );
   for( auto& x : th ) x.join();
   return std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
 }

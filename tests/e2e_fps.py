@@ -37,6 +37,45 @@ def synth_clip(width, height, frames, seed=1080):
     return y, u, v
 
 
+def synth_clip_chunk(width, height, first, frames, seed=1080):
+    """frames first .. first + frames - 1 of ONE long sequence of the same generator (pan and object keep moving; the per-frame noise is seeded per frame, so any chunk can be
+    produced on its own): the GOP chunks the N encoder instances of bench.py --gpus N encode"""
+    cache = os.path.join("/tmp", "vvhip_chunk_%dx%d_%d_%d_%d.npz" % (width, height, first, frames, seed))
+    if os.path.exists(cache):
+        try:
+            d = np.load(cache)
+            return d["y"], d["u"], d["v"]
+        except Exception:
+            pass
+    rng = np.random.default_rng(seed)
+    pad = 64 + 8 * (first + frames)
+    yy, xx = np.mgrid[0:height + 64 + 8 * frames, 0:width + 64 + 8 * frames]
+    yy, xx = yy + first, xx + 3 * first                           # the window of the endless texture this chunk pans over
+    base = 512 + 180 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 120 * np.sin((xx + yy) / 11.0) + 60 * np.sin(xx / 3.1) * np.sin(yy / 4.3)
+    obj = 700 + 150 * np.sin(np.mgrid[0:128, 0:128][1] / 5.0)
+    ys, us, vs = [], [], []
+    for k in range(frames):
+        t = first + k
+        fr = np.random.default_rng([seed, t])
+        f = base[k:k + height, 3 * k:3 * k + width] + fr.normal(0, 12, (height, width))
+        oy, ox = (100 + 2 * t) % (height - 128), (200 + 7 * t) % (width - 128)
+        f[oy:oy + 128, ox:ox + 128] = obj
+        f = np.clip(f + fr.normal(0, 3, f.shape), 0, 1023)
+        ys.append(f)
+        sub = f[::2, ::2]
+        us.append(np.clip(512 + 0.2 * (sub - 512), 0, 1023))
+        vs.append(np.clip(512 - 0.15 * (sub - 512), 0, 1023))
+    g = lambda a: np.ascontiguousarray(np.stack(a).astype(np.int16))
+    y, u, v = g(ys), g(us), g(vs)
+    try:
+        tmp = cache + ".%d.tmp.npz" % os.getpid()
+        np.savez(tmp, y=y, u=u, v=v)
+        os.replace(tmp, cache)
+    except Exception:
+        pass
+    return y, u, v
+
+
 def _synth_clip(width, height, frames, seed):
     rng = np.random.default_rng(seed)
     pad = 64 + 8 * frames
@@ -68,7 +107,7 @@ L = E.load(cfg["mask"] != 0)
 if cfg["mask"]:
     import torch  # one HIP runtime in the process
     assert L.vvref_install_hip_hooks(cfg["mask"]) == 0
-yuv = F.synth_clip(cfg["w"], cfg["h"], cfg["frames"])
+yuv = F.synth_clip_chunk(cfg["w"], cfg["h"], cfg["first"], cfg["frames"]) if "first" in cfg else F.synth_clip(cfg["w"], cfg["h"], cfg["frames"])
 md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], 10, 10, threads=cfg["threads"], preset=E.PRESETS[cfg.get("preset", "faster")])
 calls = None
 if cfg["mask"]:
@@ -80,8 +119,8 @@ print(json.dumps(out))
 ''' % os.path.join(ROOT, "tests")
 
 
-def run(cfg, timeout=3000):
-    r = subprocess.run([sys.executable, "-c", WORKER, json.dumps(cfg)], capture_output=True, text=True, timeout=timeout)
+def run(cfg, timeout=3000, env=None):
+    r = subprocess.run([sys.executable, "-c", WORKER, json.dumps(cfg)], capture_output=True, text=True, timeout=timeout, env=env)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-3000:])
     return json.loads(r.stdout.strip().splitlines()[-1])

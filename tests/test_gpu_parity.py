@@ -1083,3 +1083,7 @@ def test_bench_multi_rank_path_on_one_device(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["exchange"]["pictures"] >= 8 and d["exchange"]["bytes_per_rank"] > 0, d
     assert d["parity"]["status"] == "bit-exact", d["parity"]
+    # the metric's N-GPU form: one encoder instance per rank on its own GPU (here: both on the one GPU), GOP chunks of one sequence, CPU kernels vs --SIMD=HIP
+    inst = d["e2e_instances"]
+    assert inst["instances"] == 2 and inst["chunk_bitstreams_identical"] is True and inst["cpu_fps_aggregate"] > 0 and inst["hip_fps_aggregate"] > 0, inst
+    assert len({p["md5"] for p in inst["per_instance"]}) == 2, inst          # two different chunks

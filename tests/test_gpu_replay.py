@@ -206,6 +206,17 @@ def test_recorded_lists_1080p_layers(hp, tmp_path):
     assert 40 < pairs < 70, pairs                                    # ~54 x 1.5 W H sample pairs per B picture
 
 
+def test_recorded_lists_4k_layers(hp, tmp_path):
+    """BASELINE configs[2] geometry: the six layer pictures of the 3840x2160 x 65 preset-faster encode that bench.py's 4K pass replays (`value_4k`): bit-exact against the
+    encoder's recorded costs and the reference's TU entries"""
+    sys.path.insert(0, ROOT)
+    import bench
+    pics = _record(tmp_path, 3840, 2160, 65, pocs=sorted(bench.LAYER_POCS.values()))
+    assert len(pics) == 6
+    tot = _replay_and_check(hp, pics)
+    assert tot["integer_candidates"] > 500000 and tot["subpel_positions"] > 100000 and tot["table_calls"] > 1000000 and tot["tus"] > 200000, tot
+
+
 # ---------------------------------------------------------------------------------------------------------------- corners named by VERDICT r2
 WAVEFRONT = r'''
 import sys, json

@@ -47,7 +47,10 @@ dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* 
   struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
   struct __attribute__( ( packed, aligned( 2 ) ) ) U4 { uint32_t v; };
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int blk = blockIdx.x * 4 + wv;
+  // workgroups are dealt round-robin to the 8 XCDs: XCD x takes the x-th contiguous eighth of the list (a caller's list is in picture order: every private L2 then streams one
+  // band of the two reference planes instead of sub-blocks from the whole picture; results do not depend on it)
+  const int q = ( int ) gridDim.x >> 3, g = ( int ) blockIdx.x < ( q << 3 ) ? ( ( int ) blockIdx.x & 7 ) * q + ( ( int ) blockIdx.x >> 3 ) : ( int ) blockIdx.x;
+  const int blk = g * 4 + wv;
   if( blk >= n ) return;                                   // whole waves leave together; no workgroup barrier below
   const vvhip_dmvr_item it = items[blk];
   const int bw = dx + 4, bh = dy + 4, segs = ( bw + 7 ) >> 3;

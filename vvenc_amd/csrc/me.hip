@@ -841,6 +841,26 @@ meItemKernel( MePlanes P, MeArgs a, int nItems, int firstWave, int nWaves )
   if( wave < nWaves ) itemBody<GEN>( P, a, firstWave + wave, nItems );
 }
 
+// XCD-aware order of a launch's workgroups.  Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MB L2.  The entries of a class —
+// `group` consecutive schedule entries are one workgroup — are sorted by their position in the picture (raster order of the reference offset = horizontal bands); workgroup
+// `base + l` of the launch sits on XCD ( base + l ) % 8 and is handed the next entry of the ( ( base + l ) % 8 )-th contiguous eighth of the class: every L2 streams one band of
+// the planes instead of blocks from the whole picture.  perm[l] = which sorted workgroup runs as the l-th of the class.
+std::vector<int> xcdBandOrder( int nGroups, int base )
+{
+  std::vector<int> perm( nGroups );
+  const int q = ( nGroups + 7 ) / 8;
+  int cursor[8], endOf[8];
+  for( int x = 0; x < 8; x++ ) { cursor[x] = std::min( nGroups, x * q ); endOf[x] = std::min( nGroups, ( x + 1 ) * q ); }
+  for( int l = 0; l < nGroups; l++ )
+  {
+    int x = ( base + l ) & 7;
+    for( int t = 0; t < 8 && cursor[x] >= endOf[x]; t++ ) x = ( x + 1 ) & 7;      // (uneven split: a finished eighth borrows from its neighbour)
+    perm[l] = cursor[x]++;
+  }
+  return perm;
+}
+bool xcdBandOn() { static const bool on = !( getenv( "VVHIP_ME_XCD_BAND" ) && atoi( getenv( "VVHIP_ME_XCD_BAND" ) ) == 0 ); return on; }
+
 int hostWinPitch( int winW ) { return 2 * ( ( ( winW + 3 ) >> 1 ) | 1 ); }
 int hostWinSamples( int winW, int winH ) { return ( winH * hostWinPitch( winW ) + 7 ) & ~7; }      // the window part of a job's LDS, in samples (the original block behind it is 16-byte aligned)
 
@@ -918,10 +938,30 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   // windows that need much LDS first (their own launch), inside each class heaviest first
   auto ldsOf = []( const IntJob& j ) { return ( hostWinSamples( j.winW, j.winH ) + ( j.h >> j.subShift ) * j.w ) * 2 + j.nCand * ( int ) sizeof( PlanCand ); };      // window + original + candidate records
   const int ldsSmallCap = 6 * 1024;
+  const bool band = xcdBandOn();
   std::stable_sort( ij.begin(), ij.end(), [&]( const IntJob& a, const IntJob& b ) { const bool ba = ldsOf( a ) > ldsSmallCap, bb = ldsOf( b ) > ldsSmallCap; if( ba != bb ) return ba;
+                    if( band ) return a.refOff < b.refOff;                                    // picture order inside a class: see xcdBandOrder
                     return ( long ) a.nCand * a.w * ( a.h >> a.subShift ) + ( long ) a.winW * a.winH > ( long ) b.nCand * b.w * ( b.h >> b.subShift ) + ( long ) b.winW * b.winH; } );
   int intBig = 0, ldsIntSmall = 0;
   for( const IntJob& j : ij ) { if( ldsOf( j ) > ldsSmallCap ) intBig++; else ldsIntSmall = std::max( ldsIntSmall, ldsOf( j ) ); }
+  if( band && !ij.empty() )
+  {
+    // workgroups: one large window each, then four small windows each (meIntKernel).  Inside an XCD's eighth the heaviest jobs start first (a band's planes fit the L2 whatever
+    // the order inside it, and a raster search's windows are far heavier than a diamond's: in plain picture order the launch ended on a tail of them — 30.7 -> 34.9 us)
+    auto weightOf = []( const IntJob& j ) { return ( long ) j.nCand * j.w * ( j.h >> j.subShift ) + ( long ) j.winW * j.winH; };
+    auto heavyFirstPerEighth = [&]( int begin, int n, int per ) { const int q = ( ( n + per - 1 ) / per + 7 ) / 8 * per;
+      for( int x = 0; x < 8 && q; x++ ) { const int a = std::min( n, x * q ), b = std::min( n, ( x + 1 ) * q );
+        std::stable_sort( ij.begin() + begin + a, ij.begin() + begin + b, [&]( const IntJob& u, const IntJob& v ) { return weightOf( u ) > weightOf( v ); } ); } };
+    heavyFirstPerEighth( 0, intBig, 1 );
+    heavyFirstPerEighth( intBig, ( int ) ij.size() - intBig, 4 );
+    std::vector<IntJob> src( ij );
+    const std::vector<int> pb = xcdBandOrder( intBig, 0 );
+    for( int l = 0; l < intBig; l++ ) ij[l] = src[pb[l]];
+    const int nSmall = ( int ) src.size() - intBig, nGr = ( nSmall + 3 ) / 4;
+    const std::vector<int> ps = xcdBandOrder( nGr, intBig );
+    for( int l = 0, o = intBig; l < nGr; l++ ) for( int k = 0; k < 4 && ps[l] * 4 + k < nSmall; k++ ) ij[o++] = src[intBig + ps[l] * 4 + k];
+    // (a short last group may land in the middle: the groups behind it then start up to three jobs early — any four consecutive jobs are a valid workgroup)
+  }
 
   // ---- stage units: (stage, band of <= 32 rows, half of <= 64 columns); a wave takes a bundle of units of one unit width and tap support worth ~160 second-pass row groups.
   //      A stage of several units (h > 32 or w > 64) is shared by the two waves of ONE workgroup, half of its units each.
@@ -961,7 +1001,10 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   // per tap support: the stages of several units first (their waves must be the pairs 2g, 2g + 1 of the launch), then by unit width and work
   std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & 0xffffff]; const auto& y = stage_jobs[b & 0xffffff];
                     const bool px = unitsOf( x ) > 1, py = unitsOf( y ) > 1;
-                    return setOf( x ) != setOf( y ) ? setOf( x ) < setOf( y ) : ( px != py ? px : ( unitW( x ) != unitW( y ) ? unitW( x ) > unitW( y ) : unitWork( x ) > unitWork( y ) ) ); } );
+                    if( setOf( x ) != setOf( y ) ) return setOf( x ) < setOf( y );
+                    if( px != py ) return px;
+                    if( unitW( x ) != unitW( y ) ) return unitW( x ) > unitW( y );
+                    return band ? x.ref_off < y.ref_off : unitWork( x ) > unitWork( y ); } );      // picture order inside a sub-class (xcdBandOrder) / heaviest first
   int setWaves[6] = { 0, 0, 0, 0, 0, 0 }, setLds[6] = { 0, 0, 0, 0, 0, 0 };
   static const int bundleWork = getenv( "VVHIP_ME_BUNDLE_WORK" ) ? atoi( getenv( "VVHIP_ME_BUNDLE_WORK" ) ) : 160;      // measured on the recorded 1080p lists: 80 / 160 / 320 / 640 / 1280 -> 59.0 / 58.7 / 61.9 / 67.9 / 71.1 us
   for( size_t i = 0; i < stOrder.size(); )
@@ -985,6 +1028,26 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     i += count;
   }
 
+  if( band )
+  {
+    // per launch class and sub-class (shared stages / unit width): the workgroups (wave pairs) in XCD-band order
+    std::vector<WaveSpan> src( stWaves );
+    for( int k = 0, first = 0; k < 6; first += setWaves[k], k++ )
+    {
+      auto subOf = [&]( int w ) { const vvhip_me_stage_job& s = stage_jobs[stOrder[src[first + w].first] & 0xffffff]; return ( unitsOf( s ) > 1 ? 1024 : 0 ) + unitW( s ); };
+      for( int w0 = 0; w0 < setWaves[k]; )
+      {
+        int w1 = w0;
+        while( w1 < setWaves[k] && subOf( w1 ) == subOf( w0 ) ) w1++;
+        {
+          const int a0 = ( w0 + 1 ) & ~1, nGr = ( w1 - a0 ) / 2;      // whole workgroups of the sub-class (one that starts on an odd wave shares its first workgroup with the previous sub-class; shared stages come first and are pairs)
+          const std::vector<int> pm = xcdBandOrder( std::max( nGr, 0 ), a0 / 2 );
+          for( int l = 0; l < nGr; l++ ) { stWaves[first + a0 + 2 * l] = src[first + a0 + 2 * pm[l]]; stWaves[first + a0 + 2 * l + 1] = src[first + a0 + 2 * pm[l] + 1]; }
+        }
+        w0 = w1;
+      }
+    }
+  }
   // the kernel relies on it: the two halves of a shared stage's units are the waves 2g, 2g + 1 of their tap support's launch
   for( int k = 0, first = 0; k < 6; first += setWaves[k], k++ )
     for( int w = 0; w < setWaves[k]; w++ )
@@ -1027,6 +1090,23 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     WaveSpan sp; sp.first = i; sp.count = count; itWaves.push_back( sp );
     if( !itemGen( itOrder[i] ) ) wavesItemMain = ( int ) itWaves.size();
     i += count;
+  }
+  if( band && wavesItemMain <= 65536 )      // (four-wave workgroups; the long lists of an intra picture run one wave per workgroup in list order)
+  {
+    std::vector<WaveSpan> src( itWaves );
+    auto keyOfWave = [&]( int w ) { return itemKey( itOrder[src[w].first] ); };
+    for( int w0 = 0; w0 < wavesItemMain; )
+    {
+      int w1 = w0;
+      while( w1 < wavesItemMain && keyOfWave( w1 ) == keyOfWave( w0 ) ) w1++;
+      const int a0 = ( w0 + 3 ) & ~3, nGr = ( w1 - a0 ) / 4;      // whole workgroups inside the class
+      if( nGr > 8 )
+      {
+        const std::vector<int> pm = xcdBandOrder( nGr, a0 / 4 );
+        for( int l = 0; l < nGr; l++ ) for( int k = 0; k < 4; k++ ) itWaves[a0 + 4 * l + k] = src[a0 + 4 * pm[l] + k];
+      }
+      w0 = w1;
+    }
   }
   // masked items: their waves follow (count < 0 marks them), their schedule entries and costs sit behind the plain items'
   for( int i = 0; i < n_mask; i++ )

@@ -53,6 +53,35 @@ def _pow2(v):
     return (v > 0) & ((v & (v - 1)) == 0)
 
 
+def _covered_samples(shape, origin_xy, x0, y0, x1, y1):
+    """number of samples of a plane (storage shape, sample (0,0) at origin_xy) covered by the union of the rectangles [x0, x1) x [y0, y1) (arrays, plane coordinates)"""
+    if x0.size == 0:
+        return 0
+    H, W = shape
+    ox, oy = origin_xy
+    a0, b0 = np.clip(x0.astype(np.int64) + ox, 0, W), np.clip(y0.astype(np.int64) + oy, 0, H)
+    a1, b1 = np.clip(x1.astype(np.int64) + ox, 0, W), np.clip(y1.astype(np.int64) + oy, 0, H)
+    d = np.zeros((H + 1, W + 1), np.int32)
+    np.add.at(d, (b0, a0), 1)
+    np.add.at(d, (b1, a1), 1)
+    np.add.at(d, (b0, a1), -1)
+    np.add.at(d, (b1, a0), -1)
+    return int((d.cumsum(0).cumsum(1) > 0).sum())
+
+
+def _covered_1d(n, off, length):
+    """number of elements of a buffer of n covered by the union of the intervals [off, off + length) (sorted, merged: no dense array — a 4K picture's pool is 600 M samples)"""
+    if off.size == 0:
+        return 0
+    a = np.clip(off.astype(np.int64), 0, n)
+    b = np.clip(off.astype(np.int64) + length.astype(np.int64), 0, n)
+    o = np.argsort(a, kind="stable")
+    a, b = a[o], b[o]
+    end = np.maximum.accumulate(b)
+    prev_end = np.concatenate([[0], end[:-1]])
+    return int(np.maximum(end - np.maximum(a, prev_end), 0).sum())
+
+
 class HostPlane:
     """a picture plane in host memory with the layout the device planes get: `pad` samples of margin, row pitch a multiple of 8 samples"""
 
@@ -70,7 +99,7 @@ class RecordedLists:
     """one recorded picture as HOST-side lists in the layouts of the C ABI (vvhip_me_* records, TU / DMVR groups) over host planes; RecordedWorkload puts them on the device,
     the tests' reference driver runs them on the CPU"""
 
-    def __init__(self, pic: R.RecordedPicture, bit_depth=10):
+    def __init__(self, pic: R.RecordedPicture, bit_depth=10, unique_bytes=True):
         self.pic, self.bit_depth = pic, bit_depth
         # ---- planes: originals get 8 replicated samples of margin (no job reads them; chunk loads may), reconstructions keep theirs
         self.planes = []
@@ -181,6 +210,15 @@ class RecordedLists:
         masked = ok & is_mask & (mask_pool >= 0)
         self.items_dropped = int((~(plain | masked)).sum())
         self.dropped["table_calls"] = self.items_dropped
+        # picture order (what a caller that owns a picture's lists hands over; the recorder's order is per worker thread): by the row of the original block, relative to its plane's
+        # height; calls between two pool blocks stay behind their predecessor.  me.hip keeps this order inside every (shape, function) class and deals contiguous eighths to the XCDs
+        heights = np.array([pl.height for pl in self.planes] + [1], np.float64)
+        org_pic = all_items["org_plane"] < self.n_pic_planes
+        rowf = np.where(org_pic, (all_items["org_off"].astype(np.int64) // np.append(strides, 1)[np.minimum(all_items["org_plane"], self.n_pic_planes)]) / heights[np.minimum(all_items["org_plane"], self.n_pic_planes)], np.nan)
+        last = np.maximum.accumulate(np.where(org_pic, np.arange(all_items.size), -1))
+        rowf = np.where(last >= 0, rowf[np.maximum(last, 0)], 0.0) if all_items.size else rowf
+        order = np.argsort(rowf, kind="stable")
+        all_items, expected, is_mask, mask_pool, plain, masked = all_items[order], expected[order], is_mask[order], mask_pool[order], plain[order], masked[order]
         self.items, self.item_expected = np.ascontiguousarray(all_items[plain]), expected[plain]
         mi = np.zeros(int(masked.sum()), ME_MASK_ITEM)
         if mi.size:
@@ -216,6 +254,7 @@ class RecordedLists:
             uniq, inv = np.unique(key, axis=0, return_inverse=True)
             for g, (r0, r1, dx, dy) in enumerate(uniq):
                 sel_d = np.nonzero(inv.ravel() == g)[0]
+                sel_d = sel_d[np.argsort(dm["y0"][sel_d].astype(np.int64) * strides[r0] + dm["x0"][sel_d], kind="stable")]          # picture order (the recorder's order is per worker thread)
                 it = np.zeros(sel_d.size, DMVR_ITEM_DTYPE)
                 # recorded (x, y): top-left of the CU's bilinear search area = 2 samples (DMVR_NUM_ITERATION) before the sub-block at the merge vector, which is what the entry point takes
                 it["ref0_off"] = (dm["y0"][sel_d].astype(np.int64) + 2) * strides[r0] + dm["x0"][sel_d] + 2
@@ -241,6 +280,78 @@ class RecordedLists:
         self.alg_bytes_by_kernel["ME_item"] = int((4 * self.items["width"].astype(np.int64) * (self.items["height"].astype(np.int64) >> self.items["sub_shift"]) + 8).sum()) + \
             int((6 * mi["width"].astype(np.int64) * (mi["height"].astype(np.int64) >> mi["sub_shift"]) + 8).sum())
         self.alg_bytes_me = sum(self.alg_bytes_by_kernel.values())
+        # ---- unique bytes per kernel class: the union of everything a class reads (picture-plane rectangles, pool blocks, its records) + what it writes — the floor of its
+        #      memory traffic; counter traffic over this figure is the over-fetch (~10x)
+        self.unique_bytes_by_kernel = None
+        if not unique_bytes:          # (the short runs rocprofv3 wraps skip this accounting: it is host work per picture)
+            self.alg_bytes_tu = int(sum(g["n"] * (6 * g["w"] * g["h"] + 24) for g in self.tu_groups))
+            self.alg_bytes_dmvr = int(sum(g["n"] * (2 * 2 * (g["dx"] + 5) * (g["dy"] + 5) + 16) for g in self.dmvr_groups))
+            return
+
+        def plane_union(pairs):
+            """pairs: list of (plane index array, x0, y0, x1, y1) in plane coordinates; pool operands as (offset, length) under plane index pool_index"""
+            tot = 0
+            for pidx in range(self.n_pic_planes):
+                xs = [np.concatenate([p[k][p[0] == pidx] for p in pairs]) if pairs else np.zeros(0, np.int64) for k in range(1, 5)]
+                pl = self.planes[pidx]
+                tot += 2 * _covered_samples(pl.storage.shape, (pl.pad, pl.pad), *xs)
+            return tot
+
+        def xy(off, stride):
+            off = off.astype(np.int64)
+            y = np.floor_divide(off + 4096 * stride, stride) - 4096          # (offsets into the margin are negative)
+            return off - y * stride, y
+        st_n = np.append(strides, 1)
+        uniq = {}
+        # integer windows: the candidates' bounding window per job + the original block
+        if jobs.size:
+            cj = np.repeat(np.arange(jobs.size), jobs["n_cand"])
+            mn = lambda v: np.minimum.reduceat(v, jobs["first_cand"]) if v.size else v
+            mx = lambda v: np.maximum.reduceat(v, jobs["first_cand"]) if v.size else v
+            rx, ry = xy(jobs["ref_off"], st_n[jobs["ref_plane"]])
+            w_, h_ = jobs["width"].astype(np.int64), jobs["height"].astype(np.int64)
+            ref_r = (jobs["ref_plane"].astype(np.int64), rx + mn(pc["dx"].astype(np.int64)), ry + mn(pc["dy"].astype(np.int64)), rx + mx(pc["dx"].astype(np.int64)) + w_, ry + mx(pc["dy"].astype(np.int64)) + h_)
+            op = jobs["org_plane"].astype(np.int64)
+            ox_, oy_ = xy(jobs["org_off"], st_n[np.minimum(op, self.n_pic_planes)])
+            org_r = (op, ox_, oy_, ox_ + w_, oy_ + h_)
+            pool_sel = op == self.pool_index
+            uniq["ME_int"] = plane_union([ref_r, org_r]) + 2 * _covered_1d(self.pool.size, jobs["org_off"][pool_sel], (w_ * h_)[pool_sel]) + 32 * jobs.size + 12 * pc.size
+        else:
+            uniq["ME_int"] = 0
+        if sj.size:
+            taps = np.where(sj["filter_mode"] == 2, 4, np.where(sj["filter_mode"] == 1, 6, 8)).astype(np.int64)
+            rx, ry = xy(sj["ref_off"], st_n[sj["ref_plane"]])
+            w_, h_ = sj["width"].astype(np.int64), sj["height"].astype(np.int64)
+            ref_r = (sj["ref_plane"].astype(np.int64), rx - taps // 2, ry - taps // 2, rx + w_ + taps // 2 + 1, ry + h_ + taps // 2 + 1)          # the nine positions' window (offsets -1 .. 1)
+            op = sj["org_plane"].astype(np.int64)
+            ox_, oy_ = xy(sj["org_off"], st_n[np.minimum(op, self.n_pic_planes)])
+            pool_sel = op == self.pool_index
+            uniq["ME_stage"] = plane_union([ref_r, (op, ox_, oy_, ox_ + w_, oy_ + h_)]) + 2 * _covered_1d(self.pool.size, sj["org_off"][pool_sel], (w_ * h_)[pool_sel]) + (24 + 72) * sj.size
+        else:
+            uniq["ME_stage"] = 0
+        rects, pool_off, pool_len = [], [], []
+        for arr, fields in ((self.items, (("org_plane", "org_off"), ("cur_plane", "cur_off"))), (mi, (("org_plane", "org_off"), ("cur_plane", "cur_off"), ("mask_plane", "mask_off")))):
+            if not arr.size:
+                continue
+            w_, h_ = arr["width"].astype(np.int64), arr["height"].astype(np.int64)
+            for fp, fo in fields:
+                op = arr[fp].astype(np.int64)
+                x_, y_ = xy(arr[fo], st_n[np.minimum(op, self.n_pic_planes)])
+                rects.append((op, x_, y_, x_ + w_, y_ + h_))
+                sel_p = op == self.pool_index
+                pool_off.append(arr[fo][sel_p].astype(np.int64))
+                pool_len.append((w_ * h_)[sel_p])
+        uniq["ME_item"] = (plane_union(rects) + 2 * _covered_1d(self.pool.size, np.concatenate(pool_off), np.concatenate(pool_len)) if rects else 0) + 24 * self.items.size + 32 * mi.size
+        uniq["TU"] = (2 * _covered_1d(self.pool.size, np.concatenate([g["off"].astype(np.int64) for g in self.tu_groups]), np.concatenate([np.full(g["n"], g["w"] * g["h"], np.int64) for g in self.tu_groups]))
+                      + int(sum(g["n"] * (4 * g["w"] * g["h"] + 24 + 8) for g in self.tu_groups))) if self.tu_groups else 0
+        du = 0
+        for g in self.dmvr_groups:
+            it = g["items"]
+            r0 = (np.full(g["n"], g["r0"], np.int64),) + tuple(v for v in (lambda x_, y_: (x_ - 2, y_ - 2, x_ + g["dx"] + 3, y_ + g["dy"] + 3))(*xy(it["ref0_off"], strides[g["r0"]])))
+            r1 = (np.full(g["n"], g["r1"], np.int64),) + tuple(v for v in (lambda x_, y_: (x_ - 2, y_ - 2, x_ + g["dx"] + 3, y_ + g["dy"] + 3))(*xy(it["ref1_off"], strides[g["r1"]])))
+            du += plane_union([r0, r1]) + g["n"] * (16 + 16)
+        uniq["DMVR"] = du
+        self.unique_bytes_by_kernel = {k: int(v) for k, v in uniq.items()}
         self.alg_bytes_tu = int(sum(g["n"] * (6 * g["w"] * g["h"] + 24) for g in self.tu_groups))
         self.alg_bytes_dmvr = int(sum(g["n"] * (2 * 2 * (g["dx"] + 5) * (g["dy"] + 5) + 16) for g in self.dmvr_groups))
 
@@ -248,12 +359,12 @@ class RecordedLists:
 class RecordedWorkload:
     """one recorded picture, resident in HBM, ready to replay"""
 
-    def __init__(self, hp: HotPath, pic, max_window=16, bit_depth=10):
-        lists = pic if isinstance(pic, RecordedLists) else RecordedLists(pic, bit_depth)
+    def __init__(self, hp: HotPath, pic, max_window=16, bit_depth=10, unique_bytes=True):
+        lists = pic if isinstance(pic, RecordedLists) else RecordedLists(pic, bit_depth, unique_bytes)
         self.hp, self.lists, self.pic, self.bit_depth = hp, lists, lists.pic, lists.bit_depth
         dev = hp.device
         for k in ("n_pic_planes", "pool_index", "n_planes", "mask_items", "mask_expected", "dropped", "nothing_dropped", "int_jobs", "plan_cands", "cand_expected", "cand_index", "stage_jobs", "stage_index", "stage_expected", "stage_evaluated", "items",
-                  "item_expected", "items_dropped", "tu_coefficients", "pairs", "alg_bytes_me", "alg_bytes_by_kernel", "alg_bytes_tu", "alg_bytes_dmvr"):
+                  "item_expected", "items_dropped", "tu_coefficients", "pairs", "alg_bytes_me", "alg_bytes_by_kernel", "alg_bytes_tu", "alg_bytes_dmvr", "unique_bytes_by_kernel"):
             setattr(self, k, getattr(lists, k))
         self.planes = []
         for hpl in lists.planes:
