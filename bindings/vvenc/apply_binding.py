@@ -326,7 +326,10 @@ patch("EncCu.cpp", [
      "  m_mergeItemList.init( encCfg.m_maxMergeRdCandNumTotal, g_vvhipHooks.mergeCosts ? MRG_MAX_NUM_CANDS + 3 : ( m_pcEncCfg->m_Geo > 1 ? 3 : 1 ), chromaFormat, uiMaxSize, uiMaxSize );"),
     ("replace", "         = pu.ciip\n         = false;\n\n  for( uint32_t uiMergeCand = 0; uiMergeCand < mergeCtx.numValidMergeCand; uiMergeCand++ )\n  {\n    if( sameMv[uiMergeCand] ) continue;\n\n    mergeCtx.setMergeInfo   ( pu, uiMergeCand );",
      "         = pu.ciip\n         = false;\n\n"
-     "  const bool hipMrg = g_vvhipHooks.mergeCosts != nullptr && ( localUnitArea.lwidth() & 7 ) == 0 && localUnitArea.lwidth() == localUnitArea.lheight() && localUnitArea.lwidth() <= 64;\n"
+     "  // (a lossless test mode scores with DF_SAD, EncCu.cpp:1961: the device site covers the Hadamard families only, so it requires that the caller's distParam really holds the\n"
+     "  //  Hadamard entry it is about to replace — anything else stays with distParam.distFunc)\n"
+     "  const bool hipMrg = g_vvhipHooks.mergeCosts != nullptr && ( localUnitArea.lwidth() & 7 ) == 0 && localUnitArea.lwidth() == localUnitArea.lheight() && localUnitArea.lwidth() <= 64 &&\n"
+     "                      distParam.distFunc == m_cRdCost.m_afpDistortFunc[0][( m_pcEncCfg->m_fastHad ? DF_HAD_fast : DF_HAD ) + Log2( localUnitArea.lwidth() )];\n"
      "  MergeItem* hipItem[MRG_MAX_NUM_CANDS]; const Pel* hipPred[MRG_MAX_NUM_CANDS]; int hipStride[MRG_MAX_NUM_CANDS]; uint64_t hipBits[MRG_MAX_NUM_CANDS]; int hipN = 0;\n"
      "  for( uint32_t uiMergeCand = 0; uiMergeCand < mergeCtx.numValidMergeCand; uiMergeCand++ )\n  {\n    if( sameMv[uiMergeCand] ) continue;\n\n    mergeCtx.setMergeInfo   ( pu, uiMergeCand );"),
     ("replace", "    regularMerge->cost      = calcLumaCost4MergePrediction( ctxStart, dstBuf, sqrtLambdaForFirstPassIntra, pu, distParam );\n"

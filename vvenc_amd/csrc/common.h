@@ -35,7 +35,7 @@ struct vvhip_ctx
 inline hipError_t vvhip_wait_stream( vvhip_ctx* ctx )
 {
   if( !ctx->blockingSync ) return hipStreamSynchronize( ctx->stream );
-  if( !ctx->syncEvent ) { const hipError_t e = hipEventCreateWithFlags( &ctx->syncEvent, hipEventBlockingSync | hipEventDisableTiming ); if( e != hipSuccess ) return e; }
+  if( !ctx->syncEvent ) return hipErrorInvalidHandle;      // (created by vvhip_create on the context's device)
   const hipError_t e = hipEventRecord( ctx->syncEvent, ctx->stream );
   return e != hipSuccess ? e : hipEventSynchronize( ctx->syncEvent );
 }

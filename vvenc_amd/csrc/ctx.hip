@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <memory>
+#include <atomic>
 #include <vector>
 
 static std::string g_createError;
@@ -121,6 +122,10 @@ int vvhip_get_scan_order_host( int log2_w, int log2_h, uint32_t* host_out )
 
 const char* vvhip_version( void ) { return "vvenc_hip 0.1 (gfx950)"; }
 
+// devices that hold (or held) a context of this process: vvhip_sync_all_devices waits for these only — touching every visible GPU would create a primary context on each
+// (eight on an MI355X node) and stall callers that hold a lock while they wait
+static std::atomic<uint64_t> g_liveDevices{ 0 };
+
 int vvhip_create( vvhip_ctx** out, int device )
 {
   if( !out ) return vvhip_fail( nullptr, VVHIP_E_ARG, "vvhip_create: out == NULL" );
@@ -138,6 +143,10 @@ int vvhip_create( vvhip_ctx** out, int device )
   VVHIP_CHECK_HIP( nullptr, hipSetDevice( device ) );
   VVHIP_CHECK_HIP( nullptr, hipStreamCreateWithFlags( &ctx->ownStream, hipStreamNonBlocking ) );
   ctx->stream = ctx->ownStream;
+  // the blocking wait's event belongs to the context's device: created here, where that device is current (a lazily created one would land on whatever device the
+  // calling thread has selected and fail on the context's stream)
+  VVHIP_CHECK_HIP( nullptr, hipEventCreateWithFlags( &ctx->syncEvent, hipEventBlockingSync | hipEventDisableTiming ) );
+  if( device < 64 ) g_liveDevices.fetch_or( 1ull << device );
 
   std::vector<int16_t> mats( kTrMatTotal, 0 );
   for( int t = 0; t < 3; t++ )
@@ -289,9 +298,11 @@ int vvhip_sync_all_devices( vvhip_ctx* ctx )
   int prev = 0, n = 0;
   VVHIP_CHECK_HIP( ctx, hipGetDevice( &prev ) );
   VVHIP_CHECK_HIP( ctx, hipGetDeviceCount( &n ) );
+  const uint64_t live = g_liveDevices.load();
   hipError_t first = hipSuccess;
-  for( int d = 0; d < n; d++ )
+  for( int d = 0; d < n && d < 64; d++ )
   {
+    if( !( ( live >> d ) & 1 ) ) continue;                 // no context of this library ever lived there: nothing of ours can be in flight
     hipError_t e = hipSetDevice( d );
     if( e == hipSuccess ) e = hipDeviceSynchronize();
     if( e != hipSuccess && first == hipSuccess ) first = e;

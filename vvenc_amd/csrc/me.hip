@@ -70,10 +70,22 @@ struct MePlanes { const int16_t* p[16]; int stride[16]; };
 struct IntJob   { int32_t orgOff, refOff; int16_t w, h; uint8_t orgPlane, refPlane, subShift, pad; int16_t minDx, minDy, winW, winH; int32_t firstCand, nCand; };   // one window
 struct PlanCand { int16_t dx, dy; int32_t outIndex; };
 struct WaveSpan { int32_t first, count; };                                                                                                               // into an order array
+// one stage unit of the schedule: the job + what every lane of the wave used to re-derive from it per unit (the evaluated positions grouped by their horizontal displacement,
+// the <= 3 distinct displacements and how many positions use each): plan creation does it once (the unit skeleton)
+struct StageUnit
+{
+  vvhip_me_stage_job j;
+  int16_t hx[3]; uint8_t nHor, nPos;          // distinct horizontal displacements (1/16 sample) in first-seen order
+  uint8_t cnt0, cnt1, cnt2, pad;              // positions per displacement
+  int32_t order;                               // stage index | band << 24 | half << 27 | ST_UNIT_CONT | ST_UNIT_MORE
+  int32_t pos[9];                              // slot -> k | ( tx + 64 ) << 8 | ( ty + 64 ) << 20, grouped by displacement (variant 0 first)
+  int32_t pad2[3];
+};
+static_assert( sizeof( StageUnit ) == 88, "StageUnit layout" );
 struct MeArgs
 {
   const IntJob* intJobs; const PlanCand* cands; int wavesInt;
-  const vvhip_me_stage_job* stageJobs; const int32_t* stageOrder; const WaveSpan* stageWaves; int wavesStage;
+  const StageUnit* stageUnits; const WaveSpan* stageWaves; int wavesStage;
   const int32_t* tapTables;      // [6 = filter_mode * 2 + alt_hpel][192]: 16 phases x 8 taps, then 16 phases x 4 tap pairs of the table's tap support
   const vvhip_me_item* items; const int32_t* itemOrder; const WaveSpan* itemWaves; int wavesItem;
   const vvhip_me_mask_item* maskItems;      // in schedule order; their waves follow the plain items' (WaveSpan.count < 0), their costs follow the plain items' costs
@@ -401,8 +413,9 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
   }
   for( int si = 0; si < span.count; si++ )
   {
-    const int unit = a.stageOrder[span.first + si], stage = unit & 0xffffff;
-    const vvhip_me_stage_job j = a.stageJobs[span.first + si];                     // (the job table is in schedule order, one record per unit)
+    const StageUnit* up = a.stageUnits + span.first + si;                        // (wave-uniform address: scalar loads; the table is in schedule order, one record per unit)
+    const vvhip_me_stage_job j = up->j;
+    const int unit = up->order, stage = unit & 0xffffff;
     // the unit: <= 32 rows x <= 64 columns of the block (a band of one 64-column half).  Blocks of more than one unit (h > 32 or w > 64) are shared by the two waves of the
     // workgroup; a wave adds the sums of its units (ST_UNIT_CONT / _MORE) before the two waves meet
     const int w = j.width, h = j.height, uw = w < 64 ? w : 64, uwH = uw < 8 ? 8 : uw, G = uwH >> 3, log2G = 31 - __builtin_clz( G );
@@ -412,33 +425,12 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     const int rs = P.stride[j.ref_plane];
     const int16_t* org = P.p[j.org_plane] + j.org_off + xoff;
     const int os = P.stride[j.org_plane] ? P.stride[j.org_plane] : w;             // (stride 0: a compact pool block — bi-prediction patterns)
-    // the evaluated positions and their distinct horizontal displacements (<= 3: the refinement offsets are -1, 0, 1): one first pass each, shared like the reference's planes
-    int hx0 = 0, hx1 = 0, hx2 = 0, nHor = 0, nPos = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0;
+    // the evaluated positions and their distinct horizontal displacements (<= 3: the refinement offsets are -1, 0, 1; one first pass each, shared like the reference's planes)
+    // come precomputed with the unit; posL: the positions grouped by displacement (a pass of the unit works on the positions of the variants it holds in LDS)
+    const int hx0 = up->hx[0], hx1 = up->hx[1], hx2 = up->hx[2], nHor = up->nHor, nPos = up->nPos, cnt0 = up->cnt0, cnt1 = up->cnt1;
+    const int myPos = tid < 9 ? up->pos[tid] : 0;                                // (requested before the wait below)
     ST_SYNC();                                                                    // the previous unit's readers are done with the tables and tmp
-    for( int k = 0; k < 9; k++ )
-    {
-      if( !( ( j.mask >> k ) & 1 ) ) continue;
-      int tx, ty; stagePos( j, k, tx, ty );
-      nPos++;
-      if( nHor > 0 && tx == hx0 ) { cnt0++; continue; }
-      if( nHor > 1 && tx == hx1 ) { cnt1++; continue; }
-      if( nHor > 2 && tx == hx2 ) { cnt2++; continue; }
-      if( nHor == 0 ) { hx0 = tx; cnt0++; } else if( nHor == 1 ) { hx1 = tx; cnt1++; } else { hx2 = tx; cnt2++; }
-      nHor++;
-    }
-    ( void ) cnt2;
-    // posL: the evaluated positions grouped by their horizontal displacement (variant 0 first): a pass of the unit works on the positions of the variants it holds in LDS
-    if( tid == 0 )
-    {
-      int f0 = 0, f1 = cnt0, f2 = cnt0 + cnt1;
-      for( int k = 0; k < 9; k++ )
-      {
-        if( !( ( j.mask >> k ) & 1 ) ) continue;
-        int tx, ty; stagePos( j, k, tx, ty );
-        const int slot = tx == hx0 ? f0++ : ( ( nHor > 1 && tx == hx1 ) ? f1++ : f2++ );
-        posL[slot] = k | ( ( tx + 64 ) << 8 ) | ( ( ty + 64 ) << 20 );
-      }
-    }
+    if( tid < 9 ) posL[tid] = myPos;
     // the tap tables of the unit's (tap set, alternative half-sample filter) from the plan, 192 dwords: fetched when they differ from the previous unit's (a bundle of the
     // 4-tap search set never changes them)
     const int tabId = j.filter_mode * 2 + ( j.alt_hpel ? 1 : 0 );
@@ -1136,8 +1128,26 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   for( int i = 0; i < n_mask; i++ ) maxPlane = std::max( maxPlane, ( int ) std::max( mask_items[i].mask_plane, std::max( mask_items[i].org_plane, mask_items[i].cur_plane ) ) );
   // ---- the tables go to the device in SCHEDULE order (a wave reads its jobs at the schedule index: no order -> record indirection on the critical path of a short-lived wave;
   //      the order arrays only say where a result goes)
-  std::vector<vvhip_me_stage_job> stUnits( stOrder.size() );
-  for( size_t i = 0; i < stOrder.size(); i++ ) stUnits[i] = stage_jobs[stOrder[i] & 0xffffff];
+  std::vector<StageUnit> stUnits( stOrder.size() );
+  for( size_t i = 0; i < stOrder.size(); i++ )
+  {
+    StageUnit& u = stUnits[i];
+    memset( &u, 0, sizeof( u ) );
+    u.j = stage_jobs[stOrder[i] & 0xffffff]; u.order = stOrder[i];
+    static const int8_t rxT[9] = { 0, 0, 0, -1, 1, -1, 1, -1, 1 }, ryH[9] = { 0, -1, 1, 0, 0, -1, -1, 1, 1 }, ryQ[9] = { 0, -1, 1, -1, -1, 0, 0, 1, 1 };      // s_acMvRefineH / Q, InterSearch.cpp:67-91
+    int tx[9], ty[9], var[9], cnt[3] = { 0, 0, 0 }, nHor = 0, nPos = 0;
+    for( int k = 0; k < 9; k++ )
+    {
+      if( !( ( u.j.mask >> k ) & 1 ) ) continue;
+      tx[k] = ( rxT[k] + u.j.base_qx ) * u.j.i_frac * 4; ty[k] = ( ( u.j.i_frac == 2 ? ryH[k] : ryQ[k] ) + u.j.base_qy ) * u.j.i_frac * 4;
+      int v = 0; while( v < nHor && u.hx[v] != tx[k] ) v++;
+      if( v == nHor ) u.hx[nHor++] = ( int16_t ) tx[k];
+      var[k] = v; cnt[v]++; nPos++;
+    }
+    u.nHor = ( uint8_t ) nHor; u.nPos = ( uint8_t ) nPos; u.cnt0 = ( uint8_t ) cnt[0]; u.cnt1 = ( uint8_t ) cnt[1]; u.cnt2 = ( uint8_t ) cnt[2];
+    int slot[3] = { 0, cnt[0], cnt[0] + cnt[1] };
+    for( int k = 0; k < 9; k++ ) if( ( u.j.mask >> k ) & 1 ) u.pos[slot[var[k]]++] = k | ( ( tx[k] + 64 ) << 8 ) | ( ( ty[k] + 64 ) << 20 );
+  }
   std::vector<vvhip_me_item> itSorted( n_items );
   for( int i = 0; i < n_items; i++ ) itSorted[i] = items[itOrder[i]];
   std::vector<vvhip_me_mask_item> mkSorted( n_mask );
@@ -1157,7 +1167,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   }
   // ---- one device allocation for every table
   auto pad = []( size_t b ) { return ( b + 255 ) & ~( size_t ) 255; };
-  const size_t bInt = pad( ij.size() * sizeof( IntJob ) ), bCand = pad( pc.size() * sizeof( PlanCand ) ), bSt = pad( stUnits.size() * sizeof( vvhip_me_stage_job ) ),
+  const size_t bInt = pad( ij.size() * sizeof( IntJob ) ), bCand = pad( pc.size() * sizeof( PlanCand ) ), bSt = pad( stUnits.size() * sizeof( StageUnit ) ),
                bStO = pad( stOrder.size() * 4 ), bStW = pad( stWaves.size() * sizeof( WaveSpan ) ), bIt = pad( ( size_t ) n_items * sizeof( vvhip_me_item ) ), bItO = pad( itOrder.size() * 4 ),
                bItW = pad( itWaves.size() * sizeof( WaveSpan ) ), bMk = pad( mkSorted.size() * sizeof( vvhip_me_mask_item ) );
   const size_t bTap = pad( tapTab.size() * 4 );
@@ -1166,7 +1176,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   size_t o = 0;
   auto put = [&]( const void* src, size_t bytes, size_t padded ) { const size_t at = o; if( bytes ) memcpy( host.data() + o, src, bytes ); o += padded; return at; };
   const size_t oInt = put( ij.data(), ij.size() * sizeof( IntJob ), bInt ), oCand = put( pc.data(), pc.size() * sizeof( PlanCand ), bCand ),
-               oSt = put( stUnits.data(), stUnits.size() * sizeof( vvhip_me_stage_job ), bSt ), oStO = put( stOrder.data(), stOrder.size() * 4, bStO ),
+               oSt = put( stUnits.data(), stUnits.size() * sizeof( StageUnit ), bSt ), oStO = put( stOrder.data(), stOrder.size() * 4, bStO ),
                oStW = put( stWaves.data(), stWaves.size() * sizeof( WaveSpan ), bStW ), oIt = put( itSorted.data(), ( size_t ) n_items * sizeof( vvhip_me_item ), bIt ),
                oItO = put( itOrder.data(), itOrder.size() * 4, bItO ), oItW = put( itWaves.data(), itWaves.size() * sizeof( WaveSpan ), bItW ), oTap = put( tapTab.data(), tapTab.size() * 4, bTap ),
                oMk = put( mkSorted.data(), mkSorted.size() * sizeof( vvhip_me_mask_item ), bMk );
@@ -1248,7 +1258,7 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   for( int i = 0; i < 16; i++ ) { P.p[i] = planes_host[i < n_planes ? i : 0].d_base; P.stride[i] = planes_host[i < n_planes ? i : 0].stride; }
   MeArgs a;
   a.intJobs = static_cast<const IntJob*>( plan->d_intJobs ); a.cands = static_cast<const PlanCand*>( plan->d_cands ); a.wavesInt = plan->wavesInt;
-  a.stageJobs = static_cast<const vvhip_me_stage_job*>( plan->d_stageJobs ); a.stageOrder = static_cast<const int32_t*>( plan->d_stageOrder );
+  a.stageUnits = static_cast<const StageUnit*>( plan->d_stageJobs );
   a.stageWaves = static_cast<const WaveSpan*>( plan->d_stageWaves ); a.wavesStage = plan->wavesStage; a.tapTables = static_cast<const int32_t*>( plan->d_tapTables );
   a.items = static_cast<const vvhip_me_item*>( plan->d_items ); a.itemOrder = static_cast<const int32_t*>( plan->d_itemOrder ); a.itemWaves = static_cast<const WaveSpan*>( plan->d_itemWaves ); a.wavesItem = plan->wavesItem;
   a.maskItems = static_cast<const vvhip_me_mask_item*>( plan->d_maskItems );
