@@ -858,6 +858,7 @@ int hostWinSamples( int winW, int winH ) { return ( winH * hostWinPitch( winW ) 
 
 } // namespace
 
+#ifndef VVHIP_ME_KERNELS_ONLY      // (tools/exp/persist_stage.hip includes this file for its kernels only)
 extern "C" {
 
 static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth, int max_window, vvhip_me_plan** out );
@@ -1314,3 +1315,4 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
 }
 
 } // extern "C"
+#endif
