@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 #include "../../include/vvenc_hip.h"
 
 struct vvhip_ctx
@@ -25,6 +26,10 @@ struct vvhip_ctx
   // scratch of vvhip_subpel_dist_batch: predicted blocks + distortion items (grown on demand)
   void*        d_subpel   = nullptr;
   size_t       subpelBytes = 0;
+  // job table of the generic TU pipeline's merged launch (trquant.hip: tuRdoGenMultiKernel) + the host copy of what it holds
+  void*        d_tuGen    = nullptr;
+  size_t       tuGenBytes = 0;
+  std::vector<unsigned char> tuGenLast;
   // how the host waits for the stream (vvhip_set_blocking_sync): false = hipStreamSynchronize (the runtime's low-latency wait), true = a blocking event — the calling thread
   // sleeps, which matters when the host's cores are all busy encoding
   bool         blockingSync = false;

@@ -247,6 +247,7 @@ void vvhip_destroy( vvhip_ctx* ctx )
   if( ctx->d_tuMx64 ) ( void ) hipFree( ctx->d_tuMx64 );
   if( ctx->d_scratch ) ( void ) hipFree( ctx->d_scratch );
   if( ctx->d_subpel ) ( void ) hipFree( ctx->d_subpel );
+  if( ctx->d_tuGen ) ( void ) hipFree( ctx->d_tuGen );
   if( ctx->syncEvent ) ( void ) hipEventDestroy( ctx->syncEvent );
   if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );
   delete ctx;

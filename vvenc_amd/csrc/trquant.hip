@@ -27,6 +27,8 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -392,15 +394,15 @@ __device__ __forceinline__ unsigned long long grpAdd64( unsigned long long e, in
   return e;
 }
 
-__global__ void __launch_bounds__( 256 )
-tuRdoKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t* __restrict__ resiOff, int n,
-             TrGeom gf, TrGeom gi, TuLay y, QGeom q, int tpb, const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
-             const uint16_t* __restrict__ scan, const vvhip_tu_qp* __restrict__ qps, int thrVal,
-             int16_t* __restrict__ level, int16_t* __restrict__ rec, vvhip_tu_stats* __restrict__ stats, int phaseLimit )
+// (the body of tuRdoKernel / tuRdoGenMultiKernel: workgroup `blk` of one job's launch geometry)
+__device__ __forceinline__ void
+tuRdoBody( unsigned char* smemRaw, const int blk, const int16_t* __restrict__ resi, int resiStride, const int32_t* __restrict__ resiOff, int n,
+           const TrGeom& gf, const TrGeom& gi, const TuLay& y, const QGeom& q, int tpb, const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
+           const uint16_t* __restrict__ scan, const vvhip_tu_qp* __restrict__ qps, int thrVal,
+           int16_t* __restrict__ level, int16_t* __restrict__ rec, vvhip_tu_stats* __restrict__ stats, int phaseLimit )
 {
-  extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemRaw[];
   const int tid = threadIdx.x, nthr = blockDim.x, w = gf.w, la = gf.log2w + gf.log2h, area = 1 << la;
-  const int tu0 = blockIdx.x * tpb, nTu = min( tpb, n - tu0 );
+  const int tu0 = blk * tpb, nTu = min( tpb, n - tu0 );
   const int G = area < 64 ? area : 64, lane = tid & 63, sub = lane & ( G - 1 );
   const Lds L = carve( smemRaw, gf, y, tpb, matH, matV, true, true, tid, nthr );
   TuPar* par = reinterpret_cast<TuPar*>( L.tu + ( ( tpb * y.slot + 7 ) & ~7 ) );
@@ -568,6 +570,39 @@ tuRdoKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t* __
       stats[tu0 + t] = st;
     }
 }
+
+__global__ void __launch_bounds__( 256 )
+tuRdoKernel( const int16_t* __restrict__ resi, int resiStride, const int32_t* __restrict__ resiOff, int n,
+             TrGeom gf, TrGeom gi, TuLay y, QGeom q, int tpb, const int16_t* __restrict__ matH, const int16_t* __restrict__ matV,
+             const uint16_t* __restrict__ scan, const vvhip_tu_qp* __restrict__ qps, int thrVal,
+             int16_t* __restrict__ level, int16_t* __restrict__ rec, vvhip_tu_stats* __restrict__ stats, int phaseLimit )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemRaw[];
+  tuRdoBody( smemRaw, blockIdx.x, resi, resiStride, resiOff, n, gf, gi, y, q, tpb, matH, matV, scan, qps, thrVal, level, rec, stats, phaseLimit );
+}
+
+// Every TU list of a picture that the matrix-core kernel does not take — the rectangular shapes of preset medium's multi-type tree (TrQuant.cpp:481-564 with the
+// non-square shifts :544-545 and trShift :769-772 of Quant.cpp), 2-wide chroma, 64-point DST — in ONE launch: a job table in device memory (geometry, LDS layout, matrices,
+// lists), workgroup -> job by the jobs' first workgroup.  (One tuRdoKernel launch per (shape, types) list was 45 launches for a 4K medium picture: 420 us, mostly launch gaps.)
+struct TuGenJob
+{
+  int32_t resiStride, n, tpb, thrVal, blockStart, pad;
+  TrGeom gf, gi; TuLay y; QGeom q;
+  const int32_t* resiOff; const int16_t* matH; const int16_t* matV; const uint16_t* scan; const vvhip_tu_qp* qps; int16_t* level; int16_t* rec; vvhip_tu_stats* stats;
+};
+
+__global__ void __launch_bounds__( 256 )
+tuRdoGenMultiKernel( const int16_t* __restrict__ resi, const TuGenJob* __restrict__ jobs, int nJobs, int phaseLimit )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemRaw[];
+  // which job: the last one whose first workgroup is <= this workgroup (nJobs <= 64: one lane per job, one ballot)
+  const int lane = threadIdx.x & 63;
+  const int st = lane < nJobs ? jobs[lane].blockStart : 0x7fffffff;
+  const int k = __builtin_popcountll( __ballot( ( int ) blockIdx.x >= st ) ) - 1;
+  const TuGenJob& J = jobs[__builtin_amdgcn_readfirstlane( k )];
+  tuRdoBody( smemRaw, ( int ) blockIdx.x - J.blockStart, resi, J.resiStride, J.resiOff, J.n, J.gf, J.gi, J.y, J.q, J.tpb, J.matH, J.matV, J.scan, J.qps, J.thrVal, J.level, J.rec, J.stats, phaseLimit );
+}
+
 
 // --------------------------------------------------------------------------------------------
 // Fused TU pipeline, row-per-lane form for square N x N TUs (N = 8, 16, 32).
@@ -1848,16 +1883,58 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
   auto mergeable = []( const vvhip_tu_job& j ) { return j.n > 0 && j.width == j.height && ( j.width == 8 || j.width == 16 || j.width == 32 ||
                                                         ( tuKernelForm() == 0 && ( j.width == 4 || ( j.width == 64 && j.tr_hor == VVHIP_DCT2 && j.tr_ver == VVHIP_DCT2 ) ) ) ); };     // 4x4 / 64x64 only in the matrix-core form
   int order[64], nm = 0;
+  std::vector<TuGenJob> gen;
   for( int i = 0; i < n_jobs; i++ )
   {
     if( jobs[i].n < 0 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: job %d has n < 0", i );
     if( mergeable( jobs[i] ) && nm < 64 && !getenv( "VVHIP_TU_GENERIC" ) && ( !strides || tuKernelForm() == 0 ) ) order[nm++] = i;
     else if( jobs[i].n > 0 )
     {
-      const int rc = vvhip_tu_rdo_batch( ctx, d_resi, strides ? strides[i] : resi_stride, jobs[i].d_resi_off, jobs[i].n, jobs[i].width, jobs[i].height, jobs[i].tr_hor, jobs[i].tr_ver, bit_depth,
-                                         jobs[i].d_qp, jobs[i].thr_val, jobs[i].d_level, jobs[i].d_rec_resi, jobs[i].d_stats );
-      if( rc ) return rc;
+      static const bool separate = getenv( "VVHIP_TU_GENERIC_SEPARATE" ) != nullptr;      // (A/B: one launch per list, the round-3 route)
+      const vvhip_tu_job& jb = jobs[i];
+      const bool rowForm = jb.width == jb.height && ( jb.width == 8 || jb.width == 16 || jb.width == 32 );      // (only reached with the row kernels selected: they have their own launches)
+      if( separate || rowForm || gen.size() >= 64 )
+      {
+        const int rc = vvhip_tu_rdo_batch( ctx, d_resi, strides ? strides[i] : resi_stride, jb.d_resi_off, jb.n, jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth,
+                                           jb.d_qp, jb.thr_val, jb.d_level, jb.d_rec_resi, jb.d_stats );
+        if( rc ) return rc;
+        continue;
+      }
+      // everything the matrix-core kernel does not take goes into ONE launch of the generic pipeline (tuRdoGenMultiKernel)
+      TuGenJob g; memset( &g, 0, sizeof( g ) );
+      if( !makeGeom( jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth, false, g.gf ) || !makeGeom( jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth, true, g.gi ) || !makeQGeom( jb.width, jb.height, bit_depth, g.q ) )
+        return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_tu_rdo_multi: unsupported %dx%d types (%d,%d) bitDepth %d", jb.width, jb.height, jb.tr_hor, jb.tr_ver, bit_depth );
+      g.y = makeLayout( g.gf, jb.tr_hor, jb.tr_ver );
+      const int area = jb.width * jb.height;
+      g.tpb = area >= 1024 ? 1 : 1024 / area;          // ~1024 samples per workgroup (as vvhip_tu_rdo_batch's generic route)
+      g.resiStride = strides ? strides[i] : resi_stride; g.n = jb.n; g.thrVal = jb.thr_val;
+      g.resiOff = jb.d_resi_off; g.matH = ctx->d_trMat + trMatOffset( jb.tr_hor, g.gf.log2w ); g.matV = ctx->d_trMat + trMatOffset( jb.tr_ver, g.gf.log2h );
+      g.scan = ctx->d_scan + scanOffset( g.q.log2w, g.q.log2h ); g.qps = jb.d_qp; g.level = jb.d_level; g.rec = jb.d_rec_resi; g.stats = jb.d_stats;
+      gen.push_back( g );
     }
+  }
+  if( !gen.empty() )
+  {
+    // largest workgroups (LDS, duration) first; the table lives in device memory and is re-uploaded only when it differs from the previous call's (a caller replays a picture's lists)
+    std::stable_sort( gen.begin(), gen.end(), []( const TuGenJob& a, const TuGenJob& b ) { return a.gf.w * a.gf.h > b.gf.w * b.gf.h; } );
+    size_t smem = 0; int blocks = 0;
+    for( TuGenJob& g : gen ) { g.blockStart = blocks; blocks += ( g.n + g.tpb - 1 ) / g.tpb; smem = std::max( smem, trSmemBytes( g.y, g.tpb ) ); }
+    const size_t bytes = gen.size() * sizeof( TuGenJob );
+    if( ctx->tuGenBytes < bytes )
+    {
+      if( ctx->d_tuGen ) { VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->stream ) ); ( void ) hipFree( ctx->d_tuGen ); ctx->d_tuGen = nullptr; ctx->tuGenBytes = 0; }
+      VVHIP_CHECK_HIP( ctx, hipMalloc( &ctx->d_tuGen, 64 * sizeof( TuGenJob ) ) );
+      ctx->tuGenBytes = 64 * sizeof( TuGenJob ); ctx->tuGenLast.clear();
+    }
+    if( ctx->tuGenLast.size() != bytes || memcmp( ctx->tuGenLast.data(), gen.data(), bytes ) != 0 )
+    {
+      // (stream-ordered behind the previous launch that still reads the old table; the host copy is staged before the call returns)
+      ctx->tuGenLast.assign( reinterpret_cast<const unsigned char*>( gen.data() ), reinterpret_cast<const unsigned char*>( gen.data() ) + bytes );
+      VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( ctx->d_tuGen, ctx->tuGenLast.data(), bytes, hipMemcpyHostToDevice, ctx->stream ) );
+    }
+    if( smem > 64 * 1024 ) VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) tuRdoGenMultiKernel, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) smem ) );
+    hipLaunchKernelGGL( tuRdoGenMultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), smem, ctx->stream, d_resi, static_cast<const TuGenJob*>( ctx->d_tuGen ), ( int ) gen.size(), tuPhaseLimit() );
+    VVHIP_LAUNCH_CHECK( ctx );
   }
   // launch groups, largest size first (a wave of the largest size runs longest: it has to start first).  Matrix-core form: up to 8 jobs per launch; the 4x4 and 64x64
   // variants live in a second kernel instance (more code, same register bound) — a picture's lists go into ONE launch of that instance when they are small (a recorded
