@@ -14,6 +14,12 @@ for poc, pic in pics.items():
     # timing
     for _ in range(3): wl.run()
     torch.cuda.synchronize()
+    hp.me_plan_set_timing(wl.plan, True)
+    parts = []
+    for _ in range(5):
+        wl.run_me(); torch.cuda.synchronize(); parts.append(hp.me_plan_last_times(wl.plan))
+    hp.me_plan_set_timing(wl.plan, False)
+    parts = (np.median(np.array(parts), 0) * 1000).round(1).tolist()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     n = 20
     ev[0].record()
@@ -25,7 +31,7 @@ for poc, pic in pics.items():
     ev[3].record()
     torch.cuda.synchronize()
     line = json.dumps({"poc": poc, "tl": pic.tlayer, "build_s": round(t1 - t0, 2), "check": chk, "info": wl.me_info, "dropped": wl.items_dropped,
-                      "us": {"me": 1000 * ev[0].elapsed_time(ev[1]) / n, "tu": 1000 * ev[1].elapsed_time(ev[2]) / n, "dmvr": 1000 * ev[2].elapsed_time(ev[3]) / n},
+                      "me_parts_us_stage_int_0_item": parts, "us": {"me": 1000 * ev[0].elapsed_time(ev[1]) / n, "tu": 1000 * ev[1].elapsed_time(ev[2]) / n, "dmvr": 1000 * ev[2].elapsed_time(ev[3]) / n},
                       "n": {"int_jobs": int(wl.int_jobs.size), "cands": int(wl.plan_cands.size), "stages": int(wl.stage_jobs.size), "items": int(wl.items.size), "tus": sum(g["n"] for g in wl.tu_groups)}})
     print(line)
     open("/root/repo/gpurun_out/replay_try.jsonl", "a").write(line + "\n")

@@ -1568,7 +1568,231 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
 #undef WAVE_SYNC
 }
 
-struct TuMxJobs { int nJobs; int waveStart[8]; int size[8]; TuMxArgs j[8]; };
+// --------------------------------------------------------------------------------------------
+// 64x64 TUs over TWO waves (round 4): wave p of the pair owns row tile p — rows 32p .. 32p + 31 — in both row passes (forward rows, inverse rows: independent per
+// row), and contributes its tile's half of the forward column pass (a contraction over the 64 rows = the sum of the two tiles' products): the two halves meet through LDS, after
+// which BOTH waves hold the 32x32 coefficients and run the quantiser section on them (redundantly: it is a quarter of the wave's work and needs every coefficient for its
+// last-position / coefficient-group decisions), then each does the inverse column and row passes of its own tile.  Per TU a wave issues 12 instead of 24 matrix products and half
+// of the byte splits, clips, SSE terms and stores.  The pair meets twice per TU (coefficient halves, SSE) on an LDS counter: the two waves belong to one workgroup, so both are
+// resident; no workgroup barrier (the other pair of the workgroup runs its own TUs).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tuMxPairSync( uint32_t* ctr, uint32_t& gen, int lane )
+{
+  __builtin_amdgcn_fence( __ATOMIC_RELEASE, "workgroup" );
+  if( lane == 0 ) atomicAdd( ctr, 1u );
+  gen += 2;
+  while( *reinterpret_cast<volatile uint32_t*>( ctr ) < gen ) __builtin_amdgcn_s_sleep( 1 );
+  __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "workgroup" );
+}
+
+__device__ __forceinline__ void
+tuMx64PairBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */, v4i* __restrict__ sOps /* [512] */, int32_t* __restrict__ xch /* [2][64][17]: the pair's exchange area */,
+                uint32_t* __restrict__ ctr, const int p /* 0 / 1: which wave of the pair */, const int pairIndex, const int pairStride,
+                const int16_t* __restrict__ resi, const int resiStride, const TuMxArgs& A )
+{
+  constexpr int LP = 40, XP = 17;                 // (exchange rows of 17 dwords: lanes hit different banks)
+  struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
+  const VvhipTuMx64Ops* __restrict__ O = reinterpret_cast<const VvhipTuMx64Ops*>( A.opH );
+  const int lane = threadIdx.x & 63, h = lane >> 5, c32 = lane & 31;
+  const v16i zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+  const int rndF1 = 1 << ( A.shF1 - 1 ), rndF2 = 1 << ( A.shF2 - 1 ), rndI1 = 1 << ( A.shI1 - 1 ), rndI2 = 1 << ( A.shI2 - 1 );
+  // operand slots (as tuMx64Body): 0,1 natX[c]  2 rowPY[p]  4 natTY[p]  6,7 colPX[c]
+#pragma unroll
+  for( int q = 0; q < 2; q++ )
+  {
+    sOps[( 0 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->natX[q][lane] );
+    sOps[( 6 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->colPX[q][lane] );
+  }
+  sOps[2 * 64 + lane] = *reinterpret_cast<const v4i*>( O->rowPY[p][lane] );
+  sOps[4 * 64 + lane] = *reinterpret_cast<const v4i*>( O->natTY[p][lane] );
+  const int cP1 = O->rowSum[c32] + rndF1;
+  const int cI1 = O->colSum[32 * p + c32] + rndI1;
+  sInit[c32] = p == 0 ? O->rowSum[c32] + rndF2 : 0;            // forward columns: correction + rounding enter the sum once (wave 0's half)
+  sInit[32 + lane] = O->colSum[lane] + rndI2;                  // inverse rows: by result column x = 32c + 16h + v
+  uint32_t pos[16];
+  {
+    const u32x4 p0 = *reinterpret_cast<const u32x4*>( &O->pos[lane][0] ), p1 = *reinterpret_cast<const u32x4*>( &O->pos[lane][8] );
+    const uint32_t pw[8] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w };
+#pragma unroll
+    for( int v = 0; v < 16; v++ ) pos[v] = ( v & 1 ) ? pw[v >> 1] >> 16 : pw[v >> 1] & 0xffffu;
+  }
+  WAVE_SYNC();
+  uint32_t gen = 0;
+  int32_t* xMine = xch + p * 64 * XP + lane * XP;
+  const int32_t* xOther = xch + ( p ^ 1 ) * 64 * XP + lane * XP;
+
+  for( int tu = pairIndex; tu < A.n; tu += pairStride )
+  {
+    const int16_t* src = resi + A.resiOff[tu] + ( ptrdiff_t ) ( 32 * p ) * resiStride;      // the wave's row tile
+    const vvhip_tu_qp qq = A.qps[tu];
+    int d[16];
+    v4i bLo, bHi;
+    // ---- forward rows of the own tile: tmp[y][k] = sat16( ( sum_{x<64} blk[y][x] * T[k][x] + rnd ) >> shift1 ), k < 32            (TrQuant.cpp:548)
+    {
+      v16i lo, hi = zero16;
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) lo[v] = cP1;
+#pragma unroll
+      for( int c = 0; c < 2; c++ )
+      {
+        const int16_t* q = src + ( ptrdiff_t ) c32 * resiStride + 32 * c + 16 * h;
+        const u32x4 x0 = reinterpret_cast<const U16*>( q )->v, x1 = reinterpret_cast<const U16*>( q + 8 )->v;
+        const uint32_t xr[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
+        v4i aLo, aHi;
+#pragma unroll
+        for( int g = 0; g < 4; g++ )
+        {
+          aLo[g] = ( int ) ( __builtin_amdgcn_perm( xr[2 * g + 1], xr[2 * g], 0x06040200u ) ^ 0x80808080u );
+          aHi[g] = ( int ) __builtin_amdgcn_perm( xr[2 * g + 1], xr[2 * g], 0x07050301u );
+        }
+        const v4i op = sOps[c * 64 + lane];
+        lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, op, lo, 0, 0, 0 );
+        hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, op, hi, 0, 0, 0 );
+      }
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shF1;
+      mxSplitSat( d, bLo, bHi );
+    }
+    // ---- forward columns, the own tile's half of the contraction over y: the halves meet in LDS; coef[k2][k] = ( sum_{y<64} T[k2][y] * tmp[y][k] + rnd ) >> shift2  (:549)
+    {
+      v16i lo, hi = zero16;
+#pragma unroll
+      for( int g = 0; g < 4; g++ ) { const v4i t4 = *reinterpret_cast<const v4i*>( &sInit[h * 16 + 4 * g] ); lo[4 * g] = t4.x; lo[4 * g + 1] = t4.y; lo[4 * g + 2] = t4.z; lo[4 * g + 3] = t4.w; }
+      const v4i op = sOps[2 * 64 + lane];
+      lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bLo, lo, 0, 0, 0 );
+      hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bHi, hi, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) { d[v] = ( hi[v] << 8 ) + lo[v]; xMine[v] = d[v]; }
+      tuMxPairSync( ctr, gen, lane );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( d[v] + xOther[v] ) >> A.shF2;
+    }
+    // ---- significance, QuantCore, DeQuantCore on the 32x32 coefficients (both waves, identical): exactly the 32-point section of tuMxBody
+    const TuMxQ P = tuMxParams( A.q, qq, A.thrVal );
+    uint32_t last = 0, mx = 0, big = 0;
+    const int thr4 = P.thres >> 2;
+#pragma unroll
+    for( int v = 0; v < 16; v++ )
+    {
+      const uint32_t ac = ( uint32_t ) abs( d[v] );
+      mx = ac > mx ? ac : mx;
+      last = ( ac != 0 && pos[v] > last ) ? pos[v] : last;
+      big = ( ( int ) __umul24( ac, ( uint32_t ) P.scale ) > thr4 && pos[v] > big ) ? pos[v] : big;
+    }
+    { const uint32_t lb = tuMxGroupMaxPk16( last | ( big << 16 ), 64, lane ); last = lb & 0xffffu; big = lb >> 16; }
+    mx = vvhipGroupMax32( mx, 64, lane );
+    const uint32_t need = ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) mx * P.scale + P.addN ) >> P.qBits ) != 0 );
+    const bool narrow = !( mx >= 65536u || P.qBits > 30 || P.qBits < 9 );
+    if( !narrow )
+    {
+      big = 0;
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) big = ( ( long long ) abs( d[v] ) * ( P.scale << 2 ) > ( long long ) P.thres && pos[v] > big ) ? pos[v] : big;
+      big = vvhipGroupMax32( big, 64, lane );
+    }
+    if( last >= 16 )
+    {
+      if( big < 16 ) last = 15;
+      else if( ( big >> 4 ) != ( last >> 4 ) ) last = ( big >> 4 ) * 16 + 15;
+    }
+    uint32_t sum = 0;
+    {
+      const int addP = ( int ) P.addQ, addM = ( int ) ( ( 1u << ( P.qBits & 31 ) ) - 1u ) - addP;
+      const int rsPos = P.rightShift > 0 ? P.rightShift : 0, rndDq = P.rightShift > 0 ? 1 << ( P.rightShift - 1 ) : 0;
+      const int iscaleL = P.rightShift < 0 ? P.iscale << ( -P.rightShift ) : P.iscale;
+#pragma unroll
+      for( int v = 0; v < 16; v++ )
+      {
+        const int cv = d[v];
+        int sm;
+        if( narrow ) sm = ( __mul24( cv, P.scale ) + ( cv < 0 ? addM : addP ) ) >> P.qBits;
+        else { const int m = ( int ) ( ( ( int64_t ) abs( cv ) * P.scale + P.addQ ) >> P.qBits ); sm = cv < 0 ? -m : m; }
+        sm = pos[v] <= last ? sm : 0;
+        sum += ( uint32_t ) abs( sm );
+        const int lv = clip3i( -32768, 32767, sm );
+        stage[( 16 * h + v ) * LP + c32] = ( int16_t ) lv;
+        const int cl = med3i( lv, ~P.inMax, P.inMax );
+        const int32_t w_ = ( int32_t ) ( ( uint32_t ) __mul24( cl, iscaleL ) + ( uint32_t ) rndDq ) >> rsPos;
+        d[v] = clip3i( -32768, 32767, w_ );
+      }
+    }
+    sum = vvhipGroupSum32( sum, 64, lane );
+    if( A.stats && p == 0 && lane == 0 )
+    {
+      int32_t* st = reinterpret_cast<int32_t*>( A.stats + tu );
+      st[0] = ( int32_t ) sum; st[1] = ( int32_t ) last; st[2] = ( int32_t ) need; st[3] = 0;
+    }
+    WAVE_SYNC();
+    // ---- levels: 64x64 raster, the 32x32 region from the (own) staging tile, zeros elsewhere: 512 runs of 8 samples, the wave stores rows 32p .. 32p + 31 (4 runs per lane)
+    if( A.level )
+#pragma unroll
+      for( int u = 0; u < 4; u++ )
+      {
+        const int q = lane + 64 * ( 4 * p + u ), Y = q >> 3, X = 8 * ( q & 7 );
+        u32x4 v = { 0, 0, 0, 0 };
+        if( Y < 32 && X < 32 ) v = *reinterpret_cast<const u32x4*>( &stage[Y * LP + X] );
+        *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * 4096 + Y * 64 + X ) = v;
+      }
+    WAVE_SYNC();
+    // ---- inverse columns of the own tile: t1[y][k] = clip( ( sum_{k2<32} deq[k2][k] * T[k2][y] + 64 ) >> 7 ), y in the tile                 (TrQuant.cpp:612)
+    v4i aLo, aHi;
+    mxSplit( d, aLo, aHi );
+    {
+      v16i c;
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) c[v] = cI1;
+      const v4i op = sOps[4 * 64 + lane];
+      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, op, c, 0, 0, 0 );
+      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, op, zero16, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shI1;
+      mxSplitSat( d, bLo, bHi );
+    }
+    // ---- inverse rows of the own tile x the two column chunks; SSE vs the residual (:613)
+    unsigned long long sse = 0;
+#pragma unroll
+    for( int c = 0; c < 2; c++ )
+    {
+      const int16_t* q = src + ( ptrdiff_t ) c32 * resiStride + 32 * c + 16 * h;
+      const u32x4 x0 = reinterpret_cast<const U16*>( q )->v, x1 = reinterpret_cast<const U16*>( q + 8 )->v;
+      const uint32_t xr[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
+      v16i ci;
+#pragma unroll
+      for( int g = 0; g < 4; g++ ) { const v4i t4 = *reinterpret_cast<const v4i*>( &sInit[32 + 32 * c + h * 16 + 4 * g] ); ci[4 * g] = t4.x; ci[4 * g + 1] = t4.y; ci[4 * g + 2] = t4.z; ci[4 * g + 3] = t4.w; }
+      const v4i op = sOps[( 6 + c ) * 64 + lane];
+      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bLo, ci, 0, 0, 0 );
+      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bHi, zero16, 0, 0, 0 );
+      uint32_t rp[8];
+#pragma unroll
+      for( int k = 0; k < 8; k++ )
+      {
+        const int v0 = ( ( hi[2 * k] << 8 ) + lo[2 * k] ) >> A.shI2, v1 = ( ( hi[2 * k + 1] << 8 ) + lo[2 * k + 1] ) >> A.shI2;
+        rp[k] = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( v0, v1 ) );
+        const int e0 = ( int ) ( int16_t ) ( xr[k] & 0xffff ) - ( int ) ( int16_t ) ( rp[k] & 0xffff ), e1 = ( ( int ) xr[k] >> 16 ) - ( ( int ) rp[k] >> 16 );
+        sse += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 );
+      }
+      if( A.rec )
+      {
+        int16_t* dst = A.rec + ( size_t ) tu * 4096 + ( 32 * p + c32 ) * 64 + 32 * c + 16 * h;
+        u32x4 a, b; a.x = rp[0]; a.y = rp[1]; a.z = rp[2]; a.w = rp[3]; b.x = rp[4]; b.y = rp[5]; b.z = rp[6]; b.w = rp[7];
+        *reinterpret_cast<u32x4*>( dst ) = a; *reinterpret_cast<u32x4*>( dst + 8 ) = b;
+      }
+    }
+    sse = vvhipGroupSum64( sse, 64, lane );
+    // the two tiles' SSE meet in the exchange area (slot 16 of lane 0's row: not part of the coefficient exchange), the first wave stores the TU's sum
+    if( lane == 0 ) { xMine[16] = ( int32_t ) ( uint32_t ) sse; xMine[XP + 16] = ( int32_t ) ( uint32_t ) ( sse >> 32 ); }
+    tuMxPairSync( ctr, gen, lane );
+    if( A.stats && p == 0 && lane == 0 )
+    {
+      const unsigned long long o = ( unsigned long long ) ( uint32_t ) xOther[16] | ( ( unsigned long long ) ( uint32_t ) xOther[XP + 16] << 32 );
+      A.stats[tu].sse = sse + o;
+    }
+  }
+#undef WAVE_SYNC
+}
+
+struct TuMxJobs { int nJobs; int pair64; int waveStart[8]; int size[8]; TuMxArgs j[8]; };
 
 // Three instances, by what the launch's lists need (registers differ widely): KIND 0 the 8/16/32-point bodies (168 registers: three waves per SIMD, their memory latencies
 // overlap), KIND 1 also the 4-point body (four TUs per lane), KIND 2 also the 64-point body.  The 64x64 body wants ~230 registers: capped at 168 it spilled inside its main path
@@ -1582,6 +1806,9 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t stage[4][32 * 40];
   __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t sInit[4][WITH64 ? 96 : 64];
   __shared__ v4i sOps[4][WITH64 ? 512 : 256];
+  __shared__ int32_t xch[WITH64 ? 2 : 1][WITH64 ? 2 * 64 * 17 : 1];      // 64x64 TUs: the exchange area of a wave pair (tuMx64PairBody)
+  __shared__ uint32_t pairCtr[2];
+  if( WITH64 ) { if( threadIdx.x < 2 ) pairCtr[threadIdx.x] = 0; __syncthreads(); }      // (before any wave leaves)
   const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) );
   const int wave = blockIdx.x * 4 + wv;
   int k = 0;
@@ -1594,7 +1821,12 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   else if( jobs.size[k] == 16 ) tuMxBody<16>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
   else if( jobs.size[k] == 8 )  tuMxBody<8>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
   else if( WITH4 && jobs.size[k] == 4 )   tuMxBody<4>( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
-  else if( WITH64 && jobs.size[k] == 64 ) tuMx64Body( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
+  else if( WITH64 && jobs.size[k] == 64 )
+  {
+    // two waves per 64x64 TU: waves 2i, 2i + 1 of the job = the pair ( wv & ~1, wv | 1 ) of this workgroup (the host keeps the job's first wave and wave count even)
+    if( jobs.pair64 ) tuMx64PairBody( stage[wv], sInit[wv], sOps[wv], xch[wv >> 1], &pairCtr[wv >> 1], w & 1, w >> 1, jobs.j[k].waveStride >> 1, resi, rs, jobs.j[k] );
+    else              tuMx64Body( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
+  }
 }
 
 __global__ void __launch_bounds__( 256 )
@@ -1977,13 +2209,18 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
     //  with its long 64x64 waves in front, one tile per wave and a second partial round beat fewer, longer waves)
     const long residentWaves = residentEnv ? residentEnv : ( has64 ? 4096 : 3072 );
     int budget = 0;
-    auto repeatOf = [&]( int i ) { const int work = jobs[order[i]].width == 64 ? 4 : 1; const int r = budget / work; return r < 1 ? 1 : r; };
+    // $VVHIP_TU_PAIR64=1: a 64x64 TU as a PAIR of waves (tuMx64PairBody), each worth two 32x32-tile units.  Measured (round 4, tools/tu_mix.py) and NOT the default: one TU
+    // per launch slot 8.8 -> 7.85 us, but 955 TUs 9.9 -> 10.7 us and the recorded mix 64:955 32:2133 16:600 8:800 4:600 18.5 -> 21.8 us — a wave's life is its set-up and its
+    // memory latencies (operand records, residual rows), which a second wave repeats instead of halving, and at two waves per SIMD the doubled wave count costs a further round
+    static const bool pair64 = getenv( "VVHIP_TU_PAIR64" ) && atoi( getenv( "VVHIP_TU_PAIR64" ) ) == 1;
+    auto wavesPer = [&]( int i ) { return ( jobs[order[i]].width == 64 && pair64 ) ? 2 : 1; };
+    auto repeatOf = [&]( int i ) { const int work = jobs[order[i]].width == 64 ? ( pair64 ? 2 : 4 ) : 1; const int r = budget / work; return r < 1 ? 1 : r; };
     if( mx && groupTiles <= repeat1Tiles * 4 )
     {
       for( budget = 1; budget < 8; budget++ )
       {
         long waves = 0;
-        for( int i = first; i < groupEnd; i++ ) waves += ( tilesOf( i ) + repeatOf( i ) - 1 ) / repeatOf( i );
+        for( int i = first; i < groupEnd; i++ ) waves += wavesPer( i ) * ( ( tilesOf( i ) + repeatOf( i ) - 1 ) / repeatOf( i ) );
         if( waves <= residentWaves ) break;
       }
     }
@@ -2012,7 +2249,7 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
     if( mx )
     {
       // matrix-core form: one wave per 32x32 tile of (32/N)^2 TUs
-      TuMxJobs xj; xj.nJobs = nJobs;
+      TuMxJobs xj; xj.nJobs = nJobs; xj.pair64 = pair64 ? 1 : 0;
       long waves = 0;
       for( int i = 0; i < nJobs; i++ )
       {
@@ -2028,8 +2265,9 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
         xa.qps = jb.d_qp; xa.thrVal = jb.thr_val; xa.level = jb.d_level; xa.rec = jb.d_rec_resi; xa.stats = jb.d_stats;
         xa.tiles = ( jb.n + tpt - 1 ) / tpt; xa.phaseLimit = tuPhaseLimit();
         const int repeat = budget ? repeatOf( first + i ) : tuRepeat();
-        xa.waveStride = ( xa.tiles + repeat - 1 ) / repeat;
+        xa.waveStride = wavesPer( first + i ) * ( ( xa.tiles + repeat - 1 ) / repeat );
         xa.resiStride = strides ? strides[order[first + i]] : 0;
+        if( wavesPer( first + i ) == 2 ) waves = ( waves + 1 ) & ~1l;          // a pair = waves 2g, 2g + 1 of the launch (one workgroup)
         xj.waveStart[i] = ( int ) waves; xj.size[i] = jb.width;
         waves += xa.waveStride;
       }
