@@ -460,7 +460,11 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     ST_SYNC();                                                                    // tables and positions are written; the previous pass's readers are done with tmp
     // ---- H: tmp[v - v0][r][x] <-> plane row y0 + K0 - 4 + r, column x + sx[v].  HU units per lane and trip, all their loads issued before the first is used (a unit is short:
     //      without it every trip of the wave waits out a full memory latency)
+#if defined( VVHIP_ME_CUT ) && ( VVHIP_ME_CUT & 1 )      // (cut build for phase timing, tools/me_cut.sh: no first pass — results are wrong by construction)
+    const int nH = 0;
+#else
     const int nH = nV * rowsT * G;
+#endif
     for( int ub = tid; ub < nH; ub += HU * nthr )
     {
       u32x4 LA[HU], LB[HU]; int fxs[HU], at[HU]; bool ok[HU];
@@ -520,7 +524,11 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     }
     ST_SYNC();     
     // ---- VD: LT lanes per (position, tile); what a lane holds: see the tile table above
+#if defined( VVHIP_ME_CUT ) && ( VVHIP_ME_CUT & 2 )      // (cut build: no second pass / distortion)
+    const int nSlots = 0;
+#else
     const int nSlots = ( pEnd - pBeg ) * tilesB * LT;
+#endif
     for( int u0 = 0; u0 < nSlots; u0 += nthr )
     {
       const int u = u0 + tid, r = u & ( LT - 1 ), tt = u >> log2LT;
@@ -999,7 +1007,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
                     if( unitW( x ) != unitW( y ) ) return unitW( x ) > unitW( y );
                     return band ? x.ref_off < y.ref_off : unitWork( x ) > unitWork( y ); } );      // picture order inside a sub-class (xcdBandOrder) / heaviest first
   int setWaves[6] = { 0, 0, 0, 0, 0, 0 }, setLds[6] = { 0, 0, 0, 0, 0, 0 };
-  static const int bundleWork = getenv( "VVHIP_ME_BUNDLE_WORK" ) ? atoi( getenv( "VVHIP_ME_BUNDLE_WORK" ) ) : 160;      // measured on the recorded 1080p lists: 80 / 160 / 320 / 640 / 1280 -> 59.0 / 58.7 / 61.9 / 67.9 / 71.1 us
+  static const int bundleWork = getenv( "VVHIP_ME_BUNDLE_WORK" ) ? atoi( getenv( "VVHIP_ME_BUNDLE_WORK" ) ) : 80;      // recorded 1080p lists, round 3: 80 / 160 / 320 / 640 / 1280 -> 59.0 / 58.7 / 61.9 / 67.9 / 71.1 us; round 4 (XCD-band order): 80 / 120 / 160 / 240 / 320 -> 41.0 / 44.2 / 44.3 / 44.5 / 43.3 us
   for( size_t i = 0; i < stOrder.size(); )
   {
     const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i] & 0xffffff];
