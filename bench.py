@@ -27,6 +27,7 @@ Extra objects of the JSON line (rank 0; each can be switched off; a failure is r
   mctf          BASELINE configs[2] stage at 1080p and 4K: hierarchical ME against 4 references + bilateral filter, ms per picture
   e2e / e2e_4k  the real encoder, 1080p x 65 and 3840x2160 x 65, preset faster: CPU kernels vs --SIMD=HIP, fps + bitstream md5 equality
   e2e_instances N > 1: one encoder instance per rank / GPU over GOP chunks of one sequence (EncoderLib/EncGOP.cpp:1647-1651 chunking), aggregate fps CPU vs --SIMD=HIP, per-chunk md5
+  config3_medium_4k  one 3840x2160 picture of a preset-medium encode (BASELINE configs[3]: CTU 128, rectangular blocks, GEO) through the same path: nothing dropped, bit-exact, ms per picture
   cpu_baseline  the reference's own AVX2 entries on the host cores over the same recorded lists: median of 5 passes per layer on pinned threads, GOP-weighted
 """
 import argparse
@@ -579,6 +580,49 @@ def e2e_instances(rank, local_rank, world, width=1920, height=1080, frames=33):
             "note": "one encoder process is host-bound (DESIGN 7): N-GPU frames/s in the sense of the metric is N instances; it scales with the host cores each instance gets, the GPUs are never the limit"}
 
 
+# ---------------------------------------------------------------------------------------------------------------------- BASELINE configs[3]'s lists (preset medium)
+def replay_medium_4k(hp, streams=5):
+    """one 3840x2160 picture of a preset-MEDIUM encode (BASELINE configs[3]'s geometry and preset: CTU 128, multi-type tree -> rectangular blocks 4..128, GEO masked SADs, two
+    references per list) through the same batched path: nothing of the recording left out, every output against the encoder's own values, time per picture"""
+    from vvenc_amd.replay import RecordedWorkload
+    pics, info = prepare_recordings(3840, 2160, 9, [4], tag="medium", threads=16)
+    wl = RecordedWorkload(hp, pics[4])
+    lanes = [hp.fork(torch.cuda.Stream()) for _ in range(streams)]
+    wl.bind_lanes(lanes)
+    for _ in range(3):
+        wl.run_lanes()
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        wl.run_lanes()
+    torch.cuda.synchronize()
+    ms = 1000.0 * (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(n):
+        wl.run()
+    torch.cuda.synchronize()
+    ms1 = 1000.0 * (time.perf_counter() - t0) / n
+    par = parity_check({5: wl})
+    me = wl.pic.me
+    shapes = sorted({(int(w), int(h)) for w, h in zip(me["w"].tolist(), me["h"].tolist())})
+    out = {"clip": "3840x2160 10-bit synthetic config-2 clip, 9 frames, preset medium, picture POC 4 (TL5)", "ms_per_picture": round(ms, 4), "pictures_per_s": round(1000.0 / ms, 1),
+           "ms_per_picture_single_stream": round(ms1, 4), "sample_pairs": int(wl.pic.sample_pairs), "sample_pairs_per_1p5WH": round(wl.pic.sample_pairs / (1.5 * 3840 * 2160), 1),
+           "recorded_calls_outside_the_lists": wl.dropped, "nothing_dropped": bool(wl.nothing_dropped), "parity": par,
+           "work": {"me_calls": int(me.size), "me_block_shapes": ["%dx%d" % s_ for s_ in shapes], "integer_candidates": int(wl.plan_cands.size), "subpel_stages": int(wl.stage_jobs.size),
+                    "table_calls": int(wl.items.size), "masked_sad_calls": int(wl.mask_items.size), "tus": int(sum(g["n"] for g in wl.tu_groups)),
+                    "tu_shapes": sorted({"%dx%d" % (g["w"], g["h"]) for g in wl.tu_groups}), "dmvr_subblocks": int(sum(g["n"] for g in wl.dmvr_groups)), "plan": wl.me_info},
+           "recording": info}
+    try:
+        cb = cpu_baseline({5: wl}, passes=3)
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "passes", "threads_pinned", "seconds_per_picture_by_layer") if k in cb}
+    except Exception as e:
+        out["cpu_baseline"] = {"error": str(e)[:200]}
+    for c in lanes:
+        c.close()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------- one replay pass (a resolution)
 def replay_pass(args, hp, rank, world, width, height, steps, warmup, extras):
     """records (or loads) the layer pictures of the width x height encode, puts them on the device, times `steps` steps and collects the per-kernel times.
@@ -802,6 +846,7 @@ def main():
     ap.add_argument("--no-mctf", action="store_true")
     ap.add_argument("--no-4k", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-medium", action="store_true", help="skip the replay of the preset-medium 4K picture (BASELINE configs[3]'s lists)")
     ap.add_argument("--profile-md", default=None, help="also write the rocprofv3 summary of this run (kernel table + counters per kernel class) as markdown to this path (the 4K pass: PATH with _4k before the extension)")
     ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 passes of the inner run (kernel trace + one pass per counter)")
     ap.add_argument("--e2e-threads", type=int, default=8)
@@ -915,6 +960,11 @@ def main():
             out["value_4k"] = None
             out["error_4k"] = str(e)[:400]
 
+    if world == 1 and not args.no_4k and not args.no_medium and (args.width, args.height) == (1920, 1080):
+        try:
+            out["config3_medium_4k"] = replay_medium_4k(hp)
+        except Exception as e:
+            out["config3_medium_4k"] = {"error": str(e)[:300]}
     if not args.no_mctf and world == 1:
         try:
             import bench_synthetic as BS
