@@ -562,10 +562,10 @@ def e2e_instances(rank, local_rank, world, width=1920, height=1080, frames=33):
             r = e2e_fps.run(dict(cfg, mask=mask), timeout=1200, env=env)
         except Exception as e:
             r = {"md5": "error: " + str(e)[-200:], "fps": 0.0}
-        dt = sharding.max_over_ranks(time.perf_counter() - t0)
+        dt = sharding.max_over_ranks(time.perf_counter() - t0, device="cuda")          # (device tensors: RCCL has no host reductions)
         res[name] = (r, dt)
     same = 1.0 if res["cpu"][0]["md5"] == res["hip"][0]["md5"] and not res["cpu"][0]["md5"].startswith("error") else 0.0
-    all_same = -sharding.max_over_ranks(-same)                               # min over ranks
+    all_same = -sharding.max_over_ranks(-same, device="cuda")                # min over ranks
     gathered = [None] * world
     if dist.is_initialized():
         dist.all_gather_object(gathered, {"rank": rank, "chunk_first_frame": rank * frames, "cpu_fps": round(res["cpu"][0]["fps"], 2), "hip_fps": round(res["hip"][0]["fps"], 2), "md5": res["cpu"][0]["md5"][:12],

@@ -233,6 +233,22 @@ def test_plan_creation_rejects_what_the_kernels_do_not_cover(env):
         hp.me_plan_create(ij, np.zeros(1, RP.ME_CAND), e_st, e_it, 10, 0)
 
 
+def test_stage_without_evaluated_positions_reads_nine_zeros(env):
+    """a stage whose mask is empty still gets its nine costs written (0) by every run — no stale memory, no clearing launch"""
+    from vvenc_amd import replay as RP
+    from vvenc_amd.hotpath import DF
+    hp, _ = env
+    rng = np.random.default_rng(5)
+    org_np, ref_np, ref_pad, org, ref, M = _setup(hp, rng, 10, False)
+    sj = np.zeros(3, RP.ME_STAGE_JOB)
+    sj[0] = (40 * org.stride + 40, 40 * ref.stride + 40, 16, 16, 0, 1, 2, 2, 0, DF["HAD"], 0, 0, 0, 0)            # empty mask
+    sj[1] = (40 * org.stride + 40, 40 * ref.stride + 40, 64, 64, 0, 1, 2, 2, 0, DF["HAD_fast"], 0, 0, 0, 0)      # empty mask, a stage shared by two waves
+    sj[2] = (40 * org.stride + 40, 40 * ref.stride + 40, 16, 16, 0, 1, 2, 2, 0, DF["HAD"], 0, 0, 1, 0)
+    planes = [(org.storage.data_ptr() + 2 * org.origin, org.stride), (ref.storage.data_ptr() + 2 * ref.origin, ref.stride)]
+    _, sc, _ = _run_plan(hp, planes, np.zeros(0, RP.ME_INT_JOB), np.zeros(0, RP.ME_CAND), sj, np.zeros(0, RP.ME_ITEM), None, 10)
+    assert (sc[0] == 0).all() and (sc[1] == 0).all() and sc[2, 0] > 0 and (sc[2, 1:] == 0).all(), sc
+
+
 def test_plan_run_rejects_a_short_plane_table(env):
     import torch
     from vvenc_amd import replay as RP
