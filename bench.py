@@ -435,6 +435,9 @@ def roofline_objects(kern, live, calib, unique_by_class, profile_md=None):
                      "alg_bytes_per_launch": kern[dom]["alg_bytes_per_picture"] / max(1e-9, n / 32.0),
                      "avg_launch_ms_measured": "rocprofv3 kernel trace of the inner run (launches serialized), averaged over the class's launches of one GOP cycle",
                      "achieved": (traffic / t_s / 1e9) if traffic else None, "frac": (traffic / t_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "frac_nominal_alg": (kern[dom]["alg_bytes_per_picture"] / max(1e-9, n / 32.0) / t_s / 1e9 / HBM_PEAK_GBS),
+                     "frac_note": "frac = fabric traffic / time / 8 TB/s (physical, counter-based: it FALLS when re-reads are removed — round 3: 95 MB per launch = 0.27, round 4: 15 MB = 0.05 for a "
+                                  "shorter launch); frac_nominal_alg = SURVEY 8d's per-position bytes / time / 8 TB/s (what a kernel without any reuse would have to stream)",
                      "fetch_factor": d["fetch_factor"], "traffic_bounds_MB": d["fabric_traffic_bounds_MB"],
                      "unique_bytes_per_picture": unique_by_class.get(dom), "traffic_over_unique": d["traffic_over_unique"], "l2_hit_rate": d["l2_hit_rate"],
                      "traffic_over_alg_bytes": (traffic * (n / 32.0) / kern[dom]["alg_bytes_per_picture"]) if traffic and kern[dom]["alg_bytes_per_picture"] else None,

@@ -833,12 +833,14 @@ meIntKernel( MePlanes P, MeArgs a, int nBig, int ldsSmall, int blockBase )
 // WAVES independent waves per workgroup (wave-level synchronisation only).  A B picture's ~13 000 one-pass waves are bound by the rate workgroups start at: four per workgroup
 // 23.6 -> 21.2 us (eight: 19.2, but long lists lose: a workgroup holds its slots until its slowest wave ends — the intra picture's 168 000 waves 116 -> 129 / 143 us), so long
 // lists keep single-wave workgroups.  GEN: see itemBody (waves firstWave .. of the plan's item schedule)
+// spansPerWave: a wave takes this many consecutive spans of the schedule (long lists: the intra picture's 168 000 one-pass waves are bound by the rate workgroups start at)
 template<int WAVES, bool GEN>
 __global__ void __launch_bounds__( 64 * WAVES ) __attribute__( ( amdgpu_waves_per_eu( VVHIP_ME_ITEM_WAVES, VVHIP_ME_ITEM_WAVES ) ) )
-meItemKernel( MePlanes P, MeArgs a, int nItems, int firstWave, int nWaves )
+meItemKernel( MePlanes P, MeArgs a, int nItems, int firstWave, int nWaves, int spansPerWave )
 {
-  const int wave = blockIdx.x * WAVES + ( int ) ( threadIdx.x >> 6 );
-  if( wave < nWaves ) itemBody<GEN>( P, a, firstWave + wave, nItems );
+  const int wave = ( blockIdx.x * WAVES + ( int ) ( threadIdx.x >> 6 ) ) * spansPerWave;
+  for( int q = 0; q < spansPerWave; q++ )
+    if( wave + q < nWaves ) { itemBody<GEN>( P, a, firstWave + wave + q, nItems ); __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
 }
 
 // XCD-aware order of a launch's workgroups.  Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MB L2.  The entries of a class —
@@ -1306,16 +1308,23 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   if( plan->wavesItem && doItem )
   {
     const int nMain = plan->wavesItemMain, nGen = plan->wavesItem - nMain;
-    if( nMain )
+    static const int longSpans = getenv( "VVHIP_ME_ITEM_SPANS" ) ? atoi( getenv( "VVHIP_ME_ITEM_SPANS" ) ) : 1;
+    auto launch = [&]( bool gen, int first, int n )
     {
-      if( nMain <= 65536 ) hipLaunchKernelGGL( ( meItemKernel<4, false> ), dim3( ( unsigned ) ( ( nMain + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a, plan->nItems, 0, nMain );
-      else                 hipLaunchKernelGGL( ( meItemKernel<1, false> ), dim3( ( unsigned ) nMain ), dim3( 64 ), 0, ctx->stream, P, a, plan->nItems, 0, nMain );
-    }
-    if( nGen )
-    {
-      if( nGen <= 65536 ) hipLaunchKernelGGL( ( meItemKernel<4, true> ), dim3( ( unsigned ) ( ( nGen + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a, plan->nItems, nMain, nGen );
-      else                hipLaunchKernelGGL( ( meItemKernel<1, true> ), dim3( ( unsigned ) nGen ), dim3( 64 ), 0, ctx->stream, P, a, plan->nItems, nMain, nGen );
-    }
+      if( n <= 65536 )
+      {
+        if( gen ) hipLaunchKernelGGL( ( meItemKernel<4, true> ), dim3( ( unsigned ) ( ( n + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a, plan->nItems, first, n, 1 );
+        else      hipLaunchKernelGGL( ( meItemKernel<4, false> ), dim3( ( unsigned ) ( ( n + 3 ) / 4 ) ), dim3( 256 ), 0, ctx->stream, P, a, plan->nItems, first, n, 1 );
+      }
+      else
+      {
+        const int spw = longSpans < 1 ? 1 : longSpans, nw = ( n + spw - 1 ) / spw;
+        if( gen ) hipLaunchKernelGGL( ( meItemKernel<1, true> ), dim3( ( unsigned ) nw ), dim3( 64 ), 0, ctx->stream, P, a, plan->nItems, first, n, spw );
+        else      hipLaunchKernelGGL( ( meItemKernel<1, false> ), dim3( ( unsigned ) nw ), dim3( 64 ), 0, ctx->stream, P, a, plan->nItems, first, n, spw );
+      }
+    };
+    if( nMain ) launch( false, 0, nMain );
+    if( nGen ) launch( true, nMain, nGen );
   }
   VVHIP_LAUNCH_CHECK( ctx );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[4], ctx->stream ) );
