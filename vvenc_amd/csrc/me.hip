@@ -39,6 +39,7 @@ struct vvhip_me_plan
   int bitDepth = 0, nCands = 0, nStages = 0, nItems = 0, nMaskItems = 0, maxPlane = 0;
   int wavesInt = 0, wavesStage = 0, wavesItem = 0, wavesItemMain = 0, ldsInt = 0, ldsStage = 0;      // wavesItemMain: the leading item waves the lean body takes (the rest: generic body, own launch)
   int intBig = 0, ldsIntSmall = 0;          // the first intBig windows need up to ldsInt bytes of LDS, the others at most ldsIntSmall (two launches: small blocks keep their occupancy)
+  bool stageAtomic = false;                 // some stages add their units' sums with atomics: the cost array is cleared in front of the stage launches
   bool intSplit = false;                    // the large windows need far more LDS than four small ones: two launches (the small windows keep their occupancy)
   bool timing = false; hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };      // optional per-kernel events of the last run (vvhip_me_plan_set_timing)
   // stage bundles per launch class, in schedule order: class = 2 * tap support (4-tap search set, 6 taps / alternative half-pel, 8 taps) + generic (0: the square 8..64 blocks of
@@ -382,8 +383,8 @@ __device__ __forceinline__ uint32_t hadTeam( int ( &d )[8], int r, int LT, int k
   return hadNorm( s, kind );
 }
 
-// a stage unit in the schedule: stage index | band of 32 rows << 24 | 64-column half << 27 | continues the previous unit's sums << 28 | the next unit continues << 29
-constexpr int ST_UNIT_CONT = 1 << 28, ST_UNIT_MORE = 1 << 29;
+// a stage unit in the schedule: stage index | band of 32 rows << 24 | 64-column half << 27 | continues the previous unit's sums << 28 | the next unit continues << 29 | atomic << 30
+constexpr int ST_UNIT_CONT = 1 << 28, ST_UNIT_MORE = 1 << 29, ST_UNIT_ATOMIC = 1 << 30;      // ATOMIC: a stage of more than two units — every unit a wave of its own, sums added to the (cleared) cost array
 
 // GEN = false: the shapes of the fast presets (CTU 64, quad-tree only) — square 8..64, tiles 8x8 / 16x16_fast / SAD rows, eight lanes per tile: every tile quantity is a
 // compile-time constant.  GEN = true: any shape (CTU 128 + multi-type tree); such units run in their own launch (their own registers, their own LDS size).
@@ -596,7 +597,13 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     if( unit & ST_UNIT_MORE ) continue;                                            // the wave's next unit belongs to the same stage and adds to the same sums
     // the stage's nine costs (0 for positions outside the mask).  A block of several units is shared by the two waves of this workgroup (the schedule puts them side by
     // side, half of the units each): the second wave hands its sums over through LDS, the first stores the totals — no atomics on the cost array, no clearing of it before the launch
-    if( h <= 32 && w <= 64 ) { if( tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] : 0u; }
+    if( GEN && ( unit & ST_UNIT_ATOMIC ) )
+    {
+      // a stage of more than two units (128-wide or 128-high blocks): the units are independent waves, their sums meet in the cost array (cleared in front of the launch;
+      // integer additions commute: the result does not depend on the schedule)
+      if( tid < 9 && ( ( j.mask >> tid ) & 1 ) ) atomicAdd( reinterpret_cast<unsigned long long*>( a.stageCost ) + ( size_t ) 9 * stage + tid, ( unsigned long long ) costL[tid] );
+    }
+    else if( h <= 32 && w <= 64 ) { if( tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] : 0u; }
     else
     {
       if( wv == 1 && tid < 9 ) pairCost[tid] = costL[tid];
@@ -987,25 +994,33 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     if( !ok )
       return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: stage job %d (%dx%d, iFrac %d, mode %d, func %d, base %d,%d, mask %x)", i, s.width, s.height, s.i_frac, s.filter_mode, s.func, s.base_qx, s.base_qy, s.mask );
   }
+  // $VVHIP_ME_ATOMIC_STAGES=0: stages of more than two units as two waves of four (two) units each, the first form of round 4
+  static const bool atomicStages = !( getenv( "VVHIP_ME_ATOMIC_STAGES" ) && atoi( getenv( "VVHIP_ME_ATOMIC_STAGES" ) ) == 0 );
   auto tapSetOf = []( const vvhip_me_stage_job& s ) { return ( s.filter_mode == 2 && !s.alt_hpel ) ? 0 : ( s.filter_mode == 0 ? 2 : 1 ); };      // which tap support the bundle's kernel instance uses
   auto setOf = [&]( const vvhip_me_stage_job& s ) { const bool sq = s.width == s.height && s.width >= 8 && s.width <= 64; return 2 * tapSetOf( s ) + ( sq ? 0 : 1 ); };      // launch class
   auto unitW = []( const vvhip_me_stage_job& s ) { return std::min( ( int ) s.width, 64 ); };
   auto unitH = []( const vvhip_me_stage_job& s ) { return std::min( ( int ) s.height, 32 ); };
   auto unitsOf = [&]( const vvhip_me_stage_job& s ) { return ( s.width / unitW( s ) ) * ( s.height / unitH( s ) ); };
+  // how a stage's units are dealt: 0 = shared by the two waves of one workgroup (two units; more when the atomic form is off), 1 = more than two units, every unit a wave of its
+  // own adding into the cleared cost array, 2 = a single unit (bundled with others)
+  auto dealOf = [&]( const vvhip_me_stage_job& s ) { const int n = unitsOf( s ); return n == 1 ? 2 : ( ( n > 2 && atomicStages ) ? 1 : 0 ); };
   auto unitWork = [&]( const vvhip_me_stage_job& s ) { return __builtin_popcount( s.mask ) * std::max( 1, unitW( s ) / 8 ) * unitH( s ); };      // 8-sample row groups of the second pass
   std::vector<int32_t> stOrder;
+  bool hasAtomic = false;
   for( int i = 0; i < n_stage_jobs; i++ )      // (a stage without evaluated positions still gets its unit: the kernel writes its nine zeros)
   {
     const vvhip_me_stage_job& s = stage_jobs[i];
-    const int bands = s.height / unitH( s ), halves = s.width / unitW( s ), n = bands * halves, perWave = n > 1 ? n / 2 : 1;
+    const int bands = s.height / unitH( s ), halves = s.width / unitW( s ), n = bands * halves;
+    if( n > 2 && atomicStages ) { hasAtomic = true; for( int u = 0; u < n; u++ ) stOrder.push_back( i | ( ( u % bands ) << 24 ) | ( ( u / bands ) << 27 ) | ST_UNIT_ATOMIC ); continue; }
+    const int perWave = n > 1 ? n / 2 : 1;
     for( int u = 0; u < n; u++ )
       stOrder.push_back( i | ( ( u % bands ) << 24 ) | ( ( u / bands ) << 27 ) | ( ( u % perWave ) ? ST_UNIT_CONT : 0 ) | ( ( u % perWave ) != perWave - 1 ? ST_UNIT_MORE : 0 ) );
   }
   // per tap support: the stages of several units first (their waves must be the pairs 2g, 2g + 1 of the launch), then by unit width and work
   std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & 0xffffff]; const auto& y = stage_jobs[b & 0xffffff];
-                    const bool px = unitsOf( x ) > 1, py = unitsOf( y ) > 1;
+                    const int px = dealOf( x ), py = dealOf( y );
                     if( setOf( x ) != setOf( y ) ) return setOf( x ) < setOf( y );
-                    if( px != py ) return px;
+                    if( px != py ) return px < py;
                     if( unitW( x ) != unitW( y ) ) return unitW( x ) > unitW( y );
                     return band ? x.ref_off < y.ref_off : unitWork( x ) > unitWork( y ); } );      // picture order inside a sub-class (xcdBandOrder) / heaviest first
   int setWaves[6] = { 0, 0, 0, 0, 0, 0 }, setLds[6] = { 0, 0, 0, 0, 0, 0 };
@@ -1014,12 +1029,13 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   {
     const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i] & 0xffffff];
     int count = 0, work = 0;
-    if( unitsOf( s0 ) > 1 ) count = unitsOf( s0 ) / 2;      // half of a shared stage's units: a wave of its own, next to its sibling
+    if( dealOf( s0 ) == 0 ) count = unitsOf( s0 ) / 2;      // half of a shared stage's units: a wave of its own, next to its sibling
+    else if( dealOf( s0 ) == 1 ) count = 1;                  // a unit of an atomic stage
     else
       while( i + count < stOrder.size() && count < 8 )
       {
         const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count] & 0xffffff];
-        if( unitW( s ) != unitW( s0 ) || setOf( s ) != setOf( s0 ) || unitsOf( s ) > 1 || ( count && work + unitWork( s ) > bundleWork ) ) break;
+        if( unitW( s ) != unitW( s0 ) || setOf( s ) != setOf( s0 ) || dealOf( s ) != 2 || ( count && work + unitWork( s ) > bundleWork ) ) break;
         work += unitWork( s ); count++;
       }
     WaveSpan sp; sp.first = ( int32_t ) i; sp.count = count; stWaves.push_back( sp );
@@ -1037,7 +1053,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     std::vector<WaveSpan> src( stWaves );
     for( int k = 0, first = 0; k < 6; first += setWaves[k], k++ )
     {
-      auto subOf = [&]( int w ) { const vvhip_me_stage_job& s = stage_jobs[stOrder[src[first + w].first] & 0xffffff]; return ( unitsOf( s ) > 1 ? 1024 : 0 ) + unitW( s ); };
+      auto subOf = [&]( int w ) { const vvhip_me_stage_job& s = stage_jobs[stOrder[src[first + w].first] & 0xffffff]; return ( 2 - dealOf( s ) ) * 1024 + unitW( s ); };
       for( int w0 = 0; w0 < setWaves[k]; )
       {
         int w1 = w0;
@@ -1058,7 +1074,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
       const WaveSpan& sp = stWaves[first + w];
       const int u = stOrder[sp.first];
       const vvhip_me_stage_job& s = stage_jobs[u & 0xffffff];
-      if( unitsOf( s ) <= 1 ) continue;
+      if( dealOf( s ) != 0 ) continue;
       const int sib = ( w & 1 ) ? w - 1 : w + 1;
       if( sp.count != unitsOf( s ) / 2 || sib >= setWaves[k] || stWaves[first + sib].count != sp.count || ( stOrder[stWaves[first + sib].first] & 0xffffff ) != ( u & 0xffffff ) )
         return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: schedule error (the units of stage %d are not one workgroup)", u & 0xffffff );
@@ -1199,7 +1215,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   if( e != hipSuccess ) { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: upload: %s", hipGetErrorString( e ) ); }
   char* b = static_cast<char*>( p->d_blob );
   p->d_intJobs = b + oInt; p->d_cands = b + oCand; p->d_stageJobs = b + oSt; p->d_stageOrder = b + oStO; p->d_stageWaves = b + oStW; p->d_items = b + oIt; p->d_itemOrder = b + oItO; p->d_itemWaves = b + oItW; p->d_tapTables = b + oTap; p->d_maskItems = b + oMk;
-  p->bitDepth = bit_depth; p->nCands = n_cands; p->nStages = n_stage_jobs; p->nItems = n_items; p->nMaskItems = n_mask; p->maxPlane = maxPlane;
+  p->bitDepth = bit_depth; p->nCands = n_cands; p->nStages = n_stage_jobs; p->nItems = n_items; p->nMaskItems = n_mask; p->maxPlane = maxPlane; p->stageAtomic = hasAtomic;
   p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size(); p->wavesItemMain = wavesItemMain;
   p->ldsInt = ( ldsInt + 15 ) & ~15; p->ldsStage = ( ldsStage + 15 ) & ~15;
   for( int k = 0; k < 6; k++ ) { p->stageSetWaves[k] = setWaves[k]; p->stageSetLds[k] = setLds[k]; }
@@ -1277,6 +1293,7 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   const bool tm = plan->timing && parts == 7;
   const bool doStage = ( parts & 1 ) != 0, doInt = ( parts & 2 ) != 0, doItem = ( parts & 4 ) != 0;
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[0], ctx->stream ) );
+  if( plan->stageAtomic && doStage ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_stage_cost, 0, ( size_t ) 9 * 8 * plan->nStages, ctx->stream ) );
   int firstWave = 0;
   static const int ldsPadExp = getenv( "VVHIP_ME_LDS_PAD" ) ? atoi( getenv( "VVHIP_ME_LDS_PAD" ) ) : 0;      // experiment: occupancy sensitivity of the stage kernel
   constexpr int stW = 2;                                                                // waves per workgroup (see meStageKernel)
