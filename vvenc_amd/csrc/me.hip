@@ -39,6 +39,7 @@ struct vvhip_me_plan
   int bitDepth = 0, nCands = 0, nStages = 0, nItems = 0, nMaskItems = 0, maxPlane = 0;
   int wavesInt = 0, wavesStage = 0, wavesItem = 0, wavesItemMain = 0, ldsInt = 0, ldsStage = 0;      // wavesItemMain: the leading item waves the lean body takes (the rest: generic body, own launch)
   int intBig = 0, ldsIntSmall = 0;          // the first intBig windows need up to ldsInt bytes of LDS, the others at most ldsIntSmall (two launches: small blocks keep their occupancy)
+  int intLarge = 0, ldsIntMid = 0;          // of the intBig windows, the first intLarge are the > 24 KB class; the others need at most ldsIntMid
   bool stageAtomic = false;                 // some stages add their units' sums with atomics: the cost array is cleared in front of the stage launches
   bool intSplit = false;                    // the large windows need far more LDS than four small ones: two launches (the small windows keep their occupancy)
   bool timing = false; hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };      // optional per-kernel events of the last run (vvhip_me_plan_set_timing)
@@ -947,26 +948,32 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   }
   // windows that need much LDS first (their own launch), inside each class heaviest first
   auto ldsOf = []( const IntJob& j ) { return ( hostWinSamples( j.winW, j.winH ) + ( j.h >> j.subShift ) * j.w ) * 2 + j.nCand * ( int ) sizeof( PlanCand ); };      // window + original + candidate records
-  const int ldsSmallCap = 6 * 1024;
+  // three LDS classes, one launch each when they differ much: a launch's dynamic LDS is its largest job's, so one 128x128 window (58 KB) would cap every 64x64 window (17 KB) of
+  // the same launch at two workgroups per CU.  Class 0: > 24 KB, 1: > 6 KB (one workgroup per window), 2: the small ones (four windows per workgroup, one per wave)
+  const int ldsSmallCap = 6 * 1024, ldsMidCap = 24 * 1024;
   const bool band = xcdBandOn();
-  std::stable_sort( ij.begin(), ij.end(), [&]( const IntJob& a, const IntJob& b ) { const bool ba = ldsOf( a ) > ldsSmallCap, bb = ldsOf( b ) > ldsSmallCap; if( ba != bb ) return ba;
+  auto classOf = [&]( const IntJob& j ) { const int l = ldsOf( j ); return l > ldsMidCap ? 0 : ( l > ldsSmallCap ? 1 : 2 ); };
+  std::stable_sort( ij.begin(), ij.end(), [&]( const IntJob& a, const IntJob& b ) { const int ca = classOf( a ), cb = classOf( b ); if( ca != cb ) return ca < cb;
                     if( band ) return a.refOff < b.refOff;                                    // picture order inside a class: see xcdBandOrder
                     return ( long ) a.nCand * a.w * ( a.h >> a.subShift ) + ( long ) a.winW * a.winH > ( long ) b.nCand * b.w * ( b.h >> b.subShift ) + ( long ) b.winW * b.winH; } );
-  int intBig = 0, ldsIntSmall = 0;
-  for( const IntJob& j : ij ) { if( ldsOf( j ) > ldsSmallCap ) intBig++; else ldsIntSmall = std::max( ldsIntSmall, ldsOf( j ) ); }
+  int intLarge = 0, intBig = 0, ldsIntSmall = 0, ldsIntMid = 0;
+  for( const IntJob& j : ij ) { const int c = classOf( j ); if( c == 0 ) intLarge++; if( c <= 1 ) intBig++; if( c == 1 ) ldsIntMid = std::max( ldsIntMid, ldsOf( j ) ); if( c == 2 ) ldsIntSmall = std::max( ldsIntSmall, ldsOf( j ) ); }
   if( band && !ij.empty() )
   {
-    // workgroups: one large window each, then four small windows each (meIntKernel).  Inside an XCD's eighth the heaviest jobs start first (a band's planes fit the L2 whatever
-    // the order inside it, and a raster search's windows are far heavier than a diamond's: in plain picture order the launch ended on a tail of them — 30.7 -> 34.9 us)
+    // workgroups: one window each for classes 0 and 1, then four small windows each (meIntKernel).  Inside an XCD's eighth the heaviest jobs start first (a band's planes fit
+    // the L2 whatever the order inside it, and a raster search's windows are far heavier than a diamond's: in plain picture order the launch ended on a tail of them — 30.7 -> 34.9 us)
     auto weightOf = []( const IntJob& j ) { return ( long ) j.nCand * j.w * ( j.h >> j.subShift ) + ( long ) j.winW * j.winH; };
     auto heavyFirstPerEighth = [&]( int begin, int n, int per ) { const int q = ( ( n + per - 1 ) / per + 7 ) / 8 * per;
       for( int x = 0; x < 8 && q; x++ ) { const int a = std::min( n, x * q ), b = std::min( n, ( x + 1 ) * q );
         std::stable_sort( ij.begin() + begin + a, ij.begin() + begin + b, [&]( const IntJob& u, const IntJob& v ) { return weightOf( u ) > weightOf( v ); } ); } };
-    heavyFirstPerEighth( 0, intBig, 1 );
+    heavyFirstPerEighth( 0, intLarge, 1 );
+    heavyFirstPerEighth( intLarge, intBig - intLarge, 1 );
     heavyFirstPerEighth( intBig, ( int ) ij.size() - intBig, 4 );
     std::vector<IntJob> src( ij );
-    const std::vector<int> pb = xcdBandOrder( intBig, 0 );
-    for( int l = 0; l < intBig; l++ ) ij[l] = src[pb[l]];
+    const std::vector<int> pl = xcdBandOrder( intLarge, 0 );
+    for( int l = 0; l < intLarge; l++ ) ij[l] = src[pl[l]];
+    const std::vector<int> pb = xcdBandOrder( intBig - intLarge, intLarge );
+    for( int l = 0; l < intBig - intLarge; l++ ) ij[intLarge + l] = src[intLarge + pb[l]];
     const int nSmall = ( int ) src.size() - intBig, nGr = ( nSmall + 3 ) / 4;
     const std::vector<int> ps = xcdBandOrder( nGr, intBig );
     for( int l = 0, o = intBig; l < nGr; l++ ) for( int k = 0; k < 4 && ps[l] * 4 + k < nSmall; k++ ) ij[o++] = src[intBig + ps[l] * 4 + k];
@@ -1219,7 +1226,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size(); p->wavesItemMain = wavesItemMain;
   p->ldsInt = ( ldsInt + 15 ) & ~15; p->ldsStage = ( ldsStage + 15 ) & ~15;
   for( int k = 0; k < 6; k++ ) { p->stageSetWaves[k] = setWaves[k]; p->stageSetLds[k] = setLds[k]; }
-  p->intBig = intBig; p->ldsIntSmall = ( ldsIntSmall + 15 ) & ~15;
+  p->intBig = intBig; p->ldsIntSmall = ( ldsIntSmall + 15 ) & ~15; p->intLarge = intLarge; p->ldsIntMid = ( ldsIntMid + 15 ) & ~15;
   // 128-wide blocks make the large windows' LDS several times what four small windows need: their own launch then, so that the small windows keep their occupancy
   p->intSplit = intBig > 0 && intBig < ( int ) ij.size() && p->ldsInt > 2 * 4 * p->ldsIntSmall && p->ldsInt > 32 * 1024;
   if( p->ldsInt > 160 * 1024 || p->ldsStage > 64 * 1024 )
@@ -1313,12 +1320,22 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
     // one launch for both window classes (two launches of a few thousand short-lived waves each were mostly ramp-up and drain: 20.6 + 18.0 us on a recorded 1080p picture)
     const int nSmall = plan->wavesInt - plan->intBig, lds = std::max( plan->intBig ? plan->ldsInt : 0, nSmall ? 4 * plan->ldsIntSmall : 0 );
     if( plan->ldsInt > 64 * 1024 ) VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) meIntKernel, hipFuncAttributeMaxDynamicSharedMemorySize, plan->ldsInt ) );
-    if( plan->intSplit )
+    const int nLarge = plan->intLarge, nMid = plan->intBig - nLarge;
+    // one launch per LDS class where the classes differ much (each class keeps the occupancy its own windows allow), one launch for everything otherwise
+    const bool splitLarge = nLarge > 0 && nMid > 0 && plan->ldsInt > plan->ldsIntMid + plan->ldsIntMid / 2;
+    const bool splitSmall = plan->intSplit;
+    if( !splitLarge && !splitSmall ) hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( plan->intBig + ( nSmall + 3 ) / 4 ) ), dim3( 256 ), ( size_t ) lds, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, 0 );
+    else
     {
-      hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->intBig ), dim3( 256 ), ( size_t ) plan->ldsInt, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, 0 );
-      hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( ( nSmall + 3 ) / 4 ) ), dim3( 256 ), ( size_t ) 4 * plan->ldsIntSmall, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, plan->intBig );
+      if( splitLarge )
+      {
+        hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) nLarge ), dim3( 256 ), ( size_t ) plan->ldsInt, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, 0 );
+        const int rest = nMid + ( splitSmall ? 0 : ( nSmall + 3 ) / 4 ), ldsRest = std::max( plan->ldsIntMid, splitSmall ? 0 : 4 * plan->ldsIntSmall );
+        hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) rest ), dim3( 256 ), ( size_t ) ldsRest, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, nLarge );
+      }
+      else hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) plan->intBig ), dim3( 256 ), ( size_t ) plan->ldsInt, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, 0 );
+      if( splitSmall && nSmall ) hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( ( nSmall + 3 ) / 4 ) ), dim3( 256 ), ( size_t ) 4 * plan->ldsIntSmall, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, plan->intBig );
     }
-    else hipLaunchKernelGGL( meIntKernel, dim3( ( unsigned ) ( plan->intBig + ( nSmall + 3 ) / 4 ) ), dim3( 256 ), ( size_t ) lds, ctx->stream, P, a, plan->intBig, plan->ldsIntSmall, 0 );
   }
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[2], ctx->stream ) );
   if( tm ) VVHIP_CHECK_HIP( ctx, hipEventRecord( plan->ev[3], ctx->stream ) );
