@@ -1,22 +1,26 @@
-// me.hip — motion-search plans: the distortion work of one picture's inter search in ONE launch (include/vvenc_hip.h, "Motion-search plans").
+// me.hip — motion-search plans: the distortion work of one picture's inter search as a handful of launches (include/vvenc_hip.h, "Motion-search plans").
 //
 // Shaped by the work lists the reference encoder really produces (recorded from it: bindings/vvenc/vvenc_hip_recorder.*, vvenc_amd/recorded.py), not by uniform
 // synthetic ones: an InterSearch::xMotionEstimation call (EncoderLib/InterSearch.cpp:1976-2130) scores ~20 integer positions that lie within a few samples of each
 // other (start points, then the 4-point diamond and square at distance 1, :2385-2410; a third of them repeated), then one or two xPatternRefinement stages
-// (:760-880) of <= 9 sub-pel positions; two thirds of all sample pairs belong to 64x64 blocks.  Three kinds of work, one wave (= one workgroup) per unit:
+// (:760-880) of <= 9 sub-pel positions; at preset faster two thirds of all sample pairs belong to 64x64 blocks, preset medium (CTU 128 + multi-type tree) brings every
+// rectangular shape 4..128 and GEO's masked SADs.  Kinds of work, one wave per unit:
 //   integer job   the bounding window of the job's candidates is staged ONCE in LDS (samples biased for v_sad_u16), the original block next to it; every candidate is then
 //                 scored from LDS by a team of lanes (dword reads at the even address below the candidate + v_alignbit for odd displacements): the L1 sees the window once
-//                 per job instead of once per candidate.                                                    xGetSAD*, CommonLib/RdCost.cpp:301-644
-//   stage bundle  a few (stage, band of <= 32 rows) units of one block width.  Per unit: horizontal pass of the <= 3 distinct horizontal positions straight from the plane
-//                 into LDS (14-bit intermediates, InterpolationFilter.cpp:356-441), then eight lanes per (position, Hadamard tile): vertical pass of the lane's own row(s)
-//                 out of LDS, difference to the original block, 8x8 / 16x16_fast Hadamard with the vertical butterflies across the eight lanes (DPP) — the prediction never
-//                 exists in memory.                                                                        xGetHADs<fast>, RdCost.cpp:1818-1938; tiles :1126-1322
-//   item bundle   plain table calls (merge / AMVP / intra candidates, residual SSE) on blocks of any two planes: lane teams on 8-sample row chunks (SAD, SSE), eight lanes
-//                 per 8x8 / 16x16_fast Hadamard tile, one lane per 4x4 tile.
+//                 per job instead of once per candidate.  Three LDS classes, a launch each when they differ much.      xGetSAD*, CommonLib/RdCost.cpp:301-644
+//   stage bundle  a few (stage, <= 32 rows x <= 64 columns) units of one unit width.  Per unit: horizontal pass of the <= 3 distinct horizontal positions straight from the
+//                 plane into LDS (14-bit intermediates, InterpolationFilter.cpp:356-441), then a team of lanes per (position, Hadamard tile): vertical pass of the lane's own
+//                 row(s) out of LDS, difference to the original block, the tile's transform in registers and across the team (DPP) — the prediction never exists in memory.
+//                 The reference's tile ladder: 16x8, 8x16, 8x4, 4x8, 16x16_fast, 8x8.                    xGetHADs<fast>, RdCost.cpp:1818-1938; tiles :1028-1766
+//                 Six launch classes: tap support x (the fast presets' square shapes with compile-time tile constants / any shape).
+//   item bundle   plain table calls (merge / AMVP / intra candidates, residual SSE) on blocks of any two planes or pools: lane teams on row chunks (SAD, SSE, masked SAD),
+//                 lane teams per Hadamard tile, one lane per 4x4 block / 2x2 tile.  Lean instance for what the fast presets call, generic instance for the rest.
 // These are short-lived waves: what they cost is their chain of dependent memory accesses, not their arithmetic.  Hence: job tables in schedule order (no order -> record
-// indirection), every global request of a job issued before the first wait, candidate records / plane table / tap tables staged in LDS once per wave, a cap on the serial work
-// of one workgroup (candidates per window, row groups per bundle), one launch per kind.
-// Results are bit-exact with the reference's table entries (tests: recorded costs of the real encoder, and the per-function kernels of dist.hip / interp.hip).
+// indirection), every global request of a job issued before the first wait, candidate records / plane table / tap tables staged in LDS once per wave, per-unit derived data
+// precomputed by plan creation, a cap on the serial work of one workgroup (candidates per window, row groups per bundle, units per wave), and — round 4 — every launch's
+// workgroups in XCD-band order (xcdBandOrder): each XCD's private L2 streams one horizontal band of the picture.
+// Results are bit-exact with the reference's table entries (tests: the oracle directly over every shape, tests/test_gpu_me_shapes.py; the recorded costs of the real encoder,
+// tests/test_gpu_replay.py; the per-function kernels of dist.hip / interp.hip).
 #include <stdlib.h>
 #ifndef VVHIP_ME_HU
 #define VVHIP_ME_HU 2
