@@ -633,7 +633,7 @@ def replay_medium_4k(hp, streams=5):
 
 
 # ---------------------------------------------------------------------------------------------------------------------- one replay pass (a resolution)
-def replay_pass(args, hp, rank, world, width, height, steps, warmup, extras):
+def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     """records (or loads) the layer pictures of the width x height encode, puts them on the device, times `steps` steps and collects the per-kernel times.
     -> (core fields of the JSON line, workloads, kern)"""
     from vvenc_amd.replay import RecordedWorkload
@@ -889,7 +889,7 @@ def main():
         torch.cuda.synchronize()
         return
 
-    core, workloads, kern = replay_pass(args, hp, rank, world, args.width, args.height, args.steps, args.warmup, True)
+    core, workloads, kern = replay_pass(args, hp, rank, world, args.width, args.height, args.steps, args.warmup)
     inst = None
     if world > 1 and not args.no_e2e:
         try:
@@ -944,7 +944,7 @@ def main():
         del workloads
         torch.cuda.empty_cache()
         try:
-            c4, w4, k4 = replay_pass(args, hp, rank, world, 3840, 2160, max(8, args.steps // 2), max(4, args.warmup // 4), True)
+            c4, w4, k4 = replay_pass(args, hp, rank, world, 3840, 2160, max(8, args.steps // 2), max(4, args.warmup // 4))
             out["value_4k"], out["ms_per_step_4k"], out["steps_4k"] = c4["value"], c4["ms_per_step"], c4["steps"]
             out["config_4k"] = c4["config"]
             for k in ("gop_weighted", "single_stream", "kernels"):

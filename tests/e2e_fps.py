@@ -47,8 +47,6 @@ def synth_clip_chunk(width, height, first, frames, seed=1080):
             return d["y"], d["u"], d["v"]
         except Exception:
             pass
-    rng = np.random.default_rng(seed)
-    pad = 64 + 8 * (first + frames)
     yy, xx = np.mgrid[0:height + 64 + 8 * frames, 0:width + 64 + 8 * frames]
     yy, xx = yy + first, xx + 3 * first                           # the window of the endless texture this chunk pans over
     base = 512 + 180 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 120 * np.sin((xx + yy) / 11.0) + 60 * np.sin(xx / 3.1) * np.sin(yy / 4.3)
