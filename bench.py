@@ -8,12 +8,13 @@ in-run parity against the encoder's own values, the MCTF stage, the end-to-end e
 `value` (BASELINE configs[1]): a step = ONE picture's hot-path work exactly as the reference encoder produced it.  Before the clock starts the encoder built with the
 binding (bindings/vvenc) encodes the 1920x1080 10-bit config-2 clip (65 frames, preset faster) on its CPU kernels with the work-list recorder on (hook bit 131072): every call
 through RdCost's table, every InterSearch::xMotionEstimation with its integer candidates and xPatternRefinement stages, every TU of TrQuant::xT with its residual, every DMVR
-sub-block — for one picture of each temporal layer.  The lists + the pictures' planes are uploaded once; step s replays the picture of the layer that coding position s of the
-GOP cycle has, the cycle starting at its key picture (any prefix of K steps is close to the GOP's layer mix: 20 steps = 1 x TL0 (intra), 1 x TL1, 1 x TL2, 2 x TL3, 5 x TL4, 10 x TL5):
+sub-block — for one picture of each temporal layer.  The lists + the pictures' planes are uploaded once; step s replays the picture of layer
+STEP_LAYERS[s mod 32]: a low-discrepancy interleaving of the GOP's layer mix (1 x TL0, 1 x TL1, 2 x TL2, 4 x TL3, 8 x TL4, 16 x TL5 per 32) that starts at the key picture, so any
+prefix of K steps is close to the mix (20 steps = 1 x TL0 (intra), 0 x TL1, 1 x TL2, 3 x TL3, 5 x TL4, 10 x TL5: time-weighted within ~1 % of the cycle's mean):
     motion-search plan   integer candidates (LDS windows) + sub-pel refinement stages (interpolation fused with the Hadamard) + merge / AMVP / intra / SSE table calls
     TU lists             fused xT -> needRdoq -> quant -> dequant -> xIT -> SSE, luma + chroma, DCT-2 / DST-7, 4..64
     DMVR lists           bilinear prediction + 25-point search + error surface per sub-block
-on five HIP streams.  With N GPUs rank r takes steps r, r + N, ... of the same cycle; the reconstructed picture a sharded encoder would hand to the ranks encoding the
+on five HIP streams.  With N GPUs rank r replays position k + 32 r / N of the same cycle at its step k (N different pictures of one sequence at any time); the reconstructed picture a sharded encoder would hand to the ranks encoding the
 pictures that reference it is broadcast (RCCL) every --exchange-every steps inside the timed region, overlapped; value = N * K pictures / max-over-ranks time, "weak".
 
 Extra objects of the JSON line (rank 0; each can be switched off; a failure is reported in place and never costs the headline):
@@ -58,16 +59,21 @@ LAYER_POCS = {0: 31, 1: 15, 2: 23, 3: 3, 4: 5, 5: 2}          # one recorded pic
 KERNEL_NAMES = {"ME_stage": "meStageKernel", "ME_int": "meIntKernel", "ME_item": "meItemKernel", "TU": "tuMxMultiKernel", "DMVR": "dmvrRefineKernel"}
 
 
+# The replay order of the 32 pictures of a GOP cycle (1 x TL0, 1 x TL1, 2 x TL2, 4 x TL3, 8 x TL4, 16 x TL5): a low-discrepancy interleaving, NOT the coding order — the recorded
+# pictures are independent work for the device, and a run of K steps should hold the layers close to their GOP share whatever K is.  The cycle starts at its key (intra) picture;
+# the first 20 positions hold 1 x TL0, 0 x TL1, 1 x TL2, 3 x TL3, 5 x TL4, 10 x TL5 (time-weighted within ~1 % of the whole cycle's mean on the recorded 1080p lists), 32 = the exact mix.
+STEP_LAYERS = (0, 5, 4, 5, 3, 5, 4, 5, 2, 5, 4, 5, 3, 5, 4, 5, 3, 5, 4, 5, 2, 5, 4, 5, 1, 5, 4, 5, 3, 5, 4, 5)
+
+
 def layer_of_step(s):
-    """temporal layer of step s: the 32 pictures of the recorded encode's GOP cycle in coding-position order, the cycle STARTING at its intra / key picture (POC 31 of the cycle)
-    so that any prefix of K steps holds the layers close to their GOP share — 20 steps: 1 x TL0, 1 x TL1, 1 x TL2, 2 x TL3, 5 x TL4, 10 x TL5 (32 steps: 1, 1, 2, 4, 8, 16)"""
-    p = (s + 31) % 32
-    if p == 31:
-        return 0
-    for layer, mod in ((1, 16), (2, 8), (3, 4), (4, 2)):
-        if p % mod == mod - 1:
-            return layer
-    return 5
+    """temporal layer of the picture step s replays"""
+    return STEP_LAYERS[s % 32]
+
+
+def step_of_rank(k, rank, world):
+    """N ranks: rank r's k-th step is position k + r * (32 / N) of the same cycle — at any time the ranks work on N different pictures of one sequence, and every rank's window
+    of K steps holds (nearly) the same layer mix (taking every N-th position instead would hand one rank all the heavy layers: the odd positions are all TL5)"""
+    return k + (rank * 32) // max(1, world)
 
 
 GOP_WEIGHT = {l: sum(1 for s in range(32) if layer_of_step(s) == l) for l in range(6)}
@@ -663,13 +669,13 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         shp = (height + 2 * m, ((width + 2 * m + 7) // 8) * 8)
         ex = sharding.PictureExchange([shp, (shp[0] // 2, shp[1] // 2), (shp[0] // 2, shp[1] // 2)], slots=2, device=hp.device)
         ex.publish(0, 0)
-    step_no = [rank]                                     # rank r replays pictures r, r + N, ... of the cycle
+    step_no = [0]                                        # this rank's step count k; it replays position step_of_rank( k ) of the cycle
     ex_count = [0]
 
     def step():
-        s = step_no[0]
+        k = step_no[0]
+        s = step_of_rank(k, rank, world)
         if ex is not None:
-            k = (s - rank) // world                      # this rank's step count
             if k % args.exchange_every == 0:
                 e = k // args.exchange_every
                 ex.publish(e + 1, (e + 1) % world, readers=streams if lanes else ())      # the next reference picture is in flight while this picture's launches run
@@ -680,7 +686,7 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
             wl.run_lanes()
         else:
             wl.run()
-        step_no[0] = s + world
+        step_no[0] = k + 1
 
     for _ in range(warmup):
         step()
@@ -729,7 +735,7 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         per_layer[layer] = {k: v / reps for k, v in acc.items()}
 
     # ---- THE timed region: exactly `steps` steps between barrier + synchronize on both sides, max over ranks
-    step_no[0] = rank
+    step_no[0] = 0
     sharding.barrier()
     torch.cuda.synchronize()
     enq = [0.0] * (steps + 1)
@@ -748,11 +754,9 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     # extras (not `value`): the same K steps serialized on one stream; per layer, the multi-stream time of one picture (-> the GOP-weighted rate); N > 1: without the picture exchange
     serial = None
     if lanes:
-        step_no[0] = rank
         t1 = time.perf_counter()
         for i in range(steps):
-            workloads[layer_of_step(step_no[0])].run()
-            step_no[0] += world
+            workloads[layer_of_step(step_of_rank(i, rank, world))].run()
         torch.cuda.synchronize()
         dts = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
         serial = {"value": steps * world / dts, "unit": "frames/s", "ms_per_step": 1000.0 * dts / steps, "note": "same pictures, every launch on ONE stream (no picture exchange); not the headline value"}
@@ -768,13 +772,11 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
             layer_ms[l] = 1000.0 * (time.perf_counter() - t1) / n
     no_exchange = None
     if ex is not None:
-        step_no[0] = rank
         sharding.barrier()
         t1 = time.perf_counter()
         for i in range(steps):
-            wl = workloads[layer_of_step(step_no[0])]
+            wl = workloads[layer_of_step(step_of_rank(i, rank, world))]
             wl.run_lanes() if lanes else wl.run()
-            step_no[0] += world
         torch.cuda.synchronize()
         dtn = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
         no_exchange = {"value": steps * world / dtn, "unit": "frames/s", "ms_per_step": 1000.0 * dtn / steps, "note": "same steps without the reference-picture broadcast: kernel scaling alone"}
@@ -784,13 +786,13 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     frames = steps * world
     pairs_by_layer = {l: workloads[l].pic.sample_pairs for l in workloads}
     wsum = float(sum(GOP_WEIGHT.values()))
-    lay_seq = [layer_of_step(rank + i * world) for i in range(steps)]
+    lay_seq = [layer_of_step(step_of_rank(i, rank, world)) for i in range(steps)]
     out = {
         "value": frames / dt, "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": 1000.0 * dt / steps,
         "host_enqueue_us_per_step": {"p50": round(enq_us[len(enq_us) // 2], 1), "p90": round(enq_us[int(len(enq_us) * 0.9)], 1), "max": round(enq_us[-1], 1),
                                      "drain_ms_after_last_enqueue": round(1000.0 * (t0 + dt_local - enq[-1]), 3)},
         "config": {"workload": "work lists RECORDED from the reference encoder (bindings/vvenc recorder, hook bit 131072): %dx%d 10-bit synthetic config-2 clip, 65 frames, preset faster; one picture "
-                               "per temporal layer (POC %s); step s replays the picture of the layer that coding position s of the GOP cycle has, the cycle starting at its key picture; BASELINE configs[%d]"
+                               "per temporal layer (POC %s); step s replays the picture of layer STEP_LAYERS[s mod 32], a low-discrepancy interleaving of the GOP's 1 : 1 : 2 : 4 : 8 : 16 layer mix that starts at the key picture (bench.py); BASELINE configs[%d]"
                                % (width, height, ", ".join("%d = TL%d" % (p, l) for l, p in LAYER_POCS.items()), 1 if width == 1920 else 2),
                    "pictures_per_32_steps_by_layer": {str(l): GOP_WEIGHT[l] for l in GOP_WEIGHT},
                    "pictures_in_the_timed_steps_by_layer": {str(l): lay_seq.count(l) for l in range(6)},
@@ -807,7 +809,7 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
                    "launches_per_frame": "motion-search plan (refinement stages per tap set + integer windows + table calls) + 1 TU launch (+ one per rectangular TU shape) + 0-1 DMVR launch per reference pair",
                    "schedule": "workgroups of every launch in XCD-band order: XCD x (workgroup index mod 8) takes the x-th contiguous eighth of each class in picture order ($VVHIP_ME_XCD_BAND=0: heaviest first)",
                    "hip_streams": len(lanes) if lanes else 1, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "recording": rec_info,
-                   "sharding": "one picture per rank and step, pictures of one sequence round-robin over ranks, no data-path collective"
+                   "sharding": "one picture per rank and step: rank r replays position k + 32 r / N of the cycle at its step k (N different pictures of one sequence at any time, the same layer mix per rank), no data-path collective"
                                + (", reconstructed picture (luma + chroma, %.1f MB) RCCL-broadcast from its owner every %d step(s) inside the timed region, overlapped with the launches"
                                   % (sum(p.numel() * 2 for p in ex.slots[0]) / 1e6, args.exchange_every) if ex is not None else "")},
     }
