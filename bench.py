@@ -946,7 +946,7 @@ def main():
         del workloads
         torch.cuda.empty_cache()
         try:
-            c4, w4, k4 = replay_pass(args, hp, rank, world, 3840, 2160, max(8, args.steps // 2), max(4, args.warmup // 4))
+            c4, w4, k4 = replay_pass(args, hp, rank, world, 3840, 2160, args.steps, max(4, args.warmup // 2))
             out["value_4k"], out["ms_per_step_4k"], out["steps_4k"] = c4["value"], c4["ms_per_step"], c4["steps"]
             out["config_4k"] = c4["config"]
             for k in ("gop_weighted", "single_stream", "kernels"):
