@@ -19,7 +19,7 @@
 // indirection), every global request of a job issued before the first wait, candidate records / plane table / tap tables staged in LDS once per wave, per-unit derived data
 // precomputed by plan creation, a cap on the serial work of one workgroup (candidates per window, row groups per bundle, units per wave), and — round 4 — every launch's
 // workgroups in XCD-band order (xcdBandOrder): each XCD's private L2 streams one horizontal band of the picture.
-// Results are bit-exact with the reference's table entries (tests: the oracle directly over every shape, tests/test_gpu_me_shapes.py; the recorded costs of the real encoder,
+// Results are bit-exact with the reference's table entries (tests: the CPU restatement directly over every shape, tests/test_gpu_me_shapes.py; the recorded costs of the real encoder,
 // tests/test_gpu_replay.py; the per-function kernels of dist.hip / interp.hip).
 #include <stdlib.h>
 #ifndef VVHIP_ME_HU
