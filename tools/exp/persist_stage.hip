@@ -54,17 +54,7 @@ int main( int argc, char** argv )
   for( auto& v : hostPlane ) v = ( int16_t ) ( rand() & 1023 );
   CK( hipMemcpy( dOrg, hostPlane.data(), hostPlane.size() * 2, hipMemcpyHostToDevice ) );
   // tap tables exactly as plan creation builds them (4-tap search set only: table 4)
-  std::vector<int32_t> tapTab( 6 * 192, 0 );
-  for( int mode = 0; mode < 3; mode++ ) for( int alt = 0; alt < 2; alt++ )
-  {
-    int32_t* t = &tapTab[( mode * 2 + alt ) * 192];
-    const int set = ( mode == 2 && !alt ) ? 0 : ( mode == 0 ? 2 : 1 ), k0 = set == 0 ? 2 : ( set == 1 ? 1 : 0 ), np = set == 0 ? 2 : ( set == 1 ? 3 : 4 );
-    for( int f = 0; f < 16; f++ )
-    {
-      for( int k = 0; k < 8; k++ ) t[f * 8 + k] = stageTap( f, k, mode, alt );
-      for( int i = 0; i < 4; i++ ) t[128 + f * 4 + i] = i < np ? ( int32_t ) ( ( ( uint32_t ) stageTap( f, k0 + 2 * i, mode, alt ) & 0xffffu ) | ( ( uint32_t ) stageTap( f, k0 + 2 * i + 1, mode, alt ) << 16 ) ) : 0;
-    }
-  }
+  const std::vector<int32_t> tapTab = stageTapTables( 10 );
   int32_t* dTap = nullptr; CK( hipMalloc( &dTap, tapTab.size() * 4 ) ); CK( hipMemcpy( dTap, tapTab.data(), tapTab.size() * 4, hipMemcpyHostToDevice ) );
   // host-mapped, fine-grained: the request records, the costs, the ring
   StageUnit* hUnits = nullptr; uint64_t* hCost = nullptr; Ring* hRing = nullptr;

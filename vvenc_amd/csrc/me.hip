@@ -67,6 +67,7 @@ __device__ __forceinline__ u32x4 ld16( const int16_t* p ) { return reinterpret_c
 __device__ __forceinline__ int lo16( uint32_t v ) { return ( int ) ( int16_t ) ( v & 0xffffu ); }
 __device__ __forceinline__ int hi16( uint32_t v ) { return ( int ) ( ( int32_t ) v >> 16 ); }
 __device__ __forceinline__ uint32_t pkAdd( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, a ) + __builtin_bit_cast( s16x2, b ) ); }
+__device__ __forceinline__ uint32_t pkSub( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, a ) - __builtin_bit_cast( s16x2, b ) ); }
 __device__ __forceinline__ uint32_t pack2( int lo, int hi ) { return ( ( uint32_t ) lo & 0xffffu ) | ( ( uint32_t ) hi << 16 ); }
 constexpr uint32_t BIAS = 0x80008000u;      // signed int16 pair -> unsigned order (v_sad_u16 on biased operands is |a - b| of the signed values)
 
@@ -92,7 +93,7 @@ struct MeArgs
 {
   const IntJob* intJobs; const PlanCand* cands; int wavesInt;
   const StageUnit* stageUnits; const WaveSpan* stageWaves; int wavesStage;
-  const int32_t* tapTables;      // [6 = filter_mode * 2 + alt_hpel][192]: 16 phases x 8 taps, then 16 phases x 4 tap pairs of the table's tap support
+  const int32_t* tapTables;      // [6 = filter_mode * 2 + alt_hpel][192]: stageTapTables
   const vvhip_me_item* items; const int32_t* itemOrder; const WaveSpan* itemWaves; int wavesItem;
   const vvhip_me_mask_item* maskItems;      // in schedule order; their waves follow the plain items' (WaveSpan.count < 0), their costs follow the plain items' costs
   uint64_t* candCost; uint64_t* stageCost; uint64_t* itemCost;
@@ -255,6 +256,26 @@ static int stageTap( int frac, int k, int filterMode, int altHpel )
   return filterMode == 0 ? kLuma8[p][kk] : kLuma6[p][kk];
 }
 
+// HOST: the six tables of a plan, per (filter_mode, alternative half-sample filter) 192 dwords:
+//   [0 .. 127]   16 phases x 8 window taps for the SECOND (vertical) pass, scaled by 2^( 16 - shift2 ), shift2 = 6 + headRoom: the filtered sample is the accumulator's upper half (predRow)
+//   [128 .. 191] 16 phases x 4 packed tap pairs ( K0 + 2 i, K0 + 2 i + 1 ) of the tap support the table's kernel instance uses, for the first (horizontal) pass
+static std::vector<int32_t> stageTapTables( int bitDepth )
+{
+  const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2, vScale = 1 << ( 10 - headRoom );
+  std::vector<int32_t> tapTab( 6 * 192, 0 );
+  for( int mode = 0; mode < 3; mode++ ) for( int alt = 0; alt < 2; alt++ )
+  {
+    int32_t* t = &tapTab[( mode * 2 + alt ) * 192];
+    const int set = ( mode == 2 && !alt ) ? 0 : ( mode == 0 ? 2 : 1 ), k0 = set == 0 ? 2 : ( set == 1 ? 1 : 0 ), np = set == 0 ? 2 : ( set == 1 ? 3 : 4 );
+    for( int f = 0; f < 16; f++ )
+    {
+      for( int k = 0; k < 8; k++ ) t[f * 8 + k] = stageTap( f, k, mode, alt ) * vScale;
+      for( int i = 0; i < 4; i++ ) t[128 + f * 4 + i] = i < np ? ( int32_t ) ( ( ( uint32_t ) stageTap( f, k0 + 2 * i, mode, alt ) & 0xffffu ) | ( ( uint32_t ) stageTap( f, k0 + 2 * i + 1, mode, alt ) << 16 ) ) : 0;
+    }
+  }
+  return tapTab;
+}
+
 // position k of a stage -> displacement in 1/16 sample from the stage's integer base: ( refine[k] + base ) * iFrac quarter samples
 // refinement offsets s_acMvRefineH / s_acMvRefineQ (InterSearch.cpp:67-91) as 2-bit fields ( offset + 1 ) of literals: no table in memory
 //   H: (0,0) (0,-1) (0,1) (-1,0) (1,0) (-1,-1) (1,-1) (-1,1) (1,1)      Q: (0,0) (0,-1) (0,1) (-1,-1) (1,-1) (-1,0) (1,0) (-1,1) (1,1)
@@ -269,13 +290,6 @@ __device__ __forceinline__ void stagePos( const vvhip_me_stage_job& j, int k, in
 
 typedef short s16x2h __attribute__( ( ext_vector_type( 2 ) ) );
 __device__ __forceinline__ int dot2( uint32_t a, uint32_t b, int c ) { return __builtin_amdgcn_sdot2( __builtin_bit_cast( s16x2h, a ), __builtin_bit_cast( s16x2h, b ), c, false ); }
-// two ints -> saturated int16 pair, clamped to [0, maxv] (maxv < 2^15)
-__device__ __forceinline__ uint32_t clampPack( int lo, int hi, uint32_t maxPk )
-{
-  const s16x2h v = __builtin_amdgcn_cvt_pk_i16( lo, hi ), z = { 0, 0 };
-  return __builtin_bit_cast( uint32_t, __builtin_elementwise_min( __builtin_elementwise_max( v, z ), __builtin_bit_cast( s16x2h, maxPk ) ) );
-}
-
 // One bundle of (stage, band) units.  K0 .. K1: the window taps the bundle's filter set can use (wave-uniform: 4-tap search 2..5, 6 taps / alternative half-pel 1..6, 8 taps 0..7).
 // A band = <= 16 rows of a block (one row of 16x16_fast tiles); the bands of a block are independent units (their partial costs are added with integer atomics, which
 // commute: results do not depend on the schedule).  Per unit two cooperative phases:
@@ -284,39 +298,69 @@ __device__ __forceinline__ uint32_t clampPack( int lo, int hi, uint32_t maxPk )
 //   VD  eight lanes per (position, tile), lane r = tile row r: second pass of the lane's own prediction row(s) out of LDS (v_dot2 with (c, 0) / (0, c)), clip, difference to
 //       the original row(s), horizontal butterflies in registers, vertical ones across the eight lanes with DPP (the factorisation of dist.hip's hadKernel), |DC| >> 2,
 //       per-tile normalisation — the prediction never leaves registers.
-// 8 clipped prediction samples of band row y (columns x0 .. x0 + 7) of a position, as four sample pairs
+// the second pass's taps of one vertical phase: prepared once per (lane, slot) and shared by the slot's prediction rows
+template<int NT> struct VTaps { int c[NT]; };
 template<int K0, int K1>
-__device__ __forceinline__ void predRow( const int16_t* tv /* first-pass band of the position's horizontal variant, at column x0 */, int w, int y, int syk, int fyk, const int* tapL,
-                                         int rnd2, int shift2, int headRoom, uint32_t maxPk, uint32_t ( &o )[4] )
+__device__ __forceinline__ void loadVTaps( const int* tapL, int fyk, VTaps<K1 - K0 + 1>& vt )
+{
+#pragma unroll
+  for( int t = 0; t < K1 - K0 + 1; t++ ) vt.c[t] = tapL[fyk * 8 + K0 + t];
+}
+// acc + ( low / high 16-bit half of v ) * ( low half of c ): v_mad_i32_i16, op_sel picks the half — one full-rate instruction per product and no ( c, 0 ) / ( 0, c ) operand
+// pairs to prepare (profiles/r04_valu_rate.log: same issue rate as v_dot2_i32_i16, semantics checked on the GPU)
+__device__ __forceinline__ int madLo( uint32_t v, int c, int acc ) { int r; asm( "v_mad_i32_i16 %0, %1, %2, %3" : "=v"( r ) : "v"( v ), "v"( c ), "v"( acc ) ); return r; }
+__device__ __forceinline__ int madHi( uint32_t v, int c, int acc ) { int r; asm( "v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"( r ) : "v"( v ), "v"( c ), "v"( acc ) ); return r; }
+__device__ __forceinline__ int mulLo( uint32_t v, int c ) { int r; asm( "v_mad_i32_i16 %0, %1, %2, 0" : "=v"( r ) : "v"( v ), "v"( c ) ); return r; }
+__device__ __forceinline__ int med3( int v, int hi ) { int r; asm( "v_med3_i32 %0, %1, 0, %2" : "=v"( r ) : "v"( v ), "v"( hi ) ); return r; }      // clip to [0, hi] (hi is not a literal: the compiler emits compare + select + min)
+__device__ __forceinline__ int mulHi( uint32_t v, int c ) { int r; asm( "v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"( r ) : "v"( v ), "v"( c ) ); return r; }
+// 8 clipped prediction samples of band row y (columns x0 .. x0 + 7) of a position, as four sample pairs.
+// Where the reference adds its constants is moved, the values are the same:
+//  * the first pass leaves its 14-bit intermediates in LDS as value + 2^( headRoom - 1 ) WITHOUT the reference's -8192 offset (InterpolationFilter.cpp:401-408): every tap set
+//    sums to 64, so the second pass's rounding term ( 1 << ( shift2 - 1 ) ) + ( 8192 << 6 ) (:394-400) is exactly what the stored offset contributes to the tap sum — the
+//    accumulators start at zero, and the zero-phase copy (:309-322) is a plain shift;
+//  * the plan's vertical taps are scaled by 2^( 16 - shift2 ): the sum >> shift2 is the upper half of the accumulator — clip to [0, max] on the scaled value (v_med3_i32
+//    against ( max << 16 ) | 0xffff), then ONE v_perm_b32 shifts and packs two samples ( 3 instructions per sample pair instead of 5 ).
+// anyFrac (WAVE-UNIFORM): some lane of the wave has a fractional vertical phase -> every lane filters (a zero-phase lane with the taps of phase 0, ( 0, 64, 0, 0 ): the same
+// value as the copy; its rows beyond the staged ones meet zero taps); no lane has one -> the copy on packed pairs.  No divergent branch per row.
+template<int K0, int K1>
+__device__ __forceinline__ void predRow( const int16_t* tv /* first-pass band of the position's horizontal variant, at column x0 */, int w, int y, int syk, bool anyFrac,
+                                         const VTaps<K1 - K0 + 1>& vt, int headRoom, uint32_t maxPk, uint32_t ( &o )[4] )
 {
   constexpr int NT = K1 - K0 + 1;
-  int acc[8];
-  if( fyk )
+  if( anyFrac )
   {
-#pragma unroll
-    for( int i = 0; i < 8; i++ ) acc[i] = rnd2;
+    int acc[8];
 #pragma unroll
     for( int t = 0; t < NT; t++ )
     {
-      const int c = tapL[fyk * 8 + K0 + t];
-      const uint32_t cl = ( uint32_t ) c & 0xffffu, ch = ( uint32_t ) c << 16;
-      const u32x4 r = *reinterpret_cast<const u32x4*>( tv + ( y + syk + t + 1 ) * w );
-      acc[0] = dot2( r.x, cl, acc[0] ); acc[1] = dot2( r.x, ch, acc[1] ); acc[2] = dot2( r.y, cl, acc[2] ); acc[3] = dot2( r.y, ch, acc[3] );
-      acc[4] = dot2( r.z, cl, acc[4] ); acc[5] = dot2( r.z, ch, acc[5] ); acc[6] = dot2( r.w, cl, acc[6] ); acc[7] = dot2( r.w, ch, acc[7] );
+      const int c = vt.c[t];
+      const u32x4 r = *reinterpret_cast<const u32x4*>( tv + __mul24( y + syk + t + 1, w ) );
+      if( t == 0 )
+      {
+        acc[0] = mulLo( r.x, c ); acc[1] = mulHi( r.x, c ); acc[2] = mulLo( r.y, c ); acc[3] = mulHi( r.y, c );
+        acc[4] = mulLo( r.z, c ); acc[5] = mulHi( r.z, c ); acc[6] = mulLo( r.w, c ); acc[7] = mulHi( r.w, c );
+      }
+      else
+      {
+        acc[0] = madLo( r.x, c, acc[0] ); acc[1] = madHi( r.x, c, acc[1] ); acc[2] = madLo( r.y, c, acc[2] ); acc[3] = madHi( r.y, c, acc[3] );
+        acc[4] = madLo( r.z, c, acc[4] ); acc[5] = madHi( r.z, c, acc[5] ); acc[6] = madLo( r.w, c, acc[6] ); acc[7] = madHi( r.w, c, acc[7] );
+      }
     }
+    const int maxS = ( int ) ( ( ( maxPk & 0xffffu ) << 16 ) | 0xffffu );
 #pragma unroll
-    for( int i = 0; i < 8; i++ ) acc[i] >>= shift2;
+    for( int i = 0; i < 8; i++ ) acc[i] = med3( acc[i], maxS );
+#pragma unroll
+    for( int i = 0; i < 4; i++ ) o[i] = __builtin_amdgcn_perm( ( uint32_t ) acc[2 * i + 1], ( uint32_t ) acc[2 * i], 0x07060302u );
   }
   else
   {
-    // zero vertical phase: filterCopy<false,true> of the first-pass sample (InterpolationFilter.cpp:309-322)
-    const u32x4 r = *reinterpret_cast<const u32x4*>( tv + ( y + syk + 4 - K0 ) * w );
+    const u32x4 r = *reinterpret_cast<const u32x4*>( tv + __mul24( y + syk + 4 - K0, w ) );
     const uint32_t rw[4] = { r.x, r.y, r.z, r.w };
-    const int add = ( int ) ( int16_t ) ( ( 1 << ( headRoom - 1 ) ) + 8192 );
+    const s16x2 sh = { ( short ) headRoom, ( short ) headRoom }, z = { 0, 0 };
 #pragma unroll
-    for( int i = 0; i < 4; i++ ) { acc[2 * i] = ( lo16( rw[i] ) + add ) >> headRoom; acc[2 * i + 1] = ( hi16( rw[i] ) + add ) >> headRoom; }
+    for( int i = 0; i < 4; i++ )
+      o[i] = __builtin_bit_cast( uint32_t, __builtin_elementwise_min( __builtin_elementwise_max( __builtin_bit_cast( s16x2, rw[i] ) >> sh, z ), __builtin_bit_cast( s16x2, maxPk ) ) );
   }
-  o[0] = clampPack( acc[0], acc[1], maxPk ); o[1] = clampPack( acc[2], acc[3], maxPk ); o[2] = clampPack( acc[4], acc[5], maxPk ); o[3] = clampPack( acc[6], acc[7], maxPk );
 }
 
 // 4 rounded 2x2 averages ( a + b rows, 8 columns ) as ints
@@ -365,14 +409,9 @@ __device__ __forceinline__ uint32_t hadNorm( uint32_t s, int kind )
 
 // the team's transform: d = the lane's 8 differences, r = the lane's index inside its team of LT lanes (teams are aligned groups of consecutive lanes).
 // Returns the tile's normalised SATD in every lane of the team.  |d| < 2^23 / 128 on entry (differences of <= 12-bit values).
-__device__ __forceinline__ uint32_t hadTeam( int ( &d )[8], int r, int LT, int kind, int lane )
+// hadTeamCross: the stages across the lanes + sum, on values the lane has already transformed in its registers
+__device__ __forceinline__ uint32_t hadTeamCross( int ( &d )[8], int r, int LT, int kind, int lane )
 {
-#pragma unroll
-  for( int len = 1; len < 8; len <<= 1 )
-#pragma unroll
-    for( int i = 0; i < 8; i += 2 * len )
-#pragma unroll
-      for( int q = i; q < i + len; q++ ) { const int x = d[q], z = d[q + len]; d[q] = x + z; d[q + len] = x - z; }
 #define ME_VSTAGE( CTRL, BIT ) { const int sgn = ( r & ( BIT ) ) ? -1 : 1; _Pragma( "unroll" ) /* upper lane of a pair: other - own, lower: own + other; |d| < 2^23 */ \
   for( int i = 0; i < 8; i++ ) { const int t = __mul24( d[i], sgn ); d[i] = VVHIP_DPP( d[i], CTRL ) + t; } }
   if( LT >= 16 ) ME_VSTAGE( VVHIP_DPP_MIRROR, 8 )
@@ -386,6 +425,30 @@ __device__ __forceinline__ uint32_t hadTeam( int ( &d )[8], int r, int LT, int k
   if( r == 0 ) { const uint32_t dc = ( uint32_t ) abs( d[0] ); s = s - dc + ( dc >> 2 ); }
   s = vvhipGroupSum32( s, LT, lane );
   return hadNorm( s, kind );
+}
+__device__ __forceinline__ uint32_t hadTeam( int ( &d )[8], int r, int LT, int kind, int lane )
+{
+#pragma unroll
+  for( int len = 1; len < 8; len <<= 1 )
+#pragma unroll
+    for( int i = 0; i < 8; i += 2 * len )
+#pragma unroll
+      for( int q = i; q < i + len; q++ ) { const int x = d[q], z = d[q + len]; d[q] = x + z; d[q + len] = x - z; }
+  return hadTeamCross( d, r, LT, kind, lane );
+}
+// the same from the lane's two operand rows as PACKED sample pairs (o - p per 16-bit half): the two register stages that pair whole dwords run on packed pairs
+// (v_pk_add_i16 / v_pk_sub_i16: sums of four differences, |d| <= 2^( bitDepth + 1 ) with bitDepth <= 10 -> 14 bits), the stage inside a dword is the unpacking itself
+// (lo + hi, lo - hi as dot products with ( 1, 1 ) / ( 1, -1 )): 20 instructions for difference + register transform instead of 32.  The stages of a Hadamard transform commute;
+// the all-plus coefficient (DC) still ends in register 0.
+__device__ __forceinline__ uint32_t hadTeamPk( const uint32_t ( &o )[4], const uint32_t ( &p )[4], int r, int LT, int kind, int lane )
+{
+  const uint32_t D0 = pkSub( o[0], p[0] ), D1 = pkSub( o[1], p[1] ), D2 = pkSub( o[2], p[2] ), D3 = pkSub( o[3], p[3] );
+  const uint32_t E0 = pkAdd( D0, D1 ), E1 = pkSub( D0, D1 ), E2 = pkAdd( D2, D3 ), E3 = pkSub( D2, D3 );
+  const uint32_t F[4] = { pkAdd( E0, E2 ), pkAdd( E1, E3 ), pkSub( E0, E2 ), pkSub( E1, E3 ) };
+  int d[8];
+#pragma unroll
+  for( int q = 0; q < 4; q++ ) { d[2 * q] = dot2( F[q], 0x00010001u, 0 ); d[2 * q + 1] = dot2( F[q], 0xffff0001u, 0 ); }
+  return hadTeamCross( d, r, LT, kind, lane );
 }
 
 // a stage unit in the schedule: stage index | band of 32 rows << 24 | 64-column half << 27 | continues the previous unit's sums << 28 | the next unit continues << 29 | atomic << 30
@@ -402,8 +465,9 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
 #define ST_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
   const int tid = threadIdx.x & 63, nthr = 64, lane = tid, bd = a.bitDepth;
   const int headRoom = 14 - bd > 2 ? 14 - bd : 2;
-  const int shift1 = 6 - headRoom, off1 = -( 8192 << shift1 );                       // first (not last) pass: InterpolationFilter.cpp:401-408
-  const int shift2 = 6 + headRoom, rnd2 = ( 1 << ( shift2 - 1 ) ) + ( 8192 << 6 );   // second and last pass: :394-400
+  // first (not last) pass, InterpolationFilter.cpp:401-408: ( sum >> shift1 ) - 8192; kept in LDS as ( sum >> shift1 ) + 2^( headRoom - 1 ) instead — the second pass's
+  // constants ( :394-400 ) folded into the stored value, see predRow
+  const int shift1 = 6 - headRoom, off1 = ( 1 << ( headRoom - 1 ) ) << shift1, biasT = 1 << ( headRoom - 1 );
   const uint32_t maxPk = ( uint32_t ) ( ( 1 << bd ) - 1 ) * 0x00010001u;
   int* tapL = reinterpret_cast<int*>( lds );                                         // [16 phases][8] taps of the current unit's stage
   uint32_t* tapP = reinterpret_cast<uint32_t*>( lds ) + 128;                         // [16 phases][4] tap pairs (K0 + 2i, K0 + 2i + 1)
@@ -519,10 +583,10 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
         }
         else
         {
-          const uint32_t aw[4] = { A.x, A.y, A.z, A.w };                               // filterCopy<true,false>: ( sample << headRoom ) - 8192 (InterpolationFilter.cpp:285-296)
+          const uint32_t aw[4] = { A.x, A.y, A.z, A.w };                               // filterCopy<true,false>: ( sample << headRoom ) - 8192 (InterpolationFilter.cpp:285-296), stored with the folded constants like the filtered rows
           uint32_t o[4];
 #pragma unroll
-          for( int qq = 0; qq < 4; qq++ ) o[qq] = pack2( ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) lo16( aw[qq] ) << headRoom ) - 8192 ), ( int ) ( int16_t ) ( ( int16_t ) ( ( uint16_t ) hi16( aw[qq] ) << headRoom ) - 8192 ) );
+          for( int qq = 0; qq < 4; qq++ ) o[qq] = pack2( ( lo16( aw[qq] ) << headRoom ) + biasT, ( hi16( aw[qq] ) << headRoom ) + biasT );
           ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
         }
         *reinterpret_cast<u32x4*>( tmp + at[q] ) = ov;
@@ -544,57 +608,62 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       const int pk = posL[pi], txk = ( ( pk >> 8 ) & 0xfff ) - 64, tyk = ( ( pk >> 20 ) & 0xfff ) - 64;
       const int hv = ( txk == hx0 ? 0 : ( ( nHor > 1 && txk == hx1 ) ? 1 : 2 ) ) - v0, syk = tyk >> 4, fyk = tyk & 15;
       const int16_t* tvp = tmp + hv * rowsT * ldsPitch;
-      int d[8];
+      const bool anyFrac = __builtin_amdgcn_ballot_w64( fyk != 0 ) != 0;              // wave-uniform: see predRow
+      VTaps<NT> vt;
+      if( anyFrac ) loadVTaps<K0, K1>( tapL, fyk, vt );
+      uint32_t sres;
       if( kind == TK_16F )
       {
+        int d[8];
         const int16_t* tv = tvp + txi * 16;
         const int16_t* po = org + ( ptrdiff_t ) ( y0 + tyi * 16 + 2 * r ) * os + txi * 16;
         const u32x4 c0v = ld16( po ), c1v = ld16( po + 8 ), e0 = ld16( po + os ), e1 = ld16( po + os + 8 );
         uint32_t pa[4], pb[4]; int ap[4], ao[4];
-        predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
-        predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
+        predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r, syk, anyFrac, vt, headRoom, maxPk, pa );
+        predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
         { const uint32_t oa[4] = { c0v.x, c0v.y, c0v.z, c0v.w }, ob[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( oa, ob, ao ); }      // RdCost.cpp:1138-1160
 #pragma unroll
         for( int i = 0; i < 4; i++ ) d[i] = ao[i] - ap[i];
-        predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
-        predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
+        predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r, syk, anyFrac, vt, headRoom, maxPk, pa );
+        predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
         { const uint32_t oa[4] = { c1v.x, c1v.y, c1v.z, c1v.w }, ob[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( oa, ob, ao ); }
 #pragma unroll
         for( int i = 0; i < 4; i++ ) d[4 + i] = ao[i] - ap[i];
-      }
-      else if( rows4 )
-      {
-        // a 4-wide block (one tile column): two rows of four samples per lane; the first pass worked on 8 columns, the upper four are not part of the block
-        const int row = tyi * 8 + 2 * r;
-        const int16_t* po = org + ( ptrdiff_t ) ( y0 + row ) * os;
-        const u32x2 oa = ld8( po ), ob = ld8( po + os );
-        uint32_t pa[4], pb[4];
-        predRow<K0, K1>( tvp, ldsPitch, row, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pa );
-        predRow<K0, K1>( tvp, ldsPitch, row + 1, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pb );
-        d[0] = lo16( oa.x ) - lo16( pa[0] ); d[1] = hi16( oa.x ) - hi16( pa[0] ); d[2] = lo16( oa.y ) - lo16( pa[1] ); d[3] = hi16( oa.y ) - hi16( pa[1] );
-        d[4] = lo16( ob.x ) - lo16( pb[0] ); d[5] = hi16( ob.x ) - hi16( pb[0] ); d[6] = lo16( ob.y ) - lo16( pb[1] ); d[7] = hi16( ob.y ) - hi16( pb[1] );
+        sres = hadTeam( d, r, GEN ? LT : 8, TK_16F, lane );
       }
       else
       {
-        const int row = ( GEN && kind == TK_16x8 ) ? tyi * 8 + ( r & 7 ) : ( tyi << log2PH ) + r, col = ( GEN && kind == TK_16x8 ) ? txi * 16 + 8 * ( r >> 3 ) : txi * 8;
-        const u32x4 ovv = ld16( org + ( ptrdiff_t ) ( y0 + row ) * os + col );
-        uint32_t pw[4];
-        predRow<K0, K1>( tvp + col, ldsPitch, row, syk, fyk, tapL, rnd2, shift2, headRoom, maxPk, pw );
-        const uint32_t ow[4] = { ovv.x, ovv.y, ovv.z, ovv.w };
+        // the lane's two operand rows as packed sample pairs: original o[], prediction p[]
+        uint32_t o4[4], p4[4];
+        if( rows4 )
+        {
+          // a 4-wide block (one tile column): two rows of four samples per lane; the first pass worked on 8 columns, the upper four are not part of the block
+          const int row = tyi * 8 + 2 * r;
+          const int16_t* po = org + ( ptrdiff_t ) ( y0 + row ) * os;
+          const u32x2 oa = ld8( po ), ob = ld8( po + os );
+          uint32_t pa[4], pb[4];
+          predRow<K0, K1>( tvp, ldsPitch, row, syk, anyFrac, vt, headRoom, maxPk, pa );
+          predRow<K0, K1>( tvp, ldsPitch, row + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
+          o4[0] = oa.x; o4[1] = oa.y; o4[2] = ob.x; o4[3] = ob.y; p4[0] = pa[0]; p4[1] = pa[1]; p4[2] = pb[0]; p4[3] = pb[1];
+        }
+        else
+        {
+          const int row = ( GEN && kind == TK_16x8 ) ? tyi * 8 + ( r & 7 ) : ( tyi << log2PH ) + r, col = ( GEN && kind == TK_16x8 ) ? txi * 16 + 8 * ( r >> 3 ) : txi * 8;
+          const u32x4 ovv = ld16( org + ( ptrdiff_t ) ( y0 + row ) * os + col );
+          predRow<K0, K1>( tvp + col, ldsPitch, row, syk, anyFrac, vt, headRoom, maxPk, p4 );
+          o4[0] = ovv.x; o4[1] = ovv.y; o4[2] = ovv.z; o4[3] = ovv.w;
+        }
+        if( kind == TK_ROWS )
+        {
+          uint32_t sa = 0;
 #pragma unroll
-        for( int i = 0; i < 4; i++ ) { d[2 * i] = lo16( ow[i] ) - lo16( pw[i] ); d[2 * i + 1] = hi16( ow[i] ) - hi16( pw[i] ); }
+          for( int i = 0; i < 4; i++ ) sa = __builtin_amdgcn_sad_u16( o4[i] ^ BIAS, p4[i] ^ BIAS, sa );
+          sres = vvhipGroupSum32( sa, LT, lane );
+        }
+        else sres = hadTeamPk( o4, p4, r, GEN ? LT : 8, GEN ? kind : TK_8x8, lane );
       }
-      uint32_t sres;
-      if( kind == TK_ROWS )
-      {
-        uint32_t s = 0;
-#pragma unroll
-        for( int i = 0; i < 8; i++ ) s += ( uint32_t ) abs( d[i] );
-        sres = vvhipGroupSum32( s, LT, lane );
-      }
-      else sres = hadTeam( d, r, GEN ? LT : 8, GEN ? kind : ( kind == TK_16F ? TK_16F : TK_8x8 ), lane );
       if( valid && r == 0 ) atomicAdd( &costL[pk & 0xff], sres );
     }
     }      // passes
@@ -778,31 +847,29 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
         { const uint32_t x[4] = { c1.x, c1.y, c1.z, c1.w }, y[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( x, y, ac ); }
 #pragma unroll
         for( int i = 0; i < 4; i++ ) d[4 + i] = ao[i] - ac[i];
-      }
-      else if( GEN && kind == TK_4x8 )
-      {
-        const u32x2 xa = ld8( qa + ( ptrdiff_t ) ( 2 * r ) * os ), xb = ld8( qa + ( ptrdiff_t ) ( 2 * r + 1 ) * os ), za = ld8( qb + ( ptrdiff_t ) ( 2 * r ) * cs ), zb = ld8( qb + ( ptrdiff_t ) ( 2 * r + 1 ) * cs );
-        const uint32_t xw[4] = { xa.x, xa.y, xb.x, xb.y }, zw[4] = { za.x, za.y, zb.x, zb.y };
-#pragma unroll
-        for( int i = 0; i < 4; i++ )
-        {
-          d[2 * i] = lo16( xw[i] ) - lo16( zw[i] ); d[2 * i + 1] = hi16( xw[i] ) - hi16( zw[i] );
-          if( func == VVHIP_DF_HAD_2SAD ) sad = __builtin_amdgcn_sad_u16( xw[i] ^ BIAS, zw[i] ^ BIAS, sad );
-        }
+        sres = hadTeam( d, r, GEN ? LT : 8, TK_16F, lane );
       }
       else
       {
-        const int row = ( GEN && kind == TK_16x8 ) ? ( r & 7 ) : r, col = ( GEN && kind == TK_16x8 ) ? 8 * ( r >> 3 ) : 0;
-        const u32x4 x = ld16( qa + ( ptrdiff_t ) row * os + col ), z = ld16( qb + ( ptrdiff_t ) row * cs + col );
-        const uint32_t xw[4] = { x.x, x.y, x.z, x.w }, zw[4] = { z.x, z.y, z.z, z.w };
-#pragma unroll
-        for( int i = 0; i < 4; i++ )
+        uint32_t xw[4], zw[4];                                           // the lane's operand rows as packed sample pairs
+        if( GEN && kind == TK_4x8 )
         {
-          d[2 * i] = lo16( xw[i] ) - lo16( zw[i] ); d[2 * i + 1] = hi16( xw[i] ) - hi16( zw[i] );
-          if( func == VVHIP_DF_HAD_2SAD ) sad = __builtin_amdgcn_sad_u16( xw[i] ^ BIAS, zw[i] ^ BIAS, sad );
+          const u32x2 xa = ld8( qa + ( ptrdiff_t ) ( 2 * r ) * os ), xb = ld8( qa + ( ptrdiff_t ) ( 2 * r + 1 ) * os ), za = ld8( qb + ( ptrdiff_t ) ( 2 * r ) * cs ), zb = ld8( qb + ( ptrdiff_t ) ( 2 * r + 1 ) * cs );
+          xw[0] = xa.x; xw[1] = xa.y; xw[2] = xb.x; xw[3] = xb.y; zw[0] = za.x; zw[1] = za.y; zw[2] = zb.x; zw[3] = zb.y;
         }
+        else
+        {
+          const int row = ( GEN && kind == TK_16x8 ) ? ( r & 7 ) : r, col = ( GEN && kind == TK_16x8 ) ? 8 * ( r >> 3 ) : 0;
+          const u32x4 x = ld16( qa + ( ptrdiff_t ) row * os + col ), z = ld16( qb + ( ptrdiff_t ) row * cs + col );
+          xw[0] = x.x; xw[1] = x.y; xw[2] = x.z; xw[3] = x.w; zw[0] = z.x; zw[1] = z.y; zw[2] = z.z; zw[3] = z.w;
+        }
+        if( func == VVHIP_DF_HAD_2SAD )
+        {
+#pragma unroll
+          for( int i = 0; i < 4; i++ ) sad = __builtin_amdgcn_sad_u16( xw[i] ^ BIAS, zw[i] ^ BIAS, sad );
+        }
+        sres = hadTeamPk( xw, zw, r, GEN ? LT : 8, GEN ? kind : TK_8x8, lane );
       }
-      sres = hadTeam( d, r, GEN ? LT : 8, GEN ? kind : ( kind == TK_16F ? TK_16F : TK_8x8 ), lane );
       if( func == VVHIP_DF_HAD_2SAD ) sad = vvhipGroupSum32( sad, GEN ? LT : 8, lane );
     }
     if( valid && r == 0 ) { atomicAdd( &accL[ii], sres ); if( func == VVHIP_DF_HAD_2SAD ) atomicAdd( &accL[64 + ii], sad ); }
@@ -1190,19 +1257,8 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   for( int i = 0; i < n_items; i++ ) itSorted[i] = items[itOrder[i]];
   std::vector<vvhip_me_mask_item> mkSorted( n_mask );
   for( int i = 0; i < n_mask; i++ ) { mkSorted[i] = mask_items[itOrder[n_items + i]]; itOrder[n_items + i] += n_items; }      // (the order entry = where the cost goes)
-  // ---- the interpolation tap tables the stage kernels stage into LDS: per (filter_mode, alternative half-sample filter) 16 phases x 8 window taps, then 16 phases x 4 packed
-  //      tap pairs ( K0 + 2 i, K0 + 2 i + 1 ) of the tap support the table's kernel instance uses
-  std::vector<int32_t> tapTab( 6 * 192, 0 );
-  for( int mode = 0; mode < 3; mode++ ) for( int alt = 0; alt < 2; alt++ )
-  {
-    int32_t* t = &tapTab[( mode * 2 + alt ) * 192];
-    const int set = ( mode == 2 && !alt ) ? 0 : ( mode == 0 ? 2 : 1 ), k0 = set == 0 ? 2 : ( set == 1 ? 1 : 0 ), np = set == 0 ? 2 : ( set == 1 ? 3 : 4 );
-    for( int f = 0; f < 16; f++ )
-    {
-      for( int k = 0; k < 8; k++ ) t[f * 8 + k] = stageTap( f, k, mode, alt );
-      for( int i = 0; i < 4; i++ ) t[128 + f * 4 + i] = i < np ? ( int32_t ) ( ( ( uint32_t ) stageTap( f, k0 + 2 * i, mode, alt ) & 0xffffu ) | ( ( uint32_t ) stageTap( f, k0 + 2 * i + 1, mode, alt ) << 16 ) ) : 0;
-    }
-  }
+  // ---- the interpolation tap tables the stage kernels stage into LDS (stageTapTables)
+  const std::vector<int32_t> tapTab = stageTapTables( bit_depth );
   // ---- one device allocation for every table
   auto pad = []( size_t b ) { return ( b + 255 ) & ~( size_t ) 255; };
   const size_t bInt = pad( ij.size() * sizeof( IntJob ) ), bCand = pad( pc.size() * sizeof( PlanCand ) ), bSt = pad( stUnits.size() * sizeof( StageUnit ) ),
