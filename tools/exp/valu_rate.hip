@@ -25,6 +25,22 @@ __global__ void __launch_bounds__( 64 ) rate( const uint32_t* in, uint32_t* out,
 #define PKSUB( i ) asm volatile( "v_pk_sub_i16 %0, %0, %1" : "+v"( a##i ) : "v"( x ) );
 #define MUL24( i ) asm volatile( "v_mul_i32_i24 %0, %0, %1" : "+v"( a##i ) : "v"( x ) );
 #define ADD( i )  asm volatile( "v_add_u32 %0, %0, %1" : "+v"( a##i ) : "v"( x ) );
+#define DOTC( i ) asm volatile( "v_dot2c_i32_i16 %0, %1, %2" : "+v"( a##i ) : "v"( x ), "v"( y ) );
+#define ADD3( i ) asm volatile( "v_add3_u32 %0, %0, %1, %2" : "+v"( a##i ) : "v"( x ), "v"( y ) );
+#define ADD64( i ) asm volatile( "v_add_u32_e64 %0, %0, %1" : "+v"( a##i ) : "v"( x ) );
+#define SAD( i )  asm volatile( "v_sad_u16 %0, %1, %2, %0" : "+v"( a##i ) : "v"( x ), "v"( y ) );
+#define ALIGN( i ) asm volatile( "v_alignbit_b32 %0, %0, %1, 16" : "+v"( a##i ) : "v"( x ) );
+#define ADDDPP( i ) asm volatile( "v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"( a##i ) : "v"( x ) );
+#define PKADD( i ) asm volatile( "v_pk_add_i16 %0, %0, %1" : "+v"( a##i ) : "v"( x ) );
+#define SDWA( i ) asm volatile( "v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "+v"( a##i ) : "v"( x ) );
+    if( OP == 9 )  { REP8( DOTC ) REP8( DOTC ) }
+    if( OP == 10 ) { REP8( ADD3 ) REP8( ADD3 ) }
+    if( OP == 11 ) { REP8( ADD64 ) REP8( ADD64 ) }
+    if( OP == 12 ) { REP8( SAD ) REP8( SAD ) }
+    if( OP == 13 ) { REP8( ALIGN ) REP8( ALIGN ) }
+    if( OP == 14 ) { REP8( ADDDPP ) REP8( ADDDPP ) }
+    if( OP == 15 ) { REP8( PKADD ) REP8( PKADD ) }
+    if( OP == 16 ) { REP8( SDWA ) REP8( SDWA ) }
     if( OP == 0 ) { REP8( DOT ) REP8( DOT ) }
     if( OP == 1 ) { REP8( MAD ) REP8( MAD ) }
     if( OP == 2 ) { REP8( M24 ) REP8( M24 ) }
@@ -49,15 +65,15 @@ __global__ void semantics( const uint32_t* in, int* out )
   out[4 * threadIdx.x] = r0; out[4 * threadIdx.x + 1] = r1; out[4 * threadIdx.x + 2] = r2; out[4 * threadIdx.x + 3] = r3;
 }
 
-template<int OP> static void run( const char* name, const uint32_t* dIn, uint32_t* dOut )
+template<int OP> static void run( const char* name, const uint32_t* dIn, uint32_t* dOut, int wavesPerSimd = 1 )
 {
-  const int trips = 20000, blocks = 1024;      // one wave per SIMD (256 CUs x 4)
+  const int trips = 20000, blocks = 1024 * wavesPerSimd;      // 1024 = one wave per SIMD (256 CUs x 4)
   hipEvent_t e0, e1; hipEventCreate( &e0 ); hipEventCreate( &e1 );
   rate<OP><<<blocks, 64>>>( dIn, dOut, 100 );
   hipDeviceSynchronize();
   hipEventRecord( e0 ); rate<OP><<<blocks, 64>>>( dIn, dOut, trips ); hipEventRecord( e1 ); hipEventSynchronize( e1 );
   float ms = 0; hipEventElapsedTime( &ms, e0, e1 );
-  printf( "%-22s %8.3f ms  %6.2f ns per instruction and wave (4 cycles at 2.4 GHz = 1.67 ns)\n", name, ms, ms * 1e6 / ( ( double ) trips * 16 ) );
+  printf( "%-22s %d wave(s) per SIMD %8.3f ms  %6.2f ns per instruction and SIMD (4 cycles at 2.4 GHz = 1.67 ns)\n", name, wavesPerSimd, ms, ms * 1e6 / ( ( double ) trips * 16 * wavesPerSimd ) );
 }
 
 int main()
@@ -65,7 +81,7 @@ int main()
   std::vector<uint32_t> h( 128 );
   for( int i = 0; i < 128; i++ ) h[i] = ( uint32_t ) ( ( ( i * 2654435761u ) >> 7 ) ^ ( i * 40503u << 13 ) );
   uint32_t* dIn; uint32_t* dOut; int* dSem;
-  hipMalloc( &dIn, 512 ); hipMalloc( &dOut, 1024 * 64 * 4 ); hipMalloc( &dSem, 64 * 16 );
+  hipMalloc( &dIn, 512 ); hipMalloc( &dOut, 8 * 1024 * 64 * 4 ); hipMalloc( &dSem, 64 * 16 );
   hipMemcpy( dIn, h.data(), 512, hipMemcpyHostToDevice );
   semantics<<<1, 64>>>( dIn, dSem );
   std::vector<int> s( 256 ); hipMemcpy( s.data(), dSem, 1024, hipMemcpyDeviceToHost );
@@ -79,5 +95,12 @@ int main()
   printf( "v_mad_i32_i16 op_sel semantics: %s (%d mismatches)\n", bad ? "DIFFERENT" : "as expected", bad );
   run<0>( "v_dot2_i32_i16", dIn, dOut ); run<1>( "v_mad_i32_i16 op_sel", dIn, dOut ); run<2>( "v_mad_i32_i24", dIn, dOut ); run<3>( "v_perm_b32", dIn, dOut );
   run<4>( "v_med3_i32", dIn, dOut ); run<5>( "v_pk_ashrrev_i16", dIn, dOut ); run<6>( "v_pk_sub_i16", dIn, dOut ); run<7>( "v_mul_i32_i24", dIn, dOut ); run<8>( "v_add_u32", dIn, dOut );
+  for( int w = 2; w <= 8; w *= 2 ) { run<8>( "v_add_u32", dIn, dOut, w ); run<1>( "v_mad_i32_i16 op_sel", dIn, dOut, w ); run<0>( "v_dot2_i32_i16", dIn, dOut, w ); }
+  for( int w = 4; w <= 8; w *= 2 )
+  {
+    run<9>( "v_dot2c_i32_i16 (VOP2)", dIn, dOut, w ); run<10>( "v_add3_u32", dIn, dOut, w ); run<11>( "v_add_u32_e64", dIn, dOut, w ); run<12>( "v_sad_u16", dIn, dOut, w );
+    run<13>( "v_alignbit_b32", dIn, dOut, w ); run<14>( "v_add_u32_dpp", dIn, dOut, w ); run<15>( "v_pk_add_i16", dIn, dOut, w ); run<16>( "v_sub_u32_sdwa", dIn, dOut, w );
+    run<2>( "v_mad_i32_i24", dIn, dOut, w ); run<3>( "v_perm_b32", dIn, dOut, w ); run<4>( "v_med3_i32", dIn, dOut, w ); run<7>( "v_mul_i32_i24", dIn, dOut, w );
+  }
   return 0;
 }

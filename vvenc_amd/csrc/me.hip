@@ -258,10 +258,11 @@ static int stageTap( int frac, int k, int filterMode, int altHpel )
 
 // HOST: the six tables of a plan, per (filter_mode, alternative half-sample filter) 192 dwords:
 //   [0 .. 127]   16 phases x 8 window taps for the SECOND (vertical) pass, scaled by 2^( 16 - shift2 ), shift2 = 6 + headRoom: the filtered sample is the accumulator's upper half (predRow)
-//   [128 .. 191] 16 phases x 4 packed tap pairs ( K0 + 2 i, K0 + 2 i + 1 ) of the tap support the table's kernel instance uses, for the first (horizontal) pass
+//   [128 .. 191] 16 phases x 4 packed tap pairs ( K0 + 2 i, K0 + 2 i + 1 ) of the tap support the table's kernel instance uses, for the first (horizontal) pass, scaled by
+//                2^( 8 - shift1 ), shift1 = 6 - headRoom (<= 64 x 256: 16 bits): the first-pass value is bytes 1..2 of the accumulator (firstPass)
 static std::vector<int32_t> stageTapTables( int bitDepth )
 {
-  const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2, vScale = 1 << ( 10 - headRoom );
+  const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2, vScale = 1 << ( 10 - headRoom ), hScale = 1 << ( 2 + headRoom );      // 2^( 16 - shift2 ), 2^( 8 - shift1 )
   std::vector<int32_t> tapTab( 6 * 192, 0 );
   for( int mode = 0; mode < 3; mode++ ) for( int alt = 0; alt < 2; alt++ )
   {
@@ -270,7 +271,7 @@ static std::vector<int32_t> stageTapTables( int bitDepth )
     for( int f = 0; f < 16; f++ )
     {
       for( int k = 0; k < 8; k++ ) t[f * 8 + k] = stageTap( f, k, mode, alt ) * vScale;
-      for( int i = 0; i < 4; i++ ) t[128 + f * 4 + i] = i < np ? ( int32_t ) ( ( ( uint32_t ) stageTap( f, k0 + 2 * i, mode, alt ) & 0xffffu ) | ( ( uint32_t ) stageTap( f, k0 + 2 * i + 1, mode, alt ) << 16 ) ) : 0;
+      for( int i = 0; i < 4; i++ ) t[128 + f * 4 + i] = i < np ? ( int32_t ) ( ( ( uint32_t ) ( stageTap( f, k0 + 2 * i, mode, alt ) * hScale ) & 0xffffu ) | ( ( uint32_t ) ( stageTap( f, k0 + 2 * i + 1, mode, alt ) * hScale ) << 16 ) ) : 0;
     }
   }
   return tapTab;
@@ -451,6 +452,91 @@ __device__ __forceinline__ uint32_t hadTeamPk( const uint32_t ( &o )[4], const u
   return hadTeamCross( d, r, LT, kind, lane );
 }
 
+// 16 bytes at a 32-bit unsigned byte offset from a WAVE-UNIFORM base: global_load with scalar base + vector offset — one multiply-add per address instead of a 64-bit
+// multiply and three 64-bit adds per lane
+__device__ __forceinline__ u32x4 ld16o( const char* base, uint32_t byteOff ) { return reinterpret_cast<const U16*>( base + byteOff )->v; }
+__device__ __forceinline__ u32x2 ld8o( const char* base, uint32_t byteOff ) { return reinterpret_cast<const U8*>( base + byteOff )->v; }
+// dot product on top of a wave-uniform constant (a scalar register as the third operand: no accumulator initialisation per output)
+__device__ __forceinline__ int dot2s( uint32_t a, uint32_t b, int c ) { int r; asm( "v_dot2_i32_i16 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( b ), "s"( c ) ); return r; }
+
+// First (horizontal) pass of a stage unit: tmp[vl][r][x] <-> plane row y0 + K0 - 4 + r, column x + ( displacement of variant v0 + vl >> 4 ), for nH = variants x rowsT x G
+// units of 8 outputs.  HU units per lane and trip, all their loads issued before the first is used (a unit is short: without it every trip of the wave waits out a full
+// memory latency).  8 outputs per lane from two overlapping 16-byte loads, tap PAIRS as v_dot2_i32_i16 on the even / odd sample pairs of the window (no unpacking).
+// The plan's tap pairs are scaled by 2^( 8 - shift1 ): ( sum + offset ) >> shift1 sits in bytes 1..2 of the accumulator, ONE v_perm_b32 shifts and packs two outputs.
+// ONE: the pass holds a single horizontal variant (units of 32 / 64 columns): its displacement, phase and taps are wave-uniform.
+// refB: the unit's plane row y0 + K0 - 4, 8 samples left of the unit's column 0 (every sample offset below is >= 0).
+template<int K0, int K1, bool ONE>
+__device__ __forceinline__ void firstPass( const char* refB, int rs, int nH, int G, int log2G, int rowsT, int ldsPitch, int v0, int hx0, int hx1, int hx2,
+                                           const uint32_t* tapP, int16_t* tmp, int tid, int offS, int headRoom, uint32_t biasPk )
+{
+  constexpr int NT = K1 - K0 + 1, NP = NT / 2, B0 = ( NT - 2 ) / 2, HU = VVHIP_ME_HU;
+  const int txOne = v0 == 0 ? hx0 : ( v0 == 1 ? hx1 : hx2 );
+  for( int ub = tid; ub < nH; ub += HU * 64 )
+  {
+    u32x4 LA[HU], LB[HU]; int fxs[HU], at[HU]; bool ok[HU];
+#pragma unroll
+    for( int q = 0; q < HU; q++ )
+    {
+      const int u = ub + q * 64;
+      ok[q] = u < nH;
+      const int uu = ok[q] ? u : ub;
+      const int x0 = ( uu & ( G - 1 ) ) << 3, rr = uu >> log2G;
+      int r = rr, txv = txOne;
+      if( !ONE )
+      {
+        const int vl = ( rr >= rowsT ) + ( rr >= 2 * rowsT ), v = v0 + vl;                          // (<= 3 variants: no division)
+        r = rr - __mul24( vl, rowsT ); txv = v == 0 ? hx0 : ( v == 1 ? hx1 : hx2 );
+      }
+      fxs[q] = txv & 15; at[q] = __mul24( rr, ldsPitch ) + x0;
+      const uint32_t off = ( uint32_t ) ( __mul24( r, rs ) + x0 + ( txv >> 4 ) + 8 ) * 2u;        // bytes from refB to the output's integer position p
+      // window samples s[0 .. 6 + NT] = p[K0 - 3 ..]: A = s[0..7] as even pairs W[0..3], B = s[NT - 1 .. NT + 6] as odd pairs S[B0 .. B0 + 3]; zero phase: A = p[0..7]
+      LA[q] = ld16o( refB, fxs[q] ? off + ( uint32_t ) ( 2 * ( K0 - 3 ) ) : off ); LB[q] = ld16o( refB, off + ( uint32_t ) ( 2 * ( K0 - 3 + NT - 1 ) ) );
+    }
+#pragma unroll
+    for( int q = 0; q < HU; q++ )
+    {
+      if( !ok[q] ) continue;
+      const int fxv = fxs[q];
+      const u32x4 A = LA[q], B = LB[q];
+      u32x4 ov;
+      if( fxv )
+      {
+        uint32_t W[4 + NP], S[4 + NP];
+        W[0] = A.x; W[1] = A.y; W[2] = A.z; W[3] = A.w;
+        S[B0] = B.x; S[B0 + 1] = B.y; S[B0 + 2] = B.z; S[B0 + 3] = B.w;
+#pragma unroll
+        for( int m = B0 - 1; m >= 0; m-- ) S[m] = __builtin_amdgcn_alignbit( W[m + 1], W[m], 16 );      // the missing pairs by v_alignbit
+#pragma unroll
+        for( int m = 4; m < 4 + NP - 1; m++ ) W[m] = __builtin_amdgcn_alignbit( S[m], S[m - 1], 16 );
+        uint32_t cp[NP];
+#pragma unroll
+        for( int i = 0; i < NP; i++ ) cp[i] = tapP[fxv * 4 + i];
+        uint32_t o[4];
+#pragma unroll
+        for( int qq = 0; qq < 4; qq++ )
+        {
+          int e = dot2s( W[qq], cp[0], offS ), d = dot2s( S[qq], cp[0], offS );
+#pragma unroll
+          for( int i = 1; i < NP; i++ ) { e = dot2( W[qq + i], cp[i], e ); d = dot2( S[qq + i], cp[i], d ); }
+          o[qq] = __builtin_amdgcn_perm( ( uint32_t ) d, ( uint32_t ) e, 0x06050201u );
+        }
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+      }
+      else
+      {
+        // filterCopy<true,false>: ( sample << headRoom ) - 8192 (InterpolationFilter.cpp:285-296), stored with the folded constants like the filtered rows
+        const uint32_t aw[4] = { A.x, A.y, A.z, A.w };
+        const s16x2 sh = { ( short ) headRoom, ( short ) headRoom };
+        uint32_t o[4];
+#pragma unroll
+        for( int qq = 0; qq < 4; qq++ ) o[qq] = pkAdd( __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, aw[qq] ) << sh ), biasPk );
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+      }
+      *reinterpret_cast<u32x4*>( tmp + at[q] ) = ov;
+    }
+  }
+}
+
 // a stage unit in the schedule: stage index | band of 32 rows << 24 | 64-column half << 27 | continues the previous unit's sums << 28 | the next unit continues << 29 | atomic << 30
 constexpr int ST_UNIT_CONT = 1 << 28, ST_UNIT_MORE = 1 << 29, ST_UNIT_ATOMIC = 1 << 30;      // ATOMIC: a stage of more than two units — every unit a wave of its own, sums added to the (cleared) cost array
 
@@ -459,15 +545,15 @@ constexpr int ST_UNIT_CONT = 1 << 28, ST_UNIT_MORE = 1 << 29, ST_UNIT_ATOMIC = 1
 template<int K0, int K1, bool GEN>
 __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, const WaveSpan span, int16_t* lds, uint32_t* pairCost, const int wv )
 {
-  constexpr int NT = K1 - K0 + 1, NP = NT / 2, B0 = ( NT - 2 ) / 2;
-  constexpr int HU = VVHIP_ME_HU;                                                    // first-pass units a lane has in flight per trip
+  constexpr int NT = K1 - K0 + 1;
   // a unit belongs to ONE wave: the workgroup's other waves work on other bundles (their own LDS slice); every hand-over through LDS is inside the wave
 #define ST_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
   const int tid = threadIdx.x & 63, nthr = 64, lane = tid, bd = a.bitDepth;
   const int headRoom = 14 - bd > 2 ? 14 - bd : 2;
   // first (not last) pass, InterpolationFilter.cpp:401-408: ( sum >> shift1 ) - 8192; kept in LDS as ( sum >> shift1 ) + 2^( headRoom - 1 ) instead — the second pass's
   // constants ( :394-400 ) folded into the stored value, see predRow
-  const int shift1 = 6 - headRoom, off1 = ( 1 << ( headRoom - 1 ) ) << shift1, biasT = 1 << ( headRoom - 1 );
+  const int offS = ( 1 << ( headRoom - 1 ) ) << 8;                                   // the stored offset on the scaled accumulator (firstPass)
+  const uint32_t biasPk = ( uint32_t ) ( 1 << ( headRoom - 1 ) ) * 0x00010001u;
   const uint32_t maxPk = ( uint32_t ) ( ( 1 << bd ) - 1 ) * 0x00010001u;
   int* tapL = reinterpret_cast<int*>( lds );                                         // [16 phases][8] taps of the current unit's stage
   uint32_t* tapP = reinterpret_cast<uint32_t*>( lds ) + 128;                         // [16 phases][4] tap pairs (K0 + 2i, K0 + 2i + 1)
@@ -491,9 +577,9 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     const int w = j.width, h = j.height, uw = w < 64 ? w : 64, uwH = uw < 8 ? 8 : uw, G = uwH >> 3, log2G = 31 - __builtin_clz( G );
     const int BH = h < 32 ? h : 32, rowsT = BH + NT, y0 = ( ( unit >> 24 ) & 7 ) * BH, xoff = ( ( unit >> 27 ) & 1 ) * 64;
     const int ldsPitch = uwH + 8;                                                  // LDS row pitch: an odd number of 16-byte chunks (rows of a tile column land in different banks)
-    const int16_t* ref = P.p[j.ref_plane] + j.ref_off + xoff;
     const int rs = P.stride[j.ref_plane];
-    const int16_t* org = P.p[j.org_plane] + j.org_off + xoff;
+    const char* refB = reinterpret_cast<const char*>( P.p[j.ref_plane] + j.ref_off + xoff + ( ptrdiff_t ) ( y0 + K0 - 4 ) * rs - 8 );      // (wave-uniform)
+    const char* orgB = reinterpret_cast<const char*>( P.p[j.org_plane] + j.org_off + xoff );
     const int os = P.stride[j.org_plane] ? P.stride[j.org_plane] : w;             // (stride 0: a compact pool block — bi-prediction patterns)
     // the evaluated positions and their distinct horizontal displacements (<= 3: the refinement offsets are -1, 0, 1; one first pass each, shared like the reference's planes)
     // come precomputed with the unit; posL: the positions grouped by displacement (a pass of the unit works on the positions of the variants it holds in LDS)
@@ -528,70 +614,14 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     const int nV = nHor - v0 < vpp ? nHor - v0 : vpp;
     const int pBeg = v0 == 0 ? 0 : ( v0 == 1 ? cnt0 : cnt0 + cnt1 ), pEnd = v0 + nV >= 3 ? nPos : ( v0 + nV == 2 ? cnt0 + cnt1 : ( v0 + nV == 1 ? cnt0 : 0 ) );
     ST_SYNC();                                                                    // tables and positions are written; the previous pass's readers are done with tmp
-    // ---- H: tmp[v - v0][r][x] <-> plane row y0 + K0 - 4 + r, column x + sx[v].  HU units per lane and trip, all their loads issued before the first is used (a unit is short:
-    //      without it every trip of the wave waits out a full memory latency)
+    // ---- H: tmp[v - v0][r][x] <-> plane row y0 + K0 - 4 + r, column x + sx[v] (firstPass)
 #if defined( VVHIP_ME_CUT ) && ( VVHIP_ME_CUT & 1 )      // (cut build for phase timing, tools/me_cut.sh: no first pass — results are wrong by construction)
     const int nH = 0;
 #else
     const int nH = nV * rowsT * G;
 #endif
-    for( int ub = tid; ub < nH; ub += HU * nthr )
-    {
-      u32x4 LA[HU], LB[HU]; int fxs[HU], at[HU]; bool ok[HU];
-#pragma unroll
-      for( int q = 0; q < HU; q++ )
-      {
-        const int u = ub + q * nthr;
-        ok[q] = u < nH;
-        const int uu = ok[q] ? u : ub;
-        const int x0 = ( uu & ( G - 1 ) ) << 3, rr = uu >> log2G, vl = ( rr >= rowsT ) + ( rr >= 2 * rowsT ), r = rr - vl * rowsT, v = v0 + vl;      // (nV <= 3 variants: no division)
-        const int txv = v == 0 ? hx0 : ( v == 1 ? hx1 : hx2 ), sxv = txv >> 4;
-        fxs[q] = txv & 15; at[q] = ( vl * rowsT + r ) * ldsPitch + x0;
-        const int16_t* p = ref + ( ptrdiff_t ) ( y0 + K0 - 4 + r ) * rs + x0 + sxv;
-        // window samples s[0 .. 6 + NT] = p[K0 - 3 ..]: A = s[0..7] as even pairs W[0..3], B = s[NT - 1 .. NT + 6] as odd pairs S[B0 .. B0 + 3]; zero phase: A = p[0..7]
-        LA[q] = ld16( fxs[q] ? p + K0 - 3 : p ); LB[q] = ld16( p + K0 - 3 + NT - 1 );
-      }
-#pragma unroll
-      for( int q = 0; q < HU; q++ )
-      {
-        if( !ok[q] ) continue;
-        const int fxv = fxs[q];
-        const u32x4 A = LA[q], B = LB[q];
-        u32x4 ov;
-        if( fxv )
-        {
-          uint32_t W[4 + NP], S[4 + NP];
-          W[0] = A.x; W[1] = A.y; W[2] = A.z; W[3] = A.w;
-          S[B0] = B.x; S[B0 + 1] = B.y; S[B0 + 2] = B.z; S[B0 + 3] = B.w;
-#pragma unroll
-          for( int m = B0 - 1; m >= 0; m-- ) S[m] = __builtin_amdgcn_alignbit( W[m + 1], W[m], 16 );      // the missing pairs by v_alignbit
-#pragma unroll
-          for( int m = 4; m < 4 + NP - 1; m++ ) W[m] = __builtin_amdgcn_alignbit( S[m], S[m - 1], 16 );
-          uint32_t cp[NP];
-#pragma unroll
-          for( int i = 0; i < NP; i++ ) cp[i] = tapP[fxv * 4 + i];
-          uint32_t o[4];
-#pragma unroll
-          for( int qq = 0; qq < 4; qq++ )
-          {
-            int e = off1, d = off1;
-#pragma unroll
-            for( int i = 0; i < NP; i++ ) { e = dot2( W[qq + i], cp[i], e ); d = dot2( S[qq + i], cp[i], d ); }
-            o[qq] = pack2( e >> shift1, d >> shift1 );
-          }
-          ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
-        }
-        else
-        {
-          const uint32_t aw[4] = { A.x, A.y, A.z, A.w };                               // filterCopy<true,false>: ( sample << headRoom ) - 8192 (InterpolationFilter.cpp:285-296), stored with the folded constants like the filtered rows
-          uint32_t o[4];
-#pragma unroll
-          for( int qq = 0; qq < 4; qq++ ) o[qq] = pack2( ( lo16( aw[qq] ) << headRoom ) + biasT, ( hi16( aw[qq] ) << headRoom ) + biasT );
-          ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
-        }
-        *reinterpret_cast<u32x4*>( tmp + at[q] ) = ov;
-      }
-    }
+    if( nV == 1 ) firstPass<K0, K1, true>( refB, rs, nH, G, log2G, rowsT, ldsPitch, v0, hx0, hx1, hx2, tapP, tmp, tid, offS, headRoom, biasPk );
+    else          firstPass<K0, K1, false>( refB, rs, nH, G, log2G, rowsT, ldsPitch, v0, hx0, hx1, hx2, tapP, tmp, tid, offS, headRoom, biasPk );
     ST_SYNC();     
     // ---- VD: LT lanes per (position, tile); what a lane holds: see the tile table above
 #if defined( VVHIP_ME_CUT ) && ( VVHIP_ME_CUT & 2 )      // (cut build: no second pass / distortion)
@@ -616,8 +646,8 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       {
         int d[8];
         const int16_t* tv = tvp + txi * 16;
-        const int16_t* po = org + ( ptrdiff_t ) ( y0 + tyi * 16 + 2 * r ) * os + txi * 16;
-        const u32x4 c0v = ld16( po ), c1v = ld16( po + 8 ), e0 = ld16( po + os ), e1 = ld16( po + os + 8 );
+        const uint32_t po = ( uint32_t ) ( __mul24( y0 + tyi * 16 + 2 * r, os ) + txi * 16 ) * 2u, po1 = po + ( uint32_t ) os * 2u;
+        const u32x4 c0v = ld16o( orgB, po ), c1v = ld16o( orgB, po + 16 ), e0 = ld16o( orgB, po1 ), e1 = ld16o( orgB, po1 + 16 );
         uint32_t pa[4], pb[4]; int ap[4], ao[4];
         predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r, syk, anyFrac, vt, headRoom, maxPk, pa );
         predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
@@ -641,8 +671,8 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
         {
           // a 4-wide block (one tile column): two rows of four samples per lane; the first pass worked on 8 columns, the upper four are not part of the block
           const int row = tyi * 8 + 2 * r;
-          const int16_t* po = org + ( ptrdiff_t ) ( y0 + row ) * os;
-          const u32x2 oa = ld8( po ), ob = ld8( po + os );
+          const uint32_t po = ( uint32_t ) __mul24( y0 + row, os ) * 2u;
+          const u32x2 oa = ld8o( orgB, po ), ob = ld8o( orgB, po + ( uint32_t ) os * 2u );
           uint32_t pa[4], pb[4];
           predRow<K0, K1>( tvp, ldsPitch, row, syk, anyFrac, vt, headRoom, maxPk, pa );
           predRow<K0, K1>( tvp, ldsPitch, row + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
@@ -651,7 +681,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
         else
         {
           const int row = ( GEN && kind == TK_16x8 ) ? tyi * 8 + ( r & 7 ) : ( tyi << log2PH ) + r, col = ( GEN && kind == TK_16x8 ) ? txi * 16 + 8 * ( r >> 3 ) : txi * 8;
-          const u32x4 ovv = ld16( org + ( ptrdiff_t ) ( y0 + row ) * os + col );
+          const u32x4 ovv = ld16o( orgB, ( uint32_t ) ( __mul24( y0 + row, os ) + col ) * 2u );
           predRow<K0, K1>( tvp + col, ldsPitch, row, syk, anyFrac, vt, headRoom, maxPk, p4 );
           o4[0] = ovv.x; o4[1] = ovv.y; o4[2] = ovv.z; o4[3] = ovv.w;
         }
