@@ -402,13 +402,16 @@ def roofline_objects(kern, live, calib, unique_by_class, profile_md=None):
     dom = max(kern, key=lambda k: kern[k]["avg_ms_per_picture"])
     roof = {"kernel": KERNEL_NAMES[dom], "class": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": kern[dom]["avg_ms_per_picture"],
             "nominal_alg_GBps": kern[dom]["nominal_alg_GBps"], "alg_bytes_per_launch": kern[dom]["alg_bytes_per_picture"],
-            "basis": "PHYSICAL: traffic across the L2's memory side per launch (rocprofv3 --pmc FETCH_SIZE x the factor calibrated on this GPU for the kernel's access pattern + WRITE_SIZE, "
-                     "separate passes over the inner run of this command) / launch duration / 8 TB/s.  FETCH_SIZE counts the L2's fabric read requests: hits in the 256 MB Infinity "
-                     "Cache are INCLUDED, so `traffic` is fabric traffic and `frac` an UPPER bound of the HBM fraction (a picture's planes stay resident in the Infinity Cache).  "
-                     "nominal_alg_GBps is SURVEY 8d's per-unit figure over the same duration: the bytes the kernel would read without any reuse, not a fraction of anything"}
+            "basis": "achieved = ALGORITHMIC bytes of one launch (SURVEY 8d: 4 w h bytes per scored position, DESIGN 5) / the launch's average duration in the rocprofv3 kernel trace; "
+                     "frac = achieved / 8 TB/s.  traffic = bytes that crossed the L2's memory side per launch (rocprofv3 --pmc FETCH_SIZE x the factor calibrated on this GPU for the "
+                     "kernel's access pattern + WRITE_SIZE, separate passes over the inner run of this command); FETCH_SIZE counts the L2's fabric read requests, hits in the 256 MB "
+                     "Infinity Cache INCLUDED, so frac_physical = traffic / duration / 8 TB/s is an UPPER bound of the HBM fraction.  The kernel stages its windows in LDS and the XCD-band "
+                     "schedule keeps a band of the planes in each L2: traffic is ~ the unique bytes (traffic_over_unique), an order of magnitude below the algorithmic bytes, and what "
+                     "binds the launch is VALU issue (binding_resource), not HBM"}
     allk = {}
     if not live or not live.get("per_class"):
-        roof.update({"bound": "hbm", "traffic": None, "achieved": kern[dom]["nominal_alg_GBps"], "frac": None, "note": "no live PMC pass (rocprofv3 absent or --no-profile): no physical fraction reported"})
+        roof.update({"bound": "hbm", "traffic": None, "achieved": kern[dom]["nominal_alg_GBps"], "frac": kern[dom]["nominal_alg_GBps"] / HBM_PEAK_GBS, "frac_physical": None,
+                     "note": "no live PMC pass (rocprofv3 absent or --no-profile): HIP-event duration per picture instead of the trace's per-launch average, no counter traffic"})
         return roof, allk
     fac = calib["factors"]
     for k, c in live["per_class"].items():
@@ -425,6 +428,8 @@ def roofline_objects(kern, live, calib, unique_by_class, profile_md=None):
         allk[k] = {"kernel": KERNEL_NAMES.get(k, k), "launches_per_picture": round(lpp, 2), "avg_launch_us": round(t_k * 1e6, 2),
                    "fabric_traffic_MB_per_launch": round(traffic / 1e6, 2) if traffic is not None else None,
                    "fabric_traffic_bounds_MB": [round((f_ * 1024.0 + (w_ or 0) * 1024.0) / 1e6, 2), round((f_ * 2048.0 + (w_ or 0) * 1024.0) / 1e6, 2)] if f_ is not None else None,
+                   "alg_MB_per_launch": round(kern[k]["alg_bytes_per_picture"] / max(1e-9, lpp) / 1e6, 2) if k in kern else None,
+                   "alg_frac_of_hbm_peak": round(kern[k]["alg_bytes_per_picture"] / max(1e-9, lpp) / t_k / 1e9 / HBM_PEAK_GBS, 4) if k in kern else None,
                    "fetch_factor": round(ff, 3), "fabric_frac_of_hbm_peak": round(traffic / t_k / 1e9 / HBM_PEAK_GBS, 4) if traffic is not None else None,
                    "unique_MB_per_picture": round(uniq / 1e6, 2) if uniq else None,
                    "traffic_over_unique": round(traffic * lpp / uniq, 2) if traffic is not None and uniq else None,
@@ -440,22 +445,25 @@ def roofline_objects(kern, live, calib, unique_by_class, profile_md=None):
         roof.update({"traffic": traffic, "avg_launch_ms": t_s * 1e3, "launches_per_picture": d["launches_per_picture"], "ms_per_picture": kern[dom]["avg_ms_per_picture"],
                      "alg_bytes_per_launch": kern[dom]["alg_bytes_per_picture"] / max(1e-9, n / 32.0),
                      "avg_launch_ms_measured": "rocprofv3 kernel trace of the inner run (launches serialized), averaged over the class's launches of one GOP cycle",
-                     "achieved": (traffic / t_s / 1e9) if traffic else None, "frac": (traffic / t_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "frac_nominal_alg": (kern[dom]["alg_bytes_per_picture"] / max(1e-9, n / 32.0) / t_s / 1e9 / HBM_PEAK_GBS),
-                     "frac_note": "frac = fabric traffic / time / 8 TB/s (physical, counter-based: it FALLS when re-reads are removed — round 3: 95 MB per launch = 0.27, round 4: 15 MB = 0.05 for a "
-                                  "shorter launch); frac_nominal_alg = SURVEY 8d's per-position bytes / time / 8 TB/s (what a kernel without any reuse would have to stream)",
+                     "achieved": kern[dom]["alg_bytes_per_picture"] / max(1e-9, n / 32.0) / t_s / 1e9,
+                     "frac": kern[dom]["alg_bytes_per_picture"] / max(1e-9, n / 32.0) / t_s / 1e9 / HBM_PEAK_GBS,
+                     "achieved_physical": (traffic / t_s / 1e9) if traffic else None, "frac_physical": (traffic / t_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "frac_note": "frac = algorithmic bytes / time / 8 TB/s (the task's definition; rounds 2-3 reported the counter-based figure here, now frac_physical: 0.27 in round 3 with 95 MB of "
+                                  "fabric traffic per launch, ~0.05 now with ~15 MB for a shorter launch — it FALLS when re-reads are removed)",
                      "fetch_factor": d["fetch_factor"], "traffic_bounds_MB": d["fabric_traffic_bounds_MB"],
                      "unique_bytes_per_picture": unique_by_class.get(dom), "traffic_over_unique": d["traffic_over_unique"], "l2_hit_rate": d["l2_hit_rate"],
                      "traffic_over_alg_bytes": (traffic * (n / 32.0) / kern[dom]["alg_bytes_per_picture"]) if traffic and kern[dom]["alg_bytes_per_picture"] else None,
                      "l1_access_frac": d["l1_access_frac"], "valu_issue_frac": d["valu_issue_frac"]})
-        fr = {"hbm": roof["frac"] or 0.0, "l1_access": roof["l1_access_frac"] or 0.0, "valu": roof["valu_issue_frac"] or 0.0}
+        fr = {"hbm": roof["frac_physical"] or 0.0, "l1_access": roof["l1_access_frac"] or 0.0, "valu": roof["valu_issue_frac"] or 0.0}
         order = sorted(fr, key=lambda k: -fr[k])
-        roof["bound"] = "+".join(k for k in order if fr[k] >= 0.6 * fr[order[0]] and fr[k] > 0) or "hbm"
-        roof["binding_resource"], roof["binding_frac"] = order[0], fr[order[0]]      # the resource closest to its ceiling and how close (frac stays the fabric-traffic figure)
+        roof["bound"] = "hbm"                                                        # the ceiling `peak` / `frac` are quoted against (the task's roofline object: hbm | mfma; no MFMA on this path)
+        roof["bound_physical"] = "+".join(k for k in order if fr[k] >= 0.6 * fr[order[0]] and fr[k] > 0) or "hbm"
+        roof["binding_resource"], roof["binding_frac"] = order[0], fr[order[0]]      # the resource closest to its ceiling and how close
+        roof["valu_rate_note"] = "valu_issue_frac counts 4 cycles at %.1f GHz (1.67 ns) per wave instruction; measured sustained issue on this GPU is 1.8 ns per instruction and SIMD for the VOP3 / DPP / packed forms these kernels use (profiles/r04_valu_rate.log): the fraction of the ATTAINABLE issue rate is ~1.08 x valu_issue_frac" % CLOCK_GHZ
         roof["limiter"] = "fractions of the launch time: fabric traffic %.3f of the HBM peak, L1 (TCP) access slots %.3f (one access per 64-byte granule and instruction, %d CUs x %.1f GHz), VALU issue slots %.3f " \
                           "(wave instructions x 4 cycles / %d SIMDs); the rest is latency the resident waves do not cover" % (fr["hbm"], fr["l1_access"], N_CU, CLOCK_GHZ, fr["valu"], N_SIMD)
     else:
-        roof.update({"bound": "hbm", "traffic": None, "achieved": kern[dom]["nominal_alg_GBps"], "frac": None, "note": "the PMC passes did not see the dominant kernel"})
+        roof.update({"bound": "hbm", "traffic": None, "achieved": kern[dom]["nominal_alg_GBps"], "frac": kern[dom]["nominal_alg_GBps"] / HBM_PEAK_GBS, "frac_physical": None, "note": "the PMC passes did not see the dominant kernel"})
     if profile_md:
         try:
             with open(profile_md, "w") as f:
