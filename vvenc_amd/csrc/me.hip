@@ -51,7 +51,7 @@ struct vvhip_me_plan
   // the fast presets, every tile quantity a compile-time constant; 1: any shape)
   int stageSetWaves[6] = { 0, 0, 0, 0, 0, 0 }, stageSetLds[6] = { 0, 0, 0, 0, 0, 0 };
   void* d_blob = nullptr;                  // one allocation: every table below
-  const void* d_intJobs = nullptr; const void* d_cands = nullptr; const void* d_stageJobs = nullptr; const void* d_stageOrder = nullptr; const void* d_stageWaves = nullptr;
+  const void* d_intJobs = nullptr; const void* d_cands = nullptr; const void* d_candOut = nullptr; const void* d_stageJobs = nullptr; const void* d_stageOrder = nullptr; const void* d_stageWaves = nullptr;
   const void* d_items = nullptr; const void* d_itemOrder = nullptr; const void* d_itemWaves = nullptr; const void* d_tapTables = nullptr; const void* d_maskItems = nullptr;
 };
 
@@ -75,7 +75,7 @@ struct MePlanes { const int16_t* p[16]; int stride[16]; };
 
 // ---- plan-side job records (device) ------------------------------------------------------------------------------------------------------------
 struct IntJob   { int32_t orgOff, refOff; int16_t w, h; uint8_t orgPlane, refPlane, subShift, pad; int16_t minDx, minDy, winW, winH; int32_t firstCand, nCand; };   // one window
-struct PlanCand { int16_t dx, dy; int32_t outIndex; };
+struct PlanCand { int16_t dx, dy; uint32_t out; };      // out: the candidate's first entry in the plan's output list | ( entries - 1 ) << 24 — every entry is a position of the caller's cost array (identical positions of a job are scored once)
 struct WaveSpan { int32_t first, count; };                                                                                                               // into an order array
 // one stage unit of the schedule: the job + what every lane of the wave used to re-derive from it per unit (the evaluated positions grouped by their horizontal displacement,
 // the <= 3 distinct displacements and how many positions use each): plan creation does it once (the unit skeleton)
@@ -91,7 +91,7 @@ struct StageUnit
 static_assert( sizeof( StageUnit ) == 88, "StageUnit layout" );
 struct MeArgs
 {
-  const IntJob* intJobs; const PlanCand* cands; int wavesInt;
+  const IntJob* intJobs; const PlanCand* cands; const int32_t* candOut; int wavesInt;
   const StageUnit* stageUnits; const WaveSpan* stageWaves; int wavesStage;
   const int32_t* tapTables;      // [6 = filter_mode * 2 + alt_hpel][192]: stageTapTables
   const vvhip_me_item* items; const int32_t* itemOrder; const WaveSpan* itemWaves; int wavesItem;
@@ -144,7 +144,7 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
   {
     // every global request of the job is issued before the first one is waited for: the candidate records, the original block (<= 4 chunks per lane: any block up to
     // 64x64, 128x128 with row sub-sampling), then the window in batches of four chunks per lane — the job is one memory latency + the LDS work, not four latencies in a row
-    PlanCand myCand = { 0, 0, 0 };
+    PlanCand myCand = { 0, 0, 0u };
     if( tid < j.nCand ) myCand = a.cands[j.firstCand + tid];
     const int16_t* org = P.p[j.orgPlane] + j.orgOff;
     const int os = P.stride[j.orgPlane] ? P.stride[j.orgPlane] : w, m = rowsEff * lpr;      // (stride 0: a pool of compact blocks)
@@ -202,6 +202,9 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
     const int ci = c0 + team;
     const bool valid = ci < j.nCand;
     const PlanCand cd = candL[valid ? ci : 0];
+    // where the cost goes: the search scores its start point again and again (half of a recorded picture's integer positions repeat one of the same call) — plan creation
+    // keeps one candidate per distinct position and the list of cost-array entries it stands for; lane k of the team stores entry k (requested here, ahead of the rows)
+    const int myOut = ( valid && ( uint32_t ) lt <= ( cd.out >> 24 ) ) ? a.candOut[( cd.out & 0xffffffu ) + lt] : -1;
     const int x = cd.dx - j.minDx, y = cd.dy - j.minDy;
     const int rowBase = ss ? ( ( y & 1 ) ? half0 : 0 ) + ( y >> 1 ) : y;
     const int16_t* base = win + rowBase * pitch + ( x & ~1 );
@@ -223,7 +226,7 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
       pc += curStep; po += orgStep;
     }
     const uint32_t t = vvhipGroupSum32( sad, lpc, lane );
-    if( valid && lt == 0 ) a.candCost[cd.outIndex] = ( uint64_t ) t << ss;       // RdCost.cpp:334
+    if( myOut >= 0 ) a.candCost[myOut] = ( uint64_t ) t << ss;                    // RdCost.cpp:334
   }
 }
 
@@ -1005,6 +1008,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   const int n_int_jobs = L.n_int_jobs, n_cands = L.n_cands, n_stage_jobs = L.n_stage_jobs, n_items = L.n_items, n_mask = L.n_mask_items;
   if( n_int_jobs < 0 || n_cands < 0 || n_stage_jobs < 0 || n_items < 0 || n_mask < 0 || ( n_int_jobs && ( !int_jobs || !cands ) ) || ( n_stage_jobs && !stage_jobs ) || ( n_items && !items ) || ( n_mask && !mask_items ) )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: bad lists" );
+  if( n_cands >= ( 1 << 24 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: %d candidates (the schedule packs the output-list position into 24 bits)", n_cands );
   if( n_stage_jobs >= ( 1 << 24 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: %d stage jobs (the schedule packs the stage index into 24 bits)", n_stage_jobs );
   if( bit_depth < 8 || bit_depth > 10 ) return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_me_plan_create: bit depth %d (the packed Hadamard tile covers <= 10)", bit_depth );
   if( max_window <= 0 ) max_window = 24;
@@ -1012,23 +1016,34 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   auto shapeOk = []( int w, int h, int minW, int minH ) { return isPow2( w ) && isPow2( h ) && w >= minW && h >= minH && w <= 128 && h <= 128; };
 
   // ---- integer jobs: one window per cluster of candidates (greedy in list order: a candidate joins the first window it keeps within max_window)
-  std::vector<IntJob> ij; std::vector<PlanCand> pc;
+  std::vector<IntJob> ij; std::vector<PlanCand> pc; std::vector<int32_t> candOut;      // candOut: the cost-array entries of the kept candidates, consecutive per candidate
   int ldsInt = 0;
+  static const bool dedupe = !( getenv( "VVHIP_ME_DEDUPE" ) && atoi( getenv( "VVHIP_ME_DEDUPE" ) ) == 0 );      // (0: every position scored as often as the caller lists it — A/B measurements)
   static const int candCap = getenv( "VVHIP_ME_CAND_CAP" ) ? atoi( getenv( "VVHIP_ME_CAND_CAP" ) ) : 16;      // recorded 1080p B pictures, window launch with events: 16 / 32 / 64 / none -> 22.0 / 24.7 / 28.8 / 29.0 us
   for( int i = 0; i < n_int_jobs; i++ )
   {
     const vvhip_me_int_job& s = int_jobs[i];
     if( !shapeOk( s.width, s.height, 8, 4 ) || s.org_plane > 15 || s.ref_plane > 15 || s.sub_shift > 1 || ( s.height >> s.sub_shift ) < 1 || s.first_cand < 0 || s.n_cand < 0 || s.first_cand + s.n_cand > n_cands )
       return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: integer job %d (%dx%d, candidates %d+%d)", i, s.width, s.height, s.first_cand, s.n_cand );
-    struct Win { int x0, y0, x1, y1; std::vector<PlanCand> c; };
+    struct WinCand { int16_t dx, dy; std::vector<int32_t> outs; };
+    struct Win { int x0, y0, x1, y1; std::vector<WinCand> c; };
+    // a kept candidate stands for at most as many entries as its team has lanes (each lane stores one), min( 64, 16-byte chunks of the evaluated rows )
+    const int teamLanes = std::min( 64, ( s.height >> s.sub_shift ) * ( s.width >> 3 ) );
     std::vector<Win> wins;
     // a 128-wide block's window must still fit the LDS of a workgroup: its reach shrinks with the block
     const int reach = std::min( max_window, s.width * s.height >= 128 * 64 ? 16 : max_window );
     for( int k = 0; k < s.n_cand; k++ )
     {
       const vvhip_me_cand& c = cands[s.first_cand + k];
-      PlanCand p; p.dx = c.dx; p.dy = c.dy; p.outIndex = s.first_cand + k;
+      WinCand p; p.dx = c.dx; p.dy = c.dy; p.outs.assign( 1, s.first_cand + k );
       bool placed = false;
+      if( dedupe )
+        for( Win& wn : wins )
+        {
+          for( WinCand& q : wn.c ) if( q.dx == c.dx && q.dy == c.dy && ( int ) q.outs.size() < teamLanes ) { q.outs.push_back( s.first_cand + k ); placed = true; break; }
+          if( placed ) break;
+        }
+      if( placed ) continue;
       for( Win& wn : wins )
       {
         if( ( int ) wn.c.size() >= candCap ) continue;          // a window's candidates are one workgroup's serial work: long lists (raster searches: ~300 positions) are cut
@@ -1042,7 +1057,11 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
       IntJob j; j.orgOff = s.org_off; j.refOff = s.ref_off; j.w = s.width; j.h = s.height; j.orgPlane = s.org_plane; j.refPlane = s.ref_plane; j.subShift = s.sub_shift; j.pad = 0;
       j.minDx = ( int16_t ) wn.x0; j.minDy = ( int16_t ) wn.y0; j.winW = ( int16_t ) ( wn.x1 - wn.x0 + s.width ); j.winH = ( int16_t ) ( wn.y1 - wn.y0 + s.height );
       j.firstCand = ( int32_t ) pc.size(); j.nCand = ( int32_t ) wn.c.size();
-      pc.insert( pc.end(), wn.c.begin(), wn.c.end() );
+      for( const WinCand& q : wn.c )
+      {
+        PlanCand pcd; pcd.dx = q.dx; pcd.dy = q.dy; pcd.out = ( uint32_t ) candOut.size() | ( uint32_t ) ( q.outs.size() - 1 ) << 24;
+        pc.push_back( pcd ); candOut.insert( candOut.end(), q.outs.begin(), q.outs.end() );
+      }
       ij.push_back( j );
       ldsInt = std::max( ldsInt, ( hostWinSamples( j.winW, j.winH ) + ( s.height >> s.sub_shift ) * s.width ) * 2 + j.nCand * ( int ) sizeof( PlanCand ) );
     }
@@ -1291,15 +1310,15 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   const std::vector<int32_t> tapTab = stageTapTables( bit_depth );
   // ---- one device allocation for every table
   auto pad = []( size_t b ) { return ( b + 255 ) & ~( size_t ) 255; };
-  const size_t bInt = pad( ij.size() * sizeof( IntJob ) ), bCand = pad( pc.size() * sizeof( PlanCand ) ), bSt = pad( stUnits.size() * sizeof( StageUnit ) ),
+  const size_t bInt = pad( ij.size() * sizeof( IntJob ) ), bCand = pad( pc.size() * sizeof( PlanCand ) ), bCandO = pad( candOut.size() * 4 ), bSt = pad( stUnits.size() * sizeof( StageUnit ) ),
                bStO = pad( stOrder.size() * 4 ), bStW = pad( stWaves.size() * sizeof( WaveSpan ) ), bIt = pad( ( size_t ) n_items * sizeof( vvhip_me_item ) ), bItO = pad( itOrder.size() * 4 ),
                bItW = pad( itWaves.size() * sizeof( WaveSpan ) ), bMk = pad( mkSorted.size() * sizeof( vvhip_me_mask_item ) );
   const size_t bTap = pad( tapTab.size() * 4 );
-  const size_t total = bInt + bCand + bSt + bStO + bStW + bIt + bItO + bItW + bTap + bMk + 256;
+  const size_t total = bInt + bCand + bCandO + bSt + bStO + bStW + bIt + bItO + bItW + bTap + bMk + 256;
   std::vector<char> host( total, 0 );
   size_t o = 0;
   auto put = [&]( const void* src, size_t bytes, size_t padded ) { const size_t at = o; if( bytes ) memcpy( host.data() + o, src, bytes ); o += padded; return at; };
-  const size_t oInt = put( ij.data(), ij.size() * sizeof( IntJob ), bInt ), oCand = put( pc.data(), pc.size() * sizeof( PlanCand ), bCand ),
+  const size_t oInt = put( ij.data(), ij.size() * sizeof( IntJob ), bInt ), oCand = put( pc.data(), pc.size() * sizeof( PlanCand ), bCand ), oCandO = put( candOut.data(), candOut.size() * 4, bCandO ),
                oSt = put( stUnits.data(), stUnits.size() * sizeof( StageUnit ), bSt ), oStO = put( stOrder.data(), stOrder.size() * 4, bStO ),
                oStW = put( stWaves.data(), stWaves.size() * sizeof( WaveSpan ), bStW ), oIt = put( itSorted.data(), ( size_t ) n_items * sizeof( vvhip_me_item ), bIt ),
                oItO = put( itOrder.data(), itOrder.size() * 4, bItO ), oItW = put( itWaves.data(), itWaves.size() * sizeof( WaveSpan ), bItW ), oTap = put( tapTab.data(), tapTab.size() * 4, bTap ),
@@ -1311,7 +1330,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   if( e == hipSuccess ) e = hipStreamSynchronize( ctx->stream );
   if( e != hipSuccess ) { ( void ) hipFree( p->d_blob ); delete p; return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: upload: %s", hipGetErrorString( e ) ); }
   char* b = static_cast<char*>( p->d_blob );
-  p->d_intJobs = b + oInt; p->d_cands = b + oCand; p->d_stageJobs = b + oSt; p->d_stageOrder = b + oStO; p->d_stageWaves = b + oStW; p->d_items = b + oIt; p->d_itemOrder = b + oItO; p->d_itemWaves = b + oItW; p->d_tapTables = b + oTap; p->d_maskItems = b + oMk;
+  p->d_intJobs = b + oInt; p->d_cands = b + oCand; p->d_candOut = b + oCandO; p->d_stageJobs = b + oSt; p->d_stageOrder = b + oStO; p->d_stageWaves = b + oStW; p->d_items = b + oIt; p->d_itemOrder = b + oItO; p->d_itemWaves = b + oItW; p->d_tapTables = b + oTap; p->d_maskItems = b + oMk;
   p->bitDepth = bit_depth; p->nCands = n_cands; p->nStages = n_stage_jobs; p->nItems = n_items; p->nMaskItems = n_mask; p->maxPlane = maxPlane; p->stageAtomic = hasAtomic;
   p->wavesInt = ( int ) ij.size(); p->wavesStage = ( int ) stWaves.size(); p->wavesItem = ( int ) itWaves.size(); p->wavesItemMain = wavesItemMain;
   p->ldsInt = ( ldsInt + 15 ) & ~15; p->ldsStage = ( ldsStage + 15 ) & ~15;
@@ -1381,7 +1400,7 @@ static int mePlanRun( vvhip_ctx* ctx, const vvhip_me_plan* plan, const vvhip_me_
   MePlanes P;
   for( int i = 0; i < 16; i++ ) { P.p[i] = planes_host[i < n_planes ? i : 0].d_base; P.stride[i] = planes_host[i < n_planes ? i : 0].stride; }
   MeArgs a;
-  a.intJobs = static_cast<const IntJob*>( plan->d_intJobs ); a.cands = static_cast<const PlanCand*>( plan->d_cands ); a.wavesInt = plan->wavesInt;
+  a.intJobs = static_cast<const IntJob*>( plan->d_intJobs ); a.cands = static_cast<const PlanCand*>( plan->d_cands ); a.candOut = static_cast<const int32_t*>( plan->d_candOut ); a.wavesInt = plan->wavesInt;
   a.stageUnits = static_cast<const StageUnit*>( plan->d_stageJobs );
   a.stageWaves = static_cast<const WaveSpan*>( plan->d_stageWaves ); a.wavesStage = plan->wavesStage; a.tapTables = static_cast<const int32_t*>( plan->d_tapTables );
   a.items = static_cast<const vvhip_me_item*>( plan->d_items ); a.itemOrder = static_cast<const int32_t*>( plan->d_itemOrder ); a.itemWaves = static_cast<const WaveSpan*>( plan->d_itemWaves ); a.wavesItem = plan->wavesItem;
