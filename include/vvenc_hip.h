@@ -350,6 +350,10 @@ VVHIP_API int vvhip_subpel_refine_batch( vvhip_ctx* ctx, int func, const int16_t
  * Shapes (round 4: everything preset medium's CTU 128 + multi-type tree produces): width and height independent powers of two — integer jobs 8..128 x 4..128,
  * stage jobs 4..128 x 4..128 (not 4x4), items 2..128 x 2..128; the Hadamard family follows the reference's tile ladder (16x8, 8x16, 8x4, 4x8 with the
  * double-precision normalisation, 16x16_fast, 8x8, 4x4, 2x2: RdCost.cpp:1818-1938); bit depths <= 10 (the packed Hadamard tile, like the reference's x86 rows).
+ * Operand ranges of the Hadamard family (stage jobs and items): what the encoder hands to these table entries at the plan's bit depth — samples in [0, 2^bit_depth) or
+ * bi-prediction patterns 2 org - pred in (-2^bit_depth, 2^(bit_depth+1)) against prediction samples, i.e. |org - cur| < 2^(bit_depth+1): the first two butterfly stages run on
+ * packed 16-bit pairs.  SAD / SSE / masked-SAD items take any int16 operands.
+ * Integer jobs: positions a job lists more than once (the search re-scores its start point) are scored once; every listed candidate still gets its cost.
  * A plan owns device copies of the job tables and the schedule derived from them (which wave takes which jobs, heaviest first); running it is one launch per kind.
  * ====================================================================================================================== */
 typedef struct { const int16_t* d_base; int32_t stride; int32_t reserved; } vvhip_me_plane;

@@ -64,6 +64,10 @@ struct __attribute__( ( packed, aligned( 2 ) ) ) U8  { u32x2 v; };
 struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
 __device__ __forceinline__ u32x2 ld8( const int16_t* p )  { return reinterpret_cast<const U8*>( p )->v; }
 __device__ __forceinline__ u32x4 ld16( const int16_t* p ) { return reinterpret_cast<const U16*>( p )->v; }
+// 16 bytes at a 32-bit unsigned byte offset from a WAVE-UNIFORM base: global_load with scalar base + vector offset — one multiply-add per address instead of a 64-bit
+// multiply and three 64-bit adds per lane
+__device__ __forceinline__ u32x4 ld16o( const char* base, uint32_t byteOff ) { return reinterpret_cast<const U16*>( base + byteOff )->v; }
+__device__ __forceinline__ u32x2 ld8o( const char* base, uint32_t byteOff ) { return reinterpret_cast<const U8*>( base + byteOff )->v; }
 __device__ __forceinline__ int lo16( uint32_t v ) { return ( int ) ( int16_t ) ( v & 0xffffu ); }
 __device__ __forceinline__ int hi16( uint32_t v ) { return ( int ) ( ( int32_t ) v >> 16 ); }
 __device__ __forceinline__ uint32_t pkAdd( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, a ) + __builtin_bit_cast( s16x2, b ) ); }
@@ -146,7 +150,7 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
     // 64x64, 128x128 with row sub-sampling), then the window in batches of four chunks per lane — the job is one memory latency + the LDS work, not four latencies in a row
     PlanCand myCand = { 0, 0, 0u };
     if( tid < j.nCand ) myCand = a.cands[j.firstCand + tid];
-    const int16_t* org = P.p[j.orgPlane] + j.orgOff;
+    const char* orgB = reinterpret_cast<const char*>( P.p[j.orgPlane] + j.orgOff );      // (wave-uniform bases, 32-bit offsets: ld16o)
     const int os = P.stride[j.orgPlane] ? P.stride[j.orgPlane] : w, m = rowsEff * lpr;      // (stride 0: a pool of compact blocks)
     u32x4 ov[4]; int oat[4];
 #pragma unroll
@@ -154,22 +158,23 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
     {
       const int i = tid + nthr * q < m ? tid + nthr * q : 0, r = i >> lprShift, c = i & ( lpr - 1 );
       oat[q] = r * w + c * 8;
-      ov[q] = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 );
+      ov[q] = ld16o( orgB, ( uint32_t ) ( __mul24( r << ss, os ) + c * 8 ) * 2u );
     }
-    const int16_t* ref = P.p[j.refPlane] + j.refOff + ( ptrdiff_t ) j.minDy * P.stride[j.refPlane] + j.minDx;
+    const char* refB = reinterpret_cast<const char*>( P.p[j.refPlane] + j.refOff + ( ptrdiff_t ) j.minDy * P.stride[j.refPlane] + j.minDx );
     // window rows: with row sub-sampling the even and the odd rows are two separate halves (a candidate reads every second row: consecutive rows of one half)
     const int cpr = ( j.winW + 2 + 7 ) >> 3, n = j.winH * cpr, rs = P.stride[j.refPlane];      // 16-byte chunks per row
-    const uint32_t cprInv = ( uint32_t ) ( ( ( 1ull << 32 ) + ( uint32_t ) cpr - 1u ) / ( uint32_t ) cpr );      // wave-uniform, once per job (cpr >= 2)
+    // i / cpr as ( i * ceil( 2^20 / cpr ) ) >> 20: exact for i < 4096 (a window has at most 152 rows x 20 chunks), both factors below 2^24 — full-rate 24-bit multiplies
+    const uint32_t cprInv = ( ( 1u << 20 ) + ( uint32_t ) cpr - 1u ) / ( uint32_t ) cpr;                          // wave-uniform, once per job (cpr >= 2)
     for( int i0 = tid; i0 < n; i0 += 4 * nthr )                        // four loads in flight per lane (the loop is latency-bound otherwise)
     {
       u32x4 v[4]; int at[4], cc[4];
 #pragma unroll
       for( int q = 0; q < 4; q++ )
       {
-        const int i = i0 + nthr * q < n ? i0 + nthr * q : i0, r = ( int ) __umulhi( ( uint32_t ) i, cprInv ), c = i - r * cpr;      // i / cpr by the reciprocal (exact: i * cpr < 2^32)
+        const int i = i0 + nthr * q < n ? i0 + nthr * q : i0, r = ( int ) ( __umul24( ( uint32_t ) i, cprInv ) >> 20 ), c = i - __mul24( r, cpr );
         const int dr = ss ? ( ( r & 1 ) ? half0 : 0 ) + ( r >> 1 ) : r;
-        at[q] = dr * pitch + c * 8; cc[q] = c;
-        v[q] = ld16( ref + ( ptrdiff_t ) r * rs + c * 8 );
+        at[q] = __mul24( dr, pitch ) + c * 8; cc[q] = c;
+        v[q] = ld16o( refB, ( uint32_t ) ( __mul24( r, rs ) + c * 8 ) * 2u );
       }
 #pragma unroll
       for( int q = 0; q < 4; q++ )
@@ -186,7 +191,7 @@ __device__ __forceinline__ void intBody( const MePlanes& P, const MeArgs& a, int
     for( int i0 = tid + 4 * nthr; i0 < m; i0 += nthr )                 // (blocks beyond four chunks per lane: 128x128 without row sub-sampling, large blocks of a one-wave job)
     {
       const int r = i0 >> lprShift, c = i0 & ( lpr - 1 );
-      u32x4 x = ld16( org + ( ptrdiff_t ) ( r << ss ) * os + c * 8 ); x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS;
+      u32x4 x = ld16o( orgB, ( uint32_t ) ( __mul24( r << ss, os ) + c * 8 ) * 2u ); x.x ^= BIAS; x.y ^= BIAS; x.z ^= BIAS; x.w ^= BIAS;
       *reinterpret_cast<u32x4*>( orgL + r * w + c * 8 ) = x;
     }
     if( tid < j.nCand ) candL[tid] = myCand;
@@ -414,19 +419,31 @@ __device__ __forceinline__ uint32_t hadNorm( uint32_t s, int kind )
 // the team's transform: d = the lane's 8 differences, r = the lane's index inside its team of LT lanes (teams are aligned groups of consecutive lanes).
 // Returns the tile's normalised SATD in every lane of the team.  |d| < 2^23 / 128 on entry (differences of <= 12-bit values).
 // hadTeamCross: the stages across the lanes + sum, on values the lane has already transformed in its registers
+__device__ __forceinline__ uint32_t sadU32( uint32_t a, uint32_t b, uint32_t acc ) { uint32_t r; asm( "v_sad_u32 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( b ), "v"( acc ) ); return r; }
 __device__ __forceinline__ uint32_t hadTeamCross( int ( &d )[8], int r, int LT, int kind, int lane )
 {
-#define ME_VSTAGE( CTRL, BIT ) { const int sgn = ( r & ( BIT ) ) ? -1 : 1; _Pragma( "unroll" ) /* upper lane of a pair: other - own, lower: own + other; |d| < 2^23 */ \
+  // upper lane of a pair: other - own, lower: own + other; |d| < 2^23.  The LAST stage (lane pairs i ^ 1: every team has it) adds 2^31 with its multiply (v_mad_i32_i24):
+  // |coefficient| = |biased - 2^31| as unsigned numbers, so the sum of magnitudes is one v_sad_u32 per coefficient instead of subtract + max + add
+  constexpr uint32_t B31 = 0x80000000u;
+#define ME_VSTAGE( CTRL, BIT ) { const int sgn = ( r & ( BIT ) ) ? -1 : 1; _Pragma( "unroll" ) \
   for( int i = 0; i < 8; i++ ) { const int t = __mul24( d[i], sgn ); d[i] = VVHIP_DPP( d[i], CTRL ) + t; } }
   if( LT >= 16 ) ME_VSTAGE( VVHIP_DPP_MIRROR, 8 )
   if( LT >= 8 )  ME_VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
   if( LT >= 4 )  ME_VSTAGE( VVHIP_DPP_XOR2, 2 )
-  if( LT >= 2 )  ME_VSTAGE( VVHIP_DPP_XOR1, 1 )
 #undef ME_VSTAGE
+  {                                                                                   // (LT >= 2 for every tile type that comes here)
+    const int sgn = ( r & 1 ) ? -1 : 1;
+#pragma unroll
+    for( int i = 0; i < 8; i++ )
+    {
+      int t; asm( "v_mad_i32_i24 %0, %1, %2, %3" : "=v"( t ) : "v"( d[i] ), "v"( sgn ), "s"( B31 ) );      // (written out: the compiler turns a multiply by +-1 plus a constant into four instructions)
+      d[i] = ( int ) ( ( uint32_t ) VVHIP_DPP( d[i], VVHIP_DPP_XOR1 ) + ( uint32_t ) t );
+    }
+  }
   uint32_t s = 0;
 #pragma unroll
-  for( int i = 0; i < 8; i++ ) s += ( uint32_t ) abs( d[i] );
-  if( r == 0 ) { const uint32_t dc = ( uint32_t ) abs( d[0] ); s = s - dc + ( dc >> 2 ); }
+  for( int i = 0; i < 8; i++ ) s = sadU32( ( uint32_t ) d[i], B31, s );
+  if( r == 0 ) { const uint32_t dc = sadU32( ( uint32_t ) d[0], B31, 0u ); s = s - dc + ( dc >> 2 ); }
   s = vvhipGroupSum32( s, LT, lane );
   return hadNorm( s, kind );
 }
@@ -455,10 +472,6 @@ __device__ __forceinline__ uint32_t hadTeamPk( const uint32_t ( &o )[4], const u
   return hadTeamCross( d, r, LT, kind, lane );
 }
 
-// 16 bytes at a 32-bit unsigned byte offset from a WAVE-UNIFORM base: global_load with scalar base + vector offset — one multiply-add per address instead of a 64-bit
-// multiply and three 64-bit adds per lane
-__device__ __forceinline__ u32x4 ld16o( const char* base, uint32_t byteOff ) { return reinterpret_cast<const U16*>( base + byteOff )->v; }
-__device__ __forceinline__ u32x2 ld8o( const char* base, uint32_t byteOff ) { return reinterpret_cast<const U8*>( base + byteOff )->v; }
 // dot product on top of a wave-uniform constant (a scalar register as the third operand: no accumulator initialisation per output)
 __device__ __forceinline__ int dot2s( uint32_t a, uint32_t b, int c ) { int r; asm( "v_dot2_i32_i16 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( b ), "s"( c ) ); return r; }
 
@@ -947,7 +960,7 @@ meIntKernel( MePlanes P, MeArgs a, int nBig, int ldsSmall, int blockBase )
 // lists keep single-wave workgroups.  GEN: see itemBody (waves firstWave .. of the plan's item schedule)
 // spansPerWave: a wave takes this many consecutive spans of the schedule (long lists: the intra picture's 168 000 one-pass waves are bound by the rate workgroups start at)
 template<int WAVES, bool GEN>
-__global__ void __launch_bounds__( 64 * WAVES ) __attribute__( ( amdgpu_waves_per_eu( VVHIP_ME_ITEM_WAVES, VVHIP_ME_ITEM_WAVES ) ) )
+__global__ void __launch_bounds__( 64 * WAVES ) __attribute__( ( amdgpu_waves_per_eu( GEN ? VVHIP_ME_ITEM_WAVES - 1 : VVHIP_ME_ITEM_WAVES, GEN ? VVHIP_ME_ITEM_WAVES - 1 : VVHIP_ME_ITEM_WAVES ) ) )      // (the generic body needs 3 registers more than 8 waves leave: 7 there, no scratch)
 meItemKernel( MePlanes P, MeArgs a, int nItems, int firstWave, int nWaves, int spansPerWave )
 {
   const int wave = ( blockIdx.x * WAVES + ( int ) ( threadIdx.x >> 6 ) ) * spansPerWave;
