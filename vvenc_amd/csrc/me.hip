@@ -620,7 +620,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     const int log2PH = !GEN ? ( kind == TK_16F ? 4 : 3 ) : ( rows4 ? 3 : ( kind == TK_ROWS ? ( BH < 8 ? 31 - __builtin_clz( BH ) : 3 ) : 31 - __builtin_clz( tileH( kind ) ) ) );
     const int log2LT = !GEN ? 3 : ( rows4 ? 2 : ( kind == TK_ROWS ? log2PH : 31 - __builtin_clz( tileLanes( kind ) ) ) ), LT = 1 << log2LT;
     // (everything is a power of two: tile counts by shifts — no integer division per unit)
-    const int log2TX = ( 31 - __builtin_clz( uw ) ) - log2PW, log2TB = log2TX + ( 31 - __builtin_clz( BH ) ) - log2PH, tilesX = 1 << log2TX, tilesB = 1 << log2TB;
+    const int log2TX = ( 31 - __builtin_clz( uw ) ) - log2PW, log2TB = log2TX + ( 31 - __builtin_clz( BH ) ) - log2PH, tilesX = 1 << log2TX;
     // Units of 32 and 64 columns keep ONE horizontal variant in LDS at a time (a pass = first pass of the variant, then every position that uses it: with 32-row bands a
     // position of a 64-wide unit is exactly 64 lanes of second-pass work), narrower ones all (<= 3) of them: 6 KB of LDS per wave instead of 9.5 — the kernel is
     // occupancy-bound — and half as many units for the 64x64 blocks.
@@ -639,18 +639,47 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     if( nV == 1 ) firstPass<K0, K1, true>( refB, rs, nH, G, log2G, rowsT, ldsPitch, v0, hx0, hx1, hx2, tapP, tmp, tid, offS, headRoom, biasPk );
     else          firstPass<K0, K1, false>( refB, rs, nH, G, log2G, rowsT, ldsPitch, v0, hx0, hx1, hx2, tapP, tmp, tid, offS, headRoom, biasPk );
     ST_SYNC();     
-    // ---- VD: LT lanes per (position, tile); what a lane holds: see the tile table above
+    // ---- VD: LT lanes per (position, tile); what a lane holds: see the tile table above.  A lane keeps its part of a tile for EVERY position of the pass (the positions that
+    //      do not fit side by side into the wave follow in an inner loop): the original rows — for 16x16_fast tiles their 2x2 averages — are fetched and prepared once per pass
+    //      instead of once per position (<= 9 times: the original block was two thirds of this kernel's L1 accesses)
 #if defined( VVHIP_ME_CUT ) && ( VVHIP_ME_CUT & 2 )      // (cut build: no second pass / distortion)
-    const int nSlots = 0;
+    const int nPP = 0;
 #else
-    const int nSlots = ( pEnd - pBeg ) * tilesB * LT;
+    const int nPP = pEnd - pBeg;                                                   // positions of this pass
 #endif
-    for( int u0 = 0; u0 < nSlots; u0 += nthr )
+    const int log2L = log2TB + log2LT, log2Lw = log2L < 6 ? log2L : 6;            // lanes per position; of them inside one wave trip
+    const int trips = log2L > 6 ? 1 << ( log2L - 6 ) : 1, PL = 64 >> log2Lw, plLane = tid >> log2Lw;      // wave trips per position; positions side by side in a trip, the lane's
+    for( int c = 0; c < trips && nPP > 0; c++ )
     {
-      const int u = u0 + tid, r = u & ( LT - 1 ), tt = u >> log2LT;
-      const bool valid = u < nSlots;
-      const int pl = valid ? tt >> log2TB : 0, t = valid ? tt & ( tilesB - 1 ) : 0, pi = pBeg + pl;      // tilesX, tilesB are powers of two
+      const int sl = ( c << 6 ) + ( tid & ( ( 1 << log2Lw ) - 1 ) ), r = sl & ( LT - 1 ), t = sl >> log2LT;
       const int tyi = t >> log2TX, txi = t & ( tilesX - 1 );
+      // the lane's original rows (16x16_fast: their 2x2 averages, RdCost.cpp:1138-1160)
+      uint32_t o4[4] = { 0, 0, 0, 0 };
+      int aoA[4] = { 0, 0, 0, 0 }, aoB[4] = { 0, 0, 0, 0 };
+      if( kind == TK_16F )
+      {
+        const uint32_t po = ( uint32_t ) ( __mul24( y0 + tyi * 16 + 2 * r, os ) + txi * 16 ) * 2u, po1 = po + ( uint32_t ) os * 2u;
+        const u32x4 c0v = ld16o( orgB, po ), c1v = ld16o( orgB, po + 16 ), e0 = ld16o( orgB, po1 ), e1 = ld16o( orgB, po1 + 16 );
+        { const uint32_t oa[4] = { c0v.x, c0v.y, c0v.z, c0v.w }, ob[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( oa, ob, aoA ); }
+        { const uint32_t oa[4] = { c1v.x, c1v.y, c1v.z, c1v.w }, ob[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( oa, ob, aoB ); }
+      }
+      else if( rows4 )
+      {
+        const uint32_t po = ( uint32_t ) __mul24( y0 + tyi * 8 + 2 * r, os ) * 2u;
+        const u32x2 oa = ld8o( orgB, po ), ob = ld8o( orgB, po + ( uint32_t ) os * 2u );
+        o4[0] = oa.x; o4[1] = oa.y; o4[2] = ob.x; o4[3] = ob.y;
+      }
+      else
+      {
+        const int row = ( GEN && kind == TK_16x8 ) ? tyi * 8 + ( r & 7 ) : ( tyi << log2PH ) + r, col = ( GEN && kind == TK_16x8 ) ? txi * 16 + 8 * ( r >> 3 ) : txi * 8;
+        const u32x4 ovv = ld16o( orgB, ( uint32_t ) ( __mul24( y0 + row, os ) + col ) * 2u );
+        o4[0] = ovv.x; o4[1] = ovv.y; o4[2] = ovv.z; o4[3] = ovv.w;
+      }
+      for( int p0 = 0; p0 < nPP; p0 += PL )
+      {
+      const int pl = p0 + plLane;
+      const bool valid = pl < nPP;
+      const int pi = pBeg + ( valid ? pl : 0 );
       const int pk = posL[pi], txk = ( ( pk >> 8 ) & 0xfff ) - 64, tyk = ( ( pk >> 20 ) & 0xfff ) - 64;
       const int hv = ( txk == hx0 ? 0 : ( ( nHor > 1 && txk == hx1 ) ? 1 : 2 ) ) - v0, syk = tyk >> 4, fyk = tyk & 15;
       const int16_t* tvp = tmp + hv * rowsT * ldsPitch;
@@ -662,44 +691,36 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       {
         int d[8];
         const int16_t* tv = tvp + txi * 16;
-        const uint32_t po = ( uint32_t ) ( __mul24( y0 + tyi * 16 + 2 * r, os ) + txi * 16 ) * 2u, po1 = po + ( uint32_t ) os * 2u;
-        const u32x4 c0v = ld16o( orgB, po ), c1v = ld16o( orgB, po + 16 ), e0 = ld16o( orgB, po1 ), e1 = ld16o( orgB, po1 + 16 );
-        uint32_t pa[4], pb[4]; int ap[4], ao[4];
+        uint32_t pa[4], pb[4]; int ap[4];
         predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r, syk, anyFrac, vt, headRoom, maxPk, pa );
         predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
-        { const uint32_t oa[4] = { c0v.x, c0v.y, c0v.z, c0v.w }, ob[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( oa, ob, ao ); }      // RdCost.cpp:1138-1160
 #pragma unroll
-        for( int i = 0; i < 4; i++ ) d[i] = ao[i] - ap[i];
+        for( int i = 0; i < 4; i++ ) d[i] = aoA[i] - ap[i];
         predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r, syk, anyFrac, vt, headRoom, maxPk, pa );
         predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
-        { const uint32_t oa[4] = { c1v.x, c1v.y, c1v.z, c1v.w }, ob[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( oa, ob, ao ); }
 #pragma unroll
-        for( int i = 0; i < 4; i++ ) d[4 + i] = ao[i] - ap[i];
+        for( int i = 0; i < 4; i++ ) d[4 + i] = aoB[i] - ap[i];
         sres = hadTeam( d, r, GEN ? LT : 8, TK_16F, lane );
       }
       else
       {
-        // the lane's two operand rows as packed sample pairs: original o[], prediction p[]
-        uint32_t o4[4], p4[4];
+        // the lane's two operand rows as packed sample pairs: original o4[], prediction p4[]
+        uint32_t p4[4];
         if( rows4 )
         {
           // a 4-wide block (one tile column): two rows of four samples per lane; the first pass worked on 8 columns, the upper four are not part of the block
           const int row = tyi * 8 + 2 * r;
-          const uint32_t po = ( uint32_t ) __mul24( y0 + row, os ) * 2u;
-          const u32x2 oa = ld8o( orgB, po ), ob = ld8o( orgB, po + ( uint32_t ) os * 2u );
           uint32_t pa[4], pb[4];
           predRow<K0, K1>( tvp, ldsPitch, row, syk, anyFrac, vt, headRoom, maxPk, pa );
           predRow<K0, K1>( tvp, ldsPitch, row + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
-          o4[0] = oa.x; o4[1] = oa.y; o4[2] = ob.x; o4[3] = ob.y; p4[0] = pa[0]; p4[1] = pa[1]; p4[2] = pb[0]; p4[3] = pb[1];
+          p4[0] = pa[0]; p4[1] = pa[1]; p4[2] = pb[0]; p4[3] = pb[1];
         }
         else
         {
           const int row = ( GEN && kind == TK_16x8 ) ? tyi * 8 + ( r & 7 ) : ( tyi << log2PH ) + r, col = ( GEN && kind == TK_16x8 ) ? txi * 16 + 8 * ( r >> 3 ) : txi * 8;
-          const u32x4 ovv = ld16o( orgB, ( uint32_t ) ( __mul24( y0 + row, os ) + col ) * 2u );
           predRow<K0, K1>( tvp + col, ldsPitch, row, syk, anyFrac, vt, headRoom, maxPk, p4 );
-          o4[0] = ovv.x; o4[1] = ovv.y; o4[2] = ovv.z; o4[3] = ovv.w;
         }
         if( kind == TK_ROWS )
         {
@@ -711,7 +732,8 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
         else sres = hadTeamPk( o4, p4, r, GEN ? LT : 8, GEN ? kind : TK_8x8, lane );
       }
       if( valid && r == 0 ) atomicAdd( &costL[pk & 0xff], sres );
-    }
+      }      // positions
+    }        // trips
     }      // passes
     ST_SYNC();     
     if( unit & ST_UNIT_MORE ) continue;                                            // the wave's next unit belongs to the same stage and adds to the same sums
