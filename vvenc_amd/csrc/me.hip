@@ -62,8 +62,9 @@ typedef uint32_t u32x4 __attribute__( ( ext_vector_type( 4 ) ) );
 typedef short s16x2 __attribute__( ( ext_vector_type( 2 ) ) );
 struct __attribute__( ( packed, aligned( 2 ) ) ) U8  { u32x2 v; };
 struct __attribute__( ( packed, aligned( 2 ) ) ) U16 { u32x4 v; };
-__device__ __forceinline__ u32x2 ld8( const int16_t* p )  { return reinterpret_cast<const U8*>( p )->v; }
-__device__ __forceinline__ u32x4 ld16( const int16_t* p ) { return reinterpret_cast<const U16*>( p )->v; }
+#define ME_GLOBAL __attribute__( ( address_space( 1 ) ) )      /* a pointer that went through LDS (the item kernels' plane table) is a generic pointer to the compiler: flat loads; these say "global" */
+__device__ __forceinline__ u32x2 ld8( const int16_t* p )  { return ( ( const ME_GLOBAL U8* ) p )->v; }
+__device__ __forceinline__ u32x4 ld16( const int16_t* p ) { return ( ( const ME_GLOBAL U16* ) p )->v; }
 // 16 bytes at a 32-bit unsigned byte offset from a WAVE-UNIFORM base: global_load with scalar base + vector offset — one multiply-add per address instead of a 64-bit
 // multiply and three 64-bit adds per lane
 __device__ __forceinline__ u32x4 ld16o( const char* base, uint32_t byteOff ) { return reinterpret_cast<const U16*>( base + byteOff )->v; }
@@ -759,7 +760,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
 // =================================================================================================================================================
 // (C) plain table calls on blocks of any two planes
 // =================================================================================================================================================
-__device__ __forceinline__ uint32_t ld4( const int16_t* p ) { struct __attribute__( ( packed, aligned( 2 ) ) ) U4 { uint32_t v; }; return reinterpret_cast<const U4*>( p )->v; }
+__device__ __forceinline__ uint32_t ld4( const int16_t* p ) { struct __attribute__( ( packed, aligned( 2 ) ) ) U4 { uint32_t v; }; return ( ( const ME_GLOBAL U4* ) p )->v; }
 
 // masked SAD (xGetSADwMask, RdCost.cpp:2062-2093): lane teams on row chunks like the plain SAD; the mask block is compact, one row per evaluated row
 __device__ __forceinline__ void maskItemBody( const MeArgs& a, const WaveSpan span, int nItems, const int16_t* const* planeL, const int* strideL, int lane )
@@ -985,7 +986,9 @@ template<int WAVES, bool GEN>
 __global__ void __launch_bounds__( 64 * WAVES ) __attribute__( ( amdgpu_waves_per_eu( GEN ? VVHIP_ME_ITEM_WAVES - 1 : VVHIP_ME_ITEM_WAVES, GEN ? VVHIP_ME_ITEM_WAVES - 1 : VVHIP_ME_ITEM_WAVES ) ) )      // (the generic body needs 3 registers more than 8 waves leave: 7 there, no scratch)
 meItemKernel( MePlanes P, MeArgs a, int nItems, int firstWave, int nWaves, int spansPerWave )
 {
-  const int wave = ( blockIdx.x * WAVES + ( int ) ( threadIdx.x >> 6 ) ) * spansPerWave;
+  // (the wave's index as a scalar: everything derived from its span record — function, geometry, loop bounds — is then wave-uniform for the compiler too: scalar loads and branches
+  //  instead of per-lane copies under exec masks)
+  const int wave = ( ( int ) blockIdx.x * WAVES + __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) ) ) * spansPerWave;
   for( int q = 0; q < spansPerWave; q++ )
     if( wave + q < nWaves ) { itemBody<GEN>( P, a, firstWave + wave + q, nItems ); __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
 }
