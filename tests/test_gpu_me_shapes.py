@@ -84,6 +84,35 @@ def test_integer_windows_all_shapes_vs_oracle(env, bd, signed_org, seed):
     assert bad.size == 0, (bad[:8], [(cands[i], int(cc[i]), exp[i]) for i in bad[:4]])
 
 
+def test_integer_windows_repeated_positions(env):
+    """a search call lists its start point again and again (half of a recorded picture's integer candidates repeat a position of their call): the plan scores a position once and
+    stores the cost to every entry that listed it — also when a position is listed more often than its team has lanes (8x4: four), and when the repeats are far apart in the list"""
+    from vvenc_amd import replay as RP
+    hp, orc = env
+    bd = 10
+    rng = np.random.default_rng(77)
+    org_np, ref_np, ref_pad, org, ref, M = _setup(hp, rng, bd, False)
+    H, W = org_np.shape
+    jobs, cands, exp = [], [], []
+    for (w, h, ss) in [(8, 4, 0), (8, 8, 0), (16, 16, 1), (64, 64, 1), (32, 8, 0), (128, 64, 1)]:
+        x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        start = (int(rng.integers(-3, 4)), int(rng.integers(-3, 4)))
+        lst = [start] * 11 + [(start[0] + 1, start[1]), start, (start[0], start[1] - 1)] * 3 + [(int(a), int(b)) for a, b in rng.integers(-20, 21, (9, 2))] + [start] * 70
+        jobs.append((y * org.stride + x, y * ref.stride + x, w, h, 0, 1, ss, 0, 0, 0, 0, 0, len(cands), len(lst)))
+        memo = {}
+        for a, b in lst:
+            cands.append((a, b))
+            if (a, b) not in memo:
+                memo[(a, b)] = orc.dist("SAD", (org_np, y, x), (ref_pad, M + y + b, M + x + a), w, h, bd, ss)
+            exp.append(memo[(a, b)])
+    ij = np.array(jobs, RP.ME_INT_JOB)
+    pc = np.array(cands, RP.ME_CAND)
+    planes = [(org.storage.data_ptr() + 2 * org.origin, org.stride), (ref.storage.data_ptr() + 2 * ref.origin, ref.stride)]
+    cc, _, _ = _run_plan(hp, planes, ij, pc, np.zeros(0, RP.ME_STAGE_JOB), np.zeros(0, RP.ME_ITEM), None, bd)
+    bad = np.nonzero(cc[:len(exp)] != np.array(exp, np.int64))[0]
+    assert bad.size == 0, (bad[:8], [(cands[i], int(cc[i]), exp[i]) for i in bad[:4]])
+
+
 @pytest.mark.parametrize("filter_mode,func,bd,signed_org,seed", [(2, "HAD", 10, False, 11), (2, "HAD_fast", 10, True, 12), (2, "SAD", 10, False, 13), (1, "HAD", 10, False, 14),
                                                                  (1, "SAD", 10, True, 15), (0, "HAD", 10, False, 16), (0, "HAD_fast", 8, False, 17), (2, "HAD", 8, False, 18)])
 def test_refinement_stages_all_shapes_vs_oracle(env, filter_mode, func, bd, signed_org, seed):

@@ -1798,17 +1798,19 @@ struct TuMxJobs { int nJobs; int pair64; int waveStart[8]; int size[8]; TuMxArgs
 // overlap), KIND 1 also the 4-point body (four TUs per lane), KIND 2 also the 64-point body.  The 64x64 body wants ~230 registers: capped at 168 it spilled inside its main path
 // and ONE 64x64 TU took 13.5 us (the length of a whole picture's launch); with two waves per SIMD it takes 8.3 us and a recorded picture's launch 21.0 instead of 24.5 us
 // — although every other size of that launch also runs at two waves per SIMD (a 32x32-only list: 10.1 -> 12.5 us, which is why KIND 0 / 1 keep their bound).
+// KIND 3 = KIND 2 with a 64x64 TU over a wave pair (tuMx64PairBody, $VVHIP_TU_PAIR64=1: measured slower, not the default) — its own instance because the pair's exchange area
+// is 17 KB of LDS per workgroup that the default launch must not reserve (the TU workgroups share their CUs with the motion-search kernels of the other streams).
 template<int KIND>
-__global__ void __launch_bounds__( 256, KIND == 2 ? 2 : 3 )
+__global__ void __launch_bounds__( 256, KIND >= 2 ? 2 : 3 )
 tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs )
 {
-  constexpr bool WITH4 = KIND >= 1, WITH64 = KIND == 2;
+  constexpr bool WITH4 = KIND >= 1, WITH64 = KIND >= 2, PAIR64 = KIND == 3;
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t stage[4][32 * 40];
   __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t sInit[4][WITH64 ? 96 : 64];
   __shared__ v4i sOps[4][WITH64 ? 512 : 256];
-  __shared__ int32_t xch[WITH64 ? 2 : 1][WITH64 ? 2 * 64 * 17 : 1];      // 64x64 TUs: the exchange area of a wave pair (tuMx64PairBody)
+  __shared__ int32_t xch[PAIR64 ? 2 : 1][PAIR64 ? 2 * 64 * 17 : 1];      // 64x64 TUs over a wave pair: the pair's exchange area
   __shared__ uint32_t pairCtr[2];
-  if( WITH64 ) { if( threadIdx.x < 2 ) pairCtr[threadIdx.x] = 0; __syncthreads(); }      // (before any wave leaves)
+  if( PAIR64 ) { if( threadIdx.x < 2 ) pairCtr[threadIdx.x] = 0; __syncthreads(); }      // (before any wave leaves)
   const int wv = __builtin_amdgcn_readfirstlane( ( int ) ( threadIdx.x >> 6 ) );
   const int wave = blockIdx.x * 4 + wv;
   int k = 0;
@@ -1824,8 +1826,8 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   else if( WITH64 && jobs.size[k] == 64 )
   {
     // two waves per 64x64 TU: waves 2i, 2i + 1 of the job = the pair ( wv & ~1, wv | 1 ) of this workgroup (the host keeps the job's first wave and wave count even)
-    if( jobs.pair64 ) tuMx64PairBody( stage[wv], sInit[wv], sOps[wv], xch[wv >> 1], &pairCtr[wv >> 1], w & 1, w >> 1, jobs.j[k].waveStride >> 1, resi, rs, jobs.j[k] );
-    else              tuMx64Body( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
+    if( PAIR64 ) tuMx64PairBody( stage[wv], sInit[wv], sOps[wv], xch[wv >> 1], &pairCtr[wv >> 1], w & 1, w >> 1, jobs.j[k].waveStride >> 1, resi, rs, jobs.j[k] );
+    else         tuMx64Body( stage[wv], sInit[wv], sOps[wv], w, resi, rs, jobs.j[k] );
   }
 }
 
@@ -2277,7 +2279,8 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
       bool any64 = false;
       for( int i = 0; i < xj.nJobs; i++ ) any64 |= xj.size[i] == 64;
       const dim3 grid( ( unsigned ) ( ( waves + 3 ) / 4 ) );
-      if( any64 )     hipLaunchKernelGGL( tuMxMultiKernel<2>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
+      if( any64 && pair64 ) hipLaunchKernelGGL( tuMxMultiKernel<3>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
+      else if( any64 ) hipLaunchKernelGGL( tuMxMultiKernel<2>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
       else if( any4 ) hipLaunchKernelGGL( tuMxMultiKernel<1>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
       else            hipLaunchKernelGGL( tuMxMultiKernel<0>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
     }
