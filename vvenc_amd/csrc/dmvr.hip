@@ -10,8 +10,9 @@
 //   1  rows 0 .. dy+4 of both source windows straight from the planes: a lane = 8 adjacent samples of a row (one 16-byte load + one dword), horizontal taps as
 //      v_dot2_i32_i16 on sample pairs (v_alignbit makes the odd pairs), Pel truncation by packing;
 //   2  vertical taps on row pairs (v_perm interleaves the rows for v_dot2), results stored biased for v_sad_u16;
-//   3  25 mirrored positions x dy/2 rows: eight lanes per position (lane = row), a row is dx/2 dwords of each prediction + v_alignbit for odd columns, DPP sum;
-//   one lane replays the reference's scan order (strict <) and the error surface.
+//   3  25 mirrored positions x dy/2 rows: dy/2 lanes per position (lane = row), a row is dx/2 dwords of each prediction; the 15 positions with an even horizontal offset read
+//      whole dwords, the 10 odd ones go through v_alignbit — separate passes (wave-uniform code), rows fully unrolled (the sub-block size is a template parameter); DPP sum;
+//   the reference's scan (strict <, centre first) as ONE packed minimum over 25 lanes: key = cost << 6 | (centre ? 0 : raster index + 1); then the error surface.
 #include "common.h"
 
 namespace {
@@ -37,9 +38,12 @@ __device__ __forceinline__ int divMaxQ7( long long N, long long D )       // div
   return sign ? -q : q;
 }
 
+VVHIP_GROUP_REDUCE( dmvrGroupMin32, ( o < v ? o : v ) )
+
+template<int dx, int dy>
 __global__ void __launch_bounds__( 256 )
 dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* __restrict__ ref1, int stride1, const vvhip_dmvr_item* __restrict__ items, int n,
-                  int dx, int dy, int bitDepth, vvhip_dmvr_result* __restrict__ out )
+                  int bitDepth, vvhip_dmvr_result* __restrict__ out )
 {
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sT[4][2][22 * DP];      // first-pass rows
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sR[4][2][20 * DP];      // bilinear predictions, biased
@@ -53,7 +57,7 @@ dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* 
   const int blk = g * 4 + wv;
   if( blk >= n ) return;                                   // whole waves leave together; no workgroup barrier below
   const vvhip_dmvr_item it = items[blk];
-  const int bw = dx + 4, bh = dy + 4, segs = ( bw + 7 ) >> 3;
+  constexpr int bw = dx + 4, bh = dy + 4, segs = ( bw + 7 ) >> 3;
   const int sh1 = 4 - ( 10 - bitDepth ), of1 = 1 << ( sh1 - 1 );
   const int16_t* s0 = ref0 + it.ref0_off - 2 * stride0 - 2;       // mergeMV - (2, 2) samples (:1285-1288)
   const int16_t* s1 = ref1 + it.ref1_off - 2 * stride1 - 2;
@@ -127,52 +131,66 @@ dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* 
     }
   }
   DMVR_SYNC();
-  // ---- 3: mirrored SAD on every second row (subShift 1; (sum << 1) >> 1 == sum): position q = (ver + 2) * 5 + hor + 2; eight lanes per position, lane = row
+  // ---- 3: mirrored SAD on every second row (subShift 1; (sum << 1) >> 1 == sum): position q = (ver + 2) * 5 + hor + 2; `rows` lanes per position, lane = row.
+  //      Even horizontal offsets (hor = -2, 0, 2: 15 positions) start at a dword of both predictions (columns 2 + hor, 2 - hor); odd ones (10 positions) at an odd column of both
   {
-    const int rows = dy >> 1, dw = dx >> 1;
-    for( int pass = 0; pass < 4; pass++ )
+    constexpr int rows = dy >> 1, dw = dx >> 1, PPW = 64 / rows;                  // positions per wave pass
+    const int r = lane & ( rows - 1 ), slot = lane / rows;
+#pragma unroll
+    for( int pass = 0; pass < ( 15 + PPW - 1 ) / PPW; pass++ )                    // even offsets: idx = 0 .. 14 -> ver = idx / 3 - 2, hor = 2 ( idx % 3 ) - 2
     {
-      const int job = pass * 64 + lane, q = job >> 3, r = job & 7;
-      const bool valid = q < 25 && r < rows;
-      const int qv = valid ? q : 12, rv = valid ? r : 0;
-      const int ver = qv / 5 - 2, hor = qv - ( qv / 5 ) * 5 - 2;
-      const int c0 = 2 + hor, c1 = 2 - hor;
-      const uint32_t* p0 = reinterpret_cast<const uint32_t*>( &sR[wv][0][( 2 + 2 * rv + ver ) * DP + ( c0 & ~1 )] );
-      const uint32_t* p1 = reinterpret_cast<const uint32_t*>( &sR[wv][1][( 2 + 2 * rv - ver ) * DP + ( c1 & ~1 )] );
-      const uint32_t sh0 = ( c0 & 1 ) * 16, shB = ( c1 & 1 ) * 16;
+      const int idx = pass * PPW + slot;
+      const bool valid = idx < 15;
+      const int iv = valid ? idx : 7, v3 = ( iv * 11 ) >> 5, ver = v3 - 2, hor = 2 * ( iv - 3 * v3 ) - 2;      // ( i * 11 ) >> 5 == i / 3 for i < 16
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>( &sR[wv][0][( 2 + 2 * r + ver ) * DP + 2 + hor] );
+      const uint32_t* p1 = reinterpret_cast<const uint32_t*>( &sR[wv][1][( 2 + 2 * r - ver ) * DP + 2 - hor] );
       uint32_t sum = 0;
-      uint32_t x0 = p0[0], y0 = p1[0];
+#pragma unroll
+      for( int i = 0; i < dw; i++ ) sum = __builtin_amdgcn_sad_u16( p0[i], p1[i], sum );
+      sum = vvhipGroupSum32( valid ? sum : 0u, rows, lane );
+      if( valid && r == 0 ) sCost[wv][( ver + 2 ) * 5 + hor + 2] = sum;
+    }
+#pragma unroll
+    for( int pass = 0; pass < ( 10 + PPW - 1 ) / PPW; pass++ )                    // odd offsets: idx = 0 .. 9 -> ver = idx / 2 - 2, hor = 2 ( idx % 2 ) - 1
+    {
+      const int idx = pass * PPW + slot;
+      const bool valid = idx < 10;
+      const int iv = valid ? idx : 4, ver = ( iv >> 1 ) - 2, hor = 2 * ( iv & 1 ) - 1;
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>( &sR[wv][0][( 2 + 2 * r + ver ) * DP + 1 + hor] );      // column 2 + hor is odd: the dword below it
+      const uint32_t* p1 = reinterpret_cast<const uint32_t*>( &sR[wv][1][( 2 + 2 * r - ver ) * DP + 1 - hor] );
+      uint32_t sum = 0, x0 = p0[0], y0 = p1[0];
+#pragma unroll
       for( int i = 0; i < dw; i++ )
       {
         const uint32_t x1 = p0[i + 1], y1 = p1[i + 1];
-        sum = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( x1, x0, sh0 ), __builtin_amdgcn_alignbit( y1, y0, shB ), sum );
+        sum = __builtin_amdgcn_sad_u16( __builtin_amdgcn_alignbit( x1, x0, 16 ), __builtin_amdgcn_alignbit( y1, y0, 16 ), sum );
         x0 = x1; y0 = y1;
       }
-      sum = vvhipGroupSum32( valid ? sum : 0u, 8, lane );
-      if( valid && r == 0 ) sCost[wv][q] = sum;
+      sum = vvhipGroupSum32( valid ? sum : 0u, rows, lane );
+      if( valid && r == 0 ) sCost[wv][( ver + 2 ) * 5 + hor + 2] = sum;
     }
   }
   DMVR_SYNC();
-#undef DMVR_SYNC
 
-  if( lane == 0 )
   {
-    // (the 25 costs stay in LDS: the scan and the error surface index them dynamically — a private array would live in scratch memory)
+    // (the 25 costs stay in LDS: the error surface indexes them dynamically — a private array would live in scratch memory)
     uint32_t* sad = sCost[wv];
     // centre: distFunc(SAD, subShift 1) >> 1, minus a quarter (:1332-1333); the X5 costs are SAD >> 1 without that reduction
-    unsigned long long minCost = sad[12];
-    minCost -= minCost >> 2;
+    const uint32_t centre = sad[12] - ( sad[12] >> 2 );
+    unsigned long long minCost = centre;
     int tx = 0, ty = 0;
-    if( minCost >= ( unsigned long long ) ( dx * dy ) )
+    if( centre >= ( uint32_t ) ( dx * dy ) )                                        // (wave-uniform)
     {
-      sad[12] = ( uint32_t ) minCost;
-      int bh_ = 0, bv_ = 0;
-      for( int ver = -2; ver <= 2; ver++ )
-        for( int hor = -2; hor <= 2; hor++ )
-        {
-          const unsigned long long cost = sad[( ver + 2 ) * 5 + hor + 2];
-          if( cost < minCost ) { minCost = cost; bh_ = hor; bv_ = ver; }
-        }
+      // the reference walks ver = -2 .. 2, hor = -2 .. 2 and takes a position only when it is STRICTLY cheaper than the best so far, starting from the centre: the winner is
+      // the cheapest position, ties going to the centre, then to the first in raster order — the minimum of cost << 6 | ( centre ? 0 : q + 1 ) (costs < 2^18 at <= 10 bits)
+      const uint32_t cq = lane == 12 ? centre : sad[lane < 25 ? lane : 12];
+      const uint32_t key = lane < 25 ? ( cq << 6 | ( lane == 12 ? 0u : ( uint32_t ) lane + 1u ) ) : 0xffffffffu;
+      const uint32_t best = dmvrGroupMin32( key, 64, lane );                        // (lanes 25 .. 63: all ones)
+      const int qb = ( best & 63u ) ? ( int ) ( best & 63u ) - 1 : 12, bv_ = ( qb * 13 >> 6 ) - 2, bh_ = qb - 5 * ( qb * 13 >> 6 ) - 2;      // ( q * 13 ) >> 6 == q / 5 for q < 25
+      minCost = best >> 6;
+      DMVR_SYNC();
+      if( lane == 0 ) sad[12] = centre;
+      DMVR_SYNC();
       tx = bh_ * 16; ty = bv_ * 16;
       if( bh_ != 2 && bh_ != -2 && bv_ != 2 && bv_ != -2 )                       // xDMVRSubPixelErrorSurface (:1230-1231)
       {
@@ -193,9 +211,13 @@ dmvrRefineKernel( const int16_t* __restrict__ ref0, int stride0, const int16_t* 
         tx += t[0]; ty += t[1];
       }
     }
-    vvhip_dmvr_result r; r.mvd_x = ( int16_t ) tx; r.mvd_y = ( int16_t ) ty; r.pad = 0; r.min_cost = minCost;
-    out[blk] = r;
+    if( lane == 0 )
+    {
+      vvhip_dmvr_result r; r.mvd_x = ( int16_t ) tx; r.mvd_y = ( int16_t ) ty; r.pad = 0; r.min_cost = minCost;
+      out[blk] = r;
+    }
   }
+#undef DMVR_SYNC
 }
 
 } // namespace
@@ -209,7 +231,11 @@ int vvhip_dmvr_refine_batch( vvhip_ctx* ctx, const int16_t* d_ref0, int stride0,
   if( n < 0 || ( dx != 8 && dx != 16 ) || ( dy != 8 && dy != 16 ) || bit_depth < 8 || bit_depth > 10 || ( n && ( !d_ref0 || !d_ref1 || !d_items || !d_out ) ) )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_dmvr_refine_batch: sub-block %dx%d (8 or 16 per side, DMVR_SUBCU_SIZE 16) bitDepth %d (<= 10: the bilinear taps keep 10-bit precision)", dx, dy, bit_depth );
   if( n == 0 ) return VVHIP_OK;
-  hipLaunchKernelGGL( dmvrRefineKernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, d_ref0, stride0, d_ref1, stride1, d_items, n, dx, dy, bit_depth, d_out );
+  const dim3 grid( ( n + 3 ) / 4 ), block( 256 );
+  if( dx == 16 && dy == 16 )     hipLaunchKernelGGL( ( dmvrRefineKernel<16, 16> ), grid, block, 0, ctx->stream, d_ref0, stride0, d_ref1, stride1, d_items, n, bit_depth, d_out );
+  else if( dx == 16 )            hipLaunchKernelGGL( ( dmvrRefineKernel<16, 8> ), grid, block, 0, ctx->stream, d_ref0, stride0, d_ref1, stride1, d_items, n, bit_depth, d_out );
+  else if( dy == 16 )            hipLaunchKernelGGL( ( dmvrRefineKernel<8, 16> ), grid, block, 0, ctx->stream, d_ref0, stride0, d_ref1, stride1, d_items, n, bit_depth, d_out );
+  else                           hipLaunchKernelGGL( ( dmvrRefineKernel<8, 8> ), grid, block, 0, ctx->stream, d_ref0, stride0, d_ref1, stride1, d_items, n, bit_depth, d_out );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
 }
