@@ -2279,10 +2279,22 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
       bool any64 = false;
       for( int i = 0; i < xj.nJobs; i++ ) any64 |= xj.size[i] == 64;
       const dim3 grid( ( unsigned ) ( ( waves + 3 ) / 4 ) );
-      if( any64 && pair64 ) hipLaunchKernelGGL( tuMxMultiKernel<3>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
-      else if( any64 ) hipLaunchKernelGGL( tuMxMultiKernel<2>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
-      else if( any4 ) hipLaunchKernelGGL( tuMxMultiKernel<1>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
-      else            hipLaunchKernelGGL( tuMxMultiKernel<0>, grid, dim3( 256 ), 0, ctx->stream, d_resi, resi_stride, xj );
+      // $VVHIP_TU_LDS_PAD: extra LDS bytes reserved per workgroup (unused) = fewer TU workgroups per CU.  A TU wave holds 168 / 232 registers: three / two of them fill a SIMD's
+      // register file and nothing of the other streams' kernels can share that SIMD while they wait for memory (measurements of the five-stream step: DESIGN 6)
+      static const int ldsPad = getenv( "VVHIP_TU_LDS_PAD" ) ? atoi( getenv( "VVHIP_TU_LDS_PAD" ) ) : 0;
+      static bool padSet = false;
+      if( ldsPad > 0 && !padSet )
+      {
+        padSet = true;
+        ( void ) hipFuncSetAttribute( ( const void* ) tuMxMultiKernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsPad );
+        ( void ) hipFuncSetAttribute( ( const void* ) tuMxMultiKernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsPad );
+        ( void ) hipFuncSetAttribute( ( const void* ) tuMxMultiKernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsPad );
+        ( void ) hipFuncSetAttribute( ( const void* ) tuMxMultiKernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsPad );
+      }
+      if( any64 && pair64 ) hipLaunchKernelGGL( tuMxMultiKernel<3>, grid, dim3( 256 ), ldsPad, ctx->stream, d_resi, resi_stride, xj );
+      else if( any64 ) hipLaunchKernelGGL( tuMxMultiKernel<2>, grid, dim3( 256 ), ldsPad, ctx->stream, d_resi, resi_stride, xj );
+      else if( any4 ) hipLaunchKernelGGL( tuMxMultiKernel<1>, grid, dim3( 256 ), ldsPad, ctx->stream, d_resi, resi_stride, xj );
+      else            hipLaunchKernelGGL( tuMxMultiKernel<0>, grid, dim3( 256 ), ldsPad, ctx->stream, d_resi, resi_stride, xj );
     }
     else
     {
