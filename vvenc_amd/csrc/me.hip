@@ -796,6 +796,56 @@ __device__ __forceinline__ void maskItemBody( const MeArgs& a, const WaveSpan sp
   }
 }
 
+// one chunk (CW = 8, 4 or 2 samples) of both operands of a SAD / SSE item as CW / 2 packed pairs
+template<int CW>
+__device__ __forceinline__ void itemChunk( const int16_t* qa, const int16_t* qb, uint32_t ( &va )[CW / 2], uint32_t ( &vb )[CW / 2] )
+{
+  if( CW == 8 )      { const u32x4 x = ld16( qa ), z = ld16( qb ); va[0] = x.x; va[1] = x.y; va[2 % ( CW / 2 )] = x.z; va[3 % ( CW / 2 )] = x.w; vb[0] = z.x; vb[1] = z.y; vb[2 % ( CW / 2 )] = z.z; vb[3 % ( CW / 2 )] = z.w; }
+  else if( CW == 4 ) { const u32x2 x = ld8( qa ), z = ld8( qb ); va[0] = x.x; va[1 % ( CW / 2 )] = x.y; vb[0] = z.x; vb[1 % ( CW / 2 )] = z.y; }
+  else               { va[0] = ld4( qa ); vb[0] = ld4( qb ); }
+}
+// SAD / SSE of one item by a team of lanes: the lane's nIt chunks of CW samples start at pa / pb and lie stepA / stepB samples apart.  Returns the LANE's sum (SAD: 32 bits).
+// SSE: what the encoder hands to this entry are samples — when every sample of the wave's operands lies in [0, 4096) a difference fits 13 bits, a lane's <= 256 squares fit
+// 32 bits (256 x 4095^2 < 2^32) and a sample pair costs a packed subtraction and a v_dot2_i32_i16 (+ one v_or3_b32 that collects the operands' bits for the test); otherwise
+// (any int16 operands: the interface's contract) the wave repeats the item with 64-bit multiply-adds.
+template<int CW>
+__device__ __forceinline__ uint64_t itemSadSse( bool isSad, const int16_t* pa, const int16_t* pb, ptrdiff_t stepA, ptrdiff_t stepB, int nIt )
+{
+  if( isSad )                                                                      // (wave-uniform: the span's function)
+  {
+    uint32_t sad = 0;
+    for( int it = nIt; it > 0; it--, pa += stepA, pb += stepB )
+    {
+      uint32_t va[CW / 2], vb[CW / 2];
+      itemChunk<CW>( pa, pb, va, vb );
+#pragma unroll
+      for( int q = 0; q < CW / 2; q++ ) sad = __builtin_amdgcn_sad_u16( va[q] ^ BIAS, vb[q] ^ BIAS, sad );
+    }
+    return sad;
+  }
+  uint32_t acc = 0, bits = 0;
+  {
+    const int16_t* qa = pa; const int16_t* qb = pb;
+    for( int it = nIt; it > 0; it--, qa += stepA, qb += stepB )
+    {
+      uint32_t va[CW / 2], vb[CW / 2];
+      itemChunk<CW>( qa, qb, va, vb );
+#pragma unroll
+      for( int q = 0; q < CW / 2; q++ ) { bits |= va[q] | vb[q]; const uint32_t df = pkSub( va[q], vb[q] ); acc = ( uint32_t ) dot2( df, df, ( int ) acc ); }
+    }
+  }
+  if( __builtin_amdgcn_ballot_w64( ( bits & 0xf000f000u ) != 0 ) == 0ull ) return acc;
+  uint64_t sse = 0;
+  for( int it = nIt; it > 0; it--, pa += stepA, pb += stepB )
+  {
+    uint32_t va[CW / 2], vb[CW / 2];
+    itemChunk<CW>( pa, pb, va, vb );
+#pragma unroll
+    for( int q = 0; q < CW / 2; q++ ) { const int d0 = lo16( va[q] ) - lo16( vb[q] ), d1 = hi16( va[q] ) - hi16( vb[q] ); sse += ( uint64_t ) ( ( int64_t ) d0 * d0 ) + ( uint64_t ) ( ( int64_t ) d1 * d1 ); }
+  }
+  return sse;
+}
+
 // GEN = false: what the fast presets call (and every SAD / SSE at least four samples wide): lane teams on row chunks, 8x8 / 16x16_fast tiles with eight lanes per tile, the 4x4
 // block — the round-3 body, 57 registers.  GEN = true (its own launch): the rectangular tiles, 2x2 tiles, two-sample-wide blocks, masked SADs.
 template<bool GEN>
@@ -825,28 +875,17 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
       const vvhip_me_item it = a.items[span.first + ( valid ? ii : 0 )];
       const int16_t* po = planeL[it.org_plane] + it.org_off; const int os = strideL[it.org_plane] ? strideL[it.org_plane] : w;      // (stride 0: a pool of compact blocks)
       const int16_t* pc = planeL[it.cur_plane] + it.cur_off; const int cs = strideL[it.cur_plane] ? strideL[it.cur_plane] : w;
-      uint32_t sad = 0; uint64_t sse = 0;
       // a lane's chunks are lpc apart: the same column piece, rowStep rows further down (lpr, chunks, lpc are powers of two, lpc >= lpr): no division, constant address steps.
       // (four chunks per lane in flight were measured slower: 23.8 -> 24.6 us, the intra picture 123 -> 143 us)
       const int r0 = lt >> lprShift, s0 = lt & ( lpr - 1 ), rowStep = lpc >> lprShift;
       const int16_t* pa = po + ( ptrdiff_t ) ( r0 << ss ) * os + s0 * cw;
       const int16_t* pb = pc + ( ptrdiff_t ) ( r0 << ss ) * cs + s0 * cw;
       const ptrdiff_t stepA = ( ptrdiff_t ) ( rowStep << ss ) * os, stepB = ( ptrdiff_t ) ( rowStep << ss ) * cs;
-      for( int it = chunks >> lpcShift; it > 0; it--, pa += stepA, pb += stepB )
-      {
-        uint32_t va[4], vb[4];
-        if( cw == 8 ) { const u32x4 x = ld16( pa ), z = ld16( pb ); va[0] = x.x; va[1] = x.y; va[2] = x.z; va[3] = x.w; vb[0] = z.x; vb[1] = z.y; vb[2] = z.z; vb[3] = z.w; }
-        else if( !GEN || cw == 4 ) { const u32x2 x = ld8( pa ), z = ld8( pb ); va[0] = x.x; va[1] = x.y; va[2] = va[3] = 0; vb[0] = z.x; vb[1] = z.y; vb[2] = vb[3] = 0; }
-        else { va[0] = ld4( pa ); vb[0] = ld4( pb ); va[1] = va[2] = va[3] = 0; vb[1] = vb[2] = vb[3] = 0; }
-#pragma unroll
-        for( int q = 0; q < 4; q++ )
-        {
-          if( func == VVHIP_DF_SAD ) sad = __builtin_amdgcn_sad_u16( va[q] ^ BIAS, vb[q] ^ BIAS, sad );
-          else { const int d0 = lo16( va[q] ) - lo16( vb[q] ), d1 = hi16( va[q] ) - hi16( vb[q] ); sse += ( uint64_t ) ( ( int64_t ) d0 * d0 ) + ( uint64_t ) ( ( int64_t ) d1 * d1 ); }
-        }
-      }
-      if( func == VVHIP_DF_SAD ) { const uint32_t t = vvhipGroupSum32( sad, lpc, lane ); if( valid && lt == 0 ) a.itemCost[idx] = ( uint64_t ) t << ss; }
-      else { const uint64_t t = vvhipGroupSum64( sse, lpc, lane ); if( valid && lt == 0 ) a.itemCost[idx] = t; }
+      const int nIt = chunks >> lpcShift;
+      const bool isSad = func == VVHIP_DF_SAD;
+      const uint64_t mine = cw == 8 ? itemSadSse<8>( isSad, pa, pb, stepA, stepB, nIt ) : ( ( !GEN || cw == 4 ) ? itemSadSse<4>( isSad, pa, pb, stepA, stepB, nIt ) : itemSadSse<2>( isSad, pa, pb, stepA, stepB, nIt ) );
+      if( isSad ) { const uint32_t t = vvhipGroupSum32( ( uint32_t ) mine, lpc, lane ); if( valid && lt == 0 ) a.itemCost[idx] = ( uint64_t ) t << ss; }
+      else        { const uint64_t t = vvhipGroupSum64( mine, lpc, lane ); if( valid && lt == 0 ) a.itemCost[idx] = t; }
     }
     return;
   }
