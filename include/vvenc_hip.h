@@ -397,6 +397,11 @@ VVHIP_API int  vvhip_me_plan_info( const vvhip_me_plan* plan, int* waves_int, in
  * g_trCore* (CommonLib/RomTr.cpp:364-449) and getScanOrder (CommonLib/Rom.h:104).               */
 VVHIP_API int vvhip_get_tr_matrix_host( int tr_type, int log2_size, int16_t* host_out );
 VVHIP_API int vvhip_get_scan_order_host( int log2_w, int log2_h, uint32_t* host_out );
+/* the six tap tables of a motion-search plan's refinement-stage kernels at this bit depth (8..10), 6 x 192 dwords, table = filter_mode * 2 + alt_hpel:
+ * [0..127] 16 phases x 8 window taps (tap k multiplies the sample at offset k - 3) of the SECOND pass, scaled by 2^(16 - shift2), shift2 = 6 + headRoom, headRoom = 14 - bit_depth
+ * (InterpolationFilter.cpp:394-400: the filtered sample is the upper half of the 32-bit sum); [128..191] 16 phases x 4 packed int16 pairs (taps K0 + 2i, K0 + 2i + 1 of the table's
+ * tap support: 4-tap search set 2..5, 6 taps / alternative half-sample filter 1..6, 8 taps 0..7) of the FIRST pass, scaled by 2^(8 - shift1), shift1 = 6 - headRoom (:401-408).     */
+VVHIP_API int vvhip_get_me_tap_tables_host( int bit_depth, int32_t* host_out );
 
 /* ---------------------------------------------------------------------------------------------
  * (C) MCTF block matching — replaces MCTF::m_motionErrorLumaInt8 / m_motionErrorLumaFrac8[2] /

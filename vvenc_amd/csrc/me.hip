@@ -1062,6 +1062,15 @@ extern "C" {
 
 static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth, int max_window, vvhip_me_plan** out );
 
+// host memory out: the six interpolation tap tables a plan of this bit depth gives its stage kernels (stageTapTables) — for checks of the kernels' arithmetic without a device
+int vvhip_get_me_tap_tables_host( int bit_depth, int32_t* host_out )
+{
+  if( bit_depth < 8 || bit_depth > 10 || !host_out ) return VVHIP_E_ARG;
+  const std::vector<int32_t> t = stageTapTables( bit_depth );
+  memcpy( host_out, t.data(), t.size() * sizeof( int32_t ) );
+  return VVHIP_OK;
+}
+
 int vvhip_me_plan_create( vvhip_ctx* ctx, const vvhip_me_int_job* int_jobs, int n_int_jobs, const vvhip_me_cand* cands, int n_cands,
                           const vvhip_me_stage_job* stage_jobs, int n_stage_jobs, const vvhip_me_item* items, int n_items, int bit_depth, int max_window, vvhip_me_plan** out )
 {

@@ -95,6 +95,7 @@ PROTOTYPES = {
     "vvhip_subpel_refine_batch": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]),
     "vvhip_get_tr_matrix_host": (i32, [i32, i32, vp]),
     "vvhip_get_scan_order_host": (i32, [i32, i32, vp]),
+    "vvhip_get_me_tap_tables_host": (i32, [i32, vp]),
     "vvhip_mctf_error_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "vvhip_mctf_calc_var_batch": (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
     "vvhip_mctf_subsample": (i32, [vp, vp, i32, i32, i32, vp, i32, i32]),
