@@ -32,13 +32,6 @@ def support(mode, alt):
     return (1, 6) if (alt and mode == 2) else TAP_SUPPORT[mode]          # (the alternative half-sample filter has six taps: its table uses the 6-tap instance)
 
 
-@pytest.fixture(scope="module")
-def oracle():
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
-    return O.Oracle()
-
-
 @pytest.mark.parametrize("bd", [8, 9, 10])
 def test_tap_tables_scaling_and_sums(bd):
     head = max(14 - bd, 2)
