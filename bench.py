@@ -809,8 +809,8 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
                    "sample_pairs_note": "counted like the reference's own counter (CommonLib/SearchSpaceCounter.cpp:106-165 via RdCost.cpp:150-156: w x h per table call, DMVR excluded): "
                                         "%.1f x 1.5 W H GOP-weighted" % (sum(GOP_WEIGHT[l] * pairs_by_layer[l] for l in pairs_by_layer) / wsum / (1.5 * width * height)),
                    "coefficients_per_frame": int(sum(GOP_WEIGHT[l] * workloads[l].tu_coefficients for l in workloads) / wsum),
-                   "work_per_layer": {str(l): {"me_calls": int(workloads[l].pic.me.size), "integer_candidates": int(workloads[l].plan_cands.size), "subpel_stages": int(workloads[l].stage_jobs.size),
-                                               "subpel_positions": int(workloads[l].stage_evaluated.sum()), "table_calls": int(workloads[l].items.size), "tus": int(sum(g["n"] for g in workloads[l].tu_groups)),
+                   "work_per_layer": {str(l): {"me_calls": int(workloads[l].pic.me.size), "integer_candidates": int(workloads[l].plan_cands.size), "integer_positions_distinct": workloads[l].distinct_positions,
+                                               "subpel_stages": int(workloads[l].stage_jobs.size), "subpel_positions": int(workloads[l].stage_evaluated.sum()), "table_calls": int(workloads[l].items.size), "tus": int(sum(g["n"] for g in workloads[l].tu_groups)),
                                                "dmvr_subblocks": int(sum(g["n"] for g in workloads[l].dmvr_groups)), "plan": workloads[l].me_info} for l in workloads},
                    "recorded_calls_outside_the_lists": 0,
                    "subpel_candidates_per_block": round(float(np.mean([workloads[l].stage_evaluated.sum() / max(1, workloads[l].pic.me.size) for l in workloads if workloads[l].pic.me.size])), 2),

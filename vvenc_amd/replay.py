@@ -445,6 +445,19 @@ class RecordedWorkload:
                 timers.stop(cls)
 
     @property
+    def distinct_positions(self):
+        """integer candidates with a position no earlier candidate of the same window job has: what the plan scores (vvhip_me_plan_create keeps one candidate per distinct
+        position of a job; the search lists its start point again and again)"""
+        if not self.plan_cands.size:
+            return 0
+        n = self.int_jobs["n_cand"].astype(np.int64)
+        job = np.zeros(self.plan_cands.size, np.int64)
+        for j, (f, c) in enumerate(zip(self.int_jobs["first_cand"].astype(np.int64), n)):      # (a job's candidates are one run of the candidate list)
+            job[f:f + c] = j
+        key = (job << 32) | ((self.plan_cands["dx"].astype(np.int64) & 0xffff) << 16) | (self.plan_cands["dy"].astype(np.int64) & 0xffff)
+        return int(np.unique(key).size)
+
+    @property
     def class_launches(self):
         return {"ME": 1, "TU": max(1, len({(g["w"] in (4, 64)) for g in self.tu_groups})), "DMVR": max(1, len(self.dmvr_groups))}
 
