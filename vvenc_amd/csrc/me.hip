@@ -2,7 +2,7 @@
 //
 // Shaped by the work lists the reference encoder really produces (recorded from it: bindings/vvenc/vvenc_hip_recorder.*, vvenc_amd/recorded.py), not by uniform
 // synthetic ones: an InterSearch::xMotionEstimation call (EncoderLib/InterSearch.cpp:1976-2130) scores ~20 integer positions that lie within a few samples of each
-// other (start points, then the 4-point diamond and square at distance 1, :2385-2410; a third of them repeated), then one or two xPatternRefinement stages
+// other (start points, then the 4-point diamond and square at distance 1, :2385-2410; HALF of them repeat a position of the same call — scored once), then one or two xPatternRefinement stages
 // (:760-880) of <= 9 sub-pel positions; at preset faster two thirds of all sample pairs belong to 64x64 blocks, preset medium (CTU 128 + multi-type tree) brings every
 // rectangular shape 4..128 and GEO's masked SADs.  Kinds of work, one wave per unit:
 //   integer job   the bounding window of the job's candidates is staged ONCE in LDS (samples biased for v_sad_u16), the original block next to it; every candidate is then
@@ -15,7 +15,9 @@
 //                 Six launch classes: tap support x (the fast presets' square shapes with compile-time tile constants / any shape).
 //   item bundle   plain table calls (merge / AMVP / intra candidates, residual SSE) on blocks of any two planes or pools: lane teams on row chunks (SAD, SSE, masked SAD),
 //                 lane teams per Hadamard tile, one lane per 4x4 block / 2x2 tile.  Lean instance for what the fast presets call, generic instance for the rest.
-// These are short-lived waves: what they cost is their chain of dependent memory accesses, not their arithmetic.  Hence: job tables in schedule order (no order -> record
+// These are short-lived waves: what they cost is their chain of dependent memory accesses and — measured at 1.8 ns per wave instruction and SIMD for every form used here
+// (tools/exp/valu_rate.hip) — their instruction COUNT: scaled taps so that shifts become byte selections (v_perm_b32), v_mad_i32_i16 with op_sel, packed butterfly stages,
+// scalar bases with 32-bit offsets, wave-uniform branches.  Hence also: job tables in schedule order (no order -> record
 // indirection), every global request of a job issued before the first wait, candidate records / plane table / tap tables staged in LDS once per wave, per-unit derived data
 // precomputed by plan creation, a cap on the serial work of one workgroup (candidates per window, row groups per bundle, units per wave), and — round 4 — every launch's
 // workgroups in XCD-band order (xcdBandOrder): each XCD's private L2 streams one horizontal band of the picture.
@@ -305,7 +307,7 @@ __device__ __forceinline__ int dot2( uint32_t a, uint32_t b, int c ) { return __
 // commute: results do not depend on the schedule).  Per unit two cooperative phases:
 //   H   first pass of the <= 3 distinct horizontal positions, rows band + K0 - 4 .. band + BH + K1 - 4, straight from the plane into LDS: 8 outputs per lane from two
 //       overlapping 16-byte loads, tap PAIRS as v_dot2_i32_i16 on the even / odd sample pairs of the window (no unpacking);
-//   VD  eight lanes per (position, tile), lane r = tile row r: second pass of the lane's own prediction row(s) out of LDS (v_dot2 with (c, 0) / (0, c)), clip, difference to
+//   VD  eight lanes per (position, tile), lane r = tile row r: second pass of the lane's own prediction row(s) out of LDS (v_mad_i32_i16 on scaled taps: predRow), clip, difference to
 //       the original row(s), horizontal butterflies in registers, vertical ones across the eight lanes with DPP (the factorisation of dist.hip's hadKernel), |DC| >> 2,
 //       per-tile normalisation — the prediction never leaves registers.
 // the second pass's taps of one vertical phase: prepared once per (lane, slot) and shared by the slot's prediction rows
