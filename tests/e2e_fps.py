@@ -101,12 +101,12 @@ sys.path.insert(0, %r)
 import numpy as np
 import e2e_util as E, e2e_fps as F
 cfg = json.loads(sys.argv[1])
-L = E.load(cfg["mask"] != 0)
+L = E.load(cfg["mask"] != 0, cfg.get("lib"))
 if cfg["mask"]:
     import torch  # one HIP runtime in the process
     assert L.vvref_install_hip_hooks(cfg["mask"]) == 0
 yuv = F.synth_clip_chunk(cfg["w"], cfg["h"], cfg["first"], cfg["frames"]) if "first" in cfg else F.synth_clip(cfg["w"], cfg["h"], cfg["frames"])
-md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], 10, 10, threads=cfg["threads"], preset=E.PRESETS[cfg.get("preset", "faster")])
+md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], 10, 10, threads=cfg["threads"], preset=E.PRESETS[cfg.get("preset", "faster")], simd=cfg.get("simd"), options=cfg.get("options"))
 calls = None
 if cfg["mask"]:
     c = np.zeros(38, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 38); calls = [int(x) for x in c]
@@ -121,7 +121,27 @@ def run(cfg, timeout=3000, env=None):
     r = subprocess.run([sys.executable, "-c", WORKER, json.dumps(cfg)], capture_output=True, text=True, timeout=timeout, env=env)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-3000:])
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])          # (a profiling build prints its stage table when the library unloads: after this line)
+    if cfg.get("keep_stdout"):
+        out["stdout"] = r.stdout
+    return out
+
+
+def parse_time_profile(text):
+    """the stage table an ENABLE_TIME_PROFILING build prints when the encoder closes (CommonLib/TimeProfiler.h operator<<: one line per stage, name then milliseconds, ...)
+    -> {stage name: ms}"""
+    import re
+    stages = {}
+    for line in text.splitlines():
+        m = re.match(r"^\s*(P_[A-Z0-9_]+)\s+([0-9.eE+-]+)", line)
+        if m:
+            try:
+                stages[m.group(1)] = float(m.group(2))
+            except ValueError:
+                pass
+    for k in ("P_STAGES", "P_IGNORE"):
+        stages.pop(k, None)
+    return stages
 
 
 def main():

@@ -30,8 +30,8 @@ def synth_yuv(width, height, frames, bit_depth, seed):
     return f(ys), f(us), f(vs)
 
 
-def load(hip=False):
-    L = C.CDLL(REF_HIP_SO if hip else REF_SO)
+def load(hip=False, path=None):
+    L = C.CDLL(path or (REF_HIP_SO if hip else REF_SO))
     if hip:
         L.vvref_encode_ex = L.vvenc_hip_encode          # (same argument list: bindings/vvenc/enc_driver.cpp)
     L.vvref_encode_ex.restype = C.c_long

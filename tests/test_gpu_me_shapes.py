@@ -143,7 +143,7 @@ def test_refinement_stages_all_shapes_vs_oracle(env, filter_mode, func, bd, sign
     sj = np.array(stages, RP.ME_STAGE_JOB)
     planes = [(org.storage.data_ptr() + 2 * org.origin, org.stride), (ref.storage.data_ptr() + 2 * ref.origin, ref.stride)]
     _, sc, _ = _run_plan(hp, planes, np.zeros(0, RP.ME_INT_JOB), np.zeros(0, RP.ME_CAND), sj, np.zeros(0, RP.ME_ITEM), None, bd)
-    bad = []
+    bad, compared = [], {}
     for s, (x, y, bx, by, w, h, i_frac, bq, mask, alt) in enumerate(meta):
         refine = REFINE_H if i_frac == 2 else REFINE_Q
         for k in range(9):
@@ -156,9 +156,12 @@ def test_refinement_stages_all_shapes_vs_oracle(env, filter_mode, func, bd, sign
                 continue
             pred = orc.if_pred_luma_me((ref_pad, M + by + (ty >> 4), M + bx + (tx >> 4)), w, h, tx & 15, ty & 15, bd, bool(alt), filter_mode)
             e = orc.dist(func, (org_np, y, x), (pred, 0, 0), w, h, bd, 0)
+            compared[(w, h)] = compared.get((w, h), 0) + 1
             if int(sc[s, k]) != e:
                 bad.append((s, k, (w, h), i_frac, bq, alt, int(sc[s, k]), e))
     assert not bad, bad[:8]
+    # (positions outside the staged rows are skipped above — plan creation rejects them, the masks are built inside the reach: every shape must still have been compared)
+    assert all(compared.get(sh, 0) > 0 for sh in SHAPES_STAGE), {sh: compared.get(sh, 0) for sh in SHAPES_STAGE}
 
 
 def _stage_in_reach(i_frac, bq, mask):

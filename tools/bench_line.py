@@ -1,0 +1,156 @@
+"""bench.py's LAST stdout line: one compact JSON object (target <= 8 KB, hard cap 16 KB) that carries the measurement on its own; everything else of the run goes to
+bench_detail.json and to stdout BEFORE that line.  Host logic only (no torch, no device): tests/test_bench_line.py formats a full-size dummy run through it.
+
+The driver keeps the tail of stdout: round 4's single 34 KB line was cut and its record was lost (BENCH_r04.json parsed: null)."""
+import json
+import os
+
+TARGET_BYTES, HARD_CAP_BYTES = 8192, 16384
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _r(v, n=4):
+    if isinstance(v, float):
+        return float("%.*g" % (n + 2, v)) if abs(v) >= 1 else round(v, n + 1)
+    if isinstance(v, dict):
+        return {k: _r(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, n) for x in v]
+    return v
+
+
+ROOF_KEYS = ("bound", "kernel", "avg_launch_ms", "launches_per_picture", "alg_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "frac_physical", "unique_bytes_per_launch", "frac_unique",
+             "traffic_over_unique", "l2_hit_rate", "l1_access_frac", "valu_issue_frac", "binding_resource", "binding_frac")
+ROOF_4K_KEYS = ("kernel", "avg_launch_ms", "alg_bytes_per_launch", "achieved", "frac", "traffic", "frac_physical", "frac_unique", "l2_hit_rate", "binding_resource", "binding_frac")
+CLASS_KEYS = ("avg_launch_us", "alg_frac", "unique_frac", "fabric_frac", "traffic_over_unique", "l2_hit_rate", "l1_access_frac", "valu_issue_frac")
+E2E_KEYS = ("threads", "pairs", "cpu_fps", "hip_fps", "speedup", "cpu_fps_best", "hip_fps_best", "speedup_best", "bitstreams_identical", "md5_set")
+
+
+def _roof(r, keys, checks=None):
+    o = _pick(r, keys)
+    if "basis_short" in r or "basis" in r:
+        o["basis"] = r.get("basis_short") or r["basis"][:240]
+    if checks:
+        o["checks"] = _pick(checks, ("ok", "max_class_alg_frac", "sum_alg_over_step_time_GBps"))
+    return o
+
+
+def _e2e(e):
+    if not isinstance(e, dict):
+        return None
+    if "error" in e or "skipped" in e:
+        return _pick(e, ("error", "skipped"))
+    o = _pick(e, E2E_KEYS)
+    if e.get("other_threads"):
+        o["other_threads"] = [_pick(r, ("threads", "cpu_fps", "hip_fps", "speedup", "error")) for r in e["other_threads"]]
+    if isinstance(e.get("scalar"), dict):
+        o["scalar_md5_equal"] = e["scalar"].get("md5_equal")
+        o["scalar_md5_equal_default"] = e["scalar"].get("md5_equal_default")
+    ss = e.get("stage_split")
+    if isinstance(ss, dict) and "share" in ss:
+        o["stage_split"] = {"share": ss["share"], "device_stage_share": ss.get("device_stage_share"), "amdahl_bound_speedup": ss.get("amdahl_bound_speedup")}
+    return o
+
+
+def compact(out, detail_path):
+    """the driver-facing line from the full result object `out` (see bench.py's docstring for the objects)"""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    line.update(_pick(out, ("dtype", "data")))
+    cfg = out.get("config", {})
+    line["config"] = _pick(cfg, ("workload", "hip_streams", "sample_pairs_per_frame", "coefficients_per_frame", "recorded_calls_outside_the_lists"))
+    if "value_note" in out:
+        line["value_note"] = out["value_note"]
+    if "roofline" in out:
+        line["roofline"] = _roof(out["roofline"], ROOF_KEYS, out.get("roofline_checks"))
+    if out.get("roofline_all_kernels"):
+        line["classes"] = {k: _pick(v, CLASS_KEYS) for k, v in out["roofline_all_kernels"].items()}
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "passes", "value_fastest_passes", "value_slowest_passes", "value_1thread", "loadavg_before_after"))
+        line["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:420]
+    if "parity" in out:
+        p = out["parity"]
+        line["parity"] = _pick(p, ("status", "mismatches", "error"))
+        if isinstance(p.get("checked"), dict):
+            line["parity"]["checked"] = p["checked"]
+    for k in ("gop_weighted", "single_stream"):
+        if k in out:
+            line[k] = _pick(out[k], ("value", "ms_per_step"))
+    # ---- 3840x2160
+    line.update(_pick(out, ("value_4k", "ms_per_step_4k", "error_4k")))
+    if "roofline_4k" in out:
+        line["roofline_4k"] = _roof(out["roofline_4k"], ROOF_4K_KEYS, out.get("roofline_checks_4k"))
+        line["roofline_4k"].pop("basis", None)
+    if out.get("roofline_all_kernels_4k"):
+        line["classes_4k"] = {k: _pick(v, CLASS_KEYS) for k, v in out["roofline_all_kernels_4k"].items()}
+    if "parity_4k" in out:
+        line["parity_4k"] = _pick(out["parity_4k"], ("status", "mismatches", "error"))
+    if "cpu_baseline_4k" in out:
+        line["cpu_baseline_4k"] = _pick(out["cpu_baseline_4k"], ("value", "cores", "value_1thread"))
+    # ---- the other legs
+    m3 = out.get("config3_medium_4k")
+    if isinstance(m3, dict):
+        line["config3_medium_4k"] = _pick(m3, ("ms_per_picture", "pictures_per_s", "nothing_dropped", "error"))
+        if isinstance(m3.get("parity"), dict):
+            line["config3_medium_4k"]["parity"] = m3["parity"].get("status")
+    for k in ("mctf", "mctf_4k"):
+        if isinstance(out.get(k), dict):
+            line[k] = _pick(out[k], ("me_ms_per_picture", "me_ms_per_picture_4_in_flight", "filter_ms_per_picture", "error"))
+    for k in ("e2e", "e2e_4k"):
+        if k in out:
+            line[k] = _e2e(out[k])
+    # ---- N > 1
+    if "exchange" in out:
+        line["exchange"] = _pick(out["exchange"], ("pictures", "bytes_per_rank", "collective", "every_steps", "backend", "exchange_ms_per_picture"))
+    for k in ("no_exchange", "exchange_per_gop_cycle"):
+        if isinstance(out.get(k), dict):
+            line[k] = _pick(out[k], ("value", "ms_per_step", "every_steps"))
+    if isinstance(out.get("e2e_instances"), dict):
+        line["e2e_instances"] = _pick(out["e2e_instances"], ("instances", "threads_per_instance", "cpu_fps_aggregate", "hip_fps_aggregate", "speedup", "chunk_bitstreams_identical", "error", "skipped"))
+    line["detail"] = detail_path
+    line = _r(line)
+    s = json.dumps(line, separators=(",", ":"))
+    # shrink in a fixed order if a run ever grows the line past the target (the caps are asserted by tests/test_bench_line.py on a full-size dummy)
+    for drop in ("classes_4k", "classes", "single_stream", "gop_weighted", "mctf_4k", "mctf"):
+        if len(s) <= TARGET_BYTES:
+            break
+        line.pop(drop, None)
+        line["dropped_from_line"] = line.get("dropped_from_line", []) + [drop]
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > HARD_CAP_BYTES:
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "roofline", "cpu_baseline", "parity", "detail")
+        line = {k: line[k] for k in keep if k in line}
+        if isinstance(line.get("parity"), dict):
+            line["parity"] = _pick(line["parity"], ("status", "mismatches"))
+        line["config"] = {"workload": str(cfg.get("workload", ""))[:300]}
+        line["dropped_from_line"] = "everything but the contract's fields (line over %d bytes)" % HARD_CAP_BYTES
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > HARD_CAP_BYTES:          # (cannot happen with the fields above; a line is never lost to its own size check)
+        line = {k: line[k] for k in keep[:12] if k in line}
+        s = json.dumps(line, separators=(",", ":"))
+    return s
+
+
+def emit(out, root, name="bench_detail.json"):
+    """writes the full object to <root>/<name> (and to <root>/gpurun_out/ when that exists: it travels back from a gpurun box), prints it to stdout one top-level key per line,
+    then prints the compact line LAST and returns it"""
+    paths = [os.path.join(root, name)]
+    if os.path.isdir(os.path.join(root, "gpurun_out")):
+        paths.append(os.path.join(root, "gpurun_out", name))
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            pass
+    print("---- detail (also in %s) ----" % name)
+    for k, v in out.items():
+        print(json.dumps({k: v}))
+    print("---- result line ----", flush=True)
+    s = compact(out, name)
+    print(s, flush=True)
+    return s

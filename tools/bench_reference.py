@@ -1,0 +1,236 @@
+"""bench.py's CHECKER side (test infrastructure): the compiled reference (oracle/_ref) driven over the recorded lists — the in-run parity check and the cpu_baseline leg.
+Nothing here is on the timed path."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import torch
+
+from bench_common import GOP_WEIGHT
+
+class RecJob(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("df", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("subShift", C.c_int32), ("trHor", C.c_int32), ("trVer", C.c_int32), ("n", C.c_int32),
+                ("org", C.c_void_p), ("cur", C.c_void_p), ("orgStride", C.c_int32), ("curStride", C.c_int32), ("items", C.c_void_p), ("aux", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p)]
+
+
+REC_STAGE = np.dtype([("org_off", "<i4"), ("ref_off", "<i4"), ("base_qx", "i1"), ("base_qy", "i1"), ("i_frac", "u1"), ("filter_mode", "u1"), ("alt_hpel", "u1"), ("had_mode", "u1"), ("mask", "<u2")])
+
+
+class ReferenceJobs:
+    """a recorded picture's lists as job records of oracle/_ref's multi-threaded driver (vvref_run_recorded_mt): the reference's own x86-SIMD table entries on host copies of
+    the same planes, pool and lists the device replays.  Test infrastructure: used by the parity check and the cpu_baseline leg only."""
+
+    def __init__(self, wl, with_outputs):
+        from oracle import oracle as O
+        self.L = O.RefLib(1).L
+        self.L.vvref_run_recorded_mt.restype = C.c_double
+        self.L.vvref_run_recorded_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        wl = getattr(wl, "lists", wl)                       # the HOST lists (vvenc_amd.replay.RecordedLists) of a device workload
+        self.wl, self.keep, jobs = wl, [], []
+        host_planes = [pl.storage for pl in wl.planes]
+        pool = wl.pool
+
+        def base(idx, w):
+            """(address of sample (0,0), row pitch) of plane-table entry idx for blocks of width w (the pool holds compact blocks: pitch = width)"""
+            if idx < wl.n_pic_planes:
+                pl = wl.planes[idx]
+                return host_planes[idx].ctypes.data + 2 * pl.origin, pl.stride
+            return pool.ctypes.data, int(w)
+        df_of = {0: 0, 1: 8, 2: 16, 3: 26, 4: 24}          # C ABI function code -> DFunc base of the reference's table (TypeDef.h:339-382)
+        # integer candidates + plain table calls as distortion lists grouped by (function, size, subShift, operand planes)
+        ij, pc = wl.int_jobs, wl.plan_cands
+        recs = []
+        if pc.size:
+            jidx = np.repeat(np.arange(ij.size), ij["n_cand"])
+            ref_stride = np.array([base(int(p), 0)[1] for p in ij["ref_plane"]], np.int64)
+            cur_off = ij["ref_off"][jidx].astype(np.int64) + pc["dy"].astype(np.int64) * ref_stride[jidx] + pc["dx"]
+            recs.append(np.stack([np.full(pc.size, 1), ij["width"][jidx], ij["height"][jidx], ij["sub_shift"][jidx], ij["org_plane"][jidx], ij["ref_plane"][jidx], ij["org_off"][jidx], cur_off], 1).astype(np.int64))
+        it = wl.items
+        if it.size:
+            recs.append(np.stack([it["func"], it["width"], it["height"], it["sub_shift"], it["org_plane"], it["cur_plane"], it["org_off"], it["cur_off"]], 1).astype(np.int64))
+        self.dist_groups = []
+        if recs:
+            allr = np.concatenate(recs)
+            key = allr[:, :6]
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            inv = inv.ravel()
+            for g, (func, w, h, ss, po, pcu) in enumerate(uniq):
+                sel = np.nonzero(inv == g)[0]
+                items = np.ascontiguousarray(allr[sel][:, 6:8].astype(np.int32))
+                out = np.zeros(sel.size, np.uint64) if with_outputs else None
+                (ob, os_), (cb, cs) = base(int(po), w), base(int(pcu), w)
+                if int(func) == 4:
+                    # HAD_2SAD's SAD part assumes compact, 32-byte aligned operands (CHECKD + _mm256_load_si256, x86/RdCostX86.h:2556-2600; the encoder calls it on IntraSearch's
+                    # compact buffers): gather both operands of the list into aligned compact buffers for the reference entry
+                    w_, h_ = int(w), int(h)
+                    yy, xx = np.mgrid[0:h_, 0:w_]
+
+                    def gather(pidx, offs):
+                        if pidx < wl.n_pic_planes:
+                            pl = wl.planes[pidx]
+                            flat, o0, st = pl.storage.reshape(-1), pl.origin, pl.stride
+                        else:
+                            flat, o0, st = pool, 0, w_
+                        idx = (o0 + offs.astype(np.int64))[:, None, None] + yy[None] * st + xx[None]
+                        buf = np.zeros(sel.size * w_ * h_ + 32, np.int16)
+                        shift = (-buf.ctypes.data // 2) % 16                     # first sample at a 32-byte boundary
+                        buf[shift:shift + sel.size * w_ * h_] = flat[idx].reshape(-1)
+                        self.keep.append(buf)
+                        return buf.ctypes.data + 2 * shift
+                    ob, cb = gather(int(po), items[:, 0]), gather(int(pcu), items[:, 1])
+                    os_ = cs = w_
+                    items = np.ascontiguousarray(np.stack([np.arange(sel.size) * w_ * h_] * 2, 1).astype(np.int32))
+                self.keep += [items, out]
+                self.dist_groups.append((sel, out))
+                jobs.append(RecJob(0, df_of[int(func)], int(w), int(h), int(ss), 0, 0, sel.size, ob, cb, os_, cs, items.ctypes.data, None, out.ctypes.data if out is not None else None, None))
+        # masked SADs (GEO): grouped by (size, subShift, operand planes); the weight blocks are compact pool blocks
+        mi = getattr(wl, "mask_items", np.zeros(0))
+        self.mask_groups = []
+        if mi.size:
+            key = np.stack([mi["width"], mi["height"], mi["sub_shift"], mi["org_plane"], mi["cur_plane"]], 1).astype(np.int64)
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            inv = inv.ravel()
+            for g, (w, h, ss, po, pcu) in enumerate(uniq):
+                sel = np.nonzero(inv == g)[0]
+                items = np.ascontiguousarray(np.stack([mi["org_off"][sel], mi["cur_off"][sel], mi["mask_off"][sel]], 1).astype(np.int32))
+                out = np.zeros(sel.size, np.uint64) if with_outputs else None
+                (ob, os_), (cb, cs) = base(int(po), w), base(int(pcu), w)
+                self.keep += [items, out]
+                self.mask_groups.append((sel, out))
+                jobs.append(RecJob(3, 25, int(w), int(h), int(ss), 0, 0, sel.size, ob, cb, os_, cs, items.ctypes.data, pool.ctypes.data, out.ctypes.data if out is not None else None, None))
+        self.n_cands = int(pc.size)
+        # TU lists
+        self.tu_outs = []
+        for g in wl.tu_groups:
+            off = np.ascontiguousarray(g["off"])
+            qf = np.ascontiguousarray(g["qf"])
+            out = np.zeros(g["n"], np.uint64) if with_outputs else None
+            out2 = np.zeros((g["n"], 4), np.int32) if with_outputs else None
+            self.keep += [off, qf, out, out2]
+            self.tu_outs.append((out, out2))
+            jobs.append(RecJob(1, 0, g["w"], g["h"], 0, g["tr_hor"], g["tr_ver"], g["n"], pool.ctypes.data, None, g["w"], 0, off.ctypes.data, qf.ctypes.data,
+                               out.ctypes.data if out is not None else None, out2.ctypes.data if out2 is not None else None))
+        # refinement stages grouped by (size, planes)
+        sj = wl.stage_jobs
+        self.stage_groups = []
+        if sj.size:
+            key = np.stack([sj["width"], sj["height"], sj["org_plane"], sj["ref_plane"]], 1).astype(np.int64)
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            inv = inv.ravel()
+            for g, (w, h, po, pr) in enumerate(uniq):
+                sel = np.nonzero(inv == g)[0]
+                st = np.zeros(sel.size, REC_STAGE)
+                for f in ("org_off", "ref_off", "base_qx", "base_qy", "i_frac", "filter_mode", "alt_hpel", "mask"):
+                    st[f] = sj[f][sel]
+                st["had_mode"] = np.array([0, 0, 1, 2, 0], np.uint8)[sj["func"][sel]]          # SSE(unused) / SAD -> 0, HAD -> 1, HAD_fast -> 2
+                out = np.zeros((sel.size, 9), np.uint64) if with_outputs else None
+                (ob, os_), (cb, cs) = base(int(po), w), base(int(pr), w)
+                self.keep += [st, out]
+                self.stage_groups.append((sel, out))
+                jobs.append(RecJob(2, 0, int(w), int(h), 0, 0, 0, sel.size, ob, cb, os_, cs, st.ctypes.data, None, out.ctypes.data if out is not None else None, None))
+        self.arr = (RecJob * max(1, len(jobs)))(*jobs)
+        self.n = len(jobs)
+
+    def run(self, threads, passes):
+        return self.L.vvref_run_recorded_mt(self.arr, self.n, self.wl.bit_depth, threads, passes)
+
+
+def host_cpu_info():
+    info = {"os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup_" + os.path.basename(p)] = open(p).read().strip()
+        except OSError:
+            pass
+    return info
+
+
+def usable_cores(info):
+    n = info["affinity"]
+    q = info.get("cgroup_cpu.max", "")
+    try:
+        a, b = q.split()
+        if a != "max":
+            n = min(n, max(1, int(int(a) / int(b))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(workloads, passes=5):
+    """the reference's own x86-SIMD (AVX2) entries over the SAME recorded lists on the host cores: per layer one warm pass + `passes` timed passes on threads pinned to distinct
+    CPUs; median per layer, GOP-weighted pictures/s; the spread of the passes, the ONE-thread figure (one pinned thread, one pass per layer: what a core does, independent of how
+    many cores this box lends) and the load average are reported next to it"""
+    from oracle import oracle as O
+    info = host_cpu_info()
+    if not O.RefLib.available():
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "oracle/_ref (the compiled reference) is not built", "host": info}
+    cores = usable_cores(info)
+    os.environ["VVREF_PIN"] = "1"
+    load0 = os.getloadavg()
+    per_layer, spread, one, t_all = {}, {}, {}, time.perf_counter()
+    for layer, wl in workloads.items():
+        J = ReferenceJobs(wl, with_outputs=False)
+        ts = sorted(J.run(cores, 1) for _ in range(passes))
+        per_layer[layer] = ts[len(ts) // 2]
+        spread[layer] = (ts[0], ts[-1])
+        one[layer] = min(J.run(1, 1) for _ in range(2 if layer else 1))
+        del J
+    tot_w = sum(GOP_WEIGHT[l] for l in per_layer)
+    sec = lambda pick: sum(GOP_WEIGHT[l] * pick(l) for l in per_layer) / tot_w
+    v1 = 1.0 / sec(lambda l: one[l])
+    return {"value": 1.0 / sec(lambda l: per_layer[l]), "unit": "frames/s", "cores": cores, "kind": "reference", "host": info, "passes": passes, "threads_pinned": True,
+            "value_fastest_passes": 1.0 / sec(lambda l: spread[l][0]), "value_slowest_passes": 1.0 / sec(lambda l: spread[l][1]),
+            "value_1thread": v1, "scaling_over_1thread": (1.0 / sec(lambda l: per_layer[l])) / v1, "loadavg_before_after": [round(load0[0], 2), round(os.getloadavg()[0], 2)],
+            "seconds_per_picture_by_layer": {str(l): round(v, 4) for l, v in per_layer.items()},
+            "seconds_per_picture_1thread_by_layer": {str(l): round(v, 4) for l, v in one.items()},
+            "seconds_per_picture_min_max_by_layer": {str(l): [round(a, 4), round(b, 4)] for l, (a, b) in spread.items()},
+            "sample": "median of %d full passes (+ 1 warm-up) over every recorded list of one picture per temporal layer (integer SAD candidates, sub-pel stages, table calls, masked SADs, "
+                      "the TU pipeline's twin; DMVR lists not included) through the reference's AVX2 entries on %d pinned std::threads, GOP-weighted; value_1thread: the same on ONE pinned "
+                      "thread; %.1f s wall" % (passes, cores, time.perf_counter() - t_all),
+            "sample_detail": "sub-pel stages: one first pass per horizontal position like xPatternRefinement, then second pass + Hadamard per evaluated position; threads pull chunks from one atomic counter"}
+
+
+def parity_check(workloads):
+    """(a) device vs the values the real encoder computed while the lists were recorded; (b) device TU results vs the reference's x86-SIMD entries on the same lists"""
+    from oracle import oracle as O
+    from vvenc_amd.hotpath import STATS_DTYPE
+    res = {"status": None, "mismatches": 0, "checked": {}, "against": "the costs the reference encoder itself computed when the lists were recorded (integer SAD, sub-pel Hadamard, "
+           "table calls, DMVR vectors + costs)"}
+    tot = {}
+    for layer, wl in workloads.items():
+        wl.run()
+        for k, (n, bad) in wl.check_against_recording().items():
+            a = tot.setdefault(k, [0, 0])
+            a[0] += n
+            a[1] += bad
+    for k, (n, bad) in tot.items():
+        res["checked"][k] = n
+        res["mismatches"] += bad
+    if O.RefLib.available():
+        n_tu = bad_tu = 0
+        cores = usable_cores(host_cpu_info())
+        for layer, wl in workloads.items():
+            J = ReferenceJobs(wl, with_outputs=True)
+            J.arr = (RecJob * max(1, len(wl.tu_groups)))(*[j for j in J.arr[:J.n] if j.kind == 1])      # TU jobs only (the rest is checked against the recording)
+            J.n = len(wl.tu_groups)
+            J.run(cores, 1)
+            torch.cuda.synchronize()
+            for g, (sse, st4) in zip(wl.tu_groups, J.tu_outs):
+                st = g["stats"].cpu().numpy().view(STATS_DTYPE).reshape(-1)
+                lv = g["level"].view(g["n"], -1).to(torch.int64)
+                idx = torch.arange(1, lv.shape[1] + 1, device=lv.device, dtype=torch.int64)
+                cs = ((lv * idx).sum(1) & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
+                bad = (st["sse"] != sse) | (st["abs_sum"] != st4[:, 0]) | (st["need_rdoq"] != st4[:, 2]) | (cs != st4[:, 3].view(np.uint32))
+                has = st4[:, 0] != 0
+                bad |= has & (st["last_scan_pos"] != st4[:, 1])          # (the last position is defined when a level is non-zero)
+                bad_tu += int(bad.sum())
+                n_tu += g["n"]
+            del J
+        res["checked"]["tus_sse_abssum_last_needrdoq_levels"] = n_tu
+        res["mismatches"] += bad_tu
+        res["against"] += "; TU outputs against the reference's x86-SIMD entries (oracle/_ref) on the same residuals"
+    res["status"] = "bit-exact" if res["mismatches"] == 0 else "MISMATCH"
+    return res
+

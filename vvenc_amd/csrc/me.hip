@@ -1255,7 +1255,11 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
       }
     WaveSpan sp; sp.first = ( int32_t ) i; sp.count = count; stWaves.push_back( sp );
     setWaves[setOf( s0 )]++;
-    const int bh = unitH( s0 ), nt = tapSetOf( s0 ) == 0 ? 4 : ( tapSetOf( s0 ) == 1 ? 6 : 8 ), uw = std::max( 8, unitW( s0 ) ), vpp = unitW( s0 ) <= 16 ? 3 : 1;
+    // the wave's LDS slice must hold the TALLEST unit of the bundle: bundles group by unit width, launch class and deal, not by height — in the rectangular classes a short
+    // full-mask leader (8x4, nine positions) can be followed by a tall unit with few evaluated positions (8x32, one position) inside the same work budget
+    int bh = unitH( s0 );
+    for( int u = 1; u < count; u++ ) bh = std::max( bh, unitH( stage_jobs[stOrder[i + u] & 0xffffff] ) );
+    const int nt = tapSetOf( s0 ) == 0 ? 4 : ( tapSetOf( s0 ) == 1 ? 6 : 8 ), uw = std::max( 8, unitW( s0 ) ), vpp = unitW( s0 ) <= 16 ? 3 : 1;
     const int ldsUnit = ( 2 * ( 128 + 64 + 16 + 16 ) + vpp * ( bh + nt ) * ( uw + 8 ) ) * 2;      // tables + the first-pass bands a pass holds (row pitch unit width + 8)
     setLds[setOf( s0 )] = std::max( setLds[setOf( s0 )], ( ldsUnit + 15 ) & ~15 );
     ldsStage = std::max( ldsStage, ldsUnit );

@@ -269,9 +269,35 @@ class RecordedLists:
         cand_pairs = int((me["w"][c_me[sel]].astype(np.int64) * me["h"][c_me[sel]]).sum()) if sel.size else 0
         item_pairs = int((self.items["width"].astype(np.int64) * self.items["height"]).sum()) + int((mi["width"].astype(np.int64) * mi["height"]).sum())
         self.pairs = {"integer_candidates": cand_pairs, "subpel_positions": ev_pairs, "table_calls": item_pairs}
-        rows_eff = (me["h"][c_me[sel]].astype(np.int64) >> cand["subShift"][sel]) if sel.size else np.zeros(0, np.int64)
-        self.alg_bytes_me = int((4 * me["w"][c_me[sel]].astype(np.int64) * rows_eff + 8).sum()) if sel.size else 0
-        self.alg_bytes_by_kernel = {"ME_int": self.alg_bytes_me, "ME_stage": 0, "ME_item": 0}
+        # integer windows (both figures): per scored position 4 w h' + 8 bytes (h' = rows after subShift) over the DISTINCT positions of a job — vvhip_me_plan_create
+        # scores a position once however often the search lists it — and "with window reuse" the job's window read once: the rows and columns its candidates touch + the
+        # original block + 8 bytes per position.  The window figure is the class's algorithmic bytes (a job IS one block against its window); the per-position figure counts the
+        # same samples once per candidate and is a work rate, not memory traffic
+        self.alg_bytes_int_all_candidates = self.alg_bytes_int_per_position = self.alg_bytes_int_window = self.int_positions_distinct = 0
+        if sel.size:
+            ss_c = cand["subShift"][sel].astype(np.int64)
+            w_c, h_c = me["w"][c_me[sel]].astype(np.int64), me["h"][c_me[sel]].astype(np.int64)
+            per_cand = 4 * w_c * (h_c >> ss_c) + 8
+            cj = np.repeat(np.arange(jobs.size), jobs["n_cand"])
+            dx, dy = pc["dx"].astype(np.int64), pc["dy"].astype(np.int64)
+            _, first = np.unique((cj << 32) | ((dx & 0xffff) << 16) | (dy & 0xffff), return_index=True)
+            self.int_positions_distinct = int(first.size)
+            self.alg_bytes_int_all_candidates = int(per_cand.sum())
+            self.alg_bytes_int_per_position = int(per_cand[first].sum())
+            fc = jobs["first_cand"].astype(np.int64)
+            big = 1 << 20
+            jw, jh, jss = jobs["width"].astype(np.int64), jobs["height"].astype(np.int64), jobs["sub_shift"].astype(np.int64)
+            cols = np.maximum.reduceat(dx, fc) - np.minimum.reduceat(dx, fc) + jw
+            rows = np.zeros(jobs.size, np.int64)
+            for par in (0, 1):            # subShift 1: a candidate reads every second row from its own dy on -> the even and the odd candidates touch different row sets
+                m = (dy & 1) == par
+                hi, lo = np.maximum.reduceat(np.where(m, dy, -big), fc), np.minimum.reduceat(np.where(m, dy, big), fc)
+                rows += np.where(hi >= lo, np.where(jss > 0, (hi - lo) // 2 + (jh >> jss), 0), 0)
+            lo_all, hi_all = np.minimum.reduceat(dy, fc), np.maximum.reduceat(dy, fc)
+            rows = np.where(jss > 0, np.minimum(rows, hi_all - lo_all + jh), hi_all - lo_all + jh)
+            npos = np.bincount(cj[first], minlength=jobs.size)
+            self.alg_bytes_int_window = int((2 * cols * rows + 2 * jw * (jh >> jss) + 8 * npos).sum())
+        self.alg_bytes_by_kernel = {"ME_int": self.alg_bytes_int_window, "ME_stage": 0, "ME_item": 0}
         # a sub-pel position reads (w + 3)(h + 3) reference samples with the 4-tap search filter ((w + 7)(h + 7) with 8 taps) + w * h original samples, writes 8 bytes
         if self.stage_jobs.size:
             taps = np.where(self.stage_jobs["filter_mode"] == 2, 3, np.where(self.stage_jobs["filter_mode"] == 1, 5, 7)).astype(np.int64)
@@ -364,7 +390,7 @@ class RecordedWorkload:
         self.hp, self.lists, self.pic, self.bit_depth = hp, lists, lists.pic, lists.bit_depth
         dev = hp.device
         for k in ("n_pic_planes", "pool_index", "n_planes", "mask_items", "mask_expected", "dropped", "nothing_dropped", "int_jobs", "plan_cands", "cand_expected", "cand_index", "stage_jobs", "stage_index", "stage_expected", "stage_evaluated", "items",
-                  "item_expected", "items_dropped", "tu_coefficients", "pairs", "alg_bytes_me", "alg_bytes_by_kernel", "alg_bytes_tu", "alg_bytes_dmvr", "unique_bytes_by_kernel"):
+                  "item_expected", "items_dropped", "tu_coefficients", "pairs", "alg_bytes_me", "alg_bytes_int_all_candidates", "alg_bytes_int_per_position", "alg_bytes_int_window", "int_positions_distinct", "alg_bytes_by_kernel", "alg_bytes_tu", "alg_bytes_dmvr", "unique_bytes_by_kernel"):
             setattr(self, k, getattr(lists, k))
         self.planes = []
         for hpl in lists.planes:
@@ -448,14 +474,7 @@ class RecordedWorkload:
     def distinct_positions(self):
         """integer candidates with a position no earlier candidate of the same window job has: what the plan scores (vvhip_me_plan_create keeps one candidate per distinct
         position of a job; the search lists its start point again and again)"""
-        if not self.plan_cands.size:
-            return 0
-        n = self.int_jobs["n_cand"].astype(np.int64)
-        job = np.zeros(self.plan_cands.size, np.int64)
-        for j, (f, c) in enumerate(zip(self.int_jobs["first_cand"].astype(np.int64), n)):      # (a job's candidates are one run of the candidate list)
-            job[f:f + c] = j
-        key = (job << 32) | ((self.plan_cands["dx"].astype(np.int64) & 0xffff) << 16) | (self.plan_cands["dy"].astype(np.int64) & 0xffff)
-        return int(np.unique(key).size)
+        return self.int_positions_distinct
 
     @property
     def class_launches(self):
