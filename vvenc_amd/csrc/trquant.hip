@@ -1022,6 +1022,12 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
   const int blk0 = ( 16 * h ) / N;                                    // first TU block along the register direction
   const v16i zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+  // one 1-D pass: the product of the high bytes first, shifted up and joined with the accumulator preload (rounding + the 128 x row-sum correction), then the product of the
+  // low bytes ON TOP of it — one 16-register accumulator per pass instead of two (hi and lo side by side cost the 8/16/32-point bodies ~30 registers: 159 -> 130 for N = 32)
+#define MX_PASS( HA, HB, LA, LB, C, SH ) { v16i acc_ = __builtin_amdgcn_mfma_i32_32x32x32_i8( HA, HB, zero16, 0, 0, 0 );                      \
+    _Pragma( "unroll" ) for( int v = 0; v < 16; v++ ) acc_[v] = ( acc_[v] << 8 ) + C[v];                                                     \
+    acc_ = __builtin_amdgcn_mfma_i32_32x32x32_i8( LA, LB, acc_, 0, 0, 0 );                                                                   \
+    _Pragma( "unroll" ) for( int v = 0; v < 16; v++ ) d[v] = acc_[v] >> ( SH ); }
 #define TUMX_KEEP( ARR ) { int k_ = 0; _Pragma( "unroll" ) for( int v = 0; v < 16; v++ ) k_ ^= ARR[v]; if( k_ == 0x12345678 ) A.stats[0].pad = 1; }   /* phase profiling: keeps the values live */
 
   // residual of a tile: lane = row Y of the tile, samples X = 16h .. 16h+15 (the K-slots of this lane) in NP runs of PS samples.  The wave's first
@@ -1100,10 +1106,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 #pragma unroll
       for( int v = 0; v < 16; v++ ) c[v] = cP1;
       const v4i opP1 = sOps[lane];
-      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, opP1, c, 0, 0, 0 );
-      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, opP1, zero16, 0, 0, 0 );
-#pragma unroll
-      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shF1;
+      MX_PASS( aHi, opP1, aLo, opP1, c, A.shF1 );
       mxSplitSat( d, bLo, bHi );
     }
     // ---- forward columns: coef[k2][k] = ( sum_y Tv[k2][y] * tmp[y][k] + rnd ) >> shift2                      (TrQuant.cpp:549)
@@ -1112,10 +1115,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 #pragma unroll
       for( int g = 0; g < 4; g++ ) { const v4i t = *reinterpret_cast<const v4i*>( &sInit[h * 16 + 4 * g] ); c[4 * g] = t.x; c[4 * g + 1] = t.y; c[4 * g + 2] = t.z; c[4 * g + 3] = t.w; }
       const v4i opP2 = sOps[64 + lane];
-      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( opP2, bLo, c, 0, 0, 0 );
-      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( opP2, bHi, zero16, 0, 0, 0 );
-#pragma unroll
-      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shF2;
+      MX_PASS( opP2, bHi, opP2, bLo, c, A.shF2 );
     }
     if( A.phaseLimit == 3 ) { TUMX_KEEP( d ); continue; }
 
@@ -1260,10 +1260,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 #pragma unroll
       for( int v = 0; v < 16; v++ ) c[v] = cI1;
       const v4i opI1 = sOps[128 + lane];
-      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, opI1, c, 0, 0, 0 );
-      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, opI1, zero16, 0, 0, 0 );
-#pragma unroll
-      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shI1;
+      MX_PASS( aHi, opI1, aLo, opI1, c, A.shI1 );
       mxSplitSat( d, bLo, bHi );
     }
     // ---- inverse rows: rec[y][x] = clip( ( sum_k t1[y][k] * Th[k][x] + rnd ) >> shift2 ); SSE against the residual (re-read: L2 hit, issued
@@ -1293,10 +1290,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
 #pragma unroll
       for( int g = 0; g < 4; g++ ) { const v4i t = *reinterpret_cast<const v4i*>( &sInit[32 + h * 16 + 4 * g] ); c[4 * g] = t.x; c[4 * g + 1] = t.y; c[4 * g + 2] = t.z; c[4 * g + 3] = t.w; }
       const v4i opI2 = sOps[192 + lane];
-      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( opI2, bLo, c, 0, 0, 0 );
-      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( opI2, bHi, zero16, 0, 0, 0 );
-#pragma unroll
-      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shI2;
+      MX_PASS( opI2, bHi, opI2, bLo, c, A.shI2 );
     }
     if( A.phaseLimit == 7 ) { TUMX_KEEP( d ); continue; }
     unsigned long long sse[R];
@@ -1359,6 +1353,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
   }
 #undef WAVE_SYNC
 #undef TUMX_KEEP
+#undef MX_PASS
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1408,44 +1403,47 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
 #pragma unroll
     for( int t = 0; t < 2; t++ )
     {
-      v16i lo, hi = zero16;
-#pragma unroll
-      for( int v = 0; v < 16; v++ ) lo[v] = cP1;
+      // (one accumulator: the high-byte products of both chunks, shifted up and joined with the preload, then the low-byte products on top — as MX_PASS of tuMxBody)
+      v16i acc = zero16;
+      v4i aLo[2];
 #pragma unroll
       for( int c = 0; c < 2; c++ )
       {
         const int16_t* p = src + ( ptrdiff_t ) ( 32 * t + c32 ) * resiStride + 32 * c + 16 * h;
         const u32x4 x0 = reinterpret_cast<const U16*>( p )->v, x1 = reinterpret_cast<const U16*>( p + 8 )->v;
         const uint32_t xr[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
-        v4i aLo, aHi;
+        v4i aHi;
 #pragma unroll
         for( int g = 0; g < 4; g++ )
         {
-          aLo[g] = ( int ) ( __builtin_amdgcn_perm( xr[2 * g + 1], xr[2 * g], 0x06040200u ) ^ 0x80808080u );
+          aLo[c][g] = ( int ) ( __builtin_amdgcn_perm( xr[2 * g + 1], xr[2 * g], 0x06040200u ) ^ 0x80808080u );
           aHi[g] = ( int ) __builtin_amdgcn_perm( xr[2 * g + 1], xr[2 * g], 0x07050301u );
         }
-        const v4i op = sOps[c * 64 + lane];
-        lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, op, lo, 0, 0, 0 );
-        hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, op, hi, 0, 0, 0 );
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, sOps[c * 64 + lane], acc, 0, 0, 0 );
       }
 #pragma unroll
-      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shF1;
+      for( int v = 0; v < 16; v++ ) acc[v] = ( acc[v] << 8 ) + cP1;
+#pragma unroll
+      for( int c = 0; c < 2; c++ ) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo[c], sOps[c * 64 + lane], acc, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = acc[v] >> A.shF1;
       mxSplitSat( d, bLo[t], bHi[t] );
     }
     // ---- forward columns: coef[k2][k] = ( sum_{y<64} T[k2][y] * tmp[y][k] + rnd ) >> shift2, k2 < 32                              (TrQuant.cpp:549)
     {
-      v16i lo, hi = zero16;
+      v16i acc = zero16;
 #pragma unroll
-      for( int g = 0; g < 4; g++ ) { const v4i t4 = *reinterpret_cast<const v4i*>( &sInit[h * 16 + 4 * g] ); lo[4 * g] = t4.x; lo[4 * g + 1] = t4.y; lo[4 * g + 2] = t4.z; lo[4 * g + 3] = t4.w; }
+      for( int t = 0; t < 2; t++ ) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( sOps[( 2 + t ) * 64 + lane], bHi[t], acc, 0, 0, 0 );
 #pragma unroll
-      for( int t = 0; t < 2; t++ )
+      for( int g = 0; g < 4; g++ )
       {
-        const v4i op = sOps[( 2 + t ) * 64 + lane];
-        lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bLo[t], lo, 0, 0, 0 );
-        hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bHi[t], hi, 0, 0, 0 );
+        const v4i t4 = *reinterpret_cast<const v4i*>( &sInit[h * 16 + 4 * g] );
+        acc[4 * g] = ( acc[4 * g] << 8 ) + t4.x; acc[4 * g + 1] = ( acc[4 * g + 1] << 8 ) + t4.y; acc[4 * g + 2] = ( acc[4 * g + 2] << 8 ) + t4.z; acc[4 * g + 3] = ( acc[4 * g + 3] << 8 ) + t4.w;
       }
 #pragma unroll
-      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shF2;
+      for( int t = 0; t < 2; t++ ) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( sOps[( 2 + t ) * 64 + lane], bLo[t], acc, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = acc[v] >> A.shF2;
     }
     // ---- significance, QuantCore, DeQuantCore on the 32x32 coefficients: exactly the 32-point section of tuMxBody
     const TuMxQ P = tuMxParams( A.q, qq, A.thrVal );
@@ -1462,7 +1460,7 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
     { const uint32_t lb = tuMxGroupMaxPk16( last | ( big << 16 ), 64, lane ); last = lb & 0xffffu; big = lb >> 16; }
     mx = vvhipGroupMax32( mx, 64, lane );
     const uint32_t need = ( uint32_t ) ( ( int32_t ) ( ( ( int64_t ) mx * P.scale + P.addN ) >> P.qBits ) != 0 );
-    const bool narrow = !( mx >= 65536u || P.qBits > 30 || P.qBits < 9 );
+    const bool narrow = __builtin_amdgcn_ballot_w64( mx >= 65536u || P.qBits > 30 || P.qBits < 9 ) == 0ull;      // (wave-uniform: mx is the TU's maximum on every lane)
     if( !narrow )
     {
       big = 0;
@@ -1480,21 +1478,22 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
       const int addP = ( int ) P.addQ, addM = ( int ) ( ( 1u << ( P.qBits & 31 ) ) - 1u ) - addP;
       const int rsPos = P.rightShift > 0 ? P.rightShift : 0, rndDq = P.rightShift > 0 ? 1 << ( P.rightShift - 1 ) : 0;
       const int iscaleL = P.rightShift < 0 ? P.iscale << ( -P.rightShift ) : P.iscale;
-#pragma unroll
-      for( int v = 0; v < 16; v++ )
-      {
-        const int cv = d[v];
-        int sm;
-        if( narrow ) sm = ( __mul24( cv, P.scale ) + ( cv < 0 ? addM : addP ) ) >> P.qBits;
-        else { const int m = ( int ) ( ( ( int64_t ) abs( cv ) * P.scale + P.addQ ) >> P.qBits ); sm = cv < 0 ? -m : m; }
-        sm = pos[v] <= last ? sm : 0;
-        sum += ( uint32_t ) abs( sm );
-        const int lv = clip3i( -32768, 32767, sm );
-        stage[( 16 * h + v ) * LP + c32] = ( int16_t ) lv;
-        const int cl = med3i( lv, ~P.inMax, P.inMax );
-        const int32_t w_ = ( int32_t ) ( ( uint32_t ) __mul24( cl, iscaleL ) + ( uint32_t ) rndDq ) >> rsPos;
-        d[v] = clip3i( -32768, 32767, w_ );
+#define TU64_LEVEL( SMEXPR )                                                                                                         \
+      _Pragma( "unroll" ) for( int v = 0; v < 16; v++ )                                                                                 \
+      {                                                                                                                                 \
+        const int cv = d[v];                                                                                                            \
+        int sm = SMEXPR;                                                                                                                \
+        sm = pos[v] <= last ? sm : 0;                                                                                                   \
+        sum += ( uint32_t ) abs( sm );                                                                                                  \
+        const int lv = clip3i( -32768, 32767, sm );                                                                                     \
+        stage[( 16 * h + v ) * LP + c32] = ( int16_t ) lv;                                                                              \
+        const int cl = med3i( lv, ~P.inMax, P.inMax );                                                                                  \
+        const int32_t w_ = ( int32_t ) ( ( uint32_t ) __mul24( cl, iscaleL ) + ( uint32_t ) rndDq ) >> rsPos;                           \
+        d[v] = clip3i( -32768, 32767, w_ );                                                                                             \
       }
+      if( narrow ) { TU64_LEVEL( ( __mul24( cv, P.scale ) + ( cv < 0 ? addM : addP ) ) >> P.qBits ) }
+      else { TU64_LEVEL( ( cv < 0 ? -( int ) ( ( ( int64_t ) abs( cv ) * P.scale + P.addQ ) >> P.qBits ) : ( int ) ( ( ( int64_t ) abs( cv ) * P.scale + P.addQ ) >> P.qBits ) ) ) }
+#undef TU64_LEVEL
     }
     sum = vvhipGroupSum32( sum, 64, lane );
     if( A.stats && lane == 0 )
@@ -1524,10 +1523,12 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
 #pragma unroll
       for( int v = 0; v < 16; v++ ) c[v] = cI1[t];
       const v4i op = sOps[( 4 + t ) * 64 + lane];
-      const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, op, c, 0, 0, 0 );
-      const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, op, zero16, 0, 0, 0 );
+      v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, op, zero16, 0, 0, 0 );
 #pragma unroll
-      for( int v = 0; v < 16; v++ ) d[v] = ( ( hi[v] << 8 ) + lo[v] ) >> A.shI1;
+      for( int v = 0; v < 16; v++ ) acc[v] = ( acc[v] << 8 ) + c[v];
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( aLo, op, acc, 0, 0, 0 );
+#pragma unroll
+      for( int v = 0; v < 16; v++ ) d[v] = acc[v] >> A.shI1;
       mxSplitSat( d, bLo[t], bHi[t] );
     }
     // ---- inverse rows: rec[y][x] = clip( ( sum_{k<32} t1[y][k] * T[k][x] + rnd ) >> shift2 ), row tile t x column chunk c; SSE vs the residual (:613)
@@ -1544,17 +1545,39 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
 #pragma unroll
         for( int g = 0; g < 4; g++ ) { const v4i t4 = *reinterpret_cast<const v4i*>( &sInit[32 + 32 * c + h * 16 + 4 * g] ); ci[4 * g] = t4.x; ci[4 * g + 1] = t4.y; ci[4 * g + 2] = t4.z; ci[4 * g + 3] = t4.w; }
         const v4i op = sOps[( 6 + c ) * 64 + lane];
-        const v16i lo = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bLo[t], ci, 0, 0, 0 );
-        const v16i hi = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bHi[t], zero16, 0, 0, 0 );
-        uint32_t rp[8];
+        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bHi[t], zero16, 0, 0, 0 );
+#pragma unroll
+        for( int v = 0; v < 16; v++ ) acc[v] = ( acc[v] << 8 ) + ci[v];
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bLo[t], acc, 0, 0, 0 );
+        // SSE as in tuMxBody: residual and reconstruction within +-4095 on every lane (any residual of <= 12-bit video) -> packed subtraction + v_dot2_i32_i16 in 32 bits
+        // (16 squares < 2^30), else the 64-bit multiply-adds
+        typedef unsigned short u16x2t __attribute__( ( ext_vector_type( 2 ) ) );
+        uint32_t rp[8], magn = 0;
 #pragma unroll
         for( int k = 0; k < 8; k++ )
         {
-          const int v0 = ( ( hi[2 * k] << 8 ) + lo[2 * k] ) >> A.shI2, v1 = ( ( hi[2 * k + 1] << 8 ) + lo[2 * k + 1] ) >> A.shI2;
-          rp[k] = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( v0, v1 ) );
-          const int e0 = ( int ) ( int16_t ) ( xr[k] & 0xffff ) - ( int ) ( int16_t ) ( rp[k] & 0xffff ), e1 = ( ( int ) xr[k] >> 16 ) - ( ( int ) rp[k] >> 16 );
-          sse += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 );
+          rp[k] = __builtin_bit_cast( uint32_t, __builtin_amdgcn_cvt_pk_i16( acc[2 * k] >> A.shI2, acc[2 * k + 1] >> A.shI2 ) );
+          magn |= __builtin_bit_cast( uint32_t, __builtin_bit_cast( u16x2t, rp[k] ) + __builtin_bit_cast( u16x2t, 0x10001000u ) ) & 0xe000e000u;
+          magn |= __builtin_bit_cast( uint32_t, __builtin_bit_cast( u16x2t, xr[k] ) + __builtin_bit_cast( u16x2t, 0x10001000u ) ) & 0xe000e000u;
         }
+        if( __builtin_amdgcn_ballot_w64( magn != 0 ) == 0ull )
+        {
+          uint32_t s32 = 0;
+#pragma unroll
+          for( int k = 0; k < 8; k++ )
+          {
+            const uint32_t df = __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, xr[k] ) - __builtin_bit_cast( s16x2, rp[k] ) );
+            s32 = ( uint32_t ) dot2( df, df, ( int ) s32 );
+          }
+          sse += s32;
+        }
+        else
+#pragma unroll
+          for( int k = 0; k < 8; k++ )
+          {
+            const int e0 = ( int ) ( int16_t ) ( xr[k] & 0xffff ) - ( int ) ( int16_t ) ( rp[k] & 0xffff ), e1 = ( ( int ) xr[k] >> 16 ) - ( ( int ) rp[k] >> 16 );
+            sse += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 );
+          }
         if( A.rec )
         {
           int16_t* dst = A.rec + ( size_t ) tu * 4096 + ( 32 * t + c32 ) * 64 + 32 * c + 16 * h;
@@ -1794,14 +1817,16 @@ tuMx64PairBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96]
 
 struct TuMxJobs { int nJobs; int pair64; int waveStart[8]; int size[8]; TuMxArgs j[8]; };
 
-// Three instances, by what the launch's lists need (registers differ widely): KIND 0 the 8/16/32-point bodies (168 registers: three waves per SIMD, their memory latencies
-// overlap), KIND 1 also the 4-point body (four TUs per lane), KIND 2 also the 64-point body.  The 64x64 body wants ~230 registers: capped at 168 it spilled inside its main path
-// and ONE 64x64 TU took 13.5 us (the length of a whole picture's launch); with two waves per SIMD it takes 8.3 us and a recorded picture's launch 21.0 instead of 24.5 us
-// — although every other size of that launch also runs at two waves per SIMD (a 32x32-only list: 10.1 -> 12.5 us, which is why KIND 0 / 1 keep their bound).
+// Three instances, by what the launch's lists need: KIND 0 the 8/16/32-point bodies, KIND 1 also the 4-point body (four TUs per lane), KIND 2 also the 64-point body.
+// Registers (round 5, tools/kernel_regs.py): 148 / 164 / 166, no scratch — every instance runs three waves per SIMD.  Round 4 held 168 (1 spill) / 168 (33 spills) / 232 (two waves
+// per SIMD for EVERY size of a launch with 64x64 TUs): each 1-D pass kept the high-byte and the low-byte product in two 16-register accumulators side by side; the passes now run the
+// high-byte product first and the low-byte product on top of it (MX_PASS), and the 64-point body takes its SSE through the packed 32-bit form like the others.
+// Measured (recorded 1080p mix, same box): the TU launch alone 17.75 -> 16.9 us, the five-stream step 73.0 -> 69.1 us (the freed registers let the other streams' waves share the SIMDs).
+// Throughput of the 32-point lists is 467 tiles/us = 80 % of the VALU issue bound (1 059 wave instructions per tile): the instruction count, not occupancy, is what is left.
 // KIND 3 = KIND 2 with a 64x64 TU over a wave pair (tuMx64PairBody, $VVHIP_TU_PAIR64=1: measured slower, not the default) — its own instance because the pair's exchange area
 // is 17 KB of LDS per workgroup that the default launch must not reserve (the TU workgroups share their CUs with the motion-search kernels of the other streams).
 template<int KIND>
-__global__ void __launch_bounds__( 256, KIND >= 2 ? 2 : 3 )
+__global__ void __launch_bounds__( 256, KIND == 3 ? 2 : 3 )
 tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs )
 {
   constexpr bool WITH4 = KIND >= 1, WITH64 = KIND >= 2, PAIR64 = KIND == 3;

@@ -440,10 +440,12 @@ class RecordedWorkload:
         else:
             me = [lanes[0].bound("vvhip_me_plan_run", *args)]
             hp1, hp2 = lanes[1], lanes[2]
-        tu = hp1.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), self.bit_depth, self.tu_table[0], self.tu_table[1]) if self.tu_table else None
+        # (round 5: the 64x64 TU lists as a launch of their own on a sixth stream was measured and is SLOWER — step 68.4 -> 77.7 us — the second launch's fixed ~5.5 us and its
+        #  queue slot cost more than the long 64-point waves gain from leaving the other sizes' launch; profiles/r05_tu_kernel.md)
+        tus = [hp1.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), self.bit_depth, self.tu_table[0], self.tu_table[1])] if self.tu_table else []
         dm = [hp2.bound("vvhip_dmvr_refine_batch", self.planes[g["r0"]].buf_ptr, self.planes[g["r0"]].stride, self.planes[g["r1"]].buf_ptr, self.planes[g["r1"]].stride,
                         C.c_void_p(g["d_items"].data_ptr()), g["n"], g["dx"], g["dy"], self.bit_depth, C.c_void_p(g["out"].data_ptr())) for g in self.dmvr_groups]
-        self._lane_calls = [c for c in me + [tu] + dm if c is not None]
+        self._lane_calls = [c for c in me + tus + dm if c is not None]
         return self._lane_calls
 
     def run_lanes(self):
