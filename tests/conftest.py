@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "sim: host-logic tests of shim + binding against the CPU test double of the device library (tests/sim)")
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs oracle/_ref/libvvenc_ref.so (the compiled reference)")
+    config.addinivalue_line("markers", "long: full-length BASELINE configs[3] / [4] gates, minutes of encoder time each: opt-in with -m \"gpu and long\" or VVHIP_LONG_TESTS=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`long` tests are opt-in: the default GPU suite (-m gpu) stays at ~5 minutes"""
+    if "long" in (config.getoption("-m") or "") or os.environ.get("VVHIP_LONG_TESTS") == "1":
+        return
+    skip = pytest.mark.skip(reason="long gate: run with -m \"gpu and long\" or VVHIP_LONG_TESTS=1")
+    for it in items:
+        if "long" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

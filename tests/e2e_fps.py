@@ -59,11 +59,11 @@ def synth_clip_chunk(width, height, first, frames, seed=1080):
         oy, ox = (100 + 2 * t) % (height - 128), (200 + 7 * t) % (width - 128)
         f[oy:oy + 128, ox:ox + 128] = obj
         f = np.clip(f + fr.normal(0, 3, f.shape), 0, 1023)
-        ys.append(f)
+        ys.append(f.astype(np.int16))            # (converted per frame — the same values as converting the stack: an 8K x 65 clip would hold 26 GB of float64 frames otherwise)
         sub = f[::2, ::2]
-        us.append(np.clip(512 + 0.2 * (sub - 512), 0, 1023))
-        vs.append(np.clip(512 - 0.15 * (sub - 512), 0, 1023))
-    g = lambda a: np.ascontiguousarray(np.stack(a).astype(np.int16))
+        us.append(np.clip(512 + 0.2 * (sub - 512), 0, 1023).astype(np.int16))
+        vs.append(np.clip(512 - 0.15 * (sub - 512), 0, 1023).astype(np.int16))
+    g = lambda a: np.ascontiguousarray(np.stack(a))
     y, u, v = g(ys), g(us), g(vs)
     try:
         tmp = cache + ".%d.tmp.npz" % os.getpid()
@@ -87,11 +87,11 @@ def _synth_clip(width, height, frames, seed):
         oy, ox = (100 + 2 * t) % (height - 128), (200 + 7 * t) % (width - 128)
         f[oy:oy + 128, ox:ox + 128] = obj
         f = np.clip(f + rng.normal(0, 3, f.shape), 0, 1023)
-        ys.append(f)
+        ys.append(f.astype(np.int16))            # (converted per frame — the same values as converting the stack: an 8K x 65 clip would hold 26 GB of float64 frames otherwise)
         sub = f[::2, ::2]
-        us.append(np.clip(512 + 0.2 * (sub - 512), 0, 1023))
-        vs.append(np.clip(512 - 0.15 * (sub - 512), 0, 1023))
-    g = lambda a: np.ascontiguousarray(np.stack(a).astype(np.int16))
+        us.append(np.clip(512 + 0.2 * (sub - 512), 0, 1023).astype(np.int16))
+        vs.append(np.clip(512 - 0.15 * (sub - 512), 0, 1023).astype(np.int16))
+    g = lambda a: np.ascontiguousarray(np.stack(a))
     return g(ys), g(us), g(vs)
 
 

@@ -458,3 +458,39 @@ def test_config3_4k_medium_65_frames_two_logical_devices_bitstream_identical():
     c = hip["calls"]
     assert c[28] == 2 and c[9] >= 8 and c[16] >= 8, c
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+# ---- BASELINE configs[3] / [4] at FULL length: opt-in — `pytest -m "gpu and long"` (or VVHIP_LONG_TESTS=1); minutes of encoder time each, not part of the
+#      default GPU suite.  The builder's runs of both are in profiles/r05_long_gates.log
+@pytest.mark.gpu
+@pytest.mark.long
+def test_config3_4k_medium_129_frames_full_length_production_bitstream_identical():
+    """BASELINE configs[3] at full length: 3840x2160 10-bit, 129 frames (four GOPs of 32 + 1), preset medium (CTU 128, MTT depth 1 / 2, GEO: vvencCfg.cpp:2821-2893),
+    production mask through --SIMD=HIP, pictures sharded over two logical devices, 8 encoder threads: md5 == the CPU encoder's; MCTF and ALF device calls asserted.
+    (8 threads: above that the encoder switches its inter-frame line synchronisation on (m_ifpLines > 0) and the binding leaves the whole-picture ALF statistics to the CPU tasks
+    by design, bindings/vvenc/apply_binding.py; the 16-thread run of the same clip — md5 equal, 6.69 -> 7.08 fps — is in profiles/r05_long_gates.log)"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
+    clip = dict(w=3840, h=2160, frames=129, in_bd=10, int_bd=10, threads=8, preset="medium", clip="pan")
+    cpu = run(dict(clip, hip=False, mask=0), timeout=3000)
+    hip = run(dict(clip, hip=True, simd="HIP"), env={"VVHIP_LOGICAL_GPUS": "2", "VVHIP_GPUS": "2"}, timeout=3000)
+    print("cpu", cpu, "hip", hip, "fps cpu %.2f hip %.2f" % (129 / cpu["secs"], 129 / hip["secs"]))
+    c = hip["calls"]
+    assert c[28] == 2 and c[9] >= 16 and c[21] >= 16 and c[16] >= 16, c          # two devices; MCTF-filtered pictures, device motion-estimation calls, ALF statistics pictures
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.long
+def test_config4_8k_fast_65_frames_full_length_production_bitstream_identical():
+    """BASELINE configs[4] at full length: 7680x4320 10-bit, 65 frames, preset fast, production mask through --SIMD=HIP, 8 encoder threads: md5 == the CPU encoder's; the
+    temporal filter's block matching and the ALF statistics ran on the device at 8K (16 threads, md5 equal, 3.44 -> 3.54 fps: profiles/r05_long_gates.log)"""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
+    clip = dict(w=7680, h=4320, frames=65, in_bd=10, int_bd=10, threads=8, preset="fast", clip="pan")
+    cpu = run(dict(clip, hip=False, mask=0), timeout=3000)
+    hip = run(dict(clip, hip=True, simd="HIP"), timeout=3000)
+    print("cpu", cpu, "hip", hip, "fps cpu %.2f hip %.2f" % (65 / cpu["secs"], 65 / hip["secs"]))
+    c = hip["calls"]
+    assert c[9] >= 8 and c[21] >= 8 and c[16] >= 8, c
+    assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)

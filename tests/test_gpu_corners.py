@@ -217,3 +217,51 @@ def test_stage_bundle_with_a_taller_unit_behind_a_short_leader(env):
                 assert int(sc[s, k]) == orc.dist("HAD", (org_np, y, x), (pred, 0, 0), w, h, bd, 0), (filter_mode, s, k, (w, h))
                 n += 1
         assert n == 6 * 4 * (9 + 1)
+
+
+def test_fused_tu_all_zero_level_shortcut_vs_oracle(env):
+    """round 5: tiles (waves) whose every TU quantises to all-zero levels skip the quantiser loop, the level staging and both inverse passes (tuMxBody / tuMx64Body): what they
+    write must be what the long way writes — levels 0, reconstruction 0, abs sum 0, the oracle's last position / need-RDOQ flag / SSE — into output buffers pre-filled with
+    garbage.  Lists: all TUs tiny; whole tiles tiny next to tiles with levels; ONE TU with levels inside an otherwise all-zero tile; ragged last tiles; per-TU QPs; all sizes of the
+    matrix-core launch (4 .. 64), DCT-2 and DST-7 / DCT-8 pairs, bit depths 10 and 8"""
+    import torch
+    from vvenc_amd.hotpath import STATS_DTYPE, HotPath
+    hp, orc = env
+    rng = np.random.default_rng(4242)
+    n_zero_tus = n_level_tus = 0
+    for bd in (10, 8):
+        for S in (4, 8, 16, 32, 64):
+            tpt = 1 if S == 64 else (32 // S) ** 2                                   # TUs per 32x32 tile = per wave
+            for (th, tv) in ((0, 0),) + (((2, 2), (1, 2)) if S <= 32 else ()):
+                for pattern in ("all tiny", "tiles alternate", "one TU with levels per tile"):
+                    n = 3 * tpt + max(1, tpt // 3) if S < 64 else 7                  # whole tiles + a ragged one
+                    big = np.zeros(n, bool)
+                    if pattern == "tiles alternate":
+                        big = (np.arange(n) // tpt) % 2 == 1
+                    elif pattern == "one TU with levels per tile":
+                        starts = np.arange(0, n, tpt)
+                        big[np.minimum(starts + rng.integers(0, tpt, starts.size), n - 1)] = True
+                    amp = min(300, (1 << bd) - 1)                                            # (residuals inside the bit depth's range: the interface's contract)
+                    resi = np.where(big[:, None, None], rng.integers(-amp, amp + 1, (n, S, S)), rng.integers(-1, 2, (n, S, S))).astype(np.int16)
+                    resi[~big] *= (rng.integers(0, 3, (n, 1, 1))[~big] > 0)           # some exactly-zero residuals too
+                    qps = np.where(big, rng.integers(22, 40, n), rng.integers(30, 52, n))
+                    irap = rng.integers(0, 2, n)
+                    pool = hp.to_device(resi.reshape(-1))
+                    off = hp.to_device((np.arange(n, dtype=np.int32) * S * S).astype(np.int32))
+                    qp = hp.to_device(HotPath.tu_qp(qps, irap, 1))
+                    lev = torch.full((n * S * S,), 0x7777, dtype=torch.int16, device=hp.device)
+                    rec = torch.full((n * S * S,), 0x5555, dtype=torch.int16, device=hp.device)
+                    st = torch.full((n, STATS_DTYPE.itemsize), 0xEE, dtype=torch.uint8, device=hp.device)
+                    hp.tu_rdo_multi_strided(pool, [S], [(S, S, th, tv, n, 8, off, qp, lev, rec, st)], bd)
+                    torch.cuda.synchronize()
+                    lv, rc = lev.cpu().numpy().reshape(n, S, S), rec.cpu().numpy().reshape(n, S, S)
+                    sv = st.cpu().numpy().view(STATS_DTYPE).reshape(n)
+                    for i in range(n):
+                        el, er, es = orc.tu_rdo(resi[i], int(qps[i]), int(irap[i]), th, tv, bd, 8, 1)
+                        assert np.array_equal(lv[i], el), ("lev", bd, S, th, tv, pattern, i)
+                        assert np.array_equal(rc[i], er), ("rec", bd, S, th, tv, pattern, i)
+                        got = (int(sv["abs_sum"][i]), int(sv["last_scan_pos"][i]), int(sv["need_rdoq"][i]), int(sv["sse"][i]))
+                        assert got == (es["abs_sum"], es["last_scan_pos"], es["need_rdoq"], es["sse"]), (bd, S, th, tv, pattern, i, got, es)
+                        n_zero_tus += es["abs_sum"] == 0
+                        n_level_tus += es["abs_sum"] != 0
+    assert n_zero_tus > 1000 and n_level_tus > 300, (n_zero_tus, n_level_tus)

@@ -13,9 +13,10 @@ hp = HotPath()
 dev = hp.device
 spec = [(int(a), int(b)) for a, b in (x.split(":") for x in sys.argv[1].split(","))]
 reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 50
+amp = int(sys.argv[sys.argv.index("--amp") + 1]) if "--amp" in sys.argv else 300          # --amp 1: residuals that quantise to all-zero levels (the shortcut of round 5)
 rng = np.random.default_rng(7)
 total = sum(n * w * w for w, n in spec)
-pool = hp.to_device(rng.integers(-300, 300, total, dtype=np.int16))
+pool = hp.to_device(rng.integers(-amp, amp + 1, total, dtype=np.int16))
 jobs, strides, at, keep = [], [], 0, []
 for w, n in spec:
     off = hp.to_device((at + np.arange(n, dtype=np.int32) * w * w).astype(np.int32))
@@ -35,4 +36,4 @@ a.record()
 for _ in range(reps):
     hp.tu_rdo_multi_strided(pool, strides, tab)
 b.record(); torch.cuda.synchronize()
-print("TU mix %s: %.2f us per call" % (sys.argv[1], a.elapsed_time(b) / reps * 1e3))
+print("TU mix %s amp %d: %.2f us per call" % (sys.argv[1], amp, a.elapsed_time(b) / reps * 1e3))
