@@ -265,3 +265,39 @@ def test_fused_tu_all_zero_level_shortcut_vs_oracle(env):
                         n_zero_tus += es["abs_sum"] == 0
                         n_level_tus += es["abs_sum"] != 0
     assert n_zero_tus > 1000 and n_level_tus > 300, (n_zero_tus, n_level_tus)
+
+
+def test_masked_sad_large_operands_sum_in_64_bits(env):
+    """masked SADs take any int16 operands (include/vvenc_hip.h) and the reference sums in a 64-bit Distortion (RdCost.cpp:2062-2093): a 128x128 block of large
+    differences and weights passes 2^32 — the wave takes its 64-bit form; GEO-range operands next to it keep the 32-bit form.  Against the numpy restatement of the loop"""
+    import torch
+    from vvenc_amd import replay as RP
+    hp, _ = env
+    rng = np.random.default_rng(31)
+    H, W, M = 160, 192, 16
+    cases = [("extremes", 32767, -32768, 32767), ("large", 30000, -30000, 1000), ("geo", 1023, 0, 8)]          # (weights >= 0: what a mask is)
+    for name, hi, lo, wmax in cases:
+        org_np = rng.integers(lo, hi + 1, (H, W)).astype(np.int16)
+        cur_np = rng.integers(lo, hi + 1, (H, W)).astype(np.int16)
+        if name == "extremes":
+            org_np[:], cur_np[:] = hi, lo                                                  # every difference 65535
+        org, cur = hp.plane(org_np, 8), hp.plane(cur_np, M)
+        items, exp, at = [], [], 0
+        pool_np = np.zeros(1 << 17, np.int16)
+        for (w, h, ss) in ((128, 128, 0), (128, 128, 1), (64, 64, 0), (32, 16, 0), (8, 8, 0), (16, 4, 0), (4, 8, 0)):
+            rows = h >> ss
+            wg = (np.full((rows, w), wmax) if name == "extremes" else rng.integers(min(0, wmax), max(0, wmax) + 1, (rows, w))).astype(np.int16)
+            pool_np[at:at + rows * w] = wg.reshape(-1)
+            x, y, cx, cy = 8, 6, 11, 9
+            items.append((y * org.stride + x, cy * cur.stride + cx, at, 0, 1, 2, ss, w, h, 0))
+            a = org_np[y:y + h:1 << ss, x:x + w].astype(np.int64)
+            b = cur_np[cy:cy + h:1 << ss, cx:cx + w].astype(np.int64)
+            exp.append((int((np.abs(a - b) * wg.astype(np.int64)).sum()) << ss) & 0xFFFFFFFFFFFFFFFF)          # (Distortion is unsigned 64-bit)
+            at += (rows * w + 7) & ~7
+        pool = torch.from_numpy(pool_np).to(hp.device)
+        mi = np.array(items, RP.ME_MASK_ITEM)
+        planes = [(org.storage.data_ptr() + 2 * org.origin, org.stride), (cur.storage.data_ptr() + 2 * cur.origin, cur.stride), (pool.data_ptr(), 0)]
+        _, _, ic = _run_plan(hp, planes, np.zeros(0, RP.ME_INT_JOB), np.zeros(0, RP.ME_CAND), np.zeros(0, RP.ME_STAGE_JOB), np.zeros(0, RP.ME_ITEM), mi, 10)
+        got = ic[:len(exp)].view(np.uint64)
+        assert [int(g) for g in got] == exp, (name, [int(g) for g in got], exp)
+    assert exp is not None

@@ -1076,14 +1076,19 @@ def test_bench_multi_rank_path_on_one_device(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VVHIP_SHARE_DEVICE="1", VVHIP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29547",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--width", "640", "--height", "384", "--exchange-every", "1"]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--width", "640", "--height", "384", "--exchange-every", "1", "--detail", "bench_detail_two_ranks.json"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["exchange"]["pictures"] >= 8 and d["exchange"]["bytes_per_rank"] > 0, d
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert last.startswith('{"metric"') and len(last) <= 8192, (len(last), last[:200])          # the driver-facing line is the LAST line of stdout and compact
+    d = json.loads(last)
+    # one broadcast per step inside the timed region (--exchange-every 1); over gloo no fabric figure is printed; the two other N-GPU points are reported next to `value`
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["exchange"]["pictures"] == 6 and d["exchange"]["backend"] == "gloo" and "exchange_ms_per_picture" not in d["exchange"], d
+    assert d["no_exchange"]["value"] > 0 and d["exchange_per_gop_cycle"]["value"] > 0 and d["exchange_per_gop_cycle"]["every_steps"] == 32, d
     assert d["parity"]["status"] == "bit-exact", d["parity"]
     # the metric's N-GPU form: one encoder instance per rank on its own GPU (here: both on the one GPU), GOP chunks of one sequence, CPU kernels vs --SIMD=HIP
     inst = d["e2e_instances"]
     assert inst["instances"] == 2 and inst["chunk_bitstreams_identical"] is True and inst["cpu_fps_aggregate"] > 0 and inst["hip_fps_aggregate"] > 0, inst
-    assert len({p["md5"] for p in inst["per_instance"]}) == 2, inst          # two different chunks
+    full = json.load(open(os.path.join(root, d["detail"])))                                     # everything else of the run: next to the line
+    assert full["exchange"]["bytes_per_picture"] > 0 and full["value"] == pytest.approx(d["value"], rel=1e-4)
+    assert len({p["md5"] for p in full["e2e_instances"]["per_instance"]}) == 2, full["e2e_instances"]          # two different chunks

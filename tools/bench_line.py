@@ -51,7 +51,8 @@ def _e2e(e):
         o["scalar_md5_equal_default"] = e["scalar"].get("md5_equal_default")
     ss = e.get("stage_split")
     if isinstance(ss, dict) and "share" in ss:
-        o["stage_split"] = {"share": ss["share"], "device_stage_share": ss.get("device_stage_share"), "amdahl_bound_speedup": ss.get("amdahl_bound_speedup")}
+        o["stage_split"] = {"share": ss["share"], "device_stage_share": ss.get("device_stage_share"), "amdahl_bound_speedup": ss.get("amdahl_bound_speedup"),
+                            "amdahl_bound_speedup_with_all_of_alf": ss.get("amdahl_bound_speedup_with_all_of_alf")}
     return o
 
 

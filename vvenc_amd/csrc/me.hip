@@ -782,7 +782,10 @@ __device__ __forceinline__ void maskItemBody( const MeArgs& a, const WaveSpan sp
     const int os = strideL[it.org_plane] ? strideL[it.org_plane] : w, cs = strideL[it.cur_plane] ? strideL[it.cur_plane] : w;
     const int16_t* po = planeL[it.org_plane] + it.org_off; const int16_t* pc = planeL[it.cur_plane] + it.cur_off; const int16_t* pm = planeL[it.mask_plane] + it.mask_off;
     const int r0 = lt >> lprShift, s0 = lt & ( lpr - 1 ), rowStep = lpc >> lprShift;
-    uint32_t sum = 0;
+    // 32-bit sums while every sample of the wave's operands lies in [0, 4096) and every weight in [0, 16) (GEO: samples and weights 0..8): a product is < 2^16, a lane's <= 256
+    // products < 2^24, the item's sum < 2^30; any other int16 operands (the interface's contract; the reference sums in 64 bits, RdCost.cpp:2062-2093): the wave repeats the item
+    // with 64-bit sums (a 128x128 block of large differences overflowed the 32-bit form)
+    uint32_t sum = 0, bits = 0, mbits = 0;
     for( int r = r0; r < rowsEff; r += rowStep )
     {
       const int16_t* qa = po + ( ptrdiff_t ) ( r << ss ) * os + s0 * cw; const int16_t* qb = pc + ( ptrdiff_t ) ( r << ss ) * cs + s0 * cw; const int16_t* qm = pm + r * w + s0 * cw;
@@ -791,9 +794,24 @@ __device__ __forceinline__ void maskItemBody( const MeArgs& a, const WaveSpan sp
       else if( cw == 4 ) { const u32x2 x = ld8( qa ), z = ld8( qb ), m = ld8( qm ); va[0] = x.x; va[1] = x.y; vb[0] = z.x; vb[1] = z.y; vm[0] = m.x; vm[1] = m.y; }
       else               { va[0] = ld4( qa ); vb[0] = ld4( qb ); vm[0] = ld4( qm ); }
 #pragma unroll
-      for( int q = 0; q < 4; q++ ) sum += ( uint32_t ) ( abs( lo16( va[q] ) - lo16( vb[q] ) ) * lo16( vm[q] ) + abs( hi16( va[q] ) - hi16( vb[q] ) ) * hi16( vm[q] ) );
+      for( int q = 0; q < 4; q++ )
+      {
+        bits |= va[q] | vb[q]; mbits |= vm[q];
+        sum += ( uint32_t ) ( abs( lo16( va[q] ) - lo16( vb[q] ) ) * lo16( vm[q] ) + abs( hi16( va[q] ) - hi16( vb[q] ) ) * hi16( vm[q] ) );
+      }
     }
-    const uint32_t t = vvhipGroupSum32( sum, lpc, lane );
+    uint64_t t;
+    if( __builtin_amdgcn_ballot_w64( ( ( bits & 0xf000f000u ) | ( mbits & 0xfff0fff0u ) ) != 0 ) == 0ull ) t = vvhipGroupSum32( sum, lpc, lane );
+    else
+    {
+      uint64_t sum64 = 0;
+      for( int r = r0; r < rowsEff; r += rowStep )
+      {
+        const int16_t* qa = po + ( ptrdiff_t ) ( r << ss ) * os + s0 * cw; const int16_t* qb = pc + ( ptrdiff_t ) ( r << ss ) * cs + s0 * cw; const int16_t* qm = pm + r * w + s0 * cw;
+        for( int x = 0; x < cw; x++ ) sum64 += ( uint64_t ) ( ( int64_t ) abs( ( int ) qa[x] - ( int ) qb[x] ) * ( int64_t ) qm[x] );          // (Distortion is unsigned 64-bit; the product as the reference forms it)
+      }
+      t = vvhipGroupSum64( sum64, lpc, lane );
+    }
     if( valid && lt == 0 ) a.itemCost[idx] = ( uint64_t ) t << ss;                 // RdCost.cpp:2090
   }
 }

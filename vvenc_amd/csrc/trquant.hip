@@ -2291,6 +2291,13 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
       VVHIP_CHECK_HIP( ctx, hipMalloc( &ctx->d_tuGen, 64 * sizeof( TuGenJob ) ) );
       ctx->tuGenBytes = 64 * sizeof( TuGenJob ); ctx->tuGenLast.clear();
     }
+    // (the cache is keyed on the table's content AND the stream it was uploaded on: a caller that switched the context's stream may still have the previous launch reading the
+    //  table on the old stream — wait for that stream, then upload again on the new one)
+    if( ctx->tuGenStream != ctx->stream )
+    {
+      if( !ctx->tuGenLast.empty() ) VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->tuGenStream ) );
+      ctx->tuGenLast.clear(); ctx->tuGenStream = ctx->stream;
+    }
     if( ctx->tuGenLast.size() != bytes || memcmp( ctx->tuGenLast.data(), gen.data(), bytes ) != 0 )
     {
       // (stream-ordered behind the previous launch that still reads the old table; the host copy is staged before the call returns)
