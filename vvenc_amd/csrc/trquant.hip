@@ -2317,8 +2317,10 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
   auto tilesOf = [&]( int i ) { const vvhip_tu_job& jb = jobs[order[i]]; const int tpt = jb.width == 64 ? 1 : ( 32 / jb.width ) * ( 32 / jb.width ); return ( long ) ( jb.n + tpt - 1 ) / tpt; };
   long allTiles = 0;
   for( int i = 0; i < nm; i++ ) allTiles += tilesOf( i );
-  static const long oneLaunchTiles = getenv( "VVHIP_TU_ONE_LAUNCH_TILES" ) ? atol( getenv( "VVHIP_TU_ONE_LAUNCH_TILES" ) ) : 8192;
-  static const long repeat1Tiles = getenv( "VVHIP_TU_REPEAT1_TILES" ) ? atol( getenv( "VVHIP_TU_REPEAT1_TILES" ) ) : 4096;
+  // (round 5, recorded 4K lists, profiles/r05_tu_launch_sweep.log: all of a picture's lists in ONE launch with a budget of 8 192 waves instead of two launches of 4 096 / 3 072:
+  //  TU time per picture 66 -> 52 us, five-stream step 244 -> 227 us; 1080p unchanged.  The limits below only split what is far beyond a 4K picture)
+  static const long oneLaunchTiles = getenv( "VVHIP_TU_ONE_LAUNCH_TILES" ) ? atol( getenv( "VVHIP_TU_ONE_LAUNCH_TILES" ) ) : 65536;
+  static const long repeat1Tiles = getenv( "VVHIP_TU_REPEAT1_TILES" ) ? atol( getenv( "VVHIP_TU_REPEAT1_TILES" ) ) : 16384;
   const bool oneLaunch = mx && nm <= groupMax && allTiles <= oneLaunchTiles;
   // short lists first: a size that only a handful of waves run finds its code in no instruction cache (the five bodies are 74 KB) and those waves take several times a warm
   // wave's duration — started first, they finish under the long lists instead of after them
@@ -2347,7 +2349,7 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
     for( int i = first; i < groupEnd; i++ ) has64 |= jobs[order[i]].width == 64;
     // (the 64-point instance holds 2 048 waves; on the recorded mix 64:955 32:2 133 16:600 8:800 4:600 = 3 298 tiles a budget for 2 048 / 3 072 / 4 096 waves gives 22.4 / 20.7 / 17.6 us:
     //  with its long 64x64 waves in front, one tile per wave and a second partial round beat fewer, longer waves)
-    const long residentWaves = residentEnv ? residentEnv : ( has64 ? 4096 : 3072 );
+    const long residentWaves = residentEnv ? residentEnv : 8192;      // (round 4: 4 096 with 64-point lists at two waves per SIMD, 3 072 without; every instance holds three now)
     int budget = 0;
     // $VVHIP_TU_PAIR64=1: a 64x64 TU as a PAIR of waves (tuMx64PairBody), each worth two 32x32-tile units.  Measured (round 4, tools/tu_mix.py) and NOT the default: one TU
     // per launch slot 8.8 -> 7.85 us, but 955 TUs 9.9 -> 10.7 us and the recorded mix 64:955 32:2133 16:600 8:800 4:600 18.5 -> 21.8 us — a wave's life is its set-up and its
