@@ -2345,9 +2345,7 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
     // tiles per wave (matrix-core form): the launch should be ONE resident round of waves (3 per SIMD) with balanced work — a second round that is a tenth full costs a whole
     // wave duration.  Work budget B per wave in 32x32-tile units (a 64x64 TU counts 4): the smallest B for which the launch fits; capped, long lists simply take several rounds.
     static const long residentEnv = getenv( "VVHIP_TU_RESIDENT_WAVES" ) ? atol( getenv( "VVHIP_TU_RESIDENT_WAVES" ) ) : 0;
-    bool has64 = false;
-    for( int i = first; i < groupEnd; i++ ) has64 |= jobs[order[i]].width == 64;
-    // (the 64-point instance holds 2 048 waves; on the recorded mix 64:955 32:2 133 16:600 8:800 4:600 = 3 298 tiles a budget for 2 048 / 3 072 / 4 096 waves gives 22.4 / 20.7 / 17.6 us:
+    // (round 4, when the 64-point instance held 2 048 waves; on the recorded mix 64:955 32:2 133 16:600 8:800 4:600 = 3 298 tiles a budget for 2 048 / 3 072 / 4 096 waves gives 22.4 / 20.7 / 17.6 us:
     //  with its long 64x64 waves in front, one tile per wave and a second partial round beat fewer, longer waves)
     const long residentWaves = residentEnv ? residentEnv : 8192;      // (round 4: 4 096 with 64-point lists at two waves per SIMD, 3 072 without; every instance holds three now)
     int budget = 0;
