@@ -1179,7 +1179,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
     // within +-4095 (any residual of <= 12-bit video) a difference fits 14 bits, a lane's 16 squares fit 32 bits and the sum is eight packed subtractions + eight v_dot2_i32_i16;
     // otherwise (arbitrary int16 input) the 64-bit multiply-adds.  -4096 <= x <= 4095  <=>  ( uint16 ) ( x + 4096 ) < 8192: one packed add and one and-or per pair of samples
     typedef unsigned short u16x2t __attribute__( ( ext_vector_type( 2 ) ) );
-#define TUMX_TAIL() { \
+#define TUMX_TAIL( STORE_REC ) { \
     unsigned long long sse[R]; \
 _Pragma( "unroll" ) \
     for( int r = 0; r < R; r++ ) sse[r] = 0; \
@@ -1219,7 +1219,7 @@ _Pragma( "unroll" ) \
           sse[slot] += ( unsigned long long ) ( ( long long ) e0 * e0 ) + ( unsigned long long ) ( ( long long ) e1 * e1 ); \
         } \
       } \
-      if( A.rec && tu < A.n ) \
+      if( ( STORE_REC ) && A.rec && tu < A.n ) \
       { \
         int16_t* dst = A.rec + ( size_t ) tu * N * N + inL * N + X0 % N; \
         if( PS == 8 ) { u32x4 v; v.x = rp[0]; v.y = rp[1 % ( PS / 2 )]; v.z = rp[2 % ( PS / 2 )]; v.w = rp[3 % ( PS / 2 )]; *reinterpret_cast<u32x4*>( dst ) = v; } \
@@ -1275,22 +1275,23 @@ _Pragma( "unroll" ) \
           st[0] = 0; st[1] = ( int32_t ) last[r]; st[2] = ( int32_t ) need[r]; st[3] = 0;
         }
       }
-      if( A.level )
+      // zeros for levels AND reconstruction in the raster mapping of the level stores (a wave instruction writes whole 64-byte runs; the long way's reconstruction stores go
+      // row by row from the lanes that hold the rows: two half-filled requests per row)
 #pragma unroll
-        for( int u = 0; u < 16 / PS; u++ )
+      for( int u = 0; u < 16 / PS; u++ )
+      {
+        const int q = lane + 64 * u, Y = q / ( 32 / PS ), X = PS * ( q % ( 32 / PS ) );
+        const int tu = tile * TPT + ( Y / N ) * TPS + X / N;
+        if( tu < A.n )
         {
-          const int q = lane + 64 * u, Y = q / ( 32 / PS ), X = PS * ( q % ( 32 / PS ) );
-          const int tu = tile * TPT + ( Y / N ) * TPS + X / N;
-          if( tu < A.n )
-          {
-            int16_t* dst = A.level + ( size_t ) tu * N * N + ( Y % N ) * N + X % N;
-            if( PS == 8 ) *reinterpret_cast<u32x4*>( dst ) = u32x4{ 0, 0, 0, 0 };
-            else          *reinterpret_cast<u32x2*>( dst ) = u32x2{ 0, 0 };
-          }
+          const size_t at = ( size_t ) tu * N * N + ( Y % N ) * N + X % N;
+          if( PS == 8 ) { if( A.level ) *reinterpret_cast<u32x4*>( A.level + at ) = u32x4{ 0, 0, 0, 0 }; if( A.rec ) *reinterpret_cast<u32x4*>( A.rec + at ) = u32x4{ 0, 0, 0, 0 }; }
+          else          { if( A.level ) *reinterpret_cast<u32x2*>( A.level + at ) = u32x2{ 0, 0 }; if( A.rec ) *reinterpret_cast<u32x2*>( A.rec + at ) = u32x2{ 0, 0 }; }
         }
+      }
 #pragma unroll
       for( int v = 0; v < 16; v++ ) d[v] = 0;
-      TUMX_TAIL()
+      TUMX_TAIL( false )
       continue;
     }
     // levels -> staging tile (raster), dequantised values replace the coefficients.  When every |c| fits 16 bits the level is a 24-bit
@@ -1401,7 +1402,7 @@ _Pragma( "unroll" ) \
       MX_PASS( opI2, bHi, opI2, bLo, c, A.shI2 );
     }
     if( A.phaseLimit == 7 ) { TUMX_KEEP( d ); continue; }
-    TUMX_TAIL()
+    TUMX_TAIL( true )
   }
 #undef WAVE_SYNC
 #undef TUMX_KEEP
@@ -1546,16 +1547,17 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
           const u32x4 x0 = reinterpret_cast<const U16*>( p )->v, x1 = reinterpret_cast<const U16*>( p + 8 )->v;
           const uint32_t xr[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
           const u32x4 z4 = { 0, 0, 0, 0 };
+          // (levels and reconstruction zeros in the same raster runs: whole 64-byte requests; 512 runs of 8 samples per array, 2 per lane and chunk)
+          const int q0 = lane + 64 * ( 4 * t + 2 * c );
           if( A.rec )
           {
-            int16_t* dst = A.rec + ( size_t ) tu * 4096 + ( 32 * t + c32 ) * 64 + 32 * c + 16 * h;
-            *reinterpret_cast<u32x4*>( dst ) = z4; *reinterpret_cast<u32x4*>( dst + 8 ) = z4;
+            *reinterpret_cast<u32x4*>( A.rec + ( size_t ) tu * 4096 + ( size_t ) q0 * 8 ) = z4;
+            *reinterpret_cast<u32x4*>( A.rec + ( size_t ) tu * 4096 + ( size_t ) ( q0 + 64 ) * 8 ) = z4;
           }
           if( A.level )
           {
-            const int q0 = lane + 64 * ( 4 * t + 2 * c );
-            *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * 4096 + ( q0 >> 3 ) * 64 + 8 * ( q0 & 7 ) ) = z4;
-            *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * 4096 + ( ( q0 + 64 ) >> 3 ) * 64 + 8 * ( ( q0 + 64 ) & 7 ) ) = z4;
+            *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * 4096 + ( size_t ) q0 * 8 ) = z4;
+            *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * 4096 + ( size_t ) ( q0 + 64 ) * 8 ) = z4;
           }
           uint32_t magn = 0;
 #pragma unroll
