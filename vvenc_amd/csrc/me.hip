@@ -509,7 +509,9 @@ __device__ __forceinline__ void firstPass( const char* refB, int rs, int nH, int
       fxs[q] = txv & 15; at[q] = __mul24( rr, ldsPitch ) + x0;
       const uint32_t off = ( uint32_t ) ( __mul24( r, rs ) + x0 + ( txv >> 4 ) + 8 ) * 2u;        // bytes from refB to the output's integer position p
       // window samples s[0 .. 6 + NT] = p[K0 - 3 ..]: A = s[0..7] as even pairs W[0..3], B = s[NT - 1 .. NT + 6] as odd pairs S[B0 .. B0 + 3]; zero phase: A = p[0..7]
-      LA[q] = ld16o( refB, fxs[q] ? off + ( uint32_t ) ( 2 * ( K0 - 3 ) ) : off ); LB[q] = ld16o( refB, off + ( uint32_t ) ( 2 * ( K0 - 3 + NT - 1 ) ) );
+      // (a zero-phase unit is a copy of A: its second request would be read for nothing — a third of the variants of a half-sample stage, round 5)
+      LA[q] = ld16o( refB, fxs[q] ? off + ( uint32_t ) ( 2 * ( K0 - 3 ) ) : off );
+      if( fxs[q] ) LB[q] = ld16o( refB, off + ( uint32_t ) ( 2 * ( K0 - 3 + NT - 1 ) ) );
     }
 #pragma unroll
     for( int q = 0; q < HU; q++ )
