@@ -9,6 +9,7 @@ Nothing of a recording is left out (round 4): every block shape of preset medium
 plan, GEO's masked SADs included; `dropped` counts what could not be placed and the tests assert it is empty.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -445,6 +446,13 @@ class RecordedWorkload:
         tus = [hp1.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), self.bit_depth, self.tu_table[0], self.tu_table[1])] if self.tu_table else []
         dm = [hp2.bound("vvhip_dmvr_refine_batch", self.planes[g["r0"]].buf_ptr, self.planes[g["r0"]].stride, self.planes[g["r1"]].buf_ptr, self.planes[g["r1"]].stride,
                         C.c_void_p(g["d_items"].data_ptr()), g["n"], g["dx"], g["dy"], self.bit_depth, C.c_void_p(g["out"].data_ptr())) for g in self.dmvr_groups]
+        # $VVHIP_BENCH_SKIP_LANES=stage,int,item,tu,dmvr: leave launch groups out (measurement aid: what each group costs the five-stream step; results are then incomplete)
+        skip = set(filter(None, os.environ.get("VVHIP_BENCH_SKIP_LANES", "").split(",")))
+        if skip:
+            if len(me) == 3:
+                me = [c for c, name in zip(me, ("stage", "int", "item")) if name not in skip]
+            tus = [] if "tu" in skip else tus
+            dm = [] if "dmvr" in skip else dm
         self._lane_calls = [c for c in me + tus + dm if c is not None]
         return self._lane_calls
 
