@@ -1067,11 +1067,10 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
   const int rndF1 = A.shF1 > 0 ? 1 << ( A.shF1 - 1 ) : 0, rndF2 = 1 << ( A.shF2 - 1 ), rndI1 = 1 << ( A.shI1 - 1 ), rndI2 = 1 << ( A.shI2 - 1 );
   const bool liveCol = inL < N - A.skipW, liveRow = mxSigma( c32 ) % N < N - A.skipH;
   const v4i zero4 = { 0, 0, 0, 0 };
-  // the four matrix operands live in LDS (lane-private 16-byte slots), fetched right before their products: 16 registers less through the quantiser
+  // the two forward passes' operands live in LDS (lane-private 16-byte slots), fetched right before their products: registers less through the quantiser
   sOps[lane]       = liveCol ? *reinterpret_cast<const v4i*>( A.opH->nat[lane] ) : zero4;
   sOps[64 + lane]  = liveRow ? *reinterpret_cast<const v4i*>( A.opV->rowP[lane] ) : zero4;
-  sOps[128 + lane] = *reinterpret_cast<const v4i*>( A.opV->natT[lane] );
-  sOps[192 + lane] = *reinterpret_cast<const v4i*>( A.opH->colP[lane] );
+  // (the two inverse passes' operands are read from the records when a tile gets that far — most tiles quantise to nothing — instead of sitting in LDS: 2 KB per wave, round 5)
   const int cP1 = ( liveCol ? A.opH->rowSum[c32] : 0 ) + rndF1, cI1 = A.opV->colSum[c32] + rndI1;
   // accumulator preloads of the two passes whose matrix sits on the A side (they depend on the result register = logical row 16h + v): LDS
   sInit[c32]      = ( c32 % N < N - A.skipH ? A.opV->rowSum[c32] : 0 ) + rndF2;
@@ -1387,7 +1386,7 @@ _Pragma( "unroll" ) \
       v16i c;
 #pragma unroll
       for( int v = 0; v < 16; v++ ) c[v] = cI1;
-      const v4i opI1 = sOps[128 + lane];
+      const v4i opI1 = *reinterpret_cast<const v4i*>( A.opV->natT[lane] );
       MX_PASS( aHi, opI1, aLo, opI1, c, A.shI1 );
       mxSplitSat( d, bLo, bHi );
     }
@@ -1398,7 +1397,7 @@ _Pragma( "unroll" ) \
       v16i c;
 #pragma unroll
       for( int g = 0; g < 4; g++ ) { const v4i t = *reinterpret_cast<const v4i*>( &sInit[32 + h * 16 + 4 * g] ); c[4 * g] = t.x; c[4 * g + 1] = t.y; c[4 * g + 2] = t.z; c[4 * g + 3] = t.w; }
-      const v4i opI2 = sOps[192 + lane];
+      const v4i opI2 = *reinterpret_cast<const v4i*>( A.opH->colP[lane] );
       MX_PASS( opI2, bHi, opI2, bLo, c, A.shI2 );
     }
     if( A.phaseLimit == 7 ) { TUMX_KEEP( d ); continue; }
@@ -1426,14 +1425,14 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
   const v16i zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
   const int rndF1 = 1 << ( A.shF1 - 1 ), rndF2 = 1 << ( A.shF2 - 1 ), rndI1 = 1 << ( A.shI1 - 1 ), rndI2 = 1 << ( A.shI2 - 1 );
-  // operand slots: 0,1 natX[c]  2,3 rowPY[t]  4,5 natTY[t]  6,7 colPX[c]
+  // operand slots in LDS: 0,1 natX[c]  2,3 rowPY[t]   (natTY[t], colPX[c] of the inverse passes: from the record, see below)
 #pragma unroll
   for( int q = 0; q < 2; q++ )
   {
     sOps[( 0 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->natX[q][lane] );
     sOps[( 2 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->rowPY[q][lane] );
-    sOps[( 4 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->natTY[q][lane] );
-    sOps[( 6 + q ) * 64 + lane] = *reinterpret_cast<const v4i*>( O->colPX[q][lane] );
+    // (the operands of the two INVERSE passes are read from the record when a TU gets that far — 2–12 % of the 64x64 TUs of the recorded lists have a level at all — instead of
+    //  sitting in LDS: the instance needs the 4 KB of operand slots per wave the other sizes need, not 8: 44.5 -> 28.2 KB per workgroup, round 5)
   }
   const int cP1 = O->rowSum[c32] + rndF1;
   const int cI1[2] = { O->colSum[c32] + rndI1, O->colSum[32 + c32] + rndI1 };
@@ -1630,7 +1629,7 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
       v16i c;
 #pragma unroll
       for( int v = 0; v < 16; v++ ) c[v] = cI1[t];
-      const v4i op = sOps[( 4 + t ) * 64 + lane];
+      const v4i op = *reinterpret_cast<const v4i*>( O->natTY[t][lane] );
       v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( aHi, op, zero16, 0, 0, 0 );
 #pragma unroll
       for( int v = 0; v < 16; v++ ) acc[v] = ( acc[v] << 8 ) + c[v];
@@ -1652,7 +1651,7 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
         v16i ci;
 #pragma unroll
         for( int g = 0; g < 4; g++ ) { const v4i t4 = *reinterpret_cast<const v4i*>( &sInit[32 + 32 * c + h * 16 + 4 * g] ); ci[4 * g] = t4.x; ci[4 * g + 1] = t4.y; ci[4 * g + 2] = t4.z; ci[4 * g + 3] = t4.w; }
-        const v4i op = sOps[( 6 + c ) * 64 + lane];
+        const v4i op = *reinterpret_cast<const v4i*>( O->colPX[c][lane] );
         v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8( op, bHi[t], zero16, 0, 0, 0 );
 #pragma unroll
         for( int v = 0; v < 16; v++ ) acc[v] = ( acc[v] << 8 ) + ci[v];
@@ -1940,7 +1939,7 @@ tuMxMultiKernel( const int16_t* __restrict__ resi, int resiStride, TuMxJobs jobs
   constexpr bool WITH4 = KIND >= 1, WITH64 = KIND >= 2, PAIR64 = KIND == 3;
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t stage[4][32 * 40];
   __shared__ __attribute__( ( aligned( 16 ) ) ) int32_t sInit[4][WITH64 ? 96 : 64];
-  __shared__ v4i sOps[4][WITH64 ? 512 : 256];
+  __shared__ v4i sOps[4][PAIR64 ? 512 : ( WITH64 ? 256 : 128 )];      // forward-pass operands per wave (8/16/32-point: 2 slots, 64-point: 4; the pair form keeps all 8)
   __shared__ int32_t xch[PAIR64 ? 2 : 1][PAIR64 ? 2 * 64 * 17 : 1];      // 64x64 TUs over a wave pair: the pair's exchange area
   __shared__ uint32_t pairCtr[2];
   if( PAIR64 ) { if( threadIdx.x < 2 ) pairCtr[threadIdx.x] = 0; __syncthreads(); }      // (before any wave leaves)
