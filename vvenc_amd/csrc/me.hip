@@ -559,6 +559,8 @@ __device__ __forceinline__ void firstPass( const char* refB, int rs, int nH, int
 }
 
 // a stage unit in the schedule: stage index | band of 32 rows << 24 | 64-column half << 27 | continues the previous unit's sums << 28 | the next unit continues << 29 | atomic << 30
+// bits 0..21 the stage index, bits 22..23 the horizontal variant the unit is restricted to + 1 (0: all variants of the stage — narrow units; wide units are split, see plan creation)
+constexpr int ST_STAGE_MASK = 0x3fffff, ST_VAR_SHIFT = 22;
 constexpr int ST_UNIT_CONT = 1 << 28, ST_UNIT_MORE = 1 << 29, ST_UNIT_ATOMIC = 1 << 30;      // ATOMIC: a stage of more than two units — every unit a wave of its own, sums added to the (cleared) cost array
 
 // GEN = false: the shapes of the fast presets (CTU 64, quad-tree only) — square 8..64, tiles 8x8 / 16x16_fast / SAD rows, eight lanes per tile: every tile quantity is a
@@ -592,7 +594,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
   {
     const StageUnit* up = a.stageUnits + span.first + si;                        // (wave-uniform address: scalar loads; the table is in schedule order, one record per unit)
     const vvhip_me_stage_job j = up->j;
-    const int unit = up->order, stage = unit & 0xffffff;
+    const int unit = up->order, stage = unit & ST_STAGE_MASK, varOnly = ( unit >> ST_VAR_SHIFT ) & 3;      // varOnly: 0 = every variant, v + 1 = variant v alone
     // the unit: <= 32 rows x <= 64 columns of the block (a band of one 64-column half).  Blocks of more than one unit (h > 32 or w > 64) are shared by the two waves of the
     // workgroup; a wave adds the sums of its units (ST_UNIT_CONT / _MORE) before the two waves meet
     const int w = j.width, h = j.height, uw = w < 64 ? w : 64, uwH = uw < 8 ? 8 : uw, G = uwH >> 3, log2G = 31 - __builtin_clz( G );
@@ -630,7 +632,7 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
     // position of a 64-wide unit is exactly 64 lanes of second-pass work), narrower ones all (<= 3) of them: 6 KB of LDS per wave instead of 9.5 — the kernel is
     // occupancy-bound — and half as many units for the 64x64 blocks.
     const int vpp = uw <= 16 ? nHor : 1;
-    for( int v0 = 0; v0 < nHor; v0 += vpp )
+    for( int v0 = varOnly ? varOnly - 1 : 0; v0 < ( varOnly ? varOnly : nHor ); v0 += vpp )
     {
     const int nV = nHor - v0 < vpp ? nHor - v0 : vpp;
     const int pBeg = v0 == 0 ? 0 : ( v0 == 1 ? cnt0 : cnt0 + cnt1 ), pEnd = v0 + nV >= 3 ? nPos : ( v0 + nV == 2 ? cnt0 + cnt1 : ( v0 + nV == 1 ? cnt0 : 0 ) );
@@ -750,13 +752,23 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       // integer additions commute: the result does not depend on the schedule)
       if( tid < 9 && ( ( j.mask >> tid ) & 1 ) ) atomicAdd( reinterpret_cast<unsigned long long*>( a.stageCost ) + ( size_t ) 9 * stage + tid, ( unsigned long long ) costL[tid] );
     }
-    else if( h <= 32 && w <= 64 ) { if( tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] : 0u; }
     else
     {
-      if( wv == 1 && tid < 9 ) pairCost[tid] = costL[tid];
-      __syncthreads();
-      if( wv == 0 && tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] + pairCost[tid] : 0u;
-      __syncthreads();                                                           // (a workgroup may hold several such pairs in a row: pairCost is read before the next pair writes it)
+      // a unit restricted to one variant stores the costs of ITS positions (slots ownBeg .. ownEnd of the grouped position list); variant 0's wave also stores the zeros of the
+      // positions outside the mask.  An unrestricted unit: all nine.
+      const int ownBeg = varOnly <= 1 ? 0 : ( varOnly == 2 ? cnt0 : cnt0 + cnt1 ), ownEnd = !varOnly ? nPos : ( varOnly == 1 ? cnt0 : ( varOnly == 2 ? cnt0 + cnt1 : nPos ) );
+      const bool pair = !( h <= 32 && w <= 64 );
+      if( pair ) { if( wv == 1 && tid < 9 ) pairCost[tid] = costL[tid]; __syncthreads(); }
+      if( !pair || wv == 0 )
+      {
+        if( !varOnly ) { if( tid < 9 ) a.stageCost[( size_t ) 9 * stage + tid] = ( ( j.mask >> tid ) & 1 ) ? costL[tid] + ( pair ? pairCost[tid] : 0u ) : 0u; }
+        else
+        {
+          if( tid >= ownBeg && tid < ownEnd ) { const int k = posL[tid] & 0xff; a.stageCost[( size_t ) 9 * stage + k] = costL[k] + ( pair ? pairCost[k] : 0u ); }
+          if( varOnly == 1 && tid < 9 && !( ( j.mask >> tid ) & 1 ) ) a.stageCost[( size_t ) 9 * stage + tid] = 0u;
+        }
+      }
+      if( pair ) __syncthreads();                                                // (a workgroup may hold several such pairs in a row: pairCost is read before the next pair writes it)
     }
   }
 }
@@ -1117,7 +1129,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   if( n_int_jobs < 0 || n_cands < 0 || n_stage_jobs < 0 || n_items < 0 || n_mask < 0 || ( n_int_jobs && ( !int_jobs || !cands ) ) || ( n_stage_jobs && !stage_jobs ) || ( n_items && !items ) || ( n_mask && !mask_items ) )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: bad lists" );
   if( n_cands >= ( 1 << 24 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: %d candidates (the schedule packs the output-list position into 24 bits)", n_cands );
-  if( n_stage_jobs >= ( 1 << 24 ) ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: %d stage jobs (the schedule packs the stage index into 24 bits)", n_stage_jobs );
+  if( n_stage_jobs > ST_STAGE_MASK ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_me_plan_create: %d stage jobs (the schedule packs the stage index into 22 bits)", n_stage_jobs );
   if( bit_depth < 8 || bit_depth > 10 ) return vvhip_fail( ctx, VVHIP_E_UNSUPPORTED, "vvhip_me_plan_create: bit depth %d (the packed Hadamard tile covers <= 10)", bit_depth );
   if( max_window <= 0 ) max_window = 24;
   // block shapes: width and height independent powers of two (CTU 128 + multi-type tree: RdCost.cpp:301-336 generic SAD, the rectangular Hadamard tiles :1324-1766)
@@ -1240,19 +1252,48 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   // own adding into the cleared cost array, 2 = a single unit (bundled with others)
   auto dealOf = [&]( const vvhip_me_stage_job& s ) { const int n = unitsOf( s ); return n == 1 ? 2 : ( ( n > 2 && atomicStages ) ? 1 : 0 ); };
   auto unitWork = [&]( const vvhip_me_stage_job& s ) { return __builtin_popcount( s.mask ) * std::max( 1, unitW( s ) / 8 ) * unitH( s ); };      // 8-sample row groups of the second pass
+  // A wide unit's horizontal variants as waves of their own — when the stage launch would not fill the chip anyway: below $VVHIP_ME_SPLIT_VARIANTS units in the picture
+  // (default 8 192 ~ 1.3 resident rounds of stage waves; 0 = never, the form up to round 4; results identical).  Measured on the recorded lists (profiles/r05_stage_variants.log):
+  // 1080p (4 554 -> 10 970 waves) stage launch 31.6 -> 29.0 us, GOP-weighted rate +4 %; 4K (~20 000 waves before the split) 71 -> 78 us — there the chip is full and the extra
+  // waves only repeat the per-wave set-up.
+  static const long splitBelow = getenv( "VVHIP_ME_SPLIT_VARIANTS" ) ? atol( getenv( "VVHIP_ME_SPLIT_VARIANTS" ) ) : 8192;
+  long unitsUnsplit = 0;
+  for( int i = 0; i < n_stage_jobs; i++ ) unitsUnsplit += unitsOf( stage_jobs[i] );
+  const bool stageSplitVariants = unitsUnsplit < splitBelow;
   std::vector<int32_t> stOrder;
   bool hasAtomic = false;
   for( int i = 0; i < n_stage_jobs; i++ )      // (a stage without evaluated positions still gets its unit: the kernel writes its nine zeros)
   {
     const vvhip_me_stage_job& s = stage_jobs[i];
     const int bands = s.height / unitH( s ), halves = s.width / unitW( s ), n = bands * halves;
-    if( n > 2 && atomicStages ) { hasAtomic = true; for( int u = 0; u < n; u++ ) stOrder.push_back( i | ( ( u % bands ) << 24 ) | ( ( u / bands ) << 27 ) | ST_UNIT_ATOMIC ); continue; }
-    const int perWave = n > 1 ? n / 2 : 1;
-    for( int u = 0; u < n; u++ )
-      stOrder.push_back( i | ( ( u % bands ) << 24 ) | ( ( u / bands ) << 27 ) | ( ( u % perWave ) ? ST_UNIT_CONT : 0 ) | ( ( u % perWave ) != perWave - 1 ? ST_UNIT_MORE : 0 ) );
+    // Units of 32 and 64 columns hold ONE horizontal variant in LDS at a time (stageBody): their <= 3 variants are independent pieces of work with disjoint positions — a wave
+    // each (round 5).  A 64x32 unit with nine positions was ~3 300 instructions in one wave and the launch lasted as long as its slowest such wave (the launch's 4 554 waves do not
+    // even fill the chip once); three waves of a third each, nothing computed twice.  (Narrow units keep their variants together: they share one first pass.)
+    int nVar = 1;
+    if( stageSplitVariants && unitW( s ) >= 32 && ( n <= 2 || atomicStages ) )
+    {
+      int hx[3], nh = 0;
+      for( int k = 0; k < 9; k++ )
+        if( ( s.mask >> k ) & 1 )
+        {
+          static const int8_t rxT[9] = { 0, 0, 0, -1, 1, -1, 1, -1, 1 };
+          const int tx = ( rxT[k] + s.base_qx ) * s.i_frac * 4;
+          int v = 0; while( v < nh && hx[v] != tx ) v++;
+          if( v == nh ) hx[nh++] = tx;
+        }
+      nVar = nh > 1 ? nh : 1;
+    }
+    for( int vr = 0; vr < nVar; vr++ )
+    {
+      const int vbits = nVar > 1 ? ( vr + 1 ) << ST_VAR_SHIFT : 0;
+      if( n > 2 && atomicStages ) { hasAtomic = true; for( int u = 0; u < n; u++ ) stOrder.push_back( i | vbits | ( ( u % bands ) << 24 ) | ( ( u / bands ) << 27 ) | ST_UNIT_ATOMIC ); continue; }
+      const int perWave = n > 1 ? n / 2 : 1;
+      for( int u = 0; u < n; u++ )
+        stOrder.push_back( i | vbits | ( ( u % bands ) << 24 ) | ( ( u / bands ) << 27 ) | ( ( u % perWave ) ? ST_UNIT_CONT : 0 ) | ( ( u % perWave ) != perWave - 1 ? ST_UNIT_MORE : 0 ) );
+    }
   }
   // per tap support: the stages of several units first (their waves must be the pairs 2g, 2g + 1 of the launch), then by unit width and work
-  std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & 0xffffff]; const auto& y = stage_jobs[b & 0xffffff];
+  std::stable_sort( stOrder.begin(), stOrder.end(), [&]( int a, int b ) { const auto& x = stage_jobs[a & ST_STAGE_MASK]; const auto& y = stage_jobs[b & ST_STAGE_MASK];
                     const int px = dealOf( x ), py = dealOf( y );
                     if( setOf( x ) != setOf( y ) ) return setOf( x ) < setOf( y );
                     if( px != py ) return px < py;
@@ -1262,14 +1303,14 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   static const int bundleWork = getenv( "VVHIP_ME_BUNDLE_WORK" ) ? atoi( getenv( "VVHIP_ME_BUNDLE_WORK" ) ) : 80;      // recorded 1080p lists, round 3: 80 / 160 / 320 / 640 / 1280 -> 59.0 / 58.7 / 61.9 / 67.9 / 71.1 us; round 4 (XCD-band order): 80 / 120 / 160 / 240 / 320 -> 41.0 / 44.2 / 44.3 / 44.5 / 43.3 us
   for( size_t i = 0; i < stOrder.size(); )
   {
-    const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i] & 0xffffff];
+    const vvhip_me_stage_job& s0 = stage_jobs[stOrder[i] & ST_STAGE_MASK];
     int count = 0, work = 0;
     if( dealOf( s0 ) == 0 ) count = unitsOf( s0 ) / 2;      // half of a shared stage's units: a wave of its own, next to its sibling
     else if( dealOf( s0 ) == 1 ) count = 1;                  // a unit of an atomic stage
     else
       while( i + count < stOrder.size() && count < 8 )
       {
-        const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count] & 0xffffff];
+        const vvhip_me_stage_job& s = stage_jobs[stOrder[i + count] & ST_STAGE_MASK];
         if( unitW( s ) != unitW( s0 ) || setOf( s ) != setOf( s0 ) || dealOf( s ) != 2 || ( count && work + unitWork( s ) > bundleWork ) ) break;
         work += unitWork( s ); count++;
       }
@@ -1278,7 +1319,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     // the wave's LDS slice must hold the TALLEST unit of the bundle: bundles group by unit width, launch class and deal, not by height — in the rectangular classes a short
     // full-mask leader (8x4, nine positions) can be followed by a tall unit with few evaluated positions (8x32, one position) inside the same work budget
     int bh = unitH( s0 );
-    for( int u = 1; u < count; u++ ) bh = std::max( bh, unitH( stage_jobs[stOrder[i + u] & 0xffffff] ) );
+    for( int u = 1; u < count; u++ ) bh = std::max( bh, unitH( stage_jobs[stOrder[i + u] & ST_STAGE_MASK] ) );
     const int nt = tapSetOf( s0 ) == 0 ? 4 : ( tapSetOf( s0 ) == 1 ? 6 : 8 ), uw = std::max( 8, unitW( s0 ) ), vpp = unitW( s0 ) <= 16 ? 3 : 1;
     const int ldsUnit = ( 2 * ( 128 + 64 + 16 + 16 ) + vpp * ( bh + nt ) * ( uw + 8 ) ) * 2;      // tables + the first-pass bands a pass holds (row pitch unit width + 8)
     setLds[setOf( s0 )] = std::max( setLds[setOf( s0 )], ( ldsUnit + 15 ) & ~15 );
@@ -1292,7 +1333,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     std::vector<WaveSpan> src( stWaves );
     for( int k = 0, first = 0; k < 6; first += setWaves[k], k++ )
     {
-      auto subOf = [&]( int w ) { const vvhip_me_stage_job& s = stage_jobs[stOrder[src[first + w].first] & 0xffffff]; return ( 2 - dealOf( s ) ) * 1024 + unitW( s ); };
+      auto subOf = [&]( int w ) { const vvhip_me_stage_job& s = stage_jobs[stOrder[src[first + w].first] & ST_STAGE_MASK]; return ( 2 - dealOf( s ) ) * 1024 + unitW( s ); };
       for( int w0 = 0; w0 < setWaves[k]; )
       {
         int w1 = w0;
@@ -1312,11 +1353,11 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     {
       const WaveSpan& sp = stWaves[first + w];
       const int u = stOrder[sp.first];
-      const vvhip_me_stage_job& s = stage_jobs[u & 0xffffff];
+      const vvhip_me_stage_job& s = stage_jobs[u & ST_STAGE_MASK];
       if( dealOf( s ) != 0 ) continue;
       const int sib = ( w & 1 ) ? w - 1 : w + 1;
-      if( sp.count != unitsOf( s ) / 2 || sib >= setWaves[k] || stWaves[first + sib].count != sp.count || ( stOrder[stWaves[first + sib].first] & 0xffffff ) != ( u & 0xffffff ) )
-        return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: schedule error (the units of stage %d are not one workgroup)", u & 0xffffff );
+      if( sp.count != unitsOf( s ) / 2 || sib >= setWaves[k] || stWaves[first + sib].count != sp.count || ( stOrder[stWaves[first + sib].first] & ( ST_STAGE_MASK | ( 3 << ST_VAR_SHIFT ) ) ) != ( u & ( ST_STAGE_MASK | ( 3 << ST_VAR_SHIFT ) ) ) )
+        return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_me_plan_create: schedule error (the units of stage %d are not one workgroup)", u & ST_STAGE_MASK );
     }
 
   // ---- item bundles: same function and geometry, a few team passes per wave
@@ -1399,7 +1440,7 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
   {
     StageUnit& u = stUnits[i];
     memset( &u, 0, sizeof( u ) );
-    u.j = stage_jobs[stOrder[i] & 0xffffff]; u.order = stOrder[i];
+    u.j = stage_jobs[stOrder[i] & ST_STAGE_MASK]; u.order = stOrder[i];
     static const int8_t rxT[9] = { 0, 0, 0, -1, 1, -1, 1, -1, 1 }, ryH[9] = { 0, -1, 1, 0, 0, -1, -1, 1, 1 }, ryQ[9] = { 0, -1, 1, -1, -1, 0, 0, 1, 1 };      // s_acMvRefineH / Q, InterSearch.cpp:67-91
     int tx[9], ty[9], var[9], cnt[3] = { 0, 0, 0 }, nHor = 0, nPos = 0;
     for( int k = 0; k < 9; k++ )
