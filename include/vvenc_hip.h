@@ -352,7 +352,8 @@ VVHIP_API int vvhip_subpel_refine_batch( vvhip_ctx* ctx, int func, const int16_t
  * double-precision normalisation, 16x16_fast, 8x8, 4x4, 2x2: RdCost.cpp:1818-1938); bit depths <= 10 (the packed Hadamard tile, like the reference's x86 rows).
  * Operand ranges of the Hadamard family (stage jobs and items): what the encoder hands to these table entries at the plan's bit depth — samples in [0, 2^bit_depth) or
  * bi-prediction patterns 2 org - pred in (-2^bit_depth, 2^(bit_depth+1)) against prediction samples, i.e. |org - cur| < 2^(bit_depth+1): the first two butterfly stages run on
- * packed 16-bit pairs.  SAD / SSE / masked-SAD items take any int16 operands.
+ * packed 16-bit pairs.  SAD / SSE / masked-SAD items take any int16 operands (masked SADs: weights >= 0; sums in 64 bits outside the GEO range of samples and weights).
+ * Limits: fewer than 2^24 candidates and 2^22 stage jobs per plan.
  * Integer jobs: positions a job lists more than once (the search re-scores its start point) are scored once; every listed candidate still gets its cost.
  * A plan owns device copies of the job tables and the schedule derived from them (which wave takes which jobs, heaviest first); running it is one launch per kind.
  * ====================================================================================================================== */
