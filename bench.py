@@ -118,32 +118,6 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
             step()
         torch.cuda.synchronize()
 
-    # ---- per-kernel durations: every layer's launches serialized on one stream, HIP events around each kernel (inside the library for the plan's kernels); outside the timed region
-    per_layer = {}
-    for layer, wl in workloads.items():
-        hp.me_plan_set_timing(wl.plan, True)
-        acc = {"ME_stage": 0.0, "ME_int": 0.0, "ME_item": 0.0, "TU": 0.0, "DMVR": 0.0}
-        reps = 8
-        for it in range(reps + 1):
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            wl.run_me()
-            e[0].record()
-            wl.run_tu()
-            e[1].record()
-            wl.run_dmvr()
-            e[2].record()
-            torch.cuda.synchronize()
-            t = hp.me_plan_last_times(wl.plan)
-            if it == 0:
-                continue
-            acc["ME_stage"] += t[0]
-            acc["ME_int"] += t[1] + t[2]
-            acc["ME_item"] += t[3]
-            acc["TU"] += e[0].elapsed_time(e[1])
-            acc["DMVR"] += e[1].elapsed_time(e[2])
-        hp.me_plan_set_timing(wl.plan, False)
-        per_layer[layer] = {k: v / reps for k, v in acc.items()}
-
     # ---- THE timed region: exactly `steps` steps between barrier + synchronize on both sides, max over ranks
     step_no[0] = 0
     ex_before = ex_count[0]
@@ -203,6 +177,34 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         dtc = timed(32)
         per_cycle = {"value": steps * world / dtc, "unit": "frames/s", "ms_per_step": 1000.0 * dtc / steps, "every_steps": 32,
                      "note": "same steps with one reference-picture broadcast per GOP cycle (32 steps) and rank: the cadence of N ranks encoding their own GOP chunks"}
+    # (the per-kernel pass runs AFTER the timed region: its serialized launches and host synchronisations leave idle gaps in which the GPU's clocks fall back, and a timed region of
+    #  K = 20 steps is 1.4 ms — too short to ramp them up again: a run that timed right behind this pass read 80.5 us per step where the per-layer times said 69)
+    # ---- per-kernel durations: every layer's launches serialized on one stream, HIP events around each kernel (inside the library for the plan's kernels); outside the timed region
+    per_layer = {}
+    for layer, wl in workloads.items():
+        hp.me_plan_set_timing(wl.plan, True)
+        acc = {"ME_stage": 0.0, "ME_int": 0.0, "ME_item": 0.0, "TU": 0.0, "DMVR": 0.0}
+        reps = 8
+        for it in range(reps + 1):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            wl.run_me()
+            e[0].record()
+            wl.run_tu()
+            e[1].record()
+            wl.run_dmvr()
+            e[2].record()
+            torch.cuda.synchronize()
+            t = hp.me_plan_last_times(wl.plan)
+            if it == 0:
+                continue
+            acc["ME_stage"] += t[0]
+            acc["ME_int"] += t[1] + t[2]
+            acc["ME_item"] += t[3]
+            acc["TU"] += e[0].elapsed_time(e[1])
+            acc["DMVR"] += e[1].elapsed_time(e[2])
+        hp.me_plan_set_timing(wl.plan, False)
+        per_layer[layer] = {k: v / reps for k, v in acc.items()}
+
     if rank != 0:
         return None, workloads, None
 
