@@ -142,3 +142,38 @@ def test_early_exit_partial_sums_are_flagged_not_recorded(tmp_path):
         r = arr[c["y"][i] + mg:c["y"][i] + mg + 64, c["x"][i] + mg:c["x"][i] + mg + 64].astype(np.int64)
         ss = int(c["subShift"][i])
         assert int(np.abs(o[::1 << ss] - r[::1 << ss]).sum()) << ss == int(c["cost"][i])
+
+
+def test_window_kernel_byte_accounting(recording):
+    """the three byte counts bench.py reports for the integer windows (vvenc_amd/replay.py): every listed candidate with its whole block (round 4's figure: 3.6 x the HBM peak at
+    4K) >= every DISTINCT position with its block (a work rate) >= the job's window read once + its block + 8 B per distinct position (SURVEY 8d "with window reuse": the class's
+    algorithmic bytes) — recomputed here job by job with plain Python sets and boxes"""
+    from vvenc_amd.replay import RecordedLists
+    _, pics = recording
+    checked = 0
+    for poc, pic in pics.items():
+        L = RecordedLists(pic, unique_bytes=False)
+        if not L.plan_cands.size:
+            continue
+        assert L.alg_bytes_int_window <= L.alg_bytes_int_per_position <= L.alg_bytes_int_all_candidates
+        assert L.int_positions_distinct <= L.plan_cands.size and L.alg_bytes_by_kernel["ME_int"] == L.alg_bytes_int_window
+        tot_all = tot_pos = tot_win = n_distinct = 0
+        for j in L.int_jobs:
+            w, h, ss = int(j["width"]), int(j["height"]), int(j["sub_shift"])
+            c = L.plan_cands[int(j["first_cand"]):int(j["first_cand"]) + int(j["n_cand"])]
+            pos = {(int(a), int(b)) for a, b in zip(c["dx"], c["dy"])}
+            rows = h >> ss
+            tot_all += c.size * (4 * w * rows + 8)
+            tot_pos += len(pos) * (4 * w * rows + 8)
+            n_distinct += len(pos)
+            cols = max(p[0] for p in pos) - min(p[0] for p in pos) + w
+            touched = set()                                              # reference rows the job's candidates read (subShift 1: every second row from the candidate's dy on)
+            for _, dy in pos:
+                touched.update(range(dy, dy + h, 1 << ss))
+            tot_win += 2 * cols * len(touched) + 2 * w * rows + 8 * len(pos)
+        assert (tot_all, tot_pos, n_distinct) == (L.alg_bytes_int_all_candidates, L.alg_bytes_int_per_position, L.int_positions_distinct), poc
+        # the library's figure is the job's BOUNDING window (per row parity under subShift: what the kernel stages in LDS) — never below the rows the candidates touch, and not
+        # far above them (a search's late, far-apart candidates leave gaps inside the box)
+        assert tot_win <= L.alg_bytes_int_window <= 1.5 * tot_win, (poc, tot_win, L.alg_bytes_int_window)
+        checked += 1
+    assert checked >= 8
