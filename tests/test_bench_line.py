@@ -50,7 +50,7 @@ def test_full_size_result_formats_into_one_line_under_8k():
     assert line["value_4k"] and line["ms_per_step_4k"] and "frac" in line["roofline_4k"]
     for k in ("e2e", "e2e_4k"):
         assert {"cpu_fps", "hip_fps", "speedup", "bitstreams_identical", "cpu_fps_best", "other_threads", "scalar_md5_equal", "stage_split"} <= set(line[k]), line[k].keys()
-    assert abs(line["value"] - out["value"]) / out["value"] < 1e-4 and abs(line["ms_per_step"] - out["ms_per_step"]) / out["ms_per_step"] < 1e-4
+    assert abs(line["value"] - out["value"]) / out["value"] < 1e-3 and abs(line["ms_per_step"] - out["ms_per_step"]) / out["ms_per_step"] < 1e-3
 
 
 def test_oversized_result_still_ends_under_the_hard_cap():
