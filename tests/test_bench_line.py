@@ -64,8 +64,43 @@ def test_oversized_result_still_ends_under_the_hard_cap():
     big["parity"]["checked"] = {"k%d" % i: i for i in range(4000)}                     # past the hard cap: the contract's fields only
     s = bench_line.compact(big, "bench_detail.json")
     line = json.loads(s)
-    assert len(s) <= bench_line.HARD_CAP_BYTES or "roofline" in line
+    assert len(s) <= bench_line.HARD_CAP_BYTES and "roofline" in line
     assert line["value"] and line["roofline"]["frac"] and line["cpu_baseline"]["value"]
+
+
+def test_line_never_exceeds_the_tail_the_driver_keeps():
+    """between the target and the old 16 KB cap a line went out unchanged (several 300-character error strings, other_threads rows, the N > 1 fields): every
+    oversized shape must end at or below 8 192 bytes — the figure tests/test_gpu_parity.py asserts on the real run — and keep the contract's fields"""
+    import bench_line
+    assert bench_line.HARD_CAP_BYTES <= 8192 and bench_line.TARGET_BYTES <= bench_line.HARD_CAP_BYTES
+    base = _full_size_result()
+    shapes = []
+    a = copy.deepcopy(base)                                   # long error strings in every optional leg + N > 1 fields
+    for k in ("e2e", "e2e_4k", "config3_medium_4k", "mctf", "mctf_4k"):
+        a[k] = {"error": "E" * 300}
+    a["error_4k"] = "F" * 400
+    a["e2e_instances"] = {"error": "G" * 300}
+    a["exchange"] = {"pictures": 10, "bytes_per_rank": 7700000, "collective": "broadcast", "every_steps": 2, "backend": "nccl", "exchange_ms_per_picture": 0.0123}
+    a["no_exchange"] = a["exchange_per_gop_cycle"] = {"value": 1.0, "ms_per_step": 2.0, "every_steps": 32}
+    a["cpu_baseline"]["sample"] = "S" * 2000
+    a["value_note"] = "N" * 3000
+    shapes.append(a)
+    b = copy.deepcopy(base)                                   # many side rows
+    for k in ("e2e", "e2e_4k"):
+        b[k]["other_threads"] = [{"threads": t, "cpu_fps": 1.5, "hip_fps": 1.6, "speedup": 1.07} for t in range(1, 60)]
+        b[k]["md5_set"] = "m" * 900
+    shapes.append(b)
+    c = copy.deepcopy(base)                                   # a class table that grew
+    c["roofline_all_kernels"] = {"class%d" % i: dict(next(iter(base["roofline_all_kernels"].values()))) for i in range(60)}
+    c["config"]["workload"] = "W" * 5000
+    shapes.append(c)
+    for o in shapes:
+        s = bench_line.compact(o, "bench_detail.json")
+        assert len(s.encode()) <= bench_line.TARGET_BYTES, len(s)
+        line = json.loads(s)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "roofline", "cpu_baseline", "detail"):
+            assert k in line, k
+        assert line["roofline"]["frac"] and line["cpu_baseline"]["value"]
 
 
 def test_emit_prints_the_compact_line_last(tmp_path, capsys):

@@ -30,7 +30,9 @@ struct vvhip_ctx
   void*        d_tuGen    = nullptr;
   size_t       tuGenBytes = 0;
   std::vector<unsigned char> tuGenLast;
-  hipStream_t  tuGenStream = nullptr;      // the stream the cached generic-TU job table was uploaded on (trquant.hip: tuRdoMulti)
+  hipStream_t  tuGenStream = nullptr;      // the stream the cached generic-TU job table was uploaded on (trquant.hip: tuRdoMulti); compared only, never used as a handle
+  hipEvent_t   tuGenEvent  = nullptr;      // recorded behind every launch that reads the table: a caller that switches streams orders the new stream behind it
+  bool         tuGenEventRecorded = false;
   // how the host waits for the stream (vvhip_set_blocking_sync): false = hipStreamSynchronize (the runtime's low-latency wait), true = a blocking event — the calling thread
   // sleeps, which matters when the host's cores are all busy encoding
   bool         blockingSync = false;

@@ -249,6 +249,7 @@ void vvhip_destroy( vvhip_ctx* ctx )
   if( ctx->d_subpel ) ( void ) hipFree( ctx->d_subpel );
   if( ctx->d_tuGen ) ( void ) hipFree( ctx->d_tuGen );
   if( ctx->syncEvent ) ( void ) hipEventDestroy( ctx->syncEvent );
+  if( ctx->tuGenEvent ) ( void ) hipEventDestroy( ctx->tuGenEvent );
   if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );
   delete ctx;
 }

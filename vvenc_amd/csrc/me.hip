@@ -518,10 +518,11 @@ __device__ __forceinline__ void firstPass( const char* refB, int rs, int nH, int
     {
       if( !ok[q] ) continue;
       const int fxv = fxs[q];
-      const u32x4 A = LA[q], B = LB[q];
+      const u32x4 A = LA[q];
       u32x4 ov;
       if( fxv )
       {
+        const u32x4 B = LB[q];                                  // (requested for non-zero phases only: never read otherwise)
         uint32_t W[4 + NP], S[4 + NP];
         W[0] = A.x; W[1] = A.y; W[2] = A.z; W[3] = A.w;
         S[B0] = B.x; S[B0 + 1] = B.y; S[B0 + 2] = B.z; S[B0 + 3] = B.w;

@@ -2293,11 +2293,13 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
       ctx->tuGenBytes = 64 * sizeof( TuGenJob ); ctx->tuGenLast.clear();
     }
     // (the cache is keyed on the table's content AND the stream it was uploaded on: a caller that switched the context's stream may still have the previous launch reading the
-    //  table on the old stream — wait for that stream, then upload again on the new one)
+    //  table on the old stream.  The old stream may be a borrowed handle that no longer exists (vvhip_set_stream), so it is never touched: the new stream waits for the EVENT the
+    //  context recorded behind that launch, then the table is uploaded again; the bookkeeping is updated before anything can fail.  ADVICE r4 / r5)
     if( ctx->tuGenStream != ctx->stream )
     {
-      if( !ctx->tuGenLast.empty() ) VVHIP_CHECK_HIP( ctx, hipStreamSynchronize( ctx->tuGenStream ) );
+      const bool wait = !ctx->tuGenLast.empty() && ctx->tuGenEventRecorded;
       ctx->tuGenLast.clear(); ctx->tuGenStream = ctx->stream;
+      if( wait ) VVHIP_CHECK_HIP( ctx, hipStreamWaitEvent( ctx->stream, ctx->tuGenEvent, 0 ) );
     }
     if( ctx->tuGenLast.size() != bytes || memcmp( ctx->tuGenLast.data(), gen.data(), bytes ) != 0 )
     {
@@ -2308,6 +2310,9 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
     if( smem > 64 * 1024 ) VVHIP_CHECK_HIP( ctx, hipFuncSetAttribute( ( const void* ) tuRdoGenMultiKernel, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) smem ) );
     hipLaunchKernelGGL( tuRdoGenMultiKernel, dim3( ( unsigned ) blocks ), dim3( 256 ), smem, ctx->stream, d_resi, static_cast<const TuGenJob*>( ctx->d_tuGen ), ( int ) gen.size(), tuPhaseLimit() );
     VVHIP_LAUNCH_CHECK( ctx );
+    if( !ctx->tuGenEvent ) VVHIP_CHECK_HIP( ctx, hipEventCreateWithFlags( &ctx->tuGenEvent, hipEventDisableTiming ) );
+    VVHIP_CHECK_HIP( ctx, hipEventRecord( ctx->tuGenEvent, ctx->stream ) );
+    ctx->tuGenEventRecorded = true;
   }
   // launch groups, largest size first (a wave of the largest size runs longest: it has to start first).  Matrix-core form: up to 8 jobs per launch; the 4x4 and 64x64
   // variants live in a second kernel instance (more code, same register bound) — a picture's lists go into ONE launch of that instance when they are small (a recorded

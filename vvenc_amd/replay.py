@@ -286,6 +286,10 @@ class RecordedLists:
             self.alg_bytes_int_all_candidates = int(per_cand.sum())
             self.alg_bytes_int_per_position = int(per_cand[first].sum())
             fc = jobs["first_cand"].astype(np.int64)
+            nc = jobs["n_cand"].astype(np.int64)
+            # (np.*.reduceat over fc: every job must own a non-empty, contiguous, ascending run of candidates — otherwise it silently returns the element AT fc[i])
+            if jobs.size and not (nc.min() >= 1 and fc[0] == 0 and np.array_equal(fc[1:], fc[:-1] + nc[:-1]) and fc[-1] + nc[-1] == dx.size):
+                raise ValueError("window jobs: candidate runs must be non-empty, contiguous and in job order (first_cand / n_cand)")
             big = 1 << 20
             jw, jh, jss = jobs["width"].astype(np.int64), jobs["height"].astype(np.int64), jobs["sub_shift"].astype(np.int64)
             cols = np.maximum.reduceat(dx, fc) - np.minimum.reduceat(dx, fc) + jw
