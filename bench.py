@@ -46,6 +46,7 @@ from vvenc_amd import sharding  # noqa: E402
 from bench_common import GOP_WEIGHT, KERNEL_NAMES, LAYER_POCS, STEP_LAYERS, layer_of_step, prepare_recordings, step_of_rank  # noqa: E402,F401
 from bench_reference import ReferenceJobs, RecJob, cpu_baseline, parity_check  # noqa: E402,F401  (tests import these through bench)
 import bench_line  # noqa: E402
+import bench_mctf as BM  # noqa: E402
 
 
 # ---------------------------------------------------------------------------------------------------------------------- one replay pass (a resolution)
@@ -72,6 +73,11 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         for wl in workloads.values():
             wl.bind_lanes(lanes)
 
+    # ---- north-star leg C at the GOP's cadence (tools/bench_mctf.py): the cycle's four filtered pictures resident, issued on a SIXTH stream by the steps that replay them
+    mc = None
+    if not args.no_mctf and world == 1:
+        mc = BM.MctfCadence(hp, width, height, lane=hp.fork(torch.cuda.Stream()) if args.streams > 1 else hp)
+
     # ---- the reference-picture exchange of the sharded sequence (N > 1): ring of two reconstructed pictures (luma + 2 chroma planes with margins)
     ex = None
     if world > 1:
@@ -82,9 +88,13 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     step_no = [0]                                        # this rank's step count k; it replays position step_of_rank( k ) of the cycle
     ex_count = [0]
 
+    with_mctf = [False]
+
     def step():
         k = step_no[0]
         s = step_of_rank(k, rank, world)
+        if with_mctf[0]:
+            mc.issue_step(s)                             # (first: the filtered picture's search + filter run beside this and the following pictures' lists)
         if ex is not None:
             if k % args.exchange_every == 0 and args.exchange_every < (1 << 29):
                 e = k // args.exchange_every
@@ -136,6 +146,44 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     enq_us = sorted(1e6 * (b - a) for a, b in zip(enq[:-1], enq[1:]))
     dt = sharding.max_over_ranks(dt_local, device="cuda")
     ex_count_timed = ex_count[0] - ex_before
+
+    # ---- the same K steps WITH leg C: the steps that replay the POC-32 / 16 / 8 / 24 pictures also queue that picture's MCTF (4 / 4 / 2 / 2 motion estimations + the filter
+    #      of Y, U, V) on the sixth stream — `value_with_mctf`; and whole GOP cycles (the cadence's stable figure: 12 estimations + 4 filters per 32 steps)
+    mctf_region = None
+    if mc is not None:
+        with_mctf[0] = True
+        step_no[0] = 0
+        for _ in range(32):
+            step()
+        torch.cuda.synchronize()
+        step_no[0] = 0
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t1
+        step_no[0] = 0
+        ncyc = 3 if width <= 1920 else 2
+        t1 = time.perf_counter()
+        for _ in range(32 * ncyc):
+            step()
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t1) / ncyc
+        with_mctf[0] = False
+        # the same whole cycles WITHOUT leg C (same loop, same order): what the cadence adds to a GOP cycle
+        step_no[0] = 0
+        t1 = time.perf_counter()
+        for _ in range(32 * ncyc):
+            step()
+        torch.cuda.synchronize()
+        dtc0 = (time.perf_counter() - t1) / ncyc
+        mctf_region = {"value": steps / dtm, "ms_per_step": 1000.0 * dtm / steps, "steps": steps,
+                       "mctf_jobs_in_the_timed_steps": [BM.job_of_step(i)[1] for i in range(steps) if BM.job_of_step(i)],
+                       "gop_cycle": {"value": 32.0 / dtc, "ms_per_step": 1000.0 * dtc / 32.0, "ms_per_cycle": 1000.0 * dtc, "ms_per_cycle_without_mctf": 1000.0 * dtc0,
+                                     "value_without_mctf": 32.0 / dtc0, "cycles": ncyc,
+                                     "note": "whole GOP cycles of 32 steps in step order: 12 motion estimations (4 / 4 / 2 / 2 references) + 4 bilateral filters of Y, U, V per cycle on the sixth stream"},
+                       "note": "the timed region's K steps again with north-star leg C issued at the GOP's cadence (tools/bench_mctf.py: the steps replaying POC 32 / 16 / 8 / 24 queue that picture's "
+                               "MCTF search + filter on a sixth stream; originals of the same clip, resident); `value` is the same steps without it"}
 
     # extras (not `value`): the same K steps serialized on one stream; per layer, the multi-stream time of one picture (-> the GOP-weighted rate); N > 1: without the picture exchange
     serial = None
@@ -205,6 +253,35 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         hp.me_plan_set_timing(wl.plan, False)
         per_layer[layer] = {k: v / reps for k, v in acc.items()}
 
+    # ---- leg C per class: HIP events inside the library around every launch of a motion estimation (vvhip_mctf_set_timing) + around the three filter launches, per job, serialized;
+    #      the scored candidates and their algorithmic bytes from the library's counters (vvhip_mctf_set_stats)
+    mctf_cls = None
+    if mc is not None:
+        lane = mc.lane
+        cyc = {"MCTF_search": 0.0, "MCTF_nb": 0.0, "MCTF_fix": 0.0, "MCTF_apply": 0.0, "MCTF_rest": 0.0}
+        reps = 4
+        lane.mctf_set_timing(True)
+        for job in BM.JOBS:
+            for it in range(reps + 1):
+                mc.issue(job, apply=False)
+                t = lane.mctf_last_times()
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                st = getattr(lane, "stream", None) or torch.cuda.current_stream()
+                e[0].record(st)
+                mc.issue(job, me=False)
+                e[1].record(st)
+                torch.cuda.synchronize()
+                if it == 0:
+                    continue
+                cyc["MCTF_search"] += t[0] / reps
+                cyc["MCTF_nb"] += t[1] / reps
+                cyc["MCTF_fix"] += t[2] / reps
+                cyc["MCTF_rest"] += (t[3] + t[4]) / reps
+                cyc["MCTF_apply"] += e[0].elapsed_time(e[1]) / reps
+        lane.mctf_set_timing(False)
+        mc.count()
+        mctf_cls = cyc
+
     if rank != 0:
         return None, workloads, None
 
@@ -268,6 +345,22 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
                    **({"per_position_bytes_per_picture": int(sum(GOP_WEIGHT[l] * workloads[l].alg_bytes_int_per_position for l in per_layer) / wsum),
                        "all_candidates_bytes_per_picture": int(sum(GOP_WEIGHT[l] * workloads[l].alg_bytes_int_all_candidates for l in per_layer) / wsum)} if k == "ME_int" else {}), "ms_by_layer": {str(l): round(per_layer[l][k], 4) for l in per_layer}, "alg_bytes_per_picture": int(ab),
                    "unique_bytes_per_picture": int(ub), "nominal_alg_GBps": (ab / (ms * 1e-3) / 1e9) if ms > 0 else None}
+    if mctf_cls is not None:
+        for k in ("MCTF_search", "MCTF_nb", "MCTF_fix", "MCTF_apply"):
+            ms = mctf_cls[k] / 32.0
+            ab = mc.alg_bytes_per_cycle[k] / 32.0
+            kern[k] = {"kernel": KERNEL_NAMES[k], "avg_ms_per_picture": ms, "ms_per_gop_cycle": round(mctf_cls[k], 4), "alg_bytes_per_picture": int(ab),
+                       "unique_bytes_per_picture": int(mc.unique_bytes_per_cycle[k] / 32.0), "nominal_alg_GBps": (ab / (ms * 1e-3) / 1e9) if ms > 0 else None}
+        out["with_mctf"] = mctf_region
+        out["with_mctf"]["ms_per_gop_cycle_by_class_serialized"] = {k: round(v, 4) for k, v in mctf_cls.items()}
+        out["with_mctf"]["scored_candidates_per_gop_cycle"] = mc.candidates_per_cycle
+        out["with_mctf"]["alg_bytes_per_gop_cycle"] = mc.alg_bytes_per_cycle
+        out["with_mctf"]["per_candidate_bytes_per_gop_cycle"] = mc.per_candidate_bytes_per_cycle
+        out["with_mctf"]["alg_bytes_note"] = ("SURVEY 8d per SCORED candidate, counted by the kernels (vvhip_mctf_set_stats): integer vector 4 w h; fractional vector (w + 3)(h + 3) 2 + 2 w h "
+                                              "(4-tap search filter); the dense integer grids of a block in 8d's WINDOW form ((w + 2R)^2 2 + 2 w h per block + 8 per position: the window is "
+                                              "staged once in LDS) — per_candidate_bytes counts every grid position at 4 w h instead: a work rate (LDS-level reuse), not memory traffic; "
+                                              "filter: per block 4 w h + per reference (w + 5)(h + 5) 2 + 24")
+        out["_mctf"] = mc
     out["kernels"] = kern
     out["kernels_measured"] = "HIP events on the launch stream around every kernel (inside vvhip_me_plan_run for the plan's kernels), 8 passes per layer with the launches serialized; GOP-weighted"
     return out, workloads, kern
@@ -327,7 +420,10 @@ def main():
     if args.inner:
         pics, _ = prepare_recordings(args.width, args.height, 65, sorted(LAYER_POCS.values()))
         workloads = {layer: RecordedWorkload(hp, pics[poc], unique_bytes=False) for layer, poc in LAYER_POCS.items()}
+        mc = None if args.no_mctf else BM.MctfCadence(hp, args.width, args.height)
         for s in range(args.warmup + args.steps):
+            if mc is not None:
+                mc.issue_step(s)                         # (serialized on the same stream: the rocprofv3 passes see leg C's kernels at the GOP's cadence)
             workloads[layer_of_step(s)].run()
         torch.cuda.synchronize()
         return
@@ -344,12 +440,15 @@ def main():
     out = {"metric": "frames/sec + bit-exact vs CPU, 1080p/4K 10-bit preset=faster at 1/2/4/8 GPU", "value": core["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": core["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16", "data": "synthetic",
            "value_note": "pictures/s of the north-star hot path (recorded lists resident in HBM) — the path's throughput, NOT encoder fps; the encoder's frames/s with the device stages is e2e.hip_fps"}
+    mc = core.pop("_mctf", None)
     out.update({k: v for k, v in core.items() if k not in out})
+    if core.get("with_mctf"):
+        out["value_with_mctf"], out["ms_per_step_with_mctf"] = core["with_mctf"]["value"], core["with_mctf"]["ms_per_step"]
     if inst is not None:
         out["e2e_instances"] = inst
     can_profile = not args.no_profile and world == 1 and bool(shutil.which("rocprofv3"))
 
-    def profiled(width, height, kern_, workloads_, ms_per_step, md):
+    def profiled(width, height, kern_, workloads_, ms_per_step, md, mc_=None):
         """roofline objects of one resolution from this run's own rocprofv3 passes"""
         live = None
         res = {}
@@ -363,6 +462,8 @@ def main():
                 res["kernel_trace"] = {"error": str(e)[:300]}
         wsum = float(sum(GOP_WEIGHT.values()))
         uniq = {k: sum(GOP_WEIGHT[l] * ((workloads_[l].unique_bytes_by_kernel or {}).get(k) or 0) for l in workloads_) / wsum for k in KERNEL_NAMES}
+        if mc_ is not None:
+            uniq.update({k: v / 32.0 for k, v in mc_.unique_bytes_per_cycle.items()})
         roof, allk, checks = BP.roofline_objects(kern_, live, calib, uniq, ms_per_step, md)
         res["roofline"], res["roofline_checks"] = roof, checks
         if allk:
@@ -371,18 +472,31 @@ def main():
 
     calib = BP.counter_calibration() if can_profile else {"measured": False, "factors": {"rows16": 2.0, "stream16": 2.0, "store8": 1.0}, "how": "not run", "pattern_of_class": BP.FETCH_PATTERN}
     out["counter_calibration"] = calib
-    out.update(profiled(args.width, args.height, kern, workloads, core["ms_per_step"], args.profile_md))
+    # (with leg C's classes in the table the step time of the cross-check is the with-MCTF GOP cycle's)
+    step_ms = core["with_mctf"]["gop_cycle"]["ms_per_step"] if core.get("with_mctf") else core["ms_per_step"]
+    out.update(profiled(args.width, args.height, kern, workloads, step_ms, args.profile_md, mc))
 
     if not args.no_parity:
         try:
             out["parity"] = parity_check(workloads)
         except Exception as e:
             out["parity"] = {"status": "not checked", "error": str(e)[:300]}
+    if mc is not None and not args.no_parity:
+        try:
+            out["parity_mctf"] = mc.parity()
+        except Exception as e:
+            out["parity_mctf"] = {"status": "not checked", "error": str(e)[:300]}
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(workloads)
         except Exception as e:   # the baseline is a report, never a reason to lose the measurement
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
+        if mc is not None:
+            try:
+                out["cpu_baseline"]["mctf"] = BM.cpu_baseline_mctf(args.width, args.height, out["cpu_baseline"].get("cores") or os.cpu_count())
+            except Exception as e:
+                out["cpu_baseline"]["mctf"] = {"error": str(e)[:200]}
+    mc = None
 
     # ---- the 3840x2160 replay (BASELINE: "1080p/4K"): the same pass on lists recorded from the 4K x 65 encode
     if world == 1 and not args.no_4k and (args.width, args.height) == (1920, 1080):
@@ -392,12 +506,21 @@ def main():
             c4, w4, k4 = replay_pass(args, hp, rank, world, 3840, 2160, args.steps, max(4, args.warmup // 2))
             out["value_4k"], out["ms_per_step_4k"], out["steps_4k"] = c4["value"], c4["ms_per_step"], c4["steps"]
             out["config_4k"] = c4["config"]
-            for k in ("gop_weighted", "single_stream", "kernels"):
+            mc4 = c4.pop("_mctf", None)
+            if c4.get("with_mctf"):
+                out["value_4k_with_mctf"], out["ms_per_step_4k_with_mctf"] = c4["with_mctf"]["value"], c4["with_mctf"]["ms_per_step"]
+            for k in ("gop_weighted", "single_stream", "kernels", "with_mctf"):
                 if k in c4:
                     out[k + "_4k"] = c4[k]
             md4 = (os.path.splitext(args.profile_md)[0] + "_4k" + os.path.splitext(args.profile_md)[1]) if args.profile_md else None
-            for k, v in profiled(3840, 2160, k4, w4, c4["ms_per_step"], md4).items():
+            step_ms4 = c4["with_mctf"]["gop_cycle"]["ms_per_step"] if c4.get("with_mctf") else c4["ms_per_step"]
+            for k, v in profiled(3840, 2160, k4, w4, step_ms4, md4, mc4).items():
                 out[k + "_4k"] = v
+            if mc4 is not None and not args.no_parity:
+                try:
+                    out["parity_mctf_4k"] = mc4.parity(pocs=(8,))          # (one picture: two 3840x2160 motion estimations + its filter on the host take ~1 s)
+                except Exception as e:
+                    out["parity_mctf_4k"] = {"status": "not checked", "error": str(e)[:300]}
             if not args.no_parity:
                 try:
                     out["parity_4k"] = parity_check(w4)
@@ -408,6 +531,12 @@ def main():
                     out["cpu_baseline_4k"] = cpu_baseline(w4, passes=3)
                 except Exception as e:
                     out["cpu_baseline_4k"] = {"value": None, "sample": "failed: %r" % (e,)}
+                if mc4 is not None:
+                    try:
+                        out["cpu_baseline_4k"]["mctf"] = BM.cpu_baseline_mctf(3840, 2160, out["cpu_baseline_4k"].get("cores") or os.cpu_count())
+                    except Exception as e:
+                        out["cpu_baseline_4k"]["mctf"] = {"error": str(e)[:200]}
+            mc4 = None
             del w4
             torch.cuda.empty_cache()
         except Exception as e:

@@ -455,6 +455,30 @@ VVHIP_API int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur
                                             int unit_size, int mctf_speed, int add_level,
                                             vvhip_mv* const* d_mvs_out_host_array );
 
+/* The same call WITHOUT the host wait at its end: every launch is queued on the context's stream and the call returns (like every other entry point); results are valid
+ * once the stream has passed them.  What bench.py's sixth stream issues at the GOP's cadence while the other five run a picture's lists.  (A field whose anti-diagonals
+ * exceed a workgroup — more than 320 blocks on the shorter side: beyond 8K — takes the row hand-off with its abort flag; the call then waits like the synchronous one.)
+ * Replaces the same reference loop as above, MCTF.cpp:666-724 called per reference from MCTF::filter :779-800.                                              */
+VVHIP_API int vvhip_mctf_motion_estimation_async( vvhip_ctx* ctx, const int16_t* d_cur, const int16_t* const* d_refs_host_array,
+                                                  int n_refs, int stride, int width, int height, int pad, int bit_depth,
+                                                  int unit_size, int mctf_speed, int add_level,
+                                                  vvhip_mv* const* d_mvs_out_host_array );
+
+/* Scored-candidate counters of the MCTF search (measurement: the algorithmic bytes of SURVEY 8d are priced per SCORED candidate, and which candidates estimateLumaLn
+ * scores depends on the data — MCTF.cpp:1189-1306).  set_stats( 1 ) allocates and zeroes 18 counters and switches the counting kernel instances on, set_stats( 0 )
+ * switches them off.  get_stats copies them to the host (waits for the stream).  Three phases x 6 counters:
+ *   out[0..5]   phase A (estimateLumaLn up to the above/left tests): [0] integer candidates scored one by one, [1] their bytes (4 w h each), [2] fractional candidates,
+ *               [3] their bytes ((w + taps - 1)(h + taps - 1) 2 + 2 w h each; taps = 4 with the low-resolution search filter, 6 otherwise), [4] positions of the dense
+ *               integer grids (MCTF.cpp:1216-1228) scored out of one staged window, [5] those windows' bytes in SURVEY 8d's window form ((w + 2R)^2 2 + 2 w h per block
+ *               + 8 per position); the per-candidate figure of the grid positions is [4] x 4 w h with w = h = 32 (only full blocks take that path)
+ *   out[6..11]  the above/left candidates scored in parallel at the neighbours' phase-A vectors, out[12..17] those scored while the recurrence is resolved.        */
+VVHIP_API int vvhip_mctf_set_stats( vvhip_ctx* ctx, int on );
+/* Per-class device time of the LAST motion-estimation call of the context (measurement; HIP events on the context's stream around every launch while on):
+ * ms5 = { candidate scoring (meSearchKernel, all levels), neighbour scoring, sweep, final normalisation, everything else (pyramids, field initialisation) }.   */
+VVHIP_API int vvhip_mctf_set_timing( vvhip_ctx* ctx, int on );
+VVHIP_API int vvhip_mctf_last_times( vvhip_ctx* ctx, float* ms5 );
+VVHIP_API int vvhip_mctf_get_stats( vvhip_ctx* ctx, uint64_t* out18 );
+
 /* ======================================================================================================================
  * SURVEY 8f rank 2 — MCTF apply side: motion-compensated bilateral temporal filter of one component plane
  * (MCTF::bilateralFilter / xFinalizeBlkLine, CommonLib/MCTF.cpp:1399-1552, with applyFrac8Core_6Tap/_4Tap :259-358,

@@ -575,6 +575,16 @@ class Oracle(_Base):
     def mctf_me(self, org, ref, bit_depth=10, unit=16, speed=4, add_level=None):
         return _mctf_me(self.L.orc_mctf_me, None, org, ref, bit_depth, unit, speed, add_level)
 
+    def mctf_me_counted(self, org, ref, bit_depth=10, unit=16, speed=4, add_level=None):
+        """mctf_me + the motionErrorLuma calls it made: {int, int_bytes, frac, frac_bytes} (the reference's schedule: every call of estimateLumaLn)"""
+        self.L.orc_mctf_count_reset.restype = None
+        self.L.orc_mctf_count_get.restype = None
+        self.L.orc_mctf_count_reset()
+        res = self.mctf_me(org, ref, bit_depth, unit, speed, add_level)
+        c = np.zeros(4, np.uint64)
+        self.L.orc_mctf_count_get(_p(c))
+        return res, {"int": int(c[0]), "int_bytes": int(c[1]), "frac": int(c[2]), "frac_bytes": int(c[3])}
+
 
 def _mctf_me(fn, simd, org, ref, bit_depth, unit, speed, add_level):
     org = np.ascontiguousarray(org, np.int16)
@@ -790,6 +800,36 @@ class RefLib(_Base):
 
     def mctf_me(self, org, ref, bit_depth=10, unit=16, speed=4, add_level=None):
         return _mctf_me(self.L.vvref_mctf_me, self.simd, org, ref, bit_depth, unit, speed, add_level)
+
+    def mctf_cycle_timed(self, pictures, threads=0, bit_depth=10, qp=32, unit=16, speed=4, add_level=None):
+        """what MCTF::filter does for a list of filtered pictures — per picture every reference's motion estimation, then the bilateral filter.  threads == 0: on the calling
+        thread; threads > 0: the (picture, reference) estimations as independent jobs on that many threads, the filter on the reference's own thread pool.  Planes are set up
+        before its clocks start.  pictures: [(cur (Y, U, V), [ref (Y, U, V), ...], [ref index = |POC offset| - 1, ...], overall strength), ...]
+        -> ([final fields per reference] per picture, [filtered (Y, U, V)] per picture, (wall seconds of the motion estimations, of the filters))"""
+        h, w = pictures[0][0][0].shape
+        if add_level is None:
+            add_level = w >= 1920
+        keep_c = [np.ascontiguousarray(p, np.int16) for cur, _, _, _ in pictures for p in cur]
+        keep_r = [np.ascontiguousarray(p, np.int16) for _, refs, _, _ in pictures for r in refs for p in r]
+        cp = (C.c_void_p * len(keep_c))(*[k.ctypes.data for k in keep_c])
+        rp = (C.c_void_p * len(keep_r))(*[k.ctypes.data for k in keep_r])
+        nrefs = np.array([len(refs) for _, refs, _, _ in pictures], np.int32)
+        idx = np.array([i for _, _, ri, _ in pictures for i in ri], np.int32)
+        strength = np.array([s for _, _, _, s in pictures], np.float64)
+        wb, hb = (w + unit - 1) // unit, (h + unit - 1) // unit
+        fields = [np.zeros(wb * hb, MV_DTYPE) for _ in range(int(nrefs.sum()))]
+        fp = (C.c_void_p * len(fields))(*[f.ctypes.data for f in fields])
+        outs = [np.zeros_like(p, dtype=np.int16) for p in keep_c]
+        outp = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        secs = np.zeros(2, np.float64)
+        rc = self.L.vvref_mctf_cycle_timed(self.simd, w, h, bit_depth, qp, unit, speed, int(bool(add_level)), int(threads), len(pictures), cp, _p(nrefs), rp, _p(idx), _p(strength),
+                                           fp, outp, _p(secs))
+        assert rc == 0
+        f_by_pic, k = [], 0
+        for n in nrefs:
+            f_by_pic.append([f.reshape(hb, wb) for f in fields[k:k + int(n)]])
+            k += int(n)
+        return f_by_pic, [tuple(outs[3 * i:3 * i + 3]) for i in range(len(pictures))], (float(secs[0]), float(secs[1]))
 
 
 def _aligned(a, align=64):

@@ -58,6 +58,7 @@
 #include "CommonLib/TrQuant_EMT.h"
 #include "CommonLib/Quant.h"
 #include "CommonLib/MCTF.h"
+#include "Utilities/NoMallocThreadPool.h"
 #include "CommonLib/Rom.h"
 #include "CommonLib/ContextModelling.h"
 #include "CommonLib/Picture.h"
@@ -631,6 +632,111 @@ API int vvref_mctf_bilateral( int simd, int width, int height, int bitDepth, int
   {
     CPelBuf b = newPic.bufs[c];
     for( int r = 0; r < ( int ) b.height; r++ ) memcpy( out[c] + ( size_t ) r * b.width, b.buf + r * b.stride, sizeof( int16_t ) * b.width );
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CPU baseline of north-star leg C (bench.py cpu_baseline.mctf, kind "reference"): what MCTF::filter does for the filtered pictures of a GOP cycle (MCTF.cpp:726-870 without
+// the adaptive extra references): per picture its pyramid, motionEstimationMCTF of every reference (:666-724: the reference picture's pyramid + the five levels) and
+// bilateralFilter (:1489-1552) on 4:2:0 planes.  threads == 0: everything on the calling thread.  threads > 0: the (picture, reference) motion estimations are independent
+// jobs on `threads` host threads (each runs the reference's single-threaded row loop, :1388-1396 — its pool's row tasks busy-wait on the row above, which loses on a shared
+// host), the filter runs on the reference's OWN thread pool (NoMallocThreadPool: block rows are its tasks, :1504-1543).  Planes are allocated and filled before the clocks
+// start (the encoder holds them already).  secs[0] = wall time of the pyramids + all motion estimations, secs[1] = of the filters.
+// cur: 3 planes per picture; refs / refIndex / finals: per reference, pictures concatenated (numRefs[p] each); out: 3 planes per picture.  finals / out entries may be null.
+// ---------------------------------------------------------------------------------------------
+API int vvref_mctf_cycle_timed( int simd, int width, int height, int bitDepth, int qp, int unitSize, int mctfSpeed, int addLevel, int threads, int numPics,
+                                const int16_t* const* cur, const int* numRefs, const int16_t* const* refs, const int* refIndex, const double* overallStrength,
+                                MvOut* const* finals, int16_t* const* out, double* secs )
+{
+  MCTF m( simd != 0 );
+  VVEncCfg cfg;
+  vvenc_init_default( &cfg, width, height, 30, 0, qp, VVENC_FASTER );
+  cfg.m_internalBitDepth[0] = cfg.m_internalBitDepth[1] = bitDepth;
+  cfg.m_internChromaFormat = VVENC_CHROMA_420;
+  cfg.m_QP = qp;
+  cfg.m_picReordering = true;
+  m.m_encCfg = &cfg;
+  m.m_threadPool = nullptr;
+  m.m_area = Area( 0, 0, width, height );
+  m.m_lowResFltSearch = mctfSpeed > 0;                                        // MCTF.cpp:598
+  m.m_searchPttrn     = mctfSpeed > 0 ? ( mctfSpeed >= 3 ? 2 : 1 ) : 0;       // MCTF.cpp:599
+  m.m_mctfUnitSize    = unitSize;
+  m.m_lowResFltApply  = false;                                                // MCTF.h:190 (never set by the encoder)
+
+  struct Pic { PelStorage org, newPic, o2, o4, o8; std::deque<TemporalFilterSourcePicInfo> infos; int firstRef; };
+  std::vector<Pic> pics( numPics );
+  const int wB = ( width + unitSize - 1 ) / unitSize, hB = ( height + unitSize - 1 ) / unitSize;
+  std::vector<std::pair<int, int>> jobs;                                       // (picture, reference of the picture)
+  int rTotal = 0;
+  for( int p = 0; p < numPics; p++ )
+  {
+    Pic& P = pics[p];
+    P.firstRef = rTotal;
+    fillYuv( P.org, cur + 3 * p, width, height );
+    P.newPic.create( CHROMA_420, Area( 0, 0, width, height ), 0, MCTF_PADDING );
+    for( int i = 0; i < numRefs[p]; i++, rTotal++ )
+    {
+      P.infos.emplace_back();
+      fillYuv( P.infos.back().picBuffer, refs + 3 * rTotal, width, height );
+      P.infos.back().mvs.allocate( wB, hB );
+      P.infos.back().index = refIndex[rTotal];
+      jobs.emplace_back( p, i );
+    }
+  }
+  auto pyramid = [&]( int p ) { Pic& P = pics[p]; m.subsampleLuma( P.org, P.o2 ); m.subsampleLuma( P.o2, P.o4 ); if( addLevel ) m.subsampleLuma( P.o4, P.o8 ); };
+  auto estimate = [&]( int j )                                                // MCTF.cpp:666-707 for one (picture, reference)
+  {
+    Pic& P = pics[jobs[j].first];
+    TemporalFilterSourcePicInfo& s = P.infos[jobs[j].second];
+    PelStorage b2, b4, b8;
+    m.subsampleLuma( s.picBuffer, b2 ); m.subsampleLuma( b2, b4 );
+    if( addLevel ) m.subsampleLuma( b4, b8 );
+    Array2D<MotionVector> mv_m( width / ( unitSize * 16 ) + 1, height / ( unitSize * 16 ) + 1 );
+    Array2D<MotionVector> mv_0( width / ( unitSize * 8 ) + 1, height / ( unitSize * 8 ) + 1 );
+    Array2D<MotionVector> mv_1( width / ( unitSize * 4 ) + 1, height / ( unitSize * 4 ) + 1 );
+    Array2D<MotionVector> mv_2( width / ( unitSize * 2 ) + 1, height / ( unitSize * 2 ) + 1 );
+    if( addLevel )
+    {
+      m.motionEstimationLuma( mv_m, P.o8, b8, 2 * unitSize );
+      m.motionEstimationLuma( mv_0, P.o4, b4, 2 * unitSize, &mv_m, 2 );
+    }
+    else m.motionEstimationLuma( mv_0, P.o4, b4, 2 * unitSize );
+    m.motionEstimationLuma( mv_1, P.o2, b2, 2 * unitSize, &mv_0, 2 );
+    m.motionEstimationLuma( mv_2, P.org, s.picBuffer, 2 * unitSize, &mv_1, 2 );
+    m.motionEstimationLuma( s.mvs, P.org, s.picBuffer, unitSize, &mv_2, 1, true );
+  };
+  auto spread = [&]( int n, const std::function<void( int )>& f )
+  {
+    if( threads <= 0 ) { for( int i = 0; i < n; i++ ) f( i ); return; }
+    std::atomic<int> next( 0 );
+    std::vector<std::thread> th;
+    for( int t = 0; t < std::min( threads, n ); t++ ) th.emplace_back( [&]{ for( int i; ( i = next.fetch_add( 1 ) ) < n; ) f( i ); } );
+    for( auto& t : th ) t.join();
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  spread( numPics, pyramid );
+  spread( ( int ) jobs.size(), estimate );
+  const auto t1 = std::chrono::steady_clock::now();
+  {
+    std::unique_ptr<NoMallocThreadPool> pool;
+    if( threads > 0 ) pool.reset( new NoMallocThreadPool( threads, "mctf", &cfg ) );
+    m.m_threadPool = pool.get();
+    for( int p = 0; p < numPics; p++ ) m.bilateralFilter( pics[p].org, pics[p].infos, pics[p].newPic, overallStrength[p] );
+    m.m_threadPool = nullptr;
+  }
+  const auto t2 = std::chrono::steady_clock::now();
+  secs[0] = std::chrono::duration<double>( t1 - t0 ).count();
+  secs[1] = std::chrono::duration<double>( t2 - t1 ).count();
+  for( int p = 0; p < numPics; p++ )
+  {
+    for( int i = 0; i < numRefs[p]; i++ ) if( finals && finals[pics[p].firstRef + i] ) dumpMvs( pics[p].infos[i].mvs, finals[pics[p].firstRef + i] );
+    for( int c = 0; c < 3; c++ )
+      if( out && out[3 * p + c] )
+      {
+        CPelBuf b = pics[p].newPic.bufs[c];
+        for( int r = 0; r < ( int ) b.height; r++ ) memcpy( out[3 * p + c] + ( size_t ) r * b.width, b.buf + r * b.stride, sizeof( int16_t ) * b.width );
+      }
   }
   return 0;
 }

@@ -652,6 +652,13 @@ void orc_mctf_subsample(const int16_t *src, int srcStride, int w, int h, int16_t
         }
 }
 
+/* Calls of motionErrorLuma since the last reset and their algorithmic bytes: { integer-vector calls, 4 w h each, fractional-vector calls,
+ * (w + taps - 1)(h + taps - 1) 2 + 2 w h each }.  The REFERENCE's schedule (every call estimateLumaLn makes, MCTF.cpp:1189-1306): the upper bound the device library's
+ * own scored-candidate counters (vvhip_mctf_get_stats) are checked against in tests/ — the device skips candidates that cannot win.  Not thread-safe (tests only). */
+static uint64_t g_mctf_calls[4];
+void orc_mctf_count_reset(void) { g_mctf_calls[0] = g_mctf_calls[1] = g_mctf_calls[2] = g_mctf_calls[3] = 0; }
+void orc_mctf_count_get(uint64_t *out4) { for (int i = 0; i < 4; i++) out4[i] = g_mctf_calls[i]; }
+
 /* MCTF::motionErrorLuma, MCTF.cpp:1099-1164. */
 static int me_error(const plane_t *org, const plane_t *ref, int x, int y, int dx, int dy, int bs,
                     int lowRes, int bitDepth)
@@ -660,6 +667,8 @@ static int me_error(const plane_t *org, const plane_t *ref, int x, int y, int dx
     int w = bs < org->w - x ? bs : org->w - x; w &= ~7;
     int h = bs < org->h - y ? bs : org->h - y; h &= ~7;
     const int16_t *o = org->buf + x + (ptrdiff_t)y * org->stride;
+    if ((fx | fy) == 0) { g_mctf_calls[0]++; g_mctf_calls[1] += (uint64_t)(4 * w * h); }
+    else { const int t = lowRes ? 3 : 5; g_mctf_calls[2]++; g_mctf_calls[3] += (uint64_t)((w + t) * (h + t) * 2 + 2 * w * h); }
     if ((fx | fy) == 0) {
         dx /= 16; dy /= 16;          /* C division: both are exact multiples here */
         return orc_mctf_err_int(o, org->stride, ref->buf + x + dx + (ptrdiff_t)(y + dy) * ref->stride, ref->stride, w, h);

@@ -61,6 +61,9 @@ void   orc_extend_border(int16_t *buf, int stride, int w, int h, int pad);
 void   orc_mctf_subsample(const int16_t *src, int srcStride, int w, int h, int16_t *dst, int dstStride);
 int    orc_mctf_me(const int16_t *orgLuma, const int16_t *refLuma, int width, int height, int bitDepth, int unitSize,
                    int mctfSpeed, int addLevel, orc_mv_t **levelOut, int *levelDims);
+/* motionErrorLuma calls of orc_mctf_me since the last reset: { integer calls, their bytes (4 w h), fractional calls, their bytes } (the reference's schedule, MCTF.cpp:1189-1306) */
+void   orc_mctf_count_reset(void);
+void   orc_mctf_count_get(uint64_t *out4);
 
 /* sub-pel interpolation (InterpolationFilter.cpp) */
 int  orc_if_coeff(int set, int phase, int16_t coeff[8]);

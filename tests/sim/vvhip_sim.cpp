@@ -391,6 +391,14 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* cur, const int1
   }
   return VVHIP_OK;
 }
+int vvhip_mctf_motion_estimation_async( vvhip_ctx* ctx, const int16_t* cur, const int16_t* const* refs, int nRefs, int stride, int w, int h, int pad, int bd, int unit, int speed, int addLevel, vvhip_mv* const* outs )
+{
+  return vvhip_mctf_motion_estimation( ctx, cur, refs, nRefs, stride, w, h, pad, bd, unit, speed, addLevel, outs );      // (the test double has no streams: every call is complete on return)
+}
+int vvhip_mctf_set_stats( vvhip_ctx* ctx, int ) { UNSUPPORTED( "vvhip_mctf_set_stats" ); }
+int vvhip_mctf_get_stats( vvhip_ctx* ctx, uint64_t* ) { UNSUPPORTED( "vvhip_mctf_get_stats" ); }
+int vvhip_mctf_set_timing( vvhip_ctx* ctx, int ) { UNSUPPORTED( "vvhip_mctf_set_timing" ); }
+int vvhip_mctf_last_times( vvhip_ctx* ctx, float* ) { UNSUPPORTED( "vvhip_mctf_last_times" ); }
 int vvhip_mctf_filter_params( int qp, int bd, double strength, int chroma, double* sigmaSq, double* weightScaling )
 {
   const double lumaSigmaSq = 9.0 * ( 128.0 + 3.0 / 256.0 * qp * qp * qp ), chromaSigmaSq = 30 * 30;       // MCTF.cpp:1491-1492 (m_sigmaMultiplier 9)

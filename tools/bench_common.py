@@ -5,7 +5,10 @@ import time
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 CLOCK_GHZ, N_CU, N_SIMD = 2.4, 256, 1024
 LAYER_POCS = {0: 31, 1: 15, 2: 23, 3: 3, 4: 5, 5: 2}          # one recorded picture per temporal layer of the 65-frame encode (its GOP anchors at POC 31 / 63)
-KERNEL_NAMES = {"ME_stage": "meStageKernel", "ME_int": "meIntKernel", "ME_item": "meItemKernel", "TU": "tuMxMultiKernel", "DMVR": "dmvrRefineKernel"}
+KERNEL_NAMES = {"ME_stage": "meStageKernel", "ME_int": "meIntKernel", "ME_item": "meItemKernel", "TU": "tuMxMultiKernel", "DMVR": "dmvrRefineKernel",
+                # north-star leg C (MCTF, tools/bench_mctf.py): candidate scoring of estimateLumaLn, the above / left candidates scored in parallel, the resolution of the above / left recurrence, the bilateral filter
+                "MCTF_search": "meSearchKernel", "MCTF_nb": "meNeighbourKernel", "MCTF_fix": "meFixKernel", "MCTF_apply": "mctfApplyKernel"}
+STEP_CLASSES = ("ME_stage", "ME_int", "ME_item", "TU", "DMVR")      # the classes of `value`'s step (legs A + B); the MCTF classes join the table when leg C runs at the GOP's cadence
 
 
 # The replay order of the 32 pictures of a GOP cycle (1 x TL0, 1 x TL1, 2 x TL2, 4 x TL3, 8 x TL4, 16 x TL5): a low-discrepancy interleaving, NOT the coding order — the recorded

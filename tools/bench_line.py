@@ -59,7 +59,7 @@ def _e2e(e):
 
 def compact(out, detail_path):
     """the driver-facing line from the full result object `out` (see bench.py's docstring for the objects)"""
-    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line = _pick(out, ("metric", "value", "value_with_mctf", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_with_mctf", "higher_is_better", "scaling"))
     line["vs_baseline"] = out.get("vs_baseline")
     line.update(_pick(out, ("dtype", "data")))
     cfg = out.get("config", {})
@@ -74,16 +74,26 @@ def compact(out, detail_path):
         cb = out["cpu_baseline"]
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "passes", "value_fastest_passes", "value_slowest_passes", "value_1thread", "loadavg_before_after"))
         line["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:420]
+        if isinstance(cb.get("mctf"), dict):
+            line["cpu_baseline"]["mctf"] = _pick(cb["mctf"], ("value", "value_1thread", "unit", "cores", "kind", "error", "skipped"))
     if "parity" in out:
         p = out["parity"]
         line["parity"] = _pick(p, ("status", "mismatches", "error"))
         if isinstance(p.get("checked"), dict):
             line["parity"]["checked"] = p["checked"]
+    if isinstance(out.get("parity_mctf"), dict):
+        line["parity_mctf"] = _pick(out["parity_mctf"], ("status", "fields", "field_mismatches", "planes", "plane_mismatches", "error"))
     for k in ("gop_weighted", "single_stream"):
         if k in out:
             line[k] = _pick(out[k], ("value", "ms_per_step"))
+    if isinstance(out.get("with_mctf"), dict) and isinstance(out["with_mctf"].get("gop_cycle"), dict):
+        line["gop_cycle_with_mctf"] = _pick(out["with_mctf"]["gop_cycle"], ("value", "value_without_mctf", "ms_per_cycle", "ms_per_cycle_without_mctf"))
     # ---- 3840x2160
-    line.update(_pick(out, ("value_4k", "ms_per_step_4k", "error_4k")))
+    line.update(_pick(out, ("value_4k", "value_4k_with_mctf", "ms_per_step_4k", "ms_per_step_4k_with_mctf", "error_4k")))
+    if isinstance(out.get("with_mctf_4k"), dict) and isinstance(out["with_mctf_4k"].get("gop_cycle"), dict):
+        line["gop_cycle_with_mctf_4k"] = _pick(out["with_mctf_4k"]["gop_cycle"], ("value", "value_without_mctf"))
+    if isinstance(out.get("parity_mctf_4k"), dict):
+        line["parity_mctf_4k"] = _pick(out["parity_mctf_4k"], ("status", "error"))
     if "roofline_4k" in out:
         line["roofline_4k"] = _roof(out["roofline_4k"], ROOF_4K_KEYS, out.get("roofline_checks_4k"))
         line["roofline_4k"].pop("basis", None)
@@ -93,6 +103,8 @@ def compact(out, detail_path):
         line["parity_4k"] = _pick(out["parity_4k"], ("status", "mismatches", "error"))
     if "cpu_baseline_4k" in out:
         line["cpu_baseline_4k"] = _pick(out["cpu_baseline_4k"], ("value", "cores", "value_1thread"))
+        if isinstance(out["cpu_baseline_4k"].get("mctf"), dict):
+            line["cpu_baseline_4k"]["mctf"] = _pick(out["cpu_baseline_4k"]["mctf"], ("value", "value_1thread"))
     # ---- the other legs
     m3 = out.get("config3_medium_4k")
     if isinstance(m3, dict):

@@ -75,7 +75,8 @@ def live_profile(width, height, counters=ALL_COUNTERS):
 
 
 # which calibration pattern (tools/calib/fetch_calib.hip) a kernel class's reads look like: per-lane 16-byte row gathers out of picture planes, or streams of compact blocks
-FETCH_PATTERN = {"ME_stage": "rows16", "ME_int": "rows16", "ME_item": "rows16", "DMVR": "rows16", "TU": "stream16"}
+FETCH_PATTERN = {"ME_stage": "rows16", "ME_int": "rows16", "ME_item": "rows16", "DMVR": "rows16", "TU": "stream16",
+                 "MCTF_search": "rows16", "MCTF_nb": "rows16", "MCTF_fix": "rows16", "MCTF_apply": "rows16"}
 
 
 def counter_calibration():
@@ -95,7 +96,7 @@ def counter_calibration():
 
 
 BASIS_ALG = ("achieved = ALGORITHMIC bytes of one launch (SURVEY 8d per batch unit: integer windows = a job's window read once + its block + 8 B per distinct position; sub-pel stages = "
-             "(w+taps)(h+taps) 2 + 2 w h + 8 per scored position; table calls 4 w h + 8; TUs 6 w h + 24) / the launch's average duration in this run's rocprofv3 kernel trace; frac = achieved / 8 TB/s")
+             "(w+taps)(h+taps) 2 + 2 w h + 8 per scored position; table calls 4 w h + 8; TUs 6 w h + 24; MCTF per SCORED candidate (counted by the kernels): integer 4 w h, fractional (w+3)(h+3) 2 + 2 w h) / the launch's average duration in this run's rocprofv3 kernel trace; frac = achieved / 8 TB/s")
 BASIS_REUSE = "reuse (LDS/L1) — not an HBM fraction"
 
 

@@ -23,6 +23,12 @@ struct vvhip_ctx
   // scratch for vvhip_mctf_motion_estimation (grown on demand)
   void*        d_scratch  = nullptr;
   size_t       scratchBytes = 0;
+  // optional per-class events of the last vvhip_mctf_motion_estimation[_async] call (vvhip_mctf_set_timing): tag 0 call start, 1 before a level's candidate scoring, 2 after it,
+  // 3 after the neighbour scoring, 4 after the sweep, 5 after the final normalisation, 6 call end
+  bool         mctfTiming = false;
+  std::vector<hipEvent_t> mctfEv;
+  std::vector<int> mctfEvTag;
+  unsigned long long* d_mctfStats = nullptr;   // scored-candidate counters of the MCTF search (vvhip_mctf_set_stats): 12 x uint64, null = off
   // scratch of vvhip_subpel_dist_batch: predicted blocks + distortion items (grown on demand)
   void*        d_subpel   = nullptr;
   size_t       subpelBytes = 0;

@@ -250,6 +250,8 @@ void vvhip_destroy( vvhip_ctx* ctx )
   if( ctx->d_tuGen ) ( void ) hipFree( ctx->d_tuGen );
   if( ctx->syncEvent ) ( void ) hipEventDestroy( ctx->syncEvent );
   if( ctx->tuGenEvent ) ( void ) hipEventDestroy( ctx->tuGenEvent );
+  if( ctx->d_mctfStats ) ( void ) hipFree( ctx->d_mctfStats );
+  for( hipEvent_t e : ctx->mctfEv ) ( void ) hipEventDestroy( e );
   if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );
   delete ctx;
 }

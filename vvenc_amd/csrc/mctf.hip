@@ -224,15 +224,21 @@ __device__ __forceinline__ int errInt32( const Org32& O, const int16_t* c, int c
 // A candidate equal to the current best vector cannot win (same error, the update needs a strictly smaller one): it is not evaluated.
 #define ME_TRY( DX, DY ) do { const int dx_ = ( DX ), dy_ = ( DY );                                                              \
                               if( bestE == 0x7fffffff || dx_ != bestX || dy_ != bestY ) {                                       \
+                                ME_COUNT( dx_, dy_ );                                                                            \
                                 const int e_ = ME_ERROR( dx_, dy_ );                                                             \
                                 if( e_ < bestE ) { bestX = dx_; bestY = dy_; bestE = e_; } } } while( 0 )
 #define ME_ERROR( DX, DY ) meError( g, bx, by, ( DX ), ( DY ), sTmp, lane )
+// scored candidates, counted the way SURVEY 8d prices them: a vector with both phases zero is an integer candidate (4 w h bytes), any other a fractional one
+// ((w + taps - 1)(h + taps - 1) 2 + 2 w h bytes).  Only the STATS instances count (vvhip_mctf_set_stats); everywhere else the macro is empty.
+#define ME_COUNT( DX, DY )
+struct MeCount { int nInt, nFrac, nGrid, gridBytes; };      // nGrid: positions of a dense integer grid scored out of one staged window; gridBytes: that window + the block, read once
 
 // One refinement ring of estimateLumaLn's final level (MCTF.cpp:1229-1288): the 8 positions (cx + x2, cy + y2), x2, y2 in {-a, 0, a} without the centre, tested in the
 // reference's order (y2 outer, x2 inner) with its strict-< update.  The three x positions share their horizontal passes: one pass per x position over the rows any of its
 // y positions needs, then a vertical pass + error per candidate (3 horizontal + 8 vertical passes instead of 8 + 8).  Same integers as motionErrorLumaFrac4 per candidate
 // (an integer position through the filters is the identity: row 0 of the filter table is {0,64,0,0} and samples are already inside the clipping range).
-__device__ __forceinline__ void meRing3( const MeGeom& g, int bx, int by, int cx, int cy, int a, int& bestX, int& bestY, int& bestE, int16_t* sTmp, int lane )
+template<bool STATS>
+__device__ __forceinline__ void meRing3( const MeGeom& g, int bx, int by, int cx, int cy, int a, int& bestX, int& bestY, int& bestE, int16_t* sTmp, int lane, MeCount& cnt )
 {
   const int w = min( g.bs, g.width - bx ) & ~7, h = min( g.bs, g.height - by ) & ~7;
   const bool shared = g.lowRes && ( w == 8 || w == 16 ) && h <= 16;
@@ -243,7 +249,11 @@ __device__ __forceinline__ void meRing3( const MeGeom& g, int bx, int by, int cx
         if( x2 || y2 )
         {
           const int dx_ = cx + x2, dy_ = cy + y2;
-          if( dx_ != bestX || dy_ != bestY ) { const int e_ = meError( g, bx, by, dx_, dy_, sTmp, lane ); if( e_ < bestE ) { bestX = dx_; bestY = dy_; bestE = e_; } }
+          if( dx_ != bestX || dy_ != bestY )
+          {
+            if( STATS ) { if( ( ( dx_ | dy_ ) & 15 ) == 0 ) cnt.nInt++; else cnt.nFrac++; }
+            const int e_ = meError( g, bx, by, dx_, dy_, sTmp, lane ); if( e_ < bestE ) { bestX = dx_; bestY = dy_; bestE = e_; }
+          }
         }
     return;
   }
@@ -265,6 +275,7 @@ __device__ __forceinline__ void meRing3( const MeGeom& g, int bx, int by, int cx
       if( v == 1 && y2 == 0 ) continue;
       const int X = cx + ( v - 1 ) * a;
       if( X == bestX && Y == bestY ) continue;
+      if( STATS ) { if( ( ( X | Y ) & 15 ) == 0 ) cnt.nInt++; else cnt.nFrac++; }
       const int e_ = waveSum( verError4( o, g.orgStride, sTmp + v * region + ro * w, w, h, Y & 15, g.maxVal, lane ) );
       if( e_ < bestE ) { bestX = X; bestY = Y; bestE = e_; }
     }
@@ -272,10 +283,53 @@ __device__ __forceinline__ void meRing3( const MeGeom& g, int bx, int by, int cx
   ME_WAVE_SYNC();                                // sTmp is reused by the next ring / candidate
 }
 
-// ---- phase A -------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__( 64 )
-meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int factor, int doubleRes, int searchPttrn, int mvsW )
+// ---- phase B as a fixed-point iteration (round 6) -------------------------------------------------------------------------------------------------
+// The above / left tests make block (x, y) depend on the FINAL vectors of (x, y-1) and (x-1, y): final( b ) = f( phaseA( b ), final( up ).vec, final( left ).vec ), a recurrence
+// over a DAG with ONE solution.  The sweep walks it in topological order (nbx + nby - 1 dependent steps per level, one workgroup per reference: 230 us of a 1080p picture's
+// 690 with the rest of the device idle).  Measured on the BASELINE clips, the recurrence hardly ever fires: 3..9 of 8 160 blocks change on the final level, chains of <= 3
+// blocks.  So the solution is reached from the other side:
+//   iteration 0   every block in parallel (inside meNeighbourKernel, which already holds everything needed): f( phaseA( b ), phaseA( up ).vec, phaseA( left ).vec ) — exact
+//                 for every block whose neighbours keep their phase-A vectors; blocks whose result differs from their phase-A vector go to a list
+//   iteration k   (meFixKernel, one workgroup per reference) only the right / lower neighbours of the blocks that changed in iteration k-1 are evaluated again with their
+//                 neighbours' current vectors; a block that changes goes to the next list.  Ends when a list is empty.
+// Chaotic iteration over a DAG converges to its unique solution whatever the order (by induction over the topological order: a block is evaluated again after the last
+// change of each predecessor), so the fields are the sweep's — and the reference's — bit for bit.  Vectors are read and written as ONE 8-byte word; a block that reads a
+// neighbour just before it changes is evaluated again in the next iteration (the neighbour is in that iteration's list).
+__device__ __attribute__( ( noinline ) ) int meErrorCall( const MeGeom* g, int x, int y, int dx, int dy, int16_t* sTmp, int lane );      // (defined with the sweep kernel)
+struct FixRec { int ownX, ownY, ownE, eU, eL, upX, upY, leftX, leftY; };                         // 36 bytes per block
+struct FixLists { int* list[3]; int* stamp; int* count; };                                      // per reference: 3 x blocks ints, blocks ints, 4 ints (count[0] = blocks changed in iteration 0)
+constexpr int ME_FIX_THREADS = 1024;
+
+// f( own; vU, vL ) with the errors a record knows; `need` (out): 0 = resolved, 1 = vU has to be scored, 2 = vL has to be scored (then call again with the score)
+struct FixBest { int x, y, e; };
+__device__ __forceinline__ int fixKnown( const FixRec& r, int vx, int vy, int e1x, int e1y, int e1 )
 {
+  if( vx == r.ownX && vy == r.ownY ) return r.ownE;
+  if( r.eU >= 0 && vx == r.upX && vy == r.upY ) return r.eU;
+  if( r.eL >= 0 && vx == r.leftX && vy == r.leftY ) return r.eL;
+  if( e1 >= 0 && vx == e1x && vy == e1y ) return e1;
+  return -1;
+}
+
+
+// ---- phase A -------------------------------------------------------------------------------------------------------------
+#undef ME_COUNT
+#define ME_COUNT( DX, DY ) do { if( STATS ) { if( ( ( ( DX ) | ( DY ) ) & 15 ) == 0 ) cnt.nInt++; else cnt.nFrac++; } } while( 0 )
+// scored-candidate counters of one launch class: { integer candidates, their algorithmic bytes, fractional candidates, their algorithmic bytes }
+__device__ __forceinline__ void meCountFlush( unsigned long long* st, const MeCount& cnt, const MeGeom& g, int bx, int by, int lane )
+{
+  if( lane != 0 || !st ) return;
+  const int w = min( g.bs, g.width - bx ) & ~7, h = min( g.bs, g.height - by ) & ~7, t = g.lowRes ? 3 : 5;
+  if( cnt.nInt )  { atomicAdd( st + 0, ( unsigned long long ) cnt.nInt );  atomicAdd( st + 1, ( unsigned long long ) cnt.nInt * ( unsigned long long ) ( 4 * w * h ) ); }
+  if( cnt.nFrac ) { atomicAdd( st + 2, ( unsigned long long ) cnt.nFrac ); atomicAdd( st + 3, ( unsigned long long ) cnt.nFrac * ( unsigned long long ) ( ( w + t ) * ( h + t ) * 2 + 2 * w * h ) ); }
+  if( cnt.nGrid ) { atomicAdd( st + 4, ( unsigned long long ) cnt.nGrid ); atomicAdd( st + 5, ( unsigned long long ) cnt.gridBytes ); }
+}
+
+template<bool STATS>
+__global__ void __launch_bounds__( 64 )
+meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int factor, int doubleRes, int searchPttrn, int mvsW, unsigned long long* stats, int fixBlocks )
+{
+  MeCount cnt = { 0, 0, 0, 0 };
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[48 * 52];      // the integer-grid window of a 32 x 32 block with range 8 (48 rows, pitch 50); > ( 32 + 5 ) * 32 of the sub-pel passes
   const int lane = threadIdx.x;
   g.buf = R.buf[blockIdx.y];
@@ -361,6 +415,9 @@ meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int fac
           if( e_ < bestE ) { bestX = ( gx0 + gx ) * 16; bestY = ( gy0 + gy ) * 16; bestE = e_; }
         }
       }
+      // (SURVEY 8d's window form: "(w + 2R)(h + 2R) 2 + w h 2 bytes per block for (2R + 1)^2 candidates" + 8 per position; the per-candidate figure 4 w h each is reported
+      //  next to it as a work rate: st[4] x 4 w h)
+      if( STATS ) { const int per = 2 * range / d + 1; cnt.nGrid += per * per; cnt.gridBytes += W * W * 2 + 32 * 32 * 2 + 8 * per * per; }
       ME_WAVE_SYNC();                                                         // sTmp is reused by the refinement rings
     }
     else
@@ -372,25 +429,34 @@ meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int fac
   {
     int pbx = bestX, pby = bestY;
     const int dr = searchPttrn ? 6 : 12, d1 = searchPttrn == 2 ? 6 : 4;
-    if( d1 == dr ) meRing3( g, bx, by, pbx, pby, dr, bestX, bestY, bestE, sTmp, lane );      // the 3 x 3 ring of search pattern 2
+    if( d1 == dr ) meRing3<STATS>( g, bx, by, pbx, pby, dr, bestX, bestY, bestE, sTmp, lane, cnt );      // the 3 x 3 ring of search pattern 2
     else
       for( int y2 = -dr; y2 <= dr; y2 += d1 )
         for( int x2 = -dr; x2 <= dr; x2 += d1 )
           if( x2 || y2 ) ME_TRY( pbx + x2, pby + y2 );
     pbx = bestX; pby = bestY;
-    meRing3( g, bx, by, pbx, pby, 2, bestX, bestY, bestE, sTmp, lane );
+    meRing3<STATS>( g, bx, by, pbx, pby, 2, bestX, bestY, bestE, sTmp, lane, cnt );
     pbx = bestX; pby = bestY;
-    meRing3( g, bx, by, pbx, pby, 1, bestX, bestY, bestE, sTmp, lane );
+    meRing3<STATS>( g, bx, by, pbx, pby, 1, bestX, bestY, bestE, sTmp, lane, cnt );
   }
   if( lane == 0 )
   {
     vvhip_mv& m = mvs[byi * mvsW + bxi];
     m.x = bestX; m.y = bestY; m.error = bestE;
+    if( fixBlocks )      // the fixed-point form of phase B: this block's stamp and (first block) the changed-block count start at zero — no separate clearing launch
+    {
+      int* lists = reinterpret_cast<int*>( reinterpret_cast<char*>( R.gran[blockIdx.y] ) + ( size_t ) fixBlocks * sizeof( FixRec ) );
+      lists[3 * ( size_t ) fixBlocks + blk] = 0;
+      if( blk == 0 ) lists[4 * ( size_t ) fixBlocks] = 0;
+    }
   }
+  if( STATS ) meCountFlush( stats, cnt, g, bx, by, lane );
 }
 
 #undef ME_ERROR
 #define ME_ERROR( DX, DY ) meError( g, bx, by, ( DX ), ( DY ), sTmp, lane )
+#undef ME_COUNT
+#define ME_COUNT( DX, DY )
 
 // ---- phase B -------------------------------------------------------------------------------------------------------------
 // granule = { tag (hi 32) , x (bits 16..31), y (bits 0..15) }; tag == 1 marks "final"
@@ -449,8 +515,9 @@ meWavefrontKernel( MeGeom g, const MeRefs R, int nbx, int mvsW, int* abortFlag )
 struct NbRec { int eU, eL, upX, upY, leftX, leftY; };      // e < 0: not scored (the vector equals one whose error is known)
 
 __global__ void __launch_bounds__( 64 )
-meNeighbourKernel( MeGeom g, const MeRefs R, int nbx, int mvsW )
+meNeighbourKernel( MeGeom g, const MeRefs R, int nbx, int mvsW, unsigned long long* stats, int fix, int nBlocks )
 {
+  MeCount cnt = { 0, 0, 0, 0 };
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[( 32 + 5 ) * 32];
   const int lane = threadIdx.x;
   g.buf = R.buf[blockIdx.y];
@@ -464,15 +531,156 @@ meNeighbourKernel( MeGeom g, const MeRefs R, int nbx, int mvsW )
   {
     const vvhip_mv up = mvs[( byi - 1 ) * mvsW + bxi];
     r.upX = up.x; r.upY = up.y;
-    if( up.x != own.x || up.y != own.y ) r.eU = meError( g, bx, by, up.x, up.y, sTmp, lane );
+    if( up.x != own.x || up.y != own.y ) { r.eU = meError( g, bx, by, up.x, up.y, sTmp, lane ); if( ( ( up.x | up.y ) & 15 ) == 0 ) cnt.nInt++; else cnt.nFrac++; }
   }
   if( bxi > 0 )
   {
     const vvhip_mv lf = mvs[byi * mvsW + bxi - 1];
     r.leftX = lf.x; r.leftY = lf.y;
-    if( ( lf.x != own.x || lf.y != own.y ) && !( byi > 0 && lf.x == r.upX && lf.y == r.upY ) ) r.eL = meError( g, bx, by, lf.x, lf.y, sTmp, lane );
+    if( ( lf.x != own.x || lf.y != own.y ) && !( byi > 0 && lf.x == r.upX && lf.y == r.upY ) )
+    { r.eL = meError( g, bx, by, lf.x, lf.y, sTmp, lane ); if( ( ( lf.x | lf.y ) & 15 ) == 0 ) cnt.nInt++; else cnt.nFrac++; }
   }
-  if( lane == 0 ) nb[byi * nbx + bxi] = r;
+  if( lane == 0 )
+  {
+    if( !fix ) nb[byi * nbx + bxi] = r;
+    else
+    {
+      // iteration 0 of the fixed-point form: the record carries the block's own phase-A result, and the block is resolved against its neighbours' phase-A vectors
+      unsigned long long* base = R.gran[blockIdx.y];
+      FixRec* recs = reinterpret_cast<FixRec*>( base );
+      FixRec f; f.ownX = own.x; f.ownY = own.y; f.ownE = own.error; f.eU = r.eU; f.eL = r.eL; f.upX = r.upX; f.upY = r.upY; f.leftX = r.leftX; f.leftY = r.leftY;
+      recs[byi * nbx + bxi] = f;
+      bool changed = false;
+      int bestE = own.error;
+      if( byi > 0 && r.eU >= 0 && r.eU < bestE ) { bestE = r.eU; changed = true; }
+      if( bxi > 0 && r.eL >= 0 && r.eL < bestE ) { changed = true; }
+      if( changed )
+      {
+        int* lists = reinterpret_cast<int*>( reinterpret_cast<char*>( base ) + ( size_t ) nBlocks * sizeof( FixRec ) );      // [3 lists][stamps][counts]
+        int* count = lists + 4 * ( size_t ) nBlocks;
+        lists[atomicAdd( count, 1 )] = byi * nbx + bxi;
+      }
+    }
+  }
+  if( stats ) meCountFlush( stats, cnt, g, bx, by, lane );
+}
+
+// ---- phase B, iterations >= 1 of the fixed-point form: one workgroup per reference, a wavefront per block to evaluate ---------------------------------------------
+__global__ void __launch_bounds__( ME_FIX_THREADS )
+meFixKernel( MeGeom g, const MeRefs R, int nbx, int nby, int mvsW, unsigned long long* stats )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmpAll[ME_FIX_THREADS / 64][( 32 + 5 ) * 32];
+  __shared__ MeGeom sG;
+  __shared__ int sN[2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int WAVES = ME_FIX_THREADS / 64;
+  int16_t* sTmp = sTmpAll[wave];
+  g.buf = R.buf[blockIdx.x];
+  if( t == 0 ) sG = g;
+  vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.x];
+  const int nBlocks = nbx * nby, bs = g.bs;
+  unsigned long long* base = R.gran[blockIdx.x];
+  const FixRec* __restrict__ recs = reinterpret_cast<const FixRec*>( base );
+  int* lists = reinterpret_cast<int*>( reinterpret_cast<char*>( base ) + ( size_t ) nBlocks * sizeof( FixRec ) );
+  int* stamp = lists + 3 * ( size_t ) nBlocks;
+  int* count = lists + 4 * ( size_t ) nBlocks;
+  int n = __hip_atomic_load( count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  if( n == 0 ) return;                                                        // (the common case on smooth content: nothing to do)
+  __syncthreads();
+  auto vecOf = [&]( int b ) -> unsigned long long {                           // a block's current vector as one word (x low, y high)
+    const int by_ = b / nbx, bx_ = b - by_ * nbx;
+    return __hip_atomic_load( reinterpret_cast<const unsigned long long*>( &mvs[by_ * mvsW + bx_] ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ); };
+  // f( own; up's vector, left's vector ), errors from the record or scored by this wavefront (MCTF.cpp:1289-1306)
+  auto resolve = [&]( int b, const FixRec& r, FixBest& best ) {
+    const int by_ = b / nbx, bx_ = b - by_ * nbx;
+    best.x = r.ownX; best.y = r.ownY; best.e = r.ownE;
+    int upX = 0, upY = 0, e1 = -1;
+    const bool haveUp = by_ > 0;
+    if( haveUp )
+    {
+      const unsigned long long v = vecOf( b - nbx );
+      upX = ( int ) ( uint32_t ) v; upY = ( int ) ( uint32_t ) ( v >> 32 );
+      if( upX != best.x || upY != best.y )
+      {
+        e1 = fixKnown( r, upX, upY, 0, 0, -1 );
+        if( e1 < 0 )
+        {
+          e1 = meErrorCall( &sG, bx_ * bs, by_ * bs, upX, upY, sTmp, lane );
+          if( stats ) { MeCount c1 = { 0, 0, 0, 0 }; c1.nInt = ( ( upX | upY ) & 15 ) == 0; c1.nFrac = !c1.nInt; meCountFlush( stats, c1, sG, bx_ * bs, by_ * bs, lane ); }
+        }
+        if( e1 < best.e ) { best.x = upX; best.y = upY; best.e = e1; }
+      }
+    }
+    if( bx_ > 0 )
+    {
+      const unsigned long long v = vecOf( b - 1 );
+      const int lfX = ( int ) ( uint32_t ) v, lfY = ( int ) ( uint32_t ) ( v >> 32 );
+      if( !( haveUp && lfX == upX && lfY == upY ) && ( lfX != best.x || lfY != best.y ) )
+      {
+        int e2 = fixKnown( r, lfX, lfY, upX, upY, e1 );
+        if( e2 < 0 )
+        {
+          e2 = meErrorCall( &sG, bx_ * bs, by_ * bs, lfX, lfY, sTmp, lane );
+          if( stats ) { MeCount c1 = { 0, 0, 0, 0 }; c1.nInt = ( ( lfX | lfY ) & 15 ) == 0; c1.nFrac = !c1.nInt; meCountFlush( stats, c1, sG, bx_ * bs, by_ * bs, lane ); }
+        }
+        if( e2 < best.e ) { best.x = lfX; best.y = lfY; best.e = e2; }
+      }
+    } };
+  auto store = [&]( int b, const FixBest& best ) {
+    if( lane != 0 ) return;
+    const int by_ = b / nbx, bx_ = b - by_ * nbx;
+    vvhip_mv& m = mvs[by_ * mvsW + bx_];
+    __hip_atomic_store( reinterpret_cast<unsigned long long*>( &m ), ( unsigned long long ) ( uint32_t ) best.x | ( ( unsigned long long ) ( uint32_t ) best.y << 32 ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    m.error = best.e; };
+  // iteration 0's results: every listed block against its neighbours' PHASE-A vectors (all in its record: nothing to score, nothing read from the field), then written
+  int* cur = lists;
+  for( int i = wave; i < n; i += WAVES )
+  {
+    const int b = cur[i];
+    const FixRec r = recs[b];
+    FixBest best = { r.ownX, r.ownY, r.ownE };
+    if( b >= nbx && r.eU >= 0 && r.eU < best.e ) { best.x = r.upX; best.y = r.upY; best.e = r.eU; }
+    if( b % nbx > 0 && r.eL >= 0 && r.eL < best.e ) { best.x = r.leftX; best.y = r.leftY; best.e = r.eL; }
+    store( b, best );
+  }
+  __threadfence_block();
+  __syncthreads();
+  int* dep = lists + nBlocks;
+  int* nxt = lists + 2 * ( size_t ) nBlocks;
+  const int maxIt = nbx + nby + 2;
+  for( int it = 1; n > 0 && it <= maxIt; it++ )
+  {
+    if( t == 0 ) { sN[0] = 0; sN[1] = 0; }
+    __syncthreads();
+    // the blocks to evaluate again: right and lower neighbours of the blocks that changed, once each
+    for( int i = t; i < 2 * n; i += ME_FIX_THREADS )
+    {
+      const int c = cur[i >> 1], cy = c / nbx, cx = c - cy * nbx;
+      const int d = ( i & 1 ) ? ( cy + 1 < nby ? c + nbx : -1 ) : ( cx + 1 < nbx ? c + 1 : -1 );
+      if( d >= 0 && atomicExch( &stamp[d], it ) != it ) dep[atomicAdd( &sN[0], 1 )] = d;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int nd = sN[0];
+    for( int j = wave; j < nd; j += WAVES )
+    {
+      const int b = dep[j];
+      const FixRec r = recs[b];
+      FixBest best;
+      resolve( b, r, best );
+      const unsigned long long old = vecOf( b );
+      if( ( int ) ( uint32_t ) old != best.x || ( int ) ( uint32_t ) ( old >> 32 ) != best.y )
+      {
+        store( b, best );
+        if( lane == 0 ) nxt[atomicAdd( &sN[1], 1 )] = b;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    n = sN[1];
+    int* tmp = cur; cur = nxt; nxt = tmp;      // (the changed list just read becomes the next iteration's output list)
+    __syncthreads();
+  }
 }
 
 // ---- phase B, sequential part: anti-diagonal sweep -------------------------------------------------------------------------------
@@ -486,7 +694,7 @@ constexpr int ME_DIAG_MAX_THREADS = 320, ME_DIAG_MAX_COLS = 1024;
 __device__ __attribute__( ( noinline ) ) int meErrorCall( const MeGeom* g, int x, int y, int dx, int dy, int16_t* sTmp, int lane ) { return meError( *g, x, y, dx, dy, sTmp, lane ); }
 
 __global__ void __launch_bounds__( ME_DIAG_MAX_THREADS )
-meDiagKernel( MeGeom g, const MeRefs R, int nbx, int nby, int mvsW )
+meDiagKernel( MeGeom g, const MeRefs R, int nbx, int nby, int mvsW, unsigned long long* stats )
 {
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmpAll[ME_DIAG_MAX_THREADS / 64][( 32 + 5 ) * 32];
   __shared__ int finX[ME_DIAG_MAX_COLS], finY[ME_DIAG_MAX_COLS];      // final vector of the last finished block of every block column
@@ -541,6 +749,7 @@ meDiagKernel( MeGeom g, const MeRefs R, int nbx, int nby, int mvsW )
         const int l = __ffsll( ( long long ) m ) - 1;
         const int lx = __shfl( x, l ), ly = __shfl( y, l ), lvx = __shfl( vx, l ), lvy = __shfl( vy, l );
         const int v = meErrorCall( &sG, lx * bs, ly * bs, lvx, lvy, sTmp, lane );
+        if( stats ) { MeCount c1 = { 0, 0, 0, 0 }; c1.nInt = ( ( lvx | lvy ) & 15 ) == 0; c1.nFrac = !c1.nInt; meCountFlush( stats, c1, sG, lx * bs, ly * bs, lane ); }
         if( lane == l ) e = v;
         m &= m - 1;
       } };
@@ -714,9 +923,18 @@ int ensureScratch( vvhip_ctx* ctx, size_t bytes )
   return VVHIP_OK;
 }
 
+// per-class timing of a motion-estimation call (vvhip_mctf_set_timing): one event per mark, created on first use and kept
+void meMark( vvhip_ctx* ctx, int tag )
+{
+  if( !ctx->mctfTiming ) return;
+  const size_t k = ctx->mctfEvTag.size();
+  if( k >= ctx->mctfEv.size() ) { hipEvent_t e = nullptr; if( hipEventCreate( &e ) != hipSuccess ) return; ctx->mctfEv.push_back( e ); }
+  if( hipEventRecord( ctx->mctfEv[k], ctx->stream ) == hipSuccess ) ctx->mctfEvTag.push_back( tag );
+}
+
 // one hierarchy level for nRefs references at once (R.gran[r]: nbx * nby granules per reference, one contiguous region starting at R.gran[0] with pitch granPitch)
 int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, int height, int bs, const MeRefs& R, int nRefs, size_t granPitch,
-             int prevW, int prevH, int factor, int doubleRes, int pttrn, int lowRes, int bitDepth, int unit, int mvsW, int mvsH, int* d_abort )
+             int prevW, int prevH, int factor, int doubleRes, int pttrn, int lowRes, int bitDepth, int unit, int mvsW, int mvsH, int* d_abort, int* usedHandOff = nullptr )
 {
   // blocks processed: bx + 8 <= width, by + 8 <= height (MCTF.cpp:1174,1357)
   const int nbx = width >= 8 ? ( width - 8 ) / bs + 1 : 0, nby = height >= 8 ? ( height - 8 ) / bs + 1 : 0;
@@ -724,28 +942,49 @@ int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, i
   if( nbx > mvsW || nby > mvsH ) return vvhip_fail( ctx, VVHIP_E_ARG, "MCTF level: motion field %dx%d too small for %dx%d blocks", mvsW, mvsH, nbx, nby );
   MeGeom g; g.org = d_org; g.orgStride = os; g.buf = nullptr; g.bufStride = bsd; g.width = width; g.height = height; g.bs = bs;
   g.lowRes = lowRes; g.maxVal = ( 1 << bitDepth ) - 1;
-  hipLaunchKernelGGL( meSearchKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, doubleRes, pttrn, mvsW );
+  meMark( ctx, 1 );
+  unsigned long long* st = ctx->d_mctfStats;      // (null unless vvhip_mctf_set_stats switched the counters on: 3 phases x 6 counters, include/vvenc_hip.h)
+  // phase B: $VVHIP_MCTF_DIAG = 2 (default) the fixed-point form (any field size), 1 the anti-diagonal sweep (fields up to 320 blocks on the shorter side), 0 the row hand-off
+  static const int useDiag = []{ const char* e = getenv( "VVHIP_MCTF_DIAG" ); return e ? atoi( e ) : 2; }();
+  const int fixBlocks = useDiag >= 2 ? nbx * nby : 0;
+  if( st ) hipLaunchKernelGGL( meSearchKernel<true>,  dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, doubleRes, pttrn, mvsW, st, fixBlocks );
+  else     hipLaunchKernelGGL( meSearchKernel<false>, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, doubleRes, pttrn, mvsW, st, fixBlocks );
   VVHIP_LAUNCH_CHECK( ctx );
-  static const int useDiag = []{ const char* e = getenv( "VVHIP_MCTF_DIAG" ); return e ? atoi( e ) : 1; }();
+  meMark( ctx, 2 );
   const int diagLen = nbx < nby ? nbx : nby;
-  if( useDiag && diagLen <= ME_DIAG_MAX_THREADS && nbx <= ME_DIAG_MAX_COLS )
+  if( fixBlocks )
+  {
+    // (the granule area holds, per reference: one FixRec per block, three block lists, the stamps and the counts: 52 bytes per block + 16 <= 7 granules per block)
+    hipLaunchKernelGGL( meNeighbourKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, st ? st + 6 : nullptr, 1, fixBlocks );
+    meMark( ctx, 3 );
+    hipLaunchKernelGGL( meFixKernel, dim3( nRefs ), dim3( ME_FIX_THREADS ), 0, ctx->stream, g, R, nbx, nby, mvsW, st ? st + 12 : nullptr );
+    VVHIP_LAUNCH_CHECK( ctx );
+  }
+  else if( useDiag && diagLen <= ME_DIAG_MAX_THREADS && nbx <= ME_DIAG_MAX_COLS )
   {
     // (the granule area holds the neighbour records here: 3 granules = one NbRec per block)
-    hipLaunchKernelGGL( meNeighbourKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW );
-    hipLaunchKernelGGL( meDiagKernel, dim3( nRefs ), dim3( ( ( diagLen + 63 ) / 64 ) * 64 ), 0, ctx->stream, g, R, nbx, nby, mvsW );
+    hipLaunchKernelGGL( meNeighbourKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, st ? st + 6 : nullptr, 0, 0 );
+    meMark( ctx, 3 );
+#ifdef VVHIP_DEV_KNOBS      // (development aid, changes the results: the final level without its above / left tests = the phase-A vectors, for the analysis of the sweep's chains)
+    if( !( doubleRes && getenv( "VVHIP_MCTF_NO_SWEEP" ) ) )
+#endif
+    hipLaunchKernelGGL( meDiagKernel, dim3( nRefs ), dim3( ( ( diagLen + 63 ) / 64 ) * 64 ), 0, ctx->stream, g, R, nbx, nby, mvsW, st ? st + 12 : nullptr );
     VVHIP_LAUNCH_CHECK( ctx );
   }
   else
   {
+    if( usedHandOff ) *usedHandOff = 1;
     VVHIP_CHECK_HIP( ctx, hipMemsetAsync( R.gran[0], 0, sizeof( unsigned long long ) * ( granPitch * ( size_t ) ( nRefs - 1 ) + ( size_t ) nbx * nby ), ctx->stream ) );
     // blocks are dispatched in linear order (x fastest): the row a wave waits for — same reference, one row up — always has the smaller linear index
     hipLaunchKernelGGL( meWavefrontKernel, dim3( nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, d_abort );
     VVHIP_LAUNCH_CHECK( ctx );
   }
+  meMark( ctx, 4 );
   if( doubleRes )
   {
     hipLaunchKernelGGL( meFinalizeKernel, dim3( ( nbx * nby + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, g, R, nRefs, nbx, nby, bitDepth, unit, mvsW );
     VVHIP_LAUNCH_CHECK( ctx );
+    meMark( ctx, 5 );
   }
   return VVHIP_OK;
 }
@@ -815,7 +1054,7 @@ int vvhip_mctf_me_level( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, c
   if( ( block_size != 8 && block_size != 16 && block_size != 32 ) || width < 8 || height < 8 || bit_depth < 8 || bit_depth > 10 )
     return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_me_level: block size %d (8/16/32), bit depth %d (8..10, MCTF.cpp:1313)", block_size, bit_depth );
   const int nbx = ( width - 8 ) / block_size + 1, nby = ( height - 8 ) / block_size + 1;
-  const size_t need = 3 * sizeof( unsigned long long ) * ( size_t ) nbx * nby + 256;      // one NbRec (3 granules) per block
+  const size_t need = 7 * sizeof( unsigned long long ) * ( ( size_t ) nbx * nby + 64 ) + 256;      // per block: one FixRec + three list slots + a stamp (52 bytes <= 7 granules; the sweep's NbRec needs 3)
   int rc = ensureScratch( ctx, need );
   if( rc ) return rc;
   int* d_abort = reinterpret_cast<int*>( ctx->d_scratch );
@@ -833,8 +1072,63 @@ int vvhip_mctf_me_level( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, c
   return VVHIP_OK;
 }
 
+int vvhip_mctf_set_stats( vvhip_ctx* ctx, int on )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( on && !ctx->d_mctfStats ) VVHIP_CHECK_HIP( ctx, hipMalloc( reinterpret_cast<void**>( &ctx->d_mctfStats ), 18 * sizeof( unsigned long long ) ) );
+  if( on ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( ctx->d_mctfStats, 0, 18 * sizeof( unsigned long long ), ctx->stream ) );
+  if( !on && ctx->d_mctfStats ) { VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) ); ( void ) hipFree( ctx->d_mctfStats ); ctx->d_mctfStats = nullptr; }
+  return VVHIP_OK;
+}
+
+int vvhip_mctf_set_timing( vvhip_ctx* ctx, int on )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  ctx->mctfTiming = on != 0; ctx->mctfEvTag.clear();
+  return VVHIP_OK;
+}
+
+int vvhip_mctf_last_times( vvhip_ctx* ctx, float* ms5 )
+{
+  if( !ctx || !ms5 || !ctx->mctfTiming || ctx->mctfEvTag.size() < 2 ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipEventSynchronize( ctx->mctfEv[ctx->mctfEvTag.size() - 1] ) );
+  for( int k = 0; k < 5; k++ ) ms5[k] = 0.f;
+  for( size_t k = 1; k < ctx->mctfEvTag.size(); k++ )
+  {
+    float ms = 0.f;
+    VVHIP_CHECK_HIP( ctx, hipEventElapsedTime( &ms, ctx->mctfEv[k - 1], ctx->mctfEv[k] ) );
+    const int tag = ctx->mctfEvTag[k];
+    ms5[tag == 2 ? 0 : tag == 3 ? 1 : tag == 4 ? 2 : tag == 5 ? 3 : 4] += ms;
+  }
+  return VVHIP_OK;
+}
+
+int vvhip_mctf_get_stats( vvhip_ctx* ctx, uint64_t* out18 )
+{
+  if( !ctx || !out18 ) return VVHIP_E_ARG;
+  if( !ctx->d_mctfStats ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_get_stats: the counters are off (vvhip_mctf_set_stats)" );
+  VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( out18, ctx->d_mctfStats, 18 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) );
+  return VVHIP_OK;
+}
+
+static int mctfMotionEstimation( vvhip_ctx* ctx, const int16_t* d_cur, const int16_t* const* d_refs, int n_refs, int stride, int width, int height,
+                                 int pad, int bit_depth, int unit_size, int mctf_speed, int add_level, vvhip_mv* const* d_mvs_out, bool wait );
+
 int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const int16_t* const* d_refs, int n_refs, int stride, int width, int height,
                                   int pad, int bit_depth, int unit_size, int mctf_speed, int add_level, vvhip_mv* const* d_mvs_out )
+{
+  return mctfMotionEstimation( ctx, d_cur, d_refs, n_refs, stride, width, height, pad, bit_depth, unit_size, mctf_speed, add_level, d_mvs_out, true );
+}
+
+int vvhip_mctf_motion_estimation_async( vvhip_ctx* ctx, const int16_t* d_cur, const int16_t* const* d_refs, int n_refs, int stride, int width, int height,
+                                        int pad, int bit_depth, int unit_size, int mctf_speed, int add_level, vvhip_mv* const* d_mvs_out )
+{
+  return mctfMotionEstimation( ctx, d_cur, d_refs, n_refs, stride, width, height, pad, bit_depth, unit_size, mctf_speed, add_level, d_mvs_out, false );
+}
+
+static int mctfMotionEstimation( vvhip_ctx* ctx, const int16_t* d_cur, const int16_t* const* d_refs, int n_refs, int stride, int width, int height,
+                                 int pad, int bit_depth, int unit_size, int mctf_speed, int add_level, vvhip_mv* const* d_mvs_out, bool wait )
 {
   if( !ctx ) return VVHIP_E_ARG;
   if( n_refs < 0 || width < 64 || height < 64 || pad < 128 || stride < width + 2 * pad || ( unit_size != 8 && unit_size != 16 ) || bit_depth < 8 || bit_depth > 10 || mctf_speed < 0 || mctf_speed > 4 )
@@ -856,7 +1150,7 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
   size_t fieldElems = 0;
   for( int k = 0; k < 4; k++ ) fieldElems += ( size_t ) fw[k] * fh[k];
   const int outW = ( width + u - 1 ) / u, outH = ( height + u - 1 ) / u;      // MCTF.cpp:671-672
-  const size_t granElems = 3 * ( ( size_t ) outW * outH + 64 );      // per reference: one NbRec (3 granules) per block of the finest level
+  const size_t granElems = 7 * ( ( size_t ) outW * outH + 64 );      // per reference: one FixRec + three list slots + a stamp per block of the finest level (52 bytes <= 7 granules)
   size_t off = 256;
   const size_t offGran = off;  off += granElems * sizeof( unsigned long long ) * ( size_t ) ( n_refs < ME_MAX_REFS ? n_refs : ME_MAX_REFS );
   off = ( off + 255 ) & ~( size_t ) 255;
@@ -868,6 +1162,8 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
   char* base = reinterpret_cast<char*>( ctx->d_scratch );
   int* d_abort = reinterpret_cast<int*>( base );
   unsigned long long* d_gr = reinterpret_cast<unsigned long long*>( base + offGran );
+  ctx->mctfEvTag.clear();
+  meMark( ctx, 0 );
   VVHIP_CHECK_HIP( ctx, hipMemsetAsync( d_abort, 0, 256, ctx->stream ) );
 
   auto planePtr = [&]( int pic, int l ) -> int16_t* {   // pic 0 = current, 1.. = references; l = 1..3; returns pointer to sample (0,0)
@@ -875,6 +1171,7 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
     for( int k = 1; k < l; k++ ) p += planeElems[k];
     return p + ( size_t ) P * ls[l] + P;
   };
+  int usedHandOff = 0;
   const int levels = add_level ? 3 : 2;
   for( int l = 1; l <= levels; l++ )                                                     // MCTF.cpp:689-690,696,779-784: one level of every picture per launch
     for( int p0 = 0; p0 <= n_refs; p0 += ME_MAX_PICS )
@@ -916,7 +1213,7 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
         R.mvs[k]  = outField == 4 ? d_mvs_out[r0 + k] : f[k][outField];
       }
       return meLevel( ctx, l ? planePtr( 0, l ) : d_cur, ls[l], ls[l], lw[l], lh[l], bs, R, nr, granElems, inField < 0 ? 0 : fw[inField], inField < 0 ? 0 : fh[inField], factor, dbl, pttrn, lowRes,
-                      bit_depth, u, outField == 4 ? outW : fw[outField], outField == 4 ? outH : fh[outField], d_abort );
+                      bit_depth, u, outField == 4 ? outW : fw[outField], outField == 4 ? outH : fh[outField], d_abort, &usedHandOff );
     };
     if( add_level ) { rc = level( 3, 2 * u, -1, 0, 1, 0 ); if( rc ) return rc; }        // MCTF.cpp:692-699
     rc = level( 2, 2 * u, add_level ? 0 : -1, 1, 2, 0 );  if( rc ) return rc;           // :698 / :702
@@ -924,8 +1221,11 @@ int vvhip_mctf_motion_estimation( vvhip_ctx* ctx, const int16_t* d_cur, const in
     rc = level( 0, 2 * u, 2, 3, 2, 0 );                   if( rc ) return rc;           // :705
     rc = level( 0, u, 3, 4, 1, 1 );                       if( rc ) return rc;           // :707
   }
+  meMark( ctx, 6 );
+  // the sweep kernels cannot fail; only the row hand-off of fields whose diagonals exceed a workgroup has an abort flag to read — the asynchronous entry waits for it too
+  if( !wait && !usedHandOff ) return VVHIP_OK;
   int aborted = 0;
-  VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( &aborted, d_abort, sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
+  if( usedHandOff ) VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( &aborted, d_abort, sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
   VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) );
   if( aborted ) return vvhip_fail( ctx, VVHIP_E_HIP, "vvhip_mctf_motion_estimation: wavefront hand-off timed out" );
   return VVHIP_OK;

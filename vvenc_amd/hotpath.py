@@ -552,8 +552,9 @@ class HotPath:
                                             _ptr(mvs), mvs_dims[0], mvs_dims[1]))
         return mvs
 
-    def mctf_motion_estimation(self, cur, refs, bit_depth=10, unit=16, speed=4, add_level=None, out=None):
-        """cur / refs: Plane objects with identical geometry and pad >= 128 (borders extended)."""
+    def mctf_motion_estimation(self, cur, refs, bit_depth=10, unit=16, speed=4, add_level=None, out=None, wait=True):
+        """cur / refs: Plane objects with identical geometry and pad >= 128 (borders extended).  wait=False: queued on the context's stream, no host wait
+        (vvhip_mctf_motion_estimation_async)."""
         if add_level is None:
             add_level = cur.width >= 1920            # MCTF.cpp:768
         ow, oh = (cur.width + unit - 1) // unit, (cur.height + unit - 1) // unit
@@ -563,9 +564,28 @@ class HotPath:
         out_ptrs = (C.c_void_p * len(refs))(*[o.data_ptr() for o in out])
         for r in refs:
             assert (r.width, r.height, r.stride, r.pad) == (cur.width, cur.height, cur.stride, cur.pad)
-        self._ck(self.L.vvhip_mctf_motion_estimation(self.ctx, cur.buf_ptr, ref_ptrs, len(refs), cur.stride, cur.width, cur.height, cur.pad,
-                                                     bit_depth, unit, speed, int(bool(add_level)), out_ptrs))
+        fn = self.L.vvhip_mctf_motion_estimation if wait else self.L.vvhip_mctf_motion_estimation_async
+        self._ck(fn(self.ctx, cur.buf_ptr, ref_ptrs, len(refs), cur.stride, cur.width, cur.height, cur.pad, bit_depth, unit, speed, int(bool(add_level)), out_ptrs))
         return out, (ow, oh)
+
+    def mctf_set_stats(self, on):
+        self._ck(self.L.vvhip_mctf_set_stats(self.ctx, int(bool(on))))
+
+    def mctf_set_timing(self, on):
+        self._ck(self.L.vvhip_mctf_set_timing(self.ctx, int(bool(on))))
+
+    def mctf_last_times(self):
+        """ms of the last motion-estimation call per class: (candidate scoring, neighbour scoring, sweep, final normalisation, rest)"""
+        a = (C.c_float * 5)()
+        self._ck(self.L.vvhip_mctf_last_times(self.ctx, a))
+        return tuple(float(x) for x in a)
+
+    def mctf_get_stats(self):
+        """scored candidates of the MCTF search since mctf_set_stats(True): {phase: {int, int_bytes, frac, frac_bytes, grid, grid_window_bytes}} (include/vvenc_hip.h)"""
+        a = np.zeros(18, np.uint64)
+        self._ck(self.L.vvhip_mctf_get_stats(self.ctx, a.ctypes.data_as(C.c_void_p)))
+        return {ph: {"int": int(a[6 * i]), "int_bytes": int(a[6 * i + 1]), "frac": int(a[6 * i + 2]), "frac_bytes": int(a[6 * i + 3]), "grid": int(a[6 * i + 4]),
+                     "grid_window_bytes": int(a[6 * i + 5])} for i, ph in enumerate(("search", "neighbour", "sweep"))}
 
     @staticmethod
     def mv_to_numpy(t, dims):
