@@ -325,6 +325,131 @@ __device__ __forceinline__ void meCountFlush( unsigned long long* st, const MeCo
   if( cnt.nGrid ) { atomicAdd( st + 4, ( unsigned long long ) cnt.nGrid ); atomicAdd( st + 5, ( unsigned long long ) cnt.gridBytes ); }
 }
 
+// ---- the final level's full 16 x 16 blocks with the 4-tap search filter and search pattern 2 (MCTFSpeed >= 3: what presets faster .. medium run), round 6 --------------
+// Eight candidates at a time instead of one: lane = 8 c + p scores COLUMN PAIR p (samples 2p, 2p + 1 of all 16 rows) of candidate c, the block's original column pair stays
+// in 16 registers for every candidate of the block, a candidate's error is a sum over its 8 lanes (three DPP steps), and the reference's "first strictly smaller in scan
+// order" is one minimum over keys ( error << 3 | order ) — errors of a 16 x 16 block at <= 10 bits stay below 2^29.  Same integers as motionErrorLumaInt / Frac4 per candidate.
+__device__ __forceinline__ uint32_t groupSum8( uint32_t v )
+{
+  v += ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR1 ); v += ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_XOR2 ); v += ( uint32_t ) VVHIP_DPP( v, VVHIP_DPP_HALF_MIRROR );
+  return v;
+}
+__device__ __forceinline__ uint32_t waveMinOfGroups8( uint32_t key )      // every lane of an 8-lane group holds the group's key -> the minimum over the wave, uniform
+{
+  const uint32_t o = ( uint32_t ) VVHIP_DPP( key, VVHIP_DPP_MIRROR ); key = o < key ? o : key;
+  const uint32_t r0 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) key, 0 ), r1 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) key, 16 );
+  const uint32_t r2 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) key, 32 ), r3 = ( uint32_t ) __builtin_amdgcn_readlane( ( int ) key, 48 );
+  const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+  return a < b ? a : b;
+}
+// integer vector (vx, vy) (multiples of 16) of this lane's candidate against the block at `blkBuf` (= buf + bx + by * stride): key of the lane's candidate group
+__device__ __forceinline__ uint32_t intKey16( const uint32_t ( &orgCol )[16], const int16_t* blkBuf, int bufStride, int vx, int vy, bool valid, int lane )
+{
+  const int16_t* b = blkBuf + vx / 16 + ( ptrdiff_t ) ( vy / 16 ) * bufStride + 2 * ( lane & 7 );
+  uint32_t rows[16];
+#pragma unroll
+  for( int i = 0; i < 16; i++ ) rows[i] = ld4( b + ( ptrdiff_t ) i * bufStride );
+  int e = 0;
+#pragma unroll
+  for( int i = 0; i < 16; i++ ) { const uint32_t d = pkSub16( orgCol[i], rows[i] ); e = sdot2( d, d, e ); }
+  const uint32_t sum = groupSum8( ( uint32_t ) e );
+  return valid ? ( sum << 3 ) | ( uint32_t ) ( lane >> 3 ) : 0xffffffffu;
+}
+// one refinement ring (the 8 positions around (cx, cy) at distance a, reference order) -> updates best; sTmp: 3 regions of the horizontal passes
+template<bool STATS>
+__device__ __forceinline__ void meRing16( const MeGeom& g, int bx, int by, const uint32_t ( &orgCol )[16], int cx, int cy, int a, int& bestX, int& bestY, int& bestE, int16_t* sTmp, int lane, MeCount& cnt )
+{
+  const int iyMin = ( cy - a ) >> 4, iyMax = ( cy + a ) >> 4, nrows = iyMax - iyMin + 16 + 3, region = nrows * 16;
+#pragma unroll
+  for( int v = 0; v < 3; v++ )
+  {
+    const int X = cx + ( v - 1 ) * a;
+    horPass4( g.buf + bx + ( X >> 4 ) + ( ptrdiff_t ) ( by + iyMin - 1 ) * g.bufStride, g.bufStride, nrows, 16, X & 15, g.maxVal, sTmp + v * region, lane );
+  }
+  ME_WAVE_SYNC();
+  const int c = lane >> 3, p = lane & 7;
+  const int cc = c + ( c >= 4 ), j = ( cc * 11 ) >> 5, v = cc - 3 * j;          // position in the 3 x 3 scan without its centre: y offset index j (outer), x offset index v (inner)
+  const int Y = cy + ( j - 1 ) * a, fy = Y & 15, ro = ( Y >> 4 ) - iyMin;
+  const uint32_t c01 = pk16( kFilter4[fy][0], kFilter4[fy][1] ), c23 = pk16( kFilter4[fy][2], kFilter4[fy][3] );
+  const uint32_t* q = reinterpret_cast<const uint32_t*>( sTmp + v * region + ro * 16 + 2 * p );      // a row of a region is 16 samples = 8 dwords
+  uint32_t r0 = q[0], r1 = q[8], r2 = q[16];
+  uint32_t L0 = __builtin_amdgcn_perm( r1, r0, 0x05040100u ), H0 = __builtin_amdgcn_perm( r1, r0, 0x07060302u );      // ( row k, row k + 1 ) low / high samples
+  uint32_t L1 = __builtin_amdgcn_perm( r2, r1, 0x05040100u ), H1 = __builtin_amdgcn_perm( r2, r1, 0x07060302u );
+  int e = 0;
+#pragma unroll
+  for( int i = 0; i < 16; i++ )
+  {
+    const uint32_t r3 = q[8 * ( i + 3 )];
+    const uint32_t L2 = __builtin_amdgcn_perm( r3, r2, 0x05040100u ), H2 = __builtin_amdgcn_perm( r3, r2, 0x07060302u );
+    const int s0 = clipPel( sdot2( L0, c01, sdot2( L2, c23, 32 ) ) >> 6, g.maxVal );
+    const int s1 = clipPel( sdot2( H0, c01, sdot2( H2, c23, 32 ) ) >> 6, g.maxVal );
+    const uint32_t d = pkSub16( pk16( s0, s1 ), orgCol[i] );
+    e = sdot2( d, d, e );
+    L0 = L1; H0 = H1; L1 = L2; H1 = H2; r2 = r3;
+  }
+  const uint32_t key = waveMinOfGroups8( ( groupSum8( ( uint32_t ) e ) << 3 ) | ( uint32_t ) c );
+  if( STATS )
+#pragma unroll
+    for( int k = 0; k < 9; k++ )
+      if( k != 4 ) { if( ( ( ( cx + ( k % 3 - 1 ) * a ) | ( cy + ( k / 3 - 1 ) * a ) ) & 15 ) == 0 ) cnt.nInt++; else cnt.nFrac++; }
+  const int eMin = ( int ) ( key >> 3 );
+  if( eMin < bestE )
+  {
+    const int cm = ( int ) ( key & 7u ), ccm = cm + ( cm >= 4 ), jm = ( ccm * 11 ) >> 5, vm = ccm - 3 * jm;
+    bestX = cx + ( vm - 1 ) * a; bestY = cy + ( jm - 1 ) * a; bestE = eMin;
+  }
+  ME_WAVE_SYNC();                                // sTmp is reused by the next ring
+}
+// estimateLumaLn of one full 16 x 16 block of the final level up to (not including) the above / left tests (MCTF.cpp:1189-1288 with doubleRes, m_searchPttrn == 2)
+template<bool STATS>
+__device__ __forceinline__ bool meFinal16( const MeGeom& g, int bx, int by, const vvhip_mv* __restrict__ prev, int prevW, int prevH, int factor,
+                                           int& bestX, int& bestY, int& bestE, int16_t* sTmp, int lane, MeCount& cnt )
+{
+  // the inherited vectors of the 3 x 3 coarser blocks (:1189-1208), then the zero vector (:1210-1214): candidates 0..9 in the reference's order, eight at a time
+  int vx[2], vy[2]; bool valid[2];
+#pragma unroll
+  for( int round = 0; round < 2; round++ )
+  {
+    const int idx = 8 * round + ( lane >> 3 );
+    vx[round] = 0; vy[round] = 0; valid[round] = idx == 9;
+    if( idx < 9 )
+    {
+      const int pyI = ( idx * 11 ) >> 5, pxI = idx - 3 * pyI;
+      const int ty = by / 32 + pyI - 1, tx = bx / 32 + pxI - 1;
+      valid[round] = ty >= 0 && ty < prevH && tx >= 0 && tx < prevW;
+      if( valid[round] ) { const vvhip_mv old = prev[ty * prevW + tx]; vx[round] = old.x * factor; vy[round] = old.y * factor; }
+    }
+  }
+  // (the coarser levels only produce integer vectors; should a caller's field hold a fractional one, the block takes the general path)
+  if( __ballot( ( valid[0] && ( ( vx[0] | vy[0] ) & 15 ) ) || ( valid[1] && ( ( vx[1] | vy[1] ) & 15 ) ) ) ) return false;
+  uint32_t orgCol[16];
+  {
+    const int16_t* o = g.org + bx + ( ptrdiff_t ) by * g.orgStride + 2 * ( lane & 7 );
+#pragma unroll
+    for( int i = 0; i < 16; i++ ) orgCol[i] = ld4( o + ( ptrdiff_t ) i * g.orgStride );
+  }
+  const int16_t* blkBuf = g.buf + bx + ( ptrdiff_t ) by * g.bufStride;
+#pragma unroll
+  for( int round = 0; round < 2; round++ )
+  {
+    const uint32_t key = waveMinOfGroups8( intKey16( orgCol, blkBuf, g.bufStride, vx[round], vy[round], valid[round], lane ) );
+    if( STATS ) cnt.nInt += __popcll( __ballot( valid[round] && ( lane & 7 ) == 0 ) );
+    if( key != 0xffffffffu && ( int ) ( key >> 3 ) < bestE )
+    {
+      const int src = ( int ) ( key & 7u ) * 8;
+      bestX = __builtin_amdgcn_readlane( vx[round], src ); bestY = __builtin_amdgcn_readlane( vy[round], src ); bestE = ( int ) ( key >> 3 );
+    }
+  }
+  // (:1216-1228 with range 0: the one position is the best vector itself — same error, cannot win)
+  int pbx = bestX, pby = bestY;
+  meRing16<STATS>( g, bx, by, orgCol, pbx, pby, 6, bestX, bestY, bestE, sTmp, lane, cnt );
+  pbx = bestX; pby = bestY;
+  meRing16<STATS>( g, bx, by, orgCol, pbx, pby, 2, bestX, bestY, bestE, sTmp, lane, cnt );
+  pbx = bestX; pby = bestY;
+  meRing16<STATS>( g, bx, by, orgCol, pbx, pby, 1, bestX, bestY, bestE, sTmp, lane, cnt );
+  return true;
+}
+
 template<bool STATS>
 __global__ void __launch_bounds__( 64 )
 meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int factor, int doubleRes, int searchPttrn, int mvsW, unsigned long long* stats, int fixBlocks )
@@ -339,6 +464,25 @@ meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int fac
   const int bs = g.bs, bx = bxi * bs, by = byi * bs;
 
   int bestX = 0, bestY = 0, bestE = 0x7fffffff;
+  // the final level's full 16 x 16 blocks (4-tap search filter, search pattern 2, integer inherited vectors, <= 10 bits): eight candidates at a time
+  // (doubleRes bit 1 = the path is enabled: $VVHIP_MCTF_FINAL16=0 switches it off for A/B measurements, results identical)
+  if( ( doubleRes & 2 ) && bs == 16 && g.lowRes && searchPttrn == 2 && prev && bx + 16 <= g.width && by + 16 <= g.height && g.maxVal <= 1023 &&
+      meFinal16<STATS>( g, bx, by, prev, prevW, prevH, factor, bestX, bestY, bestE, sTmp, lane, cnt ) )
+  {
+    if( lane == 0 )
+    {
+      vvhip_mv& m = mvs[byi * mvsW + bxi];
+      m.x = bestX; m.y = bestY; m.error = bestE;
+      if( fixBlocks )
+      {
+        int* lists = reinterpret_cast<int*>( reinterpret_cast<char*>( R.gran[blockIdx.y] ) + ( size_t ) fixBlocks * sizeof( FixRec ) );
+        lists[3 * ( size_t ) fixBlocks + blk] = 0;
+        if( blk == 0 ) lists[4 * ( size_t ) fixBlocks] = 0;
+      }
+    }
+    if( STATS ) meCountFlush( stats, cnt, g, bx, by, lane );
+    return;
+  }
   // full 32 x 32 blocks: integer vectors are scored from registers (errInt32); anything else takes the general path
   const bool full32 = bs == 32 && bx + 32 <= g.width && by + 32 <= g.height;
   Org32 O32 = {};
@@ -907,6 +1051,27 @@ extendTBBatchKernel( const MePlanes P, int stride, int w, int h, int pad )
   for( int x = threadIdx.x; x < w + 2 * pad; x += blockDim.x ) dst[x] = src[x];
 }
 
+// one pyramid level of several pictures INCLUDING its replicated border, one launch (round 6: was subsample + left/right + top/bottom = three launches per level):
+// the output sample at (x, y) of the padded plane is the 2 x 2 average at the clamped position — what extendBorderPel replicates (MCTF.cpp:1072-1097)
+__global__ void __launch_bounds__( 256 )
+pyramidLevelKernel( const MePlanes P, int ss, int ds, int nw, int nh, int pad )
+{
+  const int x = ( int ) ( blockIdx.x * blockDim.x + threadIdx.x ) - pad, y = ( int ) blockIdx.y - pad;
+  if( x >= nw + pad ) return;
+  const int cx = min( max( x, 0 ), nw - 1 ), cy = min( max( y, 0 ), nh - 1 );
+  const int16_t* a = P.src[blockIdx.z] + ( ptrdiff_t ) ( 2 * cy ) * ss + 2 * cx;
+  P.dst[blockIdx.z][( ptrdiff_t ) y * ds + x] = ( int16_t ) ( ( a[0] + a[ss] + a[1] + a[ss + 1] + 2 ) >> 2 );
+}
+
+// default MotionVector() for the level fields of every reference (one contiguous array) and the result fields (R.mvs) in one launch: blockIdx.y = nRefs addresses the array
+__global__ void initMvsAllKernel( const MeRefs R, int nRefs, int count, vvhip_mv* fields, int fieldCount )
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  vvhip_mv m; m.x = 0; m.y = 0; m.error = 0x7fffffff; m.rmsme = 65535; m.overlap = 0.0;                                    // MotionVector(), MCTF.h:79
+  if( ( int ) blockIdx.y < nRefs ) { if( i < count ) R.mvs[blockIdx.y][i] = m; }
+  else for( int k = i; k < fieldCount; k += gridDim.x * blockDim.x ) fields[k] = m;
+}
+
 __global__ void initMvsBatchKernel( const MeRefs R, int count )       // R.mvs[blockIdx.y]: the result field of a reference
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -947,8 +1112,10 @@ int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, i
   // phase B: $VVHIP_MCTF_DIAG = 2 (default) the fixed-point form (any field size), 1 the anti-diagonal sweep (fields up to 320 blocks on the shorter side), 0 the row hand-off
   static const int useDiag = []{ const char* e = getenv( "VVHIP_MCTF_DIAG" ); return e ? atoi( e ) : 2; }();
   const int fixBlocks = useDiag >= 2 ? nbx * nby : 0;
-  if( st ) hipLaunchKernelGGL( meSearchKernel<true>,  dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, doubleRes, pttrn, mvsW, st, fixBlocks );
-  else     hipLaunchKernelGGL( meSearchKernel<false>, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, doubleRes, pttrn, mvsW, st, fixBlocks );
+  static const int final16 = []{ const char* e = getenv( "VVHIP_MCTF_FINAL16" ); return e ? atoi( e ) : 1; }();
+  const int dblArg = doubleRes ? ( 1 | ( final16 ? 2 : 0 ) ) : 0;
+  if( st ) hipLaunchKernelGGL( meSearchKernel<true>,  dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, dblArg, pttrn, mvsW, st, fixBlocks );
+  else     hipLaunchKernelGGL( meSearchKernel<false>, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, dblArg, pttrn, mvsW, st, fixBlocks );
   VVHIP_LAUNCH_CHECK( ctx );
   meMark( ctx, 2 );
   const int diagLen = nbx < nby ? nbx : nby;
@@ -1184,12 +1351,10 @@ static int mctfMotionEstimation( vvhip_ctx* ctx, const int16_t* d_cur, const int
         Q.src[k] = l == 1 ? ( pic == 0 ? d_cur : d_refs[pic - 1] ) : planePtr( pic, l - 1 );
         Q.dst[k] = planePtr( pic, l );
       }
-      hipLaunchKernelGGL( subsampleBatchKernel, dim3( ( lw[l] + 255 ) / 256, lh[l], np ), dim3( 256 ), 0, ctx->stream, Q, ls[l - 1], ls[l], lw[l], lh[l] );
-      hipLaunchKernelGGL( extendLRBatchKernel, dim3( lh[l], np ), dim3( 128 ), 0, ctx->stream, Q, ls[l], lw[l], lh[l], P );
-      hipLaunchKernelGGL( extendTBBatchKernel, dim3( 2 * P, np ), dim3( 256 ), 0, ctx->stream, Q, ls[l], lw[l], lh[l], P );
+      hipLaunchKernelGGL( pyramidLevelKernel, dim3( ( lw[l] + 2 * P + 255 ) / 256, lh[l] + 2 * P, np ), dim3( 256 ), 0, ctx->stream, Q, ls[l - 1], ls[l], lw[l], lh[l], P );
       VVHIP_LAUNCH_CHECK( ctx );
     }
-  rc = vvhip_mctf_init_mvs( ctx, reinterpret_cast<vvhip_mv*>( base + offFld ), ( int ) ( fieldElems * n_refs ) );   if( rc ) return rc;
+  bool fieldsInitialised = false;
   for( int r0 = 0; r0 < n_refs; r0 += ME_MAX_REFS )                                    // all references of a chunk advance through the hierarchy together
   {
     const int nr = n_refs - r0 < ME_MAX_REFS ? n_refs - r0 : ME_MAX_REFS;
@@ -1202,7 +1367,10 @@ static int mctfMotionEstimation( vvhip_ctx* ctx, const int16_t* d_cur, const int
       R.mvs[k] = d_mvs_out[r0 + k];
       R.gran[k] = d_gr + ( size_t ) k * granElems;
     }
-    hipLaunchKernelGGL( initMvsBatchKernel, dim3( ( outW * outH + 255 ) / 256, nr ), dim3( 256 ), 0, ctx->stream, R, outW * outH );
+    // (the first chunk's launch also initialises the level fields of ALL references: blockIdx.y = nr)
+    hipLaunchKernelGGL( initMvsAllKernel, dim3( ( outW * outH + 255 ) / 256, nr + ( fieldsInitialised ? 0 : 1 ) ), dim3( 256 ), 0, ctx->stream, R, nr, outW * outH,
+                        reinterpret_cast<vvhip_mv*>( base + offFld ), ( int ) ( fieldElems * n_refs ) );
+    fieldsInitialised = true;
     VVHIP_LAUNCH_CHECK( ctx );
     auto level = [&]( int l, int bs, int inField, int outField, int factor, int dbl ) -> int      // l: pyramid level (0 = full resolution); fields 0..3, 4 = result
     {
