@@ -285,6 +285,8 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     if rank != 0:
         return None, workloads, None
 
+    for wl in workloads.values():
+        wl.update_tu_alg_bytes()                         # (sparse-output contract: 2 w h + 24 for a TU whose levels are all zero — from the statistics of the runs above)
     frames = steps * world
     pairs_by_layer = {l: workloads[l].pic.sample_pairs for l in workloads}
     wsum = float(sum(GOP_WEIGHT.values()))
@@ -308,6 +310,9 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
                                                "subpel_stages": int(workloads[l].stage_jobs.size), "subpel_positions": int(workloads[l].stage_evaluated.sum()), "table_calls": int(workloads[l].items.size), "tus": int(sum(g["n"] for g in workloads[l].tu_groups)),
                                                "dmvr_subblocks": int(sum(g["n"] for g in workloads[l].dmvr_groups)), "plan": workloads[l].me_info} for l in workloads},
                    "recorded_calls_outside_the_lists": 0,
+                   "tu_outputs": ("sparse (vvhip_tu_set_sparse_outputs): a TU whose levels are all zero gets its statistics only, as the reference's caller reads neither its levels nor its "
+                                  "reconstruction (InterSearch.cpp:3696-3714); all-zero TUs by layer: %s" % {str(l): workloads[l].tu_zero_share for l in workloads})
+                                 if all(getattr(workloads[l], "tu_sparse", False) for l in workloads) else "dense: every output of every TU is written",
                    "subpel_candidates_per_block": round(float(np.mean([workloads[l].stage_evaluated.sum() / max(1, workloads[l].pic.me.size) for l in workloads if workloads[l].pic.me.size])), 2),
                    "launches_per_frame": "motion-search plan (refinement stages per tap set + integer windows + table calls) + 1 TU launch (+ one per rectangular TU shape) + 0-1 DMVR launch per reference pair",
                    "schedule": "workgroups of every launch in XCD-band order: XCD x (workgroup index mod 8) takes the x-th contiguous eighth of each class in picture order ($VVHIP_ME_XCD_BAND=0: heaviest first)",

@@ -262,6 +262,13 @@ VVHIP_API int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int res
  * caller that gathers the TUs of many CUs into one buffer has them — e.g. every TU InterSearch::xEstimateInterResidualQT tests for a picture (EncoderLib/InterSearch.cpp:3663-3714). */
 VVHIP_API int vvhip_tu_rdo_multi_strided( vvhip_ctx* ctx, const int16_t* d_resi, const int32_t* resi_strides_host, int bit_depth, const vvhip_tu_job* jobs_host, int n_jobs );
 
+/* Sparse outputs of vvhip_tu_rdo_multi / _multi_strided (default off = every output of every TU is written).  On: for a TU whose levels are ALL ZERO (stats.abs_sum == 0)
+ * d_level and d_rec_resi are UNSPECIFIED — left untouched wherever the matrix-core launch takes a whole 32x32 tile (or a 64x64 TU) through its all-zero shortcut, zeros
+ * otherwise — and the caller treats them as zero.  That is what the reference's caller does: xEstimateInterResidualQT reads neither the levels nor the reconstruction of a TU
+ * whose uiAbsSum is 0 (EncoderLib/InterSearch.cpp:3696-3714: invTransformNxN only runs for a non-zero abs sum).  Statistics (abs_sum, last_scan_pos, need_rdoq, sse) are always
+ * written.  An all-zero tile then moves 2 w h bytes in and 24 bytes per TU out instead of 6 w h + 24.                                                                          */
+VVHIP_API int vvhip_tu_set_sparse_outputs( vvhip_ctx* ctx, int on );
+
 /* ---- the g_tCoeffOps table slots one-to-one (CommonLib/TrQuant_EMT.h:63-91), device pointers, caller's matrix ------------------
  * vvhip_fast_fwd_core  <- fastFwdCore_2D/_1D[log2(tr_size)-2]  (TrQuant_EMT.cpp:1973-2000):
  *     dst[j*line + i] = ( sum_k src[i*tr_size + k] * tc[j*tr_size + k] + 2^(shift-1) ) >> shift,  i < reduced_line, j < cutoff
@@ -482,8 +489,8 @@ VVHIP_API int vvhip_mctf_get_stats( vvhip_ctx* ctx, uint64_t* out18 );
 /* ======================================================================================================================
  * SURVEY 8f rank 2 — MCTF apply side: motion-compensated bilateral temporal filter of one component plane
  * (MCTF::bilateralFilter / xFinalizeBlkLine, CommonLib/MCTF.cpp:1399-1552, with applyFrac8Core_6Tap/_4Tap :259-358,
- * applyPlanarCorrectionCore :372-421 and applyBlockCore :423-518 fused per block).  Equals the reference's SCALAR row; the reference's
- * own unit test holds its x86 row to +-1 of that.
+ * applyPlanarCorrectionCore :372-421 and applyBlockCore :423-518 fused per block).  Equals the reference's scalar row AND its x86 row
+ * (CommonLib/x86/MCTFX86.h:861-1440): the two agree sample for sample (tests/test_oracle_vs_reference.py holds both to tolerance 0).
  *   d_org / d_refs[i] : sample (0,0) of planes whose margins cover the motion vectors (MCTF_PADDING 128 luma, 64 chroma)
  *   d_mvs[i]          : final-level motion field of reference i (what vvhip_mctf_motion_estimation returns), mv_w blocks per row
  *   chroma_shift      : 0 luma, 1 the chroma planes of 4:2:0 (vectors and block size are halved)

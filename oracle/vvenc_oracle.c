@@ -1024,7 +1024,12 @@ static float mctf_fast_exp(float n, float d)
     return x;
 }
 
-/* applyBlockCore, MCTF.cpp:423-518.  corrected[i]: compact w x h blocks. */
+/* applyBlockCore, MCTF.cpp:423-518 — and, sample for sample, the reference's x86 row applyBlockSIMD (CommonLib/x86/MCTFX86.h:1207-1440) as well: the two differ in ONE operation,
+ * the rounding of the blended sample — ( Pel )( newVal + 0.5 ) with a double literal here, _mm_add_ps( v, 0.5f ) + truncation there (:1424-1427) — and the single-precision sum
+ * is exact whenever it could change the integer part (v and v + 0.5 share a binade unless the sum crosses a power of two, where the integer part is that power either way);
+ * -a / b == a / -b in IEEE arithmetic covers the other textual difference.  tests/test_oracle_vs_reference.py holds both rows to tolerance 0 (the reference's unit test allows
+ * them +-1, test/vvenc_unit_test/vvenc_unit_test.cpp:1280-1282). */
+/* corrected[i]: compact w x h blocks. */
 void orc_mctf_apply_block(const int16_t *src, ptrdiff_t ss, int16_t *dst, ptrdiff_t ds, int w, int h, int bitDepth,
                           const int16_t *const *corrected, int numRefs, const int *verror, const double *refStrengths,
                           double weightScaling, double sigmaSq)

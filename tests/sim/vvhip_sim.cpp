@@ -395,6 +395,7 @@ int vvhip_mctf_motion_estimation_async( vvhip_ctx* ctx, const int16_t* cur, cons
 {
   return vvhip_mctf_motion_estimation( ctx, cur, refs, nRefs, stride, w, h, pad, bd, unit, speed, addLevel, outs );      // (the test double has no streams: every call is complete on return)
 }
+int vvhip_tu_set_sparse_outputs( vvhip_ctx* ctx, int ) { return ctx ? VVHIP_OK : VVHIP_E_ARG; }      // (the test double always writes every output: a valid "unspecified")
 int vvhip_mctf_set_stats( vvhip_ctx* ctx, int ) { UNSUPPORTED( "vvhip_mctf_set_stats" ); }
 int vvhip_mctf_get_stats( vvhip_ctx* ctx, uint64_t* ) { UNSUPPORTED( "vvhip_mctf_get_stats" ); }
 int vvhip_mctf_set_timing( vvhip_ctx* ctx, int ) { UNSUPPORTED( "vvhip_mctf_set_timing" ); }

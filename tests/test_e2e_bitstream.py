@@ -373,6 +373,32 @@ def test_hip_cu_level_sites_bitstream_identical(site, first, second):
 
 
 @pytest.mark.gpu
+def test_production_mask_equals_the_x86_row_where_the_references_rows_differ():
+    """on the 416x240 'pan' clip the reference's OWN --SIMD=SCALAR stream differs from its default (AVX2) stream with MCTF on (equal with MCTF=0;BIM=0).
+    north_star's comparison target is the x86 row: --SIMD=HIP (production mask: MCTF search + filter + ALF statistics on the device) must equal the DEFAULT stream there, and so
+    must the MCTF stages alone (16 + 128).  The scalar stream is encoded next to them: this test fails if the device side ever follows it instead (or if either choice changes
+    silently).  What the row difference is NOT (round 6, CPU tier): the MCTF search and filter — with both replaced by scalar-row arithmetic the encoder still emits the AVX2
+    stream (tests/test_binding_sim.py::test_mctf_stages_keep_the_default_stream_on_the_pan_clip), and the filter's two rows agree sample for sample (tolerance 0)."""
+    if not os.path.exists(e2e_util.REF_HIP_SO):
+        pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
+    clip = dict(w=416, h=240, frames=9, in_bd=10, int_bd=10, clip="pan", threads=4)
+    default = run(dict(clip, hip=False, simd=None, mask=0))
+    scalar = run(dict(clip, hip=False, simd="SCALAR", mask=0))
+    hip = run(dict(clip, hip=True, simd="HIP"))
+    stages = run(dict(clip, hip=True, simd=None, mask=16 + 128))
+    print("default", default["md5"], "scalar", scalar["md5"], "hip", hip["md5"], "mctf stages", stages["md5"])
+    assert hip["calls"][21] >= 1 and hip["calls"][9] >= 1, hip["calls"]                      # the MCTF search and the filter really ran on the device
+    assert stages["calls"][21] >= 1 and stages["calls"][9] >= 1, stages["calls"]
+    assert hip["md5"] == default["md5"] and hip["bytes"] == default["bytes"], (default, hip)
+    assert stages["md5"] == default["md5"], (default, stages)
+    if scalar["md5"] != default["md5"]:
+        assert hip["md5"] != scalar["md5"]                                                   # (documented: the device side is the x86 row's twin, not the scalar row's)
+    off = "MCTF=0;BIM=0"
+    three = [run(dict(clip, hip=h, simd=sd, mask=0, options=off))["md5"] for h, sd in ((False, "SCALAR"), (False, None), (True, "HIP"))]
+    assert len(set(three)) == 1, three
+
+
+@pytest.mark.gpu
 def test_hip_lfnst_quantiser_guard_bitstream_identical():
     """with RDOQ and DepQuant off the encoder's scalar quantiser (Quant::xQuant) is the main path, and LFNST TUs must see QuantCore's first-coefficient-group
     rule (Quant.cpp:152-159): the binding leaves them to the CPU entry, everything else goes to the device core"""

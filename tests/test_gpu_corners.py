@@ -267,6 +267,77 @@ def test_fused_tu_all_zero_level_shortcut_vs_oracle(env):
     assert n_zero_tus > 1000 and n_level_tus > 300, (n_zero_tus, n_level_tus)
 
 
+def test_fused_tu_sparse_outputs_leave_all_zero_tus_untouched(env):
+    """round 6 (vvhip_tu_set_sparse_outputs): with the sparse contract a TU whose levels are all zero gets its statistics ONLY.  Garbage-prefilled level / reconstruction buffers:
+    a TU with levels must hold the oracle's levels and reconstruction; a TU without must be either untouched (0x7777 / 0x5555 everywhere: the whole tile took the shortcut) or
+    all zero (it shared its tile with a TU that has levels) — never anything else; statistics always the oracle's; whole all-zero tiles MUST be untouched (that is the point);
+    and switching the contract back restores the dense behaviour on the same context"""
+    import torch
+    from vvenc_amd.hotpath import STATS_DTYPE, HotPath
+    hp, orc = env
+    rng = np.random.default_rng(777)
+    untouched = zeroed = with_levels = 0
+    try:
+        hp.tu_set_sparse_outputs(True)
+        for bd in (10, 8):
+            for S in (8, 16, 32, 64):
+                tpt = 1 if S == 64 else (32 // S) ** 2
+                for (th, tv) in ((0, 0),) + (((2, 2),) if S <= 32 else ()):
+                    for pattern in ("all tiny", "tiles alternate", "one TU with levels per tile"):
+                        n = 3 * tpt + max(1, tpt // 3) if S < 64 else 7
+                        big = np.zeros(n, bool)
+                        if pattern == "tiles alternate":
+                            big = (np.arange(n) // tpt) % 2 == 1
+                        elif pattern == "one TU with levels per tile":
+                            starts = np.arange(0, n, tpt)
+                            big[np.minimum(starts + rng.integers(0, tpt, starts.size), n - 1)] = True
+                        amp = min(300, (1 << bd) - 1)
+                        resi = np.where(big[:, None, None], rng.integers(-amp, amp + 1, (n, S, S)), rng.integers(-1, 2, (n, S, S))).astype(np.int16)
+                        qps = np.where(big, rng.integers(22, 40, n), rng.integers(30, 52, n))
+                        irap = rng.integers(0, 2, n)
+                        pool = hp.to_device(resi.reshape(-1))
+                        off = hp.to_device((np.arange(n, dtype=np.int32) * S * S).astype(np.int32))
+                        qp = hp.to_device(HotPath.tu_qp(qps, irap, 1))
+                        lev = torch.full((n * S * S,), 0x7777, dtype=torch.int16, device=hp.device)
+                        rec = torch.full((n * S * S,), 0x5555, dtype=torch.int16, device=hp.device)
+                        st = torch.full((n, STATS_DTYPE.itemsize), 0xEE, dtype=torch.uint8, device=hp.device)
+                        hp.tu_rdo_multi_strided(pool, [S], [(S, S, th, tv, n, 8, off, qp, lev, rec, st)], bd)
+                        torch.cuda.synchronize()
+                        lv, rc = lev.cpu().numpy().reshape(n, S, S), rec.cpu().numpy().reshape(n, S, S)
+                        sv = st.cpu().numpy().view(STATS_DTYPE).reshape(n)
+                        exp = [orc.tu_rdo(resi[i], int(qps[i]), int(irap[i]), th, tv, bd, 8, 1) for i in range(n)]
+                        for i, (el, er, es) in enumerate(exp):
+                            got = (int(sv["abs_sum"][i]), int(sv["last_scan_pos"][i]), int(sv["need_rdoq"][i]), int(sv["sse"][i]))
+                            assert got == (es["abs_sum"], es["last_scan_pos"], es["need_rdoq"], es["sse"]), (bd, S, th, tv, pattern, i, got, es)
+                            if es["abs_sum"] != 0:
+                                assert np.array_equal(lv[i], el) and np.array_equal(rc[i], er), (bd, S, pattern, i)
+                                with_levels += 1
+                            else:
+                                kept = bool((lv[i] == 0x7777).all() and (rc[i] == 0x5555).all())
+                                zero = bool((lv[i] == 0).all() and (rc[i] == 0).all())
+                                assert kept or zero, ("neither untouched nor zero", bd, S, th, tv, pattern, i)
+                                tile_all_zero = all(e[2]["abs_sum"] == 0 for e in exp[(i // tpt) * tpt:(i // tpt + 1) * tpt])
+                                if tile_all_zero:
+                                    assert kept, ("an all-zero tile wrote its outputs", bd, S, th, tv, pattern, i)
+                                untouched += kept
+                                zeroed += zero
+        assert untouched > 300 and with_levels > 150, (untouched, zeroed, with_levels)
+    finally:
+        hp.tu_set_sparse_outputs(False)
+    # dense again: the same all-tiny list writes zeros everywhere
+    S, n = 16, 8
+    resi = rng.integers(-1, 2, (n, S, S)).astype(np.int16)
+    pool = hp.to_device(resi.reshape(-1))
+    off = hp.to_device((np.arange(n, dtype=np.int32) * S * S).astype(np.int32))
+    qp = hp.to_device(HotPath.tu_qp(np.full(n, 45), np.zeros(n, int), 1))
+    lev = torch.full((n * S * S,), 0x7777, dtype=torch.int16, device=hp.device)
+    rec = torch.full((n * S * S,), 0x5555, dtype=torch.int16, device=hp.device)
+    st = torch.zeros((n, STATS_DTYPE.itemsize), dtype=torch.uint8, device=hp.device)
+    hp.tu_rdo_multi_strided(pool, [S], [(S, S, 0, 0, n, 8, off, qp, lev, rec, st)], 10)
+    torch.cuda.synchronize()
+    assert int(lev.abs().sum()) == 0 and int(rec.abs().sum()) == 0
+
+
 def test_masked_sad_large_operands_sum_in_64_bits(env):
     """masked SADs take any int16 operands (include/vvenc_hip.h) and the reference sums in a 64-bit Distortion (RdCost.cpp:2062-2093): a 128x128 block of large
     differences and weights passes 2^32 — the wave takes its 64-bit form; GEO-range operands next to it keep the 32-bit form.  Against the numpy restatement of the loop"""

@@ -5,6 +5,7 @@ Mirrors the reference's own unit tests: test_RdCost (vvenc_unit_test.cpp:2136-21
 10-bit unsigned samples, random strides, subShift 0/1), test_TCoeffOps (:1175-1210) and test_MCTF
 (:1592-1654: w,h in 8..64 step 8, all 15x15 filter phases).  Skipped where the .so is absent.
 """
+import os
 import numpy as np
 import pytest
 
@@ -406,7 +407,7 @@ def test_if_luma_dispatch_and_prediction(oracle, reflib):
 def _mctf_tol(reflib):
     """the reference's own unit test holds its SIMD row to +-1 of the scalar row for the float bilateral filter (vvenc_unit_test.cpp:1280-1282);
     the oracle restates the SCALAR row and must match it exactly"""
-    return 1 if reflib.simd else 0
+    return 0 if os.environ.get("VVHIP_MCTF_ROWS_EXACT", "1") == "1" else (1 if reflib.simd else 0)
 
 
 def test_mctf_apply_frac_and_planar(oracle, reflib):

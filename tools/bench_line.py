@@ -50,6 +50,7 @@ def _e2e(e):
     if isinstance(e.get("scalar"), dict):
         o["scalar_md5_equal"] = e["scalar"].get("md5_equal")
         o["scalar_md5_equal_default"] = e["scalar"].get("md5_equal_default")
+        o["hip_equals_default_mctf_on"] = e["scalar"].get("hip_equals_default")
     ss = e.get("stage_split")
     if isinstance(ss, dict) and "share" in ss:
         o["stage_split"] = {"share": ss["share"], "device_stage_share": ss.get("device_stage_share"), "amdahl_bound_speedup": ss.get("amdahl_bound_speedup"),

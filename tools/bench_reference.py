@@ -220,6 +220,8 @@ def parity_check(workloads):
             for g, (sse, st4) in zip(wl.tu_groups, J.tu_outs):
                 st = g["stats"].cpu().numpy().view(STATS_DTYPE).reshape(-1)
                 lv = g["level"].view(g["n"], -1).to(torch.int64)
+                if getattr(wl, "tu_sparse", False):          # sparse outputs: the levels of a TU whose abs_sum is 0 are unspecified and READ AS ZERO by the caller
+                    lv = lv * torch.from_numpy((st["abs_sum"] != 0).astype(np.int64)).to(lv.device)[:, None]
                 idx = torch.arange(1, lv.shape[1] + 1, device=lv.device, dtype=torch.int64)
                 cs = ((lv * idx).sum(1) & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
                 bad = (st["sse"] != sse) | (st["abs_sum"] != st4[:, 0]) | (st["need_rdoq"] != st4[:, 2]) | (cs != st4[:, 3].view(np.uint32))

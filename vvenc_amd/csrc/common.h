@@ -36,6 +36,7 @@ struct vvhip_ctx
   void*        d_tuGen    = nullptr;
   size_t       tuGenBytes = 0;
   std::vector<unsigned char> tuGenLast;
+  bool         tuSparse   = false;     // vvhip_tu_set_sparse_outputs: the fused TU launches of vvhip_tu_rdo_multi[_strided] write no levels / reconstruction for TUs whose levels are all zero
   hipStream_t  tuGenStream = nullptr;      // the stream the cached generic-TU job table was uploaded on (trquant.hip: tuRdoMulti); compared only, never used as a handle
   hipEvent_t   tuGenEvent  = nullptr;      // recorded behind every launch that reads the table: a caller that switches streams orders the new stream behind it
   bool         tuGenEventRecorded = false;

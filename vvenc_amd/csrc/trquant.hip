@@ -928,7 +928,7 @@ struct TuMxArgs
   const vvhip_tu_qp* qps; int thrVal;
   int16_t* level; int16_t* rec; vvhip_tu_stats* stats;
   int tiles;               // 32x32 tiles of this job
-  int phaseLimit;          // profiling aid ($VVHIP_TU_PHASES): skip the rest of a tile after phase k, 0 = run everything
+  int phaseLimit;          // bits 0..7: profiling aid ($VVHIP_TU_PHASES): skip the rest of a tile after phase k, 0 = run everything; bit 8: sparse outputs (vvhip_tu_set_sparse_outputs)
   int waveStride;          // waves assigned to this job (wave w walks tiles w, w + waveStride, ...)
   int resiStride;          // row pitch of this job's residual blocks; 0: the launch's common pitch (vvhip_tu_rdo_multi_strided: compact per-TU blocks, pitch = width)
 };
@@ -1083,7 +1083,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
     for( int v = 0; v < 16; v++ ) pos[v] = ( v & 1 ) ? pw[v >> 1] >> 16 : pw[v >> 1] & 0xffffu;
   }
   WAVE_SYNC();
-  if( A.phaseLimit == 1 ) return;
+  if( ( A.phaseLimit & 0xff ) == 1 ) return;
 
   for( int tile = waveIndex; tile < A.tiles; tile += A.waveStride )
   {
@@ -1098,7 +1098,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
     vvhip_tu_qp qqs[R];                                               // QPs of the lane's TUs on the coefficient side: column block blkL, row blocks blk0 + r
 #pragma unroll
     for( int r = 0; r < R; r++ ) { const int tu = tile * TPT + ( blk0 + r ) * TPS + blkL; qqs[r] = tu < A.n ? A.qps[tu] : vvhip_tu_qp{ 32, 0 }; }
-    if( A.phaseLimit == 2 ) { int k_ = 0; _Pragma( "unroll" ) for( int g = 0; g < 4; g++ ) k_ ^= aLo[g] ^ aHi[g]; if( k_ == 0x12345678 ) A.stats[0].pad = 1; continue; }
+    if( ( A.phaseLimit & 0xff ) == 2 ) { int k_ = 0; _Pragma( "unroll" ) for( int g = 0; g < 4; g++ ) k_ ^= aLo[g] ^ aHi[g]; if( k_ == 0x12345678 ) A.stats[0].pad = 1; continue; }
 
     int d[16];
     v4i bLo, bHi;
@@ -1119,7 +1119,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
       const v4i opP2 = sOps[64 + lane];
       MX_PASS( opP2, bHi, opP2, bLo, c, A.shF2 );
     }
-    if( A.phaseLimit == 3 ) { TUMX_KEEP( d ); continue; }
+    if( ( A.phaseLimit & 0xff ) == 3 ) { TUMX_KEEP( d ); continue; }
 
     // ---- per TU: significance, QuantCore, DeQuantCore on the registers (the lane's TUs are walked in lockstep: their reduction chains overlap).
     // Significance: last non-zero scan position; largest magnitude (need-RDOQ is one test on it: the quantiser is monotonic); highest scan
@@ -1169,7 +1169,7 @@ tuMxBody( int16_t* __restrict__ stage, int32_t* __restrict__ sInit, v4i* __restr
         if( big[r] < 16 ) last[r] = 15;
         else if( ( big[r] >> 4 ) != ( last[r] >> 4 ) ) last[r] = ( big[r] >> 4 ) * 16 + 15;
       }
-    if( A.phaseLimit == 4 ) { TUMX_KEEP( d ); continue; }
+    if( ( A.phaseLimit & 0xff ) == 4 ) { TUMX_KEEP( d ); continue; }
     // Every TU of the tile quantises to all-zero levels (WAVE-UNIFORM; most TUs an encoder's RDO tries at its usual QPs: 72-98 % of the area of the recorded 1080p lists): the
     // dequantised coefficients are 0, both inverse passes give ( 0 + rnd ) >> shift = 0, the reconstructed residual is 0 and the SSE is the residual's energy — the quantiser
     // loop, the level staging and the two inverse passes are skipped; what is written is what the long way writes (levels 0, rec 0, abs sum 0, the same last / need-RDOQ).
@@ -1276,6 +1276,9 @@ _Pragma( "unroll" ) \
       }
       // zeros for levels AND reconstruction in the raster mapping of the level stores (a wave instruction writes whole 64-byte runs; the long way's reconstruction stores go
       // row by row from the lanes that hold the rows: two half-filled requests per row)
+      // (sparse outputs, vvhip_tu_set_sparse_outputs: a TU whose abs_sum is 0 gets NEITHER levels NOR reconstruction — the caller treats them as zero, as the reference does,
+      //  which reads neither for such a TU, InterSearch.cpp:3696-3714; the tile then moves its residual in and 24 bytes per TU out)
+      if( !( A.phaseLimit & 0x100 ) )
 #pragma unroll
       for( int u = 0; u < 16 / PS; u++ )
       {
@@ -1361,7 +1364,7 @@ _Pragma( "unroll" ) \
         st[0] = ( int32_t ) sum; st[1] = ( int32_t ) last[r]; st[2] = ( int32_t ) need[r]; st[3] = 0;
       }
     }
-    if( A.phaseLimit == 5 ) { TUMX_KEEP( d ); continue; }
+    if( ( A.phaseLimit & 0xff ) == 5 ) { TUMX_KEEP( d ); continue; }
     WAVE_SYNC();
     // ---- levels: staging rows -> raster in runs of PS samples (run q: row q / (32 / PS) of the tile, samples PS * (q % (32 / PS)) ..)
     if( A.level )
@@ -1379,7 +1382,7 @@ _Pragma( "unroll" ) \
       }
     WAVE_SYNC();
 
-    if( A.phaseLimit == 6 ) { TUMX_KEEP( d ); continue; }
+    if( ( A.phaseLimit & 0xff ) == 6 ) { TUMX_KEEP( d ); continue; }
     // ---- inverse columns: t1[y][k] = clip( ( sum_k2 deq[k2][k] * Tv[k2][y] + 64 ) >> 7 )                  (TrQuant.cpp:612)
     mxSplit( d, aLo, aHi );
     {
@@ -1400,7 +1403,7 @@ _Pragma( "unroll" ) \
       const v4i opI2 = *reinterpret_cast<const v4i*>( A.opH->colP[lane] );
       MX_PASS( opI2, bHi, opI2, bLo, c, A.shI2 );
     }
-    if( A.phaseLimit == 7 ) { TUMX_KEEP( d ); continue; }
+    if( ( A.phaseLimit & 0xff ) == 7 ) { TUMX_KEEP( d ); continue; }
     TUMX_TAIL( true )
   }
 #undef WAVE_SYNC
@@ -1548,12 +1551,13 @@ tuMx64Body( int16_t* __restrict__ stage, int32_t* __restrict__ sInit /* [96] */,
           const u32x4 z4 = { 0, 0, 0, 0 };
           // (levels and reconstruction zeros in the same raster runs: whole 64-byte requests; 512 runs of 8 samples per array, 2 per lane and chunk)
           const int q0 = lane + 64 * ( 4 * t + 2 * c );
-          if( A.rec )
+          const bool dense = !( A.phaseLimit & 0x100 );      // (sparse outputs: nothing but the statistics for a TU whose levels are all zero, see tuMxBody)
+          if( A.rec && dense )
           {
             *reinterpret_cast<u32x4*>( A.rec + ( size_t ) tu * 4096 + ( size_t ) q0 * 8 ) = z4;
             *reinterpret_cast<u32x4*>( A.rec + ( size_t ) tu * 4096 + ( size_t ) ( q0 + 64 ) * 8 ) = z4;
           }
-          if( A.level )
+          if( A.level && dense )
           {
             *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * 4096 + ( size_t ) q0 * 8 ) = z4;
             *reinterpret_cast<u32x4*>( A.level + ( size_t ) tu * 4096 + ( size_t ) ( q0 + 64 ) * 8 ) = z4;
@@ -2234,6 +2238,13 @@ int vvhip_tu_rdo_multi( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, 
   return tuRdoMulti( ctx, d_resi, resi_stride, nullptr, bit_depth, jobs, n_jobs );
 }
 
+int vvhip_tu_set_sparse_outputs( vvhip_ctx* ctx, int on )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  ctx->tuSparse = on != 0;
+  return VVHIP_OK;
+}
+
 int vvhip_tu_rdo_multi_strided( vvhip_ctx* ctx, const int16_t* d_resi, const int32_t* resi_strides_host, int bit_depth, const vvhip_tu_job* jobs, int n_jobs )
 {
   if( !ctx ) return VVHIP_E_ARG;
@@ -2409,7 +2420,7 @@ static int tuRdoMulti( vvhip_ctx* ctx, const int16_t* d_resi, int resi_stride, c
         xa.opH = ctx->d_tuMx + jb.tr_hor * 4 + z; xa.opV = ctx->d_tuMx + jb.tr_ver * 4 + z; xa.pos = ctx->d_tuMxPos + z * 64 * 16;
         if( jb.width == 64 ) { xa.opH = reinterpret_cast<const VvhipTuMxOps*>( ctx->d_tuMx64 ); xa.opV = xa.opH; xa.pos = nullptr; }
         xa.qps = jb.d_qp; xa.thrVal = jb.thr_val; xa.level = jb.d_level; xa.rec = jb.d_rec_resi; xa.stats = jb.d_stats;
-        xa.tiles = ( jb.n + tpt - 1 ) / tpt; xa.phaseLimit = tuPhaseLimit();
+        xa.tiles = ( jb.n + tpt - 1 ) / tpt; xa.phaseLimit = tuPhaseLimit() | ( ctx->tuSparse ? 0x100 : 0 );
         const int repeat = budget ? repeatOf( first + i ) : tuRepeat();
         xa.waveStride = wavesPer( first + i ) * ( ( xa.tiles + repeat - 1 ) / repeat );
         xa.resiStride = strides ? strides[order[first + i]] : 0;

@@ -571,6 +571,10 @@ class HotPath:
     def mctf_set_stats(self, on):
         self._ck(self.L.vvhip_mctf_set_stats(self.ctx, int(bool(on))))
 
+    def tu_set_sparse_outputs(self, on):
+        """vvhip_tu_set_sparse_outputs: the fused TU launches write no levels / reconstruction for TUs whose levels are all zero (the caller treats them as zero)"""
+        self._ck(self.L.vvhip_tu_set_sparse_outputs(self.ctx, int(bool(on))))
+
     def mctf_set_timing(self, on):
         self._ck(self.L.vvhip_mctf_set_timing(self.ctx, int(bool(on))))
 

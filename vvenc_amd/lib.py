@@ -104,6 +104,7 @@ PROTOTYPES = {
     "vvhip_mctf_me_level": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32]),
     "vvhip_mctf_motion_estimation": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "vvhip_mctf_motion_estimation_async": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "vvhip_tu_set_sparse_outputs": (i32, [vp, i32]),
     "vvhip_mctf_set_stats": (i32, [vp, i32]),
     "vvhip_mctf_get_stats": (i32, [vp, vp]),
     "vvhip_mctf_set_timing": (i32, [vp, i32]),

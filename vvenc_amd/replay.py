@@ -428,6 +428,10 @@ class RecordedWorkload:
             tu_jobs.append((w, h, g["tr_hor"], g["tr_ver"], n, 8, d["d_off"], d["d_qp"], d["level"], d["rec"], d["stats"]))
             strides_l.append(w)
         self.tu_table = hp.make_tu_jobs(tu_jobs) if tu_jobs else None
+        # sparse outputs (round 6): a TU whose levels are all zero gets only its statistics — xEstimateInterResidualQT reads neither levels nor reconstruction of such a TU
+        # (EncoderLib/InterSearch.cpp:3696-3714); $VVHIP_TU_SPARSE=0: the dense contract (every output written)
+        self.tu_sparse = os.environ.get("VVHIP_TU_SPARSE", "1") != "0"
+        hp.tu_set_sparse_outputs(self.tu_sparse)
         self.tu_strides = (C.c_int32 * max(1, len(strides_l)))(*strides_l)
         self._tu_call = hp.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), bit_depth, self.tu_table[0], self.tu_table[1]) if tu_jobs else None
         self.dmvr_groups = [dict(g, d_items=hp.to_device(g["items"]), out=torch.zeros((g["n"], 16), dtype=torch.uint8, device=dev)) for g in lists.dmvr_groups]
@@ -445,6 +449,7 @@ class RecordedWorkload:
         else:
             me = [lanes[0].bound("vvhip_me_plan_run", *args)]
             hp1, hp2 = lanes[1], lanes[2]
+        hp1.tu_set_sparse_outputs(self.tu_sparse)
         # (round 5: the 64x64 TU lists as a launch of their own on a sixth stream was measured and is SLOWER — step 68.4 -> 77.7 us — the second launch's fixed ~5.5 us and its
         #  queue slot cost more than the long 64-point waves gain from leaving the other sizes' launch; profiles/r05_tu_kernel.md)
         tus = [hp1.bound("vvhip_tu_rdo_multi_strided", C.c_void_p(self.pool.data_ptr()), C.cast(self.tu_strides, C.c_void_p), self.bit_depth, self.tu_table[0], self.tu_table[1])] if self.tu_table else []
@@ -466,6 +471,23 @@ class RecordedWorkload:
 
     def run_me(self):
         self._me_call()
+
+    def update_tu_alg_bytes(self):
+        """algorithmic bytes of the TU lists under the sparse-output contract, from the statistics of the last run: a TU with abs_sum == 0 moves its residual in and 24 bytes
+        out (2 w h + 24), any other the full 6 w h + 24.  Dense contract: 6 w h + 24 for every TU."""
+        from .hotpath import STATS_DTYPE
+        torch.cuda.synchronize()
+        tot = zero_tus = zero_area = area = 0
+        for g in self.tu_groups:
+            wh = g["w"] * g["h"]
+            nz = int((g["stats"].cpu().numpy().view(STATS_DTYPE).reshape(-1)["abs_sum"] == 0).sum()) if self.tu_sparse else 0
+            tot += nz * (2 * wh + 24) + (g["n"] - nz) * (6 * wh + 24)
+            zero_tus += nz
+            zero_area += nz * wh
+            area += g["n"] * wh
+        self.alg_bytes_tu = int(tot)
+        self.tu_zero_share = {"tus": zero_tus, "area_share": round(zero_area / area, 4) if area else None}
+        return self.alg_bytes_tu
 
     def run_tu(self):
         if self._tu_call is not None:
