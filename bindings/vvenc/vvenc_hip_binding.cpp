@@ -62,7 +62,7 @@ vvhip::RdCost*   g_rd = nullptr;
 vvhip::QuantOps* g_q  = nullptr;
 vvhip::MCTFOps*  g_m  = nullptr;
 std::atomic<uint64_t> g_calls[10];    // dist, x5, fwd, inv, quant, dequant, needrdoq, mctf, interpolation, whole-picture MCTF filter
-std::atomic<uint64_t> g_lfnstQuantFallbacks{ 0 }, g_mctfDeviceCalls{ 0 };
+std::atomic<uint64_t> g_lfnstQuantFallbacks{ 0 }, g_lfnstQuantDevice{ 0 }, g_mctfDeviceCalls{ 0 };
 
 vvhip::DistParam conv( const vvenc::DistParam& dp )
 {
@@ -105,15 +105,16 @@ void initRdCost( vvenc::RdCost* rc )
   rc->m_fxdWtdPredPtr = fxdWtdTramp;
 }
 
-// the CPU entries this binding replaced (the same functions for every Quant object): LFNST TUs keep going there — QuantCore then looks at the first coefficient
-// group only (iCGNum = 1, Quant.cpp:152-159), which the device core (lfnstIdx == 0 by contract, include/vvenc_hip.h) does not reproduce
+// the CPU entry this binding replaced (the same function for every Quant object).  Until round 6 LFNST TUs kept going there; QuantCore's first-coefficient-group rule for
+// them (iCGNum = 1, Quant.cpp:149-159) is on the device now (vvhip_quant_core_lfnst) — $VVHIP_LFNST_QUANT_ON_CPU=1 restores the old route (counter 20 counts those TUs)
 decltype( vvenc::Quant::xQuant ) g_cpuQuant = nullptr;
+static const bool g_lfnstOnCpu = []{ const char* e = getenv( "VVHIP_LFNST_QUANT_ON_CPU" ); return e && atoi( e ) != 0; }();
 
 void xQuantTramp( const vvenc::TransformUnit tu, const vvenc::ComponentID compID, const vvenc::CCoeffBuf& piCoef, vvenc::CoeffSigBuf piQCoef, vvenc::TCoeff& uiAbsSum,
                   int& lastScanPos, vvenc::TCoeff* deltaU, const int defaultQuantisationCoefficient, const int iQBits, const int64_t iAdd,
                   const vvenc::TCoeff entropyCodingMinimum, const vvenc::TCoeff entropyCodingMaximum, const bool signHiding, const vvenc::TCoeff m_thrVal )
 {
-  if( tu.cu->lfnstIdx && g_cpuQuant )
+  if( tu.cu->lfnstIdx && g_cpuQuant && g_lfnstOnCpu )
   {
     g_lfnstQuantFallbacks++;
     g_cpuQuant( tu, compID, piCoef, piQCoef, uiAbsSum, lastScanPos, deltaU, defaultQuantisationCoefficient, iQBits, iAdd, entropyCodingMinimum, entropyCodingMaximum, signHiding, m_thrVal );
@@ -124,7 +125,8 @@ void xQuantTramp( const vvenc::TransformUnit tu, const vvenc::ComponentID compID
   std::vector<vvenc::TCoeffSig> lev( ( size_t ) w * h );
   std::vector<vvenc::TCoeff> src( ( size_t ) w * h );
   for( unsigned y = 0; y < h; y++ ) memcpy( &src[( size_t ) y * w], piCoef.buf + y * piCoef.stride, sizeof( vvenc::TCoeff ) * w );
-  g_q->xQuantCore( w, h, src.data(), lev.data(), uiAbsSum, lastScanPos, deltaU, defaultQuantisationCoefficient, iQBits, iAdd, m_thrVal );
+  if( tu.cu->lfnstIdx ) { g_lfnstQuantDevice++; g_q->xQuantCoreLfnst( w, h, src.data(), lev.data(), uiAbsSum, lastScanPos, deltaU, defaultQuantisationCoefficient, iQBits, iAdd, m_thrVal, tu.cu->lfnstIdx ); }
+  else g_q->xQuantCore( w, h, src.data(), lev.data(), uiAbsSum, lastScanPos, deltaU, defaultQuantisationCoefficient, iQBits, iAdd, m_thrVal );
   for( unsigned y = 0; y < h; y++ ) memcpy( piQCoef.buf + y * piQCoef.stride, &lev[( size_t ) y * w], sizeof( vvenc::TCoeffSig ) * w );
 }
 void xDeQuantTramp( const int maxX, const int maxY, const int scale, const vvenc::TCoeffSig* const q, const size_t qStride, vvenc::TCoeff* const coef,
@@ -813,7 +815,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_install( i
   g_tzRounds = 0; g_tzHits = 0;
   g_dmvrCalls = 0;
   g_patternCalls = 0;
-  g_lfnstQuantFallbacks = 0; g_mctfDeviceCalls = 0;
+  g_lfnstQuantFallbacks = 0; g_lfnstQuantDevice = 0; g_mctfDeviceCalls = 0;
   for( auto& c : g_calls ) c = 0;
   return 0;
 }
@@ -885,5 +887,6 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
     if( n > 35 ) out[35] = g_mergeCands;
     if( n > 36 ) out[36] = g_tuPrefetchNs;
     if( n > 37 ) out[37] = g_mergeNs;
+    if( n > 38 ) out[38] = g_lfnstQuantDevice;      // LFNST TUs quantised on the device (round 6; 20 = those left to the CPU entry: 0 unless $VVHIP_LFNST_QUANT_ON_CPU=1)
   }
 }

@@ -226,12 +226,16 @@ VVHIP_API int vvhip_need_rdoq_batch( vvhip_ctx* ctx, const int32_t* d_coef, int 
 
 /* Raw-parameter forms with exactly the argument lists of the reference's table entries Quant::xDeQuant / Quant::xNeedRdoq
  * (CommonLib/Quant.h:143-151; QuantCore / DeQuantCore / needRdoqCore, Quant.cpp:132-278;
- * vvhip_quant_core takes QuantCore's defaultQuantisationCoefficient, iQBits, iAdd, m_thrVal; lfnstIdx == 0), for the table-shaped shim: ONE block per call.
+ * vvhip_quant_core takes QuantCore's defaultQuantisationCoefficient, iQBits, iAdd, m_thrVal; lfnstIdx == 0 — vvhip_quant_core_lfnst any), for the table-shaped shim: ONE block per call.
  * d_level is strided (level_stride), d_coef compact (max_x+1) x (max_y+1); *d_need receives 0/1.                            */
 VVHIP_API int vvhip_dequant_core( vvhip_ctx* ctx, int max_x, int max_y, int scale, const int16_t* d_level, size_t level_stride, int32_t* d_coef,
                                   int right_shift, int input_maximum, int32_t transform_maximum );
 VVHIP_API int vvhip_quant_core( vvhip_ctx* ctx, const int32_t* d_coef, int width, int height, int quant_coeff, int q_bits, int64_t add, int thr_val,
                                 int16_t* d_level /* w*h compact */, int32_t* d_delta_u /* may be NULL */, int32_t* d_abs_sum, int32_t* d_last_scan_pos );
+/* QuantCore for a TU of a coding unit with lfnst_idx > 0 (CodingUnit::lfnstIdx, presets fast / medium): only the first coefficient group is quantised, its first 8 scan
+ * positions for 4x4 and 8x8 TUs (Quant.cpp:149-159); lfnst_idx == 0 is vvhip_quant_core.  Replaces the same table entry (Quant::xQuant, Quant.h:143-146).            */
+VVHIP_API int vvhip_quant_core_lfnst( vvhip_ctx* ctx, const int32_t* d_coef, int width, int height, int quant_coeff, int q_bits, int64_t add, int thr_val, int lfnst_idx,
+                                      int16_t* d_level /* w*h compact */, int32_t* d_delta_u /* may be NULL */, int32_t* d_abs_sum, int32_t* d_last_scan_pos );
 VVHIP_API int vvhip_need_rdoq_core( vvhip_ctx* ctx, const int32_t* d_coef, size_t num_coeff, int quant_coeff, int64_t offset, int shift, uint8_t* d_need );
 
 /* Fused TU pipeline of the residual RDO loop (InterSearch::xEstimateInterResidualQT,

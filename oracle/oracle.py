@@ -480,13 +480,14 @@ class Oracle(_Base):
         self.L.orc_need_rdoq_params(w, h, bit_depth, qp, int(is_luma), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         return a.value, b.value, c.value, d.value
 
-    def quant_core(self, coef, quant_coeff, q_bits, add, thr_val=8, sign_hiding=False):
+    def quant_core(self, coef, quant_coeff, q_bits, add, thr_val=8, sign_hiding=False, lfnst_idx=0):
         coef = np.ascontiguousarray(coef, np.int32)
         h, w = coef.shape
         q = np.zeros((h, w), np.int16)
         du = np.zeros(h * w, np.int32)
         s, last = C.c_int32(), C.c_int()
-        self.L.orc_quant_core(_p(coef), _p(q), _p(du), w, h, quant_coeff, q_bits, add, thr_val, C.byref(s), C.byref(last))
+        self.L.orc_quant_core_lfnst.restype = None
+        self.L.orc_quant_core_lfnst(_p(coef), _p(q), _p(du), w, h, quant_coeff, q_bits, C.c_int64(add), thr_val, int(lfnst_idx), C.byref(s), C.byref(last))
         return q, du, s.value, last.value
 
     def dequant_core(self, q, scale, right_shift, input_max, tr_max=32767):
@@ -737,13 +738,13 @@ class RefLib(_Base):
         self.L.vvref_quant_scales(_p(q), _p(iq))
         return q.reshape(2, 6), iq.reshape(2, 6)
 
-    def quant_core(self, coef, quant_coeff, q_bits, add, thr_val=8, sign_hiding=False):
+    def quant_core(self, coef, quant_coeff, q_bits, add, thr_val=8, sign_hiding=False, lfnst_idx=0):
         coef = _aligned(np.ascontiguousarray(coef, np.int32))
         h, w = coef.shape
         q = _aligned(np.zeros((h, w), np.int16))
         du = _aligned(np.zeros(h * w, np.int32))
         s, last = C.c_int32(), C.c_int()
-        self.L.vvref_quant_core(_p(coef), _p(q), _p(du), w, h, quant_coeff, q_bits, add, int(sign_hiding), thr_val, C.byref(s), C.byref(last))
+        self.L.vvref_quant_core_lfnst(_p(coef), _p(q), _p(du), w, h, quant_coeff, q_bits, C.c_int64(add), int(sign_hiding), thr_val, int(lfnst_idx), C.byref(s), C.byref(last))
         return np.array(q), np.array(du), s.value, last.value
 
     def dequant_core(self, q, scale, right_shift, input_max, tr_max=32767):

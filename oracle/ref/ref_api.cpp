@@ -407,9 +407,19 @@ API int vvref_need_rdoq_core( int simd, const int32_t* coef, size_t num, int qua
 // QuantCore through the pointer Quant::xQuant (SIMD row when built with x86 SIMD).  A minimal TransformUnit is faked:
 // QuantCore only touches tu.blocks[compID], tu.cu->lfnstIdx and CoeffCodingContext( tu, ... ) which reads
 // tu.block(), tu.cs->sps->getMaxLog2TrDynamicRange() (Quant.cpp:132-230, ContextModelling.cpp:61-66).
+API int vvref_quant_core_lfnst( const int32_t* coef, int16_t* qcoef, int32_t* deltaU, int width, int height,
+                                int quantCoeff, int iQBits, int64_t iAdd, int signHiding, int thrVal, int lfnstIdx,
+                                int32_t* absSumOut, int* lastScanPosOut );
 API int vvref_quant_core( const int32_t* coef, int16_t* qcoef, int32_t* deltaU, int width, int height,
                           int quantCoeff, int iQBits, int64_t iAdd, int signHiding, int thrVal,
                           int32_t* absSumOut, int* lastScanPosOut )
+{
+  return vvref_quant_core_lfnst( coef, qcoef, deltaU, width, height, quantCoeff, iQBits, iAdd, signHiding, thrVal, 0, absSumOut, lastScanPosOut );
+}
+// the same with CodingUnit::lfnstIdx set (QuantCore's first-coefficient-group rule, Quant.cpp:149-159)
+API int vvref_quant_core_lfnst( const int32_t* coef, int16_t* qcoef, int32_t* deltaU, int width, int height,
+                                int quantCoeff, int iQBits, int64_t iAdd, int signHiding, int thrVal, int lfnstIdx,
+                                int32_t* absSumOut, int* lastScanPosOut )
 {
   static SPS* sps = new SPS;
   static void* csMem = calloc( 1, sizeof( CodingStructure ) );
@@ -417,7 +427,7 @@ API int vvref_quant_core( const int32_t* coef, int16_t* qcoef, int32_t* deltaU, 
   cs->sps = sps;
   CodingUnit cu;
   memset( ( void* ) &cu, 0, sizeof( cu ) );
-  cu.lfnstIdx = 0;
+  cu.lfnstIdx = ( uint8_t ) lfnstIdx;
   TransformUnit tu( CHROMA_420, Area( 0, 0, width, height ) );
   tu.cu = &cu;
   tu.cs = cs;

@@ -469,9 +469,17 @@ void orc_need_rdoq_params(int w, int h, int bitDepth, int qp, int isLuma, int *q
     *numCoeff = w * (h < 32 ? h : 32);
 }
 
-/* QuantCore, Quant.cpp:132-230 (lfnstIdx == 0).  qcoef is w*h compact (stride w). */
+/* QuantCore, Quant.cpp:132-230.  qcoef is w*h compact (stride w).  lfnstIdx > 0 (a TU whose coefficients went through the low-frequency non-separable transform): only the
+ * FIRST coefficient group is looked at (iCGNum = 1, :152-153), and only its first 8 scan positions for 4x4 and 8x8 TUs (:156-159). */
+void orc_quant_core_lfnst(const int32_t *coef, int16_t *qcoef, int32_t *deltaU, int w, int h, int quantCoeff,
+                          int iQBits, int64_t iAdd, int thrVal, int lfnstIdx, int32_t *absSumOut, int *lastScanPosOut);
 void orc_quant_core(const int32_t *coef, int16_t *qcoef, int32_t *deltaU, int w, int h, int quantCoeff,
                     int iQBits, int64_t iAdd, int thrVal, int32_t *absSumOut, int *lastScanPosOut)
+{
+    orc_quant_core_lfnst(coef, qcoef, deltaU, w, h, quantCoeff, iQBits, iAdd, thrVal, 0, absSumOut, lastScanPosOut);
+}
+void orc_quant_core_lfnst(const int32_t *coef, int16_t *qcoef, int32_t *deltaU, int w, int h, int quantCoeff,
+                          int iQBits, int64_t iAdd, int thrVal, int lfnstIdx, int32_t *absSumOut, int *lastScanPosOut)
 {
     const int log2w = ilog2(w), log2h = ilog2(h);
     uint32_t *scan = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)w * h);
@@ -479,8 +487,9 @@ void orc_quant_core(const int32_t *coef, int16_t *qcoef, int32_t *deltaU, int w,
     int lcw, lch;
     orc_cg_size(log2w, log2h, &lcw, &lch);
     const int log2CG = lcw + lch, cgSize = 1 << log2CG;
-    const int cgNum = ((w < 32 ? w : 32) * (h < 32 ? h : 32)) >> log2CG;
+    const int cgNum = lfnstIdx > 0 ? 1 : ((w < 32 ? w : 32) * (h < 32 ? h : 32)) >> log2CG;                 /* :152 */
     int scanPos = (cgNum << log2CG) - 1;
+    if (lfnstIdx > 0 && ((w == 4 && h == 4) || (w == 8 && h == 8))) scanPos = 7;                               /* :156-159 */
     for (; scanPos > 0; scanPos--)
         if (coef[scan[scanPos]]) break;                                     /* :162-167 */
 

@@ -47,6 +47,9 @@ void orc_dequant_params(int w, int h, int bitDepth, int qp, int *scale, int *rig
 void orc_need_rdoq_params(int w, int h, int bitDepth, int qp, int isLuma, int *quantCoeff, int *iQBits, int64_t *iAdd, int *numCoeff);
 void orc_quant_core(const int32_t *coef, int16_t *qcoef, int32_t *deltaU, int w, int h, int quantCoeff, int iQBits,
                     int64_t iAdd, int thrVal, int32_t *absSumOut, int *lastScanPosOut);
+/* QuantCore with CodingUnit::lfnstIdx (Quant.cpp:149-159: first coefficient group only; 8 positions for 4x4 / 8x8 TUs) */
+void orc_quant_core_lfnst(const int32_t *coef, int16_t *qcoef, int32_t *deltaU, int w, int h, int quantCoeff, int iQBits,
+                          int64_t iAdd, int thrVal, int lfnstIdx, int32_t *absSumOut, int *lastScanPosOut);
 void orc_dequant_core(int maxX, int maxY, int scale, const int16_t *q, size_t qStride, int32_t *coef, int rightShift,
                       int inputMaximum, int32_t transformMaximum);
 int  orc_need_rdoq(const int32_t *coef, size_t num, int quantCoeff, int64_t offset, int shift);

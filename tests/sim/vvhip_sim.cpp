@@ -194,11 +194,15 @@ int vvhip_inv_transform_batch( vvhip_ctx* ctx, const int32_t* coef, int n, int w
 }
 int vvhip_quant_core( vvhip_ctx* ctx, const int32_t* coef, int w, int h, int qc, int qbits, int64_t add, int thr, int16_t* lev, int32_t* du, int32_t* absSum, int32_t* last )
 {
+  return vvhip_quant_core_lfnst( ctx, coef, w, h, qc, qbits, add, thr, 0, lev, du, absSum, last );
+}
+int vvhip_quant_core_lfnst( vvhip_ctx* ctx, const int32_t* coef, int w, int h, int qc, int qbits, int64_t add, int thr, int lfnstIdx, int16_t* lev, int32_t* du, int32_t* absSum, int32_t* last )
+{
   if( !ctx ) return VVHIP_E_ARG;
   g_calls++;
   std::vector<int32_t> d( ( size_t ) w * h );
   int l = -1; int32_t s = 0;
-  orc_quant_core( coef, lev, du ? du : d.data(), w, h, qc, qbits, add, thr, &s, &l );
+  orc_quant_core_lfnst( coef, lev, du ? du : d.data(), w, h, qc, qbits, add, thr, lfnstIdx, &s, &l );
   if( absSum ) *absSum = s;
   if( last ) *last = l;
   return VVHIP_OK;

@@ -163,7 +163,7 @@ def test_lfnst_tus_stay_with_the_cpu_quantiser():
     clip = dict(CLIP, frames=5, preset="fast", options="RDOQ=0;DepQuant=0;LFNST=1")
     cpu = run(dict(clip, hip=False, mask=0))
     hip = run(dict(clip, hip=True, mask=4), env=sim_env())
-    assert hip["calls"][4] > 1000 and hip["calls"][20] > 100, hip["calls"]
+    assert hip["calls"][4] > 1000 and hip["calls"][20] == 0 and hip["calls"][38] > 100, hip["calls"]          # (round 6: LFNST TUs are quantised behind the C ABI too)
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
 
 

@@ -36,7 +36,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(38, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 38); calls = [int(x) for x in c]
+    c = np.zeros(39, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 39); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 
@@ -400,16 +400,19 @@ def test_production_mask_equals_the_x86_row_where_the_references_rows_differ():
 
 @pytest.mark.gpu
 def test_hip_lfnst_quantiser_guard_bitstream_identical():
-    """with RDOQ and DepQuant off the encoder's scalar quantiser (Quant::xQuant) is the main path, and LFNST TUs must see QuantCore's first-coefficient-group
-    rule (Quant.cpp:152-159): the binding leaves them to the CPU entry, everything else goes to the device core"""
+    """ADVICE r1 / VERDICT r5 #8: with RDOQ and DepQuant off the encoder's scalar quantiser (Quant::xQuant) is the main path, and LFNST TUs must see QuantCore's
+    first-coefficient-group rule (Quant.cpp:149-159).  Round 6: the rule is on the device (vvhip_quant_core_lfnst) — no TU is left to the CPU entry any more (counter 20 == 0,
+    counter 38 counts the LFNST TUs the device quantised); $VVHIP_LFNST_QUANT_ON_CPU=1 is the old route and gives the same stream"""
     if not os.path.exists(e2e_util.REF_HIP_SO):
         pytest.skip("bindings/vvenc/_build/libvvenc_hip_enc.so (the encoder with the binding) not built")
     clip = dict(w=208, h=120, frames=5, in_bd=10, int_bd=10, preset="fast", options="RDOQ=0;DepQuant=0;LFNST=1")
     cpu = run(dict(clip, hip=False, mask=0))
     hip = run(dict(clip, hip=True, mask=4))
     print("cpu", cpu, "hip", hip)
-    assert hip["calls"][4] > 1000 and hip["calls"][20] > 100, hip["calls"]      # device quantiser calls, LFNST TUs left to the CPU
+    assert hip["calls"][4] > 1000 and hip["calls"][20] == 0 and hip["calls"][38] > 100, hip["calls"]      # device quantiser calls; no LFNST TU left to the CPU; LFNST TUs on the device
     assert hip["md5"] == cpu["md5"] and hip["bytes"] == cpu["bytes"], (cpu, hip)
+    old = run(dict(clip, hip=True, mask=4), env={"VVHIP_LFNST_QUANT_ON_CPU": "1"})
+    assert old["calls"][20] > 100 and old["calls"][38] == 0 and old["md5"] == cpu["md5"], (cpu, old)
 
 
 @pytest.mark.gpu

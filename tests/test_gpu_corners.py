@@ -338,6 +338,33 @@ def test_fused_tu_sparse_outputs_leave_all_zero_tus_untouched(env):
     assert int(lev.abs().sum()) == 0 and int(rec.abs().sum()) == 0
 
 
+def test_quant_core_lfnst_rule_vs_oracle(env):
+    """round 6: QuantCore's first-coefficient-group rule for LFNST TUs on the device (vvhip_quant_core_lfnst; Quant.cpp:149-159) — the binding no longer hands those TUs to the
+    CPU entry.  Against the oracle (pinned to the reference's own entry with CodingUnit::lfnstIdx set, tests/test_oracle_vs_reference.py): levels of the WHOLE block (zeros
+    behind the first group), abs sum, last position, deltaU inside the quantised range; lfnst_idx 0 = the plain core"""
+    hp, orc = env
+    rng = np.random.default_rng(2024)
+    n = 0
+    for (w, h) in ((4, 4), (8, 8), (4, 8), (8, 4), (16, 16), (4, 16), (16, 8), (32, 32), (8, 32), (64, 64)):
+        for qp in (12 + 22, 12 + 37):
+            qc, qbits, add = orc.quant_params(w, h, 10, qp, 0)
+            for lfnst in (0, 1, 2):
+                coef = rng.integers(-(1 << 13), 1 << 13, size=(h, w)).astype(np.int32)
+                coef[rng.random((h, w)) < 0.3] = 0
+                if w > 32:
+                    coef[:, 32:] = 0
+                if h > 32:
+                    coef[32:, :] = 0
+                e = orc.quant_core(coef, qc, qbits, add, 8, lfnst_idx=lfnst)
+                g = hp.quant_core(coef, qc, qbits, add, 8, lfnst_idx=lfnst)
+                assert np.array_equal(g[0], e[0]) and g[2] == e[2] and g[3] == e[3], (w, h, qp, lfnst, g[2:], e[2:])
+                nz = np.zeros(h * w, bool)
+                nz[orc.scan_order(w.bit_length() - 1, h.bit_length() - 1)[: e[3] + 1]] = True
+                assert np.array_equal(g[1][nz], e[1][nz]), ("deltaU", w, h, qp, lfnst)
+                n += 1
+    assert n == 60
+
+
 def test_masked_sad_large_operands_sum_in_64_bits(env):
     """masked SADs take any int16 operands (include/vvenc_hip.h) and the reference sums in a 64-bit Distortion (RdCost.cpp:2062-2093): a 128x128 block of large
     differences and weights passes 2^32 — the wave takes its 64-bit form; GEO-range operands next to it keep the 32-bit form.  Against the numpy restatement of the loop"""

@@ -196,6 +196,29 @@ def test_recorded_lists_medium_preset_4k_picture(hp, tmp_path):
     assert tot["integer_candidates"] > 200000 and tot["subpel_positions"] > 20000 and tot["tus"] > 10000, tot
 
 
+def test_recorded_lists_fast_preset(hp, tmp_path):
+    """preset fast (BASELINE configs[4]'s preset, vvencCfg.cpp:2751-2819: affine, BDOF, MMVD, two references per list, DepQuant, LFNST on top of faster): every call the
+    encoder makes through the tables while those tools search — affine's gradient-search distortions, MMVD / merge pruning, the second reference of a list — lands in the
+    lists (NOTHING dropped), and every recorded output replays bit-exactly; TU lists against the reference's own entries"""
+    pics = _record(tmp_path, 416, 240, 9, pocs=(4, 8), preset="fast")
+    assert len(pics) == 2
+    refs = set()
+    for pic in pics.values():
+        refs |= set(pic.me["refPlane"].tolist())
+    assert len(refs) >= 2, refs
+    tot = _replay_and_check(hp, pics)
+    assert tot["integer_candidates"] > 20000 and tot["subpel_positions"] > 2000 and tot["table_calls"] > 10000 and tot["tus"] > 2000, tot
+
+
+def test_recorded_lists_fast_preset_4k_picture(hp, tmp_path):
+    """one 3840x2160 picture of a preset-fast encode (the 4K stand-in for BASELINE configs[4]'s 8K geometry: the same tools, a recording that fits the test budget):
+    nothing dropped, bit-exact"""
+    pics = _record(tmp_path, 3840, 2160, 9, pocs=(4,), preset="fast")
+    assert len(pics) == 1
+    tot = _replay_and_check(hp, pics)
+    assert tot["integer_candidates"] > 100000 and tot["subpel_positions"] > 20000 and tot["tus"] > 10000, tot
+
+
 def test_recorded_lists_1080p_layers(hp, tmp_path):
     """BASELINE configs[1] geometry: the six layer pictures bench.py replays, full 65-frame encode"""
     sys.path.insert(0, ROOT)

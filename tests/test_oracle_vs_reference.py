@@ -222,6 +222,26 @@ def test_scan_order_and_scales(oracle, reflib):
     assert np.array_equal(q, oq) and np.array_equal(iq, oiq)
 
 
+def test_quant_core_lfnst_rule(oracle, reflib):
+    """QuantCore for a TU whose CodingUnit::lfnstIdx is set (presets fast / medium): only the first coefficient group is looked at, and only its first 8 scan positions for
+    4x4 and 8x8 TUs (Quant.cpp:149-159).  Coefficients everywhere (what a transform WITHOUT the LFNST zero-out would leave) so that the rule, not the input, decides"""
+    rng = np.random.default_rng(81)
+    for (w, h) in ((4, 4), (8, 8), (4, 8), (8, 4), (16, 16), (4, 16), (16, 8), (32, 32), (8, 32)):
+        for qp in (12 + 22, 12 + 37):
+            qc, qbits, add = oracle.quant_params(w, h, 10, qp, 0)
+            for lfnst in (1, 2):
+                for scale_in in (1 << 10, 1 << 14):
+                    coef = rng.integers(-scale_in, scale_in, size=(h, w)).astype(np.int32)
+                    coef[rng.random((h, w)) < 0.3] = 0
+                    a = oracle.quant_core(coef, qc, qbits, add, 8, lfnst_idx=lfnst)
+                    b = reflib.quant_core(coef, qc, qbits, add, 8, sign_hiding=True, lfnst_idx=lfnst)
+                    assert a[2] == b[2] and a[3] == b[3], ("sum/last", w, h, qp, lfnst, a[2:], b[2:])
+                    assert np.array_equal(a[0], b[0]), ("levels", w, h, qp, lfnst)
+                    assert a[3] <= (7 if (w, h) in ((4, 4), (8, 8)) else 15)
+                    plain = oracle.quant_core(coef, qc, qbits, add, 8)
+                    assert plain[3] > a[3] or plain[2] == a[2]          # (the rule did cut something wherever there was something to cut)
+
+
 def test_quant_cores(oracle, reflib):
     rng = np.random.default_rng(8)
     for w in (2, 4, 8, 16, 32, 64):

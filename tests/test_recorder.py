@@ -121,6 +121,36 @@ def test_medium_preset_lists_are_complete_and_consistent(tmp_path):
     assert any(w != h for w, h in shapes) and any(w == 128 for w, h in shapes) and n_mask > 10000, (shapes, n_mask)
 
 
+def test_fast_preset_lists_are_complete_and_consistent(tmp_path):
+    """preset fast (BASELINE configs[4]'s preset: affine, BDOF, MMVD, two references per list, DepQuant, LFNST — vvencCfg.cpp:2751-2819): the host lists hold EVERY recorded
+    call (nothing dropped) and the reference's own entries driven over them return the costs the encoder computed — the CPU twin of tests/test_gpu_replay.py's fast-preset replay"""
+    need()
+    import bench
+    from vvenc_amd import recorded as R
+    from vvenc_amd.replay import RecordedLists
+    R.record(str(tmp_path), 416, 240, 9, pocs=(4, 8), threads=4, preset="fast")
+    pics = R.load_dir(str(tmp_path))
+    assert len(pics) == 2
+    refs, n_calls = set(), 0
+    for poc, pic in pics.items():
+        refs |= set(pic.me["refPlane"].tolist())
+        L = RecordedLists(pic)
+        assert L.nothing_dropped, L.dropped
+        assert L.plan_cands.size + L.items.size + L.mask_items.size == pic.cand.size + pic.dist.size
+        assert L.stage_jobs.size == pic.stage.size and sum(g["n"] for g in L.tu_groups) == pic.tu.size
+        J = bench.ReferenceJobs(L, with_outputs=True)
+        J.run(4, 1)
+        exp = np.concatenate([L.cand_expected, L.item_expected])
+        got = np.zeros(exp.size, np.uint64)
+        for sel, out in J.dist_groups:
+            got[sel] = out
+        assert np.array_equal(got, exp), (poc, int((got != exp).sum()))
+        for sel, out in J.stage_groups:
+            assert np.array_equal(out[L.stage_evaluated[sel]], L.stage_expected[sel][L.stage_evaluated[sel]]), poc
+        n_calls += exp.size
+    assert len(refs) >= 2 and n_calls > 40000, (refs, n_calls)
+
+
 def test_early_exit_partial_sums_are_flagged_not_recorded(tmp_path):
     """64-wide SADs: the x86 row returns a partial sum once it exceeds the best cost so far (x86/RdCostX86.h:390-410); the record holds the full value and flags the call"""
     need()

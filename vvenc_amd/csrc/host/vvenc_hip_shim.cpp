@@ -1285,7 +1285,7 @@ bool needRdoqOne( const TCoeff* c, size_t num, int quantCoeff, int64_t offset, i
 }
 
 void quantImpl( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal,
-                bool raw, int rawScale, int rawQBits, int64_t rawAdd );
+                bool raw, int rawScale, int rawQBits, int64_t rawAdd, int lfnstIdx = 0 );
 
 void quantOne( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal )
 {
@@ -1296,8 +1296,14 @@ void quantCoreOne( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCo
   quantImpl( w, h, coef, q, absSum, lastScanPos, deltaU, 0, false, 10, thrVal, true, quantCoeff, iQBits, iAdd );
 }
 
+void quantCoreLfnstOne( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int quantCoeff, const int iQBits, const int64_t iAdd, const TCoeff thrVal,
+                        const int lfnstIdx )
+{
+  quantImpl( w, h, coef, q, absSum, lastScanPos, deltaU, 0, false, 10, thrVal, true, quantCoeff, iQBits, iAdd, lfnstIdx );
+}
+
 void quantImpl( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff& absSum, int& lastScanPos, TCoeff* deltaU, const int qp, const bool isIRAP, const int bitDepth, const TCoeff thrVal,
-                bool raw, int rawScale, int rawQBits, int64_t rawAdd )
+                bool raw, int rawScale, int rawQBits, int64_t rawAdd, int lfnstIdx )
 {
   Device& dev = Device::get();
   const size_t area = ( size_t ) w * h;
@@ -1309,8 +1315,8 @@ void quantImpl( unsigned w, unsigned h, const TCoeff* coef, TCoeffSig* q, TCoeff
   dev.check( vvhip_upload( dev.ctx(), aux, &hdr, sizeof( hdr ) ), "quant" );
   dev.check( vvhip_upload( dev.ctx(), dCoef, coef, area * sizeof( TCoeff ) ), "quant" );
   if( raw )
-    dev.check( vvhip_quant_core( dev.ctx(), dCoef, ( int ) w, ( int ) h, rawScale, rawQBits, rawAdd, thrVal, dLev, deltaU ? dDu : nullptr,
-                                 reinterpret_cast<int32_t*>( aux + offsetof( Hdr, absSum ) ), reinterpret_cast<int32_t*>( aux + offsetof( Hdr, last ) ) ), "vvhip_quant_core" );
+    dev.check( vvhip_quant_core_lfnst( dev.ctx(), dCoef, ( int ) w, ( int ) h, rawScale, rawQBits, rawAdd, thrVal, lfnstIdx, dLev, deltaU ? dDu : nullptr,
+                                       reinterpret_cast<int32_t*>( aux + offsetof( Hdr, absSum ) ), reinterpret_cast<int32_t*>( aux + offsetof( Hdr, last ) ) ), "vvhip_quant_core" );
   else
   dev.check( vvhip_quant_batch( dev.ctx(), dCoef, 1, ( int ) w, ( int ) h, bitDepth, reinterpret_cast<vvhip_tu_qp*>( aux ), thrVal, dLev, deltaU ? dDu : nullptr,
                                 reinterpret_cast<int32_t*>( aux + offsetof( Hdr, absSum ) ), reinterpret_cast<int32_t*>( aux + offsetof( Hdr, last ) ) ), "vvhip_quant_batch" );
@@ -1328,6 +1334,7 @@ QuantOps::QuantOps()
   xNeedRdoq = needRdoqOne;
   xQuant = quantOne;
   xQuantCore = quantCoreOne;
+  xQuantCoreLfnst = quantCoreLfnstOne;
 }
 
 } // namespace vvhip

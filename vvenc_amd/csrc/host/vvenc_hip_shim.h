@@ -214,6 +214,9 @@ struct QuantOps
   // QuantCore's own argument list (Quant.cpp:132): what a trampoline for Quant::xQuant forwards (piQCoef compact, stride = width)
   void ( *xQuantCore )( unsigned width, unsigned height, const TCoeff* piCoef, TCoeffSig* piQCoef, TCoeff& uiAbsSum, int& lastScanPos, TCoeff* deltaU,
                         const int defaultQuantisationCoefficient, const int iQBits, const int64_t iAdd, const TCoeff thrVal );
+  // the same for a TU whose coding unit has lfnstIdx > 0: QuantCore's first-coefficient-group rule (Quant.cpp:149-159)
+  void ( *xQuantCoreLfnst )( unsigned width, unsigned height, const TCoeff* piCoef, TCoeffSig* piQCoef, TCoeff& uiAbsSum, int& lastScanPos, TCoeff* deltaU,
+                             const int defaultQuantisationCoefficient, const int iQBits, const int64_t iAdd, const TCoeff thrVal, const int lfnstIdx );
 };
 
 // DMVR refinement search of one CU in one device call (DMVR::xProcessDMVR, CommonLib/InterPrediction.cpp:1262-1392).

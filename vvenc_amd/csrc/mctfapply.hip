@@ -9,7 +9,7 @@
 // The reference's unit test allows +-1 between its scalar and x86 rows here (test/vvenc_unit_test/vvenc_unit_test.cpp:1280-1282); this
 // kernel follows the scalar row (IEEE float/double, no contraction: -ffp-contract=off, correctly rounded division) — which IS the x86 row sample for
 // sample on x86 hosts: the rows differ only in "+ 0.5" (double) vs "+ 0.5f" (single), and the single-precision sum is exact wherever the integer part
-// could change (oracle/vvenc_oracle.c, orc_mctf_apply_block; both rows held to tolerance 0 in tests/test_oracle_vs_reference.py, round 6).
+// could change (both rows held to tolerance 0 by the CPU tests of the repository's checker against the compiled reference, round 6).
 #include <math.h>
 #include "common.h"
 

@@ -249,7 +249,7 @@ __device__ __forceinline__ void quantParams( const QGeom& q, int qp, int& scale,
 __global__ void __launch_bounds__( 256 )
 quantKernel( const int32_t* __restrict__ coef, int n, QGeom q, int log2Lpc, const vvhip_tu_qp* __restrict__ qps, int rawScale, int rawQBits, long long rawAdd, int thrVal,
              const uint16_t* __restrict__ scan, int16_t* __restrict__ level, int32_t* __restrict__ deltaU,
-             int32_t* __restrict__ absSumOut, int32_t* __restrict__ lastPosOut )
+             int32_t* __restrict__ absSumOut, int32_t* __restrict__ lastPosOut, int lfnst = 0 )
 {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int lpc = 1 << log2Lpc, tu = gid >> log2Lpc, lt = gid & ( lpc - 1 );
@@ -268,9 +268,11 @@ quantKernel( const int32_t* __restrict__ coef, int n, QGeom q, int log2Lpc, cons
   else if( valid ) { scale = rawScale; qBits = rawQBits; add = rawAdd; }              // table-entry form: QuantCore's own argument list
   const int num = valid ? q.numScan : 0;
 
-  // (1) last non-zero scan position (Quant.cpp:162-167); 0 if none
+  // (1) last non-zero scan position (Quant.cpp:162-167); 0 if none.  LFNST TUs (CodingUnit::lfnstIdx > 0): only the first coefficient group is looked at, its first 8 positions
+  //     for 4x4 and 8x8 TUs (iCGNum = 1, :149-159) — everything behind stays zero, and the coefficient-group test (2) has nothing to test (last < 16)
+  const int numLast = !lfnst ? num : min( num, ( ( q.w == 4 && q.h == 4 ) || ( q.w == 8 && q.h == 8 ) ) ? 8 : ( 1 << q.log2CG ) );
   int last = 0;
-  for( int p = lt; p < num; p += lpc ) if( src[scan[p]] != 0 ) last = p;             // p increases -> keeps the largest
+  for( int p = lt; p < numLast; p += lpc ) if( src[scan[p]] != 0 ) last = p;         // p increases -> keeps the largest
   for( int o = lpc >> 1; o > 0; o >>= 1 ) last = max( last, __shfl_xor( last, o ) );
 
   // (2) coefficient-group early zero-out (Quant.cpp:173-208): only for 4x4 CGs, only CGs >= 1
@@ -2179,18 +2181,24 @@ int vvhip_quant_batch( vvhip_ctx* ctx, const int32_t* d_coef, int n, int width, 
   return VVHIP_OK;
 }
 
-int vvhip_quant_core( vvhip_ctx* ctx, const int32_t* d_coef, int width, int height, int quant_coeff, int q_bits, int64_t add, int thr_val,
-                      int16_t* d_level, int32_t* d_delta_u, int32_t* d_abs_sum, int32_t* d_last_scan_pos )
+int vvhip_quant_core_lfnst( vvhip_ctx* ctx, const int32_t* d_coef, int width, int height, int quant_coeff, int q_bits, int64_t add, int thr_val, int lfnst_idx,
+                            int16_t* d_level, int32_t* d_delta_u, int32_t* d_abs_sum, int32_t* d_last_scan_pos )
 {
   if( !ctx ) return VVHIP_E_ARG;
   QGeom q;
-  if( !makeQGeom( width, height, 10, q ) || q_bits < 9 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_quant_core: unsupported TU %dx%d / qBits %d", width, height, q_bits );
+  if( !makeQGeom( width, height, 10, q ) || q_bits < 9 || lfnst_idx < 0 ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_quant_core: unsupported TU %dx%d / qBits %d / lfnstIdx %d", width, height, q_bits, lfnst_idx );
   const int log2Lpc = teamLog2( q.numScan );
   hipLaunchKernelGGL( quantKernel, dim3( 1 ), dim3( 256 ), 0, ctx->stream,
                       d_coef, 1, q, log2Lpc, ( const vvhip_tu_qp* ) nullptr, quant_coeff, q_bits, ( long long ) add, thr_val,
-                      ctx->d_scan + scanOffset( q.log2w, q.log2h ), d_level, d_delta_u, d_abs_sum, d_last_scan_pos );
+                      ctx->d_scan + scanOffset( q.log2w, q.log2h ), d_level, d_delta_u, d_abs_sum, d_last_scan_pos, lfnst_idx > 0 ? 1 : 0 );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
+}
+
+int vvhip_quant_core( vvhip_ctx* ctx, const int32_t* d_coef, int width, int height, int quant_coeff, int q_bits, int64_t add, int thr_val,
+                      int16_t* d_level, int32_t* d_delta_u, int32_t* d_abs_sum, int32_t* d_last_scan_pos )
+{
+  return vvhip_quant_core_lfnst( ctx, d_coef, width, height, quant_coeff, q_bits, add, thr_val, 0, d_level, d_delta_u, d_abs_sum, d_last_scan_pos );
 }
 
 int vvhip_dequant_batch( vvhip_ctx* ctx, const int16_t* d_level, int n, int width, int height, int bit_depth, const vvhip_tu_qp* d_qp, int32_t* d_coef )

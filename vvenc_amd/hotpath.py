@@ -571,6 +571,21 @@ class HotPath:
     def mctf_set_stats(self, on):
         self._ck(self.L.vvhip_mctf_set_stats(self.ctx, int(bool(on))))
 
+    def quant_core(self, coef, quant_coeff, q_bits, add, thr_val=8, lfnst_idx=0):
+        """QuantCore's own argument list on ONE block (numpy int32 h x w) -> (levels h x w int16, deltaU w*h int32, abs sum, last scan position); lfnst_idx > 0: the
+        first-coefficient-group rule of LFNST TUs (vvhip_quant_core_lfnst)"""
+        coef = np.ascontiguousarray(coef, np.int32)
+        h, w = coef.shape
+        d_c = self.to_device(coef.reshape(-1))
+        d_l = torch.full((h * w,), 0x7777, dtype=torch.int16, device=self.device)
+        d_u = torch.zeros(h * w, dtype=torch.int32, device=self.device)
+        d_s = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._ck(self.L.vvhip_quant_core_lfnst(self.ctx, _ptr(d_c), w, h, quant_coeff, q_bits, add, thr_val, int(lfnst_idx), _ptr(d_l), _ptr(d_u), C.c_void_p(d_s.data_ptr()),
+                                               C.c_void_p(d_s.data_ptr() + 4)))
+        torch.cuda.synchronize()
+        sv = d_s.cpu().numpy()
+        return d_l.cpu().numpy().reshape(h, w), d_u.cpu().numpy(), int(sv[0]), int(sv[1])
+
     def tu_set_sparse_outputs(self, on):
         """vvhip_tu_set_sparse_outputs: the fused TU launches write no levels / reconstruction for TUs whose levels are all zero (the caller treats them as zero)"""
         self._ck(self.L.vvhip_tu_set_sparse_outputs(self.ctx, int(bool(on))))

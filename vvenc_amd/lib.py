@@ -58,6 +58,7 @@ PROTOTYPES = {
     "vvhip_need_rdoq_batch": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     "vvhip_dequant_core": (i32, [vp, i32, i32, i32, vp, sz, vp, i32, i32, i32]),
     "vvhip_quant_core": (i32, [vp, vp, i32, i32, i32, i32, C.c_int64, i32, vp, vp, vp, vp]),
+    "vvhip_quant_core_lfnst": (i32, [vp, vp, i32, i32, i32, i32, C.c_int64, i32, i32, vp, vp, vp, vp]),
     "vvhip_need_rdoq_core": (i32, [vp, vp, sz, i32, C.c_int64, i32, vp]),
     "vvhip_tu_rdo_batch": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
     "vvhip_tu_rdo_multi": (i32, [vp, vp, i32, i32, vp, i32]),
