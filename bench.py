@@ -75,8 +75,13 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
 
     # ---- north-star leg C at the GOP's cadence (tools/bench_mctf.py): the cycle's four filtered pictures resident, issued on a SIXTH stream by the steps that replay them
     mc = None
-    if not args.no_mctf and world == 1:
+    if not args.no_mctf and (world == 1 or (width, height) == (args.width, args.height)):
         mc = BM.MctfCadence(hp, width, height, lane=hp.fork(torch.cuda.Stream()) if args.streams > 1 else hp)
+    # N > 1: a filtered picture's reference originals ARRIVE through the picture exchange — the rank next to the one that filters the picture owns them (it ingested them), fills
+    # the slot and every rank joins the broadcast; the filtering rank waits for it and runs the search against the RECEIVED planes: a broadcast with a consumer
+    mex, mex_count, mex_last = None, [0], {}
+    if mc is not None and world > 1:
+        mex = sharding.PictureExchange(mc.exchange_shapes(), slots=2, device=hp.device)
 
     # ---- the reference-picture exchange of the sharded sequence (N > 1): ring of two reconstructed pictures (luma + 2 chroma planes with margins)
     ex = None
@@ -93,8 +98,29 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     def step():
         k = step_no[0]
         s = step_of_rank(k, rank, world)
-        if with_mctf[0]:
+        if with_mctf[0] and mex is None:
             mc.issue_step(s)                             # (first: the filtered picture's search + filter run beside this and the following pictures' lists)
+        elif with_mctf[0]:
+            for r2 in range(world):                      # every rank walks the same list of this step's exchanges (collectives in one order)
+                job = BM.job_of_step(step_of_rank(k, r2, world))
+                if job is None:
+                    continue
+                e, owner = mex_count[0], (r2 + 1) % world
+                mex_count[0] += 1
+                slot = mex.slot(e)
+                lane_stream = [mc.lane.stream] if hasattr(mc.lane, "stream") else []
+                if rank == owner:
+                    torch.cuda.current_stream().wait_stream(mex.stream)      # (the slot's previous broadcast has left it)
+                    for st in lane_stream:
+                        torch.cuda.current_stream().wait_stream(st)          # (and its previous consumer has read it)
+                    mc.fill_slot(job, slot)
+                mex.publish(e, owner, readers=lane_stream)
+                if rank == r2:
+                    mex.wait(e, lane_stream or None)
+                    mc.issue_from_slot(job, slot)
+                    mex_last[job[1]] = slot
+                else:
+                    mex.pending.pop(e, None)
         if ex is not None:
             if k % args.exchange_every == 0 and args.exchange_every < (1 << 29):
                 e = k // args.exchange_every
@@ -150,7 +176,36 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     # ---- the same K steps WITH leg C: the steps that replay the POC-32 / 16 / 8 / 24 pictures also queue that picture's MCTF (4 / 4 / 2 / 2 motion estimations + the filter
     #      of Y, U, V) on the sixth stream — `value_with_mctf`; and whole GOP cycles (the cadence's stable figure: 12 estimations + 4 filters per 32 steps)
     mctf_region = None
-    if mc is not None:
+    if mc is not None and world > 1:
+        # N > 1: K steps with leg C, references through the exchange (barrier + max over ranks like the headline region); then the parity of what was computed from RECEIVED planes
+        with_mctf[0] = True
+        step_no[0] = 0
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        sharding.barrier()
+        step_no[0] = 0
+        n_before = mex_count[0]
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        sharding.barrier()
+        dtm = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
+        with_mctf[0] = False
+        par = mc.exchange_parity(mex_last)
+        bad = sharding.sum_over_ranks(par["mismatches"] + (1 if par["corruption_detected"] is False else 0), device="cuda")
+        checked = sharding.sum_over_ranks(par["jobs_checked"], device="cuda")
+        detected = sharding.sum_over_ranks(1 if par["corruption_detected"] else 0, device="cuda")
+        mctf_region = {"value": steps * world / dtm, "ms_per_step": 1000.0 * dtm / steps, "steps": steps, "exchanges_in_the_timed_steps": mex_count[0] - n_before,
+                       "bytes_per_exchange": int(sum(p.numel() * 2 for p in mex.slots[0])),
+                       "parity_exchange": {"status": "bit-exact" if bad == 0 and checked > 0 else ("not checked" if checked == 0 else "MISMATCH"), "jobs_checked_over_ranks": int(checked),
+                                           "ranks_that_detected_a_corrupted_slot": int(detected),
+                                           "what": "motion fields computed from the RECEIVED reference planes == the fields from the rank's own copies; self-test: part of a received "
+                                                   "plane inverted -> the fields change (the consumer reads the slot)"},
+                       "note": "N > 1: the K steps with north-star leg C at the GOP's cadence; a filtered picture's reference originals are broadcast by the neighbouring rank (their "
+                               "owner) and the filtering rank searches against the received planes — every broadcast has one consumer; `value` is the same steps without leg C"}
+    if mc is not None and world == 1:
         with_mctf[0] = True
         step_no[0] = 0
         for _ in range(32):
@@ -256,7 +311,7 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     # ---- leg C per class: HIP events inside the library around every launch of a motion estimation (vvhip_mctf_set_timing) + around the three filter launches, per job, serialized;
     #      the scored candidates and their algorithmic bytes from the library's counters (vvhip_mctf_set_stats)
     mctf_cls = None
-    if mc is not None:
+    if mc is not None and world == 1:
         lane = mc.lane
         cyc = {"MCTF_search": 0.0, "MCTF_nb": 0.0, "MCTF_fix": 0.0, "MCTF_apply": 0.0, "MCTF_rest": 0.0}
         reps = 4
@@ -366,6 +421,8 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
                                               "staged once in LDS) — per_candidate_bytes counts every grid position at 4 w h instead: a work rate (LDS-level reuse), not memory traffic; "
                                               "filter: per block 4 w h + per reference (w + 5)(h + 5) 2 + 24")
         out["_mctf"] = mc
+    elif mctf_region is not None:
+        out["with_mctf"] = mctf_region
     out["kernels"] = kern
     out["kernels_measured"] = "HIP events on the launch stream around every kernel (inside vvhip_me_plan_run for the plan's kernels), 8 passes per layer with the launches serialized; GOP-weighted"
     return out, workloads, kern
@@ -478,7 +535,7 @@ def main():
     calib = BP.counter_calibration() if can_profile else {"measured": False, "factors": {"rows16": 2.0, "stream16": 2.0, "store8": 1.0}, "how": "not run", "pattern_of_class": BP.FETCH_PATTERN}
     out["counter_calibration"] = calib
     # (with leg C's classes in the table the step time of the cross-check is the with-MCTF GOP cycle's)
-    step_ms = core["with_mctf"]["gop_cycle"]["ms_per_step"] if core.get("with_mctf") else core["ms_per_step"]
+    step_ms = core["with_mctf"]["gop_cycle"]["ms_per_step"] if (core.get("with_mctf") or {}).get("gop_cycle") else core["ms_per_step"]
     out.update(profiled(args.width, args.height, kern, workloads, step_ms, args.profile_md, mc))
 
     if not args.no_parity:
@@ -518,7 +575,7 @@ def main():
                 if k in c4:
                     out[k + "_4k"] = c4[k]
             md4 = (os.path.splitext(args.profile_md)[0] + "_4k" + os.path.splitext(args.profile_md)[1]) if args.profile_md else None
-            step_ms4 = c4["with_mctf"]["gop_cycle"]["ms_per_step"] if c4.get("with_mctf") else c4["ms_per_step"]
+            step_ms4 = c4["with_mctf"]["gop_cycle"]["ms_per_step"] if (c4.get("with_mctf") or {}).get("gop_cycle") else c4["ms_per_step"]
             for k, v in profiled(3840, 2160, k4, w4, step_ms4, md4, mc4).items():
                 out[k + "_4k"] = v
             if mc4 is not None and not args.no_parity:

@@ -1086,6 +1086,11 @@ def test_bench_multi_rank_path_on_one_device(tmp_path):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["exchange"]["pictures"] == 6 and d["exchange"]["backend"] == "gloo" and "exchange_ms_per_picture" not in d["exchange"], d
     assert d["no_exchange"]["value"] > 0 and d["exchange_per_gop_cycle"]["value"] > 0 and d["exchange_per_gop_cycle"]["every_steps"] == 32, d
     assert d["parity"]["status"] == "bit-exact", d["parity"]
+    # round 6: a broadcast WITH A CONSUMER — the steps again with leg C, a filtered picture's reference originals arriving through the exchange from the
+    # neighbouring rank; the fields computed from the received planes equal the fields from the rank's own copies, and a corrupted slot is noticed (self-test on every consumer)
+    assert d["value_with_mctf"] > 0 and d["parity_exchange"]["status"] == "bit-exact", d.get("parity_exchange")
+    assert d["parity_exchange"]["jobs_checked_over_ranks"] >= 2 and d["parity_exchange"]["ranks_that_detected_a_corrupted_slot"] == 2, d["parity_exchange"]
+    assert d["mctf_exchanges"]["exchanges_in_the_timed_steps"] >= 2 and d["mctf_exchanges"]["bytes_per_exchange"] > 0, d["mctf_exchanges"]
     # the metric's N-GPU form: one encoder instance per rank on its own GPU (here: both on the one GPU), GOP chunks of one sequence, CPU kernels vs --SIMD=HIP
     inst = d["e2e_instances"]
     assert inst["instances"] == 2 and inst["chunk_bitstreams_identical"] is True and inst["cpu_fps_aggregate"] > 0 and inst["hip_fps_aggregate"] > 0, inst

@@ -87,6 +87,9 @@ def compact(out, detail_path):
     for k in ("gop_weighted", "single_stream"):
         if k in out:
             line[k] = _pick(out[k], ("value", "ms_per_step"))
+    if isinstance(out.get("with_mctf"), dict) and isinstance(out["with_mctf"].get("parity_exchange"), dict):
+        line["parity_exchange"] = _pick(out["with_mctf"]["parity_exchange"], ("status", "jobs_checked_over_ranks", "ranks_that_detected_a_corrupted_slot"))
+        line["mctf_exchanges"] = _pick(out["with_mctf"], ("exchanges_in_the_timed_steps", "bytes_per_exchange"))
     if isinstance(out.get("with_mctf"), dict) and isinstance(out["with_mctf"].get("gop_cycle"), dict):
         line["gop_cycle_with_mctf"] = _pick(out["with_mctf"]["gop_cycle"], ("value", "value_without_mctf", "ms_per_cycle", "ms_per_cycle_without_mctf"))
     # ---- 3840x2160

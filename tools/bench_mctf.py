@@ -93,6 +93,73 @@ class MctfCadence:
                 c.mctf_apply_plane(cur[comp], [self.planes[r][comp] for r in j["refs"]], j["fields"], self.mv_w, 1 if comp else 0, j["ref_strengths"], scaling, sigma,
                                    BIT_DEPTH, UNIT, False, QP, out=j["outs"][comp])
 
+    # ---- N > 1: the references of a job arrive through the picture exchange (vvenc_amd/sharding.PictureExchange): slot = up to four luma planes with their margins
+    def exchange_shapes(self):
+        p = self.planes[JOBS[0][1]][0]
+        return [tuple(p.storage.shape)] * 4
+
+    def fill_slot(self, job, slot):
+        """owner side: the reference originals of `job` (luma incl. margins) into the slot, on the current stream"""
+        for i, r in enumerate(job[2]):
+            slot[i].copy_(self.planes[r][0].storage)
+
+    def slot_planes(self, job, slot):
+        from vvenc_amd.hotpath import Plane
+        cur = self.planes[job[1]][0]
+        out = []
+        for i in range(len(job[2])):
+            p = Plane.__new__(Plane)
+            p.width, p.height, p.pad, p.stride, p.storage = cur.width, cur.height, cur.pad, cur.stride, slot[i]
+            out.append(p)
+        return out
+
+    def issue_from_slot(self, job, slot, fields=None):
+        """consumer side: the job's motion estimation against the RECEIVED reference planes (the fields go to `fields`, default the job's exchange fields), then the filter
+        (luma references from the slot too, chroma local)"""
+        import torch
+        from vvenc_amd.hotpath import MV_DTYPE
+        c = self.lane
+        j = self.jobs[job[1]]
+        if "fields_x" not in j:
+            j["fields_x"] = [torch.empty((self.mv_w * self.mv_h, MV_DTYPE.itemsize), dtype=torch.uint8, device=self.hp.device) for _ in j["refs"]]
+        f = fields if fields is not None else j["fields_x"]
+        cur = self.planes[j["poc"]]
+        refs_y = self.slot_planes(job, slot)
+        c.mctf_motion_estimation(cur[0], refs_y, BIT_DEPTH, UNIT, SPEED, self.add_level, out=f, wait=False)
+        for comp in range(3):
+            sigma, scaling = j["prm"][comp]
+            rp = refs_y if comp == 0 else [self.planes[r][comp] for r in j["refs"]]
+            c.mctf_apply_plane(cur[comp], rp, f, self.mv_w, 1 if comp else 0, j["ref_strengths"], scaling, sigma, BIT_DEPTH, UNIT, False, QP, out=j["outs"][comp])
+        j["consumed"] = j.get("consumed", 0) + 1
+
+    def exchange_parity(self, last_slots):
+        """the fields computed from RECEIVED planes against the fields from this rank's own copies, for every job this rank consumed; + the self-test that the consumer really
+        reads the slot: a slot with a few samples changed must give different fields.  last_slots: {poc: slot of the job's last exchange}"""
+        import torch
+        res = {"jobs_checked": 0, "mismatches": 0, "corruption_detected": None}
+        for job in JOBS:
+            j = self.jobs[job[1]]
+            if not j.get("consumed"):
+                continue
+            torch.cuda.synchronize()
+            got = [f.clone() for f in j["fields_x"]]
+            self.issue(job, apply=False)
+            torch.cuda.synchronize()
+            res["jobs_checked"] += 1
+            res["mismatches"] += sum(0 if bool(torch.equal(a, b)) else 1 for a, b in zip(got, j["fields"]))
+            if res["corruption_detected"] is None and job[1] in last_slots:
+                slot = last_slots[job[1]]
+                pad = self.planes[job[1]][0].pad
+                keep = slot[0][pad + 64:pad + 128, pad + 64:pad + 192].clone()
+                slot[0][pad + 64:pad + 128, pad + 64:pad + 192] = 1023 - keep          # "a wrong broadcast": part of the first reference inverted
+                tmp = [torch.empty_like(f) for f in got]
+                self.issue_from_slot(job, slot, fields=tmp)
+                torch.cuda.synchronize()
+                res["corruption_detected"] = any(not bool(torch.equal(a, b)) for a, b in zip(tmp, got))
+                slot[0][pad + 64:pad + 128, pad + 64:pad + 192] = keep
+        res["status"] = "bit-exact" if res["mismatches"] == 0 and res["jobs_checked"] > 0 and res["corruption_detected"] is not False else ("not checked" if res["jobs_checked"] == 0 else "MISMATCH")
+        return res
+
     def issue_step(self, s):
         job = job_of_step(s)
         if job is not None:
