@@ -11,6 +11,7 @@
 // sample on x86 hosts: the rows differ only in "+ 0.5" (double) vs "+ 0.5f" (single), and the single-precision sum is exact wherever the integer part
 // could change (both rows held to tolerance 0 by the CPU tests of the repository's checker against the compiled reference, round 6).
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -34,6 +35,7 @@ struct ApplyArgs
   double refStrengths[MAX_REFS];
   double weightScaling, sigmaSq;
   int numRefs, cs, bitDepth, blk, lowRes, qp, mvW, width, height;
+  int generic;       // $VVHIP_MCTF_APPLY_GENERIC=1: every block through the general path (A/B measurements; results identical)
 };
 
 __device__ __forceinline__ float fastExp( float n, float d )     // MCTF.cpp:359-367
@@ -45,30 +47,164 @@ __device__ __forceinline__ float fastExp( float n, float d )     // MCTF.cpp:359
 
 #define WAVE_SYNC() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
 
-// One workgroup (4 waves) per filter block.  The references are independent until the blend, so wave v compensates, corrects and measures
-// references v, v+4, ... on its own (wave-level synchronisation only, private LDS scratch, DPP reductions); one workgroup barrier, then all
-// 256 threads blend.
+// ---- packed helpers of the full-block path (round 6) ---------------------------------------------------------------------------------------------------
+typedef uint32_t au32x4 __attribute__( ( ext_vector_type( 4 ) ) );
+typedef short as16x2 __attribute__( ( ext_vector_type( 2 ) ) );
+struct __attribute__( ( packed, aligned( 2 ) ) ) AU4  { uint32_t v; };
+struct __attribute__( ( packed, aligned( 2 ) ) ) AU16 { au32x4 v; };
+__device__ __forceinline__ uint32_t ald4( const int16_t* p ) { return reinterpret_cast<const AU4*>( p )->v; }
+__device__ __forceinline__ au32x4 ald16( const int16_t* p ) { return reinterpret_cast<const AU16*>( p )->v; }
+__device__ __forceinline__ int adot2( uint32_t a, uint32_t b, int c ) { return __builtin_amdgcn_sdot2( __builtin_bit_cast( as16x2, a ), __builtin_bit_cast( as16x2, b ), c, false ); }
+__device__ __forceinline__ uint32_t apk( int lo, int hi ) { return ( uint32_t ) ( lo & 0xffff ) | ( ( uint32_t ) hi << 16 ); }
+__device__ __forceinline__ int alo( uint32_t v ) { return ( int ) ( int16_t ) ( v & 0xffffu ); }
+__device__ __forceinline__ int ahi( uint32_t v ) { return ( int ) ( ( int32_t ) v >> 16 ); }
+__device__ __forceinline__ int aclip( int v, int maxv ) { return v < 0 ? 0 : ( v > maxv ? maxv : v ); }
+
+// ( numer +- denom / 2 ) / denom of applyPlanarCorrection (MCTF.cpp:403-411), kept out of line: the 64-bit division is ~100 instructions and the kernel holds six copies otherwise
+__device__ __attribute__( ( noinline ) ) int planarDiv( long long numer, long long denom )
+{
+  return ( int ) ( ( numer < 0 ? numer - ( denom >> 1 ) : numer + ( denom >> 1 ) ) / denom );
+}
+
+// One reference of a FULL B x B block (B = 16 luma / 8 chroma at unit 16; 6-tap filter) by one wavefront — the same integers as the general path below, restated on sample
+// PAIRS: the horizontal pass takes two outputs from one 16-byte request (tap pairs as v_dot2_i32_i16, the odd-phase pairs through v_alignbit), the vertical pass gives every
+// lane a 2 x 2 patch (column pair xp, rows 2 rg, 2 rg + 1: seven dword rows of the intermediate, pairs of rows interleaved with v_perm), and that patch STAYS in registers
+// through the planar correction and the noise estimate (its right / lower neighbours' differences arrive by three lane shuffles); block sums are 32-bit (a block has <= 256
+// samples of |diff| <= 1023: variance < 2^28, diffsum < 2^31).  sT: ( B + 5 ) x B intermediate of the wave; corr: B x B result (raster, pitch B).
+template<int B>
+__device__ __forceinline__ void applyRefFull( const int16_t* __restrict__ src, int refStride, const int16_t* __restrict__ orgBlk, int orgStride, int dxF, int dyF, int maxv,
+                                              unsigned rmsme, bool planar, int bitDepth, int16_t* __restrict__ sT, int16_t* __restrict__ corr, int& noiseOut, int lane )
+{
+  constexpr int HP = B / 2, LOG2HP = B == 16 ? 3 : 2, LOG2B = B == 16 ? 4 : 3;
+  {
+    const int16_t* xf = cApply6[dxF];
+    const uint32_t t12 = apk( xf[1], xf[2] ), t34 = apk( xf[3], xf[4] ), t56 = apk( xf[5], xf[6] );
+    for( int e = lane; e < ( B + 5 ) * HP; e += 64 )       // intermediate row rr <-> source row rr - 2
+    {
+      const int rr = e >> LOG2HP, xp = e & ( HP - 1 );
+      const au32x4 d = ald16( src + ( ptrdiff_t ) ( rr - 2 ) * refStride + 2 * xp - 2 );      // samples x - 2 .. x + 5 of the row, x = 2 xp
+      const int o0 = adot2( d.x, t12, adot2( d.y, t34, adot2( d.z, t56, 32 ) ) );
+      const int o1 = adot2( __builtin_amdgcn_alignbit( d.y, d.x, 16 ), t12, adot2( __builtin_amdgcn_alignbit( d.z, d.y, 16 ), t34, adot2( __builtin_amdgcn_alignbit( d.w, d.z, 16 ), t56, 32 ) ) );
+      *reinterpret_cast<uint32_t*>( sT + rr * B + 2 * xp ) = apk( o0 >> 6, o1 >> 6 );       // ( Pel ) truncation, no clip (MCTF.cpp:287-300)
+    }
+  }
+  WAVE_SYNC();
+  const bool act = lane < HP * HP;                       // B = 8: sixteen lanes hold the block
+  const int xp = lane & ( HP - 1 ), rg = ( lane >> LOG2HP ) & ( HP - 1 ), x = 2 * xp, y = 2 * rg;
+  int c00, c01, c10, c11;
+  {
+    const int16_t* yf = cApply6[dyF];
+    const uint32_t u12 = apk( yf[1], yf[2] ), u34 = apk( yf[3], yf[4] ), u56 = apk( yf[5], yf[6] );
+    const uint32_t* q = reinterpret_cast<const uint32_t*>( sT + y * B + x );
+    uint32_t R[7];
+#pragma unroll
+    for( int k = 0; k < 7; k++ ) R[k] = q[k * HP];
+#define ALO( A, Bv ) __builtin_amdgcn_perm( Bv, A, 0x05040100u )
+#define AHI( A, Bv ) __builtin_amdgcn_perm( Bv, A, 0x07060302u )
+    c00 = aclip( adot2( ALO( R[0], R[1] ), u12, adot2( ALO( R[2], R[3] ), u34, adot2( ALO( R[4], R[5] ), u56, 32 ) ) ) >> 6, maxv );
+    c01 = aclip( adot2( AHI( R[0], R[1] ), u12, adot2( AHI( R[2], R[3] ), u34, adot2( AHI( R[4], R[5] ), u56, 32 ) ) ) >> 6, maxv );
+    c10 = aclip( adot2( ALO( R[1], R[2] ), u12, adot2( ALO( R[3], R[4] ), u34, adot2( ALO( R[5], R[6] ), u56, 32 ) ) ) >> 6, maxv );
+    c11 = aclip( adot2( AHI( R[1], R[2] ), u12, adot2( AHI( R[3], R[4] ), u34, adot2( AHI( R[5], R[6] ), u56, 32 ) ) ) >> 6, maxv );
+#undef ALO
+#undef AHI
+  }
+  const uint32_t og0 = ald4( orgBlk + ( ptrdiff_t ) y * orgStride + x ), og1 = ald4( orgBlk + ( ptrdiff_t ) ( y + 1 ) * orgStride + x );
+  const int o00 = alo( og0 ), o01 = ahi( og0 ), o10 = alo( og1 ), o11 = ahi( og1 );
+  if( planar )                                           // MCTF.cpp:372-421 (wave-uniform)
+  {
+    const int z00 = act ? c00 - o00 : 0, z01 = act ? c01 - o01 : 0, z10 = act ? c10 - o10 : 0, z11 = act ? c11 - o11 : 0;
+    const int x1yzm = ( int ) vvhipGroupSum32( ( uint32_t ) ( x * ( z00 + z10 ) + ( x + 1 ) * ( z01 + z11 ) ), 64, lane );
+    const int x2yzm = ( int ) vvhipGroupSum32( ( uint32_t ) ( y * ( z00 + z01 ) + ( y + 1 ) * ( z10 + z11 ) ), 64, lane );
+    const int ySum  = ( int ) vvhipGroupSum32( ( uint32_t ) ( z00 + z01 + z10 + z11 ), 64, lane );
+    const int xSzm[6] = { 0, 1, 20, 336, 5440, 87296 };
+    constexpr int blockSize = B * B, log2Width = LOG2B;
+    const unsigned me2 = rmsme * rmsme;
+    const int mWeight = ( int ) ( me2 < 512u ? me2 : 512u );
+    constexpr int xSum = ( blockSize * ( B - 1 ) ) >> 1;
+    const long long denom = ( long long ) blockSize * xSzm[log2Width];
+    long long numer = ( long long ) mWeight * ( ( long long ) x1yzm * blockSize - xSum * ySum );
+    int b1 = planarDiv( numer, denom );
+    b1 = b1 < -32768 ? -32768 : ( b1 > 32767 ? 32767 : b1 );
+    numer = ( long long ) mWeight * ( ( long long ) x2yzm * blockSize - xSum * ySum );
+    int b2 = planarDiv( numer, denom );
+    b2 = b2 > 32767 ? 32767 : ( b2 < -32768 ? -32768 : b2 );
+    const int b0 = ( mWeight * ySum - ( b1 + b2 ) * xSum + ( blockSize >> 1 ) ) >> ( log2Width << 1 );
+    if( b0 != 0 || b1 != 0 || b2 != 0 )
+    {
+      const int p00 = b0 + b1 * x + b2 * y + 256;
+      c00 = aclip( c00 - ( p00 >> 9 ), maxv );
+      c01 = aclip( c01 - ( ( p00 + b1 ) >> 9 ), maxv );
+      c10 = aclip( c10 - ( ( p00 + b2 ) >> 9 ), maxv );
+      c11 = aclip( c11 - ( ( p00 + b1 + b2 ) >> 9 ), maxv );
+    }
+  }
+  if( act )
+  {
+    *reinterpret_cast<uint32_t*>( corr + y * B + x ) = apk( c00, c01 );
+    *reinterpret_cast<uint32_t*>( corr + ( y + 1 ) * B + x ) = apk( c10, c11 );
+  }
+  // ---- noise estimate (MCTF.cpp:445-477): diff = org - corrected; variance = sum diff^2; diffsum = sum of squared differences of horizontally / vertically adjacent diffs
+  const int d00 = o00 - c00, d01 = o01 - c01, d10 = o10 - c10, d11 = o11 - c11;
+  const uint32_t P0 = apk( d00, d01 ), P1 = apk( d10, d11 );
+  const uint32_t nr0 = ( uint32_t ) __shfl_down( ( int ) P0, 1 ), nr1 = ( uint32_t ) __shfl_down( ( int ) P1, 1 ), nd = ( uint32_t ) __shfl_down( ( int ) P0, HP );
+  uint32_t var = 0, ds = 0;
+  if( act )
+  {
+    var = ( uint32_t ) ( d00 * d00 + d01 * d01 + d10 * d10 + d11 * d11 );
+    int t;
+    t = d01 - d00; ds += ( uint32_t ) ( t * t );  t = d11 - d10; ds += ( uint32_t ) ( t * t );                           // right neighbours inside the patch
+    t = d10 - d00; ds += ( uint32_t ) ( t * t );  t = d11 - d01; ds += ( uint32_t ) ( t * t );                           // lower neighbours inside the patch
+    if( xp != HP - 1 ) { t = alo( nr0 ) - d01; ds += ( uint32_t ) ( t * t ); t = alo( nr1 ) - d11; ds += ( uint32_t ) ( t * t ); }      // column 2 xp + 2 of the next lane
+    if( rg != HP - 1 ) { t = alo( nd ) - d10; ds += ( uint32_t ) ( t * t ); t = ahi( nd ) - d11; ds += ( uint32_t ) ( t * t ); }        // row 2 rg + 2 of the lane HP further on
+  }
+  const uint32_t varSum = vvhipGroupSum32( var, 64, lane ), dsSum = vvhipGroupSum32( ds, 64, lane );
+  long long variance = ( long long ) varSum, diffsum = ( long long ) dsSum;
+  variance *= ( long long ) 1 << ( 2 * ( 10 - bitDepth ) );
+  diffsum  *= ( long long ) 1 << ( 2 * ( 10 - bitDepth ) );
+  constexpr int cntV = B * B, cntD = 2 * cntV - B - B;
+  noiseOut = ( int ) round( ( 15.0 * cntD / cntV * variance + 5.0 ) / ( diffsum + 5.0 ) );
+  WAVE_SYNC();                                           // sT is reused by the wave's next reference
+}
+
+// One WAVEFRONT per filter block, four consecutive blocks of a block row per workgroup (round 6; was one workgroup per block with a wave per reference: an 8 x 8 chroma block
+// kept 256 threads, a barrier and the per-block scalar work — weights, plane fit, noise — busy for 64 samples, and a two-reference picture idled half the waves).  The wave
+// walks the references one after the other (wave-level synchronisation only, private LDS scratch, DPP reductions) and blends its block with all 64 lanes.
 __global__ void __launch_bounds__( 256 )
 mctfApplyKernel( const int16_t* __restrict__ org, int orgStride, int refStride, int16_t* __restrict__ out, int outStride, ApplyArgs A )
 {
-  __shared__ int16_t sCorr[MAX_REFS][MAX_BLK * MAX_BLK / 4];     // blocks up to 16x16 (256 samples) per reference; see host check
-  __shared__ int16_t sTmpAll[4][( 16 + 7 ) * 16];
-  __shared__ int sNoise[MAX_REFS], sErr[MAX_REFS];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sCorrAll[4][MAX_REFS][MAX_BLK * MAX_BLK / 4];     // blocks up to 16x16 (256 samples) per reference; see host check
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmpAll[4][( 16 + 7 ) * 16];
+  __shared__ int sNoiseAll[4][MAX_REFS], sErrAll[4][MAX_REFS];
+  __shared__ float sVwwAll[4][MAX_REFS], sVswAll[4][MAX_REFS];
 
-  const int blk = A.blk, bxI = blockIdx.x, byI = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+  const int blk = A.blk, bxI = blockIdx.x * 4 + wave, byI = blockIdx.y;
   const int bx = bxI * blk, by = byI * blk;
+  if( bx >= A.width ) return;                                                      // (no workgroup barrier below: a wave may leave)
   const int w = min( blk, A.width - bx ), h = min( blk, A.height - by );
-  const int tid = threadIdx.x, nThr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int maxv = ( 1 << A.bitDepth ) - 1;
   const int16_t* orgBlk = org + ( ptrdiff_t ) by * orgStride + bx;
   int16_t* sTmp = sTmpAll[wave];
+  int16_t ( *sCorr )[MAX_BLK * MAX_BLK / 4] = sCorrAll[wave];
+  int* sNoise = sNoiseAll[wave]; int* sErr = sErrAll[wave];
+  float* sVww = sVwwAll[wave]; float* sVsw = sVswAll[wave];
 
-  for( int i = wave; i < A.numRefs; i += ( nThr >> 6 ) )
+  for( int i = 0; i < A.numRefs; i++ )      // (a uniform index: the per-reference kernel arguments are scalar loads — indexed per lane they become 100+ vector registers of copies)
   {
     const vvhip_mv mv = A.mvs[i][byI * A.mvW + bxI];
     const int dx = mv.x >> A.cs, dy = mv.y >> A.cs, xInt = mv.x >> ( 4 + A.cs ), yInt = mv.y >> ( 4 + A.cs );
     const int16_t* src = A.refs[i] + ( ptrdiff_t ) ( by + yInt ) * refStride + bx + xInt;
     int16_t* corr = sCorr[i];
+    // full 16 x 16 / 8 x 8 blocks with the 6-tap filter (what the encoder runs: m_lowResFltApply is never set, MCTF.h:190): the packed path
+    if( !A.lowRes && w == h && ( w == 16 || w == 8 ) && A.bitDepth <= 10 && !A.generic )
+    {
+      int noise = 0;
+      const bool planar = mv.rmsme > 0 && A.qp <= 32;
+      if( w == 16 ) applyRefFull<16>( src, refStride, orgBlk, orgStride, dx & 15, dy & 15, maxv, ( unsigned ) ( uint16_t ) mv.rmsme, planar, A.bitDepth, sTmp, corr, noise, lane );
+      else          applyRefFull<8>( src, refStride, orgBlk, orgStride, dx & 15, dy & 15, maxv, ( unsigned ) ( uint16_t ) mv.rmsme, planar, A.bitDepth, sTmp, corr, noise, lane );
+      if( lane == 0 ) { sNoise[i] = noise; sErr[i] = mv.error; }
+      continue;
+    }
     // ---- applyFrac: horizontal pass into sTmp (Pel truncation, no clip), vertical pass into corr (clip)
     if( A.lowRes )
     {
@@ -132,10 +268,10 @@ mctfApplyKernel( const int16_t* __restrict__ org, int orgStride, int refStride, 
       const int xSum = ( blockSize * ( w - 1 ) ) >> 1;
       const long long denom = ( long long ) blockSize * xSzm[log2Width];
       long long numer = ( long long ) mWeight * ( ( long long ) x1yzm * blockSize - xSum * ySum );
-      int b1 = ( int ) ( ( numer < 0 ? numer - ( denom >> 1 ) : numer + ( denom >> 1 ) ) / denom );
+      int b1 = planarDiv( numer, denom );
       b1 = b1 < -32768 ? -32768 : ( b1 > 32767 ? 32767 : b1 );
       numer = ( long long ) mWeight * ( ( long long ) x2yzm * blockSize - xSum * ySum );
-      int b2 = ( int ) ( ( numer < 0 ? numer - ( denom >> 1 ) : numer + ( denom >> 1 ) ) / denom );
+      int b2 = planarDiv( numer, denom );
       b2 = b2 > 32767 ? 32767 : ( b2 < -32768 ? -32768 : b2 );
       const int b0 = ( mWeight * ySum - ( b1 + b2 ) * xSum + ( blockSize >> 1 ) ) >> ( log2Width << 1 );
       if( b0 != 0 || b1 != 0 || b2 != 0 )
@@ -170,17 +306,14 @@ mctfApplyKernel( const int16_t* __restrict__ org, int orgStride, int refStride, 
       }
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
 
-  // ---- per-reference weights (every thread evaluates the same scalar expressions) and the blend (MCTF.cpp:479-517)
-  int minError = 0x7fffffff;
-  for( int i = 0; i < A.numRefs; i++ ) minError = sErr[i] < minError ? sErr[i] : minError;
-  float vww[MAX_REFS], vsw[MAX_REFS];
-#pragma unroll
-  for( int i = 0; i < MAX_REFS; i++ )
+  // ---- per-reference weights (MCTF.cpp:479-500): thread i evaluates reference i's pair once (round 6: every thread used to evaluate all of them, 12 unrolled slots of
+  //      double arithmetic and 24 live registers), the blend reads them as LDS broadcasts
   {
-    vww[i] = 0.0f; vsw[i] = 1.0f;
-    if( i < A.numRefs )
+    int minError = 0x7fffffff;
+    for( int i = 0; i < A.numRefs; i++ ) minError = sErr[i] < minError ? sErr[i] : minError;
+    for( int i = 0; i < A.numRefs; i++ )      // (uniform index into the kernel arguments; lane i keeps reference i's pair)
     {
       const int error = sErr[i], noise = sNoise[i];
       float ww = 1, sw = 1;
@@ -189,27 +322,28 @@ mctfApplyKernel( const int16_t* __restrict__ org, int orgStride, int refStride, 
       ww *= ( error < 50 ) ? 1.2 : ( ( error > 100 ) ? 0.6 : 1.0 );
       sw *= ( error < 50 ) ? 1.0 : 0.8;
       ww *= ( ( minError + 1.0 ) / ( error + 1.0 ) );
-      vww[i] = ww * A.weightScaling * A.refStrengths[i];
-      vsw[i] = sw * 2 * A.sigmaSq;
+      const float vw = ww * A.weightScaling * A.refStrengths[i], vs = sw * 2 * A.sigmaSq;
+      if( lane == i ) { sVww[i] = vw; sVsw[i] = vs; }
     }
   }
-  for( int e = tid; e < h * w; e += nThr )
+  WAVE_SYNC();
+  // ---- the blend (MCTF.cpp:501-517)
+  const int nRefs = A.numRefs;
+  for( int e = lane; e < h * w; e += 64 )
   {
     const int y = e / w, x = e - y * w;
     const int16_t orgVal = orgBlk[( ptrdiff_t ) y * orgStride + x];
     float temporalWeightSum = 1.0;
     float newVal = ( float ) orgVal;
-#pragma unroll
-    for( int i = 0; i < MAX_REFS; i++ )
-      if( i < A.numRefs )
-      {
-        const int refVal = sCorr[i][e];
-        const int diff = refVal - orgVal;
-        const float diffSq = diff * diff;
-        const float weight = vww[i] * fastExp( -diffSq, vsw[i] );
-        newVal += weight * refVal;
-        temporalWeightSum += weight;
-      }
+    for( int i = 0; i < nRefs; i++ )
+    {
+      const int refVal = sCorr[i][e];
+      const int diff = refVal - orgVal;
+      const float diffSq = diff * diff;
+      const float weight = sVww[i] * fastExp( -diffSq, sVsw[i] );
+      newVal += weight * refVal;
+      temporalWeightSum += weight;
+    }
     newVal /= temporalWeightSum;
     int16_t sampleVal = ( int16_t ) ( newVal + 0.5 );
     sampleVal = sampleVal < 0 ? ( int16_t ) 0 : ( sampleVal > maxv ? ( int16_t ) maxv : sampleVal );
@@ -235,7 +369,9 @@ int vvhip_mctf_apply_plane( vvhip_ctx* ctx, const int16_t* d_org, int org_stride
   for( int i = 0; i < MAX_REFS; i++ ) { a.refs[i] = i < num_refs ? d_refs[i] : nullptr; a.mvs[i] = i < num_refs ? d_mvs[i] : nullptr; a.refStrengths[i] = i < num_refs ? ref_strengths[i] : 0.0; }
   a.weightScaling = weight_scaling; a.sigmaSq = sigma_sq; a.numRefs = num_refs; a.cs = chroma_shift; a.bitDepth = bit_depth; a.blk = blk; a.lowRes = low_res_flt_apply ? 1 : 0;
   a.qp = qp; a.mvW = mv_w; a.width = width; a.height = height;
-  const dim3 grid( ( width + blk - 1 ) / blk, ( height + blk - 1 ) / blk );
+  static const int generic = []{ const char* e = getenv( "VVHIP_MCTF_APPLY_GENERIC" ); return e ? atoi( e ) : 0; }();
+  a.generic = generic;
+  const dim3 grid( ( ( width + blk - 1 ) / blk + 3 ) / 4, ( height + blk - 1 ) / blk );      // four blocks of a block row per workgroup, one per wavefront
   hipLaunchKernelGGL( mctfApplyKernel, grid, dim3( 256 ), 0, ctx->stream, d_org, org_stride, ref_stride, d_out, out_stride, a );
   VVHIP_LAUNCH_CHECK( ctx );
   return VVHIP_OK;
