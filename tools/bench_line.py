@@ -26,6 +26,8 @@ ROOF_KEYS = ("bound", "kernel", "avg_launch_ms", "launches_per_picture", "alg_by
              "traffic_over_unique", "l2_hit_rate", "l1_access_frac", "valu_issue_frac", "binding_resource", "binding_frac")
 ROOF_4K_KEYS = ("kernel", "avg_launch_ms", "alg_bytes_per_launch", "achieved", "frac", "traffic", "frac_physical", "frac_unique", "l2_hit_rate", "binding_resource", "binding_frac")
 CLASS_KEYS = ("avg_launch_us", "alg_frac", "unique_frac", "fabric_frac", "traffic_over_unique", "l2_hit_rate", "l1_access_frac", "valu_issue_frac")
+CLASS_KEYS_MCTF = ("avg_launch_us", "alg_frac", "fabric_frac", "l1_access_frac", "valu_issue_frac")          # (the MCTF rows: the full set is in the detail file and in profiles/)
+CLASS_KEYS_MCTF_4K = ("avg_launch_us", "alg_frac", "valu_issue_frac")
 CLASS_KEYS_4K = ("avg_launch_us", "alg_frac", "fabric_frac", "l2_hit_rate", "l1_access_frac", "valu_issue_frac")
 E2E_KEYS = ("threads", "pairs", "cpu_fps", "hip_fps", "speedup", "cpu_fps_best", "hip_fps_best", "speedup_best", "bitstreams_identical", "md5_set")
 
@@ -70,7 +72,7 @@ def compact(out, detail_path):
     if "roofline" in out:
         line["roofline"] = _roof(out["roofline"], ROOF_KEYS, out.get("roofline_checks"))
     if out.get("roofline_all_kernels"):
-        line["classes"] = {k: _pick(v, CLASS_KEYS) for k, v in out["roofline_all_kernels"].items()}
+        line["classes"] = {k: _pick(v, CLASS_KEYS_MCTF if k.startswith("MCTF") else CLASS_KEYS) for k, v in out["roofline_all_kernels"].items()}
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "passes", "value_fastest_passes", "value_slowest_passes", "value_1thread", "loadavg_before_after"))
@@ -102,7 +104,7 @@ def compact(out, detail_path):
         line["roofline_4k"] = _roof(out["roofline_4k"], ROOF_4K_KEYS, out.get("roofline_checks_4k"))
         line["roofline_4k"].pop("basis", None)
     if out.get("roofline_all_kernels_4k"):
-        line["classes_4k"] = {k: _pick(v, CLASS_KEYS_4K) for k, v in out["roofline_all_kernels_4k"].items()}
+        line["classes_4k"] = {k: _pick(v, CLASS_KEYS_MCTF_4K if k.startswith("MCTF") else CLASS_KEYS_4K) for k, v in out["roofline_all_kernels_4k"].items()}
     if "parity_4k" in out:
         line["parity_4k"] = _pick(out["parity_4k"], ("status", "mismatches", "error"))
     if "cpu_baseline_4k" in out:

@@ -300,7 +300,7 @@ def mctf_stage(hp, wl, refs=4, reps=5):
 
     def apply():
         for c in range(3):
-            hp.mctf_apply_plane(planes_o[c], planes_r[c], outs, mv_w, 1 if c else 0, strengths, prm[c][1], prm[c][0], bd, 16, True, 32, out=outp[c])
+            hp.mctf_apply_plane(planes_o[c], planes_r[c], outs, mv_w, 1 if c else 0, strengths, prm[c][1], prm[c][0], bd, 16, False, 32, out=outp[c])      # (6-tap: m_lowResFltApply is never set, MCTF.h:190)
     out["filter_ms_per_picture"] = timed_ms(apply, reps)
     nb = dims[0] * dims[1]
     out["blocks_final_level"] = nb

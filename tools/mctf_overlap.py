@@ -27,7 +27,9 @@ def main():
     lanes = [hp.fork(torch.cuda.Stream()) for _ in range(5)]
     for wl in wls.values():
         wl.bind_lanes(lanes)
-    ml = [hp.fork(torch.cuda.Stream()) for _ in range(2)]
+    prio = int(os.environ.get("MCTF_PRIO", "0"))
+    ml = [hp.fork(torch.cuda.Stream(priority=prio)) for _ in range(2)]
+    print("MCTF lane priority", prio, "range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "?")
     mc = BM.MctfCadence(hp, w, h, lane=ml[0])
     for job in BM.JOBS:                       # scratch of both lanes
         mc.issue(job, ctx=ml[0]); mc.issue(job, ctx=ml[1])
