@@ -460,7 +460,8 @@ meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int fac
   g.buf = R.buf[blockIdx.y];
   const vvhip_mv* __restrict__ prev = R.prev[blockIdx.y];
   vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.y];
-  const int blk = blockIdx.x, byi = blk / nbx, bxi = blk - byi * nbx;
+  const int blk = blockIdx.x;
+  const int byi = blk / nbx, bxi = blk - byi * nbx;
   const int bs = g.bs, bx = bxi * bs, by = byi * bs;
 
   int bestX = 0, bestY = 0, bestE = 0x7fffffff;
@@ -601,6 +602,159 @@ meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int fac
 #define ME_ERROR( DX, DY ) meError( g, bx, by, ( DX ), ( DY ), sTmp, lane )
 #undef ME_COUNT
 #define ME_COUNT( DX, DY )
+
+// ---- phase A of the coarse levels, four wavefronts per block (round 6) ---------------------------------------------------------------------------------------
+// The levels above the full-resolution ones have a few hundred blocks: one wavefront per block leaves the device empty while every wave walks its ~60-90 candidates one
+// after the other (25 + 20 + 37 us of a 1080p call's 274 us of candidate scoring, with 160 / 540 / 2 040 waves in flight).  Here a workgroup of four waves shares a FULL
+// 32 x 32 block: the inherited vectors are dealt to the waves (all requests in flight at once), the window of the dense integer grid is staged by all 256 threads, the grid
+// positions are dealt round-robin, and the reference's "first strictly smaller in scan order" becomes a minimum over ( error, scan index ).  Blocks cut by the picture edge
+// deal their candidates the same way and score each with the general routine.  Integer vectors only (every level but the last).
+constexpr int ME_COOP_WAVES = 4;
+__global__ void __launch_bounds__( 64 * ME_COOP_WAVES )
+meSearchCoopKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int factor, int searchPttrn, int mvsW, int fixBlocks )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sWin[48 * 52];
+  __shared__ int sCandE[12], sCandX[12], sCandY[12];
+  __shared__ int sBestE[ME_COOP_WAVES], sBestP[ME_COOP_WAVES];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane( t >> 6 );
+  g.buf = R.buf[blockIdx.y];
+  const vvhip_mv* __restrict__ prev = R.prev[blockIdx.y];
+  vvhip_mv* __restrict__ mvs = R.mvs[blockIdx.y];
+  const int blk = blockIdx.x, byi = blk / nbx, bxi = blk - byi * nbx;
+  const int bx = bxi * 32, by = byi * 32;
+  // full blocks: original in registers, grid out of a staged window; blocks cut by the picture edge (8 .. 24 samples on a side): the same dealing of candidates, each scored
+  // by the general routine (wave-uniform choice, workgroup-uniform control flow)
+  const bool full = bx + 32 <= g.width && by + 32 <= g.height;
+  Org32 O32 = {};
+  if( full ) O32 = loadOrg32( g.org + bx + ( ptrdiff_t ) by * g.orgStride, g.orgStride, g.bufStride, lane );
+  int bestX = 0, bestY = 0, bestE = 0x7fffffff;
+  int range = searchPttrn == 2 ? 3 : 5;                                   // MCTF.cpp:1178 (not the final level)
+  if( !prev ) range = 8;                                                  // :1183-1186
+  else
+  {
+    // the 3 x 3 coarser blocks' vectors (:1189-1208) and the zero vector (:1210-1214): candidate k = 0..9 in the reference's order; wave w scores k = w, w + 4, w + 8
+    if( t < 12 ) sCandE[t] = 0x7fffffff;
+    __syncthreads();
+    int cx[3], cy[3]; bool ok[3]; u32x4 va[3], vb[3];
+#pragma unroll
+    for( int q = 0; q < 3; q++ )
+    {
+      const int k = wave + ME_COOP_WAVES * q;
+      cx[q] = 0; cy[q] = 0; ok[q] = k == 9;
+      if( k < 9 )
+      {
+        const int py = ( k * 11 ) >> 5, px = k - 3 * py, ty = by / 64 + py - 1, tx = bx / 64 + px - 1;
+        ok[q] = ty >= 0 && ty < prevH && tx >= 0 && tx < prevW;
+        if( ok[q] ) { const vvhip_mv old = prev[ty * prevW + tx]; cx[q] = old.x * factor; cy[q] = old.y * factor; }
+      }
+      if( full )
+      {
+        const int16_t* c = g.buf + bx + cx[q] / 16 + ( ptrdiff_t ) ( by + cy[q] / 16 ) * g.bufStride;
+        va[q] = ld16( c + O32.off ); vb[q] = ld16( c + O32.off + 16 * g.bufStride );      // (an unused slot reads the zero-vector position: in range)
+      }
+    }
+#pragma unroll
+    for( int q = 0; q < 3; q++ )
+    {
+      int e = 0; uint32_t d;
+      if( !full )
+      {
+        const int k = wave + ME_COOP_WAVES * q;
+        const int ev = meError( g, bx, by, cx[q], cy[q], sWin, lane );
+        if( lane == 0 && ok[q] && k < 10 ) { sCandE[k] = ev; sCandX[k] = cx[q]; sCandY[k] = cy[q]; }
+        continue;
+      }
+      d = pkSub16( O32.a.x, va[q].x ); e = sdot2( d, d, e ); d = pkSub16( O32.a.y, va[q].y ); e = sdot2( d, d, e ); d = pkSub16( O32.a.z, va[q].z ); e = sdot2( d, d, e ); d = pkSub16( O32.a.w, va[q].w ); e = sdot2( d, d, e );
+      d = pkSub16( O32.b.x, vb[q].x ); e = sdot2( d, d, e ); d = pkSub16( O32.b.y, vb[q].y ); e = sdot2( d, d, e ); d = pkSub16( O32.b.z, vb[q].z ); e = sdot2( d, d, e ); d = pkSub16( O32.b.w, vb[q].w ); e = sdot2( d, d, e );
+      e = waveSum( e );
+      const int k = wave + ME_COOP_WAVES * q;
+      if( lane == 0 && ok[q] && k < 10 ) { sCandE[k] = e; sCandX[k] = cx[q]; sCandY[k] = cy[q]; }
+    }
+    __syncthreads();
+    for( int k = 0; k < 10; k++ )                                         // the reference's order, strict <
+    {
+      const int e = sCandE[k];
+      if( e < bestE ) { bestE = e; bestX = sCandX[k]; bestY = sCandY[k]; }
+    }
+  }
+  // the dense integer grid around the best vector so far (:1216-1228)
+  const int d = ( !prev && searchPttrn == 2 ) ? 2 : 1;
+  const int gx0 = bestX / 16 - range, gy0 = bestY / 16 - range, W = 32 + 2 * range;
+  const int PS = 2 * ( ( ( W + 3 ) >> 1 ) | 1 ), cpr = ( W + 7 ) >> 3, total = W * cpr;
+  const uint32_t cprInv = ( 65536u + ( uint32_t ) cpr - 1u ) / ( uint32_t ) cpr;
+  const int16_t* src = g.buf + bx + gx0 + ( ptrdiff_t ) ( by + gy0 ) * g.bufStride;
+  if( full )
+  for( int i0 = t; i0 < total; i0 += 2 * 64 * ME_COOP_WAVES )
+  {
+    u32x4 v[2]; int at[2], left[2];
+#pragma unroll
+    for( int q = 0; q < 2; q++ )
+    {
+      const int i = i0 + 64 * ME_COOP_WAVES * q < total ? i0 + 64 * ME_COOP_WAVES * q : i0, r = ( int ) ( ( ( uint32_t ) i * cprInv ) >> 16 ), c = i - r * cpr;
+      at[q] = r * PS + 8 * c; left[q] = ( PS >> 1 ) - 4 * c;
+      v[q] = ld16( src + ( ptrdiff_t ) r * g.bufStride + 8 * c );
+    }
+#pragma unroll
+    for( int q = 0; q < 2; q++ )
+      if( i0 + 64 * ME_COOP_WAVES * q < total )
+      {
+        uint32_t* dst = reinterpret_cast<uint32_t*>( sWin + at[q] );
+        dst[0] = v[q].x; if( left[q] > 1 ) dst[1] = v[q].y; if( left[q] > 2 ) dst[2] = v[q].z; if( left[q] > 3 ) dst[3] = v[q].w;
+      }
+  }
+  __syncthreads();
+  {
+    const int r = lane >> 2, sgm = lane & 3, per = 2 * range / d + 1, nPos = per * per;
+    const uint32_t* rowA = reinterpret_cast<const uint32_t*>( sWin + r * PS + 8 * sgm );
+    int locE = 0x7fffffff, locP = 0x7fffffff;
+    for( int p = wave; p < nPos; p += ME_COOP_WAVES )
+    {
+      const int iy = p / per, gy = iy * d, gx = ( p - iy * per ) * d;
+      if( !full )
+      {
+        const int e_ = meError( g, bx, by, ( gx0 + gx ) * 16, ( gy0 + gy ) * 16, sWin, lane );
+        if( e_ < locE ) { locE = e_; locP = p; }
+        continue;
+      }
+      const uint32_t* pa = rowA + ( ( gy * PS + gx ) >> 1 );
+      const uint32_t* pb = pa + 8 * PS;
+      const uint32_t sh = ( gx & 1 ) * 16;
+      const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], a4 = pa[4], b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3], b4 = pb[4];
+      int e = 0; uint32_t df;
+      df = pkSub16( O32.a.x, __builtin_amdgcn_alignbit( a1, a0, sh ) ); e = sdot2( df, df, e ); df = pkSub16( O32.a.y, __builtin_amdgcn_alignbit( a2, a1, sh ) ); e = sdot2( df, df, e );
+      df = pkSub16( O32.a.z, __builtin_amdgcn_alignbit( a3, a2, sh ) ); e = sdot2( df, df, e ); df = pkSub16( O32.a.w, __builtin_amdgcn_alignbit( a4, a3, sh ) ); e = sdot2( df, df, e );
+      df = pkSub16( O32.b.x, __builtin_amdgcn_alignbit( b1, b0, sh ) ); e = sdot2( df, df, e ); df = pkSub16( O32.b.y, __builtin_amdgcn_alignbit( b2, b1, sh ) ); e = sdot2( df, df, e );
+      df = pkSub16( O32.b.z, __builtin_amdgcn_alignbit( b3, b2, sh ) ); e = sdot2( df, df, e ); df = pkSub16( O32.b.w, __builtin_amdgcn_alignbit( b4, b3, sh ) ); e = sdot2( df, df, e );
+      const int e_ = waveSum( e );
+      if( e_ < locE ) { locE = e_; locP = p; }                           // (p increases: the wave's first minimum)
+    }
+    if( lane == 0 ) { sBestE[wave] = locE; sBestP[wave] = locP; }
+    __syncthreads();
+    int gE = 0x7fffffff, gP = 0x7fffffff;
+#pragma unroll
+    for( int w2 = 0; w2 < ME_COOP_WAVES; w2++ )
+    {
+      const int e = sBestE[w2], p = sBestP[w2];
+      if( e < gE || ( e == gE && p < gP ) ) { gE = e; gP = p; }          // smallest error, then the earliest position of the scan
+    }
+    if( gE < bestE )
+    {
+      const int iy = gP / per;
+      bestX = ( gx0 + ( gP - iy * per ) * d ) * 16; bestY = ( gy0 + iy * d ) * 16; bestE = gE;
+    }
+  }
+  if( t == 0 )
+  {
+    vvhip_mv& m = mvs[byi * mvsW + bxi];
+    m.x = bestX; m.y = bestY; m.error = bestE;
+    if( fixBlocks )
+    {
+      int* lists = reinterpret_cast<int*>( reinterpret_cast<char*>( R.gran[blockIdx.y] ) + ( size_t ) fixBlocks * sizeof( FixRec ) );
+      lists[3 * ( size_t ) fixBlocks + blk] = 0;
+      if( blk == 0 ) lists[4 * ( size_t ) fixBlocks] = 0;
+    }
+  }
+}
 
 // ---- phase B -------------------------------------------------------------------------------------------------------------
 // granule = { tag (hi 32) , x (bits 16..31), y (bits 0..15) }; tag == 1 marks "final"
@@ -1114,8 +1268,14 @@ int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, i
   const int fixBlocks = useDiag >= 2 ? nbx * nby : 0;
   static const int final16 = []{ const char* e = getenv( "VVHIP_MCTF_FINAL16" ); return e ? atoi( e ) : 1; }();
   const int dblArg = doubleRes ? ( 1 | ( final16 ? 2 : 0 ) ) : 0;
-  if( st ) hipLaunchKernelGGL( meSearchKernel<true>,  dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, dblArg, pttrn, mvsW, st, fixBlocks );
-  else     hipLaunchKernelGGL( meSearchKernel<false>, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, dblArg, pttrn, mvsW, st, fixBlocks );
+  // the coarse levels (few blocks: one wave per block leaves the device empty) give their full 32 x 32 blocks to four waves each; the blocks at the picture edge and
+  // every level with enough blocks to fill the device take the one-wave-per-block kernel ($VVHIP_MCTF_COOP=0: always; the counting instance always)
+  static const int coopOn = []{ const char* e = getenv( "VVHIP_MCTF_COOP" ); return e ? atoi( e ) : 1; }();
+  static const long coopMax = []{ const char* e = getenv( "VVHIP_MCTF_COOP_MAX" ); return e ? atol( e ) : 2048l; }();
+  if( coopOn && !st && !doubleRes && bs == 32 && ( long ) nbx * nby * nRefs <= coopMax )
+    hipLaunchKernelGGL( meSearchCoopKernel, dim3( nbx * nby, nRefs ), dim3( 64 * ME_COOP_WAVES ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, pttrn, mvsW, fixBlocks );
+  else if( st ) hipLaunchKernelGGL( meSearchKernel<true>,  dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, dblArg, pttrn, mvsW, st, fixBlocks );
+  else          hipLaunchKernelGGL( meSearchKernel<false>, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, prevW, prevH, factor, dblArg, pttrn, mvsW, st, fixBlocks );
   VVHIP_LAUNCH_CHECK( ctx );
   meMark( ctx, 2 );
   const int diagLen = nbx < nby ? nbx : nby;
