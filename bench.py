@@ -43,7 +43,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from vvenc_amd import sharding  # noqa: E402
-from bench_common import GOP_WEIGHT, KERNEL_NAMES, LAYER_POCS, STEP_LAYERS, layer_of_step, prepare_recordings, step_of_rank  # noqa: E402,F401
+from bench_common import GOP_WEIGHT, KERNEL_NAMES, LAYER_POCS, STEP_LAYERS, kernel_label, layer_of_step, prepare_recordings, step_of_rank  # noqa: E402,F401
 from bench_reference import ReferenceJobs, RecJob, cpu_baseline, parity_check  # noqa: E402,F401  (tests import these through bench)
 import bench_line  # noqa: E402
 import bench_mctf as BM  # noqa: E402
@@ -409,7 +409,7 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         for k in ("MCTF_search", "MCTF_nb", "MCTF_fix", "MCTF_apply"):
             ms = mctf_cls[k] / 32.0
             ab = mc.alg_bytes_per_cycle[k] / 32.0
-            kern[k] = {"kernel": KERNEL_NAMES[k], "avg_ms_per_picture": ms, "ms_per_gop_cycle": round(mctf_cls[k], 4), "alg_bytes_per_picture": int(ab),
+            kern[k] = {"kernel": kernel_label(k), "avg_ms_per_picture": ms, "ms_per_gop_cycle": round(mctf_cls[k], 4), "alg_bytes_per_picture": int(ab),
                        "unique_bytes_per_picture": int(mc.unique_bytes_per_cycle[k] / 32.0), "nominal_alg_GBps": (ab / (ms * 1e-3) / 1e9) if ms > 0 else None}
         out["with_mctf"] = mctf_region
         out["with_mctf"]["ms_per_gop_cycle_by_class_serialized"] = {k: round(v, 4) for k, v in mctf_cls.items()}

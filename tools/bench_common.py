@@ -7,7 +7,14 @@ CLOCK_GHZ, N_CU, N_SIMD = 2.4, 256, 1024
 LAYER_POCS = {0: 31, 1: 15, 2: 23, 3: 3, 4: 5, 5: 2}          # one recorded picture per temporal layer of the 65-frame encode (its GOP anchors at POC 31 / 63)
 KERNEL_NAMES = {"ME_stage": "meStageKernel", "ME_int": "meIntKernel", "ME_item": "meItemKernel", "TU": "tuMxMultiKernel", "DMVR": "dmvrRefineKernel",
                 # north-star leg C (MCTF, tools/bench_mctf.py): candidate scoring of estimateLumaLn, the above / left candidates scored in parallel, the resolution of the above / left recurrence, the bilateral filter
-                "MCTF_search": "meSearchKernel", "MCTF_nb": "meNeighbourKernel", "MCTF_fix": "meFixKernel", "MCTF_apply": "mctfApplyKernel"}
+                "MCTF_search": "meSearch", "MCTF_nb": "meNeighbourKernel", "MCTF_fix": "meFixKernel", "MCTF_apply": "mctfApplyKernel"}
+KERNEL_LABELS = {"MCTF_search": "meSearchKernel (+ meSearchCoopKernel on the coarse levels)"}          # what a row is called where the prefix above is not a kernel's whole name
+
+
+def kernel_label(cls):
+    return KERNEL_LABELS.get(cls, KERNEL_NAMES.get(cls, cls))
+
+
 STEP_CLASSES = ("ME_stage", "ME_int", "ME_item", "TU", "DMVR")      # the classes of `value`'s step (legs A + B); the MCTF classes join the table when leg C runs at the GOP's cadence
 
 

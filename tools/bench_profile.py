@@ -7,7 +7,7 @@ import shutil
 import subprocess
 import sys
 
-from bench_common import CLOCK_GHZ, HBM_PEAK_GBS, KERNEL_NAMES, N_CU, N_SIMD
+from bench_common import CLOCK_GHZ, HBM_PEAK_GBS, KERNEL_NAMES, N_CU, N_SIMD, kernel_label
 
 BENCH_PY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
 
@@ -108,7 +108,7 @@ def roofline_objects(kern, live, calib, unique_by_class, ms_per_step, profile_md
     dom = max(kern, key=lambda k: kern[k]["avg_ms_per_picture"])
     sum_alg = sum(kern[k]["alg_bytes_per_picture"] for k in kern)
     checks = {"sum_alg_MB_per_step": round(sum_alg / 1e6, 1), "sum_alg_over_step_time_GBps": round(sum_alg / (ms_per_step * 1e-3) / 1e9, 1) if ms_per_step else None}
-    roof = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "class": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": kern[dom]["avg_ms_per_picture"],
+    roof = {"bound": "hbm", "kernel": kernel_label(dom), "class": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": kern[dom]["avg_ms_per_picture"],
             "alg_bytes_per_launch": kern[dom]["alg_bytes_per_picture"], "achieved": kern[dom]["nominal_alg_GBps"], "frac": (kern[dom]["nominal_alg_GBps"] or 0.0) / HBM_PEAK_GBS, "traffic": None}
     allk = {}
     if not live or not live.get("per_class"):
@@ -129,7 +129,7 @@ def roofline_objects(kern, live, calib, unique_by_class, ms_per_step, profile_md
         alg = kern[k]["alg_bytes_per_picture"] / lpp
         uniq = (unique_by_class.get(k) or 0) / lpp
         gbps = lambda b: b / t_k / 1e9
-        r = {"kernel": KERNEL_NAMES.get(k, k), "launches_per_picture": round(lpp, 2), "avg_launch_us": round(t_k * 1e6, 2),
+        r = {"kernel": kernel_label(k), "launches_per_picture": round(lpp, 2), "avg_launch_us": round(t_k * 1e6, 2),
              "alg_MB_per_launch": round(alg / 1e6, 2), "alg_frac": round(gbps(alg) / HBM_PEAK_GBS, 4),
              "unique_MB_per_launch": round(uniq / 1e6, 2) if uniq else None, "unique_frac": round(gbps(uniq) / HBM_PEAK_GBS, 4) if uniq else None,
              "fabric_MB_per_launch": round(traffic / 1e6, 2) if traffic is not None else None, "fabric_frac": round(gbps(traffic) / HBM_PEAK_GBS, 4) if traffic is not None else None,
