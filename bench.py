@@ -417,8 +417,9 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         out["with_mctf"]["alg_bytes_per_gop_cycle"] = mc.alg_bytes_per_cycle
         out["with_mctf"]["per_candidate_bytes_per_gop_cycle"] = mc.per_candidate_bytes_per_cycle
         out["with_mctf"]["alg_bytes_note"] = ("SURVEY 8d per SCORED candidate, counted by the kernels (vvhip_mctf_set_stats): integer vector 4 w h; fractional vector (w + 3)(h + 3) 2 + 2 w h "
-                                              "(4-tap search filter); the dense integer grids of a block in 8d's WINDOW form ((w + 2R)^2 2 + 2 w h per block + 8 per position: the window is "
-                                              "staged once in LDS) — per_candidate_bytes counts every grid position at 4 w h instead: a work rate (LDS-level reuse), not memory traffic; "
+                                              "(4-tap search filter); the dense integer grids of a block and the refinement rings in 8d's WINDOW form ((w + 2R)^2 2 + 2 w h per block + 8 per position; a ring: "
+                                              "(w + 4)(h + 4) 2 + 2 w h + 8 per position: the window is staged once in LDS) — per_candidate_bytes counts every such position at its own "
+                                              "4 w h / (w + 3)(h + 3) 2 + 2 w h instead: a work rate (LDS-level reuse), not memory traffic; "
                                               "filter: per block 4 w h + per reference (w + 5)(h + 5) 2 + 24")
         out["_mctf"] = mc
     elif mctf_region is not None:

@@ -476,19 +476,21 @@ VVHIP_API int vvhip_mctf_motion_estimation_async( vvhip_ctx* ctx, const int16_t*
                                                   vvhip_mv* const* d_mvs_out_host_array );
 
 /* Scored-candidate counters of the MCTF search (measurement: the algorithmic bytes of SURVEY 8d are priced per SCORED candidate, and which candidates estimateLumaLn
- * scores depends on the data — MCTF.cpp:1189-1306).  set_stats( 1 ) allocates and zeroes 18 counters and switches the counting kernel instances on, set_stats( 0 )
- * switches them off.  get_stats copies them to the host (waits for the stream).  Three phases x 6 counters:
- *   out[0..5]   phase A (estimateLumaLn up to the above/left tests): [0] integer candidates scored one by one, [1] their bytes (4 w h each), [2] fractional candidates,
- *               [3] their bytes ((w + taps - 1)(h + taps - 1) 2 + 2 w h each; taps = 4 with the low-resolution search filter, 6 otherwise), [4] positions of the dense
- *               integer grids (MCTF.cpp:1216-1228) scored out of one staged window, [5] those windows' bytes in SURVEY 8d's window form ((w + 2R)^2 2 + 2 w h per block
- *               + 8 per position); the per-candidate figure of the grid positions is [4] x 4 w h with w = h = 32 (only full blocks take that path)
- *   out[6..11]  the above/left candidates scored in parallel at the neighbours' phase-A vectors, out[12..17] those scored while the recurrence is resolved.        */
+ * scores depends on the data — MCTF.cpp:1189-1306).  set_stats( 1 ) allocates and zeroes 24 counters and switches the counting kernel instances on, set_stats( 0 )
+ * switches them off.  get_stats copies them to the host (waits for the stream).  Three phases x 8 counters:
+ *   out[0..7]   phase A (estimateLumaLn up to the above/left tests): [0] integer candidates scored one by one, [1] their bytes (4 w h each), [2] fractional candidates scored
+ *               one by one, [3] their bytes ((w + taps - 1)(h + taps - 1) 2 + 2 w h each; taps = 4 with the low-resolution search filter, 6 otherwise), [4] positions of the
+ *               dense integer grids (MCTF.cpp:1216-1228) scored out of one staged window, [5] those windows' bytes in SURVEY 8d's window form ((w + 2R)^2 2 + 2 w h per block
+ *               + 8 per position); the per-candidate figure of the grid positions is [4] x 4 w h with w = h = 32 (only full blocks take that path), [6] positions of the
+ *               refinement rings (:1229-1288) whose horizontal passes are shared, [7] those rings' bytes in window form (( w + 4 )( h + 4 ) 2 + 2 w h + 8 per position: the
+ *               positions of a ring lie within half a sample of its centre); per-candidate figure [6] x ((w + 3)(h + 3) 2 + 2 w h)
+ *   out[8..15]  the above/left candidates scored in parallel at the neighbours' phase-A vectors, out[16..23] those scored while the recurrence is resolved.             */
 VVHIP_API int vvhip_mctf_set_stats( vvhip_ctx* ctx, int on );
 /* Per-class device time of the LAST motion-estimation call of the context (measurement; HIP events on the context's stream around every launch while on):
  * ms5 = { candidate scoring (meSearchKernel, all levels), neighbour scoring, sweep, final normalisation, everything else (pyramids, field initialisation) }.   */
 VVHIP_API int vvhip_mctf_set_timing( vvhip_ctx* ctx, int on );
 VVHIP_API int vvhip_mctf_last_times( vvhip_ctx* ctx, float* ms5 );
-VVHIP_API int vvhip_mctf_get_stats( vvhip_ctx* ctx, uint64_t* out18 );
+VVHIP_API int vvhip_mctf_get_stats( vvhip_ctx* ctx, uint64_t* out24 );
 
 /* ======================================================================================================================
  * SURVEY 8f rank 2 — MCTF apply side: motion-compensated bilateral temporal filter of one component plane

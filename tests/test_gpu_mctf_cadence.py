@@ -74,20 +74,22 @@ def test_scored_candidate_counters_against_the_references_schedule(hip, oracle, 
     assert all(np.array_equal(a[f], b[f]) for f in ("x", "y", "error", "rmsme", "overlap"))
     exp, ref_calls = oracle.mctf_me_counted(org, ref, 10, 16, 4, add)
     assert all(np.array_equal(a[f], exp[4][f]) for f in ("x", "y", "error"))
-    tot = {k: sum(st1[p][k] for p in st1) for k in ("int", "int_bytes", "frac", "frac_bytes", "grid", "grid_window_bytes")}
+    tot = {k: sum(st1[p][k] for p in st1) for k in ("int", "int_bytes", "frac", "frac_bytes", "grid", "grid_window_bytes", "ring", "ring_window_bytes")}
     for ph in st1.values():
         assert (ph["int"] == 0) == (ph["int_bytes"] == 0) and (ph["frac"] == 0) == (ph["frac_bytes"] == 0) and (ph["grid"] == 0) == (ph["grid_window_bytes"] == 0)
         # a dense grid's window form is never more than its positions at 4 w h each, and at least a window of range 3 + the block per 81 positions
         assert ph["grid_window_bytes"] <= ph["grid"] * 4 * 32 * 32 and ph["grid_window_bytes"] * 81 >= ph["grid"] * ((32 + 6) ** 2 * 2 + 2048)
         assert ph["int_bytes"] <= ph["int"] * 4 * 32 * 32 and ph["frac_bytes"] <= ph["frac"] * ((32 + 3) * (32 + 3) * 2 + 2 * 32 * 32)
         assert ph["int_bytes"] >= ph["int"] * 4 * 8 * 8 and ph["frac_bytes"] >= ph["frac"] * ((8 + 3) * (8 + 3) * 2 + 2 * 8 * 8)
-    assert st1["search"]["int"] > 0 and st1["search"]["frac"] > 0
-    n_dev, n_ref = tot["int"] + tot["frac"] + tot["grid"], ref_calls["int"] + ref_calls["frac"]
+    assert st1["search"]["int"] > 0 and st1["search"]["ring"] > 0
+    # a ring's window form is below its positions at the per-candidate figure (8 positions share the window) and above one window per 8 positions
+    ring_pc = tot["ring"] * ((16 + 3) * (16 + 3) * 2 + 2 * 16 * 16)
+    assert tot["ring_window_bytes"] < ring_pc and tot["ring_window_bytes"] * 8 >= tot["ring"] * ((8 + 4) * (8 + 4) * 2 + 2 * 8 * 8)
+    n_dev, n_ref = tot["int"] + tot["frac"] + tot["grid"] + tot["ring"], ref_calls["int"] + ref_calls["frac"]
     assert n_dev <= n_ref, (tot, ref_calls)
     assert n_dev >= 0.75 * n_ref, (tot, ref_calls)
-    assert tot["int"] + tot["grid"] <= ref_calls["int"] and tot["frac"] <= ref_calls["frac"]
-    assert tot["int_bytes"] + tot["grid"] * 4 * 32 * 32 + tot["frac_bytes"] <= ref_calls["int_bytes"] + ref_calls["frac_bytes"]      # the per-candidate figure
-    assert tot["int_bytes"] + tot["grid_window_bytes"] + tot["frac_bytes"] < ref_calls["int_bytes"] + ref_calls["frac_bytes"]        # the window form (what the rows use)
+    assert tot["int_bytes"] + tot["grid"] * 4 * 32 * 32 + tot["frac_bytes"] + tot["ring"] * ((8 + 3) * (8 + 3) * 2 + 2 * 8 * 8) <= ref_calls["int_bytes"] + ref_calls["frac_bytes"]   # >= per candidate
+    assert tot["int_bytes"] + tot["grid_window_bytes"] + tot["frac_bytes"] + tot["ring_window_bytes"] < ref_calls["int_bytes"] + ref_calls["frac_bytes"]      # the window form (what the rows use)
     with pytest.raises(Exception):
         hp.mctf_get_stats()                                             # off: asking for them is an error, not zeros
 

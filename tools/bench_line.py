@@ -25,11 +25,11 @@ def _r(v, n=4):
 ROOF_KEYS = ("bound", "kernel", "avg_launch_ms", "launches_per_picture", "alg_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "frac_physical", "unique_bytes_per_launch", "frac_unique",
              "traffic_over_unique", "l2_hit_rate", "l1_access_frac", "valu_issue_frac", "binding_resource", "binding_frac")
 ROOF_4K_KEYS = ("kernel", "avg_launch_ms", "alg_bytes_per_launch", "achieved", "frac", "traffic", "frac_physical", "frac_unique", "l2_hit_rate", "binding_resource", "binding_frac")
-CLASS_KEYS = ("avg_launch_us", "alg_frac", "unique_frac", "fabric_frac", "traffic_over_unique", "l2_hit_rate", "l1_access_frac", "valu_issue_frac")
+CLASS_KEYS = ("avg_launch_us", "alg_frac", "fabric_frac", "l2_hit_rate", "l1_access_frac", "valu_issue_frac")          # (unique / traffic-over-unique: detail file, profiles/)
 CLASS_KEYS_MCTF = ("avg_launch_us", "alg_frac", "fabric_frac", "l1_access_frac", "valu_issue_frac")          # (the MCTF rows: the full set is in the detail file and in profiles/)
 CLASS_KEYS_MCTF_4K = ("avg_launch_us", "alg_frac", "valu_issue_frac")
 CLASS_KEYS_4K = ("avg_launch_us", "alg_frac", "fabric_frac", "l2_hit_rate", "l1_access_frac", "valu_issue_frac")
-E2E_KEYS = ("threads", "pairs", "cpu_fps", "hip_fps", "speedup", "cpu_fps_best", "hip_fps_best", "speedup_best", "bitstreams_identical", "md5_set")
+E2E_KEYS = ("threads", "pairs", "cpu_fps", "hip_fps", "speedup", "cpu_fps_best", "hip_fps_best", "speedup_best", "bitstreams_identical")
 
 
 def _roof(r, keys, checks=None):
@@ -76,7 +76,7 @@ def compact(out, detail_path):
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "passes", "value_fastest_passes", "value_slowest_passes", "value_1thread", "loadavg_before_after"))
-        line["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:420]
+        line["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:240]
         if isinstance(cb.get("mctf"), dict):
             line["cpu_baseline"]["mctf"] = _pick(cb["mctf"], ("value", "value_1thread", "unit", "cores", "kind", "error", "skipped"))
     if "parity" in out:

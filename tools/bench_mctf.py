@@ -180,17 +180,19 @@ class MctfCadence:
         torch.cuda.synchronize()
         self.stats = per_job
         cyc = {"MCTF_search": 0, "MCTF_nb": 0, "MCTF_fix": 0, "MCTF_apply": 0}
-        cand = {"int": 0, "frac": 0, "grid_positions": 0}
+        cand = {"int": 0, "frac": 0, "grid_positions": 0, "ring_positions": 0}
         per_cand = 0
         for job in JOBS:
             st = per_job[job[1]]
             for cls, ph in (("MCTF_search", "search"), ("MCTF_nb", "neighbour"), ("MCTF_fix", "sweep")):
-                # one-by-one candidates at 4 w h / (w + 3)(h + 3) 2 + 2 w h each; the dense integer grids in its WINDOW form (window + block read once + 8 B per position)
-                cyc[cls] += st[ph]["int_bytes"] + st[ph]["frac_bytes"] + st[ph]["grid_window_bytes"]
-                per_cand += st[ph]["int_bytes"] + st[ph]["frac_bytes"] + st[ph]["grid"] * 4 * 32 * 32
+                # one-by-one candidates at 4 w h / (w + 3)(h + 3) 2 + 2 w h each; the dense integer grids AND the refinement rings (positions within half a sample of
+                # their centre, horizontal passes shared) in its WINDOW form (window + block read once + 8 B per position)
+                cyc[cls] += st[ph]["int_bytes"] + st[ph]["frac_bytes"] + st[ph]["grid_window_bytes"] + st[ph]["ring_window_bytes"]
+                per_cand += st[ph]["int_bytes"] + st[ph]["frac_bytes"] + st[ph]["grid"] * 4 * 32 * 32 + st[ph]["ring"] * ((UNIT + 3) * (UNIT + 3) * 2 + 2 * UNIT * UNIT)
                 cand["int"] += st[ph]["int"]
                 cand["frac"] += st[ph]["frac"]
                 cand["grid_positions"] += st[ph]["grid"]
+                cand["ring_positions"] += st[ph]["ring"]
             cyc["MCTF_apply"] += apply_alg_bytes(self.width, self.height, len(job[2]))
         self.alg_bytes_per_cycle = cyc
         self.per_candidate_bytes_per_cycle = per_cand          # every scored position at its own 4 w h: a work rate (LDS-level reuse), not memory traffic

@@ -231,7 +231,7 @@ __device__ __forceinline__ int errInt32( const Org32& O, const int16_t* c, int c
 // scored candidates, counted the way SURVEY 8d prices them: a vector with both phases zero is an integer candidate (4 w h bytes), any other a fractional one
 // ((w + taps - 1)(h + taps - 1) 2 + 2 w h bytes).  Only the STATS instances count (vvhip_mctf_set_stats); everywhere else the macro is empty.
 #define ME_COUNT( DX, DY )
-struct MeCount { int nInt, nFrac, nGrid, gridBytes; };      // nGrid: positions of a dense integer grid scored out of one staged window; gridBytes: that window + the block, read once
+struct MeCount { int nInt, nFrac, nGrid, gridBytes, nRing, ringBytes; };      // nGrid: positions of a dense integer grid scored out of one staged window, gridBytes: that window + the block, read once; nRing / ringBytes: the same for the positions of a refinement ring
 
 // One refinement ring of estimateLumaLn's final level (MCTF.cpp:1229-1288): the 8 positions (cx + x2, cy + y2), x2, y2 in {-a, 0, a} without the centre, tested in the
 // reference's order (y2 outer, x2 inner) with its strict-< update.  The three x positions share their horizontal passes: one pass per x position over the rows any of its
@@ -275,11 +275,14 @@ __device__ __forceinline__ void meRing3( const MeGeom& g, int bx, int by, int cx
       if( v == 1 && y2 == 0 ) continue;
       const int X = cx + ( v - 1 ) * a;
       if( X == bestX && Y == bestY ) continue;
-      if( STATS ) { if( ( ( X | Y ) & 15 ) == 0 ) cnt.nInt++; else cnt.nFrac++; }
+      if( STATS ) cnt.nRing++;
       const int e_ = waveSum( verError4( o, g.orgStride, sTmp + v * region + ro * w, w, h, Y & 15, g.maxVal, lane ) );
       if( e_ < bestE ) { bestX = X; bestY = Y; bestE = e_; }
     }
   }
+  // (SURVEY 8d's window form carried to a ring: its positions lie within half a sample of the centre — the ( w + 3 + 1 ) x ( h + 3 + 1 ) samples their 4-tap supports cover are
+  //  read once (three horizontal passes over them), the block once, 8 bytes per position; the per-candidate figure is positions x ( ( w + 3 )( h + 3 ) 2 + 2 w h ))
+  if( STATS ) cnt.ringBytes += ( w + 4 ) * ( h + 4 ) * 2 + 2 * w * h + 64;
   ME_WAVE_SYNC();                                // sTmp is reused by the next ring / candidate
 }
 
@@ -323,6 +326,7 @@ __device__ __forceinline__ void meCountFlush( unsigned long long* st, const MeCo
   if( cnt.nInt )  { atomicAdd( st + 0, ( unsigned long long ) cnt.nInt );  atomicAdd( st + 1, ( unsigned long long ) cnt.nInt * ( unsigned long long ) ( 4 * w * h ) ); }
   if( cnt.nFrac ) { atomicAdd( st + 2, ( unsigned long long ) cnt.nFrac ); atomicAdd( st + 3, ( unsigned long long ) cnt.nFrac * ( unsigned long long ) ( ( w + t ) * ( h + t ) * 2 + 2 * w * h ) ); }
   if( cnt.nGrid ) { atomicAdd( st + 4, ( unsigned long long ) cnt.nGrid ); atomicAdd( st + 5, ( unsigned long long ) cnt.gridBytes ); }
+  if( cnt.nRing ) { atomicAdd( st + 6, ( unsigned long long ) cnt.nRing ); atomicAdd( st + 7, ( unsigned long long ) cnt.ringBytes ); }
 }
 
 // ---- the final level's full 16 x 16 blocks with the 4-tap search filter and search pattern 2 (MCTFSpeed >= 3: what presets faster .. medium run), round 6 --------------
@@ -388,10 +392,7 @@ __device__ __forceinline__ void meRing16( const MeGeom& g, int bx, int by, const
     L0 = L1; H0 = H1; L1 = L2; H1 = H2; r2 = r3;
   }
   const uint32_t key = waveMinOfGroups8( ( groupSum8( ( uint32_t ) e ) << 3 ) | ( uint32_t ) c );
-  if( STATS )
-#pragma unroll
-    for( int k = 0; k < 9; k++ )
-      if( k != 4 ) { if( ( ( ( cx + ( k % 3 - 1 ) * a ) | ( cy + ( k / 3 - 1 ) * a ) ) & 15 ) == 0 ) cnt.nInt++; else cnt.nFrac++; }
+  if( STATS ) { cnt.nRing += 8; cnt.ringBytes += ( 16 + 4 ) * ( 16 + 4 ) * 2 + 2 * 16 * 16 + 64; }      // (the ring in SURVEY 8d's window form, see meRing3)
   const int eMin = ( int ) ( key >> 3 );
   if( eMin < bestE )
   {
@@ -454,7 +455,7 @@ template<bool STATS>
 __global__ void __launch_bounds__( 64 )
 meSearchKernel( MeGeom g, const MeRefs R, int nbx, int prevW, int prevH, int factor, int doubleRes, int searchPttrn, int mvsW, unsigned long long* stats, int fixBlocks )
 {
-  MeCount cnt = { 0, 0, 0, 0 };
+  MeCount cnt = { 0, 0, 0, 0, 0, 0 };
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[48 * 52];      // the integer-grid window of a 32 x 32 block with range 8 (48 rows, pitch 50); > ( 32 + 5 ) * 32 of the sub-pel passes
   const int lane = threadIdx.x;
   g.buf = R.buf[blockIdx.y];
@@ -815,7 +816,7 @@ struct NbRec { int eU, eL, upX, upY, leftX, leftY; };      // e < 0: not scored 
 __global__ void __launch_bounds__( 64 )
 meNeighbourKernel( MeGeom g, const MeRefs R, int nbx, int mvsW, unsigned long long* stats, int fix, int nBlocks )
 {
-  MeCount cnt = { 0, 0, 0, 0 };
+  MeCount cnt = { 0, 0, 0, 0, 0, 0 };
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmp[( 32 + 5 ) * 32];
   const int lane = threadIdx.x;
   g.buf = R.buf[blockIdx.y];
@@ -904,7 +905,7 @@ meFixKernel( MeGeom g, const MeRefs R, int nbx, int nby, int mvsW, unsigned long
         if( e1 < 0 )
         {
           e1 = meErrorCall( &sG, bx_ * bs, by_ * bs, upX, upY, sTmp, lane );
-          if( stats ) { MeCount c1 = { 0, 0, 0, 0 }; c1.nInt = ( ( upX | upY ) & 15 ) == 0; c1.nFrac = !c1.nInt; meCountFlush( stats, c1, sG, bx_ * bs, by_ * bs, lane ); }
+          if( stats ) { MeCount c1 = { 0, 0, 0, 0, 0, 0 }; c1.nInt = ( ( upX | upY ) & 15 ) == 0; c1.nFrac = !c1.nInt; meCountFlush( stats, c1, sG, bx_ * bs, by_ * bs, lane ); }
         }
         if( e1 < best.e ) { best.x = upX; best.y = upY; best.e = e1; }
       }
@@ -919,7 +920,7 @@ meFixKernel( MeGeom g, const MeRefs R, int nbx, int nby, int mvsW, unsigned long
         if( e2 < 0 )
         {
           e2 = meErrorCall( &sG, bx_ * bs, by_ * bs, lfX, lfY, sTmp, lane );
-          if( stats ) { MeCount c1 = { 0, 0, 0, 0 }; c1.nInt = ( ( lfX | lfY ) & 15 ) == 0; c1.nFrac = !c1.nInt; meCountFlush( stats, c1, sG, bx_ * bs, by_ * bs, lane ); }
+          if( stats ) { MeCount c1 = { 0, 0, 0, 0, 0, 0 }; c1.nInt = ( ( lfX | lfY ) & 15 ) == 0; c1.nFrac = !c1.nInt; meCountFlush( stats, c1, sG, bx_ * bs, by_ * bs, lane ); }
         }
         if( e2 < best.e ) { best.x = lfX; best.y = lfY; best.e = e2; }
       }
@@ -1047,7 +1048,7 @@ meDiagKernel( MeGeom g, const MeRefs R, int nbx, int nby, int mvsW, unsigned lon
         const int l = __ffsll( ( long long ) m ) - 1;
         const int lx = __shfl( x, l ), ly = __shfl( y, l ), lvx = __shfl( vx, l ), lvy = __shfl( vy, l );
         const int v = meErrorCall( &sG, lx * bs, ly * bs, lvx, lvy, sTmp, lane );
-        if( stats ) { MeCount c1 = { 0, 0, 0, 0 }; c1.nInt = ( ( lvx | lvy ) & 15 ) == 0; c1.nFrac = !c1.nInt; meCountFlush( stats, c1, sG, lx * bs, ly * bs, lane ); }
+        if( stats ) { MeCount c1 = { 0, 0, 0, 0, 0, 0 }; c1.nInt = ( ( lvx | lvy ) & 15 ) == 0; c1.nFrac = !c1.nInt; meCountFlush( stats, c1, sG, lx * bs, ly * bs, lane ); }
         if( lane == l ) e = v;
         m &= m - 1;
       } };
@@ -1262,7 +1263,7 @@ int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, i
   MeGeom g; g.org = d_org; g.orgStride = os; g.buf = nullptr; g.bufStride = bsd; g.width = width; g.height = height; g.bs = bs;
   g.lowRes = lowRes; g.maxVal = ( 1 << bitDepth ) - 1;
   meMark( ctx, 1 );
-  unsigned long long* st = ctx->d_mctfStats;      // (null unless vvhip_mctf_set_stats switched the counters on: 3 phases x 6 counters, include/vvenc_hip.h)
+  unsigned long long* st = ctx->d_mctfStats;      // (null unless vvhip_mctf_set_stats switched the counters on: 3 phases x 8 counters, include/vvenc_hip.h)
   // phase B: $VVHIP_MCTF_DIAG = 2 (default) the fixed-point form (any field size), 1 the anti-diagonal sweep (fields up to 320 blocks on the shorter side), 0 the row hand-off
   static const int useDiag = []{ const char* e = getenv( "VVHIP_MCTF_DIAG" ); return e ? atoi( e ) : 2; }();
   const int fixBlocks = useDiag >= 2 ? nbx * nby : 0;
@@ -1282,20 +1283,20 @@ int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, i
   if( fixBlocks )
   {
     // (the granule area holds, per reference: one FixRec per block, three block lists, the stamps and the counts: 52 bytes per block + 16 <= 7 granules per block)
-    hipLaunchKernelGGL( meNeighbourKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, st ? st + 6 : nullptr, 1, fixBlocks );
+    hipLaunchKernelGGL( meNeighbourKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, st ? st + 8 : nullptr, 1, fixBlocks );
     meMark( ctx, 3 );
-    hipLaunchKernelGGL( meFixKernel, dim3( nRefs ), dim3( ME_FIX_THREADS ), 0, ctx->stream, g, R, nbx, nby, mvsW, st ? st + 12 : nullptr );
+    hipLaunchKernelGGL( meFixKernel, dim3( nRefs ), dim3( ME_FIX_THREADS ), 0, ctx->stream, g, R, nbx, nby, mvsW, st ? st + 16 : nullptr );
     VVHIP_LAUNCH_CHECK( ctx );
   }
   else if( useDiag && diagLen <= ME_DIAG_MAX_THREADS && nbx <= ME_DIAG_MAX_COLS )
   {
     // (the granule area holds the neighbour records here: 3 granules = one NbRec per block)
-    hipLaunchKernelGGL( meNeighbourKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, st ? st + 6 : nullptr, 0, 0 );
+    hipLaunchKernelGGL( meNeighbourKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, st ? st + 8 : nullptr, 0, 0 );
     meMark( ctx, 3 );
 #ifdef VVHIP_DEV_KNOBS      // (development aid, changes the results: the final level without its above / left tests = the phase-A vectors, for the analysis of the sweep's chains)
     if( !( doubleRes && getenv( "VVHIP_MCTF_NO_SWEEP" ) ) )
 #endif
-    hipLaunchKernelGGL( meDiagKernel, dim3( nRefs ), dim3( ( ( diagLen + 63 ) / 64 ) * 64 ), 0, ctx->stream, g, R, nbx, nby, mvsW, st ? st + 12 : nullptr );
+    hipLaunchKernelGGL( meDiagKernel, dim3( nRefs ), dim3( ( ( diagLen + 63 ) / 64 ) * 64 ), 0, ctx->stream, g, R, nbx, nby, mvsW, st ? st + 16 : nullptr );
     VVHIP_LAUNCH_CHECK( ctx );
   }
   else
@@ -1402,8 +1403,8 @@ int vvhip_mctf_me_level( vvhip_ctx* ctx, const int16_t* d_org, int org_stride, c
 int vvhip_mctf_set_stats( vvhip_ctx* ctx, int on )
 {
   if( !ctx ) return VVHIP_E_ARG;
-  if( on && !ctx->d_mctfStats ) VVHIP_CHECK_HIP( ctx, hipMalloc( reinterpret_cast<void**>( &ctx->d_mctfStats ), 18 * sizeof( unsigned long long ) ) );
-  if( on ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( ctx->d_mctfStats, 0, 18 * sizeof( unsigned long long ), ctx->stream ) );
+  if( on && !ctx->d_mctfStats ) VVHIP_CHECK_HIP( ctx, hipMalloc( reinterpret_cast<void**>( &ctx->d_mctfStats ), 24 * sizeof( unsigned long long ) ) );
+  if( on ) VVHIP_CHECK_HIP( ctx, hipMemsetAsync( ctx->d_mctfStats, 0, 24 * sizeof( unsigned long long ), ctx->stream ) );
   if( !on && ctx->d_mctfStats ) { VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) ); ( void ) hipFree( ctx->d_mctfStats ); ctx->d_mctfStats = nullptr; }
   return VVHIP_OK;
 }
@@ -1430,11 +1431,11 @@ int vvhip_mctf_last_times( vvhip_ctx* ctx, float* ms5 )
   return VVHIP_OK;
 }
 
-int vvhip_mctf_get_stats( vvhip_ctx* ctx, uint64_t* out18 )
+int vvhip_mctf_get_stats( vvhip_ctx* ctx, uint64_t* out24 )
 {
-  if( !ctx || !out18 ) return VVHIP_E_ARG;
+  if( !ctx || !out24 ) return VVHIP_E_ARG;
   if( !ctx->d_mctfStats ) return vvhip_fail( ctx, VVHIP_E_ARG, "vvhip_mctf_get_stats: the counters are off (vvhip_mctf_set_stats)" );
-  VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( out18, ctx->d_mctfStats, 18 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, ctx->stream ) );
+  VVHIP_CHECK_HIP( ctx, hipMemcpyAsync( out24, ctx->d_mctfStats, 24 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, ctx->stream ) );
   VVHIP_CHECK_HIP( ctx, vvhip_wait_stream( ctx ) );
   return VVHIP_OK;
 }

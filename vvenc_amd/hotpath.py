@@ -600,11 +600,12 @@ class HotPath:
         return tuple(float(x) for x in a)
 
     def mctf_get_stats(self):
-        """scored candidates of the MCTF search since mctf_set_stats(True): {phase: {int, int_bytes, frac, frac_bytes, grid, grid_window_bytes}} (include/vvenc_hip.h)"""
-        a = np.zeros(18, np.uint64)
+        """scored candidates of the MCTF search since mctf_set_stats(True): {phase: {int, int_bytes, frac, frac_bytes, grid, grid_window_bytes, ring, ring_window_bytes}}
+        (include/vvenc_hip.h)"""
+        a = np.zeros(24, np.uint64)
         self._ck(self.L.vvhip_mctf_get_stats(self.ctx, a.ctypes.data_as(C.c_void_p)))
-        return {ph: {"int": int(a[6 * i]), "int_bytes": int(a[6 * i + 1]), "frac": int(a[6 * i + 2]), "frac_bytes": int(a[6 * i + 3]), "grid": int(a[6 * i + 4]),
-                     "grid_window_bytes": int(a[6 * i + 5])} for i, ph in enumerate(("search", "neighbour", "sweep"))}
+        keys = ("int", "int_bytes", "frac", "frac_bytes", "grid", "grid_window_bytes", "ring", "ring_window_bytes")
+        return {ph: {k: int(a[8 * i + j]) for j, k in enumerate(keys)} for i, ph in enumerate(("search", "neighbour", "sweep"))}
 
     @staticmethod
     def mv_to_numpy(t, dims):
