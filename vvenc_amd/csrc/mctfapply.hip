@@ -16,7 +16,7 @@
 
 namespace {
 
-__constant__ int16_t cApply6[16][8] = {      // MCTF::m_interpolationFilter8 (MCTF.cpp:72-90), taps 1..6 are used
+__constant__ __attribute__( ( aligned( 16 ) ) ) int16_t cApply6[16][8] = {      // MCTF::m_interpolationFilter8 (MCTF.cpp:72-90), taps 1..6 are used
   { 0, 0, 0, 64, 0, 0, 0, 0 },    { 0, 1, -3, 64, 4, -2, 0, 0 },    { 0, 1, -6, 62, 9, -3, 1, 0 },    { 0, 2, -8, 60, 14, -5, 1, 0 },
   { 0, 2, -9, 57, 19, -7, 2, 0 }, { 0, 3, -10, 53, 24, -8, 2, 0 },  { 0, 3, -11, 50, 29, -9, 2, 0 },  { 0, 3, -11, 44, 35, -10, 3, 0 },
   { 0, 1, -7, 38, 38, -7, 1, 0 }, { 0, 3, -10, 35, 44, -11, 3, 0 }, { 0, 2, -9, 29, 50, -11, 3, 0 },  { 0, 2, -8, 24, 53, -10, 3, 0 },
@@ -166,6 +166,102 @@ __device__ __forceinline__ void applyRefFull( const int16_t* __restrict__ src, i
   WAVE_SYNC();                                           // sT is reused by the wave's next reference
 }
 
+// FOUR references of a full 8 x 8 block (the chroma planes at unit 16) in one pass of the wave: lane = 16 ref + 4 rg + xp — an 8 x 8 block is sixteen 2 x 2 patches, so one
+// reference leaves three quarters of a wave idle and repeats the per-reference scalar work (plane fit with its two 64-bit divisions, noise estimate in double) per pass; with
+// the references side by side that work runs once per lane group.  Same integers as applyRefFull<8> per reference.  Per-reference inputs (plane pointer, vector, rmsme) come
+// from LDS (filled with uniform indices by the caller: kernel arguments are not indexed per lane).  sT: 4 x ( 13 x 8 ) intermediates; corrBase + ref * corrPitch: results.
+struct ApplyRef8 { const int16_t* src; int dxF, dyF; unsigned rmsme; int planar; };
+__device__ __forceinline__ void applyRefs8( const ApplyRef8* __restrict__ sRef, int nRef, int refStride, const int16_t* __restrict__ orgBlk, int orgStride, int maxv, int bitDepth,
+                                            int16_t* __restrict__ sT, int16_t* __restrict__ corrBase, int corrPitch, int* __restrict__ sNoise, int lane )
+{
+  constexpr int B = 8, HP = 4, ROWS = B + 5, ITEMS = ROWS * HP;      // 52 sample pairs of the intermediate per reference
+  for( int e = lane; e < nRef * ITEMS; e += 64 )
+  {
+    const int ref = e / ITEMS, within = e - ref * ITEMS, rr = within >> 2, xp = within & 3;
+    const ApplyRef8 R = sRef[ref];
+    const au32x4 tp = *reinterpret_cast<const au32x4*>( cApply6[R.dxF] );                      // taps 0..7 as pairs; wanted: (1,2) (3,4) (5,6)
+    const uint32_t t12 = __builtin_amdgcn_alignbit( tp.y, tp.x, 16 ), t34 = __builtin_amdgcn_alignbit( tp.z, tp.y, 16 ), t56 = __builtin_amdgcn_alignbit( tp.w, tp.z, 16 );
+    const au32x4 d = ald16( R.src + ( ptrdiff_t ) ( rr - 2 ) * refStride + 2 * xp - 2 );
+    const int o0 = adot2( d.x, t12, adot2( d.y, t34, adot2( d.z, t56, 32 ) ) );
+    const int o1 = adot2( __builtin_amdgcn_alignbit( d.y, d.x, 16 ), t12, adot2( __builtin_amdgcn_alignbit( d.z, d.y, 16 ), t34, adot2( __builtin_amdgcn_alignbit( d.w, d.z, 16 ), t56, 32 ) ) );
+    *reinterpret_cast<uint32_t*>( sT + ref * ( ROWS * B ) + rr * B + 2 * xp ) = apk( o0 >> 6, o1 >> 6 );
+  }
+  WAVE_SYNC();
+  const int ref = lane >> 4, xp = lane & 3, rg = ( lane >> 2 ) & 3, x = 2 * xp, y = 2 * rg;
+  const bool act = ref < nRef;
+  const ApplyRef8 R = sRef[act ? ref : 0];
+  int c00, c01, c10, c11;
+  {
+    const au32x4 tp = *reinterpret_cast<const au32x4*>( cApply6[R.dyF] );
+    const uint32_t u12 = __builtin_amdgcn_alignbit( tp.y, tp.x, 16 ), u34 = __builtin_amdgcn_alignbit( tp.z, tp.y, 16 ), u56 = __builtin_amdgcn_alignbit( tp.w, tp.z, 16 );
+    const uint32_t* q = reinterpret_cast<const uint32_t*>( sT + ( act ? ref : 0 ) * ( ROWS * B ) + y * B + x );
+    uint32_t Rw[7];
+#pragma unroll
+    for( int k = 0; k < 7; k++ ) Rw[k] = q[k * HP];
+#define ALO( A, Bv ) __builtin_amdgcn_perm( Bv, A, 0x05040100u )
+#define AHI( A, Bv ) __builtin_amdgcn_perm( Bv, A, 0x07060302u )
+    c00 = aclip( adot2( ALO( Rw[0], Rw[1] ), u12, adot2( ALO( Rw[2], Rw[3] ), u34, adot2( ALO( Rw[4], Rw[5] ), u56, 32 ) ) ) >> 6, maxv );
+    c01 = aclip( adot2( AHI( Rw[0], Rw[1] ), u12, adot2( AHI( Rw[2], Rw[3] ), u34, adot2( AHI( Rw[4], Rw[5] ), u56, 32 ) ) ) >> 6, maxv );
+    c10 = aclip( adot2( ALO( Rw[1], Rw[2] ), u12, adot2( ALO( Rw[3], Rw[4] ), u34, adot2( ALO( Rw[5], Rw[6] ), u56, 32 ) ) ) >> 6, maxv );
+    c11 = aclip( adot2( AHI( Rw[1], Rw[2] ), u12, adot2( AHI( Rw[3], Rw[4] ), u34, adot2( AHI( Rw[5], Rw[6] ), u56, 32 ) ) ) >> 6, maxv );
+#undef ALO
+#undef AHI
+  }
+  const uint32_t og0 = ald4( orgBlk + ( ptrdiff_t ) y * orgStride + x ), og1 = ald4( orgBlk + ( ptrdiff_t ) ( y + 1 ) * orgStride + x );
+  const int o00 = alo( og0 ), o01 = ahi( og0 ), o10 = alo( og1 ), o11 = ahi( og1 );
+  if( __builtin_amdgcn_ballot_w64( act && R.planar ) )      // MCTF.cpp:372-421 for the groups whose reference wants it (the others end with b0 = b1 = b2 = 0: unchanged)
+  {
+    const int z00 = c00 - o00, z01 = c01 - o01, z10 = c10 - o10, z11 = c11 - o11;
+    const int x1yzm = ( int ) vvhipGroupSum32( ( uint32_t ) ( x * ( z00 + z10 ) + ( x + 1 ) * ( z01 + z11 ) ), 16, lane );
+    const int x2yzm = ( int ) vvhipGroupSum32( ( uint32_t ) ( y * ( z00 + z01 ) + ( y + 1 ) * ( z10 + z11 ) ), 16, lane );
+    const int ySum  = ( int ) vvhipGroupSum32( ( uint32_t ) ( z00 + z01 + z10 + z11 ), 16, lane );
+    constexpr int blockSize = B * B, log2Width = 3, xSum = ( blockSize * ( B - 1 ) ) >> 1;
+    const unsigned me2 = R.rmsme * R.rmsme;
+    const int mWeight = ( int ) ( me2 < 512u ? me2 : 512u );
+    const long long denom = ( long long ) blockSize * 336;                                        // xSzm[3]
+    int b1 = planarDiv( ( long long ) mWeight * ( ( long long ) x1yzm * blockSize - xSum * ySum ), denom );
+    b1 = b1 < -32768 ? -32768 : ( b1 > 32767 ? 32767 : b1 );
+    int b2 = planarDiv( ( long long ) mWeight * ( ( long long ) x2yzm * blockSize - xSum * ySum ), denom );
+    b2 = b2 > 32767 ? 32767 : ( b2 < -32768 ? -32768 : b2 );
+    const int b0 = ( mWeight * ySum - ( b1 + b2 ) * xSum + ( blockSize >> 1 ) ) >> ( log2Width << 1 );
+    if( act && R.planar && ( b0 != 0 || b1 != 0 || b2 != 0 ) )
+    {
+      const int p00 = b0 + b1 * x + b2 * y + 256;
+      c00 = aclip( c00 - ( p00 >> 9 ), maxv );
+      c01 = aclip( c01 - ( ( p00 + b1 ) >> 9 ), maxv );
+      c10 = aclip( c10 - ( ( p00 + b2 ) >> 9 ), maxv );
+      c11 = aclip( c11 - ( ( p00 + b1 + b2 ) >> 9 ), maxv );
+    }
+  }
+  if( act )
+  {
+    int16_t* corr = corrBase + ref * corrPitch;
+    *reinterpret_cast<uint32_t*>( corr + y * B + x ) = apk( c00, c01 );
+    *reinterpret_cast<uint32_t*>( corr + ( y + 1 ) * B + x ) = apk( c10, c11 );
+  }
+  const int d00 = o00 - c00, d01 = o01 - c01, d10 = o10 - c10, d11 = o11 - c11;
+  const uint32_t P0 = apk( d00, d01 ), P1 = apk( d10, d11 );
+  const uint32_t nr0 = ( uint32_t ) __shfl_down( ( int ) P0, 1 ), nr1 = ( uint32_t ) __shfl_down( ( int ) P1, 1 ), nd = ( uint32_t ) __shfl_down( ( int ) P0, HP );
+  uint32_t var = 0, ds = 0;
+  if( act )
+  {
+    var = ( uint32_t ) ( d00 * d00 + d01 * d01 + d10 * d10 + d11 * d11 );
+    int t;
+    t = d01 - d00; ds += ( uint32_t ) ( t * t );  t = d11 - d10; ds += ( uint32_t ) ( t * t );
+    t = d10 - d00; ds += ( uint32_t ) ( t * t );  t = d11 - d01; ds += ( uint32_t ) ( t * t );
+    if( xp != HP - 1 ) { t = alo( nr0 ) - d01; ds += ( uint32_t ) ( t * t ); t = alo( nr1 ) - d11; ds += ( uint32_t ) ( t * t ); }
+    if( rg != HP - 1 ) { t = alo( nd ) - d10; ds += ( uint32_t ) ( t * t ); t = ahi( nd ) - d11; ds += ( uint32_t ) ( t * t ); }
+  }
+  const uint32_t varSum = vvhipGroupSum32( var, 16, lane ), dsSum = vvhipGroupSum32( ds, 16, lane );
+  long long variance = ( long long ) varSum, diffsum = ( long long ) dsSum;
+  variance *= ( long long ) 1 << ( 2 * ( 10 - bitDepth ) );
+  diffsum  *= ( long long ) 1 << ( 2 * ( 10 - bitDepth ) );
+  constexpr int cntV = B * B, cntD = 2 * cntV - B - B;
+  const int noise = ( int ) round( ( 15.0 * cntD / cntV * variance + 5.0 ) / ( diffsum + 5.0 ) );
+  if( act && ( lane & 15 ) == 0 ) sNoise[ref] = noise;
+  WAVE_SYNC();
+}
+
 // One WAVEFRONT per filter block, four consecutive blocks of a block row per workgroup (round 6; was one workgroup per block with a wave per reference: an 8 x 8 chroma block
 // kept 256 threads, a barrier and the per-block scalar work — weights, plane fit, noise — busy for 64 samples, and a two-reference picture idled half the waves).  The wave
 // walks the references one after the other (wave-level synchronisation only, private LDS scratch, DPP reductions) and blends its block with all 64 lanes.
@@ -173,7 +269,8 @@ __global__ void __launch_bounds__( 256 )
 mctfApplyKernel( const int16_t* __restrict__ org, int orgStride, int refStride, int16_t* __restrict__ out, int outStride, ApplyArgs A )
 {
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sCorrAll[4][MAX_REFS][MAX_BLK * MAX_BLK / 4];     // blocks up to 16x16 (256 samples) per reference; see host check
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmpAll[4][( 16 + 7 ) * 16];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sTmpAll[4][4 * ( 8 + 5 ) * 8 + 16];      // ( 16 + 5 ) x 16 of a 16 x 16 block's reference, 4 x 13 x 8 of an 8 x 8 block's four
+  __shared__ ApplyRef8 sRef8All[4][4];
   __shared__ int sNoiseAll[4][MAX_REFS], sErrAll[4][MAX_REFS];
   __shared__ float sVwwAll[4][MAX_REFS], sVswAll[4][MAX_REFS];
 
@@ -189,7 +286,26 @@ mctfApplyKernel( const int16_t* __restrict__ org, int orgStride, int refStride, 
   int* sNoise = sNoiseAll[wave]; int* sErr = sErrAll[wave];
   float* sVww = sVwwAll[wave]; float* sVsw = sVswAll[wave];
 
-  for( int i = 0; i < A.numRefs; i++ )      // (a uniform index: the per-reference kernel arguments are scalar loads — indexed per lane they become 100+ vector registers of copies)
+  const bool refs8 = !A.lowRes && w == 8 && h == 8 && A.bitDepth <= 10 && !A.generic;      // full 8 x 8 blocks: four references per pass (applyRefs8)
+  if( refs8 )
+    for( int i0 = 0; i0 < A.numRefs; i0 += 4 )
+    {
+      const int nr = min( 4, A.numRefs - i0 );
+      for( int k = 0; k < nr; k++ )      // (uniform indices into the kernel arguments; lane 0 files the per-reference inputs)
+      {
+        const vvhip_mv mv = A.mvs[i0 + k][byI * A.mvW + bxI];
+        const int dx = mv.x >> A.cs, dy = mv.y >> A.cs, xInt = mv.x >> ( 4 + A.cs ), yInt = mv.y >> ( 4 + A.cs );
+        if( lane == 0 )
+        {
+          ApplyRef8 r; r.src = A.refs[i0 + k] + ( ptrdiff_t ) ( by + yInt ) * refStride + bx + xInt; r.dxF = dx & 15; r.dyF = dy & 15;
+          r.rmsme = ( unsigned ) ( uint16_t ) mv.rmsme; r.planar = mv.rmsme > 0 && A.qp <= 32;
+          sRef8All[wave][k] = r; sErr[i0 + k] = mv.error;
+        }
+      }
+      WAVE_SYNC();
+      applyRefs8( sRef8All[wave], nr, refStride, orgBlk, orgStride, maxv, A.bitDepth, sTmp, sCorr[i0], MAX_BLK * MAX_BLK / 4, sNoise + i0, lane );
+    }
+  for( int i = 0; i < ( refs8 ? 0 : A.numRefs ); i++ )      // (a uniform index: the per-reference kernel arguments are scalar loads — indexed per lane they become 100+ vector registers of copies)
   {
     const vvhip_mv mv = A.mvs[i][byI * A.mvW + bxI];
     const int dx = mv.x >> A.cs, dy = mv.y >> A.cs, xInt = mv.x >> ( 4 + A.cs ), yInt = mv.y >> ( 4 + A.cs );
