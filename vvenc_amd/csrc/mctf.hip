@@ -65,7 +65,8 @@ typedef short s16x2 __attribute__( ( ext_vector_type( 2 ) ) );
 __device__ __forceinline__ int sdot2( uint32_t a, uint32_t b, int c ) { return __builtin_amdgcn_sdot2( __builtin_bit_cast( s16x2, a ), __builtin_bit_cast( s16x2, b ), c, false ); }
 __device__ __forceinline__ uint32_t pk16( int lo, int hi ) { return ( uint32_t ) ( lo & 0xffff ) | ( ( uint32_t ) hi << 16 ); }
 __device__ __forceinline__ uint32_t pkSub16( uint32_t a, uint32_t b ) { return __builtin_bit_cast( uint32_t, __builtin_bit_cast( s16x2, a ) - __builtin_bit_cast( s16x2, b ) ); }
-__device__ __forceinline__ int clipPel( int v, int maxVal ) { return min( max( v, 0 ), maxVal ); }
+// clip to [0, maxVal] as ONE v_med3_i32 (with a run-time bound the compiler emits v_max + v_min: two of the ~13 instructions of a vertical filter step)
+__device__ __forceinline__ int clipPel( int v, int maxVal ) { int r; asm( "v_med3_i32 %0, %1, 0, %2" : "=v"( r ) : "v"( v ), "v"( maxVal ) ); return r; }
 
 // ---- error of one candidate, computed by a whole wavefront (all 64 lanes must call) -------------------------------------------
 // integer displacement: sum (org - buf)^2 over w x h, w,h multiples of 8 (MCTF.cpp:122-145)
