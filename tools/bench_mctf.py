@@ -152,6 +152,7 @@ class MctfCadence:
                 pad = self.planes[job[1]][0].pad
                 keep = slot[0][pad + 64:pad + 128, pad + 64:pad + 192].clone()
                 slot[0][pad + 64:pad + 128, pad + 64:pad + 192] = 1023 - keep          # "a wrong broadcast": part of the first reference inverted
+                torch.cuda.synchronize()                                                 # (written on the default stream, read on the lane's)
                 tmp = [torch.empty_like(f) for f in got]
                 self.issue_from_slot(job, slot, fields=tmp)
                 torch.cuda.synchronize()
