@@ -360,17 +360,34 @@ __device__ __forceinline__ uint32_t intKey16( const uint32_t ( &orgCol )[16], co
   const uint32_t sum = groupSum8( ( uint32_t ) e );
   return valid ? ( sum << 3 ) | ( uint32_t ) ( lane >> 3 ) : 0xffffffffu;
 }
+// the three horizontal passes of a ring in ONE loop, four outputs per item (a 16-byte request = the 7 samples four outputs need): 3 x nrows x 4 items for the wave instead of
+// three loops of nrows x 8 two-output items (cut builds, 1080p / 4 references: the horizontal passes were 46 of the final level's 124 us — instruction-bound: serving their
+// loads from a hot region changed nothing).  dst region v: nrows x 16 samples; X0..X2: the passes' horizontal positions (1/16 sample); src: row 0 of the regions, block column 0.
+__device__ __forceinline__ void horPass4x3( const int16_t* src, int bs, int nrows, int X0, int X1, int X2, int maxVal, int16_t* dst, int region, int lane )
+{
+  const int n4 = nrows * 4;
+  for( int e = lane; e < 3 * n4; e += 64 )
+  {
+    const int v = ( e >= n4 ) + ( e >= 2 * n4 ), within = e - v * n4, r = within >> 2, x = 4 * ( within & 3 );
+    const int X = v == 0 ? X0 : ( v == 1 ? X1 : X2 ), fx = X & 15;
+    const uint32_t c01 = pk16( kFilter4[fx][0], kFilter4[fx][1] ), c23 = pk16( kFilter4[fx][2], kFilter4[fx][3] );
+    const u32x4 d = ld16( src + ( X >> 4 ) + ( ptrdiff_t ) r * bs + x - 1 );                   // samples x - 1 .. x + 6
+    const uint32_t o0 = __builtin_amdgcn_alignbit( d.y, d.x, 16 ), o1 = __builtin_amdgcn_alignbit( d.z, d.y, 16 ), o2 = __builtin_amdgcn_alignbit( d.w, d.z, 16 );
+    const int t0 = clipPel( sdot2( d.x, c01, sdot2( d.y, c23, 32 ) ) >> 6, maxVal );
+    const int t1 = clipPel( sdot2( o0, c01, sdot2( o1, c23, 32 ) ) >> 6, maxVal );
+    const int t2 = clipPel( sdot2( d.y, c01, sdot2( d.z, c23, 32 ) ) >> 6, maxVal );
+    const int t3 = clipPel( sdot2( o1, c01, sdot2( o2, c23, 32 ) ) >> 6, maxVal );
+    u32x2 o; o.x = pk16( t0, t1 ); o.y = pk16( t2, t3 );
+    *reinterpret_cast<u32x2*>( dst + v * region + r * 16 + x ) = o;
+  }
+}
+
 // one refinement ring (the 8 positions around (cx, cy) at distance a, reference order) -> updates best; sTmp: 3 regions of the horizontal passes
 template<bool STATS>
 __device__ __forceinline__ void meRing16( const MeGeom& g, int bx, int by, const uint32_t ( &orgCol )[16], int cx, int cy, int a, int& bestX, int& bestY, int& bestE, int16_t* sTmp, int lane, MeCount& cnt )
 {
   const int iyMin = ( cy - a ) >> 4, iyMax = ( cy + a ) >> 4, nrows = iyMax - iyMin + 16 + 3, region = nrows * 16;
-#pragma unroll
-  for( int v = 0; v < 3; v++ )
-  {
-    const int X = cx + ( v - 1 ) * a;
-    horPass4( g.buf + bx + ( X >> 4 ) + ( ptrdiff_t ) ( by + iyMin - 1 ) * g.bufStride, g.bufStride, nrows, 16, X & 15, g.maxVal, sTmp + v * region, lane );
-  }
+  horPass4x3( g.buf + bx + ( ptrdiff_t ) ( by + iyMin - 1 ) * g.bufStride, g.bufStride, nrows, cx - a, cx, cx + a, g.maxVal, sTmp, region, lane );
   ME_WAVE_SYNC();
   const int c = lane >> 3, p = lane & 7;
   const int cc = c + ( c >= 4 ), j = ( cc * 11 ) >> 5, v = cc - 3 * j;          // position in the 3 x 3 scan without its centre: y offset index j (outer), x offset index v (inner)
