@@ -1391,6 +1391,38 @@ static int mePlanCreate( vvhip_ctx* ctx, const vvhip_me_lists& L, int bit_depth,
     if( !itemGen( itOrder[i] ) ) wavesItemMain = ( int ) itWaves.size();
     i += count;
   }
+  // Round 6: BAND-MAJOR interleave of the classes.  A call's original block is read by every class that scores it (SAD, SSE, Hadamard lists of the same CU);
+  // with one class after the other an XCD streams its eighth of class A through its 4 MB L2 before class B comes back to the same originals: at 4K the table calls moved
+  // 354 MB for 290 MB of unique bytes.  Here XCD x (workgroup index mod 8) walks its eighth of the PICTURE in sub-bands and runs every class's waves of a sub-band before the
+  // next sub-band.  Picture position of a wave = the index its first item had in the caller's list (the lists arrive in picture order).  MEASURED SLOWER (same box, A/B twice:
+  // 4K 81.2 -> 84.0 us per picture, 1080p 21.8 -> 25.6 us; 4 / 16 / 64 sub-bands alike): waves of different functions side by side cost more than the originals' second fetch
+  // from the Infinity Cache — so it is OFF; $VVHIP_ME_ITEM_INTERLEAVE=<sub-bands per eighth> switches it on for measurements (results identical).
+  static const int interleaveSub = []{ const char* e = getenv( "VVHIP_ME_ITEM_INTERLEAVE" ); return e ? atoi( e ) : 0; }();
+  if( band && interleaveSub > 0 && wavesItemMain > 64 && wavesItemMain <= 65536 && n_items > 0 )
+  {
+    const std::vector<WaveSpan> src( itWaves.begin(), itWaves.begin() + wavesItemMain );
+    const int nb = 8 * interleaveSub;
+    std::vector<int> idx( wavesItemMain ), bandOf( wavesItemMain );
+    for( int w = 0; w < wavesItemMain; w++ ) { idx[w] = w; bandOf[w] = ( int ) std::min<long>( nb - 1, ( long ) itOrder[src[w].first] * nb / n_items ); }
+    std::stable_sort( idx.begin(), idx.end(), [&]( int a, int b ) { return bandOf[a] < bandOf[b]; } );      // (stable: inside a sub-band the classes keep their order, heaviest first)
+    std::vector<int> qBeg( 9, wavesItemMain );
+    for( int k = wavesItemMain - 1; k >= 0; k-- ) qBeg[bandOf[idx[k]] / interleaveSub] = k;
+    for( int x = 7; x >= 0; x-- ) if( qBeg[x] > qBeg[x + 1] ) qBeg[x] = qBeg[x + 1];                          // (an XCD without waves)
+    int cursor[8];
+    for( int x = 0; x < 8; x++ ) cursor[x] = qBeg[x];
+    int outW = 0;
+    for( int l = 0; outW < wavesItemMain; l++ )
+    {
+      int x = l & 7;
+      for( int t = 0; t < 8 && cursor[x] >= qBeg[x + 1]; t++ ) x = ( x + 1 ) & 7;                           // (a finished eighth borrows from its neighbour)
+      for( int k = 0; k < 4 && outW < wavesItemMain; k++ )
+      {
+        if( cursor[x] >= qBeg[x + 1] ) { int t = 0; for( ; t < 8 && cursor[x] >= qBeg[x + 1]; t++ ) x = ( x + 1 ) & 7; if( t == 8 ) break; }
+        itWaves[outW++] = src[idx[cursor[x]++]];
+      }
+    }
+  }
+  else
   if( band && wavesItemMain <= 65536 )      // (four-wave workgroups; the long lists of an intra picture run one wave per workgroup in list order)
   {
     std::vector<WaveSpan> src( itWaves );
