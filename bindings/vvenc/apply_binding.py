@@ -186,7 +186,23 @@ patch("EncAdaptiveLoopFilter.cpp", [
     ("before", "  }  \n}\n\nvoid EncAdaptiveLoopFilter::copyCTUforALF(", "    }\n"),
     # whole-picture ALF statistics: the per-CTU tasks do nothing, the first thing deriveFilter does is ONE device call for the picture
     ("before", "  const PreCalcValues& pcv = *cs.pcv;\n  const int xC = ( ctuRsAddr % pcv.widthInCtus ) << pcv.maxCUSizeLog2;",
-     "  if( ( g_vvhipHooks.alfPicture && g_vvhipHooks.alfPictureOn( ( int ) m_numCTUsInPic, m_encCfg->m_numThreads ) && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) ) return;\n"),
+     "  if( ( g_vvhipHooks.alfPicture && g_vvhipHooks.alfPictureOn( ( int ) m_numCTUsInPic, m_encCfg->m_numThreads ) && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) )\n"
+     "  {\n"
+     "    // the row task's last CTU: every sample the statistics of this CTU row read is final (EncSlice.cpp:1135-1141) -> the row's statistics unit goes to the device now, asynchronously\n"
+     "    if( g_vvhipHooks.alfRow && ( ctuRsAddr % cs.pcv->widthInCtus ) == cs.pcv->widthInCtus - 1 )\n"
+     "    {\n"
+     "      const Pel* hRec[3]; const Pel* hOrg[3]; int hRs[3], hOs[3]; bool hEn[3];\n"
+     "      PelUnitBuf hOrgYuv = pic.getOrigBuf();\n"
+     "      for( int c = 0; c < 3; c++ )\n"
+     "      {\n"
+     "        hRec[c] = m_tempBuf.get( ComponentID( c ) ).buf; hRs[c] = m_tempBuf.get( ComponentID( c ) ).stride;\n"
+     "        hOrg[c] = hOrgYuv.get( ComponentID( c ) ).buf; hOs[c] = hOrgYuv.get( ComponentID( c ) ).stride; hEn[c] = m_alfFilterStatEnabled[c];\n"
+     "      }\n"
+     "      g_vvhipHooks.alfRow( this, cs.picture->poc, ctuRsAddr / cs.pcv->widthInCtus, hRec, hRs, hOrg, hOs, m_picWidth, m_picHeight, m_inputBitDepth[CH_L], m_maxCUHeight, m_maxAsuHeight,\n"
+     "                           m_alfVBLumaCTUHeight, m_alfVBLumaPos, m_alfVBChmaCTUHeight, m_alfVBChmaPos, hEn );\n"
+     "    }\n"
+     "    return;\n"
+     "  }\n"),
     ("after", "  initCABACEstimator( cs.slice );\n\n  // Accumulate ALF statistic\n",
      "  if( g_vvhipHooks.alfBeginPicture ) g_vvhipHooks.alfBeginPicture( this, cs.picture->poc );\n"
      "  if( ( g_vvhipHooks.alfPicture && g_vvhipHooks.alfPictureOn( ( int ) m_numCTUsInPic, m_encCfg->m_numThreads ) && m_encCfg->m_ifpLines == 0 && !m_accumStatCTUWise && !m_encCfg->m_useNonLinearAlfLuma && !m_encCfg->m_useNonLinearAlfChroma && m_chromaFormat == CHROMA_420 && cs.pps->getNumTiles() == 1 && cs.pps->numSlicesInPic == 1 && !cs.picHeader->virtualBoundariesEnabled ) && numCtus == ( int ) m_numCTUsInPic )\n"

@@ -667,7 +667,8 @@ bool alfCtu( const int16_t* const rec[3], const int recStride[3], const int16_t*
 // ---- whole-picture ALF stages: one vvhip::ALFOps per EncAdaptiveLoopFilter object (it keeps the unfiltered planes and the classes of its current picture in HBM
 // between the statistics call and the filtering call), on the picture's GPU
 std::mutex g_alfPicLock;
-struct AlfPictureState { std::unique_ptr<vvhip::ALFOps> ops; int donePoc = -1; bool done = false; std::mutex busy; };
+struct AlfPictureState { std::unique_ptr<vvhip::ALFOps> ops; int donePoc = -1; bool done = false; std::mutex busy;
+                         bool bandsOpen = false; int bandPoc = 0; std::vector<char> rowSeen; };      // the picture whose statistics are being issued in bands (alfRow)
 std::map<const void*, std::unique_ptr<AlfPictureState>> g_alfState;
 AlfPictureState& alfState( const void* owner )
 {
@@ -688,18 +689,84 @@ void alfBeginPicture( const void* owner, int /*poc*/ )
 std::atomic<uint64_t> g_alfPictures{ 0 };
 // The whole-picture statistics call runs inside the serial part of the ALF stage (deriveFilter): one upload + three launches + a download per picture against CPU work that is
 // spread over the worker threads.  It pays when the pool is saturated — measured: 1080p (510 CTUs) with 2 / 4 threads +16 / +14 %, 4K (2040 CTUs) with 8 threads +8...13 %,
-// 1080p with 8 threads +-0 (profiles/r02_e2e_encoder_fps.md, r03) — so the hook is taken from $VVHIP_ALF_MIN_CTUS_PER_THREAD CTUs per encoder thread on (default 100).
+// 1080p with 8 threads +-0 (profiles/r02_e2e_encoder_fps.md, r03) — so the hook was taken from 100 CTUs per encoder thread on.  Round 6: the picture goes to the device in
+// bands from the row tasks (alfRow below) and the serial part is 0.16 ms instead of 7.5 ms per 1080p picture (profiles/r06_alf_bands.log) — the rule stays for the tiny pictures
+// only: $VVHIP_ALF_MIN_CTUS_PER_THREAD, default 50 (1080p with 8 threads: on).
 bool alfPictureOn( int numCtusInPic, int numThreads )
 {
-  static const int minPerThread = []{ const char* e = getenv( "VVHIP_ALF_MIN_CTUS_PER_THREAD" ); return e ? atoi( e ) : 100; }();
+  static const int minPerThread = []{ const char* e = getenv( "VVHIP_ALF_MIN_CTUS_PER_THREAD" ); return e ? atoi( e ) : 50; }();
   return numCtusInPic >= minPerThread * ( numThreads > 0 ? numThreads : 1 );
 }
+// Statistics in bands: the statistics task of CTU row y runs when row y + 1 has left SAO (EncSlice.cpp:1135-1141) — every sample the row's statistics read is
+// final.  When the CTU rows of a statistics-unit row are all reported, the unit row goes up + is computed + comes down asynchronously on the reporting worker's stream; the
+// serial part (deriveFilter -> alfPicture) then waits for marks that are long complete instead of moving the whole picture.  $VVHIP_ALF_BANDS=0: the picture as a whole.
+std::atomic<uint64_t> g_alfBands{ 0 }, g_alfBandPictures{ 0 }, g_alfRowNs{ 0 }, g_alfPictureNs{ 0 };      // (ns: wall time inside alfRow on the workers / inside alfPicture = the serial part)
+// $VVHIP_ALF_TIMELINE=<file>: one line per alfRow / alfPicture call (measurement aid: "row|picture poc row-or--1 wait_lock_us inside_us t_us")
+void alfTimeline( const char* what, int poc, int row, uint64_t waitNs, uint64_t insideNs )
+{
+  static FILE* f = []{ const char* e = getenv( "VVHIP_ALF_TIMELINE" ); return e && *e ? fopen( e, "a" ) : ( FILE* ) nullptr; }();
+  if( !f ) return;
+  static std::mutex m; static const auto t0 = std::chrono::steady_clock::now();
+  std::lock_guard<std::mutex> g( m );
+  fprintf( f, "%s %d %d %.1f %.1f %.1f\n", what, poc, row, waitNs / 1e3, insideNs / 1e3, std::chrono::duration_cast<std::chrono::nanoseconds>( std::chrono::steady_clock::now() - t0 ).count() / 1e3 );
+  fflush( f );
+}
+struct NsScope { std::atomic<uint64_t>& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                 explicit NsScope( std::atomic<uint64_t>& a ) : acc( a ) {}
+                 ~NsScope() { acc += ( uint64_t ) std::chrono::duration_cast<std::chrono::nanoseconds>( std::chrono::steady_clock::now() - t0 ).count(); } };
+bool alfRow( const void* owner, int poc, int ctuRow, const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height,
+             int bitDepth, int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3] )
+{
+  static const bool on = []{ const char* e = getenv( "VVHIP_ALF_BANDS" ); return !e || atoi( e ) != 0; }();
+  if( !on ) return false;
+  NsScope ns( g_alfRowNs );
+  AlfPictureState& st = alfState( owner );
+  const auto tl0 = std::chrono::steady_clock::now();
+  std::lock_guard<std::mutex> g( st.busy );
+  const auto tl1 = std::chrono::steady_clock::now();
+  struct Tl { int poc, row; std::chrono::steady_clock::time_point a, b; ~Tl() { alfTimeline( "row", poc, row, ( uint64_t ) std::chrono::duration_cast<std::chrono::nanoseconds>( b - a ).count(),
+                ( uint64_t ) std::chrono::duration_cast<std::chrono::nanoseconds>( std::chrono::steady_clock::now() - b ).count() ); } } tl{ poc, ctuRow, tl0, tl1 };
+  GpuScope sc( gpuOfPicture( poc ) );
+  const int ctuRows = ( height + ctuSize - 1 ) / ctuSize;
+  if( ctuRow < 0 || ctuRow >= ctuRows ) return false;
+  if( !st.bandsOpen || st.bandPoc != poc || ( int ) st.rowSeen.size() != ctuRows || st.rowSeen[ctuRow] )      // a new picture (or the same POC again: another pass)
+  {
+    st.bandsOpen = st.ops->statisticsBegin( recStride, orgStride, width, height, bitDepth, ctuSize, unitSize, vbLumaH, vbLumaPos, vbChromaH, vbChromaPos, enabled );
+    st.bandPoc = poc; st.rowSeen.assign( ( size_t ) ctuRows, 0 );
+  }
+  if( !st.bandsOpen ) return false;
+  st.rowSeen[ctuRow] = 1;
+  const int perUnit = unitSize / ctuSize, u = ctuRow / perUnit;
+  for( int r = u * perUnit; r < std::min( ctuRows, ( u + 1 ) * perUnit ); r++ ) if( !st.rowSeen[r] ) return true;      // the unit row waits for its other CTU rows
+  if( !st.ops->statisticsBand( u, rec, org ) ) { st.bandsOpen = false; return false; }
+  g_alfBands++;
+  return true;
+}
+
 bool alfPicture( const void* owner, int poc, const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int bitDepth,
                  int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] )
 {
+  NsScope ns( g_alfPictureNs );
   AlfPictureState& st = alfState( owner );
+  const auto tl0 = std::chrono::steady_clock::now();
   std::lock_guard<std::mutex> g( st.busy );
+  const auto tl1 = std::chrono::steady_clock::now();
+  struct Tl { int poc; std::chrono::steady_clock::time_point a, b; ~Tl() { alfTimeline( "picture", poc, -1, ( uint64_t ) std::chrono::duration_cast<std::chrono::nanoseconds>( b - a ).count(),
+                ( uint64_t ) std::chrono::duration_cast<std::chrono::nanoseconds>( std::chrono::steady_clock::now() - b ).count() ); } } tl{ poc, tl0, tl1 };
   GpuScope sc( gpuOfPicture( poc ) );
+  if( st.bandsOpen && st.bandPoc == poc )
+  {
+    st.bandsOpen = false;
+    const uint8_t* hCls = nullptr; const float* hSt[3] = { nullptr, nullptr, nullptr };
+    if( st.ops->statisticsEnd( rec, &hCls, hSt ) )
+    {
+      const int units = ( ( width + unitSize - 1 ) / unitSize ) * ( ( height + unitSize - 1 ) / unitSize );
+      memcpy( cls, hCls, ( size_t ) ( width / 4 ) * ( height / 4 ) * 2 );
+      for( int c = 0; c < 3; c++ ) if( enabled[c] ) memcpy( stats[c], hSt[c], ( size_t ) units * ( c ? 1 : 25 ) * 183 * sizeof( float ) );
+      g_alfPictures++; g_alfBandPictures++;
+      return true;
+    }
+  }
   if( !st.ops->pictureStatistics( rec, recStride, org, orgStride, width, height, bitDepth, ctuSize, unitSize, vbLumaH, vbLumaPos, vbChromaH, vbChromaPos, enabled, cls, stats ) ) return false;
   g_alfPictures++;
   return true;
@@ -804,11 +871,12 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int vvenc_hip_install( i
   g_vvhipHooks.ccAlfCtu = ( mask & 4096 ) ? ccAlfCtu : nullptr; g_ccAlfCtus = 0;
   g_vvhipHooks.alfPicture = ( mask & 8192 ) ? alfPicture : nullptr; g_alfPictures = 0;
   g_vvhipHooks.alfPictureOn = alfPictureOn;
+  g_vvhipHooks.alfRow = ( mask & 8192 ) ? alfRow : nullptr; g_alfBands = 0; g_alfBandPictures = 0; g_alfRowNs = 0; g_alfPictureNs = 0;
   g_vvhipHooks.alfBeginPicture = ( mask & ( 8192 | 65536 ) ) ? alfBeginPicture : nullptr;
   g_vvhipHooks.alfFilterBlk = ( mask & 16384 ) ? alfFilterBlk : nullptr; g_alfFilterBlks = 0;
   g_vvhipHooks.ccAlfFilterBlk = ( mask & 32768 ) ? ccAlfFilterBlk : nullptr; g_ccAlfFilterBlks = 0;
   g_vvhipHooks.alfFilterPicture = ( mask & 65536 ) ? alfFilterPicture : nullptr; g_alfFilterPictures = 0;
-  { std::lock_guard<std::mutex> g( g_alfPicLock ); for( auto& kv : g_alfState ) { kv.second->done = false; kv.second->donePoc = -1; kv.second->ops->dropResident(); } }
+  { std::lock_guard<std::mutex> g( g_alfPicLock ); for( auto& kv : g_alfState ) { kv.second->done = false; kv.second->donePoc = -1; kv.second->bandsOpen = false; kv.second->ops->dropResident(); } }
   g_vvhipHooks.mergeCosts = ( mask & 524288 ) ? mergeCosts : nullptr; g_mergeCalls = 0; g_mergeCands = 0; g_mergeNs = 0; g_tuPrefetchNs = 0;
   g_vvhipHooks.tuPrefetch = ( mask & 262144 ) ? tuPrefetch : nullptr; g_vvhipHooks.tuLookup = ( mask & 262144 ) ? tuLookup : nullptr; g_tuPrefetches = 0; g_tuLookups = 0; g_tuHits = 0;
   g_vvhipHooks.tzReset = ( mask & 1024 ) ? tzReset : nullptr; g_vvhipHooks.tzPrefetch = ( mask & 1024 ) ? tzPrefetch : nullptr; g_vvhipHooks.tzLookup = ( mask & 1024 ) ? tzLookup : nullptr;
@@ -837,7 +905,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvenc_hip_release( 
   try
   {
     { std::lock_guard<std::mutex> g( g_mctfLock ); while( !g_resident.empty() ) dropResident( 0 ); g_meCache.curPoc = -1; g_meCache.fields.clear(); }
-    { std::lock_guard<std::mutex> g( g_alfPicLock ); for( auto& kv : g_alfState ) { kv.second->done = false; kv.second->donePoc = -1; kv.second->ops->dropResident(); } }
+    { std::lock_guard<std::mutex> g( g_alfPicLock ); for( auto& kv : g_alfState ) { kv.second->done = false; kv.second->donePoc = -1; kv.second->bandsOpen = false; kv.second->ops->dropResident(); } }
     {
       std::lock_guard<std::mutex> g( g_reconLock );
       for( auto& kv : g_recon ) for( int k = 0; k < std::min( numGpus(), 16 ); k++ ) { GpuScope sc( ( vvhip::Device::defaultGpu() + k ) % numGpus() ); vvhip::Device::get().unregisterPicture( kv.second.ids[k] ); }
@@ -887,6 +955,10 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) void vvref_hip_hook_call
     if( n > 35 ) out[35] = g_mergeCands;
     if( n > 36 ) out[36] = g_tuPrefetchNs;
     if( n > 37 ) out[37] = g_mergeNs;
+    if( n > 39 ) out[39] = g_alfBands;              // statistics-unit rows issued asynchronously by row tasks (round 6)
+    if( n > 40 ) out[40] = g_alfBandPictures;       // pictures whose statistics were collected from bands
+    if( n > 41 ) out[41] = g_alfRowNs;              // wall ns inside alfRow (worker threads, all pictures)
+    if( n > 42 ) out[42] = g_alfPictureNs;          // wall ns inside alfPicture (the serial part of the ALF stage)
     if( n > 38 ) out[38] = g_lfnstQuantDevice;      // LFNST TUs quantised on the device (round 6; 20 = those left to the CPU entry: 0 unless $VVHIP_LFNST_QUANT_ON_CPU=1)
   }
 }

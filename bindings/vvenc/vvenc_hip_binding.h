@@ -47,6 +47,10 @@ struct VvhipHooks
   // ALF statistics of a whole picture in one call (classes in picture raster, one record set per statistics unit)
   bool ( *alfPicture )( const void* owner, int poc, const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height, int bitDepth,
                         int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] );
+  // the same picture IN BANDS: called by the statistics task of every CTU row (its last CTU; EncSlice.cpp:1135-1167) while other rows are still in SAO — the row's statistics unit
+  // goes to the device asynchronously as soon as its CTU rows are complete, alfPicture then only collects (false: the picture goes up as a whole inside alfPicture)
+  bool ( *alfRow )( const void* owner, int poc, int ctuRow, const int16_t* const rec[3], const int recStride[3], const int16_t* const org[3], const int orgStride[3], int width, int height,
+                    int bitDepth, int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3] );
   // whether the whole-picture statistics call pays for this picture size and thread count (it sits in the serial filter derivation: worth it when the thread pool is saturated)
   bool ( *alfPictureOn )( int numCtusInPic, int numThreads );
   // CC-ALF statistics of one CTU and chroma component: record of 183 floats (E[0..6][0..6] with row pitch 13, y[0..6], pixAcc)

@@ -76,6 +76,13 @@ VVHIP_API int         vvhip_host_unregister( vvhip_ctx* ctx, const void* host_pt
 /* pinned host memory owned by the library's caller (hipHostMalloc): download / upload areas that are not the encoder's own buffers                                  */
 VVHIP_API int         vvhip_host_alloc( vvhip_ctx* ctx, void** host_ptr, size_t bytes );
 VVHIP_API int         vvhip_host_free( vvhip_ctx* ctx, void* host_ptr );
+/* Completion marks for work a worker thread leaves behind (hipEvent_t without timing): recorded on the recording context's stream, awaited by ANY thread — a picture stage
+ * issued piecewise by several workers (the ALF statistics of a picture, one band per row task: EncoderLib/EncSlice.cpp:1135-1167) is collected by the thread that needs the
+ * whole (EncAdaptiveLoopFilter::deriveFilter, EncoderLib/EncAdaptiveLoopFilter.cpp:1757) without a stream synchronisation per piece.                                          */
+VVHIP_API int         vvhip_event_create( vvhip_ctx* ctx, void** event );
+VVHIP_API int         vvhip_event_record( vvhip_ctx* ctx, void* event );          /* on the context's stream */
+VVHIP_API int         vvhip_event_wait( vvhip_ctx* ctx, void* event );            /* host wait (ctx: error reporting only; an event never recorded is complete) */
+VVHIP_API int         vvhip_event_destroy( vvhip_ctx* ctx, void* event );
 /* Several GPUs in one process (one context per device and worker thread): number of devices, the device of a context, and a device-to-device copy of a
  * picture over xGMI (hipMemcpyPeerAsync on dst's stream, ordered after the work already queued on src's stream) — how an original or reconstructed
  * picture reaches the GPU that serves the pictures depending on it without a round trip through the host.                                        */

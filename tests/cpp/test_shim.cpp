@@ -321,9 +321,60 @@ static void test_ALF()
   for( size_t i = 0; i < qg.size(); i++ ) CHECK_EQ( qg[i], qe[i], "CC-ALF filtering" );
 }
 
+// The picture's statistics in bands (ALFOps::statisticsBegin / Band / End, what the binding's row tasks drive) against the one-call form and the oracle: 4:2:0 picture of
+// 3 statistics-unit rows (the last one short), units of 128 made of CTUs of 64, bands issued out of order; float records compared by their bit patterns
+static void test_ALF_bands()
+{
+  const int W = 328, H = 296, B = 8, ctu = 64, unit = 128;
+  std::vector<Pel> recP[3], orgP[3]; const Pel* rec[3]; const Pel* org[3]; int rs[3], os[3];
+  for( int c = 0; c < 3; c++ )
+  {
+    const int w = c ? W / 2 : W, h = c ? H / 2 : H, st = w + 2 * B + 24;      // (strides wider than the rows: the bands upload whole runs of rows as they lie)
+    recP[c].assign( ( size_t ) st * ( h + 2 * B ), 0 ); orgP[c].assign( ( size_t ) ( w + 16 ) * h, 0 );
+    for( int y = 0; y < h; y++ ) for( int x = 0; x < w; x++ )
+    {
+      const int v = 500 + ( int ) ( 170 * std::sin( x / ( 7.0 + c ) ) * std::cos( y / 5.0 ) ) + ( int ) ( rng() % 41 ) - 20;
+      recP[c][( size_t ) ( y + B ) * st + x + B] = ( Pel ) std::min( 1023, std::max( 0, v ) );
+      orgP[c][( size_t ) y * ( w + 16 ) + x] = ( Pel ) std::min( 1023, std::max( 0, v + ( int ) ( rng() % 25 ) - 12 ) );
+    }
+    for( int y = 0; y < h + 2 * B; y++ ) for( int x = 0; x < w + 2 * B; x++ )
+    {
+      const int sy = std::min( h - 1, std::max( 0, y - B ) ), sx = std::min( w - 1, std::max( 0, x - B ) );
+      recP[c][( size_t ) y * st + x] = recP[c][( size_t ) ( sy + B ) * st + sx + B];
+    }
+    rec[c] = recP[c].data() + ( size_t ) B * st + B; org[c] = orgP[c].data(); rs[c] = st; os[c] = w + 16;
+  }
+  const bool en[3] = { true, true, true };
+  const int units = ( ( W + unit - 1 ) / unit ) * ( ( H + unit - 1 ) / unit );
+  const size_t nCls = ( size_t ) ( W / 4 ) * ( H / 4 ) * 2;
+  std::vector<uint8_t> clsW( nCls ), clsE( nCls );
+  std::vector<float> stW[3], stE[3]; float* pW[3];
+  for( int c = 0; c < 3; c++ ) { stW[c].assign( ( size_t ) units * ( c ? 1 : 25 ) * ORC_ALF_REC, -1.0f ); stE[c] = stW[c]; pW[c] = stW[c].data(); }
+  ALFOps whole, bands;
+  if( !whole.pictureStatistics( rec, rs, org, os, W, H, 10, ctu, unit, ctu, ctu - 4, ctu / 2, ctu / 2 - 2, en, clsW.data(), pW ) ) { printf( "ALF picture statistics refused\n" ); failures++; return; }
+  orc_alf_classify( rec[0], rs[0], W, H, 14, ctu, ctu - 4, clsE.data() );
+  orc_alf_stats_plane_units( org[0], os[0], rec[0], rs[0], W, H, unit, ctu, 7, clsE.data(), ctu, ctu - 4, stE[0].data() );
+  for( int c = 1; c < 3; c++ ) orc_alf_stats_plane_units( org[c], os[c], rec[c], rs[c], W / 2, H / 2, unit / 2, ctu / 2, 5, nullptr, ctu / 2, ctu / 2 - 2, stE[c].data() );
+  if( !bands.statisticsBegin( rs, os, W, H, 10, ctu, unit, ctu, ctu - 4, ctu / 2, ctu / 2 - 2, en ) ) { printf( "ALF statistics bands refused\n" ); failures++; return; }
+  CHECK_EQ( bands.statisticsBands(), 3, "ALF unit rows" );
+  const uint8_t* clsB = nullptr; const float* stB[3] = { nullptr, nullptr, nullptr };
+  CHECK_EQ( ( int ) bands.statisticsEnd( rec, &clsB, stB ), 0, "ALF bands: End before every band is in" );
+  if( !bands.statisticsBegin( rs, os, W, H, 10, ctu, unit, ctu, ctu - 4, ctu / 2, ctu / 2 - 2, en ) ) { failures++; return; }
+  const int order[3] = { 2, 0, 1 };
+  for( int u : order ) if( !bands.statisticsBand( u, rec, org ) ) { printf( "ALF statistics band %d refused\n", u ); failures++; return; }
+  CHECK_EQ( ( int ) bands.statisticsBand( 1, rec, org ), 0, "ALF bands: a band twice" );
+  if( !bands.statisticsEnd( rec, &clsB, stB ) ) { printf( "ALF statistics bands: End refused\n" ); failures++; return; }
+  for( size_t i = 0; i < nCls; i++ ) { CHECK_EQ( clsW[i], clsE[i], "ALF picture classes" ); CHECK_EQ( clsB[i], clsE[i], "ALF band classes" ); }
+  for( int c = 0; c < 3; c++ ) for( size_t i = 0; i < stE[c].size(); i++ )
+  {
+    uint32_t e, w, b; memcpy( &e, &stE[c][i], 4 ); memcpy( &w, &stW[c][i], 4 ); memcpy( &b, &stB[c][i], 4 );
+    CHECK_EQ( w, e, "ALF picture statistics" ); CHECK_EQ( b, e, "ALF band statistics" );
+  }
+}
+
 int main()
 {
-  try { test_RdCost(); test_TCoeffOps(); test_InterpolationFilter(); test_MCTF(); test_ALF(); }
+  try { test_RdCost(); test_TCoeffOps(); test_InterpolationFilter(); test_MCTF(); test_ALF(); test_ALF_bands(); }
   catch( const std::exception& e ) { printf( "EXCEPTION: %s\n", e.what() ); return 2; }
   printf( failures ? "FAILED: %d mismatches\n" : "shim parity OK (RdCost, TCoeffOps/Quant, InterpolationFilter, MCTF, ALF)\n", failures );
   return failures ? 1 : 0;

@@ -109,7 +109,7 @@ yuv = F.synth_clip_chunk(cfg["w"], cfg["h"], cfg["first"], cfg["frames"]) if "fi
 md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], 10, 10, threads=cfg["threads"], preset=E.PRESETS[cfg.get("preset", "faster")], simd=cfg.get("simd"), options=cfg.get("options"))
 calls = None
 if cfg["mask"]:
-    c = np.zeros(39, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 39); calls = [int(x) for x in c]
+    c = np.zeros(43, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 43); calls = [int(x) for x in c]
 out = {"mask": cfg["mask"], "md5": md5, "bytes": n, "secs": secs, "fps": cfg["frames"] / secs, "calls": calls}
 if calls:
     out["pcie_MB_per_picture"] = {"up": round(calls[25] / 1e6 / cfg["frames"], 3), "down": round(calls[26] / 1e6 / cfg["frames"], 3)}

@@ -90,6 +90,10 @@ int         vvhip_host_register( vvhip_ctx* ctx, const void*, size_t ) { return 
 int         vvhip_host_unregister( vvhip_ctx* ctx, const void* ) { return ctx ? VVHIP_OK : VVHIP_E_ARG; }
 int         vvhip_host_alloc( vvhip_ctx* ctx, void** p, size_t bytes ) { if( !ctx || !p ) return VVHIP_E_ARG; *p = malloc( bytes ? bytes : 1 ); return *p ? VVHIP_OK : VVHIP_E_NOMEM; }
 int         vvhip_host_free( vvhip_ctx* ctx, void* p ) { if( !ctx ) return VVHIP_E_ARG; free( p ); return VVHIP_OK; }
+int         vvhip_event_create( vvhip_ctx* ctx, void** e ) { if( !ctx || !e ) return VVHIP_E_ARG; *e = malloc( 1 ); return *e ? VVHIP_OK : VVHIP_E_NOMEM; }      // (every call of the sim is complete when it returns)
+int         vvhip_event_record( vvhip_ctx* ctx, void* e ) { return ctx && e ? VVHIP_OK : VVHIP_E_ARG; }
+int         vvhip_event_wait( vvhip_ctx* ctx, void* e ) { return ctx && e ? VVHIP_OK : VVHIP_E_ARG; }
+int         vvhip_event_destroy( vvhip_ctx* ctx, void* e ) { if( !ctx ) return VVHIP_E_ARG; free( e ); return VVHIP_OK; }
 const char* vvhip_version( void ) { return "vvenc_hip SIMULATED (CPU oracle test double; not a product build)"; }
 
 // ------------------------------------------------------------------------------------------------ (A) distortion

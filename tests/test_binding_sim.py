@@ -74,7 +74,7 @@ def test_simd_switch_selects_the_binding(preset):
 
 def test_alf_picture_statistics_follow_the_saturation_rule():
     """the whole-picture ALF statistics call sits in the serial filter derivation: the binding takes it only from $VVHIP_ALF_MIN_CTUS_PER_THREAD CTUs per encoder thread on
-    (default 100: 1080p with <= 4 threads, 4K with <= 16); below it the per-CTU CPU tasks stay — same bitstream either way"""
+    (default 50 since the statistics go up in bands: 1080p with <= 8 threads, 4K with <= 32); below it the per-CTU CPU tasks stay — same bitstream either way"""
     need()
     clip = dict(CLIP, frames=9, preset="faster", threads=4)
     cpu = run(dict(clip, hip=False, mask=0))
@@ -82,6 +82,25 @@ def test_alf_picture_statistics_follow_the_saturation_rule():
     on = run(dict(clip, hip=True, simd="HIP"), env=sim_env(VVHIP_ALF_MIN_CTUS_PER_THREAD=1))
     assert off["calls"][16] == 0 and on["calls"][16] >= 1 and off["calls"][9] >= 1, (off["calls"], on["calls"])
     assert off["md5"] == cpu["md5"] and on["md5"] == cpu["md5"]
+
+
+@pytest.mark.parametrize("clip", [dict(w=416, h=240, frames=9, preset="faster", threads=4),          # statistics units of 128 = two CTU rows of 64 (the last unit row: one)
+                                  dict(w=208, h=120, frames=5, preset="medium", threads=2)])         # CTU 128 = unit
+def test_alf_picture_statistics_in_bands(clip):
+    """the statistics task of every CTU row reports to the binding (alfRow); a statistics-unit row whose CTU rows are all in goes to the device at once
+    (upload of its rows + classification + statistics + download, asynchronously on the reporting worker's context), deriveFilter only collects.  Same stream as the CPU
+    encoder's and as the whole-picture call's ($VVHIP_ALF_BANDS=0); every picture's statistics came from bands, one band per unit row"""
+    need()
+    clip = dict(clip, in_bd=10, int_bd=10)
+    cpu = run(dict(clip, hip=False, mask=0))
+    bands = run(dict(clip, hip=True, mask=8192), env=sim_env())
+    whole = run(dict(clip, hip=True, mask=8192), env=sim_env(VVHIP_ALF_BANDS=0))
+    cb, cw = bands["calls"], whole["calls"]
+    unit = 128
+    rows = (clip["h"] + unit - 1) // unit
+    assert cb[16] >= 1 and cb[40] == cb[16] and cb[39] == rows * cb[16], cb
+    assert cw[16] == cb[16] and cw[39] == 0 and cw[40] == 0, cw
+    assert bands["md5"] == cpu["md5"] and whole["md5"] == cpu["md5"] and bands["bytes"] == cpu["bytes"], (cpu, bands, whole)
 
 
 def test_residual_loop_batched_site():

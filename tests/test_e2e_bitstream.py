@@ -36,7 +36,7 @@ md5, n, secs = E.encode(L, yuv, cfg["w"], cfg["h"], cfg["in_bd"], cfg["int_bd"],
 calls = None
 if cfg["hip"]:
     import numpy as np
-    c = np.zeros(39, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 39); calls = [int(x) for x in c]
+    c = np.zeros(43, np.uint64); L.vvref_hip_hook_calls_ex(c.ctypes.data, 43); calls = [int(x) for x in c]
 print(json.dumps({"md5": md5, "bytes": n, "secs": secs, "calls": calls}))
 ''' % os.path.join(ROOT, "tests")
 

@@ -442,6 +442,37 @@ int vvhip_host_free( vvhip_ctx* ctx, void* host_ptr )
   return VVHIP_OK;
 }
 
+int vvhip_event_create( vvhip_ctx* ctx, void** event )
+{
+  if( !ctx || !event ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipSetDevice( ctx->device ) );
+  hipEvent_t e;
+  VVHIP_CHECK_HIP( ctx, hipEventCreateWithFlags( &e, hipEventDisableTiming ) );
+  *event = e;
+  return VVHIP_OK;
+}
+
+int vvhip_event_record( vvhip_ctx* ctx, void* event )
+{
+  if( !ctx || !event ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipEventRecord( static_cast<hipEvent_t>( event ), ctx->stream ) );
+  return VVHIP_OK;
+}
+
+int vvhip_event_wait( vvhip_ctx* ctx, void* event )
+{
+  if( !ctx || !event ) return VVHIP_E_ARG;
+  VVHIP_CHECK_HIP( ctx, hipEventSynchronize( static_cast<hipEvent_t>( event ) ) );
+  return VVHIP_OK;
+}
+
+int vvhip_event_destroy( vvhip_ctx* ctx, void* event )
+{
+  if( !ctx ) return VVHIP_E_ARG;
+  if( event ) VVHIP_CHECK_HIP( ctx, hipEventDestroy( static_cast<hipEvent_t>( event ) ) );
+  return VVHIP_OK;
+}
+
 int vvhip_device_count( void )
 {
   int count = 0;

@@ -989,6 +989,121 @@ bool ALFOps::pictureStatistics( const Pel* const rec[3], const int recStride[3],
   return true;
 }
 
+// ---- the picture call in bands (see the header)
+bool ALFOps::statisticsBegin( const int recStride[3], const int orgStride[3], int width, int height, int bitDepth, int ctuSize, int unitSize, int vbLumaH, int vbLumaPos,
+                              int vbChromaH, int vbChromaPos, const bool enabled[3] )
+{
+  Banded& B = m_band;
+  B.open = false;
+  if( ( width & 7 ) || ( height & 7 ) || unitSize > 128 || unitSize % ctuSize || ( ctuSize & ( ctuSize - 1 ) ) ) return false;
+  Device& dev = Device::get();
+  size_t recTotal = 0, orgTotal = 0;
+  for( int c = 0; c < 3; c++ )
+  {
+    const int h = c ? height >> 1 : height;
+    B.rp[c] = recStride[c]; B.op[c] = orgStride[c]; B.enabled[c] = enabled[c];
+    B.rOff[c] = recTotal; recTotal += ( ( size_t ) B.rp[c] * ( h + 8 ) + 8 + 127 ) & ~( size_t ) 127;      // the layout pictureStatistics leaves behind for filterPicture
+    B.oOff[c] = orgTotal; orgTotal += ( ( size_t ) B.op[c] * h + 127 ) & ~( size_t ) 127;
+  }
+  m_res.valid = false;
+  if( m_res.gpu != dev.gpu() && m_res.dCls ) { vvhip_free( dev.ctx(), m_res.dCls ); m_res.dCls = nullptr; m_res.clsBytes = 0; }
+  if( m_res.gpu != dev.gpu() || m_res.elems < recTotal )
+  {
+    if( m_res.d ) { vvhip_free( dev.ctx(), m_res.d ); m_res.d = nullptr; }
+    void* p = nullptr;
+    dev.check( vvhip_malloc( dev.ctx(), &p, recTotal * sizeof( Pel ) + 256 ), "ALF resident planes" );
+    m_res.d = static_cast<int16_t*>( p ); m_res.elems = recTotal; m_res.gpu = dev.gpu();
+  }
+  const int unitsX = ( width + unitSize - 1 ) / unitSize, rows = ( height + unitSize - 1 ) / unitSize;
+  const size_t nCls = ( size_t ) ( width / 4 ) * ( height / 4 ) * 2, rec1 = ( size_t ) unitsX * rows * VVHIP_ALF_REC * sizeof( float );
+  B.stOff[0] = 0; B.stOff[1] = 25 * rec1; B.stOff[2] = 26 * rec1;
+  if( m_res.clsBytes < nCls )
+  {
+    if( m_res.dCls ) vvhip_free( dev.ctx(), m_res.dCls );
+    void* p = nullptr;
+    dev.check( vvhip_malloc( dev.ctx(), &p, nCls + 256 ), "ALF resident classes" );
+    m_res.dCls = static_cast<uint8_t*>( p ); m_res.clsBytes = nCls;
+  }
+  if( B.gpu != dev.gpu() || B.orgElems < orgTotal )
+  {
+    if( B.dOrg ) vvhip_free( dev.ctx(), B.dOrg );
+    void* p = nullptr;
+    dev.check( vvhip_malloc( dev.ctx(), &p, orgTotal * sizeof( Pel ) + 256 ), "ALF original planes" );
+    B.dOrg = static_cast<int16_t*>( p ); B.orgElems = orgTotal;
+  }
+  if( B.gpu != dev.gpu() || B.stBytes < 27 * rec1 )
+  {
+    if( B.dSt ) vvhip_free( dev.ctx(), B.dSt );
+    void* p = nullptr;
+    dev.check( vvhip_malloc( dev.ctx(), &p, 27 * rec1 + 256 ), "ALF statistics records" );
+    B.dSt = static_cast<char*>( p ); B.stBytes = 27 * rec1;
+  }
+  if( B.hostBytes < nCls + 27 * rec1 + 64 )
+  {
+    if( B.host ) vvhip_host_free( dev.ctx(), B.host );
+    void* p = nullptr;
+    dev.check( vvhip_host_alloc( dev.ctx(), &p, nCls + 27 * rec1 + 64 ), "ALF statistics download area" );
+    B.host = static_cast<char*>( p ); B.hostBytes = nCls + 27 * rec1 + 64;
+  }
+  while( ( int ) B.events.size() < rows ) { void* e = nullptr; dev.check( vvhip_event_create( dev.ctx(), &e ), "ALF band mark" ); B.events.push_back( e ); }
+  B.done.assign( ( size_t ) rows, 0 );
+  B.gpu = dev.gpu(); B.rows = rows; B.issued = 0; B.width = width; B.height = height; B.bitDepth = bitDepth; B.ctuSize = ctuSize; B.unitSize = unitSize; B.nCls = nCls;
+  B.vbLumaH = vbLumaH; B.vbLumaPos = vbLumaPos; B.vbChromaH = vbChromaH; B.vbChromaPos = vbChromaPos;
+  B.open = true;
+  return true;
+}
+
+bool ALFOps::statisticsBand( int unitRow, const Pel* const rec[3], const Pel* const org[3] )
+{
+  Banded& B = m_band;
+  Device& dev = Device::get();
+  if( !B.open || unitRow < 0 || unitRow >= B.rows || B.done[unitRow] || dev.gpu() != B.gpu ) return false;
+  const int unitsX = ( B.width + B.unitSize - 1 ) / B.unitSize;
+  const size_t clsAt = ( size_t ) ( unitRow * B.unitSize / 4 ) * ( B.width / 4 ) * 2;
+  for( int c = 0; c < 3; c++ )
+  {
+    const int w = c ? B.width >> 1 : B.width, h = c ? B.height >> 1 : B.height, us = c ? B.unitSize >> 1 : B.unitSize, cs = c ? B.ctuSize >> 1 : B.ctuSize;
+    const int y0 = unitRow * us, bh = std::min( us, h - y0 ), rp = B.rp[c], op = B.op[c];
+    // rows y0 - 4 .. y0 + bh + 3 of the unfiltered plane, from 4 samples left of column 0 to the last row's right border: the band and everything its statistics read;
+    // the rows two bands share arrive twice with the same values (both bands' row tasks run after the rows are final)
+    const size_t recElems = ( size_t ) rp * ( bh + 7 ) + w + 8, orgElems = ( size_t ) op * ( bh - 1 ) + w;
+    const size_t planeElems = ( size_t ) rp * ( h + 7 ) + w + 8;
+    Device::pinHost( rec[c] - ( ptrdiff_t ) 4 * rp - 4, planeElems * sizeof( Pel ) );
+    Device::pinHost( org[c], ( ( size_t ) op * ( h - 1 ) + w ) * sizeof( Pel ) );
+    int16_t* dBandRec = m_res.d + B.rOff[c] + ( size_t ) y0 * rp;                 // <-> host row y0 - 4, column -4
+    int16_t* dBandOrg = B.dOrg + B.oOff[c] + ( size_t ) y0 * op;
+    dev.check( vvhip_upload( dev.ctx(), dBandRec, rec[c] + ( ptrdiff_t ) ( y0 - 4 ) * rp - 4, recElems * sizeof( Pel ) ), "ALF rec band" );
+    dev.check( vvhip_upload( dev.ctx(), dBandOrg, org[c] + ( ptrdiff_t ) y0 * op, orgElems * sizeof( Pel ) ), "ALF org band" );
+    const int16_t* dRec = dBandRec + ( size_t ) 4 * rp + 4;                        // sample ( 0, y0 )
+    float* dSt = reinterpret_cast<float*>( B.dSt + B.stOff[c] ) + ( size_t ) unitRow * unitsX * ( c ? 1 : 25 ) * VVHIP_ALF_REC;
+    if( c == 0 ) dev.check( vvhip_alf_classify( dev.ctx(), dRec, rp, w, bh, B.bitDepth, B.vbLumaH, B.vbLumaPos, m_res.dCls + clsAt ), "vvhip_alf_classify (band)" );
+    if( !B.enabled[c] ) continue;
+    dev.check( vvhip_alf_stats_plane_units( dev.ctx(), dBandOrg, op, dRec, rp, w, bh, us, cs, c ? 5 : 7, c ? nullptr : m_res.dCls + clsAt, c ? B.vbChromaH : B.vbLumaH,
+                                            c ? B.vbChromaPos : B.vbLumaPos, nullptr, dSt ), "vvhip_alf_stats_plane_units (band)" );
+    const size_t bytes = ( size_t ) unitsX * ( c ? 1 : 25 ) * VVHIP_ALF_REC * sizeof( float );
+    dev.check( vvhip_download_async( dev.ctx(), B.host + B.nCls + B.stOff[c] + ( size_t ) unitRow * bytes, dSt, bytes ), "ALF statistics band" );
+  }
+  const int y0 = unitRow * B.unitSize, bh = std::min( B.unitSize, B.height - y0 );
+  dev.check( vvhip_download_async( dev.ctx(), B.host + clsAt, m_res.dCls + clsAt, ( size_t ) ( bh / 4 ) * ( B.width / 4 ) * 2 ), "ALF classes band" );
+  dev.check( vvhip_event_record( dev.ctx(), B.events[unitRow] ), "ALF band mark" );
+  B.done[unitRow] = 1; B.issued++;
+  return true;
+}
+
+bool ALFOps::statisticsEnd( const Pel* const rec[3], const uint8_t** cls, const float* stats[3] )
+{
+  Banded& B = m_band;
+  if( !B.open || B.issued != B.rows ) return false;
+  Device& dev = Device::get();
+  for( int u = 0; u < B.rows; u++ ) dev.check( vvhip_event_wait( dev.ctx(), B.events[u] ), "ALF band mark" );
+  *cls = reinterpret_cast<const uint8_t*>( B.host );
+  for( int c = 0; c < 3; c++ ) stats[c] = reinterpret_cast<const float*>( B.host + B.nCls + B.stOff[c] );
+  for( int c = 0; c < 3; c++ ) { m_res.rec[c] = rec[c]; m_res.stride[c] = B.rp[c]; m_res.off[c] = B.rOff[c] + ( size_t ) 4 * B.rp[c] + 4; }
+  m_res.width = B.width; m_res.height = B.height; m_res.valid = true;      // the unfiltered planes and the classes stay in HBM for filterPicture
+  B.open = false;
+  return true;
+}
+
 ALFOps::~ALFOps() {}      // (device areas are released with the process: HIP teardown order at exit is not ours to rely on)
 
 bool ALFOps::getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC, int slfStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC,

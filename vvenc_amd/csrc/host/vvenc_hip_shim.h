@@ -245,6 +245,18 @@ struct ALFOps
   // stats[c]: [numUnits][c == 0 ? 25 : 1][183]
   bool pictureStatistics( const Pel* const rec[3], const int recStride[3], const Pel* const org[3], const int orgStride[3], int width, int height, int bitDepth,
                           int ctuSize, int unitSize, int vbLumaH, int vbLumaPos, int vbChromaH, int vbChromaPos, const bool enabled[3], uint8_t* cls, float* const stats[3] );
+  // The same picture call IN BANDS, issued by the encoder's row tasks while the picture's SAO is still running elsewhere (EncoderLib/EncSlice.cpp:1135-1167: the statistics task
+  // of a CTU row starts when the row below it has left SAO, i.e. when every sample the row's statistics read is final): statisticsBegin sets the picture up (any thread),
+  // statisticsBand( u ) uploads the rows of statistics-unit row u (+ 4 border rows on either side) from the encoder's planes, runs classification + statistics of those units and
+  // requests their download into pinned host memory — all asynchronous on the CALLING thread's stream, completion marked by an event; statisticsEnd (the thread that runs
+  // EncAdaptiveLoopFilter::deriveFilter, EncoderLib/EncAdaptiveLoopFilter.cpp:1757) waits for the marks and hands out the host copies.  Same kernels on the same samples as
+  // pictureStatistics (a band starts on a CTU boundary: every position relative to the virtual boundaries is the one it has in the picture): bit-identical records.
+  // The caller serialises the three calls per object (the binding's per-ALF-object lock); bands may come in any order, each exactly once.
+  bool statisticsBegin( const int recStride[3], const int orgStride[3], int width, int height, int bitDepth, int ctuSize, int unitSize, int vbLumaH, int vbLumaPos,
+                        int vbChromaH, int vbChromaPos, const bool enabled[3] );
+  int  statisticsBands() const { return m_band.rows; }                                           // unit rows of the picture begun last
+  bool statisticsBand( int unitRow, const Pel* const rec[3], const Pel* const org[3] );
+  bool statisticsEnd( const Pel* const rec[3], const uint8_t** cls, const float* stats[3] );      // false: not every band was issued (the caller falls back to pictureStatistics)
   // EncAdaptiveLoopFilter::getBlkStatsCcAlf per chroma CTU (4:2:0): org / slf = chroma planes (slf = ALF-filtered), recLuma with a replicated border >= 2;
   // one record per chroma CTU (E[0..6][0..6], y[0..6], pixAcc), vb* / picHeight in luma samples
   bool getStatisticsCcAlf( const Pel* orgC, int orgStride, const Pel* slfC, int slfStride, const Pel* recLuma, int recStride, int widthC, int heightC, int ctuSizeC,
@@ -272,6 +284,11 @@ private:
   struct Resident { bool valid = false; int gpu = -1, width = 0, height = 0; const Pel* rec[3] = { nullptr, nullptr, nullptr }; int stride[3] = { 0, 0, 0 };
                     int16_t* d = nullptr; size_t elems = 0, off[3] = { 0, 0, 0 }; uint8_t* dCls = nullptr; size_t clsBytes = 0; };
   Resident m_res;
+  struct Banded { bool open = false; int gpu = -1, rows = 0, issued = 0, width = 0, height = 0, bitDepth = 0, ctuSize = 0, unitSize = 0, vbLumaH = 0, vbLumaPos = 0, vbChromaH = 0, vbChromaPos = 0;
+                  bool enabled[3] = { false, false, false }; int rp[3] = { 0, 0, 0 }, op[3] = { 0, 0, 0 }; size_t rOff[3] = { 0, 0, 0 }, oOff[3] = { 0, 0, 0 }, stOff[3] = { 0, 0, 0 };
+                  int16_t* dOrg = nullptr; size_t orgElems = 0; char* dSt = nullptr; size_t stBytes = 0; char* host = nullptr; size_t hostBytes = 0, nCls = 0;
+                  std::vector<void*> events; std::vector<char> done; };
+  Banded m_band;
   PinnedBuffer m_down;          // download area of filterPlane
   bool filterPlaneImpl( const Pel* src, int srcStride, const int16_t* dSrcResident, const uint8_t* dClsResident, Pel* dst, int dstStride, int width, int height, int ctuSize, int bitDepth,
                         int filterLength, const uint8_t* cls, const short* coeffSets, const short* clipSets, int numSets, const short* ctuSet, int vbCTUHeight, int vbPos );

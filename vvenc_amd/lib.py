@@ -34,6 +34,10 @@ PROTOTYPES = {
     "vvhip_host_unregister": (i32, [vp, vp]),
     "vvhip_host_alloc": (i32, [vp, C.POINTER(vp), sz]),
     "vvhip_host_free": (i32, [vp, vp]),
+    "vvhip_event_create": (i32, [vp, C.POINTER(vp)]),
+    "vvhip_event_record": (i32, [vp, vp]),
+    "vvhip_event_wait": (i32, [vp, vp]),
+    "vvhip_event_destroy": (i32, [vp, vp]),
     "vvhip_device_count": (i32, []),
     "vvhip_get_device": (i32, [vp]),
     "vvhip_make_current": (i32, [vp]),
