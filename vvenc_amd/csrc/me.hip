@@ -423,16 +423,17 @@ __device__ __forceinline__ uint32_t hadNorm( uint32_t s, int kind )
 // Returns the tile's normalised SATD in every lane of the team.  |d| < 2^23 / 128 on entry (differences of <= 12-bit values).
 // hadTeamCross: the stages across the lanes + sum, on values the lane has already transformed in its registers
 __device__ __forceinline__ uint32_t sadU32( uint32_t a, uint32_t b, uint32_t acc ) { uint32_t r; asm( "v_sad_u32 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( b ), "v"( acc ) ); return r; }
-__device__ __forceinline__ uint32_t hadTeamCross( int ( &d )[8], int r, int LT, int kind, int lane )
+// `done`: the lane-pair distances ( 8 / 4 / 2 ) whose stage the caller has already run (on packed pairs, hadTeamPkD)
+__device__ __forceinline__ uint32_t hadTeamCross( int ( &d )[8], int r, int LT, int kind, int lane, int done = 0 )
 {
   // upper lane of a pair: other - own, lower: own + other; |d| < 2^23.  The LAST stage (lane pairs i ^ 1: every team has it) adds 2^31 with its multiply (v_mad_i32_i24):
   // |coefficient| = |biased - 2^31| as unsigned numbers, so the sum of magnitudes is one v_sad_u32 per coefficient instead of subtract + max + add
   constexpr uint32_t B31 = 0x80000000u;
 #define ME_VSTAGE( CTRL, BIT ) { const int sgn = ( r & ( BIT ) ) ? -1 : 1; _Pragma( "unroll" ) \
   for( int i = 0; i < 8; i++ ) { const int t = __mul24( d[i], sgn ); d[i] = VVHIP_DPP( d[i], CTRL ) + t; } }
-  if( LT >= 16 ) ME_VSTAGE( VVHIP_DPP_MIRROR, 8 )
-  if( LT >= 8 )  ME_VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
-  if( LT >= 4 )  ME_VSTAGE( VVHIP_DPP_XOR2, 2 )
+  if( LT >= 16 && !( done & 8 ) ) ME_VSTAGE( VVHIP_DPP_MIRROR, 8 )
+  if( LT >= 8 && !( done & 4 ) )  ME_VSTAGE( VVHIP_DPP_HALF_MIRROR, 4 )
+  if( LT >= 4 && !( done & 2 ) )  ME_VSTAGE( VVHIP_DPP_XOR2, 2 )
 #undef ME_VSTAGE
   {                                                                                   // (LT >= 2 for every tile type that comes here)
     const int sgn = ( r & 1 ) ? -1 : 1;
@@ -464,16 +465,34 @@ __device__ __forceinline__ uint32_t hadTeam( int ( &d )[8], int r, int LT, int k
 // (v_pk_add_i16 / v_pk_sub_i16: sums of four differences, |d| <= 2^( bitDepth + 1 ) with bitDepth <= 10 -> 14 bits), the stage inside a dword is the unpacking itself
 // (lo + hi, lo - hi as dot products with ( 1, 1 ) / ( 1, -1 )): 20 instructions for difference + register transform instead of 32.  The stages of a Hadamard transform commute;
 // the all-plus coefficient (DC) still ends in register 0.
-__device__ __forceinline__ uint32_t hadTeamPk( const uint32_t ( &o )[4], const uint32_t ( &p )[4], int r, int LT, int kind, int lane )
+// Round 6: the first TWO stages across the lanes run on the packed pairs too — v_mov_b32_dpp + v_pk_mad_i16 ( own * ( +-1, +-1 ) + other ) per dword, 8 instructions per
+// stage instead of 16 ( v_mul_i32_i24 + v_add_u32_dpp per value ).  Range: a difference is |o - p| <= 2 ( 2^bitDepth - 1 ) ( o a bi-prediction pattern 2 org - pred, p a
+// sample; bitDepth <= 10 is checked at plan creation ) = 2046; two register stages + two lane stages sum 16 of them: 32736 <= 32767 — 16 bits hold every intermediate
+// ( tests/test_gpu_corners.py drives exactly these extremes ).
+__device__ __forceinline__ uint32_t pkMad( uint32_t a, uint32_t b, uint32_t c ) { uint32_t r; asm( "v_pk_mad_i16 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( b ), "v"( c ) ); return r; }
+__device__ __forceinline__ uint32_t hadTeamPkD( const uint32_t ( &D )[4], int r, int LT, int kind, int lane )
 {
-  const uint32_t D0 = pkSub( o[0], p[0] ), D1 = pkSub( o[1], p[1] ), D2 = pkSub( o[2], p[2] ), D3 = pkSub( o[3], p[3] );
-  const uint32_t E0 = pkAdd( D0, D1 ), E1 = pkSub( D0, D1 ), E2 = pkAdd( D2, D3 ), E3 = pkSub( D2, D3 );
-  const uint32_t F[4] = { pkAdd( E0, E2 ), pkAdd( E1, E3 ), pkSub( E0, E2 ), pkSub( E1, E3 ) };
+  const uint32_t E0 = pkAdd( D[0], D[1] ), E1 = pkSub( D[0], D[1] ), E2 = pkAdd( D[2], D[3] ), E3 = pkSub( D[2], D[3] );
+  uint32_t F[4] = { pkAdd( E0, E2 ), pkAdd( E1, E3 ), pkSub( E0, E2 ), pkSub( E1, E3 ) };
+#define ME_VSTAGE_PK( CTRL, BIT ) { const uint32_t sg = ( r & ( BIT ) ) ? 0xffffffffu : 0x00010001u; _Pragma( "unroll" ) \
+  for( int q = 0; q < 4; q++ ) F[q] = pkMad( F[q], sg, ( uint32_t ) VVHIP_DPP( F[q], CTRL ) ); }
+  int done = 0;
+  if( LT >= 16 )     { ME_VSTAGE_PK( VVHIP_DPP_MIRROR, 8 ) ME_VSTAGE_PK( VVHIP_DPP_HALF_MIRROR, 4 ) done = 8 | 4; }
+  else if( LT >= 8 ) { ME_VSTAGE_PK( VVHIP_DPP_HALF_MIRROR, 4 ) ME_VSTAGE_PK( VVHIP_DPP_XOR2, 2 ) done = 4 | 2; }
+  else if( LT >= 4 ) { ME_VSTAGE_PK( VVHIP_DPP_XOR2, 2 ) done = 2; }
+#undef ME_VSTAGE_PK
   int d[8];
 #pragma unroll
   for( int q = 0; q < 4; q++ ) { d[2 * q] = dot2( F[q], 0x00010001u, 0 ); d[2 * q + 1] = dot2( F[q], 0xffff0001u, 0 ); }
-  return hadTeamCross( d, r, LT, kind, lane );
+  return hadTeamCross( d, r, LT, kind, lane, done );
 }
+__device__ __forceinline__ uint32_t hadTeamPk( const uint32_t ( &o )[4], const uint32_t ( &p )[4], int r, int LT, int kind, int lane )
+{
+  const uint32_t D[4] = { pkSub( o[0], p[0] ), pkSub( o[1], p[1] ), pkSub( o[2], p[2] ), pkSub( o[3], p[3] ) };
+  return hadTeamPkD( D, r, LT, kind, lane );
+}
+// two ints ( each inside 16 bits ) as a packed pair
+__device__ __forceinline__ uint32_t pkInts( int lo, int hi ) { return __builtin_amdgcn_perm( ( uint32_t ) hi, ( uint32_t ) lo, 0x05040100u ); }
 
 // dot product on top of a wave-uniform constant (a scalar register as the third operand: no accumulator initialisation per output)
 __device__ __forceinline__ int dot2s( uint32_t a, uint32_t b, int c ) { int r; asm( "v_dot2_i32_i16 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( b ), "s"( c ) ); return r; }
@@ -662,14 +681,14 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       const int sl = ( c << 6 ) + ( tid & ( ( 1 << log2Lw ) - 1 ) ), r = sl & ( LT - 1 ), t = sl >> log2LT;
       const int tyi = t >> log2TX, txi = t & ( tilesX - 1 );
       // the lane's original rows (16x16_fast: their 2x2 averages, RdCost.cpp:1138-1160)
-      uint32_t o4[4] = { 0, 0, 0, 0 };
-      int aoA[4] = { 0, 0, 0, 0 }, aoB[4] = { 0, 0, 0, 0 };
+      uint32_t o4[4] = { 0, 0, 0, 0 };                                              // (16x16_fast: the eight averages as packed pairs)
       if( kind == TK_16F )
       {
         const uint32_t po = ( uint32_t ) ( __mul24( y0 + tyi * 16 + 2 * r, os ) + txi * 16 ) * 2u, po1 = po + ( uint32_t ) os * 2u;
         const u32x4 c0v = ld16o( orgB, po ), c1v = ld16o( orgB, po + 16 ), e0 = ld16o( orgB, po1 ), e1 = ld16o( orgB, po1 + 16 );
-        { const uint32_t oa[4] = { c0v.x, c0v.y, c0v.z, c0v.w }, ob[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( oa, ob, aoA ); }
-        { const uint32_t oa[4] = { c1v.x, c1v.y, c1v.z, c1v.w }, ob[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( oa, ob, aoB ); }
+        int ao[4];
+        { const uint32_t oa[4] = { c0v.x, c0v.y, c0v.z, c0v.w }, ob[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( oa, ob, ao ); o4[0] = pkInts( ao[0], ao[1] ); o4[1] = pkInts( ao[2], ao[3] ); }
+        { const uint32_t oa[4] = { c1v.x, c1v.y, c1v.z, c1v.w }, ob[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( oa, ob, ao ); o4[2] = pkInts( ao[0], ao[1] ); o4[3] = pkInts( ao[2], ao[3] ); }
       }
       else if( rows4 )
       {
@@ -697,20 +716,18 @@ __device__ __forceinline__ void stageBody( const MePlanes& P, const MeArgs& a, c
       uint32_t sres;
       if( kind == TK_16F )
       {
-        int d[8];
+        uint32_t D[4];                                                              // original - prediction averages, packed pairs
         const int16_t* tv = tvp + txi * 16;
         uint32_t pa[4], pb[4]; int ap[4];
         predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r, syk, anyFrac, vt, headRoom, maxPk, pa );
         predRow<K0, K1>( tv, ldsPitch, tyi * 16 + 2 * r + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
-#pragma unroll
-        for( int i = 0; i < 4; i++ ) d[i] = aoA[i] - ap[i];
+        D[0] = pkSub( o4[0], pkInts( ap[0], ap[1] ) ); D[1] = pkSub( o4[1], pkInts( ap[2], ap[3] ) );
         predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r, syk, anyFrac, vt, headRoom, maxPk, pa );
         predRow<K0, K1>( tv + 8, ldsPitch, tyi * 16 + 2 * r + 1, syk, anyFrac, vt, headRoom, maxPk, pb );
         avgInts( pa, pb, ap );
-#pragma unroll
-        for( int i = 0; i < 4; i++ ) d[4 + i] = aoB[i] - ap[i];
-        sres = hadTeam( d, r, GEN ? LT : 8, TK_16F, lane );
+        D[2] = pkSub( o4[2], pkInts( ap[0], ap[1] ) ); D[3] = pkSub( o4[3], pkInts( ap[2], ap[3] ) );
+        sres = hadTeamPkD( D, r, GEN ? LT : 8, TK_16F, lane );
       }
       else
       {
@@ -964,7 +981,7 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
     const int tyi = t >> log2TX, txi = t & ( tilesX - 1 );
     const int16_t* qa = planeL[it.org_plane] + it.org_off + ( ptrdiff_t ) ( tyi * PH ) * os + txi * PW;
     const int16_t* qb = planeL[it.cur_plane] + it.cur_off + ( ptrdiff_t ) ( tyi * PH ) * cs + txi * PW;
-    int d[8]; uint32_t sad = 0, sres;
+    uint32_t sad = 0, sres;
     if( GEN && kind == TK_2x2 )
     {
       // xCalcHADs2x2 (RdCost.cpp:1006-1026): one lane per tile
@@ -981,16 +998,14 @@ __device__ __forceinline__ void itemBody( const MePlanes& P, const MeArgs& a, in
         const int16_t* p0 = qa + ( ptrdiff_t ) ( 2 * r ) * os; const int16_t* p1 = qb + ( ptrdiff_t ) ( 2 * r ) * cs;
         const u32x4 a0 = ld16( p0 ), a1 = ld16( p0 + 8 ), b0 = ld16( p0 + os ), b1 = ld16( p0 + os + 8 );
         const u32x4 c0 = ld16( p1 ), c1 = ld16( p1 + 8 ), e0 = ld16( p1 + cs ), e1 = ld16( p1 + cs + 8 );
-        int ao[4], ac[4];
+        int ao[4], ac[4]; uint32_t D[4];
         { const uint32_t x[4] = { a0.x, a0.y, a0.z, a0.w }, y[4] = { b0.x, b0.y, b0.z, b0.w }; avgInts( x, y, ao ); }
         { const uint32_t x[4] = { c0.x, c0.y, c0.z, c0.w }, y[4] = { e0.x, e0.y, e0.z, e0.w }; avgInts( x, y, ac ); }
-#pragma unroll
-        for( int i = 0; i < 4; i++ ) d[i] = ao[i] - ac[i];
+        D[0] = pkInts( ao[0] - ac[0], ao[1] - ac[1] ); D[1] = pkInts( ao[2] - ac[2], ao[3] - ac[3] );
         { const uint32_t x[4] = { a1.x, a1.y, a1.z, a1.w }, y[4] = { b1.x, b1.y, b1.z, b1.w }; avgInts( x, y, ao ); }
         { const uint32_t x[4] = { c1.x, c1.y, c1.z, c1.w }, y[4] = { e1.x, e1.y, e1.z, e1.w }; avgInts( x, y, ac ); }
-#pragma unroll
-        for( int i = 0; i < 4; i++ ) d[4 + i] = ao[i] - ac[i];
-        sres = hadTeam( d, r, GEN ? LT : 8, TK_16F, lane );
+        D[2] = pkInts( ao[0] - ac[0], ao[1] - ac[1] ); D[3] = pkInts( ao[2] - ac[2], ao[3] - ac[3] );
+        sres = hadTeamPkD( D, r, GEN ? LT : 8, TK_16F, lane );
       }
       else
       {
