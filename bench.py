@@ -350,9 +350,9 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         "value": frames / dt, "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": 1000.0 * dt / steps,
         "host_enqueue_us_per_step": {"p50": round(enq_us[len(enq_us) // 2], 1), "p90": round(enq_us[int(len(enq_us) * 0.9)], 1), "max": round(enq_us[-1], 1),
                                      "drain_ms_after_last_enqueue": round(1000.0 * (t0 + dt_local - enq[-1]), 3)},
-        "config": {"workload": "BASELINE configs[%d]: hot-path work lists RECORDED from the reference encoder (%dx%d 10-bit synthetic clip, 65 frames, preset faster; one picture per temporal layer), "
+        "config": {"workload": "%shot-path work lists RECORDED from the reference encoder (%dx%d 10-bit synthetic clip, 65 frames, preset faster; one picture per temporal layer), "
                                "replayed resident in HBM: a step = one picture's integer-ME SAD windows + sub-pel SATD stages + table calls + fused TU transform/quant lists + DMVR lists on 5 HIP streams; "
-                               "steps follow the GOP's 1:1:2:4:8:16 layer mix from the key picture on" % (1 if width == 1920 else 2, width, height),
+                               "steps follow the GOP's 1:1:2:4:8:16 layer mix from the key picture on" % ("BASELINE configs[1]: " if ( width, height ) == ( 1920, 1080 ) else ( "BASELINE configs[2]'s geometry: " if ( width, height ) == ( 3840, 2160 ) else "(test size) " ), width, height),
                    "layer_pocs": {str(l): p for l, p in LAYER_POCS.items()},
                    "pictures_per_32_steps_by_layer": {str(l): GOP_WEIGHT[l] for l in GOP_WEIGHT},
                    "pictures_in_the_timed_steps_by_layer": {str(l): lay_seq.count(l) for l in range(6)},
