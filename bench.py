@@ -38,6 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # a picture's five launch groups go to five HIP streams: the runtime maps streams onto 4 hardware queues by default (two groups would share one and serialize);
 # measured on the recorded 1080p lists: 2 / 4 / 8 queues -> 8 519 / 12 036 / 12 326 pictures/s
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # multi-process GPU work on this pool: dmabuf IPC only (RCCL's buffer sharing fails with the legacy mode)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -24,6 +24,7 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # (dmabuf IPC: what RCCL's buffer sharing needs on this pool)
         if backend is None:
             # $VVHIP_DIST_BACKEND=gloo + $VVHIP_SHARE_DEVICE=1: every rank on GPU 0, collectives through gloo — how the N>1 path is exercised on a 1-GPU box (tests)
             backend = os.environ.get("VVHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
