@@ -13,8 +13,10 @@ for one picture of each temporal layer.  The lists + the pictures' planes are up
     TU lists             fused xT -> needRdoq -> quant -> dequant -> xIT -> SSE, luma + chroma, DCT-2 / DST-7, 4..64
     DMVR lists           bilinear prediction + 25-point search + error surface per sub-block
 on five HIP streams.  N GPUs: rank r replays position k + 32 r / N of the same cycle at its step k; the reconstructed picture a sharded encoder would hand to the other ranks is
-broadcast (RCCL) every --exchange-every steps inside the timed region, overlapped; value = N * K pictures / max-over-ranks time, "weak".  Reported next to it for N > 1:
-no_exchange (kernel scaling alone) and exchange_per_gop_cycle (one broadcast per 32 steps and rank: an encoder's cadence).
+broadcast (RCCL) every --exchange-every steps inside the timed region, overlapped; value = N * K pictures / max-over-ranks time, "weak".  The default cadence is ONE broadcast
+per GOP cycle of 32 steps and rank: north_star's sharding by GOPs — every rank works on its own GOP chunk, the chunk's key picture is the one reference that crosses ranks
+(DESIGN 7).  Reported next to it for N > 1: no_exchange (kernel scaling alone) and exchange_every_reference (a broadcast every 2 steps: the case in which the pictures of ONE
+GOP are spread over the ranks and all 16 reference pictures of the cycle cross — the worst case, `value`'s cadence up to round 5).
 
 Objects of the result (rank 0; each can be switched off; a failure is reported in place and never costs the headline).  In the compact line: a summary of each.
   roofline      dominant kernel: achieved = algorithmic bytes (SURVEY 8d per batch unit) / launch time from this run's rocprofv3 kernel trace, frac = achieved / 8 TB/s; traffic =
@@ -260,9 +262,10 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
                 wl.run_lanes() if lanes else wl.run()
             torch.cuda.synchronize()
             layer_ms[l] = 1000.0 * (time.perf_counter() - t1) / n
-    # N > 1: the same steps (a) without the picture exchange = kernel scaling alone, (b) with ONE broadcast per GOP cycle of 32 steps and rank = an encoder's cadence when every rank
-    # encodes its own GOP chunk and only the chunk's key picture crosses ranks; the timed region above (--exchange-every, default 2) is the worst case: every reference picture crosses
-    no_exchange = per_cycle = None
+    # N > 1: the same steps (a) without the picture exchange = kernel scaling alone, (b) with ONE broadcast per GOP cycle of 32 steps and rank = the cadence when every rank
+    # works on its own GOP chunk and only the chunk's key picture crosses ranks (= the timed region above at the default --exchange-every 32), (c) with a broadcast every 2 steps =
+    # the worst case: the pictures of one GOP spread over the ranks, every reference picture of the cycle crosses
+    no_exchange = per_cycle = every_ref = None
     if ex is not None:
         def timed(every):
             sharding.barrier()
@@ -280,7 +283,10 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         no_exchange = {"value": steps * world / dtn, "unit": "frames/s", "ms_per_step": 1000.0 * dtn / steps, "note": "same steps without the reference-picture broadcast: kernel scaling alone"}
         dtc = timed(32)
         per_cycle = {"value": steps * world / dtc, "unit": "frames/s", "ms_per_step": 1000.0 * dtc / steps, "every_steps": 32,
-                     "note": "same steps with one reference-picture broadcast per GOP cycle (32 steps) and rank: the cadence of N ranks encoding their own GOP chunks"}
+                     "note": "same steps with one reference-picture broadcast per GOP cycle (32 steps) and rank: the cadence of N ranks working on their own GOP chunks"}
+        dtr = timed(2)
+        every_ref = {"value": steps * world / dtr, "unit": "frames/s", "ms_per_step": 1000.0 * dtr / steps, "every_steps": 2,
+                     "note": "same steps with a reference-picture broadcast every 2 steps: the pictures of ONE GOP spread over the ranks, all 16 reference pictures of the cycle cross (worst case)"}
     # (the per-kernel pass runs AFTER the timed region: its serialized launches and host synchronisations leave idle gaps in which the GPU's clocks fall back, and a timed region of
     #  K = 20 steps is 1.4 ms — too short to ramp them up again: a run that timed right behind this pass read 80.5 us per step where the per-layer times said 69)
     # ---- per-kernel durations: every layer's launches serialized on one stream, HIP events around each kernel (inside the library for the plan's kernels); outside the timed region
@@ -389,9 +395,10 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         out["exchange"] = {"pictures": ex_count_timed, "bytes_per_picture": int(sum(p.numel() * 2 for p in ex.slots[0])), "collective": "broadcast", "backend": backend, "overlapped": True, "every_steps": args.exchange_every}
         if backend == "nccl":          # (a fabric number only on RCCL: over gloo the broadcast goes through host memory and says nothing about xGMI)
             out["exchange"]["exchange_ms_per_picture"] = round(1000.0 * (dt - (steps * world / no_exchange["value"])) / max(1, ex_count_timed), 4) if no_exchange else None
-        out["no_exchange"], out["exchange_per_gop_cycle"] = no_exchange, per_cycle
-        out["n_gpu_forms"] = "value = worst-case exchange (every reference picture crosses ranks, --exchange-every %d); exchange_per_gop_cycle = an encoder's cadence with one GOP chunk per rank " \
-                             "(THE N-GPU form of the metric for this path, DESIGN 7); no_exchange = kernel scaling alone" % args.exchange_every
+        out["no_exchange"], out["exchange_per_gop_cycle"], out["exchange_every_reference"] = no_exchange, per_cycle, every_ref
+        out["n_gpu_forms"] = "value: --exchange-every %d (default 32 = one GOP chunk per rank, the chunk's key picture crosses ranks: north_star's sharding by GOPs, DESIGN 7); " \
+                             "exchange_per_gop_cycle = the same cadence timed again; exchange_every_reference = a broadcast every 2 steps (one GOP spread over the ranks: worst case, " \
+                             "`value`'s cadence up to round 5); no_exchange = kernel scaling alone" % args.exchange_every
 
     # ---- kernels
     alg = {l: {"ME_stage": None, "ME_int": None, "ME_item": None, "TU": workloads[l].alg_bytes_tu, "DMVR": workloads[l].alg_bytes_dmvr} for l in workloads}
@@ -440,8 +447,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--streams", type=int, default=5, help="HIP streams a picture's independent launch groups are issued on: 5 = refinement stages / integer windows / table calls / TU / DMVR, "
                                                            "3 = motion-search plan / TU / DMVR, 1 = serialized")
-    ap.add_argument("--exchange-every", type=int, default=2, help="N > 1: one reference-picture broadcast every this many steps (a step is one picture; default 2: 16 of the 32 "
-                    "pictures of a random-access GOP cycle, temporal layers 0-4, are references of other pictures and have to reach the other GPUs, the 16 of layer 5 do not)")
+    ap.add_argument("--exchange-every", type=int, default=32, help="N > 1: one reference-picture broadcast every this many steps (a step is one picture).  Default 32: every rank works "
+                    "on its own GOP chunk and the chunk's key picture is the one reference that crosses ranks; 2 = the pictures of one GOP spread over the ranks (16 of the 32 pictures "
+                    "of a random-access GOP cycle, temporal layers 0-4, are references of other pictures) — reported as exchange_every_reference either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-mctf", action="store_true")

@@ -1085,6 +1085,7 @@ def test_bench_multi_rank_path_on_one_device(tmp_path):
     # one broadcast per step inside the timed region (--exchange-every 1); over gloo no fabric figure is printed; the two other N-GPU points are reported next to `value`
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["exchange"]["pictures"] == 6 and d["exchange"]["backend"] == "gloo" and "exchange_ms_per_picture" not in d["exchange"], d
     assert d["no_exchange"]["value"] > 0 and d["exchange_per_gop_cycle"]["value"] > 0 and d["exchange_per_gop_cycle"]["every_steps"] == 32, d
+    assert d["exchange_every_reference"]["value"] > 0 and d["exchange_every_reference"]["every_steps"] == 2, d
     assert d["parity"]["status"] == "bit-exact", d["parity"]
     # round 6: a broadcast WITH A CONSUMER — the steps again with leg C, a filtered picture's reference originals arriving through the exchange from the
     # neighbouring rank; the fields computed from the received planes equal the fields from the rank's own copies, and a corrupted slot is noticed (self-test on every consumer)

@@ -126,7 +126,7 @@ def compact(out, detail_path):
     # ---- N > 1
     if "exchange" in out:
         line["exchange"] = _pick(out["exchange"], ("pictures", "bytes_per_rank", "collective", "every_steps", "backend", "exchange_ms_per_picture"))
-    for k in ("no_exchange", "exchange_per_gop_cycle"):
+    for k in ("no_exchange", "exchange_per_gop_cycle", "exchange_every_reference"):
         if isinstance(out.get(k), dict):
             line[k] = _pick(out[k], ("value", "ms_per_step", "every_steps"))
     if isinstance(out.get("e2e_instances"), dict):
@@ -169,7 +169,7 @@ def compact(out, detail_path):
                     line[k].pop(q, None)
         note("e2e side rows")
         s = dumps()
-    for drop in ("e2e_instances", "exchange", "no_exchange", "exchange_per_gop_cycle", "config3_medium_4k", "cpu_baseline_4k", "parity_4k", "roofline_4k", "e2e_4k", "e2e", "value_note"):
+    for drop in ("e2e_instances", "exchange", "exchange_per_gop_cycle", "no_exchange", "exchange_every_reference", "config3_medium_4k", "cpu_baseline_4k", "parity_4k", "roofline_4k", "e2e_4k", "e2e", "value_note"):
         if len(s) <= TARGET_BYTES:
             break
         if line.pop(drop, None) is not None:
