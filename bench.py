@@ -37,9 +37,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-# a picture's five launch groups go to five HIP streams: the runtime maps streams onto 4 hardware queues by default (two groups would share one and serialize);
-# measured on the recorded 1080p lists: 2 / 4 / 8 queues -> 8 519 / 12 036 / 12 326 pictures/s
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# a picture's five launch groups go to five HIP streams: the runtime deals streams onto 4 hardware queues by default (two groups would share one and serialize);
+# measured on the recorded 1080p lists: 2 / 4 / 8 queues -> 8 519 / 12 036 / 12 326 pictures/s.  Round 6: streams are dealt IN CREATION ORDER, and every lane used to create two
+# (a torch stream + its context's own): with 8 queues the DMVR lane shared the stage lane's queue.  Lanes now run on their contexts' own streams (HotPath.fork): one process =
+# default stream + base context + 5 lanes + the MCTF lane = 8 streams on 8 queues, none shared: 15.1 -> 16.2 k pictures/s, GOP cycle with leg C 3.53 -> 3.30 ms
+# (profiles/r06_hw_queues.log).  N > 1 adds the collective library's stream and the two exchange streams: 12 queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "8")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # multi-process GPU work on this pool: dmabuf IPC only (RCCL's buffer sharing fails with the legacy mode)
 
 import numpy as np  # noqa: E402
@@ -71,15 +74,17 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     # ---- lanes: the refinement stages, integer windows and table calls of the plan, the TU lists and the DMVR lists of a picture are independent work: five HIP streams
     lanes, streams = None, []
     if args.streams > 1:
-        streams = [torch.cuda.Stream() for _ in range(5 if args.streams >= 5 else 3)]
-        lanes = [hp.fork(s) for s in streams]
+        # (lanes on their contexts' own streams unless $VVHIP_BENCH_TORCH_STREAMS=1: one HIP stream per lane, see HotPath.fork)
+        own = os.environ.get("VVHIP_BENCH_TORCH_STREAMS") != "1"
+        lanes = [hp.fork(None if own else torch.cuda.Stream()) for _ in range(5 if args.streams >= 5 else 3)]
+        streams = [l.stream for l in lanes]
         for wl in workloads.values():
             wl.bind_lanes(lanes)
 
     # ---- north-star leg C at the GOP's cadence (tools/bench_mctf.py): the cycle's four filtered pictures resident, issued on a SIXTH stream by the steps that replay them
     mc = None
     if not args.no_mctf and (world == 1 or (width, height) == (args.width, args.height)):
-        mc = BM.MctfCadence(hp, width, height, lane=hp.fork(torch.cuda.Stream()) if args.streams > 1 else hp)
+        mc = BM.MctfCadence(hp, width, height, lane=hp.fork(None if os.environ.get("VVHIP_BENCH_TORCH_STREAMS") != "1" else torch.cuda.Stream()) if args.streams > 1 else hp)
     # N > 1: a filtered picture's reference originals ARRIVE through the picture exchange — the rank next to the one that filters the picture owns them (it ingested them), fills
     # the slot and every rank joins the broadcast; the filtering rank waits for it and runs the search against the RECEIVED planes: a broadcast with a consumer
     mex, mex_count, mex_last = None, [0], {}

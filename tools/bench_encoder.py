@@ -184,7 +184,7 @@ def replay_medium_4k(hp, streams=5):
     from vvenc_amd.replay import RecordedWorkload
     pics, info = prepare_recordings(3840, 2160, 9, [4], tag="medium", threads=16)
     wl = RecordedWorkload(hp, pics[4])
-    lanes = [hp.fork(torch.cuda.Stream()) for _ in range(streams)]
+    lanes = [hp.fork() for _ in range(streams)]          # (lanes on their contexts' own streams: one HIP stream per lane, HotPath.fork)
     wl.bind_lanes(lanes)
     for _ in range(3):
         wl.run_lanes()

@@ -1298,6 +1298,16 @@ int meLevel( vvhip_ctx* ctx, const int16_t* d_org, int os, int bsd, int width, i
   VVHIP_LAUNCH_CHECK( ctx );
   meMark( ctx, 2 );
   const int diagLen = nbx < nby ? nbx : nby;
+#ifdef VVHIP_DEV_KNOBS      // (development aid, changes the results: no phase B at all — what the near-empty launches of phase B cost a GOP cycle, tools/exp/small_launches.sh)
+  static const int noPhaseB = getenv( "VVHIP_MCTF_NO_PHASE_B" ) ? atoi( getenv( "VVHIP_MCTF_NO_PHASE_B" ) ) : 0;      // 1: neither launch, 2: the neighbour tests but not the resolution
+  if( noPhaseB == 1 ) { meMark( ctx, 3 ); }
+  else if( noPhaseB == 2 && fixBlocks )
+  {
+    hipLaunchKernelGGL( meNeighbourKernel, dim3( nbx * nby, nRefs ), dim3( 64 ), 0, ctx->stream, g, R, nbx, mvsW, st ? st + 8 : nullptr, 1, fixBlocks );
+    meMark( ctx, 3 );
+  }
+  else
+#endif
   if( fixBlocks )
   {
     // (the granule area holds, per reference: one FixRec per block, three block lists, the stamps and the counts: 52 bytes per block + 16 <= 7 granules per block)

@@ -81,9 +81,12 @@ class HotPath:
         self.ctx = ctx
         self.use_torch_stream()
 
-    def fork(self, stream):
+    def fork(self, stream=None):
         """a second context on the same device, bound for good to `stream` (a torch.cuda.Stream): launches of independent work lists go to their own streams without any
-        per-call stream switching on the host (what the binding's worker threads do with their per-thread contexts)"""
+        per-call stream switching on the host (what the binding's worker threads do with their per-thread contexts).
+        stream=None: the lane IS the new context's own stream (wrapped as a torch ExternalStream for events and waits) — no second stream per lane: the runtime deals HIP
+        streams onto $GPU_MAX_HW_QUEUES hardware queues in creation order, and a lane that shares its queue with another busy lane is serialized behind it
+        (profiles/r06_hw_queues.log)"""
         o = object.__new__(HotPath)
         o.L, o.device = self.L, self.device
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -92,6 +95,10 @@ class HotPath:
         if rc != 0:
             raise VVHipError("vvhip_create failed (%d): %s" % (rc, self.L.vvhip_last_error(None).decode()))
         o.ctx = ctx
+        if stream is None:
+            with torch.cuda.device(self.device):
+                o.stream = torch.cuda.ExternalStream(int(self.L.vvhip_get_stream(ctx)))
+            return o
         o.stream = stream
         o._ck(self.L.vvhip_set_stream(ctx, C.c_void_p(stream.cuda_stream)))
         return o
