@@ -41,8 +41,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # measured on the recorded 1080p lists: 2 / 4 / 8 queues -> 8 519 / 12 036 / 12 326 pictures/s.  Round 6: streams are dealt IN CREATION ORDER, and every lane used to create two
 # (a torch stream + its context's own): with 8 queues the DMVR lane shared the stage lane's queue.  Lanes now run on their contexts' own streams (HotPath.fork): one process =
 # default stream + base context + 5 lanes + the MCTF lane = 8 streams on 8 queues, none shared: 15.1 -> 16.2 k pictures/s, GOP cycle with leg C 3.53 -> 3.30 ms
-# (profiles/r06_hw_queues.log).  N > 1 adds the collective library's stream and the two exchange streams: 12 queues.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "8")
+# (profiles/r06_hw_queues.log).  Leg C's jobs — independent pictures — are dealt over TWO lanes: a job is a chain of ~23 dependent launches whose boundaries cost ~11 us each
+# under load, one lane was the combined cycle's critical path (3.30 -> 3.0-3.1 ms per GOP cycle with two; four change nothing more): 9 streams, 10 queues.  N > 1 adds the
+# collective library's stream and the two exchange streams: 12 queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "10")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # multi-process GPU work on this pool: dmabuf IPC only (RCCL's buffer sharing fails with the legacy mode)
 
 import numpy as np  # noqa: E402
@@ -81,10 +83,12 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
         for wl in workloads.values():
             wl.bind_lanes(lanes)
 
-    # ---- north-star leg C at the GOP's cadence (tools/bench_mctf.py): the cycle's four filtered pictures resident, issued on a SIXTH stream by the steps that replay them
+    # ---- north-star leg C at the GOP's cadence (tools/bench_mctf.py): the cycle's four filtered pictures resident, issued on two more streams (the cycle's four jobs in turn) by the steps that replay them
     mc = None
     if not args.no_mctf and (world == 1 or (width, height) == (args.width, args.height)):
-        mc = BM.MctfCadence(hp, width, height, lane=hp.fork(None if os.environ.get("VVHIP_BENCH_TORCH_STREAMS") != "1" else torch.cuda.Stream()) if args.streams > 1 else hp)
+        n_ml = max(1, int(os.environ.get("VVHIP_BENCH_MCTF_LANES", "2"))) if (args.streams > 1 and world == 1) else 1
+        mk = lambda: hp.fork(None if os.environ.get("VVHIP_BENCH_TORCH_STREAMS") != "1" else torch.cuda.Stream())
+        mc = BM.MctfCadence(hp, width, height, lane=mk() if args.streams > 1 else hp, more_lanes=[mk() for _ in range(n_ml - 1)])
     # N > 1: a filtered picture's reference originals ARRIVE through the picture exchange — the rank next to the one that filters the picture owns them (it ingested them), fills
     # the slot and every rank joins the broadcast; the filtering rank waits for it and runs the search against the RECEIVED planes: a broadcast with a consumer
     mex, mex_count, mex_last = None, [0], {}
@@ -182,7 +186,7 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
     ex_count_timed = ex_count[0] - ex_before
 
     # ---- the same K steps WITH leg C: the steps that replay the POC-32 / 16 / 8 / 24 pictures also queue that picture's MCTF (4 / 4 / 2 / 2 motion estimations + the filter
-    #      of Y, U, V) on the sixth stream — `value_with_mctf`; and whole GOP cycles (the cadence's stable figure: 12 estimations + 4 filters per 32 steps)
+    #      of Y, U, V) on the MCTF lanes — `value_with_mctf`; and whole GOP cycles (the cadence's stable figure: 12 estimations + 4 filters per 32 steps)
     mctf_region = None
     if mc is not None and world > 1:
         # N > 1: K steps with leg C, references through the exchange (barrier + max over ranks like the headline region); then the parity of what was computed from RECEIVED planes
@@ -244,9 +248,9 @@ def replay_pass(args, hp, rank, world, width, height, steps, warmup):
                        "mctf_jobs_in_the_timed_steps": [BM.job_of_step(i)[1] for i in range(steps) if BM.job_of_step(i)],
                        "gop_cycle": {"value": 32.0 / dtc, "ms_per_step": 1000.0 * dtc / 32.0, "ms_per_cycle": 1000.0 * dtc, "ms_per_cycle_without_mctf": 1000.0 * dtc0,
                                      "value_without_mctf": 32.0 / dtc0, "cycles": ncyc,
-                                     "note": "whole GOP cycles of 32 steps in step order: 12 motion estimations (4 / 4 / 2 / 2 references) + 4 bilateral filters of Y, U, V per cycle on the sixth stream"},
+                                     "note": "whole GOP cycles of 32 steps in step order: 12 motion estimations (4 / 4 / 2 / 2 references) + 4 bilateral filters of Y, U, V per cycle, the four jobs dealt over the two MCTF lanes"},
                        "note": "the timed region's K steps again with north-star leg C issued at the GOP's cadence (tools/bench_mctf.py: the steps replaying POC 32 / 16 / 8 / 24 queue that picture's "
-                               "MCTF search + filter on a sixth stream; originals of the same clip, resident); `value` is the same steps without it"}
+                               "MCTF search + filter on the two MCTF lanes (independent pictures' jobs in turn); originals of the same clip, resident); `value` is the same steps without it"}
 
     # extras (not `value`): the same K steps serialized on one stream; per layer, the multi-stream time of one picture (-> the GOP-weighted rate); N > 1: without the picture exchange
     serial = None

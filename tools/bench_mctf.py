@@ -57,13 +57,14 @@ def apply_alg_bytes(width, height, n_refs, unit=UNIT, taps=6):
 class MctfCadence:
     """the four filtered pictures of a GOP cycle resident on the device (originals of the encoded clip: tests/e2e_fps.synth_clip), issued asynchronously on their own lane"""
 
-    def __init__(self, hp, width, height, lane=None):
+    def __init__(self, hp, width, height, lane=None, more_lanes=()):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import torch
         import e2e_fps
         from vvenc_amd.hotpath import MV_DTYPE
         self.hp, self.width, self.height = hp, width, height
         self.lane = lane if lane is not None else hp
+        self.lanes = [self.lane] + list(more_lanes)                     # the cadence deals the cycle's jobs over these in turn (issue_step); everything else runs on the first
         y, u, v = e2e_fps.synth_clip(width, height, 65)
         pocs = sorted({p for _, poc, refs, _ in JOBS for p in (poc,) + refs})
         self.np_planes = {p: (y[p], u[p], v[p]) for p in pocs}
@@ -164,7 +165,7 @@ class MctfCadence:
     def issue_step(self, s):
         job = job_of_step(s)
         if job is not None:
-            self.issue(job)
+            self.issue(job, ctx=self.lanes[JOBS.index(job) % len(self.lanes)])
         return job
 
     # ---- algorithmic bytes (per GOP cycle and per class), from the library's scored-candidate counters

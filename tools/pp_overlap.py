@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""experiment: P pictures in flight — the recorded pictures' five launch groups on P independent sets of streams (step s goes to set s mod P) against one set (bench.py's step)"""
+"""experiment: P pictures in flight — the recorded pictures' five launch groups on P independent sets of streams (step s goes to set s mod P) against one set (bench.py's step).
+   python tools/pp_overlap.py W H QUEUES            all configurations in one process (round-6 form: lanes = torch streams + the contexts' own: queue sharing confounds it)
+   python tools/pp_overlap.py W H QUEUES P PER      ONE configuration per process, lanes on their contexts' own streams (one HIP stream per lane; QUEUES >= P * PER + 2)"""
 import os
 import sys
 import time
@@ -20,8 +22,9 @@ def main():
     hp = HotPath("cuda:0")
     pics, _ = prepare_recordings(w, h, 65, sorted(LAYER_POCS.values()))
     wls = {l: RecordedWorkload(hp, pics[p], unique_bytes=False) for l, p in LAYER_POCS.items()}
-    for P, per in ((1, 5), (2, 5), (2, 3), (4, 3), (4, 5), (1, 5)):
-        sets = [[hp.fork(torch.cuda.Stream()) for _ in range(per)] for _ in range(P)]
+    one = len(sys.argv) > 5
+    for P, per in (((int(sys.argv[4]), int(sys.argv[5])),) if one else ((1, 5), (2, 5), (2, 3), (4, 3), (4, 5), (1, 5))):
+        sets = [[hp.fork(None if one else torch.cuda.Stream()) for _ in range(per)] for _ in range(P)]
         calls = [{l: list(wl.bind_lanes(sets[k])) for l, wl in wls.items()} for k in range(P)]
 
         def cycle():
