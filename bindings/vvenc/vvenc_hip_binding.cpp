@@ -689,12 +689,13 @@ void alfBeginPicture( const void* owner, int /*poc*/ )
 std::atomic<uint64_t> g_alfPictures{ 0 };
 // The whole-picture statistics call runs inside the serial part of the ALF stage (deriveFilter): one upload + three launches + a download per picture against CPU work that is
 // spread over the worker threads.  It pays when the pool is saturated — measured: 1080p (510 CTUs) with 2 / 4 threads +16 / +14 %, 4K (2040 CTUs) with 8 threads +8...13 %,
-// 1080p with 8 threads +-0 (profiles/r02_e2e_encoder_fps.md, r03) — so the hook was taken from 100 CTUs per encoder thread on.  Round 6: the picture goes to the device in
-// bands from the row tasks (alfRow below) and the serial part is 0.16 ms instead of 7.5 ms per 1080p picture (profiles/r06_alf_bands.log) — the rule stays for the tiny pictures
-// only: $VVHIP_ALF_MIN_CTUS_PER_THREAD, default 50 (1080p with 8 threads: on).
+// 1080p with 8 threads +-0 (profiles/r02_e2e_encoder_fps.md, r03) — so the hook is taken from $VVHIP_ALF_MIN_CTUS_PER_THREAD CTUs per encoder thread on (default 100).
+// Round 6: the picture goes to the device in bands from the row tasks (alfRow below) and the serial part is 0.16 ms instead of 7.5 ms per 1080p picture
+// (profiles/r06_alf_bands.log).  The rule stays: with the serial part gone the hook is neutral at 1080p / 8 threads on a quiet host (48.8 against 48.5 fps, eight runs each) and
+// loses on a loaded one (47.3 against 48.3, five runs each, tools/exp/e2e_queues_ab.py: the row tasks' uploads compete with the encoder's own memory traffic).
 bool alfPictureOn( int numCtusInPic, int numThreads )
 {
-  static const int minPerThread = []{ const char* e = getenv( "VVHIP_ALF_MIN_CTUS_PER_THREAD" ); return e ? atoi( e ) : 50; }();
+  static const int minPerThread = []{ const char* e = getenv( "VVHIP_ALF_MIN_CTUS_PER_THREAD" ); return e ? atoi( e ) : 100; }();
   return numCtusInPic >= minPerThread * ( numThreads > 0 ? numThreads : 1 );
 }
 // Statistics in bands: the statistics task of CTU row y runs when row y + 1 has left SAO (EncSlice.cpp:1135-1141) — every sample the row's statistics read is

@@ -118,6 +118,11 @@ print(json.dumps(out))
 
 
 def run(cfg, timeout=3000, env=None):
+    # the encoder process runs with the runtime's own number of hardware queues: bench.py's setting is for ITS five-plus-two replay streams, and the encoder measured slower with
+    # it (1080p, 8 threads, five alternating runs: 4 queues 48.7 fps, 8: 47.3, 10: 47.4; tools/exp/e2e_queues_ab.py).  $VVHIP_E2E_KEEP_QUEUES=1: pass the variable through.
+    env = dict(os.environ if env is None else env)
+    if env.get("VVHIP_E2E_KEEP_QUEUES") != "1":
+        env.pop("GPU_MAX_HW_QUEUES", None)
     r = subprocess.run([sys.executable, "-c", WORKER, json.dumps(cfg)], capture_output=True, text=True, timeout=timeout, env=env)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-3000:])

@@ -74,7 +74,7 @@ def test_simd_switch_selects_the_binding(preset):
 
 def test_alf_picture_statistics_follow_the_saturation_rule():
     """the whole-picture ALF statistics call sits in the serial filter derivation: the binding takes it only from $VVHIP_ALF_MIN_CTUS_PER_THREAD CTUs per encoder thread on
-    (default 50 since the statistics go up in bands: 1080p with <= 8 threads, 4K with <= 32); below it the per-CTU CPU tasks stay — same bitstream either way"""
+    (default 100: 1080p with <= 4 threads, 4K with <= 16); below it the per-CTU CPU tasks stay — same bitstream either way"""
     need()
     clip = dict(CLIP, frames=9, preset="faster", threads=4)
     cpu = run(dict(clip, hip=False, mask=0))
